@@ -1,0 +1,141 @@
+/*
+ * rlgpu_state.h — host-side (AoS) exchange layout for one arena ("env").
+ *
+ * This is the plain-C view of everything the batched stepper keeps per env.  It is what
+ * rlgpu_upload_states()/rlgpu_download_states() move across the C-ABI (the device keeps the same
+ * fields transposed into SoA [field][env] arrays), what the host-side
+ * StateSetter / user-plugin fallback reads and writes, and what the parity tests exchange with the
+ * oracle.  Field meaning follows the reference types they replace:
+ *
+ *   RlgpuCarState   <- RocketSim::CarState   (RocketSim/src/Sim/Car/Car.h:17-123)
+ *                      + Car::_velocityImpulseCache (Car.h:170), Car::controls (Car.h:147),
+ *                      + btWheelInfoRL::m_extraPushback (btVehicleRL.h:24; stale-persistent)
+ *   RlgpuBallState  <- RocketSim::BallState  (RocketSim/src/Sim/Ball/Ball.h:17-44) + _velocityImpulseCache
+ *   RlgpuPadState   <- RocketSim::BoostPadState (RocketSim/src/Sim/BoostPad/BoostPad.h)
+ *   RlgpuGymState   <- RLGSC::Gym::prevState counters, GameEventTracker, terminal-condition and
+ *                      EventReward carried state (RLGymSim_CPP/src/RLGymSim_CPP/Gym.h:9-20,
+ *                      RocketSim/src/Sim/GameEventTracker/GameEventTracker.h:78-86,
+ *                      Utils/TerminalConditions/NoTouchCondition.h:8, Utils/RewardFunctions/CommonRewards.h:15)
+ *
+ * Units are RocketSim's public units: positions/velocities in uu, angular velocity in rad/s.
+ * Rotation is three column vectors forward/right/up (RotMat, MathTypes.h:162).
+ * Car slot order inside an env is fixed: slot 2k = blue k, slot 2k+1 = orange k  (the reference's
+ * Gym ctor AddCar order, Gym.cpp:45-49; car id = slot + 1).
+ */
+#ifndef RLGPU_STATE_H
+#define RLGPU_STATE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLGPU_MAX_CARS 6
+#define RLGPU_NUM_PADS 34
+#define RLGPU_NUM_EVENT_VALS 11
+
+/* flag bits of RlgpuCarState.flags */
+enum {
+    RLGPU_CF_ON_GROUND       = 1u << 0,
+    RLGPU_CF_WHEEL0          = 1u << 1, /* wheelsWithContact[0..3] = bits 1..4 */
+    RLGPU_CF_WHEEL1          = 1u << 2,
+    RLGPU_CF_WHEEL2          = 1u << 3,
+    RLGPU_CF_WHEEL3          = 1u << 4,
+    RLGPU_CF_HAS_JUMPED      = 1u << 5,
+    RLGPU_CF_HAS_DOUBLE_JUMPED = 1u << 6,
+    RLGPU_CF_HAS_FLIPPED     = 1u << 7,
+    RLGPU_CF_IS_FLIPPING     = 1u << 8,
+    RLGPU_CF_IS_JUMPING      = 1u << 9,
+    RLGPU_CF_IS_SUPERSONIC   = 1u << 10,
+    RLGPU_CF_IS_AUTOFLIPPING = 1u << 11,
+    RLGPU_CF_WORLD_CONTACT   = 1u << 12,
+    RLGPU_CF_IS_DEMOED       = 1u << 13,
+    RLGPU_CF_BALLHIT_VALID   = 1u << 14
+};
+
+typedef struct RlgpuCarState {
+    float pos[3];
+    float rot[9];            /* forward[3], right[3], up[3] */
+    float vel[3];
+    float ang_vel[3];
+    uint32_t flags;          /* RLGPU_CF_* */
+    float flip_rel_torque[3];
+    float jump_time, flip_time;
+    float air_time, air_time_since_jump;
+    float boost;             /* 0..100 */
+    float time_spent_boosting;
+    float supersonic_time;
+    float handbrake_val;
+    float auto_flip_timer, auto_flip_torque_scale;
+    float world_contact_normal[3];
+    int32_t car_contact_other_id;   /* 0 = none; car id = slot+1 */
+    float car_contact_cooldown;
+    float demo_respawn_timer;
+    /* BallHitInfo (BallHitInfo.h:10-25); ticks are absolute arena tick counts, -1 = never */
+    float bh_rel_pos[3], bh_ball_pos[3], bh_extra_hit_vel[3];
+    int64_t bh_tick_hit, bh_tick_extra;
+    float last_controls[8];  /* throttle steer pitch yaw roll jump boost handbrake (bools as 0/1) */
+    float controls[8];       /* the controls the next tick will use (Car::controls) */
+    float vel_impulse_cache[3]; /* uu/s, applied at the end of the tick (Car.cpp:171-174) */
+    float extra_pushback[4]; /* per-wheel, impulse units of the reference (kg*BT/s) */
+    /* btWheelInfoRL values written by Car::_UpdateWheels in tick t and consumed by
+     * btVehicleRL::updateVehicleFirst/calcFrictionImpulses in tick t+1 (Car.cpp:330-475,
+     * btVehicleRL.cpp:64-92,313-387): they are carried state, and the reference does NOT reset
+     * them in Car::SetState. */
+    float wheel_steer_angle;      /* front wheels, radians */
+    float wheel_engine_force;     /* all wheels */
+    float wheel_brake;            /* all wheels */
+    float wheel_lat_friction[4];
+    float wheel_long_friction[4];
+} RlgpuCarState;
+
+typedef struct RlgpuBallState {
+    float pos[3];
+    float vel[3];
+    float ang_vel[3];
+    float vel_impulse_cache[3]; /* uu/s */
+} RlgpuBallState;
+
+typedef struct RlgpuPadState {
+    float cooldown;
+    uint8_t is_active;
+    uint8_t _pad[3];
+    int32_t prev_locked_car_id;  /* 0 = none */
+} RlgpuPadState;
+
+/* per-player gym-level carried state */
+typedef struct RlgpuPlayerGymState {
+    int32_t match_goals, match_saves, match_assists, match_shots, match_shot_passes,
+            match_bumps, match_demos, boost_pickups;          /* PlayerData.h:17-25 */
+    float event_last[RLGPU_NUM_EVENT_VALS];                   /* EventReward::lastRegisteredValues */
+    float prev_action[8];                                     /* Match::prevActions row */
+} RlgpuPlayerGymState;
+
+typedef struct RlgpuGymState {
+    int32_t score_line[2];           /* GameState.h:8-17 */
+    int32_t last_touch_car_id;       /* GameState.h:24 */
+    int64_t last_tick_count;         /* GameState.h:44 */
+    int32_t no_touch_steps;          /* NoTouchCondition::stepsSinceTouch */
+    /* GameEventTracker (GameEventTracker.h:78-86) */
+    float   shot_cooldown;
+    uint8_t ball_shot, ball_shot_goal_team, ball_scored_last, _pad0;
+    int64_t last_ball_update_count;
+    RlgpuPlayerGymState players[RLGPU_MAX_CARS];
+} RlgpuGymState;
+
+typedef struct RlgpuArenaState {
+    int32_t num_cars;                /* 2, 4 or 6 */
+    int32_t _pad0;
+    int64_t tick_count;              /* Arena::tickCount */
+    int64_t ball_update_counter;     /* BallState::updateCounter (reset by SetState) */
+    RlgpuBallState ball;
+    RlgpuCarState cars[RLGPU_MAX_CARS];
+    RlgpuPadState pads[RLGPU_NUM_PADS];   /* RocketSim order: 6 big then 28 small (RLConst.h:210-253) */
+    RlgpuGymState gym;
+} RlgpuArenaState;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLGPU_STATE_H */

@@ -1,0 +1,375 @@
+// oracle/ref_driver.cpp — TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// A thin C-ABI shim over the REAL reference simulator (RocketSim + RLGymSim_CPP compiled from the
+// sources where they lie under /root/reference by oracle/Makefile -> oracle/_ref/libref_oracle.so).
+// It lets the tests (a) generate the golden fixtures under tests/golden/, (b) compare the HIP path with
+// the reference itself on the GPU box (the prebuilt .so travels with gpurun), and (c) time the
+// reference's CPU path for bench.py's cpu_baseline (kind "reference").
+//
+// All state crosses this boundary as RlgpuArenaState (include/rlgpu_state.h) in SLOT order
+// (slot 2k = blue k, slot 2k+1 = orange k, car id = slot+1); the reference's own
+// std::unordered_set<Car*> iteration order (Arena.h:35) is hidden in here.
+#include <RLGymSim_CPP/Gym.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CombinedReward.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/ZeroSumReward.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
+#include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
+#include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
+#include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
+
+#include "../include/rlgpu_state.h"
+
+#include <cstring>
+#include <thread>
+#include <atomic>
+#include <chrono>
+
+using namespace RLGSC;
+
+namespace {
+
+Car* CarBySlot(Arena* a, int slot) { return a->_carIDMap[(uint32_t)slot + 1]; }
+
+void V3(float* o, const Vec& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+Vec  toV(const float* p) { return Vec(p[0], p[1], p[2]); }
+
+void CtrlToArr(const CarControls& c, float* o) {
+    o[0] = c.throttle; o[1] = c.steer; o[2] = c.pitch; o[3] = c.yaw; o[4] = c.roll;
+    o[5] = c.jump; o[6] = c.boost; o[7] = c.handbrake;
+}
+CarControls ArrToCtrl(const float* p) {
+    CarControls c; c.throttle = p[0]; c.steer = p[1]; c.pitch = p[2]; c.yaw = p[3]; c.roll = p[4];
+    c.jump = p[5] != 0; c.boost = p[6] != 0; c.handbrake = p[7] != 0; return c;
+}
+
+void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
+    memset(s, 0, sizeof(*s));
+    s->num_cars = (int)a->_cars.size();
+    s->tick_count = (int64_t)a->tickCount;
+    BallState bs = a->ball->GetState();
+    s->ball_update_counter = (int64_t)bs.updateCounter;
+    V3(s->ball.pos, bs.pos); V3(s->ball.vel, bs.vel); V3(s->ball.ang_vel, bs.angVel);
+    V3(s->ball.vel_impulse_cache, a->ball->_velocityImpulseCache * BT_TO_UU);
+    for (int i = 0; i < s->num_cars; i++) {
+        Car* car = CarBySlot(a, i);
+        CarState cs = car->GetState();
+        RlgpuCarState& o = s->cars[i];
+        V3(o.pos, cs.pos); V3(o.rot, cs.rotMat.forward); V3(o.rot + 3, cs.rotMat.right); V3(o.rot + 6, cs.rotMat.up);
+        V3(o.vel, cs.vel); V3(o.ang_vel, cs.angVel);
+        uint32_t f = 0;
+        if (cs.isOnGround) f |= RLGPU_CF_ON_GROUND;
+        for (int w = 0; w < 4; w++) if (cs.wheelsWithContact[w]) f |= (RLGPU_CF_WHEEL0 << w);
+        if (cs.hasJumped) f |= RLGPU_CF_HAS_JUMPED;
+        if (cs.hasDoubleJumped) f |= RLGPU_CF_HAS_DOUBLE_JUMPED;
+        if (cs.hasFlipped) f |= RLGPU_CF_HAS_FLIPPED;
+        if (cs.isFlipping) f |= RLGPU_CF_IS_FLIPPING;
+        if (cs.isJumping) f |= RLGPU_CF_IS_JUMPING;
+        if (cs.isSupersonic) f |= RLGPU_CF_IS_SUPERSONIC;
+        if (cs.isAutoFlipping) f |= RLGPU_CF_IS_AUTOFLIPPING;
+        if (cs.worldContact.hasContact) f |= RLGPU_CF_WORLD_CONTACT;
+        if (cs.isDemoed) f |= RLGPU_CF_IS_DEMOED;
+        if (cs.ballHitInfo.isValid) f |= RLGPU_CF_BALLHIT_VALID;
+        o.flags = f;
+        V3(o.flip_rel_torque, cs.flipRelTorque);
+        o.jump_time = cs.jumpTime; o.flip_time = cs.flipTime;
+        o.air_time = cs.airTime; o.air_time_since_jump = cs.airTimeSinceJump;
+        o.boost = cs.boost; o.time_spent_boosting = cs.timeSpentBoosting;
+        o.supersonic_time = cs.supersonicTime; o.handbrake_val = cs.handbrakeVal;
+        o.auto_flip_timer = cs.autoFlipTimer; o.auto_flip_torque_scale = cs.autoFlipTorqueScale;
+        V3(o.world_contact_normal, cs.worldContact.contactNormal);
+        o.car_contact_other_id = (int32_t)cs.carContact.otherCarID;
+        o.car_contact_cooldown = cs.carContact.cooldownTimer;
+        o.demo_respawn_timer = cs.demoRespawnTimer;
+        V3(o.bh_rel_pos, cs.ballHitInfo.relativePosOnBall); V3(o.bh_ball_pos, cs.ballHitInfo.ballPos);
+        V3(o.bh_extra_hit_vel, cs.ballHitInfo.extraHitVel);
+        o.bh_tick_hit = (int64_t)cs.ballHitInfo.tickCountWhenHit;
+        o.bh_tick_extra = (int64_t)cs.ballHitInfo.tickCountWhenExtraImpulseApplied;
+        CtrlToArr(cs.lastControls, o.last_controls);
+        CtrlToArr(car->controls, o.controls);
+        V3(o.vel_impulse_cache, car->_velocityImpulseCache * BT_TO_UU);
+        for (int w = 0; w < 4; w++) {
+            const auto& wi = car->_bulletVehicle.m_wheelInfo[w];
+            o.extra_pushback[w] = wi.m_extraPushback;
+            o.wheel_lat_friction[w] = wi.m_latFriction; o.wheel_long_friction[w] = wi.m_longFriction;
+        }
+        o.wheel_steer_angle = car->_bulletVehicle.m_wheelInfo[0].m_steerAngle;
+        o.wheel_engine_force = car->_bulletVehicle.m_wheelInfo[0].m_engineForce;
+        o.wheel_brake = car->_bulletVehicle.m_wheelInfo[0].m_brake;
+    }
+    for (int i = 0; i < RLGPU_NUM_PADS && i < (int)a->_boostPads.size(); i++) {
+        BoostPadState ps = a->_boostPads[i]->GetState();
+        s->pads[i].cooldown = ps.cooldown;
+        s->pads[i].is_active = ps.isActive;
+        s->pads[i].prev_locked_car_id = (int32_t)ps.prevLockedCarID;
+    }
+}
+
+void SetArenaPhys(Arena* a, const RlgpuArenaState* s, bool setPads) {
+    a->tickCount = (uint64_t)s->tick_count;
+    BallState bs = {};
+    bs.pos = toV(s->ball.pos); bs.vel = toV(s->ball.vel); bs.angVel = toV(s->ball.ang_vel);
+    a->ball->SetState(bs);
+    a->ball->_velocityImpulseCache = toV(s->ball.vel_impulse_cache) * UU_TO_BT;
+    a->ball->_internalState.updateCounter = (uint64_t)s->ball_update_counter;
+    for (int i = 0; i < s->num_cars; i++) {
+        Car* car = CarBySlot(a, i);
+        const RlgpuCarState& o = s->cars[i];
+        CarState cs = {};
+        cs.pos = toV(o.pos); cs.rotMat.forward = toV(o.rot); cs.rotMat.right = toV(o.rot + 3); cs.rotMat.up = toV(o.rot + 6);
+        cs.vel = toV(o.vel); cs.angVel = toV(o.ang_vel);
+        uint32_t f = o.flags;
+        cs.isOnGround = f & RLGPU_CF_ON_GROUND;
+        for (int w = 0; w < 4; w++) cs.wheelsWithContact[w] = f & (RLGPU_CF_WHEEL0 << w);
+        cs.hasJumped = f & RLGPU_CF_HAS_JUMPED; cs.hasDoubleJumped = f & RLGPU_CF_HAS_DOUBLE_JUMPED;
+        cs.hasFlipped = f & RLGPU_CF_HAS_FLIPPED; cs.isFlipping = f & RLGPU_CF_IS_FLIPPING;
+        cs.isJumping = f & RLGPU_CF_IS_JUMPING; cs.isSupersonic = f & RLGPU_CF_IS_SUPERSONIC;
+        cs.isAutoFlipping = f & RLGPU_CF_IS_AUTOFLIPPING; cs.worldContact.hasContact = f & RLGPU_CF_WORLD_CONTACT;
+        cs.isDemoed = f & RLGPU_CF_IS_DEMOED; cs.ballHitInfo.isValid = f & RLGPU_CF_BALLHIT_VALID;
+        cs.flipRelTorque = toV(o.flip_rel_torque);
+        cs.jumpTime = o.jump_time; cs.flipTime = o.flip_time; cs.airTime = o.air_time; cs.airTimeSinceJump = o.air_time_since_jump;
+        cs.boost = o.boost; cs.timeSpentBoosting = o.time_spent_boosting; cs.supersonicTime = o.supersonic_time;
+        cs.handbrakeVal = o.handbrake_val; cs.autoFlipTimer = o.auto_flip_timer; cs.autoFlipTorqueScale = o.auto_flip_torque_scale;
+        cs.worldContact.contactNormal = toV(o.world_contact_normal);
+        cs.carContact.otherCarID = (uint32_t)o.car_contact_other_id; cs.carContact.cooldownTimer = o.car_contact_cooldown;
+        cs.demoRespawnTimer = o.demo_respawn_timer;
+        cs.ballHitInfo.relativePosOnBall = toV(o.bh_rel_pos); cs.ballHitInfo.ballPos = toV(o.bh_ball_pos);
+        cs.ballHitInfo.extraHitVel = toV(o.bh_extra_hit_vel);
+        cs.ballHitInfo.tickCountWhenHit = (uint64_t)o.bh_tick_hit;
+        cs.ballHitInfo.tickCountWhenExtraImpulseApplied = (uint64_t)o.bh_tick_extra;
+        cs.lastControls = ArrToCtrl(o.last_controls);
+        car->SetState(cs);
+        car->controls = ArrToCtrl(o.controls);
+        car->_velocityImpulseCache = toV(o.vel_impulse_cache) * UU_TO_BT;
+        for (int w = 0; w < 4; w++) {
+            auto& wi = car->_bulletVehicle.m_wheelInfo[w];
+            wi.m_extraPushback = o.extra_pushback[w];
+            wi.m_latFriction = o.wheel_lat_friction[w]; wi.m_longFriction = o.wheel_long_friction[w];
+            wi.m_engineForce = o.wheel_engine_force; wi.m_brake = o.wheel_brake;
+            wi.m_steerAngle = (w < 2) ? o.wheel_steer_angle : 0.f;
+        }
+    }
+    if (setPads) {
+        for (int i = 0; i < RLGPU_NUM_PADS && i < (int)a->_boostPads.size(); i++) {
+            BoostPadState ps = {};
+            ps.cooldown = s->pads[i].cooldown; ps.isActive = s->pads[i].is_active;
+            ps.prevLockedCarID = (uint32_t)s->pads[i].prev_locked_car_id;
+            a->_boostPads[i]->SetState(ps);
+        }
+    }
+}
+
+// A state setter that installs a caller-provided state (the reference has no such built-in; the
+// plugin surface allows it: StateSetter.h:5-10).
+class FixedStateSetter : public StateSetter {
+public:
+    RlgpuArenaState next = {};
+    bool kickoffFirst = false;
+    virtual GameState ResetState(Arena* arena) {
+        SetArenaPhys(arena, &next, false);
+        return GameState(arena);
+    }
+};
+
+struct RefGym {
+    Match* match = nullptr;
+    Gym* gym = nullptr;
+    FixedStateSetter* setter = nullptr;
+    NoTouchCondition* noTouch = nullptr;
+    EventReward* eventReward = nullptr;
+    std::vector<RewardFunction*> ownedRewards;
+    std::vector<TerminalCondition*> conds;
+    OBSBuilder* obs = nullptr;
+    ActionParser* parser = nullptr;
+    RewardFunction* rootReward = nullptr;
+    int nPlayers = 0;
+};
+
+void FillGymState(RefGym* g, RlgpuArenaState* s) {
+    const GameState& st = g->gym->prevState;
+    RlgpuGymState& o = s->gym;
+    o.score_line[0] = st.scoreLine[0]; o.score_line[1] = st.scoreLine[1];
+    o.last_touch_car_id = st.lastTouchCarID;
+    o.last_tick_count = (int64_t)st.lastTickCount;
+    o.no_touch_steps = g->noTouch ? g->noTouch->stepsSinceTouch : 0;
+    const GameEventTracker& t = g->gym->eventTracker;
+    o.shot_cooldown = t._shotCooldown; o.ball_shot = t._ballShot; o.ball_shot_goal_team = (uint8_t)t._ballShotGoalTeam;
+    o.ball_scored_last = t._ballScoredLast; o.last_ball_update_count = (int64_t)t._lastBallUpdateCount;
+    for (auto& p : st.players) {
+        int slot = (int)p.carId - 1;
+        RlgpuPlayerGymState& q = o.players[slot];
+        q.match_goals = p.matchGoals; q.match_saves = p.matchSaves; q.match_assists = p.matchAssists;
+        q.match_shots = p.matchShots; q.match_shot_passes = p.matchShotPasses; q.match_bumps = p.matchBumps;
+        q.match_demos = p.matchDemos; q.boost_pickups = p.boostPickups;
+        if (g->eventReward) {
+            auto it = g->eventReward->lastRegisteredValues.find((int)p.carId);
+            if (it != g->eventReward->lastRegisteredValues.end())
+                for (int k = 0; k < RLGPU_NUM_EVENT_VALS; k++) q.event_last[k] = it->second.vals[k];
+        }
+    }
+    for (size_t i = 0; i < st.players.size() && i < g->match->prevActions.size(); i++) {
+        int slot = (int)st.players[i].carId - 1;
+        for (int k = 0; k < 8; k++) o.players[slot].prev_action[k] = g->match->prevActions[i][k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Initialise RocketSim with ONE synthetic soccar mesh given in uu (converted to the .cmf blob format:
+// i32 nTris, i32 nVerts, tris, verts in Bullet units; CollisionMeshFile.cpp:11-36). Returns 0 on success.
+int ref_init(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
+    if (RocketSim::GetStage() == RocketSim::RocketSimStage::INITIALIZED) return 0;
+    std::vector<byte> blob(8 + (size_t)n_tris * 12 + (size_t)n_verts * 12);
+    byte* p = blob.data();
+    int32_t nt = n_tris, nv = n_verts;
+    memcpy(p, &nt, 4); p += 4; memcpy(p, &nv, 4); p += 4;
+    memcpy(p, tris, (size_t)n_tris * 12); p += (size_t)n_tris * 12;
+    for (int i = 0; i < n_verts * 3; i++) { float v = verts_uu[i] * UU_TO_BT; memcpy(p, &v, 4); p += 4; }
+    std::map<GameMode, std::vector<RocketSim::FileData>> m;
+    m[GameMode::SOCCAR] = { blob };
+    try { RocketSim::InitFromMem(m, true); } catch (std::exception& e) { fprintf(stderr, "ref_init: %s\n", e.what()); return -1; }
+    return 0;
+}
+
+int ref_state_size() { return (int)sizeof(RlgpuArenaState); }
+
+void* ref_arena_new(int team_size) {
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE); a->AddCar(Team::ORANGE); }
+    return a;
+}
+void ref_arena_free(void* h) { delete (Arena*)h; }
+void ref_arena_get_state(void* h, RlgpuArenaState* s) { GetArenaPhys((Arena*)h, s); }
+void ref_arena_set_state(void* h, const RlgpuArenaState* s) { SetArenaPhys((Arena*)h, s, true); }
+void ref_arena_set_controls(void* h, int slot, const float* c8) { CarBySlot((Arena*)h, slot)->controls = ArrToCtrl(c8); }
+void ref_arena_step(void* h, int ticks) { ((Arena*)h)->Step(ticks); }
+void ref_arena_reset_kickoff(void* h, int seed) { ((Arena*)h)->ResetToRandomKickoff(seed); }
+
+// The 90x8 lookup table of DiscreteAction (DiscreteAction.cpp:3-67).
+int ref_action_table(float* out, int cap_rows) {
+    DiscreteAction da;
+    int n = (int)da.actions.size();
+    for (int i = 0; i < n && i < cap_rows; i++) for (int k = 0; k < 8; k++) out[i * 8 + k] = da.actions[i][k];
+    return n;
+}
+
+// reward_kind 0: examplemain.cpp:62-76 stack. 1: same wrapped in ZeroSumReward(teamSpirit 0.5, oppScale 1).
+// obs_kind 0: DefaultOBS. terminal: NoTouchCondition(no_touch_steps) then GoalScoreCondition (examplemain.cpp:78-81).
+void* ref_gym_new(int team_size, int tick_skip, int obs_kind, int reward_kind, int no_touch_steps) {
+    RefGym* g = new RefGym();
+    g->eventReward = new EventReward({ .teamGoal = 1.f, .concede = -1.f });
+    auto* comb = new CombinedReward({
+        { new FaceBallReward(), 0.1f }, { new VelocityPlayerToBallReward(), 0.5f },
+        { new VelocityBallToGoalReward(), 1.0f }, { g->eventReward, 50.f } });
+    g->rootReward = comb;
+    if (reward_kind == 1) g->rootReward = new ZeroSumReward(comb, 0.5f, 1.0f);
+    g->noTouch = new NoTouchCondition(no_touch_steps);
+    g->conds = { g->noTouch, new GoalScoreCondition() };
+    g->obs = new DefaultOBS();
+    g->parser = new DiscreteAction();
+    g->setter = new FixedStateSetter();
+    g->match = new Match(g->rootReward, g->conds, g->obs, g->parser, g->setter, team_size, true);
+    g->gym = new Gym(g->match, tick_skip);
+    g->nPlayers = team_size * 2;
+    return g;
+}
+void ref_gym_free(void* h) { RefGym* g = (RefGym*)h; delete g->gym; delete g->match; delete g; }
+
+void* ref_gym_arena(void* h) { return ((RefGym*)h)->gym->arena; }
+
+// Reset to a caller-provided physical state (pads are reset to default by Match::ResetState, Match.cpp:67-68).
+// obs_out: [nPlayers x D] in SLOT order. Returns D.
+int ref_gym_reset_to(void* h, const RlgpuArenaState* s, float* obs_out) {
+    RefGym* g = (RefGym*)h;
+    g->setter->next = *s;
+    FList2 obs = g->gym->Reset();
+    int D = (int)obs[0].size();
+    const auto& pl = g->gym->prevState.players;
+    for (size_t i = 0; i < pl.size(); i++) memcpy(obs_out + ((int)pl[i].carId - 1) * D, obs[i].data(), D * 4);
+    return D;
+}
+
+// One Gym::Step with SLOT-ordered action indices. Outputs in SLOT order.
+//  snap_out (optional): the physical state at the snapshot (after tick 1 of tickSkip)
+//  is not observable without modifying the reference; state_out is the arena AFTER the full step,
+//  with gym-level carried state filled in.
+void ref_gym_step(void* h, const int32_t* actions, float* obs_out, float* rew_out, int32_t* done_out, RlgpuArenaState* state_out) {
+    RefGym* g = (RefGym*)h;
+    Arena* a = g->gym->arena;
+    IList in(g->nPlayers);
+    int i = 0;
+    for (Car* c : a->_cars) in[i++] = actions[(int)c->id - 1];
+    Gym::StepResult r = g->gym->Step(in);
+    int D = (int)r.obs[0].size();
+    for (size_t k = 0; k < r.state.players.size(); k++) {
+        int slot = (int)r.state.players[k].carId - 1;
+        memcpy(obs_out + slot * D, r.obs[k].data(), D * 4);
+        rew_out[slot] = r.reward[k];
+    }
+    *done_out = r.done;
+    if (state_out) { GetArenaPhys(a, state_out); FillGymState(g, state_out); }
+}
+
+// ---- CPU baseline: the reference's own stepping path, threads x games as in ThreadAgent -------------
+// Steps `n_envs` 1v1 gyms (example obs/reward/terminal stack, RandomState(true,true,true), uniform
+// random action tape, tickSkip 8) for `steps` gym steps each on `n_threads` threads.  Returns seconds.
+double ref_bench_collect(int team_size, int n_envs, int n_threads, int steps, int tick_skip) {
+    struct Env { Match* m; Gym* g; };
+    std::vector<Env> envs(n_envs);
+    for (auto& e : envs) {
+        auto* rew = new CombinedReward({ { new FaceBallReward(), 0.1f }, { new VelocityPlayerToBallReward(), 0.5f },
+            { new VelocityBallToGoalReward(), 1.0f }, { new EventReward({ .teamGoal = 1.f, .concede = -1.f }), 50.f } });
+        std::vector<TerminalCondition*> tc = { new NoTouchCondition(150), new GoalScoreCondition() };
+        e.m = new Match(rew, tc, new DefaultOBS(), new DiscreteAction(), new RandomState(true, true, true), team_size, true);
+        e.g = new Gym(e.m, tick_skip);
+        e.g->Reset();
+    }
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) {
+        th.emplace_back([&, t]() {
+            uint32_t rng = 12345u + 977u * t;
+            for (int s = 0; s < steps; s++)
+                for (int e = t; e < n_envs; e += n_threads) {
+                    IList acts(team_size * 2);
+                    for (auto& a : acts) { rng = rng * 1664525u + 1013904223u; a = (rng >> 8) % 90; }
+                    auto r = envs[e].g->Step(acts);
+                    if (r.done) envs[e].g->Reset();
+                }
+        });
+    }
+    for (auto& x : th) x.join();
+    double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (auto& e : envs) { delete e.g; delete e.m; }
+    return sec;
+}
+
+}  // extern "C"
+
+// ---- debugging probes (used while pinning the port; not part of any test contract) ----------------------
+extern "C" void ref_debug_wheels(void* h, int slot, float* out /*4 x 12*/) {
+    Car* car = CarBySlot((Arena*)h, slot);
+    for (int w = 0; w < 4; w++) {
+        const auto& wi = car->_bulletVehicle.m_wheelInfo[w];
+        float* o = out + w * 12;
+        o[0] = wi.m_raycastInfo.m_suspensionLength; o[1] = wi.m_wheelsSuspensionForce; o[2] = wi.m_suspensionRelativeVelocity;
+        o[3] = wi.m_clippedInvContactDotSuspension;
+        o[4] = wi.m_raycastInfo.m_contactPointWS.x(); o[5] = wi.m_raycastInfo.m_contactPointWS.y(); o[6] = wi.m_raycastInfo.m_contactPointWS.z();
+        o[7] = wi.m_raycastInfo.m_contactNormalWS.x(); o[8] = wi.m_raycastInfo.m_contactNormalWS.y(); o[9] = wi.m_raycastInfo.m_contactNormalWS.z();
+        o[10] = wi.m_raycastInfo.m_hardPointWS.z(); o[11] = wi.m_impulse.length();
+    }
+}
+extern "C" void ref_probe_thresholds(void* h, float* out /*4*/) {
+    Arena* a = (Arena*)h;
+    Car* car = CarBySlot(a, 0);
+    out[0] = a->ball->_rigidBody.getCollisionShape()->getContactBreakingThreshold(gContactBreakingThreshold);
+    out[1] = car->_rigidBody.getCollisionShape()->getContactBreakingThreshold(gContactBreakingThreshold);
+    btVector3 inertia = car->_rigidBody.getLocalInertia();
+    out[2] = inertia.x(); out[3] = inertia.y(); out[4] = inertia.z();
+    out[5] = a->ball->_rigidBody.getLocalInertia().x();
+}

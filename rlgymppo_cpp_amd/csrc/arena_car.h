@@ -1,0 +1,550 @@
+// arena_car.h — the per-car part of one physics tick: suspension rays, wheel friction, drive/brake/steer
+// curves, jump / flip / double-jump, air torque, auto-flip, auto-roll, boost, post-tick bookkeeping.
+// Restates RocketSim/src/Sim/Car/Car.cpp:58-193,330-833 and RocketSim/src/Sim/btVehicleRL/btVehicleRL.cpp:64-402
+// for a fixed Octane (CarConfig.cpp:20-70).  All vectors are in BT units (uu/50) like the reference's btRigidBody.
+#pragma once
+#include "arena_body.h"
+#include "arena_world.h"
+
+namespace rlg {
+
+RLG_HD V3 wheel_conn(int i) {  // Car.cpp:243-253
+    bool front = i < 2, left = (i % 2) != 0;
+    V3 o = front ? v3(K::WHEEL_FX, K::WHEEL_FY, K::WHEEL_FZ) : v3(K::WHEEL_BX, K::WHEEL_BY, K::WHEEL_BZ);
+    if (left) o.y *= -1.f;
+    return o * UU2BT;
+}
+RLG_HD float wheel_rest(int i) { return ((i < 2 ? K::SUS_REST_FRONT : K::SUS_REST_BACK) - K::MAX_SUSPENSION_TRAVEL) * UU2BT; }  // Car.cpp:255-258
+RLG_HD float wheel_radius(int i) { return (i < 2 ? K::WHEEL_RAD_FRONT : K::WHEEL_RAD_BACK) * UU2BT; }
+RLG_HD float wheel_travel() { return ((K::MAX_SUSPENSION_TRAVEL * UU2BT) * 100) / 100; }  // m_maxSuspensionTravelCm / 100
+
+// Angle::FromRotMat roll (MathTypes.cpp:72-82 -> btMatrix3x3::getEulerYPR)
+RLG_HD float rot_roll(const M3& m) {
+    float yaw = atan2f(m.r1.x, m.r0.x);
+    float pitch = asinf(-m.r2.x);
+    float roll = atan2f(m.r2.y, m.r2.z);
+    const float HALF_PI = 1.57079632679489661923f;
+    if (fabsf(pitch) == HALF_PI) {
+        if (roll > 0) roll -= PI_F; else roll += PI_F;
+    }
+    (void)yaw;
+    return -roll;
+}
+
+struct CarTickCtx {
+    WheelTmp w[4];
+    M3 wheel_basis[4];
+    int n_contact;
+    bool wheels_world;
+    float forward_speed_uu;
+};
+
+// ---- Car::_UpdateWheels (Car.cpp:330-475) -------------------------------------------------------------
+RLG_HD void car_update_wheels(Car& c, CarTickCtx& t) {
+    const float dt = TICK_DT;
+    float abs_fwd = fabsf(t.forward_speed_uu);
+    if (c.ctl.handbrake) c.handbrake_val += K::POWERSLIDE_RISE_RATE * dt;
+    else c.handbrake_val -= K::POWERSLIDE_FALL_RATE * dt;
+    c.handbrake_val = clampf(c.handbrake_val, 0.f, 1.f);
+
+    float real_throttle = c.ctl.throttle, real_brake = 0.f;
+    if (c.ctl.boost && c.boost > 0) real_throttle = 1.f;
+    {
+        float drive_scale = curve_drive_torque(abs_fwd);
+        float engine_throttle = real_throttle;
+        if (!c.ctl.handbrake) {
+            float abs_thr = fabsf(real_throttle);
+            if (abs_thr >= K::THROTTLE_DEADZONE) {
+                if (abs_fwd > K::STOPPING_FORWARD_VEL && sgnf(real_throttle) != sgnf(t.forward_speed_uu)) {
+                    real_brake = 1.f;
+                    if (abs_fwd > K::BRAKING_NO_THROTTLE_SPEED_THRESH) engine_throttle = 0.f;
+                }
+            } else {
+                engine_throttle = 0.f;
+                real_brake = (abs_fwd < K::STOPPING_FORWARD_VEL) ? 1.f : K::COASTING_BRAKE_FACTOR;
+            }
+        }
+        if (t.n_contact < 3) drive_scale /= 4.f;
+        c.engine_force = engine_throttle * (K::THROTTLE_TORQUE_AMOUNT * UU2BT) * drive_scale;
+        c.brake = real_brake * (K::BRAKE_TORQUE_AMOUNT * UU2BT);
+    }
+    {
+        float steer = curve_steer_angle(abs_fwd);
+        if (c.handbrake_val != 0.f) steer += (curve_powerslide_steer(abs_fwd) - steer) * c.handbrake_val;
+        steer *= c.ctl.steer;
+        c.steer_angle = steer;
+    }
+    for (int i = 0; i < 4; i++) {
+        const WheelTmp& w = t.w[i];
+        if (w.ground < 0) continue;
+        V3 lat = col1(t.wheel_basis[i]);
+        V3 lon = cross(lat, w.contact_normal);
+        float input = 0.f;
+        V3 wheel_delta = w.hard_point - c.b.pos;
+        V3 cv = (cross(c.b.angvel, wheel_delta) + c.b.vel) * BT2UU;
+        float base = fabsf(dot(cv, lat));
+        if (base > 5.f) input = base / (fabsf(dot(cv, lon)) + base);
+        float latf = curve_lat_friction(input);
+        float lonf = 1.f;  // LONG_FRICTION_CURVE is empty -> default output 1 (RLConst.h:376-380, Math.cpp:31-33)
+        if (c.handbrake_val != 0.f) {
+            float hb = c.handbrake_val;
+            latf *= (0.1f - 1.f) * hb + 1.f;  // HANDBRAKE_LAT_FRICTION_FACTOR_CURVE is the constant 0.1 (RLConst.h:382-386)
+            lonf *= (curve_handbrake_long(input) - 1.f) * hb + 1.f;
+        } else {
+            lonf = 1.f;
+        }
+        if (real_throttle == 0.f) {
+            float s = curve_non_sticky(w.contact_normal.z);
+            latf *= s; lonf *= s;
+        }
+        c.lat_friction[i] = latf;
+        c.long_friction[i] = lonf;
+    }
+    if (t.wheels_world) {
+        V3 sum = v3(0, 0, 0);
+        for (int i = 0; i < 4; i++) if (t.w[i].in_contact) sum += t.w[i].contact_normal;
+        V3 up = is_zero(sum) ? col2(c.b.rot) : safe_normalized(sum);
+        bool full_stick = (real_throttle != 0.f) || (abs_fwd > K::STOPPING_FORWARD_VEL);
+        float scale = 0.5f;
+        if (full_stick) scale += 1.f - fabsf(up.z);
+        c.b.force += up * scale * (K::GRAVITY_Z * UU2BT) * K::CAR_MASS;
+    }
+}
+
+// ---- Car::_UpdateAirTorque (Car.cpp:556-641) ------------------------------------------------------------
+RLG_HD void car_update_air_torque(Car& c, bool update_air_control) {
+    V3 fwd = col0(c.b.rot), right = col1(c.b.rot), up = col2(c.b.rot);
+    V3 dir_pitch = -right, dir_yaw = up, dir_roll = -fwd;
+    bool do_air = false;
+    if (c.flags & CF_IS_FLIPPING) {
+        bool keep = (c.flags & CF_HAS_FLIPPED) && c.flip_time < K::FLIP_TORQUE_TIME;
+        if (!keep) c.flags &= ~CF_IS_FLIPPING;
+    }
+    M3 inertia_w = body_inertia_w(c.b, car_inertia_local());
+    if (c.flags & CF_IS_FLIPPING) {
+        V3 rel = c.flip_rel_torque;
+        if (!is_zero(c.flip_rel_torque)) {
+            float pitch_scale = 1.f;
+            if (rel.y != 0.f && c.ctl.pitch != 0.f) {
+                if (sgnf(rel.y) == sgnf(c.ctl.pitch)) {
+                    pitch_scale = 1.f - fminf(fabsf(c.ctl.pitch), 1.f);
+                    do_air = true;
+                }
+            }
+            rel.y *= pitch_scale;
+            V3 dodge = rel * v3(K::FLIP_TORQUE_X, K::FLIP_TORQUE_Y, 0.f);
+            c.b.torque += inertia_w * (c.b.rot * dodge);
+        } else {
+            do_air = true;
+        }
+    } else {
+        do_air = true;
+    }
+    do_air = do_air && !(c.flags & CF_IS_AUTOFLIPPING);
+    do_air = do_air && update_air_control;
+    if (do_air) {
+        float pitch_scale = 1.f;
+        V3 torque;
+        if (c.ctl.pitch != 0.f || c.ctl.yaw != 0.f || c.ctl.roll != 0.f) {
+            if (c.flags & CF_IS_FLIPPING) pitch_scale = 0.f;
+            else if (c.flags & CF_HAS_FLIPPED) {
+                if (c.flip_time < K::FLIP_TORQUE_TIME + K::FLIP_PITCHLOCK_EXTRA_TIME) pitch_scale = 0.f;
+            }
+            torque = (c.ctl.pitch * dir_pitch * pitch_scale * K::AIR_TORQUE_P) + (c.ctl.yaw * dir_yaw * K::AIR_TORQUE_Y) +
+                     (c.ctl.roll * dir_roll * K::AIR_TORQUE_R);
+        } else {
+            torque = v3(0, 0, 0);
+        }
+        V3 av = c.b.angvel;
+        float damp_pitch = dot(dir_pitch, av) * K::AIR_DAMP_P * (1.f - fabsf(c.ctl.pitch * pitch_scale));
+        float damp_yaw = dot(dir_yaw, av) * K::AIR_DAMP_Y * (1.f - fabsf(c.ctl.yaw));
+        float damp_roll = dot(dir_roll, av) * K::AIR_DAMP_R;
+        V3 damping = (dir_yaw * damp_yaw) + (dir_pitch * damp_pitch) + (dir_roll * damp_roll);
+        c.b.torque += (inertia_w * (torque - damping)) * K::CAR_TORQUE_SCALE;
+    }
+    if (c.ctl.throttle != 0.f) c.b.force += fwd * c.ctl.throttle * K::THROTTLE_AIR_ACCEL * UU2BT * K::CAR_MASS;
+}
+
+// ---- Car::_UpdateJump (Car.cpp:507-554) -------------------------------------------------------------------
+RLG_HD void car_update_jump(Car& c, bool jump_pressed) {
+    const float dt = TICK_DT;
+    bool on_ground = c.flags & CF_ON_GROUND;
+    if (on_ground && !(c.flags & CF_IS_JUMPING)) {
+        if ((c.flags & CF_HAS_JUMPED) && c.jump_time < K::JUMP_MIN_TIME + K::JUMP_RESET_TIME_PAD) {
+        } else {
+            c.flags &= ~CF_HAS_JUMPED;
+            c.jump_time = 0.f;
+        }
+    }
+    V3 up = col2(c.b.rot);
+    if (c.flags & CF_IS_JUMPING) {
+        if (c.jump_time < K::JUMP_MIN_TIME || (c.ctl.jump && c.jump_time < K::JUMP_MAX_TIME)) {
+        } else {
+            c.flags &= ~CF_IS_JUMPING;
+        }
+    } else if (on_ground && jump_pressed) {
+        c.flags |= CF_IS_JUMPING;
+        c.jump_time = 0.f;
+        V3 imp = up * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;
+        body_apply_central_impulse(c.b, imp, CAR_INV_MASS);
+    }
+    if (c.flags & CF_IS_JUMPING) {
+        c.flags |= CF_HAS_JUMPED;
+        V3 f = up * K::JUMP_ACCEL;
+        if (c.jump_time < K::JUMP_MIN_TIME) f *= 0.62f;
+        c.b.force += f * UU2BT * K::CAR_MASS;
+    }
+    if (c.flags & (CF_IS_JUMPING | CF_HAS_JUMPED)) c.jump_time += dt;
+}
+
+// ---- Car::_UpdateAutoFlip (Car.cpp:763-797) ---------------------------------------------------------------
+RLG_HD void car_update_auto_flip(Car& c, bool jump_pressed) {
+    const float dt = TICK_DT;
+    if (jump_pressed && (c.flags & CF_WORLD_CONTACT) && c.world_contact_normal.z > K::CAR_AUTOFLIP_NORMZ_THRESH) {
+        float roll = rot_roll(c.b.rot);
+        float abs_roll = fabsf(roll);
+        if (abs_roll > K::CAR_AUTOFLIP_ROLL_THRESH) {
+            c.auto_flip_timer = K::CAR_AUTOFLIP_TIME * (abs_roll / PI_F);
+            c.auto_flip_torque_scale = (roll > 0) ? 1.f : -1.f;
+            c.flags |= CF_IS_AUTOFLIPPING;
+            body_apply_central_impulse(c.b, -col2(c.b.rot) * K::CAR_AUTOFLIP_IMPULSE * UU2BT * K::CAR_MASS, CAR_INV_MASS);
+        }
+    }
+    if (c.flags & CF_IS_AUTOFLIPPING) {
+        if (c.auto_flip_timer <= 0.f) {
+            c.flags &= ~CF_IS_AUTOFLIPPING;
+            c.auto_flip_timer = 0.f;
+        } else {
+            c.b.angvel += col0(c.b.rot) * K::CAR_AUTOFLIP_TORQUE * c.auto_flip_torque_scale * dt;
+            c.auto_flip_timer -= dt;
+        }
+    }
+}
+
+// ---- Car::_UpdateDoubleJumpOrFlip (Car.cpp:643-761) -------------------------------------------------------
+RLG_HD void car_update_double_jump_or_flip(Car& c, bool jump_pressed, float forward_speed_uu) {
+    const float dt = TICK_DT;
+    if (c.flags & CF_ON_GROUND) {
+        c.flags &= ~(CF_HAS_DOUBLE_JUMPED | CF_HAS_FLIPPED);
+        c.air_time = 0.f; c.air_time_since_jump = 0.f; c.flip_time = 0.f;
+    } else {
+        c.air_time += dt;
+        if ((c.flags & CF_HAS_JUMPED) && !(c.flags & CF_IS_JUMPING)) c.air_time_since_jump += dt;
+        else c.air_time_since_jump = 0.f;
+
+        if (jump_pressed && c.air_time_since_jump < K::DOUBLEJUMP_MAX_DELAY) {
+            float mag = fabsf(c.ctl.yaw) + fabsf(c.ctl.pitch) + fabsf(c.ctl.roll);
+            bool is_flip = mag >= K::DODGE_DEADZONE;
+            bool can_use = !(c.flags & CF_HAS_DOUBLE_JUMPED) && !(c.flags & CF_HAS_FLIPPED);
+            if (c.flags & CF_IS_AUTOFLIPPING) can_use = false;
+            if (can_use) {
+                if (is_flip) {
+                    c.flip_time = 0.f;
+                    c.flags |= CF_HAS_FLIPPED | CF_IS_FLIPPING;
+                    float ratio = fabsf(forward_speed_uu) / K::CAR_MAX_SPEED;
+                    V3 dodge = v3(-c.ctl.pitch, c.ctl.yaw + c.ctl.roll, 0.f);
+                    if (fabsf(c.ctl.yaw + c.ctl.roll) < 0.1f && fabsf(c.ctl.pitch) < 0.1f) dodge = v3(0, 0, 0);
+                    else dodge = safe_normalized(dodge);
+                    c.flip_rel_torque = v3(-dodge.y, dodge.x, 0.f);
+                    if (fabsf(dodge.x) < 0.1f) dodge.x = 0.f;
+                    if (fabsf(dodge.y) < 0.1f) dodge.y = 0.f;
+                    bool fuzzy_zero = len2(dodge) < SIMD_EPS * SIMD_EPS;  // btVector3::fuzzyZero
+                    if (!fuzzy_zero) {
+                        bool backwards;
+                        if (fabsf(forward_speed_uu) < 100.0f) backwards = dodge.x < 0.0f;
+                        else backwards = (dodge.x >= 0.0f) != (forward_speed_uu >= 0.0f);
+                        V3 iv = dodge * K::FLIP_INITIAL_VEL_SCALE;
+                        float max_x = backwards ? K::FLIP_BACKWARD_IMPULSE_MAX_SPEED_SCALE : K::FLIP_FORWARD_IMPULSE_MAX_SPEED_SCALE;
+                        iv.x *= ((max_x - 1) * ratio) + 1.f;
+                        iv.y *= ((K::FLIP_SIDE_IMPULSE_MAX_SPEED_SCALE - 1) * ratio) + 1.f;
+                        if (backwards) iv.x *= K::FLIP_BACKWARD_IMPULSE_SCALE_X;
+                        V3 f = col0(c.b.rot);
+                        float ang = atan2f(f.y, f.x);
+                        V3 xdir = v3(cosf(ang), -sinf(ang), 0.f), ydir = v3(sinf(ang), cosf(ang), 0.f);
+                        V3 dv = v3(dot(iv, xdir), dot(iv, ydir), 0.f);
+                        body_apply_central_impulse(c.b, dv * UU2BT * K::CAR_MASS, CAR_INV_MASS);
+                    }
+                } else {
+                    V3 imp = col2(c.b.rot) * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;
+                    body_apply_central_impulse(c.b, imp, CAR_INV_MASS);
+                    c.flags |= CF_HAS_DOUBLE_JUMPED;
+                }
+            }
+        }
+    }
+    if (c.flags & CF_IS_FLIPPING) {
+        c.flip_time += dt;
+        if (c.flip_time <= K::FLIP_TORQUE_TIME) {
+            if (c.flip_time >= K::FLIP_Z_DAMP_START && (c.b.vel.z < 0 || c.flip_time < K::FLIP_Z_DAMP_END))
+                c.b.vel.z *= powf(1 - K::FLIP_Z_DAMP_120, dt / (1 / 120.f));
+        }
+    } else if (c.flags & CF_HAS_FLIPPED) {
+        c.flip_time += dt;
+    }
+}
+
+// ---- Car::_UpdateAutoRoll (Car.cpp:799-833) --------------------------------------------------------------
+RLG_HD void car_update_auto_roll(Car& c, const CarTickCtx& t) {
+    V3 ground_up;
+    if (t.n_contact > 0) {
+        V3 sum = v3(0, 0, 0);
+        for (int i = 0; i < 4; i++) if (t.w[i].in_contact) sum += t.w[i].contact_normal;
+        ground_up = is_zero(sum) ? col2(c.b.rot) : safe_normalized(sum);
+    } else {
+        ground_up = c.world_contact_normal;
+    }
+    V3 ground_down = -ground_up;
+    V3 fwd = col0(c.b.rot), right = col1(c.b.rot);
+    V3 cross_right = cross(ground_up, fwd), cross_fwd = cross(ground_down, cross_right);
+    float right_f = 1.f - clampf(dot(right, cross_right), 0.f, 1.f);
+    float fwd_f = 1.f - clampf(dot(fwd, cross_fwd), 0.f, 1.f);
+    V3 tdir_right = fwd * (dot(right, ground_up) >= 0 ? -1.f : 1.f);
+    V3 tdir_fwd = right * (dot(fwd, ground_up) >= 0 ? 1.f : -1.f);
+    V3 t_right = tdir_right * right_f, t_fwd = tdir_fwd * fwd_f;
+    c.b.force += ground_down * K::CAR_AUTOROLL_FORCE * UU2BT * K::CAR_MASS;
+    c.b.torque += (body_inertia_w(c.b, car_inertia_local()) * (t_fwd + t_right)) * K::CAR_AUTOROLL_TORQUE;
+}
+
+// ---- Car::_UpdateBoost (Car.cpp:477-505) -------------------------------------------------------------------
+RLG_HD void car_update_boost(Car& c) {
+    const float dt = TICK_DT;
+    if (c.time_spent_boosting > 0) {
+        if (!c.ctl.boost && c.time_spent_boosting >= K::BOOST_MIN_TIME) c.time_spent_boosting = 0.f;
+        else c.time_spent_boosting += dt;
+    } else if (c.ctl.boost) {
+        c.time_spent_boosting = dt;
+    }
+    if (c.boost > 0 && c.time_spent_boosting > 0) {
+        c.boost = fmaxf(c.boost - K::BOOST_USED_PER_SECOND * dt, 0.f);
+        float acc = (c.flags & CF_ON_GROUND) ? K::BOOST_ACCEL_GROUND : K::BOOST_ACCEL_AIR;
+        c.b.force += (acc * UU2BT) * col0(c.b.rot) * K::CAR_MASS;
+    }
+    c.boost = fminf(c.boost, K::BOOST_MAX);
+}
+
+// ---- Car::Respawn (Car.cpp:43-56): spawn slot from the caller's RNG draw ------------------------------------
+RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
+    const float RX[4] = {-2304, -2688, 2304, 2688};
+    int idx = (int)(rnd % 4u);
+    Car n = {};
+    float yaw = (PI_F / 2) + (is_blue ? 0.f : PI_F);
+    n.b.pos = v3(RX[idx], -4608.f * (is_blue ? 1.f : -1.f), K::CAR_RESPAWN_Z) * UU2BT;
+    float cy = cosf(yaw), sy = sinf(yaw);
+    n.b.rot = m3_cols(v3(cy, sy, 0.f), v3(-sy, cy, 0.f), v3(0, 0, 1));
+    n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
+    n.flags = CF_ON_GROUND;
+    n.boost = K::BOOST_SPAWN_AMOUNT;
+    n.bh_tick_hit = -1; n.bh_tick_extra = -1;
+    // carried wheel values and controls survive SetState in the reference
+    n.ctl = c.ctl;
+    n.steer_angle = c.steer_angle; n.engine_force = c.engine_force; n.brake = c.brake;
+    for (int i = 0; i < 4; i++) { n.extra_pushback[i] = c.extra_pushback[i]; n.lat_friction[i] = c.lat_friction[i]; n.long_friction[i] = c.long_friction[i]; }
+    body_update_inertia(n.b, car_inv_inertia_local());
+    c = n;
+}
+
+// ---- Car::_PreTickUpdate (Car.cpp:58-131) incl. btVehicleRL first/second halves ------------------------------
+// `world` supplies the ray cast against planes / mesh / ball / other cars (arena_world.h).
+template <int NC>
+RLG_HD void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t respawn_rnd) {
+    Car& c = A.cars[ci];
+    const float dt = TICK_DT;
+    // ClampFix
+    c.ctl.throttle = clampf(c.ctl.throttle, -1.f, 1.f); c.ctl.steer = clampf(c.ctl.steer, -1.f, 1.f);
+    c.ctl.pitch = clampf(c.ctl.pitch, -1.f, 1.f); c.ctl.yaw = clampf(c.ctl.yaw, -1.f, 1.f); c.ctl.roll = clampf(c.ctl.roll, -1.f, 1.f);
+
+    c.frozen = (c.flags & CF_IS_DEMOED) != 0;  // rigid body disabled for this tick (Car.cpp:69-80)
+    if (c.flags & CF_IS_DEMOED) {
+        c.demo_respawn_timer = fmaxf(c.demo_respawn_timer - dt, 0.f);
+        if (c.demo_respawn_timer == 0.f) car_respawn(c, (ci % 2) == 0, respawn_rnd);
+        // NB: as in the reference, a car respawned here still skips the rest of this tick only if it is
+        // still flagged demoed (Respawn clears the flag, Car.cpp:86-87 checks the NEW state).
+    }
+    if (c.flags & CF_IS_DEMOED) return;
+
+    CarTickCtx t;
+    V3 up = col2(c.b.rot);
+    // updateVehicleFirst: wheel transforms with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235)
+    for (int i = 0; i < 4; i++) {
+        V3 wheel_dir = c.b.rot * v3(0, 0, -1), axle = c.b.rot * v3(0, -1, 0);
+        V3 wup = -wheel_dir;
+        V3 fwd = normalized(cross(wup, axle));
+        float ang = (i < 2) ? c.steer_angle : 0.f;
+        M3 steer = quat_to_m3(quat_axis_angle(wup, ang));
+        M3 basis2 = m3_cols(fwd, -axle, wup);
+        t.wheel_basis[i] = steer * basis2;
+    }
+    // ray casts (btVehicleRL.cpp:118-212)
+    t.n_contact = 0; t.wheels_world = false;
+    for (int i = 0; i < 4; i++) {
+        WheelTmp& w = t.w[i];
+        float rest = wheel_rest(i), radius = wheel_radius(i), travel = wheel_travel();
+        w.hard_point = (c.b.rot * wheel_conn(i)) + c.b.pos;
+        V3 wheel_dir = c.b.rot * v3(0, 0, -1);
+        float ray_len = rest + travel + radius - K::SUSPENSION_SUBTRACTION;
+        V3 source = w.hard_point, target = source + (wheel_dir * ray_len);
+        w.contact_point = target;
+        RayHit hit = world_ray_cast(A, ci, mesh, source, target);
+        w.ground = -1; w.in_contact = false;
+        if (hit.kind >= 0) {
+            float rt = hit.frac, s = 1.f - rt;
+            w.contact_point = v3(s * source.x + rt * target.x, s * source.y + rt * target.y, s * source.z + rt * target.z);
+            w.contact_normal = hit.normal;
+            w.in_contact = true;
+            w.ground = hit.kind;
+            bool is_static = hit.kind == 0;
+            if (is_static) t.wheels_world = true;
+            float trace_len = dot(w.hard_point - w.contact_point, up);
+            w.susp_len = clampf(trace_len - radius, rest - travel, rest + travel);
+            float denom = dot(w.contact_normal, up);
+            V3 relpos = w.contact_point - c.b.pos;
+            V3 vel_at = body_vel_at(c.b, relpos);
+            float proj_vel = dot(w.contact_normal, vel_at);
+            if (denom > 0.1f) {
+                float inv = 1.f / denom;
+                w.susp_rel_vel = proj_vel * inv; w.clipped_inv = inv;
+            } else { w.susp_rel_vel = 0.f; w.clipped_inv = 10.f; }
+            if (is_static) {
+                float thresh = (rest + radius) - K::SUSPENSION_SUBTRACTION;
+                if (trace_len < thresh) {
+                    // resolveSingleCollision(..., applyImpulses=false) vs a static body (btContactConstraint.cpp:60-105)
+                    float delta = trace_len - thresh;
+                    float rel_vel = dot(w.contact_normal, vel_at);
+                    float pos_err = K::ERP * -delta / dt;
+                    float vel_err = -(1.0f + 0.f) * rel_vel;
+                    float denom0 = body_impulse_denom(c.b, w.contact_point, w.contact_normal, CAR_INV_MASS);
+                    float jac = 1.f / (denom0 + 0.f);
+                    float imp = pos_err * jac + vel_err * jac;
+                    imp = 0.f > imp ? 0.f : imp;
+                    c.extra_pushback[i] = imp / 4;
+                }
+            }
+            t.n_contact++;
+        } else {
+            w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
+            c.extra_pushback[i] = 0.f;
+        }
+    }
+    // calcFrictionImpulses with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
+    {
+        const float friction_scale = K::CAR_MASS / 3;
+        for (int i = 0; i < 4; i++) {
+            WheelTmp& w = t.w[i];
+            if (w.ground < 0) { w.impulse = v3(0, 0, 0); continue; }
+            V3 axle = col1(t.wheel_basis[i]);
+            V3 n = w.contact_normal;
+            float proj = dot(axle, n);
+            axle -= n * proj;
+            axle = safe_normalized(axle);
+            V3 fdir = safe_normalized(cross(n, axle));
+            // resolveSingleBilateral (btContactConstraint.cpp:108-155)
+            V3 rel1 = w.contact_point - c.b.pos;
+            V3 vel1 = body_vel_at(c.b, rel1);
+            V3 vel2 = v3(0, 0, 0);
+            float diag2 = 0.f;
+            const Body* gb = nullptr; float g_inv_mass = 0.f; V3 g_inv_inertia = v3(0, 0, 0);
+            if (w.ground == 1) { gb = &A.ball.b; g_inv_mass = BALL_INV_MASS; g_inv_inertia = ball_inv_inertia_local(); }
+            else if (w.ground >= 2) { gb = &A.cars[w.ground - 2].b; g_inv_mass = CAR_INV_MASS; g_inv_inertia = car_inv_inertia_local(); }
+            V3 rel2 = v3(0, 0, 0);
+            if (gb) {
+                rel2 = w.contact_point - gb->pos;
+                vel2 = body_vel_at(*gb, rel2);
+                V3 bJ = tmul(gb->rot, cross(rel2, -axle));
+                diag2 = g_inv_mass + dot(g_inv_inertia * bJ, bJ);
+            }
+            V3 aJ = tmul(c.b.rot, cross(rel1, axle));  // world2A * (rel_pos1 x normal), world2A = basis^T
+            float diag = CAR_INV_MASS + dot(car_inv_inertia_local() * aJ, aJ) + diag2;
+            float rel_vel = dot(axle, vel1 - vel2);
+            float side_impulse = -0.2f * rel_vel * (1.f / diag);
+            float rolling;
+            if (c.engine_force == 0.f) {
+                if (c.brake != 0.f) {
+                    V3 v2r = gb ? body_vel_at(*gb, rel1) : v3(0, 0, 0);  // the reference uses carRelContactPoint for both (btVehicleRL.cpp:349-352)
+                    float rv = dot(vel1 - v2r, fdir);
+                    rolling = clampf(-rv * 113.73963f, -c.brake, c.brake);
+                } else rolling = 0.f;
+            } else {
+                rolling = -c.engine_force / friction_scale;
+            }
+            V3 total = (fdir * rolling * c.long_friction[i]) + (axle * side_impulse * c.lat_friction[i]);
+            w.impulse = total * friction_scale;
+        }
+    }
+
+    bool jump_pressed = c.ctl.jump && !c.last.jump;
+    uint32_t wf = 0;
+    for (int i = 0; i < 4; i++) if (t.w[i].in_contact) wf |= (CF_WHEEL0 << i);
+    c.flags = (c.flags & ~(CF_WHEEL0 * 15u)) | wf;
+    if (t.n_contact >= 3) c.flags |= CF_ON_GROUND; else c.flags &= ~CF_ON_GROUND;
+
+    t.forward_speed_uu = dot(c.b.vel, col0(c.b.rot)) * BT2UU;
+    car_update_wheels(c, t);
+    if (t.n_contact < 3) car_update_air_torque(c, t.n_contact == 0);
+    else c.flags &= ~CF_IS_FLIPPING;
+    car_update_jump(c, jump_pressed);
+    car_update_auto_flip(c, jump_pressed);
+    car_update_double_jump_or_flip(c, jump_pressed, t.forward_speed_uu);
+    if (c.ctl.throttle != 0.f && ((t.n_contact > 0 && t.n_contact < 4) || (c.flags & CF_WORLD_CONTACT))) car_update_auto_roll(c, t);
+    c.flags &= ~CF_WORLD_CONTACT;
+
+    // updateVehicleSecond: suspension (btVehicleRL.cpp:277-310) then friction impulses (:390-402)
+    float susp_force[4];
+    for (int i = 0; i < 4; i++) {
+        const WheelTmp& w = t.w[i];
+        if (w.in_contact) {
+            float force = (wheel_rest(i) - w.susp_len) * K::SUSPENSION_STIFFNESS * w.clipped_inv;
+            float damp = (w.susp_rel_vel < 0) ? K::WHEELS_DAMPING_COMPRESSION : K::WHEELS_DAMPING_RELAXATION;
+            float f = force - (damp * w.susp_rel_vel);
+            f *= (i < 2) ? K::SUSPENSION_FORCE_SCALE_FRONT : K::SUSPENSION_FORCE_SCALE_BACK;
+            if (f < 0) f = 0;
+            susp_force[i] = f;
+        } else susp_force[i] = 0.f;
+    }
+    for (int i = 0; i < 4; i++) {
+        if (susp_force[i] != 0.f) {
+            const WheelTmp& w = t.w[i];
+            V3 off = w.contact_point - c.b.pos;
+            float scale = (susp_force[i] * dt) + c.extra_pushback[i];
+            body_apply_impulse(c.b, w.contact_normal * scale, off, CAR_INV_MASS);
+        }
+    }
+    {
+        V3 updir = col2(c.b.rot);
+        for (int i = 0; i < 4; i++) {
+            const WheelTmp& w = t.w[i];
+            if (!is_zero(w.impulse)) {
+                V3 off = w.contact_point - c.b.pos;
+                float updot = dot(updir, off);
+                V3 rel = off - updir * updot;
+                body_apply_impulse(c.b, w.impulse * dt, rel, CAR_INV_MASS);
+            }
+        }
+    }
+    car_update_boost(c);
+}
+
+// ---- Car::_PostTickUpdate + _FinishPhysicsTick (Car.cpp:133-193) ------------------------------------------
+RLG_HD void car_post_tick(Car& c) {
+    const float dt = TICK_DT;
+    if (c.flags & CF_IS_DEMOED) return;
+    {
+        V3 vuu = c.b.vel * BT2UU;
+        float sp2 = len2(vuu);
+        bool ss;
+        if ((c.flags & CF_IS_SUPERSONIC) && c.supersonic_time < K::SUPERSONIC_MAINTAIN_MAX_TIME)
+            ss = sp2 >= K::SUPERSONIC_MAINTAIN_MIN_SPEED * K::SUPERSONIC_MAINTAIN_MIN_SPEED;
+        else
+            ss = sp2 >= K::SUPERSONIC_START_SPEED * K::SUPERSONIC_START_SPEED;
+        if (ss) { c.flags |= CF_IS_SUPERSONIC; c.supersonic_time += dt; }
+        else { c.flags &= ~CF_IS_SUPERSONIC; c.supersonic_time = 0.f; }
+    }
+    if (c.car_contact_cooldown > 0) c.car_contact_cooldown = fmaxf(c.car_contact_cooldown - dt, 0.f);
+    c.last = c.ctl;
+    // _FinishPhysicsTick
+    if (!is_zero(c.vel_impulse_cache)) { c.b.vel += c.vel_impulse_cache; c.vel_impulse_cache = v3(0, 0, 0); }
+    const float vmax = K::CAR_MAX_SPEED * UU2BT;
+    if (len2(c.b.vel) > vmax * vmax) c.b.vel = normalized(c.b.vel) * vmax;
+    if (len2(c.b.angvel) > K::CAR_MAX_ANG_SPEED * K::CAR_MAX_ANG_SPEED) c.b.angvel = normalized(c.b.angvel) * K::CAR_MAX_ANG_SPEED;
+}
+
+}  // namespace rlg

@@ -1,0 +1,447 @@
+// arena_gym.h — the gym layer around the tick, per env: RLGSC::Gym::Step / Reset (RLGymSim_CPP/src/RLGymSim_CPP/
+// Gym.cpp:58-102), Match (Envs/Match.cpp:4-70), GameState snapshot (Utils/Gamestates/GameState.cpp:52-104,
+// PlayerData.cpp:4-34), GameEventTracker::Update (RocketSim/src/Sim/GameEventTracker/GameEventTracker.cpp:48-158),
+// and device fast paths of the built-in plugins: DiscreteAction, DefaultOBS, the CommonRewards stack,
+// CombinedReward / ZeroSumReward, NoTouch / GoalScore conditions, RandomState / KickoffState.
+#pragma once
+#include "arena_step.h"
+#include "arena_io.h"
+
+namespace rlg {
+
+enum RewardKind : int32_t {
+    RW_EVENT = 0,              // EventReward (CommonRewards.cpp:4-42); weights in GymConfig::event_weights
+    RW_VELOCITY = 1,           // VelocityReward(isNegative = p0 != 0)
+    RW_SAVE_BOOST = 2,         // SaveBoostReward(exponent = p0)
+    RW_VEL_BALL_TO_GOAL = 3,   // VelocityBallToGoalReward(ownGoal = p0 != 0)
+    RW_VEL_PLAYER_TO_BALL = 4, // VelocityPlayerToBallReward
+    RW_FACE_BALL = 5,          // FaceBallReward
+    RW_TOUCH_BALL = 6          // TouchBallReward(aerialWeight = p0)
+};
+enum TerminalKind : int32_t { TC_NO_TOUCH = 0, TC_GOAL_SCORE = 1 };
+enum SetterKind : int32_t { SS_RANDOM = 0, SS_KICKOFF = 1 };
+
+struct RewardTerm { int32_t kind; float weight; float p0; };
+
+struct GymConfig {
+    int32_t tick_skip;
+    int32_t n_terms; RewardTerm terms[8];          // CombinedReward order
+    float event_weights[RLGPU_NUM_EVENT_VALS];
+    int32_t zero_sum; float team_spirit, opp_scale; // ZeroSumReward wrapper (ZeroSumReward.cpp:3-29)
+    int32_t n_conds; int32_t conds[4]; int32_t no_touch_max_steps;
+    int32_t setter_kind; int32_t rand_ball_speed, rand_car_speed, cars_on_ground;
+    uint32_t seed_lo, seed_hi;
+    float pos_coef[3], vel_coef, ang_vel_coef;      // DefaultOBS.h:11-15
+    int32_t n_actions;
+};
+
+// obs-order -> RocketSim pad index (GameState.cpp:10-50 builds this by matching CommonValues::BOOST_LOCATIONS
+// against RLConst pad positions; it is a constant of the two tables)
+RLG_HD int pad_obs_to_rs(int i) {
+    const int8_t M[34] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
+    return M[i];
+}
+
+// DiscreteAction lookup table row (DiscreteAction.cpp:3-67): throttle steer pitch yaw roll jump boost handbrake
+inline int build_action_table(float* out /*[90*8]*/) {
+    const float RB[2] = {0, 1}, RF[3] = {-1, 0, 1};
+    int n = 0;
+    for (float throttle : RF) for (float steer : RF) for (float boost : RB) for (float handbrake : RB) {
+        if (boost == 1 && throttle != 1) continue;
+        float r[8] = {throttle, steer, 0, steer, 0, 0, boost, handbrake};
+        for (int k = 0; k < 8; k++) out[n * 8 + k] = r[k];
+        n++;
+    }
+    for (float pitch : RF) for (float yaw : RF) for (float roll : RF) for (float jump : RB) for (float boost : RB) {
+        if (jump == 1 && yaw != 0) continue;
+        if (pitch == roll && roll == jump && jump == 0) continue;
+        float handbrake = (jump == 1) && (pitch != 0 || yaw != 0 || roll != 0);
+        float r[8] = {boost, yaw, pitch, yaw, roll, jump, boost, handbrake};
+        for (int k = 0; k < 8; k++) out[n * 8 + k] = r[k];
+        n++;
+    }
+    return n;
+}
+
+// ---- snapshot (GameState::UpdateFromArena) ---------------------------------------------------------------
+template <int NC>
+struct Snapshot {
+    V3 ball_pos, ball_vel, ball_angvel;                 // uu
+    V3 car_pos[NC], car_fwd[NC], car_up[NC], car_vel[NC], car_angvel[NC];
+    float boost_frac[NC];
+    bool on_ground[NC], has_flip[NC], demoed[NC], touched[NC];
+    uint64_t pads_active;                               // bit i = obs-order pad i active
+};
+
+template <int NC>
+RLG_HD void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S) {
+    int64_t tick_skip = A.tick_count - G.last_tick_count; if (tick_skip < 0) tick_skip = 0;
+    S.ball_pos = A.ball.b.pos * BT2UU; S.ball_vel = A.ball.b.vel * BT2UU; S.ball_angvel = A.ball.b.angvel;
+    for (int k = 0; k < NC; k++) {
+        const Car& c = A.cars[k];
+        S.car_pos[k] = c.b.pos * BT2UU; S.car_fwd[k] = col0(c.b.rot); S.car_up[k] = col2(c.b.rot);
+        S.car_vel[k] = c.b.vel * BT2UU; S.car_angvel[k] = c.b.angvel;
+        S.touched[k] = (c.flags & CF_BALLHIT_VALID) && (c.bh_tick_hit >= (A.tick_count - tick_skip));  // PlayerData.cpp:20-25
+        if (S.touched[k]) G.last_touch_car_id = k + 1;
+        S.has_flip[k] = !(c.flags & CF_HAS_DOUBLE_JUMPED) && !(c.flags & CF_HAS_FLIPPED) && c.air_time_since_jump < K::DOUBLEJUMP_MAX_DELAY;
+        S.on_ground[k] = c.flags & CF_ON_GROUND; S.demoed[k] = c.flags & CF_IS_DEMOED;
+        S.boost_frac[k] = c.boost / 100;
+    }
+    uint64_t m = 0;
+    for (int i = 0; i < 34; i++) if (A.pads[pad_obs_to_rs(i)].is_active) m |= (1ull << i);
+    S.pads_active = m;
+    if (fabsf(S.ball_pos.y) > K::GOAL_THRESHOLD_Y + K::BALL_RADIUS) {  // GameState.cpp:100-101, Math.cpp:3-5
+        int team_from_y = S.ball_pos.y < 0 ? 0 : 1;
+        G.score_line[1 - team_from_y]++;
+    }
+    G.last_tick_count = A.tick_count;
+}
+
+// ---- GameEventTracker::Update ----------------------------------------------------------------------------
+template <int NC>
+RLG_HD bool ball_probably_going_in(const Arena<NC>& A, float max_time, int& goal_team) {  // Arena.cpp:827-863
+    V3 bp = A.ball.b.pos * BT2UU, bv = A.ball.b.vel * BT2UU;
+    if (fabsf(bv.y) < SIMD_EPS) return false;
+    float dir = sgnf(bv.y);
+    float goal_y = K::GOAL_THRESHOLD_Y * dir;
+    float dist = fabsf(bp.y - goal_y);
+    float t = dist / fabsf(bv.y);
+    if (t > max_time) return false;
+    V3 grav = v3(0, 0, K::GRAVITY_Z);
+    V3 ex = bp + (bv * t) + (grav * t * t) / 2;
+    const float HW = 892.755f, GH = 642.775f;
+    float margin = K::BALL_RADIUS * 0.1f + 0.f;
+    if (ex.z > GH + margin) return false;
+    if (fabsf(ex.x) > HW + margin) return false;
+    goal_team = dir < 0 ? 0 : 1;  // RS_TEAM_FROM_Y(scoreDirSgn)
+    return true;
+}
+template <int NC>
+RLG_HD bool shooter_passer(const Arena<NC>& A, int team, int& shooter, bool find_passer, int& passer, int64_t max_shooter_ticks, int64_t max_passer_ticks) {
+    shooter = -1; passer = -1;
+    for (int k = 0; k < NC; k++) {
+        const Car& c = A.cars[k];
+        if ((k % 2) != team || !(c.flags & CF_BALLHIT_VALID)) continue;
+        if (c.bh_tick_hit + max_shooter_ticks >= A.tick_count)
+            if (shooter < 0 || c.bh_tick_hit > A.cars[shooter].bh_tick_hit) shooter = k;
+    }
+    if (shooter >= 0 && find_passer) {
+        int64_t shoot_tick = A.cars[shooter].bh_tick_hit;
+        for (int k = 0; k < NC; k++) {
+            const Car& c = A.cars[k];
+            if ((k % 2) != team || !(c.flags & CF_BALLHIT_VALID) || k == shooter) continue;
+            if (c.bh_tick_hit + max_passer_ticks >= shoot_tick)
+                if (passer < 0 || c.bh_tick_hit > A.cars[passer].bh_tick_hit) passer = k;
+        }
+    }
+    return shooter >= 0;
+}
+template <int NC>
+RLG_HD void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
+    const float tickrate = 1.f / TICK_DT;
+    bool scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);  // Arena.cpp:949-957
+    int64_t buc = A.ball_update_counter;
+    bool ball_shot = G.tracker_flags & 1u, scored_last = G.tracker_flags & 4u; int shot_goal_team = (G.tracker_flags & 2u) ? 1 : 0;
+    if (buc > G.last_ball_update_count) {
+        int64_t delta_ticks = buc - G.last_ball_update_count;
+        float delta_time = (float)delta_ticks * TICK_DT;
+        if (scored && !scored_last) {
+            int sh, pa;
+            int team = (-A.ball.b.pos.y) < 0 ? 0 : 1;
+            if (shooter_passer(A, team, sh, true, pa, (int64_t)(4.0f * tickrate), (int64_t)(2.0f * tickrate))) {
+                G.counters[sh][0]++;                 // matchGoals
+                if (pa >= 0) G.counters[pa][2]++;    // matchAssists
+            }
+        } else if (!ball_shot) {
+            if (G.shot_cooldown > 0) G.shot_cooldown = fmaxf(G.shot_cooldown - delta_time, 0.f);
+            else {
+                float sp2 = len2(A.ball.b.vel * BT2UU);
+                if (sp2 >= 1750.f * 1750.f) {
+                    int goal_team;
+                    if (ball_probably_going_in(A, 2.0f, goal_team)) {
+                        int shooter_team = 1 - goal_team;
+                        int64_t min_delay = (int64_t)(0.3f * tickrate);
+                        int sh, pa;
+                        if (shooter_passer(A, shooter_team, sh, true, pa, delta_ticks + min_delay, (int64_t)(2.0f * tickrate))) {
+                            int64_t since = A.tick_count - A.cars[sh].bh_tick_hit;
+                            if (since >= min_delay) {
+                                ball_shot = true; shot_goal_team = goal_team; G.shot_cooldown = 1.0f;
+                                G.counters[sh][3]++;               // matchShots
+                                if (pa >= 0) G.counters[pa][4]++;  // matchShotPasses
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            int gt;
+            if (!ball_probably_going_in(A, 2.0f, gt)) {
+                int sv, un;
+                if (shooter_passer(A, shot_goal_team, sv, false, un, delta_ticks, 0)) G.counters[sv][1]++;  // matchSaves
+                ball_shot = false;
+            }
+        }
+    } else if (buc == G.last_ball_update_count) {
+        return;
+    } else {
+        ball_shot = false; scored = false; G.shot_cooldown = 0.f;  // ResetPersistentInfo, then _ballScoredLast = scored below
+        scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);
+    }
+    G.tracker_flags = (G.tracker_flags & ~7u) | (ball_shot ? 1u : 0u) | (shot_goal_team ? 2u : 0u) | (scored ? 4u : 0u);
+    G.last_ball_update_count = buc;
+}
+
+// ---- DefaultOBS (OBSBuilders/DefaultOBS.cpp:3-55) -----------------------------------------------------------
+RLG_HD V3 inv3(V3 v, bool inv) { return inv ? v3(-v.x, -v.y, v.z) : v; }
+template <int NC>
+RLG_HD int obs_size() { return 51 + 19 * NC; }
+
+template <int NC>
+RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, const GymConfig& cfg) {
+    V3 p = inv3(S.car_pos[k], inv), f = inv3(S.car_fwd[k], inv), u = inv3(S.car_up[k], inv), v = inv3(S.car_vel[k], inv), w = inv3(S.car_angvel[k], inv);
+    *o++ = p.x * cfg.pos_coef[0]; *o++ = p.y * cfg.pos_coef[1]; *o++ = p.z * cfg.pos_coef[2];
+    *o++ = f.x; *o++ = f.y; *o++ = f.z; *o++ = u.x; *o++ = u.y; *o++ = u.z;
+    *o++ = v.x * cfg.vel_coef; *o++ = v.y * cfg.vel_coef; *o++ = v.z * cfg.vel_coef;
+    *o++ = w.x * cfg.ang_vel_coef; *o++ = w.y * cfg.ang_vel_coef; *o++ = w.z * cfg.ang_vel_coef;
+    *o++ = S.boost_frac[k]; *o++ = S.on_ground[k] ? 1.f : 0.f; *o++ = S.has_flip[k] ? 1.f : 0.f; *o++ = S.demoed[k] ? 1.f : 0.f;
+    return o;
+}
+template <int NC>
+RLG_HD void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o) {
+    bool inv = (k % 2) == 1;
+    V3 bp = inv3(S.ball_pos, inv), bv = inv3(S.ball_vel, inv), bw = inv3(S.ball_angvel, inv);
+    *o++ = bp.x * cfg.pos_coef[0]; *o++ = bp.y * cfg.pos_coef[1]; *o++ = bp.z * cfg.pos_coef[2];
+    *o++ = bv.x * cfg.vel_coef; *o++ = bv.y * cfg.vel_coef; *o++ = bv.z * cfg.vel_coef;
+    *o++ = bw.x * cfg.ang_vel_coef; *o++ = bw.y * cfg.ang_vel_coef; *o++ = bw.z * cfg.ang_vel_coef;
+    for (int i = 0; i < 8; i++) *o++ = prev_action8[i];
+    for (int i = 0; i < 34; i++) { int src = inv ? (33 - i) : i; *o++ = ((S.pads_active >> src) & 1ull) ? 1.f : 0.f; }
+    o = obs_add_player(o, S, k, inv, cfg);
+    for (int j = 0; j < NC; j++) if (j != k && (j % 2) == (k % 2)) o = obs_add_player(o, S, j, inv, cfg);  // teammates, state.players order
+    for (int j = 0; j < NC; j++) if (j != k && (j % 2) != (k % 2)) o = obs_add_player(o, S, j, inv, cfg);  // opponents
+}
+
+// ---- rewards ---------------------------------------------------------------------------------------------
+RLG_HD V3 rs_normalized(V3 v) {  // RocketSim Vec::Normalized (MathTypes.h:88-95)
+    float l2 = len2(v);
+    float l = l2 > 0 ? sqrtf(l2) : 0.f;
+    if (l > SIMD_EPS * SIMD_EPS) return v / l;
+    return v3(0, 0, 0);
+}
+template <int NC>
+RLG_HD void event_values(const Snapshot<NC>& S, const GymEnv<NC>& G, int k, float* v) {  // EventReward::ExtractValues
+    int team = k % 2;
+    v[0] = (float)G.counters[k][0]; v[1] = (float)G.score_line[team]; v[2] = (float)G.score_line[1 - team]; v[3] = (float)G.counters[k][2];
+    v[4] = S.touched[k] ? 1.f : 0.f; v[5] = (float)G.counters[k][3]; v[6] = (float)G.counters[k][4]; v[7] = (float)G.counters[k][1];
+    v[8] = (float)G.counters[k][6]; v[9] = S.demoed[k] ? 1.f : 0.f; v[10] = S.boost_frac[k];
+}
+template <int NC>
+RLG_HD void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
+    for (int k = 0; k < NC; k++) rew[k] = 0.f;
+    for (int t = 0; t < cfg.n_terms; t++) {
+        const RewardTerm& T = cfg.terms[t];
+        for (int k = 0; k < NC; k++) {
+            float r = 0.f;
+            switch (T.kind) {
+                case RW_EVENT: {
+                    float nv[RLGPU_NUM_EVENT_VALS]; event_values(S, G, k, nv);
+                    for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) { r += fmaxf(nv[i] - G.event_last[k][i], 0.f) * cfg.event_weights[i]; G.event_last[k][i] = nv[i]; }
+                } break;
+                case RW_VELOCITY: r = len(S.car_vel[k]) / 2300.f * (1 - 2 * (T.p0 != 0.f ? 1 : 0)); break;
+                case RW_SAVE_BOOST: r = clampf(powf(S.boost_frac[k], T.p0), 0.f, 1.f); break;
+                case RW_VEL_BALL_TO_GOAL: {
+                    bool orange_goal = (k % 2) == 0;
+                    if (T.p0 != 0.f) orange_goal = !orange_goal;
+                    V3 target = v3(0.f, orange_goal ? 6000.f : -6000.f, 642.775f / 2);
+                    V3 dir = rs_normalized(target - S.ball_pos);
+                    r = dot(dir, S.ball_vel / 6000.f);
+                } break;
+                case RW_VEL_PLAYER_TO_BALL: {
+                    V3 dir = rs_normalized(S.ball_pos - S.car_pos[k]);
+                    r = dot(dir, S.car_vel[k] / 2300.f);
+                } break;
+                case RW_FACE_BALL: {
+                    V3 dir = rs_normalized(S.ball_pos - S.car_pos[k]);
+                    r = dot(S.car_fwd[k], dir);
+                } break;
+                case RW_TOUCH_BALL: r = S.touched[k] ? powf((S.ball_pos.z + 92.75f) / (92.75f * 2), T.p0) : 0.f; break;
+                default: break;
+            }
+            rew[k] += r * T.weight;
+        }
+    }
+    if (cfg.zero_sum) {
+        float avg[2] = {0.f, 0.f}; int cnt[2] = {0, 0};
+        for (int k = 0; k < NC; k++) { cnt[k % 2]++; avg[k % 2] += rew[k]; }
+        for (int t = 0; t < 2; t++) avg[t] /= (float)(cnt[t] > 1 ? cnt[t] : 1);
+        for (int k = 0; k < NC; k++) { int t = k % 2; rew[k] = rew[k] * (1 - cfg.team_spirit) + (avg[t] * cfg.team_spirit) - (avg[1 - t] * cfg.opp_scale); }
+    }
+}
+
+// ---- terminal conditions (Match::IsDone short-circuit, Match.cpp:32-38) ------------------------------------------
+template <int NC>
+RLG_HD bool compute_done(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg) {
+    for (int i = 0; i < cfg.n_conds; i++) {
+        if (cfg.conds[i] == TC_NO_TOUCH) {
+            bool any = false;
+            for (int k = 0; k < NC; k++) any = any || S.touched[k];
+            if (any) { G.no_touch_steps = 0; }
+            else { G.no_touch_steps++; if (G.no_touch_steps >= cfg.no_touch_max_steps) return true; }
+        } else if (cfg.conds[i] == TC_GOAL_SCORE) {
+            if (fabsf(S.ball_pos.y) > K::GOAL_THRESHOLD_Y + K::BALL_RADIUS) return true;
+        }
+    }
+    return false;
+}
+
+// ---- state setters ---------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t s0, s1, stream, ctr, sub; uint32_t buf[4]; int have;
+    RLG_HD uint32_t next() {
+        if (have == 0) { philox4(s0, s1, stream, ctr, sub, buf); sub++; have = 4; }
+        return buf[4 - (have--)];
+    }
+    RLG_HD float uni(float lo, float hi) { return lo + u32_to_unit(next()) * (hi - lo); }
+};
+RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat = setEulerYPR(yaw,-pitch,-roll) (MathTypes.cpp:84-89)
+    float ez = yaw, ey = -pitch, ex = -roll;
+    float ci = cosf(ex), cj = cosf(ey), ch = cosf(ez), si = sinf(ex), sj = sinf(ey), sh = sinf(ez);
+    float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+    return m3_rows(v3(cj * ch, sj * sc - cs, sj * cc + ss), v3(cj * sh, sj * ss + cc, sj * cs - sc), v3(-sj, cj * si, cj * ci));
+}
+RLG_HD void car_set_fresh(Car& c) {  // Car::SetState(CarState()) semantics: carried wheel values / controls survive
+    Car n = c;
+    n.flags = CF_ON_GROUND; n.flip_rel_torque = v3(0, 0, 0);
+    n.jump_time = n.flip_time = n.air_time = n.air_time_since_jump = 0.f;
+    n.boost = K::BOOST_SPAWN_AMOUNT; n.time_spent_boosting = n.supersonic_time = n.handbrake_val = 0.f;
+    n.auto_flip_timer = n.auto_flip_torque_scale = 0.f; n.world_contact_normal = v3(0, 0, 0);
+    n.car_contact_other = 0; n.car_contact_cooldown = 0.f; n.demo_respawn_timer = 0.f;
+    n.bh_rel_pos = n.bh_ball_pos = n.bh_extra_hit_vel = v3(0, 0, 0); n.bh_tick_hit = -1; n.bh_tick_extra = -1;
+    n.last.throttle = n.last.steer = n.last.pitch = n.last.yaw = n.last.roll = 0.f; n.last.jump = n.last.boost = n.last.handbrake = false;
+    n.vel_impulse_cache = v3(0, 0, 0);
+    n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
+    c = n;
+}
+template <int NC>
+RLG_HD void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id) {
+    Rng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
+    G.reset_count++;
+    A.ball.vel_impulse_cache = v3(0, 0, 0); A.ball_update_counter = 0;
+    for (int p = 0; p < 34; p++) { A.pads[p].cooldown = 0.f; A.pads[p].is_active = true; A.pads[p].prev_locked = 0; A.pads[p].cur_locked = 0; }
+    if (cfg.setter_kind == SS_KICKOFF) {
+        // Arena::ResetToRandomKickoff (Arena.cpp:112-216)
+        const float SX[5] = {-2048, 2048, -256, 256, 0}, SY[5] = {-2560, -2560, -3840, -3840, -4608};
+        const float SYAW[5] = {PI_F / 4 * 1, PI_F / 4 * 3, PI_F / 4 * 2, PI_F / 4 * 2, PI_F / 4 * 2};
+        int order[5] = {0, 1, 2, 3, 4};
+        for (int i = 4; i > 0; i--) { int j = (int)(rng.next() % (uint32_t)(i + 1)); int t = order[i]; order[i] = order[j]; order[j] = t; }
+        for (int k = 0; k < NC; k++) {
+            int i = k / 2; bool blue = (k % 2) == 0;
+            int sl = order[i < 5 ? i : 4];
+            Car& c = A.cars[k]; car_set_fresh(c);
+            V3 pos = v3(SX[sl], SY[sl], K::CAR_SPAWN_REST_Z); float yaw = SYAW[sl];
+            if (!blue) { pos = pos * v3(-1, -1, 1); yaw += PI_F; }
+            c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, 0.f, 0.f);
+        }
+        A.ball.b.pos = v3(0, 0, K::BALL_REST_Z) * UU2BT; A.ball.b.vel = v3(0, 0, 0); A.ball.b.angvel = v3(0, 0, 0);
+    } else {
+        // RandomState::ResetState (StateSetters/RandomState.cpp:8-61)
+        const float X_MAX = 3500, Y_MAX = 4000, Z_MAX = 1820, CAR_Z_MIN = 150;
+        V3 bp = v3(rng.uni(-X_MAX, X_MAX), rng.uni(-Y_MAX, Y_MAX), rng.uni(92.75f, Z_MAX));
+        V3 bv = v3(0, 0, 0), bw = v3(0, 0, 0);
+        if (cfg.rand_ball_speed) {
+            V3 d = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+            bv = d * rng.uni(0, 4000);
+            bw = v3(rng.uni(-4, 4), rng.uni(-4, 4), rng.uni(-4, 4));
+        }
+        A.ball.b.pos = bp * UU2BT; A.ball.b.vel = bv * UU2BT; A.ball.b.angvel = bw;
+        for (int k = 0; k < NC; k++) {
+            Car& c = A.cars[k]; car_set_fresh(c);
+            V3 pos = v3(rng.uni(-X_MAX, X_MAX), rng.uni(-Y_MAX, Y_MAX), rng.uni(CAR_Z_MIN, Z_MAX));
+            V3 vel = v3(0, 0, 0), av = v3(0, 0, 0);
+            if (cfg.rand_car_speed) {
+                V3 d = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+                vel = d * rng.uni(0, K::CAR_MAX_SPEED);
+                V3 d2 = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+                av = d2 * 5.5f;
+            }
+            float yaw = rng.uni(-PI_F, PI_F), pitch = rng.uni(-PI_F / 2, PI_F / 2), roll = rng.uni(-PI_F, PI_F);
+            bool on_ground = cfg.cars_on_ground ? true : (rng.uni(0, 1) > 0.5f);
+            if (on_ground) { pos.z = 17; pitch = roll = 0; vel.z = 0; av = v3(0, 0, 0); }
+            c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, pitch, roll); c.b.vel = vel * UU2BT; c.b.angvel = av;
+            c.boost = rng.uni(0, 100);
+        }
+    }
+    arena_finish_load(A);
+}
+
+// Gym::Reset bookkeeping after the state setter ran (Gym.cpp:58-66, Match.cpp:4-10, GameState ctor)
+template <int NC>
+RLG_HD void gym_episode_reset(const Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, Snapshot<NC>& S) {
+    G.score_line[0] = G.score_line[1] = 0; G.last_touch_car_id = -1; G.last_tick_count = 0;
+    for (int k = 0; k < NC; k++) for (int q = 0; q < 8; q++) G.counters[k][q] = 0;
+    take_snapshot(A, G, S);  // GameState(arena): lastTickCount was 0 -> tickSkip = tickCount
+    G.no_touch_steps = 0;
+    for (int k = 0; k < NC; k++) { G.prev_action_idx[k] = -1; event_values(S, G, k, G.event_last[k]); }
+    G.tracker_flags &= ~(1u | 4u); G.shot_cooldown = 0.f;  // ResetPersistentInfo (GameEventTracker.cpp:160-165)
+    G.episode_steps = 0;
+}
+
+// ---- Gym::Step for one env ---------------------------------------------------------------------------------------
+// actions: NC indices into the action table (slot order).  Writes, in slot order:
+//   reward[NC], done, and next_obs[NC][D] = the observation the policy sees next (post-reset when done).
+template <int NC>
+RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const MeshView& mesh, const float* action_table,
+                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out) {
+    // Match::ParseActions: demoed players (per the PREVIOUS snapshot) get a zero action (Match.cpp:44-52)
+    uint32_t snap_demoed = (G.tracker_flags >> 8) & 0xffu;
+    float pa[NC][8];
+    for (int k = 0; k < NC; k++) {
+        int idx = actions[k];
+        bool zero = (snap_demoed >> k) & 1u;
+        if (idx < 0 || idx >= cfg.n_actions) zero = true;
+        for (int i = 0; i < 8; i++) pa[k][i] = zero ? 0.f : action_table[idx * 8 + i];
+        G.prev_action_idx[k] = zero ? -1 : idx;
+        Controls& c = A.cars[k].ctl;  // Action -> CarControls (Action.h:36-46)
+        c.throttle = pa[k][0]; c.steer = pa[k][1]; c.pitch = pa[k][2]; c.yaw = pa[k][3]; c.roll = pa[k][4];
+        c.jump = pa[k][5] == 1.f; c.boost = pa[k][6] == 1.f; c.handbrake = pa[k][7] == 1.f;
+    }
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev);  // arena->Step(tickSkip - actionDelay) = 1 tick
+    // bump callbacks that fired during this first tick land in the snapshot (later ones are lost: Gym.cpp:84-96)
+    for (int k = 0; k < NC; k++) {
+        if (ev.bump_mask & (1u << k)) G.counters[k][5]++;
+        if (ev.bump_mask & (1u << (8 + k))) G.counters[k][6]++;
+    }
+    event_tracker_update(A, G);
+    Snapshot<NC> S;
+    take_snapshot(A, G, S);
+    uint32_t dm = 0; for (int k = 0; k < NC; k++) if (S.demoed[k]) dm |= (1u << k);
+    G.tracker_flags = (G.tracker_flags & ~0xff00u) | (dm << 8);
+    bool done = compute_done(S, G, cfg);
+    float rew[NC];
+    compute_rewards(S, G, cfg, rew);
+    for (int k = 0; k < NC; k++) reward[k] = rew[k];
+    *done_out = done ? 1 : 0;
+    TickEvents ev2;
+    for (int t = 1; t < cfg.tick_skip; t++) { ev2.bump_mask = 0; arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev2); }
+    G.episode_steps++;
+    if (done) {
+        reset_state(A, G, cfg, env_id);
+        gym_episode_reset(A, G, cfg, S);
+        G.tracker_flags &= ~0xff00u;
+        for (int k = 0; k < NC; k++) for (int i = 0; i < 8; i++) pa[k][i] = 0.f;
+    }
+    for (int k = 0; k < NC; k++) build_obs(S, k, pa[k], cfg, next_obs + (size_t)k * obs_row_stride);
+}
+
+// Gym::Reset for one env: state setter + bookkeeping + first observation
+template <int NC>
+RLG_HD void gym_reset_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* obs, size_t obs_row_stride, bool run_setter) {
+    if (run_setter) reset_state(A, G, cfg, env_id);
+    Snapshot<NC> S;
+    gym_episode_reset(A, G, cfg, S);
+    G.tracker_flags &= ~0xff00u;
+    float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (obs) for (int k = 0; k < NC; k++) build_obs(S, k, zero, cfg, obs + (size_t)k * obs_row_stride);
+}
+
+}  // namespace rlg

@@ -1,0 +1,222 @@
+// arena_io.h — moving one env between its three representations:
+//   (1) RlgpuArenaState   host AoS exchange struct in uu            (include/rlgpu_state.h)
+//   (2) Arena<NC>+GymEnv  the working copy a lane steps             (arena_types.h / arena_gym.h)
+//   (3) SoA words         the resident device layout [word][env]    (32-bit words, coalesced across lanes)
+// (3) is defined by ONE field visitor, `arena_visit`, so load and store can never disagree.
+#pragma once
+#include "arena_body.h"
+#include "../../include/rlgpu_state.h"
+
+namespace rlg {
+
+// gym-level carried state of one env (see RlgpuGymState for the reference fields it restates)
+template <int NC>
+struct GymEnv {
+    int32_t score_line[2];
+    int32_t last_touch_car_id;
+    int64_t last_tick_count;
+    int32_t no_touch_steps;
+    float shot_cooldown;
+    uint32_t tracker_flags;  // bit0 ball_shot, bit1 ball_shot_goal_team, bit2 ball_scored_last
+    int64_t last_ball_update_count;
+    int32_t counters[NC][8];  // goals saves assists shots shot_passes bumps demos boost_pickups
+    float event_last[NC][RLGPU_NUM_EVENT_VALS];
+    int32_t prev_action_idx[NC];   // index into the action table; -1 = zero action (reset / demoed)
+    uint32_t episode_steps;
+    uint32_t reset_count;          // RNG counter for state setters
+};
+
+RLG_HD uint32_t f2u(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
+RLG_HD float u2f(uint32_t u) { union { float f; uint32_t u; } x; x.u = u; return x.f; }
+
+// word accessors used by the visitor
+struct WordReader {
+    const uint32_t* base; size_t stride; size_t idx;
+    RLG_HD uint32_t next() { uint32_t v = base[idx * stride]; idx++; return v; }
+    RLG_HD void f(float& x) { x = u2f(next()); }
+    RLG_HD void i(int32_t& x) { x = (int32_t)next(); }
+    RLG_HD void u(uint32_t& x) { x = next(); }
+    RLG_HD void l(int64_t& x) { uint32_t lo = next(), hi = next(); x = (int64_t)(((uint64_t)hi << 32) | lo); }
+    RLG_HD void v(V3& x) { f(x.x); f(x.y); f(x.z); }
+};
+struct WordWriter {
+    uint32_t* base; size_t stride; size_t idx;
+    RLG_HD void put(uint32_t v) { base[idx * stride] = v; idx++; }
+    RLG_HD void f(float& x) { put(f2u(x)); }
+    RLG_HD void i(int32_t& x) { put((uint32_t)x); }
+    RLG_HD void u(uint32_t& x) { put(x); }
+    RLG_HD void l(int64_t& x) { put((uint32_t)((uint64_t)x & 0xffffffffu)); put((uint32_t)((uint64_t)x >> 32)); }
+    RLG_HD void v(V3& x) { f(x.x); f(x.y); f(x.z); }
+};
+struct WordCounter {
+    size_t idx = 0;
+    RLG_HD void f(float&) { idx++; }
+    RLG_HD void i(int32_t&) { idx++; }
+    RLG_HD void u(uint32_t&) { idx++; }
+    RLG_HD void l(int64_t&) { idx += 2; }
+    RLG_HD void v(V3&) { idx += 3; }
+};
+
+RLG_HD uint32_t pack_ctl(const Controls& c) { return (c.jump ? 1u : 0u) | (c.boost ? 2u : 0u) | (c.handbrake ? 4u : 0u); }
+RLG_HD void unpack_ctl(Controls& c, uint32_t b) { c.jump = b & 1u; c.boost = b & 2u; c.handbrake = b & 4u; }
+
+template <int NC, class IO>
+RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
+    io.l(A.tick_count); io.l(A.ball_update_counter);
+    io.v(A.ball.b.pos); io.v(A.ball.b.vel); io.v(A.ball.b.angvel); io.v(A.ball.vel_impulse_cache);
+    for (int k = 0; k < NC; k++) {
+        Car& c = A.cars[k];
+        io.v(c.b.pos); io.v(c.b.rot.r0); io.v(c.b.rot.r1); io.v(c.b.rot.r2); io.v(c.b.vel); io.v(c.b.angvel);
+        io.u(c.flags); io.v(c.flip_rel_torque);
+        io.f(c.jump_time); io.f(c.flip_time); io.f(c.air_time); io.f(c.air_time_since_jump); io.f(c.boost);
+        io.f(c.time_spent_boosting); io.f(c.supersonic_time); io.f(c.handbrake_val); io.f(c.auto_flip_timer); io.f(c.auto_flip_torque_scale);
+        io.v(c.world_contact_normal); io.i(c.car_contact_other); io.f(c.car_contact_cooldown); io.f(c.demo_respawn_timer);
+        io.v(c.bh_rel_pos); io.v(c.bh_ball_pos); io.v(c.bh_extra_hit_vel); io.l(c.bh_tick_hit); io.l(c.bh_tick_extra);
+        io.f(c.last.throttle); io.f(c.last.steer); io.f(c.last.pitch); io.f(c.last.yaw); io.f(c.last.roll);
+        io.f(c.ctl.throttle); io.f(c.ctl.steer); io.f(c.ctl.pitch); io.f(c.ctl.yaw); io.f(c.ctl.roll);
+        uint32_t bits = pack_ctl(c.last) | (pack_ctl(c.ctl) << 3);
+        io.u(bits);
+        Controls tmp; unpack_ctl(tmp, bits & 7u); c.last.jump = tmp.jump; c.last.boost = tmp.boost; c.last.handbrake = tmp.handbrake;
+        unpack_ctl(tmp, (bits >> 3) & 7u); c.ctl.jump = tmp.jump; c.ctl.boost = tmp.boost; c.ctl.handbrake = tmp.handbrake;
+        io.v(c.vel_impulse_cache);
+        for (int w = 0; w < 4; w++) io.f(c.extra_pushback[w]);
+        io.f(c.steer_angle); io.f(c.engine_force); io.f(c.brake);
+        for (int w = 0; w < 4; w++) io.f(c.lat_friction[w]);
+        for (int w = 0; w < 4; w++) io.f(c.long_friction[w]);
+    }
+    for (int p = 0; p < 34; p++) {
+        Pad& pd = A.pads[p];
+        io.f(pd.cooldown);
+        uint32_t bits = (pd.is_active ? 1u : 0u) | ((uint32_t)pd.prev_locked << 1);
+        io.u(bits);
+        pd.is_active = bits & 1u; pd.prev_locked = (int)(bits >> 1);
+    }
+    io.i(G.score_line[0]); io.i(G.score_line[1]); io.i(G.last_touch_car_id); io.l(G.last_tick_count); io.i(G.no_touch_steps);
+    io.f(G.shot_cooldown); io.u(G.tracker_flags); io.l(G.last_ball_update_count);
+    for (int k = 0; k < NC; k++) {
+        for (int q = 0; q < 8; q++) io.i(G.counters[k][q]);
+        for (int q = 0; q < RLGPU_NUM_EVENT_VALS; q++) io.f(G.event_last[k][q]);
+        io.i(G.prev_action_idx[k]);
+    }
+    io.u(G.episode_steps); io.u(G.reset_count);
+}
+
+template <int NC>
+constexpr size_t arena_num_words() {
+    // kept in sync with arena_visit by a static check in the tests (rlgpu_state_words() reports the visitor's count)
+    return 4 + 12 + (size_t)NC * 81 + 68 + 10 + (size_t)NC * 20 + 2;
+}
+
+// finish a freshly loaded working copy: derived values that are not stored
+template <int NC>
+RLG_HD void arena_finish_load(Arena<NC>& A) {
+    A.ball.b.rot = m3_identity();
+    A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
+    body_update_inertia(A.ball.b, ball_inv_inertia_local());
+    for (int k = 0; k < NC; k++) {
+        Car& c = A.cars[k];
+        c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0); c.frozen = false;
+        body_update_inertia(c.b, car_inv_inertia_local());
+    }
+    for (int p = 0; p < 34; p++) A.pads[p].cur_locked = 0;
+}
+
+// ---- (1) <-> (2) ----------------------------------------------------------------------------------------
+RLG_HD V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+RLG_HD void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+RLG_HD Controls ctl_from(const float* p) {
+    Controls c; c.throttle = p[0]; c.steer = p[1]; c.pitch = p[2]; c.yaw = p[3]; c.roll = p[4];
+    c.jump = p[5] != 0.f; c.boost = p[6] != 0.f; c.handbrake = p[7] != 0.f; return c;
+}
+RLG_HD void ctl_to(float* p, const Controls& c) {
+    p[0] = c.throttle; p[1] = c.steer; p[2] = c.pitch; p[3] = c.yaw; p[4] = c.roll;
+    p[5] = c.jump ? 1.f : 0.f; p[6] = c.boost ? 1.f : 0.f; p[7] = c.handbrake ? 1.f : 0.f;
+}
+
+template <int NC>
+RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& s) {
+    A.tick_count = s.tick_count; A.ball_update_counter = s.ball_update_counter;
+    A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
+    A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
+    for (int k = 0; k < NC; k++) {
+        const RlgpuCarState& o = s.cars[k]; Car& c = A.cars[k];
+        c.b.pos = ld3(o.pos) * UU2BT;
+        c.b.rot = m3_cols(ld3(o.rot), ld3(o.rot + 3), ld3(o.rot + 6));
+        c.b.vel = ld3(o.vel) * UU2BT; c.b.angvel = ld3(o.ang_vel);
+        c.flags = o.flags; c.flip_rel_torque = ld3(o.flip_rel_torque);
+        c.jump_time = o.jump_time; c.flip_time = o.flip_time; c.air_time = o.air_time; c.air_time_since_jump = o.air_time_since_jump;
+        c.boost = o.boost; c.time_spent_boosting = o.time_spent_boosting; c.supersonic_time = o.supersonic_time;
+        c.handbrake_val = o.handbrake_val; c.auto_flip_timer = o.auto_flip_timer; c.auto_flip_torque_scale = o.auto_flip_torque_scale;
+        c.world_contact_normal = ld3(o.world_contact_normal); c.car_contact_other = o.car_contact_other_id;
+        c.car_contact_cooldown = o.car_contact_cooldown; c.demo_respawn_timer = o.demo_respawn_timer;
+        c.bh_rel_pos = ld3(o.bh_rel_pos); c.bh_ball_pos = ld3(o.bh_ball_pos); c.bh_extra_hit_vel = ld3(o.bh_extra_hit_vel);
+        c.bh_tick_hit = o.bh_tick_hit; c.bh_tick_extra = o.bh_tick_extra;
+        c.last = ctl_from(o.last_controls); c.ctl = ctl_from(o.controls);
+        c.vel_impulse_cache = ld3(o.vel_impulse_cache) * UU2BT;
+        for (int w = 0; w < 4; w++) { c.extra_pushback[w] = o.extra_pushback[w]; c.lat_friction[w] = o.wheel_lat_friction[w]; c.long_friction[w] = o.wheel_long_friction[w]; }
+        c.steer_angle = o.wheel_steer_angle; c.engine_force = o.wheel_engine_force; c.brake = o.wheel_brake;
+    }
+    for (int p = 0; p < 34; p++) {
+        A.pads[p].cooldown = s.pads[p].cooldown; A.pads[p].is_active = s.pads[p].is_active != 0;
+        A.pads[p].prev_locked = s.pads[p].prev_locked_car_id; A.pads[p].cur_locked = 0;
+    }
+    const RlgpuGymState& g = s.gym;
+    G.score_line[0] = g.score_line[0]; G.score_line[1] = g.score_line[1]; G.last_touch_car_id = g.last_touch_car_id;
+    G.last_tick_count = g.last_tick_count; G.no_touch_steps = g.no_touch_steps; G.shot_cooldown = g.shot_cooldown;
+    G.tracker_flags = (g.ball_shot ? 1u : 0u) | (g.ball_shot_goal_team ? 2u : 0u) | (g.ball_scored_last ? 4u : 0u);
+    G.last_ball_update_count = g.last_ball_update_count;
+    for (int k = 0; k < NC; k++) {
+        const RlgpuPlayerGymState& q = g.players[k];
+        G.counters[k][0] = q.match_goals; G.counters[k][1] = q.match_saves; G.counters[k][2] = q.match_assists; G.counters[k][3] = q.match_shots;
+        G.counters[k][4] = q.match_shot_passes; G.counters[k][5] = q.match_bumps; G.counters[k][6] = q.match_demos; G.counters[k][7] = q.boost_pickups;
+        for (int e = 0; e < RLGPU_NUM_EVENT_VALS; e++) G.event_last[k][e] = q.event_last[e];
+        G.prev_action_idx[k] = -1;
+    }
+    G.episode_steps = 0; G.reset_count = 0;
+    arena_finish_load(A);
+}
+
+template <int NC>
+RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaState& s) {
+    s.num_cars = NC; s._pad0 = 0;
+    s.tick_count = A.tick_count; s.ball_update_counter = A.ball_update_counter;
+    st3(s.ball.pos, A.ball.b.pos * BT2UU); st3(s.ball.vel, A.ball.b.vel * BT2UU); st3(s.ball.ang_vel, A.ball.b.angvel);
+    st3(s.ball.vel_impulse_cache, A.ball.vel_impulse_cache * BT2UU);
+    for (int k = 0; k < NC; k++) {
+        RlgpuCarState& o = s.cars[k]; const Car& c = A.cars[k];
+        st3(o.pos, c.b.pos * BT2UU);
+        st3(o.rot, col0(c.b.rot)); st3(o.rot + 3, col1(c.b.rot)); st3(o.rot + 6, col2(c.b.rot));
+        st3(o.vel, c.b.vel * BT2UU); st3(o.ang_vel, c.b.angvel);
+        o.flags = c.flags; st3(o.flip_rel_torque, c.flip_rel_torque);
+        o.jump_time = c.jump_time; o.flip_time = c.flip_time; o.air_time = c.air_time; o.air_time_since_jump = c.air_time_since_jump;
+        o.boost = c.boost; o.time_spent_boosting = c.time_spent_boosting; o.supersonic_time = c.supersonic_time;
+        o.handbrake_val = c.handbrake_val; o.auto_flip_timer = c.auto_flip_timer; o.auto_flip_torque_scale = c.auto_flip_torque_scale;
+        st3(o.world_contact_normal, c.world_contact_normal); o.car_contact_other_id = c.car_contact_other;
+        o.car_contact_cooldown = c.car_contact_cooldown; o.demo_respawn_timer = c.demo_respawn_timer;
+        st3(o.bh_rel_pos, c.bh_rel_pos); st3(o.bh_ball_pos, c.bh_ball_pos); st3(o.bh_extra_hit_vel, c.bh_extra_hit_vel);
+        o.bh_tick_hit = c.bh_tick_hit; o.bh_tick_extra = c.bh_tick_extra;
+        ctl_to(o.last_controls, c.last); ctl_to(o.controls, c.ctl);
+        st3(o.vel_impulse_cache, c.vel_impulse_cache * BT2UU);
+        for (int w = 0; w < 4; w++) { o.extra_pushback[w] = c.extra_pushback[w]; o.wheel_lat_friction[w] = c.lat_friction[w]; o.wheel_long_friction[w] = c.long_friction[w]; }
+        o.wheel_steer_angle = c.steer_angle; o.wheel_engine_force = c.engine_force; o.wheel_brake = c.brake;
+    }
+    for (int p = 0; p < 34; p++) {
+        s.pads[p].cooldown = A.pads[p].cooldown; s.pads[p].is_active = A.pads[p].is_active ? 1 : 0;
+        s.pads[p]._pad[0] = s.pads[p]._pad[1] = s.pads[p]._pad[2] = 0;
+        s.pads[p].prev_locked_car_id = A.pads[p].prev_locked;
+    }
+    RlgpuGymState& g = s.gym;
+    g.score_line[0] = G.score_line[0]; g.score_line[1] = G.score_line[1]; g.last_touch_car_id = G.last_touch_car_id;
+    g.last_tick_count = G.last_tick_count; g.no_touch_steps = G.no_touch_steps; g.shot_cooldown = G.shot_cooldown;
+    g.ball_shot = G.tracker_flags & 1u ? 1 : 0; g.ball_shot_goal_team = G.tracker_flags & 2u ? 1 : 0; g.ball_scored_last = G.tracker_flags & 4u ? 1 : 0; g._pad0 = 0;
+    g.last_ball_update_count = G.last_ball_update_count;
+    for (int k = 0; k < NC; k++) {
+        RlgpuPlayerGymState& q = g.players[k];
+        q.match_goals = G.counters[k][0]; q.match_saves = G.counters[k][1]; q.match_assists = G.counters[k][2]; q.match_shots = G.counters[k][3];
+        q.match_shot_passes = G.counters[k][4]; q.match_bumps = G.counters[k][5]; q.match_demos = G.counters[k][6]; q.boost_pickups = G.counters[k][7];
+        for (int e = 0; e < RLGPU_NUM_EVENT_VALS; e++) q.event_last[e] = G.event_last[k][e];
+        for (int e = 0; e < 8; e++) q.prev_action[e] = 0.f;
+    }
+}
+
+}  // namespace rlg

@@ -1,0 +1,205 @@
+// arena_mesh.cpp — see arena_mesh.h
+#include "arena_mesh.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <queue>
+
+namespace rlg {
+
+namespace {
+struct P3 { float x, y, z; };
+P3 sub(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+P3 crs(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+float dt3(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct BuildNode { float mn[3], mx[3]; int left = -1, right = -1, first = 0, count = 0; };
+
+void tri_bounds(const MeshTri& t, float* mn, float* mx) {
+    mn[0] = std::min({t.v0x, t.v1x, t.v2x}); mx[0] = std::max({t.v0x, t.v1x, t.v2x});
+    mn[1] = std::min({t.v0y, t.v1y, t.v2y}); mx[1] = std::max({t.v0y, t.v1y, t.v2y});
+    mn[2] = std::min({t.v0z, t.v1z, t.v2z}); mx[2] = std::max({t.v0z, t.v1z, t.v2z});
+}
+
+int build_rec(std::vector<MeshTri>& tris, std::vector<BuildNode>& nodes, int first, int count) {
+    BuildNode nd;
+    for (int a = 0; a < 3; a++) { nd.mn[a] = 1e30f; nd.mx[a] = -1e30f; }
+    for (int i = first; i < first + count; i++) {
+        float mn[3], mx[3]; tri_bounds(tris[i], mn, mx);
+        for (int a = 0; a < 3; a++) { nd.mn[a] = std::min(nd.mn[a], mn[a]); nd.mx[a] = std::max(nd.mx[a], mx[a]); }
+    }
+    int idx = (int)nodes.size();
+    nodes.push_back(nd);
+    if (count <= 4) { nodes[idx].first = first; nodes[idx].count = count; return idx; }
+    int axis = 0; float ext = nd.mx[0] - nd.mn[0];
+    for (int a = 1; a < 3; a++) if (nd.mx[a] - nd.mn[a] > ext) { ext = nd.mx[a] - nd.mn[a]; axis = a; }
+    auto centroid = [axis](const MeshTri& t) {
+        const float* p = &t.v0x;
+        return p[axis] + p[3 + axis] + p[6 + axis];
+    };
+    int mid = first + count / 2;
+    std::nth_element(tris.begin() + first, tris.begin() + mid, tris.begin() + first + count,
+                     [&](const MeshTri& a, const MeshTri& b) { return centroid(a) < centroid(b); });
+    int l = build_rec(tris, nodes, first, mid - first);
+    int r = build_rec(tris, nodes, mid, first + count - mid);
+    nodes[idx].left = l; nodes[idx].right = r;
+    return idx;
+}
+
+using Key = std::tuple<int64_t, int64_t, int64_t>;
+Key qkey(float x, float y, float z) {
+    const float q = 1024.f;  // BT units -> 1/1024 BT (~0.05 uu) grid
+    return Key{(int64_t)std::llround(x * q), (int64_t)std::llround(y * q), (int64_t)std::llround(z * q)};
+}
+}  // namespace
+
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
+    HostMesh m;
+    m.tris.resize(n_tris);
+    for (int i = 0; i < n_tris; i++) {
+        MeshTri& t = m.tris[i];
+        float* p = &t.v0x;
+        for (int k = 0; k < 3; k++) {
+            int vi = tris[i * 3 + k];
+            if (vi < 0 || vi >= n_verts) vi = 0;
+            for (int a = 0; a < 3; a++) p[k * 3 + a] = verts_uu[vi * 3 + a] * UU2BT;
+        }
+        t.edge_flags = 0; t._pad0 = 0; t._pad1 = 0;
+    }
+    // edge adjacency -> flags. bit e: edge e is flat or concave seen from the FRONT (normal side);
+    // bit 3+e: flat or concave seen from the BACK. (A convex edge from one side is concave from the other.)
+    std::map<std::pair<Key, Key>, std::vector<std::pair<int, int>>> edges;
+    for (int i = 0; i < n_tris; i++) {
+        const float* p = &m.tris[i].v0x;
+        for (int e = 0; e < 3; e++) {
+            Key a = qkey(p[e * 3], p[e * 3 + 1], p[e * 3 + 2]);
+            int e2 = (e + 1) % 3;
+            Key b = qkey(p[e2 * 3], p[e2 * 3 + 1], p[e2 * 3 + 2]);
+            if (b < a) std::swap(a, b);
+            edges[{a, b}].push_back({i, e});
+        }
+    }
+    for (auto& kv : edges) {
+        if (kv.second.size() < 2) continue;
+        for (auto& self : kv.second) {
+            for (auto& other : kv.second) {
+                if (other.first == self.first) continue;
+                const float* p = &m.tris[self.first].v0x;
+                const float* q = &m.tris[other.first].v0x;
+                P3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+                P3 n = crs(sub(v1, v0), sub(v2, v0));
+                float nl = std::sqrt(dt3(n, n));
+                if (nl < 1e-12f) continue;
+                n = {n.x / nl, n.y / nl, n.z / nl};
+                int oe = other.second; int opp = (oe + 2) % 3;  // vertex of the neighbour not on the shared edge
+                P3 ov{q[opp * 3], q[opp * 3 + 1], q[opp * 3 + 2]};
+                float side = dt3(n, sub(ov, v0));
+                const float flat_eps = 1e-3f;  // BT
+                if (side >= -flat_eps) m.tris[self.first].edge_flags |= (1u << self.second);       // flat or concave from the front
+                if (side <= flat_eps) m.tris[self.first].edge_flags |= (1u << (3 + self.second));   // flat or concave from the back
+            }
+        }
+    }
+    if (n_tris == 0) return m;
+    std::vector<BuildNode> bn;
+    bn.reserve(2 * n_tris);
+    build_rec(m.tris, bn, 0, n_tris);
+    // breadth-first renumbering with sibling pairs adjacent
+    std::vector<int> order; order.reserve(bn.size());
+    std::vector<int> newidx(bn.size(), -1);
+    std::queue<int> q; q.push(0);
+    order.push_back(0); newidx[0] = 0;
+    while (!q.empty()) {
+        int i = q.front(); q.pop();
+        if (bn[i].count == 0) {
+            newidx[bn[i].left] = (int)order.size(); order.push_back(bn[i].left);
+            newidx[bn[i].right] = (int)order.size(); order.push_back(bn[i].right);
+            q.push(bn[i].left); q.push(bn[i].right);
+        }
+    }
+    m.nodes.resize(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        const BuildNode& b = bn[order[k]];
+        BvhNode& n = m.nodes[k];
+        n.minx = b.mn[0]; n.miny = b.mn[1]; n.minz = b.mn[2]; n.maxx = b.mx[0]; n.maxy = b.mx[1]; n.maxz = b.mx[2];
+        if (b.count > 0) { n.left_or_first = b.first; n.count = b.count; }
+        else { n.left_or_first = newidx[b.left]; n.count = 0; }
+    }
+    return m;
+}
+
+namespace {
+struct MeshOut {
+    std::vector<float>& v; std::vector<int32_t>& t;
+    int vert(float x, float y, float z) { v.push_back(x); v.push_back(y); v.push_back(z); return (int)(v.size() / 3) - 1; }
+    void quad(const float a[3], const float b[3], const float c[3], const float d[3]) {
+        int i0 = vert(a[0], a[1], a[2]), i1 = vert(b[0], b[1], b[2]), i2 = vert(c[0], c[1], c[2]), i3 = vert(d[0], d[1], d[2]);
+        t.push_back(i0); t.push_back(i1); t.push_back(i2);
+        t.push_back(i0); t.push_back(i2); t.push_back(i3);
+    }
+    // quarter-cylinder fillet along the segment p0->p1 lying in the junction of a horizontal surface (floor or
+    // ceiling, `up` = +1 / -1) and a vertical wall whose inward horizontal unit normal is (inx, iny)
+    void fillet(float x0, float y0, float x1, float y1, float zbase, float up, float inx, float iny, float R, int segs) {
+        for (int s = 0; s < segs; s++) {
+            float a0 = (float)(M_PI / 2) * s / segs, a1 = (float)(M_PI / 2) * (s + 1) / segs;
+            auto pt = [&](float x, float y, float a, float* o) {
+                float cx = x + inx * R, cy = y + iny * R, cz = zbase + up * R;
+                o[0] = cx - inx * R * std::sin(a); o[1] = cy - iny * R * std::sin(a); o[2] = cz - up * R * std::cos(a);
+            };
+            float A[3], B[3], C[3], D[3];
+            pt(x0, y0, a0, A); pt(x1, y1, a0, B); pt(x1, y1, a1, C); pt(x0, y0, a1, D);
+            quad(A, B, C, D);
+        }
+    }
+};
+}  // namespace
+
+void make_procedural_soccar(std::vector<float>& verts, std::vector<int32_t>& tris) {
+    MeshOut m{verts, tris};
+    const float X = 4096.f, Y = 5120.f, Z = 2048.f, GX = 892.755f, GZ = 642.775f, GY = 6000.f, CUT = 1152.f, R = 256.f;
+    const int SEG = 4;
+    for (int s = -1; s <= 1; s += 2) {
+        float y = s * Y, yb = s * GY;
+        // back wall around the goal mouth
+        { float a[3] = {-(X - CUT), y, 0}, b[3] = {-GX, y, 0}, c[3] = {-GX, y, Z}, d[3] = {-(X - CUT), y, Z}; m.quad(a, b, c, d); }
+        { float a[3] = {GX, y, 0}, b[3] = {X - CUT, y, 0}, c[3] = {X - CUT, y, Z}, d[3] = {GX, y, Z}; m.quad(a, b, c, d); }
+        { float a[3] = {-GX, y, GZ}, b[3] = {GX, y, GZ}, c[3] = {GX, y, Z}, d[3] = {-GX, y, Z}; m.quad(a, b, c, d); }
+        // goal box: sides, back, roof
+        { float a[3] = {-GX, y, 0}, b[3] = {-GX, yb, 0}, c[3] = {-GX, yb, GZ}, d[3] = {-GX, y, GZ}; m.quad(a, b, c, d); }
+        { float a[3] = {GX, y, 0}, b[3] = {GX, yb, 0}, c[3] = {GX, yb, GZ}, d[3] = {GX, y, GZ}; m.quad(a, b, c, d); }
+        { float a[3] = {-GX, yb, 0}, b[3] = {GX, yb, 0}, c[3] = {GX, yb, GZ}, d[3] = {-GX, yb, GZ}; m.quad(a, b, c, d); }
+        { float a[3] = {-GX, y, GZ}, b[3] = {GX, y, GZ}, c[3] = {GX, yb, GZ}, d[3] = {-GX, yb, GZ}; m.quad(a, b, c, d); }
+        // corner walls (45 degrees) on both x sides
+        for (int sx = -1; sx <= 1; sx += 2) {
+            float a[3] = {sx * (X - CUT), y, 0}, b[3] = {sx * X, s * (Y - CUT), 0}, c[3] = {sx * X, s * (Y - CUT), Z}, d[3] = {sx * (X - CUT), y, Z};
+            m.quad(a, b, c, d);
+            const float inv = 0.70710678f;
+            for (int up = -1; up <= 1; up += 2)
+                m.fillet(sx * (X - CUT), y, sx * X, s * (Y - CUT), up > 0 ? 0.f : Z, (float)up, -sx * inv, -s * inv, R, SEG);
+        }
+        // fillets along the back wall (left and right of the goal on the floor, full width on the ceiling)
+        m.fillet(-(X - CUT), y, -GX, y, 0.f, 1.f, 0.f, (float)-s, R, SEG);
+        m.fillet(GX, y, X - CUT, y, 0.f, 1.f, 0.f, (float)-s, R, SEG);
+        m.fillet(-(X - CUT), y, X - CUT, y, Z, -1.f, 0.f, (float)-s, R, SEG);
+    }
+    // fillets along the side walls (the walls themselves are planes, Arena.cpp:1060-1101)
+    for (int sx = -1; sx <= 1; sx += 2)
+        for (int up = -1; up <= 1; up += 2)
+            m.fillet(sx * X, -(Y - CUT), sx * X, (Y - CUT), up > 0 ? 0.f : Z, (float)up, (float)-sx, 0.f, R, SEG);
+}
+
+bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts, std::vector<int32_t>& tris) {
+    if (size < 8) return false;
+    int32_t nt, nv;
+    memcpy(&nt, data, 4); memcpy(&nv, data + 4, 4);
+    if (nt < 0 || nv < 0 || size < 8 + (size_t)nt * 12 + (size_t)nv * 12) return false;
+    int base = (int)(verts.size() / 3);
+    const uint8_t* p = data + 8;
+    for (int i = 0; i < nt * 3; i++) { int32_t v; memcpy(&v, p, 4); p += 4; tris.push_back(base + v); }
+    for (int i = 0; i < nv * 3; i++) { float v; memcpy(&v, p, 4); p += 4; verts.push_back(v * BT2UU); }
+    return true;
+}
+
+}  // namespace rlg

@@ -1,0 +1,30 @@
+// arena_mesh.h — host-side construction of the static arena mesh: the procedural soccar stand-in,
+// the .cmf reader (CollisionMeshFile.cpp:11-36 format), per-edge flags and this repo's BVH.
+//
+// The reference shares one quantized btBvhTriangleMeshShape per .cmf file between all arenas
+// (RocketSim.cpp:149-167, Arena.cpp:1054-1057).  Here all meshes are merged into one triangle soup with one
+// binary AABB tree in breadth-first order, so the first n nodes (the top levels) are contiguous and can be
+// staged in LDS by the stepper kernel; only the SET of triangles a query reports matters.
+#pragma once
+#include <vector>
+#include <cstdint>
+#include "arena_types.h"
+
+namespace rlg {
+
+struct HostMesh {
+    std::vector<MeshTri> tris;   // BT units, in BVH leaf order
+    std::vector<BvhNode> nodes;  // breadth-first
+};
+
+// verts in uu, tris index triplets
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris);
+
+// the procedural soccar arena (uu): back walls with goal mouths, goal boxes, 45-degree corner walls and
+// quarter-cylinder floor fillets.  Geometry facts from RLConst.h:14-16,109, Arena.cpp:846-849, CommonValues.h:9-13.
+void make_procedural_soccar(std::vector<float>& verts_uu, std::vector<int32_t>& tris);
+
+// parse one .cmf blob (i32 nTris, i32 nVerts, tris, verts in BT units) and append to verts(uu)/tris
+bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts_uu, std::vector<int32_t>& tris);
+
+}  // namespace rlg

@@ -1,0 +1,520 @@
+// arena_step.h — one physics tick of one arena: Arena::Step (RocketSim/src/Sim/Arena/Arena.cpp:716-812) with
+// btDiscreteDynamicsWorld::stepSimulation (btDiscreteDynamicsWorld.cpp:325-437) restated for the fixed body
+// set {ball, NC cars} and the contact list of arena_world.h.
+#pragma once
+#include "arena_car.h"
+
+namespace rlg {
+
+// ---- contact-added callbacks (Arena.cpp:283-427) ----------------------------------------------------------
+template <int NC>
+RLG_HD void on_car_ball_contact(Arena<NC>& A, int ci, V3 point_on_ball_world) {
+    Car& car = A.cars[ci];
+    Ball& ball = A.ball;
+    car.flags |= CF_BALLHIT_VALID;
+    car.bh_rel_pos = (point_on_ball_world - ball.b.pos) * BT2UU;  // m_localPoint on the ball (ball basis = identity)
+    car.bh_tick_hit = A.tick_count;
+    car.bh_ball_pos = ball.b.pos * BT2UU;
+    car.bh_extra_hit_vel = v3(0, 0, 0);
+    // unsigned arithmetic in the reference: tickCountWhenExtraImpulseApplied starts at ~0ULL ("never") -> +1 wraps to 0
+    bool never = car.bh_tick_extra < 0;
+    if (never || (A.tick_count > car.bh_tick_extra + 1) || (car.bh_tick_extra > A.tick_count)) car.bh_tick_extra = A.tick_count;
+    else return;
+    V3 car_fwd = col0(car.b.rot);
+    V3 rel_pos = (ball.b.pos * BT2UU) - (car.b.pos * BT2UU);
+    V3 rel_vel = (ball.b.vel * BT2UU) - (car.b.vel * BT2UU);
+    float rel_speed = fminf(len(rel_vel), K::BALL_CAR_EXTRA_IMPULSE_MAXDELTAVEL_UU);
+    if (rel_speed > 0.f) {
+        V3 hit_dir = safe_normalized(rel_pos * v3(1, 1, K::BALL_CAR_EXTRA_IMPULSE_Z_SCALE));
+        V3 adj = car_fwd * dot(hit_dir, car_fwd) * (1 - K::BALL_CAR_EXTRA_IMPULSE_FORWARD_SCALE);
+        hit_dir = safe_normalized(hit_dir - adj);
+        V3 added = (hit_dir * rel_speed) * curve_ball_car_extra(rel_speed) * 1.f;
+        car.bh_extra_hit_vel = added;
+        ball.vel_impulse_cache += added * UU2BT;
+    }
+}
+
+// Arena::_BtCallback_OnCarCarCollision (Arena.cpp:336-418). local points are in each car's body frame (BT).
+template <int NC>
+RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 local_b, TickEvents& ev) {
+    for (int i = 0; i < 2; i++) {
+        bool swapped = (i == 1);
+        int i1 = swapped ? ib : ia, i2 = swapped ? ia : ib;
+        Car& c1 = A.cars[i1]; Car& c2 = A.cars[i2];
+        if ((c1.flags & CF_IS_DEMOED) || (c2.flags & CF_IS_DEMOED)) return;
+        if (c1.car_contact_other == i2 + 1 && c1.car_contact_cooldown > 0) continue;
+        V3 p1 = c1.b.pos * BT2UU, p2 = c2.b.pos * BT2UU, v1 = c1.b.vel * BT2UU, v2 = c2.b.vel * BT2UU;
+        V3 delta = p2 - p1;
+        if (dot(v1, delta) > 0) {
+            float l1 = len(v1); V3 vel_dir = (l1 > SIMD_EPS * SIMD_EPS) ? v1 / l1 : v3(0, 0, 0);
+            float l2 = len(delta); V3 dir_to = (l2 > SIMD_EPS * SIMD_EPS) ? delta / l2 : v3(0, 0, 0);
+            float speed_towards = dot(v1, dir_to);
+            float other_away = dot(v2, vel_dir);
+            if (speed_towards > other_away) {
+                V3 lp = swapped ? local_b : local_a;
+                bool bumper = (lp.x * BT2UU) > K::BUMP_MIN_FORWARD_DIST;
+                if (bumper) {
+                    bool is_demo = (c1.flags & CF_IS_SUPERSONIC) != 0;
+                    if (is_demo) is_demo = (i1 % 2) != (i2 % 2);  // enableTeamDemos = false
+                    if (is_demo) {
+                        c2.flags |= CF_IS_DEMOED; c2.demo_respawn_timer = K::DEMO_RESPAWN_TIME;
+                    } else {
+                        bool ground_hit = c2.flags & CF_ON_GROUND;
+                        float base = ground_hit ? curve_bump_ground(speed_towards) : curve_bump_air(speed_towards);
+                        V3 hit_up = ground_hit ? col2(c2.b.rot) : v3(0, 0, 1);
+                        V3 imp = vel_dir * base + hit_up * curve_bump_up(speed_towards) * 1.f;
+                        c2.vel_impulse_cache += imp * UU2BT;
+                    }
+                    c1.car_contact_other = i2 + 1;
+                    c1.car_contact_cooldown = K::BUMP_COOLDOWN_TIME;
+                    if ((i1 % 2) != (i2 % 2)) {  // Gym.cpp:30-38: only bumps on opponents count
+                        ev.bump_mask |= (1u << i1);
+                        if (is_demo) ev.bump_mask |= (1u << (8 + i1));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- narrowphase over all pairs -----------------------------------------------------------------------
+template <int NC, int MAXC>
+RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool& ball_car_touch) {
+    L.n = 0; ball_car_touch = false;
+    const float r = K::BALL_RADIUS * UU2BT;
+    // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121)
+    V3 bp = A.ball.b.pos;
+    for (int i = 0; i < 4; i++) {
+        V3 n; float d; world_plane(i, n, d);
+        float dist = (dot(n, bp - n * r) - d);
+        if (dist < CBT_BALL) {
+            Contact c; c.a = 0; c.b = -1; c.n = n; c.dist = dist;
+            V3 pb = (bp - n * r) - n * dist;
+            c.ra = (pb + n * dist) - bp; c.rb = pb;
+            c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
+            push_contact(L, c);
+        }
+    }
+    // ball vs mesh
+    if (mesh.n_nodes > 0) {
+        float ext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
+        V3 lo = bp - v3(ext, ext, ext), hi = bp + v3(ext, ext, ext);
+        int stack[32]; int sp = 0; stack[sp++] = 0;
+        while (sp > 0) {
+            BvhNode nd = mesh_node(mesh, stack[--sp]);
+            if (!aabb_overlap(nd, lo, hi)) continue;
+            if (nd.count > 0) {
+                for (int k = 0; k < nd.count; k++) {
+                    V3 pt, n; float depth;
+                    if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[nd.left_or_first + k], pt, n, depth)) {
+                        Contact c; c.a = 0; c.b = -1; c.n = n; c.dist = depth;
+                        c.ra = (pt + n * depth) - bp; c.rb = pt;
+                        c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
+                        push_contact(L, c);
+                    }
+                }
+            } else if (sp < 30) { stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1; }
+        }
+    }
+    // cars
+    for (int ci = 0; ci < NC; ci++) {
+        Car& car = A.cars[ci];
+        if (car.flags & CF_IS_DEMOED) continue;  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
+        if (car.frozen) continue;
+        V3 h = hitbox_half();
+        V3 bc = car.b.pos + car.b.rot * hitbox_off();
+        Cand cs[4]; int nc = 0;
+        // planes: every hitbox corner within the threshold (see header comment)
+        for (int i = 0; i < 4; i++) {
+            V3 n; float d; world_plane(i, n, d);
+            V3 nl = tmul(car.b.rot, n);
+            float rr = h.x * fabsf(nl.x) + h.y * fabsf(nl.y) + h.z * fabsf(nl.z);
+            if (dot(n, bc) - d - rr >= CBT_CAR) continue;
+            for (int q = 0; q < 8; q++) {
+                V3 cl = v3((q & 1) ? h.x : -h.x, (q & 2) ? h.y : -h.y, (q & 4) ? h.z : -h.z);
+                V3 cw = bc + car.b.rot * cl;
+                float dist = dot(n, cw) - d;
+                if (dist < CBT_CAR) { Cand c; c.n = n; c.dist = dist; c.pb = cw - n * dist; cand_add(cs, nc, c); }
+            }
+        }
+        // mesh
+        if (mesh.n_nodes > 0) {
+            M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
+                              v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
+                              v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
+            V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
+            V3 lo = bc - ext, hi = bc + ext;
+            int stack[32]; int sp = 0; stack[sp++] = 0;
+            while (sp > 0) {
+                BvhNode nd = mesh_node(mesh, stack[--sp]);
+                if (!aabb_overlap(nd, lo, hi)) continue;
+                if (nd.count > 0) {
+                    for (int k = 0; k < nd.count; k++) box_triangle(bc, car.b.rot, h, mesh.tris[nd.left_or_first + k], CBT_CAR, cs, nc);
+                } else if (sp < 30) { stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1; }
+            }
+        }
+        for (int k = 0; k < nc; k++) {
+            Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
+            c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
+            c.friction = K::CARWORLD_FRICTION; c.restitution = K::CARWORLD_RESTITUTION; c.special = false;
+            push_contact(L, c);
+            // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
+            car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = cs[k].n;
+        }
+        // car vs ball: ball is body A of the pair (lower broadphase id), the car B
+        {
+            V3 pb, n; float dist;
+            if (sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, n, dist)) {
+                Contact c; c.a = 0; c.b = 1 + ci; c.n = n; c.dist = dist;
+                V3 pa = pb + n * dist;
+                c.ra = pa - bp; c.rb = pb - car.b.pos;
+                c.friction = K::CARBALL_FRICTION; c.restitution = K::CARBALL_RESTITUTION; c.special = false;
+                push_contact(L, c);
+                ball_car_touch = true;
+                on_car_ball_contact(A, ci, pa);
+            }
+        }
+    }
+    // car vs car
+    for (int ia = 0; ia < NC; ia++) {
+        for (int ib = ia + 1; ib < NC; ib++) {
+            Car& ca = A.cars[ia]; Car& cb = A.cars[ib];
+            if ((ca.flags & CF_IS_DEMOED) || (cb.flags & CF_IS_DEMOED) || ca.frozen || cb.frozen) continue;
+            V3 h = hitbox_half();
+            V3 cca = ca.b.pos + ca.b.rot * hitbox_off(), ccb = cb.b.pos + cb.b.rot * hitbox_off();
+            float rad = len(h);
+            if (len2(cca - ccb) > (2 * rad) * (2 * rad)) continue;
+            Cand cs[4]; int nc = 0;
+            box_box(cca, ca.b.rot, ccb, cb.b.rot, h, cs, nc);
+            for (int k = 0; k < nc; k++) {
+                Contact c; c.a = 1 + ia; c.b = 1 + ib; c.n = cs[k].n; c.dist = cs[k].dist;
+                V3 pa = cs[k].pb + cs[k].n * cs[k].dist;
+                c.ra = pa - ca.b.pos; c.rb = cs[k].pb - cb.b.pos;
+                c.friction = K::CARCAR_FRICTION; c.restitution = K::CARCAR_RESTITUTION; c.special = false;
+                push_contact(L, c);
+                on_car_car_contact(A, ia, ib, tmul(ca.b.rot, c.ra), tmul(cb.b.rot, c.rb), ev);
+            }
+        }
+    }
+}
+
+// ---- sequential-impulse solve (btSequentialImpulseConstraintSolver.cpp:795-983,1003-1211,1601-1926) ----------
+struct SolverBody {
+    V3 v, w, dv, dw, push, turn, ext_f, ext_t;
+    M3 inv_i;
+    float inv_m;
+    bool active;
+};
+struct Row {
+    int a, b;
+    V3 n1, r1xn, n2, r2xn, ang_a, ang_b;
+    float jac, rhs, rhs_pen, applied, applied_push, lo, hi, friction;
+    bool skip;     // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
+    int fric_of;   // for friction rows: index of the normal row; -1 for normal rows
+};
+
+template <int NB>
+RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, float dist, float fric, float rest, bool has_b) {
+    const float dt = TICK_DT;
+    SolverBody& A = B[c.a];
+    r.a = c.a; r.b = has_b ? c.b : -1;
+    V3 t0 = cross(ra, n);
+    r.ang_a = A.inv_i * t0;
+    V3 t1 = cross(rb, n);
+    r.ang_b = has_b ? (B[c.b].inv_i * (-t1)) : v3(0, 0, 0);
+    float d0 = A.inv_m + dot(n, cross(r.ang_a, ra));
+    float d1 = has_b ? (B[c.b].inv_m + dot(n, cross(-r.ang_b, rb))) : 0.f;
+    r.jac = 1.f / (d0 + d1);
+    r.n1 = n; r.r1xn = t0;
+    if (has_b) { r.n2 = -n; r.r2xn = -t1; } else { r.n2 = v3(0, 0, 0); r.r2xn = v3(0, 0, 0); }
+    V3 vel1 = A.v + cross(A.w, ra);
+    V3 vel2 = has_b ? (B[c.b].v + cross(B[c.b].w, rb)) : v3(0, 0, 0);
+    float rel_vel = dot(n, vel1 - vel2);
+    float restitution = 0.f;
+    if (!(fabsf(rel_vel) < K::RESTITUTION_VEL_THRESHOLD)) restitution = rest * -rel_vel;
+    if (restitution <= 0.f) restitution = 0.f;
+    r.friction = fric;
+    r.applied = 0.f; r.applied_push = 0.f;
+    V3 efa = A.ext_f, eta = A.ext_t;
+    float v1 = dot(r.n1, A.v + efa) + dot(r.r1xn, A.w + eta);
+    float v2 = has_b ? (dot(r.n2, B[c.b].v + B[c.b].ext_f) + dot(r.r2xn, B[c.b].w + B[c.b].ext_t)) : 0.f;
+    float rv = v1 + v2;
+    float vel_err = restitution - rv;
+    float pos_err = 0.f;
+    if (dist > 0.f) pos_err = 0.f; else pos_err = -dist * K::ERP2 * (1.f / dt);
+    r.rhs = vel_err * r.jac;
+    r.rhs_pen = pos_err * r.jac;
+    r.lo = 0.f; r.hi = 1e10f;
+    r.skip = false; r.fric_of = -1;
+}
+
+template <int NB>
+RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, bool has_b) {
+    SolverBody& A = B[nr.a];
+    V3 vel1 = A.v + cross(A.w, ra);
+    V3 vel2 = has_b ? (B[nr.b].v + cross(B[nr.b].w, rb)) : v3(0, 0, 0);
+    V3 vel = vel1 - vel2;
+    float rel_vel = dot(n, vel);
+    V3 lat = vel - n * rel_vel;
+    float l2 = len2(lat);
+    if (l2 > SIMD_EPS) lat = lat * (1.f / sqrtf(l2));
+    else { V3 q; plane_space1(n, lat, q); }
+    r.a = nr.a; r.b = nr.b;
+    r.friction = nr.friction; r.applied = 0.f; r.applied_push = 0.f;
+    r.n1 = lat; V3 f1 = cross(ra, lat); r.r1xn = f1; r.ang_a = A.inv_i * f1;
+    if (has_b) { r.n2 = -lat; V3 f2 = cross(rb, r.n2); r.r2xn = f2; r.ang_b = B[nr.b].inv_i * f2; }
+    else { r.n2 = v3(0, 0, 0); r.r2xn = v3(0, 0, 0); r.ang_b = v3(0, 0, 0); }
+    float d0 = A.inv_m + dot(lat, cross(r.ang_a, ra));
+    float d1 = has_b ? (B[nr.b].inv_m + dot(lat, cross(-r.ang_b, rb))) : 0.f;
+    r.jac = 1.f / (d0 + d1);
+    float v1 = dot(r.n1, A.v + A.ext_f) + dot(r.r1xn, A.w);
+    float v2 = has_b ? (dot(r.n2, B[nr.b].v + B[nr.b].ext_f) + dot(r.r2xn, B[nr.b].w)) : 0.f;
+    float rv = v1 + v2;
+    r.rhs = (0.f - rv) * r.jac; r.rhs_pen = 0.f;
+    r.lo = -r.friction; r.hi = r.friction;
+    r.skip = false; r.fric_of = normal_idx;
+}
+
+template <int NB>
+RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], bool lower_only) {
+    SolverBody& A = B[c.a];
+    float delta = c.rhs;  // cfm = 0
+    float dv1 = dot(c.n1, A.dv) + dot(c.r1xn, A.dw);
+    float dv2 = (c.b >= 0) ? (dot(c.n2, B[c.b].dv) + dot(c.r2xn, B[c.b].dw)) : 0.f;
+    delta -= dv1 * c.jac;
+    delta -= dv2 * c.jac;
+    float sum = c.applied + delta;
+    if (sum < c.lo) { delta = c.lo - c.applied; c.applied = c.lo; }
+    else if (!lower_only && sum > c.hi) { delta = c.hi - c.applied; c.applied = c.hi; }
+    else c.applied = sum;
+    A.dv += (c.n1 * A.inv_m) * delta; A.dw += c.ang_a * delta;
+    if (c.b >= 0) { B[c.b].dv += (c.n2 * B[c.b].inv_m) * delta; B[c.b].dw += c.ang_b * delta; }
+}
+template <int NB>
+RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
+    if (c.rhs_pen == 0.f) return 0.f;
+    SolverBody& A = B[c.a];
+    float delta = c.rhs_pen;
+    float dv1 = dot(c.n1, A.push) + dot(c.r1xn, A.turn);
+    float dv2 = (c.b >= 0) ? (dot(c.n2, B[c.b].push) + dot(c.r2xn, B[c.b].turn)) : 0.f;
+    delta -= dv1 * c.jac;
+    delta -= dv2 * c.jac;
+    float sum = c.applied_push + delta;
+    if (sum < c.lo) { delta = c.lo - c.applied_push; c.applied_push = c.lo; }
+    else c.applied_push = sum;
+    A.push += (c.n1 * A.inv_m) * delta; A.turn += c.ang_a * delta;
+    if (c.b >= 0) { B[c.b].push += (c.n2 * B[c.b].inv_m) * delta; B[c.b].turn += c.ang_b * delta; }
+    return delta;
+}
+
+// full tick of the dynamics world for one arena
+template <int NC>
+RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
+    const float dt = TICK_DT;
+    constexpr int NB = NC + 1;
+    constexpr int MAXC = 8 + 6 * NC;
+    // ball sleep flag (Arena.cpp:721-727)
+    bool ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
+    // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
+    const float g = K::GRAVITY_Z * UU2BT;
+    if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
+    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
+    // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
+    A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
+
+    ContactList<MAXC> L; bool touch;
+    collide_all<NC, MAXC>(A, mesh, L, ev, touch);
+    bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
+
+    // ---- solver setup
+    SolverBody B[NB];
+    {
+        SolverBody& s = B[0];
+        s.v = A.ball.b.vel; s.w = A.ball.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
+        s.inv_m = BALL_INV_MASS; s.inv_i = A.ball.b.inv_inertia_w;
+        s.ext_f = A.ball.b.force * BALL_INV_MASS * dt; s.ext_t = tmul(A.ball.b.inv_inertia_w, A.ball.b.torque) * dt;
+        s.active = ball_active;
+    }
+    for (int i = 0; i < NC; i++) {
+        SolverBody& s = B[1 + i]; const Car& c = A.cars[i];
+        s.v = c.b.vel; s.w = c.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
+        s.inv_m = CAR_INV_MASS; s.inv_i = c.b.inv_inertia_w;
+        s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
+        s.active = !c.frozen && !(c.flags & CF_IS_DEMOED);
+    }
+    constexpr int MAXR = 2 * (MAXC + 1);
+    Row R[MAXR]; int nr = 0;
+    int n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f, sp_fric = 0.f, sp_rest = 0.f;
+    int first_fric;
+    // normal rows
+    for (int k = 0; k < L.n; k++) {
+        const Contact& c = L.c[k];
+        if (c.a == 0 && !ball_active) { continue; }
+        bool has_b = c.b >= 0;
+        row_setup_normal(R[nr], c, B, c.n, c.ra, c.rb, c.dist, c.friction, c.restitution, has_b);
+        if (c.special) {
+            R[nr].skip = true;
+            n_special++; sp_fric = c.friction; sp_rest = c.restitution; sp_normal += c.n; sp_dist += len(c.ra);
+        }
+        nr++;
+    }
+    int n_contact_rows = nr;
+    Contact spc;
+    if (n_special > 0) {  // convertContactSpecial (btSequentialImpulseConstraintSolver.cpp:1164-1211)
+        float distance = sp_dist / (float)n_special;
+        V3 normal = sp_normal / (float)n_special;
+        spc.a = 0; spc.b = -1; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
+        spc.friction = sp_fric; spc.restitution = sp_rest; spc.special = false;
+        row_setup_normal(R[nr], spc, B, spc.n, spc.ra, spc.rb, spc.dist, spc.friction, spc.restitution, false);
+        nr++;
+    }
+    int n_normal = nr;
+    first_fric = nr;
+    // friction rows (one per non-special normal row + the averaged one)
+    {
+        int ci = 0;
+        for (int k = 0; k < L.n; k++) {
+            const Contact& c = L.c[k];
+            if (c.a == 0 && !ball_active) continue;
+            if (!c.special) { row_setup_friction(R[nr], ci, R[ci], B, c.n, c.ra, c.rb, c.b >= 0); nr++; }
+            ci++;
+        }
+        if (n_special > 0) { row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false); nr++; }
+    }
+    // split-impulse iterations
+    for (int it = 0; it < K::SOLVER_ITERS; it++) {
+        float resid = 0.f;
+        for (int k = 0; k < n_normal; k++) {
+            float d = row_resolve_split(R[k], B);
+            float rr = d * (1.f / R[k].jac);
+            resid = fmaxf(resid, rr * rr);
+        }
+        if (resid <= 0.f || it >= K::SOLVER_ITERS - 1) break;
+    }
+    // velocity iterations
+    for (int it = 0; it < K::SOLVER_ITERS; it++) {
+        for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, true);
+        for (int k = first_fric; k < nr; k++) {
+            float total = R[R[k].fric_of].applied;
+            if (total > 0.f) {
+                R[k].lo = -(R[k].friction * total); R[k].hi = R[k].friction * total;
+                row_resolve(R[k], B, false);
+            }
+        }
+    }
+    // finish: write back (btSequentialImpulseConstraintSolver.cpp:1878-1904), then integrateTransforms (:889-1027)
+    if (ball_active) {
+        SolverBody& s = B[0]; Body& b = A.ball.b;
+        b.vel = (s.v + s.dv) + s.ext_f; b.angvel = (s.w + s.dw) + s.ext_t;
+        if (!is_zero(s.push) || !is_zero(s.turn)) b.pos = b.pos + s.push * dt;  // m_noRot: orientation untouched
+        b.pos = b.pos + b.vel * dt;
+    }
+    for (int i = 0; i < NC; i++) {
+        SolverBody& s = B[1 + i]; Car& c = A.cars[i];
+        if (!s.active) continue;
+        c.b.vel = (s.v + s.dv) + s.ext_f; c.b.angvel = (s.w + s.dw) + s.ext_t;
+        if (!is_zero(s.push) || !is_zero(s.turn)) {
+            c.b.pos = c.b.pos + s.push * dt;
+            c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
+        }
+        c.b.pos = c.b.pos + c.b.vel * dt;
+        c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
+        body_update_inertia(c.b, car_inv_inertia_local());
+    }
+    // clearForces
+    A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
+    for (int i = 0; i < NC; i++) { A.cars[i].b.force = v3(0, 0, 0); A.cars[i].b.torque = v3(0, 0, 0); }
+}
+
+// ---- boost pads (BoostPad.cpp:51-105, BoostPadGrid.cpp:5-25; locations RLConst.h:215-253) -----------------
+RLG_HD V3 pad_pos(int i) {
+    const float BIG[6][2] = {{-3584.f, 0.f}, {3584.f, 0.f}, {-3072.f, 4096.f}, {3072.f, 4096.f}, {-3072.f, -4096.f}, {3072.f, -4096.f}};
+    const float SM[28][2] = {{0.f, -4240.f}, {-1792.f, -4184.f}, {1792.f, -4184.f}, {-940.f, -3308.f}, {940.f, -3308.f}, {0.f, -2816.f},
+        {-3584.f, -2484.f}, {3584.f, -2484.f}, {-1788.f, -2300.f}, {1788.f, -2300.f}, {-2048.f, -1036.f}, {0.f, -1024.f}, {2048.f, -1036.f},
+        {-1024.f, 0.f}, {1024.f, 0.f}, {-2048.f, 1036.f}, {0.f, 1024.f}, {2048.f, 1036.f}, {-1788.f, 2300.f}, {1788.f, 2300.f},
+        {-3584.f, 2484.f}, {3584.f, 2484.f}, {0.f, 2816.f}, {-940.f, 3308.f}, {940.f, 3308.f}, {-1792.f, 4184.f}, {1792.f, 4184.f}, {0.f, 4240.f}};
+    if (i < 6) return v3(BIG[i][0], BIG[i][1], 73.f);
+    return v3(SM[i - 6][0], SM[i - 6][1], 70.f);
+}
+
+template <int NC>
+RLG_HD void pads_check_car(Arena<NC>& A, int ci) {
+    Car& car = A.cars[ci];
+    if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return;
+    V3 cp = car.b.pos * BT2UU;
+    if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return;
+    int ix = (int)(cp.x / 1024 + 4), iy = (int)(cp.y / 1024 + 5);
+    // car AABB (btCompoundShape::getAabb): centre + |R| * half extents
+    V3 h = hitbox_half();
+    V3 bc = car.b.pos + car.b.rot * hitbox_off();
+    V3 ext = v3(h.x * fabsf(car.b.rot.r0.x) + h.y * fabsf(car.b.rot.r0.y) + h.z * fabsf(car.b.rot.r0.z),
+                h.x * fabsf(car.b.rot.r1.x) + h.y * fabsf(car.b.rot.r1.y) + h.z * fabsf(car.b.rot.r1.z),
+                h.x * fabsf(car.b.rot.r2.x) + h.y * fabsf(car.b.rot.r2.y) + h.z * fabsf(car.b.rot.r2.z));
+    V3 cmin = bc - ext, cmax = bc + ext;
+    for (int p = 0; p < 34; p++) {
+        V3 pp = pad_pos(p);
+        int px = (int)(pp.x / 1024 + 4), py = (int)(pp.y / 1024 + 5);
+        int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
+        if (px < lox || px > hix || py < loy || py > hiy) continue;
+        bool big = p < 6;
+        V3 pbt = pp * UU2BT;
+        bool colliding = false;
+        if (A.pads[p].prev_locked == ci + 1) {
+            float br = (big ? K::PAD_BOX_RAD_BIG : K::PAD_BOX_RAD_SMALL) * UU2BT;
+            V3 bmin = pbt - v3(br, br, 0), bmax = pbt + v3(br, br, K::PAD_BOX_HEIGHT * UU2BT);
+            colliding = (bmax.x > cmin.x && bmax.y > cmin.y && bmax.z > cmin.z) && (bmin.x < cmax.x && bmin.y < cmax.y && bmin.z < cmax.z);
+        } else {
+            float rad = (big ? K::PAD_CYL_RAD_BIG : K::PAD_CYL_RAD_SMALL) * UU2BT;
+            float dx = car.b.pos.x - pbt.x, dy = car.b.pos.y - pbt.y;
+            if (dx * dx + dy * dy < rad * rad) colliding = fabsf(car.b.pos.z - pbt.z) < (K::PAD_CYL_HEIGHT * UU2BT);
+        }
+        if (colliding) A.pads[p].cur_locked = ci + 1;
+    }
+}
+
+// ---- Arena::Step, one tick (Arena.cpp:716-812) ---------------------------------------------------------
+template <int NC>
+RLG_HD void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev) {
+    const float dt = TICK_DT;
+    for (int i = 0; i < NC; i++) {
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (A.cars[i].flags & CF_IS_DEMOED) philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)i, rnd);
+        car_pre_tick(A, i, mesh, rnd[0]);
+    }
+    for (int p = 0; p < 34; p++) {
+        Pad& pd = A.pads[p];
+        if (pd.cooldown > 0) pd.cooldown = fmaxf(pd.cooldown - dt, 0.f);
+        pd.is_active = (pd.cooldown == 0.f);
+        pd.cur_locked = 0;
+    }
+    world_step(A, mesh, ev);
+    for (int i = 0; i < NC; i++) {
+        car_post_tick(A.cars[i]);
+        pads_check_car(A, i);
+    }
+    for (int p = 0; p < 34; p++) {
+        Pad& pd = A.pads[p];
+        int locked = 0;
+        if (pd.cur_locked) {
+            locked = pd.cur_locked;
+            if (pd.is_active) {
+                Car& c = A.cars[locked - 1];
+                c.boost = fminf(c.boost + (p < 6 ? K::PAD_BOOST_BIG : K::PAD_BOOST_SMALL), K::BOOST_MAX);
+                pd.is_active = false;
+                pd.cooldown = p < 6 ? K::PAD_COOLDOWN_BIG : K::PAD_COOLDOWN_SMALL;
+            }
+        }
+        pd.prev_locked = locked;
+    }
+    {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
+        Ball& b = A.ball;
+        if (!is_zero(b.vel_impulse_cache)) { b.b.vel += b.vel_impulse_cache; b.vel_impulse_cache = v3(0, 0, 0); }
+        const float vmax = K::BALL_MAX_SPEED * UU2BT;
+        if (len2(b.b.vel) > vmax * vmax) b.b.vel = normalized(b.b.vel) * vmax;
+        if (len2(b.b.angvel) > K::BALL_MAX_ANG_SPEED * K::BALL_MAX_ANG_SPEED) b.b.angvel = normalized(b.b.angvel) * K::BALL_MAX_ANG_SPEED;
+        A.ball_update_counter++;
+    }
+    A.tick_count++;
+}
+
+}  // namespace rlg

@@ -1,0 +1,228 @@
+// arena_types.h — constants and per-env working types of the batched arena stepper.
+//
+// The stepper keeps rigid bodies in Bullet units (1 BT = 50 uu) exactly as the reference's
+// btRigidBody does (RocketSim/src/BulletLink.h:12-15) so that the fp32 rounding of every product
+// follows the reference; the public exchange layout (include/rlgpu_state.h) is in uu.
+//
+// Everything here restates numbers/semantics of the reference; each block cites where they come from.
+#pragma once
+#include "rl_math.h"
+
+namespace rlg {
+
+constexpr float UU2BT = 1.f / 50.f;
+constexpr float BT2UU = 50.f;
+constexpr float TICK_DT = 1.f / 120.f;  // Arena.cpp:437 tickTime = 1 / tickRate
+
+// ---- RocketSim/src/RLConst.h:9-135 ----------------------------------------------------------------
+namespace K {
+constexpr float GRAVITY_Z = -650.f;
+constexpr float ARENA_EXTENT_X = 4096.f, ARENA_EXTENT_Y = 5120.f, ARENA_HEIGHT = 2048.f;
+constexpr float CAR_MASS = 180.f, BALL_MASS = 180.f / 6.f;
+constexpr float CARBALL_FRICTION = 2.0f, CARBALL_RESTITUTION = 0.0f;
+constexpr float CARWORLD_FRICTION = 0.3f, CARWORLD_RESTITUTION = 0.3f;
+constexpr float CARCAR_FRICTION = 0.09f, CARCAR_RESTITUTION = 0.1f;
+constexpr float BALL_REST_Z = 93.15f, BALL_MAX_ANG_SPEED = 6.f, BALL_DRAG = 0.03f;
+constexpr float BALL_FRICTION = 0.35f, BALL_RESTITUTION = 0.6f;  // vs world: min(0.35,0.6), max(0.6,0.3) (btManifoldResult.cpp:56-78)
+constexpr float CAR_MAX_SPEED = 2300.f, BALL_MAX_SPEED = 6000.f;
+constexpr float BOOST_MAX = 100.f, BOOST_USED_PER_SECOND = BOOST_MAX / 3, BOOST_MIN_TIME = 0.1f;
+constexpr float BOOST_ACCEL_GROUND = 2975 / 3.f, BOOST_ACCEL_AIR = 3175 / 3.f, BOOST_SPAWN_AMOUNT = BOOST_MAX / 3;
+constexpr float CAR_MAX_ANG_SPEED = 5.5f;
+constexpr float SUPERSONIC_START_SPEED = 2200.f, SUPERSONIC_MAINTAIN_MIN_SPEED = SUPERSONIC_START_SPEED - 100.f,
+                SUPERSONIC_MAINTAIN_MAX_TIME = 1.f;
+constexpr float POWERSLIDE_RISE_RATE = 5, POWERSLIDE_FALL_RATE = 2;
+constexpr float THROTTLE_TORQUE_AMOUNT = CAR_MASS * 400.f, BRAKE_TORQUE_AMOUNT = CAR_MASS * (14.25f + (1.f / 3.f));
+constexpr float STOPPING_FORWARD_VEL = 25.f, COASTING_BRAKE_FACTOR = 0.15f, BRAKING_NO_THROTTLE_SPEED_THRESH = 0.01f,
+                THROTTLE_DEADZONE = 0.001f, THROTTLE_AIR_ACCEL = 200 / 3.f;
+constexpr float JUMP_ACCEL = 4375.f / 3.f, JUMP_IMMEDIATE_FORCE = 875.f / 3.f, JUMP_MIN_TIME = 0.025f,
+                JUMP_RESET_TIME_PAD = (1 / 40.f), JUMP_MAX_TIME = 0.2f, DOUBLEJUMP_MAX_DELAY = 1.25f;
+constexpr float FLIP_Z_DAMP_120 = 0.35f, FLIP_Z_DAMP_START = 0.15f, FLIP_Z_DAMP_END = 0.21f, FLIP_TORQUE_TIME = 0.65f,
+                FLIP_PITCHLOCK_EXTRA_TIME = 0.3f, FLIP_INITIAL_VEL_SCALE = 500.f, FLIP_TORQUE_X = 260.f, FLIP_TORQUE_Y = 224.f,
+                FLIP_FORWARD_IMPULSE_MAX_SPEED_SCALE = 1.f, FLIP_SIDE_IMPULSE_MAX_SPEED_SCALE = 1.9f,
+                FLIP_BACKWARD_IMPULSE_MAX_SPEED_SCALE = 2.5f, FLIP_BACKWARD_IMPULSE_SCALE_X = 16.f / 15.f;
+constexpr float BALL_RADIUS = 91.25f;
+constexpr float GOAL_THRESHOLD_Y = 5124.25f;
+constexpr float CAR_TORQUE_SCALE = (float)(2 * 3.14159265358979323846 / (1 << 16) * 1000);
+constexpr float CAR_AUTOFLIP_IMPULSE = 200, CAR_AUTOFLIP_TORQUE = 50, CAR_AUTOFLIP_TIME = 0.4f,
+                CAR_AUTOFLIP_NORMZ_THRESH = 0.70710678118654752440f, CAR_AUTOFLIP_ROLL_THRESH = 2.8f;
+constexpr float CAR_AUTOROLL_FORCE = 100, CAR_AUTOROLL_TORQUE = 80;
+constexpr float BALL_CAR_EXTRA_IMPULSE_Z_SCALE = 0.35f, BALL_CAR_EXTRA_IMPULSE_FORWARD_SCALE = 0.65f,
+                BALL_CAR_EXTRA_IMPULSE_MAXDELTAVEL_UU = 4600.f;
+constexpr float CAR_SPAWN_REST_Z = 17.f, CAR_RESPAWN_Z = 36.f;
+constexpr float BUMP_COOLDOWN_TIME = 0.25f, BUMP_MIN_FORWARD_DIST = 64.5f, DEMO_RESPAWN_TIME = 3.f;
+// RLConst::BTVehicle (RLConst.h:137-149)
+constexpr float SUSPENSION_FORCE_SCALE_FRONT = 36.f - (1.f / 4.f), SUSPENSION_FORCE_SCALE_BACK = 54.f + (1.f / 4.f) + (1.5f / 100.f),
+                SUSPENSION_STIFFNESS = 500.f, WHEELS_DAMPING_COMPRESSION = 25.f, WHEELS_DAMPING_RELAXATION = 40.f,
+                MAX_SUSPENSION_TRAVEL = 12.f, SUSPENSION_SUBTRACTION = 0.05f;
+constexpr float AIR_TORQUE_P = 130, AIR_TORQUE_Y = 95, AIR_TORQUE_R = 400;  // CAR_AIR_CONTROL_TORQUE (RLConst.h:188)
+constexpr float AIR_DAMP_P = 30, AIR_DAMP_Y = 20, AIR_DAMP_R = 50;           // CAR_AIR_CONTROL_DAMPING (RLConst.h:190)
+// boost pads (RLConst.h:192-253)
+constexpr float PAD_CYL_HEIGHT = 95, PAD_CYL_RAD_BIG = 208, PAD_CYL_RAD_SMALL = 144, PAD_BOX_HEIGHT = 64, PAD_BOX_RAD_BIG = 160,
+                PAD_BOX_RAD_SMALL = 120, PAD_COOLDOWN_BIG = 10, PAD_COOLDOWN_SMALL = 4, PAD_BOOST_BIG = 100, PAD_BOOST_SMALL = 12;
+// Octane (CarConfig.cpp:20-70)
+constexpr float HITBOX_X = 120.507f, HITBOX_Y = 86.6994f, HITBOX_Z = 38.6591f;
+constexpr float HITBOX_OFF_X = 13.87566f, HITBOX_OFF_Y = 0.f, HITBOX_OFF_Z = 20.755f;
+constexpr float WHEEL_RAD_FRONT = 12.50f, WHEEL_RAD_BACK = 15.00f;
+constexpr float SUS_REST_FRONT = 38.755f, SUS_REST_BACK = 37.055f;
+constexpr float WHEEL_FX = 51.25f, WHEEL_FY = 25.90f, WHEEL_FZ = 20.755f;
+constexpr float WHEEL_BX = -33.75f, WHEEL_BY = 29.50f, WHEEL_BZ = 20.755f;
+constexpr float DODGE_DEADZONE = 0.5f;  // CarConfig.h dodgeDeadzone
+// Bullet solver settings (Arena.cpp:483-488; btContactSolverInfo.h:78-113)
+constexpr int   SOLVER_ITERS = 10;
+constexpr float ERP = 0.2f, ERP2 = 0.8f, SPLIT_TURN_ERP = 0.1f, RESTITUTION_VEL_THRESHOLD = 0.2f;
+constexpr float WORLD_RESTITUTION = 0.3f, WORLD_FRICTION = 0.6f;  // Arena.cpp:502-508
+}  // namespace K
+
+// ---- piecewise-linear curves (RocketSim/src/Math/Math.cpp:5-38; tables RLConst.h:342-437) ------------
+template <int N>
+RLG_HD float curve(const float (&xs)[N], const float (&ys)[N], float in) {
+    if (in <= xs[0]) return ys[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        if (xs[i] > in) {
+            float range = xs[i] - xs[i - 1];
+            float dv = ys[i] - ys[i - 1];
+            float f = (in - xs[i - 1]) / range;
+            return ys[i - 1] + dv * f;
+        }
+    }
+    return ys[N - 1];
+}
+RLG_HD float curve_steer_angle(float v) {
+    const float xs[6] = {0, 500, 1000, 1500, 1750, 3000};
+    const float ys[6] = {0.53356f, 0.31930f, 0.18203f, 0.10570f, 0.08507f, 0.03454f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_powerslide_steer(float v) {
+    const float xs[2] = {0, 2500}; const float ys[2] = {0.39235f, 0.12610f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_drive_torque(float v) {
+    const float xs[3] = {0, 1400, 1410}; const float ys[3] = {1.0f, 0.1f, 0.0f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_non_sticky(float v) {
+    const float xs[3] = {0, 0.7075f, 1}; const float ys[3] = {0.1f, 0.5f, 1.0f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_lat_friction(float v) {
+    const float xs[2] = {0, 1}; const float ys[2] = {1.0f, 0.2f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_handbrake_long(float v) {
+    const float xs[2] = {0, 1}; const float ys[2] = {0.5f, 0.9f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_ball_car_extra(float v) {
+    const float xs[4] = {0, 500.f, 2300.f, 4600.f}; const float ys[4] = {0.65f, 0.65f, 0.55f, 0.30f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_bump_ground(float v) {
+    const float xs[3] = {0.f, 1400.f, 2200.f}; const float ys[3] = {(5.f / 6.f), 1100.f, 1530.f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_bump_air(float v) {
+    const float xs[3] = {0.f, 1400.f, 2200.f}; const float ys[3] = {(5.f / 6.f), 1390.f, 1945.f};
+    return curve(xs, ys, v);
+}
+RLG_HD float curve_bump_up(float v) {
+    const float xs[3] = {0.f, 1400.f, 2200.f}; const float ys[3] = {(2.f / 6.f), 278.f, 417.f};
+    return curve(xs, ys, v);
+}
+
+// ---- flags (same bit values as include/rlgpu_state.h) ---------------------------------------------
+enum : uint32_t {
+    CF_ON_GROUND = 1u << 0, CF_WHEEL0 = 1u << 1, CF_HAS_JUMPED = 1u << 5, CF_HAS_DOUBLE_JUMPED = 1u << 6,
+    CF_HAS_FLIPPED = 1u << 7, CF_IS_FLIPPING = 1u << 8, CF_IS_JUMPING = 1u << 9, CF_IS_SUPERSONIC = 1u << 10,
+    CF_IS_AUTOFLIPPING = 1u << 11, CF_WORLD_CONTACT = 1u << 12, CF_IS_DEMOED = 1u << 13, CF_BALLHIT_VALID = 1u << 14
+};
+
+struct Controls {
+    float throttle, steer, pitch, yaw, roll;
+    bool jump, boost, handbrake;
+};
+
+// a rigid body in BT units (the slice of btRigidBody the tick touches)
+struct Body {
+    V3 pos;
+    M3 rot;          // basis; columns forward/right/up
+    V3 vel, angvel;
+    V3 force, torque;  // m_totalForce / m_totalTorque, cleared each tick
+    M3 inv_inertia_w;  // m_invInertiaTensorWorld (refreshed when the transform is set)
+};
+
+// per-wheel values that live only inside one tick
+struct WheelTmp {
+    V3 hard_point, contact_point, contact_normal;
+    V3 impulse;
+    float susp_len, susp_rel_vel, clipped_inv;
+    int ground;  // -1 none, 0 static world, 1 ball, 2+k car k
+    bool in_contact;
+};
+
+struct Car {
+    Body b;
+    uint32_t flags;
+    V3 flip_rel_torque;
+    float jump_time, flip_time, air_time, air_time_since_jump;
+    float boost, time_spent_boosting, supersonic_time, handbrake_val;
+    float auto_flip_timer, auto_flip_torque_scale;
+    V3 world_contact_normal;
+    int car_contact_other;  // car id (slot+1), 0 none
+    float car_contact_cooldown, demo_respawn_timer;
+    V3 bh_rel_pos, bh_ball_pos, bh_extra_hit_vel;  // uu
+    int64_t bh_tick_hit, bh_tick_extra;
+    Controls last, ctl;
+    V3 vel_impulse_cache;  // BT
+    float extra_pushback[4];
+    float steer_angle, engine_force, brake;
+    float lat_friction[4], long_friction[4];
+    bool frozen;  // transient: body disabled for the current tick (demoed at tick start)
+};
+
+struct Ball {
+    Body b;
+    V3 vel_impulse_cache;  // BT
+};
+
+struct Pad {
+    float cooldown;
+    bool is_active;
+    int prev_locked;  // car id, 0 none
+    int cur_locked;   // car id during the tick
+};
+
+// ---- static world -----------------------------------------------------------------------------------
+struct BvhNode {  // 32 B; leaf when count > 0
+    float minx, miny, minz;
+    int32_t left_or_first;
+    float maxx, maxy, maxz;
+    int32_t count;  // 0 => inner node with children left, left+1 ; >0 => leaf with `count` triangles from `left_or_first`
+};
+struct MeshTri {  // 48 B, BT units
+    float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
+    uint32_t edge_flags;  // bit e (0..2): edge e (v_e -> v_{e+1}) is an internal flat/concave edge: snap edge normals to the face
+    uint32_t _pad0, _pad1;
+};
+struct MeshView {
+    const BvhNode* nodes;      // global
+    const MeshTri* tris;       // global
+    const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr
+    int n_nodes, n_tris, n_fast;
+};
+
+// events a tick can raise towards the gym layer (Gym.cpp:6-38 callbacks)
+struct TickEvents {
+    uint32_t bump_mask;  // bit i: car i bumped an opponent this tick ; bit 8+i : ... and it was a demo
+};
+
+template <int NC>
+struct Arena {
+    Ball ball;
+    Car cars[NC];
+    Pad pads[34];
+    int64_t tick_count;
+    int64_t ball_update_counter;
+};
+
+}  // namespace rlg

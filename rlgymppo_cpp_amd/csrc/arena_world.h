@@ -1,0 +1,530 @@
+// arena_world.h — static world (4 planes + BVH triangle mesh), suspension ray casts and the narrowphase that
+// produces this tick's contact list.
+//
+// What it restates (reference = RocketSim 2.1.1's patched Bullet 3.24):
+//   * world layout: floor z=0, ceiling z=2048, side walls x=+-4096 as planes (Arena.cpp:1060-1101) + trimesh
+//   * ray tests: two-sided triangle/plane test with the ray-facing normal (btRaycastCallback.cpp:34-110),
+//     closest hit wins (btDefaultVehicleRaycaster.cpp:32-52)
+//   * sphere-plane / box-plane support-vertex test (btConvexPlaneCollisionAlgorithm.cpp:92-121)
+//   * sphere-triangle (SphereTriangleDetector.cpp:139-241 with the embree closest-point routine :87-129)
+//   * contact-added callback semantics (Arena.cpp:218-427)
+// What it re-designs for a lane-per-env kernel (documented deviations):
+//   * contacts are regenerated every tick (no persistent manifold / warm start): box contacts are produced
+//     as a clipped multi-point set in ONE tick instead of Bullet's one-support-vertex-per-tick accumulation;
+//   * box-triangle and box-box use SAT + face clipping instead of GJK/EPA and ODE's dBoxBox2;
+//   * the mesh BVH is this repo's own 32-byte AABB node layout (top levels staged in LDS on the device).
+#pragma once
+#include "arena_body.h"
+
+namespace rlg {
+
+// contact breaking thresholds = getAngularMotionDisc() * 0.02 of the smaller shape
+// (btCollisionDispatcher.cpp:70-82, btCollisionShape.cpp:130-160; values verified against the compiled
+// reference by oracle/ref_driver.cpp:ref_probe_thresholds)
+constexpr float CBT_BALL = 0.0381f;   // (1.825 + 0.08) * 0.02
+constexpr float CBT_CAR = 0.040624548f;  // compound(box+offset) bounding disc * 0.02 (probed: ref_probe_thresholds)
+
+struct RayHit {
+    int kind;  // -1 miss, 0 static world, 1 ball, 2+k car k
+    float frac;
+    V3 normal;
+};
+
+struct Contact {
+    int a, b;        // 0 = ball, 1+i = car i, -1 = static world ; normal points from b towards a
+    V3 ra, rb;       // contact point on each body relative to the body origin (world axes)
+    V3 n;
+    float dist;
+    float friction, restitution;
+    bool special;    // ball-world contact: resolved through one averaged row (Arena.cpp:265-273)
+};
+
+
+// ---- BVH access ---------------------------------------------------------------------------------------
+RLG_HD BvhNode mesh_node(const MeshView& m, int i) { return (i < m.n_fast) ? m.nodes_fast[i] : m.nodes[i]; }
+
+RLG_HD bool aabb_overlap(const BvhNode& n, V3 lo, V3 hi) {
+    return !(n.minx > hi.x || n.maxx < lo.x || n.miny > hi.y || n.maxy < lo.y || n.minz > hi.z || n.maxz < lo.z);
+}
+RLG_HD bool ray_aabb(const BvhNode& n, V3 from, V3 inv_d, float tmax) {
+    float t1 = (n.minx - from.x) * inv_d.x, t2 = (n.maxx - from.x) * inv_d.x;
+    float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
+    t1 = (n.miny - from.y) * inv_d.y; t2 = (n.maxy - from.y) * inv_d.y;
+    tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
+    t1 = (n.minz - from.z) * inv_d.z; t2 = (n.maxz - from.z) * inv_d.z;
+    tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
+    return tf >= fmaxf(tn, 0.f) && tn <= tmax;
+}
+
+// btTriangleRaycastCallback::processTriangle (btRaycastCallback.cpp:34-110), flags = 0
+RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best) {
+    V3 v10 = v1 - v0, v20 = v2 - v0;
+    V3 tn = cross(v10, v20);
+    float dist = dot(v0, tn);
+    float da = dot(tn, from) - dist, db = dot(tn, to) - dist;
+    if (da * db >= 0.f) return;
+    float proj = da - db;
+    float d = da / proj;
+    if (d < best.frac) {
+        float edge_tol = len2(tn) * -0.0001f;
+        float s = 1.f - d;
+        V3 p = v3(s * from.x + d * to.x, s * from.y + d * to.y, s * from.z + d * to.z);
+        V3 v0p = v0 - p, v1p = v1 - p;
+        if (dot(cross(v0p, v1p), tn) >= edge_tol) {
+            V3 v2p = v2 - p;
+            if (dot(cross(v1p, v2p), tn) >= edge_tol) {
+                if (dot(cross(v2p, v0p), tn) >= edge_tol) {
+                    V3 nn = normalized(tn);
+                    best.frac = d; best.kind = 0;
+                    best.normal = (da <= 0.f) ? -nn : nn;
+                }
+            }
+        }
+    }
+}
+
+// the four world planes: n.x = d
+RLG_HD void world_plane(int i, V3& n, float& d) {
+    const float ex = K::ARENA_EXTENT_X * UU2BT, h = K::ARENA_HEIGHT * UU2BT;
+    if (i == 0) { n = v3(0, 0, 1); d = 0.f; }
+    else if (i == 1) { n = v3(0, 0, -1); d = -h; }
+    else if (i == 2) { n = v3(1, 0, 0); d = -ex; }
+    else { n = v3(-1, 0, 0); d = -ex; }
+}
+
+template <int NC>
+RLG_HD RayHit world_ray_cast(const Arena<NC>& A, int self_car, const MeshView& mesh, V3 from, V3 to) {
+    RayHit best; best.kind = -1; best.frac = 1.0f; best.normal = v3(0, 0, 0);
+    // planes
+    for (int i = 0; i < 4; i++) {
+        V3 n; float d; world_plane(i, n, d);
+        float da = dot(n, from) - d, db = dot(n, to) - d;
+        if (da * db >= 0.f) continue;
+        float f = da / (da - db);
+        if (f < best.frac) { best.frac = f; best.kind = 0; best.normal = (da <= 0.f) ? -n : n; }
+    }
+    // mesh
+    if (mesh.n_nodes > 0) {
+        V3 dvec = to - from;
+        V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
+        int stack[32]; int sp = 0; stack[sp++] = 0;
+        while (sp > 0) {
+            BvhNode nd = mesh_node(mesh, stack[--sp]);
+            if (!ray_aabb(nd, from, inv_d, best.frac)) continue;
+            if (nd.count > 0) {
+                for (int k = 0; k < nd.count; k++) {
+                    const MeshTri& t = mesh.tris[nd.left_or_first + k];
+                    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
+                }
+            } else if (sp < 30) {
+                stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1;
+            }
+        }
+    }
+    // ball (point vs sphere of radius 1.825)
+    {
+        const float r = K::BALL_RADIUS * UU2BT;
+        V3 d = to - from, m = from - A.ball.b.pos;
+        float a = dot(d, d), b = dot(m, d), c = dot(m, m) - r * r;
+        if (c > 0.f && b < 0.f) {
+            float disc = b * b - a * c;
+            if (disc >= 0.f) {
+                float t = (-b - sqrtf(disc)) / a;
+                if (t >= 0.f && t < best.frac) {
+                    best.frac = t; best.kind = 1;
+                    best.normal = normalized((from + d * t) - A.ball.b.pos);
+                }
+            }
+        }
+    }
+    // other cars' hitboxes (not demoed: no contact response -> no hit, btDefaultVehicleRaycaster.cpp:41-43)
+    for (int k = 0; k < NC; k++) {
+        if (k == self_car) continue;
+        const Car& o = A.cars[k];
+        if (o.flags & CF_IS_DEMOED) continue;
+        V3 center = o.b.pos + o.b.rot * hitbox_off();
+        V3 lf = tmul(o.b.rot, from - center), lt = tmul(o.b.rot, to - center);
+        V3 d = lt - lf, h = hitbox_half();
+        float tn = 0.f, tf = best.frac; int axis = -1; float sgn = 0.f; bool ok = true;
+        for (int ax = 0; ax < 3 && ok; ax++) {
+            float o_ = get(lf, ax), d_ = get(d, ax), h_ = get(h, ax);
+            if (fabsf(d_) < 1e-12f) { if (fabsf(o_) > h_) ok = false; continue; }
+            float inv = 1.f / d_;
+            float t1 = (-h_ - o_) * inv, t2 = (h_ - o_) * inv; float s = -1.f;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; s = 1.f; }
+            if (t1 > tn) { tn = t1; axis = ax; sgn = s; }
+            if (t2 < tf) tf = t2;
+            if (tn > tf) ok = false;
+        }
+        if (ok && axis >= 0 && tn < best.frac) {
+            V3 nl = v3(axis == 0 ? sgn : 0.f, axis == 1 ? sgn : 0.f, axis == 2 ? sgn : 0.f);
+            best.frac = tn; best.kind = 2 + k; best.normal = o.b.rot * nl;
+        }
+    }
+    return best;
+}
+
+// ---- contact list ---------------------------------------------------------------------------------------
+template <int MAXC>
+struct ContactList {
+    Contact c[MAXC];
+    int n;
+};
+
+template <int MAXC>
+RLG_HD void push_contact(ContactList<MAXC>& L, const Contact& c) { if (L.n < MAXC) L.c[L.n++] = c; }
+
+// embree closest point on triangle (SphereTriangleDetector.cpp:87-129). `feature` out: 0 face, 1..3 vertex a/b/c, 4 edge ab, 5 edge ac, 6 edge bc
+RLG_HD V3 closest_point_triangle(V3 p, V3 a, V3 b, V3 c, int& feature) {
+    V3 ab = b - a, ac = c - a, ap = p - a;
+    float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.f && d2 <= 0.f) { feature = 1; return a; }
+    V3 bp = p - b;
+    float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.f && d4 <= d3) { feature = 2; return b; }
+    V3 cp = p - c;
+    float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.f && d5 <= d6) { feature = 3; return c; }
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 / (d1 - d3); feature = 4; return a + v * ab; }
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float v = d2 / (d2 - d6); feature = 5; return a + v * ac; }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { float v = (d4 - d3) / ((d4 - d3) + (d5 - d6)); feature = 6; return b + v * (c - b); }
+    float denom = 1.f / (va + vb + vc);
+    float v = vb * denom, w = vc * denom;
+    feature = 0;
+    return a + v * ab + w * ac;
+}
+
+// SphereTriangleDetector::pointInTriangle (the reference's replacement, SphereTriangleDetector.cpp:245-...):
+// inside iff the point is on the inner side of the three edge planes
+RLG_HD bool point_in_triangle(V3 p, V3 v0, V3 v1, V3 v2, V3 n) {
+    V3 e1 = v1 - v0, e2 = v2 - v1, e3 = v0 - v2;
+    float r1 = dot(cross(e1, n), p - v0), r2 = dot(cross(e2, n), p - v1), r3 = dot(cross(e3, n), p - v2);
+    return (r1 > 0 && r2 > 0 && r3 > 0) || (r1 <= 0 && r2 <= 0 && r3 <= 0);
+}
+
+// sphere (ball) vs one triangle: SphereTriangleDetector::collide (:139-241) + the internal-edge snap
+RLG_HD bool sphere_triangle(V3 c, float radius, float thresh, const MeshTri& t, V3& point, V3& normal, float& depth) {
+    V3 v0 = v3(t.v0x, t.v0y, t.v0z), v1 = v3(t.v1x, t.v1y, t.v1z), v2 = v3(t.v2x, t.v2y, t.v2z);
+    float rwt = radius + thresh;
+    V3 n = cross(v1 - v0, v2 - v0);
+    float l2 = len2(n);
+    if (l2 < SIMD_EPS * SIMD_EPS) return false;
+    n = n / sqrtf(l2);
+    float dplane = dot(c - v0, n);
+    bool back_side = false;
+    if (dplane < 0.f) { dplane *= -1.f; n = n * -1.f; back_side = true; }
+    if (!(dplane < rwt)) return false;
+    V3 cp; int feature = 0; bool has = false;
+    if (point_in_triangle(c, v0, v1, v2, n)) { has = true; cp = c - n * dplane; }
+    else {
+        V3 q = closest_point_triangle(c, v0, v1, v2, feature);
+        float ds = len2(q - c);
+        if (ds < rwt * rwt) { has = true; cp = q; }
+    }
+    if (!has) return false;
+    V3 ctc = c - cp;
+    float ds = len2(ctc);
+    if (!(ds < rwt * rwt)) return false;
+    if (ds > SIMD_EPS) {
+        float d = sqrtf(ds);
+        normal = ctc / d;  // btVector3::normalize
+        point = cp; depth = -(radius - d);
+    } else { normal = n; point = cp; depth = -radius; }
+    // internal-edge fix-up (btInternalEdgeUtility.cpp:414-797, simplified): on an edge/vertex whose adjoining
+    // face is coplanar or concave the contact normal is the face normal; distance kept, point re-projected
+    if (feature != 0) {
+        uint32_t ef = back_side ? (t.edge_flags >> 3) : t.edge_flags;  // bits 0-2 front view, 3-5 back view (arena_mesh.cpp)
+        bool snap = false;  // edges: 0 = v0v1, 1 = v1v2, 2 = v2v0
+        if (feature == 4) snap = ef & 1u; else if (feature == 6) snap = ef & 2u; else if (feature == 5) snap = ef & 4u;
+        else if (feature == 1) snap = (ef & 1u) && (ef & 4u);
+        else if (feature == 2) snap = (ef & 1u) && (ef & 2u);
+        else if (feature == 3) snap = (ef & 2u) && (ef & 4u);
+        if (snap) {
+            normal = n;
+            point = (c - normal * radius) - normal * depth;  // positionWorldOnA - n * distance
+        }
+    }
+    return true;
+}
+
+// keep the `cap` deepest candidates of one body-vs-world pair
+struct Cand { V3 pb; V3 n; float dist; };
+template <int CAP>
+RLG_HD void cand_add(Cand (&cs)[CAP], int& n, const Cand& c) {
+    if (n < CAP) { cs[n++] = c; return; }
+    int worst = 0;
+    for (int i = 1; i < CAP; i++) if (cs[i].dist > cs[worst].dist) worst = i;
+    if (c.dist < cs[worst].dist) cs[worst] = c;
+}
+
+// Sutherland-Hodgman clip of a convex polygon (<= 8 pts) against the half space dot(nrm,p) <= off
+RLG_HD int clip_poly(const V3* in, int n, V3 nrm, float off, V3* out) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        V3 a = in[i], b = in[(i + 1) % n];
+        float da = dot(nrm, a) - off, db = dot(nrm, b) - off;
+        if (da <= 0.f) { if (m < 8) out[m++] = a; }
+        if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+            float t = da / (da - db);
+            if (m < 8) out[m++] = a + (b - a) * t;
+        }
+    }
+    return m;
+}
+
+// box (center bc, basis R, half extents h) vs triangle, SAT + clipping. Emits candidates with the normal
+// pointing from the triangle towards the box.
+template <int CAP>
+RLG_HD void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, float thresh, Cand (&cs)[CAP], int& nc) {
+    V3 p[3] = {tmul(R, v3(t.v0x, t.v0y, t.v0z) - bc), tmul(R, v3(t.v1x, t.v1y, t.v1z) - bc), tmul(R, v3(t.v2x, t.v2y, t.v2z) - bc)};
+    V3 e[3] = {p[1] - p[0], p[2] - p[1], p[0] - p[2]};
+    V3 n = cross(e[0], p[2] - p[0]);
+    float nl = len(n);
+    if (nl < 1e-12f) return;
+    n = n / nl;
+    float d = dot(n, p[0]);
+    if (d > 0.f) { n = -n; d = -d; }  // now the box centre is on the +n side: signed distance of centre = -d >= 0
+    float rn = h.x * fabsf(n.x) + h.y * fabsf(n.y) + h.z * fabsf(n.z);
+    float best_sep = (-d) - rn; int best_type = 0, best_i = 0, best_j = 0; V3 best_axis = n;
+    if (best_sep > thresh) return;
+    // box face axes
+    for (int i = 0; i < 3; i++) {
+        float mn = fminf(get(p[0], i), fminf(get(p[1], i), get(p[2], i)));
+        float mx = fmaxf(get(p[0], i), fmaxf(get(p[1], i), get(p[2], i)));
+        float hi_ = get(h, i);
+        float s1 = mn - hi_, s2 = -mx - hi_;
+        float s = fmaxf(s1, s2);
+        if (s > thresh) return;
+        if (s > best_sep + 1e-5f) { best_sep = s; best_type = 1; best_i = i; best_j = (s1 > s2) ? 1 : -1; }
+    }
+    // edge x edge axes
+    for (int i = 0; i < 3; i++) {
+        V3 ei = v3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+        for (int j = 0; j < 3; j++) {
+            V3 a = cross(ei, e[j]);
+            float al = len(a);
+            if (al < 1e-6f) continue;
+            a = a / al;
+            float t0 = dot(a, p[0]), t1 = dot(a, p[1]), t2 = dot(a, p[2]);
+            float mn = fminf(t0, fminf(t1, t2)), mx = fmaxf(t0, fmaxf(t1, t2));
+            float r = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
+            float s1 = mn - r, s2 = -mx - r;
+            float s = fmaxf(s1, s2);
+            if (s > thresh) return;
+            if (s > best_sep + 1e-3f) {  // prefer face axes on near ties (as dBoxBox2's fudge factor does)
+                best_sep = s; best_type = 2; best_i = i; best_j = j;
+                best_axis = (s1 > s2) ? -a : a;  // points from triangle towards the box centre
+            }
+        }
+    }
+    if (best_type == 0) {
+        // reference = triangle plane; incident = box face most anti-parallel to n
+        int k = 0; float mk = fabsf(n.x);
+        if (fabsf(n.y) > mk) { k = 1; mk = fabsf(n.y); }
+        if (fabsf(n.z) > mk) { k = 2; }
+        float sg = get(n, k) > 0.f ? -1.f : 1.f;
+        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        V3 quad[8], tmp[8];
+        for (int q = 0; q < 4; q++) {
+            float s1 = (q == 0 || q == 3) ? -1.f : 1.f, s2 = (q < 2) ? -1.f : 1.f;
+            float cv[3]; cv[k] = sg * get(h, k); cv[k1] = s1 * get(h, k1); cv[k2] = s2 * get(h, k2);
+            quad[q] = v3(cv[0], cv[1], cv[2]);
+        }
+        int m = 4;
+        // clip against the triangle's edge planes (inward side), computed with the un-flipped winding
+        V3 tn = cross(e[0], p[2] - p[0]);
+        for (int j = 0; j < 3 && m > 0; j++) {
+            V3 en = cross(e[j], tn);  // outward
+            float enl = len(en);
+            if (enl < 1e-12f) continue;
+            en = en / enl;
+            m = clip_poly(quad, m, en, dot(en, p[j]), tmp);
+            for (int q = 0; q < m; q++) quad[q] = tmp[q];
+        }
+        for (int q = 0; q < m; q++) {
+            float dist = dot(n, quad[q]) - d;
+            if (dist < thresh) {
+                Cand c; c.n = R * n; c.dist = dist; c.pb = bc + R * (quad[q] - n * dist);
+                cand_add(cs, nc, c);
+            }
+        }
+    } else if (best_type == 1) {
+        // reference = box face (axis best_i, side best_j), incident = triangle clipped to the face rectangle
+        int k = best_i, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        float side = (float)best_j;  // +1: triangle is on the +axis side
+        V3 poly[8], tmp[8]; int m = 3;
+        poly[0] = p[0]; poly[1] = p[1]; poly[2] = p[2];
+        for (int q = 0; q < 4 && m > 0; q++) {
+            int ax = (q < 2) ? k1 : k2; float sg = (q % 2) ? 1.f : -1.f;
+            V3 cn = v3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+            m = clip_poly(poly, m, cn, get(h, ax), tmp);
+            for (int r = 0; r < m; r++) poly[r] = tmp[r];
+        }
+        V3 fn = v3(k == 0 ? side : 0.f, k == 1 ? side : 0.f, k == 2 ? side : 0.f);  // outward face normal
+        for (int q = 0; q < m; q++) {
+            float dist = side * get(poly[q], k) - get(h, k);
+            if (dist < thresh) {
+                Cand c; c.n = R * (-fn); c.dist = dist; c.pb = bc + R * poly[q];
+                cand_add(cs, nc, c);
+            }
+        }
+    } else {
+        // edge-edge: box edge along axis best_i at the support corner towards -axis, triangle edge best_j
+        V3 a = best_axis;
+        V3 corner = v3(a.x > 0 ? -h.x : h.x, a.y > 0 ? -h.y : h.y, a.z > 0 ? -h.z : h.z);
+        int i = best_i;
+        V3 ei = v3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+        V3 pa = corner; if (i == 0) pa.x = 0; else if (i == 1) pa.y = 0; else pa.z = 0;  // midpoint of the box edge
+        V3 qb = p[best_j], ub = e[best_j];
+        // closest points between line pa + s*ei and segment qb + t*ub
+        V3 w = pa - qb;
+        float uaub = dot(ei, ub), q1 = dot(ei, w), q2 = -dot(ub, w);
+        float ubub = dot(ub, ub);
+        float dd = ubub - uaub * uaub;
+        float tt = (dd > 1e-12f) ? clampf((uaub * q1 * -1.f + q2 * -1.f) / -dd, 0.f, 1.f) : 0.5f;
+        // robust: recompute t directly as the projection of the closest approach
+        {
+            float den = ubub - uaub * uaub;
+            if (den > 1e-12f) tt = clampf((dot(ub, w) - uaub * dot(ei, w)) / den, 0.f, 1.f);
+        }
+        V3 pt = qb + ub * tt;
+        Cand c; c.n = R * a; c.dist = best_sep; c.pb = bc + R * pt;
+        cand_add(cs, nc, c);
+    }
+}
+
+// box vs box (SAT, 15 axes, face clipping / edge-edge). A = (ca,Ra), B = (cb,Rb); normals point from B to A.
+template <int CAP>
+RLG_HD void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Cand (&cs)[CAP], int& nc) {
+    V3 pp = tmul(Ra, cb - ca);            // B centre in A's frame
+    M3 Rr = transpose(Ra) * Rb;           // B axes in A's frame (columns)
+    V3 bcol[3] = {col0(Rr), col1(Rr), col2(Rr)};
+    float best = -1e30f; int type = -1, bi = 0, bj = 0; V3 axis = v3(1, 0, 0); float flip = 1.f;
+    // A's face axes
+    for (int i = 0; i < 3; i++) {
+        float rb = h.x * fabsf(get(bcol[0], i)) + h.y * fabsf(get(bcol[1], i)) + h.z * fabsf(get(bcol[2], i));
+        float s = fabsf(get(pp, i)) - (get(h, i) + rb);
+        if (s > 0.f) return;
+        if (s > best) { best = s; type = 0; bi = i; flip = get(pp, i) < 0 ? -1.f : 1.f; }
+    }
+    // B's face axes
+    for (int j = 0; j < 3; j++) {
+        float ra = h.x * fabsf(bcol[j].x) + h.y * fabsf(bcol[j].y) + h.z * fabsf(bcol[j].z);
+        float pj = dot(pp, bcol[j]);
+        float s = fabsf(pj) - (ra + get(h, j));
+        if (s > 0.f) return;
+        if (s > best) { best = s; type = 1; bj = j; flip = pj < 0 ? -1.f : 1.f; }
+    }
+    // edge-edge
+    for (int i = 0; i < 3; i++) {
+        V3 ei = v3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f);
+        for (int j = 0; j < 3; j++) {
+            V3 a = cross(ei, bcol[j]);
+            float al = len(a);
+            if (al < 1e-5f) continue;
+            a = a / al;
+            float ra = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
+            float rb = h.x * fabsf(dot(a, bcol[0])) + h.y * fabsf(dot(a, bcol[1])) + h.z * fabsf(dot(a, bcol[2]));
+            float pa = dot(pp, a);
+            float s = fabsf(pa) - (ra + rb);
+            if (s > 0.f) return;
+            if (s * 1.05f > best + 1e-4f && s > best * 1.05f) {  // fudge: favour face axes (btBoxBoxDetector.cpp fudge_factor)
+                best = s; type = 2; bi = i; bj = j; axis = pa < 0 ? -a : a;
+            }
+        }
+    }
+    if (type == 0 || type == 1) {
+        // reference box = the one owning the axis; incident face from the other box
+        bool ref_is_a = (type == 0);
+        V3 nrm_a;  // separating direction from A to B in A's frame
+        if (ref_is_a) nrm_a = v3(bi == 0 ? flip : 0.f, bi == 1 ? flip : 0.f, bi == 2 ? flip : 0.f);
+        else nrm_a = bcol[bj] * flip;
+        // express everything in the reference box frame
+        M3 Rref = ref_is_a ? m3_identity() : Rr;              // ref axes in A frame (columns)
+        V3 cref = ref_is_a ? v3(0, 0, 0) : pp;
+        M3 Rinc = ref_is_a ? Rr : m3_identity();
+        V3 cinc = ref_is_a ? pp : v3(0, 0, 0);
+        V3 nref = ref_is_a ? nrm_a : -nrm_a;                   // outward from ref towards inc, in A frame
+        // incident face: face of inc most anti-parallel to nref
+        V3 icol[3] = {col0(Rinc), col1(Rinc), col2(Rinc)};
+        int k = 0; float mk = fabsf(dot(nref, icol[0]));
+        for (int q = 1; q < 3; q++) { float v = fabsf(dot(nref, icol[q])); if (v > mk) { mk = v; k = q; } }
+        float sg = dot(nref, icol[k]) > 0.f ? -1.f : 1.f;
+        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        V3 quad[8], tmp[8];
+        for (int q = 0; q < 4; q++) {
+            float s1 = (q == 0 || q == 3) ? -1.f : 1.f, s2 = (q < 2) ? -1.f : 1.f;
+            quad[q] = cinc + icol[k] * (sg * get(h, k)) + icol[k1] * (s1 * get(h, k1)) + icol[k2] * (s2 * get(h, k2));
+        }
+        int m = 4;
+        V3 rcol[3] = {col0(Rref), col1(Rref), col2(Rref)};
+        int rk = ref_is_a ? bi : bj;
+        for (int q = 0; q < 4 && m > 0; q++) {
+            int ax = (q < 2) ? (rk + 1) % 3 : (rk + 2) % 3; float s = (q % 2) ? 1.f : -1.f;
+            V3 cn = rcol[ax] * s;
+            m = clip_poly(quad, m, cn, dot(cn, cref) + get(h, ax), tmp);
+            for (int r = 0; r < m; r++) quad[r] = tmp[r];
+        }
+        float face_off = dot(nref, cref) + get(h, rk);
+        for (int q = 0; q < m; q++) {
+            float dist = dot(nref, quad[q]) - face_off;  // < 0 when the incident point is inside the reference box
+            if (dist < 0.f) {
+                Cand c; c.dist = dist;
+                // normal from B to A (world). nrm_a points A->B.
+                c.n = Ra * (-nrm_a);
+                // point on B: if the reference is A the incident point is on B; else project onto B's face
+                V3 pb_a = ref_is_a ? quad[q] : (quad[q] - nref * dist);
+                c.pb = ca + Ra * pb_a;
+                cand_add(cs, nc, c);
+            }
+        }
+    } else if (type == 2) {
+        // edge-edge: support edges
+        V3 a = axis;  // A -> B in A frame
+        V3 pa = v3(a.x > 0 ? h.x : -h.x, a.y > 0 ? h.y : -h.y, a.z > 0 ? h.z : -h.z);
+        if (bi == 0) pa.x = 0; else if (bi == 1) pa.y = 0; else pa.z = 0;
+        V3 pb = pp;
+        for (int q = 0; q < 3; q++) {
+            if (q == bj) continue;
+            float s = dot(a, bcol[q]) > 0 ? -1.f : 1.f;
+            pb += bcol[q] * (s * get(h, q));
+        }
+        V3 ua = v3(bi == 0 ? 1.f : 0.f, bi == 1 ? 1.f : 0.f, bi == 2 ? 1.f : 0.f), ub = bcol[bj];
+        V3 w = pb - pa;
+        float uaub = dot(ua, ub), q1 = dot(ua, w), q2 = -dot(ub, w);
+        float dd = 1.f - uaub * uaub;
+        float beta = (dd > 1e-6f) ? (uaub * q1 + q2) / dd : 0.f;
+        V3 ptb = pb + ub * beta;
+        Cand c; c.dist = best; c.n = Ra * (-a); c.pb = ca + Ra * ptb;
+        cand_add(cs, nc, c);
+    }
+}
+
+// sphere vs rounded box (core = half extents - margin, GJK margins: btConvexConvexAlgorithm / btGjkPairDetector)
+RLG_HD bool sphere_box(V3 sc, float radius, V3 bc, const M3& R, V3 h, float thresh, V3& pb, V3& n, float& dist) {
+    V3 hc = v3(h.x - BOX_MARGIN, h.y - BOX_MARGIN, h.z - BOX_MARGIN);
+    V3 l = tmul(R, sc - bc);
+    V3 q = v3(clampf(l.x, -hc.x, hc.x), clampf(l.y, -hc.y, hc.y), clampf(l.z, -hc.z, hc.z));
+    V3 d = l - q;
+    float dl2 = len2(d);
+    V3 nl; float core_dist;
+    if (dl2 > SIMD_EPS * SIMD_EPS) {
+        core_dist = sqrtf(dl2);
+        nl = d / core_dist;
+    } else {
+        float px = hc.x - fabsf(l.x), py = hc.y - fabsf(l.y), pz = hc.z - fabsf(l.z);
+        if (px <= py && px <= pz) { nl = v3(l.x < 0 ? -1.f : 1.f, 0, 0); core_dist = -px; q.x = nl.x * hc.x; }
+        else if (py <= pz) { nl = v3(0, l.y < 0 ? -1.f : 1.f, 0); core_dist = -py; q.y = nl.y * hc.y; }
+        else { nl = v3(0, 0, l.z < 0 ? -1.f : 1.f); core_dist = -pz; q.z = nl.z * hc.z; }
+    }
+    dist = core_dist - (BOX_MARGIN + radius);
+    if (!(dist < thresh)) return false;
+    n = R * nl;
+    pb = bc + R * (q + nl * BOX_MARGIN);
+    return true;
+}
+
+}  // namespace rlg

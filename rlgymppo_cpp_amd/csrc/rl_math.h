@@ -1,0 +1,200 @@
+// rl_math.h — small fp32 vector/matrix/quaternion toolkit shared by the host and gfx950 builds of the
+// arena stepper.  Every function is `RLG_HD` (host+device under hipcc, plain inline under g++), uses
+// only fp32, and spells out the operation order (no reliance on contraction: build with
+// -ffp-contract=off) so the host build and the device build agree to rounding of the libm calls.
+//
+// Conventions follow the reference's Bullet types so the restated algorithms read the same:
+//   M3 is ROW-major like btMatrix3x3 (LinearMath/btMatrix3x3.h); the car basis COLUMNS are
+//   forward/right/up (RocketSim MathTypes.h:162).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RLG_HD __host__ __device__ __forceinline__
+#define RLG_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define RLG_HD inline
+#define RLG_HD_NOINLINE inline
+#endif
+
+namespace rlg {
+
+constexpr float SIMD_EPS = 1.1920928955078125e-7f;  // FLT_EPSILON (btScalar.h SIMD_EPSILON)
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct V3 {
+    float x, y, z;
+};
+
+RLG_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RLG_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RLG_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RLG_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RLG_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RLG_HD V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+RLG_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RLG_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+RLG_HD V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
+RLG_HD V3& operator-=(V3& a, V3 b) { a = a - b; return a; }
+RLG_HD V3& operator*=(V3& a, float s) { a = a * s; return a; }
+RLG_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RLG_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RLG_HD float len2(V3 a) { return dot(a, a); }
+RLG_HD float len(V3 a) { return sqrtf(dot(a, a)); }
+RLG_HD bool is_zero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
+RLG_HD V3 normalized(V3 a) { return a / len(a); }
+// btVector3::safeNormalize (btVector3.h:287-300): (1,0,0) when shorter than eps
+RLG_HD V3 safe_normalized(V3 a) {
+    float l2 = len2(a);
+    if (l2 >= SIMD_EPS * SIMD_EPS) return a / sqrtf(l2);
+    return v3(1.f, 0.f, 0.f);
+}
+RLG_HD float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+RLG_HD float sgnf(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+RLG_HD float get(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct M3 {
+    V3 r0, r1, r2;  // rows
+};
+RLG_HD M3 m3_rows(V3 a, V3 b, V3 c) { M3 m; m.r0 = a; m.r1 = b; m.r2 = c; return m; }
+RLG_HD M3 m3_cols(V3 c0, V3 c1, V3 c2) { return m3_rows(v3(c0.x, c1.x, c2.x), v3(c0.y, c1.y, c2.y), v3(c0.z, c1.z, c2.z)); }
+RLG_HD M3 m3_identity() { return m3_rows(v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)); }
+RLG_HD V3 col0(const M3& m) { return v3(m.r0.x, m.r1.x, m.r2.x); }
+RLG_HD V3 col1(const M3& m) { return v3(m.r0.y, m.r1.y, m.r2.y); }
+RLG_HD V3 col2(const M3& m) { return v3(m.r0.z, m.r1.z, m.r2.z); }
+RLG_HD V3 operator*(const M3& m, V3 v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
+// v * M  (btVector3 * btMatrix3x3 == M^T v)
+RLG_HD V3 tmul(const M3& m, V3 v) { return v3(dot(col0(m), v), dot(col1(m), v), dot(col2(m), v)); }
+RLG_HD M3 transpose(const M3& m) { return m3_rows(col0(m), col1(m), col2(m)); }
+RLG_HD M3 operator*(const M3& a, const M3& b) {
+    V3 c0 = col0(b), c1 = col1(b), c2 = col2(b);
+    return m3_rows(v3(dot(a.r0, c0), dot(a.r0, c1), dot(a.r0, c2)), v3(dot(a.r1, c0), dot(a.r1, c1), dot(a.r1, c2)),
+                   v3(dot(a.r2, c0), dot(a.r2, c1), dot(a.r2, c2)));
+}
+// btMatrix3x3::scaled(s): column i scaled by s[i]
+RLG_HD M3 scaled_cols(const M3& m, V3 s) { return m3_rows(m.r0 * s, m.r1 * s, m.r2 * s); }
+
+struct Q4 {
+    float x, y, z, w;
+};
+// btMatrix3x3::getRotation (btMatrix3x3.h)
+RLG_HD Q4 m3_to_quat(const M3& m) {
+    float trace = m.r0.x + m.r1.y + m.r2.z;
+    float t[4];
+    if (trace > 0.f) {
+        float s = sqrtf(trace + 1.0f);
+        t[3] = s * 0.5f;
+        s = 0.5f / s;
+        t[0] = (m.r2.y - m.r1.z) * s;
+        t[1] = (m.r0.z - m.r2.x) * s;
+        t[2] = (m.r1.x - m.r0.y) * s;
+    } else {
+        int i = m.r0.x < m.r1.y ? (m.r1.y < m.r2.z ? 2 : 1) : (m.r0.x < m.r2.z ? 2 : 0);
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        const V3 rows[3] = {m.r0, m.r1, m.r2};
+        float s = sqrtf(get(rows[i], i) - get(rows[j], j) - get(rows[k], k) + 1.0f);
+        t[i] = s * 0.5f;
+        s = 0.5f / s;
+        t[3] = (get(rows[k], j) - get(rows[j], k)) * s;
+        t[j] = (get(rows[j], i) + get(rows[i], j)) * s;
+        t[k] = (get(rows[k], i) + get(rows[i], k)) * s;
+    }
+    Q4 q; q.x = t[0]; q.y = t[1]; q.z = t[2]; q.w = t[3];
+    return q;
+}
+// btMatrix3x3::setRotation
+RLG_HD M3 quat_to_m3(Q4 q) {
+    float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    float s = 2.0f / d;
+    float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    return m3_rows(v3(1.0f - (yy + zz), xy - wz, xz + wy), v3(xy + wz, 1.0f - (xx + zz), yz - wx),
+                   v3(xz - wy, yz + wx, 1.0f - (xx + yy)));
+}
+// btQuaternion operator*(q1,q2)
+RLG_HD Q4 qmul(Q4 a, Q4 b) {
+    Q4 r;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return r;
+}
+// rotation about a unit axis (btQuaternion(axis, angle))
+RLG_HD Q4 quat_axis_angle(V3 axis, float angle) {
+    float d = len(axis);
+    float s = sinf(angle * 0.5f) / d;
+    Q4 q; q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s; q.w = cosf(angle * 0.5f);
+    return q;
+}
+
+// btTransformUtil::integrateTransform's rotation part (LinearMath/btTransformUtil.h:37-87)
+RLG_HD M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
+    const float ANGULAR_MOTION_THRESHOLD = 0.5f * (PI_F * 0.5f);
+    float fAngle2 = len2(angvel);
+    float fAngle = 0.f;
+    if (fAngle2 > SIMD_EPS) fAngle = sqrtf(fAngle2);
+    if (fAngle * dt > ANGULAR_MOTION_THRESHOLD) fAngle = ANGULAR_MOTION_THRESHOLD / dt;
+    V3 axis;
+    if (fAngle < 0.001f)
+        axis = angvel * (0.5f * dt - (dt * dt * dt) * 0.020833333333f * fAngle * fAngle);
+    else
+        axis = angvel * (sinf(0.5f * fAngle * dt) / fAngle);
+    Q4 dorn; dorn.x = axis.x; dorn.y = axis.y; dorn.z = axis.z; dorn.w = cosf(fAngle * dt * 0.5f);
+    Q4 orn0 = m3_to_quat(basis);
+    Q4 p = qmul(dorn, orn0);
+    float l2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+    if (l2 >= SIMD_EPS * SIMD_EPS) {  // safeNormalize
+        float inv = 1.f / sqrtf(l2);  // btQuaternion::operator/= multiplies by 1/s
+        p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
+    } else { p.x = 1; p.y = 0; p.z = 0; p.w = 0; }
+    l2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+    if (l2 > SIMD_EPS) return quat_to_m3(p);
+    return basis;
+}
+
+// btPlaneSpace1 (btVector3.h)
+RLG_HD void plane_space1(V3 n, V3& p, V3& q) {
+    const float SIMDSQRT12 = 0.7071067811865475244008443621048490f;
+    if (fabsf(n.z) > SIMDSQRT12) {
+        float a = n.y * n.y + n.z * n.z;
+        float k = 1.f / sqrtf(a);
+        p = v3(0.f, -n.z * k, n.y * k);
+        q = v3(a * k, -n.x * p.z, n.x * p.y);
+    } else {
+        float a = n.x * n.x + n.y * n.y;
+        float k = 1.f / sqrtf(a);
+        p = v3(-n.y * k, n.x * k, 0.f);
+        q = v3(-n.z * p.y, n.z * p.x, a * k);
+    }
+}
+
+// ---- counter-based RNG (Philox4x32-10) : one stream per env, no carried generator state --------
+struct Philox {
+    uint32_t key0, key1;
+    uint32_t c0, c1, c2, c3;
+};
+RLG_HD void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint64_t M0 = 0xD2511F53ull, M1 = 0xCD9E8D57ull;
+    uint64_t p0 = M0 * (uint64_t)c0, p1 = M1 * (uint64_t)c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// 4 x u32 for (seed, stream, counter)
+RLG_HD void philox4(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint32_t ctr_lo, uint32_t ctr_hi, uint32_t out[4]) {
+    uint32_t c0 = ctr_lo, c1 = ctr_hi, c2 = stream, c3 = 0x9E3779B9u;
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+    for (int i = 0; i < 10; i++) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+RLG_HD float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+}  // namespace rlg
