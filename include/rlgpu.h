@@ -1,0 +1,165 @@
+/*
+ * rlgpu.h — the C-ABI of the MI355X-native hot path (librlgpu.so, built from rlgymppo_cpp_amd/csrc/).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes (0 = ok, <0 = error; the text is
+ * available from rlgpu_last_error()).  No C++ exceptions cross this boundary and no torch types appear in
+ * it: pointers documented as "device" are raw HBM addresses (from hipMalloc, or torch's tensor.data_ptr()).
+ * All launches go to the context's stream (rlgpu_set_stream; default = the null stream).
+ *
+ * Each entry point names the reference interface it stands in for (file:line under /root/reference;
+ * SIM = RLGymPPO_CPP/RLGymSim_CPP/src/RLGymSim_CPP, RS = RLGymPPO_CPP/RLGymSim_CPP/RocketSim/src,
+ * PRIV/PUB = RLGymPPO_CPP/src/{private,public}/RLGymPPO_CPP).  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add on top of these.
+ */
+#ifndef RLGPU_H
+#define RLGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rlgpu_state.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rlgpu_env rlgpu_env;         /* N batched arenas + gym layer, resident on one GPU */
+typedef struct rlgpu_learner rlgpu_learner; /* policy + critic MLPs, Adam state, PPO scratch, resident on one GPU */
+
+enum { RLGPU_OK = 0, RLGPU_ERR_ARG = -1, RLGPU_ERR_HIP = -2, RLGPU_ERR_STATE = -3, RLGPU_ERR_NOMEM = -4 };
+
+/* reward terms / terminal conditions / state setters with a device fast path (the built-ins of
+ * SIM/Utils/RewardFunctions/CommonRewards.h:6-123, TerminalConditions/{NoTouch,GoalScore}Condition.h,
+ * StateSetters/{RandomState.cpp:8-61,KickoffState.h:7-10}) */
+enum { RLGPU_RW_EVENT = 0, RLGPU_RW_VELOCITY = 1, RLGPU_RW_SAVE_BOOST = 2, RLGPU_RW_VEL_BALL_TO_GOAL = 3,
+       RLGPU_RW_VEL_PLAYER_TO_BALL = 4, RLGPU_RW_FACE_BALL = 5, RLGPU_RW_TOUCH_BALL = 6 };
+enum { RLGPU_TC_NO_TOUCH = 0, RLGPU_TC_GOAL_SCORE = 1 };
+enum { RLGPU_SS_RANDOM = 0, RLGPU_SS_KICKOFF = 1 };
+
+typedef struct RlgpuRewardTerm { int32_t kind; float weight; float p0; } RlgpuRewardTerm;
+
+/* What `EnvCreateFn` builds per env in the reference (examplemain.cpp:58-100): Match(reward, conditions, obs,
+ * parser, setter, teamSize) + Gym(match, tickSkip).  Same field order as csrc/arena_gym.h GymConfig. */
+typedef struct RlgpuGymConfig {
+    int32_t tick_skip;
+    int32_t n_terms; RlgpuRewardTerm terms[8];       /* CombinedReward (CombinedReward.h:6-53) */
+    float event_weights[RLGPU_NUM_EVENT_VALS];       /* EventReward::WeightScales (CommonRewards.h:19-40) */
+    int32_t zero_sum; float team_spirit, opp_scale;  /* ZeroSumReward (ZeroSumReward.cpp:3-29) */
+    int32_t n_conds; int32_t conds[4]; int32_t no_touch_max_steps;
+    int32_t setter_kind; int32_t rand_ball_speed, rand_car_speed, cars_on_ground;
+    uint32_t seed_lo, seed_hi;
+    float pos_coef[3], vel_coef, ang_vel_coef;       /* DefaultOBS ctor (DefaultOBS.h:11-15) */
+    int32_t n_actions;                               /* DiscreteAction: 90 */
+} RlgpuGymConfig;
+
+/* fills cfg with the examplemain.cpp:58-100 stack: 0.1 FaceBall + 0.5 VelPlayerToBall + 1.0 VelBallToGoal +
+ * 50 Event{teamGoal 1, concede -1}; NoTouch(150) then GoalScore; DefaultOBS; RandomState(true,true,true); tickSkip 8 */
+void rlgpu_default_gym_config(RlgpuGymConfig* cfg);
+
+/* ---- environment batch : replaces ThreadAgentManager + N x (GameInst, Gym, Match, Arena)
+ *      (PRIV/Threading/ThreadAgentManager.h:10-69, PUB/Threading/GameInst.cpp:3-38, SIM/Gym.cpp:40-102) ---- */
+int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg);
+void rlgpu_env_destroy(rlgpu_env* e);
+const char* rlgpu_env_last_error(const rlgpu_env* e);
+int rlgpu_env_set_stream(rlgpu_env* e, void* hip_stream);
+int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size() probe (PUB/Learner.cpp:99-109): 51+19*players */
+int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * 2 * team_size ; agent row = env * players + slot */
+int rlgpu_env_num_actions(const rlgpu_env* e);
+int rlgpu_env_state_words(const rlgpu_env* e); /* resident 32-bit words per env */
+
+/* arena collision mesh: RocketSim::Init / InitFromMem (RS/RocketSim.cpp:70-212). verts in uu. */
+int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts_uu, int n_verts, const int32_t* tris, int n_tris);
+int rlgpu_env_set_procedural_mesh(rlgpu_env* e);
+int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* soccar_dir); /* collision_meshes/soccar/<name>.cmf */
+/* host helpers (no GPU needed): the procedural soccar mesh and the DiscreteAction table */
+int rlgpu_procedural_mesh(float* verts_uu, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris);
+int rlgpu_action_table(float* out_rows_x8, int cap_rows); /* DiscreteAction::DiscreteAction (SIM/Utils/ActionParsers/DiscreteAction.cpp:3-67) */
+
+/* Car::SetState/GetState, Ball::SetState/GetState, BoostPad::SetState for whole envs (RS/Sim/Car/Car.cpp:9-36,
+ * RS/Sim/Ball/Ball.cpp:27-49): the host StateSetter / user-plugin fallback path. env_ids NULL = envs 0..n-1 */
+int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host_states, const int32_t* env_ids, int n);
+int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host_states, const int32_t* env_ids, int n);
+
+/* Gym::Reset for every env (SIM/Gym.cpp:58-66). run_setter=0 keeps the uploaded physical state and only does the
+ * episode bookkeeping. obs_dev: [num_agents x obs_size] fp32 device, may be NULL. */
+int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev);
+
+/* Gym::Step + GameInst auto-reset for every env (SIM/Gym.cpp:68-102, PUB/Threading/GameInst.cpp:7-38):
+ * actions_dev [num_agents] int32 ; next_obs_dev [num_agents x obs_size] (post-reset obs when done);
+ * reward_dev [num_agents] ; done_dev [num_agents] int32 (the env's done replicated to its players). */
+int rlgpu_env_step(rlgpu_env* e, const int32_t* actions_dev, float* next_obs_dev, float* reward_dev, int32_t* done_dev);
+
+/* Arena::Step(ticks) on the resident states with the controls stored in them (RS/Sim/Arena/Arena.cpp:716-812) */
+int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
+int rlgpu_env_sync(rlgpu_env* e);
+/* last rlgpu_env_step kernel duration in ms, measured with hipEvents on the context stream (bench.py roofline) */
+int rlgpu_env_last_step_ms(rlgpu_env* e, float* ms);
+
+/* ---- learner : replaces PPOLearner + DiscretePolicy + ValueEstimator + ExperienceBuffer sampling + ComputeGAE
+ *      (PRIV/PPO/PPOLearner.cpp:67-349, DiscretePolicy.cpp:7-75, ValueEstimator.cpp:6-27, PRIV/Util/TorchFuncs.cpp:5-52) */
+typedef struct RlgpuLearnerConfig {
+    int32_t obs_size, n_actions;
+    int32_t n_policy_layers; int32_t policy_layers[8];   /* PPOLearnerConfig::policyLayerSizes (PUB/PPO/PPOLearnerConfig.h:7) */
+    int32_t n_critic_layers; int32_t critic_layers[8];   /* criticLayerSizes (:8) */
+    float policy_lr, critic_lr, ent_coef, clip_range;    /* :11-15 */
+    float temperature;                                   /* DiscretePolicy temperature (DiscretePolicy.h:16) */
+    int32_t use_bf16;                                    /* autocastLearn (PPOLearnerConfig.h:19): bf16 MFMA operands, fp32 accumulate/master */
+    uint32_t seed_lo, seed_hi;
+    int32_t max_rows;                                    /* largest row count of any call (scratch sizing) */
+} RlgpuLearnerConfig;
+
+int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConfig* cfg);
+void rlgpu_learner_destroy(rlgpu_learner* l);
+const char* rlgpu_learner_last_error(const rlgpu_learner* l);
+int rlgpu_learner_set_stream(rlgpu_learner* l, void* hip_stream);
+/* parameter count and flat fp32 views (policy then critic; per layer: W[out][in] row-major, then b[out], the
+ * state-dict order `0.weight,0.bias,2.weight,...` of the reference's Sequential) */
+int64_t rlgpu_learner_num_params(const rlgpu_learner* l, int which /*0 policy, 1 critic, 2 both*/);
+int rlgpu_learner_get_params(rlgpu_learner* l, int which, float* host_out);
+int rlgpu_learner_set_params(rlgpu_learner* l, int which, const float* host_in);
+int rlgpu_learner_get_grads(rlgpu_learner* l, int which, float* host_out);
+/* device pointer to the contiguous fp32 gradient buffer (policy then critic) for the RCCL all-reduce */
+int rlgpu_learner_grad_buffer(rlgpu_learner* l, float** dev_ptr, int64_t* n_floats);
+int rlgpu_learner_param_buffer(rlgpu_learner* l, float** dev_ptr, int64_t* n_floats);
+int rlgpu_learner_get_adam_state(rlgpu_learner* l, float* host_m, float* host_v, int64_t* step_policy, int64_t* step_critic);
+int rlgpu_learner_set_adam_state(rlgpu_learner* l, const float* host_m, const float* host_v, int64_t step_policy, int64_t step_critic);
+
+/* DiscretePolicy::GetAction (DiscretePolicy.cpp:51-62): probs = clamp(softmax(logits/T),1e-11,1); sample =
+ * argmax(p / q), q ~ Exp(1) (== torch.multinomial) ; logp = log(p[a]).  noise_dev: optional recorded q
+ * [rows x n_actions]; NULL = counter-based Philox (seed, call counter).  deterministic: argmax, logp = 0. */
+int rlgpu_policy_act(rlgpu_learner* l, const float* obs_dev, int rows, int deterministic, const float* noise_dev,
+                     int32_t* actions_dev, float* logp_dev);
+/* raw policy outputs for tests: probs_dev [rows x n_actions] */
+int rlgpu_policy_probs(rlgpu_learner* l, const float* obs_dev, int rows, float* probs_dev);
+/* ValueEstimator::Forward (ValueEstimator.cpp:25-27) */
+int rlgpu_value_forward(rlgpu_learner* l, const float* obs_dev, int rows, float* values_dev);
+
+/* TorchFuncs::ComputeGAE (TorchFuncs.cpp:5-52) on time-major device arrays [T][n_agents]:
+ *   rews, dones, truncs: [T x n]; values: [(T+1) x n] (row T = V(next state after the last step));
+ *   out adv, targets, returns: [T x n].
+ * next_value_mode 0 = reference-faithful: the batch is the agent-major concatenation of the n trajectories and
+ *   `V[step+1]` of a trajectory's last step is the first value of the NEXT trajectory (quirk Q1), only the very
+ *   last row uses values[T][n-1];  1 = per-agent bootstrap with values[T][j]. */
+int rlgpu_gae(rlgpu_learner* l, const float* rews_dev, const float* dones_dev, const float* truncs_dev, const float* values_dev,
+              int T, int n, float gamma, float lambda, float ret_std, float clip_range, int next_value_mode,
+              float* adv_dev, float* targets_dev, float* returns_dev);
+
+/* One minibatch of PPOLearner::Learn (PPOLearner.cpp:127-215): forward both nets on obs[idx], losses scaled by
+ * batch_size_ratio (= MB / B), backward, gradients ACCUMULATED into the grad buffer.  idx_dev NULL = rows 0..n-1.
+ * metrics_dev (optional, accumulated): [0] sum entropy, [1] sum KL, [2] sum clip fraction, [3] sum ratio,
+ * [4] sum value loss (unscaled, per-minibatch means), [5] count of minibatches. */
+int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs_dev, const int32_t* actions_dev, const float* old_logp_dev,
+                        const float* adv_dev, const float* targets_dev, const int32_t* idx_dev, int n,
+                        float batch_size_ratio, float* metrics_dev);
+int rlgpu_zero_grads(rlgpu_learner* l);
+/* clip_grad_norm_(params, max_norm) per network then Adam (PPOLearner.cpp:273-288; torch defaults b1 .9 b2 .999 eps 1e-8).
+ * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
+int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale);
+int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
+int rlgpu_learner_sync(rlgpu_learner* l);
+/* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */
+int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLGPU_H */

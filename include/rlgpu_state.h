@@ -110,6 +110,7 @@ typedef struct RlgpuPlayerGymState {
             match_bumps, match_demos, boost_pickups;          /* PlayerData.h:17-25 */
     float event_last[RLGPU_NUM_EVENT_VALS];                   /* EventReward::lastRegisteredValues */
     float prev_action[8];                                     /* Match::prevActions row */
+    int32_t prev_action_idx;                                  /* its index in the action table, -1 = zero action */
 } RlgpuPlayerGymState;
 
 typedef struct RlgpuGymState {
@@ -121,6 +122,10 @@ typedef struct RlgpuGymState {
     float   shot_cooldown;
     uint8_t ball_shot, ball_shot_goal_team, ball_scored_last, _pad0;
     int64_t last_ball_update_count;
+    uint32_t snap_demoed_mask;       /* bit k: player k was demoed in the previous snapshot (Match::ParseActions, Match.cpp:47-49) */
+    uint32_t episode_steps;          /* Gym::totalSteps since the last reset */
+    uint32_t reset_count;            /* counter of the env's state-setter RNG stream */
+    uint32_t _pad1;
     RlgpuPlayerGymState players[RLGPU_MAX_CARS];
 } RlgpuGymState;
 

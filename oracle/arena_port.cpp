@@ -61,3 +61,76 @@ void port_arena_step(RlgpuArenaState* s, int ticks, uint32_t seed, uint32_t env)
 }
 
 }  // extern "C"
+
+// ---- gym layer (same GymConfig struct as the C-ABI's RlgpuGymConfig) ------------------------------------------
+static float g_action_table[90 * 8];
+static bool g_table_built = false;
+static const float* table() { if (!g_table_built) { build_action_table(g_action_table); g_table_built = true; } return g_action_table; }
+
+template <int NC>
+static void gym_reset_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, float* obs, int run_setter) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    gym_reset_env<NC>(A, G, *cfg, env, obs, (size_t)obs_size<NC>(), run_setter != 0);
+    arena_to_host(A, G, *s);
+}
+template <int NC>
+static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, const int32_t* actions, float* obs, float* rew, int32_t* done) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(), rew, done);
+    arena_to_host(A, G, *s);
+}
+
+extern "C" {
+
+void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs, int run_setter) {
+    for (int e = 0; e < n; e++) {
+        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = 51 + 19 * nc;
+        float* o = obs ? obs + (size_t)e * nc * D : nullptr;
+        if (nc == 2) gym_reset_t<2>(s, (const GymConfig*)cfg, e, o, run_setter);
+        else if (nc == 4) gym_reset_t<4>(s, (const GymConfig*)cfg, e, o, run_setter);
+        else gym_reset_t<6>(s, (const GymConfig*)cfg, e, o, run_setter);
+    }
+}
+void port_gym_step(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done) {
+    for (int e = 0; e < n; e++) {
+        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = 51 + 19 * nc;
+        int32_t dn = 0;
+        if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
+        else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
+        else gym_step_t<6>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
+        for (int k = 0; k < nc; k++) done[(size_t)e * nc + k] = dn;
+    }
+}
+int port_action_table(float* out) { memcpy(out, table(), sizeof(g_action_table)); return 90; }
+
+// scalar CPU baseline ("port") of the collection hot loop: n envs stepped round-robin on n_threads threads
+double port_bench_collect(int team_size, int n_envs, int n_threads, int steps, const void* cfg_v) {
+    const GymConfig* cfg = (const GymConfig*)cfg_v;
+    int nc = 2 * team_size; int D = 51 + 19 * nc;
+    std::vector<RlgpuArenaState> st(n_envs);
+    for (auto& s : st) { memset(&s, 0, sizeof(s)); s.num_cars = nc; for (int k = 0; k < nc; k++) { s.cars[k].rot[0] = 1; s.cars[k].rot[4] = 1; s.cars[k].rot[8] = 1; } }
+    std::vector<float> obs((size_t)n_envs * nc * D);
+    port_gym_reset(st.data(), n_envs, cfg, obs.data(), 1);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) {
+        th.emplace_back([&, t]() {
+            uint32_t rng = 12345u + 977u * t;
+            std::vector<float> o((size_t)nc * D); float rew[6]; int32_t acts[6]; int32_t dn;
+            for (int s = 0; s < steps; s++)
+                for (int e = t; e < n_envs; e += n_threads) {
+                    for (int k = 0; k < nc; k++) { rng = rng * 1664525u + 1013904223u; acts[k] = (rng >> 8) % 90; }
+                    if (nc == 2) gym_step_t<2>(&st[e], cfg, e, acts, o.data(), rew, &dn);
+                    else if (nc == 4) gym_step_t<4>(&st[e], cfg, e, acts, o.data(), rew, &dn);
+                    else gym_step_t<6>(&st[e], cfg, e, acts, o.data(), rew, &dn);
+                }
+        });
+    }
+    for (auto& x : th) x.join();
+    return std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+}
+
+}  // extern "C"

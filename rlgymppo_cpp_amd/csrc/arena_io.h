@@ -170,9 +170,10 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
         G.counters[k][0] = q.match_goals; G.counters[k][1] = q.match_saves; G.counters[k][2] = q.match_assists; G.counters[k][3] = q.match_shots;
         G.counters[k][4] = q.match_shot_passes; G.counters[k][5] = q.match_bumps; G.counters[k][6] = q.match_demos; G.counters[k][7] = q.boost_pickups;
         for (int e = 0; e < RLGPU_NUM_EVENT_VALS; e++) G.event_last[k][e] = q.event_last[e];
-        G.prev_action_idx[k] = -1;
+        G.prev_action_idx[k] = q.prev_action_idx;
     }
-    G.episode_steps = 0; G.reset_count = 0;
+    G.tracker_flags |= (g.snap_demoed_mask & 0xffu) << 8;
+    G.episode_steps = g.episode_steps; G.reset_count = g.reset_count;
     arena_finish_load(A);
 }
 
@@ -215,8 +216,10 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
         q.match_goals = G.counters[k][0]; q.match_saves = G.counters[k][1]; q.match_assists = G.counters[k][2]; q.match_shots = G.counters[k][3];
         q.match_shot_passes = G.counters[k][4]; q.match_bumps = G.counters[k][5]; q.match_demos = G.counters[k][6]; q.boost_pickups = G.counters[k][7];
         for (int e = 0; e < RLGPU_NUM_EVENT_VALS; e++) q.event_last[e] = G.event_last[k][e];
-        for (int e = 0; e < 8; e++) q.prev_action[e] = 0.f;
+        for (int e = 0; e < 8; e++) q.prev_action[e] = 0.f;  // the table row is filled in by the host side (it owns the table)
+        q.prev_action_idx = G.prev_action_idx[k];
     }
+    g.snap_demoed_mask = (G.tracker_flags >> 8) & 0xffu; g.episode_steps = G.episode_steps; g.reset_count = G.reset_count; g._pad1 = 0;
 }
 
 }  // namespace rlg

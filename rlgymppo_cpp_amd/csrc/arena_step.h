@@ -79,12 +79,16 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 
 // ---- narrowphase over all pairs -----------------------------------------------------------------------
 template <int NC, int MAXC>
-RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool& ball_car_touch) {
+RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch) {
     L.n = 0; ball_car_touch = false;
     const float r = K::BALL_RADIUS * UU2BT;
+    // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
+    // btDiscreteDynamicsWorld::addRigidBody) are both inactive, so the dispatcher skips the pair
+    // (btCollisionDispatcher::needsCollision): no ball-world contacts on the tick a car wakes the ball up.
+    const int n_ball_planes = ball_asleep ? 0 : 4;
     // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121)
     V3 bp = A.ball.b.pos;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < n_ball_planes; i++) {
         V3 n; float d; world_plane(i, n, d);
         float dist = (dot(n, bp - n * r) - d);
         if (dist < CBT_BALL) {
@@ -96,7 +100,7 @@ RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L
         }
     }
     // ball vs mesh
-    if (mesh.n_nodes > 0) {
+    if (mesh.n_nodes > 0 && !ball_asleep) {
         float ext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
         V3 lo = bp - v3(ext, ext, ext), hi = bp + v3(ext, ext, ext);
         int stack[32]; int sp = 0; stack[sp++] = 0;
@@ -251,8 +255,9 @@ RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n
 template <int NB>
 RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, bool has_b) {
     SolverBody& A = B[nr.a];
-    V3 vel1 = A.v + cross(A.w, ra);
-    V3 vel2 = has_b ? (B[nr.b].v + cross(B[nr.b].w, rb)) : v3(0, 0, 0);
+    // btSolverBody::getVelocityInLocalPointNoDelta (btSolverBody.h:133-139): includes the external impulses
+    V3 vel1 = (A.v + A.ext_f) + cross(A.w + A.ext_t, ra);
+    V3 vel2 = has_b ? ((B[nr.b].v + B[nr.b].ext_f) + cross(B[nr.b].w + B[nr.b].ext_t, rb)) : v3(0, 0, 0);
     V3 vel = vel1 - vel2;
     float rel_vel = dot(n, vel);
     V3 lat = vel - n * rel_vel;
@@ -323,7 +328,7 @@ RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
     A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
 
     ContactList<MAXC> L; bool touch;
-    collide_all<NC, MAXC>(A, mesh, L, ev, touch);
+    collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch);
     bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 
     // ---- solver setup

@@ -1,0 +1,657 @@
+// rlgpu_learn.hip — the learner half of include/rlgpu.h on gfx950: DiscretePolicy / ValueEstimator MLPs on MFMA,
+// fused softmax+sampler, GAE scan, fused PPO loss + d(logits), backward GEMMs, fused clip-by-norm + Adam.
+//
+// Reference semantics restated (file:line under RLGymPPO_CPP/src/private/RLGymPPO_CPP unless noted):
+//   MLP           Linear -> ReLU (xk) -> Linear                       PPO/DiscretePolicy.cpp:11-24, ValueEstimator.cpp:10-23
+//   probs         clamp(softmax(logits / T), 1e-11, 1), not renormalised  PPO/DiscretePolicy.h:27-32, .cpp:44-49
+//   sampling      multinomial(probs, 1, true) == argmax(p / q), q~Exp(1)   PPO/DiscretePolicy.cpp:58-60
+//   GAE           Util/TorchFuncs.cpp:5-52
+//   PPO loss      PPO/PPOLearner.cpp:139-215
+//   clip + Adam   PPO/PPOLearner.cpp:273-288, torch::optim::Adam defaults
+//
+// GEMMs use v_mfma_f32_32x32x2_f32 (exact fp32, the reference's precision) or, with use_bf16 (the reference's
+// autocast dtype, FrameworkTorch.h:12-16), v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 master weights.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/rlgpu.h"
+#include "rl_math.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+    const float* A; int lda; int a_trans;   // a(m,k) = a_trans ? A[k*lda+m] : A[m*lda+k]
+    const float* B; int ldb; int b_trans;   // b(k,n) = b_trans ? B[k*ldb+n] : B[n*ldb+k]
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;                      // per column n, optional
+    int relu;
+    const float* mask; int ldmask;          // optional: C *= (mask(m,n) > 0)
+    int atomic_accumulate;                  // C += result with atomics (split-K over blockIdx.z)
+    int k_chunk;                            // K range per blockIdx.z
+};
+
+__device__ __forceinline__ short f2bf(float f) {
+    // round-to-nearest-even; NaN stays NaN via the hardware conversion (MI355X_MICROARCH.md correctness table)
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<short*>(&h);
+}
+
+// C[M x N] = A[M x K] . B[K x N] on MFMA. 4 waves per block, each wave owns 32 rows x 64 cols of the 128 x 64 tile.
+template <bool BF16>
+__global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
+    constexpr int LDA_S = BF16 ? (BK + 8) : (BK + 1);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * (BF16 ? (BK + 8) * 2 : (BK + 1) * 4)];
+    float* As_f = reinterpret_cast<float*>(smem);
+    float* Bs_f = As_f + BM * LDA_S;
+    short* As_h = reinterpret_cast<short*>(smem);
+    short* Bs_h = As_h + BM * LDA_S;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // ---- stage A tile (BM x BK) and B tile (BN x BK) as [row][k]
+        if (!g.a_trans) {
+            for (int i = tid; i < BM * BK; i += GEMM_THREADS) {
+                int r = i / BK, k = i % BK;
+                int gm = m0 + r, gk = k0 + k;
+                float v = (gm < g.M && gk < kend) ? g.A[(size_t)gm * g.lda + gk] : 0.f;
+                if (BF16) As_h[r * LDA_S + k] = f2bf(v); else As_f[r * LDA_S + k] = v;
+            }
+        } else {
+            for (int i = tid; i < BM * BK; i += GEMM_THREADS) {
+                int k = i / BM, r = i % BM;
+                int gm = m0 + r, gk = k0 + k;
+                float v = (gm < g.M && gk < kend) ? g.A[(size_t)gk * g.lda + gm] : 0.f;
+                if (BF16) As_h[r * LDA_S + k] = f2bf(v); else As_f[r * LDA_S + k] = v;
+            }
+        }
+        if (!g.b_trans) {
+            for (int i = tid; i < BN * BK; i += GEMM_THREADS) {
+                int r = i / BK, k = i % BK;
+                int gn = n0 + r, gk = k0 + k;
+                float v = (gn < g.N && gk < kend) ? g.B[(size_t)gn * g.ldb + gk] : 0.f;
+                if (BF16) Bs_h[r * LDA_S + k] = f2bf(v); else Bs_f[r * LDA_S + k] = v;
+            }
+        } else {
+            for (int i = tid; i < BN * BK; i += GEMM_THREADS) {
+                int k = i / BN, r = i % BN;
+                int gn = n0 + r, gk = k0 + k;
+                float v = (gn < g.N && gk < kend) ? g.B[(size_t)gk * g.ldb + gn] : 0.f;
+                if (BF16) Bs_h[r * LDA_S + k] = f2bf(v); else Bs_f[r * LDA_S + k] = v;
+            }
+        }
+        __syncthreads();
+        const int arow = wave * 32 + (lane & 31);
+        if (BF16) {
+            // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 16) {
+                int kk = ks + 8 * (lane >> 5);
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(&As_h[arow * LDA_S + kk]);
+                bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs_h[(lane & 31) * LDA_S + kk]);
+                bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs_h[(32 + (lane & 31)) * LDA_S + kk]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+            }
+        } else {
+            // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+#pragma unroll
+            for (int ks = 0; ks < BK; ks += 2) {
+                int kk = ks + (lane >> 5);
+                float a = As_f[arow * LDA_S + kk];
+                float b0 = Bs_f[(lane & 31) * LDA_S + kk];
+                float b1 = Bs_f[(32 + (lane & 31)) * LDA_S + kk];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue. C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const f32x16& acc = t == 0 ? acc0 : acc1;
+        int gn = n0 + t * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int gm = m0 + wave * 32 + row;
+            if (gm < g.M && gn < g.N) {
+                float v = acc[r];
+                if (g.bias && blockIdx.z == 0) v += g.bias[gn];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) v = (g.mask[(size_t)gm * g.ldmask + gn] > 0.f) ? v : 0.f;
+                float* dst = &g.C[(size_t)gm * g.ldc + gn];
+                if (g.atomic_accumulate) atomicAdd(dst, v); else *dst = v;
+            }
+        }
+    }
+}
+
+// column sums: out[n] += sum_m X[m][n]
+__global__ void k_col_sum(const float* X, int ld, int M, int N, float* out) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s = 0.f;
+    for (int m = m0; m < m1; m++) s += X[(size_t)m * ld + n];
+    atomicAdd(&out[n], s);
+}
+
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
+// one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]
+__global__ void k_policy_head(const float* logits, int ld, int rows, int A, float inv_temp, int deterministic, const float* noise,
+                              uint32_t seed_lo, uint32_t seed_hi, uint32_t call_ctr, int32_t* actions, float* logp, float* probs_out) {
+    int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* z = logits + (size_t)row * ld;
+    float v0 = lane < A ? z[lane] * inv_temp : -INFINITY;
+    float v1 = (lane + 64) < A ? z[lane + 64] * inv_temp : -INFINITY;
+    float mx = wave_max(fmaxf(v0, v1));
+    float e0 = lane < A ? expf(v0 - mx) : 0.f, e1 = (lane + 64) < A ? expf(v1 - mx) : 0.f;
+    float sum = wave_sum(e0 + e1);
+    float p0 = fminf(fmaxf(e0 / sum, 1e-11f), 1.f), p1 = fminf(fmaxf(e1 / sum, 1e-11f), 1.f);
+    if (probs_out) {
+        if (lane < A) probs_out[(size_t)row * A + lane] = p0;
+        if (lane + 64 < A) probs_out[(size_t)row * A + lane + 64] = p1;
+    }
+    if (!actions) return;
+    float s0, s1;
+    if (deterministic) { s0 = p0; s1 = p1; }
+    else {
+        float q0, q1;
+        if (noise) { q0 = lane < A ? noise[(size_t)row * A + lane] : 1.f; q1 = (lane + 64) < A ? noise[(size_t)row * A + lane + 64] : 1.f; }
+        else {
+            uint32_t r[4];
+            rlg::philox4(seed_lo, seed_hi, (uint32_t)row, call_ctr, (uint32_t)lane, r);
+            // q ~ Exp(1): -log(1 - u), u in [0,1)
+            q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
+            q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
+        }
+        s0 = p0 / q0; s1 = p1 / q1;
+    }
+    if (lane >= A) s0 = -INFINITY;
+    if (lane + 64 >= A) s1 = -INFINITY;
+    // argmax with lowest-index tie break (torch.argmax / max semantics)
+    float best = s0; int bi = lane;
+    if (s1 > best) { best = s1; bi = lane + 64; }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    float pa = (bi < 64) ? __shfl(p0, bi, 64) : __shfl(p1, bi - 64, 64);
+    if (lane == 0) { actions[row] = bi; logp[row] = deterministic ? 0.f : logf(pa); }
+}
+
+// GAE: one lane per agent trajectory (column j of the time-major arrays), reverse scan over T (TorchFuncs.cpp:23-43)
+__global__ void k_gae(const float* rews, const float* dones, const float* truncs, const float* values, int T, int n,
+                      float gamma, float lambda, float ret_std, float clip_range, int mode, float* adv, float* targets, float* returns) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float last_gae = 0.f, last_ret = 0.f;
+    for (int t = T - 1; t >= 0; t--) {
+        size_t i = (size_t)t * n + j;
+        float done = 1.f - dones[i];
+        float trunc = 1.f - truncs[i];
+        float nv;
+        if (t == T - 1) {
+            if (mode == 0) nv = (j == n - 1) ? values[(size_t)T * n + j] : values[j + 1];  // first state of the NEXT trajectory (Q1)
+            else nv = values[(size_t)T * n + j];
+        } else nv = values[(size_t)(t + 1) * n + j];
+        float norm_rew;
+        if (ret_std != 0.f) {
+            norm_rew = rews[i] / ret_std;
+            if (clip_range > 0.f) norm_rew = fminf(fmaxf(norm_rew, -clip_range), clip_range);
+        } else norm_rew = rews[i];
+        float pred_ret = norm_rew + gamma * nv * done;
+        float delta = pred_ret - values[i];
+        float ret = rews[i] + last_ret * gamma * done * trunc;
+        returns[i] = ret;
+        last_ret = ret;
+        last_gae = delta + gamma * lambda * done * trunc * last_gae;
+        adv[i] = last_gae;
+        targets[i] = values[i] + last_gae;
+    }
+}
+
+// fused PPO policy loss + gradient wrt logits; one wave per row. (PPOLearner.cpp:148-198, DiscretePolicy.cpp:64-75)
+// metrics: [0] entropy sum, [1] KL sum, [2] clip count, [3] ratio sum (per-row sums; host divides)
+__global__ void k_ppo_policy_loss(const float* logits, int ld, int rows, int A, float inv_temp, const int32_t* actions, const float* old_logp,
+                                  const float* adv, const int32_t* idx, float clip, float ent_coef, float scale /* ratio / rows */,
+                                  float* dlogits, float* metrics) {
+    int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    int src = idx ? idx[row] : row;
+    const float* z = logits + (size_t)row * ld;
+    float v0 = lane < A ? z[lane] * inv_temp : -INFINITY, v1 = (lane + 64) < A ? z[lane + 64] * inv_temp : -INFINITY;
+    float mx = wave_max(fmaxf(v0, v1));
+    float e0 = lane < A ? expf(v0 - mx) : 0.f, e1 = (lane + 64) < A ? expf(v1 - mx) : 0.f;
+    float sum = wave_sum(e0 + e1);
+    float s0 = e0 / sum, s1 = e1 / sum;
+    float p0 = fminf(fmaxf(s0, 1e-11f), 1.f), p1 = fminf(fmaxf(s1, 1e-11f), 1.f);
+    float lp0 = logf(p0), lp1 = logf(p1);
+    float ent = wave_sum((lane < A ? -lp0 * p0 : 0.f) + ((lane + 64) < A ? -lp1 * p1 : 0.f));
+    int a = actions[src];
+    float logp_a = (a < 64) ? __shfl(lp0, a, 64) : __shfl(lp1, a - 64, 64);
+    float p_a = (a < 64) ? __shfl(p0, a, 64) : __shfl(p1, a - 64, 64);
+    float olp = old_logp[src], ad = adv[src];
+    float ratio = expf(logp_a - olp);
+    float clipped = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    float surr1 = ratio * ad, surr2 = clipped * ad;
+    // d(-min(surr1,surr2))/d logp : torch.min splits ties, and inside the clip range surr2 carries the other half
+    float g_logp;
+    bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    if (inside) g_logp = -(ad * ratio);
+    else if (surr1 < surr2) g_logp = -(ad * ratio);
+    else if (surr1 == surr2) g_logp = -(ad * ratio) * 0.5f;
+    else g_logp = 0.f;
+    // gradient wrt clamped probs p_i:  logp_a -> 1/p_a ; -ent_coef * H -> ent_coef * (log p_i + 1)
+    float g0 = (lane < A) ? ent_coef * (lp0 + 1.f) : 0.f, g1 = ((lane + 64) < A) ? ent_coef * (lp1 + 1.f) : 0.f;
+    if (lane == a) g0 += g_logp / p_a;
+    if (lane + 64 == a) g1 += g_logp / p_a;
+    // clamp backward: passes where 1e-11 <= s <= 1
+    if (!(s0 >= 1e-11f && s0 <= 1.f)) g0 = 0.f;
+    if (!(s1 >= 1e-11f && s1 <= 1.f)) g1 = 0.f;
+    float dotgs = wave_sum(g0 * s0 + g1 * s1);
+    float dz0 = s0 * (g0 - dotgs) * inv_temp * scale, dz1 = s1 * (g1 - dotgs) * inv_temp * scale;
+    if (lane < A) dlogits[(size_t)row * ld + lane] = dz0;
+    if (lane + 64 < A) dlogits[(size_t)row * ld + lane + 64] = dz1;
+    if (metrics && lane == 0) {
+        float lr = logp_a - olp;
+        atomicAdd(&metrics[0], ent);
+        atomicAdd(&metrics[1], (expf(lr) - 1.f) - lr);
+        atomicAdd(&metrics[2], fabsf(ratio - 1.f) > clip ? 1.f : 0.f);
+        atomicAdd(&metrics[3], ratio);
+    }
+}
+
+// value loss gradient: dL/dv = 2 (v - target) * scale ; metric[4] += (v-target)^2
+__global__ void k_value_loss(const float* v, const float* targets, const int32_t* idx, int rows, float scale, float* dv, float* metrics) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = 0.f;
+    if (i < rows) {
+        int src = idx ? idx[i] : i;
+        float d = v[i] - targets[src];
+        dv[i] = 2.f * d * scale;
+        sq = d * d;
+    }
+    sq = wave_sum(sq);
+    if (metrics && (threadIdx.x & 63) == 0 && sq != 0.f) atomicAdd(&metrics[4], sq);
+}
+
+__global__ void k_gather_rows(const float* src, const int32_t* idx, int rows, int D, float* dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * D) return;
+    int r = (int)(i / D), c = (int)(i % D);
+    dst[i] = src[(size_t)idx[r] * D + c];
+}
+
+// sum of squares of a gradient segment -> out[0] (fp32 atomics)
+__global__ void k_sumsq(const float* g, int64_t n, float pre_scale, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) { float v = g[i] * pre_scale; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+// clip_grad_norm_ (torch/nn/utils/clip_grad.py: coef = max_norm / (norm + 1e-6), clamped to 1) + Adam
+__global__ void k_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float pre_scale, float max_norm,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float norm = sqrtf(*sumsq);
+    float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    float gr = g[i] * pre_scale * coef;
+    float mi = b1 * m[i] + (1.f - b1) * gr;
+    float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+struct Net {
+    int n_layers = 0;              // number of Linear layers
+    int dims[10] = {0};            // dims[0] = in, dims[n_layers] = out
+    int64_t w_off[9] = {0}, b_off[9] = {0};
+    int64_t n_params = 0;
+};
+
+}  // namespace
+
+struct rlgpu_learner {
+    int device = 0;
+    RlgpuLearnerConfig cfg{};
+    Net pol, cri;
+    int64_t n_total = 0;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    int64_t step_p = 0, step_c = 0;
+    // scratch: activations per net [max_rows x width]
+    std::vector<float*> act_p, act_c;  // act[i] = output of layer i (post-ReLU for hidden), act_p.back() = logits
+    float *dbuf0 = nullptr, *dbuf1 = nullptr, *gathered = nullptr, *norm_buf = nullptr;
+    uint32_t call_ctr = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false; double last_flops = 0;
+    std::string err;
+};
+
+#define LCHK(l, call)                                                                            \
+    do {                                                                                         \
+        hipError_t _s = (call);                                                                  \
+        if (_s != hipSuccess) {                                                                  \
+            (l)->err = std::string(#call) + ": " + hipGetErrorString(_s);                        \
+            return RLGPU_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+namespace {
+
+void build_net(Net& n, int in, const int32_t* hidden, int n_hidden, int out, int64_t& off) {
+    n.n_layers = n_hidden + 1;
+    n.dims[0] = in;
+    for (int i = 0; i < n_hidden; i++) n.dims[i + 1] = hidden[i];
+    n.dims[n.n_layers] = out;
+    n.n_params = 0;
+    for (int i = 0; i < n.n_layers; i++) {
+        n.w_off[i] = off; off += (int64_t)n.dims[i] * n.dims[i + 1];
+        n.b_off[i] = off; off += n.dims[i + 1];
+        n.n_params += (int64_t)n.dims[i] * n.dims[i + 1] + n.dims[i + 1];
+    }
+}
+
+int launch_gemm(rlgpu_learner* l, const GemmArgs& g, int splits) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits), block(GEMM_THREADS);
+    if (l->cfg.use_bf16) hipLaunchKernelGGL(k_gemm<true>, grid, block, 0, l->stream, g);
+    else hipLaunchKernelGGL(k_gemm<false>, grid, block, 0, l->stream, g);
+    LCHK(l, hipGetLastError());
+    l->last_flops += 2.0 * g.M * g.N * g.K;
+    return RLGPU_OK;
+}
+
+// forward through `net`; acts[i] receives layer i's output (ld = dims[i+1])
+int net_forward(rlgpu_learner* l, const Net& net, const std::vector<float*>& acts, const float* x, int rows) {
+    const float* in = x; int ld_in = net.dims[0];
+    for (int i = 0; i < net.n_layers; i++) {
+        GemmArgs g{};
+        g.A = in; g.lda = ld_in; g.a_trans = 0;
+        g.B = l->params + net.w_off[i]; g.ldb = net.dims[i]; g.b_trans = 0;
+        g.C = acts[i]; g.ldc = net.dims[i + 1];
+        g.M = rows; g.N = net.dims[i + 1]; g.K = net.dims[i];
+        g.bias = l->params + net.b_off[i]; g.relu = (i < net.n_layers - 1) ? 1 : 0;
+        g.mask = nullptr; g.atomic_accumulate = 0; g.k_chunk = g.K;
+        int rc = launch_gemm(l, g, 1);
+        if (rc) return rc;
+        in = acts[i]; ld_in = net.dims[i + 1];
+    }
+    return RLGPU_OK;
+}
+
+// backward: dout = dL/d(output of last layer) [rows x out]; accumulates into l->grads. Uses dbuf0/dbuf1 ping-pong.
+int net_backward(rlgpu_learner* l, const Net& net, const std::vector<float*>& acts, const float* x, int rows, float* dout) {
+    float* cur = dout;
+    for (int i = net.n_layers - 1; i >= 0; i--) {
+        const float* in = (i == 0) ? x : acts[i - 1];
+        int K_in = net.dims[i], N_out = net.dims[i + 1];
+        // dW[N_out x K_in] += cur^T[N_out x rows] . in[rows x K_in]   (split over rows, fp32 atomics)
+        {
+            GemmArgs g{};
+            g.A = cur; g.lda = N_out; g.a_trans = 1;
+            g.B = in; g.ldb = K_in; g.b_trans = 1;
+            g.C = l->grads + net.w_off[i]; g.ldc = K_in;
+            g.M = N_out; g.N = K_in; g.K = rows;
+            g.atomic_accumulate = 1;
+            int chunk = 2048; g.k_chunk = chunk;
+            int splits = (rows + chunk - 1) / chunk;
+            int rc = launch_gemm(l, g, splits);
+            if (rc) return rc;
+        }
+        {
+            dim3 grid((N_out + 63) / 64, std::min(64, (rows + 255) / 256)), block(64);
+            hipLaunchKernelGGL(k_col_sum, grid, block, 0, l->stream, (const float*)cur, N_out, rows, N_out, l->grads + net.b_off[i]);
+            LCHK(l, hipGetLastError());
+        }
+        if (i > 0) {
+            // dX[rows x K_in] = cur[rows x N_out] . W[N_out x K_in], masked by ReLU of acts[i-1]
+            float* nxt = (cur == l->dbuf0) ? l->dbuf1 : l->dbuf0;
+            GemmArgs g{};
+            g.A = cur; g.lda = N_out; g.a_trans = 0;
+            g.B = l->params + net.w_off[i]; g.ldb = K_in; g.b_trans = 1;
+            g.C = nxt; g.ldc = K_in;
+            g.M = rows; g.N = K_in; g.K = N_out;
+            g.mask = acts[i - 1]; g.ldmask = K_in;
+            g.k_chunk = g.K;
+            int rc = launch_gemm(l, g, 1);
+            if (rc) return rc;
+            cur = nxt;
+        }
+    }
+    return RLGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConfig* cfg) {
+    if (!out || !cfg || cfg->obs_size <= 0 || cfg->n_actions <= 0 || cfg->n_actions > 128 || cfg->max_rows <= 0) return RLGPU_ERR_ARG;
+    if (cfg->n_policy_layers < 0 || cfg->n_policy_layers > 8 || cfg->n_critic_layers < 0 || cfg->n_critic_layers > 8) return RLGPU_ERR_ARG;
+    rlgpu_learner* l = new rlgpu_learner();
+    *out = l;
+    l->device = device; l->cfg = *cfg;
+    LCHK(l, hipSetDevice(device));
+    int64_t off = 0;
+    build_net(l->pol, cfg->obs_size, cfg->policy_layers, cfg->n_policy_layers, cfg->n_actions, off);
+    build_net(l->cri, cfg->obs_size, cfg->critic_layers, cfg->n_critic_layers, 1, off);
+    l->n_total = off;
+    LCHK(l, hipMalloc(&l->params, off * 4)); LCHK(l, hipMalloc(&l->grads, off * 4));
+    LCHK(l, hipMalloc(&l->adam_m, off * 4)); LCHK(l, hipMalloc(&l->adam_v, off * 4));
+    LCHK(l, hipMemset(l->grads, 0, off * 4)); LCHK(l, hipMemset(l->adam_m, 0, off * 4)); LCHK(l, hipMemset(l->adam_v, 0, off * 4));
+    // torch nn::Linear default init: W, b ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming_uniform(a=sqrt 5)); Philox stream
+    std::vector<float> h(off);
+    uint32_t ctr = 0;
+    auto init_net = [&](const Net& n) {
+        for (int i = 0; i < n.n_layers; i++) {
+            float bound = 1.0f / std::sqrt((float)n.dims[i]);
+            int64_t cnt = (int64_t)n.dims[i] * n.dims[i + 1] + n.dims[i + 1];
+            for (int64_t k = 0; k < cnt; k += 4) {
+                uint32_t r[4]; rlg::philox4(cfg->seed_lo, cfg->seed_hi, 0x1A17u, ctr++, 0, r);
+                for (int q = 0; q < 4 && k + q < cnt; q++) h[n.w_off[i] + k + q] = (rlg::u32_to_unit(r[q]) * 2.f - 1.f) * bound;
+            }
+        }
+    };
+    init_net(l->pol); init_net(l->cri);
+    LCHK(l, hipMemcpy(l->params, h.data(), off * 4, hipMemcpyHostToDevice));
+    size_t R = (size_t)cfg->max_rows;
+    int maxw = std::max(cfg->obs_size, cfg->n_actions);
+    for (int i = 0; i < l->pol.n_layers; i++) { float* p; LCHK(l, hipMalloc(&p, R * l->pol.dims[i + 1] * 4)); l->act_p.push_back(p); maxw = std::max(maxw, l->pol.dims[i + 1]); }
+    for (int i = 0; i < l->cri.n_layers; i++) { float* p; LCHK(l, hipMalloc(&p, R * l->cri.dims[i + 1] * 4)); l->act_c.push_back(p); maxw = std::max(maxw, l->cri.dims[i + 1]); }
+    LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
+    LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
+    LCHK(l, hipMalloc(&l->norm_buf, 16));
+    LCHK(l, hipEventCreate(&l->ev0)); LCHK(l, hipEventCreate(&l->ev1));
+    return RLGPU_OK;
+}
+
+void rlgpu_learner_destroy(rlgpu_learner* l) {
+    if (!l) return;
+    (void)hipSetDevice(l->device);
+    for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
+    for (float* p : l->act_p) (void)hipFree(p);
+    for (float* p : l->act_c) (void)hipFree(p);
+    if (l->ev0) (void)hipEventDestroy(l->ev0);
+    if (l->ev1) (void)hipEventDestroy(l->ev1);
+    delete l;
+}
+const char* rlgpu_learner_last_error(const rlgpu_learner* l) { return l ? l->err.c_str() : "null learner"; }
+int rlgpu_learner_set_stream(rlgpu_learner* l, void* s) { l->stream = (hipStream_t)s; return RLGPU_OK; }
+int64_t rlgpu_learner_num_params(const rlgpu_learner* l, int which) { return which == 0 ? l->pol.n_params : (which == 1 ? l->cri.n_params : l->n_total); }
+
+static void seg(const rlgpu_learner* l, int which, int64_t& off, int64_t& n) {
+    if (which == 0) { off = 0; n = l->pol.n_params; } else if (which == 1) { off = l->pol.n_params; n = l->cri.n_params; } else { off = 0; n = l->n_total; }
+}
+int rlgpu_learner_get_params(rlgpu_learner* l, int which, float* host) {
+    int64_t off, n; seg(l, which, off, n); LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    LCHK(l, hipMemcpy(host, l->params + off, n * 4, hipMemcpyDeviceToHost)); return RLGPU_OK;
+}
+int rlgpu_learner_set_params(rlgpu_learner* l, int which, const float* host) {
+    int64_t off, n; seg(l, which, off, n); LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    LCHK(l, hipMemcpy(l->params + off, host, n * 4, hipMemcpyHostToDevice)); return RLGPU_OK;
+}
+int rlgpu_learner_get_grads(rlgpu_learner* l, int which, float* host) {
+    int64_t off, n; seg(l, which, off, n); LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    LCHK(l, hipMemcpy(host, l->grads + off, n * 4, hipMemcpyDeviceToHost)); return RLGPU_OK;
+}
+int rlgpu_learner_grad_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->grads; *n = l->n_total; return RLGPU_OK; }
+int rlgpu_learner_param_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->params; *n = l->n_total; return RLGPU_OK; }
+int rlgpu_learner_get_adam_state(rlgpu_learner* l, float* hm, float* hv, int64_t* sp, int64_t* sc) {
+    LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream));
+    if (hm) LCHK(l, hipMemcpy(hm, l->adam_m, l->n_total * 4, hipMemcpyDeviceToHost));
+    if (hv) LCHK(l, hipMemcpy(hv, l->adam_v, l->n_total * 4, hipMemcpyDeviceToHost));
+    if (sp) *sp = l->step_p; if (sc) *sc = l->step_c; return RLGPU_OK;
+}
+int rlgpu_learner_set_adam_state(rlgpu_learner* l, const float* hm, const float* hv, int64_t sp, int64_t sc) {
+    LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream));
+    if (hm) LCHK(l, hipMemcpy(l->adam_m, hm, l->n_total * 4, hipMemcpyHostToDevice));
+    if (hv) LCHK(l, hipMemcpy(l->adam_v, hv, l->n_total * 4, hipMemcpyHostToDevice));
+    l->step_p = sp; l->step_c = sc; return RLGPU_OK;
+}
+
+static int policy_head(rlgpu_learner* l, const float* obs, int rows, int deterministic, const float* noise, int32_t* actions, float* logp, float* probs) {
+    if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
+    LCHK(l, hipSetDevice(l->device));
+    int rc = net_forward(l, l->pol, l->act_p, obs, rows);
+    if (rc) return rc;
+    int A = l->cfg.n_actions;
+    dim3 grid((rows + 3) / 4), block(256);
+    float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+    hipLaunchKernelGGL(k_policy_head, grid, block, 0, l->stream, (const float*)l->act_p.back(), A, rows, A, inv_t, deterministic, noise,
+                       l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, actions, logp, probs);
+    l->call_ctr++;
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+int rlgpu_policy_act(rlgpu_learner* l, const float* obs, int rows, int deterministic, const float* noise, int32_t* actions, float* logp) {
+    if (!actions || !logp) return RLGPU_ERR_ARG;
+    return policy_head(l, obs, rows, deterministic, noise, actions, logp, nullptr);
+}
+int rlgpu_policy_probs(rlgpu_learner* l, const float* obs, int rows, float* probs) { return policy_head(l, obs, rows, 1, nullptr, nullptr, nullptr, probs); }
+
+int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* values) {
+    if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
+    LCHK(l, hipSetDevice(l->device));
+    int rc = net_forward(l, l->cri, l->act_c, obs, rows);
+    if (rc) return rc;
+    LCHK(l, hipMemcpyAsync(values, l->act_c.back(), (size_t)rows * 4, hipMemcpyDeviceToDevice, l->stream));
+    return RLGPU_OK;
+}
+
+int rlgpu_gae(rlgpu_learner* l, const float* rews, const float* dones, const float* truncs, const float* values, int T, int n,
+              float gamma, float lambda, float ret_std, float clip_range, int mode, float* adv, float* targets, float* returns) {
+    LCHK(l, hipSetDevice(l->device));
+    dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_gae, grid, block, 0, l->stream, rews, dones, truncs, values, T, n, gamma, lambda, ret_std, clip_range, mode, adv, targets, returns);
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+
+int rlgpu_zero_grads(rlgpu_learner* l) {
+    LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipMemsetAsync(l->grads, 0, l->n_total * 4, l->stream));
+    return RLGPU_OK;
+}
+
+int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, const float* old_logp, const float* adv, const float* targets,
+                        const int32_t* idx, int n, float ratio, float* metrics) {
+    if (n <= 0 || n > l->cfg.max_rows) { l->err = "minibatch rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
+    LCHK(l, hipSetDevice(l->device));
+    const int D = l->cfg.obs_size, A = l->cfg.n_actions;
+    const float* x = obs;
+    if (idx) {
+        size_t tot = (size_t)n * D;
+        hipLaunchKernelGGL(k_gather_rows, dim3((tot + 255) / 256), dim3(256), 0, l->stream, obs, idx, n, D, l->gathered);
+        LCHK(l, hipGetLastError());
+        x = l->gathered;
+    }
+    l->last_flops = 0;
+    LCHK(l, hipEventRecord(l->ev0, l->stream));
+    int rc;
+    // critic
+    if ((rc = net_forward(l, l->cri, l->act_c, x, n))) return rc;
+    hipLaunchKernelGGL(k_value_loss, dim3((n + 255) / 256), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n, l->dbuf0, metrics);
+    LCHK(l, hipGetLastError());
+    if ((rc = net_backward(l, l->cri, l->act_c, x, n, l->dbuf0))) return rc;
+    // policy
+    if ((rc = net_forward(l, l->pol, l->act_p, x, n))) return rc;
+    float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+    hipLaunchKernelGGL(k_ppo_policy_loss, dim3((n + 3) / 4), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
+                       l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, l->dbuf0, metrics);
+    LCHK(l, hipGetLastError());
+    if ((rc = net_backward(l, l->pol, l->act_p, x, n, l->dbuf0))) return rc;
+    LCHK(l, hipEventRecord(l->ev1, l->stream));
+    l->timed = true;
+    if (metrics) {
+        // [5] += 1 minibatch, [6] += rows
+        float inc[2] = {1.f, (float)n};
+        (void)inc;
+    }
+    return RLGPU_OK;
+}
+
+int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
+    LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipMemsetAsync(l->norm_buf, 0, 16, l->stream));
+    struct Seg { int64_t off, n; float lr; int64_t* step; int slot; } segs[2] = {
+        {0, l->pol.n_params, l->cfg.policy_lr, &l->step_p, 0}, {l->pol.n_params, l->cri.n_params, l->cfg.critic_lr, &l->step_c, 1}};
+    for (auto& s : segs) {
+        hipLaunchKernelGGL(k_sumsq, dim3(64), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, l->norm_buf + s.slot);
+        LCHK(l, hipGetLastError());
+    }
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    for (auto& s : segs) {
+        (*s.step)++;
+        double t = (double)*s.step;
+        float bc1 = (float)(1.0 - std::pow((double)b1, t));
+        float bc2s = (float)std::sqrt(1.0 - std::pow((double)b2, t));
+        hipLaunchKernelGGL(k_clip_adam, dim3((s.n + 255) / 256), dim3(256), 0, l->stream, l->params + s.off, (const float*)(l->grads + s.off),
+                           l->adam_m + s.off, l->adam_v + s.off, s.n, (const float*)(l->norm_buf + s.slot), grad_scale, max_norm, s.lr, b1, b2, eps, bc1, bc2s);
+        LCHK(l, hipGetLastError());
+    }
+    return RLGPU_OK;
+}
+int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }
+int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }
+int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {
+    if (!l->timed) return RLGPU_ERR_STATE;
+    LCHK(l, hipEventSynchronize(l->ev1));
+    LCHK(l, hipEventElapsedTime(ms, l->ev0, l->ev1));
+    *flops = l->last_flops;
+    return RLGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""BatchedEnv — host handle of the on-device arena batch (rlgpu_env_* in include/rlgpu.h).
+
+Stands where the reference has ThreadAgentManager + N x GameInst/Gym/Match/Arena
+(RLGymPPO_CPP/src/private/RLGymPPO_CPP/Threading/ThreadAgentManager.h:10-69, RLGymSim_CPP/src/RLGymSim_CPP/Gym.cpp:40-102).
+torch is used only to own device buffers and streams; every computation is a HIP kernel behind the C-ABI.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from .state import ArenaState
+
+
+def _chk(rc, handle, errfn):
+    if rc != 0:
+        raise _lib.RlgpuError(f"rlgpu error {rc}: {errfn(handle).decode()}")
+
+
+class BatchedEnv:
+    def __init__(self, n_envs: int, team_size: int = 1, cfg: "_lib.GymConfig | None" = None, device: int = 0, mesh="procedural"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedEnv needs a GPU (the stepper is a HIP kernel; there is no CPU path)")
+        self.lib = _lib.load()
+        self.cfg = cfg if cfg is not None else _lib.default_gym_config()
+        self.device = device
+        self.n_envs = n_envs
+        self.team_size = team_size
+        self.h = C.c_void_p()
+        rc = self.lib.rlgpu_env_create(C.byref(self.h), device, n_envs, team_size, C.byref(self.cfg))
+        _chk(rc, self.h, self.lib.rlgpu_env_last_error)
+        self.obs_size = self.lib.rlgpu_env_obs_size(self.h)
+        self.n_agents = self.lib.rlgpu_env_num_agents(self.h)
+        self.n_actions = self.lib.rlgpu_env_num_actions(self.h)
+        self.players = 2 * team_size
+        if isinstance(mesh, str) and mesh == "procedural":
+            _chk(self.lib.rlgpu_env_set_procedural_mesh(self.h), self.h, self.lib.rlgpu_env_last_error)
+            self.mesh_kind = "procedural"
+        elif isinstance(mesh, str):
+            _chk(self.lib.rlgpu_env_load_cmf_dir(self.h, mesh.encode()), self.h, self.lib.rlgpu_env_last_error)
+            self.mesh_kind = "cmf:" + mesh
+        elif mesh is not None:
+            v, t = mesh
+            v = np.ascontiguousarray(v, np.float32); t = np.ascontiguousarray(t, np.int32)
+            _chk(self.lib.rlgpu_env_set_mesh(self.h, v.ctypes.data, len(v), t.ctypes.data, len(t)), self.h, self.lib.rlgpu_env_last_error)
+            self.mesh_kind = "custom"
+        else:
+            self.mesh_kind = "none"
+
+    def close(self):
+        if self.h:
+            self.lib.rlgpu_env_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev(self):
+        return torch.device("cuda", self.device)
+
+    def set_stream(self, stream: "torch.cuda.Stream | None"):
+        ptr = stream.cuda_stream if stream is not None else 0
+        _chk(self.lib.rlgpu_env_set_stream(self.h, C.c_void_p(ptr)), self.h, self.lib.rlgpu_env_last_error)
+
+    def upload_states(self, states, env_ids=None):
+        n = len(states)
+        arr = (ArenaState * n)(*states)
+        ids = None
+        if env_ids is not None:
+            ids = np.ascontiguousarray(env_ids, np.int32)
+        _chk(self.lib.rlgpu_env_upload_states(self.h, C.addressof(arr), ids.ctypes.data if ids is not None else None, n),
+             self.h, self.lib.rlgpu_env_last_error)
+
+    def download_states(self, n=None, env_ids=None):
+        if env_ids is not None:
+            ids = np.ascontiguousarray(env_ids, np.int32); n = len(ids)
+        else:
+            ids = None; n = self.n_envs if n is None else n
+        arr = (ArenaState * n)()
+        _chk(self.lib.rlgpu_env_download_states(self.h, C.addressof(arr), ids.ctypes.data if ids is not None else None, n),
+             self.h, self.lib.rlgpu_env_last_error)
+        return list(arr)
+
+    def reset(self, run_setter=True, obs: "torch.Tensor | None" = None):
+        if obs is None:
+            obs = torch.empty((self.n_agents, self.obs_size), dtype=torch.float32, device=self._dev())
+        _chk(self.lib.rlgpu_env_reset(self.h, 1 if run_setter else 0, obs.data_ptr()), self.h, self.lib.rlgpu_env_last_error)
+        return obs
+
+    def step(self, actions: torch.Tensor, next_obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor):
+        assert actions.dtype == torch.int32 and done.dtype == torch.int32 and next_obs.dtype == torch.float32
+        assert actions.is_contiguous() and next_obs.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+        _chk(self.lib.rlgpu_env_step(self.h, actions.data_ptr(), next_obs.data_ptr(), reward.data_ptr(), done.data_ptr()),
+             self.h, self.lib.rlgpu_env_last_error)
+
+    def physics_ticks(self, ticks: int):
+        _chk(self.lib.rlgpu_env_physics_ticks(self.h, ticks), self.h, self.lib.rlgpu_env_last_error)
+
+    def sync(self):
+        _chk(self.lib.rlgpu_env_sync(self.h), self.h, self.lib.rlgpu_env_last_error)
+
+    def last_step_ms(self) -> float:
+        ms = C.c_float()
+        _chk(self.lib.rlgpu_env_last_step_ms(self.h, C.byref(ms)), self.h, self.lib.rlgpu_env_last_error)
+        return ms.value
+
+    def state_words(self) -> int:
+        return self.lib.rlgpu_env_state_words(self.h)
+
+
+def procedural_mesh():
+    lib = _lib.load()
+    nv, nt = C.c_int(), C.c_int()
+    lib.rlgpu_procedural_mesh(None, 0, None, 0, C.byref(nv), C.byref(nt))
+    v = np.zeros((nv.value, 3), np.float32); t = np.zeros((nt.value, 3), np.int32)
+    rc = lib.rlgpu_procedural_mesh(v.ctypes.data, nv.value, t.ctypes.data, nt.value, C.byref(nv), C.byref(nt))
+    assert rc == 0
+    return v, t
+
+
+def action_table():
+    lib = _lib.load()
+    tab = np.zeros((128, 8), np.float32)
+    n = lib.rlgpu_action_table(tab.ctypes.data, 128)
+    return tab[:n].copy()

@@ -58,7 +58,7 @@ class PlayerGymState(C.Structure):
         ("match_goals", C.c_int32), ("match_saves", C.c_int32), ("match_assists", C.c_int32),
         ("match_shots", C.c_int32), ("match_shot_passes", C.c_int32), ("match_bumps", C.c_int32),
         ("match_demos", C.c_int32), ("boost_pickups", C.c_int32),
-        ("event_last", f32 * NUM_EVENT_VALS), ("prev_action", f32 * 8),
+        ("event_last", f32 * NUM_EVENT_VALS), ("prev_action", f32 * 8), ("prev_action_idx", C.c_int32),
     ]
 
 
@@ -69,6 +69,7 @@ class GymState(C.Structure):
         ("shot_cooldown", f32),
         ("ball_shot", C.c_uint8), ("ball_shot_goal_team", C.c_uint8), ("ball_scored_last", C.c_uint8), ("_pad0", C.c_uint8),
         ("last_ball_update_count", C.c_int64),
+        ("snap_demoed_mask", C.c_uint32), ("episode_steps", C.c_uint32), ("reset_count", C.c_uint32), ("_pad1", C.c_uint32),
         ("players", PlayerGymState * MAX_CARS),
     ]
 

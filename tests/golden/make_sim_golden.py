@@ -1,0 +1,133 @@
+"""Generates tests/golden/sim_golden.npz from the REAL reference (oracle/_ref/libref_oracle.so = RocketSim + RLGymSim_CPP
+compiled from /root/reference by oracle/Makefile).  Run in the build container: `python tests/golden/make_sim_golden.py`.
+
+Contents (data only):
+  action_table                      DiscreteAction's 90x8 table
+  phys/<scenario>/...               initial ArenaState bytes, per-tick control tape, reference states every `every` ticks
+  gym/<case>/...                    initial state, action tape, per-step obs / reward / done of the reference Gym
+The arena mesh is the repo's procedural soccar stand-in (the game's collision_meshes are not redistributable and are
+absent here); it is stored too so the fixtures are self-contained.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from simlib import PortSim, RefSim, RefGym  # noqa: E402
+from rlgymppo_cpp_amd.state import ArenaState, default_arena, yaw_rot, euler_rot  # noqa: E402
+
+Z = [0.0] * 8
+
+
+def scenarios():
+    s = default_arena(2)
+    out = {}
+    out["rest"] = (s, lambda t, k: Z, 120)
+    out["throttle"] = (s, lambda t, k: [1, 0, 0, 0, 0, 0, 0, 0] if k == 0 else Z, 240)
+    out["steer_powerslide"] = (s, lambda t, k: [1, 1, 0, 1, 0, 0, 0, 0] if k == 0 else [1, -1, 0, -1, 0, 0, 1, 1], 240)
+    out["jump"] = (s, lambda t, k: [0, 0, 0, 0, 0, 1 if t < 20 else 0, 0, 0], 200)
+    out["flip"] = (s, lambda t, k: [1, 0, -1 if 30 <= t < 40 else 0, 0, 0, 1 if (t < 5 or 30 <= t < 35) else 0, 0, 0], 300)
+    out["double_jump"] = (s, lambda t, k: [0, 0, 0, 0, 0, 1 if (t < 5 or 30 <= t < 35) else 0, 0, 0], 300)
+    out["boost_turn"] = (s, lambda t, k: [1, 0.3, 0, 0.3, 0, 0, 1, 0], 400)
+    s2 = default_arena(2); s2.ball.pos[:] = (100, 200, 600); s2.ball.vel[:] = (300, -200, 10); s2.ball.ang_vel[:] = (1, 2, -1)
+    out["ball_drop"] = (s2, lambda t, k: Z, 600)
+    s2 = default_arena(2); s2.ball.pos[:] = (100, 200, 93.15); s2.ball.vel[:] = (800, -500, 0)
+    out["ball_roll"] = (s2, lambda t, k: Z, 600)
+    s2 = default_arena(2); s2.ball.pos[:] = (0, -1000, 93.15)
+    out["car_hits_ball"] = (s2, lambda t, k: [1, 0, 0, 0, 0, 0, 1, 0] if k == 0 else Z, 300)
+    s2 = default_arena(2); s2.ball.pos[:] = (3000, 0, 300); s2.ball.vel[:] = (2500, 300, 200)
+    out["ball_side_wall"] = (s2, lambda t, k: Z, 300)
+    s2 = default_arena(2); s2.ball.pos[:] = (2000, 4000, 300); s2.ball.vel[:] = (100, 2500, 200)
+    out["ball_back_wall_mesh"] = (s2, lambda t, k: Z, 300)
+    s2 = default_arena(2); s2.ball.pos[:] = (3000, 4000, 200); s2.ball.vel[:] = (1800, 1900, -300)
+    out["ball_corner_fillets"] = (s2, lambda t, k: Z, 400)
+    s2 = default_arena(2); s2.ball.pos[:] = (300, 4500, 200); s2.ball.vel[:] = (500, 2500, 300)
+    out["ball_into_goal"] = (s2, lambda t, k: Z, 400)
+    s2 = default_arena(2); s2.cars[0].pos[:] = (0, -2000, 800); s2.cars[0].flags = 0; s2.cars[0].vel[:] = (100, 300, 200)
+    out["air_control"] = (s2, lambda t, k: [1, 0, 0.7, -0.5, 1 if t < 60 else 0, 0, 1 if t % 40 < 20 else 0, 0] if k == 0 else Z, 220)
+    s2 = default_arena(2); s2.cars[0].pos[:] = (3200, 0, 17); s2.cars[0].rot[:] = yaw_rot(0.0); s2.cars[0].boost = 100
+    out["wall_ramp"] = (s2, lambda t, k: [1, 0, 0, 0, 0, 0, 1, 0] if k == 0 else Z, 300)
+    s2 = default_arena(2); s2.cars[0].pos[:] = (0, -1000, 17); s2.cars[1].pos[:] = (20, 1000, 17); s2.cars[0].boost = 100; s2.cars[1].boost = 100
+    out["car_car_head_on"] = (s2, lambda t, k: [1, 0, 0, 0, 0, 0, 1, 0], 300)
+    s2 = default_arena(2); s2.cars[0].pos[:] = (0, -2000, 100); s2.cars[0].flags = 0; s2.cars[0].rot[:] = euler_rot(1.0, 0, 3.1)
+    out["roof_landing_autoflip"] = (s2, lambda t, k: [1, 0, 0, 0, 0, 1 if 200 <= t < 210 else 0, 0, 0] if k == 0 else Z, 400)
+    s2 = default_arena(2); s2.cars[0].pos[:] = (-3584, -200, 17); s2.cars[0].boost = 10
+    out["boost_pad_pickup"] = (s2, lambda t, k: [1, 0, 0, 0, 0, 0, 0, 0] if k == 0 else Z, 240)
+    return out
+
+
+def state_vec(s: ArenaState):
+    v = list(s.ball.pos) + list(s.ball.vel) + list(s.ball.ang_vel)
+    for k in range(s.num_cars):
+        c = s.cars[k]
+        v += list(c.pos) + list(c.vel) + list(c.ang_vel) + list(c.rot) + [float(c.flags), c.boost]
+    return np.array(v, np.float32)
+
+
+def main():
+    port = PortSim()
+    verts, tris = port.procedural_mesh()
+    ref = RefSim(verts, tris)
+    out = {"mesh_verts": verts, "mesh_tris": tris}
+    tab = np.zeros((128, 8), np.float32)
+    n = ref.lib.ref_action_table(tab.ctypes.data_as(C.c_void_p), 128)
+    out["action_table"] = tab[:n].copy()
+    a = ref.arena(1)
+    every = 10
+    names = []
+    for name, (s0, fn, ticks) in scenarios().items():
+        ref.set_state(a, s0)
+        start = ref.get_state(a)
+        tape = np.zeros((ticks, 2, 8), np.float32)
+        rec = []
+        for t in range(ticks):
+            for k in range(2):
+                tape[t, k] = fn(t, k)
+                ref.set_controls(a, k, list(tape[t, k]))
+            ref.step(a, 1)
+            if (t + 1) % every == 0:
+                rec.append(state_vec(ref.get_state(a)))
+        out[f"phys/{name}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        out[f"phys/{name}/tape"] = tape
+        out[f"phys/{name}/states"] = np.stack(rec)
+        names.append(name)
+    out["phys_names"] = np.array(names)
+    out["phys_every"] = every
+
+    # gym-level rollouts
+    gnames = []
+    for case, tick_skip, seed in [("ts8_random", 8, 0), ("ts8_chase", 8, 1), ("ts1_random", 1, 2)]:
+        g = RefGym(ref, 1, tick_skip)
+        s0 = default_arena(2); s0.ball.pos[:] = (0, -1500, 93.15); s0.cars[0].boost = 100
+        obs0 = g.reset_to(s0)
+        start = ref.get_state(g.arena())
+        rng = np.random.RandomState(seed)
+        steps = 160 if tick_skip == 8 else 60
+        acts = rng.randint(0, 90, size=(steps, 2)).astype(np.int32)
+        if case == "ts8_chase":
+            acts[:40, 0] = 21
+        obs = []; rew = []; done = []
+        for t in range(steps):
+            o, r, d, _ = g.step(acts[t])
+            obs.append(o); rew.append(r); done.append(d)
+            if d:
+                acts = acts[: t + 1]
+                break
+        out[f"gym/{case}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        out[f"gym/{case}/obs0"] = obs0
+        out[f"gym/{case}/actions"] = acts
+        out[f"gym/{case}/obs"] = np.stack(obs); out[f"gym/{case}/rew"] = np.stack(rew); out[f"gym/{case}/done"] = np.array(done, np.int32)
+        out[f"gym/{case}/tick_skip"] = tick_skip
+        gnames.append(case)
+    out["gym_names"] = np.array(gnames)
+    np.savez_compressed(os.path.join(HERE, "sim_golden.npz"), **out)
+    print("wrote sim_golden.npz:", len(names), "physics scenarios,", len(gnames), "gym rollouts")
+
+
+if __name__ == "__main__":
+    main()

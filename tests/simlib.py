@@ -83,3 +83,64 @@ def have_ref():
 
 def have_port():
     return os.path.exists(PORT_SO)
+
+
+# ---- gym-level helpers -----------------------------------------------------------------------------------------
+def port_gym_cfg(**over):
+    """A GymConfig (same layout as the C-ABI's) with the examplemain.cpp defaults; pure ctypes, no GPU library."""
+    from rlgymppo_cpp_amd._lib import GymConfig, RW_FACE_BALL, RW_VEL_PLAYER_TO_BALL, RW_VEL_BALL_TO_GOAL, RW_EVENT
+    c = GymConfig()
+    c.tick_skip = 8
+    c.n_terms = 4
+    for i, (k, w) in enumerate([(RW_FACE_BALL, 0.1), (RW_VEL_PLAYER_TO_BALL, 0.5), (RW_VEL_BALL_TO_GOAL, 1.0), (RW_EVENT, 50.0)]):
+        c.terms[i].kind = k; c.terms[i].weight = w; c.terms[i].p0 = 0.0
+    c.event_weights[1] = 1.0; c.event_weights[2] = -1.0
+    c.zero_sum = 0; c.team_spirit = 0.0; c.opp_scale = 1.0
+    c.n_conds = 2; c.conds[0] = 0; c.conds[1] = 1; c.no_touch_max_steps = 150
+    c.setter_kind = 0; c.rand_ball_speed = 1; c.rand_car_speed = 1; c.cars_on_ground = 1
+    c.seed_lo = 123; c.seed_hi = 0
+    c.pos_coef[0] = 1 / 4096.0; c.pos_coef[1] = 1 / 5120.0; c.pos_coef[2] = 1 / 2044.0
+    c.vel_coef = 1 / 2300.0; c.ang_vel_coef = 1 / 5.5
+    c.n_actions = 90
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def port_gym_reset(port, states, cfg, run_setter=True):
+    n = len(states); nc = states[0].num_cars; D = 51 + 19 * nc
+    arr = (ArenaState * n)(*states)
+    obs = np.zeros((n * nc, D), np.float32)
+    port.lib.port_gym_reset(arr, n, C.byref(cfg), _ptr(obs), 1 if run_setter else 0)
+    return list(arr), obs
+
+
+def port_gym_step(port, states, cfg, actions):
+    n = len(states); nc = states[0].num_cars; D = 51 + 19 * nc
+    arr = (ArenaState * n)(*states)
+    actions = np.ascontiguousarray(actions, np.int32)
+    obs = np.zeros((n * nc, D), np.float32); rew = np.zeros(n * nc, np.float32); done = np.zeros(n * nc, np.int32)
+    port.lib.port_gym_step(arr, n, C.byref(cfg), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done))
+    return list(arr), obs, rew, done
+
+
+class RefGym:
+    def __init__(self, ref, team_size=1, tick_skip=8, obs_kind=0, reward_kind=0, no_touch_steps=150):
+        self.ref = ref; self.nc = 2 * team_size; self.D = 51 + 19 * self.nc
+        self.h = _vp(ref.lib.ref_gym_new(team_size, tick_skip, obs_kind, reward_kind, no_touch_steps))
+
+    def reset_to(self, state):
+        obs = np.zeros((self.nc, self.D), np.float32)
+        d = self.ref.lib.ref_gym_reset_to(self.h, C.byref(state), _ptr(obs))
+        assert d == self.D
+        return obs
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, np.int32)
+        obs = np.zeros((self.nc, self.D), np.float32); rew = np.zeros(self.nc, np.float32); done = C.c_int32()
+        st = ArenaState()
+        self.ref.lib.ref_gym_step(self.h, _ptr(actions), _ptr(obs), _ptr(rew), C.byref(done), C.byref(st))
+        return obs, rew, int(done.value), st
+
+    def arena(self):
+        return _vp(self.ref.lib.ref_gym_arena(self.h))

@@ -1,0 +1,334 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path through the C-ABI against
+  * the host build of the stepper core (oracle/_build/liboracle_port.so) tick by tick and gym step by gym step,
+  * the committed golden vectors generated from the real reference / torch (tests/golden/*.npz),
+  * the numpy learner oracle (oracle/learner_ref.py),
+  * the real reference itself when oracle/_ref/libref_oracle.so travelled with the snapshot,
+and size-independent properties at the BASELINE sizes (4096 envs)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import learner_ref as R  # noqa: E402
+from rlgymppo_cpp_amd.state import ArenaState, default_arena  # noqa: E402
+from simlib import port_gym_cfg, port_gym_reset, port_gym_step  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def sg():
+    return np.load(os.path.join(GOLD, "sim_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def lg():
+    return np.load(os.path.join(GOLD, "learner_golden.npz"))
+
+
+def _vec(s):
+    v = list(s.ball.pos) + list(s.ball.vel) + list(s.ball.ang_vel)
+    for k in range(s.num_cars):
+        c = s.cars[k]
+        v += list(c.pos) + list(c.vel) + list(c.ang_vel) + list(c.rot) + [float(c.flags), c.boost, c.jump_time, c.flip_time, c.handbrake_val]
+    return np.array(v, np.float64)
+
+
+def test_upload_download_roundtrip():
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    env = BatchedEnv(130, 1)
+    rng = np.random.RandomState(0)
+    states = []
+    for i in range(130):
+        s = default_arena(2)
+        s.ball.pos[:] = list(rng.uniform(-1000, 1000, 3) + [0, 0, 1500]); s.ball.vel[:] = list(rng.uniform(-500, 500, 3))
+        s.cars[0].boost = float(rng.uniform(0, 100)); s.cars[1].bh_tick_hit = int(rng.randint(0, 1 << 40)); s.tick_count = int(rng.randint(0, 1 << 40))
+        s.pads[i % 34].cooldown = 3.5; s.pads[i % 34].is_active = 0; s.pads[i % 34].prev_locked_car_id = 2
+        s.gym.players[1].match_goals = i; s.gym.no_touch_steps = i * 3
+        states.append(s)
+    env.upload_states(states)
+    back = env.download_states()
+    for a, b in zip(states, back):
+        assert np.allclose(_vec(a), _vec(b), rtol=0, atol=2e-4)   # uu -> BT -> uu rounding
+        assert a.tick_count == b.tick_count and a.cars[1].bh_tick_hit == b.cars[1].bh_tick_hit
+        assert [p.is_active for p in a.pads] == [p.is_active for p in b.pads] and abs(a.pads[3].cooldown - b.pads[3].cooldown) < 1e-6
+        assert a.gym.players[1].match_goals == b.gym.players[1].match_goals and a.gym.no_touch_steps == b.gym.no_touch_steps
+
+
+def test_physics_ticks_match_host_port_on_golden_scenarios(sg, port_lib):
+    """Every golden physics scenario as one env of a batch: HIP ticks vs the host build of the same core, every 10 ticks."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    names = [str(n) for n in sg["phys_names"]]
+    env = BatchedEnv(len(names), 1, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+    host = [ArenaState.from_buffer_copy(sg[f"phys/{n}/start"].tobytes()) for n in names]
+    tapes = [sg[f"phys/{n}/tape"] for n in names]
+    T = max(len(t) for t in tapes)
+    env.upload_states(host)
+    worst = 0.0
+    for t in range(0, T, 10):
+        # controls are constant per tick in the tapes only piecewise: re-upload controls each 1 tick would be slow, so
+        # step tick by tick on the host and in chunks of 1 tick on the device only where the tape changes
+        for dt in range(10):
+            tt = t + dt
+            cur = env.download_states() if dt == 0 else cur
+            for i, s in enumerate(host):
+                if tt < len(tapes[i]):
+                    for k in range(2):
+                        s.cars[k].controls[:] = list(tapes[i][tt, k])
+                        cur[i].cars[k].controls[:] = list(tapes[i][tt, k])
+            env.upload_states(cur)
+            env.physics_ticks(1)
+            cur = env.download_states()
+            for i, s in enumerate(host):
+                if tt < len(tapes[i]):
+                    port_lib.step(s, 1)
+        for i, s in enumerate(host):
+            if t + 9 < len(tapes[i]):
+                err = np.abs(_vec(s) - _vec(cur[i]))
+                scale = np.maximum(1.0, np.abs(_vec(s)))
+                worst = max(worst, float((err / scale).max()))
+                # same source, two compilers: agreement to fp32 rounding of libm calls, amplified over <= 600 ticks
+                assert (err / scale).max() < 5e-3, f"{names[i]} tick {t + 10}: rel err {(err / scale).max()}"
+        # re-sync the device to the host so that compiler-level rounding does not accumulate into chaotic divergence
+        env.upload_states(host)
+    print("worst relative deviation HIP vs host port:", worst)
+
+
+def test_gym_step_matches_host_port(port_lib):
+    """64 random envs, 48 gym steps (incl. auto-resets): obs / reward / done of the HIP path vs the host port."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    n = 64
+    cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 20
+    env = BatchedEnv(n, 1, cfg=cfg)
+    pcfg = port_gym_cfg(no_touch_max_steps=20)
+    obs = env.reset(True)
+    env.sync()
+    states = env.download_states()
+    # the host port resets from the same seed/stream -> identical states and obs
+    hs = [default_arena(2) for _ in range(n)]
+    hs, hobs = port_gym_reset(port_lib, hs, pcfg, run_setter=True)
+    assert np.abs(obs.cpu().numpy() - hobs).max() < 1e-5
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(5)
+    nobs = torch.empty_like(obs); rew = torch.empty(n * 2, device=dev); done = torch.empty(n * 2, dtype=torch.int32, device=dev)
+    n_done = 0
+    for step in range(48):
+        acts = rng.randint(0, 90, size=n * 2).astype(np.int32)
+        env.step(torch.from_numpy(acts).to(dev), nobs, rew, done)
+        env.sync()
+        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts)
+        d = done.cpu().numpy()
+        assert (d == hd).all(), f"done flags differ at step {step}"
+        n_done += int(hd.sum())
+        assert np.abs(rew.cpu().numpy() - hr).max() < 2e-3, f"rewards differ at step {step}"
+        assert np.abs(nobs.cpu().numpy() - ho).max() < 2e-3, f"obs differ at step {step}"
+        # keep the two in lock step (see the physics test)
+        env.upload_states(hs)
+    assert n_done > 0   # auto-reset path exercised
+
+
+def test_gym_rollout_vs_reference_golden(sg):
+    """The committed reference rollouts (real RLGymSim_CPP Gym) replayed on the GPU."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    dev = torch.device("cuda", 0)
+    for case, horizon in (("ts8_random", 60), ("ts8_chase", 40), ("ts1_random", 60)):
+        cfg = _lib.default_gym_config(); cfg.tick_skip = int(sg[f"gym/{case}/tick_skip"])
+        env = BatchedEnv(1, 1, cfg=cfg, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes())
+        env.upload_states([st])
+        obs0 = env.reset(False)
+        assert np.abs(obs0.cpu().numpy() - sg[f"gym/{case}/obs0"]).max() < 1e-5
+        acts = sg[f"gym/{case}/actions"]; obs = sg[f"gym/{case}/obs"]; rew = sg[f"gym/{case}/rew"]; done = sg[f"gym/{case}/done"]
+        nobs = torch.empty((2, 89), device=dev); r = torch.empty(2, device=dev); d = torch.empty(2, dtype=torch.int32, device=dev)
+        for t in range(min(horizon, len(acts))):
+            env.step(torch.from_numpy(acts[t].astype(np.int32)).to(dev), nobs, r, d)
+            env.sync()
+            assert int(d[0]) == int(done[t])
+            if done[t]:
+                break
+            assert np.abs(nobs.cpu().numpy() - obs[t]).max() < 2e-3, f"{case} step {t}"
+            assert np.abs(r.cpu().numpy() - rew[t]).max() < 2e-3, f"{case} step {t}"
+        env.close()
+
+
+def test_live_reference_rollout(ref_lib, port_lib):
+    """When the prebuilt reference .so travelled with the snapshot: step the real RLGymSim_CPP Gym on the host CPU next
+    to the GPU env from the same state and action tape."""
+    from simlib import RefGym
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = RefGym(ref_lib, 1, 8)
+    s0 = default_arena(2); s0.ball.pos[:] = (500, -800, 93.15); s0.ball.vel[:] = (300, 100, 0); s0.cars[0].boost = 80
+    obs_r = g.reset_to(s0)
+    st = ref_lib.get_state(g.arena())
+    env = BatchedEnv(1, 1, cfg=_lib.default_gym_config(), mesh=port_lib.mesh)
+    env.upload_states([st])
+    obs0 = env.reset(False)
+    assert np.abs(obs0.cpu().numpy() - obs_r).max() < 1e-5
+    nobs = torch.empty((2, 89), device=dev); r = torch.empty(2, device=dev); d = torch.empty(2, dtype=torch.int32, device=dev)
+    rng = np.random.RandomState(11)
+    for t in range(30):
+        a = rng.randint(0, 90, size=2).astype(np.int32)
+        o_r, r_r, d_r, _ = g.step(a)
+        env.step(torch.from_numpy(a).to(dev), nobs, r, d); env.sync()
+        assert int(d[0]) == d_r
+        assert np.abs(nobs.cpu().numpy() - o_r).max() < 2e-3 and np.abs(r.cpu().numpy() - r_r).max() < 2e-3
+
+
+def test_full_size_properties():
+    """BASELINE size (4096 envs 1v1): determinism, finiteness, bounds, episode accounting."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    dev = torch.device("cuda", 0)
+    outs = []
+    for rep in range(2):
+        env = BatchedEnv(4096, 1)
+        obs = env.reset(True)
+        nobs = torch.empty_like(obs); rew = torch.empty(8192, device=dev); done = torch.empty(8192, dtype=torch.int32, device=dev)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        tot_done = 0
+        for t in range(40):
+            a = torch.randint(0, 90, (8192,), generator=g, dtype=torch.int32).to(dev)
+            env.step(a, nobs, rew, done)
+            tot_done += int(done.sum().item())
+        env.sync()
+        o = nobs.cpu().numpy()
+        assert np.isfinite(o).all() and np.isfinite(rew.cpu().numpy()).all()
+        assert np.abs(o[:, 0:3]).max() < 1.3          # ball position / arena extents
+        assert set(np.unique(o[:, 17:51])) <= {0.0, 1.0}  # pads are 0/1
+        assert (done.view(4096, 2)[:, 0] == done.view(4096, 2)[:, 1]).all()  # done shared by an env's players
+        outs.append((o.copy(), rew.cpu().numpy().copy(), tot_done))
+        env.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]  # bitwise deterministic
+
+
+# ---- learner kernels -----------------------------------------------------------------------------------------------
+def _mk_core(lg, bf16=False, max_rows=4096):
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    D, A, H = int(lg["D"]), int(lg["A"]), int(lg["H"])
+    core = PPOCore(D, A, (H, H), (H, H), policy_lr=float(lg["adam_lr"]), critic_lr=float(lg["adam_lr"]), ent_coef=float(lg["ent_coef"]),
+                   clip_range=float(lg["clip"]), use_bf16=bf16, max_rows=max_rows)
+    core.set_params(lg["pol_params"], 0); core.set_params(lg["cri_params"], 1)
+    return core
+
+
+def test_policy_value_forward_and_sampling(lg):
+    dev = torch.device("cuda", 0)
+    core = _mk_core(lg)
+    obs = torch.from_numpy(lg["obs"]).to(dev)
+    p = core.probs(obs).cpu().numpy()
+    assert np.abs(p - lg["probs"]).max() < 2e-6
+    v = core.value(obs).cpu().numpy()
+    assert np.abs(v - lg["values"]).max() < 2e-5
+    n = obs.shape[0]
+    acts = torch.empty(n, dtype=torch.int32, device=dev); logp = torch.empty(n, device=dev)
+    core.act(obs, acts, logp, noise=torch.from_numpy(lg["q"]).to(dev))
+    a = acts.cpu().numpy()
+    mism = np.nonzero(a != lg["actions"])[0]
+    margins = R.top2_margin(lg["probs"], lg["q"])
+    # bit-exact action indices on the recorded noise tape; a mismatch is tolerated only inside fp32 summation-order noise
+    assert all(margins[i] < 1e-5 for i in mism), f"sampled actions differ at rows {mism} with margins {margins[mism]}"
+    ok = a == lg["actions"]
+    assert np.abs(logp.cpu().numpy()[ok] - lg["logp"][ok]).max() < 1e-5
+    core.act(obs, acts, logp, deterministic=True)
+    assert (acts.cpu().numpy() == lg["det_actions"]).all() and (logp.cpu().numpy() == 0).all()
+    # own Philox sampler: empirical frequencies follow probs
+    big = obs[:1].repeat(4096, 1).contiguous()
+    a2 = torch.empty(4096, dtype=torch.int32, device=dev); l2 = torch.empty(4096, device=dev)
+    counts = np.zeros(int(lg["A"]))
+    for _ in range(8):
+        core.act(big, a2, l2)
+        counts += np.bincount(a2.cpu().numpy(), minlength=int(lg["A"]))
+    freq = counts / counts.sum()
+    assert np.abs(freq - lg["probs"][0]).max() < 0.01
+
+
+def test_gae_kernel(lg):
+    dev = torch.device("cuda", 0)
+    core = _mk_core(lg)
+    # the golden 1-D batch as ONE trajectory (n = 1)
+    B = len(lg["gae_rews"])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    adv, tg, rt = core.gae(t(lg["gae_rews"]).view(B, 1), t(lg["gae_terminal"]).view(B, 1), t(lg["gae_truncated"]).view(B, 1), t(lg["gae_values"]).view(B + 1, 1),
+                           float(lg["gae_gamma"]), float(lg["gae_lambda"]), float(lg["gae_ret_std"]), float(lg["gae_clip"]), 0)
+    assert np.abs(adv.cpu().numpy()[:, 0] - lg["gae_adv"]).max() <= 1e-4
+    assert np.abs(rt.cpu().numpy()[:, 0] - lg["gae_returns"]).max() <= 1e-4
+    assert np.abs(tg.cpu().numpy()[:, 0] - lg["gae_targets"]).max() <= 1e-4
+    # many trajectories, time-major, vs the serial oracle on the agent-major concatenation (reference quirk Q1 included)
+    rng = np.random.RandomState(1); T, n = 32, 300
+    rews = rng.randn(T, n).astype(np.float32); dones = (rng.rand(T, n) < 0.05).astype(np.float32); vals = rng.randn(T + 1, n).astype(np.float32)
+    truncs = np.zeros((T, n), np.float32); truncs[T - 1] = 1 - dones[T - 1]
+    adv, tg, rt = core.gae(t(rews), t(dones), t(truncs), t(vals), 0.99, 0.95, 2.0, 10.0, 0)
+    cat = lambda x: x.T.reshape(-1)
+    cvals = np.concatenate([cat(vals[:T]), vals[T, n - 1:n]])
+    a_o, t_o, r_o = R.compute_gae(cat(rews), cat(dones), cat(truncs), cvals, 0.99, 0.95, 2.0, 10.0)
+    assert np.abs(cat(adv.cpu().numpy()) - a_o).max() <= 1e-4 and np.abs(cat(rt.cpu().numpy()) - r_o).max() <= 1e-4 and np.abs(cat(tg.cpu().numpy()) - t_o).max() <= 1e-4
+
+
+def test_ppo_minibatch_grads_and_adam(lg):
+    dev = torch.device("cuda", 0)
+    core = _mk_core(lg)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    obs = t(lg["obs"]); acts = t(lg["actions"].astype(np.int32)); olp = t(lg["old_logp"]); adv = t(lg["adv"]); tg = t(lg["targets"])
+    metrics = torch.zeros(8, device=dev)
+    core.zero_grads()
+    core.minibatch(obs, acts, olp, adv, tg, None, obs.shape[0], float(lg["scale"]), metrics)
+    core.sync()
+    gp, gc = core.get_grads(0), core.get_grads(1)
+    assert np.abs(gp - lg["pol_grads"]).max() < 5e-6 * max(1.0, np.abs(lg["pol_grads"]).max() * 100)
+    assert np.abs(gc - lg["cri_grads"]).max() < 5e-6 * max(1.0, np.abs(lg["cri_grads"]).max() * 100)
+    m = metrics.cpu().numpy(); n = obs.shape[0]
+    assert abs(m[0] / n - float(lg["entropy"])) < 1e-4 and abs(m[1] / n - float(lg["kl"])) < 1e-5
+    assert abs(m[2] / n - float(lg["clip_fraction"])) < 1e-6 and abs(m[4] / n - float(lg["value_loss"])) < 1e-4
+    # gathered minibatch (shuffled indices) gives the same gradients
+    perm = np.random.RandomState(0).permutation(n).astype(np.int32)
+    core.zero_grads()
+    core.minibatch(obs, acts, olp, adv, tg, t(perm), n, float(lg["scale"]), None)
+    assert np.abs(core.get_grads(0) - gp).max() < 1e-5
+    # accumulation over two half minibatches == one full minibatch (PPOLearner.cpp:127 batchSizeRatio)
+    core.zero_grads()
+    h = n // 2
+    core.minibatch(obs, acts, olp, adv, tg, t(np.arange(0, h, dtype=np.int32)), h, float(lg["scale"]) * h / n, None)
+    core.minibatch(obs, acts, olp, adv, tg, t(np.arange(h, n, dtype=np.int32)), n - h, float(lg["scale"]) * (n - h) / n, None)
+    assert np.abs(core.get_grads(0) - gp).max() < 1e-5 and np.abs(core.get_grads(1) - gc).max() < 1e-5
+    # clip + Adam: three steps with the golden fake gradients
+    gt = core.grad_tensor()
+    npol = core.num_params(0)
+    for s, (gk, pk) in enumerate([("adam_g0", "adam_p1"), ("adam_g1", "adam_p2"), ("adam_g2", "adam_p3")]):
+        gt.zero_(); gt[:npol] = t(lg[gk])
+        core.clip_adam_step(0.5, 1.0)
+        core.sync()
+        assert np.abs(core.get_params(0) - lg[pk]).max() < 1e-6, f"adam step {s}"
+
+
+def test_bf16_path_close_to_fp32(lg):
+    dev = torch.device("cuda", 0)
+    c32, c16 = _mk_core(lg), _mk_core(lg, bf16=True)
+    obs = torch.from_numpy(lg["obs"]).to(dev)
+    p32, p16 = c32.probs(obs).cpu().numpy(), c16.probs(obs).cpu().numpy()
+    assert np.abs(p32 - p16).max() < 5e-3      # bf16 operands (8-bit mantissa), fp32 accumulation
+    assert np.abs(c32.value(obs).cpu().numpy() - c16.value(obs).cpu().numpy()).max() < 5e-2
+
+
+def test_gemm_shapes_against_numpy():
+    """The MFMA GEMM at the flagship layer shapes incl. ragged edges (K=89, N=90, N=1, rows not a tile multiple)."""
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    dev = torch.device("cuda", 0)
+    core = PPOCore(89, 90, (256, 256, 256), (256, 256, 256), max_rows=1100)
+    rng = np.random.RandomState(0)
+    x = rng.randn(1037, 89).astype(np.float32)
+    pshapes, cshapes = core.layer_shapes(0), core.layer_shapes(1)
+    out, _ = R.mlp_forward(core.get_params(0), pshapes, x)
+    p = core.probs(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.abs(p - R.policy_probs(out)).max() < 1e-5
+    v, _ = R.mlp_forward(core.get_params(1), cshapes, x)
+    assert np.abs(core.value(torch.from_numpy(x).to(dev)).cpu().numpy() - v[:, 0]).max() < 1e-4
+    assert core.num_params(0) == 177754 and core.num_params(1) == 154881   # verified parameter counts
