@@ -301,6 +301,8 @@ struct Rng {
         return buf[4 - (have--)];
     }
     RLG_HD float uni(float lo, float hi) { return lo + u32_to_unit(next()) * (hi - lo); }
+    // three draws in x,y,z order (function-argument evaluation order is unspecified in C++: never draw inside an argument list)
+    RLG_HD V3 uni3(float lx, float hx, float ly, float hy, float lz, float hz) { float x = uni(lx, hx); float y = uni(ly, hy); float z = uni(lz, hz); return v3(x, y, z); }
 };
 RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat = setEulerYPR(yaw,-pitch,-roll) (MathTypes.cpp:84-89)
     float ez = yaw, ey = -pitch, ex = -roll;
@@ -345,25 +347,25 @@ RLG_HD void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint3
     } else {
         // RandomState::ResetState (StateSetters/RandomState.cpp:8-61)
         const float X_MAX = 3500, Y_MAX = 4000, Z_MAX = 1820, CAR_Z_MIN = 150;
-        V3 bp = v3(rng.uni(-X_MAX, X_MAX), rng.uni(-Y_MAX, Y_MAX), rng.uni(92.75f, Z_MAX));
+        V3 bp = rng.uni3(-X_MAX, X_MAX, -Y_MAX, Y_MAX, 92.75f, Z_MAX);
         V3 bv = v3(0, 0, 0), bw = v3(0, 0, 0);
         if (cfg.rand_ball_speed) {
-            V3 d = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+            V3 d = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
             bv = d * rng.uni(0, 4000);
-            bw = v3(rng.uni(-4, 4), rng.uni(-4, 4), rng.uni(-4, 4));
+            bw = rng.uni3(-4, 4, -4, 4, -4, 4);
         }
         A.ball.b.pos = bp * UU2BT; A.ball.b.vel = bv * UU2BT; A.ball.b.angvel = bw;
         for (int k = 0; k < NC; k++) {
             Car& c = A.cars[k]; car_set_fresh(c);
-            V3 pos = v3(rng.uni(-X_MAX, X_MAX), rng.uni(-Y_MAX, Y_MAX), rng.uni(CAR_Z_MIN, Z_MAX));
+            V3 pos = rng.uni3(-X_MAX, X_MAX, -Y_MAX, Y_MAX, CAR_Z_MIN, Z_MAX);
             V3 vel = v3(0, 0, 0), av = v3(0, 0, 0);
             if (cfg.rand_car_speed) {
-                V3 d = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+                V3 d = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
                 vel = d * rng.uni(0, K::CAR_MAX_SPEED);
-                V3 d2 = rs_normalized(v3(rng.uni(-1, 1), rng.uni(-1, 1), rng.uni(-1, 1)));
+                V3 d2 = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
                 av = d2 * 5.5f;
             }
-            float yaw = rng.uni(-PI_F, PI_F), pitch = rng.uni(-PI_F / 2, PI_F / 2), roll = rng.uni(-PI_F, PI_F);
+            float yaw = rng.uni(-PI_F, PI_F); float pitch = rng.uni(-PI_F / 2, PI_F / 2); float roll = rng.uni(-PI_F, PI_F);
             bool on_ground = cfg.cars_on_ground ? true : (rng.uni(0, 1) > 0.5f);
             if (on_ground) { pos.z = 17; pitch = roll = 0; vel.z = 0; av = v3(0, 0, 0); }
             c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, pitch, roll); c.b.vel = vel * UU2BT; c.b.angvel = av;
