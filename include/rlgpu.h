@@ -93,6 +93,9 @@ int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
 int rlgpu_env_sync(rlgpu_env* e);
 /* last rlgpu_env_step kernel duration in ms, measured with hipEvents on the context stream (bench.py roofline) */
 int rlgpu_env_last_step_ms(rlgpu_env* e, float* ms);
+/* sum of the rlgpu_env_step kernel durations (hipEvents on the context stream) and the launch count since the last
+ * reset; synchronises the stream. */
+int rlgpu_env_timing_total(rlgpu_env* e, float* total_ms, int* launches, int reset);
 
 /* ---- learner : replaces PPOLearner + DiscretePolicy + ValueEstimator + ExperienceBuffer sampling + ComputeGAE
  *      (PRIV/PPO/PPOLearner.cpp:67-349, DiscretePolicy.cpp:7-75, ValueEstimator.cpp:6-27, PRIV/Util/TorchFuncs.cpp:5-52) */
@@ -158,6 +161,16 @@ int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
 int rlgpu_learner_sync(rlgpu_learner* l);
 /* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops);
+/* the same accumulated over every rlgpu_ppo_minibatch call since the last reset; synchronises the stream */
+int rlgpu_learner_timing_total(rlgpu_learner* l, float* total_ms, double* total_flops, int* calls, int reset);
+
+/* ---- minibatch order : ExperienceBuffer::GetAllBatchesShuffled (PRIV/PPO/ExperienceBuffer.cpp:106-121): iota(n) then
+ *      std::shuffle with a PERSISTENT std::default_random_engine(seed) (ExperienceBuffer.h:33, .cpp:7-9).  Host-side
+ *      (the permutation is built on the CPU in the reference too); this library links the same libstdc++ algorithm. */
+typedef struct rlgpu_shuffler rlgpu_shuffler;
+int rlgpu_shuffler_create(rlgpu_shuffler** out, uint32_t seed);
+void rlgpu_shuffler_destroy(rlgpu_shuffler* s);
+int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm_out);
 
 #ifdef __cplusplus
 }

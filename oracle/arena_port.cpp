@@ -24,6 +24,7 @@ HostMesh g_mesh;
 MeshView view() {
     MeshView v; v.nodes = g_mesh.nodes.data(); v.tris = g_mesh.tris.data(); v.nodes_fast = nullptr;
     v.n_nodes = (int)g_mesh.nodes.size(); v.n_tris = (int)g_mesh.tris.size(); v.n_fast = 0;
+    v.grid = g_mesh.grid.empty() ? nullptr : g_mesh.grid.data();
     return v;
 }
 template <int NC>
@@ -31,7 +32,8 @@ void step_t(RlgpuArenaState* s, int ticks, uint32_t seed, uint32_t env) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, seed, env, ev); }
+    TickWork<NC> W;
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, seed, env, ev, W); }
     arena_to_host(A, G, *s);
 }
 }  // namespace
@@ -79,7 +81,8 @@ static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, c
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(), rew, done);
+    TickWork<NC> W;
+    gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(), rew, done, W);
     arena_to_host(A, G, *s);
 }
 

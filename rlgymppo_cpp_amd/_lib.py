@@ -8,7 +8,7 @@ import os
 from .state import ArenaState
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librlgpu.so")
+LIB_PATH = os.environ.get("RLGPU_LIB", os.path.join(_HERE, "librlgpu.so"))  # RLGPU_LIB: tuning experiments only
 
 NUM_EVENT_VALS = 11
 
@@ -95,6 +95,11 @@ SIGNATURES = {
     "rlgpu_learner_set_lr": (_i, [_vp, _f, _f]),
     "rlgpu_learner_sync": (_i, [_vp]),
     "rlgpu_learner_last_gemm": (_i, [_vp, C.POINTER(_f), C.POINTER(C.c_double)]),
+    "rlgpu_env_timing_total": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), _i]),
+    "rlgpu_learner_timing_total": (_i, [_vp, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(_i), _i]),
+    "rlgpu_shuffler_create": (_i, [C.POINTER(_vp), C.c_uint32]),
+    "rlgpu_shuffler_destroy": (None, [_vp]),
+    "rlgpu_shuffler_next": (_i, [_vp, C.c_int64, _vp]),
 }
 
 _lib = None

@@ -346,8 +346,21 @@ RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
 // ---- Car::_PreTickUpdate (Car.cpp:58-131) incl. btVehicleRL first/second halves ------------------------------
 // `world` supplies the ray cast against planes / mesh / ball / other cars (arena_world.h).
 template <int NC>
-RLG_HD void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t respawn_rnd) {
-    Car& c = A.cars[ci];
+RLG_HD void car_pre_tick_body(Arena<NC>& A, Car& c, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t);
+
+template <int NC>
+RLG_HD_NOINLINE void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t) {
+    // Work on a private copy: on the device A lives in LDS behind a generic pointer, which defeats alias analysis
+    // (every field would be re-loaded after every store); a local Car is promoted to registers.  The ray cast reads
+    // only the OTHER cars and the ball from A, so the stale A.cars[ci] is never observed.
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
+    Car c = A.cars[ci];
+    car_pre_tick_body(A, c, ci, mesh, respawn_rnd, t);
+    A.cars[ci] = c;
+}
+
+template <int NC>
+RLG_HD void car_pre_tick_body(Arena<NC>& A, Car& c, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t) {
     const float dt = TICK_DT;
     // ClampFix
     c.ctl.throttle = clampf(c.ctl.throttle, -1.f, 1.f); c.ctl.steer = clampf(c.ctl.steer, -1.f, 1.f);
@@ -362,20 +375,24 @@ RLG_HD void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t re
     }
     if (c.flags & CF_IS_DEMOED) return;
 
-    CarTickCtx t;
     V3 up = col2(c.b.rot);
     // updateVehicleFirst: wheel transforms with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235)
+    RLG_NOUNROLL
     for (int i = 0; i < 4; i++) {
         V3 wheel_dir = c.b.rot * v3(0, 0, -1), axle = c.b.rot * v3(0, -1, 0);
         V3 wup = -wheel_dir;
         V3 fwd = normalized(cross(wup, axle));
-        float ang = (i < 2) ? c.steer_angle : 0.f;
-        M3 steer = quat_to_m3(quat_axis_angle(wup, ang));
         M3 basis2 = m3_cols(fwd, -axle, wup);
-        t.wheel_basis[i] = steer * basis2;
+        if (i < 2 && c.steer_angle != 0.f) {
+            M3 steer = quat_to_m3(quat_axis_angle(wup, c.steer_angle));
+            t.wheel_basis[i] = steer * basis2;
+        } else {
+            t.wheel_basis[i] = basis2;  // a zero steering angle gives the exact identity quaternion (0,0,0,1)
+        }
     }
     // ray casts (btVehicleRL.cpp:118-212)
     t.n_contact = 0; t.wheels_world = false;
+    RLG_NOUNROLL
     for (int i = 0; i < 4; i++) {
         WheelTmp& w = t.w[i];
         float rest = wheel_rest(i), radius = wheel_radius(i), travel = wheel_travel();
@@ -428,6 +445,7 @@ RLG_HD void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t re
     // calcFrictionImpulses with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
     {
         const float friction_scale = K::CAR_MASS / 3;
+        RLG_NOUNROLL
         for (int i = 0; i < 4; i++) {
             WheelTmp& w = t.w[i];
             if (w.ground < 0) { w.impulse = v3(0, 0, 0); continue; }

@@ -74,7 +74,7 @@ struct Snapshot {
 };
 
 template <int NC>
-RLG_HD void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S) {
+RLG_HD_NOINLINE void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S) {
     int64_t tick_skip = A.tick_count - G.last_tick_count; if (tick_skip < 0) tick_skip = 0;
     S.ball_pos = A.ball.b.pos * BT2UU; S.ball_vel = A.ball.b.vel * BT2UU; S.ball_angvel = A.ball.b.angvel;
     for (int k = 0; k < NC; k++) {
@@ -137,7 +137,7 @@ RLG_HD bool shooter_passer(const Arena<NC>& A, int team, int& shooter, bool find
     return shooter >= 0;
 }
 template <int NC>
-RLG_HD void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
+RLG_HD_NOINLINE void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
     const float tickrate = 1.f / TICK_DT;
     bool scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);  // Arena.cpp:949-957
     int64_t buc = A.ball_update_counter;
@@ -207,7 +207,7 @@ RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, c
     return o;
 }
 template <int NC>
-RLG_HD void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o) {
+RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o) {
     bool inv = (k % 2) == 1;
     V3 bp = inv3(S.ball_pos, inv), bv = inv3(S.ball_vel, inv), bw = inv3(S.ball_angvel, inv);
     *o++ = bp.x * cfg.pos_coef[0]; *o++ = bp.y * cfg.pos_coef[1]; *o++ = bp.z * cfg.pos_coef[2];
@@ -235,7 +235,7 @@ RLG_HD void event_values(const Snapshot<NC>& S, const GymEnv<NC>& G, int k, floa
     v[8] = (float)G.counters[k][6]; v[9] = S.demoed[k] ? 1.f : 0.f; v[10] = S.boost_frac[k];
 }
 template <int NC>
-RLG_HD void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
+RLG_HD_NOINLINE void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
     for (int k = 0; k < NC; k++) rew[k] = 0.f;
     for (int t = 0; t < cfg.n_terms; t++) {
         const RewardTerm& T = cfg.terms[t];
@@ -324,7 +324,7 @@ RLG_HD void car_set_fresh(Car& c) {  // Car::SetState(CarState()) semantics: car
     c = n;
 }
 template <int NC>
-RLG_HD void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id) {
+RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id) {
     Rng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
     G.reset_count++;
     A.ball.vel_impulse_cache = v3(0, 0, 0); A.ball_update_counter = 0;
@@ -392,7 +392,7 @@ RLG_HD void gym_episode_reset(const Arena<NC>& A, GymEnv<NC>& G, const GymConfig
 //   reward[NC], done, and next_obs[NC][D] = the observation the policy sees next (post-reset when done).
 template <int NC>
 RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const MeshView& mesh, const float* action_table,
-                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out) {
+                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC>& W) {
     // Match::ParseActions: demoed players (per the PREVIOUS snapshot) get a zero action (Match.cpp:44-52)
     uint32_t snap_demoed = (G.tracker_flags >> 8) & 0xffu;
     float pa[NC][8];
@@ -407,7 +407,7 @@ RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, cons
         c.jump = pa[k][5] == 1.f; c.boost = pa[k][6] == 1.f; c.handbrake = pa[k][7] == 1.f;
     }
     TickEvents ev; ev.bump_mask = 0;
-    arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev);  // arena->Step(tickSkip - actionDelay) = 1 tick
+    arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev, W);  // arena->Step(tickSkip - actionDelay) = 1 tick
     // bump callbacks that fired during this first tick land in the snapshot (later ones are lost: Gym.cpp:84-96)
     for (int k = 0; k < NC; k++) {
         if (ev.bump_mask & (1u << k)) G.counters[k][5]++;
@@ -424,7 +424,7 @@ RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, cons
     for (int k = 0; k < NC; k++) reward[k] = rew[k];
     *done_out = done ? 1 : 0;
     TickEvents ev2;
-    for (int t = 1; t < cfg.tick_skip; t++) { ev2.bump_mask = 0; arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev2); }
+    for (int t = 1; t < cfg.tick_skip; t++) { ev2.bump_mask = 0; arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev2, W); }
     G.episode_steps++;
     if (done) {
         reset_state(A, G, cfg, env_id);

@@ -102,6 +102,34 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             }
         }
     }
+    // occupancy grid: a cell is marked when a triangle's AABB and its supporting plane both cut the cell box grown by a
+    // small margin (conservative superset of exact triangle/box overlap; tight for the axis-aligned and 45-degree walls)
+    m.grid.assign(GRID_WORDS, 0u);
+    for (int i = 0; i < n_tris; i++) {
+        const float* p = &m.tris[i].v0x;
+        float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx);
+        P3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
+        P3 n = crs(sub(v1, v0), sub(v2, v0));
+        float nl = std::sqrt(dt3(n, n));
+        const float gmin[3] = {GRID_MIN_X, GRID_MIN_Y, GRID_MIN_Z}; const int gdim[3] = {GRID_X, GRID_Y, GRID_Z};
+        int c0[3], c1[3];
+        const float margin = 0.02f;
+        for (int a = 0; a < 3; a++) {
+            c0[a] = std::max(0, (int)std::floor((mn[a] - margin - gmin[a]) / GRID_CELL));
+            c1[a] = std::min(gdim[a] - 1, (int)std::floor((mx[a] + margin - gmin[a]) / GRID_CELL));
+        }
+        for (int z = c0[2]; z <= c1[2]; z++) for (int y = c0[1]; y <= c1[1]; y++) for (int x = c0[0]; x <= c1[0]; x++) {
+            bool cut = true;
+            if (nl > 1e-12f) {
+                P3 nn{n.x / nl, n.y / nl, n.z / nl};
+                float cx = gmin[0] + (x + 0.5f) * GRID_CELL, cy = gmin[1] + (y + 0.5f) * GRID_CELL, cz = gmin[2] + (z + 0.5f) * GRID_CELL;
+                float dist = nn.x * (cx - v0.x) + nn.y * (cy - v0.y) + nn.z * (cz - v0.z);
+                float rad = (GRID_CELL * 0.5f + margin) * (std::fabs(nn.x) + std::fabs(nn.y) + std::fabs(nn.z));
+                cut = std::fabs(dist) <= rad;
+            }
+            if (cut) { int bit = (z * GRID_Y + y) * GRID_X + x; m.grid[bit >> 5] |= (1u << (bit & 31)); }
+        }
+    }
     if (n_tris == 0) return m;
     std::vector<BuildNode> bn;
     bn.reserve(2 * n_tris);

@@ -15,6 +15,7 @@ namespace rlg {
 struct HostMesh {
     std::vector<MeshTri> tris;   // BT units, in BVH leaf order
     std::vector<BvhNode> nodes;  // breadth-first
+    std::vector<uint32_t> grid;  // GRID_WORDS occupancy bits (arena_types.h)
 };
 
 // verts in uu, tris index triplets

@@ -79,7 +79,8 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 
 // ---- narrowphase over all pairs -----------------------------------------------------------------------
 template <int NC, int MAXC>
-RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch) {
+RLG_HD_NOINLINE void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
     L.n = 0; ball_car_touch = false;
     const float r = K::BALL_RADIUS * UU2BT;
     // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
@@ -100,9 +101,10 @@ RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L
         }
     }
     // ball vs mesh
-    if (mesh.n_nodes > 0 && !ball_asleep) {
-        float ext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
-        V3 lo = bp - v3(ext, ext, ext), hi = bp + v3(ext, ext, ext);
+    float bext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
+    V3 blo = bp - v3(bext, bext, bext), bhi = bp + v3(bext, bext, bext);
+    if (!ball_asleep && mesh_maybe_near(mesh, blo, bhi)) {
+        V3 lo = blo, hi = bhi;
         int stack[32]; int sp = 0; stack[sp++] = 0;
         while (sp > 0) {
             BvhNode nd = mesh_node(mesh, stack[--sp]);
@@ -110,6 +112,7 @@ RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L
             if (nd.count > 0) {
                 for (int k = 0; k < nd.count; k++) {
                     V3 pt, n; float depth;
+                    if (!tri_aabb_overlap(mesh.tris[nd.left_or_first + k], lo, hi)) continue;  // TestTriangleAgainstAabb2 (btConvexConcaveCollisionAlgorithm.cpp:75)
                     if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[nd.left_or_first + k], pt, n, depth)) {
                         Contact c; c.a = 0; c.b = -1; c.n = n; c.dist = depth;
                         c.ra = (pt + n * depth) - bp; c.rb = pt;
@@ -121,6 +124,7 @@ RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L
         }
     }
     // cars
+    RLG_NOUNROLL
     for (int ci = 0; ci < NC; ci++) {
         Car& car = A.cars[ci];
         if (car.flags & CF_IS_DEMOED) continue;  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
@@ -142,18 +146,20 @@ RLG_HD void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L
             }
         }
         // mesh
-        if (mesh.n_nodes > 0) {
+        {
             M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
                               v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
                               v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
             V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
             V3 lo = bc - ext, hi = bc + ext;
-            int stack[32]; int sp = 0; stack[sp++] = 0;
+            int stack[32]; int sp = 0;
+            if (mesh_maybe_near(mesh, lo, hi)) stack[sp++] = 0;
             while (sp > 0) {
                 BvhNode nd = mesh_node(mesh, stack[--sp]);
                 if (!aabb_overlap(nd, lo, hi)) continue;
                 if (nd.count > 0) {
-                    for (int k = 0; k < nd.count; k++) box_triangle(bc, car.b.rot, h, mesh.tris[nd.left_or_first + k], CBT_CAR, cs, nc);
+                    for (int k = 0; k < nd.count; k++)
+                        if (tri_aabb_overlap(mesh.tris[nd.left_or_first + k], lo, hi)) box_triangle(bc, car.b.rot, h, mesh.tris[nd.left_or_first + k], CBT_CAR, cs, nc);
                 } else if (sp < 30) { stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1; }
             }
         }
@@ -209,19 +215,19 @@ struct SolverBody {
     float inv_m;
     bool active;
 };
-struct Row {
-    int a, b;
-    V3 n1, r1xn, n2, r2xn, ang_a, ang_b;
-    float jac, rhs, rhs_pen, applied, applied_push, lo, hi, friction;
-    bool skip;     // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
-    int fric_of;   // for friction rows: index of the normal row; -1 for normal rows
+struct Row {   // 23 words: kept small because the device kernel holds the rows of 16 envs in LDS
+    int16_t a, b;        // body indices (b = -1: static world)
+    int16_t fric_of;     // friction rows: index of their normal row; -1 for normal rows
+    int16_t skip;        // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
+    V3 n1, r1xn, r2xn, ang_a, ang_b;   // contactNormal2 is -n1 whenever b >= 0
+    float jac, rhs, rhs_pen, applied, applied_push, friction;
 };
 
 template <int NB>
 RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, float dist, float fric, float rest, bool has_b) {
     const float dt = TICK_DT;
     SolverBody& A = B[c.a];
-    r.a = c.a; r.b = has_b ? c.b : -1;
+    r.a = (int16_t)c.a; r.b = (int16_t)(has_b ? c.b : -1);
     V3 t0 = cross(ra, n);
     r.ang_a = A.inv_i * t0;
     V3 t1 = cross(rb, n);
@@ -230,7 +236,7 @@ RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n
     float d1 = has_b ? (B[c.b].inv_m + dot(n, cross(-r.ang_b, rb))) : 0.f;
     r.jac = 1.f / (d0 + d1);
     r.n1 = n; r.r1xn = t0;
-    if (has_b) { r.n2 = -n; r.r2xn = -t1; } else { r.n2 = v3(0, 0, 0); r.r2xn = v3(0, 0, 0); }
+    r.r2xn = has_b ? -t1 : v3(0, 0, 0);
     V3 vel1 = A.v + cross(A.w, ra);
     V3 vel2 = has_b ? (B[c.b].v + cross(B[c.b].w, rb)) : v3(0, 0, 0);
     float rel_vel = dot(n, vel1 - vel2);
@@ -241,15 +247,14 @@ RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n
     r.applied = 0.f; r.applied_push = 0.f;
     V3 efa = A.ext_f, eta = A.ext_t;
     float v1 = dot(r.n1, A.v + efa) + dot(r.r1xn, A.w + eta);
-    float v2 = has_b ? (dot(r.n2, B[c.b].v + B[c.b].ext_f) + dot(r.r2xn, B[c.b].w + B[c.b].ext_t)) : 0.f;
+    float v2 = has_b ? (dot(-r.n1, B[c.b].v + B[c.b].ext_f) + dot(r.r2xn, B[c.b].w + B[c.b].ext_t)) : 0.f;
     float rv = v1 + v2;
     float vel_err = restitution - rv;
     float pos_err = 0.f;
     if (dist > 0.f) pos_err = 0.f; else pos_err = -dist * K::ERP2 * (1.f / dt);
     r.rhs = vel_err * r.jac;
     r.rhs_pen = pos_err * r.jac;
-    r.lo = 0.f; r.hi = 1e10f;
-    r.skip = false; r.fric_of = -1;
+    r.skip = 0; r.fric_of = -1;
 }
 
 template <int NB>
@@ -267,33 +272,33 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
     r.a = nr.a; r.b = nr.b;
     r.friction = nr.friction; r.applied = 0.f; r.applied_push = 0.f;
     r.n1 = lat; V3 f1 = cross(ra, lat); r.r1xn = f1; r.ang_a = A.inv_i * f1;
-    if (has_b) { r.n2 = -lat; V3 f2 = cross(rb, r.n2); r.r2xn = f2; r.ang_b = B[nr.b].inv_i * f2; }
-    else { r.n2 = v3(0, 0, 0); r.r2xn = v3(0, 0, 0); r.ang_b = v3(0, 0, 0); }
+    if (has_b) { V3 f2 = cross(rb, -lat); r.r2xn = f2; r.ang_b = B[nr.b].inv_i * f2; }
+    else { r.r2xn = v3(0, 0, 0); r.ang_b = v3(0, 0, 0); }
     float d0 = A.inv_m + dot(lat, cross(r.ang_a, ra));
     float d1 = has_b ? (B[nr.b].inv_m + dot(lat, cross(-r.ang_b, rb))) : 0.f;
     r.jac = 1.f / (d0 + d1);
     float v1 = dot(r.n1, A.v + A.ext_f) + dot(r.r1xn, A.w);
-    float v2 = has_b ? (dot(r.n2, B[nr.b].v + B[nr.b].ext_f) + dot(r.r2xn, B[nr.b].w)) : 0.f;
+    float v2 = has_b ? (dot(-r.n1, B[nr.b].v + B[nr.b].ext_f) + dot(r.r2xn, B[nr.b].w)) : 0.f;
     float rv = v1 + v2;
     r.rhs = (0.f - rv) * r.jac; r.rhs_pen = 0.f;
-    r.lo = -r.friction; r.hi = r.friction;
-    r.skip = false; r.fric_of = normal_idx;
+    r.skip = 0; r.fric_of = (int16_t)normal_idx;
 }
 
+// gResolveSingleConstraintRow{LowerLimit,Generic}_scalar_reference (btSequentialImpulseConstraintSolver.cpp:46-100), cfm = 0
 template <int NB>
-RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], bool lower_only) {
+RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
     SolverBody& A = B[c.a];
-    float delta = c.rhs;  // cfm = 0
+    float delta = c.rhs;
     float dv1 = dot(c.n1, A.dv) + dot(c.r1xn, A.dw);
-    float dv2 = (c.b >= 0) ? (dot(c.n2, B[c.b].dv) + dot(c.r2xn, B[c.b].dw)) : 0.f;
+    float dv2 = (c.b >= 0) ? (dot(-c.n1, B[c.b].dv) + dot(c.r2xn, B[c.b].dw)) : 0.f;
     delta -= dv1 * c.jac;
     delta -= dv2 * c.jac;
     float sum = c.applied + delta;
-    if (sum < c.lo) { delta = c.lo - c.applied; c.applied = c.lo; }
-    else if (!lower_only && sum > c.hi) { delta = c.hi - c.applied; c.applied = c.hi; }
+    if (sum < lo) { delta = lo - c.applied; c.applied = lo; }
+    else if (!lower_only && sum > hi) { delta = hi - c.applied; c.applied = hi; }
     else c.applied = sum;
     A.dv += (c.n1 * A.inv_m) * delta; A.dw += c.ang_a * delta;
-    if (c.b >= 0) { B[c.b].dv += (c.n2 * B[c.b].inv_m) * delta; B[c.b].dw += c.ang_b * delta; }
+    if (c.b >= 0) { B[c.b].dv += ((-c.n1) * B[c.b].inv_m) * delta; B[c.b].dw += c.ang_b * delta; }
 }
 template <int NB>
 RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
@@ -301,23 +306,40 @@ RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
     SolverBody& A = B[c.a];
     float delta = c.rhs_pen;
     float dv1 = dot(c.n1, A.push) + dot(c.r1xn, A.turn);
-    float dv2 = (c.b >= 0) ? (dot(c.n2, B[c.b].push) + dot(c.r2xn, B[c.b].turn)) : 0.f;
+    float dv2 = (c.b >= 0) ? (dot(-c.n1, B[c.b].push) + dot(c.r2xn, B[c.b].turn)) : 0.f;
     delta -= dv1 * c.jac;
     delta -= dv2 * c.jac;
     float sum = c.applied_push + delta;
-    if (sum < c.lo) { delta = c.lo - c.applied_push; c.applied_push = c.lo; }
+    if (sum < 0.f) { delta = 0.f - c.applied_push; c.applied_push = 0.f; }
     else c.applied_push = sum;
     A.push += (c.n1 * A.inv_m) * delta; A.turn += c.ang_a * delta;
-    if (c.b >= 0) { B[c.b].push += (c.n2 * B[c.b].inv_m) * delta; B[c.b].turn += c.ang_b * delta; }
+    if (c.b >= 0) { B[c.b].push += ((-c.n1) * B[c.b].inv_m) * delta; B[c.b].turn += c.ang_b * delta; }
     return delta;
 }
 
+// Per-env scratch of one tick.  It is a parameter (not locals) so the device kernel can place it in LDS next to the
+// env's state: as stack locals these arrays are dynamically indexed and would live in scratch memory.
+template <int NC>
+struct TickWork {
+    static constexpr int NB = NC + 1;
+    static constexpr int MAXC = 8 + 6 * NC;
+    static constexpr int MAXR = 2 * (MAXC + 1);
+    ContactList<MAXC> L;
+    SolverBody B[NB];
+    Row R[MAXR];
+    CarTickCtx ctx;
+};
+
 // full tick of the dynamics world for one arena
 template <int NC>
-RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
+RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev, TickWork<NC>& W) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     constexpr int NB = NC + 1;
-    constexpr int MAXC = 8 + 6 * NC;
+    constexpr int MAXC = TickWork<NC>::MAXC;
+    ContactList<MAXC>& L = W.L;
+    SolverBody (&B)[NB] = W.B;
+    Row (&R)[TickWork<NC>::MAXR] = W.R;
     // ball sleep flag (Arena.cpp:721-727)
     bool ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
@@ -327,12 +349,11 @@ RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
     A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
 
-    ContactList<MAXC> L; bool touch;
+    bool touch;
     collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch);
     bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 
     // ---- solver setup
-    SolverBody B[NB];
     {
         SolverBody& s = B[0];
         s.v = A.ball.b.vel; s.w = A.ball.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
@@ -347,8 +368,7 @@ RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
         s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
         s.active = !c.frozen && !(c.flags & CF_IS_DEMOED);
     }
-    constexpr int MAXR = 2 * (MAXC + 1);
-    Row R[MAXR]; int nr = 0;
+    int nr = 0;
     int n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f, sp_fric = 0.f, sp_rest = 0.f;
     int first_fric;
     // normal rows
@@ -358,7 +378,7 @@ RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
         bool has_b = c.b >= 0;
         row_setup_normal(R[nr], c, B, c.n, c.ra, c.rb, c.dist, c.friction, c.restitution, has_b);
         if (c.special) {
-            R[nr].skip = true;
+            R[nr].skip = 1;
             n_special++; sp_fric = c.friction; sp_rest = c.restitution; sp_normal += c.n; sp_dist += len(c.ra);
         }
         nr++;
@@ -398,12 +418,11 @@ RLG_HD void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev) {
     }
     // velocity iterations
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
-        for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, true);
+        for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, 0.f, 1e10f, true);
         for (int k = first_fric; k < nr; k++) {
             float total = R[R[k].fric_of].applied;
             if (total > 0.f) {
-                R[k].lo = -(R[k].friction * total); R[k].hi = R[k].friction * total;
-                row_resolve(R[k], B, false);
+                row_resolve(R[k], B, -(R[k].friction * total), R[k].friction * total, false);
             }
         }
     }
@@ -443,7 +462,7 @@ RLG_HD V3 pad_pos(int i) {
 }
 
 template <int NC>
-RLG_HD void pads_check_car(Arena<NC>& A, int ci) {
+RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
     Car& car = A.cars[ci];
     if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return;
     V3 cp = car.b.pos * BT2UU;
@@ -456,11 +475,15 @@ RLG_HD void pads_check_car(Arena<NC>& A, int ci) {
                 h.x * fabsf(car.b.rot.r1.x) + h.y * fabsf(car.b.rot.r1.y) + h.z * fabsf(car.b.rot.r1.z),
                 h.x * fabsf(car.b.rot.r2.x) + h.y * fabsf(car.b.rot.r2.y) + h.z * fabsf(car.b.rot.r2.z));
     V3 cmin = bc - ext, cmax = bc + ext;
-    for (int p = 0; p < 34; p++) {
+    // BoostPadGrid::pads[8][10]: one pad per cell (BoostPadGrid.cpp:27-41); cell = (int)(pos / 1024 + half)
+    const int8_t CELL_PAD[80] = {-1, -1, 12, -1, -1, 0, -1, 26, -1, -1, -1, 4, -1, -1, -1, -1, -1, -1, -1, 2, 7, -1, 14, 16, -1, -1, 21, 24, -1, 31,
+        -1, 9, -1, -1, -1, 19, -1, -1, 29, -1, 6, 10, 11, -1, 17, -1, 22, 28, 30, 33, 8, -1, 15, -1, -1, 20, -1, 25, -1, 32,
+        -1, -1, -1, 18, -1, -1, 23, -1, -1, -1, -1, 5, 13, -1, -1, 1, -1, 27, -1, 3};
+    int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
+    for (int cx = lox; cx <= hix; cx++) for (int cy = loy; cy <= hiy; cy++) {
+        int p = CELL_PAD[cx * 10 + cy];
+        if (p < 0) continue;
         V3 pp = pad_pos(p);
-        int px = (int)(pp.x / 1024 + 4), py = (int)(pp.y / 1024 + 5);
-        int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
-        if (px < lox || px > hix || py < loy || py > hiy) continue;
         bool big = p < 6;
         V3 pbt = pp * UU2BT;
         bool colliding = false;
@@ -479,12 +502,14 @@ RLG_HD void pads_check_car(Arena<NC>& A, int ci) {
 
 // ---- Arena::Step, one tick (Arena.cpp:716-812) ---------------------------------------------------------
 template <int NC>
-RLG_HD void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev) {
+RLG_HD_NOINLINE void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
+    RLG_NOUNROLL
     for (int i = 0; i < NC; i++) {
         uint32_t rnd[4] = {0, 0, 0, 0};
         if (A.cars[i].flags & CF_IS_DEMOED) philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)i, rnd);
-        car_pre_tick(A, i, mesh, rnd[0]);
+        car_pre_tick(A, i, mesh, rnd[0], W.ctx);
     }
     for (int p = 0; p < 34; p++) {
         Pad& pd = A.pads[p];
@@ -492,9 +517,16 @@ RLG_HD void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32
         pd.is_active = (pd.cooldown == 0.f);
         pd.cur_locked = 0;
     }
-    world_step(A, mesh, ev);
+    world_step(A, mesh, ev, W);
+    RLG_NOUNROLL
     for (int i = 0; i < NC; i++) {
-        car_post_tick(A.cars[i]);
+        // touch only the fields the post tick needs through locals (see car_pre_tick about generic pointers)
+        Car& cr = A.cars[i];
+        Car c; c.flags = cr.flags; c.b.vel = cr.b.vel; c.b.angvel = cr.b.angvel; c.supersonic_time = cr.supersonic_time;
+        c.car_contact_cooldown = cr.car_contact_cooldown; c.ctl = cr.ctl; c.last = cr.last; c.vel_impulse_cache = cr.vel_impulse_cache;
+        car_post_tick(c);
+        cr.flags = c.flags; cr.b.vel = c.b.vel; cr.b.angvel = c.b.angvel; cr.supersonic_time = c.supersonic_time;
+        cr.car_contact_cooldown = c.car_contact_cooldown; cr.last = c.last; cr.vel_impulse_cache = c.vel_impulse_cache;
         pads_check_car(A, i);
     }
     for (int p = 0; p < 34; p++) {

@@ -204,10 +204,18 @@ struct MeshTri {  // 48 B, BT units
     uint32_t edge_flags;  // bit e (0..2): edge e (v_e -> v_{e+1}) is an internal flat/concave edge: snap edge normals to the face
     uint32_t _pad0, _pad1;
 };
+// coarse occupancy grid over the arena volume: bit set <=> some mesh triangle overlaps the 256 uu cell.  Most queries
+// (mid-field wheel rays, ball / hitbox AABBs) touch only empty cells and skip the BVH walk altogether.
+constexpr int GRID_X = 34, GRID_Y = 48, GRID_Z = 10;
+constexpr float GRID_CELL = 5.12f;                                  // BT (256 uu)
+constexpr float GRID_MIN_X = -87.04f, GRID_MIN_Y = -122.88f, GRID_MIN_Z = -5.12f;
+constexpr int GRID_WORDS = (GRID_X * GRID_Y * GRID_Z + 31) / 32;
+
 struct MeshView {
     const BvhNode* nodes;      // global
     const MeshTri* tris;       // global
     const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr
+    const uint32_t* grid;      // GRID_WORDS occupancy words (LDS on the device), or nullptr = always traverse
     int n_nodes, n_tris, n_fast;
 };
 

@@ -43,6 +43,30 @@ struct Contact {
 // ---- BVH access ---------------------------------------------------------------------------------------
 RLG_HD BvhNode mesh_node(const MeshView& m, int i) { return (i < m.n_fast) ? m.nodes_fast[i] : m.nodes[i]; }
 
+// does the box [lo,hi] touch any occupied grid cell?  (conservative: out-of-grid space counts as occupied)
+RLG_HD bool mesh_maybe_near(const MeshView& m, V3 lo, V3 hi) {
+    if (m.n_nodes <= 0) return false;
+    if (!m.grid) return true;
+    int x0 = (int)floorf((lo.x - GRID_MIN_X) * (1.f / GRID_CELL)), x1 = (int)floorf((hi.x - GRID_MIN_X) * (1.f / GRID_CELL));
+    int y0 = (int)floorf((lo.y - GRID_MIN_Y) * (1.f / GRID_CELL)), y1 = (int)floorf((hi.y - GRID_MIN_Y) * (1.f / GRID_CELL));
+    int z0 = (int)floorf((lo.z - GRID_MIN_Z) * (1.f / GRID_CELL)), z1 = (int)floorf((hi.z - GRID_MIN_Z) * (1.f / GRID_CELL));
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x1 >= GRID_X || y1 >= GRID_Y || z1 >= GRID_Z) return true;
+    if ((x1 - x0) > 3 || (y1 - y0) > 3 || (z1 - z0) > 3) return true;
+    for (int z = z0; z <= z1; z++)
+        for (int y = y0; y <= y1; y++)
+            for (int x = x0; x <= x1; x++) {
+                int bit = (z * GRID_Y + y) * GRID_X + x;
+                if ((m.grid[bit >> 5] >> (bit & 31)) & 1u) return true;
+            }
+    return false;
+}
+RLG_HD bool tri_aabb_overlap(const MeshTri& t, V3 lo, V3 hi) {
+    if (fminf(t.v0x, fminf(t.v1x, t.v2x)) > hi.x || fmaxf(t.v0x, fmaxf(t.v1x, t.v2x)) < lo.x) return false;
+    if (fminf(t.v0y, fminf(t.v1y, t.v2y)) > hi.y || fmaxf(t.v0y, fmaxf(t.v1y, t.v2y)) < lo.y) return false;
+    if (fminf(t.v0z, fminf(t.v1z, t.v2z)) > hi.z || fmaxf(t.v0z, fmaxf(t.v1z, t.v2z)) < lo.z) return false;
+    return true;
+}
+
 RLG_HD bool aabb_overlap(const BvhNode& n, V3 lo, V3 hi) {
     return !(n.minx > hi.x || n.maxx < lo.x || n.miny > hi.y || n.maxy < lo.y || n.minz > hi.z || n.maxz < lo.z);
 }
@@ -93,7 +117,8 @@ RLG_HD void world_plane(int i, V3& n, float& d) {
 }
 
 template <int NC>
-RLG_HD RayHit world_ray_cast(const Arena<NC>& A, int self_car, const MeshView& mesh, V3 from, V3 to) {
+RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, const MeshView& mesh, V3 from, V3 to) {
+    RLG_ASSUME_LDS(A);
     RayHit best; best.kind = -1; best.frac = 1.0f; best.normal = v3(0, 0, 0);
     // planes
     for (int i = 0; i < 4; i++) {
@@ -104,7 +129,7 @@ RLG_HD RayHit world_ray_cast(const Arena<NC>& A, int self_car, const MeshView& m
         if (f < best.frac) { best.frac = f; best.kind = 0; best.normal = (da <= 0.f) ? -n : n; }
     }
     // mesh
-    if (mesh.n_nodes > 0) {
+    if (mesh_maybe_near(mesh, v3(fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)), v3(fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)))) {
         V3 dvec = to - from;
         V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
         int stack[32]; int sp = 0; stack[sp++] = 0;
@@ -206,7 +231,7 @@ RLG_HD bool point_in_triangle(V3 p, V3 v0, V3 v1, V3 v2, V3 n) {
 }
 
 // sphere (ball) vs one triangle: SphereTriangleDetector::collide (:139-241) + the internal-edge snap
-RLG_HD bool sphere_triangle(V3 c, float radius, float thresh, const MeshTri& t, V3& point, V3& normal, float& depth) {
+RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const MeshTri& t, V3& point, V3& normal, float& depth) {
     V3 v0 = v3(t.v0x, t.v0y, t.v0z), v1 = v3(t.v1x, t.v1y, t.v1z), v2 = v3(t.v2x, t.v2y, t.v2z);
     float rwt = radius + thresh;
     V3 n = cross(v1 - v0, v2 - v0);
@@ -278,7 +303,7 @@ RLG_HD int clip_poly(const V3* in, int n, V3 nrm, float off, V3* out) {
 // box (center bc, basis R, half extents h) vs triangle, SAT + clipping. Emits candidates with the normal
 // pointing from the triangle towards the box.
 template <int CAP>
-RLG_HD void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, float thresh, Cand (&cs)[CAP], int& nc) {
+RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, float thresh, Cand (&cs)[CAP], int& nc) {
     V3 p[3] = {tmul(R, v3(t.v0x, t.v0y, t.v0z) - bc), tmul(R, v3(t.v1x, t.v1y, t.v1z) - bc), tmul(R, v3(t.v2x, t.v2y, t.v2z) - bc)};
     V3 e[3] = {p[1] - p[0], p[2] - p[1], p[0] - p[2]};
     V3 n = cross(e[0], p[2] - p[0]);
@@ -398,7 +423,7 @@ RLG_HD void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, float thres
 
 // box vs box (SAT, 15 axes, face clipping / edge-edge). A = (ca,Ra), B = (cb,Rb); normals point from B to A.
 template <int CAP>
-RLG_HD void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Cand (&cs)[CAP], int& nc) {
+RLG_HD_NOINLINE void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Cand (&cs)[CAP], int& nc) {
     V3 pp = tmul(Ra, cb - ca);            // B centre in A's frame
     M3 Rr = transpose(Ra) * Rb;           // B axes in A's frame (columns)
     V3 bcol[3] = {col0(Rr), col1(Rr), col2(Rr)};
@@ -504,7 +529,7 @@ RLG_HD void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Cand (&cs)[C
 }
 
 // sphere vs rounded box (core = half extents - margin, GJK margins: btConvexConvexAlgorithm / btGjkPairDetector)
-RLG_HD bool sphere_box(V3 sc, float radius, V3 bc, const M3& R, V3 h, float thresh, V3& pb, V3& n, float& dist) {
+RLG_HD_NOINLINE bool sphere_box(V3 sc, float radius, V3 bc, const M3& R, V3 h, float thresh, V3& pb, V3& n, float& dist) {
     V3 hc = v3(h.x - BOX_MARGIN, h.y - BOX_MARGIN, h.z - BOX_MARGIN);
     V3 l = tmul(R, sc - bc);
     V3 q = v3(clampf(l.x, -hc.x, hc.x), clampf(l.y, -hc.y, hc.y), clampf(l.z, -hc.z, hc.z));

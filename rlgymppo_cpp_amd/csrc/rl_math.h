@@ -13,8 +13,21 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define RLG_HD __host__ __device__ __forceinline__
-#define RLG_HD_NOINLINE __host__ __device__ __noinline__
+// Big routines are real calls on the device: fully inlined, one gym step is ~330 KB of code and every wavefront streams
+// it through the 64 KB instruction cache on every tick.
+#define RLG_HD_NOINLINE __host__ __device__ __noinline__ inline  /* `inline` only for ODR linkage of header definitions */
+#define RLG_NOUNROLL _Pragma("nounroll")
+// The stepper kernels keep each env's state and tick scratch in LDS.  Out-of-line device functions receive them through
+// generic pointers (flat_load/flat_store, no alias information); this assumption lets LLVM's InferAddressSpaces turn
+// those accesses into ds_read/ds_write.  Only valid where EVERY device caller passes an LDS object.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RLG_ASSUME_LDS(ref) __builtin_assume(__builtin_amdgcn_is_shared((const void*)&(ref)))
 #else
+#define RLG_ASSUME_LDS(ref) ((void)0)
+#endif
+#else
+#define RLG_NOUNROLL
+#define RLG_ASSUME_LDS(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
 #endif
@@ -133,7 +146,7 @@ RLG_HD Q4 quat_axis_angle(V3 axis, float angle) {
 }
 
 // btTransformUtil::integrateTransform's rotation part (LinearMath/btTransformUtil.h:37-87)
-RLG_HD M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
+RLG_HD_NOINLINE M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
     const float ANGULAR_MOTION_THRESHOLD = 0.5f * (PI_F * 0.5f);
     float fAngle2 = len2(angvel);
     float fAngle = 0.f;

@@ -25,15 +25,45 @@ static_assert(sizeof(RlgpuGymConfig) == sizeof(GymConfig), "C-ABI gym config mus
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int LDS_NODES = 2048;  // 64 KiB of BVH top levels per workgroup (160 KiB LDS per CU)
+// Tuning knobs (overridable with -D for experiments): LDS per workgroup decides how many workgroups (= wavefronts) share
+// a CU's 160 KiB (MI355X_MICROARCH.md); RLG_WAVES_PER_SIMD is the occupancy the register allocator is asked to allow.
+#ifndef RLG_LDS_BUDGET
+#define RLG_LDS_BUDGET (40 * 1024)
+#endif
+#ifndef RLG_LDS_NODES
+#define RLG_LDS_NODES 192
+#endif
+#ifndef RLG_WAVES_PER_SIMD
+#define RLG_WAVES_PER_SIMD 1
+#endif
+constexpr int LDS_BUDGET = RLG_LDS_BUDGET;
+constexpr int LDS_NODES = RLG_LDS_NODES;   // BVH top levels staged per workgroup (the occupancy grid prunes most walks)
 
 struct EnvDev {
     uint32_t* words;      // [n_words][n_envs]
     const BvhNode* nodes; const MeshTri* tris; int n_nodes, n_tris;
+    const uint32_t* grid;
     const float* action_table;
     GymConfig cfg;
     int n_envs;
 };
+
+// Everything one env touches during a step lives in LDS (state + per-tick scratch): as stack objects these
+// dynamically indexed arrays (cars[], contacts, solver rows) would sit in scratch memory, and with one wavefront per
+// SIMD nothing hides a ~500-cycle scratch access per array element.  Only a few lanes of a wavefront are active so
+// that 4096 envs spread over all 256 CUs instead of 64 waves.
+template <int NC>
+struct LaneBlock { Arena<NC> A; GymEnv<NC> G; TickWork<NC> W; };
+
+// per-lane stride: an ODD number of 8-byte units, so lane l starts at bank (2 * odd * l) mod 32 -> conflict-free for <= 16 lanes
+template <int NC>
+constexpr size_t lane_stride() { size_t w = (sizeof(LaneBlock<NC>) + 7) / 8; return ((w % 2) ? w : w + 1) * 8; }
+template <int NC>
+constexpr int lanes_per_block() {
+    int l = 16;
+    while (l > 1 && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + GRID_WORDS * 4 > (size_t)LDS_BUDGET) l /= 2;
+    return l;
+}
 
 template <int NC>
 __device__ void load_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G) {
@@ -47,7 +77,8 @@ __device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G)
     arena_visit(A, G, w);
 }
 
-__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes) {
+__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* lds_grid) {
+    if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
     int n_fast = d.n_nodes < LDS_NODES ? d.n_nodes : LDS_NODES;
     // 32-byte nodes copied as 2 x 16-byte vectors per lane: coalesced global reads, conflict-free ds_write_b128
     const float4* src = reinterpret_cast<const float4*>(d.nodes);
@@ -55,47 +86,83 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes) {
     for (int i = threadIdx.x; i < n_fast * 2; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
+    mv.grid = d.grid ? lds_grid : nullptr;
     return mv;
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
+__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
-    MeshView mv = stage_mesh(d, lds_nodes);
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t lds_grid[GRID_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);   // all 64 threads of the wave help staging
+    if (threadIdx.x >= LANES) return;
+    int env = blockIdx.x * LANES + threadIdx.x;
     if (env >= d.n_envs) return;
-    Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d, env, S.A, S.G);
     int32_t acts[NC]; float rew[NC]; int32_t dn;
     for (int k = 0; k < NC; k++) acts[k] = actions[(size_t)env * NC + k];
     const int D = obs_size<NC>();
-    gym_step_env<NC>(A, G, d.cfg, mv, d.action_table, acts, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, rew, &dn);
+    gym_step_env<NC>(S.A, S.G, d.cfg, mv, d.action_table, acts, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, rew, &dn, S.W);
     for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
-    store_env(d, env, A, G);
+    store_env(d, env, S.A, S.G);
 }
 
 template <int NC>
 __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, float* obs) {
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    if (threadIdx.x >= LANES) return;
+    int env = blockIdx.x * LANES + threadIdx.x;
     if (env >= d.n_envs) return;
-    Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d, env, S.A, S.G);
     const int D = obs_size<NC>();
-    gym_reset_env<NC>(A, G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * NC * D : nullptr, (size_t)D, run_setter != 0);
-    store_env(d, env, A, G);
+    gym_reset_env<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * NC * D : nullptr, (size_t)D, run_setter != 0);
+    store_env(d, env, S.A, S.G);
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE) k_env_ticks(EnvDev d, int ticks) {
+__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks) {
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
-    MeshView mv = stage_mesh(d, lds_nodes);
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t lds_grid[GRID_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
+    if (threadIdx.x >= LANES) return;
+    int env = blockIdx.x * LANES + threadIdx.x;
     if (env >= d.n_envs) return;
-    Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, d.cfg.seed_lo ^ 0xA511E9B3u, (uint32_t)env, ev); }
-    store_env(d, env, A, G);
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d, env, S.A, S.G);
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(S.A, mv, d.cfg.seed_lo ^ 0xA511E9B3u, (uint32_t)env, ev, S.W); }
+    store_env(d, env, S.A, S.G);
 }
+
+// diagnostic build of k_env_ticks: per workgroup, shader cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime)
+// spent inside the tick loop.  The stamps go to their own buffer and feed nothing else (MI355X_MICROARCH.md, DVFS item 6).
+template <int NC>
+__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks_timed(EnvDev d, int ticks, unsigned long long* stamps) {
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    __shared__ BvhNode lds_nodes[LDS_NODES];
+    __shared__ uint32_t lds_grid[GRID_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
+    if (threadIdx.x >= LANES) return;
+    int env = blockIdx.x * LANES + threadIdx.x;
+    if (env >= d.n_envs) return;
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d, env, S.A, S.G);
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(S.A, mv, d.cfg.seed_lo ^ 0xA511E9B3u, (uint32_t)env, ev, S.W); }
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    store_env(d, env, S.A, S.G);
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int NC>
+int env_grid(int n_envs) { return (n_envs + lanes_per_block<NC>() - 1) / lanes_per_block<NC>(); }
 
 // AoS <-> SoA movers for the host fallback path
 template <int NC>
@@ -132,10 +199,12 @@ struct rlgpu_env {
     int device = 0, n_envs = 0, team_size = 1, nc = 2;
     size_t n_words = 0;
     EnvDev d{};
-    BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr;
+    BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // accumulated step-kernel timing: pairs of events recorded around every launch, summed lazily
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0; double acc_ms = 0; int acc_launches = 0;
     std::string err;
 };
 
@@ -200,8 +269,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     HIPCHK(e, hipMemcpy(e->d_actions, tab, sizeof(tab), hipMemcpyHostToDevice));
     e->d.action_table = e->d_actions;
     memcpy(&e->d.cfg, cfg, sizeof(GymConfig));
-    e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0;
-    HIPCHK(e, hipEventCreate(&e->ev0)); HIPCHK(e, hipEventCreate(&e->ev1));
+    e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     return RLGPU_OK;
 }
 
@@ -212,8 +280,8 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_tris) (void)hipFree(e->d_tris);
     if (e->d_actions) (void)hipFree(e->d_actions);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->d_grid) (void)hipFree(e->d_grid);
+    for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
 }
 const char* rlgpu_env_last_error(const rlgpu_env* e) { return e ? e->err.c_str() : "null env"; }
@@ -235,7 +303,12 @@ int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts, int n_verts, const int3
         HIPCHK(e, hipMemcpy(e->d_nodes, m.nodes.data(), m.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
         HIPCHK(e, hipMemcpy(e->d_tris, m.tris.data(), m.tris.size() * sizeof(MeshTri), hipMemcpyHostToDevice));
     }
-    e->d.nodes = e->d_nodes; e->d.tris = e->d_tris;
+    if (e->d_grid) { (void)hipFree(e->d_grid); e->d_grid = nullptr; }
+    if (!m.grid.empty()) {
+        HIPCHK(e, hipMalloc(&e->d_grid, m.grid.size() * 4));
+        HIPCHK(e, hipMemcpy(e->d_grid, m.grid.data(), m.grid.size() * 4, hipMemcpyHostToDevice));
+    }
+    e->d.nodes = e->d_nodes; e->d.tris = e->d_tris; e->d.grid = e->d_grid;
     return RLGPU_OK;
 }
 int rlgpu_env_set_procedural_mesh(rlgpu_env* e) {
@@ -299,7 +372,7 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
 
 int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid((e->n_envs + WAVE - 1) / WAVE), block(WAVE);
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
     DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
@@ -308,18 +381,46 @@ int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
 int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     if (!actions || !next_obs || !reward || !done) { e->err = "rlgpu_env_step: null device pointer"; return RLGPU_ERR_ARG; }
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid((e->n_envs + WAVE - 1) / WAVE), block(WAVE);
-    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
+    if (e->ev_used == e->ev_pool.size()) {
+        if (e->ev_pool.size() < 2048) {
+            hipEvent_t a, b; HIPCHK(e, hipEventCreate(&a)); HIPCHK(e, hipEventCreate(&b));
+            e->ev_pool.push_back({a, b});
+        } else {
+            float tmp; int n; int rc = rlgpu_env_timing_total(e, &tmp, &n, 0);  // drains the pool into acc_ms
+            if (rc) return rc;
+        }
+    }
+    auto& evp = e->ev_pool[e->ev_used++];
+    HIPCHK(e, hipEventRecord(evp.first, e->stream));
     DISPATCH_NC(e, k_env_step, grid, block, e->d, actions, next_obs, reward, done);
-    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipEventRecord(evp.second, e->stream));
+    e->ev0 = evp.first; e->ev1 = evp.second;
     e->timed = true;
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }
 
+// diagnostics (not part of rlgpu.h): per-workgroup {shader cycles, 100 MHz ticks} of `ticks` physics ticks; out has 2 * n_blocks entries
+int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out, int cap_pairs, int* n_blocks) {
+    HIPCHK(e, hipSetDevice(e->device));
+    int nb = e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs));
+    *n_blocks = nb;
+    if (nb > cap_pairs) return RLGPU_ERR_ARG;
+    unsigned long long* dbuf = nullptr;
+    HIPCHK(e, hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * nb));
+    dim3 grid(nb), block(WAVE);
+    DISPATCH_NC(e, k_env_ticks_timed, grid, block, e->d, ticks, dbuf);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, dbuf, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+    (void)hipFree(dbuf);
+    return RLGPU_OK;
+}
+
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid((e->n_envs + WAVE - 1) / WAVE), block(WAVE);
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
     DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
@@ -328,6 +429,19 @@ int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
 int rlgpu_env_sync(rlgpu_env* e) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return RLGPU_OK;
+}
+int rlgpu_env_timing_total(rlgpu_env* e, float* total_ms, int* launches, int reset) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < e->ev_used; i++) {
+        float ms = 0.f; HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
+        e->acc_ms += ms; e->acc_launches++;
+    }
+    e->ev_used = 0;
+    if (total_ms) *total_ms = (float)e->acc_ms;
+    if (launches) *launches = e->acc_launches;
+    if (reset) { e->acc_ms = 0; e->acc_launches = 0; }
     return RLGPU_OK;
 }
 int rlgpu_env_last_step_ms(rlgpu_env* e, float* ms) {

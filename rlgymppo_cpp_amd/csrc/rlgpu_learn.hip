@@ -18,6 +18,9 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <random>
+#include <numeric>
+#include <algorithm>
 
 #include "../../include/rlgpu.h"
 #include "rl_math.h"
@@ -355,10 +358,14 @@ struct rlgpu_learner {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; double last_flops = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0; std::vector<double> ev_flops;
+    double acc_ms = 0, acc_flops = 0; int acc_calls = 0;
     std::string err;
 };
 
-#define LCHK(l, call)                                                                            \
+struct rlgpu_shuffler { std::default_random_engine rng; };
+
+#define LCHK(l, call)                                                                           \
     do {                                                                                         \
         hipError_t _s = (call);                                                                  \
         if (_s != hipSuccess) {                                                                  \
@@ -491,7 +498,6 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
     LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
     LCHK(l, hipMalloc(&l->norm_buf, 16));
-    LCHK(l, hipEventCreate(&l->ev0)); LCHK(l, hipEventCreate(&l->ev1));
     return RLGPU_OK;
 }
 
@@ -501,8 +507,7 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
-    if (l->ev0) (void)hipEventDestroy(l->ev0);
-    if (l->ev1) (void)hipEventDestroy(l->ev1);
+    for (auto& p : l->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete l;
 }
 const char* rlgpu_learner_last_error(const rlgpu_learner* l) { return l ? l->err.c_str() : "null learner"; }
@@ -599,6 +604,17 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         x = l->gathered;
     }
     l->last_flops = 0;
+    if (l->ev_used == l->ev_pool.size()) {
+        if (l->ev_pool.size() < 1024) {
+            hipEvent_t a, b; LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b));
+            l->ev_pool.push_back({a, b}); l->ev_flops.push_back(0.0);
+        } else {
+            int rc2 = rlgpu_learner_timing_total(l, nullptr, nullptr, nullptr, 0);
+            if (rc2) return rc2;
+        }
+    }
+    const size_t ev_slot = l->ev_used++;
+    l->ev0 = l->ev_pool[ev_slot].first; l->ev1 = l->ev_pool[ev_slot].second;
     LCHK(l, hipEventRecord(l->ev0, l->stream));
     int rc;
     // critic
@@ -614,6 +630,7 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     LCHK(l, hipGetLastError());
     if ((rc = net_backward(l, l->pol, l->act_p, x, n, l->dbuf0))) return rc;
     LCHK(l, hipEventRecord(l->ev1, l->stream));
+    l->ev_flops[ev_slot] = l->last_flops;
     l->timed = true;
     if (metrics) {
         // [5] += 1 minibatch, [6] += rows
@@ -651,6 +668,34 @@ int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {
     LCHK(l, hipEventSynchronize(l->ev1));
     LCHK(l, hipEventElapsedTime(ms, l->ev0, l->ev1));
     *flops = l->last_flops;
+    return RLGPU_OK;
+}
+
+int rlgpu_learner_timing_total(rlgpu_learner* l, float* total_ms, double* total_flops, int* calls, int reset) {
+    LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    for (size_t i = 0; i < l->ev_used; i++) {
+        float ms = 0.f; LCHK(l, hipEventElapsedTime(&ms, l->ev_pool[i].first, l->ev_pool[i].second));
+        l->acc_ms += ms; l->acc_flops += l->ev_flops[i]; l->acc_calls++;
+    }
+    l->ev_used = 0;
+    if (total_ms) *total_ms = (float)l->acc_ms;
+    if (total_flops) *total_flops = l->acc_flops;
+    if (calls) *calls = l->acc_calls;
+    if (reset) { l->acc_ms = 0; l->acc_flops = 0; l->acc_calls = 0; }
+    return RLGPU_OK;
+}
+
+int rlgpu_shuffler_create(rlgpu_shuffler** out, uint32_t seed) {
+    if (!out) return RLGPU_ERR_ARG;
+    *out = new rlgpu_shuffler{std::default_random_engine(seed)};
+    return RLGPU_OK;
+}
+void rlgpu_shuffler_destroy(rlgpu_shuffler* s) { delete s; }
+int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm) {
+    if (!s || n < 0 || !perm) return RLGPU_ERR_ARG;
+    std::iota(perm, perm + n, (int64_t)0);
+    std::shuffle(perm, perm + n, s->rng);
     return RLGPU_OK;
 }
 

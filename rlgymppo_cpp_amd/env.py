@@ -107,6 +107,12 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_last_step_ms(self.h, C.byref(ms)), self.h, self.lib.rlgpu_env_last_error)
         return ms.value
 
+    def timing_total(self, reset=True):
+        """(sum of step-kernel ms, launches) since the last reset, from hipEvents on the env's stream."""
+        ms, n = C.c_float(), C.c_int()
+        _chk(self.lib.rlgpu_env_timing_total(self.h, C.byref(ms), C.byref(n), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return ms.value, n.value
+
     def state_words(self) -> int:
         return self.lib.rlgpu_env_state_words(self.h)
 

@@ -1,0 +1,358 @@
+"""Learner — the host-side orchestration of one training iteration, mirroring RLGPC::Learner
+(RLGymPPO_CPP/src/public/RLGymPPO_CPP/Learner.cpp:436-703) on top of the C-ABI hot path:
+
+    collect (policy act + batched env step, all on device)     <- ThreadAgentManager::CollectTimesteps  (Learner.cpp:460)
+    AddNewExperience: value preds, GAE, return stats, buffer   <- Learner.cpp:608-703
+    PPOLearner::Learn: epochs x batches x minibatches           <- PPOLearner.cpp:67-349
+    report / checkpoint                                         <- Learner.cpp:379-434, 245-376
+
+Config field names and defaults are the reference's (LearnerConfig.h:14-80, PPOLearnerConfig.h:6-32); new fields
+are appended only.  This module owns no math: every tensor op on the hot path is a HIP kernel behind include/rlgpu.h;
+torch provides buffers, streams and torch.distributed (RCCL) for the one gradient all-reduce per optimizer step.
+"""
+import ctypes as C
+import json
+import os
+import shutil
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .env import BatchedEnv
+from .ppo import PPOCore
+
+
+@dataclass
+class PPOLearnerConfig:  # PUB/PPO/PPOLearnerConfig.h:6-32
+    policyLayerSizes: tuple = (256, 256, 256)
+    criticLayerSizes: tuple = (256, 256, 256)
+    batchSize: int = 50 * 1000
+    epochs: int = 10
+    policyLR: float = 3e-4
+    criticLR: float = 3e-4
+    entCoef: float = 0.005
+    clipRange: float = 0.2
+    miniBatchSize: int = 0
+    autocastLearn: bool = False   # bf16 MFMA operands (the reference's autocast dtype, FrameworkTorch.h:12-16)
+    policyTemperature: float = 1.0
+
+
+@dataclass
+class LearnerConfig:  # PUB/LearnerConfig.h:14-80
+    numThreads: int = 8
+    numGamesPerThread: int = 16
+    timestepLimit: int = 0
+    expBufferSize: int = 100 * 1000
+    timestepsPerIteration: int = 50 * 1000
+    standardizeReturns: bool = True
+    maxReturnsPerStatsInc: int = 150
+    deterministic: bool = False
+    ppo: PPOLearnerConfig = field(default_factory=PPOLearnerConfig)
+    gaeLambda: float = 0.95
+    gaeGamma: float = 0.99
+    rewardClipRange: float = 10.0
+    checkpointLoadFolder: str = "checkpoints"
+    checkpointSaveFolder: str = "checkpoints"
+    timestepsPerSave: int = 500 * 1000
+    randomSeed: int = 123
+    checkpointsToKeep: int = 5
+    # ---- appended for the batched device path
+    numEnvs: int = 0            # 0 -> numThreads * numGamesPerThread (the reference's env count)
+    teamSize: int = 1
+    gaeNextValueMode: int = 0   # 0 = reference-faithful cross-trajectory bootstrap, 1 = per-agent bootstrap
+    device: int = 0
+
+
+class WelfordRunningStat:
+    """PUB/Util/WelfordRunningStat.h:5-84 (shape 1, double)."""
+
+    def __init__(self):
+        self.mean = 0.0; self.m2 = 0.0; self.count = 0
+
+    def increment(self, samples, num):
+        for x in samples[:num]:
+            x = float(x)
+            delta = x - self.mean
+            delta_n = delta / (self.count + 1)
+            self.mean += delta_n
+            self.m2 += delta * delta_n * self.count
+            self.count += 1
+
+    def get_std(self):
+        if self.count < 2:
+            return 1.0
+        var = self.m2 / (self.count - 1)
+        return 1.0 if var == 0 else float(np.sqrt(var))
+
+    def to_json(self):
+        var = self.m2 / (self.count - 1) if self.count >= 2 else 0.0
+        return {"mean": [self.mean], "var": [var], "shape": 1, "count": self.count}
+
+    def from_json(self, j):
+        self.mean = float(j["mean"][0]); self.count = int(j["count"])
+        self.m2 = float(j["var"][0]) * (self.count - 1) if self.count >= 2 else 0.0
+
+
+class Shuffler:
+    def __init__(self, seed):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        assert self.lib.rlgpu_shuffler_create(C.byref(self.h), seed & 0xffffffff) == 0
+
+    def next(self, n):
+        out = np.empty(n, np.int64)
+        assert self.lib.rlgpu_shuffler_next(self.h, n, out.ctypes.data) == 0
+        return out
+
+    def __del__(self):
+        try:
+            self.lib.rlgpu_shuffler_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Learner:
+    def __init__(self, cfg: LearnerConfig, gym_cfg=None, mesh="procedural", rank=0, world_size=1):
+        self.cfg = cfg
+        self.rank, self.world = rank, world_size
+        n_envs = cfg.numEnvs or cfg.numThreads * cfg.numGamesPerThread
+        self.gym_cfg = gym_cfg if gym_cfg is not None else _lib.default_gym_config()
+        # every rank owns its own env shard and RNG streams: seed = randomSeed + 1000 * rank
+        self.gym_cfg.seed_lo = (cfg.randomSeed + 1000 * rank) & 0xffffffff
+        self.env = BatchedEnv(n_envs, cfg.teamSize, self.gym_cfg, cfg.device, mesh)
+        self.dev = torch.device("cuda", cfg.device)
+        self.n_agents = self.env.n_agents
+        self.obs_size, self.n_actions = self.env.obs_size, self.env.n_actions
+        # steps per iteration: collect at least timestepsPerIteration agent steps (the reference returns >= requested, Q6)
+        self.T = max(1, -(-cfg.timestepsPerIteration // self.n_agents))
+        self.B = self.T * self.n_agents
+        p = cfg.ppo
+        self.batch_size = min(p.batchSize, self.B) if p.batchSize > 0 else self.B
+        self.mini = p.miniBatchSize if p.miniBatchSize > 0 else self.batch_size
+        if self.batch_size % self.mini != 0:
+            raise ValueError("RG FATAL ERROR: PPOLearner: batchSize must be a multiple of miniBatchSize")  # PPOLearner.cpp:35-36
+        max_rows = max(self.mini, self.n_agents)
+        # identical parameters on every rank: the init seed does not depend on the rank
+        self.ppo = PPOCore(self.obs_size, self.n_actions, p.policyLayerSizes, p.criticLayerSizes, p.policyLR, p.criticLR, p.entCoef, p.clipRange,
+                           p.policyTemperature, p.autocastLearn, cfg.randomSeed, max_rows, cfg.device)
+        T, N, D = self.T, self.n_agents, self.obs_size
+        f = dict(dtype=torch.float32, device=self.dev)
+        self.obs_buf = torch.empty((T + 1, N, D), **f)     # states; row T = the state after the last step
+        self.act_buf = torch.empty((T, N), dtype=torch.int32, device=self.dev)
+        self.logp_buf = torch.empty((T, N), **f)
+        self.rew_buf = torch.empty((T, N), **f)
+        self.done_buf = torch.empty((T, N), dtype=torch.int32, device=self.dev)
+        self.val_buf = torch.empty((T + 1, N), **f)
+        self.trunc_buf = torch.zeros((T, N), **f)
+        self.metrics = torch.zeros(8, **f)
+        self.return_stats = WelfordRunningStat()
+        self.shuffler = Shuffler(cfg.randomSeed)
+        self.total_timesteps = 0
+        self.total_epochs = 0
+        self.cumulative_model_updates = 0
+        self.ts_since_save = 0
+        self.report = {}
+        self.iteration_callback = None
+        self.env.reset(True, self.obs_buf[0])
+        self._first = True
+
+    # ---- collection ------------------------------------------------------------------------------------------------
+    def collect(self):
+        """T gym steps of every env with on-device policy inference (ThreadAgent::_RunFunc, ThreadAgent.cpp:58-163)."""
+        if not self._first:
+            self.obs_buf[0].copy_(self.obs_buf[self.T])
+        self._first = False
+        for t in range(self.T):
+            self.ppo.act(self.obs_buf[t], self.act_buf[t], self.logp_buf[t], deterministic=self.cfg.deterministic)
+            self.env.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t])
+        self.total_timesteps += self.B * self.world
+
+    # ---- AddNewExperience (Learner.cpp:608-703) -----------------------------------------------------------------------
+    def add_new_experience(self):
+        T, N = self.T, self.n_agents
+        rows = (T + 1) * N
+        flat_obs = self.obs_buf.view(rows, self.obs_size)
+        flat_val = self.val_buf.view(rows)
+        step = self.ppo.max_rows
+        for s in range(0, rows, step):   # minibatched value predictions (Learner.cpp:628-640)
+            e = min(rows, s + step)
+            self.ppo.value(flat_obs[s:e], flat_val[s:e])
+        ret_std = self.return_stats.get_std() if self.cfg.standardizeReturns else 1.0   # read BEFORE the update (Q2)
+        dones_f = self.done_buf.to(torch.float32)
+        # CollectTimesteps marks the last step of every player trajectory truncated unless done (ThreadAgentManager.cpp:55)
+        self.trunc_buf.zero_()
+        self.trunc_buf[T - 1] = 1.0 - dones_f[T - 1]
+        adv, tgt, ret = self.ppo.gae(self.rew_buf, dones_f, self.trunc_buf, self.val_buf, self.cfg.gaeGamma, self.cfg.gaeLambda, ret_std,
+                                     self.cfg.rewardClipRange, self.cfg.gaeNextValueMode)
+        self.adv, self.tgt, self.ret = adv, tgt, ret
+        if self.cfg.standardizeReturns:
+            # the first <=150 returns of the concatenated (agent-major) batch: trajectory 0's first steps (Learner.cpp:679-682)
+            k = min(self.cfg.maxReturnsPerStatsInc, T)
+            first = ret[:k, 0]
+            if self.world > 1:
+                import torch.distributed as dist
+                first = first.clone(); dist.broadcast(first, src=0)   # rank 0's returns feed the shared statistic
+            self.return_stats.increment(first.cpu().numpy().tolist(), k)
+        self.report["Avg Return"] = float(ret.abs().mean().item()) / ret_std
+        self.report["Avg Advantage"] = float(adv.abs().mean().item())
+        self.report["Avg Val Target"] = float(tgt.abs().mean().item())
+
+    # ---- PPOLearner::Learn (PPOLearner.cpp:67-349) ----------------------------------------------------------------
+    def learn(self):
+        T, N, B = self.T, self.n_agents, self.B
+        p = self.cfg.ppo
+        obs = self.obs_buf.view((T + 1) * N, self.obs_size)
+        acts = self.act_buf.view(-1); logp = self.logp_buf.view(-1); adv = self.adv.view(-1); tgt = self.tgt.view(-1)
+        self.metrics.zero_()
+        n_mb = 0; n_updates = 0
+        for _ in range(p.epochs):
+            perm = self.shuffler.next(B)                       # logical (agent-major) indices, ExperienceBuffer.cpp:106-121
+            phys = ((perm % T) * N + (perm // T)).astype(np.int32)   # -> physical time-major rows
+            idx = torch.from_numpy(phys).to(self.dev, non_blocking=True)
+            for b in range(B // self.batch_size):              # remainder rows are skipped (Q5)
+                self.ppo.zero_grads()
+                base = b * self.batch_size
+                for m in range(0, self.batch_size, self.mini):
+                    self.ppo.minibatch(obs, acts, logp, adv, tgt, idx[base + m: base + m + self.mini], self.mini, self.mini / self.batch_size, self.metrics)
+                    n_mb += 1
+                if self.world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(self.ppo.grad_tensor())    # ONE RCCL all-reduce per optimizer step
+                self.ppo.clip_adam_step(0.5, 1.0 / self.world)
+                n_updates += 1
+        self.total_epochs += p.epochs
+        self.cumulative_model_updates += n_updates
+        self._n_mb = n_mb
+        return n_updates
+
+    def finish_report(self):
+        m = self.metrics.cpu().numpy(); rows = max(1, self._n_mb * self.mini)
+        self.report.update({"Policy Entropy": m[0] / rows, "Mean KL Divergence": m[1] / rows, "SB3 Clip Fraction": m[2] / rows,
+                            "Value Function Loss": m[4] / rows, "Cumulative Timesteps": self.total_timesteps,
+                            "Cumulative Model Updates": self.cumulative_model_updates, "Total Iterations": self.total_epochs})
+        return self.report
+
+    def iteration(self):
+        self.collect()
+        self.add_new_experience()
+        self.learn()
+        self.ts_since_save += self.B * self.world
+
+    def run(self, iterations=None):
+        it = 0
+        while True:
+            t0 = time.time()
+            self.iteration()
+            self.ppo.sync()
+            self.finish_report()
+            dt = time.time() - t0
+            self.report["Overall Steps/Second"] = self.B * self.world / dt
+            if self.iteration_callback:
+                self.iteration_callback(self, self.report)
+            if self.ts_since_save > self.cfg.timestepsPerSave and self.rank == 0:
+                self.save()
+            it += 1
+            if iterations is not None and it >= iterations:
+                break
+            if self.cfg.timestepLimit and self.total_timesteps >= self.cfg.timestepLimit:
+                break
+
+    # ---- checkpoints: checkpoints/<timesteps>/{RUNNING_STATS.json, PPO_*.lt} (Learner.cpp:171-376, PPOLearner.cpp:362-502) ----
+    MODEL_FILES = ("PPO_POLICY.lt", "PPO_CRITIC.lt", "PPO_POLICY_OPTIM.lt", "PPO_CRITIC_OPTIM.lt")
+
+    def save(self):
+        folder = os.path.join(self.cfg.checkpointSaveFolder, str(self.total_timesteps))
+        os.makedirs(folder, exist_ok=True)
+        stats = {"cumulative_timesteps": self.total_timesteps, "cumulative_model_updates": self.cumulative_model_updates,
+                 "epoch": self.total_epochs, "reward_running_stats": self.return_stats.to_json()}
+        with open(os.path.join(folder, "RUNNING_STATS.json"), "w") as f:
+            json.dump(stats, f, indent=4)
+        m, v, sp, sc = self.ppo.get_adam_state()
+        npol = self.ppo.num_params(0)
+        _write_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.get_params(0), self.ppo.layer_shapes(0))
+        _write_lt(os.path.join(folder, "PPO_CRITIC.lt"), self.ppo.get_params(1), self.ppo.layer_shapes(1))
+        _write_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), m[:npol], v[:npol], sp)
+        _write_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), m[npol:], v[npol:], sc)
+        self.ts_since_save = 0
+        if self.cfg.checkpointsToKeep > 0:   # prune the lowest-numbered folders (Learner.cpp:256-280)
+            base = self.cfg.checkpointSaveFolder
+            nums = sorted(int(d) for d in os.listdir(base) if d.isdigit())
+            while len(nums) > self.cfg.checkpointsToKeep:
+                shutil.rmtree(os.path.join(base, str(nums.pop(0))))
+        return folder
+
+    def load(self, folder=None):
+        base = self.cfg.checkpointLoadFolder
+        if folder is None:
+            if not os.path.isdir(base):
+                return False
+            nums = [int(d) for d in os.listdir(base) if d.isdigit()]
+            if not nums:
+                return False
+            folder = os.path.join(base, str(max(nums)))   # highest-numbered sub-dir (Learner.cpp:291-309)
+        with open(os.path.join(folder, "RUNNING_STATS.json")) as f:
+            stats = json.load(f)
+        self.total_timesteps = int(stats["cumulative_timesteps"]); self.cumulative_model_updates = int(stats["cumulative_model_updates"])
+        self.total_epochs = int(stats["epoch"]); self.return_stats.from_json(stats["reward_running_stats"])
+        pol = _read_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.layer_shapes(0))     # size check of every param (PPOLearner.cpp:380-408)
+        cri = _read_lt(os.path.join(folder, "PPO_CRITIC.lt"), self.ppo.layer_shapes(1))
+        self.ppo.set_params(pol, 0); self.ppo.set_params(cri, 1)
+        n = self.ppo.num_params(2); npol = self.ppo.num_params(0)
+        m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); sp = sc = 0
+        po = _read_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), npol)
+        co = _read_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), n - npol)
+        if po is not None: m[:npol], v[:npol], sp = po          # missing/empty optimizer file -> reset (PPOLearner.cpp:442-451)
+        if co is not None: m[npol:], v[npol:], sc = co
+        self.ppo.set_adam_state(m, v, sp, sc)
+        self.ppo.set_lr(self.cfg.ppo.policyLR, self.cfg.ppo.criticLR)                        # UpdateLearningRates (Learner.cpp:501)
+        return True
+
+
+# ---- .lt payload, format v1 (own container behind the reference's file names; TorchScript-zip compatibility = SURVEY F1) ----
+_MAGIC = b"RLGPU_LT1\n"
+
+
+def _write_lt(path, flat, shapes):
+    with open(path, "wb") as f:
+        f.write(_MAGIC)
+        hdr = json.dumps({"tensors": [{"name": f"{2 * i}.weight", "shape": list(ws)} for i, (ws, bs) in enumerate(shapes)], "dtype": "<f4",
+                          "order": "0.weight,0.bias,2.weight,..."}).encode()
+        f.write(len(hdr).to_bytes(8, "little")); f.write(hdr)
+        f.write(np.ascontiguousarray(flat, "<f4").tobytes())
+
+
+def _read_lt(path, shapes):
+    want = sum(ws[0] * ws[1] + bs[0] for ws, bs in shapes)
+    with open(path, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            raise RuntimeError(f"RG FATAL ERROR: {path} is not a v1 .lt payload (TorchScript .lt import is not implemented yet)")
+        n = int.from_bytes(f.read(8), "little"); hdr = json.loads(f.read(n))
+        got = [tuple(t["shape"]) for t in hdr["tensors"]]
+        if got != [tuple(ws) for ws, _ in shapes]:
+            raise RuntimeError(f"RG FATAL ERROR: saved model has different size than the current model: {got}")
+        flat = np.frombuffer(f.read(), "<f4")
+    if flat.size != want:
+        raise RuntimeError("RG FATAL ERROR: saved model has different size than the current model")
+    return flat.astype(np.float32)
+
+
+def _write_optim(path, m, v, step):
+    with open(path, "wb") as f:
+        f.write(_MAGIC); f.write(int(step).to_bytes(8, "little")); f.write(int(m.size).to_bytes(8, "little"))
+        f.write(np.ascontiguousarray(m, "<f4").tobytes()); f.write(np.ascontiguousarray(v, "<f4").tobytes())
+
+
+def _read_optim(path, n):
+    if not os.path.exists(path) or os.path.getsize(path) == 0:
+        return None
+    with open(path, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            return None
+        step = int.from_bytes(f.read(8), "little"); cnt = int.from_bytes(f.read(8), "little")
+        if cnt != n:
+            return None
+        m = np.frombuffer(f.read(4 * n), "<f4").astype(np.float32); v = np.frombuffer(f.read(4 * n), "<f4").astype(np.float32)
+    return m, v, step

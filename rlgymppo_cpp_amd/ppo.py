@@ -144,6 +144,12 @@ class PPOCore:
     def sync(self):
         _chk(self.lib.rlgpu_learner_sync(self.h), self.h, self._err)
 
+    def timing_total(self, reset=True):
+        """(ms, flops, calls) accumulated over the ppo_minibatch regions since the last reset."""
+        ms, fl, n = C.c_float(), C.c_double(), C.c_int()
+        _chk(self.lib.rlgpu_learner_timing_total(self.h, C.byref(ms), C.byref(fl), C.byref(n), 1 if reset else 0), self.h, self._err)
+        return ms.value, fl.value, n.value
+
     def last_gemm(self):
         ms, fl = C.c_float(), C.c_double()
         _chk(self.lib.rlgpu_learner_last_gemm(self.h, C.byref(ms), C.byref(fl)), self.h, self._err)
