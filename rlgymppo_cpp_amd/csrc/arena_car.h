@@ -344,103 +344,133 @@ RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
 }
 
 // ---- Car::_PreTickUpdate (Car.cpp:58-131) incl. btVehicleRL first/second halves ------------------------------
-// `world` supplies the ray cast against planes / mesh / ball / other cars (arena_world.h).
-template <int NC>
-RLG_HD void car_pre_tick_body(Arena<NC>& A, Car& c, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t);
+// The pre-tick is cut into three phases so that a wavefront can run them over different lane sets (rlgpu_env.hip:
+// one lane per car, then one lane per wheel, then one lane per car again); the host build runs them in plain loops.
+// Results do not depend on the order of cars inside a phase:
+//   * a phase-0 respawn changes only the car itself, and a car that is demoed or was respawned this tick stays
+//     `frozen` (DISABLE_SIMULATION + CF_NO_CONTACT_RESPONSE, Car.cpp:69-80) for the whole tick, so no ray sees it;
+//   * phase 2 reads another car only when a wheel stands on it (ground >= 2): callers serialise that case by car index.
 
+// phase 0, per car: ClampFix, demo timer and respawn (Car.cpp:60-87)
 template <int NC>
-RLG_HD_NOINLINE void car_pre_tick(Arena<NC>& A, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t) {
-    // Work on a private copy: on the device A lives in LDS behind a generic pointer, which defeats alias analysis
-    // (every field would be re-loaded after every store); a local Car is promoted to registers.  The ray cast reads
-    // only the OTHER cars and the ball from A, so the stale A.cars[ci] is never observed.
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
-    Car c = A.cars[ci];
-    car_pre_tick_body(A, c, ci, mesh, respawn_rnd, t);
-    A.cars[ci] = c;
-}
-
-template <int NC>
-RLG_HD void car_pre_tick_body(Arena<NC>& A, Car& c, int ci, const MeshView& mesh, uint32_t respawn_rnd, CarTickCtx& t) {
+RLG_HD_NOINLINE void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t env_id) {
+    RLG_ASSUME_LDS(A);
     const float dt = TICK_DT;
-    // ClampFix
+    Car& c = A.cars[ci];
     c.ctl.throttle = clampf(c.ctl.throttle, -1.f, 1.f); c.ctl.steer = clampf(c.ctl.steer, -1.f, 1.f);
     c.ctl.pitch = clampf(c.ctl.pitch, -1.f, 1.f); c.ctl.yaw = clampf(c.ctl.yaw, -1.f, 1.f); c.ctl.roll = clampf(c.ctl.roll, -1.f, 1.f);
-
-    c.frozen = (c.flags & CF_IS_DEMOED) != 0;  // rigid body disabled for this tick (Car.cpp:69-80)
-    if (c.flags & CF_IS_DEMOED) {
-        c.demo_respawn_timer = fmaxf(c.demo_respawn_timer - dt, 0.f);
-        if (c.demo_respawn_timer == 0.f) car_respawn(c, (ci % 2) == 0, respawn_rnd);
-        // NB: as in the reference, a car respawned here still skips the rest of this tick only if it is
-        // still flagged demoed (Respawn clears the flag, Car.cpp:86-87 checks the NEW state).
+    bool demoed = (c.flags & CF_IS_DEMOED) != 0;
+    c.frozen = demoed;  // rigid body disabled for this tick (Car.cpp:69-80)
+    if (demoed) {
+        float tm = fmaxf(c.demo_respawn_timer - dt, 0.f);
+        c.demo_respawn_timer = tm;
+        if (tm == 0.f) {
+            uint32_t rnd[4];
+            philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)ci, rnd);
+            Car n = c;
+            car_respawn(n, (ci % 2) == 0, rnd[0]);
+            n.frozen = true;
+            c = n;
+        }
     }
-    if (c.flags & CF_IS_DEMOED) return;
+}
 
-    V3 up = col2(c.b.rot);
-    // updateVehicleFirst: wheel transforms with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235)
-    RLG_NOUNROLL
-    for (int i = 0; i < 4; i++) {
-        V3 wheel_dir = c.b.rot * v3(0, 0, -1), axle = c.b.rot * v3(0, -1, 0);
+// phase 1, per (car, wheel): wheel transform with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235), the
+// suspension ray (btVehicleRL.cpp:118-212) and the hard-stop pushback (btContactConstraint.cpp:60-105)
+template <int NC>
+RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, const MeshView& mesh, CarTickCtx& t) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
+    const float dt = TICK_DT;
+    Car& cr = A.cars[ci];
+    // NB: as in the reference, a car respawned in phase 0 runs the rest of the pre-tick (Respawn clears the flag,
+    // Car.cpp:86-87 checks the NEW state).
+    if (cr.flags & CF_IS_DEMOED) return;
+    const M3 rot = cr.b.rot; const V3 pos = cr.b.pos, vel = cr.b.vel, angvel = cr.b.angvel;
+    const float steer_angle = cr.steer_angle;
+    V3 up = col2(rot);
+    V3 wheel_dir = rot * v3(0, 0, -1), axle = rot * v3(0, -1, 0);
+    {
         V3 wup = -wheel_dir;
         V3 fwd = normalized(cross(wup, axle));
         M3 basis2 = m3_cols(fwd, -axle, wup);
-        if (i < 2 && c.steer_angle != 0.f) {
-            M3 steer = quat_to_m3(quat_axis_angle(wup, c.steer_angle));
+        if (i < 2 && steer_angle != 0.f) {
+            M3 steer = quat_to_m3(quat_axis_angle(wup, steer_angle));
             t.wheel_basis[i] = steer * basis2;
         } else {
             t.wheel_basis[i] = basis2;  // a zero steering angle gives the exact identity quaternion (0,0,0,1)
         }
     }
-    // ray casts (btVehicleRL.cpp:118-212)
-    t.n_contact = 0; t.wheels_world = false;
-    RLG_NOUNROLL
-    for (int i = 0; i < 4; i++) {
-        WheelTmp& w = t.w[i];
-        float rest = wheel_rest(i), radius = wheel_radius(i), travel = wheel_travel();
-        w.hard_point = (c.b.rot * wheel_conn(i)) + c.b.pos;
-        V3 wheel_dir = c.b.rot * v3(0, 0, -1);
-        float ray_len = rest + travel + radius - K::SUSPENSION_SUBTRACTION;
-        V3 source = w.hard_point, target = source + (wheel_dir * ray_len);
-        w.contact_point = target;
-        RayHit hit = world_ray_cast(A, ci, mesh, source, target);
-        w.ground = -1; w.in_contact = false;
-        if (hit.kind >= 0) {
-            float rt = hit.frac, s = 1.f - rt;
-            w.contact_point = v3(s * source.x + rt * target.x, s * source.y + rt * target.y, s * source.z + rt * target.z);
-            w.contact_normal = hit.normal;
-            w.in_contact = true;
-            w.ground = hit.kind;
-            bool is_static = hit.kind == 0;
-            if (is_static) t.wheels_world = true;
-            float trace_len = dot(w.hard_point - w.contact_point, up);
-            w.susp_len = clampf(trace_len - radius, rest - travel, rest + travel);
-            float denom = dot(w.contact_normal, up);
-            V3 relpos = w.contact_point - c.b.pos;
-            V3 vel_at = body_vel_at(c.b, relpos);
-            float proj_vel = dot(w.contact_normal, vel_at);
-            if (denom > 0.1f) {
-                float inv = 1.f / denom;
-                w.susp_rel_vel = proj_vel * inv; w.clipped_inv = inv;
-            } else { w.susp_rel_vel = 0.f; w.clipped_inv = 10.f; }
-            if (is_static) {
-                float thresh = (rest + radius) - K::SUSPENSION_SUBTRACTION;
-                if (trace_len < thresh) {
-                    // resolveSingleCollision(..., applyImpulses=false) vs a static body (btContactConstraint.cpp:60-105)
-                    float delta = trace_len - thresh;
-                    float rel_vel = dot(w.contact_normal, vel_at);
-                    float pos_err = K::ERP * -delta / dt;
-                    float vel_err = -(1.0f + 0.f) * rel_vel;
-                    float denom0 = body_impulse_denom(c.b, w.contact_point, w.contact_normal, CAR_INV_MASS);
-                    float jac = 1.f / (denom0 + 0.f);
-                    float imp = pos_err * jac + vel_err * jac;
-                    imp = 0.f > imp ? 0.f : imp;
-                    c.extra_pushback[i] = imp / 4;
-                }
+    WheelTmp w;
+    float rest = wheel_rest(i), radius = wheel_radius(i), travel = wheel_travel();
+    w.hard_point = (rot * wheel_conn(i)) + pos;
+    float ray_len = rest + travel + radius - K::SUSPENSION_SUBTRACTION;
+    V3 source = w.hard_point, target = source + (wheel_dir * ray_len);
+    w.contact_point = target;
+    w.impulse = v3(0, 0, 0);
+    RLG_PROF(0);
+    RayHit hit = world_ray_cast(A, ci, mesh, source, target);
+    RLG_PROF(7);
+    w.ground = -1; w.in_contact = false;
+    if (hit.kind >= 0) {
+        float rt = hit.frac, s = 1.f - rt;
+        w.contact_point = v3(s * source.x + rt * target.x, s * source.y + rt * target.y, s * source.z + rt * target.z);
+        w.contact_normal = hit.normal;
+        w.in_contact = true;
+        w.ground = hit.kind;
+        bool is_static = hit.kind == 0;
+        float trace_len = dot(w.hard_point - w.contact_point, up);
+        w.susp_len = clampf(trace_len - radius, rest - travel, rest + travel);
+        float denom = dot(w.contact_normal, up);
+        V3 relpos = w.contact_point - pos;
+        V3 vel_at = vel + cross(angvel, relpos);
+        float proj_vel = dot(w.contact_normal, vel_at);
+        if (denom > 0.1f) {
+            float inv = 1.f / denom;
+            w.susp_rel_vel = proj_vel * inv; w.clipped_inv = inv;
+        } else { w.susp_rel_vel = 0.f; w.clipped_inv = 10.f; }
+        if (is_static) {
+            float thresh = (rest + radius) - K::SUSPENSION_SUBTRACTION;
+            if (trace_len < thresh) {
+                // resolveSingleCollision(..., applyImpulses=false) vs a static body (btContactConstraint.cpp:60-105)
+                float delta = trace_len - thresh;
+                float rel_vel = dot(w.contact_normal, vel_at);
+                float pos_err = K::ERP * -delta / dt;
+                float vel_err = -(1.0f + 0.f) * rel_vel;
+                float denom0 = body_impulse_denom(cr.b, w.contact_point, w.contact_normal, CAR_INV_MASS);
+                float jac = 1.f / (denom0 + 0.f);
+                float imp = pos_err * jac + vel_err * jac;
+                imp = 0.f > imp ? 0.f : imp;
+                cr.extra_pushback[i] = imp / 4;
             }
-            t.n_contact++;
-        } else {
-            w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
-            c.extra_pushback[i] = 0.f;
         }
+    } else {
+        w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
+        cr.extra_pushback[i] = 0.f;
+    }
+    t.w[i] = w;
+}
+
+template <int NC>
+RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t);
+
+// phase 2, per car: friction impulses, the car's control logic, suspension forces (rest of Car::_PreTickUpdate)
+template <int NC>
+RLG_HD_NOINLINE void car_pre_tick_finish(Arena<NC>& A, int ci, CarTickCtx& t) {
+    // Work on a private copy: A lives in LDS behind a pointer the optimiser must assume aliases everything (every field
+    // would be re-loaded after every store); a local Car is promoted to registers.
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
+    if (A.cars[ci].flags & CF_IS_DEMOED) return;
+    Car c = A.cars[ci];
+    car_pre_tick_finish_body(A, c, ci, t);
+    A.cars[ci] = c;
+}
+
+template <int NC>
+RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t) {
+    const float dt = TICK_DT;
+    t.n_contact = 0; t.wheels_world = false;
+    for (int i = 0; i < 4; i++) {
+        if (t.w[i].in_contact) { t.n_contact++; if (t.w[i].ground == 0) t.wheels_world = true; }
     }
     // calcFrictionImpulses with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
     {

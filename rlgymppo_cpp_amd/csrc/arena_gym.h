@@ -390,49 +390,74 @@ RLG_HD void gym_episode_reset(const Arena<NC>& A, GymEnv<NC>& G, const GymConfig
 // ---- Gym::Step for one env ---------------------------------------------------------------------------------------
 // actions: NC indices into the action table (slot order).  Writes, in slot order:
 //   reward[NC], done, and next_obs[NC][D] = the observation the policy sees next (post-reset when done).
+// The step is cut at the tick boundaries (begin | tick 1 | after_first_tick | ticks 2..tickSkip | end) so that the device
+// kernel can run the ticks with a whole wavefront (rlgpu_env.hip) while the host build calls arena_tick() in between.
 template <int NC>
-RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const MeshView& mesh, const float* action_table,
-                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC>& W) {
+struct GymStepCtx {
+    float pa[NC][8];     // parsed actions (become prev_action of the next obs)
+    Snapshot<NC> S;      // the GameState of this step: taken after tick 1 (Gym.cpp:84-96)
+    bool done;
+};
+
+template <int NC>
+RLG_HD void gym_step_begin(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const float* action_table, const int32_t* actions, GymStepCtx<NC>& X) {
     // Match::ParseActions: demoed players (per the PREVIOUS snapshot) get a zero action (Match.cpp:44-52)
     uint32_t snap_demoed = (G.tracker_flags >> 8) & 0xffu;
-    float pa[NC][8];
     for (int k = 0; k < NC; k++) {
         int idx = actions[k];
         bool zero = (snap_demoed >> k) & 1u;
         if (idx < 0 || idx >= cfg.n_actions) zero = true;
-        for (int i = 0; i < 8; i++) pa[k][i] = zero ? 0.f : action_table[idx * 8 + i];
+        for (int i = 0; i < 8; i++) X.pa[k][i] = zero ? 0.f : action_table[idx * 8 + i];
         G.prev_action_idx[k] = zero ? -1 : idx;
         Controls& c = A.cars[k].ctl;  // Action -> CarControls (Action.h:36-46)
-        c.throttle = pa[k][0]; c.steer = pa[k][1]; c.pitch = pa[k][2]; c.yaw = pa[k][3]; c.roll = pa[k][4];
-        c.jump = pa[k][5] == 1.f; c.boost = pa[k][6] == 1.f; c.handbrake = pa[k][7] == 1.f;
+        c.throttle = X.pa[k][0]; c.steer = X.pa[k][1]; c.pitch = X.pa[k][2]; c.yaw = X.pa[k][3]; c.roll = X.pa[k][4];
+        c.jump = X.pa[k][5] == 1.f; c.boost = X.pa[k][6] == 1.f; c.handbrake = X.pa[k][7] == 1.f;
     }
-    TickEvents ev; ev.bump_mask = 0;
-    arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev, W);  // arena->Step(tickSkip - actionDelay) = 1 tick
+}
+
+// after arena->Step(tickSkip - actionDelay) = 1 tick: `ev` holds the bump callbacks of that tick
+template <int NC>
+RLG_HD void gym_step_after_first_tick(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const TickEvents& ev, float* reward, int32_t* done_out, GymStepCtx<NC>& X) {
     // bump callbacks that fired during this first tick land in the snapshot (later ones are lost: Gym.cpp:84-96)
     for (int k = 0; k < NC; k++) {
         if (ev.bump_mask & (1u << k)) G.counters[k][5]++;
         if (ev.bump_mask & (1u << (8 + k))) G.counters[k][6]++;
     }
     event_tracker_update(A, G);
-    Snapshot<NC> S;
-    take_snapshot(A, G, S);
-    uint32_t dm = 0; for (int k = 0; k < NC; k++) if (S.demoed[k]) dm |= (1u << k);
+    take_snapshot(A, G, X.S);
+    uint32_t dm = 0; for (int k = 0; k < NC; k++) if (X.S.demoed[k]) dm |= (1u << k);
     G.tracker_flags = (G.tracker_flags & ~0xff00u) | (dm << 8);
-    bool done = compute_done(S, G, cfg);
+    X.done = compute_done(X.S, G, cfg);
     float rew[NC];
-    compute_rewards(S, G, cfg, rew);
+    compute_rewards(X.S, G, cfg, rew);
     for (int k = 0; k < NC; k++) reward[k] = rew[k];
-    *done_out = done ? 1 : 0;
-    TickEvents ev2;
-    for (int t = 1; t < cfg.tick_skip; t++) { ev2.bump_mask = 0; arena_tick(A, mesh, cfg.seed_lo ^ 0xA511E9B3u, env_id, ev2, W); }
+    *done_out = X.done ? 1 : 0;
+}
+
+template <int NC>
+RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* next_obs, size_t obs_row_stride, GymStepCtx<NC>& X) {
     G.episode_steps++;
-    if (done) {
+    if (X.done) {
         reset_state(A, G, cfg, env_id);
-        gym_episode_reset(A, G, cfg, S);
+        gym_episode_reset(A, G, cfg, X.S);
         G.tracker_flags &= ~0xff00u;
-        for (int k = 0; k < NC; k++) for (int i = 0; i < 8; i++) pa[k][i] = 0.f;
+        for (int k = 0; k < NC; k++) for (int i = 0; i < 8; i++) X.pa[k][i] = 0.f;
     }
-    for (int k = 0; k < NC; k++) build_obs(S, k, pa[k], cfg, next_obs + (size_t)k * obs_row_stride);
+    for (int k = 0; k < NC; k++) build_obs(X.S, k, X.pa[k], cfg, next_obs + (size_t)k * obs_row_stride);
+}
+
+template <int NC>
+RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, const MeshView& mesh, const float* action_table,
+                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC>& W) {
+    GymStepCtx<NC> X;
+    gym_step_begin(A, G, cfg, action_table, actions, X);
+    const uint32_t seed = cfg.seed_lo ^ 0xA511E9B3u;
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick(A, mesh, seed, env_id, ev, W);
+    gym_step_after_first_tick(A, G, cfg, ev, reward, done_out, X);
+    TickEvents ev2;
+    for (int t = 1; t < cfg.tick_skip; t++) { ev2.bump_mask = 0; arena_tick(A, mesh, seed, env_id, ev2, W); }
+    gym_step_end(A, G, cfg, env_id, next_obs, obs_row_stride, X);
 }
 
 // Gym::Reset for one env: state setter + bookkeeping + first observation

@@ -327,7 +327,7 @@ struct TickWork {
     ContactList<MAXC> L;
     SolverBody B[NB];
     Row R[MAXR];
-    CarTickCtx ctx;
+    CarTickCtx ctx[NC];
 };
 
 // full tick of the dynamics world for one arena
@@ -350,7 +350,9 @@ RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& 
     A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
 
     bool touch;
+    RLG_PROF(1);
     collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch);
+    RLG_PROF(2);
     bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 
     // ---- solver setup
@@ -406,6 +408,7 @@ RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& 
         }
         if (n_special > 0) { row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false); nr++; }
     }
+    RLG_PROF(3);
     // split-impulse iterations
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
         float resid = 0.f;
@@ -426,6 +429,7 @@ RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& 
             }
         }
     }
+    RLG_PROF(4);
     // finish: write back (btSequentialImpulseConstraintSolver.cpp:1878-1904), then integrateTransforms (:889-1027)
     if (ball_active) {
         SolverBody& s = B[0]; Body& b = A.ball.b;
@@ -448,6 +452,7 @@ RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& 
     // clearForces
     A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
     for (int i = 0; i < NC; i++) { A.cars[i].b.force = v3(0, 0, 0); A.cars[i].b.torque = v3(0, 0, 0); }
+    RLG_PROF(5);
 }
 
 // ---- boost pads (BoostPad.cpp:51-105, BoostPadGrid.cpp:5-25; locations RLConst.h:215-253) -----------------
@@ -501,16 +506,16 @@ RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
 }
 
 // ---- Arena::Step, one tick (Arena.cpp:716-812) ---------------------------------------------------------
+// The tick is a fixed sequence of phases; each phase is a set of independent work items (cars, wheels, or the env).
+// arena_tick() below runs them in loops (host build, single-lane device callers); rlgpu_env.hip runs the same phase
+// functions with one wavefront lane per work item.
+
+// phase 3, per env: boost pad cooldowns, then the dynamics world step
 template <int NC>
-RLG_HD_NOINLINE void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
+RLG_HD_NOINLINE void tick_world(Arena<NC>& A, const MeshView& mesh, TickEvents& ev, TickWork<NC>& W) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
-    RLG_NOUNROLL
-    for (int i = 0; i < NC; i++) {
-        uint32_t rnd[4] = {0, 0, 0, 0};
-        if (A.cars[i].flags & CF_IS_DEMOED) philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)i, rnd);
-        car_pre_tick(A, i, mesh, rnd[0], W.ctx);
-    }
+    RLG_PROF(0);
     for (int p = 0; p < 34; p++) {
         Pad& pd = A.pads[p];
         if (pd.cooldown > 0) pd.cooldown = fmaxf(pd.cooldown - dt, 0.f);
@@ -518,17 +523,27 @@ RLG_HD_NOINLINE void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t see
         pd.cur_locked = 0;
     }
     world_step(A, mesh, ev, W);
+}
+
+// phase 4, per car: Car::_PostTickUpdate + _FinishPhysicsTick
+template <int NC>
+RLG_HD_NOINLINE void tick_car_post(Arena<NC>& A, int i) {
+    RLG_ASSUME_LDS(A);
+    // touch only the fields the post tick needs through locals (see car_pre_tick_finish about aliasing)
+    Car& cr = A.cars[i];
+    Car c; c.flags = cr.flags; c.b.vel = cr.b.vel; c.b.angvel = cr.b.angvel; c.supersonic_time = cr.supersonic_time;
+    c.car_contact_cooldown = cr.car_contact_cooldown; c.ctl = cr.ctl; c.last = cr.last; c.vel_impulse_cache = cr.vel_impulse_cache;
+    car_post_tick(c);
+    cr.flags = c.flags; cr.b.vel = c.b.vel; cr.b.angvel = c.b.angvel; cr.supersonic_time = c.supersonic_time;
+    cr.car_contact_cooldown = c.car_contact_cooldown; cr.last = c.last; cr.vel_impulse_cache = c.vel_impulse_cache;
+}
+
+// phase 5, per env: boost pad pickups (in car order), ball finish, tick counter
+template <int NC>
+RLG_HD_NOINLINE void tick_finish(Arena<NC>& A) {
+    RLG_ASSUME_LDS(A);
     RLG_NOUNROLL
-    for (int i = 0; i < NC; i++) {
-        // touch only the fields the post tick needs through locals (see car_pre_tick about generic pointers)
-        Car& cr = A.cars[i];
-        Car c; c.flags = cr.flags; c.b.vel = cr.b.vel; c.b.angvel = cr.b.angvel; c.supersonic_time = cr.supersonic_time;
-        c.car_contact_cooldown = cr.car_contact_cooldown; c.ctl = cr.ctl; c.last = cr.last; c.vel_impulse_cache = cr.vel_impulse_cache;
-        car_post_tick(c);
-        cr.flags = c.flags; cr.b.vel = c.b.vel; cr.b.angvel = c.b.angvel; cr.supersonic_time = c.supersonic_time;
-        cr.car_contact_cooldown = c.car_contact_cooldown; cr.last = c.last; cr.vel_impulse_cache = c.vel_impulse_cache;
-        pads_check_car(A, i);
-    }
+    for (int i = 0; i < NC; i++) pads_check_car(A, i);
     for (int p = 0; p < 34; p++) {
         Pad& pd = A.pads[p];
         int locked = 0;
@@ -552,6 +567,24 @@ RLG_HD_NOINLINE void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t see
         A.ball_update_counter++;
     }
     A.tick_count++;
+    RLG_PROF(6);
+}
+
+// true when phase 2 of car `ci` reads another car (a wheel stands on it): such ticks run phase 2 in car order
+RLG_HD bool car_needs_ordered_finish(const CarTickCtx& t) {
+    bool r = false;
+    for (int i = 0; i < 4; i++) r = r || (t.w[i].in_contact && t.w[i].ground >= 2);
+    return r;
+}
+
+template <int NC>
+RLG_HD void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
+    for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
+    for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_trace(A, i, w, mesh, W.ctx[i]);
+    for (int i = 0; i < NC; i++) car_pre_tick_finish(A, i, W.ctx[i]);
+    tick_world(A, mesh, ev, W);
+    for (int i = 0; i < NC; i++) tick_car_post(A, i);
+    tick_finish(A);
 }
 
 }  // namespace rlg

@@ -162,11 +162,11 @@ RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, const Me
             }
         }
     }
-    // other cars' hitboxes (not demoed: no contact response -> no hit, btDefaultVehicleRaycaster.cpp:41-43)
+    // other cars' hitboxes (demoed or respawned this tick: no contact response -> no hit, btDefaultVehicleRaycaster.cpp:41-43)
     for (int k = 0; k < NC; k++) {
         if (k == self_car) continue;
         const Car& o = A.cars[k];
-        if (o.flags & CF_IS_DEMOED) continue;
+        if ((o.flags & CF_IS_DEMOED) || o.frozen) continue;
         V3 center = o.b.pos + o.b.rot * hitbox_off();
         V3 lf = tmul(o.b.rot, from - center), lt = tmul(o.b.rot, to - center);
         V3 d = lt - lf, h = hitbox_half();

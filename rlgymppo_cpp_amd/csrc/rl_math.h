@@ -31,6 +31,10 @@
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
 #endif
+// Phase stamps for the tick profiler build (tools/prof_cycles.py); empty in product builds.
+#ifndef RLG_PROF
+#define RLG_PROF(i) ((void)0)
+#endif
 
 namespace rlg {
 

@@ -14,6 +14,16 @@
 #include <fstream>
 #include <algorithm>
 
+#ifdef RLG_TICK_PROFILE
+// profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
+__shared__ unsigned long long g_prof[8];
+__shared__ unsigned long long g_prof_last;
+#define RLG_PROF(i)                                                              \
+    do {                                                                         \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
+        if (threadIdx.x == 0) { g_prof[i] += _t - g_prof_last; g_prof_last = _t; } \
+    } while (0)
+#endif
 #include "../../include/rlgpu.h"
 #include "arena_gym.h"
 #include "arena_mesh.h"
@@ -90,6 +100,59 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* ld
     return mv;
 }
 
+// ---- wave-cooperative tick ------------------------------------------------------------------------------
+// A workgroup is ONE wavefront that owns LANES envs.  The tick's phases (arena_step.h) have different widths: one work
+// item per car, per wheel, or per env.  Every lane of the wave walks through the same phase sequence and picks up the
+// work item its lane id maps to, so the 8 suspension rays of a 1v1 env run on 8 lanes instead of 8 times in a row on one.
+// State and scratch sit in LDS; a wave's LDS operations execute in order, so phases only need a compiler-level fence.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NC>
+__device__ __forceinline__ LaneBlock<NC>& lane_block(unsigned char* lane_mem, int e) {
+    return *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)e * lane_stride<NC>());
+}
+
+// `ev` is meaningful on env lanes (lane e < n_valid owns env e of the workgroup)
+template <int NC>
+__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, const MeshView& mv, uint32_t seed, int env0, TickEvents& ev) {
+    constexpr int LANES = lanes_per_block<NC>();
+    static_assert(LANES * NC * 4 <= WAVE, "one lane per wheel must fit the wavefront");
+    const int tid = threadIdx.x;
+    const int e_car = tid / NC, c_car = tid % NC;
+    const int e_whl = tid / (4 * NC), c_whl = (tid >> 2) % NC, w_whl = tid & 3;
+    const bool env_lane = tid < n_valid;
+    const bool car_lane = e_car < n_valid;
+    const bool whl_lane = e_whl < n_valid;
+    LaneBlock<NC>& Sc = lane_block<NC>(lane_mem, car_lane ? e_car : 0);
+    LaneBlock<NC>& Sw = lane_block<NC>(lane_mem, whl_lane ? e_whl : 0);
+    LaneBlock<NC>& Se = lane_block<NC>(lane_mem, env_lane ? tid : 0);
+
+    if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
+    wave_sync();
+    if (whl_lane) car_wheel_trace(Sw.A, c_whl, w_whl, mv, Sw.W.ctx[c_whl]);
+    wave_sync();
+    const bool ordered = car_lane && car_needs_ordered_finish(Sc.W.ctx[c_car]);
+    if (__ballot(ordered) == 0ull) {
+        if (car_lane) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
+    } else {
+        for (int k = 0; k < NC; k++) {   // a wheel stands on another car somewhere in this wave: car order matters
+            if (car_lane && c_car == k) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
+            wave_sync();
+        }
+    }
+    wave_sync();
+    if (env_lane) tick_world(Se.A, mv, ev, Se.W);
+    wave_sync();
+    if (car_lane) tick_car_post(Sc.A, c_car);
+    wave_sync();
+    if (env_lane) tick_finish(Se.A);
+    wave_sync();
+}
+
 template <int NC>
 __global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     constexpr int LANES = lanes_per_block<NC>();
@@ -97,17 +160,31 @@ __global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d,
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     MeshView mv = stage_mesh(d, lds_nodes, lds_grid);   // all 64 threads of the wave help staging
-    if (threadIdx.x >= LANES) return;
-    int env = blockIdx.x * LANES + threadIdx.x;
-    if (env >= d.n_envs) return;
-    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
-    load_env(d, env, S.A, S.G);
-    int32_t acts[NC]; float rew[NC]; int32_t dn;
-    for (int k = 0; k < NC; k++) acts[k] = actions[(size_t)env * NC + k];
+    const int env0 = blockIdx.x * LANES;
+    const int n_valid = min(LANES, d.n_envs - env0);
+    const bool env_lane = (int)threadIdx.x < n_valid;
+    const int env = env0 + (env_lane ? (int)threadIdx.x : 0);
+    LaneBlock<NC>& S = lane_block<NC>(lane_mem, env_lane ? (int)threadIdx.x : 0);
+    const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
     const int D = obs_size<NC>();
-    gym_step_env<NC>(S.A, S.G, d.cfg, mv, d.action_table, acts, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, rew, &dn, S.W);
-    for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
-    store_env(d, env, S.A, S.G);
+    GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
+    if (env_lane) {
+        load_env(d, env, S.A, S.G);
+        int32_t acts[NC];
+        for (int k = 0; k < NC; k++) acts[k] = actions[(size_t)env * NC + k];
+        gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts, X);
+    }
+    wave_sync();
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick_wave<NC>(lane_mem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
+    if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
+    wave_sync();
+    for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(lane_mem, n_valid, mv, seed, env0, ev2); }
+    if (env_lane) {
+        gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, X);
+        for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
+        store_env(d, env, S.A, S.G);
+    }
 }
 
 template <int NC>
@@ -124,41 +201,38 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
     store_env(d, env, S.A, S.G);
 }
 
+// physics only (rlgpu_env_physics_ticks); with `stamps` (diagnostics, rlgpu_env_debug_tick_cycles) also per workgroup the shader
+// cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime) spent in the tick loop, plus the RLG_TICK_PROFILE phase buckets
 template <int NC>
-__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks) {
+__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
-    if (threadIdx.x >= LANES) return;
-    int env = blockIdx.x * LANES + threadIdx.x;
-    if (env >= d.n_envs) return;
-    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
-    load_env(d, env, S.A, S.G);
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(S.A, mv, d.cfg.seed_lo ^ 0xA511E9B3u, (uint32_t)env, ev, S.W); }
-    store_env(d, env, S.A, S.G);
-}
-
-// diagnostic build of k_env_ticks: per workgroup, shader cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime)
-// spent inside the tick loop.  The stamps go to their own buffer and feed nothing else (MI355X_MICROARCH.md, DVFS item 6).
-template <int NC>
-__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks_timed(EnvDev d, int ticks, unsigned long long* stamps) {
-    constexpr int LANES = lanes_per_block<NC>();
-    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
-    __shared__ BvhNode lds_nodes[LDS_NODES];
-    __shared__ uint32_t lds_grid[GRID_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
-    if (threadIdx.x >= LANES) return;
-    int env = blockIdx.x * LANES + threadIdx.x;
-    if (env >= d.n_envs) return;
-    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
-    load_env(d, env, S.A, S.G);
+    const int env0 = blockIdx.x * LANES;
+    const int n_valid = min(LANES, d.n_envs - env0);
+    const bool env_lane = (int)threadIdx.x < n_valid;
+    const int env = env0 + (env_lane ? (int)threadIdx.x : 0);
+    LaneBlock<NC>& S = lane_block<NC>(lane_mem, env_lane ? (int)threadIdx.x : 0);
+    if (env_lane) load_env(d, env, S.A, S.G);
+    wave_sync();
+#ifdef RLG_TICK_PROFILE
+    if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
+#endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(S.A, mv, d.cfg.seed_lo ^ 0xA511E9B3u, (uint32_t)env, ev, S.W); }
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(lane_mem, n_valid, mv, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    store_env(d, env, S.A, S.G);
-    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    if (env_lane) store_env(d, env, S.A, S.G);
+    if (stamps && threadIdx.x == 0) {
+        unsigned long long* o = stamps + 10 * (size_t)blockIdx.x;
+        o[0] = c1 - c0; o[1] = r1 - r0;
+#ifdef RLG_TICK_PROFILE
+        for (int i = 0; i < 8; i++) o[2 + i] = g_prof[i];
+#else
+        for (int i = 0; i < 8; i++) o[2 + i] = 0;
+#endif
+    }
 }
 
 template <int NC>
@@ -401,19 +475,19 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
     return RLGPU_OK;
 }
 
-// diagnostics (not part of rlgpu.h): per-workgroup {shader cycles, 100 MHz ticks} of `ticks` physics ticks; out has 2 * n_blocks entries
+// diagnostics (not part of rlgpu.h): per-workgroup {shader cycles, 100 MHz ticks} of `ticks` physics ticks; out has 10 * n_blocks entries (cycles, realtime, 8 phase accumulators of the PROFILE build)
 int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out, int cap_pairs, int* n_blocks) {
     HIPCHK(e, hipSetDevice(e->device));
     int nb = e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs));
     *n_blocks = nb;
     if (nb > cap_pairs) return RLGPU_ERR_ARG;
     unsigned long long* dbuf = nullptr;
-    HIPCHK(e, hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * nb));
+    HIPCHK(e, hipMalloc(&dbuf, sizeof(unsigned long long) * 10 * nb));
     dim3 grid(nb), block(WAVE);
-    DISPATCH_NC(e, k_env_ticks_timed, grid, block, e->d, ticks, dbuf);
+    DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks, dbuf);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, dbuf, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(out, dbuf, sizeof(unsigned long long) * 10 * nb, hipMemcpyDeviceToHost));
     (void)hipFree(dbuf);
     return RLGPU_OK;
 }
@@ -421,7 +495,7 @@ int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
     HIPCHK(e, hipSetDevice(e->device));
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
-    DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks);
+    DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks, (unsigned long long*)nullptr);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }

@@ -1,0 +1,51 @@
+"""In-kernel clocks of the physics tick: per-workgroup shader cycles and wall time (s_memtime / s_memrealtime)."""
+import os, sys, ctypes as C
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rlgymppo_cpp_amd.env import BatchedEnv
+from rlgymppo_cpp_amd.state import default_arena
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+env = BatchedEnv(n, 1)
+fn = env.lib.rlgpu_env_debug_tick_cycles
+fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+fn.restype = C.c_int
+
+
+def run(label):
+    buf = np.zeros(10 * 65536, dtype=np.uint64)
+    nb = C.c_int()
+    for _ in range(3):
+        rc = fn(env.h, ticks, buf.ctypes.data, 65536, C.byref(nb))
+        assert rc == 0, rc
+    b = buf[: 10 * nb.value].reshape(-1, 10).astype(np.float64)
+    cyc, rt = b[:, 0], b[:, 1]
+    us = rt / 100.0  # s_memrealtime: 100 MHz
+    print(f"{label}: blocks {nb.value}  cycles/tick mean {cyc.mean()/ticks:.0f} min {cyc.min()/ticks:.0f} max {cyc.max()/ticks:.0f}  "
+          f"us/tick mean {us.mean()/ticks:.1f} max {us.max()/ticks:.1f}  clock MHz {np.median(cyc/us):.0f}")
+    ph = b[:, 2:].mean(axis=0) / ticks
+    if ph.sum() > 0:
+        names = ["car_pre_tick", "gravity/damp", "collide_all", "solver setup", "solver iters", "integrate", "post/pads/ball", "wheel ray casts"]
+        print("   phases (cycles/tick, mean over blocks): " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, ph) if v > 0))
+        worst = int(np.argmax(cyc))
+        print("   slowest block: " + ", ".join(f"{n} {v/ticks:.0f}" for n, v in zip(names, b[worst, 2:]) if v > 0))
+
+
+for label, thr in (("rest", 0.0), ("throttle", 1.0)):
+    s = default_arena(2)
+    for k in range(2):
+        s.cars[k].controls[0] = thr
+    env.upload_states([s] * n)
+    run(label)
+obs = env.reset(True)
+dev = torch.device("cuda", 0)
+nobs = torch.empty_like(obs); rew = torch.empty(env.n_agents, device=dev); done = torch.empty(env.n_agents, dtype=torch.int32, device=dev)
+g = torch.Generator().manual_seed(0)
+for t in range(24):
+    a = torch.randint(0, 90, (env.n_agents,), generator=g, dtype=torch.int32).to(dev)
+    env.step(a, nobs, rew, done)
+env.sync()
+run("random-rollout")
