@@ -378,7 +378,7 @@ RLG_HD_NOINLINE void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_
 // phase 1, per (car, wheel): wheel transform with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235), the
 // suspension ray (btVehicleRL.cpp:118-212) and the hard-stop pushback (btContactConstraint.cpp:60-105)
 template <int NC>
-RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, const MeshView& mesh, CarTickCtx& t) {
+RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, MeshView mesh, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
     const float dt = TICK_DT;
     Car& cr = A.cars[ci];

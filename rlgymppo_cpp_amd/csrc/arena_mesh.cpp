@@ -152,8 +152,23 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         const BuildNode& b = bn[order[k]];
         BvhNode& n = m.nodes[k];
         n.minx = b.mn[0]; n.miny = b.mn[1]; n.minz = b.mn[2]; n.maxx = b.mx[0]; n.maxy = b.mx[1]; n.maxz = b.mx[2];
-        if (b.count > 0) { n.left_or_first = b.first; n.count = b.count; }
-        else { n.left_or_first = newidx[b.left]; n.count = 0; }
+        if (b.count > 0) { n.left_or_first = b.first; n.count_escape = (uint32_t)b.count; }
+        else { n.left_or_first = newidx[b.left]; n.count_escape = 0; }
+    }
+    // thread the tree for a right-child-first walk: after the right subtree comes the left sibling, after the left subtree
+    // whatever follows the parent
+    {
+        std::vector<std::pair<int, uint32_t>> todo; todo.push_back({0, BVH_END});
+        while (!todo.empty()) {
+            auto [k, esc] = todo.back(); todo.pop_back();
+            BvhNode& n = m.nodes[k];
+            n.count_escape = (n.count_escape & 0xffu) | (esc << 8);
+            if ((n.count_escape & 0xffu) == 0) {
+                int left = n.left_or_first;
+                todo.push_back({left + 1, (uint32_t)left});
+                todo.push_back({left, esc});
+            }
+        }
     }
     return m;
 }

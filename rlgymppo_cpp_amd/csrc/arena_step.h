@@ -78,8 +78,218 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 }
 
 // ---- narrowphase over all pairs -----------------------------------------------------------------------
-template <int NC, int MAXC>
-RLG_HD_NOINLINE void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch) {
+// The expensive pair tests (box-triangle, sphere-triangle, box-box) are "items".  collide_all() is written against a
+// narrowphase provider:
+//   NarrowInline  finds and runs every item on the spot (host build; overflow fallback on the device);
+//   NarrowQueued  reads the results of items that collide_queue_body() found and collide_run_item() ran earlier, on
+//                 other lanes of the wavefront (rlgpu_env.hip).  Item results are merged in the order the inline
+//                 provider would have produced them, so both give identical contact lists.
+// Three steps on the device, each on its own lane set:
+//   1. collide_queue_body  (a lane per body)       walks the BVH nodes only and lists the triangles of every leaf it reaches
+//                                                   as CANDIDATES -- no triangle is fetched during the walk;
+//   2. collide_test_candidate (a lane per candidate) fetches the triangle and does the AABB test; the survivors are compacted,
+//                                                   in candidate order, into ITEMS (rlgpu_env.hip does that with a ballot);
+//   3. collide_run_item    (a lane per item)        runs the pair test and stores its candidates in the pool.
+struct CollideItem {
+    int16_t type, a;   // 0 ball-triangle, 1 car-triangle (a = car), 2 car-car (a = first car)
+    int32_t ref;       // triangle index, or the second car
+    int16_t off, n;    // result candidates: pool[off .. off+n)
+};
+#ifndef RLG_ITEM_CAP
+#define RLG_ITEM_CAP 16   /* tests build a tiny queue to exercise the overflow fallback */
+#endif
+constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 96, CAND_CAP = 128;
+struct CollideQueue {
+    int n_cand, n_items, n_pool, overflow;
+    uint32_t cand[CAND_CAP];   // type << 28 | a << 24 | ref
+    CollideItem items[ITEM_CAP];
+    Cand pool[POOL_CAP];
+};
+RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
+RLG_HD CollideItem unpack_cand(uint32_t c) {
+    CollideItem it; it.type = (int16_t)(c >> 28); it.a = (int16_t)((c >> 24) & 15u); it.ref = (int32_t)(c & 0xFFFFFFu); it.off = 0; it.n = 0;
+    return it;
+}
+
+RLG_HD int fetch_add(int& x, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // lanes of one wavefront append to the same queue; the queue lives in LDS (ds_add_rtn instead of a flat atomic)
+    return __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    int o = x; x += v; return o;
+#endif
+}
+
+RLG_HD void queue_candidates(CollideQueue& Q, int type, int a, int first, int cnt) {
+    int k = fetch_add(Q.n_cand, cnt);
+    if (k + cnt > CAND_CAP) { Q.overflow = 1; return; }
+    for (int q = 0; q < cnt; q++) Q.cand[k + q] = pack_cand(type, a, first + q);
+}
+
+// every BVH leaf whose box overlaps [lo,hi], in walk order: f(first triangle, count)
+template <class F>
+RLG_HD void mesh_query_leaves(MeshView mesh, V3 lo, V3 hi, F&& f) {
+    if (!mesh_maybe_near(mesh, lo, hi)) return;
+    uint32_t i = 0;
+    while (i != BVH_END) {
+        BvhNode nd = mesh_node(mesh, (int)i);
+        uint32_t next = node_escape(nd);
+        if (aabb_overlap(nd, lo, hi)) {
+            const int cnt = node_count(nd);
+            if (cnt > 0) f(nd.left_or_first, cnt);
+            else next = (uint32_t)nd.left_or_first + 1u;
+        }
+        i = next;
+    }
+}
+
+// every mesh triangle whose AABB overlaps [lo,hi] (TestTriangleAgainstAabb2, btConvexConcaveCollisionAlgorithm.cpp:75), in BVH order
+template <class F>
+RLG_HD void mesh_query(MeshView mesh, V3 lo, V3 hi, F&& f) {
+    mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) {
+        for (int k = 0; k < cnt; k++)
+            if (tri_aabb_overlap(mesh.tris[first + k], lo, hi)) f(first + k);
+    });
+}
+
+RLG_HD void ball_query_aabb(V3 bp, V3& lo, V3& hi) {
+    const float r = K::BALL_RADIUS * UU2BT;
+    float bext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
+    lo = bp - v3(bext, bext, bext); hi = bp + v3(bext, bext, bext);
+}
+RLG_HD void car_query_aabb(const Car& car, V3& bc, V3& lo, V3& hi) {
+    V3 h = hitbox_half();
+    bc = car.b.pos + car.b.rot * hitbox_off();
+    M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
+                      v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
+                      v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
+    V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
+    lo = bc - ext; hi = bc + ext;
+}
+RLG_HD bool car_collides(const Car& car) { return !(car.flags & CF_IS_DEMOED) && !car.frozen; }  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
+template <int NC>
+RLG_HD bool cars_maybe_touch(const Arena<NC>& A, int ia, int ib) {
+    const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
+    V3 h = hitbox_half();
+    V3 cca = ca.b.pos + ca.b.rot * hitbox_off(), ccb = cb.b.pos + cb.b.rot * hitbox_off();
+    float rad = len(h);
+    return len2(cca - ccb) <= (2 * rad) * (2 * rad);
+}
+
+struct NarrowInline {
+    template <int NC, class F>
+    RLG_HD void ball_mesh(const Arena<NC>& A, MeshView mesh, F&& emit) {
+        const float r = K::BALL_RADIUS * UU2BT;
+        V3 bp = A.ball.b.pos, lo, hi;
+        ball_query_aabb(bp, lo, hi);
+        mesh_query(mesh, lo, hi, [&](int ti) {
+            Cand c;
+            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist)) emit(c);
+        });
+    }
+    template <int NC>
+    RLG_HD void car_mesh(const Arena<NC>& A, MeshView mesh, int ci, Cand (&cs)[4], int& nc) {
+        const Car& car = A.cars[ci];
+        V3 bc, lo, hi;
+        car_query_aabb(car, bc, lo, hi);
+        mesh_query(mesh, lo, hi, [&](int ti) { box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[ti], CBT_CAR, cs, nc); });
+    }
+    template <int NC>
+    RLG_HD void car_car(const Arena<NC>& A, int ia, int ib, Cand (&cs)[4], int& nc) {
+        const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
+        box_box(ca.b.pos + ca.b.rot * hitbox_off(), ca.b.rot, cb.b.pos + cb.b.rot * hitbox_off(), cb.b.rot, hitbox_half(), cs, nc);
+    }
+};
+
+struct NarrowQueued {
+    const CollideQueue& Q;
+    RLG_HD int count() const { return Q.n_items < ITEM_CAP ? Q.n_items : ITEM_CAP; }
+    template <int NC, class F>
+    RLG_HD void ball_mesh(const Arena<NC>&, MeshView, F&& emit) {
+        for (int k = 0; k < count(); k++) {
+            const CollideItem& it = Q.items[k];
+            if (it.type != 0) continue;
+            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q]);
+        }
+    }
+    template <int NC>
+    RLG_HD void car_mesh(const Arena<NC>&, MeshView, int ci, Cand (&cs)[4], int& nc) {
+        for (int k = 0; k < count(); k++) {
+            const CollideItem& it = Q.items[k];
+            if (it.type != 1 || it.a != ci) continue;
+            for (int q = 0; q < it.n; q++) cand_add(cs, nc, Q.pool[it.off + q]);
+        }
+    }
+    template <int NC>
+    RLG_HD void car_car(const Arena<NC>&, int ia, int ib, Cand (&cs)[4], int& nc) {
+        for (int k = 0; k < count(); k++) {
+            const CollideItem& it = Q.items[k];
+            if (it.type != 2 || it.a != ia || it.ref != ib) continue;
+            for (int q = 0; q < it.n; q++) cs[nc++] = Q.pool[it.off + q];
+            return;
+        }
+    }
+};
+
+// step 1: list the candidates of one body: body 0 = ball, 1 + i = car i (one lane appends them: they keep their walk order)
+template <int NC>
+RLG_HD_NOINLINE void collide_queue_body(const Arena<NC>& A, MeshView mesh, int body, bool ball_asleep, CollideQueue& Q) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
+    V3 lo, hi;
+    if (body == 0) {
+        if (ball_asleep) return;
+        ball_query_aabb(A.ball.b.pos, lo, hi);
+        mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) { queue_candidates(Q, 0, 0, first, cnt); });
+    } else {
+        const int ci = body - 1;
+        const Car& car = A.cars[ci];
+        if (!car_collides(car)) return;
+        V3 bc;
+        car_query_aabb(car, bc, lo, hi);
+        mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) { queue_candidates(Q, 1, ci, first, cnt); });
+        for (int ib = ci + 1; ib < NC; ib++)
+            if (car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
+    }
+}
+
+// step 2: does candidate `k` become an item?  (triangle AABB vs the body's query box; car-car pairs always do)
+template <int NC>
+RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const CollideQueue& Q, int k) {
+    CollideItem it = unpack_cand(Q.cand[k]);
+    if (it.type == 2) return true;
+    V3 lo, hi, bc;
+    if (it.type == 0) ball_query_aabb(A.ball.b.pos, lo, hi);
+    else car_query_aabb(A.cars[it.a], bc, lo, hi);
+    return tri_aabb_overlap(mesh.tris[it.ref], lo, hi);
+}
+
+// step 3: run item `slot`
+template <int NC>
+RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue& Q) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
+    CollideItem it = Q.items[slot];
+    Cand out[8]; int n = 0;
+    if (it.type == 0) {
+        const float r = K::BALL_RADIUS * UU2BT;
+        Cand c;
+        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], c.pb, c.n, c.dist)) out[n++] = c;
+    } else if (it.type == 1) {
+        const Car& car = A.cars[it.a];
+        V3 bc = car.b.pos + car.b.rot * hitbox_off();
+        box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[it.ref], CBT_CAR, out, n);
+    } else {
+        Cand cs[4]; int nc = 0;
+        NarrowInline().car_car(A, it.a, it.ref, cs, nc);
+        for (int q = 0; q < nc; q++) out[n++] = cs[q];
+    }
+    int off = n > 0 ? fetch_add(Q.n_pool, n) : 0;
+    if (off + n > POOL_CAP) { Q.overflow = 1; n = 0; off = 0; }
+    for (int q = 0; q < n; q++) Q.pool[off + q] = out[q];
+    Q.items[slot].off = (int16_t)off; Q.items[slot].n = (int16_t)n;
+}
+
+template <int NC, int MAXC, class NW>
+RLG_HD_NOINLINE void collide_all(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
     L.n = 0; ball_car_touch = false;
     const float r = K::BALL_RADIUS * UU2BT;
@@ -101,34 +311,19 @@ RLG_HD_NOINLINE void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList
         }
     }
     // ball vs mesh
-    float bext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
-    V3 blo = bp - v3(bext, bext, bext), bhi = bp + v3(bext, bext, bext);
-    if (!ball_asleep && mesh_maybe_near(mesh, blo, bhi)) {
-        V3 lo = blo, hi = bhi;
-        int stack[32]; int sp = 0; stack[sp++] = 0;
-        while (sp > 0) {
-            BvhNode nd = mesh_node(mesh, stack[--sp]);
-            if (!aabb_overlap(nd, lo, hi)) continue;
-            if (nd.count > 0) {
-                for (int k = 0; k < nd.count; k++) {
-                    V3 pt, n; float depth;
-                    if (!tri_aabb_overlap(mesh.tris[nd.left_or_first + k], lo, hi)) continue;  // TestTriangleAgainstAabb2 (btConvexConcaveCollisionAlgorithm.cpp:75)
-                    if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[nd.left_or_first + k], pt, n, depth)) {
-                        Contact c; c.a = 0; c.b = -1; c.n = n; c.dist = depth;
-                        c.ra = (pt + n * depth) - bp; c.rb = pt;
-                        c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
-                        push_contact(L, c);
-                    }
-                }
-            } else if (sp < 30) { stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1; }
-        }
+    if (!ball_asleep) {
+        nw.ball_mesh(A, mesh, [&](const Cand& k) {
+            Contact c; c.a = 0; c.b = -1; c.n = k.n; c.dist = k.dist;
+            c.ra = (k.pb + k.n * k.dist) - bp; c.rb = k.pb;
+            c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
+            push_contact(L, c);
+        });
     }
     // cars
     RLG_NOUNROLL
     for (int ci = 0; ci < NC; ci++) {
         Car& car = A.cars[ci];
-        if (car.flags & CF_IS_DEMOED) continue;  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
-        if (car.frozen) continue;
+        if (!car_collides(car)) continue;
         V3 h = hitbox_half();
         V3 bc = car.b.pos + car.b.rot * hitbox_off();
         Cand cs[4]; int nc = 0;
@@ -145,24 +340,7 @@ RLG_HD_NOINLINE void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList
                 if (dist < CBT_CAR) { Cand c; c.n = n; c.dist = dist; c.pb = cw - n * dist; cand_add(cs, nc, c); }
             }
         }
-        // mesh
-        {
-            M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
-                              v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
-                              v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
-            V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
-            V3 lo = bc - ext, hi = bc + ext;
-            int stack[32]; int sp = 0;
-            if (mesh_maybe_near(mesh, lo, hi)) stack[sp++] = 0;
-            while (sp > 0) {
-                BvhNode nd = mesh_node(mesh, stack[--sp]);
-                if (!aabb_overlap(nd, lo, hi)) continue;
-                if (nd.count > 0) {
-                    for (int k = 0; k < nd.count; k++)
-                        if (tri_aabb_overlap(mesh.tris[nd.left_or_first + k], lo, hi)) box_triangle(bc, car.b.rot, h, mesh.tris[nd.left_or_first + k], CBT_CAR, cs, nc);
-                } else if (sp < 30) { stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1; }
-            }
-        }
+        nw.car_mesh(A, mesh, ci, cs, nc);
         for (int k = 0; k < nc; k++) {
             Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
             c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
@@ -189,13 +367,10 @@ RLG_HD_NOINLINE void collide_all(Arena<NC>& A, const MeshView& mesh, ContactList
     for (int ia = 0; ia < NC; ia++) {
         for (int ib = ia + 1; ib < NC; ib++) {
             Car& ca = A.cars[ia]; Car& cb = A.cars[ib];
-            if ((ca.flags & CF_IS_DEMOED) || (cb.flags & CF_IS_DEMOED) || ca.frozen || cb.frozen) continue;
-            V3 h = hitbox_half();
-            V3 cca = ca.b.pos + ca.b.rot * hitbox_off(), ccb = cb.b.pos + cb.b.rot * hitbox_off();
-            float rad = len(h);
-            if (len2(cca - ccb) > (2 * rad) * (2 * rad)) continue;
+            if (!car_collides(ca) || !car_collides(cb)) continue;
+            if (!cars_maybe_touch(A, ia, ib)) continue;
             Cand cs[4]; int nc = 0;
-            box_box(cca, ca.b.rot, ccb, cb.b.rot, h, cs, nc);
+            nw.car_car(A, ia, ib, cs, nc);
             for (int k = 0; k < nc; k++) {
                 Contact c; c.a = 1 + ia; c.b = 1 + ib; c.n = cs[k].n; c.dist = cs[k].dist;
                 V3 pa = cs[k].pb + cs[k].n * cs[k].dist;
@@ -326,13 +501,34 @@ struct TickWork {
     static constexpr int MAXR = 2 * (MAXC + 1);
     ContactList<MAXC> L;
     SolverBody B[NB];
-    Row R[MAXR];
+    union {
+        Row R[MAXR];       // solver rows: built after the contact list is complete ...
+        CollideQueue Q;    // ... narrowphase items: dead by then
+    };
     CarTickCtx ctx[NC];
+    bool ball_asleep;
 };
 
-// full tick of the dynamics world for one arena
+// world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
 template <int NC>
-RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& ev, TickWork<NC>& W) {
+RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
+    const float dt = TICK_DT;
+    // ball sleep flag (Arena.cpp:721-727)
+    bool ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
+    W.ball_asleep = ball_asleep;
+    // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
+    const float g = K::GRAVITY_Z * UU2BT;
+    if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
+    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
+    // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
+    A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
+    W.Q.n_cand = 0; W.Q.n_items = 0; W.Q.n_pool = 0; W.Q.overflow = 0;
+}
+
+// world step, second part (per env): contact list, solver, integration.  `queued`: the narrowphase items of this env
+// were run through W.Q (collide_queue_body / collide_run_item); otherwise, or when the queue overflowed, run them here.
+template <int NC>
+RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     constexpr int NB = NC + 1;
@@ -340,19 +536,11 @@ RLG_HD_NOINLINE void world_step(Arena<NC>& A, const MeshView& mesh, TickEvents& 
     ContactList<MAXC>& L = W.L;
     SolverBody (&B)[NB] = W.B;
     Row (&R)[TickWork<NC>::MAXR] = W.R;
-    // ball sleep flag (Arena.cpp:721-727)
-    bool ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
-    // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
-    const float g = K::GRAVITY_Z * UU2BT;
-    if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
-    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
-    // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
-    A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
+    const bool ball_asleep = W.ball_asleep;
 
     bool touch;
-    RLG_PROF(1);
-    collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch);
-    RLG_PROF(2);
+    if (queued && !W.Q.overflow) collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowQueued{W.Q});
+    else collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowInline());
     bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 
     // ---- solver setup
@@ -510,9 +698,9 @@ RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
 // arena_tick() below runs them in loops (host build, single-lane device callers); rlgpu_env.hip runs the same phase
 // functions with one wavefront lane per work item.
 
-// phase 3, per env: boost pad cooldowns, then the dynamics world step
+// phase 3, per env: boost pad cooldowns, then the first part of the dynamics world step
 template <int NC>
-RLG_HD_NOINLINE void tick_world(Arena<NC>& A, const MeshView& mesh, TickEvents& ev, TickWork<NC>& W) {
+RLG_HD_NOINLINE void tick_world_begin(Arena<NC>& A, TickWork<NC>& W) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     RLG_PROF(0);
@@ -522,8 +710,11 @@ RLG_HD_NOINLINE void tick_world(Arena<NC>& A, const MeshView& mesh, TickEvents& 
         pd.is_active = (pd.cooldown == 0.f);
         pd.cur_locked = 0;
     }
-    world_step(A, mesh, ev, W);
+    world_step_begin(A, W);
+    RLG_PROF(0);
 }
+// (device only: phases 3a per body = collide_queue_body, 3b per item = collide_run_item)
+// phase 3c, per env: rest of the world step = world_step_finish
 
 // phase 4, per car: Car::_PostTickUpdate + _FinishPhysicsTick
 template <int NC>
@@ -578,11 +769,12 @@ RLG_HD bool car_needs_ordered_finish(const CarTickCtx& t) {
 }
 
 template <int NC>
-RLG_HD void arena_tick(Arena<NC>& A, const MeshView& mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
+RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
     for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
     for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_trace(A, i, w, mesh, W.ctx[i]);
     for (int i = 0; i < NC; i++) car_pre_tick_finish(A, i, W.ctx[i]);
-    tick_world(A, mesh, ev, W);
+    tick_world_begin(A, W);
+    world_step_finish(A, mesh, ev, W, false);
     for (int i = 0; i < NC; i++) tick_car_post(A, i);
     tick_finish(A);
 }

@@ -193,13 +193,20 @@ struct Pad {
 };
 
 // ---- static world -----------------------------------------------------------------------------------
-struct BvhNode {  // 32 B; leaf when count > 0
+// Threaded BVH: besides its children every node knows its "escape" = the node a right-child-first depth-first walk visits
+// after this node's subtree.  A walk is then `i = hit ? (leaf ? escape : right child) : escape` with no stack -- on the
+// GPU a per-lane stack is either scratch memory or (what the compiler picked) a 32-way select chain per push/pop.
+struct alignas(16) BvhNode {  // 32 B
     float minx, miny, minz;
     int32_t left_or_first;
     float maxx, maxy, maxz;
-    int32_t count;  // 0 => inner node with children left, left+1 ; >0 => leaf with `count` triangles from `left_or_first`
+    uint32_t count_escape;  // bits 0-7: 0 => inner node with children left, left+1 ; >0 => leaf with that many triangles from `left_or_first`
+                            // bits 8-31: escape node index, BVH_END when the walk is over
 };
-struct MeshTri {  // 48 B, BT units
+constexpr uint32_t BVH_END = 0xFFFFFFu;
+RLG_HD int node_count(const BvhNode& n) { return (int)(n.count_escape & 0xffu); }
+RLG_HD uint32_t node_escape(const BvhNode& n) { return n.count_escape >> 8; }
+struct alignas(16) MeshTri {  // 48 B, BT units
     float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
     uint32_t edge_flags;  // bit e (0..2): edge e (v_e -> v_{e+1}) is an internal flat/concave edge: snap edge normals to the face
     uint32_t _pad0, _pad1;

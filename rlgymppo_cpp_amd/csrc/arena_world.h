@@ -41,10 +41,15 @@ struct Contact {
 
 
 // ---- BVH access ---------------------------------------------------------------------------------------
-RLG_HD BvhNode mesh_node(const MeshView& m, int i) { return (i < m.n_fast) ? m.nodes_fast[i] : m.nodes[i]; }
+// (MeshView travels by value: behind a reference it sits in the caller's stack frame = scratch memory on the device, and
+// every node visit paid a dependent scratch round trip for `nodes_fast` before the node load itself.)
+RLG_HD BvhNode mesh_node(MeshView m, int i) {
+    if (i < m.n_fast) { RLG_ASSUME_LDS(*m.nodes_fast); return m.nodes_fast[i]; }
+    return m.nodes[i];
+}
 
 // does the box [lo,hi] touch any occupied grid cell?  (conservative: out-of-grid space counts as occupied)
-RLG_HD bool mesh_maybe_near(const MeshView& m, V3 lo, V3 hi) {
+RLG_HD bool mesh_maybe_near(MeshView m, V3 lo, V3 hi) {
     if (m.n_nodes <= 0) return false;
     if (!m.grid) return true;
     int x0 = (int)floorf((lo.x - GRID_MIN_X) * (1.f / GRID_CELL)), x1 = (int)floorf((hi.x - GRID_MIN_X) * (1.f / GRID_CELL));
@@ -52,6 +57,7 @@ RLG_HD bool mesh_maybe_near(const MeshView& m, V3 lo, V3 hi) {
     int z0 = (int)floorf((lo.z - GRID_MIN_Z) * (1.f / GRID_CELL)), z1 = (int)floorf((hi.z - GRID_MIN_Z) * (1.f / GRID_CELL));
     if (x0 < 0 || y0 < 0 || z0 < 0 || x1 >= GRID_X || y1 >= GRID_Y || z1 >= GRID_Z) return true;
     if ((x1 - x0) > 3 || (y1 - y0) > 3 || (z1 - z0) > 3) return true;
+    RLG_ASSUME_LDS(*m.grid);
     for (int z = z0; z <= z1; z++)
         for (int y = y0; y <= y1; y++)
             for (int x = x0; x <= x1; x++) {
@@ -117,7 +123,7 @@ RLG_HD void world_plane(int i, V3& n, float& d) {
 }
 
 template <int NC>
-RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, const MeshView& mesh, V3 from, V3 to) {
+RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, MeshView mesh, V3 from, V3 to) {
     RLG_ASSUME_LDS(A);
     RayHit best; best.kind = -1; best.frac = 1.0f; best.normal = v3(0, 0, 0);
     // planes
@@ -132,18 +138,20 @@ RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, const Me
     if (mesh_maybe_near(mesh, v3(fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)), v3(fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)))) {
         V3 dvec = to - from;
         V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
-        int stack[32]; int sp = 0; stack[sp++] = 0;
-        while (sp > 0) {
-            BvhNode nd = mesh_node(mesh, stack[--sp]);
-            if (!ray_aabb(nd, from, inv_d, best.frac)) continue;
-            if (nd.count > 0) {
-                for (int k = 0; k < nd.count; k++) {
-                    const MeshTri& t = mesh.tris[nd.left_or_first + k];
-                    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
-                }
-            } else if (sp < 30) {
-                stack[sp++] = nd.left_or_first; stack[sp++] = nd.left_or_first + 1;
+        uint32_t i = 0;
+        while (i != BVH_END) {
+            BvhNode nd = mesh_node(mesh, (int)i);
+            uint32_t next = node_escape(nd);
+            if (ray_aabb(nd, from, inv_d, best.frac)) {
+                const int cnt = node_count(nd);
+                if (cnt > 0) {
+                    for (int k = 0; k < cnt; k++) {
+                        const MeshTri& t = mesh.tris[nd.left_or_first + k];
+                        ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
+                    }
+                } else next = (uint32_t)nd.left_or_first + 1u;
             }
+            i = next;
         }
     }
     // ball (point vs sphere of radius 1.825)

@@ -46,6 +46,10 @@ constexpr int WAVE = 64;
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1
 #endif
+#ifndef RLG_WAVES_PER_BLOCK
+#define RLG_WAVES_PER_BLOCK 1
+#endif
+constexpr int WPB = RLG_WAVES_PER_BLOCK;   // wavefronts per workgroup: they share the staged mesh, each owns lanes_per_block / WPB envs
 constexpr int LDS_BUDGET = RLG_LDS_BUDGET;
 constexpr int LDS_NODES = RLG_LDS_NODES;   // BVH top levels staged per workgroup (the occupancy grid prunes most walks)
 
@@ -71,7 +75,7 @@ constexpr size_t lane_stride() { size_t w = (sizeof(LaneBlock<NC>) + 7) / 8; ret
 template <int NC>
 constexpr int lanes_per_block() {
     int l = 16;
-    while (l > 1 && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + GRID_WORDS * 4 > (size_t)LDS_BUDGET) l /= 2;
+    while (l > WPB && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + GRID_WORDS * 4 > (size_t)LDS_BUDGET) l /= 2;
     return l;
 }
 
@@ -116,12 +120,28 @@ __device__ __forceinline__ LaneBlock<NC>& lane_block(unsigned char* lane_mem, in
     return *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)e * lane_stride<NC>());
 }
 
-// `ev` is meaningful on env lanes (lane e < n_valid owns env e of the workgroup)
+// the envs one wavefront of the workgroup owns
+struct WaveSlot { int lane, env0, n_valid; unsigned char* mem; };
 template <int NC>
-__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, const MeshView& mv, uint32_t seed, int env0, TickEvents& ev) {
-    constexpr int LANES = lanes_per_block<NC>();
-    static_assert(LANES * NC * 4 <= WAVE, "one lane per wheel must fit the wavefront");
-    const int tid = threadIdx.x;
+__device__ __forceinline__ WaveSlot wave_slot(unsigned char* lane_mem, int n_envs) {
+    constexpr int EPW = lanes_per_block<NC>() / WPB;
+    static_assert(EPW >= 1 && EPW * WPB == lanes_per_block<NC>(), "envs per workgroup must split evenly over its wavefronts");
+    static_assert(EPW * NC * 4 <= WAVE, "one lane per wheel must fit the wavefront");
+    const int wave = threadIdx.x >> 6;
+    WaveSlot s;
+    s.lane = threadIdx.x & 63;
+    s.env0 = ((int)blockIdx.x * WPB + wave) * EPW;
+    int left = n_envs - s.env0;
+    s.n_valid = left < 0 ? 0 : (left < EPW ? left : EPW);
+    s.mem = lane_mem + (size_t)wave * EPW * lane_stride<NC>();
+    return s;
+}
+
+// `ev` is meaningful on env lanes (lane e < n_valid owns env e of the wavefront)
+template <int NC>
+__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, uint32_t seed, int env0, TickEvents& ev) {
+    constexpr int EPW = lanes_per_block<NC>() / WPB;
+    const int tid = threadIdx.x & 63;
     const int e_car = tid / NC, c_car = tid % NC;
     const int e_whl = tid / (4 * NC), c_whl = (tid >> 2) % NC, w_whl = tid & 3;
     const bool env_lane = tid < n_valid;
@@ -145,7 +165,46 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, const Mesh
         }
     }
     wave_sync();
-    if (env_lane) tick_world(Se.A, mv, ev, Se.W);
+    if (env_lane) tick_world_begin(Se.A, Se.W);
+    wave_sync();
+    {   // narrowphase (arena_step.h): lane per body lists candidates, lane per candidate tests + compacts, lane per item runs
+        constexpr int NB = NC + 1;
+        const int e_body = tid / NB, b_body = tid % NB;
+        if (e_body < n_valid) {
+            LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_body);
+            collide_queue_body(Sb.A, mv, b_body, Sb.W.ball_asleep, Sb.W.Q);
+        }
+        wave_sync();
+        RLG_PROF(1);
+        constexpr int LPE = WAVE / EPW;   // lanes that serve one env in the candidate and item phases
+        const int e_item = tid / LPE, l_item = tid % LPE;
+        const bool item_lane = e_item < n_valid;
+        LaneBlock<NC>& Si = lane_block<NC>(lane_mem, item_lane ? e_item : 0);
+        CollideQueue& Q = Si.W.Q;
+        {
+            const int n_cand = (item_lane && !Q.overflow) ? Q.n_cand : 0;
+            int base = 0;   // items of this env so far (same value on all its lanes)
+            for (int c0 = 0; __any(c0 < n_cand); c0 += LPE) {
+                const int k = c0 + l_item;
+                const bool pass = k < n_cand && collide_test_candidate(Si.A, mv, Q, k);
+                const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & ((LPE == 64) ? ~0ull : ((1ull << LPE) - 1ull));
+                if (pass) {
+                    const int pos = base + __popcll(m & ((1ull << l_item) - 1ull));
+                    if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
+                }
+                base += __popcll(m);
+            }
+            if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
+        }
+        wave_sync();
+        if (item_lane && !Q.overflow) {
+            const int n_items = Q.n_items;
+            for (int slot = l_item; slot < n_items; slot += LPE) collide_run_item(Si.A, mv, slot, Q);
+        }
+        wave_sync();
+    }
+    RLG_PROF(2);
+    if (env_lane) world_step_finish(Se.A, mv, ev, Se.W, true);
     wave_sync();
     if (car_lane) tick_car_post(Sc.A, c_car);
     wave_sync();
@@ -154,17 +213,17 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, const Mesh
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
+__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);   // all 64 threads of the wave help staging
-    const int env0 = blockIdx.x * LANES;
-    const int n_valid = min(LANES, d.n_envs - env0);
-    const bool env_lane = (int)threadIdx.x < n_valid;
-    const int env = env0 + (env_lane ? (int)threadIdx.x : 0);
-    LaneBlock<NC>& S = lane_block<NC>(lane_mem, env_lane ? (int)threadIdx.x : 0);
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);   // every thread of the workgroup helps staging
+    const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
+    unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
+    const bool env_lane = ws.lane < n_valid;
+    const int env = env0 + (env_lane ? ws.lane : 0);
+    LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
     const int D = obs_size<NC>();
     GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
@@ -176,10 +235,10 @@ __global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d,
     }
     wave_sync();
     TickEvents ev; ev.bump_mask = 0;
-    arena_tick_wave<NC>(lane_mem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
+    arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
     if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
     wave_sync();
-    for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(lane_mem, n_valid, mv, seed, env0, ev2); }
+    for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
     if (env_lane) {
         gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, X);
         for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
@@ -204,28 +263,28 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
 // physics only (rlgpu_env_physics_ticks); with `stamps` (diagnostics, rlgpu_env_debug_tick_cycles) also per workgroup the shader
 // cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime) spent in the tick loop, plus the RLG_TICK_PROFILE phase buckets
 template <int NC>
-__global__ void __launch_bounds__(WAVE, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
+__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
-    const int env0 = blockIdx.x * LANES;
-    const int n_valid = min(LANES, d.n_envs - env0);
-    const bool env_lane = (int)threadIdx.x < n_valid;
-    const int env = env0 + (env_lane ? (int)threadIdx.x : 0);
-    LaneBlock<NC>& S = lane_block<NC>(lane_mem, env_lane ? (int)threadIdx.x : 0);
+    const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
+    unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
+    const bool env_lane = ws.lane < n_valid;
+    const int env = env0 + (env_lane ? ws.lane : 0);
+    LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     if (env_lane) load_env(d, env, S.A, S.G);
     wave_sync();
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(lane_mem, n_valid, mv, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (env_lane) store_env(d, env, S.A, S.G);
     if (stamps && threadIdx.x == 0) {
-        unsigned long long* o = stamps + 10 * (size_t)blockIdx.x;
+        unsigned long long* o = stamps + 10 * (size_t)blockIdx.x;  // wave 0 of the workgroup reports
         o[0] = c1 - c0; o[1] = r1 - r0;
 #ifdef RLG_TICK_PROFILE
         for (int i = 0; i < 8; i++) o[2 + i] = g_prof[i];
@@ -455,7 +514,7 @@ int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
 int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     if (!actions || !next_obs || !reward || !done) { e->err = "rlgpu_env_step: null device pointer"; return RLGPU_ERR_ARG; }
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
     if (e->ev_used == e->ev_pool.size()) {
         if (e->ev_pool.size() < 2048) {
             hipEvent_t a, b; HIPCHK(e, hipEventCreate(&a)); HIPCHK(e, hipEventCreate(&b));
@@ -483,7 +542,7 @@ int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out
     if (nb > cap_pairs) return RLGPU_ERR_ARG;
     unsigned long long* dbuf = nullptr;
     HIPCHK(e, hipMalloc(&dbuf, sizeof(unsigned long long) * 10 * nb));
-    dim3 grid(nb), block(WAVE);
+    dim3 grid(nb), block(WAVE * WPB);
     DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks, dbuf);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -494,7 +553,7 @@ int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out
 
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
     DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks, (unsigned long long*)nullptr);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;

@@ -28,7 +28,7 @@ def run(label):
           f"us/tick mean {us.mean()/ticks:.1f} max {us.max()/ticks:.1f}  clock MHz {np.median(cyc/us):.0f}")
     ph = b[:, 2:].mean(axis=0) / ticks
     if ph.sum() > 0:
-        names = ["car_pre_tick", "gravity/damp", "collide_all", "solver setup", "solver iters", "integrate", "post/pads/ball", "wheel ray casts"]
+        names = ["car pre-tick+pads/gravity", "narrowphase walk", "narrowphase items", "contacts+solver setup", "solver iters", "integrate", "post/pads/ball", "wheel ray casts"]
         print("   phases (cycles/tick, mean over blocks): " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, ph) if v > 0))
         worst = int(np.argmax(cyc))
         print("   slowest block: " + ", ".join(f"{n} {v/ticks:.0f}" for n, v in zip(names, b[worst, 2:]) if v > 0))
