@@ -51,6 +51,8 @@ __device__ __forceinline__ short f2bf(float f) {
     return *reinterpret_cast<short*>(&h);
 }
 
+__device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((uint32_t)(uint16_t)s) << 16); }
+
 // C[M x N] = A[M x K] . B[K x N] on MFMA. 4 waves per block, each wave owns 32 rows x 64 cols of the 128 x 64 tile.
 template <bool BF16>
 __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
@@ -149,15 +151,256 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
     }
 }
 
-// column sums: out[n] += sum_m X[m][n]
-__global__ void k_col_sum(const float* X, int ld, int M, int N, float* out) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    int rows_per = (M + gridDim.y - 1) / gridDim.y;
-    int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+// =====================================================================================================================
+// bf16 fast path (use_bf16): activations, their gradients and shadow copies of the weights live in HBM as bf16, padded so
+// that every reduction dimension is a multiple of 32 and every operand row is 16-byte aligned; fp32 master weights, fp32
+// accumulation, fp32 logits / values / dW.  Two GEMM kernels cover the MLP:
+//   k_gemm_nt  C[M x N]  = A[M x K] . B[N x K]^T   both operands K-contiguous (forward with W, dX with the W^T shadow)
+//   k_gemm_tn  dW[Mo x No] += Y[R x Mo]^T . X[R x No]  both operands row(R)-major: the reduction runs DOWN the rows, so the
+//              MFMA operands are gathered with ds_read_b64_tr_b16 (gfx950 transposing LDS read, cdna_hip_programming.md T10)
+// =====================================================================================================================
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+constexpr int FBK = 32;          // K step of both kernels
+constexpr int NT_LD = FBK + 8;   // LDS row of the NT tiles: 80 B -> the 16 rows of a ds_read_b128 group land on distinct bank quads
+
+struct NtArgs {
+    const short* A; int lda;     // [M][lda] bf16, lda = K (multiple of 32), zero padded
+    const short* B; int ldb;     // [>= gridDim.x * BN][ldb] bf16, zero padded rows and columns
+    int M, N, K;
+    const float* bias;           // EPI 0/1
+    short* C16; int ldc16;       // EPI 0/2: bf16 out, columns N..ldc16 written as zeros
+    float* C32; int ldc32;       // EPI 1
+    const short* mask16; int ldm;  // EPI 2: C = mask > 0 ? acc : 0
+};
+
+// EPI 0: C16 = relu(acc + bias)   EPI 1: C32 = acc + bias   EPI 2: C16 = mask16 > 0 ? acc : 0
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ void __launch_bounds__(256) k_gemm_nt(NtArgs g) {
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_CH = (BM * 4 + 255) / 256, B_CH = (BN * 4 + 255) / 256;   // 16-byte chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) short As[BM * NT_LD];
+    __shared__ __attribute__((aligned(16))) short Bs[BN * NT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    uint4 ra[A_CH], rb[B_CH];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < A_CH; j++) {
+            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            ra[j] = make_uint4(0, 0, 0, 0);
+            if (idx < BM * 4 && m0 + row < g.M) ra[j] = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + ch * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; j++) {
+            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            rb[j] = make_uint4(0, 0, 0, 0);
+            if (idx < BN * 4) rb[j] = *reinterpret_cast<const uint4*>(g.B + (size_t)(n0 + row) * g.ldb + k0 + ch * 8);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_CH; j++) {
+            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            if (idx < BM * 4) *reinterpret_cast<uint4*>(&As[row * NT_LD + ch * 8]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; j++) {
+            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            if (idx < BN * 4) *reinterpret_cast<uint4*>(&Bs[row * NT_LD + ch * 8]) = rb[j];
+        }
+    };
+
+    load_tiles(0);
+    for (int k0 = 0; k0 < g.K; k0 += FBK) {
+        store_tiles();
+        __syncthreads();
+        if (k0 + FBK < g.K) load_tiles(k0 + FBK);   // next tile's global loads fly under this tile's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < FBK; ks += 16) {
+            // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7
+            const int kk = ks + 8 * (lane >> 5);
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * TM + i) * 32 + (lane & 31)) * NT_LD + kk]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * TN + j) * 32 + (lane & 31)) * NT_LD + kk]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+            float bias = 0.f;
+            if (EPI != 2 && g.bias && gn < g.N) bias = g.bias[gn];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gm >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (EPI == 0) {
+                    if (gn < g.ldc16) g.C16[(size_t)gm * g.ldc16 + gn] = (gn < g.N) ? f2bf(fmaxf(v, 0.f)) : (short)0;
+                } else if (EPI == 1) {
+                    if (gn < g.N) g.C32[(size_t)gm * g.ldc32 + gn] = v;
+                } else {
+                    if (gn < g.ldc16) {
+                        short o = 0;
+                        if (gn < g.N && bf2f(g.mask16[(size_t)gm * g.ldm + gn]) > 0.f) o = f2bf(v);
+                        g.C16[(size_t)gm * g.ldc16 + gn] = o;
+                    }
+                }
+            }
+        }
+}
+
+struct TnArgs {
+    const short* Y; int ldy;     // [R][ldy] bf16: dL/d(layer output), columns Mo..ldy zero
+    const short* X; int ldx;     // [R][ldx] bf16: layer input, columns No..ldx zero
+    int R, Mo, No;
+    float* dW; int ldw;          // [Mo][ldw] fp32, += with atomics
+    float* db;                   // [Mo] fp32, += column sums of Y
+    int slab;                    // rows per blockIdx.z
+};
+constexpr int TN_LD = 160;       // LDS row (elements) of the 128-wide k-major tiles: 320 B = 16 banks (mod 64) per k row, so
+                                 // the 4 rows x 4 column-quads x 2 groups of a transposing read hit 64 distinct banks
+
+__device__ __forceinline__ bf16x8 tr_operand(const short* S, int k16, int col0, int lane) {
+    // 32 (cols) x 16 (k) MFMA operand out of a k-major LDS tile: per 16-lane group a 4(k) x 16(col) block, delivered
+    // column-major; lane 4q+p of the group supplies the address of block row q, columns 4p..4p+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int kb = k16 + 8 * (g >> 1), cb = col0 + 16 * (g & 1) + 4 * p;
+    using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(S + (kb + q) * TN_LD + cb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(S + (kb + 4 + q) * TN_LD + cb));
+    bf16x8 r; r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_gemm_tn(TnArgs g) {
+    __shared__ __attribute__((aligned(16))) short Ys[FBK * TN_LD];
+    __shared__ __attribute__((aligned(16))) short Xs[FBK * TN_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int r_begin = blockIdx.z * g.slab, r_end = min(g.R, r_begin + g.slab);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = (blockIdx.x == 0) && g.db;
+
+    uint4 ry[2], rx[2];
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int idx = tid + j * 256, row = idx >> 4, ch = idx & 15;
+            int gr = r0 + row, cy = m0 + ch * 8, cx = n0 + ch * 8;
+            ry[j] = make_uint4(0, 0, 0, 0); rx[j] = make_uint4(0, 0, 0, 0);
+            if (gr < r_end) {
+                if (cy < g.ldy) ry[j] = *reinterpret_cast<const uint4*>(g.Y + (size_t)gr * g.ldy + cy);
+                if (cx < g.ldx) rx[j] = *reinterpret_cast<const uint4*>(g.X + (size_t)gr * g.ldx + cx);
+            }
+        }
+    };
+    load_tiles(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += FBK) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int idx = tid + j * 256, row = idx >> 4, ch = idx & 15;
+            *reinterpret_cast<uint4*>(&Ys[row * TN_LD + ch * 8]) = ry[j];
+            *reinterpret_cast<uint4*>(&Xs[row * TN_LD + ch * 8]) = rx[j];
+        }
+        __syncthreads();
+        if (r0 + FBK < r_end) load_tiles(r0 + FBK);
+        if (do_bias && tid < 128) {
+#pragma unroll 8
+            for (int k = 0; k < FBK; k++) bsum += bf2f(Ys[k * TN_LD + tid]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < FBK; ks += 16) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = tr_operand(Ys, ks, (wm * 2 + i) * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = tr_operand(Xs, ks, (wn * 2 + j) * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int gn = n0 + (wn * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int gm = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gm < g.Mo && gn < g.No) atomicAdd(&g.dW[(size_t)gm * g.ldw + gn], acc[i][j][r]);
+            }
+        }
+    if (do_bias && tid < 128 && m0 + tid < g.Mo) atomicAdd(&g.db[m0 + tid], bsum);
+}
+
+// fp32 rows (optionally gathered through idx) -> bf16 rows padded with zeros to ld16 columns
+__global__ void k_rows_to_bf16(const float* src, const int32_t* idx, int rows, int D, short* dst, int ld16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * ld16) return;
+    int r = (int)(i / ld16), c = (int)(i % ld16);
+    float v = 0.f;
+    if (c < D) v = src[(size_t)(idx ? idx[r] : r) * D + c];
+    dst[i] = f2bf(v);
+}
+
+// bf16 shadows of one Linear layer's fp32 master weight W[N][K]:  w16[rows16][ld16] = W (zero padded),  wt16[rowst][ldt] = W^T
+__global__ void k_weight_shadows(const float* W, int N, int K, short* w16, int rows16, int ld16, short* wt16, int rowst, int ldt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n1 = (size_t)rows16 * ld16, n2 = (size_t)rowst * ldt;
+    if (i < n1) {
+        int r = (int)(i / ld16), c = (int)(i % ld16);
+        w16[i] = (r < N && c < K) ? f2bf(W[(size_t)r * K + c]) : (short)0;
+    } else if (i < n1 + n2) {
+        size_t j = i - n1;
+        int r = (int)(j / ldt), c = (int)(j % ldt);
+        wt16[j] = (r < K && c < N) ? f2bf(W[(size_t)c * K + r]) : (short)0;
+    }
+}
+
+// column sums: out[n] += sum_m X[m][n]  (fp32 path; the bf16 path folds them into k_gemm_tn)
+__global__ void __launch_bounds__(256) k_col_sum(const float* X, int ld, int M, int N, float* out) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
     float s = 0.f;
-    for (int m = m0; m < m1; m++) s += X[(size_t)m * ld + n];
-    atomicAdd(&out[n], s);
+    if (n < N) for (int m = m0 + rg; m < m1; m += 4) s += X[(size_t)m * ld + n];
+    part[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) atomicAdd(&out[n], part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
@@ -239,70 +482,82 @@ __global__ void k_gae(const float* rews, const float* dones, const float* truncs
     }
 }
 
-// fused PPO policy loss + gradient wrt logits; one wave per row. (PPOLearner.cpp:148-198, DiscretePolicy.cpp:64-75)
-// metrics: [0] entropy sum, [1] KL sum, [2] clip count, [3] ratio sum (per-row sums; host divides)
-__global__ void k_ppo_policy_loss(const float* logits, int ld, int rows, int A, float inv_temp, const int32_t* actions, const float* old_logp,
-                                  const float* adv, const int32_t* idx, float clip, float ent_coef, float scale /* ratio / rows */,
-                                  float* dlogits, float* metrics) {
-    int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    int src = idx ? idx[row] : row;
-    const float* z = logits + (size_t)row * ld;
-    float v0 = lane < A ? z[lane] * inv_temp : -INFINITY, v1 = (lane + 64) < A ? z[lane + 64] * inv_temp : -INFINITY;
-    float mx = wave_max(fmaxf(v0, v1));
-    float e0 = lane < A ? expf(v0 - mx) : 0.f, e1 = (lane + 64) < A ? expf(v1 - mx) : 0.f;
-    float sum = wave_sum(e0 + e1);
-    float s0 = e0 / sum, s1 = e1 / sum;
-    float p0 = fminf(fmaxf(s0, 1e-11f), 1.f), p1 = fminf(fmaxf(s1, 1e-11f), 1.f);
-    float lp0 = logf(p0), lp1 = logf(p1);
-    float ent = wave_sum((lane < A ? -lp0 * p0 : 0.f) + ((lane + 64) < A ? -lp1 * p1 : 0.f));
-    int a = actions[src];
-    float logp_a = (a < 64) ? __shfl(lp0, a, 64) : __shfl(lp1, a - 64, 64);
-    float p_a = (a < 64) ? __shfl(p0, a, 64) : __shfl(p1, a - 64, 64);
-    float olp = old_logp[src], ad = adv[src];
-    float ratio = expf(logp_a - olp);
-    float clipped = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
-    float surr1 = ratio * ad, surr2 = clipped * ad;
-    // d(-min(surr1,surr2))/d logp : torch.min splits ties, and inside the clip range surr2 carries the other half
-    float g_logp;
-    bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
-    if (inside) g_logp = -(ad * ratio);
-    else if (surr1 < surr2) g_logp = -(ad * ratio);
-    else if (surr1 == surr2) g_logp = -(ad * ratio) * 0.5f;
-    else g_logp = 0.f;
-    // gradient wrt clamped probs p_i:  logp_a -> 1/p_a ; -ent_coef * H -> ent_coef * (log p_i + 1)
-    float g0 = (lane < A) ? ent_coef * (lp0 + 1.f) : 0.f, g1 = ((lane + 64) < A) ? ent_coef * (lp1 + 1.f) : 0.f;
-    if (lane == a) g0 += g_logp / p_a;
-    if (lane + 64 == a) g1 += g_logp / p_a;
-    // clamp backward: passes where 1e-11 <= s <= 1
-    if (!(s0 >= 1e-11f && s0 <= 1.f)) g0 = 0.f;
-    if (!(s1 >= 1e-11f && s1 <= 1.f)) g1 = 0.f;
-    float dotgs = wave_sum(g0 * s0 + g1 * s1);
-    float dz0 = s0 * (g0 - dotgs) * inv_temp * scale, dz1 = s1 * (g1 - dotgs) * inv_temp * scale;
-    if (lane < A) dlogits[(size_t)row * ld + lane] = dz0;
-    if (lane + 64 < A) dlogits[(size_t)row * ld + lane + 64] = dz1;
-    if (metrics && lane == 0) {
+// fused PPO policy loss + gradient wrt logits; one wave per row, grid-stride over rows. (PPOLearner.cpp:148-198, DiscretePolicy.cpp:64-75)
+// metrics: [0] entropy sum, [1] KL sum, [2] clip count, [3] ratio sum (per-row sums; host divides).  Each wave keeps its
+// sums in registers, the workgroup folds them in LDS and issues ONE atomic per metric (65536 rows x 4 same-address atomics
+// cost 3.3 ms before).  dlogits goes out as fp32 [rows][ld] or, when d16 is set, as bf16 [rows][ld16] (zero padded).
+__global__ void __launch_bounds__(256) k_ppo_policy_loss(const float* logits, int ld, int rows, int A, float inv_temp, const int32_t* actions, const float* old_logp,
+                                                         const float* adv, const int32_t* idx, float clip, float ent_coef, float scale /* ratio / rows */,
+                                                         float* dlogits, short* d16, int ld16, float* metrics) {
+    __shared__ float red[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m_ent = 0.f, m_kl = 0.f, m_clip = 0.f, m_ratio = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        int src = idx ? idx[row] : row;
+        const float* z = logits + (size_t)row * ld;
+        float v0 = lane < A ? z[lane] * inv_temp : -INFINITY, v1 = (lane + 64) < A ? z[lane + 64] * inv_temp : -INFINITY;
+        float mx = wave_max(fmaxf(v0, v1));
+        float e0 = lane < A ? expf(v0 - mx) : 0.f, e1 = (lane + 64) < A ? expf(v1 - mx) : 0.f;
+        float sum = wave_sum(e0 + e1);
+        float s0 = e0 / sum, s1 = e1 / sum;
+        float p0 = fminf(fmaxf(s0, 1e-11f), 1.f), p1 = fminf(fmaxf(s1, 1e-11f), 1.f);
+        float lp0 = logf(p0), lp1 = logf(p1);
+        float ent = wave_sum((lane < A ? -lp0 * p0 : 0.f) + ((lane + 64) < A ? -lp1 * p1 : 0.f));
+        int a = actions[src];
+        float logp_a = (a < 64) ? __shfl(lp0, a, 64) : __shfl(lp1, a - 64, 64);
+        float p_a = (a < 64) ? __shfl(p0, a, 64) : __shfl(p1, a - 64, 64);
+        float olp = old_logp[src], ad = adv[src];
+        float ratio = expf(logp_a - olp);
+        float clipped = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        float surr1 = ratio * ad, surr2 = clipped * ad;
+        // d(-min(surr1,surr2))/d logp : torch.min splits ties, and inside the clip range surr2 carries the other half
+        float g_logp;
+        bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+        if (inside) g_logp = -(ad * ratio);
+        else if (surr1 < surr2) g_logp = -(ad * ratio);
+        else if (surr1 == surr2) g_logp = -(ad * ratio) * 0.5f;
+        else g_logp = 0.f;
+        // gradient wrt clamped probs p_i:  logp_a -> 1/p_a ; -ent_coef * H -> ent_coef * (log p_i + 1)
+        float g0 = (lane < A) ? ent_coef * (lp0 + 1.f) : 0.f, g1 = ((lane + 64) < A) ? ent_coef * (lp1 + 1.f) : 0.f;
+        if (lane == a) g0 += g_logp / p_a;
+        if (lane + 64 == a) g1 += g_logp / p_a;
+        // clamp backward: passes where 1e-11 <= s <= 1
+        if (!(s0 >= 1e-11f && s0 <= 1.f)) g0 = 0.f;
+        if (!(s1 >= 1e-11f && s1 <= 1.f)) g1 = 0.f;
+        float dotgs = wave_sum(g0 * s0 + g1 * s1);
+        float dz0 = s0 * (g0 - dotgs) * inv_temp * scale, dz1 = s1 * (g1 - dotgs) * inv_temp * scale;
+        if (d16) {
+            if (lane < ld16) d16[(size_t)row * ld16 + lane] = lane < A ? f2bf(dz0) : (short)0;
+            if (lane + 64 < ld16) d16[(size_t)row * ld16 + lane + 64] = (lane + 64) < A ? f2bf(dz1) : (short)0;
+        } else {
+            if (lane < A) dlogits[(size_t)row * ld + lane] = dz0;
+            if (lane + 64 < A) dlogits[(size_t)row * ld + lane + 64] = dz1;
+        }
         float lr = logp_a - olp;
-        atomicAdd(&metrics[0], ent);
-        atomicAdd(&metrics[1], (expf(lr) - 1.f) - lr);
-        atomicAdd(&metrics[2], fabsf(ratio - 1.f) > clip ? 1.f : 0.f);
-        atomicAdd(&metrics[3], ratio);
+        m_ent += ent; m_kl += (expf(lr) - 1.f) - lr; m_clip += fabsf(ratio - 1.f) > clip ? 1.f : 0.f; m_ratio += ratio;
     }
+    if (!metrics) return;
+    if (lane == 0) { red[wave][0] = m_ent; red[wave][1] = m_kl; red[wave][2] = m_clip; red[wave][3] = m_ratio; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&metrics[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// value loss gradient: dL/dv = 2 (v - target) * scale ; metric[4] += (v-target)^2
-__global__ void k_value_loss(const float* v, const float* targets, const int32_t* idx, int rows, float scale, float* dv, float* metrics) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// value loss gradient: dL/dv = 2 (v - target) * scale ; metric[4] += (v-target)^2.  dv as fp32 [rows] or bf16 [rows][ld16] (column 0)
+__global__ void __launch_bounds__(256) k_value_loss(const float* v, const float* targets, const int32_t* idx, int rows, float scale, float* dv, short* d16, int ld16, float* metrics) {
+    __shared__ float red[4];
     float sq = 0.f;
-    if (i < rows) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
         int src = idx ? idx[i] : i;
         float d = v[i] - targets[src];
-        dv[i] = 2.f * d * scale;
-        sq = d * d;
+        float gr = 2.f * d * scale;
+        if (d16) { for (int c = 0; c < ld16; c++) d16[(size_t)i * ld16 + c] = c == 0 ? f2bf(gr) : (short)0; }
+        else dv[i] = gr;
+        sq += d * d;
     }
     sq = wave_sum(sq);
-    if (metrics && (threadIdx.x & 63) == 0 && sq != 0.f) atomicAdd(&metrics[4], sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (metrics && threadIdx.x == 0) atomicAdd(&metrics[4], red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ void k_gather_rows(const float* src, const int32_t* idx, int rows, int D, float* dst) {
@@ -340,6 +595,10 @@ struct Net {
     int dims[10] = {0};            // dims[0] = in, dims[n_layers] = out
     int64_t w_off[9] = {0}, b_off[9] = {0};
     int64_t n_params = 0;
+    // bf16 fast path: padded leading dims and the offsets (in elements) of the weight shadows inside rlgpu_learner::shadows
+    int kp[10] = {0};              // kp[i] = round_up(dims[i], 32): leading dim of layer i's bf16 input / of its gradient
+    int64_t w16_off[9] = {0}, wt16_off[9] = {0};
+    int w16_rows[9] = {0}, wt16_rows[9] = {0};   // row counts padded to the 128-wide N tile
 };
 
 }  // namespace
@@ -354,6 +613,11 @@ struct rlgpu_learner {
     // scratch: activations per net [max_rows x width]
     std::vector<float*> act_p, act_c;  // act[i] = output of layer i (post-ReLU for hidden), act_p.back() = logits
     float *dbuf0 = nullptr, *dbuf1 = nullptr, *gathered = nullptr, *norm_buf = nullptr;
+    // bf16 fast path (cfg.use_bf16)
+    short* shadows = nullptr; int64_t n_shadow = 0; bool shadows_dirty = true;
+    short* x16 = nullptr;                       // [max_rows][kp[0]] network input
+    std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
+    short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
     uint32_t call_ctr = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -436,7 +700,7 @@ int net_backward(rlgpu_learner* l, const Net& net, const std::vector<float*>& ac
             if (rc) return rc;
         }
         {
-            dim3 grid((N_out + 63) / 64, std::min(64, (rows + 255) / 256)), block(64);
+            dim3 grid((N_out + 63) / 64, std::max(1, std::min(1024, rows / 64))), block(256);
             hipLaunchKernelGGL(k_col_sum, grid, block, 0, l->stream, (const float*)cur, N_out, rows, N_out, l->grads + net.b_off[i]);
             LCHK(l, hipGetLastError());
         }
@@ -451,6 +715,108 @@ int net_backward(rlgpu_learner* l, const Net& net, const std::vector<float*>& ac
             g.mask = acts[i - 1]; g.ldmask = K_in;
             g.k_chunk = g.K;
             int rc = launch_gemm(l, g, 1);
+            if (rc) return rc;
+            cur = nxt;
+        }
+    }
+    return RLGPU_OK;
+}
+
+// ---- bf16 fast path, host side ------------------------------------------------------------------------------------
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void plan_shadows(Net& n, int64_t& off) {
+    for (int i = 0; i <= n.n_layers; i++) n.kp[i] = round_up(n.dims[i], 32);
+    for (int i = 0; i < n.n_layers; i++) {
+        n.w16_rows[i] = round_up(n.dims[i + 1], 128);   // B operand of the forward GEMM: [N padded][kp[i]]
+        n.w16_off[i] = off; off += (int64_t)n.w16_rows[i] * n.kp[i];
+        n.wt16_rows[i] = round_up(n.dims[i], 128);      // B operand of the dX GEMM: W^T as [K_in padded][kp[i+1]]
+        n.wt16_off[i] = off; off += (int64_t)n.wt16_rows[i] * n.kp[i + 1];
+    }
+}
+
+int refresh_shadows(rlgpu_learner* l) {
+    if (!l->shadows_dirty) return RLGPU_OK;
+    for (const Net* n : {&l->pol, &l->cri}) {
+        for (int i = 0; i < n->n_layers; i++) {
+            size_t tot = (size_t)n->w16_rows[i] * n->kp[i] + (size_t)n->wt16_rows[i] * n->kp[i + 1];
+            hipLaunchKernelGGL(k_weight_shadows, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
+                               l->shadows + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
+            LCHK(l, hipGetLastError());
+        }
+    }
+    l->shadows_dirty = false;
+    return RLGPU_OK;
+}
+
+template <int EPI>
+int launch_nt(rlgpu_learner* l, NtArgs g, int real_k) {
+    if (g.N > 32 || EPI == 2) {
+        dim3 grid((std::max(g.N, EPI == 1 ? g.N : g.ldc16) + 127) / 128, (g.M + 127) / 128);
+        hipLaunchKernelGGL((k_gemm_nt<2, 2, 2, 2, EPI>), grid, dim3(256), 0, l->stream, g);
+    } else {
+        dim3 grid(1, (g.M + 127) / 128);
+        hipLaunchKernelGGL((k_gemm_nt<4, 1, 1, 1, EPI>), grid, dim3(256), 0, l->stream, g);
+    }
+    LCHK(l, hipGetLastError());
+    l->last_flops += 2.0 * g.M * g.N * real_k;
+    return RLGPU_OK;
+}
+
+// x fp32 [rows][D] (rows optionally gathered through idx) -> l->x16
+int stage_input16(rlgpu_learner* l, const float* x, const int32_t* idx, int rows) {
+    const int D = l->cfg.obs_size, ld = l->pol.kp[0];
+    size_t tot = (size_t)rows * ld;
+    hipLaunchKernelGGL(k_rows_to_bf16, dim3((tot + 255) / 256), dim3(256), 0, l->stream, x, idx, rows, D, l->x16, ld);
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+
+// forward through `net` from l->x16; hidden activations -> acts16[i] (bf16), last layer -> out32 (fp32, ld = out dim)
+int net_forward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, float* out32, int rows) {
+    int rc = refresh_shadows(l);
+    if (rc) return rc;
+    const short* in = l->x16;
+    for (int i = 0; i < net.n_layers; i++) {
+        const bool last = (i == net.n_layers - 1);
+        NtArgs g{};
+        g.A = in; g.lda = net.kp[i];
+        g.B = l->shadows + net.w16_off[i]; g.ldb = net.kp[i];
+        g.M = rows; g.N = net.dims[i + 1]; g.K = net.kp[i];
+        g.bias = l->params + net.b_off[i];
+        if (last) { g.C32 = out32; g.ldc32 = net.dims[i + 1]; rc = launch_nt<1>(l, g, net.dims[i]); }
+        else { g.C16 = acts16[i]; g.ldc16 = net.kp[i + 1]; rc = launch_nt<0>(l, g, net.dims[i]); in = acts16[i]; }
+        if (rc) return rc;
+    }
+    return RLGPU_OK;
+}
+
+// backward: dout16 = dL/d(last layer output) as bf16 [rows][kp[L]] (zero padded); accumulates dW / db into l->grads
+int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, int rows, short* dout16) {
+    short* cur = dout16;
+    for (int i = net.n_layers - 1; i >= 0; i--) {
+        const short* in = (i == 0) ? l->x16 : acts16[i - 1];
+        const int K_in = net.dims[i], N_out = net.dims[i + 1];
+        {
+            TnArgs t{};
+            t.Y = cur; t.ldy = net.kp[i + 1]; t.X = in; t.ldx = net.kp[i];
+            t.R = rows; t.Mo = N_out; t.No = K_in;
+            t.dW = l->grads + net.w_off[i]; t.ldw = K_in; t.db = l->grads + net.b_off[i];
+            t.slab = 512;
+            dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
+            hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, l->stream, t);
+            LCHK(l, hipGetLastError());
+            l->last_flops += 2.0 * N_out * K_in * (double)rows;
+        }
+        if (i > 0) {
+            short* nxt = (cur == l->g16a) ? l->g16b : l->g16a;
+            NtArgs g{};
+            g.A = cur; g.lda = net.kp[i + 1];
+            g.B = l->shadows + net.wt16_off[i]; g.ldb = net.kp[i + 1];
+            g.M = rows; g.N = K_in; g.K = net.kp[i + 1];
+            g.C16 = nxt; g.ldc16 = net.kp[i];
+            g.mask16 = acts16[i - 1]; g.ldm = net.kp[i];
+            int rc = launch_nt<2>(l, g, N_out);
             if (rc) return rc;
             cur = nxt;
         }
@@ -498,6 +864,19 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
     LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
     LCHK(l, hipMalloc(&l->norm_buf, 16));
+    if (cfg->use_bf16) {
+        int64_t soff = 0;
+        plan_shadows(l->pol, soff); plan_shadows(l->cri, soff);
+        l->n_shadow = soff;
+        LCHK(l, hipMalloc(&l->shadows, soff * 2));
+        int maxkp = l->pol.kp[0];
+        for (const Net* n : {&l->pol, &l->cri}) for (int i = 0; i <= n->n_layers; i++) maxkp = std::max(maxkp, n->kp[i]);
+        LCHK(l, hipMalloc(&l->x16, R * l->pol.kp[0] * 2));
+        for (int i = 0; i + 1 < l->pol.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->pol.kp[i + 1] * 2)); l->act16_p.push_back(p); }
+        for (int i = 0; i + 1 < l->cri.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->cri.kp[i + 1] * 2)); l->act16_c.push_back(p); }
+        LCHK(l, hipMalloc(&l->g16a, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16b, R * maxkp * 2));
+        l->shadows_dirty = true;
+    }
     return RLGPU_OK;
 }
 
@@ -507,6 +886,9 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
+    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
+    for (short* p : l->act16_p) (void)hipFree(p);
+    for (short* p : l->act16_c) (void)hipFree(p);
     for (auto& p : l->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete l;
 }
@@ -525,7 +907,7 @@ int rlgpu_learner_get_params(rlgpu_learner* l, int which, float* host) {
 int rlgpu_learner_set_params(rlgpu_learner* l, int which, const float* host) {
     int64_t off, n; seg(l, which, off, n); LCHK(l, hipSetDevice(l->device));
     LCHK(l, hipStreamSynchronize(l->stream));
-    LCHK(l, hipMemcpy(l->params + off, host, n * 4, hipMemcpyHostToDevice)); return RLGPU_OK;
+    LCHK(l, hipMemcpy(l->params + off, host, n * 4, hipMemcpyHostToDevice)); l->shadows_dirty = true; return RLGPU_OK;
 }
 int rlgpu_learner_get_grads(rlgpu_learner* l, int which, float* host) {
     int64_t off, n; seg(l, which, off, n); LCHK(l, hipSetDevice(l->device));
@@ -533,7 +915,7 @@ int rlgpu_learner_get_grads(rlgpu_learner* l, int which, float* host) {
     LCHK(l, hipMemcpy(host, l->grads + off, n * 4, hipMemcpyDeviceToHost)); return RLGPU_OK;
 }
 int rlgpu_learner_grad_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->grads; *n = l->n_total; return RLGPU_OK; }
-int rlgpu_learner_param_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->params; *n = l->n_total; return RLGPU_OK; }
+int rlgpu_learner_param_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->params; *n = l->n_total; l->shadows_dirty = true; /* the caller may write (broadcast) */ return RLGPU_OK; }
 int rlgpu_learner_get_adam_state(rlgpu_learner* l, float* hm, float* hv, int64_t* sp, int64_t* sc) {
     LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream));
     if (hm) LCHK(l, hipMemcpy(hm, l->adam_m, l->n_total * 4, hipMemcpyDeviceToHost));
@@ -550,7 +932,9 @@ int rlgpu_learner_set_adam_state(rlgpu_learner* l, const float* hm, const float*
 static int policy_head(rlgpu_learner* l, const float* obs, int rows, int deterministic, const float* noise, int32_t* actions, float* logp, float* probs) {
     if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
-    int rc = net_forward(l, l->pol, l->act_p, obs, rows);
+    int rc;
+    if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), rows); }
+    else rc = net_forward(l, l->pol, l->act_p, obs, rows);
     if (rc) return rc;
     int A = l->cfg.n_actions;
     dim3 grid((rows + 3) / 4), block(256);
@@ -570,7 +954,9 @@ int rlgpu_policy_probs(rlgpu_learner* l, const float* obs, int rows, float* prob
 int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* values) {
     if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
-    int rc = net_forward(l, l->cri, l->act_c, obs, rows);
+    int rc;
+    if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), rows); }
+    else rc = net_forward(l, l->cri, l->act_c, obs, rows);
     if (rc) return rc;
     LCHK(l, hipMemcpyAsync(values, l->act_c.back(), (size_t)rows * 4, hipMemcpyDeviceToDevice, l->stream));
     return RLGPU_OK;
@@ -596,8 +982,12 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     if (n <= 0 || n > l->cfg.max_rows) { l->err = "minibatch rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
     const int D = l->cfg.obs_size, A = l->cfg.n_actions;
+    const bool fast = l->cfg.use_bf16 != 0;
     const float* x = obs;
-    if (idx) {
+    int rc;
+    if (fast) {
+        if ((rc = stage_input16(l, obs, idx, n))) return rc;   // gather + bf16 conversion in one pass
+    } else if (idx) {
         size_t tot = (size_t)n * D;
         hipLaunchKernelGGL(k_gather_rows, dim3((tot + 255) / 256), dim3(256), 0, l->stream, obs, idx, n, D, l->gathered);
         LCHK(l, hipGetLastError());
@@ -616,27 +1006,39 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     const size_t ev_slot = l->ev_used++;
     l->ev0 = l->ev_pool[ev_slot].first; l->ev1 = l->ev_pool[ev_slot].second;
     LCHK(l, hipEventRecord(l->ev0, l->stream));
-    int rc;
-    // critic
-    if ((rc = net_forward(l, l->cri, l->act_c, x, n))) return rc;
-    hipLaunchKernelGGL(k_value_loss, dim3((n + 255) / 256), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n, l->dbuf0, metrics);
-    LCHK(l, hipGetLastError());
-    if ((rc = net_backward(l, l->cri, l->act_c, x, n, l->dbuf0))) return rc;
-    // policy
-    if ((rc = net_forward(l, l->pol, l->act_p, x, n))) return rc;
-    float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
-    hipLaunchKernelGGL(k_ppo_policy_loss, dim3((n + 3) / 4), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
-                       l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, l->dbuf0, metrics);
-    LCHK(l, hipGetLastError());
-    if ((rc = net_backward(l, l->pol, l->act_p, x, n, l->dbuf0))) return rc;
+    const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+    const int loss_blocks = std::max(1, std::min(2048, (n + 3) / 4));
+    const int vloss_blocks = std::max(1, std::min(1024, (n + 255) / 256));
+    if (fast) {
+        // critic
+        if ((rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), n))) return rc;
+        hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n,
+                           (float*)nullptr, l->g16a, l->cri.kp[l->cri.n_layers], metrics);
+        LCHK(l, hipGetLastError());
+        if ((rc = net_backward16(l, l->cri, l->act16_c, n, l->g16a))) return rc;
+        // policy
+        if ((rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), n))) return rc;
+        hipLaunchKernelGGL(k_ppo_policy_loss, dim3(loss_blocks), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
+                           l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->g16a, l->pol.kp[l->pol.n_layers], metrics);
+        LCHK(l, hipGetLastError());
+        if ((rc = net_backward16(l, l->pol, l->act16_p, n, l->g16a))) return rc;
+    } else {
+        // critic
+        if ((rc = net_forward(l, l->cri, l->act_c, x, n))) return rc;
+        hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n, l->dbuf0,
+                           (short*)nullptr, 0, metrics);
+        LCHK(l, hipGetLastError());
+        if ((rc = net_backward(l, l->cri, l->act_c, x, n, l->dbuf0))) return rc;
+        // policy
+        if ((rc = net_forward(l, l->pol, l->act_p, x, n))) return rc;
+        hipLaunchKernelGGL(k_ppo_policy_loss, dim3(loss_blocks), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
+                           l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, l->dbuf0, (short*)nullptr, 0, metrics);
+        LCHK(l, hipGetLastError());
+        if ((rc = net_backward(l, l->pol, l->act_p, x, n, l->dbuf0))) return rc;
+    }
     LCHK(l, hipEventRecord(l->ev1, l->stream));
     l->ev_flops[ev_slot] = l->last_flops;
     l->timed = true;
-    if (metrics) {
-        // [5] += 1 minibatch, [6] += rows
-        float inc[2] = {1.f, (float)n};
-        (void)inc;
-    }
     return RLGPU_OK;
 }
 
@@ -659,6 +1061,7 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
                            l->adam_m + s.off, l->adam_v + s.off, s.n, (const float*)(l->norm_buf + s.slot), grad_scale, max_norm, s.lr, b1, b2, eps, bc1, bc2s);
         LCHK(l, hipGetLastError());
     }
+    l->shadows_dirty = true;
     return RLGPU_OK;
 }
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }

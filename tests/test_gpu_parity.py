@@ -320,6 +320,45 @@ def test_bf16_path_close_to_fp32(lg):
     assert np.abs(c32.value(obs).cpu().numpy() - c16.value(obs).cpu().numpy()).max() < 5e-2
 
 
+def test_bf16_fast_path_gradients_and_ragged_shapes():
+    """bf16 fast path (NT / transposing-read TN GEMMs, bf16 activations) against the exact fp32 path on the flagship layer
+    shapes with ragged edges: K = 89, N = 90 / 1, rows not a multiple of any tile.  Tolerances: bf16 has an 8-bit mantissa;
+    operands are rounded once per layer, sums are fp32."""
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(3)
+    n = 1037
+    mk = lambda bf: PPOCore(89, 90, (256, 256, 256), (256, 256, 256), use_bf16=bf, max_rows=1100, seed=7)
+    c32, c16 = mk(False), mk(True)
+    c16.set_params(c32.get_params(0), 0); c16.set_params(c32.get_params(1), 1)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    obs = t(rng.randn(n, 89).astype(np.float32))
+    p32, p16 = c32.probs(obs).cpu().numpy(), c16.probs(obs).cpu().numpy()
+    assert np.abs(p32 - p16).max() < 5e-3
+    v32, v16 = c32.value(obs).cpu().numpy(), c16.value(obs).cpu().numpy()
+    assert np.abs(v32 - v16).max() < 5e-2
+    acts = t(rng.randint(0, 90, n).astype(np.int32)); olp = t(np.log(p32[np.arange(n), acts.cpu().numpy()]).astype(np.float32) + 0.05 * rng.randn(n).astype(np.float32))
+    adv = t(rng.randn(n).astype(np.float32)); tg = t(rng.randn(n).astype(np.float32))
+    perm = t(rng.permutation(n).astype(np.int32))
+    grads = []
+    for c in (c32, c16):
+        m = torch.zeros(8, device=dev)
+        c.zero_grads(); c.minibatch(obs, acts, olp, adv, tg, perm, n, 1.0, m); c.sync()
+        grads.append((c.get_grads(0), c.get_grads(1), m.cpu().numpy()))
+    for k in (0, 1):
+        ref, got = grads[0][k], grads[1][k]
+        assert np.isfinite(got).all()
+        assert np.abs(ref - got).max() < 3e-2 * np.abs(ref).max() + 1e-6, (k, np.abs(ref - got).max(), np.abs(ref).max())
+        cos = float(np.dot(ref, got) / (np.linalg.norm(ref) * np.linalg.norm(got) + 1e-30))
+        assert cos > 0.999, (k, cos)
+    assert np.allclose(grads[0][2][:5], grads[1][2][:5], rtol=2e-2, atol=2e-2 * n)
+    # weights change -> shadows refresh: one Adam step keeps the two paths together
+    for c in (c32, c16):
+        c.clip_adam_step(0.5, 1.0); c.sync()
+    assert np.abs(c32.get_params(0) - c16.get_params(0)).max() < 2e-3
+    assert np.abs(c32.probs(obs).cpu().numpy() - c16.probs(obs).cpu().numpy()).max() < 1e-2
+
+
 def test_gemm_shapes_against_numpy():
     """The MFMA GEMM at the flagship layer shapes incl. ragged edges (K=89, N=90, N=1, rows not a tile multiple)."""
     from rlgymppo_cpp_amd.ppo import PPOCore
