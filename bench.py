@@ -82,12 +82,8 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from rlgymppo_cpp_amd import parallel
+    rank, local_rank, world = parallel.init_process_group("nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP kernels with no CPU fallback")
 
@@ -101,9 +97,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        parallel.barrier(world)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -122,9 +116,7 @@ def main():
         cs.append((c0, c1))
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=torch.device("cuda", local_rank)); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+    elapsed = parallel.max_over_ranks(elapsed, world, torch.device("cuda", local_rank))
     consume_ms = sum(a.elapsed_time(b) for a, b in cs) / max(1, len(cs))
     env_ms, env_launches = L.env.timing_total(reset=False)
     gemm_ms, gemm_flops, gemm_calls = L.ppo.timing_total(reset=False)

@@ -20,7 +20,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, parallel
 from .env import BatchedEnv
 from .ppo import PPOCore
 
@@ -121,7 +121,7 @@ class Learner:
         n_envs = cfg.numEnvs or cfg.numThreads * cfg.numGamesPerThread
         self.gym_cfg = gym_cfg if gym_cfg is not None else _lib.default_gym_config()
         # every rank owns its own env shard and RNG streams: seed = randomSeed + 1000 * rank
-        self.gym_cfg.seed_lo = (cfg.randomSeed + 1000 * rank) & 0xffffffff
+        self.gym_cfg.seed_lo = parallel.shard_seed(cfg.randomSeed, rank)
         self.env = BatchedEnv(n_envs, cfg.teamSize, self.gym_cfg, cfg.device, mesh)
         self.dev = torch.device("cuda", cfg.device)
         self.n_agents = self.env.n_agents
@@ -191,10 +191,7 @@ class Learner:
         if self.cfg.standardizeReturns:
             # the first <=150 returns of the concatenated (agent-major) batch: trajectory 0's first steps (Learner.cpp:679-682)
             k = min(self.cfg.maxReturnsPerStatsInc, T)
-            first = ret[:k, 0]
-            if self.world > 1:
-                import torch.distributed as dist
-                first = first.clone(); dist.broadcast(first, src=0)   # rank 0's returns feed the shared statistic
+            first = parallel.share_from_rank0(ret[:k, 0], self.world)   # rank 0's returns feed the shared statistic
             self.return_stats.increment(first.cpu().numpy().tolist(), k)
         self.report["Avg Return"] = float(ret.abs().mean().item()) / ret_std
         self.report["Avg Advantage"] = float(adv.abs().mean().item())
@@ -218,10 +215,8 @@ class Learner:
                 for m in range(0, self.batch_size, self.mini):
                     self.ppo.minibatch(obs, acts, logp, adv, tgt, idx[base + m: base + m + self.mini], self.mini, self.mini / self.batch_size, self.metrics)
                     n_mb += 1
-                if self.world > 1:
-                    import torch.distributed as dist
-                    dist.all_reduce(self.ppo.grad_tensor())    # ONE RCCL all-reduce per optimizer step
-                self.ppo.clip_adam_step(0.5, 1.0 / self.world)
+                scale = parallel.allreduce_gradients(self.ppo.grad_tensor(), self.world)   # ONE RCCL all-reduce per optimizer step
+                self.ppo.clip_adam_step(0.5, scale)
                 n_updates += 1
         self.total_epochs += p.epochs
         self.cumulative_model_updates += n_updates
