@@ -48,4 +48,15 @@ RLG_HD V3 ball_inv_inertia_local() {  // btSphereShape::calculateLocalInertia (b
 constexpr float CAR_INV_MASS = 1.0f / K::CAR_MASS;
 constexpr float BALL_INV_MASS = 1.0f / K::BALL_MASS;
 
+// ---- wheel geometry of the Octane (Car.cpp:243-258) ----------------------------------------------------
+RLG_HD V3 wheel_conn(int i) {  // Car.cpp:243-253
+    bool front = i < 2, left = (i % 2) != 0;
+    V3 o = front ? v3(K::WHEEL_FX, K::WHEEL_FY, K::WHEEL_FZ) : v3(K::WHEEL_BX, K::WHEEL_BY, K::WHEEL_BZ);
+    if (left) o.y *= -1.f;
+    return o * UU2BT;
+}
+RLG_HD float wheel_rest(int i) { return ((i < 2 ? K::SUS_REST_FRONT : K::SUS_REST_BACK) - K::MAX_SUSPENSION_TRAVEL) * UU2BT; }  // Car.cpp:255-258
+RLG_HD float wheel_radius(int i) { return (i < 2 ? K::WHEEL_RAD_FRONT : K::WHEEL_RAD_BACK) * UU2BT; }
+RLG_HD float wheel_travel() { return ((K::MAX_SUSPENSION_TRAVEL * UU2BT) * 100) / 100; }  // m_maxSuspensionTravelCm / 100
+
 }  // namespace rlg

@@ -8,16 +8,6 @@
 
 namespace rlg {
 
-RLG_HD V3 wheel_conn(int i) {  // Car.cpp:243-253
-    bool front = i < 2, left = (i % 2) != 0;
-    V3 o = front ? v3(K::WHEEL_FX, K::WHEEL_FY, K::WHEEL_FZ) : v3(K::WHEEL_BX, K::WHEEL_BY, K::WHEEL_BZ);
-    if (left) o.y *= -1.f;
-    return o * UU2BT;
-}
-RLG_HD float wheel_rest(int i) { return ((i < 2 ? K::SUS_REST_FRONT : K::SUS_REST_BACK) - K::MAX_SUSPENSION_TRAVEL) * UU2BT; }  // Car.cpp:255-258
-RLG_HD float wheel_radius(int i) { return (i < 2 ? K::WHEEL_RAD_FRONT : K::WHEEL_RAD_BACK) * UU2BT; }
-RLG_HD float wheel_travel() { return ((K::MAX_SUSPENSION_TRAVEL * UU2BT) * 100) / 100; }  // m_maxSuspensionTravelCm / 100
-
 // Angle::FromRotMat roll (MathTypes.cpp:72-82 -> btMatrix3x3::getEulerYPR)
 RLG_HD float rot_roll(const M3& m) {
     float yaw = atan2f(m.r1.x, m.r0.x);
@@ -37,7 +27,91 @@ struct CarTickCtx {
     int n_contact;
     bool wheels_world;
     float forward_speed_uu;
+    uint64_t pad_mask;   // boost pads this car touches this tick (bit p), from pads_check_car
+    float new_lat[4], new_long[4];   // this tick's friction factors per wheel (car_wheel_trace), adopted by car_pre_tick_finish
 };
+
+// true when phase 2 of car `ci` reads another car (a wheel stands on it): such ticks run phase 2 in car order
+RLG_HD bool car_needs_ordered_finish(const CarTickCtx& t) {
+    bool r = false;
+    for (int i = 0; i < 4; i++) r = r || (t.w[i].in_contact && t.w[i].ground >= 2);
+    return r;
+}
+
+// per-wheel part of Car::_UpdateWheels (Car.cpp:405-452): this tick's lateral / longitudinal friction factors of wheel i.
+// Needs only state that nothing changes before car_pre_tick_finish, so it runs on the wheel's own lane.
+RLG_HD void wheel_friction_factors(const Car& c, const WheelTmp& w, const M3& basis, float& latf_out, float& lonf_out) {
+    const float dt = TICK_DT;
+    float hb = c.handbrake_val;   // the value car_update_wheels is about to store
+    if (c.ctl.handbrake) hb += K::POWERSLIDE_RISE_RATE * dt; else hb -= K::POWERSLIDE_FALL_RATE * dt;
+    hb = clampf(hb, 0.f, 1.f);
+    float real_throttle = c.ctl.throttle;
+    if (c.ctl.boost && c.boost > 0) real_throttle = 1.f;
+    V3 lat = col1(basis);
+    V3 lon = cross(lat, w.contact_normal);
+    float input = 0.f;
+    V3 wheel_delta = w.hard_point - c.b.pos;
+    V3 cv = (cross(c.b.angvel, wheel_delta) + c.b.vel) * BT2UU;
+    float base = fabsf(dot(cv, lat));
+    if (base > 5.f) input = base / (fabsf(dot(cv, lon)) + base);
+    float latf = curve_lat_friction(input);
+    float lonf = 1.f;  // LONG_FRICTION_CURVE is empty -> default output 1 (RLConst.h:376-380, Math.cpp:31-33)
+    if (hb != 0.f) {
+        latf *= (0.1f - 1.f) * hb + 1.f;  // HANDBRAKE_LAT_FRICTION_FACTOR_CURVE is the constant 0.1 (RLConst.h:382-386)
+        lonf *= (curve_handbrake_long(input) - 1.f) * hb + 1.f;
+    } else {
+        lonf = 1.f;
+    }
+    if (real_throttle == 0.f) {
+        float s = curve_non_sticky(w.contact_normal.z);
+        latf *= s; lonf *= s;
+    }
+    latf_out = latf; lonf_out = lonf;
+}
+
+// one wheel of calcFrictionImpulses, with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
+template <int NC>
+RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTmp& w, const M3& basis, int i) {
+    const float friction_scale = K::CAR_MASS / 3;
+    if (w.ground < 0) return v3(0, 0, 0);
+    V3 axle = col1(basis);
+    V3 n = w.contact_normal;
+    float proj = dot(axle, n);
+    axle -= n * proj;
+    axle = safe_normalized(axle);
+    V3 fdir = safe_normalized(cross(n, axle));
+    // resolveSingleBilateral (btContactConstraint.cpp:108-155)
+    V3 rel1 = w.contact_point - c.b.pos;
+    V3 vel1 = body_vel_at(c.b, rel1);
+    V3 vel2 = v3(0, 0, 0);
+    float diag2 = 0.f;
+    const Body* gb = nullptr; float g_inv_mass = 0.f; V3 g_inv_inertia = v3(0, 0, 0);
+    if (w.ground == 1) { gb = &A.ball.b; g_inv_mass = BALL_INV_MASS; g_inv_inertia = ball_inv_inertia_local(); }
+    else if (w.ground >= 2) { gb = &A.cars[w.ground - 2].b; g_inv_mass = CAR_INV_MASS; g_inv_inertia = car_inv_inertia_local(); }
+    V3 rel2 = v3(0, 0, 0);
+    if (gb) {
+        rel2 = w.contact_point - gb->pos;
+        vel2 = body_vel_at(*gb, rel2);
+        V3 bJ = tmul(gb->rot, cross(rel2, -axle));
+        diag2 = g_inv_mass + dot(g_inv_inertia * bJ, bJ);
+    }
+    V3 aJ = tmul(c.b.rot, cross(rel1, axle));  // world2A * (rel_pos1 x normal), world2A = basis^T
+    float diag = CAR_INV_MASS + dot(car_inv_inertia_local() * aJ, aJ) + diag2;
+    float rel_vel = dot(axle, vel1 - vel2);
+    float side_impulse = -0.2f * rel_vel * (1.f / diag);
+    float rolling;
+    if (c.engine_force == 0.f) {
+        if (c.brake != 0.f) {
+            V3 v2r = gb ? body_vel_at(*gb, rel1) : v3(0, 0, 0);  // the reference uses carRelContactPoint for both (btVehicleRL.cpp:349-352)
+            float rv = dot(vel1 - v2r, fdir);
+            rolling = clampf(-rv * 113.73963f, -c.brake, c.brake);
+        } else rolling = 0.f;
+    } else {
+        rolling = -c.engine_force / friction_scale;
+    }
+    V3 total = (fdir * rolling * c.long_friction[i]) + (axle * side_impulse * c.lat_friction[i]);
+    return total * friction_scale;
+}
 
 // ---- Car::_UpdateWheels (Car.cpp:330-475) -------------------------------------------------------------
 RLG_HD void car_update_wheels(Car& c, CarTickCtx& t) {
@@ -75,30 +149,9 @@ RLG_HD void car_update_wheels(Car& c, CarTickCtx& t) {
         c.steer_angle = steer;
     }
     for (int i = 0; i < 4; i++) {
-        const WheelTmp& w = t.w[i];
-        if (w.ground < 0) continue;
-        V3 lat = col1(t.wheel_basis[i]);
-        V3 lon = cross(lat, w.contact_normal);
-        float input = 0.f;
-        V3 wheel_delta = w.hard_point - c.b.pos;
-        V3 cv = (cross(c.b.angvel, wheel_delta) + c.b.vel) * BT2UU;
-        float base = fabsf(dot(cv, lat));
-        if (base > 5.f) input = base / (fabsf(dot(cv, lon)) + base);
-        float latf = curve_lat_friction(input);
-        float lonf = 1.f;  // LONG_FRICTION_CURVE is empty -> default output 1 (RLConst.h:376-380, Math.cpp:31-33)
-        if (c.handbrake_val != 0.f) {
-            float hb = c.handbrake_val;
-            latf *= (0.1f - 1.f) * hb + 1.f;  // HANDBRAKE_LAT_FRICTION_FACTOR_CURVE is the constant 0.1 (RLConst.h:382-386)
-            lonf *= (curve_handbrake_long(input) - 1.f) * hb + 1.f;
-        } else {
-            lonf = 1.f;
-        }
-        if (real_throttle == 0.f) {
-            float s = curve_non_sticky(w.contact_normal.z);
-            latf *= s; lonf *= s;
-        }
-        c.lat_friction[i] = latf;
-        c.long_friction[i] = lonf;
+        if (t.w[i].ground < 0) continue;
+        c.lat_friction[i] = t.new_lat[i];     // computed on the wheel's lane (wheel_friction_factors)
+        c.long_friction[i] = t.new_long[i];
     }
     if (t.wheels_world) {
         V3 sum = v3(0, 0, 0);
@@ -447,6 +500,9 @@ RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, MeshView mesh,
         w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
         cr.extra_pushback[i] = 0.f;
     }
+    // per-wheel halves of calcFrictionImpulses and _UpdateWheels (see the two helpers above)
+    w.impulse = wheel_friction_impulse(A, cr, w, t.wheel_basis[i], i);
+    if (w.ground >= 0) wheel_friction_factors(cr, w, t.wheel_basis[i], t.new_lat[i], t.new_long[i]);
     t.w[i] = w;
 }
 
@@ -460,9 +516,13 @@ RLG_HD_NOINLINE void car_pre_tick_finish(Arena<NC>& A, int ci, CarTickCtx& t) {
     // would be re-loaded after every store); a local Car is promoted to registers.
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
     if (A.cars[ci].flags & CF_IS_DEMOED) return;
+#ifdef RLG_CAR_DIRECT
+    car_pre_tick_finish_body(A, A.cars[ci], ci, t);
+#else
     Car c = A.cars[ci];
     car_pre_tick_finish_body(A, c, ci, t);
     A.cars[ci] = c;
+#endif
 }
 
 template <int NC>
@@ -472,51 +532,10 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
     for (int i = 0; i < 4; i++) {
         if (t.w[i].in_contact) { t.n_contact++; if (t.w[i].ground == 0) t.wheels_world = true; }
     }
-    // calcFrictionImpulses with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
-    {
-        const float friction_scale = K::CAR_MASS / 3;
-        RLG_NOUNROLL
-        for (int i = 0; i < 4; i++) {
-            WheelTmp& w = t.w[i];
-            if (w.ground < 0) { w.impulse = v3(0, 0, 0); continue; }
-            V3 axle = col1(t.wheel_basis[i]);
-            V3 n = w.contact_normal;
-            float proj = dot(axle, n);
-            axle -= n * proj;
-            axle = safe_normalized(axle);
-            V3 fdir = safe_normalized(cross(n, axle));
-            // resolveSingleBilateral (btContactConstraint.cpp:108-155)
-            V3 rel1 = w.contact_point - c.b.pos;
-            V3 vel1 = body_vel_at(c.b, rel1);
-            V3 vel2 = v3(0, 0, 0);
-            float diag2 = 0.f;
-            const Body* gb = nullptr; float g_inv_mass = 0.f; V3 g_inv_inertia = v3(0, 0, 0);
-            if (w.ground == 1) { gb = &A.ball.b; g_inv_mass = BALL_INV_MASS; g_inv_inertia = ball_inv_inertia_local(); }
-            else if (w.ground >= 2) { gb = &A.cars[w.ground - 2].b; g_inv_mass = CAR_INV_MASS; g_inv_inertia = car_inv_inertia_local(); }
-            V3 rel2 = v3(0, 0, 0);
-            if (gb) {
-                rel2 = w.contact_point - gb->pos;
-                vel2 = body_vel_at(*gb, rel2);
-                V3 bJ = tmul(gb->rot, cross(rel2, -axle));
-                diag2 = g_inv_mass + dot(g_inv_inertia * bJ, bJ);
-            }
-            V3 aJ = tmul(c.b.rot, cross(rel1, axle));  // world2A * (rel_pos1 x normal), world2A = basis^T
-            float diag = CAR_INV_MASS + dot(car_inv_inertia_local() * aJ, aJ) + diag2;
-            float rel_vel = dot(axle, vel1 - vel2);
-            float side_impulse = -0.2f * rel_vel * (1.f / diag);
-            float rolling;
-            if (c.engine_force == 0.f) {
-                if (c.brake != 0.f) {
-                    V3 v2r = gb ? body_vel_at(*gb, rel1) : v3(0, 0, 0);  // the reference uses carRelContactPoint for both (btVehicleRL.cpp:349-352)
-                    float rv = dot(vel1 - v2r, fdir);
-                    rolling = clampf(-rv * 113.73963f, -c.brake, c.brake);
-                } else rolling = 0.f;
-            } else {
-                rolling = -c.engine_force / friction_scale;
-            }
-            V3 total = (fdir * rolling * c.long_friction[i]) + (axle * side_impulse * c.lat_friction[i]);
-            w.impulse = total * friction_scale;
-        }
+    // friction impulses: taken from the wheel lanes (car_wheel_trace) unless a wheel stands on another car -- that reads the
+    // other car's velocity, which its own phase 2 may already have changed (callers run such ticks in car order)
+    if (car_needs_ordered_finish(t)) {
+        for (int i = 0; i < 4; i++) t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], t.wheel_basis[i], i);
     }
 
     bool jump_pressed = c.ctl.jump && !c.last.jump;

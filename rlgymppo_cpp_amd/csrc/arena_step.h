@@ -84,98 +84,7 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 //   NarrowQueued  reads the results of items that collide_queue_body() found and collide_run_item() ran earlier, on
 //                 other lanes of the wavefront (rlgpu_env.hip).  Item results are merged in the order the inline
 //                 provider would have produced them, so both give identical contact lists.
-// Three steps on the device, each on its own lane set:
-//   1. collide_queue_body  (a lane per body)       walks the BVH nodes only and lists the triangles of every leaf it reaches
-//                                                   as CANDIDATES -- no triangle is fetched during the walk;
-//   2. collide_test_candidate (a lane per candidate) fetches the triangle and does the AABB test; the survivors are compacted,
-//                                                   in candidate order, into ITEMS (rlgpu_env.hip does that with a ballot);
-//   3. collide_run_item    (a lane per item)        runs the pair test and stores its candidates in the pool.
-struct CollideItem {
-    int16_t type, a;   // 0 ball-triangle, 1 car-triangle (a = car), 2 car-car (a = first car)
-    int32_t ref;       // triangle index, or the second car
-    int16_t off, n;    // result candidates: pool[off .. off+n)
-};
-#ifndef RLG_ITEM_CAP
-#define RLG_ITEM_CAP 16   /* tests build a tiny queue to exercise the overflow fallback */
-#endif
-constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 96, CAND_CAP = 128;
-struct CollideQueue {
-    int n_cand, n_items, n_pool, overflow;
-    uint32_t cand[CAND_CAP];   // type << 28 | a << 24 | ref
-    CollideItem items[ITEM_CAP];
-    Cand pool[POOL_CAP];
-};
-RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
-RLG_HD CollideItem unpack_cand(uint32_t c) {
-    CollideItem it; it.type = (int16_t)(c >> 28); it.a = (int16_t)((c >> 24) & 15u); it.ref = (int32_t)(c & 0xFFFFFFu); it.off = 0; it.n = 0;
-    return it;
-}
-
-RLG_HD int fetch_add(int& x, int v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // lanes of one wavefront append to the same queue; the queue lives in LDS (ds_add_rtn instead of a flat atomic)
-    return __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    int o = x; x += v; return o;
-#endif
-}
-
-RLG_HD void queue_candidates(CollideQueue& Q, int type, int a, int first, int cnt) {
-    int k = fetch_add(Q.n_cand, cnt);
-    if (k + cnt > CAND_CAP) { Q.overflow = 1; return; }
-    for (int q = 0; q < cnt; q++) Q.cand[k + q] = pack_cand(type, a, first + q);
-}
-
-// every BVH leaf whose box overlaps [lo,hi], in walk order: f(first triangle, count)
-template <class F>
-RLG_HD void mesh_query_leaves(MeshView mesh, V3 lo, V3 hi, F&& f) {
-    if (!mesh_maybe_near(mesh, lo, hi)) return;
-    uint32_t i = 0;
-    while (i != BVH_END) {
-        BvhNode nd = mesh_node(mesh, (int)i);
-        uint32_t next = node_escape(nd);
-        if (aabb_overlap(nd, lo, hi)) {
-            const int cnt = node_count(nd);
-            if (cnt > 0) f(nd.left_or_first, cnt);
-            else next = (uint32_t)nd.left_or_first + 1u;
-        }
-        i = next;
-    }
-}
-
-// every mesh triangle whose AABB overlaps [lo,hi] (TestTriangleAgainstAabb2, btConvexConcaveCollisionAlgorithm.cpp:75), in BVH order
-template <class F>
-RLG_HD void mesh_query(MeshView mesh, V3 lo, V3 hi, F&& f) {
-    mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) {
-        for (int k = 0; k < cnt; k++)
-            if (tri_aabb_overlap(mesh.tris[first + k], lo, hi)) f(first + k);
-    });
-}
-
-RLG_HD void ball_query_aabb(V3 bp, V3& lo, V3& hi) {
-    const float r = K::BALL_RADIUS * UU2BT;
-    float bext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
-    lo = bp - v3(bext, bext, bext); hi = bp + v3(bext, bext, bext);
-}
-RLG_HD void car_query_aabb(const Car& car, V3& bc, V3& lo, V3& hi) {
-    V3 h = hitbox_half();
-    bc = car.b.pos + car.b.rot * hitbox_off();
-    M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
-                      v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
-                      v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
-    V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
-    lo = bc - ext; hi = bc + ext;
-}
-RLG_HD bool car_collides(const Car& car) { return !(car.flags & CF_IS_DEMOED) && !car.frozen; }  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
-template <int NC>
-RLG_HD bool cars_maybe_touch(const Arena<NC>& A, int ia, int ib) {
-    const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
-    V3 h = hitbox_half();
-    V3 cca = ca.b.pos + ca.b.rot * hitbox_off(), ccb = cb.b.pos + cb.b.rot * hitbox_off();
-    float rad = len(h);
-    return len2(cca - ccb) <= (2 * rad) * (2 * rad);
-}
-
+// The candidate / item queue itself (CollideQueue) and the BVH queries live in arena_world.h: the wheel rays share it.
 struct NarrowInline {
     template <int NC, class F>
     RLG_HD void ball_mesh(const Arena<NC>& A, MeshView mesh, F&& emit) {
@@ -231,35 +140,18 @@ struct NarrowQueued {
     }
 };
 
-// step 1: list the candidates of one body: body 0 = ball, 1 + i = car i (one lane appends them: they keep their walk order)
-template <int NC>
-RLG_HD_NOINLINE void collide_queue_body(const Arena<NC>& A, MeshView mesh, int body, bool ball_asleep, CollideQueue& Q) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
-    V3 lo, hi;
-    if (body == 0) {
-        if (ball_asleep) return;
-        ball_query_aabb(A.ball.b.pos, lo, hi);
-        mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) { queue_candidates(Q, 0, 0, first, cnt); });
-    } else {
-        const int ci = body - 1;
-        const Car& car = A.cars[ci];
-        if (!car_collides(car)) return;
-        V3 bc;
-        car_query_aabb(car, bc, lo, hi);
-        mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) { queue_candidates(Q, 1, ci, first, cnt); });
-        for (int ib = ci + 1; ib < NC; ib++)
-            if (car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
-    }
-}
-
 // step 2: does candidate `k` become an item?  (triangle AABB vs the body's query box; car-car pairs always do)
 template <int NC>
 RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const CollideQueue& Q, int k) {
+    if (Q.cand[k] == CAND_HOLE) return false;
     CollideItem it = unpack_cand(Q.cand[k]);
     if (it.type == 2) return true;
     V3 lo, hi, bc;
     if (it.type == 0) ball_query_aabb(A.ball.b.pos, lo, hi);
-    else car_query_aabb(A.cars[it.a], bc, lo, hi);
+    else {
+        if (!car_collides(A.cars[it.a])) return false;
+        car_query_aabb(A.cars[it.a], bc, lo, hi);   // the tight hitbox box, not the ray-extended one the list was built for
+    }
     return tri_aabb_overlap(mesh.tris[it.ref], lo, hi);
 }
 
@@ -508,21 +400,20 @@ struct TickWork {
     CarTickCtx ctx[NC];
     bool ball_asleep;
 };
+static_assert(sizeof(CollideQueue) <= sizeof(Row) * TickWork<2>::MAXR, "the narrowphase queue must fit inside the solver rows it shares LDS with");
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
 template <int NC>
 RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
     const float dt = TICK_DT;
-    // ball sleep flag (Arena.cpp:721-727)
-    bool ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
-    W.ball_asleep = ball_asleep;
+    // ball sleep flag (Arena.cpp:721-727): taken at tick start by tick_build_candidates (nothing touches the ball before here)
+    const bool ball_asleep = W.ball_asleep;
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
     const float g = K::GRAVITY_Z * UU2BT;
     if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
     for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
     A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
-    W.Q.n_cand = 0; W.Q.n_items = 0; W.Q.n_pool = 0; W.Q.overflow = 0;
 }
 
 // world step, second part (per env): contact list, solver, integration.  `queued`: the narrowphase items of this env
@@ -654,12 +545,16 @@ RLG_HD V3 pad_pos(int i) {
     return v3(SM[i - 6][0], SM[i - 6][1], 70.f);
 }
 
+// which pads does car `ci` touch (bit p)?  Reads the pads' prev_locked only, so cars can be checked in any order; the
+// caller then sets cur_locked in car order (a later car overrides an earlier one, as the reference's loop does).
 template <int NC>
-RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
-    Car& car = A.cars[ci];
-    if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return;
+RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, int ci) {
+    RLG_ASSUME_LDS(A);
+    const Car& car = A.cars[ci];
+    uint64_t mask = 0;
+    if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return mask;
     V3 cp = car.b.pos * BT2UU;
-    if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return;
+    if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return mask;
     int ix = (int)(cp.x / 1024 + 4), iy = (int)(cp.y / 1024 + 5);
     // car AABB (btCompoundShape::getAabb): centre + |R| * half extents
     V3 h = hitbox_half();
@@ -689,8 +584,36 @@ RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
             float dx = car.b.pos.x - pbt.x, dy = car.b.pos.y - pbt.y;
             if (dx * dx + dy * dy < rad * rad) colliding = fabsf(car.b.pos.z - pbt.z) < (K::PAD_CYL_HEIGHT * UU2BT);
         }
-        if (colliding) A.pads[p].cur_locked = ci + 1;
+        if (colliding) mask |= (1ull << p);
     }
+    return mask;
+}
+
+// per-pad halves of the tick (BoostPad.cpp:37-105)
+RLG_HD void pad_pre_tick(Pad& pd) {
+    if (pd.cooldown > 0) pd.cooldown = fmaxf(pd.cooldown - TICK_DT, 0.f);
+    pd.is_active = (pd.cooldown == 0.f);
+    pd.cur_locked = 0;
+}
+RLG_HD bool pad_gives_boost(const Pad& pd) { return pd.cur_locked != 0 && pd.is_active; }
+template <int NC>
+RLG_HD void pad_post_tick(Arena<NC>& A, int p) {
+    Pad& pd = A.pads[p];
+    int locked = 0;
+    if (pd.cur_locked) {
+        locked = pd.cur_locked;
+        if (pd.is_active) {
+            Car& c = A.cars[locked - 1];
+            c.boost = fminf(c.boost + (p < 6 ? K::PAD_BOOST_BIG : K::PAD_BOOST_SMALL), K::BOOST_MAX);
+            pd.is_active = false;
+            pd.cooldown = p < 6 ? K::PAD_COOLDOWN_BIG : K::PAD_COOLDOWN_SMALL;
+        }
+    }
+    pd.prev_locked = locked;
+}
+template <int NC>
+RLG_HD void pads_lock(Arena<NC>& A, int ci, uint64_t mask) {
+    for (int p = 0; p < 34; p++) if ((mask >> p) & 1ull) A.pads[p].cur_locked = ci + 1;
 }
 
 // ---- Arena::Step, one tick (Arena.cpp:716-812) ---------------------------------------------------------
@@ -698,23 +621,29 @@ RLG_HD_NOINLINE void pads_check_car(Arena<NC>& A, int ci) {
 // arena_tick() below runs them in loops (host build, single-lane device callers); rlgpu_env.hip runs the same phase
 // functions with one wavefront lane per work item.
 
-// phase 3, per env: boost pad cooldowns, then the first part of the dynamics world step
+// phase 3, per env: boost pad cooldowns (unless the caller spread them over lanes), then the first part of the dynamics world step
 template <int NC>
-RLG_HD_NOINLINE void tick_world_begin(Arena<NC>& A, TickWork<NC>& W) {
+RLG_HD_NOINLINE void tick_world_begin(Arena<NC>& A, TickWork<NC>& W, bool pads_done) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
-    const float dt = TICK_DT;
-    RLG_PROF(0);
-    for (int p = 0; p < 34; p++) {
-        Pad& pd = A.pads[p];
-        if (pd.cooldown > 0) pd.cooldown = fmaxf(pd.cooldown - dt, 0.f);
-        pd.is_active = (pd.cooldown == 0.f);
-        pd.cur_locked = 0;
-    }
+    if (!pads_done) for (int p = 0; p < 34; p++) pad_pre_tick(A.pads[p]);
     world_step_begin(A, W);
     RLG_PROF(0);
 }
-// (device only: phases 3a per body = collide_queue_body, 3b per item = collide_run_item)
-// phase 3c, per env: rest of the world step = world_step_finish
+// phases 3b (lane per candidate: AABB test + compaction into items) and 3c (lane per item), host form
+template <int NC>
+RLG_HD void collide_compact_and_run(const Arena<NC>& A, MeshView mesh, CollideQueue& Q) {
+    if (Q.overflow) return;
+    int n = 0;
+    for (int k = 0; k < Q.n_cand; k++) {
+        if (!collide_test_candidate(A, mesh, Q, k)) continue;
+        if (n < ITEM_CAP) Q.items[n] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
+        n++;
+    }
+    if (Q.overflow) return;
+    Q.n_items = n;
+    for (int slot = 0; slot < n; slot++) collide_run_item(A, mesh, slot, Q);
+}
+// phase 3d, per env: rest of the world step = world_step_finish
 
 // phase 4, per car: Car::_PostTickUpdate + _FinishPhysicsTick
 template <int NC>
@@ -729,25 +658,15 @@ RLG_HD_NOINLINE void tick_car_post(Arena<NC>& A, int i) {
     cr.car_contact_cooldown = c.car_contact_cooldown; cr.last = c.last; cr.vel_impulse_cache = c.vel_impulse_cache;
 }
 
-// phase 5, per env: boost pad pickups (in car order), ball finish, tick counter
+// phase 5, per env: boost pad pickups (in car order), ball finish, tick counter.  `pads_done`: the caller ran
+// pads_check_car / pads_lock / pad_post_tick over lanes already.
 template <int NC>
-RLG_HD_NOINLINE void tick_finish(Arena<NC>& A) {
+RLG_HD_NOINLINE void tick_finish(Arena<NC>& A, bool pads_done) {
     RLG_ASSUME_LDS(A);
-    RLG_NOUNROLL
-    for (int i = 0; i < NC; i++) pads_check_car(A, i);
-    for (int p = 0; p < 34; p++) {
-        Pad& pd = A.pads[p];
-        int locked = 0;
-        if (pd.cur_locked) {
-            locked = pd.cur_locked;
-            if (pd.is_active) {
-                Car& c = A.cars[locked - 1];
-                c.boost = fminf(c.boost + (p < 6 ? K::PAD_BOOST_BIG : K::PAD_BOOST_SMALL), K::BOOST_MAX);
-                pd.is_active = false;
-                pd.cooldown = p < 6 ? K::PAD_COOLDOWN_BIG : K::PAD_COOLDOWN_SMALL;
-            }
-        }
-        pd.prev_locked = locked;
+    if (!pads_done) {
+        RLG_NOUNROLL
+        for (int i = 0; i < NC; i++) pads_lock(A, i, pads_check_car(A, i));
+        for (int p = 0; p < 34; p++) pad_post_tick(A, p);
     }
     {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
         Ball& b = A.ball;
@@ -761,22 +680,24 @@ RLG_HD_NOINLINE void tick_finish(Arena<NC>& A) {
     RLG_PROF(6);
 }
 
-// true when phase 2 of car `ci` reads another car (a wheel stands on it): such ticks run phase 2 in car order
-RLG_HD bool car_needs_ordered_finish(const CarTickCtx& t) {
-    bool r = false;
-    for (int i = 0; i < 4; i++) r = r || (t.w[i].in_contact && t.w[i].ground >= 2);
-    return r;
+// phase 0b, per env (host form; the device walks the BVH with a lane per frontier node): sleep flag + this tick's candidates
+template <int NC>
+RLG_HD void tick_build_candidates(const Arena<NC>& A, MeshView mesh, TickWork<NC>& W) {
+    W.ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
+    collide_build_candidates(A, mesh, W.ball_asleep, W.Q);
 }
 
 template <int NC>
 RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
     for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
+    tick_build_candidates(A, mesh, W);
     for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_trace(A, i, w, mesh, W.ctx[i]);
     for (int i = 0; i < NC; i++) car_pre_tick_finish(A, i, W.ctx[i]);
-    tick_world_begin(A, W);
-    world_step_finish(A, mesh, ev, W, false);
+    tick_world_begin(A, W, false);
+    collide_compact_and_run(A, mesh, W.Q);
+    world_step_finish(A, mesh, ev, W, true);
     for (int i = 0; i < NC; i++) tick_car_post(A, i);
-    tick_finish(A);
+    tick_finish(A, false);
 }
 
 }  // namespace rlg

@@ -87,6 +87,192 @@ RLG_HD bool ray_aabb(const BvhNode& n, V3 from, V3 inv_d, float tmax) {
 }
 
 // btTriangleRaycastCallback::processTriangle (btRaycastCallback.cpp:34-110), flags = 0
+// ---- narrowphase candidates (shared by the wheel rays and the contact narrowphase) ---------------------------
+// keep the `cap` deepest candidates of one body-vs-world pair
+struct Cand { V3 pb; V3 n; float dist; };
+template <int CAP>
+RLG_HD void cand_add(Cand (&cs)[CAP], int& n, const Cand& c) {
+    if (n < CAP) { cs[n++] = c; return; }
+    int worst = 0;
+    for (int i = 1; i < CAP; i++) if (cs[i].dist > cs[worst].dist) worst = i;
+    if (c.dist < cs[worst].dist) cs[worst] = c;
+}
+
+// Three steps on the device, each on its own lane set:
+//   1. collide_queue_body  (a lane per body)       walks the BVH nodes only and lists the triangles of every leaf it reaches
+//                                                   as CANDIDATES -- no triangle is fetched during the walk;
+//   2. collide_test_candidate (a lane per candidate) fetches the triangle and does the AABB test; the survivors are compacted,
+//                                                   in candidate order, into ITEMS (rlgpu_env.hip does that with a ballot);
+//   3. collide_run_item    (a lane per item)        runs the pair test and stores its candidates in the pool.
+struct CollideItem {
+    int16_t type, a;   // 0 ball-triangle, 1 car-triangle (a = car), 2 car-car (a = first car)
+    int32_t ref;       // triangle index, or the second car
+    int16_t off, n;    // result candidates: pool[off .. off+n)
+};
+#ifndef RLG_ITEM_CAP
+#define RLG_ITEM_CAP 16   /* tests build a tiny queue to exercise the overflow fallback */
+#endif
+constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 96, CAND_CAP = 160;
+constexpr int LEAF_SLOTS = 4;              // BVH leaves hold <= 4 triangles (arena_mesh.cpp); the device reserves a full block per leaf
+constexpr uint32_t CAND_HOLE = 0xFFFFFFFFu;  // unused slot of such a block
+constexpr int FRONTIER_CAP = 64;
+struct CollideQueue {
+    int n_cand, n_items, n_pool, overflow;
+    uint16_t cand_start[8];    // candidates of body b (0 = ball, 1 + i = car i) are cand[cand_start[b] .. cand_start[b+1]); car-car pairs follow
+    uint16_t frontier[2][FRONTIER_CAP];   // breadth-first BVH walk: nodes of the current and of the next level
+    uint32_t cand[CAND_CAP];   // type << 28 | a << 24 | ref
+    CollideItem items[ITEM_CAP];
+    Cand pool[POOL_CAP];
+};
+RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
+RLG_HD CollideItem unpack_cand(uint32_t c) {
+    CollideItem it; it.type = (int16_t)(c >> 28); it.a = (int16_t)((c >> 24) & 15u); it.ref = (int32_t)(c & 0xFFFFFFu); it.off = 0; it.n = 0;
+    return it;
+}
+
+RLG_HD int fetch_add(int& x, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // lanes of one wavefront append to the same queue; the queue lives in LDS (ds_add_rtn instead of a flat atomic)
+    return __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    int o = x; x += v; return o;
+#endif
+}
+
+RLG_HD void queue_candidates(CollideQueue& Q, int type, int a, int first, int cnt) {
+    int k = Q.n_cand;
+    if (k + cnt > CAND_CAP) { Q.overflow = 1; return; }
+    Q.n_cand = k + cnt;
+    for (int q = 0; q < cnt; q++) Q.cand[k + q] = pack_cand(type, a, first + q);
+}
+
+// every BVH leaf whose box overlaps [lo,hi], in walk order: f(first triangle, count)
+template <class F>
+RLG_HD void mesh_query_leaves(MeshView mesh, V3 lo, V3 hi, F&& f) {
+    if (!mesh_maybe_near(mesh, lo, hi)) return;
+    uint32_t i = 0;
+    while (i != BVH_END) {
+        BvhNode nd = mesh_node(mesh, (int)i);
+        uint32_t next = node_escape(nd);
+        if (aabb_overlap(nd, lo, hi)) {
+            const int cnt = node_count(nd);
+            if (cnt > 0) f(nd.left_or_first, cnt);
+            else next = (uint32_t)nd.left_or_first + 1u;
+        }
+        i = next;
+    }
+}
+
+RLG_HD void ball_query_aabb(V3 bp, V3& lo, V3& hi) {
+    const float r = K::BALL_RADIUS * UU2BT;
+    float bext = r + 0.08f + 0.04f;  // sphere AABB (+0.08 patch, btSphereShape.cpp:55) grown by the trimesh margin
+    lo = bp - v3(bext, bext, bext); hi = bp + v3(bext, bext, bext);
+}
+RLG_HD void car_query_aabb(const Car& car, V3& bc, V3& lo, V3& hi) {
+    V3 h = hitbox_half();
+    bc = car.b.pos + car.b.rot * hitbox_off();
+    M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
+                      v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
+                      v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
+    V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
+    lo = bc - ext; hi = bc + ext;
+}
+RLG_HD bool car_collides(const Car& car) { return !(car.flags & CF_IS_DEMOED) && !car.frozen; }  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
+template <int NC>
+RLG_HD bool cars_maybe_touch(const Arena<NC>& A, int ia, int ib) {
+    const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
+    V3 h = hitbox_half();
+    V3 cca = ca.b.pos + ca.b.rot * hitbox_off(), ccb = cb.b.pos + cb.b.rot * hitbox_off();
+    float rad = len(h);
+    return len2(cca - ccb) <= (2 * rad) * (2 * rad);
+}
+
+// the box the car's candidates are collected for: hitbox query box united with its four suspension rays (the rays are cast
+// from the same pose, before anything moves, so ONE candidate list per car and tick serves both)
+RLG_HD float wheel_ray_len(int i) { return wheel_rest(i) + wheel_travel() + wheel_radius(i) - K::SUSPENSION_SUBTRACTION; }
+RLG_HD void car_wide_aabb(const Car& car, V3& lo, V3& hi) {
+    V3 bc;
+    car_query_aabb(car, bc, lo, hi);
+    V3 wheel_dir = car.b.rot * v3(0, 0, -1);
+    for (int i = 0; i < 4; i++) {
+        V3 from = (car.b.rot * wheel_conn(i)) + car.b.pos, to = from + wheel_dir * wheel_ray_len(i);
+        lo = v3(fminf(lo.x, fminf(from.x, to.x)), fminf(lo.y, fminf(from.y, to.y)), fminf(lo.z, fminf(from.z, to.z)));
+        hi = v3(fmaxf(hi.x, fmaxf(from.x, to.x)), fmaxf(hi.y, fmaxf(from.y, to.y)), fmaxf(hi.z, fmaxf(from.z, to.z)));
+    }
+}
+// which bodies get candidates this tick, and for which box.  A car that is frozen but not demoed (respawned this tick) still
+// casts wheel rays, so it keeps its list; the narrowphase ignores it (car_collides).
+template <int NC>
+RLG_HD bool body_query_box(const Arena<NC>& A, int body, bool ball_asleep, V3& lo, V3& hi) {
+    if (body == 0) {
+        if (ball_asleep) return false;
+        ball_query_aabb(A.ball.b.pos, lo, hi);
+        return true;
+    }
+    const Car& car = A.cars[body - 1];
+    if (car.flags & CF_IS_DEMOED) return false;
+    car_wide_aabb(car, lo, hi);
+    return true;
+}
+
+// Breadth-first walk: every BVH leaf whose box overlaps [lo,hi], level by level, within a level in frontier order.
+// The device runs the same walk with one lane per frontier node (rlgpu_env.hip:build_candidates_wave) and must produce
+// the same sequence, overflow included.
+template <class F>
+RLG_HD void mesh_query_leaves_bfs(MeshView mesh, V3 lo, V3 hi, uint16_t (&fr)[2][FRONTIER_CAP], int& overflow, F&& leaf) {
+    if (!mesh_maybe_near(mesh, lo, hi)) return;
+    int n = 1, cur = 0;
+    fr[0][0] = 0;
+    while (n > 0) {
+        int m = 0;
+        for (int j = 0; j < n; j++) {
+            BvhNode nd = mesh_node(mesh, fr[cur][j]);
+            if (!aabb_overlap(nd, lo, hi)) continue;
+            const int cnt = node_count(nd);
+            if (cnt > 0) leaf(nd.left_or_first, cnt);
+            else {
+                if (m + 2 > FRONTIER_CAP) { overflow = 1; return; }
+                fr[cur ^ 1][m++] = (uint16_t)nd.left_or_first; fr[cur ^ 1][m++] = (uint16_t)(nd.left_or_first + 1);
+            }
+        }
+        n = m; cur ^= 1;
+    }
+}
+
+// every mesh triangle whose AABB overlaps [lo,hi] (TestTriangleAgainstAabb2, btConvexConcaveCollisionAlgorithm.cpp:75), for
+// the inline narrowphase (queue overflow fallback).  Same breadth-first order as the candidate queue, so falling back
+// changes nothing but speed; only a walk that overflows the frontier itself uses the depth-first order.
+template <class F>
+RLG_HD void mesh_query(MeshView mesh, V3 lo, V3 hi, F&& f) {
+    auto per_leaf = [&](int first, int cnt) {
+        for (int k = 0; k < cnt; k++)
+            if (tri_aabb_overlap(mesh.tris[first + k], lo, hi)) f(first + k);
+    };
+    uint16_t fr[2][FRONTIER_CAP];
+    int overflow = mesh.n_nodes > 65535 ? 1 : 0;
+    if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, [](int, int) {});   // dry run: does the frontier fit?
+    if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, per_leaf);
+    else mesh_query_leaves(mesh, lo, hi, per_leaf);
+}
+
+// all candidates of one env for this tick (host form; called before the wheel rays)
+template <int NC>
+RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool ball_asleep, CollideQueue& Q) {
+    Q.n_cand = 0; Q.n_items = 0; Q.n_pool = 0; Q.overflow = 0;
+    if (mesh.n_nodes > 65535) Q.overflow = 1;   // frontier entries are 16 bit: bigger trees use the inline walk
+    for (int body = 0; body <= NC; body++) {
+        Q.cand_start[body] = (uint16_t)Q.n_cand;
+        V3 lo, hi;
+        if (Q.overflow || !body_query_box(A, body, ball_asleep, lo, hi)) continue;
+        const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
+        mesh_query_leaves_bfs(mesh, lo, hi, Q.frontier, Q.overflow, [&](int first, int cnt) { queue_candidates(Q, type, a, first, cnt); });
+    }
+    Q.cand_start[NC + 1] = (uint16_t)Q.n_cand;
+    for (int ci = 0; ci < NC; ci++)
+        for (int ib = ci + 1; ib < NC; ib++)
+            if (car_collides(A.cars[ci]) && car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
+}
+
 RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best) {
     V3 v10 = v1 - v0, v20 = v2 - v0;
     V3 tn = cross(v10, v20);
@@ -281,16 +467,6 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
         }
     }
     return true;
-}
-
-// keep the `cap` deepest candidates of one body-vs-world pair
-struct Cand { V3 pb; V3 n; float dist; };
-template <int CAP>
-RLG_HD void cand_add(Cand (&cs)[CAP], int& n, const Cand& c) {
-    if (n < CAP) { cs[n++] = c; return; }
-    int worst = 0;
-    for (int i = 1; i < CAP; i++) if (cs[i].dist > cs[worst].dist) worst = i;
-    if (c.dist < cs[worst].dist) cs[worst] = c;
 }
 
 // Sutherland-Hodgman clip of a convex polygon (<= 8 pts) against the half space dot(nrm,p) <= off

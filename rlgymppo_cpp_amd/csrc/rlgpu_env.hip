@@ -16,7 +16,8 @@
 
 #ifdef RLG_TICK_PROFILE
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
-__shared__ unsigned long long g_prof[8];
+__shared__ unsigned long long g_prof[12];
+__device__ unsigned long long g_step_prof[16 * 4096];   // k_env_step's buckets per workgroup (first 4096 workgroups)
 __shared__ unsigned long long g_prof_last;
 #define RLG_PROF(i)                                                              \
     do {                                                                         \
@@ -137,6 +138,79 @@ __device__ __forceinline__ WaveSlot wave_slot(unsigned char* lane_mem, int n_env
     return s;
 }
 
+// Phase 0b on the device: this tick's narrowphase candidates (arena_world.h:collide_build_candidates is the host form and
+// defines the order).  The LPE lanes that serve one env walk the BVH breadth-first, one lane per frontier node; bodies
+// of an env go one after the other.  Ballots / shuffles are group-local slices of wave-wide ones, so every loop below
+// is wave-uniform.
+template <int NC>
+__device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, MeshView mv) {
+    constexpr int EPW = lanes_per_block<NC>() / WPB, LPE = WAVE / EPW, NB = NC + 1;
+    const int tid = threadIdx.x & 63, e = tid / LPE, li = tid % LPE;
+    const bool grp = e < n_valid;
+    LaneBlock<NC>& S = lane_block<NC>(lane_mem, grp ? e : 0);
+    CollideQueue& Q = S.W.Q;
+    const unsigned long long gmask = ~0ull >> (64 - LPE);
+    const unsigned long long below_mask = (1ull << li) - 1ull;
+    const bool asleep = (len2(S.A.ball.b.vel) == 0.f && len2(S.A.ball.b.angvel) == 0.f);
+    int n_cand = 0;
+    bool overflow = mv.n_nodes > 65535;
+    // query boxes: lane b of the group computes body b's, the others fetch it with a shuffle
+    V3 my_lo = v3(0, 0, 0), my_hi = v3(0, 0, 0);
+    const bool my_active = grp && li < NB && !overflow && body_query_box(S.A, li, asleep, my_lo, my_hi) && mesh_maybe_near(mv, my_lo, my_hi);
+    for (int body = 0; body < NB; body++) {
+        if (grp && li == 0) Q.cand_start[body] = (uint16_t)n_cand;
+        const int src = e * LPE + body;
+        const V3 lo = v3(__shfl(my_lo.x, src), __shfl(my_lo.y, src), __shfl(my_lo.z, src));
+        const V3 hi = v3(__shfl(my_hi.x, src), __shfl(my_hi.y, src), __shfl(my_hi.z, src));
+        const bool active = __shfl((int)my_active, src) != 0 && !overflow;
+        const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
+        int n = active ? 1 : 0, cur = 0;
+        if (active && li == 0) Q.frontier[0][0] = 0;
+        while (__any(n > 0)) {
+            wave_sync();
+            int m = 0;
+            for (int c0 = 0; __any(c0 < n); c0 += LPE) {
+                const int j = c0 + li;
+                bool inner = false, leaf = false; int cnt = 0, first = 0;
+                if (j < n) {
+                    BvhNode nd = mesh_node(mv, Q.frontier[cur][j]);
+                    if (aabb_overlap(nd, lo, hi)) { cnt = node_count(nd); first = nd.left_or_first; inner = cnt == 0; leaf = cnt > 0; }
+                }
+                const unsigned long long mi = (__ballot(inner) >> (e * LPE)) & gmask;
+                const unsigned long long ml = (__ballot(leaf) >> (e * LPE)) & gmask;
+                bool ovf = false;
+                if (inner) {
+                    const int pos = m + 2 * __popcll(mi & below_mask);
+                    if (pos + 2 > FRONTIER_CAP) ovf = true;
+                    else { Q.frontier[cur ^ 1][pos] = (uint16_t)first; Q.frontier[cur ^ 1][pos + 1] = (uint16_t)(first + 1); }
+                }
+                m += 2 * __popcll(mi);
+                // leaves: a fixed block of LEAF_SLOTS candidate slots per leaf, in frontier order (unused slots are holes) -- a
+                // ballot instead of a prefix sum over the triangle counts
+                if (leaf) {
+                    const int k = n_cand + LEAF_SLOTS * __popcll(ml & below_mask);
+                    if (k + LEAF_SLOTS > CAND_CAP) ovf = true;
+                    else for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[k + q] = q < cnt ? pack_cand(type, a, first + q) : CAND_HOLE;
+                }
+                n_cand += LEAF_SLOTS * __popcll(ml);
+                if ((__ballot(ovf) >> (e * LPE)) & gmask) overflow = true;
+            }
+            n = overflow ? 0 : m;
+            cur ^= 1;
+        }
+        wave_sync();
+    }
+    if (grp && li == 0) {
+        S.W.ball_asleep = asleep;
+        Q.cand_start[NB] = (uint16_t)(n_cand < CAND_CAP ? n_cand : CAND_CAP);
+        Q.n_cand = n_cand < CAND_CAP ? n_cand : CAND_CAP; Q.n_items = 0; Q.n_pool = 0; Q.overflow = overflow ? 1 : 0;
+        for (int ci = 0; ci < NC; ci++)
+            for (int ib = ci + 1; ib < NC; ib++)
+                if (car_collides(S.A.cars[ci]) && car_collides(S.A.cars[ib]) && cars_maybe_touch(S.A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
+    }
+    wave_sync();
+}
+
 // `ev` is meaningful on env lanes (lane e < n_valid owns env e of the wavefront)
 template <int NC>
 __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, uint32_t seed, int env0, TickEvents& ev) {
@@ -153,6 +227,9 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
 
     if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
+    RLG_PROF(0);
+    build_candidates_wave<NC>(lane_mem, n_valid, mv);
+    RLG_PROF(1);
     if (whl_lane) car_wheel_trace(Sw.A, c_whl, w_whl, mv, Sw.W.ctx[c_whl]);
     wave_sync();
     const bool ordered = car_lane && car_needs_ordered_finish(Sc.W.ctx[c_car]);
@@ -165,19 +242,15 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
-    if (env_lane) tick_world_begin(Se.A, Se.W);
+    constexpr int LPE = WAVE / EPW;           // lanes that serve one env in the pad / candidate / item phases
+    const int e_grp = tid / LPE, l_grp = tid % LPE;
+    const bool grp_lane = e_grp < n_valid;
+    LaneBlock<NC>& Sg = lane_block<NC>(lane_mem, grp_lane ? e_grp : 0);
+    if (grp_lane) for (int p = l_grp; p < 34; p += LPE) pad_pre_tick(Sg.A.pads[p]);
+    if (env_lane) tick_world_begin(Se.A, Se.W, true);
     wave_sync();
-    {   // narrowphase (arena_step.h): lane per body lists candidates, lane per candidate tests + compacts, lane per item runs
-        constexpr int NB = NC + 1;
-        const int e_body = tid / NB, b_body = tid % NB;
-        if (e_body < n_valid) {
-            LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_body);
-            collide_queue_body(Sb.A, mv, b_body, Sb.W.ball_asleep, Sb.W.Q);
-        }
-        wave_sync();
-        RLG_PROF(1);
-        constexpr int LPE = WAVE / EPW;   // lanes that serve one env in the candidate and item phases
-        const int e_item = tid / LPE, l_item = tid % LPE;
+    {   // narrowphase (arena_step.h): lane per candidate tests + compacts, lane per item runs
+        const int e_item = e_grp, l_item = l_grp;
         const bool item_lane = e_item < n_valid;
         LaneBlock<NC>& Si = lane_block<NC>(lane_mem, item_lane ? e_item : 0);
         CollideQueue& Q = Si.W.Q;
@@ -187,7 +260,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             for (int c0 = 0; __any(c0 < n_cand); c0 += LPE) {
                 const int k = c0 + l_item;
                 const bool pass = k < n_cand && collide_test_candidate(Si.A, mv, Q, k);
-                const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & ((LPE == 64) ? ~0ull : ((1ull << LPE) - 1ull));
+                const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & (~0ull >> (64 - LPE));
                 if (pass) {
                     const int pos = base + __popcll(m & ((1ull << l_item) - 1ull));
                     if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
@@ -206,9 +279,20 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     RLG_PROF(2);
     if (env_lane) world_step_finish(Se.A, mv, ev, Se.W, true);
     wave_sync();
-    if (car_lane) tick_car_post(Sc.A, c_car);
+    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, c_car); }
     wave_sync();
-    if (env_lane) tick_finish(Se.A);
+    if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
+    wave_sync();
+    {   // pads that hand out boost are rare: they go through the env lane in pad order, all the others finish in parallel
+        bool gives = false;
+        if (grp_lane) for (int p = l_grp; p < 34; p += LPE) { if (pad_gives_boost(Sg.A.pads[p])) gives = true; else pad_post_tick(Sg.A, p); }
+        if (__any(gives)) {
+            wave_sync();
+            if (env_lane) for (int p = 0; p < 34; p++) if (pad_gives_boost(Se.A.pads[p])) pad_post_tick(Se.A, p);
+        }
+    }
+    wave_sync();
+    if (env_lane) tick_finish(Se.A, true);
     wave_sync();
 }
 
@@ -227,6 +311,9 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
     const int D = obs_size<NC>();
     GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
+#ifdef RLG_TICK_PROFILE
+    if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
+#endif
     if (env_lane) {
         load_env(d, env, S.A, S.G);
         int32_t acts[NC];
@@ -234,16 +321,24 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
         gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts, X);
     }
     wave_sync();
+    RLG_PROF(8);
     TickEvents ev; ev.bump_mask = 0;
     arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
     if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
     wave_sync();
+    RLG_PROF(9);
     for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
+    RLG_PROF(6);
+    if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, X);
+    RLG_PROF(10);
     if (env_lane) {
-        gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, X);
         for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
         store_env(d, env, S.A, S.G);
     }
+#ifdef RLG_TICK_PROFILE
+    RLG_PROF(11);
+    if (threadIdx.x == 0 && blockIdx.x < 4096) for (int i = 0; i < 12; i++) g_step_prof[16 * blockIdx.x + i] = g_prof[i];
+#endif
 }
 
 template <int NC>
@@ -534,6 +629,15 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
     return RLGPU_OK;
 }
 
+#ifdef RLG_TICK_PROFILE
+// profiler build only: the 12 phase buckets (cycles) of the last k_env_step launch, 16 values per workgroup
+int rlgpu_env_debug_step_prof(rlgpu_env* e, unsigned long long* out, int n_blocks) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(unsigned long long) * 16 * (size_t)std::min(n_blocks, 4096)));
+    return RLGPU_OK;
+}
+#endif
 // diagnostics (not part of rlgpu.h): per-workgroup {shader cycles, 100 MHz ticks} of `ticks` physics ticks; out has 10 * n_blocks entries (cycles, realtime, 8 phase accumulators of the PROFILE build)
 int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out, int cap_pairs, int* n_blocks) {
     HIPCHK(e, hipSetDevice(e->device));

@@ -49,3 +49,25 @@ for t in range(24):
     env.step(a, nobs, rew, done)
 env.sync()
 run("random-rollout")
+
+# whole gym step (profiler build only): the same buckets plus the non-tick parts of k_env_step
+if hasattr(env.lib, "rlgpu_env_debug_step_prof"):
+    fn2 = env.lib.rlgpu_env_debug_step_prof
+    fn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; fn2.restype = C.c_int
+    nb = (n + 3) // 4
+    acc = np.zeros((min(nb, 4096), 16))
+    reps = 8
+    for t in range(reps):
+        a = torch.randint(0, 90, (env.n_agents,), generator=g, dtype=torch.int32).to(dev)
+        env.step(a, nobs, rew, done)
+        buf = np.zeros(16 * min(nb, 4096), dtype=np.uint64)
+        assert fn2(env.h, buf.ctypes.data, nb) == 0
+        acc += buf.reshape(-1, 16).astype(np.float64)
+    acc /= reps
+    names = ["car pre-tick+pads/gravity", "candidates", "narrowphase items", "contacts+solver setup", "solver iters", "integrate", "post/pads/ball",
+             "wheel ray casts", "load+parse actions", "tracker/snapshot/reward/done", "reset+obs", "store"]
+    tot = acc[:, :12].sum(axis=1)
+    print(f"k_env_step cycles per launch: mean {tot.mean():.0f} max {tot.max():.0f} ({tot.max()/2.38e3:.0f} us)")
+    print("   mean: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, acc[:, :12].mean(axis=0))))
+    w = int(np.argmax(tot))
+    print("   slowest wg: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, acc[w, :12])))
