@@ -3,6 +3,7 @@
 // Restates RocketSim/src/Sim/Car/Car.cpp:58-193,330-833 and RocketSim/src/Sim/btVehicleRL/btVehicleRL.cpp:64-402
 // for a fixed Octane (CarConfig.cpp:20-70).  All vectors are in BT units (uu/50) like the reference's btRigidBody.
 #pragma once
+#include <cstddef>
 #include "arena_body.h"
 #include "arena_world.h"
 
@@ -23,7 +24,8 @@ RLG_HD float rot_roll(const M3& m) {
 
 struct CarTickCtx {
     WheelTmp w[4];
-    M3 wheel_basis[4];
+    M3 wheel_basis[2];   // [0] both front wheels (steered), [1] both back wheels
+    unsigned long long ray_key[4];   // closest mesh hit of each wheel's ray (arena_world.h:ray_key)
     int n_contact;
     bool wheels_world;
     float forward_speed_uu;
@@ -428,19 +430,25 @@ RLG_HD_NOINLINE void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_
     }
 }
 
-// phase 1, per (car, wheel): wheel transform with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235), the
-// suspension ray (btVehicleRL.cpp:118-212) and the hard-stop pushback (btContactConstraint.cpp:60-105)
+// phase 1 = the suspension rays, in three steps so that the mesh part can run as one lane per (ray, candidate) pair:
+//   1a per (car, wheel)         car_wheel_ray_begin   wheel transform with LAST tick's steer angle (btVehicleRL.cpp:64-92,218-235),
+//                                                      the ray, its hit against the four planes
+//   1b per (car, wheel, cand)   car_ray_pair          ray vs one candidate triangle of the car (arena_world.h), closest wins
+//   1c per (car, wheel)         car_wheel_ray_finish  ball / other cars, suspension (btVehicleRL.cpp:118-212), hard-stop pushback
+//                                                      (btContactConstraint.cpp:60-105), the wheel's friction work
+// Between 1a and 1c the ray lives in the wheel's scratch: hard_point = origin, contact_point = end, contact_normal / susp_len /
+// ground = plane hit (normal / fraction / kind); the pair winners sit in ray_key[].
+RLG_HD unsigned long long* ray_keys(CarTickCtx& t) { return t.ray_key; }
+
 template <int NC>
-RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, MeshView mesh, CarTickCtx& t) {
+RLG_HD_NOINLINE void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
-    const float dt = TICK_DT;
     Car& cr = A.cars[ci];
     // NB: as in the reference, a car respawned in phase 0 runs the rest of the pre-tick (Respawn clears the flag,
     // Car.cpp:86-87 checks the NEW state).
     if (cr.flags & CF_IS_DEMOED) return;
-    const M3 rot = cr.b.rot; const V3 pos = cr.b.pos, vel = cr.b.vel, angvel = cr.b.angvel;
+    const M3 rot = cr.b.rot; const V3 pos = cr.b.pos;
     const float steer_angle = cr.steer_angle;
-    V3 up = col2(rot);
     V3 wheel_dir = rot * v3(0, 0, -1), axle = rot * v3(0, -1, 0);
     {
         V3 wup = -wheel_dir;
@@ -448,21 +456,54 @@ RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, MeshView mesh,
         M3 basis2 = m3_cols(fwd, -axle, wup);
         if (i < 2 && steer_angle != 0.f) {
             M3 steer = quat_to_m3(quat_axis_angle(wup, steer_angle));
-            t.wheel_basis[i] = steer * basis2;
+            t.wheel_basis[i >> 1] = steer * basis2;
         } else {
-            t.wheel_basis[i] = basis2;  // a zero steering angle gives the exact identity quaternion (0,0,0,1)
+            t.wheel_basis[i >> 1] = basis2;  // a zero steering angle gives the exact identity quaternion (0,0,0,1)
         }
     }
-    WheelTmp w;
+    WheelTmp& w = t.w[i];
+    V3 source = (rot * wheel_conn(i)) + pos, target = source + (wheel_dir * wheel_ray_len(i));
+    RayHit hit = ray_planes(source, target);
+    w.hard_point = source; w.contact_point = target;
+    w.contact_normal = hit.normal; w.susp_len = hit.frac; w.ground = hit.kind;
+    ray_keys(t)[i] = RAY_NO_HIT;
+}
+
+// pair `pair` of car ci: candidate slot = first + pair / 4, wheel = pair % 4 (the 4 wheels of a car share each triangle fetch)
+template <int NC>
+RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue& Q, int ci, int pair, CarTickCtx& t) {
+    const int slot = (int)Q.cand_start[1 + ci] + (pair >> 2), i = pair & 3;
+    const uint32_t c = Q.cand[slot];
+    if (c == CAND_HOLE) return;
+    const WheelTmp& w = t.w[i];
+    float d;
+    if (ray_triangle_pair(mesh.tris[unpack_cand(c).ref], w.hard_point, w.contact_point, w.susp_len, d)) ray_key_min(ray_keys(t)[i], ray_key(d, slot));
+}
+template <int NC>
+RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue& Q, int ci) {
+    if (A.cars[ci].flags & CF_IS_DEMOED) return 0;
+    return 4 * ((int)Q.cand_start[2 + ci] - (int)Q.cand_start[1 + ci]);
+}
+
+template <int NC>
+RLG_HD_NOINLINE void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue& Q, CarTickCtx& t) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t); RLG_ASSUME_LDS(Q);
+    const float dt = TICK_DT;
+    Car& cr = A.cars[ci];
+    if (cr.flags & CF_IS_DEMOED) return;
+    const M3 rot = cr.b.rot; const V3 pos = cr.b.pos, vel = cr.b.vel, angvel = cr.b.angvel;
+    V3 up = col2(rot);
+    V3 wheel_dir = rot * v3(0, 0, -1);
+    WheelTmp w = t.w[i];
     float rest = wheel_rest(i), radius = wheel_radius(i), travel = wheel_travel();
-    w.hard_point = (rot * wheel_conn(i)) + pos;
-    float ray_len = rest + travel + radius - K::SUSPENSION_SUBTRACTION;
-    V3 source = w.hard_point, target = source + (wheel_dir * ray_len);
-    w.contact_point = target;
-    w.impulse = v3(0, 0, 0);
+    V3 source = w.hard_point, target = w.contact_point;
+    RayHit hit; hit.kind = w.ground; hit.frac = w.susp_len; hit.normal = w.contact_normal;
     RLG_PROF(0);
-    RayHit hit = world_ray_cast(A, ci, mesh, source, target);
+    if (Q.overflow) ray_mesh_walk(mesh, source, target, hit);
+    else ray_apply_mesh_key(mesh, Q, ray_keys(t)[i], source, target, hit);
+    ray_ball_and_cars(A, ci, source, target, hit);
     RLG_PROF(7);
+    w.impulse = v3(0, 0, 0);
     w.ground = -1; w.in_contact = false;
     if (hit.kind >= 0) {
         float rt = hit.frac, s = 1.f - rt;
@@ -497,12 +538,13 @@ RLG_HD_NOINLINE void car_wheel_trace(Arena<NC>& A, int ci, int i, MeshView mesh,
             }
         }
     } else {
+        w.contact_point = target;
         w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
         cr.extra_pushback[i] = 0.f;
     }
     // per-wheel halves of calcFrictionImpulses and _UpdateWheels (see the two helpers above)
-    w.impulse = wheel_friction_impulse(A, cr, w, t.wheel_basis[i], i);
-    if (w.ground >= 0) wheel_friction_factors(cr, w, t.wheel_basis[i], t.new_lat[i], t.new_long[i]);
+    w.impulse = wheel_friction_impulse(A, cr, w, t.wheel_basis[i >> 1], i);
+    if (w.ground >= 0) wheel_friction_factors(cr, w, t.wheel_basis[i >> 1], t.new_lat[i], t.new_long[i]);
     t.w[i] = w;
 }
 
@@ -535,7 +577,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
     // friction impulses: taken from the wheel lanes (car_wheel_trace) unless a wheel stands on another car -- that reads the
     // other car's velocity, which its own phase 2 may already have changed (callers run such ticks in car order)
     if (car_needs_ordered_finish(t)) {
-        for (int i = 0; i < 4; i++) t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], t.wheel_basis[i], i);
+        for (int i = 0; i < 4; i++) t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], t.wheel_basis[i >> 1], i);
     }
 
     bool jump_pressed = c.ctl.jump && !c.last.jump;

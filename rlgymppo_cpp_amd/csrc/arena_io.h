@@ -26,7 +26,6 @@ struct GymEnv {
     uint32_t reset_count;          // RNG counter for state setters
 };
 
-RLG_HD uint32_t f2u(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
 RLG_HD float u2f(uint32_t u) { union { float f; uint32_t u; } x; x.u = u; return x.f; }
 
 // word accessors used by the visitor

@@ -691,7 +691,10 @@ template <int NC>
 RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
     for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
     tick_build_candidates(A, mesh, W);
-    for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_trace(A, i, w, mesh, W.ctx[i]);
+    for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_ray_begin(A, i, w, W.ctx[i]);
+    if (!W.Q.overflow)
+        for (int i = 0; i < NC; i++) for (int pr = 0, n = car_ray_pairs(A, W.Q, i); pr < n; pr++) car_ray_pair(A, mesh, W.Q, i, pr, W.ctx[i]);
+    for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_ray_finish(A, i, w, mesh, W.Q, W.ctx[i]);
     for (int i = 0; i < NC; i++) car_pre_tick_finish(A, i, W.ctx[i]);
     tick_world_begin(A, W, false);
     collide_compact_and_run(A, mesh, W.Q);

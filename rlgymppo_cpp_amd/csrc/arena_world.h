@@ -308,11 +308,10 @@ RLG_HD void world_plane(int i, V3& n, float& d) {
     else { n = v3(-1, 0, 0); d = -ex; }
 }
 
-template <int NC>
-RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, MeshView mesh, V3 from, V3 to) {
-    RLG_ASSUME_LDS(A);
+// A suspension ray is cast in three stages (planes | mesh | ball and cars) so that the mesh stage can run as one lane per
+// (ray, candidate triangle) pair on the device; every later stage only accepts strictly closer hits, as one loop would.
+RLG_HD RayHit ray_planes(V3 from, V3 to) {
     RayHit best; best.kind = -1; best.frac = 1.0f; best.normal = v3(0, 0, 0);
-    // planes
     for (int i = 0; i < 4; i++) {
         V3 n; float d; world_plane(i, n, d);
         float da = dot(n, from) - d, db = dot(n, to) - d;
@@ -320,27 +319,58 @@ RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, MeshView
         float f = da / (da - db);
         if (f < best.frac) { best.frac = f; best.kind = 0; best.normal = (da <= 0.f) ? -n : n; }
     }
-    // mesh
-    if (mesh_maybe_near(mesh, v3(fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)), v3(fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)))) {
-        V3 dvec = to - from;
-        V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
-        uint32_t i = 0;
-        while (i != BVH_END) {
-            BvhNode nd = mesh_node(mesh, (int)i);
-            uint32_t next = node_escape(nd);
-            if (ray_aabb(nd, from, inv_d, best.frac)) {
-                const int cnt = node_count(nd);
-                if (cnt > 0) {
-                    for (int k = 0; k < cnt; k++) {
-                        const MeshTri& t = mesh.tris[nd.left_or_first + k];
-                        ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
-                    }
-                } else next = (uint32_t)nd.left_or_first + 1u;
-            }
-            i = next;
+    return best;
+}
+
+// mesh stage, one (ray, triangle) pair: hit closer than `bound`?  (same test as ray_triangle)
+RLG_HD bool ray_triangle_pair(const MeshTri& t, V3 from, V3 to, float bound, float& d_out) {
+    RayHit probe; probe.kind = -1; probe.frac = bound; probe.normal = v3(0, 0, 0);
+    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, probe);
+    d_out = probe.frac;
+    return probe.kind == 0;
+}
+// the winner of the pairs: key = frac bits << 32 | candidate slot (smaller = closer, then earlier), ~0 = no hit
+constexpr unsigned long long RAY_NO_HIT = ~0ull;
+RLG_HD unsigned long long ray_key(float d, int slot) { return ((unsigned long long)f2u(d) << 32) | (unsigned long long)(uint32_t)slot; }
+RLG_HD void ray_key_min(unsigned long long& key, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_min((__attribute__((address_space(3))) unsigned long long*)&key, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    if (v < key) key = v;
+#endif
+}
+RLG_HD void ray_apply_mesh_key(MeshView mesh, const CollideQueue& Q, unsigned long long key, V3 from, V3 to, RayHit& best) {
+    if (key == RAY_NO_HIT) return;
+    const MeshTri& t = mesh.tris[unpack_cand(Q.cand[(uint32_t)key]).ref];
+    RayHit h; h.kind = -1; h.frac = best.frac; h.normal = v3(0, 0, 0);
+    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, h);
+    if (h.kind == 0) best = h;   // recomputed from the winning triangle: same frac, and its ray-facing normal
+}
+// mesh stage without a candidate list (queue overflow): depth-first BVH walk
+RLG_HD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
+    if (!mesh_maybe_near(mesh, v3(fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)), v3(fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)))) return;
+    V3 dvec = to - from;
+    V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
+    uint32_t i = 0;
+    while (i != BVH_END) {
+        BvhNode nd = mesh_node(mesh, (int)i);
+        uint32_t next = node_escape(nd);
+        if (ray_aabb(nd, from, inv_d, best.frac)) {
+            const int cnt = node_count(nd);
+            if (cnt > 0) {
+                for (int k = 0; k < cnt; k++) {
+                    const MeshTri& t = mesh.tris[nd.left_or_first + k];
+                    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
+                }
+            } else next = (uint32_t)nd.left_or_first + 1u;
         }
+        i = next;
     }
-    // ball (point vs sphere of radius 1.825)
+}
+
+// last stage: ball (point vs sphere of radius 1.825), then the other cars' hitboxes
+template <int NC>
+RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, RayHit& best) {
     {
         const float r = K::BALL_RADIUS * UU2BT;
         V3 d = to - from, m = from - A.ball.b.pos;
@@ -380,7 +410,6 @@ RLG_HD_NOINLINE RayHit world_ray_cast(const Arena<NC>& A, int self_car, MeshView
             best.frac = tn; best.kind = 2 + k; best.normal = o.b.rot * nl;
         }
     }
-    return best;
 }
 
 // ---- contact list ---------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -212,6 +213,7 @@ RLG_HD void philox4(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint32_
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+RLG_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }   // bit pattern (monotonic for f >= 0)
 RLG_HD float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
 }  // namespace rlg

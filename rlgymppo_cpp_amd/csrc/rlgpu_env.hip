@@ -230,7 +230,24 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     RLG_PROF(0);
     build_candidates_wave<NC>(lane_mem, n_valid, mv);
     RLG_PROF(1);
-    if (whl_lane) car_wheel_trace(Sw.A, c_whl, w_whl, mv, Sw.W.ctx[c_whl]);
+    // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
+    if (whl_lane) car_wheel_ray_begin(Sw.A, c_whl, w_whl, Sw.W.ctx[c_whl]);
+    wave_sync();
+    {
+        constexpr int LPE_R = WAVE / EPW;
+        const int e_r = tid / LPE_R, l_r = tid % LPE_R;
+        if (e_r < n_valid) {
+            LaneBlock<NC>& Sr = lane_block<NC>(lane_mem, e_r);
+            if (!Sr.W.Q.overflow) {
+                for (int ci = 0; ci < NC; ci++) {
+                    const int n_pairs = car_ray_pairs(Sr.A, Sr.W.Q, ci);
+                    for (int pr = l_r; pr < n_pairs; pr += LPE_R) car_ray_pair(Sr.A, mv, Sr.W.Q, ci, pr, Sr.W.ctx[ci]);
+                }
+            }
+        }
+    }
+    wave_sync();
+    if (whl_lane) car_wheel_ray_finish(Sw.A, c_whl, w_whl, mv, Sw.W.Q, Sw.W.ctx[c_whl]);
     wave_sync();
     const bool ordered = car_lane && car_needs_ordered_finish(Sc.W.ctx[c_car]);
     if (__ballot(ordered) == 0ull) {
