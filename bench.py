@@ -39,6 +39,18 @@ def cpu_baseline(seconds_target=12.0):
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_oracle.so")
     port_so = os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # the reference library prints to the C stdout (e.g. "DiscreteAction(): Lookup table built"): keep this process' stdout
+    # a single JSON line by parking fd 1 on stderr while the baseline runs
+    sys.stdout.flush()
+    saved_fd = os.dup(1); os.dup2(2, 1)
+    try:
+        return _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so)
+    finally:
+        sys.stdout.flush(); os.dup2(saved_fd, 1); os.close(saved_fd)
+
+
+def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so):
+    import ctypes as C
     try:
         if os.path.exists(ref_so) and os.path.exists(port_so):
             from simlib import PortSim, RefSim

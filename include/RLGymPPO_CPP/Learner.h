@@ -1,0 +1,47 @@
+// Learner (PUB/Learner.h, PUB/Learner.cpp:17-721): same construction, callbacks, Learn() loop, reports and checkpoint layout as the
+// reference, driving ONE device env batch + the device learner of include/rlgpu.h instead of agent threads and libtorch.
+#pragma once
+#include "LearnerConfig.h"
+#include "Threading/GameInst.h"
+#include "Util/WelfordRunningStat.h"
+#include "Util/Timer.h"
+namespace RLGPC {
+struct EnvCreateResult { RLGSC::Match* match; RLGSC::Gym* gym; };
+typedef std::function<EnvCreateResult()> EnvCreateFn;
+class Learner;
+typedef std::function<void(Learner*, Report&)> IterationCallback;
+
+class Learner {
+public:
+    LearnerConfig config;
+    EnvCreateFn envCreateFn;
+    int obsSize = 0, actionAmount = 0;
+    std::string runID;
+    uint64_t totalTimesteps = 0, totalEpochs = 0, totalIterations = 0;
+    WelfordRunningStat returnStats;
+    IterationCallback iterationCallback = nullptr;
+    StepCallback stepCallback = nullptr;
+
+    Learner(EnvCreateFn envCreateFn, LearnerConfig config);
+    Learner(const Learner&) = delete;
+    Learner& operator=(const Learner&) = delete;
+    ~Learner();
+
+    void Learn();                                    // Learner.cpp:436-606
+    void UpdateLearningRates(float policyLR, float criticLR);
+    std::vector<Report> GetAllGameMetrics();         // Learner.cpp:705-721 (and clears them, like the reference)
+    void Save();                                     // <checkpointSaveFolder>/<totalTimesteps>/{PPO_*.lt, RUNNING_STATS.json}
+    void Load();                                     // newest numbered subfolder of checkpointLoadFolder
+    void SaveStats(std::filesystem::path path);
+    void LoadStats(std::filesystem::path path);
+
+    // one iteration, in the pieces Learn() strings together (also what tests drive)
+    void CollectTimesteps();                         // ThreadAgentManager::CollectTimesteps for every game at once
+    void AddNewExperience(Report& report);           // Learner.cpp:608-703: value predictions, GAE, return statistics
+    void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349)
+    int NumEnvs() const;
+    int NumAgents() const;
+private:
+    struct Impl; Impl* impl;
+};
+}

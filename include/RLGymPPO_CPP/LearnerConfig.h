@@ -1,0 +1,41 @@
+// LearnerConfig: every field name and default of PUB/LearnerConfig.h:14-80
+#pragma once
+#include "Lists.h"
+#include "PPO/PPOLearnerConfig.h"
+#include "Util/SkillTrackerConfig.h"
+namespace RLGPC {
+enum class LearnerDeviceType { AUTO, CPU, GPU_CUDA };
+struct LearnerConfig {
+    int numThreads = 8;                 // envs = numThreads * numGamesPerThread (one device batch; there are no host threads)
+    int numGamesPerThread = 16;
+    int minInferenceSize = 80;          // unused: inference always covers the whole batch
+    bool renderMode = false;            // not built
+    float renderTimeScale = 1.5f;
+    bool renderDuringTraining = false;
+    uint64_t timestepLimit = 0;
+    int64_t expBufferSize = 100 * 1000;
+    int64_t timestepsPerIteration = 50 * 1000;
+    bool standardizeReturns = true;
+    bool standardizeOBS = false;
+    int maxReturnsPerStatsInc = 150;
+    int stepsPerObsStatsInc = 5;
+    bool deterministic = false;
+    bool collectionDuringLearn = false; // not built
+    PPOLearnerConfig ppo = {};
+    float gaeLambda = 0.95f;
+    float gaeGamma = 0.99f;
+    float rewardClipRange = 10;
+    std::filesystem::path checkpointLoadFolder = "checkpoints";
+    std::filesystem::path checkpointSaveFolder = "checkpoints";
+    bool saveFolderAddUnixTimestamp = false;
+    int64_t timestepsPerSave = 500 * 1000;
+    int randomSeed = 123;
+    int checkpointsToKeep = 5;
+    LearnerDeviceType deviceType = LearnerDeviceType::AUTO;   // AUTO / GPU_CUDA = the HIP device; CPU is refused (no CPU path)
+    bool sendMetrics = true;            // metrics are printed; the Python wandb receiver is out of scope
+    std::string metricsProjectName = "rlgymppo-cpp";
+    std::string metricsGroupName = "unnamed-runs";
+    std::string metricsRunName = "rlgymppo-cpp-run";
+    SkillTrackerConfig skillTrackerConfig = {};
+};
+}

@@ -1,0 +1,470 @@
+// Learner.hip -- C++ host side of the reference's API (include/RLGymPPO_CPP/Learner.h) over the C-ABI of include/rlgpu.h.
+// What it restates (reference file:line, PUB = RLGymPPO_CPP/src/public/RLGymPPO_CPP, PRIV = .../src/private/RLGymPPO_CPP):
+//   Learner::Learner            PUB/Learner.cpp:17-156       one device env batch + device learner instead of agent threads + libtorch
+//   Learner::Learn              PUB/Learner.cpp:436-606      collect -> AddNewExperience -> PPOLearner::Learn -> report -> callbacks -> save
+//   Learner::AddNewExperience   PUB/Learner.cpp:608-703
+//   PPOLearner::Learn           PRIV/PPO/PPOLearner.cpp:67-349
+//   Learner::Save / Load        PUB/Learner.cpp:171-376, PRIV/PPO/PPOLearner.cpp:362-502   (same folder layout and file names;
+//                                .lt payload = this repo's RLGPU_LT1 container, shared with rlgymppo_cpp_amd/learner.py)
+// Everything on the data path stays in device memory; this file only sequences launches.  Compiled by hipcc because of the
+// three small bookkeeping kernels below.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+
+#include <RLGymPPO_CPP/Learner.h>
+#include "../../include/rlgpu_state.h"
+
+namespace {
+
+#define HOST_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (call);                                                                          \
+        if (_e != hipSuccess) RG_ERR_CLOSE(#call << " failed: " << hipGetErrorString(_e));               \
+    } while (0)
+
+// done (int32) -> float, and the collector's truncation mark: the last step of every trajectory is truncated unless done
+// (ThreadAgentManager.cpp:55)
+__global__ void k_done_trunc(const int32_t* done, int T, int n, float* done_f, float* trunc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * n) return;
+    float d = done[i] ? 1.f : 0.f;
+    done_f[i] = d;
+    trunc[i] = (i / n == (size_t)(T - 1)) ? 1.f - d : 0.f;
+}
+// out[k] += sum |x_k| for up to three arrays (report averages, Learner.cpp:670-677)
+__global__ void k_abs_sums(const float* a, const float* b, const float* c, size_t n, float* out) {
+    float s[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { s[0] += fabsf(a[i]); s[1] += fabsf(b[i]); s[2] += fabsf(c[i]); }
+    for (int k = 0; k < 3; k++) {
+        float v = s[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v);
+    }
+}
+__global__ void k_sum(const float* a, size_t n, float* out) {
+    float s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += a[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+std::filesystem::path g_mesh_folder;
+const char MAGIC[] = "RLGPU_LT1\n";
+
+template <class T>
+T* dev_alloc(size_t n) { T* p = nullptr; HOST_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
+
+}  // namespace
+
+namespace RocketSim {
+void Init(const std::filesystem::path& collisionMeshesFolder, bool silent) {
+    g_mesh_folder = collisionMeshesFolder;
+    if (!silent) RG_LOG("RocketSim::Init: arena meshes from \"" << (collisionMeshesFolder / "soccar").string() << "\" (procedural soccar mesh if absent)");
+}
+const std::filesystem::path& GetCollisionMeshFolder() { return g_mesh_folder; }
+}
+
+namespace RLGSC {
+// GameState::UpdateFromArena / PlayerData::UpdateFromCar (SIM/Utils/Gamestates/GameState.cpp:52-104, PlayerData.cpp:4-34) from a
+// downloaded env
+GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
+    auto V = [](const float* p) { return Vec(p[0], p[1], p[2]); };
+    scoreLine.teamGoals[0] = s.gym.score_line[0]; scoreLine.teamGoals[1] = s.gym.score_line[1];
+    lastTouchCarID = s.gym.last_touch_car_id;
+    lastTickCount = (uint64_t)s.tick_count; deltaTickCount = tickSkip;
+    ball.pos = V(s.ball.pos); ball.vel = V(s.ball.vel); ball.angVel = V(s.ball.ang_vel);
+    ballInv = ball.Invert();
+    for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[p].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
+    players.resize(s.num_cars);
+    for (int k = 0; k < s.num_cars; k++) {
+        const RlgpuCarState& c = s.cars[k]; const RlgpuPlayerGymState& g = s.gym.players[k];
+        PlayerData& pd = players[k];
+        pd.carId = (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
+        pd.phys.pos = V(c.pos); pd.phys.vel = V(c.vel); pd.phys.angVel = V(c.ang_vel);
+        pd.phys.rotMat.forward = V(c.rot); pd.phys.rotMat.right = V(c.rot + 3); pd.phys.rotMat.up = V(c.rot + 6);
+        pd.physInv = pd.phys.Invert();
+        CarState& cs = pd.carState;
+        cs.pos = pd.phys.pos; cs.vel = pd.phys.vel; cs.angVel = pd.phys.angVel; cs.rotMat = pd.phys.rotMat;
+        cs.isOnGround = c.flags & RLGPU_CF_ON_GROUND; cs.hasJumped = c.flags & RLGPU_CF_HAS_JUMPED; cs.hasDoubleJumped = c.flags & RLGPU_CF_HAS_DOUBLE_JUMPED;
+        cs.hasFlipped = c.flags & RLGPU_CF_HAS_FLIPPED; cs.isJumping = c.flags & RLGPU_CF_IS_JUMPING; cs.isFlipping = c.flags & RLGPU_CF_IS_FLIPPING;
+        cs.isSupersonic = c.flags & RLGPU_CF_IS_SUPERSONIC; cs.isDemoed = c.flags & RLGPU_CF_IS_DEMOED;
+        cs.boost = c.boost; cs.airTimeSinceJump = c.air_time_since_jump; cs.jumpTime = c.jump_time; cs.flipTime = c.flip_time; cs.demoRespawnTimer = c.demo_respawn_timer;
+        pd.matchGoals = g.match_goals; pd.matchSaves = g.match_saves; pd.matchAssists = g.match_assists; pd.matchShots = g.match_shots;
+        pd.matchShotPasses = g.match_shot_passes; pd.matchBumps = g.match_bumps; pd.matchDemos = g.match_demos; pd.boostPickups = g.boost_pickups;
+        pd.boostFraction = c.boost / 100.f;
+        // PlayerData.cpp:20-30
+        pd.ballTouchedStep = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit >= s.tick_count - tickSkip;
+        pd.ballTouchedTick = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit == s.tick_count - 1;
+        pd.hasJump = !cs.hasJumped;
+        pd.hasFlip = !cs.isOnGround && !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;
+    }
+}
+}  // namespace RLGSC
+
+namespace RLGPC {
+
+struct Learner::Impl {
+    rlgpu_env* env = nullptr; rlgpu_learner* lrn = nullptr; rlgpu_shuffler* shuf = nullptr;
+    RLGSC::Match* match = nullptr; RLGSC::Gym* gym = nullptr;
+    int nEnvs = 0, nAgents = 0, nPlayers = 0, D = 0, A = 0, T = 0, tickSkip = 8;
+    int64_t B = 0, batch = 0, mini = 0; int maxRows = 0;
+    float *obs = nullptr, *logp = nullptr, *rew = nullptr, *doneF = nullptr, *trunc = nullptr, *vals = nullptr, *adv = nullptr, *tgt = nullptr, *ret = nullptr,
+          *metrics = nullptr, *scratch = nullptr;
+    int32_t *acts = nullptr, *done = nullptr, *idx = nullptr;
+    bool first = true;
+    uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
+    std::vector<GameInst> games;
+    std::vector<RlgpuArenaState> hostStates; std::vector<float> hostRew; std::vector<int32_t> hostDone;
+    std::vector<int64_t> perm; std::vector<int32_t> phys;
+    Timer iterTimer;
+
+    void EnvCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
+    void LrnCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_" << what << " failed (" << rc << "): " << rlgpu_learner_last_error(lrn)); }
+    float* ObsAt(int t) { return obs + (size_t)t * nAgents * D; }
+};
+
+Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(config_), envCreateFn(envCreateFn_), impl(new Impl()) {
+    Impl& m = *impl;
+    if (config.deviceType == LearnerDeviceType::CPU) RG_ERR_CLOSE("LearnerDeviceType::CPU: this build has no CPU path (the hot path is HIP kernels)");
+    if (config.renderMode) RG_ERR_CLOSE("renderMode is not built (DESIGN.md: out of scope)");
+    // The reference calls envCreateFn once per game and once more to probe the obs size (Learner.cpp:99-109); every call
+    // describes the same env, so one call is enough to configure the whole device batch.
+    EnvCreateResult ecr = envCreateFn();
+    if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
+    m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
+    RlgpuGymConfig gcfg = m.match->ToDeviceConfig(m.tickSkip);
+    gcfg.seed_lo = (uint32_t)config.randomSeed; gcfg.seed_hi = 0;
+    m.nEnvs = config.numThreads * config.numGamesPerThread;
+    m.nPlayers = m.match->playerAmount;
+    int rc = rlgpu_env_create(&m.env, 0, m.nEnvs, m.match->teamSize, &gcfg);
+    m.EnvCheck(rc, "create");
+    std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
+    if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
+    else {
+        RG_LOG("Learner: no collision meshes at \"" << soccar.string() << "\" -- using the procedural soccar mesh");
+        m.EnvCheck(rlgpu_env_set_procedural_mesh(m.env), "set_procedural_mesh");
+    }
+    m.nAgents = rlgpu_env_num_agents(m.env); m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);
+    obsSize = m.D; actionAmount = m.A;
+    // steps per env and iteration: enough whole steps of the batch to reach timestepsPerIteration (ThreadAgent.cpp:158-163 stops
+    // each thread once it passed its share)
+    m.T = (int)std::max<int64_t>(1, (config.timestepsPerIteration + m.nAgents - 1) / m.nAgents);
+    m.B = (int64_t)m.T * m.nAgents;
+    m.batch = config.ppo.batchSize > 0 ? std::min<int64_t>(config.ppo.batchSize, m.B) : m.B;
+    m.mini = config.ppo.miniBatchSize > 0 ? std::min<int64_t>(config.ppo.miniBatchSize, m.batch) : m.batch;
+    if (m.batch % m.mini != 0) RG_ERR_CLOSE("PPOLearner: batchSize (" << m.batch << ") must be a multiple of miniBatchSize (" << m.mini << ")");   // PPOLearner.cpp:31-33
+    m.maxRows = (int)std::max<int64_t>(m.mini, m.nAgents);
+
+    RlgpuLearnerConfig lc{};
+    lc.obs_size = m.D; lc.n_actions = m.A;
+    if (config.ppo.policyLayerSizes.size() > 8 || config.ppo.criticLayerSizes.size() > 8) RG_ERR_CLOSE("at most 8 hidden layers per network");
+    lc.n_policy_layers = (int)config.ppo.policyLayerSizes.size(); lc.n_critic_layers = (int)config.ppo.criticLayerSizes.size();
+    for (int i = 0; i < lc.n_policy_layers; i++) lc.policy_layers[i] = config.ppo.policyLayerSizes[i];
+    for (int i = 0; i < lc.n_critic_layers; i++) lc.critic_layers[i] = config.ppo.criticLayerSizes[i];
+    lc.policy_lr = config.ppo.policyLR; lc.critic_lr = config.ppo.criticLR; lc.ent_coef = config.ppo.entCoef; lc.clip_range = config.ppo.clipRange;
+    lc.temperature = config.ppo.policyTemperature; lc.use_bf16 = config.ppo.autocastLearn ? 1 : 0;
+    lc.seed_lo = (uint32_t)config.randomSeed; lc.seed_hi = 0; lc.max_rows = m.maxRows;
+    rc = rlgpu_learner_create(&m.lrn, 0, &lc);
+    m.LrnCheck(rc, "learner_create");
+    rlgpu_shuffler_create(&m.shuf, (uint32_t)config.randomSeed);
+
+    const size_t TN = (size_t)m.T * m.nAgents;
+    m.obs = dev_alloc<float>((size_t)(m.T + 1) * m.nAgents * m.D);
+    m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN); m.idx = dev_alloc<int32_t>(TN);
+    m.logp = dev_alloc<float>(TN); m.rew = dev_alloc<float>(TN); m.doneF = dev_alloc<float>(TN); m.trunc = dev_alloc<float>(TN);
+    m.adv = dev_alloc<float>(TN); m.tgt = dev_alloc<float>(TN); m.ret = dev_alloc<float>(TN);
+    m.vals = dev_alloc<float>(TN + m.nAgents); m.metrics = dev_alloc<float>(8); m.scratch = dev_alloc<float>(8);
+    m.perm.resize(m.B); m.phys.resize(m.B);
+    m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
+
+    runID = config.metricsRunName;
+    if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
+        config.checkpointSaveFolder += "-" + std::to_string(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count());
+    if (!config.checkpointLoadFolder.empty()) Load();
+}
+
+Learner::~Learner() {
+    Impl& m = *impl;
+    for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
+                    (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch})
+        if (p) (void)hipFree(p);
+    if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
+    if (m.lrn) rlgpu_learner_destroy(m.lrn);
+    if (m.env) rlgpu_env_destroy(m.env);
+    delete m.gym; delete m.match;   // GameInst deletes its gym and match in the reference (GameInst.h:53-56); plugins stay the user's
+    delete impl;
+}
+
+int Learner::NumEnvs() const { return impl->nEnvs; }
+int Learner::NumAgents() const { return impl->nAgents; }
+
+void Learner::UpdateLearningRates(float policyLR, float criticLR) {
+    config.ppo.policyLR = policyLR; config.ppo.criticLR = criticLR;
+    impl->LrnCheck(rlgpu_learner_set_lr(impl->lrn, policyLR, criticLR), "learner_set_lr");
+}
+
+// ThreadAgent::_RunFunc (ThreadAgent.cpp:24-195) for every game at once: policy inference and the env step never leave the device
+void Learner::CollectTimesteps() {
+    Impl& m = *impl;
+    const size_t rowObs = (size_t)m.nAgents * m.D;
+    if (!m.first) HOST_HIP(hipMemcpyAsync(m.ObsAt(0), m.ObsAt(m.T), rowObs * 4, hipMemcpyDeviceToDevice, nullptr));
+    m.first = false;
+    const bool slow = (bool)stepCallback;
+    if (slow && m.games.empty()) {
+        m.games.resize(m.nEnvs);
+        for (int e = 0; e < m.nEnvs; e++) { m.games[e].gym = m.gym; m.games[e].match = m.match; m.games[e].index = e; }
+        m.hostStates.resize(m.nEnvs); m.hostRew.resize(m.nAgents); m.hostDone.resize(m.nAgents);
+    }
+    for (int t = 0; t < m.T; t++) {
+        const size_t o = (size_t)t * m.nAgents;
+        m.LrnCheck(rlgpu_policy_act(m.lrn, m.ObsAt(t), m.nAgents, config.deterministic ? 1 : 0, nullptr, m.acts + o, m.logp + o), "policy_act");
+        m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
+        if (slow) {
+            // the reference hands every game's StepResult to the callback (GameInst.cpp:14-38): materialise host GameStates -- slow path.
+            // NB: the downloaded state is the one AFTER the step's auto-reset when the episode ended.
+            m.EnvCheck(rlgpu_env_download_states(m.env, m.hostStates.data(), nullptr, m.nEnvs), "download_states");
+            HOST_HIP(hipMemcpy(m.hostRew.data(), m.rew + o, (size_t)m.nAgents * 4, hipMemcpyDeviceToHost));
+            HOST_HIP(hipMemcpy(m.hostDone.data(), m.done + o, (size_t)m.nAgents * 4, hipMemcpyDeviceToHost));
+            for (int e = 0; e < m.nEnvs; e++) {
+                GameInst& g = m.games[e];
+                RLGSC::Gym::StepResult sr;
+                sr.state = RLGSC::GameState(m.hostStates[e], m.tickSkip);
+                sr.reward.assign(m.hostRew.begin() + (size_t)e * m.nPlayers, m.hostRew.begin() + (size_t)(e + 1) * m.nPlayers);
+                sr.done = m.hostDone[(size_t)e * m.nPlayers] != 0;
+                float sum = std::accumulate(sr.reward.begin(), sr.reward.end(), 0.f);
+                g.avgStepRew.Add(sum, (uint64_t)m.nPlayers); g.curEpRew += sum / m.nPlayers; g.totalSteps++;
+                if (sr.done) { g.avgEpRew += g.curEpRew; g.curEpRew = 0; }
+                stepCallback(&g, sr, g._metrics);
+            }
+        }
+    }
+    totalTimesteps += (uint64_t)m.B;
+}
+
+std::vector<Report> Learner::GetAllGameMetrics() {
+    std::vector<Report> out;
+    for (auto& g : impl->games) { out.push_back(g._metrics); g.ResetMetrics(); }
+    return out;
+}
+
+void Learner::AddNewExperience(Report& report) {
+    Impl& m = *impl;
+    const size_t TN = (size_t)m.T * m.nAgents, rows = TN + m.nAgents;
+    for (size_t s = 0; s < rows; s += m.maxRows) {   // minibatched value predictions, incl. the states after the last step (Learner.cpp:619-640)
+        int n = (int)std::min<size_t>(m.maxRows, rows - s);
+        m.LrnCheck(rlgpu_value_forward(m.lrn, m.obs + s * m.D, n, m.vals + s), "value_forward");
+    }
+    const float retStd = config.standardizeReturns ? (float)returnStats.GetSTD() : 1.f;   // read BEFORE this batch updates it (Learner.cpp:651)
+    hipLaunchKernelGGL(k_done_trunc, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)m.done, m.T, m.nAgents, m.doneF, m.trunc);
+    m.LrnCheck(rlgpu_gae(m.lrn, m.rew, m.doneF, m.trunc, m.vals, m.T, m.nAgents, config.gaeGamma, config.gaeLambda, retStd, config.rewardClipRange, 0, m.adv, m.tgt, m.ret), "gae");
+    if (config.standardizeReturns) {
+        // the first <= maxReturnsPerStatsInc returns of the (agent-major) batch = agent 0's first steps (Learner.cpp:679-682)
+        int k = std::min(config.maxReturnsPerStatsInc, m.T);
+        FList first(k);
+        HOST_HIP(hipMemcpy2D(first.data(), 4, m.ret, (size_t)m.nAgents * 4, 4, k, hipMemcpyDeviceToHost));
+        returnStats.Increment(first, k);
+    }
+    float sums[3] = {0, 0, 0};
+    HOST_HIP(hipMemsetAsync(m.scratch, 0, 32, nullptr));
+    hipLaunchKernelGGL(k_abs_sums, dim3(256), dim3(256), 0, nullptr, (const float*)m.ret, (const float*)m.adv, (const float*)m.tgt, TN, m.scratch);
+    hipLaunchKernelGGL(k_sum, dim3(256), dim3(256), 0, nullptr, (const float*)m.rew, TN, m.scratch + 3);
+    float h[4];
+    HOST_HIP(hipMemcpy(h, m.scratch, 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) sums[i] = h[i] / (float)TN;
+    report["Avg Return"] = sums[0] / retStd; report["Avg Advantage"] = sums[1]; report["Avg Val Target"] = sums[2];
+    report["Average Step Reward"] = h[3] / (float)TN;
+}
+
+void Learner::LearnPPO(Report& report) {
+    Impl& m = *impl;
+    if (config.deterministic) RG_ERR_CLOSE("PPOLearner::Learn() called with config.deterministic = true");   // Learner.cpp:472-477
+    HOST_HIP(hipMemsetAsync(m.metrics, 0, 32, nullptr));
+    int nMini = 0, nUpdates = 0;
+    Timer t;
+    for (int ep = 0; ep < config.ppo.epochs; ep++) {
+        // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126): logical rows are agent-major (trajectory after trajectory);
+        // the device buffers are time-major
+        rlgpu_shuffler_next(m.shuf, m.B, m.perm.data());
+        for (int64_t i = 0; i < m.B; i++) { int64_t p = m.perm[i]; m.phys[i] = (int32_t)((p % m.T) * m.nAgents + (p / m.T)); }
+        HOST_HIP(hipMemcpyAsync(m.idx, m.phys.data(), (size_t)m.B * 4, hipMemcpyHostToDevice, nullptr));
+        for (int64_t b = 0; b + m.batch <= m.B; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
+            m.LrnCheck(rlgpu_zero_grads(m.lrn), "zero_grads");
+            for (int64_t k = 0; k < m.batch; k += m.mini) {
+                m.LrnCheck(rlgpu_ppo_minibatch(m.lrn, m.obs, m.acts, m.logp, m.adv, m.tgt, m.idx + b + k, (int)m.mini, (float)m.mini / (float)m.batch, m.metrics), "ppo_minibatch");
+                nMini++;
+            }
+            m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)
+            nUpdates++;
+        }
+    }
+    m.LrnCheck(rlgpu_learner_sync(m.lrn), "learner_sync");
+    float h[8];
+    HOST_HIP(hipMemcpy(h, m.metrics, 32, hipMemcpyDeviceToHost));
+    const double rows = std::max<double>(1, (double)nMini * m.mini);
+    report["Policy Entropy"] = h[0] / rows; report["Mean KL Divergence"] = h[1] / rows; report["SB3 Clip Fraction"] = h[2] / rows;
+    report["Value Function Loss"] = h[4] / rows; report["PPO Learn Time"] = t.Elapsed();
+    totalEpochs += config.ppo.epochs; m.cumulativeModelUpdates += nUpdates;
+    report["Cumulative Model Updates"] = (double)m.cumulativeModelUpdates;
+}
+
+void Learner::Learn() {
+    Impl& m = *impl;
+    RG_LOG("Learner: " << m.nEnvs << " envs (" << m.nAgents << " agents), obs " << m.D << ", actions " << m.A << ", " << m.T << " steps/env/iteration = "
+           << m.B << " timesteps, batch " << m.batch << ", minibatch " << m.mini);
+    while (config.timestepLimit == 0 || totalTimesteps < config.timestepLimit) {
+        Report report;
+        Timer tAll, tCollect;
+        CollectTimesteps();
+        HOST_HIP(hipDeviceSynchronize());
+        double collectTime = tCollect.Elapsed();
+        Timer tConsume;
+        AddNewExperience(report);
+        LearnPPO(report);
+        double consumeTime = tConsume.Elapsed();
+        totalIterations++;
+        report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
+        report["Timesteps Collected"] = (double)m.B;
+        report["Collection Time"] = collectTime; report["Consumption Time"] = consumeTime; report["Total Iteration Time"] = tAll.Elapsed();
+        report["Collected Steps/Second"] = (double)m.B / std::max(collectTime, 1e-9);
+        report["Overall Steps/Second"] = (double)m.B / std::max(tAll.Elapsed(), 1e-9);
+        if (iterationCallback) iterationCallback(this, report);
+        RG_LOG(std::string(8, '\n') << std::string(20, '=') << " ITERATION COMPLETED " << std::string(20, '='));
+        const std::vector<std::string> rows = {"Average Step Reward", "Policy Entropy", "Value Function Loss", "", "Mean KL Divergence", "SB3 Clip Fraction", "Avg Return",
+                        "Avg Advantage", "Avg Val Target", "", "Collected Steps/Second", "Overall Steps/Second", "", "Collection Time", "Consumption Time",
+                        "-PPO Learn Time", "Total Iteration Time", "", "Cumulative Model Updates", "Cumulative Timesteps", "Total Iterations"};
+        report.Display(rows);
+        // metrics the iteration callback added go where the reference sends them to its metrics receiver: here, the log
+        for (auto& kv : report.data) {
+            std::string dashed = "-" + kv.first;
+            if (std::find(rows.begin(), rows.end(), kv.first) == rows.end() && std::find(rows.begin(), rows.end(), dashed) == rows.end()) RG_LOG("  [metric] " << report.SingleToString(kv.first));
+        }
+        m.tsSinceSave += (uint64_t)m.B;
+        if (!config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
+    }
+    if (!config.checkpointSaveFolder.empty()) Save();
+}
+
+// ---- checkpoints ------------------------------------------------------------------------------------------------------
+namespace {
+std::string LtHeader(const std::vector<std::pair<int, int>>& shapes) {
+    std::ostringstream h;
+    h << "{\"tensors\": [";
+    for (size_t i = 0; i < shapes.size(); i++) h << (i ? ", " : "") << "{\"name\": \"" << 2 * i << ".weight\", \"shape\": [" << shapes[i].first << ", " << shapes[i].second << "]}";
+    h << "], \"dtype\": \"<f4\", \"order\": \"0.weight,0.bias,2.weight,...\"}";
+    return h.str();
+}
+void WriteLt(const std::filesystem::path& p, const std::vector<float>& flat, const std::vector<std::pair<int, int>>& shapes) {
+    std::ofstream f(p, std::ios::binary);
+    std::string hdr = LtHeader(shapes); uint64_t n = hdr.size();
+    f.write(MAGIC, sizeof(MAGIC) - 1); f.write((const char*)&n, 8); f.write(hdr.data(), (std::streamsize)n); f.write((const char*)flat.data(), (std::streamsize)flat.size() * 4);
+}
+std::vector<float> ReadLt(const std::filesystem::path& p, size_t want, const std::vector<std::pair<int, int>>& shapes) {
+    std::ifstream f(p, std::ios::binary);
+    char mg[sizeof(MAGIC) - 1];
+    if (!f.read(mg, sizeof(mg)) || memcmp(mg, MAGIC, sizeof(mg)) != 0) RG_ERR_CLOSE(p.string() << " is not a v1 .lt payload (TorchScript .lt import is not implemented yet)");
+    uint64_t n = 0; f.read((char*)&n, 8);
+    std::string hdr(n, '\0'); f.read(hdr.data(), (std::streamsize)n);
+    // shape check of every parameter (PPOLearner.cpp:380-408): the header lists the weight shapes in order
+    std::string want_shapes; for (auto& s : shapes) want_shapes += "[" + std::to_string(s.first) + ", " + std::to_string(s.second) + "]";
+    std::string got_shapes; for (size_t i = 0; (i = hdr.find("\"shape\": ", i)) != std::string::npos; i += 9) got_shapes += hdr.substr(i + 9, hdr.find(']', i) - (i + 9) + 1);
+    std::vector<float> flat(want);
+    f.read((char*)flat.data(), (std::streamsize)want * 4);
+    if (got_shapes != want_shapes || (size_t)f.gcount() != want * 4 || f.peek() != EOF) RG_ERR_CLOSE("saved model has different size than the current model (" << p.string() << ")");
+    return flat;
+}
+}  // namespace
+
+void Learner::SaveStats(std::filesystem::path path) {
+    std::ofstream f(path);
+    double var = returnStats.count >= 2 ? returnStats.runningVariance / (double)(returnStats.count - 1) : 0.0;
+    f << std::setprecision(17) << "{\n    \"cumulative_timesteps\": " << totalTimesteps << ",\n    \"cumulative_model_updates\": " << impl->cumulativeModelUpdates
+      << ",\n    \"epoch\": " << totalEpochs << ",\n    \"reward_running_stats\": {\n        \"mean\": [" << returnStats.runningMean << "],\n        \"var\": [" << var
+      << "],\n        \"shape\": 1,\n        \"count\": " << returnStats.count << "\n    }\n}\n";
+}
+void Learner::LoadStats(std::filesystem::path path) {
+    std::ifstream f(path);
+    if (!f) RG_ERR_CLOSE("cannot open " << path.string());
+    std::string s((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    auto num = [&](const std::string& key) {
+        size_t i = s.find("\"" + key + "\"");
+        if (i == std::string::npos) RG_ERR_CLOSE(path.string() << ": missing \"" << key << "\"");
+        i = s.find(':', i) + 1;
+        while (i < s.size() && (s[i] == ' ' || s[i] == '[' || s[i] == '\n')) i++;
+        return std::stod(s.substr(i));
+    };
+    totalTimesteps = (uint64_t)num("cumulative_timesteps"); impl->cumulativeModelUpdates = (uint64_t)num("cumulative_model_updates"); totalEpochs = (uint64_t)num("epoch");
+    returnStats.runningMean = num("mean"); returnStats.count = (int64_t)num("count");
+    returnStats.runningVariance = returnStats.count >= 2 ? num("var") * (double)(returnStats.count - 1) : 0.0;
+}
+
+void Learner::Save() {
+    Impl& m = *impl;
+    if (config.checkpointSaveFolder.empty()) RG_ERR_CLOSE("Learner::Save(): checkpointSaveFolder is empty");
+    std::filesystem::path folder = config.checkpointSaveFolder / std::to_string(totalTimesteps);
+    std::filesystem::create_directories(folder);
+    SaveStats(folder / "RUNNING_STATS.json");
+    auto shapesOf = [&](const IList& hidden, int out) { std::vector<std::pair<int, int>> s; int in = m.D; for (int h : hidden) { s.push_back({h, in}); in = h; } s.push_back({out, in}); return s; };
+    const int64_t nPol = rlgpu_learner_num_params(m.lrn, 0), nCri = rlgpu_learner_num_params(m.lrn, 1);
+    std::vector<float> pol(nPol), cri(nCri), am(nPol + nCri), av(nPol + nCri); int64_t sp = 0, sc = 0;
+    m.LrnCheck(rlgpu_learner_get_params(m.lrn, 0, pol.data()), "get_params"); m.LrnCheck(rlgpu_learner_get_params(m.lrn, 1, cri.data()), "get_params");
+    m.LrnCheck(rlgpu_learner_get_adam_state(m.lrn, am.data(), av.data(), &sp, &sc), "get_adam_state");
+    WriteLt(folder / "PPO_POLICY.lt", pol, shapesOf(config.ppo.policyLayerSizes, m.A));
+    WriteLt(folder / "PPO_CRITIC.lt", cri, shapesOf(config.ppo.criticLayerSizes, 1));
+    auto writeOptim = [&](const char* name, const float* mm, const float* vv, int64_t n, int64_t step) {
+        std::ofstream f(folder / name, std::ios::binary);
+        f.write(MAGIC, sizeof(MAGIC) - 1); f.write((const char*)&step, 8); f.write((const char*)&n, 8); f.write((const char*)mm, n * 4); f.write((const char*)vv, n * 4);
+    };
+    writeOptim("PPO_POLICY_OPTIM.lt", am.data(), av.data(), nPol, sp);
+    writeOptim("PPO_CRITIC_OPTIM.lt", am.data() + nPol, av.data() + nPol, nCri, sc);
+    m.tsSinceSave = 0;
+    if (config.checkpointsToKeep > 0) {   // prune the lowest-numbered folders (Learner.cpp:256-280)
+        std::vector<uint64_t> nums;
+        for (auto& e : std::filesystem::directory_iterator(config.checkpointSaveFolder)) {
+            std::string n = e.path().filename().string();
+            if (e.is_directory() && !n.empty() && std::all_of(n.begin(), n.end(), ::isdigit)) nums.push_back(std::stoull(n));
+        }
+        std::sort(nums.begin(), nums.end());
+        for (size_t i = 0; i + config.checkpointsToKeep < nums.size(); i++) std::filesystem::remove_all(config.checkpointSaveFolder / std::to_string(nums[i]));
+    }
+    RG_LOG("Learner: saved checkpoint " << folder.string());
+}
+
+void Learner::Load() {
+    Impl& m = *impl;
+    if (config.checkpointLoadFolder.empty() || !std::filesystem::is_directory(config.checkpointLoadFolder)) return;
+    bool any = false; uint64_t best = 0;   // the highest-numbered sub-folder (Learner.cpp:291-309)
+    for (auto& e : std::filesystem::directory_iterator(config.checkpointLoadFolder)) {
+        std::string n = e.path().filename().string();
+        if (e.is_directory() && !n.empty() && std::all_of(n.begin(), n.end(), ::isdigit)) { best = std::max<uint64_t>(best, std::stoull(n)); any = true; }
+    }
+    if (!any) return;
+    std::filesystem::path folder = config.checkpointLoadFolder / std::to_string(best);
+    LoadStats(folder / "RUNNING_STATS.json");
+    auto shapesOf = [&](const IList& hidden, int out) { std::vector<std::pair<int, int>> s; int in = m.D; for (int h : hidden) { s.push_back({h, in}); in = h; } s.push_back({out, in}); return s; };
+    const int64_t nPol = rlgpu_learner_num_params(m.lrn, 0), nCri = rlgpu_learner_num_params(m.lrn, 1);
+    std::vector<float> pol = ReadLt(folder / "PPO_POLICY.lt", nPol, shapesOf(config.ppo.policyLayerSizes, m.A));
+    std::vector<float> cri = ReadLt(folder / "PPO_CRITIC.lt", nCri, shapesOf(config.ppo.criticLayerSizes, 1));
+    m.LrnCheck(rlgpu_learner_set_params(m.lrn, 0, pol.data()), "set_params"); m.LrnCheck(rlgpu_learner_set_params(m.lrn, 1, cri.data()), "set_params");
+    std::vector<float> am(nPol + nCri, 0.f), av(nPol + nCri, 0.f); int64_t sp = 0, sc = 0;
+    auto readOptim = [&](const char* name, float* mm, float* vv, int64_t n, int64_t& step) {   // missing / foreign optimizer file -> fresh Adam state (PPOLearner.cpp:442-451)
+        std::ifstream f(folder / name, std::ios::binary);
+        char mg[sizeof(MAGIC) - 1]; int64_t st = 0, cnt = 0;
+        if (!f || !f.read(mg, sizeof(mg)) || memcmp(mg, MAGIC, sizeof(mg)) != 0) return;
+        f.read((char*)&st, 8); f.read((char*)&cnt, 8);
+        if (cnt != n) return;
+        std::vector<float> a(n), b(n);
+        f.read((char*)a.data(), n * 4); f.read((char*)b.data(), n * 4);
+        if (!f) return;
+        std::copy(a.begin(), a.end(), mm); std::copy(b.begin(), b.end(), vv); step = st;
+    };
+    readOptim("PPO_POLICY_OPTIM.lt", am.data(), av.data(), nPol, sp);
+    readOptim("PPO_CRITIC_OPTIM.lt", am.data() + nPol, av.data() + nPol, nCri, sc);
+    m.LrnCheck(rlgpu_learner_set_adam_state(m.lrn, am.data(), av.data(), sp, sc), "set_adam_state");
+    UpdateLearningRates(config.ppo.policyLR, config.ppo.criticLR);   // Learner.cpp:501
+    RG_LOG("Learner: loaded checkpoint " << folder.string() << " (" << totalTimesteps << " timesteps)");
+}
+
+}  // namespace RLGPC

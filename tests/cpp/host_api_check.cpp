@@ -1,0 +1,66 @@
+// CPU-only checks of the C++ host layer (include/RLGymSim_CPP, include/RLGymPPO_CPP): the plugin classes translate to the
+// device gym configuration exactly as rlgpu_default_gym_config describes the reference's example stack, unsupported plugins
+// fail loudly with the reference's "RG FATAL ERROR" exception, and the small utility types behave like the reference's.
+#include <RLGymPPO_CPP/Learner.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CombinedReward.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/ZeroSumReward.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
+#include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
+#include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
+#include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
+#include <cstdio>
+#include <cstring>
+using namespace RLGSC; using namespace RLGPC;
+
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+struct MyReward : RewardFunction {   // a user reward without a device form
+    float GetReward(const PlayerData& p, const GameState&, const Action&) override { return p.phys.vel.Length(); }
+};
+
+int main() {
+    // the example stack == the C-ABI's default config, field by field
+    CombinedReward rew({{new FaceBallReward(), 0.1f}, {new VelocityPlayerToBallReward(), 0.5f}, {new VelocityBallToGoalReward(), 1.0f},
+                        {new EventReward({.teamGoal = 1.f, .concede = -1.f}), 50.f}}, true);
+    NoTouchCondition nt(150); GoalScoreCondition gs; DefaultOBS obs; DiscreteAction act; RandomState rs(true, true, true);
+    Match match(&rew, {&nt, &gs}, &obs, &act, &rs, 1, true);
+    RlgpuGymConfig got = match.ToDeviceConfig(8), want; rlgpu_default_gym_config(&want);
+    CHECK(got.tick_skip == want.tick_skip && got.n_terms == want.n_terms && got.n_conds == want.n_conds);
+    for (int i = 0; i < want.n_terms; i++) CHECK(got.terms[i].kind == want.terms[i].kind && got.terms[i].weight == want.terms[i].weight && got.terms[i].p0 == want.terms[i].p0);
+    CHECK(std::memcmp(got.event_weights, want.event_weights, sizeof(want.event_weights)) == 0);
+    CHECK(got.conds[0] == want.conds[0] && got.conds[1] == want.conds[1] && got.no_touch_max_steps == want.no_touch_max_steps);
+    CHECK(got.setter_kind == want.setter_kind && got.rand_ball_speed == 1 && got.rand_car_speed == 1 && got.cars_on_ground == 1);
+    CHECK(std::memcmp(got.pos_coef, want.pos_coef, 12) == 0 && got.vel_coef == want.vel_coef && got.ang_vel_coef == want.ang_vel_coef);
+    CHECK(got.n_actions == 90 && act.GetActionAmount() == 90 && match.playerAmount == 2);
+    // DiscreteAction: row 0 of the table and the parse path
+    ActionSet parsed = act.ParseActions({0, 89}, GameState());
+    CHECK(parsed.size() == 2 && parsed[0].throttle == -1.f && parsed[0].steer == -1.f);
+    // zero-sum wrapper, kickoff setter, weights multiply through nested CombinedRewards
+    ZeroSumReward zs(new CombinedReward({{new TouchBallReward(0.5f), 2.f}, {new SaveBoostReward(), 1.f}}, true), 0.3f, 0.9f);
+    KickoffState ks;
+    Match m2(&zs, {&gs}, &obs, &act, &ks, 2, true);
+    RlgpuGymConfig c2 = m2.ToDeviceConfig(4);
+    CHECK(c2.zero_sum == 1 && c2.team_spirit == 0.3f && c2.opp_scale == 0.9f && c2.n_terms == 2 && c2.terms[0].kind == RLGPU_RW_TOUCH_BALL && c2.terms[0].weight == 2.f && c2.terms[0].p0 == 0.5f);
+    CHECK(c2.setter_kind == RLGPU_SS_KICKOFF && c2.n_conds == 1 && c2.tick_skip == 4 && m2.playerAmount == 4);
+    // a reward with no device form is refused loudly, with the reference's error prefix
+    MyReward mine; Match m3(&mine, {&gs}, &obs, &act, &rs);
+    bool threw = false;
+    try { m3.ToDeviceConfig(8); } catch (const std::runtime_error& e) { threw = std::string(e.what()).rfind("RG FATAL ERROR", 0) == 0; }
+    CHECK(threw);
+    // Report / AvgTracker / WelfordRunningStat
+    Report r; r.AccumAvg("x", 2); r.AccumAvg("x", 4); r["n"] = 1234567;
+    CHECK(r.GetAvg("x") == 3 && r.Has("n") && !r.Has("y") && r.SingleToString("n", true) == "n: 1,234,567");
+    AvgTracker a; CHECK(std::isnan(a.Get())); a += 1.f; a += NAN; a += 3.f; CHECK(a.Get() == 2.f && a.count == 2);
+    WelfordRunningStat w; CHECK(w.GetSTD() == 1.0); w.Increment({1.f, 2.f, 3.f, 4.f}, 4);
+    CHECK(std::fabs(w.GetSTD() - std::sqrt(5.0 / 3.0)) < 1e-12 && w.count == 4);
+    // PhysObj::Invert mirrors x and y
+    PhysObj p; p.pos = Vec(1, 2, 3); p.rotMat.forward = Vec(0, 1, 0);
+    PhysObj q = p.Invert(); CHECK(q.pos.x == -1 && q.pos.y == -2 && q.pos.z == 3 && q.rotMat.forward.y == -1);
+    // config defaults of the reference
+    LearnerConfig lc; CHECK(lc.numThreads == 8 && lc.numGamesPerThread == 16 && lc.ppo.epochs == 10 && lc.ppo.batchSize == 50000 && lc.gaeGamma == 0.99f && lc.maxReturnsPerStatsInc == 150);
+    std::printf("host api ok\n");
+    return 0;
+}
