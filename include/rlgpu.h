@@ -49,6 +49,8 @@ typedef struct RlgpuGymConfig {
     uint32_t seed_lo, seed_hi;
     float pos_coef[3], vel_coef, ang_vel_coef;       /* DefaultOBS ctor (DefaultOBS.h:11-15) */
     int32_t n_actions;                               /* DiscreteAction: 90 */
+    int32_t obs_max_players;                         /* 0: DefaultOBS.  m > 0: DefaultOBSPadded(maxPlayers = m) (DefaultOBSPadded.cpp:3-66): teammates and
+                                                      * opponents shuffled per observation; m must equal team_size (wider padding is not built) */
 } RlgpuGymConfig;
 
 /* fills cfg with the examplemain.cpp:58-100 stack: 0.1 FaceBall + 0.5 VelPlayerToBall + 1.0 VelBallToGoal +

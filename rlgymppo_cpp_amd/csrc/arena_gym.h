@@ -33,6 +33,7 @@ struct GymConfig {
     uint32_t seed_lo, seed_hi;
     float pos_coef[3], vel_coef, ang_vel_coef;      // DefaultOBS.h:11-15
     int32_t n_actions;
+    int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers) with maxPlayers == team size: shuffled mates / opponents
 };
 
 // obs-order -> RocketSim pad index (GameState.cpp:10-50 builds this by matching CommonValues::BOOST_LOCATIONS
@@ -206,8 +207,11 @@ RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, c
     *o++ = S.boost_frac[k]; *o++ = S.on_ground[k] ? 1.f : 0.f; *o++ = S.has_flip[k] ? 1.f : 0.f; *o++ = S.demoed[k] ? 1.f : 0.f;
     return o;
 }
+// DefaultOBS::BuildOBS (DefaultOBS.cpp:3-55).  With cfg.obs_max_players (DefaultOBSPadded.cpp:3-66, maxPlayers == team size, so no
+// zero blocks) the teammate blocks and the opponent blocks are each shuffled per observation; the reference shuffles with the
+// process-wide std engine, here the permutation comes from the env's Philox stream keyed by (env, step, reset count, player).
 template <int NC>
-RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o) {
+RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o, uint32_t env_id, uint32_t step, uint32_t resets) {
     bool inv = (k % 2) == 1;
     V3 bp = inv3(S.ball_pos, inv), bv = inv3(S.ball_vel, inv), bw = inv3(S.ball_angvel, inv);
     *o++ = bp.x * cfg.pos_coef[0]; *o++ = bp.y * cfg.pos_coef[1]; *o++ = bp.z * cfg.pos_coef[2];
@@ -216,8 +220,19 @@ RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_a
     for (int i = 0; i < 8; i++) *o++ = prev_action8[i];
     for (int i = 0; i < 34; i++) { int src = inv ? (33 - i) : i; *o++ = ((S.pads_active >> src) & 1ull) ? 1.f : 0.f; }
     o = obs_add_player(o, S, k, inv, cfg);
-    for (int j = 0; j < NC; j++) if (j != k && (j % 2) == (k % 2)) o = obs_add_player(o, S, j, inv, cfg);  // teammates, state.players order
-    for (int j = 0; j < NC; j++) if (j != k && (j % 2) != (k % 2)) o = obs_add_player(o, S, j, inv, cfg);  // opponents
+    int mates[NC], opps[NC], nm = 0, no = 0;
+    for (int j = 0; j < NC; j++) if (j != k) { if ((j % 2) == (k % 2)) mates[nm++] = j; else opps[no++] = j; }   // state.players order
+    if (cfg.obs_max_players > 0) {
+        uint32_t r[4];
+        philox4(cfg.seed_lo ^ 0x0B5E55EDu, cfg.seed_hi, env_id, step, (resets << 8) | (uint32_t)k, r);
+        // Fisher-Yates from the back, one 16-bit draw per swap (lists have <= 3 entries)
+        uint32_t bits = r[0];
+        for (int i = nm - 1; i > 0; i--) { int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; int t = mates[i]; mates[i] = mates[j]; mates[j] = t; }
+        bits = r[1];
+        for (int i = no - 1; i > 0; i--) { int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; int t = opps[i]; opps[i] = opps[j]; opps[j] = t; }
+    }
+    for (int i = 0; i < nm; i++) o = obs_add_player(o, S, mates[i], inv, cfg);
+    for (int i = 0; i < no; i++) o = obs_add_player(o, S, opps[i], inv, cfg);
 }
 
 // ---- rewards ---------------------------------------------------------------------------------------------
@@ -443,7 +458,7 @@ RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint
         G.tracker_flags &= ~0xff00u;
         for (int k = 0; k < NC; k++) for (int i = 0; i < 8; i++) X.pa[k][i] = 0.f;
     }
-    for (int k = 0; k < NC; k++) build_obs(X.S, k, X.pa[k], cfg, next_obs + (size_t)k * obs_row_stride);
+    for (int k = 0; k < NC; k++) build_obs(X.S, k, X.pa[k], cfg, next_obs + (size_t)k * obs_row_stride, env_id, G.episode_steps, G.reset_count);
 }
 
 template <int NC>
@@ -468,7 +483,7 @@ RLG_HD void gym_reset_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uin
     gym_episode_reset(A, G, cfg, S);
     G.tracker_flags &= ~0xff00u;
     float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (obs) for (int k = 0; k < NC; k++) build_obs(S, k, zero, cfg, obs + (size_t)k * obs_row_stride);
+    if (obs) for (int k = 0; k < NC; k++) build_obs(S, k, zero, cfg, obs + (size_t)k * obs_row_stride, env_id, G.episode_steps, G.reset_count);
 }
 
 }  // namespace rlg

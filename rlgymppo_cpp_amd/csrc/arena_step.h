@@ -399,6 +399,8 @@ struct TickWork {
     };
     CarTickCtx ctx[NC];
     bool ball_asleep;
+    int8_t nrow[MAXC], frow[MAXC];   // solver rows of contact k (normal / friction), -1 = none (solver_prepare)
+    int16_t n_normal, n_rows;
 };
 static_assert(sizeof(CollideQueue) <= sizeof(Row) * TickWork<2>::MAXR, "the narrowphase queue must fit inside the solver rows it shares LDS with");
 
@@ -416,10 +418,14 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
     A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
 }
 
-// world step, second part (per env): contact list, solver, integration.  `queued`: the narrowphase items of this env
-// were run through W.Q (collide_queue_body / collide_run_item); otherwise, or when the queue overflowed, run them here.
+// world step, second part, in four pieces of different width (the host runs them back to back):
+//   solver_prepare   per env       contact list (`queued`: from the narrowphase queue W.Q, else / on overflow inline), solver
+//                                  bodies, the averaged ball-world contact, and which solver rows each contact gets
+//   solver_rows      per contact   its normal row and its friction row (btSequentialImpulseConstraintSolver.cpp:1003-1211)
+//   solver_iterate   per env       split-impulse + velocity iterations (:1601-1877) -- sequential by nature (Gauss-Seidel)
+//   solver_finish    per body      write back (:1878-1904), integrateTransforms (btDiscreteDynamicsWorld.cpp:889-1027), clearForces
 template <int NC>
-RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
+RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     constexpr int NB = NC + 1;
@@ -432,9 +438,8 @@ RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& 
     bool touch;
     if (queued && !W.Q.overflow) collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowQueued{W.Q});
     else collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowInline());
-    bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
+    const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 
-    // ---- solver setup
     {
         SolverBody& s = B[0];
         s.v = A.ball.b.vel; s.w = A.ball.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
@@ -449,44 +454,54 @@ RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& 
         s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
         s.active = !c.frozen && !(c.flags & CF_IS_DEMOED);
     }
-    int nr = 0;
-    int n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f, sp_fric = 0.f, sp_rest = 0.f;
-    int first_fric;
-    // normal rows
+    // row numbering: normal rows in contact order (contacts of an inactive ball are dropped), then the averaged special row,
+    // then one friction row per non-special contact, then the special row's friction row
+    int nr = 0, n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f, sp_fric = 0.f, sp_rest = 0.f;
     for (int k = 0; k < L.n; k++) {
         const Contact& c = L.c[k];
-        if (c.a == 0 && !ball_active) { continue; }
-        bool has_b = c.b >= 0;
-        row_setup_normal(R[nr], c, B, c.n, c.ra, c.rb, c.dist, c.friction, c.restitution, has_b);
-        if (c.special) {
-            R[nr].skip = 1;
-            n_special++; sp_fric = c.friction; sp_rest = c.restitution; sp_normal += c.n; sp_dist += len(c.ra);
-        }
-        nr++;
+        W.nrow[k] = -1; W.frow[k] = -1;
+        if (c.a == 0 && !ball_active) continue;
+        W.nrow[k] = (int8_t)nr++;
+        if (c.special) { n_special++; sp_fric = c.friction; sp_rest = c.restitution; sp_normal += c.n; sp_dist += len(c.ra); }
     }
-    int n_contact_rows = nr;
-    Contact spc;
-    if (n_special > 0) {  // convertContactSpecial (btSequentialImpulseConstraintSolver.cpp:1164-1211)
+    const int n_contact_rows = nr;
+    if (n_special > 0) nr++;
+    W.n_normal = nr;
+    for (int k = 0; k < L.n; k++) if (W.nrow[k] >= 0 && !L.c[k].special) W.frow[k] = (int8_t)nr++;
+    if (n_special > 0) {  // convertContactSpecial (btSequentialImpulseConstraintSolver.cpp:1164-1211): its two rows are set up here
+        Contact spc;
         float distance = sp_dist / (float)n_special;
         V3 normal = sp_normal / (float)n_special;
         spc.a = 0; spc.b = -1; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
         spc.friction = sp_fric; spc.restitution = sp_rest; spc.special = false;
-        row_setup_normal(R[nr], spc, B, spc.n, spc.ra, spc.rb, spc.dist, spc.friction, spc.restitution, false);
+        row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, spc.friction, spc.restitution, false);
+        row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false);
         nr++;
     }
-    int n_normal = nr;
-    first_fric = nr;
-    // friction rows (one per non-special normal row + the averaged one)
-    {
-        int ci = 0;
-        for (int k = 0; k < L.n; k++) {
-            const Contact& c = L.c[k];
-            if (c.a == 0 && !ball_active) continue;
-            if (!c.special) { row_setup_friction(R[nr], ci, R[ci], B, c.n, c.ra, c.rb, c.b >= 0); nr++; }
-            ci++;
-        }
-        if (n_special > 0) { row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false); nr++; }
-    }
+    W.n_rows = nr;
+}
+
+template <int NC>
+RLG_HD void solver_rows(TickWork<NC>& W, int k) {
+    const Contact& c = W.L.c[k];
+    const int ni = W.nrow[k];
+    if (ni < 0) return;
+    row_setup_normal(W.R[ni], c, W.B, c.n, c.ra, c.rb, c.dist, c.friction, c.restitution, c.b >= 0);
+    if (c.special) W.R[ni].skip = 1;
+    const int fi = W.frow[k];
+    if (fi >= 0) row_setup_friction(W.R[fi], ni, W.R[ni], W.B, c.n, c.ra, c.rb, c.b >= 0);
+}
+
+// (Tried and dropped: one lane per body when no row joins two bodies -- such rows commute exactly -- with a group vote for the
+// split-impulse early exit.  The envs that are slow here have ball-car / car-car rows and stay one sequence, and the per-row
+// chain lookup cost more than the short chains saved: 483 K -> 570 K cycles per launch on the slowest workgroup.)
+template <int NC>
+RLG_HD_NOINLINE void solver_iterate(TickWork<NC>& W) {
+    RLG_ASSUME_LDS(W);
+    constexpr int NB = NC + 1;
+    SolverBody (&B)[NB] = W.B;
+    Row (&R)[TickWork<NC>::MAXR] = W.R;
+    const int n_normal = W.n_normal, nr = W.n_rows;
     RLG_PROF(3);
     // split-impulse iterations
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
@@ -501,7 +516,7 @@ RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& 
     // velocity iterations
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
         for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, 0.f, 1e10f, true);
-        for (int k = first_fric; k < nr; k++) {
+        for (int k = n_normal; k < nr; k++) {
             float total = R[R[k].fric_of].applied;
             if (total > 0.f) {
                 row_resolve(R[k], B, -(R[k].friction * total), R[k].friction * total, false);
@@ -509,28 +524,43 @@ RLG_HD_NOINLINE void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& 
         }
     }
     RLG_PROF(4);
-    // finish: write back (btSequentialImpulseConstraintSolver.cpp:1878-1904), then integrateTransforms (:889-1027)
-    if (ball_active) {
-        SolverBody& s = B[0]; Body& b = A.ball.b;
-        b.vel = (s.v + s.dv) + s.ext_f; b.angvel = (s.w + s.dw) + s.ext_t;
-        if (!is_zero(s.push) || !is_zero(s.turn)) b.pos = b.pos + s.push * dt;  // m_noRot: orientation untouched
-        b.pos = b.pos + b.vel * dt;
-    }
-    for (int i = 0; i < NC; i++) {
-        SolverBody& s = B[1 + i]; Car& c = A.cars[i];
-        if (!s.active) continue;
-        c.b.vel = (s.v + s.dv) + s.ext_f; c.b.angvel = (s.w + s.dw) + s.ext_t;
-        if (!is_zero(s.push) || !is_zero(s.turn)) {
-            c.b.pos = c.b.pos + s.push * dt;
-            c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
+}
+
+template <int NC>
+RLG_HD_NOINLINE void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    const float dt = TICK_DT;
+    const SolverBody& s = W.B[body];
+    if (body == 0) {
+        Body& b = A.ball.b;
+        if (s.active) {
+            b.vel = (s.v + s.dv) + s.ext_f; b.angvel = (s.w + s.dw) + s.ext_t;
+            if (!is_zero(s.push) || !is_zero(s.turn)) b.pos = b.pos + s.push * dt;  // m_noRot: orientation untouched
+            b.pos = b.pos + b.vel * dt;
         }
-        c.b.pos = c.b.pos + c.b.vel * dt;
-        c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
-        body_update_inertia(c.b, car_inv_inertia_local());
+        b.force = v3(0, 0, 0); b.torque = v3(0, 0, 0);
+    } else {
+        Car& c = A.cars[body - 1];
+        if (s.active) {
+            c.b.vel = (s.v + s.dv) + s.ext_f; c.b.angvel = (s.w + s.dw) + s.ext_t;
+            if (!is_zero(s.push) || !is_zero(s.turn)) {
+                c.b.pos = c.b.pos + s.push * dt;
+                c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
+            }
+            c.b.pos = c.b.pos + c.b.vel * dt;
+            c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
+            body_update_inertia(c.b, car_inv_inertia_local());
+        }
+        c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0);
     }
-    // clearForces
-    A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
-    for (int i = 0; i < NC; i++) { A.cars[i].b.force = v3(0, 0, 0); A.cars[i].b.torque = v3(0, 0, 0); }
+}
+
+template <int NC>
+RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
+    solver_prepare(A, mesh, ev, W, queued);
+    for (int k = 0; k < W.L.n; k++) solver_rows(W, k);
+    solver_iterate(W);
+    for (int body = 0; body <= NC; body++) solver_finish(A, W, body);
     RLG_PROF(5);
 }
 

@@ -336,7 +336,19 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         wave_sync();
     }
     RLG_PROF(2);
-    if (env_lane) world_step_finish(Se.A, mv, ev, Se.W, true);
+    // rest of the world step: contact list + row plan (env) | solver rows (lane per contact) | iterations (env) | integration (lane per body)
+    if (env_lane) solver_prepare(Se.A, mv, ev, Se.W, true);
+    wave_sync();
+    if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.W, k);
+    wave_sync();
+    if (env_lane) solver_iterate(Se.W);
+    wave_sync();
+    {
+        constexpr int NB = NC + 1;
+        const int e_b = tid / NB, b_b = tid % NB;
+        if (e_b < n_valid) { LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_b); solver_finish(Sb.A, Sb.W, b_b); }
+    }
+    RLG_PROF(5);
     wave_sync();
     if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, c_car); }
     wave_sync();
@@ -520,6 +532,7 @@ void rlgpu_default_gym_config(RlgpuGymConfig* c) {
     c->pos_coef[0] = 1 / 4096.f; c->pos_coef[1] = 1 / 5120.f; c->pos_coef[2] = 1 / 2044.f;
     c->vel_coef = 1 / 2300.f; c->ang_vel_coef = 1 / 5.5f;
     c->n_actions = 90;
+    c->obs_max_players = 0;
 }
 
 int rlgpu_procedural_mesh(float* verts, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris) {
@@ -541,6 +554,7 @@ int rlgpu_action_table(float* out, int cap_rows) {
 
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg) {
     if (!out || n_envs <= 0 || team_size < 1 || team_size > 3 || !cfg) return RLGPU_ERR_ARG;
+    if (cfg->obs_max_players != 0 && cfg->obs_max_players != team_size) return RLGPU_ERR_ARG;   // DefaultOBSPadded wider than the match: not built
     rlgpu_env* e = new rlgpu_env();
     *out = e;
     e->device = device; e->n_envs = n_envs; e->team_size = team_size; e->nc = 2 * team_size;

@@ -134,6 +134,40 @@ def test_gym_step_matches_host_port(port_lib):
     assert n_done > 0   # auto-reset path exercised
 
 
+@pytest.mark.parametrize("team_size", [2, 3])
+def test_gym_step_matches_host_port_team_modes(port_lib, team_size):
+    """BASELINE configs[3]/[4] shapes: 2v2 and 3v3 envs (4 / 6 cars, obs width 127 / 165) with the zero-sum reward wrapper,
+    HIP path vs host port over 24 gym steps incl. auto-resets.  Also the only GPU coverage of the 2- and 1-env-per-wavefront
+    lane maps (32 / 64 lanes per env in the candidate, pair and item phases), and of the padded-shuffled obs."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    n, nc = 40, 2 * team_size
+    cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 12; cfg.zero_sum = 1; cfg.team_spirit = 0.3; cfg.opp_scale = 1.0
+    cfg.obs_max_players = team_size      # DefaultOBSPadded(maxPlayers = team size): shuffled teammate / opponent blocks
+    env = BatchedEnv(n, team_size, cfg=cfg)
+    assert env.obs_size == 51 + 19 * nc and env.n_agents == n * nc
+    pcfg = port_gym_cfg(no_touch_max_steps=12, zero_sum=1, team_spirit=0.3, opp_scale=1.0, obs_max_players=team_size)
+    obs = env.reset(True)
+    env.sync()
+    hs, hobs = port_gym_reset(port_lib, [default_arena(nc) for _ in range(n)], pcfg, run_setter=True)
+    assert np.abs(obs.cpu().numpy() - hobs).max() < 1e-5
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(11 + team_size)
+    nobs = torch.empty_like(obs); rew = torch.empty(n * nc, device=dev); done = torch.empty(n * nc, dtype=torch.int32, device=dev)
+    n_done = 0
+    for step in range(24):
+        acts = rng.randint(0, 90, size=n * nc).astype(np.int32)
+        env.step(torch.from_numpy(acts).to(dev), nobs, rew, done)
+        env.sync()
+        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts)
+        assert (done.cpu().numpy() == hd).all(), f"done flags differ at step {step}"
+        n_done += int(hd.sum())
+        assert np.abs(rew.cpu().numpy() - hr).max() < 2e-3, f"rewards differ at step {step}"
+        assert np.abs(nobs.cpu().numpy() - ho).max() < 2e-3, f"obs differ at step {step}"
+        env.upload_states(hs)
+    assert n_done > 0
+
+
 def test_gym_rollout_vs_reference_golden(sg):
     """The committed reference rollouts (real RLGymSim_CPP Gym) replayed on the GPU."""
     from rlgymppo_cpp_amd.env import BatchedEnv

@@ -172,3 +172,30 @@ def test_host_helpers_without_gpu():
     g = np.load(os.path.join(GOLD, "sim_golden.npz"))
     assert np.array_equal(v, g["mesh_verts"]) and np.array_equal(t, g["mesh_tris"])
     assert np.array_equal(action_table(), g["action_table"])
+
+
+def test_padded_obs_is_a_block_shuffle_of_default_obs(port_lib):
+    """DefaultOBSPadded(maxPlayers = team size) (DefaultOBSPadded.cpp:3-66) on the host port: ball / prev-action / pads / self parts
+    equal DefaultOBS; the teammate blocks and the opponent blocks are the same 19-float blocks in a permuted order, and over
+    many observations every order occurs."""
+    from simlib import port_gym_cfg, port_gym_reset
+    from rlgymppo_cpp_amd.state import default_arena
+    nc, n = 6, 64
+    states = [default_arena(nc) for _ in range(n)]
+    _, plain = port_gym_reset(port_lib, states, port_gym_cfg(), run_setter=True)
+    _, padded = port_gym_reset(port_lib, states, port_gym_cfg(obs_max_players=3), run_setter=True)
+    assert plain.shape == padded.shape == (n * nc, 51 + 19 * nc)
+    assert np.array_equal(plain[:, :70], padded[:, :70])
+    blocks = lambda o, a, b: o[:, 70 + 19 * a: 70 + 19 * b].reshape(len(o), b - a, 19)
+    orders = set()
+    for lo, hi in ((0, 2), (2, 5)):   # 2 teammates, 3 opponents
+        P, Q = blocks(plain, lo, hi), blocks(padded, lo, hi)
+        for r in range(len(P)):
+            perm = []
+            for q in Q[r]:
+                m = [i for i in range(hi - lo) if np.array_equal(P[r][i], q)]
+                assert m, "a padded block is not one of the DefaultOBS blocks"
+                perm.append(m[0])
+            assert sorted(perm) == list(range(hi - lo))
+            if hi - lo == 3: orders.add(tuple(perm))
+    assert len(orders) == 6   # all 3! opponent orders show up
