@@ -434,6 +434,9 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
     SolverBody (&B)[NB] = W.B;
     Row (&R)[TickWork<NC>::MAXR] = W.R;
     const bool ball_asleep = W.ball_asleep;
+#ifdef RLG_QSTAT
+    RLG_QSTAT(W.Q);   // host-side statistics hook of tools (queue fill levels before the rows overwrite them)
+#endif
 
     bool touch;
     if (queued && !W.Q.overflow) collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowQueued{W.Q});

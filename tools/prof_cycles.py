@@ -9,6 +9,7 @@ from rlgymppo_cpp_amd.state import default_arena
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 24   # random gym steps before the rollout measurements (300+ = steady state of episodes)
 env = BatchedEnv(n, 1)
 fn = env.lib.rlgpu_env_debug_tick_cycles
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -44,7 +45,7 @@ obs = env.reset(True)
 dev = torch.device("cuda", 0)
 nobs = torch.empty_like(obs); rew = torch.empty(env.n_agents, device=dev); done = torch.empty(env.n_agents, dtype=torch.int32, device=dev)
 g = torch.Generator().manual_seed(0)
-for t in range(24):
+for t in range(warm):
     a = torch.randint(0, 90, (env.n_agents,), generator=g, dtype=torch.int32).to(dev)
     env.step(a, nobs, rew, done)
 env.sync()
