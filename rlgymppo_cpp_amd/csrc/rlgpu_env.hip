@@ -17,7 +17,8 @@
 #ifdef RLG_TICK_PROFILE
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
 __shared__ unsigned long long g_prof[12];
-__device__ unsigned long long g_step_prof[16 * 4096];   // k_env_step's buckets per workgroup (first 4096 workgroups)
+__device__ unsigned long long g_step_prof[16 * 4096];
+__device__ int g_dbg[64];   // scratch for ad-hoc device introspection (profiler build only; read with rlgpu_env_debug_ints)   // k_env_step's buckets per workgroup (first 4096 workgroups)
 __shared__ unsigned long long g_prof_last;
 #define RLG_PROF(i)                                                              \
     do {                                                                         \
@@ -329,9 +330,21 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
         }
         wave_sync();
-        if (item_lane && !Q.overflow) {
-            const int n_items = Q.n_items;
-            for (int slot = l_item; slot < n_items; slot += LPE) collide_run_item(Si.A, mv, slot, Q);
+        {   // items of ALL envs of the wavefront as one list over the 64 lanes: a contact-heavy env borrows its neighbours' lanes
+            int n_of[EPW], total = 0;
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                const CollideQueue& Qe = lane_block<NC>(lane_mem, e < n_valid ? e : 0).W.Q;
+                n_of[e] = (e < n_valid && !Qe.overflow) ? Qe.n_items : 0;
+                total += n_of[e];
+            }
+            for (int g = tid; g < total; g += WAVE) {
+                int e = 0, slot = g;
+#pragma unroll
+                for (int q = 0; q < EPW - 1; q++) if (e == q && slot >= n_of[q]) { slot -= n_of[q]; e = q + 1; }
+                LaneBlock<NC>& Sx = lane_block<NC>(lane_mem, e);
+                collide_run_item(Sx.A, mv, slot, Sx.W.Q);
+            }
         }
         wave_sync();
     }
@@ -700,6 +713,11 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
 }
 
 #ifdef RLG_TICK_PROFILE
+int rlgpu_env_debug_ints(rlgpu_env* e, int* out) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(int) * 64));
+    return RLGPU_OK;
+}
 // profiler build only: the 12 phase buckets (cycles) of the last k_env_step launch, 16 values per workgroup
 int rlgpu_env_debug_step_prof(rlgpu_env* e, unsigned long long* out, int n_blocks) {
     HIPCHK(e, hipSetDevice(e->device));
