@@ -168,6 +168,33 @@ def test_gym_step_matches_host_port_team_modes(port_lib, team_size):
     assert n_done > 0
 
 
+def test_cmf_directory_loader_equals_procedural_mesh(tmp_path):
+    """rlgpu_env_load_cmf_dir (RocketSim::Init over collision_meshes/soccar/*.cmf, RS/RocketSim.cpp:70-212): the procedural mesh
+    written out as two .cmf files (int32 nTris, int32 nVerts, tris, verts in BT units) and loaded back steps identically."""
+    from rlgymppo_cpp_amd.env import BatchedEnv, procedural_mesh
+    v, t = procedural_mesh()
+    half = len(t) // 2
+    for name, tris in (("a_first.cmf", t[:half]), ("b_second.cmf", t[half:])):
+        used = np.unique(tris); remap = -np.ones(len(v), np.int64); remap[used] = np.arange(len(used))
+        with open(tmp_path / name, "wb") as f:
+            f.write(np.int32(len(tris)).tobytes()); f.write(np.int32(len(used)).tobytes())
+            f.write(remap[tris].astype(np.int32).tobytes()); f.write((v[used] / 50.0).astype(np.float32).tobytes())
+    dev = torch.device("cuda", 0)
+    n = 96
+    outs = []
+    for mesh in ("procedural", str(tmp_path)):
+        env = BatchedEnv(n, 1, mesh=mesh)
+        obs = env.reset(True)
+        nobs = torch.empty_like(obs); rew = torch.empty(n * 2, device=dev); done = torch.empty(n * 2, dtype=torch.int32, device=dev)
+        rng = np.random.RandomState(2)
+        for step in range(12):
+            env.step(torch.from_numpy(rng.randint(0, 90, size=n * 2).astype(np.int32)).to(dev), nobs, rew, done)
+        env.sync(); outs.append((nobs.cpu().numpy().copy(), rew.cpu().numpy().copy()))
+        env.close()
+    # same triangles in the same order -> same BVH; the vertices went through a /50 *50 round trip in fp32, so not bitwise
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-3 and np.abs(outs[0][1] - outs[1][1]).max() < 2e-3
+
+
 def test_gym_rollout_vs_reference_golden(sg):
     """The committed reference rollouts (real RLGymSim_CPP Gym) replayed on the GPU."""
     from rlgymppo_cpp_amd.env import BatchedEnv
