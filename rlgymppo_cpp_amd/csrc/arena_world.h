@@ -500,19 +500,41 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
     return true;
 }
 
-// Sutherland-Hodgman clip of a convex polygon (<= 8 pts) against the half space dot(nrm,p) <= off
-RLG_HD int clip_poly(const V3* in, int n, V3 nrm, float off, V3* out) {
-    int m = 0;
-    for (int i = 0; i < n; i++) {
-        V3 a = in[i], b = in[(i + 1) % n];
-        float da = dot(nrm, a) - off, db = dot(nrm, b) - off;
-        if (da <= 0.f) { if (m < 8) out[m++] = a; }
-        if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
-            float t = da / (da - db);
-            if (m < 8) out[m++] = a + (b - a) * t;
+// Convex polygon of <= 8 points for the Sutherland-Hodgman clips below.  Every loop over it is fully unrolled with compile-time
+// slot numbers (reads select on `i < n`, writes go through a compare chain on the insert position), so on the device the whole
+// polygon lives in registers: as V3 arrays indexed by loop variables it sat in scratch memory, and the clip was a chain of
+// dependent scratch round trips -- the slowest thing in a contact-heavy tick.
+struct Poly8 {
+    V3 p[8];
+    int n;
+};
+RLG_HD void poly_push(Poly8& P, V3 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 8; s++) if (P.n == s) P.p[s] = v;
+    if (P.n < 8) P.n++;
+}
+// clip against the half space dot(nrm,p) <= off
+RLG_HD void clip_poly(Poly8& P, V3 nrm, float off) {
+    Poly8 O; O.n = 0;
+    const V3 first = P.p[0];
+    const int n = P.n;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; i++) {
+        if (i < n) {
+            V3 a = P.p[i], b = (i + 1 < n) ? P.p[(i + 1) & 7] : first;
+            float da = dot(nrm, a) - off, db = dot(nrm, b) - off;
+            if (da <= 0.f) poly_push(O, a);
+            if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+                float t = da / (da - db);
+                poly_push(O, a + (b - a) * t);
+            }
         }
     }
-    return m;
+    P = O;
 }
 
 // box (center bc, basis R, half extents h) vs triangle, SAT + clipping. Emits candidates with the normal
@@ -567,27 +589,36 @@ RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, fl
         if (fabsf(n.z) > mk) { k = 2; }
         float sg = get(n, k) > 0.f ? -1.f : 1.f;
         int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-        V3 quad[8], tmp[8];
+        Poly8 quad; quad.n = 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int q = 0; q < 4; q++) {
             float s1 = (q == 0 || q == 3) ? -1.f : 1.f, s2 = (q < 2) ? -1.f : 1.f;
-            float cv[3]; cv[k] = sg * get(h, k); cv[k1] = s1 * get(h, k1); cv[k2] = s2 * get(h, k2);
-            quad[q] = v3(cv[0], cv[1], cv[2]);
+            float c0 = sg * get(h, k), c1 = s1 * get(h, k1), c2 = s2 * get(h, k2);   // components along axes k, k1, k2
+            quad.p[q] = v3(k == 0 ? c0 : (k1 == 0 ? c1 : c2), k == 1 ? c0 : (k1 == 1 ? c1 : c2), k == 2 ? c0 : (k1 == 2 ? c1 : c2));
         }
-        int m = 4;
         // clip against the triangle's edge planes (inward side), computed with the un-flipped winding
         V3 tn = cross(e[0], p[2] - p[0]);
-        for (int j = 0; j < 3 && m > 0; j++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 3; j++) {
+            if (quad.n <= 0) continue;
             V3 en = cross(e[j], tn);  // outward
             float enl = len(en);
             if (enl < 1e-12f) continue;
             en = en / enl;
-            m = clip_poly(quad, m, en, dot(en, p[j]), tmp);
-            for (int q = 0; q < m; q++) quad[q] = tmp[q];
+            clip_poly(quad, en, dot(en, p[j]));
         }
-        for (int q = 0; q < m; q++) {
-            float dist = dot(n, quad[q]) - d;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 8; q++) {
+            if (q >= quad.n) continue;
+            float dist = dot(n, quad.p[q]) - d;
             if (dist < thresh) {
-                Cand c; c.n = R * n; c.dist = dist; c.pb = bc + R * (quad[q] - n * dist);
+                Cand c; c.n = R * n; c.dist = dist; c.pb = bc + R * (quad.p[q] - n * dist);
                 cand_add(cs, nc, c);
             }
         }
@@ -595,19 +626,26 @@ RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, fl
         // reference = box face (axis best_i, side best_j), incident = triangle clipped to the face rectangle
         int k = best_i, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
         float side = (float)best_j;  // +1: triangle is on the +axis side
-        V3 poly[8], tmp[8]; int m = 3;
-        poly[0] = p[0]; poly[1] = p[1]; poly[2] = p[2];
-        for (int q = 0; q < 4 && m > 0; q++) {
+        Poly8 poly; poly.n = 3;
+        poly.p[0] = p[0]; poly.p[1] = p[1]; poly.p[2] = p[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) {
+            if (poly.n <= 0) continue;
             int ax = (q < 2) ? k1 : k2; float sg = (q % 2) ? 1.f : -1.f;
             V3 cn = v3(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
-            m = clip_poly(poly, m, cn, get(h, ax), tmp);
-            for (int r = 0; r < m; r++) poly[r] = tmp[r];
+            clip_poly(poly, cn, get(h, ax));
         }
         V3 fn = v3(k == 0 ? side : 0.f, k == 1 ? side : 0.f, k == 2 ? side : 0.f);  // outward face normal
-        for (int q = 0; q < m; q++) {
-            float dist = side * get(poly[q], k) - get(h, k);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 8; q++) {
+            if (q >= poly.n) continue;
+            float dist = side * get(poly.p[q], k) - get(h, k);
             if (dist < thresh) {
-                Cand c; c.n = R * (-fn); c.dist = dist; c.pb = bc + R * poly[q];
+                Cand c; c.n = R * (-fn); c.dist = dist; c.pb = bc + R * poly.p[q];
                 cand_add(cs, nc, c);
             }
         }
@@ -694,29 +732,38 @@ RLG_HD_NOINLINE void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Can
         for (int q = 1; q < 3; q++) { float v = fabsf(dot(nref, icol[q])); if (v > mk) { mk = v; k = q; } }
         float sg = dot(nref, icol[k]) > 0.f ? -1.f : 1.f;
         int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-        V3 quad[8], tmp[8];
+        Poly8 quad; quad.n = 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
         for (int q = 0; q < 4; q++) {
             float s1 = (q == 0 || q == 3) ? -1.f : 1.f, s2 = (q < 2) ? -1.f : 1.f;
-            quad[q] = cinc + icol[k] * (sg * get(h, k)) + icol[k1] * (s1 * get(h, k1)) + icol[k2] * (s2 * get(h, k2));
+            quad.p[q] = cinc + icol[k] * (sg * get(h, k)) + icol[k1] * (s1 * get(h, k1)) + icol[k2] * (s2 * get(h, k2));
         }
-        int m = 4;
         V3 rcol[3] = {col0(Rref), col1(Rref), col2(Rref)};
         int rk = ref_is_a ? bi : bj;
-        for (int q = 0; q < 4 && m > 0; q++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) {
+            if (quad.n <= 0) continue;
             int ax = (q < 2) ? (rk + 1) % 3 : (rk + 2) % 3; float s = (q % 2) ? 1.f : -1.f;
             V3 cn = rcol[ax] * s;
-            m = clip_poly(quad, m, cn, dot(cn, cref) + get(h, ax), tmp);
-            for (int r = 0; r < m; r++) quad[r] = tmp[r];
+            clip_poly(quad, cn, dot(cn, cref) + get(h, ax));
         }
         float face_off = dot(nref, cref) + get(h, rk);
-        for (int q = 0; q < m; q++) {
-            float dist = dot(nref, quad[q]) - face_off;  // < 0 when the incident point is inside the reference box
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 8; q++) {
+            if (q >= quad.n) continue;
+            float dist = dot(nref, quad.p[q]) - face_off;  // < 0 when the incident point is inside the reference box
             if (dist < 0.f) {
                 Cand c; c.dist = dist;
                 // normal from B to A (world). nrm_a points A->B.
                 c.n = Ra * (-nrm_a);
                 // point on B: if the reference is A the incident point is on B; else project onto B's face
-                V3 pb_a = ref_is_a ? quad[q] : (quad[q] - nref * dist);
+                V3 pb_a = ref_is_a ? quad.p[q] : (quad.p[q] - nref * dist);
                 c.pb = ca + Ra * pb_a;
                 cand_add(cs, nc, c);
             }
