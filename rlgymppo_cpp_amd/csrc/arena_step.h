@@ -8,11 +8,11 @@ namespace rlg {
 
 // ---- contact-added callbacks (Arena.cpp:283-427) ----------------------------------------------------------
 template <int NC>
-RLG_HD void on_car_ball_contact(Arena<NC>& A, int ci, V3 point_on_ball_world) {
+RLG_HD void on_car_ball_contact(Arena<NC>& A, int ci, V3 point_rel_ball) {   // contact point on the ball minus the ball centre (BT)
     Car& car = A.cars[ci];
     Ball& ball = A.ball;
     car.flags |= CF_BALLHIT_VALID;
-    car.bh_rel_pos = (point_on_ball_world - ball.b.pos) * BT2UU;  // m_localPoint on the ball (ball basis = identity)
+    car.bh_rel_pos = point_rel_ball * BT2UU;  // m_localPoint on the ball (ball basis = identity)
     car.bh_tick_hit = A.tick_count;
     car.bh_ball_pos = ball.b.pos * BT2UU;
     car.bh_extra_hit_vel = v3(0, 0, 0);
@@ -180,81 +180,109 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
     Q.items[slot].off = (int16_t)off; Q.items[slot].n = (int16_t)n;
 }
 
+// The contact list is produced in two steps so that the bodies of an env can work side by side:
+//   collide_body   per body   the body's contacts against the world (planes + mesh) and, for a car, against the ball, written
+//                             into the body's own region of the contact list: ball [0,8), car i [8 + 6 i, 8 + 6 i + 6)
+//                             (MAXC = 8 + 6 NC is exactly these regions); count in W.body_n[body]
+//   collide_merge  per env    regions compacted into reference order (ball, car 0, car 1, ...), the ball-touch callbacks in
+//                             car order, then the car-car pairs
+constexpr int BALL_REGION = 8, CAR_REGION = 6;
+RLG_HD int body_region(int body) { return body == 0 ? 0 : BALL_REGION + CAR_REGION * (body - 1); }
+
 template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_all(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, TickEvents& ev, bool ball_asleep, bool& ball_car_touch, NW nw) {
+RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int body, bool ball_asleep, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
-    L.n = 0; ball_car_touch = false;
     const float r = K::BALL_RADIUS * UU2BT;
-    // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
-    // btDiscreteDynamicsWorld::addRigidBody) are both inactive, so the dispatcher skips the pair
-    // (btCollisionDispatcher::needsCollision): no ball-world contacts on the tick a car wakes the ball up.
-    const int n_ball_planes = ball_asleep ? 0 : 4;
-    // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121)
-    V3 bp = A.ball.b.pos;
-    for (int i = 0; i < n_ball_planes; i++) {
-        V3 n; float d; world_plane(i, n, d);
-        float dist = (dot(n, bp - n * r) - d);
-        if (dist < CBT_BALL) {
-            Contact c; c.a = 0; c.b = -1; c.n = n; c.dist = dist;
-            V3 pb = (bp - n * r) - n * dist;
-            c.ra = (pb + n * dist) - bp; c.rb = pb;
-            c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
-            push_contact(L, c);
-        }
-    }
-    // ball vs mesh
-    if (!ball_asleep) {
-        nw.ball_mesh(A, mesh, [&](const Cand& k) {
-            Contact c; c.a = 0; c.b = -1; c.n = k.n; c.dist = k.dist;
-            c.ra = (k.pb + k.n * k.dist) - bp; c.rb = k.pb;
-            c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
-            push_contact(L, c);
-        });
-    }
-    // cars
-    RLG_NOUNROLL
-    for (int ci = 0; ci < NC; ci++) {
-        Car& car = A.cars[ci];
-        if (!car_collides(car)) continue;
-        V3 h = hitbox_half();
-        V3 bc = car.b.pos + car.b.rot * hitbox_off();
-        Cand cs[4]; int nc = 0;
-        // planes: every hitbox corner within the threshold (see header comment)
-        for (int i = 0; i < 4; i++) {
-            V3 n; float d; world_plane(i, n, d);
-            V3 nl = tmul(car.b.rot, n);
-            float rr = h.x * fabsf(nl.x) + h.y * fabsf(nl.y) + h.z * fabsf(nl.z);
-            if (dot(n, bc) - d - rr >= CBT_CAR) continue;
-            for (int q = 0; q < 8; q++) {
-                V3 cl = v3((q & 1) ? h.x : -h.x, (q & 2) ? h.y : -h.y, (q & 4) ? h.z : -h.z);
-                V3 cw = bc + car.b.rot * cl;
-                float dist = dot(n, cw) - d;
-                if (dist < CBT_CAR) { Cand c; c.n = n; c.dist = dist; c.pb = cw - n * dist; cand_add(cs, nc, c); }
+    const V3 bp = A.ball.b.pos;
+    Contact* out = &L.c[body_region(body)];
+    int n = 0;
+    if (body == 0) {
+        // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
+        // btDiscreteDynamicsWorld::addRigidBody) are both inactive, so the dispatcher skips the pair
+        // (btCollisionDispatcher::needsCollision): no ball-world contacts on the tick a car wakes the ball up.
+        if (!ball_asleep) {
+            // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121)
+            for (int i = 0; i < 4; i++) {
+                V3 pn; float d; world_plane(i, pn, d);
+                float dist = (dot(pn, bp - pn * r) - d);
+                if (dist < CBT_BALL && n < BALL_REGION) {
+                    Contact c; c.a = 0; c.b = -1; c.n = pn; c.dist = dist;
+                    V3 pb = (bp - pn * r) - pn * dist;
+                    c.ra = (pb + pn * dist) - bp; c.rb = pb;
+                    c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
+                    out[n++] = c;
+                }
             }
+            // ball vs mesh
+            nw.ball_mesh(A, mesh, [&](const Cand& k) {
+                if (n >= BALL_REGION) return;
+                Contact c; c.a = 0; c.b = -1; c.n = k.n; c.dist = k.dist;
+                c.ra = (k.pb + k.n * k.dist) - bp; c.rb = k.pb;
+                c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
+                out[n++] = c;
+            });
         }
-        nw.car_mesh(A, mesh, ci, cs, nc);
-        for (int k = 0; k < nc; k++) {
-            Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
-            c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
-            c.friction = K::CARWORLD_FRICTION; c.restitution = K::CARWORLD_RESTITUTION; c.special = false;
-            push_contact(L, c);
-            // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
-            car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = cs[k].n;
-        }
-        // car vs ball: ball is body A of the pair (lower broadphase id), the car B
-        {
-            V3 pb, n; float dist;
-            if (sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, n, dist)) {
-                Contact c; c.a = 0; c.b = 1 + ci; c.n = n; c.dist = dist;
-                V3 pa = pb + n * dist;
+    } else {
+        const int ci = body - 1;
+        Car& car = A.cars[ci];
+        if (car_collides(car)) {
+            V3 h = hitbox_half();
+            V3 bc = car.b.pos + car.b.rot * hitbox_off();
+            Cand cs[4]; int nc = 0;
+            // planes: every hitbox corner within the threshold (see header comment)
+            for (int i = 0; i < 4; i++) {
+                V3 pn; float d; world_plane(i, pn, d);
+                V3 nl = tmul(car.b.rot, pn);
+                float rr = h.x * fabsf(nl.x) + h.y * fabsf(nl.y) + h.z * fabsf(nl.z);
+                if (dot(pn, bc) - d - rr >= CBT_CAR) continue;
+                for (int q = 0; q < 8; q++) {
+                    V3 cl = v3((q & 1) ? h.x : -h.x, (q & 2) ? h.y : -h.y, (q & 4) ? h.z : -h.z);
+                    V3 cw = bc + car.b.rot * cl;
+                    float dist = dot(pn, cw) - d;
+                    if (dist < CBT_CAR) { Cand c; c.n = pn; c.dist = dist; c.pb = cw - pn * dist; cand_add(cs, nc, c); }
+                }
+            }
+            nw.car_mesh(A, mesh, ci, cs, nc);
+            for (int k = 0; k < nc; k++) {
+                Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
+                c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
+                c.friction = K::CARWORLD_FRICTION; c.restitution = K::CARWORLD_RESTITUTION; c.special = false;
+                out[n++] = c;
+                // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
+                car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = cs[k].n;
+            }
+            // car vs ball: ball is body A of the pair (lower broadphase id), the car B.  Its callback runs in collide_merge.
+            V3 pb, pn; float dist;
+            if (sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, pn, dist)) {
+                Contact c; c.a = 0; c.b = 1 + ci; c.n = pn; c.dist = dist;
+                V3 pa = pb + pn * dist;
                 c.ra = pa - bp; c.rb = pb - car.b.pos;
                 c.friction = K::CARBALL_FRICTION; c.restitution = K::CARBALL_RESTITUTION; c.special = false;
-                push_contact(L, c);
-                ball_car_touch = true;
-                on_car_ball_contact(A, ci, pa);
+                out[n++] = c;
             }
         }
     }
+    body_n[body] = (int8_t)n;
+}
+
+template <int NC, int MAXC, class NW>
+RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, const int8_t* body_n, TickEvents& ev, bool& ball_car_touch, NW nw) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
+    ball_car_touch = false;
+    int n = body_n[0];   // the ball's region already starts the list
+    for (int ci = 0; ci < NC; ci++) {
+        const int base = body_region(1 + ci);
+        for (int k = 0; k < body_n[1 + ci]; k++) {
+            if (base + k != n) L.c[n] = L.c[base + k];
+            const Contact& c = L.c[n];
+            if (c.a == 0) {   // the car's ball contact
+                ball_car_touch = true;
+                on_car_ball_contact(A, ci, c.ra);
+            }
+            n++;
+        }
+    }
+    L.n = n;
     // car vs car
     for (int ia = 0; ia < NC; ia++) {
         for (int ib = ia + 1; ib < NC; ib++) {
@@ -400,6 +428,7 @@ struct TickWork {
     CarTickCtx ctx[NC];
     bool ball_asleep;
     int8_t nrow[MAXC], frow[MAXC];   // solver rows of contact k (normal / friction), -1 = none (solver_prepare)
+    int8_t body_n[8];                // contacts in each body's region of L (collide_body)
     int16_t n_normal, n_rows;
 };
 static_assert(sizeof(CollideQueue) <= sizeof(Row) * TickWork<2>::MAXR, "the narrowphase queue must fit inside the solver rows it shares LDS with");
@@ -419,7 +448,8 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
 }
 
 // world step, second part, in four pieces of different width (the host runs them back to back):
-//   solver_prepare   per env       contact list (`queued`: from the narrowphase queue W.Q, else / on overflow inline), solver
+//   solver_body_contacts per body  the body's region of the contact list (`queued`: from the narrowphase queue W.Q, else / on overflow inline)
+//   solver_prepare   per env       contact list merged in reference order + callbacks + car-car pairs, solver
 //                                  bodies, the averaged ball-world contact, and which solver rows each contact gets
 //   solver_rows      per contact   its normal row and its friction row (btSequentialImpulseConstraintSolver.cpp:1003-1211)
 //   solver_iterate   per env       split-impulse + velocity iterations (:1601-1877) -- sequential by nature (Gauss-Seidel)
@@ -439,9 +469,12 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
 #endif
 
     bool touch;
-    if (queued && !W.Q.overflow) collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowQueued{W.Q});
-    else collide_all<NC, MAXC>(A, mesh, L, ev, ball_asleep, touch, NarrowInline());
+    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowQueued{W.Q});
+    else collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowInline());
     const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
+#ifdef RLG_PROF_SPLIT_PREPARE
+    RLG_PROF(7);
+#endif
 
     {
         SolverBody& s = B[0];
@@ -482,6 +515,15 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
         nr++;
     }
     W.n_rows = nr;
+}
+
+// contacts of one body (see collide_body); `queued` as in solver_prepare
+template <int NC>
+RLG_HD_NOINLINE void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    constexpr int MAXC = TickWork<NC>::MAXC;
+    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowQueued{W.Q});
+    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowInline());
 }
 
 template <int NC>
@@ -560,6 +602,7 @@ RLG_HD_NOINLINE void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
 
 template <int NC>
 RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
+    for (int body = 0; body <= NC; body++) solver_body_contacts(A, mesh, W, body, queued);
     solver_prepare(A, mesh, ev, W, queued);
     for (int k = 0; k < W.L.n; k++) solver_rows(W, k);
     solver_iterate(W);

@@ -349,7 +349,13 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         wave_sync();
     }
     RLG_PROF(2);
-    // rest of the world step: contact list + row plan (env) | solver rows (lane per contact) | iterations (env) | integration (lane per body)
+    // rest of the world step: contacts (lane per body) | merge + row plan (env) | solver rows (lane per contact) | iterations (env) | integration (lane per body)
+    {
+        constexpr int NB = NC + 1;
+        const int e_b = tid / NB, b_b = tid % NB;
+        if (e_b < n_valid) { LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_b); solver_body_contacts(Sb.A, mv, Sb.W, b_b, true); }
+    }
+    wave_sync();
     if (env_lane) solver_prepare(Se.A, mv, ev, Se.W, true);
     wave_sync();
     if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.W, k);
