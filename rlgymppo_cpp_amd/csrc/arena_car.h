@@ -471,8 +471,8 @@ RLG_HD_NOINLINE void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx
 
 // pair `pair` of car ci: candidate slot = first + pair / 4, wheel = pair % 4 (the 4 wheels of a car share each triangle fetch)
 template <int NC>
-RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue& Q, int ci, int pair, CarTickCtx& t) {
-    const int slot = (int)Q.cand_start[1 + ci] + (pair >> 2), i = pair & 3;
+RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue<NC>& Q, int ci, int pair, CarTickCtx& t) {
+    const int slot = CollideQueue<NC>::region(1 + ci) + (pair >> 2), i = pair & 3;
     const uint32_t c = Q.cand[slot];
     if (c == CAND_HOLE) return;
     const WheelTmp& w = t.w[i];
@@ -480,13 +480,13 @@ RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue& 
     if (ray_triangle_pair(mesh.tris[unpack_cand(c).ref], w.hard_point, w.contact_point, w.susp_len, d)) ray_key_min(ray_keys(t)[i], ray_key(d, slot));
 }
 template <int NC>
-RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue& Q, int ci) {
+RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue<NC>& Q, int ci) {
     if (A.cars[ci].flags & CF_IS_DEMOED) return 0;
-    return 4 * ((int)Q.cand_start[2 + ci] - (int)Q.cand_start[1 + ci]);
+    return 4 * (int)Q.cand_count[1 + ci];
 }
 
 template <int NC>
-RLG_HD_NOINLINE void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue& Q, CarTickCtx& t) {
+RLG_HD_NOINLINE void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue<NC>& Q, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t); RLG_ASSUME_LDS(Q);
     const float dt = TICK_DT;
     Car& cr = A.cars[ci];

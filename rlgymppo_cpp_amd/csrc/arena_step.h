@@ -4,6 +4,9 @@
 #pragma once
 #include "arena_car.h"
 
+#ifndef RLG_DBG_COUNT
+#define RLG_DBG_COUNT(i) ((void)0)
+#endif
 namespace rlg {
 
 // ---- contact-added callbacks (Arena.cpp:283-427) ----------------------------------------------------------
@@ -110,8 +113,9 @@ struct NarrowInline {
     }
 };
 
+template <int NCQ>
 struct NarrowQueued {
-    const CollideQueue& Q;
+    const CollideQueue<NCQ>& Q;
     RLG_HD int count() const { return Q.n_items < ITEM_CAP ? Q.n_items : ITEM_CAP; }
     template <int NC, class F>
     RLG_HD void ball_mesh(const Arena<NC>&, MeshView, F&& emit) {
@@ -142,7 +146,7 @@ struct NarrowQueued {
 
 // step 2: does candidate `k` become an item?  (triangle AABB vs the body's query box; car-car pairs always do)
 template <int NC>
-RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const CollideQueue& Q, int k) {
+RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const CollideQueue<NC>& Q, int k) {
     if (Q.cand[k] == CAND_HOLE) return false;
     CollideItem it = unpack_cand(Q.cand[k]);
     if (it.type == 2) return true;
@@ -157,7 +161,7 @@ RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const Coll
 
 // step 3: run item `slot`
 template <int NC>
-RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue& Q) {
+RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue<NC>& Q) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
     CollideItem it = Q.items[slot];
     Cand out[8]; int n = 0;
@@ -175,7 +179,7 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
         for (int q = 0; q < nc; q++) out[n++] = cs[q];
     }
     int off = n > 0 ? fetch_add(Q.n_pool, n) : 0;
-    if (off + n > POOL_CAP) { Q.overflow = 1; n = 0; off = 0; }
+    if (off + n > POOL_CAP) { Q.overflow = 1; n = 0; off = 0; RLG_DBG_COUNT(4); }
     for (int q = 0; q < n; q++) Q.pool[off + q] = out[q];
     Q.items[slot].off = (int16_t)off; Q.items[slot].n = (int16_t)n;
 }
@@ -423,7 +427,7 @@ struct TickWork {
     SolverBody B[NB];
     union {
         Row R[MAXR];       // solver rows: built after the contact list is complete ...
-        CollideQueue Q;    // ... narrowphase items: dead by then
+        CollideQueue<NC> Q;   // ... narrowphase items: dead by then
     };
     CarTickCtx ctx[NC];
     bool ball_asleep;
@@ -431,7 +435,8 @@ struct TickWork {
     int8_t body_n[8];                // contacts in each body's region of L (collide_body)
     int16_t n_normal, n_rows;
 };
-static_assert(sizeof(CollideQueue) <= sizeof(Row) * TickWork<2>::MAXR, "the narrowphase queue must fit inside the solver rows it shares LDS with");
+static_assert(sizeof(CollideQueue<2>) <= sizeof(Row) * TickWork<2>::MAXR && sizeof(CollideQueue<4>) <= sizeof(Row) * TickWork<4>::MAXR && sizeof(CollideQueue<6>) <= sizeof(Row) * TickWork<6>::MAXR,
+              "the narrowphase queue must fit inside the solver rows it shares LDS with");
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
 template <int NC>
@@ -469,7 +474,7 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
 #endif
 
     bool touch;
-    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowQueued{W.Q});
+    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowQueued<NC>{W.Q});
     else collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowInline());
     const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 #ifdef RLG_PROF_SPLIT_PREPARE
@@ -522,7 +527,7 @@ template <int NC>
 RLG_HD_NOINLINE void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
-    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowQueued{W.Q});
+    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
     else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowInline());
 }
 
@@ -707,14 +712,16 @@ RLG_HD_NOINLINE void tick_world_begin(Arena<NC>& A, TickWork<NC>& W, bool pads_d
 }
 // phases 3b (lane per candidate: AABB test + compaction into items) and 3c (lane per item), host form
 template <int NC>
-RLG_HD void collide_compact_and_run(const Arena<NC>& A, MeshView mesh, CollideQueue& Q) {
+RLG_HD void collide_compact_and_run(const Arena<NC>& A, MeshView mesh, CollideQueue<NC>& Q) {
     if (Q.overflow) return;
     int n = 0;
-    for (int k = 0; k < Q.n_cand; k++) {
-        if (!collide_test_candidate(A, mesh, Q, k)) continue;
+    auto consider = [&](int k) {
+        if (!collide_test_candidate(A, mesh, Q, k)) return;
         if (n < ITEM_CAP) Q.items[n] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
         n++;
-    }
+    };
+    for (int body = 0; body <= NC; body++) for (int i = 0; i < Q.cand_count[body]; i++) consider(CollideQueue<NC>::region(body) + i);
+    for (int i = 0; i < Q.n_pairs; i++) consider(CollideQueue<NC>::PAIR_BASE + i);
     if (Q.overflow) return;
     Q.n_items = n;
     for (int slot = 0; slot < n; slot++) collide_run_item(A, mesh, slot, Q);

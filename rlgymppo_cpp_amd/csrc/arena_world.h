@@ -43,9 +43,23 @@ struct Contact {
 // ---- BVH access ---------------------------------------------------------------------------------------
 // (MeshView travels by value: behind a reference it sits in the caller's stack frame = scratch memory on the device, and
 // every node visit paid a dependent scratch round trip for `nodes_fast` before the node load itself.)
+// one node = two 16-byte loads issued together (field-wise access made the compiler fetch the box first and the child / count
+// words in a second, dependent round trip after the box test)
+RLG_HD BvhNode load_node(const BvhNode* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    BvhNode n;
+    n.minx = __uint_as_float(a.x); n.miny = __uint_as_float(a.y); n.minz = __uint_as_float(a.z); n.left_or_first = (int32_t)a.w;
+    n.maxx = __uint_as_float(b.x); n.maxy = __uint_as_float(b.y); n.maxz = __uint_as_float(b.z); n.count_escape = b.w;
+    return n;
+#else
+    return *p;
+#endif
+}
 RLG_HD BvhNode mesh_node(MeshView m, int i) {
-    if (i < m.n_fast) { RLG_ASSUME_LDS(*m.nodes_fast); return m.nodes_fast[i]; }
-    return m.nodes[i];
+    if (i < m.n_fast) { RLG_ASSUME_LDS(*m.nodes_fast); return load_node(m.nodes_fast + i); }
+    return load_node(m.nodes + i);
 }
 
 // does the box [lo,hi] touch any occupied grid cell?  (conservative: out-of-grid space counts as occupied)
@@ -114,17 +128,24 @@ struct CollideItem {
 #endif
 // measured over 614 K env-ticks of random play (tools: RLG_QSTAT hook): items <= 16 in 99.93 % of the ticks (max seen > 16), candidate slots <= 88,
 // pool entries <= 12 -- the caps below leave the inline fallback to the truly pathological ticks
-constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 48, CAND_CAP = 160;
+constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 40;
 constexpr int LEAF_SLOTS = 4;              // BVH leaves hold <= 4 triangles (arena_mesh.cpp); the device reserves a full block per leaf
 constexpr uint32_t CAND_HOLE = 0xFFFFFFFFu;  // unused slot of such a block
-constexpr int FRONTIER_CAP = 64;
+constexpr int FRONTIER_CAP = 128;       // BVH nodes per level of the breadth-first walk (all bodies of an env together on the device)
+constexpr int BALL_CAND = 96, CAR_CAND = 96, PAIR_SLOTS = 16;   // candidate slots: 24 leaves per body (measured: <= 22 leaves per env; 12 were not enough for the ball in the corners)
+template <int NC>
 struct CollideQueue {
-    int n_cand, n_items, n_pool, overflow;
-    uint16_t cand_start[8];    // candidates of body b (0 = ball, 1 + i = car i) are cand[cand_start[b] .. cand_start[b+1]); car-car pairs follow
-    uint16_t frontier[2][FRONTIER_CAP];   // breadth-first BVH walk: nodes of the current and of the next level
-    uint32_t cand[CAND_CAP];   // type << 28 | a << 24 | ref
+    static constexpr int NB = NC + 1;
+    static constexpr int PAIR_BASE = BALL_CAND + NC * CAR_CAND;
+    int n_items, n_pool, overflow, n_pairs;
+    uint16_t cand_count[8];    // candidates of body b (0 = ball, 1 + i = car i) are cand[region(b) .. + cand_count[b]); pairs at PAIR_BASE
+    uint32_t frontier[2][FRONTIER_CAP];   // breadth-first BVH walk: (body << 16 | node) of the current and of the next level
+    V3 box_lo[NB], box_hi[NB];            // the bodies' query boxes during the device walk
+    uint32_t cand[PAIR_BASE + PAIR_SLOTS];   // type << 28 | a << 24 | ref
     CollideItem items[ITEM_CAP];
     Cand pool[POOL_CAP];
+    static RLG_HD int region(int body) { return body == 0 ? 0 : BALL_CAND + (body - 1) * CAR_CAND; }
+    static RLG_HD int region_cap(int body) { return body == 0 ? BALL_CAND : CAR_CAND; }
 };
 RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
 RLG_HD CollideItem unpack_cand(uint32_t c) {
@@ -141,11 +162,18 @@ RLG_HD int fetch_add(int& x, int v) {
 #endif
 }
 
-RLG_HD void queue_candidates(CollideQueue& Q, int type, int a, int first, int cnt) {
-    int k = Q.n_cand;
-    if (k + cnt > CAND_CAP) { Q.overflow = 1; return; }
-    Q.n_cand = k + cnt;
-    for (int q = 0; q < cnt; q++) Q.cand[k + q] = pack_cand(type, a, first + q);
+template <int NC>
+RLG_HD void queue_candidates(CollideQueue<NC>& Q, int body, int first, int cnt) {
+    int k = Q.cand_count[body];
+    if (k + cnt > CollideQueue<NC>::region_cap(body)) { Q.overflow = 1; return; }
+    Q.cand_count[body] = (uint16_t)(k + cnt);
+    const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
+    for (int q = 0; q < cnt; q++) Q.cand[CollideQueue<NC>::region(body) + k + q] = pack_cand(type, a, first + q);
+}
+template <int NC>
+RLG_HD void queue_pair(CollideQueue<NC>& Q, int ia, int ib) {
+    if (Q.n_pairs >= PAIR_SLOTS) { Q.overflow = 1; return; }
+    Q.cand[CollideQueue<NC>::PAIR_BASE + Q.n_pairs++] = pack_cand(2, ia, ib);
 }
 
 // every BVH leaf whose box overlaps [lo,hi], in walk order: f(first triangle, count)
@@ -221,20 +249,20 @@ RLG_HD bool body_query_box(const Arena<NC>& A, int body, bool ball_asleep, V3& l
 // The device runs the same walk with one lane per frontier node (rlgpu_env.hip:build_candidates_wave) and must produce
 // the same sequence, overflow included.
 template <class F>
-RLG_HD void mesh_query_leaves_bfs(MeshView mesh, V3 lo, V3 hi, uint16_t (&fr)[2][FRONTIER_CAP], int& overflow, F&& leaf) {
+RLG_HD void mesh_query_leaves_bfs(MeshView mesh, V3 lo, V3 hi, uint32_t (&fr)[2][FRONTIER_CAP], int& overflow, F&& leaf) {
     if (!mesh_maybe_near(mesh, lo, hi)) return;
     int n = 1, cur = 0;
     fr[0][0] = 0;
     while (n > 0) {
         int m = 0;
         for (int j = 0; j < n; j++) {
-            BvhNode nd = mesh_node(mesh, fr[cur][j]);
+            BvhNode nd = mesh_node(mesh, (int)fr[cur][j]);
             if (!aabb_overlap(nd, lo, hi)) continue;
             const int cnt = node_count(nd);
             if (cnt > 0) leaf(nd.left_or_first, cnt);
             else {
                 if (m + 2 > FRONTIER_CAP) { overflow = 1; return; }
-                fr[cur ^ 1][m++] = (uint16_t)nd.left_or_first; fr[cur ^ 1][m++] = (uint16_t)(nd.left_or_first + 1);
+                fr[cur ^ 1][m++] = (uint32_t)nd.left_or_first; fr[cur ^ 1][m++] = (uint32_t)(nd.left_or_first + 1);
             }
         }
         n = m; cur ^= 1;
@@ -250,29 +278,28 @@ RLG_HD void mesh_query(MeshView mesh, V3 lo, V3 hi, F&& f) {
         for (int k = 0; k < cnt; k++)
             if (tri_aabb_overlap(mesh.tris[first + k], lo, hi)) f(first + k);
     };
-    uint16_t fr[2][FRONTIER_CAP];
+    uint32_t fr[2][FRONTIER_CAP];
     int overflow = mesh.n_nodes > 65535 ? 1 : 0;
     if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, [](int, int) {});   // dry run: does the frontier fit?
     if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, per_leaf);
     else mesh_query_leaves(mesh, lo, hi, per_leaf);
 }
 
-// all candidates of one env for this tick (host form; called before the wheel rays)
+// all candidates of one env for this tick (host form; called before the wheel rays).  The device walks all bodies of an env in
+// ONE breadth-first pass (rlgpu_env.hip:build_candidates_wave); per body that yields the same sequence as the walk below.
 template <int NC>
-RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool ball_asleep, CollideQueue& Q) {
-    Q.n_cand = 0; Q.n_items = 0; Q.n_pool = 0; Q.overflow = 0;
-    if (mesh.n_nodes > 65535) Q.overflow = 1;   // frontier entries are 16 bit: bigger trees use the inline walk
+RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool ball_asleep, CollideQueue<NC>& Q) {
+    Q.n_items = 0; Q.n_pool = 0; Q.overflow = 0; Q.n_pairs = 0;
+    if (mesh.n_nodes > 65535) Q.overflow = 1;   // frontier entries carry 16-bit node ids: bigger trees use the inline walk
     for (int body = 0; body <= NC; body++) {
-        Q.cand_start[body] = (uint16_t)Q.n_cand;
+        Q.cand_count[body] = 0;
         V3 lo, hi;
         if (Q.overflow || !body_query_box(A, body, ball_asleep, lo, hi)) continue;
-        const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
-        mesh_query_leaves_bfs(mesh, lo, hi, Q.frontier, Q.overflow, [&](int first, int cnt) { queue_candidates(Q, type, a, first, cnt); });
+        mesh_query_leaves_bfs(mesh, lo, hi, Q.frontier, Q.overflow, [&](int first, int cnt) { queue_candidates(Q, body, first, cnt); });
     }
-    Q.cand_start[NC + 1] = (uint16_t)Q.n_cand;
     for (int ci = 0; ci < NC; ci++)
         for (int ib = ci + 1; ib < NC; ib++)
-            if (car_collides(A.cars[ci]) && car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
+            if (car_collides(A.cars[ci]) && car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_pair(Q, ci, ib);
 }
 
 RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best) {
@@ -341,7 +368,8 @@ RLG_HD void ray_key_min(unsigned long long& key, unsigned long long v) {
     if (v < key) key = v;
 #endif
 }
-RLG_HD void ray_apply_mesh_key(MeshView mesh, const CollideQueue& Q, unsigned long long key, V3 from, V3 to, RayHit& best) {
+template <class QT>
+RLG_HD void ray_apply_mesh_key(MeshView mesh, const QT& Q, unsigned long long key, V3 from, V3 to, RayHit& best) {
     if (key == RAY_NO_HIT) return;
     const MeshTri& t = mesh.tris[unpack_cand(Q.cand[(uint32_t)key]).ref];
     RayHit h; h.kind = -1; h.frac = best.frac; h.normal = v3(0, 0, 0);

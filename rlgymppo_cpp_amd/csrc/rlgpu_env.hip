@@ -18,13 +18,17 @@
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
 __shared__ unsigned long long g_prof[12];
 __device__ unsigned long long g_step_prof[16 * 4096];
-__device__ int g_dbg[64];   // scratch for ad-hoc device introspection (profiler build only; read with rlgpu_env_debug_ints)   // k_env_step's buckets per workgroup (first 4096 workgroups)
+__device__ int g_dbg[64];
+#define RLG_DBG_COUNT(i) atomicAdd(&g_dbg[i], 1)   // scratch for ad-hoc device introspection (profiler build only; read with rlgpu_env_debug_ints)   // k_env_step's buckets per workgroup (first 4096 workgroups)
 __shared__ unsigned long long g_prof_last;
 #define RLG_PROF(i)                                                              \
     do {                                                                         \
         unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
         if (threadIdx.x == 0) { g_prof[i] += _t - g_prof_last; g_prof_last = _t; } \
     } while (0)
+#endif
+#ifndef RLG_DBG_COUNT
+#define RLG_DBG_COUNT(i) ((void)0)
 #endif
 #include "../../include/rlgpu.h"
 #include "arena_gym.h"
@@ -182,74 +186,88 @@ __device__ __forceinline__ WaveSlot wave_slot(unsigned char* lane_mem, int n_env
 }
 
 // Phase 0b on the device: this tick's narrowphase candidates (arena_world.h:collide_build_candidates is the host form and
-// defines the order).  The LPE lanes that serve one env walk the BVH breadth-first, one lane per frontier node; bodies
-// of an env go one after the other.  Ballots / shuffles are group-local slices of wave-wide ones, so every loop below
-// is wave-uniform.
+// defines the order).  The LPE lanes that serve one env walk the BVH breadth-first for ALL bodies of the env at once: a
+// frontier entry is (body, node), one lane per entry tests the node against that body's query box; children and leaf
+// triangles are appended in frontier order, so per body the sequence equals a walk of its own.  Ballots are group-local
+// slices of wave-wide ones, so every loop below is wave-uniform.
 template <int NC>
 __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, MeshView mv) {
     constexpr int EPW = lanes_per_block<NC>() / WPB, LPE = WAVE / EPW, NB = NC + 1;
+    static_assert(NB <= LPE, "one lane per body for the query boxes");
     const int tid = threadIdx.x & 63, e = tid / LPE, li = tid % LPE;
     const bool grp = e < n_valid;
     LaneBlock<NC>& S = lane_block<NC>(lane_mem, grp ? e : 0);
-    CollideQueue& Q = S.W.Q;
+    CollideQueue<NC>& Q = S.W.Q;
+    const int gshift = e * LPE;
     const unsigned long long gmask = ~0ull >> (64 - LPE);
-    const unsigned long long below_mask = (1ull << li) - 1ull;
+    const unsigned long long below = (1ull << li) - 1ull;
     const bool asleep = (len2(S.A.ball.b.vel) == 0.f && len2(S.A.ball.b.angvel) == 0.f);
-    int n_cand = 0;
     bool overflow = mv.n_nodes > 65535;
-    // query boxes: lane b of the group computes body b's, the others fetch it with a shuffle
-    V3 my_lo = v3(0, 0, 0), my_hi = v3(0, 0, 0);
-    const bool my_active = grp && li < NB && !overflow && body_query_box(S.A, li, asleep, my_lo, my_hi) && mesh_maybe_near(mv, my_lo, my_hi);
-    for (int body = 0; body < NB; body++) {
-        if (grp && li == 0) Q.cand_start[body] = (uint16_t)n_cand;
-        const int src = e * LPE + body;
-        const V3 lo = v3(__shfl(my_lo.x, src), __shfl(my_lo.y, src), __shfl(my_lo.z, src));
-        const V3 hi = v3(__shfl(my_hi.x, src), __shfl(my_hi.y, src), __shfl(my_hi.z, src));
-        const bool active = __shfl((int)my_active, src) != 0 && !overflow;
-        const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
-        int n = active ? 1 : 0, cur = 0;
-        if (active && li == 0) Q.frontier[0][0] = 0;
-        while (__any(n > 0)) {
-            wave_sync();
-            int m = 0;
-            for (int c0 = 0; __any(c0 < n); c0 += LPE) {
-                const int j = c0 + li;
-                bool inner = false, leaf = false; int cnt = 0, first = 0;
-                if (j < n) {
-                    BvhNode nd = mesh_node(mv, Q.frontier[cur][j]);
-                    if (aabb_overlap(nd, lo, hi)) { cnt = node_count(nd); first = nd.left_or_first; inner = cnt == 0; leaf = cnt > 0; }
-                }
-                const unsigned long long mi = (__ballot(inner) >> (e * LPE)) & gmask;
-                const unsigned long long ml = (__ballot(leaf) >> (e * LPE)) & gmask;
-                bool ovf = false;
-                if (inner) {
-                    const int pos = m + 2 * __popcll(mi & below_mask);
-                    if (pos + 2 > FRONTIER_CAP) ovf = true;
-                    else { Q.frontier[cur ^ 1][pos] = (uint16_t)first; Q.frontier[cur ^ 1][pos + 1] = (uint16_t)(first + 1); }
-                }
-                m += 2 * __popcll(mi);
-                // leaves: a fixed block of LEAF_SLOTS candidate slots per leaf, in frontier order (unused slots are holes) -- a
-                // ballot instead of a prefix sum over the triangle counts
-                if (leaf) {
-                    const int k = n_cand + LEAF_SLOTS * __popcll(ml & below_mask);
-                    if (k + LEAF_SLOTS > CAND_CAP) ovf = true;
-                    else for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[k + q] = q < cnt ? pack_cand(type, a, first + q) : CAND_HOLE;
-                }
-                n_cand += LEAF_SLOTS * __popcll(ml);
-                if ((__ballot(ovf) >> (e * LPE)) & gmask) overflow = true;
-            }
-            n = overflow ? 0 : m;
-            cur ^= 1;
-        }
-        wave_sync();
+    const bool all_fast = mv.n_nodes <= mv.n_fast;
+    // query boxes: lane b of the group computes body b's and publishes it
+    bool my_active = false;
+    if (grp && li < NB && !overflow) {
+        V3 lo, hi;
+        my_active = body_query_box(S.A, li, asleep, lo, hi) && mesh_maybe_near(mv, lo, hi);
+        if (my_active) { Q.box_lo[li] = lo; Q.box_hi[li] = hi; }
     }
+    // level 0: the roots of the active bodies, in body order
+    const unsigned long long ma = (__ballot(my_active) >> gshift) & gmask;
+    if (my_active) Q.frontier[0][__popcll(ma & below)] = (uint32_t)li << 16;
+    int n = grp ? __popcll(ma) : 0, cur = 0;
+    int cnt_b[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) cnt_b[b] = 0;
+    while (__any(n > 0)) {
+        wave_sync();
+        int m = 0;
+        for (int c0 = 0; __any(c0 < n); c0 += LPE) {
+            const int j = c0 + li;
+            bool inner = false, leaf = false; int cnt = 0, first = 0, body = 0;
+            if (j < n) {
+                const uint32_t ent = Q.frontier[cur][j];
+                body = (int)(ent >> 16);
+                const int ni = (int)(ent & 0xffffu);
+                BvhNode nd;
+                if (all_fast) { RLG_ASSUME_LDS(*mv.nodes_fast); nd = load_node(mv.nodes_fast + ni); }   // whole tree staged: ds_read instead of a flat load
+                else nd = mesh_node(mv, ni);
+                if (aabb_overlap(nd, Q.box_lo[body], Q.box_hi[body])) { cnt = node_count(nd); first = nd.left_or_first; inner = cnt == 0; leaf = cnt > 0; }
+            }
+            const unsigned long long mi = (__ballot(inner) >> gshift) & gmask;
+            bool ovf = false;
+            if (inner) {
+                const int pos = m + 2 * __popcll(mi & below);
+                if (pos + 2 > FRONTIER_CAP) { ovf = true; RLG_DBG_COUNT(0); }
+                else { Q.frontier[cur ^ 1][pos] = ((uint32_t)body << 16) | (uint32_t)first; Q.frontier[cur ^ 1][pos + 1] = ((uint32_t)body << 16) | (uint32_t)(first + 1); }
+            }
+            m += 2 * __popcll(mi);
+            // leaves: a fixed block of LEAF_SLOTS candidate slots per leaf in the body's region, in frontier order (unused
+            // slots are holes) -- a ballot per body instead of a prefix sum over the triangle counts
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const bool mine = leaf && body == b;
+                const unsigned long long ml = (__ballot(mine) >> gshift) & gmask;
+                if (mine) {
+                    const int k = cnt_b[b] + LEAF_SLOTS * __popcll(ml & below);
+                    if (k + LEAF_SLOTS > CollideQueue<NC>::region_cap(b)) { ovf = true; RLG_DBG_COUNT(1 + (b > 0)); }
+                    else for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[CollideQueue<NC>::region(b) + k + q] = q < cnt ? pack_cand(b == 0 ? 0 : 1, b == 0 ? 0 : b - 1, first + q) : CAND_HOLE;
+                }
+                cnt_b[b] += LEAF_SLOTS * __popcll(ml);
+            }
+            if ((__ballot(ovf) >> gshift) & gmask) overflow = true;
+        }
+        n = overflow ? 0 : m;
+        cur ^= 1;
+    }
+    wave_sync();
     if (grp && li == 0) {
         S.W.ball_asleep = asleep;
-        Q.cand_start[NB] = (uint16_t)(n_cand < CAND_CAP ? n_cand : CAND_CAP);
-        Q.n_cand = n_cand < CAND_CAP ? n_cand : CAND_CAP; Q.n_items = 0; Q.n_pool = 0; Q.overflow = overflow ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) Q.cand_count[b] = (uint16_t)(cnt_b[b] < CollideQueue<NC>::region_cap(b) ? cnt_b[b] : CollideQueue<NC>::region_cap(b));
+        Q.n_items = 0; Q.n_pool = 0; Q.overflow = overflow ? 1 : 0; Q.n_pairs = 0;
         for (int ci = 0; ci < NC; ci++)
             for (int ib = ci + 1; ib < NC; ib++)
-                if (car_collides(S.A.cars[ci]) && car_collides(S.A.cars[ib]) && cars_maybe_touch(S.A, ci, ib)) queue_candidates(Q, 2, ci, ib, 1);
+                if (car_collides(S.A.cars[ci]) && car_collides(S.A.cars[ib]) && cars_maybe_touch(S.A, ci, ib)) queue_pair(Q, ci, ib);
     }
     wave_sync();
 }
@@ -313,19 +331,23 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         const int e_item = e_grp, l_item = l_grp;
         const bool item_lane = e_item < n_valid;
         LaneBlock<NC>& Si = lane_block<NC>(lane_mem, item_lane ? e_item : 0);
-        CollideQueue& Q = Si.W.Q;
+        CollideQueue<NC>& Q = Si.W.Q;
         {
-            const int n_cand = (item_lane && !Q.overflow) ? Q.n_cand : 0;
+            const bool live = item_lane && !Q.overflow;
             int base = 0;   // items of this env so far (same value on all its lanes)
-            for (int c0 = 0; __any(c0 < n_cand); c0 += LPE) {
-                const int k = c0 + l_item;
-                const bool pass = k < n_cand && collide_test_candidate(Si.A, mv, Q, k);
-                const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & (~0ull >> (64 - LPE));
-                if (pass) {
-                    const int pos = base + __popcll(m & ((1ull << l_item) - 1ull));
-                    if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
+            for (int body = 0; body <= NC + 1; body++) {   // the body regions, then the pair region
+                const int region = body <= NC ? CollideQueue<NC>::region(body) : CollideQueue<NC>::PAIR_BASE;
+                const int n_cand = !live ? 0 : (body <= NC ? (int)Q.cand_count[body] : Q.n_pairs);
+                for (int c0 = 0; __any(c0 < n_cand); c0 += LPE) {
+                    const int k = region + c0 + l_item;
+                    const bool pass = c0 + l_item < n_cand && collide_test_candidate(Si.A, mv, Q, k);
+                    const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & (~0ull >> (64 - LPE));
+                    if (pass) {
+                        const int pos = base + __popcll(m & ((1ull << l_item) - 1ull));
+                        if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(Q.cand[k]); else { Q.overflow = 1; RLG_DBG_COUNT(3); }
+                    }
+                    base += __popcll(m);
                 }
-                base += __popcll(m);
             }
             if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
         }
@@ -334,7 +356,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             int n_of[EPW], total = 0;
 #pragma unroll
             for (int e = 0; e < EPW; e++) {
-                const CollideQueue& Qe = lane_block<NC>(lane_mem, e < n_valid ? e : 0).W.Q;
+                const CollideQueue<NC>& Qe = lane_block<NC>(lane_mem, e < n_valid ? e : 0).W.Q;
                 n_of[e] = (e < n_valid && !Qe.overflow) ? Qe.n_items : 0;
                 total += n_of[e];
             }

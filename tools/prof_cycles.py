@@ -72,3 +72,7 @@ if hasattr(env.lib, "rlgpu_env_debug_step_prof"):
     print("   mean: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, acc[:, :12].mean(axis=0))))
     w = int(np.argmax(tot))
     print("   slowest wg: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, acc[w, :12])))
+
+if hasattr(env.lib, "rlgpu_env_debug_ints"):
+    buf = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]; env.lib.rlgpu_env_debug_ints(env.h, buf)
+    print("queue overflow events so far: frontier", buf[0], "ball region", buf[1], "car region", buf[2], "items", buf[3], "pool", buf[4])
