@@ -294,17 +294,22 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
     if (whl_lane) car_wheel_ray_begin(Sw.A, c_whl, w_whl, Sw.W.ctx[c_whl]);
     wave_sync();
-    {
-        constexpr int LPE_R = WAVE / EPW;
-        const int e_r = tid / LPE_R, l_r = tid % LPE_R;
-        if (e_r < n_valid) {
-            LaneBlock<NC>& Sr = lane_block<NC>(lane_mem, e_r);
-            if (!Sr.W.Q.overflow) {
-                for (int ci = 0; ci < NC; ci++) {
-                    const int n_pairs = car_ray_pairs(Sr.A, Sr.W.Q, ci);
-                    for (int pr = l_r; pr < n_pairs; pr += LPE_R) car_ray_pair(Sr.A, mv, Sr.W.Q, ci, pr, Sr.W.ctx[ci]);
-                }
-            }
+    {   // all (env, car, wheel, candidate) pairs of the wavefront as ONE list over the 64 lanes (a car next to a wall has ~100 of
+        // them, most cars none)
+        int n_of[EPW * NC], total = 0;
+#pragma unroll
+        for (int q = 0; q < EPW * NC; q++) {
+            const int e = q / NC, ci = q % NC;
+            const LaneBlock<NC>& Sq = lane_block<NC>(lane_mem, e < n_valid ? e : 0);
+            n_of[q] = (e < n_valid && !Sq.W.Q.overflow) ? car_ray_pairs(Sq.A, Sq.W.Q, ci) : 0;
+            total += n_of[q];
+        }
+        for (int g = tid; g < total; g += WAVE) {
+            int q = 0, pr = g;
+#pragma unroll
+            for (int k = 0; k < EPW * NC - 1; k++) if (q == k && pr >= n_of[k]) { pr -= n_of[k]; q = k + 1; }
+            LaneBlock<NC>& Sr = lane_block<NC>(lane_mem, q / NC);
+            car_ray_pair(Sr.A, mv, Sr.W.Q, q % NC, pr, Sr.W.ctx[q % NC]);
         }
     }
     wave_sync();
