@@ -173,6 +173,9 @@ typedef struct rlgpu_shuffler rlgpu_shuffler;
 int rlgpu_shuffler_create(rlgpu_shuffler** out, uint32_t seed);
 void rlgpu_shuffler_destroy(rlgpu_shuffler* s);
 int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm_out);
+/* the same draw for a [T][n_agents] time-major experience buffer whose LOGICAL order is agent-major (trajectory after trajectory, as
+ * ExperienceBuffer holds it): rows_out[i] = (p % T) * n_agents + p / T for p = perm[i], B = T * n_agents entries, ready for idx_dev */
+int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows_out);
 
 #ifdef __cplusplus
 }

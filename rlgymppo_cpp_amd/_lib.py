@@ -100,6 +100,7 @@ SIGNATURES = {
     "rlgpu_shuffler_create": (_i, [C.POINTER(_vp), C.c_uint32]),
     "rlgpu_shuffler_destroy": (None, [_vp]),
     "rlgpu_shuffler_next": (_i, [_vp, C.c_int64, _vp]),
+    "rlgpu_shuffler_next_rows": (_i, [_vp, C.c_int, C.c_int, _vp]),
 }
 
 _lib = None

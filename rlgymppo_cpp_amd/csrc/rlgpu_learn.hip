@@ -627,7 +627,7 @@ struct rlgpu_learner {
     std::string err;
 };
 
-struct rlgpu_shuffler { std::default_random_engine rng; };
+struct rlgpu_shuffler { std::default_random_engine rng; std::vector<int64_t> scratch; };
 
 #define LCHK(l, call)                                                                           \
     do {                                                                                         \
@@ -1099,6 +1099,15 @@ int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm) {
     if (!s || n < 0 || !perm) return RLGPU_ERR_ARG;
     std::iota(perm, perm + n, (int64_t)0);
     std::shuffle(perm, perm + n, s->rng);
+    return RLGPU_OK;
+}
+int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows) {
+    if (!s || T <= 0 || n_agents <= 0 || !rows) return RLGPU_ERR_ARG;
+    const int64_t B = (int64_t)T * n_agents;
+    s->scratch.resize((size_t)B);
+    int rc = rlgpu_shuffler_next(s, B, s->scratch.data());
+    if (rc) return rc;
+    for (int64_t i = 0; i < B; i++) { const int64_t p = s->scratch[(size_t)i]; rows[i] = (int32_t)((p % T) * n_agents + p / T); }
     return RLGPU_OK;
 }
 

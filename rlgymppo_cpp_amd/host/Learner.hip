@@ -287,8 +287,7 @@ void Learner::LearnPPO(Report& report) {
     for (int ep = 0; ep < config.ppo.epochs; ep++) {
         // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126): logical rows are agent-major (trajectory after trajectory);
         // the device buffers are time-major
-        rlgpu_shuffler_next(m.shuf, m.B, m.perm.data());
-        for (int64_t i = 0; i < m.B; i++) { int64_t p = m.perm[i]; m.phys[i] = (int32_t)((p % m.T) * m.nAgents + (p / m.T)); }
+        rlgpu_shuffler_next_rows(m.shuf, m.T, m.nAgents, m.phys.data());
         HOST_HIP(hipMemcpyAsync(m.idx, m.phys.data(), (size_t)m.B * 4, hipMemcpyHostToDevice, nullptr));
         for (int64_t b = 0; b + m.batch <= m.B; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
             m.LrnCheck(rlgpu_zero_grads(m.lrn), "zero_grads");

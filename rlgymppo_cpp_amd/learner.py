@@ -107,6 +107,13 @@ class Shuffler:
         assert self.lib.rlgpu_shuffler_next(self.h, n, out.ctypes.data) == 0
         return out
 
+    def next_rows(self, T, n_agents, out=None):
+        """The same draw as next(T * n_agents), already mapped from logical agent-major order to time-major buffer rows (int32)."""
+        if out is None:
+            out = np.empty(T * n_agents, np.int32)
+        assert self.lib.rlgpu_shuffler_next_rows(self.h, T, n_agents, out.ctypes.data) == 0
+        return out
+
     def __del__(self):
         try:
             self.lib.rlgpu_shuffler_destroy(self.h)
@@ -150,6 +157,11 @@ class Learner:
         self.metrics = torch.zeros(8, **f)
         self.return_stats = WelfordRunningStat()
         self.shuffler = Shuffler(cfg.randomSeed)
+        self._rows_host = [torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in range(2)]   # double-buffered pinned staging of the shuffle
+        self._rows_dev = torch.empty(self.B, dtype=torch.int32, device=self.dev)
+        self._rows_flip = 0
+        self._rows_ev = [None, None]
+        self._next_rows = None
         self.total_timesteps = 0
         self.total_epochs = 0
         self.cumulative_model_updates = 0
@@ -206,9 +218,14 @@ class Learner:
         self.metrics.zero_()
         n_mb = 0; n_updates = 0
         for _ in range(p.epochs):
-            perm = self.shuffler.next(B)                       # logical (agent-major) indices, ExperienceBuffer.cpp:106-121
-            phys = ((perm % T) * N + (perm // T)).astype(np.int32)   # -> physical time-major rows
-            idx = torch.from_numpy(phys).to(self.dev, non_blocking=True)
+            # shuffled logical (agent-major) indices (ExperienceBuffer.cpp:106-121) as time-major buffer rows.  The draw does not
+            # depend on data, so the NEXT one is made right after this epoch's launches, while the GPU is busy with them.
+            if self._next_rows is None:
+                self._next_rows = self.shuffler.next_rows(T, N, self._rows_host[self._rows_flip].numpy())
+            self._next_rows = None
+            idx = self._rows_dev
+            idx.copy_(self._rows_host[self._rows_flip], non_blocking=True)
+            self._rows_ev[self._rows_flip] = torch.cuda.Event(); self._rows_ev[self._rows_flip].record()
             for b in range(B // self.batch_size):              # remainder rows are skipped (Q5)
                 self.ppo.zero_grads()
                 base = b * self.batch_size
@@ -218,6 +235,10 @@ class Learner:
                 scale = parallel.allreduce_gradients(self.ppo.grad_tensor(), self.world)   # ONE RCCL all-reduce per optimizer step
                 self.ppo.clip_adam_step(0.5, scale)
                 n_updates += 1
+            self._rows_flip ^= 1
+            if self._rows_ev[self._rows_flip] is not None:
+                self._rows_ev[self._rows_flip].synchronize()   # its last upload has left the pinned buffer
+            self._next_rows = self.shuffler.next_rows(T, N, self._rows_host[self._rows_flip].numpy())   # prefetch (CPU) under the GPU work
         self.total_epochs += p.epochs
         self.cumulative_model_updates += n_updates
         self._n_mb = n_mb
