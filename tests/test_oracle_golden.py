@@ -76,6 +76,23 @@ def test_libstdcxx_shuffle(lg):
             assert (perm == lg[f"shuffle_{rep * 5 + i}"]).all()
 
 
+def test_library_shuffler_matches_oracle_and_row_mapping(lg):
+    """rlgpu_shuffler_next == libstdc++ std::shuffle with a persistent default_random_engine (the oracle restates it; the golden
+    tape comes from the real thing), and rlgpu_shuffler_next_rows is that draw mapped from agent-major logical order to
+    time-major rows.  Host-only entry points of librlgpu.so: no GPU needed."""
+    from rlgymppo_cpp_amd.learner import Shuffler
+    a, st = Shuffler(123), 123
+    for rep in range(2):
+        for i, n in enumerate([1, 2, 7, 64, 1000]):
+            want, st = R.libstdcxx_shuffle(n, st)
+            assert (a.next(n) == want).all() and (want == lg[f"shuffle_{rep * 5 + i}"]).all()
+    b, c = Shuffler(77), Shuffler(77)
+    T, N = 5, 12
+    for _ in range(3):
+        p = b.next(T * N)
+        assert (c.next_rows(T, N) == ((p % T) * N + p // T)).all()
+
+
 def test_welford():
     w = R.Welford()
     xs = np.random.RandomState(0).randn(300) * 3 + 1
