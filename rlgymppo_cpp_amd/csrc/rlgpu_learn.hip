@@ -179,8 +179,14 @@ __global__ void __launch_bounds__(256) k_gemm_nt(NtArgs g) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int A_CH = (BM * 4 + 255) / 256, B_CH = (BN * 4 + 255) / 256;   // 16-byte chunks per thread and tile
-    __shared__ __attribute__((aligned(16))) short As[BM * NT_LD];
-    __shared__ __attribute__((aligned(16))) short Bs[BN * NT_LD];
+    // bf16 outputs of the 128-wide configuration leave through LDS: the MFMA result layout has one column per lane (2-byte stores,
+    // 2-byte mask loads); staged, every lane moves 16 contiguous bytes
+    constexpr bool STAGED = (EPI != 1) && (BN == 128);
+    constexpr int C_LD = BN + 8;
+    constexpr int SMEM = STAGED ? ((BM + BN) * NT_LD > BM * C_LD ? (BM + BN) * NT_LD : BM * C_LD) : (BM + BN) * NT_LD;
+    __shared__ __attribute__((aligned(16))) short smem[SMEM];
+    short* const As = smem;
+    short* const Bs = smem + BM * NT_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -243,6 +249,43 @@ __global__ void __launch_bounds__(256) k_gemm_nt(NtArgs g) {
         __syncthreads();
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (STAGED) {
+        short* const Cs = smem;   // the k-loop ended with a barrier: As / Bs are dead
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int col = (wn * TN + j) * 32 + (lane & 31);
+                float bias = 0.f;
+                if (EPI == 0 && g.bias && n0 + col < g.N) bias = g.bias[n0 + col];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bias;
+                    if (EPI == 0) v = fmaxf(v, 0.f);
+                    Cs[row * C_LD + col] = f2bf(v);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (BM * (BN / 8)) / 256; it++) {
+            const int idx = tid + it * 256, row = idx / (BN / 8), ch = idx % (BN / 8);
+            const int gm = m0 + row, gn = n0 + ch * 8;
+            if (gm >= g.M || gn >= g.ldc16) continue;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(&Cs[row * C_LD + ch * 8]);
+            if (EPI == 2) {
+                const bf16x8 mk = *reinterpret_cast<const bf16x8*>(&g.mask16[(size_t)gm * g.ldm + gn]);
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (!(bf2f(mk[q]) > 0.f)) v[q] = 0;
+            }
+            if (gn + 8 > g.N) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (gn + q >= g.N) v[q] = 0;
+            }
+            *reinterpret_cast<bf16x8*>(&g.C16[(size_t)gm * g.ldc16 + gn]) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -802,6 +845,8 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
             t.Y = cur; t.ldy = net.kp[i + 1]; t.X = in; t.ldx = net.kp[i];
             t.R = rows; t.Mo = N_out; t.No = K_in;
             t.dW = l->grads + net.w_off[i]; t.ldw = K_in; t.db = l->grads + net.b_off[i];
+            // 512-row slabs: measured optimum between atomic traffic (128 rows: 99 TFLOP/s for the whole minibatch, 256: 139) and
+            // too few workgroups (2048: 143); slab partials + a reduction kernel instead of atomics were slower (153 vs 171)
             t.slab = 512;
             dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
             hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, l->stream, t);
