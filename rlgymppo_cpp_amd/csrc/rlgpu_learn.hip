@@ -794,8 +794,13 @@ int refresh_shadows(rlgpu_learner* l) {
 
 template <int EPI>
 int launch_nt(rlgpu_learner* l, NtArgs g, int real_k) {
-    if (g.N > 32 || EPI == 2) {
-        dim3 grid((std::max(g.N, EPI == 1 ? g.N : g.ldc16) + 127) / 128, (g.M + 127) / 128);
+    const int n_cover = std::max(g.N, EPI == 1 ? g.N : g.ldc16);
+    if ((g.N > 32 || EPI == 2) && (size_t)((n_cover + 127) / 128) * ((g.M + 127) / 128) < 256) {
+        // inference-sized M (8192 agent rows): 128x128 tiles would occupy half of the 256 CUs -- 64x64 tiles, 4x the workgroups
+        dim3 grid((n_cover + 63) / 64, (g.M + 63) / 64);
+        hipLaunchKernelGGL((k_gemm_nt<2, 2, 1, 1, EPI>), grid, dim3(256), 0, l->stream, g);
+    } else if (g.N > 32 || EPI == 2) {
+        dim3 grid((n_cover + 127) / 128, (g.M + 127) / 128);
         hipLaunchKernelGGL((k_gemm_nt<2, 2, 2, 2, EPI>), grid, dim3(256), 0, l->stream, g);
     } else {
         dim3 grid(1, (g.M + 127) / 128);
