@@ -177,6 +177,19 @@ int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm_out);
  * ExperienceBuffer holds it): rows_out[i] = (p % T) * n_agents + p / T for p = perm[i], B = T * n_agents entries, ready for idx_dev */
 int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows_out);
 
+/* ---- ExperienceBuffer (PRIV/PPO/ExperienceBuffer.{h,cpp}): FIFO over rows with capacity max_rows.  Host bookkeeping only:
+ *      every submitted iteration (T x n_agents rows, time-major) stays in one of `num_slots` device slots the caller owns; the
+ *      library tracks which rows are still inside the FIFO (shift-left on overflow, :37-58; an addition larger than the buffer
+ *      keeps its last max_rows rows, :32-35) and draws GetAllBatchesShuffled's permutation (:104-126) as device row numbers
+ *      slot * T * n_agents + t * n_agents + agent. ---- */
+typedef struct rlgpu_expbuf rlgpu_expbuf;
+int rlgpu_expbuf_create(rlgpu_expbuf** out, int64_t max_rows, int T, int n_agents);
+void rlgpu_expbuf_destroy(rlgpu_expbuf* b);
+int rlgpu_expbuf_num_slots(const rlgpu_expbuf* b);
+int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out);   /* account for one more iteration; *slot_out = where the caller must store it */
+int64_t rlgpu_expbuf_size(const rlgpu_expbuf* b);          /* curSize */
+int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows_out /* [curSize] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -672,6 +672,14 @@ struct rlgpu_learner {
 
 struct rlgpu_shuffler { std::default_random_engine rng; std::vector<int64_t> scratch; };
 
+// ExperienceBuffer bookkeeping (PRIV/PPO/ExperienceBuffer.cpp:17-68): which rows of which submitted iteration are still in the FIFO
+struct rlgpu_expbuf {
+    int64_t max_rows = 0; int T = 0, n = 0; int64_t B = 0;
+    struct Chunk { int slot; int64_t skip; };   // rows [skip, B) of the iteration stored in device slot `slot`, in agent-major order
+    std::vector<Chunk> chunks;                  // oldest first
+    int n_slots = 0;
+};
+
 #define LCHK(l, call)                                                                           \
     do {                                                                                         \
         hipError_t _s = (call);                                                                  \
@@ -1158,6 +1166,65 @@ int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* ro
     int rc = rlgpu_shuffler_next(s, B, s->scratch.data());
     if (rc) return rc;
     for (int64_t i = 0; i < B; i++) { const int64_t p = s->scratch[(size_t)i]; rows[i] = (int32_t)((p % T) * n_agents + p / T); }
+    return RLGPU_OK;
+}
+
+// ---- experience FIFO (host bookkeeping only; the rows themselves stay in the caller's device slots) ----
+int rlgpu_expbuf_create(rlgpu_expbuf** out, int64_t max_rows, int T, int n_agents) {
+    if (!out || max_rows <= 0 || T <= 0 || n_agents <= 0) return RLGPU_ERR_ARG;
+    rlgpu_expbuf* b = new rlgpu_expbuf();
+    b->max_rows = max_rows; b->T = T; b->n = n_agents; b->B = (int64_t)T * n_agents;
+    b->n_slots = (int)((max_rows + b->B - 1) / b->B) + 1;
+    *out = b;
+    return RLGPU_OK;
+}
+void rlgpu_expbuf_destroy(rlgpu_expbuf* b) { delete b; }
+int rlgpu_expbuf_num_slots(const rlgpu_expbuf* b) { return b ? b->n_slots : 0; }
+int64_t rlgpu_expbuf_size(const rlgpu_expbuf* b) {
+    int64_t n = 0;
+    if (b) for (auto& c : b->chunks) n += b->B - c.skip;
+    return n;
+}
+int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out) {
+    if (!b || !slot_out) return RLGPU_ERR_ARG;
+    // an addition larger than the buffer keeps its LAST max_rows rows (ExperienceBuffer.cpp:32-35)
+    int64_t add = b->B, new_skip = 0;
+    if (add > b->max_rows) { new_skip = add - b->max_rows; add = b->max_rows; }
+    // shift left by the overflow (ExperienceBuffer.cpp:37-58): drop the oldest rows
+    int64_t overflow = std::max<int64_t>(rlgpu_expbuf_size(b) + add - b->max_rows, 0);
+    while (overflow > 0 && !b->chunks.empty()) {
+        rlgpu_expbuf::Chunk& c = b->chunks.front();
+        int64_t have = b->B - c.skip;
+        if (have <= overflow) { overflow -= have; b->chunks.erase(b->chunks.begin()); }
+        else { c.skip += overflow; overflow = 0; }
+    }
+    int slot = -1;
+    for (int s = 0; s < b->n_slots && slot < 0; s++) {
+        bool used = false;
+        for (auto& c : b->chunks) used = used || c.slot == s;
+        if (!used) slot = s;
+    }
+    if (slot < 0) return RLGPU_ERR_STATE;
+    b->chunks.push_back({slot, new_skip});
+    *slot_out = slot;
+    return RLGPU_OK;
+}
+int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows_out) {
+    if (!b || !s || !rows_out) return RLGPU_ERR_ARG;
+    const int64_t cur = rlgpu_expbuf_size(b);
+    if ((int64_t)b->n_slots * b->B > 0x7fffffffLL) return RLGPU_ERR_ARG;
+    s->scratch.resize((size_t)cur);
+    int rc = rlgpu_shuffler_next(s, cur, s->scratch.data());
+    if (rc) return rc;
+    // logical row i of the FIFO -> (chunk, agent-major index a) -> device row slot * B + (a % T) * n + a / T
+    std::vector<int64_t> start(b->chunks.size() + 1, 0);
+    for (size_t c = 0; c < b->chunks.size(); c++) start[c + 1] = start[c] + (b->B - b->chunks[c].skip);
+    for (int64_t i = 0; i < cur; i++) {
+        const int64_t p = s->scratch[(size_t)i];
+        size_t c = (size_t)(std::upper_bound(start.begin(), start.end(), p) - start.begin()) - 1;
+        const int64_t a = p - start[c] + b->chunks[c].skip;
+        rows_out[i] = (int32_t)((int64_t)b->chunks[c].slot * b->B + (a % b->T) * b->n + a / b->T);
+    }
     return RLGPU_OK;
 }
 

@@ -114,6 +114,9 @@ struct Learner::Impl {
     float *obs = nullptr, *logp = nullptr, *rew = nullptr, *doneF = nullptr, *trunc = nullptr, *vals = nullptr, *adv = nullptr, *tgt = nullptr, *ret = nullptr,
           *metrics = nullptr, *scratch = nullptr;
     int32_t *acts = nullptr, *done = nullptr, *idx = nullptr;
+    // ExperienceBuffer (ExperienceBuffer.h): the FIFO's iterations stay in device slots of B rows, the library tracks the live rows
+    rlgpu_expbuf* fifo = nullptr;
+    float *exObs = nullptr, *exLogp = nullptr, *exAdv = nullptr, *exTgt = nullptr; int32_t* exActs = nullptr;
     bool first = true;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     std::vector<GameInst> games;
@@ -173,11 +176,15 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
 
     const size_t TN = (size_t)m.T * m.nAgents;
     m.obs = dev_alloc<float>((size_t)(m.T + 1) * m.nAgents * m.D);
-    m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN); m.idx = dev_alloc<int32_t>(TN);
+    m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN);
+    if (rlgpu_expbuf_create(&m.fifo, config.expBufferSize, m.T, m.nAgents) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: bad expBufferSize " << config.expBufferSize);
+    const size_t EX = (size_t)rlgpu_expbuf_num_slots(m.fifo) * TN;
+    m.idx = dev_alloc<int32_t>(EX);
+    m.exObs = dev_alloc<float>(EX * m.D); m.exActs = dev_alloc<int32_t>(EX); m.exLogp = dev_alloc<float>(EX); m.exAdv = dev_alloc<float>(EX); m.exTgt = dev_alloc<float>(EX);
     m.logp = dev_alloc<float>(TN); m.rew = dev_alloc<float>(TN); m.doneF = dev_alloc<float>(TN); m.trunc = dev_alloc<float>(TN);
     m.adv = dev_alloc<float>(TN); m.tgt = dev_alloc<float>(TN); m.ret = dev_alloc<float>(TN);
     m.vals = dev_alloc<float>(TN + m.nAgents); m.metrics = dev_alloc<float>(8); m.scratch = dev_alloc<float>(8);
-    m.perm.resize(m.B); m.phys.resize(m.B);
+    m.phys.resize(EX);
     m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
 
     runID = config.metricsRunName;
@@ -189,8 +196,9 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
 Learner::~Learner() {
     Impl& m = *impl;
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
-                    (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch})
+                    (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
+    if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
     if (m.lrn) rlgpu_learner_destroy(m.lrn);
     if (m.env) rlgpu_env_destroy(m.env);
@@ -276,6 +284,15 @@ void Learner::AddNewExperience(Report& report) {
     for (int i = 0; i < 3; i++) sums[i] = h[i] / (float)TN;
     report["Avg Return"] = sums[0] / retStd; report["Avg Advantage"] = sums[1]; report["Avg Val Target"] = sums[2];
     report["Average Step Reward"] = h[3] / (float)TN;
+    // ExperienceBuffer::SubmitExperience (Learner.cpp:694-702): this iteration's rows join the FIFO
+    int slot = 0;
+    if (rlgpu_expbuf_submit(m.fifo, &slot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");
+    const size_t o = (size_t)slot * TN;
+    HOST_HIP(hipMemcpyAsync(m.exObs + o * m.D, m.obs, TN * m.D * 4, hipMemcpyDeviceToDevice, nullptr));
+    HOST_HIP(hipMemcpyAsync(m.exActs + o, m.acts, TN * 4, hipMemcpyDeviceToDevice, nullptr));
+    HOST_HIP(hipMemcpyAsync(m.exLogp + o, m.logp, TN * 4, hipMemcpyDeviceToDevice, nullptr));
+    HOST_HIP(hipMemcpyAsync(m.exAdv + o, m.adv, TN * 4, hipMemcpyDeviceToDevice, nullptr));
+    HOST_HIP(hipMemcpyAsync(m.exTgt + o, m.tgt, TN * 4, hipMemcpyDeviceToDevice, nullptr));
 }
 
 void Learner::LearnPPO(Report& report) {
@@ -285,14 +302,15 @@ void Learner::LearnPPO(Report& report) {
     int nMini = 0, nUpdates = 0;
     Timer t;
     for (int ep = 0; ep < config.ppo.epochs; ep++) {
-        // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126): logical rows are agent-major (trajectory after trajectory);
-        // the device buffers are time-major
-        rlgpu_shuffler_next_rows(m.shuf, m.T, m.nAgents, m.phys.data());
-        HOST_HIP(hipMemcpyAsync(m.idx, m.phys.data(), (size_t)m.B * 4, hipMemcpyHostToDevice, nullptr));
-        for (int64_t b = 0; b + m.batch <= m.B; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
+        // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126) over the whole FIFO: logical rows are oldest iteration
+        // first and agent-major inside one (trajectory after trajectory); the device slots are time-major
+        const int64_t cur = rlgpu_expbuf_size(m.fifo);
+        if (rlgpu_expbuf_shuffled_rows(m.fifo, m.shuf, m.phys.data()) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: shuffle failed");
+        HOST_HIP(hipMemcpyAsync(m.idx, m.phys.data(), (size_t)cur * 4, hipMemcpyHostToDevice, nullptr));
+        for (int64_t b = 0; b + m.batch <= cur; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
             m.LrnCheck(rlgpu_zero_grads(m.lrn), "zero_grads");
             for (int64_t k = 0; k < m.batch; k += m.mini) {
-                m.LrnCheck(rlgpu_ppo_minibatch(m.lrn, m.obs, m.acts, m.logp, m.adv, m.tgt, m.idx + b + k, (int)m.mini, (float)m.mini / (float)m.batch, m.metrics), "ppo_minibatch");
+                m.LrnCheck(rlgpu_ppo_minibatch(m.lrn, m.exObs, m.exActs, m.exLogp, m.exAdv, m.exTgt, m.idx + b + k, (int)m.mini, (float)m.mini / (float)m.batch, m.metrics), "ppo_minibatch");
                 nMini++;
             }
             m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)

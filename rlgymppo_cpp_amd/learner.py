@@ -121,6 +121,37 @@ class Shuffler:
             pass
 
 
+class ExperienceFifo:
+    """ExperienceBuffer's FIFO bookkeeping (ExperienceBuffer.cpp:17-68): which device slot holds which iteration, and which of its rows remain."""
+
+    def __init__(self, max_rows, T, n_agents):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        if self.lib.rlgpu_expbuf_create(C.byref(self.h), max_rows, T, n_agents) != 0:
+            raise ValueError("RG FATAL ERROR: ExperienceBuffer: bad size")
+        self.num_slots = self.lib.rlgpu_expbuf_num_slots(self.h)
+
+    def submit(self):
+        slot = C.c_int()
+        assert self.lib.rlgpu_expbuf_submit(self.h, C.byref(slot)) == 0
+        return slot.value
+
+    def size(self):
+        return int(self.lib.rlgpu_expbuf_size(self.h))
+
+    def shuffled_rows(self, shuffler, out):
+        """GetAllBatchesShuffled's permutation of the whole FIFO (ExperienceBuffer.cpp:104-126) as device rows; returns how many."""
+        n = self.size()
+        assert self.lib.rlgpu_expbuf_shuffled_rows(self.h, shuffler.h, out.ctypes.data) == 0
+        return n
+
+    def __del__(self):
+        try:
+            self.lib.rlgpu_expbuf_destroy(self.h)
+        except Exception:
+            pass
+
+
 class Learner:
     def __init__(self, cfg: LearnerConfig, gym_cfg=None, mesh="procedural", rank=0, world_size=1):
         self.cfg = cfg
@@ -157,8 +188,18 @@ class Learner:
         self.metrics = torch.zeros(8, **f)
         self.return_stats = WelfordRunningStat()
         self.shuffler = Shuffler(cfg.randomSeed)
-        self._rows_host = [torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in range(2)]   # double-buffered pinned staging of the shuffle
-        self._rows_dev = torch.empty(self.B, dtype=torch.int32, device=self.dev)
+        # the experience FIFO (ExperienceBuffer.h): `num_slots` iterations stay resident in HBM, the library tracks which rows are alive
+        self.fifo = ExperienceFifo(cfg.expBufferSize, T, N)
+        S = self.fifo.num_slots
+        self.ex_obs = torch.empty((S * self.B, D), **f)
+        self.ex_act = torch.empty(S * self.B, dtype=torch.int32, device=self.dev)
+        self.ex_logp = torch.empty(S * self.B, **f)
+        self.ex_adv = torch.empty(S * self.B, **f)
+        self.ex_tgt = torch.empty(S * self.B, **f)
+        self._pending_slot = None
+        cap = min(cfg.expBufferSize, S * self.B)
+        self._rows_host = [torch.empty(cap, dtype=torch.int32).pin_memory() for _ in range(2)]   # double-buffered pinned staging of the shuffle
+        self._rows_dev = torch.empty(cap, dtype=torch.int32, device=self.dev)
         self._rows_flip = 0
         self._rows_ev = [None, None]
         self._next_rows = None
@@ -208,25 +249,30 @@ class Learner:
         self.report["Avg Return"] = float(ret.abs().mean().item()) / ret_std
         self.report["Avg Advantage"] = float(adv.abs().mean().item())
         self.report["Avg Val Target"] = float(tgt.abs().mean().item())
+        # ExperienceBuffer::SubmitExperience (Learner.cpp:694-702): this iteration's rows join the FIFO
+        slot = self._pending_slot if self._pending_slot is not None else self.fifo.submit()
+        self._pending_slot = None
+        r = slice(slot * self.B, (slot + 1) * self.B)
+        self.ex_obs[r].copy_(flat_obs[:self.B]); self.ex_act[r].copy_(self.act_buf.view(-1)); self.ex_logp[r].copy_(self.logp_buf.view(-1))
+        self.ex_adv[r].copy_(adv.view(-1)); self.ex_tgt[r].copy_(tgt.view(-1))
 
     # ---- PPOLearner::Learn (PPOLearner.cpp:67-349) ----------------------------------------------------------------
     def learn(self):
-        T, N, B = self.T, self.n_agents, self.B
         p = self.cfg.ppo
-        obs = self.obs_buf.view((T + 1) * N, self.obs_size)
-        acts = self.act_buf.view(-1); logp = self.logp_buf.view(-1); adv = self.adv.view(-1); tgt = self.tgt.view(-1)
+        obs, acts, logp, adv, tgt = self.ex_obs, self.ex_act, self.ex_logp, self.ex_adv, self.ex_tgt
         self.metrics.zero_()
         n_mb = 0; n_updates = 0
-        for _ in range(p.epochs):
-            # shuffled logical (agent-major) indices (ExperienceBuffer.cpp:106-121) as time-major buffer rows.  The draw does not
-            # depend on data, so the NEXT one is made right after this epoch's launches, while the GPU is busy with them.
+        for ep in range(p.epochs):
+            # shuffled logical (oldest first, agent-major) FIFO indices (ExperienceBuffer.cpp:106-121) as device rows.  The draw does
+            # not depend on data, so the NEXT one is made right after this epoch's launches, while the GPU is busy with them.
             if self._next_rows is None:
-                self._next_rows = self.shuffler.next_rows(T, N, self._rows_host[self._rows_flip].numpy())
+                self._next_rows = self.fifo.shuffled_rows(self.shuffler, self._rows_host[self._rows_flip].numpy())
+            cur = self._next_rows
             self._next_rows = None
             idx = self._rows_dev
-            idx.copy_(self._rows_host[self._rows_flip], non_blocking=True)
+            idx[:cur].copy_(self._rows_host[self._rows_flip][:cur], non_blocking=True)
             self._rows_ev[self._rows_flip] = torch.cuda.Event(); self._rows_ev[self._rows_flip].record()
-            for b in range(B // self.batch_size):              # remainder rows are skipped (Q5)
+            for b in range(cur // self.batch_size):            # remainder rows are skipped (Q5)
                 self.ppo.zero_grads()
                 base = b * self.batch_size
                 for m in range(0, self.batch_size, self.mini):
@@ -238,7 +284,10 @@ class Learner:
             self._rows_flip ^= 1
             if self._rows_ev[self._rows_flip] is not None:
                 self._rows_ev[self._rows_flip].synchronize()   # its last upload has left the pinned buffer
-            self._next_rows = self.shuffler.next_rows(T, N, self._rows_host[self._rows_flip].numpy())   # prefetch (CPU) under the GPU work
+            if ep == p.epochs - 1:
+                # the next draw is over the FIFO as it will be after the next submit; the bookkeeping is data-free, so do it now
+                self._pending_slot = self.fifo.submit()
+            self._next_rows = self.fifo.shuffled_rows(self.shuffler, self._rows_host[self._rows_flip].numpy())   # prefetch (CPU) under the GPU work
         self.total_epochs += p.epochs
         self.cumulative_model_updates += n_updates
         self._n_mb = n_mb

@@ -434,3 +434,40 @@ def test_gemm_shapes_against_numpy():
     v, _ = R.mlp_forward(core.get_params(1), cshapes, x)
     assert np.abs(core.value(torch.from_numpy(x).to(dev)).cpu().numpy() - v[:, 0]).max() < 1e-4
     assert core.num_params(0) == 177754 and core.num_params(1) == 154881   # verified parameter counts
+
+
+@pytest.mark.gpu
+def test_experience_fifo_keeps_older_iterations_resident():
+    """Learner with expBufferSize = 2.5 iterations (ExperienceBuffer.cpp:17-68): every live iteration's rows sit bit-exact in their
+    device slot, the FIFO size follows min(max, k*B), and each epoch makes curSize // batchSize optimizer steps."""
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    n_envs, T = 32, 8
+    B = n_envs * 2 * T
+    cap = B * 5 // 2
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=1, timestepsPerIteration=B, expBufferSize=cap, randomSeed=5,
+                        ppo=PPOLearnerConfig(batchSize=B // 2, miniBatchSize=B // 4, epochs=2, autocastLearn=False))
+    L = Learner(cfg)
+    assert L.fifo.num_slots == 4
+    kept = {}
+    for it in range(5):
+        before = L.cumulative_model_updates
+        L.collect()
+        L.add_new_experience()
+        cur = L.fifo.size()
+        assert cur == min(cap, (it + 1) * B)
+        snap = (L.obs_buf[:T].reshape(B, -1).clone(), L.act_buf.view(-1).clone(), L.logp_buf.view(-1).clone(), L.adv.view(-1).clone(), L.tgt.view(-1).clone())
+        # which slot did it go to: the one whose contents now equal this iteration's rows
+        hits = [s for s in range(L.fifo.num_slots) if torch.equal(L.ex_obs[s * B:(s + 1) * B], snap[0])]
+        assert len(hits) == 1
+        kept = {k: v for k, v in kept.items() if v[0] != hits[0]}
+        kept[it] = (hits[0], snap)
+        L.learn()
+        assert L.cumulative_model_updates - before == 2 * (cur // (B // 2))
+        # older iterations that are still (partly) alive were not disturbed by this one
+        for k, (s, sn) in kept.items():
+            if k > it - 3:
+                r = slice(s * B, (s + 1) * B)
+                assert torch.equal(L.ex_obs[r], sn[0]) and torch.equal(L.ex_act[r], sn[1]) and torch.equal(L.ex_logp[r], sn[2])
+                assert torch.equal(L.ex_adv[r], sn[3]) and torch.equal(L.ex_tgt[r], sn[4])
+    rep = L.finish_report()
+    assert np.isfinite(rep["Policy Entropy"]) and np.isfinite(rep["Value Function Loss"])

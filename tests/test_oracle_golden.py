@@ -93,6 +93,37 @@ def test_library_shuffler_matches_oracle_and_row_mapping(lg):
         assert (c.next_rows(T, N) == ((p % T) * N + p // T)).all()
 
 
+@pytest.mark.parametrize("max_rows", [60, 100, 150, 37, 400])
+def test_experience_fifo_matches_reference_buffer(max_rows):
+    """rlgpu_expbuf_* (slot bookkeeping, no data movement) against the oracle's literal ExperienceBuffer: the same rows stay alive in
+    the same logical order, and the shuffled batches name the same rows.  Sizes cover: buffer smaller than one iteration (keeps the
+    last rows), partial eviction of the oldest iteration, whole multiples, and a buffer that never fills."""
+    from rlgymppo_cpp_amd.learner import ExperienceFifo, Shuffler
+    T, N = 5, 12
+    B = T * N
+    fifo, shuf = ExperienceFifo(max_rows, T, N), Shuffler(99)
+    ref = R.ExperienceBufferRef(max_rows, 99)
+    slot_of = {}
+    for it in range(7):
+        slot = fifo.submit()
+        assert 0 <= slot < fifo.num_slots
+        slot_of = {k: v for k, v in slot_of.items() if v != slot}   # a reused slot's old iteration must be gone from the FIFO (checked below)
+        slot_of[it] = slot
+        # the reference's logical order inside one submit: trajectory after trajectory (agent-major); identity = it * B + a
+        ref.submit(it * B + np.arange(B))
+        assert fifo.size() == len(ref.data) == min(max_rows, (it + 1) * B)
+        rows = np.empty(fifo.size(), np.int32)
+        for batch_size in (16, 25):
+            n = fifo.shuffled_rows(shuf, rows)
+            want = ref.all_batches_shuffled(batch_size)
+            for b, w in enumerate(want):
+                k, a = w // B, w % B
+                assert all(int(i) in slot_of for i in k)
+                phys = np.array([slot_of[int(i)] for i in k]) * B + (a % T) * N + a // T   # device row: slot, time-major inside
+                assert (rows[b * batch_size:(b + 1) * batch_size] == phys).all()
+            assert len(want) == n // batch_size
+
+
 def test_welford():
     w = R.Welford()
     xs = np.random.RandomState(0).randn(300) * 3 + 1
