@@ -190,6 +190,17 @@ int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out);   /* account for one mo
 int64_t rlgpu_expbuf_size(const rlgpu_expbuf* b);          /* curSize */
 int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows_out /* [curSize] */);
 
+/* ---- checkpoint payloads (PRIV/PPO/PPOLearner.cpp:362-477): the TorchScript zip archives that torch::save(nn::Sequential)
+ *      (PPO_POLICY.lt, PPO_CRITIC.lt) and optim::Adam::save (PPO_*_OPTIM.lt) write, read and written without libtorch, so
+ *      checkpoints interchange with the reference.  Host-only.  dims[n_linear + 1] = {inputs, hidden..., outputs}; params and
+ *      the Adam moments are flat in state-dict order (0.weight [out][in], 0.bias, 2.weight, ...).  Reading fails (RLGPU_ERR_ARG,
+ *      text from rlgpu_lt_last_error) when the archive's shapes differ from dims ("Saved model has different size", :380-408). ---- */
+int rlgpu_lt_write_model(const char* path, const int32_t* dims, int n_linear, const float* params);
+int rlgpu_lt_read_model(const char* path, const int32_t* dims, int n_linear, float* params_out);
+int rlgpu_lt_write_adam(const char* path, const int32_t* dims, int n_linear, float lr, const float* exp_avg, const float* exp_avg_sq, int64_t step);
+int rlgpu_lt_read_adam(const char* path, const int32_t* dims, int n_linear, float* exp_avg, float* exp_avg_sq, int64_t* step);
+const char* rlgpu_lt_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,11 @@ SIGNATURES = {
     "rlgpu_expbuf_submit": (_i, [_vp, C.POINTER(C.c_int)]),
     "rlgpu_expbuf_size": (C.c_int64, [_vp]),
     "rlgpu_expbuf_shuffled_rows": (_i, [_vp, _vp, _vp]),
+    "rlgpu_lt_write_model": (_i, [C.c_char_p, _vp, C.c_int, _vp]),
+    "rlgpu_lt_read_model": (_i, [C.c_char_p, _vp, C.c_int, _vp]),
+    "rlgpu_lt_write_adam": (_i, [C.c_char_p, _vp, C.c_int, C.c_float, _vp, _vp, C.c_int64]),
+    "rlgpu_lt_read_adam": (_i, [C.c_char_p, _vp, C.c_int, _vp, _vp, C.POINTER(C.c_int64)]),
+    "rlgpu_lt_last_error": (C.c_char_p, []),
 }
 
 _lib = None

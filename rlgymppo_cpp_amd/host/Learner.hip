@@ -5,7 +5,7 @@
 //   Learner::AddNewExperience   PUB/Learner.cpp:608-703
 //   PPOLearner::Learn           PRIV/PPO/PPOLearner.cpp:67-349
 //   Learner::Save / Load        PUB/Learner.cpp:171-376, PRIV/PPO/PPOLearner.cpp:362-502   (same folder layout and file names;
-//                                .lt payload = this repo's RLGPU_LT1 container, shared with rlgymppo_cpp_amd/learner.py)
+//                                .lt payloads = the reference's TorchScript zip archives, through rlgpu_lt_* of librlgpu.so)
 // Everything on the data path stays in device memory; this file only sequences launches.  Compiled by hipcc because of the
 // three small bookkeeping kernels below.
 #include <hip/hip_runtime.h>
@@ -52,7 +52,6 @@ __global__ void k_sum(const float* a, size_t n, float* out) {
 }
 
 std::filesystem::path g_mesh_folder;
-const char MAGIC[] = "RLGPU_LT1\n";
 
 template <class T>
 T* dev_alloc(size_t n) { T* p = nullptr; HOST_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
@@ -366,32 +365,9 @@ void Learner::Learn() {
 
 // ---- checkpoints ------------------------------------------------------------------------------------------------------
 namespace {
-std::string LtHeader(const std::vector<std::pair<int, int>>& shapes) {
-    std::ostringstream h;
-    h << "{\"tensors\": [";
-    for (size_t i = 0; i < shapes.size(); i++) h << (i ? ", " : "") << "{\"name\": \"" << 2 * i << ".weight\", \"shape\": [" << shapes[i].first << ", " << shapes[i].second << "]}";
-    h << "], \"dtype\": \"<f4\", \"order\": \"0.weight,0.bias,2.weight,...\"}";
-    return h.str();
-}
-void WriteLt(const std::filesystem::path& p, const std::vector<float>& flat, const std::vector<std::pair<int, int>>& shapes) {
-    std::ofstream f(p, std::ios::binary);
-    std::string hdr = LtHeader(shapes); uint64_t n = hdr.size();
-    f.write(MAGIC, sizeof(MAGIC) - 1); f.write((const char*)&n, 8); f.write(hdr.data(), (std::streamsize)n); f.write((const char*)flat.data(), (std::streamsize)flat.size() * 4);
-}
-std::vector<float> ReadLt(const std::filesystem::path& p, size_t want, const std::vector<std::pair<int, int>>& shapes) {
-    std::ifstream f(p, std::ios::binary);
-    char mg[sizeof(MAGIC) - 1];
-    if (!f.read(mg, sizeof(mg)) || memcmp(mg, MAGIC, sizeof(mg)) != 0) RG_ERR_CLOSE(p.string() << " is not a v1 .lt payload (TorchScript .lt import is not implemented yet)");
-    uint64_t n = 0; f.read((char*)&n, 8);
-    std::string hdr(n, '\0'); f.read(hdr.data(), (std::streamsize)n);
-    // shape check of every parameter (PPOLearner.cpp:380-408): the header lists the weight shapes in order
-    std::string want_shapes; for (auto& s : shapes) want_shapes += "[" + std::to_string(s.first) + ", " + std::to_string(s.second) + "]";
-    std::string got_shapes; for (size_t i = 0; (i = hdr.find("\"shape\": ", i)) != std::string::npos; i += 9) got_shapes += hdr.substr(i + 9, hdr.find(']', i) - (i + 9) + 1);
-    std::vector<float> flat(want);
-    f.read((char*)flat.data(), (std::streamsize)want * 4);
-    if (got_shapes != want_shapes || (size_t)f.gcount() != want * 4 || f.peek() != EOF) RG_ERR_CLOSE("saved model has different size than the current model (" << p.string() << ")");
-    return flat;
-}
+// {inputs, hidden..., outputs} of one network, as rlgpu_lt_* wants it
+std::vector<int32_t> DimsOf(int in, const IList& hidden, int out) { std::vector<int32_t> d{in}; for (int h : hidden) d.push_back(h); d.push_back(out); return d; }
+void LtCheck(int rc, const char* what, const std::filesystem::path& p) { if (rc != RLGPU_OK) RG_ERR_CLOSE(what << " " << p.string() << ": " << rlgpu_lt_last_error()); }
 }  // namespace
 
 void Learner::SaveStats(std::filesystem::path path) {
@@ -423,19 +399,18 @@ void Learner::Save() {
     std::filesystem::path folder = config.checkpointSaveFolder / std::to_string(totalTimesteps);
     std::filesystem::create_directories(folder);
     SaveStats(folder / "RUNNING_STATS.json");
-    auto shapesOf = [&](const IList& hidden, int out) { std::vector<std::pair<int, int>> s; int in = m.D; for (int h : hidden) { s.push_back({h, in}); in = h; } s.push_back({out, in}); return s; };
+    const std::vector<int32_t> dPol = DimsOf(m.D, config.ppo.policyLayerSizes, m.A), dCri = DimsOf(m.D, config.ppo.criticLayerSizes, 1);
     const int64_t nPol = rlgpu_learner_num_params(m.lrn, 0), nCri = rlgpu_learner_num_params(m.lrn, 1);
     std::vector<float> pol(nPol), cri(nCri), am(nPol + nCri), av(nPol + nCri); int64_t sp = 0, sc = 0;
     m.LrnCheck(rlgpu_learner_get_params(m.lrn, 0, pol.data()), "get_params"); m.LrnCheck(rlgpu_learner_get_params(m.lrn, 1, cri.data()), "get_params");
     m.LrnCheck(rlgpu_learner_get_adam_state(m.lrn, am.data(), av.data(), &sp, &sc), "get_adam_state");
-    WriteLt(folder / "PPO_POLICY.lt", pol, shapesOf(config.ppo.policyLayerSizes, m.A));
-    WriteLt(folder / "PPO_CRITIC.lt", cri, shapesOf(config.ppo.criticLayerSizes, 1));
-    auto writeOptim = [&](const char* name, const float* mm, const float* vv, int64_t n, int64_t step) {
-        std::ofstream f(folder / name, std::ios::binary);
-        f.write(MAGIC, sizeof(MAGIC) - 1); f.write((const char*)&step, 8); f.write((const char*)&n, 8); f.write((const char*)mm, n * 4); f.write((const char*)vv, n * 4);
-    };
-    writeOptim("PPO_POLICY_OPTIM.lt", am.data(), av.data(), nPol, sp);
-    writeOptim("PPO_CRITIC_OPTIM.lt", am.data() + nPol, av.data() + nPol, nCri, sc);
+    // the reference's own payloads: torch::save(Sequential) and Adam::save archives (PPOLearner.cpp:408-411,466-472)
+    LtCheck(rlgpu_lt_write_model((folder / "PPO_POLICY.lt").string().c_str(), dPol.data(), (int)dPol.size() - 1, pol.data()), "failed to save model to", folder / "PPO_POLICY.lt");
+    LtCheck(rlgpu_lt_write_model((folder / "PPO_CRITIC.lt").string().c_str(), dCri.data(), (int)dCri.size() - 1, cri.data()), "failed to save model to", folder / "PPO_CRITIC.lt");
+    LtCheck(rlgpu_lt_write_adam((folder / "PPO_POLICY_OPTIM.lt").string().c_str(), dPol.data(), (int)dPol.size() - 1, config.ppo.policyLR, am.data(), av.data(), sp),
+            "failed to save optimizer to", folder / "PPO_POLICY_OPTIM.lt");
+    LtCheck(rlgpu_lt_write_adam((folder / "PPO_CRITIC_OPTIM.lt").string().c_str(), dCri.data(), (int)dCri.size() - 1, config.ppo.criticLR, am.data() + nPol, av.data() + nPol, sc),
+            "failed to save optimizer to", folder / "PPO_CRITIC_OPTIM.lt");
     m.tsSinceSave = 0;
     if (config.checkpointsToKeep > 0) {   // prune the lowest-numbered folders (Learner.cpp:256-280)
         std::vector<uint64_t> nums;
@@ -460,25 +435,25 @@ void Learner::Load() {
     if (!any) return;
     std::filesystem::path folder = config.checkpointLoadFolder / std::to_string(best);
     LoadStats(folder / "RUNNING_STATS.json");
-    auto shapesOf = [&](const IList& hidden, int out) { std::vector<std::pair<int, int>> s; int in = m.D; for (int h : hidden) { s.push_back({h, in}); in = h; } s.push_back({out, in}); return s; };
+    const std::vector<int32_t> dPol = DimsOf(m.D, config.ppo.policyLayerSizes, m.A), dCri = DimsOf(m.D, config.ppo.criticLayerSizes, 1);
     const int64_t nPol = rlgpu_learner_num_params(m.lrn, 0), nCri = rlgpu_learner_num_params(m.lrn, 1);
-    std::vector<float> pol = ReadLt(folder / "PPO_POLICY.lt", nPol, shapesOf(config.ppo.policyLayerSizes, m.A));
-    std::vector<float> cri = ReadLt(folder / "PPO_CRITIC.lt", nCri, shapesOf(config.ppo.criticLayerSizes, 1));
-    m.LrnCheck(rlgpu_learner_set_params(m.lrn, 0, pol.data()), "set_params"); m.LrnCheck(rlgpu_learner_set_params(m.lrn, 1, cri.data()), "set_params");
+    if (!std::filesystem::exists(folder / "PPO_POLICY.lt")) RG_ERR_CLOSE("PPOLearner: Failed to find file \"PPO_POLICY.lt\" in " << folder.string() << ".");   // PPOLearner.cpp:414-417
+    std::vector<float> pol(nPol), cri(nCri);
+    LtCheck(rlgpu_lt_read_model((folder / "PPO_POLICY.lt").string().c_str(), dPol.data(), (int)dPol.size() - 1, pol.data()), "Failed to load model from", folder / "PPO_POLICY.lt");
+    m.LrnCheck(rlgpu_learner_set_params(m.lrn, 0, pol.data()), "set_params");
+    if (std::filesystem::exists(folder / "PPO_CRITIC.lt")) {   // the critic file is optional (PPOLearner.cpp:421-422)
+        LtCheck(rlgpu_lt_read_model((folder / "PPO_CRITIC.lt").string().c_str(), dCri.data(), (int)dCri.size() - 1, cri.data()), "Failed to load model from", folder / "PPO_CRITIC.lt");
+        m.LrnCheck(rlgpu_learner_set_params(m.lrn, 1, cri.data()), "set_params");
+    }
     std::vector<float> am(nPol + nCri, 0.f), av(nPol + nCri, 0.f); int64_t sp = 0, sc = 0;
-    auto readOptim = [&](const char* name, float* mm, float* vv, int64_t n, int64_t& step) {   // missing / foreign optimizer file -> fresh Adam state (PPOLearner.cpp:442-451)
-        std::ifstream f(folder / name, std::ios::binary);
-        char mg[sizeof(MAGIC) - 1]; int64_t st = 0, cnt = 0;
-        if (!f || !f.read(mg, sizeof(mg)) || memcmp(mg, MAGIC, sizeof(mg)) != 0) return;
-        f.read((char*)&st, 8); f.read((char*)&cnt, 8);
-        if (cnt != n) return;
-        std::vector<float> a(n), b(n);
-        f.read((char*)a.data(), n * 4); f.read((char*)b.data(), n * 4);
-        if (!f) return;
-        std::copy(a.begin(), a.end(), mm); std::copy(b.begin(), b.end(), vv); step = st;
+    auto readOptim = [&](const char* name, const std::vector<int32_t>& d, float* mm, float* vv, int64_t& step) {
+        std::filesystem::path p = folder / name;
+        if (!std::filesystem::exists(p)) { RG_LOG("WARNING: No optimizer found at " << p.string() << ", optimizer will be reset"); return; }   // PPOLearner.cpp:436-441
+        if (std::filesystem::file_size(p) == 0) { RG_LOG("WARNING: Saved optimizer is empty, optimizer will be reset"); return; }               // :443-449
+        LtCheck(rlgpu_lt_read_adam(p.string().c_str(), d.data(), (int)d.size() - 1, mm, vv, &step), "Failed to load optimizers from", p);       // :460-465
     };
-    readOptim("PPO_POLICY_OPTIM.lt", am.data(), av.data(), nPol, sp);
-    readOptim("PPO_CRITIC_OPTIM.lt", am.data() + nPol, av.data() + nPol, nCri, sc);
+    readOptim("PPO_POLICY_OPTIM.lt", dPol, am.data(), av.data(), sp);
+    readOptim("PPO_CRITIC_OPTIM.lt", dCri, am.data() + nPol, av.data() + nPol, sc);
     m.LrnCheck(rlgpu_learner_set_adam_state(m.lrn, am.data(), av.data(), sp, sc), "set_adam_state");
     UpdateLearningRates(config.ppo.policyLR, config.ppo.criticLR);   // Learner.cpp:501
     RG_LOG("Learner: loaded checkpoint " << folder.string() << " (" << totalTimesteps << " timesteps)");

@@ -339,8 +339,8 @@ class Learner:
         npol = self.ppo.num_params(0)
         _write_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.get_params(0), self.ppo.layer_shapes(0))
         _write_lt(os.path.join(folder, "PPO_CRITIC.lt"), self.ppo.get_params(1), self.ppo.layer_shapes(1))
-        _write_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), m[:npol], v[:npol], sp)
-        _write_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), m[npol:], v[npol:], sc)
+        _write_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), m[:npol], v[:npol], sp, self.ppo.layer_shapes(0), self.cfg.ppo.policyLR)
+        _write_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), m[npol:], v[npol:], sc, self.ppo.layer_shapes(1), self.cfg.ppo.criticLR)
         self.ts_since_save = 0
         if self.cfg.checkpointsToKeep > 0:   # prune the lowest-numbered folders (Learner.cpp:256-280)
             base = self.cfg.checkpointSaveFolder
@@ -363,12 +363,13 @@ class Learner:
         self.total_timesteps = int(stats["cumulative_timesteps"]); self.cumulative_model_updates = int(stats["cumulative_model_updates"])
         self.total_epochs = int(stats["epoch"]); self.return_stats.from_json(stats["reward_running_stats"])
         pol = _read_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.layer_shapes(0))     # size check of every param (PPOLearner.cpp:380-408)
-        cri = _read_lt(os.path.join(folder, "PPO_CRITIC.lt"), self.ppo.layer_shapes(1))
-        self.ppo.set_params(pol, 0); self.ppo.set_params(cri, 1)
+        self.ppo.set_params(pol, 0)
+        if os.path.exists(os.path.join(folder, "PPO_CRITIC.lt")):                            # the critic file is optional (PPOLearner.cpp:421-422)
+            self.ppo.set_params(_read_lt(os.path.join(folder, "PPO_CRITIC.lt"), self.ppo.layer_shapes(1)), 1)
         n = self.ppo.num_params(2); npol = self.ppo.num_params(0)
         m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); sp = sc = 0
-        po = _read_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), npol)
-        co = _read_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), n - npol)
+        po = _read_optim(os.path.join(folder, "PPO_POLICY_OPTIM.lt"), self.ppo.layer_shapes(0))
+        co = _read_optim(os.path.join(folder, "PPO_CRITIC_OPTIM.lt"), self.ppo.layer_shapes(1))
         if po is not None: m[:npol], v[:npol], sp = po          # missing/empty optimizer file -> reset (PPOLearner.cpp:442-451)
         if co is not None: m[npol:], v[npol:], sc = co
         self.ppo.set_adam_state(m, v, sp, sc)
@@ -376,48 +377,44 @@ class Learner:
         return True
 
 
-# ---- .lt payload, format v1 (own container behind the reference's file names; TorchScript-zip compatibility = SURVEY F1) ----
-_MAGIC = b"RLGPU_LT1\n"
+# ---- .lt payloads: the reference's own TorchScript zip archives (PPOLearner.cpp:362-477), through rlgpu_lt_* (csrc/lt_archive.cpp) ----
+def _dims(shapes):
+    return np.array([shapes[0][0][1]] + [ws[0] for ws, _ in shapes], np.int32)
+
+
+def _lt_fail(lib, what, path):
+    raise RuntimeError(f"RG FATAL ERROR: {what} {path}: {lib.rlgpu_lt_last_error().decode()}")
 
 
 def _write_lt(path, flat, shapes):
-    with open(path, "wb") as f:
-        f.write(_MAGIC)
-        hdr = json.dumps({"tensors": [{"name": f"{2 * i}.weight", "shape": list(ws)} for i, (ws, bs) in enumerate(shapes)], "dtype": "<f4",
-                          "order": "0.weight,0.bias,2.weight,..."}).encode()
-        f.write(len(hdr).to_bytes(8, "little")); f.write(hdr)
-        f.write(np.ascontiguousarray(flat, "<f4").tobytes())
+    lib, d, a = _lib.load(), _dims(shapes), np.ascontiguousarray(flat, np.float32)
+    if lib.rlgpu_lt_write_model(path.encode(), d.ctypes.data, len(shapes), a.ctypes.data) != 0:
+        _lt_fail(lib, "failed to save model to", path)
 
 
 def _read_lt(path, shapes):
-    want = sum(ws[0] * ws[1] + bs[0] for ws, bs in shapes)
-    with open(path, "rb") as f:
-        if f.read(len(_MAGIC)) != _MAGIC:
-            raise RuntimeError(f"RG FATAL ERROR: {path} is not a v1 .lt payload (TorchScript .lt import is not implemented yet)")
-        n = int.from_bytes(f.read(8), "little"); hdr = json.loads(f.read(n))
-        got = [tuple(t["shape"]) for t in hdr["tensors"]]
-        if got != [tuple(ws) for ws, _ in shapes]:
-            raise RuntimeError(f"RG FATAL ERROR: saved model has different size than the current model: {got}")
-        flat = np.frombuffer(f.read(), "<f4")
-    if flat.size != want:
-        raise RuntimeError("RG FATAL ERROR: saved model has different size than the current model")
-    return flat.astype(np.float32)
+    """torch::load + the size check of every parameter (PPOLearner.cpp:372-408)."""
+    lib, d = _lib.load(), _dims(shapes)
+    out = np.empty(sum(ws[0] * ws[1] + bs[0] for ws, bs in shapes), np.float32)
+    if lib.rlgpu_lt_read_model(path.encode(), d.ctypes.data, len(shapes), out.ctypes.data) != 0:
+        _lt_fail(lib, "failed to load model from", path)
+    return out
 
 
-def _write_optim(path, m, v, step):
-    with open(path, "wb") as f:
-        f.write(_MAGIC); f.write(int(step).to_bytes(8, "little")); f.write(int(m.size).to_bytes(8, "little"))
-        f.write(np.ascontiguousarray(m, "<f4").tobytes()); f.write(np.ascontiguousarray(v, "<f4").tobytes())
+def _write_optim(path, m, v, step, shapes, lr):
+    lib, d = _lib.load(), _dims(shapes)
+    m = np.ascontiguousarray(m, np.float32); v = np.ascontiguousarray(v, np.float32)
+    if lib.rlgpu_lt_write_adam(path.encode(), d.ctypes.data, len(shapes), lr, m.ctypes.data, v.ctypes.data, int(step)) != 0:
+        _lt_fail(lib, "failed to save optimizer to", path)
 
 
-def _read_optim(path, n):
+def _read_optim(path, shapes):
+    """None when the file is missing or empty: the optimizer is reset (PPOLearner.cpp:436-451)."""
     if not os.path.exists(path) or os.path.getsize(path) == 0:
         return None
-    with open(path, "rb") as f:
-        if f.read(len(_MAGIC)) != _MAGIC:
-            return None
-        step = int.from_bytes(f.read(8), "little"); cnt = int.from_bytes(f.read(8), "little")
-        if cnt != n:
-            return None
-        m = np.frombuffer(f.read(4 * n), "<f4").astype(np.float32); v = np.frombuffer(f.read(4 * n), "<f4").astype(np.float32)
-    return m, v, step
+    lib, d = _lib.load(), _dims(shapes)
+    n = sum(ws[0] * ws[1] + bs[0] for ws, bs in shapes)
+    m = np.empty(n, np.float32); v = np.empty(n, np.float32); step = C.c_int64()
+    if lib.rlgpu_lt_read_adam(path.encode(), d.ctypes.data, len(shapes), m.ctypes.data, v.ctypes.data, C.byref(step)) != 0:
+        _lt_fail(lib, "failed to load optimizer from", path)                                # :460-465
+    return m, v, step.value

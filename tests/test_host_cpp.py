@@ -44,6 +44,11 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     assert saved and saved[-1] == 2 * 4096, saved
     for f in ("RUNNING_STATS.json", "PPO_POLICY.lt", "PPO_CRITIC.lt", "PPO_POLICY_OPTIM.lt", "PPO_CRITIC_OPTIM.lt"):
         assert os.path.getsize(os.path.join(ck, str(saved[-1]), f)) > 0
+    # the payloads are the reference's own TorchScript archives (PPOLearner.cpp:408-411): torch reads them
+    import torch
+    pol = torch.jit.load(os.path.join(ck, str(saved[-1]), "PPO_POLICY.lt"))
+    assert [tuple(p.shape) for _, p in pol.named_parameters()] == [(256, 89), (256,), (256, 256), (256,), (256, 256), (256,), (90, 256), (90,)]
+    assert [k for k, _ in pol.named_parameters()][-1] == "6.bias"
     # the Python host reads the C++ host's checkpoint (same layout and payload)
     sys.path.insert(0, ROOT)
     from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
