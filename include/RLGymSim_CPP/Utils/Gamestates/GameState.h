@@ -34,5 +34,6 @@ struct GameState {
     // materialise from one downloaded env (rlgymppo_cpp_amd/host/Host.cpp)
     explicit GameState(const RlgpuArenaState& s, int tickSkip);
     const PhysObj& GetBallPhys(bool inverted) const { return inverted ? ballInv : ball; }
+    const bool* GetBoostPads(bool inverted) const { return inverted ? boostPadsInv : boostPads; }
 };
 }

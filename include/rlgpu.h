@@ -160,6 +160,7 @@ int rlgpu_zero_grads(rlgpu_learner* l);
  * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
 int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale);
 int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
+int rlgpu_learner_set_temperature(rlgpu_learner* l, float temperature);   /* DiscretePolicy::temperature, set per call by InferUnit (InferUnit.cpp:68,95) */
 int rlgpu_learner_sync(rlgpu_learner* l);
 /* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops);

@@ -1123,6 +1123,7 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     return RLGPU_OK;
 }
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }
+int rlgpu_learner_set_temperature(rlgpu_learner* l, float t) { if (!(t > 0)) return RLGPU_ERR_ARG; l->cfg.temperature = t; return RLGPU_OK; }
 int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {
     if (!l->timed) return RLGPU_ERR_STATE;

@@ -76,7 +76,10 @@ GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
     lastTickCount = (uint64_t)s.tick_count; deltaTickCount = tickSkip;
     ball.pos = V(s.ball.pos); ball.vel = V(s.ball.vel); ball.angVel = V(s.ball.ang_vel);
     ballInv = ball.Invert();
-    for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[p].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
+    // RLGym pad order -> RocketSim pad index: the map GameState.cpp:10-50 builds by matching CommonValues::BOOST_LOCATIONS against
+    // the arena's pads (a constant of the two tables; the device obs builder uses the same one)
+    static const int8_t PAD_ORDER[RLGPU_NUM_PADS] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
+    for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[PAD_ORDER[p]].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
     players.resize(s.num_cars);
     for (int k = 0; k < s.num_cars; k++) {
         const RlgpuCarState& c = s.cars[k]; const RlgpuPlayerGymState& g = s.gym.players[k];
@@ -98,7 +101,7 @@ GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
         pd.ballTouchedStep = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit >= s.tick_count - tickSkip;
         pd.ballTouchedTick = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit == s.tick_count - 1;
         pd.hasJump = !cs.hasJumped;
-        pd.hasFlip = !cs.isOnGround && !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;
+        pd.hasFlip = !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;   // RLConst::DOUBLEJUMP_MAX_DELAY
     }
 }
 }  // namespace RLGSC

@@ -1,0 +1,138 @@
+// GPU check of the deployment path:
+//  1. the host OBS builders (DefaultOBS / DefaultOBSPadded::BuildOBS on a GameState materialised from the device state) give
+//     bit-for-bit the rows the device builder wrote for the same step (tickSkip 1, so the observed snapshot IS the final state);
+//  2. InferUnit loads a PPO_POLICY.lt / PPO_CRITIC.lt archive and infers on those states; obs rows, distributions, deterministic
+//     actions and values go to a file the Python test compares with the numpy oracle.
+// usage: infer_unit_check <policy.lt> <critic.lt> <out.bin>
+#include <hip/hip_runtime.h>
+#include <RLGymPPO_CPP/Util/InferUnit.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
+#include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
+#include "../../include/rlgpu_state.h"
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+using namespace RLGSC; using namespace RLGPC;
+
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+#define HIPOK(call) CHECK((call) == hipSuccess)
+
+static int obs_parity(int teamSize, int nEnvs, int steps, std::vector<GameState>* keepStates, std::vector<ActionSet>* keepPrev) {
+    RlgpuGymConfig g; rlgpu_default_gym_config(&g);
+    g.tick_skip = 1; g.seed_lo = 77 + teamSize; g.no_touch_max_steps = 40;
+    rlgpu_env* env = nullptr;
+    CHECK(rlgpu_env_create(&env, 0, nEnvs, teamSize, &g) == RLGPU_OK);
+    CHECK(rlgpu_env_set_procedural_mesh(env) == RLGPU_OK);
+    const int nAgents = rlgpu_env_num_agents(env), D = rlgpu_env_obs_size(env), P = 2 * teamSize;
+    float *obs = nullptr, *rew = nullptr; int32_t *acts = nullptr, *done = nullptr;
+    HIPOK(hipMalloc(&obs, (size_t)nAgents * D * 4)); HIPOK(hipMalloc(&rew, nAgents * 4)); HIPOK(hipMalloc(&acts, nAgents * 4)); HIPOK(hipMalloc(&done, nAgents * 4));
+    CHECK(rlgpu_env_reset(env, 1, obs) == RLGPU_OK);
+    DefaultOBS builder; DiscreteAction parser;
+    std::vector<int32_t> hostActs(nAgents), hostDone(nAgents);
+    std::vector<float> hostObs((size_t)nAgents * D);
+    std::vector<RlgpuArenaState> states(nEnvs);
+    uint32_t rng = 12345;
+    int compared = 0, resets = 0;
+    for (int s = 0; s < steps; s++) {
+        for (int& a : hostActs) { rng = rng * 1664525u + 1013904223u; a = (int)((rng >> 8) % 90u); }
+        HIPOK(hipMemcpy(acts, hostActs.data(), nAgents * 4, hipMemcpyHostToDevice));
+        CHECK(rlgpu_env_step(env, acts, obs, rew, done) == RLGPU_OK);
+        CHECK(rlgpu_env_sync(env) == RLGPU_OK);
+        HIPOK(hipMemcpy(hostObs.data(), obs, hostObs.size() * 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(hostDone.data(), done, nAgents * 4, hipMemcpyDeviceToHost));
+        CHECK(rlgpu_env_download_states(env, states.data(), nullptr, nEnvs) == RLGPU_OK);
+        for (int e = 0; e < nEnvs; e++) {
+            GameState gs(states[e], 1);
+            CHECK((int)gs.players.size() == P);
+            IList idx(hostActs.begin() + e * P, hostActs.begin() + (e + 1) * P);
+            ActionSet prev = parser.ParseActions(idx, gs);
+            if (hostDone[e * P]) {   // the recorded row is the first observation of the new episode: previous actions are cleared (Match.cpp:28-30)
+                resets++;
+                for (Action& a : prev) a = Action();
+            }
+            for (int k = 0; k < P; k++) {
+                FList row = builder.BuildOBS(gs.players[k], gs, prev[k]);
+                CHECK((int)row.size() == D);
+                const float* dev = &hostObs[(size_t)(e * P + k) * D];
+                for (int i = 0; i < D; i++)
+                    if (std::memcmp(&row[i], &dev[i], 4) != 0) {
+                        std::printf("obs mismatch: team size %d step %d env %d player %d column %d host %.9g device %.9g\n", teamSize, s, e, k, i, row[i], dev[i]);
+                        return 1;
+                    }
+                compared++;
+            }
+            if (keepStates && e == 0 && (s % 7) == 3) { keepStates->push_back(gs); keepPrev->push_back(prev); }
+        }
+    }
+    std::printf("obs parity: team size %d, %d rows bit-exact (%d episode resets seen)\n", teamSize, compared, resets);
+    CHECK(resets > 0);
+    // the padded builder at maxPlayers == team size only reorders the other players' blocks
+    {
+        DefaultOBSPadded padded(teamSize);
+        GameState gs(states[0], 1);
+        FList a = builder.BuildOBS(gs.players[0], gs, Action()), b = padded.BuildOBS(gs.players[0], gs, Action());
+        CHECK(a.size() == b.size());
+        CHECK(std::memcmp(a.data(), b.data(), 70 * 4) == 0);
+        auto blocks = [&](const FList& r, int from, int n) { std::vector<std::vector<float>> v; for (int i = 0; i < n; i++) v.push_back(std::vector<float>(r.begin() + from + 19 * i, r.begin() + from + 19 * (i + 1))); std::sort(v.begin(), v.end()); return v; };
+        CHECK(blocks(a, 70, teamSize - 1) == blocks(b, 70, teamSize - 1));
+        CHECK(blocks(a, 70 + 19 * (teamSize - 1), teamSize) == blocks(b, 70 + 19 * (teamSize - 1), teamSize));
+        // wider padding adds zero blocks
+        DefaultOBSPadded wide(teamSize + 1);
+        FList w = wide.BuildOBS(gs.players[0], gs, Action());
+        CHECK((int)w.size() == 70 + 19 * (2 * (teamSize + 1) - 1));
+        int zeroBlocks = 0;
+        for (auto& blk : blocks(w, 70, 2 * (teamSize + 1) - 1)) zeroBlocks += std::all_of(blk.begin(), blk.end(), [](float x) { return x == 0; });
+        CHECK(zeroBlocks == 2);
+    }
+    (void)hipFree(obs); (void)hipFree(rew); (void)hipFree(acts); (void)hipFree(done);
+    rlgpu_env_destroy(env);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::vector<GameState> states; std::vector<ActionSet> prevs;
+    if (obs_parity(1, 16, 120, &states, &prevs)) return 1;
+    if (obs_parity(2, 8, 60, nullptr, nullptr)) return 1;
+    if (obs_parity(3, 4, 60, nullptr, nullptr)) return 1;
+    CHECK(states.size() >= 8);
+
+    DefaultOBS obs; DiscreteAction parser;
+    InferUnit policy(&obs, &parser, argv[1], true, 89, {32, 24});
+    InferUnit critic(&obs, &parser, argv[2], false, 89, {16});
+    std::ofstream out(argv[3], std::ios::binary);
+    auto put = [&](const FList& v) { out.write((const char*)v.data(), (std::streamsize)v.size() * 4); };
+    int32_t n = (int32_t)states.size();
+    out.write((const char*)&n, 4);
+    for (size_t i = 0; i < states.size(); i++) {
+        const GameState& gs = states[i];
+        const PlayerData& p = gs.players[i % 2];
+        const Action& prev = prevs[i][i % 2];
+        put(policy.GetObs(p, gs, prev));
+        FList probs = policy.InferPolicySingleDistrib(p, gs, prev);
+        CHECK(probs.size() == 90);
+        put(probs);
+        put(policy.InferPolicySingleDistrib(p, gs, prev, 2.5f));                  // temperature
+        put(policy.InferPolicySingle(p, gs, prev, true).ToFList());              // deterministic: the arg-max row of the action table
+        ActionSet all = policy.InferPolicyAll(gs, prevs[i], true);
+        CHECK(all.size() == 2);
+        CHECK(std::memcmp(&all[i % 2], &(const Action&)policy.InferPolicySingle(p, gs, prev, true), sizeof(Action)) == 0);
+        Action sampled = policy.InferPolicySingle(p, gs, prev, false);           // sampled: some row of the table
+        bool inTable = false;
+        for (const Action& a : parser.actions) inTable = inTable || std::memcmp(&a, &sampled, sizeof(Action)) == 0;
+        CHECK(inTable);
+        FList vals = critic.InferCriticAll(gs, prevs[i]);
+        CHECK(vals.size() == 2 && vals[i % 2] == critic.InferCriticSingle(p, gs, prev));
+        put({vals[i % 2]});
+    }
+    // asking a policy unit for values (and the reverse) is the reference's error
+    bool threw = false;
+    try { policy.InferCriticSingle(states[0].players[0], states[0], Action()); } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("created to infer the") != std::string::npos; }
+    CHECK(threw);
+    threw = false;
+    try { InferUnit bad(&obs, &parser, argv[1], true, 89, {32, 32}); } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("different model arch") != std::string::npos; }
+    CHECK(threw);
+    std::printf("infer unit ok\n");
+    return 0;
+}
