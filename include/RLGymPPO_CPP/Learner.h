@@ -5,6 +5,8 @@
 #include "Threading/GameInst.h"
 #include "Util/WelfordRunningStat.h"
 #include "Util/Timer.h"
+#include "Util/MetricSender.h"
+#include "Util/RenderSender.h"
 namespace RLGPC {
 struct EnvCreateResult { RLGSC::Match* match; RLGSC::Gym* gym; };
 typedef std::function<EnvCreateResult()> EnvCreateFn;
@@ -21,6 +23,8 @@ public:
     WelfordRunningStat returnStats;
     IterationCallback iterationCallback = nullptr;
     StepCallback stepCallback = nullptr;
+    MetricSender* metricSender = nullptr;            // JSON-lines sender (Util/MetricSender.h); NULL unless config.sendMetrics
+    RenderSender* renderSender = nullptr;            // RocketSimVis UDP sender (Util/RenderSender.h); NULL unless config.renderMode
 
     Learner(EnvCreateFn envCreateFn, LearnerConfig config);
     Learner(const Learner&) = delete;
@@ -39,6 +43,7 @@ public:
     void CollectTimesteps();                         // ThreadAgentManager::CollectTimesteps for every game at once
     void AddNewExperience(Report& report);           // Learner.cpp:608-703: value predictions, GAE, return statistics
     void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349)
+    void RenderStep(int t);                          // ThreadAgent.cpp:164-186 for the first game
     int NumEnvs() const;
     int NumAgents() const;
 private:

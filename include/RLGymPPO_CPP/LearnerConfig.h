@@ -9,7 +9,7 @@ struct LearnerConfig {
     int numThreads = 8;                 // envs = numThreads * numGamesPerThread (one device batch; there are no host threads)
     int numGamesPerThread = 16;
     int minInferenceSize = 80;          // unused: inference always covers the whole batch
-    bool renderMode = false;            // not built
+    bool renderMode = false;            // one game paced to real time, states to RocketSimVis over UDP (Util/RenderSender.h)
     float renderTimeScale = 1.5f;
     bool renderDuringTraining = false;
     uint64_t timestepLimit = 0;
@@ -32,7 +32,7 @@ struct LearnerConfig {
     int randomSeed = 123;
     int checkpointsToKeep = 5;
     LearnerDeviceType deviceType = LearnerDeviceType::AUTO;   // AUTO / GPU_CUDA = the HIP device; CPU is refused (no CPU path)
-    bool sendMetrics = true;            // metrics are printed; the Python wandb receiver is out of scope
+    bool sendMetrics = true;            // JSON lines under metrics/<project>/<run id>.jsonl (Util/MetricSender.h); tools/metric_receiver.py -> wandb
     std::string metricsProjectName = "rlgymppo-cpp";
     std::string metricsGroupName = "unnamed-runs";
     std::string metricsRunName = "rlgymppo-cpp-run";

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <numeric>
+#include <thread>
 
 #include <RLGymPPO_CPP/Learner.h>
 #include "../../include/rlgpu_state.h"
@@ -119,7 +120,8 @@ struct Learner::Impl {
     // ExperienceBuffer (ExperienceBuffer.h): the FIFO's iterations stay in device slots of B rows, the library tracks the live rows
     rlgpu_expbuf* fifo = nullptr;
     float *exObs = nullptr, *exLogp = nullptr, *exAdv = nullptr, *exTgt = nullptr; int32_t* exActs = nullptr;
-    bool first = true;
+    bool first = true, renderOnly = false;
+    Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     std::vector<GameInst> games;
     std::vector<RlgpuArenaState> hostStates; std::vector<float> hostRew; std::vector<int32_t> hostDone;
@@ -134,7 +136,16 @@ struct Learner::Impl {
 Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(config_), envCreateFn(envCreateFn_), impl(new Impl()) {
     Impl& m = *impl;
     if (config.deviceType == LearnerDeviceType::CPU) RG_ERR_CLOSE("LearnerDeviceType::CPU: this build has no CPU path (the hot path is HIP kernels)");
-    if (config.renderMode) RG_ERR_CLOSE("renderMode is not built (DESIGN.md: out of scope)");
+    if (config.standardizeOBS) RG_ERR_CLOSE("LearnerConfig.standardizeOBS has not yet been implemented, sorry");   // Learner.cpp:33-34
+    if (config.timestepsPerSave == 0) config.timestepsPerSave = config.timestepsPerIteration;
+    m.renderOnly = config.renderMode && !config.renderDuringTraining;
+    if (m.renderOnly) {   // Learner.cpp:38-52: one game, no metrics, no checkpoints, never learns
+        RG_LOG("\tRender mode is enabled, overriding:");
+        config.numThreads = config.numGamesPerThread = 1; RG_LOG("\t > numThreads, numGamesPerThread = 1");
+        config.sendMetrics = false; RG_LOG("\t > sendMetrics = false");
+        config.checkpointSaveFolder.clear(); RG_LOG("\t > checkpointSaveFolder = none");
+        config.timestepsPerIteration = 1; RG_LOG("\t > timestepsPerIteration = inf (the render loop never hands a batch to the learner)");
+    }
     // The reference calls envCreateFn once per game and once more to probe the obs size (Learner.cpp:99-109); every call
     // describes the same env, so one call is enough to configure the whole device batch.
     EnvCreateResult ecr = envCreateFn();
@@ -189,10 +200,14 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.phys.resize(EX);
     m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
 
-    runID = config.metricsRunName;
     if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
         config.checkpointSaveFolder += "-" + std::to_string(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count());
     if (!config.checkpointLoadFolder.empty()) Load();
+    if (config.renderMode) renderSender = new RenderSender();                                                                       // Learner.cpp:128-135
+    if (config.sendMetrics) {                                                                                                         // Learner.cpp:149-155
+        if (!runID.empty()) RG_LOG("\tRun ID: " << runID);
+        metricSender = new MetricSender(config.metricsProjectName, config.metricsGroupName, config.metricsRunName, runID);
+    }
 }
 
 Learner::~Learner() {
@@ -200,6 +215,7 @@ Learner::~Learner() {
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
                     (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
+    delete metricSender; delete renderSender;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
     if (m.lrn) rlgpu_learner_destroy(m.lrn);
@@ -232,6 +248,7 @@ void Learner::CollectTimesteps() {
         const size_t o = (size_t)t * m.nAgents;
         m.LrnCheck(rlgpu_policy_act(m.lrn, m.ObsAt(t), m.nAgents, config.deterministic ? 1 : 0, nullptr, m.acts + o, m.logp + o), "policy_act");
         m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
+        if (renderSender) RenderStep(t);
         if (slow) {
             // the reference hands every game's StepResult to the callback (GameInst.cpp:14-38): materialise host GameStates -- slow path.
             // NB: the downloaded state is the one AFTER the step's auto-reset when the episode ended.
@@ -252,6 +269,21 @@ void Learner::CollectTimesteps() {
         }
     }
     totalTimesteps += (uint64_t)m.B;
+}
+
+// ThreadAgent.cpp:164-186: the first game's state goes to the renderer after every step, paced to renderTimeScale x real time
+void Learner::RenderStep(int t) {
+    Impl& m = *impl;
+    RlgpuArenaState st; const int32_t env0 = 0;
+    std::vector<int32_t> acts(m.nPlayers);
+    m.EnvCheck(rlgpu_env_download_states(m.env, &st, &env0, 1), "download_states");
+    HOST_HIP(hipMemcpy(acts.data(), m.acts + (size_t)t * m.nAgents, (size_t)m.nPlayers * 4, hipMemcpyDeviceToHost));
+    RLGSC::GameState gs(st, m.tickSkip);
+    renderSender->Send(gs, m.match->actionParser->ParseActions(RLGSC::IList(acts.begin(), acts.end()), gs));
+    const double target = (1 / 120.0) * m.tickSkip / std::max(config.renderTimeScale, 1e-3f);
+    const double sleepTime = std::max(target - m.renderTimer.Elapsed(), 0.0);
+    if (!std::getenv("RLGPU_RENDER_NO_SLEEP")) std::this_thread::sleep_for(std::chrono::microseconds((int64_t)(sleepTime * 1e6)));
+    m.renderTimer.Reset();
 }
 
 std::vector<Report> Learner::GetAllGameMetrics() {
@@ -334,6 +366,7 @@ void Learner::Learn() {
     RG_LOG("Learner: " << m.nEnvs << " envs (" << m.nAgents << " agents), obs " << m.D << ", actions " << m.A << ", " << m.T << " steps/env/iteration = "
            << m.B << " timesteps, batch " << m.batch << ", minibatch " << m.mini);
     while (config.timestepLimit == 0 || totalTimesteps < config.timestepLimit) {
+        if (m.renderOnly) { CollectTimesteps(); continue; }   // render mode: play the (loaded) policy forever, one step per "iteration"
         Report report;
         Timer tAll, tCollect;
         CollectTimesteps();
@@ -350,6 +383,7 @@ void Learner::Learn() {
         report["Collected Steps/Second"] = (double)m.B / std::max(collectTime, 1e-9);
         report["Overall Steps/Second"] = (double)m.B / std::max(tAll.Elapsed(), 1e-9);
         if (iterationCallback) iterationCallback(this, report);
+        if (config.sendMetrics) metricSender->Send(report);                                                                       // Learner.cpp:589-590
         RG_LOG(std::string(8, '\n') << std::string(20, '=') << " ITERATION COMPLETED " << std::string(20, '='));
         const std::vector<std::string> rows = {"Average Step Reward", "Policy Entropy", "Value Function Loss", "", "Mean KL Divergence", "SB3 Clip Fraction", "Avg Return",
                         "Avg Advantage", "Avg Val Target", "", "Collected Steps/Second", "Overall Steps/Second", "", "Collection Time", "Consumption Time",
@@ -375,25 +409,30 @@ void LtCheck(int rc, const char* what, const std::filesystem::path& p) { if (rc 
 
 void Learner::SaveStats(std::filesystem::path path) {
     std::ofstream f(path);
-    double var = returnStats.count >= 2 ? returnStats.runningVariance / (double)(returnStats.count - 1) : 0.0;
-    f << std::setprecision(17) << "{\n    \"cumulative_timesteps\": " << totalTimesteps << ",\n    \"cumulative_model_updates\": " << impl->cumulativeModelUpdates
-      << ",\n    \"epoch\": " << totalEpochs << ",\n    \"reward_running_stats\": {\n        \"mean\": [" << returnStats.runningMean << "],\n        \"var\": [" << var
-      << "],\n        \"shape\": 1,\n        \"count\": " << returnStats.count << "\n    }\n}\n";
+    if (!f.good()) RG_ERR_CLOSE("Learner::SaveStats(): Can't open file at " << path.string());
+    // "var" is the raw sum of squared deviations: the reference writes its `runningVariance` member as is (Learner.cpp:196-202)
+    f << std::setprecision(17) << "{\n    \"cumulative_model_updates\": " << impl->cumulativeModelUpdates << ",\n    \"cumulative_timesteps\": " << totalTimesteps
+      << ",\n    \"epoch\": " << totalEpochs << ",\n    \"reward_running_stats\": {\n        \"count\": " << returnStats.count << ",\n        \"mean\": [\n            "
+      << returnStats.runningMean << "\n        ],\n        \"shape\": 1,\n        \"var\": [\n            " << returnStats.runningVariance << "\n        ]\n    }";
+    if (config.sendMetrics && metricSender) f << ",\n    \"run_id\": " << MetricSender::JsonString(metricSender->curRunID);   // :204-205
+    f << "\n}";
 }
 void Learner::LoadStats(std::filesystem::path path) {
     std::ifstream f(path);
-    if (!f) RG_ERR_CLOSE("cannot open " << path.string());
+    if (!f) RG_ERR_CLOSE("Learner::LoadStats(): Can't open file at " << path.string());
     std::string s((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    auto num = [&](const std::string& key) {
+    auto at = [&](const std::string& key, bool required) {
         size_t i = s.find("\"" + key + "\"");
-        if (i == std::string::npos) RG_ERR_CLOSE(path.string() << ": missing \"" << key << "\"");
+        if (i == std::string::npos) { if (required) RG_ERR_CLOSE(path.string() << ": missing \"" << key << "\""); return i; }
         i = s.find(':', i) + 1;
-        while (i < s.size() && (s[i] == ' ' || s[i] == '[' || s[i] == '\n')) i++;
-        return std::stod(s.substr(i));
+        while (i < s.size() && (s[i] == ' ' || s[i] == '[' || s[i] == '\n' || s[i] == '\r' || s[i] == '\t')) i++;
+        return i;
     };
+    auto num = [&](const std::string& key) { return std::stod(s.substr(at(key, true))); };
     totalTimesteps = (uint64_t)num("cumulative_timesteps"); impl->cumulativeModelUpdates = (uint64_t)num("cumulative_model_updates"); totalEpochs = (uint64_t)num("epoch");
-    returnStats.runningMean = num("mean"); returnStats.count = (int64_t)num("count");
-    returnStats.runningVariance = returnStats.count >= 2 ? num("var") * (double)(returnStats.count - 1) : 0.0;
+    returnStats.runningMean = num("mean"); returnStats.count = (int64_t)num("count"); returnStats.runningVariance = num("var");
+    size_t r = at("run_id", false);   // Learner.cpp:238-239: the metrics run continues under its id
+    if (r != std::string::npos && r < s.size() && s[r] == '"') runID = s.substr(r + 1, s.find('"', r + 1) - r - 1);
 }
 
 void Learner::Save() {

@@ -1,6 +1,6 @@
 // example_main.cpp -- a training program written against the reference's public API (compare /examplemain.cpp of RLGymPPO_CPP:
 // same headers, same classes, same config fields), built against this repo's headers and librlgymppo_amd.so instead.
-//   usage: example_main [iterations] [numThreads] [numGamesPerThread] [timestepsPerIteration]
+//   usage: example_main [iterations] [numThreads] [numGamesPerThread] [timestepsPerIteration] [checkpoint folder] [render]
 #include <RLGymPPO_CPP/Learner.h>
 
 #include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
@@ -68,13 +68,14 @@ int main(int argc, char** argv) {
     cfg.ppo.policyLayerSizes = {256, 256, 256};
     cfg.ppo.criticLayerSizes = {256, 256, 256};
     cfg.ppo.autocastLearn = true;
-    cfg.sendMetrics = false;
-    cfg.renderMode = false;
+    cfg.sendMetrics = true;    // JSON lines under ./metrics/<project>/<run id>.jsonl
+    cfg.renderMode = argc > 6 && std::string(argv[6]) == "render";   // play the newest checkpoint for RocketSimVis instead of training
     cfg.checkpointSaveFolder = argc > 5 ? argv[5] : "";
     cfg.checkpointLoadFolder = cfg.checkpointSaveFolder;
 
     try {
         Learner learner(MakeEnv, cfg);
+        if (cfg.renderMode) learner.config.timestepLimit = learner.totalTimesteps + (uint64_t)std::max(g_iterations_left, 1) * 2;   // here "iterations" = rendered 1v1 steps
         learner.stepCallback = StepMetrics;
         learner.iterationCallback = IterationMetrics;
         learner.Learn();

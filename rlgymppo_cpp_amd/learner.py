@@ -59,6 +59,10 @@ class LearnerConfig:  # PUB/LearnerConfig.h:14-80
     timestepsPerSave: int = 500 * 1000
     randomSeed: int = 123
     checkpointsToKeep: int = 5
+    sendMetrics: bool = False   # JSON lines under metrics/<project>/<run id>.jsonl (the reference defaults to True with its wandb receiver)
+    metricsProjectName: str = "rlgymppo-cpp"
+    metricsGroupName: str = "unnamed-runs"
+    metricsRunName: str = "rlgymppo-cpp-run"
     # ---- appended for the batched device path
     numEnvs: int = 0            # 0 -> numThreads * numGamesPerThread (the reference's env count)
     teamSize: int = 1
@@ -88,12 +92,11 @@ class WelfordRunningStat:
         return 1.0 if var == 0 else float(np.sqrt(var))
 
     def to_json(self):
-        var = self.m2 / (self.count - 1) if self.count >= 2 else 0.0
-        return {"mean": [self.mean], "var": [var], "shape": 1, "count": self.count}
+        # "var" is the raw sum of squared deviations, as the reference stores its `runningVariance` member (Learner.cpp:198-201)
+        return {"mean": [self.mean], "var": [self.m2], "shape": 1, "count": self.count}
 
     def from_json(self, j):
-        self.mean = float(j["mean"][0]); self.count = int(j["count"])
-        self.m2 = float(j["var"][0]) * (self.count - 1) if self.count >= 2 else 0.0
+        self.mean = float(j["mean"][0]); self.count = int(j["count"]); self.m2 = float(j["var"][0])
 
 
 class Shuffler:
@@ -119,6 +122,24 @@ class Shuffler:
             self.lib.rlgpu_shuffler_destroy(self.h)
         except Exception:
             pass
+
+
+class MetricSender:
+    """MetricSender (PUB/Util/MetricSender.cpp:8-45) without the embedded interpreter: the same JSON-lines file the C++ host writes
+    (include/RLGymPPO_CPP/Util/MetricSender.h); tools/metric_receiver.py forwards it to wandb."""
+
+    def __init__(self, project, group, name, run_id=""):
+        self.run_id = run_id or "".join(np.random.RandomState(int(time.time() * 1e6) % (2 ** 31)).choice(list("0123456789abcdefghijklmnopqrstuvwxyz"), 8))
+        folder = os.path.join(os.environ.get("RLGPU_METRICS_DIR") or "metrics", project or "default")
+        os.makedirs(folder, exist_ok=True)
+        self.path = os.path.join(folder, self.run_id + ".jsonl")
+        if not os.path.exists(self.path):
+            with open(self.path, "a") as f:
+                f.write(json.dumps({"_run": {"project": project, "group": group, "name": name, "id": self.run_id}}) + "\n")
+
+    def send(self, report):
+        with open(self.path, "a") as f:
+            f.write(json.dumps({k: (float(v) if np.isfinite(v) else None) for k, v in report.items()}) + "\n")
 
 
 class ExperienceFifo:
@@ -209,6 +230,8 @@ class Learner:
         self.ts_since_save = 0
         self.report = {}
         self.iteration_callback = None
+        self.run_id = ""
+        self.metric_sender = None   # created by run() after a possible load(), so that a loaded run id continues (Learner.cpp:149-155)
         self.env.reset(True, self.obs_buf[0])
         self._first = True
 
@@ -317,6 +340,10 @@ class Learner:
             self.report["Overall Steps/Second"] = self.B * self.world / dt
             if self.iteration_callback:
                 self.iteration_callback(self, self.report)
+            if self.cfg.sendMetrics and self.rank == 0:
+                if self.metric_sender is None:
+                    self.metric_sender = MetricSender(self.cfg.metricsProjectName, self.cfg.metricsGroupName, self.cfg.metricsRunName, self.run_id)
+                self.metric_sender.send(self.report)                                       # Learner.cpp:589-590
             if self.ts_since_save > self.cfg.timestepsPerSave and self.rank == 0:
                 self.save()
             it += 1
@@ -333,6 +360,8 @@ class Learner:
         os.makedirs(folder, exist_ok=True)
         stats = {"cumulative_timesteps": self.total_timesteps, "cumulative_model_updates": self.cumulative_model_updates,
                  "epoch": self.total_epochs, "reward_running_stats": self.return_stats.to_json()}
+        if self.metric_sender is not None:
+            stats["run_id"] = self.metric_sender.run_id                                     # Learner.cpp:204-205
         with open(os.path.join(folder, "RUNNING_STATS.json"), "w") as f:
             json.dump(stats, f, indent=4)
         m, v, sp, sc = self.ppo.get_adam_state()
@@ -362,6 +391,7 @@ class Learner:
             stats = json.load(f)
         self.total_timesteps = int(stats["cumulative_timesteps"]); self.cumulative_model_updates = int(stats["cumulative_model_updates"])
         self.total_epochs = int(stats["epoch"]); self.return_stats.from_json(stats["reward_running_stats"])
+        self.run_id = stats.get("run_id", "")                                               # Learner.cpp:238-239
         pol = _read_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.layer_shapes(0))     # size check of every param (PPOLearner.cpp:380-408)
         self.ppo.set_params(pol, 0)
         if os.path.exists(os.path.join(folder, "PPO_CRITIC.lt")):                            # the critic file is optional (PPOLearner.cpp:421-422)

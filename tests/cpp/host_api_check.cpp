@@ -61,6 +61,41 @@ int main() {
     PhysObj q = p.Invert(); CHECK(q.pos.x == -1 && q.pos.y == -2 && q.pos.z == 3 && q.rotMat.forward.y == -1);
     // config defaults of the reference
     LearnerConfig lc; CHECK(lc.numThreads == 8 && lc.numGamesPerThread == 16 && lc.ppo.epochs == 10 && lc.ppo.batchSize == 50000 && lc.gaeGamma == 0.99f && lc.maxReturnsPerStatsInc == 150);
+    // MetricSender: JSON lines under $RLGPU_METRICS_DIR/<project>/<run id>.jsonl; a given run id continues its file
+    {
+        MetricSender ms("proj", "grp", "run \"7\"");
+        CHECK(ms.curRunID.size() == 8);
+        Report rep; rep["Policy Entropy"] = 4.25; rep["Cumulative Timesteps"] = 1234567; rep["bad"] = NAN;
+        ms.Send(rep);
+        MetricSender again("proj", "grp", "run \"7\"", ms.curRunID);
+        CHECK(again.curRunID == ms.curRunID && again.filePath == ms.filePath);
+        again.Send(rep);
+        std::ifstream f(ms.filePath); std::string line; std::vector<std::string> lines;
+        while (std::getline(f, line)) lines.push_back(line);
+        CHECK(lines.size() == 3 && lines[0].find("\"_run\"") != std::string::npos && lines[0].find("run \\\"7\\\"") != std::string::npos);
+        CHECK(lines[1] == lines[2] && lines[1].find("\"Policy Entropy\": 4.25") != std::string::npos && lines[1].find("\"bad\": null") != std::string::npos);
+        std::printf("metrics file: %s\n", ms.filePath.string().c_str());
+    }
+    // RenderSender: the RocketSimVis datagram arrives on a local UDP socket exactly as ToJSON builds it
+    {
+        int rx = socket(AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in a{}; a.sin_family = AF_INET; a.sin_port = 0; inet_pton(AF_INET, "127.0.0.1", &a.sin_addr);
+        CHECK(bind(rx, (sockaddr*)&a, sizeof a) == 0);
+        socklen_t al = sizeof a; CHECK(getsockname(rx, (sockaddr*)&a, &al) == 0);
+        timeval tv{2, 0}; setsockopt(rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        RenderSender rs("127.0.0.1", ntohs(a.sin_port));
+        GameState gs; gs.players.resize(2); gs.players[0].carId = 1; gs.players[1].carId = 2; gs.players[1].team = Team::ORANGE;
+        gs.ball.pos = Vec(1, 2, 93.15f); gs.players[1].phys.pos = Vec(-100, 250.5f, 17); gs.players[1].boostFraction = 0.5f; gs.boostPads[3] = true;
+        rs.Send(gs, ActionSet(2));
+        char buf[8192]; ssize_t n = recv(rx, buf, sizeof buf, 0);
+        CHECK(n > 0);
+        std::string got(buf, (size_t)n), want = RenderSender::ToJSON(gs, ActionSet(2));
+        CHECK(got == want && rs.sent == 1);
+        CHECK(got.find("\"gamemode\": \"soccar\"") == 1 && got.find("\"ball_phys\": {\"pos\": [1, 2, 93.1500015]") != std::string::npos);
+        CHECK(got.find("\"team_num\": 1") != std::string::npos && got.find("\"boost_amount\": 0.5") != std::string::npos);
+        std::printf("render datagram: %s\n", got.c_str());
+        close(rx);
+    }
     std::printf("host api ok\n");
     return 0;
 }

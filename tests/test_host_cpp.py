@@ -22,8 +22,20 @@ def test_host_api_translation_and_utils(tmp_path):
     r = _run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_api_check.cpp"), "-o", exe,
               "-L", PKG, "-lrlgpu", f"-Wl,-rpath,{PKG}", "-Wl,-rpath-link,/opt/rocm/lib"])
     assert r.returncode == 0, r.stdout
-    r = _run([exe])
+    r = _run([exe], env=dict(os.environ, RLGPU_METRICS_DIR=str(tmp_path / "metrics")))
     assert r.returncode == 0 and "host api ok" in r.stdout, r.stdout
+    # what the senders wrote is JSON as Python reads it, and the wandb side-car replays the metrics file
+    import json
+    mfile = [l for l in r.stdout.splitlines() if l.startswith("metrics file: ")][0][len("metrics file: "):]
+    recs = [json.loads(l) for l in open(mfile)]
+    assert recs[0]["_run"] == {"project": "proj", "group": "grp", "name": 'run "7"', "id": os.path.basename(mfile)[:-6]}
+    assert recs[1]["Policy Entropy"] == 4.25 and recs[1]["Cumulative Timesteps"] == 1234567 and recs[1]["bad"] is None
+    dgram = json.loads([l for l in r.stdout.splitlines() if l.startswith("render datagram: ")][0][len("render datagram: "):])
+    assert set(dgram) == {"gamemode", "ball_phys", "cars", "boost_pad_states"} and set(dgram["ball_phys"]) == {"pos", "vel", "ang_vel"}   # render_receiver.py:20-33
+    assert len(dgram["boost_pad_states"]) == 34 and dgram["boost_pad_states"][3] is True and dgram["cars"][1]["phys"]["pos"] == [-100, 250.5, 17]
+    assert set(dgram["cars"][0]) == {"car_id", "team_num", "phys", "boost_pickups", "is_demoed", "on_ground", "ball_touched", "has_flip", "boost_amount"}
+    t = _run([sys.executable, os.path.join(ROOT, "tools", "metric_receiver.py"), mfile, "--once", "--dry-run"])
+    assert t.returncode == 0 and t.stdout.count("log {") == 2 and "init {" in t.stdout and "'bad'" not in t.stdout, t.stdout
 
 
 def test_example_program_is_built():
@@ -59,6 +71,30 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     # and the C++ host resumes from it
     r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600)
     assert r.returncode == 0 and "loaded checkpoint" in r.stdout and str(3 * 4096) in os.listdir(ck), r.stdout[-3000:]
+    # metrics: one JSON-lines file for the run; the resumed process continued it under the run id stored in RUNNING_STATS.json
+    import json
+    mdir = tmp_path / "metrics" / "rlgymppo-cpp"
+    files = os.listdir(mdir)
+    assert len(files) == 1, files
+    recs = [json.loads(l) for l in open(mdir / files[0])]
+    assert "_run" in recs[0] and len(recs) == 1 + 3
+    assert [int(x["Cumulative Timesteps"]) for x in recs[1:]] == [4096, 8192, 12288] and "player_speed" in recs[1] and "Policy Entropy" in recs[3]
+    assert json.load(open(os.path.join(ck, str(3 * 4096), "RUNNING_STATS.json")))["run_id"] == files[0][:-6]
+    # render mode: the newest checkpoint plays one game, every step goes to RocketSimVis' UDP port as a JSON datagram
+    import socket
+    before_render = sorted(os.listdir(ck))
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 9273))
+    rx.settimeout(5)
+    r = _run([exe, "12", "4", "16", "4096", ck, "render"], cwd=str(tmp_path), timeout=600, env=dict(os.environ, RLGPU_RENDER_NO_SLEEP="1"))
+    assert r.returncode == 0 and "Render mode is enabled" in r.stdout and "loaded checkpoint" in r.stdout, r.stdout[-3000:]
+    grams = []
+    for _ in range(12):
+        grams.append(json.loads(rx.recv(65536)))
+    rx.close()
+    assert all(len(g["cars"]) == 2 and len(g["boost_pad_states"]) == 34 and g["gamemode"] == "soccar" for g in grams)
+    assert grams[0]["cars"][0]["phys"]["pos"] != grams[-1]["cars"][0]["phys"]["pos"]          # the policy is driving
+    assert sorted(os.listdir(ck)) == before_render                                               # render mode saves nothing
 
 
 def test_reference_example_source_compiles_unchanged():
