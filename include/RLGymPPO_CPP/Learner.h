@@ -7,9 +7,8 @@
 #include "Util/Timer.h"
 #include "Util/MetricSender.h"
 #include "Util/RenderSender.h"
+#include "Util/SkillTracker.h"
 namespace RLGPC {
-struct EnvCreateResult { RLGSC::Match* match; RLGSC::Gym* gym; };
-typedef std::function<EnvCreateResult()> EnvCreateFn;
 class Learner;
 typedef std::function<void(Learner*, Report&)> IterationCallback;
 
@@ -24,6 +23,7 @@ public:
     IterationCallback iterationCallback = nullptr;
     StepCallback stepCallback = nullptr;
     MetricSender* metricSender = nullptr;            // JSON-lines sender (Util/MetricSender.h); NULL unless config.sendMetrics
+    SkillTracker* skillTracker = nullptr;            // ELO evaluation against stored old versions (Util/SkillTracker.h); NULL unless enabled
     RenderSender* renderSender = nullptr;            // RocketSimVis UDP sender (Util/RenderSender.h); NULL unless config.renderMode
 
     Learner(EnvCreateFn envCreateFn, LearnerConfig config);
@@ -43,6 +43,7 @@ public:
     void CollectTimesteps();                         // ThreadAgentManager::CollectTimesteps for every game at once
     void AddNewExperience(Report& report);           // Learner.cpp:608-703: value predictions, GAE, return statistics
     void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349)
+    void LoadOldVersions(const std::vector<int32_t>& policyDims);   // Learner.cpp:311-370
     void RenderStep(int t);                          // ThreadAgent.cpp:164-186 for the first game
     int NumEnvs() const;
     int NumAgents() const;

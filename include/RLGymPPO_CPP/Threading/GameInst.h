@@ -7,6 +7,8 @@
 namespace RLGPC {
 struct GameInst;
 typedef std::function<void(GameInst*, const RLGSC::Gym::StepResult&, Report&)> StepCallback;
+struct EnvCreateResult { RLGSC::Match* match; RLGSC::Gym* gym; };   // GameInst.h:9-14
+typedef std::function<EnvCreateResult()> EnvCreateFn;
 struct GameInst {
     RLGSC::Gym* gym = nullptr; RLGSC::Match* match = nullptr;   // shared descriptors (owned by the Learner)
     int index = 0;                                              // env index inside the device batch

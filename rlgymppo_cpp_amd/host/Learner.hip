@@ -202,8 +202,12 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
 
     if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
         config.checkpointSaveFolder += "-" + std::to_string(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count());
-    if (!config.checkpointLoadFolder.empty()) Load();
     if (config.renderMode) renderSender = new RenderSender();                                                                       // Learner.cpp:128-135
+    if (config.skillTrackerConfig.enabled) {                                                                                          // Learner.cpp:136-143
+        if (config.skillTrackerConfig.envCreateFunc == NULL) config.skillTrackerConfig.envCreateFunc = envCreateFn;
+        skillTracker = new SkillTracker(config.skillTrackerConfig, m.lrn, m.D, m.A, config.ppo.policyLayerSizes, config.randomSeed, renderSender);
+    }
+    if (!config.checkpointLoadFolder.empty()) Load();
     if (config.sendMetrics) {                                                                                                         // Learner.cpp:149-155
         if (!runID.empty()) RG_LOG("\tRun ID: " << runID);
         metricSender = new MetricSender(config.metricsProjectName, config.metricsGroupName, config.metricsRunName, runID);
@@ -215,7 +219,7 @@ Learner::~Learner() {
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
                     (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
-    delete metricSender; delete renderSender;
+    delete skillTracker; delete metricSender; delete renderSender;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
     if (m.lrn) rlgpu_learner_destroy(m.lrn);
@@ -376,6 +380,12 @@ void Learner::Learn() {
         AddNewExperience(report);
         LearnPPO(report);
         double consumeTime = tConsume.Elapsed();
+        if (skillTracker) {   // Learner.cpp:527-538
+            RG_LOG("Running skill eval game(s)...");
+            if (config.skillTrackerConfig.stepCallback == NULL) skillTracker->config.stepCallback = stepCallback;
+            skillTracker->RunGames((int64_t)m.B);
+            for (auto& pair : skillTracker->curRating.data) report[std::string("Skill Rating") + (pair.first.empty() ? "" : " ") + pair.first] = pair.second;
+        }
         totalIterations++;
         report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
         report["Timesteps Collected"] = (double)m.B;
@@ -414,6 +424,7 @@ void Learner::SaveStats(std::filesystem::path path) {
     f << std::setprecision(17) << "{\n    \"cumulative_model_updates\": " << impl->cumulativeModelUpdates << ",\n    \"cumulative_timesteps\": " << totalTimesteps
       << ",\n    \"epoch\": " << totalEpochs << ",\n    \"reward_running_stats\": {\n        \"count\": " << returnStats.count << ",\n        \"mean\": [\n            "
       << returnStats.runningMean << "\n        ],\n        \"shape\": 1,\n        \"var\": [\n            " << returnStats.runningVariance << "\n        ]\n    }";
+    if (skillTracker) f << ",\n    \"skill_rating\": " << skillTracker->RatingsToJSON();                                          // :185-194
     if (config.sendMetrics && metricSender) f << ",\n    \"run_id\": " << MetricSender::JsonString(metricSender->curRunID);   // :204-205
     f << "\n}";
 }
@@ -431,6 +442,8 @@ void Learner::LoadStats(std::filesystem::path path) {
     auto num = [&](const std::string& key) { return std::stod(s.substr(at(key, true))); };
     totalTimesteps = (uint64_t)num("cumulative_timesteps"); impl->cumulativeModelUpdates = (uint64_t)num("cumulative_model_updates"); totalEpochs = (uint64_t)num("epoch");
     returnStats.runningMean = num("mean"); returnStats.count = (int64_t)num("count"); returnStats.runningVariance = num("var");
+    size_t k = at("skill_rating", false);   // Learner.cpp:229-231
+    if (skillTracker && k != std::string::npos) skillTracker->curRating = skillTracker->LoadRatingSet(s[k] == '{' ? s.substr(k, s.find('}', k) - k + 1) : s.substr(k));
     size_t r = at("run_id", false);   // Learner.cpp:238-239: the metrics run continues under its id
     if (r != std::string::npos && r < s.size() && s[r] == '"') runID = s.substr(r + 1, s.find('"', r + 1) - r - 1);
 }
@@ -466,6 +479,45 @@ void Learner::Save() {
     RG_LOG("Learner: saved checkpoint " << folder.string());
 }
 
+// Learner.cpp:311-370: older checkpoints, one per timestepsPerVersion going back from the loaded one, become the skill tracker's stored
+// versions when they carry a "skill_rating"
+void Learner::LoadOldVersions(const std::vector<int32_t>& policyDims) {
+    const SkillTrackerConfig& sc = config.skillTrackerConfig;
+    RG_LOG("Attempting to load " << sc.maxVersions << " old versions for skill tracker...");
+    const int64_t targetInterval = sc.timestepsPerVersion, maxAcceptableOverage = targetInterval;
+    int64_t targetTimesteps = (int64_t)totalTimesteps;
+    for (int i = 0; i < sc.maxVersions; i++) {
+        targetTimesteps -= targetInterval;
+        std::string bestRating; int64_t bestTimesteps = -1;
+        for (auto& entry : std::filesystem::directory_iterator(config.checkpointLoadFolder)) {
+            const std::string name = entry.path().filename().string();
+            if (!entry.is_directory() || name.empty() || !std::all_of(name.begin(), name.end(), ::isdigit)) continue;
+            const int64_t nameVal = std::stoll(name);
+            if (nameVal >= targetTimesteps + targetInterval) continue;
+            if (bestTimesteps != -1 && std::llabs(nameVal - targetTimesteps) >= std::llabs(bestTimesteps - targetTimesteps)) continue;
+            std::ifstream f(entry.path() / "RUNNING_STATS.json");
+            if (!f.good()) continue;
+            std::string js((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            size_t k = js.find("\"skill_rating\"");
+            if (k == std::string::npos) continue;
+            k = js.find(':', k) + 1;
+            while (k < js.size() && isspace((unsigned char)js[k])) k++;
+            bestRating = js[k] == '{' ? js.substr(k, js.find('}', k) - k + 1) : js.substr(k);
+            bestTimesteps = nameVal;
+        }
+        if (bestTimesteps != -1 && bestTimesteps >= targetTimesteps - maxAcceptableOverage) {
+            RG_LOG(" > [" << i << "]: Found at " << bestTimesteps << " (target = " << targetTimesteps << ", delta = " << (targetTimesteps - bestTimesteps) << ")");
+            std::filesystem::path file = config.checkpointLoadFolder / std::to_string(bestTimesteps) / "PPO_POLICY.lt";
+            std::vector<float> params((size_t)rlgpu_learner_num_params(impl->lrn, 0));
+            if (std::filesystem::exists(file) && rlgpu_lt_read_model(file.string().c_str(), policyDims.data(), (int)policyDims.size() - 1, params.data()) == RLGPU_OK)
+                skillTracker->AppendOldPolicy(params, skillTracker->LoadRatingSet(bestRating));
+            else RG_LOG(" > FAILED to load policy, policy does not exist in checkpoint!");
+        } else {
+            RG_LOG(" > [" << i << "]: None found");
+        }
+    }
+}
+
 void Learner::Load() {
     Impl& m = *impl;
     if (config.checkpointLoadFolder.empty() || !std::filesystem::is_directory(config.checkpointLoadFolder)) return;
@@ -498,6 +550,7 @@ void Learner::Load() {
     readOptim("PPO_CRITIC_OPTIM.lt", dCri, am.data() + nPol, av.data() + nPol, sc);
     m.LrnCheck(rlgpu_learner_set_adam_state(m.lrn, am.data(), av.data(), sp, sc), "set_adam_state");
     UpdateLearningRates(config.ppo.policyLR, config.ppo.criticLR);   // Learner.cpp:501
+    if (skillTracker && config.skillTrackerConfig.loadOldVersionsFromCheckpoints) LoadOldVersions(dPol);
     RG_LOG("Learner: loaded checkpoint " << folder.string() << " (" << totalTimesteps << " timesteps)");
 }
 

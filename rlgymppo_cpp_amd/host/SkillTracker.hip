@@ -1,0 +1,265 @@
+// SkillTracker.hip -- RLGPC::SkillTracker (PRIV/Util/SkillTracker.cpp:28-291) on one small device env batch.
+// Per step: the current policy and every stored version in use pick deterministic actions for all eval rows (rlgpu_policy_act),
+// the host picks per player which policy's action counts (team and teamSwap of its game), the batch steps; a goal shows up as the
+// +1 / -1 of the eval env's only reward term, EventReward{teamGoal 1, concede -1} (the reference looks at the ball's position in
+// the step result, SkillTracker.cpp:129-146; the event tracker reports the same goal, and the auto-reset of the batched env has
+// already replaced that state).
+#include <hip/hip_runtime.h>
+
+#include <RLGymPPO_CPP/Util/SkillTracker.h>
+#include "../../include/rlgpu_state.h"
+
+#include <thread>
+
+namespace RLGPC {
+
+#define SKILL_HIP(call)                                                                                    \
+    do {                                                                                                   \
+        hipError_t _e = (call);                                                                            \
+        if (_e != hipSuccess) RG_ERR_CLOSE("SkillTracker: " #call " failed: " << hipGetErrorString(_e));   \
+    } while (0)
+
+struct SkillTracker::Impl {
+    rlgpu_learner* cur = nullptr;
+    rlgpu_env* env = nullptr;
+    std::vector<rlgpu_learner*> old;            // stored versions: inference-only learner objects
+    RLGSC::Match* match = nullptr; RLGSC::Gym* gym = nullptr;
+    int obsSize = 0, actionAmount = 0, nPlayers = 0, nRows = 0, tickSkip = 8;
+    IList layers;
+    float *obs = nullptr, *obsNext = nullptr, *rew = nullptr, *logp = nullptr; int32_t *acts = nullptr, *done = nullptr;
+    std::mt19937 rng;
+    std::vector<GameInst> gameInsts;
+    void EnvCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("SkillTracker: rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
+    void LrnCheck(rlgpu_learner* l, int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("SkillTracker: rlgpu_" << what << " failed (" << rc << "): " << rlgpu_learner_last_error(l)); }
+    rlgpu_learner* MakeVersion(const float* params) {
+        RlgpuLearnerConfig lc{};
+        lc.obs_size = obsSize; lc.n_actions = actionAmount; lc.n_policy_layers = (int)layers.size(); lc.n_critic_layers = 1;
+        for (int i = 0; i < 8; i++) { lc.policy_layers[i] = 16; lc.critic_layers[i] = 16; }
+        for (size_t i = 0; i < layers.size(); i++) lc.policy_layers[i] = layers[i];
+        lc.clip_range = 0.2f; lc.temperature = 1; lc.max_rows = std::max(nRows, 64);
+        rlgpu_learner* l = nullptr;
+        int rc = rlgpu_learner_create(&l, 0, &lc);
+        LrnCheck(l, rc, "learner_create");
+        LrnCheck(l, rlgpu_learner_set_params(l, 0, params), "learner_set_params");
+        return l;
+    }
+    void ResetGame(Game& g, int numPolicies) {   // SkillTracker.h:25-28
+        g.teamSwap = std::uniform_real_distribution<float>(0, 1)(rng) > 0.5f;
+        g.oldPolicyIndex = numPolicies > 0 ? (int)(rng() % (unsigned)numPolicies) : 0;
+    }
+};
+
+SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* learner, int obsSize, int actionAmount, const IList& policyLayerSizes, int randomSeed,
+                           RenderSender* renderSender_)
+    : renderSender(renderSender_), config(config_), impl(new Impl()) {
+    Impl& m = *impl;
+    if (config.numEnvs <= 0 || config.timestepsPerVersion < 0 || config.maxVersions <= 0 || config.simTime <= 0 || config.updateInterval <= 0)
+        RG_ERR_CLOSE("SkillTracker: numEnvs, maxVersions, simTime and updateInterval must be positive");
+    if (!config.envCreateFunc) RG_ERR_CLOSE("SkillTracker: envCreateFunc is NULL");
+    m.cur = learner; m.obsSize = obsSize; m.actionAmount = actionAmount; m.layers = policyLayerSizes;
+    m.rng.seed((unsigned)randomSeed * 2654435761u + 99u);
+    EnvCreateResult ecr = config.envCreateFunc();
+    if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("SkillTracker: envCreateFunc returned a null match or gym");
+    m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
+    RlgpuGymConfig g = m.match->ToDeviceConfig(m.tickSkip);
+    // rewards play no role in evaluation (the reference swaps in a zero reward, SkillTracker.cpp:10-16,51); the one term kept is the goal detector
+    g.n_terms = 1; g.terms[0].kind = RLGPU_RW_EVENT; g.terms[0].weight = 1.f; g.terms[0].p0 = 0.f; g.zero_sum = 0;
+    for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) g.event_weights[i] = 0.f;
+    g.event_weights[1] = 1.f; g.event_weights[2] = -1.f;   // teamGoal, concede (CommonRewards.h:19-40)
+    if (config.kickoffStatesOnly) g.setter_kind = RLGPU_SS_KICKOFF;
+    g.seed_lo = (uint32_t)randomSeed + 7777u; g.seed_hi = 1;
+    int rc = rlgpu_env_create(&m.env, 0, config.numEnvs, m.match->teamSize, &g);
+    m.EnvCheck(rc, "create");
+    std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
+    if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
+    else m.EnvCheck(rlgpu_env_set_procedural_mesh(m.env), "set_procedural_mesh");
+    if (rlgpu_env_obs_size(m.env) != obsSize) RG_ERR_CLOSE("SkillTracker: the eval env's observations have " << rlgpu_env_obs_size(m.env) << " values, the policy takes " << obsSize);
+    m.nPlayers = m.match->playerAmount; m.nRows = rlgpu_env_num_agents(m.env);
+    SKILL_HIP(hipMalloc(&m.obs, (size_t)m.nRows * obsSize * 4)); SKILL_HIP(hipMalloc(&m.obsNext, (size_t)m.nRows * obsSize * 4));
+    SKILL_HIP(hipMalloc(&m.rew, m.nRows * 4)); SKILL_HIP(hipMalloc(&m.logp, m.nRows * 4));
+    SKILL_HIP(hipMalloc(&m.acts, m.nRows * 4)); SKILL_HIP(hipMalloc(&m.done, m.nRows * 4));
+    m.EnvCheck(rlgpu_env_reset(m.env, 1, m.obs), "reset");
+
+    modeName = std::to_string(m.match->teamSize) + "v" + std::to_string(m.match->teamSize);   // ModeNameFromGameInst, SkillTracker.cpp:20-26
+    if (config.perModeRatings) { modeNames.insert(modeName); curRating.data[modeName] = config.initialRating; }
+    else { modeName = ""; curRating.data[""] = config.initialRating; }
+    games.resize(config.numEnvs);
+    for (Game& game : games) m.ResetGame(game, 1);
+    m.gameInsts.resize(config.numEnvs);
+    for (int e = 0; e < config.numEnvs; e++) { m.gameInsts[e].gym = m.gym; m.gameInsts[e].match = m.match; m.gameInsts[e].index = e; m.gameInsts[e].isEval = true; }
+}
+
+SkillTracker::~SkillTracker() {
+    Impl& m = *impl;
+    for (void* p : {(void*)m.obs, (void*)m.obsNext, (void*)m.rew, (void*)m.logp, (void*)m.acts, (void*)m.done}) if (p) (void)hipFree(p);
+    for (rlgpu_learner* l : m.old) rlgpu_learner_destroy(l);
+    if (m.env) rlgpu_env_destroy(m.env);
+    delete m.gym; delete m.match;
+    delete impl;
+}
+
+int SkillTracker::NumOldPolicies() const { return (int)impl->old.size(); }
+
+void SkillTracker::AppendOldPolicy(const std::vector<float>& policyParams, RatingSet rating) {
+    impl->old.push_back(impl->MakeVersion(policyParams.data()));
+    oldRatings.push_back(rating);
+}
+
+void SkillTracker::UpdateRatings(RatingSet& winner, RatingSet& loser, bool updateWinner, bool updateLoser, std::string mode) {
+    // simple elo step per goal (SkillTracker.cpp:72-86)
+    if (!winner.data.count(mode) || !loser.data.count(mode)) RG_ERR_CLOSE("SkillTracker::UpdateRatings(): no rating for mode \"" << mode << "\"");
+    const float expDelta = (loser.data[mode] - winner.data[mode]) / 400;
+    const float expected = 1 / (powf(10, expDelta) + 1);
+    if (updateWinner) winner.data[mode] += config.ratingInc * (1 - expected);
+    if (updateLoser) loser.data[mode] += config.ratingInc * (expected - 1);
+}
+
+void SkillTracker::RunGames(int64_t timestepsDelta) {
+    Impl& m = *impl;
+    if (runCounter++ % (uint64_t)config.updateInterval != 0) return;
+
+    auto snapshot = [&]() {   // the current policy's parameters as a new stored version
+        std::vector<float> params((size_t)rlgpu_learner_num_params(m.cur, 0));
+        m.LrnCheck(m.cur, rlgpu_learner_get_params(m.cur, 0, params.data()), "learner_get_params");
+        AppendOldPolicy(params, curRating);
+    };
+    if (m.old.empty() && config.startWithVersion) snapshot();
+
+    if (!m.old.empty()) {
+        const RatingSet prevRating = curRating;
+        const float timePerGame = config.simTime / (float)games.size();
+        const int numSteps = (int)(timePerGame * 120 / m.tickSkip);
+        if (numSteps <= 0) RG_ERR_CLOSE("RLGPC::SkillTracker RunGames(): simTime is too low for the number of games, there is not enough time per game to step");
+        const int nOld = (int)m.old.size();
+        for (Game& g : games) if (g.oldPolicyIndex >= nOld) g.oldPolicyIndex = nOld - 1;
+        std::vector<int32_t> picksCur(m.nRows), picks(m.nRows), dones(m.nRows);
+        std::vector<std::vector<int32_t>> picksOld(nOld, std::vector<int32_t>(m.nRows));
+        std::vector<float> rews(m.nRows);
+        const StepCallback& cb = config.stepCallback;
+        std::vector<RlgpuArenaState> states(cb || renderSender ? games.size() : 0);
+        for (int s = 0; s < numSteps; s++) {
+            m.LrnCheck(m.cur, rlgpu_policy_act(m.cur, m.obs, m.nRows, 1, nullptr, m.acts, m.logp), "policy_act");
+            m.LrnCheck(m.cur, rlgpu_learner_sync(m.cur), "learner_sync");
+            SKILL_HIP(hipMemcpy(picksCur.data(), m.acts, m.nRows * 4, hipMemcpyDeviceToHost));
+            std::vector<char> used(nOld, 0);
+            for (const Game& g : games) used[g.oldPolicyIndex] = 1;
+            for (int k = 0; k < nOld; k++) {
+                if (!used[k]) continue;
+                m.LrnCheck(m.old[k], rlgpu_policy_act(m.old[k], m.obs, m.nRows, 1, nullptr, m.acts, m.logp), "policy_act");
+                m.LrnCheck(m.old[k], rlgpu_learner_sync(m.old[k]), "learner_sync");
+                SKILL_HIP(hipMemcpy(picksOld[k].data(), m.acts, m.nRows * 4, hipMemcpyDeviceToHost));
+            }
+            // blue plays the current policy unless the game is swapped (SkillTracker.cpp:104-127); cars alternate blue, orange, blue, ...
+            for (size_t e = 0; e < games.size(); e++)
+                for (int j = 0; j < m.nPlayers; j++) {
+                    const bool blue = (j % 2) == 0, curPlays = blue != games[e].teamSwap;
+                    const size_t row = e * m.nPlayers + j;
+                    picks[row] = curPlays ? picksCur[row] : picksOld[games[e].oldPolicyIndex][row];
+                }
+            SKILL_HIP(hipMemcpy(m.acts, picks.data(), m.nRows * 4, hipMemcpyHostToDevice));
+            m.EnvCheck(rlgpu_env_step(m.env, m.acts, m.obsNext, m.rew, m.done), "step");
+            m.EnvCheck(rlgpu_env_sync(m.env), "sync");
+            std::swap(m.obs, m.obsNext);
+            SKILL_HIP(hipMemcpy(rews.data(), m.rew, m.nRows * 4, hipMemcpyDeviceToHost));
+            SKILL_HIP(hipMemcpy(dones.data(), m.done, m.nRows * 4, hipMemcpyDeviceToHost));
+            if (!states.empty()) m.EnvCheck(rlgpu_env_download_states(m.env, states.data(), nullptr, (int)games.size()), "download_states");
+            for (size_t e = 0; e < games.size(); e++) {
+                Game& g = games[e];
+                const float blueReward = rews[e * m.nPlayers];   // +1: blue scored, -1: orange scored
+                if (blueReward > 0.5f || blueReward < -0.5f) {
+                    const bool blueScored = blueReward > 0;
+                    const bool curScored = blueScored != g.teamSwap;
+                    if (curScored) UpdateRatings(curRating, oldRatings[g.oldPolicyIndex], true, true, modeName);
+                    else UpdateRatings(oldRatings[g.oldPolicyIndex], curRating, true, true, modeName);
+                }
+                if (cb) {
+                    RLGSC::Gym::StepResult sr;
+                    sr.state = RLGSC::GameState(states[e], m.tickSkip);
+                    sr.reward.assign(rews.begin() + e * m.nPlayers, rews.begin() + (e + 1) * m.nPlayers);
+                    sr.done = dones[e * m.nPlayers] != 0;
+                    m.gameInsts[e].totalSteps++;
+                    cb(&m.gameInsts[e], sr, m.gameInsts[e]._metrics);
+                }
+                if (dones[e * m.nPlayers]) m.ResetGame(g, nOld);
+            }
+            if (renderSender) {   // SkillTracker.cpp:147-151
+                RLGSC::GameState gs(states[0], m.tickSkip);
+                renderSender->Send(gs, m.match->actionParser->ParseActions(RLGSC::IList(picks.begin(), picks.begin() + m.nPlayers), gs));
+                if (!std::getenv("RLGPU_RENDER_NO_SLEEP")) std::this_thread::sleep_for(std::chrono::microseconds((int64_t)(m.tickSkip / 120.f * 1e6f)));
+            }
+        }
+        RG_LOG("New ratings:");
+        for (auto& pair : curRating.data) {
+            auto it = prevRating.data.find(pair.first);
+            if (it == prevRating.data.end()) continue;
+            const float delta = pair.second - it->second;
+            RG_LOG(" > " << pair.first << (pair.first.empty() ? "" : " ") << std::setprecision(6) << pair.second << " (" << (delta >= 0 ? "+" : "") << std::setprecision(4) << delta << ")");
+        }
+    } else {
+        RG_LOG(" > No old policies yet, skipping");
+    }
+
+    timestepsSinceVersionMade += timestepsDelta;
+    if (timestepsSinceVersionMade >= config.timestepsPerVersion) {   // SkillTracker.cpp:237-256
+        m.EnvCheck(rlgpu_env_reset(m.env, 1, m.obs), "reset");
+        timestepsSinceVersionMade = 0;
+        snapshot();
+        if ((int)m.old.size() > config.maxVersions) {
+            rlgpu_learner_destroy(m.old[0]);
+            m.old.erase(m.old.begin());
+            oldRatings.erase(oldRatings.begin());
+        }
+    }
+}
+
+// ---- "skill_rating" in RUNNING_STATS.json (Learner.cpp:185-194; SkillTracker.cpp:259-291) ----
+std::string SkillTracker::RatingsToJSON() const {
+    std::ostringstream o;
+    o << std::setprecision(9);
+    if (!config.perModeRatings) { auto it = curRating.data.find(""); o << (it == curRating.data.end() ? config.initialRating : it->second); return o.str(); }
+    o << "{";
+    bool first = true;
+    for (auto& pair : curRating.data) { o << (first ? "" : ", ") << "\"" << pair.first << "\": " << pair.second; first = false; }
+    o << "}";
+    return o.str();
+}
+
+SkillTracker::RatingSet SkillTracker::LoadRatingSet(const std::string& jsonValue, bool warn) {
+    constexpr const char* ERR_PREFIX = "RLGPC::SkillTracker::LoadRatingSet(): ";
+    RatingSet result;
+    size_t i = 0;
+    while (i < jsonValue.size() && isspace((unsigned char)jsonValue[i])) i++;
+    if (i < jsonValue.size() && jsonValue[i] == '{') {
+        if (config.perModeRatings) {
+            // "mode": number pairs
+            while ((i = jsonValue.find('"', i)) != std::string::npos) {
+                const size_t e = jsonValue.find('"', i + 1);
+                if (e == std::string::npos) break;
+                const std::string key = jsonValue.substr(i + 1, e - i - 1);
+                const size_t c = jsonValue.find(':', e);
+                if (c == std::string::npos) break;
+                result.data[key] = std::stof(jsonValue.substr(c + 1));
+                i = c + 1;
+            }
+            for (auto& mode : modeNames)
+                if (!result.data.count(mode)) {
+                    if (warn) RG_LOG(ERR_PREFIX << "Loaded ratings are missing mode \"" << mode << "\", rating will be set to initial rating.");
+                    result.data[mode] = config.initialRating;
+                }
+        } else {
+            if (warn) RG_LOG(ERR_PREFIX << "Loaded ratings are per-mode, but per-mode ratings are disabled. Rating will be set to initial rating.");
+            result.data[""] = config.initialRating;
+        }
+    } else {
+        const float v = std::stof(jsonValue.substr(i));
+        if (config.perModeRatings) {
+            if (warn) RG_LOG(ERR_PREFIX << "Loaded ratings are not per-mode, all mode ratings will be set to the loaded rating: " << v);
+            for (auto& mode : modeNames) result.data[mode] = v;
+        } else {
+            result.data[""] = v;
+        }
+    }
+    return result;
+}
+
+}  // namespace RLGPC

@@ -70,6 +70,11 @@ int main(int argc, char** argv) {
     cfg.ppo.autocastLearn = true;
     cfg.sendMetrics = true;    // JSON lines under ./metrics/<project>/<run id>.jsonl
     cfg.renderMode = argc > 6 && std::string(argv[6]) == "render";   // play the newest checkpoint for RocketSimVis instead of training
+    if (getenv("EXAMPLE_SKILL_TRACKER")) {   // ELO evaluation against stored versions of the policy, a new version every iteration
+        cfg.skillTrackerConfig.enabled = true; cfg.skillTrackerConfig.numEnvs = 4; cfg.skillTrackerConfig.simTime = 16; cfg.skillTrackerConfig.updateInterval = 1;
+        cfg.skillTrackerConfig.timestepsPerVersion = tsPerItr; cfg.skillTrackerConfig.maxVersions = 2;
+        cfg.timestepsPerSave = tsPerItr;   // every version has its checkpoint, so a resumed run finds them (Learner.cpp:311-370)
+    }
     cfg.checkpointSaveFolder = argc > 5 ? argv[5] : "";
     cfg.checkpointLoadFolder = cfg.checkpointSaveFolder;
 

@@ -6,6 +6,11 @@
 // usage: infer_unit_check <policy.lt> <critic.lt> <out.bin>
 #include <hip/hip_runtime.h>
 #include <RLGymPPO_CPP/Util/InferUnit.h>
+#include <RLGymPPO_CPP/Util/SkillTracker.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
+#include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
 #include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
 #include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
 #include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
@@ -90,8 +95,56 @@ static int obs_parity(int teamSize, int nEnvs, int steps, std::vector<GameState>
     return 0;
 }
 
+static EnvCreateResult EvalEnv() {
+    Match* match = new Match(new VelocityReward(), {new NoTouchCondition(40), new GoalScoreCondition()}, new DefaultOBS(), new DiscreteAction(), new RandomState(true, true, true), 1, true);
+    return {match, new Gym(match, 8)};
+}
+
+// SkillTracker: rating arithmetic, the rating (de)serialisation, version bookkeeping, and eval games on the device
+static int skill_tracker_check() {
+    RlgpuLearnerConfig lc{};
+    lc.obs_size = 89; lc.n_actions = 90; lc.n_policy_layers = 2; lc.n_critic_layers = 1; lc.policy_layers[0] = 64; lc.policy_layers[1] = 64; lc.critic_layers[0] = 16;
+    lc.clip_range = 0.2f; lc.temperature = 1; lc.seed_lo = 5; lc.max_rows = 256;
+    rlgpu_learner* lrn = nullptr;
+    CHECK(rlgpu_learner_create(&lrn, 0, &lc) == RLGPU_OK);
+    SkillTrackerConfig sc;
+    sc.enabled = true; sc.envCreateFunc = EvalEnv; sc.numEnvs = 3; sc.simTime = 12; sc.updateInterval = 2; sc.timestepsPerVersion = 1000; sc.maxVersions = 2;
+    int callbacks = 0;
+    sc.stepCallback = [&](GameInst* g, const Gym::StepResult& r, Report&) { callbacks += g->isEval && r.state.players.size() == 2 && r.reward.size() == 2; };
+    SkillTracker st(sc, lrn, 89, 90, {64, 64}, 123);
+    CHECK(st.modeName == "1v1" && st.curRating.data.at("1v1") == 1000.f && st.games.size() == 3);
+    // elo step (SkillTracker.cpp:72-86): equal ratings -> +-ratingInc/2; a 400 point favourite gains 1/11 of the increment
+    SkillTracker::RatingSet a, b; a.data["1v1"] = 1000; b.data["1v1"] = 1000;
+    st.UpdateRatings(a, b, true, true, "1v1");
+    CHECK(a.data["1v1"] == 1002.5f && b.data["1v1"] == 997.5f);
+    a.data["1v1"] = 1400; b.data["1v1"] = 1000;
+    st.UpdateRatings(a, b, true, false, "1v1");
+    CHECK(std::fabs(a.data["1v1"] - (1400 + 5.f / 11)) < 1e-3f && b.data["1v1"] == 1000);
+    // rating sets in RUNNING_STATS.json: per-mode object, bare number, missing mode (SkillTracker.cpp:259-291)
+    CHECK(st.LoadRatingSet("{\"1v1\": 1234.5, \"2v2\": 900}").data.at("1v1") == 1234.5f);
+    CHECK(st.LoadRatingSet("  1100.25\n}").data.at("1v1") == 1100.25f);
+    CHECK(st.LoadRatingSet("{\"3v3\": 1}", false).data.at("1v1") == 1000.f);
+    CHECK(st.RatingsToJSON() == "{\"1v1\": 1000}");
+    // run 0 evaluates (and stores the first version), run 1 is skipped by updateInterval, versions are capped at maxVersions
+    st.RunGames(600);
+    CHECK(st.NumOldPolicies() == 1 && st.oldRatings.size() == 1 && st.runCounter == 1);
+    const int stepsPerRun = (int)(12.f / 3 * 120 / 8);
+    CHECK(callbacks == 3 * stepsPerRun);
+    st.RunGames(600);
+    CHECK(callbacks == 3 * stepsPerRun && st.NumOldPolicies() == 1 && st.timestepsSinceVersionMade == 600);   // skipped entirely, like the reference's early return
+    st.RunGames(600);
+    CHECK(callbacks == 6 * stepsPerRun && st.NumOldPolicies() == 2 && st.timestepsSinceVersionMade == 0);
+    for (int i = 0; i < 4; i++) st.RunGames(1000);
+    CHECK(st.NumOldPolicies() == 2 && st.oldRatings.size() == 2);
+    for (auto& g : st.games) CHECK(g.oldPolicyIndex >= 0 && g.oldPolicyIndex < 2);
+    std::printf("skill tracker ok: rating %.3f after %d eval steps\n", st.curRating.data.at("1v1"), callbacks);
+    rlgpu_learner_destroy(lrn);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
+    if (skill_tracker_check()) return 1;
     std::vector<GameState> states; std::vector<ActionSet> prevs;
     if (obs_parity(1, 16, 120, &states, &prevs)) return 1;
     if (obs_parity(2, 8, 60, nullptr, nullptr)) return 1;

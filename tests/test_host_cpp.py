@@ -131,7 +131,7 @@ def test_infer_unit_and_host_obs_builders(tmp_path):
         d = np.array(dims, np.int32)
         assert lib.rlgpu_lt_write_model(path.encode(), d.ctypes.data, len(dims) - 1, flat.ctypes.data) == 0
     r = _run([os.path.join(PKG, "infer_unit_check"), pp, cp, out], timeout=600)
-    assert r.returncode == 0 and "infer unit ok" in r.stdout, r.stdout[-3000:]
+    assert r.returncode == 0 and "infer unit ok" in r.stdout and "skill tracker ok" in r.stdout, r.stdout[-3000:]
     raw = np.fromfile(out, np.uint8)
     n = int(raw[:4].view(np.int32)[0])
     rec = raw[4:].view(np.float32).reshape(n, 89 + 90 + 90 + 8 + 1)
@@ -147,3 +147,26 @@ def test_infer_unit_and_host_obs_builders(tmp_path):
         assert (act == table[int(np.argmax(want))]).all()
         v = R.mlp_forward(cri, cri_shapes, obs[None])[0].reshape(-1)[0]
         assert abs(val - v) < 1e-4 * max(1.0, abs(v))
+
+
+@pytest.mark.gpu
+def test_example_program_with_skill_tracker(tmp_path):
+    """GPU: ELO evaluation against stored versions while training; ratings land in the report, the metrics file and RUNNING_STATS.json;
+    a resumed run rebuilds its old versions from the older checkpoints (Learner.cpp:311-370)."""
+    import json
+    exe = os.path.join(PKG, "example_main")
+    ck = str(tmp_path / "ck")
+    env = dict(os.environ, EXAMPLE_SKILL_TRACKER="1")
+    r = _run([exe, "3", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("Running skill eval game(s)...") == 3 and r.stdout.count("New ratings:") == 3 and "Skill Rating 1v1" in r.stdout
+    saved = sorted(int(d) for d in os.listdir(ck))
+    assert saved == [4096, 8192, 12288]
+    stats = json.load(open(os.path.join(ck, "12288", "RUNNING_STATS.json")))
+    assert set(stats["skill_rating"]) == {"1v1"} and 900 < stats["skill_rating"]["1v1"] < 1100
+    mdir = tmp_path / "metrics" / "rlgymppo-cpp"
+    recs = [json.loads(l) for l in open(mdir / os.listdir(mdir)[0])][1:]
+    assert abs(recs[-1]["Skill Rating 1v1"] - stats["skill_rating"]["1v1"]) < 1e-3
+    r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "Attempting to load 2 old versions" in r.stdout and "[0]: Found at 8192" in r.stdout and "[1]: Found at 4096" in r.stdout, r.stdout[-4000:]
