@@ -432,6 +432,17 @@ __global__ void k_weight_shadows(const float* W, int N, int K, short* w16, int r
     }
 }
 
+// w16 [rows16][K] -> the order k_mlp_infer consumes it in: for every 32-row block cb and K step s (16 deep) the 64 lanes' 16-byte
+// MFMA B operands back to back (1 KB, one fully coalesced load):  wf[((cb * K/16 + s) * 64 + lane) * 8 + j] = W[cb*32 + (lane&31)][s*16 + 8*(lane>>5) + j]
+__global__ void k_weight_frags(const short* w16, int rows16, int K, short* wf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows16 * K) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const size_t blk = i >> 9;
+    const int nk = K / 16, s = (int)(blk % nk), cb = (int)(blk / nk);
+    wf[i] = w16[(size_t)(cb * 32 + (lane & 31)) * K + s * 16 + 8 * (lane >> 5) + j];
+}
+
 // column sums: out[n] += sum_m X[m][n]  (fp32 path; the bf16 path folds them into k_gemm_tn)
 __global__ void __launch_bounds__(256) k_col_sum(const float* X, int ld, int M, int N, float* out) {
     __shared__ float part[4][64];
@@ -450,48 +461,208 @@ __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 
 // one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]
-__global__ void k_policy_head(const float* logits, int ld, int rows, int A, float inv_temp, int deterministic, const float* noise,
-                              uint32_t seed_lo, uint32_t seed_hi, uint32_t call_ctr, int32_t* actions, float* logp, float* probs_out) {
+struct HeadArgs {
+    int A; float inv_temp; int deterministic; const float* noise;
+    uint32_t seed_lo, seed_hi, call_ctr;
+    int32_t* actions; float* logp; float* probs_out;
+};
+__device__ __forceinline__ void policy_head_row(const float* z /* logits of this row, global or LDS */, int row, int lane, const HeadArgs& h);
+
+__global__ void k_policy_head(const float* logits, int ld, int rows, HeadArgs h) {
     int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float* z = logits + (size_t)row * ld;
-    float v0 = lane < A ? z[lane] * inv_temp : -INFINITY;
-    float v1 = (lane + 64) < A ? z[lane + 64] * inv_temp : -INFINITY;
-    float mx = wave_max(fmaxf(v0, v1));
-    float e0 = lane < A ? expf(v0 - mx) : 0.f, e1 = (lane + 64) < A ? expf(v1 - mx) : 0.f;
-    float sum = wave_sum(e0 + e1);
-    float p0 = fminf(fmaxf(e0 / sum, 1e-11f), 1.f), p1 = fminf(fmaxf(e1 / sum, 1e-11f), 1.f);
-    if (probs_out) {
-        if (lane < A) probs_out[(size_t)row * A + lane] = p0;
-        if (lane + 64 < A) probs_out[(size_t)row * A + lane + 64] = p1;
+    policy_head_row(logits + (size_t)row * ld, row, lane, h);
+}
+
+// NR rows at once: the head is a chain of cross-lane steps (two reductions, an arg-max butterfly), each a ~100-cycle round trip;
+// rows are independent, so a wavefront that owns several interleaves them and the round trips overlap.  Per row the arithmetic
+// is the same for every NR.
+template <int NR>
+__device__ __forceinline__ void policy_head_rows(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h) {
+    const int A = h.A; const float inv_temp = h.inv_temp; const int deterministic = h.deterministic; const float* noise = h.noise;
+    int32_t* actions = h.actions; float* logp = h.logp; float* probs_out = h.probs_out;
+    const bool in0 = lane < A, in1 = (lane + 64) < A;
+    float v0[NR], v1[NR], mx[NR], e0[NR], e1[NR], sum[NR], p0[NR], p1[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        v0[n] = in0 ? z[n][lane] * inv_temp : -INFINITY;
+        v1[n] = in1 ? z[n][lane + 64] * inv_temp : -INFINITY;
+        mx[n] = fmaxf(v0[n], v1[n]);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], o, 64));
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        e0[n] = in0 ? expf(v0[n] - mx[n]) : 0.f; e1[n] = in1 ? expf(v1[n] - mx[n]) : 0.f;
+        sum[n] = e0[n] + e1[n];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) sum[n] += __shfl_xor(sum[n], o, 64);
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        p0[n] = fminf(fmaxf(e0[n] / sum[n], 1e-11f), 1.f); p1[n] = fminf(fmaxf(e1[n] / sum[n], 1e-11f), 1.f);
+        if (probs_out) {
+            if (in0) probs_out[(size_t)row[n] * A + lane] = p0[n];
+            if (in1) probs_out[(size_t)row[n] * A + lane + 64] = p1[n];
+        }
     }
     if (!actions) return;
-    float s0, s1;
-    if (deterministic) { s0 = p0; s1 = p1; }
-    else {
-        float q0, q1;
-        if (noise) { q0 = lane < A ? noise[(size_t)row * A + lane] : 1.f; q1 = (lane + 64) < A ? noise[(size_t)row * A + lane + 64] : 1.f; }
+    float best[NR]; int bi[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        float s0, s1;
+        if (deterministic) { s0 = p0[n]; s1 = p1[n]; }
         else {
-            uint32_t r[4];
-            rlg::philox4(seed_lo, seed_hi, (uint32_t)row, call_ctr, (uint32_t)lane, r);
-            // q ~ Exp(1): -log(1 - u), u in [0,1)
-            q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
-            q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
+            float q0, q1;
+            if (noise) { q0 = in0 ? noise[(size_t)row[n] * A + lane] : 1.f; q1 = in1 ? noise[(size_t)row[n] * A + lane + 64] : 1.f; }
+            else {
+                uint32_t r[4];
+                rlg::philox4(h.seed_lo, h.seed_hi, (uint32_t)row[n], h.call_ctr, (uint32_t)lane, r);
+                // q ~ Exp(1): -log(1 - u), u in [0,1)
+                q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
+                q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
+            }
+            s0 = p0[n] / q0; s1 = p1[n] / q1;
         }
-        s0 = p0 / q0; s1 = p1 / q1;
+        if (!in0) s0 = -INFINITY;
+        if (!in1) s1 = -INFINITY;
+        best[n] = s0; bi[n] = lane;
+        if (s1 > best[n]) { best[n] = s1; bi[n] = lane + 64; }
     }
-    if (lane >= A) s0 = -INFINITY;
-    if (lane + 64 >= A) s1 = -INFINITY;
     // argmax with lowest-index tie break (torch.argmax / max semantics)
-    float best = s0; int bi = lane;
-    if (s1 > best) { best = s1; bi = lane + 64; }
-    for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
+            float ob = __shfl_xor(best[n], o, 64); int oi = __shfl_xor(bi[n], o, 64);
+            if (ob > best[n] || (ob == best[n] && oi < bi[n])) { best[n] = ob; bi[n] = oi; }
+        }
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        float pa = (bi[n] < 64) ? __shfl(p0[n], bi[n], 64) : __shfl(p1[n], bi[n] - 64, 64);
+        if (lane == 0) { actions[row[n]] = bi[n]; logp[row[n]] = deterministic ? 0.f : logf(pa); }
     }
-    float pa = (bi < 64) ? __shfl(p0, bi, 64) : __shfl(p1, bi - 64, 64);
-    if (lane == 0) { actions[row] = bi; logp[row] = deterministic ? 0.f : logf(pa); }
+}
+__device__ __forceinline__ void policy_head_row(const float* z, int row, int lane, const HeadArgs& h) {
+    const float* const zs[1] = {z}; const int rows[1] = {row};
+    policy_head_rows<1>(zs, rows, lane, h);
+}
+
+// ---- fused MLP inference (bf16 path): obs -> [Linear+ReLU]* -> Linear -> head, ONE launch --------------------------------
+// Collection calls the policy once per gym step on n_agents rows (8192): as separate kernels that is input staging + one GEMM per
+// layer + the head, ~45 us of kernels and as much again in launch gaps next to a ~670 us env step.  Here a workgroup owns 32 rows:
+// their activations never leave LDS (two ping-pong buffers), each of the 4 wavefronts computes 32-column blocks of the layer
+// output, taking the A operand from LDS and the B operand (the bf16 weight shadow, K-contiguous rows) straight from L2 with one
+// 16-byte load per lane and K step.  Same operand values, accumulation order, bias / ReLU / rounding as k_gemm_nt, so the logits
+// are those of the unfused path; the head is the same code (policy_head_row) reading the logits from LDS.
+constexpr int FI_ROWS = 32;          // rows per workgroup
+constexpr int FI_WAVES = 8;          // wavefronts per workgroup: one 32-column block of a 256-wide layer each
+constexpr int FI_LOGIT_LD = 132;     // fp32 logits row in LDS (n_actions <= 128)
+constexpr int FI_CHUNK = 16;         // K steps (of 16) whose B operands are in flight together: a whole 256-deep reduction
+struct FusedInferArgs {
+    const float* obs; int D, rows, n_layers;
+    const short* W[9]; const float* bias[9]; int K[9], N[9], Npad[9];   // layer i: W = the fragment-ordered weight shadow (k_weight_frags), K = kp[i], N = dims[i+1], Npad = kp[i+1]
+    int ld;                          // LDS activation row (elements): max kp + 8
+    int buf_elems;                   // elements (shorts) per ping-pong buffer
+    int mode;                        // 0: policy head, 1: values[row] = output column 0
+    float* values;
+    HeadArgs head;
+    unsigned long long* stamps;      // debug: phase clock stamps of workgroup 0 / wavefront 0 (NULL in production)
+};
+
+// The kernel is a chain of short dependent phases (a layer is 16 MFMAs per wavefront), so what matters is latency: every
+// wavefront asks for the weights of its NEXT column block before it starts the MFMAs of the current one -- they do not depend on
+// the activations -- and the loads land under the MFMAs, the epilogue and the barrier.
+__global__ void __launch_bounds__(64 * FI_WAVES) k_mlp_infer(FusedInferArgs g) {
+    extern __shared__ __attribute__((aligned(16))) short fi_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * FI_ROWS;
+    short* in = fi_smem;
+    short* out = fi_smem + g.buf_elems;
+    auto n_blocks = [&](int i) { return (i == g.n_layers - 1) ? (g.N[i] + 31) / 32 : g.Npad[i] / 32; };
+    // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7
+    auto fetch = [&](bf16x8 (&b)[FI_CHUNK], int i, int cb, int s0) {
+        const int nk = g.K[i] / 16;
+        const short* w = g.W[i] + ((size_t)cb * nk * 64 + lane) * 8;   // fragment order (k_weight_frags): 1 KB per (block, K step)
+#pragma unroll
+        for (int j = 0; j < FI_CHUNK; j++)
+            if (s0 + j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(s0 + j) * 512);
+    };
+    int n_stamp = 0;
+    auto stamp = [&]() { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); };
+    stamp();
+    bf16x8 bnext[FI_CHUNK];
+    if (wave < n_blocks(0)) fetch(bnext, 0, wave, 0);
+    // fp32 observations -> bf16, zero padded to K[0] columns (k_rows_to_bf16)
+    for (int r = wave; r < FI_ROWS; r += FI_WAVES)
+        for (int c = lane; c < g.K[0]; c += 64) {
+            float v = 0.f;
+            if (m0 + r < g.rows && c < g.D) v = g.obs[(size_t)(m0 + r) * g.D + c];
+            in[r * g.ld + c] = f2bf(v);
+        }
+    __syncthreads();
+    stamp();
+    for (int i = 0; i < g.n_layers; i++) {
+        const bool last = (i == g.n_layers - 1);
+        const int K = g.K[i], N = g.N[i], nk = K / 16, nblk = n_blocks(i);
+        float* const logits = reinterpret_cast<float*>(out);
+        const short* arow = in + (lane & 31) * g.ld + 8 * (lane >> 5);
+        bool prefetched_next = false;
+        for (int cb = wave; cb < nblk; cb += FI_WAVES) {
+            bf16x8 b[FI_CHUNK];
+            if (cb == wave) {
+#pragma unroll
+                for (int j = 0; j < FI_CHUNK; j++) b[j] = bnext[j];
+            } else fetch(b, i, cb, 0);
+            if (cb + FI_WAVES >= nblk && !last && wave < n_blocks(i + 1)) { fetch(bnext, i + 1, wave, 0); prefetched_next = true; }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int s0 = 0; s0 < nk; s0 += FI_CHUNK) {
+                if (s0 > 0) fetch(b, i, cb, s0);   // reductions deeper than 256: the rest arrives chunk by chunk
+#pragma unroll
+                for (int j = 0; j < FI_CHUNK; j++) {
+                    if (s0 + j >= nk) break;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + (s0 + j) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc, 0, 0, 0);
+                }
+            }
+            // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+            const int col = cb * 32 + (lane & 31);
+            const float bias = (col < N) ? g.bias[i][col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = acc[r] + bias;
+                if (last) logits[row * FI_LOGIT_LD + col] = v;
+                else out[row * g.ld + col] = (col < N) ? f2bf(fmaxf(v, 0.f)) : (short)0;
+            }
+        }
+        if (!prefetched_next && !last && wave < n_blocks(i + 1)) fetch(bnext, i + 1, wave, 0);   // a wavefront without a block in this layer
+        __syncthreads();
+        stamp();
+        short* t = in; in = out; out = t;
+    }
+    const float* logits = reinterpret_cast<const float*>(in);   // the last layer wrote into what is now `in`
+    if (g.mode == 1) {
+        if (tid < FI_ROWS && m0 + tid < g.rows) g.values[m0 + tid] = logits[tid * FI_LOGIT_LD];
+        return;
+    }
+    {   // the wavefront's FI_ROWS / FI_WAVES rows together (rows past the end redo the last real one: same values, same stores)
+        constexpr int NR = FI_ROWS / FI_WAVES;
+        const float* zs[NR]; int rows[NR];
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
+            int r = wave + n * FI_WAVES;
+            if (m0 + r >= g.rows) r = g.rows - 1 - m0;
+            zs[n] = logits + r * FI_LOGIT_LD; rows[n] = m0 + r;
+        }
+        const float* const (&zc)[NR] = reinterpret_cast<const float* const (&)[NR]>(zs);
+        policy_head_rows<NR>(zc, rows, lane, g.head);
+    }
+    stamp();
 }
 
 // GAE: one lane per agent trajectory (column j of the time-major arrays), reverse scan over T (TorchFuncs.cpp:23-43)
@@ -640,7 +811,7 @@ struct Net {
     int64_t n_params = 0;
     // bf16 fast path: padded leading dims and the offsets (in elements) of the weight shadows inside rlgpu_learner::shadows
     int kp[10] = {0};              // kp[i] = round_up(dims[i], 32): leading dim of layer i's bf16 input / of its gradient
-    int64_t w16_off[9] = {0}, wt16_off[9] = {0};
+    int64_t w16_off[9] = {0}, wt16_off[9] = {0}, wf16_off[9] = {0};   // wf16: w16 re-ordered into MFMA B fragments (k_mlp_infer)
     int w16_rows[9] = {0}, wt16_rows[9] = {0};   // row counts padded to the 128-wide N tile
 };
 
@@ -783,6 +954,7 @@ void plan_shadows(Net& n, int64_t& off) {
         n.w16_off[i] = off; off += (int64_t)n.w16_rows[i] * n.kp[i];
         n.wt16_rows[i] = round_up(n.dims[i], 128);      // B operand of the dX GEMM: W^T as [K_in padded][kp[i+1]]
         n.wt16_off[i] = off; off += (int64_t)n.wt16_rows[i] * n.kp[i + 1];
+        n.wf16_off[i] = off; off += (int64_t)n.w16_rows[i] * n.kp[i];
     }
 }
 
@@ -793,6 +965,10 @@ int refresh_shadows(rlgpu_learner* l) {
             size_t tot = (size_t)n->w16_rows[i] * n->kp[i] + (size_t)n->wt16_rows[i] * n->kp[i + 1];
             hipLaunchKernelGGL(k_weight_shadows, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
                                l->shadows + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
+            LCHK(l, hipGetLastError());
+            const size_t nf = (size_t)n->w16_rows[i] * n->kp[i];
+            hipLaunchKernelGGL(k_weight_frags, dim3((nf + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->w16_off[i]), n->w16_rows[i], n->kp[i],
+                               l->shadows + n->wf16_off[i]);
             LCHK(l, hipGetLastError());
         }
     }
@@ -987,19 +1163,51 @@ int rlgpu_learner_set_adam_state(rlgpu_learner* l, const float* hm, const float*
     l->step_p = sp; l->step_c = sc; return RLGPU_OK;
 }
 
+// the fused inference kernel (k_mlp_infer) covers this net?  (bf16 path, LDS for two activation buffers, head width)
+// the fused inference kernel (k_mlp_infer) covers this net?  (bf16 path, LDS for two activation buffers, head width)
+static size_t fused_smem(const Net& net) {
+    int maxkp = 0;
+    for (int i = 0; i < net.n_layers; i++) maxkp = std::max(maxkp, net.kp[i]);
+    return (size_t)std::max(FI_ROWS * (maxkp + 8), FI_ROWS * FI_LOGIT_LD * 2) * 2 * sizeof(short);
+}
+static bool fused_infer_fits(const rlgpu_learner* l, const Net& net, int out_dim) {
+    if (!l->cfg.use_bf16 || getenv("RLGPU_NO_FUSED_INFER")) return false;
+    return out_dim <= 128 && net.n_layers <= 9 && fused_smem(net) <= 65536;   // the default dynamic-LDS limit of a launch
+}
+static int launch_fused_infer(rlgpu_learner* l, const Net& net, const float* obs, int rows, int mode, float* values, const HeadArgs& head) {
+    int rc = refresh_shadows(l);
+    if (rc) return rc;
+    FusedInferArgs g{};
+    g.obs = obs; g.D = l->cfg.obs_size; g.rows = rows; g.n_layers = net.n_layers;
+    int maxkp = 0;
+    for (int i = 0; i < net.n_layers; i++) {
+        g.W[i] = l->shadows + net.wf16_off[i]; g.bias[i] = l->params + net.b_off[i];
+        g.K[i] = net.kp[i]; g.N[i] = net.dims[i + 1]; g.Npad[i] = net.kp[i + 1];
+        maxkp = std::max(maxkp, net.kp[i]);
+    }
+    g.ld = maxkp + 8;
+    g.buf_elems = std::max(FI_ROWS * g.ld, FI_ROWS * FI_LOGIT_LD * 2);
+    g.mode = mode; g.values = values; g.head = head;
+    g.stamps = (mode == 0 && getenv("RLGPU_FUSED_STAMPS")) ? reinterpret_cast<unsigned long long*>(l->grads) : nullptr;   // debug: lands in the gradient buffer (tools/fused_infer_check.py)
+    hipLaunchKernelGGL(k_mlp_infer, dim3((rows + FI_ROWS - 1) / FI_ROWS), dim3(64 * FI_WAVES), fused_smem(net), l->stream, g);
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+
 static int policy_head(rlgpu_learner* l, const float* obs, int rows, int deterministic, const float* noise, int32_t* actions, float* logp, float* probs) {
     if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
     int rc;
+    const int A = l->cfg.n_actions;
+    const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+    HeadArgs h{A, inv_t, deterministic, noise, l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, actions, logp, probs};
+    l->call_ctr++;
+    if (fused_infer_fits(l, l->pol, A)) return launch_fused_infer(l, l->pol, obs, rows, 0, nullptr, h);
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), rows); }
     else rc = net_forward(l, l->pol, l->act_p, obs, rows);
     if (rc) return rc;
-    int A = l->cfg.n_actions;
     dim3 grid((rows + 3) / 4), block(256);
-    float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
-    hipLaunchKernelGGL(k_policy_head, grid, block, 0, l->stream, (const float*)l->act_p.back(), A, rows, A, inv_t, deterministic, noise,
-                       l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, actions, logp, probs);
-    l->call_ctr++;
+    hipLaunchKernelGGL(k_policy_head, grid, block, 0, l->stream, (const float*)l->act_p.back(), A, rows, h);
     LCHK(l, hipGetLastError());
     return RLGPU_OK;
 }
@@ -1013,6 +1221,9 @@ int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* val
     if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
     int rc;
+    // few rows (per-step inference sizes): one fused launch; the big once-per-iteration sweeps stay on the tiled GEMMs, which read
+    // the weights once per 128 rows instead of once per 32
+    if (rows <= 16384 && fused_infer_fits(l, l->cri, 1)) return launch_fused_infer(l, l->cri, obs, rows, 1, values, HeadArgs{});
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), rows); }
     else rc = net_forward(l, l->cri, l->act_c, obs, rows);
     if (rc) return rc;
