@@ -14,6 +14,7 @@ import ctypes as C
 import json
 import os
 import shutil
+import threading
 import time
 from dataclasses import dataclass, field
 
@@ -279,6 +280,25 @@ class Learner:
         self.ex_obs[r].copy_(flat_obs[:self.B]); self.ex_act[r].copy_(self.act_buf.view(-1)); self.ex_logp[r].copy_(self.logp_buf.view(-1))
         self.ex_adv[r].copy_(adv.view(-1)); self.ex_tgt[r].copy_(tgt.view(-1))
 
+    def _start_draw(self):
+        """Draw the next permutation of the FIFO into the pinned buffer `_rows_flip` points at, on a worker thread."""
+        buf = self._rows_host[self._rows_flip].numpy()
+        box = {}
+
+        def work():
+            box["n"] = self.fifo.shuffled_rows(self.shuffler, buf)
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        self._next_rows = (t, box)
+
+    def _take_draw(self):
+        if self._next_rows is None:
+            self._start_draw()
+        t, box = self._next_rows
+        t.join()
+        self._next_rows = None
+        return box["n"]
+
     # ---- PPOLearner::Learn (PPOLearner.cpp:67-349) ----------------------------------------------------------------
     def learn(self):
         p = self.cfg.ppo
@@ -286,15 +306,21 @@ class Learner:
         self.metrics.zero_()
         n_mb = 0; n_updates = 0
         for ep in range(p.epochs):
-            # shuffled logical (oldest first, agent-major) FIFO indices (ExperienceBuffer.cpp:106-121) as device rows.  The draw does
-            # not depend on data, so the NEXT one is made right after this epoch's launches, while the GPU is busy with them.
-            if self._next_rows is None:
-                self._next_rows = self.fifo.shuffled_rows(self.shuffler, self._rows_host[self._rows_flip].numpy())
-            cur = self._next_rows
-            self._next_rows = None
+            # shuffled logical (oldest first, agent-major) FIFO indices (ExperienceBuffer.cpp:106-121) as device rows.  A draw does not
+            # depend on data, only on the FIFO's bookkeeping: the NEXT one is made by a worker thread (the library call releases the
+            # GIL) while this thread launches the epoch and the GPU runs it -- 2-3 ms of std::shuffle per 262 144 rows otherwise sit
+            # between the last kernel of one iteration and the first of the next.
+            cur = self._take_draw()
             idx = self._rows_dev
             idx[:cur].copy_(self._rows_host[self._rows_flip][:cur], non_blocking=True)
             self._rows_ev[self._rows_flip] = torch.cuda.Event(); self._rows_ev[self._rows_flip].record()
+            self._rows_flip ^= 1
+            if self._rows_ev[self._rows_flip] is not None:
+                self._rows_ev[self._rows_flip].synchronize()   # its last upload has left the pinned buffer
+            if ep == p.epochs - 1:
+                # the next draw is over the FIFO as it will be after the next submit; the bookkeeping is data-free, so do it now
+                self._pending_slot = self.fifo.submit()
+            self._start_draw()
             for b in range(cur // self.batch_size):            # remainder rows are skipped (Q5)
                 self.ppo.zero_grads()
                 base = b * self.batch_size
@@ -304,13 +330,6 @@ class Learner:
                 scale = parallel.allreduce_gradients(self.ppo.grad_tensor(), self.world)   # ONE RCCL all-reduce per optimizer step
                 self.ppo.clip_adam_step(0.5, scale)
                 n_updates += 1
-            self._rows_flip ^= 1
-            if self._rows_ev[self._rows_flip] is not None:
-                self._rows_ev[self._rows_flip].synchronize()   # its last upload has left the pinned buffer
-            if ep == p.epochs - 1:
-                # the next draw is over the FIFO as it will be after the next submit; the bookkeeping is data-free, so do it now
-                self._pending_slot = self.fifo.submit()
-            self._next_rows = self.fifo.shuffled_rows(self.shuffler, self._rows_host[self._rows_flip].numpy())   # prefetch (CPU) under the GPU work
         self.total_epochs += p.epochs
         self.cumulative_model_updates += n_updates
         self._n_mb = n_mb
