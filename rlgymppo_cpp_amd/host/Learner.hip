@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <numeric>
 #include <thread>
 
@@ -125,7 +126,26 @@ struct Learner::Impl {
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     std::vector<GameInst> games;
     std::vector<RlgpuArenaState> hostStates; std::vector<float> hostRew; std::vector<int32_t> hostDone;
-    std::vector<int64_t> perm; std::vector<int32_t> phys;
+    // the permutation of the NEXT epoch is drawn by a worker while this thread launches the current one (a draw depends on the
+    // FIFO's bookkeeping only): 2-3 ms of std::shuffle per 262 144 rows that would otherwise leave the GPU idle
+    std::vector<int32_t> phys[2]; int physFlip = 0;
+    std::future<int64_t> nextDraw; bool drawPending = false;
+    int pendingSlot = -1;
+    void StartDraw() {
+        int32_t* buf = phys[physFlip].data();
+        nextDraw = std::async(std::launch::async, [this, buf]() -> int64_t {
+            const int64_t cur = rlgpu_expbuf_size(fifo);
+            return rlgpu_expbuf_shuffled_rows(fifo, shuf, buf) == RLGPU_OK ? cur : -1;
+        });
+        drawPending = true;
+    }
+    int64_t TakeDraw() {
+        if (!drawPending) StartDraw();
+        drawPending = false;
+        const int64_t cur = nextDraw.get();
+        if (cur < 0) RG_ERR_CLOSE("ExperienceBuffer: shuffle failed");
+        return cur;
+    }
     Timer iterTimer;
 
     void EnvCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
@@ -197,7 +217,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.logp = dev_alloc<float>(TN); m.rew = dev_alloc<float>(TN); m.doneF = dev_alloc<float>(TN); m.trunc = dev_alloc<float>(TN);
     m.adv = dev_alloc<float>(TN); m.tgt = dev_alloc<float>(TN); m.ret = dev_alloc<float>(TN);
     m.vals = dev_alloc<float>(TN + m.nAgents); m.metrics = dev_alloc<float>(8); m.scratch = dev_alloc<float>(8);
-    m.phys.resize(EX);
+    m.phys[0].resize(EX); m.phys[1].resize(EX);
     m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
 
     if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
@@ -219,6 +239,7 @@ Learner::~Learner() {
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
                     (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
+    if (m.drawPending) m.nextDraw.wait();
     delete skillTracker; delete metricSender; delete renderSender;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
@@ -323,8 +344,9 @@ void Learner::AddNewExperience(Report& report) {
     report["Avg Return"] = sums[0] / retStd; report["Avg Advantage"] = sums[1]; report["Avg Val Target"] = sums[2];
     report["Average Step Reward"] = h[3] / (float)TN;
     // ExperienceBuffer::SubmitExperience (Learner.cpp:694-702): this iteration's rows join the FIFO
-    int slot = 0;
-    if (rlgpu_expbuf_submit(m.fifo, &slot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");
+    int slot = m.pendingSlot;   // LearnPPO already accounted for this iteration when it drew the permutation ahead
+    m.pendingSlot = -1;
+    if (slot < 0 && rlgpu_expbuf_submit(m.fifo, &slot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");
     const size_t o = (size_t)slot * TN;
     HOST_HIP(hipMemcpyAsync(m.exObs + o * m.D, m.obs, TN * m.D * 4, hipMemcpyDeviceToDevice, nullptr));
     HOST_HIP(hipMemcpyAsync(m.exActs + o, m.acts, TN * 4, hipMemcpyDeviceToDevice, nullptr));
@@ -342,9 +364,11 @@ void Learner::LearnPPO(Report& report) {
     for (int ep = 0; ep < config.ppo.epochs; ep++) {
         // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126) over the whole FIFO: logical rows are oldest iteration
         // first and agent-major inside one (trajectory after trajectory); the device slots are time-major
-        const int64_t cur = rlgpu_expbuf_size(m.fifo);
-        if (rlgpu_expbuf_shuffled_rows(m.fifo, m.shuf, m.phys.data()) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: shuffle failed");
-        HOST_HIP(hipMemcpyAsync(m.idx, m.phys.data(), (size_t)cur * 4, hipMemcpyHostToDevice, nullptr));
+        const int64_t cur = m.TakeDraw();
+        HOST_HIP(hipMemcpyAsync(m.idx, m.phys[m.physFlip].data(), (size_t)cur * 4, hipMemcpyHostToDevice, nullptr));   // pageable source: staged before the call returns
+        m.physFlip ^= 1;
+        if (ep == config.ppo.epochs - 1 && rlgpu_expbuf_submit(m.fifo, &m.pendingSlot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");   // the next draw sees the FIFO after the next submit
+        m.StartDraw();
         for (int64_t b = 0; b + m.batch <= cur; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
             m.LrnCheck(rlgpu_zero_grads(m.lrn), "zero_grads");
             for (int64_t k = 0; k < m.batch; k += m.mini) {
