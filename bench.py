@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--fp32", action="store_true", help="fp32 MFMA instead of bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="LearnerConfig.collectionDuringLearn: the PPO epochs run on their own stream under the next collection (not the headline mode)")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +103,7 @@ def main():
     from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
     n_agents = args.envs * 2
     B = n_agents * args.horizon
-    cfg = LearnerConfig(numEnvs=args.envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, device=local_rank, randomSeed=123,
+    cfg = LearnerConfig(numEnvs=args.envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, device=local_rank, randomSeed=123, collectionDuringLearn=args.overlap,
                         ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=args.epochs, policyLR=2e-4, criticLR=2e-4, entCoef=0.01,
                                              autocastLearn=not args.fp32))
     L = Learner(cfg, rank=rank, world_size=world)
@@ -119,12 +120,13 @@ def main():
     cs = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        L.collect()
-        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-        c0.record()   # the library launches on the null stream, which is torch's current stream here
-        L.add_new_experience()
-        L.learn()
-        c1.record()
+        with torch.cuda.stream(L.s_collect):
+            L.collect()
+            c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+            c0.record()   # the library launches on the null stream, which is torch's current stream here
+            L.add_new_experience()
+            L.learn()
+            c1.record()
         cs.append((c0, c1))
     barrier()
     elapsed = time.perf_counter() - t0
@@ -149,8 +151,9 @@ def main():
                                    "T=%d steps/iter, B=%d agent-steps/GPU, minibatch %d, epochs %d, MLP 256x3 policy(90)+critic, %s arena mesh"
                                    % (args.envs, args.horizon, B, B // 4, args.epochs, L.env.mesh_kind),
                        "envs_per_gpu": args.envs, "horizon": args.horizon, "batch": B, "minibatch": B // 4, "epochs": args.epochs},
-            "ppo_iter_ms": consume_ms, "gym_steps_per_s": value / 2, "physics_ticks_per_s": value / 2 * 8,
-            "collect_ms_per_iter": elapsed / args.steps * 1e3 - consume_ms,
+            "collection_during_learn": bool(args.overlap),
+            "ppo_iter_ms": consume_ms if not args.overlap else None, "gym_steps_per_s": value / 2, "physics_ticks_per_s": value / 2 * 8,
+            "collect_ms_per_iter": (elapsed / args.steps * 1e3 - consume_ms) if not args.overlap else None,
             "roofline": {"kernel": "k_env_step<2> (8 fused ticks + snapshot/obs/reward/done/auto-reset)", "bound": "hbm", "achieved": achieved, "peak": peak,
                          "unit": "GB/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": env_ms / max(1, env_launches), "launches": env_launches,
                          "algorithmic_bytes_per_launch": per_launch_bytes},

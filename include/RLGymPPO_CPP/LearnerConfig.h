@@ -20,7 +20,7 @@ struct LearnerConfig {
     int maxReturnsPerStatsInc = 150;
     int stepsPerObsStatsInc = 5;
     bool deterministic = false;
-    bool collectionDuringLearn = false; // not built
+    bool collectionDuringLearn = false; // honoured by the Python host (learner.py); this C++ Learner keeps the default behaviour
     PPOLearnerConfig ppo = {};
     float gaeLambda = 0.95f;
     float gaeGamma = 0.99f;

@@ -160,6 +160,10 @@ int rlgpu_zero_grads(rlgpu_learner* l);
  * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
 int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale);
 int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
+/* bf16 mode: rebuild the bf16 weight copies the GEMMs read NOW, on the learner's stream (they are otherwise rebuilt lazily by the next
+ * forward pass).  For LearnerConfig::collectionDuringLearn: the learning stream calls it after every optimizer step, so that inference on
+ * the collection stream reads the live weights like the reference's agent threads do (ThreadAgent.cpp:72-103). */
+int rlgpu_learner_refresh_shadows(rlgpu_learner* l);
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float temperature);   /* DiscretePolicy::temperature, set per call by InferUnit (InferUnit.cpp:68,95) */
 int rlgpu_learner_sync(rlgpu_learner* l);
 /* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rlgpu_clip_adam_step": (_i, [_vp, _f, _f]),
     "rlgpu_learner_set_lr": (_i, [_vp, _f, _f]),
     "rlgpu_learner_set_temperature": (_i, [_vp, _f]),
+    "rlgpu_learner_refresh_shadows": (_i, [_vp]),
     "rlgpu_learner_sync": (_i, [_vp]),
     "rlgpu_learner_last_gemm": (_i, [_vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "rlgpu_env_timing_total": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), _i]),

@@ -1221,9 +1221,10 @@ int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* val
     if (rows <= 0 || rows > l->cfg.max_rows) { l->err = "rows out of range (max_rows)"; return RLGPU_ERR_ARG; }
     LCHK(l, hipSetDevice(l->device));
     int rc;
-    // few rows (per-step inference sizes): one fused launch; the big once-per-iteration sweeps stay on the tiled GEMMs, which read
-    // the weights once per 128 rows instead of once per 32
-    if (rows <= 16384 && fused_infer_fits(l, l->cri, 1)) return launch_fused_infer(l, l->cri, obs, rows, 1, values, HeadArgs{});
+    // one fused launch; it also keeps this call off the activation scratch, so it may run on another stream than a PPO epoch
+    // (collectionDuringLearn).  RLGPU_FUSED_VALUE_ROWS caps the row count that takes this path (experiments).
+    static const int fused_cap = getenv("RLGPU_FUSED_VALUE_ROWS") ? atoi(getenv("RLGPU_FUSED_VALUE_ROWS")) : 0x7fffffff;
+    if (rows <= fused_cap && fused_infer_fits(l, l->cri, 1)) return launch_fused_infer(l, l->cri, obs, rows, 1, values, HeadArgs{});
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), rows); }
     else rc = net_forward(l, l->cri, l->act_c, obs, rows);
     if (rc) return rc;
@@ -1334,6 +1335,7 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     return RLGPU_OK;
 }
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }
+int rlgpu_learner_refresh_shadows(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); return l->cfg.use_bf16 ? refresh_shadows(l) : RLGPU_OK; }
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float t) { if (!(t > 0)) return RLGPU_ERR_ARG; l->cfg.temperature = t; return RLGPU_OK; }
 int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {

@@ -51,6 +51,7 @@ class LearnerConfig:  # PUB/LearnerConfig.h:14-80
     standardizeReturns: bool = True
     maxReturnsPerStatsInc: int = 150
     deterministic: bool = False
+    collectionDuringLearn: bool = False   # LearnerConfig.h:46-50: the PPO epochs of iteration k run while iteration k+1 is collected
     ppo: PPOLearnerConfig = field(default_factory=PPOLearnerConfig)
     gaeLambda: float = 0.95
     gaeGamma: float = 0.99
@@ -232,6 +233,14 @@ class Learner:
         self.report = {}
         self.iteration_callback = None
         self.run_id = ""
+        # collectionDuringLearn: the PPO epochs go to their own HIP stream and the next collection does not wait for them.  Like the
+        # reference's agent threads (ThreadAgent.cpp:72-103) the collector then reads whatever weights are there, mid-update included.
+        self.s_collect = torch.cuda.current_stream(self.dev)
+        self.s_learn = torch.cuda.Stream(self.dev) if cfg.collectionDuringLearn else None
+        self._learn_done = None
+        if self.s_learn is not None and os.environ.get("RLGPU_COLLECT_SIDE_STREAM"):
+            self.s_collect = torch.cuda.Stream(self.dev)      # experiment: collection off the null stream too
+            self.env.set_stream(self.s_collect); self.ppo.set_stream(self.s_collect)
         self.metric_sender = None   # created by run() after a possible load(), so that a loaded run id continues (Learner.cpp:149-155)
         self.env.reset(True, self.obs_buf[0])
         self._first = True
@@ -274,6 +283,8 @@ class Learner:
         self.report["Avg Advantage"] = float(adv.abs().mean().item())
         self.report["Avg Val Target"] = float(tgt.abs().mean().item())
         # ExperienceBuffer::SubmitExperience (Learner.cpp:694-702): this iteration's rows join the FIFO
+        if self._learn_done is not None:
+            self.s_collect.wait_event(self._learn_done)     # the epochs still running on the learn stream read the slots this may overwrite
         slot = self._pending_slot if self._pending_slot is not None else self.fifo.submit()
         self._pending_slot = None
         r = slice(slot * self.B, (slot + 1) * self.B)
@@ -301,6 +312,20 @@ class Learner:
 
     # ---- PPOLearner::Learn (PPOLearner.cpp:67-349) ----------------------------------------------------------------
     def learn(self):
+        if self.s_learn is None:
+            return self._learn_epochs()
+        ready = torch.cuda.Event(); ready.record(self.s_collect)    # this iteration's rows are in their FIFO slot
+        self.s_learn.wait_event(ready)
+        self.ppo.set_stream(self.s_learn)
+        try:
+            with torch.cuda.stream(self.s_learn):
+                n = self._learn_epochs()
+                self._learn_done = torch.cuda.Event(); self._learn_done.record(self.s_learn)
+        finally:
+            self.ppo.set_stream(self.s_collect if self.s_collect.cuda_stream != 0 else None)
+        return n
+
+    def _learn_epochs(self):
         p = self.cfg.ppo
         obs, acts, logp, adv, tgt = self.ex_obs, self.ex_act, self.ex_logp, self.ex_adv, self.ex_tgt
         self.metrics.zero_()
@@ -329,6 +354,8 @@ class Learner:
                     n_mb += 1
                 scale = parallel.allreduce_gradients(self.ppo.grad_tensor(), self.world)   # ONE RCCL all-reduce per optimizer step
                 self.ppo.clip_adam_step(0.5, scale)
+                if self.s_learn is not None:
+                    self.ppo.refresh_shadows()                  # the collector's inference reads the bf16 copies: keep them live
                 n_updates += 1
         self.total_epochs += p.epochs
         self.cumulative_model_updates += n_updates
@@ -336,6 +363,8 @@ class Learner:
         return n_updates
 
     def finish_report(self):
+        if self._learn_done is not None:
+            self._learn_done.synchronize()                      # (a report per iteration serialises the two streams again)
         m = self.metrics.cpu().numpy(); rows = max(1, self._n_mb * self.mini)
         self.report.update({"Policy Entropy": m[0] / rows, "Mean KL Divergence": m[1] / rows, "SB3 Clip Fraction": m[2] / rows,
                             "Value Function Loss": m[4] / rows, "Cumulative Timesteps": self.total_timesteps,
@@ -343,8 +372,9 @@ class Learner:
         return self.report
 
     def iteration(self):
-        self.collect()
-        self.add_new_experience()
+        with torch.cuda.stream(self.s_collect):
+            self.collect()
+            self.add_new_experience()
         self.learn()
         self.ts_since_save += self.B * self.world
 

@@ -54,6 +54,9 @@ class PPOCore:
     def set_stream(self, stream):
         _chk(self.lib.rlgpu_learner_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)), self.h, self._err)
 
+    def refresh_shadows(self):
+        _chk(self.lib.rlgpu_learner_refresh_shadows(self.h), self.h, self._err)
+
     # ---- parameters -------------------------------------------------------------------------------------------
     def num_params(self, which=2):
         return int(self.lib.rlgpu_learner_num_params(self.h, which))

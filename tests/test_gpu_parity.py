@@ -471,3 +471,27 @@ def test_experience_fifo_keeps_older_iterations_resident():
                 assert torch.equal(L.ex_adv[r], sn[3]) and torch.equal(L.ex_tgt[r], sn[4])
     rep = L.finish_report()
     assert np.isfinite(rep["Policy Entropy"]) and np.isfinite(rep["Value Function Loss"])
+
+
+@pytest.mark.gpu
+def test_collection_during_learn_mode():
+    """LearnerConfig.collectionDuringLearn: the PPO epochs run on their own stream; the FIFO slot of the next iteration is not written
+    before the epochs reading the old rows are done, every iteration still makes its optimizer steps, parameters stay finite."""
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    n_envs, T = 32, 8
+    B = n_envs * 2 * T
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, randomSeed=11, collectionDuringLearn=True,
+                        ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 2, epochs=2, autocastLearn=True))
+    L = Learner(cfg)
+    assert L.s_learn is not None
+    p0 = L.ppo.get_params(2).copy()
+    for it in range(4):
+        L.iteration()
+        assert L.cumulative_model_updates == 2 * (it + 1)
+    rep = L.finish_report()
+    torch.cuda.synchronize()
+    p1 = L.ppo.get_params(2)
+    assert np.isfinite(p1).all() and np.abs(p1 - p0).max() > 0
+    assert np.isfinite(rep["Policy Entropy"]) and 0 < rep["Policy Entropy"] < np.log(90) + 1e-3
+    # the slot holding the last iteration is intact (nothing wrote into it after its copy)
+    assert torch.equal(L.ex_act[:B] if torch.equal(L.ex_act[:B], L.act_buf.view(-1)) else L.ex_act[B:2 * B], L.act_buf.view(-1))
