@@ -542,6 +542,9 @@ RLG_HD void solver_rows(TickWork<NC>& W, int k) {
     if (fi >= 0) row_setup_friction(W.R[fi], ni, W.R[ni], W.B, c.n, c.ra, c.rb, c.b >= 0);
 }
 
+// (Tried and dropped: the velocity deltas of all bodies in registers for the whole solve, a body index becoming a compare chain over
+// the NB slots -- it removes the two LDS round trips per row from the dependent chain, but the chains are ~100 more VALU instructions
+// per row and with one wavefront per SIMD the kernel is bound by instructions issued, not by LDS latency: 553 K -> 882 K cycles.)
 // (Tried and dropped: one lane per body when no row joins two bodies -- such rows commute exactly -- with a group vote for the
 // split-impulse early exit.  The envs that are slow here have ball-car / car-car rows and stay one sequence, and the per-row
 // chain lookup cost more than the short chains saved: 483 K -> 570 K cycles per launch on the slowest workgroup.)

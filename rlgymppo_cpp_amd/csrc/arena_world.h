@@ -545,9 +545,20 @@ RLG_HD void poly_push(Poly8& P, V3 v) {
 }
 // clip against the half space dot(nrm,p) <= off
 RLG_HD void clip_poly(Poly8& P, V3 nrm, float off) {
+    const int n = P.n;
+    {   // most planes of a contact do not cut at all: with every vertex on the inner side the loop below copies P vertex by vertex,
+        // with every vertex outside it leaves nothing -- both without the per-vertex insert chains
+        bool all_in = true, all_out = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 8; i++)
+            if (i < n) { float da = dot(nrm, P.p[i]) - off; all_in = all_in && (da <= 0.f); all_out = all_out && (da > 0.f); }
+        if (all_in) return;
+        if (all_out) { P.n = 0; return; }
+    }
     Poly8 O; O.n = 0;
     const V3 first = P.p[0];
-    const int n = P.n;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
