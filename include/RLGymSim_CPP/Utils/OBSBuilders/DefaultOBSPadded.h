@@ -1,6 +1,6 @@
 // DefaultOBSPadded (SIM/Utils/OBSBuilders/DefaultOBSPadded.h:6-24, .cpp:3-66): DefaultOBS with the teammate and opponent blocks
-// padded to maxPlayers-1 / maxPlayers and shuffled per observation.  The device builds it for maxPlayers == team size (no zero
-// blocks; same width as DefaultOBS); wider padding is refused by rlgpu_env_create.
+// padded to maxPlayers-1 / maxPlayers and shuffled per observation.  The device builds it for team size <= maxPlayers <= 4
+// (rlgpu_env_create refuses anything else, like the reference's "Too many teammates" error).
 #pragma once
 #include <algorithm>
 #include <random>

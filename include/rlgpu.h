@@ -49,8 +49,9 @@ typedef struct RlgpuGymConfig {
     uint32_t seed_lo, seed_hi;
     float pos_coef[3], vel_coef, ang_vel_coef;       /* DefaultOBS ctor (DefaultOBS.h:11-15) */
     int32_t n_actions;                               /* DiscreteAction: 90 */
-    int32_t obs_max_players;                         /* 0: DefaultOBS.  m > 0: DefaultOBSPadded(maxPlayers = m) (DefaultOBSPadded.cpp:3-66): teammates and
-                                                      * opponents shuffled per observation; m must equal team_size (wider padding is not built) */
+    int32_t obs_max_players;                         /* 0: DefaultOBS.  m > 0: DefaultOBSPadded(maxPlayers = m) (DefaultOBSPadded.cpp:3-66): m-1 teammate and
+                                                      * m opponent blocks (zero blocks where there is no player), each list shuffled per observation;
+                                                      * team_size <= m <= 4, row width 51 + 38 m */
 } RlgpuGymConfig;
 
 /* fills cfg with the examplemain.cpp:58-100 stack: 0.1 FaceBall + 0.5 VelPlayerToBall + 1.0 VelBallToGoal +
@@ -63,7 +64,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
 void rlgpu_env_destroy(rlgpu_env* e);
 const char* rlgpu_env_last_error(const rlgpu_env* e);
 int rlgpu_env_set_stream(rlgpu_env* e, void* hip_stream);
-int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size() probe (PUB/Learner.cpp:99-109): 51+19*players */
+int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size() probe (PUB/Learner.cpp:99-109): 51+19*players, padded: 51+38*maxPlayers */
 int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * 2 * team_size ; agent row = env * players + slot */
 int rlgpu_env_num_actions(const rlgpu_env* e);
 int rlgpu_env_state_words(const rlgpu_env* e); /* resident 32-bit words per env */

@@ -73,7 +73,7 @@ template <int NC>
 static void gym_reset_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, float* obs, int run_setter) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
-    gym_reset_env<NC>(A, G, *cfg, env, obs, (size_t)obs_size<NC>(), run_setter != 0);
+    gym_reset_env<NC>(A, G, *cfg, env, obs, (size_t)obs_size<NC>(*cfg), run_setter != 0);
     arena_to_host(A, G, *s);
 }
 template <int NC>
@@ -82,15 +82,18 @@ static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, c
     arena_from_host(A, G, *s);
     MeshView mv = view();
     TickWork<NC> W;
-    gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(), rew, done, W);
+    gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(*cfg), rew, done, W);
     arena_to_host(A, G, *s);
 }
 
 extern "C" {
 
+// row width of the obs builder `cfg` describes (DefaultOBS, or DefaultOBSPadded when obs_max_players is set)
+int port_obs_size(const void* cfg, int nc) { int m = ((const GymConfig*)cfg)->obs_max_players; return m > 0 ? 51 + 38 * m : 51 + 19 * nc; }
+
 void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs, int run_setter) {
     for (int e = 0; e < n; e++) {
-        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = 51 + 19 * nc;
+        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = port_obs_size(cfg, nc);
         float* o = obs ? obs + (size_t)e * nc * D : nullptr;
         if (nc == 2) gym_reset_t<2>(s, (const GymConfig*)cfg, e, o, run_setter);
         else if (nc == 4) gym_reset_t<4>(s, (const GymConfig*)cfg, e, o, run_setter);
@@ -99,7 +102,7 @@ void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs,
 }
 void port_gym_step(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done) {
     for (int e = 0; e < n; e++) {
-        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = 51 + 19 * nc;
+        RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = port_obs_size(cfg, nc);
         int32_t dn = 0;
         if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
         else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
@@ -112,7 +115,7 @@ int port_action_table(float* out) { memcpy(out, table(), sizeof(g_action_table))
 // scalar CPU baseline ("port") of the collection hot loop: n envs stepped round-robin on n_threads threads
 double port_bench_collect(int team_size, int n_envs, int n_threads, int steps, const void* cfg_v) {
     const GymConfig* cfg = (const GymConfig*)cfg_v;
-    int nc = 2 * team_size; int D = 51 + 19 * nc;
+    int nc = 2 * team_size; int D = port_obs_size(cfg_v, nc);
     std::vector<RlgpuArenaState> st(n_envs);
     for (auto& s : st) { memset(&s, 0, sizeof(s)); s.num_cars = nc; for (int k = 0; k < nc; k++) { s.cars[k].rot[0] = 1; s.cars[k].rot[4] = 1; s.cars[k].rot[8] = 1; } }
     std::vector<float> obs((size_t)n_envs * nc * D);

@@ -33,7 +33,7 @@ struct GymConfig {
     uint32_t seed_lo, seed_hi;
     float pos_coef[3], vel_coef, ang_vel_coef;      // DefaultOBS.h:11-15
     int32_t n_actions;
-    int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers) with maxPlayers == team size: shuffled mates / opponents
+    int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers), team size <= maxPlayers <= 4: mates / opponents padded with zero blocks and shuffled
 };
 
 // obs-order -> RocketSim pad index (GameState.cpp:10-50 builds this by matching CommonValues::BOOST_LOCATIONS
@@ -196,6 +196,10 @@ RLG_HD_NOINLINE void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
 RLG_HD V3 inv3(V3 v, bool inv) { return inv ? v3(-v.x, -v.y, v.z) : v; }
 template <int NC>
 RLG_HD int obs_size() { return 51 + 19 * NC; }
+// row width for a config: DefaultOBS 51 + 19 * players, DefaultOBSPadded(m) 51 + 19 * 2m (self + m-1 mates + m opponents)
+template <int NC>
+RLG_HD int obs_size(const GymConfig& cfg) { return cfg.obs_max_players > 0 ? 51 + 38 * cfg.obs_max_players : obs_size<NC>(); }
+constexpr int OBS_MAX_PADDED_PLAYERS = 4;
 
 template <int NC>
 RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, const GymConfig& cfg) {
@@ -207,9 +211,9 @@ RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, c
     *o++ = S.boost_frac[k]; *o++ = S.on_ground[k] ? 1.f : 0.f; *o++ = S.has_flip[k] ? 1.f : 0.f; *o++ = S.demoed[k] ? 1.f : 0.f;
     return o;
 }
-// DefaultOBS::BuildOBS (DefaultOBS.cpp:3-55).  With cfg.obs_max_players (DefaultOBSPadded.cpp:3-66, maxPlayers == team size, so no
-// zero blocks) the teammate blocks and the opponent blocks are each shuffled per observation; the reference shuffles with the
-// process-wide std engine, here the permutation comes from the env's Philox stream keyed by (env, step, reset count, player).
+// DefaultOBS::BuildOBS (DefaultOBS.cpp:3-55).  With cfg.obs_max_players = m (DefaultOBSPadded.cpp:3-66) the teammate list is padded
+// with zero blocks to m-1 entries, the opponent list to m, and each list is shuffled per observation; the reference shuffles with
+// the process-wide std engine, here the permutation comes from the env's Philox stream keyed by (env, step, reset count, player).
 template <int NC>
 RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o, uint32_t env_id, uint32_t step, uint32_t resets) {
     bool inv = (k % 2) == 1;
@@ -220,19 +224,30 @@ RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_a
     for (int i = 0; i < 8; i++) *o++ = prev_action8[i];
     for (int i = 0; i < 34; i++) { int src = inv ? (33 - i) : i; *o++ = ((S.pads_active >> src) & 1ull) ? 1.f : 0.f; }
     o = obs_add_player(o, S, k, inv, cfg);
-    int mates[NC], opps[NC], nm = 0, no = 0;
+    constexpr int LIST = (NC > OBS_MAX_PADDED_PLAYERS ? NC : OBS_MAX_PADDED_PLAYERS) + 1;
+    int mates[LIST], opps[LIST], nm = 0, no = 0;
     for (int j = 0; j < NC; j++) if (j != k) { if ((j % 2) == (k % 2)) mates[nm++] = j; else opps[no++] = j; }   // state.players order
     if (cfg.obs_max_players > 0) {
+        while (nm < cfg.obs_max_players - 1) mates[nm++] = -1;   // zero blocks (DefaultOBSPadded.cpp:46-54)
+        while (no < cfg.obs_max_players) opps[no++] = -1;
         uint32_t r[4];
         philox4(cfg.seed_lo ^ 0x0B5E55EDu, cfg.seed_hi, env_id, step, (resets << 8) | (uint32_t)k, r);
-        // Fisher-Yates from the back, one 16-bit draw per swap (lists have <= 3 entries)
-        uint32_t bits = r[0];
-        for (int i = nm - 1; i > 0; i--) { int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; int t = mates[i]; mates[i] = mates[j]; mates[j] = t; }
-        bits = r[1];
-        for (int i = no - 1; i > 0; i--) { int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; int t = opps[i]; opps[i] = opps[j]; opps[j] = t; }
+        // Fisher-Yates from the back, one 16-bit draw per swap: two draws per Philox word, words 0 and 2 for the mates, 1 and 3 for the opponents
+        uint32_t bits = r[0]; int used = 0;
+        for (int i = nm - 1; i > 0; i--) {
+            if (used == 2) bits = r[2];
+            int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; used++;
+            int t = mates[i]; mates[i] = mates[j]; mates[j] = t;
+        }
+        bits = r[1]; used = 0;
+        for (int i = no - 1; i > 0; i--) {
+            if (used == 2) bits = r[3];
+            int j = (int)((bits & 0xffffu) % (uint32_t)(i + 1)); bits >>= 16; used++;
+            int t = opps[i]; opps[i] = opps[j]; opps[j] = t;
+        }
     }
-    for (int i = 0; i < nm; i++) o = obs_add_player(o, S, mates[i], inv, cfg);
-    for (int i = 0; i < no; i++) o = obs_add_player(o, S, opps[i], inv, cfg);
+    for (int i = 0; i < nm; i++) { if (mates[i] >= 0) o = obs_add_player(o, S, mates[i], inv, cfg); else for (int q = 0; q < 19; q++) *o++ = 0.f; }
+    for (int i = 0; i < no; i++) { if (opps[i] >= 0) o = obs_add_player(o, S, opps[i], inv, cfg); else for (int q = 0; q < 19; q++) *o++ = 0.f; }
 }
 
 // ---- rewards ---------------------------------------------------------------------------------------------

@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
-    const int D = obs_size<NC>();
+    const int D = obs_size<NC>(d.cfg);
     GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
     if (env >= d.n_envs) return;
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
     load_env(d, env, S.A, S.G);
-    const int D = obs_size<NC>();
+    const int D = obs_size<NC>(d.cfg);
     gym_reset_env<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * NC * D : nullptr, (size_t)D, run_setter != 0);
     store_env(d, env, S.A, S.G);
 }
@@ -600,7 +600,7 @@ int rlgpu_action_table(float* out, int cap_rows) {
 
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg) {
     if (!out || n_envs <= 0 || team_size < 1 || team_size > 3 || !cfg) return RLGPU_ERR_ARG;
-    if (cfg->obs_max_players != 0 && cfg->obs_max_players != team_size) return RLGPU_ERR_ARG;   // DefaultOBSPadded wider than the match: not built
+    if (cfg->obs_max_players != 0 && (cfg->obs_max_players < team_size || cfg->obs_max_players > rlg::OBS_MAX_PADDED_PLAYERS)) return RLGPU_ERR_ARG;   // DefaultOBSPadded.cpp:40-44: too many players for the padding
     rlgpu_env* e = new rlgpu_env();
     *out = e;
     e->device = device; e->n_envs = n_envs; e->team_size = team_size; e->nc = 2 * team_size;
@@ -630,7 +630,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
 }
 const char* rlgpu_env_last_error(const rlgpu_env* e) { return e ? e->err.c_str() : "null env"; }
 int rlgpu_env_set_stream(rlgpu_env* e, void* s) { e->stream = (hipStream_t)s; return RLGPU_OK; }
-int rlgpu_env_obs_size(const rlgpu_env* e) { return 51 + 19 * e->nc; }
+int rlgpu_env_obs_size(const rlgpu_env* e) { return e->d.cfg.obs_max_players > 0 ? 51 + 38 * e->d.cfg.obs_max_players : 51 + 19 * e->nc; }
 int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * e->nc; }
 int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }

@@ -108,7 +108,8 @@ def port_gym_cfg(**over):
 
 
 def port_gym_reset(port, states, cfg, run_setter=True):
-    n = len(states); nc = states[0].num_cars; D = 51 + 19 * nc
+    n = len(states); nc = states[0].num_cars
+    D = 51 + 38 * cfg.obs_max_players if cfg.obs_max_players > 0 else 51 + 19 * nc
     arr = (ArenaState * n)(*states)
     obs = np.zeros((n * nc, D), np.float32)
     port.lib.port_gym_reset(arr, n, C.byref(cfg), _ptr(obs), 1 if run_setter else 0)
@@ -116,7 +117,8 @@ def port_gym_reset(port, states, cfg, run_setter=True):
 
 
 def port_gym_step(port, states, cfg, actions):
-    n = len(states); nc = states[0].num_cars; D = 51 + 19 * nc
+    n = len(states); nc = states[0].num_cars
+    D = 51 + 38 * cfg.obs_max_players if cfg.obs_max_players > 0 else 51 + 19 * nc
     arr = (ArenaState * n)(*states)
     actions = np.ascontiguousarray(actions, np.int32)
     obs = np.zeros((n * nc, D), np.float32); rew = np.zeros(n * nc, np.float32); done = np.zeros(n * nc, np.int32)

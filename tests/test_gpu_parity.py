@@ -134,8 +134,8 @@ def test_gym_step_matches_host_port(port_lib):
     assert n_done > 0   # auto-reset path exercised
 
 
-@pytest.mark.parametrize("team_size", [2, 3])
-def test_gym_step_matches_host_port_team_modes(port_lib, team_size):
+@pytest.mark.parametrize("team_size,max_players", [(2, 2), (3, 3), (1, 2), (2, 4)])
+def test_gym_step_matches_host_port_team_modes(port_lib, team_size, max_players):
     """BASELINE configs[3]/[4] shapes: 2v2 and 3v3 envs (4 / 6 cars, obs width 127 / 165) with the zero-sum reward wrapper,
     HIP path vs host port over 24 gym steps incl. auto-resets.  Also the only GPU coverage of the 2- and 1-env-per-wavefront
     lane maps (32 / 64 lanes per env in the candidate, pair and item phases), and of the padded-shuffled obs."""
@@ -143,10 +143,10 @@ def test_gym_step_matches_host_port_team_modes(port_lib, team_size):
     from rlgymppo_cpp_amd import _lib
     n, nc = 40, 2 * team_size
     cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 12; cfg.zero_sum = 1; cfg.team_spirit = 0.3; cfg.opp_scale = 1.0
-    cfg.obs_max_players = team_size      # DefaultOBSPadded(maxPlayers = team size): shuffled teammate / opponent blocks
+    cfg.obs_max_players = max_players    # DefaultOBSPadded(maxPlayers): teammate / opponent blocks padded with zero blocks and shuffled
     env = BatchedEnv(n, team_size, cfg=cfg)
-    assert env.obs_size == 51 + 19 * nc and env.n_agents == n * nc
-    pcfg = port_gym_cfg(no_touch_max_steps=12, zero_sum=1, team_spirit=0.3, opp_scale=1.0, obs_max_players=team_size)
+    assert env.obs_size == 51 + 38 * max_players and env.n_agents == n * nc
+    pcfg = port_gym_cfg(no_touch_max_steps=12, zero_sum=1, team_spirit=0.3, opp_scale=1.0, obs_max_players=max_players)
     obs = env.reset(True)
     env.sync()
     hs, hobs = port_gym_reset(port_lib, [default_arena(nc) for _ in range(n)], pcfg, run_setter=True)

@@ -247,3 +247,23 @@ def test_padded_obs_is_a_block_shuffle_of_default_obs(port_lib):
             assert sorted(perm) == list(range(hi - lo))
             if hi - lo == 3: orders.add(tuple(perm))
     assert len(orders) == 6   # all 3! opponent orders show up
+    # wider padding (maxPlayers 4 for 3v3): 3 mate slots (2 real + 1 zero block), 4 opponent slots (3 real + 1 zero), width 51 + 19 * 8
+    _, wide = port_gym_reset(port_lib, states, port_gym_cfg(obs_max_players=4), run_setter=True)
+    assert wide.shape == (n * nc, 51 + 38 * 4) and np.array_equal(plain[:, :70], wide[:, :70])
+    zero_pos = set()
+    for (lo, hi), (wlo, whi) in (((0, 2), (0, 3)), ((2, 5), (3, 7))):
+        P, Q = blocks(plain, lo, hi), blocks(wide, wlo, whi)
+        for r in range(len(P)):
+            real = [q for q in Q[r] if q.any()]
+            assert len(real) == hi - lo and len(Q[r]) - len(real) == 1
+            assert sorted(map(tuple, real)) == sorted(map(tuple, P[r]))
+            zero_pos.add((wlo, int(np.argmin([q.any() for q in Q[r]]))))
+    assert len(zero_pos) == 3 + 4   # the zero block lands in every slot of both lists over 384 observations
+    # 1v1 with maxPlayers 2: no real mate, one zero mate block; one real and one zero opponent
+    s1 = [default_arena(2) for _ in range(8)]
+    _, p1 = port_gym_reset(port_lib, s1, port_gym_cfg(), run_setter=True)
+    _, w1 = port_gym_reset(port_lib, s1, port_gym_cfg(obs_max_players=2), run_setter=True)
+    assert w1.shape == (16, 51 + 38 * 2) and np.array_equal(p1[:, :70], w1[:, :70]) and not w1[:, 70:89].any()
+    for r in range(16):
+        opp = w1[r, 89:127].reshape(2, 19)
+        assert sum(np.array_equal(b, p1[r, 70:89]) for b in opp) == 1 and sum(not b.any() for b in opp) == 1
