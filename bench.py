@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--team-size", type=int, default=1, help="1 = BASELINE configs[1] (the headline); 2 / 3 with --padded-zero-sum = the shapes of configs[3] / [4]")
+    ap.add_argument("--padded-zero-sum", action="store_true", help="DefaultOBSPadded(maxPlayers = team size) + ZeroSumReward around the example stack")
     ap.add_argument("--fp32", action="store_true", help="fp32 MFMA instead of bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="LearnerConfig.collectionDuringLearn: the PPO epochs run on their own stream under the next collection (not the headline mode)")
@@ -101,12 +103,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP kernels with no CPU fallback")
 
     from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
-    n_agents = args.envs * 2
+    n_agents = args.envs * 2 * args.team_size
     B = n_agents * args.horizon
-    cfg = LearnerConfig(numEnvs=args.envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, device=local_rank, randomSeed=123, collectionDuringLearn=args.overlap,
+    gym_cfg = None
+    if args.padded_zero_sum:
+        from rlgymppo_cpp_amd import _lib
+        gym_cfg = _lib.default_gym_config(); gym_cfg.obs_max_players = args.team_size; gym_cfg.zero_sum = 1; gym_cfg.team_spirit = 0.3; gym_cfg.opp_scale = 1.0
+    cfg = LearnerConfig(numEnvs=args.envs, teamSize=args.team_size, timestepsPerIteration=B, expBufferSize=B, device=local_rank, randomSeed=123, collectionDuringLearn=args.overlap,
                         ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=args.epochs, policyLR=2e-4, criticLR=2e-4, entCoef=0.01,
                                              autocastLearn=not args.fp32))
-    L = Learner(cfg, rank=rank, world_size=world)
+    L = Learner(cfg, gym_cfg=gym_cfg, rank=rank, world_size=world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -138,7 +144,7 @@ def main():
     if rank == 0:
         agent_steps = B * world * args.steps
         value = agent_steps / elapsed
-        per_launch_bytes = algorithmic_bytes_per_gym_step(2, L.obs_size) * args.envs
+        per_launch_bytes = algorithmic_bytes_per_gym_step(2 * args.team_size, L.obs_size) * args.envs
         avg_launch_s = (env_ms / max(1, env_launches)) * 1e-3
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         peak = 8000.0
@@ -147,14 +153,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32 stepper + " + ("fp32" if args.fp32 else "bf16") + " MFMA MLP", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: 1v1, %d envs/GPU, tickSkip 8, DefaultObs(89)+example reward stack, RandomState resets, "
+            "config": {"workload": "%s, %d envs/GPU, tickSkip 8, %s(%d)+%sexample reward stack, RandomState resets, "
                                    "T=%d steps/iter, B=%d agent-steps/GPU, minibatch %d, epochs %d, MLP 256x3 policy(90)+critic, %s arena mesh"
-                                   % (args.envs, args.horizon, B, B // 4, args.epochs, L.env.mesh_kind),
+                                   % ("BASELINE config[1]: 1v1" if args.team_size == 1 and not args.padded_zero_sum else "%dv%d (shape of BASELINE configs[%d])" % (args.team_size, args.team_size, args.team_size + 1),
+                                      args.envs, "DefaultOBSPadded" if args.padded_zero_sum else "DefaultObs", L.obs_size, "zero-sum " if args.padded_zero_sum else "",
+                                      args.horizon, B, B // 4, args.epochs, L.env.mesh_kind),
                        "envs_per_gpu": args.envs, "horizon": args.horizon, "batch": B, "minibatch": B // 4, "epochs": args.epochs},
             "collection_during_learn": bool(args.overlap),
-            "ppo_iter_ms": consume_ms if not args.overlap else None, "gym_steps_per_s": value / 2, "physics_ticks_per_s": value / 2 * 8,
+            "ppo_iter_ms": consume_ms if not args.overlap else None, "gym_steps_per_s": value / (2 * args.team_size), "physics_ticks_per_s": value / (2 * args.team_size) * 8,
             "collect_ms_per_iter": (elapsed / args.steps * 1e3 - consume_ms) if not args.overlap else None,
-            "roofline": {"kernel": "k_env_step<2> (8 fused ticks + snapshot/obs/reward/done/auto-reset)", "bound": "hbm", "achieved": achieved, "peak": peak,
+            "roofline": {"kernel": "k_env_step<%d> (8 fused ticks" % (2 * args.team_size) + " + snapshot/obs/reward/done/auto-reset)", "bound": "hbm", "achieved": achieved, "peak": peak,
                          "unit": "GB/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": env_ms / max(1, env_launches), "launches": env_launches,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
             "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": (gemm_flops / (gemm_ms * 1e-3) / 1e12) if gemm_ms > 0 else 0.0,
