@@ -1,0 +1,143 @@
+"""The learner oracle (oracle/learner_ref.py) and the HIP learner kernels against the REAL reference learner code:
+oracle/_ref/libref_learner.so = TorchFuncs.cpp + DiscretePolicy.cpp + ValueEstimator.cpp of the reference, compiled unedited from
+/root/reference against the torch wheel's libtorch (oracle/Makefile, target ref_learner; oracle/ref_learner_driver.cpp only marshals
+arguments).  Skipped where the library was not built (no /root/reference and no prebuilt copy)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import learner_ref as R  # noqa: E402
+
+SO = os.path.join(ROOT, "oracle", "_ref", "libref_learner.so")
+HID, D, A = [48, 32], 89, 90
+
+
+@pytest.fixture(scope="module")
+def refl():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libref_learner.so not built (needs /root/reference + libtorch headers)")
+    return C.CDLL(SO)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _net(rs, out):
+    dims = [D] + HID + [out]
+    shapes = [((dims[i + 1], dims[i]), (dims[i + 1],)) for i in range(len(dims) - 1)]
+    flat = np.concatenate([(rs.uniform(-1, 1, ws[0] * ws[1] + bs[0]) / np.sqrt(ws[1])).astype(np.float32) for ws, bs in shapes])
+    return np.ascontiguousarray(flat, np.float32), shapes
+
+
+def ref_gae(refl, rews, dones, truncs, values, gamma, lam, ret_std, clip):
+    B = len(rews)
+    adv = np.zeros(B, np.float32); tgt = np.zeros(B, np.float32); ret = np.zeros(B, np.float32)
+    refl.refl_gae(_p(rews), _p(dones), _p(truncs), _p(values), B, C.c_float(gamma), C.c_float(lam), C.c_float(ret_std), C.c_float(clip), _p(adv), _p(tgt), _p(ret))
+    return adv, tgt, ret
+
+
+def ref_policy(refl, flat, obs, acts, temperature=1.0, seed=0):
+    rows = len(obs)
+    hid = np.array(HID, np.int32)
+    probs = np.zeros((rows, A), np.float32); am = np.zeros(rows, np.int32); lp = np.zeros(rows, np.float32); ent = C.c_float()
+    sa = np.zeros(rows, np.int32); sl = np.zeros(rows, np.float32); tape = np.zeros((rows, A), np.float32)
+    refl.refl_policy(_p(hid), len(HID), D, A, _p(flat), C.c_float(temperature), _p(obs), rows, _p(acts), _p(probs), _p(am), _p(lp), C.byref(ent),
+                     C.c_uint64(seed), _p(sa), _p(sl), _p(tape))
+    return probs, am, lp, ent.value, sa, sl, tape
+
+
+@pytest.mark.parametrize("ret_std,clip", [(1.0, 10.0), (2.5, 0.7), (0.0, 10.0), (3.0, 0.0)])
+def test_gae_oracle_equals_reference_compute_gae(refl, ret_std, clip):
+    """TorchFuncs::ComputeGAE (TorchFuncs.cpp:5-52) on a concatenated batch with terminals and truncations; the cases cover reward
+    standardisation with clipping that bites, no standardisation (retStd 0) and no clipping (clipRange 0)."""
+    rs = np.random.RandomState(int(ret_std * 10 + clip * 100))
+    B = 700
+    rews = (rs.randn(B) * 2).astype(np.float32); values = rs.randn(B + 1).astype(np.float32)
+    dones = (rs.rand(B) < 0.03).astype(np.float32); truncs = ((rs.rand(B) < 0.02) & (dones == 0)).astype(np.float32)
+    want = ref_gae(refl, rews, dones, truncs, values, 0.99, 0.95, ret_std, clip)
+    got = R.compute_gae(rews, dones, truncs, values, 0.99, 0.95, ret_std, clip)
+    for g, w, name in zip(got, want, ("advantages", "targets", "returns")):
+        assert np.abs(g - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), name   # stated tolerance of the path: 1e-4 on returns / advantages
+
+
+def test_policy_oracle_equals_reference_discrete_policy(refl):
+    """DiscretePolicy::GetActionProbs / GetAction(deterministic) / GetBackpropData and ValueEstimator::Forward (the real classes,
+    our parameters loaded in state-dict order) against the numpy restatement."""
+    rs = np.random.RandomState(4)
+    pol, pol_shapes = _net(rs, A); cri, cri_shapes = _net(rs, 1)
+    obs = (rs.randn(64, D) * 1.5).astype(np.float32); acts = rs.randint(0, A, 64).astype(np.int32)
+    for temp in (1.0, 1.7):
+        probs, am, lp, ent, *_ = ref_policy(refl, pol, obs, acts, temp)
+        logits = R.mlp_forward(pol, pol_shapes, obs)[0]
+        mine = R.policy_probs(logits, temp)
+        assert np.abs(mine - probs).max() < 2e-6
+        assert (np.argmax(mine, 1) == am).all()
+        assert np.abs(np.log(mine[np.arange(64), acts]) - lp).max() < 2e-5
+        assert abs(float((-(np.log(mine) * mine).sum(1)).mean()) - ent) < 2e-5
+    vals = np.zeros(64, np.float32)
+    hid = np.array(HID, np.int32)
+    refl.refl_value(_p(hid), len(HID), D, _p(cri), _p(obs), 64, _p(vals))
+    assert np.abs(R.mlp_forward(cri, cri_shapes, obs)[0].reshape(-1) - vals).max() < 1e-5
+
+
+def test_sampler_equals_reference_get_action(refl):
+    """GetAction(obs, deterministic = false) = torch::multinomial(probs, 1, true): with the Exp(1) tape of the same generator state the
+    sampler of this repo, argmax(p / q), picks the same action indices bit for bit, and log p[a] agrees."""
+    rs = np.random.RandomState(9)
+    pol, _ = _net(rs, A)
+    obs = (rs.randn(512, D) * 2).astype(np.float32); acts = np.zeros(512, np.int32)
+    probs, _, _, _, sampled, slogp, tape = ref_policy(refl, pol, obs, acts, 1.0, seed=1234)
+    a, logp = R.sample_actions(probs, tape)
+    margin = R.top2_margin(probs, tape)
+    differ = a != sampled
+    assert not (differ & (margin > 1e-6)).any() and differ.mean() < 0.01     # only exact-tie rows may differ
+    ok = ~differ
+    assert np.abs(logp[ok] - slogp[ok]).max() < 1e-6
+    assert len(set(sampled.tolist())) > 30                                      # it really sampled
+
+
+@pytest.mark.gpu
+def test_hip_learner_kernels_against_reference_code(refl):
+    """HIP kernels (fp32 mode) straight against the reference classes: probabilities, deterministic actions, sampled actions on the
+    reference's own Exp(1) tape, values, and GAE on a [T][n] batch laid out as the reference concatenates it."""
+    torch = pytest.importorskip("torch")
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    rs = np.random.RandomState(21)
+    pol, _ = _net(rs, A); cri, _ = _net(rs, 1)
+    ppo = PPOCore(D, A, tuple(HID), tuple(HID), use_bf16=False, max_rows=4096, seed=3)
+    ppo.set_params(pol, 0); ppo.set_params(cri, 1)
+    rows = 1024
+    obs = (rs.randn(rows, D) * 1.5).astype(np.float32); acts0 = np.zeros(rows, np.int32)
+    probs, am, _, _, sampled, slogp, tape = ref_policy(refl, pol, obs, acts0, 1.0, seed=77)
+    dobs = torch.from_numpy(obs).cuda()
+    assert np.abs(ppo.probs(dobs).cpu().numpy() - probs).max() < 2e-6
+    a = torch.empty(rows, dtype=torch.int32, device="cuda"); lp = torch.empty(rows, device="cuda")
+    ppo.act(dobs, a, lp, deterministic=True)
+    margin_det = np.sort(probs, 1)
+    assert ((a.cpu().numpy() == am) | (margin_det[:, -1] - margin_det[:, -2] < 1e-6)).all()
+    ppo.act(dobs, a, lp, noise=torch.from_numpy(tape).cuda())
+    differ = a.cpu().numpy() != sampled
+    assert not (differ & (R.top2_margin(probs, tape) > 1e-5)).any()             # action indices bit-exact on the reference's noise
+    assert np.abs(lp.cpu().numpy()[~differ] - slogp[~differ]).max() < 1e-5
+    vals = np.zeros(rows, np.float32); hid = np.array(HID, np.int32)
+    refl.refl_value(_p(hid), len(HID), D, _p(cri), _p(obs), rows, _p(vals))
+    dv = torch.empty(rows, device="cuda"); ppo.value(dobs, dv)
+    assert np.abs(dv.cpu().numpy() - vals).max() < 1e-5
+    # GAE: T steps of n agents; the reference sees the agent-major concatenation plus ONE extra value (the state after the last row)
+    T, n = 24, 16
+    rews = (rs.randn(T, n) * 2).astype(np.float32); dones = (rs.rand(T, n) < 0.05).astype(np.float32)
+    truncs = np.zeros((T, n), np.float32); truncs[T - 1] = 1 - dones[T - 1]       # the collector's mark (ThreadAgentManager.cpp:55)
+    values = rs.randn(T + 1, n).astype(np.float32)
+    flat = lambda x: np.ascontiguousarray(x.T.reshape(-1))                          # trajectory after trajectory
+    vcat = np.concatenate([flat(values[:T]), values[T, n - 1:n]]).astype(np.float32)
+    want = ref_gae(refl, flat(rews), flat(dones), flat(truncs), vcat, 0.99, 0.95, 1.7, 5.0)
+    adv, tgt, ret = ppo.gae(torch.from_numpy(rews).cuda(), torch.from_numpy(dones).cuda(), torch.from_numpy(truncs).cuda(), torch.from_numpy(values).cuda(),
+                            0.99, 0.95, 1.7, 5.0, 0)
+    for g, w, name in ((adv, want[0], "advantages"), (tgt, want[1], "targets"), (ret, want[2], "returns")):
+        assert np.abs(flat(g.cpu().numpy()) - w).max() < 1e-4, name                 # north_star: within 1e-4 on returns / advantages
