@@ -2,12 +2,13 @@
 // A C-ABI door into the REAL reference learner code, compiled from where it lies under /root/reference against the libtorch that
 // ships inside the torch wheel (CPU):  RLGPC::TorchFuncs::ComputeGAE (PRIV/Util/TorchFuncs.cpp:5-52), RLGPC::DiscretePolicy
 // (PRIV/PPO/DiscretePolicy.cpp: GetActionProbs :44-49, GetAction :51-62, GetBackpropData :64-75) and RLGPC::ValueEstimator
-// (PRIV/PPO/ValueEstimator.cpp).  Those three translation units build unedited; PPOLearner.cpp (loss + optimizer loop) needs the
+// (PRIV/PPO/ValueEstimator.cpp), RLGPC::ExperienceBuffer (PRIV/PPO/ExperienceBuffer.cpp).  Those translation units build unedited; PPOLearner.cpp (loss + optimizer loop) needs the
 // reference's MSVC-only gradscaler.hpp and is NOT buildable here, so the PPO loss / gradients / Adam stay pinned by the
 // torch-Python goldens (tests/golden/make_learner_golden.py).  What this driver adds is only argument marshalling.
 #include <private/RLGymPPO_CPP/Util/TorchFuncs.h>
 #include <private/RLGymPPO_CPP/PPO/DiscretePolicy.h>
 #include <private/RLGymPPO_CPP/PPO/ValueEstimator.h>
+#include <private/RLGymPPO_CPP/PPO/ExperienceBuffer.h>
 #include <torch/torch.h>
 #include <cstring>
 
@@ -71,6 +72,29 @@ void refl_policy(const int* hidden, int n_hidden, int D, int A, const float* par
         torch::Tensor q = torch::empty_like(probs).exponential_(1);
         std::memcpy(exp_tape_out, q.contiguous().data_ptr<float>(), (size_t)rows * A * 4);
     }
+}
+
+// The real ExperienceBuffer: `n_submits` submissions of `rows_per_submit` rows whose `actions` column carries the row's identity
+// (submit * rows_per_submit + i); after every submission GetAllBatchesShuffled(batch_size) is called once and the identities of all
+// batches are appended to ids_out (rows of batch 0, batch 1, ...).  counts_out[s] = number of batches after submission s.
+// Returns the number of ids written.
+int64_t refl_expbuf_run(int64_t max_size, int seed, int n_submits, int rows_per_submit, int64_t batch_size, int64_t* ids_out, int64_t ids_cap, int32_t* counts_out) {
+    ExperienceBuffer buf(max_size, seed, torch::kCPU);
+    int64_t n = 0;
+    for (int s = 0; s < n_submits; s++) {
+        ExperienceTensors t;
+        torch::Tensor ids = torch::arange((int64_t)s * rows_per_submit, (int64_t)(s + 1) * rows_per_submit, torch::kFloat64);
+        for (torch::Tensor& x : t) x = torch::zeros({rows_per_submit, 1}, torch::kFloat64);
+        t.actions = ids.view({rows_per_submit, 1}).clone();
+        buf.SubmitExperience(t);
+        auto batches = buf.GetAllBatchesShuffled(batch_size);
+        counts_out[s] = (int32_t)batches.size();
+        for (auto& b : batches) {
+            torch::Tensor a = b.actions.contiguous().view({-1});
+            for (int64_t i = 0; i < a.numel(); i++) { if (n < ids_cap) ids_out[n] = (int64_t)a[i].item<double>(); n++; }
+        }
+    }
+    return n;
 }
 
 void refl_value(const int* hidden, int n_hidden, int D, const float* params, const float* obs, int rows, float* values_out) {

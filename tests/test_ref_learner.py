@@ -141,3 +141,36 @@ def test_hip_learner_kernels_against_reference_code(refl):
                             0.99, 0.95, 1.7, 5.0, 0)
     for g, w, name in ((adv, want[0], "advantages"), (tgt, want[1], "targets"), (ret, want[2], "returns")):
         assert np.abs(flat(g.cpu().numpy()) - w).max() < 1e-4, name                 # north_star: within 1e-4 on returns / advantages
+
+
+@pytest.mark.parametrize("max_rows", [60, 100, 150, 37, 400])
+def test_experience_fifo_equals_reference_experience_buffer(refl, max_rows):
+    """The REAL ExperienceBuffer (SubmitExperience + GetAllBatchesShuffled with its own std::default_random_engine): the rows it hands
+    out, batch by batch, after every submission, against (a) the numpy oracle's literal buffer and (b) the library's slot bookkeeping
+    (rlgpu_expbuf_*) -- same rows alive, same shuffle, same batches, remainder dropped."""
+    from rlgymppo_cpp_amd.learner import ExperienceFifo, Shuffler
+    T, N, seed, n_submits, batch = 5, 12, 321, 7, 16
+    B = T * N
+    ids = np.zeros(n_submits * (max_rows + B), np.int64); counts = np.zeros(n_submits, np.int32)
+    refl.refl_expbuf_run.restype = C.c_int64
+    n = refl.refl_expbuf_run(C.c_int64(max_rows), seed, n_submits, B, C.c_int64(batch), _p(ids), C.c_int64(ids.size), _p(counts))
+    assert 0 < n <= ids.size
+    ids = ids[:n]
+    ref = R.ExperienceBufferRef(max_rows, seed)
+    fifo, shuf = ExperienceFifo(max_rows, T, N), Shuffler(seed)
+    slot_of, at = {}, 0
+    for s in range(n_submits):
+        ref.submit(s * B + np.arange(B))
+        slot = fifo.submit()
+        slot_of = {k: v for k, v in slot_of.items() if v != slot}; slot_of[s] = slot
+        want = ref.all_batches_shuffled(batch)
+        assert len(want) == counts[s] == min(max_rows, (s + 1) * B) // batch
+        rows = np.empty(fifo.size(), np.int32)
+        fifo.shuffled_rows(shuf, rows)
+        for b, w in enumerate(want):
+            got = ids[at:at + batch]; at += batch
+            assert (got == w).all()                                                  # numpy oracle == the real buffer
+            k, a = got // B, got % B                                                 # reference row id -> (submission, agent-major index)
+            phys = np.array([slot_of[int(i)] for i in k]) * B + (a % T) * N + a // T
+            assert (rows[b * batch:(b + 1) * batch] == phys).all()                   # the library's device rows name the same experience
+    assert at == n
