@@ -9,6 +9,7 @@
 #include <private/RLGymPPO_CPP/PPO/DiscretePolicy.h>
 #include <private/RLGymPPO_CPP/PPO/ValueEstimator.h>
 #include <private/RLGymPPO_CPP/PPO/ExperienceBuffer.h>
+#include <public/RLGymPPO_CPP/Util/WelfordRunningStat.h>
 #include <torch/torch.h>
 #include <cstring>
 
@@ -95,6 +96,17 @@ int64_t refl_expbuf_run(int64_t max_size, int seed, int n_submits, int rows_per_
         }
     }
     return n;
+}
+
+// WelfordRunningStat (PUB/Util/WelfordRunningStat.h:5-84), shape 1, fed in chunks of `chunk` samples like Learner.cpp:679-682 does
+void refl_welford(const float* samples, int n, int chunk, double* mean_out, double* m2_out, int64_t* count_out, float* std_out) {
+    WelfordRunningStat w(1);
+    for (int i = 0; i < n; i += chunk) {
+        const int k = std::min(chunk, n - i);
+        FList part(samples + i, samples + i + k);
+        w.Increment(part, k);
+    }
+    *mean_out = w.runningMean[0]; *m2_out = w.runningVariance[0]; *count_out = w.count; *std_out = w.GetSTD()[0];
 }
 
 void refl_value(const int* hidden, int n_hidden, int D, const float* params, const float* obs, int rows, float* values_out) {

@@ -174,3 +174,25 @@ def test_experience_fifo_equals_reference_experience_buffer(refl, max_rows):
             phys = np.array([slot_of[int(i)] for i in k]) * B + (a % T) * N + a // T
             assert (rows[b * batch:(b + 1) * batch] == phys).all()                   # the library's device rows name the same experience
     assert at == n
+
+
+def test_welford_equals_reference_header(refl):
+    """WelfordRunningStat.h: mean / raw sum of squared deviations / count / GetSTD after chunked increments, against the Python host's
+    statistic (what RUNNING_STATS.json stores) and the oracle's."""
+    from rlgymppo_cpp_amd.learner import WelfordRunningStat
+    rs = np.random.RandomState(2)
+    xs = (rs.randn(1000) * 3 + 0.5).astype(np.float32)
+    mean, m2, cnt, std = C.c_double(), C.c_double(), C.c_int64(), C.c_float()
+    refl.refl_welford(_p(xs), 1000, 150, C.byref(mean), C.byref(m2), C.byref(cnt), C.byref(std))
+    w = WelfordRunningStat()
+    for i in range(0, 1000, 150):
+        part = xs[i:i + 150].tolist()
+        w.increment(part, len(part))
+    assert w.count == cnt.value == 1000 and abs(w.mean - mean.value) < 1e-12 and abs(w.m2 - m2.value) < 1e-9 * m2.value
+    assert abs(w.get_std() - std.value) < 1e-6
+    assert w.to_json()["var"][0] == w.m2                                          # the file stores the raw accumulator, like the reference
+    o = R.Welford(); o.increment(xs, 1000)
+    assert abs(o.std() - std.value) < 1e-6
+    one = (C.c_float * 1)(3.0)
+    refl.refl_welford(one, 1, 150, C.byref(mean), C.byref(m2), C.byref(cnt), C.byref(std))
+    assert std.value == 1.0 and WelfordRunningStat().get_std() == 1.0               # fewer than two samples: std 1 (WelfordRunningStat.h:70-72)
