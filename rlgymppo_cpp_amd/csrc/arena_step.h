@@ -384,35 +384,54 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
 }
 
 // gResolveSingleConstraintRow{LowerLimit,Generic}_scalar_reference (btSequentialImpulseConstraintSolver.cpp:46-100), cfm = 0
+// One Gauss-Seidel row update.  The row's constants and both bodies' deltas are read into locals FIRST and written back LAST: the
+// row and the bodies are all floats in LDS, so with the stores in between the compiler had to assume they alias and re-read the
+// bodies after storing the accumulated impulse -- a second LDS round trip on the dependent chain of the solve.  (Same arithmetic.)
 template <int NB>
 RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
     SolverBody& A = B[c.a];
+    const int b = c.b;
+    SolverBody& Bb = B[b >= 0 ? b : 0];
+    const V3 n1 = c.n1, r1xn = c.r1xn, r2xn = c.r2xn, ang_a = c.ang_a, ang_b = c.ang_b;
+    const float jac = c.jac, applied = c.applied;
+    const V3 a_dv = A.dv, a_dw = A.dw; const float a_im = A.inv_m;
+    V3 b_dv = v3(0, 0, 0), b_dw = v3(0, 0, 0); float b_im = 0.f;
+    if (b >= 0) { b_dv = Bb.dv; b_dw = Bb.dw; b_im = Bb.inv_m; }
     float delta = c.rhs;
-    float dv1 = dot(c.n1, A.dv) + dot(c.r1xn, A.dw);
-    float dv2 = (c.b >= 0) ? (dot(-c.n1, B[c.b].dv) + dot(c.r2xn, B[c.b].dw)) : 0.f;
-    delta -= dv1 * c.jac;
-    delta -= dv2 * c.jac;
-    float sum = c.applied + delta;
-    if (sum < lo) { delta = lo - c.applied; c.applied = lo; }
-    else if (!lower_only && sum > hi) { delta = hi - c.applied; c.applied = hi; }
-    else c.applied = sum;
-    A.dv += (c.n1 * A.inv_m) * delta; A.dw += c.ang_a * delta;
-    if (c.b >= 0) { B[c.b].dv += ((-c.n1) * B[c.b].inv_m) * delta; B[c.b].dw += c.ang_b * delta; }
+    float dv1 = dot(n1, a_dv) + dot(r1xn, a_dw);
+    float dv2 = (b >= 0) ? (dot(-n1, b_dv) + dot(r2xn, b_dw)) : 0.f;
+    delta -= dv1 * jac;
+    delta -= dv2 * jac;
+    float sum = applied + delta, now;
+    if (sum < lo) { delta = lo - applied; now = lo; }
+    else if (!lower_only && sum > hi) { delta = hi - applied; now = hi; }
+    else now = sum;
+    c.applied = now;
+    A.dv = a_dv + (n1 * a_im) * delta; A.dw = a_dw + ang_a * delta;
+    if (b >= 0) { Bb.dv = b_dv + ((-n1) * b_im) * delta; Bb.dw = b_dw + ang_b * delta; }
 }
 template <int NB>
 RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
     if (c.rhs_pen == 0.f) return 0.f;
     SolverBody& A = B[c.a];
+    const int b = c.b;
+    SolverBody& Bb = B[b >= 0 ? b : 0];
+    const V3 n1 = c.n1, r1xn = c.r1xn, r2xn = c.r2xn, ang_a = c.ang_a, ang_b = c.ang_b;
+    const float jac = c.jac, applied = c.applied_push;
+    const V3 a_p = A.push, a_t = A.turn; const float a_im = A.inv_m;
+    V3 b_p = v3(0, 0, 0), b_t = v3(0, 0, 0); float b_im = 0.f;
+    if (b >= 0) { b_p = Bb.push; b_t = Bb.turn; b_im = Bb.inv_m; }
     float delta = c.rhs_pen;
-    float dv1 = dot(c.n1, A.push) + dot(c.r1xn, A.turn);
-    float dv2 = (c.b >= 0) ? (dot(-c.n1, B[c.b].push) + dot(c.r2xn, B[c.b].turn)) : 0.f;
-    delta -= dv1 * c.jac;
-    delta -= dv2 * c.jac;
-    float sum = c.applied_push + delta;
-    if (sum < 0.f) { delta = 0.f - c.applied_push; c.applied_push = 0.f; }
-    else c.applied_push = sum;
-    A.push += (c.n1 * A.inv_m) * delta; A.turn += c.ang_a * delta;
-    if (c.b >= 0) { B[c.b].push += ((-c.n1) * B[c.b].inv_m) * delta; B[c.b].turn += c.ang_b * delta; }
+    float dv1 = dot(n1, a_p) + dot(r1xn, a_t);
+    float dv2 = (b >= 0) ? (dot(-n1, b_p) + dot(r2xn, b_t)) : 0.f;
+    delta -= dv1 * jac;
+    delta -= dv2 * jac;
+    float sum = applied + delta, now;
+    if (sum < 0.f) { delta = 0.f - applied; now = 0.f; }
+    else now = sum;
+    c.applied_push = now;
+    A.push = a_p + (n1 * a_im) * delta; A.turn = a_t + ang_a * delta;
+    if (b >= 0) { Bb.push = b_p + ((-n1) * b_im) * delta; Bb.turn = b_t + ang_b * delta; }
     return delta;
 }
 
@@ -566,7 +585,8 @@ RLG_HD_NOINLINE void solver_iterate(TickWork<NC>& W) {
         }
         if (resid <= 0.f || it >= K::SOLVER_ITERS - 1) break;
     }
-    // velocity iterations
+    // velocity iterations.  (Tried and dropped: fetching row k+1 while row k computes -- the extra register copies cost more issue
+    // slots than the fetch latency they hid: 467 K -> 537 K cycles on the slowest workgroup.)
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
         for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, 0.f, 1e10f, true);
         for (int k = n_normal; k < nr; k++) {
