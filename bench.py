@@ -144,7 +144,13 @@ def main():
     if rank == 0:
         agent_steps = B * world * args.steps
         value = agent_steps / elapsed
-        per_launch_bytes = algorithmic_bytes_per_gym_step(2 * args.team_size, L.obs_size) * args.envs
+        n_p = 2 * args.team_size
+        if L._fused_collect:
+            # one launch = the whole collection phase: the resident state is read and written ONCE, every step writes its experience rows
+            # (obs, reward, done, action, log-prob) and reads its observation rows back for the in-kernel inference
+            per_launch_bytes = (2 * (336 * n_p + 264) + args.horizon * (n_p * (4 * L.obs_size + 8) + 4 + n_p * (4 * L.obs_size + 8))) * args.envs
+        else:
+            per_launch_bytes = algorithmic_bytes_per_gym_step(n_p, L.obs_size) * args.envs
         avg_launch_s = (env_ms / max(1, env_launches)) * 1e-3
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         peak = 8000.0
@@ -162,7 +168,7 @@ def main():
             "collection_during_learn": bool(args.overlap),
             "ppo_iter_ms": consume_ms if not args.overlap else None, "gym_steps_per_s": value / (2 * args.team_size), "physics_ticks_per_s": value / (2 * args.team_size) * 8,
             "collect_ms_per_iter": (elapsed / args.steps * 1e3 - consume_ms) if not args.overlap else None,
-            "roofline": {"kernel": "k_env_step<%d> (8 fused ticks" % (2 * args.team_size) + " + snapshot/obs/reward/done/auto-reset)", "bound": "hbm", "achieved": achieved, "peak": peak,
+            "roofline": {"kernel": ("k_env_collect<%d> (%d x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)" % (2 * args.team_size, args.horizon)) if L._fused_collect else ("k_env_step<%d> (8 fused ticks + snapshot/obs/reward/done/auto-reset)" % (2 * args.team_size)), "bound": "hbm", "achieved": achieved, "peak": peak,
                          "unit": "GB/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": env_ms / max(1, env_launches), "launches": env_launches,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
             "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": (gemm_flops / (gemm_ms * 1e-3) / 1e12) if gemm_ms > 0 else 0.0,

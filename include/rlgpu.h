@@ -183,6 +183,16 @@ int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm_out);
  * ExperienceBuffer holds it): rows_out[i] = (p % T) * n_agents + p / T for p = perm[i], B = T * n_agents entries, ready for idx_dev */
 int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows_out);
 
+/* ---- fused collection.  The hot loop of ThreadAgent::_RunFunc (PRIV/Threading/ThreadAgent.cpp:58-163) for all envs and T steps in ONE
+ *      launch: for t < T { policy->GetAction(obs[t]) -> actions[t], logp[t];  GameInst::Step(actions[t]) -> obs[t+1], reward[t], done[t] }.
+ *      Every wavefront infers the actions of its own envs' agents and steps them without meeting the other wavefronts between steps
+ *      (DESIGN.md 4.1).  Same results as T alternations of rlgpu_policy_act and rlgpu_env_step (same sampler counters; log-probs within one ulp).  All pointers
+ *      are device memory, time-major: obs [T+1][n_agents][obs_size] with block 0 = the current observations, the rest [T][n_agents].
+ *      Needs the learner in bf16 mode with a policy whose hidden width fits the in-kernel scratch (256-wide nets do); otherwise
+ *      RLGPU_ERR_STATE and the caller alternates the two calls itself.  Launches on the env's stream. ---- */
+int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs_dev, int32_t* actions_dev, float* logp_dev, float* reward_dev, int32_t* done_dev,
+                  int deterministic);
+
 /* ---- ExperienceBuffer (PRIV/PPO/ExperienceBuffer.{h,cpp}): FIFO over rows with capacity max_rows.  Host bookkeeping only:
  *      every submitted iteration (T x n_agents rows, time-major) stays in one of `num_slots` device slots the caller owns; the
  *      library tracks which rows are still inside the FIFO (shift-left on overflow, :37-58; an addition larger than the buffer

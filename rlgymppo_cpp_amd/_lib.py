@@ -103,6 +103,7 @@ SIGNATURES = {
     "rlgpu_shuffler_destroy": (None, [_vp]),
     "rlgpu_shuffler_next": (_i, [_vp, C.c_int64, _vp]),
     "rlgpu_shuffler_next_rows": (_i, [_vp, C.c_int, C.c_int, _vp]),
+    "rlgpu_collect": (_i, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "rlgpu_expbuf_create": (_i, [C.POINTER(_vp), C.c_int64, C.c_int, C.c_int]),
     "rlgpu_expbuf_destroy": (None, [_vp]),
     "rlgpu_expbuf_num_slots": (_i, [_vp]),

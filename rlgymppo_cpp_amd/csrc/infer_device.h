@@ -1,0 +1,196 @@
+// infer_device.h -- device code shared by the learner's inference kernels (rlgpu_learn.hip) and the fused collection kernel of the
+// env (rlgpu_env.hip): the policy head (softmax / clamp / sampler / log-prob) and the description of an MLP as the MFMA kernels read
+// it.  Device-only (hipcc); reference semantics: DiscretePolicy::GetActionProbs / GetAction (PRIV/PPO/DiscretePolicy.cpp:44-62).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "rl_math.h"
+
+namespace rlinfer {
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+__device__ __forceinline__ short to_bf16(float f) {   // the hardware conversion, exactly rlgpu_learn.hip's f2bf
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<short*>(&h);
+}
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+}  // namespace rlinfer
+
+namespace rlinfer {
+// one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]
+struct HeadArgs {
+    int A; float inv_temp; int deterministic; const float* noise;
+    uint32_t seed_lo, seed_hi, call_ctr;
+    int32_t* actions; float* logp; float* probs_out;
+};
+
+// NR rows at once: the head is a chain of cross-lane steps (two reductions, an arg-max butterfly), each a ~100-cycle round trip;
+// rows are independent, so a wavefront that owns several interleaves them and the round trips overlap.  Per row the arithmetic
+// is the same for every NR.
+template <int NR>
+__device__ __forceinline__ void policy_head_rows(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h, int* picked = nullptr) {
+    // this code is compiled into two translation units with different -ffp-contract settings and must round identically in both (the
+    // fused collection kernel promises the batched kernels' bits): pin the setting here
+#pragma clang fp contract(fast)
+    const int A = h.A; const float inv_temp = h.inv_temp; const int deterministic = h.deterministic; const float* noise = h.noise;
+    int32_t* actions = h.actions; float* logp = h.logp; float* probs_out = h.probs_out;
+    const bool in0 = lane < A, in1 = (lane + 64) < A;
+    float v0[NR], v1[NR], mx[NR], e0[NR], e1[NR], sum[NR], p0[NR], p1[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        v0[n] = in0 ? z[n][lane] * inv_temp : -INFINITY;
+        v1[n] = in1 ? z[n][lane + 64] * inv_temp : -INFINITY;
+        mx[n] = fmaxf(v0[n], v1[n]);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], o, 64));
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        e0[n] = in0 ? expf(v0[n] - mx[n]) : 0.f; e1[n] = in1 ? expf(v1[n] - mx[n]) : 0.f;
+        sum[n] = e0[n] + e1[n];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) sum[n] += __shfl_xor(sum[n], o, 64);
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        p0[n] = fminf(fmaxf(e0[n] / sum[n], 1e-11f), 1.f); p1[n] = fminf(fmaxf(e1[n] / sum[n], 1e-11f), 1.f);
+        if (probs_out) {
+            if (in0) probs_out[(size_t)row[n] * A + lane] = p0[n];
+            if (in1) probs_out[(size_t)row[n] * A + lane + 64] = p1[n];
+        }
+    }
+    if (!actions) return;
+    float best[NR]; int bi[NR];
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        float s0, s1;
+        if (deterministic) { s0 = p0[n]; s1 = p1[n]; }
+        else {
+            float q0, q1;
+            if (noise) { q0 = in0 ? noise[(size_t)row[n] * A + lane] : 1.f; q1 = in1 ? noise[(size_t)row[n] * A + lane + 64] : 1.f; }
+            else {
+                uint32_t r[4];
+                rlg::philox4(h.seed_lo, h.seed_hi, (uint32_t)row[n], h.call_ctr, (uint32_t)lane, r);
+                // q ~ Exp(1): -log(1 - u), u in [0,1)
+                q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
+                q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
+            }
+            s0 = p0[n] / q0; s1 = p1[n] / q1;
+        }
+        if (!in0) s0 = -INFINITY;
+        if (!in1) s1 = -INFINITY;
+        best[n] = s0; bi[n] = lane;
+        if (s1 > best[n]) { best[n] = s1; bi[n] = lane + 64; }
+    }
+    // argmax with lowest-index tie break (torch.argmax / max semantics)
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int n = 0; n < NR; n++) {
+            float ob = __shfl_xor(best[n], o, 64); int oi = __shfl_xor(bi[n], o, 64);
+            if (ob > best[n] || (ob == best[n] && oi < bi[n])) { best[n] = ob; bi[n] = oi; }
+        }
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+        float pa = (bi[n] < 64) ? __shfl(p0[n], bi[n], 64) : __shfl(p1[n], bi[n] - 64, 64);
+        if (lane == 0) { actions[row[n]] = bi[n]; logp[row[n]] = deterministic ? 0.f : logf(pa); }
+        if (picked) picked[n] = bi[n];   // uniform over the wavefront after the butterfly
+    }
+}
+}  // namespace rlinfer
+
+// ---- an MLP as the MFMA kernels read it, and the forward pass of a few rows on ONE wavefront -------------------------------
+namespace rlinfer {
+struct InferNet {
+    int n_layers, D, ld;             // ld = LDS activation row in elements: max K + 8
+    const short* W[9];               // fragment-ordered bf16 weights (k_weight_frags): 1 KB per (32-column block, 16-deep K step)
+    const float* bias[9];
+    int K[9], N[9], Npad[9];         // layer i: K = padded inputs, N = outputs, Npad = outputs padded to 32
+};
+constexpr int LOGIT_LD = 132;        // fp32 logits row in LDS (n_actions <= 128)
+constexpr int WAVE_ROWS = 8;         // rows one wavefront infers at most: they sit in the first 8 rows of a 32-row MFMA tile
+__host__ __device__ constexpr int wave_buf_bytes(int ld) { return (WAVE_ROWS * ld * 2 > WAVE_ROWS * LOGIT_LD * 4) ? WAVE_ROWS * ld * 2 : WAVE_ROWS * LOGIT_LD * 4; }
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Policy forward + head for rows row0 .. row0 + R - 1 (R <= 8) whose fp32 observations are obs[r * D + c], by one wavefront.
+// Same operand values, accumulation order, bias / ReLU / bf16 rounding and head code as k_mlp_infer (rlgpu_learn.hip): the logits and
+// the sampled actions are those of a batched call.  Only the first n_rows (>= 1) of the R rows exist: the others redo the
+// last real one (same values, same stores).  buf0 / buf1: LDS, wave_buf_bytes(net.ld) each.  picked[r] = the action.
+template <int R>
+__device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R]) {
+    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 8 rows");
+    constexpr int CHUNK = 16;
+    short* in = buf0; short* out = buf1;
+    const int ld = net.ld;
+    for (int r = 0; r < R; r++) {
+        const int rr = r < n_rows ? r : n_rows - 1;
+        for (int c = lane; c < net.K[0]; c += 64) in[r * ld + c] = to_bf16(c < net.D ? obs[(size_t)rr * net.D + c] : 0.f);
+    }
+    wave_fence();
+    const bool a_valid = (lane & 31) < R;
+    auto n_blocks = [&](int i) { return (i == net.n_layers - 1) ? (net.N[i] + 31) / 32 : net.Npad[i] / 32; };
+    auto fetch = [&](bf16x8 (&b)[CHUNK], int i, int cb, int s0) {
+        const int nk = net.K[i] / 16;
+        const short* w = net.W[i] + ((size_t)cb * nk * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < CHUNK; j++)
+            if (s0 + j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(s0 + j) * 512);
+    };
+    bf16x8 bnext[CHUNK];
+    fetch(bnext, 0, 0, 0);
+    for (int i = 0; i < net.n_layers; i++) {
+        const bool last = (i == net.n_layers - 1);
+        const int N = net.N[i], nk = net.K[i] / 16, nblk = n_blocks(i);
+        float* const logits = reinterpret_cast<float*>(out);
+        const short* arow = in + (lane & 31) * ld + 8 * (lane >> 5);
+        for (int cb = 0; cb < nblk; cb++) {
+            bf16x8 b[CHUNK];
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) b[j] = bnext[j];
+            // the next block's (or the next layer's first block's) weights do not depend on the activations: ask for them now
+            if (cb + 1 < nblk) fetch(bnext, i, cb + 1, 0);
+            else if (!last) fetch(bnext, i + 1, 0, 0);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int s0 = 0; s0 < nk; s0 += CHUNK) {
+                if (s0 > 0) fetch(b, i, cb, s0);
+#pragma unroll
+                for (int j = 0; j < CHUNK; j++) {
+                    if (s0 + j >= nk) break;
+                    bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (a_valid) a = *reinterpret_cast<const bf16x8*>(arow + (s0 + j) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc, 0, 0, 0);
+                }
+            }
+            // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3
+            const int col = cb * 32 + (lane & 31);
+            const float bias = (col < N) ? net.bias[i][col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = r + 4 * (lane >> 5);
+                if (row >= R) continue;
+                const float v = acc[r] + bias;
+                if (last) logits[row * LOGIT_LD + col] = v;
+                else out[row * ld + col] = (col < N) ? to_bf16(fmaxf(v, 0.f)) : (short)0;
+            }
+        }
+        wave_fence();
+        short* t = in; in = out; out = t;
+    }
+    const float* logits = reinterpret_cast<const float*>(in);
+    const float* zs[R]; int rows[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = logits + rr * LOGIT_LD; rows[r] = row0 + rr; }
+    const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
+    policy_head_rows<R>(zc, rows, lane, head, picked);
+}
+}  // namespace rlinfer

@@ -32,6 +32,7 @@ __shared__ unsigned long long g_prof_last;
 #endif
 #include "../../include/rlgpu.h"
 #include "arena_gym.h"
+#include "rlgpu_internal.h"
 #include "arena_mesh.h"
 
 using namespace rlg;
@@ -456,6 +457,84 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
 #endif
 }
 
+// ---- fused collection: T x (policy inference + gym step) in ONE launch --------------------------------------------------------
+// k_env_step ends when its slowest workgroup ends, and that is a workgroup holding an env in a contact-heavy phase: the mean workgroup
+// needs about half as long (profiles/r01f_step_phase_cycles.txt), every workgroup is resident from the start, and nothing can fill
+// the tail.  Stepping a whole collection phase inside one kernel removes the per-step rendezvous: a wavefront infers the actions of
+// ITS OWN envs' agents (wave_infer: the policy MLP on <= 8 rows of one MFMA tile, weights streamed from L2, activations in the
+// TickWork area that is dead between ticks), steps its envs, writes the experience rows of step t, and goes on to t + 1 -- slow
+// phases of different envs now add up per wavefront over T steps instead of every step paying the worst of all envs.  The arena
+// state also stays in LDS for the whole phase (one load / store per launch instead of per step).  Results are those of T alternations
+// of rlgpu_policy_act and rlgpu_env_step: same inference arithmetic, same sampler counters, same stepper (log-probs within one ulp:
+// this translation unit forbids fp contraction and the compiler's logf / expf expansions honour that).
+struct CollectArgs {
+    int T; int n_agents;
+    float* obs;          // [T + 1][n_agents][D]; row block 0 holds the current observations
+    int32_t* acts; float* logp; float* rew; int32_t* done;   // [T][n_agents]
+    rlinfer::InferNet net; rlinfer::HeadArgs head;
+};
+
+template <int NC>
+__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(EnvDev d, CollectArgs c) {
+    constexpr int LANES = lanes_per_block<NC>();
+    constexpr int EPW = LANES / WPB, R = EPW * NC;
+    static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    __shared__ BvhNode lds_nodes[LDS_NODES];
+    __shared__ uint32_t lds_grid[GRID_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
+    const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
+    unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
+    if (n_valid == 0) return;
+    const bool env_lane = ws.lane < n_valid;
+    const int env = env0 + (env_lane ? ws.lane : 0);
+    LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
+    const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
+    const int D = obs_size<NC>(d.cfg);
+    const size_t N = (size_t)c.n_agents;
+    // inference scratch inside the TickWork areas (dead between ticks): two activation buffers and the picked actions
+    const int buf_bytes = rlinfer::wave_buf_bytes(c.net.ld);
+    unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
+    short* const buf0 = reinterpret_cast<short*>(w0);
+    short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
+    int* const act_lds = reinterpret_cast<int*>(w0 + (EPW >= 2 ? buf_bytes : 2 * buf_bytes));
+    const int row0 = env0 * NC, n_rows = n_valid * NC;
+    load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    wave_sync();
+    for (int t = 0; t < c.T; t++) {
+        // the observation rows of step t were written by this wavefront at the end of step t - 1 (or by the host before the launch)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        rlinfer::HeadArgs h = c.head;
+        h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
+        int picked[R];
+        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked);
+        if (ws.lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) act_lds[r] = picked[r];
+        }
+        wave_sync();
+        GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
+        if (env_lane) {
+            int32_t acts[NC];
+            for (int k = 0; k < NC; k++) acts[k] = act_lds[ws.lane * NC + k];
+            gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts, X);
+        }
+        wave_sync();
+        TickEvents ev; ev.bump_mask = 0;
+        arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);
+        if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
+        wave_sync();
+        for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
+        if (env_lane) {
+            gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D, (size_t)D, X);
+            for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        wave_sync();
+    }
+    store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+}
+
 template <int NC>
 __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, float* obs) {
     constexpr int LANES = lanes_per_block<NC>();
@@ -738,6 +817,38 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
     auto& evp = e->ev_pool[e->ev_used++];
     HIPCHK(e, hipEventRecord(evp.first, e->stream));
     DISPATCH_NC(e, k_env_step, grid, block, e->d, actions, next_obs, reward, done);
+    HIPCHK(e, hipEventRecord(evp.second, e->stream));
+    e->ev0 = evp.first; e->ev1 = evp.second;
+    e->timed = true;
+    HIPCHK(e, hipGetLastError());
+    return RLGPU_OK;
+}
+
+// ThreadAgent::_RunFunc for a whole collection phase (ThreadAgent.cpp:58-163): T x (policy->GetAction, GameInst::Step) for every env
+int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic) {
+    if (!l || T <= 0 || !obs || !actions || !logp || !reward || !done) { e->err = "rlgpu_collect: bad argument"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    CollectArgs c{};
+    const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;
+    const size_t tw = e->nc == 2 ? sizeof(TickWork<2>) : (e->nc == 4 ? sizeof(TickWork<4>) : sizeof(TickWork<6>));
+    const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
+    int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, max_buf, (void*)e->stream);
+    if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (bf16 mode, <= 128 actions, hidden width within the LDS scratch)"; return rc; }
+    if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
+    c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    if (e->ev_used == e->ev_pool.size()) {
+        if (e->ev_pool.size() < 2048) {
+            hipEvent_t a, b; HIPCHK(e, hipEventCreate(&a)); HIPCHK(e, hipEventCreate(&b));
+            e->ev_pool.push_back({a, b});
+        } else {
+            float tmp; int n; int rc2 = rlgpu_env_timing_total(e, &tmp, &n, 0);
+            if (rc2) return rc2;
+        }
+    }
+    auto& evp = e->ev_pool[e->ev_used++];
+    HIPCHK(e, hipEventRecord(evp.first, e->stream));
+    DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
     HIPCHK(e, hipEventRecord(evp.second, e->stream));
     e->ev0 = evp.first; e->ev1 = evp.second;
     e->timed = true;

@@ -24,8 +24,12 @@
 
 #include "../../include/rlgpu.h"
 #include "rl_math.h"
+#include "infer_device.h"
+#include "rlgpu_internal.h"
 
 namespace {
+using rlinfer::HeadArgs;
+using rlinfer::policy_head_rows;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -460,12 +464,7 @@ __global__ void __launch_bounds__(256) k_col_sum(const float* X, int ld, int M, 
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 
-// one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]
-struct HeadArgs {
-    int A; float inv_temp; int deterministic; const float* noise;
-    uint32_t seed_lo, seed_hi, call_ctr;
-    int32_t* actions; float* logp; float* probs_out;
-};
+// one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]  (HeadArgs, policy_head_rows: infer_device.h)
 __device__ __forceinline__ void policy_head_row(const float* z /* logits of this row, global or LDS */, int row, int lane, const HeadArgs& h);
 
 __global__ void k_policy_head(const float* logits, int ld, int rows, HeadArgs h) {
@@ -475,76 +474,6 @@ __global__ void k_policy_head(const float* logits, int ld, int rows, HeadArgs h)
     policy_head_row(logits + (size_t)row * ld, row, lane, h);
 }
 
-// NR rows at once: the head is a chain of cross-lane steps (two reductions, an arg-max butterfly), each a ~100-cycle round trip;
-// rows are independent, so a wavefront that owns several interleaves them and the round trips overlap.  Per row the arithmetic
-// is the same for every NR.
-template <int NR>
-__device__ __forceinline__ void policy_head_rows(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h) {
-    const int A = h.A; const float inv_temp = h.inv_temp; const int deterministic = h.deterministic; const float* noise = h.noise;
-    int32_t* actions = h.actions; float* logp = h.logp; float* probs_out = h.probs_out;
-    const bool in0 = lane < A, in1 = (lane + 64) < A;
-    float v0[NR], v1[NR], mx[NR], e0[NR], e1[NR], sum[NR], p0[NR], p1[NR];
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        v0[n] = in0 ? z[n][lane] * inv_temp : -INFINITY;
-        v1[n] = in1 ? z[n][lane + 64] * inv_temp : -INFINITY;
-        mx[n] = fmaxf(v0[n], v1[n]);
-    }
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int n = 0; n < NR; n++) mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], o, 64));
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        e0[n] = in0 ? expf(v0[n] - mx[n]) : 0.f; e1[n] = in1 ? expf(v1[n] - mx[n]) : 0.f;
-        sum[n] = e0[n] + e1[n];
-    }
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int n = 0; n < NR; n++) sum[n] += __shfl_xor(sum[n], o, 64);
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        p0[n] = fminf(fmaxf(e0[n] / sum[n], 1e-11f), 1.f); p1[n] = fminf(fmaxf(e1[n] / sum[n], 1e-11f), 1.f);
-        if (probs_out) {
-            if (in0) probs_out[(size_t)row[n] * A + lane] = p0[n];
-            if (in1) probs_out[(size_t)row[n] * A + lane + 64] = p1[n];
-        }
-    }
-    if (!actions) return;
-    float best[NR]; int bi[NR];
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        float s0, s1;
-        if (deterministic) { s0 = p0[n]; s1 = p1[n]; }
-        else {
-            float q0, q1;
-            if (noise) { q0 = in0 ? noise[(size_t)row[n] * A + lane] : 1.f; q1 = in1 ? noise[(size_t)row[n] * A + lane + 64] : 1.f; }
-            else {
-                uint32_t r[4];
-                rlg::philox4(h.seed_lo, h.seed_hi, (uint32_t)row[n], h.call_ctr, (uint32_t)lane, r);
-                // q ~ Exp(1): -log(1 - u), u in [0,1)
-                q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
-                q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
-            }
-            s0 = p0[n] / q0; s1 = p1[n] / q1;
-        }
-        if (!in0) s0 = -INFINITY;
-        if (!in1) s1 = -INFINITY;
-        best[n] = s0; bi[n] = lane;
-        if (s1 > best[n]) { best[n] = s1; bi[n] = lane + 64; }
-    }
-    // argmax with lowest-index tie break (torch.argmax / max semantics)
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int n = 0; n < NR; n++) {
-            float ob = __shfl_xor(best[n], o, 64); int oi = __shfl_xor(bi[n], o, 64);
-            if (ob > best[n] || (ob == best[n] && oi < bi[n])) { best[n] = ob; bi[n] = oi; }
-        }
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        float pa = (bi[n] < 64) ? __shfl(p0[n], bi[n], 64) : __shfl(p1[n], bi[n] - 64, 64);
-        if (lane == 0) { actions[row[n]] = bi[n]; logp[row[n]] = deterministic ? 0.f : logf(pa); }
-    }
-}
 __device__ __forceinline__ void policy_head_row(const float* z, int row, int lane, const HeadArgs& h) {
     const float* const zs[1] = {z}; const int rows[1] = {row};
     policy_head_rows<1>(zs, rows, lane, h);
@@ -1335,6 +1264,30 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     return RLGPU_OK;
 }
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }
+}  // extern "C"
+int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer::HeadArgs* head, int deterministic, int n_calls, int max_buf_bytes, void* stream) {
+    if (!l->cfg.use_bf16 || l->cfg.n_actions > 128 || l->pol.n_layers > 9) return RLGPU_ERR_STATE;
+    int maxkp = 0;
+    for (int i = 0; i < l->pol.n_layers; i++) maxkp = std::max(maxkp, l->pol.kp[i]);
+    if (rlinfer::wave_buf_bytes(maxkp + 8) > max_buf_bytes) return RLGPU_ERR_STATE;
+    LCHK(l, hipSetDevice(l->device));
+    hipStream_t keep = l->stream;
+    l->stream = (hipStream_t)stream;            // the weight copies must be current on the stream the caller launches on
+    int rc = refresh_shadows(l);
+    l->stream = keep;
+    if (rc) return rc;
+    const Net& n = l->pol;
+    net->n_layers = n.n_layers; net->D = l->cfg.obs_size; net->ld = maxkp + 8;
+    for (int i = 0; i < n.n_layers; i++) {
+        net->W[i] = l->shadows + n.wf16_off[i]; net->bias[i] = l->params + n.b_off[i];
+        net->K[i] = n.kp[i]; net->N[i] = n.dims[i + 1]; net->Npad[i] = n.kp[i + 1];
+    }
+    const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+    *head = HeadArgs{l->cfg.n_actions, inv_t, deterministic, nullptr, l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, nullptr, nullptr, nullptr};
+    l->call_ctr += (uint32_t)n_calls;
+    return RLGPU_OK;
+}
+extern "C" {
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); return l->cfg.use_bf16 ? refresh_shadows(l) : RLGPU_OK; }
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float t) { if (!(t > 0)) return RLGPU_ERR_ARG; l->cfg.temperature = t; return RLGPU_OK; }
 int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }

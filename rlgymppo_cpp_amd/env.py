@@ -96,6 +96,17 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_step(self.h, actions.data_ptr(), next_obs.data_ptr(), reward.data_ptr(), done.data_ptr()),
              self.h, self.lib.rlgpu_env_last_error)
 
+    def collect(self, ppo, T: int, obs: torch.Tensor, actions: torch.Tensor, logp: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, deterministic=False) -> bool:
+        """T x (policy act + gym step) in one launch (rlgpu_collect).  obs: [T+1][n_agents][D] with obs[0] current; the others [T][n_agents].
+        Returns False -- nothing launched -- when the policy does not fit the in-kernel inference (the caller then alternates act / step)."""
+        assert obs.is_contiguous() and actions.is_contiguous() and logp.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+        assert obs.shape[0] >= T + 1 and actions.dtype == torch.int32 and done.dtype == torch.int32
+        rc = self.lib.rlgpu_collect(self.h, ppo.h, T, obs.data_ptr(), actions.data_ptr(), logp.data_ptr(), reward.data_ptr(), done.data_ptr(), 1 if deterministic else 0)
+        if rc == -3:   # RLGPU_ERR_STATE
+            return False
+        _chk(rc, self.h, self.lib.rlgpu_env_last_error)
+        return True
+
     def physics_ticks(self, ticks: int):
         _chk(self.lib.rlgpu_env_physics_ticks(self.h, ticks), self.h, self.lib.rlgpu_env_last_error)
 

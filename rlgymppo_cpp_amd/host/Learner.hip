@@ -121,7 +121,7 @@ struct Learner::Impl {
     // ExperienceBuffer (ExperienceBuffer.h): the FIFO's iterations stay in device slots of B rows, the library tracks the live rows
     rlgpu_expbuf* fifo = nullptr;
     float *exObs = nullptr, *exLogp = nullptr, *exAdv = nullptr, *exTgt = nullptr; int32_t* exActs = nullptr;
-    bool first = true, renderOnly = false;
+    bool first = true, renderOnly = false, fusedCollect = true;
     Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     std::vector<GameInst> games;
@@ -268,6 +268,13 @@ void Learner::CollectTimesteps() {
         m.games.resize(m.nEnvs);
         for (int e = 0; e < m.nEnvs; e++) { m.games[e].gym = m.gym; m.games[e].match = m.match; m.games[e].index = e; }
         m.hostStates.resize(m.nEnvs); m.hostRew.resize(m.nAgents); m.hostDone.resize(m.nAgents);
+    }
+    // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
+    if (!slow && !renderSender && m.fusedCollect) {
+        int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
+        if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B; return; }
+        if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");
+        m.fusedCollect = false;   // fp32 mode or a net too wide for the kernel's LDS scratch: alternate act / step
     }
     for (int t = 0; t < m.T; t++) {
         const size_t o = (size_t)t * m.nAgents;

@@ -244,6 +244,7 @@ class Learner:
         self.metric_sender = None   # created by run() after a possible load(), so that a loaded run id continues (Learner.cpp:149-155)
         self.env.reset(True, self.obs_buf[0])
         self._first = True
+        self._fused_collect = not os.environ.get("RLGPU_NO_FUSED_COLLECT")
 
     # ---- collection ------------------------------------------------------------------------------------------------
     def collect(self):
@@ -251,9 +252,14 @@ class Learner:
         if not self._first:
             self.obs_buf[0].copy_(self.obs_buf[self.T])
         self._first = False
-        for t in range(self.T):
-            self.ppo.act(self.obs_buf[t], self.act_buf[t], self.logp_buf[t], deterministic=self.cfg.deterministic)
-            self.env.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t])
+        # the whole phase in one launch when the policy fits the in-kernel inference (rlgpu_collect), else T x (act, step)
+        if self._fused_collect:
+            self._fused_collect = self.env.collect(self.ppo, self.T, self.obs_buf, self.act_buf, self.logp_buf, self.rew_buf, self.done_buf,
+                                                   deterministic=self.cfg.deterministic)
+        if not self._fused_collect:
+            for t in range(self.T):
+                self.ppo.act(self.obs_buf[t], self.act_buf[t], self.logp_buf[t], deterministic=self.cfg.deterministic)
+                self.env.step(self.act_buf[t], self.obs_buf[t + 1], self.rew_buf[t], self.done_buf[t])
         self.total_timesteps += self.B * self.world
 
     # ---- AddNewExperience (Learner.cpp:608-703) -----------------------------------------------------------------------

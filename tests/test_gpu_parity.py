@@ -495,3 +495,46 @@ def test_collection_during_learn_mode():
     assert np.isfinite(rep["Policy Entropy"]) and 0 < rep["Policy Entropy"] < np.log(90) + 1e-3
     # the slot holding the last iteration is intact (nothing wrote into it after its copy)
     assert torch.equal(L.ex_act[:B] if torch.equal(L.ex_act[:B], L.act_buf.view(-1)) else L.ex_act[B:2 * B], L.act_buf.view(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("team_size,n_envs", [(1, 70), (2, 21), (3, 9)])
+def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs):
+    """rlgpu_collect (T x (inference + gym step) in one launch, every wavefront on its own envs) against T alternations of
+    rlgpu_policy_act / rlgpu_env_step from the same seeds: observations, actions, rewards, dones and the final env state are
+    bit-identical, log-probs within one ulp.  Env counts that leave the last wavefront partly empty; 1v1 / 2v2 / 3v3 = 4 / 2 / 1 envs per wavefront."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    from rlgymppo_cpp_amd import _lib
+    T = 12
+    dev = torch.device("cuda", 0)
+    out = []
+    for fused in (False, True):
+        cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 5; cfg.seed_lo = 31
+        env = BatchedEnv(n_envs, team_size, cfg=cfg)
+        N, D = env.n_agents, env.obs_size
+        ppo = PPOCore(D, env.n_actions, (256, 256, 256), (64,), use_bf16=True, max_rows=max(N, 64), seed=5)
+        obs = torch.zeros((T + 1, N, D), device=dev); acts = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        logp = torch.zeros((T, N), device=dev); rew = torch.zeros((T, N), device=dev); done = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        env.reset(True, obs[0])
+        if fused:
+            assert env.collect(ppo, T, obs, acts, logp, rew, done)
+        else:
+            for t in range(T):
+                ppo.act(obs[t], acts[t], logp[t])
+                env.step(acts[t], obs[t + 1], rew[t], done[t])
+        env.sync()
+        # one more sequential step from both: the resident env state and the sampler counter moved identically
+        a2 = torch.zeros(N, dtype=torch.int32, device=dev); l2 = torch.zeros(N, device=dev); o2 = torch.zeros((N, D), device=dev)
+        r2 = torch.zeros(N, device=dev); d2 = torch.zeros(N, dtype=torch.int32, device=dev)
+        ppo.act(obs[T], a2, l2); env.step(a2, o2, r2, d2); env.sync()
+        out.append([x.cpu().numpy() for x in (obs, acts, logp, rew, done, a2, l2, o2, r2, d2)])
+    names = ("obs", "actions", "logp", "reward", "done", "next actions", "next logp", "next obs", "next reward", "next done")
+    for a, b, name in zip(out[0], out[1], names):
+        if "logp" in name:
+            # the head is compiled into two translation units; the stepper's one forbids fp contraction, and the compiler's expansion of
+            # logf / expf honours that -- the log-probs agree to the last bit or the one before
+            assert np.abs(a - b).max() < 1e-6, name
+        else:
+            assert np.array_equal(a, b), name
+    assert out[0][4].sum() > 0 and len(np.unique(out[0][1])) > 20      # episodes ended (auto-resets inside the launch) and actions vary

@@ -58,16 +58,22 @@ if hasattr(env.lib, "rlgpu_env_debug_step_prof"):
     nb = (n + 3) // 4
     acc = np.zeros((min(nb, 4096), 16))
     reps = 8
+    per_launch = []
     for t in range(reps):
         a = torch.randint(0, 90, (env.n_agents,), generator=g, dtype=torch.int32).to(dev)
         env.step(a, nobs, rew, done)
         buf = np.zeros(16 * min(nb, 4096), dtype=np.uint64)
         assert fn2(env.h, buf.ctypes.data, nb) == 0
         acc += buf.reshape(-1, 16).astype(np.float64)
+        per_launch.append(buf.reshape(-1, 16)[:, :12].astype(np.float64).sum(axis=1))
     acc /= reps
     names = ["car pre-tick+pads/gravity", "candidates", "narrowphase items", "contacts+solver setup", "solver iters", "integrate", "post/pads/ball",
              "wheel ray casts", "load+parse actions", "tracker/snapshot/reward/done", "reset+obs", "store"]
     tot = acc[:, :12].sum(axis=1)
+    pl = np.stack(per_launch)   # [launch][workgroup]
+    q = np.percentile(pl, [50, 90, 99, 99.9], axis=1).mean(axis=1)
+    print("per launch, over its workgroups: median %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f (mean of %d launches); workgroups above 80%% of their launch's max: %.1f"
+          % (q[0], q[1], q[2], q[3], pl.max(axis=1).mean(), reps, (pl > 0.8 * pl.max(axis=1, keepdims=True)).sum(axis=1).mean()))
     print(f"k_env_step cycles per launch: mean {tot.mean():.0f} max {tot.max():.0f} ({tot.max()/2.38e3:.0f} us)")
     print("   mean: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, acc[:, :12].mean(axis=0))))
     w = int(np.argmax(tot))
