@@ -125,7 +125,8 @@ __device__ __forceinline__ void wave_fence() {
 // the sampled actions are those of a batched call.  Only the first n_rows (>= 1) of the R rows exist: the others redo the
 // last real one (same values, same stores).  buf0 / buf1: LDS, wave_buf_bytes(net.ld) each.  picked[r] = the action.
 template <int R>
-__device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R]) {
+__device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R],
+                                           unsigned long long* prof_split = nullptr) {
     static_assert(R <= WAVE_ROWS, "a wavefront infers at most 8 rows");
     constexpr int CHUNK = 16;
     short* in = buf0; short* out = buf1;
@@ -144,8 +145,12 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
         for (int j = 0; j < CHUNK; j++)
             if (s0 + j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(s0 + j) * 512);
     };
+    // the bias of a block is asked for together with its weights: loaded at the end of the block it was a full L2 round trip on the
+    // dependent chain of every one of the ~26 blocks
+    auto fetch_bias = [&](int i, int cb) { const int col = cb * 32 + (lane & 31); return (col < net.N[i]) ? net.bias[i][col] : 0.f; };
     bf16x8 bnext[CHUNK];
     fetch(bnext, 0, 0, 0);
+    float bias_next = fetch_bias(0, 0);
     for (int i = 0; i < net.n_layers; i++) {
         const bool last = (i == net.n_layers - 1);
         const int N = net.N[i], nk = net.K[i] / 16, nblk = n_blocks(i);
@@ -155,9 +160,10 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
             bf16x8 b[CHUNK];
 #pragma unroll
             for (int j = 0; j < CHUNK; j++) b[j] = bnext[j];
+            const float bias = bias_next;
             // the next block's (or the next layer's first block's) weights do not depend on the activations: ask for them now
-            if (cb + 1 < nblk) fetch(bnext, i, cb + 1, 0);
-            else if (!last) fetch(bnext, i + 1, 0, 0);
+            if (cb + 1 < nblk) { fetch(bnext, i, cb + 1, 0); bias_next = fetch_bias(i, cb + 1); }
+            else if (!last) { fetch(bnext, i + 1, 0, 0); bias_next = fetch_bias(i + 1, 0); }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -173,7 +179,6 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
             }
             // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3
             const int col = cb * 32 + (lane & 31);
-            const float bias = (col < N) ? net.bias[i][col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = r + 4 * (lane >> 5);
@@ -186,6 +191,9 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
         wave_fence();
         short* t = in; in = out; out = t;
     }
+#ifdef RLG_TICK_PROFILE
+    if (prof_split) *prof_split = __builtin_amdgcn_s_memtime();   // profiler build: the MLP ends here, the head begins
+#endif
     const float* logits = reinterpret_cast<const float*>(in);
     const float* zs[R]; int rows[R];
 #pragma unroll

@@ -499,20 +499,36 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
     int* const act_lds = reinterpret_cast<int*>(w0 + (EPW >= 2 ? buf_bytes : 2 * buf_bytes));
     const int row0 = env0 * NC, n_rows = n_valid * NC;
+#ifdef RLG_TICK_PROFILE
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long prof_infer = 0, prof_mlp = 0;
+#endif
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     wave_sync();
     for (int t = 0; t < c.T; t++) {
+#ifdef RLG_TICK_PROFILE
+        const unsigned long long prof_a = __builtin_amdgcn_s_memtime();
+#endif
         // the observation rows of step t were written by this wavefront at the end of step t - 1 (or by the host before the launch)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         rlinfer::HeadArgs h = c.head;
         h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
         int picked[R];
+#ifdef RLG_TICK_PROFILE
+        unsigned long long prof_mid = 0;
+        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked, &prof_mid);
+        prof_mlp += prof_mid - prof_a;
+#else
         rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked);
+#endif
         if (ws.lane == 0) {
 #pragma unroll
             for (int r = 0; r < R; r++) act_lds[r] = picked[r];
         }
         wave_sync();
+#ifdef RLG_TICK_PROFILE
+        prof_infer += __builtin_amdgcn_s_memtime() - prof_a;
+#endif
         GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
         if (env_lane) {
             int32_t acts[NC];
@@ -533,6 +549,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         wave_sync();
     }
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+#ifdef RLG_TICK_PROFILE
+    // profiler build: this workgroup's total and inference cycles (read back with rlgpu_env_debug_step_prof)
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_step_prof[16 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_step_prof[16 * blockIdx.x + 1] = prof_infer; g_step_prof[16 * blockIdx.x + 2] = prof_mlp; }
+#endif
 }
 
 template <int NC>

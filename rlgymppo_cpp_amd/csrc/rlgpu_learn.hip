@@ -1269,7 +1269,7 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
     if (!l->cfg.use_bf16 || l->cfg.n_actions > 128 || l->pol.n_layers > 9) return RLGPU_ERR_STATE;
     int maxkp = 0;
     for (int i = 0; i < l->pol.n_layers; i++) maxkp = std::max(maxkp, l->pol.kp[i]);
-    if (rlinfer::wave_buf_bytes(maxkp + 8) > max_buf_bytes) return RLGPU_ERR_STATE;
+    if (rlinfer::wave_buf_bytes(maxkp + 8) > max_buf_bytes || maxkp > 256) return RLGPU_ERR_STATE;   // wave_infer keeps a layer's 16 K steps in registers
     LCHK(l, hipSetDevice(l->device));
     hipStream_t keep = l->stream;
     l->stream = (hipStream_t)stream;            // the weight copies must be current on the stream the caller launches on
