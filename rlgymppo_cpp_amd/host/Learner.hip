@@ -270,7 +270,7 @@ void Learner::CollectTimesteps() {
         m.hostStates.resize(m.nEnvs); m.hostRew.resize(m.nAgents); m.hostDone.resize(m.nAgents);
     }
     // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
-    if (!slow && !renderSender && m.fusedCollect) {
+    if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= 2) {   // 3v3: one env per wavefront, the in-kernel inference does not amortise
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
         if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B; return; }
         if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");
