@@ -136,7 +136,6 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
         for (int c = lane; c < net.K[0]; c += 64) in[r * ld + c] = to_bf16(c < net.D ? obs[(size_t)rr * net.D + c] : 0.f);
     }
     wave_fence();
-    const bool a_valid = (lane & 31) < R;
     auto n_blocks = [&](int i) { return (i == net.n_layers - 1) ? (net.N[i] + 31) / 32 : net.Npad[i] / 32; };
     auto fetch = [&](bf16x8 (&b)[CHUNK], int i, int cb, int s0) {
         const int nk = net.K[i] / 16;
@@ -155,7 +154,9 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
         const bool last = (i == net.n_layers - 1);
         const int N = net.N[i], nk = net.K[i] / 16, nblk = n_blocks(i);
         float* const logits = reinterpret_cast<float*>(out);
-        const short* arow = in + (lane & 31) * ld + 8 * (lane >> 5);
+        // tile rows >= R do not exist: their lanes re-read row 0 (rows of an MFMA are independent and only rows < R are stored), which
+        // keeps the operand loads free of exec masking
+        const short* arow = in + ((lane & 31) < R ? (lane & 31) : 0) * ld + 8 * (lane >> 5);
         for (int cb = 0; cb < nblk; cb++) {
             bf16x8 b[CHUNK];
 #pragma unroll
@@ -167,16 +168,26 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            for (int s0 = 0; s0 < nk; s0 += CHUNK) {
-                if (s0 > 0) fetch(b, i, cb, s0);
-#pragma unroll
-                for (int j = 0; j < CHUNK; j++) {
-                    if (s0 + j >= nk) break;
-                    bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (a_valid) a = *reinterpret_cast<const bf16x8*>(arow + (s0 + j) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc, 0, 0, 0);
-                }
+            // A operands: four K steps ahead of the MFMA that consumes them, in a rotating set of four registers -- one ds_read per
+            // step issued right in front of its MFMA, into the register the previous MFMA was still reading, serialised the whole
+            // reduction on the LDS latency (270 cycles per K step)
+            // (four named registers, not an array: indexed through the unrolled loop the array went to scratch memory)
+            const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            bf16x8 a0 = zero8, a1 = zero8, a2 = zero8, a3 = zero8;
+            if (0 < nk) a0 = *reinterpret_cast<const bf16x8*>(arow + 0 * 16);
+            if (1 < nk) a1 = *reinterpret_cast<const bf16x8*>(arow + 1 * 16);
+            if (2 < nk) a2 = *reinterpret_cast<const bf16x8*>(arow + 2 * 16);
+            if (3 < nk) a3 = *reinterpret_cast<const bf16x8*>(arow + 3 * 16);
+#define RLINFER_STEP(J, AREG)                                                                                   \
+            if ((J) < nk) {                                                                                     \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AREG, b[J], acc, 0, 0, 0);                        \
+                if ((J) + 4 < nk) AREG = *reinterpret_cast<const bf16x8*>(arow + ((J) + 4) * 16);               \
             }
+            RLINFER_STEP(0, a0) RLINFER_STEP(1, a1) RLINFER_STEP(2, a2) RLINFER_STEP(3, a3)
+            RLINFER_STEP(4, a0) RLINFER_STEP(5, a1) RLINFER_STEP(6, a2) RLINFER_STEP(7, a3)
+            RLINFER_STEP(8, a0) RLINFER_STEP(9, a1) RLINFER_STEP(10, a2) RLINFER_STEP(11, a3)
+            RLINFER_STEP(12, a0) RLINFER_STEP(13, a1) RLINFER_STEP(14, a2) RLINFER_STEP(15, a3)
+#undef RLINFER_STEP
             // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3
             const int col = cb * 32 + (lane & 31);
 #pragma unroll
