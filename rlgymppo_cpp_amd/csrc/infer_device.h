@@ -120,6 +120,49 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One 32-column block of a layer with NK K steps, guard-free (see wave_infer): weight fragments, and the MFMA chain with the A operand
+// read four steps ahead into four named registers.
+template <int NK>
+__device__ __forceinline__ void fetch_block(bf16x8 (&b)[16], const short* w) {
+#pragma unroll
+    for (int j = 0; j < NK; j++) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
+}
+template <int NK>
+__device__ __forceinline__ void mma_block(const short* arow, const bf16x8 (&b)[16], f32x16& acc) {
+#define RLINFER_A(J) (*reinterpret_cast<const bf16x8*>(arow + ((J) < NK ? (J) : 0) * 16))
+#define RLINFER_STEP(J, AREG)                                                                    \
+    if constexpr ((J) < NK) {                                                                    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AREG, b[J], acc, 0, 0, 0);                 \
+        if constexpr ((J) + 4 < NK) AREG = RLINFER_A((J) + 4);                                   \
+        __builtin_amdgcn_sched_barrier(0);   /* keep the read four steps ahead: the scheduler sinks it to its use otherwise */ \
+    }
+    bf16x8 a0 = RLINFER_A(0), a1 = RLINFER_A(1), a2 = RLINFER_A(2), a3 = RLINFER_A(3);
+    __builtin_amdgcn_sched_barrier(0);
+    RLINFER_STEP(0, a0) RLINFER_STEP(1, a1) RLINFER_STEP(2, a2) RLINFER_STEP(3, a3)
+    RLINFER_STEP(4, a0) RLINFER_STEP(5, a1) RLINFER_STEP(6, a2) RLINFER_STEP(7, a3)
+    RLINFER_STEP(8, a0) RLINFER_STEP(9, a1) RLINFER_STEP(10, a2) RLINFER_STEP(11, a3)
+    RLINFER_STEP(12, a0) RLINFER_STEP(13, a1) RLINFER_STEP(14, a2) RLINFER_STEP(15, a3)
+#undef RLINFER_STEP
+#undef RLINFER_A
+}
+// any other depth (<= 16 steps): guarded, slower
+__device__ __forceinline__ void fetch_block_any(bf16x8 (&b)[16], const short* w, int nk) {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
+}
+__device__ __forceinline__ void mma_block_any(const short* arow, const bf16x8 (&b)[16], f32x16& acc, int nk) {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < nk) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + j * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc, 0, 0, 0);
+        }
+}
+// the K depths that occur: 16 (256-wide hidden layers), and the padded observation widths 96 / 128 / 192 / 224 (89, 127, 165, 203 floats)
+#define RLINFER_DISPATCH_NK(nk, CALL, FALLBACK) \
+    switch (nk) { case 16: CALL(16); break; case 6: CALL(6); break; case 8: CALL(8); break; case 12: CALL(12); break; case 14: CALL(14); break; default: FALLBACK; }
+
 // Policy forward + head for rows row0 .. row0 + R - 1 (R <= 8) whose fp32 observations are obs[r * D + c], by one wavefront.
 // Same operand values, accumulation order, bias / ReLU / bf16 rounding and head code as k_mlp_infer (rlgpu_learn.hip): the logits and
 // the sampled actions are those of a batched call.  Only the first n_rows (>= 1) of the R rows exist: the others redo the
@@ -137,18 +180,21 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
     }
     wave_fence();
     auto n_blocks = [&](int i) { return (i == net.n_layers - 1) ? (net.N[i] + 31) / 32 : net.Npad[i] / 32; };
-    auto fetch = [&](bf16x8 (&b)[CHUNK], int i, int cb, int s0) {
+    // Weight fragments of one 32-column block (K <= 256: at most CHUNK steps).  The compiler tracks outstanding loads through straight-line
+    // code only -- behind per-step `if (step < nk)` guards it waited for EVERY load (s_waitcnt vmcnt(0)) in front of every MFMA, which
+    // turned the prefetch of the next block into a stall of the current one.  So: one guard-free path for full-depth blocks (K = 256,
+    // the hidden layers and the head, 19 of the 27 blocks of the 256x3 policy), a guarded one for the rest.
+    auto fetch = [&](bf16x8 (&b)[CHUNK], int i, int cb) {
         const int nk = net.K[i] / 16;
         const short* w = net.W[i] + ((size_t)cb * nk * 64 + lane) * 8;
-#pragma unroll
-        for (int j = 0; j < CHUNK; j++)
-            if (s0 + j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(s0 + j) * 512);
+#define RLINFER_FETCH(NK) fetch_block<NK>(b, w)
+        RLINFER_DISPATCH_NK(nk, RLINFER_FETCH, fetch_block_any(b, w, nk))
+#undef RLINFER_FETCH
     };
-    // the bias of a block is asked for together with its weights: loaded at the end of the block it was a full L2 round trip on the
-    // dependent chain of every one of the ~26 blocks
+    // the bias of a block is asked for together with its weights
     auto fetch_bias = [&](int i, int cb) { const int col = cb * 32 + (lane & 31); return (col < net.N[i]) ? net.bias[i][col] : 0.f; };
     bf16x8 bnext[CHUNK];
-    fetch(bnext, 0, 0, 0);
+    fetch(bnext, 0, 0);
     float bias_next = fetch_bias(0, 0);
     for (int i = 0; i < net.n_layers; i++) {
         const bool last = (i == net.n_layers - 1);
@@ -162,32 +208,19 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 #pragma unroll
             for (int j = 0; j < CHUNK; j++) b[j] = bnext[j];
             const float bias = bias_next;
-            // the next block's (or the next layer's first block's) weights do not depend on the activations: ask for them now
-            if (cb + 1 < nblk) { fetch(bnext, i, cb + 1, 0); bias_next = fetch_bias(i, cb + 1); }
-            else if (!last) { fetch(bnext, i + 1, 0, 0); bias_next = fetch_bias(i + 1, 0); }
+            // the next block's (or the next layer's first block's) weights do not depend on the activations: ask for them now; after
+            // the last block of the last layer the current block is simply asked for again
+            int ni = i, ncb = cb + 1;
+            if (ncb >= nblk) { ni = i + 1; ncb = 0; }
+            if (ni >= net.n_layers) { ni = i; ncb = cb; }
+            fetch(bnext, ni, ncb);
+            bias_next = fetch_bias(ni, ncb);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            // A operands: four K steps ahead of the MFMA that consumes them, in a rotating set of four registers -- one ds_read per
-            // step issued right in front of its MFMA, into the register the previous MFMA was still reading, serialised the whole
-            // reduction on the LDS latency (270 cycles per K step)
-            // (four named registers, not an array: indexed through the unrolled loop the array went to scratch memory)
-            const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            bf16x8 a0 = zero8, a1 = zero8, a2 = zero8, a3 = zero8;
-            if (0 < nk) a0 = *reinterpret_cast<const bf16x8*>(arow + 0 * 16);
-            if (1 < nk) a1 = *reinterpret_cast<const bf16x8*>(arow + 1 * 16);
-            if (2 < nk) a2 = *reinterpret_cast<const bf16x8*>(arow + 2 * 16);
-            if (3 < nk) a3 = *reinterpret_cast<const bf16x8*>(arow + 3 * 16);
-#define RLINFER_STEP(J, AREG)                                                                                   \
-            if ((J) < nk) {                                                                                     \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AREG, b[J], acc, 0, 0, 0);                        \
-                if ((J) + 4 < nk) AREG = *reinterpret_cast<const bf16x8*>(arow + ((J) + 4) * 16);               \
-            }
-            RLINFER_STEP(0, a0) RLINFER_STEP(1, a1) RLINFER_STEP(2, a2) RLINFER_STEP(3, a3)
-            RLINFER_STEP(4, a0) RLINFER_STEP(5, a1) RLINFER_STEP(6, a2) RLINFER_STEP(7, a3)
-            RLINFER_STEP(8, a0) RLINFER_STEP(9, a1) RLINFER_STEP(10, a2) RLINFER_STEP(11, a3)
-            RLINFER_STEP(12, a0) RLINFER_STEP(13, a1) RLINFER_STEP(14, a2) RLINFER_STEP(15, a3)
-#undef RLINFER_STEP
+#define RLINFER_MMA(NK) mma_block<NK>(arow, b, acc)
+            RLINFER_DISPATCH_NK(nk, RLINFER_MMA, mma_block_any(arow, b, acc, nk))
+#undef RLINFER_MMA
             // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3
             const int col = cb * 32 + (lane & 31);
 #pragma unroll
