@@ -515,6 +515,14 @@ __global__ void __launch_bounds__(64 * FI_WAVES) k_mlp_infer(FusedInferArgs g) {
     auto fetch = [&](bf16x8 (&b)[FI_CHUNK], int i, int cb, int s0) {
         const int nk = g.K[i] / 16;
         const short* w = g.W[i] + ((size_t)cb * nk * 64 + lane) * 8;   // fragment order (k_weight_frags): 1 KB per (block, K step)
+        if (s0 == 0 && nk <= FI_CHUNK) {
+            // guard-free code per depth (infer_device.h): behind per-step guards the compiler waits for every outstanding load in
+            // front of every MFMA, and the prefetch of the next layer's weights stalls the current layer
+#define RLINFER_FETCH(NK) rlinfer::fetch_block<NK>(b, w)
+            RLINFER_DISPATCH_NK(nk, RLINFER_FETCH, rlinfer::fetch_block_any(b, w, nk))
+#undef RLINFER_FETCH
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < FI_CHUNK; j++)
             if (s0 + j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(s0 + j) * 512);
@@ -549,6 +557,11 @@ __global__ void __launch_bounds__(64 * FI_WAVES) k_mlp_infer(FusedInferArgs g) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            if (nk <= FI_CHUNK) {
+#define RLINFER_MMA(NK) rlinfer::mma_block<NK>(arow, b, acc)
+                RLINFER_DISPATCH_NK(nk, RLINFER_MMA, rlinfer::mma_block_any(arow, b, acc, nk))
+#undef RLINFER_MMA
+            } else
             for (int s0 = 0; s0 < nk; s0 += FI_CHUNK) {
                 if (s0 > 0) fetch(b, i, cb, s0);   // reductions deeper than 256: the rest arrives chunk by chunk
 #pragma unroll
