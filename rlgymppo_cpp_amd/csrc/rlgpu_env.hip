@@ -428,7 +428,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
     const int D = obs_size<NC>(d.cfg);
-    GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
+    // the GameState of the step (taken after tick 1) lives in the env's TickWork area, which is dead between ticks
+    Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);
+    static_assert(sizeof(Snapshot<NC>) <= sizeof(TickWork<NC>), "the step's snapshot borrows the TickWork area");
+    float rew[NC]; bool dn = false;
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -436,20 +439,20 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     if (env_lane) {
         int32_t acts[NC];
         for (int k = 0; k < NC; k++) acts[k] = actions[(size_t)env * NC + k];
-        gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts, X);
+        gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts);
     }
     wave_sync();
     RLG_PROF(8);
     TickEvents ev; ev.bump_mask = 0;
     arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
-    if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
+    if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * NC * D, (size_t)D, snap);
     wave_sync();
     RLG_PROF(9);
     for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
     RLG_PROF(6);
-    if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, X);
+    if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, dn, snap);
     RLG_PROF(10);
-    if (env_lane) for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn; }
+    if (env_lane) for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn ? 1 : 0; }
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     RLG_PROF(11);
@@ -499,6 +502,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
     int* const act_lds = reinterpret_cast<int*>(w0 + (EPW >= 2 ? buf_bytes : 2 * buf_bytes));
     const int row0 = env0 * NC, n_rows = n_valid * NC;
+    Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);   // the step's GameState, in the env's own TickWork area (dead between ticks)
 #ifdef RLG_TICK_PROFILE
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_infer = 0, prof_mlp = 0;
@@ -529,21 +533,22 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #ifdef RLG_TICK_PROFILE
         prof_infer += __builtin_amdgcn_s_memtime() - prof_a;
 #endif
-        GymStepCtx<NC> X; float rew[NC]; int32_t dn = 0;
+        float rew[NC]; bool dn = false;
         if (env_lane) {
             int32_t acts[NC];
             for (int k = 0; k < NC; k++) acts[k] = act_lds[ws.lane * NC + k];
-            gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts, X);
+            gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts);
         }
         wave_sync();
         TickEvents ev; ev.bump_mask = 0;
         arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);
-        if (env_lane) gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, rew, &dn, X);
+        float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
+        if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
         wave_sync();
         for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
         if (env_lane) {
-            gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D, (size_t)D, X);
-            for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn; }
+            gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
+            for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         wave_sync();
