@@ -247,7 +247,11 @@ RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>
                 }
             }
             nw.car_mesh(A, mesh, ci, cs, nc);
-            for (int k = 0; k < nc; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 4; k++) {
+                if (k >= nc) break;
                 Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
                 c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
                 c.friction = K::CARWORLD_FRICTION; c.restitution = K::CARWORLD_RESTITUTION; c.special = false;

@@ -106,6 +106,26 @@ RLG_HD bool ray_aabb(const BvhNode& n, V3 from, V3 inv_d, float tmax) {
 struct Cand { V3 pb; V3 n; float dist; };
 template <int CAP>
 RLG_HD void cand_add(Cand (&cs)[CAP], int& n, const Cand& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (CAP <= 4) {
+        // every slot is addressed by a compile-time index (the insert position becomes a compare chain), so a caller-local array of
+        // four candidates stays in registers: indexed by n / worst it lived in scratch memory (collide_body, once per body and tick)
+        if (n < CAP) {
+#pragma unroll
+            for (int s = 0; s < CAP; s++) if (n == s) cs[s] = c;
+            n++;
+            return;
+        }
+        int worst = 0; float wd = cs[0].dist;
+#pragma unroll
+        for (int i = 1; i < CAP; i++) if (cs[i].dist > wd) { wd = cs[i].dist; worst = i; }
+        if (c.dist < wd) {
+#pragma unroll
+            for (int s = 0; s < CAP; s++) if (worst == s) cs[s] = c;
+        }
+        return;
+    }
+#endif
     if (n < CAP) { cs[n++] = c; return; }
     int worst = 0;
     for (int i = 1; i < CAP; i++) if (cs[i].dist > cs[worst].dist) worst = i;
