@@ -1,22 +1,47 @@
-// CombinedReward (SIM/Utils/RewardFunctions/CombinedReward.h:6-53): weighted sum of child rewards
+// CombinedReward -- a weighted sum of child rewards (SIM/Utils/RewardFunctions/CombinedReward.h:6-53).
+//
+// Both constructor forms of the reference exist: two parallel vectors, or the { {reward, weight}, ... } list the example program
+// uses.  Like the reference the children are NOT owned unless `ownsFuncs` is set.  On the device a CombinedReward is not an object
+// but up to 8 (kind, weight, parameter) terms of the env's gym configuration: AddDeviceTerms() asks every child to append its
+// term(s) with the child's weight multiplied in, so nested CombinedRewards flatten.
 #pragma once
 #include "RewardFunction.h"
+
 namespace RLGSC {
+
 class CombinedReward : public RewardFunction {
 public:
     std::vector<RewardFunction*> rewardFuncs;
     std::vector<float> rewardWeights;
     bool ownsFuncs;
-    CombinedReward(std::vector<RewardFunction*> funcs, std::vector<float> weights, bool ownsFuncs = false) : rewardFuncs(funcs), rewardWeights(weights), ownsFuncs(ownsFuncs) {
-        if (funcs.size() != weights.size()) RG_ERR_CLOSE("CombinedReward: " << funcs.size() << " rewards but " << weights.size() << " weights");
+
+    CombinedReward(std::vector<RewardFunction*> funcs, std::vector<float> weights, bool owns = false)
+        : rewardFuncs(std::move(funcs)), rewardWeights(std::move(weights)), ownsFuncs(owns) {
+        if (rewardFuncs.size() != rewardWeights.size())
+            RG_ERR_CLOSE("CombinedReward: " << rewardFuncs.size() << " rewards but " << rewardWeights.size() << " weights");
     }
-    CombinedReward(std::vector<std::pair<RewardFunction*, float>> funcsWithWeights, bool ownsFuncs = false) : ownsFuncs(ownsFuncs) {
-        for (auto& fw : funcsWithWeights) { rewardFuncs.push_back(fw.first); rewardWeights.push_back(fw.second); }
+
+    CombinedReward(std::vector<std::pair<RewardFunction*, float>> weighted, bool owns = false) : ownsFuncs(owns) {
+        rewardFuncs.reserve(weighted.size());
+        rewardWeights.reserve(weighted.size());
+        for (const auto& entry : weighted) {
+            rewardFuncs.push_back(entry.first);
+            rewardWeights.push_back(entry.second);
+        }
     }
-    bool AddDeviceTerms(RlgpuGymConfig& cfg, float weight) const override {
-        for (size_t i = 0; i < rewardFuncs.size(); i++) if (!rewardFuncs[i]->AddDeviceTerms(cfg, weight * rewardWeights[i])) return false;
+
+    ~CombinedReward() override {
+        if (!ownsFuncs) return;
+        for (RewardFunction* child : rewardFuncs) delete child;
+    }
+
+    bool AddDeviceTerms(RlgpuGymConfig& deviceCfg, float outerWeight) const override {
+        for (size_t k = 0; k < rewardFuncs.size(); k++) {
+            const bool ok = rewardFuncs[k]->AddDeviceTerms(deviceCfg, outerWeight * rewardWeights[k]);
+            if (!ok) return false;   // a child without a device form: Match::ToDeviceConfig turns this into the fatal error
+        }
         return true;
     }
-    ~CombinedReward() override { if (ownsFuncs) for (auto f : rewardFuncs) delete f; }
 };
-}
+
+}  // namespace RLGSC
