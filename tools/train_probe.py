@@ -19,3 +19,8 @@ for it in range(iters):
         # a touch shows up as the TouchBall part of no reward term here; use the obs-independent signal: episodes that did not time out
         print("iter %4d  %6.1f M steps  %5.1f s  mean step reward %+.4f  entropy %.3f  value loss %.4f  done rate %.4f" % (
             it, L.total_timesteps / 1e6, time.time() - t0, float(L.rew_buf.mean().item()), rep["Policy Entropy"], rep["Value Function Loss"], float(L.done_buf.float().mean().item())))
+
+import numpy as np
+p = L.ppo.get_params(2)
+print("soak: params finite", bool(np.isfinite(p).all()), "| obs finite", bool(torch.isfinite(L.obs_buf).all().item()), "| |obs| max %.2f" % float(L.obs_buf.abs().max().item()),
+      "| reward range [%.2f, %.2f]" % (float(L.rew_buf.min().item()), float(L.rew_buf.max().item())), "| agent-steps/s overall %.2fM" % (L.total_timesteps / (time.time() - t0) / 1e6))
