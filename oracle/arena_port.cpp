@@ -25,6 +25,7 @@ MeshView view() {
     MeshView v; v.nodes = g_mesh.nodes.data(); v.tris = g_mesh.tris.data(); v.nodes_fast = nullptr;
     v.n_nodes = (int)g_mesh.nodes.size(); v.n_tris = (int)g_mesh.tris.size(); v.n_fast = 0;
     v.grid = g_mesh.grid.empty() ? nullptr : g_mesh.grid.data();
+    v.bp = g_mesh.grid.size() > (size_t)GRID_WORDS ? g_mesh.grid.data() + GRID_WORDS : nullptr;
     return v;
 }
 template <int NC>
@@ -140,3 +141,32 @@ double port_bench_collect(int team_size, int n_envs, int n_threads, int steps, c
 }
 
 }  // extern "C"
+
+// ---- debugging probe (tools/diff_ref_port.py): one tick, then the tick's contact list as the solver saw it -------------------
+// per contact 16 floats: [0] body a (0 ball, 1+i car i, -1 world)  [1] body b  [2] row index  [3] special
+//   [4..6] ra  [7..9] rb  [10..12] normal  [13] distance  [14] applied normal impulse  [15] friction
+template <int NC>
+static int debug_tick_t(RlgpuArenaState* s, float* out, int cap) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick(A, mv, 0, 0, ev, W);
+    arena_to_host(A, G, *s);
+    int n = 0;
+    for (int k = 0; k < W.L.n && n < cap; k++) {
+        const Contact& c = W.L.c[W.cidx[k]];
+        float* o = out + 16 * n++;
+        o[0] = (float)c.a; o[1] = (float)c.b; o[2] = (float)W.nrow[k]; o[3] = c.special ? 1.f : 0.f;
+        o[4] = c.ra.x; o[5] = c.ra.y; o[6] = c.ra.z; o[7] = c.rb.x; o[8] = c.rb.y; o[9] = c.rb.z;
+        o[10] = c.n.x; o[11] = c.n.y; o[12] = c.n.z; o[13] = c.dist;
+        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c);
+    }
+    return n;
+}
+extern "C" int port_debug_tick(RlgpuArenaState* s, float* out, int cap) {
+    if (s->num_cars == 2) return debug_tick_t<2>(s, out, cap);
+    if (s->num_cars == 4) return debug_tick_t<4>(s, out, cap);
+    return debug_tick_t<6>(s, out, cap);
+}

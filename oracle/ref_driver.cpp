@@ -373,3 +373,30 @@ extern "C" void ref_probe_thresholds(void* h, float* out /*4*/) {
     out[2] = inertia.x(); out[3] = inertia.y(); out[4] = inertia.z();
     out[5] = a->ball->_rigidBody.getLocalInertia().x();
 }
+
+// Dump of the dispatcher's contact manifolds as they stand after the last Arena::Step (they live until the next tick's
+// broadphase pass, which removes every pair: btRSBroadphase.cpp calculateOverlappingPairs).  Per point 16 floats:
+//   [0] body0 kind (0 ball, 1+slot car, -1 static)  [1] body1 kind  [2] manifold index  [3] lifetime
+//   [4..6] positionWorldOnA  [7..9] positionWorldOnB  [10..12] normalWorldOnB  [13] distance  [14] appliedImpulse  [15] isSpecial
+static float BodyKind(const btCollisionObject* o) {
+    if (o->getUserIndex() == BT_USERINFO_TYPE_BALL) return 0.f;
+    if (o->getUserIndex() == BT_USERINFO_TYPE_CAR) return (float)((Car*)o->getUserPointer())->id;
+    return -1.f;
+}
+extern "C" int ref_debug_manifolds(void* h, float* out, int cap_points) {
+    Arena* a = (Arena*)h;
+    btCollisionDispatcher* d = (btCollisionDispatcher*)a->_bulletWorld.getDispatcher();
+    int n = 0;
+    for (int m = 0; m < d->getNumManifolds(); m++) {
+        btPersistentManifold* pm = d->getManifoldByIndexInternal(m);
+        for (int p = 0; p < pm->getNumContacts() && n < cap_points; p++) {
+            const btManifoldPoint& cp = pm->getContactPoint(p);
+            float* o = out + n * 16;
+            o[0] = BodyKind(pm->getBody0()); o[1] = BodyKind(pm->getBody1()); o[2] = (float)m; o[3] = (float)cp.m_lifeTime;
+            for (int k = 0; k < 3; k++) { o[4 + k] = cp.m_positionWorldOnA[k]; o[7 + k] = cp.m_positionWorldOnB[k]; o[10 + k] = cp.m_normalWorldOnB[k]; }
+            o[13] = cp.m_distance1; o[14] = cp.m_appliedImpulse; o[15] = cp.m_isSpecial ? 1.f : 0.f;
+            n++;
+        }
+    }
+    return n;
+}

@@ -1,5 +1,6 @@
 // arena_mesh.cpp — see arena_mesh.h
 #include "arena_mesh.h"
+#include "arena_contact.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -129,6 +130,41 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             }
             if (cut) { int bit = (z * GRID_Y + y) * GRID_X + x; m.grid[bit >> 5] |= (1u << (bit & 31)); }
         }
+    }
+    // The reference's broadphase grid (btRSBroadphase.cpp:95-182; cell and bounds in arena_contact.h): a dynamic body is paired with the
+    // trimesh iff the mesh is on the static list of the body's cell, i.e. iff some cell of its 27-neighbourhood holds a triangle.
+    // Appended to the occupancy words: BP_WORDS listing bits, then the mesh's own box (6 floats) for the pair's AABB test.
+    {
+        const int NXYZ = BP_CELLS_X * BP_CELLS_Y * BP_CELLS_Z;
+        std::vector<uint8_t> has(NXYZ, 0);
+        const float mnp[3] = {-4500.f * UU2BT, -6000.f * UU2BT, 0.f * UU2BT}; const int dim[3] = {BP_CELLS_X, BP_CELLS_Y, BP_CELLS_Z};
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = 0; i < n_tris; i++) {
+            float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx);
+            int c0[3], c1[3];
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], mn[a]); hi[a] = std::max(hi[a], mx[a]);
+                c0[a] = std::max(0, (int)std::floor((mn[a] - mnp[a]) / BP_CELL) - 1);
+                c1[a] = std::min(dim[a] - 1, (int)std::floor((mx[a] - mnp[a]) / BP_CELL) + 1);
+            }
+            for (int x = c0[0]; x <= c1[0]; x++) for (int y = c0[1]; y <= c1[1]; y++) for (int z = c0[2]; z <= c1[2]; z++) {
+                const float cmn[3] = {mnp[0] + x * BP_CELL, mnp[1] + y * BP_CELL, mnp[2] + z * BP_CELL};
+                bool ov = true;
+                for (int a = 0; a < 3; a++) if (mn[a] > cmn[a] + BP_CELL || mx[a] < cmn[a]) ov = false;
+                if (ov) has[bp_cell_index(x, y, z)] = 1;
+            }
+        }
+        m.grid.resize(GRID_WORDS + BP_WORDS + 6, 0u);
+        for (int x = 0; x < dim[0]; x++) for (int y = 0; y < dim[1]; y++) for (int z = 0; z < dim[2]; z++) {
+            bool listed = false;
+            for (int dx = -1; dx <= 1 && !listed; dx++) for (int dy = -1; dy <= 1 && !listed; dy++) for (int dz = -1; dz <= 1 && !listed; dz++) {
+                int xx = x + dx, yy = y + dy, zz = z + dz;
+                if (xx < 0 || yy < 0 || zz < 0 || xx >= dim[0] || yy >= dim[1] || zz >= dim[2]) continue;
+                listed = has[bp_cell_index(xx, yy, zz)] != 0;
+            }
+            if (listed) { int bit = bp_cell_index(x, y, z); m.grid[GRID_WORDS + (bit >> 5)] |= (1u << (bit & 31)); }
+        }
+        for (int a = 0; a < 3; a++) { memcpy(&m.grid[GRID_WORDS + BP_WORDS + a], &lo[a], 4); memcpy(&m.grid[GRID_WORDS + BP_WORDS + 3 + a], &hi[a], 4); }
     }
     if (n_tris == 0) return m;
     std::vector<BuildNode> bn;

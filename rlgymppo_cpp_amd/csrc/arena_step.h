@@ -99,17 +99,22 @@ struct NarrowInline {
             if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist)) emit(c);
         });
     }
-    template <int NC>
-    RLG_HD void car_mesh(const Arena<NC>& A, MeshView mesh, int ci, Cand (&cs)[4], int& nc) {
+    template <int NC, class F>
+    RLG_HD void car_mesh(const Arena<NC>& A, MeshView mesh, int ci, F&& emit) {
         const Car& car = A.cars[ci];
         V3 bc, lo, hi;
         car_query_aabb(car, bc, lo, hi);
-        mesh_query(mesh, lo, hi, [&](int ti) { box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[ti], CBT_CAR, cs, nc); });
+        mesh_query(mesh, lo, hi, [&](int ti) {
+            Cand cs[8]; int nc = 0;
+            box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[ti], CBT_CAR, cs, nc);
+            for (int q = 0; q < nc; q++) emit(cs[q]);
+        });
     }
     template <int NC>
     RLG_HD void car_car(const Arena<NC>& A, int ia, int ib, Cand (&cs)[4], int& nc) {
         const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
-        box_box(ca.b.pos + ca.b.rot * hitbox_off(), ca.b.rot, cb.b.pos + cb.b.rot * hitbox_off(), cb.b.rot, hitbox_half(), cs, nc);
+        // box A = the manifold's body0 = the HIGHER car (arena_contact.h); normals point from the lower car towards it, pb lies on the lower car
+        box_box(cb.b.pos + cb.b.rot * hitbox_off(), cb.b.rot, ca.b.pos + ca.b.rot * hitbox_off(), ca.b.rot, hitbox_half(), cs, nc);
     }
 };
 
@@ -125,12 +130,12 @@ struct NarrowQueued {
             for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q]);
         }
     }
-    template <int NC>
-    RLG_HD void car_mesh(const Arena<NC>&, MeshView, int ci, Cand (&cs)[4], int& nc) {
+    template <int NC, class F>
+    RLG_HD void car_mesh(const Arena<NC>&, MeshView, int ci, F&& emit) {
         for (int k = 0; k < count(); k++) {
             const CollideItem& it = Q.items[k];
             if (it.type != 1 || it.a != ci) continue;
-            for (int q = 0; q < it.n; q++) cand_add(cs, nc, Q.pool[it.off + q]);
+            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q]);
         }
     }
     template <int NC>
@@ -185,16 +190,13 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
 }
 
 // The contact list is produced in two steps so that the bodies of an env can work side by side:
-//   collide_body   per body   the body's contacts against the world (planes + mesh) and, for a car, against the ball, written
-//                             into the body's own region of the contact list: ball [0,8), car i [8 + 6 i, 8 + 6 i + 6)
-//                             (MAXC = 8 + 6 NC is exactly these regions); count in W.body_n[body]
-//   collide_merge  per env    regions compacted into reference order (ball, car 0, car 1, ...), the ball-touch callbacks in
-//                             car order, then the car-car pairs
-constexpr int BALL_REGION = 8, CAR_REGION = 6;
-RLG_HD int body_region(int body) { return body == 0 ? 0 : BALL_REGION + CAR_REGION * (body - 1); }
-
+//   collide_body   per body   the body's manifolds against the static world (mesh, then the four planes: the reference's pair order)
+//                             and, for a car, its contact with the ball -- written into the body's own region of the contact
+//                             list (arena_contact.h); counts in W.body_n[body] / W.ball_hit[car]
+//   collide_merge  per env    the car-car pairs, the contact-added callbacks that touch other bodies, and the ORDER in which
+//                             the solver visits the contacts (W.cidx)
 template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int body, bool ball_asleep, NW nw) {
+RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int body, bool ball_asleep, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
     const float r = K::BALL_RADIUS * UU2BT;
     const V3 bp = A.ball.b.pos;
@@ -205,110 +207,72 @@ RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>
         // btDiscreteDynamicsWorld::addRigidBody) are both inactive, so the dispatcher skips the pair
         // (btCollisionDispatcher::needsCollision): no ball-world contacts on the tick a car wakes the ball up.
         if (!ball_asleep) {
-            // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121)
+            // ball vs mesh: one manifold for the whole mesh body, a point per triangle in visiting order (btConvexConcaveCollisionAlgorithm.cpp:
+            // 76-160 -> btSphereTriangleCollisionAlgorithm on the shared manifold), reduced to 4 by manifold_replace_index
+            nw.ball_mesh(A, mesh, [&](const Cand& k) { manifold_add_static(out, n, 4, A.ball.b, k.n, k.pb, k.dist, CBT_BALL); });
+            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], A.ball.b, v3(0, 0, 0)); out[k].a = 0; out[k].b = -1; out[k].sid = 0; out[k].special = 1; }
+            // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121): the sphere's support vertex towards the plane
             for (int i = 0; i < 4; i++) {
-                V3 pn; float d; world_plane(i, pn, d);
-                float dist = (dot(pn, bp - pn * r) - d);
-                if (dist < CBT_BALL && n < BALL_REGION) {
-                    Contact c; c.a = 0; c.b = -1; c.n = pn; c.dist = dist;
-                    V3 pb = (bp - pn * r) - pn * dist;
-                    c.ra = (pb + pn * dist) - bp; c.rb = pb;
-                    c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
-                    out[n++] = c;
-                }
+                V3 pn, po; world_plane_body(i, pn, po);
+                V3 dir = -pn;                                          // planeInConvex.getBasis() * -planeNormal (ball basis = identity: m_noRot)
+                // btSphereShape::localGetSupportingVertex: the point (0,0,0) pushed out by getMargin() (= the radius) along the normalised direction
+                V3 vtx = dir * r;                                      // |dir| = 1 exactly for the axis-aligned planes
+                V3 vip = vtx + (bp + (-po));
+                float dist = dot(pn, vip);
+                if (!(dist < CBT_BALL) || n >= BALL_REGION) continue;
+                V3 pb = (vip - pn * dist) + po;
+                int cnt = 0;
+                if (manifold_add_static(&out[n], cnt, 1, A.ball.b, pn, pb, dist, CBT_BALL) < 0) continue;
+                manifold_finish_static(out[n], A.ball.b, po);
+                out[n].a = 0; out[n].b = -1; out[n].sid = (int8_t)(1 + i); out[n].special = 1;
+                n++;
             }
-            // ball vs mesh
-            nw.ball_mesh(A, mesh, [&](const Cand& k) {
-                if (n >= BALL_REGION) return;
-                Contact c; c.a = 0; c.b = -1; c.n = k.n; c.dist = k.dist;
-                c.ra = (k.pb + k.n * k.dist) - bp; c.rb = k.pb;
-                c.friction = K::BALL_FRICTION; c.restitution = K::BALL_RESTITUTION; c.special = true;
-                out[n++] = c;
-            });
         }
     } else {
         const int ci = body - 1;
         Car& car = A.cars[ci];
+        ball_hit[ci] = 0;
         if (car_collides(car)) {
             V3 h = hitbox_half();
             V3 bc = car.b.pos + car.b.rot * hitbox_off();
-            Cand cs[4]; int nc = 0;
-            // planes: every hitbox corner within the threshold (see header comment)
-            for (int i = 0; i < 4; i++) {
-                V3 pn; float d; world_plane(i, pn, d);
-                V3 nl = tmul(car.b.rot, pn);
-                float rr = h.x * fabsf(nl.x) + h.y * fabsf(nl.y) + h.z * fabsf(nl.z);
-                if (dot(pn, bc) - d - rr >= CBT_CAR) continue;
-                for (int q = 0; q < 8; q++) {
-                    V3 cl = v3((q & 1) ? h.x : -h.x, (q & 2) ? h.y : -h.y, (q & 4) ? h.z : -h.z);
-                    V3 cw = bc + car.b.rot * cl;
-                    float dist = dot(pn, cw) - d;
-                    if (dist < CBT_CAR) { Cand c; c.n = pn; c.dist = dist; c.pb = cw - pn * dist; cand_add(cs, nc, c); }
+            // pair order of the reference's broadphase (btRSBroadphase.cpp:393-469): the statics of the car's cell in creation order = mesh
+            // bodies, then floor, ceiling, -x wall, +x wall (Arena.cpp:1036-1101); the contact-added callbacks fire in that order
+            nw.car_mesh(A, mesh, ci, [&](const Cand& k) {
+                if (manifold_add_static(out, n, 4, car.b, k.n, k.pb, k.dist, CBT_CAR) >= 0) {
+                    car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
                 }
+            });
+            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], car.b, v3(0, 0, 0)); out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].sid = 0; out[k].special = 0; }
+            // planes: ONE contact per plane and tick, the hitbox's support vertex towards the plane (btConvexPlaneCollisionAlgorithm.cpp:
+            // 92-121; the perturbation passes are off: m_minimumPointsPerturbationThreshold = 0, btConvexPlaneCollisionAlgorithm.h:62-63)
+            for (int i = 0; i < 4; i++) {
+                V3 pn, po; world_plane_body(i, pn, po);
+                V3 dirl = tmul(car.b.rot, -pn);                       // planeInConvex.getBasis() * -planeNormal
+                V3 vtx = v3(dirl.x >= 0.f ? h.x : -h.x, dirl.y >= 0.f ? h.y : -h.y, dirl.z >= 0.f ? h.z : -h.z);   // btBoxShape::localGetSupportingVertex
+                V3 vip = (car.b.rot * vtx) + (bc + (-po));           // convexInPlaneTrans(vtx): origin = convex origin - plane origin
+                float dist = dot(pn, vip);                             // plane constant 0 in the plane body's frame (Arena.cpp:1067-1101)
+                if (!(dist < CBT_CAR) || n >= CAR_WORLD_MAX) continue;
+                V3 pb = (vip - pn * dist) + po;                        // planeObjWrap->getWorldTransform() * vtxInPlaneProjected
+                int cnt = 0;
+                if (manifold_add_static(&out[n], cnt, 1, car.b, pn, pb, dist, CBT_CAR) < 0) continue;
+                manifold_finish_static(out[n], car.b, po);
+                out[n].a = (int8_t)(1 + ci); out[n].b = -1; out[n].sid = (int8_t)(1 + i); out[n].special = 0;
+                n++;
+                car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = pn;
             }
-            nw.car_mesh(A, mesh, ci, cs, nc);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < 4; k++) {
-                if (k >= nc) break;
-                Contact c; c.a = 1 + ci; c.b = -1; c.n = cs[k].n; c.dist = cs[k].dist;
-                c.ra = (cs[k].pb + cs[k].n * cs[k].dist) - car.b.pos; c.rb = cs[k].pb;
-                c.friction = K::CARWORLD_FRICTION; c.restitution = K::CARWORLD_RESTITUTION; c.special = false;
-                out[n++] = c;
-                // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
-                car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = cs[k].n;
-            }
-            // car vs ball: ball is body A of the pair (lower broadphase id), the car B.  Its callback runs in collide_merge.
+            // car vs ball: the manifold's body0 is the car (arena_contact.h).  Its callback runs in collide_merge.
             V3 pb, pn; float dist;
             if (sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, pn, dist)) {
-                Contact c; c.a = 0; c.b = 1 + ci; c.n = pn; c.dist = dist;
-                V3 pa = pb + pn * dist;
-                c.ra = pa - bp; c.rb = pb - car.b.pos;
-                c.friction = K::CARBALL_FRICTION; c.restitution = K::CARBALL_RESTITUTION; c.special = false;
-                out[n++] = c;
+                // as the reference's GJK reports it with A = box, B = sphere: normal on the ball, pointing at the car; the point on the ball
+                pn = -pn; pb = bp + pn * r;
+                Contact& c = L.c[car_ball_slot(ci)];
+                manifold_point_dynamic(c, car.b, A.ball.b, pn, pb, dist);
+                c.a = (int8_t)(1 + ci); c.b = 0; c.sid = 0; c.special = 0;
+                ball_hit[ci] = 1;
             }
         }
     }
     body_n[body] = (int8_t)n;
-}
-
-template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, const int8_t* body_n, TickEvents& ev, bool& ball_car_touch, NW nw) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
-    ball_car_touch = false;
-    int n = body_n[0];   // the ball's region already starts the list
-    for (int ci = 0; ci < NC; ci++) {
-        const int base = body_region(1 + ci);
-        for (int k = 0; k < body_n[1 + ci]; k++) {
-            if (base + k != n) L.c[n] = L.c[base + k];
-            const Contact& c = L.c[n];
-            if (c.a == 0) {   // the car's ball contact
-                ball_car_touch = true;
-                on_car_ball_contact(A, ci, c.ra);
-            }
-            n++;
-        }
-    }
-    L.n = n;
-    // car vs car
-    for (int ia = 0; ia < NC; ia++) {
-        for (int ib = ia + 1; ib < NC; ib++) {
-            Car& ca = A.cars[ia]; Car& cb = A.cars[ib];
-            if (!car_collides(ca) || !car_collides(cb)) continue;
-            if (!cars_maybe_touch(A, ia, ib)) continue;
-            Cand cs[4]; int nc = 0;
-            nw.car_car(A, ia, ib, cs, nc);
-            for (int k = 0; k < nc; k++) {
-                Contact c; c.a = 1 + ia; c.b = 1 + ib; c.n = cs[k].n; c.dist = cs[k].dist;
-                V3 pa = cs[k].pb + cs[k].n * cs[k].dist;
-                c.ra = pa - ca.b.pos; c.rb = cs[k].pb - cb.b.pos;
-                c.friction = K::CARCAR_FRICTION; c.restitution = K::CARCAR_RESTITUTION; c.special = false;
-                push_contact(L, c);
-                on_car_car_contact(A, ia, ib, tmul(ca.b.rot, c.ra), tmul(cb.b.rot, c.rb), ev);
-            }
-        }
-    }
 }
 
 // ---- sequential-impulse solve (btSequentialImpulseConstraintSolver.cpp:795-983,1003-1211,1601-1926) ----------
@@ -444,8 +408,10 @@ RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
 template <int NC>
 struct TickWork {
     static constexpr int NB = NC + 1;
-    static constexpr int MAXC = 8 + 6 * NC;
-    static constexpr int MAXR = 2 * (MAXC + 1);
+    static constexpr int MAXC = ContactLayout<NC>::MAXC;
+    static constexpr int MAXM = ContactLayout<NC>::MAXM;
+    static constexpr int MAXS = 8 + 6 * NC;        // contacts the solver takes per tick (the rest of a fuller list is dropped: never seen in play)
+    static constexpr int MAXR = 2 * (MAXS + 1);    // their normal + friction rows and the ball's averaged pair
     ContactList<MAXC> L;
     SolverBody B[NB];
     union {
@@ -454,12 +420,111 @@ struct TickWork {
     };
     CarTickCtx ctx[NC];
     bool ball_asleep;
-    int8_t nrow[MAXC], frow[MAXC];   // solver rows of contact k (normal / friction), -1 = none (solver_prepare)
-    int8_t body_n[8];                // contacts in each body's region of L (collide_body)
+    int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
+    int8_t nrow[MAXS], frow[MAXS];   // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)
+    int8_t body_n[8];                // world contacts in each body's region of L (collide_body)
+    int8_t ball_hit[NC];             // car i touches the ball: its contact sits in car_ball_slot(i)
+    int8_t man_key[MAXM], man_val[MAXM], man_first[MAXM], man_cnt[MAXM];   // this tick's manifolds (collide_merge)
+    uint16_t man_stack[MAXM];
     int16_t n_normal, n_rows;
 };
 static_assert(sizeof(CollideQueue<2>) <= sizeof(Row) * TickWork<2>::MAXR && sizeof(CollideQueue<4>) <= sizeof(Row) * TickWork<4>::MAXR && sizeof(CollideQueue<6>) <= sizeof(Row) * TickWork<6>::MAXR,
               "the narrowphase queue must fit inside the solver rows it shares LDS with");
+
+// Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
+// contacts (arena_contact.h explains where each piece comes from).
+template <int NC, int MAXC, class NW>
+RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    using LY = ContactLayout<NC>;
+    ContactList<MAXC>& L = W.L;
+    constexpr int NB = NC + 1;
+    ball_car_touch = false;
+    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
+    for (int ci = 0; ci < NC; ci++)
+        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); }
+
+    // proxy boxes and cells of the dynamic bodies
+    V3 plo[NB], phi[NB]; int cx[NB], cy[NB], cz[NB]; bool live[NB];
+    live[0] = true; ball_proxy_aabb(A.ball, plo[0], phi[0]);
+    for (int i = 0; i < NC; i++) { live[1 + i] = car_collides(A.cars[i]); if (live[1 + i]) car_proxy_aabb(A.cars[i], plo[1 + i], phi[1 + i]); }
+    for (int b = 0; b < NB; b++) if (live[b]) bp_cell_of(plo[b], cx[b], cy[b], cz[b]);
+    V3 mlo = v3(-1e30f, -1e30f, -1e30f), mhi = v3(1e30f, 1e30f, 1e30f);
+    if (mesh.bp) {
+        const float* mb = reinterpret_cast<const float*>(mesh.bp + BP_WORDS);
+        mlo = v3(mb[0], mb[1], mb[2]); mhi = v3(mb[3], mb[4], mb[5]);
+    }
+    // union-find over the dynamic pairs (btSimulationIslandManager::findUnions, pair-array order; btUnionFind::unite links the root of
+    // the first element under the root of the second) and the manifold list in creation order
+    int8_t root[NB];
+    for (int b = 0; b < NB; b++) root[b] = (int8_t)b;
+    auto find = [&](int x) { while (root[x] != x) { root[x] = root[root[x]]; x = root[x]; } return x; };
+    int nm = 0, n_pair = 0;
+    int8_t (&mkey)[LY::MAXM] = W.man_key; int8_t (&mval)[LY::MAXM] = W.man_val;   // key: body0 for now, island id later; val: manifold number
+    int8_t (&mfirst)[LY::MAXM] = W.man_first; int8_t (&mcnt)[LY::MAXM] = W.man_cnt;
+    for (int p = 0; p < NB; p++) {
+        if (!live[p]) continue;
+        // statics of the cell, in creation order; a sleeping ball makes no manifold with them (needsCollision)
+        if (!(p == 0 && W.ball_asleep)) {
+            bool listed = mesh.n_tris > 0;
+            if (listed && mesh.bp) { const int bit = bp_cell_index(cx[p], cy[p], cz[p]); listed = (mesh.bp[bit >> 5] >> (bit & 31)) & 1u; }
+            if (listed) listed = aabb_touch(plo[p], phi[p], mlo, mhi);
+            const int base = body_region(p), nw_ = W.body_n[p];
+            int k = 0, nmesh = 0;
+            while (k < nw_ && L.c[base + k].sid == 0) { k++; nmesh++; }
+            if (listed) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)base; mcnt[nm] = (int8_t)nmesh; nm++; }
+            for (int s = 1; s <= 4; s++) {
+                int cnt = 0, first = base + k;
+                if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
+                mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
+            }
+        }
+        // dynamic partners filed in the same cell neighbourhood with overlapping proxy boxes (pairs are made by the lower body)
+        for (int q = p + 1; q < NB; q++) {
+            if (!live[q]) continue;
+            const int dx = cx[p] - cx[q], dy = cy[p] - cy[q], dz = cz[p] - cz[q];
+            if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
+            if (!aabb_touch(plo[p], phi[p], plo[q], phi[q])) continue;
+            { const int i = find(p), j = find(q); if (i != j) root[i] = (int8_t)j; }
+            // the pair's manifold exists when the children's own boxes touch (btCompoundCollisionAlgorithm.cpp:127-141,333-358)
+            V3 l1, h1, l2, h2;
+            if (p == 0) {
+                const Car& c = A.cars[q - 1];
+                sphere_shape_aabb(A.ball.b.pos, l1, h1); hitbox_shape_aabb(c.b.pos, c.b.rot, l2, h2);
+                if (!aabb_touch(l2, h2, l1, h1)) continue;
+                mkey[nm] = (int8_t)q; mfirst[nm] = (int8_t)car_ball_slot(q - 1); mcnt[nm] = W.ball_hit[q - 1]; nm++;
+            } else {
+                const Car& ca = A.cars[p - 1]; const Car& cb = A.cars[q - 1];
+                hitbox_shape_aabb(ca.b.pos, ca.b.rot, l1, h1); hitbox_shape_aabb(cb.b.pos, cb.b.rot, l2, h2);
+                if (!aabb_touch(l1, h1, l2, h2)) continue;
+                // narrowphase of the pair: body0 = the higher car (arena_contact.h)
+                Cand cs[4]; int nc = 0;
+                nw.car_car(A, p - 1, q - 1, cs, nc);
+                const int first = LY::PAIR_BASE + n_pair;
+                int cnt = 0;
+                for (int k = 0; k < nc && n_pair < LY::PAIR_POOL; k++) {
+                    if (cs[k].dist > CBT_CAR) continue;
+                    Contact& c = L.c[LY::PAIR_BASE + n_pair];
+                    manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
+                    c.a = (int8_t)q; c.b = (int8_t)p; c.sid = 0; c.special = 0;
+                    n_pair++; cnt++;
+                    // Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car, car2): equal user indices, no swap (Arena.cpp:231-240)
+                    on_car_car_contact(A, q - 1, p - 1, tmul(cb.b.rot, c.ra), tmul(ca.b.rot, c.rb), ev);
+                }
+                mkey[nm] = (int8_t)q; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
+            }
+        }
+    }
+    // island id of a manifold = island of its body0 (always dynamic here); quickSort by it
+    for (int m = 0; m < nm; m++) { mkey[m] = (int8_t)find(mkey[m]); mval[m] = (int8_t)m; }
+    bt_quicksort(mkey, mval, nm, W.man_stack);
+    int n = 0;
+    for (int m = 0; m < nm; m++) {
+        const int mi = mval[m];
+        for (int k = 0; k < mcnt[mi]; k++) W.cidx[n++] = (int8_t)(mfirst[mi] + k);
+    }
+    L.n = n;
+}
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
 template <int NC>
@@ -497,8 +562,9 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
 #endif
 
     bool touch;
-    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowQueued<NC>{W.Q});
-    else collide_merge<NC, MAXC>(A, mesh, L, W.body_n, ev, touch, NarrowInline());
+    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, W, ev, touch, NarrowQueued<NC>{W.Q});
+    else collide_merge<NC, MAXC>(A, mesh, W, ev, touch, NarrowInline());
+    if (L.n > TickWork<NC>::MAXS) L.n = TickWork<NC>::MAXS;
     const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 #ifdef RLG_PROF_SPLIT_PREPARE
     RLG_PROF(7);
@@ -518,27 +584,24 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
         s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
         s.active = !c.frozen && !(c.flags & CF_IS_DEMOED);
     }
-    // row numbering: normal rows in contact order (contacts of an inactive ball are dropped), then the averaged special row,
-    // then one friction row per non-special contact, then the special row's friction row
-    int nr = 0, n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f, sp_fric = 0.f, sp_rest = 0.f;
+    // row numbering: normal rows in solver order, then the averaged special row, then one friction row per non-special
+    // contact, then the special row's friction row
+    int nr = 0, n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f;
     for (int k = 0; k < L.n; k++) {
-        const Contact& c = L.c[k];
-        W.nrow[k] = -1; W.frow[k] = -1;
-        if (c.a == 0 && !ball_active) continue;
-        W.nrow[k] = (int8_t)nr++;
-        if (c.special) { n_special++; sp_fric = c.friction; sp_rest = c.restitution; sp_normal += c.n; sp_dist += len(c.ra); }
+        const Contact& c = L.c[W.cidx[k]];
+        W.nrow[k] = (int8_t)nr++; W.frow[k] = -1;
+        if (c.special) { n_special++; sp_normal += c.n; sp_dist += len(c.ra); }
     }
     const int n_contact_rows = nr;
     if (n_special > 0) nr++;
     W.n_normal = nr;
-    for (int k = 0; k < L.n; k++) if (W.nrow[k] >= 0 && !L.c[k].special) W.frow[k] = (int8_t)nr++;
+    for (int k = 0; k < L.n; k++) if (!L.c[W.cidx[k]].special) W.frow[k] = (int8_t)nr++;
     if (n_special > 0) {  // convertContactSpecial (btSequentialImpulseConstraintSolver.cpp:1164-1211): its two rows are set up here
         Contact spc;
         float distance = sp_dist / (float)n_special;
         V3 normal = sp_normal / (float)n_special;
-        spc.a = 0; spc.b = -1; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
-        spc.friction = sp_fric; spc.restitution = sp_rest; spc.special = false;
-        row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, spc.friction, spc.restitution, false);
+        spc.a = 0; spc.b = -1; spc.sid = 0; spc.special = 0; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
+        row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, K::BALL_FRICTION, K::BALL_RESTITUTION, false);
         row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false);
         nr++;
     }
@@ -550,16 +613,16 @@ template <int NC>
 RLG_HD_NOINLINE void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
-    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
-    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, body, W.ball_asleep, NarrowInline());
+    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
+    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, body, W.ball_asleep, NarrowInline());
 }
 
 template <int NC>
 RLG_HD void solver_rows(TickWork<NC>& W, int k) {
-    const Contact& c = W.L.c[k];
+    const Contact& c = W.L.c[W.cidx[k]];
     const int ni = W.nrow[k];
     if (ni < 0) return;
-    row_setup_normal(W.R[ni], c, W.B, c.n, c.ra, c.rb, c.dist, c.friction, c.restitution, c.b >= 0);
+    row_setup_normal(W.R[ni], c, W.B, c.n, c.ra, c.rb, c.dist, contact_friction(c), contact_restitution(c), c.b >= 0);
     if (c.special) W.R[ni].skip = 1;
     const int fi = W.frow[k];
     if (fi >= 0) row_setup_friction(W.R[fi], ni, W.R[ni], W.B, c.n, c.ra, c.rb, c.b >= 0);

@@ -223,6 +223,8 @@ struct MeshView {
     const MeshTri* tris;       // global
     const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr
     const uint32_t* grid;      // GRID_WORDS occupancy words (LDS on the device), or nullptr = always traverse
+    const uint32_t* bp;        // global: the reference broadphase's trimesh listing bits (BP_WORDS) + the mesh's own box (6 floats), see
+                               // arena_mesh.cpp / arena_contact.h; nullptr = the mesh is listed everywhere
     int n_nodes, n_tris, n_fast;
 };
 

@@ -14,7 +14,7 @@
 //   * box-triangle and box-box use SAT + face clipping instead of GJK/EPA and ODE's dBoxBox2;
 //   * the mesh BVH is this repo's own 32-byte AABB node layout (top levels staged in LDS on the device).
 #pragma once
-#include "arena_body.h"
+#include "arena_contact.h"
 
 namespace rlg {
 
@@ -28,15 +28,6 @@ struct RayHit {
     int kind;  // -1 miss, 0 static world, 1 ball, 2+k car k
     float frac;
     V3 normal;
-};
-
-struct Contact {
-    int a, b;        // 0 = ball, 1+i = car i, -1 = static world ; normal points from b towards a
-    V3 ra, rb;       // contact point on each body relative to the body origin (world axes)
-    V3 n;
-    float dist;
-    float friction, restitution;
-    bool special;    // ball-world contact: resolved through one averaged row (Arena.cpp:265-273)
 };
 
 
@@ -357,6 +348,35 @@ RLG_HD void world_plane(int i, V3& n, float& d) {
     else { n = v3(-1, 0, 0); d = -ex; }
 }
 
+// the same four planes as the reference builds them (Arena.cpp:1060-1101): a btStaticPlaneShape (normal n, constant 0) on a static
+// body whose world transform is a pure translation `origin` -- the convex-plane test runs in that body's frame
+RLG_HD void world_plane_body(int i, V3& n, V3& origin) {
+    const float ex = K::ARENA_EXTENT_X, h = K::ARENA_HEIGHT;
+    if (i == 0) { n = v3(0, 0, 1); origin = v3(0, 0, 0); }
+    else if (i == 1) { n = v3(0, 0, -1); origin = v3(0.f * UU2BT, 0.f * UU2BT, h * UU2BT); }
+    else if (i == 2) { n = v3(1, 0, 0); origin = v3(-ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
+    else { n = v3(-1, 0, 0); origin = v3(ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
+}
+
+// What a contact point looks like by the time the solver reads it: btManifoldResult::addContactPoint stores the point in both
+// bodies' local frames (btManifoldResult.cpp:128-150) and every narrowphase algorithm ends with refreshContactPoints, which rebuilds
+// the world positions and the distance from those local points (btPersistentManifold.cpp:245-256).  `b_origin`: world origin of
+// body B when it is a static plane body (pure translation), zero otherwise.  Out: ra = positionWorldOnA - origin of A, pb_w.
+RLG_HD void manifold_point_refresh(const Body& a, V3 pa_w, V3 pb_w, V3 n, V3 b_origin, V3& ra, V3& pb_out, float& dist) {
+    V3 la = tmul(a.rot, pa_w - a.pos);             // btTransform::invXform
+    V3 wa = (a.rot * la) + a.pos;                   // trA(localPointA)
+    V3 wb = (pb_w - b_origin) + b_origin;           // static body: identity basis
+    dist = dot(wa - wb, n);
+    ra = wa - a.pos; pb_out = wb;
+}
+// both bodies dynamic
+RLG_HD void manifold_point_refresh2(const Body& a, const Body& b, V3 pa_w, V3 pb_w, V3 n, V3& ra, V3& rb, float& dist) {
+    V3 la = tmul(a.rot, pa_w - a.pos), lb = tmul(b.rot, pb_w - b.pos);
+    V3 wa = (a.rot * la) + a.pos, wb = (b.rot * lb) + b.pos;
+    dist = dot(wa - wb, n);
+    ra = wa - a.pos; rb = wb - b.pos;
+}
+
 // A suspension ray is cast in three stages (planes | mesh | ball and cars) so that the mesh stage can run as one lane per
 // (ray, candidate triangle) pair on the device; every later stage only accepts strictly closer hits, as one loop would.
 RLG_HD RayHit ray_planes(V3 from, V3 to) {
@@ -461,16 +481,6 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
         }
     }
 }
-
-// ---- contact list ---------------------------------------------------------------------------------------
-template <int MAXC>
-struct ContactList {
-    Contact c[MAXC];
-    int n;
-};
-
-template <int MAXC>
-RLG_HD void push_contact(ContactList<MAXC>& L, const Contact& c) { if (L.n < MAXC) L.c[L.n++] = c; }
 
 // embree closest point on triangle (SphereTriangleDetector.cpp:87-129). `feature` out: 0 face, 1..3 vertex a/b/c, 4 edge ab, 5 edge ac, 6 edge bc
 RLG_HD V3 closest_point_triangle(V3 p, V3 a, V3 b, V3 c, int& feature) {

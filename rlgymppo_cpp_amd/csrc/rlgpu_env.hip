@@ -108,6 +108,7 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* ld
     __syncthreads();
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
     mv.grid = d.grid ? lds_grid : nullptr;
+    mv.bp = d.grid ? d.grid + GRID_WORDS : nullptr;
     return mv;
 }
 
