@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <array>
 #include <map>
 #include <tuple>
 #include <queue>
@@ -67,39 +68,64 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             if (vi < 0 || vi >= n_verts) vi = 0;
             for (int a = 0; a < 3; a++) p[k * 3 + a] = verts_uu[vi * 3 + a] * UU2BT;
         }
-        t.edge_flags = 0; t._pad0 = 0; t._pad1 = 0;
+        t.edge_flags = 0; t._pad0 = 0; t._pad1 = 0; t._pad2 = 0;
+        t.edge_angle[0] = t.edge_angle[1] = t.edge_angle[2] = 6.283185307179586232f;   // btTriangleInfo(): SIMD_2_PI
     }
-    // edge adjacency -> flags. bit e: edge e is flat or concave seen from the FRONT (normal side);
-    // bit 3+e: flat or concave seen from the BACK. (A convex edge from one side is concave from the other.)
-    std::map<std::pair<Key, Key>, std::vector<std::pair<int, int>>> edges;
-    for (int i = 0; i < n_tris; i++) {
-        const float* p = &m.tris[i].v0x;
-        for (int e = 0; e < 3; e++) {
-            Key a = qkey(p[e * 3], p[e * 3 + 1], p[e * 3 + 2]);
-            int e2 = (e + 1) % 3;
-            Key b = qkey(p[e2 * 3], p[e2 * 3 + 1], p[e2 * 3 + 2]);
-            if (b < a) std::swap(a, b);
-            edges[{a, b}].push_back({i, e});
-        }
-    }
-    for (auto& kv : edges) {
-        if (kv.second.size() < 2) continue;
-        for (auto& self : kv.second) {
-            for (auto& other : kv.second) {
-                if (other.first == self.first) continue;
-                const float* p = &m.tris[self.first].v0x;
-                const float* q = &m.tris[other.first].v0x;
-                P3 v0{p[0], p[1], p[2]}, v1{p[3], p[4], p[5]}, v2{p[6], p[7], p[8]};
-                P3 n = crs(sub(v1, v0), sub(v2, v0));
-                float nl = std::sqrt(dt3(n, n));
-                if (nl < 1e-12f) continue;
-                n = {n.x / nl, n.y / nl, n.z / nl};
-                int oe = other.second; int opp = (oe + 2) % 3;  // vertex of the neighbour not on the shared edge
-                P3 ov{q[opp * 3], q[opp * 3 + 1], q[opp * 3 + 2]};
-                float side = dt3(n, sub(ov, v0));
-                const float flat_eps = 1e-3f;  // BT
-                if (side >= -flat_eps) m.tris[self.first].edge_flags |= (1u << self.second);       // flat or concave from the front
-                if (side <= flat_eps) m.tris[self.first].edge_flags |= (1u << (3 + self.second));   // flat or concave from the back
+    // btGenerateInternalEdgeInfo (btInternalEdgeUtility.cpp:295-352) with btConnectivityProcessor::processTriangle (:50-290): for every
+    // triangle A, every other triangle B whose box overlaps A's; two shared vertices (closer than 1e-4) make a shared edge, whose
+    // dihedral angle, convexity and normal-swap flag go into A's record.
+    {
+        using namespace std;
+        auto V = [&](int tri, int k) { const float* p = &m.tris[tri].v0x; return v3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2]); };
+        const float EQ = 0.0001f * 0.0001f, PLANAR = 0.0001f;
+        vector<array<float, 6>> box(n_tris);
+        for (int i = 0; i < n_tris; i++) { float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx); box[i] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]}; }
+        for (int ia = 0; ia < n_tris; ia++) {
+            const V3 A[3] = {V(ia, 0), V(ia, 1), V(ia, 2)};
+            for (int ib = 0; ib < n_tris; ib++) {
+                if (ib == ia) continue;
+                bool ov = true;
+                for (int a = 0; a < 3; a++) if (box[ia][a] > box[ib][3 + a] || box[ia][3 + a] < box[ib][a]) ov = false;
+                if (!ov) continue;
+                const V3 B[3] = {V(ib, 0), V(ib, 1), V(ib, 2)};
+                if (len2(cross(B[1] - B[0], B[2] - B[0])) < EQ) continue;
+                if (len2(cross(A[1] - A[0], A[2] - A[0])) < EQ) continue;
+                int ns = 0, sa[3] = {-1, -1, -1}, sb[3] = {-1, -1, -1}; bool degenerate = false;
+                for (int i = 0; i < 3 && !degenerate; i++)
+                    for (int j = 0; j < 3; j++)
+                        if (len2(A[i] - B[j]) < EQ) { sa[ns] = i; sb[ns] = j; ns++; if (ns >= 3) { degenerate = true; break; } }
+                if (degenerate || ns != 2) continue;
+                if (sa[0] == 0 && sa[1] == 2) { sa[0] = 2; sa[1] = 0; int tmp = sb[1]; sb[1] = sb[0]; sb[0] = tmp; }
+                MeshTri& info = m.tris[ia];
+                info.edge_flags |= 0x80000000u;
+                const int sum = sa[0] + sa[1], other_a = 3 - sum, other_b = 3 - (sb[0] + sb[1]);
+                V3 edge = normalized(A[sa[1]] - A[sa[0]]);
+                V3 normal_a = normalized(cross(A[1] - A[0], A[2] - A[0]));
+                const V3 tb0 = B[sb[1]], tb1 = B[sb[0]], tb2 = B[other_b];
+                V3 normal_b = normalized(cross(tb1 - tb0, tb2 - tb0));
+                V3 eca = normalized(cross(edge, normal_a));
+                if (dot(eca, A[other_a] - A[sa[0]]) < 0) eca *= -1.f;
+                V3 ecb = normalized(cross(edge, normal_b));
+                if (dot(ecb, B[other_b] - B[sb[0]]) < 0) ecb *= -1.f;
+                float corrected = 0.f; bool convex = false;
+                V3 ce = cross(eca, ecb);
+                if (!(len2(ce) < PLANAR)) {
+                    ce = normalized(ce);
+                    V3 cna = normalized(cross(ce, eca));
+                    float angle2 = atan2f(dot(ecb, cna), dot(ecb, eca));     // btGetAngle(calculatedNormalA, edgeCrossA, edgeCrossB)
+                    float ang4 = 3.1415926535897931160f - angle2;
+                    convex = dot(normal_a, ecb) < 0.f;
+                    corrected = convex ? ang4 : -ang4;
+                }
+                // which edge of A, its rotation axis, and whether the neighbour's normal comes out flipped
+                V3 axis; int e;
+                if (sum == 1) { axis = A[0] - A[1]; e = 0; } else if (sum == 2) { axis = A[2] - A[0]; e = 2; } else { axis = A[1] - A[2]; e = 1; }
+                Q4 orn = quat_axis_angle(axis, -corrected);
+                V3 cnb = quat_rotate(orn, normal_a);
+                const uint32_t bit_convex = e == 0 ? 1u : (e == 1 ? 2u : 4u), bit_swap = e == 0 ? 8u : (e == 1 ? 16u : 32u);
+                if (dot(cnb, normal_b) < 0) info.edge_flags |= bit_swap;
+                info.edge_angle[e] = -corrected;
+                if (convex) info.edge_flags |= bit_convex;
             }
         }
     }

@@ -3,6 +3,7 @@
 // set {ball, NC cars} and the contact list of arena_world.h.
 #pragma once
 #include "arena_car.h"
+#include "arena_gjk.h"
 
 #ifndef RLG_DBG_COUNT
 #define RLG_DBG_COUNT(i) ((void)0)
@@ -88,6 +89,27 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 //                 other lanes of the wavefront (rlgpu_env.hip).  Item results are merged in the order the inline
 //                 provider would have produced them, so both give identical contact lists.
 // The candidate / item queue itself (CollideQueue) and the BVH queries live in arena_world.h: the wheel rays share it.
+// One (hitbox, triangle) pair of the car-mesh manifold: GJK on the core shapes (arena_gjk.h); where the cores themselves overlap, the
+// core polytopes' minimum-translation axis from the SAT routine (deepest clipped point), pushed out by the margin.
+RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
+    GjkOut g; bool deep = false;
+    if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, CBT_CAR, g, deep)) {
+        if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
+        c.n = g.n; c.pb = g.pb; c.dist = g.dist;
+        adjust_internal_edge(t, c.pb, c.n, c.dist);
+        return true;
+    }
+    if (!deep) return false;
+    Cand cs[4]; int nc = 0;
+    box_triangle(bc, R, hitbox_core(), t, 0.f, cs, nc);
+    if (nc == 0) return false;
+    int best = 0;
+    for (int q = 1; q < nc; q++) if (cs[q].dist < cs[best].dist) best = q;
+    c = cs[best]; c.dist -= BOX_MARGIN;
+    adjust_internal_edge(t, c.pb, c.n, c.dist);
+    return true;
+}
+
 struct NarrowInline {
     template <int NC, class F>
     RLG_HD void ball_mesh(const Arena<NC>& A, MeshView mesh, F&& emit) {
@@ -96,7 +118,7 @@ struct NarrowInline {
         ball_query_aabb(bp, lo, hi);
         mesh_query(mesh, lo, hi, [&](int ti) {
             Cand c;
-            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist)) emit(c);
+            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[ti], c.pb, c.n, c.dist); emit(c); }
         });
     }
     template <int NC, class F>
@@ -105,9 +127,8 @@ struct NarrowInline {
         V3 bc, lo, hi;
         car_query_aabb(car, bc, lo, hi);
         mesh_query(mesh, lo, hi, [&](int ti) {
-            Cand cs[8]; int nc = 0;
-            box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[ti], CBT_CAR, cs, nc);
-            for (int q = 0; q < nc; q++) emit(cs[q]);
+            Cand c;
+            if (hitbox_triangle(bc, car.b.rot, mesh.tris[ti], c)) emit(c);
         });
     }
     template <int NC>
@@ -173,11 +194,12 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
     if (it.type == 0) {
         const float r = K::BALL_RADIUS * UU2BT;
         Cand c;
-        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], c.pb, c.n, c.dist)) out[n++] = c;
+        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[it.ref], c.pb, c.n, c.dist); out[n++] = c; }
     } else if (it.type == 1) {
         const Car& car = A.cars[it.a];
         V3 bc = car.b.pos + car.b.rot * hitbox_off();
-        box_triangle(bc, car.b.rot, hitbox_half(), mesh.tris[it.ref], CBT_CAR, out, n);
+        Cand c;
+        if (hitbox_triangle(bc, car.b.rot, mesh.tris[it.ref], c)) out[n++] = c;
     } else {
         Cand cs[4]; int nc = 0;
         NarrowInline().car_car(A, it.a, it.ref, cs, nc);

@@ -206,10 +206,14 @@ struct alignas(16) BvhNode {  // 32 B
 constexpr uint32_t BVH_END = 0xFFFFFFu;
 RLG_HD int node_count(const BvhNode& n) { return (int)(n.count_escape & 0xffu); }
 RLG_HD uint32_t node_escape(const BvhNode& n) { return n.count_escape >> 8; }
-struct alignas(16) MeshTri {  // 48 B, BT units
+struct alignas(16) MeshTri {  // 64 B, BT units
     float v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z;
-    uint32_t edge_flags;  // bit e (0..2): edge e (v_e -> v_{e+1}) is an internal flat/concave edge: snap edge normals to the face
-    uint32_t _pad0, _pad1;
+    // btTriangleInfo of this triangle (BulletCollision/CollisionShapes/btTriangleInfoMap.h:27-52, filled the way btGenerateInternalEdgeInfo
+    // does, arena_mesh.cpp): dihedral angle over edge v0v1 / v1v2 / v2v0 towards the neighbour sharing it (2 pi = no neighbour) ...
+    float edge_angle[3];
+    uint32_t edge_flags;  // ... and TRI_INFO_V0V1_CONVEX = 1, V1V2_CONVEX = 2, V2V0_CONVEX = 4, V0V1_SWAP_NORMALB = 8, V1V2_SWAP = 16, V2V0_SWAP = 32;
+                          // bit 31: the triangle has an info record at all (some edge is shared)
+    uint32_t _pad0, _pad1, _pad2;
 };
 // coarse occupancy grid over the arena volume: bit set <=> some mesh triangle overlaps the 256 uu cell.  Most queries
 // (mid-field wheel rays, ball / hitbox AABBs) touch only empty cells and skip the BVH walk altogether.

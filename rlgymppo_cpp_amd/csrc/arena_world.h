@@ -215,7 +215,9 @@ RLG_HD void car_query_aabb(const Car& car, V3& bc, V3& lo, V3& hi) {
     M3 absR = m3_rows(v3(fabsf(car.b.rot.r0.x), fabsf(car.b.rot.r0.y), fabsf(car.b.rot.r0.z)),
                       v3(fabsf(car.b.rot.r1.x), fabsf(car.b.rot.r1.y), fabsf(car.b.rot.r1.z)),
                       v3(fabsf(car.b.rot.r2.x), fabsf(car.b.rot.r2.y), fabsf(car.b.rot.r2.z)));
-    V3 ext = absR * h + v3(0.04f + CBT_CAR, 0.04f + CBT_CAR, 0.04f + CBT_CAR);
+    // btConvexTriangleCallback::setTimeStepAndCounters (btConvexConcaveCollisionAlgorithm.cpp:167-188): the box's own AABB (margin included)
+    // grown by the trimesh's collision margin, which is 0 (btConcaveShape.cpp:21) -- a triangle the hitbox is merely NEAR is never tested
+    V3 ext = absR * h;
     lo = bc - ext; hi = bc + ext;
 }
 RLG_HD bool car_collides(const Car& car) { return !(car.flags & CF_IS_DEMOED) && !car.frozen; }  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
@@ -513,6 +515,63 @@ RLG_HD bool point_in_triangle(V3 p, V3 v0, V3 v1, V3 v2, V3 n) {
     return (r1 > 0 && r2 > 0 && r3 > 0) || (r1 <= 0 && r2 <= 0 && r3 <= 0);
 }
 
+// btAdjustInternalEdgeContacts (btInternalEdgeUtility.cpp:413-797, normalAdjustFlags = 0), run by the contact-added callback on every
+// new point against the mesh (Arena.cpp:275-279): a contact that lies within 0.1 of the triangle's closest shared edge gets the
+// face normal when the edge is flat / concave towards the contact normal, a normal clamped into the edge's Voronoi wedge when it is
+// convex; the point on the triangle is re-projected from the (unchanged) point on the body.  The mesh body sits at the identity.
+RLG_HD V3 nearest_on_segment(V3 p, V3 l0, V3 l1) {
+    V3 d = l1 - l0;
+    if (len2(d) < SIMD_EPS * SIMD_EPS) return l0;
+    float delta = dot(p - l0, d) / dot(d, d);
+    if (delta < 0.f) delta = 0.f; else if (delta > 1.f) delta = 1.f;
+    return l0 + d * delta;
+}
+RLG_HD_NOINLINE void adjust_internal_edge(const MeshTri& t, V3& pb, V3& n, float dist) {
+    if (!(t.edge_flags >> 31)) return;
+    const V3 pa = pb + n * dist;                      // m_positionWorldOnA (btManifoldResult.cpp:117)
+    const V3 v[3] = {v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z)};
+    const V3 tri_normal = normalized(cross(v[1] - v[0], v[2] - v[0]));
+    const V3 contact = pb;
+    const V3 local_n = normalized(n);
+    const float TWO_PI = 6.283185307179586232f;
+    int best = -1; float best_d = 1e18f;
+    for (int e = 0; e < 3; e++) {
+        if (!(fabsf(t.edge_angle[e]) < TWO_PI)) continue;
+        float l = len(contact - nearest_on_segment(contact, v[e], v[(e + 1) % 3]));
+        if (l < best_d) { best = e; best_d = l; }
+    }
+    if (best < 0 || !(best_d < 0.1f)) return;         // m_edgeDistanceThreshold
+    const int e = best;
+    const float angle = t.edge_angle[e];
+    bool concave = false;
+    if (angle == 0.f) concave = true;
+    else {
+        const V3 edge = v[e] - v[(e + 1) % 3];
+        const bool convex = (t.edge_flags >> e) & 1u;
+        const float swap = convex ? 1.f : -1.f;
+        const V3 nA = swap * tri_normal;
+        V3 cnb = quat_rotate(quat_axis_angle(edge, angle), tri_normal);
+        if ((t.edge_flags >> (3 + e)) & 1u) cnb *= -1.f;
+        const V3 nB = swap * cnb;
+        const bool back_facing = (dot(local_n, nA) < 0.f) && (dot(local_n, nB) < 0.f);
+        if (back_facing) concave = true;
+        else {
+            // btClampNormal (:375-410); edges 1 and 2 pass the un-normalised local normal (:607, :676)
+            const V3 ln = e == 0 ? local_n : n;
+            const V3 edge_cross = normalized(cross(edge, nA));
+            const float cur = atan2f(dot(ln, edge_cross), dot(ln, nA));
+            if ((angle < 0.f && cur < angle) || (angle >= 0.f && cur > angle)) {
+                const V3 clamped = quat_to_m3(quat_axis_angle(edge, angle - cur)) * ln;
+                if (dot(clamped, tri_normal) > 0.f) { n = clamped; pb = pa - n * dist; }
+            }
+        }
+    }
+    if (concave) {
+        if (dot(tri_normal, local_n) < 0.f) return;
+        n = tri_normal; pb = pa - n * dist;
+    }
+}
+
 // sphere (ball) vs one triangle: SphereTriangleDetector::collide (:139-241) + the internal-edge snap
 RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const MeshTri& t, V3& point, V3& normal, float& depth) {
     V3 v0 = v3(t.v0x, t.v0y, t.v0z), v1 = v3(t.v1x, t.v1y, t.v1z), v2 = v3(t.v2x, t.v2y, t.v2z);
@@ -541,20 +600,6 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
         normal = ctc / d;  // btVector3::normalize
         point = cp; depth = -(radius - d);
     } else { normal = n; point = cp; depth = -radius; }
-    // internal-edge fix-up (btInternalEdgeUtility.cpp:414-797, simplified): on an edge/vertex whose adjoining
-    // face is coplanar or concave the contact normal is the face normal; distance kept, point re-projected
-    if (feature != 0) {
-        uint32_t ef = back_side ? (t.edge_flags >> 3) : t.edge_flags;  // bits 0-2 front view, 3-5 back view (arena_mesh.cpp)
-        bool snap = false;  // edges: 0 = v0v1, 1 = v1v2, 2 = v2v0
-        if (feature == 4) snap = ef & 1u; else if (feature == 6) snap = ef & 2u; else if (feature == 5) snap = ef & 4u;
-        else if (feature == 1) snap = (ef & 1u) && (ef & 4u);
-        else if (feature == 2) snap = (ef & 1u) && (ef & 2u);
-        else if (feature == 3) snap = (ef & 2u) && (ef & 4u);
-        if (snap) {
-            normal = n;
-            point = (c - normal * radius) - normal * depth;  // positionWorldOnA - n * distance
-        }
-    }
     return true;
 }
 

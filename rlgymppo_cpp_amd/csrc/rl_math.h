@@ -150,6 +150,19 @@ RLG_HD Q4 quat_axis_angle(V3 axis, float angle) {
     return q;
 }
 
+// quatRotate (btQuaternion.h): q * v * q^-1 through the quaternion products Bullet uses
+RLG_HD V3 quat_rotate(Q4 r, V3 v) {
+    // q = rotation * v  (btQuaternion operator*(q, w))
+    Q4 q;
+    q.x = r.w * v.x + r.y * v.z - r.z * v.y;
+    q.y = r.w * v.y + r.z * v.x - r.x * v.z;
+    q.z = r.w * v.z + r.x * v.y - r.y * v.x;
+    q.w = -r.x * v.x - r.y * v.y - r.z * v.z;
+    Q4 inv; inv.x = -r.x; inv.y = -r.y; inv.z = -r.z; inv.w = r.w;   // rotation.inverse()
+    Q4 o = qmul(q, inv);
+    return v3(o.x, o.y, o.z);
+}
+
 // btTransformUtil::integrateTransform's rotation part (LinearMath/btTransformUtil.h:37-87)
 RLG_HD_NOINLINE M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
     const float ANGULAR_MOTION_THRESHOLD = 0.5f * (PI_F * 0.5f);

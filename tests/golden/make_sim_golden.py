@@ -61,6 +61,61 @@ def scenarios():
     return out
 
 
+def extra_scenarios():
+    """Round 2: hitbox-vs-mesh, car-car bump / demo / respawn, ball pinches, 2v2 and 3v3."""
+    out = {}
+    B = [1, 0, 0, 0, 0, 0, 1, 0]   # throttle + boost
+
+    def arena(nc, cars):
+        s = default_arena(nc)
+        for k, (pos, yaw, boost) in enumerate(cars):
+            s.cars[k].pos[:] = pos; s.cars[k].rot[:] = yaw_rot(yaw); s.cars[k].boost = boost
+        return s
+    # hitbox into the back-wall mesh, head on and at an angle (box-triangle narrowphase)
+    s = arena(2, [((2500, 4200, 17), np.pi / 2, 100), ((-2500, -4200, 17), -np.pi / 2 + 0.5, 100)])
+    out["car_into_back_wall"] = (s, lambda t, k: B, 260)
+    # into the 45-degree corner wall, and along it
+    s = arena(2, [((3300, 3500, 17), np.pi / 4, 100), ((-3400, -3300, 17), -np.pi / 2 - 0.3, 100)])
+    out["car_into_corner_wall"] = (s, lambda t, k: B, 300)
+    # goal: post (convex edge), side wall of the goal box, back of the net
+    s = arena(2, [((700, 4300, 17), np.pi / 2 + 0.12, 100), ((-300, -4400, 17), -np.pi / 2 - 0.25, 100)])
+    out["car_into_goal"] = (s, lambda t, k: B, 300)
+    # x = +4096 wall plane at an angle; floor fillet under the wheels first
+    s = arena(2, [((3000, 500, 17), 0.35, 100), ((-3000, -500, 17), np.pi - 0.6, 60)])
+    out["car_into_side_wall"] = (s, lambda t, k: B, 300)
+    # jump + flip into the ceiling region is too slow; drop a car from the ceiling upside down instead, spinning
+    s = arena(2, [((500, -500, 1900), 0.3, 50), ((-800, 900, 1200), -1.0, 50)])
+    s.cars[0].flags = 0; s.cars[0].rot[:] = euler_rot(0.3, 0.4, 2.9); s.cars[0].ang_vel[:] = (1.0, -2.0, 0.5); s.cars[0].vel[:] = (200, 100, 600)
+    s.cars[1].flags = 0; s.cars[1].rot[:] = euler_rot(-1.0, -1.2, 0.7); s.cars[1].ang_vel[:] = (-3.0, 1.0, 2.5); s.cars[1].vel[:] = (-300, 50, -900)
+    out["tumbling_drops"] = (s, lambda t, k: [0, 0, 0.3 if k == 0 else -0.5, 0.2, 0.4 if t % 60 < 30 else -0.4, 0, 0, 0], 400)
+    # supersonic demo + respawn (3 s) of the victim; the attacker drives on
+    s = arena(2, [((0, -3000, 17), np.pi / 2, 100), ((0, 1500, 17), -np.pi / 2, 0)])
+    out["demo_and_respawn"] = (s, lambda t, k: B if k == 0 else Z, 620)
+    # side-on bump (not supersonic): victim standing across the attacker's path
+    s = arena(2, [((0, -1200, 17), np.pi / 2, 30), ((10, 0, 17), 0.0, 0)])
+    out["side_bump"] = (s, lambda t, k: [1, 0, 0, 0, 0, 0, 1 if t < 40 else 0, 0] if k == 0 else Z, 300)
+    # ball pinched between a car and the back wall / floor
+    s = arena(2, [((1500, 3200, 17), np.pi / 2, 100), ((0, -3000, 17), np.pi / 2, 0)])
+    s.ball.pos[:] = (1500, 4500, 93.15)
+    out["ball_pinch_back_wall"] = (s, lambda t, k: B if k == 0 else Z, 260)
+    # dribble: ball dropped on the roof of a moving car
+    s = arena(2, [((0, -2000, 17), np.pi / 2, 100), ((2000, 2000, 17), -np.pi / 2, 0)])
+    s.cars[0].vel[:] = (0, 600, 0); s.ball.pos[:] = (0, -1980, 160); s.ball.vel[:] = (0, 600, 0)
+    out["ball_on_roof"] = (s, lambda t, k: [0.6, 0.05, 0, 0.05, 0, 0, 0, 0] if k == 0 else Z, 300)
+    # aerial hit: jump + boost into a falling ball
+    s = arena(2, [((0, -1500, 17), np.pi / 2, 100), ((0, 2500, 17), -np.pi / 2, 100)])
+    s.ball.pos[:] = (0, -300, 700); s.ball.vel[:] = (0, -100, 0)
+    out["aerial_hit"] = (s, lambda t, k: [1, 0, -0.6 if 20 <= t < 60 else 0, 0, 0, 1 if t < 25 else 0, 1, 0] if k == 0 else Z, 260)
+    # 2v2: two cars chase the ball from each side, one of them jumping
+    s = arena(4, [((-300, -1500, 17), np.pi / 2, 100), ((300, 1500, 17), -np.pi / 2, 100), ((400, -2200, 17), np.pi / 2 + 0.2, 60), ((-500, 2300, 17), -np.pi / 2 + 0.15, 60)])
+    out["2v2_ball_chase"] = (s, lambda t, k: [1, 0.1 if k == 0 else (-0.1 if k == 1 else 0), 0, 0, 0, 1 if (k == 2 and 40 <= t < 50) else 0, 1 if t < 120 else 0, 0], 400)
+    # 3v3 kickoff: everybody boosts at the ball
+    s = arena(6, [((-2048, -2560, 17), np.pi / 4, 33.3), ((2048, 2560, 17), -3 * np.pi / 4, 33.3), ((2048, -2560, 17), 3 * np.pi / 4, 33.3),
+                  ((-2048, 2560, 17), -np.pi / 4, 33.3), ((0, -4608, 17), np.pi / 2, 33.3), ((0, 4608, 17), -np.pi / 2, 33.3)])
+    out["3v3_kickoff"] = (s, lambda t, k: [1, 0, 0, 0, 0, 1 if (k == 4 and 100 <= t < 110) else 0, 1, 0], 360)
+    return out
+
+
 def state_vec(s: ArenaState):
     v = list(s.ball.pos) + list(s.ball.vel) + list(s.ball.ang_vel)
     for k in range(s.num_cars):
