@@ -400,3 +400,72 @@ extern "C" int ref_debug_manifolds(void* h, float* out, int cap_points) {
     }
     return n;
 }
+
+// every manifold of the dispatcher in array order, points or not: 4 floats each = body0 kind, body1 kind, contacts, island tag of body0
+extern "C" int ref_debug_manifold_list(void* h, float* out, int cap) {
+    Arena* a = (Arena*)h;
+    btCollisionDispatcher* d = (btCollisionDispatcher*)a->_bulletWorld.getDispatcher();
+    int n = 0;
+    for (int m = 0; m < d->getNumManifolds() && n < cap; m++) {
+        btPersistentManifold* pm = d->getManifoldByIndexInternal(m);
+        float* o = out + 4 * n++;
+        o[0] = BodyKind(pm->getBody0()); o[1] = BodyKind(pm->getBody1()); o[2] = (float)pm->getNumContacts(); o[3] = (float)pm->getBody0()->getIslandTag();
+        if (o[1] < 0) {   // which static: plane normals / mesh
+            const btCollisionShape* s = pm->getBody1()->getCollisionShape();
+            if (s->getShapeType() == STATIC_PLANE_PROXYTYPE) { const btVector3& pn = ((const btStaticPlaneShape*)s)->getPlaneNormal(); o[1] = -(2.f + (pn.z() > 0.5f ? 0.f : pn.z() < -0.5f ? 1.f : pn.x() > 0.5f ? 2.f : 3.f)); }
+        }
+    }
+    return n;
+}
+
+// ---- round 2: gyms beyond the example stack -----------------------------------------------------------
+// obs_max_players 0: DefaultOBS, m > 0: DefaultOBSPadded(m).  reward_kind 0 / 1: the example stack plain / inside ZeroSumReward(0.5, 1);
+// 2 / 3: EVERY CommonRewards.h term with distinct weights -- EventReward with eleven distinct weights, VelocityReward(false),
+// SaveBoostReward(0.5), VelocityBallToGoalReward(false), VelocityPlayerToBallReward, FaceBallReward, TouchBallReward(0.7) -- plain /
+// inside ZeroSumReward(0.3, 0.8).  The weights are mirrored by tests/simlib.py:all_terms_cfg.
+extern "C" void* ref_gym_new2(int team_size, int tick_skip, int obs_max_players, int reward_kind, int no_touch_steps) {
+    RefGym* g = new RefGym();
+    CombinedReward* comb;
+    if (reward_kind < 2) {
+        g->eventReward = new EventReward({ .teamGoal = 1.f, .concede = -1.f });
+        comb = new CombinedReward({ { new FaceBallReward(), 0.1f }, { new VelocityPlayerToBallReward(), 0.5f },
+            { new VelocityBallToGoalReward(), 1.0f }, { g->eventReward, 50.f } });
+    } else {
+        g->eventReward = new EventReward({ .goal = 1.f, .teamGoal = 0.5f, .concede = -0.75f, .assist = 0.6f, .touch = 0.05f, .shot = 0.3f,
+            .shotPass = 0.2f, .save = 0.4f, .demo = 0.35f, .demoed = -0.25f, .boostPickup = 0.15f });
+        comb = new CombinedReward({ { g->eventReward, 10.f }, { new VelocityReward(false), 0.11f }, { new SaveBoostReward(0.5f), 0.07f },
+            { new VelocityBallToGoalReward(false), 0.9f }, { new VelocityPlayerToBallReward(), 0.45f }, { new FaceBallReward(), 0.13f },
+            { new TouchBallReward(0.7f), 0.8f } });
+    }
+    g->rootReward = comb;
+    if (reward_kind == 1) g->rootReward = new ZeroSumReward(comb, 0.5f, 1.0f);
+    if (reward_kind == 3) g->rootReward = new ZeroSumReward(comb, 0.3f, 0.8f);
+    g->noTouch = new NoTouchCondition(no_touch_steps);
+    g->conds = { g->noTouch, new GoalScoreCondition() };
+    g->obs = obs_max_players > 0 ? (OBSBuilder*)new DefaultOBSPadded(obs_max_players) : (OBSBuilder*)new DefaultOBS();
+    g->parser = new DiscreteAction();
+    g->setter = new FixedStateSetter();
+    g->match = new Match(g->rootReward, g->conds, g->obs, g->parser, g->setter, team_size, true);
+    g->gym = new Gym(g->match, tick_skip);
+    g->nPlayers = team_size * 2;
+    return g;
+}
+// car ids (slot + 1) in the order of GameState::players, i.e. the reference's own iteration order of Arena::_cars (a
+// std::unordered_set<Car*>: pointer-hash order, different from run to run) -- DefaultOBS lists the other players in it
+extern "C" int ref_gym_player_order(void* h, int32_t* out) {
+    RefGym* g = (RefGym*)h;
+    int n = 0;
+    for (auto& p : g->gym->prevState.players) out[n++] = (int32_t)p.carId;
+    return n;
+}
+// state setters: `n` arenas reset by the reference's own RandomState(ballRandSpeed, carRandSpeed, carsOnGround) (kind 0) or KickoffState (kind 1)
+extern "C" void ref_setter_samples(int team_size, int kind, int n, RlgpuArenaState* out) {
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE); a->AddCar(Team::ORANGE); }
+    RandomState rs(true, true, true); KickoffState ks;
+    for (int i = 0; i < n; i++) {
+        if (kind == 0) rs.ResetState(a); else ks.ResetState(a);
+        GetArenaPhys(a, &out[i]);
+    }
+    delete a;
+}

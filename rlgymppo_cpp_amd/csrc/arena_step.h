@@ -135,7 +135,7 @@ struct NarrowInline {
     RLG_HD void car_car(const Arena<NC>& A, int ia, int ib, Cand (&cs)[4], int& nc) {
         const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
         // box A = the manifold's body0 = the HIGHER car (arena_contact.h); normals point from the lower car towards it, pb lies on the lower car
-        box_box(cb.b.pos + cb.b.rot * hitbox_off(), cb.b.rot, ca.b.pos + ca.b.rot * hitbox_off(), ca.b.rot, hitbox_half(), cs, nc);
+        box_box_ode((cb.b.rot * hitbox_off()) + cb.b.pos, cb.b.rot, (ca.b.rot * hitbox_off()) + ca.b.pos, ca.b.rot, hitbox_half(), cs, nc);
     }
 };
 
@@ -491,13 +491,18 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
             bool listed = mesh.n_tris > 0;
             if (listed && mesh.bp) { const int bit = bp_cell_index(cx[p], cy[p], cz[p]); listed = (mesh.bp[bit >> 5] >> (bit & 31)) & 1u; }
             if (listed) listed = aabb_touch(plo[p], phi[p], mlo, mhi);
+            if (listed && p > 0) { V3 l, h; hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, l, h); listed = aabb_touch(l, h, mlo, mhi); }
             const int base = body_region(p), nw_ = W.body_n[p];
             int k = 0, nmesh = 0;
             while (k < nw_ && L.c[base + k].sid == 0) { k++; nmesh++; }
             if (listed) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)base; mcnt[nm] = (int8_t)nmesh; nm++; }
+            V3 xlo = plo[p], xhi = phi[p];     // a car's child algorithm also needs the hitbox's own box to reach the plane's (btCompoundCollisionAlgorithm.cpp:333-358)
+            if (p > 0) hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, xlo, xhi);
             for (int s = 1; s <= 4; s++) {
                 int cnt = 0, first = base + k;
                 if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
+                V3 slo, shi; world_plane_aabb(s - 1, slo, shi);
+                if (!aabb_touch(plo[p], phi[p], slo, shi) || !aabb_touch(xlo, xhi, slo, shi)) continue;
                 mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
             }
         }
@@ -604,7 +609,7 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
         s.v = c.b.vel; s.w = c.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
         s.inv_m = CAR_INV_MASS; s.inv_i = c.b.inv_inertia_w;
         s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
-        s.active = !c.frozen && !(c.flags & CF_IS_DEMOED);
+        s.active = !c.frozen;
     }
     // row numbering: normal rows in solver order, then the averaged special row, then one friction row per non-special
     // contact, then the special row's friction row
@@ -705,13 +710,19 @@ RLG_HD_NOINLINE void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
         Car& c = A.cars[body - 1];
         if (s.active) {
             c.b.vel = (s.v + s.dv) + s.ext_f; c.b.angvel = (s.w + s.dw) + s.ext_t;
+            // A car demolished by this tick's contact callback: the reference's reported rotation is the copy Car::_PostTickUpdate takes
+            // (Car.cpp:135-138), which it skips for a demoed car -- so the state keeps the pre-tick basis while position and velocities
+            // come from the body (Car.cpp:10-20).  The body is disabled from the next pre-tick on and rebuilt at respawn.
+            const bool rot_stale = (c.flags & CF_IS_DEMOED) != 0;
             if (!is_zero(s.push) || !is_zero(s.turn)) {
                 c.b.pos = c.b.pos + s.push * dt;
-                c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
+                if (!rot_stale) c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
             }
             c.b.pos = c.b.pos + c.b.vel * dt;
-            c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
-            body_update_inertia(c.b, car_inv_inertia_local());
+            if (!rot_stale) {
+                c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
+                body_update_inertia(c.b, car_inv_inertia_local());
+            }
         }
         c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0);
     }

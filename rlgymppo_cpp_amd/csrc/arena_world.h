@@ -220,7 +220,9 @@ RLG_HD void car_query_aabb(const Car& car, V3& bc, V3& lo, V3& hi) {
     V3 ext = absR * h;
     lo = bc - ext; hi = bc + ext;
 }
-RLG_HD bool car_collides(const Car& car) { return !(car.flags & CF_IS_DEMOED) && !car.frozen; }  // CF_NO_CONTACT_RESPONSE (Car.cpp:77)
+// CF_NO_CONTACT_RESPONSE + DISABLE_SIMULATION are set by the NEXT pre-tick of a demoed car (Car.cpp:69-80): `frozen` = demoed at tick start.
+// A car demolished by this tick's callback (Car::Demolish only sets the state flag) still collides and integrates until the tick ends.
+RLG_HD bool car_collides(const Car& car) { return !car.frozen; }
 template <int NC>
 RLG_HD bool cars_maybe_touch(const Arena<NC>& A, int ia, int ib) {
     const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
@@ -358,6 +360,18 @@ RLG_HD void world_plane_body(int i, V3& n, V3& origin) {
     else if (i == 1) { n = v3(0, 0, -1); origin = v3(0.f * UU2BT, 0.f * UU2BT, h * UU2BT); }
     else if (i == 2) { n = v3(1, 0, 0); origin = v3(-ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
     else { n = v3(-1, 0, 0); origin = v3(ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
+}
+
+// the proxy box of plane body i: RocketSim's btStaticPlaneShape::getAabb (btStaticPlaneShape.cpp:40-54) is a half space that ends 0.2
+// in front of the plane, so a body is only paired with a plane it is within reach of
+RLG_HD void world_plane_aabb(int i, V3& lo, V3& hi) {
+    const float L = 1e18f;
+    V3 n, o; world_plane_body(i, n, o);
+    lo = v3(-L, -L, -L); hi = v3(L, L, L);
+    if (i == 0) hi.z = o.z + (0.f + 0.2f);
+    else if (i == 1) lo.z = o.z + (0.f - 0.2f);
+    else if (i == 2) hi.x = o.x + (0.f + 0.2f);
+    else lo.x = o.x + (0.f - 0.2f);
 }
 
 // What a contact point looks like by the time the solver reads it: btManifoldResult::addContactPoint stores the point in both
@@ -901,6 +915,191 @@ RLG_HD_NOINLINE void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Can
         V3 ptb = pb + ub * beta;
         Cand c; c.dist = best; c.n = Ra * (-a); c.pb = ca + Ra * ptb;
         cand_add(cs, nc, c);
+    }
+}
+
+// ---- box vs box as the reference does it: btBoxBoxDetector = ODE's dBoxBox2 (BulletCollision/CollisionDispatch/btBoxBoxDetector.cpp:
+// 264-716), on the two hitboxes WITH margin (:758-765), up to 4 points per call.  Restated with column vectors: u[i] / v[j] are the
+// axes of box 1 / box 2.  Output in btManifoldResult::addContactPoint's terms: normal on box 2 pointing at box 1, point on box 2.
+// intersectRectQuad2 (:119-183): the rectangle +-h clipped against the quadrilateral p; at most 8 points
+RLG_HD int ode_rect_quad(const float h[2], const float p[8], float ret[16]) {
+    float qa[16], ra[16];
+    for (int i = 0; i < 8; i++) qa[i] = p[i];
+    float* q = qa; float* r = ra;
+    int nq = 4, nr = 0;
+    bool done = false;
+    for (int dir = 0; dir <= 1 && !done; dir++) {
+        for (int sign = -1; sign <= 1 && !done; sign += 2) {
+            float* pq = q; float* pr = r;
+            nr = 0;
+            for (int i = nq; i > 0; i--) {
+                if (sign * pq[dir] < h[dir]) {
+                    pr[0] = pq[0]; pr[1] = pq[1]; pr += 2; nr++;
+                    if (nr & 8) { q = r; done = true; break; }
+                }
+                float* nextq = (i > 1) ? pq + 2 : q;
+                if ((sign * pq[dir] < h[dir]) ^ (sign * nextq[dir] < h[dir])) {
+                    pr[1 - dir] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) * (sign * h[dir] - pq[dir]);
+                    pr[dir] = sign * h[dir];
+                    pr += 2; nr++;
+                    if (nr & 8) { q = r; done = true; break; }
+                }
+                pq += 2;
+            }
+            if (done) break;
+            q = r;
+            r = (q == ra) ? qa : ra;
+            nq = nr;
+        }
+    }
+    for (int i = 0; i < nr * 2; i++) ret[i] = q[i];
+    return nr;
+}
+// cullPoints2 (:194-262): m of the n points, spread by angle around the centroid, starting with i0
+RLG_HD void ode_cull_points(int n, const float p[], int m, int i0, int iret[]) {
+    const float M_PI_ODE = 3.14159265f;
+    float a, cx, cy, q;
+    if (n == 1) { cx = p[0]; cy = p[1]; }
+    else if (n == 2) { cx = 0.5f * (p[0] + p[2]); cy = 0.5f * (p[1] + p[3]); }
+    else {
+        a = 0; cx = 0; cy = 0;
+        for (int i = 0; i < (n - 1); i++) {
+            q = p[i * 2] * p[i * 2 + 3] - p[i * 2 + 2] * p[i * 2 + 1];
+            a += q; cx += q * (p[i * 2] + p[i * 2 + 2]); cy += q * (p[i * 2 + 1] + p[i * 2 + 3]);
+        }
+        q = p[n * 2 - 2] * p[1] - p[0] * p[n * 2 - 1];
+        if (fabsf(a + q) > SIMD_EPS) a = 1.f / (3.0f * (a + q)); else a = 1e18f;
+        cx = a * (cx + q * (p[n * 2 - 2] + p[0]));
+        cy = a * (cy + q * (p[n * 2 - 1] + p[1]));
+    }
+    float A[8]; int avail[8];
+    for (int i = 0; i < n; i++) { A[i] = atan2f(p[i * 2 + 1] - cy, p[i * 2] - cx); avail[i] = 1; }
+    avail[i0] = 0;
+    iret[0] = i0;
+    for (int j = 1; j < m; j++) {
+        a = (float)j * (2 * M_PI_ODE / m) + A[i0];
+        if (a > M_PI_ODE) a -= 2 * M_PI_ODE;
+        float maxdiff = 1e9f, diff;
+        iret[j] = i0;
+        for (int i = 0; i < n; i++) {
+            if (avail[i]) {
+                diff = fabsf(A[i] - a);
+                if (diff > M_PI_ODE) diff = 2 * M_PI_ODE - diff;
+                if (diff < maxdiff) { maxdiff = diff; iret[j] = i; }
+            }
+        }
+        avail[iret[j]] = 0;
+    }
+}
+RLG_HD_NOINLINE void box_box_ode(V3 p1, const M3& R1, V3 p2, const M3& R2, V3 h, Cand (&cs)[4], int& nc) {
+    const float fudge_factor = 1.05f;
+    const V3 u[3] = {col0(R1), col1(R1), col2(R1)}, v[3] = {col0(R2), col1(R2), col2(R2)};
+    const V3 p = p2 - p1;
+    const float pp[3] = {dot(u[0], p), dot(u[1], p), dot(u[2], p)};
+    const float A[3] = {(2.f * h.x) * 0.5f, (2.f * h.y) * 0.5f, (2.f * h.z) * 0.5f};
+    const float* B = A;
+    float R[3][3], Q[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = dot(u[i], v[j]); Q[i][j] = fabsf(R[i][j]); }
+    float s = -3.402823466e+38f, s2, l;
+    int invert = 0, code = 0;
+    V3 normal_r = v3(0, 0, 0), normal_c = v3(0, 0, 0); bool use_r = false;
+#define RLG_TST(expr1, expr2, nrm, cc) { const float e1_ = (expr1); s2 = fabsf(e1_) - (expr2); if (s2 > 0) return; if (s2 > s) { s = s2; normal_r = (nrm); use_r = true; invert = (e1_ < 0); code = (cc); } }
+    RLG_TST(pp[0], (A[0] + B[0] * Q[0][0] + B[1] * Q[0][1] + B[2] * Q[0][2]), u[0], 1);
+    RLG_TST(pp[1], (A[1] + B[0] * Q[1][0] + B[1] * Q[1][1] + B[2] * Q[1][2]), u[1], 2);
+    RLG_TST(pp[2], (A[2] + B[0] * Q[2][0] + B[1] * Q[2][1] + B[2] * Q[2][2]), u[2], 3);
+    RLG_TST(dot(v[0], p), (A[0] * Q[0][0] + A[1] * Q[1][0] + A[2] * Q[2][0] + B[0]), v[0], 4);
+    RLG_TST(dot(v[1], p), (A[0] * Q[0][1] + A[1] * Q[1][1] + A[2] * Q[2][1] + B[1]), v[1], 5);
+    RLG_TST(dot(v[2], p), (A[0] * Q[0][2] + A[1] * Q[1][2] + A[2] * Q[2][2] + B[2]), v[2], 6);
+#undef RLG_TST
+#define RLG_TST(expr1, expr2, n1, n2, n3, cc) { const float e1_ = (expr1); s2 = fabsf(e1_) - (expr2); if (s2 > SIMD_EPS) return; l = sqrtf((n1) * (n1) + (n2) * (n2) + (n3) * (n3)); \
+        if (l > SIMD_EPS) { s2 /= l; if (s2 * fudge_factor > s) { s = s2; use_r = false; normal_c = v3((n1) / l, (n2) / l, (n3) / l); invert = (e1_ < 0); code = (cc); } } }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] += 1.0e-5f;
+    RLG_TST(pp[2] * R[1][0] - pp[1] * R[2][0], (A[1] * Q[2][0] + A[2] * Q[1][0] + B[1] * Q[0][2] + B[2] * Q[0][1]), 0.f, -R[2][0], R[1][0], 7);
+    RLG_TST(pp[2] * R[1][1] - pp[1] * R[2][1], (A[1] * Q[2][1] + A[2] * Q[1][1] + B[0] * Q[0][2] + B[2] * Q[0][0]), 0.f, -R[2][1], R[1][1], 8);
+    RLG_TST(pp[2] * R[1][2] - pp[1] * R[2][2], (A[1] * Q[2][2] + A[2] * Q[1][2] + B[0] * Q[0][1] + B[1] * Q[0][0]), 0.f, -R[2][2], R[1][2], 9);
+    RLG_TST(pp[0] * R[2][0] - pp[2] * R[0][0], (A[0] * Q[2][0] + A[2] * Q[0][0] + B[1] * Q[1][2] + B[2] * Q[1][1]), R[2][0], 0.f, -R[0][0], 10);
+    RLG_TST(pp[0] * R[2][1] - pp[2] * R[0][1], (A[0] * Q[2][1] + A[2] * Q[0][1] + B[0] * Q[1][2] + B[2] * Q[1][0]), R[2][1], 0.f, -R[0][1], 11);
+    RLG_TST(pp[0] * R[2][2] - pp[2] * R[0][2], (A[0] * Q[2][2] + A[2] * Q[0][2] + B[0] * Q[1][1] + B[1] * Q[1][0]), R[2][2], 0.f, -R[0][2], 12);
+    RLG_TST(pp[1] * R[0][0] - pp[0] * R[1][0], (A[0] * Q[1][0] + A[1] * Q[0][0] + B[1] * Q[2][2] + B[2] * Q[2][1]), -R[1][0], R[0][0], 0.f, 13);
+    RLG_TST(pp[1] * R[0][1] - pp[0] * R[1][1], (A[0] * Q[1][1] + A[1] * Q[0][1] + B[0] * Q[2][2] + B[2] * Q[2][0]), -R[1][1], R[0][1], 0.f, 14);
+    RLG_TST(pp[1] * R[0][2] - pp[0] * R[1][2], (A[0] * Q[1][2] + A[1] * Q[0][2] + B[0] * Q[2][1] + B[1] * Q[2][0]), -R[1][2], R[0][2], 0.f, 15);
+#undef RLG_TST
+    if (!code) return;
+    V3 normal = use_r ? normal_r : (R1 * normal_c);
+    if (invert) normal = -normal;
+    const float depth = -s;
+    auto emit = [&](V3 pt, float dep) { if (nc < 4) { Cand c; c.n = -normal; c.pb = pt; c.dist = -dep; cs[nc++] = c; } };
+    if (code > 6) {
+        V3 pa = p1;
+        for (int j = 0; j < 3; j++) { float sign = (dot(normal, u[j]) > 0) ? 1.0f : -1.0f; pa = pa + u[j] * (sign * A[j]); }
+        V3 pb = p2;
+        for (int j = 0; j < 3; j++) { float sign = (dot(normal, v[j]) > 0) ? -1.0f : 1.0f; pb = pb + v[j] * (sign * B[j]); }
+        const V3 ua = u[(code - 7) / 3], ub = v[(code - 7) % 3];
+        // dLineClosestApproach (:85-110)
+        V3 d = pb - pa;
+        float uaub = dot(ua, ub), q1 = dot(ua, d), q2 = -dot(ub, d), dd = 1 - uaub * uaub, beta;
+        if (dd <= 0.0001f) beta = 0; else { dd = 1.f / dd; beta = (uaub * q1 + q2) * dd; }
+        pb = pb + ub * beta;
+        emit(pb, depth);
+        return;
+    }
+    const bool first = code <= 3;
+    const V3* Ra = first ? u : v; const V3* Rb = first ? v : u;
+    const V3 pa = first ? p1 : p2, pb = first ? p2 : p1;
+    const float* Sa = A; const float* Sb = A;
+    const V3 normal2 = first ? normal : -normal;
+    const float nr[3] = {dot(Rb[0], normal2), dot(Rb[1], normal2), dot(Rb[2], normal2)};
+    const float anr[3] = {fabsf(nr[0]), fabsf(nr[1]), fabsf(nr[2])};
+    int lanr, a1, a2;
+    if (anr[1] > anr[0]) { if (anr[1] > anr[2]) { a1 = 0; lanr = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+    else { if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; } else { a1 = 0; a2 = 1; lanr = 2; } }
+    V3 center;
+    if (nr[lanr] < 0) center = (pb - pa) + Rb[lanr] * Sb[lanr]; else center = (pb - pa) - Rb[lanr] * Sb[lanr];
+    const int codeN = first ? code - 1 : code - 4;
+    int code1, code2;
+    if (codeN == 0) { code1 = 1; code2 = 2; } else if (codeN == 1) { code1 = 0; code2 = 2; } else { code1 = 0; code2 = 1; }
+    float quad[8];
+    const float c1 = dot(center, Ra[code1]), c2 = dot(center, Ra[code2]);
+    float m11 = dot(Ra[code1], Rb[a1]), m12 = dot(Ra[code1], Rb[a2]), m21 = dot(Ra[code2], Rb[a1]), m22 = dot(Ra[code2], Rb[a2]);
+    {
+        const float k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+        quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4; quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+        quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4; quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+    }
+    const float rect[2] = {Sa[code1], Sa[code2]};
+    float ret[16];
+    const int n = ode_rect_quad(rect, quad, ret);
+    if (n < 1) return;
+    V3 point[8]; float dep[8];
+    const float det1 = 1.f / (m11 * m22 - m12 * m21);
+    m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+    int cnum = 0;
+    for (int j = 0; j < n; j++) {
+        const float k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2);
+        const float k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
+        point[cnum] = center + Rb[a1] * k1 + Rb[a2] * k2;
+        // (component-wise in the reference: center[i] + k1 * Rb[i][a1] + k2 * Rb[i][a2])
+        dep[cnum] = Sa[codeN] - dot(normal2, point[cnum]);
+        if (dep[cnum] >= 0) { ret[cnum * 2] = ret[j * 2]; ret[cnum * 2 + 1] = ret[j * 2 + 1]; cnum++; }
+    }
+    if (cnum < 1) return;
+    int maxc = 4;
+    if (maxc > cnum) maxc = cnum;
+    if (cnum <= maxc) {
+        for (int j = 0; j < cnum; j++) {
+            if (first) emit(point[j] + pa, dep[j]);
+            else emit((point[j] + pa) - normal * dep[j], dep[j]);
+        }
+    } else {
+        int i1 = 0; float maxdepth = dep[0];
+        for (int i = 1; i < cnum; i++) if (dep[i] > maxdepth) { maxdepth = dep[i]; i1 = i; }
+        int iret[8];
+        ode_cull_points(cnum, ret, maxc, i1, iret);
+        for (int j = 0; j < maxc; j++) {
+            V3 pos = point[iret[j]] + pa;
+            if (first) emit(pos, dep[iret[j]]);
+            else emit(pos - normal * dep[iret[j]], dep[iret[j]]);
+        }
     }
 }
 

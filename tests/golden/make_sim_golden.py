@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from simlib import PortSim, RefSim, RefGym  # noqa: E402
-from rlgymppo_cpp_amd.state import ArenaState, default_arena, yaw_rot, euler_rot  # noqa: E402
+from rlgymppo_cpp_amd.state import ArenaState, default_arena, yaw_rot, euler_rot, CF_BALLHIT_VALID  # noqa: E402
 
 Z = [0.0] * 8
 
@@ -124,6 +124,60 @@ def state_vec(s: ArenaState):
     return np.array(v, np.float32)
 
 
+def gym_cases(ref):
+    """(name, team_size, tick_skip, obs_max_players, reward_kind, no_touch_steps, start state, actions [steps][nc])."""
+    tab = np.zeros((128, 8), np.float32)
+    n = ref.lib.ref_action_table(tab.ctypes.data_as(C.c_void_p), 128); tab = tab[:n]
+
+    def act(thr=0, steer=0, pitch=0, yaw=0, roll=0, jump=0, boost=0, hb=0):
+        d = np.abs(tab - np.array([thr, steer, pitch, yaw, roll, jump, boost, hb], np.float32)).sum(1)
+        i = int(np.argmin(d)); assert d[i] == 0
+        return i
+    FWD, IDLE = act(thr=1, boost=1), act()
+
+    def arena(nc, cars):
+        s = default_arena(nc)
+        for k, (pos, yaw, boost) in enumerate(cars):
+            s.cars[k].pos[:] = pos; s.cars[k].rot[:] = yaw_rot(yaw); s.cars[k].boost = boost
+        return s
+    out = []
+    s0 = default_arena(2); s0.ball.pos[:] = (0, -1500, 93.15); s0.cars[0].boost = 100
+    for case, ts, seed in [("ts8_random", 8, 0), ("ts8_chase", 8, 1), ("ts1_random", 1, 2)]:
+        rng = np.random.RandomState(seed)
+        steps = 160 if ts == 8 else 60
+        acts = rng.randint(0, 90, size=(steps, 2)).astype(np.int32)
+        if case == "ts8_chase":
+            acts[:40, 0] = 21
+        out.append((case, 1, ts, 0, 0, 150, s0, acts))
+    # NoTouchCondition fires (nobody reaches the ball in 12 steps); GoalScoreCondition never evaluated after it (Match.cpp:32-38)
+    out.append(("1v1_timeout", 1, 8, 0, 0, 12, s0, np.random.RandomState(3).randint(0, 90, size=(40, 2)).astype(np.int32)))
+    # a ball rolling into the orange goal: GoalScoreCondition + EventReward{teamGoal, concede}
+    s = default_arena(2); s.ball.pos[:] = (200, 4300, 93.15); s.ball.vel[:] = (0, 1500, 0)
+    out.append(("1v1_goal", 1, 8, 0, 0, 150, s, np.full((60, 2), IDLE, np.int32)))
+    # goal + shot for blue 2, assist + shot pass for blue 0 (GameEventTracker.cpp:5-116), every reward term
+    s = arena(4, [((-1500, 3900, 17), 0.0, 100), ((3000, -3000, 17), -np.pi / 2, 0), ((0, 2300, 17), np.pi / 2, 100), ((-3000, -3000, 17), -np.pi / 2, 0)])
+    s.ball.pos[:] = (-1150, 3900, 93.15)
+    a = np.full((60, 4), IDLE, np.int32); a[:6, 0] = FWD; a[2:, 2] = FWD
+    out.append(("2v2_goal_assist_allterms", 2, 8, 0, 2, 150, s, a))
+    # shot by orange 1 (its touch 40 ticks before the start), save by blue 0, who then bumps and demolishes orange 1; zero-sum of every term
+    s = arena(4, [((0, -3600, 17), np.pi / 2, 100), ((0, 1500, 17), -np.pi / 2, 100), ((2500, 2000, 17), np.pi / 2, 0), ((-2500, 2000, 17), -np.pi / 2, 0)])
+    s.tick_count = 1000; s.ball_update_counter = 1000
+    s.ball.pos[:] = (0, -600, 93.15); s.ball.vel[:] = (0, -2600, 0)
+    s.cars[1].flags |= CF_BALLHIT_VALID; s.cars[1].bh_tick_hit = 960; s.cars[1].bh_tick_extra = 960
+    a = np.full((60, 4), IDLE, np.int32); a[:, 0] = FWD
+    out.append(("2v2_shot_save_demo_zerosum", 2, 8, 0, 3, 150, s, a))
+    # 2v2, DefaultOBSPadded(3) (one zero block per list, shuffled), zero-sum of every term, random actions around the ball
+    s = arena(4, [((-400, -900, 17), np.pi / 2, 60), ((300, 800, 17), -np.pi / 2, 60), ((500, -1500, 17), np.pi / 2 + 0.3, 40), ((-600, 1400, 17), -np.pi / 2 - 0.2, 40)])
+    rng = np.random.RandomState(4); a = rng.randint(0, 90, size=(100, 4)).astype(np.int32); a[:25] = FWD
+    out.append(("2v2_padded3_zerosum_random", 2, 8, 3, 3, 150, s, a))
+    # 3v3, DefaultOBS(165), every term, from the kickoff layout
+    s = arena(6, [((-2048, -2560, 17), np.pi / 4, 33.3), ((2048, 2560, 17), -3 * np.pi / 4, 33.3), ((2048, -2560, 17), 3 * np.pi / 4, 33.3),
+                  ((-2048, 2560, 17), -np.pi / 4, 33.3), ((0, -4608, 17), np.pi / 2, 33.3), ((0, 4608, 17), -np.pi / 2, 33.3)])
+    rng = np.random.RandomState(5); a = rng.randint(0, 90, size=(90, 6)).astype(np.int32); a[:10] = FWD
+    out.append(("3v3_allterms_random", 3, 8, 0, 2, 150, s, a))
+    return out
+
+
 def main():
     port = PortSim()
     verts, tris = port.procedural_mesh()
@@ -132,44 +186,48 @@ def main():
     tab = np.zeros((128, 8), np.float32)
     n = ref.lib.ref_action_table(tab.ctypes.data_as(C.c_void_p), 128)
     out["action_table"] = tab[:n].copy()
-    a = ref.arena(1)
     every = 10
     names = []
-    for name, (s0, fn, ticks) in scenarios().items():
+    sc = scenarios(); sc.update(extra_scenarios())
+    steps_before = {2: [], 4: [], 6: []}; steps_after = {2: [], 4: [], 6: []}; steps_tag = {2: [], 4: [], 6: []}
+    mbuf = np.zeros((64, 16), np.float32)
+    for si, (name, (s0, fn, ticks)) in enumerate(sc.items()):
+        nc = s0.num_cars
+        a = ref.arena(nc // 2)
         ref.set_state(a, s0)
         start = ref.get_state(a)
-        tape = np.zeros((ticks, 2, 8), np.float32)
+        tape = np.zeros((ticks, nc, 8), np.float32)
         rec = []
         for t in range(ticks):
-            for k in range(2):
+            for k in range(nc):
                 tape[t, k] = fn(t, k)
                 ref.set_controls(a, k, list(tape[t, k]))
+            before = ref.get_state(a)
             ref.step(a, 1)
+            after = ref.get_state(a)
+            # one-step pairs: every tick on which the reference's narrowphase produced a contact, and every 16th tick
+            if ref.lib.ref_debug_manifolds(a, mbuf.ctypes.data_as(C.c_void_p), 64) > 0 or t % 16 == 0:
+                steps_before[nc].append(np.frombuffer(bytes(before), np.uint8).copy()); steps_after[nc].append(np.frombuffer(bytes(after), np.uint8).copy())
+                steps_tag[nc].append((si, t))
             if (t + 1) % every == 0:
-                rec.append(state_vec(ref.get_state(a)))
+                rec.append(state_vec(after))
         out[f"phys/{name}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
         out[f"phys/{name}/tape"] = tape
         out[f"phys/{name}/states"] = np.stack(rec)
         names.append(name)
+        ref.lib.ref_arena_free(a)
     out["phys_names"] = np.array(names)
     out["phys_every"] = every
 
-    # gym-level rollouts
     gnames = []
-    for case, tick_skip, seed in [("ts8_random", 8, 0), ("ts8_chase", 8, 1), ("ts1_random", 1, 2)]:
-        g = RefGym(ref, 1, tick_skip)
-        s0 = default_arena(2); s0.ball.pos[:] = (0, -1500, 93.15); s0.cars[0].boost = 100
+    for case, team, tick_skip, omp, rk, nts, s0, acts in gym_cases(ref):
+        g = RefGym(ref, team, tick_skip, reward_kind=rk, no_touch_steps=nts, obs_max_players=omp)
         obs0 = g.reset_to(s0)
         start = ref.get_state(g.arena())
-        rng = np.random.RandomState(seed)
-        steps = 160 if tick_skip == 8 else 60
-        acts = rng.randint(0, 90, size=(steps, 2)).astype(np.int32)
-        if case == "ts8_chase":
-            acts[:40, 0] = 21
-        obs = []; rew = []; done = []
-        for t in range(steps):
-            o, r, d, _ = g.step(acts[t])
-            obs.append(o); rew.append(r); done.append(d)
+        obs = []; rew = []; done = []; order = []; last = None
+        for t in range(len(acts)):
+            o, r, d, st = g.step(acts[t])
+            obs.append(o); rew.append(r); done.append(d); order.append(g.player_order()); last = st
             if d:
                 acts = acts[: t + 1]
                 break
@@ -177,11 +235,28 @@ def main():
         out[f"gym/{case}/obs0"] = obs0
         out[f"gym/{case}/actions"] = acts
         out[f"gym/{case}/obs"] = np.stack(obs); out[f"gym/{case}/rew"] = np.stack(rew); out[f"gym/{case}/done"] = np.array(done, np.int32)
-        out[f"gym/{case}/tick_skip"] = tick_skip
+        out[f"gym/{case}/player_order"] = np.array(order, np.int32)
+        out[f"gym/{case}/final"] = np.frombuffer(bytes(last), np.uint8).copy()     # arena + gym-level carried state after the last step
+        out[f"gym/{case}/cfg"] = np.array([team, tick_skip, omp, rk, nts], np.int32)
         gnames.append(case)
     out["gym_names"] = np.array(gnames)
+
+    # state setters (A8): the reference's own RandomState(true, true, true) and KickoffState, 4000 resets each, as data
+    for team in (1, 2, 3):
+        for kind, kname in ((0, "random"), (1, "kickoff")):
+            nset = 4000 if kind == 0 else 600
+            arr = (ArenaState * nset)()
+            ref.lib.ref_setter_samples(team, kind, nset, arr)
+            rows = np.stack([np.concatenate([state_vec(x)[:9]] + [np.concatenate([state_vec(x)[9 + 20 * k: 9 + 20 * k + 18], [x.cars[k].boost]]) for k in range(2 * team)]) for x in arr])
+            out[f"setter/{kname}/team{team}"] = rows.astype(np.float32)      # ball 9, per car pos3 vel3 ang3 rot9 boost
     np.savez_compressed(os.path.join(HERE, "sim_golden.npz"), **out)
-    print("wrote sim_golden.npz:", len(names), "physics scenarios,", len(gnames), "gym rollouts")
+    st = {}
+    for nc in (2, 4, 6):
+        if steps_before[nc]:
+            st[f"nc{nc}/before"] = np.stack(steps_before[nc]); st[f"nc{nc}/after"] = np.stack(steps_after[nc]); st[f"nc{nc}/tag"] = np.array(steps_tag[nc], np.int32)
+    st["phys_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "sim_steps.npz"), **st)
+    print("wrote sim_golden.npz:", len(names), "physics scenarios,", len(gnames), "gym rollouts; sim_steps.npz:", {k: len(v) for k, v in steps_tag.items()}, "one-tick pairs")
 
 
 if __name__ == "__main__":
