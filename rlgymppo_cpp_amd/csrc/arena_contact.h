@@ -152,6 +152,15 @@ RLG_HD_NOINLINE void car_proxy_aabb(const Car& c, V3& lo, V3& hi) {
     compound_shape_aabb(c.b.pos + c.b.vel * TICK_DT, r2, l2, h2); l2 = l2 - t; h2 = h2 + t;
     lo = vmin(l1, l2); hi = vmax(h1, h2);
 }
+// The same box bracketed without the predicted rotation: [in_lo, in_hi] = the current-transform part (contained in the proxy box),
+// [out_lo, out_hi] = it grown by how far any hitbox point can travel in one tick (contains the proxy box).  A question the two
+// brackets answer alike -- which cell, does it reach a plane's half space / another proxy -- needs no sin / cos.
+RLG_HD void car_proxy_bracket(const Car& c, V3& in_lo, V3& in_hi, V3& out_lo, V3& out_hi) {
+    const V3 t = v3(BP_THRESHOLD, BP_THRESHOLD, BP_THRESHOLD);
+    compound_shape_aabb(c.b.pos, c.b.rot, in_lo, in_hi); in_lo = in_lo - t; in_hi = in_hi + t;
+    const float reach = len(c.b.vel) * TICK_DT + len(c.b.angvel) * TICK_DT * (len(hitbox_half()) + len(hitbox_off())) * 1.01f + 1e-4f;
+    out_lo = in_lo - v3(reach, reach, reach); out_hi = in_hi + v3(reach, reach, reach);
+}
 // the voxel a proxy is filed under: cell of its box's minimum corner (btRSBroadphase.h:90-108; grid from ArenaConfig.h:23-31)
 constexpr float BP_CELL = 370.f * UU2BT;
 constexpr int BP_CELLS_X = 25, BP_CELLS_Y = 33, BP_CELLS_Z = 7;   // ceil((maxPos - minPos) / cell), (-4500,-6000,0)..(4500,6000,2500) uu

@@ -27,12 +27,24 @@ struct GjkSimplex {
     bool degenerate, needs_update, valid;
 };
 
-RLG_HD void gjk_remove_vertex(GjkSimplex& s, int i) { s.n--; s.w[i] = s.w[s.n]; s.p[i] = s.p[s.n]; s.q[i] = s.q[s.n]; }
+// (Every slot of the simplex is addressed with compile-time indices -- appends and the "move the last vertex into the hole" of
+// removeVertex go through compare chains on the count -- so that on the device the 36 floats stay in registers: indexed by s.n they
+// sat in scratch memory, and a hitbox-triangle item was ~5x the cycles of the SAT routine it replaced.)
+RLG_HD V3 gjk_pick(const V3 (&a)[4], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3])); }
+template <int I>
+RLG_HD void gjk_remove_vertex(GjkSimplex& s) { s.n--; const int k = s.n; s.w[I] = gjk_pick(s.w, k); s.p[I] = gjk_pick(s.p, k); s.q[I] = gjk_pick(s.q, k); }
+RLG_HD void gjk_append(GjkSimplex& s, V3 w, V3 p, V3 q) {
+    if (s.n == 0) { s.w[0] = w; s.p[0] = p; s.q[0] = q; }
+    else if (s.n == 1) { s.w[1] = w; s.p[1] = p; s.q[1] = q; }
+    else if (s.n == 2) { s.w[2] = w; s.p[2] = p; s.q[2] = q; }
+    else { s.w[3] = w; s.p[3] = p; s.q[3] = q; }
+    s.n++;
+}
 RLG_HD void gjk_reduce(GjkSimplex& s) {   // btVoronoiSimplexSolver::reduceVertices
-    if (s.n >= 4 && !s.used[3]) gjk_remove_vertex(s, 3);
-    if (s.n >= 3 && !s.used[2]) gjk_remove_vertex(s, 2);
-    if (s.n >= 2 && !s.used[1]) gjk_remove_vertex(s, 1);
-    if (s.n >= 1 && !s.used[0]) gjk_remove_vertex(s, 0);
+    if (s.n >= 4 && !s.used[3]) gjk_remove_vertex<3>(s);
+    if (s.n >= 3 && !s.used[2]) gjk_remove_vertex<2>(s);
+    if (s.n >= 2 && !s.used[1]) gjk_remove_vertex<1>(s);
+    if (s.n >= 1 && !s.used[0]) gjk_remove_vertex<0>(s);
 }
 struct GjkSub { V3 closest; float bc[4]; bool used[4]; };
 RLG_HD void gjk_sub_set(GjkSub& r, float a, float b, float c, float d) { r.bc[0] = a; r.bc[1] = b; r.bc[2] = c; r.bc[3] = d; }
@@ -113,7 +125,7 @@ RLG_HD bool gjk_origin_tetrahedron(V3 a, V3 b, V3 c, V3 d, GjkSub& fin, bool& de
 RLG_HD bool gjk_bc_valid(const float* bc) { return bc[0] >= 0.f && bc[1] >= 0.f && bc[2] >= 0.f && bc[3] >= 0.f; }
 
 // btVoronoiSimplexSolver::updateClosestVectorAndPoints (:81-237)
-RLG_HD_NOINLINE bool gjk_update(GjkSimplex& s) {
+RLG_HD bool gjk_update(GjkSimplex& s) {
     if (!s.needs_update) return s.valid;
     s.needs_update = false;
     s.degenerate = false;
@@ -141,7 +153,8 @@ RLG_HD_NOINLINE bool gjk_update(GjkSimplex& s) {
     } else if (s.n == 3) {
         GjkSub r; gjk_sub_set(r, 0, 0, 0, 0);
         gjk_origin_triangle(s.w[0], s.w[1], s.w[2], r);
-        for (int i = 0; i < 4; i++) { s.bc[i] = r.bc[i]; s.used[i] = r.used[i]; }
+        s.bc[0] = r.bc[0]; s.bc[1] = r.bc[1]; s.bc[2] = r.bc[2]; s.bc[3] = r.bc[3];
+        s.used[0] = r.used[0]; s.used[1] = r.used[1]; s.used[2] = r.used[2]; s.used[3] = r.used[3];
         s.cp1 = s.p[0] * s.bc[0] + s.p[1] * s.bc[1] + s.p[2] * s.bc[2];
         s.cp2 = s.q[0] * s.bc[0] + s.q[1] * s.bc[1] + s.q[2] * s.bc[2];
         s.cv = s.cp1 - s.cp2;
@@ -151,7 +164,8 @@ RLG_HD_NOINLINE bool gjk_update(GjkSimplex& s) {
         GjkSub r; gjk_sub_set(r, 0, 0, 0, 0);
         bool deg = false;
         bool sep = gjk_origin_tetrahedron(s.w[0], s.w[1], s.w[2], s.w[3], r, deg);
-        for (int i = 0; i < 4; i++) { s.bc[i] = r.bc[i]; s.used[i] = r.used[i]; }
+        s.bc[0] = r.bc[0]; s.bc[1] = r.bc[1]; s.bc[2] = r.bc[2]; s.bc[3] = r.bc[3];
+        s.used[0] = r.used[0]; s.used[1] = r.used[1]; s.used[2] = r.used[2]; s.used[3] = r.used[3];
         s.degenerate = deg;
         if (sep) {
             s.cp1 = s.p[0] * s.bc[0] + s.p[1] * s.bc[1] + s.p[2] * s.bc[2] + s.p[3] * s.bc[3];
@@ -199,14 +213,17 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         if (delta > 0.f && delta * delta > sq_dist * max_d2) { degenerate = 10; check_simplex = true; break; }
         {   // inSimplex
             bool found = false;
-            for (int i = 0; i < s.n; i++) if (v3_eq(s.w[i], w)) { found = true; break; }
+            if (s.n > 0 && v3_eq(s.w[0], w)) found = true;
+            if (s.n > 1 && v3_eq(s.w[1], w)) found = true;
+            if (s.n > 2 && v3_eq(s.w[2], w)) found = true;
+            if (s.n > 3 && v3_eq(s.w[3], w)) found = true;
             if (v3_eq(w, s.last_w)) found = true;
             if (found) { degenerate = 1; check_simplex = true; break; }
         }
         float f0 = sq_dist - delta, f1 = sq_dist * GJK_REL_ERROR2;
         if (f0 <= f1) { degenerate = f0 <= 0.f ? 2 : 11; check_simplex = true; break; }
         s.last_w = w; s.needs_update = true;
-        s.w[s.n] = w; s.p[s.n] = pw; s.q[s.n] = qw; s.n++;
+        gjk_append(s, w, pw, qw);
         if (!gjk_update(s)) { degenerate = 3; check_simplex = true; break; }
         V3 nv = s.cv;
         if (len2(nv) < GJK_REL_ERROR2) { axis = nv; degenerate = 6; check_simplex = true; break; }

@@ -92,6 +92,20 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 // One (hitbox, triangle) pair of the car-mesh manifold: GJK on the core shapes (arena_gjk.h); where the cores themselves overlap, the
 // core polytopes' minimum-translation axis from the SAT routine (deepest clipped point), pushed out by the margin.
 RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
+    {   // btConvexTriangleCallback::processTriangle's early out (btConvexConcaveCollisionAlgorithm.cpp:103-137): the hitbox's support vertex
+        // along the triangle normal, either side, is farther from the plane than the contact threshold -> no GJK for this triangle
+        const V3 v0 = v3(t.v0x, t.v0y, t.v0z);
+        V3 tn = cross(v3(t.v1x, t.v1y, t.v1z) - v0, v3(t.v2x, t.v2y, t.v2z) - v0);
+        tn = normalized(tn);
+        const V3 h = hitbox_half();
+        for (int side = 0; side < 2; side++) {
+            V3 dl = tmul(R, tn);
+            V3 lp = v3(dl.x >= 0.f ? h.x : -h.x, dl.y >= 0.f ? h.y : -h.y, dl.z >= 0.f ? h.z : -h.z);
+            V3 wp = (R * lp) + bc;
+            if (dot(tn, v0) - dot(tn, wp) > CBT_CAR) return false;
+            tn *= -1.f;
+        }
+    }
     GjkOut g; bool deep = false;
     if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, CBT_CAR, g, deep)) {
         if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
@@ -454,34 +468,50 @@ static_assert(sizeof(CollideQueue<2>) <= sizeof(Row) * TickWork<2>::MAXR && size
               "the narrowphase queue must fit inside the solver rows it shares LDS with");
 
 // Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
-// contacts (arena_contact.h explains where each piece comes from).
-template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
+// contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy
+// boxes (with the predicted rotation), broadphase cells, union-find and the quickSort are all that is needed to ORDER them.
+template <int NC, int MAXC>
+RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     constexpr int NB = NC + 1;
-    ball_car_touch = false;
-    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
-    for (int ci = 0; ci < NC; ci++)
-        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); }
-
-    // proxy boxes and cells of the dynamic bodies
-    V3 plo[NB], phi[NB]; int cx[NB], cy[NB], cz[NB]; bool live[NB];
-    live[0] = true; ball_proxy_aabb(A.ball, plo[0], phi[0]);
-    for (int i = 0; i < NC; i++) { live[1 + i] = car_collides(A.cars[i]); if (live[1 + i]) car_proxy_aabb(A.cars[i], plo[1 + i], phi[1 + i]); }
-    for (int b = 0; b < NB; b++) if (live[b]) bp_cell_of(plo[b], cx[b], cy[b], cz[b]);
     V3 mlo = v3(-1e30f, -1e30f, -1e30f), mhi = v3(1e30f, 1e30f, 1e30f);
     if (mesh.bp) {
         const float* mb = reinterpret_cast<const float*>(mesh.bp + BP_WORDS);
         mlo = v3(mb[0], mb[1], mb[2]); mhi = v3(mb[3], mb[4], mb[5]);
     }
+    // proxy boxes and cells of the dynamic bodies.  A car's exact box needs the predicted rotation (sin / cos / sqrt); the bracket
+    // [inner, outer] around it decides every question below the same way in all but borderline poses, and only those pay for it.
+    V3 plo[NB], phi[NB]; int cx[NB], cy[NB], cz[NB]; bool live[NB];
+    live[0] = true; ball_proxy_aabb(A.ball, plo[0], phi[0]);
+    for (int i = 0; i < NC; i++) {
+        live[1 + i] = car_collides(A.cars[i]);
+        if (!live[1 + i]) continue;
+        V3 il, ih, ol, oh;
+        car_proxy_bracket(A.cars[i], il, ih, ol, oh);
+        int a0, a1, a2, b0, b1, b2;
+        bp_cell_of(il, a0, a1, a2); bp_cell_of(ol, b0, b1, b2);
+        bool same = a0 == b0 && a1 == b1 && a2 == b2 && (aabb_touch(il, ih, mlo, mhi) == aabb_touch(ol, oh, mlo, mhi));
+        for (int s = 0; s < 4 && same; s++) { V3 slo, shi; world_plane_aabb(s, slo, shi); same = aabb_touch(il, ih, slo, shi) == aabb_touch(ol, oh, slo, shi); }
+        if (same) {   // against the other dynamic bodies: their own outer / inner boxes (the ball's box is exact)
+            V3 bl, bh; ball_proxy_aabb(A.ball, bl, bh);
+            same = aabb_touch(il, ih, bl, bh) == aabb_touch(ol, oh, bl, bh);
+            for (int j = 0; j < NC && same; j++) {
+                if (j == i || !car_collides(A.cars[j])) continue;
+                V3 jil, jih, jol, joh; car_proxy_bracket(A.cars[j], jil, jih, jol, joh);
+                same = aabb_touch(il, ih, jil, jih) == aabb_touch(ol, oh, jol, joh);
+            }
+        }
+        if (same) { plo[1 + i] = il; phi[1 + i] = ih; } else car_proxy_aabb(A.cars[i], plo[1 + i], phi[1 + i]);
+    }
+    for (int b = 0; b < NB; b++) if (live[b]) bp_cell_of(plo[b], cx[b], cy[b], cz[b]);
     // union-find over the dynamic pairs (btSimulationIslandManager::findUnions, pair-array order; btUnionFind::unite links the root of
     // the first element under the root of the second) and the manifold list in creation order
     int8_t root[NB];
     for (int b = 0; b < NB; b++) root[b] = (int8_t)b;
     auto find = [&](int x) { while (root[x] != x) { root[x] = root[root[x]]; x = root[x]; } return x; };
-    int nm = 0, n_pair = 0;
+    int nm = 0;
     int8_t (&mkey)[LY::MAXM] = W.man_key; int8_t (&mval)[LY::MAXM] = W.man_val;   // key: body0 for now, island id later; val: manifold number
     int8_t (&mfirst)[LY::MAXM] = W.man_first; int8_t (&mcnt)[LY::MAXM] = W.man_cnt;
     for (int p = 0; p < NB; p++) {
@@ -491,13 +521,13 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
             bool listed = mesh.n_tris > 0;
             if (listed && mesh.bp) { const int bit = bp_cell_index(cx[p], cy[p], cz[p]); listed = (mesh.bp[bit >> 5] >> (bit & 31)) & 1u; }
             if (listed) listed = aabb_touch(plo[p], phi[p], mlo, mhi);
-            if (listed && p > 0) { V3 l, h; hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, l, h); listed = aabb_touch(l, h, mlo, mhi); }
+            V3 xlo = plo[p], xhi = phi[p];     // a car's child algorithm also needs the hitbox's own box to reach the other shape's (btCompoundCollisionAlgorithm.cpp:333-358)
+            if (p > 0) hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, xlo, xhi);
+            if (listed && p > 0) listed = aabb_touch(xlo, xhi, mlo, mhi);
             const int base = body_region(p), nw_ = W.body_n[p];
             int k = 0, nmesh = 0;
             while (k < nw_ && L.c[base + k].sid == 0) { k++; nmesh++; }
             if (listed) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)base; mcnt[nm] = (int8_t)nmesh; nm++; }
-            V3 xlo = plo[p], xhi = phi[p];     // a car's child algorithm also needs the hitbox's own box to reach the plane's (btCompoundCollisionAlgorithm.cpp:333-358)
-            if (p > 0) hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, xlo, xhi);
             for (int s = 1; s <= 4; s++) {
                 int cnt = 0, first = base + k;
                 if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
@@ -524,20 +554,8 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
                 const Car& ca = A.cars[p - 1]; const Car& cb = A.cars[q - 1];
                 hitbox_shape_aabb(ca.b.pos, ca.b.rot, l1, h1); hitbox_shape_aabb(cb.b.pos, cb.b.rot, l2, h2);
                 if (!aabb_touch(l1, h1, l2, h2)) continue;
-                // narrowphase of the pair: body0 = the higher car (arena_contact.h)
-                Cand cs[4]; int nc = 0;
-                nw.car_car(A, p - 1, q - 1, cs, nc);
-                const int first = LY::PAIR_BASE + n_pair;
-                int cnt = 0;
-                for (int k = 0; k < nc && n_pair < LY::PAIR_POOL; k++) {
-                    if (cs[k].dist > CBT_CAR) continue;
-                    Contact& c = L.c[LY::PAIR_BASE + n_pair];
-                    manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
-                    c.a = (int8_t)q; c.b = (int8_t)p; c.sid = 0; c.special = 0;
-                    n_pair++; cnt++;
-                    // Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car, car2): equal user indices, no swap (Arena.cpp:231-240)
-                    on_car_car_contact(A, q - 1, p - 1, tmul(cb.b.rot, c.ra), tmul(ca.b.rot, c.rb), ev);
-                }
+                int first = LY::PAIR_BASE, cnt = 0;
+                for (int k = 0; k < n_touching; k++) if (tp[k] == p && tq[k] == q) { first = tfirst[k]; cnt = tcnt[k]; }
                 mkey[nm] = (int8_t)q; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
             }
         }
@@ -551,6 +569,53 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
         for (int k = 0; k < mcnt[mi]; k++) W.cidx[n++] = (int8_t)(mfirst[mi] + k);
     }
     L.n = n;
+}
+
+// per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts
+template <int NC, int MAXC, class NW>
+RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    using LY = ContactLayout<NC>;
+    ContactList<MAXC>& L = W.L;
+    ball_car_touch = false;
+    int n_man = 0, n = 0;          // manifolds that carry points, contacts (in slot order so far)
+    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; n_man += (L.c[k].sid != 0 || k == 0); }
+    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
+    for (int ci = 0; ci < NC; ci++) {
+        const int base = body_region(1 + ci);
+        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); W.cidx[n++] = (int8_t)car_ball_slot(ci); n_man++; }
+        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); n_man += (L.c[base + k].sid != 0 || k == 0); }
+    }
+    // car-car pairs: body0 of the manifold = the higher car (arena_contact.h); the gate is conservative, the exact box test follows
+    int8_t tp[LY::PAIR_POOL], tq[LY::PAIR_POOL], tfirst[LY::PAIR_POOL], tcnt[LY::PAIR_POOL];
+    int n_touching = 0, n_pair = 0;
+    for (int ia = 0; ia < NC; ia++) {
+        for (int ib = ia + 1; ib < NC; ib++) {
+            const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
+            if (!car_collides(ca) || !car_collides(cb) || !cars_maybe_touch(A, ia, ib)) continue;
+            V3 l1, h1, l2, h2;
+            hitbox_shape_aabb(ca.b.pos, ca.b.rot, l1, h1); hitbox_shape_aabb(cb.b.pos, cb.b.rot, l2, h2);
+            if (!aabb_touch(l1, h1, l2, h2)) continue;
+            Cand cs[4]; int nc = 0;
+            nw.car_car(A, ia, ib, cs, nc);
+            const int first = LY::PAIR_BASE + n_pair;
+            int cnt = 0;
+            for (int k = 0; k < nc && n_pair < LY::PAIR_POOL; k++) {
+                if (cs[k].dist > CBT_CAR) continue;
+                Contact& c = L.c[LY::PAIR_BASE + n_pair];
+                manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
+                c.a = (int8_t)(1 + ib); c.b = (int8_t)(1 + ia); c.sid = 0; c.special = 0;
+                W.cidx[n++] = (int8_t)(LY::PAIR_BASE + n_pair);
+                n_pair++; cnt++;
+                // Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car, car2): equal user indices, no swap (Arena.cpp:231-240)
+                on_car_car_contact(A, ib, ia, tmul(cb.b.rot, c.ra), tmul(ca.b.rot, c.rb), ev);
+            }
+            if (cnt > 0 && n_touching < LY::PAIR_POOL) { tp[n_touching] = (int8_t)(1 + ia); tq[n_touching] = (int8_t)(1 + ib); tfirst[n_touching] = (int8_t)first; tcnt[n_touching] = (int8_t)cnt; n_touching++; n_man++; }
+        }
+    }
+    L.n = n;
+    // one manifold (or none): its points in slot order IS the solver order; otherwise the reference's pair / island order decides
+    if (n_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
 }
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
