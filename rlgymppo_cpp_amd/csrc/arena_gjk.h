@@ -224,6 +224,9 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         if (f0 <= f1) { degenerate = f0 <= 0.f ? 2 : 11; check_simplex = true; break; }
         s.last_w = w; s.needs_update = true;
         gjk_append(s, w, pw, qw);
+#ifdef RLG_GJK_STATS
+        RLG_GJK_STATS(4 + s.n, 0);
+#endif
         if (!gjk_update(s)) { degenerate = 3; check_simplex = true; break; }
         V3 nv = s.cv;
         if (len2(nv) < GJK_REL_ERROR2) { axis = nv; degenerate = 6; check_simplex = true; break; }
@@ -234,6 +237,9 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         if (iter++ > 1000) break;
         if (s.n == 4) { degenerate = 13; break; }
     }
+#ifdef RLG_GJK_STATS
+    RLG_GJK_STATS(2, s.n * 100 + 0); RLG_GJK_STATS(3, 0);
+#endif
     bool valid = false; float distance = 0.f; V3 normal = v3(0, 0, 0), pa = v3(0, 0, 0), pb = v3(0, 0, 0);
     if (check_simplex) {
         gjk_update(s);
