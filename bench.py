@@ -81,11 +81,41 @@ def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so):
                       f"tickSkip 8, example obs/reward stack, random actions, procedural mesh, stepping only ({sec:.1f} s)"}
 
 
+def kernel_source_hash():
+    """sha256 over the device sources of the stepper: the key under which profiles/*_pmc.json was recorded (a profile taken from
+    other kernel code is not quoted)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(kernel_prefix):
+    """The newest committed rocprofv3 PMC summary for this kernel code (tools/profile_bench.sh writes profiles/rNN*_pmc.json on the GPU
+    box): HBM traffic per launch from FETCH_SIZE + WRITE_SIZE (separate passes, KB units; the guide's gfx950 corrections are noted in the
+    file) and the SQ figures.  None when the kernel sources changed since."""
+    best = None
+    pd = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pd)) if os.path.isdir(pd) else []:
+        if not name.endswith("_pmc.json"):
+            continue
+        try:
+            j = json.load(open(os.path.join(pd, name)))
+        except Exception:
+            continue
+        if j.get("kernel_source_hash") == kernel_source_hash() and j.get("kernel", "").startswith(kernel_prefix):
+            best = j; best["file"] = "profiles/" + name
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--epochs", type=int, default=1)
@@ -93,95 +123,78 @@ def main():
     ap.add_argument("--padded-zero-sum", action="store_true", help="DefaultOBSPadded(maxPlayers = team size) + ZeroSumReward around the example stack")
     ap.add_argument("--fp32", action="store_true", help="fp32 MFMA instead of bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="LearnerConfig.collectionDuringLearn: the PPO epochs run on their own stream under the next collection (not the headline mode)")
+    ap.add_argument("--trained-warmup", type=int, default=480, help="after the timed region: this many more iterations, then --trained-steps timed ones (the policy has started to play: more contacts per tick); 0 = skip")
+    ap.add_argument("--trained-steps", type=int, default=100)
     args = ap.parse_args()
 
-    import torch
-    from rlgymppo_cpp_amd import parallel
-    rank, local_rank, world = parallel.init_process_group("nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path is HIP kernels with no CPU fallback")
+    # The measured process is rlgymppo_cpp_amd/bench_main (C++ on librlgymppo_amd.so / librlgpu.so; HIP runtime + RCCL only).  This
+    # script never touches the GPU: it starts that program as a child (one per rank under torchrun: RANK / WORLD_SIZE / LOCAL_RANK /
+    # MASTER_PORT are inherited, the ranks meet through rlgpu_comm_init_env), adds the CPU baseline and the committed PMC figures, and
+    # prints the line.
+    import subprocess
+    exe = os.path.join(ROOT, "rlgymppo_cpp_amd", "bench_main")
+    if not os.path.exists(exe):
+        raise SystemExit("bench.py: rlgymppo_cpp_amd/bench_main is not built (python -c 'import __graft_entry__ as g; g.build()') -- there is no other path")
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    cmd = [exe, "--envs", str(args.envs), "--team-size", str(args.team_size), "--horizon", str(args.horizon), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--epochs", str(args.epochs)]
+    if args.padded_zero_sum: cmd.append("--padded-zero-sum")
+    if args.fp32: cmd.append("--fp32")
+    if args.trained_warmup > 0 and args.trained_steps > 0:
+        cmd += ["--trained-warmup", str(args.trained_warmup), "--trained-steps", str(args.trained_steps)]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench_main failed with exit code {proc.returncode}")
+    if rank != 0:
+        return
+    m = json.loads(proc.stdout.decode().strip().splitlines()[-1])
 
-    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
-    n_agents = args.envs * 2 * args.team_size
-    B = n_agents * args.horizon
-    gym_cfg = None
-    if args.padded_zero_sum:
-        from rlgymppo_cpp_amd import _lib
-        gym_cfg = _lib.default_gym_config(); gym_cfg.obs_max_players = args.team_size; gym_cfg.zero_sum = 1; gym_cfg.team_spirit = 0.3; gym_cfg.opp_scale = 1.0
-    cfg = LearnerConfig(numEnvs=args.envs, teamSize=args.team_size, timestepsPerIteration=B, expBufferSize=B, device=local_rank, randomSeed=123, collectionDuringLearn=args.overlap,
-                        ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=args.epochs, policyLR=2e-4, criticLR=2e-4, entCoef=0.01,
-                                             autocastLearn=not args.fp32))
-    L = Learner(cfg, gym_cfg=gym_cfg, rank=rank, world_size=world)
-
-    def barrier():
-        torch.cuda.synchronize()
-        parallel.barrier(world)
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        L.iteration()
-    barrier()
-    L.env.timing_total(reset=True); L.ppo.timing_total(reset=True)
-    cs = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        with torch.cuda.stream(L.s_collect):
-            L.collect()
-            c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-            c0.record()   # the library launches on the null stream, which is torch's current stream here
-            L.add_new_experience()
-            L.learn()
-            c1.record()
-        cs.append((c0, c1))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, world, torch.device("cuda", local_rank))
-    consume_ms = sum(a.elapsed_time(b) for a, b in cs) / max(1, len(cs))
-    env_ms, env_launches = L.env.timing_total(reset=False)
-    gemm_ms, gemm_flops, gemm_calls = L.ppo.timing_total(reset=False)
-
-    if rank == 0:
-        agent_steps = B * world * args.steps
-        value = agent_steps / elapsed
-        n_p = 2 * args.team_size
-        if L._fused_collect:
-            # one launch = the whole collection phase: the resident state is read and written ONCE, every step writes its experience rows
-            # (obs, reward, done, action, log-prob) and reads its observation rows back for the in-kernel inference
-            per_launch_bytes = (2 * (336 * n_p + 264) + args.horizon * (n_p * (4 * L.obs_size + 8) + 4 + n_p * (4 * L.obs_size + 8))) * args.envs
-        else:
-            per_launch_bytes = algorithmic_bytes_per_gym_step(n_p, L.obs_size) * args.envs
-        avg_launch_s = (env_ms / max(1, env_launches)) * 1e-3
-        achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        peak = 8000.0
-        out = {
-            "metric": "env steps/sec/node + PPO iter ms, 1v1 4096 envs/GPU", "value": value, "unit": "agent-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32 stepper + " + ("fp32" if args.fp32 else "bf16") + " MFMA MLP", "data": "synthetic",
-            "config": {"workload": "%s, %d envs/GPU, tickSkip 8, %s(%d)+%sexample reward stack, RandomState resets, "
-                                   "T=%d steps/iter, B=%d agent-steps/GPU, minibatch %d, epochs %d, MLP 256x3 policy(90)+critic, %s arena mesh"
-                                   % ("BASELINE config[1]: 1v1" if args.team_size == 1 and not args.padded_zero_sum else "%dv%d (shape of BASELINE configs[%d])" % (args.team_size, args.team_size, args.team_size + 1),
-                                      args.envs, "DefaultOBSPadded" if args.padded_zero_sum else "DefaultObs", L.obs_size, "zero-sum " if args.padded_zero_sum else "",
-                                      args.horizon, B, B // 4, args.epochs, L.env.mesh_kind),
-                       "envs_per_gpu": args.envs, "horizon": args.horizon, "batch": B, "minibatch": B // 4, "epochs": args.epochs},
-            "collection_during_learn": bool(args.overlap),
-            "ppo_iter_ms": consume_ms if not args.overlap else None, "gym_steps_per_s": value / (2 * args.team_size), "physics_ticks_per_s": value / (2 * args.team_size) * 8,
-            "collect_ms_per_iter": (elapsed / args.steps * 1e3 - consume_ms) if not args.overlap else None,
-            "roofline": {"kernel": ("k_env_collect<%d> (%d x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)" % (2 * args.team_size, args.horizon)) if L._fused_collect else ("k_env_step<%d> (8 fused ticks + snapshot/obs/reward/done/auto-reset)" % (2 * args.team_size)), "bound": "hbm", "achieved": achieved, "peak": peak,
-                         "unit": "GB/s", "frac": achieved / peak, "traffic": None, "avg_launch_ms": env_ms / max(1, env_launches), "launches": env_launches,
-                         "algorithmic_bytes_per_launch": per_launch_bytes},
-            "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": (gemm_flops / (gemm_ms * 1e-3) / 1e12) if gemm_ms > 0 else 0.0,
-                     "peak_tflops": 157.3 if args.fp32 else 2500.0, "ms_total": gemm_ms, "calls": gemm_calls},
-        }
-        out["mfma"]["frac"] = out["mfma"]["achieved_tflops"] / out["mfma"]["peak_tflops"]
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    n_p = 2 * args.team_size
+    A = m["algorithmic_bytes_per_gym_step_per_env"]
+    assert A == algorithmic_bytes_per_gym_step(n_p, m["obs_size"])
+    # roofline of the dominant kernel, SURVEY 8d verbatim: algorithmic bytes per gym step per env x envs x gym steps per launch / its
+    # hipEvent-measured average duration (events on the env's own stream: rlgpu_env_timing_total)
+    bytes_per_launch = A * args.envs * m["gym_steps_per_launch"]
+    avg_ms = m["env_kernel_ms_total"] / max(1, m["env_launches"])
+    gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    kname = (f"k_env_collect<{n_p}> ({args.horizon} x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)"
+             if m["fused_collect"] else f"k_env_step<{n_p}> (8 ticks + snapshot/obs/reward/done/auto-reset fused)")
+    roof = {"kernel": kname, "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": m["env_launches"], "algorithmic_bytes_per_launch": bytes_per_launch,
+            "formula": "SURVEY 8d: (2*(336*Np+264) + Np*(4*D+8) + 4) B per gym step per env x envs x gym steps per launch"}
+    pmc = pmc_profile("k_env_collect" if m["fused_collect"] else "k_env_step")
+    if pmc is not None:
+        roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+        for k in ("traffic_fetch_bytes", "traffic_write_bytes", "valu_util", "waves_per_simd", "active_lane_fraction", "wait_any_frac", "file", "note"):
+            if k in pmc:
+                roof["pmc_" + k if not k.startswith("traffic") else k] = pmc[k]
+    tflops = m["gemm_flops_total"] / (m["gemm_ms_total"] * 1e-3) / 1e12 if m["gemm_ms_total"] > 0 else 0.0
+    out = {
+        "metric": f"env steps/sec/node + PPO iter ms, {args.team_size}v{args.team_size} {args.envs} envs/GPU",
+        "value": m["value"], "unit": "agent-steps/s",
+        "n_gpus": m["n_gpus"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32 stepper + " + ("fp32" if args.fp32 else "bf16") + " MFMA MLP", "data": "synthetic",
+        "config": {"workload": (f"BASELINE config[1]: 1v1, {args.envs} envs/GPU, tickSkip 8, DefaultObs(89)+example reward stack, RandomState resets, "
+                                if args.team_size == 1 and not args.padded_zero_sum else
+                                f"{args.team_size}v{args.team_size}, {args.envs} envs/GPU, tickSkip 8, " + ("DefaultOBSPadded + zero-sum example stack, " if args.padded_zero_sum else "DefaultObs + example stack, ") + "RandomState resets, ")
+                               + f"T={args.horizon} steps/iter, B={m['batch']} agent-steps/GPU, minibatch {m['minibatch']}, epochs {args.epochs}, MLP 256x3 policy(90)+critic, procedural arena mesh",
+                   "envs_per_gpu": args.envs, "horizon": args.horizon, "batch": m["batch"], "minibatch": m["minibatch"], "epochs": args.epochs,
+                   "host": "C++ (rlgymppo_cpp_amd/bench_main on librlgymppo_amd.so; no Python or torch in the measured process)"},
+        "ppo_iter_ms": m["ppo_iter_ms"], "gym_steps_per_s": m["value"] / n_p, "physics_ticks_per_s": m["value"] / n_p * 8,
+        "collect_ms_per_iter": m["ms_per_step"] - m["ppo_iter_ms"],
+        "roofline": roof,
+        "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": tflops, "peak_tflops": 2500.0,
+                 "ms_total": m["gemm_ms_total"], "calls": m["gemm_calls"], "frac": tflops / 2500.0},
+    }
+    if "trained_regime" in m:
+        out["trained_regime"] = m["trained_regime"]
+    if not args.no_cpu_baseline and world == 1:
+        cb = cpu_baseline()
+        if cb is not None:
+            out["cpu_baseline"] = cb
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -47,6 +47,14 @@ public:
     void RenderStep(int t);                          // ThreadAgent.cpp:164-186 for the first game
     int NumEnvs() const;
     int NumAgents() const;
+    // multi-GPU (one process per GPU, launcher environment RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT; include/rlgpu.h rlgpu_comm_*):
+    // envs are sharded over the ranks, ONE gradient all-reduce per optimizer step, rank 0 writes the checkpoints
+    int Rank() const;
+    int WorldSize() const;
+    // device-side clocks since the last reset: the env batch's step / collect launches and the learner's minibatch GEMM section (bench driver)
+    void DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset);
+    bool UsesFusedCollection() const;
+    double MaxOverRanks(double v);                   // collective; returns v on a single-GPU run
 private:
     struct Impl; Impl* impl;
 };

@@ -37,5 +37,9 @@ struct LearnerConfig {
     std::string metricsGroupName = "unnamed-runs";
     std::string metricsRunName = "rlgymppo-cpp-run";
     SkillTrackerConfig skillTrackerConfig = {};
+    // ---- appended by this build (after every reference field, so aggregate initialisers written for the reference keep their meaning) ----
+    // 0 = the reference's ComputeGAE as is: at a truncated trajectory end the bootstrap value is the NEXT ROW of the concatenated batch,
+    // i.e. the first state of the neighbouring trajectory (TorchFuncs.cpp:36); 1 = the agent's own V(s_T)
+    int gaeNextValueMode = 0;
 };
 }

@@ -63,6 +63,9 @@ void rlgpu_default_gym_config(RlgpuGymConfig* cfg);
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg);
 void rlgpu_env_destroy(rlgpu_env* e);
 const char* rlgpu_env_last_error(const rlgpu_env* e);
+/* New keys for the env batch's counter-based RNG streams (RandomState resets, respawn spots, padded-obs shuffles): a resumed run passes
+ * (its shard seed, a fresh epoch number) so that it does not replay the resets of the run it continues. */
+int rlgpu_env_reseed(rlgpu_env* e, uint32_t seed_lo, uint32_t seed_hi);
 int rlgpu_env_set_stream(rlgpu_env* e, void* hip_stream);
 int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size() probe (PUB/Learner.cpp:99-109): 51+19*players, padded: 51+38*maxPlayers */
 int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * 2 * team_size ; agent row = env * players + slot */
@@ -165,6 +168,11 @@ int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
  * forward pass).  For LearnerConfig::collectionDuringLearn: the learning stream calls it after every optimizer step, so that inference on
  * the collection stream reads the live weights like the reference's agent threads do (ThreadAgent.cpp:72-103). */
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l);
+/* Action-sampler key: the Philox noise of the sampler is keyed on (seed, stream, call counter, row).  `stream` separates ranks that
+ * share an init seed (identical parameters, independent exploration: rank r sets stream r); `call_ctr` is the number of act calls made
+ * so far -- restored from a checkpoint so that a resumed run does not replay the first iterations' noise. */
+int rlgpu_learner_set_sampler(rlgpu_learner* l, uint32_t stream, uint32_t call_ctr);
+int rlgpu_learner_get_sampler(rlgpu_learner* l, uint32_t* stream, uint32_t* call_ctr);
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float temperature);   /* DiscretePolicy::temperature, set per call by InferUnit (InferUnit.cpp:68,95) */
 int rlgpu_learner_sync(rlgpu_learner* l);
 /* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */
@@ -216,6 +224,24 @@ int rlgpu_lt_read_model(const char* path, const int32_t* dims, int n_linear, flo
 int rlgpu_lt_write_adam(const char* path, const int32_t* dims, int n_linear, float lr, const float* exp_avg, const float* exp_avg_sq, int64_t step);
 int rlgpu_lt_read_adam(const char* path, const int32_t* dims, int n_linear, float* exp_avg, float* exp_avg_sq, int64_t* step);
 const char* rlgpu_lt_last_error(void);
+
+/* ---- multi-GPU: one process per GPU, envs sharded across ranks, ONE gradient all-reduce per optimizer step --------
+ * Replaces nothing in the reference (it is single-GPU); stands where BASELINE config[2] asks for "RCCL grad all-reduce over xGMI".
+ * rlgpu_comm is an RCCL communicator; the data path never leaves the C-ABI (no torch.distributed). */
+typedef struct rlgpu_comm rlgpu_comm;
+#define RLGPU_COMM_ID_BYTES 128
+int rlgpu_comm_unique_id(void* id_out /* RLGPU_COMM_ID_BYTES */);                                  /* rank 0: ncclGetUniqueId */
+int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const void* id_bytes);      /* collective: ncclCommInitRank */
+int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out);                          /* RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT + file rendezvous */
+int rlgpu_comm_destroy(rlgpu_comm* c);
+int rlgpu_comm_rank(const rlgpu_comm* c);
+int rlgpu_comm_world(const rlgpu_comm* c);
+const char* rlgpu_comm_last_error(const rlgpu_comm* c);
+/* sum over ranks of the learner's flat gradient buffer [policy | critic], in place, on the learner's stream; follow with
+ * rlgpu_clip_adam_step(l, 1 / world ...) so the clip sees the global-batch gradient (PPOLearner.cpp:273-288 semantics) */
+int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c);
+int rlgpu_comm_allreduce_f32(rlgpu_comm* c, float* dev_ptr, int64_t n, void* stream);
+int rlgpu_comm_broadcast(rlgpu_comm* c, void* dev_ptr, int64_t bytes, int root, void* stream);     /* parameters / return statistics from rank 0 */
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,19 @@ SIGNATURES = {
     "rlgpu_clip_adam_step": (_i, [_vp, _f, _f]),
     "rlgpu_learner_set_lr": (_i, [_vp, _f, _f]),
     "rlgpu_learner_set_temperature": (_i, [_vp, _f]),
+    "rlgpu_env_reseed": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "rlgpu_learner_set_sampler": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "rlgpu_learner_get_sampler": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rlgpu_comm_unique_id": (_i, [_vp]),
+    "rlgpu_comm_init": (_i, [C.POINTER(_vp), _i, _i, _i, _vp]),
+    "rlgpu_comm_init_env": (_i, [C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
+    "rlgpu_comm_destroy": (_i, [_vp]),
+    "rlgpu_comm_rank": (_i, [_vp]),
+    "rlgpu_comm_world": (_i, [_vp]),
+    "rlgpu_comm_last_error": (C.c_char_p, [_vp]),
+    "rlgpu_allreduce_grads": (_i, [_vp, _vp]),
+    "rlgpu_comm_allreduce_f32": (_i, [_vp, _vp, C.c_int64, _vp]),
+    "rlgpu_comm_broadcast": (_i, [_vp, _vp, C.c_int64, _i, _vp]),
     "rlgpu_learner_refresh_shadows": (_i, [_vp]),
     "rlgpu_learner_sync": (_i, [_vp]),
     "rlgpu_learner_last_gemm": (_i, [_vp, C.POINTER(_f), C.POINTER(C.c_double)]),

@@ -737,6 +737,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     delete e;
 }
 const char* rlgpu_env_last_error(const rlgpu_env* e) { return e ? e->err.c_str() : "null env"; }
+int rlgpu_env_reseed(rlgpu_env* e, uint32_t seed_lo, uint32_t seed_hi) { e->d.cfg.seed_lo = seed_lo; e->d.cfg.seed_hi = seed_hi; return RLGPU_OK; }
 int rlgpu_env_set_stream(rlgpu_env* e, void* s) { e->stream = (hipStream_t)s; return RLGPU_OK; }
 int rlgpu_env_obs_size(const rlgpu_env* e) { return e->d.cfg.obs_max_players > 0 ? 51 + 38 * e->d.cfg.obs_max_players : 51 + 19 * e->nc; }
 int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * e->nc; }

@@ -774,7 +774,7 @@ struct rlgpu_learner {
     short* x16 = nullptr;                       // [max_rows][kp[0]] network input
     std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
     short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
-    uint32_t call_ctr = 0;
+    uint32_t call_ctr = 0, sampler_stream = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; double last_flops = 0;
@@ -1142,7 +1142,7 @@ static int policy_head(rlgpu_learner* l, const float* obs, int rows, int determi
     int rc;
     const int A = l->cfg.n_actions;
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
-    HeadArgs h{A, inv_t, deterministic, noise, l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, actions, logp, probs};
+    HeadArgs h{A, inv_t, deterministic, noise, l->cfg.seed_lo, (l->cfg.seed_hi ^ 0x5A3C0DEu) + l->sampler_stream * 0x9E3779B9u, l->call_ctr, actions, logp, probs};
     l->call_ctr++;
     if (fused_infer_fits(l, l->pol, A)) return launch_fused_infer(l, l->pol, obs, rows, 0, nullptr, h);
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), rows); }
@@ -1296,12 +1296,15 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
         net->K[i] = n.kp[i]; net->N[i] = n.dims[i + 1]; net->Npad[i] = n.kp[i + 1];
     }
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
-    *head = HeadArgs{l->cfg.n_actions, inv_t, deterministic, nullptr, l->cfg.seed_lo, l->cfg.seed_hi ^ 0x5A3C0DEu, l->call_ctr, nullptr, nullptr, nullptr};
+    *head = HeadArgs{l->cfg.n_actions, inv_t, deterministic, nullptr, l->cfg.seed_lo, (l->cfg.seed_hi ^ 0x5A3C0DEu) + l->sampler_stream * 0x9E3779B9u, l->call_ctr, nullptr, nullptr, nullptr};
     l->call_ctr += (uint32_t)n_calls;
     return RLGPU_OK;
 }
 extern "C" {
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); return l->cfg.use_bf16 ? refresh_shadows(l) : RLGPU_OK; }
+int rlgpu_learner_set_sampler(rlgpu_learner* l, uint32_t stream, uint32_t call_ctr) { l->sampler_stream = stream; l->call_ctr = call_ctr; return RLGPU_OK; }
+int rlgpu_learner_get_sampler(rlgpu_learner* l, uint32_t* stream, uint32_t* call_ctr) { if (stream) *stream = l->sampler_stream; if (call_ctr) *call_ctr = l->call_ctr; return RLGPU_OK; }
+int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c) { LCHK(l, hipSetDevice(l->device)); return rlgpu_comm_allreduce_f32(c, l->grads, l->n_total, (void*)l->stream); }
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float t) { if (!(t > 0)) return RLGPU_ERR_ARG; l->cfg.temperature = t; return RLGPU_OK; }
 int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {

@@ -107,6 +107,9 @@ class BatchedEnv:
         _chk(rc, self.h, self.lib.rlgpu_env_last_error)
         return True
 
+    def reseed(self, seed_lo: int, seed_hi: int):
+        _chk(self.lib.rlgpu_env_reseed(self.h, C.c_uint32(seed_lo & 0xffffffff), C.c_uint32(seed_hi & 0xffffffff)), self.h, self.lib.rlgpu_env_last_error)
+
     def physics_ticks(self, ticks: int):
         _chk(self.lib.rlgpu_env_physics_ticks(self.h, ticks), self.h, self.lib.rlgpu_env_last_error)
 

@@ -112,6 +112,8 @@ namespace RLGPC {
 
 struct Learner::Impl {
     rlgpu_env* env = nullptr; rlgpu_learner* lrn = nullptr; rlgpu_shuffler* shuf = nullptr;
+    rlgpu_comm* comm = nullptr; int rank = 0, world = 1, device = 0;
+    float* retShare = nullptr;   // rank 0's first returns, broadcast so every rank feeds the same statistic
     RLGSC::Match* match = nullptr; RLGSC::Gym* gym = nullptr;
     int nEnvs = 0, nAgents = 0, nPlayers = 0, D = 0, A = 0, T = 0, tickSkip = 8;
     int64_t B = 0, batch = 0, mini = 0; int maxRows = 0;
@@ -168,14 +170,23 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     }
     // The reference calls envCreateFn once per game and once more to probe the obs size (Learner.cpp:99-109); every call
     // describes the same env, so one call is enough to configure the whole device batch.
+    {   // multi-GPU launch? (torchrun or any launcher exporting RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT)
+        const char* ws = std::getenv("WORLD_SIZE");
+        if (ws && std::atoi(ws) > 1) {
+            if (rlgpu_comm_init_env(&m.comm, &m.rank, &m.world) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_init_env failed: " << rlgpu_comm_last_error(nullptr));
+            const char* lr = std::getenv("LOCAL_RANK");
+            m.device = lr ? std::atoi(lr) : m.rank;
+        }
+        HOST_HIP(hipSetDevice(m.device));
+    }
     EnvCreateResult ecr = envCreateFn();
     if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
     RlgpuGymConfig gcfg = m.match->ToDeviceConfig(m.tickSkip);
-    gcfg.seed_lo = (uint32_t)config.randomSeed; gcfg.seed_hi = 0;
+    gcfg.seed_lo = (uint32_t)config.randomSeed + 1000u * (uint32_t)m.rank; gcfg.seed_hi = 0;   // every rank its own env RNG streams; rank 0 = the single-GPU run
     m.nEnvs = config.numThreads * config.numGamesPerThread;
     m.nPlayers = m.match->playerAmount;
-    int rc = rlgpu_env_create(&m.env, 0, m.nEnvs, m.match->teamSize, &gcfg);
+    int rc = rlgpu_env_create(&m.env, m.device, m.nEnvs, m.match->teamSize, &gcfg);
     m.EnvCheck(rc, "create");
     std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
     if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
@@ -203,8 +214,11 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     lc.policy_lr = config.ppo.policyLR; lc.critic_lr = config.ppo.criticLR; lc.ent_coef = config.ppo.entCoef; lc.clip_range = config.ppo.clipRange;
     lc.temperature = config.ppo.policyTemperature; lc.use_bf16 = config.ppo.autocastLearn ? 1 : 0;
     lc.seed_lo = (uint32_t)config.randomSeed; lc.seed_hi = 0; lc.max_rows = m.maxRows;
-    rc = rlgpu_learner_create(&m.lrn, 0, &lc);
+    rc = rlgpu_learner_create(&m.lrn, m.device, &lc);
     m.LrnCheck(rc, "learner_create");
+    // identical parameters on every rank (same init seed), independent exploration: the action sampler is keyed on the rank
+    m.LrnCheck(rlgpu_learner_set_sampler(m.lrn, (uint32_t)m.rank, 0), "learner_set_sampler");
+    m.retShare = dev_alloc<float>((size_t)std::max(1, config.maxReturnsPerStatsInc));
     rlgpu_shuffler_create(&m.shuf, (uint32_t)config.randomSeed);
 
     const size_t TN = (size_t)m.T * m.nAgents;
@@ -228,7 +242,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
         skillTracker = new SkillTracker(config.skillTrackerConfig, m.lrn, m.D, m.A, config.ppo.policyLayerSizes, config.randomSeed, renderSender);
     }
     if (!config.checkpointLoadFolder.empty()) Load();
-    if (config.sendMetrics) {                                                                                                         // Learner.cpp:149-155
+    if (config.sendMetrics && m.rank == 0) {                                                                                          // Learner.cpp:149-155
         if (!runID.empty()) RG_LOG("\tRun ID: " << runID);
         metricSender = new MetricSender(config.metricsProjectName, config.metricsGroupName, config.metricsRunName, runID);
     }
@@ -245,12 +259,32 @@ Learner::~Learner() {
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
     if (m.lrn) rlgpu_learner_destroy(m.lrn);
     if (m.env) rlgpu_env_destroy(m.env);
+    if (m.retShare) (void)hipFree(m.retShare);
+    if (m.comm) rlgpu_comm_destroy(m.comm);
     delete m.gym; delete m.match;   // GameInst deletes its gym and match in the reference (GameInst.h:53-56); plugins stay the user's
     delete impl;
 }
 
 int Learner::NumEnvs() const { return impl->nEnvs; }
 int Learner::NumAgents() const { return impl->nAgents; }
+int Learner::Rank() const { return impl->rank; }
+int Learner::WorldSize() const { return impl->world; }
+double Learner::MaxOverRanks(double v) {
+    Impl& m = *impl;
+    if (!m.comm) return v;
+    std::vector<float> h(m.world, 0.f); h[m.rank] = (float)v;
+    float* d = dev_alloc<float>(m.world);
+    HOST_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    if (rlgpu_comm_allreduce_f32(m.comm, d, m.world, nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_allreduce_f32: " << rlgpu_comm_last_error(m.comm));
+    HOST_HIP(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return (double)*std::max_element(h.begin(), h.end());
+}
+bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= 2 && !stepCallback && !renderSender; }
+void Learner::DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset) {
+    impl->EnvCheck(rlgpu_env_timing_total(impl->env, &envMs, &envLaunches, reset ? 1 : 0), "timing_total");
+    impl->LrnCheck(rlgpu_learner_timing_total(impl->lrn, &gemmMs, &gemmFlops, &gemmCalls, reset ? 1 : 0), "learner_timing_total");
+}
 
 void Learner::UpdateLearningRates(float policyLR, float criticLR) {
     config.ppo.policyLR = policyLR; config.ppo.criticLR = criticLR;
@@ -272,7 +306,7 @@ void Learner::CollectTimesteps() {
     // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
     if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= 2) {   // 3v3: one env per wavefront, the in-kernel inference does not amortise
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
-        if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B; return; }
+        if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B * (uint64_t)m.world; return; }
         if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");
         m.fusedCollect = false;   // fp32 mode or a net too wide for the kernel's LDS scratch: alternate act / step
     }
@@ -300,7 +334,7 @@ void Learner::CollectTimesteps() {
             }
         }
     }
-    totalTimesteps += (uint64_t)m.B;
+    totalTimesteps += (uint64_t)m.B * (uint64_t)m.world;
 }
 
 // ThreadAgent.cpp:164-186: the first game's state goes to the renderer after every step, paced to renderTimeScale x real time
@@ -333,12 +367,20 @@ void Learner::AddNewExperience(Report& report) {
     }
     const float retStd = config.standardizeReturns ? (float)returnStats.GetSTD() : 1.f;   // read BEFORE this batch updates it (Learner.cpp:651)
     hipLaunchKernelGGL(k_done_trunc, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)m.done, m.T, m.nAgents, m.doneF, m.trunc);
-    m.LrnCheck(rlgpu_gae(m.lrn, m.rew, m.doneF, m.trunc, m.vals, m.T, m.nAgents, config.gaeGamma, config.gaeLambda, retStd, config.rewardClipRange, 0, m.adv, m.tgt, m.ret), "gae");
+    m.LrnCheck(rlgpu_gae(m.lrn, m.rew, m.doneF, m.trunc, m.vals, m.T, m.nAgents, config.gaeGamma, config.gaeLambda, retStd, config.rewardClipRange, config.gaeNextValueMode, m.adv, m.tgt, m.ret), "gae");
     if (config.standardizeReturns) {
-        // the first <= maxReturnsPerStatsInc returns of the (agent-major) batch = agent 0's first steps (Learner.cpp:679-682)
-        int k = std::min(config.maxReturnsPerStatsInc, m.T);
+        // the first <= maxReturnsPerStatsInc returns of the concatenated batch (Learner.cpp:679-682), which is agent-major: trajectory 0's
+        // T returns, then trajectory 1's, ... -- gathered column by column from the time-major device array; on a multi-GPU run every
+        // rank feeds rank 0's, so the statistic (and with it retStd) is identical everywhere
+        const int k = (int)std::min<int64_t>(config.maxReturnsPerStatsInc, (int64_t)m.T * m.nAgents);
+        for (int j = 0, done_k = 0; done_k < k; j++) {
+            const int cnt = std::min(m.T, k - done_k);
+            HOST_HIP(hipMemcpy2DAsync(m.retShare + done_k, 4, m.ret + j, (size_t)m.nAgents * 4, 4, cnt, hipMemcpyDeviceToDevice, nullptr));
+            done_k += cnt;
+        }
+        if (m.comm && rlgpu_comm_broadcast(m.comm, m.retShare, (int64_t)k * 4, 0, nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_broadcast: " << rlgpu_comm_last_error(m.comm));
         FList first(k);
-        HOST_HIP(hipMemcpy2D(first.data(), 4, m.ret, (size_t)m.nAgents * 4, 4, k, hipMemcpyDeviceToHost));
+        HOST_HIP(hipMemcpy(first.data(), m.retShare, (size_t)k * 4, hipMemcpyDeviceToHost));
         returnStats.Increment(first, k);
     }
     float sums[3] = {0, 0, 0};
@@ -382,7 +424,10 @@ void Learner::LearnPPO(Report& report) {
                 m.LrnCheck(rlgpu_ppo_minibatch(m.lrn, m.exObs, m.exActs, m.exLogp, m.exAdv, m.exTgt, m.idx + b + k, (int)m.mini, (float)m.mini / (float)m.batch, m.metrics), "ppo_minibatch");
                 nMini++;
             }
-            m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)
+            // multi-GPU: ONE all-reduce(sum) of the flat [policy | critic] gradient on the learner's stream, then scale by 1 / world INSIDE
+            // the clip so the norm is taken of the global-batch gradient, like a single learner on the union would
+            if (m.comm) m.LrnCheck(rlgpu_allreduce_grads(m.lrn, m.comm), "allreduce_grads");
+            m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f / (float)m.world), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)
             nUpdates++;
         }
     }
@@ -421,10 +466,11 @@ void Learner::Learn() {
         report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
         report["Timesteps Collected"] = (double)m.B;
         report["Collection Time"] = collectTime; report["Consumption Time"] = consumeTime; report["Total Iteration Time"] = tAll.Elapsed();
-        report["Collected Steps/Second"] = (double)m.B / std::max(collectTime, 1e-9);
-        report["Overall Steps/Second"] = (double)m.B / std::max(tAll.Elapsed(), 1e-9);
+        report["Collected Steps/Second"] = (double)m.B * m.world / std::max(collectTime, 1e-9);
+        report["Overall Steps/Second"] = (double)m.B * m.world / std::max(tAll.Elapsed(), 1e-9);
         if (iterationCallback) iterationCallback(this, report);
-        if (config.sendMetrics) metricSender->Send(report);                                                                       // Learner.cpp:589-590
+        if (config.sendMetrics && metricSender) metricSender->Send(report);                                                                       // Learner.cpp:589-590
+        if (m.rank != 0 || std::getenv("RLGPU_QUIET")) { m.tsSinceSave += (uint64_t)m.B * (uint64_t)m.world; if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save(); continue; }
         RG_LOG(std::string(8, '\n') << std::string(20, '=') << " ITERATION COMPLETED " << std::string(20, '='));
         const std::vector<std::string> rows = {"Average Step Reward", "Policy Entropy", "Value Function Loss", "", "Mean KL Divergence", "SB3 Clip Fraction", "Avg Return",
                         "Avg Advantage", "Avg Val Target", "", "Collected Steps/Second", "Overall Steps/Second", "", "Collection Time", "Consumption Time",
@@ -435,10 +481,10 @@ void Learner::Learn() {
             std::string dashed = "-" + kv.first;
             if (std::find(rows.begin(), rows.end(), kv.first) == rows.end() && std::find(rows.begin(), rows.end(), dashed) == rows.end()) RG_LOG("  [metric] " << report.SingleToString(kv.first));
         }
-        m.tsSinceSave += (uint64_t)m.B;
-        if (!config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
+        m.tsSinceSave += (uint64_t)m.B * (uint64_t)m.world;
+        if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
     }
-    if (!config.checkpointSaveFolder.empty()) Save();
+    if (m.rank == 0 && !config.checkpointSaveFolder.empty()) Save();   // rank 0 owns the checkpoints
 }
 
 // ---- checkpoints ------------------------------------------------------------------------------------------------------

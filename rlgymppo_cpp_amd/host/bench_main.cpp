@@ -1,0 +1,114 @@
+// bench_main.cpp -- the measured process of bench.py: the reference's program shape (examplemain.cpp: EnvCreateFn + LearnerConfig +
+// Learner) on include/RLGymPPO_CPP over librlgymppo_amd.so / librlgpu.so.  No Python, no torch: the HIP runtime, the C-ABI library
+// and (multi-GPU) RCCL are all that touch the device.  Prints ONE JSON object on stdout (rank 0).
+//   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32] [--trained-warmup I --trained-steps J]
+// One "step" = one full PPO iteration: T gym steps of every env with on-device policy inference, value pass + GAE, shuffled
+// minibatches (4 per batch), clip + Adam.  With --trained-warmup the same measurement is repeated after I more iterations, when
+// the policy has started to play and contacts are more frequent ("trained_regime").
+#include <RLGymPPO_CPP/Learner.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CombinedReward.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/ZeroSumReward.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
+#include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
+#include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
+#include <hip/hip_runtime_api.h>
+#include "../../include/rlgpu.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+using namespace RLGPC;
+using namespace RLGSC;
+
+static int g_team = 1; static bool g_padded = false;
+
+static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
+    constexpr int TICK_SKIP = 8; constexpr float NO_TOUCH_TIMEOUT_SECS = 10.f;
+    auto rewards = new CombinedReward({ { new FaceBallReward(), 0.1f }, { new VelocityPlayerToBallReward(), 0.5f }, { new VelocityBallToGoalReward(), 1.0f },
+        { new EventReward({ .teamGoal = 1.f, .concede = -1.f }), 50.f } });
+    RewardFunction* root = rewards;
+    if (g_padded) root = new ZeroSumReward(rewards, 0.3f, 1.0f);
+    std::vector<TerminalCondition*> terminalConditions = { new NoTouchCondition(NO_TOUCH_TIMEOUT_SECS * 120 / TICK_SKIP), new GoalScoreCondition() };
+    OBSBuilder* obs = g_padded ? (OBSBuilder*)new DefaultOBSPadded(g_team) : (OBSBuilder*)new DefaultOBS();
+    auto match = new Match(root, terminalConditions, obs, new DiscreteAction(), new RandomState(true, true, true), g_team, true);
+    Gym* gym = new Gym(match, TICK_SKIP);
+    return { match, gym };
+}
+
+struct Timed { double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; };
+
+int main(int argc, char* argv[]) {
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0; bool fp32 = false;
+    for (int i = 1; i < argc; i++) {
+        auto is = [&](const char* k) { return !strcmp(argv[i], k); };
+        if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
+        else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
+        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true;
+        else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
+        else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
+    }
+    setenv("RLGPU_QUIET", "1", 1);
+    RocketSim::Init("./collision_meshes", true);
+    const int64_t nAgents = (int64_t)envs * 2 * g_team, B = nAgents * horizon;
+    LearnerConfig cfg = {};
+    cfg.numThreads = 1; cfg.numGamesPerThread = envs;
+    cfg.timestepsPerIteration = B; cfg.expBufferSize = B;
+    cfg.ppo.batchSize = B; cfg.ppo.miniBatchSize = B / 4; cfg.ppo.epochs = epochs;
+    cfg.ppo.policyLR = 2e-4f; cfg.ppo.criticLR = 2e-4f; cfg.ppo.entCoef = 0.01f; cfg.ppo.autocastLearn = !fp32;
+    cfg.ppo.policyLayerSizes = { 256, 256, 256 }; cfg.ppo.criticLayerSizes = { 256, 256, 256 };
+    cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
+    cfg.timestepLimit = 0;
+    Learner learner(EnvCreateFunc, cfg);
+    const int rank = learner.Rank(), world = learner.WorldSize();
+
+    auto barrier = [&]() { (void)hipDeviceSynchronize(); (void)learner.MaxOverRanks(0.0); (void)hipDeviceSynchronize(); };   // device sync + a collective = a barrier
+    auto iteration = [&](double* consumeMs) {
+        Report rep;
+        learner.CollectTimesteps();
+        auto t0 = std::chrono::steady_clock::now();
+        learner.AddNewExperience(rep);
+        learner.LearnPPO(rep);   // ends with a stream sync (it reads its metrics)
+        if (consumeMs) *consumeMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    auto measure = [&](int w, int k) {
+        for (int i = 0; i < w; i++) iteration(nullptr);
+        barrier();
+        Timed t{}; float a; int b; float c; double d; int e;
+        learner.DeviceTimings(a, b, c, d, e, true);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < k; i++) iteration(&t.consumeMs);
+        barrier();
+        t.sec = learner.MaxOverRanks(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // the slowest rank's clock
+        learner.DeviceTimings(t.envMs, t.envLaunches, t.gemmMs, t.gemmFlops, t.gemmCalls, false);
+        t.consumeMs /= std::max(1, k);
+        return t;
+    };
+    Timed m = measure(warmup, steps);
+    Timed tr{}; bool haveTr = false;
+    if (trainedWarm > 0 && trainedSteps > 0) { tr = measure(trainedWarm, trainedSteps); haveTr = true; }
+    fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations\n", rank, world, m.sec, steps);
+    if (rank == 0) {
+        const int nP = 2 * g_team, D = learner.obsSize;
+        // SURVEY 8d, verbatim: algorithmic bytes per gym step per env = 2 (336 N_p + 264) + N_p (4 D + 8) + 4
+        const double A = 2.0 * (336.0 * nP + 264.0) + nP * (4.0 * D + 8.0) + 4.0;
+        const bool fused = learner.UsesFusedCollection();
+        const double stepsPerLaunch = fused ? horizon : 1;
+        printf("{\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"envs_per_gpu\": %d, \"team_size\": %d, \"horizon\": %d, \"batch\": %lld, \"minibatch\": %lld, \"epochs\": %d, \"obs_size\": %d, "
+               "\"elapsed_s\": %.6f, \"agent_steps\": %.0f, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"fused_collect\": %s, "
+               "\"env_kernel_ms_total\": %.4f, \"env_launches\": %d, \"algorithmic_bytes_per_gym_step_per_env\": %.0f, \"gym_steps_per_launch\": %.0f, "
+               "\"gemm_ms_total\": %.4f, \"gemm_flops_total\": %.6e, \"gemm_calls\": %d",
+               world, steps, warmup, envs, g_team, horizon, (long long)B, (long long)(B / 4), epochs, D,
+               m.sec, (double)B * world * steps, (double)B * world * steps / m.sec, m.sec / steps * 1e3, m.consumeMs, fused ? "true" : "false",
+               m.envMs, m.envLaunches, A, stepsPerLaunch, m.gemmMs, m.gemmFlops, m.gemmCalls);
+        if (haveTr)
+            printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
+                   warmup + steps + trainedWarm, trainedSteps, (double)B * world * trainedSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);
+        printf("}\n");
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -176,14 +176,19 @@ class ExperienceFifo:
 
 
 class Learner:
-    def __init__(self, cfg: LearnerConfig, gym_cfg=None, mesh="procedural", rank=0, world_size=1):
+    def __init__(self, cfg: LearnerConfig, gym_cfg=None, mesh="procedural", rank=0, world_size=1, comm=None):
         self.cfg = cfg
+        # the exchange object (parallel.py): RCCL through the C-ABI on a multi-GPU launch, a no-op alone
+        self.comm = comm if comm is not None else parallel.SoloComm()
+        if comm is not None:
+            rank, world_size = comm.rank, comm.world
         self.rank, self.world = rank, world_size
         n_envs = cfg.numEnvs or cfg.numThreads * cfg.numGamesPerThread
         self.gym_cfg = gym_cfg if gym_cfg is not None else _lib.default_gym_config()
         # every rank owns its own env shard and RNG streams: seed = randomSeed + 1000 * rank
         self.gym_cfg.seed_lo = parallel.shard_seed(cfg.randomSeed, rank)
         self.env = BatchedEnv(n_envs, cfg.teamSize, self.gym_cfg, cfg.device, mesh)
+        self.env_stream_epoch = 0
         self.dev = torch.device("cuda", cfg.device)
         self.n_agents = self.env.n_agents
         self.obs_size, self.n_actions = self.env.obs_size, self.env.n_actions
@@ -199,6 +204,8 @@ class Learner:
         # identical parameters on every rank: the init seed does not depend on the rank
         self.ppo = PPOCore(self.obs_size, self.n_actions, p.policyLayerSizes, p.criticLayerSizes, p.policyLR, p.criticLR, p.entCoef, p.clipRange,
                            p.policyTemperature, p.autocastLearn, cfg.randomSeed, max_rows, cfg.device)
+        # ... but every rank explores with its own noise: the sampler is keyed on the rank (identical observations on two ranks draw different actions)
+        self.ppo.set_sampler(rank, 0)
         T, N, D = self.T, self.n_agents, self.obs_size
         f = dict(dtype=torch.float32, device=self.dev)
         self.obs_buf = torch.empty((T + 1, N, D), **f)     # states; row T = the state after the last step
@@ -288,8 +295,10 @@ class Learner:
         self.adv, self.tgt, self.ret = adv, tgt, ret
         if self.cfg.standardizeReturns:
             # the first <=150 returns of the concatenated (agent-major) batch: trajectory 0's first steps (Learner.cpp:679-682)
-            k = min(self.cfg.maxReturnsPerStatsInc, T)
-            first = parallel.share_from_rank0(ret[:k, 0], self.world)   # rank 0's returns feed the shared statistic
+            # (agent-major order: trajectory 0's T returns, then trajectory 1's, ... until maxReturnsPerStatsInc are taken)
+            k = min(self.cfg.maxReturnsPerStatsInc, T * N)
+            cols = -(-k // T)
+            first = self.comm.share_from_rank0(ret[:, :cols].t().reshape(-1)[:k])   # rank 0's returns feed the shared statistic
             # no host round trip here (each one idles the GPU for ~0.1-0.2 ms): an asynchronous copy into pinned memory, consumed by
             # _flush_returns() right before the statistic is read again -- the same value enters at the same point of the sequence
             self._ret_host[:k].copy_(first, non_blocking=True)
@@ -374,7 +383,7 @@ class Learner:
                 for m in range(0, self.batch_size, self.mini):
                     self.ppo.minibatch(obs, acts, logp, adv, tgt, idx[base + m: base + m + self.mini], self.mini, self.mini / self.batch_size, self.metrics)
                     n_mb += 1
-                scale = parallel.allreduce_gradients(self.ppo.grad_tensor(), self.world)   # ONE RCCL all-reduce per optimizer step
+                scale = self.comm.allreduce_gradients(self.ppo)   # ONE RCCL all-reduce per optimizer step, on the learner's stream
                 self.ppo.clip_adam_step(0.5, scale)
                 if self.s_learn is not None:
                     self.ppo.refresh_shadows()                  # the collector's inference reads the bf16 copies: keep them live
@@ -435,7 +444,10 @@ class Learner:
         os.makedirs(folder, exist_ok=True)
         self._flush_returns()
         stats = {"cumulative_timesteps": self.total_timesteps, "cumulative_model_updates": self.cumulative_model_updates,
-                 "epoch": self.total_epochs, "reward_running_stats": self.return_stats.to_json()}
+                 "epoch": self.total_epochs, "reward_running_stats": self.return_stats.to_json(),
+                 # not in the reference's file (its loader ignores unknown keys): where the action-noise and env-reset streams stand, so a
+                 # resumed run continues them instead of replaying the first iterations'
+                 "sampler_calls": self.ppo.get_sampler()[1], "env_stream_epoch": self.env_stream_epoch}
         if self.metric_sender is not None:
             stats["run_id"] = self.metric_sender.run_id                                     # Learner.cpp:204-205
         with open(os.path.join(folder, "RUNNING_STATS.json"), "w") as f:
@@ -468,6 +480,10 @@ class Learner:
         self.total_timesteps = int(stats["cumulative_timesteps"]); self.cumulative_model_updates = int(stats["cumulative_model_updates"])
         self.total_epochs = int(stats["epoch"]); self.return_stats.from_json(stats["reward_running_stats"])
         self.run_id = stats.get("run_id", "")                                               # Learner.cpp:238-239
+        self.ppo.set_sampler(self.rank, int(stats.get("sampler_calls", self.total_timesteps // max(1, self.n_agents))))
+        # the env batch restarts from fresh resets: key them on a new epoch of the RandomState / respawn streams
+        self.env_stream_epoch = int(stats.get("env_stream_epoch", 0)) + 1
+        self.env.reseed(parallel.shard_seed(self.cfg.randomSeed, self.rank), self.env_stream_epoch)
         pol = _read_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.layer_shapes(0))     # size check of every param (PPOLearner.cpp:380-408)
         self.ppo.set_params(pol, 0)
         if os.path.exists(os.path.join(folder, "PPO_CRITIC.lt")):                            # the critic file is optional (PPOLearner.cpp:421-422)

@@ -54,6 +54,15 @@ class PPOCore:
     def set_stream(self, stream):
         _chk(self.lib.rlgpu_learner_set_stream(self.h, C.c_void_p(stream.cuda_stream if stream is not None else 0)), self.h, self._err)
 
+    def set_sampler(self, stream: int, call_ctr: int = 0):
+        """Action-sampler key (rlgpu_learner_set_sampler): `stream` separates ranks that share the init seed, `call_ctr` resumes the noise sequence."""
+        _chk(self.lib.rlgpu_learner_set_sampler(self.h, C.c_uint32(stream & 0xffffffff), C.c_uint32(call_ctr & 0xffffffff)), self.h, self._err)
+
+    def get_sampler(self):
+        s, c = C.c_uint32(), C.c_uint32()
+        _chk(self.lib.rlgpu_learner_get_sampler(self.h, C.byref(s), C.byref(c)), self.h, self._err)
+        return int(s.value), int(c.value)
+
     def refresh_shadows(self):
         _chk(self.lib.rlgpu_learner_refresh_shadows(self.h), self.h, self._err)
 
