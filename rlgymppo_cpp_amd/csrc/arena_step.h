@@ -600,13 +600,18 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     ball_car_touch = false;
-    int n_man = 0, n = 0;          // manifolds that carry points, contacts (in slot order so far)
-    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; n_man += (L.c[k].sid != 0 || k == 0); }
+    // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
+    // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
+    int n = 0, ball_man = 0, max_man = 0;
+    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; ball_man += (L.c[k].sid != 0 || k == 0); }
+    int car_man[NC];
     // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
     for (int ci = 0; ci < NC; ci++) {
         const int base = body_region(1 + ci);
-        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); W.cidx[n++] = (int8_t)car_ball_slot(ci); n_man++; }
-        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); n_man += (L.c[base + k].sid != 0 || k == 0); }
+        int cm = 0;
+        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); W.cidx[n++] = (int8_t)car_ball_slot(ci); cm++; ball_man++; }
+        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); cm += (L.c[base + k].sid != 0 || k == 0); }
+        car_man[ci] = cm;
     }
     // car-car pairs: body0 of the manifold = the higher car (arena_contact.h); the gate is conservative, the exact box test follows
     int8_t tp[LY::PAIR_POOL], tq[LY::PAIR_POOL], tfirst[LY::PAIR_POOL], tcnt[LY::PAIR_POOL];
@@ -632,12 +637,14 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
                 // Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car, car2): equal user indices, no swap (Arena.cpp:231-240)
                 on_car_car_contact(A, ib, ia, tmul(cb.b.rot, c.ra), tmul(ca.b.rot, c.rb), ev);
             }
-            if (cnt > 0 && n_touching < LY::PAIR_POOL) { tp[n_touching] = (int8_t)(1 + ia); tq[n_touching] = (int8_t)(1 + ib); tfirst[n_touching] = (int8_t)first; tcnt[n_touching] = (int8_t)cnt; n_touching++; n_man++; }
+            if (cnt > 0 && n_touching < LY::PAIR_POOL) { tp[n_touching] = (int8_t)(1 + ia); tq[n_touching] = (int8_t)(1 + ib); tfirst[n_touching] = (int8_t)first; tcnt[n_touching] = (int8_t)cnt; n_touching++; car_man[ia]++; car_man[ib]++; }
         }
     }
     L.n = n;
-    // one manifold (or none): its points in slot order IS the solver order; otherwise the reference's pair / island order decides
-    if (n_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
+    max_man = ball_man;
+    for (int ci = 0; ci < NC; ci++) max_man = car_man[ci] > max_man ? car_man[ci] : max_man;
+    // some body is held by two manifolds: the reference's pair / island order decides which of them the solver visits first
+    if (max_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
 }
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue

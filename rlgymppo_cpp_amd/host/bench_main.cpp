@@ -69,6 +69,7 @@ int main(int argc, char* argv[]) {
     auto iteration = [&](double* consumeMs) {
         Report rep;
         learner.CollectTimesteps();
+        if (consumeMs) (void)hipDeviceSynchronize();   // the collection launch is asynchronous: the consumption clock starts when it has finished
         auto t0 = std::chrono::steady_clock::now();
         learner.AddNewExperience(rep);
         learner.LearnPPO(rep);   // ends with a stream sync (it reads its metrics)

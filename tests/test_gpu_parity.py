@@ -623,3 +623,126 @@ def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs):
         else:
             assert np.array_equal(a, b), name
     assert out[0][4].sum() > 0 and len(np.unique(out[0][1])) > 20      # episodes ended (auto-resets inside the launch) and actions vary
+
+
+# ---- the BASELINE configs beyond the headline, at their full sizes ------------------------------------------
+def test_config3_full_size_2v2_padded_zero_sum():
+    """BASELINE config[3]: 8192 envs 2v2, DefaultOBSPadded + ZeroSumReward, through the Learner's own loop (fused collection) --
+    size-independent properties: zero-sum rewards add up to zero per env, rows finite and bounded, the padded rows keep the
+    DefaultOBS prefix layout, done is shared by the four players of an env, the optimizer steps happen."""
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    from rlgymppo_cpp_amd import _lib
+    n_envs, T, team = 8192, 8, 2
+    g = _lib.default_gym_config(); g.obs_max_players = team; g.zero_sum = 1; g.team_spirit = 0.3; g.opp_scale = 1.0
+    B = n_envs * 2 * team * T
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=team, timestepsPerIteration=B, expBufferSize=B, randomSeed=3,
+                        ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=1, autocastLearn=True))
+    L = Learner(cfg, gym_cfg=g)
+    assert L.obs_size == 51 + 38 * team and L.n_agents == n_envs * 4
+    p0 = L.ppo.get_params(2).copy()
+    for _ in range(3):
+        L.iteration()
+    torch.cuda.synchronize()
+    rew = L.rew_buf.view(T, n_envs, 4); done = L.done_buf.view(T, n_envs, 4); obs = L.obs_buf
+    assert torch.isfinite(rew).all() and torch.isfinite(obs).all()
+    # ZeroSumReward with opponent scale 1: r_i (1 - s) + s mean(team) - mean(opponents) sums to zero over the four players
+    assert rew.sum(dim=2).abs().max().item() < 1e-3 * max(1.0, rew.abs().max().item())
+    assert (done == done[:, :, :1]).all()
+    assert obs[..., :9].abs().max().item() < 3.5 and obs[..., 17:51].min().item() >= 0 and obs[..., 17:51].max().item() <= 1   # ball (scaled), pads are 0 / 1
+    p1 = L.ppo.get_params(2)
+    assert np.isfinite(p1).all() and np.abs(p1 - p0).max() > 0 and L.cumulative_model_updates == 3
+    assert L.total_timesteps == 3 * B
+
+
+def test_config4_shape_3v3_16384_envs_with_collection_during_learn():
+    """BASELINE config[4]'s shape: 16 384 envs 3v3 (98 304 agent rows per step) with collectionDuringLearn -- the PPO epochs on their own
+    stream under the next collection.  (The reference's autocast dtype is bf16, FrameworkTorch.h:14; so is this build's.)"""
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    n_envs, T, team = 16384, 4, 3
+    B = n_envs * 2 * team * T
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=team, timestepsPerIteration=B, expBufferSize=B, randomSeed=4, collectionDuringLearn=True,
+                        ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=1, autocastLearn=True))
+    L = Learner(cfg)
+    assert L.s_learn is not None and L.obs_size == 165 and L.n_agents == 98304
+    p0 = L.ppo.get_params(2).copy()
+    for it in range(3):
+        L.iteration()
+        assert L.cumulative_model_updates == it + 1
+    rep = L.finish_report()
+    torch.cuda.synchronize()
+    p1 = L.ppo.get_params(2)
+    assert np.isfinite(p1).all() and np.abs(p1 - p0).max() > 0
+    assert torch.isfinite(L.rew_buf).all() and torch.isfinite(L.obs_buf).all()
+    assert (L.done_buf.view(T, n_envs, 6) == L.done_buf.view(T, n_envs, 6)[:, :, :1]).all()
+    assert 0 < rep["Policy Entropy"] < np.log(90) + 1e-3
+
+
+# ---- multi-GPU pieces that one GPU can exercise (VERDICT r01 items 3b / 6, ADVICE r01) ----------------------------------------------
+def test_fake_ranks_on_one_gpu_equal_single_learner_on_the_union():
+    """N = 4 device learners stand in for 4 ranks: identical parameters (same init seed), each takes ITS shard of a batch as a full local
+    batch, the flat gradients are summed (what rlgpu_allreduce_grads does between GPUs), every "rank" applies rlgpu_clip_adam_step with
+    grad_scale = 1 / N -- and ends up with the parameters of ONE learner that took the union as four minibatches.
+    HIP kernels throughout; only the transport is replaced by a tensor sum."""
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    dev = torch.device("cuda", 0)
+    N, rows, D, A = 4, 512, 89, 90
+    g = torch.Generator(device="cpu").manual_seed(0)
+    obs = torch.randn(N * rows, D, generator=g).to(dev); acts = torch.randint(0, A, (N * rows,), generator=g, dtype=torch.int32).to(dev)
+    adv = torch.randn(N * rows, generator=g).to(dev); tgt = torch.randn(N * rows, generator=g).to(dev)
+    mk = lambda: PPOCore(D, A, (256, 256, 256), (256, 256, 256), use_bf16=False, max_rows=rows, seed=77)
+    single = mk()
+    logp = torch.empty(N * rows, device=dev)
+    for r in range(N):   # old log-probs from the shared initial policy
+        a_tmp = torch.empty(rows, dtype=torch.int32, device=dev)
+        single.act(obs[r * rows:(r + 1) * rows], a_tmp, logp[r * rows:(r + 1) * rows])
+    logp = logp + 0.05 * torch.randn(N * rows, generator=g).to(dev)
+    ranks = [mk() for _ in range(N)]
+    assert all(np.array_equal(single.get_params(2), c.get_params(2)) for c in ranks)
+    met = torch.zeros(8, device=dev)
+    single.zero_grads()
+    for r in range(N):
+        sl = slice(r * rows, (r + 1) * rows)
+        single.minibatch(obs[sl], acts[sl], logp[sl], adv[sl], tgt[sl], None, rows, 1.0 / N, met)
+        ranks[r].zero_grads(); ranks[r].minibatch(obs[sl], acts[sl], logp[sl], adv[sl], tgt[sl], None, rows, 1.0, met)
+    single.clip_adam_step(0.5, 1.0)
+    total = torch.stack([c.grad_tensor() for c in ranks]).sum(0)
+    for c in ranks:
+        c.grad_tensor().copy_(total); c.clip_adam_step(0.5, 1.0 / N)
+    torch.cuda.synchronize()
+    want = single.get_params(2)
+    for c in ranks:
+        assert np.abs(c.get_params(2) - want).max() < 2e-6
+
+
+def test_rccl_communicator_through_the_cabi_and_rank_keyed_sampler():
+    """rlgpu_comm_* with world size 1 (what one GPU can run): unique id, init, all-reduce of the learner's gradient buffer on its stream
+    (identity), broadcast, destroy.  And the action sampler's key: two learners with the same init seed but different sampler
+    streams (= ranks) draw different actions from identical observations, the same stream reproduces them."""
+    import ctypes as C
+    from rlgymppo_cpp_amd import _lib
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    lib = _lib.load(); dev = torch.device("cuda", 0)
+    uid = (C.c_ubyte * 128)()
+    assert lib.rlgpu_comm_unique_id(uid) == 0
+    h = C.c_void_p()
+    assert lib.rlgpu_comm_init(C.byref(h), 0, 0, 1, uid) == 0, lib.rlgpu_comm_last_error(None)
+    assert lib.rlgpu_comm_rank(h) == 0 and lib.rlgpu_comm_world(h) == 1
+    core = PPOCore(89, 90, (256, 256, 256), (256, 256, 256), use_bf16=True, max_rows=256, seed=5)
+    gt = core.grad_tensor(); gt.copy_(torch.arange(gt.numel(), device=dev, dtype=torch.float32) % 97)
+    before = gt.clone()
+    assert lib.rlgpu_allreduce_grads(core.h, h) == 0
+    t = torch.arange(16, dtype=torch.float32, device=dev)
+    assert lib.rlgpu_comm_broadcast(h, C.c_void_p(t.data_ptr()), 64, 0, None) == 0
+    core.sync(); torch.cuda.synchronize()
+    assert torch.equal(gt, before) and torch.equal(t, torch.arange(16, dtype=torch.float32, device=dev))
+    assert lib.rlgpu_comm_destroy(h) == 0
+    obs = torch.randn(256, 89, device=dev)
+    draws = []
+    for stream in (0, 1, 0):
+        c = PPOCore(89, 90, (256, 256, 256), (256, 256, 256), use_bf16=True, max_rows=256, seed=5)
+        c.set_sampler(stream, 0)
+        a = torch.empty(256, dtype=torch.int32, device=dev); lp = torch.empty(256, device=dev)
+        c.act(obs, a, lp); c.sync()
+        draws.append(a.cpu().numpy().copy())
+        assert c.get_sampler() == (stream, 1)
+    assert np.array_equal(draws[0], draws[2]) and (draws[0] != draws[1]).mean() > 0.5

@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: two processes, gloo, 127.0.0.1 (envs sharded, ONE gradient all-reduce per optimizer step).
 
 The HIP kernels cannot run here, so the ranks' "learner" is the numpy oracle (oracle/learner_ref.py); what is under test
-is the host logic every rank runs around the kernels: rlgymppo_cpp_amd/parallel.py (shard seeds, gradient all-reduce +
+is the host logic every rank runs around the kernels: rlgymppo_cpp_amd/parallel.py (the Comm interface the Learner calls: shard seeds, gradient all-reduce +
 pre-clip scale, shared return statistic, max-over-ranks timing) and the claim DESIGN.md makes about it: sum-all-reduce,
 scale by 1/world, THEN clip-by-norm + Adam gives on every rank exactly what one learner gets on the union of the shards.
 """
@@ -58,30 +58,39 @@ def _step(P, flat_grad, scale):
     return np.concatenate(outs)
 
 
+class _OracleCore:
+    """Stands where the Learner has its PPOCore: the same two members the Learner's exchange call site touches
+    (learner.py: `scale = self.comm.allreduce_gradients(self.ppo)`): a flat [policy | critic] gradient tensor behind grad_tensor()."""
+    def __init__(self, flat_grad):
+        self.g = torch.from_numpy(flat_grad)
+
+    def grad_tensor(self):
+        return self.g
+
+
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     from rlgymppo_cpp_amd import parallel
     from rlgymppo_cpp_amd.learner import WelfordRunningStat
-    r, lr, w = parallel.init_process_group("gloo")
-    assert (r, w) == (rank, world)
+    comm = parallel.GlooComm("gloo")          # the CPU stand-in of RcclComm: same interface, same call sites
+    assert (comm.rank, comm.world) == (rank, world)
     P = _problem()
     half = P["n"] // world
     rows = np.arange(rank * half, (rank + 1) * half)
-    # every rank: gradient of ITS shard as one full local batch (ratio = 1), then the one collective
-    g = torch.from_numpy(_grads(P, rows, 1.0))
-    scale = parallel.allreduce_gradients(g, world)
-    new_params = _step(P, g.numpy(), scale)
-    # shared return statistic: rank-specific returns in, rank 0's out
+    # every rank: gradient of ITS shard as one full local batch (ratio = 1), then the one collective -- through the Learner's call
+    core = _OracleCore(_grads(P, rows, 1.0))
+    scale = comm.allreduce_gradients(core)
+    new_params = _step(P, core.grad_tensor().numpy(), scale)
+    # shared return statistic: rank-specific returns in, rank 0's out (learner.py add_new_experience)
     ret = torch.arange(10, dtype=torch.float32) + 100.0 * rank
-    shared = parallel.share_from_rank0(ret, world)
+    shared = comm.share_from_rank0(ret)
     ws = WelfordRunningStat(); ws.increment(shared.numpy().tolist(), 10)
-    tmax = parallel.max_over_ranks(1.0 + rank, world)
-    tsum = parallel.sum_over_ranks(1.0 + rank, world)
-    parallel.barrier(world)
+    tmax = comm.max_over_ranks(1.0 + rank)
+    tsum = comm.sum_over_ranks(1.0 + rank)
+    comm.barrier()
     q.put((rank, new_params, scale, shared.numpy(), ws.get_std(), tmax, tsum, parallel.shard_seed(123, rank)))
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    comm.close()
 
 
 @pytest.mark.timeout(300)
