@@ -47,6 +47,10 @@ public:
     void RenderStep(int t);                          // ThreadAgent.cpp:164-186 for the first game
     int NumEnvs() const;
     int NumAgents() const;
+    int StepsPerIteration() const;                   // T: steps every env takes per CollectTimesteps()
+    // the experience of the last CollectTimesteps() copied to the host (tests, tools): obs [(T + 1) x agents x obsSize] -- row t + 1 is what
+    // the policy sees after step t -- and actions / rewards / dones [T x agents]; agent row = env * players + slot.  Null = skip.
+    void CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones);
     // multi-GPU (one process per GPU, launcher environment RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT; include/rlgpu.h rlgpu_comm_*):
     // envs are sharded over the ranks, ONE gradient all-reduce per optimizer step, rank 0 writes the checkpoints
     int Rank() const;

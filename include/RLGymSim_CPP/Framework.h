@@ -2,7 +2,12 @@
 // RocketSim/src/Math/MathTypes.h) for programs written against RLGymSim_CPP.  The simulation itself runs on the GPU behind
 // include/rlgpu.h; these types are what user code (callbacks, env-creation functions) sees.
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <typeinfo>
 #include <cstdint>
 #include <cstddef>
 #include <filesystem>
@@ -48,23 +53,134 @@ struct RotMat {  // columns forward / right / up (MathTypes.h:162)
 enum class Team : uint8_t { BLUE = 0, ORANGE = 1 };
 enum class GameMode : uint8_t { SOCCAR = 0 };
 struct CarControls { float throttle = 0, steer = 0, pitch = 0, yaw = 0, roll = 0; bool jump = false, boost = false, handbrake = false; };
-// Car.h:17-123 -- the fields the gym layer and typical callbacks read
-struct CarState {
-    Vec pos, vel, angVel; RotMat rotMat;
-    bool isOnGround = true, hasJumped = false, hasDoubleJumped = false, hasFlipped = false, isJumping = false, isFlipping = false;
-    bool isSupersonic = false, isDemoed = false;
-    float boost = 33.f, airTimeSinceJump = 0, jumpTime = 0, flipTime = 0, demoRespawnTimer = 0;
-    CarControls lastControls;
+
+// RLConst.h -- the constants user code reads (values of the game; the simulation's own copies live in csrc/)
+namespace RLConst {
+constexpr float GRAVITY_Z = -650.f, CAR_MASS_BT = 180.f, BALL_MASS_BT = CAR_MASS_BT / 6.f, BALL_REST_Z = 93.15f, BALL_DRAG = 0.03f;
+constexpr float CAR_MAX_SPEED = 2300.f, BALL_MAX_SPEED = 6000.f, BOOST_MAX = 100.f, BOOST_USED_PER_SECOND = BOOST_MAX / 3, BOOST_SPAWN_AMOUNT = BOOST_MAX / 3;
+constexpr float DOUBLEJUMP_MAX_DELAY = 1.25f, BALL_COLLISION_RADIUS_SOCCAR = 91.25f, SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y = 5124.25f;
+constexpr float CAR_SPAWN_REST_Z = 17.f, CAR_RESPAWN_Z = 36.f, BUMP_COOLDOWN_TIME = 0.25f, DEMO_RESPAWN_TIME = 3.f;
+struct CarSpawnPos { float x, y, yawAng; };
+constexpr int CAR_SPAWN_LOCATION_AMOUNT = 5, CAR_RESPAWN_LOCATION_AMOUNT = 4;
+constexpr float QUARTER_PI = 0.78539816339744830962f;
+constexpr CarSpawnPos CAR_SPAWN_LOCATIONS_SOCCAR[CAR_SPAWN_LOCATION_AMOUNT] = {   // two diagonal, two off-centre, one goalie spot (blue side)
+    {-2048, -2560, QUARTER_PI * 1}, {2048, -2560, QUARTER_PI * 3}, {-256, -3840, QUARTER_PI * 2}, {256, -3840, QUARTER_PI * 2}, {0, -4608, QUARTER_PI * 2}};
+constexpr CarSpawnPos CAR_RESPAWN_LOCATIONS_SOCCAR[CAR_RESPAWN_LOCATION_AMOUNT] = {
+    {-2304, -4608, QUARTER_PI * 2}, {-2688, -4608, QUARTER_PI * 2}, {2304, -4608, QUARTER_PI * 2}, {2688, -4608, QUARTER_PI * 2}};
+namespace BoostPads { constexpr int LOCS_AMOUNT_BIG = 6, LOCS_AMOUNT_SMALL_SOCCAR = 28; constexpr float COOLDOWN_BIG = 10, COOLDOWN_SMALL = 4, BOOST_AMOUNT_BIG = 100, BOOST_AMOUNT_SMALL = 12; }
+}  // namespace RLConst
+
+// Math.h: the thread's random engine behind the host state setters (Math.cpp:44-64).  SeedRandEngine is an addition: the reference seeds
+// from the clock only.
+namespace Math {
+inline std::default_random_engine& GetRandEngine() {
+    static thread_local std::default_random_engine engine((std::default_random_engine::result_type)(
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() + std::hash<std::thread::id>()(std::this_thread::get_id())));
+    return engine;
+}
+inline void SeedRandEngine(uint64_t seed) { GetRandEngine().seed((std::default_random_engine::result_type)seed); }
+inline int RandInt(int min, int max, int seed = -1) {
+    if (seed != -1) { std::default_random_engine tmp((std::default_random_engine::result_type)seed); return min + (int)(tmp() % (unsigned)(max - min)); }
+    return min + (int)(GetRandEngine()() % (unsigned)(max - min));
+}
+inline float RandFloat(float min = 0, float max = 1) {
+    std::default_random_engine& e = GetRandEngine();
+    return min + ((e() / (float)e.max()) * (max - min));
+}
+}  // namespace Math
+
+// yaw / pitch / roll (MathTypes.h:281-320); ToRotMat = btMatrix3x3::setEulerYPR(yaw, -pitch, -roll) transposed into forward/right/up columns
+struct Angle {
+    float yaw, pitch, roll;
+    Angle(float yaw = 0, float pitch = 0, float roll = 0) : yaw(yaw), pitch(pitch), roll(roll) {}
+    RotMat ToRotMat() const {
+        const float ez = yaw, ey = -pitch, ex = -roll;
+        const float ci = std::cos(ex), cj = std::cos(ey), ch = std::cos(ez), si = std::sin(ex), sj = std::sin(ey), sh = std::sin(ez);
+        const float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+        RotMat m;   // rows of the bullet matrix are (fwd.x right.x up.x), ...
+        m.forward = Vec(cj * ch, cj * sh, -sj); m.right = Vec(sj * sc - cs, sj * ss + cc, cj * si); m.up = Vec(sj * cc + ss, sj * cs - sc, cj * ci);
+        return m;
+    }
+    Vec GetForwardVec() const { return ToRotMat().forward; }
 };
-struct BallState { Vec pos{0, 0, 93.15f}, vel, angVel; };
+
+struct BallHitInfo {   // BallHitInfo.h:10-25
+    bool isValid = false;
+    Vec relativePosOnBall, ballPos, extraHitVel;
+    uint64_t tickCountWhenHit = ~0ULL, tickCountWhenExtraImpulseApplied = ~0ULL;
+};
+struct PhysState { Vec pos, vel, angVel; RotMat rotMat; };
+// Car.h:17-123, every field
+struct CarState : PhysState {
+    uint64_t updateCounter = 0;
+    bool isOnGround = true; bool wheelsWithContact[4] = {};
+    bool hasJumped = false, hasDoubleJumped = false, hasFlipped = false;
+    Vec flipRelTorque;
+    float jumpTime = 0, flipTime = 0;
+    bool isFlipping = false, isJumping = false;
+    float airTime = 0, airTimeSinceJump = 0;
+    float boost = RLConst::BOOST_SPAWN_AMOUNT, timeSpentBoosting = 0;
+    bool isSupersonic = false; float supersonicTime = 0, handbrakeVal = 0;
+    bool isAutoFlipping = false; float autoFlipTimer = 0, autoFlipTorqueScale = 0;
+    struct { bool hasContact = false; Vec contactNormal; } worldContact;
+    struct { uint32_t otherCarID = 0; float cooldownTimer = 0; } carContact;
+    bool isDemoed = false; float demoRespawnTimer = 0;
+    BallHitInfo ballHitInfo;
+    CarControls lastControls;
+    CarState() { pos.z = RLConst::CAR_SPAWN_REST_Z; }
+    bool HasFlipOrJump() const { return isOnGround || (!hasFlipped && !hasDoubleJumped && airTimeSinceJump < RLConst::DOUBLEJUMP_MAX_DELAY); }   // Car.cpp:285-297
+    bool HasFlipReset() const { return !isOnGround && HasFlipOrJump() && !hasJumped; }
+    bool GotFlipReset() const { return !isOnGround && !hasJumped; }
+};
+struct BallState : PhysState {   // Ball.h:17-44
+    uint64_t updateCounter = 0;
+    BallState() { pos.z = RLConst::BALL_REST_Z; }
+};
+struct BoostPadConfig { Vec pos; bool isBig = false; };
+struct BoostPadState { bool isActive = true; float cooldown = 0; class Car* curLockedCar = nullptr; uint32_t prevLockedCarID = 0; };
+// CarConfig.h: the device stepper has the Octane compiled in (csrc/arena_car.h); the struct exists so that Gym's and AddCar's signatures do
+struct WheelPairConfig { float wheelRadius = 0, suspensionRestLength = 0; Vec connectionPointOffset; };
+struct CarConfig {
+    Vec hitboxSize, hitboxPosOffset; WheelPairConfig frontWheels, backWheels; float dodgeDeadzone = 0.5f;
+    int preset = 0;   // 0 = Octane
+    bool operator==(const CarConfig& o) const { return preset == o.preset && dodgeDeadzone == o.dodgeDeadzone; }
+};
+inline const CarConfig CAR_CONFIG_OCTANE = [] { CarConfig c; c.hitboxSize = Vec(120.507f, 86.6994f, 38.6591f); c.hitboxPosOffset = Vec(13.87566f, 0, 20.755f); return c; }();
+enum class DemoMode : uint8_t { NORMAL, ON_CONTACT, DISABLED };
+// MutatorConfig.h: the fields programs usually touch, at their soccar defaults; anything else is refused where it would be applied
+struct MutatorConfig {
+    Vec gravity = Vec(0, 0, RLConst::GRAVITY_Z);
+    float carMass = RLConst::CAR_MASS_BT, ballMass = RLConst::BALL_MASS_BT, ballMaxSpeed = RLConst::BALL_MAX_SPEED, ballDrag = RLConst::BALL_DRAG;
+    float boostUsedPerSecond = RLConst::BOOST_USED_PER_SECOND, respawnDelay = RLConst::DEMO_RESPAWN_TIME, bumpCooldownTime = RLConst::BUMP_COOLDOWN_TIME;
+    float boostPadCooldown_Big = RLConst::BoostPads::COOLDOWN_BIG, boostPadCooldown_Small = RLConst::BoostPads::COOLDOWN_SMALL, carSpawnBoostAmount = RLConst::BOOST_SPAWN_AMOUNT;
+    float ballHitExtraForceScale = 1, bumpForceScale = 1, ballRadius = RLConst::BALL_COLLISION_RADIUS_SOCCAR;
+    bool unlimitedFlips = false, unlimitedDoubleJumps = false; DemoMode demoMode = DemoMode::NORMAL; bool enableTeamDemos = false;
+    float goalBaseThresholdY = RLConst::SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y;
+    MutatorConfig(GameMode = GameMode::SOCCAR) {}
+    bool IsDefault() const {
+        const MutatorConfig d;
+        return gravity.x == d.gravity.x && gravity.y == d.gravity.y && gravity.z == d.gravity.z && carMass == d.carMass && ballMass == d.ballMass && ballMaxSpeed == d.ballMaxSpeed &&
+               ballDrag == d.ballDrag && boostUsedPerSecond == d.boostUsedPerSecond && respawnDelay == d.respawnDelay && bumpCooldownTime == d.bumpCooldownTime &&
+               boostPadCooldown_Big == d.boostPadCooldown_Big && boostPadCooldown_Small == d.boostPadCooldown_Small && carSpawnBoostAmount == d.carSpawnBoostAmount &&
+               ballHitExtraForceScale == 1 && bumpForceScale == 1 && ballRadius == d.ballRadius && !unlimitedFlips && !unlimitedDoubleJumps && demoMode == DemoMode::NORMAL &&
+               !enableTeamDemos && goalBaseThresholdY == d.goalBaseThresholdY;
+    }
+};
+struct ArenaConfig {};
 // RocketSim::Init(collision_meshes folder) (RS/RocketSim.cpp:70-212): here it only records where the arena meshes are; the
 // batched env loads "<folder>/soccar/*.cmf" (rlgpu_env_load_cmf_dir) or, when the folder is missing, the procedural soccar mesh.
 void Init(const std::filesystem::path& collisionMeshesFolder, bool silent = false);
 const std::filesystem::path& GetCollisionMeshFolder();
 }  // namespace RocketSim
 
+using namespace RocketSim;  // the reference injects it the same way, at global scope (SIM/Framework.h:8) -- `::Math::RandFloat` in user setters
+
+// A built-in plugin's device form is valid for objects of exactly that class: a user subclass may override any host-side virtual
+// (BuildOBS, AddPlayerToOBS, GetReward, ...), which the step kernel would not see -- such an object runs on the host instead.
+#define RLG_IS_EXACTLY(Class) (typeid(*this) == typeid(Class))
+
 namespace RLGSC {
-using namespace RocketSim;  // the reference injects it the same way (SIM/Framework.h:8)
+using namespace RocketSim;  // so that RLGSC::Vec, RLGSC::Arena ... name them too
 typedef std::vector<float> FList;
 typedef std::vector<FList> FList2;
 typedef std::vector<int> IList;
@@ -77,5 +193,14 @@ namespace CommonValues {  // Utils/CommonValues.h
 constexpr float SIDE_WALL_X = 4096, BACK_WALL_Y = 5120, CEILING_Z = 2044, BACK_NET_Y = 6000, GOAL_HEIGHT = 642.775f;
 constexpr float BALL_RADIUS = 92.75f, BALL_MAX_SPEED = 6000, CAR_MAX_SPEED = 2300, SUPERSONIC_THRESHOLD = 2200, CAR_MAX_ANG_VEL = 5.5f;
 constexpr int BLUE_TEAM = 0, ORANGE_TEAM = 1, NUM_ACTIONS = 8, BOOST_LOCATIONS_AMOUNT = 34;
+constexpr Vec BLUE_GOAL_BACK = Vec(0, -BACK_NET_Y, GOAL_HEIGHT / 2), ORANGE_GOAL_BACK = Vec(0, BACK_NET_Y, GOAL_HEIGHT / 2);
+constexpr Vec BLUE_GOAL_CENTER = Vec(0, -BACK_WALL_Y, GOAL_HEIGHT / 2), ORANGE_GOAL_CENTER = Vec(0, BACK_WALL_Y, GOAL_HEIGHT / 2);
+}
+namespace Math {  // SIM/Math.h
+inline bool IsBallScored(Vec pos) { return std::fabs(pos.y) > RLConst::SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y + RLConst::BALL_COLLISION_RADIUS_SOCCAR; }
+inline Vec RandVec(Vec min, Vec max) {   // three draws, x then y then z (Math.cpp:7-13)
+    const float x = ::Math::RandFloat(min.x, max.x); const float y = ::Math::RandFloat(min.y, max.y); const float z = ::Math::RandFloat(min.z, max.z);
+    return Vec(x, y, z);
+}
 }
 }  // namespace RLGSC

@@ -20,6 +20,6 @@ public:
         return out;
     }
     int GetActionAmount() override { return (int)actions.size(); }
-    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { cfg.n_actions = (int)actions.size(); return true; }
+    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { if (!RLG_IS_EXACTLY(DiscreteAction)) return false; cfg.n_actions = (int)actions.size(); return true; }
 };
 }

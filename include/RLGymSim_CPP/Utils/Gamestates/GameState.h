@@ -1,9 +1,10 @@
 // GameState / PlayerData / PhysObj / ScoreLine (SIM/Utils/Gamestates/{GameState.h:6-57, PlayerData.h:7-38, PhysObj.h}).
-// Filled from the device state (rlgpu_env_download_states) when a step callback asks for it -- the slow path.
+// Built from an env's state in the exchange layout of rlgpu_state.h: the snapshot the step kernel stores for host plugins and step
+// callbacks (rlgpu_env_enable_snapshots), or the state inside a host Arena facade.
 #pragma once
 #include "../../Framework.h"
+#include "../../RocketSim/Arena.h"
 #include "../BasicTypes/Action.h"
-struct RlgpuArenaState;
 namespace RLGSC {
 struct PhysObj {
     Vec pos, vel, angVel; RotMat rotMat;
@@ -31,9 +32,54 @@ struct GameState {
     bool boostPads[CommonValues::BOOST_LOCATIONS_AMOUNT] = {}, boostPadsInv[CommonValues::BOOST_LOCATIONS_AMOUNT] = {};
     uint64_t lastTickCount = 0; int deltaTickCount = 0;
     GameState() = default;
-    // materialise from one downloaded env (rlgymppo_cpp_amd/host/Host.cpp)
-    explicit GameState(const RlgpuArenaState& s, int tickSkip);
+    // from one env's state; deltaTicks = ticks since the previous GameState of that env (the window of PlayerData::ballTouchedStep)
+    explicit GameState(const RlgpuArenaState& s, int deltaTicks);
+    // GameState(Arena*) / UpdateFromArena (GameState.cpp:52-104) on the host facade: physics, pads, flags from the arena; the match
+    // counters and the score line are the ones the device step keeps in the arena's gym block
+    explicit GameState(Arena* arena) { UpdateFromArena(arena); }
+    void UpdateFromArena(Arena* arena) {
+        const uint64_t before = lastTickCount;
+        arena->_SyncToState();
+        *this = GameState(arena->_state, (int)(arena->tickCount - before));
+    }
     const PhysObj& GetBallPhys(bool inverted) const { return inverted ? ballInv : ball; }
     const bool* GetBoostPads(bool inverted) const { return inverted ? boostPadsInv : boostPads; }
 };
+// GameState::UpdateFromArena / PlayerData::UpdateFromCar (SIM/Utils/Gamestates/GameState.cpp:52-104, PlayerData.cpp:4-34) from a
+// state in the exchange layout
+inline GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
+    auto V = [](const float* p) { return Vec(p[0], p[1], p[2]); };
+    scoreLine.teamGoals[0] = s.gym.score_line[0]; scoreLine.teamGoals[1] = s.gym.score_line[1];
+    lastTouchCarID = s.gym.last_touch_car_id;
+    lastTickCount = (uint64_t)s.tick_count; deltaTickCount = tickSkip;
+    ball.pos = V(s.ball.pos); ball.vel = V(s.ball.vel); ball.angVel = V(s.ball.ang_vel);
+    ballInv = ball.Invert();
+    // RLGym pad order -> RocketSim pad index: the map GameState.cpp:10-50 builds by matching CommonValues::BOOST_LOCATIONS against
+    // the arena's pads (a constant of the two tables; the device obs builder uses the same one)
+    static const int8_t PAD_ORDER[RLGPU_NUM_PADS] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
+    for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[PAD_ORDER[p]].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
+    players.resize(s.num_cars);
+    for (int k = 0; k < s.num_cars; k++) {
+        const RlgpuCarState& c = s.cars[k]; const RlgpuPlayerGymState& g = s.gym.players[k];
+        PlayerData& pd = players[k];
+        pd.carId = (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
+        pd.phys.pos = V(c.pos); pd.phys.vel = V(c.vel); pd.phys.angVel = V(c.ang_vel);
+        pd.phys.rotMat.forward = V(c.rot); pd.phys.rotMat.right = V(c.rot + 3); pd.phys.rotMat.up = V(c.rot + 6);
+        pd.physInv = pd.phys.Invert();
+        CarState& cs = pd.carState;
+        cs.pos = pd.phys.pos; cs.vel = pd.phys.vel; cs.angVel = pd.phys.angVel; cs.rotMat = pd.phys.rotMat;
+        cs.isOnGround = c.flags & RLGPU_CF_ON_GROUND; cs.hasJumped = c.flags & RLGPU_CF_HAS_JUMPED; cs.hasDoubleJumped = c.flags & RLGPU_CF_HAS_DOUBLE_JUMPED;
+        cs.hasFlipped = c.flags & RLGPU_CF_HAS_FLIPPED; cs.isJumping = c.flags & RLGPU_CF_IS_JUMPING; cs.isFlipping = c.flags & RLGPU_CF_IS_FLIPPING;
+        cs.isSupersonic = c.flags & RLGPU_CF_IS_SUPERSONIC; cs.isDemoed = c.flags & RLGPU_CF_IS_DEMOED;
+        cs.boost = c.boost; cs.airTimeSinceJump = c.air_time_since_jump; cs.jumpTime = c.jump_time; cs.flipTime = c.flip_time; cs.demoRespawnTimer = c.demo_respawn_timer;
+        pd.matchGoals = g.match_goals; pd.matchSaves = g.match_saves; pd.matchAssists = g.match_assists; pd.matchShots = g.match_shots;
+        pd.matchShotPasses = g.match_shot_passes; pd.matchBumps = g.match_bumps; pd.matchDemos = g.match_demos; pd.boostPickups = g.boost_pickups;
+        pd.boostFraction = c.boost / 100.f;
+        // PlayerData.cpp:20-30
+        pd.ballTouchedStep = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit >= s.tick_count - tickSkip;
+        pd.ballTouchedTick = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit == s.tick_count - 1;
+        pd.hasJump = !cs.hasJumped;
+        pd.hasFlip = !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;   // RLConst::DOUBLEJUMP_MAX_DELAY
+    }
+}
 }

@@ -33,9 +33,10 @@ public:
         obs += mates; obs += opponents;
         return obs;
     }
-    bool ApplyToDevice(RlgpuGymConfig& cfg) const override {
+    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { if (!RLG_IS_EXACTLY(DefaultOBS)) return false; WriteCoefs(cfg); return true; }
+protected:
+    void WriteCoefs(RlgpuGymConfig& cfg) const {
         cfg.pos_coef[0] = posCoef.x; cfg.pos_coef[1] = posCoef.y; cfg.pos_coef[2] = posCoef.z; cfg.vel_coef = velCoef; cfg.ang_vel_coef = angVelCoef;
-        return true;
     }
 };
 }

@@ -38,6 +38,6 @@ public:
         for (const FList& b : opponents) obs += b;
         return obs;
     }
-    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { DefaultOBS::ApplyToDevice(cfg); cfg.obs_max_players = maxPlayers; return maxPlayers > 0; }
+    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { if (!RLG_IS_EXACTLY(DefaultOBSPadded)) return false; WriteCoefs(cfg); cfg.obs_max_players = maxPlayers; return maxPlayers > 0; }
 };
 }

@@ -35,7 +35,19 @@ public:
         for (RewardFunction* child : rewardFuncs) delete child;
     }
 
-    bool AddDeviceTerms(RlgpuGymConfig& deviceCfg, float outerWeight) const override {
+    // host form (CombinedReward.h:27-45): every child sees every hook; the children's reward vectors add up, weighted
+    void Reset(const GameState& initialState) override { for (RewardFunction* child : rewardFuncs) child->Reset(initialState); }
+    void PreStep(const GameState& state) override { for (RewardFunction* child : rewardFuncs) child->PreStep(state); }
+    std::vector<float> GetAllRewards(const GameState& state, const ActionSet& prevActions, bool final) override {
+        std::vector<float> total(state.players.size(), 0.f);
+        for (size_t k = 0; k < rewardFuncs.size(); k++) {
+            const std::vector<float> part = rewardFuncs[k]->GetAllRewards(state, prevActions, final);
+            for (size_t j = 0; j < part.size() && j < total.size(); j++) total[j] += part[j] * rewardWeights[k];
+        }
+        return total;
+    }
+
+    bool AddDeviceTerms(RlgpuGymConfig& deviceCfg, float outerWeight) const override { if (!RLG_IS_EXACTLY(CombinedReward)) return false;
         for (size_t k = 0; k < rewardFuncs.size(); k++) {
             const bool ok = rewardFuncs[k]->AddDeviceTerms(deviceCfg, outerWeight * rewardWeights[k]);
             if (!ok) return false;   // a child without a device form: Match::ToDeviceConfig turns this into the fatal error

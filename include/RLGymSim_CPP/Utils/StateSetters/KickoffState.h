@@ -4,6 +4,7 @@
 namespace RLGSC {
 class KickoffState : public StateSetter {
 public:
-    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { cfg.setter_kind = RLGPU_SS_KICKOFF; return true; }
+    GameState ResetState(Arena* arena) override { arena->ResetToRandomKickoff(); return GameState(arena); }
+    bool ApplyToDevice(RlgpuGymConfig& cfg) const override { if (!RLG_IS_EXACTLY(KickoffState)) return false; cfg.setter_kind = RLGPU_SS_KICKOFF; return true; }
 };
 }

@@ -12,7 +12,9 @@ namespace RLGSC {
 
 class GoalScoreCondition : public TerminalCondition {
 public:
-    bool AddDeviceCondition(RlgpuGymConfig& deviceCfg) const override {
+    bool IsTerminal(const GameState& currentState) override { return Math::IsBallScored(currentState.ball.pos); }   // host form
+
+    bool AddDeviceCondition(RlgpuGymConfig& deviceCfg) const override { if (!RLG_IS_EXACTLY(GoalScoreCondition)) return false;
         return PushCond(deviceCfg, RLGPU_TC_GOAL_SCORE);
     }
 };

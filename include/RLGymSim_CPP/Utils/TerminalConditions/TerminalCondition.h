@@ -1,4 +1,6 @@
-// TerminalCondition (SIM/Utils/TerminalConditions/TerminalCondition.h:6-9)
+// TerminalCondition (SIM/Utils/TerminalConditions/TerminalCondition.h:6-9).  Same interface as the reference; AddDeviceCondition is how
+// a condition tells the batched env that the step kernel can evaluate it.  A user subclass that only overrides IsTerminal runs on the
+// host: the Learner then evaluates ALL of the match's conditions there, per env and step, in Match::IsDone's order.
 #pragma once
 #include "../Gamestates/GameState.h"
 #include "../../../rlgpu.h"
@@ -6,7 +8,7 @@ namespace RLGSC {
 class TerminalCondition {
 public:
     virtual void Reset(const GameState& initialState) {}
-    virtual bool IsTerminal(const GameState& currentState) { RG_ERR_CLOSE("TerminalCondition::IsTerminal() is evaluated on the device for the built-in conditions only"); }
+    virtual bool IsTerminal(const GameState& currentState) = 0;
     virtual bool AddDeviceCondition(RlgpuGymConfig& cfg) const { return false; }
     virtual ~TerminalCondition() {}
 protected:

@@ -60,6 +60,8 @@ void rlgpu_default_gym_config(RlgpuGymConfig* cfg);
 
 /* ---- environment batch : replaces ThreadAgentManager + N x (GameInst, Gym, Match, Arena)
  *      (PRIV/Threading/ThreadAgentManager.h:10-69, PUB/Threading/GameInst.cpp:3-38, SIM/Gym.cpp:40-102) ---- */
+/* location (uu) of boost pad `pad` in RocketSim's order -- 6 big, then 28 small (RS/RLConst.h:215-253) -- for the host Arena facade */
+int rlgpu_pad_location(int pad, float* pos_uu, int* is_big);
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg);
 void rlgpu_env_destroy(rlgpu_env* e);
 const char* rlgpu_env_last_error(const rlgpu_env* e);
@@ -88,11 +90,26 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host_states, const 
 /* Gym::Reset for every env (SIM/Gym.cpp:58-66). run_setter=0 keeps the uploaded physical state and only does the
  * episode bookkeeping. obs_dev: [num_agents x obs_size] fp32 device, may be NULL. */
 int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev);
+/* The same for the listed envs only (host list): what GameInst::Step does for one game whose episode ended (GameInst.cpp:27-32) when
+ * the terminal conditions or the state setter run on the host.  Only the obs rows of those envs are written. */
+int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_setter, float* obs_dev);
+
+/* Host-plugin fallback (user RewardFunction / OBSBuilder / TerminalCondition subclasses, step callbacks): when enabled, every
+ * rlgpu_env_step also stores each env's arena as it stands where Gym::Step builds the step's GameState -- after the first tick and the
+ * event tracker's update (SIM/Gym.cpp:81-93) -- in the exchange layout of rlgpu_state.h, and rlgpu_env_download_snapshots copies
+ * envs [first_env, first_env + n) of that buffer to the host.  Off by default: 3.4 KB per env and step of extra HBM writes. */
+int rlgpu_env_enable_snapshots(rlgpu_env* e, int on);
+int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host_states, int first_env, int n);
 
 /* Gym::Step + GameInst auto-reset for every env (SIM/Gym.cpp:68-102, PUB/Threading/GameInst.cpp:7-38):
  * actions_dev [num_agents] int32 ; next_obs_dev [num_agents x obs_size] (post-reset obs when done);
  * reward_dev [num_agents] ; done_dev [num_agents] int32 (the env's done replicated to its players). */
 int rlgpu_env_step(rlgpu_env* e, const int32_t* actions_dev, float* next_obs_dev, float* reward_dev, int32_t* done_dev);
+
+/* The same step with the controls already parsed on the host -- a user ActionParser, or a standalone Gym (SIM/Gym.cpp:69-79 sets
+ * car->controls from Match::ParseActions): controls_dev [num_agents x 8] fp32 device, one Action row per agent
+ * {throttle, steer, pitch, yaw, roll, jump, boost, handbrake}.  The previous-action block of the device obs builder shows those rows. */
+int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next_obs_dev, float* reward_dev, int32_t* done_dev);
 
 /* Arena::Step(ticks) on the resident states with the controls stored in them (RS/Sim/Arena/Arena.cpp:716-812) */
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);

@@ -70,6 +70,7 @@ struct EnvDev {
     const float* action_table;
     GymConfig cfg;
     int n_envs;
+    RlgpuArenaState* snap_out;   // host-plugin fallback (rlgpu_env_enable_snapshots): every step's GameState source, [n_envs], or null
 };
 
 // Everything one env touches during a step lives in LDS (state + per-tick scratch): as stack objects these
@@ -450,6 +451,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     TickEvents ev; ev.bump_mask = 0;
     arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
     if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * NC * D, (size_t)D, snap);
+    // host plugins see what the reference's see: the arena as it stands where Gym::Step builds its GameState (Gym.cpp:81-93)
+    if (d.snap_out && env_lane) arena_to_host(S.A, S.G, d.snap_out[env]);
     wave_sync();
     RLG_PROF(9);
     for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
@@ -565,12 +568,13 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, float* obs) {
+__global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, float* obs, const int32_t* env_ids, int n_ids) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     if (threadIdx.x >= LANES) return;
     int env = blockIdx.x * LANES + threadIdx.x;
-    if (env >= d.n_envs) return;
+    if (env_ids) { if (env >= n_ids) return; env = env_ids[env]; }   // rlgpu_env_reset_envs: only the listed envs
+    if (env < 0 || env >= d.n_envs) return;
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
     load_env(d, env, S.A, S.G);
     const int D = obs_size<NC>(d.cfg);
@@ -650,6 +654,7 @@ struct rlgpu_env {
     size_t n_words = 0;
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr;
+    int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -687,6 +692,14 @@ void rlgpu_default_gym_config(RlgpuGymConfig* c) {
     c->vel_coef = 1 / 2300.f; c->ang_vel_coef = 1 / 5.5f;
     c->n_actions = 90;
     c->obs_max_players = 0;
+}
+
+int rlgpu_pad_location(int pad, float* pos_uu, int* is_big) {
+    if (pad < 0 || pad >= RLGPU_NUM_PADS || !pos_uu) return RLGPU_ERR_ARG;
+    V3 p = pad_pos(pad);
+    pos_uu[0] = p.x; pos_uu[1] = p.y; pos_uu[2] = p.z;
+    if (is_big) *is_big = pad < 6 ? 1 : 0;
+    return RLGPU_OK;
 }
 
 int rlgpu_procedural_mesh(float* verts, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris) {
@@ -733,6 +746,8 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_tris) (void)hipFree(e->d_tris);
     if (e->d_actions) (void)hipFree(e->d_actions);
     if (e->d_grid) (void)hipFree(e->d_grid);
+    if (e->d.snap_out) (void)hipFree(e->d.snap_out);
+    if (e->d_iota) (void)hipFree(e->d_iota);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
 }
@@ -826,8 +841,44 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
 int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
     HIPCHK(e, hipSetDevice(e->device));
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
-    DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev);
+    DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev, (const int32_t*)nullptr, 0);
     HIPCHK(e, hipGetLastError());
+    return RLGPU_OK;
+}
+
+int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_setter, float* obs_dev) {
+    if (n <= 0) return RLGPU_OK;
+    if (!env_ids) { e->err = "rlgpu_env_reset_envs: null env list"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    int32_t* dids = nullptr;
+    HIPCHK(e, hipMalloc(&dids, 4 * (size_t)n));
+    HIPCHK(e, hipMemcpyAsync(dids, env_ids, 4 * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    dim3 grid(e->nc == 2 ? env_grid<2>(n) : (e->nc == 4 ? env_grid<4>(n) : env_grid<6>(n))), block(WAVE);
+    DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev, (const int32_t*)dids, n);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    (void)hipFree(dids);
+    return RLGPU_OK;
+}
+
+int rlgpu_env_enable_snapshots(rlgpu_env* e, int on) {
+    HIPCHK(e, hipSetDevice(e->device));
+    if (on && !e->d.snap_out) {
+        HIPCHK(e, hipMalloc(&e->d.snap_out, sizeof(RlgpuArenaState) * (size_t)e->n_envs));
+        HIPCHK(e, hipMemsetAsync(e->d.snap_out, 0, sizeof(RlgpuArenaState) * (size_t)e->n_envs, e->stream));
+    } else if (!on && e->d.snap_out) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        (void)hipFree(e->d.snap_out); e->d.snap_out = nullptr;
+    }
+    return RLGPU_OK;
+}
+
+int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host, int first_env, int n) {
+    if (!e->d.snap_out) { e->err = "rlgpu_env_download_snapshots: call rlgpu_env_enable_snapshots first"; return RLGPU_ERR_STATE; }
+    if (first_env < 0 || n < 0 || first_env + n > e->n_envs) { e->err = "rlgpu_env_download_snapshots: env range out of bounds"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(host, e->d.snap_out + first_env, sizeof(RlgpuArenaState) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     return RLGPU_OK;
 }
 
@@ -850,6 +901,26 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
     HIPCHK(e, hipEventRecord(evp.second, e->stream));
     e->ev0 = evp.first; e->ev1 = evp.second;
     e->timed = true;
+    HIPCHK(e, hipGetLastError());
+    return RLGPU_OK;
+}
+
+// Gym::Step with the controls already parsed on the host (a user ActionParser, a standalone Gym): row r of controls_dev is agent r's
+// Action (8 floats).  Same kernel: the "action table" it indexes is the controls buffer itself and every agent's action is its own row.
+int rlgpu_env_step_controls(rlgpu_env* e, const float* controls, float* next_obs, float* reward, int32_t* done) {
+    if (!controls || !next_obs || !reward || !done) { e->err = "rlgpu_env_step_controls: null device pointer"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    const int n_agents = e->n_envs * e->nc;
+    if (!e->d_iota) {
+        std::vector<int32_t> iota((size_t)n_agents);
+        for (int i = 0; i < n_agents; i++) iota[i] = i;
+        HIPCHK(e, hipMalloc(&e->d_iota, 4 * (size_t)n_agents));
+        HIPCHK(e, hipMemcpy(e->d_iota, iota.data(), 4 * (size_t)n_agents, hipMemcpyHostToDevice));
+    }
+    EnvDev d = e->d;
+    d.action_table = controls; d.cfg.n_actions = n_agents;
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    DISPATCH_NC(e, k_env_step, grid, block, d, (const int32_t*)e->d_iota, next_obs, reward, done);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }

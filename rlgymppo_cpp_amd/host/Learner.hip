@@ -18,14 +18,9 @@
 
 #include <RLGymPPO_CPP/Learner.h>
 #include "../../include/rlgpu_state.h"
+#include "host_util.h"
 
 namespace {
-
-#define HOST_HIP(call)                                                                                   \
-    do {                                                                                                 \
-        hipError_t _e = (call);                                                                          \
-        if (_e != hipSuccess) RG_ERR_CLOSE(#call << " failed: " << hipGetErrorString(_e));               \
-    } while (0)
 
 // done (int32) -> float, and the collector's truncation mark: the last step of every trajectory is truncated unless done
 // (ThreadAgentManager.cpp:55)
@@ -69,41 +64,13 @@ const std::filesystem::path& GetCollisionMeshFolder() { return g_mesh_folder; }
 }
 
 namespace RLGSC {
-// GameState::UpdateFromArena / PlayerData::UpdateFromCar (SIM/Utils/Gamestates/GameState.cpp:52-104, PlayerData.cpp:4-34) from a
-// downloaded env
-GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
-    auto V = [](const float* p) { return Vec(p[0], p[1], p[2]); };
-    scoreLine.teamGoals[0] = s.gym.score_line[0]; scoreLine.teamGoals[1] = s.gym.score_line[1];
-    lastTouchCarID = s.gym.last_touch_car_id;
-    lastTickCount = (uint64_t)s.tick_count; deltaTickCount = tickSkip;
-    ball.pos = V(s.ball.pos); ball.vel = V(s.ball.vel); ball.angVel = V(s.ball.ang_vel);
-    ballInv = ball.Invert();
-    // RLGym pad order -> RocketSim pad index: the map GameState.cpp:10-50 builds by matching CommonValues::BOOST_LOCATIONS against
-    // the arena's pads (a constant of the two tables; the device obs builder uses the same one)
-    static const int8_t PAD_ORDER[RLGPU_NUM_PADS] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
-    for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[PAD_ORDER[p]].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
-    players.resize(s.num_cars);
-    for (int k = 0; k < s.num_cars; k++) {
-        const RlgpuCarState& c = s.cars[k]; const RlgpuPlayerGymState& g = s.gym.players[k];
-        PlayerData& pd = players[k];
-        pd.carId = (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
-        pd.phys.pos = V(c.pos); pd.phys.vel = V(c.vel); pd.phys.angVel = V(c.ang_vel);
-        pd.phys.rotMat.forward = V(c.rot); pd.phys.rotMat.right = V(c.rot + 3); pd.phys.rotMat.up = V(c.rot + 6);
-        pd.physInv = pd.phys.Invert();
-        CarState& cs = pd.carState;
-        cs.pos = pd.phys.pos; cs.vel = pd.phys.vel; cs.angVel = pd.phys.angVel; cs.rotMat = pd.phys.rotMat;
-        cs.isOnGround = c.flags & RLGPU_CF_ON_GROUND; cs.hasJumped = c.flags & RLGPU_CF_HAS_JUMPED; cs.hasDoubleJumped = c.flags & RLGPU_CF_HAS_DOUBLE_JUMPED;
-        cs.hasFlipped = c.flags & RLGPU_CF_HAS_FLIPPED; cs.isJumping = c.flags & RLGPU_CF_IS_JUMPING; cs.isFlipping = c.flags & RLGPU_CF_IS_FLIPPING;
-        cs.isSupersonic = c.flags & RLGPU_CF_IS_SUPERSONIC; cs.isDemoed = c.flags & RLGPU_CF_IS_DEMOED;
-        cs.boost = c.boost; cs.airTimeSinceJump = c.air_time_since_jump; cs.jumpTime = c.jump_time; cs.flipTime = c.flip_time; cs.demoRespawnTimer = c.demo_respawn_timer;
-        pd.matchGoals = g.match_goals; pd.matchSaves = g.match_saves; pd.matchAssists = g.match_assists; pd.matchShots = g.match_shots;
-        pd.matchShotPasses = g.match_shot_passes; pd.matchBumps = g.match_bumps; pd.matchDemos = g.match_demos; pd.boostPickups = g.boost_pickups;
-        pd.boostFraction = c.boost / 100.f;
-        // PlayerData.cpp:20-30
-        pd.ballTouchedStep = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit >= s.tick_count - tickSkip;
-        pd.ballTouchedTick = (c.flags & RLGPU_CF_BALLHIT_VALID) && c.bh_tick_hit == s.tick_count - 1;
-        pd.hasJump = !cs.hasJumped;
-        pd.hasFlip = !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;   // RLConst::DOUBLEJUMP_MAX_DELAY
+void LoadArenaMesh(rlgpu_env* env, bool quiet) {
+    auto check = [&](int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); };
+    const std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
+    if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) check(rlgpu_env_load_cmf_dir(env, soccar.string().c_str()), "load_cmf_dir");
+    else {
+        if (!quiet) RG_LOG("Learner: no collision meshes at \"" << soccar.string() << "\" -- using the procedural soccar mesh");
+        check(rlgpu_env_set_procedural_mesh(env), "set_procedural_mesh");
     }
 }
 }  // namespace RLGSC
@@ -127,7 +94,35 @@ struct Learner::Impl {
     Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     std::vector<GameInst> games;
-    std::vector<RlgpuArenaState> hostStates; std::vector<float> hostRew; std::vector<int32_t> hostDone;
+    // ---- host path: plugin kinds without a device form (Match::DevicePlan) and step callbacks -------------------------------------
+    RLGSC::Match::DevicePlan plan;
+    bool hostReady = false;
+    std::vector<RLGSC::Match*> envMatch; std::vector<RLGSC::Gym*> envGym;   // one plugin set per env, like GameInst's; [0] = match / gym
+    int Ddev = 0, workers = 1;
+    float *devObs = nullptr, *devControls = nullptr;   // the device builder's rows when the obs builder runs on the host; host-parsed controls
+    std::vector<RlgpuArenaState> snaps, fresh;
+    std::vector<RLGSC::GameState> prevGs;
+    std::vector<float> hObs, hRew, hControls; std::vector<int32_t> hDone, hActs;
+    std::vector<RLGSC::Arena*> arenas;                 // scratch facades for user state setters, one per worker
+
+    // fn(env, worker) for every env in `ids` (all envs when null) on `workers` host threads; the first exception is rethrown here
+    template <class F>
+    void ForEnvs(const std::vector<int32_t>* ids, F fn) {
+        const int n = ids ? (int)ids->size() : nEnvs;
+        const int nw = std::max(1, std::min(workers, n));
+        std::vector<std::exception_ptr> errs(nw);
+        auto run = [&](int w) {
+            try { for (int i = w; i < n; i += nw) fn(ids ? (*ids)[i] : i, i, w); } catch (...) { errs[w] = std::current_exception(); }
+        };
+        std::vector<std::thread> th;
+        for (int w = 1; w < nw; w++) th.emplace_back(run, w);
+        run(0);
+        for (auto& t : th) t.join();
+        for (auto& e : errs) if (e) std::rethrow_exception(e);
+    }
+    void SetupHostPath(const EnvCreateFn& create, int numThreads);
+    void HostResetEnvs(const std::vector<int32_t>& ids, float* obsRows, bool deviceDidReset);
+    void HostStep(Learner* self, int t);
     // the permutation of the NEXT epoch is drawn by a worker while this thread launches the current one (a draw depends on the
     // FIFO's bookkeeping only): 2-3 ms of std::shuffle per 262 144 rows that would otherwise leave the GPU idle
     std::vector<int32_t> phys[2]; int physFlip = 0;
@@ -182,19 +177,29 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     EnvCreateResult ecr = envCreateFn();
     if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
-    RlgpuGymConfig gcfg = m.match->ToDeviceConfig(m.tickSkip);
+    m.plan = m.match->PlanDevice(m.tickSkip);   // which plugin kinds the step kernel runs, which stay on the host
+    RlgpuGymConfig gcfg = m.plan.cfg;
     gcfg.seed_lo = (uint32_t)config.randomSeed + 1000u * (uint32_t)m.rank; gcfg.seed_hi = 0;   // every rank its own env RNG streams; rank 0 = the single-GPU run
     m.nEnvs = config.numThreads * config.numGamesPerThread;
     m.nPlayers = m.match->playerAmount;
     int rc = rlgpu_env_create(&m.env, m.device, m.nEnvs, m.match->teamSize, &gcfg);
     m.EnvCheck(rc, "create");
-    std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
-    if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
-    else {
-        RG_LOG("Learner: no collision meshes at \"" << soccar.string() << "\" -- using the procedural soccar mesh");
-        m.EnvCheck(rlgpu_env_set_procedural_mesh(m.env), "set_procedural_mesh");
+    RLGSC::LoadArenaMesh(m.env, m.rank != 0 || std::getenv("RLGPU_QUIET"));
+    m.nAgents = rlgpu_env_num_agents(m.env); m.Ddev = m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);
+    if (m.plan.AnyHost()) {
+        if (m.rank == 0 && !std::getenv("RLGPU_QUIET"))
+            RG_LOG("Learner: plugins without a device form run on the host every step (" << (m.plan.hostReward ? "reward " : "") << (m.plan.hostTerminal ? "terminal-conditions " : "")
+                   << (m.plan.hostObs ? "obs-builder " : "") << (m.plan.hostSetter ? "state-setter " : "") << (m.plan.hostParser ? "action-parser " : "") << "); the rest stays on the device");
+        m.SetupHostPath(envCreateFn, config.numThreads);
+        if (m.plan.hostObs) {   // the obs width is whatever the user's builder returns (Learner.cpp:99-109 probes it the same way)
+            m.EnvCheck(rlgpu_env_reset(m.env, 1, m.devObs), "reset");
+            RlgpuArenaState st; const int32_t env0 = 0;
+            m.EnvCheck(rlgpu_env_download_states(m.env, &st, &env0, 1), "download_states");
+            RLGSC::GameState gs(st, (int)st.tick_count);
+            m.match->EpisodeReset(gs);
+            m.D = (int)m.match->BuildObservations(gs).at(0).size();
+        }
     }
-    m.nAgents = rlgpu_env_num_agents(m.env); m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);
     obsSize = m.D; actionAmount = m.A;
     // steps per env and iteration: enough whole steps of the batch to reach timestepsPerIteration (ThreadAgent.cpp:158-163 stops
     // each thread once it passed its share)
@@ -232,7 +237,11 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.adv = dev_alloc<float>(TN); m.tgt = dev_alloc<float>(TN); m.ret = dev_alloc<float>(TN);
     m.vals = dev_alloc<float>(TN + m.nAgents); m.metrics = dev_alloc<float>(8); m.scratch = dev_alloc<float>(8);
     m.phys[0].resize(EX); m.phys[1].resize(EX);
-    m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
+    if (!m.plan.hostObs) m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
+    if (m.plan.AnyHost()) {
+        std::vector<int32_t> all(m.nEnvs); std::iota(all.begin(), all.end(), 0);
+        m.HostResetEnvs(all, m.ObsAt(0), true);
+    }
 
     if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
         config.checkpointSaveFolder += "-" + std::to_string(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count());
@@ -261,12 +270,26 @@ Learner::~Learner() {
     if (m.env) rlgpu_env_destroy(m.env);
     if (m.retShare) (void)hipFree(m.retShare);
     if (m.comm) rlgpu_comm_destroy(m.comm);
+    for (size_t e = 1; e < m.envMatch.size(); e++) { delete m.envGym[e]; delete m.envMatch[e]; }
+    for (RLGSC::Arena* a : m.arenas) delete a;
+    if (m.devObs) (void)hipFree(m.devObs);
+    if (m.devControls) (void)hipFree(m.devControls);
     delete m.gym; delete m.match;   // GameInst deletes its gym and match in the reference (GameInst.h:53-56); plugins stay the user's
     delete impl;
 }
 
 int Learner::NumEnvs() const { return impl->nEnvs; }
 int Learner::NumAgents() const { return impl->nAgents; }
+int Learner::StepsPerIteration() const { return impl->T; }
+void Learner::CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones) {
+    Impl& m = *impl;
+    const size_t TN = (size_t)m.T * m.nAgents;
+    HOST_HIP(hipDeviceSynchronize());
+    if (obs) { obs->resize((size_t)(m.T + 1) * m.nAgents * m.D); HOST_HIP(hipMemcpy(obs->data(), m.obs, obs->size() * 4, hipMemcpyDeviceToHost)); }
+    if (actions) { actions->resize(TN); HOST_HIP(hipMemcpy(actions->data(), m.acts, TN * 4, hipMemcpyDeviceToHost)); }
+    if (rewards) { rewards->resize(TN); HOST_HIP(hipMemcpy(rewards->data(), m.rew, TN * 4, hipMemcpyDeviceToHost)); }
+    if (dones) { dones->resize(TN); HOST_HIP(hipMemcpy(dones->data(), m.done, TN * 4, hipMemcpyDeviceToHost)); }
+}
 int Learner::Rank() const { return impl->rank; }
 int Learner::WorldSize() const { return impl->world; }
 double Learner::MaxOverRanks(double v) {
@@ -292,16 +315,144 @@ void Learner::UpdateLearningRates(float policyLR, float criticLR) {
 }
 
 // ThreadAgent::_RunFunc (ThreadAgent.cpp:24-195) for every game at once: policy inference and the env step never leave the device
+// ---- the host path --------------------------------------------------------------------------------------------------------------
+void Learner::Impl::SetupHostPath(const EnvCreateFn& create, int numThreads) {
+    if (hostReady) return;
+    hostReady = true;
+    workers = std::max(1, std::min({numThreads, (int)std::thread::hardware_concurrency(), 32}));
+    EnvCheck(rlgpu_env_enable_snapshots(env, 1), "enable_snapshots");
+    snaps.resize(nEnvs); prevGs.resize(nEnvs); hRew.resize(nAgents); hDone.resize(nAgents); hActs.resize(nAgents);
+    games.resize(nEnvs);
+    envMatch.assign(nEnvs, match); envGym.assign(nEnvs, gym);
+    if (plan.AnyHost()) {   // user plugins may carry per-episode state: every env gets its own set, as every GameInst does (Learner.cpp:99-109)
+        for (int e = 1; e < nEnvs; e++) {
+            EnvCreateResult r = create();
+            if (!r.match || !r.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
+            envMatch[e] = r.match; envGym[e] = r.gym;
+        }
+        for (int w = 0; w < workers; w++) arenas.push_back(RLGSC::MakeScratchArena(nPlayers));
+        if (plan.hostObs) devObs = dev_alloc<float>((size_t)nAgents * Ddev);
+        if (plan.hostParser) { devControls = dev_alloc<float>((size_t)nAgents * 8); hControls.resize((size_t)nAgents * 8); }
+    }
+    for (int e = 0; e < nEnvs; e++) { games[e].gym = envGym[e]; games[e].match = envMatch[e]; games[e].index = e; }
+}
+
+// GameInst::Step's `gym->Reset()` for the listed envs (GameInst.cpp:27-32, Gym.cpp:58-66): state setter (host or device), the device's
+// episode bookkeeping, then the host plugins' Reset hooks and -- with a host obs builder -- the first observation rows
+void Learner::Impl::HostResetEnvs(const std::vector<int32_t>& ids, float* obsRows, bool deviceDidReset) {
+    const int n = (int)ids.size();
+    if (n == 0) return;
+    float* devRows = plan.hostObs ? devObs : obsRows;
+    fresh.resize(n);
+    if (plan.hostSetter) {
+        EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
+        ForEnvs(&ids, [&](int e, int i, int w) {
+            RLGSC::Arena* arena = arenas[w];
+            arena->_state = fresh[i]; arena->_SyncFromState();
+            (void)envMatch[e]->ResetState(arena);
+            arena->_SyncToState();
+            fresh[i] = arena->_state;
+        });
+        EnvCheck(rlgpu_env_upload_states(env, fresh.data(), ids.data(), n), "upload_states");
+        EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 0, devRows), "reset_envs");
+    } else if (!deviceDidReset) {
+        EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 1, devRows), "reset_envs");
+    }
+    if (!plan.AnyHost()) return;
+    EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
+    if (plan.hostObs && hObs.size() < (size_t)nAgents * D) hObs.resize((size_t)nAgents * D);
+    ForEnvs(&ids, [&](int e, int i, int) {
+        RLGSC::GameState gs0(fresh[i], (int)fresh[i].tick_count);
+        envMatch[e]->EpisodeReset(gs0);
+        prevGs[e] = gs0;
+        if (plan.hostObs) {
+            const RLGSC::FList2 rows = envMatch[e]->BuildObservations(gs0);
+            for (int k = 0; k < nPlayers; k++) {
+                if ((int)rows[k].size() != D) RG_ERR_CLOSE("OBSBuilder::BuildOBS returned " << rows[k].size() << " values, the first observation had " << D);
+                std::copy(rows[k].begin(), rows[k].end(), hObs.begin() + ((size_t)e * nPlayers + k) * D);
+            }
+        }
+    });
+    if (plan.hostObs)
+        for (int32_t e : ids) HOST_HIP(hipMemcpy(obsRows + (size_t)e * nPlayers * D, hObs.data() + (size_t)e * nPlayers * D, (size_t)nPlayers * D * 4, hipMemcpyHostToDevice));
+}
+
+// One step of every game with host work in it: the policy's actions are on the device already (acts + t * nAgents).  Follows Gym::Step
+// (Gym.cpp:68-102) and GameInst::Step (GameInst.cpp:7-38) per env, with the arena work done by one launch for all of them.
+void Learner::Impl::HostStep(Learner* self, int t) {
+    const size_t o = (size_t)t * nAgents;
+    const int P = nPlayers;
+    float* nextObs = ObsAt(t + 1);
+    const bool plugins = plan.AnyHost();
+    if (plugins) HOST_HIP(hipMemcpy(hActs.data(), acts + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
+    if (plan.hostParser) {
+        ForEnvs(nullptr, [&](int e, int, int) {
+            RLGSC::Match* M = envMatch[e];
+            M->prevActions = M->ParseActions(RLGSC::IList(hActs.begin() + (size_t)e * P, hActs.begin() + (size_t)(e + 1) * P), prevGs[e]);
+            if ((int)M->prevActions.size() != P) RG_ERR_CLOSE("ActionParser::ParseActions returned " << M->prevActions.size() << " actions for " << P << " players");
+            for (int k = 0; k < P; k++) for (int j = 0; j < 8; j++) hControls[((size_t)e * P + k) * 8 + j] = M->prevActions[k][j];
+        });
+        HOST_HIP(hipMemcpy(devControls, hControls.data(), hControls.size() * 4, hipMemcpyHostToDevice));
+        EnvCheck(rlgpu_env_step_controls(env, devControls, plan.hostObs ? devObs : nextObs, rew + o, done + o), "step_controls");
+    } else {
+        EnvCheck(rlgpu_env_step(env, acts + o, plan.hostObs ? devObs : nextObs, rew + o, done + o), "step");
+    }
+    // every env's arena as it stood where Gym::Step builds the GameState (after the first tick and the event tracker)
+    EnvCheck(rlgpu_env_download_snapshots(env, snaps.data(), 0, nEnvs), "download_snapshots");
+    HOST_HIP(hipMemcpy(hRew.data(), rew + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
+    HOST_HIP(hipMemcpy(hDone.data(), done + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
+    if (plan.hostObs && hObs.size() < (size_t)nAgents * D) hObs.resize((size_t)nAgents * D);
+    const StepCallback& callback = self->stepCallback;
+    ForEnvs(nullptr, [&](int e, int, int) {
+        RLGSC::Match* M = envMatch[e];
+        RLGSC::Gym::StepResult sr;
+        // deltaTickCount: ticks since this env's previous GameState (tickSkip, or 1 on the first step of an episode)
+        sr.state = RLGSC::GameState(snaps[e], (int)((uint64_t)snaps[e].tick_count - prevGs[e].lastTickCount));
+        if (plugins && !plan.hostParser) M->prevActions = M->ParseActions(RLGSC::IList(hActs.begin() + (size_t)e * P, hActs.begin() + (size_t)(e + 1) * P), prevGs[e]);
+        if (plan.hostObs) {
+            sr.obs = M->BuildObservations(sr.state);
+            for (int k = 0; k < P; k++) {
+                if ((int)sr.obs[k].size() != D) RG_ERR_CLOSE("OBSBuilder::BuildOBS returned " << sr.obs[k].size() << " values, the first observation had " << D);
+                std::copy(sr.obs[k].begin(), sr.obs[k].end(), hObs.begin() + ((size_t)e * P + k) * D);
+            }
+        }
+        sr.done = plan.hostTerminal ? M->IsDone(sr.state) : hDone[(size_t)e * P] != 0;
+        if (plan.hostReward) {
+            sr.reward = M->GetRewards(sr.state, sr.done);
+            if ((int)sr.reward.size() != P) RG_ERR_CLOSE("RewardFunction::GetAllRewards returned " << sr.reward.size() << " rewards for " << P << " players");
+            std::copy(sr.reward.begin(), sr.reward.end(), hRew.begin() + (size_t)e * P);
+        } else sr.reward.assign(hRew.begin() + (size_t)e * P, hRew.begin() + (size_t)(e + 1) * P);
+        for (int k = 0; k < P; k++) hDone[(size_t)e * P + k] = sr.done ? 1 : 0;
+        prevGs[e] = sr.state;
+        GameInst& g = games[e];   // GameInst.cpp:14-34
+        const float sum = std::accumulate(sr.reward.begin(), sr.reward.end(), 0.f);
+        g.avgStepRew.Add(sum, (uint64_t)P); g.curEpRew += sum / P; g.totalSteps++;
+        if (callback) callback(&g, sr, g._metrics);
+        if (sr.done) { g.avgEpRew += g.curEpRew; g.curEpRew = 0; }
+    });
+    if (plan.hostReward) HOST_HIP(hipMemcpy(rew + o, hRew.data(), (size_t)nAgents * 4, hipMemcpyHostToDevice));
+    if (plan.hostTerminal) HOST_HIP(hipMemcpy(done + o, hDone.data(), (size_t)nAgents * 4, hipMemcpyHostToDevice));
+    if (plan.hostObs) HOST_HIP(hipMemcpy(nextObs, hObs.data(), (size_t)nAgents * D * 4, hipMemcpyHostToDevice));
+    if (plugins) {
+        std::vector<int32_t> ended;
+        for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) ended.push_back(e);
+        HostResetEnvs(ended, nextObs, !plan.hostTerminal);
+    } else {
+        // a step callback only: the kernel reset the ended envs itself; their next GameState starts a new tick window
+        for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) prevGs[e].lastTickCount = (uint64_t)snaps[e].tick_count + (uint64_t)(tickSkip - 1);
+    }
+}
+
 void Learner::CollectTimesteps() {
     Impl& m = *impl;
     const size_t rowObs = (size_t)m.nAgents * m.D;
     if (!m.first) HOST_HIP(hipMemcpyAsync(m.ObsAt(0), m.ObsAt(m.T), rowObs * 4, hipMemcpyDeviceToDevice, nullptr));
     m.first = false;
-    const bool slow = (bool)stepCallback;
-    if (slow && m.games.empty()) {
-        m.games.resize(m.nEnvs);
-        for (int e = 0; e < m.nEnvs; e++) { m.games[e].gym = m.gym; m.games[e].match = m.match; m.games[e].index = e; }
-        m.hostStates.resize(m.nEnvs); m.hostRew.resize(m.nAgents); m.hostDone.resize(m.nAgents);
+    const bool slow = (bool)stepCallback || m.plan.AnyHost();
+    if (slow && !m.hostReady) {   // a step callback was installed after construction
+        m.SetupHostPath(envCreateFn, config.numThreads);
+        m.EnvCheck(rlgpu_env_download_states(m.env, m.snaps.data(), nullptr, m.nEnvs), "download_states");
+        for (int e = 0; e < m.nEnvs; e++) m.prevGs[e] = RLGSC::GameState(m.snaps[e], m.tickSkip);
     }
     // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
     if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= 2) {   // 3v3: one env per wavefront, the in-kernel inference does not amortise
@@ -313,26 +464,9 @@ void Learner::CollectTimesteps() {
     for (int t = 0; t < m.T; t++) {
         const size_t o = (size_t)t * m.nAgents;
         m.LrnCheck(rlgpu_policy_act(m.lrn, m.ObsAt(t), m.nAgents, config.deterministic ? 1 : 0, nullptr, m.acts + o, m.logp + o), "policy_act");
-        m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
+        if (slow) m.HostStep(this, t);
+        else m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
         if (renderSender) RenderStep(t);
-        if (slow) {
-            // the reference hands every game's StepResult to the callback (GameInst.cpp:14-38): materialise host GameStates -- slow path.
-            // NB: the downloaded state is the one AFTER the step's auto-reset when the episode ended.
-            m.EnvCheck(rlgpu_env_download_states(m.env, m.hostStates.data(), nullptr, m.nEnvs), "download_states");
-            HOST_HIP(hipMemcpy(m.hostRew.data(), m.rew + o, (size_t)m.nAgents * 4, hipMemcpyDeviceToHost));
-            HOST_HIP(hipMemcpy(m.hostDone.data(), m.done + o, (size_t)m.nAgents * 4, hipMemcpyDeviceToHost));
-            for (int e = 0; e < m.nEnvs; e++) {
-                GameInst& g = m.games[e];
-                RLGSC::Gym::StepResult sr;
-                sr.state = RLGSC::GameState(m.hostStates[e], m.tickSkip);
-                sr.reward.assign(m.hostRew.begin() + (size_t)e * m.nPlayers, m.hostRew.begin() + (size_t)(e + 1) * m.nPlayers);
-                sr.done = m.hostDone[(size_t)e * m.nPlayers] != 0;
-                float sum = std::accumulate(sr.reward.begin(), sr.reward.end(), 0.f);
-                g.avgStepRew.Add(sum, (uint64_t)m.nPlayers); g.curEpRew += sum / m.nPlayers; g.totalSteps++;
-                if (sr.done) { g.avgEpRew += g.curEpRew; g.curEpRew = 0; }
-                stepCallback(&g, sr, g._metrics);
-            }
-        }
     }
     totalTimesteps += (uint64_t)m.B * (uint64_t)m.world;
 }

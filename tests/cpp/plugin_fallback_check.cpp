@@ -1,0 +1,311 @@
+// GPU check of the open plugin boundary (tests/test_host_cpp.py runs it): user subclasses of RewardFunction, OBSBuilder,
+// TerminalCondition, StateSetter and ActionParser -- written against include/ exactly as against the reference's headers -- run on the
+// host every step while the arenas stay on the device; the standalone Gym steps one arena through the same kernel.
+//   part 1  host forms == device forms: the built-in stack forced onto the host gives the device path's experience
+//   part 2  user plugins: rewards / dones / observations / resets are what the plugins compute, step callbacks see them, training runs
+//   part 3  Gym::Reset / Gym::Step / Arena facade
+#include <RLGymPPO_CPP/Learner.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/CombinedReward.h>
+#include <RLGymSim_CPP/Utils/RewardFunctions/ZeroSumReward.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
+#include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
+#include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
+#include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
+#include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
+#include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+
+using namespace RLGPC;
+using namespace RLGSC;
+
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+// ---- part 1: the built-ins with their device form switched off ---------------------------------------------------------------------
+struct HostOnlyReward : CombinedReward {
+    using CombinedReward::CombinedReward;
+    bool AddDeviceTerms(RlgpuGymConfig&, float) const override { return false; }
+};
+struct HostOnlyZeroSum : ZeroSumReward {
+    using ZeroSumReward::ZeroSumReward;
+    bool AddDeviceTerms(RlgpuGymConfig&, float) const override { return false; }
+};
+struct HostOnlyNoTouch : NoTouchCondition {
+    using NoTouchCondition::NoTouchCondition;
+    bool AddDeviceCondition(RlgpuGymConfig&) const override { return false; }
+};
+struct HostOnlyOBS : DefaultOBS {
+    bool ApplyToDevice(RlgpuGymConfig&) const override { return false; }
+};
+struct HostOnlyParser : DiscreteAction {
+    bool ApplyToDevice(RlgpuGymConfig&) const override { return false; }
+};
+
+static int g_teamSize = 1;
+static bool g_host = false, g_hostParser = false;
+static EnvCreateResult MakeBuiltinEnv() {
+    auto terms = std::vector<std::pair<RewardFunction*, float>>{
+        {new FaceBallReward(), 0.1f}, {new VelocityPlayerToBallReward(), 0.5f}, {new VelocityBallToGoalReward(), 1.0f}, {new TouchBallReward(0.5f), 2.f},
+        {new SaveBoostReward(), 0.3f}, {new VelocityReward(), 0.2f}, {new EventReward({.teamGoal = 1.f, .concede = -1.f, .touch = 0.5f, .boostPickup = 0.25f}), 10.f}};
+    RewardFunction* reward;
+    if (g_teamSize > 1) reward = g_host ? (RewardFunction*)new HostOnlyZeroSum(new CombinedReward(terms), 0.4f, 0.8f) : new ZeroSumReward(new CombinedReward(terms), 0.4f, 0.8f);
+    else reward = g_host ? (RewardFunction*)new HostOnlyReward(terms) : new CombinedReward(terms);
+    std::vector<TerminalCondition*> terminal = {g_host ? (TerminalCondition*)new HostOnlyNoTouch(12) : new NoTouchCondition(12), new GoalScoreCondition()};
+    OBSBuilder* obs = g_host ? (OBSBuilder*)new HostOnlyOBS() : new DefaultOBS();
+    ActionParser* parser = g_hostParser ? (ActionParser*)new HostOnlyParser() : new DiscreteAction();
+    Match* match = new Match(reward, terminal, obs, parser, new RandomState(true, true, false), g_teamSize, true);
+    return {match, new Gym(match, 8)};
+}
+
+static LearnerConfig SmallConfig(int envs, int steps, int players) {
+    LearnerConfig cfg = {};
+    cfg.numThreads = 4; cfg.numGamesPerThread = envs / 4;
+    cfg.timestepsPerIteration = (int64_t)envs * players * steps;
+    cfg.ppo.batchSize = cfg.timestepsPerIteration; cfg.ppo.miniBatchSize = cfg.timestepsPerIteration; cfg.expBufferSize = cfg.timestepsPerIteration;
+    cfg.ppo.epochs = 1; cfg.ppo.policyLayerSizes = {64, 64}; cfg.ppo.criticLayerSizes = {64, 64};
+    cfg.ppo.policyLR = cfg.ppo.criticLR = 3e-4f;
+    cfg.randomSeed = 77;
+    return cfg;
+}
+
+struct Collected { std::vector<float> obs, rew; std::vector<int32_t> acts, done; int D = 0, T = 0, agents = 0; };
+static Collected CollectOnce(bool host, bool hostParser, int teamSize, int envs, int steps, int iterations = 1) {
+    g_host = host; g_hostParser = hostParser; g_teamSize = teamSize;
+    Learner learner(MakeBuiltinEnv, SmallConfig(envs, steps, 2 * teamSize));
+    Collected c;
+    for (int i = 0; i < iterations; i++) learner.CollectTimesteps();
+    learner.CopyCollected(&c.obs, &c.acts, &c.rew, &c.done);
+    c.D = learner.obsSize; c.T = learner.StepsPerIteration(); c.agents = learner.NumAgents();
+    return c;
+}
+
+static int ComparePaths(int teamSize, bool hostParser) {
+    const int envs = 32, steps = 48;
+    Collected dev = CollectOnce(false, false, teamSize, envs, steps, 2), host = CollectOnce(true, hostParser, teamSize, envs, steps, 2);
+    CHECK(dev.D == host.D && dev.T == host.T && dev.agents == host.agents && dev.T == steps);
+    CHECK(dev.acts == host.acts);                       // same observations -> same sampled actions, step after step
+    CHECK(dev.done == host.done);
+    int dones = 0; for (int32_t d : dev.done) dones += d;
+    CHECK(dones > 0);                                   // episodes ended (and restarted through the host path) inside the window
+    double worstObs = 0, worstRew = 0, sumAbsRew = 0;
+    for (size_t i = 0; i < dev.obs.size(); i++) worstObs = std::max(worstObs, (double)std::fabs(dev.obs[i] - host.obs[i]));
+    for (size_t i = 0; i < dev.rew.size(); i++) { worstRew = std::max(worstRew, (double)std::fabs(dev.rew[i] - host.rew[i])); sumAbsRew += std::fabs(dev.rew[i]); }
+    std::printf("team size %d%s: %d dones, max |obs diff| %.3g, max |reward diff| %.3g (mean |reward| %.3g)\n", teamSize, hostParser ? " + host parser" : "", dones,
+                worstObs, worstRew, sumAbsRew / dev.rew.size());
+    CHECK(worstObs <= 1e-6);                            // same arithmetic on both sides: one multiply per value
+    CHECK(worstRew <= 2e-5);                            // sums of products: fp32 rounding order only
+    return 0;
+}
+
+// ---- part 2: plugins only a user would write ----------------------------------------------------------------------------------------
+struct BallHeightReward : RewardFunction {                  // stateless custom reward
+    float GetReward(const PlayerData& player, const GameState& state, const Action& prev) override {
+        return state.ball.pos.z / CommonValues::CEILING_Z + 0.01f * prev.throttle - (player.carState.isOnGround ? 0.f : 0.05f);
+    }
+};
+struct StepLimitCondition : TerminalCondition {             // per-episode state: needs its Reset hook and one instance per env
+    int steps = 0, limit;
+    StepLimitCondition(int limit) : limit(limit) {}
+    void Reset(const GameState&) override { steps = 0; }
+    bool IsTerminal(const GameState&) override { return ++steps >= limit; }
+};
+struct RangeOBS : DefaultOBS {                              // DefaultOBS plus three values of its own
+    FList BuildOBS(const PlayerData& player, const GameState& state, const Action& prevAction) override {
+        FList obs = DefaultOBS::BuildOBS(player, state, prevAction);
+        const Vec d = state.ball.pos - player.phys.pos;
+        obs += {d.Length() / 6000.f, (float)state.lastTickCount, (float)player.carId};
+        return obs;
+    }
+};
+struct BallOverCarSetter : StateSetter {                    // kickoff, then the ball 300 uu above blue's first car, falling
+    GameState ResetState(Arena* arena) override {
+        arena->ResetToRandomKickoff();
+        Car* first = arena->_cars[0];
+        CarState cs = first->GetState();
+        cs.boost = 77.f;
+        first->SetState(cs);
+        BallState bs;
+        bs.pos = cs.pos + Vec(0, 0, 300); bs.vel = Vec(0, 0, -100);
+        arena->ball->SetState(bs);
+        return GameState(arena);
+    }
+};
+struct EightWayParser : ActionParser {                      // 8 actions: throttle x steer x boost
+    int GetActionAmount() override { return 8; }
+    ActionSet ParseActions(const Input& in, const GameState&) override {
+        ActionSet out(in.size());
+        for (size_t i = 0; i < in.size(); i++) { out[i].throttle = (in[i] & 1) ? 1.f : -1.f; out[i].steer = (in[i] & 2) ? 1.f : -1.f; out[i].boost = (in[i] & 4) ? 1.f : 0.f; }
+        return out;
+    }
+};
+
+static std::atomic<int> g_envsMade{0};
+static EnvCreateResult MakeUserEnv() {
+    g_envsMade++;
+    Match* match = new Match(new BallHeightReward(), {new StepLimitCondition(5)}, new RangeOBS(), new EightWayParser(), new BallOverCarSetter(), 1, true);
+    return {match, new Gym(match, 8)};
+}
+
+static std::atomic<int> g_callbacks{0}, g_callbackErrors{0};
+static void CheckingCallback(GameInst* game, const Gym::StepResult& r, Report& metrics) {
+    g_callbacks++;
+    BallHeightReward again;
+    for (size_t i = 0; i < r.state.players.size(); i++) {
+        const float want = again.GetReward(r.state.players[i], r.state, game->match->prevActions[i]);
+        if (std::fabs(want - r.reward[i]) > 1e-6f) g_callbackErrors++;
+    }
+    if (r.obs.size() != 2 || r.obs[0].size() != 89 + 3) g_callbackErrors++;
+    metrics.AccumAvg("ball_height", r.state.ball.pos.z);
+}
+
+static int UserPlugins() {
+    const int envs = 16, steps = 12;
+    LearnerConfig cfg = SmallConfig(envs, steps, 2);
+    Learner learner(MakeUserEnv, cfg);
+    CHECK(g_envsMade == envs);                          // one plugin set per game, like the reference's GameInsts
+    CHECK(learner.obsSize == 89 + 3 && learner.actionAmount == 8);
+    learner.stepCallback = CheckingCallback;
+    learner.CollectTimesteps();
+    Collected c;
+    learner.CopyCollected(&c.obs, &c.acts, &c.rew, &c.done);
+    const int D = learner.obsSize, N = learner.NumAgents(), T = learner.StepsPerIteration();
+    CHECK(T == steps && g_callbacks == envs * steps && g_callbackErrors == 0);
+    for (int t = 0; t < T; t++)
+        for (int a = 0; a < N; a++) {
+            CHECK(c.done[(size_t)t * N + a] == ((t + 1) % 5 == 0 ? 1 : 0));        // StepLimitCondition(5), counted per env on the host
+            CHECK(c.acts[(size_t)t * N + a] >= 0 && c.acts[(size_t)t * N + a] < 8);
+            const float* row = &c.obs[((size_t)(t + 1) * N + a) * D];
+            CHECK(row[D - 1] == (float)(a % 2 + 1));                               // RangeOBS's own values arrive in the policy's input
+            const float* prevAct = row + 9;                                        // DefaultOBS: ball (9) | previous action (8) | ...
+            if ((t + 1) % 5 == 0) {
+                // first observation of the next episode, from BallOverCarSetter: ball 300 uu above blue's first car, no previous action
+                const float* blueCar = (a % 2 == 0) ? row + 51 : row + 51 + 19;    // own block for blue, the opponent block for orange
+                const float sx = (a % 2 == 0) ? 1.f : -1.f;                        // orange sees the mirrored field
+                CHECK(std::fabs(row[0] - blueCar[0]) < 1e-6f && std::fabs(row[1] - blueCar[1]) < 1e-6f);
+                CHECK(std::fabs(row[2] * CommonValues::CEILING_Z - (17.f + 300.f)) < 1e-2f);
+                CHECK(std::fabs(row[5] * CommonValues::CAR_MAX_SPEED - (-100.f)) < 1e-3f);
+                CHECK(std::fabs(blueCar[15] - 0.77f) < 1e-6f);                     // boost fraction set through Car::SetState
+                (void)sx;
+                for (int j = 0; j < 8; j++) CHECK(prevAct[j] == 0.f);
+            } else {
+                const int32_t act = c.acts[(size_t)t * N + a];                     // EightWayParser's controls, as the obs builder saw them
+                CHECK(prevAct[0] == ((act & 1) ? 1.f : -1.f) && prevAct[1] == ((act & 2) ? 1.f : -1.f) && prevAct[6] == ((act & 4) ? 1.f : 0.f));
+            }
+        }
+    // the rewards in the experience buffer are BallHeightReward's
+    double sum = 0; for (float r : c.rew) sum += r;
+    CHECK(sum > 0 && std::isfinite(sum));
+    std::vector<Report> perGame = learner.GetAllGameMetrics();
+    CHECK((int)perGame.size() == envs && perGame[3].Has("ball_height_avg_count"));
+    // and it trains: two full iterations with finite statistics
+    int iterations = 0; bool finite = true;
+    learner.stepCallback = nullptr;
+    learner.iterationCallback = [&](Learner* l, Report& report) {
+        iterations++;
+        finite = finite && std::isfinite(report["Policy Entropy"]) && std::isfinite(report["Value Function Loss"]) && report["Policy Entropy"] > 0;
+        if (iterations == 2) l->config.timestepLimit = 1;
+    };
+    setenv("RLGPU_QUIET", "1", 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    learner.Learn();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(iterations == 2 && finite);
+    std::printf("user plugins: %d envs x %d steps per iteration, 2 iterations in %.2f s\n", envs, steps, secs);
+    return 0;
+}
+
+// throughput of the paths that leave the device every step, for DESIGN.md: agent-steps per second of CollectTimesteps()
+static void StepCounter(GameInst*, const Gym::StepResult&, Report&) {}
+static int Throughput() {
+    const int envs = 1024, steps = 16;
+    for (int mode = 0; mode < 3; mode++) {
+        g_host = mode == 2; g_hostParser = false; g_teamSize = 1;
+        Learner learner(MakeBuiltinEnv, SmallConfig(envs, steps, 2));
+        if (mode == 1) learner.stepCallback = StepCounter;
+        learner.CollectTimesteps();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 3; i++) learner.CollectTimesteps();
+        std::vector<int32_t> d; learner.CopyCollected(nullptr, nullptr, nullptr, &d);
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const char* name[3] = {"all plugins on the device", "device plugins + step callback", "reward, obs, terminal conditions on the host"};
+        std::printf("collection, %d envs 1v1: %-46s %10.0f agent-steps/s\n", envs, name[mode], 3.0 * envs * 2 * steps / secs);
+    }
+    return 0;
+}
+
+// ---- part 3: the standalone Gym ------------------------------------------------------------------------------------------------------
+static int StandaloneGym() {
+    RocketSim::Math::SeedRandEngine(5);
+    CombinedReward reward({{new VelocityPlayerToBallReward(), 1.f}, {new EventReward({.touch = 1.f}), 1.f}}, true);
+    NoTouchCondition noTouch(400); GoalScoreCondition goal; DefaultOBS obs; DiscreteAction parser; KickoffState kickoff;
+    Match match(&reward, {&noTouch, &goal}, &obs, &parser, &kickoff, 1, true);
+    Gym gym(&match, 8);
+    CHECK(gym.arena && gym.arena->_cars.size() == 2 && gym.carIds.size() == 2 && gym.arena->_boostPads.size() == 34 && gym.actionDelay == 7);
+    FList2 first = gym.Reset();
+    CHECK(first.size() == 2 && first[0].size() == 89);
+    const CarState blue = gym.arena->_cars[0]->GetState(), orange = gym.arena->_cars[1]->GetState();
+    CHECK(blue.pos.y < 0 && std::fabs(blue.pos.x + orange.pos.x) < 1e-3f && std::fabs(blue.pos.y + orange.pos.y) < 1e-3f && blue.pos.z == 17.f);   // mirrored kickoff spots
+    CHECK(gym.arena->ball->GetState().pos.z == RLConst::BALL_REST_Z && gym.prevState.players.size() == 2);
+    // full throttle + boost straight at the ball (action row: throttle 1, steer 0, ..., boost 1): both cars reach it
+    ActionParser::Input drive(2, 0);
+    {
+        ActionSet probe; int best = -1;
+        for (int a = 0; a < parser.GetActionAmount(); a++) {
+            probe = parser.ParseActions({a, a}, gym.prevState);
+            if (probe[0].throttle == 1 && probe[0].steer == 0 && probe[0].boost == 1 && probe[0].jump == 0 && probe[0].handbrake == 0 && probe[0].pitch == 0 && probe[0].yaw == 0) { best = a; break; }
+        }
+        CHECK(best >= 0);
+        drive = {best, best};
+    }
+    const uint64_t tick0 = gym.arena->tickCount;
+    bool touched = false, done = false; float total = 0; int stepsTaken = 0;
+    for (int i = 0; i < 120 && !done; i++) {
+        Gym::StepResult r = gym.Step(drive);
+        stepsTaken++;
+        CHECK(r.obs.size() == 2 && r.obs[0].size() == 89 && r.reward.size() == 2 && r.state.players.size() == 2);
+        CHECK(r.state.deltaTickCount == (i == 0 ? 1 : 8));                                                  // GameState is taken one tick into the step
+        CHECK(gym.arena->tickCount == tick0 + 8ull * (uint64_t)(i + 1) && r.state.lastTickCount == gym.arena->tickCount - 7);
+        touched = touched || r.state.players[0].ballTouchedStep || r.state.players[1].ballTouchedStep;
+        total += r.reward[0];
+        done = r.done;
+    }
+    CHECK(touched && total > 1.f && gym.totalSteps == stepsTaken && gym.totalTicks == 8 * stepsTaken);
+    const float yAfter = gym.arena->_cars[0]->GetState().pos.y;
+    CHECK(yAfter > blue.pos.y + 500.f);
+    // the arena can be edited between steps through the facade: teleport the ball into the orange goal -> GoalScoreCondition ends the episode
+    BallState in; in.pos = Vec(0, 5300, 200); in.vel = Vec(0, 500, 0);
+    gym.arena->ball->SetState(in);
+    Gym::StepResult scored = gym.Step(drive);
+    CHECK(scored.done && scored.state.scoreLine[0] == 1 && scored.state.scoreLine[1] == 0);
+    // Arena::Step on its own (no gym layer): the ball falls
+    Arena* arena = Arena::Create(GameMode::SOCCAR);
+    arena->AddCar(Team::BLUE); arena->AddCar(Team::ORANGE);
+    arena->ResetToRandomKickoff(123);
+    BallState up; up.pos = Vec(0, 0, 1000);
+    arena->ball->SetState(up);
+    arena->Step(60);
+    const BallState fell = arena->ball->GetState();
+    CHECK(arena->tickCount == 60 && fell.pos.z < 1000.f - 70.f && fell.pos.z > 1000.f - 90.f && fell.vel.z < -300.f);   // 0.5 s of -650 uu/s^2
+    delete arena;
+    std::printf("standalone gym: %d steps to the first touch-and-beyond, reward %.2f\n", stepsTaken, total);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    RocketSim::Init("./collision_meshes", true);
+    setenv("RLGPU_QUIET", "1", 1);
+    try {
+        if (argc > 1 && std::string(argv[1]) == "throughput") return Throughput();
+        if (ComparePaths(1, false)) return 1;
+        if (ComparePaths(2, true)) return 1;
+        if (UserPlugins()) return 1;
+        if (StandaloneGym()) return 1;
+    } catch (const std::exception& e) {
+        std::printf("exception: %s\n", e.what());
+        return 1;
+    }
+    std::printf("plugin fallback ok\n");
+    return 0;
+}

@@ -40,7 +40,7 @@ def test_host_api_translation_and_utils(tmp_path):
 
 def test_example_program_is_built():
     """CPU: build() produced the host library and the example program written against the reference's API."""
-    for f in ("librlgymppo_amd.so", "example_main", "infer_unit_check"):
+    for f in ("librlgymppo_amd.so", "example_main", "infer_unit_check", "bench_main", "plugin_fallback_check"):
         assert os.path.exists(os.path.join(PKG, f)), f
 
 
@@ -95,6 +95,15 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     assert all(len(g["cars"]) == 2 and len(g["boost_pad_states"]) == 34 and g["gamemode"] == "soccar" for g in grams)
     assert grams[0]["cars"][0]["phys"]["pos"] != grams[-1]["cars"][0]["phys"]["pos"]          # the policy is driving
     assert sorted(os.listdir(ck)) == before_render                                               # render mode saves nothing
+
+
+@pytest.mark.gpu
+def test_user_plugins_run_on_the_host_and_standalone_gym(tmp_path):
+    """GPU: tests/cpp/plugin_fallback_check.cpp -- user RewardFunction / OBSBuilder / TerminalCondition / StateSetter / ActionParser subclasses
+    compiled against include/ train through the Learner (their kinds on the host, the arenas on the device), the built-ins' host forms
+    reproduce the device path's experience, and a standalone Gym resets / steps its Arena facade."""
+    r = _run([os.path.join(PKG, "plugin_fallback_check")], cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0 and "plugin fallback ok" in r.stdout, r.stdout[-4000:]
 
 
 def test_reference_example_source_compiles_unchanged():
