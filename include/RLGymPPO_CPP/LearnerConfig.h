@@ -41,5 +41,9 @@ struct LearnerConfig {
     // 0 = the reference's ComputeGAE as is: at a truncated trajectory end the bootstrap value is the NEXT ROW of the concatenated batch,
     // i.e. the first state of the neighbouring trajectory (TorchFuncs.cpp:36); 1 = the agent's own V(s_T)
     int gaeNextValueMode = 0;
+    // The example program's per-step metrics without a step callback: the step kernels accumulate them from every step's GameState and each
+    // iteration's report gets "player_speed" (mean |car velocity|, uu/s), "ball_touch_ratio" and "in_air_ratio" (fractions of player-steps)
+    // -- collection stays in one launch instead of leaving the device every step (rlgpu_env_enable_step_stats)
+    bool deviceStepMetrics = false;
 };
 }

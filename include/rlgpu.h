@@ -101,6 +101,12 @@ int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_se
 int rlgpu_env_enable_snapshots(rlgpu_env* e, int on);
 int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host_states, int first_env, int n);
 
+/* The per-step player statistics the reference's example program gathers in its step callback (examplemain.cpp:23-36: speed, touch
+ * ratio, airborne ratio), accumulated by the step kernels from every step's GameState so that they cost no host work:
+ * out4 = {player-steps, sum of |car velocity| in uu/s, ball touches, airborne player-steps} since the last reset. */
+int rlgpu_env_enable_step_stats(rlgpu_env* e, int on);
+int rlgpu_env_step_stats(rlgpu_env* e, float* out4, int reset);
+
 /* Gym::Step + GameInst auto-reset for every env (SIM/Gym.cpp:68-102, PUB/Threading/GameInst.cpp:7-38):
  * actions_dev [num_agents] int32 ; next_obs_dev [num_agents x obs_size] (post-reset obs when done);
  * reward_dev [num_agents] ; done_dev [num_agents] int32 (the env's done replicated to its players). */

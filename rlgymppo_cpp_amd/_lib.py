@@ -74,6 +74,8 @@ SIGNATURES = {
     "rlgpu_env_download_snapshots": (_i, [_vp, _vp, _i, _i]),
     "rlgpu_env_step_controls": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rlgpu_pad_location": (_i, [_i, _vp, _vp]),
+    "rlgpu_env_enable_step_stats": (_i, [_vp, _i]),
+    "rlgpu_env_step_stats": (_i, [_vp, _vp, _i]),
     "rlgpu_env_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rlgpu_env_physics_ticks": (_i, [_vp, _i]),
     "rlgpu_env_sync": (_i, [_vp]),

@@ -70,6 +70,7 @@ struct EnvDev {
     const float* action_table;
     GymConfig cfg;
     int n_envs;
+    float* step_stats;           // rlgpu_env_enable_step_stats: {player-steps, sum |car vel| (uu/s), ball touches, airborne} accumulated by the step kernels, or null
     RlgpuArenaState* snap_out;   // host-plugin fallback (rlgpu_env_enable_snapshots): every step's GameState source, [n_envs], or null
 };
 
@@ -419,6 +420,22 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     wave_sync();
 }
 
+// per-step player statistics of the step's GameState (what the example program's step callback averages: examplemain.cpp:23-36), kept
+// in registers by the env lanes and added to the env batch's totals once per launch
+struct StepStats { float speed = 0.f, touches = 0.f, airborne = 0.f, count = 0.f; };
+template <int NC>
+__device__ void step_stats_add(StepStats& st, const Snapshot<NC>& S) {
+    for (int k = 0; k < NC; k++) { st.speed += len(S.car_vel[k]); st.touches += S.touched[k] ? 1.f : 0.f; st.airborne += S.on_ground[k] ? 0.f : 1.f; st.count += 1.f; }
+}
+__device__ void step_stats_flush(float* out, StepStats st, int lane) {
+    float v[4] = {st.count, st.speed, st.touches, st.airborne};
+    for (int i = 0; i < 4; i++) {
+        float x = v[i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0 && x != 0.f) atomicAdd(&out[i], x);
+    }
+}
+
 template <int NC>
 __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     constexpr int LANES = lanes_per_block<NC>();
@@ -453,6 +470,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * NC * D, (size_t)D, snap);
     // host plugins see what the reference's see: the arena as it stands where Gym::Step builds its GameState (Gym.cpp:81-93)
     if (d.snap_out && env_lane) arena_to_host(S.A, S.G, d.snap_out[env]);
+    if (d.step_stats) { StepStats st; if (env_lane) step_stats_add<NC>(st, snap); step_stats_flush(d.step_stats, st, ws.lane); }
     wave_sync();
     RLG_PROF(9);
     for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
@@ -516,6 +534,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #endif
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     wave_sync();
+    StepStats stats;
     for (int t = 0; t < c.T; t++) {
 #ifdef RLG_TICK_PROFILE
         const unsigned long long prof_a = __builtin_amdgcn_s_memtime();
@@ -551,6 +570,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);
         float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
         if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
+        if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
         wave_sync();
         for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
         if (env_lane) {
@@ -560,6 +580,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         wave_sync();
     }
+    if (d.step_stats) step_stats_flush(d.step_stats, stats, ws.lane);
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     // profiler build: this workgroup's total and inference cycles (read back with rlgpu_env_debug_step_prof)
@@ -748,6 +769,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_grid) (void)hipFree(e->d_grid);
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
+    if (e->d.step_stats) (void)hipFree(e->d.step_stats);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
 }
@@ -858,6 +880,26 @@ int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_se
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     (void)hipFree(dids);
+    return RLGPU_OK;
+}
+
+int rlgpu_env_enable_step_stats(rlgpu_env* e, int on) {
+    HIPCHK(e, hipSetDevice(e->device));
+    if (on && !e->d.step_stats) {
+        HIPCHK(e, hipMalloc(&e->d.step_stats, 4 * sizeof(float)));
+        HIPCHK(e, hipMemsetAsync(e->d.step_stats, 0, 4 * sizeof(float), e->stream));
+    } else if (!on && e->d.step_stats) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        (void)hipFree(e->d.step_stats); e->d.step_stats = nullptr;
+    }
+    return RLGPU_OK;
+}
+int rlgpu_env_step_stats(rlgpu_env* e, float* out4, int reset) {
+    if (!e->d.step_stats) { e->err = "rlgpu_env_step_stats: call rlgpu_env_enable_step_stats first"; return RLGPU_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(out4, e->d.step_stats, 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (reset) HIPCHK(e, hipMemsetAsync(e->d.step_stats, 0, 4 * sizeof(float), e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     return RLGPU_OK;
 }
 

@@ -96,6 +96,37 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_step(self.h, actions.data_ptr(), next_obs.data_ptr(), reward.data_ptr(), done.data_ptr()),
              self.h, self.lib.rlgpu_env_last_error)
 
+    def step_controls(self, controls: torch.Tensor, next_obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor):
+        """The step with host-parsed controls: one Action row (8 floats) per agent (rlgpu_env_step_controls)."""
+        assert controls.dtype == torch.float32 and controls.is_contiguous() and controls.shape == (self.n_agents, 8)
+        _chk(self.lib.rlgpu_env_step_controls(self.h, controls.data_ptr(), next_obs.data_ptr(), reward.data_ptr(), done.data_ptr()),
+             self.h, self.lib.rlgpu_env_last_error)
+
+    def reset_envs(self, env_ids, run_setter=True, obs: "torch.Tensor | None" = None):
+        """Gym::Reset for the listed envs only; writes only their rows of `obs` (rlgpu_env_reset_envs)."""
+        ids = np.ascontiguousarray(env_ids, np.int32)
+        _chk(self.lib.rlgpu_env_reset_envs(self.h, ids.ctypes.data, len(ids), 1 if run_setter else 0, obs.data_ptr() if obs is not None else None),
+             self.h, self.lib.rlgpu_env_last_error)
+
+    def enable_snapshots(self, on=True):
+        _chk(self.lib.rlgpu_env_enable_snapshots(self.h, 1 if on else 0), self.h, self.lib.rlgpu_env_last_error)
+
+    def download_snapshots(self, first_env=0, n=None):
+        """Every env's arena as it stood where the last step built its GameState (after the first tick + event tracker)."""
+        n = self.n_envs - first_env if n is None else n
+        arr = (ArenaState * n)()
+        _chk(self.lib.rlgpu_env_download_snapshots(self.h, C.addressof(arr), first_env, n), self.h, self.lib.rlgpu_env_last_error)
+        return list(arr)
+
+    def enable_step_stats(self, on=True):
+        _chk(self.lib.rlgpu_env_enable_step_stats(self.h, 1 if on else 0), self.h, self.lib.rlgpu_env_last_error)
+
+    def step_stats(self, reset=True):
+        """{player-steps, sum |car vel|, ball touches, airborne player-steps} accumulated by the step kernels since the last reset."""
+        out = (C.c_float * 4)()
+        _chk(self.lib.rlgpu_env_step_stats(self.h, C.addressof(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return np.array(out[:], np.float64)
+
     def collect(self, ppo, T: int, obs: torch.Tensor, actions: torch.Tensor, logp: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, deterministic=False) -> bool:
         """T x (policy act + gym step) in one launch (rlgpu_collect).  obs: [T+1][n_agents][D] with obs[0] current; the others [T][n_agents].
         Returns False -- nothing launched -- when the policy does not fit the in-kernel inference (the caller then alternates act / step)."""

@@ -185,6 +185,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     int rc = rlgpu_env_create(&m.env, m.device, m.nEnvs, m.match->teamSize, &gcfg);
     m.EnvCheck(rc, "create");
     RLGSC::LoadArenaMesh(m.env, m.rank != 0 || std::getenv("RLGPU_QUIET"));
+    if (config.deviceStepMetrics) m.EnvCheck(rlgpu_env_enable_step_stats(m.env, 1), "enable_step_stats");
     m.nAgents = rlgpu_env_num_agents(m.env); m.Ddev = m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);
     if (m.plan.AnyHost()) {
         if (m.rank == 0 && !std::getenv("RLGPU_QUIET"))
@@ -586,6 +587,12 @@ void Learner::Learn() {
         CollectTimesteps();
         HOST_HIP(hipDeviceSynchronize());
         double collectTime = tCollect.Elapsed();
+        if (config.deviceStepMetrics) {   // what examplemain.cpp's step callback averages, from the device's running totals of this iteration
+            float st[4];
+            m.EnvCheck(rlgpu_env_step_stats(m.env, st, 1), "step_stats");
+            const double n = std::max(1.f, st[0]);
+            report["player_speed"] = st[1] / n; report["ball_touch_ratio"] = st[2] / n; report["in_air_ratio"] = st[3] / n;
+        }
         Timer tConsume;
         AddNewExperience(report);
         LearnPPO(report);

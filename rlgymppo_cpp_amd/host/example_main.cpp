@@ -16,7 +16,9 @@ using namespace RLGSC;
 
 static int g_iterations_left = 2;
 
-// per-step metrics (slow path: the learner materialises every game's GameState on the host for this)
+// per-step metrics the reference's way (examplemain.cpp:23-36).  A step callback makes the learner hand every game's GameState to the
+// host each step; LearnerConfig::deviceStepMetrics gives the same three numbers from the step kernels -- this program uses that unless
+// EXAMPLE_STEP_CALLBACK is set
 static void StepMetrics(GameInst* game, const Gym::StepResult& result, Report& metrics) {
     for (const PlayerData& player : result.state.players) {
         metrics.AccumAvg("player_speed", player.phys.vel.Length());
@@ -31,7 +33,7 @@ static void IterationMetrics(Learner* learner, Report& all) {
         if (!r.Has("player_speed_avg_count")) continue;
         speed += (float)r.GetAvg("player_speed"); touch += (float)r.GetAvg("ball_touch_ratio"); air += (float)r.GetAvg("in_air_ratio");
     }
-    all["player_speed"] = speed.Get(); all["ball_touch_ratio"] = touch.Get(); all["in_air_ratio"] = air.Get();
+    if (speed.count > 0) { all["player_speed"] = speed.Get(); all["ball_touch_ratio"] = touch.Get(); all["in_air_ratio"] = air.Get(); }
     if (--g_iterations_left <= 0) learner->config.timestepLimit = 1;   // stop after this iteration
 }
 
@@ -75,13 +77,15 @@ int main(int argc, char** argv) {
         cfg.skillTrackerConfig.timestepsPerVersion = tsPerItr; cfg.skillTrackerConfig.maxVersions = 2;
         cfg.timestepsPerSave = tsPerItr;   // every version has its checkpoint, so a resumed run finds them (Learner.cpp:311-370)
     }
+    const bool useStepCallback = getenv("EXAMPLE_STEP_CALLBACK") != nullptr;
+    cfg.deviceStepMetrics = !useStepCallback;
     cfg.checkpointSaveFolder = argc > 5 ? argv[5] : "";
     cfg.checkpointLoadFolder = cfg.checkpointSaveFolder;
 
     try {
         Learner learner(MakeEnv, cfg);
         if (cfg.renderMode) learner.config.timestepLimit = learner.totalTimesteps + (uint64_t)std::max(g_iterations_left, 1) * 2;   // here "iterations" = rendered 1v1 steps
-        learner.stepCallback = StepMetrics;
+        if (useStepCallback) learner.stepCallback = StepMetrics;
         learner.iterationCallback = IterationMetrics;
         learner.Learn();
     } catch (const std::exception& e) {

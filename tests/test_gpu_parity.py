@@ -746,3 +746,66 @@ def test_rccl_communicator_through_the_cabi_and_rank_keyed_sampler():
         draws.append(a.cpu().numpy().copy())
         assert c.get_sampler() == (stream, 1)
     assert np.array_equal(draws[0], draws[2]) and (draws[0] != draws[1]).mean() > 0.5
+
+
+# ---- the host-plugin boundary of the C-ABI: snapshots, masked reset, host-parsed controls, device step statistics ----
+def test_snapshots_masked_reset_controls_step_and_step_stats():
+    """rlgpu_env_enable_snapshots / download_snapshots: the snapshot is the arena one tick into the step, and the rewards / dones the kernel
+    wrote follow from it; rlgpu_env_step_controls with the table rows of the chosen actions == rlgpu_env_step; rlgpu_env_reset_envs resets
+    exactly the listed envs; rlgpu_env_step_stats == the sums over the snapshots."""
+    from rlgymppo_cpp_amd import _lib
+    from rlgymppo_cpp_amd.env import BatchedEnv, action_table
+    n_envs, team, K = 96, 2, 40
+    g = _lib.default_gym_config(); g.no_touch_max_steps = 15
+    envs = [BatchedEnv(n_envs, team, cfg=g) for _ in range(2)]
+    a, b = envs
+    a.enable_snapshots(); a.enable_step_stats()
+    dev = torch.device("cuda", 0)
+    N, D = a.n_agents, a.obs_size
+    table = torch.from_numpy(action_table()).to(dev)
+    obs = [e.reset(True) for e in envs]
+    assert torch.equal(obs[0], obs[1])
+    rng = np.random.RandomState(9)
+    o = [torch.empty((N, D), device=dev) for _ in envs]; r = [torch.empty(N, device=dev) for _ in envs]; d = [torch.empty(N, dtype=torch.int32, device=dev) for _ in envs]
+    tot = np.zeros(4); tick0 = np.array([s.tick_count for s in a.download_states()])
+    ended = 0
+    for k in range(K):
+        acts = torch.from_numpy(rng.randint(0, 90, N).astype(np.int32)).to(dev)
+        a.step(acts, o[0], r[0], d[0])
+        b.step_controls(table[acts.long()].contiguous(), o[1], r[1], d[1])
+        torch.cuda.synchronize()
+        assert torch.equal(o[0], o[1]) and torch.equal(r[0], r[1]) and torch.equal(d[0], d[1]), k
+        snaps = a.download_snapshots()
+        after = a.download_states()
+        dn = d[0].view(n_envs, 2 * team)[:, 0].cpu().numpy()
+        for e in range(n_envs):
+            s = snaps[e]
+            assert s.tick_count == tick0[e] + 1                                 # one tick into the step
+            for c in range(2 * team):
+                car = s.cars[c]
+                tot += [1, float(np.linalg.norm(car.vel[:])), float(bool(car.flags & (1 << 14)) and car.bh_tick_hit >= s.tick_count - g.tick_skip),
+                        float(not (car.flags & 1))]
+            if not dn[e]:
+                assert after[e].tick_count == s.tick_count + g.tick_skip - 1
+        ended += int(dn.sum())
+        tick0 = np.array([s.tick_count for s in after])
+    assert ended > 0
+    got = a.step_stats(reset=True)
+    assert got[0] == tot[0] == K * N
+    assert abs(got[1] - tot[1]) <= 1e-4 * tot[1] and abs(got[3] - tot[3]) < 0.5
+    assert abs(got[2] - tot[2]) <= max(2, ended)   # the touch window of an episode's first step is 1 tick, not tick_skip (PlayerData.cpp:20-25)
+    assert a.step_stats()[0] == 0
+    # masked reset: only the listed envs change
+    before = a.download_states()
+    ids = [3, 17, 64]
+    rows = torch.full((N, D), -7.0, device=dev)
+    a.reset_envs(ids, run_setter=True, obs=rows)
+    torch.cuda.synchronize()
+    now = a.download_states()
+    for e in range(n_envs):
+        same = bytes(before[e]) == bytes(now[e])
+        assert same == (e not in ids), e
+        block = rows.view(n_envs, 2 * team, D)[e]
+        assert bool((block == -7.0).all()) == (e not in ids)
+    for e in ids:
+        assert now[e].gym.episode_steps == 0 and now[e].gym.score_line[0] == 0 and now[e].gym.reset_count == before[e].gym.reset_count + 1

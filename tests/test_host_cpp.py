@@ -52,6 +52,7 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     r = _run([exe, "2", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ITERATION COMPLETED") == 2 and "player_speed" in r.stdout and "Policy Entropy" in r.stdout
+    first_run_out = r.stdout
     saved = sorted(int(d) for d in os.listdir(ck))
     assert saved and saved[-1] == 2 * 4096, saved
     for f in ("RUNNING_STATS.json", "PPO_POLICY.lt", "PPO_CRITIC.lt", "PPO_POLICY_OPTIM.lt", "PPO_CRITIC_OPTIM.lt"):
@@ -69,8 +70,13 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     L = Learner(cfg)
     assert L.load() and L.total_timesteps == 2 * 4096
     # and the C++ host resumes from it
-    r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600)
+    # ... this time with the reference's step callback (every game's GameState on the host each step) instead of the device-side metrics
+    r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=dict(os.environ, EXAMPLE_STEP_CALLBACK="1"))
     assert r.returncode == 0 and "loaded checkpoint" in r.stdout and str(3 * 4096) in os.listdir(ck), r.stdout[-3000:]
+    def metric(out, name):
+        return float([l for l in out.splitlines() if l.strip().startswith("[metric] " + name)][-1].split(":")[-1].replace(",", ""))
+    assert 100 < metric(r.stdout, "player_speed") < 2300 and 0 <= metric(r.stdout, "in_air_ratio") <= 1
+    assert 100 < metric(first_run_out, "player_speed") < 2300 and 0 <= metric(first_run_out, "ball_touch_ratio") <= 1   # LearnerConfig::deviceStepMetrics
     # metrics: one JSON-lines file for the run; the resumed process continued it under the run id stored in RUNNING_STATS.json
     import json
     mdir = tmp_path / "metrics" / "rlgymppo-cpp"
