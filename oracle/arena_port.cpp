@@ -5,7 +5,7 @@
 // rlgymppo_cpp_amd/csrc/arena_*.h as host/device-neutral inline functions; this file compiles those headers
 // for the CPU and exposes them to the tests.  It is the "port" CPU restatement of the stepper:
 //   * pinned against the REAL reference (oracle/_ref, golden trajectories under tests/golden/) by
-//     tests/test_arena_port_vs_ref.py, and
+//     tests/test_oracle_golden.py, and
 //   * used by the -m gpu tests as the tick-by-tick oracle of the HIP kernel (same source, different
 //     compiler/ISA: agreement is to fp32 rounding of libm calls).
 // The dependency runs oracle -> product headers only; nothing in rlgymppo_cpp_amd/ includes, links or calls
