@@ -17,72 +17,83 @@
 
 namespace rlg {
 
+// The two shapes of one query.  A support point is a box corner (3 sign bits) or a triangle vertex (2 bits): the simplex remembers
+// that code per vertex instead of the two support points (24 floats), and rebuilds them -- with the expressions that produced them, so
+// bit for bit -- where btVoronoiSimplexSolver reads its m_simplexPointsP / Q arrays.
+// Selections between vectors go through scalar prvalues: `c ? a : b` on two V3 lvalues is itself an lvalue -- the compiler selects the
+// ADDRESS and copies from it, and an object read through a computed address cannot be kept in registers.
+RLG_HD float gjk_fsel(bool c, float a, float b) { return c ? a : b; }
+RLG_HD V3 gjk_sel(bool c, V3 a, V3 b) { return v3(gjk_fsel(c, a.x, b.x), gjk_fsel(c, a.y, b.y), gjk_fsel(c, a.z, b.z)); }
+
+struct GjkShapes {
+    M3 R; V3 core; V3 oa, ob; V3 t0, t1, t2;
+    RLG_HD V3 point_a(uint32_t code) const { return (R * v3((code & 1u) ? core.x : -core.x, (code & 2u) ? core.y : -core.y, (code & 4u) ? core.z : -core.z)) + oa; }
+    RLG_HD V3 point_b(uint32_t code) const { const uint32_t k = (code >> 3) & 3u; return gjk_sel(k == 0, t0, gjk_sel(k == 1, t1, t2)) + ob; }
+};
+
 struct GjkSimplex {
-    V3 w[4], p[4], q[4];    // Minkowski point, support point on A, on B
+    V3 w0, w1, w2, w3;      // Minkowski points
+    uint32_t codes;         // 5 bits per vertex: which corner of A, which vertex of B
     int n;
     V3 last_w;
     V3 cp1, cp2, cv;        // cached closest points on A / B and their difference
-    float bc[4];            // barycentric coordinates of the closest point
-    bool used[4];
+    float bc0, bc1, bc2, bc3;   // barycentric coordinates of the closest point
+    uint32_t used;          // bit k: vertex k supports the closest point
     bool degenerate, needs_update, valid;
 };
 
-// (Every slot of the simplex is addressed with compile-time indices -- appends and the "move the last vertex into the hole" of
-// removeVertex go through compare chains on the count -- so that on the device the 36 floats stay in registers: indexed by s.n they
-// sat in scratch memory, and a hitbox-triangle item was ~5x the cycles of the SAT routine it replaced.)
-RLG_HD V3 gjk_pick(const V3 (&a)[4], int k) { return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3])); }
-template <int I>
-RLG_HD void gjk_remove_vertex(GjkSimplex& s) { s.n--; const int k = s.n; s.w[I] = gjk_pick(s.w, k); s.p[I] = gjk_pick(s.p, k); s.q[I] = gjk_pick(s.q, k); }
-RLG_HD void gjk_append(GjkSimplex& s, V3 w, V3 p, V3 q) {
-    if (s.n == 0) { s.w[0] = w; s.p[0] = p; s.q[0] = q; }
-    else if (s.n == 1) { s.w[1] = w; s.p[1] = p; s.q[1] = q; }
-    else if (s.n == 2) { s.w[2] = w; s.p[2] = p; s.q[2] = q; }
-    else { s.w[3] = w; s.p[3] = p; s.q[3] = q; }
-    s.n++;
+// (No slot of the simplex is ever addressed with a run-time index -- appends, the "move the last vertex into the hole" of
+// removeVertex and the face loop of the tetrahedron case go through compare chains -- so that on the device all of it stays in
+// registers: indexed by s.n it sat in scratch memory, and a hitbox-triangle item was ~5x the cycles of the SAT routine it replaced.)
+RLG_HD V3 gjk_w(const GjkSimplex& s, int k) { return gjk_sel(k == 0, s.w0, gjk_sel(k == 1, s.w1, gjk_sel(k == 2, s.w2, s.w3))); }
+RLG_HD uint32_t gjk_code(const GjkSimplex& s, int k) { return (s.codes >> (5 * k)) & 31u; }
+RLG_HD void gjk_set_slot(GjkSimplex& s, int k, V3 w, uint32_t code) {
+    // every slot is assigned, by value: conditional stores would be merged into one store through a selected POINTER, and an object
+    // addressed that way stays in (scratch) memory (gjk_sel: likewise for reads)
+    s.w0 = gjk_sel(k == 0, w, s.w0); s.w1 = gjk_sel(k == 1, w, s.w1); s.w2 = gjk_sel(k == 2, w, s.w2); s.w3 = gjk_sel(k == 3, w, s.w3);
+    s.codes = (s.codes & ~(31u << (5 * k))) | (code << (5 * k));
 }
+RLG_HD void gjk_remove_vertex(GjkSimplex& s, int k) { s.n--; gjk_set_slot(s, k, gjk_w(s, s.n), gjk_code(s, s.n)); }   // removeVertex: the last one fills the hole
+RLG_HD void gjk_append(GjkSimplex& s, V3 w, uint32_t code) { gjk_set_slot(s, s.n, w, code); s.n++; }
 RLG_HD void gjk_reduce(GjkSimplex& s) {   // btVoronoiSimplexSolver::reduceVertices
-    if (s.n >= 4 && !s.used[3]) gjk_remove_vertex<3>(s);
-    if (s.n >= 3 && !s.used[2]) gjk_remove_vertex<2>(s);
-    if (s.n >= 2 && !s.used[1]) gjk_remove_vertex<1>(s);
-    if (s.n >= 1 && !s.used[0]) gjk_remove_vertex<0>(s);
+    if (s.n >= 4 && !(s.used & 8u)) gjk_remove_vertex(s, 3);
+    if (s.n >= 3 && !(s.used & 4u)) gjk_remove_vertex(s, 2);
+    if (s.n >= 2 && !(s.used & 2u)) gjk_remove_vertex(s, 1);
+    if (s.n >= 1 && !(s.used & 1u)) gjk_remove_vertex(s, 0);
 }
-struct GjkSub { V3 closest; float bc[4]; bool used[4]; };
-RLG_HD void gjk_sub_set(GjkSub& r, float a, float b, float c, float d) { r.bc[0] = a; r.bc[1] = b; r.bc[2] = c; r.bc[3] = d; }
-RLG_HD void gjk_sub_used(GjkSub& r, bool a, bool b, bool c, bool d) { r.used[0] = a; r.used[1] = b; r.used[2] = c; r.used[3] = d; }
+struct GjkSub { V3 closest; float b0, b1, b2; uint32_t used; };   // closest point of one triangle: barycentrics and support bits of its 3 vertices
 
 // btVoronoiSimplexSolver::closestPtPointTriangle with p = origin (btVoronoiSimplexSolver.cpp:313-405)
 RLG_HD void gjk_origin_triangle(V3 a, V3 b, V3 c, GjkSub& r) {
-    gjk_sub_used(r, false, false, false, false);
     const V3 p = v3(0, 0, 0);
     V3 ab = b - a, ac = c - a, ap = p - a;
     float d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0.f && d2 <= 0.f) { r.closest = a; r.used[0] = true; gjk_sub_set(r, 1, 0, 0, 0); return; }
+    if (d1 <= 0.f && d2 <= 0.f) { r.closest = a; r.used = 1u; r.b0 = 1; r.b1 = 0; r.b2 = 0; return; }
     V3 bp = p - b;
     float d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0.f && d4 <= d3) { r.closest = b; r.used[1] = true; gjk_sub_set(r, 0, 1, 0, 0); return; }
+    if (d3 >= 0.f && d4 <= d3) { r.closest = b; r.used = 2u; r.b0 = 0; r.b1 = 1; r.b2 = 0; return; }
     float vc = d1 * d4 - d3 * d2;
     if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
         float v = d1 / (d1 - d3);
-        r.closest = a + v * ab; r.used[0] = true; r.used[1] = true; gjk_sub_set(r, 1 - v, v, 0, 0); return;
+        r.closest = a + v * ab; r.used = 3u; r.b0 = 1 - v; r.b1 = v; r.b2 = 0; return;
     }
     V3 cp = p - c;
     float d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0.f && d5 <= d6) { r.closest = c; r.used[2] = true; gjk_sub_set(r, 0, 0, 1, 0); return; }
+    if (d6 >= 0.f && d5 <= d6) { r.closest = c; r.used = 4u; r.b0 = 0; r.b1 = 0; r.b2 = 1; return; }
     float vb = d5 * d2 - d1 * d6;
     if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
         float w = d2 / (d2 - d6);
-        r.closest = a + w * ac; r.used[0] = true; r.used[2] = true; gjk_sub_set(r, 1 - w, 0, w, 0); return;
+        r.closest = a + w * ac; r.used = 5u; r.b0 = 1 - w; r.b1 = 0; r.b2 = w; return;
     }
     float va = d3 * d6 - d5 * d4;
     if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
         float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        r.closest = b + w * (c - b); r.used[1] = true; r.used[2] = true; gjk_sub_set(r, 0, 1 - w, w, 0); return;
+        r.closest = b + w * (c - b); r.used = 6u; r.b0 = 0; r.b1 = 1 - w; r.b2 = w; return;
     }
     float denom = 1.0f / (va + vb + vc);
     float v = vb * denom, w = vc * denom;
     r.closest = a + ab * v + ac * w;
-    gjk_sub_used(r, true, true, true, false);
-    gjk_sub_set(r, 1 - v - w, v, w, 0);
+    r.used = 7u; r.b0 = 1 - v - w; r.b1 = v; r.b2 = w;
 }
 // pointOutsideOfPlane with p = origin: 1 outside, 0 inside, -1 degenerate tetrahedron (:408-434)
 RLG_HD int gjk_origin_outside(V3 a, V3 b, V3 c, V3 d) {
@@ -91,88 +102,92 @@ RLG_HD int gjk_origin_outside(V3 a, V3 b, V3 c, V3 d) {
     if (signd * signd < (1e-4f * 1e-4f)) return -1;
     return (signp * signd < 0.f) ? 1 : 0;
 }
-// closestPtPointTetrahedron with p = origin (:436-577).  false: the origin is inside (or the tetrahedron is degenerate)
-RLG_HD bool gjk_origin_tetrahedron(V3 a, V3 b, V3 c, V3 d, GjkSub& fin, bool& degenerate) {
-    fin.closest = v3(0, 0, 0);
-    gjk_sub_used(fin, true, true, true, true);
-    int oabc = gjk_origin_outside(a, b, c, d), oacd = gjk_origin_outside(a, c, d, b), oadb = gjk_origin_outside(a, d, b, c), obdc = gjk_origin_outside(b, d, c, a);
-    if (oabc < 0 || oacd < 0 || oadb < 0 || obdc < 0) { degenerate = true; return false; }
-    if (!oabc && !oacd && !oadb && !obdc) return false;
+// closestPtPointTetrahedron with p = origin (:436-577) on the simplex' four points; writes the simplex' barycentrics and support bits.
+// false: the origin is inside (or the tetrahedron is degenerate).  The four faces in the reference's order -- abc, acd, adb, bdc, each
+// tested against the remaining vertex d, b, c, a -- are walked by ONE copy of the face code: 2-bit vertex numbers per face.
+RLG_HD bool gjk_origin_tetrahedron(GjkSimplex& s, V3& closest, bool& degenerate) {
+    constexpr uint32_t FACE_I = 0u | (0u << 2) | (0u << 4) | (1u << 6), FACE_J = 1u | (2u << 2) | (3u << 4) | (3u << 6),
+                       FACE_K = 2u | (3u << 2) | (1u << 4) | (2u << 6), FACE_OPP = 3u | (1u << 2) | (2u << 4) | (0u << 6);
+    closest = v3(0, 0, 0);
+    s.used = 15u;
+    uint32_t outside = 0; bool bad = false;
+    RLG_NOUNROLL
+    for (int f = 0; f < 4; f++) {
+        const int i = (FACE_I >> (2 * f)) & 3, j = (FACE_J >> (2 * f)) & 3, k = (FACE_K >> (2 * f)) & 3, o = (FACE_OPP >> (2 * f)) & 3;
+        const int side = gjk_origin_outside(gjk_w(s, i), gjk_w(s, j), gjk_w(s, k), gjk_w(s, o));
+        bad = bad || side < 0;
+        if (side > 0) outside |= 1u << f;
+    }
+    if (bad) { degenerate = true; return false; }
+    if (!outside) return false;
     float best = 3.402823466e+38f;
-    GjkSub t;
-    if (oabc) {
-        gjk_origin_triangle(a, b, c, t);
-        float sq = dot(t.closest, t.closest);
-        if (sq < best) { best = sq; fin.closest = t.closest; gjk_sub_used(fin, t.used[0], t.used[1], t.used[2], false); gjk_sub_set(fin, t.bc[0], t.bc[1], t.bc[2], 0); }
-    }
-    if (oacd) {
-        gjk_origin_triangle(a, c, d, t);
-        float sq = dot(t.closest, t.closest);
-        if (sq < best) { best = sq; fin.closest = t.closest; gjk_sub_used(fin, t.used[0], false, t.used[1], t.used[2]); gjk_sub_set(fin, t.bc[0], 0, t.bc[1], t.bc[2]); }
-    }
-    if (oadb) {
-        gjk_origin_triangle(a, d, b, t);
-        float sq = dot(t.closest, t.closest);
-        if (sq < best) { best = sq; fin.closest = t.closest; gjk_sub_used(fin, t.used[0], t.used[2], false, t.used[1]); gjk_sub_set(fin, t.bc[0], t.bc[2], 0, t.bc[1]); }
-    }
-    if (obdc) {
-        gjk_origin_triangle(b, d, c, t);
-        float sq = dot(t.closest, t.closest);
-        if (sq < best) { best = sq; fin.closest = t.closest; gjk_sub_used(fin, false, t.used[0], t.used[2], t.used[1]); gjk_sub_set(fin, 0, t.bc[0], t.bc[2], t.bc[1]); }
+    RLG_NOUNROLL
+    for (int f = 0; f < 4; f++) {
+        if (!((outside >> f) & 1u)) continue;
+        const int i = (FACE_I >> (2 * f)) & 3, j = (FACE_J >> (2 * f)) & 3, k = (FACE_K >> (2 * f)) & 3;
+        GjkSub t;
+        gjk_origin_triangle(gjk_w(s, i), gjk_w(s, j), gjk_w(s, k), t);
+        const float sq = dot(t.closest, t.closest);
+        if (sq < best) {
+            best = sq; closest = t.closest;
+            s.used = ((t.used & 1u) ? (1u << i) : 0u) | ((t.used & 2u) ? (1u << j) : 0u) | ((t.used & 4u) ? (1u << k) : 0u);
+            s.bc0 = i == 0 ? t.b0 : (j == 0 ? t.b1 : (k == 0 ? t.b2 : 0.f));
+            s.bc1 = i == 1 ? t.b0 : (j == 1 ? t.b1 : (k == 1 ? t.b2 : 0.f));
+            s.bc2 = i == 2 ? t.b0 : (j == 2 ? t.b1 : (k == 2 ? t.b2 : 0.f));
+            s.bc3 = i == 3 ? t.b0 : (j == 3 ? t.b1 : (k == 3 ? t.b2 : 0.f));
+        }
     }
     return true;
 }
-RLG_HD bool gjk_bc_valid(const float* bc) { return bc[0] >= 0.f && bc[1] >= 0.f && bc[2] >= 0.f && bc[3] >= 0.f; }
+RLG_HD bool gjk_bc_valid(const GjkSimplex& s) { return s.bc0 >= 0.f && s.bc1 >= 0.f && s.bc2 >= 0.f && s.bc3 >= 0.f; }
 
 // btVoronoiSimplexSolver::updateClosestVectorAndPoints (:81-237)
-RLG_HD bool gjk_update(GjkSimplex& s) {
+RLG_HD bool gjk_update(GjkSimplex& s, const GjkShapes& sh) {
     if (!s.needs_update) return s.valid;
     s.needs_update = false;
     s.degenerate = false;
-    s.bc[0] = s.bc[1] = s.bc[2] = s.bc[3] = 0.f;
-    s.used[0] = s.used[1] = s.used[2] = s.used[3] = false;
+    s.bc0 = s.bc1 = s.bc2 = s.bc3 = 0.f;
+    s.used = 0u;
     if (s.n == 1) {
-        s.cp1 = s.p[0]; s.cp2 = s.q[0]; s.cv = s.cp1 - s.cp2;
-        s.bc[0] = 1.f;
-        s.valid = gjk_bc_valid(s.bc);
+        s.cp1 = sh.point_a(gjk_code(s, 0)); s.cp2 = sh.point_b(gjk_code(s, 0)); s.cv = s.cp1 - s.cp2;
+        s.bc0 = 1.f;
+        s.valid = gjk_bc_valid(s);
     } else if (s.n == 2) {
-        const V3 from = s.w[0], to = s.w[1];
+        const V3 from = s.w0, to = s.w1;
         V3 diff = v3(0, 0, 0) - from, v = to - from;
         float t = dot(v, diff);
         if (t > 0.f) {
             float dvv = dot(v, v);
-            if (t < dvv) { t /= dvv; diff -= t * v; s.used[0] = true; s.used[1] = true; }
-            else { t = 1.f; diff -= v; s.used[1] = true; }
-        } else { t = 0.f; s.used[0] = true; }
-        s.bc[0] = 1 - t; s.bc[1] = t;
-        s.cp1 = s.p[0] + t * (s.p[1] - s.p[0]);
-        s.cp2 = s.q[0] + t * (s.q[1] - s.q[0]);
+            if (t < dvv) { t /= dvv; diff -= t * v; s.used = 3u; }
+            else { t = 1.f; diff -= v; s.used = 2u; }
+        } else { t = 0.f; s.used = 1u; }
+        s.bc0 = 1 - t; s.bc1 = t;
+        const V3 p0 = sh.point_a(gjk_code(s, 0)), p1 = sh.point_a(gjk_code(s, 1)), q0 = sh.point_b(gjk_code(s, 0)), q1 = sh.point_b(gjk_code(s, 1));
+        s.cp1 = p0 + t * (p1 - p0);
+        s.cp2 = q0 + t * (q1 - q0);
         s.cv = s.cp1 - s.cp2;
         gjk_reduce(s);
-        s.valid = gjk_bc_valid(s.bc);
+        s.valid = gjk_bc_valid(s);
     } else if (s.n == 3) {
-        GjkSub r; gjk_sub_set(r, 0, 0, 0, 0);
-        gjk_origin_triangle(s.w[0], s.w[1], s.w[2], r);
-        s.bc[0] = r.bc[0]; s.bc[1] = r.bc[1]; s.bc[2] = r.bc[2]; s.bc[3] = r.bc[3];
-        s.used[0] = r.used[0]; s.used[1] = r.used[1]; s.used[2] = r.used[2]; s.used[3] = r.used[3];
-        s.cp1 = s.p[0] * s.bc[0] + s.p[1] * s.bc[1] + s.p[2] * s.bc[2];
-        s.cp2 = s.q[0] * s.bc[0] + s.q[1] * s.bc[1] + s.q[2] * s.bc[2];
+        GjkSub r;
+        gjk_origin_triangle(s.w0, s.w1, s.w2, r);
+        s.bc0 = r.b0; s.bc1 = r.b1; s.bc2 = r.b2; s.bc3 = 0.f;
+        s.used = r.used;
+        s.cp1 = sh.point_a(gjk_code(s, 0)) * s.bc0 + sh.point_a(gjk_code(s, 1)) * s.bc1 + sh.point_a(gjk_code(s, 2)) * s.bc2;
+        s.cp2 = sh.point_b(gjk_code(s, 0)) * s.bc0 + sh.point_b(gjk_code(s, 1)) * s.bc1 + sh.point_b(gjk_code(s, 2)) * s.bc2;
         s.cv = s.cp1 - s.cp2;
         gjk_reduce(s);
-        s.valid = gjk_bc_valid(s.bc);
+        s.valid = gjk_bc_valid(s);
     } else if (s.n == 4) {
-        GjkSub r; gjk_sub_set(r, 0, 0, 0, 0);
-        bool deg = false;
-        bool sep = gjk_origin_tetrahedron(s.w[0], s.w[1], s.w[2], s.w[3], r, deg);
-        s.bc[0] = r.bc[0]; s.bc[1] = r.bc[1]; s.bc[2] = r.bc[2]; s.bc[3] = r.bc[3];
-        s.used[0] = r.used[0]; s.used[1] = r.used[1]; s.used[2] = r.used[2]; s.used[3] = r.used[3];
+        bool deg = false; V3 closest;
+        const bool sep = gjk_origin_tetrahedron(s, closest, deg);
         s.degenerate = deg;
         if (sep) {
-            s.cp1 = s.p[0] * s.bc[0] + s.p[1] * s.bc[1] + s.p[2] * s.bc[2] + s.p[3] * s.bc[3];
-            s.cp2 = s.q[0] * s.bc[0] + s.q[1] * s.bc[1] + s.q[2] * s.bc[2] + s.q[3] * s.bc[3];
+            s.cp1 = sh.point_a(gjk_code(s, 0)) * s.bc0 + sh.point_a(gjk_code(s, 1)) * s.bc1 + sh.point_a(gjk_code(s, 2)) * s.bc2 + sh.point_a(gjk_code(s, 3)) * s.bc3;
+            s.cp2 = sh.point_b(gjk_code(s, 0)) * s.bc0 + sh.point_b(gjk_code(s, 1)) * s.bc1 + sh.point_b(gjk_code(s, 2)) * s.bc2 + sh.point_b(gjk_code(s, 3)) * s.bc3;
             s.cv = s.cp1 - s.cp2;
             gjk_reduce(s);
-            s.valid = gjk_bc_valid(s.bc);
+            s.valid = gjk_bc_valid(s);
         } else if (deg) s.valid = false;
         else { s.valid = true; s.cv = v3(0, 0, 0); }
     } else s.valid = false;
@@ -188,46 +203,48 @@ constexpr float GJK_REL_ERROR2 = 1.0e-6f;
 // contact breaking threshold.  true: `out` is the point btManifoldResult::addContactPoint receives.
 RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_a, const MeshTri& t, float breaking, GjkOut& out, bool& deep) {
     deep = false;
-    const V3 tv[3] = {v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z)};
     const V3 offset = (bc + v3(0, 0, 0)) * 0.5f;                 // positionOffset
-    const V3 oa = bc - offset, ob = v3(0, 0, 0) - offset;         // local origins
+    GjkShapes sh;
+    sh.R = R; sh.core = core; sh.oa = bc - offset; sh.ob = v3(0, 0, 0) - offset;   // local origins
+    sh.t0 = v3(t.v0x, t.v0y, t.v0z); sh.t1 = v3(t.v1x, t.v1y, t.v1z); sh.t2 = v3(t.v2x, t.v2y, t.v2z);
+    const V3 oa = sh.oa, ob = sh.ob;
     const float margin = margin_a + 0.f;
     float max_d2 = margin_a + 0.f + breaking; max_d2 *= max_d2;    // btConvexConvexAlgorithm.cpp:313-317
     V3 axis = v3(0, 1, 0);
-    GjkSimplex s; s.n = 0; s.needs_update = true; s.valid = false; s.degenerate = false;
+    GjkSimplex s; s.n = 0; s.codes = 0u; s.needs_update = true; s.valid = false; s.degenerate = false;
+    s.w0 = s.w1 = s.w2 = s.w3 = v3(0, 0, 0);
     s.last_w = v3(1e18f, 1e18f, 1e18f); s.cp1 = s.cp2 = s.cv = v3(0, 0, 0);
-    s.bc[0] = s.bc[1] = s.bc[2] = s.bc[3] = 0.f; s.used[0] = s.used[1] = s.used[2] = s.used[3] = false;
+    s.bc0 = s.bc1 = s.bc2 = s.bc3 = 0.f; s.used = 0u;
     float sq_dist = 1e18f;
     int degenerate = 0; bool check_simplex = false;
     for (int iter = 0;; ) {
         V3 dir_a = tmul(R, -axis);                                  // (-axis) * basisA
         V3 dir_b = axis;                                            // axis * identity
-        V3 p_in_a = v3(dir_a.x >= 0.f ? core.x : -core.x, dir_a.y >= 0.f ? core.y : -core.y, dir_a.z >= 0.f ? core.z : -core.z);
-        float d0 = dot(dir_b, tv[0]), d1 = dot(dir_b, tv[1]), d2 = dot(dir_b, tv[2]);
+        float d0 = dot(dir_b, sh.t0), d1 = dot(dir_b, sh.t1), d2 = dot(dir_b, sh.t2);
         int mi = d0 < d1 ? (d1 < d2 ? 2 : 1) : (d0 < d2 ? 2 : 0);  // btVector3::maxAxis
-        V3 q_in_b = mi == 0 ? tv[0] : (mi == 1 ? tv[1] : tv[2]);
-        V3 pw = (R * p_in_a) + oa;
-        V3 qw = q_in_b + ob;
+        const uint32_t code = (dir_a.x >= 0.f ? 1u : 0u) | (dir_a.y >= 0.f ? 2u : 0u) | (dir_a.z >= 0.f ? 4u : 0u) | ((uint32_t)mi << 3);
+        V3 pw = sh.point_a(code);                                   // (R * localGetSupportVertexWithoutMargin) + origin
+        V3 qw = sh.point_b(code);
         V3 w = pw - qw;
         float delta = dot(axis, w);
         if (delta > 0.f && delta * delta > sq_dist * max_d2) { degenerate = 10; check_simplex = true; break; }
         {   // inSimplex
             bool found = false;
-            if (s.n > 0 && v3_eq(s.w[0], w)) found = true;
-            if (s.n > 1 && v3_eq(s.w[1], w)) found = true;
-            if (s.n > 2 && v3_eq(s.w[2], w)) found = true;
-            if (s.n > 3 && v3_eq(s.w[3], w)) found = true;
+            if (s.n > 0 && v3_eq(s.w0, w)) found = true;
+            if (s.n > 1 && v3_eq(s.w1, w)) found = true;
+            if (s.n > 2 && v3_eq(s.w2, w)) found = true;
+            if (s.n > 3 && v3_eq(s.w3, w)) found = true;
             if (v3_eq(w, s.last_w)) found = true;
             if (found) { degenerate = 1; check_simplex = true; break; }
         }
         float f0 = sq_dist - delta, f1 = sq_dist * GJK_REL_ERROR2;
         if (f0 <= f1) { degenerate = f0 <= 0.f ? 2 : 11; check_simplex = true; break; }
         s.last_w = w; s.needs_update = true;
-        gjk_append(s, w, pw, qw);
+        gjk_append(s, w, code);
 #ifdef RLG_GJK_STATS
         RLG_GJK_STATS(4 + s.n, 0);
 #endif
-        if (!gjk_update(s)) { degenerate = 3; check_simplex = true; break; }
+        if (!gjk_update(s, sh)) { degenerate = 3; check_simplex = true; break; }
         V3 nv = s.cv;
         if (len2(nv) < GJK_REL_ERROR2) { axis = nv; degenerate = 6; check_simplex = true; break; }
         float prev = sq_dist;
@@ -242,7 +259,7 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
 #endif
     bool valid = false; float distance = 0.f; V3 normal = v3(0, 0, 0), pa = v3(0, 0, 0), pb = v3(0, 0, 0);
     if (check_simplex) {
-        gjk_update(s);
+        gjk_update(s, sh);
         pa = s.cp1; pb = s.cp2;
         normal = axis;
         float l2 = len2(axis);
@@ -268,7 +285,7 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         V3 e = abs_rows_dot(R, v3(core.x + margin_a, core.y + margin_a, core.z + margin_a));
         V3 amin = oa - e, amax = oa + e;
         V3 pos_a = (amax + amin) * 0.5f;
-        V3 bmin = vmin(vmin(tv[0] + ob, tv[1] + ob), tv[2] + ob), bmax = vmax(vmax(tv[0] + ob, tv[1] + ob), tv[2] + ob);
+        V3 bmin = vmin(vmin(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob), bmax = vmax(vmax(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob);
         V3 pos_b = (bmin + bmax) * 0.5f;
         if (dot(pos_a - pos_b, normal) < 0.f) normal *= -1.f;
     }

@@ -123,6 +123,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
 #ifdef RLG_GJK_STATS
     RLG_GJK_STATS(1, 0);
 #endif
+    RLG_DBG_COUNT(8);
     if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, CBT_CAR, g, deep)) {
         if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
         c.n = g.n; c.pb = g.pb; c.dist = g.dist;
@@ -130,6 +131,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
         return true;
     }
     if (!deep) return false;
+    RLG_DBG_COUNT(9);
     Cand cs[4]; int nc = 0;
     box_triangle(bc, R, hitbox_core(), t, 0.f, cs, nc);
     if (nc == 0) return false;
@@ -220,30 +222,28 @@ template <int NC>
 RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue<NC>& Q) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
     CollideItem it = Q.items[slot];
-    Cand out[8]; int n = 0;
+    // a triangle item yields at most one point, kept in registers until its pool slot is known; only the (rare) car-car item has a list
+    Cand one; Cand many[4]; int n = 0;
 #ifdef RLG_ITEM_CLOCK
     const unsigned long long t0_ = RLG_ITEM_CLOCK();
 #endif
     if (it.type == 0) {
         const float r = K::BALL_RADIUS * UU2BT;
-        Cand c;
-        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[it.ref], c.pb, c.n, c.dist); out[n++] = c; }
+        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], one.pb, one.n, one.dist) && !(one.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[it.ref], one.pb, one.n, one.dist); n = 1; }
     } else if (it.type == 1) {
         const Car& car = A.cars[it.a];
         V3 bc = car.b.pos + car.b.rot * hitbox_off();
-        Cand c;
-        if (hitbox_triangle(bc, car.b.rot, mesh.tris[it.ref], c)) out[n++] = c;
+        if (hitbox_triangle(bc, car.b.rot, mesh.tris[it.ref], one)) n = 1;
     } else {
-        Cand cs[4]; int nc = 0;
-        NarrowInline().car_car(A, it.a, it.ref, cs, nc);
-        for (int q = 0; q < nc; q++) out[n++] = cs[q];
+        NarrowInline().car_car(A, it.a, it.ref, many, n);
     }
 #ifdef RLG_ITEM_CLOCK
     RLG_ITEM_DONE(it.type, n, RLG_ITEM_CLOCK() - t0_);
 #endif
     int off = n > 0 ? fetch_add(Q.n_pool, n) : 0;
     if (off + n > POOL_CAP) { Q.overflow = 1; n = 0; off = 0; RLG_DBG_COUNT(4); }
-    for (int q = 0; q < n; q++) Q.pool[off + q] = out[q];
+    if (it.type == 2) { for (int q = 0; q < n; q++) Q.pool[off + q] = many[q]; }
+    else if (n == 1) Q.pool[off] = one;
     Q.items[slot].off = (int16_t)off; Q.items[slot].n = (int16_t)n;
 }
 

@@ -83,6 +83,7 @@ if hasattr(env.lib, "rlgpu_env_debug_ints"):
     buf = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]; env.lib.rlgpu_env_debug_ints(env.h, buf)
     print("queue overflow events so far: frontier", buf[0], "ball region", buf[1], "car region", buf[2], "items", buf[3], "pool", buf[4])
 
+    print("hitbox-triangle GJK runs", buf[8], " of them answered by the deep-penetration fallback", buf[9])
     for t, nm in enumerate(("ball-triangle", "hitbox-triangle", "car-car")):
         c = buf[16 + 4 * t]
         if c: print(f"items {nm}: {c} run, {buf[17 + 4 * t]} with a contact, mean {64.0 * buf[18 + 4 * t] / c:.0f} cycles, slowest {buf[19 + 4 * t]}")
