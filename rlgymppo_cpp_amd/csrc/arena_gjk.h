@@ -15,6 +15,10 @@
 #pragma once
 #include "arena_world.h"
 
+#ifndef RLG_GJK_FACE_LOOP
+#define RLG_GJK_FACE_LOOP RLG_UNROLL
+#endif
+
 namespace rlg {
 
 // The two shapes of one query.  A support point is a box corner (3 sign bits) or a triangle vertex (2 bits): the simplex remembers
@@ -111,7 +115,7 @@ RLG_HD bool gjk_origin_tetrahedron(GjkSimplex& s, V3& closest, bool& degenerate)
     closest = v3(0, 0, 0);
     s.used = 15u;
     uint32_t outside = 0; bool bad = false;
-    RLG_NOUNROLL
+    RLG_GJK_FACE_LOOP
     for (int f = 0; f < 4; f++) {
         const int i = (FACE_I >> (2 * f)) & 3, j = (FACE_J >> (2 * f)) & 3, k = (FACE_K >> (2 * f)) & 3, o = (FACE_OPP >> (2 * f)) & 3;
         const int side = gjk_origin_outside(gjk_w(s, i), gjk_w(s, j), gjk_w(s, k), gjk_w(s, o));
@@ -121,7 +125,7 @@ RLG_HD bool gjk_origin_tetrahedron(GjkSimplex& s, V3& closest, bool& degenerate)
     if (bad) { degenerate = true; return false; }
     if (!outside) return false;
     float best = 3.402823466e+38f;
-    RLG_NOUNROLL
+    RLG_GJK_FACE_LOOP
     for (int f = 0; f < 4; f++) {
         if (!((outside >> f) & 1u)) continue;
         const int i = (FACE_I >> (2 * f)) & 3, j = (FACE_J >> (2 * f)) & 3, k = (FACE_K >> (2 * f)) & 3;

@@ -18,6 +18,7 @@
 // it through the 64 KB instruction cache on every tick.
 #define RLG_HD_NOINLINE __host__ __device__ __noinline__ inline  /* `inline` only for ODR linkage of header definitions */
 #define RLG_NOUNROLL _Pragma("nounroll")
+#define RLG_UNROLL _Pragma("unroll")
 // The stepper kernels keep each env's state and tick scratch in LDS.  Out-of-line device functions receive them through
 // generic pointers (flat_load/flat_store, no alias information); this assumption lets LLVM's InferAddressSpaces turn
 // those accesses into ds_read/ds_write.  Only valid where EVERY device caller passes an LDS object.
@@ -28,6 +29,7 @@
 #endif
 #else
 #define RLG_NOUNROLL
+#define RLG_UNROLL
 #define RLG_ASSUME_LDS(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline

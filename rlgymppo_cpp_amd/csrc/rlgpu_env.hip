@@ -364,6 +364,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
         }
         wave_sync();
+        RLG_PROF(1);   // (the candidate tests count as "candidates", like the walk that listed them)
         {   // items of ALL envs of the wavefront as one list over the 64 lanes: a contact-heavy env borrows its neighbours' lanes
             int n_of[EPW], total = 0;
 #pragma unroll
