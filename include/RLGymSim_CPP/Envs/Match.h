@@ -71,7 +71,7 @@ public:
         rlgpu_default_gym_config(&cfg);
         cfg.tick_skip = tickSkip;
         auto noReward = [&] { cfg.n_terms = 0; cfg.zero_sum = 0; for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) cfg.event_weights[i] = 0.f; };
-        if (!spawnOpponents) RG_ERR_CLOSE("Match: spawnOpponents = false is not supported by the batched env");
+        cfg.one_team = spawnOpponents ? 0 : 1;   // teamSize blue cars and nobody else: the env's orange slots stay empty
         if (!rewardFn || !obsBuilder || !actionParser || !stateSetter) RG_ERR_CLOSE("Match: a plugin is null");
         noReward();
         if (!rewardFn->AddDeviceTerms(cfg, 1.f)) { noReward(); plan.hostReward = true; }

@@ -170,21 +170,39 @@ public:
         _mutatorConfig = m;
     }
 
-    // Arena::AddCar (Arena.cpp:33-69).  The device layout fixes the slots (even = blue, odd = orange, id = slot + 1), which is the order
-    // Gym's constructor adds them in (Gym.cpp:45-49): blue, orange, blue, orange, ...
+    // Arena::AddCar (Arena.cpp:33-69).  The device layout fixes the slots (even = blue, odd = orange), so the cars come in the order Gym's
+    // constructor adds them (Gym.cpp:45-49): blue, orange, blue, orange, ... (car id = slot + 1), or -- spawnOpponents = false -- blue cars
+    // only (ids 1, 2, 3 on slots 0, 2, 4; the orange slots stay empty, flagged RLGPU_CF_ABSENT).
     Car* AddCar(Team team, const CarConfig& config = CAR_CONFIG_OCTANE) {
-        const int slot = (int)_cars.size();
-        if (slot >= RLGPU_MAX_CARS) RG_ERR_CLOSE("Arena::AddCar(): at most " << RLGPU_MAX_CARS << " cars per arena");
-        if ((slot % 2 == 0) != (team == Team::BLUE)) RG_ERR_CLOSE("Arena::AddCar(): cars have to be added blue, orange, blue, orange, ... (the device's slot order)");
+        const int n = (int)_cars.size();
         if (!(config == CAR_CONFIG_OCTANE)) RG_ERR_CLOSE("Arena::AddCar(): the device stepper has the Octane hitbox compiled in");
+        if (n == 1 && team == Team::BLUE) _oneTeam = true;         // the second car decides: blue again = an arena without opponents (car 0 sits on slot 0 either way)
+        const bool oneTeam = _oneTeam;
+        if (oneTeam ? team != Team::BLUE : ((n % 2 == 0) != (team == Team::BLUE)))
+            RG_ERR_CLOSE("Arena::AddCar(): cars have to be added blue, orange, blue, orange, ... or all blue (the device's slot order)");
+        const int slot = oneTeam ? 2 * n : n;
+        if (slot >= RLGPU_MAX_CARS) RG_ERR_CLOSE("Arena::AddCar(): at most " << RLGPU_MAX_CARS / (oneTeam ? 2 : 1) << " cars per arena");
         Car* car = new Car();
         car->config = config; car->team = team; car->id = ++_lastCarID; car->raw = &_state.cars[slot];
         _cars.push_back(car);
-        _state.num_cars = (int32_t)_cars.size();
+        _state.num_cars = (int32_t)(oneTeam ? 2 * _cars.size() : _cars.size());
         CarState fresh; fresh.pos = Vec(0, team == Team::BLUE ? -1000.f - 300.f * (slot / 2) : 1000.f + 300.f * (slot / 2), RLConst::CAR_SPAWN_REST_Z);
         car->SetState(fresh);
+        if (oneTeam) _MarkAbsentSlots();
         return car;
     }
+    // a single blue car is a one-team arena until an orange one joins (Gym adds blue first either way)
+    void _MarkAbsentSlots() {
+        for (int k = 1; k < _state.num_cars; k += 2) {
+            RlgpuCarState& c = _state.cars[k];
+            std::memset(&c, 0, sizeof(c));
+            c.flags = RLGPU_CF_IS_DEMOED | RLGPU_CF_ABSENT; c.demo_respawn_timer = 1e30f; c.pos[2] = -10000.f;
+            c.rot[0] = c.rot[4] = c.rot[8] = 1.f; c.bh_tick_hit = -1; c.bh_tick_extra = -1;
+        }
+    }
+    // an arena that will never get orange cars (Gym with spawnOpponents = false and teamSize 1 has to say so: nothing else tells)
+    void _SetOneTeam() { _oneTeam = true; _state.num_cars = (int32_t)(2 * _cars.size()); _MarkAbsentSlots(); }
+    bool _IsOneTeam() const { return _oneTeam; }
     Car* GetCar(uint32_t id) { return (id >= 1 && id <= _cars.size()) ? _cars[id - 1] : nullptr; }
 
     void SetGoalScoreCallback(GoalScoreEventFn fn, void* userInfo = nullptr) { _goalScoreCallback = {fn, userInfo}; }
@@ -233,6 +251,7 @@ public:
     }
     void _SyncFromState() { tickCount = (uint64_t)_state.tick_count; }
     void* _device = nullptr;               // the one-env device batch behind Step() / Gym (host/Gym.hip)
+    bool _oneTeam = false;                 // blue cars only (spawnOpponents = false)
 
 private:
     Arena() {

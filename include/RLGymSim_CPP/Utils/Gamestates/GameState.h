@@ -58,11 +58,18 @@ inline GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
     // the arena's pads (a constant of the two tables; the device obs builder uses the same one)
     static const int8_t PAD_ORDER[RLGPU_NUM_PADS] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
     for (int p = 0; p < RLGPU_NUM_PADS; p++) { boostPads[p] = s.pads[PAD_ORDER[p]].is_active != 0; boostPadsInv[RLGPU_NUM_PADS - 1 - p] = boostPads[p]; }
-    players.resize(s.num_cars);
+    // a one-team env (spawnOpponents = false) keeps its orange slots empty: its players are the even slots, numbered 1, 2, 3 like the
+    // reference's only cars
+    bool oneTeam = false;
+    for (int k = 1; k < s.num_cars; k += 2) oneTeam = oneTeam || (s.cars[k].flags & RLGPU_CF_ABSENT);
+    if (oneTeam && lastTouchCarID > 0) lastTouchCarID = (lastTouchCarID - 1) / 2 + 1;
+    players.clear();
     for (int k = 0; k < s.num_cars; k++) {
         const RlgpuCarState& c = s.cars[k]; const RlgpuPlayerGymState& g = s.gym.players[k];
-        PlayerData& pd = players[k];
-        pd.carId = (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
+        if (c.flags & RLGPU_CF_ABSENT) continue;
+        players.emplace_back();
+        PlayerData& pd = players.back();
+        pd.carId = oneTeam ? (uint32_t)(k / 2 + 1) : (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
         pd.phys.pos = V(c.pos); pd.phys.vel = V(c.vel); pd.phys.angVel = V(c.ang_vel);
         pd.phys.rotMat.forward = V(c.rot); pd.phys.rotMat.right = V(c.rot + 3); pd.phys.rotMat.up = V(c.rot + 6);
         pd.physInv = pd.phys.Invert();

@@ -52,6 +52,8 @@ typedef struct RlgpuGymConfig {
     int32_t obs_max_players;                         /* 0: DefaultOBS.  m > 0: DefaultOBSPadded(maxPlayers = m) (DefaultOBSPadded.cpp:3-66): m-1 teammate and
                                                       * m opponent blocks (zero blocks where there is no player), each list shuffled per observation;
                                                       * team_size <= m <= 4, row width 51 + 38 m */
+    int32_t one_team;                                /* Match(..., spawnOpponents = false) (SIM/Envs/Match.h:40, Gym.cpp:45-49): team_size blue cars, no orange ones.
+                                                      * Agents per env = team_size; the env's state keeps 2 * team_size slots, the odd ones flagged RLGPU_CF_ABSENT */
 } RlgpuGymConfig;
 
 /* fills cfg with the examplemain.cpp:58-100 stack: 0.1 FaceBall + 0.5 VelPlayerToBall + 1.0 VelBallToGoal +
@@ -70,7 +72,7 @@ const char* rlgpu_env_last_error(const rlgpu_env* e);
 int rlgpu_env_reseed(rlgpu_env* e, uint32_t seed_lo, uint32_t seed_hi);
 int rlgpu_env_set_stream(rlgpu_env* e, void* hip_stream);
 int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size() probe (PUB/Learner.cpp:99-109): 51+19*players, padded: 51+38*maxPlayers */
-int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * 2 * team_size ; agent row = env * players + slot */
+int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * players, players = 2 * team_size (team_size with one_team); agent row = env * players + slot (slot / 2 with one_team) */
 int rlgpu_env_num_actions(const rlgpu_env* e);
 int rlgpu_env_state_words(const rlgpu_env* e); /* resident 32-bit words per env */
 

@@ -51,7 +51,8 @@ enum {
     RLGPU_CF_IS_AUTOFLIPPING = 1u << 11,
     RLGPU_CF_WORLD_CONTACT   = 1u << 12,
     RLGPU_CF_IS_DEMOED       = 1u << 13,
-    RLGPU_CF_BALLHIT_VALID   = 1u << 14
+    RLGPU_CF_BALLHIT_VALID   = 1u << 14,
+    RLGPU_CF_ABSENT          = 1u << 15  /* no car in this slot: the orange slots of an env created with one_team (spawnOpponents = false) */
 };
 
 typedef struct RlgpuCarState {

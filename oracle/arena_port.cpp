@@ -90,12 +90,13 @@ static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, c
 extern "C" {
 
 // row width of the obs builder `cfg` describes (DefaultOBS, or DefaultOBSPadded when obs_max_players is set)
-int port_obs_size(const void* cfg, int nc) { int m = ((const GymConfig*)cfg)->obs_max_players; return m > 0 ? 51 + 38 * m : 51 + 19 * nc; }
+int port_obs_size(const void* cfg, int nc) { const GymConfig& g = *(const GymConfig*)cfg; return g.obs_max_players > 0 ? 51 + 38 * g.obs_max_players : 51 + 19 * (g.one_team ? nc / 2 : nc); }
 
 void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs, int run_setter) {
     for (int e = 0; e < n; e++) {
         RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = port_obs_size(cfg, nc);
-        float* o = obs ? obs + (size_t)e * nc * D : nullptr;
+        const int P = ((const GymConfig*)cfg)->one_team ? nc / 2 : nc;   // agent rows per env
+        float* o = obs ? obs + (size_t)e * P * D : nullptr;
         if (nc == 2) gym_reset_t<2>(s, (const GymConfig*)cfg, e, o, run_setter);
         else if (nc == 4) gym_reset_t<4>(s, (const GymConfig*)cfg, e, o, run_setter);
         else gym_reset_t<6>(s, (const GymConfig*)cfg, e, o, run_setter);
@@ -104,11 +105,12 @@ void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs,
 void port_gym_step(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done) {
     for (int e = 0; e < n; e++) {
         RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = port_obs_size(cfg, nc);
+        const int P = ((const GymConfig*)cfg)->one_team ? nc / 2 : nc;   // agent rows per env
         int32_t dn = 0;
-        if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
-        else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
-        else gym_step_t<6>(s, (const GymConfig*)cfg, e, actions + (size_t)e * nc, obs + (size_t)e * nc * D, rew + (size_t)e * nc, &dn);
-        for (int k = 0; k < nc; k++) done[(size_t)e * nc + k] = dn;
+        if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
+        else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
+        else gym_step_t<6>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
+        for (int k = 0; k < P; k++) done[(size_t)e * P + k] = dn;
     }
 }
 int port_action_table(float* out) { memcpy(out, table(), sizeof(g_action_table)); return 90; }

@@ -32,7 +32,17 @@ using namespace RLGSC;
 
 namespace {
 
-Car* CarBySlot(Arena* a, int slot) { return a->_carIDMap[(uint32_t)slot + 1]; }
+// Exchange-layout slots: blue cars on the even ones, orange on the odd ones, in AddCar order (car id = slot + 1 for Gym's blue / orange
+// alternation).  An arena WITHOUT orange cars -- Match(..., spawnOpponents = false) -- has ids 1..P for its P blue cars: slot 2 (id - 1),
+// and its odd slots are empty (flagged RLGPU_CF_ABSENT in the exchange state).
+bool OneTeam(Arena* a) { for (Car* c : a->_cars) if (c->team != Team::BLUE) return false; return !a->_cars.empty(); }
+int SlotOfCar(Arena* a, uint32_t id) { return OneTeam(a) ? 2 * ((int)id - 1) : (int)id - 1; }
+int SlotCount(Arena* a) { return OneTeam(a) ? 2 * (int)a->_cars.size() : (int)a->_cars.size(); }
+Car* CarBySlot(Arena* a, int slot) {
+    if (OneTeam(a)) { if (slot % 2) return nullptr; slot /= 2; }
+    auto it = a->_carIDMap.find((uint32_t)slot + 1);
+    return it == a->_carIDMap.end() ? nullptr : it->second;
+}
 
 void V3(float* o, const Vec& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 Vec  toV(const float* p) { return Vec(p[0], p[1], p[2]); }
@@ -48,7 +58,7 @@ CarControls ArrToCtrl(const float* p) {
 
 void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
     memset(s, 0, sizeof(*s));
-    s->num_cars = (int)a->_cars.size();
+    s->num_cars = SlotCount(a);
     s->tick_count = (int64_t)a->tickCount;
     BallState bs = a->ball->GetState();
     s->ball_update_counter = (int64_t)bs.updateCounter;
@@ -56,8 +66,13 @@ void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
     V3(s->ball.vel_impulse_cache, a->ball->_velocityImpulseCache * BT_TO_UU);
     for (int i = 0; i < s->num_cars; i++) {
         Car* car = CarBySlot(a, i);
-        CarState cs = car->GetState();
         RlgpuCarState& o = s->cars[i];
+        if (!car) {   // empty slot of a one-team arena, as the device parks it (csrc/arena_gym.h park_absent_players)
+            o.flags = RLGPU_CF_IS_DEMOED | RLGPU_CF_ABSENT; o.demo_respawn_timer = 1e30f; o.pos[2] = -10000.f;
+            o.rot[0] = o.rot[4] = o.rot[8] = 1.f; o.bh_tick_hit = -1; o.bh_tick_extra = -1;
+            continue;
+        }
+        CarState cs = car->GetState();
         V3(o.pos, cs.pos); V3(o.rot, cs.rotMat.forward); V3(o.rot + 3, cs.rotMat.right); V3(o.rot + 6, cs.rotMat.up);
         V3(o.vel, cs.vel); V3(o.ang_vel, cs.angVel);
         uint32_t f = 0;
@@ -117,6 +132,7 @@ void SetArenaPhys(Arena* a, const RlgpuArenaState* s, bool setPads) {
     a->ball->_internalState.updateCounter = (uint64_t)s->ball_update_counter;
     for (int i = 0; i < s->num_cars; i++) {
         Car* car = CarBySlot(a, i);
+        if (!car) continue;
         const RlgpuCarState& o = s->cars[i];
         CarState cs = {};
         cs.pos = toV(o.pos); cs.rotMat.forward = toV(o.rot); cs.rotMat.right = toV(o.rot + 3); cs.rotMat.up = toV(o.rot + 6);
@@ -192,14 +208,14 @@ void FillGymState(RefGym* g, RlgpuArenaState* s) {
     const GameState& st = g->gym->prevState;
     RlgpuGymState& o = s->gym;
     o.score_line[0] = st.scoreLine[0]; o.score_line[1] = st.scoreLine[1];
-    o.last_touch_car_id = st.lastTouchCarID;
+    o.last_touch_car_id = st.lastTouchCarID > 0 ? SlotOfCar(g->gym->arena, (uint32_t)st.lastTouchCarID) + 1 : st.lastTouchCarID;
     o.last_tick_count = (int64_t)st.lastTickCount;
     o.no_touch_steps = g->noTouch ? g->noTouch->stepsSinceTouch : 0;
     const GameEventTracker& t = g->gym->eventTracker;
     o.shot_cooldown = t._shotCooldown; o.ball_shot = t._ballShot; o.ball_shot_goal_team = (uint8_t)t._ballShotGoalTeam;
     o.ball_scored_last = t._ballScoredLast; o.last_ball_update_count = (int64_t)t._lastBallUpdateCount;
     for (auto& p : st.players) {
-        int slot = (int)p.carId - 1;
+        int slot = SlotOfCar(g->gym->arena, p.carId);
         RlgpuPlayerGymState& q = o.players[slot];
         q.match_goals = p.matchGoals; q.match_saves = p.matchSaves; q.match_assists = p.matchAssists;
         q.match_shots = p.matchShots; q.match_shot_passes = p.matchShotPasses; q.match_bumps = p.matchBumps;
@@ -211,7 +227,7 @@ void FillGymState(RefGym* g, RlgpuArenaState* s) {
         }
     }
     for (size_t i = 0; i < st.players.size() && i < g->match->prevActions.size(); i++) {
-        int slot = (int)st.players[i].carId - 1;
+        int slot = SlotOfCar(g->gym->arena, st.players[i].carId);
         for (int k = 0; k < 8; k++) o.players[slot].prev_action[k] = g->match->prevActions[i][k];
     }
 }
@@ -295,6 +311,7 @@ int ref_gym_reset_to(void* h, const RlgpuArenaState* s, float* obs_out) {
 }
 
 // One Gym::Step with SLOT-ordered action indices. Outputs in SLOT order.
+//  (rows are AGENT rows: slot order with two teams; blue car order in a one-team gym, where agent row = car id - 1 = slot / 2)
 //  snap_out (optional): the physical state at the snapshot (after tick 1 of tickSkip)
 //  is not observable without modifying the reference; state_out is the arena AFTER the full step,
 //  with gym-level carried state filled in.
@@ -448,6 +465,16 @@ extern "C" void* ref_gym_new2(int team_size, int tick_skip, int obs_max_players,
     g->match = new Match(g->rootReward, g->conds, g->obs, g->parser, g->setter, team_size, true);
     g->gym = new Gym(g->match, tick_skip);
     g->nPlayers = team_size * 2;
+    return g;
+}
+// the same gyms without opponents: Match(..., teamSize, spawnOpponents = false)
+extern "C" void* ref_gym_new3(int team_size, int tick_skip, int obs_max_players, int reward_kind, int no_touch_steps, int spawn_opponents) {
+    RefGym* g = (RefGym*)ref_gym_new2(team_size, tick_skip, obs_max_players, reward_kind, no_touch_steps);
+    if (spawn_opponents) return g;
+    delete g->gym; delete g->match;
+    g->match = new Match(g->rootReward, g->conds, g->obs, g->parser, g->setter, team_size, false);
+    g->gym = new Gym(g->match, tick_skip);
+    g->nPlayers = team_size;
     return g;
 }
 // car ids (slot + 1) in the order of GameState::players, i.e. the reference's own iteration order of Arena::_cars (a

@@ -34,7 +34,17 @@ struct GymConfig {
     float pos_coef[3], vel_coef, ang_vel_coef;      // DefaultOBS.h:11-15
     int32_t n_actions;
     int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers), team size <= maxPlayers <= 4: mates / opponents padded with zero blocks and shuffled
+    int32_t one_team;          // Match(..., spawnOpponents = false): only the blue slots (even k) hold a car; see player_present()
 };
+
+// spawnOpponents = false (Gym.cpp:45-49 adds no orange cars).  The env keeps its 2 * teamSize slots -- slot parity IS the team everywhere in
+// the stepper -- and the orange ones are ABSENT: parked as demolished cars whose respawn timer never runs out (so the physics never sees
+// them), skipped by the obs builder, the rewards and the agent rows.  Agent row of slot k inside its env: k / 2.
+RLG_HD bool player_present(const GymConfig& cfg, int k) { return !cfg.one_team || (k % 2) == 0; }
+RLG_HD int agent_row(const GymConfig& cfg, int k) { return cfg.one_team ? (k >> 1) : k; }
+template <int NC>
+RLG_HD int players_per_env(const GymConfig& cfg) { return cfg.one_team ? NC / 2 : NC; }
+constexpr float ABSENT_RESPAWN_TIMER = 1e30f;
 
 // obs-order -> RocketSim pad index (GameState.cpp:10-50 builds this by matching CommonValues::BOOST_LOCATIONS
 // against RLConst pad positions; it is a constant of the two tables)
@@ -198,7 +208,7 @@ template <int NC>
 RLG_HD int obs_size() { return 51 + 19 * NC; }
 // row width for a config: DefaultOBS 51 + 19 * players, DefaultOBSPadded(m) 51 + 19 * 2m (self + m-1 mates + m opponents)
 template <int NC>
-RLG_HD int obs_size(const GymConfig& cfg) { return cfg.obs_max_players > 0 ? 51 + 38 * cfg.obs_max_players : obs_size<NC>(); }
+RLG_HD int obs_size(const GymConfig& cfg) { return cfg.obs_max_players > 0 ? 51 + 38 * cfg.obs_max_players : 51 + 19 * players_per_env<NC>(cfg); }
 constexpr int OBS_MAX_PADDED_PLAYERS = 4;
 
 template <int NC>
@@ -226,7 +236,7 @@ RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_a
     o = obs_add_player(o, S, k, inv, cfg);
     constexpr int LIST = (NC > OBS_MAX_PADDED_PLAYERS ? NC : OBS_MAX_PADDED_PLAYERS) + 1;
     int mates[LIST], opps[LIST], nm = 0, no = 0;
-    for (int j = 0; j < NC; j++) if (j != k) { if ((j % 2) == (k % 2)) mates[nm++] = j; else opps[no++] = j; }   // state.players order
+    for (int j = 0; j < NC; j++) if (j != k && player_present(cfg, j)) { if ((j % 2) == (k % 2)) mates[nm++] = j; else opps[no++] = j; }   // state.players order
     if (cfg.obs_max_players > 0) {
         while (nm < cfg.obs_max_players - 1) mates[nm++] = -1;   // zero blocks (DefaultOBSPadded.cpp:46-54)
         while (no < cfg.obs_max_players) opps[no++] = -1;
@@ -270,6 +280,7 @@ RLG_HD_NOINLINE void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const
     for (int t = 0; t < cfg.n_terms; t++) {
         const RewardTerm& T = cfg.terms[t];
         for (int k = 0; k < NC; k++) {
+            if (!player_present(cfg, k)) continue;
             float r = 0.f;
             switch (T.kind) {
                 case RW_EVENT: {
@@ -301,9 +312,9 @@ RLG_HD_NOINLINE void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const
     }
     if (cfg.zero_sum) {
         float avg[2] = {0.f, 0.f}; int cnt[2] = {0, 0};
-        for (int k = 0; k < NC; k++) { cnt[k % 2]++; avg[k % 2] += rew[k]; }
+        for (int k = 0; k < NC; k++) if (player_present(cfg, k)) { cnt[k % 2]++; avg[k % 2] += rew[k]; }
         for (int t = 0; t < 2; t++) avg[t] /= (float)(cnt[t] > 1 ? cnt[t] : 1);
-        for (int k = 0; k < NC; k++) { int t = k % 2; rew[k] = rew[k] * (1 - cfg.team_spirit) + (avg[t] * cfg.team_spirit) - (avg[1 - t] * cfg.opp_scale); }
+        for (int k = 0; k < NC; k++) { if (!player_present(cfg, k)) continue; int t = k % 2; rew[k] = rew[k] * (1 - cfg.team_spirit) + (avg[t] * cfg.team_spirit) - (avg[1 - t] * cfg.opp_scale); }
     }
 }
 
@@ -404,10 +415,22 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
     }
     arena_finish_load(A);
 }
+// the orange slots of a one-team env (also after a host state setter, which knows nothing about them)
+template <int NC>
+RLG_HD void park_absent_players(Arena<NC>& A, const GymConfig& cfg) {
+    if (!cfg.one_team) return;
+    for (int k = 1; k < NC; k += 2) {
+        Car& c = A.cars[k];
+        c.flags = CF_IS_DEMOED | CF_ABSENT; c.demo_respawn_timer = ABSENT_RESPAWN_TIMER;
+        c.b.pos = v3(0, 0, -10000.f) * UU2BT; c.b.vel = v3(0, 0, 0); c.b.angvel = v3(0, 0, 0); c.vel_impulse_cache = v3(0, 0, 0);
+        c.bh_tick_hit = -1; c.bh_tick_extra = -1; c.boost = 0.f;
+    }
+}
 
 // Gym::Reset bookkeeping after the state setter ran (Gym.cpp:58-66, Match.cpp:4-10, GameState ctor)
 template <int NC>
-RLG_HD void gym_episode_reset(const Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, Snapshot<NC>& S) {
+RLG_HD void gym_episode_reset(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, Snapshot<NC>& S) {
+    park_absent_players(A, cfg);
     G.score_line[0] = G.score_line[1] = 0; G.last_touch_car_id = -1; G.last_tick_count = 0;
     for (int k = 0; k < NC; k++) for (int q = 0; q < 8; q++) G.counters[k][q] = 0;
     take_snapshot(A, G, S);  // GameState(arena): lastTickCount was 0 -> tickSkip = tickCount
@@ -431,7 +454,7 @@ RLG_HD void gym_step_begin(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, co
     // Match::ParseActions: demoed players (per the PREVIOUS snapshot) get a zero action (Match.cpp:44-52)
     uint32_t snap_demoed = (G.tracker_flags >> 8) & 0xffu;
     for (int k = 0; k < NC; k++) {
-        int idx = actions[k];
+        int idx = player_present(cfg, k) ? actions[agent_row(cfg, k)] : -1;
         bool zero = (snap_demoed >> k) & 1u;
         if (idx < 0 || idx >= cfg.n_actions) zero = true;
         float pa[8];
@@ -460,13 +483,14 @@ RLG_HD bool gym_step_after_first_tick(Arena<NC>& A, GymEnv<NC>& G, const GymConf
     const bool done = compute_done(S, G, cfg);
     float rew[NC];
     compute_rewards(S, G, cfg, rew);
-    for (int k = 0; k < NC; k++) reward[k] = rew[k];
+    for (int k = 0; k < NC; k++) if (player_present(cfg, k)) reward[agent_row(cfg, k)] = rew[k];
     if (!done) {   // the step counter the obs builder keys its shuffle with is the one gym_step_end is about to write
         for (int k = 0; k < NC; k++) {
+            if (!player_present(cfg, k)) continue;
             float pa[8];
             const int idx = G.prev_action_idx[k];
             for (int i = 0; i < 8; i++) pa[i] = idx < 0 ? 0.f : action_table[idx * 8 + i];
-            build_obs(S, k, pa, cfg, next_obs + (size_t)k * obs_row_stride, env_id, G.episode_steps + 1, G.reset_count);
+            build_obs(S, k, pa, cfg, next_obs + (size_t)agent_row(cfg, k) * obs_row_stride, env_id, G.episode_steps + 1, G.reset_count);
         }
     }
     return done;
@@ -480,7 +504,7 @@ RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint
         gym_episode_reset(A, G, cfg, S);
         G.tracker_flags &= ~0xff00u;
         const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < NC; k++) build_obs(S, k, zero, cfg, next_obs + (size_t)k * obs_row_stride, env_id, G.episode_steps, G.reset_count);
+        for (int k = 0; k < NC; k++) if (player_present(cfg, k)) build_obs(S, k, zero, cfg, next_obs + (size_t)agent_row(cfg, k) * obs_row_stride, env_id, G.episode_steps, G.reset_count);
     }
 }
 
@@ -507,7 +531,7 @@ RLG_HD void gym_reset_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uin
     gym_episode_reset(A, G, cfg, S);
     G.tracker_flags &= ~0xff00u;
     float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (obs) for (int k = 0; k < NC; k++) build_obs(S, k, zero, cfg, obs + (size_t)k * obs_row_stride, env_id, G.episode_steps, G.reset_count);
+    if (obs) for (int k = 0; k < NC; k++) if (player_present(cfg, k)) build_obs(S, k, zero, cfg, obs + (size_t)agent_row(cfg, k) * obs_row_stride, env_id, G.episode_steps, G.reset_count);
 }
 
 }  // namespace rlg

@@ -134,7 +134,8 @@ RLG_HD float curve_bump_up(float v) {
 enum : uint32_t {
     CF_ON_GROUND = 1u << 0, CF_WHEEL0 = 1u << 1, CF_HAS_JUMPED = 1u << 5, CF_HAS_DOUBLE_JUMPED = 1u << 6,
     CF_HAS_FLIPPED = 1u << 7, CF_IS_FLIPPING = 1u << 8, CF_IS_JUMPING = 1u << 9, CF_IS_SUPERSONIC = 1u << 10,
-    CF_IS_AUTOFLIPPING = 1u << 11, CF_WORLD_CONTACT = 1u << 12, CF_IS_DEMOED = 1u << 13, CF_BALLHIT_VALID = 1u << 14
+    CF_IS_AUTOFLIPPING = 1u << 11, CF_WORLD_CONTACT = 1u << 12, CF_IS_DEMOED = 1u << 13, CF_BALLHIT_VALID = 1u << 14,
+    CF_ABSENT = 1u << 15          // an orange slot of a one-team env (spawnOpponents = false): no car here, ever
 };
 
 struct Controls {

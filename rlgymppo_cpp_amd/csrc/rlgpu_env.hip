@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
     const int D = obs_size<NC>(d.cfg);
+    const int P = players_per_env<NC>(d.cfg);   // agent rows per env: NC, or NC / 2 in a one-team env
     // the GameState of the step (taken after tick 1) lives in the env's TickWork area, which is dead between ticks
     Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);
     static_assert(sizeof(Snapshot<NC>) <= sizeof(TickWork<NC>), "the step's snapshot borrows the TickWork area");
@@ -461,14 +462,14 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) {
         int32_t acts[NC];
-        for (int k = 0; k < NC; k++) acts[k] = actions[(size_t)env * NC + k];
+        for (int k = 0; k < P; k++) acts[k] = actions[(size_t)env * P + k];   // agent rows of this env (gym_step_begin maps them to slots)
         gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts);
     }
     wave_sync();
     RLG_PROF(8);
     TickEvents ev; ev.bump_mask = 0;
     arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
-    if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * NC * D, (size_t)D, snap);
+    if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * P * D, (size_t)D, snap);
     // host plugins see what the reference's see: the arena as it stands where Gym::Step builds its GameState (Gym.cpp:81-93)
     if (d.snap_out && env_lane) arena_to_host(S.A, S.G, d.snap_out[env]);
     if (d.step_stats) { StepStats st; if (env_lane) step_stats_add<NC>(st, snap); step_stats_flush(d.step_stats, st, ws.lane); }
@@ -476,9 +477,9 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     RLG_PROF(9);
     for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
     RLG_PROF(6);
-    if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * NC * D, (size_t)D, dn, snap);
+    if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * P * D, (size_t)D, dn, snap);
     RLG_PROF(10);
-    if (env_lane) for (int k = 0; k < NC; k++) { reward[(size_t)env * NC + k] = rew[k]; done[(size_t)env * NC + k] = dn ? 1 : 0; }
+    if (env_lane) for (int k = 0; k < P; k++) { reward[(size_t)env * P + k] = rew[k]; done[(size_t)env * P + k] = dn ? 1 : 0; }
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     RLG_PROF(11);
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
     load_env(d, env, S.A, S.G);
     const int D = obs_size<NC>(d.cfg);
-    gym_reset_env<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * NC * D : nullptr, (size_t)D, run_setter != 0);
+    gym_reset_env<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * players_per_env<NC>(d.cfg) * D : nullptr, (size_t)D, run_setter != 0);
     store_env(d, env, S.A, S.G);
 }
 
@@ -714,6 +715,7 @@ void rlgpu_default_gym_config(RlgpuGymConfig* c) {
     c->vel_coef = 1 / 2300.f; c->ang_vel_coef = 1 / 5.5f;
     c->n_actions = 90;
     c->obs_max_players = 0;
+    c->one_team = 0;
 }
 
 int rlgpu_pad_location(int pad, float* pos_uu, int* is_big) {
@@ -777,8 +779,8 @@ void rlgpu_env_destroy(rlgpu_env* e) {
 const char* rlgpu_env_last_error(const rlgpu_env* e) { return e ? e->err.c_str() : "null env"; }
 int rlgpu_env_reseed(rlgpu_env* e, uint32_t seed_lo, uint32_t seed_hi) { e->d.cfg.seed_lo = seed_lo; e->d.cfg.seed_hi = seed_hi; return RLGPU_OK; }
 int rlgpu_env_set_stream(rlgpu_env* e, void* s) { e->stream = (hipStream_t)s; return RLGPU_OK; }
-int rlgpu_env_obs_size(const rlgpu_env* e) { return e->d.cfg.obs_max_players > 0 ? 51 + 38 * e->d.cfg.obs_max_players : 51 + 19 * e->nc; }
-int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * e->nc; }
+int rlgpu_env_obs_size(const rlgpu_env* e) { return e->d.cfg.obs_max_players > 0 ? 51 + 38 * e->d.cfg.obs_max_players : 51 + 19 * (e->d.cfg.one_team ? e->nc / 2 : e->nc); }
+int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * (e->d.cfg.one_team ? e->nc / 2 : e->nc); }
 int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }
 
@@ -953,7 +955,7 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float*
 int rlgpu_env_step_controls(rlgpu_env* e, const float* controls, float* next_obs, float* reward, int32_t* done) {
     if (!controls || !next_obs || !reward || !done) { e->err = "rlgpu_env_step_controls: null device pointer"; return RLGPU_ERR_ARG; }
     HIPCHK(e, hipSetDevice(e->device));
-    const int n_agents = e->n_envs * e->nc;
+    const int n_agents = rlgpu_env_num_agents(e);
     if (!e->d_iota) {
         std::vector<int32_t> iota((size_t)n_agents);
         for (int i = 0; i < n_agents; i++) iota[i] = i;
@@ -971,6 +973,7 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls, float* next_obs
 // ThreadAgent::_RunFunc for a whole collection phase (ThreadAgent.cpp:58-163): T x (policy->GetAction, GameInst::Step) for every env
 int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic) {
     if (!l || T <= 0 || !obs || !actions || !logp || !reward || !done) { e->err = "rlgpu_collect: bad argument"; return RLGPU_ERR_ARG; }
+    if (e->d.cfg.one_team) { e->err = "rlgpu_collect: one-team envs are collected step by step (rlgpu_policy_act + rlgpu_env_step)"; return RLGPU_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     CollectArgs c{};
     const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;

@@ -15,12 +15,17 @@ struct ArenaDevice {
 };
 void EnvCheck(rlgpu_env* env, int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
 
-ArenaDevice* EnsureDevice(void*& slot, const RlgpuGymConfig& cfg, int players) {
+ArenaDevice* EnsureDevice(RocketSim::Arena* arena, RlgpuGymConfig cfg) {
+    void*& slot = arena->_device;
     ArenaDevice* d = static_cast<ArenaDevice*>(slot);
-    if (players != 2 && players != 4 && players != 6) RG_ERR_CLOSE("Arena: the device stepper runs 1v1, 2v2 or 3v3 (got " << players << " cars)");
-    if (d && (std::memcmp(&d->cfg, &cfg, sizeof(cfg)) != 0 || d->teamSize != players / 2)) { delete d; d = nullptr; }
+    const int cars = (int)arena->_cars.size();
+    if (cars == 1 && !arena->_IsOneTeam()) arena->_SetOneTeam();   // a lone blue car: an arena without opponents
+    cfg.one_team = arena->_IsOneTeam() ? 1 : 0;
+    const int teamSize = cfg.one_team ? cars : cars / 2;
+    if (teamSize < 1 || teamSize > 3 || (!cfg.one_team && cars % 2)) RG_ERR_CLOSE("Arena: the device stepper runs 1 to 3 cars per team, with or without opponents (got " << cars << " cars)");
+    if (d && (std::memcmp(&d->cfg, &cfg, sizeof(cfg)) != 0 || d->teamSize != teamSize)) { delete d; d = nullptr; }
     if (!d) {
-        d = new ArenaDevice(); d->cfg = cfg; d->teamSize = players / 2;
+        d = new ArenaDevice(); d->cfg = cfg; d->teamSize = teamSize;
         int rc = rlgpu_env_create(&d->env, 0, 1, d->teamSize, &cfg);
         if (rc != RLGPU_OK) { delete d; RG_ERR_CLOSE("rlgpu_env_create failed (" << rc << ")"); }
         RLGSC::LoadArenaMesh(d->env, true);
@@ -41,9 +46,7 @@ RlgpuGymConfig NeutralConfig(int tickSkip) {
 namespace RocketSim {
 void Arena::Step(int ticksToSimulate) {
     if (ticksToSimulate <= 0) return;
-    void* slot = _device;
-    ArenaDevice* d = _device ? static_cast<ArenaDevice*>(_device) : EnsureDevice(slot, NeutralConfig(8), (int)_cars.size());
-    _device = slot;
+    ArenaDevice* d = _device ? static_cast<ArenaDevice*>(_device) : EnsureDevice(this, NeutralConfig(8));
     _SyncToState();
     EnvCheck(d->env, rlgpu_env_upload_states(d->env, &_state, nullptr, 1), "upload_states");
     EnvCheck(d->env, rlgpu_env_physics_ticks(d->env, ticksToSimulate), "physics_ticks");
@@ -55,9 +58,10 @@ void Arena::ReleaseDevice() { delete static_cast<ArenaDevice*>(_device); _device
 
 namespace RLGSC {
 
-Arena* MakeScratchArena(int players) {
+Arena* MakeScratchArena(int teamSize, bool spawnOpponents) {
     Arena* a = Arena::Create(GameMode::SOCCAR);
-    for (int k = 0; k < players; k++) a->AddCar(k % 2 == 0 ? Team::BLUE : Team::ORANGE);
+    for (int i = 0; i < teamSize; i++) { a->AddCar(Team::BLUE); if (spawnOpponents) a->AddCar(Team::ORANGE); }
+    if (!spawnOpponents) a->_SetOneTeam();
     return a;
 }
 
@@ -70,11 +74,11 @@ Gym::Gym(Match* match, int tickSkip, CarConfig carConfig, GameMode gameMode, Mut
     : match(match), tickSkip(tickSkip), actionDelay(tickSkip - 1) {
     arena = Arena::Create(gameMode);
     arena->SetMutatorConfig(mutatorConfig);
-    if (!match->spawnOpponents) RG_ERR_CLOSE("Gym: spawnOpponents = false is not supported by the device stepper");
     for (int i = 0; i < match->teamSize; i++) {
         carIds.push_back(arena->AddCar(Team::BLUE, carConfig)->id);
-        carIds.push_back(arena->AddCar(Team::ORANGE, carConfig)->id);
+        if (match->spawnOpponents) carIds.push_back(arena->AddCar(Team::ORANGE, carConfig)->id);
     }
+    if (!match->spawnOpponents) arena->_SetOneTeam();
 }
 Gym::~Gym() { delete dev; delete arena; }
 
@@ -82,7 +86,7 @@ Gym::~Gym() { delete dev; delete arena; }
 FList2 Gym::Reset() {
     (void)match->ResetState(arena);
     // the device does the episode bookkeeping on the new state: counters, score line, event tracker (Gym.cpp:62-63)
-    ArenaDevice* d = EnsureDevice(arena->_device, NeutralConfig(tickSkip), match->playerAmount);
+    ArenaDevice* d = EnsureDevice(arena, NeutralConfig(tickSkip));
     arena->_SyncToState();
     const int32_t env0 = 0;
     EnvCheck(d->env, rlgpu_env_upload_states(d->env, &arena->_state, nullptr, 1), "upload_states");
@@ -101,7 +105,7 @@ Gym::StepResult Gym::Step(const ActionParser::Input& actionsData) {
     match->prevActions = actions;
     const int P = match->playerAmount;
     if ((int)actions.size() != P) RG_ERR_CLOSE("Gym::Step(): " << actions.size() << " actions for " << P << " players");
-    ArenaDevice* d = EnsureDevice(arena->_device, NeutralConfig(tickSkip), P);
+    ArenaDevice* d = EnsureDevice(arena, NeutralConfig(tickSkip));
     if (!dev) {
         dev = new Device();
         dev->controls = dev_alloc<float>((size_t)P * 8); dev->obs = dev_alloc<float>((size_t)P * rlgpu_env_obs_size(d->env));

@@ -331,7 +331,7 @@ void Learner::Impl::SetupHostPath(const EnvCreateFn& create, int numThreads) {
             if (!r.match || !r.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
             envMatch[e] = r.match; envGym[e] = r.gym;
         }
-        for (int w = 0; w < workers; w++) arenas.push_back(RLGSC::MakeScratchArena(nPlayers));
+        for (int w = 0; w < workers; w++) arenas.push_back(RLGSC::MakeScratchArena(match->teamSize, match->spawnOpponents));
         if (plan.hostObs) devObs = dev_alloc<float>((size_t)nAgents * Ddev);
         if (plan.hostParser) { devControls = dev_alloc<float>((size_t)nAgents * 8); hControls.resize((size_t)nAgents * 8); }
     }

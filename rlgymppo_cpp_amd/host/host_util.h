@@ -12,6 +12,6 @@
 namespace RLGSC {
 // the arena mesh RocketSim::Init pointed at ("<folder>/soccar/*.cmf"), or the procedural soccar mesh when there is none
 void LoadArenaMesh(rlgpu_env* env, bool quiet);
-// a host Arena facade with `players` cars in the device's slot order (blue, orange, blue, ...)
-Arena* MakeScratchArena(int players);
+// a host Arena facade with the cars of one env in the device's slot order (blue, orange, blue, ...; blue only without opponents)
+Arena* MakeScratchArena(int teamSize, bool spawnOpponents);
 }

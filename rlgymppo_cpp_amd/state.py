@@ -22,6 +22,7 @@ CF_IS_AUTOFLIPPING = 1 << 11
 CF_WORLD_CONTACT = 1 << 12
 CF_IS_DEMOED = 1 << 13
 CF_BALLHIT_VALID = 1 << 14
+CF_ABSENT = 1 << 15   # no car in this slot (the orange slots of a one-team env)
 
 f32 = C.c_float
 

@@ -44,7 +44,7 @@ struct HostOnlyParser : DiscreteAction {
 };
 
 static int g_teamSize = 1;
-static bool g_host = false, g_hostParser = false;
+static bool g_host = false, g_hostParser = false, g_spawnOpponents = true;
 static EnvCreateResult MakeBuiltinEnv() {
     auto terms = std::vector<std::pair<RewardFunction*, float>>{
         {new FaceBallReward(), 0.1f}, {new VelocityPlayerToBallReward(), 0.5f}, {new VelocityBallToGoalReward(), 1.0f}, {new TouchBallReward(0.5f), 2.f},
@@ -55,7 +55,7 @@ static EnvCreateResult MakeBuiltinEnv() {
     std::vector<TerminalCondition*> terminal = {g_host ? (TerminalCondition*)new HostOnlyNoTouch(12) : new NoTouchCondition(12), new GoalScoreCondition()};
     OBSBuilder* obs = g_host ? (OBSBuilder*)new HostOnlyOBS() : new DefaultOBS();
     ActionParser* parser = g_hostParser ? (ActionParser*)new HostOnlyParser() : new DiscreteAction();
-    Match* match = new Match(reward, terminal, obs, parser, new RandomState(true, true, false), g_teamSize, true);
+    Match* match = new Match(reward, terminal, obs, parser, new RandomState(true, true, false), g_teamSize, g_spawnOpponents);
     return {match, new Gym(match, 8)};
 }
 
@@ -72,9 +72,9 @@ static LearnerConfig SmallConfig(int envs, int steps, int players) {
 }
 
 struct Collected { std::vector<float> obs, rew; std::vector<int32_t> acts, done; int D = 0, T = 0, agents = 0; };
-static Collected CollectOnce(bool host, bool hostParser, int teamSize, int envs, int steps, int iterations = 1) {
+static Collected CollectOnce(bool host, bool hostParser, int teamSize, int envs, int steps, int iterations = 1, int players = 0) {
     g_host = host; g_hostParser = hostParser; g_teamSize = teamSize;
-    Learner learner(MakeBuiltinEnv, SmallConfig(envs, steps, 2 * teamSize));
+    Learner learner(MakeBuiltinEnv, SmallConfig(envs, steps, players ? players : 2 * teamSize));
     Collected c;
     for (int i = 0; i < iterations; i++) learner.CollectTimesteps();
     learner.CopyCollected(&c.obs, &c.acts, &c.rew, &c.done);
@@ -82,9 +82,13 @@ static Collected CollectOnce(bool host, bool hostParser, int teamSize, int envs,
     return c;
 }
 
-static int ComparePaths(int teamSize, bool hostParser) {
+static int ComparePaths(int teamSize, bool hostParser, bool spawnOpponents = true) {
     const int envs = 32, steps = 48;
-    Collected dev = CollectOnce(false, false, teamSize, envs, steps, 2), host = CollectOnce(true, hostParser, teamSize, envs, steps, 2);
+    g_spawnOpponents = spawnOpponents;
+    const int players = spawnOpponents ? 2 * teamSize : teamSize;
+    Collected dev = CollectOnce(false, false, teamSize, envs, steps, 2, players), host = CollectOnce(true, hostParser, teamSize, envs, steps, 2, players);
+    g_spawnOpponents = true;
+    CHECK(dev.agents == envs * players && dev.D == 51 + 19 * players);
     CHECK(dev.D == host.D && dev.T == host.T && dev.agents == host.agents && dev.T == steps);
     CHECK(dev.acts == host.acts);                       // same observations -> same sampled actions, step after step
     CHECK(dev.done == host.done);
@@ -93,7 +97,7 @@ static int ComparePaths(int teamSize, bool hostParser) {
     double worstObs = 0, worstRew = 0, sumAbsRew = 0;
     for (size_t i = 0; i < dev.obs.size(); i++) worstObs = std::max(worstObs, (double)std::fabs(dev.obs[i] - host.obs[i]));
     for (size_t i = 0; i < dev.rew.size(); i++) { worstRew = std::max(worstRew, (double)std::fabs(dev.rew[i] - host.rew[i])); sumAbsRew += std::fabs(dev.rew[i]); }
-    std::printf("team size %d%s: %d dones, max |obs diff| %.3g, max |reward diff| %.3g (mean |reward| %.3g)\n", teamSize, hostParser ? " + host parser" : "", dones,
+    std::printf("team size %d%s%s: %d dones, max |obs diff| %.3g, max |reward diff| %.3g (mean |reward| %.3g)\n", teamSize, hostParser ? " + host parser" : "", spawnOpponents ? "" : ", no opponents", dones,
                 worstObs, worstRew, sumAbsRew / dev.rew.size());
     CHECK(worstObs <= 1e-6);                            // same arithmetic on both sides: one multiply per value
     CHECK(worstRew <= 2e-5);                            // sums of products: fp32 rounding order only
@@ -295,6 +299,17 @@ static int StandaloneGym() {
     const BallState fell = arena->ball->GetState();
     CHECK(arena->tickCount == 60 && fell.pos.z < 1000.f - 70.f && fell.pos.z > 1000.f - 90.f && fell.vel.z < -300.f);   // 0.5 s of -650 uu/s^2
     delete arena;
+    {   // a gym without opponents: one car, one observation row with no other player in it
+        CombinedReward solo({{new VelocityPlayerToBallReward(), 1.f}}, true);
+        NoTouchCondition nt(4);
+        Match m1(&solo, {&nt}, &obs, &parser, &kickoff, 1, false);
+        Gym g1(&m1, 8);
+        FList2 o1 = g1.Reset();
+        CHECK(m1.playerAmount == 1 && g1.arena->_cars.size() == 1 && o1.size() == 1 && o1[0].size() == 51 + 19 && g1.prevState.players.size() == 1 && g1.prevState.players[0].carId == 1);
+        bool ended = false;
+        for (int i = 0; i < 4; i++) { Gym::StepResult r = g1.Step({drive[0]}); CHECK(r.obs.size() == 1 && r.reward.size() == 1 && r.state.players.size() == 1); ended = r.done; }
+        CHECK(ended);   // NoTouchCondition(4)
+    }
     std::printf("standalone gym: %d steps to the first touch-and-beyond, reward %.2f\n", stepsTaken, total);
     return 0;
 }
@@ -306,6 +321,8 @@ int main(int argc, char** argv) {
         if (argc > 1 && std::string(argv[1]) == "throughput") return Throughput();
         if (ComparePaths(1, false)) return 1;
         if (ComparePaths(2, true)) return 1;
+        if (ComparePaths(2, false, false)) return 1;    // Match(..., spawnOpponents = false): two blue cars and nobody else
+        if (ComparePaths(1, true, false)) return 1;     // a single car
         if (UserPlugins()) return 1;
         if (StandaloneGym()) return 1;
     } catch (const std::exception& e) {

@@ -178,6 +178,78 @@ def gym_cases(ref):
     return out
 
 
+def one_team_cases(ref):
+    """Gyms WITHOUT opponents -- Match(..., spawnOpponents = false) -- as (name, team_size, tick_skip, obs_max_players, reward_kind,
+    no_touch_steps, start state, actions [steps][team_size]).  The start state has 2 * team_size slots, the blue cars on the even ones."""
+    from rlgymppo_cpp_amd.state import CF_ABSENT, CF_IS_DEMOED
+    tab = np.zeros((128, 8), np.float32)
+    n = ref.lib.ref_action_table(tab.ctypes.data_as(C.c_void_p), 128); tab = tab[:n]
+
+    def act(thr=0, steer=0, boost=0):
+        d = np.abs(tab - np.array([thr, steer, 0, steer, 0, 0, boost, 0], np.float32)).sum(1)
+        i = int(np.argmin(d)); assert d[i] == 0
+        return i
+    FWD = act(thr=1, boost=1)
+
+    def arena(team, cars):
+        s = default_arena(2 * team)
+        for k in range(1, 2 * team, 2):
+            s.cars[k].flags = CF_IS_DEMOED | CF_ABSENT; s.cars[k].demo_respawn_timer = 1e30; s.cars[k].pos[:] = (0, 0, -10000)
+        for j, (pos, yaw, boost) in enumerate(cars):
+            s.cars[2 * j].pos[:] = pos; s.cars[2 * j].rot[:] = yaw_rot(yaw); s.cars[2 * j].boost = boost
+        return s
+    out = []
+    # one car pushes the ball into the orange goal: touch, shot, goal; EventReward{teamGoal}, GoalScoreCondition
+    s = arena(1, [((0, 3000, 17), np.pi / 2, 100)]); s.ball.pos[:] = (0, 3900, 93.15)
+    out.append(("1v0_push_into_goal", 1, 8, 0, 0, 150, s, np.full((80, 1), FWD, np.int32)))
+    # nobody touches the ball: NoTouchCondition ends the episode
+    s = arena(1, [((2000, -3000, 17), 0.0, 30)]); s.ball.pos[:] = (-1000, 2000, 93.15)
+    out.append(("1v0_timeout", 1, 8, 0, 0, 10, s, np.random.RandomState(11).randint(0, 90, size=(30, 1)).astype(np.int32)))
+    # two team mates, every reward term inside ZeroSumReward (the opponents' mean is that of an empty team), random play around the ball
+    s = arena(2, [((-300, -1000, 17), np.pi / 2, 80), ((400, -1500, 17), np.pi / 2 + 0.2, 50)]); s.ball.pos[:] = (0, 0, 93.15)
+    a = np.random.RandomState(12).randint(0, 90, size=(70, 2)).astype(np.int32); a[:22] = FWD
+    out.append(("2v0_allterms_zerosum_random", 2, 8, 0, 3, 150, s, a))
+    # three team mates, DefaultOBSPadded(3): two teammate blocks and three zero opponent blocks, shuffled
+    # (not the mirror-symmetric kickoff spots: two cars meeting exactly head-on at the centre line is a coin toss between which of them
+    # bumps the other, decided by the last bit of the first contact point)
+    s = arena(3, [((-2048, -2560, 17), np.pi / 4, 33.3), ((1500, -3300, 17), 2.0, 60.0), ((0, -4608, 17), np.pi / 2, 33.3)])
+    a = np.random.RandomState(13).randint(0, 90, size=(60, 3)).astype(np.int32); a[:20] = FWD
+    out.append(("3v0_padded3_allterms", 3, 8, 3, 2, 150, s, a))
+    return out
+
+
+def main_one_team():
+    """tests/golden/sim_golden_one_team.npz: the one-team gym rollouts of the reference (kept apart from sim_golden.npz so that file stays as it is)."""
+    port = PortSim()
+    verts, tris = port.procedural_mesh()
+    ref = RefSim(verts, tris)
+    out = {"mesh_verts": verts, "mesh_tris": tris}
+    gnames = []
+    for case, team, tick_skip, omp, rk, nts, s0, acts in one_team_cases(ref):
+        g = RefGym(ref, team, tick_skip, reward_kind=rk, no_touch_steps=nts, obs_max_players=omp, spawn_opponents=False)
+        obs0 = g.reset_to(s0)
+        start = ref.get_state(g.arena())
+        obs = []; rew = []; done = []; order = []; last = None
+        for t in range(len(acts)):
+            o, r, d, st = g.step(acts[t])
+            obs.append(o); rew.append(r); done.append(d); order.append(g.player_order()); last = st
+            if d:
+                acts = acts[: t + 1]
+                break
+        out[f"gym/{case}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        out[f"gym/{case}/obs0"] = obs0
+        out[f"gym/{case}/actions"] = acts
+        out[f"gym/{case}/obs"] = np.stack(obs); out[f"gym/{case}/rew"] = np.stack(rew); out[f"gym/{case}/done"] = np.array(done, np.int32)
+        out[f"gym/{case}/player_order"] = np.array(order, np.int32)
+        out[f"gym/{case}/final"] = np.frombuffer(bytes(last), np.uint8).copy()
+        out[f"gym/{case}/cfg"] = np.array([team, tick_skip, omp, rk, nts, 0], np.int32)     # last entry: spawnOpponents
+        gnames.append(case)
+        print(case, "steps", len(acts), "done", done[-1], "reward sum", np.sum(rew))
+    out["gym_names"] = np.array(gnames)
+    np.savez_compressed(os.path.join(HERE, "sim_golden_one_team.npz"), **out)
+    print("wrote sim_golden_one_team.npz:", len(gnames), "gym rollouts")
+
+
 def main():
     port = PortSim()
     verts, tris = port.procedural_mesh()
@@ -259,5 +331,7 @@ def main():
     print("wrote sim_golden.npz:", len(names), "physics scenarios,", len(gnames), "gym rollouts; sim_steps.npz:", {k: len(v) for k, v in steps_tag.items()}, "one-tick pairs")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--one-team" in sys.argv:
+    main_one_team()
+elif __name__ == "__main__":
     main()

@@ -123,9 +123,13 @@ def all_terms_cfg(zero_sum=False, **over):
     return c
 
 
+def _gym_rows(cfg, nc):
+    rows = nc // 2 if cfg.one_team else nc
+    return rows, (51 + 38 * cfg.obs_max_players if cfg.obs_max_players > 0 else 51 + 19 * rows)
+
+
 def port_gym_reset(port, states, cfg, run_setter=True):
-    n = len(states); nc = states[0].num_cars
-    D = 51 + 38 * cfg.obs_max_players if cfg.obs_max_players > 0 else 51 + 19 * nc
+    n = len(states); nc, D = _gym_rows(cfg, states[0].num_cars)
     arr = (ArenaState * n)(*states)
     obs = np.zeros((n * nc, D), np.float32)
     port.lib.port_gym_reset(arr, n, C.byref(cfg), _ptr(obs), 1 if run_setter else 0)
@@ -133,8 +137,7 @@ def port_gym_reset(port, states, cfg, run_setter=True):
 
 
 def port_gym_step(port, states, cfg, actions):
-    n = len(states); nc = states[0].num_cars
-    D = 51 + 38 * cfg.obs_max_players if cfg.obs_max_players > 0 else 51 + 19 * nc
+    n = len(states); nc, D = _gym_rows(cfg, states[0].num_cars)
     arr = (ArenaState * n)(*states)
     actions = np.ascontiguousarray(actions, np.int32)
     obs = np.zeros((n * nc, D), np.float32); rew = np.zeros(n * nc, np.float32); done = np.zeros(n * nc, np.int32)
@@ -145,16 +148,16 @@ def port_gym_step(port, states, cfg, actions):
 class RefGym:
     """The reference's Gym behind oracle/ref_driver.cpp.  obs_max_players 0: DefaultOBS, m: DefaultOBSPadded(m); reward_kind 0/1: example
     stack plain / zero-sum, 2/3: every CommonRewards term plain / zero-sum (ref_gym_new2)."""
-    def __init__(self, ref, team_size=1, tick_skip=8, obs_kind=0, reward_kind=0, no_touch_steps=150, obs_max_players=0):
-        self.ref = ref; self.nc = 2 * team_size
+    def __init__(self, ref, team_size=1, tick_skip=8, obs_kind=0, reward_kind=0, no_touch_steps=150, obs_max_players=0, spawn_opponents=True):
+        self.ref = ref; self.nc = 2 * team_size if spawn_opponents else team_size   # agent rows
         self.D = 51 + 38 * obs_max_players if obs_max_players > 0 else 51 + 19 * self.nc
-        ref.lib.ref_gym_new2.restype = _vp
-        self.h = _vp(ref.lib.ref_gym_new2(team_size, tick_skip, obs_max_players, reward_kind, no_touch_steps))
+        ref.lib.ref_gym_new3.restype = _vp
+        self.h = _vp(ref.lib.ref_gym_new3(team_size, tick_skip, obs_max_players, reward_kind, no_touch_steps, 1 if spawn_opponents else 0))
 
     def player_order(self):
         out = (C.c_int32 * 8)()
         n = self.ref.lib.ref_gym_player_order(self.h, out)
-        return [int(out[i]) - 1 for i in range(n)]     # slots
+        return [int(out[i]) - 1 for i in range(n)]     # agent rows (= slots with two teams)
 
     def reset_to(self, state):
         obs = np.zeros((self.nc, self.D), np.float32)
@@ -250,16 +253,18 @@ def gym_cfg_for_case(team, tick_skip, obs_max_players, reward_kind, no_touch_ste
     return c
 
 
-def gym_compare_obs(got, ref, nc, obs_max_players, ref_order, tol, what):
+def gym_compare_obs(got, ref, nc, obs_max_players, ref_order, tol, what, one_team=False):
     """Observation rows in slot order.  DefaultOBS lists the OTHER players in the reference's GameState::players order (an unordered_set
     iteration, recorded per step in the fixture) where this build uses slot order; DefaultOBSPadded shuffles both lists with a
     process-wide RNG: compared as the fixed part + the multiset of 19-float blocks per list."""
     got = np.asarray(got); ref = np.asarray(ref)
     assert got.shape == ref.shape, f"{what}: obs shape {got.shape} vs {ref.shape}"
     assert np.abs(got[:, :70] - ref[:, :70]).max() < tol, f"{what}: ball / prev action / pads / self part differs by {np.abs(got[:, :70] - ref[:, :70]).max()}"
-    for row in range(nc):
-        mates = [s for s in ref_order if s != row and s % 2 == row % 2]; opps = [s for s in ref_order if s % 2 != row % 2]
-        mine_m = [s for s in range(nc) if s != row and s % 2 == row % 2]; mine_o = [s for s in range(nc) if s % 2 != row % 2]
+    rows = nc // 2 if one_team else nc                       # one-team gyms (spawnOpponents = false): agent rows = the blue cars, all teammates
+    team = (lambda s: 0) if one_team else (lambda s: s % 2)
+    for row in range(rows):
+        mates = [s for s in ref_order if s != row and team(s) == team(row)]; opps = [s for s in ref_order if team(s) != team(row)]
+        mine_m = [s for s in range(rows) if s != row and team(s) == team(row)]; mine_o = [s for s in range(rows) if team(s) != team(row)]
         if obs_max_players > 0:
             nm, no = obs_max_players - 1, obs_max_players
             for lo, n in ((70, nm), (70 + 19 * nm, no)):

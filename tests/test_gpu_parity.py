@@ -204,6 +204,12 @@ def _gym_cfg(team, tick_skip, omp, rk, nts):
     return gym_cfg_for_case(team, tick_skip, omp, rk, nts)
 
 
+def test_hip_one_team_gym_rollouts_vs_reference_fixtures():
+    """Match(..., spawnOpponents = false) on the HIP path against the reference's one-team gyms (tests/golden/sim_golden_one_team.npz):
+    agent rows = the blue cars only, no opponent blocks in DefaultOBS, zero blocks in DefaultOBSPadded, ZeroSumReward with an empty team."""
+    test_hip_gym_rollouts_vs_reference_fixtures(np.load(os.path.join(GOLD, "sim_golden_one_team.npz")))
+
+
 def test_hip_gym_rollouts_vs_reference_fixtures(sg):
     """Every committed rollout of the REAL reference Gym replayed on the HIP path, no port in between: 1v1 example stack (full 160
     steps, the NoTouch timeout, a goal), 2v2 with every CommonRewards term (goal + assist + shot pass; shot + save + bump + demo),
@@ -213,15 +219,19 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
     dev = torch.device("cuda", 0)
     for case in sg["gym_names"]:
         case = str(case)
-        team, tick_skip, omp, rk, nts = [int(x) for x in sg[f"gym/{case}/cfg"]]
+        team, tick_skip, omp, rk, nts = [int(x) for x in sg[f"gym/{case}/cfg"][:5]]
+        one_team = len(sg[f"gym/{case}/cfg"]) > 5 and int(sg[f"gym/{case}/cfg"][5]) == 0      # spawnOpponents = false
         nc = 2 * team
-        env = BatchedEnv(1, team, cfg=_gym_cfg(team, tick_skip, omp, rk, nts), mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+        gcfg = _gym_cfg(team, tick_skip, omp, rk, nts); gcfg.one_team = 1 if one_team else 0
+        env = BatchedEnv(1, team, cfg=gcfg, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+        rows = env.n_agents
+        assert rows == (team if one_team else nc)
         st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes())
         env.upload_states([st])
         obs0 = env.reset(False)
-        gym_compare_obs(obs0.cpu().numpy(), sg[f"gym/{case}/obs0"], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][0]], 1e-5, f"{case} reset")
+        gym_compare_obs(obs0.cpu().numpy(), sg[f"gym/{case}/obs0"], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][0]], 1e-5, f"{case} reset", one_team)
         acts = sg[f"gym/{case}/actions"]; obs = sg[f"gym/{case}/obs"]; rew = sg[f"gym/{case}/rew"]; done = sg[f"gym/{case}/done"]
-        nobs = torch.empty((nc, env.obs_size), device=dev); r = torch.empty(nc, device=dev); d = torch.empty(nc, dtype=torch.int32, device=dev)
+        nobs = torch.empty((rows, env.obs_size), device=dev); r = torch.empty(rows, device=dev); d = torch.empty(rows, dtype=torch.int32, device=dev)
         for t in range(min(len(acts), GYM_HORIZON.get(case, len(acts)))):
             env.step(torch.from_numpy(acts[t].astype(np.int32)).to(dev), nobs, r, d)
             env.sync()
@@ -230,11 +240,11 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
             assert np.abs(rr - rew[t]).max() < 2e-3 * max(1.0, np.abs(rew[t]).max()), f"{case}: reward differs at step {t}: {rr} vs {rew[t]}"
             if done[t]:
                 break
-            gym_compare_obs(nobs.cpu().numpy(), obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}")
+            gym_compare_obs(nobs.cpu().numpy(), obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}", one_team)
         if not (done[-1] or case in GYM_HORIZON):
             fin = ArenaState.from_buffer_copy(sg[f"gym/{case}/final"].tobytes())
             got = env.download_states()[0]
-            for k in range(nc):
+            for k in range(0, nc, 2 if one_team else 1):
                 a, b = got.gym.players[k], fin.gym.players[k]
                 assert (a.match_goals, a.match_assists, a.match_shots, a.match_saves, a.match_shot_passes, a.match_bumps, a.match_demos, a.boost_pickups) == \
                        (b.match_goals, b.match_assists, b.match_shots, b.match_saves, b.match_shot_passes, b.match_bumps, b.match_demos, b.boost_pickups), f"{case}: counters of player {k}"

@@ -185,18 +185,31 @@ def test_port_one_tick_vs_reference_states():
     assert n_tight >= 0.95 * n_all, f"only {n_tight} of {n_all} one-tick pairs within 0.01 uu/s"
 
 
+@pytest.fixture(scope="module")
+def sg1():
+    return np.load(os.path.join(GOLD, "sim_golden_one_team.npz"))
+
+
+def test_port_one_team_gym_vs_reference_golden(sg1, port_lib):
+    """Match(..., spawnOpponents = false): the reference's one-team gyms (1v0 push into the goal, 1v0 NoTouch timeout, 2v0 every reward term
+    inside ZeroSumReward, 3v0 DefaultOBSPadded(3)) step by step: done exactly, rewards, observation rows, counters."""
+    test_port_gym_vs_reference_golden(sg1, port_lib)
+
+
 def test_port_gym_vs_reference_golden(sg, port_lib):
     """Gym rollouts of the reference -- 1v1 example stack (incl. the NoTouch timeout and a goal), 2v2 with every CommonRewards term
     (goal + assist + shot pass; shot + save + bump + demo), zero-sum, DefaultOBSPadded, 3v3 -- step by step: done exactly, reward and
     observation rows (for 2v2 / 3v3 with the reference's own player order), and the event counters at the end."""
     for case in sg["gym_names"]:
         case = str(case)
-        team, tick_skip, omp, rk, nts = [int(x) for x in sg[f"gym/{case}/cfg"]]
+        team, tick_skip, omp, rk, nts = [int(x) for x in sg[f"gym/{case}/cfg"][:5]]
+        one_team = len(sg[f"gym/{case}/cfg"]) > 5 and int(sg[f"gym/{case}/cfg"][5]) == 0      # spawnOpponents = false
         cfg = gym_cfg_for_case(team, tick_skip, omp, rk, nts)
+        cfg.one_team = 1 if one_team else 0
         st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes()); nc = 2 * team
         (st,), obs0 = port_gym_reset(port_lib, [st], cfg, run_setter=False)
         order0 = [int(x) for x in sg[f"gym/{case}/player_order"][0]]
-        gym_compare_obs(obs0, sg[f"gym/{case}/obs0"], nc, omp, order0, 1e-5, f"{case} reset")
+        gym_compare_obs(obs0, sg[f"gym/{case}/obs0"], nc, omp, order0, 1e-5, f"{case} reset", one_team)
         acts = sg[f"gym/{case}/actions"]; obs = sg[f"gym/{case}/obs"]; rew = sg[f"gym/{case}/rew"]; done = sg[f"gym/{case}/done"]
         for t in range(min(len(acts), GYM_HORIZON.get(case, len(acts)))):
             (st,), o, r, d = port_gym_step(port_lib, [st], cfg, acts[t])
@@ -204,11 +217,11 @@ def test_port_gym_vs_reference_golden(sg, port_lib):
             assert np.abs(r - rew[t]).max() < 2e-3 * max(1.0, np.abs(rew[t]).max()), f"{case}: reward differs at step {t}: {r} vs {rew[t]}"
             if done[t]:
                 break     # GameInst semantics (GameInst.cpp:27-32): the row returned with done is the first observation of the NEXT episode
-            gym_compare_obs(o, obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}")
+            gym_compare_obs(o, obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}", one_team)
         fin = ArenaState.from_buffer_copy(sg[f"gym/{case}/final"].tobytes())
         if done[-1] or case in GYM_HORIZON:
             continue      # the env has auto-reset: the terminal step's events are pinned through its reward (EventReward terms) above
-        for k in range(nc):
+        for k in range(0, nc, 2 if one_team else 1):
             a, b = st.gym.players[k], fin.gym.players[k]
             got = (a.match_goals, a.match_assists, a.match_shots, a.match_saves, a.match_shot_passes, a.match_bumps, a.match_demos, a.boost_pickups)
             ref = (b.match_goals, b.match_assists, b.match_shots, b.match_saves, b.match_shot_passes, b.match_bumps, b.match_demos, b.boost_pickups)
