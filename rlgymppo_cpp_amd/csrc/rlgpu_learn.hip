@@ -774,6 +774,8 @@ struct rlgpu_learner {
     short* x16 = nullptr;                       // [max_rows][kp[0]] network input
     std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
     short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
+    short *g16c = nullptr, *g16d = nullptr;     // the critic's own pair: its chain runs beside the policy's on a second stream (rlgpu_ppo_minibatch)
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t call_ctr = 0, sampler_stream = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -985,7 +987,7 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
             l->last_flops += 2.0 * N_out * K_in * (double)rows;
         }
         if (i > 0) {
-            short* nxt = (cur == l->g16a) ? l->g16b : l->g16a;
+            short* nxt = (cur == l->g16a) ? l->g16b : (cur == l->g16b ? l->g16a : (cur == l->g16c ? l->g16d : l->g16c));
             NtArgs g{};
             g.A = cur; g.lda = net.kp[i + 1];
             g.B = l->shadows + net.wt16_off[i]; g.ldb = net.kp[i + 1];
@@ -1051,6 +1053,9 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
         for (int i = 0; i + 1 < l->pol.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->pol.kp[i + 1] * 2)); l->act16_p.push_back(p); }
         for (int i = 0; i + 1 < l->cri.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->cri.kp[i + 1] * 2)); l->act16_c.push_back(p); }
         LCHK(l, hipMalloc(&l->g16a, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16b, R * maxkp * 2));
+        LCHK(l, hipMalloc(&l->g16c, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16d, R * maxkp * 2));
+        LCHK(l, hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking));
+        LCHK(l, hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); LCHK(l, hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming));
         l->shadows_dirty = true;
     }
     return RLGPU_OK;
@@ -1062,7 +1067,10 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
-    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
+    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b, l->g16c, l->g16d}) if (p) (void)hipFree(p);
+    if (l->side) (void)hipStreamDestroy(l->side);
+    if (l->ev_fork) (void)hipEventDestroy(l->ev_fork);
+    if (l->ev_join) (void)hipEventDestroy(l->ev_join);
     for (short* p : l->act16_p) (void)hipFree(p);
     for (short* p : l->act16_c) (void)hipFree(p);
     for (auto& p : l->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -1222,18 +1230,30 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     const int loss_blocks = std::max(1, std::min(2048, (n + 3) / 4));
     const int vloss_blocks = std::max(1, std::min(1024, (n + 255) / 256));
     if (fast) {
+        // The two networks are independent until the optimizer step: the critic's chain goes to a side stream, the policy's stays on the
+        // learner's, and they meet again before the closing timing event.  A chain is ~12 short dependent launches; every launch boundary
+        // waits for the previous layer's output to leave the per-XCD L2s, and the other chain's kernels fill those gaps.
+        if ((rc = refresh_shadows(l))) return rc;
+        hipStream_t main_stream = l->stream;
+        const bool two = l->side != nullptr && !std::getenv("RLGPU_ONE_STREAM");
+        if (two) { LCHK(l, hipEventRecord(l->ev_fork, main_stream)); LCHK(l, hipStreamWaitEvent(l->side, l->ev_fork, 0)); l->stream = l->side; }
         // critic
-        if ((rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), n))) return rc;
-        hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n,
-                           (float*)nullptr, l->g16a, l->cri.kp[l->cri.n_layers], metrics);
+        rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), n);
+        if (!rc) {
+            hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n,
+                               (float*)nullptr, l->g16c, l->cri.kp[l->cri.n_layers], metrics);
+            rc = net_backward16(l, l->cri, l->act16_c, n, l->g16c);
+        }
+        if (two) { l->stream = main_stream; if (!rc) { LCHK(l, hipEventRecord(l->ev_join, l->side)); } }
+        if (rc) return rc;
         LCHK(l, hipGetLastError());
-        if ((rc = net_backward16(l, l->cri, l->act16_c, n, l->g16a))) return rc;
         // policy
         if ((rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), n))) return rc;
         hipLaunchKernelGGL(k_ppo_policy_loss, dim3(loss_blocks), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
                            l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->g16a, l->pol.kp[l->pol.n_layers], metrics);
         LCHK(l, hipGetLastError());
         if ((rc = net_backward16(l, l->pol, l->act16_p, n, l->g16a))) return rc;
+        if (two) LCHK(l, hipStreamWaitEvent(main_stream, l->ev_join, 0));
     } else {
         // critic
         if ((rc = net_forward(l, l->cri, l->act_c, x, n))) return rc;
