@@ -774,8 +774,11 @@ struct rlgpu_learner {
     short* x16 = nullptr;                       // [max_rows][kp[0]] network input
     std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
     short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
-    short *g16c = nullptr, *g16d = nullptr;     // the critic's own pair: its chain runs beside the policy's on a second stream (rlgpu_ppo_minibatch)
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // bf16 fast path, rlgpu_ppo_minibatch: the critic's chain runs beside the policy's on a side stream, and each network's dW GEMMs run
+    // beside its dX chain on a stream of their own -- so every layer's activation gradient keeps its own buffer until the dW GEMM read it
+    short* dy16[2][9] = {};                     // [policy, critic][layer]: dL/d(layer output), [max_rows][max kp]
+    hipStream_t side = nullptr, dw_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_dy[2][9] = {}, ev_dw_done[2] = {nullptr, nullptr};
     uint32_t call_ctr = 0, sampler_stream = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -967,12 +970,22 @@ int net_forward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& a
     return RLGPU_OK;
 }
 
-// backward: dout16 = dL/d(last layer output) as bf16 [rows][kp[L]] (zero padded); accumulates dW / db into l->grads
-int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, int rows, short* dout16) {
+// backward: dout16 = dL/d(last layer output) as bf16 [rows][kp[L]] (zero padded); accumulates dW / db into l->grads.
+// which < 0: everything on l->stream, gradients ping-pong between g16a / g16b.  which = 0 / 1 (policy / critic, bf16 minibatch path): the dX
+// chain stays on l->stream and writes layer i's input gradient to dy16[which][i - 1]; the dW GEMM of layer i goes to dw_stream[which]
+// behind the event that marks its dY ready -- dW work (45 % of the section) leaves the chain's critical path.
+int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, int rows, short* dout16, int which = -1) {
     short* cur = dout16;
+    const bool split = which >= 0 && l->dw_stream[which] != nullptr;
     for (int i = net.n_layers - 1; i >= 0; i--) {
         const short* in = (i == 0) ? l->x16 : acts16[i - 1];
         const int K_in = net.dims[i], N_out = net.dims[i + 1];
+        hipStream_t dws = l->stream;
+        if (split) {
+            LCHK(l, hipEventRecord(l->ev_dy[which][i], l->stream));            // `cur` (this layer's dY) is complete on the chain
+            LCHK(l, hipStreamWaitEvent(l->dw_stream[which], l->ev_dy[which][i], 0));
+            dws = l->dw_stream[which];
+        }
         {
             TnArgs t{};
             t.Y = cur; t.ldy = net.kp[i + 1]; t.X = in; t.ldx = net.kp[i];
@@ -982,12 +995,12 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
             // too few workgroups (2048: 143); slab partials + a reduction kernel instead of atomics were slower (153 vs 171)
             t.slab = 512;
             dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
-            hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, l->stream, t);
+            hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, dws, t);
             LCHK(l, hipGetLastError());
             l->last_flops += 2.0 * N_out * K_in * (double)rows;
         }
         if (i > 0) {
-            short* nxt = (cur == l->g16a) ? l->g16b : (cur == l->g16b ? l->g16a : (cur == l->g16c ? l->g16d : l->g16c));
+            short* nxt = split ? l->dy16[which][i - 1] : ((cur == l->g16a) ? l->g16b : l->g16a);
             NtArgs g{};
             g.A = cur; g.lda = net.kp[i + 1];
             g.B = l->shadows + net.wt16_off[i]; g.ldb = net.kp[i + 1];
@@ -999,6 +1012,7 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
             cur = nxt;
         }
     }
+    if (split) LCHK(l, hipEventRecord(l->ev_dw_done[which], l->dw_stream[which]));
     return RLGPU_OK;
 }
 
@@ -1053,7 +1067,15 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
         for (int i = 0; i + 1 < l->pol.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->pol.kp[i + 1] * 2)); l->act16_p.push_back(p); }
         for (int i = 0; i + 1 < l->cri.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->cri.kp[i + 1] * 2)); l->act16_c.push_back(p); }
         LCHK(l, hipMalloc(&l->g16a, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16b, R * maxkp * 2));
-        LCHK(l, hipMalloc(&l->g16c, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16d, R * maxkp * 2));
+        for (int w = 0; w < 2; w++) {
+            const Net& net = w == 0 ? l->pol : l->cri;
+            for (int i = 0; i < net.n_layers; i++) {
+                LCHK(l, hipMalloc(&l->dy16[w][i], R * maxkp * 2));
+                LCHK(l, hipEventCreateWithFlags(&l->ev_dy[w][i], hipEventDisableTiming));
+            }
+            LCHK(l, hipStreamCreateWithFlags(&l->dw_stream[w], hipStreamNonBlocking));
+            LCHK(l, hipEventCreateWithFlags(&l->ev_dw_done[w], hipEventDisableTiming));
+        }
         LCHK(l, hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking));
         LCHK(l, hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); LCHK(l, hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming));
         l->shadows_dirty = true;
@@ -1067,7 +1089,12 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
-    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b, l->g16c, l->g16d}) if (p) (void)hipFree(p);
+    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
+    for (int w = 0; w < 2; w++) {
+        for (int i = 0; i < 9; i++) { if (l->dy16[w][i]) (void)hipFree(l->dy16[w][i]); if (l->ev_dy[w][i]) (void)hipEventDestroy(l->ev_dy[w][i]); }
+        if (l->dw_stream[w]) (void)hipStreamDestroy(l->dw_stream[w]);
+        if (l->ev_dw_done[w]) (void)hipEventDestroy(l->ev_dw_done[w]);
+    }
     if (l->side) (void)hipStreamDestroy(l->side);
     if (l->ev_fork) (void)hipEventDestroy(l->ev_fork);
     if (l->ev_join) (void)hipEventDestroy(l->ev_join);
@@ -1241,8 +1268,8 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), n);
         if (!rc) {
             hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n,
-                               (float*)nullptr, l->g16c, l->cri.kp[l->cri.n_layers], metrics);
-            rc = net_backward16(l, l->cri, l->act16_c, n, l->g16c);
+                               (float*)nullptr, l->dy16[1][l->cri.n_layers - 1], l->cri.kp[l->cri.n_layers], metrics);
+            rc = net_backward16(l, l->cri, l->act16_c, n, l->dy16[1][l->cri.n_layers - 1], two ? 1 : -1);
         }
         if (two) { l->stream = main_stream; if (!rc) { LCHK(l, hipEventRecord(l->ev_join, l->side)); } }
         if (rc) return rc;
@@ -1250,10 +1277,13 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         // policy
         if ((rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), n))) return rc;
         hipLaunchKernelGGL(k_ppo_policy_loss, dim3(loss_blocks), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
-                           l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->g16a, l->pol.kp[l->pol.n_layers], metrics);
+                           l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->dy16[0][l->pol.n_layers - 1], l->pol.kp[l->pol.n_layers], metrics);
         LCHK(l, hipGetLastError());
-        if ((rc = net_backward16(l, l->pol, l->act16_p, n, l->g16a))) return rc;
-        if (two) LCHK(l, hipStreamWaitEvent(main_stream, l->ev_join, 0));
+        if ((rc = net_backward16(l, l->pol, l->act16_p, n, l->dy16[0][l->pol.n_layers - 1], two ? 0 : -1))) return rc;
+        if (two) {
+            LCHK(l, hipStreamWaitEvent(main_stream, l->ev_join, 0));
+            LCHK(l, hipStreamWaitEvent(main_stream, l->ev_dw_done[0], 0)); LCHK(l, hipStreamWaitEvent(main_stream, l->ev_dw_done[1], 0));
+        }
     } else {
         // critic
         if ((rc = net_forward(l, l->cri, l->act_c, x, n))) return rc;
