@@ -93,6 +93,7 @@ struct Learner::Impl {
     bool first = true, renderOnly = false, fusedCollect = true;
     Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
+    uint32_t envStreamEpoch = 0;   // second key word of the env batch's RNG streams: bumped on every resume (no replay of the resets of the run continued)
     std::vector<GameInst> games;
     // ---- host path: plugin kinds without a device form (Match::DevicePlan) and step callbacks -------------------------------------
     RLGSC::Match::DevicePlan plan;
@@ -282,6 +283,11 @@ Learner::~Learner() {
 int Learner::NumEnvs() const { return impl->nEnvs; }
 int Learner::NumAgents() const { return impl->nAgents; }
 int Learner::StepsPerIteration() const { return impl->T; }
+uint32_t Learner::SamplerCalls() const {
+    uint32_t stream = 0, calls = 0;
+    impl->LrnCheck(rlgpu_learner_get_sampler(impl->lrn, &stream, &calls), "learner_get_sampler");
+    return calls;
+}
 void Learner::CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones) {
     Impl& m = *impl;
     const size_t TN = (size_t)m.T * m.nAgents;
@@ -640,7 +646,7 @@ void Learner::SaveStats(std::filesystem::path path) {
     if (!f.good()) RG_ERR_CLOSE("Learner::SaveStats(): Can't open file at " << path.string());
     // "var" is the raw sum of squared deviations: the reference writes its `runningVariance` member as is (Learner.cpp:196-202)
     f << std::setprecision(17) << "{\n    \"cumulative_model_updates\": " << impl->cumulativeModelUpdates << ",\n    \"cumulative_timesteps\": " << totalTimesteps
-      << ",\n    \"epoch\": " << totalEpochs << ",\n    \"reward_running_stats\": {\n        \"count\": " << returnStats.count << ",\n        \"mean\": [\n            "
+      << ",\n    \"epoch\": " << totalEpochs << ",\n    \"sampler_calls\": " << SamplerCalls() << ",\n    \"env_stream_epoch\": " << impl->envStreamEpoch << ",\n    \"reward_running_stats\": {\n        \"count\": " << returnStats.count << ",\n        \"mean\": [\n            "
       << returnStats.runningMean << "\n        ],\n        \"shape\": 1,\n        \"var\": [\n            " << returnStats.runningVariance << "\n        ]\n    }";
     if (skillTracker) f << ",\n    \"skill_rating\": " << skillTracker->RatingsToJSON();                                          // :185-194
     if (config.sendMetrics && metricSender) f << ",\n    \"run_id\": " << MetricSender::JsonString(metricSender->curRunID);   // :204-205
@@ -660,6 +666,14 @@ void Learner::LoadStats(std::filesystem::path path) {
     auto num = [&](const std::string& key) { return std::stod(s.substr(at(key, true))); };
     totalTimesteps = (uint64_t)num("cumulative_timesteps"); impl->cumulativeModelUpdates = (uint64_t)num("cumulative_model_updates"); totalEpochs = (uint64_t)num("epoch");
     returnStats.runningMean = num("mean"); returnStats.count = (int64_t)num("count"); returnStats.runningVariance = num("var");
+    // (additions of this build, also written by the Python host) where the action sampler's and the env batch's counter-based RNG streams go on
+    {
+        const size_t sc = at("sampler_calls", false), ee = at("env_stream_epoch", false);
+        const uint32_t calls = sc != std::string::npos ? (uint32_t)std::stod(s.substr(sc)) : (uint32_t)(totalTimesteps / (uint64_t)std::max(1, impl->nAgents));
+        impl->LrnCheck(rlgpu_learner_set_sampler(impl->lrn, (uint32_t)impl->rank, calls), "learner_set_sampler");
+        impl->envStreamEpoch = (ee != std::string::npos ? (uint32_t)std::stod(s.substr(ee)) : 0u) + 1u;
+        impl->EnvCheck(rlgpu_env_reseed(impl->env, (uint32_t)config.randomSeed + 1000u * (uint32_t)impl->rank, impl->envStreamEpoch), "reseed");
+    }
     size_t k = at("skill_rating", false);   // Learner.cpp:229-231
     if (skillTracker && k != std::string::npos) skillTracker->curRating = skillTracker->LoadRatingSet(s[k] == '{' ? s.substr(k, s.find('}', k) - k + 1) : s.substr(k));
     size_t r = at("run_id", false);   // Learner.cpp:238-239: the metrics run continues under its id

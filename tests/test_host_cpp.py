@@ -85,7 +85,10 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     recs = [json.loads(l) for l in open(mdir / files[0])]
     assert "_run" in recs[0] and len(recs) == 1 + 3
     assert [int(x["Cumulative Timesteps"]) for x in recs[1:]] == [4096, 8192, 12288] and "player_speed" in recs[1] and "Policy Entropy" in recs[3]
-    assert json.load(open(os.path.join(ck, str(3 * 4096), "RUNNING_STATS.json")))["run_id"] == files[0][:-6]
+    st2, st3 = (json.load(open(os.path.join(ck, str(k * 4096), "RUNNING_STATS.json"))) for k in (2, 3))
+    assert st3["run_id"] == files[0][:-6]
+    # the resumed run goes on in the action sampler's stream where the first one stopped, and moves the env batch to a fresh RNG epoch
+    assert st2["sampler_calls"] > 0 and st3["sampler_calls"] > st2["sampler_calls"] and st2["env_stream_epoch"] == 0 and st3["env_stream_epoch"] == 1
     # render mode: the newest checkpoint plays one game, every step goes to RocketSimVis' UDP port as a JSON datagram
     import socket
     before_render = sorted(os.listdir(ck))
