@@ -123,6 +123,8 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
 int rlgpu_env_sync(rlgpu_env* e);
 /* last rlgpu_env_step kernel duration in ms, measured with hipEvents on the context stream (bench.py roofline) */
+/* Timing is opt-in (bench, profiling tools): without it the step / collect launches are not bracketed by events at all */
+int rlgpu_env_enable_timing(rlgpu_env* e, int on);
 int rlgpu_env_last_step_ms(rlgpu_env* e, float* ms);
 /* sum of the rlgpu_env_step kernel durations (hipEvents on the context stream) and the launch count since the last
  * reset; synchronises the stream. */
@@ -203,6 +205,7 @@ int rlgpu_learner_sync(rlgpu_learner* l);
 /* last ppo_minibatch GEMM time in ms + its flop count (bench.py roofline for the MFMA-bound kernels) */
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops);
 /* the same accumulated over every rlgpu_ppo_minibatch call since the last reset; synchronises the stream */
+int rlgpu_learner_enable_timing(rlgpu_learner* l, int on);   /* opt-in, like rlgpu_env_enable_timing */
 int rlgpu_learner_timing_total(rlgpu_learner* l, float* total_ms, double* total_flops, int* calls, int reset);
 
 /* ---- minibatch order : ExperienceBuffer::GetAllBatchesShuffled (PRIV/PPO/ExperienceBuffer.cpp:106-121): iota(n) then

@@ -681,6 +681,7 @@ struct rlgpu_env {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool timing_on = false;   // rlgpu_env_enable_timing: the step / collect launches are bracketed by events only when asked to (bench, profiling tools)
     // accumulated step-kernel timing: pairs of events recorded around every launch, summed lazily
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0; double acc_ms = 0; int acc_launches = 0;
     std::string err;
@@ -927,25 +928,31 @@ int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host, int first_
     return RLGPU_OK;
 }
 
-int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
-    if (!actions || !next_obs || !reward || !done) { e->err = "rlgpu_env_step: null device pointer"; return RLGPU_ERR_ARG; }
-    HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+// the next pair of timing events of the pool (drained into the running totals when all 2048 are in use)
+static int env_next_events(rlgpu_env* e, std::pair<hipEvent_t, hipEvent_t>** out) {
     if (e->ev_used == e->ev_pool.size()) {
         if (e->ev_pool.size() < 2048) {
             hipEvent_t a, b; HIPCHK(e, hipEventCreate(&a)); HIPCHK(e, hipEventCreate(&b));
             e->ev_pool.push_back({a, b});
         } else {
-            float tmp; int n; int rc = rlgpu_env_timing_total(e, &tmp, &n, 0);  // drains the pool into acc_ms
+            float tmp; int n; int rc = rlgpu_env_timing_total(e, &tmp, &n, 0);
             if (rc) return rc;
         }
     }
-    auto& evp = e->ev_pool[e->ev_used++];
-    HIPCHK(e, hipEventRecord(evp.first, e->stream));
+    *out = &e->ev_pool[e->ev_used++];
+    return RLGPU_OK;
+}
+
+int rlgpu_env_enable_timing(rlgpu_env* e, int on) { e->timing_on = on != 0; if (!on) e->timed = false; return RLGPU_OK; }
+
+int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
+    if (!actions || !next_obs || !reward || !done) { e->err = "rlgpu_env_step: null device pointer"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    if (e->timing_on) { int rc_ev = env_next_events(e, &evp); if (rc_ev) return rc_ev; HIPCHK(e, hipEventRecord(evp->first, e->stream)); }
     DISPATCH_NC(e, k_env_step, grid, block, e->d, actions, next_obs, reward, done);
-    HIPCHK(e, hipEventRecord(evp.second, e->stream));
-    e->ev0 = evp.first; e->ev1 = evp.second;
-    e->timed = true;
+    if (evp) { HIPCHK(e, hipEventRecord(evp->second, e->stream)); e->ev0 = evp->first; e->ev1 = evp->second; e->timed = true; }
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }
@@ -984,21 +991,10 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
-    if (e->ev_used == e->ev_pool.size()) {
-        if (e->ev_pool.size() < 2048) {
-            hipEvent_t a, b; HIPCHK(e, hipEventCreate(&a)); HIPCHK(e, hipEventCreate(&b));
-            e->ev_pool.push_back({a, b});
-        } else {
-            float tmp; int n; int rc2 = rlgpu_env_timing_total(e, &tmp, &n, 0);
-            if (rc2) return rc2;
-        }
-    }
-    auto& evp = e->ev_pool[e->ev_used++];
-    HIPCHK(e, hipEventRecord(evp.first, e->stream));
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    if (e->timing_on) { int rc_ev = env_next_events(e, &evp); if (rc_ev) return rc_ev; HIPCHK(e, hipEventRecord(evp->first, e->stream)); }
     DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
-    HIPCHK(e, hipEventRecord(evp.second, e->stream));
-    e->ev0 = evp.first; e->ev1 = evp.second;
-    e->timed = true;
+    if (evp) { HIPCHK(e, hipEventRecord(evp->second, e->stream)); e->ev0 = evp->first; e->ev1 = evp->second; e->timed = true; }
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }
@@ -1049,7 +1045,7 @@ int rlgpu_env_sync(rlgpu_env* e) {
 }
 int rlgpu_env_timing_total(rlgpu_env* e, float* total_ms, int* launches, int reset) {
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->ev_used) HIPCHK(e, hipEventSynchronize(e->ev_pool[e->ev_used - 1].second));   // the newest pair: whatever stream it was recorded on
     for (size_t i = 0; i < e->ev_used; i++) {
         float ms = 0.f; HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
         e->acc_ms += ms; e->acc_launches++;

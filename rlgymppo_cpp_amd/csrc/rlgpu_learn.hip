@@ -783,6 +783,7 @@ struct rlgpu_learner {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false; double last_flops = 0;
+    bool timing_on = false;   // rlgpu_learner_enable_timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0; std::vector<double> ev_flops;
     double acc_ms = 0, acc_flops = 0; int acc_calls = 0;
     std::string err;
@@ -1241,18 +1242,21 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         x = l->gathered;
     }
     l->last_flops = 0;
-    if (l->ev_used == l->ev_pool.size()) {
-        if (l->ev_pool.size() < 1024) {
-            hipEvent_t a, b; LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b));
-            l->ev_pool.push_back({a, b}); l->ev_flops.push_back(0.0);
-        } else {
-            int rc2 = rlgpu_learner_timing_total(l, nullptr, nullptr, nullptr, 0);
-            if (rc2) return rc2;
+    size_t ev_slot = 0;
+    if (l->timing_on) {   // rlgpu_learner_enable_timing (bench, profiling tools): the GEMM section of every minibatch between two events
+        if (l->ev_used == l->ev_pool.size()) {
+            if (l->ev_pool.size() < 1024) {
+                hipEvent_t a, b; LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b));
+                l->ev_pool.push_back({a, b}); l->ev_flops.push_back(0.0);
+            } else {
+                int rc2 = rlgpu_learner_timing_total(l, nullptr, nullptr, nullptr, 0);
+                if (rc2) return rc2;
+            }
         }
+        ev_slot = l->ev_used++;
+        l->ev0 = l->ev_pool[ev_slot].first; l->ev1 = l->ev_pool[ev_slot].second;
+        LCHK(l, hipEventRecord(l->ev0, l->stream));
     }
-    const size_t ev_slot = l->ev_used++;
-    l->ev0 = l->ev_pool[ev_slot].first; l->ev1 = l->ev_pool[ev_slot].second;
-    LCHK(l, hipEventRecord(l->ev0, l->stream));
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
     const int loss_blocks = std::max(1, std::min(2048, (n + 3) / 4));
     const int vloss_blocks = std::max(1, std::min(1024, (n + 255) / 256));
@@ -1298,9 +1302,11 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         LCHK(l, hipGetLastError());
         if ((rc = net_backward(l, l->pol, l->act_p, x, n, l->dbuf0))) return rc;
     }
-    LCHK(l, hipEventRecord(l->ev1, l->stream));
-    l->ev_flops[ev_slot] = l->last_flops;
-    l->timed = true;
+    if (l->timing_on) {
+        LCHK(l, hipEventRecord(l->ev1, l->stream));
+        l->ev_flops[ev_slot] = l->last_flops;
+        l->timed = true;
+    }
     return RLGPU_OK;
 }
 
@@ -1365,9 +1371,10 @@ int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {
     return RLGPU_OK;
 }
 
+int rlgpu_learner_enable_timing(rlgpu_learner* l, int on) { l->timing_on = on != 0; if (!on) l->timed = false; return RLGPU_OK; }
 int rlgpu_learner_timing_total(rlgpu_learner* l, float* total_ms, double* total_flops, int* calls, int reset) {
     LCHK(l, hipSetDevice(l->device));
-    LCHK(l, hipStreamSynchronize(l->stream));
+    if (l->ev_used) LCHK(l, hipEventSynchronize(l->ev_pool[l->ev_used - 1].second));   // the newest pair: whatever stream it was recorded on
     for (size_t i = 0; i < l->ev_used; i++) {
         float ms = 0.f; LCHK(l, hipEventElapsedTime(&ms, l->ev_pool[i].first, l->ev_pool[i].second));
         l->acc_ms += ms; l->acc_flops += l->ev_flops[i]; l->acc_calls++;

@@ -31,6 +31,7 @@ class BatchedEnv:
         _chk(rc, self.h, self.lib.rlgpu_env_last_error)
         self.obs_size = self.lib.rlgpu_env_obs_size(self.h)
         self.n_agents = self.lib.rlgpu_env_num_agents(self.h)
+        self.lib.rlgpu_env_enable_timing(self.h, 1)   # the Python host is the test / tools host: last_step_ms() and timing_total() are read there
         self.n_actions = self.lib.rlgpu_env_num_actions(self.h)
         self.players = 2 * team_size
         if isinstance(mesh, str) and mesh == "procedural":

@@ -312,6 +312,9 @@ double Learner::MaxOverRanks(double v) {
 }
 bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= 2 && !stepCallback && !renderSender; }
 void Learner::DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset) {
+    // the device-side clocks are opt-in: the first call switches them on (a training run that never asks pays for no events)
+    impl->EnvCheck(rlgpu_env_enable_timing(impl->env, 1), "enable_timing");
+    impl->LrnCheck(rlgpu_learner_enable_timing(impl->lrn, 1), "learner_enable_timing");
     impl->EnvCheck(rlgpu_env_timing_total(impl->env, &envMs, &envLaunches, reset ? 1 : 0), "timing_total");
     impl->LrnCheck(rlgpu_learner_timing_total(impl->lrn, &gemmMs, &gemmFlops, &gemmCalls, reset ? 1 : 0), "learner_timing_total");
 }

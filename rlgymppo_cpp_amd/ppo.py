@@ -35,6 +35,7 @@ class PPOCore:
         self.policy_layers, self.critic_layers = tuple(policy_layers), tuple(critic_layers)
         self.h = C.c_void_p()
         _chk(self.lib.rlgpu_learner_create(C.byref(self.h), device, C.byref(c)), self.h, self.lib.rlgpu_learner_last_error)
+        self.lib.rlgpu_learner_enable_timing(self.h, 1)   # test / tools host: the GEMM-section timers are read there
         self._err = self.lib.rlgpu_learner_last_error
 
     def close(self):
