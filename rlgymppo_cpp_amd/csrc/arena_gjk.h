@@ -221,7 +221,8 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
     s.bc0 = s.bc1 = s.bc2 = s.bc3 = 0.f; s.used = 0u;
     float sq_dist = 1e18f;
     int degenerate = 0; bool check_simplex = false;
-    for (int iter = 0;; ) {
+    int iter = 0;
+    for (;;) {
         V3 dir_a = tmul(R, -axis);                                  // (-axis) * basisA
         V3 dir_b = axis;                                            // axis * identity
         float d0 = dot(dir_b, sh.t0), d1 = dot(dir_b, sh.t1), d2 = dot(dir_b, sh.t2);
@@ -259,7 +260,7 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         if (s.n == 4) { degenerate = 13; break; }
     }
 #ifdef RLG_GJK_STATS
-    RLG_GJK_STATS(2, s.n * 100 + 0); RLG_GJK_STATS(3, 0);
+    RLG_GJK_STATS(2, iter);   // runs, and their iteration counts (sum / max / histogram)
 #endif
     bool valid = false; float distance = 0.f; V3 normal = v3(0, 0, 0), pa = v3(0, 0, 0), pb = v3(0, 0, 0);
     if (check_simplex) {

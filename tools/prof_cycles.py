@@ -84,6 +84,9 @@ if hasattr(env.lib, "rlgpu_env_debug_ints"):
     print("queue overflow events so far: frontier", buf[0], "ball region", buf[1], "car region", buf[2], "items", buf[3], "pool", buf[4])
 
     print("hitbox-triangle GJK runs", buf[8], " of them answered by the deep-penetration fallback", buf[9])
+    if buf[34]:
+        print(f"GJK: {buf[32]} hitbox-triangle tests, {buf[33]} runs, iterations per run mean {buf[35] / buf[34]:.2f} max {buf[36]}; simplex updates with 1..4 vertices {list(buf[37:41])}; "
+              f"runs by iteration count 0..22+: {list(buf[41:64])}")
     for t, nm in enumerate(("ball-triangle", "hitbox-triangle", "car-car")):
         c = buf[16 + 4 * t]
         if c: print(f"items {nm}: {c} run, {buf[17 + 4 * t]} with a contact, mean {64.0 * buf[18 + 4 * t] / c:.0f} cycles, slowest {buf[19 + 4 * t]}")
