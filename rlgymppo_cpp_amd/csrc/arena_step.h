@@ -124,10 +124,23 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
     RLG_GJK_STATS(1, 0);
 #endif
     RLG_DBG_COUNT(8);
-    if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, CBT_CAR, g, deep)) {
+#ifdef RLG_ITEM_CLOCK
+    const unsigned long long tg0_ = RLG_ITEM_CLOCK();
+#endif
+    const bool hit_ = gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, CBT_CAR, g, deep);
+#ifdef RLG_ITEM_CLOCK
+    RLG_SPAN_DONE(10, RLG_ITEM_CLOCK() - tg0_);
+#endif
+    if (hit_) {
         if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
         c.n = g.n; c.pb = g.pb; c.dist = g.dist;
+#ifdef RLG_ITEM_CLOCK
+        const unsigned long long te0_ = RLG_ITEM_CLOCK();
+#endif
         adjust_internal_edge(t, c.pb, c.n, c.dist);
+#ifdef RLG_ITEM_CLOCK
+        RLG_SPAN_DONE(12, RLG_ITEM_CLOCK() - te0_);
+#endif
         return true;
     }
     if (!deep) return false;

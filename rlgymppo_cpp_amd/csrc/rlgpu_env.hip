@@ -23,8 +23,11 @@ __device__ int g_dbg[64];
 // per-item clocks of the narrowphase (collide_run_item): g_dbg[16 + 4 t] items of type t, [17 + 4 t] of them with a contact, [18 + 4 t] cycles / 64, [19 + 4 t] the slowest
 // GJK statistics (arena_gjk.h hooks): g_dbg[32] hitbox_triangle calls, [33] GJK runs, [34] finished runs, [35] sum of their iteration counts, [36] the most
 // iterations of one run, [37..40] simplex updates with 1..4 vertices, [41..63] runs by iteration count (capped)
+#ifdef RLG_GJK_COUNT   // (-DRLG_GJK_COUNT: the atomics sit inside the GJK loop and distort every clock; off for timing runs)
 #define RLG_GJK_STATS(i, v) do { if ((i) == 2) { atomicAdd(&g_dbg[34], 1); atomicAdd(&g_dbg[35], (int)(v)); atomicMax(&g_dbg[36], (int)(v)); atomicAdd(&g_dbg[41 + ((v) < 22 ? (int)(v) : 22)], 1); } else if ((i) >= 5) atomicAdd(&g_dbg[32 + (i)], 1); else atomicAdd(&g_dbg[32 + (i)], 1); } while (0)
+#endif
 #define RLG_ITEM_CLOCK() __builtin_amdgcn_s_memtime()
+#define RLG_SPAN_DONE(slot, cyc) do { atomicAdd(&g_dbg[slot], (int)((cyc) >> 6)); atomicAdd(&g_dbg[(slot) + 1], 1); } while (0)   // [slot] cycles / 64, [slot + 1] spans
 #define RLG_ITEM_DONE(type, n, cyc) do { atomicAdd(&g_dbg[16 + 4 * (type)], 1); if ((n) > 0) atomicAdd(&g_dbg[17 + 4 * (type)], 1); atomicAdd(&g_dbg[18 + 4 * (type)], (int)((cyc) >> 6)); atomicMax(&g_dbg[19 + 4 * (type)], (int)(cyc)); } while (0)
 __shared__ unsigned long long g_prof_last;
 #define RLG_PROF(i)                                                              \

@@ -84,6 +84,9 @@ if hasattr(env.lib, "rlgpu_env_debug_ints"):
     print("queue overflow events so far: frontier", buf[0], "ball region", buf[1], "car region", buf[2], "items", buf[3], "pool", buf[4])
 
     print("hitbox-triangle GJK runs", buf[8], " of them answered by the deep-penetration fallback", buf[9])
+    if buf[11]:
+        print(f"in-wavefront spans: GJK {64.0 * buf[10] / buf[11]:.0f} cycles per run ({buf[11]} runs), internal-edge adjustment {64.0 * buf[12] / max(1, buf[13]):.0f} cycles per contact ({buf[13]})"
+              " -- wall cycles of the wavefront while the lane was inside, i.e. including lanes of other items diverged into the same call")
     if buf[34]:
         print(f"GJK: {buf[32]} hitbox-triangle tests, {buf[33]} runs, iterations per run mean {buf[35] / buf[34]:.2f} max {buf[36]}; simplex updates with 1..4 vertices {list(buf[37:41])}; "
               f"runs by iteration count 0..22+: {list(buf[41:64])}")
