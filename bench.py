@@ -111,6 +111,16 @@ def pmc_profile(kernel_prefix):
     return best
 
 
+def rank_child_env(environ):
+    """Environment of the measured process of one rank.  The ranks' bench_main processes meet through a file named after MASTER_PORT and
+    a tag common to the launch (rlgpu_comm_init_env); left alone the tag is the parent pid, which here is this script -- one per rank --
+    so the tag handed down is THIS script's parent: the launcher (torch.distributed.run's agent), the same for every rank of the node."""
+    env = dict(environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(env.get("WORLD_SIZE", "1")) > 1:
+        env.setdefault("RLGPU_COMM_TAG", "%s_%d" % (env.get("TORCHELASTIC_RUN_ID", "run"), os.getppid()))
+    return env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +152,7 @@ def main():
     if args.fp32: cmd.append("--fp32")
     if args.trained_warmup > 0 and args.trained_steps > 0:
         cmd += ["--trained-warmup", str(args.trained_warmup), "--trained-steps", str(args.trained_steps)]
-    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env = rank_child_env(os.environ)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
     if proc.returncode != 0:
         raise SystemExit(f"bench_main failed with exit code {proc.returncode}")

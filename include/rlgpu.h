@@ -260,6 +260,7 @@ typedef struct rlgpu_comm rlgpu_comm;
 #define RLGPU_COMM_ID_BYTES 128
 int rlgpu_comm_unique_id(void* id_out /* RLGPU_COMM_ID_BYTES */);                                  /* rank 0: ncclGetUniqueId */
 int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const void* id_bytes);      /* collective: ncclCommInitRank */
+int rlgpu_comm_rendezvous_path(char* buf, int cap);   /* the file rlgpu_comm_init_env will use in this process's environment (diagnostics, tests) */
 int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out);                          /* RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT + file rendezvous */
 int rlgpu_comm_destroy(rlgpu_comm* c);
 int rlgpu_comm_rank(const rlgpu_comm* c);

@@ -56,14 +56,26 @@ int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const voi
 
 // rank / world / rendezvous from the launcher's environment (torchrun or any launcher that sets RANK, WORLD_SIZE, LOCAL_RANK,
 // MASTER_PORT): rank 0 writes its id to $RLGPU_COMM_DIR (default /tmp)/rlgpu_comm_<MASTER_PORT>_<RLGPU_COMM_TAG or the launcher's pid>.id, the others wait for it
+// Where the ranks of one launch meet: <RLGPU_COMM_DIR or /tmp>/rlgpu_comm_<MASTER_PORT>_<tag>.id.  The tag keeps a stale file of an earlier
+// launch on the same port apart: RLGPU_COMM_TAG when the launcher of the ranks sets one (bench.py does: its ranks' programs are children of
+// one Python process EACH), else the parent's pid -- the ranks of `torch.distributed.run my_program` are children of the same agent.
+static std::string rendezvous_path() {
+    const char* dir = getenv("RLGPU_COMM_DIR"); const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG");
+    return std::string(dir ? dir : "/tmp") + "/rlgpu_comm_" + (port ? port : "0") + "_" + (tag ? tag : std::to_string((long)getppid())) + ".id";
+}
+int rlgpu_comm_rendezvous_path(char* buf, int cap) {
+    const std::string p = rendezvous_path();
+    if (!buf || cap <= (int)p.size()) return RLGPU_ERR_ARG;
+    memcpy(buf, p.c_str(), p.size() + 1);
+    return RLGPU_OK;
+}
+
 int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     auto env_i = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
     const int rank = env_i("RANK", 0), world = env_i("WORLD_SIZE", 1), local = env_i("LOCAL_RANK", rank);
     if (rank_out) *rank_out = rank;
     if (world_out) *world_out = world;
-    const char* dir = getenv("RLGPU_COMM_DIR"); const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG");
-    // the ranks of one launch are children of the same launcher process: its pid keeps a stale file of an earlier launch on the same port apart
-    std::string path = std::string(dir ? dir : "/tmp") + "/rlgpu_comm_" + (port ? port : "0") + "_" + (tag ? tag : std::to_string((long)getppid())) + ".id";
+    const std::string path = rendezvous_path();
     unsigned char id[RLGPU_COMM_ID_BYTES];
     if (rank == 0) {
         int rc = rlgpu_comm_unique_id(id);

@@ -27,7 +27,11 @@ __device__ int g_dbg[64];
 #define RLG_GJK_STATS(i, v) do { if ((i) == 2) { atomicAdd(&g_dbg[34], 1); atomicAdd(&g_dbg[35], (int)(v)); atomicMax(&g_dbg[36], (int)(v)); atomicAdd(&g_dbg[41 + ((v) < 22 ? (int)(v) : 22)], 1); } else if ((i) >= 5) atomicAdd(&g_dbg[32 + (i)], 1); else atomicAdd(&g_dbg[32 + (i)], 1); } while (0)
 #endif
 #define RLG_ITEM_CLOCK() __builtin_amdgcn_s_memtime()
+#ifdef RLG_SPAN_CLOCKS   // (-DRLG_SPAN_CLOCKS: two contended atomics per GJK run -- at 4096 envs they triple the tick time; off unless asked for)
 #define RLG_SPAN_DONE(slot, cyc) do { atomicAdd(&g_dbg[slot], (int)((cyc) >> 6)); atomicAdd(&g_dbg[(slot) + 1], 1); } while (0)   // [slot] cycles / 64, [slot + 1] spans
+#else
+#define RLG_SPAN_DONE(slot, cyc) ((void)0)
+#endif
 #define RLG_ITEM_DONE(type, n, cyc) do { atomicAdd(&g_dbg[16 + 4 * (type)], 1); if ((n) > 0) atomicAdd(&g_dbg[17 + 4 * (type)], 1); atomicAdd(&g_dbg[18 + 4 * (type)], (int)((cyc) >> 6)); atomicMax(&g_dbg[19 + 4 * (type)], (int)(cyc)); } while (0)
 __shared__ unsigned long long g_prof_last;
 #define RLG_PROF(i)                                                              \

@@ -117,3 +117,45 @@ def test_two_ranks_allreduce_equals_single_learner():
     assert np.array_equal(res[0][1], res[1][1])                               # replicas stay bitwise identical
     assert res[0][4] == res[1][4]
     assert res[0][7] == 123 and res[1][7] == 1123                             # disjoint env RNG streams, rank 0 = single-GPU run
+
+
+_RDV_CHILD = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from rlgymppo_cpp_amd import _lib
+lib = _lib.load()
+buf = C.create_string_buffer(512)
+assert lib.rlgpu_comm_rendezvous_path(buf, 512) == 0
+print("PATH", buf.value.decode())
+"""
+
+
+def _rdv_rank(rank, port, tmp):
+    """What one rank of `python -m torch.distributed.run ... bench.py --gpus 2` does up to the rendezvous: bench.py's own child environment,
+    then a process (standing in for bench_main) that asks the library where it would meet the others.  Runs in a process of its own, like a rank."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    env = bench.rank_child_env(dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RLGPU_COMM_DIR=tmp))
+    r = subprocess.run([sys.executable, "-c", _RDV_CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=200)
+    open(os.path.join(tmp, f"rank{rank}.out"), "w").write(r.stdout)
+
+
+@pytest.mark.timeout(300)
+def test_bench_ranks_meet_at_the_same_rendezvous_file(tmp_path):
+    """bench.py starts one bench_main per rank, each from its OWN Python process: the ncclUniqueId file has to be named after something the
+    ranks share (the launcher's pid, handed down as RLGPU_COMM_TAG), not after each child's parent -- or rank 1 waits for a file that
+    rank 0 never writes.  (The communicator itself needs GPUs; the file name does not.)"""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rdv_rank, args=(r, port, str(tmp_path))) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs:
+        p.join(250); assert p.exitcode == 0
+    paths = []
+    for r in range(2):
+        out = open(tmp_path / f"rank{r}.out").read()
+        line = [ln for ln in out.splitlines() if ln.startswith("PATH ")]
+        assert line, out
+        paths.append(line[0][5:])
+    assert paths[0] == paths[1] and str(port) in paths[0] and paths[0].startswith(str(tmp_path)), paths
