@@ -166,6 +166,11 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_gemm(GemmArgs g) {
 using bf16x4 = __attribute__((ext_vector_type(4))) short;
 constexpr int FBK = 32;          // K step of both kernels
 constexpr int NT_LD = FBK + 8;   // LDS row of the NT tiles: 80 B -> the 16 rows of a ds_read_b128 group land on distinct bank quads
+#ifndef RLG_NT_BK
+#define RLG_NT_BK 64
+#endif
+constexpr int NBK = RLG_NT_BK;   // K step of k_gemm_nt: 64 -> every row piece a wavefront loads is a full 128-byte line (with 32 it was half of one): 0.55 -> 0.517 ms per minibatch; 128 (69 KB of LDS, 2 workgroups per CU) 0.559
+constexpr int NTK_LD = NBK + 8;  // 144 B rows: the 16 rows of a ds_read_b128 group start 36 banks apart -> distinct bank quads
 
 struct NtArgs {
     const short* A; int lda;     // [M][lda] bf16, lda = K (multiple of 32), zero padded
@@ -182,15 +187,16 @@ template <int WM, int WN, int TM, int TN, int EPI>
 __global__ void __launch_bounds__(256) k_gemm_nt(NtArgs g) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_CH = (BM * 4 + 255) / 256, B_CH = (BN * 4 + 255) / 256;   // 16-byte chunks per thread and tile
+    constexpr int CPR = NBK / 8;                                                    // 16-byte chunks per tile row
+    constexpr int A_CH = (BM * CPR + 255) / 256, B_CH = (BN * CPR + 255) / 256;   // 16-byte chunks per thread and tile
     // bf16 outputs of the 128-wide configuration leave through LDS: the MFMA result layout has one column per lane (2-byte stores,
     // 2-byte mask loads); staged, every lane moves 16 contiguous bytes
     constexpr bool STAGED = (EPI != 1) && (BN == 128);
     constexpr int C_LD = BN + 8;
-    constexpr int SMEM = STAGED ? ((BM + BN) * NT_LD > BM * C_LD ? (BM + BN) * NT_LD : BM * C_LD) : (BM + BN) * NT_LD;
+    constexpr int SMEM = STAGED ? ((BM + BN) * NTK_LD > BM * C_LD ? (BM + BN) * NTK_LD : BM * C_LD) : (BM + BN) * NTK_LD;
     __shared__ __attribute__((aligned(16))) short smem[SMEM];
     short* const As = smem;
-    short* const Bs = smem + BM * NT_LD;
+    short* const Bs = smem + BM * NTK_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -207,44 +213,44 @@ __global__ void __launch_bounds__(256) k_gemm_nt(NtArgs g) {
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < A_CH; j++) {
-            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            int idx = tid + j * 256, row = idx / CPR, ch = idx % CPR;
             ra[j] = make_uint4(0, 0, 0, 0);
-            if (idx < BM * 4 && m0 + row < g.M) ra[j] = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + ch * 8);
+            if (idx < BM * CPR && m0 + row < g.M && k0 + ch * 8 < g.K) ra[j] = *reinterpret_cast<const uint4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + ch * 8);
         }
 #pragma unroll
         for (int j = 0; j < B_CH; j++) {
-            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
+            int idx = tid + j * 256, row = idx / CPR, ch = idx % CPR;
             rb[j] = make_uint4(0, 0, 0, 0);
-            if (idx < BN * 4) rb[j] = *reinterpret_cast<const uint4*>(g.B + (size_t)(n0 + row) * g.ldb + k0 + ch * 8);
+            if (idx < BN * CPR && k0 + ch * 8 < g.K) rb[j] = *reinterpret_cast<const uint4*>(g.B + (size_t)(n0 + row) * g.ldb + k0 + ch * 8);
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int j = 0; j < A_CH; j++) {
-            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
-            if (idx < BM * 4) *reinterpret_cast<uint4*>(&As[row * NT_LD + ch * 8]) = ra[j];
+            int idx = tid + j * 256, row = idx / CPR, ch = idx % CPR;
+            if (idx < BM * CPR) *reinterpret_cast<uint4*>(&As[row * NTK_LD + ch * 8]) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < B_CH; j++) {
-            int idx = tid + j * 256, row = idx >> 2, ch = idx & 3;
-            if (idx < BN * 4) *reinterpret_cast<uint4*>(&Bs[row * NT_LD + ch * 8]) = rb[j];
+            int idx = tid + j * 256, row = idx / CPR, ch = idx % CPR;
+            if (idx < BN * CPR) *reinterpret_cast<uint4*>(&Bs[row * NTK_LD + ch * 8]) = rb[j];
         }
     };
 
     load_tiles(0);
-    for (int k0 = 0; k0 < g.K; k0 += FBK) {
+    for (int k0 = 0; k0 < g.K; k0 += NBK) {
         store_tiles();
         __syncthreads();
-        if (k0 + FBK < g.K) load_tiles(k0 + FBK);   // next tile's global loads fly under this tile's MFMAs
+        if (k0 + NBK < g.K) load_tiles(k0 + NBK);   // next tile's global loads fly under this tile's MFMAs
 #pragma unroll
-        for (int ks = 0; ks < FBK; ks += 16) {
+        for (int ks = 0; ks < NBK; ks += 16) {
             // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7
             const int kk = ks + 8 * (lane >> 5);
             bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * TM + i) * 32 + (lane & 31)) * NT_LD + kk]);
+            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * TM + i) * 32 + (lane & 31)) * NTK_LD + kk]);
 #pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * TN + j) * 32 + (lane & 31)) * NT_LD + kk]);
+            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * TN + j) * 32 + (lane & 31)) * NTK_LD + kk]);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
