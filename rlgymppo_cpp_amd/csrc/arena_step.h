@@ -119,6 +119,9 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
         if (fminf(p0.y, fminf(p1.y, p2.y)) > h.y + m || fmaxf(p0.y, fmaxf(p1.y, p2.y)) < -(h.y + m)) return false;
         if (fminf(p0.z, fminf(p1.z, p2.z)) > h.z + m || fmaxf(p0.z, fmaxf(p1.z, p2.z)) < -(h.z + m)) return false;
     }
+#ifdef RLG_EXPERIMENT_GJK_TWICE   // what-if build only: every GJK run done twice, same physics -> the launch grows by what the runs cost in place
+    { GjkOut g0; bool d0 = false; const float thr = CBT_CAR * (1.f + 1e-7f * (float)(t.edge_flags & 1u)); if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, thr, g0, d0) && g0.dist == 1234.5678f) c.dist = 0.f; }
+#endif
     GjkOut g; bool deep = false;
 #ifdef RLG_GJK_STATS
     RLG_GJK_STATS(1, 0);
