@@ -42,7 +42,8 @@ public:
     // one iteration, in the pieces Learn() strings together (also what tests drive)
     void CollectTimesteps();                         // ThreadAgentManager::CollectTimesteps for every game at once
     void AddNewExperience(Report& report);           // Learner.cpp:608-703: value predictions, GAE, return statistics
-    void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349)
+    void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349); with collectionDuringLearn it only LAUNCHES the epochs
+    void FinishLearn(Report& report);                // ... and this waits for them and adds their statistics (Learn() calls it after the next collection)
     void LoadOldVersions(const std::vector<int32_t>& policyDims);   // Learner.cpp:311-370
     void RenderStep(int t);                          // ThreadAgent.cpp:164-186 for the first game
     int NumEnvs() const;

@@ -20,7 +20,7 @@ struct LearnerConfig {
     int maxReturnsPerStatsInc = 150;
     int stepsPerObsStatsInc = 5;
     bool deterministic = false;
-    bool collectionDuringLearn = false; // honoured by the Python host (learner.py); this C++ Learner keeps the default behaviour
+    bool collectionDuringLearn = false; // the PPO epochs of iteration k run on their own stream while iteration k + 1 is collected (its report carries their statistics)
     PPOLearnerConfig ppo = {};
     float gaeLambda = 0.95f;
     float gaeGamma = 0.99f;

@@ -93,6 +93,10 @@ struct Learner::Impl {
     bool first = true, renderOnly = false, fusedCollect = true;
     Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
+    // collectionDuringLearn (LearnerConfig.h:46-50, Learner.cpp:473-510): the PPO epochs of iteration k run on their own stream while iteration
+    // k + 1 is collected; their statistics reach the report one iteration later
+    hipStream_t learnStream = nullptr; hipEvent_t evReady = nullptr, evLearnDone = nullptr;
+    bool learnPending = false; int pendMini = 0; Timer pendTimer;
     uint32_t envStreamEpoch = 0;   // second key word of the env batch's RNG streams: bumped on every resume (no replay of the resets of the run continued)
     std::vector<GameInst> games;
     // ---- host path: plugin kinds without a device form (Match::DevicePlan) and step callbacks -------------------------------------
@@ -252,6 +256,10 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
         if (config.skillTrackerConfig.envCreateFunc == NULL) config.skillTrackerConfig.envCreateFunc = envCreateFn;
         skillTracker = new SkillTracker(config.skillTrackerConfig, m.lrn, m.D, m.A, config.ppo.policyLayerSizes, config.randomSeed, renderSender);
     }
+    if (config.collectionDuringLearn && !m.renderOnly) {
+        HOST_HIP(hipStreamCreateWithFlags(&m.learnStream, hipStreamNonBlocking));
+        HOST_HIP(hipEventCreateWithFlags(&m.evReady, hipEventDisableTiming)); HOST_HIP(hipEventCreateWithFlags(&m.evLearnDone, hipEventDisableTiming));
+    }
     if (!config.checkpointLoadFolder.empty()) Load();
     if (config.sendMetrics && m.rank == 0) {                                                                                          // Learner.cpp:149-155
         if (!runID.empty()) RG_LOG("\tRun ID: " << runID);
@@ -264,6 +272,8 @@ Learner::~Learner() {
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
                     (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
+    if (m.learnPending) (void)hipEventSynchronize(m.evLearnDone);
+    if (m.learnStream) { (void)hipStreamDestroy(m.learnStream); (void)hipEventDestroy(m.evReady); (void)hipEventDestroy(m.evLearnDone); }
     if (m.drawPending) m.nextDraw.wait();
     delete skillTracker; delete metricSender; delete renderSender;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
@@ -551,14 +561,20 @@ void Learner::AddNewExperience(Report& report) {
 void Learner::LearnPPO(Report& report) {
     Impl& m = *impl;
     if (config.deterministic) RG_ERR_CLOSE("PPOLearner::Learn() called with config.deterministic = true");   // Learner.cpp:472-477
-    HOST_HIP(hipMemsetAsync(m.metrics, 0, 32, nullptr));
+    const bool overlap = m.learnStream != nullptr;
+    hipStream_t ls = overlap ? m.learnStream : nullptr;
+    if (overlap) {   // this iteration's rows are in their FIFO slot once the default stream gets here
+        HOST_HIP(hipEventRecord(m.evReady, nullptr)); HOST_HIP(hipStreamWaitEvent(ls, m.evReady, 0));
+        m.LrnCheck(rlgpu_learner_set_stream(m.lrn, (void*)ls), "learner_set_stream");
+    }
+    HOST_HIP(hipMemsetAsync(m.metrics, 0, 32, ls));
     int nMini = 0, nUpdates = 0;
     Timer t;
     for (int ep = 0; ep < config.ppo.epochs; ep++) {
         // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126) over the whole FIFO: logical rows are oldest iteration
         // first and agent-major inside one (trajectory after trajectory); the device slots are time-major
         const int64_t cur = m.TakeDraw();
-        HOST_HIP(hipMemcpyAsync(m.idx, m.phys[m.physFlip].data(), (size_t)cur * 4, hipMemcpyHostToDevice, nullptr));   // pageable source: staged before the call returns
+        HOST_HIP(hipMemcpyAsync(m.idx, m.phys[m.physFlip].data(), (size_t)cur * 4, hipMemcpyHostToDevice, ls));   // pageable source: staged before the call returns
         m.physFlip ^= 1;
         if (ep == config.ppo.epochs - 1 && rlgpu_expbuf_submit(m.fifo, &m.pendingSlot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");   // the next draw sees the FIFO after the next submit
         m.StartDraw();
@@ -572,18 +588,34 @@ void Learner::LearnPPO(Report& report) {
             // the clip so the norm is taken of the global-batch gradient, like a single learner on the union would
             if (m.comm) m.LrnCheck(rlgpu_allreduce_grads(m.lrn, m.comm), "allreduce_grads");
             m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f / (float)m.world), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)
+            if (overlap) m.LrnCheck(rlgpu_learner_refresh_shadows(m.lrn), "learner_refresh_shadows");   // the collector reads the bf16 copies while this stream goes on: keep them live
             nUpdates++;
         }
     }
-    m.LrnCheck(rlgpu_learner_sync(m.lrn), "learner_sync");
-    float h[8];
-    HOST_HIP(hipMemcpy(h, m.metrics, 32, hipMemcpyDeviceToHost));
-    const double rows = std::max<double>(1, (double)nMini * m.mini);
-    report["Policy Entropy"] = h[0] / rows; report["Mean KL Divergence"] = h[1] / rows; report["SB3 Clip Fraction"] = h[2] / rows;
-    report["Value Function Loss"] = h[4] / rows; report["PPO Learn Time"] = t.Elapsed();
     totalEpochs += config.ppo.epochs; m.cumulativeModelUpdates += nUpdates;
     report["Cumulative Model Updates"] = (double)m.cumulativeModelUpdates;
+    if (overlap) {   // the epochs go on while the next iteration is collected; FinishLearn() reads their statistics then
+        HOST_HIP(hipEventRecord(m.evLearnDone, ls));
+        m.LrnCheck(rlgpu_learner_set_stream(m.lrn, nullptr), "learner_set_stream");
+        m.learnPending = true; m.pendMini = nMini; m.pendTimer = t;
+        return;
+    }
+    m.LrnCheck(rlgpu_learner_sync(m.lrn), "learner_sync");
+    m.pendMini = nMini; m.pendTimer = t;
+    FinishLearn(report);
 }
+
+// the PPO statistics of the epochs LearnPPO launched (with collectionDuringLearn: one iteration later, when they are done)
+void Learner::FinishLearn(Report& report) {
+    Impl& m = *impl;
+    if (m.learnPending) { HOST_HIP(hipEventSynchronize(m.evLearnDone)); m.learnPending = false; }
+    float h[8];
+    HOST_HIP(hipMemcpy(h, m.metrics, 32, hipMemcpyDeviceToHost));
+    const double rows = std::max<double>(1, (double)m.pendMini * m.mini);
+    report["Policy Entropy"] = h[0] / rows; report["Mean KL Divergence"] = h[1] / rows; report["SB3 Clip Fraction"] = h[2] / rows;
+    report["Value Function Loss"] = h[4] / rows; report["PPO Learn Time"] = m.pendTimer.Elapsed();
+}
+
 
 void Learner::Learn() {
     Impl& m = *impl;
@@ -596,6 +628,7 @@ void Learner::Learn() {
         CollectTimesteps();
         HOST_HIP(hipDeviceSynchronize());
         double collectTime = tCollect.Elapsed();
+        if (m.learnPending) FinishLearn(report);   // collectionDuringLearn: the previous iteration's epochs ran beside this collection
         if (config.deviceStepMetrics) {   // what examplemain.cpp's step callback averages, from the device's running totals of this iteration
             float st[4];
             m.EnvCheck(rlgpu_env_step_stats(m.env, st, 1), "step_stats");
@@ -634,6 +667,7 @@ void Learner::Learn() {
         m.tsSinceSave += (uint64_t)m.B * (uint64_t)m.world;
         if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
     }
+    if (m.learnPending) { Report last; FinishLearn(last); }
     if (m.rank == 0 && !config.checkpointSaveFolder.empty()) Save();   // rank 0 owns the checkpoints
 }
 
@@ -686,6 +720,7 @@ void Learner::LoadStats(std::filesystem::path path) {
 void Learner::Save() {
     Impl& m = *impl;
     if (config.checkpointSaveFolder.empty()) RG_ERR_CLOSE("Learner::Save(): checkpointSaveFolder is empty");
+    if (m.learnPending) HOST_HIP(hipEventSynchronize(m.evLearnDone));   // collectionDuringLearn: the epochs still running write the parameters saved here
     std::filesystem::path folder = config.checkpointSaveFolder / std::to_string(totalTimesteps);
     std::filesystem::create_directories(folder);
     SaveStats(folder / "RUNNING_STATS.json");

@@ -1,7 +1,7 @@
 // bench_main.cpp -- the measured process of bench.py: the reference's program shape (examplemain.cpp: EnvCreateFn + LearnerConfig +
 // Learner) on include/RLGymPPO_CPP over librlgymppo_amd.so / librlgpu.so.  No Python, no torch: the HIP runtime, the C-ABI library
 // and (multi-GPU) RCCL are all that touch the device.  Prints ONE JSON object on stdout (rank 0).
-//   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32] [--trained-warmup I --trained-steps J]
+//   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32] [--overlap] [--trained-warmup I --trained-steps J]
 // One "step" = one full PPO iteration: T gym steps of every env with on-device policy inference, value pass + GAE, shuffled
 // minibatches (4 per batch), clip + Adam.  With --trained-warmup the same measurement is repeated after I more iterations, when
 // the policy has started to play and contacts are more frequent ("trained_regime").
@@ -42,12 +42,12 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
 struct Timed { double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0; bool fp32 = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0; bool fp32 = false, overlap = false;
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
         else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
-        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true;
+        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true;
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
         else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
     }
@@ -62,6 +62,7 @@ int main(int argc, char* argv[]) {
     cfg.ppo.policyLayerSizes = { 256, 256, 256 }; cfg.ppo.criticLayerSizes = { 256, 256, 256 };
     cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
     cfg.timestepLimit = 0;
+    cfg.collectionDuringLearn = overlap;   // not the headline: the reference's default pauses collection while it learns
     Learner learner(EnvCreateFunc, cfg);
     const int rank = learner.Rank(), world = learner.WorldSize();
 
@@ -69,6 +70,7 @@ int main(int argc, char* argv[]) {
     auto iteration = [&](double* consumeMs) {
         Report rep;
         learner.CollectTimesteps();
+        if (overlap) { learner.FinishLearn(rep); learner.AddNewExperience(rep); learner.LearnPPO(rep); return; }   // the epochs run beside the next collection
         if (consumeMs) (void)hipDeviceSynchronize();   // the collection launch is asynchronous: the consumption clock starts when it has finished
         auto t0 = std::chrono::steady_clock::now();
         learner.AddNewExperience(rep);

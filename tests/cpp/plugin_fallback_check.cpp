@@ -240,6 +240,28 @@ static int Throughput() {
     return 0;
 }
 
+// collectionDuringLearn in the C++ host: the epochs of iteration k on their own stream beside the collection of k + 1
+static int CollectionDuringLearn() {
+    g_host = false; g_hostParser = false; g_teamSize = 1; g_spawnOpponents = true;
+    LearnerConfig cfg = SmallConfig(256, 16, 2);
+    cfg.collectionDuringLearn = true; cfg.ppo.epochs = 2; cfg.ppo.miniBatchSize = cfg.ppo.batchSize / 2;
+    Learner learner(MakeBuiltinEnv, cfg);
+    int iterations = 0, withStats = 0; bool finite = true;
+    learner.iterationCallback = [&](Learner* l, Report& report) {
+        iterations++;
+        if (report.Has("Policy Entropy")) {   // the epochs of the PREVIOUS iteration: absent from the first report
+            withStats++;
+            finite = finite && std::isfinite(report["Policy Entropy"]) && report["Policy Entropy"] > 0 && std::isfinite(report["Value Function Loss"]);
+        }
+        if (iterations == 4) l->config.timestepLimit = 1;
+    };
+    learner.Learn();
+    CHECK(iterations == 4 && withStats == 3 && finite);
+    CHECK(learner.totalTimesteps == 4ull * 256 * 2 * 16 && learner.totalEpochs == 8);
+    std::printf("collectionDuringLearn: 4 iterations, PPO statistics in reports 2..4\n");
+    return 0;
+}
+
 // ---- part 3: the standalone Gym ------------------------------------------------------------------------------------------------------
 static int StandaloneGym() {
     RocketSim::Math::SeedRandEngine(5);
@@ -324,6 +346,7 @@ int main(int argc, char** argv) {
         if (ComparePaths(2, false, false)) return 1;    // Match(..., spawnOpponents = false): two blue cars and nobody else
         if (ComparePaths(1, true, false)) return 1;     // a single car
         if (UserPlugins()) return 1;
+        if (CollectionDuringLearn()) return 1;
         if (StandaloneGym()) return 1;
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
