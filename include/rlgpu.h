@@ -119,6 +119,10 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions_dev, float* next_obs_dev
  * {throttle, steer, pitch, yaw, roll, jump, boost, handbrake}.  The previous-action block of the device obs builder shows those rows. */
 int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next_obs_dev, float* reward_dev, int32_t* done_dev);
 
+/* How often the narrowphase's fixed-size queues overflowed since the last reset (process-wide; every overflow sends that env through the
+ * inline fallback for that tick -- same results, slower): out5 = {BVH frontier, ball candidate region, car candidate region, item queue, result pool} */
+int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
+
 /* Arena::Step(ticks) on the resident states with the controls stored in them (RS/Sim/Arena/Arena.cpp:716-812) */
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
 int rlgpu_env_sync(rlgpu_env* e);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "rlgpu_pad_location": (_i, [_i, _vp, _vp]),
     "rlgpu_env_enable_step_stats": (_i, [_vp, _i]),
     "rlgpu_comm_rendezvous_path": (_i, [C.c_char_p, _i]),
+    "rlgpu_env_overflow_counts": (_i, [_vp, _vp, _i]),
     "rlgpu_env_enable_timing": (_i, [_vp, _i]),
     "rlgpu_learner_enable_timing": (_i, [_vp, _i]),
     "rlgpu_env_step_stats": (_i, [_vp, _vp, _i]),

@@ -41,7 +41,12 @@ __shared__ unsigned long long g_prof_last;
     } while (0)
 #endif
 #ifndef RLG_DBG_COUNT
-#define RLG_DBG_COUNT(i) ((void)0)
+// Product build: the narrowphase's queue overflows are counted (they are rare -- 1.8 per million env-ticks while a policy learns -- and each
+// one sends its env through the inline fallback for that tick, same results): 0 BVH frontier, 1 ball region, 2 car region, 3 item queue,
+// 4 result pool.  rlgpu_env_overflow_counts reads them; other counter slots (profiler build) compile to nothing.
+__device__ unsigned int g_overflow[8];
+#define RLG_DBG_COUNT(i) do { if ((i) < 5) atomicAdd(&g_overflow[(i)], 1u); } while (0)
+#define RLG_HAVE_OVERFLOW_COUNTS 1
 #endif
 #include "../../include/rlgpu.h"
 #include "arena_gym.h"
@@ -1006,6 +1011,22 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
     if (evp) { HIPCHK(e, hipEventRecord(evp->second, e->stream)); e->ev0 = evp->first; e->ev1 = evp->second; e->timed = true; }
     HIPCHK(e, hipGetLastError());
+    return RLGPU_OK;
+}
+
+int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RLG_HAVE_OVERFLOW_COUNTS
+    HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h)));
+    if (reset) { const unsigned int z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), z, sizeof(z))); }
+#else
+    int d[64]; HIPCHK(e, hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d)));   // profiler build: the same events live in its scratch counters
+    for (int i = 0; i < 5; i++) h[i] = (unsigned int)d[i];
+    (void)reset;
+#endif
+    for (int i = 0; i < 5; i++) out5[i] = h[i];
     return RLGPU_OK;
 }
 

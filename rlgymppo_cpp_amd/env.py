@@ -119,6 +119,12 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_download_snapshots(self.h, C.addressof(arr), first_env, n), self.h, self.lib.rlgpu_env_last_error)
         return list(arr)
 
+    def overflow_counts(self, reset=False):
+        """Narrowphase queue overflows since the last reset, process-wide: [BVH frontier, ball region, car region, item queue, result pool]."""
+        out = (C.c_uint64 * 5)()
+        _chk(self.lib.rlgpu_env_overflow_counts(self.h, C.addressof(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return [int(x) for x in out]
+
     def enable_step_stats(self, on=True):
         _chk(self.lib.rlgpu_env_enable_step_stats(self.h, 1 if on else 0), self.h, self.lib.rlgpu_env_last_error)
 
