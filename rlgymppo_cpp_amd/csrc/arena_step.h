@@ -661,6 +661,9 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
     for (int ci = 0; ci < NC; ci++) max_man = car_man[ci] > max_man ? car_man[ci] : max_man;
     // some body is held by two manifolds: the reference's pair / island order decides which of them the solver visits first
     if (max_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
+#ifdef RLG_EXPERIMENT_ORDER_TWICE   // what-if build only: prices the order emulation in place (it is idempotent)
+    if (max_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
+#endif
 }
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue

@@ -45,7 +45,7 @@ __shared__ unsigned long long g_prof_last;
 // one sends its env through the inline fallback for that tick, same results): 0 BVH frontier, 1 ball region, 2 car region, 3 item queue,
 // 4 result pool.  rlgpu_env_overflow_counts reads them; other counter slots (profiler build) compile to nothing.
 __device__ unsigned int g_overflow[8];
-#define RLG_DBG_COUNT(i) do { if ((i) < 5) atomicAdd(&g_overflow[(i)], 1u); } while (0)
+#define RLG_DBG_COUNT(i) do { if ((i) < 5) atomicAdd(&g_overflow[(i) & 7], 1u); } while (0)
 #define RLG_HAVE_OVERFLOW_COUNTS 1
 #endif
 #include "../../include/rlgpu.h"
