@@ -25,13 +25,7 @@ p = L.ppo.get_params(2)
 print("soak: params finite", bool(np.isfinite(p).all()), "| obs finite", bool(torch.isfinite(L.obs_buf).all().item()), "| |obs| max %.2f" % float(L.obs_buf.abs().max().item()),
       "| reward range [%.2f, %.2f]" % (float(L.rew_buf.min().item()), float(L.rew_buf.max().item())), "| agent-steps/s overall %.2fM" % (L.total_timesteps / (time.time() - t0) / 1e6))
 
-# profiling build only (RLGPU_LIB=.../librlgpu_prof.so): how often the narrowphase queues overflowed into the inline fallback
-import ctypes as C
-try:
-    fn = L.env.lib.rlgpu_env_debug_ints
-    fn.argtypes = [C.c_void_p, C.c_void_p]
-    buf = (C.c_int * 64)(); fn(L.env.h, buf)
-    print("queue overflow events over the run: frontier", buf[0], "ball region", buf[1], "car region", buf[2], "items", buf[3], "pool", buf[4],
-          "(of %.0fM env-ticks)" % (L.total_timesteps / 2 * 8 / 1e6))
-except AttributeError:
-    pass
+# how often the narrowphase queues overflowed into the inline fallback (release build: rlgpu_env_overflow_counts)
+ovf = L.env.overflow_counts()
+print("queue overflow events over the run: frontier", ovf[0], "ball region", ovf[1], "car region", ovf[2], "items", ovf[3], "pool", ovf[4],
+      "(of %.0fM env-ticks)" % (L.total_timesteps / 2 * 8 / 1e6))
