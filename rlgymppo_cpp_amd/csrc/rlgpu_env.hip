@@ -66,7 +66,7 @@ constexpr int WAVE = 64;
 #define RLG_LDS_BUDGET (40 * 1024)
 #endif
 #ifndef RLG_LDS_NODES
-#define RLG_LDS_NODES 192
+#define RLG_LDS_NODES 144   /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS) */
 #endif
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1
@@ -93,8 +93,28 @@ struct EnvDev {
 // dynamically indexed arrays (cars[], contacts, solver rows) would sit in scratch memory, and with one wavefront per
 // SIMD nothing hides a ~500-cycle scratch access per array element.  Only a few lanes of a wavefront are active so
 // that 4096 envs spread over all 256 CUs instead of 64 waves.
+// The candidate lists of an env outlive the tick that walked the BVH for them.  The walk is done for FAT query boxes (the bodies' boxes grown
+// by CAND_FAT on every side) and its leaves are kept; as long as every body's box of the tick still lies inside its fat box (and the same
+// bodies take part), the kept leaves are a superset of what a fresh walk would list, in the same relative order, and the exact per-triangle
+// tests that follow see to it that the tick's items -- and with them every result -- are those of a fresh walk.  Worth it because the
+// walk was ~10 % of a collection launch (priced by running it twice) and most bodies move a fraction of CAND_FAT per tick.
+#ifndef RLG_CAND_FAT
+#define RLG_CAND_FAT 2.0f          // Bullet units (100 uu); measured 1.0 / 2.0 / 3.0: collection launch 23.0 / 22.4 / 22.65 ms (23.4 without the cache)
+#endif
+constexpr float CAND_FAT = RLG_CAND_FAT;
+constexpr int CACHE_LEAVES = BALL_CAND / LEAF_SLOTS;
+static_assert(BALL_CAND == CAR_CAND, "one leaf capacity for every body");
 template <int NC>
-struct LaneBlock { Arena<NC> A; GymEnv<NC> G; TickWork<NC> W; };
+struct CandCache {
+    static constexpr int NB = NC + 1;
+    V3 lo[NB], hi[NB];                    // the fat boxes the lists were walked for
+    uint32_t leaf[NB][CACHE_LEAVES];      // first triangle | count << 24, in walk order
+    uint8_t n[NB];                        // leaves of body b
+    uint8_t active;                       // bit b: body b had a query box then
+    uint8_t valid;                        // 0: walk again (cleared when a launch loads the env)
+};
+template <int NC>
+struct LaneBlock { Arena<NC> A; GymEnv<NC> G; TickWork<NC> W; CandCache<NC> C; };
 
 // per-lane stride: an ODD number of 8-byte units, so lane l starts at bank (2 * odd * l) mod 32 -> conflict-free for <= 16 lanes
 template <int NC>
@@ -220,72 +240,110 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     const bool grp = e < n_valid;
     LaneBlock<NC>& S = lane_block<NC>(lane_mem, grp ? e : 0);
     CollideQueue<NC>& Q = S.W.Q;
+    CandCache<NC>& C = S.C;
     const int gshift = e * LPE;
     const unsigned long long gmask = ~0ull >> (64 - LPE);
     const unsigned long long below = (1ull << li) - 1ull;
     const bool asleep = (len2(S.A.ball.b.vel) == 0.f && len2(S.A.ball.b.angvel) == 0.f);
-    bool overflow = mv.n_nodes > 65535;
+    const bool too_big = mv.n_nodes > 65535;   // frontier entries carry 16-bit node ids: bigger trees use the inline walk
     const bool all_fast = mv.n_nodes <= mv.n_fast;
-    // query boxes: lane b of the group computes body b's and publishes it
-    bool my_active = false;
-    if (grp && li < NB && !overflow) {
-        V3 lo, hi;
+    // this tick's query boxes: lane b of the group computes body b's and checks it against the kept fat box
+    bool my_active = false, my_stale = false;
+    V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
+    if (grp && li < NB && !too_big) {
         my_active = body_query_box(S.A, li, asleep, lo, hi) && mesh_maybe_near(mv, lo, hi);
-        if (my_active) { Q.box_lo[li] = lo; Q.box_hi[li] = hi; }
-    }
-    // level 0: the roots of the active bodies, in body order
-    const unsigned long long ma = (__ballot(my_active) >> gshift) & gmask;
-    if (my_active) Q.frontier[0][__popcll(ma & below)] = (uint32_t)li << 16;
-    int n = grp ? __popcll(ma) : 0, cur = 0;
-    int cnt_b[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) cnt_b[b] = 0;
-    while (__any(n > 0)) {
-        wave_sync();
-        int m = 0;
-        for (int c0 = 0; __any(c0 < n); c0 += LPE) {
-            const int j = c0 + li;
-            bool inner = false, leaf = false; int cnt = 0, first = 0, body = 0;
-            if (j < n) {
-                const uint32_t ent = Q.frontier[cur][j];
-                body = (int)(ent >> 16);
-                const int ni = (int)(ent & 0xffffu);
-                BvhNode nd;
-                if (all_fast) { RLG_ASSUME_LDS(*mv.nodes_fast); nd = load_node(mv.nodes_fast + ni); }   // whole tree staged: ds_read instead of a flat load
-                else nd = mesh_node(mv, ni);
-                if (aabb_overlap(nd, Q.box_lo[body], Q.box_hi[body])) { cnt = node_count(nd); first = nd.left_or_first; inner = cnt == 0; leaf = cnt > 0; }
-            }
-            const unsigned long long mi = (__ballot(inner) >> gshift) & gmask;
-            bool ovf = false;
-            if (inner) {
-                const int pos = m + 2 * __popcll(mi & below);
-                if (pos + 2 > FRONTIER_CAP) { ovf = true; RLG_DBG_COUNT(0); }
-                else { Q.frontier[cur ^ 1][pos] = ((uint32_t)body << 16) | (uint32_t)first; Q.frontier[cur ^ 1][pos + 1] = ((uint32_t)body << 16) | (uint32_t)(first + 1); }
-            }
-            m += 2 * __popcll(mi);
-            // leaves: a fixed block of LEAF_SLOTS candidate slots per leaf in the body's region, in frontier order (unused
-            // slots are holes) -- a ballot per body instead of a prefix sum over the triangle counts
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const bool mine = leaf && body == b;
-                const unsigned long long ml = (__ballot(mine) >> gshift) & gmask;
-                if (mine) {
-                    const int k = cnt_b[b] + LEAF_SLOTS * __popcll(ml & below);
-                    if (k + LEAF_SLOTS > CollideQueue<NC>::region_cap(b)) { ovf = true; RLG_DBG_COUNT(1 + (b > 0)); }
-                    else for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[CollideQueue<NC>::region(b) + k + q] = q < cnt ? pack_cand(b == 0 ? 0 : 1, b == 0 ? 0 : b - 1, first + q) : CAND_HOLE;
-                }
-                cnt_b[b] += LEAF_SLOTS * __popcll(ml);
-            }
-            if ((__ballot(ovf) >> gshift) & gmask) overflow = true;
+        const bool was = (C.active >> li) & 1u;
+        if (!C.valid || was != my_active) my_stale = true;
+        else if (my_active) {
+            const V3 cl = C.lo[li], ch = C.hi[li];
+            my_stale = lo.x < cl.x || lo.y < cl.y || lo.z < cl.z || hi.x > ch.x || hi.y > ch.y || hi.z > ch.z;
         }
-        n = overflow ? 0 : m;
-        cur ^= 1;
+    }
+    const bool walk = grp && !too_big && ((__ballot(my_stale) >> gshift) & gmask) != 0ull;   // the whole env walks again when one of its bodies left its box
+    bool overflow = too_big;
+    // The walk (fat boxes first; should their lists not fit, once more with the exact boxes, and the result is not kept).
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const float fat = attempt == 0 ? CAND_FAT : 0.f;
+        const bool go = walk && (attempt == 0 || overflow);
+        if (!__any(go)) break;
+        if (go) overflow = false;
+        if (go && li < NB) {
+            if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); C.lo[li] = Q.box_lo[li]; C.hi[li] = Q.box_hi[li]; }
+            C.n[li] = 0;
+        }
+        // level 0: the roots of the active bodies, in body order
+        const unsigned long long ma = (__ballot(go && my_active) >> gshift) & gmask;
+        if (go && my_active) Q.frontier[0][__popcll(ma & below)] = (uint32_t)li << 16;
+        int n = go ? __popcll(ma) : 0, cur = 0;
+        int cnt_b[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) cnt_b[b] = 0;
+        while (__any(n > 0)) {
+            wave_sync();
+            int m = 0;
+            for (int c0 = 0; __any(c0 < n); c0 += LPE) {
+                const int j = c0 + li;
+                bool inner = false, leaf = false; int cnt = 0, first = 0, body = 0;
+                if (j < n) {
+                    const uint32_t ent = Q.frontier[cur][j];
+                    body = (int)(ent >> 16);
+                    const int ni = (int)(ent & 0xffffu);
+                    BvhNode nd;
+                    if (all_fast) { RLG_ASSUME_LDS(*mv.nodes_fast); nd = load_node(mv.nodes_fast + ni); }   // whole tree staged: ds_read instead of a flat load
+                    else nd = mesh_node(mv, ni);
+                    if (aabb_overlap(nd, Q.box_lo[body], Q.box_hi[body])) { cnt = node_count(nd); first = nd.left_or_first; inner = cnt == 0; leaf = cnt > 0; }
+                }
+                const unsigned long long mi = (__ballot(inner) >> gshift) & gmask;
+                bool ovf = false;
+                if (inner) {
+                    const int pos = m + 2 * __popcll(mi & below);
+                    if (pos + 2 > FRONTIER_CAP) { ovf = true; if (attempt == 1) RLG_DBG_COUNT(0); }
+                    else { Q.frontier[cur ^ 1][pos] = ((uint32_t)body << 16) | (uint32_t)first; Q.frontier[cur ^ 1][pos + 1] = ((uint32_t)body << 16) | (uint32_t)(first + 1); }
+                }
+                m += 2 * __popcll(mi);
+                // leaves, in frontier order per body (a ballot per body instead of a prefix sum over the triangle counts)
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const bool mine = leaf && body == b;
+                    const unsigned long long ml = (__ballot(mine) >> gshift) & gmask;
+                    if (mine) {
+                        const int k = cnt_b[b] + __popcll(ml & below);
+                        if (k >= CACHE_LEAVES) { ovf = true; if (attempt == 1) RLG_DBG_COUNT(1 + (b > 0)); }
+                        else C.leaf[b][k] = (uint32_t)first | ((uint32_t)cnt << 24);
+                    }
+                    cnt_b[b] += __popcll(ml);
+                }
+                if ((__ballot(ovf) >> gshift) & gmask) overflow = true;
+            }
+            n = overflow ? 0 : m;
+            cur ^= 1;
+        }
+        wave_sync();
+        if (go && li == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) C.n[b] = (uint8_t)(cnt_b[b] < CACHE_LEAVES ? cnt_b[b] : CACHE_LEAVES);
+            C.active = (uint8_t)ma;
+            C.valid = (!overflow && attempt == 0) ? 1 : 0;
+        }
+        wave_sync();
+    }
+    // this tick's candidate slots from the kept leaves: a fixed block of LEAF_SLOTS slots per leaf in the body's region (unused slots are holes)
+    if (grp && !overflow) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int nl = ((C.active >> b) & 1u) ? (int)C.n[b] : 0;
+            for (int k = li; k < nl; k += LPE) {
+                const uint32_t lf = C.leaf[b][k];
+                const int first = (int)(lf & 0xFFFFFFu), cnt = (int)(lf >> 24);
+                for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[CollideQueue<NC>::region(b) + k * LEAF_SLOTS + q] = q < cnt ? pack_cand(b == 0 ? 0 : 1, b == 0 ? 0 : b - 1, first + q) : CAND_HOLE;
+            }
+        }
     }
     wave_sync();
     if (grp && li == 0) {
         S.W.ball_asleep = asleep;
 #pragma unroll
-        for (int b = 0; b < NB; b++) Q.cand_count[b] = (uint16_t)(cnt_b[b] < CollideQueue<NC>::region_cap(b) ? cnt_b[b] : CollideQueue<NC>::region_cap(b));
+        for (int b = 0; b < NB; b++) Q.cand_count[b] = (uint16_t)((!overflow && ((C.active >> b) & 1u)) ? (int)C.n[b] * LEAF_SLOTS : 0);
         Q.n_items = 0; Q.n_pool = 0; Q.overflow = overflow ? 1 : 0; Q.n_pairs = 0;
         for (int ci = 0; ci < NC; ci++)
             for (int ib = ci + 1; ib < NC; ib++)
@@ -312,6 +370,9 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     wave_sync();
     RLG_PROF(0);
     build_candidates_wave<NC>(lane_mem, n_valid, mv);
+#ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
+    build_candidates_wave<NC>(lane_mem, n_valid, mv);
+#endif
     RLG_PROF(1);
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
     if (whl_lane) car_wheel_ray_begin(Sw.A, c_whl, w_whl, Sw.W.ctx[c_whl]);
@@ -475,6 +536,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
     if (env_lane) {
         int32_t acts[NC];
         for (int k = 0; k < P; k++) acts[k] = actions[(size_t)env * P + k];   // agent rows of this env (gym_step_begin maps them to slots)
@@ -550,6 +612,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     unsigned long long prof_infer = 0, prof_mlp = 0;
 #endif
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
     wave_sync();
     StepStats stats;
     for (int t = 0; t < c.T; t++) {
@@ -635,6 +698,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
