@@ -96,6 +96,57 @@ int main() {
         std::printf("render datagram: %s\n", got.c_str());
         close(rx);
     }
+    // ---- the open plugin boundary, host side only (no GPU needed): which kinds go where, and the Arena facade ----
+    {
+        struct MyOBS : DefaultOBS { void AddPlayerToOBS(FList& o, const PlayerData& p, bool inv) override { DefaultOBS::AddPlayerToOBS(o, p, inv); o += 1.f; } };
+        struct MySetter : StateSetter { GameState ResetState(Arena* a) override { a->ResetToRandomKickoff(7); return GameState(a); } };
+        struct MyTerminal : TerminalCondition { bool IsTerminal(const GameState&) override { return false; } };
+        MyOBS myObs; MySetter mySetter; MyTerminal myTerm;
+        Match::DevicePlan all = match.PlanDevice(8);
+        CHECK(!all.AnyHost() && all.cfg.one_team == 0);
+        Match::DevicePlan p1 = Match(&rew, {&nt, &gs}, &myObs, &act, &rs, 1, true).PlanDevice(8);
+        CHECK(p1.hostObs && !p1.hostReward && !p1.hostTerminal && !p1.hostSetter && !p1.hostParser);   // a subclass of a built-in does not get the built-in's device form
+        Match::DevicePlan p2 = Match(&mine, {&nt, &myTerm}, &obs, &act, &mySetter, 2, false).PlanDevice(4);
+        CHECK(p2.hostReward && p2.hostTerminal && p2.hostSetter && !p2.hostObs && p2.cfg.n_conds == 0 && p2.cfg.n_terms == 0 && p2.cfg.one_team == 1 && p2.cfg.tick_skip == 4);
+        // Arena facade: slots, ids, GetState / SetState, kickoff with a seed, GameState(Arena*)
+        Arena* arena = Arena::Create(GameMode::SOCCAR);
+        Car* b0 = arena->AddCar(Team::BLUE); Car* o0 = arena->AddCar(Team::ORANGE); Car* b1 = arena->AddCar(Team::BLUE); Car* o1 = arena->AddCar(Team::ORANGE);
+        CHECK(b0->id == 1 && o0->id == 2 && b1->id == 3 && o1->id == 4 && arena->_state.num_cars == 4 && arena->GetCar(3) == b1 && arena->_boostPads.size() == 34);
+        bool threw2 = false;
+        try { arena->AddCar(Team::ORANGE); } catch (const std::runtime_error&) { threw2 = true; }   // blue is next
+        CHECK(threw2);
+        CarState cs; cs.pos = Vec(100, -200, 300); cs.vel = Vec(1, 2, 3); cs.boost = 55; cs.isOnGround = false; cs.hasFlipped = true; cs.worldContact.hasContact = true;
+        cs.ballHitInfo.isValid = true; cs.ballHitInfo.tickCountWhenHit = 77; cs.lastControls.jump = true; cs.rotMat = Angle(0.3f, 0.1f, -0.2f).ToRotMat();
+        b1->SetState(cs);
+        CarState back = b1->GetState();
+        CHECK(back.pos.x == 100 && back.vel.z == 3 && back.boost == 55 && !back.isOnGround && back.hasFlipped && back.worldContact.hasContact && back.ballHitInfo.isValid &&
+              back.ballHitInfo.tickCountWhenHit == 77 && back.lastControls.jump && back.rotMat.forward.x == cs.rotMat.forward.x && back.rotMat.up.z == cs.rotMat.up.z);
+        const float fx = cs.rotMat.forward.x, fy = cs.rotMat.forward.y, fz = cs.rotMat.forward.z;
+        CHECK(std::fabs(fx * fx + fy * fy + fz * fz - 1.f) < 1e-6f && std::fabs(cs.rotMat.forward.Dot(cs.rotMat.up)) < 1e-6f);   // Angle::ToRotMat is a rotation
+        arena->ResetToRandomKickoff(5);
+        const CarState kb = b0->GetState(), ko = o0->GetState();
+        CHECK(kb.pos.y < 0 && kb.pos.z == 17.f && ko.pos.x == -kb.pos.x && ko.pos.y == -kb.pos.y && arena->ball->GetState().pos.z == RLConst::BALL_REST_Z);
+        Arena* again = Arena::Create(GameMode::SOCCAR);
+        again->AddCar(Team::BLUE); again->AddCar(Team::ORANGE); again->ResetToRandomKickoff(5);
+        CHECK(again->_cars[0]->GetState().pos.x == kb.pos.x && again->_cars[0]->GetState().pos.y == kb.pos.y);   // same seed, same spot
+        GameState fresh(arena);
+        CHECK(fresh.players.size() == 4 && fresh.players[2].carId == 3 && fresh.players[1].team == Team::ORANGE && fresh.players[0].phys.pos.y == kb.pos.y);
+        // the reference's RandomState on the facade: everything inside its ranges, cars on the ground flat
+        RocketSim::Math::SeedRandEngine(3);
+        RandomState scatter(true, true, true);
+        for (int i = 0; i < 50; i++) {
+            GameState st = scatter.ResetState(arena);
+            CHECK(std::fabs(st.ball.pos.x) <= 3500 && std::fabs(st.ball.pos.y) <= 4000 && st.ball.pos.z >= 92.75f && st.ball.pos.z <= 1820 && st.ball.vel.Length() <= 4000.01f);
+            for (const PlayerData& pd : st.players) CHECK(pd.phys.pos.z == 17.f && pd.phys.vel.z == 0 && pd.phys.rotMat.up.z > 0.9999f && pd.carState.boost >= 0 && pd.carState.boost <= 100);
+        }
+        // one-team arena: blue cars only, ids 1, 2, 3; the orange slots stay empty
+        Arena* solo = Arena::Create(GameMode::SOCCAR);
+        solo->AddCar(Team::BLUE); solo->AddCar(Team::BLUE); solo->AddCar(Team::BLUE);
+        CHECK(solo->_IsOneTeam() && solo->_state.num_cars == 6 && solo->_cars[2]->id == 3 && (solo->_state.cars[1].flags & RLGPU_CF_ABSENT) && !(solo->_state.cars[2].flags & RLGPU_CF_ABSENT));
+        GameState soloState(solo);
+        CHECK(soloState.players.size() == 3 && soloState.players[2].carId == 3);
+        delete arena; delete again; delete solo;
+    }
     std::printf("host api ok\n");
     return 0;
 }

@@ -20,7 +20,7 @@ def test_host_api_translation_and_utils(tmp_path):
     assert os.path.exists(lib), "librlgpu.so missing: run __graft_entry__.build()"
     exe = str(tmp_path / "host_api_check")
     r = _run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_api_check.cpp"), "-o", exe,
-              "-L", PKG, "-lrlgpu", f"-Wl,-rpath,{PKG}", "-Wl,-rpath-link,/opt/rocm/lib"])
+              "-L", PKG, "-lrlgymppo_amd", "-lrlgpu", f"-Wl,-rpath,{PKG}", "-Wl,-rpath-link,/opt/rocm/lib"])
     assert r.returncode == 0, r.stdout
     r = _run([exe], env=dict(os.environ, RLGPU_METRICS_DIR=str(tmp_path / "metrics")))
     assert r.returncode == 0 and "host api ok" in r.stdout, r.stdout
