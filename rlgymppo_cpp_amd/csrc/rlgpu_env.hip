@@ -259,7 +259,9 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
             my_stale = lo.x < cl.x || lo.y < cl.y || lo.z < cl.z || hi.x > ch.x || hi.y > ch.y || hi.z > ch.z;
         }
     }
-    const bool walk = grp && !too_big && ((__ballot(my_stale) >> gshift) & gmask) != 0ull;   // the whole env walks again when one of its bodies left its box
+    // one body out of its box and EVERY env of the wavefront walks again: the walk is level-synchronous over the whole wavefront anyway (an env
+    // that would not have had to walk costs nothing extra), and boxes that are renewed together tend to run out together
+    const bool walk = grp && !too_big && __any(my_stale);
     bool overflow = too_big;
     // The walk (fat boxes first; should their lists not fit, once more with the exact boxes, and the result is not kept).
     for (int attempt = 0; attempt < 2; attempt++) {
