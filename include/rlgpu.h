@@ -82,6 +82,9 @@ int rlgpu_env_set_procedural_mesh(rlgpu_env* e);
 int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* soccar_dir); /* collision_meshes/soccar/<name>.cmf */
 /* host helpers (no GPU needed): the procedural soccar mesh and the DiscreteAction table */
 int rlgpu_procedural_mesh(float* verts_uu, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris);
+/* order_out[i] = input triangle that is collided i-th when everything overlaps: the visiting order of the reference's quantized BVH
+   (btOptimizedBvh::build + walkStacklessQuantizedTreeCacheFriendly, btQuantizedBvh.cpp:116-277,655-674), which this library's mesh keeps */
+int rlgpu_mesh_visit_order(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, int32_t* order_out);
 int rlgpu_action_table(float* out_rows_x8, int cap_rows); /* DiscreteAction::DiscreteAction (SIM/Utils/ActionParsers/DiscreteAction.cpp:3-67) */
 
 /* Car::SetState/GetState, Ball::SetState/GetState, BoostPad::SetState for whole envs (RS/Sim/Car/Car.cpp:9-36,

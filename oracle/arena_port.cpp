@@ -54,6 +54,7 @@ int port_procedural_mesh(float* verts_out, int cap_verts, int32_t* tris_out, int
     memcpy(verts_out, v.data(), v.size() * 4); memcpy(tris_out, t.data(), t.size() * 4);
     return 0;
 }
+int port_mesh_visit_order(int32_t* out, int cap) { int n = (int)g_mesh.source_tri.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_mesh.source_tri[i]; return n; }
 int port_mesh_counts(int* n_nodes, int* n_tris) { *n_nodes = (int)g_mesh.nodes.size(); *n_tris = (int)g_mesh.tris.size(); return 0; }
 
 // advance the physical state by `ticks` ticks with the controls stored in the state

@@ -252,6 +252,21 @@ int ref_init(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris
     return 0;
 }
 
+// The order in which the arena mesh's triangles are handed to a convex body's collision callback when everything overlaps
+// (btBvhTriangleMeshShape::processAllTriangles): out[i] = triangle index visited i-th.  Returns the triangle count.
+int ref_mesh_visit_order(int32_t* out, int cap) {
+    struct Rec : public btTriangleCallback {
+        int32_t* out; int cap; int n = 0;
+        void processTriangle(btVector3*, int, int triangleIndex) override { if (n < cap) out[n] = triangleIndex; n++; }
+    } rec;
+    rec.out = out; rec.cap = cap;
+    auto& shapes = RocketSim::GetArenaCollisionShapes(GameMode::SOCCAR);
+    if (shapes.empty()) return -1;
+    const btVector3 lo(-1e9f, -1e9f, -1e9f), hi(1e9f, 1e9f, 1e9f);
+    shapes[0]->processAllTriangles(&rec, lo, hi);
+    return rec.n;
+}
+
 int ref_state_size() { return (int)sizeof(RlgpuArenaState); }
 
 void* ref_arena_new(int team_size) {

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rlgpu_env_set_procedural_mesh": (_i, [_vp]),
     "rlgpu_env_load_cmf_dir": (_i, [_vp, C.c_char_p]),
     "rlgpu_procedural_mesh": (_i, [_vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "rlgpu_mesh_visit_order": (_i, [_vp, _i, _vp, _i, _vp]),
     "rlgpu_action_table": (_i, [_vp, _i]),
     "rlgpu_env_upload_states": (_i, [_vp, _vp, _vp, _i]),
     "rlgpu_env_download_states": (_i, [_vp, _vp, _vp, _i]),

@@ -25,29 +25,141 @@ void tri_bounds(const MeshTri& t, float* mn, float* mx) {
     mn[2] = std::min({t.v0z, t.v1z, t.v2z}); mx[2] = std::max({t.v0z, t.v1z, t.v2z});
 }
 
-int build_rec(std::vector<MeshTri>& tris, std::vector<BuildNode>& nodes, int first, int count) {
-    BuildNode nd;
-    for (int a = 0; a < 3; a++) { nd.mn[a] = 1e30f; nd.mx[a] = -1e30f; }
-    for (int i = first; i < first + count; i++) {
-        float mn[3], mx[3]; tri_bounds(tris[i], mn, mx);
-        for (int a = 0; a < 3; a++) { nd.mn[a] = std::min(nd.mn[a], mn[a]); nd.mx[a] = std::max(nd.mx[a], mx[a]); }
+// ---- the reference's triangle visiting order --------------------------------------------------------------------------------------
+// A convex body is collided with the mesh triangles in the order btBvhTriangleMeshShape::processAllTriangles reports them
+// (btBvhTriangleMeshShape.cpp:115-117), and that order decides the order of a manifold's points and which point a fifth one replaces.
+// It is a property of the tree btOptimizedBvh::build makes (btOptimizedBvh.cpp:30-170, quantized: RocketSim.cpp:167 passes
+// useQuantizedAabbCompression = true), restated here:
+//  * quantization frame: the mesh's vertex box (btTriangleMeshShape::recalcLocalAabb, margin 0: btConcaveShape.cpp:21) through
+//    setQuantizationValues (btQuantizedBvh.cpp:73-106);
+//  * one leaf per triangle: its box (zero extents widened, btOptimizedBvh.cpp:103-119) quantized to 16 bits, min rounded down to even,
+//    max rounded up to odd (btQuantizedBvh.h:331-358);
+//  * buildTree (btQuantizedBvh.cpp:116-188): split axis = largest variance of the DEQUANTIZED box centres (calcSplittingAxis :279-304),
+//    leaves with centre > mean swapped to the front (sortAndCalcSplittingIndex :218-277), the middle instead when that leaves less than
+//    a third on one side; nodes are laid out depth-first;
+//  * the query (walkStacklessQuantizedTreeCacheFriendly :655-674) goes through the SUBTREE HEADERS in the order they were made
+//    (updateSubtreeHeaders :190-216: when a subtree exceeds 2048 bytes = 128 nodes, each child that does not gets a header, and that
+//    happens after both children are built) and walks each header's nodes in array order.  So the visiting order is the depth-first
+//    order with the children swapped wherever the left child is small (<= 64 leaves) and the right one is not.
+// All arithmetic is the reference's, operation by operation (scalar fp32: BT_USE_SSE is not defined on Linux, btScalar.h:117-137).
+struct QBvhFrame {
+    float mn[3], mx[3], q[3];
+    void quantize(uint16_t* out, const float* p, bool is_max) const {
+        for (int a = 0; a < 3; a++) {
+            float v = (p[a] - mn[a]) * q[a];
+            out[a] = is_max ? (uint16_t)(((uint16_t)(v + 1.f)) | 1) : (uint16_t)(((uint16_t)(v)) & 0xfffe);
+        }
     }
-    int idx = (int)nodes.size();
-    nodes.push_back(nd);
-    if (count <= 4) { nodes[idx].first = first; nodes[idx].count = count; return idx; }
-    int axis = 0; float ext = nd.mx[0] - nd.mn[0];
-    for (int a = 1; a < 3; a++) if (nd.mx[a] - nd.mn[a] > ext) { ext = nd.mx[a] - nd.mn[a]; axis = a; }
-    auto centroid = [axis](const MeshTri& t) {
-        const float* p = &t.v0x;
-        return p[axis] + p[3 + axis] + p[6 + axis];
-    };
-    int mid = first + count / 2;
-    std::nth_element(tris.begin() + first, tris.begin() + mid, tris.begin() + first + count,
-                     [&](const MeshTri& a, const MeshTri& b) { return centroid(a) < centroid(b); });
-    int l = build_rec(tris, nodes, first, mid - first);
-    int r = build_rec(tris, nodes, mid, first + count - mid);
-    nodes[idx].left = l; nodes[idx].right = r;
-    return idx;
+    void unquantize(const uint16_t* in, float* out) const {
+        for (int a = 0; a < 3; a++) { float v = (float)in[a] / q[a]; v += mn[a]; out[a] = v; }
+    }
+    void set(const float* lo, const float* hi) {   // setQuantizationValues(lo, hi, quantizationMargin = 1)
+        float size[3];
+        for (int a = 0; a < 3; a++) { mn[a] = lo[a] - 1.f; mx[a] = hi[a] + 1.f; size[a] = mx[a] - mn[a]; q[a] = 65533.f / size[a]; }
+        uint16_t w[3]; float v[3];
+        quantize(w, mn, false); unquantize(w, v);
+        for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], v[a] - 1.f);
+        for (int a = 0; a < 3; a++) { size[a] = mx[a] - mn[a]; q[a] = 65533.f / size[a]; }
+        quantize(w, mx, true); unquantize(w, v);
+        for (int a = 0; a < 3; a++) mx[a] = std::max(mx[a], v[a] + 1.f);
+        for (int a = 0; a < 3; a++) { size[a] = mx[a] - mn[a]; q[a] = 65533.f / size[a]; }
+    }
+};
+struct QLeaf { uint16_t mn[3], mx[3]; int tri; };
+struct QTree {
+    const QBvhFrame& F; std::vector<QLeaf>& L;
+    struct Node { int left = -1, right = -1, first = 0, count = 0; };   // leaf range [first, first + count) of L
+    std::vector<Node> nodes;
+    void centre(int i, float* c) const {
+        float lo[3], hi[3]; F.unquantize(L[i].mn, lo); F.unquantize(L[i].mx, hi);
+        for (int a = 0; a < 3; a++) c[a] = 0.5f * (hi[a] + lo[a]);
+    }
+    void means_of(int s, int e, float* means) const {
+        means[0] = means[1] = means[2] = 0.f;
+        for (int i = s; i < e; i++) { float c[3]; centre(i, c); for (int a = 0; a < 3; a++) means[a] += c[a]; }
+        const float inv = 1.f / (float)(e - s);
+        for (int a = 0; a < 3; a++) means[a] *= inv;
+    }
+    int split_axis(int s, int e) const {
+        float means[3], var[3] = {0.f, 0.f, 0.f};
+        means_of(s, e, means);
+        for (int i = s; i < e; i++) { float c[3]; centre(i, c); for (int a = 0; a < 3; a++) { float d = c[a] - means[a]; d = d * d; var[a] += d; } }
+        const float inv = 1.f / ((float)(e - s) - 1.f);
+        for (int a = 0; a < 3; a++) var[a] *= inv;
+        return var[0] < var[1] ? (var[1] < var[2] ? 2 : 1) : (var[0] < var[2] ? 2 : 0);   // btVector3::maxAxis
+    }
+    int split_index(int s, int e, int axis) {
+        float means[3]; means_of(s, e, means);
+        const float split = means[axis];
+        int k = s;
+        for (int i = s; i < e; i++) { float c[3]; centre(i, c); if (c[axis] > split) { std::swap(L[i], L[k]); k++; } }
+        const int n = e - s, third = n / 3;
+        if (k <= s + third || k >= e - 1 - third) k = s + (n >> 1);
+        return k;
+    }
+    int build(int s, int e) {
+        const int idx = (int)nodes.size();
+        nodes.push_back(Node{});
+        nodes[idx].first = s; nodes[idx].count = e - s;
+        if (e - s == 1) return idx;
+        const int axis = split_axis(s, e);
+        const int k = split_index(s, e, axis);
+        const int l = build(s, k), r = build(k, e);
+        nodes[idx].left = l; nodes[idx].right = r;
+        return idx;
+    }
+};
+
+// One mesh object: the reference's tree over triangles [t0, t0 + n) of `src`; appends them to `out` in visiting order and this repo's
+// nodes to `bn` (the reference's tree cut off where a subtree holds <= 4 triangles, children in visiting order).  Returns the root.
+int build_part(const std::vector<MeshTri>& src, int t0, int n, std::vector<MeshTri>& out, std::vector<BuildNode>& bn, std::vector<int>* visit_order) {
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int i = t0; i < t0 + n; i++) { float mn[3], mx[3]; tri_bounds(src[i], mn, mx); for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], mn[a]); hi[a] = std::max(hi[a], mx[a]); } }
+    QBvhFrame F; F.set(lo, hi);
+    std::vector<QLeaf> L(n);
+    for (int i = 0; i < n; i++) {
+        float mn[3], mx[3]; tri_bounds(src[t0 + i], mn, mx);
+        for (int a = 0; a < 3; a++) if (mx[a] - mn[a] < 0.002f) { mx[a] = mx[a] + 0.001f; mn[a] = mn[a] - 0.001f; }
+        F.quantize(L[i].mn, mn, false); F.quantize(L[i].mx, mx, true); L[i].tri = t0 + i;
+    }
+    QTree T{F, L, {}};
+    T.nodes.reserve(2 * n);
+    T.build(0, n);
+    // visiting order + this repo's nodes
+    struct Rec {
+        const QTree& T; const std::vector<MeshTri>& src; std::vector<MeshTri>& out; std::vector<BuildNode>& bn; std::vector<int>* vo;
+        void emit(int ti) { const QTree::Node& nd = T.nodes[ti]; if (nd.left < 0) { out.push_back(src[T.L[nd.first].tri]); if (vo) vo->push_back(T.L[nd.first].tri); return; } emit(nd.left); emit(nd.right); }
+        int go(int ti) {
+            const QTree::Node& nd = T.nodes[ti];
+            const int idx = (int)bn.size();
+            bn.push_back(BuildNode{});
+            if (nd.count <= 4) {   // (<= 64 leaves: no header inside, plain depth-first order)
+                bn[idx].first = (int)out.size(); bn[idx].count = nd.count;
+                emit(ti);
+            } else {
+                int a = nd.left, b = nd.right;
+                if (T.nodes[a].count <= 64 && T.nodes[b].count > 64) std::swap(a, b);   // the right child's headers were made first
+                const int l = go(a), r = go(b);
+                bn[idx].left = l; bn[idx].right = r;
+            }
+            return idx;
+        }
+    } rec{T, src, out, bn, visit_order};
+    return rec.go(0);
+}
+
+void fit_bounds(const std::vector<MeshTri>& tris, std::vector<BuildNode>& bn, int i) {
+    BuildNode& nd = bn[i];
+    for (int a = 0; a < 3; a++) { nd.mn[a] = 1e30f; nd.mx[a] = -1e30f; }
+    if (nd.count > 0) {
+        for (int t = nd.first; t < nd.first + nd.count; t++) {
+            float mn[3], mx[3]; tri_bounds(tris[t], mn, mx);
+            for (int a = 0; a < 3; a++) { nd.mn[a] = std::min(nd.mn[a], mn[a]); nd.mx[a] = std::max(nd.mx[a], mx[a]); }
+        }
+        return;
+    }
+    fit_bounds(tris, bn, nd.left); fit_bounds(tris, bn, nd.right);
+    for (int a = 0; a < 3; a++) { bn[i].mn[a] = std::min(bn[bn[i].left].mn[a], bn[bn[i].right].mn[a]); bn[i].mx[a] = std::max(bn[bn[i].left].mx[a], bn[bn[i].right].mx[a]); }
 }
 
 using Key = std::tuple<int64_t, int64_t, int64_t>;
@@ -57,7 +169,7 @@ Key qkey(float x, float y, float z) {
 }
 }  // namespace
 
-HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris) {
     HostMesh m;
     m.tris.resize(n_tris);
     for (int i = 0; i < n_tris; i++) {
@@ -193,14 +305,36 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         for (int a = 0; a < 3; a++) { memcpy(&m.grid[GRID_WORDS + BP_WORDS + a], &lo[a], 4); memcpy(&m.grid[GRID_WORDS + BP_WORDS + 3 + a], &hi[a], 4); }
     }
     if (n_tris == 0) return m;
+    // The tree: per mesh object the reference's own (see build_part), the objects joined pairwise in file order above them; triangles are
+    // stored in the reference's visiting order, so "ascending first-triangle index" IS that order for any set of leaves.
     std::vector<BuildNode> bn;
-    bn.reserve(2 * n_tris);
-    build_rec(m.tris, bn, 0, n_tris);
+    bn.reserve(2 * n_tris + 64);
+    int root;
+    {
+        std::vector<MeshTri> ordered; ordered.reserve(n_tris);
+        std::vector<int> src_of; src_of.reserve(n_tris);
+        std::vector<int> part_n;
+        if (part_tris && !part_tris->empty()) { int sum = 0; for (int c : *part_tris) { if (c > 0) part_n.push_back(c); sum += c; } if (sum != n_tris) part_n.assign(1, n_tris); }
+        else part_n.assign(1, n_tris);
+        std::vector<int> roots;
+        int t0 = 0;
+        for (int c : part_n) { roots.push_back(build_part(m.tris, t0, c, ordered, bn, &src_of)); t0 += c; }
+        while (roots.size() > 1) {
+            std::vector<int> up;
+            for (size_t i = 0; i + 1 < roots.size(); i += 2) { BuildNode j; j.left = roots[i]; j.right = roots[i + 1]; up.push_back((int)bn.size()); bn.push_back(j); }
+            if (roots.size() & 1) up.push_back(roots.back());
+            roots.swap(up);
+        }
+        root = roots[0];
+        m.tris.swap(ordered);
+        m.source_tri.assign(src_of.begin(), src_of.end());
+        fit_bounds(m.tris, bn, root);
+    }
     // breadth-first renumbering with sibling pairs adjacent
     std::vector<int> order; order.reserve(bn.size());
     std::vector<int> newidx(bn.size(), -1);
-    std::queue<int> q; q.push(0);
-    order.push_back(0); newidx[0] = 0;
+    std::queue<int> q; q.push(root);
+    order.push_back(root); newidx[root] = 0;
     while (!q.empty()) {
         int i = q.front(); q.pop();
         if (bn[i].count == 0) {
@@ -217,8 +351,8 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         if (b.count > 0) { n.left_or_first = b.first; n.count_escape = (uint32_t)b.count; }
         else { n.left_or_first = newidx[b.left]; n.count_escape = 0; }
     }
-    // thread the tree for a right-child-first walk: after the right subtree comes the left sibling, after the left subtree
-    // whatever follows the parent
+    // thread the tree for the stackless depth-first walk, left child first (= visiting order): after the left subtree comes the right
+    // sibling, after the right subtree whatever follows the parent
     {
         std::vector<std::pair<int, uint32_t>> todo; todo.push_back({0, BVH_END});
         while (!todo.empty()) {
@@ -227,8 +361,8 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             n.count_escape = (n.count_escape & 0xffu) | (esc << 8);
             if ((n.count_escape & 0xffu) == 0) {
                 int left = n.left_or_first;
-                todo.push_back({left + 1, (uint32_t)left});
-                todo.push_back({left, esc});
+                todo.push_back({left, (uint32_t)(left + 1)});
+                todo.push_back({left + 1, esc});
             }
         }
     }

@@ -3,8 +3,10 @@
 //
 // The reference shares one quantized btBvhTriangleMeshShape per .cmf file between all arenas
 // (RocketSim.cpp:149-167, Arena.cpp:1054-1057).  Here all meshes are merged into one triangle soup with one
-// binary AABB tree in breadth-first order, so the first n nodes (the top levels) are contiguous and can be
-// staged in LDS by the stepper kernel; only the SET of triangles a query reports matters.
+// binary AABB tree laid out breadth-first, so the first n nodes (the top levels) are contiguous and can be
+// staged in LDS by the stepper kernel.  The SET of triangles a query reports and the ORDER they are collided in
+// are the reference's: per mesh object the tree is btOptimizedBvh's own (arena_mesh.cpp:build_part restates its
+// build), cut off at <= 4 triangles per leaf, and the triangles are stored in its visiting order.
 #pragma once
 #include <vector>
 #include <cstdint>
@@ -13,13 +15,14 @@
 namespace rlg {
 
 struct HostMesh {
-    std::vector<MeshTri> tris;   // BT units, in BVH leaf order
+    std::vector<MeshTri> tris;   // BT units, in the reference's visiting order (object by object)
+    std::vector<int32_t> source_tri;   // tris[i] is triangle source_tri[i] of the input
     std::vector<BvhNode> nodes;  // breadth-first
     std::vector<uint32_t> grid;  // GRID_WORDS occupancy bits (arena_types.h)
 };
 
-// verts in uu, tris index triplets
-HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris);
+// verts in uu, tris index triplets; part_tris: triangles per mesh object (.cmf file) in input order, or null = one object
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris = nullptr);
 
 // the procedural soccar arena (uu): back walls with goal mouths, goal boxes, 45-degree corner walls and
 // quarter-cylinder floor fillets.  Geometry facts from RLConst.h:14-16,109, Arena.cpp:846-849, CommonValues.h:9-13.

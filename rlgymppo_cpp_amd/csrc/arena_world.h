@@ -198,7 +198,7 @@ RLG_HD void mesh_query_leaves(MeshView mesh, V3 lo, V3 hi, F&& f) {
         if (aabb_overlap(nd, lo, hi)) {
             const int cnt = node_count(nd);
             if (cnt > 0) f(nd.left_or_first, cnt);
-            else next = (uint32_t)nd.left_or_first + 1u;
+            else next = (uint32_t)nd.left_or_first;   // left child first: leaves come out in ascending first-triangle order = the reference's visiting order
         }
         i = next;
     }
@@ -260,48 +260,19 @@ RLG_HD bool body_query_box(const Arena<NC>& A, int body, bool ball_asleep, V3& l
     return true;
 }
 
-// Breadth-first walk: every BVH leaf whose box overlaps [lo,hi], level by level, within a level in frontier order.
-// The device runs the same walk with one lane per frontier node (rlgpu_env.hip:build_candidates_wave) and must produce
-// the same sequence, overflow included.
-template <class F>
-RLG_HD void mesh_query_leaves_bfs(MeshView mesh, V3 lo, V3 hi, uint32_t (&fr)[2][FRONTIER_CAP], int& overflow, F&& leaf) {
-    if (!mesh_maybe_near(mesh, lo, hi)) return;
-    int n = 1, cur = 0;
-    fr[0][0] = 0;
-    while (n > 0) {
-        int m = 0;
-        for (int j = 0; j < n; j++) {
-            BvhNode nd = mesh_node(mesh, (int)fr[cur][j]);
-            if (!aabb_overlap(nd, lo, hi)) continue;
-            const int cnt = node_count(nd);
-            if (cnt > 0) leaf(nd.left_or_first, cnt);
-            else {
-                if (m + 2 > FRONTIER_CAP) { overflow = 1; return; }
-                fr[cur ^ 1][m++] = (uint32_t)nd.left_or_first; fr[cur ^ 1][m++] = (uint32_t)(nd.left_or_first + 1);
-            }
-        }
-        n = m; cur ^= 1;
-    }
-}
-
-// every mesh triangle whose AABB overlaps [lo,hi] (TestTriangleAgainstAabb2, btConvexConcaveCollisionAlgorithm.cpp:75), for
-// the inline narrowphase (queue overflow fallback).  Same breadth-first order as the candidate queue, so falling back
-// changes nothing but speed; only a walk that overflows the frontier itself uses the depth-first order.
+// every mesh triangle whose AABB overlaps [lo,hi] (TestTriangleAgainstAabb2, btConvexConcaveCollisionAlgorithm.cpp:75), in the reference's
+// visiting order, for the inline narrowphase (queue overflow fallback): falling back changes nothing but speed.
 template <class F>
 RLG_HD void mesh_query(MeshView mesh, V3 lo, V3 hi, F&& f) {
-    auto per_leaf = [&](int first, int cnt) {
+    mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) {
         for (int k = 0; k < cnt; k++)
             if (tri_aabb_overlap(mesh.tris[first + k], lo, hi)) f(first + k);
-    };
-    uint32_t fr[2][FRONTIER_CAP];
-    int overflow = mesh.n_nodes > 65535 ? 1 : 0;
-    if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, [](int, int) {});   // dry run: does the frontier fit?
-    if (!overflow) mesh_query_leaves_bfs(mesh, lo, hi, fr, overflow, per_leaf);
-    else mesh_query_leaves(mesh, lo, hi, per_leaf);
+    });
 }
 
-// all candidates of one env for this tick (host form; called before the wheel rays).  The device walks all bodies of an env in
-// ONE breadth-first pass (rlgpu_env.hip:build_candidates_wave); per body that yields the same sequence as the walk below.
+// all candidates of one env for this tick (host form; called before the wheel rays): per body the overlapping leaves in ascending
+// first-triangle order, which is the reference's visiting order (arena_mesh.cpp).  The device walks all bodies of an env in ONE
+// breadth-first pass, keeps the leaves over several ticks and sorts them (rlgpu_env.hip:build_candidates_wave): same sequence per body.
 template <int NC>
 RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool ball_asleep, CollideQueue<NC>& Q) {
     Q.n_items = 0; Q.n_pool = 0; Q.overflow = 0; Q.n_pairs = 0;
@@ -310,7 +281,7 @@ RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool bal
         Q.cand_count[body] = 0;
         V3 lo, hi;
         if (Q.overflow || !body_query_box(A, body, ball_asleep, lo, hi)) continue;
-        mesh_query_leaves_bfs(mesh, lo, hi, Q.frontier, Q.overflow, [&](int first, int cnt) { queue_candidates(Q, body, first, cnt); });
+        mesh_query_leaves(mesh, lo, hi, [&](int first, int cnt) { queue_candidates(Q, body, first, cnt); });
     }
     for (int ci = 0; ci < NC; ci++)
         for (int ib = ci + 1; ib < NC; ib++)
@@ -448,7 +419,7 @@ RLG_HD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
                     const MeshTri& t = mesh.tris[nd.left_or_first + k];
                     ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
                 }
-            } else next = (uint32_t)nd.left_or_first + 1u;
+            } else next = (uint32_t)nd.left_or_first;   // left child first: leaves come out in ascending first-triangle order = the reference's visiting order
         }
         i = next;
     }

@@ -34,11 +34,28 @@ __device__ int g_dbg[64];
 #endif
 #define RLG_ITEM_DONE(type, n, cyc) do { atomicAdd(&g_dbg[16 + 4 * (type)], 1); if ((n) > 0) atomicAdd(&g_dbg[17 + 4 * (type)], 1); atomicAdd(&g_dbg[18 + 4 * (type)], (int)((cyc) >> 6)); atomicMax(&g_dbg[19 + 4 * (type)], (int)(cyc)); } while (0)
 __shared__ unsigned long long g_prof_last;
+#ifdef RLG_FINE_PROF   // (-DRLG_FINE_PROF: one bucket per phase of arena_tick_wave instead of the coarse ones; tools/fine_prof.py reads the sums from g_dbg)
+__shared__ unsigned long long g_fine[32];
+#define RLG_PROF(i) ((void)0)
+#define RLG_FPROF(i)                                                             \
+    do {                                                                         \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
+        if (threadIdx.x == 0) { g_fine[i] += _t - g_prof_last; g_prof_last = _t; } \
+    } while (0)
+#undef RLG_ITEM_DONE
+#define RLG_ITEM_DONE(type, n, cyc) ((void)0)
+#undef RLG_DBG_COUNT
+#define RLG_DBG_COUNT(i) ((void)0)
+#else
 #define RLG_PROF(i)                                                              \
     do {                                                                         \
         unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
         if (threadIdx.x == 0) { g_prof[i] += _t - g_prof_last; g_prof_last = _t; } \
     } while (0)
+#endif
+#endif
+#ifndef RLG_FPROF
+#define RLG_FPROF(i) ((void)0)
 #endif
 #ifndef RLG_DBG_COUNT
 // Product build: the narrowphase's queue overflows are counted (they are rare -- 1.8 per million env-ticks while a policy learns -- and each
@@ -108,7 +125,7 @@ template <int NC>
 struct CandCache {
     static constexpr int NB = NC + 1;
     V3 lo[NB], hi[NB];                    // the fat boxes the lists were walked for
-    uint32_t leaf[NB][CACHE_LEAVES];      // first triangle | count << 24, in walk order
+    uint32_t leaf[NB][CACHE_LEAVES];      // first triangle | count << 24, ascending (= the reference's visiting order)
     uint8_t n[NB];                        // leaves of body b
     uint8_t active;                       // bit b: body b had a query box then
     uint8_t valid;                        // 0: walk again (cleared when a launch loads the env)
@@ -321,6 +338,32 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
             cur ^= 1;
         }
         wave_sync();
+        // the leaves came level by level; the narrowphase wants them in the reference's visiting order = ascending first triangle
+        // (arena_mesh.cpp): every lane ranks its leaves among the body's, then all are written back in place
+        if (__any(go && !overflow)) {
+            constexpr int PER = (CACHE_LEAVES + LPE - 1) / LPE;
+            uint32_t mine[NB][PER]; int rank[NB][PER];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int nl = (go && !overflow) ? cnt_b[b] : 0;
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    const int k = li + r * LPE;
+                    mine[b][r] = 0; rank[b][r] = -1;
+                    if (k < nl) {
+                        const uint32_t v = C.leaf[b][k]; const uint32_t f = v & 0xFFFFFFu;
+                        int below_me = 0;
+                        for (int j = 0; j < nl; j++) below_me += ((C.leaf[b][j] & 0xFFFFFFu) < f) ? 1 : 0;
+                        mine[b][r] = v; rank[b][r] = below_me;
+                    }
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int r = 0; r < PER; r++) if (rank[b][r] >= 0) C.leaf[b][rank[b][r]] = mine[b][r];
+        }
         if (go && li == 0) {
 #pragma unroll
             for (int b = 0; b < NB; b++) C.n[b] = (uint8_t)(cnt_b[b] < CACHE_LEAVES ? cnt_b[b] : CACHE_LEAVES);
@@ -358,6 +401,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 template <int NC>
 __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, uint32_t seed, int env0, TickEvents& ev) {
     constexpr int EPW = lanes_per_block<NC>() / WPB;
+    RLG_ASSUME_LDS(*lane_mem);   // (not inlined into the step / collect kernels: without this every access below is a flat_load / flat_store)
     const int tid = threadIdx.x & 63;
     const int e_car = tid / NC, c_car = tid % NC;
     const int e_whl = tid / (4 * NC), c_whl = (tid >> 2) % NC, w_whl = tid & 3;
@@ -370,15 +414,16 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
 
     if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
-    RLG_PROF(0);
+    RLG_PROF(0); RLG_FPROF(0);
     build_candidates_wave<NC>(lane_mem, n_valid, mv);
 #ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
     build_candidates_wave<NC>(lane_mem, n_valid, mv);
 #endif
-    RLG_PROF(1);
+    RLG_PROF(1); RLG_FPROF(1);
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
     if (whl_lane) car_wheel_ray_begin(Sw.A, c_whl, w_whl, Sw.W.ctx[c_whl]);
     wave_sync();
+    RLG_FPROF(2);
     {   // all (env, car, wheel, candidate) pairs of the wavefront as ONE list over the 64 lanes (a car next to a wall has ~100 of
         // them, most cars none)
         int n_of[EPW * NC], total = 0;
@@ -398,8 +443,10 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
+    RLG_FPROF(3);
     if (whl_lane) car_wheel_ray_finish(Sw.A, c_whl, w_whl, mv, Sw.W.Q, Sw.W.ctx[c_whl]);
     wave_sync();
+    RLG_FPROF(4);
     const bool ordered = car_lane && car_needs_ordered_finish(Sc.W.ctx[c_car]);
     if (__ballot(ordered) == 0ull) {
         if (car_lane) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
@@ -410,6 +457,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
+    RLG_FPROF(5);
     constexpr int LPE = WAVE / EPW;           // lanes that serve one env in the pad / candidate / item phases
     const int e_grp = tid / LPE, l_grp = tid % LPE;
     const bool grp_lane = e_grp < n_valid;
@@ -417,6 +465,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (grp_lane) for (int p = l_grp; p < 34; p += LPE) pad_pre_tick(Sg.A.pads[p]);
     if (env_lane) tick_world_begin(Se.A, Se.W, true);
     wave_sync();
+    RLG_FPROF(6);
     {   // narrowphase (arena_step.h): lane per candidate tests + compacts, lane per item runs
         const int e_item = e_grp, l_item = l_grp;
         const bool item_lane = e_item < n_valid;
@@ -442,6 +491,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
         }
         wave_sync();
+        RLG_FPROF(7);
         RLG_PROF(1);   // (the candidate tests count as "candidates", like the walk that listed them)
         {   // items of ALL envs of the wavefront as one list over the 64 lanes: a contact-heavy env borrows its neighbours' lanes
             int n_of[EPW], total = 0;
@@ -461,7 +511,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
         wave_sync();
     }
-    RLG_PROF(2);
+    RLG_PROF(2); RLG_FPROF(8);
     // rest of the world step: contacts (lane per body) | merge + row plan (env) | solver rows (lane per contact) | iterations (env) | integration (lane per body)
     {
         constexpr int NB = NC + 1;
@@ -469,12 +519,16 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         if (e_b < n_valid) { LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_b); solver_body_contacts(Sb.A, mv, Sb.W, b_b, true); }
     }
     wave_sync();
+    RLG_FPROF(9);
     if (env_lane) solver_prepare(Se.A, mv, ev, Se.W, true);
     wave_sync();
+    RLG_FPROF(10);
     if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.W, k);
     wave_sync();
+    RLG_FPROF(11);
     if (env_lane) solver_iterate(Se.W);
     wave_sync();
+    RLG_FPROF(12);
     {
         constexpr int NB = NC + 1;
         const int e_b = tid / NB, b_b = tid % NB;
@@ -482,10 +536,13 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     }
     RLG_PROF(5);
     wave_sync();
+    RLG_FPROF(13);
     if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, c_car); }
     wave_sync();
+    RLG_FPROF(14);
     if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
     wave_sync();
+    RLG_FPROF(15);
     {   // pads that hand out boost are rare: they go through the env lane in pad order, all the others finish in parallel
         bool gives = false;
         if (grp_lane) for (int p = l_grp; p < 34; p += LPE) { if (pad_gives_boost(Sg.A.pads[p])) gives = true; else pad_post_tick(Sg.A, p); }
@@ -495,8 +552,10 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
+    RLG_FPROF(16);
     if (env_lane) tick_finish(Se.A, true);
     wave_sync();
+    RLG_FPROF(17);
 }
 
 // per-step player statistics of the step's GameState (what the example program's step callback averages: examplemain.cpp:23-36), kept
@@ -704,10 +763,16 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
+#ifdef RLG_FINE_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 32; i++) g_fine[i] = 0;
+#endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+#ifdef RLG_FINE_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 32; i++) atomicAdd(&g_dbg[i], (int)(g_fine[i] >> 10));   // summed over workgroups, cycles / 1024
+#endif
     if (stamps && threadIdx.x == 0) {
         unsigned long long* o = stamps + 10 * (size_t)blockIdx.x;  // wave 0 of the workgroup reports
         o[0] = c1 - c0; o[1] = r1 - r0;
@@ -866,9 +931,17 @@ int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * (e->d.cfg.one_
 int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }
 
-int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris) {
-    HIPCHK(e, hipSetDevice(e->device));
+static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts);
+int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris) { return env_set_mesh_parts(e, verts, n_verts, tris, n_tris, nullptr); }
+int rlgpu_mesh_visit_order(const float* verts, int n_verts, const int32_t* tris, int n_tris, int32_t* order_out) {
+    if (!verts || !tris || !order_out || n_tris < 0) return RLGPU_ERR_ARG;
     HostMesh m = build_host_mesh(verts, n_verts, tris, n_tris);
+    for (int i = 0; i < n_tris; i++) order_out[i] = m.source_tri[i];
+    return RLGPU_OK;
+}
+static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HostMesh m = build_host_mesh(verts, n_verts, tris, n_tris, parts);
     if (e->d_nodes) { (void)hipFree(e->d_nodes); e->d_nodes = nullptr; }
     if (e->d_tris) { (void)hipFree(e->d_tris); e->d_tris = nullptr; }
     e->d.n_nodes = (int)m.nodes.size(); e->d.n_tris = (int)m.tris.size();
@@ -900,12 +973,15 @@ int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* dir) {
     std::sort(files.begin(), files.end());
     if (files.empty()) { e->err = std::string("no .cmf files in ") + dir; return RLGPU_ERR_ARG; }
     std::vector<float> v; std::vector<int32_t> t;
+    std::vector<int> parts;   // one mesh object per file, as in the reference (RocketSim.cpp:149-167): each keeps its own triangle order
     for (auto& f : files) {
         std::ifstream in(f, std::ios::binary);
         std::vector<uint8_t> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        const size_t before = t.size() / 3;
         if (!append_cmf(buf.data(), buf.size(), v, t)) { e->err = "bad cmf file " + f; return RLGPU_ERR_ARG; }
+        parts.push_back((int)(t.size() / 3 - before));
     }
-    return rlgpu_env_set_mesh(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3);
+    return env_set_mesh_parts(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3, &parts);
 }
 
 #define DISPATCH_NC(e, KERNEL, grid, block, ...)                                                             \

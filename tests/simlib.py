@@ -204,7 +204,9 @@ def _tol(pos, vel, ang, rot, until=None):
 # deviations (tools/diff_ref_port.py) are 3-10x below these.  fp32 bit-exactness with the reference is not attainable (Bullet on x86
 # runs SSE code paths; the device has its own libm), so trajectories that pass through a contact decision at the contact threshold
 # leave the reference eventually: the four tapes with `until` do so after the given tick (one-tick agreement still holds, see
-# ONE_TICK_TOL) -- car_into_goal: two mesh triangles touched at once are visited in this repo's BVH order, not Bullet's;
+# ONE_TICK_TOL) -- car_into_goal: at tick 163 a hitbox edge meets a goal-post edge and GJK's answer for that near-degenerate pair ends
+# 4e-4 apart in the normal, at tick 166 a contact 12 uu deep goes through the reference's EPA (triangles are visited in the reference's
+# own order since round 2: arena_mesh.cpp restates btOptimizedBvh's build, checked against the reference in test_oracle_golden.py);
 # car_into_side_wall: a contact at the 2 uu threshold appears one tick apart; demo_and_respawn: the attacker hits the back wall 10 uu
 # deep (the reference's EPA vs the minimum-translation axis here); 3v3_kickoff: six cars in one heap (pair order in the reference's
 # broadphase cell lists is history dependent).
@@ -225,7 +227,7 @@ PHYS_FREE_RUN = {
 ONE_TICK_TOL = {
     "default": {"pos": 0.1, "vel": 0.15},                               # pos: a mesh contact deeper than the hitbox margin is pushed out along the
                                                                         # minimum-translation axis here, along EPA's answer in the reference (<= 0.06 uu apart in the fixtures)
-    "car_into_goal": {"pos": 0.5, "vel": 50.0},                         # ticks 163-189: triangle visiting order (above)
+    "car_into_goal": {"pos": 0.1, "vel": 1.0},                          # ticks 163, 166-168: GJK on a near-degenerate edge pair / a 12 uu deep contact (EPA), 0.77 uu/s at most
     "demo_and_respawn": {"pos": 0.02, "vel": 1.0},                      # ticks 587-591: deep wall hit, EPA
     "car_into_side_wall": {"pos": 0.1, "vel": 0.15},                    # tick 298: the same (push-out of a deep mesh contact)
     "3v3_kickoff": {"pos": 0.5, "vel": 50.0, "flags_loose": True},      # ticks 300-355: the six-car heap, wheels standing on hitboxes

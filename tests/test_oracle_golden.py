@@ -283,6 +283,29 @@ def test_host_helpers_without_gpu():
     assert np.array_equal(action_table(), g["action_table"])
 
 
+def test_mesh_triangle_visiting_order_is_the_references(port_lib):
+    """The order in which a body meets the mesh triangles (it decides the order of a manifold's points) is the reference's:
+    btOptimizedBvh::build + the subtree-header walk (btQuantizedBvh.cpp:116-277,655-674), restated in csrc/arena_mesh.cpp:build_part.
+    Golden: tests/golden/mesh_order_golden.npz, recorded from the real reference (make_mesh_order_golden.py) for the procedural arena
+    and for a 1500-triangle clustered soup; checked on the host port's mesh and through the product library's C-ABI helper."""
+    from rlgymppo_cpp_amd import _lib
+    lib = _lib.load()
+    g = np.load(os.path.join(GOLD, "mesh_order_golden.npz"))
+    pv, pt = port_lib.procedural_mesh()
+    for name, (v, t) in {"procedural": (pv, pt), "soup": (g["soup/verts"], g["soup/tris"])}.items():
+        v = np.ascontiguousarray(v, np.float32); t = np.ascontiguousarray(t, np.int32)
+        want = g[f"{name}/order"]
+        port_lib.set_mesh(v, t)
+        got = np.zeros(len(t), np.int32)
+        port_lib.lib.port_mesh_visit_order.argtypes = [C.c_void_p, C.c_int]
+        assert port_lib.lib.port_mesh_visit_order(got.ctypes.data_as(C.c_void_p), len(t)) == len(t)
+        assert np.array_equal(got, want), f"{name}: host port visits triangles in another order than the reference"
+        got2 = np.zeros(len(t), np.int32)
+        assert lib.rlgpu_mesh_visit_order(v.ctypes.data_as(C.c_void_p), len(v), t.ctypes.data_as(C.c_void_p), len(t), got2.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(got2, want), f"{name}: librlgpu.so visits triangles in another order than the reference"
+    port_lib.set_mesh(pv, pt)   # (the module's other tests use the procedural arena)
+
+
 def test_padded_obs_is_a_block_shuffle_of_default_obs(port_lib):
     """DefaultOBSPadded(maxPlayers = team size) (DefaultOBSPadded.cpp:3-66) on the host port: ball / prev-action / pads / self parts
     equal DefaultOBS; the teammate blocks and the opponent blocks are the same 19-float blocks in a permuted order, and over

@@ -1,0 +1,52 @@
+"""Per-phase cycles of arena_tick_wave, one bucket per phase (needs a build with -DRLG_TICK_PROFILE -DRLG_FINE_PROF:
+   make -C rlgymppo_cpp_amd/csrc prof EXTRA=-DRLG_FINE_PROF, loaded through RLGPU_LIB).  Sums over all workgroups; printed per workgroup and tick."""
+import os, sys, ctypes as C
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rlgymppo_cpp_amd.env import BatchedEnv
+from rlgymppo_cpp_amd.state import default_arena
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+ticks, reps = 8, 4
+env = BatchedEnv(n, 1)
+fn = env.lib.rlgpu_env_debug_tick_cycles
+fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]; fn.restype = C.c_int
+env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
+NAMES = ["car_tick_begin", "build_candidates", "wheel_ray_begin", "ray pairs", "wheel_ray_finish", "car_pre_tick_finish", "pads + world_begin",
+         "candidate tests", "items", "body contacts", "solver_prepare", "solver_rows", "solver_iterate", "solver_finish", "car post + pad check",
+         "pads_lock", "pad post", "tick_finish"]
+
+
+def ints():
+    buf = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints(env.h, buf); return np.array(buf[:32], dtype=np.int64)
+
+
+def run(label):
+    buf = np.zeros(10 * 65536, dtype=np.uint64); nb = C.c_int()
+    fn(env.h, ticks, buf.ctypes.data, 65536, C.byref(nb))   # warm
+    a = ints()
+    tot = np.zeros(0)
+    for _ in range(reps):
+        assert fn(env.h, ticks, buf.ctypes.data, 65536, C.byref(nb)) == 0
+        tot = np.concatenate([tot, buf[: 10 * nb.value].reshape(-1, 10)[:, 0].astype(np.float64)])
+    d = (ints() - a) * 1024.0 / (reps * ticks * nb.value)
+    print(f"{label}: cycles/tick mean {tot.mean()/ticks:.0f} max {tot.max()/ticks:.0f}; buckets sum {d.sum():.0f}")
+    for nm, v in zip(NAMES, d):
+        print(f"   {nm:24s} {v:8.0f}  {100*v/d.sum():5.1f} %")
+
+
+s = default_arena(2)
+env.upload_states([s] * n)
+run("rest")
+obs = env.reset(True)
+dev = torch.device("cuda", 0)
+nobs = torch.empty_like(obs); rew = torch.empty(env.n_agents, device=dev); done = torch.empty(env.n_agents, dtype=torch.int32, device=dev)
+g = torch.Generator().manual_seed(0)
+for t in range(warm):
+    a = torch.randint(0, 90, (env.n_agents,), generator=g, dtype=torch.int32).to(dev)
+    env.step(a, nobs, rew, done)
+env.sync()
+run("random-rollout")
