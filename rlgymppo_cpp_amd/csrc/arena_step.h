@@ -862,17 +862,72 @@ RLG_HD V3 pad_pos(int i) {
     return v3(SM[i - 6][0], SM[i - 6][1], 70.f);
 }
 
+// BoostPadGrid::pads[8][10]: one pad per cell (BoostPadGrid.cpp:27-41); cell = (int)(pos / 1024 + half)
+RLG_HD int pad_of_cell(int cell) {
+    const int8_t CELL_PAD[80] = {-1, -1, 12, -1, -1, 0, -1, 26, -1, -1, -1, 4, -1, -1, -1, -1, -1, -1, -1, 2, 7, -1, 14, 16, -1, -1, 21, 24, -1, 31,
+        -1, 9, -1, -1, -1, 19, -1, -1, 29, -1, 6, 10, 11, -1, 17, -1, 22, 28, 30, 33, 8, -1, 15, -1, -1, 20, -1, 25, -1, 32,
+        -1, -1, -1, 18, -1, -1, 23, -1, -1, -1, -1, 5, 13, -1, -1, 1, -1, 27, -1, 3};
+    return CELL_PAD[cell];
+}
+// the lookup words of MeshView::pad_tab (filled once on the host; staged in LDS by the kernels).  A car whose position falls into cell
+// (ix, iy) is tested against the pads of the 3 x 3 cells around it (BoostPadGrid.cpp:5-25); of those only a pad within 300 uu of the
+// cell's own extent can pass either test (cylinder radius <= 208 uu about the car's origin; locked-pad box half width <= 160 uu against
+// the car's box, which reaches <= 89 uu from its origin), so the others are left out: at most three remain.
+inline void pad_table_fill(uint32_t* out) {
+    for (int p = 0; p < 34; p++) { V3 pp = pad_pos(p); out[p] = (uint32_t)((int)pp.x + 8192) | ((uint32_t)((int)pp.y + 8192) << 16); }
+    const float REACH = 300.f;
+    for (int ix = 0; ix < 8; ix++) for (int iy = 0; iy < 10; iy++) {
+        // positions that truncate to this cell: (int)(x / 1024 + 4) == ix  (cell 0 also takes the values in (-1, 0))
+        const float x0 = (float)((ix == 0 ? -1 : ix) - 4) * 1024.f, x1 = (float)(ix + 1 - 4) * 1024.f;
+        const float y0 = (float)((iy == 0 ? -1 : iy) - 5) * 1024.f, y1 = (float)(iy + 1 - 5) * 1024.f;
+        uint32_t w = 0; int n = 0;
+        for (int cx = ix - 1; cx <= ix + 1; cx++) for (int cy = iy - 1; cy <= iy + 1; cy++) {   // same cell order as the reference's loops
+            if (cx < 0 || cx > 7 || cy < 0 || cy > 9) continue;
+            const int p = pad_of_cell(cx * 10 + cy);
+            if (p < 0) continue;
+            const V3 pp = pad_pos(p);
+            if (pp.x < x0 - REACH || pp.x > x1 + REACH || pp.y < y0 - REACH || pp.y > y1 + REACH) continue;
+            if (n < 3) w |= (uint32_t)(p + 1) << (8 * n);
+            n++;
+        }
+        out[34 + ix * 10 + iy] = n <= 3 ? w : 0xFFFFFFFFu;   // (never more than three with the soccar layout; 0xFFFFFFFF = use the plain loops)
+    }
+}
+
+// one pad against one car: BoostPad::CheckCollide (BoostPad.cpp:51-81) -- the cylinder about the car's origin, or for the car that holds
+// the pad's lock the pad's box against the car's box
+RLG_HD bool pad_touches_car(int p, V3 pad_uu, bool locked_by_car, V3 car_pos, V3 cmin, V3 cmax) {
+    const bool big = p < 6;
+    V3 pbt = pad_uu * UU2BT;
+    if (locked_by_car) {
+        float br = (big ? K::PAD_BOX_RAD_BIG : K::PAD_BOX_RAD_SMALL) * UU2BT;
+        V3 bmin = pbt - v3(br, br, 0), bmax = pbt + v3(br, br, K::PAD_BOX_HEIGHT * UU2BT);
+        return (bmax.x > cmin.x && bmax.y > cmin.y && bmax.z > cmin.z) && (bmin.x < cmax.x && bmin.y < cmax.y && bmin.z < cmax.z);
+    }
+    float rad = (big ? K::PAD_CYL_RAD_BIG : K::PAD_CYL_RAD_SMALL) * UU2BT;
+    float dx = car_pos.x - pbt.x, dy = car_pos.y - pbt.y;
+    if (dx * dx + dy * dy < rad * rad) return fabsf(car_pos.z - pbt.z) < (K::PAD_CYL_HEIGHT * UU2BT);
+    return false;
+}
+
 // which pads does car `ci` touch (bit p)?  Reads the pads' prev_locked only, so cars can be checked in any order; the
 // caller then sets cur_locked in car order (a later car overrides an earlier one, as the reference's loop does).
+// (The cell tables used to sit in constant memory behind computed indices: up to 9 + 4 dependent ~400-cycle loads, 8 % of a tick.)
 template <int NC>
-RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, int ci) {
+RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, const uint32_t* tab, int ci) {
     RLG_ASSUME_LDS(A);
+#if defined(__HIP_DEVICE_COMPILE__)
+    RLG_ASSUME_LDS(*tab);
+#endif
     const Car& car = A.cars[ci];
     uint64_t mask = 0;
     if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return mask;
     V3 cp = car.b.pos * BT2UU;
     if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return mask;
     int ix = (int)(cp.x / 1024 + 4), iy = (int)(cp.y / 1024 + 5);
+    const bool in_grid = ix >= 0 && ix <= 7 && iy >= 0 && iy <= 9;
+    const uint32_t near_pads = in_grid ? tab[34 + ix * 10 + iy] : 0xFFFFFFFFu;
+    if (near_pads == 0u) return mask;
     // car AABB (btCompoundShape::getAabb): centre + |R| * half extents
     V3 h = hitbox_half();
     V3 bc = car.b.pos + car.b.rot * hitbox_off();
@@ -880,28 +935,22 @@ RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, int ci) {
                 h.x * fabsf(car.b.rot.r1.x) + h.y * fabsf(car.b.rot.r1.y) + h.z * fabsf(car.b.rot.r1.z),
                 h.x * fabsf(car.b.rot.r2.x) + h.y * fabsf(car.b.rot.r2.y) + h.z * fabsf(car.b.rot.r2.z));
     V3 cmin = bc - ext, cmax = bc + ext;
-    // BoostPadGrid::pads[8][10]: one pad per cell (BoostPadGrid.cpp:27-41); cell = (int)(pos / 1024 + half)
-    const int8_t CELL_PAD[80] = {-1, -1, 12, -1, -1, 0, -1, 26, -1, -1, -1, 4, -1, -1, -1, -1, -1, -1, -1, 2, 7, -1, 14, 16, -1, -1, 21, 24, -1, 31,
-        -1, 9, -1, -1, -1, 19, -1, -1, 29, -1, 6, 10, 11, -1, 17, -1, 22, 28, 30, 33, 8, -1, 15, -1, -1, 20, -1, 25, -1, 32,
-        -1, -1, -1, 18, -1, -1, 23, -1, -1, -1, -1, 5, 13, -1, -1, 1, -1, 27, -1, 3};
+    if (near_pads != 0xFFFFFFFFu) {
+        RLG_NOUNROLL
+        for (uint32_t w = near_pads; w != 0u; w >>= 8) {
+            const int p = (int)(w & 0xffu) - 1;
+            const uint32_t word = tab[p];
+            const V3 pp = v3((float)((int)(word & 0xffffu) - 8192), (float)((int)(word >> 16) - 8192), p < 6 ? 73.f : 70.f);
+            if (pad_touches_car(p, pp, A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
+        }
+        return mask;
+    }
+    // a car outside the pad grid (never in play), or a pad layout with a crowded cell: the reference's loops as they stand
     int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
     for (int cx = lox; cx <= hix; cx++) for (int cy = loy; cy <= hiy; cy++) {
-        int p = CELL_PAD[cx * 10 + cy];
+        int p = pad_of_cell(cx * 10 + cy);
         if (p < 0) continue;
-        V3 pp = pad_pos(p);
-        bool big = p < 6;
-        V3 pbt = pp * UU2BT;
-        bool colliding = false;
-        if (A.pads[p].prev_locked == ci + 1) {
-            float br = (big ? K::PAD_BOX_RAD_BIG : K::PAD_BOX_RAD_SMALL) * UU2BT;
-            V3 bmin = pbt - v3(br, br, 0), bmax = pbt + v3(br, br, K::PAD_BOX_HEIGHT * UU2BT);
-            colliding = (bmax.x > cmin.x && bmax.y > cmin.y && bmax.z > cmin.z) && (bmin.x < cmax.x && bmin.y < cmax.y && bmin.z < cmax.z);
-        } else {
-            float rad = (big ? K::PAD_CYL_RAD_BIG : K::PAD_CYL_RAD_SMALL) * UU2BT;
-            float dx = car.b.pos.x - pbt.x, dy = car.b.pos.y - pbt.y;
-            if (dx * dx + dy * dy < rad * rad) colliding = fabsf(car.b.pos.z - pbt.z) < (K::PAD_CYL_HEIGHT * UU2BT);
-        }
-        if (colliding) mask |= (1ull << p);
+        if (pad_touches_car(p, pad_pos(p), A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
     }
     return mask;
 }
@@ -980,11 +1029,11 @@ RLG_HD_NOINLINE void tick_car_post(Arena<NC>& A, int i) {
 // phase 5, per env: boost pad pickups (in car order), ball finish, tick counter.  `pads_done`: the caller ran
 // pads_check_car / pads_lock / pad_post_tick over lanes already.
 template <int NC>
-RLG_HD_NOINLINE void tick_finish(Arena<NC>& A, bool pads_done) {
+RLG_HD_NOINLINE void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_done) {
     RLG_ASSUME_LDS(A);
     if (!pads_done) {
         RLG_NOUNROLL
-        for (int i = 0; i < NC; i++) pads_lock(A, i, pads_check_car(A, i));
+        for (int i = 0; i < NC; i++) pads_lock(A, i, pads_check_car(A, pad_tab, i));
         for (int p = 0; p < 34; p++) pad_post_tick(A, p);
     }
     {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
@@ -1019,7 +1068,7 @@ RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_
     collide_compact_and_run(A, mesh, W.Q);
     world_step_finish(A, mesh, ev, W, true);
     for (int i = 0; i < NC; i++) tick_car_post(A, i);
-    tick_finish(A, false);
+    tick_finish(A, mesh.pad_tab, false);
 }
 
 }  // namespace rlg

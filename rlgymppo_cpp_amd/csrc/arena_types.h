@@ -223,7 +223,13 @@ constexpr float GRID_CELL = 5.12f;                                  // BT (256 u
 constexpr float GRID_MIN_X = -87.04f, GRID_MIN_Y = -122.88f, GRID_MIN_Z = -5.12f;
 constexpr int GRID_WORDS = (GRID_X * GRID_Y * GRID_Z + 31) / 32;
 
+// boost pad lookup words (arena_step.h:pad_table_fill): per pad (x + 8192) | (y + 8192) << 16 in uu, then per cell of the reference's
+// 8 x 10 pad grid (BoostPadGrid.cpp:27-41) the pads of its 3 x 3 neighbourhood that a car in the cell can reach at all: up to three
+// bytes (pad + 1, 0 = none) per word
+constexpr int PAD_TAB_WORDS = 34 + 80;
+
 struct MeshView {
+    const uint32_t* pad_tab;   // PAD_TAB_WORDS (LDS on the device: a table behind a computed index in constant memory costs a ~500-cycle global load per lookup)
     const BvhNode* nodes;      // global
     const MeshTri* tris;       // global
     const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr

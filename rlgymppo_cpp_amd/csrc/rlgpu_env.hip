@@ -83,7 +83,7 @@ constexpr int WAVE = 64;
 #define RLG_LDS_BUDGET (40 * 1024)
 #endif
 #ifndef RLG_LDS_NODES
-#define RLG_LDS_NODES 144   /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS) */
+#define RLG_LDS_NODES 136   /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B) */
 #endif
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1
@@ -99,6 +99,7 @@ struct EnvDev {
     uint32_t* words;      // [n_words][n_envs]
     const BvhNode* nodes; const MeshTri* tris; int n_nodes, n_tris;
     const uint32_t* grid;
+    const uint32_t* pad_tab;     // PAD_TAB_WORDS boost pad lookup words (arena_step.h:pad_table_fill)
     const float* action_table;
     GymConfig cfg;
     int n_envs;
@@ -139,7 +140,7 @@ constexpr size_t lane_stride() { size_t w = (sizeof(LaneBlock<NC>) + 7) / 8; ret
 template <int NC>
 constexpr int lanes_per_block() {
     int l = 16;
-    while (l > WPB && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + GRID_WORDS * 4 > (size_t)LDS_BUDGET) l /= 2;
+    while (l > WPB && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET) l /= 2;
     return l;
 }
 
@@ -155,8 +156,9 @@ __device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G)
     arena_visit(A, G, w);
 }
 
-__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* lds_grid) {
+__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* lds_grid, uint32_t* lds_pad) {
     if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
+    for (int i = threadIdx.x; i < PAD_TAB_WORDS; i += blockDim.x) lds_pad[i] = d.pad_tab[i];
     int n_fast = d.n_nodes < LDS_NODES ? d.n_nodes : LDS_NODES;
     // 32-byte nodes copied as 2 x 16-byte vectors per lane: coalesced global reads, conflict-free ds_write_b128
     const float4* src = reinterpret_cast<const float4*>(d.nodes);
@@ -165,6 +167,7 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* ld
     __syncthreads();
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
     mv.grid = d.grid ? lds_grid : nullptr;
+    mv.pad_tab = lds_pad;
     mv.bp = d.grid ? d.grid + GRID_WORDS : nullptr;
     return mv;
 }
@@ -537,7 +540,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     RLG_PROF(5);
     wave_sync();
     RLG_FPROF(13);
-    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, c_car); }
+    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, mv.pad_tab, c_car); }
     wave_sync();
     RLG_FPROF(14);
     if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
@@ -553,7 +556,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     }
     wave_sync();
     RLG_FPROF(16);
-    if (env_lane) tick_finish(Se.A, true);
+    if (env_lane) tick_finish(Se.A, mv.pad_tab, true);
     wave_sync();
     RLG_FPROF(17);
 }
@@ -580,7 +583,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);   // every thread of the workgroup helps staging
+    __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);   // every thread of the workgroup helps staging
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     const bool env_lane = ws.lane < n_valid;
@@ -650,7 +654,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
+    __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     if (n_valid == 0) return;
@@ -752,7 +757,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
     __shared__ uint32_t lds_grid[GRID_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid);
+    __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     const bool env_lane = ws.lane < n_valid;
@@ -822,7 +828,7 @@ struct rlgpu_env {
     int device = 0, n_envs = 0, team_size = 1, nc = 2;
     size_t n_words = 0;
     EnvDev d{};
-    BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr;
+    BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -904,6 +910,10 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     HIPCHK(e, hipMalloc(&e->d_actions, sizeof(tab)));
     HIPCHK(e, hipMemcpy(e->d_actions, tab, sizeof(tab), hipMemcpyHostToDevice));
     e->d.action_table = e->d_actions;
+    uint32_t ptab[PAD_TAB_WORDS]; pad_table_fill(ptab);
+    HIPCHK(e, hipMalloc(&e->d_pad_tab, sizeof(ptab)));
+    HIPCHK(e, hipMemcpy(e->d_pad_tab, ptab, sizeof(ptab), hipMemcpyHostToDevice));
+    e->d.pad_tab = e->d_pad_tab;
     memcpy(&e->d.cfg, cfg, sizeof(GymConfig));
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     return RLGPU_OK;
@@ -917,6 +927,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_tris) (void)hipFree(e->d_tris);
     if (e->d_actions) (void)hipFree(e->d_actions);
     if (e->d_grid) (void)hipFree(e->d_grid);
+    if (e->d_pad_tab) (void)hipFree(e->d_pad_tab);
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
     if (e->d.step_stats) (void)hipFree(e->d.step_stats);
