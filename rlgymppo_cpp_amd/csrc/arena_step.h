@@ -140,6 +140,9 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
 #ifdef RLG_ITEM_CLOCK
         const unsigned long long te0_ = RLG_ITEM_CLOCK();
 #endif
+#ifdef RLG_EXPERIMENT_ADJUST_TWICE   // what-if build only: the edge adjustment priced in place (first result unused)
+        { V3 pb2 = c.pb, n2 = c.n; float d2 = c.dist * (1.f + 1e-7f * (float)(t.edge_flags & 1u)); adjust_internal_edge(t, pb2, n2, d2); if (d2 == 1234.5678f) c.dist = 0.f; }
+#endif
         adjust_internal_edge(t, c.pb, c.n, c.dist);
 #ifdef RLG_ITEM_CLOCK
         RLG_SPAN_DONE(12, RLG_ITEM_CLOCK() - te0_);
@@ -149,6 +152,9 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
     if (!deep) return false;
     RLG_DBG_COUNT(9);
     Cand cs[4]; int nc = 0;
+#ifdef RLG_EXPERIMENT_DEEP_TWICE   // what-if build only: the deep-penetration fallback priced in place
+    { Cand c2[4]; int n2 = 0; box_triangle(bc, R, hitbox_core(), t, 1e-7f * (float)(t.edge_flags & 1u), c2, n2); if (n2 == 77) c.dist = 0.f; }
+#endif
     box_triangle(bc, R, hitbox_core(), t, 0.f, cs, nc);
     if (nc == 0) return false;
     int best = 0;

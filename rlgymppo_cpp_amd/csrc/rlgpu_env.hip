@@ -36,6 +36,7 @@ __device__ int g_dbg[64];
 __shared__ unsigned long long g_prof_last;
 #ifdef RLG_FINE_PROF   // (-DRLG_FINE_PROF: one bucket per phase of arena_tick_wave instead of the coarse ones; tools/fine_prof.py reads the sums from g_dbg)
 __shared__ unsigned long long g_fine[32];
+__device__ unsigned int g_fine_blk[4096 * 32];   // the buckets of every workgroup of the last k_env_ticks launch, cycles / 16
 #define RLG_PROF(i) ((void)0)
 #define RLG_FPROF(i)                                                             \
     do {                                                                         \
@@ -778,6 +779,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_FINE_PROF
     if (threadIdx.x == 0) for (int i = 0; i < 32; i++) atomicAdd(&g_dbg[i], (int)(g_fine[i] >> 10));   // summed over workgroups, cycles / 1024
+    if (threadIdx.x == 0 && blockIdx.x < 4096) for (int i = 0; i < 32; i++) g_fine_blk[32 * blockIdx.x + i] = (unsigned int)(g_fine[i] >> 4);
 #endif
     if (stamps && threadIdx.x == 0) {
         unsigned long long* o = stamps + 10 * (size_t)blockIdx.x;  // wave 0 of the workgroup reports
@@ -1189,6 +1191,13 @@ int rlgpu_env_debug_ints(rlgpu_env* e, int* out) {
     HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(int) * 64));
     return RLGPU_OK;
 }
+#ifdef RLG_FINE_PROF
+int rlgpu_env_debug_fine(rlgpu_env* e, unsigned int* out, int n_blocks) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fine_blk), sizeof(unsigned int) * 32 * (size_t)std::min(n_blocks, 4096)));
+    return RLGPU_OK;
+}
+#endif
 // profiler build only: the 12 phase buckets (cycles) of the last k_env_step launch, 16 values per workgroup
 int rlgpu_env_debug_step_prof(rlgpu_env* e, unsigned long long* out, int n_blocks) {
     HIPCHK(e, hipSetDevice(e->device));

@@ -34,8 +34,16 @@ def run(label):
         tot = np.concatenate([tot, buf[: 10 * nb.value].reshape(-1, 10)[:, 0].astype(np.float64)])
     d = (ints() - a) * 1024.0 / (reps * ticks * nb.value)
     print(f"{label}: cycles/tick mean {tot.mean()/ticks:.0f} max {tot.max()/ticks:.0f}; buckets sum {d.sum():.0f}")
-    for nm, v in zip(NAMES, d):
-        print(f"   {nm:24s} {v:8.0f}  {100*v/d.sum():5.1f} %")
+    blk = np.zeros(32 * nb.value, dtype=np.uint32)
+    env.lib.rlgpu_env_debug_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    env.lib.rlgpu_env_debug_fine(env.h, blk.ctypes.data, nb.value)
+    blk = blk.reshape(-1, 32).astype(np.float64) * 16.0 / ticks
+    order = np.argsort(-blk.sum(axis=1))
+    slow = blk[order[: max(1, nb.value // 100)]].mean(axis=0)   # the slowest 1 % of the workgroups of the last launch
+    print(f"   {'phase':24s} {'mean':>8s}  {'share':>7s}  {'slowest 1 %':>12s}")
+    for nm, v, w in zip(NAMES, d, slow):
+        print(f"   {nm:24s} {v:8.0f}  {100*v/d.sum():5.1f} %  {w:12.0f}")
+    print(f"   {'sum':24s} {d.sum():8.0f}           {slow.sum():12.0f}")
 
 
 s = default_arena(2)
