@@ -22,8 +22,7 @@ using namespace rlg;
 namespace {
 HostMesh g_mesh;
 MeshView view() {
-    static const struct PadTab { uint32_t w[PAD_TAB_WORDS]; PadTab() { pad_table_fill(w); } } pad_tab;   // (thread-safe one-time fill)
-    MeshView v; v.pad_tab = pad_tab.w; v.nodes = g_mesh.nodes.data(); v.tris = g_mesh.tris.data(); v.nodes_fast = nullptr;
+    MeshView v; v.nodes = g_mesh.nodes.data(); v.tris = g_mesh.tris.data(); v.nodes_fast = nullptr;
     v.n_nodes = (int)g_mesh.nodes.size(); v.n_tris = (int)g_mesh.tris.size(); v.n_fast = 0;
     v.grid = g_mesh.grid.empty() ? nullptr : g_mesh.grid.data();
     v.bp = g_mesh.grid.size() > (size_t)GRID_WORDS ? g_mesh.grid.data() + GRID_WORDS : nullptr;

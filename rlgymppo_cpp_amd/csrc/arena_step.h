@@ -875,7 +875,9 @@ RLG_HD int pad_of_cell(int cell) {
         -1, -1, -1, 18, -1, -1, 23, -1, -1, -1, -1, 5, 13, -1, -1, 1, -1, 27, -1, 3};
     return CELL_PAD[cell];
 }
-// the lookup words of MeshView::pad_tab (filled once on the host; staged in LDS by the kernels).  A car whose position falls into cell
+// the boost pad lookup words (PAD_TAB_WORDS; filled once on the host, staged in LDS by the kernels -- a table behind a computed index
+// in constant memory costs a ~400-cycle global load per lookup; handed to the tick as a pointer of its own: one more member in MeshView
+// pushes that by-value argument onto the stack at every call).  A car whose position falls into cell
 // (ix, iy) is tested against the pads of the 3 x 3 cells around it (BoostPadGrid.cpp:5-25); of those only a pad within 300 uu of the
 // cell's own extent can pass either test (cylinder radius <= 208 uu about the car's origin; locked-pad box half width <= 160 uu against
 // the car's box, which reaches <= 89 uu from its origin), so the others are left out: at most three remain.
@@ -900,6 +902,15 @@ inline void pad_table_fill(uint32_t* out) {
     }
 }
 
+RLG_HD const uint32_t* pad_table_default() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return nullptr;
+#else
+    static const struct PadTab { uint32_t w[PAD_TAB_WORDS]; PadTab() { pad_table_fill(w); } } t;   // (thread-safe one-time fill)
+    return t.w;
+#endif
+}
+
 // one pad against one car: BoostPad::CheckCollide (BoostPad.cpp:51-81) -- the cylinder about the car's origin, or for the car that holds
 // the pad's lock the pad's box against the car's box
 RLG_HD bool pad_touches_car(int p, V3 pad_uu, bool locked_by_car, V3 car_pos, V3 cmin, V3 cmax) {
@@ -919,44 +930,53 @@ RLG_HD bool pad_touches_car(int p, V3 pad_uu, bool locked_by_car, V3 car_pos, V3
 // which pads does car `ci` touch (bit p)?  Reads the pads' prev_locked only, so cars can be checked in any order; the
 // caller then sets cur_locked in car order (a later car overrides an earlier one, as the reference's loop does).
 // (The cell tables used to sit in constant memory behind computed indices: up to 9 + 4 dependent ~400-cycle loads, 8 % of a tick.)
+// car box for the locked-pad test (btCompoundShape::getAabb: centre + |R| * half extents)
+RLG_HD void pad_car_box(const Car& car, V3& cmin, V3& cmax) {
+    V3 h = hitbox_half();
+    V3 bc = car.b.pos + car.b.rot * hitbox_off();
+    V3 ext = v3(h.x * fabsf(car.b.rot.r0.x) + h.y * fabsf(car.b.rot.r0.y) + h.z * fabsf(car.b.rot.r0.z),
+                h.x * fabsf(car.b.rot.r1.x) + h.y * fabsf(car.b.rot.r1.y) + h.z * fabsf(car.b.rot.r1.z),
+                h.x * fabsf(car.b.rot.r2.x) + h.y * fabsf(car.b.rot.r2.y) + h.z * fabsf(car.b.rot.r2.z));
+    cmin = bc - ext; cmax = bc + ext;
+}
+// the reference's loops as they stand (BoostPadGrid.cpp:5-25): the 3 x 3 cells around the car's
+template <int NC>
+RLG_HD uint64_t pads_check_car_cells(const Arena<NC>& A, int ci, int ix, int iy) {
+    const Car& car = A.cars[ci];
+    V3 cmin, cmax; pad_car_box(car, cmin, cmax);
+    uint64_t mask = 0;
+    int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
+    for (int cx = lox; cx <= hix; cx++) for (int cy = loy; cy <= hiy; cy++) {
+        int p = pad_of_cell(cx * 10 + cy);
+        if (p < 0) continue;
+        if (pad_touches_car(p, pad_pos(p), A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
+    }
+    return mask;
+}
 template <int NC>
 RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, const uint32_t* tab, int ci) {
     RLG_ASSUME_LDS(A);
-#if defined(__HIP_DEVICE_COMPILE__)
-    RLG_ASSUME_LDS(*tab);
-#endif
     const Car& car = A.cars[ci];
     uint64_t mask = 0;
     if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return mask;
     V3 cp = car.b.pos * BT2UU;
     if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return mask;
     int ix = (int)(cp.x / 1024 + 4), iy = (int)(cp.y / 1024 + 5);
-    const bool in_grid = ix >= 0 && ix <= 7 && iy >= 0 && iy <= 9;
-    const uint32_t near_pads = in_grid ? tab[34 + ix * 10 + iy] : 0xFFFFFFFFu;
+    // no table (single-lane device callers of arena_tick: none on the product path) or a car outside the pad grid (never in play)
+    if (!tab || ix < 0 || ix > 7 || iy < 0 || iy > 9) return pads_check_car_cells(A, ci, ix, iy);
+#if defined(__HIP_DEVICE_COMPILE__)
+    RLG_ASSUME_LDS(*tab);
+#endif
+    const uint32_t near_pads = tab[34 + ix * 10 + iy];
     if (near_pads == 0u) return mask;
-    // car AABB (btCompoundShape::getAabb): centre + |R| * half extents
-    V3 h = hitbox_half();
-    V3 bc = car.b.pos + car.b.rot * hitbox_off();
-    V3 ext = v3(h.x * fabsf(car.b.rot.r0.x) + h.y * fabsf(car.b.rot.r0.y) + h.z * fabsf(car.b.rot.r0.z),
-                h.x * fabsf(car.b.rot.r1.x) + h.y * fabsf(car.b.rot.r1.y) + h.z * fabsf(car.b.rot.r1.z),
-                h.x * fabsf(car.b.rot.r2.x) + h.y * fabsf(car.b.rot.r2.y) + h.z * fabsf(car.b.rot.r2.z));
-    V3 cmin = bc - ext, cmax = bc + ext;
-    if (near_pads != 0xFFFFFFFFu) {
-        RLG_NOUNROLL
-        for (uint32_t w = near_pads; w != 0u; w >>= 8) {
-            const int p = (int)(w & 0xffu) - 1;
-            const uint32_t word = tab[p];
-            const V3 pp = v3((float)((int)(word & 0xffffu) - 8192), (float)((int)(word >> 16) - 8192), p < 6 ? 73.f : 70.f);
-            if (pad_touches_car(p, pp, A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
-        }
-        return mask;
-    }
-    // a car outside the pad grid (never in play), or a pad layout with a crowded cell: the reference's loops as they stand
-    int lox = ix - 1 < 0 ? 0 : ix - 1, hix = ix + 1 > 7 ? 7 : ix + 1, loy = iy - 1 < 0 ? 0 : iy - 1, hiy = iy + 1 > 9 ? 9 : iy + 1;
-    for (int cx = lox; cx <= hix; cx++) for (int cy = loy; cy <= hiy; cy++) {
-        int p = pad_of_cell(cx * 10 + cy);
-        if (p < 0) continue;
-        if (pad_touches_car(p, pad_pos(p), A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
+    if (near_pads == 0xFFFFFFFFu) return pads_check_car_cells(A, ci, ix, iy);   // a pad layout with a crowded cell
+    V3 cmin, cmax; pad_car_box(car, cmin, cmax);
+    RLG_NOUNROLL
+    for (uint32_t w = near_pads; w != 0u; w >>= 8) {
+        const int p = (int)(w & 0xffu) - 1;
+        const uint32_t word = tab[p];
+        const V3 pp = v3((float)((int)(word & 0xffffu) - 8192), (float)((int)(word >> 16) - 8192), p < 6 ? 73.f : 70.f);
+        if (pad_touches_car(p, pp, A.pads[p].prev_locked == ci + 1, car.b.pos, cmin, cmax)) mask |= (1ull << p);
     }
     return mask;
 }
@@ -1074,7 +1094,7 @@ RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_
     collide_compact_and_run(A, mesh, W.Q);
     world_step_finish(A, mesh, ev, W, true);
     for (int i = 0; i < NC; i++) tick_car_post(A, i);
-    tick_finish(A, mesh.pad_tab, false);
+    tick_finish(A, pad_table_default(), false);
 }
 
 }  // namespace rlg

@@ -229,7 +229,6 @@ constexpr int GRID_WORDS = (GRID_X * GRID_Y * GRID_Z + 31) / 32;
 constexpr int PAD_TAB_WORDS = 34 + 80;
 
 struct MeshView {
-    const uint32_t* pad_tab;   // PAD_TAB_WORDS (LDS on the device: a table behind a computed index in constant memory costs a ~500-cycle global load per lookup)
     const BvhNode* nodes;      // global
     const MeshTri* tris;       // global
     const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr

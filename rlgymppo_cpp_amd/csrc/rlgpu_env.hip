@@ -168,7 +168,6 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* ld
     __syncthreads();
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
     mv.grid = d.grid ? lds_grid : nullptr;
-    mv.pad_tab = lds_pad;
     mv.bp = d.grid ? d.grid + GRID_WORDS : nullptr;
     return mv;
 }
@@ -403,7 +402,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 
 // `ev` is meaningful on env lanes (lane e < n_valid owns env e of the wavefront)
 template <int NC>
-__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, uint32_t seed, int env0, TickEvents& ev) {
+__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, const uint32_t* pad_tab, uint32_t seed, int env0, TickEvents& ev) {
     constexpr int EPW = lanes_per_block<NC>() / WPB;
     RLG_ASSUME_LDS(*lane_mem);   // (not inlined into the step / collect kernels: without this every access below is a flat_load / flat_store)
     const int tid = threadIdx.x & 63;
@@ -541,7 +540,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     RLG_PROF(5);
     wave_sync();
     RLG_FPROF(13);
-    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, mv.pad_tab, c_car); }
+    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, pad_tab, c_car); }
     wave_sync();
     RLG_FPROF(14);
     if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
@@ -557,7 +556,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     }
     wave_sync();
     RLG_FPROF(16);
-    if (env_lane) tick_finish(Se.A, mv.pad_tab, true);
+    if (env_lane) tick_finish(Se.A, pad_tab, true);
     wave_sync();
     RLG_FPROF(17);
 }
@@ -611,14 +610,14 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     wave_sync();
     RLG_PROF(8);
     TickEvents ev; ev.bump_mask = 0;
-    arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
+    arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev);   // arena->Step(tickSkip - actionDelay) = 1 tick
     if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, next_obs + (size_t)env * P * D, (size_t)D, snap);
     // host plugins see what the reference's see: the arena as it stands where Gym::Step builds its GameState (Gym.cpp:81-93)
     if (d.snap_out && env_lane) arena_to_host(S.A, S.G, d.snap_out[env]);
     if (d.step_stats) { StepStats st; if (env_lane) step_stats_add<NC>(st, snap); step_stats_flush(d.step_stats, st, ws.lane); }
     wave_sync();
     RLG_PROF(9);
-    for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
+    for (int t = 1; t < d.cfg.tick_skip; t++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); }
     RLG_PROF(6);
     if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * P * D, (size_t)D, dn, snap);
     RLG_PROF(10);
@@ -714,12 +713,12 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         }
         wave_sync();
         TickEvents ev; ev.bump_mask = 0;
-        arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev);
+        arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev);
         float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
         if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
         if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
         wave_sync();
-        for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, seed, env0, ev2); }
+        for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); }
         if (env_lane) {
             gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
             for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
@@ -774,7 +773,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     if (threadIdx.x == 0) for (int i = 0; i < 32; i++) g_fine[i] = 0;
 #endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_FINE_PROF
