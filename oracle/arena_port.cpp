@@ -54,6 +54,34 @@ int port_procedural_mesh(float* verts_out, int cap_verts, int32_t* tris_out, int
     memcpy(verts_out, v.data(), v.size() * 4); memcpy(tris_out, t.data(), t.size() * 4);
     return 0;
 }
+// the host build of csrc/arena_gjk.h:gjk_box_triangle for the Octane hitbox (core, margin as the tick uses them) against one triangle
+// with margin 0: out8 = normal[3], point on the triangle side[3], distance, deep flag.  Returns 1 when a point was reported.
+int port_gjk_box_triangle(const float* pos3, const float* rot9, const float* tri9, float breaking, float* out8) {
+    MeshTri t; memset(&t, 0, sizeof(t));
+    float* p = &t.v0x; for (int k = 0; k < 9; k++) p[k] = tri9[k];
+    t.edge_angle[0] = t.edge_angle[1] = t.edge_angle[2] = 6.283185307179586232f;
+    M3 R = m3_rows(v3(rot9[0], rot9[1], rot9[2]), v3(rot9[3], rot9[4], rot9[5]), v3(rot9[6], rot9[7], rot9[8]));
+    GjkOut g; g.n = v3(0, 0, 0); g.pb = v3(0, 0, 0); g.dist = 0.f; bool deep = false;
+    const bool hit = gjk_box_triangle(v3(pos3[0], pos3[1], pos3[2]), R, hitbox_core(), BOX_MARGIN, t, breaking, g, deep);
+    out8[0] = g.n.x; out8[1] = g.n.y; out8[2] = g.n.z; out8[3] = g.pb.x; out8[4] = g.pb.y; out8[5] = g.pb.z; out8[6] = g.dist; out8[7] = deep ? 1.f : 0.f;
+    return hit ? 1 : 0;
+}
+// the host build of csrc/arena_world.h:adjust_internal_edge on stored triangle `stored_index` of the mesh port_set_mesh built
+// (g_mesh.source_tri maps it to the input's numbering): out7 = normal[3], point on the triangle[3], distance
+int port_adjust_internal_edge(int stored_index, const float* pb3, const float* n3, float dist, float* out7) {
+    if (stored_index < 0 || stored_index >= (int)g_mesh.tris.size()) return -1;
+    V3 pb = v3(pb3[0], pb3[1], pb3[2]), n = v3(n3[0], n3[1], n3[2]);
+    adjust_internal_edge(g_mesh.tris[stored_index], pb, n, dist);
+    out7[0] = n.x; out7[1] = n.y; out7[2] = n.z; out7[3] = pb.x; out7[4] = pb.y; out7[5] = pb.z; out7[6] = dist;
+    return 0;
+}
+int port_mesh_triangle(int stored_index, float* tri9, uint32_t* flags, float* angles3) {
+    if (stored_index < 0 || stored_index >= (int)g_mesh.tris.size()) return -1;
+    const MeshTri& t = g_mesh.tris[stored_index];
+    const float* p = &t.v0x; for (int k = 0; k < 9; k++) tri9[k] = p[k];
+    *flags = t.edge_flags; for (int k = 0; k < 3; k++) angles3[k] = t.edge_angle[k];
+    return g_mesh.source_tri[stored_index];
+}
 int port_mesh_visit_order(int32_t* out, int cap) { int n = (int)g_mesh.source_tri.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_mesh.source_tri[i]; return n; }
 int port_mesh_counts(int* n_nodes, int* n_tris) { *n_nodes = (int)g_mesh.nodes.size(); *n_tris = (int)g_mesh.tris.size(); return 0; }
 

@@ -21,6 +21,13 @@
 #include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
 #include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
 
+#include <bullet3-3.24/BulletCollision/CollisionShapes/btTriangleShape.h>
+#include <bullet3-3.24/BulletCollision/CollisionShapes/btBoxShape.h>
+#include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkPairDetector.h>
+#include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btVoronoiSimplexSolver.h>
+#include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkEpaPenetrationDepthSolver.h>
+#include <bullet3-3.24/BulletCollision/CollisionDispatch/btInternalEdgeUtility.h>
+#include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionObjectWrapper.h>
 #include "../include/rlgpu_state.h"
 
 #include <cstring>
@@ -265,6 +272,72 @@ int ref_mesh_visit_order(int32_t* out, int cap) {
     const btVector3 lo(-1e9f, -1e9f, -1e9f), hi(1e9f, 1e9f, 1e9f);
     shapes[0]->processAllTriangles(&rec, lo, hi);
     return rec.n;
+}
+
+// One convex-convex query exactly as btConvexConvexAlgorithm::processCollision sets it up for a hitbox child against one mesh triangle
+// (btConvexConvexAlgorithm.cpp:268-320,508: btGjkPairDetector + btVoronoiSimplexSolver + btGjkEpaPenetrationDepthSolver, maximum
+// distance = both margins + the breaking threshold): a btBoxShape built from the full half extents (its constructor and setSafeMargin
+// make the core and the margin RocketSim's hitbox has), transform (pos, rot row-major), against btTriangleShape(tri) with margin
+// tri_margin in the identity frame.  out: normalOnBInWorld[3], pointInWorld[3], depth, box margin.  Returns 1 when the detector
+// reported a point.  Unit-level oracle for csrc/arena_gjk.h (tests/test_oracle_golden.py, tools/gjk_fuzz.py).
+int ref_gjk_box_triangle(const float* half3, const float* pos3, const float* rot9, const float* tri9, float tri_margin, float breaking, float* out8) {
+    btBoxShape box(btVector3(half3[0], half3[1], half3[2]));
+    btTriangleShape tri(btVector3(tri9[0], tri9[1], tri9[2]), btVector3(tri9[3], tri9[4], tri9[5]), btVector3(tri9[6], tri9[7], tri9[8]));
+    tri.setMargin(tri_margin);
+    btVoronoiSimplexSolver simplex;
+    btGjkEpaPenetrationDepthSolver pd;
+    btGjkPairDetector det(&box, &tri, &simplex, &pd);
+    det.setMinkowskiA(&box); det.setMinkowskiB(&tri);
+    btGjkPairDetector::ClosestPointInput input;
+    input.m_maximumDistanceSquared = box.getMargin() + tri.getMargin() + breaking;
+    input.m_maximumDistanceSquared *= input.m_maximumDistanceSquared;
+    btMatrix3x3 basis(rot9[0], rot9[1], rot9[2], rot9[3], rot9[4], rot9[5], rot9[6], rot9[7], rot9[8]);
+    input.m_transformA = btTransform(basis, btVector3(pos3[0], pos3[1], pos3[2]));
+    input.m_transformB.setIdentity();
+    struct Res : public btDiscreteCollisionDetectorInterface::Result {
+        bool has = false; btVector3 n, p; btScalar d = 0;
+        void setShapeIdentifiersA(int, int) override {}
+        void setShapeIdentifiersB(int, int) override {}
+        void addContactPoint(const btVector3& normalOnBInWorld, const btVector3& pointInWorld, btScalar depth) override { has = true; n = normalOnBInWorld; p = pointInWorld; d = depth; }
+    } res;
+    det.getClosestPoints(input, res);
+    for (int k = 0; k < 3; k++) { out8[k] = res.has ? (float)res.n[k] : 0.f; out8[3 + k] = res.has ? (float)res.p[k] : 0.f; }
+    out8[6] = res.has ? (float)res.d : 0.f; out8[7] = box.getMargin();
+    return res.has ? 1 : 0;
+}
+
+// btAdjustInternalEdgeContacts as the contact-added callback runs it (Arena.cpp:275-279) on one new point against triangle `tri_index`
+// of the arena mesh ref_init loaded (its btTriangleInfoMap comes from RocketSim.cpp:168-170): the point btManifoldResult::addContactPoint
+// builds from (normalOnBInWorld n, pointInWorld pb, depth) with the mesh body at the identity (btManifoldResult.cpp:112-150).
+// out7 = normalWorldOnB[3], positionWorldOnB[3], distance.  Unit-level oracle for csrc/arena_world.h:adjust_internal_edge.
+int ref_adjust_internal_edge(int tri_index, const float* tri9, const float* pb3, const float* n3, float depth, float* out7) {
+    auto& shapes = RocketSim::GetArenaCollisionShapes(GameMode::SOCCAR);
+    if (shapes.empty()) return -1;
+    btCollisionObject mesh_obj; mesh_obj.setCollisionShape(shapes[0]);
+    btTransform id; id.setIdentity(); mesh_obj.setWorldTransform(id);
+    btTriangleShape tm(btVector3(tri9[0], tri9[1], tri9[2]), btVector3(tri9[3], tri9[4], tri9[5]), btVector3(tri9[6], tri9[7], tri9[8]));
+    btCollisionObjectWrapper tri_wrap(nullptr, &tm, &mesh_obj, mesh_obj.getWorldTransform(), 0, tri_index);
+    btCollisionObject other; other.setWorldTransform(id);
+    btCollisionObjectWrapper other_wrap(nullptr, nullptr, &other, other.getWorldTransform(), -1, -1);
+    const btVector3 n(n3[0], n3[1], n3[2]), pb(pb3[0], pb3[1], pb3[2]);
+    const btVector3 pa = pb + n * depth;
+    btManifoldPoint cp(pa, pb, n, depth);   // local points = world points: both bodies at the identity
+    cp.m_positionWorldOnA = pa; cp.m_positionWorldOnB = pb;
+    btAdjustInternalEdgeContacts(cp, &tri_wrap, &other_wrap, 0, tri_index);
+    for (int k = 0; k < 3; k++) { out7[k] = cp.m_normalWorldOnB[k]; out7[3 + k] = cp.m_positionWorldOnB[k]; }
+    out7[6] = cp.m_distance1;
+    return 0;
+}
+
+// the btTriangleInfo record btGenerateInternalEdgeInfo made for triangle `tri_index` of the arena mesh: out4 = flags, edge angles V0V1, V1V2, V2V0.  0 = no record.
+int ref_triangle_info(int tri_index, float* out4) {
+    auto& shapes = RocketSim::GetArenaCollisionShapes(GameMode::SOCCAR);
+    if (shapes.empty()) return -1;
+    btTriangleInfoMap* map = (btTriangleInfoMap*)shapes[0]->getTriangleInfoMap();
+    btTriangleInfo* info = map ? map->find(tri_index)   /* btGetHash(partId 0, index) = index, btInternalEdgeUtility.cpp:32-36 */ : nullptr;
+    if (!info) return 0;
+    out4[0] = (float)info->m_flags; out4[1] = info->m_edgeV0V1Angle; out4[2] = info->m_edgeV1V2Angle; out4[3] = info->m_edgeV2V0Angle;
+    return 1;
 }
 
 int ref_state_size() { return (int)sizeof(RlgpuArenaState); }

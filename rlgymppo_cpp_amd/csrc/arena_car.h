@@ -11,9 +11,9 @@ namespace rlg {
 
 // Angle::FromRotMat roll (MathTypes.cpp:72-82 -> btMatrix3x3::getEulerYPR)
 RLG_HD float rot_roll(const M3& m) {
-    float yaw = atan2f(m.r1.x, m.r0.x);
-    float pitch = asinf(-m.r2.x);
-    float roll = atan2f(m.r2.y, m.r2.z);
+    float yaw = rl_atan2f(m.r1.x, m.r0.x);
+    float pitch = rl_asinf(-m.r2.x);
+    float roll = rl_atan2f(m.r2.y, m.r2.z);
     const float HALF_PI = 1.57079632679489661923f;
     if (fabsf(pitch) == HALF_PI) {
         if (roll > 0) roll -= PI_F; else roll += PI_F;
@@ -314,8 +314,8 @@ RLG_HD void car_update_double_jump_or_flip(Car& c, bool jump_pressed, float forw
                         iv.y *= ((K::FLIP_SIDE_IMPULSE_MAX_SPEED_SCALE - 1) * ratio) + 1.f;
                         if (backwards) iv.x *= K::FLIP_BACKWARD_IMPULSE_SCALE_X;
                         V3 f = col0(c.b.rot);
-                        float ang = atan2f(f.y, f.x);
-                        V3 xdir = v3(cosf(ang), -sinf(ang), 0.f), ydir = v3(sinf(ang), cosf(ang), 0.f);
+                        float ang = rl_atan2f(f.y, f.x);
+                        V3 xdir = v3(rl_cosf(ang), -rl_sinf(ang), 0.f), ydir = v3(rl_sinf(ang), rl_cosf(ang), 0.f);
                         V3 dv = v3(dot(iv, xdir), dot(iv, ydir), 0.f);
                         body_apply_central_impulse(c.b, dv * UU2BT * K::CAR_MASS, CAR_INV_MASS);
                     }
@@ -331,7 +331,7 @@ RLG_HD void car_update_double_jump_or_flip(Car& c, bool jump_pressed, float forw
         c.flip_time += dt;
         if (c.flip_time <= K::FLIP_TORQUE_TIME) {
             if (c.flip_time >= K::FLIP_Z_DAMP_START && (c.b.vel.z < 0 || c.flip_time < K::FLIP_Z_DAMP_END))
-                c.b.vel.z *= powf(1 - K::FLIP_Z_DAMP_120, dt / (1 / 120.f));
+                c.b.vel.z *= K::FLIP_Z_DAMP_PER_TICK;   // pow(1 - FLIP_Z_DAMP_120, dt / (1 / 120)) with dt = 1 / 120: the base itself
         }
     } else if (c.flags & CF_HAS_FLIPPED) {
         c.flip_time += dt;
@@ -384,7 +384,7 @@ RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
     Car n = {};
     float yaw = (PI_F / 2) + (is_blue ? 0.f : PI_F);
     n.b.pos = v3(RX[idx], -4608.f * (is_blue ? 1.f : -1.f), K::CAR_RESPAWN_Z) * UU2BT;
-    float cy = cosf(yaw), sy = sinf(yaw);
+    float cy = rl_cosf(yaw), sy = rl_sinf(yaw);
     n.b.rot = m3_cols(v3(cy, sy, 0.f), v3(-sy, cy, 0.f), v3(0, 0, 1));
     n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
     n.flags = CF_ON_GROUND;

@@ -119,7 +119,7 @@ RLG_HD bool ball_probably_going_in(const Arena<NC>& A, float max_time, int& goal
     float t = dist / fabsf(bv.y);
     if (t > max_time) return false;
     V3 grav = v3(0, 0, K::GRAVITY_Z);
-    V3 ex = bp + (bv * t) + (grav * t * t) / 2;
+    V3 ex = bp + (bv * t) + vdiv_rs(grav * t * t, 2.f);
     const float HW = 892.755f, GH = 642.775f;
     float margin = K::BALL_RADIUS * 0.1f + 0.f;
     if (ex.z > GH + margin) return false;
@@ -264,7 +264,7 @@ RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_a
 RLG_HD V3 rs_normalized(V3 v) {  // RocketSim Vec::Normalized (MathTypes.h:88-95)
     float l2 = len2(v);
     float l = l2 > 0 ? sqrtf(l2) : 0.f;
-    if (l > SIMD_EPS * SIMD_EPS) return v / l;
+    if (l > SIMD_EPS * SIMD_EPS) return vdiv_rs(v, l);
     return v3(0, 0, 0);
 }
 template <int NC>
@@ -294,11 +294,11 @@ RLG_HD_NOINLINE void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const
                     if (T.p0 != 0.f) orange_goal = !orange_goal;
                     V3 target = v3(0.f, orange_goal ? 6000.f : -6000.f, 642.775f / 2);
                     V3 dir = rs_normalized(target - S.ball_pos);
-                    r = dot(dir, S.ball_vel / 6000.f);
+                    r = dot(dir, vdiv_rs(S.ball_vel, 6000.f));
                 } break;
                 case RW_VEL_PLAYER_TO_BALL: {
                     V3 dir = rs_normalized(S.ball_pos - S.car_pos[k]);
-                    r = dot(dir, S.car_vel[k] / 2300.f);
+                    r = dot(dir, vdiv_rs(S.car_vel[k], 2300.f));
                 } break;
                 case RW_FACE_BALL: {
                     V3 dir = rs_normalized(S.ball_pos - S.car_pos[k]);
@@ -347,7 +347,7 @@ struct Rng {
 };
 RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat = setEulerYPR(yaw,-pitch,-roll) (MathTypes.cpp:84-89)
     float ez = yaw, ey = -pitch, ex = -roll;
-    float ci = cosf(ex), cj = cosf(ey), ch = cosf(ez), si = sinf(ex), sj = sinf(ey), sh = sinf(ez);
+    float ci = rl_cosf(ex), cj = rl_cosf(ey), ch = rl_cosf(ez), si = rl_sinf(ex), sj = rl_sinf(ey), sh = rl_sinf(ez);
     float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
     return m3_rows(v3(cj * ch, sj * sc - cs, sj * cc + ss), v3(cj * sh, sj * ss + cc, sj * cs - sc), v3(-sj, cj * si, cj * ci));
 }

@@ -41,7 +41,8 @@ void tri_bounds(const MeshTri& t, float* mn, float* mx) {
 //    (updateSubtreeHeaders :190-216: when a subtree exceeds 2048 bytes = 128 nodes, each child that does not gets a header, and that
 //    happens after both children are built) and walks each header's nodes in array order.  So the visiting order is the depth-first
 //    order with the children swapped wherever the left child is small (<= 64 leaves) and the right one is not.
-// All arithmetic is the reference's, operation by operation (scalar fp32: BT_USE_SSE is not defined on Linux, btScalar.h:117-137).
+// All arithmetic is the reference's, operation by operation (its x86 build runs btVector3's SSE forms, btScalar.h:216-223, but everything
+// used here -- differences, products with a scalar, component-wise quotients -- is element-wise there too, so the results are the same).
 struct QBvhFrame {
     float mn[3], mx[3], q[3];
     void quantize(uint16_t* out, const float* p, bool is_max) const {
@@ -183,9 +184,42 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         t.edge_flags = 0; t._pad0 = 0; t._pad1 = 0; t._pad2 = 0;
         t.edge_angle[0] = t.edge_angle[1] = t.edge_angle[2] = 6.283185307179586232f;   // btTriangleInfo(): SIMD_2_PI
     }
+    // The tree first: per mesh object the reference's own (see build_part), the objects joined pairwise in file order above them.  Triangles
+    // are stored in the reference's visiting order from here on, so "ascending first-triangle index" IS that order for any set of leaves
+    // -- and the edge records below are made in it too.
+    std::vector<BuildNode> bn;
+    bn.reserve(2 * n_tris + 64);
+    int root = -1;
+    std::vector<int> part_n, part_of(n_tris, 0), part_first;
+    if (n_tris > 0) {
+        std::vector<MeshTri> ordered; ordered.reserve(n_tris);
+        std::vector<int> src_of; src_of.reserve(n_tris);
+        if (part_tris && !part_tris->empty()) { int sum = 0; for (int c : *part_tris) { if (c > 0) part_n.push_back(c); sum += c; } if (sum != n_tris) part_n.assign(1, n_tris); }
+        else part_n.assign(1, n_tris);
+        std::vector<int> roots;
+        int t0 = 0;
+        for (size_t k = 0; k < part_n.size(); k++) {
+            const int c = part_n[k];
+            part_first.push_back(t0);
+            for (int i = t0; i < t0 + c; i++) part_of[i] = (int)k;
+            roots.push_back(build_part(m.tris, t0, c, ordered, bn, &src_of)); t0 += c;
+        }
+        while (roots.size() > 1) {
+            std::vector<int> up;
+            for (size_t i = 0; i + 1 < roots.size(); i += 2) { BuildNode j; j.left = roots[i]; j.right = roots[i + 1]; up.push_back((int)bn.size()); bn.push_back(j); }
+            if (roots.size() & 1) up.push_back(roots.back());
+            roots.swap(up);
+        }
+        root = roots[0];
+        m.tris.swap(ordered);
+        m.source_tri.assign(src_of.begin(), src_of.end());
+        fit_bounds(m.tris, bn, root);
+    }
     // btGenerateInternalEdgeInfo (btInternalEdgeUtility.cpp:295-352) with btConnectivityProcessor::processTriangle (:50-290): for every
-    // triangle A, every other triangle B whose box overlaps A's; two shared vertices (closer than 1e-4) make a shared edge, whose
-    // dihedral angle, convexity and normal-swap flag go into A's record.
+    // triangle A, every other triangle B of the same mesh object whose box overlaps A's, in the order processAllTriangles reports them
+    // (= stored order); two shared vertices (closer than 1e-4) make a shared edge, whose dihedral angle, convexity and normal-swap flag
+    // go into A's record.  Where three triangles meet in one edge the flags of both neighbours accumulate and the LAST neighbour's angle
+    // stays, so the order matters (the goal frame of the procedural arena has such edges; tools/edge_fuzz.py found them).
     {
         using namespace std;
         auto V = [&](int tri, int k) { const float* p = &m.tris[tri].v0x; return v3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2]); };
@@ -194,7 +228,8 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         for (int i = 0; i < n_tris; i++) { float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx); box[i] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]}; }
         for (int ia = 0; ia < n_tris; ia++) {
             const V3 A[3] = {V(ia, 0), V(ia, 1), V(ia, 2)};
-            for (int ib = 0; ib < n_tris; ib++) {
+            const int pf = part_first[part_of[ia]], pl = pf + part_n[part_of[ia]];
+            for (int ib = pf; ib < pl; ib++) {
                 if (ib == ia) continue;
                 bool ov = true;
                 for (int a = 0; a < 3; a++) if (box[ia][a] > box[ib][3 + a] || box[ia][3 + a] < box[ib][a]) ov = false;
@@ -305,31 +340,6 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         for (int a = 0; a < 3; a++) { memcpy(&m.grid[GRID_WORDS + BP_WORDS + a], &lo[a], 4); memcpy(&m.grid[GRID_WORDS + BP_WORDS + 3 + a], &hi[a], 4); }
     }
     if (n_tris == 0) return m;
-    // The tree: per mesh object the reference's own (see build_part), the objects joined pairwise in file order above them; triangles are
-    // stored in the reference's visiting order, so "ascending first-triangle index" IS that order for any set of leaves.
-    std::vector<BuildNode> bn;
-    bn.reserve(2 * n_tris + 64);
-    int root;
-    {
-        std::vector<MeshTri> ordered; ordered.reserve(n_tris);
-        std::vector<int> src_of; src_of.reserve(n_tris);
-        std::vector<int> part_n;
-        if (part_tris && !part_tris->empty()) { int sum = 0; for (int c : *part_tris) { if (c > 0) part_n.push_back(c); sum += c; } if (sum != n_tris) part_n.assign(1, n_tris); }
-        else part_n.assign(1, n_tris);
-        std::vector<int> roots;
-        int t0 = 0;
-        for (int c : part_n) { roots.push_back(build_part(m.tris, t0, c, ordered, bn, &src_of)); t0 += c; }
-        while (roots.size() > 1) {
-            std::vector<int> up;
-            for (size_t i = 0; i + 1 < roots.size(); i += 2) { BuildNode j; j.left = roots[i]; j.right = roots[i + 1]; up.push_back((int)bn.size()); bn.push_back(j); }
-            if (roots.size() & 1) up.push_back(roots.back());
-            roots.swap(up);
-        }
-        root = roots[0];
-        m.tris.swap(ordered);
-        m.source_tri.assign(src_of.begin(), src_of.end());
-        fit_bounds(m.tris, bn, root);
-    }
     // breadth-first renumbering with sibling pairs adjacent
     std::vector<int> order; order.reserve(bn.size());
     std::vector<int> newidx(bn.size(), -1);

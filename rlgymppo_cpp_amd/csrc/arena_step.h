@@ -50,8 +50,8 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
         V3 p1 = c1.b.pos * BT2UU, p2 = c2.b.pos * BT2UU, v1 = c1.b.vel * BT2UU, v2 = c2.b.vel * BT2UU;
         V3 delta = p2 - p1;
         if (dot(v1, delta) > 0) {
-            float l1 = len(v1); V3 vel_dir = (l1 > SIMD_EPS * SIMD_EPS) ? v1 / l1 : v3(0, 0, 0);
-            float l2 = len(delta); V3 dir_to = (l2 > SIMD_EPS * SIMD_EPS) ? delta / l2 : v3(0, 0, 0);
+            float l1 = len(v1); V3 vel_dir = (l1 > SIMD_EPS * SIMD_EPS) ? vdiv_rs(v1, l1) : v3(0, 0, 0);
+            float l2 = len(delta); V3 dir_to = (l2 > SIMD_EPS * SIMD_EPS) ? vdiv_rs(delta, l2) : v3(0, 0, 0);
             float speed_towards = dot(v1, dir_to);
             float other_away = dot(v2, vel_dir);
             if (speed_towards > other_away) {
@@ -683,7 +683,7 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
     if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
     for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
-    A.ball.b.vel *= powf(1.f - K::BALL_DRAG, dt);
+    A.ball.b.vel *= K::BALL_DAMP_PER_TICK;   // btPow(1 - linearDamping, timeStep)
 }
 
 // world step, second part, in four pieces of different width (the host runs them back to back):
@@ -745,7 +745,7 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
     if (n_special > 0) {  // convertContactSpecial (btSequentialImpulseConstraintSolver.cpp:1164-1211): its two rows are set up here
         Contact spc;
         float distance = sp_dist / (float)n_special;
-        V3 normal = sp_normal / (float)n_special;
+        V3 normal = vdiv_bt(sp_normal, (float)n_special);
         spc.a = 0; spc.b = -1; spc.sid = 0; spc.special = 0; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
         row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, K::BALL_FRICTION, K::BALL_RESTITUTION, false);
         row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false);

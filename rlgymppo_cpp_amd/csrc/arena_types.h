@@ -23,6 +23,9 @@ constexpr float CARBALL_FRICTION = 2.0f, CARBALL_RESTITUTION = 0.0f;
 constexpr float CARWORLD_FRICTION = 0.3f, CARWORLD_RESTITUTION = 0.3f;
 constexpr float CARCAR_FRICTION = 0.09f, CARCAR_RESTITUTION = 0.1f;
 constexpr float BALL_REST_Z = 93.15f, BALL_MAX_ANG_SPEED = 6.f, BALL_DRAG = 0.03f;
+// powf(1 - BALL_DRAG, 1 / 120) and powf(1 - FLIP_Z_DAMP_120, 1) as glibc rounds them (constants, so that no libm call is left in the tick;
+// tests/cpp/libm_check.cpp checks both against the C library)
+constexpr float BALL_DAMP_PER_TICK = 0x1.ffdebcp-1f, FLIP_Z_DAMP_PER_TICK = 0x1.4cccccp-1f;
 constexpr float BALL_FRICTION = 0.35f, BALL_RESTITUTION = 0.6f;  // vs world: min(0.35,0.6), max(0.6,0.3) (btManifoldResult.cpp:56-78)
 constexpr float CAR_MAX_SPEED = 2300.f, BALL_MAX_SPEED = 6000.f;
 constexpr float BOOST_MAX = 100.f, BOOST_USED_PER_SECOND = BOOST_MAX / 3, BOOST_MIN_TIME = 0.1f;

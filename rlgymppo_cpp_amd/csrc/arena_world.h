@@ -544,7 +544,7 @@ RLG_HD_NOINLINE void adjust_internal_edge(const MeshTri& t, V3& pb, V3& n, float
             // btClampNormal (:375-410); edges 1 and 2 pass the un-normalised local normal (:607, :676)
             const V3 ln = e == 0 ? local_n : n;
             const V3 edge_cross = normalized(cross(edge, nA));
-            const float cur = atan2f(dot(ln, edge_cross), dot(ln, nA));
+            const float cur = rl_atan2f(dot(ln, edge_cross), dot(ln, nA));
             if ((angle < 0.f && cur < angle) || (angle >= 0.f && cur > angle)) {
                 const V3 clamped = quat_to_m3(quat_axis_angle(edge, angle - cur)) * ln;
                 if (dot(clamped, tri_normal) > 0.f) { n = clamped; pb = pa - n * dist; }
@@ -564,7 +564,7 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
     V3 n = cross(v1 - v0, v2 - v0);
     float l2 = len2(n);
     if (l2 < SIMD_EPS * SIMD_EPS) return false;
-    n = n / sqrtf(l2);
+    n = vdiv_bt(n, sqrtf(l2));
     float dplane = dot(c - v0, n);
     bool back_side = false;
     if (dplane < 0.f) { dplane *= -1.f; n = n * -1.f; back_side = true; }
@@ -582,7 +582,7 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
     if (!(ds < rwt * rwt)) return false;
     if (ds > SIMD_EPS) {
         float d = sqrtf(ds);
-        normal = ctc / d;  // btVector3::normalize
+        normal = vdiv_bt(ctc, d);  // btVector3::normalize
         point = cp; depth = -(radius - d);
     } else { normal = n; point = cp; depth = -radius; }
     return true;
@@ -645,7 +645,7 @@ RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, fl
     V3 n = cross(e[0], p[2] - p[0]);
     float nl = len(n);
     if (nl < 1e-12f) return;
-    n = n / nl;
+    n = vdiv_bt(n, nl);
     float d = dot(n, p[0]);
     if (d > 0.f) { n = -n; d = -d; }  // now the box centre is on the +n side: signed distance of centre = -d >= 0
     float rn = h.x * fabsf(n.x) + h.y * fabsf(n.y) + h.z * fabsf(n.z);
@@ -668,7 +668,7 @@ RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, fl
             V3 a = cross(ei, e[j]);
             float al = len(a);
             if (al < 1e-6f) continue;
-            a = a / al;
+            a = vdiv_bt(a, al);
             float t0 = dot(a, p[0]), t1 = dot(a, p[1]), t2 = dot(a, p[2]);
             float mn = fminf(t0, fminf(t1, t2)), mx = fmaxf(t0, fmaxf(t1, t2));
             float r = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
@@ -707,7 +707,7 @@ RLG_HD_NOINLINE void box_triangle(V3 bc, const M3& R, V3 h, const MeshTri& t, fl
             V3 en = cross(e[j], tn);  // outward
             float enl = len(en);
             if (enl < 1e-12f) continue;
-            en = en / enl;
+            en = vdiv_bt(en, enl);
             clip_poly(quad, en, dot(en, p[j]));
         }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -802,7 +802,7 @@ RLG_HD_NOINLINE void box_box(V3 ca, const M3& Ra, V3 cb, const M3& Rb, V3 h, Can
             V3 a = cross(ei, bcol[j]);
             float al = len(a);
             if (al < 1e-5f) continue;
-            a = a / al;
+            a = vdiv_bt(a, al);
             float ra = h.x * fabsf(a.x) + h.y * fabsf(a.y) + h.z * fabsf(a.z);
             float rb = h.x * fabsf(dot(a, bcol[0])) + h.y * fabsf(dot(a, bcol[1])) + h.z * fabsf(dot(a, bcol[2]));
             float pa = dot(pp, a);
@@ -944,7 +944,7 @@ RLG_HD void ode_cull_points(int n, const float p[], int m, int i0, int iret[]) {
         cy = a * (cy + q * (p[n * 2 - 1] + p[1]));
     }
     float A[8]; int avail[8];
-    for (int i = 0; i < n; i++) { A[i] = atan2f(p[i * 2 + 1] - cy, p[i * 2] - cx); avail[i] = 1; }
+    for (int i = 0; i < n; i++) { A[i] = rl_atan2f(p[i * 2 + 1] - cy, p[i * 2] - cx); avail[i] = 1; }
     avail[i0] = 0;
     iret[0] = i0;
     for (int j = 1; j < m; j++) {
@@ -1084,7 +1084,7 @@ RLG_HD_NOINLINE bool sphere_box(V3 sc, float radius, V3 bc, const M3& R, V3 h, f
     V3 nl; float core_dist;
     if (dl2 > SIMD_EPS * SIMD_EPS) {
         core_dist = sqrtf(dl2);
-        nl = d / core_dist;
+        nl = vdiv_bt(d, core_dist);
     } else {
         float px = hc.x - fabsf(l.x), py = hc.y - fabsf(l.y), pz = hc.z - fabsf(l.z);
         if (px <= py && px <= pz) { nl = v3(l.x < 0 ? -1.f : 1.f, 0, 0); core_dist = -px; q.x = nl.x * hc.x; }

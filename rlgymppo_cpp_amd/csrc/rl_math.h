@@ -34,6 +34,7 @@
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
 #endif
+#include "rl_libm.h"   // rl_sinf / rl_cosf / rl_atan2f / rl_asinf: the same bits on the device and on the host (= glibc's)
 // Phase stamps for the tick profiler build (tools/prof_cycles.py); empty in product builds.
 #ifndef RLG_PROF
 #define RLG_PROF(i) ((void)0)
@@ -55,7 +56,12 @@ RLG_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 RLG_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 RLG_HD V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 RLG_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
-RLG_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// Two divisions by a scalar, because the reference has two vector types: RocketSim's Vec divides every component (MathTypes.cpp:11-22),
+// btVector3 multiplies by the reciprocal (btVector3.h:210-226, 852-865; safeNormalize too).  One ulp apart; every site says which one it
+// restates.  btVector3::normalize itself cannot be restated exactly: the reference's x86 build takes the SSE branch (btScalar.h:216-223,
+// btVector3.h:308-346: rsqrtss + one Newton step, a hardware-specific approximation), `normalized` below is the portable branch.
+RLG_HD V3 vdiv_rs(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+RLG_HD V3 vdiv_bt(V3 a, float s) { const float r = 1.0f / s; return v3(a.x * r, a.y * r, a.z * r); }
 RLG_HD V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
 RLG_HD V3& operator-=(V3& a, V3 b) { a = a - b; return a; }
 RLG_HD V3& operator*=(V3& a, float s) { a = a * s; return a; }
@@ -64,11 +70,11 @@ RLG_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 RLG_HD float len2(V3 a) { return dot(a, a); }
 RLG_HD float len(V3 a) { return sqrtf(dot(a, a)); }
 RLG_HD bool is_zero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
-RLG_HD V3 normalized(V3 a) { return a / len(a); }
+RLG_HD V3 normalized(V3 a) { return vdiv_bt(a, len(a)); }   // btVector3::normalize / normalized
 // btVector3::safeNormalize (btVector3.h:287-300): (1,0,0) when shorter than eps
 RLG_HD V3 safe_normalized(V3 a) {
     float l2 = len2(a);
-    if (l2 >= SIMD_EPS * SIMD_EPS) return a / sqrtf(l2);
+    if (l2 >= SIMD_EPS * SIMD_EPS) return vdiv_bt(a, sqrtf(l2));
     return v3(1.f, 0.f, 0.f);
 }
 RLG_HD float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -147,8 +153,8 @@ RLG_HD Q4 qmul(Q4 a, Q4 b) {
 // rotation about a unit axis (btQuaternion(axis, angle))
 RLG_HD Q4 quat_axis_angle(V3 axis, float angle) {
     float d = len(axis);
-    float s = sinf(angle * 0.5f) / d;
-    Q4 q; q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s; q.w = cosf(angle * 0.5f);
+    float s = rl_sinf(angle * 0.5f) / d;
+    Q4 q; q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s; q.w = rl_cosf(angle * 0.5f);
     return q;
 }
 
@@ -176,8 +182,8 @@ RLG_HD_NOINLINE M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
     if (fAngle < 0.001f)
         axis = angvel * (0.5f * dt - (dt * dt * dt) * 0.020833333333f * fAngle * fAngle);
     else
-        axis = angvel * (sinf(0.5f * fAngle * dt) / fAngle);
-    Q4 dorn; dorn.x = axis.x; dorn.y = axis.y; dorn.z = axis.z; dorn.w = cosf(fAngle * dt * 0.5f);
+        axis = angvel * (rl_sinf(0.5f * fAngle * dt) / fAngle);
+    Q4 dorn; dorn.x = axis.x; dorn.y = axis.y; dorn.z = axis.z; dorn.w = rl_cosf(fAngle * dt * 0.5f);
     Q4 orn0 = m3_to_quat(basis);
     Q4 p = qmul(dorn, orn0);
     float l2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;

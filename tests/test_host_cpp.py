@@ -38,6 +38,18 @@ def test_host_api_translation_and_utils(tmp_path):
     assert t.returncode == 0 and t.stdout.count("log {") == 2 and "init {" in t.stdout and "'bad'" not in t.stdout, t.stdout
 
 
+def test_portable_libm_is_the_c_librarys_bit_for_bit(tmp_path):
+    """CPU: csrc/rl_libm.h (the sinf / cosf / atan2f / atanf / asinf the physics calls on the device AND on the host) against glibc over
+    20 million arguments per function, and the two powf constants of the tick: identical everywhere (tests/cpp/libm_check.cpp; the same
+    program over 4e8 arguments per function was clean too).  With these the HIP stepper and the host build compute the same bits
+    (tests/test_gpu_parity.py::test_physics_ticks_match_host_port_on_golden_scenarios compares them for equality)."""
+    exe = str(tmp_path / "libm_check")
+    r = _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "libm_check.cpp"), "-o", exe, "-lm"])
+    assert r.returncode == 0, r.stdout
+    r = _run([exe, "20"])
+    assert r.returncode == 0 and "mismatches sinf 0 cosf 0 atan2f 0 atanf 0 asinf 0" in r.stdout, r.stdout
+
+
 def test_example_program_is_built():
     """CPU: build() produced the host library and the example program written against the reference's API."""
     for f in ("librlgymppo_amd.so", "example_main", "infer_unit_check", "bench_main", "plugin_fallback_check"):

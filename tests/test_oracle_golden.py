@@ -306,6 +306,53 @@ def test_mesh_triangle_visiting_order_is_the_references(port_lib):
     port_lib.set_mesh(pv, pt)   # (the module's other tests use the procedural arena)
 
 
+def test_narrowphase_routines_vs_reference_golden(port_lib):
+    """The two Bullet routines the narrowphase restates, against outputs of the reference's OWN code (tests/golden/narrowphase_golden.npz,
+    make_narrowphase_golden.py): (1) csrc/arena_gjk.h:gjk_box_triangle vs btGjkPairDetector set up as btConvexConvexAlgorithm does for a
+    hitbox against a mesh triangle, 3000 poses -- same report flag, normal / point / distance equal (bit-identical on the build host;
+    1e-6 allowed for another compiler), except where the box cores overlap and the reference asks EPA (flagged `deep` here, DESIGN 2);
+    (2) csrc/arena_world.h:adjust_internal_edge vs btAdjustInternalEdgeContacts on the procedural arena's edge records, 7200 points --
+    normals within 1e-6 except a handful of points whose clamp decision sits on the fence (a normal turned exactly into the face plane
+    at a right-angled edge: the sign of a 1e-7 dot product decides, and the reference's normalisations are rsqrtss approximations)."""
+    g = np.load(os.path.join(GOLD, "narrowphase_golden.npz"))
+    lib = port_lib.lib
+    FP = C.POINTER(C.c_float)
+    lib.port_gjk_box_triangle.argtypes = [FP, FP, FP, C.c_float, FP]
+    n = len(g["gjk/pos"]); compared = 0; deep = 0; worst = 0.0
+    for i in range(n):
+        pos = np.ascontiguousarray(g["gjk/pos"][i]); rot = np.ascontiguousarray(g["gjk/rot"][i]); tri = np.ascontiguousarray(g["gjk/tri"][i])
+        out = np.zeros(8, np.float32)
+        hit = lib.port_gjk_box_triangle(pos.ctypes.data_as(FP), rot.ctypes.data_as(FP), tri.ctypes.data_as(FP), float(g["gjk/breaking"]), out.ctypes.data_as(FP))
+        if out[7] != 0:
+            deep += 1; continue
+        assert hit == g["gjk/hit"][i], f"gjk case {i}: reported {hit}, reference {g['gjk/hit'][i]}"
+        if hit:
+            compared += 1
+            err = float(np.abs(out[:7] - g["gjk/out"][i][:7]).max()); worst = max(worst, err)
+            assert err <= 1e-6, f"gjk case {i}: {out[:7]} vs reference {g['gjk/out'][i][:7]}"
+    assert compared > 1500 and deep < n // 2
+    print(f"gjk: {compared} points compared, worst |diff| {worst:g}, {deep} deep cases left to the fallback")
+    # edge adjustment
+    pv, pt = port_lib.procedural_mesh(); port_lib.set_mesh(pv, pt)
+    order = np.zeros(len(pt), np.int32)
+    lib.port_mesh_visit_order.argtypes = [C.c_void_p, C.c_int]; lib.port_mesh_visit_order(order.ctypes.data_as(C.c_void_p), len(pt))
+    stored_of = np.zeros(len(pt), np.int32); stored_of[order] = np.arange(len(pt), dtype=np.int32)
+    lib.port_adjust_internal_edge.argtypes = [C.c_int, FP, FP, C.c_float, FP]
+    m = len(g["edge/tri"]); on_fence = 0; worst = 0.0; adjusted = 0
+    for k in range(m):
+        pb = np.ascontiguousarray(g["edge/pb"][k]); nn = np.ascontiguousarray(g["edge/n"][k]); out = np.zeros(7, np.float32)
+        assert lib.port_adjust_internal_edge(int(stored_of[g["edge/tri"][k]]), pb.ctypes.data_as(FP), nn.ctypes.data_as(FP), float(g["edge/dist"][k]), out.ctypes.data_as(FP)) == 0
+        ref = g["edge/out"][k]
+        adjusted += int(np.abs(ref[:3] - nn).max() > 0)
+        err = float(np.abs(out[:3] - ref[:3]).max())
+        if err > 1e-6:
+            on_fence += 1
+        else:
+            worst = max(worst, err, float(np.abs(out[3:6] - ref[3:6]).max()))
+    assert adjusted > m // 3 and on_fence <= m // 500, f"{on_fence} of {m} adjusted differently from the reference"
+    print(f"edge adjustment: {m} points ({adjusted} adjusted by the reference), worst |diff| {worst:g}, {on_fence} on the fence")
+
+
 def test_padded_obs_is_a_block_shuffle_of_default_obs(port_lib):
     """DefaultOBSPadded(maxPlayers = team size) (DefaultOBSPadded.cpp:3-66) on the host port: ball / prev-action / pads / self parts
     equal DefaultOBS; the teammate blocks and the opponent blocks are the same 19-float blocks in a permuted order, and over
