@@ -680,8 +680,9 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
     const bool ball_asleep = W.ball_asleep;
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
     const float g = K::GRAVITY_Z * UU2BT;
-    if (!ball_asleep) A.ball.b.force += v3(0, 0, K::BALL_MASS * g);
-    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, K::CAR_MASS * g);
+    // btRigidBody::setGravity keeps acceleration * (1 / m_inverseMass) (btRigidBody.cpp:132-139): not quite mass * g in float
+    if (!ball_asleep) A.ball.b.force += v3(0, 0, g * (1.0f / BALL_INV_MASS));
+    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, g * (1.0f / CAR_INV_MASS));
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
     A.ball.b.vel *= K::BALL_DAMP_PER_TICK;   // btPow(1 - linearDamping, timeStep)
 }
