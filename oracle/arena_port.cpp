@@ -196,6 +196,29 @@ static int debug_tick_t(RlgpuArenaState* s, float* out, int cap) {
     }
     return n;
 }
+// one tick, then car `slot`'s wheel scratch as the tick left it: per wheel 12 floats laid out like oracle/ref_driver.cpp:ref_debug_wheels
+// (suspension length, 0, suspension relative velocity, clipped inverse contact dot, contact point, contact normal, hard point z, |impulse|)
+template <int NC>
+static void debug_wheels_t(RlgpuArenaState* s, int slot, float* out) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick(A, mv, 0, 0, ev, W);
+    arena_to_host(A, G, *s);
+    for (int w = 0; w < 4; w++) {
+        const WheelTmp& wt = W.ctx[slot].w[w];
+        float* o = out + 12 * w;
+        o[0] = wt.susp_len; o[1] = 0.f; o[2] = wt.susp_rel_vel; o[3] = wt.clipped_inv;
+        o[4] = wt.contact_point.x; o[5] = wt.contact_point.y; o[6] = wt.contact_point.z;
+        o[7] = wt.contact_normal.x; o[8] = wt.contact_normal.y; o[9] = wt.contact_normal.z;
+        o[10] = wt.hard_point.z; o[11] = len(wt.impulse);
+    }
+}
+extern "C" void port_debug_wheels(RlgpuArenaState* s, int slot, float* out) {
+    if (s->num_cars == 2) debug_wheels_t<2>(s, slot, out); else if (s->num_cars == 4) debug_wheels_t<4>(s, slot, out); else debug_wheels_t<6>(s, slot, out);
+}
 extern "C" int port_debug_tick(RlgpuArenaState* s, float* out, int cap) {
     if (s->num_cars == 2) return debug_tick_t<2>(s, out, cap);
     if (s->num_cars == 4) return debug_tick_t<4>(s, out, cap);
