@@ -70,7 +70,23 @@ RLG_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 RLG_HD float len2(V3 a) { return dot(a, a); }
 RLG_HD float len(V3 a) { return sqrtf(dot(a, a)); }
 RLG_HD bool is_zero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
-RLG_HD V3 normalized(V3 a) { return vdiv_bt(a, len(a)); }   // btVector3::normalize / normalized
+// btVector3::normalize / normalized as the reference's x86 build computes it (btVector3.h:308-346, the SSE branch): the reciprocal
+// square root is `rsqrtss` + one Newton step, not a division by the length.  The instruction's result is hardware-defined; on the Intel
+// core that recorded the fixtures it is 1 / sqrt(midpoint of the argument's 2^-10-wide mantissa bucket) rounded to 12 bits, which the
+// routine below reproduces for every normal argument (checked against the instruction on 2e8 inputs) -- on the host and on the device.
+// Effect: a unit vector normalises to 0.99999994 of itself, as in the reference (the floor normal under a resting car).
+RLG_HD float rsqrtss_emulated(float x) {
+    const float mid = rl_u2f((rl_f2u(x) & 0xFFFFE000u) | 0x1000u);
+    const float r = 1.0f / sqrtf(mid);
+    return rl_u2f((rl_f2u(r) + 0x400u) & 0xFFFFF800u);
+}
+RLG_HD V3 normalized(V3 a) {
+    float vd = a.x * a.x; vd = vd + a.y * a.y; vd = vd + a.z * a.z;
+    float y = rsqrtss_emulated(vd);
+    vd = vd * 0.5f; vd = vd * y; vd = vd * y;
+    y = y * (1.5f - vd);
+    return v3(a.x * y, a.y * y, a.z * y);
+}
 // btVector3::safeNormalize (btVector3.h:287-300): (1,0,0) when shorter than eps
 RLG_HD V3 safe_normalized(V3 a) {
     float l2 = len2(a);
@@ -105,49 +121,47 @@ RLG_HD M3 scaled_cols(const M3& m, V3 s) { return m3_rows(m.r0 * s, m.r1 * s, m.
 struct Q4 {
     float x, y, z, w;
 };
-// btMatrix3x3::getRotation (btMatrix3x3.h)
+// The quaternion / matrix conversions and products below follow the SSE branches of Bullet's headers, which is what the reference's
+// x86 build runs (btScalar.h:216-223): same products as the portable branches, but summed in another order, so the last bit differs.
+// Each is checked bit for bit against the reference's own inline functions (tests/cpp/bullet_math_check.cpp).
+// btQuaternion::dot / length2 (btQuaternion.h:336-353): (x x + z z) + (y y + w w)
+RLG_HD float qlen2(Q4 q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
+// btMatrix3x3::getRotation (btMatrix3x3.h:421-487): the four numerators first, all scaled by 0.5 / sqrt(x) at the end
 RLG_HD Q4 m3_to_quat(const M3& m) {
     float trace = m.r0.x + m.r1.y + m.r2.z;
-    float t[4];
+    float t[4]; float x;
     if (trace > 0.f) {
-        float s = sqrtf(trace + 1.0f);
-        t[3] = s * 0.5f;
-        s = 0.5f / s;
-        t[0] = (m.r2.y - m.r1.z) * s;
-        t[1] = (m.r0.z - m.r2.x) * s;
-        t[2] = (m.r1.x - m.r0.y) * s;
+        x = trace + 1.0f;
+        t[0] = m.r2.y - m.r1.z; t[1] = m.r0.z - m.r2.x; t[2] = m.r1.x - m.r0.y; t[3] = x;
     } else {
         int i = m.r0.x < m.r1.y ? (m.r1.y < m.r2.z ? 2 : 1) : (m.r0.x < m.r2.z ? 2 : 0);
         int j = (i + 1) % 3, k = (i + 2) % 3;
         const V3 rows[3] = {m.r0, m.r1, m.r2};
-        float s = sqrtf(get(rows[i], i) - get(rows[j], j) - get(rows[k], k) + 1.0f);
-        t[i] = s * 0.5f;
-        s = 0.5f / s;
-        t[3] = (get(rows[k], j) - get(rows[j], k)) * s;
-        t[j] = (get(rows[j], i) + get(rows[i], j)) * s;
-        t[k] = (get(rows[k], i) + get(rows[i], k)) * s;
+        x = get(rows[i], i) - get(rows[j], j) - get(rows[k], k) + 1.0f;
+        t[3] = get(rows[k], j) - get(rows[j], k);
+        t[j] = get(rows[j], i) + get(rows[i], j);
+        t[k] = get(rows[k], i) + get(rows[i], k);
+        t[i] = x;
     }
-    Q4 q; q.x = t[0]; q.y = t[1]; q.z = t[2]; q.w = t[3];
+    const float s = 0.5f / sqrtf(x);
+    Q4 q; q.x = t[0] * s; q.y = t[1] * s; q.z = t[2] * s; q.w = t[3] * s;
     return q;
 }
-// btMatrix3x3::setRotation
+// btMatrix3x3::setRotation (btMatrix3x3.h:216-272): raw products, summed, times 2 / |q|^2, plus the identity
 RLG_HD M3 quat_to_m3(Q4 q) {
-    float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    float s = 2.0f / d;
-    float xs = q.x * s, ys = q.y * s, zs = q.z * s;
-    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
-    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
-    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
-    return m3_rows(v3(1.0f - (yy + zz), xy - wz, xz + wy), v3(xy + wz, 1.0f - (xx + zz), yz - wx),
-                   v3(xz - wy, yz + wx, 1.0f - (xx + yy)));
+    const float s = 2.0f / qlen2(q);
+    const float X = q.x, Y = q.y, Z = q.z, W = q.w;
+    return m3_rows(v3((-(Y * Y) - Z * Z) * s + 1.0f, (X * Y - W * Z) * s + 0.0f, (Z * X + Y * W) * s + 0.0f),
+                   v3((X * Y + Z * W) * s + 0.0f, (-(X * X) - Z * Z) * s + 1.0f, (Y * Z - W * X) * s + 0.0f),
+                   v3((Z * X - W * Y) * s + 0.0f, (Y * Z + W * X) * s + 0.0f, (-(X * X) - Y * Y) * s + 1.0f));
 }
-// btQuaternion operator*(q1,q2)
+// btQuaternion operator*(q1, q2) (btQuaternion.h:619-650): (w1 v2 - v1 x' v2) + (v1 w2 + v1 x'' v2) component by component
 RLG_HD Q4 qmul(Q4 a, Q4 b) {
     Q4 r;
-    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
-    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
-    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
-    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = (a.w * b.x - a.z * b.y) + (a.x * b.w + a.y * b.z);
+    r.y = (a.w * b.y - a.x * b.z) + (a.y * b.w + a.z * b.x);
+    r.z = (a.w * b.z - a.y * b.x) + (a.z * b.w + a.x * b.y);
+    r.w = (a.w * b.w - a.z * b.z) - (a.x * b.x + a.y * b.y);
     return r;
 }
 // rotation about a unit axis (btQuaternion(axis, angle))
@@ -186,13 +200,11 @@ RLG_HD_NOINLINE M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
     Q4 dorn; dorn.x = axis.x; dorn.y = axis.y; dorn.z = axis.z; dorn.w = rl_cosf(fAngle * dt * 0.5f);
     Q4 orn0 = m3_to_quat(basis);
     Q4 p = qmul(dorn, orn0);
-    float l2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
-    if (l2 >= SIMD_EPS * SIMD_EPS) {  // safeNormalize
-        float inv = 1.f / sqrtf(l2);  // btQuaternion::operator/= multiplies by 1/s
+    if (qlen2(p) > SIMD_EPS) {        // btQuaternion::safeNormalize -> normalize (btQuaternion.h:374-402): times 1 / sqrt(length2)
+        const float inv = 1.f / sqrtf(qlen2(p));
         p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
-    } else { p.x = 1; p.y = 0; p.z = 0; p.w = 0; }
-    l2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
-    if (l2 > SIMD_EPS) return quat_to_m3(p);
+    }
+    if (qlen2(p) > SIMD_EPS) return quat_to_m3(p);
     return basis;
 }
 

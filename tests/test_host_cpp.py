@@ -50,6 +50,20 @@ def test_portable_libm_is_the_c_librarys_bit_for_bit(tmp_path):
     assert r.returncode == 0 and "mismatches sinf 0 cosf 0 atan2f 0 atanf 0 asinf 0" in r.stdout, r.stdout
 
 
+def test_restated_bullet_math_is_the_references_bit_for_bit(tmp_path):
+    """CPU, build container (needs the reference's headers): csrc/rl_math.h against Bullet's own inline functions compiled the way the
+    reference compiles them (SSE branches) -- btVector3::normalize (rsqrtss + Newton step, emulated), quaternion construction and
+    products, quatRotate, setRotation, getRotation, matrix * vector, safeNormalize: identical on 300 000 random arguments each."""
+    inc = "/root/reference/RLGymPPO_CPP/RLGymSim_CPP/RocketSim/libsrc"
+    if not os.path.isdir(inc):
+        pytest.skip("/root/reference is not mounted here")
+    exe = str(tmp_path / "bullet_math_check")
+    r = _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-w", "-I", inc, os.path.join(ROOT, "tests", "cpp", "bullet_math_check.cpp"), "-o", exe, "-lm"])
+    assert r.returncode == 0, r.stdout
+    r = _run([exe])
+    assert r.returncode == 0 and "mismatches normalize 0," in r.stdout, r.stdout
+
+
 def test_example_program_is_built():
     """CPU: build() produced the host library and the example program written against the reference's API."""
     for f in ("librlgymppo_amd.so", "example_main", "infer_unit_check", "bench_main", "plugin_fallback_check"):
