@@ -175,7 +175,7 @@ RLG_HD void car_update_air_torque(Car& c, bool update_air_control) {
         bool keep = (c.flags & CF_HAS_FLIPPED) && c.flip_time < K::FLIP_TORQUE_TIME;
         if (!keep) c.flags &= ~CF_IS_FLIPPING;
     }
-    M3 inertia_w = body_inertia_w(c.b, car_inertia_local());
+    const M3 inertia_w = m3_inverse(c.b.inv_inertia_w);   // the reference inverts m_invInertiaTensorWorld numerically where it needs the world inertia (Car.cpp:590,636,832)
     if (c.flags & CF_IS_FLIPPING) {
         V3 rel = c.flip_rel_torque;
         if (!is_zero(c.flip_rel_torque)) {
@@ -188,7 +188,7 @@ RLG_HD void car_update_air_torque(Car& c, bool update_air_control) {
             }
             rel.y *= pitch_scale;
             V3 dodge = rel * v3(K::FLIP_TORQUE_X, K::FLIP_TORQUE_Y, 0.f);
-            c.b.torque += inertia_w * (c.b.rot * dodge);
+            c.b.torque += (inertia_w * c.b.rot) * dodge;      // inverse() * basis * dodgeTorque, left to right
         } else {
             do_air = true;
         }
@@ -357,7 +357,7 @@ RLG_HD void car_update_auto_roll(Car& c, const CarTickCtx& t) {
     V3 tdir_fwd = right * (dot(fwd, ground_up) >= 0 ? 1.f : -1.f);
     V3 t_right = tdir_right * right_f, t_fwd = tdir_fwd * fwd_f;
     c.b.force += ground_down * K::CAR_AUTOROLL_FORCE * UU2BT * K::CAR_MASS;
-    c.b.torque += (body_inertia_w(c.b, car_inertia_local()) * (t_fwd + t_right)) * K::CAR_AUTOROLL_TORQUE;
+    c.b.torque += (m3_inverse(c.b.inv_inertia_w) * (t_fwd + t_right)) * K::CAR_AUTOROLL_TORQUE;
 }
 
 // ---- Car::_UpdateBoost (Car.cpp:477-505) -------------------------------------------------------------------
@@ -508,7 +508,7 @@ RLG_HD_NOINLINE void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView 
     if (hit.kind >= 0) {
         float rt = hit.frac, s = 1.f - rt;
         w.contact_point = v3(s * source.x + rt * target.x, s * source.y + rt * target.y, s * source.z + rt * target.z);
-        w.contact_normal = hit.normal;
+        w.contact_normal = normalized(hit.normal);   // btDefaultVehicleRaycaster::castRay normalises the reported normal once more (btDefaultVehicleRaycaster.cpp:45)
         w.in_contact = true;
         w.ground = hit.kind;
         bool is_static = hit.kind == 0;

@@ -327,10 +327,13 @@ RLG_HD void world_plane(int i, V3& n, float& d) {
 // body whose world transform is a pure translation `origin` -- the convex-plane test runs in that body's frame
 RLG_HD void world_plane_body(int i, V3& n, V3& origin) {
     const float ex = K::ARENA_EXTENT_X, h = K::ARENA_HEIGHT;
-    if (i == 0) { n = v3(0, 0, 1); origin = v3(0, 0, 0); }
-    else if (i == 1) { n = v3(0, 0, -1); origin = v3(0.f * UU2BT, 0.f * UU2BT, h * UU2BT); }
-    else if (i == 2) { n = v3(1, 0, 0); origin = v3(-ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
-    else { n = v3(-1, 0, 0); origin = v3(ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
+    // btStaticPlaneShape keeps planeNormal.normalized() (btStaticPlaneShape.cpp:19): through the reference's rsqrtss-based normalize the
+    // unit axis becomes 0.99999994 of itself, and that is the normal its contact and ray code work with
+    const float u = normalized(v3(0, 0, 1)).z;
+    if (i == 0) { n = v3(0, 0, u); origin = v3(0, 0, 0); }
+    else if (i == 1) { n = v3(0, 0, -u); origin = v3(0.f * UU2BT, 0.f * UU2BT, h * UU2BT); }
+    else if (i == 2) { n = v3(u, 0, 0); origin = v3(-ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
+    else { n = v3(-u, 0, 0); origin = v3(ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
 }
 
 // the proxy box of plane body i: RocketSim's btStaticPlaneShape::getAabb (btStaticPlaneShape.cpp:40-54) is a half space that ends 0.2
@@ -366,14 +369,31 @@ RLG_HD void manifold_point_refresh2(const Body& a, const Body& b, V3 pa_w, V3 pb
 
 // A suspension ray is cast in three stages (planes | mesh | ball and cars) so that the mesh stage can run as one lane per
 // (ray, candidate triangle) pair on the device; every later stage only accepts strictly closer hits, as one loop would.
+// A suspension ray against the four arena planes, the way the reference gets there: every car's own box marks the suspension grid
+// cells around it as "dynamic" (Arena.cpp:733-748, SuspensionCollisionGrid.cpp:185-205), so CastSuspensionRay never takes its analytic
+// shortcut for a car's wheel (:124-134) and the ray goes through btCollisionWorld::rayTest.  There a btStaticPlaneShape is a concave shape:
+// the ray, moved into the plane body's frame (a pure translation), is tested against the TWO TRIANGLES btStaticPlaneShape::processAllTriangles
+// spans over the ray's own box (btStaticPlaneShape.cpp:56-82) with btTriangleRaycastCallback (= ray_triangle above).  Same hits as the
+// analytic intersection, but the hit fraction comes out of the triangles' cross products -- a few ulps that every suspension length
+// and force of a car on the ground inherits.  (A plane the ray does not cross cannot be hit by its triangles either: the callback's
+// first test is the same sign test, with the triangle normal c * n.)
 RLG_HD RayHit ray_planes(V3 from, V3 to) {
     RayHit best; best.kind = -1; best.frac = 1.0f; best.normal = v3(0, 0, 0);
     for (int i = 0; i < 4; i++) {
-        V3 n; float d; world_plane(i, n, d);
-        float da = dot(n, from) - d, db = dot(n, to) - d;
+        V3 n, origin; world_plane_body(i, n, origin);
+        const V3 lf = from - origin, lt = to - origin;
+        const float da = dot(n, lf), db = dot(n, lt);
         if (da * db >= 0.f) continue;
-        float f = da / (da - db);
-        if (f < best.frac) { best.frac = f; best.kind = 0; best.normal = (da <= 0.f) ? -n : n; }
+        const V3 bmin = v3(fminf(lf.x, lt.x), fminf(lf.y, lt.y), fminf(lf.z, lt.z)), bmax = v3(fmaxf(lf.x, lt.x), fmaxf(lf.y, lt.y), fmaxf(lf.z, lt.z));
+        const V3 half = (bmax - bmin) * 0.5f;
+        const float radius = len(half);
+        const V3 center = (bmax + bmin) * 0.5f;
+        V3 t0, t1; plane_space1(n, t0, t1);
+        const V3 pc = center - n * (dot(n, center) - 0.f);
+        const V3 a0 = t0 * radius, a1 = t1 * radius;
+        const V3 ppp = (pc + a0) + a1, ppm = (pc + a0) - a1, pmm = (pc - a0) - a1, pmp = (pc - a0) + a1;
+        ray_triangle(ppp, ppm, pmm, lf, lt, best);
+        ray_triangle(pmm, pmp, ppp, lf, lt, best);
     }
     return best;
 }

@@ -115,6 +115,17 @@ RLG_HD M3 operator*(const M3& a, const M3& b) {
     return m3_rows(v3(dot(a.r0, c0), dot(a.r0, c1), dot(a.r0, c2)), v3(dot(a.r1, c0), dot(a.r1, c1), dot(a.r1, c2)),
                    v3(dot(a.r2, c0), dot(a.r2, c1), dot(a.r2, c2)));
 }
+// btMatrix3x3::inverse (btMatrix3x3.h:1093-1103): cofactors over the determinant
+RLG_HD M3 m3_inverse(const M3& m) {
+    const float e[3][3] = {{m.r0.x, m.r0.y, m.r0.z}, {m.r1.x, m.r1.y, m.r1.z}, {m.r2.x, m.r2.y, m.r2.z}};
+    auto cofac = [&](int r1, int c1, int r2, int c2) { return e[r1][c1] * e[r2][c2] - e[r1][c2] * e[r2][c1]; };
+    const V3 co = v3(cofac(1, 1, 2, 2), cofac(1, 2, 2, 0), cofac(1, 0, 2, 1));
+    const float det = dot(m.r0, co);
+    const float s = 1.0f / det;
+    return m3_rows(v3(co.x * s, cofac(0, 2, 2, 1) * s, cofac(0, 1, 1, 2) * s),
+                   v3(co.y * s, cofac(0, 0, 2, 2) * s, cofac(0, 2, 1, 0) * s),
+                   v3(co.z * s, cofac(0, 1, 2, 0) * s, cofac(0, 0, 1, 1) * s));
+}
 // btMatrix3x3::scaled(s): column i scaled by s[i]
 RLG_HD M3 scaled_cols(const M3& m, V3 s) { return m3_rows(m.r0 * s, m.r1 * s, m.r2 * s); }
 

@@ -268,6 +268,7 @@ def main():
         a = ref.arena(nc // 2)
         ref.set_state(a, s0)
         start = ref.get_state(a)
+        pair_arena = ref.arena(nc // 2)   # one-tick pairs are stepped from the RECORDED state (set_state) in an arena of their own
         tape = np.zeros((ticks, nc, 8), np.float32)
         rec = []
         for t in range(ticks):
@@ -279,7 +280,15 @@ def main():
             after = ref.get_state(a)
             # one-step pairs: every tick on which the reference's narrowphase produced a contact, and every 16th tick
             if ref.lib.ref_debug_manifolds(a, mbuf.ctypes.data_as(C.c_void_p), 64) > 0 or t % 16 == 0:
-                steps_before[nc].append(np.frombuffer(bytes(before), np.uint8).copy()); steps_after[nc].append(np.frombuffer(bytes(after), np.uint8).copy())
+                # The free-running arena above never leaves Bullet units; a state read from it is rounded to uu and back once more than
+                # its own next tick sees.  So the pair's "after" is what the reference computes FROM the recorded "before": both sides of
+                # the comparison then start from the same bits (grounded cars and a flying ball come out bit-equal that way).
+                ref.set_state(pair_arena, before)
+                for k in range(nc):
+                    ref.set_controls(pair_arena, k, list(tape[t, k]))
+                ref.step(pair_arena, 1)
+                after_pair = ref.get_state(pair_arena)
+                steps_before[nc].append(np.frombuffer(bytes(before), np.uint8).copy()); steps_after[nc].append(np.frombuffer(bytes(after_pair), np.uint8).copy())
                 steps_tag[nc].append((si, t))
             if (t + 1) % every == 0:
                 rec.append(state_vec(after))
@@ -287,7 +296,7 @@ def main():
         out[f"phys/{name}/tape"] = tape
         out[f"phys/{name}/states"] = np.stack(rec)
         names.append(name)
-        ref.lib.ref_arena_free(a)
+        ref.lib.ref_arena_free(a); ref.lib.ref_arena_free(pair_arena)
     out["phys_names"] = np.array(names)
     out["phys_every"] = every
 
