@@ -128,6 +128,11 @@ int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
 
 /* Arena::Step(ticks) on the resident states with the controls stored in them (RS/Sim/Arena/Arena.cpp:716-812) */
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
+/* Car::controls of every car of every env from a host array [n_envs][2 * team_size][8] (throttle, steer, pitch, yaw, roll, jump, boost,
+   handbrake: CarControls.h:6-24), nothing else touched: what `car->controls = c` does on the reference's Arena between Step calls.  The
+   resident state is not rounded to uu and back (a download / upload pair would), so a tape of controls run this way through
+   rlgpu_env_physics_ticks is the reference's free-running arena tick for tick. */
+int rlgpu_env_set_controls(rlgpu_env* e, const float* controls_host);
 int rlgpu_env_sync(rlgpu_env* e);
 /* last rlgpu_env_step kernel duration in ms, measured with hipEvents on the context stream (bench.py roofline) */
 /* Timing is opt-in (bench, profiling tools): without it the step / collect launches are not bracketed by events at all */

@@ -37,9 +37,30 @@ void step_t(RlgpuArenaState* s, int ticks, uint32_t seed, uint32_t env) {
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, seed, env, ev, W); }
     arena_to_host(A, G, *s);
 }
+// a whole control tape without leaving the stepper's own units: the state is converted once, every tick takes its controls from the tape
+// ([ticks][nc][8], the reference's CarControls order), and every `every`-th tick a copy is written out.  (port_arena_step tick by tick
+// rounds the state to uu and back between ticks, which the reference's free-running arena does not do.)
+template <int NC>
+void run_tape_t(RlgpuArenaState* s, const float* tape, int ticks, int every, RlgpuArenaState* out) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    int n_out = 0;
+    for (int t = 0; t < ticks; t++) {
+        for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(tape + ((size_t)t * NC + k) * 8);
+        TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
+        if (out && (t + 1) % every == 0) { out[n_out] = *s; arena_to_host(A, G, out[n_out]); n_out++; }
+    }
+    arena_to_host(A, G, *s);
+}
 }  // namespace
 
 extern "C" {
+
+void port_run_tape(RlgpuArenaState* s, const float* tape, int ticks, int every, RlgpuArenaState* out) {
+    if (s->num_cars == 2) run_tape_t<2>(s, tape, ticks, every, out); else if (s->num_cars == 4) run_tape_t<4>(s, tape, ticks, every, out); else run_tape_t<6>(s, tape, ticks, every, out);
+}
 
 int port_state_size() { return (int)sizeof(RlgpuArenaState); }
 

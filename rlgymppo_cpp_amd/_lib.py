@@ -83,6 +83,7 @@ SIGNATURES = {
     "rlgpu_env_step_stats": (_i, [_vp, _vp, _i]),
     "rlgpu_env_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rlgpu_env_physics_ticks": (_i, [_vp, _i]),
+    "rlgpu_env_set_controls": (_i, [_vp, _vp]),
     "rlgpu_env_sync": (_i, [_vp]),
     "rlgpu_env_last_step_ms": (_i, [_vp, C.POINTER(_f)]),
     "rlgpu_learner_create": (_i, [C.POINTER(_vp), _i, C.POINTER(LearnerConfigC)]),

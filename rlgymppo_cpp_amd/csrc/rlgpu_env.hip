@@ -816,6 +816,18 @@ __global__ void k_download(EnvDev d, RlgpuArenaState* dst, const int32_t* env_id
     arena_to_host(A, G, dst[i]);
 }
 
+// Car::controls of every car of every env (Arena facade: car->controls = ...), nothing else of the state touched: the resident words are
+// the stepper's own units, so unlike a download / upload pair this does not round anything
+template <int NC>
+__global__ void k_set_controls(EnvDev d, const float* ctl /*[n_envs][NC][8]*/) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.n_envs) return;
+    Arena<NC> A; GymEnv<NC> G;
+    load_env(d, env, A, G);
+    for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(ctl + ((size_t)env * NC + k) * 8);
+    store_env(d, env, A, G);
+}
+
 template <int NC>
 size_t count_words() {
     Arena<NC> A; GymEnv<NC> G; memset(&A, 0, sizeof(A)); memset(&G, 0, sizeof(G));
@@ -1222,6 +1234,20 @@ int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out
     return RLGPU_OK;
 }
 
+int rlgpu_env_set_controls(rlgpu_env* e, const float* controls_host) {
+    if (!controls_host) return RLGPU_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bytes = sizeof(float) * 8 * (size_t)e->nc * (size_t)e->n_envs;
+    float* dctl = nullptr;
+    HIPCHK(e, hipMalloc(&dctl, bytes));
+    HIPCHK(e, hipMemcpyAsync(dctl, controls_host, bytes, hipMemcpyHostToDevice, e->stream));
+    dim3 grid((e->n_envs + 63) / 64), block(64);
+    DISPATCH_NC(e, k_set_controls, grid, block, e->d, dctl);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipFree(dctl));
+    return RLGPU_OK;
+}
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
     HIPCHK(e, hipSetDevice(e->device));
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);

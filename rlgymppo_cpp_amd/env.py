@@ -148,6 +148,13 @@ class BatchedEnv:
     def reseed(self, seed_lo: int, seed_hi: int):
         _chk(self.lib.rlgpu_env_reseed(self.h, C.c_uint32(seed_lo & 0xffffffff), C.c_uint32(seed_hi & 0xffffffff)), self.h, self.lib.rlgpu_env_last_error)
 
+    def set_controls(self, controls):
+        """controls: float32 [n_envs, 2 * team_size, 8] (CarControls order); only the cars' controls change, the state is not rounded."""
+        import numpy as np
+        c = np.ascontiguousarray(controls, np.float32)
+        assert c.shape == (self.n_envs, 2 * self.team_size, 8), c.shape
+        _chk(self.lib.rlgpu_env_set_controls(self.h, c.ctypes.data), self.h, self.lib.rlgpu_env_last_error)
+
     def physics_ticks(self, ticks: int):
         _chk(self.lib.rlgpu_env_physics_ticks(self.h, ticks), self.h, self.lib.rlgpu_env_last_error)
 
