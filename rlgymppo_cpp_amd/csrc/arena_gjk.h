@@ -208,15 +208,17 @@ constexpr float GJK_REL_ERROR2 = 1.0e-6f;
 // One (hitbox, triangle) pair.  bc / R: the hitbox child's world transform; core: btBoxShape's implicit dimensions; margin_a: its
 // collision margin; the triangle has margin 0 (btConcaveShape.cpp:21) and sits in a body at the origin.  `breaking`: the manifold's
 // contact breaking threshold.  true: `out` is the point btManifoldResult::addContactPoint receives.
-RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_a, const MeshTri& t, float breaking, GjkOut& out, bool& deep) {
+// (shape B in general: up to three vertices t0..t2 in the frame of a body at origin_b, collision margin margin_b -- the mesh triangle
+// is (origin 0, margin 0), the ball's btSphereShape is the single point (0,0,0) with the radius as its margin, btSphereShape.h:41-52)
+RLG_HD bool gjk_box_convex(V3 bc, const M3& R, V3 core, float margin_a, V3 origin_b, V3 t0, V3 t1, V3 t2, float margin_b, float breaking, GjkOut& out, bool& deep) {
     deep = false;
-    const V3 offset = (bc + v3(0, 0, 0)) * 0.5f;                 // positionOffset
+    const V3 offset = (bc + origin_b) * 0.5f;                    // positionOffset
     GjkShapes sh;
-    sh.R = R; sh.core = core; sh.oa = bc - offset; sh.ob = v3(0, 0, 0) - offset;   // local origins
-    sh.t0 = v3(t.v0x, t.v0y, t.v0z); sh.t1 = v3(t.v1x, t.v1y, t.v1z); sh.t2 = v3(t.v2x, t.v2y, t.v2z);
+    sh.R = R; sh.core = core; sh.oa = bc - offset; sh.ob = origin_b - offset;   // local origins
+    sh.t0 = t0; sh.t1 = t1; sh.t2 = t2;
     const V3 oa = sh.oa, ob = sh.ob;
-    const float margin = margin_a + 0.f;
-    float max_d2 = margin_a + 0.f + breaking; max_d2 *= max_d2;    // btConvexConvexAlgorithm.cpp:313-317
+    const float margin = margin_a + margin_b;
+    float max_d2 = margin_a + margin_b + breaking; max_d2 *= max_d2;    // btConvexConvexAlgorithm.cpp:313-317
     V3 axis = v3(0, 1, 0);
     GjkSimplex s; s.n = 0; s.codes = 0u; s.needs_update = true; s.valid = false; s.degenerate = false;
     s.w0 = s.w1 = s.w2 = s.w3 = v3(0, 0, 0);
@@ -277,7 +279,7 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
             normal *= rlen;
             float sd = sqrtf(sq_dist);
             pa -= axis * (margin_a / sd);
-            pb += axis * (0.f / sd);
+            pb += axis * (margin_b / sd);
             distance = (1.f / rlen) - margin;
             valid = true;
         }
@@ -293,12 +295,20 @@ RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_
         V3 e = abs_rows_dot(R, v3(core.x + margin_a, core.y + margin_a, core.z + margin_a));
         V3 amin = oa - e, amax = oa + e;
         V3 pos_a = (amax + amin) * 0.5f;
-        V3 bmin = vmin(vmin(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob), bmax = vmax(vmax(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob);
+        V3 bmin = vmin(vmin(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob) - v3(margin_b, margin_b, margin_b), bmax = vmax(vmax(sh.t0 + ob, sh.t1 + ob), sh.t2 + ob) + v3(margin_b, margin_b, margin_b);
         V3 pos_b = (bmin + bmax) * 0.5f;
         if (dot(pos_a - pos_b, normal) < 0.f) normal *= -1.f;
     }
     out.n = normal; out.pb = pb + offset; out.dist = distance;
     return true;
+}
+
+// the two out-of-line instances (the general form is inlined into each: as a call its eighteen by-value floats would travel through the stack)
+RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_a, const MeshTri& t, float breaking, GjkOut& out, bool& deep) {
+    return gjk_box_convex(bc, R, core, margin_a, v3(0, 0, 0), v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), 0.f, breaking, out, deep);
+}
+RLG_HD_NOINLINE bool gjk_box_sphere(V3 bc, const M3& R, V3 core, float margin_a, V3 centre, float radius, float breaking, GjkOut& out, bool& deep) {
+    return gjk_box_convex(bc, R, core, margin_a, centre, v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), radius, breaking, out, deep);
 }
 
 }  // namespace rlg

@@ -341,10 +341,21 @@ RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>
                 car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = pn;
             }
             // car vs ball: the manifold's body0 is the car (arena_contact.h).  Its callback runs in collide_merge.
-            V3 pb, pn; float dist;
-            if (sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, pn, dist)) {
-                // as the reference's GJK reports it with A = box, B = sphere: normal on the ball, pointing at the car; the point on the ball
-                pn = -pn; pb = bp + pn * r;
+            // The pair goes through the same btGjkPairDetector as a hitbox against a triangle (btConvexConvexAlgorithm; the sphere-box
+            // algorithm is not registered, btDefaultCollisionConfiguration.cpp): A = the box, B = the ball's btSphereShape, a point whose margin
+            // is the radius.  Where the point gets inside the box core (never seen in play) the analytic form answers instead of EPA.
+            V3 pb, pn; float dist; bool have = false;
+            V3 sl, sh_, hl, hh;
+            sphere_shape_aabb(bp, sl, sh_); hitbox_shape_aabb(car.b.pos, car.b.rot, hl, hh);
+            if (aabb_touch(hl, hh, sl, sh_)) {   // the child shapes' boxes must touch before the pair's algorithm runs at all (btCompoundCollisionAlgorithm.cpp:333-358)
+                GjkOut g; bool deep = false;
+                if (gjk_box_sphere(bc, car.b.rot, hitbox_core(), BOX_MARGIN, bp, r, CBT_BALL, g, deep)) {
+                    if (!(g.dist > CBT_BALL)) { pn = g.n; pb = g.pb; dist = g.dist; have = true; }
+                } else if (deep && sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, pn, dist)) {
+                    pn = -pn; pb = bp + pn * r; have = true;   // normal on the ball, pointing at the car; the point on the ball
+                }
+            }
+            if (have) {
                 Contact& c = L.c[car_ball_slot(ci)];
                 manifold_point_dynamic(c, car.b, A.ball.b, pn, pb, dist);
                 c.a = (int8_t)(1 + ci); c.b = 0; c.sid = 0; c.special = 0;

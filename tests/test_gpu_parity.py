@@ -285,8 +285,8 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
 def test_hip_physics_free_run_vs_reference_fixtures(sg):
     """The 31 physics scenarios stepped by the HIP kernel from the reference's start state under the recorded control tape and compared
     with the REFERENCE's states every 10 ticks -- position, velocity, angular velocity, rotation of the ball and every car, flags of
-    every car exactly -- with no re-sync to anything (tolerances and the four horizons: simlib.PHYS_FREE_RUN, 1.5x for the device's
-    own libm)."""
+    every car exactly -- with no re-sync to anything (tolerances and the three horizons: simlib.PHYS_FREE_RUN; the 1v1 tapes that are
+    bit-identical to the reference are asserted so in test_hip_free_run_is_bit_identical_to_the_reference)."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from simlib import PHYS_FREE_RUN, state_vec, phys_errors
     every = int(sg["phys_every"])
@@ -300,13 +300,12 @@ def test_hip_physics_free_run_vs_reference_fixtures(sg):
         tapes = [sg[f"phys/{n}/tape"] for n in grp]
         T = max(len(t) for t in tapes)
         env.upload_states(cur)
+        ctl = np.zeros((len(grp), nc, 8), np.float32)
         for t in range(T):
-            cur = env.download_states()
             for i in range(len(grp)):
                 if t < len(tapes[i]):
-                    for k in range(nc):
-                        cur[i].cars[k].controls[:] = list(tapes[i][t, k])
-            env.upload_states(cur)          # only the controls changed: the exchange layout round-trips exactly (test_upload_download_roundtrip)
+                    ctl[i] = tapes[i][t]
+            env.set_controls(ctl)           # only the controls change; the resident state is not rounded to uu and back between ticks
             env.physics_ticks(1)
             if (t + 1) % every == 0:
                 got = env.download_states()
