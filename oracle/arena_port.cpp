@@ -240,6 +240,31 @@ static void debug_wheels_t(RlgpuArenaState* s, int slot, float* out) {
 extern "C" void port_debug_wheels(RlgpuArenaState* s, int slot, float* out) {
     if (s->num_cars == 2) debug_wheels_t<2>(s, slot, out); else if (s->num_cars == 4) debug_wheels_t<4>(s, slot, out); else debug_wheels_t<6>(s, slot, out);
 }
+// friction rows of the tick's contacts in solver order: 8 floats = friction direction[3], applied friction impulse, friction coefficient, 0, applied normal impulse, 0
+template <int NC>
+static int debug_friction_t(RlgpuArenaState* s, float* out, int cap) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    TickEvents ev; ev.bump_mask = 0;
+    arena_tick(A, mv, 0, 0, ev, W);
+    int n = 0;
+    for (int k = 0; k < W.L.n && n < cap; k++) {
+        float* o = out + 8 * n++;
+        const int fr = W.frow[k], nr = W.nrow[k];
+        for (int q = 0; q < 8; q++) o[q] = 0.f;
+        if (fr >= 0) { o[0] = W.R[fr].n1.x; o[1] = W.R[fr].n1.y; o[2] = W.R[fr].n1.z; o[3] = W.R[fr].applied; o[4] = W.R[fr].friction; }
+        if (nr >= 0) o[6] = W.R[nr].applied;
+    }
+    return n;
+}
+extern "C" int port_debug_friction(RlgpuArenaState* s, float* out, int cap) {
+    RlgpuArenaState c = *s;
+    if (c.num_cars == 2) return debug_friction_t<2>(&c, out, cap);
+    if (c.num_cars == 4) return debug_friction_t<4>(&c, out, cap);
+    return debug_friction_t<6>(&c, out, cap);
+}
 extern "C" int port_debug_tick(RlgpuArenaState* s, float* out, int cap) {
     if (s->num_cars == 2) return debug_tick_t<2>(s, out, cap);
     if (s->num_cars == 4) return debug_tick_t<4>(s, out, cap);

@@ -506,6 +506,24 @@ extern "C" int ref_debug_manifolds(void* h, float* out, int cap_points) {
     return n;
 }
 
+// friction side of the same points, in the same order: 8 floats = lateralFrictionDir1[3], appliedImpulseLateral1, combinedFriction, combinedRestitution, appliedImpulse, 0
+extern "C" int ref_debug_manifold_friction(void* h, float* out, int cap_points) {
+    Arena* a = (Arena*)h;
+    btCollisionDispatcher* d = (btCollisionDispatcher*)a->_bulletWorld.getDispatcher();
+    int n = 0;
+    for (int m = 0; m < d->getNumManifolds(); m++) {
+        btPersistentManifold* pm = d->getManifoldByIndexInternal(m);
+        for (int p = 0; p < pm->getNumContacts() && n < cap_points; p++) {
+            const btManifoldPoint& cp = pm->getContactPoint(p);
+            float* o = out + n * 8;
+            for (int k = 0; k < 3; k++) o[k] = cp.m_lateralFrictionDir1[k];
+            o[3] = cp.m_appliedImpulseLateral1; o[4] = cp.m_combinedFriction; o[5] = cp.m_combinedRestitution; o[6] = cp.m_appliedImpulse; o[7] = 0.f;
+            n++;
+        }
+    }
+    return n;
+}
+
 // every manifold of the dispatcher in array order, points or not: 4 floats each = body0 kind, body1 kind, contacts, island tag of body0
 extern "C" int ref_debug_manifold_list(void* h, float* out, int cap) {
     Arena* a = (Arena*)h;

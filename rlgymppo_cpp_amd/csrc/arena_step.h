@@ -446,6 +446,9 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
 // One Gauss-Seidel row update.  The row's constants and both bodies' deltas are read into locals FIRST and written back LAST: the
 // row and the bodies are all floats in LDS, so with the stores in between the compiler had to assume they alias and re-read the
 // bodies after storing the accumulated impulse -- a second LDS round trip on the dependent chain of the solve.  (Same arithmetic.)
+// the row solvers are the reference's SSE2 variants (btSequentialImpulseConstraintSolver.cpp:102-110,149-176,207-232,317-349; SOLVER_SIMD is
+// on): their three-term dot product adds x to (y + z), not (x + y) to z
+RLG_HD float sdot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 template <int NB>
 RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
     SolverBody& A = B[c.a];
@@ -457,8 +460,8 @@ RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lo
     V3 b_dv = v3(0, 0, 0), b_dw = v3(0, 0, 0); float b_im = 0.f;
     if (b >= 0) { b_dv = Bb.dv; b_dw = Bb.dw; b_im = Bb.inv_m; }
     float delta = c.rhs;
-    float dv1 = dot(n1, a_dv) + dot(r1xn, a_dw);
-    float dv2 = (b >= 0) ? (dot(-n1, b_dv) + dot(r2xn, b_dw)) : 0.f;
+    float dv1 = sdot3(n1, a_dv) + sdot3(r1xn, a_dw);
+    float dv2 = (b >= 0) ? (sdot3(-n1, b_dv) + sdot3(r2xn, b_dw)) : 0.f;
     delta -= dv1 * jac;
     delta -= dv2 * jac;
     float sum = applied + delta, now;
@@ -481,8 +484,8 @@ RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
     V3 b_p = v3(0, 0, 0), b_t = v3(0, 0, 0); float b_im = 0.f;
     if (b >= 0) { b_p = Bb.push; b_t = Bb.turn; b_im = Bb.inv_m; }
     float delta = c.rhs_pen;
-    float dv1 = dot(n1, a_p) + dot(r1xn, a_t);
-    float dv2 = (b >= 0) ? (dot(-n1, b_p) + dot(r2xn, b_t)) : 0.f;
+    float dv1 = sdot3(n1, a_p) + sdot3(r1xn, a_t);
+    float dv2 = (b >= 0) ? (sdot3(-n1, b_p) + sdot3(r2xn, b_t)) : 0.f;
     delta -= dv1 * jac;
     delta -= dv2 * jac;
     float sum = applied + delta, now;

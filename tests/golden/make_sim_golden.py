@@ -293,6 +293,7 @@ def main():
             if (t + 1) % every == 0:
                 rec.append(state_vec(after))
         out[f"phys/{name}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        out[f"phys/{name}/start_raw"] = np.frombuffer(bytes(s0), np.uint8).copy()   # what set_state was given: `start` is that state read back (once through Bullet units)
         out[f"phys/{name}/tape"] = tape
         out[f"phys/{name}/states"] = np.stack(rec)
         names.append(name)

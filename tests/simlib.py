@@ -224,6 +224,15 @@ PHYS_FREE_RUN = {
     "ball_pinch_back_wall": _tol(2.0, 4.0, 0.05, 0.01), "ball_on_roof": _tol(0.05, 0.05, 1e-3, 1e-4), "aerial_hit": _tol(0.03, 0.05, 1e-3, 1e-4),
     "2v2_ball_chase": _tol(0.15, 0.1, 2e-3, 1e-4), "3v3_kickoff": _tol(0.1, 0.1, 1e-3, 1e-4, until=230),
 }
+# Ticks for which a free run (inside the stepper's units, from the state the reference's set_state was given: phys/<name>/start_raw) is
+# BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed: their whole length.  What ends the
+# five: ball_corner_fillets -- a ball contact on a fillet edge at tick 41 (1e-4 uu apart afterwards); car_into_goal -- a 12 uu deep
+# contact at tick 163 (EPA); car_into_side_wall -- the last ten ticks; demo_and_respawn -- the ball on the crossbar edge at tick 445;
+# 3v3_kickoff -- the six-car heap from tick 282 on.
+PHYS_EXACT_UNTIL = {"ball_corner_fillets": 40, "car_into_goal": 160, "car_into_side_wall": 290, "demo_and_respawn": 440, "3v3_kickoff": 280}
+# ... and how close the five stay after that, until the given tick (pos uu, vel uu/s, ang rad/s, rot)
+PHYS_AFTER_EXACT = {"ball_corner_fillets": (400, (1e-3, 1e-3, 1e-5, 1e-6)), "demo_and_respawn": (600, (0.2, 1.5, 0.02, 5e-3))}
+
 # One tick from the reference's own state: 98 % of the 1721 recorded pairs agree to 0.01 uu/s (median 2e-5).
 ONE_TICK_TOL = {
     "default": {"pos": 0.1, "vel": 0.15},                               # pos: a mesh contact deeper than the hitbox margin is pushed out along the

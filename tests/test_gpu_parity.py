@@ -62,39 +62,37 @@ def test_upload_download_roundtrip():
 
 
 def test_hip_free_run_is_bit_identical_to_the_reference(sg):
-    """The HIP stepper against the REFERENCE's recorded trajectories, directly: every 1v1 tape runs as one env of a batch, the controls
-    of the tape go in through rlgpu_env_set_controls (nothing else of the resident state is touched or rounded) and every 10 ticks the
-    states are downloaded and compared with the reference's for EQUALITY of every field of every body -- the seventeen tapes
-    test_oracle_golden.py::test_port_free_run_is_bit_identical_to_the_reference lists, over their whole length (car_into_side_wall 290
-    ticks, car_into_goal 160)."""
+    """The HIP stepper against the REFERENCE's recorded trajectories, directly: every tape runs as one env of a batch (1v1, 2v2, 3v3), the
+    controls of the tape go in through rlgpu_env_set_controls (nothing else of the resident state is touched or rounded) and every 10 ticks
+    the states are downloaded and compared with the reference's for EQUALITY of every field of every body: 26 of the 31 tapes over their
+    whole length (up to 600 ticks), the other five up to simlib.PHYS_EXACT_UNTIL."""
     from rlgymppo_cpp_amd.env import BatchedEnv
-    from simlib import state_vec
-    EXACT_UNTIL = {"rest": None, "throttle": None, "steer_powerslide": None, "jump": None, "flip": None, "double_jump": None, "boost_turn": None,
-                   "ball_drop": None, "ball_roll": None, "ball_side_wall": None, "ball_back_wall_mesh": None, "ball_into_goal": None,
-                   "air_control": None, "wall_ramp": None, "boost_pad_pickup": None, "car_into_back_wall": None, "car_into_corner_wall": None,
-                   "car_into_side_wall": 290, "car_into_goal": 160}
-    names = [n for n in EXACT_UNTIL if ArenaState.from_buffer_copy(sg[f"phys/{n}/start"].tobytes()).num_cars == 2]
-    assert len(names) == len(EXACT_UNTIL)
+    from simlib import state_vec, PHYS_EXACT_UNTIL
     every = int(sg["phys_every"])
-    env = BatchedEnv(len(names), 1, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
-    env.upload_states([ArenaState.from_buffer_copy(sg[f"phys/{n}/start"].tobytes()) for n in names])
-    tapes = [sg[f"phys/{n}/tape"] for n in names]
-    T = max(len(t) for t in tapes)
-    ctl = np.zeros((len(names), 2, 8), np.float32)
+    names = [str(n) for n in sg["phys_names"]]
     compared = 0
-    for t in range(T):
-        for i, tp in enumerate(tapes):
-            if t < len(tp):
-                ctl[i] = tp[t]
-        env.set_controls(ctl)
-        env.physics_ticks(1)
-        if (t + 1) % every == 0:
-            cur = env.download_states()
-            for i, n in enumerate(names):
-                lim = EXACT_UNTIL[n] or len(tapes[i])
-                if t + 1 <= min(lim, len(tapes[i])):
-                    assert np.array_equal(state_vec(cur[i]), sg[f"phys/{n}/states"][(t + 1) // every - 1]), f"{n} tick {t + 1}: HIP state is not the reference's"
-                    compared += every
+    for nc in (2, 4, 6):
+        grp = [n for n in names if ArenaState.from_buffer_copy(sg[f"phys/{n}/start_raw"].tobytes()).num_cars == nc]
+        if not grp:
+            continue
+        env = BatchedEnv(len(grp), nc // 2, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+        env.upload_states([ArenaState.from_buffer_copy(sg[f"phys/{n}/start_raw"].tobytes()) for n in grp])
+        tapes = [sg[f"phys/{n}/tape"] for n in grp]
+        T = max(len(t) for t in tapes)
+        ctl = np.zeros((len(grp), nc, 8), np.float32)
+        for t in range(T):
+            for i, tp in enumerate(tapes):
+                if t < len(tp):
+                    ctl[i] = tp[t]
+            env.set_controls(ctl)
+            env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states()
+                for i, n in enumerate(grp):
+                    if t + 1 <= min(PHYS_EXACT_UNTIL.get(n, len(tapes[i])), len(tapes[i])):
+                        assert np.array_equal(state_vec(cur[i]), sg[f"phys/{n}/states"][(t + 1) // every - 1]), f"{n} tick {t + 1}: HIP state is not the reference's"
+                        compared += every
+        env.close()
     print("HIP free-run ticks bit-identical to the reference:", compared)
 
 

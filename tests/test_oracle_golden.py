@@ -169,59 +169,51 @@ def test_port_physics_vs_reference_golden(sg, port_lib):
 
 
 def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
-    """The same 31 tapes, run inside the stepper's own units from the start state to the end (port_run_tape: no rounding to uu and back
-    between ticks, exactly like the reference's free-running arena) and compared with the reference's recorded trajectory every 10 ticks
-    for EQUALITY of every field of every body: seventeen tapes -- up to 600 ticks of resting, driving, powersliding, boosting, jumping,
-    flipping, air control, wall riding, pad pick-ups, ball flight / rolling / wall, fillet-free mesh and goal bounces, a car driving
-    into the back wall and into a corner -- are bit-identical to the reference over their whole length, car_into_side_wall for 290 of
-    its 300 ticks, car_into_goal for 160 (then a 12 uu deep contact goes through the reference's EPA); the rest (car-ball, car-car,
-    tumbling, demolition, 2v2, 3v3) stay within the tolerances below, 10 to 1000 times tighter than the tick-by-tick table."""
+    """The 31 tapes run inside the stepper's own units from the state the reference's set_state was given to the end (port_run_tape: no
+    rounding to uu and back between ticks, exactly like the reference's free-running arena) and compared with the reference's recorded
+    trajectory every 10 ticks for EQUALITY of every field of every body: 26 tapes -- up to 600 ticks of driving, jumping, flipping, air
+    control, wall riding, ball flight / rolling / wall and goal bounces, car-ball hits, aerials, a roof landing with auto-flip, tumbling
+    drops, a car into the back wall / a corner, car-car head-on and side bumps, a ball pinch, 2v2 -- are bit-identical to the reference
+    over their whole length, the other five up to simlib.PHYS_EXACT_UNTIL (3v3: 280 ticks)."""
     import ctypes as C
+    from simlib import PHYS_EXACT_UNTIL, PHYS_AFTER_EXACT
     every = int(sg["phys_every"])
     port_lib.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    EXACT_UNTIL = {"rest": None, "throttle": None, "steer_powerslide": None, "jump": None, "flip": None, "double_jump": None, "boost_turn": None,
-                   "ball_drop": None, "ball_roll": None, "ball_side_wall": None, "ball_back_wall_mesh": None, "ball_into_goal": None,
-                   "air_control": None, "wall_ramp": None, "boost_pad_pickup": None, "car_into_back_wall": None, "car_into_corner_wall": None,
-                   "car_into_side_wall": 290, "car_into_goal": 160}
-    # (pos uu, vel uu/s, ang rad/s, rot) for the others, over the whole tape (3v3_kickoff: 230 ticks, the six-car heap)
-    TOL = {"car_hits_ball": (2e-3, 2e-3, 1e-4, 1e-5), "ball_corner_fillets": (1e-3, 1e-3, 1e-5, 1e-6), "car_car_head_on": (0.02, 0.03, 1e-4, 5e-5),
-           "roof_landing_autoflip": (0.01, 5e-3, 1e-4, 1e-5), "tumbling_drops": (5e-3, 0.01, 2e-4, 3e-5), "demo_and_respawn": (0.2, 1.5, 0.02, 5e-3),
-           "side_bump": (0.01, 0.02, 1e-3, 1e-4), "ball_pinch_back_wall": (0.2, 0.5, 0.02, 5e-3), "ball_on_roof": (1e-3, 1e-3, 1e-5, 1e-6),
-           "aerial_hit": (3e-3, 5e-3, 1e-4, 1e-5), "2v2_ball_chase": (2e-3, 2e-3, 1e-5, 1e-6), "3v3_kickoff": (5e-3, 5e-3, 1e-4, 1e-5)}
-    n_exact_ticks = 0
+    n_exact_ticks = 0; whole = 0
     for name in [str(x) for x in sg["phys_names"]]:
-        st = ArenaState.from_buffer_copy(sg[f"phys/{name}/start"].tobytes()); nc = st.num_cars
+        st = ArenaState.from_buffer_copy(sg[f"phys/{name}/start_raw"].tobytes()); nc = st.num_cars
         tape = np.ascontiguousarray(sg[f"phys/{name}/tape"], np.float32); want = sg[f"phys/{name}/states"]
         outs = (ArenaState * (len(tape) // every))()
         port_lib.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+        lim = PHYS_EXACT_UNTIL.get(name, len(tape)); whole += name not in PHYS_EXACT_UNTIL
         for j in range(len(tape) // every):
             t = (j + 1) * every
             got = state_vec(outs[j])
-            if name in EXACT_UNTIL:
-                if EXACT_UNTIL[name] is None or t <= EXACT_UNTIL[name]:
-                    assert np.array_equal(got, want[j]), f"{name} tick {t}: not bit-identical to the reference"
-                    n_exact_ticks += every
-            elif t <= {"3v3_kickoff": 230, "demo_and_respawn": 600}.get(name, 10 ** 9):   # (the six-car heap; the last sample after the second demolition)
+            if t <= lim:
+                assert np.array_equal(got, want[j]), f"{name} tick {t}: not bit-identical to the reference"
+                n_exact_ticks += every
+            elif name in PHYS_AFTER_EXACT and t <= PHYS_AFTER_EXACT[name][0]:
                 pos, vel, ang, rot, flags_differ = phys_errors(got, want[j], nc)
-                tp, tv, ta, tr = TOL[name]
-                assert pos <= tp and vel <= tv and ang <= ta and rot <= tr and not flags_differ, \
-                    f"{name} tick {t}: pos {pos:.5f} vel {vel:.5f} ang {ang:.6f} rot {rot:.7f} flags {flags_differ} (tol {TOL[name]})"
-    print("free-run ticks bit-identical to the reference:", n_exact_ticks)
+                tp, tv, ta, tr = PHYS_AFTER_EXACT[name][1]
+                assert pos <= tp and vel <= tv and ang <= ta and rot <= tr and not flags_differ, f"{name} tick {t}: pos {pos:.5f} vel {vel:.5f} ang {ang:.6f} rot {rot:.7f}"
+    assert whole == 26
+    print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 5 partial")
 
 
 def test_port_one_tick_vs_reference_states():
     """1722 (state, state one tick later) pairs recorded from the reference -- every tick with a narrowphase contact and every 16th
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),
     so both sides start from the same bits.  Since the restatement follows the reference's x86 arithmetic (rl_math.h, rl_libm.h, the
-    planes' ray triangles, the numeric inertia inverse) most pairs are EQUAL bit for bit -- every grounded, flying, jumping, flipping
-    car and every ball tick without a deep or multi-body contact; asserted: at least 80 % of all pairs, and every pair of the
-    scenarios listed in EXACT."""
+    planes' ray triangles, the numeric inertia inverse, the SSE2 row solver's dot products, the ball through GJK) nearly all pairs are
+    EQUAL bit for bit; asserted: at least 93 % of all pairs, and every pair of the 25 scenarios listed in EXACT (what is left: the
+    six-car heap of 3v3_kickoff, contacts 10+ uu deep -- EPA --, two ball contacts on fillet / wall edges)."""
     from simlib import PortSim
     sgl = np.load(os.path.join(GOLD, "sim_golden.npz")); ss = np.load(os.path.join(GOLD, "sim_steps.npz"))
     port = PortSim(); port.set_mesh(sgl["mesh_verts"], sgl["mesh_tris"])
     names = [str(x) for x in ss["phys_names"]]
-    EXACT = {"rest", "throttle", "steer_powerslide", "jump", "flip", "double_jump", "boost_turn", "ball_drop", "ball_roll", "ball_side_wall",
-             "ball_into_goal", "air_control", "wall_ramp", "boost_pad_pickup", "car_into_back_wall"}
+    EXACT = {"2v2_ball_chase", "aerial_hit", "air_control", "ball_drop", "ball_into_goal", "ball_on_roof", "ball_pinch_back_wall", "ball_roll",
+             "ball_side_wall", "boost_pad_pickup", "boost_turn", "car_car_head_on", "car_hits_ball", "car_into_back_wall", "car_into_corner_wall",
+             "double_jump", "flip", "jump", "rest", "roof_landing_autoflip", "side_bump", "steer_powerslide", "throttle", "tumbling_drops", "wall_ramp"}
     n_tight = n_all = n_exact = 0
     for nc in (2, 4, 6):
         B, A, T = ss[f"nc{nc}/before"], ss[f"nc{nc}/after"], ss[f"nc{nc}/tag"]
@@ -236,7 +228,7 @@ def test_port_one_tick_vs_reference_states():
             assert exact or names[T[i][0]] not in EXACT, f"{names[T[i][0]]} tick {T[i][1]}: not bit-equal to the reference (pos {pos:.3g} vel {vel:.3g})"
             n_all += 1; n_tight += (vel <= 0.01 and pos <= 0.002); n_exact += exact
     assert n_tight >= 0.95 * n_all, f"only {n_tight} of {n_all} one-tick pairs within 0.01 uu/s"
-    assert n_exact >= 0.80 * n_all, f"only {n_exact} of {n_all} one-tick pairs bit-equal to the reference"
+    assert n_exact >= 0.93 * n_all, f"only {n_exact} of {n_all} one-tick pairs bit-equal to the reference"
     print(f"one-tick pairs: {n_exact} of {n_all} bit-equal to the reference, {n_tight} within 0.01 uu/s")
 
 
