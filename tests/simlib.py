@@ -200,17 +200,14 @@ def _tol(pos, vel, ang, rot, until=None):
     return {"pos": pos, "vel": vel, "ang": ang, "rot": rot, "until": until}
 
 
-# Free-run tolerances (uu, uu/s, rad/s, rotation-matrix entries) over the WHOLE tape unless `until` is given.  Measured port-vs-reference
-# deviations (tools/diff_ref_port.py) are 3-10x below these.  The restatement follows the reference's x86 arithmetic down to its
-# rsqrtss-based normalize and the SSE summation orders of its quaternion / matrix code (rl_math.h), and the narrowphase routines are
-# bit-identical to Bullet's on fuzzed inputs; what is still not the reference's to the bit is the suspension raycast (the reference
-# switches between an analytic plane hit and Bullet's ray-triangle test by grid cell, SuspensionCollisionGrid.cpp:124-175) and EPA, so
-# a trajectory that passes through a contact decision at the contact threshold leaves the reference eventually: the three tapes with
-# `until` do so after the given tick (one-tick agreement still holds, see ONE_TICK_TOL) -- car_into_goal: at tick 163 / 166 a contact
-# 12 uu deep goes through the reference's EPA; car_into_side_wall: bit-identical for 290 of its 300 ticks (run inside the stepper's units; with a uu round trip per tick a contact at the 2 uu threshold appeared one tick apart at tick 127);
-# 3v3_kickoff: six cars in one heap (pair order in the reference's broadphase cell lists is history dependent).  demo_and_respawn,
-# which used to leave at tick 370 (a ball contact on the crossbar edge decided on the sign of a 1e-8 dot product), now holds for 600 of
-# its 620 ticks.
+# Free-run tolerances (uu, uu/s, rad/s, rotation-matrix entries) over the WHOLE tape unless `until` is given: the loose table, kept for
+# runs that start from the state READ BACK from the reference (phys/<name>/start: once through Bullet units) -- the exact statement is
+# PHYS_EXACT_UNTIL below, for runs from the state set_state was given.  The restatement follows the reference's x86 arithmetic down to its
+# rsqrtss-based normalize, the SSE summation orders of its quaternion / matrix code and of its row solver (rl_math.h, arena_step.h), and
+# the narrowphase routines are bit-identical to Bullet's on fuzzed inputs; what is not the reference's to the bit is EPA (contacts 10+ uu
+# deep), so a trajectory that passes through such a contact leaves the reference: car_into_goal at tick 163; car_into_side_wall in its
+# last ten ticks; 3v3_kickoff in the six-car heap; demo_and_respawn (which used to leave at tick 370: a ball contact on the crossbar edge
+# decided on the sign of a 1e-8 dot product) holds for 600 of its 620 ticks.
 PHYS_FREE_RUN = {
     "rest": _tol(0.005, 0.005, 1e-4, 1e-5), "throttle": _tol(0.01, 0.02, 1e-4, 1e-5), "steer_powerslide": _tol(0.03, 0.02, 1e-3, 1e-4),
     "jump": _tol(0.01, 0.05, 1e-3, 1e-4), "flip": _tol(0.02, 0.02, 1e-3, 1e-4), "double_jump": _tol(0.02, 0.05, 1e-3, 1e-4),
