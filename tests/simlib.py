@@ -247,6 +247,11 @@ GYM_OBS_TOL = {
 }
 
 
+# gym rollouts of the reference that the HIP gym reproduces EXACTLY (resident state, no uu round trip between steps): every observation
+# row and every reward bit-equal, dones and counters equal (tools/gym_fixture_errors.py; the other two: the padded-obs random 2v2 rollout
+# is within 1e-4, the random 3v3 one within 2e-3 -- car-car heaps)
+GYM_EXACT = {"ts8_random", "ts8_chase", "ts1_random", "1v1_timeout", "1v1_goal", "2v2_goal_assist_allterms", "2v2_shot_save_demo_zerosum"}
+
 # steps up to which a free-running gym rollout is compared (random actions with hitbox contacts: chaotic afterwards, like PHYS_FREE_RUN's `until`)
 GYM_HORIZON = {"2v2_padded3_zerosum_random": 64}
 
