@@ -602,7 +602,7 @@ RLG_HD_NOINLINE bool sphere_triangle(V3 c, float radius, float thresh, const Mes
     if (!(ds < rwt * rwt)) return false;
     if (ds > SIMD_EPS) {
         float d = sqrtf(ds);
-        normal = vdiv_bt(ctc, d);  // btVector3::normalize
+        normal = normalized(ctc);   // resultNormal.normalize() (SphereTriangleDetector.cpp:227-228): the SSE normalise, not a division by d
         point = cp; depth = -(radius - d);
     } else { normal = n; point = cp; depth = -radius; }
     return true;

@@ -222,13 +222,12 @@ PHYS_FREE_RUN = {
     "2v2_ball_chase": _tol(0.15, 0.1, 2e-3, 1e-4), "3v3_kickoff": _tol(0.1, 0.1, 1e-3, 1e-4, until=230),
 }
 # Ticks for which a free run (inside the stepper's units, from the state the reference's set_state was given: phys/<name>/start_raw) is
-# BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed: their whole length.  What ends the
-# five: ball_corner_fillets -- a ball contact on a fillet edge at tick 41 (1e-4 uu apart afterwards); car_into_goal -- a 12 uu deep
-# contact at tick 163 (EPA); car_into_side_wall -- the last ten ticks; demo_and_respawn -- the ball on the crossbar edge at tick 445;
-# 3v3_kickoff -- the six-car heap from tick 282 on.
-PHYS_EXACT_UNTIL = {"ball_corner_fillets": 40, "car_into_goal": 160, "car_into_side_wall": 290, "demo_and_respawn": 440, "3v3_kickoff": 280}
-# ... and how close the five stay after that, until the given tick (pos uu, vel uu/s, ang rad/s, rot)
-PHYS_AFTER_EXACT = {"ball_corner_fillets": (400, (1e-3, 1e-3, 1e-5, 1e-6)), "demo_and_respawn": (600, (0.2, 1.5, 0.02, 5e-3))}
+# BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed (27 of the 31): their whole length.
+# What ends the four: car_into_goal -- a 12 uu deep contact at tick 163 (EPA); car_into_side_wall -- the last ten ticks;
+# demo_and_respawn -- the last forty ticks (after the second wall hit of the respawned car); 3v3_kickoff -- the six-car heap from tick 282 on.
+PHYS_EXACT_UNTIL = {"car_into_goal": 160, "car_into_side_wall": 290, "demo_and_respawn": 580, "3v3_kickoff": 280}
+# ... and how close a tape stays after that, until the given tick (pos uu, vel uu/s, ang rad/s, rot)
+PHYS_AFTER_EXACT = {"demo_and_respawn": (600, (0.2, 1.5, 0.02, 5e-3))}
 
 # One tick from the reference's own state: 98 % of the 1721 recorded pairs agree to 0.01 uu/s (median 2e-5).
 ONE_TICK_TOL = {

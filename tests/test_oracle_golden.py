@@ -171,10 +171,10 @@ def test_port_physics_vs_reference_golden(sg, port_lib):
 def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
     """The 31 tapes run inside the stepper's own units from the state the reference's set_state was given to the end (port_run_tape: no
     rounding to uu and back between ticks, exactly like the reference's free-running arena) and compared with the reference's recorded
-    trajectory every 10 ticks for EQUALITY of every field of every body: 26 tapes -- up to 600 ticks of driving, jumping, flipping, air
-    control, wall riding, ball flight / rolling / wall and goal bounces, car-ball hits, aerials, a roof landing with auto-flip, tumbling
-    drops, a car into the back wall / a corner, car-car head-on and side bumps, a ball pinch, 2v2 -- are bit-identical to the reference
-    over their whole length, the other five up to simlib.PHYS_EXACT_UNTIL (3v3: 280 ticks)."""
+    trajectory every 10 ticks for EQUALITY of every field of every body: 27 tapes -- up to 600 ticks of driving, jumping, flipping, air
+    control, wall riding, ball flight / rolling / wall, fillet and goal bounces, car-ball hits, aerials, a roof landing with auto-flip,
+    tumbling drops, a car into the back wall / a corner, car-car head-on and side bumps, a ball pinch, 2v2 -- are bit-identical to the
+    reference over their whole length, the other four up to simlib.PHYS_EXACT_UNTIL (3v3: 280 ticks, the demolition tape: 580 of 620)."""
     import ctypes as C
     from simlib import PHYS_EXACT_UNTIL, PHYS_AFTER_EXACT
     every = int(sg["phys_every"])
@@ -196,8 +196,8 @@ def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
                 pos, vel, ang, rot, flags_differ = phys_errors(got, want[j], nc)
                 tp, tv, ta, tr = PHYS_AFTER_EXACT[name][1]
                 assert pos <= tp and vel <= tv and ang <= ta and rot <= tr and not flags_differ, f"{name} tick {t}: pos {pos:.5f} vel {vel:.5f} ang {ang:.6f} rot {rot:.7f}"
-    assert whole == 26
-    print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 5 partial")
+    assert whole == 27
+    print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 4 partial")
 
 
 def test_port_one_tick_vs_reference_states():
