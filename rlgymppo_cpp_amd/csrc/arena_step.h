@@ -450,7 +450,7 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
 // on): their three-term dot product adds x to (y + z), not (x + y) to z
 RLG_HD float sdot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 template <int NB>
-RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
+RLG_HD float row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
     SolverBody& A = B[c.a];
     const int b = c.b;
     SolverBody& Bb = B[b >= 0 ? b : 0];
@@ -471,6 +471,7 @@ RLG_HD void row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lo
     c.applied = now;
     A.dv = a_dv + (n1 * a_im) * delta; A.dw = a_dw + ang_a * delta;
     if (b >= 0) { Bb.dv = b_dv + ((-n1) * b_im) * delta; Bb.dw = b_dw + ang_b * delta; }
+    return delta;
 }
 template <int NB>
 RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
@@ -815,14 +816,20 @@ RLG_HD_NOINLINE void solver_iterate(TickWork<NC>& W) {
     }
     // velocity iterations.  (Tried and dropped: fetching row k+1 while row k computes -- the extra register copies cost more issue
     // slots than the fetch latency they hid: 467 K -> 537 K cycles on the slowest workgroup.)
+    // An iteration in which every row's impulse change is exactly zero leaves the bodies and the accumulated impulses as they were
+    // (x + 0 = x; the deltas start at +0 and never hold a -0), so every later iteration would repeat it: stopping there gives the
+    // reference's ten iterations' result bit for bit.  A ball rolling on the floor -- one normal and one friction row -- gets there
+    // in three or four.
     for (int it = 0; it < K::SOLVER_ITERS; it++) {
-        for (int k = 0; k < n_normal; k++) if (!R[k].skip) row_resolve(R[k], B, 0.f, 1e10f, true);
+        bool moved = false;
+        for (int k = 0; k < n_normal; k++) if (!R[k].skip) moved |= row_resolve(R[k], B, 0.f, 1e10f, true) != 0.f;
         for (int k = n_normal; k < nr; k++) {
             float total = R[R[k].fric_of].applied;
             if (total > 0.f) {
-                row_resolve(R[k], B, -(R[k].friction * total), R[k].friction * total, false);
+                moved |= row_resolve(R[k], B, -(R[k].friction * total), R[k].friction * total, false) != 0.f;
             }
         }
+        if (!moved) break;
     }
     RLG_PROF(4);
 }

@@ -1,5 +1,7 @@
 """Per-phase cycles of arena_tick_wave, one bucket per phase (needs a build with -DRLG_TICK_PROFILE -DRLG_FINE_PROF:
-   make -C rlgymppo_cpp_amd/csrc prof EXTRA=-DRLG_FINE_PROF, loaded through RLGPU_LIB).  Sums over all workgroups; printed per workgroup and tick."""
+   make -C rlgymppo_cpp_amd/csrc prof EXTRA=-DRLG_FINE_PROF, loaded through RLGPU_LIB).  Sums over all workgroups; printed per workgroup and tick.
+   usage: fine_prof.py [envs] [random warm-up steps] [learner iterations]: with the third argument the arenas are profiled where a policy
+   trained for that many iterations (tools/train_probe.py's configuration) has left them, instead of after a random rollout."""
 import os, sys, ctypes as C
 import numpy as np
 import torch
@@ -10,8 +12,16 @@ from rlgymppo_cpp_amd.state import default_arena
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+trained = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ticks, reps = 8, 4
-env = BatchedEnv(n, 1)
+if trained:
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    B = n * 2 * 32
+    L = Learner(LearnerConfig(numEnvs=n, teamSize=1, timestepsPerIteration=B, expBufferSize=B, randomSeed=1,
+                              ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=2, policyLR=2e-4, criticLR=2e-4, entCoef=0.01, autocastLearn=True)))
+    env = L.env
+else:
+    env = BatchedEnv(n, 1)
 fn = env.lib.rlgpu_env_debug_tick_cycles
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]; fn.restype = C.c_int
 env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
@@ -46,6 +56,12 @@ def run(label):
     print(f"   {'sum':24s} {d.sum():8.0f}           {slow.sum():12.0f}")
 
 
+if trained:
+    for it in range(trained):
+        L.iteration()
+    env.sync()
+    run("after %d learner iterations" % trained)
+    sys.exit(0)
 s = default_arena(2)
 env.upload_states([s] * n)
 run("rest")
