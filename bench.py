@@ -199,7 +199,9 @@ def main():
                  "ms_total": m["gemm_ms_total"], "calls": m["gemm_calls"], "frac": tflops / 2500.0},
     }
     if "trained_regime" in m:
-        out["trained_regime"] = m["trained_regime"]
+        out["trained_regime"] = dict(m["trained_regime"], note="same learner config (1 epoch) continued; at this point play is still close to random. "
+                                     "A policy that has learned to chase the ball costs more per tick (DESIGN.md 4.3, profiles/r02l_train_probe.txt: "
+                                     "7.9 M agent-steps/s over 1600 two-epoch iterations, Python host)")
     if not args.no_cpu_baseline and world == 1:
         cb = cpu_baseline()
         if cb is not None:
