@@ -126,6 +126,11 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next
  * inline fallback for that tick -- same results, slower): out5 = {BVH frontier, ball candidate region, car candidate region, item queue, result pool} */
 int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
 
+/* Penetration-depth queries since the last reset (process-wide): hitbox-mesh / hitbox-ball pairs whose cores overlap go through the
+ * reference's second GJK + EPA (btGjkEpaPenetrationDepthSolver.cpp:24-79, btGjkEpa2.cpp; csrc/arena_epa.h).  out2 = {queries, queries that
+ * did not fit the LDS arena and were repeated in the full-size one (Bullet's 128 vertices / 256 faces) in global memory} */
+int rlgpu_env_epa_counts(rlgpu_env* e, uint64_t* out2, int reset);
+
 /* Arena::Step(ticks) on the resident states with the controls stored in them (RS/Sim/Arena/Arena.cpp:716-812) */
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks);
 /* Car::controls of every car of every env from a host array [n_envs][2 * team_size][8] (throttle, steer, pitch, yaw, roll, jump, boost,

@@ -10,6 +10,10 @@
 //     compiler/ISA: agreement is to fp32 rounding of libm calls).
 // The dependency runs oracle -> product headers only; nothing in rlgymppo_cpp_amd/ includes, links or calls
 // anything in oracle/ (the product path fails loudly without its HIP library).
+// EPA usage statistics of the host build (tools/gjk_fuzz.py, tools/epa_stats.py): runs, max / histogram of support vertices and faces, statuses
+static int g_epa_stats[64];   // [0] runs, [1] max verts, [2] max faces, [3] max iterations, [4 + status] status counts, [16 + min(verts / 4, 31)] histogram
+#define RLG_EPA_STATS(nv, nf, it, st) do { g_epa_stats[0]++; if ((nv) > g_epa_stats[1]) g_epa_stats[1] = (nv); if ((nf) > g_epa_stats[2]) g_epa_stats[2] = (nf); \
+    if ((it) > g_epa_stats[3]) g_epa_stats[3] = (it); g_epa_stats[4 + ((st) < 10 ? (st) : 10)]++; g_epa_stats[16 + ((nv) / 4 < 31 ? (nv) / 4 : 31)]++; } while (0)
 #include "../rlgymppo_cpp_amd/csrc/arena_gym.h"
 #include "../rlgymppo_cpp_amd/csrc/arena_mesh.h"
 #include <cstring>
@@ -63,6 +67,7 @@ void port_run_tape(RlgpuArenaState* s, const float* tape, int ticks, int every, 
 }
 
 int port_state_size() { return (int)sizeof(RlgpuArenaState); }
+void port_epa_stats(int* out64, int reset) { memcpy(out64, g_epa_stats, sizeof(g_epa_stats)); if (reset) memset(g_epa_stats, 0, sizeof(g_epa_stats)); }
 
 void port_set_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
     g_mesh = build_host_mesh(verts_uu, n_verts, tris, n_tris);

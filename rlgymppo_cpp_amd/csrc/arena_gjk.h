@@ -9,17 +9,29 @@
 // exist, so the iteration is restated here step by step (same start direction, same support tie-breaks, same simplex reduction,
 // same termination tests, fp32) instead of being replaced by an analytic box-triangle distance.
 //
-// Penetration deeper than the margin (cores overlap; the reference then runs EPA on the margin-inflated shapes,
-// btGjkEpaPenetrationDepthSolver.cpp) is answered by the minimum-translation axis of the two core polytopes plus the margin:
-// same depth and normal as a converged EPA, a witness point that may differ where the deepest feature is not a single point.
+// Penetration deeper than the margin (cores overlap, or a degenerate ending with the cores closer than 0.01): the reference then asks
+// btGjkEpaPenetrationDepthSolver -- a second GJK and EPA on the margin-inflated shapes -- restated in arena_epa.h and consumed below
+// exactly as btGjkPairDetector.cpp:847-927 consumes it.
 #pragma once
 #include "arena_world.h"
+#include "arena_epa.h"
 
 #ifndef RLG_GJK_TRIANGLE_FN
 #define RLG_GJK_TRIANGLE_FN RLG_HD   /* out of line (one copy for the 3-vertex case and the tetrahedron's faces) measured slower: 26 K vs 21.5 K cycles per run in isolation */
 #endif
 #ifndef RLG_GJK_FACE_LOOP
 #define RLG_GJK_FACE_LOOP RLG_UNROLL
+#endif
+
+// Where the penetration-depth solver keeps its state (arena_epa.h).  Host default: a full-size arena on the stack.  The device kernels
+// define these before including this header (rlgpu_env.hip): a small arena in LDS shared by the wavefront's lanes one at a time, and a
+// full-size one in global memory for the queries that do not fit.
+#ifndef RLG_EPA_ARENA_DECL
+#define RLG_EPA_ARENA_DECL alignas(16) unsigned char epa_mem_[epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES)]; \
+    EpaArena epa_small_ = epa_arena_at(epa_mem_, EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); EpaArena* epa_big_ = nullptr;
+#define RLG_EPA_SERIALIZE_BEGIN
+#define RLG_EPA_SERIALIZE_END
+#define RLG_EPA_COUNT_BIG() ((void)0)
 #endif
 
 namespace rlg {
@@ -205,6 +217,44 @@ RLG_HD bool v3_eq(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 struct GjkOut { V3 n, pb; float dist; };
 constexpr float GJK_REL_ERROR2 = 1.0e-6f;
 
+// The penetration case of btGjkPairDetector (btGjkPairDetector.cpp:847-927) on what the first GJK left in `p`: out of line, so that the
+// rare deep contact does not weigh on the register allocation of the GJK loop every pair runs.  false: the arena was too small and no
+// full-size one is available.
+struct GjkPen { bool valid; float distance; V3 pa, pb, normal; };
+RLG_HD_NOINLINE bool gjk_penetration(const M3& R, V3 oa, V3 core, float margin_a, V3 ob, V3 t0, V3 t1, V3 t2, float margin_b, GjkPen& p) {
+    RLG_EPA_ARENA_DECL
+    const float margin = margin_a + margin_b;
+    const EpaShapes es = epa_shapes(R, oa, core, margin_a, ob, t0, t1, t2, margin_b);
+    PenDepth pd; pd.v = pd.wa = pd.wb = v3(0, 0, 0);
+    int rc = EPA_ARENA_FULL;
+    RLG_EPA_SERIALIZE_BEGIN
+    rc = epa_calc_pen_depth(epa_small_, es, pd);
+    if (rc == EPA_ARENA_FULL && epa_big_) { RLG_EPA_COUNT_BIG(); rc = epa_calc_pen_depth(*epa_big_, es, pd); }
+    RLG_EPA_SERIALIZE_END
+    if (rc == EPA_ARENA_FULL) return false;
+    const V3 axis = pd.v;                                       // m_cachedSeparatingAxis
+    if (rc == 1) {
+        V3 tn = pd.wb - pd.wa;
+        float l2 = len2(tn);
+        if (l2 <= SIMD_EPS * SIMD_EPS) { tn = axis; l2 = len2(axis); }
+        if (l2 > SIMD_EPS * SIMD_EPS) {
+            tn = vdiv_bt(tn, sqrtf(l2));
+            const float distance2 = -len(pd.wa - pd.wb);
+            if (!p.valid || distance2 < p.distance) { p.distance = distance2; p.pa = pd.wa; p.pb = pd.wb; p.normal = tn; p.valid = true; }   // only replace valid penetrations when the result is deeper
+        }
+    } else if (len2(axis) > 0.f) {
+        // EPA reports no penetration and the second GJK (cores, no margins) a positive distance (:894-921)
+        const float distance2 = len(pd.wa - pd.wb) - margin;
+        if (!p.valid || distance2 < p.distance) {
+            p.distance = distance2; p.pa = pd.wa; p.pb = pd.wb;
+            p.pa -= axis * margin_a; p.pb += axis * margin_b;
+            p.normal = normalized(axis);
+            p.valid = true;
+        }
+    }
+    return true;
+}
+
 // One (hitbox, triangle) pair.  bc / R: the hitbox child's world transform; core: btBoxShape's implicit dimensions; margin_a: its
 // collision margin; the triangle has margin 0 (btConcaveShape.cpp:21) and sits in a body at the origin.  `breaking`: the manifold's
 // contact breaking threshold.  true: `out` is the point btManifoldResult::addContactPoint receives.
@@ -284,11 +334,13 @@ RLG_HD bool gjk_box_convex(V3 bc, const M3& R, V3 core, float margin_a, V3 origi
             valid = true;
         }
     }
-    // btGjkPairDetector.cpp:856-927: penetration (or a degenerate ending with the cores closer than 0.01): the reference asks EPA
+    // btGjkPairDetector.cpp:847-927: penetration, or a degenerate ending with the cores closer than 0.01: the reference asks its penetration
+    // depth solver (a second GJK + EPA on the margin-inflated shapes, arena_epa.h) and keeps whichever answer is deeper
     if (!valid || (degenerate && (distance + margin) < 0.01f)) {
-        deep = true;
-        if (!valid) return false;   // the caller answers with the core polytopes' minimum-translation axis
-        // valid but close: EPA's answer replaces GJK's only when it is deeper; both measure the same rounded shapes, so GJK's stands
+        GjkPen pen; pen.valid = valid; pen.distance = distance; pen.pa = pa; pen.pb = pb; pen.normal = normal;
+        if (!gjk_penetration(R, oa, core, margin_a, ob, t0, t1, t2, margin_b, pen)) { deep = true; return false; }   // (no full-size arena: the caller's minimum-translation answer stands in, counted)
+        valid = pen.valid; distance = pen.distance; pa = pen.pa; pb = pen.pb; normal = pen.normal;
+        if (!valid) return false;
     }
     if (!(distance < 0.f || distance * distance < max_d2)) return false;
     {   // m_fixContactNormalDirection (:929-948): the normal must point from the triangle's box centre towards the hitbox's

@@ -14,6 +14,10 @@
 #include <fstream>
 #include <algorithm>
 
+#ifndef RLG_WAVES_PER_BLOCK
+#define RLG_WAVES_PER_BLOCK 1
+#endif
+#define RLG_WAVES_PER_BLOCK_DEFAULTED RLG_WAVES_PER_BLOCK
 #ifdef RLG_TICK_PROFILE
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
 __shared__ unsigned long long g_prof[12];
@@ -63,8 +67,32 @@ __device__ unsigned int g_fine_blk[4096 * 32];   // the buckets of every workgro
 // one sends its env through the inline fallback for that tick, same results): 0 BVH frontier, 1 ball region, 2 car region, 3 item queue,
 // 4 result pool.  rlgpu_env_overflow_counts reads them; other counter slots (profiler build) compile to nothing.
 __device__ unsigned int g_overflow[8];
-#define RLG_DBG_COUNT(i) do { if ((i) < 5) atomicAdd(&g_overflow[(i) & 7], 1u); } while (0)
+#define RLG_DBG_COUNT(i) do { if ((i) < 7) atomicAdd(&g_overflow[(i) & 7], 1u); } while (0)   // (5, 6: penetration-depth queries / those that needed the full-size arena)
 #define RLG_HAVE_OVERFLOW_COUNTS 1
+#endif
+// Where the penetration-depth solver (arena_epa.h: Bullet's second GJK + EPA, for hitbox-mesh contacts deeper than the collision margin)
+// keeps its state on the device.  Small arena: the frontier / query-box / candidate-slot part of the wavefront's first env's CollideQueue,
+// which is dead from the item compaction to the next tick's candidate walk -- 16 support vertices and 40 faces, enough for 99.9 % of the
+// queries (tools/gjk_fuzz.py prints the histogram); the wavefront's lanes use it one at a time (a ballot loop: only lanes that are in this
+// very branch together can collide).  Full-size arena (Bullet's 128 vertices / 256 faces): global memory, one per wavefront (EnvDev::epa_big).
+__shared__ unsigned char* g_epa_small_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
+__shared__ unsigned char* g_epa_big_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
+#define RLG_EPA_LDS_V 16
+#define RLG_EPA_LDS_F 40
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RLG_EPA_ARENA_DECL \
+    EpaArena epa_small_ = epa_arena_at(g_epa_small_ptr[threadIdx.x >> 6], RLG_EPA_LDS_V, RLG_EPA_LDS_F); \
+    EpaArena epa_bigv_ = epa_arena_at(g_epa_big_ptr[threadIdx.x >> 6], EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); \
+    EpaArena* epa_big_ = g_epa_big_ptr[threadIdx.x >> 6] ? &epa_bigv_ : nullptr;
+#define RLG_EPA_SERIALIZE_BEGIN for (unsigned long long pend_ = __ballot(1); pend_; pend_ &= pend_ - 1ull) { if ((int)(threadIdx.x & 63u) == __ffsll((unsigned long long)pend_) - 1) { RLG_DBG_COUNT(5);
+#define RLG_EPA_SERIALIZE_END } }
+#define RLG_EPA_COUNT_BIG() RLG_DBG_COUNT(6)
+#else   // host pass of this translation unit: never executed
+#define RLG_EPA_ARENA_DECL alignas(16) unsigned char epa_mem_[epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES)]; \
+    EpaArena epa_small_ = epa_arena_at(epa_mem_, EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); EpaArena* epa_big_ = nullptr;
+#define RLG_EPA_SERIALIZE_BEGIN
+#define RLG_EPA_SERIALIZE_END
+#define RLG_EPA_COUNT_BIG() ((void)0)
 #endif
 #include "../../include/rlgpu.h"
 #include "arena_gym.h"
@@ -105,6 +133,7 @@ struct EnvDev {
     GymConfig cfg;
     int n_envs;
     float* step_stats;           // rlgpu_env_enable_step_stats: {player-steps, sum |car vel| (uu/s), ball touches, airborne} accumulated by the step kernels, or null
+    unsigned char* epa_big;      // [wavefronts of a step launch][EPA_BIG_BYTES]: full-size penetration-depth arenas (arena_epa.h), or null
     RlgpuArenaState* snap_out;   // host-plugin fallback (rlgpu_env_enable_snapshots): every step's GameState source, [n_envs], or null
 };
 
@@ -141,7 +170,8 @@ constexpr size_t lane_stride() { size_t w = (sizeof(LaneBlock<NC>) + 7) / 8; ret
 template <int NC>
 constexpr int lanes_per_block() {
     int l = 16;
-    while (l > WPB && (size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET) l /= 2;
+    // (a wavefront infers its own envs' agents in one 8-row MFMA tile: at most 8 / NC envs per wavefront whatever the LDS budget)
+    while (l > WPB && ((size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET || (l / WPB) * NC > 8)) l /= 2;
     return l;
 }
 
@@ -181,6 +211,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroups of several wavefronts (RLG_WAVES_PER_BLOCK > 1) can keep their wavefronts in step: all of a CU's wavefronts then run the same
+// phase's code at the same time, which is what an instruction cache shared by the CU's wavefronts wants (one tick is ~330 KB of code).
+// RLG_PHASE_BARRIER: 0 none, 1 one s_barrier per tick, 2 one per phase.  Only at points every wavefront of the workgroup passes equally often.
+#ifndef RLG_PHASE_BARRIER
+#define RLG_PHASE_BARRIER 0
+#endif
+__device__ __forceinline__ void phase_sync(int level) {
+    if (WPB > 1 && RLG_PHASE_BARRIER >= level) __builtin_amdgcn_s_barrier();
 }
 
 template <int NC>
@@ -245,6 +285,20 @@ __device__ __forceinline__ WaveSlot wave_slot(unsigned char* lane_mem, int n_env
     s.n_valid = left < 0 ? 0 : (left < EPW ? left : EPW);
     s.mem = lane_mem + (size_t)wave * EPW * lane_stride<NC>();
     return s;
+}
+
+constexpr size_t EPA_BIG_BYTES = (epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES) + 63) & ~(size_t)63;
+// the wavefront's penetration-depth arenas (see the top of this file): called once per launch by every kernel that ticks
+template <int NC>
+__device__ __forceinline__ void epa_arenas_setup(const EnvDev& d, unsigned char* wmem) {
+    using Q = CollideQueue<NC>;
+    static_assert(offsetof(Q, items) - offsetof(Q, frontier) >= epa_arena_bytes(RLG_EPA_LDS_V, RLG_EPA_LDS_F), "the small EPA arena borrows the frontier / box / candidate part of a CollideQueue");
+    static_assert(offsetof(Q, frontier) % 4 == 0, "arena alignment");
+    if ((threadIdx.x & 63) == 0) {
+        const int wave = threadIdx.x >> 6;
+        g_epa_small_ptr[wave] = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W.Q.frontier[0][0]);
+        g_epa_big_ptr[wave] = d.epa_big ? d.epa_big + ((size_t)blockIdx.x * WPB + wave) * EPA_BIG_BYTES : nullptr;
+    }
 }
 
 // Phase 0b on the device: this tick's narrowphase candidates (arena_world.h:collide_build_candidates is the host form and
@@ -415,6 +469,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     LaneBlock<NC>& Sw = lane_block<NC>(lane_mem, whl_lane ? e_whl : 0);
     LaneBlock<NC>& Se = lane_block<NC>(lane_mem, env_lane ? tid : 0);
 
+    phase_sync(1);
     if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
     RLG_PROF(0); RLG_FPROF(0);
@@ -422,11 +477,11 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
 #ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
     build_candidates_wave<NC>(lane_mem, n_valid, mv);
 #endif
-    RLG_PROF(1); RLG_FPROF(1);
+    RLG_PROF(1); RLG_FPROF(1); phase_sync(2);
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
     if (whl_lane) car_wheel_ray_begin(Sw.A, c_whl, w_whl, Sw.W.ctx[c_whl]);
     wave_sync();
-    RLG_FPROF(2);
+    RLG_FPROF(2); phase_sync(2);
     {   // all (env, car, wheel, candidate) pairs of the wavefront as ONE list over the 64 lanes (a car next to a wall has ~100 of
         // them, most cars none)
         int n_of[EPW * NC], total = 0;
@@ -446,10 +501,10 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
-    RLG_FPROF(3);
+    RLG_FPROF(3); phase_sync(2);
     if (whl_lane) car_wheel_ray_finish(Sw.A, c_whl, w_whl, mv, Sw.W.Q, Sw.W.ctx[c_whl]);
     wave_sync();
-    RLG_FPROF(4);
+    RLG_FPROF(4); phase_sync(2);
     const bool ordered = car_lane && car_needs_ordered_finish(Sc.W.ctx[c_car]);
     if (__ballot(ordered) == 0ull) {
         if (car_lane) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
@@ -460,7 +515,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
-    RLG_FPROF(5);
+    RLG_FPROF(5); phase_sync(2);
     constexpr int LPE = WAVE / EPW;           // lanes that serve one env in the pad / candidate / item phases
     const int e_grp = tid / LPE, l_grp = tid % LPE;
     const bool grp_lane = e_grp < n_valid;
@@ -468,7 +523,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (grp_lane) for (int p = l_grp; p < 34; p += LPE) pad_pre_tick(Sg.A.pads[p]);
     if (env_lane) tick_world_begin(Se.A, Se.W, true);
     wave_sync();
-    RLG_FPROF(6);
+    RLG_FPROF(6); phase_sync(2);
     {   // narrowphase (arena_step.h): lane per candidate tests + compacts, lane per item runs
         const int e_item = e_grp, l_item = l_grp;
         const bool item_lane = e_item < n_valid;
@@ -494,7 +549,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
             if (item_lane && l_item == 0 && !Q.overflow) Q.n_items = base;
         }
         wave_sync();
-        RLG_FPROF(7);
+        RLG_FPROF(7); phase_sync(2);
         RLG_PROF(1);   // (the candidate tests count as "candidates", like the walk that listed them)
         {   // items of ALL envs of the wavefront as one list over the 64 lanes: a contact-heavy env borrows its neighbours' lanes
             int n_of[EPW], total = 0;
@@ -514,7 +569,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
         wave_sync();
     }
-    RLG_PROF(2); RLG_FPROF(8);
+    RLG_PROF(2); RLG_FPROF(8); phase_sync(2);
     // rest of the world step: contacts (lane per body) | merge + row plan (env) | solver rows (lane per contact) | iterations (env) | integration (lane per body)
     {
         constexpr int NB = NC + 1;
@@ -522,16 +577,16 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         if (e_b < n_valid) { LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_b); solver_body_contacts(Sb.A, mv, Sb.W, b_b, true); }
     }
     wave_sync();
-    RLG_FPROF(9);
+    RLG_FPROF(9); phase_sync(2);
     if (env_lane) solver_prepare(Se.A, mv, ev, Se.W, true);
     wave_sync();
-    RLG_FPROF(10);
+    RLG_FPROF(10); phase_sync(2);
     if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.W, k);
     wave_sync();
-    RLG_FPROF(11);
+    RLG_FPROF(11); phase_sync(2);
     if (env_lane) solver_iterate(Se.W);
     wave_sync();
-    RLG_FPROF(12);
+    RLG_FPROF(12); phase_sync(2);
     {
         constexpr int NB = NC + 1;
         const int e_b = tid / NB, b_b = tid % NB;
@@ -539,13 +594,13 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     }
     RLG_PROF(5);
     wave_sync();
-    RLG_FPROF(13);
+    RLG_FPROF(13); phase_sync(2);
     if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, pad_tab, c_car); }
     wave_sync();
-    RLG_FPROF(14);
+    RLG_FPROF(14); phase_sync(2);
     if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
     wave_sync();
-    RLG_FPROF(15);
+    RLG_FPROF(15); phase_sync(2);
     {   // pads that hand out boost are rare: they go through the env lane in pad order, all the others finish in parallel
         bool gives = false;
         if (grp_lane) for (int p = l_grp; p < 34; p += LPE) { if (pad_gives_boost(Sg.A.pads[p])) gives = true; else pad_post_tick(Sg.A, p); }
@@ -555,7 +610,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
         }
     }
     wave_sync();
-    RLG_FPROF(16);
+    RLG_FPROF(16); phase_sync(2);
     if (env_lane) tick_finish(Se.A, pad_tab, true);
     wave_sync();
     RLG_FPROF(17);
@@ -600,6 +655,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
+    epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
     if (env_lane) {
@@ -677,6 +733,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_infer = 0, prof_mlp = 0;
 #endif
+    epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
     wave_sync();
@@ -764,6 +821,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     const bool env_lane = ws.lane < n_valid;
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
+    epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
 #ifdef RLG_TICK_PROFILE
@@ -843,6 +901,7 @@ struct rlgpu_env {
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
+    unsigned char* d_epa_big = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -928,6 +987,11 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     HIPCHK(e, hipMemcpy(e->d_pad_tab, ptab, sizeof(ptab), hipMemcpyHostToDevice));
     e->d.pad_tab = e->d_pad_tab;
     memcpy(&e->d.cfg, cfg, sizeof(GymConfig));
+    {   // full-size penetration-depth arenas, one per wavefront of a step launch (11.7 KB each; touched only by the rare query the LDS arena cannot hold)
+        const size_t waves = (size_t)(e->nc == 2 ? env_grid<2>(n_envs) : (e->nc == 4 ? env_grid<4>(n_envs) : env_grid<6>(n_envs))) * WPB;
+        HIPCHK(e, hipMalloc(&e->d_epa_big, waves * EPA_BIG_BYTES));
+        e->d.epa_big = e->d_epa_big;
+    }
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     return RLGPU_OK;
 }
@@ -943,6 +1007,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_pad_tab) (void)hipFree(e->d_pad_tab);
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
+    if (e->d_epa_big) (void)hipFree(e->d_epa_big);
     if (e->d.step_stats) (void)hipFree(e->d.step_stats);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
@@ -1193,6 +1258,21 @@ int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset) {
     (void)reset;
 #endif
     for (int i = 0; i < 5; i++) out5[i] = h[i];
+    return RLGPU_OK;
+}
+
+int rlgpu_env_epa_counts(rlgpu_env* e, uint64_t* out2, int reset) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RLG_HAVE_OVERFLOW_COUNTS
+    HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h)));
+    if (reset) { h[5] = h[6] = 0; const unsigned int keep[8] = {h[0], h[1], h[2], h[3], h[4], 0, 0, h[7]}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), keep, sizeof(keep))); HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h))); }
+#else
+    int d[64]; HIPCHK(e, hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d)));
+    h[5] = (unsigned int)d[5]; h[6] = (unsigned int)d[6]; (void)reset;
+#endif
+    out2[0] = h[5]; out2[1] = h[6];
     return RLGPU_OK;
 }
 

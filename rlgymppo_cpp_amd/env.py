@@ -125,6 +125,12 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_overflow_counts(self.h, C.addressof(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
         return [int(x) for x in out]
 
+    def epa_counts(self, reset=False):
+        """Penetration-depth queries (Bullet's second GJK + EPA, csrc/arena_epa.h) since the last reset, process-wide: [queries, of them in the full-size arena]."""
+        out = (C.c_uint64 * 2)()
+        _chk(self.lib.rlgpu_env_epa_counts(self.h, C.addressof(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return [int(x) for x in out]
+
     def enable_step_stats(self, on=True):
         _chk(self.lib.rlgpu_env_enable_step_stats(self.h, 1 if on else 0), self.h, self.lib.rlgpu_env_last_error)
 
