@@ -132,7 +132,10 @@ typedef struct RlgpuGymState {
 
 typedef struct RlgpuArenaState {
     int32_t num_cars;                /* 2, 4 or 6 */
-    int32_t _pad0;
+    uint32_t car_order;              /* the order in which the arena's per-car loops visit the cars: 4 bits per rank, slot + 1 (rank 0 in bits 0-3);
+                                        0 = slot order.  The reference iterates `std::unordered_set<Car*> _cars` (Arena.h:35, Arena.cpp:716-812), i.e. in
+                                        an order that follows from heap addresses; it matters only where one car's update reads another's (a wheel
+                                        standing on a car, two cars on one boost pad).  States read from the reference carry its order. */
     int64_t tick_count;              /* Arena::tickCount */
     int64_t ball_update_counter;     /* BallState::updateCounter (reset by SetState) */
     RlgpuBallState ball;

@@ -92,6 +92,19 @@ int port_gjk_box_triangle(const float* pos3, const float* rot9, const float* tri
     out8[0] = g.n.x; out8[1] = g.n.y; out8[2] = g.n.z; out8[3] = g.pb.x; out8[4] = g.pb.y; out8[5] = g.pb.z; out8[6] = g.dist; out8[7] = deep ? 1.f : 0.f;
     return hit ? 1 : 0;
 }
+// the host build of csrc/arena_simplex.h:ray_convex_cast as the wheel rays use it (arena_world.h:ray_ball_and_cars): out4 = fraction, normal as
+// btCollisionWorld::rayTestSingleInternal reports it (normalised once more); returns 1 on a hit
+int port_ray_convex(const float* from3, const float* to3, const float* half3, float radius, const float* pos3, const float* rot9, float* out4) {
+    M3 R = m3_rows(v3(rot9[0], rot9[1], rot9[2]), v3(rot9[3], rot9[4], rot9[5]), v3(rot9[6], rot9[7], rot9[8]));
+    RayHit best; best.kind = -1; best.frac = 1.f; best.normal = v3(0, 0, 0);
+    // half3 is what btBoxShape's constructor is given: the shape keeps (half - 0.04) and a margin of 0.1 * the smallest half extent (setSafeMargin),
+    // and its localGetSupportingVertex adds the two (btBoxShape.cpp:19-35, btBoxShape.h:47-56) -- arena_body.h:hitbox_core / BOX_MARGIN / hitbox_half
+    const float mg = 0.1f * fminf(half3[0], fminf(half3[1], half3[2]));
+    const V3 half = v3((half3[0] - 0.04f) + mg, (half3[1] - 0.04f) + mg, (half3[2] - 0.04f) + mg);
+    const bool hit = ray_convex_hit(v3(from3[0], from3[1], from3[2]), v3(to3[0], to3[1], to3[2]), R, v3(pos3[0], pos3[1], pos3[2]), half, radius, 7, best);
+    out4[0] = best.frac; out4[1] = best.normal.x; out4[2] = best.normal.y; out4[3] = best.normal.z;
+    return hit ? 1 : 0;
+}
 // the host build of csrc/arena_world.h:adjust_internal_edge on stored triangle `stored_index` of the mesh port_set_mesh built
 // (g_mesh.source_tri maps it to the input's numbering): out7 = normal[3], point on the triangle[3], distance
 int port_adjust_internal_edge(int stored_index, const float* pb3, const float* n3, float dist, float* out7) {

@@ -28,6 +28,8 @@
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkEpaPenetrationDepthSolver.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btInternalEdgeUtility.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionObjectWrapper.h>
+#include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionWorld.h>
+#include <bullet3-3.24/BulletCollision/CollisionShapes/btSphereShape.h>
 #include "../include/rlgpu_state.h"
 
 #include <cstring>
@@ -66,6 +68,13 @@ CarControls ArrToCtrl(const float* p) {
 void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
     memset(s, 0, sizeof(*s));
     s->num_cars = SlotCount(a);
+    {   // the order in which Arena::Step's `for (Car* car : _cars)` loops visit the cars (an unordered_set of pointers: Arena.h:35), as slots;
+        // absent slots of a one-team arena go last so that the word stays a permutation
+        uint32_t order = 0; int rank = 0; uint32_t seen = 0;
+        for (Car* car : a->_cars) { const int slot = SlotOfCar(a, car->id); order |= (uint32_t)(slot + 1) << (4 * rank++); seen |= 1u << slot; }
+        for (int slot = 0; slot < s->num_cars; slot++) if (!((seen >> slot) & 1u)) order |= (uint32_t)(slot + 1) << (4 * rank++);
+        s->car_order = order;
+    }
     s->tick_count = (int64_t)a->tickCount;
     BallState bs = a->ball->GetState();
     s->ball_update_counter = (int64_t)bs.updateCounter;
@@ -304,6 +313,26 @@ int ref_gjk_box_triangle(const float* half3, const float* pos3, const float* rot
     for (int k = 0; k < 3; k++) { out8[k] = res.has ? (float)res.n[k] : 0.f; out8[3 + k] = res.has ? (float)res.p[k] : 0.f; }
     out8[6] = res.has ? (float)res.d : 0.f; out8[7] = box.getMargin();
     return res.has ? 1 : 0;
+}
+
+// btCollisionWorld::rayTestSingle on one convex object -- what a wheel's suspension ray meets when another car's hitbox child or the ball is
+// in its way (btDefaultVehicleRaycaster.cpp:34-52 -> btCollisionWorld::rayTest -> rayTestSingleInternal: btSubsimplexConvexCast of a point
+// against the shape, btCollisionWorld.cpp:267-310).  radius > 0: a btSphereShape, else a btBoxShape(half3).  out4 = hit fraction, m_hitNormalWorld.
+// Unit-level oracle for csrc/arena_simplex.h:ray_convex_cast.
+int ref_ray_convex(const float* from3, const float* to3, const float* half3, float radius, const float* pos3, const float* rot9, float* out4) {
+    btBoxShape box(btVector3(half3[0], half3[1], half3[2]));
+    btSphereShape sph(radius);
+    btCollisionShape* shape = radius > 0.f ? (btCollisionShape*)&sph : (btCollisionShape*)&box;
+    btCollisionObject obj; obj.setCollisionShape(shape);
+    btMatrix3x3 basis(rot9[0], rot9[1], rot9[2], rot9[3], rot9[4], rot9[5], rot9[6], rot9[7], rot9[8]);
+    btTransform tr(basis, btVector3(pos3[0], pos3[1], pos3[2]));
+    obj.setWorldTransform(tr);
+    const btVector3 from(from3[0], from3[1], from3[2]), to(to3[0], to3[1], to3[2]);
+    btTransform tf, tt; tf.setIdentity(); tf.setOrigin(from); tt.setIdentity(); tt.setOrigin(to);
+    btCollisionWorld::ClosestRayResultCallback cb(from, to, nullptr);   // (RocketSim adds the ignored object)
+    btCollisionWorld::rayTestSingle(tf, tt, &obj, shape, tr, cb);
+    out4[0] = cb.m_closestHitFraction; out4[1] = cb.m_hitNormalWorld[0]; out4[2] = cb.m_hitNormalWorld[1]; out4[3] = cb.m_hitNormalWorld[2];
+    return cb.hasHit() ? 1 : 0;
 }
 
 // btAdjustInternalEdgeContacts as the contact-added callback runs it (Arena.cpp:275-279) on one new point against triangle `tri_index`

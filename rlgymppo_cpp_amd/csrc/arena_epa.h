@@ -39,26 +39,6 @@ struct EpaGjkState {                              // GJK's fields and the locals
     V3 lastw[4];
     V3 ray; float distance; int status;           // 0 Valid, 1 Inside, 2 Failed
 };
-struct EpaArena {
-    EpaGjkState* g;
-    EpaSV* sv;                                    // [4 + cap_v]
-    EpaFace* fc;                                  // [cap_f]
-    uint16_t* stack;                              // [cap_f]: the recursion of EPA::expand
-    int cap_v, cap_f;
-};
-constexpr size_t epa_arena_bytes(int cap_v, int cap_f) {
-    return sizeof(EpaGjkState) + sizeof(EpaSV) * (size_t)(4 + cap_v) + sizeof(EpaFace) * (size_t)cap_f + 2 * (size_t)cap_f + 16;
-}
-RLG_HD EpaArena epa_arena_at(void* mem, int cap_v, int cap_f) {
-    EpaArena a; unsigned char* p = reinterpret_cast<unsigned char*>(mem);
-    a.g = reinterpret_cast<EpaGjkState*>(p); p += sizeof(EpaGjkState);
-    a.sv = reinterpret_cast<EpaSV*>(p); p += sizeof(EpaSV) * (size_t)(4 + cap_v);
-    a.fc = reinterpret_cast<EpaFace*>(p); p += sizeof(EpaFace) * (size_t)cap_f;
-    a.stack = reinterpret_cast<uint16_t*>(p);
-    a.cap_v = cap_v; a.cap_f = cap_f;
-    return a;
-}
-
 // The two shapes in shape 0's (the box's) local frame: gjkepa2_impl::MinkowskiDiff after Initialize (btGjkEpa2.cpp:874-891) with
 // wtrs0 = (R0, o0), wtrs1 = (identity, o1): m_toshape1 = wtrs1.basis^T * wtrs0.basis = R0, m_toshape0 = wtrs0.inverseTimes(wtrs1) =
 // (R0^T, (o1 - o0) * R0).  Shape 1 is up to three points (a mesh triangle; the ball's btSphereShape is the single point 0) plus a margin.
@@ -67,6 +47,41 @@ struct EpaShapes {
     V3 t0, t1, t2; float margin_b;
     V3 to0_origin;
 };
+enum { EPA_VALID = 0, EPA_TOUCHING, EPA_DEGENERATED, EPA_NONCONVEX, EPA_INVALIDHULL, EPA_OUTOFFACES, EPA_OUTOFVERTICES, EPA_ACCURACY_REACHED, EPA_FALLBACK, EPA_FAILED,
+       EPA_ARENA_FULL = 100 };
+struct EpaRun {
+    int status;
+    int hull_root, hull_count;      // m_hull
+    int free_root, next_fresh;      // m_stock = freed faces (LIFO) followed by the never-used ones in index order (Initialize, :637-647)
+    int nextsv;
+    bool arena_full;
+};
+struct EpaResult { int status; V3 normal; float depth; int rank; EpaSV c[3]; float p[3]; };
+struct EpaArena {
+    EpaShapes* sh;                                // the pair, in the box's frame (kept here so that the out-of-line routines below share it without a stack copy)
+    EpaGjkState* g;
+    EpaRun* run; EpaResult* res;    // EPA's fields / m_result (kept in the arena: the routines below are real calls on the device)
+    EpaSV* sv;                                    // [4 + cap_v]
+    EpaFace* fc;                                  // [cap_f]
+    uint16_t* stack;                              // [cap_f]: the recursion of EPA::expand
+    int cap_v, cap_f;
+};
+constexpr size_t epa_arena_bytes(int cap_v, int cap_f) {
+    return sizeof(EpaShapes) + sizeof(EpaGjkState) + sizeof(EpaRun) + sizeof(EpaResult) + sizeof(EpaSV) * (size_t)(4 + cap_v) + sizeof(EpaFace) * (size_t)cap_f + 2 * (size_t)cap_f + 16;
+}
+RLG_HD EpaArena epa_arena_at(void* mem, int cap_v, int cap_f) {
+    EpaArena a; unsigned char* p = reinterpret_cast<unsigned char*>(mem);
+    a.sh = reinterpret_cast<EpaShapes*>(p); p += sizeof(EpaShapes);
+    a.g = reinterpret_cast<EpaGjkState*>(p); p += sizeof(EpaGjkState);
+    a.run = reinterpret_cast<EpaRun*>(p); p += sizeof(EpaRun);
+    a.res = reinterpret_cast<EpaResult*>(p); p += sizeof(EpaResult);
+    a.sv = reinterpret_cast<EpaSV*>(p); p += sizeof(EpaSV) * (size_t)(4 + cap_v);
+    a.fc = reinterpret_cast<EpaFace*>(p); p += sizeof(EpaFace) * (size_t)cap_f;
+    a.stack = reinterpret_cast<uint16_t*>(p);
+    a.cap_v = cap_v; a.cap_f = cap_f;
+    return a;
+}
+
 RLG_HD EpaShapes epa_shapes(const M3& R0, V3 o0, V3 core, float margin_a, V3 o1, V3 t0, V3 t1, V3 t2, float margin_b) {
     EpaShapes s; s.R0 = R0; s.o0 = o0; s.o1 = o1; s.core = core; s.margin_a = margin_a; s.t0 = t0; s.t1 = t1; s.t2 = t2; s.margin_b = margin_b;
     s.to0_origin = tmul(R0, o1 - o0);             // v * m_basis (btTransform.h:218-223)
@@ -98,7 +113,7 @@ RLG_HD V3 epa_support1(const EpaShapes& s, V3 d, bool margins) {   // m_toshape0
     return tmul(s.R0, p) + s.to0_origin;
 }
 RLG_HD V3 epa_support(const EpaShapes& s, V3 d, bool margins) { return epa_support0(s, d, margins) - epa_support1(s, -d, margins); }
-RLG_HD void epa_getsupport(const EpaShapes& s, bool margins, V3 d, EpaSV& sv) {   // GJK::getsupport (:422-426)
+RLG_HD_NOINLINE void epa_getsupport(const EpaShapes& s, bool margins, V3 d, EpaSV& sv) {   // GJK::getsupport (:422-426)
     sv.d = vdiv_bt(d, len(d));
     sv.w = epa_support(s, sv.d, margins);
 }
@@ -120,7 +135,7 @@ RLG_HD float epa_project2(V3 a, V3 b, float& w0, float& w1, uint32_t& m) {
 }
 struct EpaW3 { float w0, w1, w2; };
 RLG_HD void epa_w3_set(EpaW3& w, int i, float v) { if (i == 0) w.w0 = v; else if (i == 1) w.w1 = v; else w.w2 = v; }
-RLG_HD float epa_project3(V3 a, V3 b, V3 c, EpaW3& w, uint32_t& m) {
+RLG_HD_NOINLINE float epa_project3(V3 a, V3 b, V3 c, EpaW3& w, uint32_t& m) {
     const V3 dl0 = a - b, dl1 = b - c, dl2 = c - a;
     const V3 n = cross(dl0, dl1);
     const float l = len2(n);
@@ -157,7 +172,7 @@ RLG_HD float epa_project3(V3 a, V3 b, V3 c, EpaW3& w, uint32_t& m) {
 }
 struct EpaW4 { float w0, w1, w2, w3; };
 RLG_HD void epa_w4_set(EpaW4& w, int i, float v) { if (i == 0) w.w0 = v; else if (i == 1) w.w1 = v; else if (i == 2) w.w2 = v; else w.w3 = v; }
-RLG_HD float epa_project4(V3 a, V3 b, V3 c, V3 d, EpaW4& w, uint32_t& m) {
+RLG_HD_NOINLINE float epa_project4(V3 a, V3 b, V3 c, V3 d, EpaW4& w, uint32_t& m) {
     const V3 dl0 = a - d, dl1 = b - d, dl2 = c - d;
     const float vl = epa_det(dl0, dl1, dl2);
     const bool ng = (vl * dot(a, cross(b - c, a - b))) <= 0.f;
@@ -193,7 +208,7 @@ RLG_HD float epa_project4(V3 a, V3 b, V3 c, V3 d, EpaW4& w, uint32_t& m) {
 }
 
 // GJK::Evaluate (:204-347).  The simplices hold their vertices by value (the reference's pointer / free-list bookkeeping only shares them).
-RLG_HD int epa_gjk_evaluate(EpaGjkState& G, const EpaShapes& sh, bool margins, V3 guess) {
+RLG_HD_NOINLINE int epa_gjk_evaluate(EpaGjkState& G, const EpaShapes& sh, bool margins, V3 guess) {
     int iterations = 0;
     float sqdist = 0.f, alpha = 0.f;
     int clastw = 0;
@@ -291,7 +306,7 @@ RLG_HD bool epa_enclose2(EpaGjkState& G, const EpaShapes& sh, bool margins) {
     }
     return false;
 }
-RLG_HD bool epa_enclose_origin(EpaGjkState& G, const EpaShapes& sh, bool margins) {
+RLG_HD_NOINLINE bool epa_enclose_origin(EpaGjkState& G, const EpaShapes& sh, bool margins) {
     const int r = G.rank[G.cur];
     if (r == 2) return epa_enclose2(G, sh, margins);
     if (r == 3) return epa_enclose3(G, sh, margins);
@@ -300,44 +315,34 @@ RLG_HD bool epa_enclose_origin(EpaGjkState& G, const EpaShapes& sh, bool margins
 }
 
 // ---- EPA (:557-872) ---------------------------------------------------------------------------------------------------------------------
-enum { EPA_VALID = 0, EPA_TOUCHING, EPA_DEGENERATED, EPA_NONCONVEX, EPA_INVALIDHULL, EPA_OUTOFFACES, EPA_OUTOFVERTICES, EPA_ACCURACY_REACHED, EPA_FALLBACK, EPA_FAILED,
-       EPA_ARENA_FULL = 100 };
-struct EpaRun {
-    EpaArena A;
-    int status;
-    int hull_root, hull_count;      // m_hull
-    int free_root, next_fresh;      // m_stock = freed faces (LIFO) followed by the never-used ones in index order (Initialize, :637-647)
-    int nextsv;
-    bool arena_full;
-};
-RLG_HD void epa_bind(EpaArena& A, int fa, int ea, int fb, int eb) { A.fc[fa].e[ea] = (uint8_t)eb; A.fc[fa].f[ea] = (uint8_t)fb; A.fc[fb].e[eb] = (uint8_t)ea; A.fc[fb].f[eb] = (uint8_t)fa; }
-RLG_HD void epa_hull_append(EpaRun& E, int f) {
-    EpaFace& F = E.A.fc[f];
+RLG_HD void epa_bind(const EpaArena& A, int fa, int ea, int fb, int eb) { A.fc[fa].e[ea] = (uint8_t)eb; A.fc[fa].f[ea] = (uint8_t)fb; A.fc[fb].e[eb] = (uint8_t)ea; A.fc[fb].f[eb] = (uint8_t)fa; }
+RLG_HD void epa_hull_append(const EpaArena& A, int f) {
+    EpaRun& E = *A.run; EpaFace& F = A.fc[f];
     F.l[0] = -1; F.l[1] = (int16_t)E.hull_root;
-    if (E.hull_root >= 0) E.A.fc[E.hull_root].l[0] = (int16_t)f;
+    if (E.hull_root >= 0) A.fc[E.hull_root].l[0] = (int16_t)f;
     E.hull_root = f; E.hull_count++;
 }
-RLG_HD void epa_hull_remove(EpaRun& E, int f) {
-    EpaFace& F = E.A.fc[f];
-    if (F.l[1] >= 0) E.A.fc[F.l[1]].l[0] = F.l[0];
-    if (F.l[0] >= 0) E.A.fc[F.l[0]].l[1] = F.l[1];
+RLG_HD void epa_hull_remove(const EpaArena& A, int f) {
+    EpaRun& E = *A.run; EpaFace& F = A.fc[f];
+    if (F.l[1] >= 0) A.fc[F.l[1]].l[0] = F.l[0];
+    if (F.l[0] >= 0) A.fc[F.l[0]].l[1] = F.l[1];
     if (f == E.hull_root) E.hull_root = F.l[1];
     E.hull_count--;
 }
-RLG_HD void epa_stock_push(EpaRun& E, int f) { E.A.fc[f].l[1] = (int16_t)E.free_root; E.free_root = f; }
-RLG_HD bool epa_edge_dist(const EpaFace& F, const EpaSV& a, const EpaSV& b, float& dist) {   // EPA::getedgedist (:743-779)
-    const V3 ba = b.w - a.w;
-    const V3 n_ab = cross(ba, F.n);
-    const float a_dot_nab = dot(a.w, n_ab);
+RLG_HD void epa_stock_push(const EpaArena& A, int f) { A.fc[f].l[1] = (int16_t)A.run->free_root; A.run->free_root = f; }
+RLG_HD bool epa_edge_dist(V3 fn, V3 aw, V3 bw, float& dist) {   // EPA::getedgedist (:743-779)
+    const V3 ba = bw - aw;
+    const V3 n_ab = cross(ba, fn);
+    const float a_dot_nab = dot(aw, n_ab);
     if (a_dot_nab < 0.f) {
         const float ba_l2 = len2(ba);
-        const float a_dot_ba = dot(a.w, ba);
-        const float b_dot_ba = dot(b.w, ba);
-        if (a_dot_ba > 0.f) dist = len(a.w);
-        else if (b_dot_ba < 0.f) dist = len(b.w);
+        const float a_dot_ba = dot(aw, ba);
+        const float b_dot_ba = dot(bw, ba);
+        if (a_dot_ba > 0.f) dist = len(aw);
+        else if (b_dot_ba < 0.f) dist = len(bw);
         else {
-            const float a_dot_b = dot(a.w, b.w);
-            const float q = (len2(a.w) * len2(b.w) - a_dot_b * a_dot_b) / ba_l2;
+            const float a_dot_b = dot(aw, bw);
+            const float q = (len2(aw) * len2(bw) - a_dot_b * a_dot_b) / ba_l2;
             dist = sqrtf(q > 0.f ? q : 0.f);           // btMax(q, 0)
         }
         return true;
@@ -345,61 +350,64 @@ RLG_HD bool epa_edge_dist(const EpaFace& F, const EpaSV& a, const EpaSV& b, floa
     return false;
 }
 // EPA::newface (:780-824); -1 = none (m_status says why)
-RLG_HD int epa_newface(EpaRun& E, int a, int b, int c, bool forced) {
+RLG_HD_NOINLINE int epa_newface(EpaArena A, int a, int b, int c, bool forced) {
+    EpaRun& E = *A.run;
     int face;
-    if (E.free_root >= 0) { face = E.free_root; E.free_root = E.A.fc[face].l[1]; }
-    else if (E.next_fresh < E.A.cap_f) face = E.next_fresh++;
+    if (E.free_root >= 0) { face = E.free_root; E.free_root = A.fc[face].l[1]; }
+    else if (E.next_fresh < A.cap_f) face = E.next_fresh++;
     else {
-        if (E.A.cap_f < EPA_BT_MAX_FACES) { E.arena_full = true; return -1; }
+        if (A.cap_f < EPA_BT_MAX_FACES) { E.arena_full = true; return -1; }
         E.status = EPA_OUTOFFACES;                    // m_stock.root == 0
         return -1;
     }
-    epa_hull_append(E, face);
-    EpaFace& F = E.A.fc[face];
-    const EpaSV& A = E.A.sv[a]; const EpaSV& B = E.A.sv[b]; const EpaSV& C = E.A.sv[c];
+    epa_hull_append(A, face);
+    EpaFace& F = A.fc[face];
+    const V3 aw = A.sv[a].w, bw = A.sv[b].w, cw = A.sv[c].w;
     F.pass = 0; F.c[0] = (uint8_t)a; F.c[1] = (uint8_t)b; F.c[2] = (uint8_t)c;
-    F.n = cross(B.w - A.w, C.w - A.w);
-    const float l = len(F.n);
+    V3 n = cross(bw - aw, cw - aw);
+    const float l = len(n);
     const bool v = l > EPA_ACCURACY;
     if (v) {
         float d;
-        if (!(epa_edge_dist(F, A, B, d) || epa_edge_dist(F, B, C, d) || epa_edge_dist(F, C, A, d))) d = dot(A.w, F.n) / l;
+        if (!(epa_edge_dist(n, aw, bw, d) || epa_edge_dist(n, bw, cw, d) || epa_edge_dist(n, cw, aw, d))) d = dot(aw, n) / l;
         F.d = d;
-        F.n = vdiv_bt(F.n, l);
-        if (forced || (F.d >= -EPA_PLANE_EPS)) return face;
+        F.n = vdiv_bt(n, l);
+        if (forced || (d >= -EPA_PLANE_EPS)) return face;
         else E.status = EPA_NONCONVEX;
-    } else E.status = EPA_DEGENERATED;
-    epa_hull_remove(E, face);
-    epa_stock_push(E, face);
+    } else { F.n = n; E.status = EPA_DEGENERATED; }
+    epa_hull_remove(A, face);
+    epa_stock_push(A, face);
     return -1;
 }
-RLG_HD int epa_findbest(const EpaRun& E) {   // EPA::findbest (:825-839)
-    int minf = E.hull_root;
-    float mind = E.A.fc[minf].d * E.A.fc[minf].d;
-    for (int f = E.A.fc[minf].l[1]; f >= 0; f = E.A.fc[f].l[1]) {
-        const float sqd = E.A.fc[f].d * E.A.fc[f].d;
+RLG_HD int epa_findbest(const EpaArena& A) {   // EPA::findbest (:825-839)
+    int minf = A.run->hull_root;
+    float mind = A.fc[minf].d * A.fc[minf].d;
+    for (int f = A.fc[minf].l[1]; f >= 0; f = A.fc[f].l[1]) {
+        const float sqd = A.fc[f].d * A.fc[f].d;
         if (sqd < mind) { minf = f; mind = sqd; }
     }
     return minf;
 }
 struct EpaHorizon { int cf, ff, nf; };
 // EPA::expand (:840-871), its recursion unrolled onto A.stack: entry = face | edge << 8 | stage << 10
-RLG_HD bool epa_expand(EpaRun& E, int pass, int w, int f0, int e0, EpaHorizon& hz) {
-    uint16_t* st = E.A.stack; int sp = 0;
+RLG_HD_NOINLINE bool epa_expand(EpaArena A, int pass, int w, int f0, int e0, EpaHorizon& hz) {
+    EpaRun& E = *A.run;
+    uint16_t* st = A.stack; int sp = 0;
     st[sp++] = (uint16_t)(f0 | (e0 << 8));
     bool ret = false;
+    const V3 ww = A.sv[w].w;
     while (sp > 0) {
         const uint16_t top = st[sp - 1];
         const int f = top & 0xff, e = (top >> 8) & 3, stage = top >> 10;
-        EpaFace& F = E.A.fc[f];
+        EpaFace& F = A.fc[f];
         const int e1 = e == 2 ? 0 : e + 1, e2 = e == 0 ? 2 : e - 1;   // i1m3, i2m3
         if (stage == 0) {
             if (F.pass != (uint8_t)pass) {
-                if ((dot(F.n, E.A.sv[w].w) - F.d) < -EPA_PLANE_EPS) {
-                    const int nf = epa_newface(E, F.c[e1], F.c[e], w, false);
+                if ((dot(F.n, ww) - F.d) < -EPA_PLANE_EPS) {
+                    const int nf = epa_newface(A, F.c[e1], F.c[e], w, false);
                     if (nf >= 0) {
-                        epa_bind(E.A, nf, 0, f, e);
-                        if (hz.cf >= 0) epa_bind(E.A, hz.cf, 1, nf, 2); else hz.ff = nf;
+                        epa_bind(A, nf, 0, f, e);
+                        if (hz.cf >= 0) epa_bind(A, hz.cf, 1, nf, 2); else hz.ff = nf;
                         hz.cf = nf; ++hz.nf;
                         ret = true;
                     } else ret = false;
@@ -407,18 +415,18 @@ RLG_HD bool epa_expand(EpaRun& E, int pass, int w, int f0, int e0, EpaHorizon& h
                 } else {
                     F.pass = (uint8_t)pass;
                     st[sp - 1] = (uint16_t)(f | (e << 8) | (1 << 10));
-                    if (sp >= E.A.cap_f) { E.arena_full = true; return false; }
+                    if (sp >= A.cap_f) { E.arena_full = true; return false; }
                     st[sp++] = (uint16_t)(F.f[e1] | ((int)F.e[e1] << 8));
                 }
             } else { ret = false; sp--; }
         } else if (stage == 1) {
             if (ret) {
                 st[sp - 1] = (uint16_t)(f | (e << 8) | (2 << 10));
-                if (sp >= E.A.cap_f) { E.arena_full = true; return false; }
+                if (sp >= A.cap_f) { E.arena_full = true; return false; }
                 st[sp++] = (uint16_t)(F.f[e2] | ((int)F.e[e2] << 8));
             } else { ret = false; sp--; }
         } else {
-            if (ret) { epa_hull_remove(E, f); epa_stock_push(E, f); ret = true; }
+            if (ret) { epa_hull_remove(A, f); epa_stock_push(A, f); ret = true; }
             sp--;
         }
         if (E.arena_full) return false;
@@ -426,35 +434,31 @@ RLG_HD bool epa_expand(EpaRun& E, int pass, int w, int f0, int e0, EpaHorizon& h
     return ret;
 }
 
-struct EpaResult { int status; V3 normal; float depth; int rank; EpaSV c[3]; float p[3]; };
-// EPA::Evaluate (:648-742)
-RLG_HD int epa_evaluate(EpaArena& A, const EpaShapes& sh, bool margins, V3 guess, EpaResult& out, int* stat_verts = nullptr) {
-    EpaGjkState& G = *A.g;
-    EpaRun E; E.A = A; E.status = EPA_FAILED; E.hull_root = -1; E.hull_count = 0; E.free_root = -1; E.next_fresh = 0; E.nextsv = 0; E.arena_full = false;
+// EPA::Evaluate (:648-742); the result goes to *A.res
+RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
+    EpaGjkState& G = *A.g; const EpaShapes& sh = *A.sh; EpaResult& out = *A.res;
+    EpaRun& E = *A.run; E.status = EPA_FAILED; E.hull_root = -1; E.hull_count = 0; E.free_root = -1; E.next_fresh = 0; E.nextsv = 0; E.arena_full = false;
     if ((G.rank[G.cur] > 1) && epa_enclose_origin(G, sh, margins)) {
         E.status = EPA_VALID;
-        int sc[4] = {0, 1, 2, 3};
         for (int i = 0; i < 4; i++) A.sv[i] = G.sv[G.cur][i];
         if (epa_det(A.sv[0].w - A.sv[3].w, A.sv[1].w - A.sv[3].w, A.sv[2].w - A.sv[3].w) < 0.f) {
             const EpaSV t = A.sv[0]; A.sv[0] = A.sv[1]; A.sv[1] = t;   // btSwap(simplex.c[0], simplex.c[1]) (the weights p are not read again)
         }
-        (void)sc;
-        int tetra[4];
-        tetra[0] = epa_newface(E, 0, 1, 2, true);
-        tetra[1] = epa_newface(E, 1, 0, 3, true);
-        tetra[2] = epa_newface(E, 2, 1, 3, true);
-        tetra[3] = epa_newface(E, 0, 2, 3, true);
+        const int t0 = epa_newface(A, 0, 1, 2, true);
+        const int t1 = epa_newface(A, 1, 0, 3, true);
+        const int t2 = epa_newface(A, 2, 1, 3, true);
+        const int t3 = epa_newface(A, 0, 2, 3, true);
         if (E.arena_full) return EPA_ARENA_FULL;
         if (E.hull_count == 4) {
-            int best = epa_findbest(E);
+            int best = epa_findbest(A);
             EpaFace outer = A.fc[best];
             int pass = 0, iterations = 0;
-            epa_bind(A, tetra[0], 0, tetra[1], 0);
-            epa_bind(A, tetra[0], 1, tetra[2], 0);
-            epa_bind(A, tetra[0], 2, tetra[3], 0);
-            epa_bind(A, tetra[1], 1, tetra[3], 2);
-            epa_bind(A, tetra[1], 2, tetra[2], 1);
-            epa_bind(A, tetra[2], 2, tetra[3], 1);
+            epa_bind(A, t0, 0, t1, 0);
+            epa_bind(A, t0, 1, t2, 0);
+            epa_bind(A, t0, 2, t3, 0);
+            epa_bind(A, t1, 1, t3, 2);
+            epa_bind(A, t1, 2, t2, 1);
+            epa_bind(A, t2, 2, t3, 1);
             E.status = EPA_VALID;
             for (; iterations < EPA_BT_MAX_ITERATIONS; ++iterations) {
                 if (E.nextsv < EPA_BT_MAX_VERTICES) {
@@ -463,24 +467,24 @@ RLG_HD int epa_evaluate(EpaArena& A, const EpaShapes& sh, bool margins, V3 guess
                     const int w = 4 + E.nextsv++;
                     bool valid = true;
                     A.fc[best].pass = (uint8_t)(++pass);
-                    epa_getsupport(sh, margins, A.fc[best].n, A.sv[w]);
-                    const float wdist = dot(A.fc[best].n, A.sv[w].w) - A.fc[best].d;
+                    const V3 bn = A.fc[best].n;
+                    epa_getsupport(sh, margins, bn, A.sv[w]);
+                    const float wdist = dot(bn, A.sv[w].w) - A.fc[best].d;
                     if (wdist > EPA_ACCURACY) {
                         for (int j = 0; (j < 3) && valid; ++j) {
-                            valid &= epa_expand(E, pass, w, A.fc[best].f[j], A.fc[best].e[j], hz);
+                            valid &= epa_expand(A, pass, w, A.fc[best].f[j], A.fc[best].e[j], hz);
                             if (E.arena_full) return EPA_ARENA_FULL;
                         }
                         if (valid && (hz.nf >= 3)) {
                             epa_bind(A, hz.cf, 1, hz.ff, 2);
-                            epa_hull_remove(E, best);
-                            epa_stock_push(E, best);
-                            best = epa_findbest(E);
+                            epa_hull_remove(A, best);
+                            epa_stock_push(A, best);
+                            best = epa_findbest(A);
                             outer = A.fc[best];
                         } else { E.status = EPA_INVALIDHULL; break; }
                     } else { E.status = EPA_ACCURACY_REACHED; break; }
                 } else { E.status = EPA_OUTOFVERTICES; break; }
             }
-            if (stat_verts) *stat_verts = E.nextsv;
 #ifdef RLG_EPA_STATS
             RLG_EPA_STATS(E.nextsv, E.next_fresh, iterations, E.status);
 #endif
@@ -489,11 +493,12 @@ RLG_HD int epa_evaluate(EpaArena& A, const EpaShapes& sh, bool margins, V3 guess
             out.depth = outer.d;
             out.rank = 3;
             out.c[0] = A.sv[outer.c[0]]; out.c[1] = A.sv[outer.c[1]]; out.c[2] = A.sv[outer.c[2]];
-            out.p[0] = len(cross(out.c[1].w - projection, out.c[2].w - projection));
-            out.p[1] = len(cross(out.c[2].w - projection, out.c[0].w - projection));
-            out.p[2] = len(cross(out.c[0].w - projection, out.c[1].w - projection));
-            const float sum = out.p[0] + out.p[1] + out.p[2];
-            out.p[0] /= sum; out.p[1] /= sum; out.p[2] /= sum;
+            const V3 c0 = out.c[0].w, c1 = out.c[1].w, c2 = out.c[2].w;
+            float p0 = len(cross(c1 - projection, c2 - projection));
+            float p1 = len(cross(c2 - projection, c0 - projection));
+            float p2 = len(cross(c0 - projection, c1 - projection));
+            const float sum = p0 + p1 + p2;
+            out.p[0] = p0 / sum; out.p[1] = p1 / sum; out.p[2] = p2 / sum;
             out.status = E.status;
             return E.status;
         }
@@ -501,9 +506,10 @@ RLG_HD int epa_evaluate(EpaArena& A, const EpaShapes& sh, bool margins, V3 guess
     if (E.arena_full) return EPA_ARENA_FULL;
     // Fallback
     out.status = EPA_FALLBACK;
-    out.normal = -guess;
-    const float nl = len(out.normal);
-    if (nl > 0.f) out.normal = vdiv_bt(out.normal, nl); else out.normal = v3(1.f, 0.f, 0.f);
+    V3 nrm = -guess;
+    const float nl = len(nrm);
+    if (nl > 0.f) nrm = vdiv_bt(nrm, nl); else nrm = v3(1.f, 0.f, 0.f);
+    out.normal = nrm;
     out.depth = 0.f;
     out.rank = 1;
     out.c[0] = G.sv[G.cur][0];
@@ -516,7 +522,9 @@ RLG_HD int epa_evaluate(EpaArena& A, const EpaShapes& sh, bool margins, V3 guess
 // Returns 1: penetration (isValid2 = true), 0: calcPenDepth returned false (`v` and the witnesses may still be set: the second GJK's
 // distance), EPA_ARENA_FULL: repeat in a bigger arena.
 struct PenDepth { V3 v, wa, wb; };
-RLG_HD int epa_calc_pen_depth(EpaArena& A, const EpaShapes& sh, PenDepth& out, int* stat_verts = nullptr) {
+RLG_HD int epa_calc_pen_depth(EpaArena A, const EpaShapes& shapes, PenDepth& out) {
+    *A.sh = shapes;
+    const EpaShapes& sh = *A.sh;
     EpaGjkState& G = *A.g;
     for (int i = 0; i < 9; i++) {
         V3 guess;
@@ -526,9 +534,9 @@ RLG_HD int epa_calc_pen_depth(EpaArena& A, const EpaShapes& sh, PenDepth& out, i
         // Penetration
         const int gs = epa_gjk_evaluate(G, sh, true, -guess);
         if (gs == 1) {
-            EpaResult r;
-            const int es = epa_evaluate(A, sh, true, -guess, r, stat_verts);
+            const int es = epa_evaluate(A, true, -guess);
             if (es == EPA_ARENA_FULL) return EPA_ARENA_FULL;
+            const EpaResult& r = *A.res;
             V3 w0 = v3(0.f, 0.f, 0.f);
             for (int k = 0; k < r.rank; ++k) w0 += epa_support0(sh, r.c[k].d, true) * r.p[k];
             out.wa = (sh.R0 * w0) + sh.o0;

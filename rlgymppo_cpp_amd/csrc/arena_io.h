@@ -91,7 +91,13 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         pd.is_active = bits & 1u; pd.prev_locked = (int)(bits >> 1);
     }
     io.i(G.score_line[0]); io.i(G.score_line[1]); io.i(G.last_touch_car_id); io.l(G.last_tick_count); io.i(G.no_touch_steps);
-    io.f(G.shot_cooldown); io.u(G.tracker_flags); io.l(G.last_ball_update_count);
+    io.f(G.shot_cooldown);
+    {   // one word: the event tracker's three flags and, above them, the per-car loop order
+        uint32_t tf = (G.tracker_flags & 0xffu) | (A.car_order << 8);
+        io.u(tf);
+        G.tracker_flags = tf & 0xffu; A.car_order = tf >> 8;
+    }
+    io.l(G.last_ball_update_count);
     for (int k = 0; k < NC; k++) {
         for (int q = 0; q < 8; q++) io.i(G.counters[k][q]);
         for (int q = 0; q < RLGPU_NUM_EVENT_VALS; q++) io.f(G.event_last[k][q]);
@@ -135,6 +141,7 @@ RLG_HD void ctl_to(float* p, const Controls& c) {
 template <int NC>
 RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& s) {
     A.tick_count = s.tick_count; A.ball_update_counter = s.ball_update_counter;
+    A.car_order = car_order_checked(s.car_order, NC);
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
     for (int k = 0; k < NC; k++) {
@@ -178,7 +185,7 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
 
 template <int NC>
 RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaState& s) {
-    s.num_cars = NC; s._pad0 = 0;
+    s.num_cars = NC; s.car_order = A.car_order;
     s.tick_count = A.tick_count; s.ball_update_counter = A.ball_update_counter;
     st3(s.ball.pos, A.ball.b.pos * BT2UU); st3(s.ball.vel, A.ball.b.vel * BT2UU); st3(s.ball.ang_vel, A.ball.b.angvel);
     st3(s.ball.vel_impulse_cache, A.ball.vel_impulse_cache * BT2UU);

@@ -1081,7 +1081,7 @@ RLG_HD_NOINLINE void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pad
     RLG_ASSUME_LDS(A);
     if (!pads_done) {
         RLG_NOUNROLL
-        for (int i = 0; i < NC; i++) pads_lock(A, i, pads_check_car(A, pad_tab, i));
+        for (int k = 0; k < NC; k++) { const int i = car_at_rank(A, k); pads_lock(A, i, pads_check_car(A, pad_tab, i)); }
         for (int p = 0; p < 34; p++) pad_post_tick(A, p);
     }
     {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
@@ -1111,7 +1111,7 @@ RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_
     if (!W.Q.overflow)
         for (int i = 0; i < NC; i++) for (int pr = 0, n = car_ray_pairs(A, W.Q, i); pr < n; pr++) car_ray_pair(A, mesh, W.Q, i, pr, W.ctx[i]);
     for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_ray_finish(A, i, w, mesh, W.Q, W.ctx[i]);
-    for (int i = 0; i < NC; i++) car_pre_tick_finish(A, i, W.ctx[i]);
+    for (int k = 0; k < NC; k++) { const int i = car_at_rank(A, k); car_pre_tick_finish(A, i, W.ctx[i]); }   // Arena.cpp:716-812: the reference's car order
     tick_world_begin(A, W, false);
     collide_compact_and_run(A, mesh, W.Q);
     world_step_finish(A, mesh, ev, W, true);

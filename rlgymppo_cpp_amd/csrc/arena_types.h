@@ -253,6 +253,15 @@ struct Arena {
     Pad pads[34];
     int64_t tick_count;
     int64_t ball_update_counter;
+    uint32_t car_order;   // RlgpuArenaState::car_order: 4 bits per rank (slot + 1), 0 = slot order
 };
+// the car the arena's per-car loops visit k-th (Arena.cpp:716-812 iterates an unordered set of car pointers)
+template <int NC>
+RLG_HD int car_at_rank(const Arena<NC>& A, int k) { return A.car_order ? (int)((A.car_order >> (4 * k)) & 15u) - 1 : k; }
+RLG_HD uint32_t car_order_checked(uint32_t order, int nc) {   // a permutation of the slots, or 0
+    uint32_t seen = 0u;
+    for (int k = 0; k < nc; k++) { const int s = (int)((order >> (4 * k)) & 15u) - 1; if (s < 0 || s >= nc) return 0u; seen |= 1u << s; }
+    return seen == (1u << nc) - 1u && (order >> (4 * nc)) == 0u ? order : 0u;
+}
 
 }  // namespace rlg

@@ -15,6 +15,7 @@
 //   * the mesh BVH is this repo's own 32-byte AABB node layout (top levels staged in LDS on the device).
 #pragma once
 #include "arena_contact.h"
+#include "arena_simplex.h"
 
 namespace rlg {
 
@@ -445,47 +446,43 @@ RLG_HD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
     }
 }
 
-// last stage: ball (point vs sphere of radius 1.825), then the other cars' hitboxes
+// One dynamic object in a wheel ray's way, as btCollisionWorld::rayTestSingleInternal handles a convex shape (btCollisionWorld.cpp:267-310):
+// the subsimplex cast of a point, the reported normal normalised, kept when its fraction is below the closest so far.
+RLG_HD bool ray_convex_hit(V3 from, V3 to, const M3& Rb, V3 ob, V3 half, float radius, int kind, RayHit& best) {
+    float frac; V3 n;
+    if (!ray_convex_cast(from, to, Rb, ob, half, radius, frac, n)) return false;
+    if (!(len2(n) > 0.0001f)) return false;
+    if (!(frac < best.frac)) return false;
+    best.frac = frac; best.kind = kind; best.normal = normalized(n);
+    return true;
+}
+// the ray's and an object's boxes must come within 0.05 of each other before the cast is worth its GJK iterations (not in the reference's
+// result: the cast reports a hit only once the point is within sqrt(1e-4) = 0.01 of the shape, so a ray farther than that from the
+// object's box ends with lambda > 1 or VdotR >= 0)
+RLG_HD bool ray_box_near(V3 from, V3 to, V3 lo, V3 hi) {
+    const V3 m = v3(0.05f, 0.05f, 0.05f); lo = lo - m; hi = hi + m;
+    return !(fminf(from.x, to.x) > hi.x || fmaxf(from.x, to.x) < lo.x || fminf(from.y, to.y) > hi.y || fmaxf(from.y, to.y) < lo.y || fminf(from.z, to.z) > hi.z || fmaxf(from.z, to.z) < lo.z);
+}
+// last stage: the dynamic objects -- the ball (a btSphereShape), then the other cars' hitbox children (btBoxShape), each through the convex
+// cast.  (The ball's rotation is not part of the state this build keeps; its basis is taken as the identity: the support point of a sphere
+// does not depend on it beyond rounding.)
 template <int NC>
 RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, RayHit& best) {
     {
         const float r = K::BALL_RADIUS * UU2BT;
-        V3 d = to - from, m = from - A.ball.b.pos;
-        float a = dot(d, d), b = dot(m, d), c = dot(m, m) - r * r;
-        if (c > 0.f && b < 0.f) {
-            float disc = b * b - a * c;
-            if (disc >= 0.f) {
-                float t = (-b - sqrtf(disc)) / a;
-                if (t >= 0.f && t < best.frac) {
-                    best.frac = t; best.kind = 1;
-                    best.normal = normalized((from + d * t) - A.ball.b.pos);
-                }
-            }
-        }
+        const V3 bp = A.ball.b.pos;
+        if (ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r))) ray_convex_hit(from, to, m3_identity(), bp, v3(0, 0, 0), r, 1, best);
     }
     // other cars' hitboxes (demoed or respawned this tick: no contact response -> no hit, btDefaultVehicleRaycaster.cpp:41-43)
     for (int k = 0; k < NC; k++) {
         if (k == self_car) continue;
         const Car& o = A.cars[k];
         if ((o.flags & CF_IS_DEMOED) || o.frozen) continue;
-        V3 center = o.b.pos + o.b.rot * hitbox_off();
-        V3 lf = tmul(o.b.rot, from - center), lt = tmul(o.b.rot, to - center);
-        V3 d = lt - lf, h = hitbox_half();
-        float tn = 0.f, tf = best.frac; int axis = -1; float sgn = 0.f; bool ok = true;
-        for (int ax = 0; ax < 3 && ok; ax++) {
-            float o_ = get(lf, ax), d_ = get(d, ax), h_ = get(h, ax);
-            if (fabsf(d_) < 1e-12f) { if (fabsf(o_) > h_) ok = false; continue; }
-            float inv = 1.f / d_;
-            float t1 = (-h_ - o_) * inv, t2 = (h_ - o_) * inv; float s = -1.f;
-            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; s = 1.f; }
-            if (t1 > tn) { tn = t1; axis = ax; sgn = s; }
-            if (t2 < tf) tf = t2;
-            if (tn > tf) ok = false;
-        }
-        if (ok && axis >= 0 && tn < best.frac) {
-            V3 nl = v3(axis == 0 ? sgn : 0.f, axis == 1 ? sgn : 0.f, axis == 2 ? sgn : 0.f);
-            best.frac = tn; best.kind = 2 + k; best.normal = o.b.rot * nl;
-        }
+        const V3 center = o.b.pos + o.b.rot * hitbox_off();
+        const V3 h = hitbox_half();
+        const V3 e = abs_rows_dot(o.b.rot, h);
+        if (!ray_box_near(from, to, center - e, center + e)) continue;
+        ray_convex_hit(from, to, o.b.rot, center, h, 0.f, 2 + k, best);
     }
 }
 

@@ -71,27 +71,40 @@ __device__ unsigned int g_overflow[8];
 #define RLG_HAVE_OVERFLOW_COUNTS 1
 #endif
 // Where the penetration-depth solver (arena_epa.h: Bullet's second GJK + EPA, for hitbox-mesh contacts deeper than the collision margin)
-// keeps its state on the device.  Small arena: the frontier / query-box / candidate-slot part of the wavefront's first env's CollideQueue,
-// which is dead from the item compaction to the next tick's candidate walk -- 16 support vertices and 40 faces, enough for 99.9 % of the
-// queries (tools/gjk_fuzz.py prints the histogram); the wavefront's lanes use it one at a time (a ballot loop: only lanes that are in this
-// very branch together can collide).  Full-size arena (Bullet's 128 vertices / 256 faces): global memory, one per wavefront (EnvDev::epa_big).
-__shared__ unsigned char* g_epa_small_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
+// keeps its state on the device.  Small arenas: the frontier / query-box / candidate-slot part of every env's CollideQueue, which is dead
+// from the item compaction to the next tick's candidate walk -- 14 support vertices and 34 faces each, enough for 99.8 % of the queries
+// (tools/gjk_fuzz.py prints the histogram).  The lanes of a wavefront that need the solver at the same time (a ballot: only lanes that are
+// in this very branch together can collide) take the wavefront's arenas in rounds of one lane per arena.  Full-size arena (Bullet's 128
+// vertices / 256 faces): global memory, one per wavefront (EnvDev::epa_big), used by one lane at a time.
+#define RLG_EPA_MAX_ARENAS 4
+__shared__ unsigned char* g_epa_small_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED][RLG_EPA_MAX_ARENAS];
+__shared__ int g_epa_small_n[RLG_WAVES_PER_BLOCK_DEFAULTED];
 __shared__ unsigned char* g_epa_big_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
-#define RLG_EPA_LDS_V 16
-#define RLG_EPA_LDS_F 40
+#define RLG_EPA_LDS_V 14
+#define RLG_EPA_LDS_F 34
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RLG_EPA_ARENA_DECL \
-    EpaArena epa_small_ = epa_arena_at(g_epa_small_ptr[threadIdx.x >> 6], RLG_EPA_LDS_V, RLG_EPA_LDS_F); \
-    EpaArena epa_bigv_ = epa_arena_at(g_epa_big_ptr[threadIdx.x >> 6], EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); \
-    EpaArena* epa_big_ = g_epa_big_ptr[threadIdx.x >> 6] ? &epa_bigv_ : nullptr;
-#define RLG_EPA_SERIALIZE_BEGIN for (unsigned long long pend_ = __ballot(1); pend_; pend_ &= pend_ - 1ull) { if ((int)(threadIdx.x & 63u) == __ffsll((unsigned long long)pend_) - 1) { RLG_DBG_COUNT(5);
-#define RLG_EPA_SERIALIZE_END } }
-#define RLG_EPA_COUNT_BIG() RLG_DBG_COUNT(6)
+    const int epa_wave_ = threadIdx.x >> 6; \
+    EpaArena epa_small_ = epa_arena_at(g_epa_small_ptr[epa_wave_][0], RLG_EPA_LDS_V, RLG_EPA_LDS_F); \
+    EpaArena epa_bigv_ = epa_arena_at(g_epa_big_ptr[epa_wave_], EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); \
+    EpaArena* epa_big_ = nullptr;   /* (the full-size arena is taken in its own serialised pass: RLG_EPA_BIG_PASS) */
+// rounds over the lanes that are here together: lane of rank r takes arena r mod n in round r / n
+#define RLG_EPA_SERIALIZE_BEGIN { \
+    const unsigned long long pend_ = __ballot(1); \
+    const int rank_ = __popcll(pend_ & ((1ull << (threadIdx.x & 63u)) - 1ull)), total_ = __popcll(pend_), n_ar_ = g_epa_small_n[epa_wave_]; \
+    for (int base_ = 0; base_ < total_; base_ += n_ar_) { if (rank_ >= base_ && rank_ < base_ + n_ar_) { RLG_DBG_COUNT(5); \
+        epa_small_ = epa_arena_at(g_epa_small_ptr[epa_wave_][rank_ - base_], RLG_EPA_LDS_V, RLG_EPA_LDS_F);
+#define RLG_EPA_SERIALIZE_END } } }
+#define RLG_EPA_BIG_PASS(rc_, CALL) { \
+    for (unsigned long long pb_ = __ballot((rc_) == EPA_ARENA_FULL && g_epa_big_ptr[epa_wave_] != nullptr); pb_; pb_ &= pb_ - 1ull) \
+        if ((int)(threadIdx.x & 63u) == __ffsll((unsigned long long)pb_) - 1) { RLG_DBG_COUNT(6); epa_big_ = &epa_bigv_; CALL; } }
+#define RLG_EPA_COUNT_BIG() ((void)0)
 #else   // host pass of this translation unit: never executed
 #define RLG_EPA_ARENA_DECL alignas(16) unsigned char epa_mem_[epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES)]; \
     EpaArena epa_small_ = epa_arena_at(epa_mem_, EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES); EpaArena* epa_big_ = nullptr;
 #define RLG_EPA_SERIALIZE_BEGIN
 #define RLG_EPA_SERIALIZE_END
+#define RLG_EPA_BIG_PASS(rc_, CALL)
 #define RLG_EPA_COUNT_BIG() ((void)0)
 #endif
 #include "../../include/rlgpu.h"
@@ -296,7 +309,9 @@ __device__ __forceinline__ void epa_arenas_setup(const EnvDev& d, unsigned char*
     static_assert(offsetof(Q, frontier) % 4 == 0, "arena alignment");
     if ((threadIdx.x & 63) == 0) {
         const int wave = threadIdx.x >> 6;
-        g_epa_small_ptr[wave] = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W.Q.frontier[0][0]);
+        constexpr int EPW = lanes_per_block<NC>() / WPB, NA = EPW < RLG_EPA_MAX_ARENAS ? EPW : RLG_EPA_MAX_ARENAS;
+        for (int k = 0; k < NA; k++) g_epa_small_ptr[wave][k] = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k).W.Q.frontier[0][0]);
+        g_epa_small_n[wave] = NA;   // (the TickWork areas of a wavefront's empty env slots are as good as any)
         g_epa_big_ptr[wave] = d.epa_big ? d.epa_big + ((size_t)blockIdx.x * WPB + wave) * EPA_BIG_BYTES : nullptr;
     }
 }
@@ -509,8 +524,8 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (__ballot(ordered) == 0ull) {
         if (car_lane) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
     } else {
-        for (int k = 0; k < NC; k++) {   // a wheel stands on another car somewhere in this wave: car order matters
-            if (car_lane && c_car == k) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
+        for (int k = 0; k < NC; k++) {   // a wheel stands on another car somewhere in this wave: car order matters (the env's car_order: Arena.cpp:716-812)
+            if (car_lane && c_car == car_at_rank(Sc.A, k)) car_pre_tick_finish(Sc.A, c_car, Sc.W.ctx[c_car]);
             wave_sync();
         }
     }
@@ -598,7 +613,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, pad_tab, c_car); }
     wave_sync();
     RLG_FPROF(14); phase_sync(2);
-    if (env_lane) for (int i = 0; i < NC; i++) { const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
+    if (env_lane) for (int k = 0; k < NC; k++) { const int i = car_at_rank(Se.A, k); const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
     wave_sync();
     RLG_FPROF(15); phase_sync(2);
     {   // pads that hand out boost are rare: they go through the env lane in pad order, all the others finish in parallel

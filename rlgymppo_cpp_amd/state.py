@@ -77,7 +77,7 @@ class GymState(C.Structure):
 
 class ArenaState(C.Structure):
     _fields_ = [
-        ("num_cars", C.c_int32), ("_pad0", C.c_int32),
+        ("num_cars", C.c_int32), ("car_order", C.c_uint32),
         ("tick_count", C.c_int64), ("ball_update_counter", C.c_int64),
         ("ball", BallState), ("cars", CarState * MAX_CARS), ("pads", PadState * NUM_PADS), ("gym", GymState),
     ]

@@ -3,6 +3,7 @@
 mesh triangle; ref_adjust_internal_edge = btAdjustInternalEdgeContacts on the arena mesh's btTriangleInfoMap):
 
   gjk/*   3000 random Octane hitbox poses x triangles (faces, edges, vertices around the contact threshold): inputs + the detector's output
+  cast/*  3000 wheel rays against a hitbox / the ball: inputs + what btCollisionWorld::rayTestSingle (btSubsimplexConvexCast) reports
   edge/*  40 contact points per triangle of the procedural arena (near its edges, normals around the face's and the neighbour's):
           inputs + the adjusted point
 
@@ -63,6 +64,15 @@ def main():
             assert ref.ref_adjust_internal_edge(ti, p(V32.reshape(9).copy()), p(e_pb[k]), p(e_n[k]), e_d[k], p(e_out[k])) == 0
             k += 1
     res.update({"edge/tri": e_tri, "edge/pb": e_pb, "edge/n": e_n, "edge/dist": e_d, "edge/out": e_out})
+    # cast/*: 3000 wheel-sized rays against an Octane hitbox at a random pose or the ball: btCollisionWorld::rayTestSingle (btSubsimplexConvexCast)
+    import cast_fuzz
+    m = 3000
+    c_from = np.zeros((m, 3), np.float32); c_to = np.zeros((m, 3), np.float32); c_rad = np.zeros(m, np.float32); c_pos = np.zeros((m, 3), np.float32)
+    c_rot = np.zeros((m, 9), np.float32); c_out = np.zeros((m, 4), np.float32); c_hit = np.zeros(m, np.int32)
+    for i in range(m):
+        c_from[i], c_to[i], c_rad[i], c_pos[i], c_rot[i] = cast_fuzz.case(rng)
+        c_hit[i] = cast_fuzz.ref.ref_ray_convex(p(c_from[i]), p(c_to[i]), p(cast_fuzz.HALF), c_rad[i], p(c_pos[i]), p(c_rot[i]), p(c_out[i]))
+    res.update({"cast/half": cast_fuzz.HALF, "cast/from": c_from, "cast/to": c_to, "cast/radius": c_rad, "cast/pos": c_pos, "cast/rot": c_rot, "cast/hit": c_hit, "cast/out": c_out})
     np.savez_compressed(os.path.join(HERE, "narrowphase_golden.npz"), **res)
     print({k: v.shape for k, v in res.items()}, "gjk hits", int(hit.sum()))
 

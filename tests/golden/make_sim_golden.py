@@ -268,6 +268,7 @@ def main():
         a = ref.arena(nc // 2)
         ref.set_state(a, s0)
         start = ref.get_state(a)
+        s0.car_order = start.car_order     # the arena's per-car loop order (an accident of heap addresses in the reference) travels with the state
         pair_arena = ref.arena(nc // 2)   # one-tick pairs are stepped from the RECORDED state (set_state) in an arena of their own
         tape = np.zeros((ticks, nc, 8), np.float32)
         rec = []
@@ -283,7 +284,11 @@ def main():
                 # The free-running arena above never leaves Bullet units; a state read from it is rounded to uu and back once more than
                 # its own next tick sees.  So the pair's "after" is what the reference computes FROM the recorded "before": both sides of
                 # the comparison then start from the same bits (grounded cars and a flying ball come out bit-equal that way).
+                # (One pair arena per tape, stepped through the tape's pairs in turn: what a state does not carry -- the wheels' previous-tick
+                # raycast records -- is then what the previous contact tick left, as in the free-running arena.  Its car order is its own:
+                # the pair's "before" is given the pair arena's order.)
                 ref.set_state(pair_arena, before)
+                before.car_order = ref.get_state(pair_arena).car_order
                 for k in range(nc):
                     ref.set_controls(pair_arena, k, list(tape[t, k]))
                 ref.step(pair_arena, 1)

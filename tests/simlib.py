@@ -203,11 +203,9 @@ def _tol(pos, vel, ang, rot, until=None):
 # Free-run tolerances (uu, uu/s, rad/s, rotation-matrix entries) over the WHOLE tape unless `until` is given: the loose table, kept for
 # runs that start from the state READ BACK from the reference (phys/<name>/start: once through Bullet units) -- the exact statement is
 # PHYS_EXACT_UNTIL below, for runs from the state set_state was given.  The restatement follows the reference's x86 arithmetic down to its
-# rsqrtss-based normalize, the SSE summation orders of its quaternion / matrix code and of its row solver (rl_math.h, arena_step.h), and
-# the narrowphase routines are bit-identical to Bullet's on fuzzed inputs; what is not the reference's to the bit is EPA (contacts 10+ uu
-# deep), so a trajectory that passes through such a contact leaves the reference: car_into_goal at tick 163; car_into_side_wall in its
-# last ten ticks; 3v3_kickoff in the six-car heap; demo_and_respawn (which used to leave at tick 370: a ball contact on the crossbar edge
-# decided on the sign of a 1e-8 dot product) holds for 600 of its 620 ticks.
+# rsqrtss-based normalize, the SSE summation orders of its quaternion / matrix code and of its row solver (rl_math.h, arena_step.h); the
+# narrowphase routines -- GJK, the penetration-depth solver (second GJK + EPA, arena_epa.h), the internal-edge adjustment -- are
+# bit-identical to Bullet's on fuzzed inputs.
 PHYS_FREE_RUN = {
     "rest": _tol(0.005, 0.005, 1e-4, 1e-5), "throttle": _tol(0.01, 0.02, 1e-4, 1e-5), "steer_powerslide": _tol(0.03, 0.02, 1e-3, 1e-4),
     "jump": _tol(0.01, 0.05, 1e-3, 1e-4), "flip": _tol(0.02, 0.02, 1e-3, 1e-4), "double_jump": _tol(0.02, 0.05, 1e-3, 1e-4),
@@ -222,22 +220,21 @@ PHYS_FREE_RUN = {
     "2v2_ball_chase": _tol(0.15, 0.1, 2e-3, 1e-4), "3v3_kickoff": _tol(0.1, 0.1, 1e-3, 1e-4, until=230),
 }
 # Ticks for which a free run (inside the stepper's units, from the state the reference's set_state was given: phys/<name>/start_raw) is
-# BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed (27 of the 31): their whole length.
-# What ends the four: car_into_goal -- a 12 uu deep contact at tick 163 (EPA); car_into_side_wall -- the last ten ticks;
-# demo_and_respawn -- the last forty ticks (after the second wall hit of the respawned car); 3v3_kickoff -- the six-car heap from tick 282 on.
-PHYS_EXACT_UNTIL = {"car_into_goal": 160, "car_into_side_wall": 290, "demo_and_respawn": 580, "3v3_kickoff": 280}
+# BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed: their whole length.
+PHYS_EXACT_UNTIL = {"3v3_kickoff": 280}   # the six-car heap.  What is left there is not a function of the state the reference exposes: the order of
+# the pairs inside a broadphase cell follows the order in which the bodies entered it, and a wheel ray only sees the bodies whose boxes of the
+# PREVIOUS tick reach the ray's cell (btRSBroadphase.cpp:326-358, 393-469) -- the reference itself gives another answer from the same state in
+# a fresh arena (tools/exact_horizons.py).  Wheels standing on cars (btSubsimplexConvexCast) and the arena's car order are exact.
 # ... and how close a tape stays after that, until the given tick (pos uu, vel uu/s, ang rad/s, rot)
-PHYS_AFTER_EXACT = {"demo_and_respawn": (600, (0.2, 1.5, 0.02, 5e-3))}
+PHYS_AFTER_EXACT = {}
 
-# One tick from the reference's own state: 98 % of the 1721 recorded pairs agree to 0.01 uu/s (median 2e-5).
+# One tick from the reference's own state: every recorded pair of 30 of the 31 scenarios is bit-equal (asserted in the tests); the tolerances
+# below are what the 19 pairs of the six-car heap that are not (of its 113) stay within.
 ONE_TICK_TOL = {
-    "default": {"pos": 0.1, "vel": 0.15},                               # pos: a mesh contact deeper than the hitbox margin is pushed out along the
-                                                                        # minimum-translation axis here, along EPA's answer in the reference (<= 0.06 uu apart in the fixtures)
-    "car_into_goal": {"pos": 0.1, "vel": 1.0},                          # ticks 163, 166-168: GJK on a near-degenerate edge pair / a 12 uu deep contact (EPA), 0.77 uu/s at most
-    "demo_and_respawn": {"pos": 0.02, "vel": 1.0},                      # ticks 587-591: deep wall hit, EPA
-    "car_into_side_wall": {"pos": 0.1, "vel": 0.15},                    # tick 298: the same (push-out of a deep mesh contact)
-    "3v3_kickoff": {"pos": 1.5, "vel": 150.0, "flags_loose": True},     # ticks 300-355: the six-car heap, wheels standing on hitboxes (a wheel ray against another car's box is a convex cast in the reference)
+    "default": {"pos": 0.0, "vel": 0.0},
+    "3v3_kickoff": {"pos": 5.0, "vel": 500.0, "flags_loose": True},     # ticks 282-356: pair order inside a broadphase cell / stale proxy boxes (see PHYS_EXACT_UNTIL); tick 317: a supersonic car into the heap
 }
+ONE_TICK_NOT_EXACT_MAX = 19      # pairs (of 1722) that are not bit-equal to the reference, all in 3v3_kickoff
 
 
 # observation tolerance per gym fixture (default 2e-3 = 8 uu on a position, 4.6 uu/s on a velocity, 0.011 rad/s on an angular velocity)

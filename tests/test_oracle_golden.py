@@ -196,40 +196,35 @@ def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
                 pos, vel, ang, rot, flags_differ = phys_errors(got, want[j], nc)
                 tp, tv, ta, tr = PHYS_AFTER_EXACT[name][1]
                 assert pos <= tp and vel <= tv and ang <= ta and rot <= tr and not flags_differ, f"{name} tick {t}: pos {pos:.5f} vel {vel:.5f} ang {ang:.6f} rot {rot:.7f}"
-    assert whole == 27
+    assert whole == 31 - len(PHYS_EXACT_UNTIL)
     print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 4 partial")
 
 
 def test_port_one_tick_vs_reference_states():
     """1722 (state, state one tick later) pairs recorded from the reference -- every tick with a narrowphase contact and every 16th
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),
-    so both sides start from the same bits.  Since the restatement follows the reference's x86 arithmetic (rl_math.h, rl_libm.h, the
-    planes' ray triangles, the numeric inertia inverse, the SSE2 row solver's dot products, the ball through GJK) nearly all pairs are
-    EQUAL bit for bit; asserted: at least 93 % of all pairs, and every pair of the 25 scenarios listed in EXACT (what is left: the
-    six-car heap of 3v3_kickoff, contacts 10+ uu deep -- EPA --, two ball contacts on fillet / wall edges)."""
-    from simlib import PortSim
+    so both sides start from the same bits.  The restatement follows the reference's x86 arithmetic (rl_math.h, rl_libm.h) and its
+    narrowphase to the bit (GJK, the penetration-depth solver with EPA, the wheel rays' convex cast, the internal-edge adjustment), and the
+    state carries the arena's car order: EVERY pair of 30 scenarios is EQUAL bit for bit, and all but 19 of the six-car heap's 113."""
+    from simlib import PortSim, ONE_TICK_NOT_EXACT_MAX
     sgl = np.load(os.path.join(GOLD, "sim_golden.npz")); ss = np.load(os.path.join(GOLD, "sim_steps.npz"))
     port = PortSim(); port.set_mesh(sgl["mesh_verts"], sgl["mesh_tris"])
     names = [str(x) for x in ss["phys_names"]]
-    EXACT = {"2v2_ball_chase", "aerial_hit", "air_control", "ball_drop", "ball_into_goal", "ball_on_roof", "ball_pinch_back_wall", "ball_roll",
-             "ball_side_wall", "boost_pad_pickup", "boost_turn", "car_car_head_on", "car_hits_ball", "car_into_back_wall", "car_into_corner_wall",
-             "double_jump", "flip", "jump", "rest", "roof_landing_autoflip", "side_bump", "steer_powerslide", "throttle", "tumbling_drops", "wall_ramp"}
-    n_tight = n_all = n_exact = 0
+    n_all = n_exact = 0
     for nc in (2, 4, 6):
         B, A, T = ss[f"nc{nc}/before"], ss[f"nc{nc}/after"], ss[f"nc{nc}/tag"]
         for i in range(len(B)):
             st = ArenaState.from_buffer_copy(B[i].tobytes()); port.step(st, 1)
             want = ArenaState.from_buffer_copy(A[i].tobytes())
-            pos, vel, ang, rot, flags_differ = phys_errors(state_vec(st), state_vec(want), nc)
-            tol = ONE_TICK_TOL.get(names[T[i][0]], ONE_TICK_TOL["default"])
-            assert pos <= tol["pos"] and vel <= tol["vel"], f"{names[T[i][0]]} tick {T[i][1]}: one-tick error pos {pos:.4f} vel {vel:.4f}"
-            assert not flags_differ or tol.get("flags_loose"), f"{names[T[i][0]]} tick {T[i][1]}: flags differ"
             exact = np.array_equal(state_vec(st), state_vec(want))
-            assert exact or names[T[i][0]] not in EXACT, f"{names[T[i][0]]} tick {T[i][1]}: not bit-equal to the reference (pos {pos:.3g} vel {vel:.3g})"
-            n_all += 1; n_tight += (vel <= 0.01 and pos <= 0.002); n_exact += exact
-    assert n_tight >= 0.95 * n_all, f"only {n_tight} of {n_all} one-tick pairs within 0.01 uu/s"
-    assert n_exact >= 0.93 * n_all, f"only {n_exact} of {n_all} one-tick pairs bit-equal to the reference"
-    print(f"one-tick pairs: {n_exact} of {n_all} bit-equal to the reference, {n_tight} within 0.01 uu/s")
+            if not exact:
+                pos, vel, ang, rot, flags_differ = phys_errors(state_vec(st), state_vec(want), nc)
+                tol = ONE_TICK_TOL.get(names[T[i][0]], ONE_TICK_TOL["default"])
+                assert pos <= tol["pos"] and vel <= tol["vel"], f"{names[T[i][0]]} tick {T[i][1]}: not bit-equal to the reference (pos {pos:.4g} vel {vel:.4g})"
+                assert not flags_differ or tol.get("flags_loose"), f"{names[T[i][0]]} tick {T[i][1]}: flags differ"
+            n_all += 1; n_exact += exact
+    assert n_all - n_exact <= ONE_TICK_NOT_EXACT_MAX, f"only {n_exact} of {n_all} one-tick pairs bit-equal to the reference"
+    print(f"one-tick pairs: {n_exact} of {n_all} bit-equal to the reference")
 
 
 @pytest.fixture(scope="module")
@@ -300,10 +295,11 @@ def test_state_setters_against_reference_samples(sg, port_lib):
                 for c in range(ref.shape[1]):
                     lo, hi = float(ref[:, c].min()), float(ref[:, c].max()); span = max(hi - lo, 1e-3)
                     # sample extremes of 4000 draws are noisy where the density thins out towards the end of the support: 10 % slack there,
-                    # 4 % of the span on the quantiles
+                    # 5 % of the span on the quantiles (the reference's generator is seeded from the wall clock: every regeneration of the
+                    # fixture is another sample, and 4 % was within one sample's noise for the rotation-matrix columns)
                     assert got[:, c].min() >= lo - 0.1 * span - 1e-4 and got[:, c].max() <= hi + 0.1 * span + 1e-4, f"random team {team} col {c}: outside the reference's support"
                     dq = np.abs(np.percentile(got[:, c], qs) - np.percentile(ref[:, c], qs)).max()
-                    assert dq < 0.04 * span + 1e-4, f"random team {team} col {c}: quantiles differ by {dq} (span {span})"
+                    assert dq < 0.05 * span + 1e-4, f"random team {team} col {c}: quantiles differ by {dq} (span {span})"
 
 
 def test_cabi_exports_every_declared_symbol():
@@ -354,32 +350,46 @@ def test_mesh_triangle_visiting_order_is_the_references(port_lib):
 
 
 def test_narrowphase_routines_vs_reference_golden(port_lib):
-    """The two Bullet routines the narrowphase restates, against outputs of the reference's OWN code (tests/golden/narrowphase_golden.npz,
+    """The Bullet routines the narrowphase restates, against outputs of the reference's OWN code (tests/golden/narrowphase_golden.npz,
     make_narrowphase_golden.py): (1) csrc/arena_gjk.h:gjk_box_triangle vs btGjkPairDetector set up as btConvexConvexAlgorithm does for a
-    hitbox against a mesh triangle, 3000 poses -- same report flag, normal / point / distance equal (bit-identical on the build host;
-    1e-6 allowed for another compiler), except where the box cores overlap and the reference asks EPA (flagged `deep` here, DESIGN 2);
-    (2) csrc/arena_world.h:adjust_internal_edge vs btAdjustInternalEdgeContacts on the procedural arena's edge records, 7200 points --
-    every normal and point EQUAL (the routine decides on the sign of 1e-8 dot products at right-angled edges, so this needs the
-    reference's arithmetic to the bit: its rsqrtss-based normalize and the SSE summation orders of its quaternion / matrix code,
-    csrc/rl_math.h; with the portable forms 3 of these points came out on the other side of the fence)."""
+    hitbox against a mesh triangle, 3000 poses -- same report flag, normal / point / distance EQUAL, including the ~800 poses whose cores
+    overlap and go through the penetration-depth solver (second GJK + EPA, csrc/arena_epa.h); (2) csrc/arena_simplex.h:ray_convex_cast vs
+    btCollisionWorld::rayTestSingle (btSubsimplexConvexCast), 3000 wheel rays against a hitbox or the ball -- same hit flag, fraction and
+    normal EQUAL; (3) csrc/arena_world.h:adjust_internal_edge vs btAdjustInternalEdgeContacts on the procedural arena's edge records,
+    7200 points -- every normal and point EQUAL (the routine decides on the sign of 1e-8 dot products at right-angled edges, so this needs
+    the reference's arithmetic to the bit: its rsqrtss-based normalize and the SSE summation orders of its quaternion / matrix code)."""
     g = np.load(os.path.join(GOLD, "narrowphase_golden.npz"))
     lib = port_lib.lib
     FP = C.POINTER(C.c_float)
     lib.port_gjk_box_triangle.argtypes = [FP, FP, FP, C.c_float, FP]
-    n = len(g["gjk/pos"]); compared = 0; deep = 0; worst = 0.0
+    n = len(g["gjk/pos"]); compared = 0
+    st = (C.c_int * 64)(); lib.port_epa_stats(st, 1)
     for i in range(n):
         pos = np.ascontiguousarray(g["gjk/pos"][i]); rot = np.ascontiguousarray(g["gjk/rot"][i]); tri = np.ascontiguousarray(g["gjk/tri"][i])
         out = np.zeros(8, np.float32)
         hit = lib.port_gjk_box_triangle(pos.ctypes.data_as(FP), rot.ctypes.data_as(FP), tri.ctypes.data_as(FP), float(g["gjk/breaking"]), out.ctypes.data_as(FP))
-        if out[7] != 0:
-            deep += 1; continue
+        assert out[7] == 0, "the host build has a full-size penetration-depth arena"
         assert hit == g["gjk/hit"][i], f"gjk case {i}: reported {hit}, reference {g['gjk/hit'][i]}"
         if hit:
             compared += 1
-            err = float(np.abs(out[:7] - g["gjk/out"][i][:7]).max()); worst = max(worst, err)
-            assert err <= 1e-6, f"gjk case {i}: {out[:7]} vs reference {g['gjk/out'][i][:7]}"
-    assert compared > 1500 and deep < n // 2
-    print(f"gjk: {compared} points compared, worst |diff| {worst:g}, {deep} deep cases left to the fallback")
+            assert np.array_equal(out[:7], g["gjk/out"][i][:7]), f"gjk case {i}: {out[:7]} vs reference {g['gjk/out'][i][:7]}"
+    lib.port_epa_stats(st, 1)
+    assert compared > 2500 and st[0] > 500, (compared, st[0])
+    print(f"gjk: {compared} points equal to the reference's, {st[0]} of them through EPA (at most {st[1]} support vertices, {st[2]} faces)")
+    # convex cast of the wheel rays
+    lib.port_ray_convex.argtypes = [FP, FP, FP, C.c_float, FP, FP, FP]
+    m = len(g["cast/from"]); hits = 0
+    half = np.ascontiguousarray(g["cast/half"])
+    for i in range(m):
+        a = [np.ascontiguousarray(g[f"cast/{k}"][i]) for k in ("from", "to", "pos", "rot")]
+        out = np.zeros(4, np.float32)
+        hit = lib.port_ray_convex(a[0].ctypes.data_as(FP), a[1].ctypes.data_as(FP), half.ctypes.data_as(FP), float(g["cast/radius"][i]), a[2].ctypes.data_as(FP), a[3].ctypes.data_as(FP), out.ctypes.data_as(FP))
+        assert hit == g["cast/hit"][i], f"cast case {i}: hit {hit}, reference {g['cast/hit'][i]}"
+        if hit:
+            hits += 1
+            assert np.array_equal(out, g["cast/out"][i]), f"cast case {i}: {out} vs reference {g['cast/out'][i]}"
+    assert hits > 1000
+    print(f"convex cast: {hits} hits of {m} rays equal to the reference's")
     # edge adjustment
     pv, pt = port_lib.procedural_mesh(); port_lib.set_mesh(pv, pt)
     order = np.zeros(len(pt), np.int32)
