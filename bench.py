@@ -146,6 +146,9 @@ def main():
     if not os.path.exists(exe):
         raise SystemExit("bench.py: rlgymppo_cpp_amd/bench_main is not built (python -c 'import __graft_entry__ as g; g.build()') -- there is no other path")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     cmd = [exe, "--envs", str(args.envs), "--team-size", str(args.team_size), "--horizon", str(args.horizon), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--epochs", str(args.epochs)]
     if args.padded_zero_sum: cmd.append("--padded-zero-sum")
@@ -170,9 +173,14 @@ def main():
     gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     kname = (f"k_env_collect<{n_p}> ({args.horizon} x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)"
              if m["fused_collect"] else f"k_env_step<{n_p}> (8 ticks + snapshot/obs/reward/done/auto-reset fused)")
+    # (the fused launch keeps the arena state in LDS for all its gym steps: counted once per launch instead of once per step the same
+    # launch moves `bytes_state_once` -- the 8d figure is the algorithmic upper bound the survey prescribes, this is what must cross HBM)
+    state_bytes = 2.0 * (336.0 * n_p + 264.0)
+    bytes_state_once = (state_bytes + (A - state_bytes) * m["gym_steps_per_launch"]) * args.envs
     roof = {"kernel": kname, "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
             "avg_launch_ms": avg_ms, "launches": m["env_launches"], "algorithmic_bytes_per_launch": bytes_per_launch,
-            "formula": "SURVEY 8d: (2*(336*Np+264) + Np*(4*D+8) + 4) B per gym step per env x envs x gym steps per launch"}
+            "formula": "SURVEY 8d: (2*(336*Np+264) + Np*(4*D+8) + 4) B per gym step per env x envs x gym steps per launch",
+            "achieved_state_once": bytes_state_once / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "bytes_per_launch_state_once": bytes_state_once}
     pmc = pmc_profile("k_env_collect" if m["fused_collect"] else "k_env_step")
     if pmc is not None:
         roof["traffic"] = pmc.get("hbm_bytes_per_launch")
@@ -180,6 +188,7 @@ def main():
             if k in pmc:
                 roof["pmc_" + k if not k.startswith("traffic") else k] = pmc[k]
     tflops = m["gemm_flops_total"] / (m["gemm_ms_total"] * 1e-3) / 1e12 if m["gemm_ms_total"] > 0 else 0.0
+    peak_tflops = 157.3 if args.fp32 else 2500.0     # dense MFMA peaks, MI355X_MICROARCH.md: fp32 (v_mfma_f32_32x32x2_f32) / bf16
     out = {
         "metric": f"env steps/sec/node + PPO iter ms, {args.team_size}v{args.team_size} {args.envs} envs/GPU",
         "value": m["value"], "unit": "agent-steps/s",
@@ -195,8 +204,11 @@ def main():
         "ppo_iter_ms": m["ppo_iter_ms"], "gym_steps_per_s": m["value"] / n_p, "physics_ticks_per_s": m["value"] / n_p * 8,
         "collect_ms_per_iter": m["ms_per_step"] - m["ppo_iter_ms"],
         "roofline": roof,
-        "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": tflops, "peak_tflops": 2500.0,
-                 "ms_total": m["gemm_ms_total"], "calls": m["gemm_calls"], "frac": tflops / 2500.0},
+        "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": tflops, "peak_tflops": peak_tflops,
+                 "ms_total": m["gemm_ms_total"], "calls": m["gemm_calls"], "frac": tflops / peak_tflops},
+        # multi-GPU audit trail (bench_main): RCCL ranks that took part (0 = no communicator), each rank's own ms per iteration, one gradient all-reduce
+        "rccl_ranks": m.get("rccl_ranks", 0), "rank_ms_per_step": m.get("rank_ms_per_step", []),
+        "allreduce_ms_per_optimizer_step": m.get("allreduce_ms_per_optimizer_step", 0.0), "allreduce_calls": m.get("allreduce_calls", 0),
     }
     if "trained_regime" in m:
         out["trained_regime"] = dict(m["trained_regime"], note="same learner config (1 epoch) continued; at this point play is still close to random. "

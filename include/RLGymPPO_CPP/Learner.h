@@ -61,6 +61,9 @@ public:
     void DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset);
     bool UsesFusedCollection() const;
     double MaxOverRanks(double v);                   // collective; returns v on a single-GPU run
+    std::vector<double> GatherOverRanks(double v);   // collective; every rank's v, indexed by rank
+    // the gradient all-reduces timed with events on the learner's stream since DeviceTimings() switched the device clocks on
+    void AllReduceTimings(float& ms, int& calls, bool reset);
 private:
     struct Impl; Impl* impl;
 };

@@ -212,6 +212,11 @@ int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
  * forward pass).  For LearnerConfig::collectionDuringLearn: the learning stream calls it after every optimizer step, so that inference on
  * the collection stream reads the live weights like the reference's agent threads do (ThreadAgent.cpp:72-103). */
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l);
+/* collectionDuringLearn (LearnerConfig.h:46-50) puts rlgpu_policy_act / rlgpu_value_forward on another stream than the PPO epochs.  That is
+ * only sound when inference does not share the learner's activation scratch with rlgpu_ppo_minibatch: 1 = it runs in the fused inference
+ * kernel (bf16 mode, nets that fit its LDS), 0 = it does not and the host must keep collection and learning in sequence.  (The collector
+ * reads the live weights either way, as the reference's does: PRIV/Threading/ThreadAgent.cpp:60-70 has no snapshot.) */
+int rlgpu_learner_inference_is_standalone(const rlgpu_learner* l);
 /* Action-sampler key: the Philox noise of the sampler is keyed on (seed, stream, call counter, row).  `stream` separates ranks that
  * share an init seed (identical parameters, independent exploration: rank r sets stream r); `call_ctr` is the number of act calls made
  * so far -- restored from a checkpoint so that a resumed run does not replay the first iterations' noise. */

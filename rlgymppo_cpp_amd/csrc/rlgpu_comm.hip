@@ -15,6 +15,13 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
+#include <ctime>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include "../../include/rlgpu.h"
 
@@ -42,26 +49,54 @@ int rlgpu_comm_unique_id(void* id_out) {
     return RLGPU_OK;
 }
 
+// ncclCommInitRank is collective and has no timeout of its own: a rank that never arrives (a crashed peer, a stale rendezvous id) would
+// hang the others for ever.  It runs on a helper thread; past RLGPU_COMM_TIMEOUT_S (default 60 s) the caller gets an error back and is
+// expected to exit (the helper thread is left behind: a process in that state cannot use the communicator anyway).
 int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const void* id_bytes) {
     if (!out || !id_bytes || world < 1 || rank < 0 || rank >= world) return RLGPU_ERR_ARG;
-    rlgpu_comm* c = new rlgpu_comm();
-    c->device = device; c->rank = rank; c->world = world;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, "hipSetDevice failed"); }
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "hipSetDevice(" + std::to_string(device) + ") failed");
+    struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto job = std::make_shared<Job>();
     ncclUniqueId id; memcpy(&id, id_bytes, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
-    if (r != ncclSuccess) { std::string m = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); delete c; return fail(nullptr, m); }
+    std::thread([job, id, device, rank, world]() {
+        (void)hipSetDevice(device);
+        ncclComm_t comm = nullptr;
+        ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->r = r; job->comm = comm; job->done = true; job->cv.notify_all();
+    }).detach();
+    const char* tv = getenv("RLGPU_COMM_TIMEOUT_S");
+    const int timeout_s = tv && atoi(tv) > 0 ? atoi(tv) : 60;
+    {
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (!job->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return job->done; }))
+            return fail(nullptr, "ncclCommInitRank: rank " + std::to_string(rank) + " of " + std::to_string(world) + " timed out after " + std::to_string(timeout_s) + " s (a peer never arrived, or a stale rendezvous id)");
+    }
+    if (job->r != ncclSuccess) return fail(nullptr, std::string("ncclCommInitRank: ") + ncclGetErrorString(job->r));
+    rlgpu_comm* c = new rlgpu_comm();
+    c->device = device; c->rank = rank; c->world = world; c->comm = job->comm;
     *out = c;
     return RLGPU_OK;
 }
 
-// rank / world / rendezvous from the launcher's environment (torchrun or any launcher that sets RANK, WORLD_SIZE, LOCAL_RANK,
-// MASTER_PORT): rank 0 writes its id to $RLGPU_COMM_DIR (default /tmp)/rlgpu_comm_<MASTER_PORT>_<RLGPU_COMM_TAG or the launcher's pid>.id, the others wait for it
-// Where the ranks of one launch meet: <RLGPU_COMM_DIR or /tmp>/rlgpu_comm_<MASTER_PORT>_<tag>.id.  The tag keeps a stale file of an earlier
-// launch on the same port apart: RLGPU_COMM_TAG when the launcher of the ranks sets one (bench.py does: its ranks' programs are children of
-// one Python process EACH), else the parent's pid -- the ranks of `torch.distributed.run my_program` are children of the same agent.
+// Where the ranks of one launch meet: <dir>/rlgpu_comm_<MASTER_PORT>_<tag>.id.  dir = RLGPU_COMM_DIR, else a directory of the user's own
+// (/tmp/rlgpu_comm_<uid>, mode 0700, checked to be a real directory owned by the user) -- not a predictable name in world-writable /tmp.
+// The tag keeps launches on the same port apart: RLGPU_COMM_TAG when the launcher of the ranks sets one (bench.py does: its ranks' programs
+// are children of one Python process EACH), else the parent's pid -- the ranks of `torch.distributed.run my_program` are children of the
+// same agent.  Node-local: a multi-node launch needs RLGPU_COMM_DIR on a shared file system.
+static std::string rendezvous_dir() {
+    const char* dir = getenv("RLGPU_COMM_DIR");
+    if (dir && *dir) return dir;
+    const std::string d = "/tmp/rlgpu_comm_" + std::to_string((long)getuid());
+    (void)mkdir(d.c_str(), 0700);
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string();   // somebody else's: refuse
+    return d;
+}
 static std::string rendezvous_path() {
-    const char* dir = getenv("RLGPU_COMM_DIR"); const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG");
-    return std::string(dir ? dir : "/tmp") + "/rlgpu_comm_" + (port ? port : "0") + "_" + (tag ? tag : std::to_string((long)getppid())) + ".id";
+    const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG");
+    const std::string dir = rendezvous_dir();
+    return (dir.empty() ? std::string("/nonexistent") : dir) + "/rlgpu_comm_" + (port ? port : "0") + "_" + (tag ? tag : std::to_string((long)getppid())) + ".id";
 }
 int rlgpu_comm_rendezvous_path(char* buf, int cap) {
     const std::string p = rendezvous_path();
@@ -70,35 +105,54 @@ int rlgpu_comm_rendezvous_path(char* buf, int cap) {
     return RLGPU_OK;
 }
 
+// The file: 8 bytes magic, 8 bytes wall-clock seconds at which rank 0 wrote it, then the id.  A reader only takes a file written after
+// its own process started minus RLGPU_COMM_STALE_S (default 120 s: ranks of one launch start within that of each other) -- what an
+// earlier launch with the same port and tag left behind (a crash between write and remove) is not this launch's id.
+namespace {
+constexpr uint64_t RDV_MAGIC = 0x31444950475f4c52ull;   // "RL_GPID1"
+const int64_t g_process_start = (int64_t)time(nullptr);
+}
+
+// rank / world / rendezvous from the launcher's environment (torchrun or any launcher that sets RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT)
 int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     auto env_i = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
     const int rank = env_i("RANK", 0), world = env_i("WORLD_SIZE", 1), local = env_i("LOCAL_RANK", rank);
     if (rank_out) *rank_out = rank;
     if (world_out) *world_out = world;
+    if (rendezvous_dir().empty()) return fail(nullptr, "rendezvous directory /tmp/rlgpu_comm_<uid> is not a private directory of this user (set RLGPU_COMM_DIR)");
     const std::string path = rendezvous_path();
+    const int timeout_s = env_i("RLGPU_COMM_TIMEOUT_S", 60) > 0 ? env_i("RLGPU_COMM_TIMEOUT_S", 60) : 60;
     unsigned char id[RLGPU_COMM_ID_BYTES];
     if (rank == 0) {
         int rc = rlgpu_comm_unique_id(id);
         if (rc != RLGPU_OK) return rc;
-        std::string tmp = path + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f) return fail(nullptr, "cannot write " + tmp);
-        fwrite(id, 1, sizeof(id), f); fclose(f);
-        rename(tmp.c_str(), path.c_str());
+        (void)unlink(path.c_str());                          // whatever an earlier launch left under this name
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        if (fd < 0) return fail(nullptr, "cannot create " + tmp + ": " + strerror(errno));
+        const uint64_t hdr[2] = {RDV_MAGIC, (uint64_t)time(nullptr)};
+        const bool ok = write(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && write(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+        close(fd);
+        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return fail(nullptr, "cannot write " + path); }
     } else {
+        const int64_t stale_s = env_i("RLGPU_COMM_STALE_S", 120);
         bool ok = false;
-        for (int tries = 0; tries < 6000 && !ok; tries++) {     // up to 60 s
-            FILE* f = fopen(path.c_str(), "rb");
-            if (f) { ok = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+        for (int tries = 0; tries < timeout_s * 100 && !ok; tries++) {
+            const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
+            if (fd >= 0) {
+                uint64_t hdr[2] = {0, 0};
+                const bool whole = read(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && read(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+                close(fd);
+                ok = whole && hdr[0] == RDV_MAGIC && (int64_t)hdr[1] >= g_process_start - stale_s;
+            }
             if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
-        if (!ok) return fail(nullptr, "timed out waiting for " + path);
+        if (!ok) return fail(nullptr, "timed out waiting for a fresh " + path);
     }
     int rc = rlgpu_comm_init(out, local, rank, world, id);
-    if (rc == RLGPU_OK && rank == 0 && world > 1) {
-        // everybody has read the file once the communicator exists (ncclCommInitRank is collective)
-        remove(path.c_str());
-    } else if (rc == RLGPU_OK && world == 1) remove(path.c_str());
+    // everybody has read the file once ncclCommInitRank has returned (it is collective), whatever it returned
+    if (rank == 0) (void)unlink(path.c_str());
     return rc;
 }
 

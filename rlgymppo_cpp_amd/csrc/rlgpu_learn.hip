@@ -1195,6 +1195,11 @@ static int policy_head(rlgpu_learner* l, const float* obs, int rows, int determi
     LCHK(l, hipGetLastError());
     return RLGPU_OK;
 }
+// 1: policy and value inference run in the fused kernel (activations in its own LDS) -- such calls may go to another stream than a PPO
+// epoch.  0: they use the learner's activation scratch (fp32 mode, nets too wide for the kernel), which rlgpu_ppo_minibatch uses too.
+int rlgpu_learner_inference_is_standalone(const rlgpu_learner* l) {
+    return (l && fused_infer_fits(l, l->pol, l->cfg.n_actions) && fused_infer_fits(l, l->cri, 1)) ? 1 : 0;
+}
 int rlgpu_policy_act(rlgpu_learner* l, const float* obs, int rows, int deterministic, const float* noise, int32_t* actions, float* logp) {
     if (!actions || !logp) return RLGPU_ERR_ARG;
     return policy_head(l, obs, rows, deterministic, noise, actions, logp, nullptr);

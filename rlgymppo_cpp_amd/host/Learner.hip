@@ -80,6 +80,7 @@ namespace RLGPC {
 struct Learner::Impl {
     rlgpu_env* env = nullptr; rlgpu_learner* lrn = nullptr; rlgpu_shuffler* shuf = nullptr;
     rlgpu_comm* comm = nullptr; int rank = 0, world = 1, device = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> arEvents; size_t arUsed = 0; double arMs = 0; int arCalls = 0; bool arTimed = false;   // all-reduce clocks (bench)
     float* retShare = nullptr;   // rank 0's first returns, broadcast so every rank feeds the same statistic
     RLGSC::Match* match = nullptr; RLGSC::Gym* gym = nullptr;
     int nEnvs = 0, nAgents = 0, nPlayers = 0, D = 0, A = 0, T = 0, tickSkip = 8;
@@ -256,7 +257,11 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
         if (config.skillTrackerConfig.envCreateFunc == NULL) config.skillTrackerConfig.envCreateFunc = envCreateFn;
         skillTracker = new SkillTracker(config.skillTrackerConfig, m.lrn, m.D, m.A, config.ppo.policyLayerSizes, config.randomSeed, renderSender);
     }
-    if (config.collectionDuringLearn && !m.renderOnly) {
+    if (config.collectionDuringLearn && !m.renderOnly && !rlgpu_learner_inference_is_standalone(m.lrn)) {
+        // inference would share the learner's activation scratch with the PPO minibatches running on the other stream (fp32 mode, nets too
+        // wide for the fused inference kernel): collection and learning stay in sequence, as with collectionDuringLearn = false
+        RG_LOG("\tcollectionDuringLearn: inference is not standalone in this configuration (autocastLearn = false or wide nets) -> collection pauses during learning");
+    } else if (config.collectionDuringLearn && !m.renderOnly) {
         HOST_HIP(hipStreamCreateWithFlags(&m.learnStream, hipStreamNonBlocking));
         HOST_HIP(hipEventCreateWithFlags(&m.evReady, hipEventDisableTiming)); HOST_HIP(hipEventCreateWithFlags(&m.evLearnDone, hipEventDisableTiming));
     }
@@ -309,16 +314,33 @@ void Learner::CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actio
 }
 int Learner::Rank() const { return impl->rank; }
 int Learner::WorldSize() const { return impl->world; }
-double Learner::MaxOverRanks(double v) {
+std::vector<double> Learner::GatherOverRanks(double v) {
     Impl& m = *impl;
-    if (!m.comm) return v;
-    std::vector<float> h(m.world, 0.f); h[m.rank] = (float)v;
+    if (!m.comm) return {v};
+    std::vector<float> h(m.world, 0.f); h[m.rank] = (float)v;      // a sum of one-hot vectors = a gather
     float* d = dev_alloc<float>(m.world);
     HOST_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     if (rlgpu_comm_allreduce_f32(m.comm, d, m.world, nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_allreduce_f32: " << rlgpu_comm_last_error(m.comm));
     HOST_HIP(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d);
-    return (double)*std::max_element(h.begin(), h.end());
+    return std::vector<double>(h.begin(), h.end());
+}
+double Learner::MaxOverRanks(double v) {
+    const std::vector<double> all = GatherOverRanks(v);
+    return *std::max_element(all.begin(), all.end());
+}
+void Learner::AllReduceTimings(float& ms, int& calls, bool reset) {
+    Impl& m = *impl;
+    m.arTimed = true;
+    for (size_t i = 0; i < m.arUsed; i++) {
+        float t = 0.f;
+        HOST_HIP(hipEventSynchronize(m.arEvents[i].second));
+        HOST_HIP(hipEventElapsedTime(&t, m.arEvents[i].first, m.arEvents[i].second));
+        m.arMs += t; m.arCalls++;
+    }
+    m.arUsed = 0;
+    ms = (float)m.arMs; calls = m.arCalls;
+    if (reset) { m.arMs = 0; m.arCalls = 0; }
 }
 bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= 2 && !stepCallback && !renderSender; }
 void Learner::DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset) {
@@ -586,7 +608,19 @@ void Learner::LearnPPO(Report& report) {
             }
             // multi-GPU: ONE all-reduce(sum) of the flat [policy | critic] gradient on the learner's stream, then scale by 1 / world INSIDE
             // the clip so the norm is taken of the global-batch gradient, like a single learner on the union would
-            if (m.comm) m.LrnCheck(rlgpu_allreduce_grads(m.lrn, m.comm), "allreduce_grads");
+            if (m.comm) {
+                std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+                if (m.arTimed) {   // (bench only: a pair of events around the collective on the learner's stream)
+                    if (m.arUsed == m.arEvents.size()) {
+                        if (m.arEvents.size() < 1024) { hipEvent_t a, b; HOST_HIP(hipEventCreate(&a)); HOST_HIP(hipEventCreate(&b)); m.arEvents.push_back({a, b}); }
+                        else { float t; int c; AllReduceTimings(t, c, false); }
+                    }
+                    ev = &m.arEvents[m.arUsed++];
+                    HOST_HIP(hipEventRecord(ev->first, ls));
+                }
+                m.LrnCheck(rlgpu_allreduce_grads(m.lrn, m.comm), "allreduce_grads");
+                if (ev) HOST_HIP(hipEventRecord(ev->second, ls));
+            }
             m.LrnCheck(rlgpu_clip_adam_step(m.lrn, 0.5f, 1.f / (float)m.world), "clip_adam_step");   // clip_grad_norm_(0.5) per network, then Adam (PPOLearner.cpp:273-288)
             if (overlap) m.LrnCheck(rlgpu_learner_refresh_shadows(m.lrn), "learner_refresh_shadows");   // the collector reads the bf16 copies while this stream goes on: keep them live
             nUpdates++;

@@ -17,7 +17,9 @@
 #include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
 #include <hip/hip_runtime_api.h>
 #include "../../include/rlgpu.h"
+#include <algorithm>
 #include <chrono>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 
@@ -39,7 +41,7 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
     return { match, gym };
 }
 
-struct Timed { double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; };
+struct Timed { double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
     int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0; bool fp32 = false, overlap = false;
@@ -82,10 +84,13 @@ int main(int argc, char* argv[]) {
         barrier();
         Timed t{}; float a; int b; float c; double d; int e;
         learner.DeviceTimings(a, b, c, d, e, true);
+        learner.AllReduceTimings(a, b, true);
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < k; i++) iteration(&t.consumeMs);
         barrier();
-        t.sec = learner.MaxOverRanks(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // the slowest rank's clock
+        t.rankSec = learner.GatherOverRanks(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // every rank's own clock
+        t.sec = *std::max_element(t.rankSec.begin(), t.rankSec.end());                                                        // the slowest rank's
+        learner.AllReduceTimings(t.arMs, t.arCalls, false);
         learner.DeviceTimings(t.envMs, t.envLaunches, t.gemmMs, t.gemmFlops, t.gemmCalls, false);
         t.consumeMs /= std::max(1, k);
         return t;
@@ -107,6 +112,10 @@ int main(int argc, char* argv[]) {
                world, steps, warmup, envs, g_team, horizon, (long long)B, (long long)(B / 4), epochs, D,
                m.sec, (double)B * world * steps, (double)B * world * steps / m.sec, m.sec / steps * 1e3, m.consumeMs, fused ? "true" : "false",
                m.envMs, m.envLaunches, A, stepsPerLaunch, m.gemmMs, m.gemmFlops, m.gemmCalls);
+        // multi-GPU audit trail: how many RCCL ranks took part, every rank's own ms per iteration, and (rank 0) what one gradient all-reduce costs
+        printf(", \"rccl_ranks\": %d, \"rank_ms_per_step\": [", world > 1 ? world : 0);
+        for (size_t r = 0; r < m.rankSec.size(); r++) printf("%s%.4f", r ? ", " : "", m.rankSec[r] / steps * 1e3);
+        printf("], \"allreduce_calls\": %d, \"allreduce_ms_per_optimizer_step\": %.5f", m.arCalls, m.arCalls ? m.arMs / m.arCalls : 0.0);
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
                    warmup + steps + trainedWarm, trainedSteps, (double)B * world * trainedSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);

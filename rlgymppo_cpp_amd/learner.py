@@ -8,7 +8,8 @@
 
 Config field names and defaults are the reference's (LearnerConfig.h:14-80, PPOLearnerConfig.h:6-32); new fields
 are appended only.  This module owns no math: every tensor op on the hot path is a HIP kernel behind include/rlgpu.h;
-torch provides buffers, streams and torch.distributed (RCCL) for the one gradient all-reduce per optimizer step.
+torch provides buffers and streams; the one gradient all-reduce per optimizer step is the C-ABI's own (rlgpu_comm_* on RCCL,
+parallel.RcclComm) -- torch.distributed appears only in the CPU stand-in of the tests (parallel.GlooComm).
 """
 import ctypes as C
 import json
@@ -178,10 +179,15 @@ class ExperienceFifo:
 class Learner:
     def __init__(self, cfg: LearnerConfig, gym_cfg=None, mesh="procedural", rank=0, world_size=1, comm=None):
         self.cfg = cfg
-        # the exchange object (parallel.py): RCCL through the C-ABI on a multi-GPU launch, a no-op alone
-        self.comm = comm if comm is not None else parallel.SoloComm()
-        if comm is not None:
-            rank, world_size = comm.rank, comm.world
+        # the exchange object (parallel.py): RCCL through the C-ABI on a multi-GPU launch (the launcher's WORLD_SIZE > 1), a no-op alone.
+        # A world of several ranks WITHOUT an exchange would train diverging replicas on disjoint shards: refused.
+        if comm is None:
+            if world_size > 1:
+                raise ValueError("Learner(world_size > 1) needs the ranks' communicator: pass comm=parallel.make_comm() (RCCL from the launcher's "
+                                 "environment) -- without it no gradient would ever be exchanged")
+            comm = parallel.make_comm() if parallel.env_ranks()[2] > 1 else parallel.SoloComm()
+        self.comm = comm
+        rank, world_size = comm.rank, comm.world
         self.rank, self.world = rank, world_size
         n_envs = cfg.numEnvs or cfg.numThreads * cfg.numGamesPerThread
         self.gym_cfg = gym_cfg if gym_cfg is not None else _lib.default_gym_config()
@@ -246,7 +252,10 @@ class Learner:
         # collectionDuringLearn: the PPO epochs go to their own HIP stream and the next collection does not wait for them.  Like the
         # reference's agent threads (ThreadAgent.cpp:72-103) the collector then reads whatever weights are there, mid-update included.
         self.s_collect = torch.cuda.current_stream(self.dev)
-        self.s_learn = torch.cuda.Stream(self.dev) if cfg.collectionDuringLearn else None
+        # Only sound when inference keeps off the learner's activation scratch (the fused inference kernel: bf16 mode, nets that fit its
+        # LDS); otherwise collection pauses during learning as with collectionDuringLearn = False.
+        overlap = bool(cfg.collectionDuringLearn) and bool(self.ppo.lib.rlgpu_learner_inference_is_standalone(self.ppo.h))
+        self.s_learn = torch.cuda.Stream(self.dev) if overlap else None
         self._learn_done = None
         if self.s_learn is not None and os.environ.get("RLGPU_COLLECT_SIDE_STREAM"):
             self.s_collect = torch.cuda.Stream(self.dev)      # experiment: collection off the null stream too

@@ -80,6 +80,8 @@ class RcclComm(SoloComm):
         return t
 
     def _gather_scalar(self, value, device):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         t = torch.zeros(self.world, dtype=torch.float32, device=device)
         t[self.rank] = float(value)
         return self._allreduce(t).double().cpu()

@@ -131,7 +131,8 @@ def test_physics_ticks_match_host_port_on_golden_scenarios(sg, port_lib):
 
 
 def test_gym_step_matches_host_port(port_lib):
-    """64 random envs, 48 gym steps (incl. auto-resets): obs / reward / done of the HIP path vs the host port."""
+    """64 random envs, 48 gym steps (incl. auto-resets): obs / reward / done of the HIP path vs the host build of the same source, EQUAL
+    bit for bit at every step (both start each step from the same bits)."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from rlgymppo_cpp_amd import _lib
     n = 64
@@ -157,9 +158,9 @@ def test_gym_step_matches_host_port(port_lib):
         d = done.cpu().numpy()
         assert (d == hd).all(), f"done flags differ at step {step}"
         n_done += int(hd.sum())
-        assert np.abs(rew.cpu().numpy() - hr).max() < 2e-3, f"rewards differ at step {step}"
-        assert np.abs(nobs.cpu().numpy() - ho).max() < 2e-3, f"obs differ at step {step}"
-        # keep the two in lock step (see the physics test)
+        assert np.array_equal(rew.cpu().numpy(), hr), f"rewards differ at step {step}: max |diff| {np.abs(rew.cpu().numpy() - hr).max()}"
+        assert np.array_equal(nobs.cpu().numpy(), ho), f"obs differ at step {step}: max |diff| {np.abs(nobs.cpu().numpy() - ho).max()}"
+        # the host build hands its states over in uu: the device continues from those bits (a gym step from equal bits gives EQUAL rows)
         env.upload_states(hs)
     assert n_done > 0   # auto-reset path exercised
 
@@ -167,7 +168,7 @@ def test_gym_step_matches_host_port(port_lib):
 @pytest.mark.parametrize("team_size,max_players", [(2, 2), (3, 3), (1, 2), (2, 4)])
 def test_gym_step_matches_host_port_team_modes(port_lib, team_size, max_players):
     """BASELINE configs[3]/[4] shapes: 2v2 and 3v3 envs (4 / 6 cars, obs width 127 / 165) with the zero-sum reward wrapper,
-    HIP path vs host port over 24 gym steps incl. auto-resets.  Also the only GPU coverage of the 2- and 1-env-per-wavefront
+    HIP path vs host port over 24 gym steps incl. auto-resets, every observation row and reward EQUAL.  Also the only GPU coverage of the 2- and 1-env-per-wavefront
     lane maps (32 / 64 lanes per env in the candidate, pair and item phases), and of the padded-shuffled obs."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from rlgymppo_cpp_amd import _lib
@@ -192,8 +193,8 @@ def test_gym_step_matches_host_port_team_modes(port_lib, team_size, max_players)
         hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts)
         assert (done.cpu().numpy() == hd).all(), f"done flags differ at step {step}"
         n_done += int(hd.sum())
-        assert np.abs(rew.cpu().numpy() - hr).max() < 2e-3, f"rewards differ at step {step}"
-        assert np.abs(nobs.cpu().numpy() - ho).max() < 2e-3, f"obs differ at step {step}"
+        assert np.array_equal(rew.cpu().numpy(), hr), f"rewards differ at step {step}: max |diff| {np.abs(rew.cpu().numpy() - hr).max()}"
+        assert np.array_equal(nobs.cpu().numpy(), ho), f"obs differ at step {step}: max |diff| {np.abs(nobs.cpu().numpy() - ho).max()}"
         env.upload_states(hs)
     assert n_done > 0
 
@@ -246,7 +247,7 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
     nine rollouts (simlib.GYM_EXACT: up to 160 gym steps = 1280 ticks of random play, a chase, the timeout, goals, assists, a save, a
     demolition, every reward term, zero-sum) are reproduced EXACTLY: every observation row and every reward bit-equal to the reference's."""
     from rlgymppo_cpp_amd.env import BatchedEnv
-    from simlib import gym_compare_obs, GYM_OBS_TOL, GYM_HORIZON, GYM_EXACT
+    from simlib import gym_compare_obs, GYM_OBS_TOL, GYM_HORIZON, GYM_EXACT, GYM_EXACT_OBS
     dev = torch.device("cuda", 0)
     for case in sg["gym_names"]:
         case = str(case)
@@ -273,7 +274,7 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
             assert not exact or np.array_equal(rr, rew[t]), f"{case}: reward not bit-equal to the reference at step {t}: {rr} vs {rew[t]}"
             if done[t]:
                 break
-            gym_compare_obs(nobs.cpu().numpy(), obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], 1e-30 if exact else GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}", one_team)
+            gym_compare_obs(nobs.cpu().numpy(), obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], 1e-30 if (exact or case in GYM_EXACT_OBS) else GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}", one_team)
         if not (done[-1] or case in GYM_HORIZON):
             fin = ArenaState.from_buffer_copy(sg[f"gym/{case}/final"].tobytes())
             got = env.download_states()[0]
@@ -350,6 +351,23 @@ def test_hip_one_tick_vs_reference_states(sg):
         env.close()
     assert n_all - n_exact <= ONE_TICK_NOT_EXACT_MAX, f"only {n_exact} of {n_all} one-tick pairs bit-equal to the reference"
     print(f"HIP one-tick pairs bit-equal to the reference: {n_exact} of {n_all}")
+
+
+@pytest.mark.parametrize("team", [1, 2, 3])
+def test_hip_state_setters_against_reference_samples(sg, team):
+    """SURVEY A8 on the GPU: the KERNEL's RandomState(true, true, true) and KickoffState (rlgpu_env_reset with run_setter = 1) against the
+    reference's own 4000 / 600 resets (RandomState.cpp:8-61, Arena.cpp:112-216; sim_golden.npz setter/*): kickoff -- exactly the reference's
+    spawn set per car; random -- every column inside the reference's support, quantiles within 5 % of the span."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    from simlib import setter_samples_compare
+    nc = 2 * team
+    for kname, kind, n in (("random", 0, 4000), ("kickoff", 1, 600)):
+        cfg = _lib.default_gym_config(); cfg.setter_kind = kind; cfg.seed_lo = 77 + team
+        env = BatchedEnv(n, team, cfg=cfg)
+        env.reset(True); env.sync()
+        setter_samples_compare(env.download_states(), sg[f"setter/{kname}/team{team}"], kind, nc, f"HIP {kname} team {team}")
+        env.close()
 
 
 def test_live_reference_rollout(ref_lib, port_lib):
@@ -786,6 +804,17 @@ def test_rccl_communicator_through_the_cabi_and_rank_keyed_sampler():
     core.sync(); torch.cuda.synchronize()
     assert torch.equal(gt, before) and torch.equal(t, torch.arange(16, dtype=torch.float32, device=dev))
     assert lib.rlgpu_comm_destroy(h) == 0
+    # the Python host's wrapper over the same calls, from the launcher's environment (a world of one here): scalar gathers default to the
+    # current device (they used to build a CPU tensor), barrier, gradient all-reduce scale
+    from rlgymppo_cpp_amd import parallel
+    rc = parallel.RcclComm()
+    assert (rc.rank, rc.world) == (0, 1) and rc.max_over_ranks(3.5) == 3.5 and rc.sum_over_ranks(2.25) == 2.25
+    rc.barrier()
+    assert rc.allreduce_gradients(core) == 1.0 and torch.equal(rc.share_from_rank0(t), t)
+    rc.close()
+    with pytest.raises(ValueError):
+        from rlgymppo_cpp_amd.learner import Learner, LearnerConfig
+        Learner(LearnerConfig(numEnvs=4), world_size=2)       # several ranks without an exchange object: refused, not silently diverging
     obs = torch.randn(256, 89, device=dev)
     draws = []
     for stream in (0, 1, 0):

@@ -214,3 +214,42 @@ def test_example_program_with_skill_tracker(tmp_path):
     r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "Attempting to load 2 old versions" in r.stdout and "[0]: Found at 8192" in r.stdout and "[1]: Found at 4096" in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(240)
+def test_two_rank_launch_on_one_gpu_ends_instead_of_hanging(tmp_path):
+    """De-risking the first real N > 1 run (only the driver has 8 GPUs): two bench_main processes as RANK 0 / 1 of WORLD_SIZE 2, both on the
+    ONE visible GPU, through the same code a torchrun launch takes -- rlgpu_comm_init_env: rank 0 writes the rendezvous file (private
+    directory, O_EXCL, magic + time stamp), rank 1 reads it, both enter ncclCommInitRank.  RCCL normally refuses two ranks on one device;
+    the assertion is on the FAILURE MODE: the error comes back through rlgpu_comm_last_error into the Learner's exception, both processes
+    end non-zero within the time limit instead of hanging, and the rendezvous file is gone.  (Should this RCCL accept the pair, the run
+    must then complete as a 2-rank run: rccl_ranks 2 and two per-rank clocks in rank 0's line.)  Every line of the multi-rank host path
+    except the collective on >= 2 devices has then executed before the driver's 8-GPU bench.  Fresh child processes only."""
+    import json, socket, time
+    exe = os.path.join(PKG, "bench_main")
+    assert os.path.exists(exe)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdv = str(tmp_path / "rdv"); os.mkdir(rdv, 0o700)
+    base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TAG="t%d" % os.getpid(),
+                RLGPU_COMM_TIMEOUT_S="45", HSA_ENABLE_IPC_MODE_LEGACY="0", RLGPU_QUIET="1")
+    cmd = [exe, "--envs", "64", "--horizon", "4", "--steps", "2", "--warmup", "1"]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=150))
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            pytest.fail("a rank of the two-rank launch hung")
+    took = time.time() - t0
+    codes = [p.returncode for p in procs]
+    assert not os.listdir(rdv), f"rendezvous file left behind: {os.listdir(rdv)}"
+    if codes == [0, 0]:      # this RCCL build lets two ranks share a device: then it was a real 2-rank run
+        line = json.loads(outs[0][0].strip().splitlines()[-1])
+        assert line["rccl_ranks"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["n_gpus"] == 2 and line["allreduce_calls"] > 0, line
+    else:
+        assert all(c != 0 for c in codes), (codes, outs)
+        assert took < 140
+        assert any("ncclCommInitRank" in o[1] or "rlgpu_comm_init_env" in o[1] for o in outs), outs

@@ -139,7 +139,7 @@ def test_action_table(sg, port_lib):
     assert (tab == sg["action_table"]).all()
 
 
-from simlib import (PHYS_FREE_RUN, ONE_TICK_TOL, GYM_OBS_TOL, GYM_HORIZON, state_vec, phys_errors, gym_compare_obs, gym_cfg_for_case)   # noqa: E402  shared with the GPU tests
+from simlib import (PHYS_FREE_RUN, ONE_TICK_TOL, GYM_OBS_TOL, GYM_HORIZON, GYM_HORIZON_PORT, state_vec, phys_errors, gym_compare_obs, gym_cfg_for_case)   # noqa: E402  shared with the GPU tests
 
 
 def test_port_physics_vs_reference_golden(sg, port_lib):
@@ -253,7 +253,7 @@ def test_port_gym_vs_reference_golden(sg, port_lib):
         order0 = [int(x) for x in sg[f"gym/{case}/player_order"][0]]
         gym_compare_obs(obs0, sg[f"gym/{case}/obs0"], nc, omp, order0, 1e-5, f"{case} reset", one_team)
         acts = sg[f"gym/{case}/actions"]; obs = sg[f"gym/{case}/obs"]; rew = sg[f"gym/{case}/rew"]; done = sg[f"gym/{case}/done"]
-        for t in range(min(len(acts), GYM_HORIZON.get(case, len(acts)))):
+        for t in range(min(len(acts), GYM_HORIZON_PORT.get(case, len(acts)))):
             (st,), o, r, d = port_gym_step(port_lib, [st], cfg, acts[t])
             assert int(d[0]) == int(done[t]), f"{case}: done differs at step {t}"
             assert np.abs(r - rew[t]).max() < 2e-3 * max(1.0, np.abs(rew[t]).max()), f"{case}: reward differs at step {t}: {r} vs {rew[t]}"
@@ -261,7 +261,7 @@ def test_port_gym_vs_reference_golden(sg, port_lib):
                 break     # GameInst semantics (GameInst.cpp:27-32): the row returned with done is the first observation of the NEXT episode
             gym_compare_obs(o, obs[t], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][t]], GYM_OBS_TOL.get(case, 2e-3), f"{case} step {t}", one_team)
         fin = ArenaState.from_buffer_copy(sg[f"gym/{case}/final"].tobytes())
-        if done[-1] or case in GYM_HORIZON:
+        if done[-1] or case in GYM_HORIZON_PORT:
             continue      # the env has auto-reset: the terminal step's events are pinned through its reward (EventReward terms) above
         for k in range(0, nc, 2 if one_team else 1):
             a, b = st.gym.players[k], fin.gym.players[k]
@@ -275,31 +275,13 @@ def test_state_setters_against_reference_samples(sg, port_lib):
     """RandomState(true, true, true) and KickoffState: the device / port setters against 4000 / 600 resets of the reference's own
     (RandomState.cpp:8-61, Arena.cpp:112-216): same supports, means and spreads; kickoff: exactly the reference's spawn set."""
     from rlgymppo_cpp_amd.state import default_arena
+    from simlib import setter_samples_compare
     for team in (1, 2, 3):
         nc = 2 * team
         for kname, kind, n in (("random", 0, 4000), ("kickoff", 1, 600)):
-            ref = sg[f"setter/{kname}/team{team}"]
             states = [default_arena(nc) for _ in range(n)]
             got_states, _ = port_gym_reset(port_lib, states, port_gym_cfg(setter_kind=kind), run_setter=True)
-            got = np.stack([np.concatenate([state_vec(x)[:9]] + [np.concatenate([state_vec(x)[9 + 20 * k: 9 + 20 * k + 18], [x.cars[k].boost]]) for k in range(nc)]) for x in got_states])
-            assert got.shape == ref.shape
-            if kind == 1:
-                # kickoff: per car the set of (x, y, yaw column) combinations, ball and boost fixed
-                for k in range(nc):
-                    cols = [9 + 19 * k + i for i in (0, 1, 2, 9, 10, 18)]
-                    a = {tuple((np.round(np.asarray(r, np.float64), 2) + 0.0).tolist()) for r in got[:, cols]}; b = {tuple((np.round(np.asarray(r, np.float64), 2) + 0.0).tolist()) for r in ref[:, cols]}
-                    assert a == b, f"kickoff team {team} car {k}: spawn set differs: {sorted(a ^ b)[:4]}"
-                assert np.abs(got[:, :9] - ref[0, :9]).max() < 1e-4
-            else:
-                qs = [0.5, 5, 25, 50, 75, 95, 99.5]
-                for c in range(ref.shape[1]):
-                    lo, hi = float(ref[:, c].min()), float(ref[:, c].max()); span = max(hi - lo, 1e-3)
-                    # sample extremes of 4000 draws are noisy where the density thins out towards the end of the support: 10 % slack there,
-                    # 5 % of the span on the quantiles (the reference's generator is seeded from the wall clock: every regeneration of the
-                    # fixture is another sample, and 4 % was within one sample's noise for the rotation-matrix columns)
-                    assert got[:, c].min() >= lo - 0.1 * span - 1e-4 and got[:, c].max() <= hi + 0.1 * span + 1e-4, f"random team {team} col {c}: outside the reference's support"
-                    dq = np.abs(np.percentile(got[:, c], qs) - np.percentile(ref[:, c], qs)).max()
-                    assert dq < 0.05 * span + 1e-4, f"random team {team} col {c}: quantiles differ by {dq} (span {span})"
+            setter_samples_compare(got_states, sg[f"setter/{kname}/team{team}"], kind, nc, f"{kname} team {team}")
 
 
 def test_cabi_exports_every_declared_symbol():

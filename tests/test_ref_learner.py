@@ -196,3 +196,66 @@ def test_welford_equals_reference_header(refl):
     one = (C.c_float * 1)(3.0)
     refl.refl_welford(one, 1, 150, C.byref(mean), C.byref(m2), C.byref(cnt), C.byref(std))
     assert std.value == 1.0 and WelfordRunningStat().get_std() == 1.0               # fewer than two samples: std 1 (WelfordRunningStat.h:70-72)
+
+
+@pytest.mark.gpu
+def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
+    """SURVEY A14 / section 4-3: the COMPOSITION of one training iteration, not its pieces.  The Learner (fp32 mode) collects on the GPU;
+    the collected rows then go through a pipeline assembled from the reference's own code (libref_learner.so: ValueEstimator, ComputeGAE,
+    DiscretePolicy) and the numpy PPO oracle, in the reference's order (Learner.cpp:608-703, PPOLearner.cpp:67-349):
+      B + 1 value rows (every state of the agent-major concatenation + the single final nextStates[B - 1]) | retStd read BEFORE this
+      iteration's returns enter the statistic | ComputeGAE on the concatenation with the collector's truncation marks | the three report
+      averages | returnStats.Increment with the FIRST min(150, B) returns of the concatenation | one epoch of two accumulated minibatches,
+      clip-by-norm per network, one Adam step.
+    Three iterations, so that retStd is 1 (n < 2), then the std of 150 samples, then of 300.  Also: the action the policy sampled for every
+    collected row is the reference DiscretePolicy's choice on the same probabilities (log-probs within 1e-5)."""
+    torch = pytest.importorskip("torch")
+    from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
+    n_envs, T = 16, 12
+    N = n_envs * 2; B = N * T
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, randomSeed=9, standardizeReturns=True, maxReturnsPerStatsInc=150,
+                        ppo=PPOLearnerConfig(policyLayerSizes=tuple(HID), criticLayerSizes=tuple(HID), batchSize=B, miniBatchSize=B // 2, epochs=1,
+                                             policyLR=3e-4, criticLR=3e-4, entCoef=0.01, clipRange=0.2, autocastLearn=False))
+    L = Learner(cfg)
+    assert L.obs_size == D and L.n_agents == N
+    pshapes, cshapes = L.ppo.layer_shapes(0), L.ppo.layer_shapes(1)
+    hid = np.array(HID, np.int32)
+    stat = R.Welford()
+    mom = {0: [np.zeros(L.ppo.num_params(0), np.float32), np.zeros(L.ppo.num_params(0), np.float32)], 1: [np.zeros(L.ppo.num_params(1), np.float32), np.zeros(L.ppo.num_params(1), np.float32)]}
+    am = lambda x: np.ascontiguousarray(np.moveaxis(x, 0, 1).reshape((-1,) + x.shape[2:]))      # [T][N]... -> agent-major concatenation (trajectory after trajectory)
+    for it in range(3):
+        pol, cri = L.ppo.get_params(0).copy(), L.ppo.get_params(1).copy()
+        L.collect(); L.ppo.sync(); torch.cuda.synchronize()
+        obs = L.obs_buf.cpu().numpy().reshape(T + 1, N, D); acts = L.act_buf.cpu().numpy().reshape(T, N); logp = L.logp_buf.cpu().numpy().reshape(T, N)
+        rew = L.rew_buf.cpu().numpy().reshape(T, N); done = L.done_buf.cpu().numpy().reshape(T, N).astype(np.float32)
+        L.add_new_experience(); torch.cuda.synchronize()
+        # -- the reference pipeline on the same rows
+        states = am(obs[:T]); final_next = obs[T, N - 1][None]
+        vin = np.ascontiguousarray(np.concatenate([states, final_next]), np.float32)
+        vals = np.zeros(B + 1, np.float32); refl.refl_value(_p(hid), len(HID), D, _p(cri), _p(vin), B + 1, _p(vals))
+        ret_std = stat.std()                                                          # before this iteration's update (Learner.cpp:651)
+        trunc = np.zeros((T, N), np.float32); trunc[T - 1] = 1 - done[T - 1]          # ThreadAgentManager.cpp:55
+        adv_r, tgt_r, ret_r = ref_gae(refl, am(rew), am(done), am(trunc), vals, cfg.gaeGamma, cfg.gaeLambda, ret_std, cfg.rewardClipRange)
+        adv = am(L.adv.cpu().numpy().reshape(T, N)); tgt = am(L.tgt.cpu().numpy().reshape(T, N)); ret = am(L.ret.cpu().numpy().reshape(T, N))
+        assert np.abs(adv - adv_r).max() < 1e-4 and np.abs(ret - ret_r).max() < 1e-4 and np.abs(tgt - tgt_r).max() < 1e-4, f"iteration {it}: GAE composition"
+        rep = L.finish_report()
+        assert abs(rep["Avg Return"] - float(np.abs(ret_r).mean()) / ret_std) < 1e-4 * max(1.0, float(np.abs(ret_r).mean()) / ret_std)
+        assert abs(rep["Avg Advantage"] - float(np.abs(adv_r).mean())) < 1e-4 and abs(rep["Avg Val Target"] - float(np.abs(tgt_r).mean())) < 1e-4
+        stat.increment(ret_r, min(cfg.maxReturnsPerStatsInc, B))                      # the first 150 returns of the concatenation (Learner.cpp:679-682)
+        L._flush_returns()
+        assert L.return_stats.count == stat.count == 150 * (it + 1)
+        assert abs(L.return_stats.mean - stat.mean) < 1e-4 * max(1.0, abs(stat.mean)) and abs(L.return_stats.get_std() - stat.std()) < 1e-4 * max(1.0, stat.std())
+        # -- the sampled actions are the reference policy's on these observations (its probabilities, the Learner's own recorded choice)
+        probs, _, lp_ref, _, _, _, _ = ref_policy(refl, pol, states, am(acts).astype(np.int32), 1.0, seed=1)
+        assert np.abs(am(logp) - lp_ref).max() < 1e-5, f"iteration {it}: log-probs of the collected actions"
+        # -- one epoch = one optimizer step over the two accumulated minibatches (PPOLearner.cpp:127-288)
+        L.learn(); L.ppo.sync(); torch.cuda.synchronize()
+        gp = np.zeros_like(pol); gc = np.zeros_like(cri)
+        for h in range(2):     # any split into two halves gives the same sums: the batch gradient is the mean over all B rows
+            sl = slice(h * B // 2, (h + 1) * B // 2)
+            g0, g1, _ = R.ppo_minibatch_grads(pol, pshapes, cri, cshapes, states[sl], am(acts)[sl], am(logp)[sl], adv_r[sl], tgt_r[sl], clip=0.2, ent_coef=0.01, ratio_scale=0.5)
+            gp += g0; gc += g1
+        want_p, mom[0][0], mom[0][1] = R.clip_adam_step(pol, gp, mom[0][0], mom[0][1], it + 1, 3e-4)
+        want_c, mom[1][0], mom[1][1] = R.clip_adam_step(cri, gc, mom[1][0], mom[1][1], it + 1, 3e-4)
+        assert np.abs(L.ppo.get_params(0) - want_p).max() < 2e-6 and np.abs(L.ppo.get_params(1) - want_c).max() < 2e-6, f"iteration {it}: parameters after the optimizer step"
+    assert L.cumulative_model_updates == 3
