@@ -21,6 +21,10 @@
 #pragma once
 #include "rl_math.h"
 
+#ifndef RLG_EPA_PROF
+#define RLG_EPA_PROF(i) ((void)0)   /* phase stamps for tools/probes/epa_probe.hip: 0 start, 1 after the margin GJK, 2 after EncloseOrigin + the first four faces, 3 after the EPA loop, 4 end */
+#endif
+
 namespace rlg {
 
 constexpr int   EPA_BT_MAX_VERTICES = 128, EPA_BT_MAX_FACES = 256, EPA_BT_MAX_ITERATIONS = 255, EPA_GJK_MAX_ITERATIONS = 128;
@@ -28,12 +32,21 @@ constexpr float EPA_GJK_ACCURACY = 0.0001f, EPA_GJK_MIN_DISTANCE = 0.0001f, EPA_
 constexpr float EPA_ACCURACY = 0.0001f, EPA_PLANE_EPS = 0.00001f;
 
 struct EpaSV { V3 d, w; };                        // GJK::sSV: direction and Minkowski support point
-struct EpaFace {                                  // EPA::sFace with indices for pointers
+struct alignas(16) EpaFace {                      // EPA::sFace with indices for pointers, packed so that a face is two 16-byte accesses
     V3 n; float d;
-    uint8_t c[3]; uint8_t pass;                   // vertex slots (0..3: the simplex GJK ended on, 4..: EPA's own)
-    uint8_t f[3]; uint8_t e[3];                   // neighbour face / its edge, per edge
-    int16_t l[2];                                 // hull list links (prev, next), -1 = none; l[1] doubles as the free list's link
+    uint32_t cp;                                  // c[0] | c[1] << 8 | c[2] << 16 | pass << 24: vertex slots (0..3: the simplex GJK ended on, 4..: EPA's own), pass
+    uint32_t fe;                                  // f[0] | f[1] << 8 | f[2] << 16 | e[0] << 24 | e[1] << 26 | e[2] << 28: neighbour face / its edge, per edge
+    uint32_t links;                               // hull list: (prev + 1) | (next + 1) << 16, 0 = none; the next half doubles as the free list's link
+    uint32_t _pad;
 };
+RLG_HD int epa_face_c(uint32_t cp, int k) { return (int)((cp >> (8 * k)) & 255u); }
+RLG_HD int epa_face_pass(uint32_t cp) { return (int)(cp >> 24); }
+RLG_HD int epa_face_f(uint32_t fe, int k) { return (int)((fe >> (8 * k)) & 255u); }
+RLG_HD int epa_face_e(uint32_t fe, int k) { return (int)((fe >> (24 + 2 * k)) & 3u); }
+RLG_HD uint32_t epa_face_set_fe(uint32_t fe, int k, int f, int e) { return (fe & ~((255u << (8 * k)) | (3u << (24 + 2 * k)))) | ((uint32_t)f << (8 * k)) | ((uint32_t)e << (24 + 2 * k)); }
+RLG_HD int epa_link_prev(uint32_t l) { return (int)(l & 0xffffu) - 1; }
+RLG_HD int epa_link_next(uint32_t l) { return (int)(l >> 16) - 1; }
+RLG_HD uint32_t epa_links(int prev, int next) { return (uint32_t)(prev + 1) | ((uint32_t)(next + 1) << 16); }
 struct EpaGjkState {                              // GJK's fields and the locals of Evaluate that are indexed at run time
     EpaSV sv[2][4]; float p[2][4]; int rank[2]; int cur;
     V3 lastw[4];
@@ -76,6 +89,7 @@ RLG_HD EpaArena epa_arena_at(void* mem, int cap_v, int cap_f) {
     a.run = reinterpret_cast<EpaRun*>(p); p += sizeof(EpaRun);
     a.res = reinterpret_cast<EpaResult*>(p); p += sizeof(EpaResult);
     a.sv = reinterpret_cast<EpaSV*>(p); p += sizeof(EpaSV) * (size_t)(4 + cap_v);
+    p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15u) & ~(uintptr_t)15u);
     a.fc = reinterpret_cast<EpaFace*>(p); p += sizeof(EpaFace) * (size_t)cap_f;
     a.stack = reinterpret_cast<uint16_t*>(p);
     a.cap_v = cap_v; a.cap_f = cap_f;
@@ -315,21 +329,26 @@ RLG_HD_NOINLINE bool epa_enclose_origin(EpaGjkState& G, const EpaShapes& sh, boo
 }
 
 // ---- EPA (:557-872) ---------------------------------------------------------------------------------------------------------------------
-RLG_HD void epa_bind(const EpaArena& A, int fa, int ea, int fb, int eb) { A.fc[fa].e[ea] = (uint8_t)eb; A.fc[fa].f[ea] = (uint8_t)fb; A.fc[fb].e[eb] = (uint8_t)ea; A.fc[fb].f[eb] = (uint8_t)fa; }
+RLG_HD void epa_bind(const EpaArena& A, int fa, int ea, int fb, int eb) {
+    A.fc[fa].fe = epa_face_set_fe(A.fc[fa].fe, ea, fb, eb);
+    A.fc[fb].fe = epa_face_set_fe(A.fc[fb].fe, eb, fa, ea);
+}
 RLG_HD void epa_hull_append(const EpaArena& A, int f) {
-    EpaRun& E = *A.run; EpaFace& F = A.fc[f];
-    F.l[0] = -1; F.l[1] = (int16_t)E.hull_root;
-    if (E.hull_root >= 0) A.fc[E.hull_root].l[0] = (int16_t)f;
+    EpaRun& E = *A.run;
+    const int root = E.hull_root;
+    A.fc[f].links = epa_links(-1, root);
+    if (root >= 0) A.fc[root].links = epa_links(f, epa_link_next(A.fc[root].links));
     E.hull_root = f; E.hull_count++;
 }
 RLG_HD void epa_hull_remove(const EpaArena& A, int f) {
-    EpaRun& E = *A.run; EpaFace& F = A.fc[f];
-    if (F.l[1] >= 0) A.fc[F.l[1]].l[0] = F.l[0];
-    if (F.l[0] >= 0) A.fc[F.l[0]].l[1] = F.l[1];
-    if (f == E.hull_root) E.hull_root = F.l[1];
+    EpaRun& E = *A.run;
+    const uint32_t l = A.fc[f].links; const int prev = epa_link_prev(l), next = epa_link_next(l);
+    if (next >= 0) A.fc[next].links = epa_links(prev, epa_link_next(A.fc[next].links));
+    if (prev >= 0) A.fc[prev].links = epa_links(epa_link_prev(A.fc[prev].links), next);
+    if (f == E.hull_root) E.hull_root = next;
     E.hull_count--;
 }
-RLG_HD void epa_stock_push(const EpaArena& A, int f) { A.fc[f].l[1] = (int16_t)A.run->free_root; A.run->free_root = f; }
+RLG_HD void epa_stock_push(const EpaArena& A, int f) { A.fc[f].links = epa_links(-1, A.run->free_root); A.run->free_root = f; }
 RLG_HD bool epa_edge_dist(V3 fn, V3 aw, V3 bw, float& dist) {   // EPA::getedgedist (:743-779)
     const V3 ba = bw - aw;
     const V3 n_ab = cross(ba, fn);
@@ -353,7 +372,7 @@ RLG_HD bool epa_edge_dist(V3 fn, V3 aw, V3 bw, float& dist) {   // EPA::getedged
 RLG_HD_NOINLINE int epa_newface(EpaArena A, int a, int b, int c, bool forced) {
     EpaRun& E = *A.run;
     int face;
-    if (E.free_root >= 0) { face = E.free_root; E.free_root = A.fc[face].l[1]; }
+    if (E.free_root >= 0) { face = E.free_root; E.free_root = epa_link_next(A.fc[face].links); }
     else if (E.next_fresh < A.cap_f) face = E.next_fresh++;
     else {
         if (A.cap_f < EPA_BT_MAX_FACES) { E.arena_full = true; return -1; }
@@ -363,7 +382,7 @@ RLG_HD_NOINLINE int epa_newface(EpaArena A, int a, int b, int c, bool forced) {
     epa_hull_append(A, face);
     EpaFace& F = A.fc[face];
     const V3 aw = A.sv[a].w, bw = A.sv[b].w, cw = A.sv[c].w;
-    F.pass = 0; F.c[0] = (uint8_t)a; F.c[1] = (uint8_t)b; F.c[2] = (uint8_t)c;
+    F.cp = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16);   // pass = 0
     V3 n = cross(bw - aw, cw - aw);
     const float l = len(n);
     const bool v = l > EPA_ACCURACY;
@@ -382,7 +401,7 @@ RLG_HD_NOINLINE int epa_newface(EpaArena A, int a, int b, int c, bool forced) {
 RLG_HD int epa_findbest(const EpaArena& A) {   // EPA::findbest (:825-839)
     int minf = A.run->hull_root;
     float mind = A.fc[minf].d * A.fc[minf].d;
-    for (int f = A.fc[minf].l[1]; f >= 0; f = A.fc[f].l[1]) {
+    for (int f = epa_link_next(A.fc[minf].links); f >= 0; f = epa_link_next(A.fc[f].links)) {
         const float sqd = A.fc[f].d * A.fc[f].d;
         if (sqd < mind) { minf = f; mind = sqd; }
     }
@@ -402,9 +421,10 @@ RLG_HD_NOINLINE bool epa_expand(EpaArena A, int pass, int w, int f0, int e0, Epa
         EpaFace& F = A.fc[f];
         const int e1 = e == 2 ? 0 : e + 1, e2 = e == 0 ? 2 : e - 1;   // i1m3, i2m3
         if (stage == 0) {
-            if (F.pass != (uint8_t)pass) {
+            const uint32_t cp = F.cp;
+            if (epa_face_pass(cp) != (pass & 255)) {
                 if ((dot(F.n, ww) - F.d) < -EPA_PLANE_EPS) {
-                    const int nf = epa_newface(A, F.c[e1], F.c[e], w, false);
+                    const int nf = epa_newface(A, epa_face_c(cp, e1), epa_face_c(cp, e), w, false);
                     if (nf >= 0) {
                         epa_bind(A, nf, 0, f, e);
                         if (hz.cf >= 0) epa_bind(A, hz.cf, 1, nf, 2); else hz.ff = nf;
@@ -413,17 +433,19 @@ RLG_HD_NOINLINE bool epa_expand(EpaArena A, int pass, int w, int f0, int e0, Epa
                     } else ret = false;
                     sp--;
                 } else {
-                    F.pass = (uint8_t)pass;
+                    F.cp = (cp & 0x00ffffffu) | ((uint32_t)(pass & 255) << 24);
                     st[sp - 1] = (uint16_t)(f | (e << 8) | (1 << 10));
                     if (sp >= A.cap_f) { E.arena_full = true; return false; }
-                    st[sp++] = (uint16_t)(F.f[e1] | ((int)F.e[e1] << 8));
+                    const uint32_t fe = F.fe;
+                    st[sp++] = (uint16_t)(epa_face_f(fe, e1) | (epa_face_e(fe, e1) << 8));
                 }
             } else { ret = false; sp--; }
         } else if (stage == 1) {
             if (ret) {
                 st[sp - 1] = (uint16_t)(f | (e << 8) | (2 << 10));
                 if (sp >= A.cap_f) { E.arena_full = true; return false; }
-                st[sp++] = (uint16_t)(F.f[e2] | ((int)F.e[e2] << 8));
+                const uint32_t fe = F.fe;
+                st[sp++] = (uint16_t)(epa_face_f(fe, e2) | (epa_face_e(fe, e2) << 8));
             } else { ret = false; sp--; }
         } else {
             if (ret) { epa_hull_remove(A, f); epa_stock_push(A, f); ret = true; }
@@ -449,6 +471,7 @@ RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
         const int t2 = epa_newface(A, 2, 1, 3, true);
         const int t3 = epa_newface(A, 0, 2, 3, true);
         if (E.arena_full) return EPA_ARENA_FULL;
+        RLG_EPA_PROF(2);
         if (E.hull_count == 4) {
             int best = epa_findbest(A);
             EpaFace outer = A.fc[best];
@@ -466,13 +489,15 @@ RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
                     EpaHorizon hz; hz.cf = -1; hz.ff = -1; hz.nf = 0;
                     const int w = 4 + E.nextsv++;
                     bool valid = true;
-                    A.fc[best].pass = (uint8_t)(++pass);
+                    ++pass;
+                    A.fc[best].cp = (A.fc[best].cp & 0x00ffffffu) | ((uint32_t)(pass & 255) << 24);
                     const V3 bn = A.fc[best].n;
                     epa_getsupport(sh, margins, bn, A.sv[w]);
                     const float wdist = dot(bn, A.sv[w].w) - A.fc[best].d;
                     if (wdist > EPA_ACCURACY) {
                         for (int j = 0; (j < 3) && valid; ++j) {
-                            valid &= epa_expand(A, pass, w, A.fc[best].f[j], A.fc[best].e[j], hz);
+                            const uint32_t bfe = A.fc[best].fe;
+                            valid &= epa_expand(A, pass, w, epa_face_f(bfe, j), epa_face_e(bfe, j), hz);
                             if (E.arena_full) return EPA_ARENA_FULL;
                         }
                         if (valid && (hz.nf >= 3)) {
@@ -492,7 +517,7 @@ RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
             out.normal = outer.n;
             out.depth = outer.d;
             out.rank = 3;
-            out.c[0] = A.sv[outer.c[0]]; out.c[1] = A.sv[outer.c[1]]; out.c[2] = A.sv[outer.c[2]];
+            out.c[0] = A.sv[epa_face_c(outer.cp, 0)]; out.c[1] = A.sv[epa_face_c(outer.cp, 1)]; out.c[2] = A.sv[epa_face_c(outer.cp, 2)];
             const V3 c0 = out.c[0].w, c1 = out.c[1].w, c2 = out.c[2].w;
             float p0 = len(cross(c1 - projection, c2 - projection));
             float p1 = len(cross(c2 - projection, c0 - projection));
@@ -532,9 +557,12 @@ RLG_HD int epa_calc_pen_depth(EpaArena A, const EpaShapes& shapes, PenDepth& out
         else if (i == 1) guess = safe_normalized(sh.o0 - sh.o1);
         else guess = v3((i == 4 || i == 5 || i == 6 || i == 8) ? 1.f : 0.f, (i == 3 || i == 5 || i == 6 || i == 7) ? 1.f : 0.f, (i == 2 || i == 6 || i == 7 || i == 8) ? 1.f : 0.f);
         // Penetration
+        RLG_EPA_PROF(0);
         const int gs = epa_gjk_evaluate(G, sh, true, -guess);
+        RLG_EPA_PROF(1);
         if (gs == 1) {
             const int es = epa_evaluate(A, true, -guess);
+            RLG_EPA_PROF(3);
             if (es == EPA_ARENA_FULL) return EPA_ARENA_FULL;
             const EpaResult& r = *A.res;
             V3 w0 = v3(0.f, 0.f, 0.f);
@@ -542,6 +570,7 @@ RLG_HD int epa_calc_pen_depth(EpaArena A, const EpaShapes& shapes, PenDepth& out
             out.wa = (sh.R0 * w0) + sh.o0;
             out.wb = (sh.R0 * (w0 - r.normal * r.depth)) + sh.o0;
             out.v = -r.normal;
+            RLG_EPA_PROF(4);
             return 1;
         }
         // Distance (no margins)

@@ -249,6 +249,7 @@ class Learner:
         self._ret_host = torch.empty(max(1, cfg.maxReturnsPerStatsInc), dtype=torch.float32).pin_memory()
         self._ret_pending = None
         self._rep_dev = None
+        self._n_mb = 0
         # collectionDuringLearn: the PPO epochs go to their own HIP stream and the next collection does not wait for them.  Like the
         # reference's agent threads (ThreadAgent.cpp:72-103) the collector then reads whatever weights are there, mid-update included.
         self.s_collect = torch.cuda.current_stream(self.dev)

@@ -245,6 +245,7 @@ static int CollectionDuringLearn() {
     g_host = false; g_hostParser = false; g_teamSize = 1; g_spawnOpponents = true;
     LearnerConfig cfg = SmallConfig(256, 16, 2);
     cfg.collectionDuringLearn = true; cfg.ppo.epochs = 2; cfg.ppo.miniBatchSize = cfg.ppo.batchSize / 2;
+    cfg.ppo.autocastLearn = true;   // the overlap needs standalone inference (the fused inference kernel: bf16 mode); in fp32 mode the Learner keeps collection and learning in sequence
     Learner learner(MakeBuiltinEnv, cfg);
     int iterations = 0, withStats = 0; bool finite = true;
     learner.iterationCallback = [&](Learner* l, Report& report) {
@@ -259,6 +260,16 @@ static int CollectionDuringLearn() {
     CHECK(iterations == 4 && withStats == 3 && finite);
     CHECK(learner.totalTimesteps == 4ull * 256 * 2 * 16 && learner.totalEpochs == 8);
     std::printf("collectionDuringLearn: 4 iterations, PPO statistics in reports 2..4\n");
+    {   // fp32 mode: inference would share the learner's activation scratch with the epochs on the other stream -> serial, statistics in every report
+        LearnerConfig c2 = SmallConfig(64, 8, 2);
+        c2.collectionDuringLearn = true; c2.ppo.autocastLearn = false;
+        Learner l2(MakeBuiltinEnv, c2);
+        int its = 0, stats = 0;
+        l2.iterationCallback = [&](Learner* l, Report& report) { its++; if (report.Has("Policy Entropy")) stats++; if (its == 2) l->config.timestepLimit = 1; };
+        l2.Learn();
+        CHECK(its == 2 && stats == 2);
+        std::printf("collectionDuringLearn in fp32 mode: falls back to serial (statistics in every report)\n");
+    }
     return 0;
 }
 

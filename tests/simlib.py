@@ -251,7 +251,7 @@ GYM_EXACT = {"ts8_random", "ts8_chase", "ts1_random", "1v1_timeout", "1v1_goal",
 GYM_EXACT_OBS = {"2v2_padded3_zerosum_random"}
 
 # steps up to which a free-running gym rollout is compared (random actions with hitbox contacts: chaotic afterwards, like PHYS_FREE_RUN's `until`)
-GYM_HORIZON = {}
+GYM_HORIZON = {"2v2_padded3_zerosum_random": 64}
 # the host build's gym test hands the state over in uu after every step (one rounding per step the reference's resident arena does not
 # make): its random 2v2 rollout with hitbox contacts is compared up to here
 GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64}

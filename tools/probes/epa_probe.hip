@@ -5,6 +5,8 @@
 __shared__ unsigned char* g_epa_small_ptr[1];
 __shared__ unsigned char* g_epa_big_ptr[1];
 __device__ int g_cnt[4];
+__device__ unsigned long long g_phase[8]; __device__ unsigned long long g_last;
+#define RLG_EPA_PROF(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) atomicAdd(&g_phase[i], t_ - g_last); g_last = t_; } while (0)
 #ifndef PROBE_V
 #define PROBE_V 14
 #define PROBE_F 34
@@ -51,7 +53,9 @@ int main() {
         hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, d, z0, 200, out, sink, big);
         hipDeviceSynchronize();
         unsigned long long h[8]; hipMemcpy(h, out, 64, hipMemcpyDeviceToHost); int c[4]; hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cnt), sizeof(c));
+        unsigned long long ph[8]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)); unsigned long long zz[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zz, sizeof(zz));
         std::printf("box centre %.2f above the floor triangle: %llu cycles per call; contacts %llu / 200; penetration-depth queries %d (full-size arena %d)\n", z0, h[0], h[1], c[0], c[1]);
+        if (c[0]) std::printf("    per query: margin GJK %llu, enclose + first faces %llu, EPA loop + result %llu, witnesses %llu cycles\n", ph[1] / c[0], ph[2] / c[0], ph[3] / c[0], ph[4] / c[0]);
     }
     return 0;
 }
