@@ -29,7 +29,7 @@ def algorithmic_bytes_per_gym_step(n_players, obs_dim):
     return 2 * (336 * n_players + 264) + n_players * (4 * obs_dim + 8) + 4
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_baseline(seconds_target=12.0, mesh_dir=None):
     """The reference's CPU collection path on this host's cores (32 envs 1v1 = BASELINE config[0], threads x games like
     ThreadAgent): the real RocketSim/RLGymSim_CPP when the prebuilt oracle/_ref library is present (kind "reference"),
     else the oracle's scalar host build of the stepper (kind "port").  Stepping only, uniform random action tape."""
@@ -44,18 +44,20 @@ def cpu_baseline(seconds_target=12.0):
     sys.stdout.flush()
     saved_fd = os.dup(1); os.dup2(2, 1)
     try:
-        return _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so)
+        return _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so, mesh_dir)
     finally:
         sys.stdout.flush(); os.dup2(saved_fd, 1); os.close(saved_fd)
 
 
-def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so):
+def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so, mesh_dir=None):
     import ctypes as C
     try:
+        if mesh_dir is not None and not os.path.exists(ref_so):
+            return None          # a mesh of several files is the reference's own loader's business; the port baseline is quoted on the one-object mesh only
         if os.path.exists(ref_so) and os.path.exists(port_so):
             from simlib import PortSim, RefSim
             port = PortSim(); v, t = port.procedural_mesh()
-            ref = RefSim(v, t)
+            ref = RefSim(v, t, mesh_dir=mesh_dir)
             steps = 200
             sec = ref.lib.ref_bench_collect(team, n_envs, min(cores, n_envs), steps, 8)
             steps = max(200, int(steps * seconds_target / max(sec, 1e-3)))
@@ -78,7 +80,7 @@ def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so):
     agent_steps = n_envs * 2 * team * steps
     return {"value": agent_steps / sec, "unit": "agent-steps/s", "cores": min(cores, n_envs), "kind": kind,
             "sample": f"{n_envs} envs 1v1 (BASELINE config[0]), {min(cores, n_envs)} threads x {n_envs // min(cores, n_envs)} games, {steps} gym steps/env, "
-                      f"tickSkip 8, example obs/reward stack, random actions, procedural mesh, stepping only ({sec:.1f} s)"}
+                      f"tickSkip 8, example obs/reward stack, random actions, {'the tessellated mesh files' if mesh_dir else 'procedural mesh'}, stepping only ({sec:.1f} s)"}
 
 
 def kernel_source_hash():
@@ -135,6 +137,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trained-warmup", type=int, default=480, help="after the timed region: this many more iterations, then --trained-steps timed ones (the policy has started to play: more contacts per tick); 0 = skip")
     ap.add_argument("--trained-steps", type=int, default=100)
+    ap.add_argument("--learned-warmup", type=int, default=1000, help="then: this many more iterations of LEARNING with --learned-epochs PPO epochs each (the policy then chases and hits the ball), "
+                    "and --learned-steps timed iterations with the headline's settings: `trained_regime_learned`; 0 = skip")
+    ap.add_argument("--learned-epochs", type=int, default=2)
+    ap.add_argument("--learned-steps", type=int, default=100)
+    ap.add_argument("--mesh", choices=["procedural", "tessellated", "both"], default="both",
+                    help="procedural: the 180-triangle arena (the headline); tessellated: the same arena at ~9 k triangles in 16 .cmf files (what the game's own soccar set looks "
+                         "like to the stepper), given to the HIP path and to the reference baseline through their directory loaders; both: headline + a `mesh_tessellated` leg")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)   # internal: print the CPU baseline for the mesh directory given, as JSON
     args = ap.parse_args()
 
     # The measured process is rlgymppo_cpp_amd/bench_main (C++ on librlgymppo_amd.so / librlgpu.so; HIP runtime + RCCL only).  This
@@ -142,6 +152,9 @@ def main():
     # MASTER_PORT are inherited, the ranks meet through rlgpu_comm_init_env), adds the CPU baseline and the committed PMC figures, and
     # prints the line.
     import subprocess
+    if args.cpu_baseline_child is not None:      # a process initialises the reference once: the second mesh gets a process of its own
+        print(json.dumps(cpu_baseline(8.0, mesh_dir=args.cpu_baseline_child)))
+        return
     exe = os.path.join(ROOT, "rlgymppo_cpp_amd", "bench_main")
     if not os.path.exists(exe):
         raise SystemExit("bench.py: rlgymppo_cpp_amd/bench_main is not built (python -c 'import __graft_entry__ as g; g.build()') -- there is no other path")
@@ -155,7 +168,12 @@ def main():
     if args.fp32: cmd.append("--fp32")
     if args.trained_warmup > 0 and args.trained_steps > 0:
         cmd += ["--trained-warmup", str(args.trained_warmup), "--trained-steps", str(args.trained_steps)]
+    if args.learned_warmup > 0 and args.learned_steps > 0 and world == 1:
+        cmd += ["--learned-warmup", str(args.learned_warmup), "--learned-epochs", str(args.learned_epochs), "--learned-steps", str(args.learned_steps)]
     env = rank_child_env(os.environ)
+    if args.mesh == "tessellated":
+        mesh_dir, mesh_info = make_tessellated_mesh_dir()
+        cmd += ["--mesh-dir", mesh_dir]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
     if proc.returncode != 0:
         raise SystemExit(f"bench_main failed with exit code {proc.returncode}")
@@ -214,11 +232,58 @@ def main():
         out["trained_regime"] = dict(m["trained_regime"], note="same learner config (1 epoch) continued; at this point play is still close to random. "
                                      "A policy that has learned to chase the ball costs more per tick (DESIGN.md 4.3, profiles/r02l_train_probe.txt: "
                                      "7.9 M agent-steps/s over 1600 two-epoch iterations, Python host)")
+    if "trained_regime_learned" in m:
+        out["trained_regime_learned"] = dict(m["trained_regime_learned"], note="the same learner after learning on with 2 PPO epochs per iteration until the policy plays "
+                                             "(mean step reward and entropy next to the fresh policy's); measured with the headline's settings (1 epoch)")
+    if args.mesh == "tessellated":
+        out["config"]["workload"] = out["config"]["workload"].replace("procedural arena mesh", f"tessellated arena mesh ({mesh_info['triangles']} triangles in {mesh_info['files']} .cmf files)")
+        out["mesh"] = mesh_info
     if not args.no_cpu_baseline and world == 1:
-        cb = cpu_baseline()
+        cb = cpu_baseline(mesh_dir=mesh_dir if args.mesh == "tessellated" else None) if args.mesh != "tessellated" else tessellated_cpu_baseline(mesh_dir)
         if cb is not None:
             out["cpu_baseline"] = cb
+    if args.mesh == "both" and world == 1:
+        # the same measurement (shorter) on the tessellated mesh, with its own CPU baseline: both sides load the same 16 files
+        mesh_dir, mesh_info = make_tessellated_mesh_dir()
+        cmd2 = [exe, "--envs", str(args.envs), "--team-size", str(args.team_size), "--horizon", str(args.horizon), "--steps", str(max(20, args.steps // 4)), "--warmup", str(max(5, args.warmup // 2)),
+                "--epochs", str(args.epochs), "--mesh-dir", mesh_dir]
+        if args.padded_zero_sum: cmd2.append("--padded-zero-sum")
+        if args.fp32: cmd2.append("--fp32")
+        p2 = subprocess.run(cmd2, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+        if p2.returncode == 0:
+            m2 = json.loads(p2.stdout.decode().strip().splitlines()[-1])
+            leg = dict(mesh_info, value=m2["value"], unit="agent-steps/s", ms_per_step=m2["ms_per_step"], ppo_iter_ms=m2["ppo_iter_ms"], steps=m2["steps"],
+                       env_kernel_avg_ms=m2["env_kernel_ms_total"] / max(1, m2["env_launches"]), fused_collect=m2["fused_collect"])
+            if not args.no_cpu_baseline:
+                cb2 = tessellated_cpu_baseline(mesh_dir)
+                if cb2 is not None:
+                    leg["cpu_baseline"] = cb2
+            out["mesh_tessellated"] = leg
+        else:
+            out["mesh_tessellated"] = {"error": f"bench_main exit code {p2.returncode}"}
     print(json.dumps(out))
+
+
+def make_tessellated_mesh_dir():
+    """The procedural arena at ~9 k triangles (fillets of 8 strips, no edge longer than 700 uu) written as 16 .cmf files into a fresh
+    directory <tmp>/soccar/ -- host code only (librlgpu.so's mesh generator), no GPU."""
+    import tempfile
+    from rlgymppo_cpp_amd.env import procedural_mesh_ex, write_cmf_files
+    v, t = procedural_mesh_ex(8, 700.0)
+    d = tempfile.mkdtemp(prefix="rlgpu_mesh_")
+    paths = write_cmf_files(v, t, os.path.join(d, "soccar"), 16)
+    return d, {"triangles": int(len(t)), "files": len(paths), "generator": "rlgpu_procedural_mesh_ex(fillet_segments=8, max_edge_uu=700), split by sector into .cmf files"}
+
+
+def tessellated_cpu_baseline(mesh_dir):
+    """The reference on the same files, in a process of its own (RocketSim initialises once per process)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", mesh_dir], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT)
+        line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{") or ln == "null"]
+        return json.loads(line[-1]) if line else None
+    except Exception as e:
+        return {"value": None, "unit": "agent-steps/s", "kind": "error", "sample": str(e)[:200]}
 
 
 if __name__ == "__main__":

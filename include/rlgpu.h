@@ -82,6 +82,10 @@ int rlgpu_env_set_procedural_mesh(rlgpu_env* e);
 int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* soccar_dir); /* collision_meshes/soccar/<name>.cmf */
 /* host helpers (no GPU needed): the procedural soccar mesh and the DiscreteAction table */
 int rlgpu_procedural_mesh(float* verts_uu, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris);
+/* The same arena at a chosen resolution (bench.py --mesh tessellated: a stand-in for the triangle counts of the game's own soccar meshes):
+ * fillets of `fillet_segments` strips (4 = rlgpu_procedural_mesh), every edge longer than max_edge_uu split at its midpoint (0 = none).
+ * With null buffers only the counts are returned. */
+int rlgpu_procedural_mesh_ex(int fillet_segments, float max_edge_uu, float* verts_uu, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris);
 /* order_out[i] = input triangle that is collided i-th when everything overlaps: the visiting order of the reference's quantized BVH
    (btOptimizedBvh::build + walkStacklessQuantizedTreeCacheFriendly, btQuantizedBvh.cpp:116-277,655-674), which this library's mesh keeps */
 int rlgpu_mesh_visit_order(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, int32_t* order_out);

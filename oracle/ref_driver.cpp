@@ -268,6 +268,25 @@ int ref_init(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris
     return 0;
 }
 
+// RocketSim::Init on a directory of .cmf files (<dir>/soccar/*.cmf), the reference's own loader (RS/RocketSim.cpp:70-212): one
+// btBvhTriangleMeshShape and one static rigid body per file (Arena.cpp:1028-1054).  Used for meshes of several files (the tessellated
+// bench leg, the per-file parity fixtures); a process can be initialised once.
+// (RocketSim::Init takes the files in std::filesystem::directory_iterator order, which is unspecified; the objects' creation order decides
+// the order of a car's world manifolds, so this loader reads the same files in NAME order -- what rlgpu_env_load_cmf_dir does -- and hands
+// them to RocketSim::InitFromMem, which is all Init does with them.)
+int ref_init_dir(const char* dir) {
+    if (RocketSim::GetStage() == RocketSim::RocketSimStage::INITIALIZED) return 0;
+    std::vector<std::filesystem::path> files;
+    const std::filesystem::path folder = std::filesystem::path(dir) / "soccar";
+    if (!std::filesystem::exists(folder)) { fprintf(stderr, "ref_init_dir: no %s\n", folder.string().c_str()); return -1; }
+    for (auto& entry : std::filesystem::directory_iterator(folder)) if (entry.path().extension() == ".cmf") files.push_back(entry.path());
+    std::sort(files.begin(), files.end());
+    std::map<GameMode, std::vector<RocketSim::FileData>> m;
+    for (auto& f : files) { DataStreamIn in(f, false); m[GameMode::SOCCAR].push_back(in.data); }
+    try { RocketSim::InitFromMem(m, true); } catch (std::exception& e) { fprintf(stderr, "ref_init_dir: %s\n", e.what()); return -1; }
+    return 0;
+}
+
 // The order in which the arena mesh's triangles are handed to a convex body's collision callback when everything overlaps
 // (btBvhTriangleMeshShape::processAllTriangles): out[i] = triangle index visited i-th.  Returns the triangle count.
 int ref_mesh_visit_order(int32_t* out, int cap) {

@@ -79,6 +79,7 @@ SIGNATURES = {
     "rlgpu_comm_rendezvous_path": (_i, [C.c_char_p, _i]),
     "rlgpu_env_overflow_counts": (_i, [_vp, _vp, _i]),
     "rlgpu_env_epa_counts": (_i, [_vp, _vp, _i]),
+    "rlgpu_procedural_mesh_ex": (_i, [_i, C.c_float, _vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "rlgpu_learner_inference_is_standalone": (_i, [_vp]),
     "rlgpu_env_enable_timing": (_i, [_vp, _i]),
     "rlgpu_learner_enable_timing": (_i, [_vp, _i]),

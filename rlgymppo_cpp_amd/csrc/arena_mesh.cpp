@@ -405,10 +405,41 @@ struct MeshOut {
 };
 }  // namespace
 
-void make_procedural_soccar(std::vector<float>& verts, std::vector<int32_t>& tris) {
+void make_procedural_soccar(std::vector<float>& verts, std::vector<int32_t>& tris) { make_procedural_soccar_ex(verts, tris, 4, 0.f); }
+
+// Every edge longer than max_edge is split at its midpoint (a triangle with 1 / 2 / 3 such edges becomes 2 / 3 / 4), until none is left.
+// The decision is per EDGE, so neighbours split the edge they share at the same point and the surface stays free of T-junctions.
+static void subdivide_long_edges(std::vector<float>& v, std::vector<int32_t>& t, float max_edge) {
+    if (!(max_edge > 0.f)) return;
+    const float lim2 = max_edge * max_edge;
+    auto P = [&](int i) { return &v[3 * (size_t)i]; };
+    auto len2 = [&](int a, int b) { const float* p = P(a); const float* q = P(b); const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2]; return dx * dx + dy * dy + dz * dz; };
+    auto mid = [&](int a, int b) { const float x = (P(a)[0] + P(b)[0]) * 0.5f, y = (P(a)[1] + P(b)[1]) * 0.5f, z = (P(a)[2] + P(b)[2]) * 0.5f; v.push_back(x); v.push_back(y); v.push_back(z); return (int)(v.size() / 3) - 1; };
+    for (bool any = true; any;) {
+        any = false;
+        std::vector<int32_t> out; out.reserve(t.size() * 2);
+        for (size_t k = 0; k + 2 < t.size(); k += 3) {
+            const int a = t[k], b = t[k + 1], c = t[k + 2];
+            const bool sab = len2(a, b) > lim2, sbc = len2(b, c) > lim2, sca = len2(c, a) > lim2;
+            const int n = (int)sab + (int)sbc + (int)sca;
+            auto tri = [&](int x, int y, int z) { out.push_back(x); out.push_back(y); out.push_back(z); };
+            if (n == 0) { tri(a, b, c); continue; }
+            any = true;
+            const int mab = sab ? mid(a, b) : -1, mbc = sbc ? mid(b, c) : -1, mca = sca ? mid(c, a) : -1;
+            if (n == 3) { tri(a, mab, mca); tri(mab, b, mbc); tri(mca, mbc, c); tri(mab, mbc, mca); }
+            else if (n == 1) { if (sab) { tri(a, mab, c); tri(mab, b, c); } else if (sbc) { tri(a, b, mbc); tri(a, mbc, c); } else { tri(a, b, mca); tri(mca, b, c); } }
+            else if (!sab) { tri(a, b, mbc); tri(a, mbc, mca); tri(mca, mbc, c); }     // bc and ca split
+            else if (!sbc) { tri(a, mab, mca); tri(mab, b, c); tri(mab, c, mca); }     // ab and ca split
+            else { tri(a, mab, mbc); tri(a, mbc, c); tri(mab, b, mbc); }               // ab and bc split
+        }
+        t.swap(out);
+    }
+}
+
+void make_procedural_soccar_ex(std::vector<float>& verts, std::vector<int32_t>& tris, int fillet_segments, float max_edge_uu) {
     MeshOut m{verts, tris};
     const float X = 4096.f, Y = 5120.f, Z = 2048.f, GX = 892.755f, GZ = 642.775f, GY = 6000.f, CUT = 1152.f, R = 256.f;
-    const int SEG = 4;
+    const int SEG = fillet_segments > 0 ? fillet_segments : 4;
     for (int s = -1; s <= 1; s += 2) {
         float y = s * Y, yb = s * GY;
         // back wall around the goal mouth
@@ -437,6 +468,7 @@ void make_procedural_soccar(std::vector<float>& verts, std::vector<int32_t>& tri
     for (int sx = -1; sx <= 1; sx += 2)
         for (int up = -1; up <= 1; up += 2)
             m.fillet(sx * X, -(Y - CUT), sx * X, (Y - CUT), up > 0 ? 0.f : Z, (float)up, (float)-sx, 0.f, R, SEG);
+    subdivide_long_edges(verts, tris, max_edge_uu);
 }
 
 bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts, std::vector<int32_t>& tris) {

@@ -27,6 +27,9 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
 // the procedural soccar arena (uu): back walls with goal mouths, goal boxes, 45-degree corner walls and
 // quarter-cylinder floor fillets.  Geometry facts from RLConst.h:14-16,109, Arena.cpp:846-849, CommonValues.h:9-13.
 void make_procedural_soccar(std::vector<float>& verts_uu, std::vector<int32_t>& tris);
+// the same arena at a chosen resolution: quarter-cylinder fillets of `fillet_segments` strips, every edge longer than max_edge_uu split
+// (0 = none) -- a stand-in for the triangle counts of the game's own soccar meshes (thousands of triangles in 16 files)
+void make_procedural_soccar_ex(std::vector<float>& verts_uu, std::vector<int32_t>& tris, int fillet_segments, float max_edge_uu);
 
 // parse one .cmf blob (i32 nTris, i32 nVerts, tris, verts in BT units) and append to verts(uu)/tris
 bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts_uu, std::vector<int32_t>& tris);

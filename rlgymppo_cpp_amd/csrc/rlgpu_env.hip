@@ -976,6 +976,16 @@ int rlgpu_procedural_mesh(float* verts, int cap_verts, int32_t* tris, int cap_tr
     return RLGPU_OK;
 }
 
+int rlgpu_procedural_mesh_ex(int fillet_segments, float max_edge_uu, float* verts, int cap_verts, int32_t* tris, int cap_tris, int* n_verts, int* n_tris) {
+    std::vector<float> v; std::vector<int32_t> t;
+    make_procedural_soccar_ex(v, t, fillet_segments, max_edge_uu);
+    *n_verts = (int)v.size() / 3; *n_tris = (int)t.size() / 3;
+    if (!verts || !tris) return RLGPU_OK;
+    if (*n_verts > cap_verts || *n_tris > cap_tris) return RLGPU_ERR_ARG;
+    memcpy(verts, v.data(), v.size() * 4); memcpy(tris, t.data(), t.size() * 4);
+    return RLGPU_OK;
+}
+
 int rlgpu_action_table(float* out, int cap_rows) {
     float tab[90 * 8];
     int n = build_action_table(tab);

@@ -192,6 +192,39 @@ def procedural_mesh():
     return v, t
 
 
+def procedural_mesh_ex(fillet_segments=12, max_edge_uu=330.0):
+    """The procedural arena at a chosen resolution (rlgpu_procedural_mesh_ex): the defaults give ~9 k triangles."""
+    lib = _lib.load()
+    nv, nt = C.c_int(), C.c_int()
+    lib.rlgpu_procedural_mesh_ex(fillet_segments, C.c_float(max_edge_uu), None, 0, None, 0, C.byref(nv), C.byref(nt))
+    v = np.zeros((nv.value, 3), np.float32); t = np.zeros((nt.value, 3), np.int32)
+    rc = lib.rlgpu_procedural_mesh_ex(fillet_segments, C.c_float(max_edge_uu), v.ctypes.data, nv.value, t.ctypes.data, nt.value, C.byref(nv), C.byref(nt))
+    assert rc == 0
+    return v, t
+
+
+def write_cmf_files(verts_uu, tris, out_dir, n_files=16):
+    """Split a mesh into n_files .cmf files the way the game's soccar set is split (RocketSim::Init reads a directory of them:
+    RS/RocketSim.cpp:70-212; format CollisionMeshFile.cpp:11-36: i32 nTris, i32 nVerts, index triplets, vertices in Bullet units = uu / 50).
+    The triangles are grouped by the angle of their centroid around the field centre, so every file is one sector of the arena."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    cen = verts_uu[tris].mean(axis=1)
+    sector = ((np.arctan2(cen[:, 1], cen[:, 0]) + np.pi) / (2 * np.pi) * n_files).astype(np.int64).clip(0, n_files - 1)
+    paths = []
+    for k in range(n_files):
+        tk = tris[sector == k]
+        if len(tk) == 0:
+            continue
+        used = np.unique(tk); remap = -np.ones(len(verts_uu), np.int64); remap[used] = np.arange(len(used))
+        path = os.path.join(out_dir, "mesh_%02d.cmf" % k)
+        with open(path, "wb") as f:
+            f.write(np.int32(len(tk)).tobytes()); f.write(np.int32(len(used)).tobytes())
+            f.write(remap[tk].astype(np.int32).tobytes()); f.write((verts_uu[used] / 50.0).astype(np.float32).tobytes())
+        paths.append(path)
+    return paths
+
+
 def action_table():
     lib = _lib.load()
     tab = np.zeros((128, 8), np.float32)

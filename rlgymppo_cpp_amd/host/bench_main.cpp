@@ -2,9 +2,13 @@
 // Learner) on include/RLGymPPO_CPP over librlgymppo_amd.so / librlgpu.so.  No Python, no torch: the HIP runtime, the C-ABI library
 // and (multi-GPU) RCCL are all that touch the device.  Prints ONE JSON object on stdout (rank 0).
 //   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32] [--overlap] [--trained-warmup I --trained-steps J]
+//              [--learned-warmup I --learned-epochs n --learned-steps J] [--mesh-dir DIR]
 // One "step" = one full PPO iteration: T gym steps of every env with on-device policy inference, value pass + GAE, shuffled
 // minibatches (4 per batch), clip + Adam.  With --trained-warmup the same measurement is repeated after I more iterations, when
-// the policy has started to play and contacts are more frequent ("trained_regime").
+// the policy has started to play and contacts are more frequent ("trained_regime").  With --learned-warmup the run then goes on LEARNING
+// (--learned-epochs PPO epochs per iteration, what tools/train_probe.py uses) for I more iterations -- by then the policy chases and hits the
+// ball -- and is measured once more with the headline's settings ("trained_regime_learned"; mean step reward and entropy are printed with it).
+// --mesh-dir: a directory of .cmf collision meshes for RocketSim::Init (default ./collision_meshes; absent -> the procedural arena).
 #include <RLGymPPO_CPP/Learner.h>
 #include <RLGymSim_CPP/Utils/RewardFunctions/CommonRewards.h>
 #include <RLGymSim_CPP/Utils/RewardFunctions/CombinedReward.h>
@@ -22,6 +26,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 using namespace RLGPC;
 using namespace RLGSC;
@@ -41,20 +46,23 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
     return { match, gym };
 }
 
-struct Timed { double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
+struct Timed { double stepReward = 0, entropy = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0; bool fp32 = false, overlap = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, overlap = false;
+    std::string meshDir = "./collision_meshes";
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
         else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
         else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true;
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
+        else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
+        else if (is("--mesh-dir")) meshDir = argv[++i];
         else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
     }
     setenv("RLGPU_QUIET", "1", 1);
-    RocketSim::Init("./collision_meshes", true);
+    RocketSim::Init(meshDir, true);
     const int64_t nAgents = (int64_t)envs * 2 * g_team, B = nAgents * horizon;
     LearnerConfig cfg = {};
     cfg.numThreads = 1; cfg.numGamesPerThread = envs;
@@ -69,8 +77,10 @@ int main(int argc, char* argv[]) {
     const int rank = learner.Rank(), world = learner.WorldSize();
 
     auto barrier = [&]() { (void)hipDeviceSynchronize(); (void)learner.MaxOverRanks(0.0); (void)hipDeviceSynchronize(); };   // device sync + a collective = a barrier
+    double lastStepReward = 0, lastEntropy = 0;
     auto iteration = [&](double* consumeMs) {
         Report rep;
+        struct Keep { Report& r; double& a; double& b; ~Keep() { if (r.Has("Average Step Reward")) a = r["Average Step Reward"]; if (r.Has("Policy Entropy")) b = r["Policy Entropy"]; } } keep{rep, lastStepReward, lastEntropy};
         learner.CollectTimesteps();
         if (overlap) { learner.FinishLearn(rep); learner.AddNewExperience(rep); learner.LearnPPO(rep); return; }   // the epochs run beside the next collection
         if (consumeMs) (void)hipDeviceSynchronize();   // the collection launch is asynchronous: the consumption clock starts when it has finished
@@ -93,11 +103,19 @@ int main(int argc, char* argv[]) {
         learner.AllReduceTimings(t.arMs, t.arCalls, false);
         learner.DeviceTimings(t.envMs, t.envLaunches, t.gemmMs, t.gemmFlops, t.gemmCalls, false);
         t.consumeMs /= std::max(1, k);
+        t.stepReward = lastStepReward; t.entropy = lastEntropy;
         return t;
     };
     Timed m = measure(warmup, steps);
     Timed tr{}; bool haveTr = false;
     if (trainedWarm > 0 && trainedSteps > 0) { tr = measure(trainedWarm, trainedSteps); haveTr = true; }
+    Timed ln{}; bool haveLn = false;
+    if (learnedWarm > 0 && learnedSteps > 0) {   // learn on with more epochs per iteration, then measure with the headline's settings again
+        learner.config.ppo.epochs = learnedEpochs;
+        for (int i = 0; i < learnedWarm; i++) iteration(nullptr);
+        learner.config.ppo.epochs = epochs;
+        ln = measure(0, learnedSteps); haveLn = true;
+    }
     fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations\n", rank, world, m.sec, steps);
     if (rank == 0) {
         const int nP = 2 * g_team, D = learner.obsSize;
@@ -119,6 +137,11 @@ int main(int argc, char* argv[]) {
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
                    warmup + steps + trainedWarm, trainedSteps, (double)B * world * trainedSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);
+        if (haveLn)
+            printf(", \"trained_regime_learned\": {\"after_iterations\": %d, \"learning_epochs\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f, "
+                   "\"mean_step_reward\": %.5f, \"policy_entropy\": %.4f, \"mean_step_reward_fresh_policy\": %.5f, \"policy_entropy_fresh_policy\": %.4f}",
+                   warmup + steps + trainedWarm + trainedSteps + learnedWarm, learnedEpochs, learnedSteps, (double)B * world * learnedSteps / ln.sec, ln.sec / learnedSteps * 1e3, ln.consumeMs,
+                   ln.envLaunches ? ln.envMs / ln.envLaunches : 0.0, ln.stepReward, ln.entropy, m.stepReward, m.entropy);
         printf("}\n");
         fflush(stdout);
     }

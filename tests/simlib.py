@@ -46,16 +46,21 @@ class PortSim:
 class RefSim:
     _inited = False
 
-    def __init__(self, verts, tris):
+    def __init__(self, verts, tris, mesh_dir=None):
+        """mesh_dir: a directory holding soccar/*.cmf, loaded by the reference's own RocketSim::Init (one collision object per file);
+        else the one-blob mesh (verts, tris).  A process initialises the reference once."""
         self.lib = C.CDLL(REF_SO)
         assert self.lib.ref_state_size() == C.sizeof(ArenaState)
         self.lib.ref_arena_new.restype = _vp
         self.lib.ref_gym_new.restype = _vp
         self.lib.ref_gym_arena.restype = _vp
         self.lib.ref_bench_collect.restype = C.c_double
-        verts = np.ascontiguousarray(verts, np.float32)
-        tris = np.ascontiguousarray(tris, np.int32)
-        rc = self.lib.ref_init(_ptr(verts), len(verts), _ptr(tris), len(tris))
+        if mesh_dir is not None:
+            rc = self.lib.ref_init_dir(str(mesh_dir).encode())
+        else:
+            verts = np.ascontiguousarray(verts, np.float32)
+            tris = np.ascontiguousarray(tris, np.int32)
+            rc = self.lib.ref_init(_ptr(verts), len(verts), _ptr(tris), len(tris))
         assert rc == 0
 
     def arena(self, team_size=1):
