@@ -91,10 +91,8 @@ RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 loca
 // The candidate / item queue itself (CollideQueue) and the BVH queries live in arena_world.h: the wheel rays share it.
 // One (hitbox, triangle) pair of the car-mesh manifold: GJK on the core shapes (arena_gjk.h); where the cores themselves overlap, the
 // core polytopes' minimum-translation axis from the SAT routine (deepest clipped point), pushed out by the margin.
-RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
-#ifdef RLG_GJK_STATS
-    RLG_GJK_STATS(0, 0);
-#endif
+// The two rejections that come before GJK: true = this triangle yields no contact point.
+RLG_HD bool hitbox_triangle_rejected(V3 bc, const M3& R, const MeshTri& t) {
     {   // btConvexTriangleCallback::processTriangle's early out (btConvexConcaveCollisionAlgorithm.cpp:103-137): the hitbox's support vertex
         // along the triangle normal, either side, is farther from the plane than the contact threshold -> no GJK for this triangle
         const V3 v0 = v3(t.v0x, t.v0y, t.v0z);
@@ -105,7 +103,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
             V3 dl = tmul(R, tn);
             V3 lp = v3(dl.x >= 0.f ? h.x : -h.x, dl.y >= 0.f ? h.y : -h.y, dl.z >= 0.f ? h.z : -h.z);
             V3 wp = (R * lp) + bc;
-            if (dot(tn, v0) - dot(tn, wp) > CBT_CAR) return false;
+            if (dot(tn, v0) - dot(tn, wp) > CBT_CAR) return true;
             tn *= -1.f;
         }
     }
@@ -115,10 +113,19 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c) {
         const V3 h = hitbox_half();
         const V3 p0 = tmul(R, v3(t.v0x, t.v0y, t.v0z) - bc), p1 = tmul(R, v3(t.v1x, t.v1y, t.v1z) - bc), p2 = tmul(R, v3(t.v2x, t.v2y, t.v2z) - bc);
         const float m = CBT_CAR + 1e-4f;
-        if (fminf(p0.x, fminf(p1.x, p2.x)) > h.x + m || fmaxf(p0.x, fmaxf(p1.x, p2.x)) < -(h.x + m)) return false;
-        if (fminf(p0.y, fminf(p1.y, p2.y)) > h.y + m || fmaxf(p0.y, fmaxf(p1.y, p2.y)) < -(h.y + m)) return false;
-        if (fminf(p0.z, fminf(p1.z, p2.z)) > h.z + m || fmaxf(p0.z, fmaxf(p1.z, p2.z)) < -(h.z + m)) return false;
+        if (fminf(p0.x, fminf(p1.x, p2.x)) > h.x + m || fmaxf(p0.x, fmaxf(p1.x, p2.x)) < -(h.x + m)) return true;
+        if (fminf(p0.y, fminf(p1.y, p2.y)) > h.y + m || fmaxf(p0.y, fmaxf(p1.y, p2.y)) < -(h.y + m)) return true;
+        if (fminf(p0.z, fminf(p1.z, p2.z)) > h.z + m || fmaxf(p0.z, fmaxf(p1.z, p2.z)) < -(h.z + m)) return true;
     }
+    return false;
+}
+// `prechecked`: the caller has already applied hitbox_triangle_rejected (the device's candidate phase does, one lane per candidate, so
+// that only triangles that reach GJK take a slot of the item queue -- with the game's own meshes a car near a wall overlaps dozens)
+RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c, bool prechecked = false) {
+#ifdef RLG_GJK_STATS
+    RLG_GJK_STATS(0, 0);
+#endif
+    if (!prechecked && hitbox_triangle_rejected(bc, R, t)) return false;
 #ifdef RLG_EXPERIMENT_GJK_TWICE   // what-if build only: every GJK run done twice, same physics -> the launch grows by what the runs cost in place
     { GjkOut g0; bool d0 = false; const float thr = CBT_CAR * (1.f + 1e-7f * (float)(t.edge_flags & 1u)); if (gjk_box_triangle(bc, R, hitbox_core(), BOX_MARGIN, t, thr, g0, d0) && g0.dist == 1234.5678f) c.dist = 0.f; }
 #endif
@@ -236,7 +243,18 @@ RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const Coll
         if (!car_collides(A.cars[it.a])) return false;
         car_query_aabb(A.cars[it.a], bc, lo, hi);   // the tight hitbox box, not the ray-extended one the list was built for
     }
-    return tri_aabb_overlap(mesh.tris[it.ref], lo, hi);
+    const MeshTri& t = mesh.tris[it.ref];
+    if (!tri_aabb_overlap(t, lo, hi)) return false;
+    if (it.type == 1) return !hitbox_triangle_rejected(bc, A.cars[it.a].b.rot, t);    // (same decisions hitbox_triangle would make: no contact either way)
+    {   // the ball: SphereTriangleDetector's plane test (sphere_triangle's first exit)
+        const V3 v0 = v3(t.v0x, t.v0y, t.v0z);
+        V3 n = cross(v3(t.v1x, t.v1y, t.v1z) - v0, v3(t.v2x, t.v2y, t.v2z) - v0);
+        const float l2 = len2(n);
+        if (l2 < SIMD_EPS * SIMD_EPS) return false;
+        n = vdiv_bt(n, sqrtf(l2));
+        const float dplane = fabsf(dot(A.ball.b.pos - v0, n));
+        return dplane < K::BALL_RADIUS * UU2BT + CBT_BALL;
+    }
 }
 
 // step 3: run item `slot`
@@ -255,7 +273,7 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
     } else if (it.type == 1) {
         const Car& car = A.cars[it.a];
         V3 bc = car.b.pos + car.b.rot * hitbox_off();
-        if (hitbox_triangle(bc, car.b.rot, mesh.tris[it.ref], one)) n = 1;
+        if (hitbox_triangle(bc, car.b.rot, mesh.tris[it.ref], one, true)) n = 1;
     } else {
         NarrowInline().car_car(A, it.a, it.ref, many, n);
     }
@@ -523,8 +541,7 @@ struct TickWork {
     uint16_t man_stack[MAXM];
     int16_t n_normal, n_rows;
 };
-static_assert(sizeof(CollideQueue<2>) <= sizeof(Row) * TickWork<2>::MAXR && sizeof(CollideQueue<4>) <= sizeof(Row) * TickWork<4>::MAXR && sizeof(CollideQueue<6>) <= sizeof(Row) * TickWork<6>::MAXR,
-              "the narrowphase queue must fit inside the solver rows it shares LDS with");
+// (with the default caps the narrowphase queue fits inside the solver rows it shares LDS with; bigger caps -- RLG_BODY_CAND, RLG_ITEM_CAP -- grow the union)
 
 // Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
 // contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy

@@ -136,7 +136,7 @@ struct CollideItem {
     int16_t off, n;    // result candidates: pool[off .. off+n)
 };
 #ifndef RLG_ITEM_CAP
-#define RLG_ITEM_CAP 32   /* tests build a tiny queue to exercise the overflow fallback */
+#define RLG_ITEM_CAP 48   /* tests build a tiny queue to exercise the overflow fallback */
 #endif
 // measured over 614 K env-ticks of random play (tools: RLG_QSTAT hook): items <= 16 in 99.93 % of the ticks (max seen > 16), candidate slots <= 88,
 // pool entries <= 12 -- the caps below leave the inline fallback to the truly pathological ticks
@@ -144,7 +144,10 @@ constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 40;
 constexpr int LEAF_SLOTS = 4;              // BVH leaves hold <= 4 triangles (arena_mesh.cpp); the device reserves a full block per leaf
 constexpr uint32_t CAND_HOLE = 0xFFFFFFFFu;  // unused slot of such a block
 constexpr int FRONTIER_CAP = 128;       // BVH nodes per level of the breadth-first walk (all bodies of an env together on the device)
-constexpr int BALL_CAND = 96, CAR_CAND = 96, PAIR_SLOTS = 16;   // candidate slots: 24 leaves per body (measured: <= 22 leaves per env; 12 were not enough for the ball in the corners)
+#ifndef RLG_BODY_CAND
+#define RLG_BODY_CAND 128   /* (96 until the tessellated arena -- 10 k triangles -- overflowed a car's region 5 times per 1000 env-ticks) */
+#endif
+constexpr int BALL_CAND = RLG_BODY_CAND, CAR_CAND = RLG_BODY_CAND, PAIR_SLOTS = 16;   // candidate slots: 24 leaves per body (measured: <= 22 leaves per env; 12 were not enough for the ball in the corners)
 template <int NC>
 struct CollideQueue {
     static constexpr int NB = NC + 1;

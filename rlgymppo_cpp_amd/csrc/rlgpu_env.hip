@@ -125,7 +125,7 @@ constexpr int WAVE = 64;
 #define RLG_LDS_BUDGET (40 * 1024)
 #endif
 #ifndef RLG_LDS_NODES
-#define RLG_LDS_NODES 136   /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B) */
+#define RLG_LDS_NODES 52    /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B, 136 before the candidate / item caps grew for fine meshes: 128 slots per body, 48 items) */
 #endif
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1

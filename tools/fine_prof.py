@@ -13,6 +13,10 @@ from rlgymppo_cpp_amd.state import default_arena
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 trained = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mesh = "procedural"
+if len(sys.argv) > 4 and sys.argv[4] == "tess":      # the arena at ~10 k triangles in 16 .cmf files (bench.py --mesh tessellated)
+    import bench
+    mesh, info = bench.make_tessellated_mesh_dir(); mesh = os.path.join(mesh, "soccar"); print("mesh:", info)
 ticks, reps = 8, 4
 if trained:
     from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
@@ -21,7 +25,7 @@ if trained:
                               ppo=PPOLearnerConfig(batchSize=B, miniBatchSize=B // 4, epochs=2, policyLR=2e-4, criticLR=2e-4, entCoef=0.01, autocastLearn=True)))
     env = L.env
 else:
-    env = BatchedEnv(n, 1)
+    env = BatchedEnv(n, 1, mesh=mesh)
 fn = env.lib.rlgpu_env_debug_tick_cycles
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]; fn.restype = C.c_int
 env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
