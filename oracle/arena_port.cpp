@@ -72,6 +72,11 @@ void port_epa_stats(int* out64, int reset) { memcpy(out64, g_epa_stats, sizeof(g
 void port_set_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
     g_mesh = build_host_mesh(verts_uu, n_verts, tris, n_tris);
 }
+// a mesh of several objects (.cmf files): part_tris[k] triangles each, in input order (what rlgpu_env_load_cmf_dir hands to the same builder)
+void port_set_mesh_parts(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const int32_t* part_tris, int n_parts) {
+    std::vector<int> parts(part_tris, part_tris + n_parts);
+    g_mesh = build_host_mesh(verts_uu, n_verts, tris, n_tris, &parts);
+}
 int port_procedural_mesh(float* verts_out, int cap_verts, int32_t* tris_out, int cap_tris, int* n_verts, int* n_tris) {
     std::vector<float> v; std::vector<int32_t> t;
     make_procedural_soccar(v, t);

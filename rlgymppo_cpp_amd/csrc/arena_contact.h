@@ -30,7 +30,8 @@ struct Contact {      // 44 B (LDS-resident on the device: 24..56 of them per en
                       // is body0 follows the reference's algorithm nesting: {ball, car} vs static -> a = the dynamic body;
                       // car vs ball -> a = car, b = ball (btCompoundCollisionAlgorithm swapped + btConvexConvexAlgorithm(box, sphere));
                       // car i vs car j, i < j -> a = car j, b = car i (two nested compound algorithms, the inner one swapped)
-    int8_t sid;       // static body when b == -1: 0 = the triangle mesh, 1..4 = floor, ceiling, -x wall, +x wall (creation order, Arena.cpp:1036-1101)
+    int8_t sid;       // static body when b == -1: 0 = the (first) triangle mesh object the body touches, 1..4 = floor, ceiling, -x wall, +x wall
+                      // (creation order, Arena.cpp:1036-1101), SID_MESH2 = a second mesh object (one manifold per .cmf file: Arena.cpp:1028-1054)
     int8_t special;   // ball-world contact: resolved through one averaged row (Arena.cpp:265-273)
 };
 RLG_HD float contact_friction(const Contact& c) {   // m_combinedFriction after the contact-added callback (Arena.cpp:283-427) / btManifoldResult.cpp:56-78
@@ -48,17 +49,20 @@ struct ContactList {
 
 // ---- where the contacts of an env live -----------------------------------------------------------------------------------
 // Fixed regions, so the bodies of an env can write side by side (collide_body, one lane per body on the device):
-//   ball          [0, 6)                      mesh manifold (<= 4 points) first, then <= 2 plane manifolds of one point each
-//   car i         [6 + 7 i, 6 + 7 i + 6)      the same against the world
-//                 [6 + 7 i + 6]               the car's contact with the ball
-//   car pairs     [6 + 7 NC, + PAIR_POOL)     <= 4 points per touching pair (btBoxBoxDetector), pairs in (i, j) order
-constexpr int BALL_REGION = 6, CAR_REGION = 7, CAR_WORLD_MAX = 6;
+//   ball          [0, 10)                     <= 2 mesh manifolds (one per mesh object touched, <= 4 points each) first, then <= 2 plane manifolds of one point each
+//   car i         [10 + 11 i, 10 + 11 i + 10) the same against the world
+//                 [10 + 11 i + 10]            the car's contact with the ball
+//   car pairs     [10 + 11 NC, + PAIR_POOL)   <= 4 points per touching pair (btBoxBoxDetector), pairs in (i, j) order
+// (A body touching THREE mesh objects with points at once loses the third manifold: counted like a queue overflow.)
+constexpr int BALL_REGION = 10, CAR_REGION = 11, CAR_WORLD_MAX = 10, MESH_MANIFOLDS = 2, OBJ_LISTED_MAX = 4;
+constexpr int8_t SID_MESH2 = 5;
 template <int NC> struct ContactLayout {
     static constexpr int PAIR_POOL = NC == 2 ? 4 : 8;
     static constexpr int PAIR_BASE = BALL_REGION + CAR_REGION * NC;
     static constexpr int MAXC = PAIR_BASE + PAIR_POOL;
-    // manifolds of one tick at most: every dynamic body against mesh + 4 planes, every car against the ball, every car pair
-    static constexpr int MAXM = 5 * (NC + 1) + NC + NC * (NC - 1) / 2;
+    // manifolds of one tick at most: every dynamic body against <= OBJ_LISTED_MAX mesh objects (with or without points) + 4 planes, every
+    // car against the ball, every car pair
+    static constexpr int MAXM = (OBJ_LISTED_MAX + MESH_MANIFOLDS + 4) * (NC + 1) + NC + NC * (NC - 1) / 2;
 };
 RLG_HD int body_region(int body) { return body == 0 ? 0 : BALL_REGION + CAR_REGION * (body - 1); }
 RLG_HD int car_ball_slot(int ci) { return BALL_REGION + CAR_REGION * ci + CAR_WORLD_MAX; }
@@ -165,6 +169,7 @@ RLG_HD void car_proxy_bracket(const Car& c, V3& in_lo, V3& in_hi, V3& out_lo, V3
 constexpr float BP_CELL = 370.f * UU2BT;
 constexpr int BP_CELLS_X = 25, BP_CELLS_Y = 33, BP_CELLS_Z = 7;   // ceil((maxPos - minPos) / cell), (-4500,-6000,0)..(4500,6000,2500) uu
 constexpr int BP_WORDS = (BP_CELLS_X * BP_CELLS_Y * BP_CELLS_Z + 31) / 32;
+constexpr int BP_MAX_OBJECTS = 32;   // mesh objects (.cmf files) a cell's listing mask tells apart (the game's soccar set has 16)
 RLG_HD void bp_cell_of(V3 lo, int& i, int& j, int& k) {
     const V3 mn = v3(-4500.f * UU2BT, -6000.f * UU2BT, 0.f * UU2BT);
     const float inv = 1.f / BP_CELL;          // btVector3::operator/(scalar) multiplies by the reciprocal

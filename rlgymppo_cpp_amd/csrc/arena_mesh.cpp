@@ -170,7 +170,7 @@ Key qkey(float x, float y, float z) {
 }
 }  // namespace
 
-HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris) {
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris, bool verts_in_bt) {
     HostMesh m;
     m.tris.resize(n_tris);
     for (int i = 0; i < n_tris; i++) {
@@ -179,9 +179,9 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         for (int k = 0; k < 3; k++) {
             int vi = tris[i * 3 + k];
             if (vi < 0 || vi >= n_verts) vi = 0;
-            for (int a = 0; a < 3; a++) p[k * 3 + a] = verts_uu[vi * 3 + a] * UU2BT;
+            for (int a = 0; a < 3; a++) p[k * 3 + a] = verts_in_bt ? verts_uu[vi * 3 + a] : verts_uu[vi * 3 + a] * UU2BT;   // (.cmf files hold Bullet units: kept to the bit)
         }
-        t.edge_flags = 0; t._pad0 = 0; t._pad1 = 0; t._pad2 = 0;
+        t.edge_flags = 0; t.obj = 0; t._pad1 = 0; t._pad2 = 0;
         t.edge_angle[0] = t.edge_angle[1] = t.edge_angle[2] = 6.283185307179586232f;   // btTriangleInfo(): SIMD_2_PI
     }
     // The tree first: per mesh object the reference's own (see build_part), the objects joined pairwise in file order above them.  Triangles
@@ -212,6 +212,7 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
         }
         root = roots[0];
         m.tris.swap(ordered);
+        for (int i = 0; i < n_tris; i++) m.tris[i].obj = (uint32_t)part_of[i];     // (a part keeps its index range through the reordering)
         m.source_tri.assign(src_of.begin(), src_of.end());
         fit_bounds(m.tris, bn, root);
     }
@@ -304,40 +305,52 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             if (cut) { int bit = (z * GRID_Y + y) * GRID_X + x; m.grid[bit >> 5] |= (1u << (bit & 31)); }
         }
     }
-    // The reference's broadphase grid (btRSBroadphase.cpp:95-182; cell and bounds in arena_contact.h): a dynamic body is paired with the
-    // trimesh iff the mesh is on the static list of the body's cell, i.e. iff some cell of its 27-neighbourhood holds a triangle.
-    // Appended to the occupancy words: BP_WORDS listing bits, then the mesh's own box (6 floats) for the pair's AABB test.
+    // The reference's broadphase grid (btRSBroadphase.cpp:95-182; cell and bounds in arena_contact.h): a dynamic body is paired with a
+    // mesh OBJECT (one per .cmf file: Arena.cpp:1028-1054) iff the object is on the static list of the body's cell, i.e. iff some cell of
+    // its 27-neighbourhood holds one of the object's triangles.  Appended to the occupancy words: the number of objects, the objects' own
+    // boxes (6 floats each) for the pair's AABB test, and per broadphase cell the mask of the objects listed there.
     {
         const int NXYZ = BP_CELLS_X * BP_CELLS_Y * BP_CELLS_Z;
-        std::vector<uint8_t> has(NXYZ, 0);
         const float mnp[3] = {-4500.f * UU2BT, -6000.f * UU2BT, 0.f * UU2BT}; const int dim[3] = {BP_CELLS_X, BP_CELLS_Y, BP_CELLS_Z};
-        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-        for (int i = 0; i < n_tris; i++) {
-            float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx);
-            int c0[3], c1[3];
-            for (int a = 0; a < 3; a++) {
-                lo[a] = std::min(lo[a], mn[a]); hi[a] = std::max(hi[a], mx[a]);
-                c0[a] = std::max(0, (int)std::floor((mn[a] - mnp[a]) / BP_CELL) - 1);
-                c1[a] = std::min(dim[a] - 1, (int)std::floor((mx[a] - mnp[a]) / BP_CELL) + 1);
+        int n_obj = 0;
+        for (int i = 0; i < n_tris; i++) n_obj = std::max(n_obj, (int)m.tris[i].obj + 1);
+        if (n_obj == 0) n_obj = 1;
+        if (n_obj > BP_MAX_OBJECTS) n_obj = BP_MAX_OBJECTS;     // (objects beyond the mask's width share the last bit: only the ORDER of empty manifolds is affected)
+        // layout: [n_obj] [n_obj x 6 floats: the objects' boxes] [one word per broadphase cell: bit o = object o is listed there]
+        m.grid.resize(GRID_WORDS + 1 + (size_t)n_obj * 6 + (size_t)NXYZ, 0u);
+        m.grid[GRID_WORDS] = (uint32_t)n_obj;
+        uint32_t* boxes = &m.grid[GRID_WORDS + 1];
+        uint32_t* cellmask = &m.grid[GRID_WORDS + 1 + (size_t)n_obj * 6];
+        for (int o = 0; o < n_obj; o++) {
+            std::vector<uint8_t> has(NXYZ, 0);
+            float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+            for (int i = 0; i < n_tris; i++) {
+                if (std::min((int)m.tris[i].obj, BP_MAX_OBJECTS - 1) != o) continue;
+                float mn[3], mx[3]; tri_bounds(m.tris[i], mn, mx);
+                int c0[3], c1[3];
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = std::min(lo[a], mn[a]); hi[a] = std::max(hi[a], mx[a]);
+                    c0[a] = std::max(0, (int)std::floor((mn[a] - mnp[a]) / BP_CELL) - 1);
+                    c1[a] = std::min(dim[a] - 1, (int)std::floor((mx[a] - mnp[a]) / BP_CELL) + 1);
+                }
+                for (int x = c0[0]; x <= c1[0]; x++) for (int y = c0[1]; y <= c1[1]; y++) for (int z = c0[2]; z <= c1[2]; z++) {
+                    const float cmn[3] = {mnp[0] + x * BP_CELL, mnp[1] + y * BP_CELL, mnp[2] + z * BP_CELL};
+                    bool ov = true;
+                    for (int a = 0; a < 3; a++) if (mn[a] > cmn[a] + BP_CELL || mx[a] < cmn[a]) ov = false;
+                    if (ov) has[bp_cell_index(x, y, z)] = 1;
+                }
             }
-            for (int x = c0[0]; x <= c1[0]; x++) for (int y = c0[1]; y <= c1[1]; y++) for (int z = c0[2]; z <= c1[2]; z++) {
-                const float cmn[3] = {mnp[0] + x * BP_CELL, mnp[1] + y * BP_CELL, mnp[2] + z * BP_CELL};
-                bool ov = true;
-                for (int a = 0; a < 3; a++) if (mn[a] > cmn[a] + BP_CELL || mx[a] < cmn[a]) ov = false;
-                if (ov) has[bp_cell_index(x, y, z)] = 1;
+            for (int x = 0; x < dim[0]; x++) for (int y = 0; y < dim[1]; y++) for (int z = 0; z < dim[2]; z++) {
+                bool listed = false;
+                for (int dx = -1; dx <= 1 && !listed; dx++) for (int dy = -1; dy <= 1 && !listed; dy++) for (int dz = -1; dz <= 1 && !listed; dz++) {
+                    int xx = x + dx, yy = y + dy, zz = z + dz;
+                    if (xx < 0 || yy < 0 || zz < 0 || xx >= dim[0] || yy >= dim[1] || zz >= dim[2]) continue;
+                    listed = has[bp_cell_index(xx, yy, zz)] != 0;
+                }
+                if (listed) cellmask[bp_cell_index(x, y, z)] |= 1u << o;
             }
+            for (int a = 0; a < 3; a++) { memcpy(&boxes[o * 6 + a], &lo[a], 4); memcpy(&boxes[o * 6 + 3 + a], &hi[a], 4); }
         }
-        m.grid.resize(GRID_WORDS + BP_WORDS + 6, 0u);
-        for (int x = 0; x < dim[0]; x++) for (int y = 0; y < dim[1]; y++) for (int z = 0; z < dim[2]; z++) {
-            bool listed = false;
-            for (int dx = -1; dx <= 1 && !listed; dx++) for (int dy = -1; dy <= 1 && !listed; dy++) for (int dz = -1; dz <= 1 && !listed; dz++) {
-                int xx = x + dx, yy = y + dy, zz = z + dz;
-                if (xx < 0 || yy < 0 || zz < 0 || xx >= dim[0] || yy >= dim[1] || zz >= dim[2]) continue;
-                listed = has[bp_cell_index(xx, yy, zz)] != 0;
-            }
-            if (listed) { int bit = bp_cell_index(x, y, z); m.grid[GRID_WORDS + (bit >> 5)] |= (1u << (bit & 31)); }
-        }
-        for (int a = 0; a < 3; a++) { memcpy(&m.grid[GRID_WORDS + BP_WORDS + a], &lo[a], 4); memcpy(&m.grid[GRID_WORDS + BP_WORDS + 3 + a], &hi[a], 4); }
     }
     if (n_tris == 0) return m;
     // breadth-first renumbering with sibling pairs adjacent
@@ -471,7 +484,7 @@ void make_procedural_soccar_ex(std::vector<float>& verts, std::vector<int32_t>& 
     subdivide_long_edges(verts, tris, max_edge_uu);
 }
 
-bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts, std::vector<int32_t>& tris) {
+bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts, std::vector<int32_t>& tris, bool keep_bt) {
     if (size < 8) return false;
     int32_t nt, nv;
     memcpy(&nt, data, 4); memcpy(&nv, data + 4, 4);
@@ -479,7 +492,7 @@ bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts, std
     int base = (int)(verts.size() / 3);
     const uint8_t* p = data + 8;
     for (int i = 0; i < nt * 3; i++) { int32_t v; memcpy(&v, p, 4); p += 4; tris.push_back(base + v); }
-    for (int i = 0; i < nv * 3; i++) { float v; memcpy(&v, p, 4); p += 4; verts.push_back(v * BT2UU); }
+    for (int i = 0; i < nv * 3; i++) { float v; memcpy(&v, p, 4); p += 4; verts.push_back(keep_bt ? v : v * BT2UU); }
     return true;
 }
 

@@ -22,7 +22,8 @@ struct HostMesh {
 };
 
 // verts in uu, tris index triplets; part_tris: triangles per mesh object (.cmf file) in input order, or null = one object
-HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris = nullptr);
+// (verts_in_bt: the vertices are already in Bullet units, as .cmf files hold them -- no uu round trip, the triangles are the reference's to the bit)
+HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* part_tris = nullptr, bool verts_in_bt = false);
 
 // the procedural soccar arena (uu): back walls with goal mouths, goal boxes, 45-degree corner walls and
 // quarter-cylinder floor fillets.  Geometry facts from RLConst.h:14-16,109, Arena.cpp:846-849, CommonValues.h:9-13.
@@ -32,6 +33,6 @@ void make_procedural_soccar(std::vector<float>& verts_uu, std::vector<int32_t>& 
 void make_procedural_soccar_ex(std::vector<float>& verts_uu, std::vector<int32_t>& tris, int fillet_segments, float max_edge_uu);
 
 // parse one .cmf blob (i32 nTris, i32 nVerts, tris, verts in BT units) and append to verts(uu)/tris
-bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts_uu, std::vector<int32_t>& tris);
+bool append_cmf(const uint8_t* data, size_t size, std::vector<float>& verts_uu, std::vector<int32_t>& tris, bool keep_bt = false);
 
 }  // namespace rlg

@@ -179,7 +179,7 @@ struct NarrowInline {
         ball_query_aabb(bp, lo, hi);
         mesh_query(mesh, lo, hi, [&](int ti) {
             Cand c;
-            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[ti], c.pb, c.n, c.dist); emit(c); }
+            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[ti], c.pb, c.n, c.dist); emit(c, (int)mesh.tris[ti].obj); }
         });
     }
     template <int NC, class F>
@@ -189,7 +189,7 @@ struct NarrowInline {
         car_query_aabb(car, bc, lo, hi);
         mesh_query(mesh, lo, hi, [&](int ti) {
             Cand c;
-            if (hitbox_triangle(bc, car.b.rot, mesh.tris[ti], c)) emit(c);
+            if (hitbox_triangle(bc, car.b.rot, mesh.tris[ti], c)) emit(c, (int)mesh.tris[ti].obj);
         });
     }
     template <int NC>
@@ -205,19 +205,19 @@ struct NarrowQueued {
     const CollideQueue<NCQ>& Q;
     RLG_HD int count() const { return Q.n_items < ITEM_CAP ? Q.n_items : ITEM_CAP; }
     template <int NC, class F>
-    RLG_HD void ball_mesh(const Arena<NC>&, MeshView, F&& emit) {
+    RLG_HD void ball_mesh(const Arena<NC>&, MeshView mesh, F&& emit) {
         for (int k = 0; k < count(); k++) {
             const CollideItem& it = Q.items[k];
             if (it.type != 0) continue;
-            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q]);
+            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q], (int)mesh.tris[it.ref].obj);
         }
     }
     template <int NC, class F>
-    RLG_HD void car_mesh(const Arena<NC>&, MeshView, int ci, F&& emit) {
+    RLG_HD void car_mesh(const Arena<NC>&, MeshView mesh, int ci, F&& emit) {
         for (int k = 0; k < count(); k++) {
             const CollideItem& it = Q.items[k];
             if (it.type != 1 || it.a != ci) continue;
-            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q]);
+            for (int q = 0; q < it.n; q++) emit(Q.pool[it.off + q], (int)mesh.tris[it.ref].obj);
         }
     }
     template <int NC>
@@ -294,12 +294,27 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
 //   collide_merge  per env    the car-car pairs, the contact-added callbacks that touch other bodies, and the ORDER in which
 //                             the solver visits the contacts (W.cidx)
 template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int body, bool ball_asleep, NW nw) {
+RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
     const float r = K::BALL_RADIUS * UU2BT;
     const V3 bp = A.ball.b.pos;
     Contact* out = &L.c[body_region(body)];
     int n = 0;
+    // The mesh points arrive triangle by triangle in the reference's visiting order = object by object (arena_mesh.cpp).  One manifold per
+    // object (Arena.cpp:1028-1054: one btBvhTriangleMeshShape + body per .cmf file): a new object opens the next window of <= 4 points.
+    int m_start = 0, m_cnt = 0, m_obj = -1, n_man = 0;
+    body_obj[body][0] = -1; body_obj[body][1] = -1;
+    auto mesh_point = [&](const Body& b, const Cand& k, int obj, float breaking) -> bool {
+        if (obj != m_obj) {
+            if (m_cnt > 0) { n_man++; m_start += m_cnt; m_cnt = 0; }   // the manifold filled so far is complete (one that kept no point is reused)
+            m_obj = obj;
+        }
+        if (n_man >= MESH_MANIFOLDS) { RLG_DBG_COUNT(4); return false; }   // a third mesh object with points at once: dropped (counted with the pool overflows)
+        if (manifold_add_static(out + m_start, m_cnt, 4, b, k.n, k.pb, k.dist, breaking) < 0) return false;
+        body_obj[body][n_man] = (int8_t)obj;
+        n = m_start + m_cnt;
+        return true;
+    };
     if (body == 0) {
         // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
         // btDiscreteDynamicsWorld::addRigidBody) are both inactive, so the dispatcher skips the pair
@@ -307,8 +322,8 @@ RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>
         if (!ball_asleep) {
             // ball vs mesh: one manifold for the whole mesh body, a point per triangle in visiting order (btConvexConcaveCollisionAlgorithm.cpp:
             // 76-160 -> btSphereTriangleCollisionAlgorithm on the shared manifold), reduced to 4 by manifold_replace_index
-            nw.ball_mesh(A, mesh, [&](const Cand& k) { manifold_add_static(out, n, 4, A.ball.b, k.n, k.pb, k.dist, CBT_BALL); });
-            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], A.ball.b, v3(0, 0, 0)); out[k].a = 0; out[k].b = -1; out[k].sid = 0; out[k].special = 1; }
+            nw.ball_mesh(A, mesh, [&](const Cand& k, int obj) { mesh_point(A.ball.b, k, obj, CBT_BALL); });
+            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], A.ball.b, v3(0, 0, 0)); out[k].a = 0; out[k].b = -1; out[k].sid = (n_man > 0 && k >= m_start) ? SID_MESH2 : 0; out[k].special = 1; }
             // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121): the sphere's support vertex towards the plane
             for (int i = 0; i < 4; i++) {
                 V3 pn, po; world_plane_body(i, pn, po);
@@ -335,12 +350,12 @@ RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>
             V3 bc = car.b.pos + car.b.rot * hitbox_off();
             // pair order of the reference's broadphase (btRSBroadphase.cpp:393-469): the statics of the car's cell in creation order = mesh
             // bodies, then floor, ceiling, -x wall, +x wall (Arena.cpp:1036-1101); the contact-added callbacks fire in that order
-            nw.car_mesh(A, mesh, ci, [&](const Cand& k) {
-                if (manifold_add_static(out, n, 4, car.b, k.n, k.pb, k.dist, CBT_CAR) >= 0) {
+            nw.car_mesh(A, mesh, ci, [&](const Cand& k, int obj) {
+                if (mesh_point(car.b, k, obj, CBT_CAR)) {
                     car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
                 }
             });
-            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], car.b, v3(0, 0, 0)); out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].sid = 0; out[k].special = 0; }
+            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], car.b, v3(0, 0, 0)); out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].sid = (n_man > 0 && k >= m_start) ? SID_MESH2 : 0; out[k].special = 0; }
             // planes: ONE contact per plane and tick, the hitbox's support vertex towards the plane (btConvexPlaneCollisionAlgorithm.cpp:
             // 92-121; the perturbation passes are off: m_minimumPointsPerturbationThreshold = 0, btConvexPlaneCollisionAlgorithm.h:62-63)
             for (int i = 0; i < 4; i++) {
@@ -536,6 +551,7 @@ struct TickWork {
     int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
     int8_t nrow[MAXS], frow[MAXS];   // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)
     int8_t body_n[8];                // world contacts in each body's region of L (collide_body)
+    int8_t body_obj[8][MESH_MANIFOLDS];   // the mesh object of the body's first / second mesh manifold with points, -1 = none
     int8_t ball_hit[NC];             // car i touches the ball: its contact sits in car_ball_slot(i)
     int8_t man_key[MAXM], man_val[MAXM], man_first[MAXM], man_cnt[MAXM];   // this tick's manifolds (collide_merge)
     uint16_t man_stack[MAXM];
@@ -552,11 +568,17 @@ RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     constexpr int NB = NC + 1;
-    V3 mlo = v3(-1e30f, -1e30f, -1e30f), mhi = v3(1e30f, 1e30f, 1e30f);
-    if (mesh.bp) {
-        const float* mb = reinterpret_cast<const float*>(mesh.bp + BP_WORDS);
-        mlo = v3(mb[0], mb[1], mb[2]); mhi = v3(mb[3], mb[4], mb[5]);
-    }
+    // the mesh objects (one per .cmf file): each has its own proxy -- a box and the broadphase cells it is listed in (arena_mesh.cpp)
+    const int n_obj = mesh.n_tris > 0 ? (mesh.bp ? (int)mesh.bp[0] : 1) : 0;
+    auto obj_box = [&](int o, V3& lo, V3& hi) {
+        if (!mesh.bp) { lo = v3(-1e30f, -1e30f, -1e30f); hi = v3(1e30f, 1e30f, 1e30f); return; }
+        const float* mb = reinterpret_cast<const float*>(mesh.bp + 1 + (size_t)o * 6);
+        lo = v3(mb[0], mb[1], mb[2]); hi = v3(mb[3], mb[4], mb[5]);
+    };
+    auto cell_objects = [&](int ci, int cj, int ck) -> uint32_t {     // the mesh objects on the static list of a broadphase cell
+        if (!mesh.bp) return n_obj > 0 ? 1u : 0u;
+        return mesh.bp[1 + (size_t)n_obj * 6 + bp_cell_index(ci, cj, ck)];
+    };
     // proxy boxes and cells of the dynamic bodies.  A car's exact box needs the predicted rotation (sin / cos / sqrt); the bracket
     // [inner, outer] around it decides every question below the same way in all but borderline poses, and only those pay for it.
     V3 plo[NB], phi[NB]; int cx[NB], cy[NB], cz[NB]; bool live[NB];
@@ -568,7 +590,10 @@ RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
         car_proxy_bracket(A.cars[i], il, ih, ol, oh);
         int a0, a1, a2, b0, b1, b2;
         bp_cell_of(il, a0, a1, a2); bp_cell_of(ol, b0, b1, b2);
-        bool same = a0 == b0 && a1 == b1 && a2 == b2 && (aabb_touch(il, ih, mlo, mhi) == aabb_touch(ol, oh, mlo, mhi));
+        bool same = a0 == b0 && a1 == b1 && a2 == b2;
+        for (uint32_t om = same ? cell_objects(a0, a1, a2) : 0u; om && same; om &= om - 1u) {
+            V3 mlo, mhi; obj_box(__builtin_ctz(om), mlo, mhi); same = aabb_touch(il, ih, mlo, mhi) == aabb_touch(ol, oh, mlo, mhi);
+        }
         for (int s = 0; s < 4 && same; s++) { V3 slo, shi; world_plane_aabb(s, slo, shi); same = aabb_touch(il, ih, slo, shi) == aabb_touch(ol, oh, slo, shi); }
         if (same) {   // against the other dynamic bodies: their own outer / inner boxes (the ball's box is exact)
             V3 bl, bh; ball_proxy_aabb(A.ball, bl, bh);
@@ -594,22 +619,35 @@ RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
         if (!live[p]) continue;
         // statics of the cell, in creation order; a sleeping ball makes no manifold with them (needsCollision)
         if (!(p == 0 && W.ball_asleep)) {
-            bool listed = mesh.n_tris > 0;
-            if (listed && mesh.bp) { const int bit = bp_cell_index(cx[p], cy[p], cz[p]); listed = (mesh.bp[bit >> 5] >> (bit & 31)) & 1u; }
-            if (listed) listed = aabb_touch(plo[p], phi[p], mlo, mhi);
             V3 xlo = plo[p], xhi = phi[p];     // a car's child algorithm also needs the hitbox's own box to reach the other shape's (btCompoundCollisionAlgorithm.cpp:333-358)
             if (p > 0) hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, xlo, xhi);
-            if (listed && p > 0) listed = aabb_touch(xlo, xhi, mlo, mhi);
             const int base = body_region(p), nw_ = W.body_n[p];
-            int k = 0, nmesh = 0;
-            while (k < nw_ && L.c[base + k].sid == 0) { k++; nmesh++; }
-            if (listed) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)base; mcnt[nm] = (int8_t)nmesh; nm++; }
+            int k = 0, mi = 0, n_listed = 0;
+            // the mesh objects listed in the body's cell, in creation (= file) order, each a manifold of its own, with or without points; the
+            // (<= 2) manifolds that DO hold points are merged in at their objects' places
+            uint32_t om = cell_objects(cx[p], cy[p], cz[p]);
+            for (int q = 0; q < MESH_MANIFOLDS; q++) if (W.body_obj[p][q] >= 0) om |= 1u << (W.body_obj[p][q] < BP_MAX_OBJECTS ? W.body_obj[p][q] : BP_MAX_OBJECTS - 1);
+            for (; om; om &= om - 1u) {
+                const int o = __builtin_ctz(om);
+                V3 mlo, mhi; obj_box(o, mlo, mhi);
+                bool listed = aabb_touch(plo[p], phi[p], mlo, mhi);
+                if (listed && p > 0) listed = aabb_touch(xlo, xhi, mlo, mhi);
+                int cnt = 0; const int first = base + k;
+                if (mi < MESH_MANIFOLDS && W.body_obj[p][mi] == o) {
+                    const int8_t want = mi == 0 ? (int8_t)0 : SID_MESH2;
+                    while (k < nw_ && L.c[base + k].sid == want) { k++; cnt++; }
+                    mi++;
+                }
+                if (!(listed || cnt > 0)) continue;
+                if (cnt == 0 && n_listed >= OBJ_LISTED_MAX) continue;     // (more empty manifolds than the list holds: only their place in the sort is lost)
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++; n_listed++; }
+            }
             for (int s = 1; s <= 4; s++) {
                 int cnt = 0, first = base + k;
                 if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
                 V3 slo, shi; world_plane_aabb(s - 1, slo, shi);
                 if (!aabb_touch(plo[p], phi[p], slo, shi) || !aabb_touch(xlo, xhi, slo, shi)) continue;
-                mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++; }
             }
         }
         // dynamic partners filed in the same cell neighbourhood with overlapping proxy boxes (pairs are made by the lower body)
@@ -657,14 +695,14 @@ RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
     // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
     // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
     int n = 0, ball_man = 0, max_man = 0;
-    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; ball_man += (L.c[k].sid != 0 || k == 0); }
+    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; ball_man += (k == 0 || L.c[k].sid != L.c[k - 1].sid); }
     int car_man[NC];
     // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
     for (int ci = 0; ci < NC; ci++) {
         const int base = body_region(1 + ci);
         int cm = 0;
         if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); W.cidx[n++] = (int8_t)car_ball_slot(ci); cm++; ball_man++; }
-        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); cm += (L.c[base + k].sid != 0 || k == 0); }
+        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); cm += (k == 0 || L.c[base + k].sid != L.c[base + k - 1].sid); }
         car_man[ci] = cm;
     }
     // car-car pairs: body0 of the manifold = the higher car (arena_contact.h); the gate is conservative, the exact box test follows
@@ -792,8 +830,8 @@ template <int NC>
 RLG_HD_NOINLINE void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
-    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
-    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, body, W.ball_asleep, NarrowInline());
+    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
+    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
 }
 
 template <int NC>

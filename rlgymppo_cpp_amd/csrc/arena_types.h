@@ -217,7 +217,9 @@ struct alignas(16) MeshTri {  // 64 B, BT units
     float edge_angle[3];
     uint32_t edge_flags;  // ... and TRI_INFO_V0V1_CONVEX = 1, V1V2_CONVEX = 2, V2V0_CONVEX = 4, V0V1_SWAP_NORMALB = 8, V1V2_SWAP = 16, V2V0_SWAP = 32;
                           // bit 31: the triangle has an info record at all (some edge is shared)
-    uint32_t _pad0, _pad1, _pad2;
+    uint32_t obj;         // the mesh OBJECT (.cmf file) the triangle belongs to: the reference makes one collision object, and with it one
+                          // contact manifold per dynamic body, per file (Arena.cpp:1028-1054)
+    uint32_t _pad1, _pad2;
 };
 // coarse occupancy grid over the arena volume: bit set <=> some mesh triangle overlaps the 256 uu cell.  Most queries
 // (mid-field wheel rays, ball / hitbox AABBs) touch only empty cells and skip the BVH walk altogether.
@@ -236,8 +238,8 @@ struct MeshView {
     const MeshTri* tris;       // global
     const BvhNode* nodes_fast; // LDS-staged copy of the first n_fast nodes (device) or nullptr
     const uint32_t* grid;      // GRID_WORDS occupancy words (LDS on the device), or nullptr = always traverse
-    const uint32_t* bp;        // global: the reference broadphase's trimesh listing bits (BP_WORDS) + the mesh's own box (6 floats), see
-                               // arena_mesh.cpp / arena_contact.h; nullptr = the mesh is listed everywhere
+    const uint32_t* bp;        // global: the number of mesh objects, their boxes (6 floats each), then per cell of the reference's broadphase the
+                               // mask of the objects listed there, see arena_mesh.cpp / arena_contact.h; nullptr = one object, listed everywhere
     int n_nodes, n_tris, n_fast;
 };
 

@@ -143,7 +143,10 @@ struct CollideItem {
 constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 40;
 constexpr int LEAF_SLOTS = 4;              // BVH leaves hold <= 4 triangles (arena_mesh.cpp); the device reserves a full block per leaf
 constexpr uint32_t CAND_HOLE = 0xFFFFFFFFu;  // unused slot of such a block
-constexpr int FRONTIER_CAP = 128;       // BVH nodes per level of the breadth-first walk (all bodies of an env together on the device)
+#ifndef RLG_FRONTIER_CAP
+#define RLG_FRONTIER_CAP 64   /* (128 until the per-file manifolds needed its LDS: the tessellated arena -- 10 k triangles -- never filled 64) */
+#endif
+constexpr int FRONTIER_CAP = RLG_FRONTIER_CAP;       // BVH nodes per level of the breadth-first walk (all bodies of an env together on the device)
 #ifndef RLG_BODY_CAND
 #define RLG_BODY_CAND 128   /* (96 until the tessellated arena -- 10 k triangles -- overflowed a car's region 5 times per 1000 env-ticks) */
 #endif

@@ -125,7 +125,7 @@ constexpr int WAVE = 64;
 #define RLG_LDS_BUDGET (40 * 1024)
 #endif
 #ifndef RLG_LDS_NODES
-#define RLG_LDS_NODES 52    /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B, 136 before the candidate / item caps grew for fine meshes: 128 slots per body, 48 items) */
+#define RLG_LDS_NODES 36    /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B, 136 before the candidate / item caps grew for fine meshes: 128 slots per body, 48 items) */
 #endif
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1
@@ -1045,7 +1045,7 @@ int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * (e->d.cfg.one_
 int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }
 
-static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts);
+static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts, bool verts_in_bt = false);
 int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris) { return env_set_mesh_parts(e, verts, n_verts, tris, n_tris, nullptr); }
 int rlgpu_mesh_visit_order(const float* verts, int n_verts, const int32_t* tris, int n_tris, int32_t* order_out) {
     if (!verts || !tris || !order_out || n_tris < 0) return RLGPU_ERR_ARG;
@@ -1053,9 +1053,9 @@ int rlgpu_mesh_visit_order(const float* verts, int n_verts, const int32_t* tris,
     for (int i = 0; i < n_tris; i++) order_out[i] = m.source_tri[i];
     return RLGPU_OK;
 }
-static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts) {
+static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts, bool verts_in_bt) {
     HIPCHK(e, hipSetDevice(e->device));
-    HostMesh m = build_host_mesh(verts, n_verts, tris, n_tris, parts);
+    HostMesh m = build_host_mesh(verts, n_verts, tris, n_tris, parts, verts_in_bt);
     if (e->d_nodes) { (void)hipFree(e->d_nodes); e->d_nodes = nullptr; }
     if (e->d_tris) { (void)hipFree(e->d_tris); e->d_tris = nullptr; }
     e->d.n_nodes = (int)m.nodes.size(); e->d.n_tris = (int)m.tris.size();
@@ -1092,10 +1092,10 @@ int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* dir) {
         std::ifstream in(f, std::ios::binary);
         std::vector<uint8_t> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
         const size_t before = t.size() / 3;
-        if (!append_cmf(buf.data(), buf.size(), v, t)) { e->err = "bad cmf file " + f; return RLGPU_ERR_ARG; }
+        if (!append_cmf(buf.data(), buf.size(), v, t, true)) { e->err = "bad cmf file " + f; return RLGPU_ERR_ARG; }   // vertices stay in Bullet units, bit for bit
         parts.push_back((int)(t.size() / 3 - before));
     }
-    return env_set_mesh_parts(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3, &parts);
+    return env_set_mesh_parts(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3, &parts, true);
 }
 
 #define DISPATCH_NC(e, KERNEL, grid, block, ...)                                                             \

@@ -372,6 +372,40 @@ def test_hip_state_setters_against_reference_samples(sg, team):
         env.close()
 
 
+def test_hip_mesh_of_two_files_vs_reference_golden(tmp_path):
+    """The HIP path with a mesh loaded from TWO .cmf files (rlgpu_env_load_cmf_dir keeps one collision object per file, as the reference does:
+    Arena.cpp:1028-1054) against the reference's recording on the same two files (tests/golden/seam_golden.npz): all 115 one-tick pairs
+    EQUAL, the five tapes bit-identical (simlib.SEAM_EXACT_UNTIL), through the seam in the panel above the goal and in the goal roof."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import write_cmf_parts, state_vec, SEAM_EXACT_UNTIL
+    sg = np.load(os.path.join(GOLD, "seam_golden.npz"))
+    root = write_cmf_parts(sg["mesh_verts"], sg["mesh_tris"], sg["mesh_parts"], str(tmp_path))
+    mesh_dir = os.path.join(root, "soccar")
+    B, A = sg["pairs/before"], sg["pairs/after"]
+    env = BatchedEnv(len(B), 1, mesh=mesh_dir)
+    env.upload_states([ArenaState.from_buffer_copy(b.tobytes()) for b in B])
+    env.physics_ticks(1)
+    got = env.download_states()
+    bad = [i for i in range(len(B)) if not np.array_equal(state_vec(got[i]), state_vec(ArenaState.from_buffer_copy(A[i].tobytes())))]
+    assert not bad, f"one-tick pairs {bad[:8]} of the two-file mesh are not bit-equal to the reference"
+    env.close()
+    names = [str(x) for x in sg["phys_names"]]; every = int(sg["phys_every"])
+    env = BatchedEnv(len(names), 1, mesh=mesh_dir)
+    env.upload_states([ArenaState.from_buffer_copy(sg[f"phys/{n}/start_raw"].tobytes()) for n in names])
+    tapes = [sg[f"phys/{n}/tape"] for n in names]; T = max(len(t) for t in tapes)
+    ctl = np.zeros((len(names), 2, 8), np.float32)
+    for t in range(T):
+        for i, tp in enumerate(tapes):
+            if t < len(tp): ctl[i] = tp[t]
+        env.set_controls(ctl); env.physics_ticks(1)
+        if (t + 1) % every == 0:
+            cur = env.download_states()
+            for i, n in enumerate(names):
+                if t + 1 <= min(SEAM_EXACT_UNTIL.get(n, len(tapes[i])), len(tapes[i])):
+                    assert np.array_equal(state_vec(cur[i]), sg[f"phys/{n}/states"][(t + 1) // every - 1]), f"{n} tick {t + 1}: HIP state is not the reference's"
+    env.close()
+
+
 def test_live_reference_rollout(ref_lib, port_lib):
     """When the prebuilt reference .so travelled with the snapshot: step the real RLGymSim_CPP Gym on the host CPU next
     to the GPU env from the same state and action tape."""

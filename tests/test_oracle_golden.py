@@ -200,6 +200,40 @@ def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
     print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 4 partial")
 
 
+def test_port_mesh_of_two_files_vs_reference_golden():
+    """One collision object -- and one contact manifold per dynamic body -- per mesh FILE (RS/Sim/Arena/Arena.cpp:1028-1054): the procedural
+    arena split into two .cmf files, recorded from the reference through its own per-file loading (tests/golden/seam_golden.npz,
+    make_seam_golden.py: a ball and a car into the panel above the goal and into the goal roof, whose two triangles lie in different files).
+    The host build with the same two objects: every one of the 115 one-tick pairs EQUAL, the tapes bit-identical (simlib.SEAM_EXACT_UNTIL);
+    with the files merged into one object three pairs differ -- asserted too, so the fixture keeps telling the two apart."""
+    import ctypes as C
+    from simlib import PortSim, SEAM_EXACT_UNTIL
+    sg = np.load(os.path.join(GOLD, "seam_golden.npz"))
+    names = [str(x) for x in sg["phys_names"]]; every = int(sg["phys_every"])
+    not_exact = {}
+    for parts in (sg["mesh_parts"], None):
+        port = PortSim(); port.set_mesh(sg["mesh_verts"], sg["mesh_tris"], parts)
+        B, A = sg["pairs/before"], sg["pairs/after"]
+        bad = 0
+        for i in range(len(B)):
+            st = ArenaState.from_buffer_copy(B[i].tobytes()); port.step(st, 1)
+            bad += not np.array_equal(state_vec(st), state_vec(ArenaState.from_buffer_copy(A[i].tobytes())))
+        not_exact[parts is None] = bad
+        if parts is None:
+            continue
+        port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        for name in names:
+            st = ArenaState.from_buffer_copy(sg[f"phys/{name}/start_raw"].tobytes())
+            tape = np.ascontiguousarray(sg[f"phys/{name}/tape"], np.float32); want = sg[f"phys/{name}/states"]
+            outs = (ArenaState * (len(tape) // every))()
+            port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+            for j in range(len(tape) // every):
+                if (j + 1) * every <= SEAM_EXACT_UNTIL.get(name, len(tape)):
+                    assert np.array_equal(state_vec(outs[j]), want[j]), f"{name} tick {(j + 1) * every}: not bit-identical to the reference"
+    assert not_exact[False] == 0, f"{not_exact[False]} one-tick pairs of the two-file mesh are not bit-equal to the reference"
+    assert not_exact[True] > 0, "the fixture no longer distinguishes per-file objects from a merged mesh"
+
+
 def test_port_one_tick_vs_reference_states():
     """1722 (state, state one tick later) pairs recorded from the reference -- every tick with a narrowphase contact and every 16th
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),
