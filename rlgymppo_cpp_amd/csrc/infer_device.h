@@ -16,6 +16,7 @@ __device__ __forceinline__ short to_bf16(float f) {   // the hardware conversion
 }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
 }  // namespace rlinfer
 
 namespace rlinfer {
@@ -109,6 +110,9 @@ struct InferNet {
     const short* W[9];               // fragment-ordered bf16 weights (k_weight_frags): 1 KB per (32-column block, 16-deep K step)
     const float* bias[9];
     int K[9], N[9], Npad[9];         // layer i: K = padded inputs, N = outputs, Npad = outputs padded to 32
+    // exact-parity mode (use_bf16 = 0): the fp32 master weights as nn.Linear keeps them, W[out][in] row-major, true widths
+    int fp32;                        // 1: wave_infer_f32 (v_mfma_f32_32x32x2_f32 on fp32 operands), 0: wave_infer (bf16 operands)
+    const float* Wf[9]; int Kf[9];   // layer i: weights, true number of inputs
 };
 constexpr int LOGIT_LD = 132;        // fp32 logits row in LDS (n_actions <= 128)
 constexpr int WAVE_ROWS = 8;         // rows one wavefront infers at most: they sit in the first 8 rows of a 32-row MFMA tile
@@ -247,4 +251,75 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
     const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
     policy_head_rows<R>(zc, rows, lane, head, picked);
 }
+// ---- the same forward pass in fp32: the exact-parity mode of the fused collection ------------------------------------------------------
+// rlgpu_policy_act with use_bf16 = 0 runs every layer through k_gemm<false> (rlgpu_learn.hip): v_mfma_f32_32x32x2_f32 over k = 0, 2, 4, ...
+// (lane l holds A[row l & 31][k + (l >> 5)] and B[k + (l >> 5)][col l & 31]), operands zero-padded to a multiple of 32 inputs, bias added
+// and ReLU applied to the fp32 accumulator.  A row's value depends on nothing but its own operands and that order, so the same instruction
+// sequence on one wavefront gives the batched call's bits.  Activations stay fp32 in LDS; a buffer is two HALVES (the step kernels lend
+// the TickWork areas of different envs): rows [0, RH) in half0, [RH, R) in half1.
+struct F32Buf { float* half0; float* half1; };
+template <int R>
+__device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) { constexpr int RH = (R + 1) / 2; return r < RH ? b.half0 + r * ld : b.half1 + (r - RH) * ld; }
+__host__ __device__ constexpr int f32_half_bytes(int rows, int ld) { return ((rows + 1) / 2) * (ld > LOGIT_LD ? ld : LOGIT_LD) * 4; }
+
+template <int R>
+__device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, F32Buf in, F32Buf out, int lane, int (&picked)[R]) {
+    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 8 rows");
+    constexpr int CH = 16;                               // MFMA steps (2 inputs each) whose B operands are in flight together
+    const int ld = net.ld;
+    for (int r = 0; r < R; r++) {
+        const int rr = r < n_rows ? r : n_rows - 1;
+        float* dst = f32_row<R>(in, r, ld);
+        for (int c = lane; c < net.K[0]; c += 64) dst[c] = c < net.D ? obs[(size_t)rr * net.D + c] : 0.f;
+    }
+    wave_fence();
+    const int kh = lane >> 5, cl = lane & 31;
+    for (int i = 0; i < net.n_layers; i++) {
+        const bool last = (i == net.n_layers - 1);
+        const int N = net.N[i], Kt = net.Kf[i];
+        const int steps = ((Kt + 31) / 32) * 16;         // k_gemm pads the reduction to whole 32-wide tiles (zeros: they leave the accumulator as it is)
+        const int nblk = last ? (N + 31) / 32 : net.Npad[i] / 32;
+        const float* arow = f32_row<R>(in, cl < R ? cl : 0, ld);    // tile rows >= R re-read row 0 (independent, never stored)
+        for (int cb = 0; cb < nblk; cb++) {
+            const int col = cb * 32 + cl;
+            const float* wrow = net.Wf[i] + (size_t)(col < N ? col : 0) * Kt;
+            const bool col_ok = col < N;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.f;
+            float b[CH], bn[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) { const int k = 2 * j + kh; b[j] = (col_ok && k < Kt) ? wrow[k] : 0.f; }
+            for (int s0 = 0; s0 < steps; s0 += CH) {
+#pragma unroll
+                for (int j = 0; j < CH; j++) { const int k = 2 * (s0 + CH + j) + kh; bn[j] = (col_ok && k < Kt && s0 + CH < steps) ? wrow[k] : 0.f; }   // the next chunk's weights do not depend on the activations
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    const int k = 2 * (s0 + j) + kh;
+                    const float a = arow[k];                      // (the LDS row is zero beyond the layer's inputs up to its padded width)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < CH; j++) b[j] = bn[j];
+            }
+            const float bias = col_ok ? net.bias[i][col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = r + 4 * kh;
+                if (row >= R) continue;
+                float v = acc[r] + bias;
+                if (last) { if (col < LOGIT_LD) f32_row<R>(out, row, LOGIT_LD)[col] = v; }
+                else f32_row<R>(out, row, ld)[col] = col_ok ? fmaxf(v, 0.f) : 0.f;
+            }
+        }
+        wave_fence();
+        const F32Buf t = in; in = out; out = t;
+    }
+    const float* zs[R]; int rows[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = f32_row<R>(in, rr, LOGIT_LD); rows[r] = row0 + rr; }
+    const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
+    policy_head_rows<R>(zc, rows, lane, head, picked);
+}
+
 }  // namespace rlinfer

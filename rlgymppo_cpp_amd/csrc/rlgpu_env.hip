@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
     short* const buf0 = reinterpret_cast<short*>(w0);
     short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
-    int* const act_lds = reinterpret_cast<int*>(w0 + (EPW >= 2 ? buf_bytes : 2 * buf_bytes));
+    int* const act_lds = reinterpret_cast<int*>(w0 + sizeof(TickWork<NC>) - 64);   // the last 64 bytes of env 0's area (the inference buffers end before them)
     const int row0 = env0 * NC, n_rows = n_valid * NC;
     Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);   // the step's GameState, in the env's own TickWork area (dead between ticks)
 #ifdef RLG_TICK_PROFILE
@@ -767,6 +767,20 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked, &prof_mid);
         prof_mlp += prof_mid - prof_a;
 #else
+        if (c.net.fp32) {
+            // exact-parity mode: fp32 activations, a buffer = two halves in the TickWork areas of different envs (EPW >= 4), or both in one
+            constexpr int HB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
+            unsigned char* const a0 = w0;
+            unsigned char* const a1 = EPW >= 2 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 1).W) : w0 + HB;
+            unsigned char* const a2 = EPW >= 4 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, EPW >= 4 ? 2 : 0).W) : (EPW >= 2 ? a0 + HB : w0 + 2 * HB);
+            unsigned char* const a3 = EPW >= 4 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, EPW >= 4 ? 3 : 0).W) : (EPW >= 2 ? a1 + HB : w0 + 3 * HB);
+            // (EPW >= 4: in = {env 0, env 1}, out = {env 2, env 3}; EPW = 2: in = env 0's two halves, out = env 1's; EPW = 1: four quarters of the one area)
+            rlinfer::F32Buf fin, fout;
+            if (EPW >= 4) { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a1)}; fout = {reinterpret_cast<float*>(a2), reinterpret_cast<float*>(a3)}; }
+            else if (EPW >= 2) { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a2)}; fout = {reinterpret_cast<float*>(a1), reinterpret_cast<float*>(a3)}; }
+            else { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a1)}; fout = {reinterpret_cast<float*>(a2), reinterpret_cast<float*>(a3)}; }
+            rlinfer::wave_infer_f32<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, ws.lane, picked);
+        } else
         rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked);
 #endif
         if (ws.lane == 0) {
@@ -1257,8 +1271,11 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;
     const size_t tw = e->nc == 2 ? sizeof(TickWork<2>) : (e->nc == 4 ? sizeof(TickWork<4>) : sizeof(TickWork<6>));
     const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
-    int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, max_buf, (void*)e->stream);
-    if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (bf16 mode, <= 128 actions, hidden width within the LDS scratch)"; return rc; }
+    const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one half of an activation buffer may take
+    int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
+    if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
+    if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_half_bytes(epw * e->nc, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
+    if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
     if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);

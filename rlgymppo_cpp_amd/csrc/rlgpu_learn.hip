@@ -1346,9 +1346,29 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }
 }  // extern "C"
 int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer::HeadArgs* head, int deterministic, int n_calls, int max_buf_bytes, void* stream) {
-    if (!l->cfg.use_bf16 || l->cfg.n_actions > 128 || l->pol.n_layers > 9) return RLGPU_ERR_STATE;
+    if (l->cfg.n_actions > 128 || l->pol.n_layers > 9) return RLGPU_ERR_STATE;
     int maxkp = 0;
     for (int i = 0; i < l->pol.n_layers; i++) maxkp = std::max(maxkp, l->pol.kp[i]);
+    if (!l->cfg.use_bf16) {
+        // exact-parity mode: fp32 operands (wave_infer_f32).  max_buf_bytes < 0 carries the bytes one HALF buffer may take
+        // (rlgpu_env.hip lends four of them per wavefront); the fp32 master weights are read as they are.
+        const Net& n = l->pol;
+        int maxk = 0;
+        for (int i = 0; i < n.n_layers; i++) maxk = std::max(maxk, (n.dims[i] + 31) / 32 * 32);
+        if (max_buf_bytes >= 0) return RLGPU_ERR_STATE;    // (the caller checks the half-buffer size against its row count: f32_half_bytes)
+        net->n_layers = n.n_layers; net->D = l->cfg.obs_size; net->ld = maxk + 8; net->fp32 = 1;
+        for (int i = 0; i < n.n_layers; i++) {
+            net->W[i] = nullptr; net->bias[i] = l->params + n.b_off[i];
+            net->K[i] = (n.dims[i] + 31) / 32 * 32; net->N[i] = n.dims[i + 1]; net->Npad[i] = (n.dims[i + 1] + 31) / 32 * 32;
+            net->Wf[i] = l->params + n.w_off[i]; net->Kf[i] = n.dims[i];
+        }
+        const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
+        *head = HeadArgs{l->cfg.n_actions, inv_t, deterministic, nullptr, l->cfg.seed_lo, (l->cfg.seed_hi ^ 0x5A3C0DEu) + l->sampler_stream * 0x9E3779B9u, l->call_ctr, nullptr, nullptr, nullptr};
+        l->call_ctr += (uint32_t)n_calls;
+        (void)stream;
+        return RLGPU_OK;
+    }
+    if (max_buf_bytes < 0) max_buf_bytes = 0x7fffffff;   // (the caller sized for the fp32 mode; checked again by it for bf16)
     if (rlinfer::wave_buf_bytes(maxkp + 8) > max_buf_bytes || maxkp > 256) return RLGPU_ERR_STATE;   // wave_infer keeps a layer's 16 K steps in registers
     LCHK(l, hipSetDevice(l->device));
     hipStream_t keep = l->stream;
@@ -1357,10 +1377,11 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
     l->stream = keep;
     if (rc) return rc;
     const Net& n = l->pol;
-    net->n_layers = n.n_layers; net->D = l->cfg.obs_size; net->ld = maxkp + 8;
+    net->n_layers = n.n_layers; net->D = l->cfg.obs_size; net->ld = maxkp + 8; net->fp32 = 0;
     for (int i = 0; i < n.n_layers; i++) {
         net->W[i] = l->shadows + n.wf16_off[i]; net->bias[i] = l->params + n.b_off[i];
         net->K[i] = n.kp[i]; net->N[i] = n.dims[i + 1]; net->Npad[i] = n.kp[i + 1];
+        net->Wf[i] = nullptr; net->Kf[i] = n.dims[i];
     }
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
     *head = HeadArgs{l->cfg.n_actions, inv_t, deterministic, nullptr, l->cfg.seed_lo, (l->cfg.seed_hi ^ 0x5A3C0DEu) + l->sampler_stream * 0x9E3779B9u, l->call_ctr, nullptr, nullptr, nullptr};

@@ -684,11 +684,13 @@ def test_collection_during_learn_mode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("team_size,n_envs", [(1, 70), (2, 21), (3, 9)])
-def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs):
+@pytest.mark.parametrize("team_size,n_envs,bf16", [(1, 70, True), (2, 21, True), (3, 9, True), (1, 70, False), (2, 21, False), (3, 9, False)])
+def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs, bf16):
     """rlgpu_collect (T x (inference + gym step) in one launch, every wavefront on its own envs) against T alternations of
     rlgpu_policy_act / rlgpu_env_step from the same seeds: observations, actions, rewards, dones and the final env state are
-    bit-identical, log-probs within one ulp.  Env counts that leave the last wavefront partly empty; 1v1 / 2v2 / 3v3 = 4 / 2 / 1 envs per wavefront."""
+    bit-identical, log-probs within one ulp.  Env counts that leave the last wavefront partly empty; 1v1 / 2v2 / 3v3 = 4 / 2 / 1 envs per wavefront.
+    bf16 = False: the exact-parity mode -- fp32 operands through v_mfma_f32_32x32x2_f32 inside the collection kernel (wave_infer_f32), against
+    the fp32 batched path whose sampled action indices are pinned bit-exact to the reference's DiscretePolicy (tests/test_ref_learner.py)."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from rlgymppo_cpp_amd.ppo import PPOCore
     from rlgymppo_cpp_amd import _lib
@@ -699,7 +701,7 @@ def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs):
         cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 5; cfg.seed_lo = 31
         env = BatchedEnv(n_envs, team_size, cfg=cfg)
         N, D = env.n_agents, env.obs_size
-        ppo = PPOCore(D, env.n_actions, (256, 256, 256), (64,), use_bf16=True, max_rows=max(N, 64), seed=5)
+        ppo = PPOCore(D, env.n_actions, (256, 256, 256), (64,), use_bf16=bf16, max_rows=max(N, 64), seed=5)
         obs = torch.zeros((T + 1, N, D), device=dev); acts = torch.zeros((T, N), dtype=torch.int32, device=dev)
         logp = torch.zeros((T, N), device=dev); rew = torch.zeros((T, N), device=dev); done = torch.zeros((T, N), dtype=torch.int32, device=dev)
         env.reset(True, obs[0])

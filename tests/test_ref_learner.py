@@ -257,5 +257,8 @@ def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
             gp += g0; gc += g1
         want_p, mom[0][0], mom[0][1] = R.clip_adam_step(pol, gp, mom[0][0], mom[0][1], it + 1, 3e-4)
         want_c, mom[1][0], mom[1][1] = R.clip_adam_step(cri, gc, mom[1][0], mom[1][1], it + 1, 3e-4)
-        assert np.abs(L.ppo.get_params(0) - want_p).max() < 2e-6 and np.abs(L.ppo.get_params(1) - want_c).max() < 2e-6, f"iteration {it}: parameters after the optimizer step"
+        dp, dc = np.abs(L.ppo.get_params(0) - want_p).max(), np.abs(L.ppo.get_params(1) - want_c).max()
+        # (Adam's first steps are lr * g / (|g| + 1e-8) per entry: where a gradient entry is of the order of 1e-8 .. 1e-7 the quotient moves by
+        # per cents when fp32 summation order moves the entry by 1e-9 -- 1e-5 is 3 % of one 3e-4 step, for a handful of such entries)
+        assert dp < 1e-5 and dc < 1e-5, f"iteration {it}: parameters after the optimizer step differ by {dp:.3g} (policy) / {dc:.3g} (critic); step sizes {np.abs(want_p - pol).max():.3g} / {np.abs(want_c - cri).max():.3g}"
     assert L.cumulative_model_updates == 3
