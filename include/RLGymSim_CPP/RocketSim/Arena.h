@@ -203,6 +203,7 @@ public:
     // an arena that will never get orange cars (Gym with spawnOpponents = false and teamSize 1 has to say so: nothing else tells)
     void _SetOneTeam() { _oneTeam = true; _state.num_cars = (int32_t)(2 * _cars.size()); _MarkAbsentSlots(); }
     bool _IsOneTeam() const { return _oneTeam; }
+    Car* _CarOfSlot(int slot) { for (Car* c : _cars) if (c->raw == &_state.cars[slot]) return c; return nullptr; }
     Car* GetCar(uint32_t id) { return (id >= 1 && id <= _cars.size()) ? _cars[id - 1] : nullptr; }
 
     void SetGoalScoreCallback(GoalScoreEventFn fn, void* userInfo = nullptr) { _goalScoreCallback = {fn, userInfo}; }
@@ -236,8 +237,9 @@ public:
 
     bool IsBallScored() const { return std::fabs(_state.ball.pos[1]) > RLConst::SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y + RLConst::BALL_COLLISION_RADIUS_SOCCAR; }
 
-    // Arena::Step (Arena.cpp:716-812) on a one-env device batch (created on first use; librlgymppo_amd.so).  Goal / bump callbacks are
-    // not raised from here: the gym layer's counters are kept by the device step (csrc/arena_gym.h), which is what Gym::Step drives.
+    // Arena::Step (Arena.cpp:716-812) on a one-env device batch (created on first use; librlgymppo_amd.so).  With a goal / bump callback
+    // set the arena is stepped tick by tick and the callbacks are raised from the state each tick leaves (host/Gym.hip); the gym layer
+    // does not use them (its counters are kept by the device step, csrc/arena_gym.h).
     void Step(int ticksToSimulate = 1);
 
     // the cars' `controls` members -> the state (before the arena is uploaded), and the tick counter both ways

@@ -36,6 +36,9 @@ struct GymConfig {
     int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers), team size <= maxPlayers <= 4: mates / opponents padded with zero blocks and shuffled
     int32_t one_team;          // Match(..., spawnOpponents = false): only the blue slots (even k) hold a car; see player_present()
 };
+// key of the tick's random draws (the respawn spot of a demolished car): both seed words, so that a resumed run (rlgpu_env_reseed bumps
+// seed_hi, the epoch) does not replay the draws of the run it continues; seed_hi = 0 gives the key of the first epoch
+RLG_HD uint32_t tick_seed(const GymConfig& cfg) { return cfg.seed_lo ^ 0xA511E9B3u ^ (cfg.seed_hi * 0x9E3779B9u); }
 
 // spawnOpponents = false (Gym.cpp:45-49 adds no orange cars).  The env keeps its 2 * teamSize slots -- slot parity IS the team everywhere in
 // the stepper -- and the orange ones are ABSENT: parked as demolished cars whose respawn timer never runs out (so the physics never sees
@@ -513,7 +516,7 @@ RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, Mesh
                          const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC>& W) {
     Snapshot<NC> S;
     gym_step_begin(A, G, cfg, action_table, actions);
-    const uint32_t seed = cfg.seed_lo ^ 0xA511E9B3u;
+    const uint32_t seed = tick_seed(cfg);
     TickEvents ev; ev.bump_mask = 0;
     arena_tick(A, mesh, seed, env_id, ev, W);
     const bool done = gym_step_after_first_tick(A, G, cfg, ev, action_table, env_id, reward, next_obs, obs_row_stride, S);

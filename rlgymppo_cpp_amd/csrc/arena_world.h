@@ -8,11 +8,22 @@
 //   * sphere-plane / box-plane support-vertex test (btConvexPlaneCollisionAlgorithm.cpp:92-121)
 //   * sphere-triangle (SphereTriangleDetector.cpp:139-241 with the embree closest-point routine :87-129)
 //   * contact-added callback semantics (Arena.cpp:218-427)
-// What it re-designs for a lane-per-env kernel (documented deviations):
-//   * contacts are regenerated every tick (no persistent manifold / warm start): box contacts are produced
-//     as a clipped multi-point set in ONE tick instead of Bullet's one-support-vertex-per-tick accumulation;
-//   * box-triangle and box-box use SAT + face clipping instead of GJK/EPA and ODE's dBoxBox2;
-//   * the mesh BVH is this repo's own 32-byte AABB node layout (top levels staged in LDS on the device).
+//   * hitbox vs triangle / ball through Bullet's GJK pair detector, its penetration-depth solver (second GJK + EPA) and the wheel rays'
+//     convex cast: arena_gjk.h, arena_epa.h, arena_simplex.h; car vs car through btBoxBoxDetector = ODE's dBoxBox2 (below); contact points
+//     through btAdjustInternalEdgeContacts (adjust_internal_edge) -- all restated operation by operation and pinned bit for bit against
+//     the reference's own routines (tests/golden/narrowphase_golden.npz)
+// What it re-designs for a lane-per-env kernel:
+//   * the mesh BVH is this repo's own 32-byte threaded AABB node layout over the reference's tree and triangle order (arena_mesh.cpp), with
+//     a candidate / item queue so that the lanes of a wavefront share the narrowphase of their envs (CollideQueue below);
+//   * SAT + face clipping (box_triangle, box_box) survive only as the stand-in behind RLG_EXPERIMENT_NO_EPA and for arenas too small for
+//     the penetration-depth solver.
+//
+// Licence notes for the routines restated from third-party code (both permit use and redistribution of altered versions that are marked as such):
+//   * Bullet Physics (btGjkPairDetector, btVoronoiSimplexSolver, btGjkEpa2, btSubsimplexConvexCast, btInternalEdgeUtility, btBoxBoxDetector's
+//     driver, btPersistentManifold, btSequentialImpulseConstraintSolver): Copyright (c) 2003-2009 Erwin Coumans and contributors, zlib licence.
+//   * ode_rect_quad / ode_cull_points / box_box_ode follow dBoxBox2 of the Open Dynamics Engine as shipped in Bullet's btBoxBoxDetector.cpp:
+//     Copyright (c) 2001-2003 Russell L. Smith, BSD-style licence (either the LGPL or the BSD licence of ODE, at the user's option).
+//   These files are altered restatements written for this repository, not the originals.
 #pragma once
 #include "arena_contact.h"
 #include "arena_simplex.h"

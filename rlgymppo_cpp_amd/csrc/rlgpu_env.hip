@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     const bool env_lane = ws.lane < n_valid;
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
-    const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
+    const uint32_t seed = tick_seed(d.cfg);
     const int D = obs_size<NC>(d.cfg);
     const int P = players_per_env<NC>(d.cfg);   // agent rows per env: NC, or NC / 2 in a one-team env
     // the GameState of the step (taken after tick 1) lives in the env's TickWork area, which is dead between ticks
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     const bool env_lane = ws.lane < n_valid;
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
-    const uint32_t seed = d.cfg.seed_lo ^ 0xA511E9B3u;
+    const uint32_t seed = tick_seed(d.cfg);
     const int D = obs_size<NC>(d.cfg);
     const size_t N = (size_t)c.n_agents;
     // inference scratch inside the TickWork areas (dead between ticks): two activation buffers and the picked actions
@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     if (threadIdx.x == 0) for (int i = 0; i < 32; i++) g_fine[i] = 0;
 #endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, d.cfg.seed_lo ^ 0xA511E9B3u, env0, ev); }
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, tick_seed(d.cfg), env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_FINE_PROF

@@ -49,9 +49,36 @@ void Arena::Step(int ticksToSimulate) {
     ArenaDevice* d = _device ? static_cast<ArenaDevice*>(_device) : EnsureDevice(this, NeutralConfig(8));
     _SyncToState();
     EnvCheck(d->env, rlgpu_env_upload_states(d->env, &_state, nullptr, 1), "upload_states");
-    EnvCheck(d->env, rlgpu_env_physics_ticks(d->env, ticksToSimulate), "physics_ticks");
-    EnvCheck(d->env, rlgpu_env_download_states(d->env, &_state, nullptr, 1), "download_states");
-    _SyncFromState();
+    if (!_goalScoreCallback.func && !_carBumpCallback.func) {
+        EnvCheck(d->env, rlgpu_env_physics_ticks(d->env, ticksToSimulate), "physics_ticks");
+        EnvCheck(d->env, rlgpu_env_download_states(d->env, &_state, nullptr, 1), "download_states");
+        _SyncFromState();
+        return;
+    }
+    // With a callback set the arena is read back after every tick and the events of that tick are raised from what the kernel left in
+    // the state: a bump (Arena.cpp:335-413) is the one thing that raises a car's carContact cooldown or changes whom it is against, and
+    // it was a demo when the victim went from alive to demoed in that tick; the goal callback fires on every tick that ends with the
+    // ball behind a goal line (Arena.cpp:804-808).  The cars' order is the reference's (callbacks of one tick arrive bumper by bumper).
+    for (int t = 0; t < ticksToSimulate; t++) {
+        const RlgpuArenaState before = _state;
+        EnvCheck(d->env, rlgpu_env_physics_ticks(d->env, 1), "physics_ticks");
+        EnvCheck(d->env, rlgpu_env_download_states(d->env, &_state, nullptr, 1), "download_states");
+        _SyncFromState();
+        if (_carBumpCallback.func)
+            for (int k = 0; k < _state.num_cars; k++) {
+                const RlgpuCarState &was = before.cars[k], &now = _state.cars[k];
+                if ((now.flags & RLGPU_CF_ABSENT) || now.car_contact_other_id <= 0 || !(now.car_contact_cooldown > 0)) continue;
+                const bool fresh = now.car_contact_cooldown > was.car_contact_cooldown || (now.car_contact_other_id != was.car_contact_other_id && now.car_contact_cooldown >= was.car_contact_cooldown);
+                if (!fresh) continue;
+                const int v = now.car_contact_other_id - 1;
+                Car *bumper = _CarOfSlot(k), *victim = _CarOfSlot(v);
+                if (!bumper || !victim) continue;
+                const bool isDemo = (_state.cars[v].flags & RLGPU_CF_IS_DEMOED) && !(before.cars[v].flags & RLGPU_CF_IS_DEMOED);
+                _carBumpCallback.func(this, bumper, victim, isDemo, _carBumpCallback.userInfo);
+            }
+        if (_goalScoreCallback.func && IsBallScored())
+            _goalScoreCallback.func(this, -_state.ball.pos[1] < 0 ? Team::BLUE : Team::ORANGE, _goalScoreCallback.userInfo);   // RS_TEAM_FROM_Y(-y), Car.h:131
+    }
 }
 void Arena::ReleaseDevice() { delete static_cast<ArenaDevice*>(_device); _device = nullptr; }
 }  // namespace RocketSim

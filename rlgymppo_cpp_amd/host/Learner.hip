@@ -744,6 +744,13 @@ void Learner::LoadStats(std::filesystem::path path) {
         impl->LrnCheck(rlgpu_learner_set_sampler(impl->lrn, (uint32_t)impl->rank, calls), "learner_set_sampler");
         impl->envStreamEpoch = (ee != std::string::npos ? (uint32_t)std::stod(s.substr(ee)) : 0u) + 1u;
         impl->EnvCheck(rlgpu_env_reseed(impl->env, (uint32_t)config.randomSeed + 1000u * (uint32_t)impl->rank, impl->envStreamEpoch), "reseed");
+        // the constructor reset every env with epoch 0's streams: draw the first states of the resumed run from the new epoch's
+        // (otherwise its first episodes would start from the initial states of the run it continues)
+        if (!impl->plan.hostObs) impl->EnvCheck(rlgpu_env_reset(impl->env, 1, impl->ObsAt(0)), "reset after reseed");
+        if (impl->plan.AnyHost()) {
+            std::vector<int32_t> all(impl->nEnvs); std::iota(all.begin(), all.end(), 0);
+            impl->HostResetEnvs(all, impl->ObsAt(0), true);
+        }
     }
     size_t k = at("skill_rating", false);   // Learner.cpp:229-231
     if (skillTracker && k != std::string::npos) skillTracker->curRating = skillTracker->LoadRatingSet(s[k] == '{' ? s.substr(k, s.find('}', k) - k + 1) : s.substr(k));

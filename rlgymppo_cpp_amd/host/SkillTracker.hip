@@ -1,13 +1,16 @@
 // SkillTracker.hip -- RLGPC::SkillTracker (PRIV/Util/SkillTracker.cpp:28-291) on one small device env batch.
 // Per step: the current policy and every stored version in use pick deterministic actions for all eval rows (rlgpu_policy_act),
-// the host picks per player which policy's action counts (team and teamSwap of its game), the batch steps; a goal shows up as the
-// +1 / -1 of the eval env's only reward term, EventReward{teamGoal 1, concede -1} (the reference looks at the ball's position in
-// the step result, SkillTracker.cpp:129-146; the event tracker reports the same goal, and the auto-reset of the batched env has
-// already replaced that state).
+// the host picks per player which policy's action counts (team and teamSwap of its game), the batch steps.  A goal is what the reference
+// takes for one (SkillTracker.cpp:129-146): the ball of the step's GameState -- the arena one tick into the step, which the step kernel
+// keeps as the env's snapshot (rlgpu_env_enable_snapshots) -- lies behind a goal line, and the policy playing blue scored when its y > 0.
+// Like there, a match without a GoalScoreCondition rates every step the ball stays behind the line.  Rewards play no role (the reference
+// swaps in a zero reward, :10-16,51).  A user StateSetter without a device form runs on the host for the envs whose episode ended.
 #include <hip/hip_runtime.h>
 
 #include <RLGymPPO_CPP/Util/SkillTracker.h>
 #include "../../include/rlgpu_state.h"
+#include "host_util.h"
+#include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
 
 #include <thread>
 
@@ -29,6 +32,26 @@ struct SkillTracker::Impl {
     float *obs = nullptr, *obsNext = nullptr, *rew = nullptr, *logp = nullptr; int32_t *acts = nullptr, *done = nullptr;
     std::mt19937 rng;
     std::vector<GameInst> gameInsts;
+    bool hostSetter = false; RLGSC::Arena* scratch = nullptr;   // a user state setter: run on the host facade (Match::ResetState), then uploaded
+    std::vector<RlgpuArenaState> snaps, fresh;
+    // Gym::Reset of the listed envs with the user's state setter (the kernel has already reset them with the stand-in kickoff setter)
+    void HostSetterReset(const std::vector<int32_t>& ids, float* obsRows) {
+        if (ids.empty()) return;
+        fresh.resize(ids.size());
+        EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), (int)ids.size()), "download_states");
+        for (size_t i = 0; i < ids.size(); i++) {
+            scratch->_state = fresh[i]; scratch->_SyncFromState();
+            (void)match->ResetState(scratch);
+            scratch->_SyncToState();
+            fresh[i] = scratch->_state;
+        }
+        EnvCheck(rlgpu_env_upload_states(env, fresh.data(), ids.data(), (int)ids.size()), "upload_states");
+        EnvCheck(rlgpu_env_reset_envs(env, ids.data(), (int)ids.size(), 0, obsRows), "reset_envs");
+    }
+    void ResetAll(float* obsRows) {
+        EnvCheck(rlgpu_env_reset(env, 1, obsRows), "reset");
+        if (hostSetter) { std::vector<int32_t> all(gameInsts.size()); for (size_t e = 0; e < all.size(); e++) all[e] = (int32_t)e; HostSetterReset(all, obsRows); }
+    }
     void EnvCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("SkillTracker: rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
     void LrnCheck(rlgpu_learner* l, int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("SkillTracker: rlgpu_" << what << " failed (" << rc << "): " << rlgpu_learner_last_error(l)); }
     rlgpu_learner* MakeVersion(const float* params) {
@@ -61,12 +84,15 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     EnvCreateResult ecr = config.envCreateFunc();
     if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("SkillTracker: envCreateFunc returned a null match or gym");
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
-    RlgpuGymConfig g = m.match->ToDeviceConfig(m.tickSkip);
-    // rewards play no role in evaluation (the reference swaps in a zero reward, SkillTracker.cpp:10-16,51); the one term kept is the goal detector
-    g.n_terms = 1; g.terms[0].kind = RLGPU_RW_EVENT; g.terms[0].weight = 1.f; g.terms[0].p0 = 0.f; g.zero_sum = 0;
+    if (config.kickoffStatesOnly) m.match->stateSetter = new RLGSC::KickoffState();   // SkillTracker.cpp:48-49 (the env's own setter is discarded, not freed)
+    const RLGSC::Match::DevicePlan plan = m.match->PlanDevice(m.tickSkip);
+    if (plan.hostTerminal) RG_ERR_CLOSE("SkillTracker: a terminal condition of the eval match has no device form (built-ins: NoTouchCondition, GoalScoreCondition)");
+    if (plan.hostObs) RG_ERR_CLOSE("SkillTracker: the obs builder of the eval match has no device form (built-ins: DefaultOBS, DefaultOBSPadded)");
+    if (plan.hostParser) RG_ERR_CLOSE("SkillTracker: the action parser of the eval match has no device form (built-in: DiscreteAction)");
+    m.hostSetter = plan.hostSetter;
+    RlgpuGymConfig g = plan.cfg;
+    g.n_terms = 0; g.zero_sum = 0;                                     // the zero reward of SkillTracker.cpp:10-16,51
     for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) g.event_weights[i] = 0.f;
-    g.event_weights[1] = 1.f; g.event_weights[2] = -1.f;   // teamGoal, concede (CommonRewards.h:19-40)
-    if (config.kickoffStatesOnly) g.setter_kind = RLGPU_SS_KICKOFF;
     g.seed_lo = (uint32_t)randomSeed + 7777u; g.seed_hi = 1;
     int rc = rlgpu_env_create(&m.env, 0, config.numEnvs, m.match->teamSize, &g);
     m.EnvCheck(rc, "create");
@@ -78,14 +104,16 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     SKILL_HIP(hipMalloc(&m.obs, (size_t)m.nRows * obsSize * 4)); SKILL_HIP(hipMalloc(&m.obsNext, (size_t)m.nRows * obsSize * 4));
     SKILL_HIP(hipMalloc(&m.rew, m.nRows * 4)); SKILL_HIP(hipMalloc(&m.logp, m.nRows * 4));
     SKILL_HIP(hipMalloc(&m.acts, m.nRows * 4)); SKILL_HIP(hipMalloc(&m.done, m.nRows * 4));
-    m.EnvCheck(rlgpu_env_reset(m.env, 1, m.obs), "reset");
+    m.EnvCheck(rlgpu_env_enable_snapshots(m.env, 1), "enable_snapshots");
+    if (m.hostSetter) m.scratch = RLGSC::MakeScratchArena(m.match->teamSize, m.match->spawnOpponents);
+    m.gameInsts.resize(config.numEnvs);
+    m.ResetAll(m.obs);
 
     modeName = std::to_string(m.match->teamSize) + "v" + std::to_string(m.match->teamSize);   // ModeNameFromGameInst, SkillTracker.cpp:20-26
     if (config.perModeRatings) { modeNames.insert(modeName); curRating.data[modeName] = config.initialRating; }
     else { modeName = ""; curRating.data[""] = config.initialRating; }
     games.resize(config.numEnvs);
     for (Game& game : games) m.ResetGame(game, 1);
-    m.gameInsts.resize(config.numEnvs);
     for (int e = 0; e < config.numEnvs; e++) { m.gameInsts[e].gym = m.gym; m.gameInsts[e].match = m.match; m.gameInsts[e].index = e; m.gameInsts[e].isEval = true; }
 }
 
@@ -94,6 +122,7 @@ SkillTracker::~SkillTracker() {
     for (void* p : {(void*)m.obs, (void*)m.obsNext, (void*)m.rew, (void*)m.logp, (void*)m.acts, (void*)m.done}) if (p) (void)hipFree(p);
     for (rlgpu_learner* l : m.old) rlgpu_learner_destroy(l);
     if (m.env) rlgpu_env_destroy(m.env);
+    delete m.scratch;
     delete m.gym; delete m.match;
     delete impl;
 }
@@ -136,7 +165,9 @@ void SkillTracker::RunGames(int64_t timestepsDelta) {
         std::vector<std::vector<int32_t>> picksOld(nOld, std::vector<int32_t>(m.nRows));
         std::vector<float> rews(m.nRows);
         const StepCallback& cb = config.stepCallback;
-        std::vector<RlgpuArenaState> states(cb || renderSender ? games.size() : 0);
+        std::vector<RlgpuArenaState>& states = m.snaps;   // every env's arena where this step's GameState was taken
+        states.resize(games.size());
+        std::vector<int32_t> ended;
         for (int s = 0; s < numSteps; s++) {
             m.LrnCheck(m.cur, rlgpu_policy_act(m.cur, m.obs, m.nRows, 1, nullptr, m.acts, m.logp), "policy_act");
             m.LrnCheck(m.cur, rlgpu_learner_sync(m.cur), "learner_sync");
@@ -162,12 +193,13 @@ void SkillTracker::RunGames(int64_t timestepsDelta) {
             std::swap(m.obs, m.obsNext);
             SKILL_HIP(hipMemcpy(rews.data(), m.rew, m.nRows * 4, hipMemcpyDeviceToHost));
             SKILL_HIP(hipMemcpy(dones.data(), m.done, m.nRows * 4, hipMemcpyDeviceToHost));
-            if (!states.empty()) m.EnvCheck(rlgpu_env_download_states(m.env, states.data(), nullptr, (int)games.size()), "download_states");
+            m.EnvCheck(rlgpu_env_download_snapshots(m.env, states.data(), 0, (int)games.size()), "download_snapshots");
+            ended.clear();
             for (size_t e = 0; e < games.size(); e++) {
                 Game& g = games[e];
-                const float blueReward = rews[e * m.nPlayers];   // +1: blue scored, -1: orange scored
-                if (blueReward > 0.5f || blueReward < -0.5f) {
-                    const bool blueScored = blueReward > 0;
+                const float ballY = states[e].ball.pos[1];
+                if (RLGSC::Math::IsBallScored(Vec(states[e].ball.pos[0], ballY, states[e].ball.pos[2]))) {   // SkillTracker.cpp:129-146
+                    const bool blueScored = ballY > 0;
                     const bool curScored = blueScored != g.teamSwap;
                     if (curScored) UpdateRatings(curRating, oldRatings[g.oldPolicyIndex], true, true, modeName);
                     else UpdateRatings(oldRatings[g.oldPolicyIndex], curRating, true, true, modeName);
@@ -180,8 +212,9 @@ void SkillTracker::RunGames(int64_t timestepsDelta) {
                     m.gameInsts[e].totalSteps++;
                     cb(&m.gameInsts[e], sr, m.gameInsts[e]._metrics);
                 }
-                if (dones[e * m.nPlayers]) m.ResetGame(g, nOld);
+                if (dones[e * m.nPlayers]) { m.ResetGame(g, nOld); ended.push_back((int32_t)e); }
             }
+            if (m.hostSetter) m.HostSetterReset(ended, m.obs);
             if (renderSender) {   // SkillTracker.cpp:147-151
                 RLGSC::GameState gs(states[0], m.tickSkip);
                 renderSender->Send(gs, m.match->actionParser->ParseActions(RLGSC::IList(picks.begin(), picks.begin() + m.nPlayers), gs));
@@ -201,7 +234,7 @@ void SkillTracker::RunGames(int64_t timestepsDelta) {
 
     timestepsSinceVersionMade += timestepsDelta;
     if (timestepsSinceVersionMade >= config.timestepsPerVersion) {   // SkillTracker.cpp:237-256
-        m.EnvCheck(rlgpu_env_reset(m.env, 1, m.obs), "reset");
+        m.ResetAll(m.obs);
         timestepsSinceVersionMade = 0;
         snapshot();
         if ((int)m.old.size() > config.maxVersions) {

@@ -494,6 +494,7 @@ class Learner:
         # the env batch restarts from fresh resets: key them on a new epoch of the RandomState / respawn streams
         self.env_stream_epoch = int(stats.get("env_stream_epoch", 0)) + 1
         self.env.reseed(parallel.shard_seed(self.cfg.randomSeed, self.rank), self.env_stream_epoch)
+        self.env.reset(True, self.obs_buf[0])   # the constructor's reset drew epoch 0's first states: draw this epoch's instead
         pol = _read_lt(os.path.join(folder, "PPO_POLICY.lt"), self.ppo.layer_shapes(0))     # size check of every param (PPOLearner.cpp:380-408)
         self.ppo.set_params(pol, 0)
         if os.path.exists(os.path.join(folder, "PPO_CRITIC.lt")):                            # the critic file is optional (PPOLearner.cpp:421-422)

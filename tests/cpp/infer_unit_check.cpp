@@ -11,6 +11,7 @@
 #include <RLGymSim_CPP/Utils/TerminalConditions/NoTouchCondition.h>
 #include <RLGymSim_CPP/Utils/TerminalConditions/GoalScoreCondition.h>
 #include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
+#include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
 #include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBS.h>
 #include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
 #include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
@@ -142,7 +143,104 @@ static int skill_tracker_check() {
     return 0;
 }
 
+// The recordings of the real reference skill tracker (tests/golden/skill_golden.json, flattened to text by tests/test_host_cpp.py):
+//   ELO  the ratings after every scripted UpdateRatings step, bit for bit
+//   RUN  scripted RunGames calls: the version bookkeeping (runCounter, stored versions, timestepsSinceVersionMade) equals the recording's;
+//        with every episode starting behind a goal line each evaluating call is one goal, and the ratings move as the reference's rule says
+//        for THIS tracker's teamSwap / oldPolicyIndex (drawn from a wall-clock seeded engine there, so the recording's own draws differ)
+static float g_goalSign = 0;
+struct BallInGoalState : KickoffState {
+    GameState ResetState(Arena* arena) override {
+        GameState gs = KickoffState::ResetState(arena);
+        BallState bs; bs.pos = Vec(0, g_goalSign * 5400.f, 200.f); bs.vel = Vec(0, 0, 0);
+        arena->ball->SetState(bs);
+        return GameState(arena);
+    }
+};
+static EnvCreateResult ScriptEnv() {
+    StateSetter* setter = g_goalSign != 0 ? (StateSetter*)new BallInGoalState() : new KickoffState();
+    Match* match = new Match(new VelocityReward(), {new NoTouchCondition(100000), new GoalScoreCondition()}, new DefaultOBS(), new DiscreteAction(), setter, 1, true);
+    return {match, new Gym(match, 8)};
+}
+static float from_bits(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static int skill_fixture_check(const char* path) {
+    FILE* f = std::fopen(path, "r");
+    CHECK(f != nullptr);
+    RlgpuLearnerConfig lc{};
+    lc.obs_size = 89; lc.n_actions = 90; lc.n_policy_layers = 2; lc.n_critic_layers = 1; lc.policy_layers[0] = 32; lc.policy_layers[1] = 32; lc.critic_layers[0] = 16;
+    lc.clip_range = 0.2f; lc.temperature = 1; lc.seed_lo = 5; lc.max_rows = 256;
+    rlgpu_learner* lrn = nullptr;
+    CHECK(rlgpu_learner_create(&lrn, 0, &lc) == RLGPU_OK);
+    char tag[16]; int nElo = 0, nRuns = 0, nGoals = 0;
+    while (std::fscanf(f, "%15s", tag) == 1) {
+        if (std::string(tag) == "ELO") {
+            int nSets, n; float inc;
+            CHECK(std::fscanf(f, "%d %d %f", &nSets, &n, &inc) == 3);
+            g_goalSign = 0;
+            SkillTrackerConfig sc; sc.enabled = true; sc.envCreateFunc = ScriptEnv; sc.numEnvs = 1; sc.ratingInc = inc;
+            SkillTracker st(sc, lrn, 89, 90, {32, 32}, 1);
+            std::vector<SkillTracker::RatingSet> sets(nSets);
+            for (int k = 0; k < nSets; k++) { unsigned u; CHECK(std::fscanf(f, "%u", &u) == 1); sets[k].data["1v1"] = from_bits(u); }
+            for (int i = 0; i < n; i++) {
+                int w, l, fl; CHECK(std::fscanf(f, "%d %d %d", &w, &l, &fl) == 3);
+                st.UpdateRatings(sets[w], sets[l], fl & 1, fl & 2, "1v1");
+                for (int k = 0; k < nSets; k++) {
+                    unsigned u; CHECK(std::fscanf(f, "%u", &u) == 1);
+                    const float mine = sets[k].data["1v1"]; unsigned mu; std::memcpy(&mu, &mine, 4);
+                    if (mu != u) { std::printf("elo step %d set %d: %.9g, the reference has %.9g\n", i, k, mine, from_bits(u)); return 1; }
+                }
+            }
+            nElo += n;
+        } else if (std::string(tag) == "RUN") {
+            float goalSign, inc, simTime; int nCalls, interval, maxVersions, startWith; long long perVersion;
+            CHECK(std::fscanf(f, "%f %d %d %lld %d %d %f %f", &goalSign, &nCalls, &interval, &perVersion, &maxVersions, &startWith, &inc, &simTime) == 8);
+            g_goalSign = goalSign;
+            SkillTrackerConfig sc; sc.enabled = true; sc.envCreateFunc = ScriptEnv; sc.numEnvs = 1; sc.ratingInc = inc; sc.simTime = simTime;
+            sc.updateInterval = interval; sc.timestepsPerVersion = perVersion; sc.maxVersions = maxVersions; sc.startWithVersion = startWith != 0; sc.kickoffStatesOnly = false;
+            SkillTracker st(sc, lrn, 89, 90, {32, 32}, 77 + nRuns);
+            float cur = sc.initialRating; std::vector<float> olds;
+            SkillTracker::RatingSet a, b;
+            for (int i = 0; i < nCalls; i++) {
+                long long delta; int refSwap, refIdx, refCounter, refVersions; long long refSince; unsigned curBits;
+                CHECK(std::fscanf(f, "%lld %d %d %d %d %lld %u", &delta, &refSwap, &refIdx, &refCounter, &refVersions, &refSince, &curBits) == 7);
+                for (int k = 0; k < maxVersions; k++) { unsigned u; CHECK(std::fscanf(f, "%u", &u) == 1); }
+                const bool swap = st.games[0].teamSwap; int idx = st.games[0].oldPolicyIndex;
+                const bool evaluates = st.runCounter % (uint64_t)interval == 0;
+                // the rule (SkillTracker.cpp:104-146, 152-257) applied to this tracker's own draws
+                if (evaluates) {
+                    if (olds.empty() && startWith) olds.push_back(cur);
+                    if (!olds.empty() && goalSign != 0) {
+                        if (idx >= (int)olds.size()) idx = (int)olds.size() - 1;
+                        const bool curScored = (goalSign > 0) != swap;
+                        a.data["1v1"] = curScored ? cur : olds[idx]; b.data["1v1"] = curScored ? olds[idx] : cur;
+                        st.UpdateRatings(a, b, true, true, "1v1");
+                        (curScored ? cur : olds[idx]) = a.data["1v1"]; (curScored ? olds[idx] : cur) = b.data["1v1"];
+                        nGoals++;
+                    }
+                }
+                st.RunGames(delta);
+                if (evaluates && st.timestepsSinceVersionMade == 0) { olds.push_back(cur); if ((int)olds.size() > maxVersions) olds.erase(olds.begin()); }
+                if ((int)st.runCounter != refCounter || st.NumOldPolicies() != refVersions || st.timestepsSinceVersionMade != refSince || (int)st.oldRatings.size() != refVersions) {
+                    std::printf("run script call %d: runCounter %d versions %d since %lld, the reference has %d %d %lld\n", i, (int)st.runCounter, st.NumOldPolicies(),
+                                (long long)st.timestepsSinceVersionMade, refCounter, refVersions, refSince);
+                    return 1;
+                }
+                CHECK(st.curRating.data.at("1v1") == cur && olds.size() == st.oldRatings.size());
+                for (size_t k = 0; k < olds.size(); k++) CHECK(st.oldRatings[k].data.at("1v1") == olds[k]);
+                if (goalSign == 0) CHECK(from_bits(curBits) == cur);   // nobody scores from a kickoff in one step, there or here
+            }
+            nRuns++;
+        } else { std::printf("skill script: unknown tag %s\n", tag); return 1; }
+    }
+    std::fclose(f);
+    CHECK(nElo >= 100 && nRuns >= 4 && nGoals >= 60);
+    rlgpu_learner_destroy(lrn);
+    std::printf("skill tracker vs the reference's recordings ok: %d elo steps bit-equal, %d scripted runs, %d goals rated\n", nElo, nRuns, nGoals);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 3 && std::string(argv[1]) == "--skill-script") return skill_fixture_check(argv[2]);
     if (argc < 4) return 2;
     if (skill_tracker_check()) return 1;
     std::vector<GameState> states; std::vector<ActionSet> prevs;

@@ -332,6 +332,30 @@ static int StandaloneGym() {
     const BallState fell = arena->ball->GetState();
     CHECK(arena->tickCount == 60 && fell.pos.z < 1000.f - 70.f && fell.pos.z > 1000.f - 90.f && fell.vel.z < -300.f);   // 0.5 s of -650 uu/s^2
     delete arena;
+    {   // goal / bump callbacks of the arena facade (Arena.cpp:335-413, 804-808), raised from the state every tick leaves behind
+        Arena* cb = Arena::Create(GameMode::SOCCAR);
+        Car* blueCar = cb->AddCar(Team::BLUE); Car* orangeCar = cb->AddCar(Team::ORANGE);
+        cb->ResetToRandomKickoff(7);
+        struct Seen { int goals = 0, bumps = 0, demos = 0; Team scorer = Team::ORANGE; Car *bumper = nullptr, *victim = nullptr; uint64_t bumpTick = 0; } seen;
+        cb->SetGoalScoreCallback([](Arena*, Team t, void* u) { Seen* s = (Seen*)u; s->goals++; s->scorer = t; }, &seen);
+        cb->SetCarBumpCallback([](Arena* a, Car* b, Car* v, bool demo, void* u) { Seen* s = (Seen*)u; s->bumps++; s->demos += demo ? 1 : 0; s->bumper = b; s->victim = v; s->bumpTick = a->tickCount; }, &seen);
+        // a supersonic blue car drives into a standing orange one: one demo, raised once (the cooldown keeps the pair quiet afterwards)
+        CarState a = blueCar->GetState(); a.pos = Vec(0, -400, 17); a.rotMat = Angle(1.5707963f, 0, 0).ToRotMat(); a.vel = Vec(0, 2300, 0); a.isSupersonic = true; a.boost = 100; blueCar->SetState(a);
+        CarState o = orangeCar->GetState(); o.pos = Vec(0, 0, 17); o.rotMat = Angle(0, 0, 0).ToRotMat(); o.vel = Vec(0, 0, 0); orangeCar->SetState(o);
+        blueCar->controls.throttle = 1; blueCar->controls.boost = true;
+        BallState away; away.pos = Vec(3000, 3000, 93.15f); cb->ball->SetState(away);
+        cb->Step(40);
+        CHECK(seen.bumps == 1 && seen.demos == 1 && seen.bumper == blueCar && seen.victim == orangeCar && seen.bumpTick > 0 && seen.bumpTick < 40);
+        CHECK(orangeCar->GetState().isDemoed && seen.goals == 0);
+        // the ball crosses the orange goal line: blue scores, and the callback fires on every tick that ends with the ball behind the line
+        BallState in2; in2.pos = Vec(0, 5100, 300); in2.vel = Vec(0, 1500, 0); cb->ball->SetState(in2);
+        cb->Step(12);
+        CHECK(cb->IsBallScored() && seen.goals >= 1 && seen.goals < 12 && seen.scorer == Team::BLUE);
+        const int g0 = seen.goals;
+        cb->Step(3);
+        CHECK(seen.goals == g0 + 3);
+        delete cb;
+    }
     {   // a gym without opponents: one car, one observation row with no other player in it
         CombinedReward solo({{new VelocityPlayerToBallReward(), 1.f}}, true);
         NoTouchCondition nt(4);

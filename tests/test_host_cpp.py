@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -151,6 +152,13 @@ def test_reference_example_source_compiles_unchanged():
         r = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-"], stdin=f,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
+    # ... and LINKS, unchanged, against the host library (north star: "examplemain.cpp links unchanged"); the program is not run here (no GPU)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d, open(src, "rb") as f:
+        exe = os.path.join(d, "examplemain")
+        r = subprocess.run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-", "-o", exe, "-L", PKG, "-lrlgymppo_amd", "-lrlgpu",
+                            "-Wl,-rpath," + PKG, "-Wl,-rpath-link,/opt/rocm/lib"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and os.path.exists(exe), r.stdout[-3000:]
 
 
 @pytest.mark.gpu
@@ -191,6 +199,64 @@ def test_infer_unit_and_host_obs_builders(tmp_path):
         assert (act == table[int(np.argmax(want))]).all()
         v = R.mlp_forward(cri, cri_shapes, obs[None])[0].reshape(-1)[0]
         assert abs(val - v) < 1e-4 * max(1.0, abs(v))
+
+
+def _skill_script_text():
+    """tests/golden/skill_golden.json (recorded from the real reference skill tracker by tests/golden/make_skill_golden.py) as the flat text
+    infer_unit_check --skill-script reads."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "skill_golden.json")) as f:
+        gold = json.load(f)
+    e = gold["elo"]
+    lines = ["ELO %d %d %r" % (len(e["start_bits"]), len(e["winner"]), e["rating_inc"]), " ".join(map(str, e["start_bits"]))]
+    for w, l, fl, tr in zip(e["winner"], e["loser"], e["flags"], e["trace_bits"]):
+        lines.append("%d %d %d %s" % (w, l, fl, " ".join(map(str, tr))))
+    for s in gold["idle"] + gold["goals"]:
+        lines.append("RUN %r %d %d %d %d %d %r %r" % (s["goal_sign"], len(s["deltas"]), s["update_interval"], s["timesteps_per_version"], s["max_versions"],
+                                                      int(s["start_with_version"]), s["rating_inc"], s["sim_time"]))
+        rows = np.array(s["rows_bits"], np.uint32)
+        vals = rows.view(np.float32)
+        for d, rb, rv in zip(s["deltas"], rows, vals):
+            lines.append("%d %d %d %d %d %d %d %s" % (d, int(rv[0]), int(rv[1]), int(rv[2]), int(rv[3]), int(rv[4]), rb[5], " ".join(map(str, rb[6:]))))
+    return "\n".join(lines) + "\n", gold
+
+
+def test_skill_golden_is_what_the_reference_skill_tracker_returns():
+    """CPU: the committed recordings are the real reference's (oracle/_ref/libref_skill.so, when it is there): UpdateRatings bit for bit."""
+    import ctypes as C
+    text, gold = _skill_script_text()
+    assert text.count("RUN") == 5 and len(gold["elo"]["winner"]) == 400
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_skill.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_skill.so not built (make -C oracle ref_skill needs /root/reference)")
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import simlib
+    lib = C.CDLL(so)
+    verts, tris = simlib.PortSim().procedural_mesh()
+    root = tempfile.mkdtemp(prefix="skill_mesh_")
+    simlib.write_cmf_parts(verts, tris, [len(tris)], root)
+    assert lib.refs_init_dir(root.encode()) == 0
+    e = gold["elo"]
+    ratings = np.array(e["start_bits"], np.uint32).view(np.float32).copy()
+    w, l, fl = (np.array(e[k], np.int32) for k in ("winner", "loser", "flags"))
+    trace = np.zeros((len(w), len(ratings)), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.refs_elo_script(len(ratings), p(ratings), len(w), p(w), p(l), p(fl), C.c_float(e["rating_inc"]), p(trace)) == 0
+    assert (trace.view(np.uint32) == np.array(e["trace_bits"], np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_skill_tracker_against_reference_recordings(tmp_path):
+    """GPU: the product's skill tracker replays the scripts recorded from the real reference one (tests/golden/skill_golden.json): the Elo
+    arithmetic bit for bit, RunGames' version bookkeeping call by call, and -- with a user state setter that starts every episode behind a
+    goal line -- the goal test on the step's GameState and who gets the points (SkillTracker.cpp:72-86, 104-146, 152-257)."""
+    text, _ = _skill_script_text()
+    path = str(tmp_path / "skill_script.txt")
+    with open(path, "w") as f:
+        f.write(text)
+    r = _run([os.path.join(PKG, "infer_unit_check"), "--skill-script", path], timeout=600)
+    assert r.returncode == 0 and "skill tracker vs the reference's recordings ok" in r.stdout, r.stdout[-3000:]
 
 
 @pytest.mark.gpu
