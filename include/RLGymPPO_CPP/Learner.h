@@ -12,9 +12,18 @@ namespace RLGPC {
 class Learner;
 typedef std::function<void(Learner*, Report&)> IterationCallback;
 
+// The reference's public header names three of its private classes as members (Learner.h:18-20).  Here they are the device objects of
+// include/rlgpu.h that do those jobs: the PPO learner, the env batch that stands where the agent threads stood, the experience FIFO.
+class PPOLearner { public: rlgpu_learner* device = nullptr; };
+class ThreadAgentManager { public: rlgpu_env* device = nullptr; int numGames = 0; };
+class ExperienceBuffer { public: rlgpu_expbuf* device = nullptr; };
+
 class Learner {
 public:
     LearnerConfig config;
+    PPOLearner* ppo = nullptr;
+    ThreadAgentManager* agentMgr = nullptr;
+    ExperienceBuffer* expBuffer = nullptr;
     EnvCreateFn envCreateFn;
     int obsSize = 0, actionAmount = 0;
     std::string runID;

@@ -237,6 +237,9 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.obs = dev_alloc<float>((size_t)(m.T + 1) * m.nAgents * m.D);
     m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN);
     if (rlgpu_expbuf_create(&m.fifo, config.expBufferSize, m.T, m.nAgents) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: bad expBufferSize " << config.expBufferSize);
+    ppo = new PPOLearner(); ppo->device = m.lrn;
+    agentMgr = new ThreadAgentManager(); agentMgr->device = m.env; agentMgr->numGames = m.nEnvs;
+    expBuffer = new ExperienceBuffer(); expBuffer->device = m.fifo;
     const size_t EX = (size_t)rlgpu_expbuf_num_slots(m.fifo) * TN;
     m.idx = dev_alloc<int32_t>(EX);
     m.exObs = dev_alloc<float>(EX * m.D); m.exActs = dev_alloc<int32_t>(EX); m.exLogp = dev_alloc<float>(EX); m.exAdv = dev_alloc<float>(EX); m.exTgt = dev_alloc<float>(EX);
@@ -281,6 +284,7 @@ Learner::~Learner() {
     if (m.learnStream) { (void)hipStreamDestroy(m.learnStream); (void)hipEventDestroy(m.evReady); (void)hipEventDestroy(m.evLearnDone); }
     if (m.drawPending) m.nextDraw.wait();
     delete skillTracker; delete metricSender; delete renderSender;
+    delete ppo; delete agentMgr; delete expBuffer;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
     if (m.shuf) rlgpu_shuffler_destroy(m.shuf);
     if (m.lrn) rlgpu_learner_destroy(m.lrn);
