@@ -29,7 +29,6 @@ struct CarTickCtx {
     int n_contact;
     bool wheels_world;
     float forward_speed_uu;
-    uint64_t pad_mask;   // boost pads this car touches this tick (bit p), from pads_check_car
     float new_lat[4], new_long[4];   // this tick's friction factors per wheel (car_wheel_trace), adopted by car_pre_tick_finish
 };
 

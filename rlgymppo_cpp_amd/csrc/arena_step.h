@@ -540,13 +540,21 @@ struct TickWork {
     static constexpr int MAXM = ContactLayout<NC>::MAXM;
     static constexpr int MAXS = 8 + 6 * NC;        // contacts the solver takes per tick (the rest of a fuller list is dropped: never seen in play)
     static constexpr int MAXR = 2 * (MAXS + 1);    // their normal + friction rows and the ball's averaged pair
+    // The cars' tick context lives from car_tick_begin to car_pre_tick_finish, the contact list from tick_world_begin (which follows) to
+    // solver_finish: the device kernels (RLG_TICKWORK_OVERLAY) keep them in the same LDS bytes; the host build keeps both (the oracle's
+    // debug dumps read the wheels after the tick).
+#ifdef RLG_TICKWORK_OVERLAY
+    union { ContactList<MAXC> L; CarTickCtx ctx[NC]; };
+#else
     ContactList<MAXC> L;
+    CarTickCtx ctx[NC];
+#endif
     SolverBody B[NB];
     union {
         Row R[MAXR];       // solver rows: built after the contact list is complete ...
         CollideQueue<NC> Q;   // ... narrowphase items: dead by then
     };
-    CarTickCtx ctx[NC];
+    uint64_t pad_mask[NC];           // boost pads car i touches this tick (bit p), from pads_check_car
     bool ball_asleep;
     int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
     int8_t nrow[MAXS], frow[MAXS];   // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)

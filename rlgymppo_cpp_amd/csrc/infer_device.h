@@ -115,8 +115,27 @@ struct InferNet {
     const float* Wf[9]; int Kf[9];   // layer i: weights, true number of inputs
 };
 constexpr int LOGIT_LD = 132;        // fp32 logits row in LDS (n_actions <= 128)
-constexpr int WAVE_ROWS = 8;         // rows one wavefront infers at most: they sit in the first 8 rows of a 32-row MFMA tile
-__host__ __device__ constexpr int wave_buf_bytes(int ld) { return (WAVE_ROWS * ld * 2 > WAVE_ROWS * LOGIT_LD * 4) ? WAVE_ROWS * ld * 2 : WAVE_ROWS * LOGIT_LD * 4; }
+constexpr int WAVE_ROWS = 16;        // rows one wavefront infers at most: they sit in the first 8 or 16 rows of a 32-row MFMA tile
+__host__ __device__ constexpr int wave_buf_bytes(int rows, int ld) { return (rows * ld * 2 > rows * LOGIT_LD * 4) ? rows * ld * 2 : rows * LOGIT_LD * 4; }
+// the head of R rows in batches of at most 8 (policy_head_rows keeps ~10 registers per row)
+template <int R>
+__device__ __forceinline__ void policy_head_batched(const float* const (&z)[R], const int (&row)[R], int lane, const HeadArgs& h, int (&picked)[R]) {
+    if constexpr (R <= 8) policy_head_rows<R>(z, row, lane, h, picked);
+    else {
+        constexpr int R1 = R - 8;
+        const float* za[8]; int ra[8], pa[8]; const float* zb[R1]; int rb[R1], pb[R1];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { za[r] = z[r]; ra[r] = row[r]; }
+#pragma unroll
+        for (int r = 0; r < R1; r++) { zb[r] = z[8 + r]; rb[r] = row[8 + r]; }
+        policy_head_rows<8>(reinterpret_cast<const float* const (&)[8]>(za), ra, lane, h, pa);
+        policy_head_rows<R1>(reinterpret_cast<const float* const (&)[R1]>(zb), rb, lane, h, pb);
+#pragma unroll
+        for (int r = 0; r < 8; r++) picked[r] = pa[r];
+#pragma unroll
+        for (int r = 0; r < R1; r++) picked[8 + r] = pb[r];
+    }
+}
 
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -167,14 +186,14 @@ __device__ __forceinline__ void mma_block_any(const short* arow, const bf16x8 (&
 #define RLINFER_DISPATCH_NK(nk, CALL, FALLBACK) \
     switch (nk) { case 16: CALL(16); break; case 6: CALL(6); break; case 8: CALL(8); break; case 12: CALL(12); break; case 14: CALL(14); break; default: FALLBACK; }
 
-// Policy forward + head for rows row0 .. row0 + R - 1 (R <= 8) whose fp32 observations are obs[r * D + c], by one wavefront.
+// Policy forward + head for rows row0 .. row0 + R - 1 (R <= 16) whose fp32 observations are obs[r * D + c], by one wavefront.
 // Same operand values, accumulation order, bias / ReLU / bf16 rounding and head code as k_mlp_infer (rlgpu_learn.hip): the logits and
 // the sampled actions are those of a batched call.  Only the first n_rows (>= 1) of the R rows exist: the others redo the
-// last real one (same values, same stores).  buf0 / buf1: LDS, wave_buf_bytes(net.ld) each.  picked[r] = the action.
+// last real one (same values, same stores).  buf0 / buf1: LDS, wave_buf_bytes(R, net.ld) each.  picked[r] = the action.
 template <int R>
 __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R],
                                            unsigned long long* prof_split = nullptr) {
-    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 8 rows");
+    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 16 rows");
     constexpr int CHUNK = 16;
     short* in = buf0; short* out = buf1;
     const int ld = net.ld;
@@ -227,11 +246,11 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 #define RLINFER_MMA(NK) mma_block<NK>(arow, b, acc)
             RLINFER_DISPATCH_NK(nk, RLINFER_MMA, mma_block_any(arow, b, acc, nk))
 #undef RLINFER_MMA
-            // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3
+            // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3, rows 8..15 registers 4..7
             const int col = cb * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = r + 4 * (lane >> 5);
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= R) continue;
                 const float v = acc[r] + bias;
                 if (last) logits[row * LOGIT_LD + col] = v;
@@ -249,7 +268,7 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 #pragma unroll
     for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = logits + rr * LOGIT_LD; rows[r] = row0 + rr; }
     const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
-    policy_head_rows<R>(zc, rows, lane, head, picked);
+    policy_head_batched<R>(zc, rows, lane, head, picked);
 }
 // ---- the same forward pass in fp32: the exact-parity mode of the fused collection ------------------------------------------------------
 // rlgpu_policy_act with use_bf16 = 0 runs every layer through k_gemm<false> (rlgpu_learn.hip): v_mfma_f32_32x32x2_f32 over k = 0, 2, 4, ...
@@ -264,7 +283,7 @@ __host__ __device__ constexpr int f32_half_bytes(int rows, int ld) { return ((ro
 
 template <int R>
 __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, F32Buf in, F32Buf out, int lane, int (&picked)[R]) {
-    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 8 rows");
+    static_assert(R <= WAVE_ROWS, "a wavefront infers at most 16 rows");
     constexpr int CH = 16;                               // MFMA steps (2 inputs each) whose B operands are in flight together
     const int ld = net.ld;
     for (int r = 0; r < R; r++) {
@@ -304,8 +323,8 @@ __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadAr
             }
             const float bias = col_ok ? net.bias[i][col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = r + 4 * kh;
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row >= R) continue;
                 float v = acc[r] + bias;
                 if (last) { if (col < LOGIT_LD) f32_row<R>(out, row, LOGIT_LD)[col] = v; }
@@ -319,7 +338,7 @@ __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadAr
 #pragma unroll
     for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = f32_row<R>(in, rr, LOGIT_LD); rows[r] = row0 + rr; }
     const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
-    policy_head_rows<R>(zc, rows, lane, head, picked);
+    policy_head_batched<R>(zc, rows, lane, head, picked);
 }
 
 }  // namespace rlinfer

@@ -17,6 +17,7 @@
 #ifndef RLG_WAVES_PER_BLOCK
 #define RLG_WAVES_PER_BLOCK 1
 #endif
+#define RLG_TICKWORK_OVERLAY 1   /* arena_step.h TickWork: the car tick context shares its LDS bytes with the contact list */
 #define RLG_WAVES_PER_BLOCK_DEFAULTED RLG_WAVES_PER_BLOCK
 #ifdef RLG_TICK_PROFILE
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
@@ -182,10 +183,15 @@ template <int NC>
 constexpr size_t lane_stride() { size_t w = (sizeof(LaneBlock<NC>) + 7) / 8; return ((w % 2) ? w : w + 1) * 8; }
 template <int NC>
 constexpr int lanes_per_block() {
-    int l = 16;
-    // (a wavefront infers its own envs' agents in one 8-row MFMA tile: at most 8 / NC envs per wavefront whatever the LDS budget)
-    while (l > WPB && ((size_t)l * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET || (l / WPB) * NC > 8)) l /= 2;
-    return l;
+#ifdef RLG_EXPERIMENT_EPW   /* what-if builds (tools/build_variant.sh): a fixed number of envs per wavefront whatever the budgets say; only k_env_ticks is meaningful */
+    if (NC == 2) return RLG_EXPERIMENT_EPW * WPB;
+#endif
+    // as many envs per wavefront as the workgroup's LDS budget holds, at most 8 (bank-conflict-free lane strides), one lane per wheel
+    // (64 / (4 NC)), and the rows of one inference tile (a wavefront infers its own envs' agents: rlinfer::WAVE_ROWS)
+    int epw = 8;
+    while (epw > 1 && ((size_t)epw * WPB * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET
+                       || epw * NC * 4 > WAVE || epw * NC > rlinfer::WAVE_ROWS)) epw--;
+    return epw * WPB;
 }
 
 template <int NC>
@@ -610,10 +616,10 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     RLG_PROF(5);
     wave_sync();
     RLG_FPROF(13); phase_sync(2);
-    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.ctx[c_car].pad_mask = pads_check_car(Sc.A, pad_tab, c_car); }
+    if (car_lane) { tick_car_post(Sc.A, c_car); Sc.W.pad_mask[c_car] = pads_check_car(Sc.A, pad_tab, c_car); }
     wave_sync();
     RLG_FPROF(14); phase_sync(2);
-    if (env_lane) for (int k = 0; k < NC; k++) { const int i = car_at_rank(Se.A, k); const uint64_t pm = Se.W.ctx[i].pad_mask; if (pm) pads_lock(Se.A, i, pm); }
+    if (env_lane) for (int k = 0; k < NC; k++) { const int i = car_at_rank(Se.A, k); const uint64_t pm = Se.W.pad_mask[i]; if (pm) pads_lock(Se.A, i, pm); }
     wave_sync();
     RLG_FPROF(15); phase_sync(2);
     {   // pads that hand out boost are rare: they go through the env lane in pad order, all the others finish in parallel
@@ -720,7 +726,11 @@ struct CollectArgs {
 template <int NC>
 __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(EnvDev d, CollectArgs c) {
     constexpr int LANES = lanes_per_block<NC>();
+#ifdef RLG_EXPERIMENT_EPW
+    constexpr int EPW = LANES / WPB, R = EPW * NC < rlinfer::WAVE_ROWS ? EPW * NC : rlinfer::WAVE_ROWS;
+#else
     constexpr int EPW = LANES / WPB, R = EPW * NC;
+#endif
     static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[LDS_NODES];
@@ -737,7 +747,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     const int D = obs_size<NC>(d.cfg);
     const size_t N = (size_t)c.n_agents;
     // inference scratch inside the TickWork areas (dead between ticks): two activation buffers and the picked actions
-    const int buf_bytes = rlinfer::wave_buf_bytes(c.net.ld);
+    const int buf_bytes = rlinfer::wave_buf_bytes(R, c.net.ld);
     unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
     short* const buf0 = reinterpret_cast<short*>(w0);
     short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
@@ -1112,9 +1122,11 @@ int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* dir) {
     return env_set_mesh_parts(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3, &parts, true);
 }
 
+// what-if runs: RLGPU_EXPERIMENT_DYN_LDS=<bytes> of unused dynamic LDS per 1v1 workgroup lowers the workgroups a CU holds (tools/fine_prof.py)
+static size_t experiment_dyn_lds() { static const size_t v = [] { const char* s = getenv("RLGPU_EXPERIMENT_DYN_LDS"); return s ? (size_t)atol(s) : (size_t)0; }(); return v; }
 #define DISPATCH_NC(e, KERNEL, grid, block, ...)                                                             \
     do {                                                                                                     \
-        if ((e)->nc == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, (e)->stream, __VA_ARGS__);          \
+        if ((e)->nc == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, experiment_dyn_lds(), (e)->stream, __VA_ARGS__);          \
         else if ((e)->nc == 4) hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, (e)->stream, __VA_ARGS__);     \
         else hipLaunchKernelGGL((KERNEL<6>), grid, block, 0, (e)->stream, __VA_ARGS__);                       \
     } while (0)
@@ -1273,7 +1285,7 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
     const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one half of an activation buffer may take
     int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
-    if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
+    if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(epw * e->nc, c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
     if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_half_bytes(epw * e->nc, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
     if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
     if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }

@@ -1369,7 +1369,7 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
         return RLGPU_OK;
     }
     if (max_buf_bytes < 0) max_buf_bytes = 0x7fffffff;   // (the caller sized for the fp32 mode; checked again by it for bf16)
-    if (rlinfer::wave_buf_bytes(maxkp + 8) > max_buf_bytes || maxkp > 256) return RLGPU_ERR_STATE;   // wave_infer keeps a layer's 16 K steps in registers
+    if (maxkp > 256) return RLGPU_ERR_STATE;   // wave_infer keeps a layer's 16 K steps in registers
     LCHK(l, hipSetDevice(l->device));
     hipStream_t keep = l->stream;
     l->stream = (hipStream_t)stream;            // the weight copies must be current on the stream the caller launches on

@@ -346,7 +346,9 @@ void Learner::AllReduceTimings(float& ms, int& calls, bool reset) {
     ms = (float)m.arMs; calls = m.arCalls;
     if (reset) { m.arMs = 0; m.arCalls = 0; }
 }
-bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= 2 && !stepCallback && !renderSender; }
+// (RLGPU_FUSED_MAX_TEAM = 2 puts 3v3 back on alternating act / step launches: the faster way while a wavefront held ONE 3v3 env)
+static int FusedMaxTeam() { static const int v = [] { const char* s = std::getenv("RLGPU_FUSED_MAX_TEAM"); return s ? std::atoi(s) : 3; }(); return v; }
+bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= FusedMaxTeam() && !stepCallback && !renderSender; }
 void Learner::DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset) {
     // the device-side clocks are opt-in: the first call switches them on (a training run that never asks pays for no events)
     impl->EnvCheck(rlgpu_env_enable_timing(impl->env, 1), "enable_timing");
@@ -501,7 +503,7 @@ void Learner::CollectTimesteps() {
         for (int e = 0; e < m.nEnvs; e++) m.prevGs[e] = RLGSC::GameState(m.snaps[e], m.tickSkip);
     }
     // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
-    if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= 2) {   // 3v3: one env per wavefront, the in-kernel inference does not amortise
+    if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= FusedMaxTeam()) {
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
         if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B * (uint64_t)m.world; return; }
         if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");

@@ -264,9 +264,8 @@ class Learner:
         self.metric_sender = None   # created by run() after a possible load(), so that a loaded run id continues (Learner.cpp:149-155)
         self.env.reset(True, self.obs_buf[0])
         self._first = True
-        # one launch per collection phase pays where a wavefront's in-kernel inference serves several envs (1v1: 4, 2v2: 2); with one 3v3
-        # env per wavefront the weights are streamed once per env and step, and the alternating path is faster (8.3 M vs 11.3 M agent-steps/s)
-        self._fused_collect = not os.environ.get("RLGPU_NO_FUSED_COLLECT") and cfg.teamSize <= 2
+        # one launch per collection phase: a wavefront's in-kernel inference serves its own envs (1v1: 4, 2v2: 2, 3v3: 2 per wavefront)
+        self._fused_collect = not os.environ.get("RLGPU_NO_FUSED_COLLECT") and cfg.teamSize <= int(os.environ.get("RLGPU_FUSED_MAX_TEAM", "3"))
 
     # ---- collection ------------------------------------------------------------------------------------------------
     def collect(self):
