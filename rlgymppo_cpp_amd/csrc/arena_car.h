@@ -472,7 +472,7 @@ RLG_HD_NOINLINE void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx
 template <int NC>
 RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue<NC>& Q, int ci, int pair, CarTickCtx& t) {
     const int slot = CollideQueue<NC>::region(1 + ci) + (pair >> 2), i = pair & 3;
-    const uint32_t c = Q.cand[slot];
+    const uint32_t c = queue_cand(Q, slot);
     if (c == CAND_HOLE) return;
     const WheelTmp& w = t.w[i];
     float d;

@@ -88,7 +88,7 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         io.f(pd.cooldown);
         uint32_t bits = (pd.is_active ? 1u : 0u) | ((uint32_t)pd.prev_locked << 1);
         io.u(bits);
-        pd.is_active = bits & 1u; pd.prev_locked = (int)(bits >> 1);
+        pd.is_active = bits & 1u; pd.prev_locked = (int8_t)(bits >> 1);
     }
     io.i(G.score_line[0]); io.i(G.score_line[1]); io.i(G.last_touch_car_id); io.l(G.last_tick_count); io.i(G.no_touch_steps);
     io.f(G.shot_cooldown);
@@ -164,7 +164,7 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
     }
     for (int p = 0; p < 34; p++) {
         A.pads[p].cooldown = s.pads[p].cooldown; A.pads[p].is_active = s.pads[p].is_active != 0;
-        A.pads[p].prev_locked = s.pads[p].prev_locked_car_id; A.pads[p].cur_locked = 0;
+        A.pads[p].prev_locked = (int8_t)s.pads[p].prev_locked_car_id; A.pads[p].cur_locked = 0;
     }
     const RlgpuGymState& g = s.gym;
     G.score_line[0] = g.score_line[0]; G.score_line[1] = g.score_line[1]; G.last_touch_car_id = g.last_touch_car_id;

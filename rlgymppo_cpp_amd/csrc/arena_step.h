@@ -234,8 +234,9 @@ struct NarrowQueued {
 // step 2: does candidate `k` become an item?  (triangle AABB vs the body's query box; car-car pairs always do)
 template <int NC>
 RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const CollideQueue<NC>& Q, int k) {
-    if (Q.cand[k] == CAND_HOLE) return false;
-    CollideItem it = unpack_cand(Q.cand[k]);
+    const uint32_t cw = queue_cand(Q, k);
+    if (cw == CAND_HOLE) return false;
+    CollideItem it = unpack_cand(cw);
     if (it.type == 2) return true;
     V3 lo, hi, bc;
     if (it.type == 0) ball_query_aabb(A.ball.b.pos, lo, hi);
@@ -406,10 +407,10 @@ struct SolverBody {
     float inv_m;
     bool active;
 };
-struct Row {   // 23 words: kept small because the device kernel holds the rows of 16 envs in LDS
-    int16_t a, b;        // body indices (b = -1: static world)
-    int16_t fric_of;     // friction rows: index of their normal row; -1 for normal rows
-    int16_t skip;        // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
+struct Row {   // 22 words: kept small because the device kernel holds its envs' rows in LDS
+    int8_t a, b;         // body indices (b = -1: static world)
+    int8_t fric_of;      // friction rows: index of their normal row (< MAXR <= 90); -1 for normal rows
+    int8_t skip;         // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
     V3 n1, r1xn, r2xn, ang_a, ang_b;   // contactNormal2 is -n1 whenever b >= 0
     float jac, rhs, rhs_pen, applied, applied_push, friction;
 };
@@ -418,7 +419,7 @@ template <int NB>
 RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, float dist, float fric, float rest, bool has_b) {
     const float dt = TICK_DT;
     SolverBody& A = B[c.a];
-    r.a = (int16_t)c.a; r.b = (int16_t)(has_b ? c.b : -1);
+    r.a = (int8_t)c.a; r.b = (int8_t)(has_b ? c.b : -1);
     V3 t0 = cross(ra, n);
     r.ang_a = A.inv_i * t0;
     V3 t1 = cross(rb, n);
@@ -472,7 +473,7 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
     float v2 = has_b ? (dot(-r.n1, B[nr.b].v + B[nr.b].ext_f) + dot(r.r2xn, B[nr.b].w)) : 0.f;
     float rv = v1 + v2;
     r.rhs = (0.f - rv) * r.jac; r.rhs_pen = 0.f;
-    r.skip = 0; r.fric_of = (int16_t)normal_idx;
+    r.skip = 0; r.fric_of = (int8_t)normal_idx;
 }
 
 // gResolveSingleConstraintRow{LowerLimit,Generic}_scalar_reference (btSequentialImpulseConstraintSolver.cpp:46-100), cfm = 0
@@ -549,11 +550,11 @@ struct TickWork {
     ContactList<MAXC> L;
     CarTickCtx ctx[NC];
 #endif
-    SolverBody B[NB];
     union {
         Row R[MAXR];       // solver rows: built after the contact list is complete ...
         CollideQueue<NC> Q;   // ... narrowphase items: dead by then
     };
+    SolverBody B[NB];      // (directly behind the union: with the queue's dead tail one stretch that nothing uses during the narrowphase, rlgpu_env.hip)
     uint64_t pad_mask[NC];           // boost pads car i touches this tick (bit p), from pads_check_car
     bool ball_asleep;
     int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
@@ -1086,11 +1087,11 @@ RLG_HD void pad_post_tick(Arena<NC>& A, int p) {
             pd.cooldown = p < 6 ? K::PAD_COOLDOWN_BIG : K::PAD_COOLDOWN_SMALL;
         }
     }
-    pd.prev_locked = locked;
+    pd.prev_locked = (int8_t)locked;
 }
 template <int NC>
 RLG_HD void pads_lock(Arena<NC>& A, int ci, uint64_t mask) {
-    for (int p = 0; p < 34; p++) if ((mask >> p) & 1ull) A.pads[p].cur_locked = ci + 1;
+    for (int p = 0; p < 34; p++) if ((mask >> p) & 1ull) A.pads[p].cur_locked = (int8_t)(ci + 1);
 }
 
 // ---- Arena::Step, one tick (Arena.cpp:716-812) ---------------------------------------------------------
@@ -1113,7 +1114,7 @@ RLG_HD void collide_compact_and_run(const Arena<NC>& A, MeshView mesh, CollideQu
     int n = 0;
     auto consider = [&](int k) {
         if (!collide_test_candidate(A, mesh, Q, k)) return;
-        if (n < ITEM_CAP) Q.items[n] = unpack_cand(Q.cand[k]); else Q.overflow = 1;
+        if (n < ITEM_CAP) Q.items[n] = unpack_cand(queue_cand(Q, k)); else Q.overflow = 1;
         n++;
     };
     for (int body = 0; body <= NC; body++) for (int i = 0; i < Q.cand_count[body]; i++) consider(CollideQueue<NC>::region(body) + i);

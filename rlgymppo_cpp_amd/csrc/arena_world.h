@@ -161,22 +161,51 @@ constexpr int FRONTIER_CAP = RLG_FRONTIER_CAP;       // BVH nodes per level of t
 #ifndef RLG_BODY_CAND
 #define RLG_BODY_CAND 128   /* (96 until the tessellated arena -- 10 k triangles -- overflowed a car's region 5 times per 1000 env-ticks) */
 #endif
+static_assert(RLG_BODY_CAND % 4 == 0, "whole leaves");
 constexpr int BALL_CAND = RLG_BODY_CAND, CAR_CAND = RLG_BODY_CAND, PAIR_SLOTS = 16;   // candidate slots: 24 leaves per body (measured: <= 22 leaves per env; 12 were not enough for the ball in the corners)
+constexpr int CACHE_LEAVES = BALL_CAND / LEAF_SLOTS;   // leaves per body the device keeps
+RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
+// Candidate k of an env: the slots [region(b), region(b) + cand_count[b]) belong to body b (0 = ball, 1 + i = car i), the car pairs sit at
+// PAIR_BASE.  The host build keeps every slot as a word.  The device build (RLG_QUEUE_LEAVES) keeps a body's LEAVES -- first triangle |
+// count << 24, a block of LEAF_SLOTS slots each, unused slots are holes -- and derives slot k from them (queue_cand): a quarter of the LDS.
+// Device member order: what the item phase still needs first (items, pool); the walk's frontier, the boxes and the leaves -- dead by then --
+// last, so that together with what the solver rows add to the union (TickWork) they are one free stretch for the EPA arenas.
 template <int NC>
 struct CollideQueue {
     static constexpr int NB = NC + 1;
     static constexpr int PAIR_BASE = BALL_CAND + NC * CAR_CAND;
     int n_items, n_pool, overflow, n_pairs;
-    uint16_t cand_count[8];    // candidates of body b (0 = ball, 1 + i = car i) are cand[region(b) .. + cand_count[b]); pairs at PAIR_BASE
+    uint16_t cand_count[8];
+#ifdef RLG_QUEUE_LEAVES
+    CollideItem items[ITEM_CAP];
+    Cand pool[POOL_CAP];
     uint32_t frontier[2][FRONTIER_CAP];   // breadth-first BVH walk: (body << 16 | node) of the current and of the next level
     V3 box_lo[NB], box_hi[NB];            // the bodies' query boxes during the device walk
+    uint32_t leaf[NB][CACHE_LEAVES];      // this tick's leaves per body, ascending first triangle (= the reference's visiting order)
+    uint32_t pair[PAIR_SLOTS];            // type << 28 | a << 24 | b
+#else
+    uint32_t frontier[2][FRONTIER_CAP];
+    V3 box_lo[NB], box_hi[NB];
     uint32_t cand[PAIR_BASE + PAIR_SLOTS];   // type << 28 | a << 24 | ref
     CollideItem items[ITEM_CAP];
     Cand pool[POOL_CAP];
+#endif
     static RLG_HD int region(int body) { return body == 0 ? 0 : BALL_CAND + (body - 1) * CAR_CAND; }
     static RLG_HD int region_cap(int body) { return body == 0 ? BALL_CAND : CAR_CAND; }
 };
-RLG_HD uint32_t pack_cand(int type, int a, int ref) { return ((uint32_t)type << 28) | ((uint32_t)a << 24) | (uint32_t)ref; }
+template <int NC>
+RLG_HD uint32_t queue_cand(const CollideQueue<NC>& Q, int k) {
+#ifdef RLG_QUEUE_LEAVES
+    if (k >= CollideQueue<NC>::PAIR_BASE) return Q.pair[k - CollideQueue<NC>::PAIR_BASE];
+    const int body = k < BALL_CAND ? 0 : 1 + (k - BALL_CAND) / CAR_CAND;
+    const int slot = k - CollideQueue<NC>::region(body);
+    const uint32_t lf = Q.leaf[body][slot / LEAF_SLOTS];
+    const int q = slot % LEAF_SLOTS, first = (int)(lf & 0xFFFFFFu), cnt = (int)(lf >> 24);
+    return q < cnt ? pack_cand(body == 0 ? 0 : 1, body == 0 ? 0 : body - 1, first + q) : CAND_HOLE;
+#else
+    return Q.cand[k];
+#endif
+}
 RLG_HD CollideItem unpack_cand(uint32_t c) {
     CollideItem it; it.type = (int16_t)(c >> 28); it.a = (int16_t)((c >> 24) & 15u); it.ref = (int32_t)(c & 0xFFFFFFu); it.off = 0; it.n = 0;
     return it;
@@ -192,17 +221,27 @@ RLG_HD int fetch_add(int& x, int v) {
 }
 
 template <int NC>
-RLG_HD void queue_candidates(CollideQueue<NC>& Q, int body, int first, int cnt) {
+RLG_HD void queue_candidates(CollideQueue<NC>& Q, int body, int first, int cnt) {   // host form of the walk (the device's: rlgpu_env.hip build_candidates_wave)
     int k = Q.cand_count[body];
+#ifdef RLG_QUEUE_LEAVES
+    if (k / LEAF_SLOTS >= CACHE_LEAVES) { Q.overflow = 1; return; }
+    Q.leaf[body][k / LEAF_SLOTS] = (uint32_t)first | ((uint32_t)cnt << 24);
+    Q.cand_count[body] = (uint16_t)(k + LEAF_SLOTS);
+#else
     if (k + cnt > CollideQueue<NC>::region_cap(body)) { Q.overflow = 1; return; }
     Q.cand_count[body] = (uint16_t)(k + cnt);
     const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
     for (int q = 0; q < cnt; q++) Q.cand[CollideQueue<NC>::region(body) + k + q] = pack_cand(type, a, first + q);
+#endif
 }
 template <int NC>
 RLG_HD void queue_pair(CollideQueue<NC>& Q, int ia, int ib) {
     if (Q.n_pairs >= PAIR_SLOTS) { Q.overflow = 1; return; }
+#ifdef RLG_QUEUE_LEAVES
+    Q.pair[Q.n_pairs++] = pack_cand(2, ia, ib);
+#else
     Q.cand[CollideQueue<NC>::PAIR_BASE + Q.n_pairs++] = pack_cand(2, ia, ib);
+#endif
 }
 
 // every BVH leaf whose box overlaps [lo,hi], in walk order: f(first triangle, count)
@@ -436,7 +475,7 @@ RLG_HD void ray_key_min(unsigned long long& key, unsigned long long v) {
 template <class QT>
 RLG_HD void ray_apply_mesh_key(MeshView mesh, const QT& Q, unsigned long long key, V3 from, V3 to, RayHit& best) {
     if (key == RAY_NO_HIT) return;
-    const MeshTri& t = mesh.tris[unpack_cand(Q.cand[(uint32_t)key]).ref];
+    const MeshTri& t = mesh.tris[unpack_cand(queue_cand(Q, (int)(uint32_t)key)).ref];
     RayHit h; h.kind = -1; h.frac = best.frac; h.normal = v3(0, 0, 0);
     ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, h);
     if (h.kind == 0) best = h;   // recomputed from the winning triangle: same frac, and its ray-facing normal

@@ -274,21 +274,21 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 // rlgpu_policy_act with use_bf16 = 0 runs every layer through k_gemm<false> (rlgpu_learn.hip): v_mfma_f32_32x32x2_f32 over k = 0, 2, 4, ...
 // (lane l holds A[row l & 31][k + (l >> 5)] and B[k + (l >> 5)][col l & 31]), operands zero-padded to a multiple of 32 inputs, bias added
 // and ReLU applied to the fp32 accumulator.  A row's value depends on nothing but its own operands and that order, so the same instruction
-// sequence on one wavefront gives the batched call's bits.  Activations stay fp32 in LDS; a buffer is two HALVES (the step kernels lend
-// the TickWork areas of different envs): rows [0, RH) in half0, [RH, R) in half1.
-struct F32Buf { float* half0; float* half1; };
-template <int R>
-__device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) { constexpr int RH = (R + 1) / 2; return r < RH ? b.half0 + r * ld : b.half1 + (r - RH) * ld; }
-__host__ __device__ constexpr int f32_half_bytes(int rows, int ld) { return ((rows + 1) / 2) * (ld > LOGIT_LD ? ld : LOGIT_LD) * 4; }
+// sequence on one wavefront gives the batched call's bits.  Activations stay fp32 in LDS; a buffer is two or three PARTS (the step kernels lend
+// the TickWork areas of different envs) of ceil(R / NP) rows each.
+struct F32Buf { float* part[3]; };   // NP = 2 or 3 parts of ceil(R / NP) rows each
+template <int R, int NP>
+__device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) { constexpr int RP = (R + NP - 1) / NP; return b.part[r / RP] + (r % RP) * ld; }
+__host__ __device__ constexpr int f32_part_bytes(int rows, int np, int ld) { return ((rows + np - 1) / np) * (ld > LOGIT_LD ? ld : LOGIT_LD) * 4; }
 
-template <int R>
+template <int R, int NP>
 __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, F32Buf in, F32Buf out, int lane, int (&picked)[R]) {
     static_assert(R <= WAVE_ROWS, "a wavefront infers at most 16 rows");
     constexpr int CH = 16;                               // MFMA steps (2 inputs each) whose B operands are in flight together
     const int ld = net.ld;
     for (int r = 0; r < R; r++) {
         const int rr = r < n_rows ? r : n_rows - 1;
-        float* dst = f32_row<R>(in, r, ld);
+        float* dst = f32_row<R, NP>(in, r, ld);
         for (int c = lane; c < net.K[0]; c += 64) dst[c] = c < net.D ? obs[(size_t)rr * net.D + c] : 0.f;
     }
     wave_fence();
@@ -298,7 +298,7 @@ __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadAr
         const int N = net.N[i], Kt = net.Kf[i];
         const int steps = ((Kt + 31) / 32) * 16;         // k_gemm pads the reduction to whole 32-wide tiles (zeros: they leave the accumulator as it is)
         const int nblk = last ? (N + 31) / 32 : net.Npad[i] / 32;
-        const float* arow = f32_row<R>(in, cl < R ? cl : 0, ld);    // tile rows >= R re-read row 0 (independent, never stored)
+        const float* arow = f32_row<R, NP>(in, cl < R ? cl : 0, ld);    // tile rows >= R re-read row 0 (independent, never stored)
         for (int cb = 0; cb < nblk; cb++) {
             const int col = cb * 32 + cl;
             const float* wrow = net.Wf[i] + (size_t)(col < N ? col : 0) * Kt;
@@ -327,8 +327,8 @@ __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadAr
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row >= R) continue;
                 float v = acc[r] + bias;
-                if (last) { if (col < LOGIT_LD) f32_row<R>(out, row, LOGIT_LD)[col] = v; }
-                else f32_row<R>(out, row, ld)[col] = col_ok ? fmaxf(v, 0.f) : 0.f;
+                if (last) { if (col < LOGIT_LD) f32_row<R, NP>(out, row, LOGIT_LD)[col] = v; }
+                else f32_row<R, NP>(out, row, ld)[col] = col_ok ? fmaxf(v, 0.f) : 0.f;
             }
         }
         wave_fence();
@@ -336,7 +336,7 @@ __device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadAr
     }
     const float* zs[R]; int rows[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = f32_row<R>(in, rr, LOGIT_LD); rows[r] = row0 + rr; }
+    for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = f32_row<R, NP>(in, rr, LOGIT_LD); rows[r] = row0 + rr; }
     const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
     policy_head_batched<R>(zc, rows, lane, head, picked);
 }

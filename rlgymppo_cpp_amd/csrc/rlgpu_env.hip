@@ -18,6 +18,7 @@
 #define RLG_WAVES_PER_BLOCK 1
 #endif
 #define RLG_TICKWORK_OVERLAY 1   /* arena_step.h TickWork: the car tick context shares its LDS bytes with the contact list */
+#define RLG_QUEUE_LEAVES 1       /* arena_world.h CollideQueue: candidates are kept as BVH leaves, a slot's word is derived */
 #define RLG_WAVES_PER_BLOCK_DEFAULTED RLG_WAVES_PER_BLOCK
 #ifdef RLG_TICK_PROFILE
 // profiler build only (make PROFILE=1 -> librlgpu_prof.so): per-workgroup phase accumulators fed by RLG_PROF(i) in arena_step.h
@@ -126,7 +127,7 @@ constexpr int WAVE = 64;
 #define RLG_LDS_BUDGET (40 * 1024)
 #endif
 #ifndef RLG_LDS_NODES
-#define RLG_LDS_NODES 36    /* (192 before the candidate cache took 1.5 KB of the 1v1 workgroup's LDS, 144 before the boost pad tables took 456 B, 136 before the candidate / item caps grew for fine meshes: 128 slots per body, 48 items) */
+#define RLG_LDS_NODES 16    /* the FEWEST BVH top nodes a workgroup stages (staged_nodes<NC>() takes what its envs leave of the budget, up to 192) */
 #endif
 #ifndef RLG_WAVES_PER_SIMD
 #define RLG_WAVES_PER_SIMD 1
@@ -136,7 +137,13 @@ constexpr int WAVE = 64;
 #endif
 constexpr int WPB = RLG_WAVES_PER_BLOCK;   // wavefronts per workgroup: they share the staged mesh, each owns lanes_per_block / WPB envs
 constexpr int LDS_BUDGET = RLG_LDS_BUDGET;
-constexpr int LDS_NODES = RLG_LDS_NODES;   // BVH top levels staged per workgroup (the occupancy grid prunes most walks)
+constexpr int LDS_NODES = RLG_LDS_NODES;   // BVH top levels staged per workgroup at least (the occupancy grid prunes most walks)
+// Envs per wavefront at most.  1v1: BASELINE's shape is 4096 envs per GPU = ONE wavefront of four envs on each of the 1024 SIMDs; a fifth env
+// per wavefront would fit the LDS but leaves a fifth of the SIMDs idle while every wavefront takes ~10 % longer (measured: 10.3 M -> 10.0 M
+// agent-steps/s).  Batches of 16 K envs and more gain 13 % ticks/s with -DRLG_MAX_EPW_1V1=5.
+#ifndef RLG_MAX_EPW_1V1
+#define RLG_MAX_EPW_1V1 4
+#endif
 
 struct EnvDev {
     uint32_t* words;      // [n_words][n_envs]
@@ -148,6 +155,7 @@ struct EnvDev {
     int n_envs;
     float* step_stats;           // rlgpu_env_enable_step_stats: {player-steps, sum |car vel| (uu/s), ball touches, airborne} accumulated by the step kernels, or null
     unsigned char* epa_big;      // [wavefronts of a step launch][EPA_BIG_BYTES]: full-size penetration-depth arenas (arena_epa.h), or null
+    uint32_t* leaf_cache;        // [n_envs][NC + 1][CACHE_LEAVES]: the candidate leaves kept over the ticks of a launch (CandCache)
     RlgpuArenaState* snap_out;   // host-plugin fallback (rlgpu_env_enable_snapshots): every step's GameState source, [n_envs], or null
 };
 
@@ -164,13 +172,18 @@ struct EnvDev {
 #define RLG_CAND_FAT 2.0f          // Bullet units (100 uu); measured 1.0 / 2.0 / 3.0: collection launch 23.0 / 22.4 / 22.65 ms (23.4 without the cache)
 #endif
 constexpr float CAND_FAT = RLG_CAND_FAT;
-constexpr int CACHE_LEAVES = BALL_CAND / LEAF_SLOTS;
 static_assert(BALL_CAND == CAR_CAND, "one leaf capacity for every body");
+// The kept leaves themselves (first triangle | count << 24, ascending = the reference's visiting order): a tick that does not walk copies
+// them into its queue (CollideQueue::leaf).  Where the wavefront's envs leave LDS to spare (1v1 at four envs per wavefront) they stay in
+// LDS; otherwise in global memory (EnvDev::leaf_cache, [env][body][CACHE_LEAVES]: one extra round trip per tick, which buys the third 2v2 /
+// second 3v3 env of a wavefront).
+template <int NC>
+constexpr bool leaves_in_lds() { return NC == 2 && RLG_MAX_EPW_1V1 <= 4; }
 template <int NC>
 struct CandCache {
     static constexpr int NB = NC + 1;
     V3 lo[NB], hi[NB];                    // the fat boxes the lists were walked for
-    uint32_t leaf[NB][CACHE_LEAVES];      // first triangle | count << 24, ascending (= the reference's visiting order)
+    uint32_t leaf[leaves_in_lds<NC>() ? NB : 1][leaves_in_lds<NC>() ? CACHE_LEAVES : 1];
     uint8_t n[NB];                        // leaves of body b
     uint8_t active;                       // bit b: body b had a query box then
     uint8_t valid;                        // 0: walk again (cleared when a launch loads the env)
@@ -188,10 +201,17 @@ constexpr int lanes_per_block() {
 #endif
     // as many envs per wavefront as the workgroup's LDS budget holds, at most 8 (bank-conflict-free lane strides), one lane per wheel
     // (64 / (4 NC)), and the rows of one inference tile (a wavefront infers its own envs' agents: rlinfer::WAVE_ROWS)
-    int epw = 8;
+    int epw = NC == 2 ? RLG_MAX_EPW_1V1 : 8;
     while (epw > 1 && ((size_t)epw * WPB * lane_stride<NC>() + (size_t)LDS_NODES * sizeof(BvhNode) + (GRID_WORDS + PAD_TAB_WORDS) * 4 > (size_t)LDS_BUDGET
                        || epw * NC * 4 > WAVE || epw * NC > rlinfer::WAVE_ROWS)) epw--;
     return epw * WPB;
+}
+// BVH top nodes a workgroup stages: what its envs leave of the LDS budget, in steps of 8 nodes, at most 192
+template <int NC>
+constexpr int staged_nodes() {
+    const size_t used = (size_t)lanes_per_block<NC>() * lane_stride<NC>() + (GRID_WORDS + PAD_TAB_WORDS) * 4 + 256;   // (256: the few other __shared__ words)
+    int n = used < (size_t)LDS_BUDGET ? (int)(((size_t)LDS_BUDGET - used) / sizeof(BvhNode)) / 8 * 8 : 0;
+    return n > 192 ? 192 : (n < LDS_NODES ? LDS_NODES : n);
 }
 
 template <int NC>
@@ -206,10 +226,10 @@ __device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G)
     arena_visit(A, G, w);
 }
 
-__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* lds_grid, uint32_t* lds_pad) {
+__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage, uint32_t* lds_grid, uint32_t* lds_pad) {
     if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
     for (int i = threadIdx.x; i < PAD_TAB_WORDS; i += blockDim.x) lds_pad[i] = d.pad_tab[i];
-    int n_fast = d.n_nodes < LDS_NODES ? d.n_nodes : LDS_NODES;
+    int n_fast = d.n_nodes < n_stage ? d.n_nodes : n_stage;
     // 32-byte nodes copied as 2 x 16-byte vectors per lane: coalesced global reads, conflict-free ds_write_b128
     const float4* src = reinterpret_cast<const float4*>(d.nodes);
     float4* dst = reinterpret_cast<float4*>(lds_nodes);
@@ -218,6 +238,7 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, uint32_t* ld
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
     mv.grid = d.grid ? lds_grid : nullptr;
     mv.bp = d.grid ? d.grid + GRID_WORDS : nullptr;
+    mv.leaf_cache = d.leaf_cache;
     return mv;
 }
 
@@ -310,8 +331,11 @@ constexpr size_t EPA_BIG_BYTES = (epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MA
 // the wavefront's penetration-depth arenas (see the top of this file): called once per launch by every kernel that ticks
 template <int NC>
 __device__ __forceinline__ void epa_arenas_setup(const EnvDev& d, unsigned char* wmem) {
-    using Q = CollideQueue<NC>;
-    static_assert(offsetof(Q, items) - offsetof(Q, frontier) >= epa_arena_bytes(RLG_EPA_LDS_V, RLG_EPA_LDS_F), "the small EPA arena borrows the frontier / box / candidate part of a CollideQueue");
+    using Q = CollideQueue<NC>; using TW = TickWork<NC>;
+    // free during the narrowphase: the queue's walk part (frontier, boxes, leaves, pairs are all consumed by the item compaction), what the
+    // solver rows add to the union behind it, and the solver bodies
+    static_assert(offsetof(TW, B) + sizeof(((TW*)nullptr)->B) - (offsetof(TW, Q) + offsetof(Q, frontier)) >= epa_arena_bytes(RLG_EPA_LDS_V, RLG_EPA_LDS_F) + 16,
+                  "the small EPA arena borrows the stretch from a CollideQueue's frontier to the end of the solver bodies");
     static_assert(offsetof(Q, frontier) % 4 == 0, "arena alignment");
     if ((threadIdx.x & 63) == 0) {
         const int wave = threadIdx.x >> 6;
@@ -328,7 +352,7 @@ __device__ __forceinline__ void epa_arenas_setup(const EnvDev& d, unsigned char*
 // triangles are appended in frontier order, so per body the sequence equals a walk of its own.  Ballots are group-local
 // slices of wave-wide ones, so every loop below is wave-uniform.
 template <int NC>
-__device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, MeshView mv) {
+__device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, MeshView mv, uint32_t* leaf_cache, int env0) {
     constexpr int EPW = lanes_per_block<NC>() / WPB, LPE = WAVE / EPW, NB = NC + 1;
     static_assert(NB <= LPE, "one lane per body for the query boxes");
     const int tid = threadIdx.x & 63, e = tid / LPE, li = tid % LPE;
@@ -336,6 +360,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     LaneBlock<NC>& S = lane_block<NC>(lane_mem, grp ? e : 0);
     CollideQueue<NC>& Q = S.W.Q;
     CandCache<NC>& C = S.C;
+    uint32_t* const gleaf = leaf_cache + (size_t)(env0 + (grp ? e : 0)) * NB * CACHE_LEAVES;
     const int gshift = e * LPE;
     const unsigned long long gmask = ~0ull >> (64 - LPE);
     const unsigned long long below = (1ull << li) - 1ull;
@@ -406,7 +431,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                     if (mine) {
                         const int k = cnt_b[b] + __popcll(ml & below);
                         if (k >= CACHE_LEAVES) { ovf = true; if (attempt == 1) RLG_DBG_COUNT(1 + (b > 0)); }
-                        else C.leaf[b][k] = (uint32_t)first | ((uint32_t)cnt << 24);
+                        else Q.leaf[b][k] = (uint32_t)first | ((uint32_t)cnt << 24);
                     }
                     cnt_b[b] += __popcll(ml);
                 }
@@ -429,9 +454,9 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                     const int k = li + r * LPE;
                     mine[b][r] = 0; rank[b][r] = -1;
                     if (k < nl) {
-                        const uint32_t v = C.leaf[b][k]; const uint32_t f = v & 0xFFFFFFu;
+                        const uint32_t v = Q.leaf[b][k]; const uint32_t f = v & 0xFFFFFFu;
                         int below_me = 0;
-                        for (int j = 0; j < nl; j++) below_me += ((C.leaf[b][j] & 0xFFFFFFu) < f) ? 1 : 0;
+                        for (int j = 0; j < nl; j++) below_me += ((Q.leaf[b][j] & 0xFFFFFFu) < f) ? 1 : 0;
                         mine[b][r] = v; rank[b][r] = below_me;
                     }
                 }
@@ -440,7 +465,13 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
-                for (int r = 0; r < PER; r++) if (rank[b][r] >= 0) C.leaf[b][rank[b][r]] = mine[b][r];
+                for (int r = 0; r < PER; r++) {
+                    if (rank[b][r] < 0) continue;
+                    Q.leaf[b][rank[b][r]] = mine[b][r];
+                    if (attempt == 0) {   // kept for the ticks that do not walk (C.valid below)
+                        if constexpr (leaves_in_lds<NC>()) C.leaf[b][rank[b][r]] = mine[b][r]; else gleaf[b * CACHE_LEAVES + rank[b][r]] = mine[b][r];
+                    }
+                }
         }
         if (go && li == 0) {
 #pragma unroll
@@ -450,15 +481,13 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         }
         wave_sync();
     }
-    // this tick's candidate slots from the kept leaves: a fixed block of LEAF_SLOTS slots per leaf in the body's region (unused slots are holes)
-    if (grp && !overflow) {
+    // a tick that did not walk takes the kept leaves (a block of LEAF_SLOTS candidate slots per leaf in the body's region: queue_cand)
+    if (grp && !walk && !overflow) {
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const int nl = ((C.active >> b) & 1u) ? (int)C.n[b] : 0;
             for (int k = li; k < nl; k += LPE) {
-                const uint32_t lf = C.leaf[b][k];
-                const int first = (int)(lf & 0xFFFFFFu), cnt = (int)(lf >> 24);
-                for (int q = 0; q < LEAF_SLOTS; q++) Q.cand[CollideQueue<NC>::region(b) + k * LEAF_SLOTS + q] = q < cnt ? pack_cand(b == 0 ? 0 : 1, b == 0 ? 0 : b - 1, first + q) : CAND_HOLE;
+                if constexpr (leaves_in_lds<NC>()) Q.leaf[b][k] = C.leaf[b][k]; else Q.leaf[b][k] = gleaf[b * CACHE_LEAVES + k];
             }
         }
     }
@@ -494,9 +523,9 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
     RLG_PROF(0); RLG_FPROF(0);
-    build_candidates_wave<NC>(lane_mem, n_valid, mv);
+    build_candidates_wave<NC>(lane_mem, n_valid, mv, mv.leaf_cache, env0);
 #ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
-    build_candidates_wave<NC>(lane_mem, n_valid, mv);
+    build_candidates_wave<NC>(lane_mem, n_valid, mv, mv.leaf_cache, env0);
 #endif
     RLG_PROF(1); RLG_FPROF(1); phase_sync(2);
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
@@ -562,7 +591,7 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
                     const unsigned long long m = (__ballot(pass) >> (e_item * LPE)) & (~0ull >> (64 - LPE));
                     if (pass) {
                         const int pos = base + __popcll(m & ((1ull << l_item) - 1ull));
-                        if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(Q.cand[k]); else { Q.overflow = 1; RLG_DBG_COUNT(3); }
+                        if (pos < ITEM_CAP) Q.items[pos] = unpack_cand(queue_cand(Q, k)); else { Q.overflow = 1; RLG_DBG_COUNT(3); }
                     }
                     base += __popcll(m);
                 }
@@ -657,10 +686,10 @@ template <int NC>
 __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
-    __shared__ BvhNode lds_nodes[LDS_NODES];
+    __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);   // every thread of the workgroup helps staging
+    MeshView mv = stage_mesh(d, lds_nodes, staged_nodes<NC>(), lds_grid, lds_pad);   // every thread of the workgroup helps staging
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     const bool env_lane = ws.lane < n_valid;
@@ -733,10 +762,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #endif
     static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
-    __shared__ BvhNode lds_nodes[LDS_NODES];
+    __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);
+    MeshView mv = stage_mesh(d, lds_nodes, staged_nodes<NC>(), lds_grid, lds_pad);
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     if (n_valid == 0) return;
@@ -778,18 +807,19 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         prof_mlp += prof_mid - prof_a;
 #else
         if (c.net.fp32) {
-            // exact-parity mode: fp32 activations, a buffer = two halves in the TickWork areas of different envs (EPW >= 4), or both in one
-            constexpr int HB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
-            unsigned char* const a0 = w0;
-            unsigned char* const a1 = EPW >= 2 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 1).W) : w0 + HB;
-            unsigned char* const a2 = EPW >= 4 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, EPW >= 4 ? 2 : 0).W) : (EPW >= 2 ? a0 + HB : w0 + 2 * HB);
-            unsigned char* const a3 = EPW >= 4 ? reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, EPW >= 4 ? 3 : 0).W) : (EPW >= 2 ? a1 + HB : w0 + 3 * HB);
-            // (EPW >= 4: in = {env 0, env 1}, out = {env 2, env 3}; EPW = 2: in = env 0's two halves, out = env 1's; EPW = 1: four quarters of the one area)
-            rlinfer::F32Buf fin, fout;
-            if (EPW >= 4) { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a1)}; fout = {reinterpret_cast<float*>(a2), reinterpret_cast<float*>(a3)}; }
-            else if (EPW >= 2) { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a2)}; fout = {reinterpret_cast<float*>(a1), reinterpret_cast<float*>(a3)}; }
-            else { fin = {reinterpret_cast<float*>(a0), reinterpret_cast<float*>(a1)}; fout = {reinterpret_cast<float*>(a2), reinterpret_cast<float*>(a3)}; }
-            rlinfer::wave_infer_f32<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, ws.lane, picked);
+            // exact-parity mode: fp32 activations; a buffer = NP parts of ceil(R / NP) rows, lent by the TickWork areas (dead between ticks):
+            // EPW >= 4: in = envs 0, 1, out = envs 2, 3; EPW = 3: six thirds, two per area; EPW = 2: in = env 0's two halves, out = env 1's;
+            // EPW = 1: four quarters of the one area
+            constexpr int NP = EPW == 3 ? 3 : 2;
+            constexpr int PB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
+            auto area = [&](int k) { return reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k < EPW ? k : 0).W); };
+            rlinfer::F32Buf fin{}, fout{};
+            auto f = [](unsigned char* p) { return reinterpret_cast<float*>(p); };
+            if (EPW >= 4) { fin = {{f(area(0)), f(area(1)), nullptr}}; fout = {{f(area(2)), f(area(3)), nullptr}}; }
+            else if (EPW == 3) { fin = {{f(area(0)), f(area(0) + PB), f(area(1))}}; fout = {{f(area(1) + PB), f(area(2)), f(area(2) + PB)}}; }
+            else if (EPW == 2) { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(1)), f(area(1) + PB), nullptr}}; }
+            else { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(0) + 2 * PB), f(area(0) + 3 * PB), nullptr}}; }
+            rlinfer::wave_infer_f32<R, NP>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, ws.lane, picked);
         } else
         rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked);
 #endif
@@ -851,10 +881,10 @@ template <int NC>
 __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
-    __shared__ BvhNode lds_nodes[LDS_NODES];
+    __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
     __shared__ uint32_t lds_grid[GRID_WORDS];
     __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
-    MeshView mv = stage_mesh(d, lds_nodes, lds_grid, lds_pad);
+    MeshView mv = stage_mesh(d, lds_nodes, staged_nodes<NC>(), lds_grid, lds_pad);
     const WaveSlot ws = wave_slot<NC>(lane_mem, d.n_envs);
     unsigned char* const wmem = ws.mem; const int env0 = ws.env0, n_valid = ws.n_valid;
     const bool env_lane = ws.lane < n_valid;
@@ -1040,6 +1070,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
         const size_t waves = (size_t)(e->nc == 2 ? env_grid<2>(n_envs) : (e->nc == 4 ? env_grid<4>(n_envs) : env_grid<6>(n_envs))) * WPB;
         HIPCHK(e, hipMalloc(&e->d_epa_big, waves * EPA_BIG_BYTES));
         e->d.epa_big = e->d_epa_big;
+        HIPCHK(e, hipMalloc(&e->d.leaf_cache, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));   // CandCache: 0.4 - 0.9 KB per env
     }
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     return RLGPU_OK;
@@ -1057,6 +1088,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
     if (e->d_epa_big) (void)hipFree(e->d_epa_big);
+    if (e->d.leaf_cache) (void)hipFree(e->d.leaf_cache);
     if (e->d.step_stats) (void)hipFree(e->d.step_stats);
     for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
@@ -1283,10 +1315,10 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;
     const size_t tw = e->nc == 2 ? sizeof(TickWork<2>) : (e->nc == 4 ? sizeof(TickWork<4>) : sizeof(TickWork<6>));
     const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
-    const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one half of an activation buffer may take
+    const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one part of an activation buffer may take
     int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
     if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(epw * e->nc, c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
-    if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_half_bytes(epw * e->nc, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
+    if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_part_bytes(epw * e->nc, epw == 3 ? 3 : 2, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
     if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
     if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;

@@ -1355,7 +1355,7 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
         const Net& n = l->pol;
         int maxk = 0;
         for (int i = 0; i < n.n_layers; i++) maxk = std::max(maxk, (n.dims[i] + 31) / 32 * 32);
-        if (max_buf_bytes >= 0) return RLGPU_ERR_STATE;    // (the caller checks the half-buffer size against its row count: f32_half_bytes)
+        if (max_buf_bytes >= 0) return RLGPU_ERR_STATE;    // (the caller checks the buffer parts against its row count: f32_part_bytes)
         net->n_layers = n.n_layers; net->D = l->cfg.obs_size; net->ld = maxk + 8; net->fp32 = 1;
         for (int i = 0; i < n.n_layers; i++) {
             net->W[i] = nullptr; net->bias[i] = l->params + n.b_off[i];
