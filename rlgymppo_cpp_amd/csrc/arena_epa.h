@@ -79,6 +79,13 @@ struct EpaArena {
     uint16_t* stack;                              // [cap_f]: the recursion of EPA::expand
     int cap_v, cap_f;
 };
+
+// Address-space hints (device builds): RLG_EPA_IN_LDS(x) tells the optimiser that x lives in LDS -- ds_read / ds_write instead of flat
+// accesses -- in the instantiations that only ever see the LDS arenas.
+#ifndef RLG_EPA_IN_LDS
+#define RLG_EPA_IN_LDS(ref) ((void)0)
+#endif
+#define RLG_EPA_ARENA_IN_LDS(A) do { RLG_EPA_IN_LDS(*(A).sh); RLG_EPA_IN_LDS(*(A).g); RLG_EPA_IN_LDS(*(A).run); RLG_EPA_IN_LDS(*(A).res); RLG_EPA_IN_LDS(*(A).sv); RLG_EPA_IN_LDS(*(A).fc); RLG_EPA_IN_LDS(*(A).stack); } while (0)
 constexpr size_t epa_arena_bytes(int cap_v, int cap_f) {
     return sizeof(EpaShapes) + sizeof(EpaGjkState) + sizeof(EpaRun) + sizeof(EpaResult) + sizeof(EpaSV) * (size_t)(4 + cap_v) + sizeof(EpaFace) * (size_t)cap_f + 2 * (size_t)cap_f + 16;
 }
@@ -128,6 +135,7 @@ RLG_HD V3 epa_support1(const EpaShapes& s, V3 d, bool margins) {   // m_toshape0
 }
 RLG_HD V3 epa_support(const EpaShapes& s, V3 d, bool margins) { return epa_support0(s, d, margins) - epa_support1(s, -d, margins); }
 RLG_HD_NOINLINE void epa_getsupport(const EpaShapes& s, bool margins, V3 d, EpaSV& sv) {   // GJK::getsupport (:422-426)
+    RLG_EPA_IN_LDS(s); RLG_EPA_IN_LDS(sv);
     sv.d = vdiv_bt(d, len(d));
     sv.w = epa_support(s, sv.d, margins);
 }
@@ -223,6 +231,7 @@ RLG_HD_NOINLINE float epa_project4(V3 a, V3 b, V3 c, V3 d, EpaW4& w, uint32_t& m
 
 // GJK::Evaluate (:204-347).  The simplices hold their vertices by value (the reference's pointer / free-list bookkeeping only shares them).
 RLG_HD_NOINLINE int epa_gjk_evaluate(EpaGjkState& G, const EpaShapes& sh, bool margins, V3 guess) {
+    RLG_EPA_IN_LDS(G); RLG_EPA_IN_LDS(sh);
     int iterations = 0;
     float sqdist = 0.f, alpha = 0.f;
     int clastw = 0;
@@ -321,6 +330,7 @@ RLG_HD bool epa_enclose2(EpaGjkState& G, const EpaShapes& sh, bool margins) {
     return false;
 }
 RLG_HD_NOINLINE bool epa_enclose_origin(EpaGjkState& G, const EpaShapes& sh, bool margins) {
+    RLG_EPA_IN_LDS(G); RLG_EPA_IN_LDS(sh);
     const int r = G.rank[G.cur];
     if (r == 2) return epa_enclose2(G, sh, margins);
     if (r == 3) return epa_enclose3(G, sh, margins);
@@ -370,6 +380,7 @@ RLG_HD bool epa_edge_dist(V3 fn, V3 aw, V3 bw, float& dist) {   // EPA::getedged
 }
 // EPA::newface (:780-824); -1 = none (m_status says why)
 RLG_HD_NOINLINE int epa_newface(EpaArena A, int a, int b, int c, bool forced) {
+    RLG_EPA_ARENA_IN_LDS(A);
     EpaRun& E = *A.run;
     int face;
     if (E.free_root >= 0) { face = E.free_root; E.free_root = epa_link_next(A.fc[face].links); }
@@ -410,6 +421,7 @@ RLG_HD int epa_findbest(const EpaArena& A) {   // EPA::findbest (:825-839)
 struct EpaHorizon { int cf, ff, nf; };
 // EPA::expand (:840-871), its recursion unrolled onto A.stack: entry = face | edge << 8 | stage << 10
 RLG_HD_NOINLINE bool epa_expand(EpaArena A, int pass, int w, int f0, int e0, EpaHorizon& hz) {
+    RLG_EPA_ARENA_IN_LDS(A);
     EpaRun& E = *A.run;
     uint16_t* st = A.stack; int sp = 0;
     st[sp++] = (uint16_t)(f0 | (e0 << 8));
@@ -458,6 +470,7 @@ RLG_HD_NOINLINE bool epa_expand(EpaArena A, int pass, int w, int f0, int e0, Epa
 
 // EPA::Evaluate (:648-742); the result goes to *A.res
 RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
+    RLG_EPA_ARENA_IN_LDS(A);
     EpaGjkState& G = *A.g; const EpaShapes& sh = *A.sh; EpaResult& out = *A.res;
     EpaRun& E = *A.run; E.status = EPA_FAILED; E.hull_root = -1; E.hull_count = 0; E.free_root = -1; E.next_fresh = 0; E.nextsv = 0; E.arena_full = false;
     if ((G.rank[G.cur] > 1) && epa_enclose_origin(G, sh, margins)) {
@@ -548,6 +561,7 @@ RLG_HD_NOINLINE int epa_evaluate(EpaArena A, bool margins, V3 guess) {
 // distance), EPA_ARENA_FULL: repeat in a bigger arena.
 struct PenDepth { V3 v, wa, wb; };
 RLG_HD int epa_calc_pen_depth(EpaArena A, const EpaShapes& shapes, PenDepth& out) {
+    RLG_EPA_ARENA_IN_LDS(A);
     *A.sh = shapes;
     const EpaShapes& sh = *A.sh;
     EpaGjkState& G = *A.g;

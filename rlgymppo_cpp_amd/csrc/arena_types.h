@@ -241,7 +241,6 @@ struct MeshView {
     const uint32_t* bp;        // global: the number of mesh objects, their boxes (6 floats each), then per cell of the reference's broadphase the
                                // mask of the objects listed there, see arena_mesh.cpp / arena_contact.h; nullptr = one object, listed everywhere
     int n_nodes, n_tris, n_fast;
-    uint32_t* leaf_cache;      // device only: the env batch's kept candidate leaves (rlgpu_env.hip CandCache), nullptr on the host
 };
 
 // events a tick can raise towards the gym layer (Gym.cpp:6-38 callbacks)

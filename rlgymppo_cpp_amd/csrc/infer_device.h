@@ -278,7 +278,11 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 // the TickWork areas of different envs) of ceil(R / NP) rows each.
 struct F32Buf { float* part[3]; };   // NP = 2 or 3 parts of ceil(R / NP) rows each
 template <int R, int NP>
-__device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) { constexpr int RP = (R + NP - 1) / NP; return b.part[r / RP] + (r % RP) * ld; }
+__device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) {   // (selects, not an indexed load: the three pointers stay in registers)
+    constexpr int RP = (R + NP - 1) / NP;
+    if (NP == 2) return r < RP ? b.part[0] + r * ld : b.part[1] + (r - RP) * ld;
+    return r < RP ? b.part[0] + r * ld : (r < 2 * RP ? b.part[1] + (r - RP) * ld : b.part[2] + (r - 2 * RP) * ld);
+}
 __host__ __device__ constexpr int f32_part_bytes(int rows, int np, int ld) { return ((rows + np - 1) / np) * (ld > LOGIT_LD ? ld : LOGIT_LD) * 4; }
 
 template <int R, int NP>

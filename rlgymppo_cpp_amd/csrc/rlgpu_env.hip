@@ -79,6 +79,14 @@ __device__ unsigned int g_overflow[8];
 // in this very branch together can collide) take the wavefront's arenas in rounds of one lane per arena.  Full-size arena (Bullet's 128
 // vertices / 256 faces): global memory, one per wavefront (EnvDev::epa_big), used by one lane at a time.
 #define RLG_EPA_MAX_ARENAS 4
+#ifdef RLG_TICK_PROFILE   /* profiler build: penetration-depth queries per workgroup of a collection launch (slot 3 of its g_step_prof row) */
+#define RLG_EPA_WG_COUNT() do { if (blockIdx.x < 4096) atomicAdd(&g_step_prof[16 * blockIdx.x + 3], 1ull); } while (0)
+#else
+#define RLG_EPA_WG_COUNT() ((void)0)
+#endif
+#if defined(RLG_EXPERIMENT_EPA_LDS) && defined(__HIP_DEVICE_COMPILE__)   /* what-if build: every EPA arena is assumed to be in LDS, the full-size pass is dropped */
+#define RLG_EPA_IN_LDS(ref) __builtin_assume(__builtin_amdgcn_is_shared((const void*)&(ref)))
+#endif
 __shared__ unsigned char* g_epa_small_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED][RLG_EPA_MAX_ARENAS];
 __shared__ int g_epa_small_n[RLG_WAVES_PER_BLOCK_DEFAULTED];
 __shared__ unsigned char* g_epa_big_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
@@ -94,12 +102,16 @@ __shared__ unsigned char* g_epa_big_ptr[RLG_WAVES_PER_BLOCK_DEFAULTED];
 #define RLG_EPA_SERIALIZE_BEGIN { \
     const unsigned long long pend_ = __ballot(1); \
     const int rank_ = __popcll(pend_ & ((1ull << (threadIdx.x & 63u)) - 1ull)), total_ = __popcll(pend_), n_ar_ = g_epa_small_n[epa_wave_]; \
-    for (int base_ = 0; base_ < total_; base_ += n_ar_) { if (rank_ >= base_ && rank_ < base_ + n_ar_) { RLG_DBG_COUNT(5); \
+    for (int base_ = 0; base_ < total_; base_ += n_ar_) { if (rank_ >= base_ && rank_ < base_ + n_ar_) { RLG_DBG_COUNT(5); RLG_EPA_WG_COUNT(); \
         epa_small_ = epa_arena_at(g_epa_small_ptr[epa_wave_][rank_ - base_], RLG_EPA_LDS_V, RLG_EPA_LDS_F);
 #define RLG_EPA_SERIALIZE_END } } }
+#ifdef RLG_EXPERIMENT_EPA_LDS
+#define RLG_EPA_BIG_PASS(rc_, CALL)
+#else
 #define RLG_EPA_BIG_PASS(rc_, CALL) { \
     for (unsigned long long pb_ = __ballot((rc_) == EPA_ARENA_FULL && g_epa_big_ptr[epa_wave_] != nullptr); pb_; pb_ &= pb_ - 1ull) \
         if ((int)(threadIdx.x & 63u) == __ffsll((unsigned long long)pb_) - 1) { RLG_DBG_COUNT(6); epa_big_ = &epa_bigv_; CALL; } }
+#endif
 #define RLG_EPA_COUNT_BIG() ((void)0)
 #else   // host pass of this translation unit: never executed
 #define RLG_EPA_ARENA_DECL alignas(16) unsigned char epa_mem_[epa_arena_bytes(EPA_BT_MAX_VERTICES, EPA_BT_MAX_FACES)]; \
@@ -226,7 +238,9 @@ __device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G)
     arena_visit(A, G, w);
 }
 
+__shared__ uint32_t* g_leaf_cache;   // EnvDev::leaf_cache for the tick's candidate phase (kept out of the argument lists of the per-phase calls)
 __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage, uint32_t* lds_grid, uint32_t* lds_pad) {
+    if (threadIdx.x == 0) g_leaf_cache = d.leaf_cache;
     if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
     for (int i = threadIdx.x; i < PAD_TAB_WORDS; i += blockDim.x) lds_pad[i] = d.pad_tab[i];
     int n_fast = d.n_nodes < n_stage ? d.n_nodes : n_stage;
@@ -238,7 +252,6 @@ __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage,
     MeshView mv; mv.nodes = d.nodes; mv.tris = d.tris; mv.nodes_fast = lds_nodes; mv.n_nodes = d.n_nodes; mv.n_tris = d.n_tris; mv.n_fast = n_fast;
     mv.grid = d.grid ? lds_grid : nullptr;
     mv.bp = d.grid ? d.grid + GRID_WORDS : nullptr;
-    mv.leaf_cache = d.leaf_cache;
     return mv;
 }
 
@@ -523,9 +536,9 @@ __device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView m
     if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
     RLG_PROF(0); RLG_FPROF(0);
-    build_candidates_wave<NC>(lane_mem, n_valid, mv, mv.leaf_cache, env0);
+    build_candidates_wave<NC>(lane_mem, n_valid, mv, g_leaf_cache, env0);
 #ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
-    build_candidates_wave<NC>(lane_mem, n_valid, mv, mv.leaf_cache, env0);
+    build_candidates_wave<NC>(lane_mem, n_valid, mv, g_leaf_cache, env0);
 #endif
     RLG_PROF(1); RLG_FPROF(1); phase_sync(2);
     // suspension rays: begin (lane per wheel) | mesh pairs (lane per ray x candidate triangle of the car) | finish (lane per wheel)
@@ -785,6 +798,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);   // the step's GameState, in the env's own TickWork area (dead between ticks)
 #ifdef RLG_TICK_PROFILE
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_step_prof[16 * blockIdx.x + 3] = 0;
     unsigned long long prof_infer = 0, prof_mlp = 0;
 #endif
     epa_arenas_setup<NC>(d, wmem);
