@@ -50,7 +50,8 @@ int rlgpu_comm_unique_id(void* id_out) {
 }
 
 // ncclCommInitRank is collective and has no timeout of its own: a rank that never arrives (a crashed peer, a stale rendezvous id) would
-// hang the others for ever.  It runs on a helper thread; past RLGPU_COMM_TIMEOUT_S (default 60 s) the caller gets an error back and is
+// hang the others for ever.  It runs on a helper thread; past RLGPU_COMM_TIMEOUT_S (default 300 s: the first init of an 8-GPU node builds
+// its topology and rings for tens of seconds) the caller gets an error back and is
 // expected to exit (the helper thread is left behind: a process in that state cannot use the communicator anyway).
 int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const void* id_bytes) {
     if (!out || !id_bytes || world < 1 || rank < 0 || rank >= world) return RLGPU_ERR_ARG;
@@ -66,7 +67,7 @@ int rlgpu_comm_init(rlgpu_comm** out, int device, int rank, int world, const voi
         job->r = r; job->comm = comm; job->done = true; job->cv.notify_all();
     }).detach();
     const char* tv = getenv("RLGPU_COMM_TIMEOUT_S");
-    const int timeout_s = tv && atoi(tv) > 0 ? atoi(tv) : 60;
+    const int timeout_s = tv && atoi(tv) > 0 ? atoi(tv) : 300;
     {
         std::unique_lock<std::mutex> lk(job->mu);
         if (!job->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return job->done; }))
@@ -106,7 +107,7 @@ int rlgpu_comm_rendezvous_path(char* buf, int cap) {
 }
 
 // The file: 8 bytes magic, 8 bytes wall-clock seconds at which rank 0 wrote it, then the id.  A reader only takes a file written after
-// its own process started minus RLGPU_COMM_STALE_S (default 120 s: ranks of one launch start within that of each other) -- what an
+// its own process started minus RLGPU_COMM_STALE_S (default 300 s: ranks of one launch start within that of each other) -- what an
 // earlier launch with the same port and tag left behind (a crash between write and remove) is not this launch's id.
 namespace {
 constexpr uint64_t RDV_MAGIC = 0x31444950475f4c52ull;   // "RL_GPID1"
@@ -121,7 +122,7 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     if (world_out) *world_out = world;
     if (rendezvous_dir().empty()) return fail(nullptr, "rendezvous directory /tmp/rlgpu_comm_<uid> is not a private directory of this user (set RLGPU_COMM_DIR)");
     const std::string path = rendezvous_path();
-    const int timeout_s = env_i("RLGPU_COMM_TIMEOUT_S", 60) > 0 ? env_i("RLGPU_COMM_TIMEOUT_S", 60) : 60;
+    const int timeout_s = env_i("RLGPU_COMM_TIMEOUT_S", 300) > 0 ? env_i("RLGPU_COMM_TIMEOUT_S", 300) : 300;
     unsigned char id[RLGPU_COMM_ID_BYTES];
     if (rank == 0) {
         int rc = rlgpu_comm_unique_id(id);
@@ -136,7 +137,7 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
         close(fd);
         if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return fail(nullptr, "cannot write " + path); }
     } else {
-        const int64_t stale_s = env_i("RLGPU_COMM_STALE_S", 120);
+        const int64_t stale_s = env_i("RLGPU_COMM_STALE_S", 300);
         bool ok = false;
         for (int tries = 0; tries < timeout_s * 100 && !ok; tries++) {
             const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
