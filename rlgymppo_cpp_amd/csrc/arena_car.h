@@ -407,7 +407,7 @@ RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
 
 // phase 0, per car: ClampFix, demo timer and respawn (Car.cpp:60-87)
 template <int NC>
-RLG_HD_NOINLINE void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t env_id) {
+RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t env_id) {
     RLG_ASSUME_LDS(A);
     const float dt = TICK_DT;
     Car& c = A.cars[ci];

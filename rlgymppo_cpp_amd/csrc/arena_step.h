@@ -836,7 +836,7 @@ RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev,
 
 // contacts of one body (see collide_body); `queued` as in solver_prepare
 template <int NC>
-RLG_HD_NOINLINE void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
+RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
     if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
@@ -861,7 +861,7 @@ RLG_HD void solver_rows(TickWork<NC>& W, int k) {
 // split-impulse early exit.  The envs that are slow here have ball-car / car-car rows and stay one sequence, and the per-row
 // chain lookup cost more than the short chains saved: 483 K -> 570 K cycles per launch on the slowest workgroup.)
 template <int NC>
-RLG_HD_NOINLINE void solver_iterate(TickWork<NC>& W) {
+RLG_HD_SMALL void solver_iterate(TickWork<NC>& W) {
     RLG_ASSUME_LDS(W);
     constexpr int NB = NC + 1;
     SolverBody (&B)[NB] = W.B;
@@ -899,7 +899,7 @@ RLG_HD_NOINLINE void solver_iterate(TickWork<NC>& W) {
 }
 
 template <int NC>
-RLG_HD_NOINLINE void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
+RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     const SolverBody& s = W.B[body];
@@ -1040,7 +1040,7 @@ RLG_HD uint64_t pads_check_car_cells(const Arena<NC>& A, int ci, int ix, int iy)
     return mask;
 }
 template <int NC>
-RLG_HD_NOINLINE uint64_t pads_check_car(const Arena<NC>& A, const uint32_t* tab, int ci) {
+RLG_HD_SMALL uint64_t pads_check_car(const Arena<NC>& A, const uint32_t* tab, int ci) {
     RLG_ASSUME_LDS(A);
     const Car& car = A.cars[ci];
     uint64_t mask = 0;
@@ -1101,7 +1101,7 @@ RLG_HD void pads_lock(Arena<NC>& A, int ci, uint64_t mask) {
 
 // phase 3, per env: boost pad cooldowns (unless the caller spread them over lanes), then the first part of the dynamics world step
 template <int NC>
-RLG_HD_NOINLINE void tick_world_begin(Arena<NC>& A, TickWork<NC>& W, bool pads_done) {
+RLG_HD_SMALL void tick_world_begin(Arena<NC>& A, TickWork<NC>& W, bool pads_done) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     if (!pads_done) for (int p = 0; p < 34; p++) pad_pre_tick(A.pads[p]);
     world_step_begin(A, W);
@@ -1127,7 +1127,7 @@ RLG_HD void collide_compact_and_run(const Arena<NC>& A, MeshView mesh, CollideQu
 
 // phase 4, per car: Car::_PostTickUpdate + _FinishPhysicsTick
 template <int NC>
-RLG_HD_NOINLINE void tick_car_post(Arena<NC>& A, int i) {
+RLG_HD_SMALL void tick_car_post(Arena<NC>& A, int i) {
     RLG_ASSUME_LDS(A);
     // touch only the fields the post tick needs through locals (see car_pre_tick_finish about aliasing)
     Car& cr = A.cars[i];
@@ -1141,7 +1141,7 @@ RLG_HD_NOINLINE void tick_car_post(Arena<NC>& A, int i) {
 // phase 5, per env: boost pad pickups (in car order), ball finish, tick counter.  `pads_done`: the caller ran
 // pads_check_car / pads_lock / pad_post_tick over lanes already.
 template <int NC>
-RLG_HD_NOINLINE void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_done) {
+RLG_HD_SMALL void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_done) {
     RLG_ASSUME_LDS(A);
     if (!pads_done) {
         RLG_NOUNROLL

@@ -17,6 +17,11 @@
 // Big routines are real calls on the device: fully inlined, one gym step is ~330 KB of code and every wavefront streams
 // it through the 64 KB instruction cache on every tick.
 #define RLG_HD_NOINLINE __host__ __device__ __noinline__ inline  /* `inline` only for ODR linkage of header definitions */
+#ifdef RLG_INLINE_SMALL
+#define RLG_HD_SMALL RLG_HD
+#else
+#define RLG_HD_SMALL RLG_HD_NOINLINE
+#endif
 #define RLG_NOUNROLL _Pragma("nounroll")
 #define RLG_UNROLL _Pragma("unroll")
 // The stepper kernels keep each env's state and tick scratch in LDS.  Out-of-line device functions receive them through
@@ -33,6 +38,11 @@
 #define RLG_ASSUME_LDS(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
+#ifdef RLG_INLINE_SMALL
+#define RLG_HD_SMALL RLG_HD
+#else
+#define RLG_HD_SMALL RLG_HD_NOINLINE
+#endif
 #endif
 #include "rl_libm.h"   // rl_sinf / rl_cosf / rl_atan2f / rl_asinf: the same bits on the device and on the host (= glibc's)
 // Phase stamps for the tick profiler build (tools/prof_cycles.py); empty in product builds.

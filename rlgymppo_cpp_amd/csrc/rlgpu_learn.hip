@@ -938,6 +938,9 @@ int launch_nt(rlgpu_learner* l, NtArgs g, int real_k) {
         dim3 grid((n_cover + 63) / 64, (g.M + 63) / 64);
         hipLaunchKernelGGL((k_gemm_nt<2, 2, 1, 1, EPI>), grid, dim3(256), 0, l->stream, g);
     } else if (g.N > 32 || EPI == 2) {
+        // (Tried in round 3 and dropped: ONE column of 128 x 256 tiles for the 256-wide layers, so that the activation operand is read once
+        // instead of twice -- 0.521 -> 0.546 ms per minibatch at two workgroups per CU, 0.638 at one: the second read of A comes from L2 /
+        // MALL anyway, and a workgroup's ~10 us are load latency and epilogue around ~1 us of MFMA work, hidden only by workgroups in flight.)
         dim3 grid((n_cover + 127) / 128, (g.M + 127) / 128);
         hipLaunchKernelGGL((k_gemm_nt<2, 2, 2, 2, EPI>), grid, dim3(256), 0, l->stream, g);
     } else {
