@@ -440,7 +440,7 @@ RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t e
 RLG_HD unsigned long long* ray_keys(CarTickCtx& t) { return t.ray_key; }
 
 template <int NC>
-RLG_HD_NOINLINE void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx& t) {
+RLG_HD_MID void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
     Car& cr = A.cars[ci];
     // NB: as in the reference, a car respawned in phase 0 runs the rest of the pre-tick (Respawn clears the flag,
@@ -485,7 +485,7 @@ RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue<NC>& Q, int ci) 
 }
 
 template <int NC>
-RLG_HD_NOINLINE void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue<NC>& Q, CarTickCtx& t) {
+RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue<NC>& Q, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t); RLG_ASSUME_LDS(Q);
     const float dt = TICK_DT;
     Car& cr = A.cars[ci];
@@ -552,7 +552,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
 
 // phase 2, per car: friction impulses, the car's control logic, suspension forces (rest of Car::_PreTickUpdate)
 template <int NC>
-RLG_HD_NOINLINE void car_pre_tick_finish(Arena<NC>& A, int ci, CarTickCtx& t) {
+RLG_HD_BIG void car_pre_tick_finish(Arena<NC>& A, int ci, CarTickCtx& t) {
     // Work on a private copy: A lives in LDS behind a pointer the optimiser must assume aliases everything (every field
     // would be re-loaded after every store); a local Car is promoted to registers.
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);

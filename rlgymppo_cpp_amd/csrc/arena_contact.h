@@ -148,7 +148,7 @@ RLG_HD void ball_proxy_aabb(const Ball& b, V3& lo, V3& hi) {
     sphere_shape_aabb(b.b.pos + b.b.vel * TICK_DT, l2, h2); l2 = l2 - t; h2 = h2 + t;
     lo = vmin(l1, l2); hi = vmax(h1, h2);
 }
-RLG_HD_NOINLINE void car_proxy_aabb(const Car& c, V3& lo, V3& hi) {
+RLG_HD_T7 void car_proxy_aabb(const Car& c, V3& lo, V3& hi) {
     const V3 t = v3(BP_THRESHOLD, BP_THRESHOLD, BP_THRESHOLD);
     V3 l1, h1, l2, h2;
     compound_shape_aabb(c.b.pos, c.b.rot, l1, h1); l1 = l1 - t; h1 = h1 + t;

@@ -178,10 +178,10 @@ RLG_HD bool gjk_box_convex(V3 bc, const M3& R, V3 core, float margin_a, V3 origi
 }
 
 // the two out-of-line instances (the general form is inlined into each: as a call its eighteen by-value floats would travel through the stack)
-RLG_HD_NOINLINE bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_a, const MeshTri& t, float breaking, GjkOut& out, bool& deep) {
+RLG_HD_T5 bool gjk_box_triangle(V3 bc, const M3& R, V3 core, float margin_a, const MeshTri& t, float breaking, GjkOut& out, bool& deep) {
     return gjk_box_convex(bc, R, core, margin_a, v3(0, 0, 0), v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), 0.f, breaking, out, deep);
 }
-RLG_HD_NOINLINE bool gjk_box_sphere(V3 bc, const M3& R, V3 core, float margin_a, V3 centre, float radius, float breaking, GjkOut& out, bool& deep) {
+RLG_HD_T7 bool gjk_box_sphere(V3 bc, const M3& R, V3 core, float margin_a, V3 centre, float radius, float breaking, GjkOut& out, bool& deep) {
     return gjk_box_convex(bc, R, core, margin_a, centre, v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), radius, breaking, out, deep);
 }
 

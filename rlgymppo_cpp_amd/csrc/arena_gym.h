@@ -88,7 +88,7 @@ struct Snapshot {
 };
 
 template <int NC>
-RLG_HD_NOINLINE void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S) {
+RLG_HD_T6A void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S) {
     int64_t tick_skip = A.tick_count - G.last_tick_count; if (tick_skip < 0) tick_skip = 0;
     S.ball_pos = A.ball.b.pos * BT2UU; S.ball_vel = A.ball.b.vel * BT2UU; S.ball_angvel = A.ball.b.angvel;
     for (int k = 0; k < NC; k++) {
@@ -151,7 +151,7 @@ RLG_HD bool shooter_passer(const Arena<NC>& A, int team, int& shooter, bool find
     return shooter >= 0;
 }
 template <int NC>
-RLG_HD_NOINLINE void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
+RLG_HD_T6A void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
     const float tickrate = 1.f / TICK_DT;
     bool scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);  // Arena.cpp:949-957
     int64_t buc = A.ball_update_counter;
@@ -228,7 +228,7 @@ RLG_HD float* obs_add_player(float* o, const Snapshot<NC>& S, int k, bool inv, c
 // with zero blocks to m-1 entries, the opponent list to m, and each list is shuffled per observation; the reference shuffles with
 // the process-wide std engine, here the permutation comes from the env's Philox stream keyed by (env, step, reset count, player).
 template <int NC>
-RLG_HD_NOINLINE void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o, uint32_t env_id, uint32_t step, uint32_t resets) {
+RLG_HD_T6B void build_obs(const Snapshot<NC>& S, int k, const float* prev_action8, const GymConfig& cfg, float* o, uint32_t env_id, uint32_t step, uint32_t resets) {
     bool inv = (k % 2) == 1;
     V3 bp = inv3(S.ball_pos, inv), bv = inv3(S.ball_vel, inv), bw = inv3(S.ball_angvel, inv);
     *o++ = bp.x * cfg.pos_coef[0]; *o++ = bp.y * cfg.pos_coef[1]; *o++ = bp.z * cfg.pos_coef[2];
@@ -278,7 +278,7 @@ RLG_HD void event_values(const Snapshot<NC>& S, const GymEnv<NC>& G, int k, floa
     v[8] = (float)G.counters[k][6]; v[9] = S.demoed[k] ? 1.f : 0.f; v[10] = S.boost_frac[k];
 }
 template <int NC>
-RLG_HD_NOINLINE void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
+RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
     for (int k = 0; k < NC; k++) rew[k] = 0.f;
     for (int t = 0; t < cfg.n_terms; t++) {
         const RewardTerm& T = cfg.terms[t];

@@ -260,7 +260,7 @@ RLG_HD bool collide_test_candidate(const Arena<NC>& A, MeshView mesh, const Coll
 
 // step 3: run item `slot`
 template <int NC>
-RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue<NC>& Q) {
+RLG_HD_T4 void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, CollideQueue<NC>& Q) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(Q);
     CollideItem it = Q.items[slot];
     // a triangle item yields at most one point, kept in registers until its pool slot is known; only the (rare) car-car item has a list
@@ -295,7 +295,7 @@ RLG_HD_NOINLINE void collide_run_item(const Arena<NC>& A, MeshView mesh, int slo
 //   collide_merge  per env    the car-car pairs, the contact-added callbacks that touch other bodies, and the ORDER in which
 //                             the solver visits the contacts (W.cidx)
 template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
+RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
     const float r = K::BALL_RADIUS * UU2BT;
     const V3 bp = A.ball.b.pos;
@@ -572,7 +572,7 @@ struct TickWork {
 // contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy
 // boxes (with the predicted rotation), broadphase cells, union-find and the quickSort are all that is needed to ORDER them.
 template <int NC, int MAXC>
-RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
+RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
@@ -696,7 +696,7 @@ RLG_HD_NOINLINE void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W,
 
 // per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts
 template <int NC, int MAXC, class NW>
-RLG_HD_NOINLINE void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
+RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
@@ -774,7 +774,7 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
 //   solver_iterate   per env       split-impulse + velocity iterations (:1601-1877) -- sequential by nature (Gauss-Seidel)
 //   solver_finish    per body      write back (:1878-1904), integrateTransforms (btDiscreteDynamicsWorld.cpp:889-1027), clearForces
 template <int NC>
-RLG_HD_NOINLINE void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
+RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
     constexpr int NB = NC + 1;

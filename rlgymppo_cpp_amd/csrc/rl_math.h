@@ -17,10 +17,56 @@
 // Big routines are real calls on the device: fully inlined, one gym step is ~330 KB of code and every wavefront streams
 // it through the 64 KB instruction cache on every tick.
 #define RLG_HD_NOINLINE __host__ __device__ __noinline__ inline  /* `inline` only for ODR linkage of header definitions */
-#ifdef RLG_INLINE_SMALL
-#define RLG_HD_SMALL RLG_HD
-#else
+// The tick's small per-phase routines (a few hundred instructions, called once per tick) are inlined: as real calls they cost 2 % of a
+// collection launch and 11 % of its scratch write-back in register saves (-DRLG_NO_INLINE_SMALL restores the calls).  Inlining the mid-size
+// ones (wheel rays, solver_prepare: 1.3 - 2.8 K instructions) takes another 19 % off the write-back at equal time (-DRLG_NO_INLINE_MID);
+// the big per-phase ones (car_pre_tick_finish, collide_body, collide_merge: 2 - 6 K instructions, one call site each) another 55 % and
+// 1.7 % of the launch (-DRLG_NO_INLINE_BIG).  What stays a call: routines with several call sites or rare execution (GJK, EPA, box-box,
+// the order emulation) -- inlining ALL of the penetration-depth code once cost 50 % of the launch in instruction-cache misses.
+#ifdef RLG_NO_INLINE_SMALL
 #define RLG_HD_SMALL RLG_HD_NOINLINE
+#else
+#define RLG_HD_SMALL RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_MID
+#define RLG_HD_MID RLG_HD_NOINLINE
+#else
+#define RLG_HD_MID RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_BIG
+#define RLG_HD_BIG RLG_HD_NOINLINE
+#else
+#define RLG_HD_BIG RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T4
+#define RLG_HD_T4 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T4 RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T5
+#define RLG_HD_T5 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T5 RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T7
+#define RLG_HD_T7 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T7 RLG_HD
+#endif
+#ifdef RLG_INLINE_T8
+#define RLG_HD_T8 RLG_HD
+#else
+#define RLG_HD_T8 RLG_HD_NOINLINE
+#endif
+#ifdef RLG_INLINE_T6A   /* take_snapshot / event_tracker_update stay calls: with them AND the T6B pair inlined the 2v2 collection kernel faults on the GPU (either pair alone is fine and T6B carries the gain) */
+#define RLG_HD_T6A RLG_HD
+#else
+#define RLG_HD_T6A RLG_HD_NOINLINE
+#endif
+#ifdef RLG_NO_INLINE_T6B
+#define RLG_HD_T6B RLG_HD_NOINLINE
+#else
+#define RLG_HD_T6B RLG_HD
 #endif
 #define RLG_NOUNROLL _Pragma("nounroll")
 #define RLG_UNROLL _Pragma("unroll")
@@ -38,10 +84,56 @@
 #define RLG_ASSUME_LDS(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
-#ifdef RLG_INLINE_SMALL
-#define RLG_HD_SMALL RLG_HD
-#else
+// The tick's small per-phase routines (a few hundred instructions, called once per tick) are inlined: as real calls they cost 2 % of a
+// collection launch and 11 % of its scratch write-back in register saves (-DRLG_NO_INLINE_SMALL restores the calls).  Inlining the mid-size
+// ones (wheel rays, solver_prepare: 1.3 - 2.8 K instructions) takes another 19 % off the write-back at equal time (-DRLG_NO_INLINE_MID);
+// the big per-phase ones (car_pre_tick_finish, collide_body, collide_merge: 2 - 6 K instructions, one call site each) another 55 % and
+// 1.7 % of the launch (-DRLG_NO_INLINE_BIG).  What stays a call: routines with several call sites or rare execution (GJK, EPA, box-box,
+// the order emulation) -- inlining ALL of the penetration-depth code once cost 50 % of the launch in instruction-cache misses.
+#ifdef RLG_NO_INLINE_SMALL
 #define RLG_HD_SMALL RLG_HD_NOINLINE
+#else
+#define RLG_HD_SMALL RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_MID
+#define RLG_HD_MID RLG_HD_NOINLINE
+#else
+#define RLG_HD_MID RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_BIG
+#define RLG_HD_BIG RLG_HD_NOINLINE
+#else
+#define RLG_HD_BIG RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T4
+#define RLG_HD_T4 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T4 RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T5
+#define RLG_HD_T5 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T5 RLG_HD
+#endif
+#ifdef RLG_NO_INLINE_T7
+#define RLG_HD_T7 RLG_HD_NOINLINE
+#else
+#define RLG_HD_T7 RLG_HD
+#endif
+#ifdef RLG_INLINE_T8
+#define RLG_HD_T8 RLG_HD
+#else
+#define RLG_HD_T8 RLG_HD_NOINLINE
+#endif
+#ifdef RLG_INLINE_T6A   /* take_snapshot / event_tracker_update stay calls: with them AND the T6B pair inlined the 2v2 collection kernel faults on the GPU (either pair alone is fine and T6B carries the gain) */
+#define RLG_HD_T6A RLG_HD
+#else
+#define RLG_HD_T6A RLG_HD_NOINLINE
+#endif
+#ifdef RLG_NO_INLINE_T6B
+#define RLG_HD_T6B RLG_HD_NOINLINE
+#else
+#define RLG_HD_T6B RLG_HD
 #endif
 #endif
 #include "rl_libm.h"   // rl_sinf / rl_cosf / rl_atan2f / rl_asinf: the same bits on the device and on the host (= glibc's)
@@ -207,7 +299,7 @@ RLG_HD V3 quat_rotate(Q4 r, V3 v) {
 }
 
 // btTransformUtil::integrateTransform's rotation part (LinearMath/btTransformUtil.h:37-87)
-RLG_HD_NOINLINE M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
+RLG_HD_T7 M3 integrate_rotation(const M3& basis, V3 angvel, float dt) {
     const float ANGULAR_MOTION_THRESHOLD = 0.5f * (PI_F * 0.5f);
     float fAngle2 = len2(angvel);
     float fAngle = 0.f;

@@ -518,8 +518,13 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 }
 
 // `ev` is meaningful on env lanes (lane e < n_valid owns env e of the wavefront)
+#ifdef RLG_INLINE_T8
+#define RLG_TICK_INLINE __forceinline__
+#else
+#define RLG_TICK_INLINE
+#endif
 template <int NC>
-__device__ void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, const uint32_t* pad_tab, uint32_t seed, int env0, TickEvents& ev) {
+__device__ RLG_TICK_INLINE void arena_tick_wave(unsigned char* lane_mem, int n_valid, MeshView mv, const uint32_t* pad_tab, uint32_t seed, int env0, TickEvents& ev) {
     constexpr int EPW = lanes_per_block<NC>() / WPB;
     RLG_ASSUME_LDS(*lane_mem);   // (not inlined into the step / collect kernels: without this every access below is a flat_load / flat_store)
     const int tid = threadIdx.x & 63;

@@ -2,8 +2,8 @@ cd $GRAFT_REPO_ROOT
 for cfg in "2 8192" "3 16384"; do set -- $cfg
   for n in old tree; do
     mkdir -p /tmp/vab_$n && cp rlgymppo_cpp_amd/bench_main rlgymppo_cpp_amd/librlgymppo_amd.so /tmp/vab_$n/
-    if [ "$n" = tree ]; then cp rlgymppo_cpp_amd/librlgpu.so /tmp/vab_$n/librlgpu.so; M=3; else cp rlgymppo_cpp_amd/librlgpu_$n.so /tmp/vab_$n/librlgpu.so; M=2; fi
-    RLGPU_FUSED_MAX_TEAM=$M /tmp/vab_$n/bench_main --envs $2 --team-size $1 --padded-zero-sum --horizon 32 --steps 8 --warmup 2 2>/dev/null | python3 -c "
+    if [ "$n" = tree ]; then cp rlgymppo_cpp_amd/librlgpu.so /tmp/vab_$n/librlgpu.so; else cp rlgymppo_cpp_amd/librlgpu_$n.so /tmp/vab_$n/librlgpu.so; fi
+    /tmp/vab_$n/bench_main --envs $2 --team-size $1 --padded-zero-sum --horizon 32 --steps 8 --warmup 2 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print('$1v$1 $2 envs %-6s' % '$n', round(d['value']), 'collect/env_ms', round(d['env_kernel_ms_total']/max(d['env_launches'],1),3), 'ppo_ms', round(d.get('ppo_iter_ms',0),3), 'ms_per_step', round(d['ms_per_step'],2), flush=True)"
   done
