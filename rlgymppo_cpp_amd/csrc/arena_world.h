@@ -584,7 +584,7 @@ RLG_HD V3 nearest_on_segment(V3 p, V3 l0, V3 l1) {
     if (delta < 0.f) delta = 0.f; else if (delta > 1.f) delta = 1.f;
     return l0 + d * delta;
 }
-RLG_HD_T8 void adjust_internal_edge(const MeshTri& t, V3& pb, V3& n, float dist) {
+RLG_HD_T9 void adjust_internal_edge(const MeshTri& t, V3& pb, V3& n, float dist) {
     if (!(t.edge_flags >> 31)) return;
     const V3 pa = pb + n * dist;                      // m_positionWorldOnA (btManifoldResult.cpp:117)
     const V3 v[3] = {v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z)};

@@ -53,10 +53,10 @@
 #else
 #define RLG_HD_T7 RLG_HD
 #endif
-#ifdef RLG_INLINE_T8
-#define RLG_HD_T8 RLG_HD
+#ifdef RLG_INLINE_T9
+#define RLG_HD_T9 RLG_HD
 #else
-#define RLG_HD_T8 RLG_HD_NOINLINE
+#define RLG_HD_T9 RLG_HD_NOINLINE
 #endif
 #ifdef RLG_INLINE_T6A   /* take_snapshot / event_tracker_update stay calls: with them AND the T6B pair inlined the 2v2 collection kernel faults on the GPU (either pair alone is fine and T6B carries the gain) */
 #define RLG_HD_T6A RLG_HD
@@ -120,10 +120,10 @@
 #else
 #define RLG_HD_T7 RLG_HD
 #endif
-#ifdef RLG_INLINE_T8
-#define RLG_HD_T8 RLG_HD
+#ifdef RLG_INLINE_T9
+#define RLG_HD_T9 RLG_HD
 #else
-#define RLG_HD_T8 RLG_HD_NOINLINE
+#define RLG_HD_T9 RLG_HD_NOINLINE
 #endif
 #ifdef RLG_INLINE_T6A   /* take_snapshot / event_tracker_update stay calls: with them AND the T6B pair inlined the 2v2 collection kernel faults on the GPU (either pair alone is fine and T6B carries the gain) */
 #define RLG_HD_T6A RLG_HD
