@@ -684,7 +684,7 @@ def test_collection_during_learn_mode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("team_size,n_envs,bf16", [(1, 70, True), (2, 21, True), (3, 9, True), (1, 70, False), (2, 21, False), (3, 9, False)])
+@pytest.mark.parametrize("team_size,n_envs,bf16", [(1, 70, True), (2, 21, True), (2, 20, True), (3, 9, True), (1, 70, False), (2, 21, False), (2, 20, False), (3, 9, False)])
 def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs, bf16):
     """rlgpu_collect (T x (inference + gym step) in one launch, every wavefront on its own envs) against T alternations of
     rlgpu_policy_act / rlgpu_env_step from the same seeds: observations, actions, rewards, dones and the final env state are
