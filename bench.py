@@ -84,13 +84,13 @@ def _cpu_baseline(seconds_target, cores, n_envs, team, ref_so, port_so, mesh_dir
 
 
 def kernel_source_hash():
-    """sha256 over the device sources of the stepper: the key under which profiles/*_pmc.json was recorded (a profile taken from
-    other kernel code is not quoted)."""
+    """sha256 over the device sources of the stepper and the learner kernels: the key under which profiles/*_pmc.json was recorded (a
+    profile taken from other kernel code is not quoted).  The RCCL glue (rlgpu_comm.hip) launches no kernel of its own and is left out."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
+        if name.endswith((".h", ".hip")) and name != "rlgpu_comm.hip":
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

@@ -117,6 +117,9 @@ const int64_t g_process_start = (int64_t)time(nullptr);
 // rank / world / rendezvous from the launcher's environment (torchrun or any launcher that sets RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT)
 int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     auto env_i = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
+    // this pool's host driver only supports dmabuf IPC; RCCL's peer mappings fail with the legacy mode.  Only effective when the HSA runtime
+    // has not been initialised yet (the hosts call this before their first HIP call); an exported value is left alone.
+    (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     const int rank = env_i("RANK", 0), world = env_i("WORLD_SIZE", 1), local = env_i("LOCAL_RANK", rank);
     if (rank_out) *rank_out = rank;
     if (world_out) *world_out = world;
