@@ -723,6 +723,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 12; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
+#ifdef RLG_POISON_LDS   /* test build: every env byte of the wavefront starts as 0xFF (NaN floats, -1 ints): results must not depend on what LDS held before */
+    for (int i = (threadIdx.x & 63); i < (int)((lanes_per_block<NC>() / WPB) * lane_stride<NC>() / 4); i += 64) reinterpret_cast<uint32_t*>(wmem)[i] = 0xFFFFFFFFu;
+    wave_sync();
+#endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
@@ -805,6 +809,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_step_prof[16 * blockIdx.x + 3] = 0;
     unsigned long long prof_infer = 0, prof_mlp = 0;
+#endif
+#ifdef RLG_POISON_LDS   /* test build: every env byte of the wavefront starts as 0xFF (NaN floats, -1 ints): results must not depend on what LDS held before */
+    for (int i = (threadIdx.x & 63); i < (int)((lanes_per_block<NC>() / WPB) * lane_stride<NC>() / 4); i += 64) reinterpret_cast<uint32_t*>(wmem)[i] = 0xFFFFFFFFu;
+    wave_sync();
 #endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
@@ -909,6 +917,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     const bool env_lane = ws.lane < n_valid;
     const int env = env0 + (env_lane ? ws.lane : 0);
     LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? ws.lane : 0);
+#ifdef RLG_POISON_LDS   /* test build: every env byte of the wavefront starts as 0xFF (NaN floats, -1 ints): results must not depend on what LDS held before */
+    for (int i = (threadIdx.x & 63); i < (int)((lanes_per_block<NC>() / WPB) * lane_stride<NC>() / 4); i += 64) reinterpret_cast<uint32_t*>(wmem)[i] = 0xFFFFFFFFu;
+    wave_sync();
+#endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
