@@ -58,10 +58,72 @@ void run_tape_t(RlgpuArenaState* s, const float* tape, int ticks, int every, Rlg
     }
     arena_to_host(A, G, *s);
 }
+// the same run, writing every tick's Bullet-unit state: per body 18 floats = pos[3], rot rows[9], vel[3], angvel[3]; raw_out: ticks x (1 + NC) x 18
+template <int NC>
+void run_tape_raw_t(RlgpuArenaState* s, const float* tape, int ticks, float* raw_out) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    auto put = [](float* o, const Body& b) {
+        o[0] = b.pos.x; o[1] = b.pos.y; o[2] = b.pos.z;
+        const V3 r0 = b.rot.r0, r1 = b.rot.r1, r2 = b.rot.r2;
+        o[3] = r0.x; o[4] = r0.y; o[5] = r0.z; o[6] = r1.x; o[7] = r1.y; o[8] = r1.z; o[9] = r2.x; o[10] = r2.y; o[11] = r2.z;
+        o[12] = b.vel.x; o[13] = b.vel.y; o[14] = b.vel.z; o[15] = b.angvel.x; o[16] = b.angvel.y; o[17] = b.angvel.z;
+    };
+    for (int t = 0; t < ticks; t++) {
+        for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(tape + ((size_t)t * NC + k) * 8);
+        TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
+        float* o = raw_out + (size_t)t * (1 + NC) * 18;
+        put(o, A.ball.b);
+        for (int k = 0; k < NC; k++) put(o + 18 * (1 + k), A.cars[k].b);
+    }
+    arena_to_host(A, G, *s);
+}
+// ... and the contact list of the LAST tick as the solver saw it (the 16 floats of debug_tick_t), for a tick reached inside the stepper's own units
+template <int NC>
+int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    TickWork<NC> W;
+    for (int t = 0; t < ticks; t++) {
+        for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(tape + ((size_t)t * NC + k) * 8);
+        TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
+    }
+    int n = 0;
+    for (int k = 0; k < W.L.n && n < cap; k++) {
+        const Contact& c = W.L.c[W.cidx[k]];
+        float* o = out + 16 * n++;
+        o[0] = (float)c.a; o[1] = (float)c.b; o[2] = (float)c.sid; o[3] = c.special ? 1.f : 0.f;
+        o[4] = c.ra.x; o[5] = c.ra.y; o[6] = c.ra.z; o[7] = c.rb.x; o[8] = c.rb.y; o[9] = c.rb.z;
+        o[10] = c.n.x; o[11] = c.n.y; o[12] = c.n.z; o[13] = c.dist;
+        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c);
+        if (out2) {   // the rows: friction direction[3], applied friction impulse, normal rhs, normal jac, body a's external impulses ext_f[3] / ext_t[3], friction rhs, friction jac, v.x, w.y
+            float* q = out2 + 16 * (n - 1);
+            for (int i = 0; i < 16; i++) q[i] = 0.f;
+            const int fr = W.frow[k], nr = W.nrow[k];
+            if (fr >= 0) { q[0] = W.R[fr].n1.x; q[1] = W.R[fr].n1.y; q[2] = W.R[fr].n1.z; q[3] = W.R[fr].applied; }
+            if (nr >= 0) { q[4] = W.R[nr].rhs; q[5] = W.R[nr].jac; }
+            const SolverBody& sb = W.B[c.a];
+            q[6] = sb.ext_f.x; q[7] = sb.ext_f.y; q[8] = sb.ext_f.z; q[9] = sb.ext_t.x; q[10] = sb.ext_t.y; q[11] = sb.ext_t.z;
+            if (fr >= 0) { q[12] = W.R[fr].rhs; q[13] = W.R[fr].jac; }
+            q[14] = sb.v.x; q[15] = sb.w.y;
+        }
+    }
+    arena_to_host(A, G, *s);
+    return n;
+}
 }  // namespace
 
 extern "C" {
 
+int port_run_tape_contacts(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2) {
+    if (s->num_cars == 2) return run_tape_contacts_t<2>(s, tape, ticks, out, cap, out2); else if (s->num_cars == 4) return run_tape_contacts_t<4>(s, tape, ticks, out, cap, out2); else return run_tape_contacts_t<6>(s, tape, ticks, out, cap, out2);
+}
+void port_run_tape_raw(RlgpuArenaState* s, const float* tape, int ticks, float* raw_out) {
+    if (s->num_cars == 2) run_tape_raw_t<2>(s, tape, ticks, raw_out); else if (s->num_cars == 4) run_tape_raw_t<4>(s, tape, ticks, raw_out); else run_tape_raw_t<6>(s, tape, ticks, raw_out);
+}
 void port_run_tape(RlgpuArenaState* s, const float* tape, int ticks, int every, RlgpuArenaState* out) {
     if (s->num_cars == 2) run_tape_t<2>(s, tape, ticks, every, out); else if (s->num_cars == 4) run_tape_t<4>(s, tape, ticks, every, out); else run_tape_t<6>(s, tape, ticks, every, out);
 }

@@ -650,3 +650,22 @@ extern "C" void ref_setter_samples(int team_size, int kind, int n, RlgpuArenaSta
     }
     delete a;
 }
+
+// Bullet-unit state of the ball and of every car slot, straight from the rigid bodies (no unit conversion, no rounding): per body 18 floats
+// = origin[3], basis rows[9], linear velocity[3], angular velocity[3].  out: (1 + n_slots) x 18.  For tools/raw_divergence.py, which looks
+// for differences the uu exchange format rounds away.
+extern "C" void ref_arena_get_raw(void* h, int n_slots, float* out) {
+    Arena* a = (Arena*)h;
+    auto put = [&](float* o, const btRigidBody& rb) {
+        const btTransform& t = rb.getWorldTransform();
+        for (int i = 0; i < 3; i++) o[i] = t.getOrigin()[i];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o[3 + 3 * r + c] = t.getBasis()[r][c];
+        for (int i = 0; i < 3; i++) { o[12 + i] = rb.getLinearVelocity()[i]; o[15 + i] = rb.getAngularVelocity()[i]; }
+    };
+    put(out, a->ball->_rigidBody);
+    for (int k = 0; k < n_slots; k++) {
+        Car* car = CarBySlot(a, k);
+        float* o = out + 18 * (1 + k);
+        if (car) put(o, car->_rigidBody); else for (int i = 0; i < 18; i++) o[i] = 0.f;
+    }
+}

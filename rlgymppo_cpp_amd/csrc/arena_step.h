@@ -143,7 +143,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c, bool 
 #endif
     if (hit_) {
         if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
-        c.n = g.n; c.pb = g.pb; c.dist = g.dist;
+        c.n = g.n; c.pb = g.pb; c.dist = g.dist; c.n_raw = g.n;
 #ifdef RLG_ITEM_CLOCK
         const unsigned long long te0_ = RLG_ITEM_CLOCK();
 #endif
@@ -166,7 +166,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c, bool 
     if (nc == 0) return false;
     int best = 0;
     for (int q = 1; q < nc; q++) if (cs[q].dist < cs[best].dist) best = q;
-    c = cs[best]; c.dist -= BOX_MARGIN;
+    c = cs[best]; c.dist -= BOX_MARGIN; c.n_raw = c.n;
     adjust_internal_edge(t, c.pb, c.n, c.dist);
     return true;
 }
@@ -353,7 +353,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             // bodies, then floor, ceiling, -x wall, +x wall (Arena.cpp:1036-1101); the contact-added callbacks fire in that order
             nw.car_mesh(A, mesh, ci, [&](const Cand& k, int obj) {
                 if (mesh_point(car.b, k, obj, CBT_CAR)) {
-                    car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427)
+                    car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n_raw;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427) sees the point BEFORE btAdjustInternalEdgeContacts (Arena.cpp:276-280)
                 }
             });
             for (int k = 0; k < n; k++) { manifold_finish_static(out[k], car.b, v3(0, 0, 0)); out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].sid = (n_man > 0 && k >= m_start) ? SID_MESH2 : 0; out[k].special = 0; }

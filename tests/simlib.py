@@ -346,6 +346,6 @@ def write_cmf_parts(verts_uu, tris, parts, root):
 
 
 # the two-file fixture (tests/golden/seam_golden.npz): ticks for which a tape is bit-identical to the reference; not listed = its whole length.
-# car_slides_along_panel: the car ends up in a corner far from the seam, where at tick 251 GJK between a hitbox edge and two nearly coplanar
-# fillet triangles amplifies a last-bit difference that the uu-rounded comparison had not shown (its one-tick pairs are all bit-equal)
-SEAM_EXACT_UNTIL = {"car_slides_along_panel": 250}
+# (Empty since the car's world-contact normal is the one the reference's callback sees -- the narrowphase normal BEFORE the internal-edge
+# adjustment, Arena.cpp:218-282; `car_slides_along_panel` had left at tick 251, found with tools/raw_divergence.py.)
+SEAM_EXACT_UNTIL = {}
