@@ -82,7 +82,7 @@ void run_tape_raw_t(RlgpuArenaState* s, const float* tape, int ticks, float* raw
 }
 // ... and the contact list of the LAST tick as the solver saw it (the 16 floats of debug_tick_t), for a tick reached inside the stepper's own units
 template <int NC>
-int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2) {
+int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2, float* wheels_out) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
@@ -111,6 +111,15 @@ int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float*
             q[14] = sb.v.x; q[15] = sb.w.y;
         }
     }
+    if (wheels_out)   // every car's wheel scratch of that last tick, laid out like ref_debug_wheels (4 x 12 floats per car; [1] is unused)
+        for (int k = 0; k < NC; k++) for (int w = 0; w < 4; w++) {
+            const WheelTmp& wt = W.ctx[k].w[w];
+            float* o = wheels_out + (size_t)(k * 4 + w) * 12;
+            o[0] = wt.susp_len; o[1] = (float)wt.ground; o[2] = wt.susp_rel_vel; o[3] = wt.clipped_inv;
+            o[4] = wt.contact_point.x; o[5] = wt.contact_point.y; o[6] = wt.contact_point.z;
+            o[7] = wt.contact_normal.x; o[8] = wt.contact_normal.y; o[9] = wt.contact_normal.z;
+            o[10] = wt.hard_point.z; o[11] = len(wt.impulse);
+        }
     arena_to_host(A, G, *s);
     return n;
 }
@@ -118,8 +127,8 @@ int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float*
 
 extern "C" {
 
-int port_run_tape_contacts(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2) {
-    if (s->num_cars == 2) return run_tape_contacts_t<2>(s, tape, ticks, out, cap, out2); else if (s->num_cars == 4) return run_tape_contacts_t<4>(s, tape, ticks, out, cap, out2); else return run_tape_contacts_t<6>(s, tape, ticks, out, cap, out2);
+int port_run_tape_contacts(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2, float* wheels_out) {
+    if (s->num_cars == 2) return run_tape_contacts_t<2>(s, tape, ticks, out, cap, out2, wheels_out); else if (s->num_cars == 4) return run_tape_contacts_t<4>(s, tape, ticks, out, cap, out2, wheels_out); else return run_tape_contacts_t<6>(s, tape, ticks, out, cap, out2, wheels_out);
 }
 void port_run_tape_raw(RlgpuArenaState* s, const float* tape, int ticks, float* raw_out) {
     if (s->num_cars == 2) run_tape_raw_t<2>(s, tape, ticks, raw_out); else if (s->num_cars == 4) run_tape_raw_t<4>(s, tape, ticks, raw_out); else run_tape_raw_t<6>(s, tape, ticks, raw_out);

@@ -571,6 +571,10 @@ struct TickWork {
 // Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
 // contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy
 // boxes (with the predicted rotation), broadphase cells, union-find and the quickSort are all that is needed to ORDER them.
+#ifdef RLG_BP_HISTORY
+struct BpHistory { int cell[8]; int seq[8]; int next_seq; bool init; };
+inline BpHistory& bp_history() { static thread_local BpHistory h{}; return h; }
+#endif
 template <int NC, int MAXC>
 RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
@@ -660,8 +664,17 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
             }
         }
         // dynamic partners filed in the same cell neighbourhood with overlapping proxy boxes (pairs are made by the lower body)
+#ifdef RLG_BP_HISTORY
+        int qorder[NB], nq = 0;
+        for (int q = p + 1; q < NB; q++) qorder[nq++] = q;
+        for (int a = 1; a < nq; a++) { const int v = qorder[a]; int b2 = a - 1; while (b2 >= 0 && bp_history().seq[qorder[b2]] > bp_history().seq[v]) { qorder[b2 + 1] = qorder[b2]; b2--; } qorder[b2 + 1] = v; }
+        for (int qi = 0; qi < nq; qi++) {
+            const int q = qorder[qi];
+            if (!live[q]) continue;
+#else
         for (int q = p + 1; q < NB; q++) {
             if (!live[q]) continue;
+#endif
             const int dx = cx[p] - cx[q], dy = cy[p] - cy[q], dz = cz[p] - cz[q];
             if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
             if (!aabb_touch(plo[p], phi[p], plo[q], phi[q])) continue;
@@ -694,6 +707,35 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
     L.n = n;
 }
 
+#ifdef RLG_BP_HISTORY   /* HOST PROTOTYPE (tools/raw_divergence.py): the arrival order of the dynamic proxies in btRSBroadphase's cell lists, one env */
+template <int NC>
+inline void bp_history_track(const Arena<NC>& A, bool ball_asleep) {
+    BpHistory& H = bp_history();
+    constexpr int NB = NC + 1;
+    if (!H.init) {   // a fresh arena: proxies created in order (ball, cars) at their creation poses (btCollisionWorld::addCollisionObject: the shape's box, no threshold)
+        int i, j, k; V3 lo, hi;
+        sphere_shape_aabb(v3(0.f, 0.f, K::BALL_REST_Z * UU2BT), lo, hi); bp_cell_of(lo, i, j, k); H.cell[0] = bp_cell_index(i, j, k);
+        M3 id; id.r0 = v3(1, 0, 0); id.r1 = v3(0, 1, 0); id.r2 = v3(0, 0, 1);
+        compound_shape_aabb(v3(0.f, 0.f, 17.f * UU2BT), id, lo, hi); bp_cell_of(lo, i, j, k);
+        for (int b = 1; b < NB; b++) H.cell[b] = bp_cell_index(i, j, k);
+        for (int b = 0; b < NB; b++) H.seq[b] = b;
+        H.next_seq = NB; H.init = true;
+    }
+    bool moved[8];
+    for (int b = 0; b < NB; b++) {
+        moved[b] = false;
+        if (b == 0 && ball_asleep) continue;                 // updateAabbs skips inactive objects
+        if (b > 0 && !car_collides(A.cars[b - 1])) continue;
+        V3 lo, hi;
+        if (b == 0) ball_proxy_aabb(A.ball, lo, hi); else car_proxy_aabb(A.cars[b - 1], lo, hi);
+        int i, j, k; bp_cell_of(lo, i, j, k);
+        const int c = bp_cell_index(i, j, k);
+        if (c != H.cell[b]) { H.cell[b] = c; moved[b] = true; }
+    }
+    for (int b = 0; b < NB; b++) if (moved[b]) H.seq[b] = H.next_seq++;   // erased from its old lists, pushed back onto the new ones, in object order
+}
+#endif
+
 // per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts
 template <int NC, int MAXC, class NW>
 RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
@@ -701,6 +743,9 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     ball_car_touch = false;
+#ifdef RLG_BP_HISTORY
+    bp_history_track(A, W.ball_asleep);
+#endif
     // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
     // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
     int n = 0, ball_man = 0, max_man = 0;

@@ -58,8 +58,9 @@ if first is not None and os.environ.get("RAWDIV_CONTACTS", "1") == "1":
     st = ArenaState.from_buffer_copy(bytes(st0))
     buf = np.zeros((64, 16), np.float32)
     buf2 = np.zeros((64, 16), np.float32)
-    port.lib.port_run_tape_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]; port.lib.port_run_tape_contacts.restype = C.c_int
-    n = port.lib.port_run_tape_contacts(C.byref(st), tape.ctypes.data, T, buf.ctypes.data, 64, buf2.ctypes.data)
+    wp = np.zeros((nc, 4, 12), np.float32)
+    port.lib.port_run_tape_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]; port.lib.port_run_tape_contacts.restype = C.c_int
+    n = port.lib.port_run_tape_contacts(C.byref(st), tape.ctypes.data, T, buf.ctypes.data, 64, buf2.ctypes.data, wp.ctypes.data)
     print(f"port contacts of tick {T} (a, b, sid | ra | rb | normal | dist | applied):")
     for r in buf[:n]:
         print("   a %2d b %2d sid %d | ra (%.6f %.6f %.6f) | rb (%.6f %.6f %.6f) | n (%.7f %.7f %.7f) | dist %.7g | applied %.7g" % (r[0], r[1], r[2], *r[4:7], *r[7:10], *r[10:13], r[13], r[14]))
@@ -83,6 +84,15 @@ if first is not None and os.environ.get("RAWDIV_CONTACTS", "1") == "1":
     nf = ref.lib.ref_debug_manifold_friction(a2, fb.ctypes.data, 64)
     for q in fb[:nf]:
         print("      friction dir (%.7f %.7f %.7f) applied %.7g | mu %.4g restitution %.4g | applied normal %.7g" % (*q[0:3], q[3], q[4], q[5], q[6]))
+    # wheels of that tick: suspension length, relative velocity, contact point / normal, |friction impulse| (the port's column 1 = what the ray hit: -1 none, 0 world, 1 ball, 2 + i car i)
+    ref.lib.ref_debug_wheels.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for k in range(nc):
+        wr = np.zeros((4, 12), np.float32); ref.lib.ref_debug_wheels(a2, k, wr.ctypes.data)
+        cols = [0, 2, 3, 4, 5, 6, 7, 8, 9, 11]
+        if not np.array_equal(wp[k][:, cols].view(np.uint32), wr[:, cols].view(np.uint32)):
+            for w in range(4):
+                print("   car%d wheel %d port: susp %.7g relvel %.7g inv %.7g cp (%.6f %.6f %.6f) n (%.6f %.6f %.6f) |imp| %.7g hit %d" % (k, w, wp[k, w, 0], wp[k, w, 2], wp[k, w, 3], *wp[k, w, 4:7], *wp[k, w, 7:10], wp[k, w, 11], int(wp[k, w, 1])))
+                print("   car%d wheel %d ref : susp %.7g relvel %.7g inv %.7g cp (%.6f %.6f %.6f) n (%.6f %.6f %.6f) |imp| %.7g" % (k, w, wr[w, 0], wr[w, 2], wr[w, 3], *wr[w, 4:7], *wr[w, 7:10], wr[w, 11]))
     print("car0 before that tick (reference): origin", pre[1, :3], "vel", pre[1, 12:15], "angvel", pre[1, 15:18])
 
 if first is not None:
