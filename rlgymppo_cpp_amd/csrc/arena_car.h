@@ -85,7 +85,7 @@ RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTm
     V3 rel1 = w.contact_point - c.b.pos;
     V3 vel1 = body_vel_at(c.b, rel1);
     V3 vel2 = v3(0, 0, 0);
-    float diag2 = 0.f;
+    float g_dot = 0.f;
     const Body* gb = nullptr; float g_inv_mass = 0.f; V3 g_inv_inertia = v3(0, 0, 0);
     if (w.ground == 1) { gb = &A.ball.b; g_inv_mass = BALL_INV_MASS; g_inv_inertia = ball_inv_inertia_local(); }
     else if (w.ground >= 2) { gb = &A.cars[w.ground - 2].b; g_inv_mass = CAR_INV_MASS; g_inv_inertia = car_inv_inertia_local(); }
@@ -94,10 +94,11 @@ RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTm
         rel2 = w.contact_point - gb->pos;
         vel2 = body_vel_at(*gb, rel2);
         V3 bJ = tmul(gb->rot, cross(rel2, -axle));
-        diag2 = g_inv_mass + dot(g_inv_inertia * bJ, bJ);
+        g_dot = dot(g_inv_inertia * bJ, bJ);
     }
     V3 aJ = tmul(c.b.rot, cross(rel1, axle));  // world2A * (rel_pos1 x normal), world2A = basis^T
-    float diag = CAR_INV_MASS + dot(car_inv_inertia_local() * aJ, aJ) + diag2;
+    // btJacobianEntry (btJacobianEntry.h:50): m_Adiag = massInvA + m_0MinvJt.dot(m_aJ) + massInvB + m_1MinvJt.dot(m_bJ), summed left to right
+    float diag = ((CAR_INV_MASS + dot(car_inv_inertia_local() * aJ, aJ)) + g_inv_mass) + g_dot;
     float rel_vel = dot(axle, vel1 - vel2);
     float side_impulse = -0.2f * rel_vel * (1.f / diag);
     float rolling;

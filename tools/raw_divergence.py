@@ -23,13 +23,16 @@ if which == "seam":
     ref = RefSim(verts, tris, mesh_dir=root)
 else:
     port.set_mesh(verts, tris); ref = RefSim(verts, tris)
+# the live arena visits its cars in ITS unordered_set's order (heap addresses of this process), not in the recording arena's: the port follows it
+a = ref.arena(nc // 2); ref.set_state(a, st0)
+st0.car_order = ref.get_state(a).car_order
+print("car order of the live reference arena: %x (the fixture's: %x)" % (st0.car_order, ArenaState.from_buffer_copy(gold[f"phys/{name}/start_raw"].tobytes()).car_order))
 # port: raw state after every tick
 raw_p = np.zeros((ticks, 1 + nc, 18), np.float32)
 st = ArenaState.from_buffer_copy(bytes(st0))
 port.lib.port_run_tape_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 port.lib.port_run_tape_raw(C.byref(st), tape.ctypes.data, ticks, raw_p.ctypes.data)
 # reference: the same tape, tick by tick
-a = ref.arena(nc // 2); ref.set_state(a, st0)
 ref.lib.ref_arena_get_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 raw_r = np.zeros((ticks, 1 + nc, 18), np.float32)
 for t in range(ticks):
@@ -67,6 +70,8 @@ if first is not None and os.environ.get("RAWDIV_CONTACTS", "1") == "1":
     for q in buf2[:n]:
         print("      friction dir (%.7f %.7f %.7f) applied %.7g | normal rhs %.7g jac %.7g | ext_f (%.7g %.7g %.7g) ext_t (%.7g %.7g %.7g) | friction rhs %.7g jac %.7g" % (*q[0:3], q[3], q[4], q[5], *q[6:9], *q[9:12], q[12], q[13]))
     a2 = ref.arena(nc // 2); ref.set_state(a2, st0)
+    if ref.get_state(a2).car_order != st0.car_order:
+        print("   (the second reference arena visits its cars in another order, %x: its dumps below may not belong to the same run)" % ref.get_state(a2).car_order)
     for t in range(T):
         for k in range(nc):
             ref.set_controls(a2, k, tape[t, k])
@@ -89,7 +94,7 @@ if first is not None and os.environ.get("RAWDIV_CONTACTS", "1") == "1":
     for k in range(nc):
         wr = np.zeros((4, 12), np.float32); ref.lib.ref_debug_wheels(a2, k, wr.ctypes.data)
         cols = [0, 2, 3, 4, 5, 6, 7, 8, 9, 11]
-        if not np.array_equal(wp[k][:, cols].view(np.uint32), wr[:, cols].view(np.uint32)):
+        if not np.array_equal(wp[k][:, cols], wr[:, cols]):   # (values: a -0 against a +0 is not a difference here)
             for w in range(4):
                 print("   car%d wheel %d port: susp %.7g relvel %.7g inv %.7g cp (%.6f %.6f %.6f) n (%.6f %.6f %.6f) |imp| %.7g hit %d" % (k, w, wp[k, w, 0], wp[k, w, 2], wp[k, w, 3], *wp[k, w, 4:7], *wp[k, w, 7:10], wp[k, w, 11], int(wp[k, w, 1])))
                 print("   car%d wheel %d ref : susp %.7g relvel %.7g inv %.7g cp (%.6f %.6f %.6f) n (%.6f %.6f %.6f) |imp| %.7g" % (k, w, wr[w, 0], wr[w, 2], wr[w, 3], *wr[w, 4:7], *wr[w, 7:10], wr[w, 11]))
