@@ -239,12 +239,12 @@ PHYS_EXACT_UNTIL = {"3v3_kickoff": 280}   # the six-car heap.  What is left ther
 PHYS_AFTER_EXACT = {}
 
 # One tick from the reference's own state: every recorded pair of 30 of the 31 scenarios is bit-equal (asserted in the tests); the tolerances
-# below are what the 19 pairs of the six-car heap that are not (of its 113) stay within.
+# below are what the 14 pairs of the six-car heap that are not (of its 113) stay within.
 ONE_TICK_TOL = {
     "default": {"pos": 0.0, "vel": 0.0},
     "3v3_kickoff": {"pos": 5.0, "vel": 500.0, "flags_loose": True},     # ticks 282-356: pair order inside a broadphase cell / stale proxy boxes (see PHYS_EXACT_UNTIL); tick 317: a supersonic car into the heap
 }
-ONE_TICK_NOT_EXACT_MAX = 19      # pairs (of 1722) that are not bit-equal to the reference, all in 3v3_kickoff
+ONE_TICK_NOT_EXACT_MAX = 14      # pairs (of 1722) that are not bit-equal to the reference, all in 3v3_kickoff
 
 
 # observation tolerance per gym fixture (default 2e-3 = 8 uu on a position, 4.6 uu/s on a velocity, 0.011 rad/s on an angular velocity)

@@ -239,7 +239,7 @@ def test_port_one_tick_vs_reference_states():
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),
     so both sides start from the same bits.  The restatement follows the reference's x86 arithmetic (rl_math.h, rl_libm.h) and its
     narrowphase to the bit (GJK, the penetration-depth solver with EPA, the wheel rays' convex cast, the internal-edge adjustment), and the
-    state carries the arena's car order: EVERY pair of 30 scenarios is EQUAL bit for bit, and all but 19 of the six-car heap's 113."""
+    state carries the arena's car order: EVERY pair of 30 scenarios is EQUAL bit for bit, and all but 14 of the six-car heap's 113."""
     from simlib import PortSim, ONE_TICK_NOT_EXACT_MAX
     sgl = np.load(os.path.join(GOLD, "sim_golden.npz")); ss = np.load(os.path.join(GOLD, "sim_steps.npz"))
     port = PortSim(); port.set_mesh(sgl["mesh_verts"], sgl["mesh_tris"])
