@@ -84,11 +84,14 @@ RLG_HD int manifold_replace_index(const Contact* pts, V3 new_local, float new_di
     for (int i = 0; i < 4; i++) { float v = fabsf(res[i]); if (v > mv) { best = i; mv = v; } }
     return best < 0 ? 0 : best;
 }
-// Adds a point (normal n on b, world point pb on b, depth) of body `a` against a STATIC body; returns the slot it went to, -1 if
-// rejected (btManifoldResult.cpp:112-115).  `cap` <= 4 slots are available at pts.
+// Adds a point (normal n on b, world point pb on b, depth; pa = the world point on a as the detector reported it) of body `a` against a
+// STATIC body; returns the slot it went to, -1 if rejected (btManifoldResult.cpp:112-115).  `cap` <= 4 slots are available at pts.
+RLG_HD int manifold_add_static(Contact* pts, int& count, int cap, const Body& a, V3 n, V3 pb, float depth, float breaking, V3 pa);
 RLG_HD int manifold_add_static(Contact* pts, int& count, int cap, const Body& a, V3 n, V3 pb, float depth, float breaking) {
+    return manifold_add_static(pts, count, cap, a, n, pb, depth, breaking, pb + n * depth);
+}
+RLG_HD int manifold_add_static(Contact* pts, int& count, int cap, const Body& a, V3 n, V3 pb, float depth, float breaking, V3 pa) {
     if (depth > breaking) return -1;
-    V3 pa = pb + n * depth;
     V3 la = tmul(a.rot, pa - a.pos);     // invXform into body a's frame
     int slot = count;
     if (count >= cap) slot = cap == 4 ? manifold_replace_index(pts, la, depth) : cap - 1;

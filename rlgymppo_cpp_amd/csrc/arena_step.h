@@ -143,7 +143,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c, bool 
 #endif
     if (hit_) {
         if (g.dist > CBT_CAR) return false;          // btManifoldResult::addContactPoint's own gate (btManifoldResult.cpp:112)
-        c.n = g.n; c.pb = g.pb; c.dist = g.dist; c.n_raw = g.n;
+        c.n = g.n; c.pb = g.pb; c.dist = g.dist; c.n_raw = g.n; c.pa = g.pb + g.n * g.dist;
 #ifdef RLG_ITEM_CLOCK
         const unsigned long long te0_ = RLG_ITEM_CLOCK();
 #endif
@@ -166,7 +166,7 @@ RLG_HD bool hitbox_triangle(V3 bc, const M3& R, const MeshTri& t, Cand& c, bool 
     if (nc == 0) return false;
     int best = 0;
     for (int q = 1; q < nc; q++) if (cs[q].dist < cs[best].dist) best = q;
-    c = cs[best]; c.dist -= BOX_MARGIN; c.n_raw = c.n;
+    c = cs[best]; c.dist -= BOX_MARGIN; c.n_raw = c.n; c.pa = c.pb + c.n * c.dist;
     adjust_internal_edge(t, c.pb, c.n, c.dist);
     return true;
 }
@@ -179,7 +179,7 @@ struct NarrowInline {
         ball_query_aabb(bp, lo, hi);
         mesh_query(mesh, lo, hi, [&](int ti) {
             Cand c;
-            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[ti], c.pb, c.n, c.dist); emit(c, (int)mesh.tris[ti].obj); }
+            if (sphere_triangle(bp, r, CBT_BALL, mesh.tris[ti], c.pb, c.n, c.dist) && !(c.dist > CBT_BALL)) { c.n_raw = c.n; c.pa = c.pb + c.n * c.dist; adjust_internal_edge(mesh.tris[ti], c.pb, c.n, c.dist); emit(c, (int)mesh.tris[ti].obj); }
         });
     }
     template <int NC, class F>
@@ -270,7 +270,7 @@ RLG_HD_T4 void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, Col
 #endif
     if (it.type == 0) {
         const float r = K::BALL_RADIUS * UU2BT;
-        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], one.pb, one.n, one.dist) && !(one.dist > CBT_BALL)) { adjust_internal_edge(mesh.tris[it.ref], one.pb, one.n, one.dist); n = 1; }
+        if (sphere_triangle(A.ball.b.pos, r, CBT_BALL, mesh.tris[it.ref], one.pb, one.n, one.dist) && !(one.dist > CBT_BALL)) { one.n_raw = one.n; one.pa = one.pb + one.n * one.dist; adjust_internal_edge(mesh.tris[it.ref], one.pb, one.n, one.dist); n = 1; }
     } else if (it.type == 1) {
         const Car& car = A.cars[it.a];
         V3 bc = car.b.pos + car.b.rot * hitbox_off();
@@ -311,7 +311,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             m_obj = obj;
         }
         if (n_man >= MESH_MANIFOLDS) { RLG_DBG_COUNT(4); return false; }   // a third mesh object with points at once: dropped (counted with the pool overflows)
-        if (manifold_add_static(out + m_start, m_cnt, 4, b, k.n, k.pb, k.dist, breaking) < 0) return false;
+        if (manifold_add_static(out + m_start, m_cnt, 4, b, k.n, k.pb, k.dist, breaking, k.pa) < 0) return false;
         body_obj[body][n_man] = (int8_t)obj;
         n = m_start + m_cnt;
         return true;

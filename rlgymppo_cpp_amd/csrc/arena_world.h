@@ -109,7 +109,11 @@ RLG_HD bool ray_aabb(const BvhNode& n, V3 from, V3 inv_d, float tmax) {
 // n_raw: the normal as the narrowphase reported it, BEFORE the internal-edge adjustment -- what the reference's contact-added callback hands
 // to Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:218-282: the callbacks run first, btAdjustInternalEdgeContacts last); n is the
 // manifold point's normal after it.  Only the hitbox-triangle path fills n_raw.
-struct Cand { V3 pb; V3 n; float dist; V3 n_raw; };
+// pa: the world point on A as the detector reported it (pb + n * dist with the UNadjusted normal, btManifoldResult.cpp:117): the manifold
+// point's local point on A is taken from it before the callback moves pb along the adjusted normal (btInternalEdgeUtility.cpp: "reproject
+// collision point along normal") -- rebuilding it from the adjusted pb and n is off by a rounding.  Filled where n_raw is, and by the ball's
+// mesh contacts.
+struct Cand { V3 pb; V3 n; float dist; V3 n_raw; V3 pa; };
 template <int CAP>
 RLG_HD void cand_add(Cand (&cs)[CAP], int& n, const Cand& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,7 +158,7 @@ struct CollideItem {
 #endif
 // measured over 614 K env-ticks of random play (tools: RLG_QSTAT hook): items <= 16 in 99.93 % of the ticks (max seen > 16), candidate slots <= 88,
 // pool entries <= 12 -- the caps below leave the inline fallback to the truly pathological ticks
-constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 28;   // (pool entries of 40 bytes; measured fill <= 12)
+constexpr int ITEM_CAP = RLG_ITEM_CAP, POOL_CAP = 22;   // (pool entries of 52 bytes; measured fill <= 12)
 constexpr int LEAF_SLOTS = 4;              // BVH leaves hold <= 4 triangles (arena_mesh.cpp); the device reserves a full block per leaf
 constexpr uint32_t CAND_HOLE = 0xFFFFFFFFu;  // unused slot of such a block
 #ifndef RLG_FRONTIER_CAP

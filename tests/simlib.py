@@ -260,8 +260,10 @@ GYM_EXACT = {"ts8_random", "ts8_chase", "ts1_random", "1v1_timeout", "1v1_goal",
 # players in the reference's unordered-set order, this build in slot order)
 GYM_EXACT_OBS = {"2v2_padded3_zerosum_random"}
 
-# steps up to which a free-running gym rollout is compared (random actions with hitbox contacts: chaotic afterwards, like PHYS_FREE_RUN's `until`)
-GYM_HORIZON = {"2v2_padded3_zerosum_random": 64}
+# steps up to which a free-running gym rollout is compared on the HIP path (resident arenas).  Empty since the manifold point's local point
+# on the car comes from the detector's world point and not from the edge-adjusted one (round 3: `2v2_padded3_zerosum_random` had left at
+# step 65; as tapes against the live reference both random rollouts are bit-identical in Bullet units to their end, tools/raw_divergence.py gym)
+GYM_HORIZON = {}
 # the host build's gym test hands the state over in uu after every step (one rounding per step the reference's resident arena does not
 # make): its random 2v2 rollout with hitbox contacts is compared up to here
 GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64}

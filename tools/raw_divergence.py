@@ -2,7 +2,7 @@
 round to the same uu float, so a tape that is bit-identical in the exchanged fields can already differ underneath.  Runs the LIVE reference
 (oracle/_ref/libref_oracle.so, needs /root/reference's build) and the host build of the stepper over a tape of the two-file mesh fixture
 (tests/golden/seam_golden.npz) or of the main fixture and prints, per tick, the first raw field (pos / rot / vel / angvel of ball and
-cars) whose bits differ.      usage: raw_divergence.py <seam|main> <scenario> [ticks]"""
+cars) whose bits differ.      usage: raw_divergence.py <seam|main|gym> <scenario or gym case> [ticks]"""
 import ctypes as C, os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,9 +12,25 @@ from rlgymppo_cpp_amd.state import ArenaState
 
 which, name = sys.argv[1], sys.argv[2]
 gold = np.load(os.path.join(ROOT, "tests", "golden", "seam_golden.npz" if which == "seam" else "sim_golden.npz"))
-tape = np.ascontiguousarray(gold[f"phys/{name}/tape"], np.float32)
+if which == "gym":
+    # a recorded gym rollout as a control tape, up to its first episode end: Gym::Step runs ONE tick on the previous step's controls, takes
+    # the GameState, then sets the new controls and runs tickSkip - 1 more (Gym.cpp:68-102); the first step's "previous" controls are zeros
+    acts, dones = gold[f"gym/{name}/actions"], gold[f"gym/{name}/done"]
+    n_steps = int(np.argmax(dones)) if dones.any() else len(acts)
+    st0 = ArenaState.from_buffer_copy(gold[f"gym/{name}/start"].tobytes()); nc = st0.num_cars
+    table = np.zeros((90, 8), np.float32); _pl = PortSim().lib; _pl.port_action_table.argtypes = [C.c_void_p]; _pl.port_action_table(table.ctypes.data)
+    skip = int(gold[f"gym/{name}/cfg"][1])
+    tape = np.zeros((n_steps * skip, nc, 8), np.float32)
+    for s_ in range(n_steps):
+        for k in range(nc):
+            tape[s_ * skip + 1:(s_ + 1) * skip, k] = table[acts[s_, k]]
+            if s_ + 1 < n_steps:
+                tape[(s_ + 1) * skip, k] = table[acts[s_, k]]
+    print(f"gym rollout {name}: {n_steps} steps x {skip} ticks before its first episode end")
+else:
+    tape = np.ascontiguousarray(gold[f"phys/{name}/tape"], np.float32)
+    st0 = ArenaState.from_buffer_copy(gold[f"phys/{name}/start_raw"].tobytes()); nc = st0.num_cars
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else len(tape)
-st0 = ArenaState.from_buffer_copy(gold[f"phys/{name}/start_raw"].tobytes()); nc = st0.num_cars
 verts, tris = gold["mesh_verts"], gold["mesh_tris"]
 port = PortSim()
 if which == "seam":
@@ -26,7 +42,7 @@ else:
 # the live arena visits its cars in ITS unordered_set's order (heap addresses of this process), not in the recording arena's: the port follows it
 a = ref.arena(nc // 2); ref.set_state(a, st0)
 st0.car_order = ref.get_state(a).car_order
-print("car order of the live reference arena: %x (the fixture's: %x)" % (st0.car_order, ArenaState.from_buffer_copy(gold[f"phys/{name}/start_raw"].tobytes()).car_order))
+print("car order of the live reference arena: %x" % st0.car_order)
 # port: raw state after every tick
 raw_p = np.zeros((ticks, 1 + nc, 18), np.float32)
 st = ArenaState.from_buffer_copy(bytes(st0))
