@@ -277,6 +277,17 @@ RLG_HD void event_values(const Snapshot<NC>& S, const GymEnv<NC>& G, int k, floa
     v[4] = S.touched[k] ? 1.f : 0.f; v[5] = (float)G.counters[k][3]; v[6] = (float)G.counters[k][4]; v[7] = (float)G.counters[k][1];
     v[8] = (float)G.counters[k][6]; v[9] = S.demoed[k] ? 1.f : 0.f; v[10] = S.boost_frac[k];
 }
+// powf as the reference's host libm returns it.  glibc's powf works in double and rounds once (its result is the correctly rounded one
+// but for arguments within 2^-26 relative of a rounding boundary); the device library's powf is a float algorithm good to 1 ulp, which
+// showed as last-bit differences in SaveBoostReward / TouchBallReward on the random 2v2 / 3v3 rollouts.  The double pow rounded to float
+// is correctly rounded too (double rounding aside), a few hundred cycles per player and STEP -- nothing next to the 8 ticks before it.
+RLG_HD float libm_powf(float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)pow((double)x, (double)y);
+#else
+    return powf(x, y);
+#endif
+}
 template <int NC>
 RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
     for (int k = 0; k < NC; k++) rew[k] = 0.f;
@@ -291,7 +302,7 @@ RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymC
                     for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) { r += fmaxf(nv[i] - G.event_last[k][i], 0.f) * cfg.event_weights[i]; G.event_last[k][i] = nv[i]; }
                 } break;
                 case RW_VELOCITY: r = len(S.car_vel[k]) / 2300.f * (1 - 2 * (T.p0 != 0.f ? 1 : 0)); break;
-                case RW_SAVE_BOOST: r = clampf(powf(S.boost_frac[k], T.p0), 0.f, 1.f); break;
+                case RW_SAVE_BOOST: r = clampf(libm_powf(S.boost_frac[k], T.p0), 0.f, 1.f); break;
                 case RW_VEL_BALL_TO_GOAL: {
                     bool orange_goal = (k % 2) == 0;
                     if (T.p0 != 0.f) orange_goal = !orange_goal;
@@ -307,7 +318,7 @@ RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymC
                     V3 dir = rs_normalized(S.ball_pos - S.car_pos[k]);
                     r = dot(S.car_fwd[k], dir);
                 } break;
-                case RW_TOUCH_BALL: r = S.touched[k] ? powf((S.ball_pos.z + 92.75f) / (92.75f * 2), T.p0) : 0.f; break;
+                case RW_TOUCH_BALL: r = S.touched[k] ? libm_powf((S.ball_pos.z + 92.75f) / (92.75f * 2), T.p0) : 0.f; break;
                 default: break;
             }
             rew[k] += r * T.weight;

@@ -237,6 +237,8 @@ def main_one_team():
                 acts = acts[: t + 1]
                 break
         out[f"gym/{case}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        s0.car_order = start.car_order
+        out[f"gym/{case}/start_raw"] = np.frombuffer(bytes(s0), np.uint8).copy()
         out[f"gym/{case}/obs0"] = obs0
         out[f"gym/{case}/actions"] = acts
         out[f"gym/{case}/obs"] = np.stack(obs); out[f"gym/{case}/rew"] = np.stack(rew); out[f"gym/{case}/done"] = np.array(done, np.int32)
@@ -319,6 +321,8 @@ def main():
                 acts = acts[: t + 1]
                 break
         out[f"gym/{case}/start"] = np.frombuffer(bytes(start), np.uint8).copy()
+        s0.car_order = start.car_order   # what the gym was reset to (the rollout continues from THAT, not from the copy read back): see add_gym_start_raw.py
+        out[f"gym/{case}/start_raw"] = np.frombuffer(bytes(s0), np.uint8).copy()
         out[f"gym/{case}/obs0"] = obs0
         out[f"gym/{case}/actions"] = acts
         out[f"gym/{case}/obs"] = np.stack(obs); out[f"gym/{case}/rew"] = np.stack(rew); out[f"gym/{case}/done"] = np.array(done, np.int32)

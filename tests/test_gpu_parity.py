@@ -245,9 +245,10 @@ def test_hip_one_team_gym_rollouts_vs_reference_fixtures():
 def test_hip_gym_rollouts_vs_reference_fixtures(sg):
     """Every committed rollout of the REAL reference Gym replayed on the HIP path, no port in between: 1v1 example stack (full 160
     steps, the NoTouch timeout, a goal), 2v2 with every CommonRewards term (goal + assist + shot pass; shot + save + bump + demo),
-    zero-sum, DefaultOBSPadded(3), 3v3 DefaultOBS(165): done exactly, rewards, observation rows, and the event counters.  Seven of the
-    nine rollouts (simlib.GYM_EXACT: up to 160 gym steps = 1280 ticks of random play, a chase, the timeout, goals, assists, a save, a
-    demolition, every reward term, zero-sum) are reproduced EXACTLY: every observation row and every reward bit-equal to the reference's."""
+    zero-sum, DefaultOBSPadded(3), 3v3 DefaultOBS(165): done exactly, rewards, observation rows, and the event counters.  ALL of them
+    (simlib.GYM_EXACT: up to 160 gym steps = 1280 ticks of random play in 1v1, 100 steps of random 2v2, 90 of random 3v3, a chase, the
+    timeout, goals, assists, a save, a demolition, every reward term, zero-sum) are reproduced EXACTLY: every observation row and every
+    reward bit-equal to the reference's.  (The one-team test below runs the same body over the four spawnOpponents = false rollouts.)"""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from simlib import gym_compare_obs, GYM_OBS_TOL, GYM_HORIZON, GYM_EXACT, GYM_EXACT_OBS
     dev = torch.device("cuda", 0)
@@ -261,7 +262,7 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
         env = BatchedEnv(1, team, cfg=gcfg, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
         rows = env.n_agents
         assert rows == (team if one_team else nc)
-        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes())
+        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start_raw" if f"gym/{case}/start_raw" in sg.files else f"gym/{case}/start"].tobytes())
         env.upload_states([st])
         obs0 = env.reset(False)
         gym_compare_obs(obs0.cpu().numpy(), sg[f"gym/{case}/obs0"], nc, omp, [int(x) for x in sg[f"gym/{case}/player_order"][0]], 1e-5, f"{case} reset", one_team)

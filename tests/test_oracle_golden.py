@@ -282,7 +282,7 @@ def test_port_gym_vs_reference_golden(sg, port_lib):
         one_team = len(sg[f"gym/{case}/cfg"]) > 5 and int(sg[f"gym/{case}/cfg"][5]) == 0      # spawnOpponents = false
         cfg = gym_cfg_for_case(team, tick_skip, omp, rk, nts)
         cfg.one_team = 1 if one_team else 0
-        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes()); nc = 2 * team
+        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start_raw" if f"gym/{case}/start_raw" in sg.files else f"gym/{case}/start"].tobytes()); nc = 2 * team
         (st,), obs0 = port_gym_reset(port_lib, [st], cfg, run_setter=False)
         order0 = [int(x) for x in sg[f"gym/{case}/player_order"][0]]
         gym_compare_obs(obs0, sg[f"gym/{case}/obs0"], nc, omp, order0, 1e-5, f"{case} reset", one_team)

@@ -13,7 +13,7 @@ for fn in ("sim_golden.npz", "sim_golden_one_team.npz"):
         one_team = len(c5) > 5 and int(c5[5]) == 0
         cfg = gym_cfg_for_case(team, tick_skip, omp, rk, nts); cfg.one_team = 1 if one_team else 0
         nc = 2 * team
-        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start"].tobytes())
+        st = ArenaState.from_buffer_copy(sg[f"gym/{case}/start_raw" if f"gym/{case}/start_raw" in sg.files else f"gym/{case}/start"].tobytes())
         (st,), obs0 = port_gym_reset(port, [st], cfg, run_setter=False)
         acts = sg[f"gym/{case}/actions"]; obs = sg[f"gym/{case}/obs"]; rew = sg[f"gym/{case}/rew"]; done = sg[f"gym/{case}/done"]
         first_bad = None; worst_r = 0.0

@@ -17,7 +17,7 @@ if which == "gym":
     # the GameState, then sets the new controls and runs tickSkip - 1 more (Gym.cpp:68-102); the first step's "previous" controls are zeros
     acts, dones = gold[f"gym/{name}/actions"], gold[f"gym/{name}/done"]
     n_steps = int(np.argmax(dones)) if dones.any() else len(acts)
-    st0 = ArenaState.from_buffer_copy(gold[f"gym/{name}/start"].tobytes()); nc = st0.num_cars
+    st0 = ArenaState.from_buffer_copy(gold[f"gym/{name}/start_raw" if f"gym/{name}/start_raw" in gold.files else f"gym/{name}/start"].tobytes()); nc = st0.num_cars
     table = np.zeros((90, 8), np.float32); _pl = PortSim().lib; _pl.port_action_table.argtypes = [C.c_void_p]; _pl.port_action_table(table.ctypes.data)
     skip = int(gold[f"gym/{name}/cfg"][1])
     tape = np.zeros((n_steps * skip, nc, 8), np.float32)
