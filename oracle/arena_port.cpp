@@ -41,6 +41,35 @@ void step_t(RlgpuArenaState* s, int ticks, uint32_t seed, uint32_t env) {
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, seed, env, ev, W); }
     arena_to_host(A, G, *s);
 }
+// ... the same with the history in the caller's hands: hist[8] (all zero = a fresh arena) goes in before the ticks and comes back after them
+template <int NC>
+void step_hist_t(RlgpuArenaState* s, int ticks, uint16_t* hist) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];
+    MeshView mv = view();
+    TickWork<NC> W;
+    for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W); }
+    for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
+    arena_to_host(A, G, *s);
+}
+// n states stepped one tick each, one after the other, in ONE arena: what the state does not carry -- the broadphase's memory of where its
+// proxies were and in which order they arrived (Arena::bp_hist) -- passes from each to the next, as in an arena of the reference that is
+// set_state'd and stepped again and again (how the one-tick fixtures were recorded: tests/golden/make_sim_golden.py, the pair arena)
+template <int NC>
+void step_chain_t(RlgpuArenaState* s, int n) {
+    Arena<NC> A; GymEnv<NC> G;
+    MeshView mv = view();
+    TickWork<NC> W;
+    uint16_t hist[NC + 1] = {};
+    for (int i = 0; i < n; i++) {
+        arena_from_host(A, G, s[i]);
+        for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];
+        TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
+        for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
+        arena_to_host(A, G, s[i]);
+    }
+}
 // a whole control tape without leaving the stepper's own units: the state is converted once, every tick takes its controls from the tape
 // ([ticks][nc][8], the reference's CarControls order), and every `every`-th tick a copy is written out.  (port_arena_step tick by tick
 // rounds the state to uu and back between ticks, which the reference's free-running arena does not do.)
@@ -76,7 +105,11 @@ void run_tape_raw_t(RlgpuArenaState* s, const float* tape, int ticks, float* raw
         TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
         float* o = raw_out + (size_t)t * (1 + NC) * 18;
         put(o, A.ball.b);
-        for (int k = 0; k < NC; k++) put(o + 18 * (1 + k), A.cars[k].b);
+        for (int k = 0; k < NC; k++) {
+            Body b = A.cars[k].b;
+            if (A.cars[k].flags & CF_IS_DEMOED) b.rot = car_ghost_rot(A.cars[k]);     // the rigid body's own basis (the reference's raw dump reads the body)
+            put(o + 18 * (1 + k), b);
+        }
     }
     arena_to_host(A, G, *s);
 }
@@ -130,6 +163,13 @@ extern "C" {
 int port_run_tape_contacts(RlgpuArenaState* s, const float* tape, int ticks, float* out, int cap, float* out2, float* wheels_out) {
     if (s->num_cars == 2) return run_tape_contacts_t<2>(s, tape, ticks, out, cap, out2, wheels_out); else if (s->num_cars == 4) return run_tape_contacts_t<4>(s, tape, ticks, out, cap, out2, wheels_out); else return run_tape_contacts_t<6>(s, tape, ticks, out, cap, out2, wheels_out);
 }
+void port_step_hist(RlgpuArenaState* s, int ticks, uint16_t* hist8) {
+    if (s->num_cars == 2) step_hist_t<2>(s, ticks, hist8); else if (s->num_cars == 4) step_hist_t<4>(s, ticks, hist8); else step_hist_t<6>(s, ticks, hist8);
+}
+void port_step_chain(RlgpuArenaState* s, int n) {
+    if (n <= 0) return;
+    if (s->num_cars == 2) step_chain_t<2>(s, n); else if (s->num_cars == 4) step_chain_t<4>(s, n); else step_chain_t<6>(s, n);
+}
 void port_run_tape_raw(RlgpuArenaState* s, const float* tape, int ticks, float* raw_out) {
     if (s->num_cars == 2) run_tape_raw_t<2>(s, tape, ticks, raw_out); else if (s->num_cars == 4) run_tape_raw_t<4>(s, tape, ticks, raw_out); else run_tape_raw_t<6>(s, tape, ticks, raw_out);
 }
@@ -167,6 +207,17 @@ int port_gjk_box_triangle(const float* pos3, const float* rot9, const float* tri
     const bool hit = gjk_box_triangle(v3(pos3[0], pos3[1], pos3[2]), R, hitbox_core(), BOX_MARGIN, t, breaking, g, deep);
     out8[0] = g.n.x; out8[1] = g.n.y; out8[2] = g.n.z; out8[3] = g.pb.x; out8[4] = g.pb.y; out8[5] = g.pb.z; out8[6] = g.dist; out8[7] = deep ? 1.f : 0.f;
     return hit ? 1 : 0;
+}
+// the half extents btBoxShape's constructor is given for the hitbox (it keeps them minus 0.04 as the core: btBoxShape.h:82-90)
+void port_hitbox_ctor_half(float* out3) { const V3 h = hitbox_core(); out3[0] = h.x + 0.04f; out3[1] = h.y + 0.04f; out3[2] = h.z + 0.04f; }
+// the host build of csrc/arena_world.h:box_box_ode for two Octane hitboxes (box 1 = the manifold's body0): out = n x (normal[3], point[3], dist)
+int port_box_box(const float* pos1, const float* rot1, const float* pos2, const float* rot2, float* out) {
+    M3 R1 = m3_rows(v3(rot1[0], rot1[1], rot1[2]), v3(rot1[3], rot1[4], rot1[5]), v3(rot1[6], rot1[7], rot1[8]));
+    M3 R2 = m3_rows(v3(rot2[0], rot2[1], rot2[2]), v3(rot2[3], rot2[4], rot2[5]), v3(rot2[6], rot2[7], rot2[8]));
+    Cand cs[4]; int nc = 0;
+    box_box_ode(v3(pos1[0], pos1[1], pos1[2]), R1, v3(pos2[0], pos2[1], pos2[2]), R2, hitbox_half(), cs, nc);
+    for (int k = 0; k < nc; k++) { float* o = out + 7 * k; o[0] = cs[k].n.x; o[1] = cs[k].n.y; o[2] = cs[k].n.z; o[3] = cs[k].pb.x; o[4] = cs[k].pb.y; o[5] = cs[k].pb.z; o[6] = cs[k].dist; }
+    return nc;
 }
 // the host build of csrc/arena_simplex.h:ray_convex_cast as the wheel rays use it (arena_world.h:ray_ball_and_cars): out4 = fraction, normal as
 // btCollisionWorld::rayTestSingleInternal reports it (normalised once more); returns 1 on a hit
@@ -222,12 +273,14 @@ static void gym_reset_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, 
     arena_to_host(A, G, *s);
 }
 template <int NC>
-static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, const int32_t* actions, float* obs, float* rew, int32_t* done) {
+static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, const int32_t* actions, float* obs, float* rew, int32_t* done, uint16_t* hist = nullptr) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
+    if (hist) for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];      // the arena's broadphase history, kept by the caller (port_step_hist)
     MeshView mv = view();
     TickWork<NC> W;
     gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(*cfg), rew, done, W);
+    if (hist) for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     arena_to_host(A, G, *s);
 }
 
@@ -246,16 +299,20 @@ void port_gym_reset(RlgpuArenaState* states, int n, const void* cfg, float* obs,
         else gym_reset_t<6>(s, (const GymConfig*)cfg, e, o, run_setter);
     }
 }
-void port_gym_step(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done) {
+void port_gym_step_hist(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done, uint16_t* hist /* [n][8] or null */) {
     for (int e = 0; e < n; e++) {
+        uint16_t* h = hist ? hist + (size_t)e * 8 : nullptr;
         RlgpuArenaState* s = &states[e]; int nc = s->num_cars; int D = port_obs_size(cfg, nc);
         const int P = ((const GymConfig*)cfg)->one_team ? nc / 2 : nc;   // agent rows per env
         int32_t dn = 0;
-        if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
-        else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
-        else gym_step_t<6>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn);
+        if (nc == 2) gym_step_t<2>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn, h);
+        else if (nc == 4) gym_step_t<4>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn, h);
+        else gym_step_t<6>(s, (const GymConfig*)cfg, e, actions + (size_t)e * P, obs + (size_t)e * P * D, rew + (size_t)e * P, &dn, h);
         for (int k = 0; k < P; k++) done[(size_t)e * P + k] = dn;
     }
+}
+void port_gym_step(RlgpuArenaState* states, int n, const void* cfg, const int32_t* actions, float* obs, float* rew, int32_t* done) {
+    port_gym_step_hist(states, n, cfg, actions, obs, rew, done, nullptr);
 }
 int port_action_table(float* out) { memcpy(out, table(), sizeof(g_action_table)); return 90; }
 

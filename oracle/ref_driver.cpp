@@ -30,6 +30,7 @@
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionObjectWrapper.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionWorld.h>
 #include <bullet3-3.24/BulletCollision/CollisionShapes/btSphereShape.h>
+#include <bullet3-3.24/BulletCollision/CollisionDispatch/btBoxBoxDetector.h>
 #include "../include/rlgpu_state.h"
 
 #include <cstring>
@@ -334,6 +335,29 @@ int ref_gjk_box_triangle(const float* half3, const float* pos3, const float* rot
     return res.has ? 1 : 0;
 }
 
+// btBoxBoxDetector (ODE's dBoxBox2) on two boxes of the same full half extents, as btBoxBoxCollisionAlgorithm.cpp:55-70 runs it for two hitbox
+// children: every point it reports, in order.  out: n x (normalOnBInWorld[3], pointInWorld[3], depth).  Unit-level oracle for
+// csrc/arena_world.h:box_box_ode.
+int ref_box_box(const float* half3, const float* pos1, const float* rot1, const float* pos2, const float* rot2, float* out, int cap) {
+    btBoxShape b1(btVector3(half3[0], half3[1], half3[2])), b2(btVector3(half3[0], half3[1], half3[2]));
+    btBoxBoxDetector det(&b1, &b2);
+    btDiscreteCollisionDetectorInterface::ClosestPointInput input;
+    input.m_maximumDistanceSquared = BT_LARGE_FLOAT;
+    input.m_transformA = btTransform(btMatrix3x3(rot1[0], rot1[1], rot1[2], rot1[3], rot1[4], rot1[5], rot1[6], rot1[7], rot1[8]), btVector3(pos1[0], pos1[1], pos1[2]));
+    input.m_transformB = btTransform(btMatrix3x3(rot2[0], rot2[1], rot2[2], rot2[3], rot2[4], rot2[5], rot2[6], rot2[7], rot2[8]), btVector3(pos2[0], pos2[1], pos2[2]));
+    struct Res : public btDiscreteCollisionDetectorInterface::Result {
+        float* out; int cap; int n = 0;
+        void setShapeIdentifiersA(int, int) override {}
+        void setShapeIdentifiersB(int, int) override {}
+        void addContactPoint(const btVector3& nb, const btVector3& p, btScalar depth) override {
+            if (n < cap) { float* o = out + 7 * n; o[0] = nb[0]; o[1] = nb[1]; o[2] = nb[2]; o[3] = p[0]; o[4] = p[1]; o[5] = p[2]; o[6] = depth; }
+            n++;
+        }
+    } res; res.out = out; res.cap = cap;
+    det.getClosestPoints(input, res);
+    return res.n;
+}
+
 // btCollisionWorld::rayTestSingle on one convex object -- what a wheel's suspension ray meets when another car's hitbox child or the ball is
 // in its way (btDefaultVehicleRaycaster.cpp:34-52 -> btCollisionWorld::rayTest -> rayTestSingleInternal: btSubsimplexConvexCast of a point
 // against the shape, btCollisionWorld.cpp:267-310).  radius > 0: a btSphereShape, else a btBoxShape(half3).  out4 = hit fraction, m_hitNormalWorld.
@@ -395,6 +419,21 @@ void* ref_arena_new(int team_size) {
     for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE); a->AddCar(Team::ORANGE); }
     return a;
 }
+// The same arena with the cars at OTHER heap addresses: Arena::_cars is a std::unordered_set<Car*>, so the order of the reference's per-car
+// loops is a function of where malloc put the cars.  A few odd-sized allocations between the AddCar calls move them (kept: freeing would
+// give the addresses back); callers try seeds until ref_arena_get_state reports the car order they want to reproduce (tools/raw_divergence.py).
+void* ref_arena_new_shuffled(int team_size, unsigned seed) {
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    unsigned x = seed * 2654435761u + 12345u;
+    for (int i = 0; i < 2 * team_size; i++) {
+        x = x * 1664525u + 1013904223u;
+        if (seed) (void)malloc(16 + (x >> 8) % 9000);
+        a->AddCar((i & 1) ? Team::ORANGE : Team::BLUE);
+    }
+    return a;
+}
+// ... and with another bucket count in that set: the iteration order of the same pointers changes with it
+void ref_arena_rehash(void* h, int buckets) { ((Arena*)h)->_cars.rehash((size_t)buckets); }
 void ref_arena_free(void* h) { delete (Arena*)h; }
 void ref_arena_get_state(void* h, RlgpuArenaState* s) { GetArenaPhys((Arena*)h, s); }
 void ref_arena_set_state(void* h, const RlgpuArenaState* s) { SetArenaPhys((Arena*)h, s, true); }

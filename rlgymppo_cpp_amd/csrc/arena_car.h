@@ -93,7 +93,9 @@ RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTm
     if (gb) {
         rel2 = w.contact_point - gb->pos;
         vel2 = body_vel_at(*gb, rel2);
-        V3 bJ = tmul(gb->rot, cross(rel2, -axle));
+        // (a wreck met on the tick after its demolition, ray_ball_and_cars: the rigid body's basis, not the reported one)
+        const M3 grot = (w.ground >= 2 && (A.cars[w.ground - 2].flags & CF_IS_DEMOED)) ? car_ghost_rot(A.cars[w.ground - 2]) : gb->rot;
+        V3 bJ = tmul(grot, cross(rel2, -axle));
         g_dot = dot(g_inv_inertia * bJ, bJ);
     }
     V3 aJ = tmul(c.b.rot, cross(rel1, axle));  // world2A * (rel_pos1 x normal), world2A = basis^T
@@ -403,7 +405,7 @@ RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
 // one lane per car, then one lane per wheel, then one lane per car again); the host build runs them in plain loops.
 // Results do not depend on the order of cars inside a phase:
 //   * a phase-0 respawn changes only the car itself, and a car that is demoed or was respawned this tick stays
-//     `frozen` (DISABLE_SIMULATION + CF_NO_CONTACT_RESPONSE, Car.cpp:69-80) for the whole tick, so no ray sees it;
+//     `frozen` (DISABLE_SIMULATION + CF_NO_CONTACT_RESPONSE, Car.cpp:69-80) for the whole tick: a ray that meets it first is a miss, whatever its pose details (arena_world.h ray_ball_and_cars);
 //   * phase 2 reads another car only when a wheel stands on it (ground >= 2): callers serialise that case by car index.
 
 // phase 0, per car: ClampFix, demo timer and respawn (Car.cpp:60-87)

@@ -57,7 +57,7 @@ struct ContactList {
 constexpr int BALL_REGION = 10, CAR_REGION = 11, CAR_WORLD_MAX = 10, MESH_MANIFOLDS = 2, OBJ_LISTED_MAX = 4;
 constexpr int8_t SID_MESH2 = 5;
 template <int NC> struct ContactLayout {
-    static constexpr int PAIR_POOL = NC == 2 ? 4 : 8;
+    static constexpr int PAIR_POOL = NC == 2 ? 4 : (NC == 4 ? 8 : 12);   // (a six-car heap: nine points in one tick, `3v3_kickoff` tick 318 under another car order)
     static constexpr int PAIR_BASE = BALL_REGION + CAR_REGION * NC;
     static constexpr int MAXC = PAIR_BASE + PAIR_POOL;
     // manifolds of one tick at most: every dynamic body against <= OBJ_LISTED_MAX mesh objects (with or without points) + 4 planes, every

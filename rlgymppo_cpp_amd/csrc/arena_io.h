@@ -82,6 +82,9 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         io.f(c.steer_angle); io.f(c.engine_force); io.f(c.brake);
         for (int w = 0; w < 4; w++) io.f(c.lat_friction[w]);
         for (int w = 0; w < 4; w++) io.f(c.long_friction[w]);
+        // hidden state, not part of the exchange struct: the basis of a DEMOLISHED car's rigid body (car_ghost_rot; any other car: its
+        // world inverse inertia, recomputed on load)
+        io.v(c.b.inv_inertia_w.r0); io.v(c.b.inv_inertia_w.r1); io.v(c.b.inv_inertia_w.r2);
     }
     for (int p = 0; p < 34; p++) {
         Pad& pd = A.pads[p];
@@ -98,6 +101,11 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         G.tracker_flags = tf & 0xffu; A.car_order = tf >> 8;
     }
     io.l(G.last_ball_update_count);
+    for (int b = 0; b <= NC; b += 2) {     // the broadphase history, two bodies per word
+        uint32_t w = (uint32_t)A.bp_hist[b] | (b + 1 <= NC ? (uint32_t)A.bp_hist[b + 1] << 16 : 0u);
+        io.u(w);
+        A.bp_hist[b] = (uint16_t)(w & 0xffffu); if (b + 1 <= NC) A.bp_hist[b + 1] = (uint16_t)(w >> 16);
+    }
     for (int k = 0; k < NC; k++) {
         for (int q = 0; q < 8; q++) io.i(G.counters[k][q]);
         for (int q = 0; q < RLGPU_NUM_EVENT_VALS; q++) io.f(G.event_last[k][q]);
@@ -109,7 +117,7 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
 template <int NC>
 constexpr size_t arena_num_words() {
     // kept in sync with arena_visit by a static check in the tests (rlgpu_state_words() reports the visitor's count)
-    return 4 + 12 + (size_t)NC * 81 + 68 + 10 + (size_t)NC * 20 + 2;
+    return 4 + 12 + (size_t)NC * 90 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * 20 + 2;
 }
 
 // finish a freshly loaded working copy: derived values that are not stored
@@ -121,7 +129,7 @@ RLG_HD void arena_finish_load(Arena<NC>& A) {
     for (int k = 0; k < NC; k++) {
         Car& c = A.cars[k];
         c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0); c.frozen = false;
-        body_update_inertia(c.b, car_inv_inertia_local());
+        if (!(c.flags & CF_IS_DEMOED)) body_update_inertia(c.b, car_inv_inertia_local());    // (demoed: the slot holds car_ghost_rot)
     }
     for (int p = 0; p < 34; p++) A.pads[p].cur_locked = 0;
 }
@@ -142,6 +150,7 @@ template <int NC>
 RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& s) {
     A.tick_count = s.tick_count; A.ball_update_counter = s.ball_update_counter;
     A.car_order = car_order_checked(s.car_order, NC);
+    for (int b = 0; b <= NC; b++) A.bp_hist[b] = 0;      // no history travels with the exchange struct: a fresh arena set to this state
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
     for (int k = 0; k < NC; k++) {
@@ -161,6 +170,7 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
         c.vel_impulse_cache = ld3(o.vel_impulse_cache) * UU2BT;
         for (int w = 0; w < 4; w++) { c.extra_pushback[w] = o.extra_pushback[w]; c.lat_friction[w] = o.wheel_lat_friction[w]; c.long_friction[w] = o.wheel_long_friction[w]; }
         c.steer_angle = o.wheel_steer_angle; c.engine_force = o.wheel_engine_force; c.brake = o.wheel_brake;
+        c.b.inv_inertia_w = c.b.rot;     // car_ghost_rot of a demolished car: Car::SetState gives the rigid body the reported basis (Car.cpp:22-36)
     }
     for (int p = 0; p < 34; p++) {
         A.pads[p].cooldown = s.pads[p].cooldown; A.pads[p].is_active = s.pads[p].is_active != 0;

@@ -571,10 +571,6 @@ struct TickWork {
 // Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
 // contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy
 // boxes (with the predicted rotation), broadphase cells, union-find and the quickSort are all that is needed to ORDER them.
-#ifdef RLG_BP_HISTORY
-struct BpHistory { int cell[8]; int seq[8]; int next_seq; bool init; };
-inline BpHistory& bp_history() { static thread_local BpHistory h{}; return h; }
-#endif
 template <int NC, int MAXC>
 RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
@@ -664,17 +660,16 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
             }
         }
         // dynamic partners filed in the same cell neighbourhood with overlapping proxy boxes (pairs are made by the lower body)
-#ifdef RLG_BP_HISTORY
-        int qorder[NB], nq = 0;
-        for (int q = p + 1; q < NB; q++) qorder[nq++] = q;
-        for (int a = 1; a < nq; a++) { const int v = qorder[a]; int b2 = a - 1; while (b2 >= 0 && bp_history().seq[qorder[b2]] > bp_history().seq[v]) { qorder[b2 + 1] = qorder[b2]; b2--; } qorder[b2 + 1] = v; }
+        // ... in the order of the cell's dynamic list = the order in which the proxies last ARRIVED in their cells (bp_history_track)
+        int8_t qorder[NB]; int nq = 0;
+        for (int q = p + 1; q < NB; q++) {
+            int at = nq++;
+            while (at > 0 && (A.bp_hist[qorder[at - 1]] & 7u) > (A.bp_hist[q] & 7u)) { qorder[at] = qorder[at - 1]; at--; }
+            qorder[at] = (int8_t)q;
+        }
         for (int qi = 0; qi < nq; qi++) {
             const int q = qorder[qi];
             if (!live[q]) continue;
-#else
-        for (int q = p + 1; q < NB; q++) {
-            if (!live[q]) continue;
-#endif
             const int dx = cx[p] - cx[q], dy = cy[p] - cy[q], dz = cz[p] - cz[q];
             if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
             if (!aabb_touch(plo[p], phi[p], plo[q], phi[q])) continue;
@@ -707,34 +702,50 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
     L.n = n;
 }
 
-#ifdef RLG_BP_HISTORY   /* HOST PROTOTYPE (tools/raw_divergence.py): the arrival order of the dynamic proxies in btRSBroadphase's cell lists, one env */
+// btRSBroadphase keeps, per cell, the list of dynamic proxies filed under it and the 26 cells around it (btRSBroadphase.h:65-72).  When
+// setAabb finds a proxy in a new cell it is erased from its old 27 lists and pushed back onto the new 27 (btRSBroadphase.cpp:185-203,
+// 287-325), so every list is ordered by when its proxies last changed cell -- creation order to begin with, object order within a tick --
+// and calculateOverlappingPairs makes a body's pairs in THAT order (:393-469).  The pair array orders the manifold array, and Bullet's
+// unstable island sort turns another array into another solver order once an island holds several manifolds (a heap of cars).  This is
+// the per-tick bookkeeping: the cell of every active body's proxy, and a new arrival rank for those that changed it.
 template <int NC>
-inline void bp_history_track(const Arena<NC>& A, bool ball_asleep) {
-    BpHistory& H = bp_history();
+RLG_HD_SMALL void bp_history_track(Arena<NC>& A, bool ball_asleep) {
+    RLG_ASSUME_LDS(A);
     constexpr int NB = NC + 1;
-    if (!H.init) {   // a fresh arena: proxies created in order (ball, cars) at their creation poses (btCollisionWorld::addCollisionObject: the shape's box, no threshold)
+    bool fresh = true;
+    for (int b = 0; b < NB; b++) fresh = fresh && A.bp_hist[b] == 0;
+    if (fresh) {   // proxies created in object order (ball, cars) at their creation poses (btCollisionWorld::addCollisionObject: the shape's box, no threshold)
         int i, j, k; V3 lo, hi;
-        sphere_shape_aabb(v3(0.f, 0.f, K::BALL_REST_Z * UU2BT), lo, hi); bp_cell_of(lo, i, j, k); H.cell[0] = bp_cell_index(i, j, k);
-        M3 id; id.r0 = v3(1, 0, 0); id.r1 = v3(0, 1, 0); id.r2 = v3(0, 0, 1);
-        compound_shape_aabb(v3(0.f, 0.f, 17.f * UU2BT), id, lo, hi); bp_cell_of(lo, i, j, k);
-        for (int b = 1; b < NB; b++) H.cell[b] = bp_cell_index(i, j, k);
-        for (int b = 0; b < NB; b++) H.seq[b] = b;
-        H.next_seq = NB; H.init = true;
+        sphere_shape_aabb(v3(0.f, 0.f, K::BALL_REST_Z * UU2BT), lo, hi); bp_cell_of(lo, i, j, k);
+        A.bp_hist[0] = (uint16_t)(bp_cell_index(i, j, k) << 3);
+        compound_shape_aabb(v3(0.f, 0.f, 17.f * UU2BT), m3_identity(), lo, hi); bp_cell_of(lo, i, j, k);
+        for (int b = 1; b < NB; b++) A.bp_hist[b] = (uint16_t)((bp_cell_index(i, j, k) << 3) | b);
     }
-    bool moved[8];
+    uint32_t moved = 0u;
     for (int b = 0; b < NB; b++) {
-        moved[b] = false;
-        if (b == 0 && ball_asleep) continue;                 // updateAabbs skips inactive objects
-        if (b > 0 && !car_collides(A.cars[b - 1])) continue;
-        V3 lo, hi;
-        if (b == 0) ball_proxy_aabb(A.ball, lo, hi); else car_proxy_aabb(A.cars[b - 1], lo, hi);
-        int i, j, k; bp_cell_of(lo, i, j, k);
+        if (b == 0 ? ball_asleep : !car_collides(A.cars[b - 1])) continue;     // updateAabbs skips inactive objects
+        int i, j, k;
+        if (b == 0) { V3 lo, hi; ball_proxy_aabb(A.ball, lo, hi); bp_cell_of(lo, i, j, k); }
+        else {       // the bracket around the proxy box names the cell without the predicted rotation in all but borderline poses
+            V3 il, ih, ol, oh; car_proxy_bracket(A.cars[b - 1], il, ih, ol, oh);
+            int i2, j2, k2; bp_cell_of(il, i, j, k); bp_cell_of(ol, i2, j2, k2);
+            if (i != i2 || j != j2 || k != k2) { V3 lo, hi; car_proxy_aabb(A.cars[b - 1], lo, hi); bp_cell_of(lo, i, j, k); }
+        }
         const int c = bp_cell_index(i, j, k);
-        if (c != H.cell[b]) { H.cell[b] = c; moved[b] = true; }
+        if (c != (int)(A.bp_hist[b] >> 3)) { A.bp_hist[b] = (uint16_t)((c << 3) | (A.bp_hist[b] & 7u)); moved |= 1u << b; }
     }
-    for (int b = 0; b < NB; b++) if (moved[b]) H.seq[b] = H.next_seq++;   // erased from its old lists, pushed back onto the new ones, in object order
+    if (!moved) return;
+    // those that stayed keep their order and close ranks; the movers follow in object order
+    int8_t nr[NB]; int n_stay = 0;
+    for (int b = 0; b < NB; b++) {
+        if (moved >> b & 1u) continue;
+        int r = 0;
+        for (int o = 0; o < NB; o++) r += (!(moved >> o & 1u) && (A.bp_hist[o] & 7u) < (A.bp_hist[b] & 7u)) ? 1 : 0;
+        nr[b] = (int8_t)r; n_stay++;
+    }
+    for (int b = 0; b < NB; b++) if (moved >> b & 1u) nr[b] = (int8_t)n_stay++;
+    for (int b = 0; b < NB; b++) A.bp_hist[b] = (uint16_t)((A.bp_hist[b] & ~7u) | (uint32_t)nr[b]);
 }
-#endif
 
 // per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts
 template <int NC, int MAXC, class NW>
@@ -743,9 +754,7 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     ball_car_touch = false;
-#ifdef RLG_BP_HISTORY
     bp_history_track(A, W.ball_asleep);
-#endif
     // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
     // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
     int n = 0, ball_man = 0, max_man = 0;
@@ -963,14 +972,18 @@ RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
             // A car demolished by this tick's contact callback: the reference's reported rotation is the copy Car::_PostTickUpdate takes
             // (Car.cpp:135-138), which it skips for a demoed car -- so the state keeps the pre-tick basis while position and velocities
             // come from the body (Car.cpp:10-20).  The body is disabled from the next pre-tick on and rebuilt at respawn.
+            // The BODY turns all the same, and stays in the world as it then stands: car_ghost_rot (arena_world.h).
             const bool rot_stale = (c.flags & CF_IS_DEMOED) != 0;
+            M3 rot = c.b.rot;
             if (!is_zero(s.push) || !is_zero(s.turn)) {
                 c.b.pos = c.b.pos + s.push * dt;
-                if (!rot_stale) c.b.rot = integrate_rotation(c.b.rot, s.turn * K::SPLIT_TURN_ERP, dt);
+                rot = integrate_rotation(rot, s.turn * K::SPLIT_TURN_ERP, dt);
             }
             c.b.pos = c.b.pos + c.b.vel * dt;
-            if (!rot_stale) {
-                c.b.rot = integrate_rotation(c.b.rot, c.b.angvel, dt);
+            rot = integrate_rotation(rot, c.b.angvel, dt);
+            if (rot_stale) c.b.inv_inertia_w = rot;
+            else {
+                c.b.rot = rot;
                 body_update_inertia(c.b, car_inv_inertia_local());
             }
         }

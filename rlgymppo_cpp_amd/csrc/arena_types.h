@@ -256,6 +256,10 @@ struct Arena {
     int64_t tick_count;
     int64_t ball_update_counter;
     uint32_t car_order;   // RlgpuArenaState::car_order: 4 bits per rank (slot + 1), 0 = slot order
+    // btRSBroadphase's memory of its dynamic proxies (ball, cars), hidden state of the reference that no CarState shows: the cell of each
+    // proxy's last setAabb (13 bits) and its arrival rank among the dynamic proxies (3 bits) -- arena_step.h bp_history_track.  All zero
+    // = a fresh arena (what a state uploaded from the host starts as).
+    uint16_t bp_hist[NC + 1];
 };
 // the car the arena's per-car loops visit k-th (Arena.cpp:716-812 iterates an unordered set of car pointers)
 template <int NC>

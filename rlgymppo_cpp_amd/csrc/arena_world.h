@@ -526,6 +526,16 @@ RLG_HD bool ray_box_near(V3 from, V3 to, V3 lo, V3 hi) {
     const V3 m = v3(0.05f, 0.05f, 0.05f); lo = lo - m; hi = hi + m;
     return !(fminf(from.x, to.x) > hi.x || fmaxf(from.x, to.x) < lo.x || fminf(from.y, to.y) > hi.y || fmaxf(from.y, to.y) < lo.y || fminf(from.z, to.z) > hi.z || fmaxf(from.z, to.z) < lo.z);
 }
+// The rigid body of a demolished car stays in the world, disabled, where the demolition tick left it (Car.cpp:69-80) -- and its basis is
+// NOT the one the car's state reports: Car::_PostTickUpdate stops copying the rotation once the car is demoed (Car.cpp:135-138), so the
+// state keeps the basis from before the demolition tick while the body has turned through it (a supersonic hit: several degrees).  The body's
+// own basis is kept in the slot of the world inverse inertia, which a disabled body has no use for (written by solver_finish, restored by
+// the respawn; resident layout: arena_io.h).
+RLG_HD const M3& car_ghost_rot(const Car& car) { return car.b.inv_inertia_w; }
+// (after car_tick_begin) this is the wreck's first pre-tick: Car::Demolish set the timer, one tick has been taken off it
+RLG_HD bool car_demolished_last_tick(const Car& car) { return (car.flags & CF_IS_DEMOED) && car.demo_respawn_timer == fmaxf(K::DEMO_RESPAWN_TIME - TICK_DT, 0.f); }
+template <int NC>
+RLG_HD int car_rank_of(const Arena<NC>& A, int slot) { for (int k = 0; k < NC; k++) if (car_at_rank(A, k) == slot) return k; return slot; }
 // last stage: the dynamic objects -- the ball (a btSphereShape), then the other cars' hitbox children (btBoxShape), each through the convex
 // cast.  (The ball's rotation is not part of the state this build keeps; its basis is taken as the identity: the support point of a sphere
 // does not depend on it beyond rounding.)
@@ -536,17 +546,27 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
         const V3 bp = A.ball.b.pos;
         if (ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r))) ray_convex_hit(from, to, m3_identity(), bp, v3(0, 0, 0), r, 1, best);
     }
-    // other cars' hitboxes (demoed or respawned this tick: no contact response -> no hit, btDefaultVehicleRaycaster.cpp:41-43)
+    // other cars' hitboxes.  A car that is demoed, or was respawned this tick, has no contact response (Car.cpp:69-80) but its rigid body
+    // stays in the world where it stopped: the ray test finds the CLOSEST object first and only then asks whether it responds
+    // (btDefaultVehicleRaycaster.cpp:36-51) -- so such a body does not let the ray through to the ground behind it, it turns the whole ray
+    // into a miss.  (Found on `3v3_kickoff`, tick 341, with tools/raw_divergence.py: a wheel over a wreck.)
+    constexpr int GHOST = 2 + NC;
     for (int k = 0; k < NC; k++) {
         if (k == self_car) continue;
         const Car& o = A.cars[k];
-        if ((o.flags & CF_IS_DEMOED) || o.frozen) continue;
-        const V3 center = o.b.pos + o.b.rot * hitbox_off();
+        if (o.flags & CF_ABSENT) continue;      // an empty slot of a one-team env: no body at all
+        bool ghost = (o.flags & CF_IS_DEMOED) || o.frozen;
+        // ... from ITS OWN pre-tick on: Car::_PreTickUpdate is what clears the body's contact response (Car.cpp:69-80), so on the first
+        // tick after a demolition the cars the arena visits BEFORE the wreck still find a body like any other (Arena.cpp:716-812)
+        if (ghost && car_demolished_last_tick(o) && car_rank_of(A, self_car) < car_rank_of(A, k)) ghost = false;
+        const M3 R = (o.flags & CF_IS_DEMOED) ? car_ghost_rot(o) : o.b.rot;
+        const V3 center = o.b.pos + R * hitbox_off();
         const V3 h = hitbox_half();
-        const V3 e = abs_rows_dot(o.b.rot, h);
+        const V3 e = abs_rows_dot(R, h);
         if (!ray_box_near(from, to, center - e, center + e)) continue;
-        ray_convex_hit(from, to, o.b.rot, center, h, 0.f, 2 + k, best);
+        ray_convex_hit(from, to, R, center, h, 0.f, ghost ? GHOST : 2 + k, best);
     }
+    if (best.kind == GHOST) best.kind = -1;
 }
 
 // embree closest point on triangle (SphereTriangleDetector.cpp:87-129). `feature` out: 0 face, 1..3 vertex a/b/c, 4 edge ab, 5 edge ac, 6 edge bc

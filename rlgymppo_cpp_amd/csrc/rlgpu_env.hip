@@ -959,8 +959,14 @@ __global__ void k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* en
     if (i >= n) return;
     int env = env_ids ? env_ids[i] : i;
     if (env < 0 || env >= d.n_envs) return;
+    // an upload is Arena::SetState on the env's arena, not a new arena: what the broadphase remembers of its proxies stays (bp_hist; all
+    // zero in an env that has never ticked = a fresh arena)
     Arena<NC> A; GymEnv<NC> G;
+    load_env(d, env, A, G);
+    uint16_t hist[NC + 1];
+    for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     arena_from_host(A, G, src[i]);
+    for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];
     store_env(d, env, A, G);
 }
 template <int NC>

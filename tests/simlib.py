@@ -12,7 +12,7 @@ from rlgymppo_cpp_amd.state import ArenaState
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_oracle.so")
-PORT_SO = os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")
+PORT_SO = os.environ.get("RLG_PORT_SO") or os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")     # (override: development builds of the port, e.g. -DRLG_BP_HISTORY for tools/raw_divergence.py)
 
 _vp = C.c_void_p
 
@@ -44,8 +44,13 @@ class PortSim:
             parts = np.ascontiguousarray(parts, np.int32)
             self.lib.port_set_mesh_parts(_ptr(verts), len(verts), _ptr(tris), len(tris), _ptr(parts), len(parts))
 
-    def step(self, state: ArenaState, ticks=1, seed=0, env=0):
-        self.lib.port_arena_step(C.byref(state), ticks, C.c_uint32(seed), C.c_uint32(env))
+    def step(self, state: ArenaState, ticks=1, seed=0, env=0, hist=None):
+        """hist: a (C.c_uint16 * 8)() the caller keeps per arena -- the broadphase's memory of its proxies, which no state carries; without it
+        every call steps a FRESH arena set to `state` (like BatchedEnv, whose env slots keep theirs across uploads)."""
+        if hist is not None:
+            self.lib.port_step_hist(C.byref(state), ticks, C.byref(hist))
+        else:
+            self.lib.port_arena_step(C.byref(state), ticks, C.c_uint32(seed), C.c_uint32(env))
 
 
 class RefSim:
@@ -146,12 +151,13 @@ def port_gym_reset(port, states, cfg, run_setter=True):
     return list(arr), obs
 
 
-def port_gym_step(port, states, cfg, actions):
+def port_gym_step(port, states, cfg, actions, hist=None):
+    """hist: np.zeros((n, 8), np.uint16) kept by the caller across steps -- each arena's broadphase history (PortSim.step)."""
     n = len(states); nc, D = _gym_rows(cfg, states[0].num_cars)
     arr = (ArenaState * n)(*states)
     actions = np.ascontiguousarray(actions, np.int32)
     obs = np.zeros((n * nc, D), np.float32); rew = np.zeros(n * nc, np.float32); done = np.zeros(n * nc, np.int32)
-    port.lib.port_gym_step(arr, n, C.byref(cfg), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done))
+    port.lib.port_gym_step_hist(arr, n, C.byref(cfg), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(hist) if hist is not None else None)
     return list(arr), obs, rew, done
 
 
@@ -231,20 +237,21 @@ PHYS_FREE_RUN = {
 }
 # Ticks for which a free run (inside the stepper's units, from the state the reference's set_state was given: phys/<name>/start_raw) is
 # BIT-IDENTICAL to the reference's recorded trajectory, every field of every body; tapes not listed: their whole length.
-PHYS_EXACT_UNTIL = {"3v3_kickoff": 280}   # the six-car heap.  What is left there is not a function of the state the reference exposes: the order of
-# the pairs inside a broadphase cell follows the order in which the bodies entered it, and a wheel ray only sees the bodies whose boxes of the
-# PREVIOUS tick reach the ray's cell (btRSBroadphase.cpp:326-358, 393-469) -- the reference itself gives another answer from the same state in
-# a fresh arena (tools/exact_horizons.py).  Wheels standing on cars (btSubsimplexConvexCast) and the arena's car order are exact.
+PHYS_EXACT_UNTIL = {}     # empty since round 3: all 31 tapes over their whole length.  The last one, `3v3_kickoff` (a six-car heap with two
+# demolitions, 360 ticks), needed the two pieces of state the reference keeps outside its CarStates: the order in which the dynamic proxies
+# arrived in their broadphase cells (btRSBroadphase.cpp:185-203, 287-325, 393-469 -> arena_step.h bp_history_track) and the basis of a
+# demolished car's rigid body, which stays in the world and swallows wheel rays (btDefaultVehicleRaycaster.cpp:36-51 -> arena_world.h
+# car_ghost_rot).  Both live in the resident state and start as a fresh arena's when a state comes from the host.
 # ... and how close a tape stays after that, until the given tick (pos uu, vel uu/s, ang rad/s, rot)
 PHYS_AFTER_EXACT = {}
 
-# One tick from the reference's own state: every recorded pair of 30 of the 31 scenarios is bit-equal (asserted in the tests); the tolerances
-# below are what the 14 pairs of the six-car heap that are not (of its 113) stay within.
+# One tick from the reference's own state: every one of the 1722 recorded pairs is bit-equal (asserted in the tests).  A scenario's pairs are
+# stepped one after the other in ONE arena / env slot, as they were recorded: the broadphase's arrival order, which a state does not
+# carry, passes from pair to pair (round 3; before that 14 pairs of the six-car heap were not exact and had a tolerance here).
 ONE_TICK_TOL = {
     "default": {"pos": 0.0, "vel": 0.0},
-    "3v3_kickoff": {"pos": 5.0, "vel": 500.0, "flags_loose": True},     # ticks 282-356: pair order inside a broadphase cell / stale proxy boxes (see PHYS_EXACT_UNTIL); tick 317: a supersonic car into the heap
 }
-ONE_TICK_NOT_EXACT_MAX = 14      # pairs (of 1722) that are not bit-equal to the reference, all in 3v3_kickoff
+ONE_TICK_NOT_EXACT_MAX = 0
 
 
 # observation tolerance per gym fixture (default 2e-3 = 8 uu on a position, 4.6 uu/s on a velocity, 0.011 rad/s on an angular velocity)

@@ -110,6 +110,7 @@ def test_physics_ticks_match_host_port_on_golden_scenarios(sg, port_lib):
     tapes = [sg[f"phys/{n}/tape"] for n in names]
     T = max(len(t) for t in tapes)
     env.upload_states(host)
+    hists = [(C.c_uint16 * 8)() for _ in host]     # an env slot keeps its broadphase history across uploads (an upload is a SetState): so does the host side
     compared = 0
     for t in range(T):
         cur = env.download_states()
@@ -123,7 +124,7 @@ def test_physics_ticks_match_host_port_on_golden_scenarios(sg, port_lib):
         cur = env.download_states()
         for i, s in enumerate(host):
             if t < len(tapes[i]):
-                port_lib.step(s, 1)
+                port_lib.step(s, 1, hist=hists[i])
                 a, b = _vec(s), _vec(cur[i])
                 assert np.array_equal(a, b), f"{names[i]} tick {t + 1}: HIP and host build differ, max |diff| {np.abs(a - b).max()} at {int(np.abs(a - b).argmax())}"
                 compared += 1
@@ -151,11 +152,12 @@ def test_gym_step_matches_host_port(port_lib):
     rng = np.random.RandomState(5)
     nobs = torch.empty_like(obs); rew = torch.empty(n * 2, device=dev); done = torch.empty(n * 2, dtype=torch.int32, device=dev)
     n_done = 0
+    hist = np.zeros((n, 8), np.uint16)     # the host side keeps each arena's broadphase history across the hand-overs, as the env slots do
     for step in range(48):
         acts = rng.randint(0, 90, size=n * 2).astype(np.int32)
         env.step(torch.from_numpy(acts).to(dev), nobs, rew, done)
         env.sync()
-        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts)
+        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts, hist)
         d = done.cpu().numpy()
         assert (d == hd).all(), f"done flags differ at step {step}"
         n_done += int(hd.sum())
@@ -188,11 +190,12 @@ def test_gym_step_matches_host_port_team_modes(port_lib, team_size, max_players)
     rng = np.random.RandomState(11 + team_size)
     nobs = torch.empty_like(obs); rew = torch.empty(n * nc, device=dev); done = torch.empty(n * nc, dtype=torch.int32, device=dev)
     n_done = 0
+    hist = np.zeros((n, 8), np.uint16)
     for step in range(24):
         acts = rng.randint(0, 90, size=n * nc).astype(np.int32)
         env.step(torch.from_numpy(acts).to(dev), nobs, rew, done)
         env.sync()
-        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts)
+        hs, ho, hr, hd = port_gym_step(port_lib, hs, pcfg, acts, hist)
         assert (done.cpu().numpy() == hd).all(), f"done flags differ at step {step}"
         n_done += int(hd.sum())
         assert np.abs(rew.cpu().numpy() - hr).max() <= 2.4e-7, f"rewards differ at step {step}: max |diff| {np.abs(rew.cpu().numpy() - hr).max()}"   # (the host build converts a state to uu and back once more: two ulps of a reward)
@@ -327,10 +330,11 @@ def test_hip_physics_free_run_vs_reference_fixtures(sg):
 
 
 def test_hip_one_tick_vs_reference_states(sg):
-    """All 1722 recorded (reference state, reference state one tick later) pairs as ONE batch per team size: upload, one tick of the HIP
-    kernel, compare for EQUALITY of every field of every body.  Every pair of 30 of the 31 scenarios is bit-equal to the reference
-    (1580 1v1 pairs, every tick with a narrowphase contact among them; deep contacts through the penetration-depth solver), and all but
-    simlib.ONE_TICK_NOT_EXACT_MAX of the six-car heap's."""
+    """All 1722 recorded (reference state, reference state one tick later) pairs: upload, one tick of the HIP kernel, compare for EQUALITY
+    of every field of every body -- every pair of all 31 scenarios is bit-equal to the reference (1580 1v1 pairs, every tick with a
+    narrowphase contact among them; deep contacts through the penetration-depth solver; the six-car heap with its two demolitions).
+    One env slot per scenario, its pairs uploaded and ticked one after the other as the reference recorded them in one arena
+    (make_sim_golden.py): an upload is a SetState, the broadphase's arrival order passes from pair to pair."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from simlib import ONE_TICK_TOL, ONE_TICK_NOT_EXACT_MAX, state_vec, phys_errors
     ss = np.load(os.path.join(GOLD, "sim_steps.npz"))
@@ -338,10 +342,16 @@ def test_hip_one_tick_vs_reference_states(sg):
     n_exact = n_all = 0
     for nc in (2, 4, 6):
         B, A, T = ss[f"nc{nc}/before"], ss[f"nc{nc}/after"], ss[f"nc{nc}/tag"]
-        env = BatchedEnv(len(B), nc // 2, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
-        env.upload_states([ArenaState.from_buffer_copy(b.tobytes()) for b in B])
-        env.physics_ticks(1)
-        got = env.download_states()
+        scen = sorted(set(int(t[0]) for t in T))
+        pairs = {si: [i for i in range(len(B)) if int(T[i][0]) == si] for si in scen}
+        env = BatchedEnv(len(scen), nc // 2, mesh=(sg["mesh_verts"], sg["mesh_tris"]))
+        got = [None] * len(B)
+        for j in range(max(len(v) for v in pairs.values())):
+            slots = [e for e, si in enumerate(scen) if j < len(pairs[si])]
+            env.upload_states([ArenaState.from_buffer_copy(B[pairs[scen[e]][j]].tobytes()) for e in slots], env_ids=slots)
+            env.physics_ticks(1)
+            out = env.download_states(env_ids=slots)
+            for e, st in zip(slots, out): got[pairs[scen[e]][j]] = st
         for i in range(len(B)):
             want = ArenaState.from_buffer_copy(A[i].tobytes())
             exact = np.array_equal(state_vec(got[i]), state_vec(want))

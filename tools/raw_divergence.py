@@ -40,7 +40,17 @@ if which == "seam":
 else:
     port.set_mesh(verts, tris); ref = RefSim(verts, tris)
 # the live arena visits its cars in ITS unordered_set's order (heap addresses of this process), not in the recording arena's: the port follows it
-a = ref.arena(nc // 2); ref.set_state(a, st0)
+# RAWDIV_REHASH=<buckets> [RAWDIV_SHUFFLE=<seed>]: another car order in the live arena -- Arena::_cars is an unordered_set of pointers, so
+# its iteration order changes with the bucket count (ref_arena_rehash) and with where the cars lie on the heap (ref_arena_new_shuffled);
+# e.g. RAWDIV_REHASH=1 gives 654321 where the plain arena has 123456
+_seed = int(os.environ.get("RAWDIV_SHUFFLE", "0")); _buckets = int(os.environ.get("RAWDIV_REHASH", "0"))
+ref.lib.ref_arena_new_shuffled.restype = C.c_void_p; ref.lib.ref_arena_new_shuffled.argtypes = [C.c_int, C.c_uint]
+ref.lib.ref_arena_rehash.argtypes = [C.c_void_p, C.c_int]
+def _new_arena(n):
+    h = C.c_void_p(ref.lib.ref_arena_new_shuffled(n, _seed))
+    if _buckets: ref.lib.ref_arena_rehash(h, _buckets)
+    return h
+a = _new_arena(nc // 2); ref.set_state(a, st0)
 st0.car_order = ref.get_state(a).car_order
 print("car order of the live reference arena: %x" % st0.car_order)
 # port: raw state after every tick
@@ -85,7 +95,7 @@ if first is not None and os.environ.get("RAWDIV_CONTACTS", "1") == "1":
         print("   a %2d b %2d sid %d | ra (%.6f %.6f %.6f) | rb (%.6f %.6f %.6f) | n (%.7f %.7f %.7f) | dist %.7g | applied %.7g" % (r[0], r[1], r[2], *r[4:7], *r[7:10], *r[10:13], r[13], r[14]))
     for q in buf2[:n]:
         print("      friction dir (%.7f %.7f %.7f) applied %.7g | normal rhs %.7g jac %.7g | ext_f (%.7g %.7g %.7g) ext_t (%.7g %.7g %.7g) | friction rhs %.7g jac %.7g" % (*q[0:3], q[3], q[4], q[5], *q[6:9], *q[9:12], q[12], q[13]))
-    a2 = ref.arena(nc // 2); ref.set_state(a2, st0)
+    a2 = _new_arena(nc // 2); ref.set_state(a2, st0)
     if ref.get_state(a2).car_order != st0.car_order:
         print("   (the second reference arena visits its cars in another order, %x: its dumps below may not belong to the same run)" % ref.get_state(a2).car_order)
     for t in range(T):
@@ -122,7 +132,7 @@ if first is not None:
     st = ArenaState.from_buffer_copy(bytes(st0))
     port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     port.lib.port_run_tape(C.byref(st), tape.ctypes.data, T0, 1 << 30, None)
-    a3 = ref.arena(nc // 2); ref.set_state(a3, st0)
+    a3 = _new_arena(nc // 2); ref.set_state(a3, st0)
     for t in range(T0):
         for k in range(nc):
             ref.set_controls(a3, k, tape[t, k])
