@@ -560,6 +560,7 @@ struct TickWork {
     int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
     int8_t nrow[MAXS], frow[MAXS];   // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)
     int8_t body_n[8];                // world contacts in each body's region of L (collide_body)
+    int8_t bp_moved[8];              // the body's proxy changed its broadphase cell this tick (bp_history_cell)
     int8_t body_obj[8][MESH_MANIFOLDS];   // the mesh object of the body's first / second mesh manifold with points, -1 = none
     int8_t ball_hit[NC];             // car i touches the ball: its contact sits in car_ball_slot(i)
     int8_t man_key[MAXM], man_val[MAXM], man_first[MAXM], man_cnt[MAXM];   // this tick's manifolds (collide_merge)
@@ -708,32 +709,41 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
 // and calculateOverlappingPairs makes a body's pairs in THAT order (:393-469).  The pair array orders the manifold array, and Bullet's
 // unstable island sort turns another array into another solver order once an island holds several manifolds (a heap of cars).  This is
 // the per-tick bookkeeping: the cell of every active body's proxy, and a new arrival rank for those that changed it.
+// In two parts: per body (a lane each on the device, with the body's contacts) the cell, per env the ranks.
 template <int NC>
-RLG_HD_SMALL void bp_history_track(Arena<NC>& A, bool ball_asleep) {
-    RLG_ASSUME_LDS(A);
+RLG_HD_SMALL void bp_history_cell(Arena<NC>& A, TickWork<NC>& W, int b) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    W.bp_moved[b] = 0;
+#ifdef RLG_EXPERIMENT_NO_BP_TRACK   /* what-if build only (tools/build_variant.sh): prices the bookkeeping */
+    return;
+#endif
+    int i, j, k;
+    uint32_t h = A.bp_hist[b];
+    if (h == 0u) {   // never filed (no body can be in cell 0 with rank 0): a fresh arena's proxies, created in object order (ball, cars) at
+                     // their creation poses (btCollisionWorld::addCollisionObject: the shape's box, no threshold)
+        V3 lo, hi;
+        if (b == 0) sphere_shape_aabb(v3(0.f, 0.f, K::BALL_REST_Z * UU2BT), lo, hi);
+        else compound_shape_aabb(v3(0.f, 0.f, 17.f * UU2BT), m3_identity(), lo, hi);
+        bp_cell_of(lo, i, j, k);
+        h = ((uint32_t)bp_cell_index(i, j, k) << 3) | (uint32_t)b;
+        A.bp_hist[b] = (uint16_t)h;
+    }
+    if (b == 0 ? W.ball_asleep : !car_collides(A.cars[b - 1])) return;     // updateAabbs skips inactive objects
+    if (b == 0) { V3 lo, hi; ball_proxy_aabb(A.ball, lo, hi); bp_cell_of(lo, i, j, k); }
+    else {       // the bracket around the proxy box names the cell without the predicted rotation in all but borderline poses
+        V3 il, ih, ol, oh; car_proxy_bracket(A.cars[b - 1], il, ih, ol, oh);
+        int i2, j2, k2; bp_cell_of(il, i, j, k); bp_cell_of(ol, i2, j2, k2);
+        if (i != i2 || j != j2 || k != k2) { V3 lo, hi; car_proxy_aabb(A.cars[b - 1], lo, hi); bp_cell_of(lo, i, j, k); }
+    }
+    const uint32_t c = (uint32_t)bp_cell_index(i, j, k);
+    if (c != (h >> 3)) { A.bp_hist[b] = (uint16_t)((c << 3) | (h & 7u)); W.bp_moved[b] = 1; }
+}
+template <int NC>
+RLG_HD_SMALL void bp_history_ranks(Arena<NC>& A, const TickWork<NC>& W) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int NB = NC + 1;
-    bool fresh = true;
-    for (int b = 0; b < NB; b++) fresh = fresh && A.bp_hist[b] == 0;
-    if (fresh) {   // proxies created in object order (ball, cars) at their creation poses (btCollisionWorld::addCollisionObject: the shape's box, no threshold)
-        int i, j, k; V3 lo, hi;
-        sphere_shape_aabb(v3(0.f, 0.f, K::BALL_REST_Z * UU2BT), lo, hi); bp_cell_of(lo, i, j, k);
-        A.bp_hist[0] = (uint16_t)(bp_cell_index(i, j, k) << 3);
-        compound_shape_aabb(v3(0.f, 0.f, 17.f * UU2BT), m3_identity(), lo, hi); bp_cell_of(lo, i, j, k);
-        for (int b = 1; b < NB; b++) A.bp_hist[b] = (uint16_t)((bp_cell_index(i, j, k) << 3) | b);
-    }
     uint32_t moved = 0u;
-    for (int b = 0; b < NB; b++) {
-        if (b == 0 ? ball_asleep : !car_collides(A.cars[b - 1])) continue;     // updateAabbs skips inactive objects
-        int i, j, k;
-        if (b == 0) { V3 lo, hi; ball_proxy_aabb(A.ball, lo, hi); bp_cell_of(lo, i, j, k); }
-        else {       // the bracket around the proxy box names the cell without the predicted rotation in all but borderline poses
-            V3 il, ih, ol, oh; car_proxy_bracket(A.cars[b - 1], il, ih, ol, oh);
-            int i2, j2, k2; bp_cell_of(il, i, j, k); bp_cell_of(ol, i2, j2, k2);
-            if (i != i2 || j != j2 || k != k2) { V3 lo, hi; car_proxy_aabb(A.cars[b - 1], lo, hi); bp_cell_of(lo, i, j, k); }
-        }
-        const int c = bp_cell_index(i, j, k);
-        if (c != (int)(A.bp_hist[b] >> 3)) { A.bp_hist[b] = (uint16_t)((c << 3) | (A.bp_hist[b] & 7u)); moved |= 1u << b; }
-    }
+    for (int b = 0; b < NB; b++) moved |= W.bp_moved[b] ? 1u << b : 0u;
     if (!moved) return;
     // those that stayed keep their order and close ranks; the movers follow in object order
     int8_t nr[NB]; int n_stay = 0;
@@ -754,7 +764,7 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
     using LY = ContactLayout<NC>;
     ContactList<MAXC>& L = W.L;
     ball_car_touch = false;
-    bp_history_track(A, W.ball_asleep);
+    bp_history_ranks(A, W);
     // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
     // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
     int n = 0, ball_man = 0, max_man = 0;
@@ -893,6 +903,7 @@ template <int NC>
 RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
+    bp_history_cell(A, W, body);
     if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
     else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
 }
