@@ -92,7 +92,10 @@ int rlgpu_mesh_visit_order(const float* verts_uu, int n_verts, const int32_t* tr
 int rlgpu_action_table(float* out_rows_x8, int cap_rows); /* DiscreteAction::DiscreteAction (SIM/Utils/ActionParsers/DiscreteAction.cpp:3-67) */
 
 /* Car::SetState/GetState, Ball::SetState/GetState, BoostPad::SetState for whole envs (RS/Sim/Car/Car.cpp:9-36,
- * RS/Sim/Ball/Ball.cpp:27-49): the host StateSetter / user-plugin fallback path. env_ids NULL = envs 0..n-1 */
+ * RS/Sim/Ball/Ball.cpp:27-49): the host StateSetter / user-plugin fallback path. env_ids NULL = envs 0..n-1.
+ * An upload is a SetState on the env's arena, as in the reference: what the arena keeps outside its car / ball states -- the broadphase's
+ * memory of where its proxies were filed and in which order they arrived (btRSBroadphase.cpp:185-203) -- stays as it is; an env that has
+ * never ticked is a fresh arena.  A demolished car's rigid body takes the uploaded rotation (Car.cpp:22-36). */
 int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host_states, const int32_t* env_ids, int n);
 int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host_states, const int32_t* env_ids, int n);
 
