@@ -373,6 +373,27 @@ def test_mesh_triangle_visiting_order_is_the_references(port_lib):
     port_lib.set_mesh(pv, pt)   # (the module's other tests use the procedural arena)
 
 
+def test_box_box_detector_vs_reference_golden(port_lib):
+    """csrc/arena_world.h:box_box_ode (car against car) against the reference's btBoxBoxDetector = ODE's dBoxBox2 (btBoxBoxDetector.cpp) on
+    600 recorded pairs of Octane hitboxes (tests/golden/boxbox_golden.npz, make_boxbox_golden.py; 461 touching, 258 with the full four
+    clipped points): the same number of points in the same order, every normal, point and depth EQUAL bit for bit.  (tools/boxbox_fuzz.py
+    runs the same comparison against the live reference: 20 000 pairs, none differ.)"""
+    import ctypes as C
+    g = np.load(os.path.join(GOLD, "boxbox_golden.npz"))
+    P = C.c_void_p
+    half = np.zeros(3, np.float32); port_lib.lib.port_hitbox_ctor_half(P(half.ctypes.data))
+    assert np.array_equal(half, g["ctor_half"])
+    n_pts = 0
+    for i in range(len(g["n"])):
+        p1, R1, p2, R2 = (np.ascontiguousarray(g[k][i], np.float32) for k in ("pos1", "rot1", "pos2", "rot2"))
+        o = np.zeros((8, 7), np.float32)
+        n = port_lib.lib.port_box_box(P(p1.ctypes.data), P(R1.ctypes.data), P(p2.ctypes.data), P(R2.ctypes.data), P(o.ctypes.data))
+        assert n == int(g["n"][i]), f"pair {i}: {n} points, the reference reports {int(g['n'][i])}"
+        assert np.array_equal(o[:n].view(np.uint32), g["pts"][i][:n].view(np.uint32)), f"pair {i}: points differ from the reference's\n{o[:n]}\n{g['pts'][i][:n]}"
+        n_pts += n
+    assert n_pts > 1200
+
+
 def test_narrowphase_routines_vs_reference_golden(port_lib):
     """The Bullet routines the narrowphase restates, against outputs of the reference's OWN code (tests/golden/narrowphase_golden.npz,
     make_narrowphase_golden.py): (1) csrc/arena_gjk.h:gjk_box_triangle vs btGjkPairDetector set up as btConvexConvexAlgorithm does for a
