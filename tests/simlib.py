@@ -12,7 +12,7 @@ from rlgymppo_cpp_amd.state import ArenaState
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_oracle.so")
-PORT_SO = os.environ.get("RLG_PORT_SO") or os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")     # (override: development builds of the port, e.g. -DRLG_BP_HISTORY for tools/raw_divergence.py)
+PORT_SO = os.environ.get("RLG_PORT_SO") or os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")     # (override: development builds of the port for tools/raw_divergence.py)
 
 _vp = C.c_void_p
 
