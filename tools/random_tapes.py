@@ -1,7 +1,8 @@
 """The host build of the stepper against the LIVE reference (oracle/_ref) on random control tapes that no fixture holds: a kickoff of
 1v1 / 2v2 / 3v3 (ResetToRandomKickoff), every car driven by random controls held for random spans -- everybody converges on the ball, so
 car-ball, car-car and wall contacts, bumps and demolitions all occur -- compared in BULLET units after every tick, like
-tools/raw_divergence.py.          usage: random_tapes.py [tapes] [ticks] [first seed]"""
+tools/raw_divergence.py.  With a fourth argument the live arena's car set is rehashed per tape (ref_arena_rehash), so the reference visits its
+cars in a different order from tape to tape.          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,13 +18,15 @@ port = PortSim(); port.set_mesh(verts, tris); ref = RefSim(verts, tris)
 port.lib.port_run_tape_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 ref.lib.ref_arena_get_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 ref.lib.ref_arena_reset_kickoff.argtypes = [C.c_void_p, C.c_int]
-ref.lib.ref_arena_free.argtypes = [C.c_void_p]
+ref.lib.ref_arena_free.argtypes = [C.c_void_p]; ref.lib.ref_arena_rehash.argtypes = [C.c_void_p, C.c_int]
 exact = 0; exact_ticks = 0
 for seed in range(seed0, seed0 + n_tapes):
     rng = np.random.RandomState(seed)
     team = 1 + seed % 3; nc = 2 * team
     k0 = ref.arena(team); ref.lib.ref_arena_reset_kickoff(k0, seed); s0 = ref.get_state(k0); ref.lib.ref_arena_free(k0)
-    a = ref.arena(team); ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
+    a = ref.arena(team)
+    if len(sys.argv) > 4: ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
+    ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
     tape = np.zeros((ticks, nc, 8), np.float32)
     for k in range(nc):
         t = 0
