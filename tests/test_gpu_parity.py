@@ -64,8 +64,8 @@ def test_upload_download_roundtrip():
 def test_hip_free_run_is_bit_identical_to_the_reference(sg):
     """The HIP stepper against the REFERENCE's recorded trajectories, directly: every tape runs as one env of a batch (1v1, 2v2, 3v3), the
     controls of the tape go in through rlgpu_env_set_controls (nothing else of the resident state is touched or rounded) and every 10 ticks
-    the states are downloaded and compared with the reference's for EQUALITY of every field of every body: 27 of the 31 tapes over their
-    whole length (up to 600 ticks), the other four up to simlib.PHYS_EXACT_UNTIL."""
+    the states are downloaded and compared with the reference's for EQUALITY of every field of every body: all 31 tapes over their
+    whole length (up to 620 ticks; simlib.PHYS_EXACT_UNTIL, the table of tapes that stop being exact at a named tick, is empty)."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from simlib import state_vec, PHYS_EXACT_UNTIL
     every = int(sg["phys_every"])

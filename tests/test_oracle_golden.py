@@ -171,10 +171,10 @@ def test_port_physics_vs_reference_golden(sg, port_lib):
 def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
     """The 31 tapes run inside the stepper's own units from the state the reference's set_state was given to the end (port_run_tape: no
     rounding to uu and back between ticks, exactly like the reference's free-running arena) and compared with the reference's recorded
-    trajectory every 10 ticks for EQUALITY of every field of every body: 27 tapes -- up to 600 ticks of driving, jumping, flipping, air
+    trajectory every 10 ticks for EQUALITY of every field of every body: all 31 tapes -- up to 620 ticks of driving, jumping, flipping, air
     control, wall riding, ball flight / rolling / wall, fillet and goal bounces, car-ball hits, aerials, a roof landing with auto-flip,
-    tumbling drops, a car into the back wall / a corner, car-car head-on and side bumps, a ball pinch, 2v2 -- are bit-identical to the
-    reference over their whole length, the other four up to simlib.PHYS_EXACT_UNTIL (3v3: 280 ticks, the demolition tape: 580 of 620)."""
+    tumbling drops, a car into the back wall / a corner, car-car head-on and side bumps, a ball pinch, 2v2, a demolition with respawn, a
+    six-car heap with two demolitions -- are bit-identical to the reference over their whole length (simlib.PHYS_EXACT_UNTIL is empty)."""
     import ctypes as C
     from simlib import PHYS_EXACT_UNTIL, PHYS_AFTER_EXACT
     every = int(sg["phys_every"])
@@ -239,7 +239,8 @@ def test_port_one_tick_vs_reference_states():
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),
     so both sides start from the same bits.  The restatement follows the reference's x86 arithmetic (rl_math.h, rl_libm.h) and its
     narrowphase to the bit (GJK, the penetration-depth solver with EPA, the wheel rays' convex cast, the internal-edge adjustment), and the
-    state carries the arena's car order: EVERY pair of 30 scenarios is EQUAL bit for bit, and all but 14 of the six-car heap's 113."""
+    state carries the arena's car order: EVERY pair of all 31 scenarios is EQUAL bit for bit (a scenario's pairs are stepped one after the other in one
+    arena, as they were recorded: the broadphase's arrival order passes from pair to pair)."""
     from simlib import PortSim, ONE_TICK_NOT_EXACT_MAX
     sgl = np.load(os.path.join(GOLD, "sim_golden.npz")); ss = np.load(os.path.join(GOLD, "sim_steps.npz"))
     port = PortSim(); port.set_mesh(sgl["mesh_verts"], sgl["mesh_tris"])
