@@ -130,7 +130,9 @@ int rlgpu_env_step(rlgpu_env* e, const int32_t* actions_dev, float* next_obs_dev
 int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next_obs_dev, float* reward_dev, int32_t* done_dev);
 
 /* How often the narrowphase's fixed-size queues overflowed since the last reset (process-wide; every overflow sends that env through the
- * inline fallback for that tick -- same results, slower): out5 = {BVH frontier, ball candidate region, car candidate region, item queue, result pool} */
+ * inline fallback for that tick -- same results, slower): out5 = {BVH frontier, ball candidate region, car candidate region, item queue, result pool}.
+ * The last one also counts the two cases in which a contact point is LOST: a body touching a third mesh object with points at once, and a car-car
+ * point beyond the pair pool of the env (4 / 8 / 12 points for 1v1 / 2v2 / 3v3; a six-car heap has shown 9) */
 int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
 
 /* Penetration-depth queries since the last reset (process-wide): hitbox-mesh / hitbox-ball pairs whose cores overlap go through the

@@ -792,8 +792,9 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
             nw.car_car(A, ia, ib, cs, nc);
             const int first = LY::PAIR_BASE + n_pair;
             int cnt = 0;
-            for (int k = 0; k < nc && n_pair < LY::PAIR_POOL; k++) {
+            for (int k = 0; k < nc; k++) {
                 if (cs[k].dist > CBT_CAR) continue;
+                if (n_pair >= LY::PAIR_POOL) { RLG_DBG_COUNT(4); break; }     // a car-car point DROPPED (never seen with the present pool sizes): counted with the pool overflows
                 Contact& c = L.c[LY::PAIR_BASE + n_pair];
                 manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
                 c.a = (int8_t)(1 + ib); c.b = (int8_t)(1 + ia); c.sid = 0; c.special = 0;
