@@ -2,7 +2,8 @@
 1v1 / 2v2 / 3v3 (ResetToRandomKickoff), every car driven by random controls held for random spans -- everybody converges on the ball, so
 car-ball, car-car and wall contacts, bumps and demolitions all occur -- compared in BULLET units after every tick, like
 tools/raw_divergence.py.  With a fourth argument the live arena's car set is rehashed per tape (ref_arena_rehash), so the reference visits its
-cars in a different order from tape to tape.          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash]"""
+cars in a different order from tape to tape; with a fifth ("hunt") every car boosts at the nearest opponent, steering by the reference's
+state of the tick before (demolitions, wrecks, respawns).          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash|-] [hunt]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +26,7 @@ for seed in range(seed0, seed0 + n_tapes):
     team = 1 + seed % 3; nc = 2 * team
     k0 = ref.arena(team); ref.lib.ref_arena_reset_kickoff(k0, seed); s0 = ref.get_state(k0); ref.lib.ref_arena_free(k0)
     a = ref.arena(team)
-    if len(sys.argv) > 4: ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
+    if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
     ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
     tape = np.zeros((ticks, nc, 8), np.float32)
     for k in range(nc):
@@ -36,17 +37,33 @@ for seed in range(seed0, seed0 + n_tapes):
             c[0] = rng.choice([1.0, 1.0, 1.0, -1.0, 0.0]); c[1:5] = rng.choice([-1.0, 0.0, 0.0, 1.0], size=4)
             c[5] = float(rng.rand() < 0.15); c[6] = float(rng.rand() < 0.6); c[7] = float(rng.rand() < 0.1)
             tape[t:t + span, k] = c; t += span
-    raw_p = np.zeros((ticks, 1 + nc, 18), np.float32)
-    st = ArenaState.from_buffer_copy(bytes(s0))
-    port.lib.port_run_tape_raw(C.byref(st), tape.ctypes.data, ticks, raw_p.ctypes.data)
+    hunt = len(sys.argv) > 5
     raw_r = np.zeros((ticks, 1 + nc, 18), np.float32)
+    n_demo = 0; was = [False] * nc
     for t in range(ticks):
+        if hunt:      # the tape is written as the reference runs: full throttle and boost at the nearest opponent
+            cur = ref.get_state(a)
+            for k in range(nc):
+                me = cur.cars[k]; opp = [cur.cars[j] for j in range(nc) if j % 2 != k % 2 and not (cur.cars[j].flags & (1 << 13))]
+                c = np.zeros(8, np.float32); c[0] = 1.0; c[6] = 1.0
+                if opp:
+                    o = min(opp, key=lambda q: (q.pos[0] - me.pos[0]) ** 2 + (q.pos[1] - me.pos[1]) ** 2)
+                    dx, dy = o.pos[0] - me.pos[0], o.pos[1] - me.pos[1]
+                    fx, fy = me.rot[0], me.rot[1]          # forward axis = the first three floats of rot[9] (RlgpuCarState: forward, right, up)
+                    cross = fx * dy - fy * dx
+                    c[1] = -1.0 if cross > 0 else 1.0
+                tape[t, k] = c
+                dm = bool(me.flags & (1 << 13)); n_demo += dm and not was[k]; was[k] = dm
         for k in range(nc):
             ref.set_controls(a, k, tape[t, k])
         ref.step(a, 1)
         ref.lib.ref_arena_get_raw(a, nc, raw_r[t].ctypes.data)
+    raw_p = np.zeros((ticks, 1 + nc, 18), np.float32)
+    st = ArenaState.from_buffer_copy(bytes(s0))
+    port.lib.port_run_tape_raw(C.byref(st), tape.ctypes.data, ticks, raw_p.ctypes.data)
     fin = ref.get_state(a)
     demos = sum(1 for k in range(nc) if fin.cars[k].flags & (1 << 13))
+    if hunt: print(f"   demolitions during the tape: {n_demo}")
     bp, br = raw_p.view(np.uint32), raw_r.view(np.uint32)
     first = next((t + 1 for t in range(ticks) if (bp[t] != br[t]).any()), None)
     exact += first is None; exact_ticks += (ticks if first is None else first - 1)
