@@ -51,6 +51,7 @@ public:
     // one iteration, in the pieces Learn() strings together (also what tests drive)
     void CollectTimesteps();                         // ThreadAgentManager::CollectTimesteps for every game at once
     void AddNewExperience(Report& report);           // Learner.cpp:608-703: value predictions, GAE, return statistics
+    void AddNewExperienceRagged(Report& report);     // ... of an iteration whose trajectories have their own lengths (free-running collection)
     void LearnPPO(Report& report);                   // PPOLearner::Learn (PPOLearner.cpp:67-349); with collectionDuringLearn it only LAUNCHES the epochs
     void FinishLearn(Report& report);                // ... and this waits for them and adds their statistics (Learn() calls it after the next collection)
     void LoadOldVersions(const std::vector<int32_t>& policyDims);   // Learner.cpp:311-370
@@ -62,6 +63,12 @@ public:
     // the experience of the last CollectTimesteps() copied to the host (tests, tools): obs [(T + 1) x agents x obsSize] -- row t + 1 is what
     // the policy sees after step t -- and actions / rewards / dones [T x agents]; agent row = env * players + slot.  Null = skip.
     void CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones);
+    // free-running collection (LearnerConfig::lockstepCollection = false): the arrays above are laid out for StepCapacity() steps and game e's
+    // players have CollectedSteps()[e] of them (rows beyond are stale); lockstep: every entry is StepsPerIteration()
+    int StepCapacity() const;
+    std::vector<int32_t> CollectedSteps() const;
+    bool UsesFreeRunningCollection() const;
+    uint64_t LastIterationTimesteps() const;         // agent-steps the last CollectTimesteps() gathered on this rank
     // multi-GPU (one process per GPU, launcher environment RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT; include/rlgpu.h rlgpu_comm_*):
     // envs are sharded over the ranks, ONE gradient all-reduce per optimizer step, rank 0 writes the checkpoints
     int Rank() const;

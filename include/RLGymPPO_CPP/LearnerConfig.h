@@ -45,5 +45,12 @@ struct LearnerConfig {
     // iteration's report gets "player_speed" (mean |car velocity|, uu/s), "ball_touch_ratio" and "in_air_ratio" (fractions of player-steps)
     // -- collection stays in one launch instead of leaving the device every step (rlgpu_env_enable_step_stats)
     bool deviceStepMetrics = false;
+    // false (default) = collection as the reference's agent threads run it (ThreadAgentManager.cpp:16-82, ThreadAgent.cpp:57-59): every wavefront
+    // of the collection launch steps its games at its own pace until the batch has timestepsPerIteration steps TOGETHER, and an iteration's
+    // trajectories have whatever length each game reached (a launch does not wait for its slowest game; an iteration holds between
+    // timestepsPerIteration and timestepsPerIteration + one step of every game).  Used when the whole batch is resident on the device at once and
+    // no plugin or callback needs the host per step; otherwise -- and with true -- every game makes the same number of steps per iteration
+    // (reproducible from the seed alone: the free-running iteration's trajectory LENGTHS depend on timing, their contents do not).
+    bool lockstepCollection = false;
 };
 }

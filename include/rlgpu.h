@@ -212,6 +212,14 @@ int rlgpu_gae(rlgpu_learner* l, const float* rews_dev, const float* dones_dev, c
 int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs_dev, const int32_t* actions_dev, const float* old_logp_dev,
                         const float* adv_dev, const float* targets_dev, const int32_t* idx_dev, int n,
                         float batch_size_ratio, float* metrics_dev);
+/* The same for trajectories of their own lengths (free-running collection, rlgpu_collect_free): agent j's trajectory is rows 0 .. steps[j / players] - 1
+ * of column j of the time-major arrays (row stride n), values has one more row per trajectory (V of the state after its last step).  The batch
+ * ComputeGAE sees in the reference is the concatenation of the NON-EMPTY trajectories (ThreadAgentManager.cpp:47-60): with next_value_mode 0 the
+ * row after a trajectory's last step is the first state of the next non-empty trajectory (quirk Q1), the batch's last row uses its own next state.
+ * truncs_dev NULL = the collector's mark (1 - done on every trajectory's last row, ThreadAgentManager.cpp:55).  Rows beyond a trajectory are not written. */
+int rlgpu_gae_ragged(rlgpu_learner* l, const float* rews_dev, const float* dones_dev, const float* truncs_dev, const float* values_dev, int n,
+                     const int32_t* steps_dev /* [n / players] */, int players, float gamma, float lambda, float ret_std, float clip_range,
+                     int next_value_mode, float* adv_dev, float* targets_dev, float* returns_dev);
 int rlgpu_zero_grads(rlgpu_learner* l);
 /* clip_grad_norm_(params, max_norm) per network then Adam (PPOLearner.cpp:273-288; torch defaults b1 .9 b2 .999 eps 1e-8).
  * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
@@ -246,6 +254,11 @@ typedef struct rlgpu_shuffler rlgpu_shuffler;
 int rlgpu_shuffler_create(rlgpu_shuffler** out, uint32_t seed);
 void rlgpu_shuffler_destroy(rlgpu_shuffler* s);
 int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm_out);
+int rlgpu_shuffler_next_i32(rlgpu_shuffler* s, int64_t n, int32_t* perm_out);   /* the same draw (same engine consumption), 32-bit entries */
+/* the engine's state as text (operator<< / >> of std::default_random_engine): a host that draws a permutation AHEAD for a size it predicts
+ * puts the engine back when the prediction fails */
+int rlgpu_shuffler_get_state(const rlgpu_shuffler* s, char* buf, int cap);
+int rlgpu_shuffler_set_state(rlgpu_shuffler* s, const char* buf);
 /* the same draw for a [T][n_agents] time-major experience buffer whose LOGICAL order is agent-major (trajectory after trajectory, as
  * ExperienceBuffer holds it): rows_out[i] = (p % T) * n_agents + p / T for p = perm[i], B = T * n_agents entries, ready for idx_dev */
 int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows_out);
@@ -260,6 +273,17 @@ int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* ro
 int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs_dev, int32_t* actions_dev, float* logp_dev, float* reward_dev, int32_t* done_dev,
                   int deterministic);
 
+/* The same phase as the reference's agents run it: FREE.  ThreadAgentManager::CollectTimesteps (PRIV/Threading/ThreadAgentManager.cpp:16-82) lets every
+ * agent thread step its games at its own pace and takes whatever each trajectory holds once the agents TOGETHER have `amount` timesteps; an agent
+ * stops by itself after maxCollect / numThreads of them (ThreadAgent.cpp:57-59).  Here: every wavefront goes on stepping its envs until the launch's
+ * shared counter reaches target_agent_steps (checked before every gym step), at most T_cap steps; steps_dev[env] = gym steps env made (its players'
+ * trajectory length), so sum(steps) * players >= target (short of it only when every env ran into T_cap) and < target + num_agents.  A launch no longer ends with its slowest
+ * wavefront.  Rows beyond an env's own count are not written.  An env's rows are those of the lockstep call's first steps_dev[env] steps, bit for bit
+ * (same sampler counters, same stepper).  Needs every workgroup of the launch resident at once: RLGPU_ERR_STATE otherwise (and whenever rlgpu_collect
+ * would return it) -- the caller then collects in lockstep.  obs [T_cap+1][n_agents][obs_size], the rest [T_cap][n_agents], steps_dev [n_envs] int32. */
+int rlgpu_collect_free(rlgpu_env* e, rlgpu_learner* l, int T_cap, int64_t target_agent_steps, float* obs_dev, int32_t* actions_dev, float* logp_dev,
+                       float* reward_dev, int32_t* done_dev, int32_t* steps_dev, int deterministic);
+
 /* ---- ExperienceBuffer (PRIV/PPO/ExperienceBuffer.{h,cpp}): FIFO over rows with capacity max_rows.  Host bookkeeping only:
  *      every submitted iteration (T x n_agents rows, time-major) stays in one of `num_slots` device slots the caller owns; the
  *      library tracks which rows are still inside the FIFO (shift-left on overflow, :37-58; an addition larger than the buffer
@@ -272,6 +296,19 @@ int rlgpu_expbuf_num_slots(const rlgpu_expbuf* b);
 int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out);   /* account for one more iteration; *slot_out = where the caller must store it */
 int64_t rlgpu_expbuf_size(const rlgpu_expbuf* b);          /* curSize */
 int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows_out /* [curSize] */);
+/* Iterations whose trajectories have their own lengths (rlgpu_collect_free; what ExperienceBuffer::SubmitExperience gets in the reference: the
+ * concatenation of ragged trajectories, Learner.cpp:694-702).  A device slot holds T_cap x n_agents rows, time-major; slots are provided for
+ * max_rows / min_rows_per_iteration + 1 iterations (at most 16).  submit_ragged: agent_steps [n_agents] host = every trajectory's length; with
+ * keep_last > 0 only the iteration's LAST keep_last logical rows join the FIFO (a multi-GPU run keeps every rank's FIFO the same size this way).
+ * rlgpu_expbuf_shuffled_rows / _map_rows handle both kinds of iteration.  _map_rows: a permutation of [0, curSize) drawn elsewhere
+ * (rlgpu_shuffler_next_i32) -> device rows; _map_rows_dev: the same on the device (all iterations in the FIFO must be ragged submissions),
+ * traj_off_dev [num_slots][n_agents + 1] int32 = rlgpu_traj_offsets of the iteration in each slot. */
+int rlgpu_expbuf_create_ragged(rlgpu_expbuf** out, int64_t max_rows, int T_cap, int n_agents, int64_t min_rows_per_iteration);
+int rlgpu_expbuf_submit_ragged(rlgpu_expbuf* b, const int32_t* agent_steps, int64_t keep_last, int* slot_out);
+int rlgpu_expbuf_map_rows(rlgpu_expbuf* b, const int32_t* perm, int64_t n, int32_t* rows_out);
+int rlgpu_expbuf_map_rows_dev(rlgpu_expbuf* b, const int32_t* perm_dev, int64_t n, const int32_t* traj_off_dev, int32_t* rows_dev, void* hip_stream);
+/* off_dev[a] = sum of steps_dev[a' / players] over agents a' < a, off_dev[n_agents] = all rows (one small launch on hip_stream) */
+int rlgpu_traj_offsets(const int32_t* steps_dev, int n_agents, int players, int32_t* off_dev, void* hip_stream);
 
 /* ---- checkpoint payloads (PRIV/PPO/PPOLearner.cpp:362-477): the TorchScript zip archives that torch::save(nn::Sequential)
  *      (PPO_POLICY.lt, PPO_CRITIC.lt) and optim::Adam::save (PPO_*_OPTIM.lt) write, read and written without libtorch, so

@@ -98,6 +98,29 @@ int64_t refl_expbuf_run(int64_t max_size, int seed, int n_submits, int rows_per_
     return n;
 }
 
+// The same with submissions of different sizes (what a free-running collection hands over: ThreadAgentManager.cpp:47-60 concatenates whatever each
+// trajectory holds): submission s has sizes[s] rows with identities first_id[s] + i.
+int64_t refl_expbuf_run_sizes(int64_t max_size, int seed, int n_submits, const int32_t* sizes, int64_t batch_size, int64_t* ids_out, int64_t ids_cap, int32_t* counts_out) {
+    ExperienceBuffer buf(max_size, seed, torch::kCPU);
+    int64_t n = 0, next_id = 0;
+    for (int s = 0; s < n_submits; s++) {
+        ExperienceTensors t;
+        const int64_t rows = sizes[s];
+        torch::Tensor ids = torch::arange(next_id, next_id + rows, torch::kFloat64);
+        next_id += rows;
+        for (torch::Tensor& x : t) x = torch::zeros({rows, 1}, torch::kFloat64);
+        t.actions = ids.view({rows, 1}).clone();
+        buf.SubmitExperience(t);
+        auto batches = buf.GetAllBatchesShuffled(batch_size);
+        counts_out[s] = (int32_t)batches.size();
+        for (auto& b : batches) {
+            torch::Tensor a = b.actions.contiguous().view({-1});
+            for (int64_t i = 0; i < a.numel(); i++) { if (n < ids_cap) ids_out[n] = (int64_t)a[i].item<double>(); n++; }
+        }
+    }
+    return n;
+}
+
 // WelfordRunningStat (PUB/Util/WelfordRunningStat.h:5-84), shape 1, fed in chunks of `chunk` samples like Learner.cpp:679-682 does
 void refl_welford(const float* samples, int n, int chunk, double* mean_out, double* m2_out, int64_t* count_out, float* std_out) {
     WelfordRunningStat w(1);

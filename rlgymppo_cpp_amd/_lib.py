@@ -133,6 +133,16 @@ SIGNATURES = {
     "rlgpu_shuffler_next": (_i, [_vp, C.c_int64, _vp]),
     "rlgpu_shuffler_next_rows": (_i, [_vp, C.c_int, C.c_int, _vp]),
     "rlgpu_collect": (_i, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "rlgpu_collect_free": (_i, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "rlgpu_gae_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "rlgpu_shuffler_next_i32": (_i, [_vp, C.c_int64, _vp]),
+    "rlgpu_shuffler_get_state": (_i, [_vp, C.c_char_p, _i]),
+    "rlgpu_shuffler_set_state": (_i, [_vp, C.c_char_p]),
+    "rlgpu_expbuf_create_ragged": (_i, [C.POINTER(_vp), C.c_int64, C.c_int, C.c_int, C.c_int64]),
+    "rlgpu_expbuf_submit_ragged": (_i, [_vp, _vp, C.c_int64, C.POINTER(C.c_int)]),
+    "rlgpu_expbuf_map_rows": (_i, [_vp, _vp, C.c_int64, _vp]),
+    "rlgpu_expbuf_map_rows_dev": (_i, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "rlgpu_traj_offsets": (_i, [_vp, _i, _i, _vp, _vp]),
     "rlgpu_expbuf_create": (_i, [C.POINTER(_vp), C.c_int64, C.c_int, C.c_int]),
     "rlgpu_expbuf_destroy": (None, [_vp]),
     "rlgpu_expbuf_num_slots": (_i, [_vp]),

@@ -772,6 +772,10 @@ struct CollectArgs {
     float* obs;          // [T + 1][n_agents][D]; row block 0 holds the current observations
     int32_t* acts; float* logp; float* rew; int32_t* done;   // [T][n_agents]
     rlinfer::InferNet net; rlinfer::HeadArgs head;
+    // free-running collection (rlgpu_collect_free): every wavefront goes on stepping its envs until the launch as a whole has gathered
+    // `free_target` agent-steps (ThreadAgentManager::CollectTimesteps, ThreadAgentManager.cpp:16-32: the agents run free and the manager
+    // takes what they have once the total is reached), at most T steps each (ThreadAgent.cpp:57-59, maxCollect); null counter = lockstep
+    unsigned int* counter; unsigned int free_target; int32_t* steps_out;   // steps_out [n_envs]: gym steps env e made in this launch
 };
 
 template <int NC>
@@ -819,7 +823,12 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
     wave_sync();
     StepStats stats;
-    for (int t = 0; t < c.T; t++) {
+    int t = 0;
+    for (; t < c.T; t++) {
+        if (c.counter) {   // free-running: stop as soon as the launch has its agent-steps together (the value is the same on every lane: one address)
+            const unsigned int have = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (have >= c.free_target) break;
+        }
 #ifdef RLG_TICK_PROFILE
         const unsigned long long prof_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -877,8 +886,10 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
             for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (c.counter && ws.lane == 0) __hip_atomic_fetch_add(c.counter, (unsigned int)n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wave_sync();
     }
+    if (c.steps_out && env_lane) c.steps_out[env] = t;
     if (d.step_stats) step_stats_flush(d.step_stats, stats, ws.lane);
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
@@ -1007,6 +1018,7 @@ struct rlgpu_env {
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
+    unsigned int* d_free_counter = nullptr; int free_capacity = -1;   // rlgpu_collect_free: the launch's agent-step counter; workgroups the device keeps resident at once
     unsigned char* d_epa_big = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1124,6 +1136,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_pad_tab) (void)hipFree(e->d_pad_tab);
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
+    if (e->d_free_counter) (void)hipFree(e->d_free_counter);
     if (e->d_epa_big) (void)hipFree(e->d_epa_big);
     if (e->d.leaf_cache) (void)hipFree(e->d.leaf_cache);
     if (e->d.step_stats) (void)hipFree(e->d.step_stats);
@@ -1344,9 +1357,10 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls, float* next_obs
 }
 
 // ThreadAgent::_RunFunc for a whole collection phase (ThreadAgent.cpp:58-163): T x (policy->GetAction, GameInst::Step) for every env
-int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic) {
-    if (!l || T <= 0 || !obs || !actions || !logp || !reward || !done) { e->err = "rlgpu_collect: bad argument"; return RLGPU_ERR_ARG; }
-    if (e->d.cfg.one_team) { e->err = "rlgpu_collect: one-team envs are collected step by step (rlgpu_policy_act + rlgpu_env_step)"; return RLGPU_ERR_STATE; }
+static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic,
+                        int64_t free_target, int32_t* steps_out, const char* who) {
+    if (!l || T <= 0 || !obs || !actions || !logp || !reward || !done) { e->err = std::string(who) + ": bad argument"; return RLGPU_ERR_ARG; }
+    if (e->d.cfg.one_team) { e->err = std::string(who) + ": one-team envs are collected step by step (rlgpu_policy_act + rlgpu_env_step)"; return RLGPU_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     CollectArgs c{};
     const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;
@@ -1356,16 +1370,43 @@ int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* ac
     int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
     if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(epw * e->nc, c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
     if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_part_bytes(epw * e->nc, epw == 3 ? 3 : 2, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
-    if (rc) { e->err = "rlgpu_collect: the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
-    if (c.net.D != rlgpu_env_obs_size(e)) { e->err = "rlgpu_collect: the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
+    if (rc) { e->err = std::string(who) + ": the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
+    if (c.net.D != rlgpu_env_obs_size(e)) { e->err = std::string(who) + ": the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    if (free_target > 0) {
+        // The agents must all be RUNNING for "stop when the total is there" to mean what it means in the reference (every agent thread runs
+        // from the start): all workgroups of the launch resident at once.  A batch with more wavefronts than the device holds is load-balanced
+        // by the dispatcher anyway (a retiring wavefront makes room for the next) and is collected in lockstep (RLGPU_ERR_STATE: rlgpu_collect).
+        if (e->free_capacity < 0) {
+            int per_cu = 0; hipDeviceProp_t prop{};
+            HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
+            hipError_t oc = e->nc == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<2>, WAVE * WPB, 0)
+                          : e->nc == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<4>, WAVE * WPB, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<6>, WAVE * WPB, 0);
+            HIPCHK(e, oc);
+            e->free_capacity = per_cu * prop.multiProcessorCount;
+        }
+        if ((int)grid.x > e->free_capacity) { e->err = std::string(who) + ": more workgroups than the device keeps resident at once; collect in lockstep (rlgpu_collect)"; return RLGPU_ERR_STATE; }
+        if (free_target > 0xFFFFFFFFll - (int64_t)c.n_agents || !steps_out) { e->err = std::string(who) + ": bad target / steps_out"; return RLGPU_ERR_ARG; }
+        if (!e->d_free_counter) HIPCHK(e, hipMalloc(&e->d_free_counter, 64));
+        HIPCHK(e, hipMemsetAsync(e->d_free_counter, 0, 4, e->stream));
+        c.counter = e->d_free_counter; c.free_target = (unsigned int)free_target; c.steps_out = steps_out;
+    } else c.steps_out = steps_out;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if (e->timing_on) { int rc_ev = env_next_events(e, &evp); if (rc_ev) return rc_ev; HIPCHK(e, hipEventRecord(evp->first, e->stream)); }
     DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
     if (evp) { HIPCHK(e, hipEventRecord(evp->second, e->stream)); e->ev0 = evp->first; e->ev1 = evp->second; e->timed = true; }
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
+}
+int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic) {
+    return collect_impl(e, l, T, obs, actions, logp, reward, done, deterministic, 0, nullptr, "rlgpu_collect");
+}
+int rlgpu_collect_free(rlgpu_env* e, rlgpu_learner* l, int T_cap, int64_t target_agent_steps, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done,
+                       int32_t* steps_dev, int deterministic) {
+    if (target_agent_steps <= 0) { e->err = "rlgpu_collect_free: target_agent_steps must be positive"; return RLGPU_ERR_ARG; }
+    return collect_impl(e, l, T_cap, obs, actions, logp, reward, done, deterministic, target_agent_steps, steps_dev, "rlgpu_collect_free");
 }
 
 int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset) {

@@ -12,6 +12,7 @@
 // GEMMs use v_mfma_f32_32x32x2_f32 (exact fp32, the reference's precision) or, with use_bf16 (the reference's
 // autocast dtype, FrameworkTorch.h:12-16), v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 master weights.
 #include <hip/hip_runtime.h>
+#include <sstream>
 #include <hip/hip_bf16.h>
 #include <cstdio>
 #include <cstring>
@@ -644,6 +645,76 @@ __global__ void k_gae(const float* rews, const float* dones, const float* truncs
     }
 }
 
+// The same scan over trajectories of DIFFERENT lengths (free-running collection, rlgpu_collect_free): agent j's trajectory has
+// steps[j / players] rows, rows beyond it do not exist.  The batch the reference hands to ComputeGAE is the concatenation of the non-empty
+// trajectories (ThreadAgentManager.cpp:47-60), so with mode 0 "the next row" after a trajectory's last step is the first state of the
+// next NON-EMPTY trajectory, and the batch's very last row is followed by the value of its own next state (Learner.cpp:619-640).
+// With `trunc_marks` null the collector's truncation mark is applied here: 1 - done on a trajectory's last row, 0 elsewhere (ThreadAgentManager.cpp:55).
+__global__ void k_gae_ragged(const float* rews, const float* dones, const float* truncs, const float* values, int n, const int32_t* steps, int players,
+                             float gamma, float lambda, float ret_std, float clip_range, int mode, float* adv, float* targets, float* returns) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int len = steps[j / players];
+    if (len <= 0) return;
+    float nv_last;
+    if (mode == 0) {
+        int j2 = j + 1;
+        while (j2 < n && steps[j2 / players] <= 0) j2++;
+        nv_last = j2 < n ? values[j2] : values[(size_t)len * n + j];
+    } else nv_last = values[(size_t)len * n + j];
+    float last_gae = 0.f, last_ret = 0.f;
+    for (int t = len - 1; t >= 0; t--) {
+        size_t i = (size_t)t * n + j;
+        float done = 1.f - dones[i];
+        float trunc = truncs ? 1.f - truncs[i] : (t == len - 1 ? dones[i] : 1.f);   // 1 - truncated; truncated = 1 - done on the last row
+        float nv = (t == len - 1) ? nv_last : values[(size_t)(t + 1) * n + j];
+        float norm_rew;
+        if (ret_std != 0.f) {
+            norm_rew = rews[i] / ret_std;
+            if (clip_range > 0.f) norm_rew = fminf(fmaxf(norm_rew, -clip_range), clip_range);
+        } else norm_rew = rews[i];
+        float pred_ret = norm_rew + gamma * nv * done;
+        float delta = pred_ret - values[i];
+        float ret = rews[i] + last_ret * gamma * done * trunc;
+        returns[i] = ret;
+        last_ret = ret;
+        last_gae = delta + gamma * lambda * done * trunc * last_gae;
+        adv[i] = last_gae;
+        targets[i] = values[i] + last_gae;
+    }
+}
+
+// off[a] = rows of the trajectories before agent a's in the concatenated batch (exclusive prefix sum of steps[a / players]), off[n] = all rows.
+// One workgroup of 1024 threads: contiguous ranges per thread, the 1024 range sums scanned in LDS.
+__global__ void __launch_bounds__(1024) k_traj_offsets(const int32_t* steps, int n, int players, int32_t* off) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024, a0 = tid * per, a1 = min(n, a0 + per);
+    int sum = 0;
+    for (int a = a0; a < a1; a++) sum += max(steps[a / players], 0);
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { int v = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
+    int run = part[tid] - sum;
+    for (int a = a0; a < a1; a++) { off[a] = run; run += max(steps[a / players], 0); }
+    if (tid == 1023) off[n] = part[1023];
+}
+
+// GetAllBatchesShuffled's permutation (logical FIFO rows, oldest iteration first, trajectory after trajectory inside one) -> device rows
+// slot * slot_rows + t * n + agent, for iterations whose trajectories have their own lengths: off_base + slot * (n + 1) = that slot's k_traj_offsets
+struct ExpChunks { int count; int slot[16]; long long start[17]; long long skip[16]; };
+__global__ void k_map_rows(const int32_t* perm, long long cur, ExpChunks ch, const int32_t* off_base, int n, long long slot_rows, int32_t* rows) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cur) return;
+    const long long p = perm[i];
+    int c = 0;
+    while (c + 1 < ch.count && p >= ch.start[c + 1]) c++;
+    const long long a = p - ch.start[c] + ch.skip[c];
+    const int32_t* off = off_base + (size_t)ch.slot[c] * (n + 1);
+    int lo = 0, hi = n;   // the last agent whose offset is <= a (empty trajectories share their successor's offset: take the one that owns row a)
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if ((long long)off[mid] <= a) lo = mid; else hi = mid; }
+    rows[i] = (int32_t)((long long)ch.slot[c] * slot_rows + (a - off[lo]) * n + lo);
+}
+
 // fused PPO policy loss + gradient wrt logits; one wave per row, grid-stride over rows. (PPOLearner.cpp:148-198, DiscretePolicy.cpp:64-75)
 // metrics: [0] entropy sum, [1] KL sum, [2] clip count, [3] ratio sum (per-row sums; host divides).  Each wave keeps its
 // sums in registers, the workgroup folds them in LDS and issues ONE atomic per metric (65536 rows x 4 same-address atomics
@@ -799,8 +870,10 @@ struct rlgpu_shuffler { std::default_random_engine rng; std::vector<int64_t> scr
 
 // ExperienceBuffer bookkeeping (PRIV/PPO/ExperienceBuffer.cpp:17-68): which rows of which submitted iteration are still in the FIFO
 struct rlgpu_expbuf {
-    int64_t max_rows = 0; int T = 0, n = 0; int64_t B = 0;
-    struct Chunk { int slot; int64_t skip; };   // rows [skip, B) of the iteration stored in device slot `slot`, in agent-major order
+    int64_t max_rows = 0; int T = 0, n = 0; int64_t B = 0;   // B = rows of a device slot (T x n); T = steps of a lockstep iteration
+    // rows [skip, rows) of the iteration stored in device slot `slot`, in agent-major order; off (n + 1 entries) = where each trajectory starts when
+    // the trajectories have their own lengths (rlgpu_expbuf_submit_ragged), empty = n trajectories of T rows
+    struct Chunk { int slot; int64_t skip; int64_t rows; std::vector<int64_t> off; };
     std::vector<Chunk> chunks;                  // oldest first
     int n_slots = 0;
 };
@@ -1233,6 +1306,16 @@ int rlgpu_gae(rlgpu_learner* l, const float* rews, const float* dones, const flo
     return RLGPU_OK;
 }
 
+int rlgpu_gae_ragged(rlgpu_learner* l, const float* rews, const float* dones, const float* truncs, const float* values, int n, const int32_t* steps, int players,
+                     float gamma, float lambda, float ret_std, float clip_range, int mode, float* adv, float* targets, float* returns) {
+    if (!rews || !dones || !values || !steps || !adv || !targets || !returns || n <= 0 || players <= 0 || n % players) { l->err = "rlgpu_gae_ragged: bad argument"; return RLGPU_ERR_ARG; }
+    LCHK(l, hipSetDevice(l->device));
+    dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_gae_ragged, grid, block, 0, l->stream, rews, dones, truncs, values, n, steps, players, gamma, lambda, ret_std, clip_range, mode, adv, targets, returns);
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+
 int rlgpu_zero_grads(rlgpu_learner* l) {
     LCHK(l, hipSetDevice(l->device));
     LCHK(l, hipMemsetAsync(l->grads, 0, l->n_total * 4, l->stream));
@@ -1434,6 +1517,27 @@ int rlgpu_shuffler_next(rlgpu_shuffler* s, int64_t n, int64_t* perm) {
     std::shuffle(perm, perm + n, s->rng);
     return RLGPU_OK;
 }
+int rlgpu_shuffler_next_i32(rlgpu_shuffler* s, int64_t n, int32_t* perm) {
+    if (!s || n < 0 || n > 0x7fffffffLL || !perm) return RLGPU_ERR_ARG;
+    s->scratch.resize((size_t)n);
+    int rc = rlgpu_shuffler_next(s, n, s->scratch.data());   // the 64-bit draw, narrowed: the engine is consumed exactly as by rlgpu_shuffler_next
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++) perm[i] = (int32_t)s->scratch[(size_t)i];
+    return RLGPU_OK;
+}
+int rlgpu_shuffler_get_state(const rlgpu_shuffler* s, char* buf, int cap) {
+    if (!s || !buf) return RLGPU_ERR_ARG;
+    std::ostringstream o; o << s->rng;
+    const std::string t = o.str();
+    if ((int)t.size() + 1 > cap) return RLGPU_ERR_ARG;
+    memcpy(buf, t.c_str(), t.size() + 1);
+    return RLGPU_OK;
+}
+int rlgpu_shuffler_set_state(rlgpu_shuffler* s, const char* buf) {
+    if (!s || !buf) return RLGPU_ERR_ARG;
+    std::istringstream i{std::string(buf)}; i >> s->rng;
+    return i.fail() ? RLGPU_ERR_ARG : RLGPU_OK;
+}
 int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* rows) {
     if (!s || T <= 0 || n_agents <= 0 || !rows) return RLGPU_ERR_ARG;
     const int64_t B = (int64_t)T * n_agents;
@@ -1453,26 +1557,37 @@ int rlgpu_expbuf_create(rlgpu_expbuf** out, int64_t max_rows, int T, int n_agent
     *out = b;
     return RLGPU_OK;
 }
+int rlgpu_expbuf_create_ragged(rlgpu_expbuf** out, int64_t max_rows, int T_cap, int n_agents, int64_t min_rows_per_iteration) {
+    if (!out || max_rows <= 0 || T_cap <= 0 || n_agents <= 0 || min_rows_per_iteration <= 0) return RLGPU_ERR_ARG;
+    rlgpu_expbuf* b = new rlgpu_expbuf();
+    b->max_rows = max_rows; b->T = T_cap; b->n = n_agents; b->B = (int64_t)T_cap * n_agents;
+    b->n_slots = (int)((max_rows + min_rows_per_iteration - 1) / min_rows_per_iteration) + 1;
+    if (b->n_slots > 16) { delete b; return RLGPU_ERR_ARG; }   // (k_map_rows takes the chunk table by value)
+    *out = b;
+    return RLGPU_OK;
+}
 void rlgpu_expbuf_destroy(rlgpu_expbuf* b) { delete b; }
 int rlgpu_expbuf_num_slots(const rlgpu_expbuf* b) { return b ? b->n_slots : 0; }
 int64_t rlgpu_expbuf_size(const rlgpu_expbuf* b) {
     int64_t n = 0;
-    if (b) for (auto& c : b->chunks) n += b->B - c.skip;
+    if (b) for (auto& c : b->chunks) n += c.rows - c.skip;
     return n;
 }
-int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out) {
-    if (!b || !slot_out) return RLGPU_ERR_ARG;
+static int expbuf_submit(rlgpu_expbuf* b, int64_t rows, int64_t keep_last, std::vector<int64_t>&& off, int* slot_out) {
     // an addition larger than the buffer keeps its LAST max_rows rows (ExperienceBuffer.cpp:32-35)
-    int64_t add = b->B, new_skip = 0;
-    if (add > b->max_rows) { new_skip = add - b->max_rows; add = b->max_rows; }
+    int64_t add = rows, new_skip = 0;
+    if (keep_last > 0 && add > keep_last) add = keep_last;
+    if (add > b->max_rows) add = b->max_rows;
+    new_skip = rows - add;
     // shift left by the overflow (ExperienceBuffer.cpp:37-58): drop the oldest rows
     int64_t overflow = std::max<int64_t>(rlgpu_expbuf_size(b) + add - b->max_rows, 0);
     while (overflow > 0 && !b->chunks.empty()) {
         rlgpu_expbuf::Chunk& c = b->chunks.front();
-        int64_t have = b->B - c.skip;
+        int64_t have = c.rows - c.skip;
         if (have <= overflow) { overflow -= have; b->chunks.erase(b->chunks.begin()); }
         else { c.skip += overflow; overflow = 0; }
     }
+    while (!b->chunks.empty() && b->chunks.front().rows == b->chunks.front().skip) b->chunks.erase(b->chunks.begin());   // (an iteration of no rows)
     int slot = -1;
     for (int s = 0; s < b->n_slots && slot < 0; s++) {
         bool used = false;
@@ -1480,9 +1595,32 @@ int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out) {
         if (!used) slot = s;
     }
     if (slot < 0) return RLGPU_ERR_STATE;
-    b->chunks.push_back({slot, new_skip});
+    b->chunks.push_back({slot, new_skip, rows, std::move(off)});
     *slot_out = slot;
     return RLGPU_OK;
+}
+int rlgpu_expbuf_submit(rlgpu_expbuf* b, int* slot_out) {
+    if (!b || !slot_out) return RLGPU_ERR_ARG;
+    return expbuf_submit(b, b->B, 0, {}, slot_out);
+}
+int rlgpu_expbuf_submit_ragged(rlgpu_expbuf* b, const int32_t* agent_steps, int64_t keep_last, int* slot_out) {
+    if (!b || !slot_out || !agent_steps || keep_last < 0) return RLGPU_ERR_ARG;
+    std::vector<int64_t> off((size_t)b->n + 1, 0);
+    for (int a = 0; a < b->n; a++) {
+        if (agent_steps[a] < 0 || agent_steps[a] > b->T) return RLGPU_ERR_ARG;
+        off[(size_t)a + 1] = off[(size_t)a] + agent_steps[a];
+    }
+    const int64_t rows = off[(size_t)b->n];
+    return expbuf_submit(b, rows, keep_last, std::move(off), slot_out);
+}
+// logical FIFO row p -> device row
+static inline int32_t expbuf_row(const rlgpu_expbuf* b, const std::vector<int64_t>& start, int64_t p) {
+    size_t c = (size_t)(std::upper_bound(start.begin(), start.end(), p) - start.begin()) - 1;
+    const rlgpu_expbuf::Chunk& ch = b->chunks[c];
+    const int64_t a = p - start[c] + ch.skip;
+    if (ch.off.empty()) return (int32_t)((int64_t)ch.slot * b->B + (a % b->T) * b->n + a / b->T);
+    const size_t ag = (size_t)(std::upper_bound(ch.off.begin(), ch.off.end(), a) - ch.off.begin()) - 1;   // the trajectory that owns row a (empty ones own none)
+    return (int32_t)((int64_t)ch.slot * b->B + (a - ch.off[ag]) * b->n + (int64_t)ag);
 }
 int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows_out) {
     if (!b || !s || !rows_out) return RLGPU_ERR_ARG;
@@ -1491,16 +1629,34 @@ int rlgpu_expbuf_shuffled_rows(rlgpu_expbuf* b, rlgpu_shuffler* s, int32_t* rows
     s->scratch.resize((size_t)cur);
     int rc = rlgpu_shuffler_next(s, cur, s->scratch.data());
     if (rc) return rc;
-    // logical row i of the FIFO -> (chunk, agent-major index a) -> device row slot * B + (a % T) * n + a / T
+    // logical row i of the FIFO -> (chunk, agent-major index a) -> device row slot * B + t * n + agent
     std::vector<int64_t> start(b->chunks.size() + 1, 0);
-    for (size_t c = 0; c < b->chunks.size(); c++) start[c + 1] = start[c] + (b->B - b->chunks[c].skip);
-    for (int64_t i = 0; i < cur; i++) {
-        const int64_t p = s->scratch[(size_t)i];
-        size_t c = (size_t)(std::upper_bound(start.begin(), start.end(), p) - start.begin()) - 1;
-        const int64_t a = p - start[c] + b->chunks[c].skip;
-        rows_out[i] = (int32_t)((int64_t)b->chunks[c].slot * b->B + (a % b->T) * b->n + a / b->T);
-    }
+    for (size_t c = 0; c < b->chunks.size(); c++) start[c + 1] = start[c] + (b->chunks[c].rows - b->chunks[c].skip);
+    for (int64_t i = 0; i < cur; i++) rows_out[i] = expbuf_row(b, start, s->scratch[(size_t)i]);
     return RLGPU_OK;
+}
+int rlgpu_expbuf_map_rows(rlgpu_expbuf* b, const int32_t* perm, int64_t n, int32_t* rows_out) {
+    if (!b || !perm || !rows_out || n != rlgpu_expbuf_size(b) || (int64_t)b->n_slots * b->B > 0x7fffffffLL) return RLGPU_ERR_ARG;
+    std::vector<int64_t> start(b->chunks.size() + 1, 0);
+    for (size_t c = 0; c < b->chunks.size(); c++) start[c + 1] = start[c] + (b->chunks[c].rows - b->chunks[c].skip);
+    for (int64_t i = 0; i < n; i++) { if (perm[i] < 0 || perm[i] >= n) return RLGPU_ERR_ARG; rows_out[i] = expbuf_row(b, start, perm[i]); }
+    return RLGPU_OK;
+}
+int rlgpu_expbuf_map_rows_dev(rlgpu_expbuf* b, const int32_t* perm_dev, int64_t n, const int32_t* traj_off_dev, int32_t* rows_dev, void* stream) {
+    if (!b || !perm_dev || !rows_dev || !traj_off_dev || n != rlgpu_expbuf_size(b) || b->chunks.size() > 16 || (int64_t)b->n_slots * b->B > 0x7fffffffLL) return RLGPU_ERR_ARG;
+    ExpChunks ch{}; ch.count = (int)b->chunks.size(); ch.start[0] = 0;
+    for (int c = 0; c < ch.count; c++) {
+        if (b->chunks[(size_t)c].off.empty()) return RLGPU_ERR_STATE;   // (a lockstep iteration in the FIFO: its offsets are not on the device; map on the host)
+        ch.slot[c] = b->chunks[(size_t)c].slot; ch.skip[c] = b->chunks[(size_t)c].skip; ch.start[c + 1] = ch.start[c] + (b->chunks[(size_t)c].rows - b->chunks[(size_t)c].skip);
+    }
+    if (n == 0) return RLGPU_OK;
+    hipLaunchKernelGGL(k_map_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, perm_dev, (long long)n, ch, traj_off_dev, b->n, (long long)b->B, rows_dev);
+    return hipGetLastError() == hipSuccess ? RLGPU_OK : RLGPU_ERR_HIP;
+}
+int rlgpu_traj_offsets(const int32_t* steps_dev, int n_agents, int players, int32_t* off_dev, void* stream) {
+    if (!steps_dev || !off_dev || n_agents <= 0 || players <= 0) return RLGPU_ERR_ARG;
+    hipLaunchKernelGGL(k_traj_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, steps_dev, n_agents, players, off_dev);
+    return hipGetLastError() == hipSuccess ? RLGPU_OK : RLGPU_ERR_HIP;
 }
 
 }  // extern "C"

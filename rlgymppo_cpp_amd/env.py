@@ -151,6 +151,19 @@ class BatchedEnv:
         _chk(rc, self.h, self.lib.rlgpu_env_last_error)
         return True
 
+    def collect_free(self, ppo, T_cap: int, target_agent_steps: int, obs, actions, logp, reward, done, steps, deterministic=False) -> bool:
+        """The collection phase as the reference's agent threads run it (rlgpu_collect_free): every wavefront steps its envs until the launch has
+        `target_agent_steps` together, at most T_cap steps each; steps [n_envs] int32 = gym steps each env made.  Buffers as for collect() with T = T_cap.
+        Returns False -- nothing launched -- when the launch would not be resident as a whole or the policy does not fit (collect in lockstep then)."""
+        assert obs.is_contiguous() and actions.is_contiguous() and logp.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+        assert obs.shape[0] >= T_cap + 1 and actions.dtype == torch.int32 and done.dtype == torch.int32 and steps.dtype == torch.int32 and steps.numel() >= self.n_envs
+        rc = self.lib.rlgpu_collect_free(self.h, ppo.h, T_cap, C.c_int64(int(target_agent_steps)), obs.data_ptr(), actions.data_ptr(), logp.data_ptr(), reward.data_ptr(),
+                                         done.data_ptr(), steps.data_ptr(), 1 if deterministic else 0)
+        if rc == -3:   # RLGPU_ERR_STATE
+            return False
+        _chk(rc, self.h, self.lib.rlgpu_env_last_error)
+        return True
+
     def reseed(self, seed_lo: int, seed_hi: int):
         _chk(self.lib.rlgpu_env_reseed(self.h, C.c_uint32(seed_lo & 0xffffffff), C.c_uint32(seed_hi & 0xffffffff)), self.h, self.lib.rlgpu_env_last_error)
 

@@ -48,6 +48,30 @@ __global__ void k_sum(const float* a, size_t n, float* out) {
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// ---- iterations whose trajectories have their own lengths (free-running collection) ----
+__global__ void k_fill_i32(int32_t* p, int n, int32_t v) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_done_f(const int32_t* done, size_t n, float* done_f) { size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) done_f[i] = done[i] ? 1.f : 0.f; }
+// every player's current observation = the row after ITS OWN last step becomes row block 0 of the next launch
+__global__ void k_carry_obs(float* obs, const int32_t* steps, int players, int nAgents, int D) {
+    const int a = blockIdx.x;
+    const size_t src = ((size_t)steps[a / players] * nAgents + a) * D, dst = (size_t)a * D;
+    if (src != dst) for (int i = threadIdx.x; i < D; i += blockDim.x) obs[dst + i] = obs[src + i];
+}
+// out[0..2] += sum |ret|, |adv|, |tgt|, out[3] += sum rew over the rows that exist: t < steps[a / players]
+__global__ void k_ragged_sums(const float* ret, const float* adv, const float* tgt, const float* rew, const int32_t* steps, int players, int Tused, int n, float* out) {
+    float s[4] = {0, 0, 0, 0};
+    const size_t total = (size_t)Tused * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / n), a = (int)(i % n);
+        if (t < steps[a / players]) { s[0] += fabsf(ret[i]); s[1] += fabsf(adv[i]); s[2] += fabsf(tgt[i]); s[3] += rew[i]; }
+    }
+    for (int k = 0; k < 4; k++) {
+        float v = s[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v);
+    }
+}
+
 std::filesystem::path g_mesh_folder;
 
 template <class T>
@@ -92,6 +116,33 @@ struct Learner::Impl {
     rlgpu_expbuf* fifo = nullptr;
     float *exObs = nullptr, *exLogp = nullptr, *exAdv = nullptr, *exTgt = nullptr; int32_t* exActs = nullptr;
     bool first = true, renderOnly = false, fusedCollect = true;
+    // free-running collection (LearnerConfig::lockstepCollection = false; rlgpu_collect_free): buffers and FIFO slots are laid out for Tcap steps,
+    // steps[e] = what env e made in the last launch (== T after a lockstep launch), trajOff[slot] = where each trajectory of the iteration in
+    // that FIFO slot starts in the concatenated batch
+    bool ragged = false, freeOk = true, lastFree = false; int Tcap = 0, Tused = 0; int64_t lastRows = 0;
+    int32_t *steps = nullptr, *trajOff = nullptr, *permDev = nullptr;
+    std::vector<int32_t> hSteps, hAgentSteps, perm[2]; int permFlip = 0;
+    std::future<int64_t> permDraw; bool permPending = false; std::string permEngine;   // a permutation drawn ahead for a predicted FIFO size + the engine before it
+    void StartPermDraw(int64_t size) {
+        char buf[256];
+        if (rlgpu_shuffler_get_state(shuf, buf, sizeof(buf)) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: shuffler state");
+        permEngine = buf;
+        int32_t* out = perm[permFlip].data();
+        permDraw = std::async(std::launch::async, [this, out, size]() -> int64_t { return rlgpu_shuffler_next_i32(shuf, size, out) == RLGPU_OK ? size : -1; });
+        permPending = true;
+    }
+    // the permutation of [0, size): the one drawn ahead when it was drawn for this size, else the engine goes back and draws again
+    const int32_t* TakePerm(int64_t size) {
+        if (permPending) {
+            permPending = false;
+            const int64_t got = permDraw.get();
+            if (got < 0) RG_ERR_CLOSE("ExperienceBuffer: shuffle failed");
+            if (got == size) { const int32_t* r = perm[permFlip].data(); permFlip ^= 1; return r; }
+            if (rlgpu_shuffler_set_state(shuf, permEngine.c_str()) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: shuffler state");
+        }
+        if (rlgpu_shuffler_next_i32(shuf, size, perm[permFlip].data()) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: shuffle failed");
+        const int32_t* r = perm[permFlip].data(); permFlip ^= 1; return r;
+    }
     Timer renderTimer;
     uint64_t cumulativeModelUpdates = 0, tsSinceSave = 0;
     // collectionDuringLearn (LearnerConfig.h:46-50, Learner.cpp:473-510): the PPO epochs of iteration k run on their own stream while iteration
@@ -233,10 +284,23 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.retShare = dev_alloc<float>((size_t)std::max(1, config.maxReturnsPerStatsInc));
     rlgpu_shuffler_create(&m.shuf, (uint32_t)config.randomSeed);
 
-    const size_t TN = (size_t)m.T * m.nAgents;
-    m.obs = dev_alloc<float>((size_t)(m.T + 1) * m.nAgents * m.D);
+    // free-running collection is tried when nothing needs the host between steps and the games have both teams (the fused launch's row mapping);
+    // whether the batch is resident at once is known at the first launch (rlgpu_collect_free: RLGPU_ERR_STATE -> lockstep from then on)
+    m.ragged = !config.lockstepCollection && !m.renderOnly && !m.plan.AnyHost() && !config.renderMode && m.match->spawnOpponents && !config.deterministic;
+    m.Tcap = m.ragged ? 2 * m.T : m.T;
+    const size_t TN = (size_t)m.Tcap * m.nAgents;
+    m.obs = dev_alloc<float>((size_t)(m.Tcap + 1) * m.nAgents * m.D);
     m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN);
-    if (rlgpu_expbuf_create(&m.fifo, config.expBufferSize, m.T, m.nAgents) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: bad expBufferSize " << config.expBufferSize);
+    m.steps = dev_alloc<int32_t>((size_t)m.nEnvs); m.hSteps.assign((size_t)m.nEnvs, m.T); m.hAgentSteps.assign((size_t)m.nAgents, m.T);
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
+    m.Tused = m.T; m.lastRows = m.B;
+    if (m.ragged) {
+        if (rlgpu_expbuf_create_ragged(&m.fifo, config.expBufferSize, m.Tcap, m.nAgents, m.B) != RLGPU_OK) {
+            RG_LOG("\tfree-running collection: expBufferSize " << config.expBufferSize << " would keep more than 15 iterations resident -> lockstep collection");
+            m.ragged = false; m.Tcap = m.T;
+        }
+    }
+    if (!m.ragged && rlgpu_expbuf_create(&m.fifo, config.expBufferSize, m.T, m.nAgents) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: bad expBufferSize " << config.expBufferSize);
     ppo = new PPOLearner(); ppo->device = m.lrn;
     agentMgr = new ThreadAgentManager(); agentMgr->device = m.env; agentMgr->numGames = m.nEnvs;
     expBuffer = new ExperienceBuffer(); expBuffer->device = m.fifo;
@@ -247,6 +311,10 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.adv = dev_alloc<float>(TN); m.tgt = dev_alloc<float>(TN); m.ret = dev_alloc<float>(TN);
     m.vals = dev_alloc<float>(TN + m.nAgents); m.metrics = dev_alloc<float>(8); m.scratch = dev_alloc<float>(8);
     m.phys[0].resize(EX); m.phys[1].resize(EX);
+    if (m.ragged) {
+        m.trajOff = dev_alloc<int32_t>((size_t)rlgpu_expbuf_num_slots(m.fifo) * (m.nAgents + 1)); m.permDev = dev_alloc<int32_t>(EX);
+        m.perm[0].resize(EX); m.perm[1].resize(EX);
+    }
     if (!m.plan.hostObs) m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
     if (m.plan.AnyHost()) {
         std::vector<int32_t> all(m.nEnvs); std::iota(all.begin(), all.end(), 0);
@@ -283,6 +351,8 @@ Learner::~Learner() {
     if (m.learnPending) (void)hipEventSynchronize(m.evLearnDone);
     if (m.learnStream) { (void)hipStreamDestroy(m.learnStream); (void)hipEventDestroy(m.evReady); (void)hipEventDestroy(m.evLearnDone); }
     if (m.drawPending) m.nextDraw.wait();
+    if (m.permPending) m.permDraw.wait();
+    for (void* p : {(void*)m.steps, (void*)m.trajOff, (void*)m.permDev}) if (p) (void)hipFree(p);
     delete skillTracker; delete metricSender; delete renderSender;
     delete ppo; delete agentMgr; delete expBuffer;
     if (m.fifo) rlgpu_expbuf_destroy(m.fifo);
@@ -309,13 +379,17 @@ uint32_t Learner::SamplerCalls() const {
 }
 void Learner::CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones) {
     Impl& m = *impl;
-    const size_t TN = (size_t)m.T * m.nAgents;
+    const size_t TN = (size_t)m.Tcap * m.nAgents;
     HOST_HIP(hipDeviceSynchronize());
-    if (obs) { obs->resize((size_t)(m.T + 1) * m.nAgents * m.D); HOST_HIP(hipMemcpy(obs->data(), m.obs, obs->size() * 4, hipMemcpyDeviceToHost)); }
+    if (obs) { obs->resize((size_t)(m.Tcap + 1) * m.nAgents * m.D); HOST_HIP(hipMemcpy(obs->data(), m.obs, obs->size() * 4, hipMemcpyDeviceToHost)); }
     if (actions) { actions->resize(TN); HOST_HIP(hipMemcpy(actions->data(), m.acts, TN * 4, hipMemcpyDeviceToHost)); }
     if (rewards) { rewards->resize(TN); HOST_HIP(hipMemcpy(rewards->data(), m.rew, TN * 4, hipMemcpyDeviceToHost)); }
     if (dones) { dones->resize(TN); HOST_HIP(hipMemcpy(dones->data(), m.done, TN * 4, hipMemcpyDeviceToHost)); }
 }
+int Learner::StepCapacity() const { return impl->Tcap; }
+std::vector<int32_t> Learner::CollectedSteps() const { return impl->hSteps; }
+bool Learner::UsesFreeRunningCollection() const { return impl->lastFree; }
+uint64_t Learner::LastIterationTimesteps() const { return (uint64_t)impl->lastRows; }
 int Learner::Rank() const { return impl->rank; }
 int Learner::WorldSize() const { return impl->world; }
 std::vector<double> Learner::GatherOverRanks(double v) {
@@ -494,7 +568,11 @@ void Learner::Impl::HostStep(Learner* self, int t) {
 void Learner::CollectTimesteps() {
     Impl& m = *impl;
     const size_t rowObs = (size_t)m.nAgents * m.D;
-    if (!m.first) HOST_HIP(hipMemcpyAsync(m.ObsAt(0), m.ObsAt(m.T), rowObs * 4, hipMemcpyDeviceToDevice, nullptr));
+    if (!m.first) {
+        // the observation every player acts on next = the row after its own last step
+        if (m.ragged) hipLaunchKernelGGL(k_carry_obs, dim3((unsigned)m.nAgents), dim3(64), 0, nullptr, m.obs, (const int32_t*)m.steps, m.nPlayers, m.nAgents, m.D);
+        else HOST_HIP(hipMemcpyAsync(m.ObsAt(0), m.ObsAt(m.T), rowObs * 4, hipMemcpyDeviceToDevice, nullptr));
+    }
     m.first = false;
     const bool slow = (bool)stepCallback || m.plan.AnyHost();
     if (slow && !m.hostReady) {   // a step callback was installed after construction
@@ -502,10 +580,35 @@ void Learner::CollectTimesteps() {
         m.EnvCheck(rlgpu_env_download_states(m.env, m.snaps.data(), nullptr, m.nEnvs), "download_states");
         for (int e = 0; e < m.nEnvs; e++) m.prevGs[e] = RLGSC::GameState(m.snaps[e], m.tickSkip);
     }
-    // no per-step host work: the whole phase in one launch (rlgpu_collect), when the policy fits the in-kernel inference
+    auto lockstepDone = [&]() {   // every game made T steps
+        if (m.ragged) hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
+        std::fill(m.hSteps.begin(), m.hSteps.end(), m.T); std::fill(m.hAgentSteps.begin(), m.hAgentSteps.end(), m.T);
+        m.Tused = m.T; m.lastRows = m.B; m.lastFree = false;
+        totalTimesteps += (uint64_t)m.B * (uint64_t)m.world;
+    };
+    // no per-step host work: the whole phase in one launch (rlgpu_collect / rlgpu_collect_free), when the policy fits the in-kernel inference
     if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= FusedMaxTeam()) {
+        if (m.ragged && m.freeOk) {
+            // the agents run free until the batch has its timesteps together (ThreadAgentManager.cpp:16-32)
+            int rc = rlgpu_collect_free(m.env, m.lrn, m.Tcap, m.B, m.obs, m.acts, m.logp, m.rew, m.done, m.steps, config.deterministic ? 1 : 0);
+            if (rc == RLGPU_OK) {
+                HOST_HIP(hipMemcpy(m.hSteps.data(), m.steps, (size_t)m.nEnvs * 4, hipMemcpyDeviceToHost));   // (waits for the launch)
+                int64_t rows = 0; int tmax = 0;
+                for (int e = 0; e < m.nEnvs; e++) {
+                    const int32_t st = m.hSteps[(size_t)e];
+                    rows += (int64_t)st * m.nPlayers; tmax = std::max(tmax, (int)st);
+                    for (int k = 0; k < m.nPlayers; k++) m.hAgentSteps[(size_t)e * m.nPlayers + k] = st;
+                }
+                m.Tused = tmax; m.lastRows = rows; m.lastFree = true;
+                totalTimesteps += (uint64_t)rows * (uint64_t)m.world;   // (the other ranks' counts differ by less than one step of every game; rank 0's stands for each)
+                return;
+            }
+            if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect_free");
+            m.freeOk = false;   // the batch is not resident at once (or the policy does not fit the kernel): lockstep launches from now on
+            if (m.rank == 0 && !std::getenv("RLGPU_QUIET")) RG_LOG("Learner: " << rlgpu_env_last_error(m.env) << " -> lockstep collection");
+        }
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
-        if (rc == RLGPU_OK) { totalTimesteps += (uint64_t)m.B * (uint64_t)m.world; return; }
+        if (rc == RLGPU_OK) { lockstepDone(); return; }
         if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");
         m.fusedCollect = false;   // fp32 mode or a net too wide for the kernel's LDS scratch: alternate act / step
     }
@@ -516,7 +619,7 @@ void Learner::CollectTimesteps() {
         else m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
         if (renderSender) RenderStep(t);
     }
-    totalTimesteps += (uint64_t)m.B * (uint64_t)m.world;
+    lockstepDone();
 }
 
 // ThreadAgent.cpp:164-186: the first game's state goes to the renderer after every step, paced to renderTimeScale x real time
@@ -540,8 +643,60 @@ std::vector<Report> Learner::GetAllGameMetrics() {
     return out;
 }
 
+// Learner.cpp:608-703 for an iteration whose trajectories have their own lengths (steps[e] rows for the players of game e, laid out time-major
+// with Tcap rows of room): the batch is the concatenation of the trajectories, as ThreadAgentManager::CollectTimesteps hands it over
+void Learner::AddNewExperienceRagged(Report& report) {
+    Impl& m = *impl;
+    const size_t TU = (size_t)m.Tused * m.nAgents, rows = TU + m.nAgents, slotRows = (size_t)m.Tcap * m.nAgents;
+    const int64_t R = m.lastRows;
+    for (size_t s = 0; s < rows; s += m.maxRows) {   // value predictions of every state incl. the one after each trajectory's last step (rows beyond a trajectory are not used)
+        int n = (int)std::min<size_t>(m.maxRows, rows - s);
+        m.LrnCheck(rlgpu_value_forward(m.lrn, m.obs + s * m.D, n, m.vals + s), "value_forward");
+    }
+    const float retStd = config.standardizeReturns ? (float)returnStats.GetSTD() : 1.f;   // read BEFORE this batch updates it (Learner.cpp:651)
+    if (TU) hipLaunchKernelGGL(k_done_f, dim3((unsigned)((TU + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)m.done, TU, m.doneF);
+    // truncation marks: the last step of every trajectory unless done (ThreadAgentManager.cpp:55) -- applied by the kernel
+    m.LrnCheck(rlgpu_gae_ragged(m.lrn, m.rew, m.doneF, nullptr, m.vals, m.nAgents, m.steps, m.nPlayers, config.gaeGamma, config.gaeLambda, retStd, config.rewardClipRange,
+                                config.gaeNextValueMode, m.adv, m.tgt, m.ret), "gae_ragged");
+    if (config.standardizeReturns) {   // the first <= maxReturnsPerStatsInc returns of the concatenated batch (Learner.cpp:679-682): trajectory 0's, then trajectory 1's, ...
+        const int k = (int)std::min<int64_t>(config.maxReturnsPerStatsInc, R);
+        for (int j = 0, done_k = 0; done_k < k && j < m.nAgents; j++) {
+            const int cnt = std::min((int)m.hAgentSteps[(size_t)j], k - done_k);
+            if (cnt > 0) HOST_HIP(hipMemcpy2DAsync(m.retShare + done_k, 4, m.ret + j, (size_t)m.nAgents * 4, 4, cnt, hipMemcpyDeviceToDevice, nullptr));
+            done_k += cnt;
+        }
+        if (m.comm && rlgpu_comm_broadcast(m.comm, m.retShare, (int64_t)k * 4, 0, nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_broadcast: " << rlgpu_comm_last_error(m.comm));
+        FList first(k);
+        HOST_HIP(hipMemcpy(first.data(), m.retShare, (size_t)k * 4, hipMemcpyDeviceToHost));
+        returnStats.Increment(first, k);
+    }
+    HOST_HIP(hipMemsetAsync(m.scratch, 0, 32, nullptr));
+    hipLaunchKernelGGL(k_ragged_sums, dim3(256), dim3(256), 0, nullptr, (const float*)m.ret, (const float*)m.adv, (const float*)m.tgt, (const float*)m.rew, (const int32_t*)m.steps,
+                       m.nPlayers, m.Tused, m.nAgents, m.scratch);
+    float h[4];
+    HOST_HIP(hipMemcpy(h, m.scratch, 16, hipMemcpyDeviceToHost));
+    const float inv = 1.f / (float)std::max<int64_t>(R, 1);
+    report["Avg Return"] = h[0] * inv / retStd; report["Avg Advantage"] = h[1] * inv; report["Avg Val Target"] = h[2] * inv;
+    report["Average Step Reward"] = h[3] * inv;
+    // ExperienceBuffer::SubmitExperience (Learner.cpp:694-702).  On a multi-GPU run only the batch's last B rows join, so that every rank's FIFO
+    // holds the same number of rows and the ranks make the same number of optimizer steps (one all-reduce each)
+    int slot = -1;
+    if (rlgpu_expbuf_submit_ragged(m.fifo, m.hAgentSteps.data(), m.world > 1 ? m.B : 0, &slot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");
+    if (m.learnPending) HOST_HIP(hipStreamWaitEvent(nullptr, m.evLearnDone, 0));   // collectionDuringLearn: the epochs still running read the slot this may overwrite
+    if (rlgpu_traj_offsets(m.steps, m.nAgents, m.nPlayers, m.trajOff + (size_t)slot * (m.nAgents + 1), nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_traj_offsets failed");
+    const size_t o = (size_t)slot * slotRows;
+    if (TU) {
+        HOST_HIP(hipMemcpyAsync(m.exObs + o * m.D, m.obs, TU * m.D * 4, hipMemcpyDeviceToDevice, nullptr));
+        HOST_HIP(hipMemcpyAsync(m.exActs + o, m.acts, TU * 4, hipMemcpyDeviceToDevice, nullptr));
+        HOST_HIP(hipMemcpyAsync(m.exLogp + o, m.logp, TU * 4, hipMemcpyDeviceToDevice, nullptr));
+        HOST_HIP(hipMemcpyAsync(m.exAdv + o, m.adv, TU * 4, hipMemcpyDeviceToDevice, nullptr));
+        HOST_HIP(hipMemcpyAsync(m.exTgt + o, m.tgt, TU * 4, hipMemcpyDeviceToDevice, nullptr));
+    }
+}
+
 void Learner::AddNewExperience(Report& report) {
     Impl& m = *impl;
+    if (m.ragged) { AddNewExperienceRagged(report); return; }
     const size_t TN = (size_t)m.T * m.nAgents, rows = TN + m.nAgents;
     for (size_t s = 0; s < rows; s += m.maxRows) {   // minibatched value predictions, incl. the states after the last step (Learner.cpp:619-640)
         int n = (int)std::min<size_t>(m.maxRows, rows - s);
@@ -601,11 +756,24 @@ void Learner::LearnPPO(Report& report) {
     for (int ep = 0; ep < config.ppo.epochs; ep++) {
         // ExperienceBuffer::GetAllBatchesShuffled (ExperienceBuffer.cpp:104-126) over the whole FIFO: logical rows are oldest iteration
         // first and agent-major inside one (trajectory after trajectory); the device slots are time-major
-        const int64_t cur = m.TakeDraw();
+        int64_t cur;
+        if (m.ragged) {
+            // the permutation depends on the FIFO's SIZE only: it was drawn (by a worker, beside the GPU's work) for the size expected; the rows it
+            // stands for depend on this iteration's trajectory lengths and are looked up on the device
+            cur = rlgpu_expbuf_size(m.fifo);
+            const int32_t* perm = m.TakePerm(cur);
+            HOST_HIP(hipMemcpyAsync(m.permDev, perm, (size_t)cur * 4, hipMemcpyHostToDevice, ls));   // pageable source: staged before the call returns
+            if (rlgpu_expbuf_map_rows_dev(m.fifo, m.permDev, cur, m.trajOff, m.idx, (void*)ls) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: row mapping failed");
+            // next: this FIFO again (another epoch), or the FIFO after the next iteration joined (as many rows as this one brought, or the buffer full)
+            const int64_t add = m.world > 1 ? std::min<int64_t>(m.lastRows, m.B) : m.lastRows;
+            m.StartPermDraw(ep == config.ppo.epochs - 1 ? std::min<int64_t>(cur + std::min<int64_t>(add, config.expBufferSize), config.expBufferSize) : cur);
+        } else {
+        cur = m.TakeDraw();
         HOST_HIP(hipMemcpyAsync(m.idx, m.phys[m.physFlip].data(), (size_t)cur * 4, hipMemcpyHostToDevice, ls));   // pageable source: staged before the call returns
         m.physFlip ^= 1;
         if (ep == config.ppo.epochs - 1 && rlgpu_expbuf_submit(m.fifo, &m.pendingSlot) != RLGPU_OK) RG_ERR_CLOSE("ExperienceBuffer: no free slot");   // the next draw sees the FIFO after the next submit
         m.StartDraw();
+        }
         for (int64_t b = 0; b + m.batch <= cur; b += m.batch) {   // the remainder is dropped (ExperienceBuffer.cpp:115-117)
             m.LrnCheck(rlgpu_zero_grads(m.lrn), "zero_grads");
             for (int64_t k = 0; k < m.batch; k += m.mini) {
@@ -660,7 +828,7 @@ void Learner::FinishLearn(Report& report) {
 void Learner::Learn() {
     Impl& m = *impl;
     RG_LOG("Learner: " << m.nEnvs << " envs (" << m.nAgents << " agents), obs " << m.D << ", actions " << m.A << ", " << m.T << " steps/env/iteration = "
-           << m.B << " timesteps, batch " << m.batch << ", minibatch " << m.mini);
+           << m.B << " timesteps" << (m.ragged ? " (free-running collection: every game at its own pace until the batch has them)" : "") << ", batch " << m.batch << ", minibatch " << m.mini);
     while (config.timestepLimit == 0 || totalTimesteps < config.timestepLimit) {
         if (m.renderOnly) { CollectTimesteps(); continue; }   // render mode: play the (loaded) policy forever, one step per "iteration"
         Report report;
@@ -682,18 +850,18 @@ void Learner::Learn() {
         if (skillTracker) {   // Learner.cpp:527-538
             RG_LOG("Running skill eval game(s)...");
             if (config.skillTrackerConfig.stepCallback == NULL) skillTracker->config.stepCallback = stepCallback;
-            skillTracker->RunGames((int64_t)m.B);
+            skillTracker->RunGames((int64_t)m.lastRows);
             for (auto& pair : skillTracker->curRating.data) report[std::string("Skill Rating") + (pair.first.empty() ? "" : " ") + pair.first] = pair.second;
         }
         totalIterations++;
         report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
-        report["Timesteps Collected"] = (double)m.B;
+        report["Timesteps Collected"] = (double)m.lastRows;
         report["Collection Time"] = collectTime; report["Consumption Time"] = consumeTime; report["Total Iteration Time"] = tAll.Elapsed();
-        report["Collected Steps/Second"] = (double)m.B * m.world / std::max(collectTime, 1e-9);
-        report["Overall Steps/Second"] = (double)m.B * m.world / std::max(tAll.Elapsed(), 1e-9);
+        report["Collected Steps/Second"] = (double)m.lastRows * m.world / std::max(collectTime, 1e-9);
+        report["Overall Steps/Second"] = (double)m.lastRows * m.world / std::max(tAll.Elapsed(), 1e-9);
         if (iterationCallback) iterationCallback(this, report);
         if (config.sendMetrics && metricSender) metricSender->Send(report);                                                                       // Learner.cpp:589-590
-        if (m.rank != 0 || std::getenv("RLGPU_QUIET")) { m.tsSinceSave += (uint64_t)m.B * (uint64_t)m.world; if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save(); continue; }
+        if (m.rank != 0 || std::getenv("RLGPU_QUIET")) { m.tsSinceSave += (uint64_t)m.lastRows * (uint64_t)m.world; if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save(); continue; }
         RG_LOG(std::string(8, '\n') << std::string(20, '=') << " ITERATION COMPLETED " << std::string(20, '='));
         const std::vector<std::string> rows = {"Average Step Reward", "Policy Entropy", "Value Function Loss", "", "Mean KL Divergence", "SB3 Clip Fraction", "Avg Return",
                         "Avg Advantage", "Avg Val Target", "", "Collected Steps/Second", "Overall Steps/Second", "", "Collection Time", "Consumption Time",
@@ -704,7 +872,7 @@ void Learner::Learn() {
             std::string dashed = "-" + kv.first;
             if (std::find(rows.begin(), rows.end(), kv.first) == rows.end() && std::find(rows.begin(), rows.end(), dashed) == rows.end()) RG_LOG("  [metric] " << report.SingleToString(kv.first));
         }
-        m.tsSinceSave += (uint64_t)m.B * (uint64_t)m.world;
+        m.tsSinceSave += (uint64_t)m.lastRows * (uint64_t)m.world;
         if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
     }
     if (m.learnPending) { Report last; FinishLearn(last); }

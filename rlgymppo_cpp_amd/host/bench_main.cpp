@@ -46,16 +46,16 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
     return { match, gym };
 }
 
-struct Timed { double stepReward = 0, entropy = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
+struct Timed { double stepReward = 0, entropy = 0; double agentSteps = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, overlap = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, overlap = false, lockstep = false;
     std::string meshDir = "./collision_meshes";
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
         else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
-        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true;
+        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true; else if (is("--lockstep")) lockstep = true;
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
         else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
         else if (is("--mesh-dir")) meshDir = argv[++i];
@@ -72,6 +72,7 @@ int main(int argc, char* argv[]) {
     cfg.ppo.policyLayerSizes = { 256, 256, 256 }; cfg.ppo.criticLayerSizes = { 256, 256, 256 };
     cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
     cfg.timestepLimit = 0;
+    cfg.lockstepCollection = lockstep;     // default: the reference's free-running agents (every game at its own pace until the batch is full)
     cfg.collectionDuringLearn = overlap;   // not the headline: the reference's default pauses collection while it learns
     Learner learner(EnvCreateFunc, cfg);
     const int rank = learner.Rank(), world = learner.WorldSize();
@@ -96,8 +97,10 @@ int main(int argc, char* argv[]) {
         learner.DeviceTimings(a, b, c, d, e, true);
         learner.AllReduceTimings(a, b, true);
         auto t0 = std::chrono::steady_clock::now();
+        const uint64_t ts0 = learner.totalTimesteps;
         for (int i = 0; i < k; i++) iteration(&t.consumeMs);
         barrier();
+        t.agentSteps = (double)(learner.totalTimesteps - ts0);   // what the iterations really gathered, all ranks (a free-running iteration holds B .. B + one step of every game)
         t.rankSec = learner.GatherOverRanks(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());   // every rank's own clock
         t.sec = *std::max_element(t.rankSec.begin(), t.rankSec.end());                                                        // the slowest rank's
         learner.AllReduceTimings(t.arMs, t.arCalls, false);
@@ -122,13 +125,14 @@ int main(int argc, char* argv[]) {
         // SURVEY 8d, verbatim: algorithmic bytes per gym step per env = 2 (336 N_p + 264) + N_p (4 D + 8) + 4
         const double A = 2.0 * (336.0 * nP + 264.0) + nP * (4.0 * D + 8.0) + 4.0;
         const bool fused = learner.UsesFusedCollection();
-        const double stepsPerLaunch = fused ? horizon : 1;
+        // gym steps of every env per collection launch, on average (free-running: what the launches really made)
+        const double stepsPerLaunch = fused ? (m.envLaunches ? m.agentSteps / world / (double)nAgents / m.envLaunches : horizon) : 1;
         printf("{\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"envs_per_gpu\": %d, \"team_size\": %d, \"horizon\": %d, \"batch\": %lld, \"minibatch\": %lld, \"epochs\": %d, \"obs_size\": %d, "
-               "\"elapsed_s\": %.6f, \"agent_steps\": %.0f, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"fused_collect\": %s, "
+               "\"elapsed_s\": %.6f, \"agent_steps\": %.0f, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"fused_collect\": %s, \"collection\": \"%s\", "
                "\"env_kernel_ms_total\": %.4f, \"env_launches\": %d, \"algorithmic_bytes_per_gym_step_per_env\": %.0f, \"gym_steps_per_launch\": %.0f, "
                "\"gemm_ms_total\": %.4f, \"gemm_flops_total\": %.6e, \"gemm_calls\": %d",
                world, steps, warmup, envs, g_team, horizon, (long long)B, (long long)(B / 4), epochs, D,
-               m.sec, (double)B * world * steps, (double)B * world * steps / m.sec, m.sec / steps * 1e3, m.consumeMs, fused ? "true" : "false",
+               m.sec, m.agentSteps, m.agentSteps / m.sec, m.sec / steps * 1e3, m.consumeMs, fused ? "true" : "false", learner.UsesFreeRunningCollection() ? "free-running" : "lockstep",
                m.envMs, m.envLaunches, A, stepsPerLaunch, m.gemmMs, m.gemmFlops, m.gemmCalls);
         // multi-GPU audit trail: how many RCCL ranks took part, every rank's own ms per iteration, and (rank 0) what one gradient all-reduce costs
         printf(", \"rccl_ranks\": %d, \"rank_ms_per_step\": [", world > 1 ? world : 0);
@@ -136,11 +140,11 @@ int main(int argc, char* argv[]) {
         printf("], \"allreduce_calls\": %d, \"allreduce_ms_per_optimizer_step\": %.5f", m.arCalls, m.arCalls ? m.arMs / m.arCalls : 0.0);
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
-                   warmup + steps + trainedWarm, trainedSteps, (double)B * world * trainedSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);
+                   warmup + steps + trainedWarm, trainedSteps, tr.agentSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);
         if (haveLn)
             printf(", \"trained_regime_learned\": {\"after_iterations\": %d, \"learning_epochs\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f, "
                    "\"mean_step_reward\": %.5f, \"policy_entropy\": %.4f, \"mean_step_reward_fresh_policy\": %.5f, \"policy_entropy_fresh_policy\": %.4f}",
-                   warmup + steps + trainedWarm + trainedSteps + learnedWarm, learnedEpochs, learnedSteps, (double)B * world * learnedSteps / ln.sec, ln.sec / learnedSteps * 1e3, ln.consumeMs,
+                   warmup + steps + trainedWarm + trainedSteps + learnedWarm, learnedEpochs, learnedSteps, ln.agentSteps / ln.sec, ln.sec / learnedSteps * 1e3, ln.consumeMs,
                    ln.envLaunches ? ln.envMs / ln.envLaunches : 0.0, ln.stepReward, ln.entropy, m.stepReward, m.entropy);
         printf("}\n");
         fflush(stdout);

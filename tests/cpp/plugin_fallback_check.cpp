@@ -17,6 +17,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <cmath>
 
 using namespace RLGPC;
 using namespace RLGSC;
@@ -68,6 +70,7 @@ static LearnerConfig SmallConfig(int envs, int steps, int players) {
     cfg.ppo.policyLR = cfg.ppo.criticLR = 3e-4f;
     cfg.randomSeed = 77;
     cfg.sendMetrics = false; cfg.checkpointSaveFolder = ""; cfg.checkpointLoadFolder = "";
+    cfg.lockstepCollection = true;   // these checks compare paths row by row: every game makes the same number of steps
     return cfg;
 }
 
@@ -371,6 +374,60 @@ static int StandaloneGym() {
     return 0;
 }
 
+// Free-running collection (LearnerConfig::lockstepCollection = false, the default; ThreadAgentManager.cpp:16-82): every game steps at its own
+// pace until the batch has timestepsPerIteration together.  What a game's players experienced does not depend on the pace: its rows are the first
+// rows of a lockstep learner's with the same seed.  Then the iteration goes through AddNewExperience / LearnPPO with its ragged trajectories.
+static int FreeRunning() {
+    const int envs = 256, S = 12;
+    g_host = false; g_hostParser = false; g_teamSize = 1; g_spawnOpponents = true;
+    LearnerConfig lock = SmallConfig(envs, 2 * S, 2);
+    LearnerConfig free = SmallConfig(envs, S, 2); free.lockstepCollection = false;
+    Learner a(MakeBuiltinEnv, lock), b(MakeBuiltinEnv, free);
+    CHECK(b.StepCapacity() == 2 * S && a.StepsPerIteration() == 2 * S && b.StepsPerIteration() == S);
+    a.CollectTimesteps(); b.CollectTimesteps();
+    CHECK(b.UsesFreeRunningCollection() && !a.UsesFreeRunningCollection());
+    Collected ca, cb;
+    a.CopyCollected(&ca.obs, &ca.acts, &ca.rew, &ca.done); b.CopyCollected(&cb.obs, &cb.acts, &cb.rew, &cb.done);
+    const std::vector<int32_t> st = b.CollectedSteps();
+    const int N = b.NumAgents(), D = b.obsSize, P = 2;
+    int64_t rows = 0; int lo = 1 << 30, hi = 0;
+    for (int e = 0; e < envs; e++) { rows += (int64_t)st[e] * P; lo = std::min(lo, (int)st[e]); hi = std::max(hi, (int)st[e]); }
+    CHECK(rows == (int64_t)b.LastIterationTimesteps() && rows >= (int64_t)envs * P * S && rows < (int64_t)envs * P * (S + 1) + 1 && hi <= 2 * S);
+    size_t bad = 0;
+    for (int e = 0; e < envs; e++)
+        for (int t = 0; t < st[e]; t++)
+            for (int k = 0; k < P; k++) {
+                const size_t i = (size_t)t * N + (size_t)e * P + k;
+                if (ca.acts[i] != cb.acts[i] || ca.rew[i] != cb.rew[i] || ca.done[i] != cb.done[i]) bad++;
+                if (std::memcmp(&ca.obs[((size_t)(t + 1) * N + (size_t)e * P + k) * D], &cb.obs[((size_t)(t + 1) * N + (size_t)e * P + k) * D], (size_t)D * 4)) bad++;
+            }
+    std::printf("free-running collection: %d games made %d..%d steps (%lld agent-steps for a batch of %d), rows differing from the lockstep learner's: %zu\n", envs, lo, hi, (long long)rows, envs * P * S, bad);
+    CHECK(bad == 0);
+    // three whole iterations: the second starts from every game's OWN last observation
+    for (int it = 0; it < 3; it++) {
+        Report rep;
+        if (it) b.CollectTimesteps();
+        b.AddNewExperience(rep); b.LearnPPO(rep);
+        CHECK(rep.Has("Policy Entropy") && std::isfinite(rep["Policy Entropy"]) && std::isfinite(rep["Avg Return"]) && std::isfinite(rep["Value Function Loss"]));
+        CHECK((int64_t)b.LastIterationTimesteps() >= (int64_t)envs * P * S);
+    }
+    // ... and what the second launch read as its first observations is what the first wrote after each game's last step
+    {
+        Learner c(MakeBuiltinEnv, free);
+        c.CollectTimesteps();
+        Collected c1; c.CopyCollected(&c1.obs, nullptr, nullptr, nullptr);
+        const std::vector<int32_t> s1 = c.CollectedSteps();
+        c.CollectTimesteps();
+        Collected c2; c.CopyCollected(&c2.obs, nullptr, nullptr, nullptr);
+        size_t off = 0;
+        for (int e = 0; e < envs; e++)
+            for (int k = 0; k < P; k++)
+                if (std::memcmp(&c1.obs[((size_t)s1[e] * N + (size_t)e * P + k) * D], &c2.obs[((size_t)e * P + k) * D], (size_t)D * 4)) off++;
+        CHECK(off == 0);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     RocketSim::Init("./collision_meshes", true);
     setenv("RLGPU_QUIET", "1", 1);
@@ -382,6 +439,7 @@ int main(int argc, char** argv) {
         if (ComparePaths(1, true, false)) return 1;     // a single car
         if (UserPlugins()) return 1;
         if (CollectionDuringLearn()) return 1;
+        if (FreeRunning()) return 1;
         if (StandaloneGym()) return 1;
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
