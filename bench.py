@@ -5,11 +5,13 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is ONE full PPO iteration of the hot path at BASELINE config[1] (1v1, 4096 envs per GPU, MLP 256x3, bf16 MFMA):
-T = 32 gym steps of every env (on-device policy inference + batched arena stepper, tickSkip 8, example
-obs/reward/terminal stack, RandomState resets), value predictions, GAE, one epoch of PPO over the B = 8192*32 = 262 144
-collected agent-steps in 4 minibatches of 65 536 with one clip+Adam step (and one RCCL gradient all-reduce when N > 1).
-Nothing is skipped inside the timed region.  `value` = agent-steps / second over the whole job (the reference's
-"steps" unit, ThreadAgent.cpp:158); "PPO iter ms" (the consumption phase: values + GAE + learn) is reported next to it.
+timestepsPerIteration = B = 8192*32 = 262 144 agent-steps gathered by the 4096 envs (on-device policy inference + batched arena stepper,
+tickSkip 8, example obs/reward/terminal stack, RandomState resets) the way the reference's agent threads gather them -- every game at its
+own pace until the batch has them together (ThreadAgentManager.cpp:16-82; `collection: free-running`, on average 33 gym steps per env,
+B .. B + one step of every game per iteration; `--lockstep` makes every env take exactly T = 32 steps, reported as the `lockstep_collection`
+leg) --, value predictions, GAE, one epoch of PPO over B rows in 4 minibatches of 65 536 with one clip+Adam step (and one RCCL gradient
+all-reduce when N > 1).  Nothing is skipped inside the timed region.  `value` = agent-steps REALLY gathered / second over the whole job (the
+reference's "steps" unit, ThreadAgent.cpp:158); "PPO iter ms" (the consumption phase: values + GAE + learn) is reported next to it.
 
 The JSON line also carries the dominant kernel's roofline (the env step kernel: algorithmic bytes of SURVEY 8d over
 its hipEvent-measured duration) and a CPU baseline of the collection path measured on this host in the same run.
@@ -134,6 +136,7 @@ def main():
     ap.add_argument("--team-size", type=int, default=1, help="1 = BASELINE configs[1] (the headline); 2 / 3 with --padded-zero-sum = the shapes of configs[3] / [4]")
     ap.add_argument("--padded-zero-sum", action="store_true", help="DefaultOBSPadded(maxPlayers = team size) + ZeroSumReward around the example stack")
     ap.add_argument("--fp32", action="store_true", help="fp32 MFMA instead of bf16 operands")
+    ap.add_argument("--lockstep", action="store_true", help="every env takes exactly --horizon steps per iteration (LearnerConfig::lockstepCollection) instead of the reference's free-running agents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trained-warmup", type=int, default=480, help="after the timed region: this many more iterations, then --trained-steps timed ones (the policy has started to play: more contacts per tick); 0 = skip")
     ap.add_argument("--trained-steps", type=int, default=100)
@@ -166,6 +169,7 @@ def main():
            "--epochs", str(args.epochs)]
     if args.padded_zero_sum: cmd.append("--padded-zero-sum")
     if args.fp32: cmd.append("--fp32")
+    if args.lockstep: cmd.append("--lockstep")
     if args.trained_warmup > 0 and args.trained_steps > 0:
         cmd += ["--trained-warmup", str(args.trained_warmup), "--trained-steps", str(args.trained_steps)]
     if args.learned_warmup > 0 and args.learned_steps > 0 and world == 1:
@@ -189,7 +193,7 @@ def main():
     bytes_per_launch = A * args.envs * m["gym_steps_per_launch"]
     avg_ms = m["env_kernel_ms_total"] / max(1, m["env_launches"])
     gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    kname = (f"k_env_collect<{n_p}> ({args.horizon} x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)"
+    kname = (f"k_env_collect<{n_p}> ({m['gym_steps_per_launch']:.1f} x (policy inference + 8 ticks + snapshot/obs/reward/done/auto-reset) in one launch)"
              if m["fused_collect"] else f"k_env_step<{n_p}> (8 ticks + snapshot/obs/reward/done/auto-reset fused)")
     # (the fused launch keeps the arena state in LDS for all its gym steps: counted once per launch instead of once per step the same
     # launch moves `bytes_state_once` -- the 8d figure is the algorithmic upper bound the survey prescribes, this is what must cross HBM)
@@ -217,6 +221,9 @@ def main():
                                 if args.team_size == 1 and not args.padded_zero_sum else
                                 f"{args.team_size}v{args.team_size}, {args.envs} envs/GPU, tickSkip 8, " + ("DefaultOBSPadded + zero-sum example stack, " if args.padded_zero_sum else "DefaultObs + example stack, ") + "RandomState resets, ")
                                + f"T={args.horizon} steps/iter, B={m['batch']} agent-steps/GPU, minibatch {m['minibatch']}, epochs {args.epochs}, MLP 256x3 policy(90)+critic, procedural arena mesh",
+                   "collection": m.get("collection", "lockstep") + (" (every game at its own pace until the batch holds B agent-steps: ThreadAgentManager.cpp:16-82; %.2f gym steps per env and iteration)" % m["gym_steps_per_launch"]
+                                                                     if m.get("collection") == "free-running" else ""),
+                   "agent_steps_per_iter": m["agent_steps"] / max(1, args.steps) / max(1, m["n_gpus"]),
                    "envs_per_gpu": args.envs, "horizon": args.horizon, "batch": m["batch"], "minibatch": m["minibatch"], "epochs": args.epochs,
                    "host": "C++ (rlgymppo_cpp_amd/bench_main on librlgymppo_amd.so; no Python or torch in the measured process)"},
         "ppo_iter_ms": m["ppo_iter_ms"], "gym_steps_per_s": m["value"] / n_p, "physics_ticks_per_s": m["value"] / n_p * 8,
@@ -242,6 +249,17 @@ def main():
         cb = cpu_baseline(mesh_dir=mesh_dir if args.mesh == "tessellated" else None) if args.mesh != "tessellated" else tessellated_cpu_baseline(mesh_dir)
         if cb is not None:
             out["cpu_baseline"] = cb
+    if world == 1 and not args.lockstep and m.get("collection") == "free-running":
+        # the same measurement (shorter) with every env taking exactly T steps per iteration: what the launch's slowest wavefront costs
+        cmd3 = [exe, "--envs", str(args.envs), "--team-size", str(args.team_size), "--horizon", str(args.horizon), "--steps", str(max(20, args.steps // 4)), "--warmup", str(max(5, args.warmup // 2)),
+                "--epochs", str(args.epochs), "--lockstep"]
+        if args.padded_zero_sum: cmd3.append("--padded-zero-sum")
+        if args.fp32: cmd3.append("--fp32")
+        p3 = subprocess.run(cmd3, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+        if p3.returncode == 0:
+            m3 = json.loads(p3.stdout.decode().strip().splitlines()[-1])
+            out["lockstep_collection"] = {"value": m3["value"], "unit": "agent-steps/s", "ms_per_step": m3["ms_per_step"], "ppo_iter_ms": m3["ppo_iter_ms"], "steps": m3["steps"],
+                                          "env_kernel_avg_ms": m3["env_kernel_ms_total"] / max(1, m3["env_launches"]), "gym_steps_per_launch": m3["gym_steps_per_launch"]}
     if args.mesh == "both" and world == 1:
         # the same measurement (shorter) on the tessellated mesh, with its own CPU baseline: both sides load the same 16 files
         mesh_dir, mesh_info = make_tessellated_mesh_dir()

@@ -19,6 +19,7 @@
 #include <RLGymSim_CPP/Utils/OBSBuilders/DefaultOBSPadded.h>
 #include <RLGymSim_CPP/Utils/StateSetters/RandomState.h>
 #include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
+#include <RLGymPPO_CPP/Threading/GameInst.h>
 #include <RLGymSim_CPP/Utils/ActionParsers/DiscreteAction.h>
 
 #include <bullet3-3.24/BulletCollision/CollisionShapes/btTriangleShape.h>
@@ -678,6 +679,64 @@ extern "C" int ref_gym_player_order(void* h, int32_t* out) {
     for (auto& p : g->gym->prevState.players) out[n++] = (int32_t)p.carId;
     return n;
 }
+// ---- round 4: GameInst::Step across episode ends (PUB/Threading/GameInst.cpp:7-38, compiled unedited next to this file: oracle/Makefile) ----
+// A user state setter written against the reference's plugin surface: its k-th call installs the caller's k-th state (the last one again once
+// the list is used up).  With it an episode boundary -- gym->Reset() inside GameInst::Step, the observation the agent acts on next, the reward
+// trackers' roll-over -- is reproducible, which the reference's own setters (thread-local std RNG) are not.
+class ListStateSetter : public StateSetter {
+public:
+    const RlgpuArenaState* list = nullptr; int n = 0, calls = 0;
+    virtual GameState ResetState(Arena* arena) {
+        SetArenaPhys(arena, &list[calls < n ? calls : n - 1], false);
+        calls++;
+        return GameState(arena);
+    }
+};
+// Runs GameInst::Start() and n_steps x GameInst::Step(actions[t]) on one of the gyms above.  actions [n_steps][players] by SLOT.  Outputs by slot:
+// cur_obs_out [(n_steps + 1)][players][D] = GameInst::curObs after Start() and after every Step (the NEW episode's first observation when the step
+// ended one); step_obs_out [n_steps][players][D] = StepResult::obs (the same rows: GameInst overwrites them before it returns); rew_out [n_steps][players];
+// (both in the players' order AFTER the step -- order_out -- which is what the rows' "other players" blocks follow); done_out [n_steps]; trackers_out [n_steps][6] = curEpRew, avgEpRew.total, avgEpRew.count, avgStepRew.total, avgStepRew.count, totalSteps;
+// resets_out [n_steps + 1] = state-setter calls made so far.  Returns D.
+extern "C" int ref_gameinst_run(int team_size, int tick_skip, int obs_max_players, int reward_kind, int no_touch_steps, const RlgpuArenaState* states, int n_states,
+                                const int32_t* actions, int n_steps, float* cur_obs_out, float* step_obs_out, float* rew_out, int32_t* done_out, float* trackers_out, int32_t* resets_out,
+                                int32_t* order_out /* [(n_steps + 1)][players]: car ids - 1 in the order of the gym's current GameState::players */) {
+    RefGym* g = (RefGym*)ref_gym_new2(team_size, tick_skip, obs_max_players, reward_kind, no_touch_steps);
+    ListStateSetter* ls = new ListStateSetter(); ls->list = states; ls->n = n_states;
+    g->match->stateSetter = ls;
+    const int P = g->nPlayers;
+    int D = 0;
+    {
+        RLGPC::GameInst gi(g->gym, g->match);   // (owns and deletes the gym and the match, GameInst.h:53-56)
+        gi.Start();
+        D = (int)gi.curObs[0].size();
+        auto put_obs = [&](float* dst, const FList2& obs) {
+            const auto& pl = g->gym->prevState.players;
+            for (size_t i = 0; i < pl.size(); i++) memcpy(dst + ((int)pl[i].carId - 1) * D, obs[i].data(), (size_t)D * 4);
+        };
+        auto put_order = [&](int32_t* dst) { int n = 0; for (auto& p : g->gym->prevState.players) dst[n++] = (int32_t)p.carId - 1; };
+        put_obs(cur_obs_out, gi.curObs);
+        put_order(order_out);
+        resets_out[0] = ls->calls;
+        for (int t = 0; t < n_steps; t++) {
+            IList in(P);
+            int i = 0;
+            for (Car* c : g->gym->arena->_cars) in[i++] = actions[(size_t)t * P + (int)c->id - 1];
+            Gym::StepResult r = gi.Step(in);
+            // rewards belong to the players of the state the step was made in (r.state), the observations to the state the gym holds now
+            for (size_t k = 0; k < r.state.players.size(); k++) rew_out[(size_t)t * P + (int)r.state.players[k].carId - 1] = r.reward[k];
+            put_obs(step_obs_out + (size_t)t * P * D, r.obs);
+            put_obs(cur_obs_out + (size_t)(t + 1) * P * D, gi.curObs);
+            done_out[t] = r.done;
+            float* tr = trackers_out + (size_t)t * 6;
+            tr[0] = gi.curEpRew; tr[1] = gi.avgEpRew.total; tr[2] = (float)gi.avgEpRew.count; tr[3] = gi.avgStepRew.total; tr[4] = (float)gi.avgStepRew.count; tr[5] = (float)gi.totalSteps;
+            resets_out[t + 1] = ls->calls;
+            put_order(order_out + (size_t)(t + 1) * P);
+        }
+    }
+    delete ls; delete g;
+    return D;
+}
+
 // state setters: `n` arenas reset by the reference's own RandomState(ballRandSpeed, carRandSpeed, carsOnGround) (kind 0) or KickoffState (kind 1)
 extern "C" void ref_setter_samples(int team_size, int kind, int n, RlgpuArenaState* out) {
     Arena* a = Arena::Create(GameMode::SOCCAR);

@@ -76,7 +76,8 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     """GPU: two iterations of the example program (step + iteration callbacks, slow GameState path), a checkpoint, and a resume."""
     exe = os.path.join(PKG, "example_main")
     ck = str(tmp_path / "ck")
-    r = _run([exe, "2", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600)
+    lock = dict(os.environ, RLGPU_LOCKSTEP_COLLECTION="1")     # this test counts timesteps exactly: every game makes the same number of steps per iteration
+    r = _run([exe, "2", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=lock)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ITERATION COMPLETED") == 2 and "player_speed" in r.stdout and "Policy Entropy" in r.stdout
     first_run_out = r.stdout
@@ -98,7 +99,7 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     assert L.load() and L.total_timesteps == 2 * 4096
     # and the C++ host resumes from it
     # ... this time with the reference's step callback (every game's GameState on the host each step) instead of the device-side metrics
-    r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=dict(os.environ, EXAMPLE_STEP_CALLBACK="1"))
+    r = _run([exe, "1", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=dict(lock, EXAMPLE_STEP_CALLBACK="1"))
     assert r.returncode == 0 and "loaded checkpoint" in r.stdout and str(3 * 4096) in os.listdir(ck), r.stdout[-3000:]
     def metric(out, name):
         return float([l for l in out.splitlines() if l.strip().startswith("[metric] " + name)][-1].split(":")[-1].replace(",", ""))
@@ -122,7 +123,7 @@ def test_example_program_trains_and_checkpoints(tmp_path):
     rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
     rx.bind(("127.0.0.1", 9273))
     rx.settimeout(5)
-    r = _run([exe, "12", "4", "16", "4096", ck, "render"], cwd=str(tmp_path), timeout=600, env=dict(os.environ, RLGPU_RENDER_NO_SLEEP="1"))
+    r = _run([exe, "12", "4", "16", "4096", ck, "render"], cwd=str(tmp_path), timeout=600, env=dict(lock, RLGPU_RENDER_NO_SLEEP="1"))
     assert r.returncode == 0 and "Render mode is enabled" in r.stdout and "loaded checkpoint" in r.stdout, r.stdout[-3000:]
     grams = []
     for _ in range(12):
@@ -260,13 +261,33 @@ def test_skill_tracker_against_reference_recordings(tmp_path):
 
 
 @pytest.mark.gpu
+def test_example_program_default_collection_is_free_running(tmp_path):
+    """GPU: the example program as it comes (LearnerConfig::lockstepCollection = false): every game steps at its own pace until the batch has
+    timestepsPerIteration together (ThreadAgentManager.cpp:16-82), so an iteration holds between 4096 and 4096 + one step of each of the 64
+    games' two players; the run trains, reports and checkpoints under the exact count."""
+    import json
+    exe = os.path.join(PKG, "example_main")
+    ck = str(tmp_path / "ck")
+    r = _run([exe, "3", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "free-running collection" in r.stdout and r.stdout.count("ITERATION COMPLETED") == 3 and "Policy Entropy" in r.stdout
+    saved = sorted(int(d) for d in os.listdir(ck))
+    assert saved and 3 * 4096 <= saved[-1] <= 3 * (4096 + 128), saved
+    mdir = tmp_path / "metrics" / "rlgymppo-cpp"
+    recs = [json.loads(l) for l in open(mdir / os.listdir(mdir)[0])][1:]
+    ts = [int(x["Cumulative Timesteps"]) for x in recs]
+    assert len(ts) == 3 and all(4096 <= b - a <= 4096 + 128 for a, b in zip([0] + ts, ts)) and ts[-1] == saved[-1]
+    assert all(np.isfinite(x["Policy Entropy"]) and np.isfinite(x["Value Function Loss"]) for x in recs)
+
+
+@pytest.mark.gpu
 def test_example_program_with_skill_tracker(tmp_path):
     """GPU: ELO evaluation against stored versions while training; ratings land in the report, the metrics file and RUNNING_STATS.json;
     a resumed run rebuilds its old versions from the older checkpoints (Learner.cpp:311-370)."""
     import json
     exe = os.path.join(PKG, "example_main")
     ck = str(tmp_path / "ck")
-    env = dict(os.environ, EXAMPLE_SKILL_TRACKER="1")
+    env = dict(os.environ, EXAMPLE_SKILL_TRACKER="1", RLGPU_LOCKSTEP_COLLECTION="1")     # (checkpoint folders are named by exact timestep counts below)
     r = _run([exe, "3", "4", "16", "4096", ck], cwd=str(tmp_path), timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("Running skill eval game(s)...") == 3 and r.stdout.count("New ratings:") == 3 and "Skill Rating 1v1" in r.stdout
