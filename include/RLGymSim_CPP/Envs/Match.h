@@ -55,7 +55,8 @@ public:
             RG_ERR_CLOSE("Match::ResetState(): New state has a different amount of players, expected " << playerAmount << " but got " << fresh.players.size() << ".\n"
                          "Changing number of players at state reset is currently not supported.");
         for (BoostPad* pad : arena->_boostPads) pad->SetState({});
-        return GameState(arena);   // (the setter's return value predates the pad reset)
+        return fresh;   // Match.cpp:55-69: the setter's GameState -- it predates the pad reset, so the new episode's first state shows the pads as the
+                        // previous episode left them (unless the setter reset them itself, as KickoffState does through Arena::ResetToRandomKickoff)
     }
 
     // ---- device description ----
@@ -65,7 +66,7 @@ public:
         bool AnyHost() const { return hostReward || hostTerminal || hostObs || hostSetter || hostParser; }
     };
     // Which plugin kinds the step kernel runs and which stay on the host.  A kind on the host leaves a neutral device setting behind
-    // (no reward terms, no conditions, the kickoff setter; a host parser's controls reach the kernel as rows, rlgpu_env_step_controls).
+    // (no reward terms, no conditions, no reset inside the step; a host parser's controls reach the kernel as rows, rlgpu_env_step_controls).
     DevicePlan PlanDevice(int tickSkip) const {
         DevicePlan plan; RlgpuGymConfig& cfg = plan.cfg;
         rlgpu_default_gym_config(&cfg);
@@ -81,6 +82,9 @@ public:
         if (!obsBuilder->ApplyToDevice(cfg)) plan.hostObs = true;
         if (!actionParser->ApplyToDevice(cfg)) { cfg.n_actions = actionParser->GetActionAmount(); plan.hostParser = true; }   // parsed on the host, stepped with rlgpu_env_step_controls
         if (!stateSetter->ApplyToDevice(cfg)) { cfg.setter_kind = RLGPU_SS_KICKOFF; plan.hostSetter = true; }
+        // any plugin on the host: an env whose episode ended stays as it ended (the step kernel does not reset it) until the host has looked at it --
+        // the new episode's first GameState shows the boost pads of that moment (Match.cpp:55-69) -- and has run the setter / asked for the reset
+        if (plan.AnyHost()) cfg.host_resets = 1;
         return plan;
     }
     // the whole match as the device's gym configuration; throws when a plugin kind would have to run on the host

@@ -54,6 +54,10 @@ typedef struct RlgpuGymConfig {
                                                       * team_size <= m <= 4, row width 51 + 38 m */
     int32_t one_team;                                /* Match(..., spawnOpponents = false) (SIM/Envs/Match.h:40, Gym.cpp:45-49): team_size blue cars, no orange ones.
                                                       * Agents per env = team_size; the env's state keeps 2 * team_size slots, the odd ones flagged RLGPU_CF_ABSENT */
+    int32_t host_resets;                             /* 1: the state setter runs on the host (a user StateSetter: GameInst.cpp:27-32 -> Gym::Reset -> Match::ResetState).  A step that ends
+                                                      * an episode then leaves the env as the episode left it -- boost pads included, which the new episode's first GameState still
+                                                      * shows (Match.cpp:55-69) -- and writes no observation rows for it; the host downloads the state, runs the setter, uploads and calls
+                                                      * rlgpu_env_reset_envs(run_setter = 0).  0: the kernel resets the env itself with setter_kind */
 } RlgpuGymConfig;
 
 /* fills cfg with the examplemain.cpp:58-100 stack: 0.1 FaceBall + 0.5 VelPlayerToBall + 1.0 VelBallToGoal +

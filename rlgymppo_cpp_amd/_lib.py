@@ -31,7 +31,7 @@ class GymConfig(C.Structure):
         ("setter_kind", C.c_int32), ("rand_ball_speed", C.c_int32), ("rand_car_speed", C.c_int32), ("cars_on_ground", C.c_int32),
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
         ("pos_coef", C.c_float * 3), ("vel_coef", C.c_float), ("ang_vel_coef", C.c_float),
-        ("n_actions", C.c_int32), ("obs_max_players", C.c_int32), ("one_team", C.c_int32),
+        ("n_actions", C.c_int32), ("obs_max_players", C.c_int32), ("one_team", C.c_int32), ("host_resets", C.c_int32),
     ]
 
 

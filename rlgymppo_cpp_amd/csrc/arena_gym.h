@@ -35,6 +35,7 @@ struct GymConfig {
     int32_t n_actions;
     int32_t obs_max_players;   // 0 DefaultOBS, else DefaultOBSPadded(maxPlayers), team size <= maxPlayers <= 4: mates / opponents padded with zero blocks and shuffled
     int32_t one_team;          // Match(..., spawnOpponents = false): only the blue slots (even k) hold a car; see player_present()
+    int32_t host_resets;       // 1: a step that ends an episode leaves the env as the episode left it; the host runs its state setter and resets the env (rlgpu_env_reset_envs)
 };
 // key of the tick's random draws (the respawn spot of a demolished car): both seed words, so that a resumed run (rlgpu_env_reseed bumps
 // seed_hi, the epoch) does not replay the draws of the run it continues; seed_hi = 0 gives the key of the first epoch
@@ -85,6 +86,7 @@ struct Snapshot {
     float boost_frac[NC];
     bool on_ground[NC], has_flip[NC], demoed[NC], touched[NC];
     uint64_t pads_active;                               // bit i = obs-order pad i active
+    uint32_t car_order;                                 // Arena::car_order: GameState::players lists the cars in this order (the iteration order of Arena::_cars)
 };
 
 template <int NC>
@@ -104,6 +106,7 @@ RLG_HD_T6A void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S
     uint64_t m = 0;
     for (int i = 0; i < 34; i++) if (A.pads[pad_obs_to_rs(i)].is_active) m |= (1ull << i);
     S.pads_active = m;
+    S.car_order = A.car_order;
     if (fabsf(S.ball_pos.y) > K::GOAL_THRESHOLD_Y + K::BALL_RADIUS) {  // GameState.cpp:100-101, Math.cpp:3-5
         int team_from_y = S.ball_pos.y < 0 ? 0 : 1;
         G.score_line[1 - team_from_y]++;
@@ -325,8 +328,10 @@ RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymC
         }
     }
     if (cfg.zero_sum) {
+        // the team sums run over GameState::players (ZeroSumReward.cpp:9-13), i.e. in the arena's car order: with three players per team the
+        // order of a float sum shows in the last bit
         float avg[2] = {0.f, 0.f}; int cnt[2] = {0, 0};
-        for (int k = 0; k < NC; k++) if (player_present(cfg, k)) { cnt[k % 2]++; avg[k % 2] += rew[k]; }
+        for (int r = 0; r < NC; r++) { const int k = S.car_order ? (int)((S.car_order >> (4 * r)) & 15u) - 1 : r; if (player_present(cfg, k)) { cnt[k % 2]++; avg[k % 2] += rew[k]; } }
         for (int t = 0; t < 2; t++) avg[t] /= (float)(cnt[t] > 1 ? cnt[t] : 1);
         for (int k = 0; k < NC; k++) { if (!player_present(cfg, k)) continue; int t = k % 2; rew[k] = rew[k] * (1 - cfg.team_spirit) + (avg[t] * cfg.team_spirit) - (avg[1 - t] * cfg.opp_scale); }
     }
@@ -378,13 +383,20 @@ RLG_HD void car_set_fresh(Car& c) {  // Car::SetState(CarState()) semantics: car
     n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
     c = n;
 }
+// BoostPad::SetState(BoostPadState()) for every pad
+template <int NC>
+RLG_HD void reset_pads(Arena<NC>& A) {
+    for (int p = 0; p < 34; p++) { A.pads[p].cooldown = 0.f; A.pads[p].is_active = true; A.pads[p].prev_locked = 0; A.pads[p].cur_locked = 0; }
+}
 template <int NC>
 RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id) {
     Rng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
     G.reset_count++;
     A.ball.vel_impulse_cache = v3(0, 0, 0); A.ball_update_counter = 0;
-    for (int p = 0; p < 34; p++) { A.pads[p].cooldown = 0.f; A.pads[p].is_active = true; A.pads[p].prev_locked = 0; A.pads[p].cur_locked = 0; }
+    // (the boost pads: ResetToRandomKickoff resets them itself, Arena.cpp:209-210; RandomState leaves them alone -- Match::ResetState resets them
+    // AFTER the setter has built the new episode's first GameState, Match.cpp:55-69: reset_pads below, called once the snapshot is taken)
     if (cfg.setter_kind == SS_KICKOFF) {
+        reset_pads(A);
         // Arena::ResetToRandomKickoff (Arena.cpp:112-216)
         const float SX[5] = {-2048, 2048, -256, 256, 0}, SY[5] = {-2560, -2560, -3840, -3840, -4608};
         const float SYAW[5] = {PI_F / 4 * 1, PI_F / 4 * 3, PI_F / 4 * 2, PI_F / 4 * 2, PI_F / 4 * 2};
@@ -448,6 +460,10 @@ RLG_HD void gym_episode_reset(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg,
     G.score_line[0] = G.score_line[1] = 0; G.last_touch_car_id = -1; G.last_tick_count = 0;
     for (int k = 0; k < NC; k++) for (int q = 0; q < 8; q++) G.counters[k][q] = 0;
     take_snapshot(A, G, S);  // GameState(arena): lastTickCount was 0 -> tickSkip = tickCount
+    // Match::ResetState resets the pads only now (Match.cpp:55-69: `newState = stateSetter->ResetState(arena)` first, `pad->SetState({})` after):
+    // the new episode's first GameState -- and with it the first observation -- still shows the pads as the previous episode left them, unless
+    // the setter itself reset them (KickoffState through Arena::ResetToRandomKickoff)
+    reset_pads(A);
     G.no_touch_steps = 0;
     for (int k = 0; k < NC; k++) { G.prev_action_idx[k] = -1; event_values(S, G, k, G.event_last[k]); }
     G.tracker_flags &= ~(1u | 4u); G.shot_cooldown = 0.f;  // ResetPersistentInfo (GameEventTracker.cpp:160-165)
@@ -513,7 +529,7 @@ RLG_HD bool gym_step_after_first_tick(Arena<NC>& A, GymEnv<NC>& G, const GymConf
 template <int NC>
 RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* next_obs, size_t obs_row_stride, bool done, Snapshot<NC>& S) {
     G.episode_steps++;
-    if (done) {   // GameInst::Step: the recorded next observation is the first one of the new episode (GameInst.cpp:27-32)
+    if (done && !cfg.host_resets) {   // GameInst::Step: the recorded next observation is the first one of the new episode (GameInst.cpp:27-32)
         reset_state(A, G, cfg, env_id);
         gym_episode_reset(A, G, cfg, S);
         G.tracker_flags &= ~0xff00u;

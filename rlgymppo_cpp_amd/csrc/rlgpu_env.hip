@@ -913,6 +913,21 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
     store_env(d, env, S.A, S.G);
 }
 
+// a freshly created env is a fresh arena: every boost pad active (BoostPad's initial state) -- the first Gym::Reset shows the pads as they are
+// BEFORE Match::ResetState resets them (arena_gym.h gym_episode_reset), so "all words zero" would show 34 inactive pads
+template <int NC>
+__global__ void __launch_bounds__(WAVE) k_env_fresh(EnvDev d) {
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    if (threadIdx.x >= LANES) return;
+    const int env = blockIdx.x * LANES + threadIdx.x;
+    if (env >= d.n_envs) return;
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d, env, S.A, S.G);
+    reset_pads(S.A);
+    store_env(d, env, S.A, S.G);
+}
+
 // physics only (rlgpu_env_physics_ticks); with `stamps` (diagnostics, rlgpu_env_debug_tick_cycles) also per workgroup the shader
 // cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime) spent in the tick loop, plus the RLG_TICK_PROFILE phase buckets
 template <int NC>
@@ -1122,6 +1137,14 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
         HIPCHK(e, hipMalloc(&e->d.leaf_cache, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));   // CandCache: 0.4 - 0.9 KB per env
     }
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
+    {
+        dim3 grid(e->nc == 2 ? env_grid<2>(n_envs) : (e->nc == 4 ? env_grid<4>(n_envs) : env_grid<6>(n_envs))), block(WAVE);
+        if (e->nc == 2) hipLaunchKernelGGL((k_env_fresh<2>), grid, block, 0, e->stream, e->d);
+        else if (e->nc == 4) hipLaunchKernelGGL((k_env_fresh<4>), grid, block, 0, e->stream, e->d);
+        else hipLaunchKernelGGL((k_env_fresh<6>), grid, block, 0, e->stream, e->d);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipDeviceSynchronize());
+    }
     return RLGPU_OK;
 }
 

@@ -111,7 +111,7 @@ Gym::~Gym() { delete dev; delete arena; }
 
 // Gym.cpp:58-66
 FList2 Gym::Reset() {
-    (void)match->ResetState(arena);
+    const GameState setterState = match->ResetState(arena);
     // the device does the episode bookkeeping on the new state: counters, score line, event tracker (Gym.cpp:62-63)
     ArenaDevice* d = EnsureDevice(arena, NeutralConfig(tickSkip));
     arena->_SyncToState();
@@ -120,6 +120,9 @@ FList2 Gym::Reset() {
     EnvCheck(d->env, rlgpu_env_reset_envs(d->env, &env0, 1, 0, nullptr), "reset_envs");
     EnvCheck(d->env, rlgpu_env_download_states(d->env, &arena->_state, nullptr, 1), "download_states");
     GameState resetState(arena);
+    // the episode's first GameState is the one the state setter returned: built BEFORE Match::ResetState reset the pads (Match.cpp:55-69)
+    std::copy(std::begin(setterState.boostPads), std::end(setterState.boostPads), std::begin(resetState.boostPads));
+    std::copy(std::begin(setterState.boostPadsInv), std::end(setterState.boostPadsInv), std::begin(resetState.boostPadsInv));
     match->EpisodeReset(resetState);
     prevState = resetState;
     eventTracker.ResetPersistentInfo();

@@ -10,6 +10,7 @@
 // three small bookkeeping kernels below.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <fstream>
 #include <future>
@@ -467,14 +468,24 @@ void Learner::Impl::HostResetEnvs(const std::vector<int32_t>& ids, float* obsRow
     if (n == 0) return;
     float* devRows = plan.hostObs ? devObs : obsRows;
     fresh.resize(n);
-    if (plan.hostSetter) {
+    // the pads as the state setter's GameState showed them: Match::ResetState resets them only after the setter returned (Match.cpp:55-69), so the
+    // new episode's first GameState / observation still carries the previous episode's pad states
+    std::vector<std::array<uint8_t, RLGPU_NUM_PADS>> padsBefore;
+    if (plan.AnyHost() && !deviceDidReset) {   // (the envs are still as their episodes ended: RlgpuGymConfig::host_resets)
         EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
+        padsBefore.resize(n);
+        for (int i = 0; i < n; i++) for (int p = 0; p < RLGPU_NUM_PADS; p++) padsBefore[i][p] = fresh[i].pads[p].is_active;
+    }
+    if (plan.hostSetter) {
+        if (padsBefore.empty()) EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
         ForEnvs(&ids, [&](int e, int i, int w) {
             RLGSC::Arena* arena = arenas[w];
             arena->_state = fresh[i]; arena->_SyncFromState();
-            (void)envMatch[e]->ResetState(arena);
+            const RLGSC::GameState gs = envMatch[e]->stateSetter->ResetState(arena);   // (the pad reset of Match::ResetState is the device's: gym_episode_reset)
+            if ((int)gs.players.size() != nPlayers) RG_ERR_CLOSE("Match::ResetState(): New state has a different amount of players, expected " << nPlayers << " but got " << gs.players.size() << ".");
             arena->_SyncToState();
             fresh[i] = arena->_state;
+            if (!padsBefore.empty()) for (int p = 0; p < RLGPU_NUM_PADS; p++) padsBefore[i][p] = fresh[i].pads[p].is_active;   // (a setter may have touched them)
         });
         EnvCheck(rlgpu_env_upload_states(env, fresh.data(), ids.data(), n), "upload_states");
         EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 0, devRows), "reset_envs");
@@ -485,7 +496,9 @@ void Learner::Impl::HostResetEnvs(const std::vector<int32_t>& ids, float* obsRow
     EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
     if (plan.hostObs && hObs.size() < (size_t)nAgents * D) hObs.resize((size_t)nAgents * D);
     ForEnvs(&ids, [&](int e, int i, int) {
-        RLGSC::GameState gs0(fresh[i], (int)fresh[i].tick_count);
+        RlgpuArenaState st = fresh[i];
+        if (!padsBefore.empty()) for (int p = 0; p < RLGPU_NUM_PADS; p++) st.pads[p].is_active = padsBefore[i][p];
+        RLGSC::GameState gs0(st, (int)st.tick_count);
         envMatch[e]->EpisodeReset(gs0);
         prevGs[e] = gs0;
         if (plan.hostObs) {
@@ -559,7 +572,7 @@ void Learner::Impl::HostStep(Learner* self, int t) {
     if (plugins) {
         std::vector<int32_t> ended;
         for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) ended.push_back(e);
-        HostResetEnvs(ended, nextObs, !plan.hostTerminal);
+        HostResetEnvs(ended, nextObs, false);   // (host_resets: the kernel left the ended envs as they ended)
     } else {
         // a step callback only: the kernel reset the ended envs itself; their next GameState starts a new tick window
         for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) prevGs[e].lastTickCount = (uint64_t)snaps[e].tick_count + (uint64_t)(tickSkip - 1);

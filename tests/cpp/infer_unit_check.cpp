@@ -34,10 +34,11 @@ static int obs_parity(int teamSize, int nEnvs, int steps, std::vector<GameState>
     float *obs = nullptr, *rew = nullptr; int32_t *acts = nullptr, *done = nullptr;
     HIPOK(hipMalloc(&obs, (size_t)nAgents * D * 4)); HIPOK(hipMalloc(&rew, nAgents * 4)); HIPOK(hipMalloc(&acts, nAgents * 4)); HIPOK(hipMalloc(&done, nAgents * 4));
     CHECK(rlgpu_env_reset(env, 1, obs) == RLGPU_OK);
+    CHECK(rlgpu_env_enable_snapshots(env, 1) == RLGPU_OK);   // every step's GameState source = the arena where the episode ended, for the steps that end one
     DefaultOBS builder; DiscreteAction parser;
     std::vector<int32_t> hostActs(nAgents), hostDone(nAgents);
     std::vector<float> hostObs((size_t)nAgents * D);
-    std::vector<RlgpuArenaState> states(nEnvs);
+    std::vector<RlgpuArenaState> states(nEnvs), snaps(nEnvs);
     uint32_t rng = 12345;
     int compared = 0, resets = 0;
     for (int s = 0; s < steps; s++) {
@@ -48,7 +49,11 @@ static int obs_parity(int teamSize, int nEnvs, int steps, std::vector<GameState>
         HIPOK(hipMemcpy(hostObs.data(), obs, hostObs.size() * 4, hipMemcpyDeviceToHost));
         HIPOK(hipMemcpy(hostDone.data(), done, nAgents * 4, hipMemcpyDeviceToHost));
         CHECK(rlgpu_env_download_states(env, states.data(), nullptr, nEnvs) == RLGPU_OK);
+        CHECK(rlgpu_env_download_snapshots(env, snaps.data(), 0, nEnvs) == RLGPU_OK);
         for (int e = 0; e < nEnvs; e++) {
+            // a new episode's first GameState is the one its state setter built -- before Match::ResetState reset the boost pads (Match.cpp:55-69):
+            // it shows the pads as the previous episode left them (tick skip 1 here: the step's snapshot IS the arena at the episode's end)
+            if (hostDone[e * P]) for (int p = 0; p < RLGPU_NUM_PADS; p++) states[e].pads[p].is_active = snaps[e].pads[p].is_active;
             GameState gs(states[e], 1);
             CHECK((int)gs.players.size() == P);
             IList idx(hostActs.begin() + e * P, hostActs.begin() + (e + 1) * P);

@@ -361,3 +361,57 @@ def write_cmf_parts(verts_uu, tris, parts, root):
 # (Empty since the car's world-contact normal is the one the reference's callback sees -- the narrowphase normal BEFORE the internal-edge
 # adjustment, Arena.cpp:218-282; `car_slides_along_panel` had left at tick 251, found with tools/raw_divergence.py.)
 SEAM_EXACT_UNTIL = {}
+
+
+def with_pads_of(state, current):
+    """what a user state setter that sets ball and cars leaves behind: `state` with the boost pads of `current`"""
+    from rlgymppo_cpp_amd.state import ArenaState
+    out = ArenaState.from_buffer_copy(bytes(state))
+    C.memmove(C.addressof(out.pads), C.addressof(current.pads), C.sizeof(out.pads))
+    return out
+
+
+# ---- GameInst::Step across episode ends (tests/golden/gameinst_golden.npz, recorded from the reference's own GameInst.cpp) -------------------
+def gameinst_replay(gg, case, reset_to, step, obs_tol, rew_exact, what):
+    """Replays one case of the fixture.  reset_to(state, first) -> obs rows [players][D] after a Gym::Reset whose state setter installs that
+    state (the recorded setter's k-th call: ball, cars and tick count; the boost pads stay as the previous episode left them, which the new
+    episode's first observation shows -- Match::ResetState resets them only after the setter returned, Match.cpp:55-69); step(actions) -> (obs rows, rewards, done) of one gym step, where the rows returned with done = 1 are not looked at: like
+    GameInst::Step (GameInst.cpp:27-35) the replay then resets to the setter's next state and takes THOSE rows.  Compared with the reference:
+    done and rewards every step, the rows of curObs every step (the first observation of the new episode where one ended), and the reward
+    trackers -- curEpRew, avgEpRew, avgStepRew, totalSteps -- recomputed from the replay's own rewards the way GameInst.cpp:14-34 does."""
+    from rlgymppo_cpp_amd.state import ArenaState
+    team, tick_skip, omp, rk, nts = [int(x) for x in gg[f"gi/{case}/cfg"]]
+    nc = 2 * team
+    states = [ArenaState.from_buffer_copy(b.tobytes()) for b in gg[f"gi/{case}/states"]]
+    acts = gg[f"gi/{case}/actions"]; cur = gg[f"gi/{case}/cur_obs"]; rew = gg[f"gi/{case}/rew"]; done = gg[f"gi/{case}/done"]
+    trk = gg[f"gi/{case}/trackers"]; order = gg[f"gi/{case}/order"]; resets = gg[f"gi/{case}/resets"]
+    k = 0
+    obs = reset_to(states[k], True); k += 1
+    gym_compare_obs(obs, cur[0], nc, omp, [int(x) for x in order[0]], obs_tol, f"{what} {case} start")
+    f32 = np.float32
+    cur_ep, ep_total, ep_count, st_total, st_count = f32(0), f32(0), 0, f32(0), 0
+    ends = 0
+    for t in range(len(acts)):
+        o, r, d = step(acts[t])
+        assert int(d) == int(done[t]), f"{what} {case}: done differs at step {t}"
+        r = np.asarray(r, np.float32)
+        if rew_exact:
+            assert np.array_equal(r, rew[t]), f"{what} {case}: reward not bit-equal to the reference at step {t}: {r} vs {rew[t]}"
+        else:
+            assert np.abs(r - rew[t]).max() < 2e-3 * max(1.0, np.abs(rew[t]).max()), f"{what} {case}: reward differs at step {t}: {r} vs {rew[t]}"
+        total = f32(0)
+        for slot in order[t]:            # GameInst.cpp:16-18: in the players' order
+            total = f32(total + r[int(slot)])
+        st_total = f32(st_total + total); st_count += nc
+        cur_ep = f32(cur_ep + f32(total / f32(nc)))
+        if d:
+            o = reset_to(states[k], False); k += 1; ends += 1
+            ep_total = f32(ep_total + cur_ep); ep_count += 1; cur_ep = f32(0)
+        assert k == int(resets[t + 1])
+        gym_compare_obs(o, cur[t + 1], nc, omp, [int(x) for x in order[t + 1]], obs_tol, f"{what} {case} step {t}" + (" (first observation of the new episode)" if d else ""))
+        got = np.array([cur_ep, ep_total, ep_count, st_total, st_count, t + 1], np.float32)
+        if rew_exact:
+            assert np.array_equal(got, trk[t]), f"{what} {case}: reward trackers at step {t}: {got} vs {trk[t]}"
+        else:
+            assert np.abs(got - trk[t]).max() < 2e-3 * max(1.0, np.abs(trk[t]).max()), f"{what} {case}: reward trackers at step {t}: {got} vs {trk[t]}"
+    return ends

@@ -291,6 +291,42 @@ def test_hip_gym_rollouts_vs_reference_fixtures(sg):
         env.close()
 
 
+def test_hip_gameinst_episode_boundaries_vs_reference(sg):
+    """SURVEY A9 on the HIP path: GameInst::Step ACROSS episode ends against recordings of the reference's own GameInst.cpp (30 episode ends over
+    four cases: NoTouch timeouts and goals; 1v1 example stack, 2v2 every reward term inside ZeroSumReward, 3v3 DefaultOBSPadded(3)) with a
+    replayable user state setter: the k-th reset installs the fixture's k-th state through the boundary the C++ host's user state setters use
+    (rlgpu_env_upload_states + rlgpu_env_reset_envs with run_setter = 0, Learner::Impl::HostResetEnvs).  EQUALITY: done, every reward, every
+    row of curObs -- after an end the first observation of the new episode -- and curEpRew / avgEpRew / avgStepRew / totalSteps."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import gameinst_replay, with_pads_of
+    gg = np.load(os.path.join(GOLD, "gameinst_golden.npz"))
+    dev = torch.device("cuda", 0)
+    total = 0
+    for case in gg["names"]:
+        case = str(case)
+        team, tick_skip, omp, rk, nts = [int(x) for x in gg[f"gi/{case}/cfg"]]
+        gcfg = _gym_cfg(team, tick_skip, omp, rk, nts)
+        gcfg.host_resets = 1      # the state setter is the test's (a user StateSetter): an env whose episode ended stays as it ended until the masked reset
+        env = BatchedEnv(1, team, cfg=gcfg, mesh=(gg["mesh_verts"], gg["mesh_tris"]))
+        rows = env.n_agents
+        nobs = torch.empty((rows, env.obs_size), device=dev); r = torch.empty(rows, device=dev); d = torch.empty(rows, dtype=torch.int32, device=dev)
+        def reset_to(state, first):
+            if first:
+                env.upload_states([state])
+                return env.reset(False).cpu().numpy()
+            env.upload_states([with_pads_of(state, env.download_states()[0])])     # what Learner::Impl::HostResetEnvs does around the user's ResetState(Arena*)
+            env.reset_envs([0], run_setter=False, obs=nobs)      # the masked reset of an env whose episode ended (GameInst.cpp:27-32)
+            env.sync()
+            return nobs.cpu().numpy()
+        def step(a):
+            env.step(torch.from_numpy(a.astype(np.int32)).to(dev), nobs, r, d)
+            env.sync()
+            return nobs.cpu().numpy(), r.cpu().numpy(), int(d[0])
+        total += gameinst_replay(gg, case, reset_to, step, 1e-30, True, "HIP")
+        env.close()
+    assert total >= 12
+
+
 def test_hip_physics_free_run_vs_reference_fixtures(sg):
     """The 31 physics scenarios stepped by the HIP kernel from the reference's start state under the recorded control tape and compared
     with the REFERENCE's states every 10 ticks -- position, velocity, angular velocity, rotation of the ball and every car, flags of

@@ -314,6 +314,31 @@ def test_port_gym_vs_reference_golden(sg, port_lib):
         assert list(st.gym.score_line) == list(fin.gym.score_line)
 
 
+def test_port_gameinst_episode_boundaries_vs_reference(port_lib):
+    """SURVEY A9: GameInst::Step ACROSS episode ends (GameInst.cpp:7-38) as recorded from the reference's own GameInst with a replayable user
+    state setter (tests/golden/gameinst_golden.npz, generator next to it): 6-9 episode ends per case by NoTouchCondition and by goals, 1v1 / 2v2
+    every reward term inside ZeroSumReward / 3v3 DefaultOBSPadded.  After an end the agent's next observation is the NEW episode's first one and
+    curEpRew / avgEpRew / avgStepRew / totalSteps roll over as in the reference.  (The host build hands its state over in uu every step, one
+    rounding per step the reference's resident arena does not make: tolerance 2e-3; the HIP test asserts equality.)"""
+    from simlib import gameinst_replay, with_pads_of
+    gg = np.load(os.path.join(GOLD, "gameinst_golden.npz"))
+    total = 0
+    for case in gg["names"]:
+        case = str(case)
+        team, tick_skip, omp, rk, nts = [int(x) for x in gg[f"gi/{case}/cfg"]]
+        cfg = gym_cfg_for_case(team, tick_skip, omp, rk, nts)
+        cfg.host_resets = 1       # the state setter is the test's: an env whose episode ended stays as it ended until the masked reset
+        box = {}
+        def reset_to(state, first):
+            (box["st"],), obs = port_gym_reset(port_lib, [state if first else with_pads_of(state, box["st"])], cfg, run_setter=False)
+            return obs
+        def step(a):
+            (box["st"],), o, r, d = port_gym_step(port_lib, [box["st"]], cfg, a)
+            return o, r, int(d[0])
+        total += gameinst_replay(gg, case, reset_to, step, 2e-3, False, "host build")
+    assert total >= 12
+
+
 def test_state_setters_against_reference_samples(sg, port_lib):
     """RandomState(true, true, true) and KickoffState: the device / port setters against 4000 / 600 resets of the reference's own
     (RandomState.cpp:8-61, Arena.cpp:112-216): same supports, means and spreads; kickoff: exactly the reference's spawn set."""

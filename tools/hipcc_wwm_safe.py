@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""hipcc for one translation unit with the device assembly checked -- and, when needed, repaired -- for the whole-wave-bracket defect
+tools/wwm_lint.py describes (LLVM AMDGPU, ROCm 7.2 clang 22: an ordinary per-lane spill copy placed inside the `s_or_saveexec_b64 sN, -1 ...
+s_mov_b64 exec, sN` bracket that guards an access to an SGPR-spill VGPR, so that it runs for ALL lanes and destroys what inactive lanes had
+parked in the destination; found with rocgdb in k_env_collect<4>).
+
+    tools/hipcc_wwm_safe.py [--log FILE] <hipcc arguments for ONE -c compile>
+
+Runs hipcc's own four steps (hipcc -###: device cc1, lld, clang-offload-bundler, host cc1) with the device step split in two -- cc1 -S, then
+the assembler -- and between them moves every instruction the lint flags to just in front of its bracket, where it runs under the exec mask
+of its own program point (it depends on nothing inside the bracket: checked).  The object is otherwise what plain hipcc makes.
+"""
+import os
+import re
+import shlex
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import wwm_lint  # noqa: E402
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def patch(path, log):
+    n, bad = wwm_lint.lint(path)
+    if not bad:
+        log.write(f"wwm: {n} whole-wave brackets, clean\n")
+        return 0
+    lines = open(path).read().split("\n")
+    flagged = sorted({ln - 1 for _, ln, _, _ in bad})
+    moved = 0
+    for idx in reversed(flagged):          # bottom-up: indices above stay valid
+        ins = lines[idx]
+        # the bracket's opening line
+        j = idx
+        while not re.match(r"\s+s_or_saveexec_b64 s\[\d+:\d+\], -1", lines[j]):
+            j -= 1
+            if idx - j > 40:
+                raise SystemExit(f"wwm: no bracket start above line {idx + 1}")
+        # independence: no register of the moved instruction is written or read by the bracket's own instructions in between
+        regs = set(re.findall(r"\b[vas]\d+\b", ins))
+        for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]", ins):
+            regs |= {f"{m.group(1)}{k}" for k in range(int(m.group(2)), int(m.group(3)) + 1)}
+        for k in range(j, idx):
+            other = set(re.findall(r"\b[vas]\d+\b", lines[k]))
+            for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]", lines[k]):
+                other |= {f"{m.group(1)}{q}" for q in range(int(m.group(2)), int(m.group(3)) + 1)}
+            if k in flagged:
+                continue
+            if regs & other:
+                raise SystemExit(f"wwm: cannot move `{ins.strip()}` (line {idx + 1}) in front of its bracket: shares {sorted(regs & other)} with `{lines[k].strip()}`")
+        del lines[idx]
+        lines.insert(j, ins + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)")
+        lines.insert(j + 1, "\ts_nop 1")
+        moved += 1
+        log.write(f"wwm: moved `{ins.strip()}` out of the bracket at line {j + 1} ({[b for b in bad if b[1] - 1 == idx][0][0][:70]})\n")
+    open(path, "w").write("\n".join(lines))
+    n2, bad2 = wwm_lint.lint(path)
+    if bad2:
+        raise SystemExit(f"wwm: {len(bad2)} flagged instruction(s) left after patching")
+    return moved
+
+
+def main():
+    args = sys.argv[1:]
+    log = sys.stderr
+    if args and args[0] == "--log":
+        log = open(args[1], "w"); args = args[2:]
+    out = subprocess.run([HIPCC] + args + ["-###"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    cmds = [shlex.split(l) for l in out.stdout.split("\n") if l.startswith(' "')]
+    if len(cmds) != 4 or "-fcuda-is-device" not in cmds[0] or "-emit-obj" not in cmds[0]:
+        raise SystemExit("hipcc_wwm_safe: unexpected hipcc pipeline:\n" + out.stdout[-3000:])
+    dev, lld, bundle, host = cmds
+    dev_obj = dev[dev.index("-o") + 1]
+    dev_asm = dev_obj[:-2] + ".s"
+    dev_s = list(dev); dev_s[dev_s.index("-emit-obj")] = "-S"; dev_s[dev_s.index("-o") + 1] = dev_asm
+    tmp = [dev_asm, dev_obj, lld[lld.index("-o") + 1], [a for a in bundle if a.startswith("-output=")][0][8:]]
+    try:
+        r = subprocess.run(dev_s)
+        if r.returncode: sys.exit(r.returncode)
+        moved = patch(dev_asm, log)
+        clang = dev[0]
+        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_asm, "-o", dev_obj])
+        if r.returncode: sys.exit(r.returncode)
+        for c in (lld, bundle, host):
+            r = subprocess.run(c)
+            if r.returncode: sys.exit(r.returncode)
+        if moved:
+            log.write(f"wwm: object built from the repaired assembly ({moved} instruction(s) moved)\n")
+    finally:
+        for t in tmp:
+            try: os.remove(t)
+            except OSError: pass
+        if log is not sys.stderr: log.close()
+
+
+if __name__ == "__main__":
+    main()
