@@ -973,3 +973,100 @@ def test_snapshots_masked_reset_controls_step_and_step_stats():
         assert bool((block == -7.0).all()) == (e not in ids)
     for e in ids:
         assert now[e].gym.episode_steps == 0 and now[e].gym.score_line[0] == 0 and now[e].gym.reset_count == before[e].gym.reset_count + 1
+
+
+def _torch_ppo_reference(pol_flat, cri_flat, D, H, A, obs, acts, old_logp, adv, tgt, clip, ent_coef, scale, dtype, dev):
+    """PPOLearner::Learn's minibatch body (PPOLearner.cpp:139-215; DiscretePolicy::GetBackpropData, DiscretePolicy.cpp:64-75; policy forward
+    DiscretePolicy.h:27-31) as a torch autograd graph in `dtype` on `dev`, with this repo's flat parameter layout loaded into nn.Sequential's
+    state-dict order.  Returns (policy grads, critic grads, entropy, kl, clip fraction, value loss)."""
+    def mlp(flat, sizes):
+        layers, off = [], 0
+        for i in range(len(sizes) - 1):
+            lin = torch.nn.Linear(sizes[i], sizes[i + 1]).to(dev, dtype)
+            n = sizes[i] * sizes[i + 1]
+            with torch.no_grad():
+                lin.weight.copy_(torch.from_numpy(flat[off:off + n].reshape(sizes[i + 1], sizes[i])).to(dev, dtype)); off += n
+                lin.bias.copy_(torch.from_numpy(flat[off:off + sizes[i + 1]]).to(dev, dtype)); off += sizes[i + 1]
+            layers.append(lin)
+            if i < len(sizes) - 2:
+                layers.append(torch.nn.ReLU())
+        assert off == len(flat)
+        return torch.nn.Sequential(*layers)
+    pol, cri = mlp(pol_flat, [D] + list(H) + [A]), mlp(cri_flat, [D] + list(H) + [1])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    o = t(obs).to(dtype); a = t(acts).long(); olp = t(old_logp).to(dtype); ad = t(adv).to(dtype); tg = t(tgt).to(dtype)
+    vals = cri(o).view(-1)
+    probs = torch.clamp(torch.softmax(pol(o) / 1.0, dim=-1), min=1e-11, max=1)
+    log_probs = torch.log(probs)
+    alp = log_probs.gather(-1, a[:, None]).view(-1)
+    entropy = -(log_probs * probs).sum(dim=-1).mean()
+    ratio = torch.exp(alp - olp)
+    clipped = torch.clamp(ratio, 1 - clip, 1 + clip)
+    policy_loss = -torch.min(ratio * ad, clipped * ad).mean()
+    ((policy_loss - entropy * ent_coef) * scale).backward()
+    value_loss = torch.nn.functional.mse_loss(vals, tg)
+    (value_loss * scale).backward()
+    flat = lambda seq: np.concatenate([p.grad.detach().double().cpu().numpy().reshape(-1) for p in seq.parameters()])
+    with torch.no_grad():
+        lr = alp - olp
+        kl = ((torch.exp(lr) - 1) - lr).mean().item(); cf = (torch.abs(ratio - 1) > clip).double().mean().item()
+    return flat(pol), flat(cri), entropy.item(), kl, cf, value_loss.item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [8192 + 37, 65536])
+def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows):
+    """SURVEY A18 at the shape the bench runs: obs 89 -> 256 x 3 -> 90 / 1, a minibatch of 8 229 rows (ragged against every tile: 128-row GEMM
+    tiles, 512-row dW slabs) and one of 65 536 (the bench's: 128 slabs per dW GEMM summed with fp32 atomics, four streams joined), gathered
+    through a shuffled index list out of a larger buffer.  Reference: PPOLearner.cpp:139-215 as a torch autograd graph built IN the test, in
+    float64, with the same graph in torch fp32 next to it: the fp32 path's gradients are within 5e-6 of the largest entry per network (8 229
+    rows) or, where an fp32 sum over 65 536 largely cancelling rows cannot be, within 3 x the error torch's own fp32 pass makes; entropy / KL /
+    clip fraction / value loss 1e-5; the bf16 path (bf16 operands, fp32 sums) against the same: cosine > 0.999 per
+    network and 3 % of the largest entry."""
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    dev = torch.device("cuda", 0)
+    D, A, H = 89, 90, (256, 256, 256)
+    rng = np.random.RandomState(rows % 1000)
+    pool = rows + 4099
+    obs = (rng.randn(pool, D) * 0.7).astype(np.float32)
+    acts = rng.randint(0, A, size=pool).astype(np.int32)
+    adv = rng.randn(pool).astype(np.float32); tgt = rng.randn(pool).astype(np.float32)
+    idx = rng.permutation(pool)[:rows].astype(np.int32)
+    clip, ent_coef, scale = 0.2, 0.01, 0.25
+    want = None
+    for bf16 in (False, True):
+        core = PPOCore(D, A, H, H, ent_coef=ent_coef, clip_range=clip, use_bf16=bf16, seed=99, max_rows=rows)
+        pol_flat, cri_flat = core.get_params(0), core.get_params(1)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        d_obs, d_acts, d_adv, d_tgt, d_idx = t(obs), t(acts), t(adv), t(tgt), t(idx)
+        if want is None:
+            # old log-probs near the policy's own (ratios around 1, some outside the clip range), from the fp32 policy's probabilities
+            with torch.no_grad():
+                p = core.probs(d_obs[:core.max_rows]) if pool <= core.max_rows else torch.cat([core.probs(d_obs[s:s + core.max_rows].contiguous()) for s in range(0, pool, core.max_rows)])
+            lp = torch.log(p).gather(-1, d_acts.long()[:, None]).view(-1).cpu().numpy()
+            old_logp = (lp + rng.randn(pool).astype(np.float32) * 0.15).astype(np.float32)
+            want = _torch_ppo_reference(pol_flat, cri_flat, D, H, A, obs[idx], acts[idx], old_logp[idx], adv[idx], tgt[idx], clip, ent_coef, scale, torch.float64, dev)
+            # ... and what plain PyTorch fp32 (the reference's own arithmetic: libtorch fp32 GEMMs + autograd) makes of the same minibatch: a sum
+            # over 65 536 rows of terms that largely cancel is only so accurate in fp32, whoever adds them up
+            t32 = _torch_ppo_reference(pol_flat, cri_flat, D, H, A, obs[idx], acts[idx], old_logp[idx], adv[idx], tgt[idx], clip, ent_coef, scale, torch.float32, dev)
+            torch_err = [np.abs(t32[k] - want[k]).max() for k in (0, 1)]
+        d_olp = t(old_logp)
+        metrics = torch.zeros(8, device=dev)
+        core.zero_grads()
+        core.minibatch(d_obs, d_acts, d_olp, d_adv, d_tgt, d_idx, rows, scale, metrics)
+        core.sync()
+        gp, gc = core.get_grads(0).astype(np.float64), core.get_grads(1).astype(np.float64)
+        m = metrics.cpu().numpy().astype(np.float64)
+        for g, w, name, terr in ((gp, want[0], "policy", torch_err[0]), (gc, want[1], "critic", torch_err[1])):
+            assert np.isfinite(g).all()
+            big = np.abs(w).max()
+            if not bf16:
+                # 5e-6 of the largest entry, or -- where fp32 summation itself cannot do that -- within 3 x the error of torch's own fp32 pass
+                assert np.abs(g - w).max() <= max(5e-6 * big, 3 * terr), f"fp32 {name} gradient: {np.abs(g - w).max()} vs largest entry {big} (torch fp32: {terr})"
+            else:
+                cos = float(g @ w / (np.linalg.norm(g) * np.linalg.norm(w)))
+                assert cos > 0.999 and np.abs(g - w).max() <= 0.03 * big, f"bf16 {name} gradient: cosine {cos}, max diff {np.abs(g - w).max()} vs {big}"
+        tol = 1e-5 if not bf16 else 5e-3
+        assert abs(m[0] / rows - want[2]) < tol * max(1, abs(want[2])) and abs(m[1] / rows - want[3]) < tol and abs(m[2] / rows - want[4]) < (1e-9 if not bf16 else 2e-3)
+        assert abs(m[4] / rows - want[5]) < tol * max(1, abs(want[5])) * (1 if not bf16 else 4)
+        core.close()
