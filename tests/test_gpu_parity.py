@@ -6,6 +6,7 @@
 and size-independent properties at the BASELINE sizes (4096 envs)."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1070,3 +1071,40 @@ def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows):
         assert abs(m[0] / rows - want[2]) < tol * max(1, abs(want[2])) and abs(m[1] / rows - want[3]) < tol and abs(m[2] / rows - want[4]) < (1e-9 if not bf16 else 2e-3)
         assert abs(m[4] / rows - want[5]) < tol * max(1, abs(want[5])) * (1 if not bf16 else 4)
         core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_previously_faulting_inlining_variant_builds_and_runs(tmp_path):
+    """VERDICT r03 item 3.  With take_snapshot / event_tracker_update inlined next to build_obs / compute_rewards (-DRLG_INLINE_T6A) the 2v2
+    collection kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in round 3, and in round 4 the default build did the same after an
+    unrelated change.  Cause (rocgdb, profiles/r04a_collect4_fault_rocgdb.txt): a compiler defect -- a per-lane spill copy emitted inside the
+    whole-wave bracket around an SGPR-spill VGPR access runs for all 64 lanes and destroys a hoisted zero parked in the inactive lanes of an
+    AGPR; the zero is the high half of a 64-bit index of the in-kernel inference.  Here: the variant is compiled on the box through
+    tools/hipcc_wwm_safe.py, the lint must FIND the defect in it (this compiler, this source: if it stops doing so the assertion says so and
+    the repair is simply not exercised), the repaired library runs four 2v2 collection launches, and its experience equals the default
+    library's bit for bit."""
+    import subprocess
+    csrc = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
+    obj = str(tmp_path / "rlgpu_env_t6a.o"); log = str(tmp_path / "wwm.log"); so = str(tmp_path / "librlgpu_t6a.so")
+    flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-ffp-contract=off", "-DRLG_INLINE_T6A"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipcc_wwm_safe.py"), "--log", log] + flags + ["-c", os.path.join(csrc, "rlgpu_env.hip"), "-o", obj],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=csrc)
+    assert r.returncode == 0, r.stdout[-3000:]
+    found = open(log).read()
+    others = [os.path.join(csrc, "_obj", f) for f in ("rlgpu_learn.o", "rlgpu_comm.o", "arena_mesh.o", "lt_archive.o")]
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", so, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    outs = []
+    for lib in (so, None):
+        out = str(tmp_path / ("t6a.npz" if lib else "default.npz"))
+        env = dict(os.environ); env.pop("RLGPU_LIB", None)
+        if lib: env["RLGPU_LIB"] = lib
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repro_collect4.py"), "2", "96", "9", "12", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT)
+        assert r.returncode == 0 and "launch 3 ok" in r.stdout, r.stdout[-3000:]
+        outs.append(np.load(out))
+    for k in ("obs", "act", "logp", "rew", "done"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["done"].sum() > 0
+    assert "moved `v_accvgpr_write_b32" in found, "the compiler no longer produces the defect in this variant (lint clean): " + found
