@@ -812,7 +812,12 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #ifdef RLG_TICK_PROFILE
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_step_prof[16 * blockIdx.x + 3] = 0;
-    unsigned long long prof_infer = 0, prof_mlp = 0;
+    unsigned long long prof_infer = 0, prof_mlp = 0, prof_ticks = 0, prof_gym = 0;
+#define RLG_CPROF_T0() const unsigned long long prof_c0_ = __builtin_amdgcn_s_memtime()
+#define RLG_CPROF_ADD(acc) acc += __builtin_amdgcn_s_memtime() - prof_c0_
+#else
+#define RLG_CPROF_T0() ((void)0)
+#define RLG_CPROF_ADD(acc) ((void)0)
 #endif
 #ifdef RLG_POISON_LDS   /* test build: every env byte of the wavefront starts as 0xFF (NaN floats, -1 ints): results must not depend on what LDS held before */
     for (int i = (threadIdx.x & 63); i < (int)((lanes_per_block<NC>() / WPB) * lane_stride<NC>() / 4); i += 64) reinterpret_cast<uint32_t*>(wmem)[i] = 0xFFFFFFFFu;
@@ -875,16 +880,19 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         }
         wave_sync();
         TickEvents ev; ev.bump_mask = 0;
-        arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev);
+        { RLG_CPROF_T0(); arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev); RLG_CPROF_ADD(prof_ticks); }
         float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
+        { RLG_CPROF_T0();
         if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
         if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
-        wave_sync();
-        for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); }
+        wave_sync(); RLG_CPROF_ADD(prof_gym); }
+        { RLG_CPROF_T0(); for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); } RLG_CPROF_ADD(prof_ticks); }
+        { RLG_CPROF_T0();
         if (env_lane) {
             gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
             for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
         }
+        RLG_CPROF_ADD(prof_gym); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (c.counter && ws.lane == 0) __hip_atomic_fetch_add(c.counter, (unsigned int)n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wave_sync();
@@ -894,7 +902,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     // profiler build: this workgroup's total and inference cycles (read back with rlgpu_env_debug_step_prof)
-    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_step_prof[16 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_step_prof[16 * blockIdx.x + 1] = prof_infer; g_step_prof[16 * blockIdx.x + 2] = prof_mlp; }
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_step_prof[16 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_step_prof[16 * blockIdx.x + 1] = prof_infer; g_step_prof[16 * blockIdx.x + 2] = prof_mlp;
+        g_step_prof[16 * blockIdx.x + 4] = prof_ticks; g_step_prof[16 * blockIdx.x + 5] = prof_gym; g_step_prof[16 * blockIdx.x + 6] = (unsigned long long)t; }
 #endif
 }
 

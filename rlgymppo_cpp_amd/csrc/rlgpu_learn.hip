@@ -27,6 +27,7 @@
 #include "rl_math.h"
 #include "infer_device.h"
 #include "rlgpu_internal.h"
+#include "mlp_stripe.h"
 
 namespace {
 using rlinfer::HeadArgs;
@@ -830,7 +831,8 @@ struct Net {
     int64_t n_params = 0;
     // bf16 fast path: padded leading dims and the offsets (in elements) of the weight shadows inside rlgpu_learner::shadows
     int kp[10] = {0};              // kp[i] = round_up(dims[i], 32): leading dim of layer i's bf16 input / of its gradient
-    int64_t w16_off[9] = {0}, wt16_off[9] = {0}, wf16_off[9] = {0};   // wf16: w16 re-ordered into MFMA B fragments (k_mlp_infer)
+    int64_t w16_off[9] = {0}, wt16_off[9] = {0}, wf16_off[9] = {0}, wtf16_off[9] = {0};   // wtf16: wt16 in fragment order too (mlp_stripe.h k_bwd_stripe)
+    // (wf16: w16 re-ordered into MFMA B fragments: k_mlp_infer, k_fwd_stripe)
     int w16_rows[9] = {0}, wt16_rows[9] = {0};   // row counts padded to the 128-wide N tile
 };
 
@@ -982,6 +984,7 @@ void plan_shadows(Net& n, int64_t& off) {
         n.wt16_rows[i] = round_up(n.dims[i], 128);      // B operand of the dX GEMM: W^T as [K_in padded][kp[i+1]]
         n.wt16_off[i] = off; off += (int64_t)n.wt16_rows[i] * n.kp[i + 1];
         n.wf16_off[i] = off; off += (int64_t)n.w16_rows[i] * n.kp[i];
+        n.wtf16_off[i] = off; off += (int64_t)n.wt16_rows[i] * n.kp[i + 1];
     }
 }
 
@@ -996,6 +999,10 @@ int refresh_shadows(rlgpu_learner* l) {
             const size_t nf = (size_t)n->w16_rows[i] * n->kp[i];
             hipLaunchKernelGGL(k_weight_frags, dim3((nf + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->w16_off[i]), n->w16_rows[i], n->kp[i],
                                l->shadows + n->wf16_off[i]);
+            LCHK(l, hipGetLastError());
+            const size_t nft = (size_t)n->wt16_rows[i] * n->kp[i + 1];
+            hipLaunchKernelGGL(k_weight_frags, dim3((nft + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->wt16_off[i]), n->wt16_rows[i], n->kp[i + 1],
+                               l->shadows + n->wtf16_off[i]);
             LCHK(l, hipGetLastError());
         }
     }
@@ -1096,6 +1103,74 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
         }
     }
     if (split) LCHK(l, hipEventRecord(l->ev_dw_done[which], l->dw_stream[which]));
+    return RLGPU_OK;
+}
+
+// ---- the stripe path (mlp_stripe.h): forward and dX chains of BOTH networks in one launch each -----------------------------------------------
+#ifndef RLG_STRIPE_RT
+#define RLG_STRIPE_RT 2          // 32-row tiles per stripe: 2 -> 64 rows, 68 KB of LDS, two workgroups per CU
+#endif
+bool stripe_capable(const rlgpu_learner* l) {
+    // opt-in for now (RLGPU_STRIPE=1): the two fused launches give the per-layer kernels' results bit for bit, but with the dW GEMMs still
+    // separate a minibatch takes 0.74 ms against the four-stream per-layer path's 0.52 (what is missing is dW inside the stripe)
+    static const bool on = std::getenv("RLGPU_STRIPE") != nullptr;
+    if (!on || !l->cfg.use_bf16) return false;
+    for (const Net* n : {&l->pol, &l->cri}) {
+        if (n->n_layers < 2 || n->n_layers > stripe::MAXL) return false;
+        for (int i = 0; i <= n->n_layers; i++) if (n->kp[i] > stripe::MAXW || !stripe::nk_supported(n->kp[i] / 16)) return false;
+    }
+    return l->pol.kp[0] == l->cri.kp[0];
+}
+void stripe_fill(const rlgpu_learner* l, stripe::Args& a, int rows) {
+    a.x16 = l->x16; a.ldx = l->pol.kp[0]; a.rows = rows;
+    int w = 0;
+    for (const Net* n : {&l->pol, &l->cri}) {
+        stripe::Net& s = a.net[w];
+        s.n_layers = n->n_layers;
+        for (int i = 0; i <= n->n_layers; i++) { s.dims[i] = n->dims[i]; s.kp[i] = n->kp[i]; }
+        const std::vector<short*>& acts = w == 0 ? l->act16_p : l->act16_c;
+        for (int i = 0; i < n->n_layers; i++) {
+            s.wf[i] = l->shadows + n->wf16_off[i]; s.wtf[i] = l->shadows + n->wtf16_off[i]; s.bias[i] = l->params + n->b_off[i];
+            s.act[i] = i + 1 < n->n_layers ? acts[i] : nullptr;
+            s.dy[i] = l->dy16[w][i];
+        }
+        s.out32 = w == 0 ? l->act_p.back() : l->act_c.back(); s.ld32 = n->dims[n->n_layers];
+        w++;
+    }
+}
+int stripe_launch(rlgpu_learner* l, bool backward, int rows) {
+    constexpr int RT = RLG_STRIPE_RT;
+    constexpr size_t smem = (size_t)2 * 32 * RT * stripe::LD * sizeof(short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&stripe::k_fwd_stripe<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&stripe::k_bwd_stripe<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    stripe::Args a; stripe_fill(l, a, rows);
+    dim3 grid((rows + 32 * RT - 1) / (32 * RT), 2);
+    if (backward) hipLaunchKernelGGL((stripe::k_bwd_stripe<RT>), grid, dim3(256), smem, l->stream, a);
+    else hipLaunchKernelGGL((stripe::k_fwd_stripe<RT>), grid, dim3(256), smem, l->stream, a);
+    LCHK(l, hipGetLastError());
+    for (const Net* n : {&l->pol, &l->cri})
+        for (int i = backward ? 1 : 0; i < n->n_layers; i++) l->last_flops += 2.0 * rows * (double)n->dims[i] * n->dims[i + 1];
+    return RLGPU_OK;
+}
+// dW / db of every layer of one network from the stored activations and activation gradients (the TN GEMMs of net_backward16)
+int net_dw16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, int rows, int which, hipStream_t st) {
+    for (int i = net.n_layers - 1; i >= 0; i--) {
+        const short* in = (i == 0) ? l->x16 : acts16[i - 1];
+        const int K_in = net.dims[i], N_out = net.dims[i + 1];
+        TnArgs t{};
+        t.Y = l->dy16[which][i]; t.ldy = net.kp[i + 1]; t.X = in; t.ldx = net.kp[i];
+        t.R = rows; t.Mo = N_out; t.No = K_in;
+        t.dW = l->grads + net.w_off[i]; t.ldw = K_in; t.db = l->grads + net.b_off[i];
+        t.slab = 512;
+        dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
+        hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, t);
+        LCHK(l, hipGetLastError());
+        l->last_flops += 2.0 * N_out * K_in * (double)rows;
+    }
     return RLGPU_OK;
 }
 
@@ -1357,7 +1432,31 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
     const int loss_blocks = std::max(1, std::min(2048, (n + 3) / 4));
     const int vloss_blocks = std::max(1, std::min(1024, (n + 255) / 256));
-    if (fast) {
+    if (fast && stripe_capable(l)) {
+        // mlp_stripe.h: forward of both networks in ONE launch (activations in LDS from layer to layer), the two loss kernels, the dX chain of
+        // both networks in ONE launch, then the eight dW GEMMs -- the policy's and the critic's on a stream each
+        if ((rc = refresh_shadows(l))) return rc;
+        if ((rc = stripe_launch(l, false, n))) return rc;
+        hipLaunchKernelGGL(k_value_loss, dim3(vloss_blocks), dim3(256), 0, l->stream, (const float*)l->act_c.back(), targets, idx, n, ratio / (float)n,
+                           (float*)nullptr, l->dy16[1][l->cri.n_layers - 1], l->cri.kp[l->cri.n_layers], metrics);
+        hipLaunchKernelGGL(k_ppo_policy_loss, dim3(loss_blocks), dim3(256), 0, l->stream, (const float*)l->act_p.back(), A, n, A, inv_t, actions, old_logp, adv, idx,
+                           l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->dy16[0][l->pol.n_layers - 1], l->pol.kp[l->pol.n_layers], metrics);
+        LCHK(l, hipGetLastError());
+        if ((rc = stripe_launch(l, true, n))) return rc;
+        const bool two = l->dw_stream[0] != nullptr && l->dw_stream[1] != nullptr && !std::getenv("RLGPU_ONE_STREAM");
+        if (two) {
+            LCHK(l, hipEventRecord(l->ev_fork, l->stream));
+            for (int w = 0; w < 2; w++) {
+                LCHK(l, hipStreamWaitEvent(l->dw_stream[w], l->ev_fork, 0));
+                if ((rc = net_dw16(l, w == 0 ? l->pol : l->cri, w == 0 ? l->act16_p : l->act16_c, n, w, l->dw_stream[w]))) return rc;
+                LCHK(l, hipEventRecord(l->ev_dw_done[w], l->dw_stream[w]));
+                LCHK(l, hipStreamWaitEvent(l->stream, l->ev_dw_done[w], 0));
+            }
+        } else {
+            if ((rc = net_dw16(l, l->pol, l->act16_p, n, 0, l->stream))) return rc;
+            if ((rc = net_dw16(l, l->cri, l->act16_c, n, 1, l->stream))) return rc;
+        }
+    } else if (fast) {
         // The two networks are independent until the optimizer step: the critic's chain goes to a side stream, the policy's stays on the
         // learner's, and they meet again before the closing timing event.  A chain is ~12 short dependent launches; every launch boundary
         // waits for the previous layer's output to leave the per-XCD L2s, and the other chain's kernels fill those gaps.

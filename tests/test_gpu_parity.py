@@ -1108,3 +1108,38 @@ def test_previously_faulting_inlining_variant_builds_and_runs(tmp_path):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     assert outs[0]["done"].sum() > 0
     assert "moved `v_accvgpr_write_b32" in found, "the compiler no longer produces the defect in this variant (lint clean): " + found
+
+
+@pytest.mark.gpu
+def test_stripe_kernels_equal_the_per_layer_path(tmp_path):
+    """csrc/mlp_stripe.h (RLGPU_STRIPE=1): forward and dX chains of both networks in one launch each, activations in LDS from layer to layer.
+    Same operands, same accumulation order per 32x32 tile, same rounding points as the per-layer GEMMs: gradients and metrics of a ragged
+    flagship-shape minibatch (8 229 rows) are compared with the default path's for EQUALITY up to the fp32 atomics' summation order (1e-6 of the
+    largest entry)."""
+    import subprocess
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from rlgymppo_cpp_amd.ppo import PPOCore
+dev = torch.device('cuda', 0); rows = 8229; D, A = 89, 90
+rng = np.random.RandomState(5)
+core = PPOCore(D, A, (256, 256, 256), (256, 256, 256), use_bf16=True, seed=3, max_rows=rows)
+t = lambda x: torch.from_numpy(x).to(dev)
+obs = t((rng.randn(rows + 100, D) * 0.7).astype(np.float32)); acts = t(rng.randint(0, A, rows + 100).astype(np.int32))
+olp = t((-4.5 + rng.randn(rows + 100) * 0.2).astype(np.float32)); adv = t(rng.randn(rows + 100).astype(np.float32)); tgt = t(rng.randn(rows + 100).astype(np.float32))
+idx = t(rng.permutation(rows + 100)[:rows].astype(np.int32)); m = torch.zeros(8, device=dev)
+core.zero_grads(); core.minibatch(obs, acts, olp, adv, tgt, idx, rows, 0.25, m); core.sync()
+np.savez(sys.argv[1], gp=core.get_grads(0), gc=core.get_grads(1), m=m.cpu().numpy())
+""" % ROOT
+    outs = []
+    for stripe in (False, True):
+        out = str(tmp_path / ("s%d.npz" % stripe))
+        env = dict(os.environ); env.pop("RLGPU_STRIPE", None)
+        if stripe: env["RLGPU_STRIPE"] = "1"
+        r = subprocess.run([sys.executable, "-c", code, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+        assert r.returncode == 0, r.stdout[-3000:]
+        outs.append(np.load(out))
+    for k in ("gp", "gc"):
+        big = np.abs(outs[0][k]).max()
+        assert np.abs(outs[0][k] - outs[1][k]).max() <= 1e-6 * big, k
+    assert np.allclose(outs[0]["m"], outs[1]["m"], rtol=1e-6, atol=0)

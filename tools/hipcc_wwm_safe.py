@@ -30,32 +30,37 @@ def patch(path, log):
         return 0
     lines = open(path).read().split("\n")
     flagged = sorted({ln - 1 for _, ln, _, _ in bad})
-    moved = 0
-    for idx in reversed(flagged):          # bottom-up: indices above stay valid
-        ins = lines[idx]
-        # the bracket's opening line
+
+    def regs_of(text):
+        r = set(re.findall(r"\b[vas]\d+\b", text))
+        for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]", text):
+            r |= {f"{m.group(1)}{k}" for k in range(int(m.group(2)), int(m.group(3)) + 1)}
+        return r
+    # group the flagged lines by the bracket they sit in (its opening s_or_saveexec line)
+    groups = {}
+    for idx in flagged:
         j = idx
         while not re.match(r"\s+s_or_saveexec_b64 s\[\d+:\d+\], -1", lines[j]):
             j -= 1
             if idx - j > 40:
                 raise SystemExit(f"wwm: no bracket start above line {idx + 1}")
-        # independence: no register of the moved instruction is written or read by the bracket's own instructions in between
-        regs = set(re.findall(r"\b[vas]\d+\b", ins))
-        for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]", ins):
-            regs |= {f"{m.group(1)}{k}" for k in range(int(m.group(2)), int(m.group(3)) + 1)}
-        for k in range(j, idx):
-            other = set(re.findall(r"\b[vas]\d+\b", lines[k]))
-            for m in re.finditer(r"\b([vas])\[(\d+):(\d+)\]", lines[k]):
-                other |= {f"{m.group(1)}{q}" for q in range(int(m.group(2)), int(m.group(3)) + 1)}
-            if k in flagged:
-                continue
-            if regs & other:
-                raise SystemExit(f"wwm: cannot move `{ins.strip()}` (line {idx + 1}) in front of its bracket: shares {sorted(regs & other)} with `{lines[k].strip()}`")
-        del lines[idx]
-        lines.insert(j, ins + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)")
-        lines.insert(j + 1, "\ts_nop 1")
-        moved += 1
-        log.write(f"wwm: moved `{ins.strip()}` out of the bracket at line {j + 1} ({[b for b in bad if b[1] - 1 == idx][0][0][:70]})\n")
+        groups.setdefault(j, []).append(idx)
+    moved = 0
+    for j in sorted(groups, reverse=True):          # bottom-up: indices above stay valid
+        idxs = groups[j]
+        keep = [k for k in range(j, max(idxs) + 1) if k not in idxs]
+        for idx in idxs:
+            # independence: no register of a moved instruction is touched by the bracket's own instructions it jumps over
+            for k in keep:
+                if k < idx and regs_of(lines[idx]) & regs_of(lines[k]):
+                    raise SystemExit(f"wwm: cannot move `{lines[idx].strip()}` (line {idx + 1}) in front of its bracket: shares {sorted(regs_of(lines[idx]) & regs_of(lines[k]))} with `{lines[k].strip()}`")
+        out = [lines[idx] + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)" for idx in idxs]
+        for idx in idxs:
+            log.write(f"wwm: moved `{lines[idx].strip()}` out of the bracket at line {j + 1} ({[b for b in bad if b[1] - 1 == idx][0][0][:70]})\n")
+        for idx in reversed(idxs):
+            del lines[idx]
+        lines[j:j] = out + ["\ts_nop 1"]
+        moved += len(idxs)
     open(path, "w").write("\n".join(lines))
     n2, bad2 = wwm_lint.lint(path)
     if bad2:

@@ -43,6 +43,9 @@ for it in range(12):
             print("      env %d: ball (%.0f %.0f %.0f) |v| %.0f | %s" % (e, s_.ball.pos[0], s_.ball.pos[1], s_.ball.pos[2], np.linalg.norm(s_.ball.vel[:]), " | ".join(desc)))
     prev = tot
     if it >= 9:
+        tk = buf.reshape(-1, 16)[:, 4].astype(np.float64); gy = buf.reshape(-1, 16)[:, 5].astype(np.float64)
+        print("launch %d: per gym step (mean workgroup): total %.0fK cycles = ticks %.0fK (%.1fK per tick) + inference %.0fK + gym bookkeeping (snapshot, events, rewards, done, obs rows, reset) %.0fK + rest %.0fK"
+              % (it, tot.mean() / T / 1e3, tk.mean() / T / 1e3, tk.mean() / T / 8e3, inf.mean() / T / 1e3, gy.mean() / T / 1e3, (tot - tk - inf - gy).mean() / T / 1e3))
         q = np.percentile(tot, [1, 50, 90, 99])
         print("launch %d: workgroup cycles min %.2fM p1 %.2fM median %.2fM mean %.2fM p90 %.2fM p99 %.2fM max %.2fM (%.1f ms); inference share of the mean %.1f%% (per step: MLP %.0fK cycles, head %.0fK); mean/max %.2f"
               % (it, tot.min() / 1e6, q[0] / 1e6, q[1] / 1e6, tot.mean() / 1e6, q[2] / 1e6, q[3] / 1e6, tot.max() / 1e6, tot.max() / 2.38e6, 100 * inf.mean() / tot.mean(), mlp.mean() / T / 1e3, (inf.mean() - mlp.mean()) / T / 1e3, tot.mean() / tot.max()))
