@@ -73,6 +73,8 @@ public:
     // envs are sharded over the ranks, ONE gradient all-reduce per optimizer step, rank 0 writes the checkpoints
     int Rank() const;
     int WorldSize() const;
+    void CheckReplicas();                            // exchange errors and (every RLGPU_REPLICA_CHECK_EVERY = 50 iterations) a parameter checksum against rank 0's: RG_ERR_CLOSE on failure
+    uint64_t ParamChecksum() const;                  // FNV-1a over the fp32 parameter bits of this rank
     // device-side clocks since the last reset: the env batch's step / collect launches and the learner's minibatch GEMM section (bench driver)
     void DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset);
     bool UsesFusedCollection() const;

@@ -337,12 +337,26 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out);       
 int rlgpu_comm_destroy(rlgpu_comm* c);
 int rlgpu_comm_rank(const rlgpu_comm* c);
 int rlgpu_comm_world(const rlgpu_comm* c);
+int rlgpu_comm_device(const rlgpu_comm* c);   /* the device the communicator is bound to (LOCAL_RANK): the learner whose gradients it reduces must live there */
 const char* rlgpu_comm_last_error(const rlgpu_comm* c);
 /* sum over ranks of the learner's flat gradient buffer [policy | critic], in place, on the learner's stream; follow with
  * rlgpu_clip_adam_step(l, 1 / world ...) so the clip sees the global-batch gradient (PPOLearner.cpp:273-288 semantics) */
 int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c);
 int rlgpu_comm_allreduce_f32(rlgpu_comm* c, float* dev_ptr, int64_t n, void* stream);
 int rlgpu_comm_broadcast(rlgpu_comm* c, void* dev_ptr, int64_t bytes, int root, void* stream);     /* parameters / return statistics from rank 0 */
+/* fail-fast: RLGPU_OK, or an error whose text (rlgpu_comm_last_error) names what went wrong with the ranks' exchange since the last look -- RCCL's
+ * asynchronous error (ncclCommGetAsyncError; also polled before and after every collective above), or a peer's failure.  Hosts call it once per
+ * iteration and END THE PROCESS on an error: the replicas can no longer be assumed equal; a restart is a fresh launch of every rank. */
+int rlgpu_comm_check(rlgpu_comm* c);
+/* Replica consistency.  sync_from_rank0: parameters, Adam moments and step counters of rank 0 replace every other rank's (after construction and after
+ * loading a checkpoint: equal seeds and equal files make the replicas equal, this makes them equal whatever the files were).  param_checksum: a 64-bit
+ * digest of the fp32 parameter bits; replicas_equal broadcasts rank 0's and compares: *equal_out = 0 on a rank whose parameters differ. */
+int rlgpu_learner_sync_from_rank0(rlgpu_learner* l, rlgpu_comm* c);
+int rlgpu_learner_param_checksum(rlgpu_learner* l, uint64_t* out);
+int rlgpu_learner_replicas_equal(rlgpu_learner* l, rlgpu_comm* c, int* equal_out);
+/* RLGPU_COMM_TRANSPORT=shm (tests): rlgpu_comm_init_env builds the communicator on a POSIX shared-memory segment instead of RCCL -- host-staged
+ * all-reduce / broadcast with sums in rank order -- so that the ranks of a launch can share one device (RCCL refuses that) and a one-GPU box runs
+ * the hosts' whole N > 1 path. */
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,11 @@ SIGNATURES = {
     "rlgpu_comm_allreduce_f32": (_i, [_vp, _vp, C.c_int64, _vp]),
     "rlgpu_comm_broadcast": (_i, [_vp, _vp, C.c_int64, _i, _vp]),
     "rlgpu_learner_refresh_shadows": (_i, [_vp]),
+    "rlgpu_comm_check": (_i, [_vp]),
+    "rlgpu_comm_device": (_i, [_vp]),
+    "rlgpu_learner_sync_from_rank0": (_i, [_vp, _vp]),
+    "rlgpu_learner_param_checksum": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "rlgpu_learner_replicas_equal": (_i, [_vp, _vp, C.POINTER(_i)]),
     "rlgpu_learner_sync": (_i, [_vp]),
     "rlgpu_learner_last_gemm": (_i, [_vp, C.POINTER(_f), C.POINTER(C.c_double)]),
     "rlgpu_env_timing_total": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), _i]),

@@ -23,17 +23,71 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <vector>
+#include <algorithm>
 #include "../../include/rlgpu.h"
+
+// Test-only second transport (RLGPU_COMM_TRANSPORT=shm): the same three collectives staged through a POSIX shared-memory segment, so that the
+// ranks of a launch can share ONE device -- RCCL refuses two ranks on a device, and this pool's boxes have one GPU: with it every line of the
+// hosts' N > 1 path (sharded envs, rank-keyed sampler, all-reduce per optimizer step, rank-0 broadcasts, replica checks, fail-fast) executes
+// before the first real multi-GPU run.  Sums are taken in rank order by every rank itself: identical bits everywhere, run to run.
+struct ShmSeg {
+    uint64_t magic; int32_t world; int32_t pad;
+    volatile int32_t arrive[2];     // sense-reversing barrier: arrivals of the current phase
+    volatile int32_t phase;
+    volatile int32_t dead;          // a rank that failed sets it: everybody else stops waiting
+    // then world slots of SLOT bytes
+};
+constexpr size_t SHM_SLOT = 8u << 20;
+constexpr uint64_t SHM_MAGIC = 0x314d48535f4c52ull;
 
 struct rlgpu_comm {
     ncclComm_t comm = nullptr;
     int device = 0, rank = 0, world = 1;
+    // shm transport
+    ShmSeg* seg = nullptr; size_t seg_bytes = 0; std::string seg_name; int my_phase = 0; int timeout_s = 300;
     std::string err;
 };
 
 namespace {
 std::string g_comm_err;
-int fail(rlgpu_comm* c, const std::string& m) { if (c) c->err = m; g_comm_err = m; return RLGPU_ERR_HIP; }
+int fail(rlgpu_comm* c, const std::string& m) { if (c) c->err = m; g_comm_err = m; if (c && c->seg) c->seg->dead = 1; return RLGPU_ERR_HIP; }
+
+unsigned char* shm_slot(rlgpu_comm* c, int r) { return reinterpret_cast<unsigned char*>(c->seg) + 4096 + (size_t)r * SHM_SLOT; }
+// everybody arrives, or the wait ends with an error: a peer that died (its process gone or its `dead` mark) must not hang the others
+int shm_barrier(rlgpu_comm* c, const char* what) {
+    ShmSeg* s = c->seg;
+    const int ph = c->my_phase & 1;
+    __sync_fetch_and_add(&s->arrive[ph], 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->arrive[ph] < c->world) {
+        if (s->dead) return fail(c, std::string(what) + ": a peer rank failed");
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s))
+            return fail(c, std::string(what) + ": rank " + std::to_string(c->rank) + " waited " + std::to_string(c->timeout_s) + " s for its peers (a rank died?)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    // the last one to leave re-arms the OTHER phase's counter: nobody can be waiting on it (they are all here)
+    c->my_phase++;
+    if (c->rank == 0) s->arrive[(c->my_phase) & 1] = 0;
+    // second half: nobody proceeds to the next barrier before rank 0 has re-armed it
+    __sync_fetch_and_add(&s->phase, 1);
+    const int want = c->my_phase * c->world;
+    while (s->phase < want) {
+        if (s->dead) return fail(c, std::string(what) + ": a peer rank failed");
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s)) return fail(c, std::string(what) + ": timed out leaving the barrier");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    return RLGPU_OK;
+}
+// RCCL reports failures of earlier, asynchronous work (a peer that went away, a link error) through the communicator's async error
+int rccl_async(rlgpu_comm* c, const char* what) {
+    ncclResult_t st = ncclSuccess;
+    ncclResult_t r = ncclCommGetAsyncError(c->comm, &st);
+    if (r != ncclSuccess) return fail(c, std::string(what) + ": ncclCommGetAsyncError: " + ncclGetErrorString(r));
+    if (st != ncclSuccess && st != ncclInProgress) return fail(c, std::string(what) + ": asynchronous RCCL error: " + ncclGetErrorString(st));
+    return RLGPU_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -126,6 +180,44 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     if (rendezvous_dir().empty()) return fail(nullptr, "rendezvous directory /tmp/rlgpu_comm_<uid> is not a private directory of this user (set RLGPU_COMM_DIR)");
     const std::string path = rendezvous_path();
     const int timeout_s = env_i("RLGPU_COMM_TIMEOUT_S", 300) > 0 ? env_i("RLGPU_COMM_TIMEOUT_S", 300) : 300;
+    const char* transport = getenv("RLGPU_COMM_TRANSPORT");
+    if (transport && !strcmp(transport, "shm")) {
+        // the segment is named after the rendezvous file; rank 0 creates it, the others wait for its magic word
+        std::string name = path.substr(path.find_last_of('/') + 1);
+        for (char& ch : name) if (ch == '.') ch = '_';
+        name = "/" + name;
+        const size_t bytes = 4096 + (size_t)world * SHM_SLOT;
+        rlgpu_comm* c = new rlgpu_comm();
+        c->device = local; c->rank = rank; c->world = world; c->timeout_s = timeout_s; c->seg_name = name; c->seg_bytes = bytes;
+        int fd = -1;
+        if (rank == 0) {
+            (void)shm_unlink(name.c_str());
+            fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { delete c; return fail(nullptr, "shm transport: cannot create " + name + ": " + strerror(errno)); }
+        } else {
+            for (int tries = 0; tries < timeout_s * 100 && fd < 0; tries++) {
+                fd = shm_open(name.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) { close(fd); fd = -1; }
+                if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            if (fd < 0) { delete c; return fail(nullptr, "shm transport: timed out waiting for " + name); }
+        }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { delete c; return fail(nullptr, std::string("shm transport: mmap: ") + strerror(errno)); }
+        c->seg = reinterpret_cast<ShmSeg*>(m);
+        if (rank == 0) { c->seg->world = world; c->seg->arrive[0] = c->seg->arrive[1] = 0; c->seg->phase = 0; c->seg->dead = 0; __sync_synchronize(); c->seg->magic = SHM_MAGIC; }
+        else {
+            for (int tries = 0; tries < timeout_s * 100 && c->seg->magic != SHM_MAGIC; tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (c->seg->magic != SHM_MAGIC || c->seg->world != world) { munmap(m, bytes); delete c; return fail(nullptr, "shm transport: " + name + " is not this launch's segment"); }
+        }
+        int rc = shm_barrier(c, "shm transport: first barrier");
+        if (rank == 0) (void)shm_unlink(name.c_str());   // everybody has it mapped
+        if (rc != RLGPU_OK) { const std::string e = c->err; munmap(m, bytes); delete c; return fail(nullptr, e); }
+        *out = c;
+        return RLGPU_OK;
+    }
     unsigned char id[RLGPU_COMM_ID_BYTES];
     if (rank == 0) {
         int rc = rlgpu_comm_unique_id(id);
@@ -162,24 +254,69 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
 
 int rlgpu_comm_destroy(rlgpu_comm* c) {
     if (!c) return RLGPU_OK;
+    if (c->seg) munmap(c->seg, c->seg_bytes);
     if (c->comm) ncclCommDestroy(c->comm);
     delete c;
     return RLGPU_OK;
 }
 int rlgpu_comm_rank(const rlgpu_comm* c) { return c ? c->rank : 0; }
 int rlgpu_comm_world(const rlgpu_comm* c) { return c ? c->world : 1; }
+int rlgpu_comm_device(const rlgpu_comm* c) { return c ? c->device : -1; }
 
 int rlgpu_comm_allreduce_f32(rlgpu_comm* c, float* dev_ptr, int64_t n, void* stream) {
     if (!c || !dev_ptr || n < 0) return RLGPU_ERR_ARG;
+    if (c->seg) {   // host-staged, in chunks of a slot: D2H into the own slot | barrier | sum of all slots in rank order | H2D | barrier
+        const int64_t per = (int64_t)(SHM_SLOT / 4);
+        std::vector<float> sum;
+        for (int64_t o = 0; o < n; o += per) {
+            const int64_t k = std::min(per, n - o);
+            if (hipMemcpyAsync(shm_slot(c, c->rank), dev_ptr + o, (size_t)k * 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                return fail(c, "shm all-reduce: device -> host copy failed");
+            int rc = shm_barrier(c, "shm all-reduce");
+            if (rc) return rc;
+            sum.assign((size_t)k, 0.f);
+            for (int r = 0; r < c->world; r++) { const float* p = reinterpret_cast<const float*>(shm_slot(c, r)); for (int64_t i = 0; i < k; i++) sum[(size_t)i] += p[i]; }
+            rc = shm_barrier(c, "shm all-reduce");   // (everybody has read every slot before anybody overwrites its own)
+            if (rc) return rc;
+            if (hipMemcpyAsync(dev_ptr + o, sum.data(), (size_t)k * 4, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                return fail(c, "shm all-reduce: host -> device copy failed");
+        }
+        return RLGPU_OK;
+    }
+    int rc = rccl_async(c, "before ncclAllReduce");
+    if (rc) return rc;
     ncclResult_t r = ncclAllReduce(dev_ptr, dev_ptr, (size_t)n, ncclFloat, ncclSum, c->comm, (hipStream_t)stream);
     if (r != ncclSuccess) return fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    return RLGPU_OK;
+    return rccl_async(c, "after ncclAllReduce");
 }
 int rlgpu_comm_broadcast(rlgpu_comm* c, void* dev_ptr, int64_t bytes, int root, void* stream) {
-    if (!c || !dev_ptr || bytes < 0) return RLGPU_ERR_ARG;
+    if (!c || !dev_ptr || bytes < 0 || root < 0 || root >= c->world) return RLGPU_ERR_ARG;
+    if (c->seg) {
+        for (int64_t o = 0; o < bytes; o += (int64_t)SHM_SLOT) {
+            const int64_t k = std::min<int64_t>((int64_t)SHM_SLOT, bytes - o);
+            if (c->rank == root && (hipMemcpyAsync(shm_slot(c, root), (char*)dev_ptr + o, (size_t)k, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
+                return fail(c, "shm broadcast: device -> host copy failed");
+            int rc = shm_barrier(c, "shm broadcast");
+            if (rc) return rc;
+            if (c->rank != root && (hipMemcpyAsync((char*)dev_ptr + o, shm_slot(c, root), (size_t)k, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess))
+                return fail(c, "shm broadcast: host -> device copy failed");
+            rc = shm_barrier(c, "shm broadcast");
+            if (rc) return rc;
+        }
+        return RLGPU_OK;
+    }
+    int rc = rccl_async(c, "before ncclBroadcast");
+    if (rc) return rc;
     ncclResult_t r = ncclBroadcast(dev_ptr, dev_ptr, (size_t)bytes, ncclChar, root, c->comm, (hipStream_t)stream);
     if (r != ncclSuccess) return fail(c, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
-    return RLGPU_OK;
+    return rccl_async(c, "after ncclBroadcast");
+}
+// Has anything gone wrong with the ranks' exchange since the last look?  RCCL: the communicator's asynchronous error; shm: a peer's failure mark.
+// The hosts call it once per iteration and end the process with the text (a restart is a fresh launch of every rank).
+int rlgpu_comm_check(rlgpu_comm* c) {
+    if (!c) return RLGPU_OK;
+    if (c->seg) return c->seg->dead ? fail(c, "a peer rank failed") : RLGPU_OK;
+    return rccl_async(c, "rlgpu_comm_check");
 }
 
 }  // extern "C"

@@ -802,12 +802,25 @@ __global__ void k_gather_rows(const float* src, const int32_t* idx, int rows, in
 }
 
 // sum of squares of a gradient segment -> out[0] (fp32 atomics)
-__global__ void k_sumsq(const float* g, int64_t n, float pre_scale, float* out) {
+// The squared norm of the (scaled) gradient in a FIXED order: a partial per workgroup (wave sums, then the workgroup's waves in order), then the
+// partials in order by one thread.  With atomics the order -- and with it the last bit of the clip coefficient -- changed from launch to
+// launch: the replicas of a multi-GPU run, which start every optimizer step from bit-identical summed gradients, drifted apart by an ulp at a
+// time (found by the replica check, tests/test_host_cpp.py::test_two_ranks_on_one_gpu_...).
+constexpr int SUMSQ_BLOCKS = 64;
+__global__ void __launch_bounds__(256) k_sumsq(const float* g, int64_t n, float pre_scale, float* partial) {
+    __shared__ float ws[4];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float s = 0.f;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) { float v = g[i] * pre_scale; s += v * v; }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+}
+__global__ void k_sumsq_finish(const float* partial, int n_partial, float* out) {
+    float s = 0.f;
+    for (int i = 0; i < n_partial; i++) s += partial[i];
+    *out = s;
 }
 // clip_grad_norm_ (torch/nn/utils/clip_grad.py: coef = max_norm / (norm + 1e-6), clamped to 1) + Adam
 __global__ void k_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float pre_scale, float max_norm,
@@ -1213,7 +1226,7 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     for (int i = 0; i < l->cri.n_layers; i++) { float* p; LCHK(l, hipMalloc(&p, R * l->cri.dims[i + 1] * 4)); l->act_c.push_back(p); maxw = std::max(maxw, l->cri.dims[i + 1]); }
     LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
     LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
-    LCHK(l, hipMalloc(&l->norm_buf, 16));
+    LCHK(l, hipMalloc(&l->norm_buf, (4 + 2 * SUMSQ_BLOCKS) * 4));   // [0..1] the two networks' squared gradient norms, then their per-workgroup partials
     if (cfg->use_bf16) {
         int64_t soff = 0;
         plan_shadows(l->pol, soff); plan_shadows(l->cri, soff);
@@ -1508,11 +1521,12 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
 
 int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     LCHK(l, hipSetDevice(l->device));
-    LCHK(l, hipMemsetAsync(l->norm_buf, 0, 16, l->stream));
     struct Seg { int64_t off, n; float lr; int64_t* step; int slot; } segs[2] = {
         {0, l->pol.n_params, l->cfg.policy_lr, &l->step_p, 0}, {l->pol.n_params, l->cri.n_params, l->cfg.critic_lr, &l->step_c, 1}};
     for (auto& s : segs) {
-        hipLaunchKernelGGL(k_sumsq, dim3(64), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, l->norm_buf + s.slot);
+        float* const partial = l->norm_buf + 4 + s.slot * SUMSQ_BLOCKS;
+        hipLaunchKernelGGL(k_sumsq, dim3(SUMSQ_BLOCKS), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, partial);
+        hipLaunchKernelGGL(k_sumsq_finish, dim3(1), dim3(1), 0, l->stream, (const float*)partial, SUMSQ_BLOCKS, l->norm_buf + s.slot);
         LCHK(l, hipGetLastError());
     }
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
@@ -1577,7 +1591,58 @@ extern "C" {
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); return l->cfg.use_bf16 ? refresh_shadows(l) : RLGPU_OK; }
 int rlgpu_learner_set_sampler(rlgpu_learner* l, uint32_t stream, uint32_t call_ctr) { l->sampler_stream = stream; l->call_ctr = call_ctr; return RLGPU_OK; }
 int rlgpu_learner_get_sampler(rlgpu_learner* l, uint32_t* stream, uint32_t* call_ctr) { if (stream) *stream = l->sampler_stream; if (call_ctr) *call_ctr = l->call_ctr; return RLGPU_OK; }
-int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c) { LCHK(l, hipSetDevice(l->device)); return rlgpu_comm_allreduce_f32(c, l->grads, l->n_total, (void*)l->stream); }
+int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c) {
+    if (c && rlgpu_comm_device(c) != l->device) { l->err = "rlgpu_allreduce_grads: the learner lives on device " + std::to_string(l->device) + ", the communicator on device " + std::to_string(rlgpu_comm_device(c)); return RLGPU_ERR_ARG; }
+    LCHK(l, hipSetDevice(l->device));
+    int rc = rlgpu_comm_allreduce_f32(c, l->grads, l->n_total, (void*)l->stream);
+    if (rc) l->err = rlgpu_comm_last_error(c);
+    return rc;
+}
+int rlgpu_learner_sync_from_rank0(rlgpu_learner* l, rlgpu_comm* c) {
+    if (!c) return RLGPU_OK;
+    LCHK(l, hipSetDevice(l->device));
+    for (float* p : {l->params, l->adam_m, l->adam_v}) { int rc = rlgpu_comm_broadcast(c, p, l->n_total * 4, 0, (void*)l->stream); if (rc) { l->err = rlgpu_comm_last_error(c); return rc; } }
+    int64_t* steps = nullptr;
+    LCHK(l, hipMalloc(&steps, 16));
+    const int64_t h[2] = {l->step_p, l->step_c};
+    LCHK(l, hipMemcpyAsync(steps, h, 16, hipMemcpyHostToDevice, l->stream));
+    int rc = rlgpu_comm_broadcast(c, steps, 16, 0, (void*)l->stream);
+    int64_t g[2] = {0, 0};
+    if (!rc) { LCHK(l, hipMemcpyAsync(g, steps, 16, hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream)); l->step_p = g[0]; l->step_c = g[1]; }
+    (void)hipFree(steps);
+    if (rc) { l->err = rlgpu_comm_last_error(c); return rc; }
+    l->shadows_dirty = true;
+    return RLGPU_OK;
+}
+int rlgpu_learner_param_checksum(rlgpu_learner* l, uint64_t* out) {
+    if (!out) return RLGPU_ERR_ARG;
+    LCHK(l, hipSetDevice(l->device));
+    std::vector<uint32_t> h((size_t)l->n_total);
+    LCHK(l, hipMemcpyAsync(h.data(), l->params, (size_t)l->n_total * 4, hipMemcpyDeviceToHost, l->stream));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    uint64_t a = 0xcbf29ce484222325ull;   // FNV-1a over the words
+    for (uint32_t w : h) { a ^= w; a *= 0x100000001b3ull; }
+    *out = a;
+    return RLGPU_OK;
+}
+int rlgpu_learner_replicas_equal(rlgpu_learner* l, rlgpu_comm* c, int* equal_out) {
+    if (!equal_out) return RLGPU_ERR_ARG;
+    *equal_out = 1;
+    if (!c) return RLGPU_OK;
+    uint64_t mine = 0;
+    int rc = rlgpu_learner_param_checksum(l, &mine);
+    if (rc) return rc;
+    uint64_t* d = nullptr;
+    LCHK(l, hipMalloc(&d, 8));
+    LCHK(l, hipMemcpyAsync(d, &mine, 8, hipMemcpyHostToDevice, l->stream));
+    rc = rlgpu_comm_broadcast(c, d, 8, 0, (void*)l->stream);
+    uint64_t root = 0;
+    if (!rc) { LCHK(l, hipMemcpyAsync(&root, d, 8, hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream)); }
+    (void)hipFree(d);
+    if (rc) { l->err = rlgpu_comm_last_error(c); return rc; }
+    *equal_out = root == mine ? 1 : 0;
+    return RLGPU_OK;
+}
 int rlgpu_learner_set_temperature(rlgpu_learner* l, float t) { if (!(t > 0)) return RLGPU_ERR_ARG; l->cfg.temperature = t; return RLGPU_OK; }
 int rlgpu_learner_sync(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream)); return RLGPU_OK; }
 int rlgpu_learner_last_gemm(rlgpu_learner* l, float* ms, double* flops) {

@@ -339,6 +339,8 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
         HOST_HIP(hipEventCreateWithFlags(&m.evReady, hipEventDisableTiming)); HOST_HIP(hipEventCreateWithFlags(&m.evLearnDone, hipEventDisableTiming));
     }
     if (!config.checkpointLoadFolder.empty()) Load();
+    // replicas: whatever the seeds and the checkpoint files made of them, every rank goes on from rank 0's parameters, Adam moments and step counters
+    if (m.comm) m.LrnCheck(rlgpu_learner_sync_from_rank0(m.lrn, m.comm), "learner_sync_from_rank0");
     if (config.sendMetrics && m.rank == 0) {                                                                                          // Learner.cpp:149-155
         if (!runID.empty()) RG_LOG("\tRun ID: " << runID);
         metricSender = new MetricSender(config.metricsProjectName, config.metricsGroupName, config.metricsRunName, runID);
@@ -392,6 +394,24 @@ int Learner::StepCapacity() const { return impl->Tcap; }
 std::vector<int32_t> Learner::CollectedSteps() const { return impl->hSteps; }
 bool Learner::UsesFreeRunningCollection() const { return impl->lastFree; }
 uint64_t Learner::LastIterationTimesteps() const { return (uint64_t)impl->lastRows; }
+// multi-GPU fail-fast: an error of the ranks' exchange (RCCL's asynchronous error, a lost peer) or replicas that are no longer equal END the
+// process with the text -- the launcher restarts every rank from the last checkpoint (a fresh process each: nothing is re-executed in place)
+void Learner::CheckReplicas() {
+    Impl& m = *impl;
+    if (!m.comm) return;
+    if (rlgpu_comm_check(m.comm) != RLGPU_OK) RG_ERR_CLOSE("multi-GPU exchange failed: " << rlgpu_comm_last_error(m.comm));
+    static const int every = [] { const char* s = std::getenv("RLGPU_REPLICA_CHECK_EVERY"); return s && std::atoi(s) > 0 ? std::atoi(s) : 50; }();
+    if (totalIterations % (uint64_t)every != 0) return;
+    if (m.learnPending) return;   // (collectionDuringLearn: the epochs in flight are writing the parameters)
+    int equal = 1;
+    m.LrnCheck(rlgpu_learner_replicas_equal(m.lrn, m.comm, &equal), "learner_replicas_equal");
+    if (!equal) RG_ERR_CLOSE("rank " << m.rank << ": parameters differ from rank 0's after " << totalIterations << " iterations (replicas diverged)");
+}
+uint64_t Learner::ParamChecksum() const {
+    uint64_t v = 0;
+    impl->LrnCheck(rlgpu_learner_param_checksum(impl->lrn, &v), "learner_param_checksum");
+    return v;
+}
 int Learner::Rank() const { return impl->rank; }
 int Learner::WorldSize() const { return impl->world; }
 std::vector<double> Learner::GatherOverRanks(double v) {
@@ -868,6 +888,7 @@ void Learner::Learn() {
             for (auto& pair : skillTracker->curRating.data) report[std::string("Skill Rating") + (pair.first.empty() ? "" : " ") + pair.first] = pair.second;
         }
         totalIterations++;
+        CheckReplicas();
         report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
         report["Timesteps Collected"] = (double)m.lastRows;
         report["Collection Time"] = collectTime; report["Consumption Time"] = consumeTime; report["Total Iteration Time"] = tAll.Elapsed();

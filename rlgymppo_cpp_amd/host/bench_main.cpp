@@ -82,6 +82,8 @@ int main(int argc, char* argv[]) {
     auto iteration = [&](double* consumeMs) {
         Report rep;
         struct Keep { Report& r; double& a; double& b; ~Keep() { if (r.Has("Average Step Reward")) a = r["Average Step Reward"]; if (r.Has("Policy Entropy")) b = r["Policy Entropy"]; } } keep{rep, lastStepReward, lastEntropy};
+        learner.totalIterations++;
+        learner.CheckReplicas();
         learner.CollectTimesteps();
         if (overlap) { learner.FinishLearn(rep); learner.AddNewExperience(rep); learner.LearnPPO(rep); return; }   // the epochs run beside the next collection
         if (consumeMs) (void)hipDeviceSynchronize();   // the collection launch is asynchronous: the consumption clock starts when it has finished
@@ -119,7 +121,8 @@ int main(int argc, char* argv[]) {
         learner.config.ppo.epochs = epochs;
         ln = measure(0, learnedSteps); haveLn = true;
     }
-    fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations\n", rank, world, m.sec, steps);
+    learner.CheckReplicas();
+    fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations, parameter checksum %016llx\n", rank, world, m.sec, steps, (unsigned long long)learner.ParamChecksum());
     if (rank == 0) {
         const int nP = 2 * g_team, D = learner.obsSize;
         // SURVEY 8d, verbatim: algorithmic bytes per gym step per env = 2 (336 N_p + 264) + N_p (4 D + 8) + 4

@@ -185,7 +185,16 @@ class Learner:
             if world_size > 1:
                 raise ValueError("Learner(world_size > 1) needs the ranks' communicator: pass comm=parallel.make_comm() (RCCL from the launcher's "
                                  "environment) -- without it no gradient would ever be exchanged")
-            comm = parallel.make_comm() if parallel.env_ranks()[2] > 1 else parallel.SoloComm()
+            if parallel.env_ranks()[2] > 1:
+                # the communicator binds RCCL to LOCAL_RANK's device: the env batch, the learner and every buffer must live there too
+                comm = parallel.make_comm()
+                local = int(os.environ.get("LOCAL_RANK", str(comm.rank)))
+                if cfg.device != local:
+                    cfg.device = local
+            else:
+                comm = parallel.SoloComm()
+        elif world_size > 1 and hasattr(comm, "device") and comm.device is not None and comm.device != cfg.device:
+            raise ValueError(f"Learner: the communicator is bound to device {comm.device} but cfg.device is {cfg.device}: one process per GPU, everything on its device")
         self.comm = comm
         rank, world_size = comm.rank, comm.world
         self.rank, self.world = rank, world_size

@@ -57,6 +57,7 @@ class RcclComm(SoloComm):
         if rc != 0:
             raise _lib.RlgpuError(f"rlgpu_comm_init_env failed ({rc}): {self.lib.rlgpu_comm_last_error(None).decode()}")
         self.rank, self.world = r.value, w.value
+        self.device = self.lib.rlgpu_comm_device(self.h)    # LOCAL_RANK: the learner whose gradients this reduces must live there
         self._lib_mod = _lib
 
     def _chk(self, rc):

@@ -340,3 +340,66 @@ def test_two_rank_launch_on_one_gpu_ends_instead_of_hanging(tmp_path):
         assert all(c != 0 for c in codes), (codes, outs)
         assert took < 140
         assert any("ncclCommInitRank" in o[1] or "rlgpu_comm_init_env" in o[1] for o in outs), outs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_path):
+    """VERDICT r03 item 5.  RCCL refuses two ranks on one device and this pool's boxes have one GPU, so the hosts' N > 1 path had never executed
+    end to end.  RLGPU_COMM_TRANSPORT=shm puts the three collectives of include/rlgpu.h on a host-staged shared-memory transport (sums in
+    rank order); everything above it is the product's: two bench_main ranks (C++ Learner) shard the envs (seed + 1000 rank), explore with
+    rank-keyed samplers, take rank 0's parameters / Adam state at construction (rlgpu_learner_sync_from_rank0), all-reduce the flat gradient
+    once per optimizer step, scale inside the clip, share rank 0's returns for the Welford statistic, and check a parameter checksum against
+    rank 0's every iteration (RLGPU_REPLICA_CHECK_EVERY=1).
+      * both ranks finish 3 iterations with EQUAL parameter checksums although their experience differs (the replicas stay replicas);
+      * the result differs from a single-rank run's (the other rank's gradients did enter);
+      * a rank that is killed ends the other one within the communicator's timeout, non-zero, with the reason in its output."""
+    import json, re, signal, socket, time
+    exe = os.path.join(PKG, "bench_main")
+
+    def launch(steps, tag, timeout_s="60"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        rdv = str(tmp_path / ("rdv_" + tag)); os.mkdir(rdv, 0o700)
+        base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TAG=tag,
+                    RLGPU_COMM_TRANSPORT="shm", RLGPU_COMM_TIMEOUT_S=timeout_s, RLGPU_REPLICA_CHECK_EVERY="1", RLGPU_LOCKSTEP_COLLECTION="1", RLGPU_QUIET="1")
+        cmd = [exe, "--envs", "256", "--horizon", "8", "--steps", str(steps), "--warmup", "0"]
+        return [subprocess.Popen(cmd, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(2)]
+
+    def finish(procs):
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=200))
+            except subprocess.TimeoutExpired:
+                for q in procs: q.kill()
+                pytest.fail("a rank hung")
+        return outs
+
+    sums = []
+    for attempt in range(1):
+        procs = launch(3, "a%d" % attempt)
+        outs = finish(procs)
+        assert [p.returncode for p in procs] == [0, 0], outs
+        cs = [re.search(r"parameter checksum ([0-9a-f]{16})", o[1]).group(1) for o in outs]
+        assert cs[0] == cs[1], cs
+        line = json.loads(outs[0][0].strip().splitlines()[-1])
+        assert line["rccl_ranks"] == 2 and line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["allreduce_calls"] == 3, line
+        sums.append(cs[0])
+    # (two launches do not end in the same bits: the dW GEMMs sum their row slabs with fp32 atomics, in whatever order the slabs finish)
+    solo = subprocess.run([exe, "--envs", "256", "--horizon", "8", "--steps", "3", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                          env=dict(os.environ, RLGPU_LOCKSTEP_COLLECTION="1", RLGPU_QUIET="1"))
+    assert solo.returncode == 0
+    assert re.search(r"parameter checksum ([0-9a-f]{16})", solo.stderr).group(1) != sums[0]       # the other rank's gradients did enter
+    # fail-fast: kill rank 1 in the middle of a long run
+    procs = launch(1000000, "kill", timeout_s="8")
+    time.sleep(6)
+    assert procs[0].poll() is None and procs[1].poll() is None, "the long run ended by itself"
+    procs[1].send_signal(signal.SIGKILL)
+    t0 = time.time()
+    try:
+        out0 = procs[0].communicate(timeout=60)
+    except subprocess.TimeoutExpired:
+        procs[0].kill()
+        pytest.fail("rank 0 went on waiting for a dead peer")
+    assert procs[0].returncode != 0 and time.time() - t0 < 40
+    assert "peer" in out0[1] or "peers" in out0[1], out0[1][-1500:]
