@@ -108,6 +108,36 @@ RLG_HD void manifold_finish_static(Contact& c, const Body& a, V3 b_origin) {
     c.dist = dot(wa - wb, c.n);
     c.ra = wa - a.pos; c.rb = wb;
 }
+// The same for a whole manifold of `count` points, INCLUDING the refresh's second pass (btPersistentManifold.cpp:272-301): a point whose refreshed
+// distance exceeds the contact breaking threshold, or whose two world points have drifted apart sideways by more than it, is removed -- and
+// removeContactPoint (btPersistentManifold.h:164-185) fills the hole with the LAST point, so the survivors' order changes.  Within the tick the
+// transforms have not moved, so only a point the detector reported at the very edge of the threshold is affected: its distance, recomputed from
+// the local points, lands one rounding on the other side.  (Seen on the tessellated arena: two nearly coplanar fillet triangles, the first
+// point accepted at depth <= 0.040624548 and refreshed to 0.04062467.)  The callbacks that fired when the point was added stay fired.
+// Returns the number of points left.
+RLG_HD int manifold_refresh_static(Contact* pts, int count, const Body& a, V3 b_origin, float breaking) {
+    V3 wa[4], wb[4];
+    for (int i = count - 1; i >= 0; i--) {
+        wa[i] = (a.rot * pts[i].ra) + a.pos;
+        wb[i] = (pts[i].rb - b_origin) + b_origin;
+        pts[i].dist = dot(wa[i] - wb[i], pts[i].n);
+    }
+    for (int i = count - 1; i >= 0; i--) {
+        bool drop = !(pts[i].dist <= breaking);
+        if (!drop) {
+            const V3 projected = wa[i] - pts[i].n * pts[i].dist;
+            const V3 diff = wb[i] - projected;
+            drop = dot(diff, diff) > breaking * breaking;
+        }
+        if (drop) {
+            const int last = count - 1;
+            if (i != last) { pts[i] = pts[last]; wa[i] = wa[last]; wb[i] = wb[last]; }
+            count--;
+        }
+    }
+    for (int i = 0; i < count; i++) { pts[i].ra = wa[i] - a.pos; pts[i].rb = wb[i]; }
+    return count;
+}
 // both bodies dynamic: pa_w / pb_w are the world points the algorithm reported
 RLG_HD void manifold_point_dynamic(Contact& c, const Body& a, const Body& b, V3 n, V3 pb_w, float depth) {
     V3 pa_w = pb_w + n * depth;

@@ -294,6 +294,15 @@ RLG_HD_T4 void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, Col
 //                             list (arena_contact.h); counts in W.body_n[body] / W.ball_hit[car]
 //   collide_merge  per env    the car-car pairs, the contact-added callbacks that touch other bodies, and the ORDER in which
 //                             the solver visits the contacts (W.cidx)
+// the end-of-algorithm refresh of a body's <= 2 mesh manifolds (points [0, first) and [first, n)): distances and world points rebuilt, points that
+// fail the refresh removed (manifold_refresh_static), the second manifold moved down behind what is left of the first; sets sid.  Returns the new n.
+RLG_HD int refresh_mesh_manifolds(Contact* out, int n, int first, const Body& b, float breaking) {
+    const int c0 = manifold_refresh_static(out, first, b, v3(0, 0, 0), breaking);
+    const int c1 = manifold_refresh_static(out + first, n - first, b, v3(0, 0, 0), breaking);
+    if (c0 != first) for (int k = 0; k < c1; k++) out[c0 + k] = out[first + k];
+    for (int k = 0; k < c0 + c1; k++) out[k].sid = (first < n && k >= c0) ? SID_MESH2 : 0;
+    return c0 + c1;
+}
 template <int NC, int MAXC, class NW>
 RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
@@ -324,7 +333,8 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             // ball vs mesh: one manifold for the whole mesh body, a point per triangle in visiting order (btConvexConcaveCollisionAlgorithm.cpp:
             // 76-160 -> btSphereTriangleCollisionAlgorithm on the shared manifold), reduced to 4 by manifold_replace_index
             nw.ball_mesh(A, mesh, [&](const Cand& k, int obj) { mesh_point(A.ball.b, k, obj, CBT_BALL); });
-            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], A.ball.b, v3(0, 0, 0)); out[k].a = 0; out[k].b = -1; out[k].sid = (n_man > 0 && k >= m_start) ? SID_MESH2 : 0; out[k].special = 1; }
+            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, A.ball.b, CBT_BALL);
+            for (int k = 0; k < n; k++) { out[k].a = 0; out[k].b = -1; out[k].special = 1; }
             // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121): the sphere's support vertex towards the plane
             for (int i = 0; i < 4; i++) {
                 V3 pn, po; world_plane_body(i, pn, po);
@@ -337,7 +347,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                 V3 pb = (vip - pn * dist) + po;
                 int cnt = 0;
                 if (manifold_add_static(&out[n], cnt, 1, A.ball.b, pn, pb, dist, CBT_BALL) < 0) continue;
-                manifold_finish_static(out[n], A.ball.b, po);
+                if (manifold_refresh_static(&out[n], 1, A.ball.b, po, CBT_BALL) == 0) continue;
                 out[n].a = 0; out[n].b = -1; out[n].sid = (int8_t)(1 + i); out[n].special = 1;
                 n++;
             }
@@ -356,7 +366,8 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                     car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n_raw;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427) sees the point BEFORE btAdjustInternalEdgeContacts (Arena.cpp:276-280)
                 }
             });
-            for (int k = 0; k < n; k++) { manifold_finish_static(out[k], car.b, v3(0, 0, 0)); out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].sid = (n_man > 0 && k >= m_start) ? SID_MESH2 : 0; out[k].special = 0; }
+            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, car.b, CBT_CAR);
+            for (int k = 0; k < n; k++) { out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].special = 0; }
             // planes: ONE contact per plane and tick, the hitbox's support vertex towards the plane (btConvexPlaneCollisionAlgorithm.cpp:
             // 92-121; the perturbation passes are off: m_minimumPointsPerturbationThreshold = 0, btConvexPlaneCollisionAlgorithm.h:62-63)
             for (int i = 0; i < 4; i++) {
@@ -369,10 +380,10 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                 V3 pb = (vip - pn * dist) + po;                        // planeObjWrap->getWorldTransform() * vtxInPlaneProjected
                 int cnt = 0;
                 if (manifold_add_static(&out[n], cnt, 1, car.b, pn, pb, dist, CBT_CAR) < 0) continue;
-                manifold_finish_static(out[n], car.b, po);
+                car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = pn;    // (the contact-added callback: before the algorithm's refresh)
+                if (manifold_refresh_static(&out[n], 1, car.b, po, CBT_CAR) == 0) continue;
                 out[n].a = (int8_t)(1 + ci); out[n].b = -1; out[n].sid = (int8_t)(1 + i); out[n].special = 0;
                 n++;
-                car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = pn;
             }
             // car vs ball: the manifold's body0 is the car (arena_contact.h).  Its callback runs in collide_merge.
             // The pair goes through the same btGjkPairDetector as a hitbox against a triangle (btConvexConvexAlgorithm; the sphere-box

@@ -454,6 +454,54 @@ def test_hip_mesh_of_two_files_vs_reference_golden(tmp_path):
     env.close()
 
 
+def test_hip_tessellated_mesh_of_sixteen_files_vs_reference_golden(tmp_path):
+    """VERDICT r03 4b.  The HIP path on the mesh of bench.py's `mesh_tessellated` leg -- 10 084 triangles in 16 .cmf files, one collision object
+    and one contact manifold per file (Arena.cpp:1028-1054), loaded by rlgpu_env_load_cmf_dir -- against recordings of the reference on the same
+    16 files (tests/golden/tess_golden.npz).  This is the workload that reaches the device-only mesh machinery at size: BVH top levels staged
+    in LDS, frontiers of up to 128 nodes, the kept candidate leaves, up to 24 leaves per body, two mesh manifolds per body.  EQUALITY with the
+    reference: all 360 one-tick pairs (79 of them touch two or more files at once; a tape's pairs in one env slot one after the other, as
+    recorded), and the six kickoff tapes of 1v1 / 2v2 / 3v3 under random controls over their whole 1 200 ticks, every field of every body."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import write_cmf_parts, state_vec
+    tg = np.load(os.path.join(GOLD, "tess_golden.npz"))
+    root = write_cmf_parts(tg["mesh_verts"], tg["mesh_tris"], tg["mesh_parts"], str(tmp_path))
+    mesh_dir = os.path.join(root, "soccar")
+    names = [str(x) for x in tg["phys_names"]]; every = int(tg["phys_every"])
+    B, A, T = tg["pairs/before"], tg["pairs/after"], tg["pairs/tag"]
+    n_pairs = 0
+    for team in (1, 2, 3):
+        nc = 2 * team
+        mine = [i for i, n in enumerate(names) if n.startswith(f"{team}v{team}")]
+        # one-tick pairs
+        per_tape = {ti: [i for i in range(len(B)) if int(T[i][0]) == ti] for ti in mine}
+        env = BatchedEnv(len(mine), team, mesh=mesh_dir)
+        for j in range(max(len(v) for v in per_tape.values())):
+            slots = [e for e, ti in enumerate(mine) if j < len(per_tape[ti])]
+            env.upload_states([ArenaState.from_buffer_copy(B[per_tape[mine[e]][j]].tobytes()) for e in slots], env_ids=slots)
+            env.physics_ticks(1)
+            got = env.download_states(env_ids=slots)
+            for e, st in zip(slots, got):
+                i = per_tape[mine[e]][j]
+                assert np.array_equal(state_vec(st), state_vec(ArenaState.from_buffer_copy(A[i].tobytes()))), \
+                    f"{names[mine[e]]} tick {int(T[i][1])} ({int(T[i][2])} mesh files touched): one tick on the HIP path is not the reference's"
+                n_pairs += 1
+        env.close()
+        # free-running tapes
+        env = BatchedEnv(len(mine), team, mesh=mesh_dir)
+        env.upload_states([ArenaState.from_buffer_copy(tg[f"phys/{names[ti]}/start_raw"].tobytes()) for ti in mine])
+        tapes = [tg[f"phys/{names[ti]}/tape"] for ti in mine]
+        ctl = np.zeros((len(mine), nc, 8), np.float32)
+        for t in range(len(tapes[0])):
+            for e, tp in enumerate(tapes): ctl[e] = tp[t]
+            env.set_controls(ctl); env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states()
+                for e, ti in enumerate(mine):
+                    assert np.array_equal(state_vec(cur[e]), tg[f"phys/{names[ti]}/states"][(t + 1) // every - 1]), f"{names[ti]} tick {t + 1}: HIP state is not the reference's"
+        env.close()
+    assert n_pairs == len(B) == 360
+
+
 def test_live_reference_rollout(ref_lib, port_lib):
     """When the prebuilt reference .so travelled with the snapshot: step the real RLGymSim_CPP Gym on the host CPU next
     to the GPU env from the same state and action tape."""

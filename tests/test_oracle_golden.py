@@ -234,6 +234,35 @@ def test_port_mesh_of_two_files_vs_reference_golden():
     assert not_exact[True] > 0, "the fixture no longer distinguishes per-file objects from a merged mesh"
 
 
+def test_port_tessellated_mesh_of_sixteen_files_vs_reference_golden():
+    """The arena at the game meshes' density -- 10 084 triangles in 16 .cmf files = 16 collision objects, bench.py's `mesh_tessellated` leg --
+    recorded from the reference through its own directory loader (tests/golden/tess_golden.npz, make_tess_golden.py): six kickoff tapes of
+    1v1 / 2v2 / 3v3 under random controls, 1 200 ticks each, and 360 one-tick pairs from ticks with a mesh contact (79 of them touching two or
+    more files at once).  The host build on the same 16 objects: every pair EQUAL, every tape bit-identical over its whole length."""
+    import ctypes as C
+    from simlib import PortSim
+    tg = np.load(os.path.join(GOLD, "tess_golden.npz"))
+    port = PortSim(); port.set_mesh(tg["mesh_verts"], tg["mesh_tris"], tg["mesh_parts"])
+    names = [str(x) for x in tg["phys_names"]]; every = int(tg["phys_every"])
+    B, A, T = tg["pairs/before"], tg["pairs/after"], tg["pairs/tag"]
+    hist = {}
+    bad = []
+    for i in range(len(B)):     # a tape's pairs one after the other in ONE arena, as they were recorded (the broadphase's arrival order passes on)
+        st = ArenaState.from_buffer_copy(B[i].tobytes())
+        h = hist.setdefault(int(T[i][0]), (C.c_uint16 * 8)())
+        port.step(st, 1, hist=h)
+        if not np.array_equal(state_vec(st), state_vec(ArenaState.from_buffer_copy(A[i].tobytes()))): bad.append((names[T[i][0]], int(T[i][1])))
+    assert not bad, f"{len(bad)} of {len(B)} one-tick pairs of the 16-file mesh are not bit-equal to the reference: {bad[:6]}"
+    port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for name in names:
+        st = ArenaState.from_buffer_copy(tg[f"phys/{name}/start_raw"].tobytes())
+        tape = np.ascontiguousarray(tg[f"phys/{name}/tape"], np.float32); want = tg[f"phys/{name}/states"]
+        outs = (ArenaState * (len(tape) // every))()
+        port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+        for j in range(len(tape) // every):
+            assert np.array_equal(state_vec(outs[j]), want[j]), f"{name} tick {(j + 1) * every}: not bit-identical to the reference"
+
+
 def test_port_one_tick_vs_reference_states():
     """1722 (state, state one tick later) pairs recorded from the reference -- every tick with a narrowphase contact and every 16th
     other tick of the 31 scenarios; the "after" state is what the reference computes from the recorded "before" (set_state, one tick),

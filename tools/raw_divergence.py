@@ -11,7 +11,7 @@ from simlib import PortSim, RefSim, write_cmf_parts
 from rlgymppo_cpp_amd.state import ArenaState
 
 which, name = sys.argv[1], sys.argv[2]
-gold = np.load(os.path.join(ROOT, "tests", "golden", "seam_golden.npz" if which == "seam" else "sim_golden.npz"))
+gold = np.load(os.path.join(ROOT, "tests", "golden", {"seam": "seam_golden.npz", "tess": "tess_golden.npz"}.get(which, "sim_golden.npz")))
 if which == "gym":
     # a recorded gym rollout as a control tape, up to its first episode end: Gym::Step runs ONE tick on the previous step's controls, takes
     # the GameState, then sets the new controls and runs tickSkip - 1 more (Gym.cpp:68-102); the first step's "previous" controls are zeros
@@ -33,7 +33,7 @@ else:
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else len(tape)
 verts, tris = gold["mesh_verts"], gold["mesh_tris"]
 port = PortSim()
-if which == "seam":
+if which in ("seam", "tess"):
     parts = gold["mesh_parts"]; port.set_mesh(verts, tris, parts)
     root = tempfile.mkdtemp(prefix="rawdiv_"); write_cmf_parts(verts, tris, parts, root)
     ref = RefSim(verts, tris, mesh_dir=root)
