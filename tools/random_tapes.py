@@ -26,6 +26,8 @@ for seed in range(seed0, seed0 + n_tapes):
     team = 1 + seed % 3; nc = 2 * team
     k0 = ref.arena(team); ref.lib.ref_arena_reset_kickoff(k0, seed); s0 = ref.get_state(k0); ref.lib.ref_arena_free(k0)
     a = ref.arena(team)
+    if len(sys.argv) > 5:      # hunt: full tanks -- a demolition needs a SUPERSONIC attacker (Arena.cpp:372-385), which a kickoff's 33 boost does not buy
+        for k in range(nc): s0.cars[k].boost = 100.0
     if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
     ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
     tape = np.zeros((ticks, nc, 8), np.float32)
@@ -50,8 +52,11 @@ for seed in range(seed0, seed0 + n_tapes):
                     o = min(opp, key=lambda q: (q.pos[0] - me.pos[0]) ** 2 + (q.pos[1] - me.pos[1]) ** 2)
                     dx, dy = o.pos[0] - me.pos[0], o.pos[1] - me.pos[1]
                     fx, fy = me.rot[0], me.rot[1]          # forward axis = the first three floats of rot[9] (RlgpuCarState: forward, right, up)
-                    cross = fx * dy - fy * dx
-                    c[1] = -1.0 if cross > 0 else 1.0
+                    cross = fx * dy - fy * dx; along = fx * dx + fy * dy
+                    ang = float(np.arctan2(cross, along))          # the opponent's bearing, left positive
+                    c[1] = float(np.clip(-2.0 * ang, -1.0, 1.0))    # steer towards it (a bang-bang steer never lines the bumper up)
+                    c[6] = 1.0 if abs(ang) < 0.6 else 0.0           # boost when it is ahead
+                    c[7] = 1.0 if abs(ang) > 1.5 else 0.0           # powerslide around when it is behind
                 tape[t, k] = c
                 dm = bool(me.flags & (1 << 13)); n_demo += dm and not was[k]; was[k] = dm
         for k in range(nc):
