@@ -84,15 +84,25 @@ int main() {
         socklen_t al = sizeof a; CHECK(getsockname(rx, (sockaddr*)&a, &al) == 0);
         timeval tv{2, 0}; setsockopt(rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
         RenderSender rs("127.0.0.1", ntohs(a.sin_port));
+        // (the GameState of tests/golden/make_sender_golden.py: its datagram, produced by the reference's own render_receiver.py, is compared in Python)
         GameState gs; gs.players.resize(2); gs.players[0].carId = 1; gs.players[1].carId = 2; gs.players[1].team = Team::ORANGE;
-        gs.ball.pos = Vec(1, 2, 93.15f); gs.players[1].phys.pos = Vec(-100, 250.5f, 17); gs.players[1].boostFraction = 0.5f; gs.boostPads[3] = true;
+        for (PhysObj* q : {&gs.ball, &gs.players[0].phys, &gs.players[1].phys}) { q->pos = q->vel = q->angVel = Vec(0, 0, 0); q->rotMat.forward = Vec(1, 0, 0); q->rotMat.right = Vec(0, 1, 0); q->rotMat.up = Vec(0, 0, 1); }
+        gs.ball.pos = Vec(1, 2, 93.15f); gs.ball.vel = Vec(-2300.f, 1e16f, 123456789.f); gs.ball.angVel = Vec(0, 0, 6);
+        PlayerData& p1 = gs.players[1];
+        p1.phys.pos = Vec(-100, 250.5f, 17); p1.phys.rotMat.forward = Vec(0.6f, -0.8f, 0); p1.phys.rotMat.right = Vec(0.8f, 0.6f, 0);
+        p1.phys.vel = Vec(1234.5678f, -0.0001f, 1e-5f); p1.phys.angVel = Vec(0.1f, -5.5f, 2.25f);
+        p1.boostPickups = 3; p1.carState.isDemoed = true; p1.carState.isOnGround = true; p1.ballTouchedStep = true; p1.hasFlip = true; p1.boostFraction = 0.33f;
+        gs.players[0].boostFraction = 0.f; gs.players[0].hasFlip = false; gs.players[0].carState.isOnGround = false;
+        gs.boostPads[3] = true;
         rs.Send(gs, ActionSet(2));
         char buf[8192]; ssize_t n = recv(rx, buf, sizeof buf, 0);
         CHECK(n > 0);
         std::string got(buf, (size_t)n), want = RenderSender::ToJSON(gs, ActionSet(2));
         CHECK(got == want && rs.sent == 1);
-        CHECK(got.find("\"gamemode\": \"soccar\"") == 1 && got.find("\"ball_phys\": {\"pos\": [1, 2, 93.1500015]") != std::string::npos);
-        CHECK(got.find("\"team_num\": 1") != std::string::npos && got.find("\"boost_amount\": 0.5") != std::string::npos);
+        CHECK(got.find("\"gamemode\": \"soccar\"") == 1 && got.find("\"pos\": [1.0, 2.0, 93.1500015258789]") != std::string::npos);
+        CHECK(got.find("\"team_num\": 1") != std::string::npos && got.find("\"boost_amount\": 0.33000001311302185") != std::string::npos);
+        CHECK(RenderSender::PyFloat(1e-5f) == "9.999999747378752e-06" && RenderSender::PyFloat(-0.0001f) == "-9.999999747378752e-05" && RenderSender::PyFloat(1e16f) == "1.0000000272564224e+16"
+              && RenderSender::PyFloat(123456789.f) == "123456792.0" && RenderSender::PyFloat(0.5f) == "0.5" && RenderSender::PyFloat(-0.f) == "-0.0" && RenderSender::PyFloat(1e22f) == "9.999999778196308e+21");
         std::printf("render datagram: %s\n", got.c_str());
         close(rx);
     }

@@ -31,12 +31,21 @@ def test_host_api_translation_and_utils(tmp_path):
     recs = [json.loads(l) for l in open(mfile)]
     assert recs[0]["_run"] == {"project": "proj", "group": "grp", "name": 'run "7"', "id": os.path.basename(mfile)[:-6]}
     assert recs[1]["Policy Entropy"] == 4.25 and recs[1]["Cumulative Timesteps"] == 1234567 and recs[1]["bad"] is None
-    dgram = json.loads([l for l in r.stdout.splitlines() if l.startswith("render datagram: ")][0][len("render datagram: "):])
-    assert set(dgram) == {"gamemode", "ball_phys", "cars", "boost_pad_states"} and set(dgram["ball_phys"]) == {"pos", "vel", "ang_vel"}   # render_receiver.py:20-33
+    # F3: the datagram is, BYTE FOR BYTE, what the reference's own render_receiver.py sends for this GameState (tests/golden/sender_golden.json,
+    # recorded by make_sender_golden.py from /root/reference/RLGymPPO_CPP/python_scripts/render_receiver.py with the socket captured)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "sender_golden.json")))
+    got = [l for l in r.stdout.splitlines() if l.startswith("render datagram: ")][0][len("render datagram: "):]
+    assert got == golden["render"]["datagram"], (got, golden["render"]["datagram"])
+    dgram = json.loads(got)
     assert len(dgram["boost_pad_states"]) == 34 and dgram["boost_pad_states"][3] is True and dgram["cars"][1]["phys"]["pos"] == [-100, 250.5, 17]
-    assert set(dgram["cars"][0]) == {"car_id", "team_num", "phys", "boost_pickups", "is_demoed", "on_ground", "ball_touched", "has_flip", "boost_amount"}
-    t = _run([sys.executable, os.path.join(ROOT, "tools", "metric_receiver.py"), mfile, "--once", "--dry-run"])
-    assert t.returncode == 0 and t.stdout.count("log {") == 2 and "init {" in t.stdout and "'bad'" not in t.stdout, t.stdout
+    # ... and the wandb side-car makes, call for call, the calls the reference's metric_receiver.py makes for a resumed run with this report
+    t = _run([sys.executable, os.path.join(ROOT, "tools", "metric_receiver.py"), mfile, "--once", "--record-calls"])
+    assert t.returncode == 0, t.stdout
+    calls = json.loads(t.stdout.strip().splitlines()[-1])
+    want = golden["metric"]["calls"]
+    rid = os.path.basename(mfile)[:-6]
+    assert calls[0] == ["init", dict(want[0][1], id=rid)]                        # (the run id is the sender's: a new run's too, where the reference lets wandb choose)
+    assert calls[1] == want[1] and calls[2] == want[1] and len(calls) == 3       # the report, NaN included, as MetricSender.cpp:31-44 hands it over
 
 
 def test_portable_libm_is_the_c_librarys_bit_for_bit(tmp_path):

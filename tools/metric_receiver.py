@@ -21,10 +21,20 @@ def main():
     ap.add_argument("path")
     ap.add_argument("--once", action="store_true")
     ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--record-calls", action="store_true", help="(tests) make the calls on a stand-in for wandb and print them as one JSON line")
     args = ap.parse_args()
     run = None
     wandb = None
-    if not args.dry_run:
+    recorded = []
+    if args.record_calls:
+        class _Run:
+            def log(self, d): recorded.append(["log", {k: (repr(v) if isinstance(v, float) else v) for k, v in d.items()}])
+
+        class _Wandb:
+            @staticmethod
+            def init(**kw): recorded.append(["init", dict(kw)]); return _Run()
+        wandb = _Wandb
+    elif not args.dry_run:
         try:
             import wandb
         except Exception as e:  # same failure mode as the reference receiver: say which interpreter lacks wandb
@@ -52,11 +62,14 @@ def main():
                 else:
                     run = wandb.init(project=d["project"], group=d["group"], name=d["name"], id=d["id"], resume="allow")
                 continue
-            rec = {k: v for k, v in rec.items() if v is not None}
+            # a NaN metric is a null in the file (JSON has no NaN); the reference hands wandb the NaN itself (MetricSender.cpp:31-44)
+            rec = {k: (float("nan") if v is None else (float(v) if isinstance(v, int) and not isinstance(v, bool) else v)) for k, v in rec.items()}
             if args.dry_run:
                 print("log", rec)
             elif run is not None:
                 run.log(rec)
+    if args.record_calls:
+        print(json.dumps(recorded))
 
 
 if __name__ == "__main__":
