@@ -116,26 +116,26 @@ RLG_HD void manifold_finish_static(Contact& c, const Body& a, V3 b_origin) {
 // point accepted at depth <= 0.040624548 and refreshed to 0.04062467.)  The callbacks that fired when the point was added stay fired.
 // Returns the number of points left.
 RLG_HD int manifold_refresh_static(Contact* pts, int count, const Body& a, V3 b_origin, float breaking) {
-    V3 wa[4], wb[4];
+    // one pass, last point first: the refresh's first loop touches every point by itself, and when its second loop looks at point i the points
+    // behind it are final already -- so a removed point's place is taken by the finished last one, as removeContactPoint does it
     for (int i = count - 1; i >= 0; i--) {
-        wa[i] = (a.rot * pts[i].ra) + a.pos;
-        wb[i] = (pts[i].rb - b_origin) + b_origin;
-        pts[i].dist = dot(wa[i] - wb[i], pts[i].n);
-    }
-    for (int i = count - 1; i >= 0; i--) {
-        bool drop = !(pts[i].dist <= breaking);
+        const V3 n = pts[i].n;
+        const V3 wa = (a.rot * pts[i].ra) + a.pos;
+        const V3 wb = (pts[i].rb - b_origin) + b_origin;
+        const float dist = dot(wa - wb, n);
+        bool drop = !(dist <= breaking);
         if (!drop) {
-            const V3 projected = wa[i] - pts[i].n * pts[i].dist;
-            const V3 diff = wb[i] - projected;
+            const V3 projected = wa - n * dist;
+            const V3 diff = wb - projected;
             drop = dot(diff, diff) > breaking * breaking;
         }
         if (drop) {
-            const int last = count - 1;
-            if (i != last) { pts[i] = pts[last]; wa[i] = wa[last]; wb[i] = wb[last]; }
+            if (i != count - 1) pts[i] = pts[count - 1];
             count--;
+        } else {
+            pts[i].ra = wa - a.pos; pts[i].rb = wb; pts[i].dist = dist;
         }
     }
-    for (int i = 0; i < count; i++) { pts[i].ra = wa[i] - a.pos; pts[i].rb = wb[i]; }
     return count;
 }
 // both bodies dynamic: pa_w / pb_w are the world points the algorithm reported

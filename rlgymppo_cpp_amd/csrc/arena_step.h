@@ -297,6 +297,7 @@ RLG_HD_T4 void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, Col
 // the end-of-algorithm refresh of a body's <= 2 mesh manifolds (points [0, first) and [first, n)): distances and world points rebuilt, points that
 // fail the refresh removed (manifold_refresh_static), the second manifold moved down behind what is left of the first; sets sid.  Returns the new n.
 RLG_HD int refresh_mesh_manifolds(Contact* out, int n, int first, const Body& b, float breaking) {
+    if (n == 0) return 0;
     const int c0 = manifold_refresh_static(out, first, b, v3(0, 0, 0), breaking);
     const int c1 = manifold_refresh_static(out + first, n - first, b, v3(0, 0, 0), breaking);
     if (c0 != first) for (int k = 0; k < c1; k++) out[c0 + k] = out[first + k];
