@@ -28,6 +28,7 @@
 #include "infer_device.h"
 #include "rlgpu_internal.h"
 #include "mlp_stripe.h"
+#include "ppo_fused.h"
 
 namespace {
 using rlinfer::HeadArgs;
@@ -1169,6 +1170,106 @@ int stripe_launch(rlgpu_learner* l, bool backward, int rows) {
         for (int i = backward ? 1 : 0; i < n->n_layers; i++) l->last_flops += 2.0 * rows * (double)n->dims[i] * n->dims[i + 1];
     return RLGPU_OK;
 }
+// ---- the fused path (ppo_fused.h): gather + forward + loss + dX chain of both networks in ONE launch, every dW / db in a second one -------------
+bool fused_capable(const rlgpu_learner* l) {
+    static const bool off = std::getenv("RLGPU_NO_FUSED") != nullptr;
+    if (off || !l->cfg.use_bf16) return false;
+    for (const Net* n : {&l->pol, &l->cri}) {
+        if (n->n_layers != 4) return false;
+        for (int i = 1; i <= 3; i++) if (n->dims[i] != fused::H) return false;
+    }
+    const int k0 = l->pol.kp[0];
+    if (k0 != l->cri.kp[0] || (k0 != 96 && k0 != 128 && k0 != 192)) return false;   // 1v1 / 2v2-padded / 3v3-padded observation rows
+    return l->pol.kp[4] == 96 && l->cri.dims[4] == 1;
+}
+template <int K0P>
+int fused_launch_t(rlgpu_learner* l, const fused::Args& a, dim3 grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_ppo_fwd_bwd<K0P, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::SMEM_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((fused::k_ppo_fwd_bwd<K0P, 96>), grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
+    LCHK(l, hipGetLastError());
+    return RLGPU_OK;
+}
+int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, const float* old_logp, const float* adv, const float* targets,
+                    const int32_t* idx, int n, float ratio, float* metrics) {
+    int rc = refresh_shadows(l);
+    if (rc) return rc;
+    fused::Args a{};
+    a.obs = obs; a.idx = idx; a.rows = n; a.D = l->cfg.obs_size; a.x16 = l->x16;
+    a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.targets = targets;
+    a.inv_temp = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f); a.clip = l->cfg.clip_range; a.ent_coef = l->cfg.ent_coef;
+    a.scale = ratio / (float)n; a.metrics = metrics;
+    static const int fz_debug = std::getenv("RLGPU_FZ_DEBUG") ? std::atoi(std::getenv("RLGPU_FZ_DEBUG")) : 0;
+    a.debug = fz_debug;
+    fused::DwArgs d{};
+    d.rows = n;
+    static const int slab_env = std::getenv("RLGPU_DW_SLAB") ? std::atoi(std::getenv("RLGPU_DW_SLAB")) : 0;
+    d.slab = slab_env > 0 ? (slab_env + 31) / 32 * 32 : 2048;   // measured: the fp32 atomics of a flush cost 173 us per minibatch at 512 rows, 33 at 2048
+    static const int dw_debug = std::getenv("RLGPU_DW_DEBUG") ? std::atoi(std::getenv("RLGPU_DW_DEBUG")) : 0;
+    d.debug = dw_debug;
+    int w = 0;
+    for (const Net* nn : {&l->pol, &l->cri}) {
+        fused::NetArgs& s = a.net[w];
+        const std::vector<short*>& acts = w == 0 ? l->act16_p : l->act16_c;
+        for (int i = 0; i < 4; i++) {
+            s.wf[i] = l->shadows + nn->wf16_off[i]; s.wtf[i] = l->shadows + nn->wtf16_off[i]; s.bias[i] = l->params + nn->b_off[i];
+            if (i < 3) s.act[i] = acts[i];
+            s.dy[i] = l->dy16[w][i];
+            fused::DwLayer& L = d.L[w][i];
+            L.Y = l->dy16[w][i]; L.ldy = nn->kp[i + 1]; L.X = i == 0 ? l->x16 : acts[i - 1]; L.ldx = nn->kp[i];
+            L.Mo = nn->dims[i + 1]; L.No = nn->dims[i]; L.dW = l->grads + nn->w_off[i]; L.db = l->grads + nn->b_off[i];
+            l->last_flops += (i > 0 ? 6.0 : 4.0) * n * (double)nn->dims[i] * nn->dims[i + 1];   // forward + dW (+ dX above layer 0)
+        }
+        s.out_dim = nn->dims[4];
+        w++;
+    }
+    // The two kernels alternate over chunks of rows (RLGPU_FUSED_CHUNK, 0 = the whole minibatch at once): what the first writes for a chunk is
+    // still in the last-level cache when the second reads it
+    static const int chunk_env = std::getenv("RLGPU_FUSED_CHUNK") ? std::atoi(std::getenv("RLGPU_FUSED_CHUNK")) : 0;
+    const int chunk = chunk_env > 0 ? (chunk_env + fused::R - 1) / fused::R * fused::R : n;
+    static const bool prof_on = std::getenv("RLGPU_FUSED_PROF") != nullptr;   // (tools only, with a -DFZ_PROF build: per-phase cycles of k_ppo_fwd_bwd, printed every 16 calls)
+    static unsigned long long* prof_buf = nullptr; static int prof_calls = 0;
+    if (prof_on) {
+        if (!prof_buf) { LCHK(l, hipMalloc(&prof_buf, 32 * 8)); LCHK(l, hipMemset(prof_buf, 0, 32 * 8)); }
+        a.prof = prof_buf;
+    }
+    static bool dw_attr = false;
+    if (!dw_attr) {
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_dw_grouped), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::DW_SMEM_BYTES));
+        dw_attr = true;
+    }
+    const dim3 grid_all((n + fused::R - 1) / fused::R, 2);
+    for (int r0 = 0; r0 < n; r0 += chunk) {
+        const int r1 = std::min(n, r0 + chunk);
+        a.row0 = r0; a.rows = r1; d.row0 = r0; d.rows = r1;
+        const dim3 grid((r1 - r0 + fused::R - 1) / fused::R, 2);
+        switch (l->pol.kp[0]) {
+            case 96: rc = fused_launch_t<96>(l, a, grid); break;
+            case 128: rc = fused_launch_t<128>(l, a, grid); break;
+            default: rc = fused_launch_t<192>(l, a, grid); break;
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(fused::k_dw_grouped, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
+        LCHK(l, hipGetLastError());
+    }
+    const dim3 grid = grid_all;
+    if (prof_on && ++prof_calls % 16 == 0) {
+        unsigned long long h[32];
+        LCHK(l, hipDeviceSynchronize()); LCHK(l, hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost)); LCHK(l, hipMemset(prof_buf, 0, 32 * 8));
+        const double wg = 16.0 * grid.x;
+        static const char* names[10] = {"gather", "L0", "L1", "L2", "L3", "loss", "bwd3", "bwd2", "bwd1", "store dy0"};
+        for (int net = 0; net < 2; net++) {
+            fprintf(stderr, "k_ppo_fwd_bwd %s cycles/workgroup:", net ? "critic" : "policy");
+            double tot = 0;
+            for (int k = 0; k < 10; k++) { fprintf(stderr, " %s %.0f", names[k], h[net * 16 + k] / wg); tot += h[net * 16 + k] / wg; }
+            fprintf(stderr, " | sum %.0f\n", tot);
+        }
+    }
+    return RLGPU_OK;
+}
 // dW / db of every layer of one network from the stored activations and activation gradients (the TN GEMMs of net_backward16)
 int net_dw16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16, int rows, int which, hipStream_t st) {
     for (int i = net.n_layers - 1; i >= 0; i--) {
@@ -1418,7 +1519,9 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     const bool fast = l->cfg.use_bf16 != 0;
     const float* x = obs;
     int rc;
-    if (fast) {
+    const bool use_fused = fast && fused_capable(l);   // (gathers by itself, inside the timed section)
+    if (use_fused) {
+    } else if (fast) {
         if ((rc = stage_input16(l, obs, idx, n))) return rc;   // gather + bf16 conversion in one pass
     } else if (idx) {
         size_t tot = (size_t)n * D;
@@ -1445,7 +1548,9 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
     const float inv_t = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f);
     const int loss_blocks = std::max(1, std::min(2048, (n + 3) / 4));
     const int vloss_blocks = std::max(1, std::min(1024, (n + 255) / 256));
-    if (fast && stripe_capable(l)) {
+    if (use_fused) {
+        if ((rc = fused_minibatch(l, obs, actions, old_logp, adv, targets, idx, n, ratio, metrics))) return rc;
+    } else if (fast && stripe_capable(l)) {
         // mlp_stripe.h: forward of both networks in ONE launch (activations in LDS from layer to layer), the two loss kernels, the dX chain of
         // both networks in ONE launch, then the eight dW GEMMs -- the policy's and the critic's on a stream each
         if ((rc = refresh_shadows(l))) return rc;
