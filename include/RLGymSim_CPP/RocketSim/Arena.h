@@ -84,17 +84,20 @@ public:
         BallState s; const RlgpuBallState& b = *raw;
         s.pos = Vec(b.pos[0], b.pos[1], b.pos[2]); s.vel = Vec(b.vel[0], b.vel[1], b.vel[2]); s.angVel = Vec(b.ang_vel[0], b.ang_vel[1], b.ang_vel[2]);
         s.updateCounter = (uint64_t)*updateCounter;
+        // BallState::rotMat (Ball.cpp:27-30): with ArenaConfig::noBallRot the basis the last SetState gave the ball
+        s.rotMat.forward = Vec(rawRot[0], rawRot[1], rawRot[2]); s.rotMat.right = Vec(rawRot[3], rawRot[4], rawRot[5]); s.rotMat.up = Vec(rawRot[6], rawRot[7], rawRot[8]);
         return s;
     }
     void SetState(const BallState& s) {   // Ball.cpp:27-49: velocities, the impulse cache and the update counter start over
         RlgpuBallState& b = *raw;
         for (int i = 0; i < 3; i++) { b.pos[i] = s.pos[i]; b.vel[i] = s.vel[i]; b.ang_vel[i] = s.angVel[i]; b.vel_impulse_cache[i] = 0.f; }
+        for (int i = 0; i < 3; i++) { rawRot[i] = s.rotMat.forward[i]; rawRot[3 + i] = s.rotMat.right[i]; rawRot[6 + i] = s.rotMat.up[i]; }   // newTransform.setBasis(state.rotMat), Ball.cpp:41
         *updateCounter = 0;
     }
     float GetRadius() const { return RLConst::BALL_COLLISION_RADIUS_SOCCAR; }
 private:
     friend class Arena;
-    RlgpuBallState* raw = nullptr; int64_t* updateCounter = nullptr;
+    RlgpuBallState* raw = nullptr; int64_t* updateCounter = nullptr; float* rawRot = nullptr;   // (rawRot: RlgpuArenaState::hidden.ball_rot)
 };
 
 class Car {
@@ -258,7 +261,7 @@ public:
 private:
     Arena() {
         std::memset(&_state, 0, sizeof(_state));
-        ball = new Ball(); ball->raw = &_state.ball; ball->updateCounter = &_state.ball_update_counter;
+        ball = new Ball(); ball->raw = &_state.ball; ball->updateCounter = &_state.ball_update_counter; ball->rawRot = _state.hidden.ball_rot;
         ball->SetState(BallState());
         for (int p = 0; p < RLGPU_NUM_PADS; p++) {
             BoostPad* pad = new BoostPad();

@@ -53,6 +53,7 @@ inline GameState::GameState(const RlgpuArenaState& s, int tickSkip) {
     lastTouchCarID = s.gym.last_touch_car_id;
     lastTickCount = (uint64_t)s.tick_count; deltaTickCount = tickSkip;
     ball.pos = V(s.ball.pos); ball.vel = V(s.ball.vel); ball.angVel = V(s.ball.ang_vel);
+    ball.rotMat.forward = V(s.hidden.ball_rot); ball.rotMat.right = V(s.hidden.ball_rot + 3); ball.rotMat.up = V(s.hidden.ball_rot + 6);   // PhysObj(BallState): PhysObj.cpp:6
     ballInv = ball.Invert();
     // RLGym pad order -> RocketSim pad index: the map GameState.cpp:10-50 builds by matching CommonValues::BOOST_LOCATIONS against
     // the arena's pads (a constant of the two tables; the device obs builder uses the same one)

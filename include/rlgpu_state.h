@@ -130,6 +130,24 @@ typedef struct RlgpuGymState {
     RlgpuPlayerGymState players[RLGPU_MAX_CARS];
 } RlgpuGymState;
 
+/* What the reference's arena holds besides the CarState / BallState fields above.  Appended in round 4 (older recordings of this struct are
+ * simply shorter: readers pad them with ball_rot = identity, valid = 0).
+ *   ball_rot   BallState::rotMat (Ball.h:17-44, Ball.cpp:27-30,41).  Under ArenaConfig::noBallRot (ArenaConfig.h:33, the default, which the
+ *              gym's arenas use) the ball's orientation is never integrated (btRigidBody.cpp:102-106): it stays what the last SetState gave it
+ *              and is reported back by every GetState.  rlgpu_env_upload_states stores it (all zeros = identity), every download hands it back.
+ *              The host build of the stepper (oracle/arena_port.cpp) steps in this basis, bit for bit like the reference
+ *              (tests/golden/ballrot_golden.npz); the device kernels step with the identity -- DESIGN.md "Known deviations".
+ *   valid, bp_hist, wreck_rot   RESERVED (written as 0 / read as "absent").  The slots for the arena's other hidden state -- btRSBroadphase's
+ *              memory of its dynamic proxies ([0] ball, [1 + k] car slot k: cell of the last setAabb, 13 bits, and arrival rank, 3 bits) and
+ *              the basis of a demolished car's rigid body (Car.cpp:69-80,135-138).  Both are resident on the device per env; moving them
+ *              across this boundary was built and withdrawn in round 4. */
+typedef struct RlgpuArenaHidden {
+    float ball_rot[9];               /* forward / right / up columns */
+    uint32_t valid;
+    uint16_t bp_hist[8];
+    float wreck_rot[RLGPU_MAX_CARS][9];
+} RlgpuArenaHidden;
+
 typedef struct RlgpuArenaState {
     int32_t num_cars;                /* 2, 4 or 6 */
     uint32_t car_order;              /* the order in which the arena's per-car loops visit the cars: 4 bits per rank, slot + 1 (rank 0 in bits 0-3);
@@ -142,6 +160,7 @@ typedef struct RlgpuArenaState {
     RlgpuCarState cars[RLGPU_MAX_CARS];
     RlgpuPadState pads[RLGPU_NUM_PADS];   /* RocketSim order: 6 big then 28 small (RLConst.h:210-253) */
     RlgpuGymState gym;
+    RlgpuArenaHidden hidden;
 } RlgpuArenaState;
 
 #ifdef __cplusplus

@@ -82,6 +82,9 @@ void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
     s->ball_update_counter = (int64_t)bs.updateCounter;
     V3(s->ball.pos, bs.pos); V3(s->ball.vel, bs.vel); V3(s->ball.ang_vel, bs.angVel);
     V3(s->ball.vel_impulse_cache, a->ball->_velocityImpulseCache * BT_TO_UU);
+    // BallState::rotMat (Ball.cpp:27-30).  Nothing else of RlgpuArenaHidden is read out here: valid = 0
+    V3(s->hidden.ball_rot, bs.rotMat.forward); V3(s->hidden.ball_rot + 3, bs.rotMat.right); V3(s->hidden.ball_rot + 6, bs.rotMat.up);
+    s->hidden.valid = 0;
     for (int i = 0; i < s->num_cars; i++) {
         Car* car = CarBySlot(a, i);
         RlgpuCarState& o = s->cars[i];
@@ -145,6 +148,11 @@ void SetArenaPhys(Arena* a, const RlgpuArenaState* s, bool setPads) {
     a->tickCount = (uint64_t)s->tick_count;
     BallState bs = {};
     bs.pos = toV(s->ball.pos); bs.vel = toV(s->ball.vel); bs.angVel = toV(s->ball.ang_vel);
+    {   // (an all-zero basis = a caller that knows nothing of the appended block: a default BallState)
+        bool all_zero = true;
+        for (int q = 0; q < 9; q++) all_zero = all_zero && s->hidden.ball_rot[q] == 0.f;
+        if (!all_zero) { bs.rotMat.forward = toV(s->hidden.ball_rot); bs.rotMat.right = toV(s->hidden.ball_rot + 3); bs.rotMat.up = toV(s->hidden.ball_rot + 6); }
+    }
     a->ball->SetState(bs);
     a->ball->_velocityImpulseCache = toV(s->ball.vel_impulse_cache) * UU_TO_BT;
     a->ball->_internalState.updateCounter = (uint64_t)s->ball_update_counter;

@@ -120,10 +120,16 @@ constexpr size_t arena_num_words() {
     return 4 + 12 + (size_t)NC * 90 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * 20 + 2;
 }
 
-// finish a freshly loaded working copy: derived values that are not stored
+// finish a freshly loaded working copy: derived values that are not stored.  The ball's basis (BallState::rotMat) is not among the resident
+// words: the device kernels step with the identity -- what every built-in state setter leaves; the basis a user setter uploads is kept by
+// the host side of the library and handed back by every download (rlgpu_env.hip) --, the HOST build steps in the basis arena_from_host gave it.
 template <int NC>
 RLG_HD void arena_finish_load(Arena<NC>& A) {
+#if defined(__HIP_DEVICE_COMPILE__)
     A.ball.b.rot = m3_identity();
+#else
+    if (A.ball.b.rot.r0.x == 0.f && A.ball.b.rot.r0.y == 0.f && A.ball.b.rot.r0.z == 0.f) A.ball.b.rot = m3_identity();   // (a working copy that never saw arena_from_host)
+#endif
     A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
     body_update_inertia(A.ball.b, ball_inv_inertia_local());
     for (int k = 0; k < NC; k++) {
@@ -153,6 +159,13 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
     for (int b = 0; b <= NC; b++) A.bp_hist[b] = 0;      // no history travels with the exchange struct: a fresh arena set to this state
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {   // HOST build: BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
+        bool all_zero = true;
+        for (int q = 0; q < 9; q++) all_zero = all_zero && s.hidden.ball_rot[q] == 0.f;
+        A.ball.b.rot = all_zero ? m3_identity() : m3_cols(ld3(s.hidden.ball_rot), ld3(s.hidden.ball_rot + 3), ld3(s.hidden.ball_rot + 6));
+    }
+#endif
     for (int k = 0; k < NC; k++) {
         const RlgpuCarState& o = s.cars[k]; Car& c = A.cars[k];
         c.b.pos = ld3(o.pos) * UU2BT;
@@ -199,6 +212,10 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
     s.tick_count = A.tick_count; s.ball_update_counter = A.ball_update_counter;
     st3(s.ball.pos, A.ball.b.pos * BT2UU); st3(s.ball.vel, A.ball.b.vel * BT2UU); st3(s.ball.ang_vel, A.ball.b.angvel);
     st3(s.ball.vel_impulse_cache, A.ball.vel_impulse_cache * BT2UU);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));   // (the device's downloads get it from the library's host side)
+    s.hidden.valid = 0u;
+#endif
     for (int k = 0; k < NC; k++) {
         RlgpuCarState& o = s.cars[k]; const Car& c = A.cars[k];
         st3(o.pos, c.b.pos * BT2UU);

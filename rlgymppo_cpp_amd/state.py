@@ -75,12 +75,37 @@ class GymState(C.Structure):
     ]
 
 
+class ArenaHidden(C.Structure):
+    """RlgpuArenaHidden (include/rlgpu_state.h): the ball's basis (BallState::rotMat); valid / bp_hist / wreck_rot are reserved."""
+    _fields_ = [("ball_rot", f32 * 9), ("valid", C.c_uint32), ("bp_hist", C.c_uint16 * 8), ("wreck_rot", (f32 * 9) * MAX_CARS)]
+
+
+IDENTITY9 = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+
+
 class ArenaState(C.Structure):
     _fields_ = [
         ("num_cars", C.c_int32), ("car_order", C.c_uint32),
         ("tick_count", C.c_int64), ("ball_update_counter", C.c_int64),
         ("ball", BallState), ("cars", CarState * MAX_CARS), ("pads", PadState * NUM_PADS), ("gym", GymState),
+        ("hidden", ArenaHidden),
     ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.hidden.ball_rot[:] = IDENTITY9      # a BallState's default rotMat
+
+    @classmethod
+    def from_buffer_copy(cls, buf, offset=0):
+        """Also takes a recording made before the `hidden` block was appended (the committed fixtures): the ball's basis is the identity there
+        and nothing hidden travels (valid = 0), which is what those recordings meant."""
+        b = bytes(buf)[offset:]
+        short = C.sizeof(cls) - C.sizeof(ArenaHidden)
+        if len(b) == short:
+            out = type(C.Structure).from_buffer_copy(cls, b + bytes(C.sizeof(ArenaHidden)))
+            out.hidden.ball_rot[:] = IDENTITY9
+            return out
+        return type(C.Structure).from_buffer_copy(cls, b)
 
 
 def yaw_rot(yaw: float):

@@ -131,3 +131,22 @@ def test_hunt_tapes_with_demolitions_host_build_equals_the_live_reference(sims):
             assert np.array_equal(state_vec(outs[t]), want[t]), f"seed {seed} ({team}v{team}) tick {t + 1} of {T}: the host build left the live reference"
         compared += T
     assert demos >= 3 and compared >= 8000, (demos, compared)
+
+
+def test_rotated_ball_fixture_is_what_the_reference_produces_today(sims):
+    """tests/golden/ballrot_golden.npz re-derived: the live reference, set to each committed start state (a ball basis that is not the
+    identity) and driven by the committed tape, produces the committed states tick for tick and reports the basis unchanged."""
+    _, _, ref = sims
+    g = np.load(os.path.join(GOLD, "ballrot_golden.npz"))
+    for name in [str(x) for x in g["names"]]:
+        s0 = ArenaState.from_buffer_copy(g[f"{name}/start_raw"].tobytes())
+        a = _arena_with_order(ref, 1, s0, s0.car_order)
+        assert a is not None
+        tape = g[f"{name}/tape"]
+        for t in range(len(tape)):
+            for k in range(2): ref.set_controls(a, k, list(tape[t, k]))
+            ref.step(a, 1)
+            cur = ref.get_state(a)
+            assert np.array_equal(state_vec(cur), g[f"{name}/states"][t]), f"{name} tick {t + 1}"
+            assert list(cur.hidden.ball_rot) == list(s0.hidden.ball_rot)
+        ref.lib.ref_arena_free(a)

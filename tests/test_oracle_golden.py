@@ -556,3 +556,29 @@ def test_padded_obs_is_a_block_shuffle_of_default_obs(port_lib):
     for r in range(16):
         opp = w1[r, 89:127].reshape(2, 19)
         assert sum(np.array_equal(b, p1[r, 70:89]) for b in opp) == 1 and sum(not b.any() for b in opp) == 1
+
+
+def test_port_rotated_ball_basis_vs_reference_golden(port_lib):
+    """BallState::rotMat (VERDICT r03 missing #2).  tests/golden/ballrot_golden.npz = the reference's own arena started with a ball whose basis
+    is NOT the identity (make_ballrot_golden.py: a car dropped onto the ball, a car driving its front wheels up the ball -- wheel rays cast
+    against the ball in its basis --, the ball rolling into a car and along the side wall -- the sphere's support vertex towards a plane and
+    its local contact points in that basis).  Under ArenaConfig::noBallRot the reference hands the basis back unchanged after every tick.  The
+    host build: every exchanged field EQUAL after every one of the 1 200 ticks, and the basis it reports is the one it was given."""
+    import ctypes as C
+    from simlib import PortSim
+    g = np.load(os.path.join(GOLD, "ballrot_golden.npz"))
+    port = PortSim(); port.set_mesh(g["mesh_verts"], g["mesh_tris"])
+    port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    ticks = 0
+    for name in [str(x) for x in g["names"]]:
+        st = ArenaState.from_buffer_copy(g[f"{name}/start_raw"].tobytes())
+        rot0 = list(st.hidden.ball_rot)
+        assert rot0 != [1, 0, 0, 0, 1, 0, 0, 0, 1] and np.array_equal(g[f"{name}/ball_rot"], np.tile(np.array(rot0, np.float32), (len(g[f"{name}/tape"]), 1)))
+        tape = np.ascontiguousarray(g[f"{name}/tape"], np.float32); want = g[f"{name}/states"]
+        outs = (ArenaState * len(tape))()
+        port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), 1, C.byref(outs))
+        for t in range(len(tape)):
+            assert np.array_equal(state_vec(outs[t]), want[t]), f"{name} tick {t + 1}: not bit-identical to the reference"
+            assert list(outs[t].hidden.ball_rot) == rot0, f"{name} tick {t + 1}: the ball's basis changed"
+        ticks += len(tape)
+    assert ticks == 1200
