@@ -229,7 +229,7 @@ def main():
         "ppo_iter_ms": m["ppo_iter_ms"], "gym_steps_per_s": m["value"] / n_p, "physics_ticks_per_s": m["value"] / n_p * 8,
         "collect_ms_per_iter": m["ms_per_step"] - m["ppo_iter_ms"],
         "roofline": roof,
-        "mfma": {"kernels": "k_gemm fwd+bwd of policy and critic inside rlgpu_ppo_minibatch (incl. loss kernels)", "achieved_tflops": tflops, "peak_tflops": peak_tflops,
+        "mfma": {"kernels": "rlgpu_ppo_minibatch: k_ppo_fwd_bwd (gather + forward + loss + dX chain of both networks) + k_dw_grouped (every dW / db), csrc/ppo_fused.h", "achieved_tflops": tflops, "peak_tflops": peak_tflops,
                  "ms_total": m["gemm_ms_total"], "calls": m["gemm_calls"], "frac": tflops / peak_tflops},
         # multi-GPU audit trail (bench_main): RCCL ranks that took part (0 = no communicator), each rank's own ms per iteration, one gradient all-reduce
         "rccl_ranks": m.get("rccl_ranks", 0), "rank_ms_per_step": m.get("rank_ms_per_step", []),
