@@ -422,6 +422,76 @@ __global__ void __launch_bounds__(512) k_ppo_fwd_bwd(Args g) {
     else stripe_body<K0P, 32, false>(g, g.net[1], buf0, buf1, red);
 }
 
+// ---- the value pass (Learner::AddNewExperience, Learner.cpp:296-316: valueNet->Forward over every row of the iteration) -----------------------
+// The critic's forward chain of a 128-row stripe with the activations in LDS, as in k_ppo_fwd_bwd, and nothing written but the values:
+// was k_mlp_infer (32 rows per workgroup, the 350 KB of weights streamed once per 32 rows).
+struct ValueArgs { const float* obs; int rows; int D; const short* wf[4]; const float* bias[4]; float* values; };
+
+template <int K0P>
+__global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
+    extern __shared__ __attribute__((aligned(16))) short fz_smem[];
+    constexpr int NK0 = K0P / 16, NKH = H / 16;
+    short* buf0 = fz_smem;
+    short* buf1 = fz_smem + R * LD;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * R;
+    Fr<NK0> f0; load_fr(f0, g.wf[0], w, lane);
+    {   // rows -> bf16 (the gather of stripe_body without an index list)
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+        const int row = tid >> 2, sub = tid & 3, gm = m0 + row;
+        const bool valid = gm < g.rows;
+        const float* src = g.obs + (size_t)(valid ? gm : g.rows - 1) * g.D;
+        const int full = g.D >> 3;
+        F4 va[K0P / 32], vb[K0P / 32]; float tail[8];
+#pragma unroll
+        for (int jj = 0; jj < K0P / 32; jj++) {
+            const int pi = sub + 4 * jj, pc = pi < full ? pi : full - 1;
+            va[jj] = *reinterpret_cast<const F4*>(src + pc * 8); vb[jj] = *reinterpret_cast<const F4*>(src + pc * 8 + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) tail[q] = src[full * 8 + q < g.D ? full * 8 + q : g.D - 1];
+#pragma unroll
+        for (int jj = 0; jj < K0P / 32; jj++) {
+            const int pi = sub + 4 * jj, c0 = pi * 8;
+            float x[8] = {va[jj].x, va[jj].y, va[jj].z, va[jj].w, vb[jj].x, vb[jj].y, vb[jj].z, vb[jj].w};
+            bf16x8 v;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float e = pi < full ? x[q] : ((pi == full && c0 + q < g.D) ? tail[q] : 0.f);
+                v[q] = valid ? f2bf_(e) : (short)0;
+            }
+            *reinterpret_cast<bf16x8*>(buf0 + row * LD + c0) = v;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[RT];
+    Fr<NKH> f1, f2, f3;
+    load_fr(f1, g.wf[1], w, lane);
+    f32x16 bi = load_bias(g.bias[0], w, lane);
+    mma_tiles<NK0>(f0, buf0, lane, bi, acc);
+    epilogue_hidden(acc, w, buf1, lane);
+    __syncthreads();
+    load_fr(f2, g.wf[2], w, lane);
+    bi = load_bias(g.bias[1], w, lane);
+    mma_tiles<NKH>(f1, buf1, lane, bi, acc);
+    epilogue_hidden(acc, w, buf0, lane);
+    __syncthreads();
+    load_fr(f3, g.wf[3], 0, lane);                   // the last layer has ONE feature block (the value in column 0): row tile w of wavefronts 0..3
+    bi = load_bias(g.bias[2], w, lane);
+    mma_tiles<NKH>(f2, buf0, lane, bi, acc);
+    epilogue_hidden(acc, w, buf1, lane);
+    __syncthreads();
+    if (w < RT) {
+        f32x16 a1 = zero16();
+        const short* brow = buf1 + (w * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < NKH; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f3.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1, 0, 0, 0);
+        // feature 0 of the block = register 0 of the lanes 0..31 (features 4 (lane >> 5) + ...: the lower half holds feature 0)
+        const int gm = m0 + w * 32 + (lane & 31);
+        if (lane < 32 && gm < g.rows) g.values[gm] = a1[0] + g.bias[3][0];
+    }
+}
+
 // ---- grouped dW ---------------------------------------------------------------------------------------------------------------------------
 constexpr int DBK = 32;          // rows per step
 constexpr int DLD = 288;         // LDS row of the 256-wide k-major tiles (576 B = 16 banks mod 64 per k row: the transposing read's 4 rows x 4 column-quads x 2 groups hit 64 distinct banks)

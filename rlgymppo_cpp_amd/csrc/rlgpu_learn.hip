@@ -1478,6 +1478,24 @@ int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* val
     // one fused launch; it also keeps this call off the activation scratch, so it may run on another stream than a PPO epoch
     // (collectionDuringLearn).  RLGPU_FUSED_VALUE_ROWS caps the row count that takes this path (experiments).
     static const int fused_cap = getenv("RLGPU_FUSED_VALUE_ROWS") ? atoi(getenv("RLGPU_FUSED_VALUE_ROWS")) : 0x7fffffff;
+    static const bool no_stripe_value = getenv("RLGPU_NO_VALUE_STRIPE") != nullptr;
+    if (!no_stripe_value && fused_capable(l) && rows >= 4 * fused::R) {
+        // the critic's forward chain per 128-row stripe (ppo_fused.h k_value_stripe): the weights are streamed once per 128 rows instead of once per 32
+        if ((rc = refresh_shadows(l))) return rc;
+        fused::ValueArgs a{};
+        a.obs = obs; a.rows = rows; a.D = l->cfg.obs_size; a.values = values;
+        for (int i = 0; i < 4; i++) { a.wf[i] = l->shadows + l->cri.wf16_off[i]; a.bias[i] = l->params + l->cri.b_off[i]; }
+        const dim3 grid((rows + fused::R - 1) / fused::R);
+        static bool attr[3] = {false, false, false};
+        const int which = l->cri.kp[0] == 96 ? 0 : (l->cri.kp[0] == 128 ? 1 : 2);
+        const void* fn = which == 0 ? reinterpret_cast<const void*>(&fused::k_value_stripe<96>) : (which == 1 ? reinterpret_cast<const void*>(&fused::k_value_stripe<128>) : reinterpret_cast<const void*>(&fused::k_value_stripe<192>));
+        if (!attr[which]) { LCHK(l, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::SMEM_BYTES)); attr[which] = true; }
+        if (which == 0) hipLaunchKernelGGL(fused::k_value_stripe<96>, grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
+        else if (which == 1) hipLaunchKernelGGL(fused::k_value_stripe<128>, grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
+        else hipLaunchKernelGGL(fused::k_value_stripe<192>, grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
+        LCHK(l, hipGetLastError());
+        return RLGPU_OK;
+    }
     if (rows <= fused_cap && fused_infer_fits(l, l->cri, 1)) return launch_fused_infer(l, l->cri, obs, rows, 1, values, HeadArgs{});
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), rows); }
     else rc = net_forward(l, l->cri, l->act_c, obs, rows);

@@ -1249,3 +1249,15 @@ def test_hip_rotated_ball_basis_vs_reference_golden():
     exact_at_least = {"rotated_ball_side_wall": 300, "car_drives_up_rotated_ball": 100, "car_dropped_on_rotated_ball": 30, "rotated_ball_into_car": 10}
     for n in names:
         assert first_diff.get(n, len(g[f"{n}/tape"]) + 1) > exact_at_least[n], (n, first_diff.get(n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,obs_size", [(70001, 89), (1000, 127), (513, 165)])
+def test_value_stripe_kernel_against_the_inference_kernel(rows, obs_size):
+    """The value pass of Learner::AddNewExperience (Learner.cpp:296-316) at the flagship shape: k_value_stripe (csrc/ppo_fused.h: the critic's
+    forward chain per 128-row stripe, activations in LDS, nothing written but the values) against k_mlp_infer (RLGPU_NO_VALUE_STRIPE=1; pinned to
+    the reference's ValueEstimator by tests/test_ref_learner.py in fp32 mode) on a ragged row count, for the three observation widths.  Same
+    bf16 operands and rounding points; the bias is the first addend instead of the last: within 2e-3 of the largest value."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "value_stripe_check.py"), str(rows), str(obs_size)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-3000:]
