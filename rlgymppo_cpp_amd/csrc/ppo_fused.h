@@ -26,7 +26,8 @@ constexpr int NWAVE = 8;         // 512 threads: wavefront w owns the 32-feature
 constexpr int H = 256;           // hidden width this kernel is built for
 constexpr int LD = 264;          // LDS activation row, bf16 elements (528 B: the 16 rows of a ds_read_b128 group land on distinct bank quads)
 constexpr int LDF = 100;         // LDS logits row, floats (400 B: 16 consecutive rows start on distinct bank quads)
-constexpr size_t SMEM_BYTES = (size_t)2 * R * LD * sizeof(short);
+constexpr int BIAS_FLOATS = 3 * H + 128;   // the three hidden layers' biases and the last layer's (zero padded), staged in LDS behind the activation buffers
+constexpr size_t SMEM_BYTES = (size_t)2 * R * LD * sizeof(short) + BIAS_FLOATS * sizeof(float);
 
 struct NetArgs {
     const short* wf[4];          // forward fragments  (k_weight_frags of W   [N pad][kp in])
@@ -90,14 +91,24 @@ __device__ __forceinline__ f32x16 zero16() {
 // C layout of the 32x32 tile with the weights as the A operand: lane l holds row (l & 31) of the row tile and features
 // 8 g + 4 (l >> 5) + j of the block for register 4 g + j
 // hidden layer: relu(acc + bias) -> bf16 -> out[row][cb * 32 + ...], mask bit (rt * 16 + q) = activation > 0
-// the lane's 16 bias values of feature block cb, in accumulator order (scalar loads: a network's parameters start wherever the previous
-// network's end, so the bias is only 4-byte aligned); requested before the layer's MFMAs, whose first step takes them as its C operand
-__device__ __forceinline__ f32x16 load_bias(const float* bias, int cb, int lane) {
+// the lane's 16 bias values of feature block cb, in accumulator order, from the LDS copy (stage_bias): a global load here would sit right in
+// front of the MFMA that takes them as its C operand
+__device__ __forceinline__ f32x16 load_bias(const float* bias_lds, int cb, int lane) {
     f32x16 r;
     const int nb = cb * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int q = 0; q < 16; q++) r[q] = bias[nb + 8 * (q >> 2) + (q & 3)];
+    for (int g = 0; g < 4; g++) {
+        const float4 v = *reinterpret_cast<const float4*>(bias_lds + nb + 8 * g);
+        r[4 * g] = v.x; r[4 * g + 1] = v.y; r[4 * g + 2] = v.z; r[4 * g + 3] = v.w;
+    }
     return r;
+}
+// all four layers' biases -> LDS (hidden layer i at [i * H, + H), the last layer at [3 H, + 128) zero padded); visible after the next barrier
+__device__ __forceinline__ void stage_bias(float* bias_lds, const float* const (&bias)[4], int out_dim, int tid) {
+    for (int i = tid; i < BIAS_FLOATS; i += 512) {
+        const int layer = i / H < 3 ? i / H : 3, k = i - layer * H;
+        bias_lds[i] = (layer < 3 || k < out_dim) ? bias[layer][k] : 0.f;
+    }
 }
 using s16x2 = __attribute__((ext_vector_type(2))) short;
 using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
@@ -204,6 +215,8 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
 #endif
 
     Fr<NK0> f0; load_fr(f0, n.wf[0], w, lane);       // lands under the gather
+    float* const bias_lds = reinterpret_cast<float*>(buf0 + 2 * R * LD);
+    stage_bias(bias_lds, n.bias, n.out_dim, tid);
     // the loss's per-row inputs, requested now (policy: row tid >> 2, as the loss phase deals the rows; critic: row tid)
     int pre_a = 0; float pre_olp = 0.f, pre_adv = 0.f, pre_tgt = 0.f;
     {   // gather + bf16 staging: four lanes per row, pieces of 8 columns.  Every load is unconditional, so that all of a lane's loads are in flight
@@ -247,13 +260,13 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
     // fragment requests come before the copy's stores: memory operations retire in order, so a store issued first would gate them.
     Fr<NKH> f1, f2, f3, f3b;
     load_fr(f1, n.wf[1], w, lane);
-    f32x16 bi = load_bias(n.bias[0], w, lane);
+    f32x16 bi = load_bias(bias_lds, w, lane);
     if (!FZ_DBG(2)) mma_tiles<NK0>(f0, buf0, lane, bi, acc);
     const Mask mask0 = epilogue_hidden(acc, w, buf1, lane);
     __syncthreads();
     stamp(1);
     load_fr(f2, n.wf[2], w, lane);
-    bi = load_bias(n.bias[1], w, lane);
+    bi = load_bias(bias_lds + H, w, lane);
     if (!FZ_DBG(1)) copy_out<H>(buf1, n.act[0], m0, g.rows, tid);
     if (!FZ_DBG(2)) mma_tiles<NKH>(f1, buf1, lane, bi, acc);
     const Mask mask1 = epilogue_hidden(acc, w, buf0, lane);
@@ -261,7 +274,7 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
     stamp(2);
     // last-layer tiles t = w, w + 8 (feature block t / RT, row tile t % RT); fragments of a block that does not exist are clamped (loaded, unused)
     load_fr(f3, n.wf[3], (w / RT < OB) ? w / RT : OB - 1, lane);
-    bi = load_bias(n.bias[2], w, lane);
+    bi = load_bias(bias_lds + 2 * H, w, lane);
     if (!FZ_DBG(1)) copy_out<H>(buf0, n.act[1], m0, g.rows, tid);
     if (!FZ_DBG(2)) mma_tiles<NKH>(f2, buf0, lane, bi, acc);
     if (T3 > 1) load_fr(f3b, n.wf[3], ((w + NWAVE) / RT < OB) ? (w + NWAVE) / RT : OB - 1, lane);
@@ -285,16 +298,12 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
 #pragma unroll
             for (int s = 0; s < NKH; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1, 0, 0, 0);
             const int nb = cb * 32 + 4 * (lane >> 5);
-            float bv[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) { const int nn = nb + 8 * (q >> 2) + (q & 3); bv[q] = n.bias[3][nn < n.out_dim ? nn : n.out_dim - 1]; }
             float* zrow = zf + (rt * 32 + (lane & 31)) * LDF + nb;
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
-                const int nn = nb + 8 * gq;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + 3 * H + nb + 8 * gq);      // (zero beyond the layer's outputs)
                 float4 v;
-                v.x = a1[4 * gq + 0] + (nn + 0 < n.out_dim ? bv[4 * gq + 0] : 0.f); v.y = a1[4 * gq + 1] + (nn + 1 < n.out_dim ? bv[4 * gq + 1] : 0.f);
-                v.z = a1[4 * gq + 2] + (nn + 2 < n.out_dim ? bv[4 * gq + 2] : 0.f); v.w = a1[4 * gq + 3] + (nn + 3 < n.out_dim ? bv[4 * gq + 3] : 0.f);
+                v.x = a1[4 * gq + 0] + b4.x; v.y = a1[4 * gq + 1] + b4.y; v.z = a1[4 * gq + 2] + b4.z; v.w = a1[4 * gq + 3] + b4.w;
                 *reinterpret_cast<float4*>(zrow + 8 * gq) = v;
             }
         }
@@ -436,6 +445,8 @@ __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.x * R;
     Fr<NK0> f0; load_fr(f0, g.wf[0], w, lane);
+    float* const bias_lds = reinterpret_cast<float*>(fz_smem + 2 * R * LD);
+    stage_bias(bias_lds, g.bias, 1, tid);
     {   // rows -> bf16 (the gather of stripe_body without an index list)
         struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int row = tid >> 2, sub = tid & 3, gm = m0 + row;
@@ -467,17 +478,17 @@ __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
     f32x16 acc[RT];
     Fr<NKH> f1, f2, f3;
     load_fr(f1, g.wf[1], w, lane);
-    f32x16 bi = load_bias(g.bias[0], w, lane);
+    f32x16 bi = load_bias(bias_lds, w, lane);
     mma_tiles<NK0>(f0, buf0, lane, bi, acc);
     epilogue_hidden(acc, w, buf1, lane);
     __syncthreads();
     load_fr(f2, g.wf[2], w, lane);
-    bi = load_bias(g.bias[1], w, lane);
+    bi = load_bias(bias_lds + H, w, lane);
     mma_tiles<NKH>(f1, buf1, lane, bi, acc);
     epilogue_hidden(acc, w, buf0, lane);
     __syncthreads();
     load_fr(f3, g.wf[3], 0, lane);                   // the last layer has ONE feature block (the value in column 0): row tile w of wavefronts 0..3
-    bi = load_bias(g.bias[2], w, lane);
+    bi = load_bias(bias_lds + 2 * H, w, lane);
     mma_tiles<NKH>(f2, buf0, lane, bi, acc);
     epilogue_hidden(acc, w, buf1, lane);
     __syncthreads();
@@ -488,7 +499,7 @@ __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
         for (int s = 0; s < NKH; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f3.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1, 0, 0, 0);
         // feature 0 of the block = register 0 of the lanes 0..31 (features 4 (lane >> 5) + ...: the lower half holds feature 0)
         const int gm = m0 + w * 32 + (lane & 31);
-        if (lane < 32 && gm < g.rows) g.values[gm] = a1[0] + g.bias[3][0];
+        if (lane < 32 && gm < g.rows) g.values[gm] = a1[0] + bias_lds[3 * H];
     }
 }
 
