@@ -168,7 +168,9 @@ typedef struct RlgpuLearnerConfig {
     int32_t n_critic_layers; int32_t critic_layers[8];   /* criticLayerSizes (:8) */
     float policy_lr, critic_lr, ent_coef, clip_range;    /* :11-15 */
     float temperature;                                   /* DiscretePolicy temperature (DiscretePolicy.h:16) */
-    int32_t use_bf16;                                    /* autocastLearn (PPOLearnerConfig.h:19): bf16 MFMA operands, fp32 accumulate/master */
+    int32_t use_bf16;                                    /* autocastLearn (PPOLearnerConfig.h:19): 1 = bf16 MFMA operands (the reference's autocast dtype,
+                                                            FrameworkTorch.h:14), fp32 accumulate / master; 2 = fp16 operands in the PPO minibatch kernels with
+                                                            a dynamic loss scale (gradscaler.hpp:26-34), flagship shape only; 0 = fp32 */
     uint32_t seed_lo, seed_hi;
     int32_t max_rows;                                    /* largest row count of any call (scratch sizing) */
 } RlgpuLearnerConfig;
@@ -229,6 +231,11 @@ int rlgpu_zero_grads(rlgpu_learner* l);
  * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
 int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale);
 int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
+/* fp16 mode (use_bf16 = 2): amp::GradScaler's state (PRIV/Util/gradscaler.hpp:26-34,162,291) -- the loss scale the NEXT minibatch's loss gradient is
+ * multiplied by (rlgpu_ppo_minibatch leaves scale x gradient in the gradient buffer; rlgpu_clip_adam_step unscales BEFORE the clip, skips an
+ * optimizer whose gradient norm is not finite and then halves the scale; 2000 clean steps double it), the clean steps counted so far, the steps
+ * skipped so far.  Other modes: scale 1. */
+int rlgpu_learner_loss_scale(rlgpu_learner* l, float* scale, int* growth_steps, int* skipped_steps);
 /* bf16 mode: rebuild the bf16 weight copies the GEMMs read NOW, on the learner's stream (they are otherwise rebuilt lazily by the next
  * forward pass).  For LearnerConfig::collectionDuringLearn: the learning stream calls it after every optimizer step, so that inference on
  * the collection stream reads the live weights like the reference's agent threads do (ThreadAgent.cpp:72-103). */

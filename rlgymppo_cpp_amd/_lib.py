@@ -109,6 +109,7 @@ SIGNATURES = {
     "rlgpu_zero_grads": (_i, [_vp]),
     "rlgpu_clip_adam_step": (_i, [_vp, _f, _f]),
     "rlgpu_learner_set_lr": (_i, [_vp, _f, _f]),
+    "rlgpu_learner_loss_scale": (_i, [_vp, _vp, _vp, _vp]),
     "rlgpu_learner_set_temperature": (_i, [_vp, _f]),
     "rlgpu_env_reseed": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "rlgpu_learner_set_sampler": (_i, [_vp, C.c_uint32, C.c_uint32]),

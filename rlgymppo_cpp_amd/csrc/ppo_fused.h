@@ -46,6 +46,7 @@ struct Args {
     float inv_temp, clip, ent_coef, scale;   // scale = ratio / rows
     int debug;                   // experiments only (FZ_DEBUG builds): 1 no copies to HBM, 2 no MFMAs, 4 no epilogues
     unsigned long long* prof;    // profiling builds of the host only (RLGPU_FUSED_PROF): cycles per phase summed over the workgroups' first wavefronts
+    float loss_scale;            // fp16 mode: the dynamic loss scale the loss gradient is multiplied by (the host keeps and updates it); else 1
     float* metrics;              // [0] entropy, [1] KL, [2] clip count, [3] ratio, [4] value squared error: sums over rows
 };
 
@@ -54,6 +55,20 @@ using bf16x4 = __attribute__((ext_vector_type(4))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ short f2bf_(float f) { __hip_bfloat16 h = __float2bfloat16(f); return *reinterpret_cast<short*>(&h); }
+// Operand type of the kernels below: bf16 (autocastLearn as the reference's FrameworkTorch.h:14 configures it) or, HALF = true, fp16 (BASELINE
+// configs[4]'s wording) -- with fp16 the loss gradient is multiplied by a dynamic loss scale (LossScale below).  Both are 16-bit patterns whose
+// top bit is the sign, so the packed ReLU / "positive" tricks of the epilogues hold for either.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+template <bool HALF> __device__ __forceinline__ short f2s(float f) {
+    if constexpr (HALF) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(short, h); }
+    else return f2bf_(f);
+}
+template <bool HALF> __device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// (The dynamic loss scale of the fp16 mode -- PRIV/Util/gradscaler.hpp:26-34: init 2^16, growth 2 every 2000 clean steps, backoff 0.5 -- is host
+// state of the learner, rlgpu_learn.hip rlgpu_clip_adam_step; the kernels get it as a number.)
 __device__ __forceinline__ float bf2f_(short s) { return __uint_as_float(((unsigned int)(unsigned short)s) << 16); }
 
 template <int NK> struct Fr { bf16x8 f[NK]; };
@@ -66,7 +81,7 @@ __device__ __forceinline__ void load_fr(Fr<NK>& F, const short* wf, int cb, int 
 // acc[rt][feature m of the block][row] = init + W-fragments . in[32 rt + row][K].  `init` is the first MFMA's C operand (the bias of a forward
 // layer, zeros for a gradient: no accumulator is written before the MFMAs); the activation operands of step s + 1 are requested before step
 // s's MFMAs are issued.
-template <int NK>
+template <int NK, bool HALF>
 __device__ __forceinline__ void mma_tiles(const Fr<NK>& F, const short* in, int lane, const f32x16& init, f32x16 (&acc)[RT]) {
     const short* brow = in + (lane & 31) * LD + 8 * (lane >> 5);
     bf16x8 b[2][RT];
@@ -79,7 +94,7 @@ __device__ __forceinline__ void mma_tiles(const Fr<NK>& F, const short* in, int 
             for (int r = 0; r < RT; r++) b[(s + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(brow + r * 32 * LD + (s + 1) * 16);
         }
 #pragma unroll
-        for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.f[s], b[s & 1][r], s == 0 ? init : acc[r], 0, 0, 0);
+        for (int r = 0; r < RT; r++) acc[r] = mma16<HALF>(F.f[s], b[s & 1][r], s == 0 ? init : acc[r]);
     }
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -113,12 +128,14 @@ __device__ __forceinline__ void stage_bias(float* bias_lds, const float* const (
 using s16x2 = __attribute__((ext_vector_type(2))) short;
 using u16x2 = __attribute__((ext_vector_type(2))) unsigned short;
 struct Mask { unsigned int m[2]; };   // ReLU mask of a wavefront's 4 tiles: pair p = 8 r + 2 g + h of (register 4 g + 2 h, + 1) -> bits (p & 15) and 16 + (p & 15) of m[p >> 4]
-__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
-    s16x2 v; v[0] = f2bf_(a); v[1] = f2bf_(b);
+template <bool HALF>
+__device__ __forceinline__ unsigned int pack16(float a, float b) {
+    s16x2 v; v[0] = f2s<HALF>(a); v[1] = f2s<HALF>(b);
     return __builtin_bit_cast(unsigned int, v);
 }
 // hidden layer (accumulators started from the bias): relu -> bf16 -> out[row][cb * 32 + ...].  On packed pairs: max with 0 as SIGNED 16-bit integers
 // is the ReLU of a bf16 pair, min with 1 as UNSIGNED ones is "positive" -- two instructions per pair where the fp32 form took six per element.
+template <bool HALF>
 __device__ __forceinline__ Mask epilogue_hidden(const f32x16 (&acc)[RT], int cb, short* out, int lane) {
     Mask mk; mk.m[0] = 0; mk.m[1] = 0;
     const int nb = cb * 32 + 4 * (lane >> 5);
@@ -131,7 +148,7 @@ __device__ __forceinline__ Mask epilogue_hidden(const f32x16 (&acc)[RT], int cb,
             unsigned int pk[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const s16x2 v = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(acc[r][4 * g + 2 * h], acc[r][4 * g + 2 * h + 1])), zero2);
+                const s16x2 v = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack16<HALF>(acc[r][4 * g + 2 * h], acc[r][4 * g + 2 * h + 1])), zero2);
                 pk[h] = __builtin_bit_cast(unsigned int, v);
                 const unsigned int t = __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), one2));
                 const int p = 8 * r + 2 * g + h;
@@ -146,6 +163,7 @@ __device__ __forceinline__ Mask epilogue_hidden(const f32x16 (&acc)[RT], int cb,
     return mk;
 }
 // input gradient of a hidden layer: bf16(acc) where the forward activation was positive
+template <bool HALF>
 __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[RT], const Mask& mk, int cb, short* out, int lane) {
     const int nb = cb * 32 + 4 * (lane >> 5);
     const u16x2 zero2 = {0, 0};
@@ -160,7 +178,7 @@ __device__ __forceinline__ void epilogue_dx(const f32x16 (&acc)[RT], const Mask&
                 const int p = 8 * r + 2 * g + h;
                 const unsigned int t = (mk.m[p >> 4] >> (p & 15)) & 0x00010001u;
                 const u16x2 keep = zero2 - __builtin_bit_cast(u16x2, t);          // 0xFFFF where the activation was positive
-                pk[h] = pack_bf16(acc[r][4 * g + 2 * h], acc[r][4 * g + 2 * h + 1]) & __builtin_bit_cast(unsigned int, keep);
+                pk[h] = pack16<HALF>(acc[r][4 * g + 2 * h], acc[r][4 * g + 2 * h + 1]) & __builtin_bit_cast(unsigned int, keep);
             }
             *reinterpret_cast<uint2*>(orow + 8 * g) = make_uint2(pk[0], pk[1]);
         }
@@ -198,7 +216,7 @@ __device__ __forceinline__ float wave_sum_(float x) {
 #else
 #define FZ_DBG(b) false
 #endif
-template <int K0P, int OUTP, bool POLICY>
+template <int K0P, int OUTP, bool POLICY, bool HALF>
 __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, short* buf0, short* buf1, float (*red)[4]) {
     constexpr int NK0 = K0P / 16, NKH = H / 16, NKO = OUTP / 16;
     constexpr int OB = OUTP / 32;                    // 32-feature blocks of the last layer
@@ -247,7 +265,7 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const float e = pi < full ? x[q] : ((pi == full && c0 + q < g.D) ? tail[q] : 0.f);
-                v[q] = valid ? f2bf_(e) : (short)0;
+                v[q] = valid ? f2s<HALF>(e) : (short)0;
             }
             *reinterpret_cast<bf16x8*>(buf0 + row * LD + c0) = v;
             if (POLICY && valid) *reinterpret_cast<bf16x8*>(g.x16 + (size_t)gm * K0P + c0) = v;
@@ -261,24 +279,24 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
     Fr<NKH> f1, f2, f3, f3b;
     load_fr(f1, n.wf[1], w, lane);
     f32x16 bi = load_bias(bias_lds, w, lane);
-    if (!FZ_DBG(2)) mma_tiles<NK0>(f0, buf0, lane, bi, acc);
-    const Mask mask0 = epilogue_hidden(acc, w, buf1, lane);
+    if (!FZ_DBG(2)) mma_tiles<NK0, HALF>(f0, buf0, lane, bi, acc);
+    const Mask mask0 = epilogue_hidden<HALF>(acc, w, buf1, lane);
     __syncthreads();
     stamp(1);
     load_fr(f2, n.wf[2], w, lane);
     bi = load_bias(bias_lds + H, w, lane);
     if (!FZ_DBG(1)) copy_out<H>(buf1, n.act[0], m0, g.rows, tid);
-    if (!FZ_DBG(2)) mma_tiles<NKH>(f1, buf1, lane, bi, acc);
-    const Mask mask1 = epilogue_hidden(acc, w, buf0, lane);
+    if (!FZ_DBG(2)) mma_tiles<NKH, HALF>(f1, buf1, lane, bi, acc);
+    const Mask mask1 = epilogue_hidden<HALF>(acc, w, buf0, lane);
     __syncthreads();
     stamp(2);
     // last-layer tiles t = w, w + 8 (feature block t / RT, row tile t % RT); fragments of a block that does not exist are clamped (loaded, unused)
     load_fr(f3, n.wf[3], (w / RT < OB) ? w / RT : OB - 1, lane);
     bi = load_bias(bias_lds + 2 * H, w, lane);
     if (!FZ_DBG(1)) copy_out<H>(buf0, n.act[1], m0, g.rows, tid);
-    if (!FZ_DBG(2)) mma_tiles<NKH>(f2, buf0, lane, bi, acc);
+    if (!FZ_DBG(2)) mma_tiles<NKH, HALF>(f2, buf0, lane, bi, acc);
     if (T3 > 1) load_fr(f3b, n.wf[3], ((w + NWAVE) / RT < OB) ? (w + NWAVE) / RT : OB - 1, lane);
-    const Mask mask2 = epilogue_hidden(acc, w, buf1, lane);
+    const Mask mask2 = epilogue_hidden<HALF>(acc, w, buf1, lane);
     __syncthreads();
     stamp(3);
     Fr<NKO> g3; load_fr(g3, n.wtf[3], w, lane);      // lands under the last layer and the loss
@@ -296,7 +314,7 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
             for (int q = 0; q < 16; q++) a1[q] = 0.f;
             const short* brow = buf1 + (rt * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
-            for (int s = 0; s < NKH; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1, 0, 0, 0);
+            for (int s = 0; s < NKH; s++) a1 = mma16<HALF>(fk.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1);
             const int nb = cb * 32 + 4 * (lane >> 5);
             float* zrow = zf + (rt * 32 + (lane & 31)) * LDF + nb;
 #pragma unroll
@@ -360,10 +378,10 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
             lp[j] = gj; dot = fmaf(gj, s[j], dot);
         }
         dot = quad_sum(dot);
-        const float c = valid ? g.inv_temp * g.scale : 0.f;
+        const float c = valid ? g.inv_temp * g.scale * g.loss_scale : 0.f;
         short* drow = buf1 + row * LD + sub;
 #pragma unroll
-        for (int j = 0; j < PER; j++) drow[4 * j] = f2bf_(s[j] * (lp[j] - dot) * c);      // (s = 0 beyond the A logits: zeros)
+        for (int j = 0; j < PER; j++) drow[4 * j] = f2s<HALF>(s[j] * (lp[j] - dot) * c);      // (s = 0 beyond the A logits: zeros)
         if (g.metrics) {
             const bool cnt = valid && sub == 0;
             const float lr = lpa - olp;
@@ -377,9 +395,9 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
             const int gm = m0 + tid;
             const bool valid = gm < g.rows;
             const float d = zf[tid * LDF] - pre_tgt;
-            const float grd = 2.f * d * g.scale;
+            const float grd = 2.f * d * g.scale * g.loss_scale;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            v[0] = valid ? f2bf_(grd) : (short)0;
+            v[0] = valid ? f2s<HALF>(grd) : (short)0;
             short* drow = buf1 + tid * LD;
             *reinterpret_cast<bf16x8*>(drow) = v;
 #pragma unroll
@@ -398,19 +416,19 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
     Fr<NKH> g2, g1;
     load_fr(g2, n.wtf[2], w, lane);
     if (!FZ_DBG(1)) copy_out<OUTP>(buf1, n.dy[3], m0, g.rows, tid);
-    if (!FZ_DBG(2)) mma_tiles<NKO>(g3, buf1, lane, zero16(), acc);
-    epilogue_dx(acc, mask2, w, buf0, lane);
+    if (!FZ_DBG(2)) mma_tiles<NKO, HALF>(g3, buf1, lane, zero16(), acc);
+    epilogue_dx<HALF>(acc, mask2, w, buf0, lane);
     __syncthreads();
     stamp(6);
     load_fr(g1, n.wtf[1], w, lane);
     if (!FZ_DBG(1)) copy_out<H>(buf0, n.dy[2], m0, g.rows, tid);
-    if (!FZ_DBG(2)) mma_tiles<NKH>(g2, buf0, lane, zero16(), acc);
-    epilogue_dx(acc, mask1, w, buf1, lane);
+    if (!FZ_DBG(2)) mma_tiles<NKH, HALF>(g2, buf0, lane, zero16(), acc);
+    epilogue_dx<HALF>(acc, mask1, w, buf1, lane);
     __syncthreads();
     stamp(7);
     if (!FZ_DBG(1)) copy_out<H>(buf1, n.dy[1], m0, g.rows, tid);
-    if (!FZ_DBG(2)) mma_tiles<NKH>(g1, buf1, lane, zero16(), acc);
-    epilogue_dx(acc, mask0, w, buf0, lane);
+    if (!FZ_DBG(2)) mma_tiles<NKH, HALF>(g1, buf1, lane, zero16(), acc);
+    epilogue_dx<HALF>(acc, mask0, w, buf0, lane);
     __syncthreads();
     stamp(8);
     if (!FZ_DBG(1)) copy_out<H>(buf0, n.dy[0], m0, g.rows, tid);
@@ -421,14 +439,14 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
 }
 
 // grid (stripes, 2): blockIdx.y = 0 policy, 1 critic
-template <int K0P, int OUTP>
+template <int K0P, int OUTP, bool HALF = false>
 __global__ void __launch_bounds__(512) k_ppo_fwd_bwd(Args g) {
     extern __shared__ __attribute__((aligned(16))) short fz_smem[];
     __shared__ float red[NWAVE][4];
     short* buf0 = fz_smem;
     short* buf1 = fz_smem + R * LD;
-    if (blockIdx.y == 0) stripe_body<K0P, OUTP, true>(g, g.net[0], buf0, buf1, red);
-    else stripe_body<K0P, 32, false>(g, g.net[1], buf0, buf1, red);
+    if (blockIdx.y == 0) stripe_body<K0P, OUTP, true, HALF>(g, g.net[0], buf0, buf1, red);
+    else stripe_body<K0P, 32, false, HALF>(g, g.net[1], buf0, buf1, red);
 }
 
 // ---- the value pass (Learner::AddNewExperience, Learner.cpp:296-316: valueNet->Forward over every row of the iteration) -----------------------
@@ -436,7 +454,7 @@ __global__ void __launch_bounds__(512) k_ppo_fwd_bwd(Args g) {
 // was k_mlp_infer (32 rows per workgroup, the 350 KB of weights streamed once per 32 rows).
 struct ValueArgs { const float* obs; int rows; int D; const short* wf[4]; const float* bias[4]; float* values; };
 
-template <int K0P>
+template <int K0P, bool HALF = false>
 __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
     extern __shared__ __attribute__((aligned(16))) short fz_smem[];
     constexpr int NK0 = K0P / 16, NKH = H / 16;
@@ -469,7 +487,7 @@ __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const float e = pi < full ? x[q] : ((pi == full && c0 + q < g.D) ? tail[q] : 0.f);
-                v[q] = valid ? f2bf_(e) : (short)0;
+                v[q] = valid ? f2s<HALF>(e) : (short)0;
             }
             *reinterpret_cast<bf16x8*>(buf0 + row * LD + c0) = v;
         }
@@ -479,24 +497,24 @@ __global__ void __launch_bounds__(512) k_value_stripe(ValueArgs g) {
     Fr<NKH> f1, f2, f3;
     load_fr(f1, g.wf[1], w, lane);
     f32x16 bi = load_bias(bias_lds, w, lane);
-    mma_tiles<NK0>(f0, buf0, lane, bi, acc);
-    epilogue_hidden(acc, w, buf1, lane);
+    mma_tiles<NK0, HALF>(f0, buf0, lane, bi, acc);
+    epilogue_hidden<HALF>(acc, w, buf1, lane);
     __syncthreads();
     load_fr(f2, g.wf[2], w, lane);
     bi = load_bias(bias_lds + H, w, lane);
-    mma_tiles<NKH>(f1, buf1, lane, bi, acc);
-    epilogue_hidden(acc, w, buf0, lane);
+    mma_tiles<NKH, HALF>(f1, buf1, lane, bi, acc);
+    epilogue_hidden<HALF>(acc, w, buf0, lane);
     __syncthreads();
     load_fr(f3, g.wf[3], 0, lane);                   // the last layer has ONE feature block (the value in column 0): row tile w of wavefronts 0..3
     bi = load_bias(bias_lds + 2 * H, w, lane);
-    mma_tiles<NKH>(f2, buf0, lane, bi, acc);
-    epilogue_hidden(acc, w, buf1, lane);
+    mma_tiles<NKH, HALF>(f2, buf0, lane, bi, acc);
+    epilogue_hidden<HALF>(acc, w, buf1, lane);
     __syncthreads();
     if (w < RT) {
         f32x16 a1 = zero16();
         const short* brow = buf1 + (w * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
 #pragma unroll
-        for (int s = 0; s < NKH; s++) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f3.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1, 0, 0, 0);
+        for (int s = 0; s < NKH; s++) a1 = mma16<HALF>(f3.f[s], *reinterpret_cast<const bf16x8*>(brow + s * 16), a1);
         // feature 0 of the block = register 0 of the lanes 0..31 (features 4 (lane >> 5) + ...: the lower half holds feature 0)
         const int gm = m0 + w * 32 + (lane & 31);
         if (lane < 32 && gm < g.rows) g.values[gm] = a1[0] + bias_lds[3 * H];
@@ -528,6 +546,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const short* S, int k16, int col0, 
 }
 
 // grid (slabs, 4 layers, 2 networks), 512 threads: wavefront w owns the dW blocks [2 (w >> 1), +2) x [4 (w & 1), +4) of 32 x 32
+template <bool HALF = false>
 __global__ void __launch_bounds__(512) k_dw_grouped(DwArgs g) {
     extern __shared__ __attribute__((aligned(16))) short dw_smem[];
     const DwLayer L = g.L[blockIdx.z][blockIdx.y];
@@ -553,7 +572,8 @@ __global__ void __launch_bounds__(512) k_dw_grouped(DwArgs g) {
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
     }
-    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    constexpr short ONE = HALF ? (short)0x3C00 : (short)0x3F80;
+    const bf16x8 ones = {ONE, ONE, ONE, ONE, ONE, ONE, ONE, ONE};
     // a step's operands: 32 rows x 256 columns each = 2 x 1024 pieces of 16 bytes; thread t moves pieces t and t + 512 of both.  Loads are
     // UNCONDITIONAL (row and column clamped into the matrix, the value zeroed when it is stored to LDS): with predicated loads the compiler
     // cannot count what is in flight and waits for everything before every LDS store -- no prefetch left.
@@ -596,8 +616,8 @@ __global__ void __launch_bounds__(512) k_dw_grouped(DwArgs g) {
             for (int i = 0; i < 2; i++) {
                 if (!vi[i]) continue;
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (vj[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                if (bias_wave) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+                for (int j = 0; j < 4; j++) if (vj[j]) acc[i][j] = mma16<HALF>(a[i], b[j], acc[i][j]);
+                if (bias_wave) accb[i] = mma16<HALF>(a[i], ones, accb[i]);
             }
         }
     };

@@ -432,16 +432,17 @@ __global__ void k_rows_to_bf16(const float* src, const int32_t* idx, int rows, i
 }
 
 // bf16 shadows of one Linear layer's fp32 master weight W[N][K]:  w16[rows16][ld16] = W (zero padded),  wt16[rowst][ldt] = W^T
+template <bool HALF>
 __global__ void k_weight_shadows(const float* W, int N, int K, short* w16, int rows16, int ld16, short* wt16, int rowst, int ldt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t n1 = (size_t)rows16 * ld16, n2 = (size_t)rowst * ldt;
     if (i < n1) {
         int r = (int)(i / ld16), c = (int)(i % ld16);
-        w16[i] = (r < N && c < K) ? f2bf(W[(size_t)r * K + c]) : (short)0;
+        w16[i] = (r < N && c < K) ? fused::f2s<HALF>(W[(size_t)r * K + c]) : (short)0;
     } else if (i < n1 + n2) {
         size_t j = i - n1;
         int r = (int)(j / ldt), c = (int)(j % ldt);
-        wt16[j] = (r < K && c < N) ? f2bf(W[(size_t)c * K + r]) : (short)0;
+        wt16[j] = (r < K && c < N) ? fused::f2s<HALF>(W[(size_t)c * K + r]) : (short)0;
     }
 }
 
@@ -864,6 +865,10 @@ struct rlgpu_learner {
     float *dbuf0 = nullptr, *dbuf1 = nullptr, *gathered = nullptr, *norm_buf = nullptr;
     // bf16 fast path (cfg.use_bf16)
     short* shadows = nullptr; int64_t n_shadow = 0; bool shadows_dirty = true;
+    // fp16 operand mode (cfg.use_bf16 == 2; BASELINE configs[4] "fp16 autocast"): the minibatch kernels of ppo_fused.h take fp16 copies of the
+    // weights (same layout as `shadows`) and the loss gradient times a dynamic loss scale (PRIV/Util/gradscaler.hpp:26-34: 2^16 at the start,
+    // x 2 after 2000 steps without an overflow, x 0.5 and the step SKIPPED after one).  Inference (collection, value pass) stays bf16.
+    short* shadows_h = nullptr; float loss_scale = 65536.f; int ls_growth = 0; int ls_skipped = 0;
     short* x16 = nullptr;                       // [max_rows][kp[0]] network input
     std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
     short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
@@ -1007,8 +1012,16 @@ int refresh_shadows(rlgpu_learner* l) {
     for (const Net* n : {&l->pol, &l->cri}) {
         for (int i = 0; i < n->n_layers; i++) {
             size_t tot = (size_t)n->w16_rows[i] * n->kp[i] + (size_t)n->wt16_rows[i] * n->kp[i + 1];
-            hipLaunchKernelGGL(k_weight_shadows, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
+            hipLaunchKernelGGL(k_weight_shadows<false>, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
                                l->shadows + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
+            if (l->shadows_h) {   // fp16 mode: the same four copies in fp16 for the minibatch kernels
+                hipLaunchKernelGGL(k_weight_shadows<true>, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
+                                   l->shadows_h + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows_h + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
+                hipLaunchKernelGGL(k_weight_frags, dim3(((size_t)n->w16_rows[i] * n->kp[i] + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows_h + n->w16_off[i]), n->w16_rows[i], n->kp[i],
+                                   l->shadows_h + n->wf16_off[i]);
+                hipLaunchKernelGGL(k_weight_frags, dim3(((size_t)n->wt16_rows[i] * n->kp[i + 1] + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows_h + n->wt16_off[i]), n->wt16_rows[i], n->kp[i + 1],
+                                   l->shadows_h + n->wtf16_off[i]);
+            }
             LCHK(l, hipGetLastError());
             const size_t nf = (size_t)n->w16_rows[i] * n->kp[i];
             hipLaunchKernelGGL(k_weight_frags, dim3((nf + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->w16_off[i]), n->w16_rows[i], n->kp[i],
@@ -1182,14 +1195,14 @@ bool fused_capable(const rlgpu_learner* l) {
     if (k0 != l->cri.kp[0] || (k0 != 96 && k0 != 128 && k0 != 192)) return false;   // 1v1 / 2v2-padded / 3v3-padded observation rows
     return l->pol.kp[4] == 96 && l->cri.dims[4] == 1;
 }
-template <int K0P>
-int fused_launch_t(rlgpu_learner* l, const fused::Args& a, dim3 grid) {
+template <int K0P, bool HALF>
+int fused_launch_th(rlgpu_learner* l, const fused::Args& a, dim3 grid) {
     static bool attr_set = false;
     if (!attr_set) {
-        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_ppo_fwd_bwd<K0P, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::SMEM_BYTES));
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_ppo_fwd_bwd<K0P, 96, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::SMEM_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((fused::k_ppo_fwd_bwd<K0P, 96>), grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
+    hipLaunchKernelGGL((fused::k_ppo_fwd_bwd<K0P, 96, HALF>), grid, dim3(512), fused::SMEM_BYTES, l->stream, a);
     LCHK(l, hipGetLastError());
     return RLGPU_OK;
 }
@@ -1201,7 +1214,7 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     a.obs = obs; a.idx = idx; a.rows = n; a.D = l->cfg.obs_size; a.x16 = l->x16;
     a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.targets = targets;
     a.inv_temp = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f); a.clip = l->cfg.clip_range; a.ent_coef = l->cfg.ent_coef;
-    a.scale = ratio / (float)n; a.metrics = metrics;
+    a.scale = ratio / (float)n; a.metrics = metrics; a.loss_scale = l->shadows_h ? l->loss_scale : 1.f;
     static const int fz_debug = std::getenv("RLGPU_FZ_DEBUG") ? std::atoi(std::getenv("RLGPU_FZ_DEBUG")) : 0;
     a.debug = fz_debug;
     fused::DwArgs d{};
@@ -1215,7 +1228,8 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
         fused::NetArgs& s = a.net[w];
         const std::vector<short*>& acts = w == 0 ? l->act16_p : l->act16_c;
         for (int i = 0; i < 4; i++) {
-            s.wf[i] = l->shadows + nn->wf16_off[i]; s.wtf[i] = l->shadows + nn->wtf16_off[i]; s.bias[i] = l->params + nn->b_off[i];
+            const short* const sh = l->shadows_h ? l->shadows_h : l->shadows;
+            s.wf[i] = sh + nn->wf16_off[i]; s.wtf[i] = sh + nn->wtf16_off[i]; s.bias[i] = l->params + nn->b_off[i];
             if (i < 3) s.act[i] = acts[i];
             s.dy[i] = l->dy16[w][i];
             fused::DwLayer& L = d.L[w][i];
@@ -1238,7 +1252,8 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     }
     static bool dw_attr = false;
     if (!dw_attr) {
-        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_dw_grouped), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::DW_SMEM_BYTES));
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_dw_grouped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::DW_SMEM_BYTES));
+        LCHK(l, hipFuncSetAttribute(reinterpret_cast<const void*>(&fused::k_dw_grouped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused::DW_SMEM_BYTES));
         dw_attr = true;
     }
     const dim3 grid_all((n + fused::R - 1) / fused::R, 2);
@@ -1246,13 +1261,15 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
         const int r1 = std::min(n, r0 + chunk);
         a.row0 = r0; a.rows = r1; d.row0 = r0; d.rows = r1;
         const dim3 grid((r1 - r0 + fused::R - 1) / fused::R, 2);
+        const bool half = l->shadows_h != nullptr;
         switch (l->pol.kp[0]) {
-            case 96: rc = fused_launch_t<96>(l, a, grid); break;
-            case 128: rc = fused_launch_t<128>(l, a, grid); break;
-            default: rc = fused_launch_t<192>(l, a, grid); break;
+            case 96: rc = half ? fused_launch_th<96, true>(l, a, grid) : fused_launch_th<96, false>(l, a, grid); break;
+            case 128: rc = half ? fused_launch_th<128, true>(l, a, grid) : fused_launch_th<128, false>(l, a, grid); break;
+            default: rc = half ? fused_launch_th<192, true>(l, a, grid) : fused_launch_th<192, false>(l, a, grid); break;
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(fused::k_dw_grouped, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
+        if (half) hipLaunchKernelGGL(fused::k_dw_grouped<true>, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
+        else hipLaunchKernelGGL(fused::k_dw_grouped<false>, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
         LCHK(l, hipGetLastError());
     }
     const dim3 grid = grid_all;
@@ -1328,11 +1345,17 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
     LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
     LCHK(l, hipMalloc(&l->norm_buf, (4 + 2 * SUMSQ_BLOCKS) * 4));   // [0..1] the two networks' squared gradient norms, then their per-workgroup partials
+    if (cfg->use_bf16 < 0 || cfg->use_bf16 > 2) { l->err = "use_bf16: 0 (fp32), 1 (bf16) or 2 (fp16 operands + dynamic loss scale)"; return RLGPU_ERR_ARG; }
     if (cfg->use_bf16) {
         int64_t soff = 0;
         plan_shadows(l->pol, soff); plan_shadows(l->cri, soff);
         l->n_shadow = soff;
         LCHK(l, hipMalloc(&l->shadows, soff * 2));
+        if (cfg->use_bf16 == 2) {
+            // (kp is planned now: the shape test of fused_capable applies)
+            if (!fused_capable(l)) { l->err = "use_bf16 = 2 (fp16 operands): only the shape the fused minibatch kernels cover (obs <= 192 padded, 256 x 3 hidden, n_actions 65..96)"; return RLGPU_ERR_ARG; }
+            LCHK(l, hipMalloc(&l->shadows_h, soff * 2));
+        }
         int maxkp = l->pol.kp[0];
         for (const Net* n : {&l->pol, &l->cri}) for (int i = 0; i <= n->n_layers; i++) maxkp = std::max(maxkp, n->kp[i]);
         LCHK(l, hipMalloc(&l->x16, R * l->pol.kp[0] * 2));
@@ -1361,7 +1384,7 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
-    for (short* p : {l->shadows, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
+    for (short* p : {l->shadows, l->shadows_h, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
     for (int w = 0; w < 2; w++) {
         for (int i = 0; i < 9; i++) { if (l->dy16[w][i]) (void)hipFree(l->dy16[w][i]); if (l->ev_dy[w][i]) (void)hipEventDestroy(l->ev_dy[w][i]); }
         if (l->dw_stream[w]) (void)hipStreamDestroy(l->dw_stream[w]);
@@ -1646,14 +1669,29 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     LCHK(l, hipSetDevice(l->device));
     struct Seg { int64_t off, n; float lr; int64_t* step; int slot; } segs[2] = {
         {0, l->pol.n_params, l->cfg.policy_lr, &l->step_p, 0}, {l->pol.n_params, l->cri.n_params, l->cfg.critic_lr, &l->step_c, 1}};
+    // fp16 mode: the gradients are loss_scale times too large.  GradScaler::unscale_ BEFORE the clip (the reference clips the scaled gradients and
+    // unscales inside step(), PPOLearner.cpp:273-297 -- an effective clip norm of 0.5 / scale), a step with a non-finite gradient
+    // norm is skipped for that optimizer and the scale backs off, gradscaler.hpp:162,291.
+    const bool half = l->shadows_h != nullptr;
+    if (half) grad_scale /= l->loss_scale;
     for (auto& s : segs) {
         float* const partial = l->norm_buf + 4 + s.slot * SUMSQ_BLOCKS;
         hipLaunchKernelGGL(k_sumsq, dim3(SUMSQ_BLOCKS), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, partial);
         hipLaunchKernelGGL(k_sumsq_finish, dim3(1), dim3(1), 0, l->stream, (const float*)partial, SUMSQ_BLOCKS, l->norm_buf + s.slot);
         LCHK(l, hipGetLastError());
     }
+    bool skip[2] = {false, false};
+    if (half) {
+        float norms[2];
+        LCHK(l, hipMemcpyAsync(norms, l->norm_buf, 8, hipMemcpyDeviceToHost, l->stream));
+        LCHK(l, hipStreamSynchronize(l->stream));
+        skip[0] = !std::isfinite(norms[0]); skip[1] = !std::isfinite(norms[1]);
+        if (skip[0] || skip[1]) { l->loss_scale *= 0.5f; l->ls_growth = 0; l->ls_skipped++; }
+        else if (++l->ls_growth >= 2000) { l->loss_scale *= 2.f; l->ls_growth = 0; }
+    }
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     for (auto& s : segs) {
+        if (skip[s.slot]) continue;
         (*s.step)++;
         double t = (double)*s.step;
         float bc1 = (float)(1.0 - std::pow((double)b1, t));
@@ -1663,6 +1701,11 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
         LCHK(l, hipGetLastError());
     }
     l->shadows_dirty = true;
+    return RLGPU_OK;
+}
+int rlgpu_learner_loss_scale(rlgpu_learner* l, float* scale, int* growth_steps, int* skipped_steps) {
+    if (scale) *scale = l->shadows_h ? l->loss_scale : 1.f;
+    if (growth_steps) *growth_steps = l->ls_growth; if (skipped_steps) *skipped_steps = l->ls_skipped;
     return RLGPU_OK;
 }
 int rlgpu_learner_set_lr(rlgpu_learner* l, float plr, float clr) { l->cfg.policy_lr = plr; l->cfg.critic_lr = clr; return RLGPU_OK; }

@@ -276,7 +276,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     for (int i = 0; i < lc.n_policy_layers; i++) lc.policy_layers[i] = config.ppo.policyLayerSizes[i];
     for (int i = 0; i < lc.n_critic_layers; i++) lc.critic_layers[i] = config.ppo.criticLayerSizes[i];
     lc.policy_lr = config.ppo.policyLR; lc.critic_lr = config.ppo.criticLR; lc.ent_coef = config.ppo.entCoef; lc.clip_range = config.ppo.clipRange;
-    lc.temperature = config.ppo.policyTemperature; lc.use_bf16 = config.ppo.autocastLearn ? 1 : 0;
+    lc.temperature = config.ppo.policyTemperature; lc.use_bf16 = config.ppo.autocastLearn ? (std::getenv("RLGPU_AUTOCAST_FP16") ? 2 : 1) : 0;   // autocastLearn: bf16 operands (the reference's autocast dtype, FrameworkTorch.h:14); RLGPU_AUTOCAST_FP16=1: fp16 operands + dynamic loss scale in the minibatch kernels (BASELINE configs[4]'s wording)
     lc.seed_lo = (uint32_t)config.randomSeed; lc.seed_hi = 0; lc.max_rows = m.maxRows;
     rc = rlgpu_learner_create(&m.lrn, m.device, &lc);
     m.LrnCheck(rc, "learner_create");

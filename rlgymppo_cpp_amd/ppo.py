@@ -27,7 +27,7 @@ class PPOCore:
         for i, w in enumerate(policy_layers): c.policy_layers[i] = w
         for i, w in enumerate(critic_layers): c.critic_layers[i] = w
         c.policy_lr = policy_lr; c.critic_lr = critic_lr; c.ent_coef = ent_coef; c.clip_range = clip_range
-        c.temperature = temperature; c.use_bf16 = 1 if use_bf16 else 0
+        c.temperature = temperature; c.use_bf16 = 2 if use_bf16 == "fp16" else (1 if use_bf16 else 0)   # "fp16": fp16 operands + dynamic loss scale (include/rlgpu.h)
         c.seed_lo = seed & 0xffffffff; c.seed_hi = (seed >> 32) & 0xffffffff; c.max_rows = max_rows
         self.cfg = c
         self.device = device
@@ -150,6 +150,13 @@ class PPOCore:
 
     def clip_adam_step(self, max_norm=0.5, grad_scale=1.0):
         _chk(self.lib.rlgpu_clip_adam_step(self.h, max_norm, grad_scale), self.h, self._err)
+
+    def loss_scale(self):
+        """(scale, clean steps counted, steps skipped) of the fp16 mode's dynamic loss scale; scale 1 in the other modes."""
+        import ctypes as C
+        sc, g, k = C.c_float(), C.c_int(), C.c_int()
+        _chk(self.lib.rlgpu_learner_loss_scale(self.h, C.byref(sc), C.byref(g), C.byref(k)), self.h, self._err)
+        return sc.value, g.value, k.value
 
     def set_lr(self, policy_lr, critic_lr):
         _chk(self.lib.rlgpu_learner_set_lr(self.h, policy_lr, critic_lr), self.h, self._err)
