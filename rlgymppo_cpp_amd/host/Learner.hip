@@ -955,7 +955,9 @@ void Learner::LoadStats(std::filesystem::path path) {
         impl->EnvCheck(rlgpu_env_reseed(impl->env, (uint32_t)config.randomSeed + 1000u * (uint32_t)impl->rank, impl->envStreamEpoch), "reseed");
         // the constructor reset every env with epoch 0's streams: draw the first states of the resumed run from the new epoch's
         // (otherwise its first episodes would start from the initial states of the run it continues)
-        if (!impl->plan.hostObs) impl->EnvCheck(rlgpu_env_reset(impl->env, 1, impl->ObsAt(0)), "reset after reseed");
+        // (with a host OBS builder the device rows go to the scratch buffer -- the constructor's probe did the same: the device setter must run
+        // with the new epoch in that case too)
+        impl->EnvCheck(rlgpu_env_reset(impl->env, 1, impl->plan.hostObs ? impl->devObs : impl->ObsAt(0)), "reset after reseed");
         if (impl->plan.AnyHost()) {
             std::vector<int32_t> all(impl->nEnvs); std::iota(all.begin(), all.end(), 0);
             impl->HostResetEnvs(all, impl->ObsAt(0), true);

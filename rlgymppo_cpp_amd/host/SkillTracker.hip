@@ -32,6 +32,7 @@ struct SkillTracker::Impl {
     float *obs = nullptr, *obsNext = nullptr, *rew = nullptr, *logp = nullptr; int32_t *acts = nullptr, *done = nullptr;
     std::mt19937 rng;
     std::vector<GameInst> gameInsts;
+    bool disabled = false;                      // the eval match uses a plugin without a device form: no eval games (a warning at construction)
     bool hostSetter = false; RLGSC::Arena* scratch = nullptr;   // a user state setter: run on the host facade (Match::ResetState), then uploaded
     std::vector<RlgpuArenaState> snaps, fresh;
     // Gym::Reset of the listed envs with the user's state setter (the kernel has already reset them with the stand-in kickoff setter)
@@ -86,9 +87,14 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
     if (config.kickoffStatesOnly) m.match->stateSetter = new RLGSC::KickoffState();   // SkillTracker.cpp:48-49 (the env's own setter is discarded, not freed)
     const RLGSC::Match::DevicePlan plan = m.match->PlanDevice(m.tickSkip);
-    if (plan.hostTerminal) RG_ERR_CLOSE("SkillTracker: a terminal condition of the eval match has no device form (built-ins: NoTouchCondition, GoalScoreCondition)");
-    if (plan.hostObs) RG_ERR_CLOSE("SkillTracker: the obs builder of the eval match has no device form (built-ins: DefaultOBS, DefaultOBSPadded)");
-    if (plan.hostParser) RG_ERR_CLOSE("SkillTracker: the action parser of the eval match has no device form (built-in: DiscreteAction)");
+    if (plan.hostTerminal || plan.hostObs || plan.hostParser) {
+        // The eval games run without per-step host work, so they need device forms of these plugin kinds (a user STATE SETTER is fine: it runs on
+        // the host facade at episode boundaries).  A training run with a custom OBSBuilder must not die for it: the tracker switches itself off.
+        RG_LOG("SkillTracker: WARNING -- the eval match uses " << (plan.hostTerminal ? "a terminal condition " : "") << (plan.hostObs ? "an obs builder " : "") << (plan.hostParser ? "an action parser " : "")
+               << "without a device form (built-ins: NoTouchCondition / GoalScoreCondition, DefaultOBS / DefaultOBSPadded, DiscreteAction): no eval games will be played, the ratings stay where they are");
+        m.disabled = true;
+        return;
+    }
     m.hostSetter = plan.hostSetter;
     RlgpuGymConfig g = plan.cfg;
     g.n_terms = 0; g.zero_sum = 0;                                     // the zero reward of SkillTracker.cpp:10-16,51
@@ -145,6 +151,7 @@ void SkillTracker::UpdateRatings(RatingSet& winner, RatingSet& loser, bool updat
 
 void SkillTracker::RunGames(int64_t timestepsDelta) {
     Impl& m = *impl;
+    if (m.disabled) return;
     if (runCounter++ % (uint64_t)config.updateInterval != 0) return;
 
     auto snapshot = [&]() {   // the current policy's parameters as a new stored version
