@@ -148,10 +148,28 @@ static std::string rendezvous_dir() {
     if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string();   // somebody else's: refuse
     return d;
 }
+// the launching agent as a name no later launch can have: its pid AND the kernel's start time of that pid (/proc/<pid>/stat field 22) -- a pid
+// alone comes round again, and a file a crashed launch left under it would be taken for this launch's id
+static std::string parent_identity() {
+    const long pp = (long)getppid();
+    std::string id = std::to_string(pp);
+    if (FILE* f = fopen(("/proc/" + id + "/stat").c_str(), "r")) {
+        char buf[1024]; const size_t n = fread(buf, 1, sizeof(buf) - 1, f); fclose(f); buf[n] = 0;
+        if (const char* close = strrchr(buf, ')')) {     // fields after "(comm)": state is field 3, starttime field 22
+            int field = 2; const char* q = close + 1;
+            while (*q && field < 21) { while (*q == ' ') q++; while (*q && *q != ' ') q++; field++; }
+            while (*q == ' ') q++;
+            if (*q) { std::string st; while (*q && *q != ' ') st += *q++; id += "_" + st; }
+        }
+    }
+    return id;
+}
 static std::string rendezvous_path() {
-    const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG");
+    const char* port = getenv("MASTER_PORT"); const char* tag = getenv("RLGPU_COMM_TAG"); const char* run = getenv("TORCHELASTIC_RUN_ID");
     const std::string dir = rendezvous_dir();
-    return (dir.empty() ? std::string("/nonexistent") : dir) + "/rlgpu_comm_" + (port ? port : "0") + "_" + (tag ? tag : std::to_string((long)getppid())) + ".id";
+    std::string name = std::string("/rlgpu_comm_") + (port ? port : "0") + "_" + (tag ? std::string(tag) : parent_identity());
+    if (run && *run && strcmp(run, "none") != 0) name += std::string("_") + run;      // torchrun's own id of the launch, when it has one
+    return (dir.empty() ? std::string("/nonexistent") : dir) + name + ".id";
 }
 int rlgpu_comm_rendezvous_path(char* buf, int cap) {
     const std::string p = rendezvous_path();
