@@ -79,6 +79,8 @@ int rlgpu_env_obs_size(const rlgpu_env* e);    /* OBSBuilder::BuildOBS(...).size
 int rlgpu_env_num_agents(const rlgpu_env* e);  /* n_envs * players, players = 2 * team_size (team_size with one_team); agent row = env * players + slot (slot / 2 with one_team) */
 int rlgpu_env_num_actions(const rlgpu_env* e);
 int rlgpu_env_state_words(const rlgpu_env* e); /* resident 32-bit words per env */
+/* the two counts that must agree (no GPU needed): words arena_visit visits for a team size, and word rows the kernels stage per env */
+int rlgpu_state_word_counts(int team_size, int* visited, int* staged);
 
 /* arena collision mesh: RocketSim::Init / InitFromMem (RS/RocketSim.cpp:70-212). verts in uu. */
 int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts_uu, int n_verts, const int32_t* tris, int n_tris);

@@ -116,8 +116,12 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
 
 template <int NC>
 constexpr size_t arena_num_words() {
-    // kept in sync with arena_visit by a static check in the tests (rlgpu_state_words() reports the visitor's count)
-    return 4 + 12 + (size_t)NC * 90 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * 20 + 2;
+    // MUST equal what arena_visit visits: the staged load / store loops of the kernels run over this many word rows of n_envs words each,
+    // the allocation is sized by the visitor's own count.  (Until round 4 this said NC * 90 for the 89 words of a car: every step and
+    // collection launch read and WROTE NC rows past the end of the resident words -- harmless while the rows fell into the allocation's
+    // page slack, garbage in the allocation behind it (the action table) when they did not.)  rlgpu_env_create refuses to run on a
+    // mismatch, rlgpu_state_word_counts reports both numbers to the CPU tests.
+    return 4 + 12 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2;
 }
 
 // finish a freshly loaded working copy: derived values that are not stored.  The ball's basis (BallState::rotMat) is not among the resident

@@ -1133,6 +1133,10 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     e->device = device; e->n_envs = n_envs; e->team_size = team_size; e->nc = 2 * team_size;
     HIPCHK(e, hipSetDevice(device));
     e->n_words = e->nc == 2 ? count_words<2>() : (e->nc == 4 ? count_words<4>() : count_words<6>());
+    {   // the kernels stage arena_num_words<NC>() rows, the visitor defines how many there are: one number, or nothing runs
+        const size_t staged = e->nc == 2 ? arena_num_words<2>() : (e->nc == 4 ? arena_num_words<4>() : arena_num_words<6>());
+        if (staged != e->n_words) { e->err = "arena_num_words disagrees with arena_visit (" + std::to_string(staged) + " vs " + std::to_string(e->n_words) + " words per env)"; return RLGPU_ERR_ARG; }
+    }
     e->ball_rot.assign(9 * (size_t)n_envs, 0.f);
     for (int i = 0; i < n_envs; i++) e->ball_rot[9 * (size_t)i] = e->ball_rot[9 * (size_t)i + 4] = e->ball_rot[9 * (size_t)i + 8] = 1.f;
     HIPCHK(e, hipMalloc(&e->d.words, e->n_words * (size_t)n_envs * 4));
@@ -1151,6 +1155,15 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
         HIPCHK(e, hipMalloc(&e->d_epa_big, waves * EPA_BIG_BYTES));
         e->d.epa_big = e->d_epa_big;
         HIPCHK(e, hipMalloc(&e->d.leaf_cache, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));   // CandCache: 0.4 - 0.9 KB per env
+        // Both scratch buffers start as zeros (RLGPU_SCRATCH_FILL=<byte>: another pattern, for tests): hipMalloc hands back whatever an earlier
+        // allocation of the process left there, and a batch created after other GPU work in the same process must not behave differently from one
+        // created in a fresh process (tests/test_gpu_parity.py::test_fused_collection_equals_alternating_act_and_step failed that way)
+        {
+            const char* f = std::getenv("RLGPU_SCRATCH_FILL");
+            const int fill = f ? (int)std::strtol(f, nullptr, 0) : 0;
+            HIPCHK(e, hipMemset(e->d_epa_big, fill, waves * EPA_BIG_BYTES));
+            HIPCHK(e, hipMemset(e->d.leaf_cache, fill, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));
+        }
     }
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     {
@@ -1189,6 +1202,12 @@ int rlgpu_env_obs_size(const rlgpu_env* e) { return e->d.cfg.obs_max_players > 0
 int rlgpu_env_num_agents(const rlgpu_env* e) { return e->n_envs * (e->d.cfg.one_team ? e->nc / 2 : e->nc); }
 int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }
+int rlgpu_state_word_counts(int team_size, int* visited, int* staged) {
+    if (team_size < 1 || team_size > 3 || !visited || !staged) return RLGPU_ERR_ARG;
+    *visited = (int)(team_size == 1 ? count_words<2>() : (team_size == 2 ? count_words<4>() : count_words<6>()));
+    *staged = (int)(team_size == 1 ? arena_num_words<2>() : (team_size == 2 ? arena_num_words<4>() : arena_num_words<6>()));
+    return RLGPU_OK;
+}
 
 static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris, const std::vector<int>* parts, bool verts_in_bt = false);
 int rlgpu_env_set_mesh(rlgpu_env* e, const float* verts, int n_verts, const int32_t* tris, int n_tris) { return env_set_mesh_parts(e, verts, n_verts, tris, n_tris, nullptr); }

@@ -457,6 +457,30 @@ __global__ void k_weight_frags(const short* w16, int rows16, int K, short* wf) {
     wf[i] = w16[(size_t)(cb * 32 + (lane & 31)) * K + s * 16 + 8 * (lane >> 5) + j];
 }
 
+// All four 16-bit copies of every Linear layer of both networks in ONE launch (was k_weight_shadows + 2 x k_weight_frags per layer: 24 launches per
+// optimizer step): blockIdx.y = layer; thread i writes element i of the row-major copies and element i of the fragment-ordered ones.
+struct RefreshLayer { const float* W; int N, K; short *w16, *wt16, *wf, *wtf; int rows16, ld16, rowst, ldt; };
+struct RefreshArgs { RefreshLayer L[18]; };
+template <bool HALF>
+__global__ void k_refresh_all(RefreshArgs g) {
+    const RefreshLayer& L = g.L[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n1 = (size_t)L.rows16 * L.ld16, n2 = (size_t)L.rowst * L.ldt;
+    auto w_at = [&](int r, int c) { return (r < L.N && c < L.K) ? fused::f2s<HALF>(L.W[(size_t)r * L.K + c]) : (short)0; };
+    auto frag_rc = [](size_t idx, int K, int& r, int& c) {    // k_weight_frags: fragment element idx of a [rows][K] matrix sits at (r, c)
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63); const size_t blk = idx >> 9; const int nk = K / 16, s = (int)(blk % nk), cb = (int)(blk / nk);
+        r = cb * 32 + (lane & 31); c = s * 16 + 8 * (lane >> 5) + j;
+    };
+    if (i < n1) {
+        L.w16[i] = w_at((int)(i / L.ld16), (int)(i % L.ld16));
+        int r, c; frag_rc(i, L.ld16, r, c); L.wf[i] = w_at(r, c);
+    }
+    if (i < n2) {
+        L.wt16[i] = w_at((int)(i % L.ldt), (int)(i / L.ldt));                 // W^T[r][c] = W[c][r]
+        int r, c; frag_rc(i, L.ldt, r, c); L.wtf[i] = w_at(c, r);
+    }
+}
+
 // column sums: out[n] += sum_m X[m][n]  (fp32 path; the bf16 path folds them into k_gemm_tn)
 __global__ void __launch_bounds__(256) k_col_sum(const float* X, int ld, int M, int N, float* out) {
     __shared__ float part[4][64];
@@ -1009,29 +1033,21 @@ void plan_shadows(Net& n, int64_t& off) {
 
 int refresh_shadows(rlgpu_learner* l) {
     if (!l->shadows_dirty) return RLGPU_OK;
-    for (const Net* n : {&l->pol, &l->cri}) {
-        for (int i = 0; i < n->n_layers; i++) {
-            size_t tot = (size_t)n->w16_rows[i] * n->kp[i] + (size_t)n->wt16_rows[i] * n->kp[i + 1];
-            hipLaunchKernelGGL(k_weight_shadows<false>, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
-                               l->shadows + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
-            if (l->shadows_h) {   // fp16 mode: the same four copies in fp16 for the minibatch kernels
-                hipLaunchKernelGGL(k_weight_shadows<true>, dim3((tot + 255) / 256), dim3(256), 0, l->stream, (const float*)(l->params + n->w_off[i]), n->dims[i + 1], n->dims[i],
-                                   l->shadows_h + n->w16_off[i], n->w16_rows[i], n->kp[i], l->shadows_h + n->wt16_off[i], n->wt16_rows[i], n->kp[i + 1]);
-                hipLaunchKernelGGL(k_weight_frags, dim3(((size_t)n->w16_rows[i] * n->kp[i] + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows_h + n->w16_off[i]), n->w16_rows[i], n->kp[i],
-                                   l->shadows_h + n->wf16_off[i]);
-                hipLaunchKernelGGL(k_weight_frags, dim3(((size_t)n->wt16_rows[i] * n->kp[i + 1] + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows_h + n->wt16_off[i]), n->wt16_rows[i], n->kp[i + 1],
-                                   l->shadows_h + n->wtf16_off[i]);
+    for (int pass = 0; pass < (l->shadows_h ? 2 : 1); pass++) {      // bf16 copies; in fp16 mode the same four copies in fp16 for the minibatch kernels
+        short* const base = pass == 0 ? l->shadows : l->shadows_h;
+        RefreshArgs a{}; int nl = 0; size_t most = 0;
+        for (const Net* n : {&l->pol, &l->cri})
+            for (int i = 0; i < n->n_layers; i++) {
+                RefreshLayer& L = a.L[nl++];
+                L.W = l->params + n->w_off[i]; L.N = n->dims[i + 1]; L.K = n->dims[i];
+                L.w16 = base + n->w16_off[i]; L.wt16 = base + n->wt16_off[i]; L.wf = base + n->wf16_off[i]; L.wtf = base + n->wtf16_off[i];
+                L.rows16 = n->w16_rows[i]; L.ld16 = n->kp[i]; L.rowst = n->wt16_rows[i]; L.ldt = n->kp[i + 1];
+                most = std::max(most, std::max((size_t)L.rows16 * L.ld16, (size_t)L.rowst * L.ldt));
             }
-            LCHK(l, hipGetLastError());
-            const size_t nf = (size_t)n->w16_rows[i] * n->kp[i];
-            hipLaunchKernelGGL(k_weight_frags, dim3((nf + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->w16_off[i]), n->w16_rows[i], n->kp[i],
-                               l->shadows + n->wf16_off[i]);
-            LCHK(l, hipGetLastError());
-            const size_t nft = (size_t)n->wt16_rows[i] * n->kp[i + 1];
-            hipLaunchKernelGGL(k_weight_frags, dim3((nft + 255) / 256), dim3(256), 0, l->stream, (const short*)(l->shadows + n->wt16_off[i]), n->wt16_rows[i], n->kp[i + 1],
-                               l->shadows + n->wtf16_off[i]);
-            LCHK(l, hipGetLastError());
-        }
+        const dim3 grid((unsigned)((most + 255) / 256), (unsigned)nl);
+        if (pass == 0) hipLaunchKernelGGL(k_refresh_all<false>, grid, dim3(256), 0, l->stream, a);
+        else hipLaunchKernelGGL(k_refresh_all<true>, grid, dim3(256), 0, l->stream, a);
+        LCHK(l, hipGetLastError());
     }
     l->shadows_dirty = false;
     return RLGPU_OK;

@@ -62,15 +62,27 @@ __global__ void k_carry_obs(float* obs, const int32_t* steps, int players, int n
 __global__ void k_ragged_sums(const float* ret, const float* adv, const float* tgt, const float* rew, const int32_t* steps, int players, int Tused, int n, float* out) {
     float s[4] = {0, 0, 0, 0};
     const size_t total = (size_t)Tused * n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i / n), a = (int)(i % n);
-        if (t < steps[a / players]) { s[0] += fabsf(ret[i]); s[1] += fabsf(adv[i]); s[2] += fabsf(tgt[i]); s[3] += rew[i]; }
+    const size_t nt = (size_t)gridDim.x * blockDim.x, g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt % (size_t)n == 0) {
+        // a thread keeps its column (one division per thread, not per element: the 64-bit i / n, i % n of the general loop below were most of
+        // this kernel's 57 us) and walks down the steps
+        const int a = (int)(g % (size_t)n), dt = (int)(nt / (size_t)n), lim = min(Tused, steps[a / players]);
+        for (int t = (int)(g / (size_t)n); t < lim; t += dt) { const size_t i = (size_t)t * n + a; s[0] += fabsf(ret[i]); s[1] += fabsf(adv[i]); s[2] += fabsf(tgt[i]); s[3] += rew[i]; }
+    } else {
+        for (size_t i = g; i < total; i += nt) {
+            const int t = (int)(i / n), a = (int)(i % n);
+            if (t < steps[a / players]) { s[0] += fabsf(ret[i]); s[1] += fabsf(adv[i]); s[2] += fabsf(tgt[i]); s[3] += rew[i]; }
+        }
     }
+    // one atomic per workgroup and value (four same-address atomics per WAVEFRONT were most of this kernel's 57 us)
+    __shared__ float part[4][4];
     for (int k = 0; k < 4; k++) {
         float v = s[k];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < 4) { float v = 0.f; for (int w = 0; w < (int)(blockDim.x >> 6); w++) v += part[w][threadIdx.x]; atomicAdd(&out[threadIdx.x], v); }
 }
 
 std::filesystem::path g_mesh_folder;
@@ -705,7 +717,7 @@ void Learner::AddNewExperienceRagged(Report& report) {
         returnStats.Increment(first, k);
     }
     HOST_HIP(hipMemsetAsync(m.scratch, 0, 32, nullptr));
-    hipLaunchKernelGGL(k_ragged_sums, dim3(256), dim3(256), 0, nullptr, (const float*)m.ret, (const float*)m.adv, (const float*)m.tgt, (const float*)m.rew, (const int32_t*)m.steps,
+    hipLaunchKernelGGL(k_ragged_sums, dim3(128), dim3(256), 0, nullptr, (const float*)m.ret, (const float*)m.adv, (const float*)m.tgt, (const float*)m.rew, (const int32_t*)m.steps,
                        m.nPlayers, m.Tused, m.nAgents, m.scratch);
     float h[4];
     HOST_HIP(hipMemcpy(h, m.scratch, 16, hipMemcpyDeviceToHost));

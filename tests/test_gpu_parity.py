@@ -806,14 +806,17 @@ def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs, bf1
             assert env.collect(ppo, T, obs, acts, logp, rew, done)
         else:
             for t in range(T):
-                ppo.act(obs[t], acts[t], logp[t])
-                env.step(acts[t], obs[t + 1], rew[t], done[t])
+                # the learner and the env batch work on streams of their own: every hand-over is synchronised (without this the step kernel can
+                # read acts[t] before the policy wrote it -- whether it does depends on which hardware queues the two streams landed on, i.e. on
+                # how many streams earlier tests of the process created: this test failed exactly when it ran right after the learner tests)
+                ppo.act(obs[t], acts[t], logp[t]); ppo.sync()
+                env.step(acts[t], obs[t + 1], rew[t], done[t]); env.sync()
         env.sync()
         # one more sequential step from both: the resident env state and the sampler counter moved identically
         a2 = torch.zeros(N, dtype=torch.int32, device=dev); l2 = torch.zeros(N, device=dev); o2 = torch.zeros((N, D), device=dev)
         r2 = torch.zeros(N, device=dev); d2 = torch.zeros(N, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        ppo.act(obs[T], a2, l2); env.step(a2, o2, r2, d2); env.sync()
+        ppo.act(obs[T], a2, l2); ppo.sync(); env.step(a2, o2, r2, d2); env.sync()
         out.append([x.cpu().numpy() for x in (obs, acts, logp, rew, done, a2, l2, o2, r2, d2)])
     names = ("obs", "actions", "logp", "reward", "done", "next actions", "next logp", "next obs", "next reward", "next done")
     for a, b, name in zip(out[0], out[1], names):

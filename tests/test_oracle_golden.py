@@ -396,6 +396,18 @@ def test_cabi_exports_every_declared_symbol():
     assert C.sizeof(ArenaState) > 0
 
 
+def test_staged_word_rows_equal_the_visitor_count():
+    """The kernels' staged load / store loops run over arena_num_words<NC>() word rows, the resident allocation is sized by what arena_visit
+    visits: the two are one number for every team size (a formula one word per car too large wrote NC rows past the allocation)."""
+    from rlgymppo_cpp_amd import _lib
+    lib = _lib.load()
+    for team in (1, 2, 3):
+        v, s = C.c_int(0), C.c_int(0)
+        assert lib.rlgpu_state_word_counts(team, C.byref(v), C.byref(s)) == 0
+        assert v.value == s.value > 0, (team, v.value, s.value)
+    assert lib.rlgpu_state_word_counts(4, C.byref(v), C.byref(s)) != 0
+
+
 def test_host_helpers_without_gpu():
     from rlgymppo_cpp_amd.env import procedural_mesh, action_table
     v, t = procedural_mesh()
