@@ -134,9 +134,9 @@ typedef struct RlgpuGymState {
  * simply shorter: readers pad them with ball_rot = identity, valid = 0).
  *   ball_rot   BallState::rotMat (Ball.h:17-44, Ball.cpp:27-30,41).  Under ArenaConfig::noBallRot (ArenaConfig.h:33, the default, which the
  *              gym's arenas use) the ball's orientation is never integrated (btRigidBody.cpp:102-106): it stays what the last SetState gave it
- *              and is reported back by every GetState.  rlgpu_env_upload_states stores it (all zeros = identity), every download hands it back.
- *              The host build of the stepper (oracle/arena_port.cpp) steps in this basis, bit for bit like the reference
- *              (tests/golden/ballrot_golden.npz); the device kernels step with the identity -- DESIGN.md "Known deviations".
+ *              and is reported back by every GetState.  rlgpu_env_upload_states stores it (all zeros = identity) in the env's resident
+ *              words, every download hands it back.  The kernels and the host build of the stepper (oracle/arena_port.cpp) step in this
+ *              basis, bit for bit like the reference (tests/golden/ballrot_golden.npz).
  *   valid, bp_hist, wreck_rot   RESERVED (written as 0 / read as "absent").  The slots for the arena's other hidden state -- btRSBroadphase's
  *              memory of its dynamic proxies ([0] ball, [1 + k] car slot k: cell of the last setAabb, 13 bits, and arrival rank, 3 bits) and
  *              the basis of a demolished car's rigid body (Car.cpp:69-80,135-138).  Both are resident on the device per env; moving them

@@ -411,9 +411,7 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
             c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, 0.f, 0.f);
         }
         A.ball.b.pos = v3(0, 0, K::BALL_REST_Z) * UU2BT; A.ball.b.vel = v3(0, 0, 0); A.ball.b.angvel = v3(0, 0, 0);
-#if !defined(__HIP_DEVICE_COMPILE__)
-        A.ball.b.rot = m3_identity();      // a BallState's default rotMat (on the device the basis IS the identity: arena_io.h arena_finish_load)
-#endif
+        A.ball.b.rot = m3_identity();      // a BallState's default rotMat
     } else {
         // RandomState::ResetState (StateSetters/RandomState.cpp:8-61)
         const float X_MAX = 3500, Y_MAX = 4000, Z_MAX = 1820, CAR_Z_MIN = 150;
@@ -425,9 +423,7 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
             bw = rng.uni3(-4, 4, -4, 4, -4, 4);
         }
         A.ball.b.pos = bp * UU2BT; A.ball.b.vel = bv * UU2BT; A.ball.b.angvel = bw;
-#if !defined(__HIP_DEVICE_COMPILE__)
         A.ball.b.rot = m3_identity();
-#endif
         for (int k = 0; k < NC; k++) {
             Car& c = A.cars[k]; car_set_fresh(c);
             V3 pos = rng.uni3(-X_MAX, X_MAX, -Y_MAX, Y_MAX, CAR_Z_MIN, Z_MAX);

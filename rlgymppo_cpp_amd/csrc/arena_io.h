@@ -63,6 +63,7 @@ template <int NC, class IO>
 RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
     io.l(A.tick_count); io.l(A.ball_update_counter);
     io.v(A.ball.b.pos); io.v(A.ball.b.vel); io.v(A.ball.b.angvel); io.v(A.ball.vel_impulse_cache);
+    io.v(A.ball.b.rot.r0); io.v(A.ball.b.rot.r1); io.v(A.ball.b.rot.r2);   // BallState::rotMat: constant under ArenaConfig::noBallRot, but whatever a state setter made it
     for (int k = 0; k < NC; k++) {
         Car& c = A.cars[k];
         io.v(c.b.pos); io.v(c.b.rot.r0); io.v(c.b.rot.r1); io.v(c.b.rot.r2); io.v(c.b.vel); io.v(c.b.angvel);
@@ -121,19 +122,14 @@ constexpr size_t arena_num_words() {
     // collection launch read and WROTE NC rows past the end of the resident words -- harmless while the rows fell into the allocation's
     // page slack, garbage in the allocation behind it (the action table) when they did not.)  rlgpu_env_create refuses to run on a
     // mismatch, rlgpu_state_word_counts reports both numbers to the CPU tests.
-    return 4 + 12 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2;
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2;
 }
 
-// finish a freshly loaded working copy: derived values that are not stored.  The ball's basis (BallState::rotMat) is not among the resident
-// words: the device kernels step with the identity -- what every built-in state setter leaves; the basis a user setter uploads is kept by
-// the host side of the library and handed back by every download (rlgpu_env.hip) --, the HOST build steps in the basis arena_from_host gave it.
+// finish a freshly loaded working copy: derived values that are not stored.  The ball's basis (BallState::rotMat) IS stored (nine resident
+// words): every built-in state setter leaves the identity, a user setter's basis arrives through arena_from_host.
 template <int NC>
 RLG_HD void arena_finish_load(Arena<NC>& A) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    A.ball.b.rot = m3_identity();
-#else
-    if (A.ball.b.rot.r0.x == 0.f && A.ball.b.rot.r0.y == 0.f && A.ball.b.rot.r0.z == 0.f) A.ball.b.rot = m3_identity();   // (a working copy that never saw arena_from_host)
-#endif
+    if (A.ball.b.rot.r0.x == 0.f && A.ball.b.rot.r0.y == 0.f && A.ball.b.rot.r0.z == 0.f) A.ball.b.rot = m3_identity();   // (words that never saw a setter or arena_from_host: all zero)
     A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
     body_update_inertia(A.ball.b, ball_inv_inertia_local());
     for (int k = 0; k < NC; k++) {
@@ -163,13 +159,11 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
     for (int b = 0; b <= NC; b++) A.bp_hist[b] = 0;      // no history travels with the exchange struct: a fresh arena set to this state
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
-#if !defined(__HIP_DEVICE_COMPILE__)
-    {   // HOST build: BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
+    {   // BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
         bool all_zero = true;
         for (int q = 0; q < 9; q++) all_zero = all_zero && s.hidden.ball_rot[q] == 0.f;
         A.ball.b.rot = all_zero ? m3_identity() : m3_cols(ld3(s.hidden.ball_rot), ld3(s.hidden.ball_rot + 3), ld3(s.hidden.ball_rot + 6));
     }
-#endif
     for (int k = 0; k < NC; k++) {
         const RlgpuCarState& o = s.cars[k]; Car& c = A.cars[k];
         c.b.pos = ld3(o.pos) * UU2BT;
@@ -216,10 +210,8 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
     s.tick_count = A.tick_count; s.ball_update_counter = A.ball_update_counter;
     st3(s.ball.pos, A.ball.b.pos * BT2UU); st3(s.ball.vel, A.ball.b.vel * BT2UU); st3(s.ball.ang_vel, A.ball.b.angvel);
     st3(s.ball.vel_impulse_cache, A.ball.vel_impulse_cache * BT2UU);
-#if !defined(__HIP_DEVICE_COMPILE__)
-    st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));   // (the device's downloads get it from the library's host side)
+    st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));
     s.hidden.valid = 0u;
-#endif
     for (int k = 0; k < NC; k++) {
         RlgpuCarState& o = s.cars[k]; const Car& c = A.cars[k];
         st3(o.pos, c.b.pos * BT2UU);

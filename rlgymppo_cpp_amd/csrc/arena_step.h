@@ -343,13 +343,10 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                 // btSphereShape::localGetSupportingVertex: the point (0,0,0) pushed out by getMargin() (= the radius) along the normalised direction
                 V3 vtx = dir * r;                                      // |dir| = 1 exactly for the axis-aligned planes
                 V3 vip = vtx + (bp + (-po));
-#if !defined(__HIP_DEVICE_COMPILE__)
-                // HOST build only: the ball in the basis a user state setter gave it (BallState::rotMat, constant under ArenaConfig::noBallRot;
-                // tests/golden/ballrot_golden.npz).  The device kernels step with the identity (arena_io.h arena_finish_load).
+                // the ball in the basis a user state setter gave it (BallState::rotMat, constant under ArenaConfig::noBallRot; tests/golden/ballrot_golden.npz)
                 if (!(A.ball.b.rot.r0.x == 1.f && A.ball.b.rot.r1.y == 1.f && A.ball.b.rot.r2.z == 1.f)) {
                     vtx = normalized(tmul(A.ball.b.rot, -pn)) * r; vip = (A.ball.b.rot * vtx) + (bp + (-po));
                 }
-#endif
                 float dist = dot(pn, vip);
                 if (!(dist < CBT_BALL) || n >= BALL_REGION) continue;
                 V3 pb = (vip - pn * dist) + po;

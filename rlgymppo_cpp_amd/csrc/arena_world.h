@@ -544,11 +544,8 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
     {
         const float r = K::BALL_RADIUS * UU2BT;
         const V3 bp = A.ball.b.pos;
-#if !defined(__HIP_DEVICE_COMPILE__)   /* HOST build: the cast runs in the ball's basis (BallState::rotMat), as btCollisionWorld::rayTestSingle's convex cast does */
+        // the cast runs in the ball's basis (BallState::rotMat), as btCollisionWorld::rayTestSingle's convex cast does
         if (ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r))) ray_convex_hit(from, to, A.ball.b.rot, bp, v3(0, 0, 0), r, 1, best);
-#else
-        if (ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r))) ray_convex_hit(from, to, m3_identity(), bp, v3(0, 0, 0), r, 1, best);
-#endif
     }
     // other cars' hitboxes.  A car that is demoed, or was respawned this tick, has no contact response (Car.cpp:69-80) but its rigid body
     // stays in the world where it stopped: the ray test finds the CLOSEST object first and only then asks whether it responds

@@ -1043,7 +1043,6 @@ struct rlgpu_env {
     // integrates the ball's orientation: it is whatever the last SetState gave it and every GetState hands it back (Ball.cpp:27-49).  The device
     // kernels step with the identity basis (csrc/arena_io.h arena_finish_load) and never see this: uploads store it, downloads report it, an explicit
     // reset by a built-in setter puts the identity back (the resets inside the step kernels leave it alone).
-    std::vector<float> ball_rot;
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
@@ -1137,8 +1136,6 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
         const size_t staged = e->nc == 2 ? arena_num_words<2>() : (e->nc == 4 ? arena_num_words<4>() : arena_num_words<6>());
         if (staged != e->n_words) { e->err = "arena_num_words disagrees with arena_visit (" + std::to_string(staged) + " vs " + std::to_string(e->n_words) + " words per env)"; return RLGPU_ERR_ARG; }
     }
-    e->ball_rot.assign(9 * (size_t)n_envs, 0.f);
-    for (int i = 0; i < n_envs; i++) e->ball_rot[9 * (size_t)i] = e->ball_rot[9 * (size_t)i + 4] = e->ball_rot[9 * (size_t)i + 8] = 1.f;
     HIPCHK(e, hipMalloc(&e->d.words, e->n_words * (size_t)n_envs * 4));
     HIPCHK(e, hipMemset(e->d.words, 0, e->n_words * (size_t)n_envs * 4));
     float tab[90 * 8]; build_action_table(tab);
@@ -1283,13 +1280,6 @@ int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host, const int
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     (void)hipFree(dsrc); if (dids) (void)hipFree(dids);
-    for (int i = 0; i < n; i++) {      // Ball::SetState: newTransform.setBasis(state.rotMat) (Ball.cpp:41); all zeros = a caller that knows nothing of the appended block
-        const int env = env_ids ? env_ids[i] : i;
-        if (env < 0 || env >= e->n_envs) continue;
-        bool all_zero = true;
-        for (int q = 0; q < 9; q++) all_zero = all_zero && host[i].hidden.ball_rot[q] == 0.f;
-        for (int q = 0; q < 9; q++) e->ball_rot[9 * (size_t)env + q] = all_zero ? ((q % 4 == 0) ? 1.f : 0.f) : host[i].hidden.ball_rot[q];
-    }
     return RLGPU_OK;
 }
 int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t* env_ids, int n) {
@@ -1305,12 +1295,6 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
     HIPCHK(e, hipMemcpyAsync(host, ddst, sizeof(RlgpuArenaState) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     (void)hipFree(ddst); if (dids) (void)hipFree(dids);
-    for (int i = 0; i < n; i++) {      // Ball::GetState: _internalState.rotMat = the rigid body's basis (Ball.cpp:27-30)
-        const int env = env_ids ? env_ids[i] : i;
-        if (env < 0 || env >= e->n_envs) continue;
-        for (int q = 0; q < 9; q++) host[i].hidden.ball_rot[q] = e->ball_rot[9 * (size_t)env + q];
-        host[i].hidden.valid = 0;
-    }
     return RLGPU_OK;
 }
 
@@ -1319,7 +1303,6 @@ int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
     dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
     DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev, (const int32_t*)nullptr, 0);
     HIPCHK(e, hipGetLastError());
-    if (run_setter) for (int i = 0; i < e->n_envs; i++) for (int q = 0; q < 9; q++) e->ball_rot[9 * (size_t)i + q] = (q % 4 == 0) ? 1.f : 0.f;   // a built-in setter's BallState: the default basis
     return RLGPU_OK;
 }
 
@@ -1335,7 +1318,6 @@ int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_se
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     (void)hipFree(dids);
-    if (run_setter) for (int i = 0; i < n; i++) if (env_ids[i] >= 0 && env_ids[i] < e->n_envs) for (int q = 0; q < 9; q++) e->ball_rot[9 * (size_t)env_ids[i] + q] = (q % 4 == 0) ? 1.f : 0.f;
     return RLGPU_OK;
 }
 
@@ -1377,7 +1359,6 @@ int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host, int first_
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpyAsync(host, e->d.snap_out + first_env, sizeof(RlgpuArenaState) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    for (int i = 0; i < n; i++) { for (int q = 0; q < 9; q++) host[i].hidden.ball_rot[q] = e->ball_rot[9 * (size_t)(first_env + i) + q]; host[i].hidden.valid = 0; }
     return RLGPU_OK;
 }
 

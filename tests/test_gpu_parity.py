@@ -780,6 +780,41 @@ def test_collection_during_learn_mode():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("team_size,n_envs", [(1, 512), (1, 1024), (2, 256), (3, 171)])
+def test_identical_collection_flows_are_identical(team_size, n_envs):
+    """Two env batches under the same flow of fused collection launches (sampler rewound in between): outputs AND the downloaded resident states are
+    equal byte for byte after every launch.  Regression for the staged word rows that ran NC x n_envs words past the resident allocation
+    (csrc/arena_io.h arena_num_words): with batches this size the rows no longer fit the page slack and overwrote the action table behind it,
+    and one of two identical flows ended launches with car controls that are no rows of the table (tools/determinism/)."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    from rlgymppo_cpp_amd import _lib
+    dev = torch.device("cuda", 0); CAP = 12
+    cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 9
+    ea, eb = BatchedEnv(n_envs, team_size, cfg=cfg), BatchedEnv(n_envs, team_size, cfg=cfg)
+    v, st = C.c_int(0), C.c_int(0)
+    assert ea.lib.rlgpu_state_word_counts(team_size, C.byref(v), C.byref(st)) == 0 and v.value == st.value == ea.state_words()
+    core = PPOCore(ea.obs_size, ea.n_actions, (64, 64), (64, 64), use_bf16=True, max_rows=max(4096, ea.n_agents))
+    N, D = ea.n_agents, ea.obs_size
+    def bufs():
+        return (torch.zeros((CAP + 1, N, D), device=dev), torch.zeros((CAP, N), dtype=torch.int32, device=dev), torch.zeros((CAP, N), device=dev),
+                torch.full((CAP, N), -777.0, device=dev), torch.zeros((CAP, N), dtype=torch.int32, device=dev))
+    A, B = bufs(), bufs(); torch.cuda.synchronize()
+    ea.reset(True, A[0][0]); eb.reset(True, B[0][0]); ea.sync(); eb.sync()
+    for k in range(3):
+        s, c = core.get_sampler()
+        assert ea.collect(core, CAP, *A); ea.sync()
+        core.set_sampler(s, c)
+        assert eb.collect(core, CAP, *B); eb.sync()
+        for name, x, y in zip(("obs", "actions", "logp", "reward", "done"), A, B):
+            assert torch.equal(x, y), (k, name)
+        sa, sb = ea.download_states(), eb.download_states()
+        bad = [e for e in range(n_envs) if bytes(sa[e]) != bytes(sb[e])]
+        assert not bad, (k, bad[:8])
+        A[0][0].copy_(A[0][CAP]); B[0][0].copy_(B[0][CAP]); torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("team_size,n_envs,bf16", [(1, 70, True), (2, 21, True), (2, 20, True), (3, 9, True), (1, 70, False), (2, 21, False), (2, 20, False), (3, 9, False)])
 def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs, bf16):
     """rlgpu_collect (T x (inference + gym step) in one launch, every wavefront on its own envs) against T alternations of
@@ -1216,14 +1251,11 @@ def test_fused_minibatch_kernels_against_the_per_layer_path(rows, obs_size):
 
 @pytest.mark.gpu
 def test_hip_rotated_ball_basis_vs_reference_golden():
-    """BallState::rotMat across the device boundary (VERDICT r03 missing #2): the four tapes of tests/golden/ballrot_golden.npz (recorded from the
-    reference with a ball basis that is not the identity; the host build equals them bit for bit: test_port_rotated_ball_basis_vs_reference_golden)
-    as four envs of one batch.  The basis travels in RlgpuArenaState::hidden.ball_rot, is kept per env by the library and handed back unchanged
-    by every download, as the reference's GetState does under ArenaConfig::noBallRot.  The device KERNELS step with the identity basis (what
-    every built-in state setter leaves; DESIGN.md "Known deviations"), so against a reference whose ball IS rotated a tape is equal only until
-    the basis first rounds differently (a wheel ray's hit fraction, the plane contact's support vertex): the ball rolling up the side wall is
-    EQUAL to the reference over all its 300 ticks, the others for their first 12 / 33 / 124 ticks -- the horizons are asserted (with a
-    margin), so a change in either direction shows."""
+    """BallState::rotMat on the device (VERDICT r03 missing #2): the four tapes of tests/golden/ballrot_golden.npz (recorded from the reference
+    with a ball basis that is not the identity; the host build equals them bit for bit: test_port_rotated_ball_basis_vs_reference_golden) as
+    four envs of one batch.  The basis travels in RlgpuArenaState::hidden.ball_rot, is nine of the resident words, is what the plane contact's
+    support vertex and the wheel rays' convex cast are computed in, and comes back unchanged from every download, as the reference's GetState
+    does under ArenaConfig::noBallRot: every tick of every tape EQUAL to the reference."""
     from rlgymppo_cpp_amd.env import BatchedEnv
     from simlib import state_vec
     g = np.load(os.path.join(GOLD, "ballrot_golden.npz"))
@@ -1248,10 +1280,7 @@ def test_hip_rotated_ball_basis_vs_reference_golden():
     env.reset(True); env.sync()
     assert all(list(s.hidden.ball_rot) == [1, 0, 0, 0, 1, 0, 0, 0, 1] for s in env.download_states())
     env.close()
-    print("first differing tick per tape:", first_diff)
-    exact_at_least = {"rotated_ball_side_wall": 300, "car_drives_up_rotated_ball": 100, "car_dropped_on_rotated_ball": 30, "rotated_ball_into_car": 10}
-    for n in names:
-        assert first_diff.get(n, len(g[f"{n}/tape"]) + 1) > exact_at_least[n], (n, first_diff.get(n))
+    assert not first_diff, f"first differing tick per tape: {first_diff}"
 
 
 @pytest.mark.gpu
