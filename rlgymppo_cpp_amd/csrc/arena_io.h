@@ -122,7 +122,11 @@ constexpr size_t arena_num_words() {
     // collection launch read and WROTE NC rows past the end of the resident words -- harmless while the rows fell into the allocation's
     // page slack, garbage in the allocation behind it (the action table) when they did not.)  rlgpu_env_create refuses to run on a
     // mismatch, rlgpu_state_word_counts reports both numbers to the CPU tests.
+#ifdef RLG_TEST_EXTRA_WORD_ROWS   /* test build only (tools/build_variant.sh): the old defect on purpose, so the redzone test can be seen to catch it */
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2 + (size_t)NC * RLG_TEST_EXTRA_WORD_ROWS;
+#else
     return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2;
+#endif
 }
 
 // finish a freshly loaded working copy: derived values that are not stored.  The ball's basis (BallState::rotMat) IS stored (nine resident

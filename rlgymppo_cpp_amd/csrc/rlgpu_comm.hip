@@ -75,7 +75,7 @@ int shm_barrier(rlgpu_comm* c, const char* what) {
     const int want = c->my_phase * c->world;
     while (s->phase < want) {
         if (s->dead) return fail(c, std::string(what) + ": a peer rank failed");
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s)) return fail(c, std::string(what) + ": timed out leaving the barrier");
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s)) return fail(c, std::string(what) + ": rank " + std::to_string(c->rank) + " waited " + std::to_string(c->timeout_s) + " s for its peers to leave the barrier (a rank died?)");
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     return RLGPU_OK;

@@ -194,6 +194,11 @@ class BatchedEnv:
     def state_words(self) -> int:
         return self.lib.rlgpu_env_state_words(self.h)
 
+    def check_redzones(self) -> None:
+        """Debug mode (RLGPU_REDZONE=<bytes> in the environment when the batch was created): raises, naming the buffer, if a kernel wrote past the end
+        of one of the batch's device buffers."""
+        _chk(self.lib.rlgpu_env_check_redzones(self.h), self.h, self.lib.rlgpu_env_last_error)
+
 
 def procedural_mesh():
     lib = _lib.load()

@@ -780,6 +780,51 @@ def test_collection_during_learn_mode():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("team_size,n_envs,tess", [(1, 700, False), (2, 300, False), (3, 171, False), (1, 260, True)])
+def test_no_kernel_writes_past_a_device_buffer(team_size, n_envs, tess, monkeypatch):
+    """RLGPU_REDZONE: 64 KB of guard bytes behind every persistent device buffer of the batch; after resets, steps, physics ticks, uploads, downloads,
+    snapshots, lockstep and free-running collection launches every guard byte is what it was.  (The staged word rows of rounds 3-4 wrote
+    NC x n_envs words behind the resident state: this test fails on that build with "redzone of 'resident state words' overwritten".)"""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    from rlgymppo_cpp_amd import _lib
+    monkeypatch.setenv("RLGPU_REDZONE", "65536")
+    dev = torch.device("cuda", 0); T = 6
+    cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 7
+    mesh = "procedural"
+    if tess:
+        import bench
+        mesh = os.path.join(bench.make_tessellated_mesh_dir()[0], "soccar")
+    env = BatchedEnv(n_envs, team_size, cfg=cfg, mesh=mesh)
+    N, D = env.n_agents, env.obs_size
+    core = PPOCore(D, env.n_actions, (64, 64), (64, 64), use_bf16=True, max_rows=max(4096, N))
+    obs = torch.zeros((T + 1, N, D), device=dev); acts = torch.zeros((T, N), dtype=torch.int32, device=dev); logp = torch.zeros((T, N), device=dev)
+    rew = torch.zeros((T, N), device=dev); done = torch.zeros((T, N), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    env.reset(True, obs[0]); env.sync(); env.check_redzones()
+    env.enable_snapshots(True)
+    for t in range(3):
+        core.act(obs[0], acts[0], logp[0]); core.sync(); env.step(acts[0], obs[1], rew[0], done[0]); env.sync()
+    env.check_redzones()
+    st = env.download_states(); env.upload_states(st); env.physics_ticks(3); env.sync(); env.check_redzones()
+    env.enable_snapshots(False)
+    for k in range(2):
+        assert env.collect(core, T, obs, acts, logp, rew, done); env.sync()
+        obs[0].copy_(obs[T]); torch.cuda.synchronize()
+    env.check_redzones()
+    steps = torch.zeros(n_envs, dtype=torch.int32, device=dev); torch.cuda.synchronize()
+    assert env.collect_free(core, T, (T // 2) * N, obs, acts, logp, rew, done, steps); env.sync()
+    env.check_redzones()
+    env.reset(True, obs[0]); env.sync()
+    env.check_redzones()
+    # and the checker does see a stray store: one byte, 40 000 bytes behind the first buffer
+    assert env.lib.rlgpu_env_debug_overrun(env.h, 0, 40000) == 0
+    with pytest.raises(_lib.RlgpuError, match="redzone of 'resident state words'.*first at \\+40000"):
+        env.check_redzones()
+    env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("team_size,n_envs", [(1, 512), (1, 1024), (2, 256), (3, 171)])
 def test_identical_collection_flows_are_identical(team_size, n_envs):
     """Two env batches under the same flow of fused collection launches (sampler rewound in between): outputs AND the downloaded resident states are
