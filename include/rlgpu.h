@@ -82,6 +82,7 @@ int rlgpu_env_state_words(const rlgpu_env* e); /* resident 32-bit words per env 
 /* Debug mode: with RLGPU_REDZONE=<bytes> in the environment at rlgpu_env_create, every persistent device buffer of the batch is followed by that
  * many guard bytes; this reads them back (after a device synchronise) and fails, naming the buffer, if a kernel wrote past one. */
 int rlgpu_env_check_redzones(rlgpu_env* e);
+int rlgpu_learner_check_redzones(rlgpu_learner* l);   /* the same for the learner's buffers (RLGPU_REDZONE at rlgpu_learner_create) */
 int rlgpu_env_debug_overrun(rlgpu_env* e, int which, int past);   /* test hook: writes one guard byte of buffer `which`, so the check can be seen to fail */
 /* the two counts that must agree (no GPU needed): words arena_visit visits for a team size, and word rows the kernels stage per env */
 int rlgpu_state_word_counts(int team_size, int* visited, int* staged);

@@ -909,6 +909,9 @@ struct rlgpu_learner {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0; std::vector<double> ev_flops;
     double acc_ms = 0, acc_flops = 0; int acc_calls = 0;
     std::string err;
+    struct Redzone { void* base; size_t bytes; std::string name; };
+    std::vector<Redzone> redzones;   // RLGPU_REDZONE (debug): the guarded tail of every device buffer the learner owns (rlgpu_learner_check_redzones)
+    size_t redzone_bytes = 0;
 };
 
 struct rlgpu_shuffler { std::default_random_engine rng; std::vector<int64_t> scratch; };
@@ -1325,6 +1328,31 @@ int net_dw16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16
 
 extern "C" {
 
+// Debug mode RLGPU_REDZONE=<bytes> (read at create), as for the env batch (rlgpu_env.hip): guard bytes behind every device buffer of the learner.
+static hipError_t lz_malloc(rlgpu_learner* l, void** p, size_t bytes, const char* name) {
+    const size_t rz = l->redzone_bytes;
+    hipError_t r = hipMalloc(p, bytes + rz);
+    if (r != hipSuccess || !rz) return r;
+    r = hipMemset((char*)*p + bytes, 0xC5, rz);
+    l->redzones.push_back({*p, bytes, name});
+    return r;
+}
+int rlgpu_learner_check_redzones(rlgpu_learner* l) {
+    if (!l->redzone_bytes) { l->err = "rlgpu_learner_check_redzones: the learner was created without RLGPU_REDZONE"; return RLGPU_ERR_STATE; }
+    LCHK(l, hipSetDevice(l->device));
+    LCHK(l, hipDeviceSynchronize());
+    std::vector<unsigned char> h(l->redzone_bytes);
+    for (const auto& z : l->redzones) {
+        LCHK(l, hipMemcpy(h.data(), (const char*)z.base + z.bytes, h.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); i++) if (h[i] != 0xC5) {
+            size_t last = i; for (size_t j = i; j < h.size(); j++) if (h[j] != 0xC5) last = j;
+            l->err = "redzone of '" + z.name + "' (" + std::to_string(z.bytes) + " bytes) overwritten: first at +" + std::to_string(i) + ", last at +" + std::to_string(last) + " past its end";
+            return RLGPU_ERR_STATE;
+        }
+    }
+    return RLGPU_OK;
+}
+
 int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConfig* cfg) {
     if (!out || !cfg || cfg->obs_size <= 0 || cfg->n_actions <= 0 || cfg->n_actions > 128 || cfg->max_rows <= 0) return RLGPU_ERR_ARG;
     if (cfg->n_policy_layers < 0 || cfg->n_policy_layers > 8 || cfg->n_critic_layers < 0 || cfg->n_critic_layers > 8) return RLGPU_ERR_ARG;
@@ -1332,12 +1360,13 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     *out = l;
     l->device = device; l->cfg = *cfg;
     LCHK(l, hipSetDevice(device));
+    { const char* rz = getenv("RLGPU_REDZONE"); l->redzone_bytes = rz ? (size_t)atol(rz) : 0; }
     int64_t off = 0;
     build_net(l->pol, cfg->obs_size, cfg->policy_layers, cfg->n_policy_layers, cfg->n_actions, off);
     build_net(l->cri, cfg->obs_size, cfg->critic_layers, cfg->n_critic_layers, 1, off);
     l->n_total = off;
-    LCHK(l, hipMalloc(&l->params, off * 4)); LCHK(l, hipMalloc(&l->grads, off * 4));
-    LCHK(l, hipMalloc(&l->adam_m, off * 4)); LCHK(l, hipMalloc(&l->adam_v, off * 4));
+    LCHK(l, lz_malloc(l, (void**)&l->params, (size_t)(off * 4), "params")); LCHK(l, lz_malloc(l, (void**)&l->grads, (size_t)(off * 4), "grads"));
+    LCHK(l, lz_malloc(l, (void**)&l->adam_m, (size_t)(off * 4), "adam_m")); LCHK(l, lz_malloc(l, (void**)&l->adam_v, (size_t)(off * 4), "adam_v"));
     LCHK(l, hipMemset(l->grads, 0, off * 4)); LCHK(l, hipMemset(l->adam_m, 0, off * 4)); LCHK(l, hipMemset(l->adam_v, 0, off * 4));
     // torch nn::Linear default init: W, b ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming_uniform(a=sqrt 5)); Philox stream
     std::vector<float> h(off);
@@ -1356,32 +1385,32 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
     LCHK(l, hipMemcpy(l->params, h.data(), off * 4, hipMemcpyHostToDevice));
     size_t R = (size_t)cfg->max_rows;
     int maxw = std::max(cfg->obs_size, cfg->n_actions);
-    for (int i = 0; i < l->pol.n_layers; i++) { float* p; LCHK(l, hipMalloc(&p, R * l->pol.dims[i + 1] * 4)); l->act_p.push_back(p); maxw = std::max(maxw, l->pol.dims[i + 1]); }
-    for (int i = 0; i < l->cri.n_layers; i++) { float* p; LCHK(l, hipMalloc(&p, R * l->cri.dims[i + 1] * 4)); l->act_c.push_back(p); maxw = std::max(maxw, l->cri.dims[i + 1]); }
-    LCHK(l, hipMalloc(&l->dbuf0, R * maxw * 4)); LCHK(l, hipMalloc(&l->dbuf1, R * maxw * 4));
-    LCHK(l, hipMalloc(&l->gathered, R * cfg->obs_size * 4));
-    LCHK(l, hipMalloc(&l->norm_buf, (4 + 2 * SUMSQ_BLOCKS) * 4));   // [0..1] the two networks' squared gradient norms, then their per-workgroup partials
+    for (int i = 0; i < l->pol.n_layers; i++) { float* p; LCHK(l, lz_malloc(l, (void**)&p, (size_t)(R * l->pol.dims[i + 1] * 4), "policy activations")); l->act_p.push_back(p); maxw = std::max(maxw, l->pol.dims[i + 1]); }
+    for (int i = 0; i < l->cri.n_layers; i++) { float* p; LCHK(l, lz_malloc(l, (void**)&p, (size_t)(R * l->cri.dims[i + 1] * 4), "critic activations")); l->act_c.push_back(p); maxw = std::max(maxw, l->cri.dims[i + 1]); }
+    LCHK(l, lz_malloc(l, (void**)&l->dbuf0, (size_t)(R * maxw * 4), "dbuf0")); LCHK(l, lz_malloc(l, (void**)&l->dbuf1, (size_t)(R * maxw * 4), "dbuf1"));
+    LCHK(l, lz_malloc(l, (void**)&l->gathered, (size_t)(R * cfg->obs_size * 4), "gathered"));
+    LCHK(l, lz_malloc(l, (void**)&l->norm_buf, (size_t)((4 + 2 * SUMSQ_BLOCKS) * 4), "norm_buf"));   // [0..1] the two networks' squared gradient norms, then their per-workgroup partials
     if (cfg->use_bf16 < 0 || cfg->use_bf16 > 2) { l->err = "use_bf16: 0 (fp32), 1 (bf16) or 2 (fp16 operands + dynamic loss scale)"; return RLGPU_ERR_ARG; }
     if (cfg->use_bf16) {
         int64_t soff = 0;
         plan_shadows(l->pol, soff); plan_shadows(l->cri, soff);
         l->n_shadow = soff;
-        LCHK(l, hipMalloc(&l->shadows, soff * 2));
+        LCHK(l, lz_malloc(l, (void**)&l->shadows, (size_t)(soff * 2), "shadows"));
         if (cfg->use_bf16 == 2) {
             // (kp is planned now: the shape test of fused_capable applies)
             if (!fused_capable(l)) { l->err = "use_bf16 = 2 (fp16 operands): only the shape the fused minibatch kernels cover (obs <= 192 padded, 256 x 3 hidden, n_actions 65..96)"; return RLGPU_ERR_ARG; }
-            LCHK(l, hipMalloc(&l->shadows_h, soff * 2));
+            LCHK(l, lz_malloc(l, (void**)&l->shadows_h, (size_t)(soff * 2), "shadows_h"));
         }
         int maxkp = l->pol.kp[0];
         for (const Net* n : {&l->pol, &l->cri}) for (int i = 0; i <= n->n_layers; i++) maxkp = std::max(maxkp, n->kp[i]);
-        LCHK(l, hipMalloc(&l->x16, R * l->pol.kp[0] * 2));
-        for (int i = 0; i + 1 < l->pol.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->pol.kp[i + 1] * 2)); l->act16_p.push_back(p); }
-        for (int i = 0; i + 1 < l->cri.n_layers; i++) { short* p; LCHK(l, hipMalloc(&p, R * l->cri.kp[i + 1] * 2)); l->act16_c.push_back(p); }
-        LCHK(l, hipMalloc(&l->g16a, R * maxkp * 2)); LCHK(l, hipMalloc(&l->g16b, R * maxkp * 2));
+        LCHK(l, lz_malloc(l, (void**)&l->x16, (size_t)(R * l->pol.kp[0] * 2), "x16"));
+        for (int i = 0; i + 1 < l->pol.n_layers; i++) { short* p; LCHK(l, lz_malloc(l, (void**)&p, (size_t)(R * l->pol.kp[i + 1] * 2), "policy activations (16-bit)")); l->act16_p.push_back(p); }
+        for (int i = 0; i + 1 < l->cri.n_layers; i++) { short* p; LCHK(l, lz_malloc(l, (void**)&p, (size_t)(R * l->cri.kp[i + 1] * 2), "critic activations (16-bit)")); l->act16_c.push_back(p); }
+        LCHK(l, lz_malloc(l, (void**)&l->g16a, (size_t)(R * maxkp * 2), "g16a")); LCHK(l, lz_malloc(l, (void**)&l->g16b, (size_t)(R * maxkp * 2), "g16b"));
         for (int w = 0; w < 2; w++) {
             const Net& net = w == 0 ? l->pol : l->cri;
             for (int i = 0; i < net.n_layers; i++) {
-                LCHK(l, hipMalloc(&l->dy16[w][i], R * maxkp * 2));
+                LCHK(l, lz_malloc(l, (void**)&l->dy16[w][i], (size_t)(R * maxkp * 2), "dy16"));
                 LCHK(l, hipEventCreateWithFlags(&l->ev_dy[w][i], hipEventDisableTiming));
             }
             LCHK(l, hipStreamCreateWithFlags(&l->dw_stream[w], hipStreamNonBlocking));

@@ -151,6 +151,11 @@ class PPOCore:
     def clip_adam_step(self, max_norm=0.5, grad_scale=1.0):
         _chk(self.lib.rlgpu_clip_adam_step(self.h, max_norm, grad_scale), self.h, self._err)
 
+    def check_redzones(self) -> None:
+        """Debug mode (RLGPU_REDZONE=<bytes> in the environment when the learner was created): raises, naming the buffer, if a kernel wrote past the end of
+        one of the learner's device buffers."""
+        _chk(self.lib.rlgpu_learner_check_redzones(self.h), self.h, self._err)
+
     def loss_scale(self):
         """(scale, clean steps counted, steps skipped) of the fp16 mode's dynamic loss scale; scale 1 in the other modes."""
         import ctypes as C

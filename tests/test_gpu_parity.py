@@ -815,6 +815,7 @@ def test_no_kernel_writes_past_a_device_buffer(team_size, n_envs, tess, monkeypa
     steps = torch.zeros(n_envs, dtype=torch.int32, device=dev); torch.cuda.synchronize()
     assert env.collect_free(core, T, (T // 2) * N, obs, acts, logp, rew, done, steps); env.sync()
     env.check_redzones()
+    core.check_redzones()
     env.reset(True, obs[0]); env.sync()
     env.check_redzones()
     # and the checker does see a stray store: one byte, 40 000 bytes behind the first buffer
@@ -1149,7 +1150,7 @@ def _torch_ppo_reference(pol_flat, cri_flat, D, H, A, obs, acts, old_logp, adv, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows", [8192 + 37, 65536])
-def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows):
+def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows, monkeypatch):
     """SURVEY A18 at the shape the bench runs: obs 89 -> 256 x 3 -> 90 / 1, a minibatch of 8 229 rows (ragged against every tile: 128-row GEMM
     tiles, 512-row dW slabs) and one of 65 536 (the bench's: 128 slabs per dW GEMM summed with fp32 atomics, four streams joined), gathered
     through a shuffled index list out of a larger buffer.  Reference: PPOLearner.cpp:139-215 as a torch autograd graph built IN the test, in
@@ -1168,6 +1169,7 @@ def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows):
     idx = rng.permutation(pool)[:rows].astype(np.int32)
     clip, ent_coef, scale = 0.2, 0.01, 0.25
     want = None
+    monkeypatch.setenv("RLGPU_REDZONE", "65536")   # guard bytes behind every buffer of the learner: checked after the minibatch (fp32 per-layer path, bf16 fused path)
     for bf16 in (False, True):
         core = PPOCore(D, A, H, H, ent_coef=ent_coef, clip_range=clip, use_bf16=bf16, seed=99, max_rows=rows)
         pol_flat, cri_flat = core.get_params(0), core.get_params(1)
@@ -1189,6 +1191,7 @@ def test_ppo_minibatch_at_the_flagship_shape_against_torch_autograd(rows):
         core.zero_grads()
         core.minibatch(d_obs, d_acts, d_olp, d_adv, d_tgt, d_idx, rows, scale, metrics)
         core.sync()
+        core.check_redzones()
         gp, gc = core.get_grads(0).astype(np.float64), core.get_grads(1).astype(np.float64)
         m = metrics.cpu().numpy().astype(np.float64)
         for g, w, name, terr in ((gp, want[0], "policy", torch_err[0]), (gc, want[1], "critic", torch_err[1])):
@@ -1341,7 +1344,7 @@ def test_value_stripe_kernel_against_the_inference_kernel(rows, obs_size):
 
 
 @pytest.mark.gpu
-def test_fp16_operand_mode_with_dynamic_loss_scale():
+def test_fp16_operand_mode_with_dynamic_loss_scale(monkeypatch):
     """BASELINE configs[4] words its precision "fp16 autocast" (VERDICT r03 row G2).  use_bf16 = 2: the PPO minibatch kernels (csrc/ppo_fused.h)
     take fp16 operands -- weights, activations, activation gradients -- with fp32 sums and master weights, and the loss gradient is multiplied by
     amp::GradScaler's dynamic scale (PRIV/Util/gradscaler.hpp:26-34: 2^16 at the start, x 2 after 2000 clean steps, x 0.5 after an overflow,
@@ -1352,6 +1355,7 @@ def test_fp16_operand_mode_with_dynamic_loss_scale():
     optimizer step moves the parameters and counts towards the next doubling; (3) an overflowing minibatch (advantages of 1e30) leaves
     the parameters and Adam's step count alone, halves the scale and is counted as skipped."""
     from rlgymppo_cpp_amd.ppo import PPOCore
+    monkeypatch.setenv("RLGPU_REDZONE", "65536")
     dev = torch.device("cuda", 0)
     D, A, H, rows = 89, 90, (256, 256, 256), 8229
     rng = np.random.RandomState(11)
@@ -1389,4 +1393,5 @@ def test_fp16_operand_mode_with_dynamic_loss_scale():
     assert core.loss_scale() == (32768.0, 0, 1)
     _, _, sp, sc = core.get_adam_state()
     assert sp == 1 and sc == 1
+    core.check_redzones()   # no kernel of the fp16 mode wrote past a buffer of the learner (RLGPU_REDZONE, set above)
     core.close()

@@ -18,12 +18,13 @@ olp = t((-4.5 + rng.randn(rows + 100) * 0.2).astype(np.float32)); adv = t(rng.ra
 idx = t(rng.permutation(rows + 100)[:rows].astype(np.int32)); m = torch.zeros(8, device=dev)
 core.zero_grads(); core.minibatch(obs, acts, olp, adv, tgt, idx, rows, 0.25, m); core.sync()
 np.savez(sys.argv[1], gp=core.get_grads(0), gc=core.get_grads(1), m=m.cpu().numpy())
+core.check_redzones()   # (RLGPU_REDZONE, set below: no kernel of the minibatch wrote past a buffer of the learner)
 """ % (ROOT, rows, D)
 outs = []
 with tempfile.TemporaryDirectory() as tmp:
     for fused in (False, True):
         out = os.path.join(tmp, "f%d.npz" % fused)
-        env = dict(os.environ); env.pop("RLGPU_NO_FUSED", None)
+        env = dict(os.environ); env.pop("RLGPU_NO_FUSED", None); env["RLGPU_REDZONE"] = "65536"
         if not fused: env["RLGPU_NO_FUSED"] = "1"
         r = subprocess.run([sys.executable, "-c", code, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
         assert r.returncode == 0, r.stdout[-3000:]

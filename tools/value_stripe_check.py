@@ -15,12 +15,13 @@ core = PPOCore(D, 90, (256, 256, 256), (256, 256, 256), use_bf16=True, seed=3, m
 obs = torch.from_numpy((rng.randn(rows, D) * 0.7).astype(np.float32)).to(dev)
 v = core.value(obs); core.sync()
 np.save(sys.argv[1], v.cpu().numpy())
+core.check_redzones()   # (RLGPU_REDZONE, set below)
 """ % (ROOT, rows, D)
 outs = []
 with tempfile.TemporaryDirectory() as tmp:
     for stripe in (False, True):
         out = os.path.join(tmp, "v%d.npy" % stripe)
-        env = dict(os.environ); env.pop("RLGPU_NO_VALUE_STRIPE", None)
+        env = dict(os.environ); env.pop("RLGPU_NO_VALUE_STRIPE", None); env["RLGPU_REDZONE"] = "65536"
         if not stripe: env["RLGPU_NO_VALUE_STRIPE"] = "1"
         r = subprocess.run([sys.executable, "-c", code, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
         assert r.returncode == 0, r.stdout[-3000:]
