@@ -1336,6 +1336,9 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
     HIPCHK(e, hipMalloc(&ddst, sizeof(RlgpuArenaState) * (size_t)n));
     HIPCHK(e, hipMemsetAsync(ddst, 0, sizeof(RlgpuArenaState) * (size_t)n, e->stream));
     if (env_ids) { HIPCHK(e, hipMalloc(&dids, 4 * (size_t)n)); HIPCHK(e, hipMemcpyAsync(dids, env_ids, 4 * (size_t)n, hipMemcpyHostToDevice, e->stream)); }
+    // every byte of what the caller gets is defined: car slots beyond the env's cars, the reserved part of the appended block and the struct's
+    // padding are zeros (arena_to_host writes the live fields only)
+    HIPCHK(e, hipMemsetAsync(ddst, 0, sizeof(RlgpuArenaState) * (size_t)n, e->stream));
     dim3 grid((n + 63) / 64), block(64);
     DISPATCH_NC(e, k_download, grid, block, e->d, ddst, (const int32_t*)dids, n);
     HIPCHK(e, hipGetLastError());
@@ -1517,7 +1520,7 @@ int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset) {
     unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef RLG_HAVE_OVERFLOW_COUNTS
     HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h)));
-    if (reset) { const unsigned int z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), z, sizeof(z))); }
+    if (reset) { const unsigned int z[5] = {0, 0, 0, 0, 0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), z, sizeof(z))); }   // slots 0-4 only: 5 and 6 are rlgpu_env_epa_counts's
 #else
     int d[64]; HIPCHK(e, hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d)));   // profiler build: the same events live in its scratch counters
     for (int i = 0; i < 5; i++) h[i] = (unsigned int)d[i];
@@ -1533,7 +1536,8 @@ int rlgpu_env_epa_counts(rlgpu_env* e, uint64_t* out2, int reset) {
     unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef RLG_HAVE_OVERFLOW_COUNTS
     HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h)));
-    if (reset) { h[5] = h[6] = 0; const unsigned int keep[8] = {h[0], h[1], h[2], h[3], h[4], 0, 0, h[7]}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), keep, sizeof(keep))); HIPCHK(e, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_overflow), sizeof(h))); }
+    // reset: the counts as they stood are what is reported (as rlgpu_env_overflow_counts does); only the two EPA slots are cleared
+    if (reset) { const unsigned int z2[2] = {0, 0}; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), z2, sizeof(z2), 5 * sizeof(unsigned int))); }
 #else
     int d[64]; HIPCHK(e, hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d)));
     h[5] = (unsigned int)d[5]; h[6] = (unsigned int)d[6]; (void)reset;

@@ -826,13 +826,15 @@ def test_no_kernel_writes_past_a_device_buffer(team_size, n_envs, tess, monkeypa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("team_size,n_envs", [(1, 512), (1, 1024), (2, 256), (3, 171)])
-def test_identical_collection_flows_are_identical(team_size, n_envs):
+@pytest.mark.parametrize("team_size,n_envs", [(1, 512), (1, 1024), (2, 256), (3, 171), (1, 4096), (2, 8192), (3, 16384)])
+def test_identical_collection_flows_are_identical(team_size, n_envs, monkeypatch):
     """Two env batches under the same flow of fused collection launches (sampler rewound in between): outputs AND the downloaded resident states are
     equal byte for byte after every launch.  Regression for the staged word rows that ran NC x n_envs words past the resident allocation
     (csrc/arena_io.h arena_num_words): with batches this size the rows no longer fit the page slack and overwrote the action table behind it,
-    and one of two identical flows ended launches with car controls that are no rows of the table (tools/determinism/)."""
+    and one of two identical flows ended launches with car controls that are no rows of the table (tools/determinism/).  The last three cases are
+    BASELINE configs[1], [3] and [4] at their full env counts (two batches each), with guard bytes behind every device buffer (RLGPU_REDZONE)."""
     from rlgymppo_cpp_amd.env import BatchedEnv
+    monkeypatch.setenv("RLGPU_REDZONE", "65536")
     from rlgymppo_cpp_amd.ppo import PPOCore
     from rlgymppo_cpp_amd import _lib
     dev = torch.device("cuda", 0); CAP = 12
@@ -847,7 +849,7 @@ def test_identical_collection_flows_are_identical(team_size, n_envs):
                 torch.full((CAP, N), -777.0, device=dev), torch.zeros((CAP, N), dtype=torch.int32, device=dev))
     A, B = bufs(), bufs(); torch.cuda.synchronize()
     ea.reset(True, A[0][0]); eb.reset(True, B[0][0]); ea.sync(); eb.sync()
-    for k in range(3):
+    for k in range(3 if n_envs <= 1024 else 2):
         s, c = core.get_sampler()
         assert ea.collect(core, CAP, *A); ea.sync()
         core.set_sampler(s, c)
@@ -858,6 +860,8 @@ def test_identical_collection_flows_are_identical(team_size, n_envs):
         bad = [e for e in range(n_envs) if bytes(sa[e]) != bytes(sb[e])]
         assert not bad, (k, bad[:8])
         A[0][0].copy_(A[0][CAP]); B[0][0].copy_(B[0][CAP]); torch.cuda.synchronize()
+    ea.check_redzones(); eb.check_redzones(); core.check_redzones()
+    ea.close(); eb.close(); core.close()
 
 
 @pytest.mark.gpu
