@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--team-size", type=int, default=1, help="1 = BASELINE configs[1] (the headline); 2 / 3 with --padded-zero-sum = the shapes of configs[3] / [4]")
     ap.add_argument("--padded-zero-sum", action="store_true", help="DefaultOBSPadded(maxPlayers = team size) + ZeroSumReward around the example stack")
     ap.add_argument("--fp32", action="store_true", help="fp32 MFMA instead of bf16 operands")
+    ap.add_argument("--fp16", action="store_true", help="fp16 operands + dynamic loss scale in the minibatch kernels (BASELINE configs[4]: 'fp16 autocast MFMA')")
+    ap.add_argument("--overlap", action="store_true", help="LearnerConfig::collectionDuringLearn: the epochs run beside the next collection (BASELINE configs[4])")
     ap.add_argument("--lockstep", action="store_true", help="every env takes exactly --horizon steps per iteration (LearnerConfig::lockstepCollection) instead of the reference's free-running agents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trained-warmup", type=int, default=480, help="after the timed region: this many more iterations, then --trained-steps timed ones (the policy has started to play: more contacts per tick); 0 = skip")
@@ -169,6 +171,8 @@ def main():
            "--epochs", str(args.epochs)]
     if args.padded_zero_sum: cmd.append("--padded-zero-sum")
     if args.fp32: cmd.append("--fp32")
+    if args.fp16: cmd.append("--fp16")
+    if args.overlap: cmd.append("--overlap")
     if args.lockstep: cmd.append("--lockstep")
     if args.trained_warmup > 0 and args.trained_steps > 0:
         cmd += ["--trained-warmup", str(args.trained_warmup), "--trained-steps", str(args.trained_steps)]
@@ -216,7 +220,7 @@ def main():
         "value": m["value"], "unit": "agent-steps/s",
         "n_gpus": m["n_gpus"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp32 stepper + " + ("fp32" if args.fp32 else "bf16") + " MFMA MLP", "data": "synthetic",
+        "dtype": "fp32 stepper + " + ("fp32" if args.fp32 else ("fp16 (dynamic loss scale)" if args.fp16 else "bf16")) + " MFMA MLP", "data": "synthetic",
         "config": {"workload": (f"BASELINE config[1]: 1v1, {args.envs} envs/GPU, tickSkip 8, DefaultObs(89)+example reward stack, RandomState resets, "
                                 if args.team_size == 1 and not args.padded_zero_sum else
                                 f"{args.team_size}v{args.team_size}, {args.envs} envs/GPU, tickSkip 8, " + ("DefaultOBSPadded + zero-sum example stack, " if args.padded_zero_sum else "DefaultObs + example stack, ") + "RandomState resets, ")
@@ -255,6 +259,7 @@ def main():
                 "--epochs", str(args.epochs), "--lockstep"]
         if args.padded_zero_sum: cmd3.append("--padded-zero-sum")
         if args.fp32: cmd3.append("--fp32")
+        if args.fp16: cmd3.append("--fp16")
         p3 = subprocess.run(cmd3, stdout=subprocess.PIPE, env=env, cwd=ROOT)
         if p3.returncode == 0:
             m3 = json.loads(p3.stdout.decode().strip().splitlines()[-1])
@@ -267,6 +272,7 @@ def main():
                 "--epochs", str(args.epochs), "--mesh-dir", mesh_dir]
         if args.padded_zero_sum: cmd2.append("--padded-zero-sum")
         if args.fp32: cmd2.append("--fp32")
+        if args.fp16: cmd2.append("--fp16")
         p2 = subprocess.run(cmd2, stdout=subprocess.PIPE, env=env, cwd=ROOT)
         if p2.returncode == 0:
             m2 = json.loads(p2.stdout.decode().strip().splitlines()[-1])

@@ -46,7 +46,9 @@ struct Args {
     float inv_temp, clip, ent_coef, scale;   // scale = ratio / rows
     int debug;                   // experiments only (FZ_DEBUG builds): 1 no copies to HBM, 2 no MFMAs, 4 no epilogues
     unsigned long long* prof;    // profiling builds of the host only (RLGPU_FUSED_PROF): cycles per phase summed over the workgroups' first wavefronts
-    float loss_scale;            // fp16 mode: the dynamic loss scale the loss gradient is multiplied by (the host keeps and updates it); else 1
+    float loss_scale;            // the factor the loss gradient is multiplied by when loss_scale_dev is null: 1 (bf16 mode)
+    const float* loss_scale_dev; // fp16 mode: the dynamic loss scale, kept and updated ON THE DEVICE (rlgpu_learn.hip k_ls_decide) so that an optimizer step
+                                 // needs no answer from the host -- with collectionDuringLearn the host must get on to the next collection launch
     float* metrics;              // [0] entropy, [1] KL, [2] clip count, [3] ratio, [4] value squared error: sums over rows
 };
 
@@ -378,7 +380,7 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
             lp[j] = gj; dot = fmaf(gj, s[j], dot);
         }
         dot = quad_sum(dot);
-        const float c = valid ? g.inv_temp * g.scale * g.loss_scale : 0.f;
+        const float c = valid ? g.inv_temp * g.scale * (g.loss_scale_dev ? *g.loss_scale_dev : g.loss_scale) : 0.f;
         short* drow = buf1 + row * LD + sub;
 #pragma unroll
         for (int j = 0; j < PER; j++) drow[4 * j] = f2s<HALF>(s[j] * (lp[j] - dot) * c);      // (s = 0 beyond the A logits: zeros)
@@ -395,7 +397,7 @@ __device__ __forceinline__ void stripe_body(const Args& g, const NetArgs& n, sho
             const int gm = m0 + tid;
             const bool valid = gm < g.rows;
             const float d = zf[tid * LDF] - pre_tgt;
-            const float grd = 2.f * d * g.scale * g.loss_scale;
+            const float grd = 2.f * d * g.scale * (g.loss_scale_dev ? *g.loss_scale_dev : g.loss_scale);
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
             v[0] = valid ? f2s<HALF>(grd) : (short)0;
             short* drow = buf1 + tid * LD;

@@ -833,9 +833,18 @@ __global__ void k_gather_rows(const float* src, const int32_t* idx, int rows, in
 // launch: the replicas of a multi-GPU run, which start every optimizer step from bit-identical summed gradients, drifted apart by an ulp at a
 // time (found by the replica check, tests/test_host_cpp.py::test_two_ranks_on_one_gpu_...).
 constexpr int SUMSQ_BLOCKS = 64;
-__global__ void __launch_bounds__(256) k_sumsq(const float* g, int64_t n, float pre_scale, float* partial) {
+// The fp16 mode's dynamic loss scale and what hangs on it (GradScaler: gradscaler.hpp:26-34,162,291), resident on the device: an optimizer step
+// decides there whether it happens (k_ls_decide), so rlgpu_clip_adam_step returns without waiting for the minibatch -- under
+// collectionDuringLearn the host thread has the next collection to launch (with the decision on the host, fp16 + overlap measured no overlap at all).
+struct LsDev {
+    float scale; int growth; int skipped;      // the scale, clean steps since it last changed, steps skipped so far
+    int skip[2]; float unscale;                // this step: skip optimizer 0 / 1; the scale the step's gradients carry
+    float bc1[2], bc2s[2]; long long step[2];  // Adam's bias corrections for this step and the step counts (policy, critic)
+};
+__global__ void __launch_bounds__(256) k_sumsq(const float* g, int64_t n, float pre_scale, float* partial, const LsDev* ls) {
     __shared__ float ws[4];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ls) pre_scale /= ls->scale;
     float s = 0.f;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) { float v = g[i] * pre_scale; s += v * v; }
     s = wave_sum(s);
@@ -849,10 +858,22 @@ __global__ void k_sumsq_finish(const float* partial, int n_partial, float* out) 
     *out = s;
 }
 // clip_grad_norm_ (torch/nn/utils/clip_grad.py: coef = max_norm / (norm + 1e-6), clamped to 1) + Adam
+// one thread, after both gradient norms are known: skip or step, back the scale off or count towards its next doubling
+__global__ void k_ls_decide(const float* sumsq2, LsDev* ls, float b1, float b2) {
+    const bool s0 = !isfinite(sumsq2[0]), s1 = !isfinite(sumsq2[1]);
+    ls->skip[0] = s0; ls->skip[1] = s1; ls->unscale = ls->scale;
+    if (s0 || s1) { ls->scale *= 0.5f; ls->growth = 0; ls->skipped++; }
+    else if (++ls->growth >= 2000) { ls->scale *= 2.f; ls->growth = 0; }
+    for (int k = 0; k < 2; k++) if (!ls->skip[k]) {
+        const double t = (double)(++ls->step[k]);
+        ls->bc1[k] = (float)(1.0 - pow((double)b1, t)); ls->bc2s[k] = (float)sqrt(1.0 - pow((double)b2, t));
+    }
+}
 __global__ void k_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float pre_scale, float max_norm,
-                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const LsDev* ls, int slot) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (ls) { if (ls->skip[slot]) return; pre_scale /= ls->unscale; bc1 = ls->bc1[slot]; bc2_sqrt = ls->bc2s[slot]; }
     float norm = sqrtf(*sumsq);
     float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
     float gr = g[i] * pre_scale * coef;
@@ -892,7 +913,8 @@ struct rlgpu_learner {
     // fp16 operand mode (cfg.use_bf16 == 2; BASELINE configs[4] "fp16 autocast"): the minibatch kernels of ppo_fused.h take fp16 copies of the
     // weights (same layout as `shadows`) and the loss gradient times a dynamic loss scale (PRIV/Util/gradscaler.hpp:26-34: 2^16 at the start,
     // x 2 after 2000 steps without an overflow, x 0.5 and the step SKIPPED after one).  Inference (collection, value pass) stays bf16.
-    short* shadows_h = nullptr; float loss_scale = 65536.f; int ls_growth = 0; int ls_skipped = 0;
+    short* shadows_h = nullptr; float loss_scale = 65536.f; int ls_growth = 0; int ls_skipped = 0;   // fp16 mode: host mirror of *ls_dev (ls_pull / ls_push)
+    LsDev* ls_dev = nullptr;
     short* x16 = nullptr;                       // [max_rows][kp[0]] network input
     std::vector<short*> act16_p, act16_c;       // hidden activations [max_rows][kp[i+1]]
     short *g16a = nullptr, *g16b = nullptr;     // activation gradients, ping-pong [max_rows][max kp]
@@ -1233,7 +1255,7 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     a.obs = obs; a.idx = idx; a.rows = n; a.D = l->cfg.obs_size; a.x16 = l->x16;
     a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.targets = targets;
     a.inv_temp = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f); a.clip = l->cfg.clip_range; a.ent_coef = l->cfg.ent_coef;
-    a.scale = ratio / (float)n; a.metrics = metrics; a.loss_scale = l->shadows_h ? l->loss_scale : 1.f;
+    a.scale = ratio / (float)n; a.metrics = metrics; a.loss_scale = 1.f; a.loss_scale_dev = l->ls_dev ? &l->ls_dev->scale : nullptr;
     static const int fz_debug = std::getenv("RLGPU_FZ_DEBUG") ? std::atoi(std::getenv("RLGPU_FZ_DEBUG")) : 0;
     a.debug = fz_debug;
     fused::DwArgs d{};
@@ -1329,6 +1351,7 @@ int net_dw16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16
 extern "C" {
 
 // Debug mode RLGPU_REDZONE=<bytes> (read at create), as for the env batch (rlgpu_env.hip): guard bytes behind every device buffer of the learner.
+static int ls_push(rlgpu_learner* l);
 static hipError_t lz_malloc(rlgpu_learner* l, void** p, size_t bytes, const char* name) {
     const size_t rz = l->redzone_bytes;
     hipError_t r = hipMalloc(p, bytes + rz);
@@ -1400,6 +1423,8 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
             // (kp is planned now: the shape test of fused_capable applies)
             if (!fused_capable(l)) { l->err = "use_bf16 = 2 (fp16 operands): only the shape the fused minibatch kernels cover (obs <= 192 padded, 256 x 3 hidden, n_actions 65..96)"; return RLGPU_ERR_ARG; }
             LCHK(l, lz_malloc(l, (void**)&l->shadows_h, (size_t)(soff * 2), "shadows_h"));
+            LCHK(l, lz_malloc(l, (void**)&l->ls_dev, sizeof(LsDev), "loss scale state"));
+            { int rc = ls_push(l); if (rc) return rc; }      // scale 65536, no steps counted, Adam's step counts 0
         }
         int maxkp = l->pol.kp[0];
         for (const Net* n : {&l->pol, &l->cri}) for (int i = 0; i <= n->n_layers; i++) maxkp = std::max(maxkp, n->kp[i]);
@@ -1430,6 +1455,7 @@ void rlgpu_learner_destroy(rlgpu_learner* l) {
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
     for (short* p : {l->shadows, l->shadows_h, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
+    if (l->ls_dev) (void)hipFree(l->ls_dev);
     for (int w = 0; w < 2; w++) {
         for (int i = 0; i < 9; i++) { if (l->dy16[w][i]) (void)hipFree(l->dy16[w][i]); if (l->ev_dy[w][i]) (void)hipEventDestroy(l->ev_dy[w][i]); }
         if (l->dw_stream[w]) (void)hipStreamDestroy(l->dw_stream[w]);
@@ -1467,8 +1493,23 @@ int rlgpu_learner_get_grads(rlgpu_learner* l, int which, float* host) {
 }
 int rlgpu_learner_grad_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->grads; *n = l->n_total; return RLGPU_OK; }
 int rlgpu_learner_param_buffer(rlgpu_learner* l, float** p, int64_t* n) { *p = l->params; *n = l->n_total; l->shadows_dirty = true; /* the caller may write (broadcast) */ return RLGPU_OK; }
+// fp16 mode: the loss scale, its counters and Adam's step counts live on the device (LsDev); the host fields are a mirror, refreshed on demand
+static int ls_pull(rlgpu_learner* l) {
+    if (!l->ls_dev) return RLGPU_OK;
+    LsDev h;
+    LCHK(l, hipMemcpyAsync(&h, l->ls_dev, sizeof(h), hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream));
+    l->loss_scale = h.scale; l->ls_growth = h.growth; l->ls_skipped = h.skipped; l->step_p = h.step[0]; l->step_c = h.step[1];
+    return RLGPU_OK;
+}
+static int ls_push(rlgpu_learner* l) {
+    if (!l->ls_dev) return RLGPU_OK;
+    LsDev h{}; h.scale = l->loss_scale; h.growth = l->ls_growth; h.skipped = l->ls_skipped; h.unscale = l->loss_scale; h.step[0] = l->step_p; h.step[1] = l->step_c;
+    LCHK(l, hipMemcpyAsync(l->ls_dev, &h, sizeof(h), hipMemcpyHostToDevice, l->stream)); LCHK(l, hipStreamSynchronize(l->stream));
+    return RLGPU_OK;
+}
 int rlgpu_learner_get_adam_state(rlgpu_learner* l, float* hm, float* hv, int64_t* sp, int64_t* sc) {
     LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream));
+    { int rc = ls_pull(l); if (rc) return rc; }
     if (hm) LCHK(l, hipMemcpy(hm, l->adam_m, l->n_total * 4, hipMemcpyDeviceToHost));
     if (hv) LCHK(l, hipMemcpy(hv, l->adam_v, l->n_total * 4, hipMemcpyDeviceToHost));
     if (sp) *sp = l->step_p; if (sc) *sc = l->step_c; return RLGPU_OK;
@@ -1477,7 +1518,7 @@ int rlgpu_learner_set_adam_state(rlgpu_learner* l, const float* hm, const float*
     LCHK(l, hipSetDevice(l->device)); LCHK(l, hipStreamSynchronize(l->stream));
     if (hm) LCHK(l, hipMemcpy(l->adam_m, hm, l->n_total * 4, hipMemcpyHostToDevice));
     if (hv) LCHK(l, hipMemcpy(l->adam_v, hv, l->n_total * 4, hipMemcpyHostToDevice));
-    l->step_p = sp; l->step_c = sc; return RLGPU_OK;
+    l->step_p = sp; l->step_c = sc; return ls_push(l);
 }
 
 // the fused inference kernel (k_mlp_infer) covers this net?  (bf16 path, LDS for two activation buffers, head width)
@@ -1717,38 +1758,34 @@ int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale) {
     // fp16 mode: the gradients are loss_scale times too large.  GradScaler::unscale_ BEFORE the clip (the reference clips the scaled gradients and
     // unscales inside step(), PPOLearner.cpp:273-297 -- an effective clip norm of 0.5 / scale), a step with a non-finite gradient
     // norm is skipped for that optimizer and the scale backs off, gradscaler.hpp:162,291.
-    const bool half = l->shadows_h != nullptr;
-    if (half) grad_scale /= l->loss_scale;
+    // All of it on the device (LsDev, k_ls_decide): the call returns without waiting for the minibatch.
+    const LsDev* const ls = l->ls_dev;
     for (auto& s : segs) {
         float* const partial = l->norm_buf + 4 + s.slot * SUMSQ_BLOCKS;
-        hipLaunchKernelGGL(k_sumsq, dim3(SUMSQ_BLOCKS), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, partial);
+        hipLaunchKernelGGL(k_sumsq, dim3(SUMSQ_BLOCKS), dim3(256), 0, l->stream, (const float*)(l->grads + s.off), s.n, grad_scale, partial, ls);
         hipLaunchKernelGGL(k_sumsq_finish, dim3(1), dim3(1), 0, l->stream, (const float*)partial, SUMSQ_BLOCKS, l->norm_buf + s.slot);
         LCHK(l, hipGetLastError());
     }
-    bool skip[2] = {false, false};
-    if (half) {
-        float norms[2];
-        LCHK(l, hipMemcpyAsync(norms, l->norm_buf, 8, hipMemcpyDeviceToHost, l->stream));
-        LCHK(l, hipStreamSynchronize(l->stream));
-        skip[0] = !std::isfinite(norms[0]); skip[1] = !std::isfinite(norms[1]);
-        if (skip[0] || skip[1]) { l->loss_scale *= 0.5f; l->ls_growth = 0; l->ls_skipped++; }
-        else if (++l->ls_growth >= 2000) { l->loss_scale *= 2.f; l->ls_growth = 0; }
-    }
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    if (ls) { hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(1), 0, l->stream, (const float*)l->norm_buf, l->ls_dev, b1, b2); LCHK(l, hipGetLastError()); }
     for (auto& s : segs) {
-        if (skip[s.slot]) continue;
-        (*s.step)++;
-        double t = (double)*s.step;
-        float bc1 = (float)(1.0 - std::pow((double)b1, t));
-        float bc2s = (float)std::sqrt(1.0 - std::pow((double)b2, t));
+        float bc1 = 1.f, bc2s = 1.f;
+        if (!ls) {      // (fp16 mode: the step counts and bias corrections are the device's)
+            (*s.step)++;
+            double t = (double)*s.step;
+            bc1 = (float)(1.0 - std::pow((double)b1, t));
+            bc2s = (float)std::sqrt(1.0 - std::pow((double)b2, t));
+        }
         hipLaunchKernelGGL(k_clip_adam, dim3((s.n + 255) / 256), dim3(256), 0, l->stream, l->params + s.off, (const float*)(l->grads + s.off),
-                           l->adam_m + s.off, l->adam_v + s.off, s.n, (const float*)(l->norm_buf + s.slot), grad_scale, max_norm, s.lr, b1, b2, eps, bc1, bc2s);
+                           l->adam_m + s.off, l->adam_v + s.off, s.n, (const float*)(l->norm_buf + s.slot), grad_scale, max_norm, s.lr, b1, b2, eps, bc1, bc2s, ls, s.slot);
         LCHK(l, hipGetLastError());
     }
     l->shadows_dirty = true;
     return RLGPU_OK;
 }
 int rlgpu_learner_loss_scale(rlgpu_learner* l, float* scale, int* growth_steps, int* skipped_steps) {
+    LCHK(l, hipSetDevice(l->device));
+    { int rc = ls_pull(l); if (rc) return rc; }
     if (scale) *scale = l->shadows_h ? l->loss_scale : 1.f;
     if (growth_steps) *growth_steps = l->ls_growth; if (skipped_steps) *skipped_steps = l->ls_skipped;
     return RLGPU_OK;
@@ -1815,11 +1852,12 @@ int rlgpu_learner_sync_from_rank0(rlgpu_learner* l, rlgpu_comm* c) {
     for (float* p : {l->params, l->adam_m, l->adam_v}) { int rc = rlgpu_comm_broadcast(c, p, l->n_total * 4, 0, (void*)l->stream); if (rc) { l->err = rlgpu_comm_last_error(c); return rc; } }
     int64_t* steps = nullptr;
     LCHK(l, hipMalloc(&steps, 16));
+    { int rc0 = ls_pull(l); if (rc0) return rc0; }
     const int64_t h[2] = {l->step_p, l->step_c};
     LCHK(l, hipMemcpyAsync(steps, h, 16, hipMemcpyHostToDevice, l->stream));
     int rc = rlgpu_comm_broadcast(c, steps, 16, 0, (void*)l->stream);
     int64_t g[2] = {0, 0};
-    if (!rc) { LCHK(l, hipMemcpyAsync(g, steps, 16, hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream)); l->step_p = g[0]; l->step_c = g[1]; }
+    if (!rc) { LCHK(l, hipMemcpyAsync(g, steps, 16, hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream)); l->step_p = g[0]; l->step_c = g[1]; rc = ls_push(l); }
     (void)hipFree(steps);
     if (rc) { l->err = rlgpu_comm_last_error(c); return rc; }
     l->shadows_dirty = true;

@@ -1,7 +1,7 @@
 // bench_main.cpp -- the measured process of bench.py: the reference's program shape (examplemain.cpp: EnvCreateFn + LearnerConfig +
 // Learner) on include/RLGymPPO_CPP over librlgymppo_amd.so / librlgpu.so.  No Python, no torch: the HIP runtime, the C-ABI library
 // and (multi-GPU) RCCL are all that touch the device.  Prints ONE JSON object on stdout (rank 0).
-//   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32] [--overlap] [--trained-warmup I --trained-steps J]
+//   bench_main --envs E --team-size S --horizon T --steps K --warmup W [--epochs n] [--padded-zero-sum] [--fp32 | --fp16] [--overlap] [--trained-warmup I --trained-steps J]
 //              [--learned-warmup I --learned-epochs n --learned-steps J] [--mesh-dir DIR]
 // One "step" = one full PPO iteration: T gym steps of every env with on-device policy inference, value pass + GAE, shuffled
 // minibatches (4 per batch), clip + Adam.  With --trained-warmup the same measurement is repeated after I more iterations, when
@@ -49,13 +49,13 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
 struct Timed { double stepReward = 0, entropy = 0; double agentSteps = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, overlap = false, lockstep = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, fp16 = false, overlap = false, lockstep = false;
     std::string meshDir = "./collision_meshes";
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
         else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
-        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true; else if (is("--lockstep")) lockstep = true;
+        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true; else if (is("--fp16")) fp16 = true; else if (is("--lockstep")) lockstep = true;
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
         else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
         else if (is("--mesh-dir")) meshDir = argv[++i];
@@ -73,6 +73,7 @@ int main(int argc, char* argv[]) {
     cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
     cfg.timestepLimit = 0;
     cfg.lockstepCollection = lockstep;     // default: the reference's free-running agents (every game at its own pace until the batch is full)
+    if (fp16) setenv("RLGPU_AUTOCAST_FP16", "1", 1);   // fp16 operands + dynamic loss scale in the minibatch kernels (BASELINE configs[4]'s "fp16 autocast"; Learner.hip reads it at construction)
     cfg.collectionDuringLearn = overlap;   // not the headline: the reference's default pauses collection while it learns
     Learner learner(EnvCreateFunc, cfg);
     const int rank = learner.Rank(), world = learner.WorldSize();
@@ -133,10 +134,10 @@ int main(int argc, char* argv[]) {
         printf("{\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"envs_per_gpu\": %d, \"team_size\": %d, \"horizon\": %d, \"batch\": %lld, \"minibatch\": %lld, \"epochs\": %d, \"obs_size\": %d, "
                "\"elapsed_s\": %.6f, \"agent_steps\": %.0f, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"fused_collect\": %s, \"collection\": \"%s\", "
                "\"env_kernel_ms_total\": %.4f, \"env_launches\": %d, \"algorithmic_bytes_per_gym_step_per_env\": %.0f, \"gym_steps_per_launch\": %.0f, "
-               "\"gemm_ms_total\": %.4f, \"gemm_flops_total\": %.6e, \"gemm_calls\": %d",
+               "\"gemm_ms_total\": %.4f, \"gemm_flops_total\": %.6e, \"gemm_calls\": %d, \"operands\": \"%s\", \"collection_during_learn\": %s",
                world, steps, warmup, envs, g_team, horizon, (long long)B, (long long)(B / 4), epochs, D,
                m.sec, m.agentSteps, m.agentSteps / m.sec, m.sec / steps * 1e3, m.consumeMs, fused ? "true" : "false", learner.UsesFreeRunningCollection() ? "free-running" : "lockstep",
-               m.envMs, m.envLaunches, A, stepsPerLaunch, m.gemmMs, m.gemmFlops, m.gemmCalls);
+               m.envMs, m.envLaunches, A, stepsPerLaunch, m.gemmMs, m.gemmFlops, m.gemmCalls, fp32 ? "fp32" : (std::getenv("RLGPU_AUTOCAST_FP16") ? "fp16 + dynamic loss scale" : "bf16"), overlap ? "true" : "false");
         // multi-GPU audit trail: how many RCCL ranks took part, every rank's own ms per iteration, and (rank 0) what one gradient all-reduce costs
         printf(", \"rccl_ranks\": %d, \"rank_ms_per_step\": [", world > 1 ? world : 0);
         for (size_t r = 0; r < m.rankSec.size(); r++) printf("%s%.4f", r ? ", " : "", m.rankSec[r] / steps * 1e3);
