@@ -142,10 +142,13 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next
 
 /* How often the narrowphase's fixed-size queues overflowed since the last reset (process-wide; every overflow sends that env through the
  * inline fallback for that tick -- same results, slower): out5 = {BVH frontier, ball candidate region, car candidate region, item queue, result pool}.
- * The last one also counts the two cases in which a contact point is LOST: a body touching a third mesh object with points at once, and a car-car
- * point beyond the pair pool of the env (4 / 8 / 12 points for 1v1 / 2v2 / 3v3; a six-car heap has shown 9).
+ * (Until round 4 the last one also counted the two cases in which a contact point is LOST; they have a counter of their own now, below.)
  * reset != 0: the counts as they stood are returned, then these five are cleared (the EPA counts below are not touched). */
 int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
+/* The two places where contact points are LOST instead of going through an exact fallback: a body touching a third mesh object with points at once
+ * (two manifolds per body and tick), and a car-car point beyond the pair pool of the env (4 / 8 / 12 points for 1v1 / 2v2 / 3v3; a six-car heap has
+ * shown 9).  out1 = such events since the last reset (process-wide); reset != 0 clears it after reading. */
+int rlgpu_env_lost_contact_count(rlgpu_env* e, uint64_t* out1, int reset);
 
 /* Penetration-depth queries since the last reset (process-wide): hitbox-mesh / hitbox-ball pairs whose cores overlap go through the
  * reference's second GJK + EPA (btGjkEpaPenetrationDepthSolver.cpp:24-79, btGjkEpa2.cpp; csrc/arena_epa.h).  out2 = {queries, queries that

@@ -320,7 +320,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             if (m_cnt > 0) { n_man++; m_start += m_cnt; m_cnt = 0; }   // the manifold filled so far is complete (one that kept no point is reused)
             m_obj = obj;
         }
-        if (n_man >= MESH_MANIFOLDS) { RLG_DBG_COUNT(4); return false; }   // a third mesh object with points at once: dropped (counted with the pool overflows)
+        if (n_man >= MESH_MANIFOLDS) { RLG_DBG_COUNT(7); return false; }   // a third mesh object with points at once: its points are LOST (slot 7: rlgpu_env_lost_contact_count)
         if (manifold_add_static(out + m_start, m_cnt, 4, b, k.n, k.pb, k.dist, breaking, k.pa) < 0) return false;
         body_obj[body][n_man] = (int8_t)obj;
         n = m_start + m_cnt;
@@ -810,7 +810,7 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
             int cnt = 0;
             for (int k = 0; k < nc; k++) {
                 if (cs[k].dist > CBT_CAR) continue;
-                if (n_pair >= LY::PAIR_POOL) { RLG_DBG_COUNT(4); break; }     // a car-car point DROPPED (never seen with the present pool sizes): counted with the pool overflows
+                if (n_pair >= LY::PAIR_POOL) { RLG_DBG_COUNT(7); break; }     // a car-car point LOST (never seen with the present pool sizes; slot 7: rlgpu_env_lost_contact_count)
                 Contact& c = L.c[LY::PAIR_BASE + n_pair];
                 manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
                 c.a = (int8_t)(1 + ib); c.b = (int8_t)(1 + ia); c.sid = 0; c.special = 0;

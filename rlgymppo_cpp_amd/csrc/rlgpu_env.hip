@@ -69,7 +69,7 @@ __device__ unsigned int g_fine_blk[4096 * 32];   // the buckets of every workgro
 // one sends its env through the inline fallback for that tick, same results): 0 BVH frontier, 1 ball region, 2 car region, 3 item queue,
 // 4 result pool.  rlgpu_env_overflow_counts reads them; other counter slots (profiler build) compile to nothing.
 __device__ unsigned int g_overflow[8];
-#define RLG_DBG_COUNT(i) do { if ((i) < 7) atomicAdd(&g_overflow[(i) & 7], 1u); } while (0)   // (5, 6: penetration-depth queries / those that needed the full-size arena)
+#define RLG_DBG_COUNT(i) do { if ((i) < 8) atomicAdd(&g_overflow[(i) & 7], 1u); } while (0)   // (5, 6: penetration-depth queries / those that needed the full-size arena)
 #define RLG_HAVE_OVERFLOW_COUNTS 1
 #endif
 // Where the penetration-depth solver (arena_epa.h: Bullet's second GJK + EPA, for hitbox-mesh contacts deeper than the collision margin)
@@ -1530,6 +1530,21 @@ int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset) {
     return RLGPU_OK;
 }
 
+// The two places where the stepper LOSES contact points (everything else that overflows goes through an exact fallback): a body touching a third
+// mesh object with points at once, a car-car point beyond the env's pair pool.  Events since the last reset, process-wide.
+int rlgpu_env_lost_contact_count(rlgpu_env* e, uint64_t* out1, int reset) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    unsigned int h = 0;
+#ifdef RLG_HAVE_OVERFLOW_COUNTS
+    HIPCHK(e, hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_overflow), sizeof(h), 7 * sizeof(unsigned int)));
+    if (reset) { const unsigned int z = 0; HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_overflow), &z, sizeof(z), 7 * sizeof(unsigned int))); }
+#else
+    int d[64]; HIPCHK(e, hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbg), sizeof(d))); h = (unsigned int)d[7]; (void)reset;
+#endif
+    *out1 = h;
+    return RLGPU_OK;
+}
 int rlgpu_env_epa_counts(rlgpu_env* e, uint64_t* out2, int reset) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));

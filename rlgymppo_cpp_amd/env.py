@@ -125,6 +125,13 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_overflow_counts(self.h, C.addressof(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
         return [int(x) for x in out]
 
+    def lost_contact_count(self, reset=False) -> int:
+        """Events in which the stepper LOST contact points (a third mesh object with points at once on one body, a car-car point beyond the pair pool)
+        since the last reset, process-wide."""
+        out = C.c_uint64(0)
+        _chk(self.lib.rlgpu_env_lost_contact_count(self.h, C.byref(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return int(out.value)
+
     def epa_counts(self, reset=False):
         """Penetration-depth queries (Bullet's second GJK + EPA, csrc/arena_epa.h) since the last reset, process-wide: [queries, of them in the full-size arena]."""
         out = (C.c_uint64 * 2)()

@@ -815,6 +815,10 @@ def test_no_kernel_writes_past_a_device_buffer(team_size, n_envs, tess, monkeypa
     steps = torch.zeros(n_envs, dtype=torch.int32, device=dev); torch.cuda.synchronize()
     assert env.collect_free(core, T, (T // 2) * N, obs, acts, logp, rew, done, steps); env.sync()
     env.check_redzones()
+    # (the counters next to the kernels: a read with reset hands back what was counted and leaves zero)
+    lost = env.lost_contact_count(reset=True); assert lost >= 0 and env.lost_contact_count() == 0
+    ovf = env.overflow_counts(reset=True); assert len(ovf) == 5 and env.overflow_counts() == [0, 0, 0, 0, 0]
+    epa = env.epa_counts(reset=True); assert len(epa) == 2 and env.epa_counts() == [0, 0]
     core.check_redzones()
     env.reset(True, obs[0]); env.sync()
     env.check_redzones()
