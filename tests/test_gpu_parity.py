@@ -895,9 +895,8 @@ def test_fused_collection_equals_alternating_act_and_step(team_size, n_envs, bf1
             assert env.collect(ppo, T, obs, acts, logp, rew, done)
         else:
             for t in range(T):
-                # the learner and the env batch work on streams of their own: every hand-over is synchronised (without this the step kernel can
-                # read acts[t] before the policy wrote it -- whether it does depends on which hardware queues the two streams landed on, i.e. on
-                # how many streams earlier tests of the process created: this test failed exactly when it ran right after the learner tests)
+                # the learner and the env batch work on streams of their own: every hand-over is synchronised.  (When this test failed behind the
+                # learner tests in round 4 it was not this: the staged word rows ran past the resident state, csrc/arena_io.h arena_num_words.)
                 ppo.act(obs[t], acts[t], logp[t]); ppo.sync()
                 env.step(acts[t], obs[t + 1], rew[t], done[t]); env.sync()
         env.sync()
