@@ -520,8 +520,10 @@ def test_live_reference_rollout(ref_lib, port_lib):
     nobs = torch.empty((2, 89), device=dev); r = torch.empty(2, device=dev); d = torch.empty(2, dtype=torch.int32, device=dev)
     rng = np.random.RandomState(11)
     for t in range(30):
-        # ground actions only (table rows 0..23): wheels, ball hits and boost are compared live against the reference;
-        # hitbox-vs-ground landings are chaotic and covered by the looser golden scenarios
+        # A LIVE comparison on whatever CPU the GPU box has: the reference normalises with rsqrtss, whose table belongs to the CPU vendor, and the
+        # stepper restates the table of the CPU the fixtures were recorded on (csrc/rl_math.h) -- so this test cannot ask for equality (the
+        # bit-exact ones are the recorded fixtures: sim_golden / sim_steps / gym_golden / tess_golden / gameinst_golden, all equal on the HIP path).
+        # Ground actions only (table rows 0..23), so that a last-bit difference is not amplified by a landing.
         a = rng.randint(0, 24, size=2).astype(np.int32)
         o_r, r_r, d_r, _ = g.step(a)
         env.step(torch.from_numpy(a).to(dev), nobs, r, d); env.sync()
