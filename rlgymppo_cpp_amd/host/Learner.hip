@@ -8,6 +8,7 @@
 //                                .lt payloads = the reference's TorchScript zip archives, through rlgpu_lt_* of librlgpu.so)
 // Everything on the data path stays in device memory; this file only sequences launches.  Compiled by hipcc because of the
 // three small bookkeeping kernels below.
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <array>
@@ -87,8 +88,33 @@ __global__ void k_ragged_sums(const float* ret, const float* adv, const float* t
 
 std::filesystem::path g_mesh_folder;
 
+// Debug mode RLGPU_REDZONE=<bytes> (as in librlgpu.so: rlgpu_env_check_redzones): guard bytes behind every device buffer this library owns;
+// ~Learner checks them, the env batch's and the learner's, and says so on stderr -- or ends the process with the name of what was overwritten.
+struct HostRedzone { void* base; size_t bytes; };
+std::vector<HostRedzone> g_redzones;
+size_t redzone_bytes() { const char* s = std::getenv("RLGPU_REDZONE"); return s ? (size_t)atol(s) : 0; }
 template <class T>
-T* dev_alloc(size_t n) { T* p = nullptr; HOST_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
+T* dev_alloc(size_t n) {
+    T* p = nullptr; const size_t bytes = std::max<size_t>(n, 1) * sizeof(T), rz = redzone_bytes();
+    HOST_HIP(hipMalloc(&p, bytes + rz));
+    if (rz) { HOST_HIP(hipMemset((char*)p + bytes, 0xC5, rz)); g_redzones.push_back({(void*)p, bytes}); }
+    return p;
+}
+void dev_release(void* p) {
+    for (size_t i = 0; i < g_redzones.size(); i++) if (g_redzones[i].base == p) { g_redzones.erase(g_redzones.begin() + (long)i); break; }
+    (void)hipFree(p);
+}
+// returns "" or what was overwritten
+std::string host_redzones_check() {
+    const size_t rz = redzone_bytes();
+    std::vector<unsigned char> h(rz);
+    for (size_t k = 0; k < g_redzones.size(); k++) {
+        HOST_HIP(hipMemcpy(h.data(), (const char*)g_redzones[k].base + g_redzones[k].bytes, rz, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rz; i++) if (h[i] != 0xC5)
+            return "host-library device buffer #" + std::to_string(k) + " (" + std::to_string(g_redzones[k].bytes) + " bytes, allocation order of Learner.hip) overwritten at +" + std::to_string(i) + " past its end";
+    }
+    return "";
+}
 
 }  // namespace
 
@@ -361,6 +387,15 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
 
 Learner::~Learner() {
     Impl& m = *impl;
+    if (redzone_bytes()) {      // debug mode: did anything write past a device buffer during this run?
+        (void)hipDeviceSynchronize();
+        std::string bad = host_redzones_check();
+        if (bad.empty() && m.env && rlgpu_env_check_redzones(m.env) != RLGPU_OK) bad = std::string("env batch: ") + rlgpu_env_last_error(m.env);
+        if (bad.empty() && m.lrn && rlgpu_learner_check_redzones(m.lrn) != RLGPU_OK) bad = std::string("learner: ") + rlgpu_learner_last_error(m.lrn);
+        if (!bad.empty()) { fprintf(stderr, "RLGPU_REDZONE: %s\n", bad.c_str()); fflush(stderr); _exit(3); }
+        fprintf(stderr, "RLGPU_REDZONE: clean (%zu host-library buffers, the env batch, the learner)\n", g_redzones.size());
+        g_redzones.clear();
+    }
     for (void* p : {(void*)m.obs, (void*)m.acts, (void*)m.done, (void*)m.idx, (void*)m.logp, (void*)m.rew, (void*)m.doneF, (void*)m.trunc, (void*)m.adv, (void*)m.tgt,
                     (void*)m.ret, (void*)m.vals, (void*)m.metrics, (void*)m.scratch, (void*)m.exObs, (void*)m.exActs, (void*)m.exLogp, (void*)m.exAdv, (void*)m.exTgt})
         if (p) (void)hipFree(p);
@@ -434,7 +469,7 @@ std::vector<double> Learner::GatherOverRanks(double v) {
     HOST_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     if (rlgpu_comm_allreduce_f32(m.comm, d, m.world, nullptr) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_allreduce_f32: " << rlgpu_comm_last_error(m.comm));
     HOST_HIP(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    dev_release(d);
     return std::vector<double>(h.begin(), h.end());
 }
 double Learner::MaxOverRanks(double v) {

@@ -412,3 +412,21 @@ def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_pat
         pytest.fail("rank 0 went on waiting for a dead peer")
     assert procs[0].returncode != 0 and time.time() - t0 < 40
     assert "peer" in out0[1] or "peers" in out0[1], out0[1][-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--envs", "1024"], ["--envs", "1024", "--lockstep"], ["--envs", "700", "--overlap", "--fp16"],
+                                  ["--envs", "600", "--team-size", "2", "--padded-zero-sum"], ["--envs", "300", "--team-size", "3", "--padded-zero-sum", "--epochs", "2"]])
+def test_cpp_host_runs_clean_under_redzones(args):
+    """RLGPU_REDZONE: guard bytes behind every device buffer of the C++ host library (experience FIFO staging, GAE / statistics scratch, index lists),
+    of the env batch and of the learner; the Learner's destructor checks all three after a run of the whole training loop -- free-running and lockstep
+    collection, collect-during-learn with fp16 operands, 2v2 / 3v3 with padded observations, two epochs -- and ends the process with the name of an
+    overwritten buffer otherwise."""
+    import json
+    exe = os.path.join(PKG, "bench_main")
+    r = subprocess.run([exe, "--horizon", "16", "--steps", "6", "--warmup", "1"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                       env=dict(os.environ, RLGPU_REDZONE="65536", RLGPU_QUIET="1"), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RLGPU_REDZONE: clean" in r.stderr, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0
