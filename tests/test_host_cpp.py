@@ -430,3 +430,36 @@ def test_cpp_host_runs_clean_under_redzones(args):
     assert "RLGPU_REDZONE: clean" in r.stderr, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_python_host_two_ranks_on_one_gpu(tmp_path):
+    """the Python host with WORLD_SIZE > 1 builds its communicator from the launcher's environment and must put the env batch,
+    the learner and every buffer on the communicator's device.  Two ranks of tools/py_two_rank_worker.py on the one GPU (LOCAL_RANK 0 for both,
+    collectives over the shared-memory transport): both finish, on device 0, with EQUAL parameters although their env shards differ (seed + 1000 rank),
+    and those differ from a single-rank run's."""
+    import re, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdv = str(tmp_path / "rdv"); os.mkdir(rdv, 0o700)
+    base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TAG="py2",
+                RLGPU_COMM_TRANSPORT="shm", RLGPU_COMM_TIMEOUT_S="60", RLGPU_QUIET="1")
+    worker = os.path.join(ROOT, "tools", "py_two_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, "3"], env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            pytest.fail("a rank hung")
+    assert [p.returncode for p in procs] == [0, 0], outs
+    got = [re.search(r"rank (\d) of 2: device (\d+), parameter checksum ([0-9a-f]{16})", o) for o in outs]
+    assert all(got), outs
+    assert sorted(g.group(1) for g in got) == ["0", "1"] and all(g.group(2) == "0" for g in got)
+    assert got[0].group(3) == got[1].group(3), outs
+    solo_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    solo = subprocess.run([sys.executable, worker, "3"], env=dict(solo_env, RLGPU_QUIET="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT, timeout=240)
+    assert solo.returncode == 0, solo.stdout[-2000:]
+    m = re.search(r"rank 0 of 1: device 0, parameter checksum ([0-9a-f]{16})", solo.stdout)
+    assert m and m.group(1) != got[0].group(3), solo.stdout[-1000:]
