@@ -691,10 +691,16 @@ extern "C" int ref_gym_player_order(void* h, int32_t* out) {
 // A user state setter written against the reference's plugin surface: its k-th call installs the caller's k-th state (the last one again once
 // the list is used up).  With it an episode boundary -- gym->Reset() inside GameInst::Step, the observation the agent acts on next, the reward
 // trackers' roll-over -- is reproducible, which the reference's own setters (thread-local std RNG) are not.
+// (ref_list_setter_then_random(1): once the list is used up the calls go to the reference's own RandomState instead -- the first episode starts
+// from a chosen state, every later one the way the example program's setter starts it; tests/golden/make_padreset_golden.py)
+static int g_list_then_random = 0;
+extern "C" void ref_list_setter_then_random(int on) { g_list_then_random = on; }
 class ListStateSetter : public StateSetter {
 public:
     const RlgpuArenaState* list = nullptr; int n = 0, calls = 0;
+    RandomState random{true, true, true};
     virtual GameState ResetState(Arena* arena) {
+        if (g_list_then_random && calls >= n) { calls++; return random.ResetState(arena); }
         SetArenaPhys(arena, &list[calls < n ? calls : n - 1], false);
         calls++;
         return GameState(arena);

@@ -393,10 +393,13 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
     Rng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
     G.reset_count++;
     A.ball.vel_impulse_cache = v3(0, 0, 0); A.ball_update_counter = 0;
-    // (the boost pads: ResetToRandomKickoff resets them itself, Arena.cpp:209-210; RandomState leaves them alone -- Match::ResetState resets them
-    // AFTER the setter has built the new episode's first GameState, Match.cpp:55-69: reset_pads below, called once the snapshot is taken)
+    // The boost pads: both built-in setters reset them BEFORE they build the new episode's first GameState -- KickoffState through
+    // Arena::ResetToRandomKickoff (Arena.cpp:209-210), RandomState because its first statement is that same call (RandomState.cpp:11) -- so the
+    // first observation of the new episode shows all 34 pads active (tests/golden/padreset_golden.npz).  Only a USER setter that leaves the pads
+    // alone shows the previous episode's pads there: Match::ResetState resets them after the setter returned (Match.cpp:55-69; the reset_pads of
+    // gym_episode_reset, the only one that runs on the host-setter path).
+    reset_pads(A);
     if (cfg.setter_kind == SS_KICKOFF) {
-        reset_pads(A);
         // Arena::ResetToRandomKickoff (Arena.cpp:112-216)
         const float SX[5] = {-2048, 2048, -256, 256, 0}, SY[5] = {-2560, -2560, -3840, -3840, -4608};
         const float SYAW[5] = {PI_F / 4 * 1, PI_F / 4 * 3, PI_F / 4 * 2, PI_F / 4 * 2, PI_F / 4 * 2};

@@ -328,6 +328,33 @@ def test_hip_gameinst_episode_boundaries_vs_reference(sg):
     assert total >= 12
 
 
+def test_hip_random_state_resets_pads_before_first_observation():
+    """ADVICE r04 (high) on the HIP path: with the built-in RandomState every new episode's first observation shows all 34 pads active, as the
+    reference's does (RandomState.cpp:11 -> Arena.cpp:209-210; tests/golden/padreset_golden.npz recorded from the reference's GameInst with its
+    own RandomState: the cars empty their pads in the first episode, the pad columns are compared for equality up to the second episode's start)."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from test_oracle_golden import padreset_replay
+    pg = np.load(os.path.join(GOLD, "padreset_golden.npz"))
+    dev = torch.device("cuda", 0)
+    total = 0
+    for case in pg["names"]:
+        case = str(case)
+        team, tick_skip, nts = [int(x) for x in pg[f"pr/{case}/cfg"]]
+        env = BatchedEnv(1, team, cfg=_gym_cfg(team, tick_skip, 0, 0, nts), mesh=(pg["mesh_verts"], pg["mesh_tris"]))
+        rows = env.n_agents
+        nobs = torch.empty((rows, env.obs_size), device=dev); r = torch.empty(rows, device=dev); d = torch.empty(rows, dtype=torch.int32, device=dev)
+        def reset_first(state):
+            env.upload_states([state])
+            return env.reset(False).cpu().numpy()
+        def step(a):
+            env.step(torch.from_numpy(a.astype(np.int32)).to(dev), nobs, r, d)
+            env.sync()
+            return nobs.cpu().numpy(), int(d[0])
+        total += padreset_replay(pg, case, reset_first, step, "HIP")
+        env.close()
+    assert total >= 6
+
+
 def test_hip_physics_free_run_vs_reference_fixtures(sg):
     """The 31 physics scenarios stepped by the HIP kernel from the reference's start state under the recorded control tape and compared
     with the REFERENCE's states every 10 ticks -- position, velocity, angular velocity, rotation of the ball and every car, flags of

@@ -368,6 +368,49 @@ def test_port_gameinst_episode_boundaries_vs_reference(port_lib):
     assert total >= 12
 
 
+def padreset_replay(pg, case, reset_first, step, what):
+    """One case of tests/golden/padreset_golden.npz: from the recorded start state under the recorded actions with the BUILT-IN RandomState as the
+    state setter; the pad columns (17..50) of every agent row must equal the reference's up to and including the first observation of the second
+    episode (whose other columns are the setter's draws: not comparable), and be all ones in the first observation after every later end."""
+    from rlgymppo_cpp_amd.state import ArenaState
+    start = ArenaState.from_buffer_copy(pg[f"pr/{case}/start"].tobytes())
+    acts = pg[f"pr/{case}/actions"]; pads = pg[f"pr/{case}/pads"]; done = pg[f"pr/{case}/done"]
+    obs = reset_first(start)
+    assert np.array_equal(obs[:, 17:51], pads[0]), f"{what} {case}: pads of the start observation"
+    first_end = int(np.flatnonzero(done)[0])
+    ends = 0
+    for t in range(len(acts)):
+        o, d = step(acts[t])
+        if t <= first_end:
+            assert int(d) == int(done[t]), f"{what} {case}: done differs at step {t}"
+            assert np.array_equal(o[:, 17:51], pads[t + 1]), f"{what} {case}: pad columns at step {t}" + (" (first observation of the new episode: RandomState resets the pads first, RandomState.cpp:11)" if d else "")
+        if d:
+            ends += 1
+            assert (o[:, 17:51] == 1).all(), f"{what} {case}: a new episode's first observation shows an inactive pad (step {t})"
+    return ends
+
+
+def test_port_random_state_resets_pads_before_first_observation(port_lib):
+    """the reference's RandomState calls arena->ResetToRandomKickoff() first (RandomState.cpp:11), which resets all 34 pads
+    (Arena.cpp:209-210) BEFORE the setter builds the new episode's first GameState; recorded from the reference's own GameInst with that setter
+    (tests/golden/padreset_golden.npz: the cars empty their pads in the first episode).  Host build of the stepper's gym layer."""
+    pg = np.load(os.path.join(GOLD, "padreset_golden.npz"))
+    total = 0
+    for case in pg["names"]:
+        case = str(case)
+        team, tick_skip, nts = [int(x) for x in pg[f"pr/{case}/cfg"]]
+        cfg = gym_cfg_for_case(team, tick_skip, 0, 0, nts)     # setter_kind 0 = RandomState(true, true, true): the device setter runs at every episode end
+        box = {}
+        def reset_first(state):
+            (box["st"],), obs = port_gym_reset(port_lib, [state], cfg, run_setter=False)
+            return obs
+        def step(a):
+            (box["st"],), o, r, d = port_gym_step(port_lib, [box["st"]], cfg, a)
+            return o, int(d[0])
+        total += padreset_replay(pg, case, reset_first, step, "host build")
+    assert total >= 6
+
+
 def test_state_setters_against_reference_samples(sg, port_lib):
     """RandomState(true, true, true) and KickoffState: the device / port setters against 4000 / 600 resets of the reference's own
     (RandomState.cpp:8-61, Arena.cpp:112-216): same supports, means and spreads; kickoff: exactly the reference's spawn set."""
