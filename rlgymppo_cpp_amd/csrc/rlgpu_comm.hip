@@ -34,9 +34,9 @@
 // before the first real multi-GPU run.  Sums are taken in rank order by every rank itself: identical bits everywhere, run to run.
 struct ShmSeg {
     uint64_t magic; int32_t world; int32_t pad;
-    volatile int32_t arrive[2];     // sense-reversing barrier: arrivals of the current phase
-    volatile int32_t phase;
-    volatile int32_t dead;          // a rank that failed sets it: everybody else stops waiting
+    int32_t arrive[2];              // sense-reversing barrier: arrivals of the current phase (all flags below: __atomic accesses only)
+    int32_t phase;
+    int32_t dead;                   // a rank that failed sets it: everybody else stops waiting
     // then world slots of SLOT bytes
 };
 constexpr size_t SHM_SLOT = 8u << 20;
@@ -52,29 +52,32 @@ struct rlgpu_comm {
 
 namespace {
 std::string g_comm_err;
-int fail(rlgpu_comm* c, const std::string& m) { if (c) c->err = m; g_comm_err = m; if (c && c->seg) c->seg->dead = 1; return RLGPU_ERR_HIP; }
+int fail(rlgpu_comm* c, const std::string& m) { if (c) c->err = m; g_comm_err = m; if (c && c->seg) __atomic_store_n(&c->seg->dead, 1, __ATOMIC_RELEASE); return RLGPU_ERR_HIP; }
 
 unsigned char* shm_slot(rlgpu_comm* c, int r) { return reinterpret_cast<unsigned char*>(c->seg) + 4096 + (size_t)r * SHM_SLOT; }
 // everybody arrives, or the wait ends with an error: a peer that died (its process gone or its `dead` mark) must not hang the others
 int shm_barrier(rlgpu_comm* c, const char* what) {
     ShmSeg* s = c->seg;
     const int ph = c->my_phase & 1;
-    __sync_fetch_and_add(&s->arrive[ph], 1);
+    // (acquire / release on every flag: the slots a rank wrote before it arrived must be visible to whoever sees its arrival -- x86 gave that for
+    // free with plain volatile accesses, other hosts do not: ADVICE r04)
+    auto ld = [](const int32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); };
+    __atomic_fetch_add(&s->arrive[ph], 1, __ATOMIC_ACQ_REL);
     const auto t0 = std::chrono::steady_clock::now();
-    while (s->arrive[ph] < c->world) {
-        if (s->dead) return fail(c, std::string(what) + ": a peer rank failed");
+    while (ld(&s->arrive[ph]) < c->world) {
+        if (ld(&s->dead)) return fail(c, std::string(what) + ": a peer rank failed");
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s))
             return fail(c, std::string(what) + ": rank " + std::to_string(c->rank) + " waited " + std::to_string(c->timeout_s) + " s for its peers (a rank died?)");
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     // the last one to leave re-arms the OTHER phase's counter: nobody can be waiting on it (they are all here)
     c->my_phase++;
-    if (c->rank == 0) s->arrive[(c->my_phase) & 1] = 0;
+    if (c->rank == 0) __atomic_store_n(&s->arrive[(c->my_phase) & 1], 0, __ATOMIC_RELEASE);
     // second half: nobody proceeds to the next barrier before rank 0 has re-armed it
-    __sync_fetch_and_add(&s->phase, 1);
+    __atomic_fetch_add(&s->phase, 1, __ATOMIC_ACQ_REL);
     const int want = c->my_phase * c->world;
-    while (s->phase < want) {
-        if (s->dead) return fail(c, std::string(what) + ": a peer rank failed");
+    while (ld(&s->phase) < want) {
+        if (ld(&s->dead)) return fail(c, std::string(what) + ": a peer rank failed");
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(c->timeout_s)) return fail(c, std::string(what) + ": rank " + std::to_string(c->rank) + " waited " + std::to_string(c->timeout_s) + " s for its peers to leave the barrier (a rank died?)");
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
@@ -198,71 +201,87 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     if (rendezvous_dir().empty()) return fail(nullptr, "rendezvous directory /tmp/rlgpu_comm_<uid> is not a private directory of this user (set RLGPU_COMM_DIR)");
     const std::string path = rendezvous_path();
     const int timeout_s = env_i("RLGPU_COMM_TIMEOUT_S", 300) > 0 ? env_i("RLGPU_COMM_TIMEOUT_S", 300) : 300;
-    const char* transport = getenv("RLGPU_COMM_TRANSPORT");
-    if (transport && !strcmp(transport, "shm")) {
-        // the segment is named after the rendezvous file; rank 0 creates it, the others wait for its magic word
-        std::string name = path.substr(path.find_last_of('/') + 1);
-        for (char& ch : name) if (ch == '.') ch = '_';
-        name = "/" + name;
-        const size_t bytes = 4096 + (size_t)world * SHM_SLOT;
-        rlgpu_comm* c = new rlgpu_comm();
-        c->device = local; c->rank = rank; c->world = world; c->timeout_s = timeout_s; c->seg_name = name; c->seg_bytes = bytes;
-        int fd = -1;
-        if (rank == 0) {
-            (void)shm_unlink(name.c_str());
-            fd = shm_open(name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
-            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { delete c; return fail(nullptr, "shm transport: cannot create " + name + ": " + strerror(errno)); }
-        } else {
-            for (int tries = 0; tries < timeout_s * 100 && fd < 0; tries++) {
-                fd = shm_open(name.c_str(), O_RDWR, 0600);
-                struct stat st;
-                if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) { close(fd); fd = -1; }
-                if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            }
-            if (fd < 0) { delete c; return fail(nullptr, "shm transport: timed out waiting for " + name); }
-        }
-        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (m == MAP_FAILED) { delete c; return fail(nullptr, std::string("shm transport: mmap: ") + strerror(errno)); }
-        c->seg = reinterpret_cast<ShmSeg*>(m);
-        if (rank == 0) { c->seg->world = world; c->seg->arrive[0] = c->seg->arrive[1] = 0; c->seg->phase = 0; c->seg->dead = 0; __sync_synchronize(); c->seg->magic = SHM_MAGIC; }
-        else {
-            for (int tries = 0; tries < timeout_s * 100 && c->seg->magic != SHM_MAGIC; tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            if (c->seg->magic != SHM_MAGIC || c->seg->world != world) { munmap(m, bytes); delete c; return fail(nullptr, "shm transport: " + name + " is not this launch's segment"); }
-        }
-        int rc = shm_barrier(c, "shm transport: first barrier");
-        if (rank == 0) (void)shm_unlink(name.c_str());   // everybody has it mapped
-        if (rc != RLGPU_OK) { const std::string e = c->err; munmap(m, bytes); delete c; return fail(nullptr, e); }
-        *out = c;
-        return RLGPU_OK;
-    }
-    unsigned char id[RLGPU_COMM_ID_BYTES];
-    if (rank == 0) {
-        int rc = rlgpu_comm_unique_id(id);
-        if (rc != RLGPU_OK) return rc;
+    // rank 0 publishes RLGPU_COMM_ID_BYTES of payload through the rendezvous file (tmp file + rename: a reader never sees half of it), the others
+    // wait for a FRESH file (written after their own start minus RLGPU_COMM_STALE_S: what a crashed earlier launch left under the name is refused)
+    auto publish = [&](const unsigned char* payload) -> int {
         (void)unlink(path.c_str());                          // whatever an earlier launch left under this name
         const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
         (void)unlink(tmp.c_str());
         const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
         if (fd < 0) return fail(nullptr, "cannot create " + tmp + ": " + strerror(errno));
         const uint64_t hdr[2] = {RDV_MAGIC, (uint64_t)time(nullptr)};
-        const bool ok = write(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && write(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+        const bool ok = write(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && write(fd, payload, RLGPU_COMM_ID_BYTES) == (ssize_t)RLGPU_COMM_ID_BYTES;
         close(fd);
         if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return fail(nullptr, "cannot write " + path); }
-    } else {
+        return RLGPU_OK;
+    };
+    auto await = [&](unsigned char* payload) -> int {
         const int64_t stale_s = env_i("RLGPU_COMM_STALE_S", 300);
         bool ok = false;
         for (int tries = 0; tries < timeout_s * 100 && !ok; tries++) {
             const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
             if (fd >= 0) {
                 uint64_t hdr[2] = {0, 0};
-                const bool whole = read(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && read(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+                const bool whole = read(fd, hdr, sizeof(hdr)) == (ssize_t)sizeof(hdr) && read(fd, payload, RLGPU_COMM_ID_BYTES) == (ssize_t)RLGPU_COMM_ID_BYTES;
                 close(fd);
                 ok = whole && hdr[0] == RDV_MAGIC && (int64_t)hdr[1] >= g_process_start - stale_s;
             }
             if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
-        if (!ok) return fail(nullptr, "timed out waiting for a fresh " + path);
+        return ok ? RLGPU_OK : fail(nullptr, "timed out waiting for a fresh " + path);
+    };
+    unsigned char id[RLGPU_COMM_ID_BYTES];
+    const char* transport = getenv("RLGPU_COMM_TRANSPORT");
+    if (transport && !strcmp(transport, "shm")) {
+        // The segment's name is this launch's own -- rank 0's pid and clock -- and travels through the rendezvous file like an RCCL id does: a segment
+        // a crashed earlier launch left behind (right size, magic and world: it used to be accepted when it was opened before rank 0 had replaced
+        // it) has another name and is never looked at.
+        const size_t bytes = 4096 + (size_t)world * SHM_SLOT;
+        rlgpu_comm* c = new rlgpu_comm();
+        c->device = local; c->rank = rank; c->world = world; c->timeout_s = timeout_s; c->seg_bytes = bytes;
+        int fd = -1;
+        memset(id, 0, sizeof(id));
+        if (rank == 0) {
+            const auto now = std::chrono::steady_clock::now().time_since_epoch();
+            snprintf(reinterpret_cast<char*>(id), sizeof(id), "/rlgpu_shm_%ld_%lld", (long)getpid(), (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(now).count());
+            c->seg_name = reinterpret_cast<const char*>(id);
+            fd = shm_open(c->seg_name.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { const std::string why = strerror(errno); if (fd >= 0) { close(fd); (void)shm_unlink(c->seg_name.c_str()); } const std::string n = c->seg_name; delete c; return fail(nullptr, "shm transport: cannot create " + n + ": " + why); }
+        } else {
+            if (await(id) != RLGPU_OK) { delete c; return RLGPU_ERR_HIP; }
+            id[sizeof(id) - 1] = 0;
+            c->seg_name = reinterpret_cast<const char*>(id);
+            fd = shm_open(c->seg_name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) { close(fd); fd = -1; }
+            if (fd < 0) { const std::string n = c->seg_name; delete c; return fail(nullptr, "shm transport: cannot open this launch's segment " + n); }
+        }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { if (rank == 0) (void)shm_unlink(c->seg_name.c_str()); delete c; return fail(nullptr, std::string("shm transport: mmap: ") + strerror(errno)); }
+        c->seg = reinterpret_cast<ShmSeg*>(m);
+        if (rank == 0) {
+            // the header is complete BEFORE the name is published: a reader that can open the segment sees this launch's magic and world
+            c->seg->world = world; c->seg->arrive[0] = c->seg->arrive[1] = 0; c->seg->phase = 0; c->seg->dead = 0;
+            __atomic_store_n(&c->seg->magic, SHM_MAGIC, __ATOMIC_RELEASE);
+            if (publish(id) != RLGPU_OK) { (void)shm_unlink(c->seg_name.c_str()); munmap(m, bytes); delete c; return RLGPU_ERR_HIP; }
+        } else if (__atomic_load_n(&c->seg->magic, __ATOMIC_ACQUIRE) != SHM_MAGIC || c->seg->world != world) {
+            const std::string n = c->seg_name; munmap(m, bytes); delete c; return fail(nullptr, "shm transport: " + n + " is not this launch's segment");
+        }
+        int rc = shm_barrier(c, "shm transport: first barrier");
+        if (rank == 0) { (void)shm_unlink(c->seg_name.c_str()); (void)unlink(path.c_str()); }   // everybody has it mapped (or the wait ended): nothing is left behind
+        if (rc != RLGPU_OK) { const std::string e = c->err; munmap(m, bytes); delete c; return fail(nullptr, e); }
+        *out = c;
+        return RLGPU_OK;
+    }
+    if (rank == 0) {
+        int rc = rlgpu_comm_unique_id(id);
+        if (rc != RLGPU_OK) return rc;
+        rc = publish(id);
+        if (rc != RLGPU_OK) return rc;
+    } else {
+        int rc = await(id);
+        if (rc != RLGPU_OK) return rc;
     }
     int rc = rlgpu_comm_init(out, local, rank, world, id);
     // everybody has read the file once ncclCommInitRank has returned (it is collective), whatever it returned

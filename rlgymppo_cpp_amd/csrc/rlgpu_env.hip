@@ -1334,7 +1334,6 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
     HIPCHK(e, hipSetDevice(e->device));
     RlgpuArenaState* ddst = nullptr; int32_t* dids = nullptr;
     HIPCHK(e, hipMalloc(&ddst, sizeof(RlgpuArenaState) * (size_t)n));
-    HIPCHK(e, hipMemsetAsync(ddst, 0, sizeof(RlgpuArenaState) * (size_t)n, e->stream));
     if (env_ids) { HIPCHK(e, hipMalloc(&dids, 4 * (size_t)n)); HIPCHK(e, hipMemcpyAsync(dids, env_ids, 4 * (size_t)n, hipMemcpyHostToDevice, e->stream)); }
     // every byte of what the caller gets is defined: car slots beyond the env's cars, the reserved part of the appended block and the struct's
     // padding are zeros (arena_to_host writes the live fields only)

@@ -1850,15 +1850,15 @@ int rlgpu_learner_sync_from_rank0(rlgpu_learner* l, rlgpu_comm* c) {
     if (!c) return RLGPU_OK;
     LCHK(l, hipSetDevice(l->device));
     for (float* p : {l->params, l->adam_m, l->adam_v}) { int rc = rlgpu_comm_broadcast(c, p, l->n_total * 4, 0, (void*)l->stream); if (rc) { l->err = rlgpu_comm_last_error(c); return rc; } }
+    { int rc0 = ls_pull(l); if (rc0) return rc0; }
     int64_t* steps = nullptr;
     LCHK(l, hipMalloc(&steps, 16));
-    { int rc0 = ls_pull(l); if (rc0) return rc0; }
+    struct Free { int64_t* p; ~Free() { (void)hipFree(p); } } free_steps{steps};   // (released on every way out of the function, the LCHK returns included)
     const int64_t h[2] = {l->step_p, l->step_c};
     LCHK(l, hipMemcpyAsync(steps, h, 16, hipMemcpyHostToDevice, l->stream));
     int rc = rlgpu_comm_broadcast(c, steps, 16, 0, (void*)l->stream);
     int64_t g[2] = {0, 0};
     if (!rc) { LCHK(l, hipMemcpyAsync(g, steps, 16, hipMemcpyDeviceToHost, l->stream)); LCHK(l, hipStreamSynchronize(l->stream)); l->step_p = g[0]; l->step_c = g[1]; rc = ls_push(l); }
-    (void)hipFree(steps);
     if (rc) { l->err = rlgpu_comm_last_error(c); return rc; }
     l->shadows_dirty = true;
     return RLGPU_OK;

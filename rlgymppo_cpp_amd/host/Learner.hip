@@ -158,7 +158,7 @@ struct Learner::Impl {
     // free-running collection (LearnerConfig::lockstepCollection = false; rlgpu_collect_free): buffers and FIFO slots are laid out for Tcap steps,
     // steps[e] = what env e made in the last launch (== T after a lockstep launch), trajOff[slot] = where each trajectory of the iteration in
     // that FIFO slot starts in the concatenated batch
-    bool ragged = false, freeOk = true, lastFree = false; int Tcap = 0, Tused = 0; int64_t lastRows = 0;
+    bool ragged = false, freeOk = true, lastFree = false; int Tcap = 0, Tused = 0; int64_t lastRows = 0, lastRowsAll = 0;   // lastRowsAll: the iteration's timesteps of ALL ranks
     int32_t *steps = nullptr, *trajOff = nullptr, *permDev = nullptr;
     std::vector<int32_t> hSteps, hAgentSteps, perm[2]; int permFlip = 0;
     std::future<int64_t> permDraw; bool permPending = false; std::string permEngine;   // a permutation drawn ahead for a predicted FIFO size + the engine before it
@@ -333,7 +333,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.acts = dev_alloc<int32_t>(TN); m.done = dev_alloc<int32_t>(TN);
     m.steps = dev_alloc<int32_t>((size_t)m.nEnvs); m.hSteps.assign((size_t)m.nEnvs, m.T); m.hAgentSteps.assign((size_t)m.nAgents, m.T);
     hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
-    m.Tused = m.T; m.lastRows = m.B;
+    m.Tused = m.T; m.lastRows = m.B; m.lastRowsAll = (int64_t)m.B * m.world;
     if (m.ragged) {
         if (rlgpu_expbuf_create_ragged(&m.fifo, config.expBufferSize, m.Tcap, m.nAgents, m.B) != RLGPU_OK) {
             RG_LOG("\tfree-running collection: expBufferSize " << config.expBufferSize << " would keep more than 15 iterations resident -> lockstep collection");
@@ -558,6 +558,9 @@ void Learner::Impl::HostResetEnvs(const std::vector<int32_t>& ids, float* obsRow
         EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 0, devRows), "reset_envs");
     } else if (!deviceDidReset) {
         EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 1, devRows), "reset_envs");
+        // the device's setters are the built-in ones, and both reset the pads BEFORE they build the episode's first GameState (KickoffState and
+        // RandomState through Arena::ResetToRandomKickoff, RandomState.cpp:11, Arena.cpp:209-210): that GameState shows every pad active
+        for (auto& pb : padsBefore) pb.fill(1);
     }
     if (!plan.AnyHost()) return;
     EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
@@ -664,8 +667,8 @@ void Learner::CollectTimesteps() {
     auto lockstepDone = [&]() {   // every game made T steps
         if (m.ragged) hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
         std::fill(m.hSteps.begin(), m.hSteps.end(), m.T); std::fill(m.hAgentSteps.begin(), m.hAgentSteps.end(), m.T);
-        m.Tused = m.T; m.lastRows = m.B; m.lastFree = false;
-        totalTimesteps += (uint64_t)m.B * (uint64_t)m.world;
+        m.Tused = m.T; m.lastRows = m.B; m.lastFree = false; m.lastRowsAll = (int64_t)m.B * m.world;
+        totalTimesteps += (uint64_t)m.lastRowsAll;
     };
     // no per-step host work: the whole phase in one launch (rlgpu_collect / rlgpu_collect_free), when the policy fits the in-kernel inference
     if (!slow && !renderSender && m.fusedCollect && m.match->teamSize <= FusedMaxTeam()) {
@@ -681,7 +684,11 @@ void Learner::CollectTimesteps() {
                     for (int k = 0; k < m.nPlayers; k++) m.hAgentSteps[(size_t)e * m.nPlayers + k] = st;
                 }
                 m.Tused = tmax; m.lastRows = rows; m.lastFree = true;
-                totalTimesteps += (uint64_t)rows * (uint64_t)m.world;   // (the other ranks' counts differ by less than one step of every game; rank 0's stands for each)
+                // every rank's own pace gives it its own count (they differ by less than one step of every game): the job's count is the SUM, taken
+                // collectively so that totalTimesteps -- the Learn() loop's exit, the checkpoint cadence and folder names -- is the same number on every rank
+                m.lastRowsAll = rows;
+                if (m.comm) { m.lastRowsAll = 0; for (double v : GatherOverRanks((double)rows)) m.lastRowsAll += (int64_t)std::llround(v); }
+                totalTimesteps += (uint64_t)m.lastRowsAll;
                 return;
             }
             if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect_free");
@@ -939,11 +946,11 @@ void Learner::Learn() {
         report["Total Iterations"] = (double)totalIterations; report["Cumulative Timesteps"] = (double)totalTimesteps;
         report["Timesteps Collected"] = (double)m.lastRows;
         report["Collection Time"] = collectTime; report["Consumption Time"] = consumeTime; report["Total Iteration Time"] = tAll.Elapsed();
-        report["Collected Steps/Second"] = (double)m.lastRows * m.world / std::max(collectTime, 1e-9);
-        report["Overall Steps/Second"] = (double)m.lastRows * m.world / std::max(tAll.Elapsed(), 1e-9);
+        report["Collected Steps/Second"] = (double)m.lastRowsAll / std::max(collectTime, 1e-9);
+        report["Overall Steps/Second"] = (double)m.lastRowsAll / std::max(tAll.Elapsed(), 1e-9);
         if (iterationCallback) iterationCallback(this, report);
         if (config.sendMetrics && metricSender) metricSender->Send(report);                                                                       // Learner.cpp:589-590
-        if (m.rank != 0 || std::getenv("RLGPU_QUIET")) { m.tsSinceSave += (uint64_t)m.lastRows * (uint64_t)m.world; if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save(); continue; }
+        if (m.rank != 0 || std::getenv("RLGPU_QUIET")) { m.tsSinceSave += (uint64_t)m.lastRowsAll; if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save(); continue; }
         RG_LOG(std::string(8, '\n') << std::string(20, '=') << " ITERATION COMPLETED " << std::string(20, '='));
         const std::vector<std::string> rows = {"Average Step Reward", "Policy Entropy", "Value Function Loss", "", "Mean KL Divergence", "SB3 Clip Fraction", "Avg Return",
                         "Avg Advantage", "Avg Val Target", "", "Collected Steps/Second", "Overall Steps/Second", "", "Collection Time", "Consumption Time",
@@ -954,7 +961,7 @@ void Learner::Learn() {
             std::string dashed = "-" + kv.first;
             if (std::find(rows.begin(), rows.end(), kv.first) == rows.end() && std::find(rows.begin(), rows.end(), dashed) == rows.end()) RG_LOG("  [metric] " << report.SingleToString(kv.first));
         }
-        m.tsSinceSave += (uint64_t)m.lastRows * (uint64_t)m.world;
+        m.tsSinceSave += (uint64_t)m.lastRowsAll;
         if (m.rank == 0 && !config.checkpointSaveFolder.empty() && m.tsSinceSave >= (uint64_t)std::max<int64_t>(config.timestepsPerSave, 1)) Save();
     }
     if (m.learnPending) { Report last; FinishLearn(last); }

@@ -34,7 +34,7 @@ static void IterationMetrics(Learner* learner, Report& all) {
         speed += (float)r.GetAvg("player_speed"); touch += (float)r.GetAvg("ball_touch_ratio"); air += (float)r.GetAvg("in_air_ratio");
     }
     if (speed.count > 0) { all["player_speed"] = speed.Get(); all["ball_touch_ratio"] = touch.Get(); all["in_air_ratio"] = air.Get(); }
-    if (--g_iterations_left <= 0) learner->config.timestepLimit = 1;   // stop after this iteration
+    if (--g_iterations_left <= 0 && !getenv("EXAMPLE_TIMESTEP_LIMIT")) learner->config.timestepLimit = 1;   // stop after this iteration
 }
 
 static EnvCreateResult MakeEnv() {
@@ -87,7 +87,9 @@ int main(int argc, char** argv) {
         if (cfg.renderMode) learner.config.timestepLimit = learner.totalTimesteps + (uint64_t)std::max(g_iterations_left, 1) * 2;   // here "iterations" = rendered 1v1 steps
         if (useStepCallback) learner.stepCallback = StepMetrics;
         learner.iterationCallback = IterationMetrics;
+        if (const char* lim = getenv("EXAMPLE_TIMESTEP_LIMIT")) learner.config.timestepLimit = strtoull(lim, nullptr, 10);   // run to a timestep count instead of an iteration count
         learner.Learn();
+        std::cerr << "[example_main rank " << learner.Rank() << "/" << learner.WorldSize() << "] " << learner.totalIterations << " iterations, " << learner.totalTimesteps << " timesteps" << std::endl;
     } catch (const std::exception& e) {
         std::cerr << e.what() << std::endl;
         return 1;

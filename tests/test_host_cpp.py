@@ -415,6 +415,39 @@ def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_free_running_ranks_count_timesteps_together_and_stop_together(tmp_path):
+    """with free-running collection (the default) every rank gathers its own number of timesteps per iteration -- they differ
+    by up to one step of every game -- so the job's count must be taken collectively: Learner::Learn's exit test (`totalTimesteps < timestepLimit`),
+    the checkpoint cadence and the folder names hang on it, and a rank that leaves the loop one iteration before its peer leaves the peer waiting in
+    the next all-reduce.  Two example_main ranks on the one GPU (shm transport), NO RLGPU_LOCKSTEP_COLLECTION, a timestep limit that falls
+    inside an iteration: both end by themselves, after the same number of iterations, with the same cumulative count, which is not a multiple of
+    the lockstep batch."""
+    import re, socket
+    exe = os.path.join(PKG, "example_main")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdv = str(tmp_path / "rdv_free"); os.mkdir(rdv, 0o700)
+    B = 16384
+    base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TAG="free",
+                RLGPU_COMM_TRANSPORT="shm", RLGPU_COMM_TIMEOUT_S="30", RLGPU_REPLICA_CHECK_EVERY="1", RLGPU_QUIET="1", EXAMPLE_TIMESTEP_LIMIT=str(2 * B * 4 + 2 * B // 2))
+    base.pop("RLGPU_LOCKSTEP_COLLECTION", None)
+    procs = [subprocess.Popen([exe, "1000000", "1", "256", str(B)], env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=200))
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            pytest.fail("a rank went on waiting for its peer: the ranks' timestep counts parted")
+    assert [p.returncode for p in procs] == [0, 0], outs
+    got = [re.search(r"\[example_main rank (\d)/2\] (\d+) iterations, (\d+) timesteps", o[1]) for o in outs]
+    assert all(got), outs
+    assert got[0].group(2) == got[1].group(2) and got[0].group(3) == got[1].group(3), [g.group(0) for g in got]
+    iters, total = int(got[0].group(2)), int(got[0].group(3))
+    assert iters == 5 and total >= 2 * B * 5 and total % B != 0, (iters, total)      # free-running: B .. B + one step of every game per rank and iteration
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [["--envs", "1024"], ["--envs", "1024", "--lockstep"], ["--envs", "700", "--overlap", "--fp16"],
                                   ["--envs", "600", "--team-size", "2", "--padded-zero-sum"], ["--envs", "300", "--team-size", "3", "--padded-zero-sum", "--epochs", "2"]])
 def test_cpp_host_runs_clean_under_redzones(args):
