@@ -31,6 +31,7 @@ RLG_HD M3 body_inertia_w(const Body& b, V3 inertia_local) { return scaled_cols(b
 constexpr float BOX_MARGIN = 0.1f * ((K::HITBOX_Z * UU2BT) / 2);
 RLG_HD V3 hitbox_core() { return v3((K::HITBOX_X * UU2BT) / 2 - 0.04f, (K::HITBOX_Y * UU2BT) / 2 - 0.04f, (K::HITBOX_Z * UU2BT) / 2 - 0.04f); }
 RLG_HD V3 hitbox_half() { V3 c = hitbox_core(); return v3(c.x + BOX_MARGIN, c.y + BOX_MARGIN, c.z + BOX_MARGIN); }
+constexpr float HITBOX_REACH = 1.6f;   // > |hitbox_half()| = 1.534 BT: no point of the hitbox (margin included) is farther from the hitbox centre, along any direction
 RLG_HD V3 hitbox_off() { return v3(K::HITBOX_OFF_X, K::HITBOX_OFF_Y, K::HITBOX_OFF_Z) * UU2BT; }
 
 RLG_HD V3 car_inertia_local() {  // btBoxShape::calculateLocalInertia (btBoxShape.cpp:34-47), mass 180

@@ -32,16 +32,27 @@ struct CarTickCtx {
     float new_lat[4], new_long[4];   // this tick's friction factors per wheel (car_wheel_trace), adopted by car_pre_tick_finish
 };
 
+// phase 2's private copy of what the wheel lanes left in the car's CarTickCtx (car_pre_tick_finish): read in one go into registers -- the context
+// lives in LDS behind a reference, where every conditional read is a dependent round trip and every store in between forces the reads after it
+struct CarWheels {
+    WheelTmp w[4];
+    float new_lat[4], new_long[4];
+    int n_contact;
+    bool wheels_world;
+    float forward_speed_uu;
+};
+
 // true when phase 2 of car `ci` reads another car (a wheel stands on it): such ticks run phase 2 in car order
 RLG_HD bool car_needs_ordered_finish(const CarTickCtx& t) {
-    bool r = false;
-    for (int i = 0; i < 4; i++) r = r || (t.w[i].in_contact && t.w[i].ground >= 2);
-    return r;
+    // (bitwise on purpose: `||` / `&&` over values behind an LDS reference compile to one dependent load + branch per term, a chain of ~100-cycle round trips)
+    const bool c0 = t.w[0].in_contact, c1 = t.w[1].in_contact, c2 = t.w[2].in_contact, c3 = t.w[3].in_contact;
+    const int g0 = t.w[0].ground, g1 = t.w[1].ground, g2 = t.w[2].ground, g3 = t.w[3].ground;
+    return (c0 & (g0 >= 2)) | (c1 & (g1 >= 2)) | (c2 & (g2 >= 2)) | (c3 & (g3 >= 2));
 }
 
 // per-wheel part of Car::_UpdateWheels (Car.cpp:405-452): this tick's lateral / longitudinal friction factors of wheel i.
 // Needs only state that nothing changes before car_pre_tick_finish, so it runs on the wheel's own lane.
-RLG_HD void wheel_friction_factors(const Car& c, const WheelTmp& w, const M3& basis, float& latf_out, float& lonf_out) {
+RLG_HD void wheel_friction_factors(const CarHot& c, const WheelTmp& w, const M3& basis, float& latf_out, float& lonf_out) {
     const float dt = TICK_DT;
     float hb = c.handbrake_val;   // the value car_update_wheels is about to store
     if (c.ctl.handbrake) hb += K::POWERSLIDE_RISE_RATE * dt; else hb -= K::POWERSLIDE_FALL_RATE * dt;
@@ -72,7 +83,7 @@ RLG_HD void wheel_friction_factors(const Car& c, const WheelTmp& w, const M3& ba
 
 // one wheel of calcFrictionImpulses, with LAST tick's engine force / brake / friction factors (btVehicleRL.cpp:313-387)
 template <int NC>
-RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTmp& w, const M3& basis, int i) {
+RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const CarHot& c, const WheelTmp& w, const M3& basis, int i) {
     const float friction_scale = K::CAR_MASS / 3;
     if (w.ground < 0) return v3(0, 0, 0);
     V3 axle = col1(basis);
@@ -118,7 +129,7 @@ RLG_HD V3 wheel_friction_impulse(const Arena<NC>& A, const Car& c, const WheelTm
 }
 
 // ---- Car::_UpdateWheels (Car.cpp:330-475) -------------------------------------------------------------
-RLG_HD void car_update_wheels(Car& c, CarTickCtx& t) {
+RLG_HD void car_update_wheels(CarHot& c, const CarWheels& t) {
     const float dt = TICK_DT;
     float abs_fwd = fabsf(t.forward_speed_uu);
     if (c.ctl.handbrake) c.handbrake_val += K::POWERSLIDE_RISE_RATE * dt;
@@ -169,7 +180,7 @@ RLG_HD void car_update_wheels(Car& c, CarTickCtx& t) {
 }
 
 // ---- Car::_UpdateAirTorque (Car.cpp:556-641) ------------------------------------------------------------
-RLG_HD void car_update_air_torque(Car& c, bool update_air_control) {
+RLG_HD void car_update_air_torque(CarHot& c, bool update_air_control) {
     V3 fwd = col0(c.b.rot), right = col1(c.b.rot), up = col2(c.b.rot);
     V3 dir_pitch = -right, dir_yaw = up, dir_roll = -fwd;
     bool do_air = false;
@@ -223,7 +234,7 @@ RLG_HD void car_update_air_torque(Car& c, bool update_air_control) {
 }
 
 // ---- Car::_UpdateJump (Car.cpp:507-554) -------------------------------------------------------------------
-RLG_HD void car_update_jump(Car& c, bool jump_pressed) {
+RLG_HD void car_update_jump(CarHot& c, bool jump_pressed) {
     const float dt = TICK_DT;
     bool on_ground = c.flags & CF_ON_GROUND;
     if (on_ground && !(c.flags & CF_IS_JUMPING)) {
@@ -255,7 +266,7 @@ RLG_HD void car_update_jump(Car& c, bool jump_pressed) {
 }
 
 // ---- Car::_UpdateAutoFlip (Car.cpp:763-797) ---------------------------------------------------------------
-RLG_HD void car_update_auto_flip(Car& c, bool jump_pressed) {
+RLG_HD void car_update_auto_flip(CarHot& c, bool jump_pressed) {
     const float dt = TICK_DT;
     if (jump_pressed && (c.flags & CF_WORLD_CONTACT) && c.world_contact_normal.z > K::CAR_AUTOFLIP_NORMZ_THRESH) {
         float roll = rot_roll(c.b.rot);
@@ -279,7 +290,7 @@ RLG_HD void car_update_auto_flip(Car& c, bool jump_pressed) {
 }
 
 // ---- Car::_UpdateDoubleJumpOrFlip (Car.cpp:643-761) -------------------------------------------------------
-RLG_HD void car_update_double_jump_or_flip(Car& c, bool jump_pressed, float forward_speed_uu) {
+RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float forward_speed_uu) {
     const float dt = TICK_DT;
     if (c.flags & CF_ON_GROUND) {
         c.flags &= ~(CF_HAS_DOUBLE_JUMPED | CF_HAS_FLIPPED);
@@ -341,7 +352,7 @@ RLG_HD void car_update_double_jump_or_flip(Car& c, bool jump_pressed, float forw
 }
 
 // ---- Car::_UpdateAutoRoll (Car.cpp:799-833) --------------------------------------------------------------
-RLG_HD void car_update_auto_roll(Car& c, const CarTickCtx& t) {
+RLG_HD void car_update_auto_roll(CarHot& c, const CarWheels& t) {
     V3 ground_up;
     if (t.n_contact > 0) {
         V3 sum = v3(0, 0, 0);
@@ -363,7 +374,7 @@ RLG_HD void car_update_auto_roll(Car& c, const CarTickCtx& t) {
 }
 
 // ---- Car::_UpdateBoost (Car.cpp:477-505) -------------------------------------------------------------------
-RLG_HD void car_update_boost(Car& c) {
+RLG_HD void car_update_boost(CarHot& c) {
     const float dt = TICK_DT;
     if (c.time_spent_boosting > 0) {
         if (!c.ctl.boost && c.time_spent_boosting >= K::BOOST_MIN_TIME) c.time_spent_boosting = 0.f;
@@ -463,6 +474,7 @@ RLG_HD_MID void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx& t) 
             t.wheel_basis[i >> 1] = basis2;  // a zero steering angle gives the exact identity quaternion (0,0,0,1)
         }
     }
+    RLG_SPROF(47);
     WheelTmp& w = t.w[i];
     V3 source = (rot * wheel_conn(i)) + pos, target = source + (wheel_dir * wheel_ray_len(i));
     RayHit hit = ray_planes(source, target);
@@ -504,7 +516,7 @@ RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh,
     if (Q.overflow) ray_mesh_walk(mesh, source, target, hit);
     else ray_apply_mesh_key(mesh, Q, ray_keys(t)[i], source, target, hit);
     ray_ball_and_cars(A, ci, source, target, hit);
-    RLG_PROF(7);
+    RLG_PROF(7); RLG_SPROF(40);
     w.impulse = v3(0, 0, 0);
     w.ground = -1; w.in_contact = false;
     if (hit.kind >= 0) {
@@ -544,14 +556,16 @@ RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh,
         w.susp_len = rest + travel; w.susp_rel_vel = 0.f; w.contact_normal = -wheel_dir; w.clipped_inv = 1.f;
         cr.extra_pushback[i] = 0.f;
     }
+    RLG_SPROF(41);
     // per-wheel halves of calcFrictionImpulses and _UpdateWheels (see the two helpers above)
     w.impulse = wheel_friction_impulse(A, cr, w, t.wheel_basis[i >> 1], i);
+    RLG_SPROF(42);
     if (w.ground >= 0) wheel_friction_factors(cr, w, t.wheel_basis[i >> 1], t.new_lat[i], t.new_long[i]);
     t.w[i] = w;
 }
 
 template <int NC>
-RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t);
+RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx& t, bool last_jump);
 
 // phase 2, per car: friction impulses, the car's control logic, suspension forces (rest of Car::_PreTickUpdate)
 template <int NC>
@@ -560,36 +574,40 @@ RLG_HD_BIG void car_pre_tick_finish(Arena<NC>& A, int ci, CarTickCtx& t) {
     // would be re-loaded after every store); a local Car is promoted to registers.
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t);
     if (A.cars[ci].flags & CF_IS_DEMOED) return;
-#ifdef RLG_CAR_DIRECT
-    car_pre_tick_finish_body(A, A.cars[ci], ci, t);
-#else
-    Car c = A.cars[ci];
-    car_pre_tick_finish_body(A, c, ci, t);
-    A.cars[ci] = c;
-#endif
+    CarHot c = A.cars[ci];   // (only the part of the car this phase touches: arena_types.h CarHot)
+    car_pre_tick_finish_body(A, c, ci, t, A.cars[ci].last.jump);
+    static_cast<CarHot&>(A.cars[ci]) = c;
 }
 
 template <int NC>
-RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t) {
+RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx& ctx, bool last_jump) {
     const float dt = TICK_DT;
+    CarWheels t;
+    for (int i = 0; i < 4; i++) { t.w[i] = ctx.w[i]; t.new_lat[i] = ctx.new_lat[i]; t.new_long[i] = ctx.new_long[i]; }
     t.n_contact = 0; t.wheels_world = false;
+    bool ordered = false;
     for (int i = 0; i < 4; i++) {
-        if (t.w[i].in_contact) { t.n_contact++; if (t.w[i].ground == 0) t.wheels_world = true; }
+        t.n_contact += t.w[i].in_contact ? 1 : 0;
+        t.wheels_world |= t.w[i].in_contact & (t.w[i].ground == 0);
+        ordered |= t.w[i].in_contact & (t.w[i].ground >= 2);
     }
     // friction impulses: taken from the wheel lanes (car_wheel_trace) unless a wheel stands on another car -- that reads the
     // other car's velocity, which its own phase 2 may already have changed (callers run such ticks in car order)
-    if (car_needs_ordered_finish(t)) {
-        for (int i = 0; i < 4; i++) t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], t.wheel_basis[i >> 1], i);
+    if (ordered) {
+        for (int i = 0; i < 4; i++) { t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], ctx.wheel_basis[i >> 1], i); ctx.w[i].impulse = t.w[i].impulse; }
     }
 
-    bool jump_pressed = c.ctl.jump && !c.last.jump;
+    bool jump_pressed = c.ctl.jump && !last_jump;
     uint32_t wf = 0;
-    for (int i = 0; i < 4; i++) if (t.w[i].in_contact) wf |= (CF_WHEEL0 << i);
+    for (int i = 0; i < 4; i++) wf |= t.w[i].in_contact ? (CF_WHEEL0 << i) : 0u;
     c.flags = (c.flags & ~(CF_WHEEL0 * 15u)) | wf;
     if (t.n_contact >= 3) c.flags |= CF_ON_GROUND; else c.flags &= ~CF_ON_GROUND;
 
     t.forward_speed_uu = dot(c.b.vel, col0(c.b.rot)) * BT2UU;
+    ctx.n_contact = t.n_contact; ctx.wheels_world = t.wheels_world; ctx.forward_speed_uu = t.forward_speed_uu;   // (the host build's debug dumps read them)
+    RLG_SPROF(32);
     car_update_wheels(c, t);
+    RLG_SPROF(33);
     if (t.n_contact < 3) car_update_air_torque(c, t.n_contact == 0);
     else c.flags &= ~CF_IS_FLIPPING;
     car_update_jump(c, jump_pressed);
@@ -597,6 +615,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
     car_update_double_jump_or_flip(c, jump_pressed, t.forward_speed_uu);
     if (c.ctl.throttle != 0.f && ((t.n_contact > 0 && t.n_contact < 4) || (c.flags & CF_WORLD_CONTACT))) car_update_auto_roll(c, t);
     c.flags &= ~CF_WORLD_CONTACT;
+    RLG_SPROF(34);
 
     // updateVehicleSecond: suspension (btVehicleRL.cpp:277-310) then friction impulses (:390-402)
     float susp_force[4];
@@ -619,6 +638,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
             body_apply_impulse(c.b, w.contact_normal * scale, off, CAR_INV_MASS);
         }
     }
+    RLG_SPROF(35);
     {
         V3 updir = col2(c.b.rot);
         for (int i = 0; i < 4; i++) {
@@ -632,6 +652,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, Car& c, int ci, CarTickCtx& t
         }
     }
     car_update_boost(c);
+    RLG_SPROF(36);
 }
 
 // ---- Car::_PostTickUpdate + _FinishPhysicsTick (Car.cpp:133-193) ------------------------------------------

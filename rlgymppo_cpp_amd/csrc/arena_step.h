@@ -363,30 +363,34 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
         ball_hit[ci] = 0;
         if (car_collides(car)) {
             V3 h = hitbox_half();
-            V3 bc = car.b.pos + car.b.rot * hitbox_off();
+            const Body cb = car.b;   // (a register copy: the loops below store contacts and car flags between their reads of the pose)
+            V3 bc = cb.pos + cb.rot * hitbox_off();
             // pair order of the reference's broadphase (btRSBroadphase.cpp:393-469): the statics of the car's cell in creation order = mesh
             // bodies, then floor, ceiling, -x wall, +x wall (Arena.cpp:1036-1101); the contact-added callbacks fire in that order
             nw.car_mesh(A, mesh, ci, [&](const Cand& k, int obj) {
-                if (mesh_point(car.b, k, obj, CBT_CAR)) {
+                if (mesh_point(cb, k, obj, CBT_CAR)) {
                     car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n_raw;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427) sees the point BEFORE btAdjustInternalEdgeContacts (Arena.cpp:276-280)
                 }
             });
-            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, car.b, CBT_CAR);
+            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, cb, CBT_CAR);
             for (int k = 0; k < n; k++) { out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].special = 0; }
             // planes: ONE contact per plane and tick, the hitbox's support vertex towards the plane (btConvexPlaneCollisionAlgorithm.cpp:
             // 92-121; the perturbation passes are off: m_minimumPointsPerturbationThreshold = 0, btConvexPlaneCollisionAlgorithm.h:62-63)
             for (int i = 0; i < 4; i++) {
                 V3 pn, po; world_plane_body(i, pn, po);
-                V3 dirl = tmul(car.b.rot, -pn);                       // planeInConvex.getBasis() * -planeNormal
+                // (no point of the hitbox is farther from its centre than |half extents| = 1.534: a plane farther than that plus the threshold from the
+                // centre cannot give a point, whatever the pose -- three of the four planes for a car on the floor)
+                if (dot(pn, bc + (-po)) - HITBOX_REACH >= CBT_CAR) continue;
+                V3 dirl = tmul(cb.rot, -pn);                       // planeInConvex.getBasis() * -planeNormal
                 V3 vtx = v3(dirl.x >= 0.f ? h.x : -h.x, dirl.y >= 0.f ? h.y : -h.y, dirl.z >= 0.f ? h.z : -h.z);   // btBoxShape::localGetSupportingVertex
-                V3 vip = (car.b.rot * vtx) + (bc + (-po));           // convexInPlaneTrans(vtx): origin = convex origin - plane origin
+                V3 vip = (cb.rot * vtx) + (bc + (-po));           // convexInPlaneTrans(vtx): origin = convex origin - plane origin
                 float dist = dot(pn, vip);                             // plane constant 0 in the plane body's frame (Arena.cpp:1067-1101)
                 if (!(dist < CBT_CAR) || n >= CAR_WORLD_MAX) continue;
                 V3 pb = (vip - pn * dist) + po;                        // planeObjWrap->getWorldTransform() * vtxInPlaneProjected
                 int cnt = 0;
-                if (manifold_add_static(&out[n], cnt, 1, car.b, pn, pb, dist, CBT_CAR) < 0) continue;
+                if (manifold_add_static(&out[n], cnt, 1, cb, pn, pb, dist, CBT_CAR) < 0) continue;
                 car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = pn;    // (the contact-added callback: before the algorithm's refresh)
-                if (manifold_refresh_static(&out[n], 1, car.b, po, CBT_CAR) == 0) continue;
+                if (manifold_refresh_static(&out[n], 1, cb, po, CBT_CAR) == 0) continue;
                 out[n].a = (int8_t)(1 + ci); out[n].b = -1; out[n].sid = (int8_t)(1 + i); out[n].special = 0;
                 n++;
             }
@@ -396,18 +400,21 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             // is the radius.  Where the point gets inside the box core (never seen in play) the analytic form answers instead of EPA.
             V3 pb, pn; float dist; bool have = false;
             V3 sl, sh_, hl, hh;
-            sphere_shape_aabb(bp, sl, sh_); hitbox_shape_aabb(car.b.pos, car.b.rot, hl, hh);
-            if (aabb_touch(hl, hh, sl, sh_)) {   // the child shapes' boxes must touch before the pair's algorithm runs at all (btCompoundCollisionAlgorithm.cpp:333-358)
+            // (the hitbox's box reaches at most HITBOX_REACH from its centre along every axis, the ball's r + 0.08: farther apart than both along some axis, the boxes cannot touch)
+            const V3 sep = bp - bc; const float far = HITBOX_REACH + (r + 0.08f);
+            const bool maybe = !(fabsf(sep.x) > far || fabsf(sep.y) > far || fabsf(sep.z) > far);
+            if (maybe) { sphere_shape_aabb(bp, sl, sh_); hitbox_shape_aabb(cb.pos, cb.rot, hl, hh); }
+            if (maybe && aabb_touch(hl, hh, sl, sh_)) {   // the child shapes' boxes must touch before the pair's algorithm runs at all (btCompoundCollisionAlgorithm.cpp:333-358)
                 GjkOut g; bool deep = false;
-                if (gjk_box_sphere(bc, car.b.rot, hitbox_core(), BOX_MARGIN, bp, r, CBT_BALL, g, deep)) {
+                if (gjk_box_sphere(bc, cb.rot, hitbox_core(), BOX_MARGIN, bp, r, CBT_BALL, g, deep)) {
                     if (!(g.dist > CBT_BALL)) { pn = g.n; pb = g.pb; dist = g.dist; have = true; }
-                } else if (deep && sphere_box(bp, r, bc, car.b.rot, h, CBT_BALL, pb, pn, dist)) {
+                } else if (deep && sphere_box(bp, r, bc, cb.rot, h, CBT_BALL, pb, pn, dist)) {
                     pn = -pn; pb = bp + pn * r; have = true;   // normal on the ball, pointing at the car; the point on the ball
                 }
             }
             if (have) {
                 Contact& c = L.c[car_ball_slot(ci)];
-                manifold_point_dynamic(c, car.b, A.ball.b, pn, pb, dist);
+                manifold_point_dynamic(c, cb, A.ball.b, pn, pb, dist);
                 c.a = (int8_t)(1 + ci); c.b = 0; c.sid = 0; c.special = 0;
                 ball_hit[ci] = 1;
             }
@@ -876,21 +883,11 @@ RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, Tick
 #ifdef RLG_PROF_SPLIT_PREPARE
     RLG_PROF(7);
 #endif
+    RLG_SPROF(44);
 
-    {
-        SolverBody& s = B[0];
-        s.v = A.ball.b.vel; s.w = A.ball.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
-        s.inv_m = BALL_INV_MASS; s.inv_i = A.ball.b.inv_inertia_w;
-        s.ext_f = A.ball.b.force * BALL_INV_MASS * dt; s.ext_t = tmul(A.ball.b.inv_inertia_w, A.ball.b.torque) * dt;
-        s.active = ball_active;
-    }
-    for (int i = 0; i < NC; i++) {
-        SolverBody& s = B[1 + i]; const Car& c = A.cars[i];
-        s.v = c.b.vel; s.w = c.b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
-        s.inv_m = CAR_INV_MASS; s.inv_i = c.b.inv_inertia_w;
-        s.ext_f = c.b.force * CAR_INV_MASS * dt; s.ext_t = tmul(c.b.inv_inertia_w, c.b.torque) * dt;
-        s.active = !c.frozen;
-    }
+    // (the solver bodies were filled by solver_body_setup, a lane per body; what the merge decides is whether the ball's island is awake)
+    B[0].active = ball_active;
+    RLG_SPROF(45);
     // row numbering: normal rows in solver order, then the averaged special row, then one friction row per non-special
     // contact, then the special row's friction row
     int nr = 0, n_special = 0; V3 sp_normal = v3(0, 0, 0); float sp_dist = 0.f;
@@ -915,12 +912,29 @@ RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, Tick
     W.n_rows = nr;
 }
 
+// the solver's view of one body (btSequentialImpulseConstraintSolver.cpp:initSolverBody): velocities, inverse mass / inertia, the external
+// impulses of this tick's forces.  Per body (a lane each on the device), between the body's contacts and solver_prepare; `active` of the ball
+// is settled by solver_prepare (a car that touches it wakes its island).
+template <int NC>
+RLG_HD_SMALL void solver_body_setup(const Arena<NC>& A, TickWork<NC>& W, int body) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+    const float dt = TICK_DT;
+    SolverBody& s = W.B[body];
+    const Body& b = body == 0 ? A.ball.b : A.cars[body - 1].b;
+    const float inv_m = body == 0 ? BALL_INV_MASS : CAR_INV_MASS;
+    s.v = b.vel; s.w = b.angvel; s.dv = s.dw = s.push = s.turn = v3(0, 0, 0);
+    s.inv_m = inv_m; s.inv_i = b.inv_inertia_w;
+    s.ext_f = b.force * inv_m * dt; s.ext_t = tmul(b.inv_inertia_w, b.torque) * dt;
+    s.active = body == 0 ? true : !A.cars[body - 1].frozen;
+}
+
 // contacts of one body (see collide_body); `queued` as in solver_prepare
 template <int NC>
 RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     constexpr int MAXC = TickWork<NC>::MAXC;
     bp_history_cell(A, W, body);
+    RLG_SPROF(43);
     if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
     else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
 }
@@ -984,44 +998,53 @@ template <int NC>
 RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
     const float dt = TICK_DT;
-    const SolverBody& s = W.B[body];
+    const SolverBody s = W.B[body];   // (register copies of the solver body and of the rigid body: see car_wheel_ray_finish)
     if (body == 0) {
-        Body& b = A.ball.b;
+        Body b = A.ball.b;
         if (s.active) {
             b.vel = (s.v + s.dv) + s.ext_f; b.angvel = (s.w + s.dw) + s.ext_t;
             if (!is_zero(s.push) || !is_zero(s.turn)) b.pos = b.pos + s.push * dt;  // m_noRot: orientation untouched
             b.pos = b.pos + b.vel * dt;
+            A.ball.b.vel = b.vel; A.ball.b.angvel = b.angvel; A.ball.b.pos = b.pos;
         }
-        b.force = v3(0, 0, 0); b.torque = v3(0, 0, 0);
+        A.ball.b.force = v3(0, 0, 0); A.ball.b.torque = v3(0, 0, 0);
     } else {
         Car& c = A.cars[body - 1];
         if (s.active) {
-            c.b.vel = (s.v + s.dv) + s.ext_f; c.b.angvel = (s.w + s.dw) + s.ext_t;
+            const uint32_t flags = c.flags;
+            Body b = c.b;
+            b.vel = (s.v + s.dv) + s.ext_f; b.angvel = (s.w + s.dw) + s.ext_t;
             // A car demolished by this tick's contact callback: the reference's reported rotation is the copy Car::_PostTickUpdate takes
             // (Car.cpp:135-138), which it skips for a demoed car -- so the state keeps the pre-tick basis while position and velocities
             // come from the body (Car.cpp:10-20).  The body is disabled from the next pre-tick on and rebuilt at respawn.
             // The BODY turns all the same, and stays in the world as it then stands: car_ghost_rot (arena_world.h).
-            const bool rot_stale = (c.flags & CF_IS_DEMOED) != 0;
-            M3 rot = c.b.rot;
+            const bool rot_stale = (flags & CF_IS_DEMOED) != 0;
+            M3 rot = b.rot;
             if (!is_zero(s.push) || !is_zero(s.turn)) {
-                c.b.pos = c.b.pos + s.push * dt;
+                b.pos = b.pos + s.push * dt;
                 rot = integrate_rotation(rot, s.turn * K::SPLIT_TURN_ERP, dt);
             }
-            c.b.pos = c.b.pos + c.b.vel * dt;
-            rot = integrate_rotation(rot, c.b.angvel, dt);
-            if (rot_stale) c.b.inv_inertia_w = rot;
+            b.pos = b.pos + b.vel * dt;
+            RLG_SPROF(46);
+            rot = integrate_rotation(rot, b.angvel, dt);
+            RLG_SPROF(48);
+            if (rot_stale) b.inv_inertia_w = rot;
             else {
-                c.b.rot = rot;
-                body_update_inertia(c.b, car_inv_inertia_local());
+                b.rot = rot;
+                body_update_inertia(b, car_inv_inertia_local());
             }
+            b.force = v3(0, 0, 0); b.torque = v3(0, 0, 0);
+            c.b = b;
+        } else {
+            c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0);
         }
-        c.b.force = v3(0, 0, 0); c.b.torque = v3(0, 0, 0);
     }
 }
 
 template <int NC>
 RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
     for (int body = 0; body <= NC; body++) solver_body_contacts(A, mesh, W, body, queued);
+    for (int body = 0; body <= NC; body++) solver_body_setup(A, W, body);
     solver_prepare(A, mesh, ev, W, queued);
     for (int k = 0; k < W.L.n; k++) solver_rows(W, k);
     solver_iterate(W);

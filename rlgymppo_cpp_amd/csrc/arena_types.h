@@ -6,6 +6,7 @@
 //
 // Everything here restates numbers/semantics of the reference; each block cites where they come from.
 #pragma once
+#include <cstddef>
 #include "rl_math.h"
 
 namespace rlg {
@@ -164,23 +165,30 @@ struct WheelTmp {
     bool in_contact;
 };
 
-struct Car {
+// CarHot = what the car's control phase (arena_car.h:car_pre_tick_finish, every tick, on a register copy of the car) reads or writes; the rest of
+// a Car is never touched there and stays out of that copy -- a whole-struct copy moved those 26 words LDS -> scratch -> LDS every tick, because a
+// slice of a local that is only ever copied is not promoted to registers.
+struct CarHot {
     Body b;
     uint32_t flags;
     V3 flip_rel_torque;
     float jump_time, flip_time, air_time, air_time_since_jump;
-    float boost, time_spent_boosting, supersonic_time, handbrake_val;
+    float boost, time_spent_boosting, handbrake_val;
     float auto_flip_timer, auto_flip_torque_scale;
     V3 world_contact_normal;
+    Controls ctl;
+    float extra_pushback[4];
+    float steer_angle, engine_force, brake;
+    float lat_friction[4], long_friction[4];
+};
+struct Car : CarHot {
+    float supersonic_time;
     int car_contact_other;  // car id (slot+1), 0 none
     float car_contact_cooldown, demo_respawn_timer;
     V3 bh_rel_pos, bh_ball_pos, bh_extra_hit_vel;  // uu
     int64_t bh_tick_hit, bh_tick_extra;
-    Controls last, ctl;
+    Controls last;
     V3 vel_impulse_cache;  // BT
-    float extra_pushback[4];
-    float steer_angle, engine_force, brake;
-    float lat_friction[4], long_friction[4];
     bool frozen;  // transient: body disabled for the current tick (demoed at tick start)
 };
 

@@ -141,6 +141,9 @@
 #ifndef RLG_PROF
 #define RLG_PROF(i) ((void)0)
 #endif
+#ifndef RLG_SPROF   // sub-phase stamps of the -DRLG_FINE_PROF build (tools/fine_prof.py buckets 32..63)
+#define RLG_SPROF(i) ((void)0)
+#endif
 
 namespace rlg {
 

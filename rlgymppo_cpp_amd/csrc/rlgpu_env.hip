@@ -41,7 +41,7 @@ __device__ int g_dbg[64];
 #define RLG_ITEM_DONE(type, n, cyc) do { atomicAdd(&g_dbg[16 + 4 * (type)], 1); if ((n) > 0) atomicAdd(&g_dbg[17 + 4 * (type)], 1); atomicAdd(&g_dbg[18 + 4 * (type)], (int)((cyc) >> 6)); atomicMax(&g_dbg[19 + 4 * (type)], (int)(cyc)); } while (0)
 __shared__ unsigned long long g_prof_last;
 #ifdef RLG_FINE_PROF   // (-DRLG_FINE_PROF: one bucket per phase of arena_tick_wave instead of the coarse ones; tools/fine_prof.py reads the sums from g_dbg)
-__shared__ unsigned long long g_fine[32];
+__shared__ unsigned long long g_fine[64];   // [0, 32): the phases of arena_tick_wave (RLG_FPROF); [32, 64): sub-phase stamps inside the phase functions (RLG_SPROF)
 __device__ unsigned int g_fine_blk[4096 * 32];   // the buckets of every workgroup of the last k_env_ticks launch, cycles / 16
 #define RLG_PROF(i) ((void)0)
 #define RLG_FPROF(i)                                                             \
@@ -49,6 +49,7 @@ __device__ unsigned int g_fine_blk[4096 * 32];   // the buckets of every workgro
         unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
         if (threadIdx.x == 0) { g_fine[i] += _t - g_prof_last; g_prof_last = _t; } \
     } while (0)
+#define RLG_SPROF(i) RLG_FPROF(i)
 #undef RLG_ITEM_DONE
 #define RLG_ITEM_DONE(type, n, cyc) ((void)0)
 #undef RLG_DBG_COUNT
@@ -191,13 +192,34 @@ static_assert(BALL_CAND == CAR_CAND, "one leaf capacity for every body");
 // second 3v3 env of a wavefront).
 template <int NC>
 constexpr bool leaves_in_lds() { return NC == 2 && RLG_MAX_EPW_1V1 <= 4; }
+// The box a body's candidates are collected for, and when a kept list is still good.  Any box that CONTAINS the body's query box of the tick
+// (arena_world.h:body_query_box: the hitbox's box united with the four suspension rays; the ball's box) gives the same results, bit for bit --
+// the exact per-triangle tests of the narrowphase and of the wheel rays filter the list -- so the walk uses the cheapest one there is: the CUBE
+// around the body's position that holds the query box in every orientation (every point of it is pos + R q with |q| <= 1.895 BT: a hitbox
+// corner), grown by CAND_FAT.  No box arithmetic (three matrix-vector products, four wheel transforms: 7 % of an idle tick went into computing
+// the exact box every tick only to compare it with the kept one), and the list stays good for as long as the POSITION has moved less than
+// CAND_FAT along every axis, whatever the car's rotation does.  Measured on one box (bench_main, alternating): exact boxes with the same
+// renewal bound 13.50 ms per collection launch, cubes 13.29 (13.94 before either); CAND_FAT 3.0 instead of 2.0: no difference.
+// Whether a body takes part is decided as before -- `active`: its box touches an occupied grid cell -- with one more bit for the bodies whose
+// box does not but whose FAT box does (`watch`): only those can become active without leaving their fat box, and only they still pay for the
+// occupancy-grid test every tick.
+constexpr float CAND_CUBE_CAR = 1.95f;                                       // BT, > 1.895
+constexpr float CAND_CUBE_BALL = (K::BALL_RADIUS * UU2BT + 0.12f) * 1.001f;   // the ball's query box is pos +- (r + 0.08 + 0.04) (arena_world.h:ball_query_aabb)
+template <int NC>
+__device__ __forceinline__ void cand_box(const Arena<NC>& A, int body, V3& lo, V3& hi) {
+    const float r = body == 0 ? CAND_CUBE_BALL : CAND_CUBE_CAR;
+    const V3 p = body == 0 ? A.ball.b.pos : A.cars[body - 1].b.pos;
+    lo = p - v3(r, r, r); hi = p + v3(r, r, r);
+}
 template <int NC>
 struct CandCache {
     static constexpr int NB = NC + 1;
-    V3 lo[NB], hi[NB];                    // the fat boxes the lists were walked for
+    V3 pos0[NB];                          // the positions the lists were walked for
     uint32_t leaf[leaves_in_lds<NC>() ? NB : 1][leaves_in_lds<NC>() ? CACHE_LEAVES : 1];
     uint8_t n[NB];                        // leaves of body b
-    uint8_t active;                       // bit b: body b had a query box then
+    uint8_t alive;                        // bit b: body b had a query box then (the ball awake, the car not demolished)
+    uint8_t active;                       // bit b: ... and its box touched an occupied grid cell
+    uint8_t watch;                        // bit b: ... it did not, but its fat box did
     uint8_t valid;                        // 0: walk again (cleared when a launch loads the env)
 };
 template <int NC>
@@ -380,21 +402,35 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     const bool asleep = (len2(S.A.ball.b.vel) == 0.f && len2(S.A.ball.b.angvel) == 0.f);
     const bool too_big = mv.n_nodes > 65535;   // frontier entries carry 16-bit node ids: bigger trees use the inline walk
     const bool all_fast = mv.n_nodes <= mv.n_fast;
-    // this tick's query boxes: lane b of the group computes body b's and checks it against the kept fat box
-    bool my_active = false, my_stale = false;
+    // is body b's kept list still good?  lane b of the group looks how far the body has moved since the walk (cand_box)
+    bool my_active = false, my_stale = false, my_alive = false;
     V3 lo = v3(0, 0, 0), hi = v3(0, 0, 0);
     if (grp && li < NB && !too_big) {
-        my_active = body_query_box(S.A, li, asleep, lo, hi) && mesh_maybe_near(mv, lo, hi);
-        const bool was = (C.active >> li) & 1u;
-        if (!C.valid || was != my_active) my_stale = true;
-        else if (my_active) {
-            const V3 cl = C.lo[li], ch = C.hi[li];
-            my_stale = lo.x < cl.x || lo.y < cl.y || lo.z < cl.z || hi.x > ch.x || hi.y > ch.y || hi.z > ch.z;
+        const Body& bd = li == 0 ? S.A.ball.b : S.A.cars[li - 1].b;
+        my_alive = li == 0 ? !asleep : !(S.A.cars[li - 1].flags & CF_IS_DEMOED);
+        const bool was = (C.alive >> li) & 1u;
+        if (!C.valid || was != my_alive) my_stale = true;
+        else if (my_alive) {
+            const V3 p = bd.pos, p0 = C.pos0[li];
+            const float moved = fmaxf(fabsf(p.x - p0.x), fmaxf(fabsf(p.y - p0.y), fabsf(p.z - p0.z)));
+            my_stale = !(moved <= 0.97f * CAND_FAT);   // (a NaN pose renews the list every tick)
+            if (!my_stale && ((C.watch >> li) & 1u)) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
+                cand_box(S.A, li, lo, hi);
+                my_stale = mesh_maybe_near(mv, lo, hi);
+            }
         }
     }
     // one body out of its box and EVERY env of the wavefront walks again: the walk is level-synchronous over the whole wavefront anyway (an env
     // that would not have had to walk costs nothing extra), and boxes that are renewed together tend to run out together
     const bool walk = grp && !too_big && __any(my_stale);
+    RLG_SPROF(37);
+    // a walking tick needs the boxes themselves: does the body's reach the mesh, and if not, does its fat version
+    bool my_watch = false;
+    if (walk && li < NB && my_alive) {
+        cand_box(S.A, li, lo, hi);
+        my_active = mesh_maybe_near(mv, lo, hi);
+        if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(CAND_FAT, CAND_FAT, CAND_FAT), hi + v3(CAND_FAT, CAND_FAT, CAND_FAT));
+    }
     bool overflow = too_big;
     // The walk (fat boxes first; should their lists not fit, once more with the exact boxes, and the result is not kept).
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -403,11 +439,14 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         if (!__any(go)) break;
         if (go) overflow = false;
         if (go && li < NB) {
-            if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); C.lo[li] = Q.box_lo[li]; C.hi[li] = Q.box_hi[li]; }
+            if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); }
+            if (my_alive) C.pos0[li] = li == 0 ? S.A.ball.b.pos : S.A.cars[li - 1].b.pos;
             C.n[li] = 0;
         }
         // level 0: the roots of the active bodies, in body order
         const unsigned long long ma = (__ballot(go && my_active) >> gshift) & gmask;
+        const unsigned long long mal = (__ballot(go && my_alive) >> gshift) & gmask;
+        const unsigned long long mwa = (__ballot(go && my_watch) >> gshift) & gmask;
         if (go && my_active) Q.frontier[0][__popcll(ma & below)] = (uint32_t)li << 16;
         int n = go ? __popcll(ma) : 0, cur = 0;
         int cnt_b[NB];
@@ -490,10 +529,12 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 #pragma unroll
             for (int b = 0; b < NB; b++) C.n[b] = (uint8_t)(cnt_b[b] < CACHE_LEAVES ? cnt_b[b] : CACHE_LEAVES);
             C.active = (uint8_t)ma;
+            C.alive = (uint8_t)mal; C.watch = (uint8_t)mwa;
             C.valid = (!overflow && attempt == 0) ? 1 : 0;
         }
         wave_sync();
     }
+    RLG_SPROF(38);
     // a tick that did not walk takes the kept leaves (a block of LEAF_SLOTS candidate slots per leaf in the body's region: queue_cand)
     if (grp && !walk && !overflow) {
 #pragma unroll
@@ -505,6 +546,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         }
     }
     wave_sync();
+    RLG_SPROF(39);
     if (grp && li == 0) {
         S.W.ball_asleep = asleep;
 #pragma unroll
@@ -646,6 +688,12 @@ __device__ RLG_TICK_INLINE void arena_tick_wave(unsigned char* lane_mem, int n_v
     }
     wave_sync();
     RLG_FPROF(9); phase_sync(2);
+    {   // (a phase of its own: during the contacts an overflowing env may still run penetration-depth queries in the arenas that borrow these bytes)
+        constexpr int NB = NC + 1;
+        const int e_b = tid / NB, b_b = tid % NB;
+        if (e_b < n_valid) { LaneBlock<NC>& Sb = lane_block<NC>(lane_mem, e_b); solver_body_setup(Sb.A, Sb.W, b_b); }
+    }
+    wave_sync();
     if (env_lane) solver_prepare(Se.A, mv, ev, Se.W, true);
     wave_sync();
     RLG_FPROF(10); phase_sync(2);
@@ -729,7 +777,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
 #endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
-    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
     if (env_lane) {
         int32_t acts[NC];
         for (int k = 0; k < P; k++) acts[k] = actions[(size_t)env * P + k];   // agent rows of this env (gym_step_begin maps them to slots)
@@ -825,7 +873,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
-    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
     wave_sync();
     StepStats stats;
     int t = 0;
@@ -958,19 +1006,19 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
 #endif
     epa_arenas_setup<NC>(d, wmem);
     load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
-    if (env_lane) { S.C.valid = 0; S.C.active = 0; }   // candidate lists are per launch
+    if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
 #endif
 #ifdef RLG_FINE_PROF
-    if (threadIdx.x == 0) for (int i = 0; i < 32; i++) g_fine[i] = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < 64; i++) g_fine[i] = 0;
 #endif
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, tick_seed(d.cfg), env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_FINE_PROF
-    if (threadIdx.x == 0) for (int i = 0; i < 32; i++) atomicAdd(&g_dbg[i], (int)(g_fine[i] >> 10));   // summed over workgroups, cycles / 1024
+    if (threadIdx.x == 0) for (int i = 0; i < 64; i++) atomicAdd(&g_dbg[i], (int)(g_fine[i] >> 10));   // summed over workgroups, cycles / 1024
     if (threadIdx.x == 0 && blockIdx.x < 4096) for (int i = 0; i < 32; i++) g_fine_blk[32 * blockIdx.x + i] = (unsigned int)(g_fine[i] >> 4);
 #endif
     if (stamps && threadIdx.x == 0) {
@@ -1060,6 +1108,21 @@ struct rlgpu_env {
     size_t redzone_bytes = 0;
 };
 
+// what-if runs: RLGPU_EXPERIMENT_DYN_LDS=<bytes> of unused dynamic LDS per 1v1 workgroup lowers the workgroups a CU holds (tools/fine_prof.py)
+static size_t experiment_dyn_lds() { static const size_t v = [] { const char* s = getenv("RLGPU_EXPERIMENT_DYN_LDS"); return s ? (size_t)atol(s) : (size_t)0; }(); return v; }
+// -DRLG_ONLY_NC2: experiment builds (tools/build_variant.sh) instantiate the 1v1 kernels only -- a third of the compile time; rlgpu_env_create refuses other team sizes
+#ifdef RLG_ONLY_NC2
+#define RLG_NC_PICK(nc, X2, X4, X6) (X2)
+#define DISPATCH_NC(e, KERNEL, grid, block, ...) hipLaunchKernelGGL((KERNEL<2>), grid, block, experiment_dyn_lds(), (e)->stream, __VA_ARGS__)
+#else
+#define RLG_NC_PICK(nc, X2, X4, X6) ((nc) == 2 ? (X2) : ((nc) == 4 ? (X4) : (X6)))
+#define DISPATCH_NC(e, KERNEL, grid, block, ...)                                                             \
+    do {                                                                                                     \
+        if ((e)->nc == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, experiment_dyn_lds(), (e)->stream, __VA_ARGS__);          \
+        else if ((e)->nc == 4) hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, (e)->stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((KERNEL<6>), grid, block, 0, (e)->stream, __VA_ARGS__);                       \
+    } while (0)
+#endif
 #define HIPCHK(e, call)                                                                          \
     do {                                                                                         \
         hipError_t _s = (call);                                                                  \
@@ -1170,14 +1233,17 @@ int rlgpu_env_check_redzones(rlgpu_env* e) {
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg) {
     if (!out || n_envs <= 0 || team_size < 1 || team_size > 3 || !cfg) return RLGPU_ERR_ARG;
     if (cfg->obs_max_players != 0 && (cfg->obs_max_players < team_size || cfg->obs_max_players > rlg::OBS_MAX_PADDED_PLAYERS)) return RLGPU_ERR_ARG;   // DefaultOBSPadded.cpp:40-44: too many players for the padding
+#ifdef RLG_ONLY_NC2
+    if (team_size != 1) return RLGPU_ERR_ARG;   // (an experiment build: 1v1 kernels only)
+#endif
     rlgpu_env* e = new rlgpu_env();
     *out = e;
     e->device = device; e->n_envs = n_envs; e->team_size = team_size; e->nc = 2 * team_size;
     HIPCHK(e, hipSetDevice(device));
     { const char* rz = getenv("RLGPU_REDZONE"); e->redzone_bytes = rz ? (size_t)atol(rz) : 0; }
-    e->n_words = e->nc == 2 ? count_words<2>() : (e->nc == 4 ? count_words<4>() : count_words<6>());
+    e->n_words = RLG_NC_PICK(e->nc, count_words<2>(), count_words<4>(), count_words<6>());
     {   // the kernels stage arena_num_words<NC>() rows, the visitor defines how many there are: one number, or nothing runs
-        const size_t staged = e->nc == 2 ? arena_num_words<2>() : (e->nc == 4 ? arena_num_words<4>() : arena_num_words<6>());
+        const size_t staged = RLG_NC_PICK(e->nc, arena_num_words<2>(), arena_num_words<4>(), arena_num_words<6>());
 #ifndef RLG_TEST_EXTRA_WORD_ROWS
         if (staged != e->n_words) { e->err = "arena_num_words disagrees with arena_visit (" + std::to_string(staged) + " vs " + std::to_string(e->n_words) + " words per env)"; return RLGPU_ERR_ARG; }
 #else
@@ -1196,7 +1262,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     e->d.pad_tab = e->d_pad_tab;
     memcpy(&e->d.cfg, cfg, sizeof(GymConfig));
     {   // full-size penetration-depth arenas, one per wavefront of a step launch (11.7 KB each; touched only by the rare query the LDS arena cannot hold)
-        const size_t waves = (size_t)(e->nc == 2 ? env_grid<2>(n_envs) : (e->nc == 4 ? env_grid<4>(n_envs) : env_grid<6>(n_envs))) * WPB;
+        const size_t waves = (size_t)(RLG_NC_PICK(e->nc, env_grid<2>(n_envs), env_grid<4>(n_envs), env_grid<6>(n_envs))) * WPB;
         HIPCHK(e, RZ_MALLOC(e, e->d_epa_big, waves * EPA_BIG_BYTES, "EPA arenas"));
         e->d.epa_big = e->d_epa_big;
         HIPCHK(e, RZ_MALLOC(e, e->d.leaf_cache, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t), "candidate leaf cache"));   // CandCache: 0.4 - 0.9 KB per env
@@ -1211,10 +1277,8 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
     }
     e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
     {
-        dim3 grid(e->nc == 2 ? env_grid<2>(n_envs) : (e->nc == 4 ? env_grid<4>(n_envs) : env_grid<6>(n_envs))), block(WAVE);
-        if (e->nc == 2) hipLaunchKernelGGL((k_env_fresh<2>), grid, block, 0, e->stream, e->d);
-        else if (e->nc == 4) hipLaunchKernelGGL((k_env_fresh<4>), grid, block, 0, e->stream, e->d);
-        else hipLaunchKernelGGL((k_env_fresh<6>), grid, block, 0, e->stream, e->d);
+        dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(n_envs), env_grid<4>(n_envs), env_grid<6>(n_envs))), block(WAVE);
+        DISPATCH_NC(e, k_env_fresh, grid, block, e->d);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipDeviceSynchronize());
     }
@@ -1248,8 +1312,8 @@ int rlgpu_env_num_actions(const rlgpu_env* e) { return e->d.cfg.n_actions; }
 int rlgpu_env_state_words(const rlgpu_env* e) { return (int)e->n_words; }
 int rlgpu_state_word_counts(int team_size, int* visited, int* staged) {
     if (team_size < 1 || team_size > 3 || !visited || !staged) return RLGPU_ERR_ARG;
-    *visited = (int)(team_size == 1 ? count_words<2>() : (team_size == 2 ? count_words<4>() : count_words<6>()));
-    *staged = (int)(team_size == 1 ? arena_num_words<2>() : (team_size == 2 ? arena_num_words<4>() : arena_num_words<6>()));
+    *visited = (int)(RLG_NC_PICK(2 * team_size, count_words<2>(), count_words<4>(), count_words<6>()));
+    *staged = (int)(RLG_NC_PICK(2 * team_size, arena_num_words<2>(), arena_num_words<4>(), arena_num_words<6>()));
     return RLGPU_OK;
 }
 
@@ -1306,14 +1370,7 @@ int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* dir) {
     return env_set_mesh_parts(e, v.data(), (int)v.size() / 3, t.data(), (int)t.size() / 3, &parts, true);
 }
 
-// what-if runs: RLGPU_EXPERIMENT_DYN_LDS=<bytes> of unused dynamic LDS per 1v1 workgroup lowers the workgroups a CU holds (tools/fine_prof.py)
-static size_t experiment_dyn_lds() { static const size_t v = [] { const char* s = getenv("RLGPU_EXPERIMENT_DYN_LDS"); return s ? (size_t)atol(s) : (size_t)0; }(); return v; }
-#define DISPATCH_NC(e, KERNEL, grid, block, ...)                                                             \
-    do {                                                                                                     \
-        if ((e)->nc == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, experiment_dyn_lds(), (e)->stream, __VA_ARGS__);          \
-        else if ((e)->nc == 4) hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, (e)->stream, __VA_ARGS__);     \
-        else hipLaunchKernelGGL((KERNEL<6>), grid, block, 0, (e)->stream, __VA_ARGS__);                       \
-    } while (0)
+
 
 int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host, const int32_t* env_ids, int n) {
     if (n <= 0) return RLGPU_OK;
@@ -1349,7 +1406,7 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
 
 int rlgpu_env_reset(rlgpu_env* e, int run_setter, float* obs_dev) {
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE);
     DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev, (const int32_t*)nullptr, 0);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
@@ -1362,7 +1419,7 @@ int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_se
     int32_t* dids = nullptr;
     HIPCHK(e, hipMalloc(&dids, 4 * (size_t)n));
     HIPCHK(e, hipMemcpyAsync(dids, env_ids, 4 * (size_t)n, hipMemcpyHostToDevice, e->stream));
-    dim3 grid(e->nc == 2 ? env_grid<2>(n) : (e->nc == 4 ? env_grid<4>(n) : env_grid<6>(n))), block(WAVE);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(n), env_grid<4>(n), env_grid<6>(n))), block(WAVE);
     DISPATCH_NC(e, k_env_reset, grid, block, e->d, run_setter, obs_dev, (const int32_t*)dids, n);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1431,7 +1488,7 @@ int rlgpu_env_enable_timing(rlgpu_env* e, int on) { e->timing_on = on != 0; if (
 int rlgpu_env_step(rlgpu_env* e, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     if (!actions || !next_obs || !reward || !done) { e->err = "rlgpu_env_step: null device pointer"; return RLGPU_ERR_ARG; }
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if (e->timing_on) { int rc_ev = env_next_events(e, &evp); if (rc_ev) return rc_ev; HIPCHK(e, hipEventRecord(evp->first, e->stream)); }
     DISPATCH_NC(e, k_env_step, grid, block, e->d, actions, next_obs, reward, done);
@@ -1454,7 +1511,7 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls, float* next_obs
     }
     EnvDev d = e->d;
     d.action_table = controls; d.cfg.n_actions = n_agents;
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     DISPATCH_NC(e, k_env_step, grid, block, d, (const int32_t*)e->d_iota, next_obs, reward, done);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
@@ -1467,8 +1524,8 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
     if (e->d.cfg.one_team) { e->err = std::string(who) + ": one-team envs are collected step by step (rlgpu_policy_act + rlgpu_env_step)"; return RLGPU_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     CollectArgs c{};
-    const int epw = (e->nc == 2 ? lanes_per_block<2>() : (e->nc == 4 ? lanes_per_block<4>() : lanes_per_block<6>())) / WPB;
-    const size_t tw = e->nc == 2 ? sizeof(TickWork<2>) : (e->nc == 4 ? sizeof(TickWork<4>) : sizeof(TickWork<6>));
+    const int epw = (RLG_NC_PICK(e->nc, lanes_per_block<2>(), lanes_per_block<4>(), lanes_per_block<6>())) / WPB;
+    const size_t tw = RLG_NC_PICK(e->nc, sizeof(TickWork<2>), sizeof(TickWork<4>), sizeof(TickWork<6>));
     const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
     const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one part of an activation buffer may take
     int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
@@ -1477,7 +1534,7 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
     if (rc) { e->err = std::string(who) + ": the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
     if (c.net.D != rlgpu_env_obs_size(e)) { e->err = std::string(who) + ": the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     if (free_target > 0) {
         // The agents must all be RUNNING for "stop when the total is there" to mean what it means in the reference (every agent thread runs
         // from the start): all workgroups of the launch resident at once.  A batch with more wavefronts than the device holds is load-balanced
@@ -1485,9 +1542,9 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
         if (e->free_capacity < 0) {
             int per_cu = 0; hipDeviceProp_t prop{};
             HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
-            hipError_t oc = e->nc == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<2>, WAVE * WPB, 0)
-                          : e->nc == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<4>, WAVE * WPB, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<6>, WAVE * WPB, 0);
+            hipError_t oc = RLG_NC_PICK(e->nc, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<2>, WAVE * WPB, 0),
+                                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<4>, WAVE * WPB, 0),
+                                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect<6>, WAVE * WPB, 0));
             HIPCHK(e, oc);
             e->free_capacity = per_cu * prop.multiProcessorCount;
         }
@@ -1584,7 +1641,7 @@ int rlgpu_env_debug_step_prof(rlgpu_env* e, unsigned long long* out, int n_block
 // diagnostics (not part of rlgpu.h): per-workgroup {shader cycles, 100 MHz ticks} of `ticks` physics ticks; out has 10 * n_blocks entries (cycles, realtime, 8 phase accumulators of the PROFILE build)
 int rlgpu_env_debug_tick_cycles(rlgpu_env* e, int ticks, unsigned long long* out, int cap_pairs, int* n_blocks) {
     HIPCHK(e, hipSetDevice(e->device));
-    int nb = e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs));
+    int nb = RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs));
     *n_blocks = nb;
     if (nb > cap_pairs) return RLGPU_ERR_ARG;
     unsigned long long* dbuf = nullptr;
@@ -1614,7 +1671,7 @@ int rlgpu_env_set_controls(rlgpu_env* e, const float* controls_host) {
 }
 int rlgpu_env_physics_ticks(rlgpu_env* e, int ticks) {
     HIPCHK(e, hipSetDevice(e->device));
-    dim3 grid(e->nc == 2 ? env_grid<2>(e->n_envs) : (e->nc == 4 ? env_grid<4>(e->n_envs) : env_grid<6>(e->n_envs))), block(WAVE * WPB);
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     DISPATCH_NC(e, k_env_ticks, grid, block, e->d, ticks, (unsigned long long*)nullptr);
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;

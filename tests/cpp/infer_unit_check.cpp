@@ -51,9 +51,10 @@ static int obs_parity(int teamSize, int nEnvs, int steps, std::vector<GameState>
         CHECK(rlgpu_env_download_states(env, states.data(), nullptr, nEnvs) == RLGPU_OK);
         CHECK(rlgpu_env_download_snapshots(env, snaps.data(), 0, nEnvs) == RLGPU_OK);
         for (int e = 0; e < nEnvs; e++) {
-            // a new episode's first GameState is the one its state setter built -- before Match::ResetState reset the boost pads (Match.cpp:55-69):
-            // it shows the pads as the previous episode left them (tick skip 1 here: the step's snapshot IS the arena at the episode's end)
-            if (hostDone[e * P]) for (int p = 0; p < RLGPU_NUM_PADS; p++) states[e].pads[p].is_active = snaps[e].pads[p].is_active;
+            // a new episode's first GameState is the one its state setter built.  This env's setter is the built-in RandomState, which resets the
+            // pads before it builds it (RandomState.cpp:11 -> Arena::ResetToRandomKickoff, Arena.cpp:209-210): the downloaded state (all pads
+            // active after the reset) is what the first observation shows.  (Only a user setter that leaves the pads alone shows the previous
+            // episode's: Match.cpp:55-69, tests/golden/gameinst_golden.npz.)
             GameState gs(states[e], 1);
             CHECK((int)gs.players.size() == P);
             IList idx(hostActs.begin() + e * P, hostActs.begin() + (e + 1) * P);

@@ -29,13 +29,17 @@ else:
 fn = env.lib.rlgpu_env_debug_tick_cycles
 fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]; fn.restype = C.c_int
 env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
+SUB = {32: "car2: copy-in + wheel flags", 33: "car2: update_wheels", 34: "car2: air/jump/flip/roll", 35: "car2: suspension impulses", 36: "car2: friction impulses + boost",
+       37: "cand: query boxes + stale vote", 38: "cand: walk", 39: "cand: kept leaves copy", 40: "wheel1c: load + mesh key + ball/cars", 41: "wheel1c: suspension",
+       42: "wheel1c: friction impulse", 43: "body: bp_history_cell", 44: "prepare: collide_merge", 45: "prepare: solver bodies", 46: "finish: velocities + position",
+       47: "wheel1a: basis", 48: "finish: integrate_rotation"}
 NAMES = ["car_tick_begin", "build_candidates", "wheel_ray_begin", "ray pairs", "wheel_ray_finish", "car_pre_tick_finish", "pads + world_begin",
          "candidate tests", "items", "body contacts", "solver_prepare", "solver_rows", "solver_iterate", "solver_finish", "car post + pad check",
          "pads_lock", "pad post", "tick_finish"]
 
 
 def ints():
-    buf = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints(env.h, buf); return np.array(buf[:32], dtype=np.int64)
+    buf = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints(env.h, buf); return np.array(buf[:64], dtype=np.int64)
 
 
 def run(label):
@@ -46,6 +50,8 @@ def run(label):
     for _ in range(reps):
         assert fn(env.h, ticks, buf.ctypes.data, 65536, C.byref(nb)) == 0
         tot = np.concatenate([tot, buf[: 10 * nb.value].reshape(-1, 10)[:, 0].astype(np.float64)])
+        clk = buf[: 10 * nb.value].reshape(-1, 10)[:, 0].astype(np.float64) / np.maximum(1.0, buf[: 10 * nb.value].reshape(-1, 10)[:, 1].astype(np.float64)) * 0.1   # shader cycles per 100 MHz tick -> GHz
+        print(f"   in-kernel clock (s_memtime / s_memrealtime): median {np.median(clk):.3f} GHz")
     d = (ints() - a) * 1024.0 / (reps * ticks * nb.value)
     print(f"{label}: cycles/tick mean {tot.mean()/ticks:.0f} max {tot.max()/ticks:.0f}; buckets sum {d.sum():.0f}")
     blk = np.zeros(32 * nb.value, dtype=np.uint32)
@@ -57,6 +63,8 @@ def run(label):
     print(f"   {'phase':24s} {'mean':>8s}  {'share':>7s}  {'slowest 1 %':>12s}")
     for nm, v, w in zip(NAMES, d, slow):
         print(f"   {nm:24s} {v:8.0f}  {100*v/d.sum():5.1f} %  {w:12.0f}")
+    for i in range(32, 64):      # sub-phase stamps (RLG_SPROF(i) inside the phase functions): the cycles up to stamp i since the stamp before it
+        if d[i] > 0: print(f"   sub {i:2d} {SUB.get(i, ''):32s} {d[i]:8.0f}  {100*d[i]/d.sum():5.1f} %")
     print(f"   {'sum':24s} {d.sum():8.0f}           {slow.sum():12.0f}")
 
 
