@@ -143,13 +143,26 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One 32-column block of a layer with NK K steps, guard-free (see wave_infer): weight fragments, and the MFMA chain with the A operand
-// read four steps ahead into four named registers.
+// One 32-column block of a layer with NK K steps, guard-free (see wave_infer): the MFMA chain over the block's weight fragments.  The A operands
+// (the wavefront's activation rows) are the same for every column block of a layer: the caller reads them from LDS once per layer.
+template <int NK>
+__device__ __forceinline__ void mma_block_regs(const bf16x8 (&a)[16], const bf16x8 (&b)[16], f32x16& acc) {
+#pragma unroll
+    for (int j = 0; j < NK; j++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], acc, 0, 0, 0);
+}
+// weight fragments of one block, as k_mlp_infer (rlgpu_learn.hip) asks for them
 template <int NK>
 __device__ __forceinline__ void fetch_block(bf16x8 (&b)[16], const short* w) {
 #pragma unroll
     for (int j = 0; j < NK; j++) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
 }
+__device__ __forceinline__ void fetch_block_any(bf16x8 (&b)[16], const short* w, int nk) {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
+}
+// The same chain with the A operand read from LDS four steps ahead into four named registers (k_mlp_infer, rlgpu_learn.hip: a wavefront's rows change
+// with every tile there).
 template <int NK>
 __device__ __forceinline__ void mma_block(const short* arow, const bf16x8 (&b)[16], f32x16& acc) {
 #define RLINFER_A(J) (*reinterpret_cast<const bf16x8*>(arow + ((J) < NK ? (J) : 0) * 16))
@@ -168,12 +181,6 @@ __device__ __forceinline__ void mma_block(const short* arow, const bf16x8 (&b)[1
 #undef RLINFER_STEP
 #undef RLINFER_A
 }
-// any other depth (<= 16 steps): guarded, slower
-__device__ __forceinline__ void fetch_block_any(bf16x8 (&b)[16], const short* w, int nk) {
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (j < nk) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
-}
 __device__ __forceinline__ void mma_block_any(const short* arow, const bf16x8 (&b)[16], f32x16& acc, int nk) {
 #pragma unroll
     for (int j = 0; j < 16; j++)
@@ -181,6 +188,12 @@ __device__ __forceinline__ void mma_block_any(const short* arow, const bf16x8 (&
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + j * 16);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc, 0, 0, 0);
         }
+}
+// any other depth (<= 16 steps): guarded, slower
+__device__ __forceinline__ void mma_block_regs_any(const bf16x8 (&a)[16], const bf16x8 (&b)[16], f32x16& acc, int nk) {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < nk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], acc, 0, 0, 0);
 }
 // the K depths that occur: 16 (256-wide hidden layers), and the padded observation widths 96 / 128 / 192 / 224 (89, 127, 165, 203 floats)
 #define RLINFER_DISPATCH_NK(nk, CALL, FALLBACK) \
@@ -197,68 +210,135 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
     constexpr int CHUNK = 16;
     short* in = buf0; short* out = buf1;
     const int ld = net.ld;
-    for (int r = 0; r < R; r++) {
-        const int rr = r < n_rows ? r : n_rows - 1;
-        for (int c = lane; c < net.K[0]; c += 64) in[r * ld + c] = to_bf16(c < net.D ? obs[(size_t)rr * net.D + c] : 0.f);
-    }
-    wave_fence();
-    auto n_blocks = [&](int i) { return (i == net.n_layers - 1) ? (net.N[i] + 31) / 32 : net.Npad[i] / 32; };
-    // Weight fragments of one 32-column block (K <= 256: at most CHUNK steps).  The compiler tracks outstanding loads through straight-line
-    // code only -- behind per-step `if (step < nk)` guards it waited for EVERY load (s_waitcnt vmcnt(0)) in front of every MFMA, which
-    // turned the prefetch of the next block into a stall of the current one.  So: one guard-free path for full-depth blocks (K = 256,
-    // the hidden layers and the head, 19 of the 27 blocks of the 256x3 policy), a guarded one for the rest.
-    auto fetch = [&](bf16x8 (&b)[CHUNK], int i, int cb) {
-        const int nk = net.K[i] / 16;
-        const short* w = net.W[i] + ((size_t)cb * nk * 64 + lane) * 8;
-#define RLINFER_FETCH(NK) fetch_block<NK>(b, w)
-        RLINFER_DISPATCH_NK(nk, RLINFER_FETCH, fetch_block_any(b, w, nk))
-#undef RLINFER_FETCH
+    // A layer's parameters are read when the stream ENTERS the layer, not per column block: `net` sits in the kernel-argument segment, and a field
+    // behind a run-time layer index is a scalar load plus a full s_waitcnt wherever it is used -- half a dozen per block, ~1 K cycles of a block
+    // that computes for ~0.5 K (tools/probes/infer_probe.hip).  Two sets: the layer whose chain runs (`cur`) and the layer whose weights are
+    // being requested (`fet`, up to RLINFER_BUFS - 1 blocks ahead).
+    struct LayerP { const short* W; const float* bias; int nk, N, nblk; };
+    const int n_layers = net.n_layers;
+    auto layer_load = [&](int i) { LayerP q; q.W = net.W[i]; q.bias = net.bias[i]; q.nk = net.K[i] / 16; q.N = net.N[i]; q.nblk = (i == n_layers - 1) ? (net.N[i] + 31) / 32 : net.Npad[i] / 32; return q; };
+    LayerP cur = layer_load(0), fet = cur;
+    // The weights of a 32-column block are 16 (K = 256) or fewer 1 KB fragments straight from L2, and nothing about them depends on the
+    // activations: the NEXT block's are requested before the current block's MFMA chain starts.  For that to overlap anything the wait in
+    // front of the chain must be "all but the youngest N loads" (s_waitcnt vmcnt(N)), and the compiler only emits that when N is the same
+    // number on every path into the chain -- with a block-dependent number of loads (or a register copy of the prefetched fragments at the top
+    // of a loop) it fell back to vmcnt(0), i.e. every block first waited for the block AFTER it (3 K cycles per block for a 512-cycle chain:
+    // 80 K cycles per inference; profiles/r05*_collect*.txt).  So: every block issues exactly 16 fragment loads + 1 bias load for its successor
+    // (steps beyond the successor's depth re-read its last fragment: same cache line, never used; after the last block the block itself again),
+    // into the buffer the chain is NOT reading -- two buffers with fixed roles per half of a loop unrolled by two, no copies.
+    int fi = 0, fcb = 0;          // the block whose weights are requested next (RLINFER_BUFS - 1 blocks ahead of the chain)
+    auto load_next = [&](bf16x8 (&b)[CHUNK], float& bias) {
+        const int nk = fet.nk, cb = fcb;
+        const short* w = fet.W + ((size_t)cb * nk * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < CHUNK; j++) {
+#ifdef PROBE_NO_LOAD
+            b[j] = bf16x8{(short)j, 1, 2, 3, 4, 5, 6, (short)cb};
+#else
+            b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(j < nk ? j : nk - 1) * 512);
+#endif
+        }
+        const int col = cb * 32 + (lane & 31), nn = fet.N;
+        const float bv = fet.bias[col < nn ? col : nn - 1];    // (always issued: a load under a branch would make the count path-dependent)
+        bias = col < nn ? bv : 0.f;
+        // the block after it; the last block's successor is the last block itself (its loads keep the count, nothing uses them)
+        if (fcb + 1 < fet.nblk) fcb++;
+        else if (fi + 1 < n_layers) { fi++; fcb = 0; fet = layer_load(fi); }
     };
-    // the bias of a block is asked for together with its weights
-    auto fetch_bias = [&](int i, int cb) { const int col = cb * 32 + (lane & 31); return (col < net.N[i]) ? net.bias[i][col] : 0.f; };
-    // (Tried and dropped: two blocks of look-ahead in three fixed-role buffers -- no copies, no spills -- 79 K -> 97 K cycles per step:
-    // the stream is not waiting on look-ahead depth.)
-    bf16x8 bnext[CHUNK];
-    fetch(bnext, 0, 0);
-    float bias_next = fetch_bias(0, 0);
-    for (int i = 0; i < net.n_layers; i++) {
-        const bool last = (i == net.n_layers - 1);
-        const int N = net.N[i], nk = net.K[i] / 16, nblk = n_blocks(i);
+    int li = 0, lcb = 0;          // the block whose MFMA chain runs next
+    bf16x8 areg[CHUNK];           // the current layer's A operands: this lane's 16-byte slice of its tile row, one per K step
+    auto run_block = [&](const bf16x8 (&b)[CHUNK], float bias, bf16x8 (&bn)[CHUNK], float& bias_n) {
+        const int i = li, cb = lcb;
+        const bool last = (i == n_layers - 1);
+        const int N = cur.N, nk = cur.nk, nblk = cur.nblk;
+        load_next(bn, bias_n);
         float* const logits = reinterpret_cast<float*>(out);
-        // tile rows >= R do not exist: their lanes re-read row 0 (rows of an MFMA are independent and only rows < R are stored), which
-        // keeps the operand loads free of exec masking
-        const short* arow = in + ((lane & 31) < R ? (lane & 31) : 0) * ld + 8 * (lane >> 5);
-        for (int cb = 0; cb < nblk; cb++) {
-            bf16x8 b[CHUNK];
+        if (cb == 0) {
+            // tile rows >= R do not exist: their lanes re-read row 0 (rows of an MFMA are independent and only rows < R are stored), which
+            // keeps the operand loads free of exec masking
+            const short* arow = in + ((lane & 31) < R ? (lane & 31) : 0) * ld + 8 * (lane >> 5);
 #pragma unroll
-            for (int j = 0; j < CHUNK; j++) b[j] = bnext[j];
-            const float bias = bias_next;
-            // the next block's (or the next layer's first block's) weights do not depend on the activations: ask for them now; after
-            // the last block of the last layer the current block is simply asked for again
-            int ni = i, ncb = cb + 1;
-            if (ncb >= nblk) { ni = i + 1; ncb = 0; }
-            if (ni >= net.n_layers) { ni = i; ncb = cb; }
-            fetch(bnext, ni, ncb);
-            bias_next = fetch_bias(ni, ncb);
-            f32x16 acc;
+            for (int j = 0; j < CHUNK; j++) areg[j] = *reinterpret_cast<const bf16x8*>(arow + (j < nk ? j : 0) * 16);
+        }
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#define RLINFER_MMA(NK) mma_block<NK>(arow, b, acc)
-            RLINFER_DISPATCH_NK(nk, RLINFER_MMA, mma_block_any(arow, b, acc, nk))
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#ifdef PROBE_NO_MMA
+        for (int j = 0; j < 16; j++) acc[j] = (float)b[j][0] + (float)areg[j][0];
+#else
+#define RLINFER_MMA(NK) mma_block_regs<NK>(areg, b, acc)
+        RLINFER_DISPATCH_NK(nk, RLINFER_MMA, mma_block_regs_any(areg, b, acc, nk))
 #undef RLINFER_MMA
-            // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3, rows 8..15 registers 4..7
-            const int col = cb * 32 + (lane & 31);
+#endif
+        // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3, rows 8..15 registers 4..7
+        const int col = cb * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= R) continue;
-                const float v = acc[r] + bias;
-                if (last) logits[row * LOGIT_LD + col] = v;
-                else out[row * ld + col] = (col < N) ? to_bf16(fmaxf(v, 0.f)) : (short)0;
+        for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= R) continue;
+            const float v = acc[r] + bias;
+            if (last) logits[row * LOGIT_LD + col] = v;
+            else out[row * ld + col] = (col < N) ? to_bf16(fmaxf(v, 0.f)) : (short)0;
+        }
+        const bool layer_done = cb + 1 >= nblk;
+        if (layer_done) { wave_fence(); short* t = in; in = out; out = t; }   // the layer is complete: its outputs are the next layer's inputs
+#ifdef RLG_TICK_PROFILE
+        if (layer_done && prof_split && i < 6) prof_split[2 + i] = __builtin_amdgcn_s_memtime();
+#endif
+        if (layer_done) { li = i + 1; lcb = 0; if (li < n_layers) cur = layer_load(li); } else lcb = cb + 1;
+    };
+    {
+#ifndef RLINFER_BUFS
+#define RLINFER_BUFS 2   /* weight buffers: the chain reads one while RLINFER_BUFS - 1 blocks are on their way (measured with tools/probes/infer_probe.hip: 2 and 3 run alike -- the loads are 5 K of an inference's cycles) */
+#endif
+        bf16x8 B0[CHUNK], B1[CHUNK]; float bias0, bias1 = 0.f;
+        load_next(B0, bias0);
+#if RLINFER_BUFS >= 3
+        bf16x8 B2[CHUNK]; float bias2 = 0.f;
+        load_next(B1, bias1);
+#endif
+#if RLINFER_BUFS >= 4
+        bf16x8 B3[CHUNK]; float bias3 = 0.f;
+        load_next(B2, bias2);
+#endif
+        // (the first blocks' weights are on their way while the observations are converted: they do not depend on them)
+        {   // every value of the R rows is asked for before the first one is used: a load inside `if (c < D)` inside a loop waits for itself (16 serial L2
+            // round trips for 8 rows of 89 floats: 11 K cycles).  Lanes past the row's end read its last element and store a zero.
+            const int D = net.D, K0 = net.K[0];
+            constexpr int CH = 4;                 // 64-column chunks per row held in registers at once (K0 <= 256)
+            for (int c0 = 0; c0 < K0; c0 += 64 * CH) {
+                float v[R][CH];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int rr = r < n_rows ? r : n_rows - 1;
+#pragma unroll
+                    for (int q = 0; q < CH; q++) { const int c = c0 + 64 * q + lane; v[r][q] = obs[(size_t)rr * D + (c < D ? c : D - 1)]; }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int q = 0; q < CH; q++) { const int c = c0 + 64 * q + lane; if (c < K0) in[r * ld + c] = to_bf16(c < D ? v[r][q] : 0.f); }
             }
         }
         wave_fence();
-        short* t = in; in = out; out = t;
+#ifdef RLG_TICK_PROFILE
+        if (prof_split) prof_split[1] = __builtin_amdgcn_s_memtime();   // profiler build: observations staged
+#endif
+        while (true) {
+#if RLINFER_BUFS == 2
+            run_block(B0, bias0, B1, bias1); if (li >= n_layers) break;
+            run_block(B1, bias1, B0, bias0); if (li >= n_layers) break;
+#elif RLINFER_BUFS == 3
+            run_block(B0, bias0, B2, bias2); if (li >= n_layers) break;
+            run_block(B1, bias1, B0, bias0); if (li >= n_layers) break;
+            run_block(B2, bias2, B1, bias1); if (li >= n_layers) break;
+#else
+            run_block(B0, bias0, B3, bias3); if (li >= n_layers) break;
+            run_block(B1, bias1, B0, bias0); if (li >= n_layers) break;
+            run_block(B2, bias2, B1, bias1); if (li >= n_layers) break;
+            run_block(B3, bias3, B2, bias2); if (li >= n_layers) break;
+#endif
+        }
     }
 #ifdef RLG_TICK_PROFILE
     if (prof_split) *prof_split = __builtin_amdgcn_s_memtime();   // profiler build: the MLP ends here, the head begins
@@ -268,7 +348,11 @@ __device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& 
 #pragma unroll
     for (int r = 0; r < R; r++) { const int rr = r < n_rows ? r : n_rows - 1; zs[r] = logits + rr * LOGIT_LD; rows[r] = row0 + rr; }
     const float* const (&zc)[R] = reinterpret_cast<const float* const (&)[R]>(zs);
+#ifdef PROBE_NO_HEAD
+    for (int r = 0; r < R; r++) picked[r] = (int)zc[r][0];
+#else
     policy_head_batched<R>(zc, rows, lane, head, picked);
+#endif
 }
 // ---- the same forward pass in fp32: the exact-parity mode of the fused collection ------------------------------------------------------
 // rlgpu_policy_act with use_bf16 = 0 runs every layer through k_gemm<false> (rlgpu_learn.hip): v_mfma_f32_32x32x2_f32 over k = 0, 2, 4, ...

@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #ifdef RLG_TICK_PROFILE
     const unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_step_prof[16 * blockIdx.x + 3] = 0;
-    unsigned long long prof_infer = 0, prof_mlp = 0, prof_ticks = 0, prof_gym = 0;
+    unsigned long long prof_infer = 0, prof_mlp = 0, prof_ticks = 0, prof_gym = 0, prof_stage = 0, prof_layer[4] = {0, 0, 0, 0};
 #define RLG_CPROF_T0() const unsigned long long prof_c0_ = __builtin_amdgcn_s_memtime()
 #define RLG_CPROF_ADD(acc) acc += __builtin_amdgcn_s_memtime() - prof_c0_
 #else
@@ -891,9 +891,11 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
         int picked[R];
 #ifdef RLG_TICK_PROFILE
-        unsigned long long prof_mid = 0;
-        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked, &prof_mid);
-        prof_mlp += prof_mid - prof_a;
+        unsigned long long prof_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked, prof_st);
+        prof_mlp += prof_st[0] - prof_a;
+        prof_stage += prof_st[1] - prof_a;
+        for (int q = 0; q < 4; q++) prof_layer[q] += prof_st[2 + q] - prof_st[1 + q];
 #else
         if (c.net.fp32) {
             // exact-parity mode: fp32 activations; a buffer = NP parts of ceil(R / NP) rows, lent by the TickWork areas (dead between ticks):
@@ -951,7 +953,8 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #ifdef RLG_TICK_PROFILE
     // profiler build: this workgroup's total and inference cycles (read back with rlgpu_env_debug_step_prof)
     if (threadIdx.x == 0 && blockIdx.x < 4096) { g_step_prof[16 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_step_prof[16 * blockIdx.x + 1] = prof_infer; g_step_prof[16 * blockIdx.x + 2] = prof_mlp;
-        g_step_prof[16 * blockIdx.x + 4] = prof_ticks; g_step_prof[16 * blockIdx.x + 5] = prof_gym; g_step_prof[16 * blockIdx.x + 6] = (unsigned long long)t; }
+        g_step_prof[16 * blockIdx.x + 4] = prof_ticks; g_step_prof[16 * blockIdx.x + 5] = prof_gym; g_step_prof[16 * blockIdx.x + 6] = (unsigned long long)t;
+        g_step_prof[16 * blockIdx.x + 7] = prof_stage; for (int q = 0; q < 4; q++) g_step_prof[16 * blockIdx.x + 8 + q] = prof_layer[q]; }
 #endif
 }
 

@@ -46,6 +46,8 @@ for it in range(12):
         tk = buf.reshape(-1, 16)[:, 4].astype(np.float64); gy = buf.reshape(-1, 16)[:, 5].astype(np.float64)
         print("launch %d: per gym step (mean workgroup): total %.0fK cycles = ticks %.0fK (%.1fK per tick) + inference %.0fK + gym bookkeeping (snapshot, events, rewards, done, obs rows, reset) %.0fK + rest %.0fK"
               % (it, tot.mean() / T / 1e3, tk.mean() / T / 1e3, tk.mean() / T / 8e3, inf.mean() / T / 1e3, gy.mean() / T / 1e3, (tot - tk - inf - gy).mean() / T / 1e3))
+        b = buf.reshape(-1, 16).astype(np.float64)
+        print("   inference per step: fence + observation staging %.1fK, layers %s K cycles" % (b[:, 7].mean() / T / 1e3, [round(b[:, 8 + q].mean() / T / 1e3, 1) for q in range(4)]))
         q = np.percentile(tot, [1, 50, 90, 99])
         print("launch %d: workgroup cycles min %.2fM p1 %.2fM median %.2fM mean %.2fM p90 %.2fM p99 %.2fM max %.2fM (%.1f ms); inference share of the mean %.1f%% (per step: MLP %.0fK cycles, head %.0fK); mean/max %.2f"
               % (it, tot.min() / 1e6, q[0] / 1e6, q[1] / 1e6, tot.mean() / 1e6, q[2] / 1e6, q[3] / 1e6, tot.max() / 1e6, tot.max() / 2.38e6, 100 * inf.mean() / tot.mean(), mlp.mean() / T / 1e3, (inf.mean() - mlp.mean()) / T / 1e3, tot.mean() / tot.max()))
