@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--mesh", choices=["procedural", "tessellated", "both"], default="both",
                     help="procedural: the 180-triangle arena (the headline); tessellated: the same arena at ~9 k triangles in 16 .cmf files (what the game's own soccar set looks "
                          "like to the stepper), given to the HIP path and to the reference baseline through their directory loaders; both: headline + a `mesh_tessellated` leg")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[3] (2v2, 8192 envs, padded obs + zero-sum) and configs[4] "
+                    "(3v3, 16384 envs, collect-during-learn + fp16 operands) that follow the headline (`configs` in the line; 1 GPU only)")
+    ap.add_argument("--allow-test-transport", action="store_true", help="tests only: print a line for N > 1 although the gradients went over the host-staged "
+                    "shared-memory transport (RLGPU_COMM_TRANSPORT=shm, ranks sharing one GPU) instead of RCCL; such a line carries \"transport\": \"shm\"")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)   # internal: print the CPU baseline for the mesh directory given, as JSON
     args = ap.parse_args()
 
@@ -188,6 +192,10 @@ def main():
     if rank != 0:
         return
     m = json.loads(proc.stdout.decode().strip().splitlines()[-1])
+    # a multi-GPU line is a scaling result only when the gradients went over RCCL: the shared-memory test transport (ranks on ONE device) is refused
+    transport = m.get("transport", "none")
+    if m["n_gpus"] > 1 and transport != "rccl" and not args.allow_test_transport:
+        raise SystemExit(f"bench.py: {m['n_gpus']} ranks exchanged gradients over the '{transport}' transport, not RCCL: not a benchmark line (tests pass --allow-test-transport)")
 
     n_p = 2 * args.team_size
     A = m["algorithmic_bytes_per_gym_step_per_env"]
@@ -238,6 +246,8 @@ def main():
         # multi-GPU audit trail (bench_main): RCCL ranks that took part (0 = no communicator), each rank's own ms per iteration, one gradient all-reduce
         "rccl_ranks": m.get("rccl_ranks", 0), "rank_ms_per_step": m.get("rank_ms_per_step", []),
         "allreduce_ms_per_optimizer_step": m.get("allreduce_ms_per_optimizer_step", 0.0), "allreduce_calls": m.get("allreduce_calls", 0),
+        # what carried the gradient exchange ("rccl"; "shm" = test transport; "none" = one rank) and every RLGPU_* switch the measured process saw
+        "transport": transport, "env_overrides": m.get("env_overrides", []),
     }
     if "trained_regime" in m:
         out["trained_regime"] = dict(m["trained_regime"], note="same learner config (1 epoch) continued; at this point play is still close to random. "
@@ -285,6 +295,23 @@ def main():
             out["mesh_tessellated"] = leg
         else:
             out["mesh_tessellated"] = {"error": f"bench_main exit code {p2.returncode}"}
+    if world == 1 and not args.no_config_legs and args.team_size == 1 and not args.padded_zero_sum:
+        # BASELINE configs[3] and configs[4] AS WORDED, short legs outside the timed region: every number here is one bench_main run
+        legs = {"c3": (["--team-size", "2", "--envs", "8192", "--padded-zero-sum", "--steps", "16", "--warmup", "4"],
+                       "configs[3]: 2v2, 8192 envs/GPU, DefaultOBSPadded(2) shuffled + ZeroSumReward around the example stack, bf16 operands"),
+                "c4": (["--team-size", "3", "--envs", "16384", "--padded-zero-sum", "--overlap", "--fp16", "--steps", "12", "--warmup", "3"],
+                       "configs[4]: 3v3, 16384 envs/GPU, collect-during-learn overlap + fp16 operands with the dynamic loss scale, padded obs + zero-sum")}
+        out["configs"] = {}
+        for key, (extra, what) in legs.items():
+            pc = subprocess.run([exe, "--horizon", str(args.horizon), "--epochs", str(args.epochs)] + extra, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+            if pc.returncode != 0:
+                out["configs"][key] = {"workload": what, "error": f"bench_main exit code {pc.returncode}"}
+                continue
+            mc = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+            out["configs"][key] = {"workload": what, "value": mc["value"], "unit": "agent-steps/s", "ms_per_step": mc["ms_per_step"], "ppo_iter_ms": mc["ppo_iter_ms"], "steps": mc["steps"],
+                                   "envs_per_gpu": mc["envs_per_gpu"], "team_size": mc["team_size"], "batch": mc["batch"], "operands": mc.get("operands"),
+                                   "collection": mc.get("collection"), "collection_during_learn": mc.get("collection_during_learn"), "fused_collect": mc.get("fused_collect"),
+                                   "env_kernel_avg_ms": mc["env_kernel_ms_total"] / max(1, mc["env_launches"])}
     print(json.dumps(out))
 
 

@@ -644,7 +644,9 @@ __global__ void __launch_bounds__(512) k_dw_grouped(DwArgs g) {
         store(r0, t + 3);
         __syncthreads();
     }
+#ifdef FZ_DEBUG   /* experiments only, like FZ_DBG above: a release library has no way to leave the flush out */
     if (g.debug & 1) return;
+#endif
     // C layout: m = (q & 3) + 8 (q >> 2) + 4 (lane >> 5) down the block's dW rows, lane & 31 along its columns
 #pragma unroll
     for (int i = 0; i < 2; i++) {

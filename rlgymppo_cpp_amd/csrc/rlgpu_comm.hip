@@ -195,7 +195,7 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
     // this pool's host driver only supports dmabuf IPC; RCCL's peer mappings fail with the legacy mode.  Only effective when the HSA runtime
     // has not been initialised yet (the hosts call this before their first HIP call); an exported value is left alone.
     (void)setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
-    const int rank = env_i("RANK", 0), world = env_i("WORLD_SIZE", 1), local = env_i("LOCAL_RANK", rank);
+    const int rank = env_i("RANK", 0), world = env_i("WORLD_SIZE", 1), local_rank = env_i("LOCAL_RANK", rank);
     if (rank_out) *rank_out = rank;
     if (world_out) *world_out = world;
     if (rendezvous_dir().empty()) return fail(nullptr, "rendezvous directory /tmp/rlgpu_comm_<uid> is not a private directory of this user (set RLGPU_COMM_DIR)");
@@ -238,6 +238,9 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
         // it) has another name and is never looked at.
         const size_t bytes = 4096 + (size_t)world * SHM_SLOT;
         rlgpu_comm* c = new rlgpu_comm();
+        // (the test transport exists so that the ranks of a launch can share ONE device: RLGPU_SHM_DEVICE puts every rank there whatever the
+        // launcher's LOCAL_RANK says -- `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on a one-GPU box, tests/test_host_cpp.py)
+        const int local = env_i("RLGPU_SHM_DEVICE", local_rank);
         c->device = local; c->rank = rank; c->world = world; c->timeout_s = timeout_s; c->seg_bytes = bytes;
         int fd = -1;
         memset(id, 0, sizeof(id));
@@ -283,7 +286,7 @@ int rlgpu_comm_init_env(rlgpu_comm** out, int* rank_out, int* world_out) {
         int rc = await(id);
         if (rc != RLGPU_OK) return rc;
     }
-    int rc = rlgpu_comm_init(out, local, rank, world, id);
+    int rc = rlgpu_comm_init(out, local_rank, rank, world, id);
     // everybody has read the file once ncclCommInitRank has returned (it is collective), whatever it returned
     if (rank == 0) (void)unlink(path.c_str());
     return rc;

@@ -194,27 +194,39 @@ template <int NC>
 constexpr bool leaves_in_lds() { return NC == 2 && RLG_MAX_EPW_1V1 <= 4; }
 // The box a body's candidates are collected for, and when a kept list is still good.  Any box that CONTAINS the body's query box of the tick
 // (arena_world.h:body_query_box: the hitbox's box united with the four suspension rays; the ball's box) gives the same results, bit for bit --
-// the exact per-triangle tests of the narrowphase and of the wheel rays filter the list -- so the walk uses the cheapest one there is: the CUBE
-// around the body's position that holds the query box in every orientation (every point of it is pos + R q with |q| <= 1.895 BT: a hitbox
-// corner), grown by CAND_FAT.  No box arithmetic (three matrix-vector products, four wheel transforms: 7 % of an idle tick went into computing
-// the exact box every tick only to compare it with the kept one), and the list stays good for as long as the POSITION has moved less than
-// CAND_FAT along every axis, whatever the car's rotation does.  Measured on one box (bench_main, alternating): exact boxes with the same
-// renewal bound 13.50 ms per collection launch, cubes 13.29 (13.94 before either); CAND_FAT 3.0 instead of 2.0: no difference.
+// the exact per-triangle tests of the narrowphase and of the wheel rays filter the list.  The walk is done for the query box grown by CAND_FAT
+// on every side, and the list is kept while the box cannot have left that: every point of a query box is pos + R q with a FIXED body-frame q
+// (hitbox corners, ray ends), so no face of it has moved by more than
+//     max_i |pos_i - pos0_i|  +  max_ij |R_ij - R0_ij| * (|q_x| + |q_y| + |q_z|)_max
+// since the walk -- twelve subtractions against the remembered pose.  (Until round 5 every tick computed the exact box -- three matrix-vector
+// products, four wheel transforms, the occupancy-grid loop: 7 % of an idle tick -- only to compare it with the kept one.)  Renewal at 97 % of
+// CAND_FAT; the rest covers the rounding of the box arithmetic.
+// -DRLG_CAND_EXACT=0 walks for the CUBE around the position that holds the query box in every orientation instead (no box arithmetic even in
+// walking ticks, no rotation term).  Measured on one box, collection launch in ms, procedural arena / the 10 084-triangle arena: round 4
+// 13.9 / 17.6, exact boxes 13.3 / 17.3, cubes 13.05 / 19.9 -- on a dense mesh the cube's longer lists cost more than its arithmetic saves.
 // Whether a body takes part is decided as before -- `active`: its box touches an occupied grid cell -- with one more bit for the bodies whose
 // box does not but whose FAT box does (`watch`): only those can become active without leaving their fat box, and only they still pay for the
 // occupancy-grid test every tick.
 constexpr float CAND_CUBE_CAR = 1.95f;                                       // BT, > 1.895
 constexpr float CAND_CUBE_BALL = (K::BALL_RADIUS * UU2BT + 0.12f) * 1.001f;   // the ball's query box is pos +- (r + 0.08 + 0.04) (arena_world.h:ball_query_aabb)
+#ifndef RLG_CAND_EXACT
+#define RLG_CAND_EXACT 1   /* 1: the walk uses the body's exact query box and the renewal bound has a rotation term; 0: the cube (no box arithmetic, no rotation term, bigger lists) */
+#endif
+constexpr float CAND_REACH = 3.5f;   // BT; (|q_x| + |q_y| + |q_z|)_max = 3.152 (a hitbox corner: |offset| + half extents; the ray ends reach 2.39)
 template <int NC>
 __device__ __forceinline__ void cand_box(const Arena<NC>& A, int body, V3& lo, V3& hi) {
+#if RLG_CAND_EXACT
+    body_query_box(A, body, false, lo, hi);   // (only called for bodies that have one: the caller's `alive`)
+#else
     const float r = body == 0 ? CAND_CUBE_BALL : CAND_CUBE_CAR;
     const V3 p = body == 0 ? A.ball.b.pos : A.cars[body - 1].b.pos;
     lo = p - v3(r, r, r); hi = p + v3(r, r, r);
+#endif
 }
 template <int NC>
 struct CandCache {
     static constexpr int NB = NC + 1;
-    V3 pos0[NB];                          // the positions the lists were walked for
+    V3 pos0[NB]; M3 rot0[RLG_CAND_EXACT ? NC : 1];   // the poses the lists were walked for
     uint32_t leaf[leaves_in_lds<NC>() ? NB : 1][leaves_in_lds<NC>() ? CACHE_LEAVES : 1];
     uint8_t n[NB];                        // leaves of body b
     uint8_t alive;                        // bit b: body b had a query box then (the ball awake, the car not demolished)
@@ -412,7 +424,15 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         if (!C.valid || was != my_alive) my_stale = true;
         else if (my_alive) {
             const V3 p = bd.pos, p0 = C.pos0[li];
-            const float moved = fmaxf(fabsf(p.x - p0.x), fmaxf(fabsf(p.y - p0.y), fabsf(p.z - p0.z)));
+            float moved = fmaxf(fabsf(p.x - p0.x), fmaxf(fabsf(p.y - p0.y), fabsf(p.z - p0.z)));
+#if RLG_CAND_EXACT
+            if (li > 0) {   // every point of a car's query box is pos + R q with a fixed q: a face moves by at most |dpos| + max |dR_ij| * (|q_x| + |q_y| + |q_z|)_max
+                const M3 r = bd.rot, r0 = C.rot0[li - 1];
+                const float turned = fmaxf(fmaxf(fmaxf(fabsf(r.r0.x - r0.r0.x), fabsf(r.r0.y - r0.r0.y)), fmaxf(fabsf(r.r0.z - r0.r0.z), fabsf(r.r1.x - r0.r1.x))),
+                                           fmaxf(fmaxf(fabsf(r.r1.y - r0.r1.y), fabsf(r.r1.z - r0.r1.z)), fmaxf(fmaxf(fabsf(r.r2.x - r0.r2.x), fabsf(r.r2.y - r0.r2.y)), fabsf(r.r2.z - r0.r2.z))));
+                moved += turned * CAND_REACH;
+            }
+#endif
             my_stale = !(moved <= 0.97f * CAND_FAT);   // (a NaN pose renews the list every tick)
             if (!my_stale && ((C.watch >> li) & 1u)) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
                 cand_box(S.A, li, lo, hi);
@@ -441,6 +461,9 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         if (go && li < NB) {
             if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); }
             if (my_alive) C.pos0[li] = li == 0 ? S.A.ball.b.pos : S.A.cars[li - 1].b.pos;
+#if RLG_CAND_EXACT
+            if (my_alive && li > 0) C.rot0[li - 1] = S.A.cars[li - 1].b.rot;
+#endif
             C.n[li] = 0;
         }
         // level 0: the roots of the active bodies, in body order
@@ -1112,7 +1135,7 @@ struct rlgpu_env {
 };
 
 // what-if runs: RLGPU_EXPERIMENT_DYN_LDS=<bytes> of unused dynamic LDS per 1v1 workgroup lowers the workgroups a CU holds (tools/fine_prof.py)
-static size_t experiment_dyn_lds() { static const size_t v = [] { const char* s = getenv("RLGPU_EXPERIMENT_DYN_LDS"); return s ? (size_t)atol(s) : (size_t)0; }(); return v; }
+static size_t experiment_dyn_lds() { static const size_t v = [] { const char* s = RLGPU_EXPERIMENT_ENV("RLGPU_EXPERIMENT_DYN_LDS"); return s ? (size_t)atol(s) : (size_t)0; }(); return v; }
 // -DRLG_ONLY_NC2: experiment builds (tools/build_variant.sh) instantiate the 1v1 kernels only -- a third of the compile time; rlgpu_env_create refuses other team sizes
 #ifdef RLG_ONLY_NC2
 #define RLG_NC_PICK(nc, X2, X4, X6) (X2)
@@ -1272,7 +1295,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
         // Both scratch buffers start as zeros (RLGPU_SCRATCH_FILL=<byte>: another pattern, for tests): hipMalloc hands back whatever an earlier
         // allocation of the process left there; nothing reads either before writing it, and a known start makes that checkable
         {
-            const char* f = std::getenv("RLGPU_SCRATCH_FILL");
+            const char* f = RLGPU_EXPERIMENT_ENV("RLGPU_SCRATCH_FILL");
             const int fill = f ? (int)std::strtol(f, nullptr, 0) : 0;
             HIPCHK(e, hipMemset(e->d_epa_big, fill, waves * EPA_BIG_BYTES));
             HIPCHK(e, hipMemset(e->d.leaf_cache, fill, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));

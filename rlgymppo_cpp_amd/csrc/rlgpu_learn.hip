@@ -1256,13 +1256,13 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.targets = targets;
     a.inv_temp = 1.0f / (l->cfg.temperature > 0 ? l->cfg.temperature : 1.f); a.clip = l->cfg.clip_range; a.ent_coef = l->cfg.ent_coef;
     a.scale = ratio / (float)n; a.metrics = metrics; a.loss_scale = 1.f; a.loss_scale_dev = l->ls_dev ? &l->ls_dev->scale : nullptr;
-    static const int fz_debug = std::getenv("RLGPU_FZ_DEBUG") ? std::atoi(std::getenv("RLGPU_FZ_DEBUG")) : 0;
+    static const int fz_debug = RLGPU_EXPERIMENT_ENV("RLGPU_FZ_DEBUG") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_FZ_DEBUG")) : 0;
     a.debug = fz_debug;
     fused::DwArgs d{};
     d.rows = n;
-    static const int slab_env = std::getenv("RLGPU_DW_SLAB") ? std::atoi(std::getenv("RLGPU_DW_SLAB")) : 0;
+    static const int slab_env = RLGPU_EXPERIMENT_ENV("RLGPU_DW_SLAB") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_DW_SLAB")) : 0;
     d.slab = slab_env > 0 ? (slab_env + 31) / 32 * 32 : 2048;   // measured: the fp32 atomics of a flush cost 173 us per minibatch at 512 rows, 33 at 2048
-    static const int dw_debug = std::getenv("RLGPU_DW_DEBUG") ? std::atoi(std::getenv("RLGPU_DW_DEBUG")) : 0;
+    static const int dw_debug = RLGPU_EXPERIMENT_ENV("RLGPU_DW_DEBUG") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_DW_DEBUG")) : 0;
     d.debug = dw_debug;
     int w = 0;
     for (const Net* nn : {&l->pol, &l->cri}) {
@@ -1283,9 +1283,9 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     }
     // The two kernels alternate over chunks of rows (RLGPU_FUSED_CHUNK, 0 = the whole minibatch at once): what the first writes for a chunk is
     // still in the last-level cache when the second reads it
-    static const int chunk_env = std::getenv("RLGPU_FUSED_CHUNK") ? std::atoi(std::getenv("RLGPU_FUSED_CHUNK")) : 0;
+    static const int chunk_env = RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_CHUNK") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_CHUNK")) : 0;
     const int chunk = chunk_env > 0 ? (chunk_env + fused::R - 1) / fused::R * fused::R : n;
-    static const bool prof_on = std::getenv("RLGPU_FUSED_PROF") != nullptr;   // (tools only, with a -DFZ_PROF build: per-phase cycles of k_ppo_fwd_bwd, printed every 16 calls)
+    static const bool prof_on = RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_PROF") != nullptr;   // (tools only, with a -DFZ_PROF build: per-phase cycles of k_ppo_fwd_bwd, printed every 16 calls)
     static unsigned long long* prof_buf = nullptr; static int prof_calls = 0;
     if (prof_on) {
         if (!prof_buf) { LCHK(l, hipMalloc(&prof_buf, 32 * 8)); LCHK(l, hipMemset(prof_buf, 0, 32 * 8)); }
@@ -1546,7 +1546,7 @@ static int launch_fused_infer(rlgpu_learner* l, const Net& net, const float* obs
     g.ld = maxkp + 8;
     g.buf_elems = std::max(FI_ROWS * g.ld, FI_ROWS * FI_LOGIT_LD * 2);
     g.mode = mode; g.values = values; g.head = head;
-    g.stamps = (mode == 0 && getenv("RLGPU_FUSED_STAMPS")) ? reinterpret_cast<unsigned long long*>(l->grads) : nullptr;   // debug: lands in the gradient buffer (tools/fused_infer_check.py)
+    g.stamps = (mode == 0 && RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_STAMPS")) ? reinterpret_cast<unsigned long long*>(l->grads) : nullptr;   // debug: lands in the gradient buffer (tools/fused_infer_check.py)
     hipLaunchKernelGGL(k_mlp_infer, dim3((rows + FI_ROWS - 1) / FI_ROWS), dim3(64 * FI_WAVES), fused_smem(net), l->stream, g);
     LCHK(l, hipGetLastError());
     return RLGPU_OK;
@@ -1586,7 +1586,7 @@ int rlgpu_value_forward(rlgpu_learner* l, const float* obs, int rows, float* val
     int rc;
     // one fused launch; it also keeps this call off the activation scratch, so it may run on another stream than a PPO epoch
     // (collectionDuringLearn).  RLGPU_FUSED_VALUE_ROWS caps the row count that takes this path (experiments).
-    static const int fused_cap = getenv("RLGPU_FUSED_VALUE_ROWS") ? atoi(getenv("RLGPU_FUSED_VALUE_ROWS")) : 0x7fffffff;
+    static const int fused_cap = RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_VALUE_ROWS") ? atoi(RLGPU_EXPERIMENT_ENV("RLGPU_FUSED_VALUE_ROWS")) : 0x7fffffff;
     static const bool no_stripe_value = getenv("RLGPU_NO_VALUE_STRIPE") != nullptr;
     if (!no_stripe_value && fused_capable(l) && rows >= 4 * fused::R) {
         // the critic's forward chain per 128-row stripe (ppo_fused.h k_value_stripe): the weights are streamed once per 128 rows instead of once per 32
@@ -1688,7 +1688,7 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
                            l->cfg.clip_range, l->cfg.ent_coef, ratio / (float)n, (float*)nullptr, l->dy16[0][l->pol.n_layers - 1], l->pol.kp[l->pol.n_layers], metrics);
         LCHK(l, hipGetLastError());
         if ((rc = stripe_launch(l, true, n))) return rc;
-        const bool two = l->dw_stream[0] != nullptr && l->dw_stream[1] != nullptr && !std::getenv("RLGPU_ONE_STREAM");
+        const bool two = l->dw_stream[0] != nullptr && l->dw_stream[1] != nullptr && !RLGPU_EXPERIMENT_ENV("RLGPU_ONE_STREAM");
         if (two) {
             LCHK(l, hipEventRecord(l->ev_fork, l->stream));
             for (int w = 0; w < 2; w++) {
@@ -1707,7 +1707,7 @@ int rlgpu_ppo_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actio
         // waits for the previous layer's output to leave the per-XCD L2s, and the other chain's kernels fill those gaps.
         if ((rc = refresh_shadows(l))) return rc;
         hipStream_t main_stream = l->stream;
-        const bool two = l->side != nullptr && !std::getenv("RLGPU_ONE_STREAM");
+        const bool two = l->side != nullptr && !RLGPU_EXPERIMENT_ENV("RLGPU_ONE_STREAM");
         if (two) { LCHK(l, hipEventRecord(l->ev_fork, main_stream)); LCHK(l, hipStreamWaitEvent(l->side, l->ev_fork, 0)); l->stream = l->side; }
         // critic
         rc = net_forward16(l, l->cri, l->act16_c, l->act_c.back(), n);

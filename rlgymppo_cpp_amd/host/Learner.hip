@@ -265,8 +265,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
         const char* ws = std::getenv("WORLD_SIZE");
         if (ws && std::atoi(ws) > 1) {
             if (rlgpu_comm_init_env(&m.comm, &m.rank, &m.world) != RLGPU_OK) RG_ERR_CLOSE("rlgpu_comm_init_env failed: " << rlgpu_comm_last_error(nullptr));
-            const char* lr = std::getenv("LOCAL_RANK");
-            m.device = lr ? std::atoi(lr) : m.rank;
+            m.device = rlgpu_comm_device(m.comm);   // LOCAL_RANK's device: the one the communicator is bound to (one source for both)
         }
         HOST_HIP(hipSetDevice(m.device));
     }

@@ -30,6 +30,7 @@
 
 using namespace RLGPC;
 using namespace RLGSC;
+extern char** environ;
 
 static int g_team = 1; static bool g_padded = false;
 
@@ -61,6 +62,17 @@ int main(int argc, char* argv[]) {
         else if (is("--mesh-dir")) meshDir = argv[++i];
         else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
     }
+    // every RLGPU_* variable this process was started with goes into the JSON line ("env_overrides"): a number measured under a path selector or on the
+    // test transport says so itself (the launcher's rendezvous plumbing -- directory, tag, timeouts -- is left out)
+    std::string overrides;
+    for (char** e = environ; e && *e; e++) {
+        if (strncmp(*e, "RLGPU_", 6) != 0) continue;
+        std::string kv(*e); const std::string name = kv.substr(0, kv.find('='));
+        if (name == "RLGPU_QUIET" || name == "RLGPU_COMM_DIR" || name == "RLGPU_COMM_TAG" || name == "RLGPU_COMM_TIMEOUT_S" || name == "RLGPU_COMM_STALE_S") continue;
+        for (char& ch : kv) if (ch == '"' || ch == '\\') ch = '?';
+        overrides += std::string(overrides.empty() ? "" : ", ") + "\"" + kv + "\"";
+    }
+    const char* transport_env = getenv("RLGPU_COMM_TRANSPORT");
     setenv("RLGPU_QUIET", "1", 1);
     RocketSim::Init(meshDir, true);
     const int64_t nAgents = (int64_t)envs * 2 * g_team, B = nAgents * horizon;
@@ -142,6 +154,8 @@ int main(int argc, char* argv[]) {
         printf(", \"rccl_ranks\": %d, \"rank_ms_per_step\": [", world > 1 ? world : 0);
         for (size_t r = 0; r < m.rankSec.size(); r++) printf("%s%.4f", r ? ", " : "", m.rankSec[r] / steps * 1e3);
         printf("], \"allreduce_calls\": %d, \"allreduce_ms_per_optimizer_step\": %.5f", m.arCalls, m.arCalls ? m.arMs / m.arCalls : 0.0);
+        // which exchange carried the gradients ("rccl" over xGMI; "shm" = the host-staged test transport, never a scaling result), and the switches seen
+        printf(", \"transport\": \"%s\", \"env_overrides\": [%s]", world > 1 ? (transport_env && !strcmp(transport_env, "shm") ? "shm" : "rccl") : "none", overrides.c_str());
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
                    warmup + steps + trainedWarm, trainedSteps, tr.agentSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);

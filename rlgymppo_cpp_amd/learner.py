@@ -188,7 +188,7 @@ class Learner:
             if parallel.env_ranks()[2] > 1:
                 # the communicator binds RCCL to LOCAL_RANK's device: the env batch, the learner and every buffer must live there too
                 comm = parallel.make_comm()
-                local = int(os.environ.get("LOCAL_RANK", str(comm.rank)))
+                local = comm.device if getattr(comm, "device", None) is not None else int(os.environ.get("LOCAL_RANK", str(comm.rank)))
                 if cfg.device != local:
                     cfg.device = local
             else:

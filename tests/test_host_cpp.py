@@ -415,6 +415,41 @@ def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_the_drivers_multi_gpu_bench_command_on_one_gpu(tmp_path):
+    """the command the driver will run on an 8-GPU node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- executed end to end with N = 2 on the one GPU of the box:
+    the launcher starts two bench.py ranks (fresh processes, the launcher itself never touches the GPU), each starts its bench_main, the two
+    meet through the rendezvous file named after the launcher, shard the envs, all-reduce per optimizer step over the shared-memory TEST
+    transport (RLGPU_COMM_TRANSPORT=shm, RLGPU_SHM_DEVICE=0: RCCL refuses two ranks on a device) and rank 0 prints ONE JSON line.  Everything of
+    the driver's future command runs except the RCCL ring itself.  The line says which transport it was; without --allow-test-transport
+    bench.py refuses to print a multi-rank line that did not go over RCCL."""
+    import json, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdv = str(tmp_path / "rdv_torchrun"); os.mkdir(rdv, 0o700)
+    env = dict(os.environ, RLGPU_COMM_TRANSPORT="shm", RLGPU_SHM_DEVICE="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TIMEOUT_S="60", RLGPU_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--envs", "512", "--no-cpu-baseline", "--mesh", "procedural", "--trained-warmup", "0", "--learned-warmup", "0"]
+    r = subprocess.run(base + ["--allow-test-transport"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["transport"] == "shm", line
+    assert line["allreduce_calls"] == 3 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert any(kv.startswith("RLGPU_COMM_TRANSPORT=shm") for kv in line["env_overrides"]), line["env_overrides"]
+    # value = the agent-steps of BOTH ranks over the slowest rank's time: two shards of 512 envs gather at least 2 x 512 x 2 x 32 per iteration
+    per_iter = line["value"] * line["ms_per_step"] * 1e-3
+    assert per_iter >= 2 * 512 * 2 * 32 * 0.999, (per_iter, line["value"], line["ms_per_step"])
+    assert abs(line["config"]["agent_steps_per_iter"] * 2 - per_iter) < 1e-3 * per_iter
+    assert not os.listdir(rdv), os.listdir(rdv)
+    # the same launch without the test flag: no line, a reason
+    r2 = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    assert "not a benchmark line" in r2.stderr, r2.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_two_free_running_ranks_count_timesteps_together_and_stop_together(tmp_path):
     """with free-running collection (the default) every rank gathers its own number of timesteps per iteration -- they differ

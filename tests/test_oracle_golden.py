@@ -439,6 +439,18 @@ def test_cabi_exports_every_declared_symbol():
     assert C.sizeof(ArenaState) > 0
 
 
+def test_release_library_has_no_experiment_switches():
+    """the release librlgpu.so cannot be told from the environment to leave work out or to change tile sizes -- the names of the
+    experiment / debug switches (csrc/rlgpu_internal.h: only a `make EXPERIMENTS=1` build reads them) do not occur in it.  The PATH selectors the
+    tests use to run complete alternative implementations against each other do."""
+    blob = open(os.path.join(ROOT, "rlgymppo_cpp_amd", "librlgpu.so"), "rb").read()
+    for name in (b"RLGPU_DW_DEBUG", b"RLGPU_FZ_DEBUG", b"RLGPU_DW_SLAB", b"RLGPU_FUSED_CHUNK", b"RLGPU_FUSED_PROF", b"RLGPU_FUSED_STAMPS", b"RLGPU_FUSED_VALUE_ROWS",
+                 b"RLGPU_ONE_STREAM", b"RLGPU_EXPERIMENT_DYN_LDS", b"RLGPU_SCRATCH_FILL"):
+        assert name not in blob, name.decode() + " is readable by the release library"
+    for name in (b"RLGPU_NO_FUSED", b"RLGPU_REDZONE", b"RLGPU_COMM_TRANSPORT"):
+        assert name in blob, name.decode()
+
+
 def test_staged_word_rows_equal_the_visitor_count():
     """The kernels' staged load / store loops run over arena_num_words<NC>() word rows, the resident allocation is sized by what arena_visit
     visits: the two are one number for every team size (a formula one word per car too large wrote NC rows past the allocation)."""

@@ -50,10 +50,16 @@ def patch(path, log):
         idxs = groups[j]
         keep = [k for k in range(j, max(idxs) + 1) if k not in idxs]
         for idx in idxs:
-            # independence: no register of a moved instruction is touched by the bracket's own instructions it jumps over
+            # independence: no register of a moved instruction is touched by the bracket's own instructions it jumps over ...
             for k in keep:
                 if k < idx and regs_of(lines[idx]) & regs_of(lines[k]):
                     raise SystemExit(f"wwm: cannot move `{lines[idx].strip()}` (line {idx + 1}) in front of its bracket: shares {sorted(regs_of(lines[idx]) & regs_of(lines[k]))} with `{lines[k].strip()}`")
+                # ... and it jumps over nothing that orders it: a wait (the moved instruction may read a register whose load that s_waitcnt is there
+                # for: in front of it the value would be stale), or a writer of exec / vcc other than the bracket's own first instruction
+                if j < k < idx:
+                    ins = lines[k].strip()
+                    if ins.startswith("s_waitcnt") or re.search(r"\b(exec|vcc)(_lo|_hi)?\b", ins.split(";")[0].split(",")[0]):
+                        raise SystemExit(f"wwm: cannot move `{lines[idx].strip()}` (line {idx + 1}) in front of its bracket: `{ins}` lies between (a wait or an exec / vcc writer)")
         out = [lines[idx] + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)" for idx in idxs]
         for idx in idxs:
             log.write(f"wwm: moved `{lines[idx].strip()}` out of the bracket at line {j + 1} ({[b for b in bad if b[1] - 1 == idx][0][0][:70]})\n")
@@ -76,7 +82,22 @@ def main():
     out = subprocess.run([HIPCC] + args + ["-###"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     cmds = [shlex.split(l) for l in out.stdout.split("\n") if l.startswith(' "')]
     if len(cmds) != 4 or "-fcuda-is-device" not in cmds[0] or "-emit-obj" not in cmds[0]:
-        raise SystemExit("hipcc_wwm_safe: unexpected hipcc pipeline:\n" + out.stdout[-3000:])
+        # not the four steps this script knows how to split (another ROCm, extra flags): build with plain hipcc, and make the lint a HARD check on
+        # the device assembly of the same command -- an object with the defect in it is never produced silently
+        log.write("wwm: unexpected hipcc pipeline (%d steps): plain hipcc + lint of the device assembly\n" % len(cmds))
+        r = subprocess.run([HIPCC] + args)
+        if r.returncode: sys.exit(r.returncode)
+        if "-o" in args:
+            asm = args[args.index("-o") + 1] + ".wwm_check.s"
+            sargs = [a for a in args if a != "-c"]; sargs[sargs.index("-o") + 1] = asm
+            r = subprocess.run([HIPCC] + sargs + ["-S", "--cuda-device-only"])
+            if r.returncode: sys.exit(r.returncode)
+            n, bad = wwm_lint.lint(asm)
+            os.remove(asm)
+            if bad:
+                raise SystemExit(f"wwm: {len(bad)} instruction(s) inside a whole-wave bracket that do not belong there, and no way to repair them with this toolchain: " + "; ".join(b[2] for b in bad[:4]))
+            log.write(f"wwm: {n} whole-wave brackets, clean\n")
+        return
     dev, lld, bundle, host = cmds
     dev_obj = dev[dev.index("-o") + 1]
     dev_asm = dev_obj[:-2] + ".s"
@@ -87,7 +108,8 @@ def main():
         if r.returncode: sys.exit(r.returncode)
         moved = patch(dev_asm, log)
         clang = dev[0]
-        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_asm, "-o", dev_obj])
+        mcpu = dev[dev.index("-target-cpu") + 1] if "-target-cpu" in dev else "gfx950"   # (the --offload-arch the caller asked for)
+        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + mcpu, "-c", dev_asm, "-o", dev_obj])
         if r.returncode: sys.exit(r.returncode)
         for c in (lld, bundle, host):
             r = subprocess.run(c)
