@@ -52,5 +52,11 @@ struct LearnerConfig {
     // no plugin or callback needs the host per step; otherwise -- and with true -- every game makes the same number of steps per iteration
     // (reproducible from the seed alone: the free-running iteration's trajectory LENGTHS depend on timing, their contents do not).
     bool lockstepCollection = false;
+    // (added) The reference sums its gradients in a fixed order (single stream, PPOLearner.cpp:205-215); so do this build's fused minibatch kernels
+    // (per-slab partials added in slab order).  What still varies from run to run by default is how many steps each game contributes to a
+    // free-running iteration, and -- in fp32 mode or with nets wider than 256 -- the order of the per-layer kernels' atomics.  true: lockstep
+    // collection AND fixed-order sums everywhere (rlgpu_learner_set_deterministic): the run is a function of its seed, bit for bit, on one rank
+    // or several.
+    bool deterministicGradients = false;
 };
 }

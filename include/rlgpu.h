@@ -243,6 +243,12 @@ int rlgpu_zero_grads(rlgpu_learner* l);
  * grad_scale multiplies the gradients first (1/world_size after the all-reduce). */
 int rlgpu_clip_adam_step(rlgpu_learner* l, float max_norm, float grad_scale);
 int rlgpu_learner_set_lr(rlgpu_learner* l, float policy_lr, float critic_lr);
+/* Deterministic-gradient mode (LearnerConfig::deterministicGradients).  The reference's gradients are sums in a fixed order (one stream,
+ * PRIV/PPO/PPOLearner.cpp:205-215).  The fused minibatch kernels (bf16 / fp16 operands, layers up to 256 wide: the flagship shape) always sum
+ * that way: every row slab's partial dW / db goes to its own buffer and the slabs are added in slab order.  The per-layer kernels (fp32 mode, wider
+ * nets) split a minibatch's rows over blocks that add with fp32 atomics in the order they finish; on = 1 makes one block sum all rows of its
+ * tile instead (slower, fixed order).  With lockstep collection a run is then a function of its seed, bit for bit, on one rank or several. */
+int rlgpu_learner_set_deterministic(rlgpu_learner* l, int on);
 /* fp16 mode (use_bf16 = 2): amp::GradScaler's state (PRIV/Util/gradscaler.hpp:26-34,162,291) -- the loss scale the NEXT minibatch's loss gradient is
  * multiplied by (rlgpu_ppo_minibatch leaves scale x gradient in the gradient buffer; rlgpu_clip_adam_step unscales BEFORE the clip, skips an
  * optimizer whose gradient norm is not finite and then halves the scale; 2000 clean steps double it), the clean steps counted so far, the steps

@@ -118,6 +118,7 @@ SIGNATURES = {
     "rlgpu_learner_set_temperature": (_i, [_vp, _f]),
     "rlgpu_env_reseed": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "rlgpu_learner_set_sampler": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "rlgpu_learner_set_deterministic": (_i, [_vp, _i]),
     "rlgpu_learner_get_sampler": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rlgpu_comm_unique_id": (_i, [_vp]),
     "rlgpu_comm_init": (_i, [C.POINTER(_vp), _i, _i, _i, _vp]),

@@ -534,7 +534,13 @@ struct DwLayer {
     int Mo, No;                  // dW is [Mo][No]
     float* dW; float* db;
 };
-struct DwArgs { DwLayer L[2][4]; int rows; int slab; int debug; int row0; };   // rows [row0, rows)   // debug & 1 (tools): no flush
+struct DwArgs {
+    DwLayer L[2][4]; int rows; int slab; int debug; int row0;   // rows [row0, rows)   // debug & 1 (tools): no flush
+    // deterministic-gradient mode (rlgpu_learner_set_deterministic): a slab's dW / db go to ITS OWN copy of the flat gradient layout, with plain
+    // stores -- partial[slab][offset of the element in the gradient buffer] -- and k_dw_reduce adds the slabs up in slab order.  null: fp32 atomics
+    // straight into the gradient buffer, in whatever order the slabs finish.
+    float* partial; size_t partial_stride; const float* grads_base;
+};
 
 __device__ __forceinline__ bf16x8 tr_operand(const short* S, int k16, int col0, int lane) {
     // 32 (cols) x 16 (k) MFMA operand out of a k-major LDS tile: per 16-lane group a 4 (k) x 16 (col) block, delivered column-major
@@ -658,17 +664,34 @@ __global__ void __launch_bounds__(512) k_dw_grouped(DwArgs g) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int gm = (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                if (gm < L.Mo && gn < L.No) atomicAdd(&L.dW[(size_t)gm * L.No + gn], acc[i][j][q]);
+                if (gm < L.Mo && gn < L.No) {
+                    float* dst = &L.dW[(size_t)gm * L.No + gn];
+                    if (g.partial) g.partial[(size_t)blockIdx.x * g.partial_stride + (size_t)(dst - g.grads_base)] = acc[i][j][q];
+                    else atomicAdd(dst, acc[i][j][q]);
+                }
             }
         }
         if (bias_wave && (lane & 31) == 0) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int gm = (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                if (gm < L.Mo) atomicAdd(&L.db[gm], accb[i][q]);
+                if (gm < L.Mo) {
+                    float* dst = &L.db[gm];
+                    if (g.partial) g.partial[(size_t)blockIdx.x * g.partial_stride + (size_t)(dst - g.grads_base)] = accb[i][q];
+                    else atomicAdd(dst, accb[i][q]);
+                }
             }
         }
     }
+}
+
+// deterministic-gradient mode: grads[i] += partial[0][i] + partial[1][i] + ... in slab order (one thread per parameter of the layers the dW launch covered)
+__global__ void k_dw_reduce(const float* partial, size_t stride, int n_slabs, float* grads, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < n_slabs; k++) s += partial[(size_t)k * stride + (size_t)i];
+    grads[i] += s;
 }
 
 }  // namespace fused

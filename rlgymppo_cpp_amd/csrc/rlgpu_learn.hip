@@ -908,6 +908,9 @@ struct rlgpu_learner {
     // scratch: activations per net [max_rows x width]
     std::vector<float*> act_p, act_c;  // act[i] = output of layer i (post-ReLU for hidden), act_p.back() = logits
     float *dbuf0 = nullptr, *dbuf1 = nullptr, *gathered = nullptr, *norm_buf = nullptr;
+    // deterministic-gradient mode (rlgpu_learner_set_deterministic): every dW / db element has ONE writer per launch, or goes through per-slab partials
+    // that are summed in slab order (dw_partial: [slabs][n_total], allocated on first use)
+    bool deterministic = false; float* dw_partial = nullptr; size_t dw_partial_slabs = 0;
     // bf16 fast path (cfg.use_bf16)
     short* shadows = nullptr; int64_t n_shadow = 0; bool shadows_dirty = true;
     // fp16 operand mode (cfg.use_bf16 == 2; BASELINE configs[4] "fp16 autocast"): the minibatch kernels of ppo_fused.h take fp16 copies of the
@@ -1013,13 +1016,13 @@ int net_backward(rlgpu_learner* l, const Net& net, const std::vector<float*>& ac
             g.C = l->grads + net.w_off[i]; g.ldc = K_in;
             g.M = N_out; g.N = K_in; g.K = rows;
             g.atomic_accumulate = 1;
-            int chunk = 2048; g.k_chunk = chunk;
+            int chunk = l->deterministic ? rows : 2048; g.k_chunk = chunk;   // (deterministic mode: one block per dW tile sums all rows in order; its single atomic add lands on a value nothing else touches meanwhile)
             int splits = (rows + chunk - 1) / chunk;
             int rc = launch_gemm(l, g, splits);
             if (rc) return rc;
         }
         {
-            dim3 grid((N_out + 63) / 64, std::max(1, std::min(1024, rows / 64))), block(256);
+            dim3 grid((N_out + 63) / 64, l->deterministic ? 1 : std::max(1, std::min(1024, rows / 64))), block(256);
             hipLaunchKernelGGL(k_col_sum, grid, block, 0, l->stream, (const float*)cur, N_out, rows, N_out, l->grads + net.b_off[i]);
             LCHK(l, hipGetLastError());
         }
@@ -1151,7 +1154,7 @@ int net_backward16(rlgpu_learner* l, const Net& net, const std::vector<short*>& 
             t.dW = l->grads + net.w_off[i]; t.ldw = K_in; t.db = l->grads + net.b_off[i];
             // 512-row slabs: measured optimum between atomic traffic (128 rows: 99 TFLOP/s for the whole minibatch, 256: 139) and
             // too few workgroups (2048: 143); slab partials + a reduction kernel instead of atomics were slower (153 vs 171)
-            t.slab = 512;
+            t.slab = l->deterministic ? std::max(rows, 1) : 512;
             dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
             hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, dws, t);
             LCHK(l, hipGetLastError());
@@ -1309,9 +1312,28 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
             default: rc = half ? fused_launch_th<192, true>(l, a, grid) : fused_launch_th<192, false>(l, a, grid); break;
         }
         if (rc) return rc;
-        if (half) hipLaunchKernelGGL(fused::k_dw_grouped<true>, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
-        else hipLaunchKernelGGL(fused::k_dw_grouped<false>, dim3((r1 - r0 + d.slab - 1) / d.slab, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
+        const int n_slabs = (r1 - r0 + d.slab - 1) / d.slab;
+        d.partial = nullptr; d.partial_stride = (size_t)l->n_total; d.grads_base = l->grads;
+        // Per-slab partial gradients + a fixed-order sum are this path's ONLY form since round 5: measured at the flagship shape they cost no more than
+        // the fp32 atomics they replace (ppo_iter_ms 1.63 vs 1.69, one box, alternating) and the gradient no longer depends on the order in which
+        // the slabs finish.  (A make EXPERIMENTS=1 build can go back to atomics with RLGPU_DW_ATOMICS=1 for A/B runs.)
+        static const bool dw_atomics = RLGPU_EXPERIMENT_ENV("RLGPU_DW_ATOMICS") != nullptr;
+        if (!dw_atomics || l->deterministic) {
+            if (l->dw_partial_slabs < (size_t)n_slabs) {
+                if (l->dw_partial) (void)hipFree(l->dw_partial);
+                l->dw_partial = nullptr; l->dw_partial_slabs = 0;
+                LCHK(l, hipMalloc(&l->dw_partial, (size_t)n_slabs * (size_t)l->n_total * sizeof(float)));
+                l->dw_partial_slabs = (size_t)n_slabs;
+            }
+            d.partial = l->dw_partial;
+        }
+        if (half) hipLaunchKernelGGL(fused::k_dw_grouped<true>, dim3(n_slabs, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
+        else hipLaunchKernelGGL(fused::k_dw_grouped<false>, dim3(n_slabs, 4, 2), dim3(512), fused::DW_SMEM_BYTES, l->stream, d);
         LCHK(l, hipGetLastError());
+        if (d.partial) {   // (every element of both networks' gradients was stored by every slab: the fused path covers all eight layers)
+            hipLaunchKernelGGL(fused::k_dw_reduce, dim3((unsigned)((l->n_total + 255) / 256)), dim3(256), 0, l->stream, (const float*)d.partial, d.partial_stride, n_slabs, l->grads, (long long)l->n_total);
+            LCHK(l, hipGetLastError());
+        }
     }
     const dim3 grid = grid_all;
     if (prof_on && ++prof_calls % 16 == 0) {
@@ -1337,7 +1359,7 @@ int net_dw16(rlgpu_learner* l, const Net& net, const std::vector<short*>& acts16
         t.Y = l->dy16[which][i]; t.ldy = net.kp[i + 1]; t.X = in; t.ldx = net.kp[i];
         t.R = rows; t.Mo = N_out; t.No = K_in;
         t.dW = l->grads + net.w_off[i]; t.ldw = K_in; t.db = l->grads + net.b_off[i];
-        t.slab = 512;
+        t.slab = l->deterministic ? std::max(rows, 1) : 512;
         dim3 grid((K_in + 127) / 128, (N_out + 127) / 128, (rows + t.slab - 1) / t.slab);
         hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, st, t);
         LCHK(l, hipGetLastError());
@@ -1451,7 +1473,7 @@ int rlgpu_learner_create(rlgpu_learner** out, int device, const RlgpuLearnerConf
 void rlgpu_learner_destroy(rlgpu_learner* l) {
     if (!l) return;
     (void)hipSetDevice(l->device);
-    for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf}) if (p) (void)hipFree(p);
+    for (float* p : {l->params, l->grads, l->adam_m, l->adam_v, l->dbuf0, l->dbuf1, l->gathered, l->norm_buf, l->dw_partial}) if (p) (void)hipFree(p);
     for (float* p : l->act_p) (void)hipFree(p);
     for (float* p : l->act_c) (void)hipFree(p);
     for (short* p : {l->shadows, l->shadows_h, l->x16, l->g16a, l->g16b}) if (p) (void)hipFree(p);
@@ -1837,6 +1859,7 @@ int rlgpu_internal_policy_net(rlgpu_learner* l, rlinfer::InferNet* net, rlinfer:
 }
 extern "C" {
 int rlgpu_learner_refresh_shadows(rlgpu_learner* l) { LCHK(l, hipSetDevice(l->device)); return l->cfg.use_bf16 ? refresh_shadows(l) : RLGPU_OK; }
+int rlgpu_learner_set_deterministic(rlgpu_learner* l, int on) { l->deterministic = on != 0; return RLGPU_OK; }
 int rlgpu_learner_set_sampler(rlgpu_learner* l, uint32_t stream, uint32_t call_ctr) { l->sampler_stream = stream; l->call_ctr = call_ctr; return RLGPU_OK; }
 int rlgpu_learner_get_sampler(rlgpu_learner* l, uint32_t* stream, uint32_t* call_ctr) { if (stream) *stream = l->sampler_stream; if (call_ctr) *call_ctr = l->call_ctr; return RLGPU_OK; }
 int rlgpu_allreduce_grads(rlgpu_learner* l, rlgpu_comm* c) {

@@ -52,6 +52,7 @@ class LearnerConfig:  # PUB/LearnerConfig.h:14-80
     standardizeReturns: bool = True
     maxReturnsPerStatsInc: int = 150
     deterministic: bool = False
+    deterministicGradients: bool = False   # fixed-order dW / db sums (rlgpu_learner_set_deterministic): a run is reproducible from its seed
     collectionDuringLearn: bool = False   # LearnerConfig.h:46-50: the PPO epochs of iteration k run while iteration k+1 is collected
     ppo: PPOLearnerConfig = field(default_factory=PPOLearnerConfig)
     gaeLambda: float = 0.95
@@ -221,6 +222,8 @@ class Learner:
                            p.policyTemperature, p.autocastLearn, cfg.randomSeed, max_rows, cfg.device)
         # ... but every rank explores with its own noise: the sampler is keyed on the rank (identical observations on two ranks draw different actions)
         self.ppo.set_sampler(rank, 0)
+        if cfg.deterministicGradients:
+            self.ppo.set_deterministic(True)
         T, N, D = self.T, self.n_agents, self.obs_size
         f = dict(dtype=torch.float32, device=self.dev)
         self.obs_buf = torch.empty((T + 1, N, D), **f)     # states; row T = the state after the last step

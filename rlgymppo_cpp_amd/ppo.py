@@ -163,6 +163,10 @@ class PPOCore:
         _chk(self.lib.rlgpu_learner_loss_scale(self.h, C.byref(sc), C.byref(g), C.byref(k)), self.h, self._err)
         return sc.value, g.value, k.value
 
+    def set_deterministic(self, on: bool = True):
+        """Deterministic-gradient mode (rlgpu_learner_set_deterministic): dW / db summed in a fixed order instead of with fp32 atomics."""
+        _chk(self.lib.rlgpu_learner_set_deterministic(self.h, 1 if on else 0), self.h, self._err)
+
     def set_lr(self, policy_lr, critic_lr):
         _chk(self.lib.rlgpu_learner_set_lr(self.h, policy_lr, critic_lr), self.h, self._err)
 

@@ -415,6 +415,50 @@ def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_deterministic_gradient_mode_makes_a_run_a_function_of_its_seed(tmp_path):
+    """VERDICT r04 item 3 (north star: "a fixed-seed run matches ... bit-exact").  The reference's gradients are sums in a fixed order (one stream,
+    PPOLearner.cpp:205-215); this build's default adds the dW / db partials of a minibatch's row slabs with fp32 atomics in the order the slabs
+    finish, so two launches of one seed part after the first optimizer step.  LearnerConfig::deterministicGradients (bench_main --deterministic):
+    per-slab partial gradients summed in slab order + lockstep collection.
+      * two single-rank runs of 50 iterations end with the SAME parameter checksum;
+      * two two-rank runs (shm transport on the one GPU: sums in rank order) end with the same checksum as each other, on both ranks;
+      * the deterministic single-rank result differs from the two-rank one (the other rank's gradients entered)."""
+    import re, socket
+    exe = os.path.join(PKG, "bench_main")
+    args = ["--envs", "512", "--horizon", "16", "--steps", "50", "--warmup", "0", "--deterministic"]
+
+    def solo():
+        r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=dict(os.environ, RLGPU_QUIET="1"), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return re.search(r"parameter checksum ([0-9a-f]{16})", r.stderr).group(1)
+
+    def pair(tag):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        rdv = str(tmp_path / ("rdv_" + tag)); os.mkdir(rdv, 0o700)
+        base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TAG=tag,
+                    RLGPU_COMM_TRANSPORT="shm", RLGPU_COMM_TIMEOUT_S="60", RLGPU_REPLICA_CHECK_EVERY="1", RLGPU_QUIET="1")
+        procs = [subprocess.Popen([exe] + args, env=dict(base, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for r in range(2)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=300))
+            except subprocess.TimeoutExpired:
+                for q in procs: q.kill()
+                pytest.fail("a rank hung")
+        assert [p.returncode for p in procs] == [0, 0], outs
+        cs = [re.search(r"parameter checksum ([0-9a-f]{16})", o[1]).group(1) for o in outs]
+        assert cs[0] == cs[1], cs
+        return cs[0]
+
+    a, b = solo(), solo()
+    assert a == b, f"two deterministic runs of one seed ended with different parameters: {a} vs {b}"
+    c, d = pair("d1"), pair("d2")
+    assert c == d, f"two deterministic two-rank runs ended with different parameters: {c} vs {d}"
+    assert a != c
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(400)
 def test_the_drivers_multi_gpu_bench_command_on_one_gpu(tmp_path):
     """the command the driver will run on an 8-GPU node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N

@@ -199,7 +199,8 @@ def test_welford_equals_reference_header(refl):
 
 
 @pytest.mark.gpu
-def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl, deterministic):
     """SURVEY A14 / section 4-3: the COMPOSITION of one training iteration, not its pieces.  The Learner (fp32 mode) collects on the GPU;
     the collected rows then go through a pipeline assembled from the reference's own code (libref_learner.so: ValueEstimator, ComputeGAE,
     DiscretePolicy) and the numpy PPO oracle, in the reference's order (Learner.cpp:608-703, PPOLearner.cpp:67-349):
@@ -207,13 +208,14 @@ def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
       iteration's returns enter the statistic | ComputeGAE on the concatenation with the collector's truncation marks | the three report
       averages | returnStats.Increment with the FIRST min(150, B) returns of the concatenation | one epoch of two accumulated minibatches,
       clip-by-norm per network, one Adam step.
-    Three iterations, so that retStd is 1 (n < 2), then the std of 150 samples, then of 300.  Also: the action the policy sampled for every
+    Three iterations, so that retStd is 1 (n < 2), then the std of 150 samples, then of 300 -- ten in the deterministic-gradient mode
+    (LearnerConfig.deterministicGradients: fixed-order dW / db sums).  Also: the action the policy sampled for every
     collected row is the reference DiscretePolicy's choice on the same probabilities (log-probs within 1e-5)."""
     torch = pytest.importorskip("torch")
     from rlgymppo_cpp_amd.learner import Learner, LearnerConfig, PPOLearnerConfig
     n_envs, T = 16, 12
     N = n_envs * 2; B = N * T
-    cfg = LearnerConfig(numEnvs=n_envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, randomSeed=9, standardizeReturns=True, maxReturnsPerStatsInc=150,
+    cfg = LearnerConfig(numEnvs=n_envs, teamSize=1, timestepsPerIteration=B, expBufferSize=B, randomSeed=9, standardizeReturns=True, maxReturnsPerStatsInc=150, deterministicGradients=deterministic,
                         ppo=PPOLearnerConfig(policyLayerSizes=tuple(HID), criticLayerSizes=tuple(HID), batchSize=B, miniBatchSize=B // 2, epochs=1,
                                              policyLR=3e-4, criticLR=3e-4, entCoef=0.01, clipRange=0.2, autocastLearn=False))
     L = Learner(cfg)
@@ -223,7 +225,8 @@ def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
     stat = R.Welford()
     mom = {0: [np.zeros(L.ppo.num_params(0), np.float32), np.zeros(L.ppo.num_params(0), np.float32)], 1: [np.zeros(L.ppo.num_params(1), np.float32), np.zeros(L.ppo.num_params(1), np.float32)]}
     am = lambda x: np.ascontiguousarray(np.moveaxis(x, 0, 1).reshape((-1,) + x.shape[2:]))      # [T][N]... -> agent-major concatenation (trajectory after trajectory)
-    for it in range(3):
+    n_iter = 10 if deterministic else 3
+    for it in range(n_iter):
         pol, cri = L.ppo.get_params(0).copy(), L.ppo.get_params(1).copy()
         L.collect(); L.ppo.sync(); torch.cuda.synchronize()
         obs = L.obs_buf.cpu().numpy().reshape(T + 1, N, D); acts = L.act_buf.cpu().numpy().reshape(T, N); logp = L.logp_buf.cpu().numpy().reshape(T, N)
@@ -261,4 +264,10 @@ def test_add_new_experience_and_learn_composition_vs_reference_pipeline(refl):
         # (Adam's first steps are lr * g / (|g| + 1e-8) per entry: where a gradient entry is of the order of 1e-8 .. 1e-7 the quotient moves by
         # per cents when fp32 summation order moves the entry by 1e-9 -- 1e-5 is 3 % of one 3e-4 step, for a handful of such entries)
         assert dp < 1e-5 and dc < 1e-5, f"iteration {it}: parameters after the optimizer step differ by {dp:.3g} (policy) / {dc:.3g} (critic); step sizes {np.abs(want_p - pol).max():.3g} / {np.abs(want_c - cri).max():.3g}"
-    assert L.cumulative_model_updates == 3
+    assert L.cumulative_model_updates == n_iter
+    if deterministic:   # the mode's own promise: the same seed gives the same bits (a second learner, the same ten iterations)
+        L2 = Learner(cfg)
+        for it in range(n_iter):
+            L2.collect(); L2.add_new_experience(); L2.finish_report(); L2._flush_returns(); L2.learn()
+        L2.ppo.sync(); torch.cuda.synchronize()
+        assert np.array_equal(L2.ppo.get_params(2), L.ppo.get_params(2)), "two deterministic-mode runs of one seed differ"
