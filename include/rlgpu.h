@@ -145,10 +145,15 @@ int rlgpu_env_step_controls(rlgpu_env* e, const float* controls_dev, float* next
  * (Until round 4 the last one also counted the two cases in which a contact point is LOST; they have a counter of their own now, below.)
  * reset != 0: the counts as they stood are returned, then these five are cleared (the EPA counts below are not touched). */
 int rlgpu_env_overflow_counts(rlgpu_env* e, uint64_t* out5, int reset);
-/* The two places where contact points are LOST instead of going through an exact fallback: a body touching a third mesh object with points at once
- * (two manifolds per body and tick), and a car-car point beyond the pair pool of the env (4 / 8 / 12 points for 1v1 / 2v2 / 3v3; a six-car heap has
- * shown 9).  out1 = such events since the last reset (process-wide); reset != 0 clears it after reading. */
+/* Contact points LOST since the last reset (process-wide): always 0.  Until round 4 two cases lost points (a body touching a third mesh object with
+ * points at once; a car-car point beyond the env's pair pool); such a tick is now detected before any contact callback has fired and the env's
+ * world step is redone with a contact layout that has a manifold for every mesh object, a slot for every pair and a solver row for every slot
+ * (csrc/arena_contact.h, arena_step.h:world_step_finish_big).  The counter stays as an invariant for tests and soak runs to assert.
+ * reset != 0 clears it after reading. */
 int rlgpu_env_lost_contact_count(rlgpu_env* e, uint64_t* out1, int reset);
+/* env-ticks since the last reset (process-wide) that took that path: contacts beyond the LDS-resident layout, redone with the big one in global
+ * memory -- same results as the reference, a few hundred microseconds each (two in 393 M env-ticks of learned 3v3).  reset != 0 clears it after reading. */
+int rlgpu_env_big_layout_ticks(rlgpu_env* e, uint64_t* out1, int reset);
 
 /* Penetration-depth queries since the last reset (process-wide): hitbox-mesh / hitbox-ball pairs whose cores overlap go through the
  * reference's second GJK + EPA (btGjkEpaPenetrationDepthSolver.cpp:24-79, btGjkEpa2.cpp; csrc/arena_epa.h).  out2 = {queries, queries that

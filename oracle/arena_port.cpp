@@ -14,6 +14,8 @@
 static int g_epa_stats[64];   // [0] runs, [1] max verts, [2] max faces, [3] max iterations, [4 + status] status counts, [16 + min(verts / 4, 31)] histogram
 #define RLG_EPA_STATS(nv, nf, it, st) do { g_epa_stats[0]++; if ((nv) > g_epa_stats[1]) g_epa_stats[1] = (nv); if ((nf) > g_epa_stats[2]) g_epa_stats[2] = (nf); \
     if ((it) > g_epa_stats[3]) g_epa_stats[3] = (it); g_epa_stats[4 + ((st) < 10 ? (st) : 10)]++; g_epa_stats[16 + ((nv) / 4 < 31 ? (nv) / 4 : 31)]++; } while (0)
+static long g_port_counts[16];   // events of the stepper's bookkeeping (RLG_DBG_COUNT; 8 = env-ticks redone with the big contact layout, 7 = contacts lost: never)
+#define RLG_DBG_COUNT(i) (void)(__atomic_fetch_add(&g_port_counts[(i) & 15], 1L, __ATOMIC_RELAXED))
 #include "../rlgymppo_cpp_amd/csrc/arena_gym.h"
 #include "../rlgymppo_cpp_amd/csrc/arena_mesh.h"
 #include <cstring>
@@ -22,6 +24,16 @@ static int g_epa_stats[64];   // [0] runs, [1] max verts, [2] max faces, [3] max
 #include <vector>
 
 using namespace rlg;
+
+// The contact layout the port steps with (arena_contact.h): the big one -- a manifold for every mesh object, a slot for every pair, a row for every
+// slot: nothing can overflow, which is what makes the port the oracle of the device's small layout + fallback.  -DORACLE_SMALL_LAYOUT builds
+// the small layout with its fallback instead (with -DRLG_TINY_LAYOUT: one that overflows all the time; tests/test_oracle_golden.py holds both
+// builds to the same fixtures).
+#ifdef ORACLE_SMALL_LAYOUT
+template <int NC> using PortWork = TickWork<NC, 0>;
+#else
+template <int NC> using PortWork = TickWork<NC, 1>;
+#endif
 
 namespace {
 HostMesh g_mesh;
@@ -37,7 +49,7 @@ void step_t(RlgpuArenaState* s, int ticks, uint32_t seed, uint32_t env) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, seed, env, ev, W); }
     arena_to_host(A, G, *s);
 }
@@ -48,7 +60,7 @@ void step_hist_t(RlgpuArenaState* s, int ticks, uint16_t* hist) {
     arena_from_host(A, G, *s);
     for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W); }
     for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     arena_to_host(A, G, *s);
@@ -60,7 +72,7 @@ template <int NC>
 void step_chain_t(RlgpuArenaState* s, int n) {
     Arena<NC> A; GymEnv<NC> G;
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     uint16_t hist[NC + 1] = {};
     for (int i = 0; i < n; i++) {
         arena_from_host(A, G, s[i]);
@@ -78,7 +90,7 @@ void run_tape_t(RlgpuArenaState* s, const float* tape, int ticks, int every, Rlg
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     int n_out = 0;
     for (int t = 0; t < ticks; t++) {
         for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(tape + ((size_t)t * NC + k) * 8);
@@ -93,7 +105,7 @@ void run_tape_raw_t(RlgpuArenaState* s, const float* tape, int ticks, float* raw
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     auto put = [](float* o, const Body& b) {
         o[0] = b.pos.x; o[1] = b.pos.y; o[2] = b.pos.z;
         const V3 r0 = b.rot.r0, r1 = b.rot.r1, r2 = b.rot.r2;
@@ -119,7 +131,7 @@ int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float*
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     for (int t = 0; t < ticks; t++) {
         for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(tape + ((size_t)t * NC + k) * 8);
         TickEvents ev; ev.bump_mask = 0; arena_tick(A, mv, 0, 0, ev, W);
@@ -178,6 +190,8 @@ void port_run_tape(RlgpuArenaState* s, const float* tape, int ticks, int every, 
 }
 
 int port_state_size() { return (int)sizeof(RlgpuArenaState); }
+// RLG_DBG_COUNT events since the last reset (16 slots)
+void port_debug_counts(long* out16, int reset) { memcpy(out16, g_port_counts, sizeof(g_port_counts)); if (reset) memset(g_port_counts, 0, sizeof(g_port_counts)); }
 void port_epa_stats(int* out64, int reset) { memcpy(out64, g_epa_stats, sizeof(g_epa_stats)); if (reset) memset(g_epa_stats, 0, sizeof(g_epa_stats)); }
 
 void port_set_mesh(const float* verts_uu, int n_verts, const int32_t* tris, int n_tris) {
@@ -278,7 +292,7 @@ static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, c
     arena_from_host(A, G, *s);
     if (hist) for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];      // the arena's broadphase history, kept by the caller (port_step_hist)
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     gym_step_env<NC>(A, G, *cfg, mv, table(), actions, env, obs, (size_t)obs_size<NC>(*cfg), rew, done, W);
     if (hist) for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     arena_to_host(A, G, *s);
@@ -353,7 +367,7 @@ static int debug_tick_t(RlgpuArenaState* s, float* out, int cap) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     TickEvents ev; ev.bump_mask = 0;
     arena_tick(A, mv, 0, 0, ev, W);
     arena_to_host(A, G, *s);
@@ -375,7 +389,7 @@ static void debug_wheels_t(RlgpuArenaState* s, int slot, float* out) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     TickEvents ev; ev.bump_mask = 0;
     arena_tick(A, mv, 0, 0, ev, W);
     arena_to_host(A, G, *s);
@@ -397,7 +411,7 @@ static int debug_friction_t(RlgpuArenaState* s, float* out, int cap) {
     Arena<NC> A; GymEnv<NC> G;
     arena_from_host(A, G, *s);
     MeshView mv = view();
-    TickWork<NC> W;
+    PortWork<NC> W;
     TickEvents ev; ev.bump_mask = 0;
     arena_tick(A, mv, 0, 0, ev, W);
     int n = 0;

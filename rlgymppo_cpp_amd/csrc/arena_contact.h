@@ -18,6 +18,7 @@
 //   * the end-of-algorithm refreshContactPoints that rebuilds world positions and the distance from the local points.
 // This file restates those three things for the fixed body set {ball, NC cars} against {mesh, floor, ceiling, -x wall, +x wall}.
 #pragma once
+#include <type_traits>
 #include "arena_body.h"
 
 namespace rlg {
@@ -31,7 +32,7 @@ struct Contact {      // 44 B (LDS-resident on the device: 24..56 of them per en
                       // car vs ball -> a = car, b = ball (btCompoundCollisionAlgorithm swapped + btConvexConvexAlgorithm(box, sphere));
                       // car i vs car j, i < j -> a = car j, b = car i (two nested compound algorithms, the inner one swapped)
     int8_t sid;       // static body when b == -1: 0 = the (first) triangle mesh object the body touches, 1..4 = floor, ceiling, -x wall, +x wall
-                      // (creation order, Arena.cpp:1036-1101), SID_MESH2 = a second mesh object (one manifold per .cmf file: Arena.cpp:1028-1054)
+                      // (creation order, Arena.cpp:1036-1101), 5.. = further mesh objects (mesh_sid; one manifold per .cmf file: Arena.cpp:1028-1054)
     int8_t special;   // ball-world contact: resolved through one averaged row (Arena.cpp:265-273)
 };
 RLG_HD float contact_friction(const Contact& c) {   // m_combinedFriction after the contact-added callback (Arena.cpp:283-427) / btManifoldResult.cpp:56-78
@@ -48,24 +49,51 @@ struct ContactList {
 };
 
 // ---- where the contacts of an env live -----------------------------------------------------------------------------------
-// Fixed regions, so the bodies of an env can write side by side (collide_body, one lane per body on the device):
-//   ball          [0, 10)                     <= 2 mesh manifolds (one per mesh object touched, <= 4 points each) first, then <= 2 plane manifolds of one point each
-//   car i         [10 + 11 i, 10 + 11 i + 10) the same against the world
-//                 [10 + 11 i + 10]            the car's contact with the ball
-//   car pairs     [10 + 11 NC, + PAIR_POOL)   <= 4 points per touching pair (btBoxBoxDetector), pairs in (i, j) order
-// (A body touching THREE mesh objects with points at once loses the third manifold: counted like a queue overflow.)
-constexpr int BALL_REGION = 10, CAR_REGION = 11, CAR_WORLD_MAX = 10, MESH_MANIFOLDS = 2, OBJ_LISTED_MAX = 4;
-constexpr int8_t SID_MESH2 = 5;
-template <int NC> struct ContactLayout {
-    static constexpr int PAIR_POOL = NC == 2 ? 4 : (NC == 4 ? 8 : 12);   // (a six-car heap: nine points in one tick, `3v3_kickoff` tick 318 under another car order)
+// Fixed regions, so the bodies of an env can write side by side (collide_body, one lane per body on the device).  Two sets of capacities:
+//
+//   BIG = 0 (the device's LDS-resident TickWork)                        BIG = 1 (the fallback's TickWork in global memory; the host build)
+//   ball          [0, 10)      <= 2 mesh manifolds (one per mesh object     [0, 132)   one manifold for EVERY mesh object there can be (BP_MAX_OBJECTS),
+//                              touched, <= 4 points each), then <= 2 plane             then all four planes
+//                              manifolds of one point each
+//   car i         the same against the world, + 1 slot: its contact with the ball
+//   car pairs     PAIR_POOL points, <= 4 per touching pair                  4 points for every pair there is
+//   solver        MAXS contacts, 2 (MAXS + 1) rows                          every slot of the list
+//
+// The small set holds every tick of ordinary play; the few that do not fit -- a third mesh object with points on one body, a car-car point
+// beyond the pool, more contacts than solver rows: two events in 393 M env-ticks of learned 3v3 (profiles/r04h_soak.txt) -- used to LOSE
+// those points.  Since round 5 such a tick is detected before any contact callback has fired and the env's world step is redone from its
+// contacts on with the big set (arena_step.h:world_step_finish_big): nothing is dropped, by construction.
+constexpr int BP_MAX_OBJECTS = 32;   // mesh objects (.cmf files) a cell's listing mask tells apart (the game's soccar set has 16)
+template <int NC, int BIG = 0> struct ContactLayout {
+    static constexpr int IS_BIG = BIG;
+#ifdef RLG_TINY_LAYOUT   // test builds only: a small layout that overflows in ordinary play, so that the fallback is what the suites exercise
+    static constexpr int MESH_MANIFOLDS = BIG ? BP_MAX_OBJECTS : 1;
+    static constexpr int OBJ_LISTED_MAX = BIG ? BP_MAX_OBJECTS : 4;
+    static constexpr int PLANE_SLOTS = BIG ? 4 : 1;
+    static constexpr int PAIR_POOL_SMALL = 1, MAXS_SMALL = 3;
+#else
+    static constexpr int PAIR_POOL_SMALL = NC == 2 ? 4 : (NC == 4 ? 8 : 12);   // (a six-car heap: nine points in one tick, `3v3_kickoff` tick 318 under another car order)
+    static constexpr int MAXS_SMALL = 8 + 6 * NC;
+    static constexpr int MESH_MANIFOLDS = BIG ? BP_MAX_OBJECTS : 2;    // mesh manifolds WITH points of one body
+    static constexpr int OBJ_LISTED_MAX = BIG ? BP_MAX_OBJECTS : 4;    // mesh manifolds WITHOUT points that still take part in the island sort
+    static constexpr int PLANE_SLOTS = BIG ? 4 : 2;
+#endif
+    static constexpr int CAR_WORLD_MAX = 4 * MESH_MANIFOLDS + PLANE_SLOTS, BALL_REGION = CAR_WORLD_MAX, CAR_REGION = CAR_WORLD_MAX + 1;
+    static constexpr int PAIR_POOL = BIG ? (NC * (NC - 1) / 2) * 4 : PAIR_POOL_SMALL;
     static constexpr int PAIR_BASE = BALL_REGION + CAR_REGION * NC;
     static constexpr int MAXC = PAIR_BASE + PAIR_POOL;
     // manifolds of one tick at most: every dynamic body against <= OBJ_LISTED_MAX mesh objects (with or without points) + 4 planes, every
     // car against the ball, every car pair
     static constexpr int MAXM = (OBJ_LISTED_MAX + MESH_MANIFOLDS + 4) * (NC + 1) + NC + NC * (NC - 1) / 2;
+    static constexpr int MAXS = BIG ? MAXC : MAXS_SMALL;   // contacts the solver takes per tick
+    static constexpr int MAXR = 2 * ((BIG ? MAXS : 8 + 6 * NC) + 1);   // their normal + friction rows and the ball's averaged pair (the small layout's rows keep their size in the cut-down test build: other things borrow those LDS bytes)
+    using idx_t = typename std::conditional<BIG != 0, int16_t, int8_t>::type;        // a slot / row / manifold number
+    using stack_t = typename std::conditional<BIG != 0, uint32_t, uint16_t>::type;   // a (lo, hi) range of bt_quicksort
+    RLG_HD static int body_region(int body) { return body == 0 ? 0 : BALL_REGION + CAR_REGION * (body - 1); }
+    RLG_HD static int car_ball_slot(int ci) { return BALL_REGION + CAR_REGION * ci + CAR_WORLD_MAX; }
 };
-RLG_HD int body_region(int body) { return body == 0 ? 0 : BALL_REGION + CAR_REGION * (body - 1); }
-RLG_HD int car_ball_slot(int ci) { return BALL_REGION + CAR_REGION * ci + CAR_WORLD_MAX; }
+// Contact::sid of a body's mi-th mesh manifold with points (0 = the first; 1..4 are the planes)
+RLG_HD int8_t mesh_sid(int mi) { return (int8_t)(mi == 0 ? 0 : 4 + mi); }
 
 // ---- one manifold being filled (btManifoldResult::addContactPoint -> btPersistentManifold::addManifoldPoint) -------------
 // While a manifold fills up, its points sit in `pts[0..4)` with ra = m_localPointA (body a's frame) and rb = the world point on b.
@@ -202,7 +230,6 @@ RLG_HD void car_proxy_bracket(const Car& c, V3& in_lo, V3& in_hi, V3& out_lo, V3
 constexpr float BP_CELL = 370.f * UU2BT;
 constexpr int BP_CELLS_X = 25, BP_CELLS_Y = 33, BP_CELLS_Z = 7;   // ceil((maxPos - minPos) / cell), (-4500,-6000,0)..(4500,6000,2500) uu
 constexpr int BP_WORDS = (BP_CELLS_X * BP_CELLS_Y * BP_CELLS_Z + 31) / 32;
-constexpr int BP_MAX_OBJECTS = 32;   // mesh objects (.cmf files) a cell's listing mask tells apart (the game's soccar set has 16)
 RLG_HD void bp_cell_of(V3 lo, int& i, int& j, int& k) {
     const V3 mn = v3(-4500.f * UU2BT, -6000.f * UU2BT, 0.f * UU2BT);
     const float inv = 1.f / BP_CELL;          // btVector3::operator/(scalar) multiplies by the reciprocal
@@ -217,13 +244,15 @@ RLG_HD int bp_cell_index(int i, int j, int k) { return i * BP_CELLS_Y * BP_CELLS
 // ---- btAlignedObjectArray::quickSortInternal (LinearMath/btAlignedObjectArray.h), on (key, payload) pairs -----------------
 // The island manager sorts the manifolds by island id with this; elements with EQUAL keys get swapped around, so the exact
 // procedure matters.  Iterative: the two sub-ranges of a partition are disjoint, their order of treatment is free.
-RLG_HD void bt_quicksort(int8_t* key, int8_t* val, int n, uint16_t* stack) {
+template <class VT, class ST>
+RLG_HD void bt_quicksort(int8_t* key, VT* val, int n, ST* stack) {
+    constexpr int SH = sizeof(ST) * 4;   // a range (lo, hi) in one stack word: half its bits each
     if (n <= 1) return;
     int sp = 0;
-    stack[sp++] = (uint16_t)((0 << 8) | (n - 1));
+    stack[sp++] = (ST)(((ST)0 << SH) | (ST)(n - 1));
     while (sp > 0) {
-        const uint16_t r = stack[--sp];
-        const int lo = r >> 8, hi = r & 0xff;
+        const ST r = stack[--sp];
+        const int lo = (int)(r >> SH), hi = (int)(r & (((ST)1 << SH) - 1));
         int i = lo, j = hi;
         const int8_t x = key[(lo + hi) / 2];
         do {
@@ -231,12 +260,12 @@ RLG_HD void bt_quicksort(int8_t* key, int8_t* val, int n, uint16_t* stack) {
             while (x < key[j]) j--;
             if (i <= j) {
                 int8_t t = key[i]; key[i] = key[j]; key[j] = t;
-                t = val[i]; val[i] = val[j]; val[j] = t;
+                VT u = val[i]; val[i] = val[j]; val[j] = u;
                 i++; j--;
             }
         } while (i <= j);
-        if (lo < j) stack[sp++] = (uint16_t)((lo << 8) | j);
-        if (i < hi) stack[sp++] = (uint16_t)((i << 8) | hi);
+        if (lo < j) stack[sp++] = (ST)(((ST)lo << SH) | (ST)j);
+        if (i < hi) stack[sp++] = (ST)(((ST)i << SH) | (ST)hi);
     }
 }
 

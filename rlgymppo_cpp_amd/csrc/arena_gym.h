@@ -543,9 +543,9 @@ RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint
     }
 }
 
-template <int NC>
+template <int NC, int BIG>
 RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, MeshView mesh, const float* action_table,
-                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC>& W) {
+                         const int32_t* actions, uint32_t env_id, float* next_obs, size_t obs_row_stride, float* reward, int32_t* done_out, TickWork<NC, BIG>& W) {
     Snapshot<NC> S;
     gym_step_begin(A, G, cfg, action_table, actions);
     const uint32_t seed = tick_seed(cfg);

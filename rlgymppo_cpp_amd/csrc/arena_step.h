@@ -294,37 +294,76 @@ RLG_HD_T4 void collide_run_item(const Arena<NC>& A, MeshView mesh, int slot, Col
 //                             list (arena_contact.h); counts in W.body_n[body] / W.ball_hit[car]
 //   collide_merge  per env    the car-car pairs, the contact-added callbacks that touch other bodies, and the ORDER in which
 //                             the solver visits the contacts (W.cidx)
-// the end-of-algorithm refresh of a body's <= 2 mesh manifolds (points [0, first) and [first, n)): distances and world points rebuilt, points that
-// fail the refresh removed (manifold_refresh_static), the second manifold moved down behind what is left of the first; sets sid.  Returns the new n.
-RLG_HD int refresh_mesh_manifolds(Contact* out, int n, int first, const Body& b, float breaking) {
-    if (n == 0) return 0;
-    const int c0 = manifold_refresh_static(out, first, b, v3(0, 0, 0), breaking);
-    const int c1 = manifold_refresh_static(out + first, n - first, b, v3(0, 0, 0), breaking);
-    if (c0 != first) for (int k = 0; k < c1; k++) out[c0 + k] = out[first + k];
-    for (int k = 0; k < c0 + c1; k++) out[k].sid = (first < n && k >= c0) ? SID_MESH2 : 0;
-    return c0 + c1;
+// the end-of-algorithm refresh of a body's mesh manifolds (n_man windows; window j holds cnt[j] points from start[j] on): distances and world points
+// rebuilt, points that fail the refresh removed (manifold_refresh_static), what is left of the windows moved down back to back; sets sid and
+// rewrites start / cnt.  Returns the number of points left.
+template <int MM>
+RLG_HD int refresh_mesh_manifolds(Contact* out, int n_man, int (&start)[MM], int (&cnt)[MM], const Body& b, float breaking) {
+    int n = 0;
+    if constexpr (MM > 4) {
+        for (int j = 0; j < n_man; j++) {
+            const int c = manifold_refresh_static(out + start[j], cnt[j], b, v3(0, 0, 0), breaking);
+            if (start[j] != n) for (int k = 0; k < c; k++) out[n + k] = out[start[j] + k];
+            for (int k = 0; k < c; k++) out[n + k].sid = mesh_sid(j);
+            start[j] = n; cnt[j] = c; n += c;
+        }
+    } else {
+        RLG_UNROLL
+        for (int j = 0; j < MM; j++) {     // (static window numbers: the arrays stay in registers)
+            if (j >= n_man) break;
+            const int c = manifold_refresh_static(out + start[j], cnt[j], b, v3(0, 0, 0), breaking);
+            if (start[j] != n) for (int k = 0; k < c; k++) out[n + k] = out[start[j] + k];
+            for (int k = 0; k < c; k++) out[n + k].sid = mesh_sid(j);
+            start[j] = n; cnt[j] = c; n += c;
+        }
+    }
+    return n;
 }
-template <int NC, int MAXC, class NW>
-RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, int8_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(L);
+// Returns false when the body's contacts do not fit the layout LY (a mesh object with points beyond the last manifold window, a plane point beyond
+// the plane slots): nothing has been lost yet -- the caller redoes the env's world step with the big layout (world_step_finish_big).
+template <int NC, class LY, class NW>
+RLG_HD_BIG bool collide_body(Arena<NC>& A, MeshView mesh, Contact* list, int16_t* body_n, int8_t* ball_hit, int8_t (*body_obj)[LY::MESH_MANIFOLDS], int body, bool ball_asleep, NW nw) {
+    RLG_ASSUME_LDS(A);
+    if constexpr (!LY::IS_BIG) { RLG_ASSUME_LDS(*list); RLG_ASSUME_LDS(*body_n); RLG_ASSUME_LDS(*ball_hit); RLG_ASSUME_LDS(**body_obj); }   // (the small layout's TickWork is LDS-resident on the device)
+    constexpr int MM = LY::MESH_MANIFOLDS;
     const float r = K::BALL_RADIUS * UU2BT;
     const V3 bp = A.ball.b.pos;
-    Contact* out = &L.c[body_region(body)];
+    Contact* out = &list[LY::body_region(body)];
     int n = 0;
+    bool fits = true;
     // The mesh points arrive triangle by triangle in the reference's visiting order = object by object (arena_mesh.cpp).  One manifold per
     // object (Arena.cpp:1028-1054: one btBvhTriangleMeshShape + body per .cmf file): a new object opens the next window of <= 4 points.
-    int m_start = 0, m_cnt = 0, m_obj = -1, n_man = 0;
-    body_obj[body][0] = -1; body_obj[body][1] = -1;
+    // (the window arrays are indexed by a run-time manifold number: as plain arrays they live in scratch memory -- with the small layout's two
+    // windows a compare-select per access keeps them in registers; the big layout's thirty-two stay arrays)
+    int m_start[MM], m_cntv[MM];
+    auto wget = [&](const int (&a)[MM], int i) -> int {
+        if constexpr (MM > 4) return a[i];
+        else { int v = a[0]; RLG_UNROLL for (int q = 1; q < MM; q++) v = (i == q) ? a[q] : v; return v; }
+    };
+    auto wset = [&](int (&a)[MM], int i, int v) {
+        if constexpr (MM > 4) a[i] = v;
+        else { RLG_UNROLL for (int q = 0; q < MM; q++) a[q] = (i == q) ? v : a[q]; }
+    };
+    int m_obj = -1, n_man = 0;   // n_man: the window being filled
+#pragma unroll
+    for (int q = 0; q < MM; q++) { body_obj[body][q] = -1; m_start[q] = 0; m_cntv[q] = 0; }
     auto mesh_point = [&](const Body& b, const Cand& k, int obj, float breaking) -> bool {
         if (obj != m_obj) {
-            if (m_cnt > 0) { n_man++; m_start += m_cnt; m_cnt = 0; }   // the manifold filled so far is complete (one that kept no point is reused)
+            if (n_man < MM && wget(m_cntv, n_man) > 0) { const int nxt = wget(m_start, n_man) + wget(m_cntv, n_man); n_man++; if (n_man < MM) { wset(m_start, n_man, nxt); wset(m_cntv, n_man, 0); } }   // the manifold filled so far is complete (one that kept no point is reused)
             m_obj = obj;
         }
-        if (n_man >= MESH_MANIFOLDS) { RLG_DBG_COUNT(7); return false; }   // a third mesh object with points at once: its points are LOST (slot 7: rlgpu_env_lost_contact_count)
-        if (manifold_add_static(out + m_start, m_cnt, 4, b, k.n, k.pb, k.dist, breaking, k.pa) < 0) return false;
+        if (RLG_UNLIKELY(n_man >= MM)) { fits = false; return false; }   // one more mesh object with points than the layout has windows: the caller takes the big layout
+        const int ws = wget(m_start, n_man); int wc = wget(m_cntv, n_man);
+        const int slot = manifold_add_static(out + ws, wc, 4, b, k.n, k.pb, k.dist, breaking, k.pa);
+        wset(m_cntv, n_man, wc);
+        if (slot < 0) return false;
         body_obj[body][n_man] = (int8_t)obj;
-        n = m_start + m_cnt;
+        n = ws + wc;
         return true;
+    };
+    auto mesh_done = [&](const Body& b, float breaking) {   // the windows in use: [0, n_man] when the last one holds points, else [0, n_man)
+        const int used = n_man < MM ? (wget(m_cntv, n_man) > 0 ? n_man + 1 : n_man) : MM;
+        n = refresh_mesh_manifolds<MM>(out, used, m_start, m_cntv, b, breaking);
     };
     if (body == 0) {
         // A sleeping ball (ISLAND_SLEEPING, Arena.cpp:721-727) and the static world bodies (put to sleep by
@@ -334,7 +373,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             // ball vs mesh: one manifold for the whole mesh body, a point per triangle in visiting order (btConvexConcaveCollisionAlgorithm.cpp:
             // 76-160 -> btSphereTriangleCollisionAlgorithm on the shared manifold), reduced to 4 by manifold_replace_index
             nw.ball_mesh(A, mesh, [&](const Cand& k, int obj) { mesh_point(A.ball.b, k, obj, CBT_BALL); });
-            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, A.ball.b, CBT_BALL);
+            mesh_done(A.ball.b, CBT_BALL);
             for (int k = 0; k < n; k++) { out[k].a = 0; out[k].b = -1; out[k].special = 1; }
             // ball vs planes (btConvexPlaneCollisionAlgorithm.cpp:92-121): the sphere's support vertex towards the plane
             for (int i = 0; i < 4; i++) {
@@ -344,11 +383,12 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                 V3 vtx = dir * r;                                      // |dir| = 1 exactly for the axis-aligned planes
                 V3 vip = vtx + (bp + (-po));
                 // the ball in the basis a user state setter gave it (BallState::rotMat, constant under ArenaConfig::noBallRot; tests/golden/ballrot_golden.npz)
-                if (!(A.ball.b.rot.r0.x == 1.f && A.ball.b.rot.r1.y == 1.f && A.ball.b.rot.r2.z == 1.f)) {
+                if (RLG_UNLIKELY(!(A.ball.b.rot.r0.x == 1.f && A.ball.b.rot.r1.y == 1.f && A.ball.b.rot.r2.z == 1.f))) {
                     vtx = normalized(tmul(A.ball.b.rot, -pn)) * r; vip = (A.ball.b.rot * vtx) + (bp + (-po));
                 }
                 float dist = dot(pn, vip);
-                if (!(dist < CBT_BALL) || n >= BALL_REGION) continue;
+                if (!(dist < CBT_BALL)) continue;
+                if (RLG_UNLIKELY(n >= LY::BALL_REGION)) { fits = false; continue; }
                 V3 pb = (vip - pn * dist) + po;
                 int cnt = 0;
                 if (manifold_add_static(&out[n], cnt, 1, A.ball.b, pn, pb, dist, CBT_BALL) < 0) continue;
@@ -372,7 +412,7 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                     car.flags |= CF_WORLD_CONTACT; car.world_contact_normal = k.n_raw;   // Arena::_BtCallback_OnCarWorldCollision (Arena.cpp:420-427) sees the point BEFORE btAdjustInternalEdgeContacts (Arena.cpp:276-280)
                 }
             });
-            n = refresh_mesh_manifolds(out, n, n_man > 0 ? m_start : n, cb, CBT_CAR);
+            mesh_done(cb, CBT_CAR);
             for (int k = 0; k < n; k++) { out[k].a = (int8_t)(1 + ci); out[k].b = -1; out[k].special = 0; }
             // planes: ONE contact per plane and tick, the hitbox's support vertex towards the plane (btConvexPlaneCollisionAlgorithm.cpp:
             // 92-121; the perturbation passes are off: m_minimumPointsPerturbationThreshold = 0, btConvexPlaneCollisionAlgorithm.h:62-63)
@@ -385,7 +425,8 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                 V3 vtx = v3(dirl.x >= 0.f ? h.x : -h.x, dirl.y >= 0.f ? h.y : -h.y, dirl.z >= 0.f ? h.z : -h.z);   // btBoxShape::localGetSupportingVertex
                 V3 vip = (cb.rot * vtx) + (bc + (-po));           // convexInPlaneTrans(vtx): origin = convex origin - plane origin
                 float dist = dot(pn, vip);                             // plane constant 0 in the plane body's frame (Arena.cpp:1067-1101)
-                if (!(dist < CBT_CAR) || n >= CAR_WORLD_MAX) continue;
+                if (!(dist < CBT_CAR)) continue;
+                if (RLG_UNLIKELY(n >= LY::CAR_WORLD_MAX)) { fits = false; continue; }
                 V3 pb = (vip - pn * dist) + po;                        // planeObjWrap->getWorldTransform() * vtxInPlaneProjected
                 int cnt = 0;
                 if (manifold_add_static(&out[n], cnt, 1, cb, pn, pb, dist, CBT_CAR) < 0) continue;
@@ -403,8 +444,8 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
             // (the hitbox's box reaches at most HITBOX_REACH from its centre along every axis, the ball's r + 0.08: farther apart than both along some axis, the boxes cannot touch)
             const V3 sep = bp - bc; const float far = HITBOX_REACH + (r + 0.08f);
             const bool maybe = !(fabsf(sep.x) > far || fabsf(sep.y) > far || fabsf(sep.z) > far);
-            if (maybe) { sphere_shape_aabb(bp, sl, sh_); hitbox_shape_aabb(cb.pos, cb.rot, hl, hh); }
-            if (maybe && aabb_touch(hl, hh, sl, sh_)) {   // the child shapes' boxes must touch before the pair's algorithm runs at all (btCompoundCollisionAlgorithm.cpp:333-358)
+            if (RLG_UNLIKELY(maybe)) { sphere_shape_aabb(bp, sl, sh_); hitbox_shape_aabb(cb.pos, cb.rot, hl, hh); }
+            if (RLG_UNLIKELY(maybe && aabb_touch(hl, hh, sl, sh_))) {   // the child shapes' boxes must touch before the pair's algorithm runs at all (btCompoundCollisionAlgorithm.cpp:333-358)
                 GjkOut g; bool deep = false;
                 if (gjk_box_sphere(bc, cb.rot, hitbox_core(), BOX_MARGIN, bp, r, CBT_BALL, g, deep)) {
                     if (!(g.dist > CBT_BALL)) { pn = g.n; pb = g.pb; dist = g.dist; have = true; }
@@ -412,15 +453,16 @@ RLG_HD_BIG void collide_body(Arena<NC>& A, MeshView mesh, ContactList<MAXC>& L, 
                     pn = -pn; pb = bp + pn * r; have = true;   // normal on the ball, pointing at the car; the point on the ball
                 }
             }
-            if (have) {
-                Contact& c = L.c[car_ball_slot(ci)];
+            if (RLG_UNLIKELY(have)) {
+                Contact& c = list[LY::car_ball_slot(ci)];
                 manifold_point_dynamic(c, cb, A.ball.b, pn, pb, dist);
                 c.a = (int8_t)(1 + ci); c.b = 0; c.sid = 0; c.special = 0;
                 ball_hit[ci] = 1;
             }
         }
     }
-    body_n[body] = (int8_t)n;
+    body_n[body] = (int16_t)n;
+    return fits;
 }
 
 // ---- sequential-impulse solve (btSequentialImpulseConstraintSolver.cpp:795-983,1003-1211,1601-1926) ----------
@@ -430,16 +472,18 @@ struct SolverBody {
     float inv_m;
     bool active;
 };
-struct Row {   // 22 words: kept small because the device kernel holds its envs' rows in LDS
+template <class IDX>
+struct RowT {   // 22 words with IDX = int8_t: kept small because the device kernel holds its envs' rows in LDS
     int8_t a, b;         // body indices (b = -1: static world)
-    int8_t fric_of;      // friction rows: index of their normal row (< MAXR <= 90); -1 for normal rows
+    IDX fric_of;         // friction rows: index of their normal row; -1 for normal rows
     int8_t skip;         // individual ball-world rows are not iterated (m_isSpecial), only their split impulse
     V3 n1, r1xn, r2xn, ang_a, ang_b;   // contactNormal2 is -n1 whenever b >= 0
     float jac, rhs, rhs_pen, applied, applied_push, friction;
 };
+using Row = RowT<int8_t>;
 
-template <int NB>
-RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, float dist, float fric, float rest, bool has_b) {
+template <class ROW, int NB>
+RLG_HD void row_setup_normal(ROW& r, const Contact& c, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, float dist, float fric, float rest, bool has_b) {
     const float dt = TICK_DT;
     SolverBody& A = B[c.a];
     r.a = (int8_t)c.a; r.b = (int8_t)(has_b ? c.b : -1);
@@ -472,8 +516,8 @@ RLG_HD void row_setup_normal(Row& r, const Contact& c, SolverBody (&B)[NB], V3 n
     r.skip = 0; r.fric_of = -1;
 }
 
-template <int NB>
-RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, bool has_b) {
+template <class ROW, int NB>
+RLG_HD void row_setup_friction(ROW& r, int normal_idx, const ROW& nr, SolverBody (&B)[NB], V3 n, V3 ra, V3 rb, bool has_b) {
     SolverBody& A = B[nr.a];
     // btSolverBody::getVelocityInLocalPointNoDelta (btSolverBody.h:133-139): includes the external impulses
     V3 vel1 = (A.v + A.ext_f) + cross(A.w + A.ext_t, ra);
@@ -506,8 +550,8 @@ RLG_HD void row_setup_friction(Row& r, int normal_idx, const Row& nr, SolverBody
 // the row solvers are the reference's SSE2 variants (btSequentialImpulseConstraintSolver.cpp:102-110,149-176,207-232,317-349; SOLVER_SIMD is
 // on): their three-term dot product adds x to (y + z), not (x + y) to z
 RLG_HD float sdot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
-template <int NB>
-RLG_HD float row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
+template <class ROW, int NB>
+RLG_HD float row_resolve(ROW& c, SolverBody (&B)[NB], float lo, float hi, bool lower_only) {
     SolverBody& A = B[c.a];
     const int b = c.b;
     SolverBody& Bb = B[b >= 0 ? b : 0];
@@ -530,8 +574,8 @@ RLG_HD float row_resolve(Row& c, SolverBody (&B)[NB], float lo, float hi, bool l
     if (b >= 0) { Bb.dv = b_dv + ((-n1) * b_im) * delta; Bb.dw = b_dw + ang_b * delta; }
     return delta;
 }
-template <int NB>
-RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
+template <class ROW, int NB>
+RLG_HD float row_resolve_split(ROW& c, SolverBody (&B)[NB]) {
     if (c.rhs_pen == 0.f) return 0.f;
     SolverBody& A = B[c.a];
     const int b = c.b;
@@ -557,13 +601,15 @@ RLG_HD float row_resolve_split(Row& c, SolverBody (&B)[NB]) {
 
 // Per-env scratch of one tick.  It is a parameter (not locals) so the device kernel can place it in LDS next to the
 // env's state: as stack locals these arrays are dynamically indexed and would live in scratch memory.
-template <int NC>
+template <int NC, int BIG = 0>
 struct TickWork {
+    using LY = ContactLayout<NC, BIG>;
+    using idx_t = typename LY::idx_t;
     static constexpr int NB = NC + 1;
-    static constexpr int MAXC = ContactLayout<NC>::MAXC;
-    static constexpr int MAXM = ContactLayout<NC>::MAXM;
-    static constexpr int MAXS = 8 + 6 * NC;        // contacts the solver takes per tick (the rest of a fuller list is dropped: never seen in play)
-    static constexpr int MAXR = 2 * (MAXS + 1);    // their normal + friction rows and the ball's averaged pair
+    static constexpr int MAXC = LY::MAXC;
+    static constexpr int MAXM = LY::MAXM;
+    static constexpr int MAXS = LY::MAXS;          // contacts the solver takes per tick (more than that: the caller takes the big layout)
+    static constexpr int MAXR = LY::MAXR;          // their normal + friction rows and the ball's averaged pair
     // The cars' tick context lives from car_tick_begin to car_pre_tick_finish, the contact list from tick_world_begin (which follows) to
     // solver_finish: the device kernels (RLG_TICKWORK_OVERLAY) keep them in the same LDS bytes; the host build keeps both (the oracle's
     // debug dumps read the wheels after the tick).
@@ -574,20 +620,22 @@ struct TickWork {
     CarTickCtx ctx[NC];
 #endif
     union {
-        Row R[MAXR];       // solver rows: built after the contact list is complete ...
+        RowT<idx_t> R[MAXR];   // solver rows: built after the contact list is complete ...
         CollideQueue<NC> Q;   // ... narrowphase items: dead by then
     };
     SolverBody B[NB];      // (directly behind the union: with the queue's dead tail one stretch that nothing uses during the narrowphase, rlgpu_env.hip)
     uint64_t pad_mask[NC];           // boost pads car i touches this tick (bit p), from pads_check_car
     bool ball_asleep;
-    int8_t cidx[MAXC];               // slot in L of the k-th contact in solver order (collide_merge)
-    int8_t nrow[MAXS], frow[MAXS];   // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)
-    int8_t body_n[8];                // world contacts in each body's region of L (collide_body)
+    int8_t needs_big;                // this tick's contacts do not fit the layout (collide_body / collide_merge): the env's world step is redone with the big one
+    idx_t cidx[MAXC];                // slot in L of the k-th contact in solver order (collide_merge)
+    idx_t nrow[MAXS], frow[MAXS];    // solver rows of the k-th contact (normal / friction), -1 = none (solver_prepare)
+    int16_t body_n[8];               // world contacts in each body's region of L (collide_body)
     int8_t bp_moved[8];              // the body's proxy changed its broadphase cell this tick (bp_history_cell)
-    int8_t body_obj[8][MESH_MANIFOLDS];   // the mesh object of the body's first / second mesh manifold with points, -1 = none
+    int8_t body_obj[8][LY::MESH_MANIFOLDS];   // the mesh object of the body's k-th mesh manifold with points, -1 = none
     int8_t ball_hit[NC];             // car i touches the ball: its contact sits in car_ball_slot(i)
-    int8_t man_key[MAXM], man_val[MAXM], man_first[MAXM], man_cnt[MAXM];   // this tick's manifolds (collide_merge)
-    uint16_t man_stack[MAXM];
+    int8_t man_key[MAXM], man_cnt[MAXM]; idx_t man_val[MAXM], man_first[MAXM];   // this tick's manifolds (collide_merge)
+    typename LY::stack_t man_stack[MAXM];
+    int8_t touch_p[LY::PAIR_POOL], touch_q[LY::PAIR_POOL], touch_cnt[LY::PAIR_POOL]; idx_t touch_first[LY::PAIR_POOL];   // the car pairs with points this tick: bodies (1 + car, lower first), their slots in L (collide_merge)
     int16_t n_normal, n_rows;
 };
 // (with the default caps the narrowphase queue fits inside the solver rows it shares LDS with; bigger caps -- RLG_BODY_CAND, RLG_ITEM_CAP -- grow the union)
@@ -595,11 +643,13 @@ struct TickWork {
 // Which manifolds exist this tick, in the order the island manager hands them to the solver, and with them the solver order of the
 // contacts (arena_contact.h explains where each piece comes from).  Only reached when at least two manifolds carry points: proxy
 // boxes (with the predicted rotation), broadphase cells, union-find and the quickSort are all that is needed to ORDER them.
-template <int NC, int MAXC>
-RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n_touching, const int8_t* tp, const int8_t* tq, const int8_t* tfirst, const int8_t* tcnt) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
-    using LY = ContactLayout<NC>;
-    ContactList<MAXC>& L = W.L;
+template <int NC, int BIG>
+RLG_HD_T4 bool collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, int n_touching) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
+    using LY = ContactLayout<NC, BIG>;
+    using idx_t = typename LY::idx_t;
+    constexpr int MESH_MANIFOLDS = LY::MESH_MANIFOLDS, OBJ_LISTED_MAX = LY::OBJ_LISTED_MAX;
+    ContactList<LY::MAXC>& L = W.L;
     constexpr int NB = NC + 1;
     // the mesh objects (one per .cmf file): each has its own proxy -- a box and the broadphase cells it is listed in (arena_mesh.cpp)
     const int n_obj = mesh.n_tris > 0 ? (mesh.bp ? (int)mesh.bp[0] : 1) : 0;
@@ -645,16 +695,16 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
     int8_t root[NB];
     for (int b = 0; b < NB; b++) root[b] = (int8_t)b;
     auto find = [&](int x) { while (root[x] != x) { root[x] = root[root[x]]; x = root[x]; } return x; };
-    int nm = 0;
-    int8_t (&mkey)[LY::MAXM] = W.man_key; int8_t (&mval)[LY::MAXM] = W.man_val;   // key: body0 for now, island id later; val: manifold number
-    int8_t (&mfirst)[LY::MAXM] = W.man_first; int8_t (&mcnt)[LY::MAXM] = W.man_cnt;
+    int nm = 0; bool fits = true;
+    int8_t (&mkey)[LY::MAXM] = W.man_key; idx_t (&mval)[LY::MAXM] = W.man_val;   // key: body0 for now, island id later; val: manifold number
+    idx_t (&mfirst)[LY::MAXM] = W.man_first; int8_t (&mcnt)[LY::MAXM] = W.man_cnt;
     for (int p = 0; p < NB; p++) {
         if (!live[p]) continue;
         // statics of the cell, in creation order; a sleeping ball makes no manifold with them (needsCollision)
         if (!(p == 0 && W.ball_asleep)) {
             V3 xlo = plo[p], xhi = phi[p];     // a car's child algorithm also needs the hitbox's own box to reach the other shape's (btCompoundCollisionAlgorithm.cpp:333-358)
             if (p > 0) hitbox_shape_aabb(A.cars[p - 1].b.pos, A.cars[p - 1].b.rot, xlo, xhi);
-            const int base = body_region(p), nw_ = W.body_n[p];
+            const int base = LY::body_region(p), nw_ = W.body_n[p];
             int k = 0, mi = 0, n_listed = 0;
             // the mesh objects listed in the body's cell, in creation (= file) order, each a manifold of its own, with or without points; the
             // (<= 2) manifolds that DO hold points are merged in at their objects' places
@@ -667,20 +717,20 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
                 if (listed && p > 0) listed = aabb_touch(xlo, xhi, mlo, mhi);
                 int cnt = 0; const int first = base + k;
                 if (mi < MESH_MANIFOLDS && W.body_obj[p][mi] == o) {
-                    const int8_t want = mi == 0 ? (int8_t)0 : SID_MESH2;
+                    const int8_t want = mesh_sid(mi);
                     while (k < nw_ && L.c[base + k].sid == want) { k++; cnt++; }
                     mi++;
                 }
                 if (!(listed || cnt > 0)) continue;
-                if (cnt == 0 && n_listed >= OBJ_LISTED_MAX) continue;     // (more empty manifolds than the list holds: only their place in the sort is lost)
-                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++; n_listed++; }
+                if (cnt == 0 && n_listed >= OBJ_LISTED_MAX) { fits = false; continue; }     // (more empty manifolds than the list holds: their place in the sort would be lost)
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (idx_t)first; mcnt[nm] = (int8_t)cnt; nm++; n_listed++; } else fits = false;
             }
             for (int s = 1; s <= 4; s++) {
                 int cnt = 0, first = base + k;
                 if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
                 V3 slo, shi; world_plane_aabb(s - 1, slo, shi);
                 if (!aabb_touch(plo[p], phi[p], slo, shi) || !aabb_touch(xlo, xhi, slo, shi)) continue;
-                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++; }
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (idx_t)first; mcnt[nm] = (int8_t)cnt; nm++; } else fits = false;
             }
         }
         // dynamic partners filed in the same cell neighbourhood with overlapping proxy boxes (pairs are made by the lower body)
@@ -704,26 +754,28 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
                 const Car& c = A.cars[q - 1];
                 sphere_shape_aabb(A.ball.b.pos, l1, h1); hitbox_shape_aabb(c.b.pos, c.b.rot, l2, h2);
                 if (!aabb_touch(l2, h2, l1, h1)) continue;
-                mkey[nm] = (int8_t)q; mfirst[nm] = (int8_t)car_ball_slot(q - 1); mcnt[nm] = W.ball_hit[q - 1]; nm++;
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)q; mfirst[nm] = (idx_t)LY::car_ball_slot(q - 1); mcnt[nm] = W.ball_hit[q - 1]; nm++; } else fits = false;
             } else {
                 const Car& ca = A.cars[p - 1]; const Car& cb = A.cars[q - 1];
                 hitbox_shape_aabb(ca.b.pos, ca.b.rot, l1, h1); hitbox_shape_aabb(cb.b.pos, cb.b.rot, l2, h2);
                 if (!aabb_touch(l1, h1, l2, h2)) continue;
                 int first = LY::PAIR_BASE, cnt = 0;
-                for (int k = 0; k < n_touching; k++) if (tp[k] == p && tq[k] == q) { first = tfirst[k]; cnt = tcnt[k]; }
-                mkey[nm] = (int8_t)q; mfirst[nm] = (int8_t)first; mcnt[nm] = (int8_t)cnt; nm++;
+                for (int k = 0; k < n_touching; k++) if (W.touch_p[k] == p && W.touch_q[k] == q) { first = W.touch_first[k]; cnt = W.touch_cnt[k]; }
+                if (nm < LY::MAXM) { mkey[nm] = (int8_t)q; mfirst[nm] = (idx_t)first; mcnt[nm] = (int8_t)cnt; nm++; } else fits = false;
             }
         }
     }
+    if (!fits) return false;   // (the caller takes the big layout, whose list holds every manifold there can be)
     // island id of a manifold = island of its body0 (always dynamic here); quickSort by it
-    for (int m = 0; m < nm; m++) { mkey[m] = (int8_t)find(mkey[m]); mval[m] = (int8_t)m; }
+    for (int m = 0; m < nm; m++) { mkey[m] = (int8_t)find(mkey[m]); mval[m] = (idx_t)m; }
     bt_quicksort(mkey, mval, nm, W.man_stack);
     int n = 0;
     for (int m = 0; m < nm; m++) {
         const int mi = mval[m];
-        for (int k = 0; k < mcnt[mi]; k++) W.cidx[n++] = (int8_t)(mfirst[mi] + k);
+        for (int k = 0; k < mcnt[mi]; k++) W.cidx[n++] = (idx_t)(mfirst[mi] + k);
     }
     L.n = n;
+    return true;
 }
 
 // btRSBroadphase keeps, per cell, the list of dynamic proxies filed under it and the 26 cells around it (btRSBroadphase.h:65-72).  When
@@ -733,9 +785,9 @@ RLG_HD_T4 void collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int n
 // unstable island sort turns another array into another solver order once an island holds several manifolds (a heap of cars).  This is
 // the per-tick bookkeeping: the cell of every active body's proxy, and a new arrival rank for those that changed it.
 // In two parts: per body (a lane each on the device, with the body's contacts) the cell, per env the ranks.
-template <int NC>
-RLG_HD_SMALL void bp_history_cell(Arena<NC>& A, TickWork<NC>& W, int b) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void bp_history_cell(Arena<NC>& A, TickWork<NC, BIG>& W, int b) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
     W.bp_moved[b] = 0;
 #ifdef RLG_EXPERIMENT_NO_BP_TRACK   /* what-if build only (tools/build_variant.sh): prices the bookkeeping */
     return;
@@ -761,9 +813,9 @@ RLG_HD_SMALL void bp_history_cell(Arena<NC>& A, TickWork<NC>& W, int b) {
     const uint32_t c = (uint32_t)bp_cell_index(i, j, k);
     if (c != (h >> 3)) { A.bp_hist[b] = (uint16_t)((c << 3) | (h & 7u)); W.bp_moved[b] = 1; }
 }
-template <int NC>
-RLG_HD_SMALL void bp_history_ranks(Arena<NC>& A, const TickWork<NC>& W) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void bp_history_ranks(Arena<NC>& A, const TickWork<NC, BIG>& W) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
     constexpr int NB = NC + 1;
     uint32_t moved = 0u;
     for (int b = 0; b < NB; b++) moved |= W.bp_moved[b] ? 1u << b : 0u;
@@ -780,34 +832,26 @@ RLG_HD_SMALL void bp_history_ranks(Arena<NC>& A, const TickWork<NC>& W) {
     for (int b = 0; b < NB; b++) A.bp_hist[b] = (uint16_t)((A.bp_hist[b] & ~7u) | (uint32_t)nr[b]);
 }
 
-// per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts
-template <int NC, int MAXC, class NW>
-RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
-    using LY = ContactLayout<NC>;
-    ContactList<MAXC>& L = W.L;
+// per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts.
+// Returns false -- BEFORE any callback has fired or any history has been written -- when the tick's contacts do not fit the layout (a car-car
+// point beyond the pair pool, more contacts than the solver has rows for): the caller redoes the env's world step with the big layout.
+template <int NC, int BIG, class NW>
+RLG_HD_BIG bool collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, TickEvents& ev, bool& ball_car_touch, NW nw) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
+    using LY = ContactLayout<NC, BIG>;
+    using idx_t = typename LY::idx_t;
+    ContactList<LY::MAXC>& L = W.L;
     ball_car_touch = false;
-    bp_history_ranks(A, W);
-    // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
-    // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
-    int n = 0, ball_man = 0, max_man = 0;
-    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (int8_t)k; ball_man += (k == 0 || L.c[k].sid != L.c[k - 1].sid); }
-    int car_man[NC];
-    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
-    for (int ci = 0; ci < NC; ci++) {
-        const int base = body_region(1 + ci);
-        int cm = 0;
-        if (W.ball_hit[ci]) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[car_ball_slot(ci)].rb); W.cidx[n++] = (int8_t)car_ball_slot(ci); cm++; ball_man++; }
-        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (int8_t)(base + k); cm += (k == 0 || L.c[base + k].sid != L.c[base + k - 1].sid); }
-        car_man[ci] = cm;
-    }
-    // car-car pairs: body0 of the manifold = the higher car (arena_contact.h); the gate is conservative, the exact box test follows
-    int8_t tp[LY::PAIR_POOL], tq[LY::PAIR_POOL], tfirst[LY::PAIR_POOL], tcnt[LY::PAIR_POOL];
+    // car-car pairs first, points only: body0 of the manifold = the higher car (arena_contact.h); the gate is conservative, the exact box test
+    // follows.  (Nothing here depends on what the callbacks below change: car_collides reads the tick-start `frozen`.)
     int n_touching = 0, n_pair = 0;
-    for (int ia = 0; ia < NC; ia++) {
-        for (int ib = ia + 1; ib < NC; ib++) {
+    int pair_man[NC];   // manifolds with points each car shares with other cars
+    for (int ci = 0; ci < NC; ci++) pair_man[ci] = 0;
+    bool fits = true;
+    for (int ia = 0; ia < NC && fits; ia++) {
+        for (int ib = ia + 1; ib < NC && fits; ib++) {
             const Car& ca = A.cars[ia]; const Car& cb = A.cars[ib];
-            if (!car_collides(ca) || !car_collides(cb) || !cars_maybe_touch(A, ia, ib)) continue;
+            if (RLG_LIKELY(!car_collides(ca) || !car_collides(cb) || !cars_maybe_touch(A, ia, ib))) continue;
             V3 l1, h1, l2, h2;
             hitbox_shape_aabb(ca.b.pos, ca.b.rot, l1, h1); hitbox_shape_aabb(cb.b.pos, cb.b.rot, l2, h2);
             if (!aabb_touch(l1, h1, l2, h2)) continue;
@@ -817,34 +861,69 @@ RLG_HD_BIG void collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, Tick
             int cnt = 0;
             for (int k = 0; k < nc; k++) {
                 if (cs[k].dist > CBT_CAR) continue;
-                if (n_pair >= LY::PAIR_POOL) { RLG_DBG_COUNT(7); break; }     // a car-car point LOST (never seen with the present pool sizes; slot 7: rlgpu_env_lost_contact_count)
+                if (n_pair >= LY::PAIR_POOL) { fits = false; break; }     // a car-car point beyond the pool: the big layout has room for every pair's four
                 Contact& c = L.c[LY::PAIR_BASE + n_pair];
                 manifold_point_dynamic(c, cb.b, ca.b, cs[k].n, cs[k].pb, cs[k].dist);
                 c.a = (int8_t)(1 + ib); c.b = (int8_t)(1 + ia); c.sid = 0; c.special = 0;
-                W.cidx[n++] = (int8_t)(LY::PAIR_BASE + n_pair);
                 n_pair++; cnt++;
-                // Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car, car2): equal user indices, no swap (Arena.cpp:231-240)
-                on_car_car_contact(A, ib, ia, tmul(cb.b.rot, c.ra), tmul(ca.b.rot, c.rb), ev);
             }
-            if (cnt > 0 && n_touching < LY::PAIR_POOL) { tp[n_touching] = (int8_t)(1 + ia); tq[n_touching] = (int8_t)(1 + ib); tfirst[n_touching] = (int8_t)first; tcnt[n_touching] = (int8_t)cnt; n_touching++; car_man[ia]++; car_man[ib]++; }
+            if (cnt > 0 && n_touching < LY::PAIR_POOL) {
+                W.touch_p[n_touching] = (int8_t)(1 + ia); W.touch_q[n_touching] = (int8_t)(1 + ib); W.touch_first[n_touching] = (idx_t)first; W.touch_cnt[n_touching] = (int8_t)cnt; n_touching++;
+                pair_man[ia]++; pair_man[ib]++;
+            }
         }
     }
+    int total = W.body_n[0] + n_pair;
+    for (int ci = 0; ci < NC; ci++) total += (W.ball_hit[ci] ? 1 : 0) + W.body_n[1 + ci];
+    if (RLG_UNLIKELY(!fits || total > LY::MAXS)) return false;
+    bp_history_ranks(A, W);    // (idempotent for a given set of movers: the big layout's second run files the same ranks)
+    // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
+    // that touch it: while no body has two, every row stands alone -- any order gives bit-identical results -- and slot order is used.
+    int n = 0, ball_man = 0, max_man = 0;
+    for (int k = 0; k < W.body_n[0]; k++) { W.cidx[n++] = (idx_t)k; ball_man += (k == 0 || L.c[k].sid != L.c[k - 1].sid); }
+    int car_man[NC];
+    for (int ci = 0; ci < NC; ci++) {
+        const int base = LY::body_region(1 + ci);
+        int cm = 0;
+        if (RLG_UNLIKELY(W.ball_hit[ci])) { W.cidx[n++] = (idx_t)LY::car_ball_slot(ci); cm++; ball_man++; }
+        for (int k = 0; k < W.body_n[1 + ci]; k++) { W.cidx[n++] = (idx_t)(base + k); cm += (k == 0 || L.c[base + k].sid != L.c[base + k - 1].sid); }
+        car_man[ci] = cm + pair_man[ci];
+    }
+    if (RLG_UNLIKELY(n_touching > 0))
+        for (int t = 0; t < n_touching; t++)
+            for (int k = 0, first = W.touch_first[t], cnt = W.touch_cnt[t]; k < cnt; k++) W.cidx[n++] = (idx_t)(first + k);
     L.n = n;
     max_man = ball_man;
     for (int ci = 0; ci < NC; ci++) max_man = car_man[ci] > max_man ? car_man[ci] : max_man;
-    // some body is held by two manifolds: the reference's pair / island order decides which of them the solver visits first
-    if (max_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
+    // some body is held by two manifolds: the reference's pair / island order decides which of them the solver visits first.  (Nothing the
+    // callbacks below change is read by it: poses, the tick-start `frozen`, the broadphase history.)
+    if (RLG_UNLIKELY(max_man >= 2)) { if (!collide_order<NC, BIG>(A, mesh, W, n_touching)) return false; }
 #ifdef RLG_EXPERIMENT_ORDER_TWICE   // what-if build only: prices the order emulation in place (it is idempotent)
-    if (max_man >= 2) collide_order<NC, MAXC>(A, mesh, W, n_touching, tp, tq, tfirst, tcnt);
+    if (max_man >= 2) collide_order<NC, BIG>(A, mesh, W, n_touching);
 #endif
+    // ---- from here on the tick is committed to this layout: the contact-added callbacks that touch other bodies ----
+    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
+    for (int ci = 0; ci < NC; ci++)
+        if (RLG_UNLIKELY(W.ball_hit[ci])) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[LY::car_ball_slot(ci)].rb); }
+    // ... and the car-car callbacks, pair by pair, point by point (Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car,
+    // car2): equal user indices, no swap, Arena.cpp:231-240)
+    if (RLG_UNLIKELY(n_touching > 0)) for (int t = 0; t < n_touching; t++) {
+        const int ia = W.touch_p[t] - 1, ib = W.touch_q[t] - 1;
+        for (int k = 0, first = W.touch_first[t], cnt = W.touch_cnt[t]; k < cnt; k++) {
+            const Contact c = L.c[first + k];
+            on_car_car_contact(A, ib, ia, tmul(A.cars[ib].b.rot, c.ra), tmul(A.cars[ia].b.rot, c.rb), ev);
+        }
+    }
+    return true;
 }
 
 // world step, first part (per env): sleep flag, gravity, damping; leaves an empty narrowphase queue
-template <int NC>
-RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
+template <int NC, int BIG>
+RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC, BIG>& W) {
     const float dt = TICK_DT;
     // ball sleep flag (Arena.cpp:721-727): taken at tick start by tick_build_candidates (nothing touches the ball before here)
     const bool ball_asleep = W.ball_asleep;
+    W.needs_big = 0;
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
     const float g = K::GRAVITY_Z * UU2BT;
     // btRigidBody::setGravity keeps acceleration * (1 / m_inverseMass) (btRigidBody.cpp:132-139): not quite mass * g in float
@@ -861,24 +940,25 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC>& W) {
 //   solver_rows      per contact   its normal row and its friction row (btSequentialImpulseConstraintSolver.cpp:1003-1211)
 //   solver_iterate   per env       split-impulse + velocity iterations (:1601-1877) -- sequential by nature (Gauss-Seidel)
 //   solver_finish    per body      write back (:1878-1904), integrateTransforms (btDiscreteDynamicsWorld.cpp:889-1027), clearForces
-template <int NC>
-RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC, BIG>& W, bool queued) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
     const float dt = TICK_DT;
     constexpr int NB = NC + 1;
-    constexpr int MAXC = TickWork<NC>::MAXC;
+    constexpr int MAXC = TickWork<NC, BIG>::MAXC;
     ContactList<MAXC>& L = W.L;
     SolverBody (&B)[NB] = W.B;
-    Row (&R)[TickWork<NC>::MAXR] = W.R;
+    auto& R = W.R;
     const bool ball_asleep = W.ball_asleep;
 #ifdef RLG_QSTAT
     RLG_QSTAT(W.Q);   // host-side statistics hook of tools (queue fill levels before the rows overwrite them)
 #endif
 
-    bool touch;
-    if (queued && !W.Q.overflow) collide_merge<NC, MAXC>(A, mesh, W, ev, touch, NarrowQueued<NC>{W.Q});
-    else collide_merge<NC, MAXC>(A, mesh, W, ev, touch, NarrowInline());
-    if (L.n > TickWork<NC>::MAXS) L.n = TickWork<NC>::MAXS;
+    bool touch = false, fits;
+    if (RLG_UNLIKELY(W.needs_big)) return;      // (a body's contacts did not fit: collide_body)
+    if (RLG_LIKELY(queued && !W.Q.overflow)) fits = collide_merge<NC, BIG>(A, mesh, W, ev, touch, NarrowQueued<NC>{W.Q});
+    else fits = collide_merge<NC, BIG>(A, mesh, W, ev, touch, NarrowInline());
+    if (RLG_UNLIKELY(!fits)) { W.needs_big = 1; return; }   // (with the big layout: cannot happen, every pair and every slot has a row)
     const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 #ifdef RLG_PROF_SPLIT_PREPARE
     RLG_PROF(7);
@@ -915,9 +995,9 @@ RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, Tick
 // the solver's view of one body (btSequentialImpulseConstraintSolver.cpp:initSolverBody): velocities, inverse mass / inertia, the external
 // impulses of this tick's forces.  Per body (a lane each on the device), between the body's contacts and solver_prepare; `active` of the ball
 // is settled by solver_prepare (a car that touches it wakes its island).
-template <int NC>
-RLG_HD_SMALL void solver_body_setup(const Arena<NC>& A, TickWork<NC>& W, int body) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void solver_body_setup(const Arena<NC>& A, TickWork<NC, BIG>& W, int body) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
     const float dt = TICK_DT;
     SolverBody& s = W.B[body];
     const Body& b = body == 0 ? A.ball.b : A.cars[body - 1].b;
@@ -929,18 +1009,20 @@ RLG_HD_SMALL void solver_body_setup(const Arena<NC>& A, TickWork<NC>& W, int bod
 }
 
 // contacts of one body (see collide_body); `queued` as in solver_prepare
-template <int NC>
-RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC>& W, int body, bool queued) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
-    constexpr int MAXC = TickWork<NC>::MAXC;
+template <int NC, int BIG>
+RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, int body, bool queued) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
+    using LY = typename TickWork<NC, BIG>::LY;
     bp_history_cell(A, W, body);
     RLG_SPROF(43);
-    if (queued && !W.Q.overflow) collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
-    else collide_body<NC, MAXC>(A, mesh, W.L, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
+    bool fits;
+    if (RLG_LIKELY(queued && !W.Q.overflow)) fits = collide_body<NC, LY>(A, mesh, W.L.c, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
+    else fits = collide_body<NC, LY>(A, mesh, W.L.c, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
+    if (RLG_UNLIKELY(!fits)) W.needs_big = 1;   // (cleared by tick_world_begin; the bodies of an env may all store the same 1)
 }
 
-template <int NC>
-RLG_HD void solver_rows(TickWork<NC>& W, int k) {
+template <int NC, int BIG>
+RLG_HD void solver_rows(TickWork<NC, BIG>& W, int k) {
     const Contact& c = W.L.c[W.cidx[k]];
     const int ni = W.nrow[k];
     if (ni < 0) return;
@@ -956,12 +1038,12 @@ RLG_HD void solver_rows(TickWork<NC>& W, int k) {
 // (Tried and dropped: one lane per body when no row joins two bodies -- such rows commute exactly -- with a group vote for the
 // split-impulse early exit.  The envs that are slow here have ball-car / car-car rows and stay one sequence, and the per-row
 // chain lookup cost more than the short chains saved: 483 K -> 570 K cycles per launch on the slowest workgroup.)
-template <int NC>
-RLG_HD_SMALL void solver_iterate(TickWork<NC>& W) {
-    RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void solver_iterate(TickWork<NC, BIG>& W) {
+    RLG_ASSUME_LDS_W(W);
     constexpr int NB = NC + 1;
     SolverBody (&B)[NB] = W.B;
-    Row (&R)[TickWork<NC>::MAXR] = W.R;
+    auto& R = W.R;
     const int n_normal = W.n_normal, nr = W.n_rows;
     RLG_PROF(3);
     // split-impulse iterations
@@ -994,9 +1076,10 @@ RLG_HD_SMALL void solver_iterate(TickWork<NC>& W) {
     RLG_PROF(4);
 }
 
-template <int NC>
-RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC, BIG>& W, int body) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
+    if constexpr (BIG == 0) { if (RLG_UNLIKELY(W.needs_big)) return; }   // (the env's world step was finished by world_step_finish_big)
     const float dt = TICK_DT;
     const SolverBody s = W.B[body];   // (register copies of the solver body and of the rigid body: see car_wheel_ray_finish)
     if (body == 0) {
@@ -1041,11 +1124,46 @@ RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC>& W, int body) {
     }
 }
 
+// The world step of an env whose contacts did not fit the small layout, redone from the contacts on with the big one (arena_contact.h: a manifold
+// for every mesh object, a slot for every car pair's four points, a solver row for every slot).  Nothing of the first attempt has left a trace
+// that the second does not write again: collide_body's only stores into the arena are the car's world-contact flag and normal (same points, same
+// order, now all of them), collide_merge gave up before its first callback and before the broadphase ranks.  The broadphase CELLS were filed by
+// the first attempt (bp_history_cell is not idempotent): `moved` hands them over.  One lane on the device, Wb in global memory.
 template <int NC>
-RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC>& W, bool queued) {
+RLG_HD_NOINLINE void world_step_finish_big(Arena<NC>& A, MeshView mesh, TickEvents& ev, bool ball_asleep, const int8_t* moved, TickWork<NC, 1>& Wb) {
+    using LY = ContactLayout<NC, 1>;
+    Wb.ball_asleep = ball_asleep; Wb.needs_big = 0;
+    for (int b = 0; b <= NC; b++) Wb.bp_moved[b] = moved[b];
+    bool fits = true;
+    for (int body = 0; body <= NC; body++) fits &= collide_body<NC, LY>(A, mesh, Wb.L.c, Wb.body_n, Wb.ball_hit, Wb.body_obj, body, ball_asleep, NarrowInline());
+    for (int body = 0; body <= NC; body++) solver_body_setup(A, Wb, body);
+    solver_prepare(A, mesh, ev, Wb, false);
+    if (!fits || Wb.needs_big) RLG_DBG_COUNT(7);   // (not reachable: the big layout has room for whatever the mesh format can describe)
+    for (int k = 0; k < Wb.L.n; k++) solver_rows(Wb, k);
+    solver_iterate(Wb);
+    for (int body = 0; body <= NC; body++) solver_finish(A, Wb, body);
+}
+
+// (host form of the world step's second part; `big`: where the fallback may put its work -- the host allocates it when it is needed)
+template <int NC, int BIG>
+RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickWork<NC, BIG>& W, bool queued, TickWork<NC, 1>* big = nullptr) {
     for (int body = 0; body <= NC; body++) solver_body_contacts(A, mesh, W, body, queued);
     for (int body = 0; body <= NC; body++) solver_body_setup(A, W, body);
     solver_prepare(A, mesh, ev, W, queued);
+    if constexpr (BIG == 0) {
+        if (W.needs_big) {
+            RLG_DBG_COUNT(10);
+#if !defined(__HIP_DEVICE_COMPILE__)
+            TickWork<NC, 1>* own = big ? nullptr : new TickWork<NC, 1>;
+            world_step_finish_big(A, mesh, ev, W.ball_asleep, W.bp_moved, big ? *big : *own);
+            delete own;
+#else
+            world_step_finish_big(A, mesh, ev, W.ball_asleep, W.bp_moved, *big);
+#endif
+            RLG_PROF(5);
+            return;
+        }
+    }
     for (int k = 0; k < W.L.n; k++) solver_rows(W, k);
     solver_iterate(W);
     for (int body = 0; body <= NC; body++) solver_finish(A, W, body);
@@ -1209,9 +1327,9 @@ RLG_HD void pads_lock(Arena<NC>& A, int ci, uint64_t mask) {
 // functions with one wavefront lane per work item.
 
 // phase 3, per env: boost pad cooldowns (unless the caller spread them over lanes), then the first part of the dynamics world step
-template <int NC>
-RLG_HD_SMALL void tick_world_begin(Arena<NC>& A, TickWork<NC>& W, bool pads_done) {
-    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(W);
+template <int NC, int BIG>
+RLG_HD_SMALL void tick_world_begin(Arena<NC>& A, TickWork<NC, BIG>& W, bool pads_done) {
+    RLG_ASSUME_LDS(A); RLG_ASSUME_LDS_W(W);
     if (!pads_done) for (int p = 0; p < 34; p++) pad_pre_tick(A.pads[p]);
     world_step_begin(A, W);
     RLG_PROF(0);
@@ -1270,14 +1388,14 @@ RLG_HD_SMALL void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_d
 }
 
 // phase 0b, per env (host form; the device walks the BVH with a lane per frontier node): sleep flag + this tick's candidates
-template <int NC>
-RLG_HD void tick_build_candidates(const Arena<NC>& A, MeshView mesh, TickWork<NC>& W) {
+template <int NC, int BIG>
+RLG_HD void tick_build_candidates(const Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W) {
     W.ball_asleep = (len2(A.ball.b.vel) == 0.f && len2(A.ball.b.angvel) == 0.f);
     collide_build_candidates(A, mesh, W.ball_asleep, W.Q);
 }
 
-template <int NC>
-RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC>& W) {
+template <int NC, int BIG>
+RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC, BIG>& W) {
     for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
     tick_build_candidates(A, mesh, W);
     for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_ray_begin(A, i, w, W.ctx[i]);

@@ -7,6 +7,10 @@
 //   M3 is ROW-major like btMatrix3x3 (LinearMath/btMatrix3x3.h); the car basis COLUMNS are
 //   forward/right/up (RocketSim MathTypes.h:162).
 #pragma once
+// static branch hints: the tick's code is far bigger than the instruction cache and every wavefront runs alone on its SIMD, so a taken branch
+// into a cold cache line is a stall nothing hides -- the rare sides of the tick's branches are marked so that the common path is laid out straight
+#define RLG_LIKELY(x) __builtin_expect(!!(x), 1)
+#define RLG_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -75,13 +79,16 @@
 // those accesses into ds_read/ds_write.  Only valid where EVERY device caller passes an LDS object.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RLG_ASSUME_LDS(ref) __builtin_assume(__builtin_amdgcn_is_shared((const void*)&(ref)))
+#define RLG_ASSUME_LDS_W(ref) do { if constexpr (BIG == 0) RLG_ASSUME_LDS(ref); } while (0)   // (a TickWork<NC, BIG>: the big one lives in global memory)
 #else
 #define RLG_ASSUME_LDS(ref) ((void)0)
+#define RLG_ASSUME_LDS_W(ref) ((void)0)
 #endif
 #else
 #define RLG_NOUNROLL
 #define RLG_UNROLL
 #define RLG_ASSUME_LDS(ref) ((void)0)
+#define RLG_ASSUME_LDS_W(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
 // The tick's small per-phase routines (a few hundred instructions, called once per tick) are inlined: as real calls they cost 2 % of a

@@ -126,10 +126,15 @@ class BatchedEnv:
         return [int(x) for x in out]
 
     def lost_contact_count(self, reset=False) -> int:
-        """Events in which the stepper LOST contact points (a third mesh object with points at once on one body, a car-car point beyond the pair pool)
-        since the last reset, process-wide."""
+        """Contact points LOST since the last reset, process-wide: always 0 (include/rlgpu.h) -- an invariant for tests and soak runs to assert."""
         out = C.c_uint64(0)
         _chk(self.lib.rlgpu_env_lost_contact_count(self.h, C.byref(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
+        return int(out.value)
+
+    def big_layout_ticks(self, reset=False) -> int:
+        """Env-ticks since the last reset (process-wide) whose contacts did not fit the LDS layout and were redone with the big one."""
+        out = C.c_uint64(0)
+        _chk(self.lib.rlgpu_env_big_layout_ticks(self.h, C.byref(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
         return int(out.value)
 
     def epa_counts(self, reset=False):

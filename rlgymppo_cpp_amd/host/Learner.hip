@@ -21,6 +21,7 @@
 #include <RLGymPPO_CPP/Learner.h>
 #include "../../include/rlgpu_state.h"
 #include "host_util.h"
+#include "HostEnvPath.h"
 
 namespace {
 
@@ -190,34 +191,11 @@ struct Learner::Impl {
     bool learnPending = false; int pendMini = 0; Timer pendTimer;
     uint32_t envStreamEpoch = 0;   // second key word of the env batch's RNG streams: bumped on every resume (no replay of the resets of the run continued)
     std::vector<GameInst> games;
-    // ---- host path: plugin kinds without a device form (Match::DevicePlan) and step callbacks -------------------------------------
+    // ---- host path: plugin kinds without a device form (Match::DevicePlan) and step callbacks: HostEnvPath.h (shared with the skill tracker) ----
     RLGSC::Match::DevicePlan plan;
-    bool hostReady = false;
-    std::vector<RLGSC::Match*> envMatch; std::vector<RLGSC::Gym*> envGym;   // one plugin set per env, like GameInst's; [0] = match / gym
-    int Ddev = 0, workers = 1;
-    float *devObs = nullptr, *devControls = nullptr;   // the device builder's rows when the obs builder runs on the host; host-parsed controls
-    std::vector<RlgpuArenaState> snaps, fresh;
-    std::vector<RLGSC::GameState> prevGs;
-    std::vector<float> hObs, hRew, hControls; std::vector<int32_t> hDone, hActs;
-    std::vector<RLGSC::Arena*> arenas;                 // scratch facades for user state setters, one per worker
-
-    // fn(env, worker) for every env in `ids` (all envs when null) on `workers` host threads; the first exception is rethrown here
-    template <class F>
-    void ForEnvs(const std::vector<int32_t>* ids, F fn) {
-        const int n = ids ? (int)ids->size() : nEnvs;
-        const int nw = std::max(1, std::min(workers, n));
-        std::vector<std::exception_ptr> errs(nw);
-        auto run = [&](int w) {
-            try { for (int i = w; i < n; i += nw) fn(ids ? (*ids)[i] : i, i, w); } catch (...) { errs[w] = std::current_exception(); }
-        };
-        std::vector<std::thread> th;
-        for (int w = 1; w < nw; w++) th.emplace_back(run, w);
-        run(0);
-        for (auto& t : th) t.join();
-        for (auto& e : errs) if (e) std::rethrow_exception(e);
-    }
+    int Ddev = 0;
+    HostEnvPath hp;
     void SetupHostPath(const EnvCreateFn& create, int numThreads);
-    void HostResetEnvs(const std::vector<int32_t>& ids, float* obsRows, bool deviceDidReset);
     void HostStep(Learner* self, int t);
     // the permutation of the NEXT epoch is drawn by a worker while this thread launches the current one (a draw depends on the
     // FIFO's bookkeeping only): 2-3 ms of std::shuffle per 262 144 rows that would otherwise leave the GPU idle
@@ -288,12 +266,13 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
                    << (m.plan.hostObs ? "obs-builder " : "") << (m.plan.hostSetter ? "state-setter " : "") << (m.plan.hostParser ? "action-parser " : "") << "); the rest stays on the device");
         m.SetupHostPath(envCreateFn, config.numThreads);
         if (m.plan.hostObs) {   // the obs width is whatever the user's builder returns (Learner.cpp:99-109 probes it the same way)
-            m.EnvCheck(rlgpu_env_reset(m.env, 1, m.devObs), "reset");
+            m.EnvCheck(rlgpu_env_reset(m.env, 1, m.hp.devObs), "reset");
             RlgpuArenaState st; const int32_t env0 = 0;
             m.EnvCheck(rlgpu_env_download_states(m.env, &st, &env0, 1), "download_states");
             RLGSC::GameState gs(st, (int)st.tick_count);
             m.match->EpisodeReset(gs);
             m.D = (int)m.match->BuildObservations(gs).at(0).size();
+            m.hp.D = m.D;
         }
     }
     obsSize = m.D; actionAmount = m.A;
@@ -358,7 +337,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     if (!m.plan.hostObs) m.EnvCheck(rlgpu_env_reset(m.env, 1, m.ObsAt(0)), "reset");
     if (m.plan.AnyHost()) {
         std::vector<int32_t> all(m.nEnvs); std::iota(all.begin(), all.end(), 0);
-        m.HostResetEnvs(all, m.ObsAt(0), true);
+        m.hp.ResetEnvs(all, m.ObsAt(0), true);
     }
 
     if (config.saveFolderAddUnixTimestamp && !config.checkpointSaveFolder.empty())
@@ -412,10 +391,7 @@ Learner::~Learner() {
     if (m.env) rlgpu_env_destroy(m.env);
     if (m.retShare) (void)hipFree(m.retShare);
     if (m.comm) rlgpu_comm_destroy(m.comm);
-    for (size_t e = 1; e < m.envMatch.size(); e++) if (m.envMatch[e] != m.match) { delete m.envGym[e]; delete m.envMatch[e]; }   // per-env plugin sets (not the aliases of a callback-only run)
-    for (RLGSC::Arena* a : m.arenas) delete a;
-    if (m.devObs) (void)hipFree(m.devObs);
-    if (m.devControls) (void)hipFree(m.devControls);
+    // (the per-env plugin sets, scratch arenas and host-path device rows go with m.hp)
     delete m.gym; delete m.match;   // GameInst deletes its gym and match in the reference (GameInst.h:53-56); plugins stay the user's
     delete impl;
 }
@@ -508,145 +484,27 @@ void Learner::UpdateLearningRates(float policyLR, float criticLR) {
 // ThreadAgent::_RunFunc (ThreadAgent.cpp:24-195) for every game at once: policy inference and the env step never leave the device
 // ---- the host path --------------------------------------------------------------------------------------------------------------
 void Learner::Impl::SetupHostPath(const EnvCreateFn& create, int numThreads) {
-    if (hostReady) return;
-    hostReady = true;
-    workers = std::max(1, std::min({numThreads, (int)std::thread::hardware_concurrency(), 32}));
-    EnvCheck(rlgpu_env_enable_snapshots(env, 1), "enable_snapshots");
-    snaps.resize(nEnvs); prevGs.resize(nEnvs); hRew.resize(nAgents); hDone.resize(nAgents); hActs.resize(nAgents);
+    if (hp.ready) return;
+    hp.allocF32 = [](size_t n) { return dev_alloc<float>(n); };
+    hp.Setup(env, plan, match, gym, create, numThreads, nEnvs, nPlayers, nAgents, D, Ddev, tickSkip);
     games.resize(nEnvs);
-    envMatch.assign(nEnvs, match); envGym.assign(nEnvs, gym);
-    if (plan.AnyHost()) {   // user plugins may carry per-episode state: every env gets its own set, as every GameInst does (Learner.cpp:99-109)
-        for (int e = 1; e < nEnvs; e++) {
-            EnvCreateResult r = create();
-            if (!r.match || !r.gym) RG_ERR_CLOSE("EnvCreateFn returned a null match or gym");
-            envMatch[e] = r.match; envGym[e] = r.gym;
-        }
-        for (int w = 0; w < workers; w++) arenas.push_back(RLGSC::MakeScratchArena(match->teamSize, match->spawnOpponents));
-        if (plan.hostObs) devObs = dev_alloc<float>((size_t)nAgents * Ddev);
-        if (plan.hostParser) { devControls = dev_alloc<float>((size_t)nAgents * 8); hControls.resize((size_t)nAgents * 8); }
-    }
-    for (int e = 0; e < nEnvs; e++) { games[e].gym = envGym[e]; games[e].match = envMatch[e]; games[e].index = e; }
+    for (int e = 0; e < nEnvs; e++) { games[e].gym = hp.envGym[e]; games[e].match = hp.envMatch[e]; games[e].index = e; }
 }
 
-// GameInst::Step's `gym->Reset()` for the listed envs (GameInst.cpp:27-32, Gym.cpp:58-66): state setter (host or device), the device's
-// episode bookkeeping, then the host plugins' Reset hooks and -- with a host obs builder -- the first observation rows
-void Learner::Impl::HostResetEnvs(const std::vector<int32_t>& ids, float* obsRows, bool deviceDidReset) {
-    const int n = (int)ids.size();
-    if (n == 0) return;
-    float* devRows = plan.hostObs ? devObs : obsRows;
-    fresh.resize(n);
-    // the pads as the state setter's GameState showed them: Match::ResetState resets them only after the setter returned (Match.cpp:55-69), so the
-    // new episode's first GameState / observation still carries the previous episode's pad states
-    std::vector<std::array<uint8_t, RLGPU_NUM_PADS>> padsBefore;
-    if (plan.AnyHost() && !deviceDidReset) {   // (the envs are still as their episodes ended: RlgpuGymConfig::host_resets)
-        EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
-        padsBefore.resize(n);
-        for (int i = 0; i < n; i++) for (int p = 0; p < RLGPU_NUM_PADS; p++) padsBefore[i][p] = fresh[i].pads[p].is_active;
-    }
-    if (plan.hostSetter) {
-        if (padsBefore.empty()) EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
-        ForEnvs(&ids, [&](int e, int i, int w) {
-            RLGSC::Arena* arena = arenas[w];
-            arena->_state = fresh[i]; arena->_SyncFromState();
-            const RLGSC::GameState gs = envMatch[e]->stateSetter->ResetState(arena);   // (the pad reset of Match::ResetState is the device's: gym_episode_reset)
-            if ((int)gs.players.size() != nPlayers) RG_ERR_CLOSE("Match::ResetState(): New state has a different amount of players, expected " << nPlayers << " but got " << gs.players.size() << ".");
-            arena->_SyncToState();
-            fresh[i] = arena->_state;
-            if (!padsBefore.empty()) for (int p = 0; p < RLGPU_NUM_PADS; p++) padsBefore[i][p] = fresh[i].pads[p].is_active;   // (a setter may have touched them)
-        });
-        EnvCheck(rlgpu_env_upload_states(env, fresh.data(), ids.data(), n), "upload_states");
-        EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 0, devRows), "reset_envs");
-    } else if (!deviceDidReset) {
-        EnvCheck(rlgpu_env_reset_envs(env, ids.data(), n, 1, devRows), "reset_envs");
-        // the device's setters are the built-in ones, and both reset the pads BEFORE they build the episode's first GameState (KickoffState and
-        // RandomState through Arena::ResetToRandomKickoff, RandomState.cpp:11, Arena.cpp:209-210): that GameState shows every pad active
-        for (auto& pb : padsBefore) pb.fill(1);
-    }
-    if (!plan.AnyHost()) return;
-    EnvCheck(rlgpu_env_download_states(env, fresh.data(), ids.data(), n), "download_states");
-    if (plan.hostObs && hObs.size() < (size_t)nAgents * D) hObs.resize((size_t)nAgents * D);
-    ForEnvs(&ids, [&](int e, int i, int) {
-        RlgpuArenaState st = fresh[i];
-        if (!padsBefore.empty()) for (int p = 0; p < RLGPU_NUM_PADS; p++) st.pads[p].is_active = padsBefore[i][p];
-        RLGSC::GameState gs0(st, (int)st.tick_count);
-        envMatch[e]->EpisodeReset(gs0);
-        prevGs[e] = gs0;
-        if (plan.hostObs) {
-            const RLGSC::FList2 rows = envMatch[e]->BuildObservations(gs0);
-            for (int k = 0; k < nPlayers; k++) {
-                if ((int)rows[k].size() != D) RG_ERR_CLOSE("OBSBuilder::BuildOBS returned " << rows[k].size() << " values, the first observation had " << D);
-                std::copy(rows[k].begin(), rows[k].end(), hObs.begin() + ((size_t)e * nPlayers + k) * D);
-            }
-        }
-    });
-    if (plan.hostObs)
-        for (int32_t e : ids) HOST_HIP(hipMemcpy(obsRows + (size_t)e * nPlayers * D, hObs.data() + (size_t)e * nPlayers * D, (size_t)nPlayers * D * 4, hipMemcpyHostToDevice));
-}
-
-// One step of every game with host work in it: the policy's actions are on the device already (acts + t * nAgents).  Follows Gym::Step
-// (Gym.cpp:68-102) and GameInst::Step (GameInst.cpp:7-38) per env, with the arena work done by one launch for all of them.
+// One step of every game with host work in it: the policy's actions are on the device already (acts + t * nAgents).  HostEnvPath::Step does
+// Gym::Step's part (Gym.cpp:68-102); GameInst::Step's bookkeeping (GameInst.cpp:7-38) and the step callback run per env here.
 void Learner::Impl::HostStep(Learner* self, int t) {
     const size_t o = (size_t)t * nAgents;
     const int P = nPlayers;
-    float* nextObs = ObsAt(t + 1);
-    const bool plugins = plan.AnyHost();
-    if (plugins) HOST_HIP(hipMemcpy(hActs.data(), acts + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
-    if (plan.hostParser) {
-        ForEnvs(nullptr, [&](int e, int, int) {
-            RLGSC::Match* M = envMatch[e];
-            M->prevActions = M->ParseActions(RLGSC::IList(hActs.begin() + (size_t)e * P, hActs.begin() + (size_t)(e + 1) * P), prevGs[e]);
-            if ((int)M->prevActions.size() != P) RG_ERR_CLOSE("ActionParser::ParseActions returned " << M->prevActions.size() << " actions for " << P << " players");
-            for (int k = 0; k < P; k++) for (int j = 0; j < 8; j++) hControls[((size_t)e * P + k) * 8 + j] = M->prevActions[k][j];
-        });
-        HOST_HIP(hipMemcpy(devControls, hControls.data(), hControls.size() * 4, hipMemcpyHostToDevice));
-        EnvCheck(rlgpu_env_step_controls(env, devControls, plan.hostObs ? devObs : nextObs, rew + o, done + o), "step_controls");
-    } else {
-        EnvCheck(rlgpu_env_step(env, acts + o, plan.hostObs ? devObs : nextObs, rew + o, done + o), "step");
-    }
-    // every env's arena as it stood where Gym::Step builds the GameState (after the first tick and the event tracker)
-    EnvCheck(rlgpu_env_download_snapshots(env, snaps.data(), 0, nEnvs), "download_snapshots");
-    HOST_HIP(hipMemcpy(hRew.data(), rew + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
-    HOST_HIP(hipMemcpy(hDone.data(), done + o, (size_t)nAgents * 4, hipMemcpyDeviceToHost));
-    if (plan.hostObs && hObs.size() < (size_t)nAgents * D) hObs.resize((size_t)nAgents * D);
     const StepCallback& callback = self->stepCallback;
-    ForEnvs(nullptr, [&](int e, int, int) {
-        RLGSC::Match* M = envMatch[e];
-        RLGSC::Gym::StepResult sr;
-        // deltaTickCount: ticks since this env's previous GameState (tickSkip, or 1 on the first step of an episode)
-        sr.state = RLGSC::GameState(snaps[e], (int)((uint64_t)snaps[e].tick_count - prevGs[e].lastTickCount));
-        if (plugins && !plan.hostParser) M->prevActions = M->ParseActions(RLGSC::IList(hActs.begin() + (size_t)e * P, hActs.begin() + (size_t)(e + 1) * P), prevGs[e]);
-        if (plan.hostObs) {
-            sr.obs = M->BuildObservations(sr.state);
-            for (int k = 0; k < P; k++) {
-                if ((int)sr.obs[k].size() != D) RG_ERR_CLOSE("OBSBuilder::BuildOBS returned " << sr.obs[k].size() << " values, the first observation had " << D);
-                std::copy(sr.obs[k].begin(), sr.obs[k].end(), hObs.begin() + ((size_t)e * P + k) * D);
-            }
-        }
-        sr.done = plan.hostTerminal ? M->IsDone(sr.state) : hDone[(size_t)e * P] != 0;
-        if (plan.hostReward) {
-            sr.reward = M->GetRewards(sr.state, sr.done);
-            if ((int)sr.reward.size() != P) RG_ERR_CLOSE("RewardFunction::GetAllRewards returned " << sr.reward.size() << " rewards for " << P << " players");
-            std::copy(sr.reward.begin(), sr.reward.end(), hRew.begin() + (size_t)e * P);
-        } else sr.reward.assign(hRew.begin() + (size_t)e * P, hRew.begin() + (size_t)(e + 1) * P);
-        for (int k = 0; k < P; k++) hDone[(size_t)e * P + k] = sr.done ? 1 : 0;
-        prevGs[e] = sr.state;
+    hp.D = D;   // (the obs width of a host builder is known only after the first reset: Learner's constructor)
+    hp.Step(acts + o, ObsAt(t + 1), rew + o, done + o, [&](int e, RLGSC::Gym::StepResult& sr) {
         GameInst& g = games[e];   // GameInst.cpp:14-34
         const float sum = std::accumulate(sr.reward.begin(), sr.reward.end(), 0.f);
         g.avgStepRew.Add(sum, (uint64_t)P); g.curEpRew += sum / P; g.totalSteps++;
         if (callback) callback(&g, sr, g._metrics);
         if (sr.done) { g.avgEpRew += g.curEpRew; g.curEpRew = 0; }
     });
-    if (plan.hostReward) HOST_HIP(hipMemcpy(rew + o, hRew.data(), (size_t)nAgents * 4, hipMemcpyHostToDevice));
-    if (plan.hostTerminal) HOST_HIP(hipMemcpy(done + o, hDone.data(), (size_t)nAgents * 4, hipMemcpyHostToDevice));
-    if (plan.hostObs) HOST_HIP(hipMemcpy(nextObs, hObs.data(), (size_t)nAgents * D * 4, hipMemcpyHostToDevice));
-    if (plugins) {
-        std::vector<int32_t> ended;
-        for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) ended.push_back(e);
-        HostResetEnvs(ended, nextObs, false);   // (host_resets: the kernel left the ended envs as they ended)
-    } else {
-        // a step callback only: the kernel reset the ended envs itself; their next GameState starts a new tick window
-        for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) prevGs[e].lastTickCount = (uint64_t)snaps[e].tick_count + (uint64_t)(tickSkip - 1);
-    }
 }
 
 void Learner::CollectTimesteps() {
@@ -659,10 +517,10 @@ void Learner::CollectTimesteps() {
     }
     m.first = false;
     const bool slow = (bool)stepCallback || m.plan.AnyHost();
-    if (slow && !m.hostReady) {   // a step callback was installed after construction
+    if (slow && !m.hp.ready) {   // a step callback was installed after construction
         m.SetupHostPath(envCreateFn, config.numThreads);
-        m.EnvCheck(rlgpu_env_download_states(m.env, m.snaps.data(), nullptr, m.nEnvs), "download_states");
-        for (int e = 0; e < m.nEnvs; e++) m.prevGs[e] = RLGSC::GameState(m.snaps[e], m.tickSkip);
+        m.EnvCheck(rlgpu_env_download_states(m.env, m.hp.snaps.data(), nullptr, m.nEnvs), "download_states");
+        for (int e = 0; e < m.nEnvs; e++) m.hp.prevGs[e] = RLGSC::GameState(m.hp.snaps[e], m.tickSkip);
     }
     auto lockstepDone = [&]() {   // every game made T steps
         if (m.ragged) hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
@@ -1011,10 +869,10 @@ void Learner::LoadStats(std::filesystem::path path) {
         // (otherwise its first episodes would start from the initial states of the run it continues)
         // (with a host OBS builder the device rows go to the scratch buffer -- the constructor's probe did the same: the device setter must run
         // with the new epoch in that case too)
-        impl->EnvCheck(rlgpu_env_reset(impl->env, 1, impl->plan.hostObs ? impl->devObs : impl->ObsAt(0)), "reset after reseed");
+        impl->EnvCheck(rlgpu_env_reset(impl->env, 1, impl->plan.hostObs ? impl->hp.devObs : impl->ObsAt(0)), "reset after reseed");
         if (impl->plan.AnyHost()) {
             std::vector<int32_t> all(impl->nEnvs); std::iota(all.begin(), all.end(), 0);
-            impl->HostResetEnvs(all, impl->ObsAt(0), true);
+            impl->hp.ResetEnvs(all, impl->ObsAt(0), true);
         }
     }
     size_t k = at("skill_rating", false);   // Learner.cpp:229-231

@@ -10,6 +10,7 @@
 #include <RLGymPPO_CPP/Util/SkillTracker.h>
 #include "../../include/rlgpu_state.h"
 #include "host_util.h"
+#include "HostEnvPath.h"
 #include <RLGymSim_CPP/Utils/StateSetters/KickoffState.h>
 
 #include <thread>
@@ -32,7 +33,9 @@ struct SkillTracker::Impl {
     float *obs = nullptr, *obsNext = nullptr, *rew = nullptr, *logp = nullptr; int32_t *acts = nullptr, *done = nullptr;
     std::mt19937 rng;
     std::vector<GameInst> gameInsts;
-    bool disabled = false;                      // the eval match uses a plugin without a device form: no eval games (a warning at construction)
+    // the eval match uses an obs builder / terminal condition / action parser without a device form: the eval batch steps through the same host
+    // path as the training batch does then (HostEnvPath.h; until round 5 the tracker switched itself off instead)
+    bool hostPlugins = false; HostEnvPath hp;
     bool hostSetter = false; RLGSC::Arena* scratch = nullptr;   // a user state setter: run on the host facade (Match::ResetState), then uploaded
     std::vector<RlgpuArenaState> snaps, fresh;
     // Gym::Reset of the listed envs with the user's state setter (the kernel has already reset them with the stand-in kickoff setter)
@@ -50,6 +53,12 @@ struct SkillTracker::Impl {
         EnvCheck(rlgpu_env_reset_envs(env, ids.data(), (int)ids.size(), 0, obsRows), "reset_envs");
     }
     void ResetAll(float* obsRows) {
+        if (hostPlugins) {
+            EnvCheck(rlgpu_env_reset(env, 1, hp.plan.hostObs ? hp.devObs : obsRows), "reset");
+            std::vector<int32_t> all(gameInsts.size()); for (size_t e = 0; e < all.size(); e++) all[e] = (int32_t)e;
+            hp.ResetEnvs(all, obsRows, true);
+            return;
+        }
         EnvCheck(rlgpu_env_reset(env, 1, obsRows), "reset");
         if (hostSetter) { std::vector<int32_t> all(gameInsts.size()); for (size_t e = 0; e < all.size(); e++) all[e] = (int32_t)e; HostSetterReset(all, obsRows); }
     }
@@ -86,16 +95,15 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     if (!ecr.match || !ecr.gym) RG_ERR_CLOSE("SkillTracker: envCreateFunc returned a null match or gym");
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
     if (config.kickoffStatesOnly) m.match->stateSetter = new RLGSC::KickoffState();   // SkillTracker.cpp:48-49 (the env's own setter is discarded, not freed)
-    const RLGSC::Match::DevicePlan plan = m.match->PlanDevice(m.tickSkip);
-    if (plan.hostTerminal || plan.hostObs || plan.hostParser) {
-        // The eval games run without per-step host work, so they need device forms of these plugin kinds (a user STATE SETTER is fine: it runs on
-        // the host facade at episode boundaries).  A training run with a custom OBSBuilder must not die for it: the tracker switches itself off.
-        RG_LOG("SkillTracker: WARNING -- the eval match uses " << (plan.hostTerminal ? "a terminal condition " : "") << (plan.hostObs ? "an obs builder " : "") << (plan.hostParser ? "an action parser " : "")
-               << "without a device form (built-ins: NoTouchCondition / GoalScoreCondition, DefaultOBS / DefaultOBSPadded, DiscreteAction): no eval games will be played, the ratings stay where they are");
-        m.disabled = true;
-        return;
-    }
-    m.hostSetter = plan.hostSetter;
+    RLGSC::Match::DevicePlan plan = m.match->PlanDevice(m.tickSkip);
+    // the eval games' reward is the zero reward of SkillTracker.cpp:10-16,51, whatever the match's own function is: nothing to run for it, on either side
+    plan.hostReward = false;
+    m.hostPlugins = plan.hostTerminal || plan.hostObs || plan.hostParser;
+    if (m.hostPlugins)
+        RG_LOG("SkillTracker: the eval match uses " << (plan.hostTerminal ? "a terminal condition " : "") << (plan.hostObs ? "an obs builder " : "") << (plan.hostParser ? "an action parser " : "")
+               << "without a device form: its games step through the host path (the plugins run on the host every step, the arenas stay on the device)");
+    m.hostSetter = plan.hostSetter && !m.hostPlugins;   // (with host plugins the host path runs the user's setter too)
+    plan.cfg.host_resets = (m.hostPlugins || plan.hostSetter) ? 1 : 0;   // (a host REWARD alone asks for nothing here)
     RlgpuGymConfig g = plan.cfg;
     g.n_terms = 0; g.zero_sum = 0;                                     // the zero reward of SkillTracker.cpp:10-16,51
     for (int i = 0; i < RLGPU_NUM_EVENT_VALS; i++) g.event_weights[i] = 0.f;
@@ -105,7 +113,7 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
     if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
     else m.EnvCheck(rlgpu_env_set_procedural_mesh(m.env), "set_procedural_mesh");
-    if (rlgpu_env_obs_size(m.env) != obsSize) RG_ERR_CLOSE("SkillTracker: the eval env's observations have " << rlgpu_env_obs_size(m.env) << " values, the policy takes " << obsSize);
+    if (!plan.hostObs && rlgpu_env_obs_size(m.env) != obsSize) RG_ERR_CLOSE("SkillTracker: the eval env's observations have " << rlgpu_env_obs_size(m.env) << " values, the policy takes " << obsSize);
     m.nPlayers = m.match->playerAmount; m.nRows = rlgpu_env_num_agents(m.env);
     SKILL_HIP(hipMalloc(&m.obs, (size_t)m.nRows * obsSize * 4)); SKILL_HIP(hipMalloc(&m.obsNext, (size_t)m.nRows * obsSize * 4));
     SKILL_HIP(hipMalloc(&m.rew, m.nRows * 4)); SKILL_HIP(hipMalloc(&m.logp, m.nRows * 4));
@@ -113,6 +121,13 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     m.EnvCheck(rlgpu_env_enable_snapshots(m.env, 1), "enable_snapshots");
     if (m.hostSetter) m.scratch = RLGSC::MakeScratchArena(m.match->teamSize, m.match->spawnOpponents);
     m.gameInsts.resize(config.numEnvs);
+    if (m.hostPlugins) {
+        if (config.kickoffStatesOnly) {   // every env's own plugin set plays kickoffs too (SkillTracker.cpp:48-49)
+            const EnvCreateFn inner = config.envCreateFunc;
+            config.envCreateFunc = [inner]() { EnvCreateResult r = inner(); if (r.match) r.match->stateSetter = new RLGSC::KickoffState(); return r; };
+        }
+        m.hp.Setup(m.env, plan, m.match, m.gym, config.envCreateFunc, (int)std::thread::hardware_concurrency(), config.numEnvs, m.nPlayers, m.nRows, obsSize, rlgpu_env_obs_size(m.env), m.tickSkip);
+    }
     m.ResetAll(m.obs);
 
     modeName = std::to_string(m.match->teamSize) + "v" + std::to_string(m.match->teamSize);   // ModeNameFromGameInst, SkillTracker.cpp:20-26
@@ -151,7 +166,6 @@ void SkillTracker::UpdateRatings(RatingSet& winner, RatingSet& loser, bool updat
 
 void SkillTracker::RunGames(int64_t timestepsDelta) {
     Impl& m = *impl;
-    if (m.disabled) return;
     if (runCounter++ % (uint64_t)config.updateInterval != 0) return;
 
     auto snapshot = [&]() {   // the current policy's parameters as a new stored version
@@ -195,12 +209,20 @@ void SkillTracker::RunGames(int64_t timestepsDelta) {
                     picks[row] = curPlays ? picksCur[row] : picksOld[games[e].oldPolicyIndex][row];
                 }
             SKILL_HIP(hipMemcpy(m.acts, picks.data(), m.nRows * 4, hipMemcpyHostToDevice));
+            if (m.hostPlugins) {
+                // Gym::Step with the user's plugins on the host (HostEnvPath::Step: parser, obs builder, terminal conditions; the ended games are reset
+                // there, by the user's state setter or the device's); what this loop needs comes back in hp.snaps / hp.hRew / hp.hDone
+                m.hp.Step(m.acts, m.obsNext, m.rew, m.done, [](int, RLGSC::Gym::StepResult&) {});
+                std::swap(m.obs, m.obsNext);
+                rews = m.hp.hRew; dones = m.hp.hDone; states = m.hp.snaps;
+            } else {
             m.EnvCheck(rlgpu_env_step(m.env, m.acts, m.obsNext, m.rew, m.done), "step");
             m.EnvCheck(rlgpu_env_sync(m.env), "sync");
             std::swap(m.obs, m.obsNext);
             SKILL_HIP(hipMemcpy(rews.data(), m.rew, m.nRows * 4, hipMemcpyDeviceToHost));
             SKILL_HIP(hipMemcpy(dones.data(), m.done, m.nRows * 4, hipMemcpyDeviceToHost));
             m.EnvCheck(rlgpu_env_download_snapshots(m.env, states.data(), 0, (int)games.size()), "download_snapshots");
+            }
             ended.clear();
             for (size_t e = 0; e < games.size(); e++) {
                 Game& g = games[e];

@@ -35,3 +35,16 @@ def ref_lib(port_lib):
     if not have_ref():
         pytest.skip("oracle/_ref/libref_oracle.so not built (needs /root/reference; golden fixtures cover this case)")
     return RefSim(*port_lib.mesh)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """RLGPU_COUNTS_OUT=<path> (set by test_gpu_parity.py for its run of the suite against the cut-down contact layout): the stepper's process-wide
+    counters of this session, as JSON."""
+    out = os.environ.get("RLGPU_COUNTS_OUT")
+    if not out:
+        return
+    import json
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    env = BatchedEnv(4, 1)
+    with open(out, "w") as f:
+        json.dump({"big_layout_ticks": env.big_layout_ticks(), "lost_contacts": env.lost_contact_count(), "overflows": env.overflow_counts()}, f)

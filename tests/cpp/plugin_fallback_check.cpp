@@ -224,6 +224,61 @@ static int UserPlugins() {
     return 0;
 }
 
+// ---- part 2b: the skill tracker with a custom OBSBuilder ---------------------------------------------------------
+// SkillTracker.cpp:165-257 plays its eval games through GameInst::Step like any other game: whatever plugins the env has, they run.  Until
+// round 5 the tracker here switched itself off when the eval match had an obs builder / terminal condition / action parser without a device
+// form; now its batch steps through the same host path as the training batch (HostEnvPath.h).  Every eval episode starts with the ball a few
+// ticks from one of the goal lines, so goals are scored whatever the policies do: the ratings must move, in both directions.
+static std::atomic<int> g_mouthResets{0}, g_evalCallbacks{0}, g_evalGoals{0}, g_evalObsErrors{0};
+struct GoalMouthSetter : StateSetter {
+    GameState ResetState(Arena* arena) override {
+        arena->ResetToRandomKickoff();
+        const float side = (g_mouthResets++ % 2) ? 1.f : -1.f;
+        BallState bs;
+        bs.pos = Vec(0, side * 4900.f, 200.f); bs.vel = Vec(0, side * 2500.f, 0);
+        arena->ball->SetState(bs);
+        return GameState(arena);
+    }
+};
+static EnvCreateResult MakeEvalEnv() {
+    Match* match = new Match(new BallHeightReward(), {new StepLimitCondition(5)}, new RangeOBS(), new EightWayParser(), new GoalMouthSetter(), 1, true);
+    return {match, new Gym(match, 8)};
+}
+static void EvalCallback(GameInst* game, const Gym::StepResult& r, Report&) {
+    if (!game->isEval) return;
+    g_evalCallbacks++;
+    if (RLGSC::Math::IsBallScored(r.state.ball.pos)) g_evalGoals++;
+    for (float v : r.reward) if (v != 0.f) g_evalObsErrors++;        // the eval games' reward is the zero reward (SkillTracker.cpp:10-16,51)
+}
+static int SkillTrackerWithUserPlugins() {
+    const int envs = 8, steps = 10;
+    LearnerConfig cfg = SmallConfig(envs, steps, 2);
+    cfg.skillTrackerConfig.enabled = true;
+    cfg.skillTrackerConfig.envCreateFunc = MakeEvalEnv;
+    cfg.skillTrackerConfig.stepCallback = EvalCallback;
+    cfg.skillTrackerConfig.numEnvs = 4; cfg.skillTrackerConfig.simTime = 16.f;        // 4 s per game = 60 steps of 8 ticks = 12 episodes of 5 steps
+    cfg.skillTrackerConfig.updateInterval = 1; cfg.skillTrackerConfig.timestepsPerVersion = 2 * cfg.timestepsPerIteration;
+    cfg.skillTrackerConfig.kickoffStatesOnly = false;                                 // (the user's setter is the point)
+    cfg.skillTrackerConfig.perModeRatings = false; cfg.skillTrackerConfig.loadOldVersionsFromCheckpoints = false;
+    Learner learner(MakeUserEnv, cfg);
+    CHECK(learner.obsSize == 89 + 3 && learner.actionAmount == 8);
+    int iterations = 0; std::vector<float> ratings;
+    learner.iterationCallback = [&](Learner* l, Report& report) {
+        iterations++;
+        if (report.Has("Skill Rating")) ratings.push_back(report["Skill Rating"]);
+        if (iterations == 4) l->config.timestepLimit = 1;
+    };
+    learner.Learn();
+    CHECK(iterations == 4 && (int)ratings.size() == 4);
+    bool moved = false; for (float r : ratings) moved = moved || r != cfg.skillTrackerConfig.initialRating;
+    std::printf("skill tracker with a custom OBSBuilder / terminal condition / parser / setter: ratings %.2f %.2f %.2f %.2f; %d eval steps, %d with the ball in a goal, %d setter resets\n",
+                ratings[0], ratings[1], ratings[2], ratings[3], (int)g_evalCallbacks, (int)g_evalGoals, (int)g_mouthResets);
+    CHECK(moved);                                       // goals were scored and counted
+    CHECK(g_evalCallbacks >= 3 * 4 * 60 && g_evalGoals > 20 && g_evalObsErrors == 0);
+    CHECK(g_mouthResets >= 3 * 4 * 11);                 // the user's setter started every eval episode (5-step episodes: the user's terminal condition ran too)
+    return 0;
+}
+
 // throughput of the paths that leave the device every step, for DESIGN.md: agent-steps per second of CollectTimesteps()
 static void StepCounter(GameInst*, const Gym::StepResult&, Report&) {}
 static int Throughput() {
@@ -438,6 +493,7 @@ int main(int argc, char** argv) {
         if (ComparePaths(2, false, false)) return 1;    // Match(..., spawnOpponents = false): two blue cars and nobody else
         if (ComparePaths(1, true, false)) return 1;     // a single car
         if (UserPlugins()) return 1;
+        if (SkillTrackerWithUserPlugins()) return 1;
         if (CollectionDuringLearn()) return 1;
         if (FreeRunning()) return 1;
         if (StandaloneGym()) return 1;

@@ -22,8 +22,8 @@ def _ptr(a):
 
 
 class PortSim:
-    def __init__(self):
-        self.lib = C.CDLL(PORT_SO)
+    def __init__(self, so=None):
+        self.lib = C.CDLL(so or PORT_SO)
         assert self.lib.port_state_size() == C.sizeof(ArenaState)
 
     def procedural_mesh(self):

@@ -200,6 +200,121 @@ def test_port_free_run_is_bit_identical_to_the_reference(sg, port_lib):
     print("free-run ticks bit-identical to the reference:", n_exact_ticks, "in", whole, "whole tapes + 4 partial")
 
 
+def _port_variant(target):
+    """oracle/_build/liboracle_<target>.so, built on demand (oracle/Makefile: port_small = the device's small contact layout + its fallback on the
+    host, port_tiny = the same with capacities cut down until ordinary play overflows them)."""
+    import subprocess
+    from simlib import PortSim
+    so = os.path.join(ROOT, "oracle", "_build", f"liboracle_{target}.so")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "Makefile")): pytest.skip("oracle sources absent")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), target], stdout=subprocess.DEVNULL)
+    # a private copy: the library keeps its mesh in a global, and the session's port_lib fixture (the same file for target "port") must keep its own
+    import shutil, tempfile
+    private = os.path.join(tempfile.mkdtemp(prefix="port_variant_"), os.path.basename(so))
+    shutil.copy(so, private)
+    return PortSim(private)
+
+
+@pytest.mark.parametrize("target,min_redone", [("port_small", 0), ("port_tiny", 40)])
+def test_no_contact_is_ever_dropped_small_layout_plus_fallback_equals_the_reference(sg, target, min_redone):
+    """Where a tick's contacts do not fit the stepper's small layout (a further mesh object with points on one body, a plane point beyond the
+    plane slots, a car-car point beyond the pair pool, more contacts than solver rows) the env's world step is redone with the big layout
+    (arena_step.h:world_step_finish_big) -- detected before any contact callback has fired, so nothing is lost and nothing happens twice.
+    Two host builds of the SMALL layout against the reference's recorded trajectories, all 31 tapes for equality of every field every 10 ticks,
+    and the two-file mesh fixture: the layout as shipped (which fits all of them: no tick redone), and one cut down to one mesh manifold, one
+    plane slot, one pair point and three solver contacts, where hundreds of ticks take the fallback.  Nothing is ever counted as lost."""
+    import ctypes as C
+    port = _port_variant(target)
+    port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    port.lib.port_debug_counts.argtypes = [C.c_void_p, C.c_int]
+    cnt = (C.c_long * 16)(); port.lib.port_debug_counts(cnt, 1)
+    redone = 0
+
+    def run(g, parts, names, exact_until):
+        nonlocal redone
+        port.set_mesh(g["mesh_verts"], g["mesh_tris"], parts)
+        every = int(g["phys_every"])
+        for name in names:
+            st = ArenaState.from_buffer_copy(g[f"phys/{name}/start_raw"].tobytes())
+            tape = np.ascontiguousarray(g[f"phys/{name}/tape"], np.float32); want = g[f"phys/{name}/states"]
+            outs = (ArenaState * (len(tape) // every))()
+            port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+            for j in range(min(len(tape), exact_until.get(name, len(tape))) // every):
+                assert np.array_equal(state_vec(outs[j]), want[j]), f"{target} {name} tick {(j + 1) * every}: not bit-identical to the reference"
+            port.lib.port_debug_counts(cnt, 1)
+            assert cnt[7] == 0, f"{name}: {cnt[7]} contacts lost"
+            redone += cnt[10]
+
+    from simlib import PHYS_EXACT_UNTIL, SEAM_EXACT_UNTIL
+    run(sg, None, [str(x) for x in sg["phys_names"]], PHYS_EXACT_UNTIL)
+    seam = np.load(os.path.join(GOLD, "seam_golden.npz"))
+    before = redone
+    run(seam, seam["mesh_parts"], [str(x) for x in seam["phys_names"]], SEAM_EXACT_UNTIL)
+    print(f"{target}: {redone} env-ticks redone with the big layout ({redone - before} on the two-file mesh)")
+    assert redone >= min_redone
+    if target == "port_small": assert redone == 0, "a fixture overflows the shipped small layout: fine, but then say so here"
+    else: assert redone - before > 0, "the two-file mesh never touched two objects at once"
+
+
+@pytest.mark.parametrize("target", ["port", "port_small"])
+def test_port_wedge_fixture_contacts_beyond_the_small_layout_vs_reference_golden(target):
+    """tests/golden/wedge_golden.npz (make_wedge_golden.py): the reference on the tessellated arena dealt round-robin into 16 .cmf files, where a
+    car on a fillet holds points in up to five (once: fourteen) mesh manifolds at once, plus two six-car pile-ups.  The oracle (big contact
+    layout) and the host build of the device's small layout + fallback: all five tapes EQUAL to the reference over their whole length; the small
+    layout redoes 111 env-ticks with the big one.  (Round 4's stepper left the reference at ticks 830 / 560 / 570 of three of these tapes.)"""
+    import ctypes as C
+    port = _port_variant(target)
+    port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    port.lib.port_debug_counts.argtypes = [C.c_void_p, C.c_int]
+    g = np.load(os.path.join(GOLD, "wedge_golden.npz"))
+    port.set_mesh(g["mesh_verts"], g["mesh_tris"], g["mesh_parts"])
+    every = int(g["phys_every"])
+    cnt = (C.c_long * 16)(); port.lib.port_debug_counts(cnt, 1)
+    for name in [str(x) for x in g["phys_names"]]:
+        st = ArenaState.from_buffer_copy(g[f"phys/{name}/start_raw"].tobytes())
+        tape = np.ascontiguousarray(g[f"phys/{name}/tape"], np.float32); want = g[f"phys/{name}/states"]
+        outs = (ArenaState * (len(tape) // every))()
+        port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+        for j in range(len(tape) // every):
+            assert np.array_equal(state_vec(outs[j]), want[j]), f"{target} {name} tick {(j + 1) * every}: not bit-identical to the reference"
+        assert (g[f"phys/{name}/tag"][:, 0] >= 3).sum() >= 0
+    port.lib.port_debug_counts(cnt, 1)
+    assert cnt[7] == 0
+    assert cnt[10] == (111 if target == "port_small" else 0), cnt[10]
+    tags = np.concatenate([g[f"phys/{n}/tag"] for n in [str(x) for x in g["phys_names"]]])
+    assert (tags[:, 0] >= 3).sum() >= 100 and tags[:, 0].max() == 14    # what the fixture is for: static manifolds with points on ONE body
+
+
+def test_fallback_in_random_play_tiny_layout_equals_big_layout(port_lib):
+    """... and over random play, where the fixtures end: 24 arenas of 3v3 from kickoff states under uniformly random actions, 300 gym steps
+    of 8 ticks, stepped by the big-layout host build (the oracle) and by the cut-down small layout with its fallback -- every state, observation,
+    reward and terminal equal after every step, dozens of env-ticks redone."""
+    import ctypes as C
+    tiny = _port_variant("port_tiny"); tiny.set_mesh(*port_lib.mesh)
+    tiny.lib.port_debug_counts.argtypes = [C.c_void_p, C.c_int]
+    cnt = (C.c_long * 16)(); tiny.lib.port_debug_counts(cnt, 1)
+    cfg = port_gym_cfg(no_touch_max_steps=40)
+    n, nc = 24, 6
+    rng = np.random.default_rng(5)
+    st0 = []
+    for e in range(n):
+        st = ArenaState(); st.num_cars = nc
+        for i in range(nc): st.cars[i].team = i % 2
+        st0.append(st)
+    cfg.seed_lo = 77
+    sa, oa = port_gym_reset(port_lib, st0, cfg); sb, ob = port_gym_reset(tiny, st0, cfg)
+    assert np.array_equal(oa, ob)
+    ha = np.zeros((n, 8), np.uint16); hb = np.zeros((n, 8), np.uint16)
+    for step in range(300):
+        act = rng.integers(0, 90, size=n * nc).astype(np.int32)
+        sa, oa, ra, da = port_gym_step(port_lib, sa, cfg, act, ha); sb, ob, rb, db = port_gym_step(tiny, sb, cfg, act, hb)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and np.array_equal(ha, hb), f"step {step}"
+        for x, y in zip(sa, sb): assert bytes(x) == bytes(y), f"step {step}: states differ"
+    tiny.lib.port_debug_counts(cnt, 1)
+    print("env-ticks redone with the big layout:", cnt[10], "of", 300 * 8 * n, "; lost:", cnt[7])
+    assert cnt[10] > 20 and cnt[7] == 0
+
+
 def test_port_mesh_of_two_files_vs_reference_golden():
     """One collision object -- and one contact manifold per dynamic body -- per mesh FILE (RS/Sim/Arena/Arena.cpp:1028-1054): the procedural
     arena split into two .cmf files, recorded from the reference through its own per-file loading (tests/golden/seam_golden.npz,
