@@ -250,7 +250,7 @@ RLG_HD void car_update_jump(CarHot& c, bool jump_pressed) {
         } else {
             c.flags &= ~CF_IS_JUMPING;
         }
-    } else if (on_ground && jump_pressed) {
+    } else if (RLG_UNLIKELY(on_ground && jump_pressed)) {
         c.flags |= CF_IS_JUMPING;
         c.jump_time = 0.f;
         V3 imp = up * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;
@@ -268,7 +268,7 @@ RLG_HD void car_update_jump(CarHot& c, bool jump_pressed) {
 // ---- Car::_UpdateAutoFlip (Car.cpp:763-797) ---------------------------------------------------------------
 RLG_HD void car_update_auto_flip(CarHot& c, bool jump_pressed) {
     const float dt = TICK_DT;
-    if (jump_pressed && (c.flags & CF_WORLD_CONTACT) && c.world_contact_normal.z > K::CAR_AUTOFLIP_NORMZ_THRESH) {
+    if (RLG_UNLIKELY(jump_pressed && (c.flags & CF_WORLD_CONTACT) && c.world_contact_normal.z > K::CAR_AUTOFLIP_NORMZ_THRESH)) {
         float roll = rot_roll(c.b.rot);
         float abs_roll = fabsf(roll);
         if (abs_roll > K::CAR_AUTOFLIP_ROLL_THRESH) {
@@ -278,7 +278,7 @@ RLG_HD void car_update_auto_flip(CarHot& c, bool jump_pressed) {
             body_apply_central_impulse(c.b, -col2(c.b.rot) * K::CAR_AUTOFLIP_IMPULSE * UU2BT * K::CAR_MASS, CAR_INV_MASS);
         }
     }
-    if (c.flags & CF_IS_AUTOFLIPPING) {
+    if (RLG_UNLIKELY(c.flags & CF_IS_AUTOFLIPPING)) {
         if (c.auto_flip_timer <= 0.f) {
             c.flags &= ~CF_IS_AUTOFLIPPING;
             c.auto_flip_timer = 0.f;
@@ -300,7 +300,7 @@ RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float f
         if ((c.flags & CF_HAS_JUMPED) && !(c.flags & CF_IS_JUMPING)) c.air_time_since_jump += dt;
         else c.air_time_since_jump = 0.f;
 
-        if (jump_pressed && c.air_time_since_jump < K::DOUBLEJUMP_MAX_DELAY) {
+        if (RLG_UNLIKELY(jump_pressed && c.air_time_since_jump < K::DOUBLEJUMP_MAX_DELAY)) {
             float mag = fabsf(c.ctl.yaw) + fabsf(c.ctl.pitch) + fabsf(c.ctl.roll);
             bool is_flip = mag >= K::DODGE_DEADZONE;
             bool can_use = !(c.flags & CF_HAS_DOUBLE_JUMPED) && !(c.flags & CF_HAS_FLIPPED);
@@ -391,7 +391,7 @@ RLG_HD void car_update_boost(CarHot& c) {
 }
 
 // ---- Car::Respawn (Car.cpp:43-56): spawn slot from the caller's RNG draw ------------------------------------
-RLG_HD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
+RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
     const float RX[4] = {-2304, -2688, 2304, 2688};
     int idx = (int)(rnd % 4u);
     Car n = {};
@@ -429,7 +429,7 @@ RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t e
     c.ctl.pitch = clampf(c.ctl.pitch, -1.f, 1.f); c.ctl.yaw = clampf(c.ctl.yaw, -1.f, 1.f); c.ctl.roll = clampf(c.ctl.roll, -1.f, 1.f);
     bool demoed = (c.flags & CF_IS_DEMOED) != 0;
     c.frozen = demoed;  // rigid body disabled for this tick (Car.cpp:69-80)
-    if (demoed) {
+    if (RLG_UNLIKELY(demoed)) {
         float tm = fmaxf(c.demo_respawn_timer - dt, 0.f);
         c.demo_respawn_timer = tm;
         if (tm == 0.f) {
@@ -459,7 +459,7 @@ RLG_HD_MID void car_wheel_ray_begin(Arena<NC>& A, int ci, int i, CarTickCtx& t) 
     Car& cr = A.cars[ci];
     // NB: as in the reference, a car respawned in phase 0 runs the rest of the pre-tick (Respawn clears the flag,
     // Car.cpp:86-87 checks the NEW state).
-    if (cr.flags & CF_IS_DEMOED) return;
+    if (RLG_UNLIKELY(cr.flags & CF_IS_DEMOED)) return;
     const M3 rot = cr.b.rot; const V3 pos = cr.b.pos;
     const float steer_angle = cr.steer_angle;
     V3 wheel_dir = rot * v3(0, 0, -1), axle = rot * v3(0, -1, 0);
@@ -504,7 +504,7 @@ RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh,
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t); RLG_ASSUME_LDS(Q);
     const float dt = TICK_DT;
     Car& cr = A.cars[ci];
-    if (cr.flags & CF_IS_DEMOED) return;
+    if (RLG_UNLIKELY(cr.flags & CF_IS_DEMOED)) return;
     const M3 rot = cr.b.rot; const V3 pos = cr.b.pos, vel = cr.b.vel, angvel = cr.b.angvel;
     V3 up = col2(rot);
     V3 wheel_dir = rot * v3(0, 0, -1);
@@ -513,7 +513,7 @@ RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh,
     V3 source = w.hard_point, target = w.contact_point;
     RayHit hit; hit.kind = w.ground; hit.frac = w.susp_len; hit.normal = w.contact_normal;
     RLG_PROF(0);
-    if (Q.overflow) ray_mesh_walk(mesh, source, target, hit);
+    if (RLG_UNLIKELY(Q.overflow)) ray_mesh_walk(mesh, source, target, hit);
     else ray_apply_mesh_key(mesh, Q, ray_keys(t)[i], source, target, hit);
     ray_ball_and_cars(A, ci, source, target, hit);
     RLG_PROF(7); RLG_SPROF(40);
@@ -593,7 +593,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
     }
     // friction impulses: taken from the wheel lanes (car_wheel_trace) unless a wheel stands on another car -- that reads the
     // other car's velocity, which its own phase 2 may already have changed (callers run such ticks in car order)
-    if (ordered) {
+    if (RLG_UNLIKELY(ordered)) {
         for (int i = 0; i < 4; i++) { t.w[i].impulse = wheel_friction_impulse(A, c, t.w[i], ctx.wheel_basis[i >> 1], i); ctx.w[i].impulse = t.w[i].impulse; }
     }
 
@@ -613,7 +613,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
     car_update_jump(c, jump_pressed);
     car_update_auto_flip(c, jump_pressed);
     car_update_double_jump_or_flip(c, jump_pressed, t.forward_speed_uu);
-    if (c.ctl.throttle != 0.f && ((t.n_contact > 0 && t.n_contact < 4) || (c.flags & CF_WORLD_CONTACT))) car_update_auto_roll(c, t);
+    if (RLG_UNLIKELY(c.ctl.throttle != 0.f && ((t.n_contact > 0 && t.n_contact < 4) || (c.flags & CF_WORLD_CONTACT)))) car_update_auto_roll(c, t);
     c.flags &= ~CF_WORLD_CONTACT;
     RLG_SPROF(34);
 

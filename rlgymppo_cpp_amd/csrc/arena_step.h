@@ -40,7 +40,7 @@ RLG_HD void on_car_ball_contact(Arena<NC>& A, int ci, V3 point_rel_ball) {   // 
 
 // Arena::_BtCallback_OnCarCarCollision (Arena.cpp:336-418). local points are in each car's body frame (BT).
 template <int NC>
-RLG_HD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 local_b, TickEvents& ev) {
+RLG_HD_COLD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3 local_b, TickEvents& ev) {
     for (int i = 0; i < 2; i++) {
         bool swapped = (i == 1);
         int i1 = swapped ? ib : ia, i2 = swapped ? ia : ib;
@@ -933,6 +933,16 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC, BIG>& W) {
     A.ball.b.vel *= K::BALL_DAMP_PER_TICK;   // btPow(1 - linearDamping, timeStep)
 }
 
+// the narrowphase run inline (an env whose queue overflowed this tick, 1.8 per million env-ticks; the host build without a queue): cold calls, so
+// that the common path does not carry a second copy of collide_body / collide_merge
+template <int NC, int BIG>
+RLG_HD_COLD bool collide_body_inline(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, int body) {
+    return collide_body<NC, typename TickWork<NC, BIG>::LY>(A, mesh, W.L.c, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
+}
+template <int NC, int BIG>
+RLG_HD_COLD bool collide_merge_inline(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, TickEvents& ev, bool& touch) {
+    return collide_merge<NC, BIG>(A, mesh, W, ev, touch, NarrowInline());
+}
 // world step, second part, in four pieces of different width (the host runs them back to back):
 //   solver_body_contacts per body  the body's region of the contact list (`queued`: from the narrowphase queue W.Q, else / on overflow inline)
 //   solver_prepare   per env       contact list merged in reference order + callbacks + car-car pairs, solver
@@ -957,7 +967,7 @@ RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, Tick
     bool touch = false, fits;
     if (RLG_UNLIKELY(W.needs_big)) return;      // (a body's contacts did not fit: collide_body)
     if (RLG_LIKELY(queued && !W.Q.overflow)) fits = collide_merge<NC, BIG>(A, mesh, W, ev, touch, NarrowQueued<NC>{W.Q});
-    else fits = collide_merge<NC, BIG>(A, mesh, W, ev, touch, NarrowInline());
+    else fits = collide_merge_inline(A, mesh, W, ev, touch);
     if (RLG_UNLIKELY(!fits)) { W.needs_big = 1; return; }   // (with the big layout: cannot happen, every pair and every slot has a row)
     const bool ball_active = !ball_asleep || touch;  // island woken by an active car (btSimulationIslandManager.cpp)
 #ifdef RLG_PROF_SPLIT_PREPARE
@@ -1017,7 +1027,7 @@ RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC,
     RLG_SPROF(43);
     bool fits;
     if (RLG_LIKELY(queued && !W.Q.overflow)) fits = collide_body<NC, LY>(A, mesh, W.L.c, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowQueued<NC>{W.Q});
-    else fits = collide_body<NC, LY>(A, mesh, W.L.c, W.body_n, W.ball_hit, W.body_obj, body, W.ball_asleep, NarrowInline());
+    else fits = collide_body_inline(A, mesh, W, body);
     if (RLG_UNLIKELY(!fits)) W.needs_big = 1;   // (cleared by tick_world_begin; the bodies of an env may all store the same 1)
 }
 

@@ -231,11 +231,11 @@ template <int NC>
 RLG_HD void queue_candidates(CollideQueue<NC>& Q, int body, int first, int cnt) {   // host form of the walk (the device's: rlgpu_env.hip build_candidates_wave)
     int k = Q.cand_count[body];
 #ifdef RLG_QUEUE_LEAVES
-    if (k / LEAF_SLOTS >= CACHE_LEAVES) { Q.overflow = 1; return; }
+    if (RLG_UNLIKELY(k / LEAF_SLOTS >= CACHE_LEAVES)) { Q.overflow = 1; return; }
     Q.leaf[body][k / LEAF_SLOTS] = (uint32_t)first | ((uint32_t)cnt << 24);
     Q.cand_count[body] = (uint16_t)(k + LEAF_SLOTS);
 #else
-    if (k + cnt > CollideQueue<NC>::region_cap(body)) { Q.overflow = 1; return; }
+    if (RLG_UNLIKELY(k + cnt > CollideQueue<NC>::region_cap(body))) { Q.overflow = 1; return; }
     Q.cand_count[body] = (uint16_t)(k + cnt);
     const int type = body == 0 ? 0 : 1, a = body == 0 ? 0 : body - 1;
     for (int q = 0; q < cnt; q++) Q.cand[CollideQueue<NC>::region(body) + k + q] = pack_cand(type, a, first + q);
@@ -243,7 +243,7 @@ RLG_HD void queue_candidates(CollideQueue<NC>& Q, int body, int first, int cnt) 
 }
 template <int NC>
 RLG_HD void queue_pair(CollideQueue<NC>& Q, int ia, int ib) {
-    if (Q.n_pairs >= PAIR_SLOTS) { Q.overflow = 1; return; }
+    if (RLG_UNLIKELY(Q.n_pairs >= PAIR_SLOTS)) { Q.overflow = 1; return; }
 #ifdef RLG_QUEUE_LEAVES
     Q.pair[Q.n_pairs++] = pack_cand(2, ia, ib);
 #else
@@ -488,7 +488,7 @@ RLG_HD void ray_apply_mesh_key(MeshView mesh, const QT& Q, unsigned long long ke
     if (h.kind == 0) best = h;   // recomputed from the winning triangle: same frac, and its ray-facing normal
 }
 // mesh stage without a candidate list (queue overflow): depth-first BVH walk
-RLG_HD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
+RLG_HD_COLD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
     if (!mesh_maybe_near(mesh, v3(fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)), v3(fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)))) return;
     V3 dvec = to - from;
     V3 inv_d = v3(1.f / dvec.x, 1.f / dvec.y, 1.f / dvec.z);
@@ -545,7 +545,7 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
         const float r = K::BALL_RADIUS * UU2BT;
         const V3 bp = A.ball.b.pos;
         // the cast runs in the ball's basis (BallState::rotMat), as btCollisionWorld::rayTestSingle's convex cast does
-        if (ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r))) ray_convex_hit(from, to, A.ball.b.rot, bp, v3(0, 0, 0), r, 1, best);
+        if (RLG_UNLIKELY(ray_box_near(from, to, bp - v3(r, r, r), bp + v3(r, r, r)))) ray_convex_hit(from, to, A.ball.b.rot, bp, v3(0, 0, 0), r, 1, best);
     }
     // other cars' hitboxes.  A car that is demoed, or was respawned this tick, has no contact response (Car.cpp:69-80) but its rigid body
     // stays in the world where it stopped: the ray test finds the CLOSEST object first and only then asks whether it responds
@@ -564,7 +564,7 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
         const V3 center = o.b.pos + R * hitbox_off();
         const V3 h = hitbox_half();
         const V3 e = abs_rows_dot(R, h);
-        if (!ray_box_near(from, to, center - e, center + e)) continue;
+        if (RLG_LIKELY(!ray_box_near(from, to, center - e, center + e))) continue;
         ray_convex_hit(from, to, R, center, h, 0.f, ghost ? GHOST : 2 + k, best);
     }
     if (best.kind == GHOST) best.kind = -1;

@@ -21,6 +21,8 @@
 // Big routines are real calls on the device: fully inlined, one gym step is ~330 KB of code and every wavefront streams
 // it through the 64 KB instruction cache on every tick.
 #define RLG_HD_NOINLINE __host__ __device__ __noinline__ inline  /* `inline` only for ODR linkage of header definitions */
+// rarely executed routines (overflow fallbacks, respawns, car-car bumps): real calls, and `cold` so that the branches into them are laid out off the common path
+#define RLG_HD_COLD __host__ __device__ __noinline__ __attribute__((cold)) inline
 // The tick's small per-phase routines (a few hundred instructions, called once per tick) are inlined: as real calls they cost 2 % of a
 // collection launch and 11 % of its scratch write-back in register saves (-DRLG_NO_INLINE_SMALL restores the calls).  Inlining the mid-size
 // ones (wheel rays, solver_prepare: 1.3 - 2.8 K instructions) takes another 19 % off the write-back at equal time (-DRLG_NO_INLINE_MID);
@@ -91,6 +93,7 @@
 #define RLG_ASSUME_LDS_W(ref) ((void)0)
 #define RLG_HD inline
 #define RLG_HD_NOINLINE inline
+#define RLG_HD_COLD inline
 // The tick's small per-phase routines (a few hundred instructions, called once per tick) are inlined: as real calls they cost 2 % of a
 // collection launch and 11 % of its scratch write-back in register saves (-DRLG_NO_INLINE_SMALL restores the calls).  Inlining the mid-size
 // ones (wheel rays, solver_prepare: 1.3 - 2.8 K instructions) takes another 19 % off the write-back at equal time (-DRLG_NO_INLINE_MID);

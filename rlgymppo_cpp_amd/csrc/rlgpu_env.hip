@@ -463,7 +463,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         const Body& bd = li == 0 ? S.A.ball.b : S.A.cars[li - 1].b;
         my_alive = li == 0 ? !asleep : !(S.A.cars[li - 1].flags & CF_IS_DEMOED);
         const bool was = (C.alive >> li) & 1u;
-        if (!C.valid || was != my_alive) my_stale = true;
+        if (RLG_UNLIKELY(!C.valid || was != my_alive)) my_stale = true;
         else if (my_alive) {
             const V3 p = bd.pos, p0 = C.pos0[li];
             float moved = fmaxf(fabsf(p.x - p0.x), fmaxf(fabsf(p.y - p0.y), fabsf(p.z - p0.z)));
@@ -476,7 +476,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
             }
 #endif
             my_stale = !(moved <= 0.97f * CAND_FAT);   // (a NaN pose renews the list every tick)
-            if (!my_stale && ((C.watch >> li) & 1u)) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
+            if (RLG_UNLIKELY(!my_stale && ((C.watch >> li) & 1u))) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
                 cand_box(S.A, li, lo, hi);
                 my_stale = mesh_maybe_near(mv, lo, hi);
             }
@@ -488,7 +488,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     RLG_SPROF(37);
     // a walking tick needs the boxes themselves: does the body's reach the mesh, and if not, does its fat version
     bool my_watch = false;
-    if (walk && li < NB && my_alive) {
+    if (RLG_UNLIKELY(walk && li < NB && my_alive)) {
         cand_box(S.A, li, lo, hi);
         my_active = mesh_maybe_near(mv, lo, hi);
         if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(CAND_FAT, CAND_FAT, CAND_FAT), hi + v3(CAND_FAT, CAND_FAT, CAND_FAT));
@@ -498,7 +498,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     for (int attempt = 0; attempt < 2; attempt++) {
         const float fat = attempt == 0 ? CAND_FAT : 0.f;
         const bool go = walk && (attempt == 0 || overflow);
-        if (!__any(go)) break;
+        if (RLG_LIKELY(!__any(go))) break;
         if (go) overflow = false;
         if (go && li < NB) {
             if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); }
