@@ -137,10 +137,19 @@ typedef struct RlgpuGymState {
  *              and is reported back by every GetState.  rlgpu_env_upload_states stores it (all zeros = identity) in the env's resident
  *              words, every download hands it back.  The kernels and the host build of the stepper (oracle/arena_port.cpp) step in this
  *              basis, bit for bit like the reference (tests/golden/ballrot_golden.npz).
- *   valid, bp_hist, wreck_rot   RESERVED (written as 0 / read as "absent").  The slots for the arena's other hidden state -- btRSBroadphase's
- *              memory of its dynamic proxies ([0] ball, [1 + k] car slot k: cell of the last setAabb, 13 bits, and arrival rank, 3 bits) and
- *              the basis of a demolished car's rigid body (Car.cpp:69-80,135-138).  Both are resident on the device per env; moving them
- *              across this boundary was built and withdrawn in round 4. */
+ *   valid      which of the two fields below mean something (RLGPU_HIDDEN_*).  Downloads set both bits; a struct with a bit clear (every
+ *              recording, every state a user fills in) is Arena::SetState on an arena that keeps what it has: an env slot keeps its own
+ *              broadphase history, a demolished car's body takes the reported basis (Car.cpp:22-36).
+ *   bp_hist    btRSBroadphase's memory of its dynamic proxies ([0] ball, [1 + k] car slot k): cell of the last setAabb (bits 3..15) and arrival
+ *              rank among the dynamic proxies (bits 0..2) -- which decide the order of the overlapping pairs, hence of the manifolds, hence
+ *              of the solver's rows (csrc/arena_contact.h).  0 = never filed (a fresh arena).
+ *   wreck_rot  forward / right / up of a DEMOLISHED car's rigid body: the body keeps turning while the car's state reports the rotation of the
+ *              moment it was demolished (Car.cpp:69-80,135-138); all zeros for a car that is not demolished.
+ *              With both, a state downloaded mid-episode and uploaded into another env slot (or another batch) continues exactly as the env it
+ *              came from would have from that same struct (tests/golden/midtape_golden.npz: against the reference, whose side of this is read by
+ *              oracle/ref_driver.cpp:ref_arena_get_hidden from btRSBroadphase's cell lists). */
+#define RLGPU_HIDDEN_BP_HIST   1u
+#define RLGPU_HIDDEN_WRECK_ROT 2u
 typedef struct RlgpuArenaHidden {
     float ball_rot[9];               /* forward / right / up columns */
     uint32_t valid;

@@ -27,6 +27,7 @@
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkPairDetector.h>
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btVoronoiSimplexSolver.h>
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkEpaPenetrationDepthSolver.h>
+#include <bullet3-3.24/BulletCollision/BroadphaseCollision/btRSBroadphase.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btInternalEdgeUtility.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionObjectWrapper.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionWorld.h>
@@ -445,6 +446,50 @@ void* ref_arena_new_shuffled(int team_size, unsigned seed) {
 void ref_arena_rehash(void* h, int buckets) { ((Arena*)h)->_cars.rehash((size_t)buckets); }
 void ref_arena_free(void* h) { delete (Arena*)h; }
 void ref_arena_get_state(void* h, RlgpuArenaState* s) { GetArenaPhys((Arena*)h, s); }
+// The arena's hidden state into s->hidden (s: a state of this arena, from ref_arena_get_state): what btRSBroadphase remembers of its dynamic proxies --
+// the cell each was last filed under (btRSBroadphaseProxy::cellIdx) and the order in which they last ARRIVED in their cells, which is the order of
+// every cell's dynHandles list (btRSBroadphase.cpp:185-203,287-325: a proxy that changes cell is erased from its old 27 lists and pushed back onto
+// the new 27) -- and the basis of every demolished car's rigid body.  The arrival order is a total order here: any order that agrees with all the
+// cell lists (two proxies that share no list have no order yet; the first one to move next to the other goes to the back of the lists).
+void ref_arena_get_hidden(void* h, RlgpuArenaState* s) {
+    Arena* a = (Arena*)h;
+    btRSBroadphase* bp = dynamic_cast<btRSBroadphase*>(a->_bulletWorld.getBroadphase());
+    if (!bp) return;
+    const int nb = 1 + s->num_cars;
+    btRSBroadphaseProxy* px[8] = {};
+    px[0] = (btRSBroadphaseProxy*)a->ball->_rigidBody.getBroadphaseHandle();
+    for (int k = 0; k < s->num_cars; k++) if (Car* car = CarBySlot(a, k)) px[1 + k] = (btRSBroadphaseProxy*)car->_rigidBody.getBroadphaseHandle();
+    auto idx = [&](btRSBroadphaseProxy* p) { for (int b = 0; b < nb; b++) if (px[b] == p) return b; return -1; };
+    bool before[8][8] = {};
+    for (auto& cell : bp->cells)
+        for (size_t i = 0; i < cell.dynHandles.size(); i++)
+            for (size_t j = i + 1; j < cell.dynHandles.size(); j++) {
+                const int x = idx(cell.dynHandles[i]), y = idx(cell.dynHandles[j]);
+                if (x >= 0 && y >= 0) before[x][y] = true;
+            }
+    bool placed[8] = {}; int rank[8] = {};
+    for (int r = 0; r < nb; r++) {
+        int pick = -1;
+        for (int b = 0; b < nb && pick < 0; b++) {
+            if (placed[b]) continue;
+            bool free_ = true;
+            for (int o = 0; o < nb; o++) if (!placed[o] && o != b && before[o][b]) free_ = false;
+            if (free_) pick = b;
+        }
+        if (pick < 0) for (int b = 0; b < nb; b++) if (!placed[b]) { pick = b; break; }   // (cannot happen: the lists agree)
+        placed[pick] = true; rank[pick] = r;
+    }
+    for (int b = 0; b < 8; b++) s->hidden.bp_hist[b] = 0;
+    for (int b = 0; b < nb; b++) if (px[b]) s->hidden.bp_hist[b] = (uint16_t)(((uint32_t)px[b]->cellIdx << 3) | (uint32_t)rank[b]);
+    for (int k = 0; k < s->num_cars; k++) {
+        Car* car = CarBySlot(a, k);
+        for (int q = 0; q < 9; q++) s->hidden.wreck_rot[k][q] = 0.f;
+        if (!car || !car->_internalState.isDemoed) continue;
+        const RotMat rm = car->_rigidBody.getWorldTransform().getBasis();
+        V3(s->hidden.wreck_rot[k], rm.forward); V3(s->hidden.wreck_rot[k] + 3, rm.right); V3(s->hidden.wreck_rot[k] + 6, rm.up);
+    }
+    s->hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;
+}
 void ref_arena_set_state(void* h, const RlgpuArenaState* s) { SetArenaPhys((Arena*)h, s, true); }
 void ref_arena_set_controls(void* h, int slot, const float* c8) { CarBySlot((Arena*)h, slot)->controls = ArrToCtrl(c8); }
 void ref_arena_step(void* h, int ticks) { ((Arena*)h)->Step(ticks); }

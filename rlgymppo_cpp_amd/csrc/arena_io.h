@@ -160,7 +160,9 @@ template <int NC>
 RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& s) {
     A.tick_count = s.tick_count; A.ball_update_counter = s.ball_update_counter;
     A.car_order = car_order_checked(s.car_order, NC);
-    for (int b = 0; b <= NC; b++) A.bp_hist[b] = 0;      // no history travels with the exchange struct: a fresh arena set to this state
+    // the broadphase's memory of its proxies (RlgpuArenaHidden::bp_hist): what a download handed out goes back in; a struct without it (valid bit 0
+    // clear: every recording, every state a user builds) means a fresh arena set to this state -- an env slot keeps its own history then (k_upload)
+    for (int b = 0; b <= NC; b++) A.bp_hist[b] = (s.hidden.valid & RLGPU_HIDDEN_BP_HIST) ? s.hidden.bp_hist[b] : (uint16_t)0;
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
     {   // BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
@@ -185,7 +187,9 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
         c.vel_impulse_cache = ld3(o.vel_impulse_cache) * UU2BT;
         for (int w = 0; w < 4; w++) { c.extra_pushback[w] = o.extra_pushback[w]; c.lat_friction[w] = o.wheel_lat_friction[w]; c.long_friction[w] = o.wheel_long_friction[w]; }
         c.steer_angle = o.wheel_steer_angle; c.engine_force = o.wheel_engine_force; c.brake = o.wheel_brake;
-        c.b.inv_inertia_w = c.b.rot;     // car_ghost_rot of a demolished car: Car::SetState gives the rigid body the reported basis (Car.cpp:22-36)
+        c.b.inv_inertia_w = c.b.rot;     // car_ghost_rot of a demolished car: Car::SetState gives the rigid body the reported basis (Car.cpp:22-36) ...
+        if ((s.hidden.valid & RLGPU_HIDDEN_WRECK_ROT) && (o.flags & CF_IS_DEMOED))   // ... unless the state carries the basis the wreck's body really has
+            c.b.inv_inertia_w = m3_cols(ld3(s.hidden.wreck_rot[k]), ld3(s.hidden.wreck_rot[k] + 3), ld3(s.hidden.wreck_rot[k] + 6));
     }
     for (int p = 0; p < 34; p++) {
         A.pads[p].cooldown = s.pads[p].cooldown; A.pads[p].is_active = s.pads[p].is_active != 0;
@@ -215,7 +219,12 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
     st3(s.ball.pos, A.ball.b.pos * BT2UU); st3(s.ball.vel, A.ball.b.vel * BT2UU); st3(s.ball.ang_vel, A.ball.b.angvel);
     st3(s.ball.vel_impulse_cache, A.ball.vel_impulse_cache * BT2UU);
     st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));
-    s.hidden.valid = 0u;
+    // the arena's other hidden state: the broadphase history of the dynamic proxies, and the basis a demolished car's rigid body has turned to
+    // behind the stale rotation its state reports (car_ghost_rot, arena_world.h)
+    s.hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;
+    for (int b = 0; b < 8; b++) s.hidden.bp_hist[b] = b <= NC ? A.bp_hist[b] : (uint16_t)0;
+    for (int k = 0; k < RLGPU_MAX_CARS; k++) for (int q = 0; q < 9; q++) s.hidden.wreck_rot[k][q] = 0.f;
+    for (int k = 0; k < NC; k++) if (A.cars[k].flags & CF_IS_DEMOED) { const M3& g = A.cars[k].b.inv_inertia_w; st3(s.hidden.wreck_rot[k], col0(g)); st3(s.hidden.wreck_rot[k] + 3, col1(g)); st3(s.hidden.wreck_rot[k] + 6, col2(g)); }
     for (int k = 0; k < NC; k++) {
         RlgpuCarState& o = s.cars[k]; const Car& c = A.cars[k];
         st3(o.pos, c.b.pos * BT2UU);

@@ -1118,7 +1118,7 @@ __global__ void k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* en
     uint16_t hist[NC + 1];
     for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     arena_from_host(A, G, src[i]);
-    for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];
+    if (!(src[i].hidden.valid & RLGPU_HIDDEN_BP_HIST)) for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];   // (a state that carries a history brings its own)
     store_env(d, env, A, G);
 }
 template <int NC>

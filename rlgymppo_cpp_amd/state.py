@@ -76,7 +76,8 @@ class GymState(C.Structure):
 
 
 class ArenaHidden(C.Structure):
-    """RlgpuArenaHidden (include/rlgpu_state.h): the ball's basis (BallState::rotMat); valid / bp_hist / wreck_rot are reserved."""
+    """RlgpuArenaHidden (include/rlgpu_state.h): the ball's basis (BallState::rotMat); the broadphase's memory of its dynamic proxies (bp_hist) and a
+    demolished car's own rigid-body basis (wreck_rot), valid bit 0 / bit 1 saying which of the two mean something (downloads set both)."""
     _fields_ = [("ball_rot", f32 * 9), ("valid", C.c_uint32), ("bp_hist", C.c_uint16 * 8), ("wreck_rot", (f32 * 9) * MAX_CARS)]
 
 

@@ -559,6 +559,60 @@ def test_hip_wedge_fixture_contacts_beyond_the_lds_layout_vs_reference_golden(tm
     if "tiny" not in os.environ.get("RLGPU_LIB", ""): assert 100 < redone < 200    # (the host build of the same layout: 111)
 
 
+def test_hip_continues_a_mid_episode_reference_state_with_its_hidden_state():
+    """the hidden-state read-out, rebuilt.  tests/golden/midtape_golden.npz: ten mid-episode states of the reference with the
+    arena's hidden state (btRSBroadphase's cell and arrival rank of every dynamic proxy, read from its cell lists by oracle/ref_driver.cpp) and
+    the reference's continuation.  Uploaded into a FRESH env slot and into a USED one (a slot that has been ticking another game: its own history
+    must give way), the HIP path continues bit for bit like the arena the state came from, every field of every body to the end of the tape; the
+    same state with hidden.valid = 0 -- a fresh arena set to it, as before round 5 -- leaves the reference on the two cuts inside the six-car heap.
+    Then device to device: a state downloaded while a car lies demolished carries the wreck's own basis (it has turned away from the reported
+    one); uploaded into another slot and back into its own, both continue alike."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import state_vec
+    g = np.load(os.path.join(GOLD, "midtape_golden.npz"))
+    every = int(g["every"]); told_apart = []
+    for name in [str(x) for x in g["names"]]:
+        st = ArenaState.from_buffer_copy(g[f"cut/{name}/state"].tobytes()); nc = st.num_cars
+        bare = ArenaState.from_buffer_copy(g[f"cut/{name}/state"].tobytes()); bare.hidden.valid = 0
+        tape = g[f"cut/{name}/tape"]; want = g[f"cut/{name}/states"]
+        env = BatchedEnv(3, nc // 2)
+        # slot 1 plays something else first
+        other = default_arena(nc); env.upload_states([other], env_ids=[1])
+        ctl = np.zeros((3, nc, 8), np.float32); ctl[1, :, 0] = 1.0; ctl[1, :, 6] = 1.0
+        env.set_controls(ctl); env.physics_ticks(90)
+        env.upload_states([st, st, bare], env_ids=[0, 1, 2])
+        same_bare = True
+        for t in range(len(tape)):
+            ctl[:] = tape[t][None]; env.set_controls(ctl); env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states(); w = want[(t + 1) // every - 1]
+                assert np.array_equal(state_vec(cur[0]), w), f"{name} + {t + 1} ticks, fresh slot: HIP state is not the reference's"
+                assert np.array_equal(state_vec(cur[1]), w), f"{name} + {t + 1} ticks, used slot: HIP state is not the reference's"
+                same_bare = same_bare and np.array_equal(state_vec(cur[2]), w)
+        if not same_bare: told_apart.append(name)
+        env.close()
+    assert told_apart == ["3v3_kickoff@280", "3v3_kickoff@300"], told_apart
+    # a wreck's basis
+    sg = np.load(os.path.join(GOLD, "sim_golden.npz"))
+    s0 = ArenaState.from_buffer_copy(sg["phys/demo_and_respawn/start_raw"].tobytes()); tape = sg["phys/demo_and_respawn/tape"]; nc = s0.num_cars
+    env = BatchedEnv(2, nc // 2); env.upload_states([s0], env_ids=[0])
+    ctl = np.zeros((2, nc, 8), np.float32); t = 0; mid = None
+    while t < len(tape) and mid is None:
+        ctl[0] = tape[t]; env.set_controls(ctl); env.physics_ticks(1); t += 1
+        cur = env.download_states(env_ids=[0])[0]
+        wrecks = [k for k in range(nc) if cur.cars[k].flags & (1 << 13)]
+        if wrecks and cur.cars[wrecks[0]].demo_respawn_timer < 2.5: mid = cur
+    assert mid is not None and mid.hidden.valid == 3
+    k = wrecks[0]
+    assert any(abs(mid.hidden.wreck_rot[k][q] - mid.cars[k].rot[q]) > 1e-4 for q in range(9)), "the wreck's body has not turned away from the reported rotation"
+    env.upload_states([mid, mid], env_ids=[0, 1])
+    for t2 in range(t, len(tape)):
+        ctl[0] = tape[t2]; ctl[1] = tape[t2]; env.set_controls(ctl); env.physics_ticks(1)
+    a, b = env.download_states()
+    assert bytes(a) == bytes(b)
+    env.close()
+
+
 def test_live_reference_rollout(ref_lib, port_lib):
     """When the prebuilt reference .so travelled with the snapshot: step the real RLGymSim_CPP Gym on the host CPU next
     to the GPU env from the same state and action tape."""

@@ -315,6 +315,37 @@ def test_fallback_in_random_play_tiny_layout_equals_big_layout(port_lib):
     assert cnt[10] > 20 and cnt[7] == 0
 
 
+def test_port_continues_a_mid_episode_reference_state_with_its_hidden_state(port_lib):
+    """VERDICT r04 item 9.  tests/golden/midtape_golden.npz (make_midtape_golden.py): ten states taken mid-episode from the reference -- inside and
+    around the six-car heap of `3v3_kickoff`, bumps, a demolition, a pinch -- each with the arena's hidden state as oracle/ref_driver.cpp reads it
+    from btRSBroadphase's cell lists (RlgpuArenaState::hidden.bp_hist: cell and arrival rank of every dynamic proxy), and the reference's own
+    continuation of the tape from there.  The stepper given such a state continues bit for bit like the arena it came from, all ten; given the
+    same state WITHOUT the hidden block (a fresh arena set to it) it leaves the reference within 20 ticks on the two cuts inside the heap --
+    which is what the block is for."""
+    import ctypes as C
+    from simlib import PortSim
+    g = np.load(os.path.join(GOLD, "midtape_golden.npz"))
+    port = PortSim(); port.set_mesh(g["mesh_verts"], g["mesh_tris"])
+    port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    every = int(g["every"]); told_apart = []
+    try:
+        for name in [str(x) for x in g["names"]]:
+            for use_hidden in (True, False):
+                st = ArenaState.from_buffer_copy(g[f"cut/{name}/state"].tobytes())
+                assert st.hidden.valid == 3
+                if not use_hidden: st.hidden.valid = 0
+                tape = np.ascontiguousarray(g[f"cut/{name}/tape"], np.float32); want = g[f"cut/{name}/states"]
+                outs = (ArenaState * (len(tape) // every))()
+                port.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+                same = all(np.array_equal(state_vec(outs[j]), want[j]) for j in range(len(tape) // every))
+                if use_hidden: assert same, f"{name}: the continuation is not the reference's"
+                elif not same: told_apart.append(name)
+                else: assert outs[0].hidden.valid == 3 and any(outs[0].hidden.bp_hist[b] for b in range(st.num_cars + 1))   # (a download carries the block)
+    finally:
+        port.set_mesh(*port_lib.mesh)    # (the library's mesh is a global shared with the session's port_lib)
+    assert told_apart == ["3v3_kickoff@280", "3v3_kickoff@300"], told_apart
+
+
 def test_port_mesh_of_two_files_vs_reference_golden():
     """One collision object -- and one contact manifold per dynamic body -- per mesh FILE (RS/Sim/Arena/Arena.cpp:1028-1054): the procedural
     arena split into two .cmf files, recorded from the reference through its own per-file loading (tests/golden/seam_golden.npz,
