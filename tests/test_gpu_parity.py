@@ -205,33 +205,9 @@ def test_gym_step_matches_host_port_team_modes(port_lib, team_size, max_players)
     assert n_done > 0
 
 
-def test_cmf_directory_loader_equals_procedural_mesh(tmp_path):
-    """rlgpu_env_load_cmf_dir (RocketSim::Init over collision_meshes/soccar/*.cmf, RS/RocketSim.cpp:70-212): the procedural mesh
-    written out as two .cmf files (int32 nTris, int32 nVerts, tris, verts in BT units) and loaded back steps identically."""
-    from rlgymppo_cpp_amd.env import BatchedEnv, procedural_mesh
-    v, t = procedural_mesh()
-    half = len(t) // 2
-    for name, tris in (("a_first.cmf", t[:half]), ("b_second.cmf", t[half:])):
-        used = np.unique(tris); remap = -np.ones(len(v), np.int64); remap[used] = np.arange(len(used))
-        with open(tmp_path / name, "wb") as f:
-            f.write(np.int32(len(tris)).tobytes()); f.write(np.int32(len(used)).tobytes())
-            f.write(remap[tris].astype(np.int32).tobytes()); f.write((v[used] / 50.0).astype(np.float32).tobytes())
-    dev = torch.device("cuda", 0)
-    n = 96
-    outs = []
-    for mesh in ("procedural", str(tmp_path)):
-        env = BatchedEnv(n, 1, mesh=mesh)
-        obs = env.reset(True)
-        nobs = torch.empty_like(obs); rew = torch.empty(n * 2, device=dev); done = torch.empty(n * 2, dtype=torch.int32, device=dev)
-        rng = np.random.RandomState(2)
-        for step in range(12):
-            env.step(torch.from_numpy(rng.randint(0, 90, size=n * 2).astype(np.int32)).to(dev), nobs, rew, done)
-        env.sync(); outs.append((nobs.cpu().numpy().copy(), rew.cpu().numpy().copy()))
-        env.close()
-    # same triangles in the same order -> same BVH; the vertices went through a /50 *50 round trip in fp32, so not bitwise: a contact
-    # that sits at the 2 uu contact threshold may appear a tick apart in a few of the 96 envs
-    d_obs = np.abs(outs[0][0] - outs[1][0]).max(axis=1); d_rew = np.abs(outs[0][1] - outs[1][1])
-    assert (d_obs < 2e-3).mean() > 0.97 and (d_rew < 2e-3).mean() > 0.97 and d_obs.max() < 0.5
+# (The .cmf directory loader -- rlgpu_env_load_cmf_dir, RS/RocketSim.cpp:70-212 -- is held to EQUALITY with the reference by the two-file, sixteen-file
+# and round-robin fixtures below (test_hip_mesh_of_two_files..., ..._tessellated_mesh_of_sixteen_files..., ..._wedge_fixture...); a looser test that
+# compared it with the procedural mesh through a uu round trip of the vertices, 97 % of envs within 2e-3, was deleted in round 5.)
 
 
 def _gym_cfg(team, tick_skip, omp, rk, nts):

@@ -394,7 +394,8 @@ def test_two_ranks_on_one_gpu_run_the_whole_multi_gpu_path_and_fail_fast(tmp_pat
         line = json.loads(outs[0][0].strip().splitlines()[-1])
         assert line["rccl_ranks"] == 2 and line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["allreduce_calls"] == 3, line
         sums.append(cs[0])
-    # (two launches do not end in the same bits: the dW GEMMs sum their row slabs with fp32 atomics, in whatever order the slabs finish)
+    # (since round 5 the fused minibatch kernels sum their row slabs in a fixed order -- per-slab partials + an ordered reduce, csrc/ppo_fused.h -- so
+    # two launches of the same flow do end in the same bits; what this test holds is that BOTH ranks do, and that the other rank's gradients entered)
     solo = subprocess.run([exe, "--envs", "256", "--horizon", "8", "--steps", "3", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
                           env=dict(os.environ, RLGPU_LOCKSTEP_COLLECTION="1", RLGPU_QUIET="1"))
     assert solo.returncode == 0
