@@ -499,6 +499,38 @@ RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue<NC>& Q, int ci) 
     return 4 * (int)Q.cand_count[1 + ci];
 }
 
+// updateVehicleSecond for one wheel (btVehicleRL.cpp:277-310 suspension, :390-402 friction), up to the products: the velocity changes its two
+// impulses make.  Nothing here reads the car's velocities, so the wheel's lane can do it ahead of the car's control phase.
+RLG_HD float wheel_suspension_force(const WheelTmp& w, int i) {
+    if (!w.in_contact) return 0.f;
+    float force = (wheel_rest(i) - w.susp_len) * K::SUSPENSION_STIFFNESS * w.clipped_inv;
+    float damp = (w.susp_rel_vel < 0) ? K::WHEELS_DAMPING_COMPRESSION : K::WHEELS_DAMPING_RELAXATION;
+    float f = force - (damp * w.susp_rel_vel);
+    f *= (i < 2) ? K::SUSPENSION_FORCE_SCALE_FRONT : K::SUSPENSION_FORCE_SCALE_BACK;
+    if (f < 0) f = 0;
+    return f;
+}
+RLG_HD void wheel_velocity_deltas(WheelTmp& w, const Body& b, int i, float extra_pushback) {
+    const float dt = TICK_DT;
+    const float f = wheel_suspension_force(w, i);
+    w.susp_nz = f != 0.f;
+    if (w.susp_nz) {
+        V3 off = w.contact_point - b.pos;
+        float scale = (f * dt) + extra_pushback;
+        V3 imp = w.contact_normal * scale;
+        w.susp_dv = imp * CAR_INV_MASS; w.susp_dw = b.inv_inertia_w * cross(off, imp);
+    }
+    w.fric_nz = !is_zero(w.impulse);
+    if (w.fric_nz) {
+        V3 updir = col2(b.rot);
+        V3 off = w.contact_point - b.pos;
+        float updot = dot(updir, off);
+        V3 rel = off - updir * updot;
+        V3 imp = w.impulse * dt;
+        w.fric_dv = imp * CAR_INV_MASS; w.fric_dw = b.inv_inertia_w * cross(rel, imp);
+    }
+}
+
 template <int NC>
 RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh, const CollideQueue<NC>& Q, CarTickCtx& t) {
     RLG_ASSUME_LDS(A); RLG_ASSUME_LDS(t); RLG_ASSUME_LDS(Q);
@@ -561,6 +593,7 @@ RLG_HD_MID void car_wheel_ray_finish(Arena<NC>& A, int ci, int i, MeshView mesh,
     w.impulse = wheel_friction_impulse(A, cr, w, t.wheel_basis[i >> 1], i);
     RLG_SPROF(42);
     if (w.ground >= 0) wheel_friction_factors(cr, w, t.wheel_basis[i >> 1], t.new_lat[i], t.new_long[i]);
+    wheel_velocity_deltas(w, cr.b, i, cr.extra_pushback[i]);
     t.w[i] = w;
 }
 
@@ -617,29 +650,23 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
     c.flags &= ~CF_WORLD_CONTACT;
     RLG_SPROF(34);
 
-    // updateVehicleSecond: suspension (btVehicleRL.cpp:277-310) then friction impulses (:390-402)
-    float susp_force[4];
-    for (int i = 0; i < 4; i++) {
-        const WheelTmp& w = t.w[i];
-        if (w.in_contact) {
-            float force = (wheel_rest(i) - w.susp_len) * K::SUSPENSION_STIFFNESS * w.clipped_inv;
-            float damp = (w.susp_rel_vel < 0) ? K::WHEELS_DAMPING_COMPRESSION : K::WHEELS_DAMPING_RELAXATION;
-            float f = force - (damp * w.susp_rel_vel);
-            f *= (i < 2) ? K::SUSPENSION_FORCE_SCALE_FRONT : K::SUSPENSION_FORCE_SCALE_BACK;
-            if (f < 0) f = 0;
-            susp_force[i] = f;
-        } else susp_force[i] = 0.f;
-    }
-    for (int i = 0; i < 4; i++) {
-        if (susp_force[i] != 0.f) {
-            const WheelTmp& w = t.w[i];
-            V3 off = w.contact_point - c.b.pos;
-            float scale = (susp_force[i] * dt) + c.extra_pushback[i];
-            body_apply_impulse(c.b, w.contact_normal * scale, off, CAR_INV_MASS);
+    // updateVehicleSecond: suspension (btVehicleRL.cpp:277-310) then friction impulses (:390-402): the velocity changes were formed by the wheels'
+    // lanes (wheel_velocity_deltas); here they are added up, in the reference's order
+    if (RLG_LIKELY(!ordered)) {
+        for (int i = 0; i < 4; i++) if (t.w[i].susp_nz) { c.b.vel += t.w[i].susp_dv; c.b.angvel += t.w[i].susp_dw; }
+        RLG_SPROF(35);
+        for (int i = 0; i < 4; i++) if (t.w[i].fric_nz) { c.b.vel += t.w[i].fric_dv; c.b.angvel += t.w[i].fric_dw; }
+    } else {   // (a wheel on another car: its friction impulse was formed just now, in car order)
+        for (int i = 0; i < 4; i++) {
+            const float f = wheel_suspension_force(t.w[i], i);
+            if (f != 0.f) {
+                const WheelTmp& w = t.w[i];
+                V3 off = w.contact_point - c.b.pos;
+                float scale = (f * dt) + c.extra_pushback[i];
+                body_apply_impulse(c.b, w.contact_normal * scale, off, CAR_INV_MASS);
+            }
         }
-    }
-    RLG_SPROF(35);
-    {
+        RLG_SPROF(35);
         V3 updir = col2(c.b.rot);
         for (int i = 0; i < 4; i++) {
             const WheelTmp& w = t.w[i];

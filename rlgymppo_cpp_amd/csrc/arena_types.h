@@ -163,6 +163,11 @@ struct WheelTmp {
     float susp_len, susp_rel_vel, clipped_inv;
     int ground;  // -1 none, 0 static world, 1 ball, 2+k car k
     bool in_contact;
+    // what the wheel's suspension force and friction impulse add to the car's velocities (btRigidBody::applyImpulse, btRigidBody.h:342-352): computed by
+    // the wheel's own lane at the end of phase 1c -- they depend on the wheel and on the car's pose only --, added up by the car's lane in wheel order
+    // (the sums are formed in the reference's order; only the products moved).  *_nz: the reference applies the impulse at all (it skips zero ones)
+    bool susp_nz, fric_nz;
+    V3 susp_dv, susp_dw, fric_dv, fric_dw;
 };
 
 // CarHot = what the car's control phase (arena_car.h:car_pre_tick_finish, every tick, on a register copy of the car) reads or writes; the rest of
