@@ -51,7 +51,7 @@ mesh = os.path.join(bench.make_tessellated_mesh_dir()[0], "soccar")
 ne = envs_b; Bsz = ne * 2 * team_b * 32
 L = Learner(LearnerConfig(numEnvs=ne, teamSize=team_b, timestepsPerIteration=Bsz, expBufferSize=Bsz, randomSeed=1,
                           ppo=PPOLearnerConfig(batchSize=Bsz, miniBatchSize=Bsz // 4, epochs=2, policyLR=2e-4, criticLR=2e-4, entCoef=0.01, autocastLearn=True)), mesh=mesh)
-L.env.overflow_counts(reset=True); L.env.lost_contact_count(reset=True); L.env.epa_counts(reset=True)
+L.env.overflow_counts(reset=True); L.env.lost_contact_count(reset=True); L.env.epa_counts(reset=True); L.env.big_layout_ticks(reset=True)
 t0 = time.time(); rews = []
 for i in range(iters):
     L.iteration()
@@ -60,4 +60,4 @@ for i in range(iters):
 L.env.check_redzones(); L.ppo.check_redzones()
 ticks = iters * 32 * ne * 8
 print(f"B: {team_b}v{team_b}, {ne} envs, {iters} learning iterations ({ticks / 1e6:.0f} M env-ticks, tessellated arena), mean step reward every 50 iterations {rews}: redzones clean; "
-      f"lost-contact events {L.env.lost_contact_count()}, exact fallbacks {L.env.overflow_counts()}, EPA queries {L.env.epa_counts()} ({time.time() - t0:.0f} s)")
+      f"lost-contact events {L.env.lost_contact_count()}, env-ticks redone with the big contact layout {L.env.big_layout_ticks()}, exact fallbacks {L.env.overflow_counts()}, EPA queries {L.env.epa_counts()} ({time.time() - t0:.0f} s)")
