@@ -685,7 +685,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
 // ---- Car::_PostTickUpdate + _FinishPhysicsTick (Car.cpp:133-193) ------------------------------------------
 RLG_HD void car_post_tick(Car& c) {
     const float dt = TICK_DT;
-    if (c.flags & CF_IS_DEMOED) return;
+    if (RLG_UNLIKELY(c.flags & CF_IS_DEMOED)) return;
     {
         V3 vuu = c.b.vel * BT2UU;
         float sp2 = len2(vuu);
@@ -697,13 +697,13 @@ RLG_HD void car_post_tick(Car& c) {
         if (ss) { c.flags |= CF_IS_SUPERSONIC; c.supersonic_time += dt; }
         else { c.flags &= ~CF_IS_SUPERSONIC; c.supersonic_time = 0.f; }
     }
-    if (c.car_contact_cooldown > 0) c.car_contact_cooldown = fmaxf(c.car_contact_cooldown - dt, 0.f);
+    if (RLG_UNLIKELY(c.car_contact_cooldown > 0)) c.car_contact_cooldown = fmaxf(c.car_contact_cooldown - dt, 0.f);
     c.last = c.ctl;
     // _FinishPhysicsTick
-    if (!is_zero(c.vel_impulse_cache)) { c.b.vel += c.vel_impulse_cache; c.vel_impulse_cache = v3(0, 0, 0); }
+    if (RLG_UNLIKELY(!is_zero(c.vel_impulse_cache))) { c.b.vel += c.vel_impulse_cache; c.vel_impulse_cache = v3(0, 0, 0); }
     const float vmax = K::CAR_MAX_SPEED * UU2BT;
     if (len2(c.b.vel) > vmax * vmax) c.b.vel = normalized(c.b.vel) * vmax;
-    if (len2(c.b.angvel) > K::CAR_MAX_ANG_SPEED * K::CAR_MAX_ANG_SPEED) c.b.angvel = normalized(c.b.angvel) * K::CAR_MAX_ANG_SPEED;
+    if (RLG_UNLIKELY(len2(c.b.angvel) > K::CAR_MAX_ANG_SPEED * K::CAR_MAX_ANG_SPEED)) c.b.angvel = normalized(c.b.angvel) * K::CAR_MAX_ANG_SPEED;
 }
 
 }  // namespace rlg

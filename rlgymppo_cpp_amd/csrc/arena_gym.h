@@ -162,7 +162,7 @@ RLG_HD_T6A void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
     if (buc > G.last_ball_update_count) {
         int64_t delta_ticks = buc - G.last_ball_update_count;
         float delta_time = (float)delta_ticks * TICK_DT;
-        if (scored && !scored_last) {
+        if (RLG_UNLIKELY(scored && !scored_last)) {
             int sh, pa;
             int team = (-A.ball.b.pos.y) < 0 ? 0 : 1;
             if (shooter_passer(A, team, sh, true, pa, (int64_t)(4.0f * tickrate), (int64_t)(2.0f * tickrate))) {
@@ -173,7 +173,7 @@ RLG_HD_T6A void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
             if (G.shot_cooldown > 0) G.shot_cooldown = fmaxf(G.shot_cooldown - delta_time, 0.f);
             else {
                 float sp2 = len2(A.ball.b.vel * BT2UU);
-                if (sp2 >= 1750.f * 1750.f) {
+                if (RLG_UNLIKELY(sp2 >= 1750.f * 1750.f)) {
                     int goal_team;
                     if (ball_probably_going_in(A, 2.0f, goal_team)) {
                         int shooter_team = 1 - goal_team;
@@ -534,7 +534,7 @@ RLG_HD bool gym_step_after_first_tick(Arena<NC>& A, GymEnv<NC>& G, const GymConf
 template <int NC>
 RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* next_obs, size_t obs_row_stride, bool done, Snapshot<NC>& S) {
     G.episode_steps++;
-    if (done && !cfg.host_resets) {   // GameInst::Step: the recorded next observation is the first one of the new episode (GameInst.cpp:27-32)
+    if (RLG_UNLIKELY(done && !cfg.host_resets)) {   // GameInst::Step: the recorded next observation is the first one of the new episode (GameInst.cpp:27-32)
         reset_state(A, G, cfg, env_id);
         gym_episode_reset(A, G, cfg, S);
         G.tracker_flags &= ~0xff00u;

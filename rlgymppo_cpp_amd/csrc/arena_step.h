@@ -1111,9 +1111,9 @@ RLG_HD_SMALL void solver_finish(Arena<NC>& A, TickWork<NC, BIG>& W, int body) {
             // (Car.cpp:135-138), which it skips for a demoed car -- so the state keeps the pre-tick basis while position and velocities
             // come from the body (Car.cpp:10-20).  The body is disabled from the next pre-tick on and rebuilt at respawn.
             // The BODY turns all the same, and stays in the world as it then stands: car_ghost_rot (arena_world.h).
-            const bool rot_stale = (flags & CF_IS_DEMOED) != 0;
+            const bool rot_stale = RLG_UNLIKELY((flags & CF_IS_DEMOED) != 0);
             M3 rot = b.rot;
-            if (!is_zero(s.push) || !is_zero(s.turn)) {
+            if (RLG_UNLIKELY(!is_zero(s.push) || !is_zero(s.turn))) {
                 b.pos = b.pos + s.push * dt;
                 rot = integrate_rotation(rot, s.turn * K::SPLIT_TURN_ERP, dt);
             }
@@ -1281,18 +1281,18 @@ RLG_HD_SMALL uint64_t pads_check_car(const Arena<NC>& A, const uint32_t* tab, in
     RLG_ASSUME_LDS(A);
     const Car& car = A.cars[ci];
     uint64_t mask = 0;
-    if ((car.flags & CF_IS_DEMOED) || car.boost >= 100) return mask;
+    if (RLG_UNLIKELY((car.flags & CF_IS_DEMOED) || car.boost >= 100)) return mask;
     V3 cp = car.b.pos * BT2UU;
     if (cp.z > K::PAD_CYL_HEIGHT + 250.f) return mask;
     int ix = (int)(cp.x / 1024 + 4), iy = (int)(cp.y / 1024 + 5);
     // no table (single-lane device callers of arena_tick: none on the product path) or a car outside the pad grid (never in play)
-    if (!tab || ix < 0 || ix > 7 || iy < 0 || iy > 9) return pads_check_car_cells(A, ci, ix, iy);
+    if (RLG_UNLIKELY(!tab || ix < 0 || ix > 7 || iy < 0 || iy > 9)) return pads_check_car_cells(A, ci, ix, iy);
 #if defined(__HIP_DEVICE_COMPILE__)
     RLG_ASSUME_LDS(*tab);
 #endif
     const uint32_t near_pads = tab[34 + ix * 10 + iy];
     if (near_pads == 0u) return mask;
-    if (near_pads == 0xFFFFFFFFu) return pads_check_car_cells(A, ci, ix, iy);   // a pad layout with a crowded cell
+    if (RLG_UNLIKELY(near_pads == 0xFFFFFFFFu)) return pads_check_car_cells(A, ci, ix, iy);   // a pad layout with a crowded cell
     V3 cmin, cmax; pad_car_box(car, cmin, cmax);
     RLG_NOUNROLL
     for (uint32_t w = near_pads; w != 0u; w >>= 8) {
@@ -1387,10 +1387,10 @@ RLG_HD_SMALL void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_d
     }
     {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
         Ball& b = A.ball;
-        if (!is_zero(b.vel_impulse_cache)) { b.b.vel += b.vel_impulse_cache; b.vel_impulse_cache = v3(0, 0, 0); }
+        if (RLG_UNLIKELY(!is_zero(b.vel_impulse_cache))) { b.b.vel += b.vel_impulse_cache; b.vel_impulse_cache = v3(0, 0, 0); }
         const float vmax = K::BALL_MAX_SPEED * UU2BT;
-        if (len2(b.b.vel) > vmax * vmax) b.b.vel = normalized(b.b.vel) * vmax;
-        if (len2(b.b.angvel) > K::BALL_MAX_ANG_SPEED * K::BALL_MAX_ANG_SPEED) b.b.angvel = normalized(b.b.angvel) * K::BALL_MAX_ANG_SPEED;
+        if (RLG_UNLIKELY(len2(b.b.vel) > vmax * vmax)) b.b.vel = normalized(b.b.vel) * vmax;
+        if (RLG_UNLIKELY(len2(b.b.angvel) > K::BALL_MAX_ANG_SPEED * K::BALL_MAX_ANG_SPEED)) b.b.angvel = normalized(b.b.angvel) * K::BALL_MAX_ANG_SPEED;
         A.ball_update_counter++;
     }
     A.tick_count++;
