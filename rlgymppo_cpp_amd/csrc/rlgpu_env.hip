@@ -174,6 +174,7 @@ struct EnvDev {
     RlgpuArenaState* snap_out;   // host-plugin fallback (rlgpu_env_enable_snapshots): every step's GameState source, [n_envs], or null
     unsigned char* big_work;     // [BIG_WORK_SLOTS][big_work_bytes<NC>()]: where a tick whose contacts do not fit the LDS layout is redone (tick_world_big)
     uint32_t* big_locks;         // [BIG_WORK_SLOTS] 0 = free
+    float cand_fat;              // how far the candidate walk's boxes are grown (chosen by the mesh's density: see CAND_FAT above)
 };
 
 // Everything one env touches during a step lives in LDS (state + per-tick scratch): as stack objects these
@@ -185,10 +186,20 @@ struct EnvDev {
 // bodies take part), the kept leaves are a superset of what a fresh walk would list, in the same relative order, and the exact per-triangle
 // tests that follow see to it that the tick's items -- and with them every result -- are those of a fresh walk.  Worth it because the
 // walk was ~10 % of a collection launch (priced by running it twice) and most bodies move a fraction of CAND_FAT per tick.
+// How fat: a fatter box is renewed less often and lists more leaves, each of which costs four candidate tests on every tick it is kept.  On the
+// 180-triangle procedural arena the optimum is flat around 2.0 Bullet units (round 3: 1.0 / 2.0 / 3.0 -> 23.0 / 22.4 / 22.65 ms per launch; round
+// 5: 0.5 / 1.0 / 2.0 / 4.0 -> 17.65 / 18.02 / 18.14 / 18.07 M agent-steps/s); on the 10 084-triangle tessellated arena leaves are what costs:
+// 0.5 / 1.0 / 1.5 / 2.0 / 3.0 / 4.0 -> 15.44 / 15.21 / 14.86 / 14.19 / 13.02 / 12.46 M.  So the value is chosen when the mesh is set (EnvDev::cand_fat):
+// RLG_CAND_FAT for meshes up to RLG_CAND_DENSE_TRIS triangles, RLG_CAND_FAT_DENSE beyond.  Results do not depend on it.
 #ifndef RLG_CAND_FAT
-#define RLG_CAND_FAT 2.0f          // Bullet units (100 uu); measured 1.0 / 2.0 / 3.0: collection launch 23.0 / 22.4 / 22.65 ms (23.4 without the cache)
+#define RLG_CAND_FAT 2.0f          // Bullet units (100 uu)
 #endif
-constexpr float CAND_FAT = RLG_CAND_FAT;
+#ifndef RLG_CAND_FAT_DENSE
+#define RLG_CAND_FAT_DENSE 1.0f
+#endif
+#ifndef RLG_CAND_DENSE_TRIS
+#define RLG_CAND_DENSE_TRIS 2000
+#endif
 static_assert(BALL_CAND == CAR_CAND, "one leaf capacity for every body");
 // The kept leaves themselves (first triangle | count << 24, ascending = the reference's visiting order): a tick that does not walk copies
 // them into its queue (CollideQueue::leaf).  Where the wavefront's envs leave LDS to spare (1v1 at four envs per wavefront) they stay in
@@ -277,8 +288,9 @@ __device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G)
 }
 
 __shared__ uint32_t* g_leaf_cache;   // EnvDev::leaf_cache for the tick's candidate phase (kept out of the argument lists of the per-phase calls)
+__shared__ float g_cand_fat;         // EnvDev::cand_fat
 __device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage, uint32_t* lds_grid, uint32_t* lds_pad) {
-    if (threadIdx.x == 0) g_leaf_cache = d.leaf_cache;
+    if (threadIdx.x == 0) { g_leaf_cache = d.leaf_cache; g_cand_fat = d.cand_fat; }
     if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
     for (int i = threadIdx.x; i < PAD_TAB_WORDS; i += blockDim.x) lds_pad[i] = d.pad_tab[i];
     int n_fast = d.n_nodes < n_stage ? d.n_nodes : n_stage;
@@ -455,6 +467,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     const unsigned long long below = (1ull << li) - 1ull;
     const bool asleep = (len2(S.A.ball.b.vel) == 0.f && len2(S.A.ball.b.angvel) == 0.f);
     const bool too_big = mv.n_nodes > 65535;   // frontier entries carry 16-bit node ids: bigger trees use the inline walk
+    const float cand_fat = g_cand_fat;
     const bool all_fast = mv.n_nodes <= mv.n_fast;
     // is body b's kept list still good?  lane b of the group looks how far the body has moved since the walk (cand_box)
     bool my_active = false, my_stale = false, my_alive = false;
@@ -475,7 +488,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                 moved += turned * CAND_REACH;
             }
 #endif
-            my_stale = !(moved <= 0.97f * CAND_FAT);   // (a NaN pose renews the list every tick)
+            my_stale = !(moved <= 0.97f * cand_fat);   // (a NaN pose renews the list every tick)
             if (RLG_UNLIKELY(!my_stale && ((C.watch >> li) & 1u))) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
                 cand_box(S.A, li, lo, hi);
                 my_stale = mesh_maybe_near(mv, lo, hi);
@@ -491,12 +504,12 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     if (RLG_UNLIKELY(walk && li < NB && my_alive)) {
         cand_box(S.A, li, lo, hi);
         my_active = mesh_maybe_near(mv, lo, hi);
-        if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(CAND_FAT, CAND_FAT, CAND_FAT), hi + v3(CAND_FAT, CAND_FAT, CAND_FAT));
+        if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(cand_fat, cand_fat, cand_fat), hi + v3(cand_fat, cand_fat, cand_fat));
     }
     bool overflow = too_big;
     // The walk (fat boxes first; should their lists not fit, once more with the exact boxes, and the result is not kept).
     for (int attempt = 0; attempt < 2; attempt++) {
-        const float fat = attempt == 0 ? CAND_FAT : 0.f;
+        const float fat = attempt == 0 ? cand_fat : 0.f;
         const bool go = walk && (attempt == 0 || overflow);
         if (RLG_LIKELY(!__any(go))) break;
         if (go) overflow = false;
@@ -1351,7 +1364,7 @@ int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, con
             HIPCHK(e, hipMemset(e->d.leaf_cache, fill, (size_t)n_envs * (e->nc + 1) * CACHE_LEAVES * sizeof(uint32_t)));
         }
     }
-    e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr;
+    e->d.n_envs = n_envs; e->d.nodes = nullptr; e->d.tris = nullptr; e->d.n_nodes = 0; e->d.n_tris = 0; e->d.grid = nullptr; e->d.cand_fat = RLG_CAND_FAT;
     {
         dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(n_envs), env_grid<4>(n_envs), env_grid<6>(n_envs))), block(WAVE);
         DISPATCH_NC(e, k_env_fresh, grid, block, e->d);
@@ -1409,6 +1422,7 @@ static int env_set_mesh_parts(rlgpu_env* e, const float* verts, int n_verts, con
     if (e->d_nodes) { rz_free(e, e->d_nodes); e->d_nodes = nullptr; }
     if (e->d_tris) { rz_free(e, e->d_tris); e->d_tris = nullptr; }
     e->d.n_nodes = (int)m.nodes.size(); e->d.n_tris = (int)m.tris.size();
+    e->d.cand_fat = e->d.n_tris > RLG_CAND_DENSE_TRIS ? RLG_CAND_FAT_DENSE : RLG_CAND_FAT;
     if (!m.nodes.empty()) {
         HIPCHK(e, RZ_MALLOC(e, e->d_nodes, m.nodes.size() * sizeof(BvhNode), "BVH nodes"));
         HIPCHK(e, RZ_MALLOC(e, e->d_tris, m.tris.size() * sizeof(MeshTri), "mesh triangles"));

@@ -6,7 +6,11 @@ sys.path.insert(0, ROOT)
 from rlgymppo_cpp_amd.env import BatchedEnv
 from rlgymppo_cpp_amd.ppo import PPOCore
 n, T = 4096, 32
-env = BatchedEnv(n, 1); dev = torch.device("cuda", 0)
+mesh = "procedural"
+if len(sys.argv) > 1 and sys.argv[1] == "tess":      # the arena at ~10 k triangles in 16 .cmf files (bench.py --mesh tessellated)
+    import bench
+    mesh, info = bench.make_tessellated_mesh_dir(); mesh = os.path.join(mesh, "soccar"); print("mesh:", info)
+env = BatchedEnv(n, 1, mesh=mesh); dev = torch.device("cuda", 0)
 N, D = env.n_agents, env.obs_size
 ppo = PPOCore(D, 90, (256, 256, 256), (256, 256, 256), use_bf16=True, max_rows=65536, seed=1)
 obs = torch.zeros((T + 1, N, D), device=dev); acts = torch.zeros((T, N), dtype=torch.int32, device=dev); logp = torch.zeros((T, N), device=dev)
