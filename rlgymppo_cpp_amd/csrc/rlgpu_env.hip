@@ -498,6 +498,9 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     // one body out of its box and EVERY env of the wavefront walks again: the walk is level-synchronous over the whole wavefront anyway (an env
     // that would not have had to walk costs nothing extra), and boxes that are renewed together tend to run out together
     const bool walk = grp && !too_big && __any(my_stale);
+#ifdef RLG_TICK_PROFILE
+    if (grp && li == 0) RLG_DBG_COUNT(13);   // (env-ticks)
+#endif
     RLG_SPROF(37);
     // a walking tick needs the boxes themselves: does the body's reach the mesh, and if not, does its fat version
     bool my_watch = false;
@@ -512,6 +515,9 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         const float fat = attempt == 0 ? cand_fat : 0.f;
         const bool go = walk && (attempt == 0 || overflow);
         if (RLG_LIKELY(!__any(go))) break;
+#ifdef RLG_TICK_PROFILE   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
+        if (go && li == 0) { if (attempt == 0) RLG_DBG_COUNT(11); else RLG_DBG_COUNT(12); }
+#endif
         if (go) overflow = false;
         if (go && li < NB) {
             if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); }

@@ -55,3 +55,10 @@ for it in range(12):
         q = np.percentile(tot, [1, 50, 90, 99])
         print("launch %d: workgroup cycles min %.2fM p1 %.2fM median %.2fM mean %.2fM p90 %.2fM p99 %.2fM max %.2fM (%.1f ms); inference share of the mean %.1f%% (per step: MLP %.0fK cycles, head %.0fK); mean/max %.2f"
               % (it, tot.min() / 1e6, q[0] / 1e6, q[1] / 1e6, tot.mean() / 1e6, q[2] / 1e6, q[3] / 1e6, tot.max() / 1e6, tot.max() / 2.38e6, 100 * inf.mean() / tot.mean(), mlp.mean() / T / 1e3, (inf.mean() - mlp.mean()) / T / 1e3, tot.mean() / tot.max()))
+
+try:
+    env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
+    dbg = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints(env.h, dbg)
+    if dbg[13]: print("candidate walks: %d env-ticks, %.1f %% of them walk, %.1f %% of the walks did not fit their fat boxes (redone with the exact boxes, list not kept)" % (dbg[13], 100.0 * dbg[11] / dbg[13], 100.0 * dbg[12] / max(1, dbg[11])))
+except Exception as ex:
+    print("no debug ints:", ex)
