@@ -498,7 +498,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     // one body out of its box and EVERY env of the wavefront walks again: the walk is level-synchronous over the whole wavefront anyway (an env
     // that would not have had to walk costs nothing extra), and boxes that are renewed together tend to run out together
     const bool walk = grp && !too_big && __any(my_stale);
-#ifdef RLG_TICK_PROFILE
+#if defined(RLG_TICK_PROFILE) || defined(RLG_WWM_WAIT_CASE)   /* (RLG_WWM_WAIT_CASE: a test variant whose two dead statements move the whole-wave-bracket defect behind a wait: tests/test_gpu_parity.py) */
     if (grp && li == 0) RLG_DBG_COUNT(13);   // (env-ticks)
 #endif
     RLG_SPROF(37);
@@ -515,7 +515,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         const float fat = attempt == 0 ? cand_fat : 0.f;
         const bool go = walk && (attempt == 0 || overflow);
         if (RLG_LIKELY(!__any(go))) break;
-#ifdef RLG_TICK_PROFILE   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
+#if defined(RLG_TICK_PROFILE) || defined(RLG_WWM_WAIT_CASE)   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
         if (go && li == 0) { if (attempt == 0) RLG_DBG_COUNT(11); else RLG_DBG_COUNT(12); }
 #endif
         if (go) overflow = false;

@@ -1412,6 +1412,41 @@ def test_previously_faulting_inlining_variant_builds_and_runs(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_wwm_repair_that_has_to_cross_a_wait_builds_and_runs(tmp_path):
+    """Round 5: two counters that compile to nothing in the release build (-DRLG_WWM_WAIT_CASE puts them back as dead statements) shift the register
+    allocation of `k_env_collect<4>` so that one instance of the whole-wave-bracket defect sits BEHIND an `s_waitcnt` inside its bracket.  The repair
+    (tools/hipcc_wwm_safe.py) used to refuse that case and the build failed; now the moved instruction takes a full `s_waitcnt vmcnt(0) expcnt(0)
+    lgkmcnt(0)` with it (the same counter value would promise less at the earlier position).  Here: the variant is compiled on the box through the
+    tool, the log must say that it took that path (this compiler, this source: if it stops doing so the assertion says so), the repaired library
+    runs 2v2 and 3v3 collection launches, and its experience equals the default library's bit for bit."""
+    import subprocess
+    csrc = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
+    obj = str(tmp_path / "rlgpu_env_waitcase.o"); log = str(tmp_path / "wwm.log"); so = str(tmp_path / "librlgpu_waitcase.so")
+    flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-ffp-contract=off", "-DRLG_WWM_WAIT_CASE"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipcc_wwm_safe.py"), "--log", log] + flags + ["-c", os.path.join(csrc, "rlgpu_env.hip"), "-o", obj],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=csrc)
+    assert r.returncode == 0, r.stdout[-3000:]
+    found = open(log).read()
+    others = [os.path.join(csrc, "_obj", f) for f in ("rlgpu_learn.o", "rlgpu_comm.o", "arena_mesh.o", "lt_archive.o")]
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", so, "-L/opt/rocm/lib", "-lrccl", "-lrt", "-Wl,-rpath,/opt/rocm/lib"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    for team, envs in (("2", "96"), ("3", "48")):
+        outs = []
+        for lib in (so, None):
+            out = str(tmp_path / (f"waitcase{team}.npz" if lib else f"default{team}.npz"))
+            env = dict(os.environ); env.pop("RLGPU_LIB", None)
+            if lib: env["RLGPU_LIB"] = lib
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repro_collect4.py"), team, envs, "9", "12", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT)
+            assert r.returncode == 0 and "launch 3 ok" in r.stdout, r.stdout[-3000:]
+            outs.append(np.load(out))
+        for k in ("obs", "act", "logp", "rew", "done"):
+            assert np.array_equal(outs[0][k], outs[1][k]), (team, k)
+    assert "a full s_waitcnt goes with" in found, "the compiler no longer produces the behind-a-wait case in this variant: " + found[-1500:]
+
+
+@pytest.mark.gpu
 def test_stripe_kernels_equal_the_per_layer_path(tmp_path):
     """csrc/mlp_stripe.h (RLGPU_STRIPE=1): forward and dX chains of both networks in one launch each, activations in LDS from layer to layer.
     Same operands, same accumulation order per 32x32 tile, same rounding points as the per-layer GEMMs: gradients and metrics of a ragged

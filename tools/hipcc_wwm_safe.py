@@ -49,6 +49,7 @@ def patch(path, log):
     for j in sorted(groups, reverse=True):          # bottom-up: indices above stay valid
         idxs = groups[j]
         keep = [k for k in range(j, max(idxs) + 1) if k not in idxs]
+        drain = False
         for idx in idxs:
             # independence: no register of a moved instruction is touched by the bracket's own instructions it jumps over ...
             for k in keep:
@@ -58,9 +59,16 @@ def patch(path, log):
                 # for: in front of it the value would be stale), or a writer of exec / vcc other than the bracket's own first instruction
                 if j < k < idx:
                     ins = lines[k].strip()
-                    if ins.startswith("s_waitcnt") or re.search(r"\b(exec|vcc)(_lo|_hi)?\b", ins.split(";")[0].split(",")[0]):
-                        raise SystemExit(f"wwm: cannot move `{lines[idx].strip()}` (line {idx + 1}) in front of its bracket: `{ins}` lies between (a wait or an exec / vcc writer)")
-        out = [lines[idx] + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)" for idx in idxs]
+                    if re.search(r"\b(exec|vcc)(_lo|_hi)?\b", ins.split(";")[0].split(",")[0]):
+                        raise SystemExit(f"wwm: cannot move `{lines[idx].strip()}` (line {idx + 1}) in front of its bracket: `{ins}` lies between (an exec / vcc writer)")
+                    if ins.startswith("s_waitcnt"):
+                        # The moved instruction may read a register whose load that wait is there for.  The same counter value would promise LESS at the
+                        # earlier position (memory operations issued in between count towards it), so the instruction takes a full drain with it: always
+                        # sufficient, and these are spill copies on rare paths.
+                        drain = True
+        out = (["\ts_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)\t; (a wait lay between the bracket's start and a moved instruction: tools/hipcc_wwm_safe.py)"] if drain else []) + \
+              [lines[idx] + "\t; moved in front of the whole-wave bracket (tools/hipcc_wwm_safe.py)" for idx in idxs]
+        if drain: log.write(f"wwm: a full s_waitcnt goes with the instruction(s) moved out of the bracket at line {j + 1}\n")
         for idx in idxs:
             log.write(f"wwm: moved `{lines[idx].strip()}` out of the bracket at line {j + 1} ({[b for b in bad if b[1] - 1 == idx][0][0][:70]})\n")
         for idx in reversed(idxs):
