@@ -227,6 +227,11 @@ constexpr float CAND_CUBE_BALL = (K::BALL_RADIUS * UU2BT + 0.12f) * 1.001f;   //
 #ifndef RLG_CAND_EXACT
 #define RLG_CAND_EXACT 1   /* 1: the walk uses the body's exact query box and the renewal bound has a rotation term; 0: the cube (no box arithmetic, no rotation term, bigger lists) */
 #endif
+#ifndef RLG_CAND_TICKS
+#define RLG_CAND_TICKS 6.0f
+#endif
+constexpr float CAND_TICKS = RLG_CAND_TICKS;   // ticks a body's kept list should last at its present speed (cand_growth)
+constexpr float CAND_FAT_SMALL = 0.25f;   // second try of a walk whose fat boxes listed more leaves than a body keeps: a quarter of the growth
 constexpr float CAND_REACH = 3.5f;   // BT; (|q_x| + |q_y| + |q_z|)_max = 3.152 (a hitbox corner: |offset| + half extents; the ray ends reach 2.39)
 template <int NC>
 __device__ __forceinline__ void cand_box(const Arena<NC>& A, int body, V3& lo, V3& hi) {
@@ -242,12 +247,13 @@ template <int NC>
 struct CandCache {
     static constexpr int NB = NC + 1;
     V3 pos0[NB]; M3 rot0[RLG_CAND_EXACT ? NC : 1];   // the poses the lists were walked for
+    float fat[NB];                        // ... and how far each body's box was grown (cand_growth)
     uint32_t leaf[leaves_in_lds<NC>() ? NB : 1][leaves_in_lds<NC>() ? CACHE_LEAVES : 1];
     uint8_t n[NB];                        // leaves of body b
     uint8_t alive;                        // bit b: body b had a query box then (the ball awake, the car not demolished)
     uint8_t active;                       // bit b: ... and its box touched an occupied grid cell
     uint8_t watch;                        // bit b: ... it did not, but its fat box did
-    uint8_t valid;                        // 0: walk again (cleared when a launch loads the env)
+    uint8_t valid;                        // 0: walk again (cleared when a launch loads the env); 1 / 2: lists walked for boxes grown by cand_fat / by CAND_FAT_SMALL of it
 };
 template <int NC>
 struct LaneBlock { Arena<NC> A; GymEnv<NC> G; TickWork<NC> W; CandCache<NC> C; };
@@ -488,7 +494,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                 moved += turned * CAND_REACH;
             }
 #endif
-            my_stale = !(moved <= 0.97f * cand_fat);   // (a NaN pose renews the list every tick)
+            my_stale = !(moved <= 0.97f * (C.valid == 2 ? CAND_FAT_SMALL * C.fat[li] : C.fat[li]));   // (a NaN pose renews the list every tick; valid == 2: the list was walked for the smaller boxes)
             if (RLG_UNLIKELY(!my_stale && ((C.watch >> li) & 1u))) {   // not on any list, but close enough to the mesh to get onto one inside its fat box
                 cand_box(S.A, li, lo, hi);
                 my_stale = mesh_maybe_near(mv, lo, hi);
@@ -503,25 +509,32 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
 #endif
     RLG_SPROF(37);
     // a walking tick needs the boxes themselves: does the body's reach the mesh, and if not, does its fat version
-    bool my_watch = false;
+    bool my_watch = false; float my_fat = cand_fat;
     if (RLG_UNLIKELY(walk && li < NB && my_alive)) {
         cand_box(S.A, li, lo, hi);
         my_active = mesh_maybe_near(mv, lo, hi);
-        if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(cand_fat, cand_fat, cand_fat), hi + v3(cand_fat, cand_fat, cand_fat));
+        // how far this body's box is grown: what it travels in CAND_TICKS ticks at its present speed (a face of a car's box moves by at most
+        // |v| dt + |w| dt x reach per tick), within [1/2, 2] x the mesh's value -- a resting body keeps few leaves, a fast one does not renew
+        // every other tick, and the bodies of a wavefront (one stale body renews them all) run out at about the same time
+        const Body& bd = li == 0 ? S.A.ball.b : S.A.cars[li - 1].b;
+        const float per_tick = (len(bd.vel) + (li > 0 ? len(bd.angvel) * CAND_REACH : 0.f)) * TICK_DT;
+        my_fat = fminf(fmaxf(per_tick * CAND_TICKS, 0.5f * cand_fat), 2.f * cand_fat);
+        if (!my_active) my_watch = mesh_maybe_near(mv, lo - v3(my_fat, my_fat, my_fat), hi + v3(my_fat, my_fat, my_fat));
     }
     bool overflow = too_big;
-    // The walk (fat boxes first; should their lists not fit, once more with the exact boxes, and the result is not kept).
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const float fat = attempt == 0 ? cand_fat : 0.f;
+    // The walk: fat boxes first; should their lists not fit (a body in a corner of a dense mesh), once more with boxes grown by a quarter of that, kept
+    // like the first; should those not fit either, with the exact boxes, and that result is not kept (the env walks again on the next tick).
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const float fat = attempt == 0 ? my_fat : (attempt == 1 ? CAND_FAT_SMALL * my_fat : 0.f);
         const bool go = walk && (attempt == 0 || overflow);
         if (RLG_LIKELY(!__any(go))) break;
 #if defined(RLG_TICK_PROFILE) || defined(RLG_WWM_WAIT_CASE)   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
-        if (go && li == 0) { if (attempt == 0) RLG_DBG_COUNT(11); else RLG_DBG_COUNT(12); }
+        if (go && li == 0) { if (attempt == 0) RLG_DBG_COUNT(11); else if (attempt == 1) RLG_DBG_COUNT(12); else RLG_DBG_COUNT(14); }
 #endif
         if (go) overflow = false;
         if (go && li < NB) {
             if (my_active) { Q.box_lo[li] = lo - v3(fat, fat, fat); Q.box_hi[li] = hi + v3(fat, fat, fat); }
-            if (my_alive) C.pos0[li] = li == 0 ? S.A.ball.b.pos : S.A.cars[li - 1].b.pos;
+            if (my_alive) { C.pos0[li] = li == 0 ? S.A.ball.b.pos : S.A.cars[li - 1].b.pos; C.fat[li] = my_fat; }
 #if RLG_CAND_EXACT
             if (my_alive && li > 0) C.rot0[li - 1] = S.A.cars[li - 1].b.rot;
 #endif
@@ -555,7 +568,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                 bool ovf = false;
                 if (inner) {
                     const int pos = m + 2 * __popcll(mi & below);
-                    if (pos + 2 > FRONTIER_CAP) { ovf = true; if (attempt == 1) RLG_DBG_COUNT(0); }
+                    if (pos + 2 > FRONTIER_CAP) { ovf = true; if (attempt == 2) RLG_DBG_COUNT(0); }
                     else { Q.frontier[cur ^ 1][pos] = ((uint32_t)body << 16) | (uint32_t)first; Q.frontier[cur ^ 1][pos + 1] = ((uint32_t)body << 16) | (uint32_t)(first + 1); }
                 }
                 m += 2 * __popcll(mi);
@@ -566,7 +579,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                     const unsigned long long ml = (__ballot(mine) >> gshift) & gmask;
                     if (mine) {
                         const int k = cnt_b[b] + __popcll(ml & below);
-                        if (k >= CACHE_LEAVES) { ovf = true; if (attempt == 1) RLG_DBG_COUNT(1 + (b > 0)); }
+                        if (k >= CACHE_LEAVES) { ovf = true; if (attempt == 2) RLG_DBG_COUNT(1 + (b > 0)); }
                         else Q.leaf[b][k] = (uint32_t)first | ((uint32_t)cnt << 24);
                     }
                     cnt_b[b] += __popcll(ml);
@@ -604,7 +617,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
                 for (int r = 0; r < PER; r++) {
                     if (rank[b][r] < 0) continue;
                     Q.leaf[b][rank[b][r]] = mine[b][r];
-                    if (attempt == 0) {   // kept for the ticks that do not walk (C.valid below)
+                    if (attempt < 2) {   // kept for the ticks that do not walk (C.valid below)
                         if constexpr (leaves_in_lds<NC>()) C.leaf[b][rank[b][r]] = mine[b][r]; else gleaf[b * CACHE_LEAVES + rank[b][r]] = mine[b][r];
                     }
                 }
@@ -614,7 +627,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
             for (int b = 0; b < NB; b++) C.n[b] = (uint8_t)(cnt_b[b] < CACHE_LEAVES ? cnt_b[b] : CACHE_LEAVES);
             C.active = (uint8_t)ma;
             C.alive = (uint8_t)mal; C.watch = (uint8_t)mwa;
-            C.valid = (!overflow && attempt == 0) ? 1 : 0;
+            C.valid = (uint8_t)((!overflow && attempt < 2) ? 1 + attempt : 0);
         }
         wave_sync();
     }

@@ -795,3 +795,41 @@ def test_port_rotated_ball_basis_vs_reference_golden(port_lib):
             assert list(outs[t].hidden.ball_rot) == rot0, f"{name} tick {t + 1}: the ball's basis changed"
         ticks += len(tape)
     assert ticks == 1200
+
+
+def test_wwm_repair_on_synthetic_assembly(tmp_path):
+    """tools/hipcc_wwm_safe.py (the build step that repairs one code-generation defect of this compiler: a per-lane spill copy placed inside the whole-wave
+    bracket around an SGPR-spill VGPR access) on hand-written assembly, so that its rules do not depend on what the register allocator does
+    with today's sources: (a) a clean bracket is left alone; (b) a flagged copy moves in front of its bracket; (c) one that has to cross an `s_waitcnt`
+    takes a FULL wait with it (the same counter would promise less at the earlier position); (d) one that would cross a writer of exec / vcc, or shares a
+    register with what it jumps over, is refused."""
+    import io
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hipcc_wwm_safe as W
+    head = "_Z3foov:\n\tv_writelane_b32 v254, s30, 0\n\tv_readlane_b32 s31, v254, 1\n"
+    tail = "\ts_endpgm\n.Lfunc_end0:\n"
+
+    def run(body):
+        path = tmp_path / "t.s"; path.write_text(head + body + tail)
+        log = io.StringIO()
+        moved = W.patch(str(path), log)
+        return moved, path.read_text().split("\n"), log.getvalue()
+
+    clean = "\ts_or_saveexec_b64 s[2:3], -1\n\tscratch_store_dword off, v254, s33 offset:16\n\ts_mov_b64 exec, s[2:3]\n"
+    moved, out, log = run(clean)
+    assert moved == 0 and "clean" in log
+    plain = "\ts_or_saveexec_b64 s[2:3], -1\n\tv_accvgpr_write_b32 a7, v12\n\tscratch_load_dword v254, off, s33 offset:16\n\ts_mov_b64 exec, s[2:3]\n"
+    moved, out, log = run(plain)
+    txt = [l.strip().split("\t")[0].split(";")[0].strip() for l in out]
+    assert moved == 1 and txt.index("v_accvgpr_write_b32 a7, v12") < txt.index("s_or_saveexec_b64 s[2:3], -1") and not any("s_waitcnt vmcnt(0)" in l for l in out)
+    waited = "\ts_or_saveexec_b64 s[2:3], -1\n\tscratch_load_dword v254, off, s33 offset:16\n\ts_waitcnt lgkmcnt(14)\n\tv_accvgpr_write_b32 a7, v12\n\ts_mov_b64 exec, s[2:3]\n"
+    moved, out, log = run(waited)
+    txt = [l.strip().split("\t")[0].split(";")[0].strip() for l in out]
+    i_drain = next(i for i, l in enumerate(txt) if l.startswith("s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)"))
+    assert moved == 1 and i_drain + 1 == txt.index("v_accvgpr_write_b32 a7, v12") < txt.index("s_or_saveexec_b64 s[2:3], -1") and "a full s_waitcnt goes with" in log
+    assert "s_waitcnt lgkmcnt(14)" in txt     # (the bracket keeps its own wait)
+    for refused in ("\ts_or_saveexec_b64 s[2:3], -1\n\tv_cmp_eq_u32_e32 vcc, 0, v254\n\tv_accvgpr_write_b32 a7, v12\n\ts_mov_b64 exec, s[2:3]\n",
+                    "\ts_or_saveexec_b64 s[2:3], -1\n\tv_readlane_b32 s5, v254, 3\n\tv_mov_b32_e32 v12, s5\n\ts_mov_b64 exec, s[2:3]\n"):
+        with pytest.raises(SystemExit):
+            run(refused)

@@ -59,6 +59,6 @@ for it in range(12):
 try:
     env.lib.rlgpu_env_debug_ints.argtypes = [C.c_void_p, C.c_void_p]
     dbg = (C.c_int * 64)(); env.lib.rlgpu_env_debug_ints(env.h, dbg)
-    if dbg[13]: print("candidate walks: %d env-ticks, %.1f %% of them walk, %.1f %% of the walks did not fit their fat boxes (redone with the exact boxes, list not kept)" % (dbg[13], 100.0 * dbg[11] / dbg[13], 100.0 * dbg[12] / max(1, dbg[11])))
+    if dbg[13]: print("candidate walks: %d env-ticks, %.1f %% of them walk, %.1f %% of the walks did not fit their fat boxes (redone with boxes grown by a quarter of that, list kept), %.2f %% not those either (exact boxes, list not kept)" % (dbg[13], 100.0 * dbg[11] / dbg[13], 100.0 * dbg[12] / max(1, dbg[11]), 100.0 * dbg[14] / max(1, dbg[11])))
 except Exception as ex:
     print("no debug ints:", ex)
