@@ -58,5 +58,8 @@ struct LearnerConfig {
     // collection AND fixed-order sums everywhere (rlgpu_learner_set_deterministic): the run is a function of its seed, bit for bit, on one rank
     // or several.
     bool deterministicGradients = false;
+    // lockstep collection of a batch with more wavefront-groups than the GPU keeps resident: -1 = through the step queue (rlgpu_env_set_collect_queue;
+    // same results, the launch does not wait for the slot that got the slow groups), 0 = one workgroup per group as before, 1 = the queue always
+    int collectStepQueue = -1;
 };
 }

@@ -306,6 +306,11 @@ int rlgpu_shuffler_next_rows(rlgpu_shuffler* s, int T, int n_agents, int32_t* ro
  *      RLGPU_ERR_STATE and the caller alternates the two calls itself.  Launches on the env's stream. ---- */
 int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs_dev, int32_t* actions_dev, float* logp_dev, float* reward_dev, int32_t* done_dev,
                   int deterministic);
+/* Lockstep collection of a batch with more wavefront-groups than the device keeps resident (BASELINE configs[3] / [4]) goes through a queue of
+ * (step, group) tickets taken by as many wavefronts as fit the device (csrc/rlgpu_env.hip:k_env_collect_q): the launch no longer waits for the
+ * slot that happened to get the slow groups.  Same results as the per-group launch, bit for bit.  mode: -1 = automatic (the default: the queue
+ * when the groups do not all fit), 0 = never, 1 = always (tests run small batches through it). */
+int rlgpu_env_set_collect_queue(rlgpu_env* e, int mode);
 
 /* The same phase as the reference's agents run it: FREE.  ThreadAgentManager::CollectTimesteps (PRIV/Threading/ThreadAgentManager.cpp:16-82) lets every
  * agent thread step its games at its own pace and takes whatever each trajectory holds once the agents TOGETHER have `amount` timesteps; an agent

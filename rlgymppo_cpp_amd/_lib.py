@@ -64,6 +64,7 @@ SIGNATURES = {
     "rlgpu_env_check_redzones": (_i, [_vp]),
     "rlgpu_env_lost_contact_count": (_i, [_vp, C.POINTER(C.c_uint64), _i]),
     "rlgpu_env_big_layout_ticks": (_i, [_vp, C.POINTER(C.c_uint64), _i]),
+    "rlgpu_env_set_collect_queue": (_i, [_vp, _i]),
     "rlgpu_learner_check_redzones": (_i, [_vp]),
     "rlgpu_env_debug_overrun": (_i, [_vp, _i, _i]),
     "rlgpu_state_word_counts": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

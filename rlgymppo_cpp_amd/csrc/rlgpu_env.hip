@@ -922,6 +922,8 @@ struct CollectArgs {
     // `free_target` agent-steps (ThreadAgentManager::CollectTimesteps, ThreadAgentManager.cpp:16-32: the agents run free and the manager
     // takes what they have once the total is reached), at most T steps each (ThreadAgent.cpp:57-59, maxCollect); null counter = lockstep
     unsigned int* counter; unsigned int free_target; int32_t* steps_out;   // steps_out [n_envs]: gym steps env e made in this launch
+    // step queue (k_env_collect_q): the ticket counter, every wavefront-group's finished steps, the number of groups
+    unsigned int* q_ticket; int32_t* q_done; int q_groups;
 };
 
 template <int NC>
@@ -1054,6 +1056,104 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
         g_step_prof[16 * blockIdx.x + 4] = prof_ticks; g_step_prof[16 * blockIdx.x + 5] = prof_gym; g_step_prof[16 * blockIdx.x + 6] = (unsigned long long)t;
         g_step_prof[16 * blockIdx.x + 7] = prof_stage; for (int q = 0; q < 4; q++) g_step_prof[16 * blockIdx.x + 8 + q] = prof_layer[q]; }
 #endif
+}
+
+// ---- lockstep collection of a batch with MORE wavefront-groups than the device keeps resident: a queue of (step, group) tickets -------------------
+// k_env_collect on such a batch (BASELINE configs[3] / [4]: 2 731 / 8 192 groups for 1 024 SIMDs) is balanced by the dispatcher in units of a whole
+// group's T steps, and a group in a contact-heavy phase stays slow for all of them: the launch is 67 - 81 % of sum / slots (tools/prof_teams.py).
+// Here as many wavefronts as fit the device stay for the whole launch and take tickets: ticket k = step k / groups of group k % groups.  A ticket's
+// group state comes from HBM and goes back (13 KB per step of a 2v2 group: nothing), the observation rows of its previous step were written by
+// whoever held ticket k - groups, which was handed out at least groups - wavefronts tickets earlier -- q_done[group] says when it is finished.
+// Every wavefront that holds a ticket is running and waits for an EARLIER ticket only: no cycle.  Results are k_env_collect's, bit for bit: an env's
+// steps do not depend on which wavefront runs them (the kept candidate lists are per ticket; they are supersets by construction).
+template <int NC>
+__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_q(EnvDev d, CollectArgs c) {
+    constexpr int LANES = lanes_per_block<NC>();
+    constexpr int EPW = LANES / WPB, R = EPW * NC;
+    static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
+    __shared__ uint32_t lds_grid[GRID_WORDS];
+    __shared__ uint32_t lds_pad[PAD_TAB_WORDS];
+    MeshView mv = stage_mesh(d, lds_nodes, staged_nodes<NC>(), lds_grid, lds_pad);
+    const int lane = threadIdx.x & 63;
+    unsigned char* const wmem = lane_mem + (size_t)(threadIdx.x >> 6) * EPW * lane_stride<NC>();
+    const uint32_t seed = tick_seed(d.cfg);
+    const int D = obs_size<NC>(d.cfg);
+    const size_t N = (size_t)c.n_agents;
+    const int buf_bytes = rlinfer::wave_buf_bytes(R, c.net.ld);
+    unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
+    short* const buf0 = reinterpret_cast<short*>(w0);
+    short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
+    int* const act_lds = reinterpret_cast<int*>(w0 + sizeof(TickWork<NC>) - 64);
+    epa_arenas_setup<NC>(d, wmem);
+    StepStats stats;
+    const unsigned int total = (unsigned int)c.q_groups * (unsigned int)c.T;
+    for (;;) {
+        unsigned int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(c.q_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+        if (tk >= total) break;
+        const int g = (int)(tk % (unsigned int)c.q_groups), t = (int)(tk / (unsigned int)c.q_groups);
+        if (t > 0) while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&c.q_done[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t) __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the group's state words and its observation rows of step t, written by another wavefront
+        const int env0 = g * EPW;
+        const int left = d.n_envs - env0, n_valid = left < EPW ? left : EPW;
+        const bool env_lane = lane < n_valid;
+        const int env = env0 + (env_lane ? lane : 0);
+        LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? lane : 0);
+        const int row0 = env0 * NC, n_rows = n_valid * NC;
+        Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);
+        load_envs_wave<NC>(d, wmem, env0, n_valid, lane);
+        if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per ticket
+        wave_sync();
+        rlinfer::HeadArgs h = c.head;
+        h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
+        int picked[R];
+        if (c.net.fp32) {
+            constexpr int NP = EPW == 3 ? 3 : 2;
+            constexpr int PB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
+            auto area = [&](int k) { return reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k < EPW ? k : 0).W); };
+            rlinfer::F32Buf fin{}, fout{};
+            auto f = [](unsigned char* p) { return reinterpret_cast<float*>(p); };
+            if (EPW >= 4) { fin = {{f(area(0)), f(area(1)), nullptr}}; fout = {{f(area(2)), f(area(3)), nullptr}}; }
+            else if (EPW == 3) { fin = {{f(area(0)), f(area(0) + PB), f(area(1))}}; fout = {{f(area(1) + PB), f(area(2)), f(area(2) + PB)}}; }
+            else if (EPW == 2) { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(1)), f(area(1) + PB), nullptr}}; }
+            else { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(0) + 2 * PB), f(area(0) + 3 * PB), nullptr}}; }
+            rlinfer::wave_infer_f32<R, NP>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, lane, picked);
+        } else
+        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, lane, picked);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) act_lds[r] = picked[r];
+        }
+        wave_sync();
+        float rew[NC]; bool dn = false;
+        if (env_lane) {
+            int32_t acts[NC];
+            for (int k = 0; k < NC; k++) acts[k] = act_lds[lane * NC + k];
+            gym_step_begin<NC>(S.A, S.G, d.cfg, d.action_table, acts);
+        }
+        wave_sync();
+        TickEvents ev; ev.bump_mask = 0;
+        arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev);
+        float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
+        if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
+        if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
+        wave_sync();
+        for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); }
+        if (env_lane) {
+            gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
+            for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
+            if (c.steps_out) c.steps_out[env] = t + 1;
+        }
+        wave_sync();
+        store_envs_wave<NC>(d, wmem, env0, n_valid, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        wave_sync();
+        if (lane == 0) __hip_atomic_store(&c.q_done[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (d.step_stats) step_stats_flush(d.step_stats, stats, lane);
 }
 
 template <int NC>
@@ -1195,6 +1295,7 @@ struct rlgpu_env {
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
+    unsigned int* d_queue = nullptr; int queue_groups = 0, queue_capacity = -1, queue_mode = -1;   // k_env_collect_q: [0] ticket, [16 ..] finished steps per group; -1 auto, 0 never, 1 always
     unsigned int* d_free_counter = nullptr; int free_capacity = -1;   // rlgpu_collect_free: the launch's agent-step counter; workgroups the device keeps resident at once
     unsigned char* d_epa_big = nullptr;
     hipStream_t stream = nullptr;
@@ -1405,6 +1506,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
     if (e->d_free_counter) (void)hipFree(e->d_free_counter);
+    if (e->d_queue) (void)hipFree(e->d_queue);
     if (e->d_epa_big) (void)hipFree(e->d_epa_big);
     if (e->d.leaf_cache) (void)hipFree(e->d.leaf_cache);
     if (e->d.big_work) (void)hipFree(e->d.big_work);
@@ -1665,13 +1767,41 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
         HIPCHK(e, hipMemsetAsync(e->d_free_counter, 0, 4, e->stream));
         c.counter = e->d_free_counter; c.free_target = (unsigned int)free_target; c.steps_out = steps_out;
     } else c.steps_out = steps_out;
+    // lockstep collection of more wavefront-groups than stay resident: the step queue (k_env_collect_q)
+    bool queued = false;
+    if (free_target <= 0 && e->queue_mode != 0) {
+        if (e->queue_capacity < 0) {
+            int per_cu = 0; hipDeviceProp_t prop{};
+            HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
+            hipError_t oc = RLG_NC_PICK(e->nc, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect_q<2>, WAVE * WPB, 0),
+                                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect_q<4>, WAVE * WPB, 0),
+                                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_env_collect_q<6>, WAVE * WPB, 0));
+            HIPCHK(e, oc);
+            e->queue_capacity = per_cu * prop.multiProcessorCount;
+        }
+        const int groups = (int)grid.x * WPB;
+        if (e->queue_capacity > 0 && (e->queue_mode == 1 || (int)grid.x > e->queue_capacity)) {
+            if (!e->d_queue || e->queue_groups < groups) {
+                if (e->d_queue) rz_free(e, e->d_queue);
+                e->d_queue = nullptr;
+                HIPCHK(e, RZ_MALLOC(e, e->d_queue, 4 * (size_t)(16 + groups), "collection step queue"));
+                e->queue_groups = groups;
+            }
+            HIPCHK(e, hipMemsetAsync(e->d_queue, 0, 4 * (size_t)(16 + groups), e->stream));
+            c.q_ticket = e->d_queue; c.q_done = reinterpret_cast<int32_t*>(e->d_queue + 16); c.q_groups = groups;
+            if ((int)grid.x > e->queue_capacity) grid.x = (unsigned)e->queue_capacity;
+            queued = true;
+        }
+    }
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if (e->timing_on) { int rc_ev = env_next_events(e, &evp); if (rc_ev) return rc_ev; HIPCHK(e, hipEventRecord(evp->first, e->stream)); }
-    DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
+    if (queued) { DISPATCH_NC(e, k_env_collect_q, grid, block, e->d, c); }
+    else DISPATCH_NC(e, k_env_collect, grid, block, e->d, c);
     if (evp) { HIPCHK(e, hipEventRecord(evp->second, e->stream)); e->ev0 = evp->first; e->ev1 = evp->second; e->timed = true; }
     HIPCHK(e, hipGetLastError());
     return RLGPU_OK;
 }
+int rlgpu_env_set_collect_queue(rlgpu_env* e, int mode) { if (mode < -1 || mode > 1) return RLGPU_ERR_ARG; e->queue_mode = mode; return RLGPU_OK; }
 int rlgpu_collect(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32_t* actions, float* logp, float* reward, int32_t* done, int deterministic) {
     return collect_impl(e, l, T, obs, actions, logp, reward, done, deterministic, 0, nullptr, "rlgpu_collect");
 }

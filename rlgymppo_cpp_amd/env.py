@@ -131,6 +131,10 @@ class BatchedEnv:
         _chk(self.lib.rlgpu_env_lost_contact_count(self.h, C.byref(out), 1 if reset else 0), self.h, self.lib.rlgpu_env_last_error)
         return int(out.value)
 
+    def set_collect_queue(self, mode: int):
+        """-1: lockstep collection takes the step queue when its wavefront-groups do not all fit the device (default); 0: never; 1: always."""
+        _chk(self.lib.rlgpu_env_set_collect_queue(self.h, int(mode)), self.h, self.lib.rlgpu_env_last_error)
+
     def big_layout_ticks(self, reset=False) -> int:
         """Env-ticks since the last reset (process-wide) whose contacts did not fit the LDS layout and were redone with the big one."""
         out = C.c_uint64(0)

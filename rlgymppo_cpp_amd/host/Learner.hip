@@ -304,6 +304,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     // free-running collection is tried when nothing needs the host between steps and the games have both teams (the fused launch's row mapping);
     // whether the batch is resident at once is known at the first launch (rlgpu_collect_free: RLGPU_ERR_STATE -> lockstep from then on)
     if (std::getenv("RLGPU_LOCKSTEP_COLLECTION")) config.lockstepCollection = true;   // (tests that count timesteps exactly)
+    m.EnvCheck(rlgpu_env_set_collect_queue(m.env, config.collectStepQueue), "set_collect_queue");
     if (config.deterministicGradients) { config.lockstepCollection = true; m.LrnCheck(rlgpu_learner_set_deterministic(m.lrn, 1), "learner_set_deterministic"); }
     m.ragged = !config.lockstepCollection && !m.renderOnly && !m.plan.AnyHost() && !config.renderMode && m.match->spawnOpponents && !config.deterministic;
     m.Tcap = m.ragged ? 2 * m.T : m.T;

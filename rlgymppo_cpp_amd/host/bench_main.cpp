@@ -50,13 +50,13 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
 struct Timed { double stepReward = 0, entropy = 0; double agentSteps = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0; bool fp32 = false, fp16 = false, overlap = false, lockstep = false, deterministic = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0, collectQueue = -1; bool fp32 = false, fp16 = false, overlap = false, lockstep = false, deterministic = false;
     std::string meshDir = "./collision_meshes";
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
         else if (is("--steps")) steps = atoi(argv[++i]); else if (is("--warmup")) warmup = atoi(argv[++i]); else if (is("--epochs")) epochs = atoi(argv[++i]);
-        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true; else if (is("--fp16")) fp16 = true; else if (is("--lockstep")) lockstep = true; else if (is("--deterministic")) deterministic = true;
+        else if (is("--padded-zero-sum")) g_padded = true; else if (is("--fp32")) fp32 = true; else if (is("--overlap")) overlap = true; else if (is("--fp16")) fp16 = true; else if (is("--lockstep")) lockstep = true; else if (is("--deterministic")) deterministic = true; else if (is("--collect-queue")) collectQueue = atoi(argv[++i]);
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
         else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
         else if (is("--mesh-dir")) meshDir = argv[++i];
@@ -84,6 +84,7 @@ int main(int argc, char* argv[]) {
     cfg.ppo.policyLayerSizes = { 256, 256, 256 }; cfg.ppo.criticLayerSizes = { 256, 256, 256 };
     cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
     cfg.timestepLimit = 0;
+    cfg.collectStepQueue = collectQueue;
     cfg.deterministicGradients = deterministic;   // fixed-order gradient sums + lockstep collection: the run is a function of its seed (tests)
     cfg.lockstepCollection = lockstep;     // default: the reference's free-running agents (every game at its own pace until the batch is full)
     if (fp16) setenv("RLGPU_AUTOCAST_FP16", "1", 1);   // fp16 operands + dynamic loss scale in the minibatch kernels (BASELINE configs[4]'s "fp16 autocast"; Learner.hip reads it at construction)

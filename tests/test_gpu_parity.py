@@ -1454,6 +1454,41 @@ def test_wwm_repair_that_has_to_cross_a_wait_builds_and_runs(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("team_size,n_envs,bf16", [(1, 70, True), (2, 41, True), (3, 19, True), (2, 20, False), (2, 5000, True)])
+def test_step_queue_collection_equals_one_workgroup_per_group(team_size, n_envs, bf16):
+    """Lockstep collection of a batch with more wavefront-groups than the device keeps resident runs through a queue of (step, group) tickets taken by
+    resident wavefronts (rlgpu_env.hip:k_env_collect_q; BASELINE configs[3] / [4]).  The same flow -- reset, three launches of T gym steps with the
+    sampler rewound -- through the queue (forced, also for batches that would fit) and through the one-workgroup-per-group kernel: observations,
+    actions, log-probs, rewards, terminals and the downloaded states equal, bit for bit; 2v2 / 5 000 envs is a batch that takes the queue by itself."""
+    from rlgymppo_cpp_amd import _lib
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd.ppo import PPOCore
+    dev = torch.device("cuda", 0); T = 6
+    outs = []
+    for mode in (1, 0):
+        cfg = _lib.default_gym_config(); cfg.no_touch_max_steps = 9
+        env = BatchedEnv(n_envs, team_size, cfg); env.set_collect_queue(mode)
+        core = PPOCore(env.obs_size, env.n_actions, (64, 64), (64, 64), use_bf16=bf16, max_rows=max(4096, env.n_agents), seed=3)
+        N, D = env.n_agents, env.obs_size
+        obs = torch.zeros((T + 1, N, D), device=dev); act = torch.zeros((T, N), dtype=torch.int32, device=dev); logp = torch.zeros((T, N), device=dev)
+        rew = torch.zeros((T, N), device=dev); done = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        env.reset(True, obs[0])
+        keep = []
+        for it in range(3):
+            assert env.collect(core, T, obs, act, logp, rew, done); env.sync()
+            keep.append([x.cpu().numpy().copy() for x in (obs, act, logp, rew, done)])
+            obs[0].copy_(obs[T])
+        states = env.download_states()
+        outs.append((keep, [bytes(s) for s in states]))
+        env.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        for x, y, name in zip(a, b, ("obs", "act", "logp", "rew", "done")):
+            assert np.array_equal(x, y), name
+    assert outs[0][1] == outs[1][1]
+    assert sum(int(k[4].sum()) for k in outs[0][0]) > 0      # episodes ended and were reset inside the launches
+
+
+@pytest.mark.gpu
 def test_stripe_kernels_equal_the_per_layer_path(tmp_path):
     """csrc/mlp_stripe.h (RLGPU_STRIPE=1): forward and dX chains of both networks in one launch each, activations in LDS from layer to layer.
     Same operands, same accumulation order per 32x32 tile, same rounding points as the per-layer GEMMs: gradients and metrics of a ragged
