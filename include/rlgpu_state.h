@@ -147,14 +147,27 @@ typedef struct RlgpuGymState {
  *              moment it was demolished (Car.cpp:69-80,135-138); all zeros for a car that is not demolished.
  *              With both, a state downloaded mid-episode and uploaded into another env slot (or another batch) continues exactly as the env it
  *              came from would have from that same struct (tests/golden/midtape_golden.npz: against the reference, whose side of this is read by
- *              oracle/ref_driver.cpp:ref_arena_get_hidden from btRSBroadphase's cell lists). */
+ *              oracle/ref_driver.cpp:ref_arena_get_hidden from btRSBroadphase's cell lists).
+ *   ref_engine (round 6, parity tests) the state of the std::default_random_engine the reference's thread draws from (Math::GetRandEngine,
+ *              RocketSim Math.cpp:59-64: libstdc++'s minstd_rand0, a value in [1, 2^31 - 2]) as it stands for this arena.  The reference seeds it from
+ *              the wall clock, so no two of its runs draw alike and the product draws from counter-based streams of its own (Philox keyed by seed,
+ *              env, tick / reset count: csrc/arena_car.h, arena_gym.h) -- ref_engine = 0, the default.  With a non-zero value the env draws
+ *              EVERYTHING the reference draws for an arena -- the respawn slot of a demolished car (Car.cpp:43-56), ResetToRandomKickoff's shuffle
+ *              (Arena.cpp:112-216), RandomState's values (RandomState.cpp:8-61) -- from that engine, with the reference's formulas, in the
+ *              reference's order (car_order where it loops over the cars), and hands the advanced state back: an arena of the real reference whose
+ *              engine was assigned the same state (oracle/ref_driver.cpp:ref_seed_engine) then makes the same draws, and tapes through respawns and
+ *              setter outputs compare for EQUALITY (tests/golden/respawn_golden.npz, setter_golden.npz).  An upload without the valid bit leaves the
+ *              slot's engine alone (Arena::SetState does not touch the thread's engine either). */
 #define RLGPU_HIDDEN_BP_HIST   1u
 #define RLGPU_HIDDEN_WRECK_ROT 2u
+#define RLGPU_HIDDEN_REF_ENGINE 4u
 typedef struct RlgpuArenaHidden {
     float ball_rot[9];               /* forward / right / up columns */
     uint32_t valid;
     uint16_t bp_hist[8];
     float wreck_rot[RLGPU_MAX_CARS][9];
+    uint32_t ref_engine;             /* 0 = the env's own streams */
+    uint32_t _pad;
 } RlgpuArenaHidden;
 
 typedef struct RlgpuArenaState {

@@ -808,6 +808,33 @@ extern "C" void ref_setter_samples(int team_size, int kind, int n, RlgpuArenaSta
     delete a;
 }
 
+// ---- the reference's random engine, pinned (round 6) -------------------------------------------------------------------------------------------
+// Math::GetRandEngine() hands out a REFERENCE to the calling thread's std::default_random_engine (RocketSim Math.cpp:59-64), which the reference seeds
+// from the wall clock.  Assigning it an engine in a known state makes every draw this thread makes afterwards -- Car::Respawn's slot (Car.cpp:48),
+// ResetToRandomKickoff's shuffle (Arena.cpp:127-134), RandomState's values (RandomState.cpp:8-61), DefaultOBSPadded's shuffles -- a function of that
+// state; the stepper's test mode (RlgpuArenaHidden::ref_engine) draws from the same state with the same formulas, so both sides can be compared for
+// equality through respawns and resets.  The engine's state is its last output (minstd_rand0).
+#include <sstream>
+extern "C" void ref_seed_engine(unsigned state) { RocketSim::Math::GetRandEngine() = std::default_random_engine(state); }
+extern "C" unsigned ref_engine_state() { std::ostringstream os; os << RocketSim::Math::GetRandEngine(); return (unsigned)std::stoul(os.str()); }
+// `n` resets of one arena by the reference's own setters with the thread's engine started from `engine`: kind 0 RandomState(flags bit 0 ball speed, bit 1
+// car speed, bit 2 cars on the ground), kind 1 KickoffState (the thread's engine), kind 2 Arena::ResetToRandomKickoff(seed0 + i) (an engine of its own per
+// call: Arena.cpp:126-131).  `rehash` > 0 re-buckets the arena's car set first (another iteration order of `_cars`).  out[i] = the state after reset i
+// (car_order included), engine_after[i] = the thread engine's state after it.
+extern "C" void ref_setter_samples_seeded(int team_size, int kind, int flags, int n, unsigned engine, int seed0, int rehash, RlgpuArenaState* out, unsigned* engine_after) {
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE); a->AddCar(Team::ORANGE); }
+    if (rehash > 0) a->_cars.rehash((size_t)rehash);
+    RandomState rs((flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0); KickoffState ks;
+    ref_seed_engine(engine);
+    for (int i = 0; i < n; i++) {
+        if (kind == 0) rs.ResetState(a); else if (kind == 1) ks.ResetState(a); else a->ResetToRandomKickoff(seed0 + i);
+        GetArenaPhys(a, &out[i]);
+        engine_after[i] = ref_engine_state();
+    }
+    delete a;
+}
+
 // Bullet-unit state of the ball and of every car slot, straight from the rigid bodies (no unit conversion, no rounding): per body 18 floats
 // = origin[3], basis rows[9], linear velocity[3], angular velocity[3].  out: (1 + n_slots) x 18.  For tools/raw_divergence.py, which looks
 // for differences the uu exchange format rounds away.

@@ -390,15 +390,21 @@ RLG_HD void car_update_boost(CarHot& c) {
     c.boost = fminf(c.boost, K::BOOST_MAX);
 }
 
+RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat = setEulerYPR(yaw,-pitch,-roll) (MathTypes.cpp:84-89)
+    float ez = yaw, ey = -pitch, ex = -roll;
+    float ci = rl_cosf(ex), cj = rl_cosf(ey), ch = rl_cosf(ez), si = rl_sinf(ex), sj = rl_sinf(ey), sh = rl_sinf(ez);
+    float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+    return m3_rows(v3(cj * ch, sj * sc - cs, sj * cc + ss), v3(cj * sh, sj * ss + cc, sj * cs - sc), v3(-sj, cj * si, cj * ci));
+}
+
 // ---- Car::Respawn (Car.cpp:43-56): spawn slot from the caller's RNG draw ------------------------------------
 RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
     const float RX[4] = {-2304, -2688, 2304, 2688};
     int idx = (int)(rnd % 4u);
     Car n = {};
-    float yaw = (PI_F / 2) + (is_blue ? 0.f : PI_F);
+    const float yaw = is_blue ? (PI_F / 2) : (float)((double)(PI_F / 2) + 3.14159265358979323846);   // Angle(spawnPos.yawAng + (blue ? 0 : M_PI), 0, 0): the sum is a double, rounded once (Car.cpp:52)
     n.b.pos = v3(RX[idx], -4608.f * (is_blue ? 1.f : -1.f), K::CAR_RESPAWN_Z) * UU2BT;
-    float cy = rl_cosf(yaw), sy = rl_sinf(yaw);
-    n.b.rot = m3_cols(v3(cy, sy, 0.f), v3(-sy, cy, 0.f), v3(0, 0, 1));
+    n.b.rot = euler_to_rot(yaw, 0.f, 0.f);   // (Angle::ToRotMat with pitch = roll = 0: the same numbers as the yaw-only matrix up to the SIGN of its zeros, which the rigid body shows for one tick)
     n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
     n.flags = CF_ON_GROUND;
     n.boost = K::BOOST_SPAWN_AMOUNT;
@@ -419,9 +425,11 @@ RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
 //     `frozen` (DISABLE_SIMULATION + CF_NO_CONTACT_RESPONSE, Car.cpp:69-80) for the whole tick: a ray that meets it first is a miss, whatever its pose details (arena_world.h ray_ball_and_cars);
 //   * phase 2 reads another car only when a wheel stands on it (ground >= 2): callers serialise that case by car index.
 
-// phase 0, per car: ClampFix, demo timer and respawn (Car.cpp:60-87)
+// phase 0, per car: ClampFix, demo timer and respawn (Car.cpp:60-87).  Returns true when the car's respawn is due and has to draw from the reference's
+// engine (Arena::ref_engine, parity tests): those draws go in the arena's car order, so they are left to cars_respawn_ref_engine (the car stays a
+// wreck with a timer of zero until then -- a state no other path leaves behind).
 template <int NC>
-RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t env_id) {
+RLG_HD_SMALL bool car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t env_id) {
     RLG_ASSUME_LDS(A);
     const float dt = TICK_DT;
     Car& c = A.cars[ci];
@@ -433,6 +441,7 @@ RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t e
         float tm = fmaxf(c.demo_respawn_timer - dt, 0.f);
         c.demo_respawn_timer = tm;
         if (tm == 0.f) {
+            if (A.ref_engine != 0u) return true;
             uint32_t rnd[4];
             philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)ci, rnd);
             Car n = c;
@@ -441,6 +450,23 @@ RLG_HD_SMALL void car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t e
             c = n;
         }
     }
+    return false;
+}
+// ... the respawns that draw from the reference's engine: Car::Respawn's Math::RandInt(0, 4) (Car.cpp:48, Math.cpp:44-52) in the order in which
+// Arena::Step visits the cars (Arena.cpp:716-812)
+template <int NC>
+RLG_HD_COLD void cars_respawn_ref_engine(Arena<NC>& A) {
+    RefEngine e; e.x = A.ref_engine;
+    for (int k = 0; k < NC; k++) {
+        const int ci = car_at_rank(A, k);
+        Car& c = A.cars[ci];
+        if (!(c.flags & CF_IS_DEMOED) || c.demo_respawn_timer != 0.f) continue;
+        Car n = c;
+        car_respawn(n, (ci % 2) == 0, (uint32_t)e.rand_int(0, 4));
+        n.frozen = true;
+        c = n;
+    }
+    A.ref_engine = e.x;
 }
 
 // phase 1 = the suspension rays, in three steps so that the mesh part can run as one lane per (ray, candidate) pair:

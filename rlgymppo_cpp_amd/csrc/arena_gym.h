@@ -364,12 +364,7 @@ struct Rng {
     // three draws in x,y,z order (function-argument evaluation order is unspecified in C++: never draw inside an argument list)
     RLG_HD V3 uni3(float lx, float hx, float ly, float hy, float lz, float hz) { float x = uni(lx, hx); float y = uni(ly, hy); float z = uni(lz, hz); return v3(x, y, z); }
 };
-RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat = setEulerYPR(yaw,-pitch,-roll) (MathTypes.cpp:84-89)
-    float ez = yaw, ey = -pitch, ex = -roll;
-    float ci = rl_cosf(ex), cj = rl_cosf(ey), ch = rl_cosf(ez), si = rl_sinf(ex), sj = rl_sinf(ey), sh = rl_sinf(ez);
-    float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
-    return m3_rows(v3(cj * ch, sj * sc - cs, sj * cc + ss), v3(cj * sh, sj * ss + cc, sj * cs - sc), v3(-sj, cj * si, cj * ci));
-}
+// (euler_to_rot -- Angle::ToRotMat -- lives in arena_car.h, next to Car::Respawn, its other user)
 RLG_HD void car_set_fresh(Car& c) {  // Car::SetState(CarState()) semantics: carried wheel values / controls survive
     Car n = c;
     n.flags = CF_ON_GROUND; n.flip_rel_torque = v3(0, 0, 0);
@@ -388,10 +383,32 @@ template <int NC>
 RLG_HD void reset_pads(Arena<NC>& A) {
     for (int p = 0; p < 34; p++) { A.pads[p].cooldown = 0.f; A.pads[p].is_active = true; A.pads[p].prev_locked = 0; A.pads[p].cur_locked = 0; }
 }
-template <int NC>
-RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id) {
-    Rng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
-    G.reset_count++;
+// what a built-in setter reads of the gym's configuration, BY VALUE: reset_state is a real call, and a reference into a kernel's argument struct that
+// escapes into one makes the compiler keep the whole struct in scratch memory (every cfg.x of the step loop then is a scratch load instead of a scalar load)
+struct SetterCfg { int32_t setter_kind, rand_ball_speed, rand_car_speed, cars_on_ground; uint32_t seed_lo, seed_hi; };
+RLG_HD SetterCfg setter_cfg(const GymConfig& c) { SetterCfg s; s.setter_kind = c.setter_kind; s.rand_ball_speed = c.rand_ball_speed; s.rand_car_speed = c.rand_car_speed; s.cars_on_ground = c.cars_on_ground; s.seed_lo = c.seed_lo; s.seed_hi = c.seed_hi; return s; }
+// The setters' draws come from one of two sources.  `Rng` above: the env's Philox stream (product).  `RefRng`: the reference thread's engine
+// (Arena::ref_engine != 0, parity tests), with RocketSim's RandFloat and -- where the reference draws inside an argument list -- in the order in which
+// its compiled code evaluates them: g++ evaluates the arguments of `Vec(RandFloat(x), RandFloat(y), RandFloat(z))` (Math.cpp:7-13) and of
+// `Angle(RandFloat(yaw), RandFloat(pitch), RandFloat(roll))` (RandomState.cpp:44) RIGHT TO LEFT, and `RandNormVec() * RandFloat(0, s)` left operand
+// first (pinned against the reference as compiled by oracle/Makefile: tests/golden/setter_golden.npz).
+struct RefRng {
+    RefEngine e;
+    static constexpr bool REF = true;
+    RLG_HD float uni(float lo, float hi) { return e.uni(lo, hi); }
+    RLG_HD V3 uni3(float lx, float hx, float ly, float hy, float lz, float hz) { float z = uni(lz, hz); float y = uni(ly, hy); float x = uni(lx, hx); return v3(x, y, z); }
+    RLG_HD void ypr(float& yaw, float& pitch, float& roll) { roll = uni(-PI_F, PI_F); pitch = uni(-PI_F / 2, PI_F / 2); yaw = uni(-PI_F, PI_F); }
+    RLG_HD V3 dir_times_speed(float max_speed) { const float sp = uni(0, max_speed); const V3 d = rs_normalized(uni3(-1, 1, -1, 1, -1, 1)); return d * sp; }   // `RandNormVec() * RandFloat(0, s)`: the right operand first
+    RLG_HD void kickoff_order(int (&order)[5]) { e.shuffle5(order); }
+};
+struct PhiloxRng : Rng {
+    static constexpr bool REF = false;
+    RLG_HD void ypr(float& yaw, float& pitch, float& roll) { yaw = uni(-PI_F, PI_F); pitch = uni(-PI_F / 2, PI_F / 2); roll = uni(-PI_F, PI_F); }
+    RLG_HD V3 dir_times_speed(float max_speed) { const V3 d = rs_normalized(uni3(-1, 1, -1, 1, -1, 1)); return d * uni(0, max_speed); }
+    RLG_HD void kickoff_order(int (&order)[5]) { for (int i = 4; i > 0; i--) { int j = (int)(next() % (uint32_t)(i + 1)); int t = order[i]; order[i] = order[j]; order[j] = t; } }
+};
+template <int NC, class RNG>
+RLG_HD void reset_state_with(Arena<NC>& A, const SetterCfg cfg, RNG& rng) {
     A.ball.vel_impulse_cache = v3(0, 0, 0); A.ball_update_counter = 0;
     // The boost pads: both built-in setters reset them BEFORE they build the new episode's first GameState -- KickoffState through
     // Arena::ResetToRandomKickoff (Arena.cpp:209-210), RandomState because its first statement is that same call (RandomState.cpp:11) -- so the
@@ -399,45 +416,53 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
     // alone shows the previous episode's pads there: Match::ResetState resets them after the setter returned (Match.cpp:55-69; the reset_pads of
     // gym_episode_reset, the only one that runs on the host-setter path).
     reset_pads(A);
-    if (cfg.setter_kind == SS_KICKOFF) {
-        // Arena::ResetToRandomKickoff (Arena.cpp:112-216)
+    // Arena::ResetToRandomKickoff (Arena.cpp:112-216).  RandomState begins with the same call (RandomState.cpp:11): every car and the ball are placed
+    // anew right after, but the shuffle's draws are taken from the thread's engine first -- skipped on the env's own stream, which nobody compares draw for draw
+    if (cfg.setter_kind == SS_KICKOFF || RNG::REF) {
         const float SX[5] = {-2048, 2048, -256, 256, 0}, SY[5] = {-2560, -2560, -3840, -3840, -4608};
-        const float SYAW[5] = {PI_F / 4 * 1, PI_F / 4 * 3, PI_F / 4 * 2, PI_F / 4 * 2, PI_F / 4 * 2};
+        // yawAng = (float)(M_PI_4 * k) (RLConst.h:297-303: a double product rounded once); orange: `angle.yaw += M_PI` in double, rounded once (Arena.cpp:186)
+        const double PI_4_D = 0.78539816339744830962, PI_D = 3.14159265358979323846;
+        const float SYAW[5] = {(float)(PI_4_D * 1), (float)(PI_4_D * 3), (float)(PI_4_D * 2), (float)(PI_4_D * 2), (float)(PI_4_D * 2)};
         int order[5] = {0, 1, 2, 3, 4};
-        for (int i = 4; i > 0; i--) { int j = (int)(rng.next() % (uint32_t)(i + 1)); int t = order[i]; order[i] = order[j]; order[j] = t; }
-        for (int k = 0; k < NC; k++) {
-            int i = k / 2; bool blue = (k % 2) == 0;
+        rng.kickoff_order(order);
+        // position i goes to the i-th car of each team in the order in which the arena's car set lists them (Arena.cpp:149-151: blueCars / orangeCars are
+        // filled by iterating `_cars`)
+        int per_team[2] = {0, 0};
+        for (int r = 0; r < NC; r++) {
+            const int k = car_at_rank(A, r); const bool blue = (k % 2) == 0;
+            const int i = per_team[blue ? 0 : 1]++;
             int sl = order[i < 5 ? i : 4];
             Car& c = A.cars[k]; car_set_fresh(c);
             V3 pos = v3(SX[sl], SY[sl], K::CAR_SPAWN_REST_Z); float yaw = SYAW[sl];
-            if (!blue) { pos = pos * v3(-1, -1, 1); yaw += PI_F; }
+            if (!blue) { pos = pos * v3(-1, -1, 1); yaw = (float)((double)yaw + PI_D); }
             c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, 0.f, 0.f);
         }
         A.ball.b.pos = v3(0, 0, K::BALL_REST_Z) * UU2BT; A.ball.b.vel = v3(0, 0, 0); A.ball.b.angvel = v3(0, 0, 0);
         A.ball.b.rot = m3_identity();      // a BallState's default rotMat
-    } else {
+    }
+    if (cfg.setter_kind != SS_KICKOFF) {
         // RandomState::ResetState (StateSetters/RandomState.cpp:8-61)
         const float X_MAX = 3500, Y_MAX = 4000, Z_MAX = 1820, CAR_Z_MIN = 150;
         V3 bp = rng.uni3(-X_MAX, X_MAX, -Y_MAX, Y_MAX, 92.75f, Z_MAX);
         V3 bv = v3(0, 0, 0), bw = v3(0, 0, 0);
         if (cfg.rand_ball_speed) {
-            V3 d = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
-            bv = d * rng.uni(0, 4000);
+            bv = rng.dir_times_speed(4000);
             bw = rng.uni3(-4, 4, -4, 4, -4, 4);
         }
         A.ball.b.pos = bp * UU2BT; A.ball.b.vel = bv * UU2BT; A.ball.b.angvel = bw;
         A.ball.b.rot = m3_identity();
-        for (int k = 0; k < NC; k++) {
+        for (int r = 0; r < NC; r++) {
+            const int k = RNG::REF ? car_at_rank(A, r) : r;     // `for (Car* car : arena->_cars)`: the arena's car order (only the reference's engine cares)
             Car& c = A.cars[k]; car_set_fresh(c);
             V3 pos = rng.uni3(-X_MAX, X_MAX, -Y_MAX, Y_MAX, CAR_Z_MIN, Z_MAX);
             V3 vel = v3(0, 0, 0), av = v3(0, 0, 0);
             if (cfg.rand_car_speed) {
-                V3 d = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
-                vel = d * rng.uni(0, K::CAR_MAX_SPEED);
+                if (RNG::REF) (void)rng.uni3(-1, 1, -1, 1, -1, 1);   // `randVelDir` (RandomState.cpp:39): drawn and never used
+                vel = rng.dir_times_speed(K::CAR_MAX_SPEED);
                 V3 d2 = rs_normalized(rng.uni3(-1, 1, -1, 1, -1, 1));
                 av = d2 * 5.5f;
             }
-            float yaw = rng.uni(-PI_F, PI_F); float pitch = rng.uni(-PI_F / 2, PI_F / 2); float roll = rng.uni(-PI_F, PI_F);
+            float yaw, pitch, roll; rng.ypr(yaw, pitch, roll);
             bool on_ground = cfg.cars_on_ground ? true : (rng.uni(0, 1) > 0.5f);
             if (on_ground) { pos.z = 17; pitch = roll = 0; vel.z = 0; av = v3(0, 0, 0); }
             c.b.pos = pos * UU2BT; c.b.rot = euler_to_rot(yaw, pitch, roll); c.b.vel = vel * UU2BT; c.b.angvel = av;
@@ -445,6 +470,19 @@ RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& c
         }
     }
     arena_finish_load(A);
+}
+template <int NC>
+RLG_HD_NOINLINE void reset_state(Arena<NC>& A, GymEnv<NC>& G, const SetterCfg cfg, uint32_t env_id) {
+    if (RLG_UNLIKELY(A.ref_engine != 0u)) {
+        RefRng rng; rng.e.x = A.ref_engine;
+        G.reset_count++;
+        reset_state_with(A, cfg, rng);
+        A.ref_engine = rng.e.x;
+        return;
+    }
+    PhiloxRng rng; rng.s0 = cfg.seed_lo; rng.s1 = cfg.seed_hi; rng.stream = env_id; rng.ctr = G.reset_count; rng.sub = 0; rng.have = 0;
+    G.reset_count++;
+    reset_state_with(A, cfg, rng);
 }
 // the orange slots of a one-team env (also after a host state setter, which knows nothing about them)
 template <int NC>
@@ -535,7 +573,7 @@ template <int NC>
 RLG_HD void gym_step_end(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* next_obs, size_t obs_row_stride, bool done, Snapshot<NC>& S) {
     G.episode_steps++;
     if (RLG_UNLIKELY(done && !cfg.host_resets)) {   // GameInst::Step: the recorded next observation is the first one of the new episode (GameInst.cpp:27-32)
-        reset_state(A, G, cfg, env_id);
+        reset_state(A, G, setter_cfg(cfg), env_id);
         gym_episode_reset(A, G, cfg, S);
         G.tracker_flags &= ~0xff00u;
         const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -561,7 +599,7 @@ RLG_HD void gym_step_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, Mesh
 // Gym::Reset for one env: state setter + bookkeeping + first observation
 template <int NC>
 RLG_HD void gym_reset_env(Arena<NC>& A, GymEnv<NC>& G, const GymConfig& cfg, uint32_t env_id, float* obs, size_t obs_row_stride, bool run_setter) {
-    if (run_setter) reset_state(A, G, cfg, env_id);
+    if (run_setter) reset_state(A, G, setter_cfg(cfg), env_id);
     Snapshot<NC> S;
     gym_episode_reset(A, G, cfg, S);
     G.tracker_flags &= ~0xff00u;

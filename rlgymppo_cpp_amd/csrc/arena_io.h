@@ -113,6 +113,7 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         io.i(G.prev_action_idx[k]);
     }
     io.u(G.episode_steps); io.u(G.reset_count);
+    io.u(A.ref_engine);
 }
 
 template <int NC>
@@ -123,9 +124,9 @@ constexpr size_t arena_num_words() {
     // page slack, garbage in the allocation behind it (the action table) when they did not.)  rlgpu_env_create refuses to run on a
     // mismatch, rlgpu_state_word_counts reports both numbers to the CPU tests.
 #ifdef RLG_TEST_EXTRA_WORD_ROWS   /* test build only (tools/build_variant.sh): the old defect on purpose, so the redzone test can be seen to catch it */
-    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2 + (size_t)NC * RLG_TEST_EXTRA_WORD_ROWS;
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 3 + (size_t)NC * RLG_TEST_EXTRA_WORD_ROWS;
 #else
-    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 2;
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 3;
 #endif
 }
 
@@ -163,6 +164,7 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
     // the broadphase's memory of its proxies (RlgpuArenaHidden::bp_hist): what a download handed out goes back in; a struct without it (valid bit 0
     // clear: every recording, every state a user builds) means a fresh arena set to this state -- an env slot keeps its own history then (k_upload)
     for (int b = 0; b <= NC; b++) A.bp_hist[b] = (s.hidden.valid & RLGPU_HIDDEN_BP_HIST) ? s.hidden.bp_hist[b] : (uint16_t)0;
+    A.ref_engine = (s.hidden.valid & RLGPU_HIDDEN_REF_ENGINE) ? s.hidden.ref_engine : 0u;   // (k_upload keeps the slot's engine when the state brings none)
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
     {   // BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
@@ -221,7 +223,8 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
     st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));
     // the arena's other hidden state: the broadphase history of the dynamic proxies, and the basis a demolished car's rigid body has turned to
     // behind the stale rotation its state reports (car_ghost_rot, arena_world.h)
-    s.hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;
+    s.hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT | RLGPU_HIDDEN_REF_ENGINE;
+    s.hidden.ref_engine = A.ref_engine; s.hidden._pad = 0;
     for (int b = 0; b < 8; b++) s.hidden.bp_hist[b] = b <= NC ? A.bp_hist[b] : (uint16_t)0;
     for (int k = 0; k < RLGPU_MAX_CARS; k++) for (int q = 0; q < 9; q++) s.hidden.wreck_rot[k][q] = 0.f;
     for (int k = 0; k < NC; k++) if (A.cars[k].flags & CF_IS_DEMOED) { const M3& g = A.cars[k].b.inv_inertia_w; st3(s.hidden.wreck_rot[k], col0(g)); st3(s.hidden.wreck_rot[k] + 3, col1(g)); st3(s.hidden.wreck_rot[k] + 6, col2(g)); }

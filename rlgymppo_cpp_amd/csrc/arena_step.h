@@ -1406,7 +1406,9 @@ RLG_HD void tick_build_candidates(const Arena<NC>& A, MeshView mesh, TickWork<NC
 
 template <int NC, int BIG>
 RLG_HD void arena_tick(Arena<NC>& A, MeshView mesh, uint32_t seed, uint32_t env_id, TickEvents& ev, TickWork<NC, BIG>& W) {
-    for (int i = 0; i < NC; i++) car_tick_begin(A, i, seed, env_id);
+    bool ref_due = false;
+    for (int i = 0; i < NC; i++) ref_due = car_tick_begin(A, i, seed, env_id) || ref_due;
+    if (ref_due) cars_respawn_ref_engine(A);
     tick_build_candidates(A, mesh, W);
     for (int i = 0; i < NC; i++) for (int w = 0; w < 4; w++) car_wheel_ray_begin(A, i, w, W.ctx[i]);
     if (!W.Q.overflow)

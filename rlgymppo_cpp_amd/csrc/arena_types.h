@@ -269,6 +269,8 @@ struct Arena {
     int64_t tick_count;
     int64_t ball_update_counter;
     uint32_t car_order;   // RlgpuArenaState::car_order: 4 bits per rank (slot + 1), 0 = slot order
+    uint32_t ref_engine;  // RlgpuArenaHidden::ref_engine: 0 = the env draws from its own Philox streams; else the state of the reference thread's
+                          // std::default_random_engine, from which the env then draws what the reference draws, as the reference draws it (parity tests)
     // btRSBroadphase's memory of its dynamic proxies (ball, cars), hidden state of the reference that no CarState shows: the cell of each
     // proxy's last setAabb (13 bits) and its arrival rank among the dynamic proxies (3 bits) -- arena_step.h bp_history_track.  All zero
     // = a fresh arena (what a state uploaded from the host starts as).

@@ -114,6 +114,22 @@ struct InferNet {
     int fp32;                        // 1: wave_infer_f32 (v_mfma_f32_32x32x2_f32 on fp32 operands), 0: wave_infer (bf16 operands)
     const float* Wf[9]; int Kf[9];   // layer i: weights, true number of inputs
 };
+// What the fused collection kernels are given (one device copy per env batch, written on the env's stream before every collection launch): read through a
+// pointer into the constant address space so that the layer table costs scalar loads and no registers between uses
+#define RLINFER_CONST __attribute__((address_space(4)))
+struct InferPack { InferNet net; HeadArgs head; };
+// a wave-uniform pointer that reached a real call's callee in vector registers, made scalar again
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+__device__ __forceinline__ HeadArgs head_from_const(const RLINFER_CONST HeadArgs& c) {
+    HeadArgs h; h.A = c.A; h.inv_temp = c.inv_temp; h.deterministic = c.deterministic; h.noise = c.noise; h.seed_lo = c.seed_lo; h.seed_hi = c.seed_hi; h.call_ctr = c.call_ctr;
+    h.actions = c.actions; h.logp = c.logp; h.probs_out = c.probs_out;
+    return h;
+}
 constexpr int LOGIT_LD = 132;        // fp32 logits row in LDS (n_actions <= 128)
 constexpr int WAVE_ROWS = 16;        // rows one wavefront infers at most: they sit in the first 8 or 16 rows of a 32-row MFMA tile
 __host__ __device__ constexpr int wave_buf_bytes(int rows, int ld) { return (rows * ld * 2 > rows * LOGIT_LD * 4) ? rows * ld * 2 : rows * LOGIT_LD * 4; }
@@ -203,8 +219,10 @@ __device__ __forceinline__ void mma_block_regs_any(const bf16x8 (&a)[16], const 
 // Same operand values, accumulation order, bias / ReLU / bf16 rounding and head code as k_mlp_infer (rlgpu_learn.hip): the logits and
 // the sampled actions are those of a batched call.  Only the first n_rows (>= 1) of the R rows exist: the others redo the
 // last real one (same values, same stores).  buf0 / buf1: LDS, wave_buf_bytes(R, net.ld) each.  picked[r] = the action.
-template <int R>
-__device__ __forceinline__ void wave_infer(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R],
+// `NET` is InferNet behind whatever kind of reference the caller has: the collection kernels read it through a pointer into the CONSTANT address space
+// (RLINFER_CONST: every field is a scalar load, every loop over layers and blocks a scalar branch), rlgpu_learn.hip's kernels have their own.
+template <int R, class NET>
+__device__ __forceinline__ void wave_infer(const NET& net, const HeadArgs& head, const float* obs, int row0, int n_rows, short* buf0, short* buf1, int lane, int (&picked)[R],
                                            unsigned long long* prof_split = nullptr) {
     static_assert(R <= WAVE_ROWS, "a wavefront infers at most 16 rows");
     constexpr int CHUNK = 16;
@@ -369,8 +387,8 @@ __device__ __forceinline__ float* f32_row(const F32Buf& b, int r, int ld) {   //
 }
 __host__ __device__ constexpr int f32_part_bytes(int rows, int np, int ld) { return ((rows + np - 1) / np) * (ld > LOGIT_LD ? ld : LOGIT_LD) * 4; }
 
-template <int R, int NP>
-__device__ __forceinline__ void wave_infer_f32(const InferNet& net, const HeadArgs& head, const float* obs, int row0, int n_rows, F32Buf in, F32Buf out, int lane, int (&picked)[R]) {
+template <int R, int NP, class NET>
+__device__ __forceinline__ void wave_infer_f32(const NET& net, const HeadArgs& head, const float* obs, int row0, int n_rows, F32Buf in, F32Buf out, int lane, int (&picked)[R]) {
     static_assert(R <= WAVE_ROWS, "a wavefront infers at most 16 rows");
     constexpr int CH = 16;                               // MFMA steps (2 inputs each) whose B operands are in flight together
     const int ld = net.ld;

@@ -372,6 +372,40 @@ RLG_HD void philox4(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint32_
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// ---- the reference's own engine (parity tests: RlgpuArenaHidden::ref_engine) ---------------------------------------------------------------
+// std::default_random_engine of libstdc++ = minstd_rand0: x <- 16807 x mod (2^31 - 1), operator() returns the new state, min() = 1, max() = 2^31 - 2.
+// The formulas are RocketSim's (Math.cpp:44-57) and libstdc++'s (bits/uniform_int_dist.h, bits/stl_algo.h), restated; pinned draw for draw against the
+// real reference with its thread engine assigned a known state (tests/golden/make_rng_golden.py).
+struct RefEngine {
+    uint32_t x;
+    RLG_HD uint32_t next() {
+        const uint64_t p = (uint64_t)x * 16807ull;                     // < 2^46
+        uint32_t r = (uint32_t)(p & 0x7fffffffull) + (uint32_t)(p >> 31);   // 2^31 = 1 (mod 2^31 - 1)
+        if (r >= 0x7fffffffu) r -= 0x7fffffffu;
+        x = r; return r;
+    }
+    // Math::RandFloat(min, max) = min + (engine() / (float)engine.max()) * (max - min)   (engine.max() = 2147483646 is 2^31 as a float)
+    RLG_HD float uni(float lo, float hi) { const float u = (float)next() / 2147483648.f; return lo + u * (hi - lo); }
+    // Math::RandInt(min, max) = min + engine() % (max - min)
+    RLG_HD int rand_int(int lo, int hi) { return lo + (int)(next() % (uint32_t)(hi - lo)); }
+    // std::uniform_int_distribution<unsigned long>(0, hi)(engine): the engine's range 2^31 - 3 is scaled down and draws past the last whole bucket are redrawn
+    RLG_HD uint32_t uniform_int(uint32_t hi) {
+        const uint32_t ue = hi + 1u, scaling = 2147483645u / ue, past = ue * scaling;
+        uint32_t r;
+        do r = next() - 1u; while (r >= past);
+        return r / scaling;
+    }
+    // std::shuffle(a, a + 5, engine): an odd count goes in pairs, one draw for two swap positions (__gen_two_uniform_ints)
+    RLG_HD void shuffle5(int (&a)[5]) {
+        for (int i = 1; i < 5; i += 2) {
+            const uint32_t b0 = (uint32_t)i + 1u, b1 = b0 + 1u, xx = uniform_int(b0 * b1 - 1u);
+            const int p0 = (int)(xx / b1), p1 = (int)(xx % b1);
+            int t = a[i]; a[i] = a[p0]; a[p0] = t;
+            t = a[i + 1]; a[i + 1] = a[p1]; a[p1] = t;
+        }
+    }
+};
+
 RLG_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }   // bit pattern (monotonic for f >= 0)
 RLG_HD float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 

@@ -136,6 +136,12 @@ static_assert(sizeof(RlgpuGymConfig) == sizeof(GymConfig), "C-ABI gym config mus
 namespace {
 
 constexpr int WAVE = 64;
+// The stepping kernels' real calls (the tick, the inference step, the candidate walk) are to LOCAL functions: LLVM's inter-procedural register allocation
+// then drops the callee-saved convention for them (no saves in the callee's prologue; the caller is told exactly what the callee clobbers and keeps what it
+// needs elsewhere) -- unless a call site carries the `tail` marker, which the optimiser puts on every call that cannot see the caller's stack (the inference
+// step, once its arguments stopped pointing into the kernel's frame, saved and restored 84 vector + 36 scalar registers per call: ~20 K cycles per step).
+// The attribute keeps the marker off the kernels' call sites; nothing here is, or could be, a real tail call.
+#define RLG_NO_TAIL_MARK __attribute__((disable_tail_calls))
 // Tuning knobs (overridable with -D for experiments): LDS per workgroup decides how many workgroups (= wavefronts) share
 // a CU's 160 KiB (MI355X_MICROARCH.md); RLG_WAVES_PER_SIMD is the occupancy the register allocator is asked to allow.
 #ifndef RLG_LDS_BUDGET
@@ -282,20 +288,20 @@ constexpr int staged_nodes() {
 }
 
 template <int NC>
-__device__ void load_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G) {
-    WordReader r; r.base = d.words + env; r.stride = (size_t)d.n_envs; r.idx = 0;
+__device__ void load_env(const uint32_t* words, int n_envs, int env, Arena<NC>& A, GymEnv<NC>& G) {
+    WordReader r; r.base = words + env; r.stride = (size_t)n_envs; r.idx = 0;
     arena_visit(A, G, r);
     arena_finish_load(A);
 }
 template <int NC>
-__device__ void store_env(const EnvDev& d, int env, Arena<NC>& A, GymEnv<NC>& G) {
-    WordWriter w; w.base = d.words + env; w.stride = (size_t)d.n_envs; w.idx = 0;
+__device__ void store_env(uint32_t* words, int n_envs, int env, Arena<NC>& A, GymEnv<NC>& G) {
+    WordWriter w; w.base = words + env; w.stride = (size_t)n_envs; w.idx = 0;
     arena_visit(A, G, w);
 }
 
 __shared__ uint32_t* g_leaf_cache;   // EnvDev::leaf_cache for the tick's candidate phase (kept out of the argument lists of the per-phase calls)
 __shared__ float g_cand_fat;         // EnvDev::cand_fat
-__device__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage, uint32_t* lds_grid, uint32_t* lds_pad) {
+__device__ __forceinline__ MeshView stage_mesh(const EnvDev& d, BvhNode* lds_nodes, int n_stage, uint32_t* lds_grid, uint32_t* lds_pad) {
     if (threadIdx.x == 0) { g_leaf_cache = d.leaf_cache; g_cand_fat = d.cand_fat; }
     if (d.grid) for (int i = threadIdx.x; i < GRID_WORDS; i += blockDim.x) lds_grid[i] = d.grid[i];
     for (int i = threadIdx.x; i < PAD_TAB_WORDS; i += blockDim.x) lds_pad[i] = d.pad_tab[i];
@@ -347,12 +353,13 @@ __device__ __forceinline__ uint32_t* word_stage(unsigned char* wmem, int e) {
     static_assert(sizeof(TickWork<NC>) >= arena_num_words<NC>() * 4, "TickWork doubles as the word staging area");
     return reinterpret_cast<uint32_t*>(&lane_block<NC>(wmem, e).W);
 }
+// (`words` / `n_envs`: EnvDev's, by value -- a reference to a kernel's argument struct that escapes into a real call puts the struct into scratch memory)
 template <int NC>
-__device__ void load_envs_wave(const EnvDev& d, unsigned char* wmem, int env0, int n_valid, int lane) {
+__device__ void load_envs_wave(const uint32_t* words, int n_envs, unsigned char* wmem, int env0, int n_valid, int lane) {
     constexpr int NW = (int)arena_num_words<NC>(), EPW = lanes_per_block<NC>() / WPB;
     for (int idx = lane; idx < NW * EPW; idx += WAVE) {
         const int w = idx / EPW, e = idx % EPW;
-        if (e < n_valid) word_stage<NC>(wmem, e)[w] = d.words[(size_t)w * d.n_envs + env0 + e];
+        if (e < n_valid) word_stage<NC>(wmem, e)[w] = words[(size_t)w * n_envs + env0 + e];
     }
     wave_sync();
     if (lane < n_valid) {
@@ -364,7 +371,7 @@ __device__ void load_envs_wave(const EnvDev& d, unsigned char* wmem, int env0, i
     wave_sync();
 }
 template <int NC>
-__device__ void store_envs_wave(const EnvDev& d, unsigned char* wmem, int env0, int n_valid, int lane) {
+__device__ void store_envs_wave(uint32_t* words, int n_envs, unsigned char* wmem, int env0, int n_valid, int lane) {
     constexpr int NW = (int)arena_num_words<NC>(), EPW = lanes_per_block<NC>() / WPB;
     wave_sync();
     if (lane < n_valid) {
@@ -375,7 +382,7 @@ __device__ void store_envs_wave(const EnvDev& d, unsigned char* wmem, int env0, 
     wave_sync();
     for (int idx = lane; idx < NW * EPW; idx += WAVE) {
         const int w = idx / EPW, e = idx % EPW;
-        if (e < n_valid) d.words[(size_t)w * d.n_envs + env0 + e] = word_stage<NC>(wmem, e)[w];
+        if (e < n_valid) words[(size_t)w * n_envs + env0 + e] = word_stage<NC>(wmem, e)[w];
     }
 }
 
@@ -504,7 +511,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
     // one body out of its box and EVERY env of the wavefront walks again: the walk is level-synchronous over the whole wavefront anyway (an env
     // that would not have had to walk costs nothing extra), and boxes that are renewed together tend to run out together
     const bool walk = grp && !too_big && __any(my_stale);
-#if defined(RLG_TICK_PROFILE) || defined(RLG_WWM_WAIT_CASE)   /* (RLG_WWM_WAIT_CASE: a test variant whose two dead statements move the whole-wave-bracket defect behind a wait: tests/test_gpu_parity.py) */
+#ifdef RLG_TICK_PROFILE
     if (grp && li == 0) RLG_DBG_COUNT(13);   // (env-ticks)
 #endif
     RLG_SPROF(37);
@@ -528,7 +535,7 @@ __device__ void build_candidates_wave(unsigned char* lane_mem, int n_valid, Mesh
         const float fat = attempt == 0 ? my_fat : (attempt == 1 ? CAND_FAT_SMALL * my_fat : 0.f);
         const bool go = walk && (attempt == 0 || overflow);
         if (RLG_LIKELY(!__any(go))) break;
-#if defined(RLG_TICK_PROFILE) || defined(RLG_WWM_WAIT_CASE)   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
+#ifdef RLG_TICK_PROFILE   /* profiler build only: env-ticks that walk / whose fat walk did not fit (tools/prof_collect.py) */
         if (go && li == 0) { if (attempt == 0) RLG_DBG_COUNT(11); else if (attempt == 1) RLG_DBG_COUNT(12); else RLG_DBG_COUNT(14); }
 #endif
         if (go) overflow = false;
@@ -677,8 +684,12 @@ __device__ RLG_TICK_INLINE void arena_tick_wave(unsigned char* lane_mem, int n_v
     LaneBlock<NC>& Se = lane_block<NC>(lane_mem, env_lane ? tid : 0);
 
     phase_sync(1);
-    if (car_lane) car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
+    const bool ref_due = car_lane && car_tick_begin(Sc.A, c_car, seed, (uint32_t)(env0 + e_car));
     wave_sync();
+    if (RLG_UNLIKELY(__any(ref_due))) {   // parity tests only: respawn draws from the reference's engine go in the arena's car order (arena_car.h)
+        if (env_lane && Se.A.ref_engine != 0u) cars_respawn_ref_engine(Se.A);
+        wave_sync();
+    }
     RLG_PROF(0); RLG_FPROF(0);
     build_candidates_wave<NC>(lane_mem, n_valid, mv, g_leaf_cache, env0);
 #ifdef RLG_EXPERIMENT_BFS_TWICE   // what-if build only: the candidate walk is idempotent
@@ -847,7 +858,7 @@ __device__ void step_stats_flush(float* out, StepStats st, int lane) {
 }
 
 template <int NC>
-__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
+__global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(EnvDev d, const int32_t* actions, float* next_obs, float* reward, int32_t* done) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
@@ -874,7 +885,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     wave_sync();
 #endif
     epa_arenas_setup<NC>(d, wmem);
-    load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    load_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
     if (env_lane) {
         int32_t acts[NC];
@@ -896,7 +907,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_step(Env
     if (env_lane) gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, next_obs + (size_t)env * P * D, (size_t)D, dn, snap);
     RLG_PROF(10);
     if (env_lane) for (int k = 0; k < P; k++) { reward[(size_t)env * P + k] = rew[k]; done[(size_t)env * P + k] = dn ? 1 : 0; }
-    store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    store_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     RLG_PROF(11);
     if (threadIdx.x == 0 && blockIdx.x < 4096) for (int i = 0; i < 12; i++) g_step_prof[16 * blockIdx.x + i] = g_prof[i];
@@ -917,7 +928,7 @@ struct CollectArgs {
     int T; int n_agents;
     float* obs;          // [T + 1][n_agents][D]; row block 0 holds the current observations
     int32_t* acts; float* logp; float* rew; int32_t* done;   // [T][n_agents]
-    rlinfer::InferNet net; rlinfer::HeadArgs head;
+    const rlinfer::InferPack* pack;   // the policy as the in-kernel inference reads it + the head's arguments (device memory: rlgpu_env::d_infer_pack)
     // free-running collection (rlgpu_collect_free): every wavefront goes on stepping its envs until the launch as a whole has gathered
     // `free_target` agent-steps (ThreadAgentManager::CollectTimesteps, ThreadAgentManager.cpp:16-32: the agents run free and the manager
     // takes what they have once the total is reached), at most T steps each (ThreadAgent.cpp:57-59, maxCollect); null counter = lockstep
@@ -926,8 +937,79 @@ struct CollectArgs {
     unsigned int* q_ticket; int32_t* q_done; int q_groups;
 };
 
+// The inference of one collection step for the wavefront's agents: actions and log-probs of step t go to the experience rows, the picked actions
+// to `act_lds` (R ints in the last 64 bytes of env 0's TickWork area, read by the env lanes).  A real call with an allocation of its own: nothing of
+// the tick is live across it (the state is in LDS), and inlined the MLP's ~220 registers (two weight buffers, a layer's A operands) sit on top of the
+// step loop's -- the collection kernels then spill SGPRs into VGPR lanes and those VGPRs to scratch.  -DRLG_INFER_INLINE restores the inlined form.
+#ifdef RLG_INFER_INLINE
+#define RLG_INFER_STEP_ATTR __forceinline__
+#else
+#define RLG_INFER_STEP_ATTR __noinline__
+#endif
 template <int NC>
-__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(EnvDev d, CollectArgs c) {
+__device__ RLG_INFER_STEP_ATTR void infer_step_wave(const rlinfer::InferPack* pack_, const float* obs_, int32_t* acts_, float* logp_, int n_agents_, int t_, unsigned char* wmem_, int env0_, int n_valid_, int D_
+#ifdef RLG_TICK_PROFILE
+                                                    , unsigned long long* prof_st
+#endif
+                                                    ) {
+    constexpr int LANES = lanes_per_block<NC>();
+#ifdef RLG_EXPERIMENT_EPW
+    constexpr int EPW = LANES / WPB, R = EPW * NC < rlinfer::WAVE_ROWS ? EPW * NC : rlinfer::WAVE_ROWS;
+#else
+    constexpr int EPW = LANES / WPB, R = EPW * NC;
+#endif
+    static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
+    unsigned char* const wmem = rlinfer::uniform_ptr(wmem_);
+    // the arguments of a real call arrive in vector registers; every one of these is the same on all lanes: back into scalar registers, so that the layer
+    // table is read with scalar loads and the loops over layers and column blocks are scalar branches
+    const rlinfer::InferPack RLINFER_CONST* const pk = (const rlinfer::InferPack RLINFER_CONST*)rlinfer::uniform_ptr(pack_);
+    const float* const obs_base = rlinfer::uniform_ptr(obs_); int32_t* const acts_base = rlinfer::uniform_ptr(acts_); float* const logp_base = rlinfer::uniform_ptr(logp_);
+    const int n_agents = __builtin_amdgcn_readfirstlane(n_agents_), t = __builtin_amdgcn_readfirstlane(t_), env0 = __builtin_amdgcn_readfirstlane(env0_),
+              n_valid = __builtin_amdgcn_readfirstlane(n_valid_), D = __builtin_amdgcn_readfirstlane(D_);
+    const auto& net = pk->net;
+    RLG_ASSUME_LDS(*wmem);
+    const int lane = threadIdx.x & 63;
+    const size_t N = (size_t)n_agents;
+    // inference scratch inside the TickWork areas (dead between ticks): two activation buffers and the picked actions
+    const int buf_bytes = rlinfer::wave_buf_bytes(R, net.ld);
+    unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
+    short* const buf0 = reinterpret_cast<short*>(w0);
+    short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
+    int* const act_lds = reinterpret_cast<int*>(w0 + sizeof(TickWork<NC>) - 64);   // the last 64 bytes of env 0's area (the inference buffers end before them)
+    const int row0 = env0 * NC, n_rows = n_valid * NC;
+    rlinfer::HeadArgs h = rlinfer::head_from_const(pk->head);
+    h.call_ctr += (uint32_t)t; h.actions = acts_base + (size_t)t * N; h.logp = logp_base + (size_t)t * N;
+    const float* const obs = obs_base + ((size_t)t * N + row0) * D;
+    int picked[R];
+#ifdef RLG_TICK_PROFILE
+    rlinfer::wave_infer<R>(net, h, obs, row0, n_rows, buf0, buf1, lane, picked, prof_st);
+#else
+    if (net.fp32) {
+        // exact-parity mode: fp32 activations; a buffer = NP parts of ceil(R / NP) rows, lent by the TickWork areas (dead between ticks):
+        // EPW >= 4: in = envs 0, 1, out = envs 2, 3; EPW = 3: six thirds, two per area; EPW = 2: in = env 0's two halves, out = env 1's;
+        // EPW = 1: four quarters of the one area
+        constexpr int NP = EPW == 3 ? 3 : 2;
+        constexpr int PB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
+        auto area = [&](int k) { return reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k < EPW ? k : 0).W); };
+        rlinfer::F32Buf fin{}, fout{};
+        auto f = [](unsigned char* p) { return reinterpret_cast<float*>(p); };
+        if (EPW >= 4) { fin = {{f(area(0)), f(area(1)), nullptr}}; fout = {{f(area(2)), f(area(3)), nullptr}}; }
+        else if (EPW == 3) { fin = {{f(area(0)), f(area(0) + PB), f(area(1))}}; fout = {{f(area(1) + PB), f(area(2)), f(area(2) + PB)}}; }
+        else if (EPW == 2) { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(1)), f(area(1) + PB), nullptr}}; }
+        else { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(0) + 2 * PB), f(area(0) + 3 * PB), nullptr}}; }
+        rlinfer::wave_infer_f32<R, NP>(net, h, obs, row0, n_rows, fin, fout, lane, picked);
+    } else
+        rlinfer::wave_infer<R>(net, h, obs, row0, n_rows, buf0, buf1, lane, picked);
+#endif
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) act_lds[r] = picked[r];
+    }
+    wave_sync();
+}
+
+template <int NC>
+__global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(EnvDev d, CollectArgs c) {
     constexpr int LANES = lanes_per_block<NC>();
 #ifdef RLG_EXPERIMENT_EPW
     constexpr int EPW = LANES / WPB, R = EPW * NC < rlinfer::WAVE_ROWS ? EPW * NC : rlinfer::WAVE_ROWS;
@@ -949,12 +1031,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     const uint32_t seed = tick_seed(d.cfg);
     const int D = obs_size<NC>(d.cfg);
     const size_t N = (size_t)c.n_agents;
-    // inference scratch inside the TickWork areas (dead between ticks): two activation buffers and the picked actions
-    const int buf_bytes = rlinfer::wave_buf_bytes(R, c.net.ld);
-    unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
-    short* const buf0 = reinterpret_cast<short*>(w0);
-    short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
-    int* const act_lds = reinterpret_cast<int*>(w0 + sizeof(TickWork<NC>) - 64);   // the last 64 bytes of env 0's area (the inference buffers end before them)
+    int* const act_lds = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W) + sizeof(TickWork<NC>) - 64);   // the picked actions (infer_step_wave)
     const int row0 = env0 * NC, n_rows = n_valid * NC;
     Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);   // the step's GameState, in the env's own TickWork area (dead between ticks)
 #ifdef RLG_TICK_PROFILE
@@ -972,7 +1049,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     wave_sync();
 #endif
     epa_arenas_setup<NC>(d, wmem);
-    load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    load_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
     wave_sync();
     StepStats stats;
@@ -987,38 +1064,15 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 #endif
         // the observation rows of step t were written by this wavefront at the end of step t - 1 (or by the host before the launch)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        rlinfer::HeadArgs h = c.head;
-        h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
-        int picked[R];
 #ifdef RLG_TICK_PROFILE
         unsigned long long prof_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked, prof_st);
+        infer_step_wave<NC>(c.pack, c.obs, c.acts, c.logp, c.n_agents, t, wmem, env0, n_valid, D, prof_st);
         prof_mlp += prof_st[0] - prof_a;
         prof_stage += prof_st[1] - prof_a;
         for (int q = 0; q < 4; q++) prof_layer[q] += prof_st[2 + q] - prof_st[1 + q];
 #else
-        if (c.net.fp32) {
-            // exact-parity mode: fp32 activations; a buffer = NP parts of ceil(R / NP) rows, lent by the TickWork areas (dead between ticks):
-            // EPW >= 4: in = envs 0, 1, out = envs 2, 3; EPW = 3: six thirds, two per area; EPW = 2: in = env 0's two halves, out = env 1's;
-            // EPW = 1: four quarters of the one area
-            constexpr int NP = EPW == 3 ? 3 : 2;
-            constexpr int PB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
-            auto area = [&](int k) { return reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k < EPW ? k : 0).W); };
-            rlinfer::F32Buf fin{}, fout{};
-            auto f = [](unsigned char* p) { return reinterpret_cast<float*>(p); };
-            if (EPW >= 4) { fin = {{f(area(0)), f(area(1)), nullptr}}; fout = {{f(area(2)), f(area(3)), nullptr}}; }
-            else if (EPW == 3) { fin = {{f(area(0)), f(area(0) + PB), f(area(1))}}; fout = {{f(area(1) + PB), f(area(2)), f(area(2) + PB)}}; }
-            else if (EPW == 2) { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(1)), f(area(1) + PB), nullptr}}; }
-            else { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(0) + 2 * PB), f(area(0) + 3 * PB), nullptr}}; }
-            rlinfer::wave_infer_f32<R, NP>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, ws.lane, picked);
-        } else
-        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, ws.lane, picked);
+        infer_step_wave<NC>(c.pack, c.obs, c.acts, c.logp, c.n_agents, t, wmem, env0, n_valid, D);
 #endif
-        if (ws.lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r++) act_lds[r] = picked[r];
-        }
-        wave_sync();
 #ifdef RLG_TICK_PROFILE
         prof_infer += __builtin_amdgcn_s_memtime() - prof_a;
 #endif
@@ -1049,7 +1103,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
     }
     if (c.steps_out && env_lane) c.steps_out[env] = t;
     if (d.step_stats) step_stats_flush(d.step_stats, stats, ws.lane);
-    store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    store_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_TICK_PROFILE
     // profiler build: this workgroup's total and inference cycles (read back with rlgpu_env_debug_step_prof)
     if (threadIdx.x == 0 && blockIdx.x < 4096) { g_step_prof[16 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_step_prof[16 * blockIdx.x + 1] = prof_infer; g_step_prof[16 * blockIdx.x + 2] = prof_mlp;
@@ -1067,7 +1121,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect(
 // Every wavefront that holds a ticket is running and waits for an EARLIER ticket only: no cycle.  Results are k_env_collect's, bit for bit: an env's
 // steps do not depend on which wavefront runs them (the kept candidate lists are per ticket; they are supersets by construction).
 template <int NC>
-__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_q(EnvDev d, CollectArgs c) {
+__global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_q(EnvDev d, CollectArgs c) {
     constexpr int LANES = lanes_per_block<NC>();
     constexpr int EPW = LANES / WPB, R = EPW * NC;
     static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
@@ -1081,11 +1135,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_
     const uint32_t seed = tick_seed(d.cfg);
     const int D = obs_size<NC>(d.cfg);
     const size_t N = (size_t)c.n_agents;
-    const int buf_bytes = rlinfer::wave_buf_bytes(R, c.net.ld);
-    unsigned char* const w0 = reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W);
-    short* const buf0 = reinterpret_cast<short*>(w0);
-    short* const buf1 = (EPW >= 2) ? reinterpret_cast<short*>(&lane_block<NC>(wmem, 1).W) : reinterpret_cast<short*>(w0 + buf_bytes);
-    int* const act_lds = reinterpret_cast<int*>(w0 + sizeof(TickWork<NC>) - 64);
+    int* const act_lds = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, 0).W) + sizeof(TickWork<NC>) - 64);   // the picked actions (infer_step_wave)
     epa_arenas_setup<NC>(d, wmem);
     StepStats stats;
     const unsigned int total = (unsigned int)c.q_groups * (unsigned int)c.T;
@@ -1104,30 +1154,14 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_
         LaneBlock<NC>& S = lane_block<NC>(wmem, env_lane ? lane : 0);
         const int row0 = env0 * NC, n_rows = n_valid * NC;
         Snapshot<NC>& snap = *reinterpret_cast<Snapshot<NC>*>(&S.W);
-        load_envs_wave<NC>(d, wmem, env0, n_valid, lane);
+        load_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, lane);
         if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per ticket
         wave_sync();
-        rlinfer::HeadArgs h = c.head;
-        h.call_ctr += (uint32_t)t; h.actions = c.acts + (size_t)t * N; h.logp = c.logp + (size_t)t * N;
-        int picked[R];
-        if (c.net.fp32) {
-            constexpr int NP = EPW == 3 ? 3 : 2;
-            constexpr int PB = (int)((sizeof(TickWork<NC>) - 64) / (EPW >= 4 ? 1 : (EPW >= 2 ? 2 : 4))) & ~15;
-            auto area = [&](int k) { return reinterpret_cast<unsigned char*>(&lane_block<NC>(wmem, k < EPW ? k : 0).W); };
-            rlinfer::F32Buf fin{}, fout{};
-            auto f = [](unsigned char* p) { return reinterpret_cast<float*>(p); };
-            if (EPW >= 4) { fin = {{f(area(0)), f(area(1)), nullptr}}; fout = {{f(area(2)), f(area(3)), nullptr}}; }
-            else if (EPW == 3) { fin = {{f(area(0)), f(area(0) + PB), f(area(1))}}; fout = {{f(area(1) + PB), f(area(2)), f(area(2) + PB)}}; }
-            else if (EPW == 2) { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(1)), f(area(1) + PB), nullptr}}; }
-            else { fin = {{f(area(0)), f(area(0) + PB), nullptr}}; fout = {{f(area(0) + 2 * PB), f(area(0) + 3 * PB), nullptr}}; }
-            rlinfer::wave_infer_f32<R, NP>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, fin, fout, lane, picked);
-        } else
-        rlinfer::wave_infer<R>(c.net, h, c.obs + ((size_t)t * N + row0) * D, row0, n_rows, buf0, buf1, lane, picked);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r++) act_lds[r] = picked[r];
-        }
-        wave_sync();
+        infer_step_wave<NC>(c.pack, c.obs, c.acts, c.logp, c.n_agents, t, wmem, env0, n_valid, D
+#ifdef RLG_TICK_PROFILE
+                            , nullptr
+#endif
+                            );
         float rew[NC]; bool dn = false;
         if (env_lane) {
             int32_t acts[NC];
@@ -1148,7 +1182,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_collect_
             if (c.steps_out) c.steps_out[env] = t + 1;
         }
         wave_sync();
-        store_envs_wave<NC>(d, wmem, env0, n_valid, lane);
+        store_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         wave_sync();
         if (lane == 0) __hip_atomic_store(&c.q_done[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1165,10 +1199,10 @@ __global__ void __launch_bounds__(WAVE) k_env_reset(EnvDev d, int run_setter, fl
     if (env_ids) { if (env >= n_ids) return; env = env_ids[env]; }   // rlgpu_env_reset_envs: only the listed envs
     if (env < 0 || env >= d.n_envs) return;
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
-    load_env(d, env, S.A, S.G);
+    load_env(d.words, d.n_envs, env, S.A, S.G);
     const int D = obs_size<NC>(d.cfg);
     gym_reset_env<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs ? obs + (size_t)env * players_per_env<NC>(d.cfg) * D : nullptr, (size_t)D, run_setter != 0);
-    store_env(d, env, S.A, S.G);
+    store_env(d.words, d.n_envs, env, S.A, S.G);
 }
 
 // a freshly created env is a fresh arena: every boost pad active (BoostPad's initial state) -- the first Gym::Reset shows the pads as they are
@@ -1181,15 +1215,15 @@ __global__ void __launch_bounds__(WAVE) k_env_fresh(EnvDev d) {
     const int env = blockIdx.x * LANES + threadIdx.x;
     if (env >= d.n_envs) return;
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
-    load_env(d, env, S.A, S.G);
+    load_env(d.words, d.n_envs, env, S.A, S.G);
     reset_pads(S.A);
-    store_env(d, env, S.A, S.G);
+    store_env(d.words, d.n_envs, env, S.A, S.G);
 }
 
 // physics only (rlgpu_env_physics_ticks); with `stamps` (diagnostics, rlgpu_env_debug_tick_cycles) also per workgroup the shader
 // cycles (s_memtime) and 100 MHz real-time ticks (s_memrealtime) spent in the tick loop, plus the RLG_TICK_PROFILE phase buckets
 template <int NC>
-__global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
+__global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(EnvDev d, int ticks, unsigned long long* stamps) {
     constexpr int LANES = lanes_per_block<NC>();
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
@@ -1206,7 +1240,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     wave_sync();
 #endif
     epa_arenas_setup<NC>(d, wmem);
-    load_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    load_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
     if (env_lane) { S.C.valid = 0; S.C.active = 0; S.C.alive = 0; S.C.watch = 0; }   // candidate lists are per launch
 #ifdef RLG_TICK_PROFILE
     if (threadIdx.x == 0) { for (int i = 0; i < 8; i++) g_prof[i] = 0; g_prof_last = __builtin_amdgcn_s_memtime(); }
@@ -1217,7 +1251,7 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < ticks; t++) { TickEvents ev; ev.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, tick_seed(d.cfg), env0, ev); }
     unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    store_envs_wave<NC>(d, wmem, env0, n_valid, ws.lane);
+    store_envs_wave<NC>(d.words, d.n_envs, wmem, env0, n_valid, ws.lane);
 #ifdef RLG_FINE_PROF
     if (threadIdx.x == 0) for (int i = 0; i < 64; i++) atomicAdd(&g_dbg[i], (int)(g_fine[i] >> 10));   // summed over workgroups, cycles / 1024
     if (threadIdx.x == 0 && blockIdx.x < 4096) for (int i = 0; i < 32; i++) g_fine_blk[32 * blockIdx.x + i] = (unsigned int)(g_fine[i] >> 4);
@@ -1233,6 +1267,11 @@ __global__ void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIMD) k_env_ticks(En
     }
 }
 
+__global__ void k_put_infer_pack(rlinfer::InferPack p, rlinfer::InferPack* dst) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&p); uint32_t* o = reinterpret_cast<uint32_t*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(rlinfer::InferPack) / 4); i += blockDim.x) o[i] = s[i];
+}
+
 template <int NC>
 int env_grid(int n_envs) { return (n_envs + lanes_per_block<NC>() - 1) / lanes_per_block<NC>(); }
 
@@ -1246,12 +1285,14 @@ __global__ void k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* en
     // an upload is Arena::SetState on the env's arena, not a new arena: what the broadphase remembers of its proxies stays (bp_hist; all
     // zero in an env that has never ticked = a fresh arena)
     Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
+    load_env(d.words, d.n_envs, env, A, G);
     uint16_t hist[NC + 1];
     for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
+    const uint32_t engine = A.ref_engine;
     arena_from_host(A, G, src[i]);
     if (!(src[i].hidden.valid & RLGPU_HIDDEN_BP_HIST)) for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];   // (a state that carries a history brings its own)
-    store_env(d, env, A, G);
+    if (!(src[i].hidden.valid & RLGPU_HIDDEN_REF_ENGINE)) A.ref_engine = engine;                              // (likewise the reference-engine test mode: SetState does not touch the thread's engine)
+    store_env(d.words, d.n_envs, env, A, G);
 }
 template <int NC>
 __global__ void k_download(EnvDev d, RlgpuArenaState* dst, const int32_t* env_ids, int n) {
@@ -1260,7 +1301,7 @@ __global__ void k_download(EnvDev d, RlgpuArenaState* dst, const int32_t* env_id
     int env = env_ids ? env_ids[i] : i;
     if (env < 0 || env >= d.n_envs) return;
     Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
+    load_env(d.words, d.n_envs, env, A, G);
     arena_to_host(A, G, dst[i]);
 }
 
@@ -1271,9 +1312,9 @@ __global__ void k_set_controls(EnvDev d, const float* ctl /*[n_envs][NC][8]*/) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= d.n_envs) return;
     Arena<NC> A; GymEnv<NC> G;
-    load_env(d, env, A, G);
+    load_env(d.words, d.n_envs, env, A, G);
     for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(ctl + ((size_t)env * NC + k) * 8);
-    store_env(d, env, A, G);
+    store_env(d.words, d.n_envs, env, A, G);
 }
 
 template <int NC>
@@ -1295,6 +1336,7 @@ struct rlgpu_env {
     EnvDev d{};
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
+    rlinfer::InferPack* d_infer_pack = nullptr;   // CollectArgs::pack
     unsigned int* d_queue = nullptr; int queue_groups = 0, queue_capacity = -1, queue_mode = -1;   // k_env_collect_q: [0] ticket, [16 ..] finished steps per group; -1 auto, 0 never, 1 always
     unsigned int* d_free_counter = nullptr; int free_capacity = -1;   // rlgpu_collect_free: the launch's agent-step counter; workgroups the device keeps resident at once
     unsigned char* d_epa_big = nullptr;
@@ -1505,6 +1547,7 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d_pad_tab) (void)hipFree(e->d_pad_tab);
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
+    if (e->d_infer_pack) (void)hipFree(e->d_infer_pack);
     if (e->d_free_counter) (void)hipFree(e->d_free_counter);
     if (e->d_queue) (void)hipFree(e->d_queue);
     if (e->d_epa_big) (void)hipFree(e->d_epa_big);
@@ -1737,15 +1780,20 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
     if (e->d.cfg.one_team) { e->err = std::string(who) + ": one-team envs are collected step by step (rlgpu_policy_act + rlgpu_env_step)"; return RLGPU_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     CollectArgs c{};
+    rlinfer::InferPack pk{};
     const int epw = (RLG_NC_PICK(e->nc, lanes_per_block<2>(), lanes_per_block<4>(), lanes_per_block<6>())) / WPB;
     const size_t tw = RLG_NC_PICK(e->nc, sizeof(TickWork<2>), sizeof(TickWork<4>), sizeof(TickWork<6>));
     const int max_buf = (int)((tw - 64) / (epw >= 2 ? 1 : 2));
     const int half_buf = (int)((tw - 64) / (epw >= 4 ? 1 : (epw >= 2 ? 2 : 4))) & ~15;     // fp32 mode: what one part of an activation buffer may take
-    int rc = rlgpu_internal_policy_net(l, &c.net, &c.head, deterministic, T, -half_buf, (void*)e->stream);
-    if (rc == RLGPU_OK && !c.net.fp32 && rlinfer::wave_buf_bytes(epw * e->nc, c.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
-    if (rc == RLGPU_OK && c.net.fp32 && rlinfer::f32_part_bytes(epw * e->nc, epw == 3 ? 3 : 2, c.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
+    int rc = rlgpu_internal_policy_net(l, &pk.net, &pk.head, deterministic, T, -half_buf, (void*)e->stream);
+    if (rc == RLGPU_OK && !pk.net.fp32 && rlinfer::wave_buf_bytes(epw * e->nc, pk.net.ld) > max_buf) rc = RLGPU_ERR_STATE;
+    if (rc == RLGPU_OK && pk.net.fp32 && rlinfer::f32_part_bytes(epw * e->nc, epw == 3 ? 3 : 2, pk.net.ld) > half_buf) rc = RLGPU_ERR_STATE;
     if (rc) { e->err = std::string(who) + ": the policy does not fit the in-kernel inference (<= 128 actions, hidden width within the LDS scratch)"; return rc; }
-    if (c.net.D != rlgpu_env_obs_size(e)) { e->err = std::string(who) + ": the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
+    if (pk.net.D != rlgpu_env_obs_size(e)) { e->err = std::string(who) + ": the policy's input width is not the env's observation width"; return RLGPU_ERR_ARG; }
+    // the net's description goes to device memory on the env's stream (a kernel with the struct as its argument: stream-ordered with the launches that read it, no pinned staging)
+    if (!e->d_infer_pack) HIPCHK(e, RZ_MALLOC(e, e->d_infer_pack, sizeof(rlinfer::InferPack), "policy description of the in-kernel inference"));
+    hipLaunchKernelGGL(k_put_infer_pack, dim3(1), dim3(64), 0, e->stream, pk, e->d_infer_pack);
+    c.pack = e->d_infer_pack;
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
     dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     if (free_target > 0) {

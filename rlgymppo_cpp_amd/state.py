@@ -77,8 +77,12 @@ class GymState(C.Structure):
 
 class ArenaHidden(C.Structure):
     """RlgpuArenaHidden (include/rlgpu_state.h): the ball's basis (BallState::rotMat); the broadphase's memory of its dynamic proxies (bp_hist) and a
-    demolished car's own rigid-body basis (wreck_rot), valid bit 0 / bit 1 saying which of the two mean something (downloads set both)."""
-    _fields_ = [("ball_rot", f32 * 9), ("valid", C.c_uint32), ("bp_hist", C.c_uint16 * 8), ("wreck_rot", (f32 * 9) * MAX_CARS)]
+    demolished car's own rigid-body basis (wreck_rot), valid bit 0 / bit 1 saying which of the two mean something (downloads set both); ref_engine
+    (valid bit 2, parity tests): the state of the reference thread's std::default_random_engine this env draws from instead of its own streams, 0 = off."""
+    _fields_ = [("ball_rot", f32 * 9), ("valid", C.c_uint32), ("bp_hist", C.c_uint16 * 8), ("wreck_rot", (f32 * 9) * MAX_CARS), ("ref_engine", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+HIDDEN_BP_HIST, HIDDEN_WRECK_ROT, HIDDEN_REF_ENGINE = 1, 2, 4
 
 
 IDENTITY9 = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
@@ -106,6 +110,8 @@ class ArenaState(C.Structure):
             out = type(C.Structure).from_buffer_copy(cls, b + bytes(C.sizeof(ArenaHidden)))
             out.hidden.ball_rot[:] = IDENTITY9
             return out
+        if short < len(b) < C.sizeof(cls):     # a recording of rounds 4 - 5: the block ended with wreck_rot (no ref_engine: 0 = the env's own streams)
+            b = b + bytes(C.sizeof(cls) - len(b))
         return type(C.Structure).from_buffer_copy(cls, b)
 
 

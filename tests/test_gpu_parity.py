@@ -423,6 +423,73 @@ def test_hip_state_setters_against_reference_samples(sg, team):
         env.close()
 
 
+def test_hip_tapes_through_respawns_equal_the_reference():
+    """VERDICT r05 "next" 2 on the GPU: the seven recorded tapes of tests/golden/respawn_golden.npz (the reference with its thread engine in a known
+    state: 2v2 / 3v3 charges with two or three demolitions, two hunts whose mutual demolition brings both cars back in one tick) as envs of a batch,
+    each env drawing its respawn slots from that engine state (RlgpuArenaHidden::ref_engine, uploaded with the start state) -- EQUAL to the reference in
+    every field of every body every 10 ticks over the whole tape, >= 300 ticks after the last respawn, and the engine's state with it."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import state_vec
+    rg = np.load(os.path.join(GOLD, "respawn_golden.npz")); sgm = np.load(os.path.join(GOLD, "sim_golden.npz"))
+    every = int(rg["every"]); names = [str(n) for n in rg["phys_names"]]
+    compared = 0
+    for nc in (4, 6):
+        grp = [n for n in names if ArenaState.from_buffer_copy(rg[f"phys/{n}/start_raw"].tobytes()).num_cars == nc]
+        env = BatchedEnv(len(grp), nc // 2, mesh=(sgm["mesh_verts"], sgm["mesh_tris"]))
+        env.upload_states([ArenaState.from_buffer_copy(rg[f"phys/{n}/start_raw"].tobytes()) for n in grp])
+        tapes = [rg[f"phys/{n}/tape"] for n in grp]; T = max(len(t) for t in tapes)
+        ctl = np.zeros((len(grp), nc, 8), np.float32)
+        for t in range(T):
+            for i, tp in enumerate(tapes):
+                if t < len(tp): ctl[i] = tp[t]
+            env.set_controls(ctl)
+            env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states()
+                for i, n in enumerate(grp):
+                    if t + 1 <= len(tapes[i]):
+                        j = (t + 1) // every - 1
+                        assert np.array_equal(state_vec(cur[i]), rg[f"phys/{n}/states"][j]), f"{n} tick {t + 1}: HIP state is not the reference's"
+                        assert cur[i].hidden.ref_engine == int(rg[f"phys/{n}/engines"][j]), f"{n} tick {t + 1}: the engines parted"
+                        compared += every
+        env.close()
+    assert compared >= 5500, compared
+
+
+@pytest.mark.parametrize("team", [1, 2, 3])
+def test_hip_state_setters_equal_the_reference_draw_for_draw(team):
+    """SURVEY A8 on the GPU, exactly: the KERNEL's RandomState / KickoffState (rlgpu_env_reset with run_setter = 1) drawing from the reference's engine
+    (tests/golden/setter_golden.npz: 64 resets of one reference arena per setter and car order, its thread engine started from a known state).  Reset i of
+    the reference's arena continues the engine where reset i - 1 left it: here env i of a batch starts from the recorded engine state before reset i, so
+    the 64 resets run as ONE launch -- every state EQUAL to the reference's (ball, every car's position, velocity, angular velocity, basis, flags, boost),
+    and the engine after it."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from rlgymppo_cpp_amd import _lib
+    from rlgymppo_cpp_amd.state import default_arena
+    from simlib import state_vec
+    sg2 = np.load(os.path.join(GOLD, "setter_golden.npz"))
+    for label in ("random_air", "random_ground", "kickoff"):
+        for rehash in (0, 11):
+            key = f"{label}/{team}/{rehash}"
+            want = [ArenaState.from_buffer_copy(b.tobytes()) for b in sg2[key + "/states"]]; engines = [int(e) for e in sg2[key + "/engine_after"]]
+            flags = int(sg2[key + "/flags"]); kind = int(sg2[key + "/kind"])
+            cfg = _lib.default_gym_config(); cfg.setter_kind = kind
+            cfg.rand_ball_speed = flags & 1; cfg.rand_car_speed = (flags >> 1) & 1; cfg.cars_on_ground = (flags >> 2) & 1
+            env = BatchedEnv(len(want), team, cfg=cfg)
+            starts = []
+            for i in range(len(want)):
+                st = default_arena(2 * team); st.car_order = want[0].car_order
+                st.hidden.valid |= 4; st.hidden.ref_engine = int(sg2[key + "/engine0"]) if i == 0 else engines[i - 1]
+                starts.append(st)
+            env.upload_states(starts)
+            env.reset(True); env.sync()
+            got = env.download_states()
+            for i in range(len(want)):
+                assert np.array_equal(state_vec(got[i]), state_vec(want[i])), f"{key} reset {i}: not the reference's state"
+                assert got[i].hidden.ref_engine == engines[i], f"{key} reset {i}: the engines parted"
+            env.close()
+
+
 def test_hip_mesh_of_two_files_vs_reference_golden(tmp_path):
     """The HIP path with a mesh loaded from TWO .cmf files (rlgpu_env_load_cmf_dir keeps one collision object per file, as the reference does:
     Arena.cpp:1028-1054) against the reference's recording on the same two files (tests/golden/seam_golden.npz): all 115 one-tick pairs
@@ -578,7 +645,7 @@ def test_hip_continues_a_mid_episode_reference_state_with_its_hidden_state():
         cur = env.download_states(env_ids=[0])[0]
         wrecks = [k for k in range(nc) if cur.cars[k].flags & (1 << 13)]
         if wrecks and cur.cars[wrecks[0]].demo_respawn_timer < 2.5: mid = cur
-    assert mid is not None and mid.hidden.valid == 3
+    assert mid is not None and (mid.hidden.valid & 3) == 3
     k = wrecks[0]
     assert any(abs(mid.hidden.wreck_rot[k][q] - mid.cars[k].rot[q]) > 1e-4 for q in range(9)), "the wreck's body has not turned away from the reported rotation"
     env.upload_states([mid, mid], env_ids=[0, 1])
@@ -1372,85 +1439,6 @@ def test_no_contact_is_ever_dropped_device_fallback_against_the_reference_fixtur
     # ... and the shipped layout, in this process so far: nothing lost either
     from rlgymppo_cpp_amd.env import BatchedEnv
     assert BatchedEnv(4, 1).lost_contact_count() == 0
-
-
-@pytest.mark.gpu
-@pytest.mark.timeout(900)
-def test_previously_faulting_inlining_variant_builds_and_runs(tmp_path):
-    """VERDICT r03 item 3.  With take_snapshot / event_tracker_update inlined next to build_obs / compute_rewards (-DRLG_INLINE_T6A) the 2v2
-    collection kernel died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in round 3, and in round 4 the default build did the same after an
-    unrelated change.  Cause (rocgdb, profiles/r04a_collect4_fault_rocgdb.txt): a compiler defect -- a per-lane spill copy emitted inside the
-    whole-wave bracket around an SGPR-spill VGPR access runs for all 64 lanes and destroys a hoisted zero parked in the inactive lanes of an
-    AGPR; the zero is the high half of a 64-bit index of the in-kernel inference.  Here: the variant is compiled on the box through
-    tools/hipcc_wwm_safe.py, the lint must FIND the defect in it (this compiler, this source: if it stops doing so the assertion says so and
-    the repair is simply not exercised), the repaired library runs four 2v2 collection launches, and its experience equals the default
-    library's bit for bit."""
-    import subprocess
-    csrc = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
-    obj = str(tmp_path / "rlgpu_env_t6a.o"); log = str(tmp_path / "wwm.log"); so = str(tmp_path / "librlgpu_t6a.so")
-    flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-ffp-contract=off", "-DRLG_INLINE_T6A"]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipcc_wwm_safe.py"), "--log", log] + flags + ["-c", os.path.join(csrc, "rlgpu_env.hip"), "-o", obj],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=csrc)
-    assert r.returncode == 0, r.stdout[-3000:]
-    found = open(log).read()
-    others = [os.path.join(csrc, "_obj", f) for f in ("rlgpu_learn.o", "rlgpu_comm.o", "arena_mesh.o", "lt_archive.o")]
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", so, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-    outs = []
-    for lib in (so, None):
-        out = str(tmp_path / ("t6a.npz" if lib else "default.npz"))
-        env = dict(os.environ); env.pop("RLGPU_LIB", None)
-        if lib: env["RLGPU_LIB"] = lib
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repro_collect4.py"), "2", "96", "9", "12", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT)
-        assert r.returncode == 0 and "launch 3 ok" in r.stdout, r.stdout[-3000:]
-        outs.append(np.load(out))
-    for k in ("obs", "act", "logp", "rew", "done"):
-        assert np.array_equal(outs[0][k], outs[1][k]), k
-    assert outs[0]["done"].sum() > 0
-    if "moved `v_accvgpr_write_b32" not in found:    # (codegen of another day: the repair is simply not exercised here; the synthetic-assembly test pins the tool)
-        import warnings
-        warnings.warn("the compiler no longer produces the whole-wave-bracket defect in the -DRLG_INLINE_T6A variant (lint: " + found.strip().splitlines()[-1] + ")")
-
-
-@pytest.mark.gpu
-@pytest.mark.timeout(1200)
-def test_wwm_repair_that_has_to_cross_a_wait_builds_and_runs(tmp_path):
-    """Round 5: two counters that compile to nothing in the release build (-DRLG_WWM_WAIT_CASE puts them back as dead statements) shift the register
-    allocation of `k_env_collect<4>` so that one instance of the whole-wave-bracket defect sits BEHIND an `s_waitcnt` inside its bracket.  The repair
-    (tools/hipcc_wwm_safe.py) used to refuse that case and the build failed; now the moved instruction takes a full `s_waitcnt vmcnt(0) expcnt(0)
-    lgkmcnt(0)` with it (the same counter value would promise less at the earlier position).  Here: the variant is compiled on the box through the
-    tool, the log must say that it took that path (this compiler, this source: if it stops doing so the assertion says so), the repaired library
-    runs 2v2 and 3v3 collection launches, and its experience equals the default library's bit for bit."""
-    import subprocess
-    csrc = os.path.join(ROOT, "rlgymppo_cpp_amd", "csrc")
-    obj = str(tmp_path / "rlgpu_env_waitcase.o"); log = str(tmp_path / "wwm.log"); so = str(tmp_path / "librlgpu_waitcase.so")
-    flags = ["-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-ffp-contract=off", "-DRLG_WWM_WAIT_CASE"]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipcc_wwm_safe.py"), "--log", log] + flags + ["-c", os.path.join(csrc, "rlgpu_env.hip"), "-o", obj],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=csrc)
-    assert r.returncode == 0, r.stdout[-3000:]
-    found = open(log).read()
-    others = [os.path.join(csrc, "_obj", f) for f in ("rlgpu_learn.o", "rlgpu_comm.o", "arena_mesh.o", "lt_archive.o")]
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + others + ["-o", so, "-L/opt/rocm/lib", "-lrccl", "-lrt", "-Wl,-rpath,/opt/rocm/lib"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]
-    for team, envs in (("2", "96"), ("3", "48")):
-        outs = []
-        for lib in (so, None):
-            out = str(tmp_path / (f"waitcase{team}.npz" if lib else f"default{team}.npz"))
-            env = dict(os.environ); env.pop("RLGPU_LIB", None)
-            if lib: env["RLGPU_LIB"] = lib
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "repro_collect4.py"), team, envs, "9", "12", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT)
-            assert r.returncode == 0 and "launch 3 ok" in r.stdout, r.stdout[-3000:]
-            outs.append(np.load(out))
-        for k in ("obs", "act", "logp", "rew", "done"):
-            assert np.array_equal(outs[0][k], outs[1][k]), (team, k)
-    # (whether THIS source still puts an instance of the defect behind a wait is the register allocator's business: it did when the test was written --
-    # profiles/r05_wwm_wait_case.log -- and any later edit of the stepper may move it; the tool's handling of the case is pinned without a compiler by
-    # tests/test_oracle_golden.py::test_wwm_repair_on_synthetic_assembly)
-    if "a full s_waitcnt goes with" not in found:
-        import warnings
-        warnings.warn("the compiler no longer produces the behind-a-wait case in the -DRLG_WWM_WAIT_CASE variant; the variant built, ran and equals the default library")
 
 
 @pytest.mark.gpu

@@ -89,25 +89,28 @@ def test_committed_tapes_and_one_tick_pairs_are_what_the_reference_produces_toda
 def test_hunt_tapes_with_demolitions_host_build_equals_the_live_reference(sims):
     """Ten kickoffs of 1v1 / 2v2 / 3v3 with full tanks in which every car boosts at its nearest opponent, steering by the reference's state of the
     tick before (tools/random_tapes.py hunt): bumps, supersonic hits, demolitions.  The host build under the same tape equals the live reference
-    in every exchanged field after every tick, from the kickoff through the demolitions up to the first respawn (the respawn spot is drawn from
-    the process-wide std RNG in the reference, Car.cpp:43-48, and from the env's Philox stream here: DESIGN.md "known deviations")."""
+    in every exchanged field after every tick, from the kickoff through the demolitions AND the respawns to the end of the tape: the respawn spot is
+    drawn from the thread's std engine in the reference (Car.cpp:43-48), which ref_seed_engine sets to a known state, and from the same state here
+    (RlgpuArenaHidden::ref_engine: csrc/arena_car.h cars_respawn_ref_engine) -- the engines are compared too."""
     g, port, ref = sims
     port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    demos = 0; compared = 0
+    demos = 0; compared = 0; respawns = 0
+    ref.lib.ref_engine_state.restype = C.c_uint32
     for seed in range(1, 11):
         team = 1 + seed % 3; nc = 2 * team
         k0 = ref.arena(team); ref.lib.ref_arena_reset_kickoff(k0, seed); s0 = ref.get_state(k0); ref.lib.ref_arena_free(k0)
         for k in range(nc): s0.cars[k].boost = 100.0
         a = ref.arena(team); ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
+        engine0 = 1 + (seed * 2654435761) % 2147483645
+        ref.lib.ref_seed_engine(C.c_uint32(engine0)); s0.hidden.valid |= 4; s0.hidden.ref_engine = engine0
         was = [False] * nc
         tape, want = [], []
         for t in range(1500):      # the tape is written as the reference runs
             cur = ref.get_state(a)
             ctl = np.zeros((nc, 8), np.float32)
-            respawned = False
             for k in range(nc):
                 me = cur.cars[k]; dm = bool(me.flags & (1 << 13))
-                demos += dm and not was[k]; respawned |= (was[k] and not dm); was[k] = dm
+                demos += dm and not was[k]; respawns += (was[k] and not dm); was[k] = dm
                 opp = [cur.cars[j] for j in range(nc) if j % 2 != k % 2 and not (cur.cars[j].flags & (1 << 13))]
                 ctl[k, 0] = 1.0
                 if opp:
@@ -115,12 +118,10 @@ def test_hunt_tapes_with_demolitions_host_build_equals_the_live_reference(sims):
                     dx, dy = o.pos[0] - me.pos[0], o.pos[1] - me.pos[1]; fx, fy = me.rot[0], me.rot[1]
                     ang = float(np.arctan2(fx * dy - fy * dx, fx * dx + fy * dy))
                     ctl[k, 1] = float(np.clip(-2.0 * ang, -1.0, 1.0)); ctl[k, 6] = 1.0 if abs(ang) < 0.6 else 0.0; ctl[k, 7] = 1.0 if abs(ang) > 1.5 else 0.0
-            if respawned:
-                tape, want = tape[:-1], want[:-1]      # (the tick that respawned drew the spot from the reference's std RNG)
-                break
             for k in range(nc): ref.set_controls(a, k, list(ctl[k]))
             ref.step(a, 1)
             tape.append(ctl); want.append(state_vec(ref.get_state(a)))
+        engine_end = ref.lib.ref_engine_state()
         ref.lib.ref_arena_free(a)
         # the host build under the same tape, resident in its own units like the reference's arena (no uu round trip between ticks)
         T = len(tape)
@@ -129,8 +130,9 @@ def test_hunt_tapes_with_demolitions_host_build_equals_the_live_reference(sims):
         port.lib.port_run_tape(C.byref(st), tp.ctypes.data, T, 1, C.byref(outs))
         for t in range(T):
             assert np.array_equal(state_vec(outs[t]), want[t]), f"seed {seed} ({team}v{team}) tick {t + 1} of {T}: the host build left the live reference"
+        assert outs[T - 1].hidden.ref_engine == engine_end, f"seed {seed}: the engines parted ({outs[T - 1].hidden.ref_engine} / {engine_end})"
         compared += T
-    assert demos >= 3 and compared >= 8000, (demos, compared)
+    assert demos >= 3 and respawns >= 2 and compared >= 15000, (demos, respawns, compared)
 
 
 def test_rotated_ball_fixture_is_what_the_reference_produces_today(sims):

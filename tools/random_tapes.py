@@ -30,6 +30,10 @@ for seed in range(seed0, seed0 + n_tapes):
         for k in range(nc): s0.cars[k].boost = 100.0
     if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
     ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
+    # both sides draw the respawn slots from the same engine state (RlgpuArenaHidden::ref_engine; oracle/ref_driver.cpp:ref_seed_engine): a tape stays
+    # comparable through its respawns
+    engine0 = 1 + (seed * 2654435761) % 2147483645
+    ref.lib.ref_seed_engine(C.c_uint32(engine0)); s0.hidden.valid |= 4; s0.hidden.ref_engine = engine0
     tape = np.zeros((ticks, nc, 8), np.float32)
     for k in range(nc):
         t = 0
@@ -41,7 +45,7 @@ for seed in range(seed0, seed0 + n_tapes):
             tape[t:t + span, k] = c; t += span
     hunt = len(sys.argv) > 5
     raw_r = np.zeros((ticks, 1 + nc, 18), np.float32)
-    n_demo = 0; was = [False] * nc
+    n_demo = 0; n_resp = 0; was = [False] * nc
     for t in range(ticks):
         if hunt:      # the tape is written as the reference runs: full throttle and boost at the nearest opponent
             cur = ref.get_state(a)
@@ -58,7 +62,7 @@ for seed in range(seed0, seed0 + n_tapes):
                     c[6] = 1.0 if abs(ang) < 0.6 else 0.0           # boost when it is ahead
                     c[7] = 1.0 if abs(ang) > 1.5 else 0.0           # powerslide around when it is behind
                 tape[t, k] = c
-                dm = bool(me.flags & (1 << 13)); n_demo += dm and not was[k]; was[k] = dm
+                dm = bool(me.flags & (1 << 13)); n_demo += dm and not was[k]; n_resp += was[k] and not dm; was[k] = dm
         for k in range(nc):
             ref.set_controls(a, k, tape[t, k])
         ref.step(a, 1)
@@ -68,7 +72,7 @@ for seed in range(seed0, seed0 + n_tapes):
     port.lib.port_run_tape_raw(C.byref(st), tape.ctypes.data, ticks, raw_p.ctypes.data)
     fin = ref.get_state(a)
     demos = sum(1 for k in range(nc) if fin.cars[k].flags & (1 << 13))
-    if hunt: print(f"   demolitions during the tape: {n_demo}")
+    if hunt: print(f"   demolitions during the tape: {n_demo}, respawns: {n_resp}")
     bp, br = raw_p.view(np.uint32), raw_r.view(np.uint32)
     first = next((t + 1 for t in range(ticks) if (bp[t] != br[t]).any()), None)
     exact += first is None; exact_ticks += (ticks if first is None else first - 1)
