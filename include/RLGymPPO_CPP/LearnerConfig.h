@@ -61,5 +61,12 @@ struct LearnerConfig {
     // lockstep collection of a batch with more wavefront-groups than the GPU keeps resident: -1 = through the step queue (rlgpu_env_set_collect_queue;
     // same results, the launch does not wait for the slot that got the slow groups), 0 = one workgroup per group as before, 1 = the queue always
     int collectStepQueue = -1;
+    // (added, round 6) A user RewardFunction and / or a step callback as the ONLY host work: true (default) = collection stays in one fused launch, the kernel
+    // stores every step's GameState source (rlgpu_env_enable_step_records: 336 B per 1v1 env and step), and after the launch every env's steps are replayed in
+    // order on numThreads host threads -- Match::GetRewards (PreStep, GetAllRewards(state, prevActions, final)), the plugins' Reset at episode starts, GameInst's
+    // bookkeeping, the callback -- before the value pass reads the rewards.  A reward does not feed the next action, so the experience is the per-step host
+    // path's (tests/cpp/plugin_fallback_check.cpp).  false = such plugins run between the device's steps, like every other host kind (obs builder, terminal
+    // conditions, state setter, action parser always do).
+    bool deferHostRewards = true;
 };
 }

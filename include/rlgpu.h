@@ -124,6 +124,17 @@ int rlgpu_env_reset_envs(rlgpu_env* e, const int32_t* env_ids, int n, int run_se
 int rlgpu_env_enable_snapshots(rlgpu_env* e, int on);
 int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host_states, int first_env, int n);
 
+/* Step records for plugins whose work can wait until a collection launch is over (round 6): a user RewardFunction -- in the reference it runs inside the
+ * agent threads between steps (PRIV/Threading/ThreadAgent.cpp:100-160, SIM/Envs/Match.cpp:25-30), but nothing of it feeds the next action -- and step callbacks.
+ * With a ring of t_cap steps enabled, rlgpu_collect / rlgpu_collect_free also store, per env and step, what a GameState is made of where Gym::Step builds it
+ * (RlgpuStepHead + num_cars x RlgpuStepCar, rlgpu_state.h: 336 B for 1v1 against 3.7 KB of a full snapshot), and for every episode a launch ends the first
+ * state of the next one (what the plugins' Reset hooks get).  rlgpu_env_download_step_records waits for the env's stream and copies steps [0, t_used) of
+ * the ring -- host_ring [t_used][n_envs][record words] -- and the reset list: host_resets [n][2 + record words] = {env, step, record}, *n_resets = n
+ * (RLGPU_ERR_ARG when n > reset_cap; n_envs * t_used is always enough); the list starts over with the next launch.  t_cap = 0 frees the ring. */
+int rlgpu_env_enable_step_records(rlgpu_env* e, int t_cap);
+int rlgpu_env_step_record_words(const rlgpu_env* e);
+int rlgpu_env_download_step_records(rlgpu_env* e, int t_used, uint32_t* host_ring, uint32_t* host_resets, int reset_cap, int* n_resets);
+
 /* The per-step player statistics the reference's example program gathers in its step callback (examplemain.cpp:23-36: speed, touch
  * ratio, airborne ratio), accumulated by the step kernels from every step's GameState so that they cost no host work:
  * out4 = {player-steps, sum of |car velocity| in uu/s, ball touches, airborne player-steps} since the last reset. */

@@ -185,6 +185,30 @@ typedef struct RlgpuArenaState {
     RlgpuArenaHidden hidden;
 } RlgpuArenaState;
 
+/* Step records (round 6): what a GameState is made of -- GameState::UpdateFromArena / PlayerData::UpdateFromCar, SIM/Utils/Gamestates/GameState.cpp:52-104,
+ * PlayerData.cpp:4-34 -- and nothing else, for plugins whose work can wait until a collection launch has finished: a user RewardFunction, a step callback
+ * (rlgpu_env_enable_step_records).  One record = RlgpuStepHead followed by num_cars x RlgpuStepCar, all 32-bit words; a 1v1 record is 336 bytes where a
+ * full RlgpuArenaState snapshot is 3.7 KB.  Units as above (uu, rad/s; rot = forward / right / up). */
+typedef struct RlgpuStepHead {
+    int64_t tick_count;              /* Arena::tickCount where Gym::Step builds the step's GameState (after the first tick, Gym.cpp:81-93) */
+    int32_t score_line[2];
+    int32_t last_touch_car_id;
+    uint32_t pads_active[2];         /* bit p of the 64: BoostPad p (RocketSim order) is active */
+    float ball_pos[3], ball_vel[3], ball_ang_vel[3];
+    uint32_t done;                   /* the step ended the episode (the terminal conditions' verdict); 0 in a reset record */
+    int32_t num_cars;
+} RlgpuStepHead;
+typedef struct RlgpuStepCar {
+    float pos[3], rot[9], vel[3], ang_vel[3];
+    uint32_t flags;                  /* RLGPU_CF_* */
+    float boost, air_time_since_jump, jump_time, flip_time, demo_respawn_timer;
+    uint32_t touched;                /* bit 0: PlayerData::ballTouchedStep, bit 1: ballTouchedTick (PlayerData.cpp:20-30) */
+    int32_t counters[8];             /* match goals, saves, assists, shots, shot passes, bumps, demos, boost pickups (PlayerData.h:17-25) */
+} RlgpuStepCar;
+#define RLGPU_STEP_HEAD_WORDS ((int)(sizeof(RlgpuStepHead) / 4))
+#define RLGPU_STEP_CAR_WORDS ((int)(sizeof(RlgpuStepCar) / 4))
+#define RLGPU_STEP_RECORD_WORDS(num_cars) (RLGPU_STEP_HEAD_WORDS + (num_cars) * RLGPU_STEP_CAR_WORDS)
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,9 @@ SIGNATURES = {
     "rlgpu_env_reset_envs": (_i, [_vp, _vp, _i, _i, _vp]),
     "rlgpu_env_enable_snapshots": (_i, [_vp, _i]),
     "rlgpu_env_download_snapshots": (_i, [_vp, _vp, _i, _i]),
+    "rlgpu_env_enable_step_records": (_i, [_vp, _i]),
+    "rlgpu_env_step_record_words": (_i, [_vp]),
+    "rlgpu_env_download_step_records": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "rlgpu_env_step_controls": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rlgpu_pad_location": (_i, [_i, _vp, _vp]),
     "rlgpu_env_enable_step_stats": (_i, [_vp, _i]),

@@ -114,6 +114,32 @@ RLG_HD_T6A void take_snapshot(const Arena<NC>& A, GymEnv<NC>& G, Snapshot<NC>& S
     G.last_tick_count = A.tick_count;
 }
 
+// ---- step records (rlgpu_state.h RlgpuStepHead / RlgpuStepCar): a GameState's worth of an env, for host plugins that run after the launch -------------
+// `touched_step`: PlayerData::ballTouchedStep per car as take_snapshot found it (the window ends where the previous GameState was taken, and
+// take_snapshot has moved that mark already); null = a freshly reset arena (nobody has touched anything).
+template <int NC>
+RLG_HD void write_step_record(const Arena<NC>& A, const GymEnv<NC>& G, const bool* touched_step, bool done, uint32_t* o) {
+    static_assert(sizeof(RlgpuStepHead) == 72 && sizeof(RlgpuStepCar) == 132, "step record layout");
+    auto F = [](float f) { return f2u(f); };
+    auto V = [&](uint32_t*& q, V3 v) { *q++ = F(v.x); *q++ = F(v.y); *q++ = F(v.z); };
+    uint32_t* q = o;
+    *q++ = (uint32_t)((uint64_t)A.tick_count & 0xffffffffu); *q++ = (uint32_t)((uint64_t)A.tick_count >> 32);
+    *q++ = (uint32_t)G.score_line[0]; *q++ = (uint32_t)G.score_line[1]; *q++ = (uint32_t)G.last_touch_car_id;
+    uint64_t pm = 0;
+    for (int p = 0; p < 34; p++) if (A.pads[p].is_active) pm |= 1ull << p;
+    *q++ = (uint32_t)pm; *q++ = (uint32_t)(pm >> 32);
+    V(q, A.ball.b.pos * BT2UU); V(q, A.ball.b.vel * BT2UU); V(q, A.ball.b.angvel);
+    *q++ = done ? 1u : 0u; *q++ = (uint32_t)NC;
+    for (int k = 0; k < NC; k++) {
+        const Car& c = A.cars[k];
+        V(q, c.b.pos * BT2UU); V(q, col0(c.b.rot)); V(q, col1(c.b.rot)); V(q, col2(c.b.rot)); V(q, c.b.vel * BT2UU); V(q, c.b.angvel);
+        *q++ = c.flags; *q++ = F(c.boost); *q++ = F(c.air_time_since_jump); *q++ = F(c.jump_time); *q++ = F(c.flip_time); *q++ = F(c.demo_respawn_timer);
+        const bool tick = (c.flags & CF_BALLHIT_VALID) && c.bh_tick_hit == A.tick_count - 1;
+        *q++ = ((touched_step && touched_step[k]) ? 1u : 0u) | (tick ? 2u : 0u);
+        for (int i = 0; i < 8; i++) *q++ = (uint32_t)G.counters[k][i];
+    }
+}
+
 // ---- GameEventTracker::Update ----------------------------------------------------------------------------
 template <int NC>
 RLG_HD bool ball_probably_going_in(const Arena<NC>& A, float max_time, int& goal_team) {  // Arena.cpp:827-863

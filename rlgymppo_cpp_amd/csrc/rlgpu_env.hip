@@ -181,6 +181,10 @@ struct EnvDev {
     unsigned char* big_work;     // [BIG_WORK_SLOTS][big_work_bytes<NC>()]: where a tick whose contacts do not fit the LDS layout is redone (tick_world_big)
     uint32_t* big_locks;         // [BIG_WORK_SLOTS] 0 = free
     float cand_fat;              // how far the candidate walk's boxes are grown (chosen by the mesh's density: see CAND_FAT above)
+    // step records for plugins that run after a collection launch (rlgpu_env_enable_step_records): rec_ring [T_cap][n_envs][record words] = every step's
+    // GameState source; rec_resets [n_envs * T_cap][2 + record words] = (env, step, the new episode's first state) of every episode the launch ended,
+    // appended through rec_count[0]; all null when off
+    uint32_t* rec_ring; uint32_t* rec_resets; unsigned int* rec_count;
 };
 
 // Everything one env touches during a step lives in LDS (state + per-tick scratch): as stack objects these
@@ -937,6 +941,15 @@ struct CollectArgs {
     unsigned int* q_ticket; int32_t* q_done; int q_groups;
 };
 
+// the first state of the episode a step just started (the env was reset inside the step: gym_step_end), appended for the host plugins' Reset hooks
+template <int NC>
+__device__ __noinline__ __attribute__((cold)) void record_reset(uint32_t* rec_resets, unsigned int* rec_count, const Arena<NC>& A, const GymEnv<NC>& G, int env, int t) {
+    const unsigned int i = atomicAdd(rec_count, 1u);   // (the list has room for every env ending an episode in every step)
+    uint32_t* o = rec_resets + (size_t)i * (2 + RLGPU_STEP_RECORD_WORDS(NC));
+    o[0] = (uint32_t)env; o[1] = (uint32_t)t;
+    write_step_record<NC>(A, G, nullptr, false, o + 2);
+}
+
 // The inference of one collection step for the wavefront's agents: actions and log-probs of step t go to the experience rows, the picked actions
 // to `act_lds` (R ints in the last 64 bytes of env 0's TickWork area, read by the env lanes).  A real call with an allocation of its own: nothing of
 // the tick is live across it (the state is in LDS), and inlined the MLP's ~220 registers (two weight buffers, a layer's A operands) sit on top of the
@@ -1089,12 +1102,14 @@ __global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIM
         { RLG_CPROF_T0();
         if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
         if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
+        if (d.rec_ring && env_lane) write_step_record<NC>(S.A, S.G, snap.touched, dn, d.rec_ring + ((size_t)t * d.n_envs + env) * RLGPU_STEP_RECORD_WORDS(NC));
         wave_sync(); RLG_CPROF_ADD(prof_gym); }
         { RLG_CPROF_T0(); for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); } RLG_CPROF_ADD(prof_ticks); }
         { RLG_CPROF_T0();
         if (env_lane) {
             gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
             for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
+            if (RLG_UNLIKELY(dn && d.rec_resets != nullptr)) record_reset<NC>(d.rec_resets, d.rec_count, S.A, S.G, env, t);
         }
         RLG_CPROF_ADD(prof_gym); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1174,11 +1189,13 @@ __global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIM
         float* const obs_next = c.obs + ((size_t)(t + 1) * N + (size_t)env * NC) * D;
         if (env_lane) dn = gym_step_after_first_tick<NC>(S.A, S.G, d.cfg, ev, d.action_table, (uint32_t)env, rew, obs_next, (size_t)D, snap);
         if (d.step_stats && env_lane) step_stats_add<NC>(stats, snap);
+        if (d.rec_ring && env_lane) write_step_record<NC>(S.A, S.G, snap.touched, dn, d.rec_ring + ((size_t)t * d.n_envs + env) * RLGPU_STEP_RECORD_WORDS(NC));
         wave_sync();
         for (int k = 1; k < d.cfg.tick_skip; k++) { TickEvents ev2; ev2.bump_mask = 0; arena_tick_wave<NC>(wmem, n_valid, mv, lds_pad, seed, env0, ev2); }
         if (env_lane) {
             gym_step_end<NC>(S.A, S.G, d.cfg, (uint32_t)env, obs_next, (size_t)D, dn, snap);
             for (int k = 0; k < NC; k++) { c.rew[(size_t)t * N + (size_t)env * NC + k] = rew[k]; c.done[(size_t)t * N + (size_t)env * NC + k] = dn ? 1 : 0; }
+            if (RLG_UNLIKELY(dn && d.rec_resets != nullptr)) record_reset<NC>(d.rec_resets, d.rec_count, S.A, S.G, env, t);
             if (c.steps_out) c.steps_out[env] = t + 1;
         }
         wave_sync();
@@ -1337,6 +1354,7 @@ struct rlgpu_env {
     BvhNode* d_nodes = nullptr; MeshTri* d_tris = nullptr; float* d_actions = nullptr; uint32_t* d_grid = nullptr; uint32_t* d_pad_tab = nullptr;
     int32_t* d_iota = nullptr;   // 0..n_agents-1 (rlgpu_env_step_controls)
     rlinfer::InferPack* d_infer_pack = nullptr;   // CollectArgs::pack
+    int rec_t_cap = 0;                            // steps the step-record ring has room for (rlgpu_env_enable_step_records)
     unsigned int* d_queue = nullptr; int queue_groups = 0, queue_capacity = -1, queue_mode = -1;   // k_env_collect_q: [0] ticket, [16 ..] finished steps per group; -1 auto, 0 never, 1 always
     unsigned int* d_free_counter = nullptr; int free_capacity = -1;   // rlgpu_collect_free: the launch's agent-step counter; workgroups the device keeps resident at once
     unsigned char* d_epa_big = nullptr;
@@ -1548,6 +1566,9 @@ void rlgpu_env_destroy(rlgpu_env* e) {
     if (e->d.snap_out) (void)hipFree(e->d.snap_out);
     if (e->d_iota) (void)hipFree(e->d_iota);
     if (e->d_infer_pack) (void)hipFree(e->d_infer_pack);
+    if (e->d.rec_ring) (void)hipFree(e->d.rec_ring);
+    if (e->d.rec_resets) (void)hipFree(e->d.rec_resets);
+    if (e->d.rec_count) (void)hipFree(e->d.rec_count);
     if (e->d_free_counter) (void)hipFree(e->d_free_counter);
     if (e->d_queue) (void)hipFree(e->d_queue);
     if (e->d_epa_big) (void)hipFree(e->d_epa_big);
@@ -1715,6 +1736,37 @@ int rlgpu_env_enable_snapshots(rlgpu_env* e, int on) {
     return RLGPU_OK;
 }
 
+// ---- step records: the GameState source of every step of a collection launch, for plugins that run after it (a user RewardFunction, a step callback) ----
+int rlgpu_env_enable_step_records(rlgpu_env* e, int t_cap) {
+    HIPCHK(e, hipSetDevice(e->device));
+    if (t_cap < 0) { e->err = "rlgpu_env_enable_step_records: t_cap < 0"; return RLGPU_ERR_ARG; }
+    if (e->d.rec_ring) { HIPCHK(e, hipStreamSynchronize(e->stream)); rz_free(e, e->d.rec_ring); rz_free(e, e->d.rec_resets); rz_free(e, e->d.rec_count); e->d.rec_ring = e->d.rec_resets = nullptr; e->d.rec_count = nullptr; e->rec_t_cap = 0; }
+    if (t_cap == 0) return RLGPU_OK;
+    const size_t W = (size_t)RLGPU_STEP_RECORD_WORDS(e->nc), slots = (size_t)t_cap * (size_t)e->n_envs;
+    HIPCHK(e, RZ_MALLOC(e, e->d.rec_ring, slots * W * 4, "step records"));
+    HIPCHK(e, RZ_MALLOC(e, e->d.rec_resets, slots * (W + 2) * 4, "reset records"));
+    HIPCHK(e, RZ_MALLOC(e, e->d.rec_count, 64, "reset record count"));
+    HIPCHK(e, hipMemsetAsync(e->d.rec_count, 0, 64, e->stream));
+    e->rec_t_cap = t_cap;
+    return RLGPU_OK;
+}
+int rlgpu_env_step_record_words(const rlgpu_env* e) { return RLGPU_STEP_RECORD_WORDS(e->nc); }
+int rlgpu_env_download_step_records(rlgpu_env* e, int t_used, uint32_t* host_ring, uint32_t* host_resets, int reset_cap, int* n_resets) {
+    if (!e->d.rec_ring) { e->err = "rlgpu_env_download_step_records: call rlgpu_env_enable_step_records first"; return RLGPU_ERR_STATE; }
+    if (t_used < 0 || t_used > e->rec_t_cap || !host_ring || !n_resets || (reset_cap > 0 && !host_resets)) { e->err = "rlgpu_env_download_step_records: bad argument"; return RLGPU_ERR_ARG; }
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t W = (size_t)RLGPU_STEP_RECORD_WORDS(e->nc);
+    unsigned int cnt = 0;
+    HIPCHK(e, hipMemcpyAsync(&cnt, e->d.rec_count, 4, hipMemcpyDeviceToHost, e->stream));
+    if (t_used > 0) HIPCHK(e, hipMemcpyAsync(host_ring, e->d.rec_ring, (size_t)t_used * e->n_envs * W * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    *n_resets = (int)cnt;
+    if ((int)cnt > reset_cap) { e->err = "rlgpu_env_download_step_records: more reset records than the caller has room for"; return RLGPU_ERR_ARG; }
+    if (cnt) HIPCHK(e, hipMemcpy(host_resets, e->d.rec_resets, (size_t)cnt * (W + 2) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemsetAsync(e->d.rec_count, 0, 4, e->stream));   // the next launch appends from the start
+    return RLGPU_OK;
+}
+
 int rlgpu_env_download_snapshots(rlgpu_env* e, RlgpuArenaState* host, int first_env, int n) {
     if (!e->d.snap_out) { e->err = "rlgpu_env_download_snapshots: call rlgpu_env_enable_snapshots first"; return RLGPU_ERR_STATE; }
     if (first_env < 0 || n < 0 || first_env + n > e->n_envs) { e->err = "rlgpu_env_download_snapshots: env range out of bounds"; return RLGPU_ERR_ARG; }
@@ -1794,6 +1846,7 @@ static int collect_impl(rlgpu_env* e, rlgpu_learner* l, int T, float* obs, int32
     if (!e->d_infer_pack) HIPCHK(e, RZ_MALLOC(e, e->d_infer_pack, sizeof(rlinfer::InferPack), "policy description of the in-kernel inference"));
     hipLaunchKernelGGL(k_put_infer_pack, dim3(1), dim3(64), 0, e->stream, pk, e->d_infer_pack);
     c.pack = e->d_infer_pack;
+    if (e->d.rec_ring && T > e->rec_t_cap) { e->err = std::string(who) + ": more steps than the step-record ring has room for (rlgpu_env_enable_step_records)"; return RLGPU_ERR_ARG; }
     c.T = T; c.n_agents = e->n_envs * e->nc; c.obs = obs; c.acts = actions; c.logp = logp; c.rew = reward; c.done = done;
     dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->n_envs), env_grid<4>(e->n_envs), env_grid<6>(e->n_envs))), block(WAVE * WPB);
     if (free_target > 0) {

@@ -30,6 +30,8 @@ struct HostEnvPath {
     std::vector<float> hObs, hRew, hControls; std::vector<int32_t> hDone, hActs;
     std::vector<RLGSC::Arena*> arenas;                 // scratch facades for user state setters, one per worker
     std::function<float*(size_t)> allocF32;            // device allocator of the owner (the learner's is redzone-aware); hipMalloc when empty
+    bool deviceResets = false;                         // the step kernel resets an env whose episode ended itself (RlgpuGymConfig::host_resets = 0 although a plugin
+                                                       // runs on the host: the deferred-reward mode of the Learner when it has to step by step after all)
 
     HostEnvPath() = default;
     HostEnvPath(const HostEnvPath&) = delete;
@@ -39,6 +41,7 @@ struct HostEnvPath {
         for (RLGSC::Arena* a : arenas) delete a;
         if (devObs) (void)hipFree(devObs);
         if (devControls) (void)hipFree(devControls);
+        if (recRing) (void)hipHostFree(recRing);
     }
 
     void EnvCheck(int rc, const char* what) { if (rc != RLGPU_OK) RG_ERR_CLOSE("rlgpu_env_" << what << " failed (" << rc << "): " << rlgpu_env_last_error(env)); }
@@ -70,7 +73,7 @@ struct HostEnvPath {
         if (ready) return;
         ready = true;
         env = env_; plan = plan_; nEnvs = nEnvs_; nPlayers = nPlayers_; nAgents = nAgents_; D = D_; Ddev = Ddev_; tickSkip = tickSkip_;
-        workers = std::max(1, std::min({numThreads, (int)std::thread::hardware_concurrency(), 32}));
+        workers = std::max(1, std::min({numThreads, (int)std::thread::hardware_concurrency(), 64}));
         EnvCheck(rlgpu_env_enable_snapshots(env, 1), "enable_snapshots");
         snaps.resize(nEnvs); prevGs.resize(nEnvs); hRew.resize(nAgents); hDone.resize(nAgents); hActs.resize(nAgents);
         envMatch.assign(nEnvs, match); envGym.assign(nEnvs, gym);
@@ -141,6 +144,110 @@ struct HostEnvPath {
             for (int32_t e : ids) HOST_HIP(hipMemcpy(obsRows + (size_t)e * nPlayers * D, hObs.data() + (size_t)e * nPlayers * D, (size_t)nPlayers * D * 4, hipMemcpyHostToDevice));
     }
 
+    // ---- deferred plugins (LearnerConfig::deferHostRewards): the steps of a finished collection launch, replayed per env in order ----------------------
+    // A GameState from a step record (rlgpu_state.h RlgpuStepHead / RlgpuStepCar = what GameState::UpdateFromArena / PlayerData::UpdateFromCar read),
+    // filled IN PLACE: the object and its players vector are reused from step to step.
+    // (deltaTickCount: ticks since the env's previous GameState; a reset state's is its tick count, as GameState(arena) after Gym::Reset has it)
+    static void FillGameState(RLGSC::GameState& gs, const uint32_t* rec, uint64_t prevTick, bool resetState) {
+        const RlgpuStepHead& h = *reinterpret_cast<const RlgpuStepHead*>(rec);
+        if (h.num_cars < 1 || h.num_cars > RLGPU_MAX_CARS) RG_ERR_CLOSE("step record with " << h.num_cars << " cars: not a record the collection kernel wrote");
+        const RlgpuStepCar* cars = reinterpret_cast<const RlgpuStepCar*>(rec + RLGPU_STEP_HEAD_WORDS);
+        auto V = [](const float* p) { return Vec(p[0], p[1], p[2]); };
+        gs.scoreLine.teamGoals[0] = h.score_line[0]; gs.scoreLine.teamGoals[1] = h.score_line[1];
+        gs.lastTouchCarID = h.last_touch_car_id;
+        gs.lastTickCount = (uint64_t)h.tick_count; gs.deltaTickCount = resetState ? (int)h.tick_count : (int)((uint64_t)h.tick_count - prevTick);
+        gs.ball.pos = V(h.ball_pos); gs.ball.vel = V(h.ball_vel); gs.ball.angVel = V(h.ball_ang_vel);
+        gs.ball.rotMat.forward = Vec(1, 0, 0); gs.ball.rotMat.right = Vec(0, 1, 0); gs.ball.rotMat.up = Vec(0, 0, 1);   // (the device's setters leave a BallState's default rotMat)
+        gs.ballInv = gs.ball.Invert();
+        static const int8_t PAD_ORDER[RLGPU_NUM_PADS] = {6, 7, 8, 4, 5, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 0, 19, 20, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 2, 3, 31, 32, 33};
+        const uint64_t pm = (uint64_t)h.pads_active[0] | ((uint64_t)h.pads_active[1] << 32);
+        for (int p = 0; p < RLGPU_NUM_PADS; p++) { gs.boostPads[p] = (pm >> PAD_ORDER[p]) & 1ull; gs.boostPadsInv[RLGPU_NUM_PADS - 1 - p] = gs.boostPads[p]; }
+        gs.players.resize((size_t)h.num_cars);
+        for (int k = 0; k < h.num_cars; k++) {
+            const RlgpuStepCar& c = cars[k];
+            RLGSC::PlayerData& pd = gs.players[(size_t)k];
+            pd.carId = (uint32_t)(k + 1); pd.team = (k % 2 == 0) ? Team::BLUE : Team::ORANGE;
+            pd.phys.pos = V(c.pos); pd.phys.vel = V(c.vel); pd.phys.angVel = V(c.ang_vel);
+            pd.phys.rotMat.forward = V(c.rot); pd.phys.rotMat.right = V(c.rot + 3); pd.phys.rotMat.up = V(c.rot + 6);
+            pd.physInv = pd.phys.Invert();
+            CarState& cs = pd.carState;
+            cs = CarState();
+            cs.pos = pd.phys.pos; cs.vel = pd.phys.vel; cs.angVel = pd.phys.angVel; cs.rotMat = pd.phys.rotMat;
+            cs.isOnGround = c.flags & RLGPU_CF_ON_GROUND; cs.hasJumped = c.flags & RLGPU_CF_HAS_JUMPED; cs.hasDoubleJumped = c.flags & RLGPU_CF_HAS_DOUBLE_JUMPED;
+            cs.hasFlipped = c.flags & RLGPU_CF_HAS_FLIPPED; cs.isJumping = c.flags & RLGPU_CF_IS_JUMPING; cs.isFlipping = c.flags & RLGPU_CF_IS_FLIPPING;
+            cs.isSupersonic = c.flags & RLGPU_CF_IS_SUPERSONIC; cs.isDemoed = c.flags & RLGPU_CF_IS_DEMOED;
+            cs.boost = c.boost; cs.airTimeSinceJump = c.air_time_since_jump; cs.jumpTime = c.jump_time; cs.flipTime = c.flip_time; cs.demoRespawnTimer = c.demo_respawn_timer;
+            pd.matchGoals = c.counters[0]; pd.matchSaves = c.counters[1]; pd.matchAssists = c.counters[2]; pd.matchShots = c.counters[3];
+            pd.matchShotPasses = c.counters[4]; pd.matchBumps = c.counters[5]; pd.matchDemos = c.counters[6]; pd.boostPickups = c.counters[7];
+            pd.boostFraction = c.boost / 100.f;
+            pd.ballTouchedStep = c.touched & 1u; pd.ballTouchedTick = c.touched & 2u;
+            pd.hasJump = !cs.hasJumped;
+            pd.hasFlip = !cs.hasDoubleJumped && !cs.hasFlipped && cs.airTimeSinceJump < 1.25f;
+        }
+    }
+
+    uint32_t* recRing = nullptr;   // PINNED host memory, recCap steps of room: the ring's download (45 MB per iteration at BASELINE configs[1]) runs at the link's rate, not at a staged copy's
+    std::vector<uint32_t> recResets; std::vector<int32_t> hActsAll, hDoneAll; std::vector<float> hRewAll;
+    int recWords = 0, recCap = 0;
+    void EnableStepRecords(int tCap) {
+        EnvCheck(rlgpu_env_enable_step_records(env, tCap), "enable_step_records");
+        recWords = rlgpu_env_step_record_words(env); recCap = tCap;
+        if (recRing) { (void)hipHostFree(recRing); recRing = nullptr; }
+        if (tCap > 0) HOST_HIP(hipHostMalloc((void**)&recRing, (size_t)tCap * nEnvs * recWords * 4, hipHostMallocDefault));
+    }
+    // After a fused collection launch of `tUsed` steps at most (env e made steps[e] of them; rows are time-major [t][agent] with `stride` agents per step):
+    // every env's steps in order on the worker threads.  With plan.hostReward the rewards come from Match::GetRewards and are written to `rew` (device);
+    // otherwise the device's rewards are handed to perEnv.  perEnv(env, StepResult&) as in Step().
+    template <class F>
+    void ReplayCollected(int tUsed, const int32_t* steps, const int32_t* acts, float* rew, const int32_t* done, F perEnv) {
+        const int P = nPlayers; const size_t W = (size_t)recWords, TN = (size_t)tUsed * nAgents;
+        if (tUsed <= 0) return;
+        if (tUsed > recCap) RG_ERR_CLOSE("deferred host plugins: " << tUsed << " steps collected, the record ring holds " << recCap);
+        recResets.resize((size_t)tUsed * nEnvs * (W + 2));
+        int nResets = 0;
+        EnvCheck(rlgpu_env_download_step_records(env, tUsed, recRing, recResets.data(), tUsed * nEnvs, &nResets), "download_step_records");
+        hActsAll.resize(TN); hDoneAll.resize(TN); hRewAll.resize(TN);
+        HOST_HIP(hipMemcpy(hActsAll.data(), acts, TN * 4, hipMemcpyDeviceToHost));
+        HOST_HIP(hipMemcpy(hDoneAll.data(), done, TN * 4, hipMemcpyDeviceToHost));
+        if (!plan.hostReward) HOST_HIP(hipMemcpy(hRewAll.data(), rew, TN * 4, hipMemcpyDeviceToHost));
+        // the reset records of every env, by step
+        std::vector<std::vector<std::pair<int, const uint32_t*>>> resetsOf((size_t)nEnvs);
+        for (int i = 0; i < nResets; i++) {
+            const uint32_t* r = recResets.data() + (size_t)i * (W + 2);
+            if (r[0] >= (uint32_t)nEnvs || r[1] >= (uint32_t)tUsed) RG_ERR_CLOSE("reset record " << i << " names env " << r[0] << " step " << r[1]);
+            resetsOf[r[0]].push_back({(int)r[1], r + 2});
+        }
+        ForEnvs(nullptr, [&](int e, int, int) {
+            RLGSC::Match* M = envMatch[e];
+            auto& mine = resetsOf[(size_t)e];
+            std::sort(mine.begin(), mine.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            size_t nextReset = 0;
+            RLGSC::Gym::StepResult sr;
+            for (int t = 0; t < steps[e]; t++) {
+                const uint32_t* rec = recRing + ((size_t)t * nEnvs + e) * W;
+                FillGameState(sr.state, rec, prevGs[e].lastTickCount, false);
+                const int32_t* a = hActsAll.data() + (size_t)t * nAgents + (size_t)e * P;
+                if (plan.AnyHost()) M->prevActions = M->ParseActions(RLGSC::IList(a, a + P), prevGs[e]);   // (a callback-only run shares one plugin set: nothing of it is touched)
+                sr.done = hDoneAll[(size_t)t * nAgents + (size_t)e * P] != 0;
+                if (plan.hostReward) {
+                    sr.reward = M->GetRewards(sr.state, sr.done);
+                    if ((int)sr.reward.size() != P) RG_ERR_CLOSE("RewardFunction::GetAllRewards returned " << sr.reward.size() << " rewards for " << P << " players");
+                    std::copy(sr.reward.begin(), sr.reward.end(), hRewAll.begin() + (size_t)t * nAgents + (size_t)e * P);
+                } else sr.reward.assign(hRewAll.begin() + (size_t)t * nAgents + (size_t)e * P, hRewAll.begin() + (size_t)t * nAgents + (size_t)(e + 1) * P);
+                prevGs[e] = sr.state;
+                perEnv(e, sr);
+                if (sr.done) {   // GameInst::Step: gym->Reset() (GameInst.cpp:27-32) -- the kernel did the arena's part inside the step; the plugins' Reset hooks get the new episode's first GameState
+                    if (nextReset >= mine.size() || mine[nextReset].first != t) RG_ERR_CLOSE("deferred host plugins: no reset record for env " << e << " step " << t);
+                    RLGSC::GameState gs0;
+                    FillGameState(gs0, mine[nextReset++].second, 0, true);
+                    M->EpisodeReset(gs0);
+                    prevGs[e] = gs0;
+                }
+            }
+        });
+        if (plan.hostReward) HOST_HIP(hipMemcpy(rew, hRewAll.data(), TN * 4, hipMemcpyHostToDevice));
+    }
+
     // One step of every game with host work in it.  The policy's actions are on the device (`acts`, one per agent); the step's rewards and
     // terminals end up in `rew` / `done`, the observations every player acts on next in `nextObs` (all device rows, one per agent).
     // perEnv(env, StepResult&) runs on the worker threads once the env's StepResult is complete (GameInst's bookkeeping and the step callback).
@@ -195,7 +302,7 @@ struct HostEnvPath {
         if (plugins) {
             std::vector<int32_t> ended;
             for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) ended.push_back(e);
-            ResetEnvs(ended, nextObs, false);   // (host_resets: the kernel left the ended envs as they ended)
+            ResetEnvs(ended, nextObs, deviceResets);   // (host_resets: the kernel left the ended envs as they ended -- unless deviceResets)
         } else {
             // a step callback only: the kernel reset the ended envs itself; their next GameState starts a new tick window
             for (int e = 0; e < nEnvs; e++) if (hDone[(size_t)e * P]) prevGs[e].lastTickCount = (uint64_t)snaps[e].tick_count + (uint64_t)(tickSkip - 1);

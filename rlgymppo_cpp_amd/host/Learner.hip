@@ -197,6 +197,11 @@ struct Learner::Impl {
     HostEnvPath hp;
     void SetupHostPath(const EnvCreateFn& create, int numThreads);
     void HostStep(Learner* self, int t);
+    // LearnerConfig::deferHostRewards: a user reward function is the only host plugin (deferredReward; the step kernel then resets ended envs itself), or
+    // there is none and a step callback is installed -- collection stays fused and the host work is replayed after the launch (HostEnvPath::ReplayCollected)
+    bool deferredReward = false;
+    bool DeferredNow(const Learner* self) const;
+    void DeferredReplay(Learner* self);
     // the permutation of the NEXT epoch is drawn by a worker while this thread launches the current one (a draw depends on the
     // FIFO's bookkeeping only): 2-3 ms of std::shuffle per 262 144 rows that would otherwise leave the GPU idle
     std::vector<int32_t> phys[2]; int physFlip = 0;
@@ -252,6 +257,8 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.match = ecr.match; m.gym = ecr.gym; m.tickSkip = ecr.gym->tickSkip;
     m.plan = m.match->PlanDevice(m.tickSkip);   // which plugin kinds the step kernel runs, which stay on the host
     RlgpuGymConfig gcfg = m.plan.cfg;
+    m.deferredReward = config.deferHostRewards && m.plan.hostReward && !m.plan.hostTerminal && !m.plan.hostObs && !m.plan.hostSetter && !m.plan.hostParser && m.match->spawnOpponents;
+    if (m.deferredReward) { gcfg.host_resets = 0; m.plan.cfg.host_resets = 0; m.hp.deviceResets = true; }   // the terminal conditions and the setter are the device's: an ended env is reset inside the step
     gcfg.seed_lo = (uint32_t)config.randomSeed + 1000u * (uint32_t)m.rank; gcfg.seed_hi = 0;   // every rank its own env RNG streams; rank 0 = the single-GPU run
     m.nEnvs = config.numThreads * config.numGamesPerThread;
     m.nPlayers = m.match->playerAmount;
@@ -262,7 +269,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.nAgents = rlgpu_env_num_agents(m.env); m.Ddev = m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);
     if (m.plan.AnyHost()) {
         if (m.rank == 0 && !std::getenv("RLGPU_QUIET"))
-            RG_LOG("Learner: plugins without a device form run on the host every step (" << (m.plan.hostReward ? "reward " : "") << (m.plan.hostTerminal ? "terminal-conditions " : "")
+            RG_LOG("Learner: plugins without a device form run on the host " << (m.deferredReward ? "after every collection launch (" : "every step (") << (m.plan.hostReward ? "reward " : "") << (m.plan.hostTerminal ? "terminal-conditions " : "")
                    << (m.plan.hostObs ? "obs-builder " : "") << (m.plan.hostSetter ? "state-setter " : "") << (m.plan.hostParser ? "action-parser " : "") << "); the rest stays on the device");
         m.SetupHostPath(envCreateFn, config.numThreads);
         if (m.plan.hostObs) {   // the obs width is whatever the user's builder returns (Learner.cpp:99-109 probes it the same way)
@@ -306,7 +313,7 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     if (std::getenv("RLGPU_LOCKSTEP_COLLECTION")) config.lockstepCollection = true;   // (tests that count timesteps exactly)
     m.EnvCheck(rlgpu_env_set_collect_queue(m.env, config.collectStepQueue), "set_collect_queue");
     if (config.deterministicGradients) { config.lockstepCollection = true; m.LrnCheck(rlgpu_learner_set_deterministic(m.lrn, 1), "learner_set_deterministic"); }
-    m.ragged = !config.lockstepCollection && !m.renderOnly && !m.plan.AnyHost() && !config.renderMode && m.match->spawnOpponents && !config.deterministic;
+    m.ragged = !config.lockstepCollection && !m.renderOnly && (!m.plan.AnyHost() || m.deferredReward) && !config.renderMode && m.match->spawnOpponents && !config.deterministic;
     m.Tcap = m.ragged ? 2 * m.T : m.T;
     const size_t TN = (size_t)m.Tcap * m.nAgents;
     m.obs = dev_alloc<float>((size_t)(m.Tcap + 1) * m.nAgents * m.D);
@@ -468,7 +475,7 @@ void Learner::AllReduceTimings(float& ms, int& calls, bool reset) {
 }
 // (RLGPU_FUSED_MAX_TEAM = 2 puts 3v3 back on alternating act / step launches: the faster way while a wavefront held ONE 3v3 env)
 static int FusedMaxTeam() { static const int v = [] { const char* s = std::getenv("RLGPU_FUSED_MAX_TEAM"); return s ? std::atoi(s) : 3; }(); return v; }
-bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= FusedMaxTeam() && !stepCallback && !renderSender; }
+bool Learner::UsesFusedCollection() const { return impl->fusedCollect && impl->match->teamSize <= FusedMaxTeam() && (!(stepCallback || impl->plan.AnyHost()) || impl->DeferredNow(this)) && !renderSender; }
 void Learner::DeviceTimings(float& envMs, int& envLaunches, float& gemmMs, double& gemmFlops, int& gemmCalls, bool reset) {
     // the device-side clocks are opt-in: the first call switches them on (a training run that never asks pays for no events)
     impl->EnvCheck(rlgpu_env_enable_timing(impl->env, 1), "enable_timing");
@@ -508,6 +515,24 @@ void Learner::Impl::HostStep(Learner* self, int t) {
     });
 }
 
+bool Learner::Impl::DeferredNow(const Learner* self) const {
+    if (!self->config.deferHostRewards || !fusedCollect || match->teamSize > FusedMaxTeam() || self->renderSender || !match->spawnOpponents) return false;
+    return deferredReward || (!plan.AnyHost() && (bool)self->stepCallback);
+}
+// the steps of the launch that just ended, per env in order: rewards (when the reward function is the user's), GameInst's bookkeeping (GameInst.cpp:14-34), the callback
+void Learner::Impl::DeferredReplay(Learner* self) {
+    const StepCallback& callback = self->stepCallback;
+    const int P = nPlayers;
+    hp.D = D;
+    hp.ReplayCollected(Tused, hSteps.data(), acts, rew, done, [&](int e, RLGSC::Gym::StepResult& sr) {
+        GameInst& g = games[e];
+        const float sum = std::accumulate(sr.reward.begin(), sr.reward.end(), 0.f);
+        g.avgStepRew.Add(sum, (uint64_t)P); g.curEpRew += sum / P; g.totalSteps++;
+        if (callback) callback(&g, sr, g._metrics);
+        if (sr.done) { g.avgEpRew += g.curEpRew; g.curEpRew = 0; }
+    });
+}
+
 void Learner::CollectTimesteps() {
     Impl& m = *impl;
     const size_t rowObs = (size_t)m.nAgents * m.D;
@@ -517,12 +542,16 @@ void Learner::CollectTimesteps() {
         else HOST_HIP(hipMemcpyAsync(m.ObsAt(0), m.ObsAt(m.T), rowObs * 4, hipMemcpyDeviceToDevice, nullptr));
     }
     m.first = false;
-    const bool slow = (bool)stepCallback || m.plan.AnyHost();
-    if (slow && !m.hp.ready) {   // a step callback was installed after construction
+    const bool hostWork = (bool)stepCallback || m.plan.AnyHost();
+    const bool deferred = hostWork && m.DeferredNow(this);   // a user reward / a callback and nothing else: replayed after the fused launch
+    const bool slow = hostWork && !deferred;
+    if (hostWork && !m.hp.ready) {   // a step callback was installed after construction
         m.SetupHostPath(envCreateFn, config.numThreads);
         m.EnvCheck(rlgpu_env_download_states(m.env, m.hp.snaps.data(), nullptr, m.nEnvs), "download_states");
         for (int e = 0; e < m.nEnvs; e++) m.hp.prevGs[e] = RLGSC::GameState(m.hp.snaps[e], m.tickSkip);
     }
+    if (deferred && m.hp.recCap < m.Tcap) m.hp.EnableStepRecords(m.Tcap);
+    if (!deferred && m.hp.recCap > 0) m.hp.EnableStepRecords(0);   // (the callback went away)
     auto lockstepDone = [&]() {   // every game made T steps
         if (m.ragged) hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
         std::fill(m.hSteps.begin(), m.hSteps.end(), m.T); std::fill(m.hAgentSteps.begin(), m.hAgentSteps.end(), m.T);
@@ -548,6 +577,7 @@ void Learner::CollectTimesteps() {
                 m.lastRowsAll = rows;
                 if (m.comm) { m.lastRowsAll = 0; for (double v : GatherOverRanks((double)rows)) m.lastRowsAll += (int64_t)std::llround(v); }
                 totalTimesteps += (uint64_t)m.lastRowsAll;
+                if (deferred) m.DeferredReplay(this);
                 return;
             }
             if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect_free");
@@ -555,14 +585,14 @@ void Learner::CollectTimesteps() {
             if (m.rank == 0 && !std::getenv("RLGPU_QUIET")) RG_LOG("Learner: " << rlgpu_env_last_error(m.env) << " -> lockstep collection");
         }
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
-        if (rc == RLGPU_OK) { lockstepDone(); return; }
+        if (rc == RLGPU_OK) { lockstepDone(); if (deferred) m.DeferredReplay(this); return; }
         if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect");
         m.fusedCollect = false;   // fp32 mode or a net too wide for the kernel's LDS scratch: alternate act / step
     }
     for (int t = 0; t < m.T; t++) {
         const size_t o = (size_t)t * m.nAgents;
         m.LrnCheck(rlgpu_policy_act(m.lrn, m.ObsAt(t), m.nAgents, config.deterministic ? 1 : 0, nullptr, m.acts + o, m.logp + o), "policy_act");
-        if (slow) m.HostStep(this, t);
+        if (hostWork) m.HostStep(this, t);   // (also a deferred kind whose fused launch is not available: fp32 mode, wide nets)
         else m.EnvCheck(rlgpu_env_step(m.env, m.acts + o, m.ObsAt(t + 1), m.rew + o, m.done + o), "step");
         if (renderSender) RenderStep(t);
     }

@@ -27,16 +27,20 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 
 using namespace RLGPC;
 using namespace RLGSC;
 extern char** environ;
 
-static int g_team = 1; static bool g_padded = false;
+static int g_team = 1; static bool g_padded = false, g_userReward = false;
+// --user-reward: what every RLGym user writes -- a reward class of their own (here a subclass of a built-in that changes nothing: the Learner cannot know
+// that, a subclass has no device form).  The reward then runs on the host; with LearnerConfig::deferHostRewards it does so after the fused collection launch
+struct MyVelocityPlayerToBallReward : VelocityPlayerToBallReward {};
 
 static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
     constexpr int TICK_SKIP = 8; constexpr float NO_TOUCH_TIMEOUT_SECS = 10.f;
-    auto rewards = new CombinedReward({ { new FaceBallReward(), 0.1f }, { new VelocityPlayerToBallReward(), 0.5f }, { new VelocityBallToGoalReward(), 1.0f },
+    auto rewards = new CombinedReward({ { new FaceBallReward(), 0.1f }, { g_userReward ? (RewardFunction*)new MyVelocityPlayerToBallReward() : new VelocityPlayerToBallReward(), 0.5f }, { new VelocityBallToGoalReward(), 1.0f },
         { new EventReward({ .teamGoal = 1.f, .concede = -1.f }), 50.f } });
     RewardFunction* root = rewards;
     if (g_padded) root = new ZeroSumReward(rewards, 0.3f, 1.0f);
@@ -50,7 +54,7 @@ static EnvCreateResult EnvCreateFunc() {   // examplemain.cpp:58-100
 struct Timed { double stepReward = 0, entropy = 0; double agentSteps = 0; double sec; float envMs; int envLaunches; float gemmMs; double gemmFlops; int gemmCalls; double consumeMs; std::vector<double> rankSec; float arMs; int arCalls; };
 
 int main(int argc, char* argv[]) {
-    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0, collectQueue = -1; bool fp32 = false, fp16 = false, overlap = false, lockstep = false, deterministic = false;
+    int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0, collectQueue = -1; bool fp32 = false, fp16 = false, overlap = false, lockstep = false, deterministic = false, noDefer = false;
     std::string meshDir = "./collision_meshes";
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
@@ -60,6 +64,7 @@ int main(int argc, char* argv[]) {
         else if (is("--trained-warmup")) trainedWarm = atoi(argv[++i]); else if (is("--trained-steps")) trainedSteps = atoi(argv[++i]);
         else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
         else if (is("--mesh-dir")) meshDir = argv[++i];
+        else if (is("--user-reward")) g_userReward = true; else if (is("--no-defer")) noDefer = true;
         else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
     }
     // every RLGPU_* variable this process was started with goes into the JSON line ("env_overrides"): a number measured under a path selector or on the
@@ -78,6 +83,12 @@ int main(int argc, char* argv[]) {
     const int64_t nAgents = (int64_t)envs * 2 * g_team, B = nAgents * horizon;
     LearnerConfig cfg = {};
     cfg.numThreads = 1; cfg.numGamesPerThread = envs;
+    if (g_userReward) {   // host plugins run on numThreads host threads (one plugin set per game, as in the reference): as many as the host has, dividing the batch
+        int th = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+        while (th > 1 && envs % th != 0) th--;
+        cfg.numThreads = th; cfg.numGamesPerThread = envs / th;
+        cfg.deferHostRewards = !noDefer;
+    }
     cfg.timestepsPerIteration = B; cfg.expBufferSize = B;
     cfg.ppo.batchSize = B; cfg.ppo.miniBatchSize = B / 4; cfg.ppo.epochs = epochs;
     cfg.ppo.policyLR = 2e-4f; cfg.ppo.criticLR = 2e-4f; cfg.ppo.entCoef = 0.01f; cfg.ppo.autocastLearn = !fp32;
@@ -158,6 +169,8 @@ int main(int argc, char* argv[]) {
         printf("], \"allreduce_calls\": %d, \"allreduce_ms_per_optimizer_step\": %.5f", m.arCalls, m.arCalls ? m.arMs / m.arCalls : 0.0);
         // which exchange carried the gradients ("rccl" over xGMI; "shm" = the host-staged test transport, never a scaling result), and the switches seen
         printf(", \"transport\": \"%s\", \"env_overrides\": [%s]", world > 1 ? (transport_env && !strcmp(transport_env, "shm") ? "shm" : "rccl") : "none", overrides.c_str());
+        if (g_userReward) printf(", \"user_reward\": \"a user RewardFunction subclass on %d host threads, %s\", \"host_threads\": %d, \"host_cores\": %u", cfg.numThreads,
+                                 cfg.deferHostRewards ? "replayed after the fused launch (deferHostRewards)" : "between the device's steps", cfg.numThreads, std::thread::hardware_concurrency());
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
                    warmup + steps + trainedWarm, trainedSteps, tr.agentSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);

@@ -224,6 +224,101 @@ static int UserPlugins() {
     return 0;
 }
 
+// ---- part 2c: a user RewardFunction as the only host plugin stays in the fused launch (LearnerConfig::deferHostRewards; VERDICT r05 "next" 3) ----------
+// In the reference a user's reward runs inside the agent threads at full speed (ThreadAgent.cpp:100-160, Match.cpp:25-30).  Nothing of it feeds the next
+// action, so the Learner keeps the fused collection launch, has the kernel store every step's GameState source (rlgpu_env_enable_step_records) and replays
+// each env's steps in order on the host afterwards: Match::GetRewards, the plugins' Reset at episode starts, GameInst's bookkeeping, the step callback.
+// The reward below carries per-episode state and reads the previous action and the match counters, so a wrong order, a missing Reset or a wrong initial
+// state shows.  Against the per-step host path (deferHostRewards = false): same actions, observations and terminals; rewards to 1e-6.
+static std::atomic<int> g_rewardResets{0}, g_rewardPreSteps{0};
+struct EpisodeProgressReward : RewardFunction {
+    int stepsInEpisode = 0; float startBallZ = 0, lastBallSpeed = 0;
+    void Reset(const GameState& initialState) override { g_rewardResets++; stepsInEpisode = 0; startBallZ = initialState.ball.pos.z; lastBallSpeed = initialState.ball.vel.Length(); }
+    void PreStep(const GameState& state) override { g_rewardPreSteps++; stepsInEpisode++; }
+    float GetReward(const PlayerData& player, const GameState& state, const Action& prev) override {
+        const float speed = state.ball.vel.Length();
+        const float r = 0.001f * (state.ball.pos.z - startBallZ) + 0.01f * stepsInEpisode + 0.1f * prev.throttle + 0.05f * prev.boost + (player.ballTouchedStep ? 1.f : 0.f)
+                        + 0.2f * player.boostFraction + 0.5f * (float)player.matchGoals + 1e-4f * (speed - lastBallSpeed) + (player.carState.isOnGround ? 0.f : -0.02f)
+                        + 1e-3f * (float)state.deltaTickCount + (state.boostPads[3] ? 0.003f : 0.f);
+        return r;
+    }
+    float GetFinalReward(const PlayerData& player, const GameState& state, const Action& prev) override { return GetReward(player, state, prev) + 5.f; }
+    std::vector<float> GetAllRewards(const GameState& state, const ActionSet& prevActions, bool final) override {
+        std::vector<float> out = RewardFunction::GetAllRewards(state, prevActions, final);
+        lastBallSpeed = state.ball.vel.Length();
+        return out;
+    }
+};
+static int g_deferTeam = 1;
+static EnvCreateResult MakeUserRewardEnv() {
+    Match* match = new Match(new EpisodeProgressReward(), {new NoTouchCondition(10), new GoalScoreCondition()}, new DefaultOBS(), new DiscreteAction(), new RandomState(true, true, false), g_deferTeam, true);
+    return {match, new Gym(match, 8)};
+}
+static std::atomic<int> g_deferCallbacks{0};
+static std::atomic<long long> g_deferCallbackSum{0};
+static void DeferCallback(GameInst* game, const Gym::StepResult& r, Report& metrics) {
+    g_deferCallbacks++;
+    long long v = (long long)r.state.lastTickCount + (r.done ? 1000 : 0);
+    for (float x : r.reward) v += (long long)std::llround(x * 1000.0);
+    g_deferCallbackSum += v;
+    metrics.AccumAvg("ball_height", r.state.ball.pos.z);
+}
+static int DeferredUserReward(int teamSize) {
+    const int envs = 32, steps = 48, players = 2 * teamSize;
+    g_deferTeam = teamSize;
+    Collected got[2]; int resets[2], presteps[2], callbacks[2]; long long sums[2]; bool fused[2];
+    for (int pass = 0; pass < 2; pass++) {
+        g_rewardResets = 0; g_rewardPreSteps = 0; g_deferCallbacks = 0; g_deferCallbackSum = 0;
+        LearnerConfig cfg = SmallConfig(envs, steps, players);
+        cfg.deferHostRewards = pass == 0;
+        Learner learner(MakeUserRewardEnv, cfg);
+        learner.stepCallback = DeferCallback;
+        for (int i = 0; i < 2; i++) learner.CollectTimesteps();
+        fused[pass] = learner.UsesFusedCollection();
+        learner.CopyCollected(&got[pass].obs, &got[pass].acts, &got[pass].rew, &got[pass].done);
+        got[pass].T = learner.StepsPerIteration(); got[pass].agents = learner.NumAgents();
+        resets[pass] = g_rewardResets; presteps[pass] = g_rewardPreSteps; callbacks[pass] = g_deferCallbacks; sums[pass] = g_deferCallbackSum;
+    }
+    CHECK(fused[0] && !fused[1]);                       // the deferred run stayed in the fused launch, the other one stepped with the host in between
+    CHECK(got[0].T == steps && got[0].agents == envs * players);
+    CHECK(got[0].acts == got[1].acts && got[0].done == got[1].done);
+    int dones = 0; for (int32_t d : got[0].done) dones += d;
+    CHECK(dones > 0);
+    double worstObs = 0, worstRew = 0, sumAbs = 0;
+    for (size_t i = 0; i < got[0].obs.size(); i++) worstObs = std::max(worstObs, (double)std::fabs(got[0].obs[i] - got[1].obs[i]));
+    for (size_t i = 0; i < got[0].rew.size(); i++) { worstRew = std::max(worstRew, (double)std::fabs(got[0].rew[i] - got[1].rew[i])); sumAbs += std::fabs(got[0].rew[i]); }
+    std::printf("user reward only, fused (%dv%d): %d dones, max |obs diff| %.3g, max |reward diff| %.3g (mean |reward| %.3g); Reset hooks %d / %d, PreStep %d / %d, callbacks %d / %d\n",
+                teamSize, teamSize, dones / players, worstObs, worstRew, sumAbs / got[0].rew.size(), resets[0], resets[1], presteps[0], presteps[1], callbacks[0], callbacks[1]);
+    CHECK(worstObs == 0.0 && worstRew <= 1e-6);
+    CHECK(resets[0] == resets[1] && presteps[0] == presteps[1] && presteps[0] == 2 * envs * steps);
+    CHECK(callbacks[0] == callbacks[1] && callbacks[0] == 2 * envs * steps && sums[0] == sums[1]);
+    // ... and free-running (the default): game e's rows are the lockstep run's first steps[e] rows, rewards included
+    {
+        g_rewardResets = 0; g_rewardPreSteps = 0;
+        LearnerConfig cfg = SmallConfig(envs, steps, players); cfg.lockstepCollection = false;
+        Learner learner(MakeUserRewardEnv, cfg);
+        learner.CollectTimesteps();
+        if (learner.UsesFreeRunningCollection()) {
+            Collected fr; learner.CopyCollected(&fr.obs, &fr.acts, &fr.rew, &fr.done);
+            const std::vector<int32_t> st = learner.CollectedSteps(); const int N = learner.NumAgents(); long long rows = 0;
+            // (first iteration of both runs: same seeds, same states)
+            LearnerConfig cfg2 = SmallConfig(envs, learner.StepCapacity(), players);
+            Learner lock(MakeUserRewardEnv, cfg2); lock.CollectTimesteps();
+            Collected lk; lock.CopyCollected(&lk.obs, &lk.acts, &lk.rew, &lk.done);
+            for (int e = 0; e < envs; e++)
+                for (int t = 0; t < st[e]; t++)
+                    for (int k = 0; k < players; k++) {
+                        const size_t i = (size_t)t * N + (size_t)e * players + k;
+                        CHECK(fr.acts[i] == lk.acts[i] && fr.done[i] == lk.done[i] && std::fabs(fr.rew[i] - lk.rew[i]) <= 1e-6f);
+                        rows++;
+                    }
+            CHECK(rows == (long long)learner.LastIterationTimesteps());
+            std::printf("user reward only, fused + free-running: %lld rows equal the lockstep run's\n", rows);
+        }
+    }
+    return 0;
+}
+
 // ---- part 2b: the skill tracker with a custom OBSBuilder ---------------------------------------------------------
 // SkillTracker.cpp:165-257 plays its eval games through GameInst::Step like any other game: whatever plugins the env has, they run.  Until
 // round 5 the tracker here switched itself off when the eval match had an obs builder / terminal condition / action parser without a device
@@ -493,6 +588,8 @@ int main(int argc, char** argv) {
         if (ComparePaths(2, false, false)) return 1;    // Match(..., spawnOpponents = false): two blue cars and nobody else
         if (ComparePaths(1, true, false)) return 1;     // a single car
         if (UserPlugins()) return 1;
+        if (DeferredUserReward(1)) return 1;
+        if (DeferredUserReward(2)) return 1;
         if (SkillTrackerWithUserPlugins()) return 1;
         if (CollectionDuringLearn()) return 1;
         if (FreeRunning()) return 1;
