@@ -151,6 +151,7 @@ def main():
                          "like to the stepper), given to the HIP path and to the reference baseline through their directory loaders; both: headline + a `mesh_tessellated` leg")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs[3] (2v2, 8192 envs, padded obs + zero-sum) and configs[4] "
                     "(3v3, 16384 envs, collect-during-learn + fp16 operands) that follow the headline (`configs` in the line; 1 GPU only)")
+    ap.add_argument("--no-user-reward-leg", action="store_true", help="skip the leg that runs the headline with a user RewardFunction subclass (host reward, deferred: `user_reward` in the line)")
     ap.add_argument("--allow-test-transport", action="store_true", help="tests only: print a line for N > 1 although the gradients went over the host-staged "
                     "shared-memory transport (RLGPU_COMM_TRANSPORT=shm, ranks sharing one GPU) instead of RCCL; such a line carries \"transport\": \"shm\"")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)   # internal: print the CPU baseline for the mesh directory given, as JSON
@@ -186,6 +187,12 @@ def main():
     if args.mesh == "tessellated":
         mesh_dir, mesh_info = make_tessellated_mesh_dir()
         cmd += ["--mesh-dir", mesh_dir]
+    ckpt_dir = None
+    if world == 1 and args.mesh == "both" and args.learned_warmup > 0 and args.learned_steps > 0:
+        # the learned policy is kept (Learner::Save) so that the tessellated mesh can be measured under it too: what a real user runs
+        import tempfile
+        ckpt_dir = tempfile.mkdtemp(prefix="rlgpu_ckpt_")
+        cmd += ["--save-checkpoint", ckpt_dir]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
     if proc.returncode != 0:
         raise SystemExit(f"bench_main failed with exit code {proc.returncode}")
@@ -251,8 +258,7 @@ def main():
     }
     if "trained_regime" in m:
         out["trained_regime"] = dict(m["trained_regime"], note="same learner config (1 epoch) continued; at this point play is still close to random. "
-                                     "A policy that has learned to chase the ball costs more per tick (DESIGN.md 4.3, profiles/r02l_train_probe.txt: "
-                                     "7.9 M agent-steps/s over 1600 two-epoch iterations, Python host)")
+                                     "A policy that has learned to chase the ball costs more per tick: the `trained_regime_learned` leg")
     if "trained_regime_learned" in m:
         out["trained_regime_learned"] = dict(m["trained_regime_learned"], note="the same learner after learning on with 2 PPO epochs per iteration until the policy plays "
                                              "(mean step reward and entropy next to the fresh policy's); measured with the headline's settings (1 epoch)")
@@ -293,8 +299,36 @@ def main():
                 if cb2 is not None:
                     leg["cpu_baseline"] = cb2
             out["mesh_tessellated"] = leg
+            if ckpt_dir is not None:
+                # ... and the same mesh under the policy the `trained_regime_learned` leg learned (loaded from its checkpoint; 40 iterations first, so that the
+                # episodes in flight are that policy's): learned play AND a game-like mesh, the combination a real user runs
+                cmd4 = [exe, "--envs", str(args.envs), "--team-size", str(args.team_size), "--horizon", str(args.horizon), "--steps", str(max(20, args.steps // 4)), "--warmup", "40",
+                        "--epochs", str(args.epochs), "--mesh-dir", mesh_dir, "--load-checkpoint", ckpt_dir]
+                p4 = subprocess.run(cmd4, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+                if p4.returncode == 0:
+                    m4 = json.loads(p4.stdout.decode().strip().splitlines()[-1])
+                    out["mesh_tessellated"]["learned_policy"] = {"value": m4["value"], "unit": "agent-steps/s", "ms_per_step": m4["ms_per_step"], "ppo_iter_ms": m4["ppo_iter_ms"], "steps": m4["steps"],
+                                                                 "env_kernel_avg_ms": m4["env_kernel_ms_total"] / max(1, m4["env_launches"]),
+                                                                 "mean_step_reward": m4.get("mean_step_reward"), "policy_entropy": m4.get("policy_entropy"),
+                                                                 "note": "the policy of `trained_regime_learned` (its checkpoint), 40 iterations of play first, measured with the headline's settings"}
+                else:
+                    out["mesh_tessellated"]["learned_policy"] = {"error": f"bench_main exit code {p4.returncode}"}
         else:
             out["mesh_tessellated"] = {"error": f"bench_main exit code {p2.returncode}"}
+    if ckpt_dir is not None:
+        import shutil
+        shutil.rmtree(ckpt_dir, ignore_errors=True)
+    if world == 1 and not args.no_user_reward_leg and args.team_size == 1 and not args.padded_zero_sum:
+        # what every RLGym user writes: a RewardFunction class of their own.  It has no device form, so it runs on the host -- after the fused collection launch
+        # (LearnerConfig::deferHostRewards), on the host's threads
+        cmd5 = [exe, "--envs", str(args.envs), "--horizon", str(args.horizon), "--steps", str(max(20, args.steps // 4)), "--warmup", str(max(5, args.warmup // 2)), "--epochs", str(args.epochs), "--user-reward"]
+        p5 = subprocess.run(cmd5, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+        if p5.returncode == 0:
+            m5 = json.loads(p5.stdout.decode().strip().splitlines()[-1])
+            out["user_reward"] = {"value": m5["value"], "unit": "agent-steps/s", "ms_per_step": m5["ms_per_step"], "ppo_iter_ms": m5["ppo_iter_ms"], "steps": m5["steps"], "what": m5.get("user_reward"),
+                                  "host_threads": m5.get("host_threads"), "host_cores": m5.get("host_cores"), "fused_collect": m5.get("fused_collect"), "collection": m5.get("collection")}
+        else:
+            out["user_reward"] = {"error": f"bench_main exit code {p5.returncode}"}
     if world == 1 and not args.no_config_legs and args.team_size == 1 and not args.padded_zero_sum:
         # BASELINE configs[3] and configs[4] AS WORDED, short legs outside the timed region: every number here is one bench_main run
         legs = {"c3": (["--team-size", "2", "--envs", "8192", "--padded-zero-sum", "--steps", "16", "--warmup", "4"],

@@ -60,6 +60,7 @@ public:
     int NumAgents() const;
     int StepsPerIteration() const;                   // T: steps every env takes per CollectTimesteps()
     uint32_t SamplerCalls() const;                   // launches the action sampler's counter-based stream has served (stored in RUNNING_STATS.json)
+    uint32_t SamplerStream() const;                  // the action sampler's stream: the rank on a multi-GPU run (every rank explores on its own)
     // the experience of the last CollectTimesteps() copied to the host (tests, tools): obs [(T + 1) x agents x obsSize] -- row t + 1 is what
     // the policy sees after step t -- and actions / rewards / dones [T x agents]; agent row = env * players + slot.  Null = skip.
     void CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones);

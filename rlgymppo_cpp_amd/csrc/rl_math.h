@@ -260,14 +260,19 @@ RLG_HD Q4 m3_to_quat(const M3& m) {
         x = trace + 1.0f;
         t[0] = m.r2.y - m.r1.z; t[1] = m.r0.z - m.r2.x; t[2] = m.r1.x - m.r0.y; t[3] = x;
     } else {
-        int i = m.r0.x < m.r1.y ? (m.r1.y < m.r2.z ? 2 : 1) : (m.r0.x < m.r2.z ? 2 : 0);
-        int j = (i + 1) % 3, k = (i + 2) % 3;
-        const V3 rows[3] = {m.r0, m.r1, m.r2};
-        x = get(rows[i], i) - get(rows[j], j) - get(rows[k], k) + 1.0f;
-        t[3] = get(rows[k], j) - get(rows[j], k);
-        t[j] = get(rows[j], i) + get(rows[i], j);
-        t[k] = get(rows[k], i) + get(rows[i], k);
-        t[i] = x;
+        // (i = the largest diagonal entry; the three cases written out -- `rows[i]` and `t[j]` behind run-time indices put both arrays into scratch memory
+        // on the device, and a car that faces backwards takes this branch on every tick)
+        const int i = m.r0.x < m.r1.y ? (m.r1.y < m.r2.z ? 2 : 1) : (m.r0.x < m.r2.z ? 2 : 0);
+        if (i == 0) {        // j = 1, k = 2
+            x = m.r0.x - m.r1.y - m.r2.z + 1.0f;
+            t[3] = m.r2.y - m.r1.z; t[1] = m.r1.x + m.r0.y; t[2] = m.r2.x + m.r0.z; t[0] = x;
+        } else if (i == 1) { // j = 2, k = 0
+            x = m.r1.y - m.r2.z - m.r0.x + 1.0f;
+            t[3] = m.r0.z - m.r2.x; t[2] = m.r2.y + m.r1.z; t[0] = m.r0.y + m.r1.x; t[1] = x;
+        } else {             // j = 0, k = 1
+            x = m.r2.z - m.r0.x - m.r1.y + 1.0f;
+            t[3] = m.r1.x - m.r0.y; t[0] = m.r0.z + m.r2.x; t[1] = m.r1.z + m.r2.y; t[2] = x;
+        }
     }
     const float s = 0.5f / sqrtf(x);
     Q4 q; q.x = t[0] * s; q.y = t[1] * s; q.z = t[2] * s; q.w = t[3] * s;

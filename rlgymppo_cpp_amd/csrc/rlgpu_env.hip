@@ -444,6 +444,7 @@ __device__ __noinline__ void tick_world_big(unsigned char* lane_mem, int n_valid
     if (tid == 0) {   // (holders of a slot wait for nothing: whoever spins here gets one)
         slot = (int)((blockIdx.x * WPB + wave) % BIG_WORK_SLOTS);
         while (atomicCAS(&g_big_locks_ptr[slot], 0u, 1u) != 0u) { slot = slot + 1 == BIG_WORK_SLOTS ? 0 : slot + 1; __builtin_amdgcn_s_sleep(8); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the previous holder's __threadfence + atomicExch: nothing of its TickWork is read stale from another CU's cache
     }
     slot = __builtin_amdgcn_readfirstlane(slot);
     unsigned char* const mem = g_big_work_ptr + (size_t)slot * big_work_bytes<NC>();
@@ -1140,6 +1141,7 @@ __global__ RLG_NO_TAIL_MARK void __launch_bounds__(WAVE * WPB, RLG_WAVES_PER_SIM
     constexpr int LANES = lanes_per_block<NC>();
     constexpr int EPW = LANES / WPB, R = EPW * NC;
     static_assert(R <= rlinfer::WAVE_ROWS, "a wavefront infers its own envs' agents in one MFMA tile");
+    static_assert(WPB == 1, "the step queue counts its groups as workgroups (collect_impl: q_groups = grid.x): with several wavefronts per workgroup the trailing groups would hold no env");
     __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
     __shared__ BvhNode lds_nodes[staged_nodes<NC>()];
     __shared__ uint32_t lds_grid[GRID_WORDS];
@@ -1292,16 +1294,24 @@ __global__ void k_put_infer_pack(rlinfer::InferPack p, rlinfer::InferPack* dst) 
 template <int NC>
 int env_grid(int n_envs) { return (n_envs + lanes_per_block<NC>() - 1) / lanes_per_block<NC>(); }
 
-// AoS <-> SoA movers for the host fallback path
+// AoS <-> SoA movers for the host fallback path.  An env's working copy (Arena + GymEnv, 1.5 - 3.7 KB) lives in LDS while it is converted: as per-lane
+// locals the two structs plus the exchange struct's fields went to scratch memory (k_set_controls<6>: 368 spilled registers; these run every step when a
+// plugin is on the host).  MOVE_LANES envs per 64-thread workgroup.
+constexpr int MOVE_LANES = 8;
+template <int NC> struct MoveBlock { Arena<NC> A; GymEnv<NC> G; };
+template <int NC> constexpr size_t move_stride() { size_t w = (sizeof(MoveBlock<NC>) + 7) / 8; return ((w % 2) ? w : w + 1) * 8; }
 template <int NC>
-__global__ void k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* env_ids, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(WAVE) k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* env_ids, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned char mem[MOVE_LANES * move_stride<NC>()];
+    if (threadIdx.x >= MOVE_LANES) return;
+    int i = blockIdx.x * MOVE_LANES + threadIdx.x;
     if (i >= n) return;
     int env = env_ids ? env_ids[i] : i;
     if (env < 0 || env >= d.n_envs) return;
     // an upload is Arena::SetState on the env's arena, not a new arena: what the broadphase remembers of its proxies stays (bp_hist; all
     // zero in an env that has never ticked = a fresh arena)
-    Arena<NC> A; GymEnv<NC> G;
+    MoveBlock<NC>& S = *reinterpret_cast<MoveBlock<NC>*>(mem + (size_t)threadIdx.x * move_stride<NC>());
+    Arena<NC>& A = S.A; GymEnv<NC>& G = S.G;
     load_env(d.words, d.n_envs, env, A, G);
     uint16_t hist[NC + 1];
     for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
@@ -1312,26 +1322,30 @@ __global__ void k_upload(EnvDev d, const RlgpuArenaState* src, const int32_t* en
     store_env(d.words, d.n_envs, env, A, G);
 }
 template <int NC>
-__global__ void k_download(EnvDev d, RlgpuArenaState* dst, const int32_t* env_ids, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(WAVE) k_download(EnvDev d, RlgpuArenaState* dst, const int32_t* env_ids, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned char mem[MOVE_LANES * move_stride<NC>()];
+    if (threadIdx.x >= MOVE_LANES) return;
+    int i = blockIdx.x * MOVE_LANES + threadIdx.x;
     if (i >= n) return;
     int env = env_ids ? env_ids[i] : i;
     if (env < 0 || env >= d.n_envs) return;
-    Arena<NC> A; GymEnv<NC> G;
-    load_env(d.words, d.n_envs, env, A, G);
-    arena_to_host(A, G, dst[i]);
+    MoveBlock<NC>& S = *reinterpret_cast<MoveBlock<NC>*>(mem + (size_t)threadIdx.x * move_stride<NC>());
+    load_env(d.words, d.n_envs, env, S.A, S.G);
+    arena_to_host(S.A, S.G, dst[i]);
 }
 
 // Car::controls of every car of every env (Arena facade: car->controls = ...), nothing else of the state touched: the resident words are
 // the stepper's own units, so unlike a download / upload pair this does not round anything
 template <int NC>
-__global__ void k_set_controls(EnvDev d, const float* ctl /*[n_envs][NC][8]*/) {
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(WAVE) k_set_controls(EnvDev d, const float* ctl /*[n_envs][NC][8]*/) {
+    __shared__ __attribute__((aligned(16))) unsigned char mem[MOVE_LANES * move_stride<NC>()];
+    if (threadIdx.x >= MOVE_LANES) return;
+    int env = blockIdx.x * MOVE_LANES + threadIdx.x;
     if (env >= d.n_envs) return;
-    Arena<NC> A; GymEnv<NC> G;
-    load_env(d.words, d.n_envs, env, A, G);
-    for (int k = 0; k < NC; k++) A.cars[k].ctl = ctl_from(ctl + ((size_t)env * NC + k) * 8);
-    store_env(d.words, d.n_envs, env, A, G);
+    MoveBlock<NC>& S = *reinterpret_cast<MoveBlock<NC>*>(mem + (size_t)threadIdx.x * move_stride<NC>());
+    load_env(d.words, d.n_envs, env, S.A, S.G);
+    for (int k = 0; k < NC; k++) S.A.cars[k].ctl = ctl_from(ctl + ((size_t)env * NC + k) * 8);
+    store_env(d.words, d.n_envs, env, S.A, S.G);
 }
 
 template <int NC>
@@ -1656,7 +1670,7 @@ int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host, const int
     HIPCHK(e, hipMalloc(&dsrc, sizeof(RlgpuArenaState) * (size_t)n));
     HIPCHK(e, hipMemcpyAsync(dsrc, host, sizeof(RlgpuArenaState) * (size_t)n, hipMemcpyHostToDevice, e->stream));
     if (env_ids) { HIPCHK(e, hipMalloc(&dids, 4 * (size_t)n)); HIPCHK(e, hipMemcpyAsync(dids, env_ids, 4 * (size_t)n, hipMemcpyHostToDevice, e->stream)); }
-    dim3 grid((n + 63) / 64), block(64);
+    dim3 grid((n + MOVE_LANES - 1) / MOVE_LANES), block(64);
     DISPATCH_NC(e, k_upload, grid, block, e->d, (const RlgpuArenaState*)dsrc, (const int32_t*)dids, n);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1672,7 +1686,7 @@ int rlgpu_env_download_states(rlgpu_env* e, RlgpuArenaState* host, const int32_t
     // every byte of what the caller gets is defined: car slots beyond the env's cars, the reserved part of the appended block and the struct's
     // padding are zeros (arena_to_host writes the live fields only)
     HIPCHK(e, hipMemsetAsync(ddst, 0, sizeof(RlgpuArenaState) * (size_t)n, e->stream));
-    dim3 grid((n + 63) / 64), block(64);
+    dim3 grid((n + MOVE_LANES - 1) / MOVE_LANES), block(64);
     DISPATCH_NC(e, k_download, grid, block, e->d, ddst, (const int32_t*)dids, n);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(host, ddst, sizeof(RlgpuArenaState) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
@@ -2008,7 +2022,7 @@ int rlgpu_env_set_controls(rlgpu_env* e, const float* controls_host) {
     float* dctl = nullptr;
     HIPCHK(e, hipMalloc(&dctl, bytes));
     HIPCHK(e, hipMemcpyAsync(dctl, controls_host, bytes, hipMemcpyHostToDevice, e->stream));
-    dim3 grid((e->n_envs + 63) / 64), block(64);
+    dim3 grid((e->n_envs + MOVE_LANES - 1) / MOVE_LANES), block(64);
     DISPATCH_NC(e, k_set_controls, grid, block, e->d, dctl);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -1265,6 +1265,10 @@ int fused_minibatch(rlgpu_learner* l, const float* obs, const int32_t* actions, 
     d.rows = n;
     static const int slab_env = RLGPU_EXPERIMENT_ENV("RLGPU_DW_SLAB") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_DW_SLAB")) : 0;
     d.slab = slab_env > 0 ? (slab_env + 31) / 32 * 32 : 2048;   // measured: the fp32 atomics of a flush cost 173 us per minibatch at 512 rows, 33 at 2048
+    // at most 64 slabs, i.e. 64 partial gradient buffers (1.33 MB each at 256 x 3): a minibatch of millions of rows (BASELINE configs[4]) would otherwise ask
+    // for gigabytes of partials, re-read by the reduction; the slab grows instead (whole 32-row tiles)
+    constexpr int DW_MAX_SLABS = 64;
+    if ((n + d.slab - 1) / d.slab > DW_MAX_SLABS) d.slab = ((n + DW_MAX_SLABS - 1) / DW_MAX_SLABS + 31) / 32 * 32;
     static const int dw_debug = RLGPU_EXPERIMENT_ENV("RLGPU_DW_DEBUG") ? std::atoi(RLGPU_EXPERIMENT_ENV("RLGPU_DW_DEBUG")) : 0;
     d.debug = dw_debug;
     int w = 0;

@@ -412,6 +412,11 @@ uint32_t Learner::SamplerCalls() const {
     impl->LrnCheck(rlgpu_learner_get_sampler(impl->lrn, &stream, &calls), "learner_get_sampler");
     return calls;
 }
+uint32_t Learner::SamplerStream() const {
+    uint32_t stream = 0, calls = 0;
+    impl->LrnCheck(rlgpu_learner_get_sampler(impl->lrn, &stream, &calls), "learner_get_sampler");
+    return stream;
+}
 void Learner::CopyCollected(std::vector<float>* obs, std::vector<int32_t>* actions, std::vector<float>* rewards, std::vector<int32_t>* dones) {
     Impl& m = *impl;
     const size_t TN = (size_t)m.Tcap * m.nAgents;
@@ -552,10 +557,11 @@ void Learner::CollectTimesteps() {
     }
     if (deferred && m.hp.recCap < m.Tcap) m.hp.EnableStepRecords(m.Tcap);
     if (!deferred && m.hp.recCap > 0) m.hp.EnableStepRecords(0);   // (the callback went away)
+    int64_t lockstepJobRows = -1;   // (set when the other ranks of this iteration collected free-running: see below)
     auto lockstepDone = [&]() {   // every game made T steps
         if (m.ragged) hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((m.nEnvs + 255) / 256)), dim3(256), 0, nullptr, m.steps, m.nEnvs, (int32_t)m.T);
         std::fill(m.hSteps.begin(), m.hSteps.end(), m.T); std::fill(m.hAgentSteps.begin(), m.hAgentSteps.end(), m.T);
-        m.Tused = m.T; m.lastRows = m.B; m.lastFree = false; m.lastRowsAll = (int64_t)m.B * m.world;
+        m.Tused = m.T; m.lastRows = m.B; m.lastFree = false; m.lastRowsAll = lockstepJobRows >= 0 ? lockstepJobRows : (int64_t)m.B * m.world;
         totalTimesteps += (uint64_t)m.lastRowsAll;
     };
     // no per-step host work: the whole phase in one launch (rlgpu_collect / rlgpu_collect_free), when the policy fits the in-kernel inference
@@ -563,26 +569,38 @@ void Learner::CollectTimesteps() {
         if (m.ragged && m.freeOk) {
             // the agents run free until the batch has its timesteps together (ThreadAgentManager.cpp:16-32)
             int rc = rlgpu_collect_free(m.env, m.lrn, m.Tcap, m.B, m.obs, m.acts, m.logp, m.rew, m.done, m.steps, config.deterministic ? 1 : 0);
+            if (rc != RLGPU_OK && rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect_free");
+            int64_t rows = 0; int tmax = 0;
             if (rc == RLGPU_OK) {
                 HOST_HIP(hipMemcpy(m.hSteps.data(), m.steps, (size_t)m.nEnvs * 4, hipMemcpyDeviceToHost));   // (waits for the launch)
-                int64_t rows = 0; int tmax = 0;
                 for (int e = 0; e < m.nEnvs; e++) {
                     const int32_t st = m.hSteps[(size_t)e];
                     rows += (int64_t)st * m.nPlayers; tmax = std::max(tmax, (int)st);
                     for (int k = 0; k < m.nPlayers; k++) m.hAgentSteps[(size_t)e * m.nPlayers + k] = st;
                 }
+            }
+            // every rank's own pace gives it its own count (they differ by less than one step of every game): the job's count is the SUM, taken
+            // collectively so that totalTimesteps -- the Learn() loop's exit, the checkpoint cadence and folder names -- is the same number on every rank.
+            // The same exchange carries each rank's verdict on free-running itself (-1: its batch is not resident at once, or the policy does not fit the
+            // kernel): EVERY rank makes this call in this branch, so a rank that has to fall back never leaves the others waiting in a collective, and
+            // from the next iteration on all of them collect in lockstep.
+            int64_t jobRows = rc == RLGPU_OK ? rows : m.B; bool allFree = rc == RLGPU_OK;
+            if (m.comm) {
+                jobRows = 0;
+                for (double v : GatherOverRanks(rc == RLGPU_OK ? (double)rows : -1.0)) { if (v < 0) { allFree = false; jobRows += m.B; } else jobRows += (int64_t)std::llround(v); }
+            }
+            if (!allFree) {
+                m.freeOk = false;
+                if (m.rank == 0 && !std::getenv("RLGPU_QUIET")) RG_LOG("Learner: " << (rc == RLGPU_OK ? "another rank cannot collect free-running" : rlgpu_env_last_error(m.env)) << " -> lockstep collection");
+            }
+            if (rc == RLGPU_OK) {
                 m.Tused = tmax; m.lastRows = rows; m.lastFree = true;
-                // every rank's own pace gives it its own count (they differ by less than one step of every game): the job's count is the SUM, taken
-                // collectively so that totalTimesteps -- the Learn() loop's exit, the checkpoint cadence and folder names -- is the same number on every rank
-                m.lastRowsAll = rows;
-                if (m.comm) { m.lastRowsAll = 0; for (double v : GatherOverRanks((double)rows)) m.lastRowsAll += (int64_t)std::llround(v); }
+                m.lastRowsAll = jobRows;
                 totalTimesteps += (uint64_t)m.lastRowsAll;
                 if (deferred) m.DeferredReplay(this);
                 return;
             }
-            if (rc != RLGPU_ERR_STATE) m.EnvCheck(rc, "collect_free");
-            m.freeOk = false;   // the batch is not resident at once (or the policy does not fit the kernel): lockstep launches from now on
-            if (m.rank == 0 && !std::getenv("RLGPU_QUIET")) RG_LOG("Learner: " << rlgpu_env_last_error(m.env) << " -> lockstep collection");
+            lockstepJobRows = jobRows;   // this rank collects the iteration in lockstep below; the job's count is the one every rank computed
         }
         int rc = rlgpu_collect(m.env, m.lrn, m.T, m.obs, m.acts, m.logp, m.rew, m.done, config.deterministic ? 1 : 0);
         if (rc == RLGPU_OK) { lockstepDone(); if (deferred) m.DeferredReplay(this); return; }

@@ -55,7 +55,7 @@ struct Timed { double stepReward = 0, entropy = 0; double agentSteps = 0; double
 
 int main(int argc, char* argv[]) {
     int envs = 4096, horizon = 32, steps = 200, warmup = 20, epochs = 1, trainedWarm = 0, trainedSteps = 0, learnedWarm = 0, learnedEpochs = 2, learnedSteps = 0, collectQueue = -1; bool fp32 = false, fp16 = false, overlap = false, lockstep = false, deterministic = false, noDefer = false;
-    std::string meshDir = "./collision_meshes";
+    std::string meshDir = "./collision_meshes", saveDir, loadDir;   // --save-checkpoint DIR: Learner::Save() at the end; --load-checkpoint DIR: start from its newest checkpoint (a policy that has learned, on another mesh)
     for (int i = 1; i < argc; i++) {
         auto is = [&](const char* k) { return !strcmp(argv[i], k); };
         if (is("--envs")) envs = atoi(argv[++i]); else if (is("--team-size")) g_team = atoi(argv[++i]); else if (is("--horizon")) horizon = atoi(argv[++i]);
@@ -65,6 +65,7 @@ int main(int argc, char* argv[]) {
         else if (is("--learned-warmup")) learnedWarm = atoi(argv[++i]); else if (is("--learned-epochs")) learnedEpochs = atoi(argv[++i]); else if (is("--learned-steps")) learnedSteps = atoi(argv[++i]);
         else if (is("--mesh-dir")) meshDir = argv[++i];
         else if (is("--user-reward")) g_userReward = true; else if (is("--no-defer")) noDefer = true;
+        else if (is("--save-checkpoint")) saveDir = argv[++i]; else if (is("--load-checkpoint")) loadDir = argv[++i];
         else { fprintf(stderr, "bench_main: unknown argument %s\n", argv[i]); return 2; }
     }
     // every RLGPU_* variable this process was started with goes into the JSON line ("env_overrides"): a number measured under a path selector or on the
@@ -93,7 +94,7 @@ int main(int argc, char* argv[]) {
     cfg.ppo.batchSize = B; cfg.ppo.miniBatchSize = B / 4; cfg.ppo.epochs = epochs;
     cfg.ppo.policyLR = 2e-4f; cfg.ppo.criticLR = 2e-4f; cfg.ppo.entCoef = 0.01f; cfg.ppo.autocastLearn = !fp32;
     cfg.ppo.policyLayerSizes = { 256, 256, 256 }; cfg.ppo.criticLayerSizes = { 256, 256, 256 };
-    cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder.clear(); cfg.checkpointLoadFolder.clear();
+    cfg.randomSeed = 123; cfg.sendMetrics = false; cfg.checkpointSaveFolder = saveDir; cfg.checkpointLoadFolder = loadDir; cfg.timestepsPerSave = (int64_t)1 << 60;
     cfg.timestepLimit = 0;
     cfg.collectStepQueue = collectQueue;
     cfg.deterministicGradients = deterministic;   // fixed-order gradient sums + lockstep collection: the run is a function of its seed (tests)
@@ -148,7 +149,9 @@ int main(int argc, char* argv[]) {
         ln = measure(0, learnedSteps); haveLn = true;
     }
     learner.CheckReplicas();
-    fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations, parameter checksum %016llx\n", rank, world, m.sec, steps, (unsigned long long)learner.ParamChecksum());
+    if (!saveDir.empty() && rank == 0) learner.Save();
+    fprintf(stderr, "[bench_main rank %d/%d] %.3f s for %d iterations, parameter checksum %016llx, sampler stream %u, env seed %u\n", rank, world, m.sec, steps,
+            (unsigned long long)learner.ParamChecksum(), learner.SamplerStream(), (unsigned)cfg.randomSeed + 1000u * (unsigned)rank);
     if (rank == 0) {
         const int nP = 2 * g_team, D = learner.obsSize;
         // SURVEY 8d, verbatim: algorithmic bytes per gym step per env = 2 (336 N_p + 264) + N_p (4 D + 8) + 4
@@ -171,6 +174,7 @@ int main(int argc, char* argv[]) {
         printf(", \"transport\": \"%s\", \"env_overrides\": [%s]", world > 1 ? (transport_env && !strcmp(transport_env, "shm") ? "shm" : "rccl") : "none", overrides.c_str());
         if (g_userReward) printf(", \"user_reward\": \"a user RewardFunction subclass on %d host threads, %s\", \"host_threads\": %d, \"host_cores\": %u", cfg.numThreads,
                                  cfg.deferHostRewards ? "replayed after the fused launch (deferHostRewards)" : "between the device's steps", cfg.numThreads, std::thread::hardware_concurrency());
+        if (!loadDir.empty()) printf(", \"policy\": \"loaded from a checkpoint\", \"mean_step_reward\": %.5f, \"policy_entropy\": %.4f", m.stepReward, m.entropy);
         if (haveTr)
             printf(", \"trained_regime\": {\"after_iterations\": %d, \"steps\": %d, \"value\": %.3f, \"ms_per_step\": %.6f, \"ppo_iter_ms\": %.6f, \"env_kernel_avg_ms\": %.4f}",
                    warmup + steps + trainedWarm, trainedSteps, tr.agentSteps / tr.sec, tr.sec / trainedSteps * 1e3, tr.consumeMs, tr.envLaunches ? tr.envMs / tr.envLaunches : 0.0);

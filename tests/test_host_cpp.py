@@ -495,6 +495,77 @@ def test_the_drivers_multi_gpu_bench_command_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_eight_ranks_on_one_gpu_the_drivers_command_equal_replicas_and_a_lost_rank(tmp_path):
+    """VERDICT r05 "next" 7: WORLD = 8 before the driver's first 8-GPU run, on the one GPU of the box (shm test transport, 256 envs per rank, fresh child
+    processes only).  (a) The driver's own command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8` -- prints ONE JSON
+    line with n_gpus 8 and eight per-rank times.  (b) Eight bench_main ranks started directly: equal parameter checksums on all of them after three optimizer
+    steps, eight distinct sampler streams and env seeds.  (c) Rank 7 killed in the middle of a long run ends the other seven, non-zero, within the
+    communicator's timeout.  That is every line of `bench.py --gpus 8` except the RCCL ring itself."""
+    import json, re, signal, socket, time
+    exe = os.path.join(PKG, "bench_main")
+    N = 8
+
+    def free_port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close(); return port
+
+    # (a) the driver's command
+    rdv = str(tmp_path / "rdv_torchrun8"); os.mkdir(rdv, 0o700)
+    env = dict(os.environ, RLGPU_COMM_TRANSPORT="shm", RLGPU_SHM_DEVICE="0", RLGPU_COMM_DIR=rdv, RLGPU_COMM_TIMEOUT_S="120", RLGPU_QUIET="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(N), "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--steps", "3", "--warmup", "1", "--envs", "256", "--no-cpu-baseline", "--mesh", "procedural", "--trained-warmup", "0",
+           "--learned-warmup", "0", "--allow-test-transport"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, timeout=400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == N and line["rccl_ranks"] == N and len(line["rank_ms_per_step"]) == N and line["transport"] == "shm" and line["allreduce_calls"] == 3, line
+    per_iter = line["value"] * line["ms_per_step"] * 1e-3
+    assert per_iter >= N * 256 * 2 * 32 * 0.999, (per_iter, line["value"], line["ms_per_step"])
+
+    # (b) + (c): eight ranks started directly, so that one of them can be killed by its own handle
+    def launch(steps, tag, timeout_s="120"):
+        rdv2 = str(tmp_path / ("rdv_" + tag)); os.mkdir(rdv2, 0o700)
+        base = dict(os.environ, WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0", RLGPU_COMM_DIR=rdv2, RLGPU_COMM_TAG=tag,
+                    RLGPU_COMM_TRANSPORT="shm", RLGPU_COMM_TIMEOUT_S=timeout_s, RLGPU_REPLICA_CHECK_EVERY="1", RLGPU_LOCKSTEP_COLLECTION="1", RLGPU_QUIET="1")
+        c = [exe, "--envs", "256", "--horizon", "8", "--steps", str(steps), "--warmup", "0"]
+        return [subprocess.Popen(c, env=dict(base, RANK=str(k)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for k in range(N)]
+
+    procs = launch(3, "eq8")
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            pytest.fail("a rank hung")
+    assert [p.returncode for p in procs] == [0] * N, [o[1][-400:] for o in outs]
+    found = [re.search(r"parameter checksum ([0-9a-f]{16}), sampler stream (\d+), env seed (\d+)", o[1]) for o in outs]
+    assert all(found), [o[1][-300:] for o in outs]
+    assert len({m.group(1) for m in found}) == 1, [m.group(1) for m in found]             # the replicas stayed replicas
+    assert sorted(int(m.group(2)) for m in found) == list(range(N))                       # eight sampler streams
+    assert len({int(m.group(3)) for m in found}) == N                                     # eight env seeds
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == N and len(line["rank_ms_per_step"]) == N and line["allreduce_calls"] == 3, line
+
+    procs = launch(1000000, "kill8", timeout_s="10")
+    time.sleep(10)
+    assert all(p.poll() is None for p in procs), "the long run ended by itself"
+    procs[N - 1].send_signal(signal.SIGKILL)
+    t0 = time.time()
+    for k in range(N - 1):
+        try:
+            out = procs[k].communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            pytest.fail(f"rank {k} went on waiting for a dead peer")
+        assert procs[k].returncode != 0, k
+    assert time.time() - t0 < 80
+    procs[N - 1].wait()
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_two_free_running_ranks_count_timesteps_together_and_stop_together(tmp_path):
     """with free-running collection (the default) every rank gathers its own number of timesteps per iteration -- they differ
