@@ -27,79 +27,135 @@ struct HeadArgs {
     int32_t* actions; float* logp; float* probs_out;
 };
 
-// NR rows at once: the head is a chain of cross-lane steps (two reductions, an arg-max butterfly), each a ~100-cycle round trip;
-// rows are independent, so a wavefront that owns several interleaves them and the round trips overlap.  Per row the arithmetic
-// is the same for every NR.
-template <int NR>
-__device__ __forceinline__ void policy_head_rows(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h, int* picked = nullptr) {
+// Cross-lane steps of the head.  A row lives in HALF a wavefront (32 lanes x 4 columns, n_actions <= 128), so a reduction is five exchanges: four of them
+// DPP modifiers on the VALU instruction itself (quad_perm 1032, quad_perm 2301, row_half_mirror, row_mirror: after each, twice as many neighbouring lanes
+// hold the same value) and one ds_bpermute (lanes 16 apart).  Round 5 had 64 lanes x 2 columns and six ds_bpermute round trips per reduction.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+// NR rows at once, two per pass (lanes 0-31 own row 2p, lanes 32-63 row 2p + 1; an odd last row is done by both halves: same values, same stores).  The
+// passes are independent and interleaved, so their cross-lane round trips overlap.  Lane l of a half owns columns l, l + 32, l + 64, l + 96 and draws
+// the exponential variates of its columns from ONE philox4 block (stream = row, counter = (call, l)).  Per column the arithmetic is what it always
+// was; per row the sampler's stream is not round 5's (then: lane = column mod 64, two words of a block used).
+template <int NR, int NCOL>
+__device__ __forceinline__ void policy_head_rows_cols(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h, int* picked) {
     // this code is compiled into two translation units with different -ffp-contract settings and must round identically in both (the
     // fused collection kernel promises the batched kernels' bits): pin the setting here
 #pragma clang fp contract(fast)
+    constexpr int NP = (NR + 1) / 2;
     const int A = h.A; const float inv_temp = h.inv_temp; const int deterministic = h.deterministic; const float* noise = h.noise;
     int32_t* actions = h.actions; float* logp = h.logp; float* probs_out = h.probs_out;
-    const bool in0 = lane < A, in1 = (lane + 64) < A;
-    float v0[NR], v1[NR], mx[NR], e0[NR], e1[NR], sum[NR], p0[NR], p1[NR];
+    const int l = lane & 31; const bool hi = lane >= 32;
+    bool in[NCOL];
 #pragma unroll
-    for (int n = 0; n < NR; n++) {
-        v0[n] = in0 ? z[n][lane] * inv_temp : -INFINITY;
-        v1[n] = in1 ? z[n][lane + 64] * inv_temp : -INFINITY;
-        mx[n] = fmaxf(v0[n], v1[n]);
+    for (int c = 0; c < NCOL; c++) in[c] = (l + 32 * c) < A;
+    const float* zp[NP]; int rw[NP];
+    float v[NP][NCOL], e[NP][NCOL], pr[NP][NCOL], mx[NP], sum[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int n1 = (2 * p + 1 < NR) ? 2 * p + 1 : NR - 1;
+        zp[p] = hi ? z[n1] : z[2 * p]; rw[p] = hi ? row[n1] : row[2 * p];
+#pragma unroll
+        for (int c = 0; c < NCOL; c++) v[p][c] = in[c] ? zp[p][l + 32 * c] * inv_temp : -INFINITY;
+        mx[p] = v[p][0];
+#pragma unroll
+        for (int c = 1; c < NCOL; c++) mx[p] = fmaxf(mx[p], v[p][c]);
     }
-    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int n = 0; n < NR; n++) mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], o, 64));
+    for (int p = 0; p < NP; p++) mx[p] = fmaxf(mx[p], dpp_f<DPP_QUAD_1032>(mx[p]));
 #pragma unroll
-    for (int n = 0; n < NR; n++) {
-        e0[n] = in0 ? expf(v0[n] - mx[n]) : 0.f; e1[n] = in1 ? expf(v1[n] - mx[n]) : 0.f;
-        sum[n] = e0[n] + e1[n];
+    for (int p = 0; p < NP; p++) mx[p] = fmaxf(mx[p], dpp_f<DPP_QUAD_2301>(mx[p]));
+#pragma unroll
+    for (int p = 0; p < NP; p++) mx[p] = fmaxf(mx[p], dpp_f<DPP_ROW_HALF_MIRROR>(mx[p]));
+#pragma unroll
+    for (int p = 0; p < NP; p++) mx[p] = fmaxf(mx[p], dpp_f<DPP_ROW_MIRROR>(mx[p]));
+#pragma unroll
+    for (int p = 0; p < NP; p++) mx[p] = fmaxf(mx[p], __shfl_xor(mx[p], 16, 64));
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+#pragma unroll
+        for (int c = 0; c < NCOL; c++) e[p][c] = in[c] ? expf(v[p][c] - mx[p]) : 0.f;
+        sum[p] = e[p][0];
+#pragma unroll
+        for (int c = 1; c < NCOL; c++) sum[p] += e[p][c];
     }
-    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int n = 0; n < NR; n++) sum[n] += __shfl_xor(sum[n], o, 64);
+    for (int p = 0; p < NP; p++) sum[p] += dpp_f<DPP_QUAD_1032>(sum[p]);
 #pragma unroll
-    for (int n = 0; n < NR; n++) {
-        p0[n] = fminf(fmaxf(e0[n] / sum[n], 1e-11f), 1.f); p1[n] = fminf(fmaxf(e1[n] / sum[n], 1e-11f), 1.f);
-        if (probs_out) {
-            if (in0) probs_out[(size_t)row[n] * A + lane] = p0[n];
-            if (in1) probs_out[(size_t)row[n] * A + lane + 64] = p1[n];
+    for (int p = 0; p < NP; p++) sum[p] += dpp_f<DPP_QUAD_2301>(sum[p]);
+#pragma unroll
+    for (int p = 0; p < NP; p++) sum[p] += dpp_f<DPP_ROW_HALF_MIRROR>(sum[p]);
+#pragma unroll
+    for (int p = 0; p < NP; p++) sum[p] += dpp_f<DPP_ROW_MIRROR>(sum[p]);
+#pragma unroll
+    for (int p = 0; p < NP; p++) sum[p] += __shfl_xor(sum[p], 16, 64);
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+#pragma unroll
+        for (int c = 0; c < NCOL; c++) {
+            pr[p][c] = fminf(fmaxf(e[p][c] / sum[p], 1e-11f), 1.f);
+            if (probs_out && in[c]) probs_out[(size_t)rw[p] * A + l + 32 * c] = pr[p][c];
         }
     }
     if (!actions) return;
-    float best[NR]; int bi[NR];
+    float best[NP]; int bi[NP];
 #pragma unroll
-    for (int n = 0; n < NR; n++) {
-        float s0, s1;
-        if (deterministic) { s0 = p0[n]; s1 = p1[n]; }
-        else {
-            float q0, q1;
-            if (noise) { q0 = in0 ? noise[(size_t)row[n] * A + lane] : 1.f; q1 = in1 ? noise[(size_t)row[n] * A + lane + 64] : 1.f; }
-            else {
+    for (int p = 0; p < NP; p++) {
+        float s[NCOL];
+        if (deterministic) {
+#pragma unroll
+            for (int c = 0; c < NCOL; c++) s[c] = pr[p][c];
+        } else {
+            if (noise) {   // a recorded tape of variates (the parity tests): the reference's own expression, p / q
+#pragma unroll
+                for (int c = 0; c < NCOL; c++) s[c] = pr[p][c] / (in[c] ? noise[(size_t)rw[p] * A + l + 32 * c] : 1.f);
+            } else {
                 uint32_t r[4];
-                rlg::philox4(h.seed_lo, h.seed_hi, (uint32_t)row[n], h.call_ctr, (uint32_t)lane, r);
-                // q ~ Exp(1): -log(1 - u), u in [0,1)
-                q0 = -logf(1.f - rlg::u32_to_unit(r[0])); q1 = -logf(1.f - rlg::u32_to_unit(r[1]));
-                q0 = fmaxf(q0, 1e-30f); q1 = fmaxf(q1, 1e-30f);
+                rlg::philox4(h.seed_lo, h.seed_hi, (uint32_t)rw[p], h.call_ctr, (uint32_t)l, r);
+                // q ~ Exp(1): -log(1 - u), u in [0,1) (1 - u is exact).  The hardware logarithm and reciprocal (1 ulp) are all a VARIATE and a score that
+                // only orders the columns need; the softmax and the log-probability keep the correctly rounded library functions
+#pragma unroll
+                for (int c = 0; c < NCOL; c++) {
+                    const float q = fmaxf(-0.6931471805599453f * __builtin_amdgcn_logf(1.f - rlg::u32_to_unit(r[c])), 1e-30f);
+                    s[c] = pr[p][c] * __builtin_amdgcn_rcpf(q);
+                }
             }
-            s0 = p0[n] / q0; s1 = p1[n] / q1;
         }
-        if (!in0) s0 = -INFINITY;
-        if (!in1) s1 = -INFINITY;
-        best[n] = s0; bi[n] = lane;
-        if (s1 > best[n]) { best[n] = s1; bi[n] = lane + 64; }
-    }
-    // argmax with lowest-index tie break (torch.argmax / max semantics)
-    for (int o = 32; o > 0; o >>= 1)
+        // argmax with lowest-index tie break (torch.argmax / max semantics): ascending columns, strict comparison
+        best[p] = in[0] ? s[0] : -INFINITY; bi[p] = l;
 #pragma unroll
-        for (int n = 0; n < NR; n++) {
-            float ob = __shfl_xor(best[n], o, 64); int oi = __shfl_xor(bi[n], o, 64);
-            if (ob > best[n] || (ob == best[n] && oi < bi[n])) { best[n] = ob; bi[n] = oi; }
+        for (int c = 1; c < NCOL; c++) { const float sc = in[c] ? s[c] : -INFINITY; if (sc > best[p]) { best[p] = sc; bi[p] = l + 32 * c; } }
+    }
+#define RLINFER_ARGMAX_STEP(OB, OI)                                                                                               \
+    _Pragma("unroll") for (int p = 0; p < NP; p++) {                                                                              \
+        const float ob = (OB); const int oi = (OI);                                                                               \
+        if (ob > best[p] || (ob == best[p] && oi < bi[p])) { best[p] = ob; bi[p] = oi; }                                          \
+    }
+    RLINFER_ARGMAX_STEP(dpp_f<DPP_QUAD_1032>(best[p]), dpp_i<DPP_QUAD_1032>(bi[p]))
+    RLINFER_ARGMAX_STEP(dpp_f<DPP_QUAD_2301>(best[p]), dpp_i<DPP_QUAD_2301>(bi[p]))
+    RLINFER_ARGMAX_STEP(dpp_f<DPP_ROW_HALF_MIRROR>(best[p]), dpp_i<DPP_ROW_HALF_MIRROR>(bi[p]))
+    RLINFER_ARGMAX_STEP(dpp_f<DPP_ROW_MIRROR>(best[p]), dpp_i<DPP_ROW_MIRROR>(bi[p]))
+    RLINFER_ARGMAX_STEP(__shfl_xor(best[p], 16, 64), __shfl_xor(bi[p], 16, 64))
+#undef RLINFER_ARGMAX_STEP
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        // the probability of the picked column sits in lane (bi & 31) of this half, in its column slot bi >> 5
+        const int cs = bi[p] >> 5;
+        float mine = pr[p][0];
+#pragma unroll
+        for (int c = 1; c < NCOL; c++) mine = cs == c ? pr[p][c] : mine;
+        const float pa = __shfl(mine, (lane & 32) | (bi[p] & 31), 64);
+        if (l == 0) { actions[rw[p]] = bi[p]; logp[rw[p]] = deterministic ? 0.f : logf(pa); }
+        if (picked) {   // uniform over the wavefront
+            picked[2 * p] = __builtin_amdgcn_readlane(bi[p], 0);
+            if (2 * p + 1 < NR) picked[2 * p + 1] = __builtin_amdgcn_readlane(bi[p], 32);
         }
-#pragma unroll
-    for (int n = 0; n < NR; n++) {
-        float pa = (bi[n] < 64) ? __shfl(p0[n], bi[n], 64) : __shfl(p1[n], bi[n] - 64, 64);
-        if (lane == 0) { actions[row[n]] = bi[n]; logp[row[n]] = deterministic ? 0.f : logf(pa); }
-        if (picked) picked[n] = bi[n];   // uniform over the wavefront after the butterfly
     }
+}
+template <int NR>
+__device__ __forceinline__ void policy_head_rows(const float* const (&z)[NR], const int (&row)[NR], int lane, const HeadArgs& h, int* picked = nullptr) {
+    policy_head_rows_cols<NR, 4>(z, row, lane, h, picked);
 }
 }  // namespace rlinfer
 

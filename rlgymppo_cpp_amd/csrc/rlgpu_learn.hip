@@ -498,19 +498,15 @@ __global__ void __launch_bounds__(256) k_col_sum(const float* X, int ld, int M, 
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 
-// one wave per row: probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]  (HeadArgs, policy_head_rows: infer_device.h)
-__device__ __forceinline__ void policy_head_row(const float* z /* logits of this row, global or LDS */, int row, int lane, const HeadArgs& h);
-
+// two rows per wavefront (32 lanes each): probs = clamp(softmax(logits / T), 1e-11, 1); action = argmax(p / q) or argmax(p); logp = log p[a]  (HeadArgs,
+// policy_head_rows: infer_device.h); an odd last row is done by both halves
 __global__ void k_policy_head(const float* logits, int ld, int rows, HeadArgs h) {
-    int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    policy_head_row(logits + (size_t)row * ld, row, lane, h);
-}
-
-__device__ __forceinline__ void policy_head_row(const float* z, int row, int lane, const HeadArgs& h) {
-    const float* const zs[1] = {z}; const int rows[1] = {row};
-    policy_head_rows<1>(zs, rows, lane, h);
+    const int r0 = 2 * (blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (r0 >= rows) return;
+    const int r1 = r0 + 1 < rows ? r0 + 1 : r0;
+    const float* const zs[2] = {logits + (size_t)r0 * ld, logits + (size_t)r1 * ld}; const int rw[2] = {r0, r1};
+    policy_head_rows<2>(zs, rw, lane, h);
 }
 
 // ---- fused MLP inference (bf16 path): obs -> [Linear+ReLU]* -> Linear -> head, ONE launch --------------------------------
@@ -1590,7 +1586,7 @@ static int policy_head(rlgpu_learner* l, const float* obs, int rows, int determi
     if (l->cfg.use_bf16) { if ((rc = stage_input16(l, obs, nullptr, rows))) return rc; rc = net_forward16(l, l->pol, l->act16_p, l->act_p.back(), rows); }
     else rc = net_forward(l, l->pol, l->act_p, obs, rows);
     if (rc) return rc;
-    dim3 grid((rows + 3) / 4), block(256);
+    dim3 grid((rows + 7) / 8), block(256);   // 4 wavefronts x 2 rows
     hipLaunchKernelGGL(k_policy_head, grid, block, 0, l->stream, (const float*)l->act_p.back(), A, rows, h);
     LCHK(l, hipGetLastError());
     return RLGPU_OK;
