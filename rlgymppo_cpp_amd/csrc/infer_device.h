@@ -304,14 +304,18 @@ __device__ __forceinline__ void wave_infer(const NET& net, const HeadArgs& head,
     auto load_next = [&](bf16x8 (&b)[CHUNK], float& bias) {
         const int nk = fet.nk, cb = fcb;
         const short* w = fet.W + ((size_t)cb * nk * 64 + lane) * 8;
-#pragma unroll
-        for (int j = 0; j < CHUNK; j++) {
 #ifdef PROBE_NO_LOAD
-            b[j] = bf16x8{(short)j, 1, 2, 3, 4, 5, 6, (short)cb};
+#pragma unroll
+        for (int j = 0; j < CHUNK; j++) b[j] = bf16x8{(short)j, 1, 2, 3, 4, 5, 6, (short)cb};
 #else
-            b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(j < nk ? j : nk - 1) * 512);
-#endif
+        if (nk == CHUNK) {   // the 256-wide layers: constant offsets from one base (four address adds instead of sixteen clamped ones)
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)j * 512);
+        } else {
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) b[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)(j < nk ? j : nk - 1) * 512);
         }
+#endif
         const int col = cb * 32 + (lane & 31), nn = fet.N;
         const float bv = fet.bias[col < nn ? col : nn - 1];    // (always issued: a load under a branch would make the count path-dependent)
         bias = col < nn ? bv : 0.f;
@@ -346,13 +350,18 @@ __device__ __forceinline__ void wave_infer(const NET& net, const HeadArgs& head,
 #endif
         // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): rows 0..7 are registers 0..3, rows 8..15 registers 4..7
         const int col = cb * 32 + (lane & 31);
+        if (last) {
 #pragma unroll
-        for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= R) continue;
-            const float v = acc[r] + bias;
-            if (last) logits[row * LOGIT_LD + col] = v;
-            else out[row * ld + col] = (col < N) ? to_bf16(fmaxf(v, 0.f)) : (short)0;
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) logits[row * LOGIT_LD + col] = acc[r] + bias;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) out[row * ld + col] = (col < N) ? to_bf16(fmaxf(acc[r] + bias, 0.f)) : (short)0;
+            }
         }
         const bool layer_done = cb + 1 >= nblk;
         if (layer_done) { wave_fence(); short* t = in; in = out; out = t; }   // the layer is complete: its outputs are the next layer's inputs
