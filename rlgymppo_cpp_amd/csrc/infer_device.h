@@ -222,6 +222,23 @@ __device__ __forceinline__ void mma_block_regs(const bf16x8 (&a)[16], const bf16
 #pragma unroll
     for (int j = 0; j < NK; j++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], acc, 0, 0, 0);
 }
+// Two column blocks of a layer at once: the same two chains (each block's sum is formed in the order mma_block_regs forms it), issued alternately
+template <int NK>
+__device__ __forceinline__ void mma_pair_regs(const bf16x8 (&a)[16], const bf16x8 (&b0)[16], const bf16x8 (&b1)[16], f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int j = 0; j < NK; j++) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b1[j], acc1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mma_pair_regs_any(const bf16x8 (&a)[16], const bf16x8 (&b0)[16], const bf16x8 (&b1)[16], f32x16& acc0, f32x16& acc1, int nk) {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < nk) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b1[j], acc1, 0, 0, 0);
+        }
+}
 // weight fragments of one block, as k_mlp_infer (rlgpu_learn.hip) asks for them
 template <int NK>
 __device__ __forceinline__ void fetch_block(bf16x8 (&b)[16], const short* w) {
@@ -370,6 +387,108 @@ __device__ __forceinline__ void wave_infer(const NET& net, const HeadArgs& head,
 #endif
         if (layer_done) { li = i + 1; lcb = 0; if (li < n_layers) cur = layer_load(li); } else lcb = cb + 1;
     };
+#ifndef RLINFER_PAIR
+#define RLINFER_PAIR 1   /* column blocks per pass of the block loop: 2 = a pair shares the A operands, the bookkeeping and the output stage's control flow (round 6) */
+#endif
+#if RLINFER_PAIR
+    // Two column blocks per pass.  What a block costs is ~1.5 K cycles of scalar / address / control instructions around a 0.5 K chain (one wavefront issuing
+    // alone); a pair pays them once.  Blocks cb and cb + 1 (an odd last block is paired with itself: same values, same stores) -- four fragment buffers, two being
+    // read by the chains while the next pair's two are on their way; every pass issues exactly 32 fragment loads + 2 bias loads (see above).
+    auto load_next2 = [&](bf16x8 (&b0)[CHUNK], float& bias_0, bf16x8 (&b1)[CHUNK], float& bias_1) {
+        const int nk = fet.nk, cb0 = fcb, cb1 = (fcb + 1 < fet.nblk) ? fcb + 1 : fcb;
+        const short* w0 = fet.W + ((size_t)cb0 * nk * 64 + lane) * 8;
+        const short* w1 = fet.W + ((size_t)cb1 * nk * 64 + lane) * 8;
+        if (nk == CHUNK) {
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) { b0[j] = *reinterpret_cast<const bf16x8*>(w0 + (size_t)j * 512); b1[j] = *reinterpret_cast<const bf16x8*>(w1 + (size_t)j * 512); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) {
+                const size_t o = (size_t)(j < nk ? j : nk - 1) * 512;
+                b0[j] = *reinterpret_cast<const bf16x8*>(w0 + o); b1[j] = *reinterpret_cast<const bf16x8*>(w1 + o);
+            }
+        }
+        const int nn = fet.N, c0 = cb0 * 32 + (lane & 31), c1 = cb1 * 32 + (lane & 31);
+        const float bv0 = fet.bias[c0 < nn ? c0 : nn - 1], bv1 = fet.bias[c1 < nn ? c1 : nn - 1];
+        bias_0 = c0 < nn ? bv0 : 0.f; bias_1 = c1 < nn ? bv1 : 0.f;
+        if (fcb + 2 < fet.nblk) fcb += 2;
+        else if (fi + 1 < n_layers) { fi++; fcb = 0; fet = layer_load(fi); }
+    };
+    auto run_pair = [&](const bf16x8 (&b0)[CHUNK], float bias_0, const bf16x8 (&b1)[CHUNK], float bias_1,
+                        bf16x8 (&bn0)[CHUNK], float& bias_n0, bf16x8 (&bn1)[CHUNK], float& bias_n1) {
+        const int i = li, cb = lcb;
+        const bool last = (i == n_layers - 1);
+        const int N = cur.N, nk = cur.nk, nblk = cur.nblk;
+        const int cb1 = (cb + 1 < nblk) ? cb + 1 : cb;
+        load_next2(bn0, bias_n0, bn1, bias_n1);
+        float* const logits = reinterpret_cast<float*>(out);
+        if (cb == 0) {
+            const short* arow = in + ((lane & 31) < R ? (lane & 31) : 0) * ld + 8 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) areg[j] = *reinterpret_cast<const bf16x8*>(arow + (j < nk ? j : 0) * 16);
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#define RLINFER_MMA2(NK) mma_pair_regs<NK>(areg, b0, b1, acc0, acc1)
+        RLINFER_DISPATCH_NK(nk, RLINFER_MMA2, mma_pair_regs_any(areg, b0, b1, acc0, acc1, nk))
+#undef RLINFER_MMA2
+        const int col0 = cb * 32 + (lane & 31), col1 = cb1 * 32 + (lane & 31);
+        if (last) {
+#pragma unroll
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) { logits[row * LOGIT_LD + col0] = acc0[r] + bias_0; logits[row * LOGIT_LD + col1] = acc1[r] + bias_1; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < (R <= 8 ? 4 : 8); r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) {
+                    out[row * ld + col0] = (col0 < N) ? to_bf16(fmaxf(acc0[r] + bias_0, 0.f)) : (short)0;
+                    out[row * ld + col1] = (col1 < N) ? to_bf16(fmaxf(acc1[r] + bias_1, 0.f)) : (short)0;
+                }
+            }
+        }
+        const bool layer_done = cb + 2 >= nblk;
+        if (layer_done) { wave_fence(); short* t = in; in = out; out = t; }
+#ifdef RLG_TICK_PROFILE
+        if (layer_done && prof_split && i < 6) prof_split[2 + i] = __builtin_amdgcn_s_memtime();
+#endif
+        if (layer_done) { li = i + 1; lcb = 0; if (li < n_layers) cur = layer_load(li); } else lcb = cb + 2;
+    };
+    {
+        bf16x8 B0a[CHUNK], B0b[CHUNK], B1a[CHUNK], B1b[CHUNK]; float bias0a, bias0b, bias1a = 0.f, bias1b = 0.f;
+        load_next2(B0a, bias0a, B0b, bias0b);
+        // (the first blocks' weights are on their way while the observations are converted: they do not depend on them)
+        {   // every value of the R rows is asked for before the first one is used: a load inside `if (c < D)` inside a loop waits for itself (16 serial L2
+            // round trips for 8 rows of 89 floats: 11 K cycles).  Lanes past the row's end read its last element and store a zero.
+            const int D = net.D, K0 = net.K[0];
+            constexpr int CH = 4;                 // 64-column chunks per row held in registers at once (K0 <= 256)
+            for (int c0 = 0; c0 < K0; c0 += 64 * CH) {
+                float v[R][CH];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int rr = r < n_rows ? r : n_rows - 1;
+#pragma unroll
+                    for (int q = 0; q < CH; q++) { const int c = c0 + 64 * q + lane; v[r][q] = obs[(size_t)rr * D + (c < D ? c : D - 1)]; }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int q = 0; q < CH; q++) { const int c = c0 + 64 * q + lane; if (c < K0) in[r * ld + c] = to_bf16(c < D ? v[r][q] : 0.f); }
+            }
+        }
+        wave_fence();
+#ifdef RLG_TICK_PROFILE
+        if (prof_split) prof_split[1] = __builtin_amdgcn_s_memtime();   // profiler build: observations staged
+#endif
+        while (true) {
+            run_pair(B0a, bias0a, B0b, bias0b, B1a, bias1a, B1b, bias1b); if (li >= n_layers) break;
+            run_pair(B1a, bias1a, B1b, bias1b, B0a, bias0a, B0b, bias0b); if (li >= n_layers) break;
+        }
+    }
+#else
     {
 #ifndef RLINFER_BUFS
 #define RLINFER_BUFS 2   /* weight buffers: the chain reads one while RLINFER_BUFS - 1 blocks are on their way (measured with tools/probes/infer_probe.hip: 2 and 3 run alike -- the loads are 5 K of an inference's cycles) */
@@ -423,6 +542,7 @@ __device__ __forceinline__ void wave_infer(const NET& net, const HeadArgs& head,
 #endif
         }
     }
+#endif
 #ifdef RLG_TICK_PROFILE
     if (prof_split) *prof_split = __builtin_amdgcn_s_memtime();   // profiler build: the MLP ends here, the head begins
 #endif
