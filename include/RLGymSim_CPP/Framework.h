@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <filesystem>
 #include <functional>
+#include "../rlgpu.h"
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -60,6 +61,8 @@ constexpr float GRAVITY_Z = -650.f, CAR_MASS_BT = 180.f, BALL_MASS_BT = CAR_MASS
 constexpr float CAR_MAX_SPEED = 2300.f, BALL_MAX_SPEED = 6000.f, BOOST_MAX = 100.f, BOOST_USED_PER_SECOND = BOOST_MAX / 3, BOOST_SPAWN_AMOUNT = BOOST_MAX / 3;
 constexpr float DOUBLEJUMP_MAX_DELAY = 1.25f, BALL_COLLISION_RADIUS_SOCCAR = 91.25f, SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y = 5124.25f;
 constexpr float CAR_SPAWN_REST_Z = 17.f, CAR_RESPAWN_Z = 36.f, BUMP_COOLDOWN_TIME = 0.25f, DEMO_RESPAWN_TIME = 3.f;
+constexpr float CARWORLD_COLLISION_FRICTION = 0.3f, CARWORLD_COLLISION_RESTITUTION = 0.3f, BALL_FRICTION = 0.35f, BALL_RESTITUTION = 0.6f;
+constexpr float BOOST_ACCEL_GROUND = 2975 / 3.f, BOOST_ACCEL_AIR = 3175 / 3.f, JUMP_ACCEL = 4375.f / 3.f, JUMP_IMMEDIATE_FORCE = 875.f / 3.f;
 struct CarSpawnPos { float x, y, yawAng; };
 constexpr int CAR_SPAWN_LOCATION_AMOUNT = 5, CAR_RESPAWN_LOCATION_AMOUNT = 4;
 constexpr float QUARTER_PI = 0.78539816339744830962f;
@@ -147,23 +150,48 @@ struct CarConfig {
 };
 inline const CarConfig CAR_CONFIG_OCTANE = [] { CarConfig c; c.hitboxSize = Vec(120.507f, 86.6994f, 38.6591f); c.hitboxPosOffset = Vec(13.87566f, 0, 20.755f); return c; }();
 enum class DemoMode : uint8_t { NORMAL, ON_CONTACT, DISABLED };
-// MutatorConfig.h: the fields programs usually touch, at their soccar defaults; anything else is refused where it would be applied
+// MutatorConfig.h (RS/Sim/MutatorConfig/MutatorConfig.h:18-75), the reference's fields under the reference's names.  The device stepper takes the ones that change
+// no collision shape, no mass and no material at run time (RlgpuMutators, include/rlgpu_state.h); carMass, ballMass, ballRadius, the four world friction /
+// restitution values and gravity's x / y stay compiled in and are refused off their defaults where they would be applied (Arena::SetMutatorConfig).
 struct MutatorConfig {
     Vec gravity = Vec(0, 0, RLConst::GRAVITY_Z);
-    float carMass = RLConst::CAR_MASS_BT, ballMass = RLConst::BALL_MASS_BT, ballMaxSpeed = RLConst::BALL_MAX_SPEED, ballDrag = RLConst::BALL_DRAG;
-    float boostUsedPerSecond = RLConst::BOOST_USED_PER_SECOND, respawnDelay = RLConst::DEMO_RESPAWN_TIME, bumpCooldownTime = RLConst::BUMP_COOLDOWN_TIME;
+    float carMass = RLConst::CAR_MASS_BT, carWorldFriction = RLConst::CARWORLD_COLLISION_FRICTION, carWorldRestitution = RLConst::CARWORLD_COLLISION_RESTITUTION;
+    float ballMass = RLConst::BALL_MASS_BT, ballMaxSpeed = RLConst::BALL_MAX_SPEED, ballDrag = RLConst::BALL_DRAG;
+    float ballWorldFriction = RLConst::BALL_FRICTION, ballWorldRestitution = RLConst::BALL_RESTITUTION;
+    float jumpAccel = RLConst::JUMP_ACCEL, jumpImmediateForce = RLConst::JUMP_IMMEDIATE_FORCE;
+    float boostAccelGround = RLConst::BOOST_ACCEL_GROUND, boostAccelAir = RLConst::BOOST_ACCEL_AIR, boostUsedPerSecond = RLConst::BOOST_USED_PER_SECOND;
+    float respawnDelay = RLConst::DEMO_RESPAWN_TIME, bumpCooldownTime = RLConst::BUMP_COOLDOWN_TIME;
     float boostPadCooldown_Big = RLConst::BoostPads::COOLDOWN_BIG, boostPadCooldown_Small = RLConst::BoostPads::COOLDOWN_SMALL, carSpawnBoostAmount = RLConst::BOOST_SPAWN_AMOUNT;
     float ballHitExtraForceScale = 1, bumpForceScale = 1, ballRadius = RLConst::BALL_COLLISION_RADIUS_SOCCAR;
     bool unlimitedFlips = false, unlimitedDoubleJumps = false; DemoMode demoMode = DemoMode::NORMAL; bool enableTeamDemos = false;
     float goalBaseThresholdY = RLConst::SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y;
     MutatorConfig(GameMode = GameMode::SOCCAR) {}
+    // the fields the stepper has compiled in are at their defaults
+    bool CompiledInFieldsAreDefault() const {
+        const MutatorConfig d;
+        return gravity.x == 0 && gravity.y == 0 && carMass == d.carMass && carWorldFriction == d.carWorldFriction && carWorldRestitution == d.carWorldRestitution && ballMass == d.ballMass &&
+               ballWorldFriction == d.ballWorldFriction && ballWorldRestitution == d.ballWorldRestitution && ballRadius == d.ballRadius;
+    }
     bool IsDefault() const {
         const MutatorConfig d;
-        return gravity.x == d.gravity.x && gravity.y == d.gravity.y && gravity.z == d.gravity.z && carMass == d.carMass && ballMass == d.ballMass && ballMaxSpeed == d.ballMaxSpeed &&
-               ballDrag == d.ballDrag && boostUsedPerSecond == d.boostUsedPerSecond && respawnDelay == d.respawnDelay && bumpCooldownTime == d.bumpCooldownTime &&
+        return CompiledInFieldsAreDefault() && gravity.z == d.gravity.z && ballMaxSpeed == d.ballMaxSpeed && ballDrag == d.ballDrag && jumpAccel == d.jumpAccel &&
+               jumpImmediateForce == d.jumpImmediateForce && boostAccelGround == d.boostAccelGround && boostAccelAir == d.boostAccelAir &&
+               boostUsedPerSecond == d.boostUsedPerSecond && respawnDelay == d.respawnDelay && bumpCooldownTime == d.bumpCooldownTime &&
                boostPadCooldown_Big == d.boostPadCooldown_Big && boostPadCooldown_Small == d.boostPadCooldown_Small && carSpawnBoostAmount == d.carSpawnBoostAmount &&
-               ballHitExtraForceScale == 1 && bumpForceScale == 1 && ballRadius == d.ballRadius && !unlimitedFlips && !unlimitedDoubleJumps && demoMode == DemoMode::NORMAL &&
+               ballHitExtraForceScale == 1 && bumpForceScale == 1 && !unlimitedFlips && !unlimitedDoubleJumps && demoMode == DemoMode::NORMAL &&
                !enableTeamDemos && goalBaseThresholdY == d.goalBaseThresholdY;
+    }
+    // the run-time fields as the C-ABI takes them (rlgpu_env_set_mutators, RlgpuArenaState::mutators)
+    RlgpuMutators ToDevice() const {
+        RlgpuMutators m;
+        m.gravity_z = gravity.z; m.boost_accel_ground = boostAccelGround; m.boost_accel_air = boostAccelAir; m.boost_used_per_second = boostUsedPerSecond;
+        m.jump_accel = jumpAccel; m.jump_immediate_force = jumpImmediateForce; m.ball_max_speed = ballMaxSpeed; m.ball_damp_per_tick = rlgpu_ball_damp_per_tick(ballDrag);
+        m.respawn_delay = respawnDelay; m.bump_cooldown_time = bumpCooldownTime; m.boost_pad_cooldown_big = boostPadCooldown_Big; m.boost_pad_cooldown_small = boostPadCooldown_Small;
+        m.car_spawn_boost_amount = carSpawnBoostAmount; m.ball_hit_extra_force_scale = ballHitExtraForceScale; m.bump_force_scale = bumpForceScale; m.goal_base_threshold_y = goalBaseThresholdY;
+        m.flags = (unlimitedFlips ? RLGPU_MUT_UNLIMITED_FLIPS : 0u) | (unlimitedDoubleJumps ? RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS : 0u) |
+                  (demoMode == DemoMode::ON_CONTACT ? RLGPU_MUT_DEMO_ON_CONTACT : demoMode == DemoMode::DISABLED ? RLGPU_MUT_DEMO_DISABLED : 0u) | (enableTeamDemos ? RLGPU_MUT_TEAM_DEMOS : 0u);
+        m._pad = 0;
+        return m;
     }
 };
 struct ArenaConfig {};

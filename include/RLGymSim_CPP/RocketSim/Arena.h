@@ -168,9 +168,13 @@ public:
     const std::vector<Car*>& GetCars() { return _cars; }
     const std::vector<BoostPad*>& GetBoostPads() { return _boostPads; }
     const MutatorConfig& GetMutatorConfig() { return _mutatorConfig; }
+    // Arena::SetMutatorConfig (Arena.cpp:15-48).  The run-time fields travel with the arena's state from here on (RlgpuArenaState::mutators: the next upload
+    // hands them to the env); car / ball mass, ball radius, the world friction / restitution values and a sideways gravity are compiled into the stepper.
     void SetMutatorConfig(const MutatorConfig& m) {
-        if (!m.IsDefault()) RG_ERR_CLOSE("Arena::SetMutatorConfig(): the device stepper has the default soccar mutators compiled in");
+        if (!m.CompiledInFieldsAreDefault())
+            RG_ERR_CLOSE("Arena::SetMutatorConfig(): carMass, ballMass, ballRadius, carWorld / ballWorld friction and restitution and gravity.x / .y are compiled into the device stepper (defaults only)");
         _mutatorConfig = m;
+        _state.mutators = m.ToDevice(); _state.hidden.valid |= RLGPU_HIDDEN_MUTATORS;
     }
 
     // Arena::AddCar (Arena.cpp:33-69).  The device layout fixes the slots (even = blue, odd = orange), so the cars come in the order Gym's
@@ -238,7 +242,7 @@ public:
         for (BoostPad* p : _boostPads) p->SetState(BoostPadState());
     }
 
-    bool IsBallScored() const { return std::fabs(_state.ball.pos[1]) > RLConst::SOCCAR_GOAL_SCORE_BASE_THRESHOLD_Y + RLConst::BALL_COLLISION_RADIUS_SOCCAR; }
+    bool IsBallScored() const { return std::fabs(_state.ball.pos[1]) > _mutatorConfig.goalBaseThresholdY + _mutatorConfig.ballRadius; }   // Arena.cpp:949-957
 
     // Arena::Step (Arena.cpp:716-812) on a one-env device batch (created on first use; librlgymppo_amd.so).  With a goal / bump callback
     // set the arena is stepped tick by tick and the callbacks are raised from the state each tick leaves (host/Gym.hip); the gym layer

@@ -71,6 +71,13 @@ int rlgpu_pad_location(int pad, float* pos_uu, int* is_big);
 int rlgpu_env_create(rlgpu_env** out, int device, int n_envs, int team_size, const RlgpuGymConfig* cfg);
 void rlgpu_env_destroy(rlgpu_env* e);
 const char* rlgpu_env_last_error(const rlgpu_env* e);
+/* MutatorConfig's run-time scalars for every env of the batch: replaces Arena::SetMutatorConfig on each of the reference's arenas (Gym's constructor,
+ * SIM/Gym.cpp:40-44; RS/Sim/Arena/Arena.cpp:15-48).  A fresh batch runs RLConst's defaults (rlgpu_default_mutators); episode resets keep what was set; an
+ * uploaded state that carries a block (RLGPU_HIDDEN_MUTATORS) replaces its env's.  Which of MutatorConfig's fields these are, and which stay compiled in:
+ * rlgpu_state.h RlgpuMutators.  rlgpu_ball_damp_per_tick(ballDrag) = what the struct's ball_damp_per_tick has to hold for that drag. */
+void rlgpu_default_mutators(RlgpuMutators* m);
+float rlgpu_ball_damp_per_tick(float ball_drag);
+int rlgpu_env_set_mutators(rlgpu_env* e, const RlgpuMutators* m);
 /* New keys for the env batch's counter-based RNG streams (RandomState resets, respawn spots, padded-obs shuffles): a resumed run passes
  * (its shard seed, a fresh epoch number) so that it does not replay the resets of the run it continues. */
 int rlgpu_env_reseed(rlgpu_env* e, uint32_t seed_lo, uint32_t seed_hi);

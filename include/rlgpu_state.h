@@ -161,6 +161,7 @@ typedef struct RlgpuGymState {
 #define RLGPU_HIDDEN_BP_HIST   1u
 #define RLGPU_HIDDEN_WRECK_ROT 2u
 #define RLGPU_HIDDEN_REF_ENGINE 4u
+#define RLGPU_HIDDEN_MUTATORS  8u   /* RlgpuArenaState::mutators is filled in */
 typedef struct RlgpuArenaHidden {
     float ball_rot[9];               /* forward / right / up columns */
     uint32_t valid;
@@ -169,6 +170,31 @@ typedef struct RlgpuArenaHidden {
     uint32_t ref_engine;             /* 0 = the env's own streams */
     uint32_t _pad;
 } RlgpuArenaHidden;
+
+/* MutatorConfig's run-time scalars (RocketSim MutatorConfig.h:18-75; round 6): what an env simulates with instead of RLConst's defaults.  The fields are the
+ * reference's, in its units, except ball_damp_per_tick = powf(1 - ballDrag, 1 / 120) as the C library rounds it (btRigidBody::applyDamping computes that
+ * every tick; the device has no bit-identical powf, so whoever fills the struct computes it on the host: rlgpu_default_mutators / the facade's
+ * Arena::SetMutatorConfig).  NOT here, because they change a collision shape, a mass or a material and stay compiled in: carMass, ballMass, ballRadius,
+ * carWorld / ballWorld friction and restitution, gravity's x / y.  A state carries its env's block when hidden.valid has RLGPU_HIDDEN_MUTATORS (downloads
+ * set it); an upload without the bit leaves the slot's mutators alone. */
+#define RLGPU_MUT_UNLIMITED_FLIPS        1u
+#define RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS 2u
+#define RLGPU_MUT_DEMO_ON_CONTACT        4u   /* DemoMode::ON_CONTACT */
+#define RLGPU_MUT_DEMO_DISABLED          8u   /* DemoMode::DISABLED (neither bit: NORMAL) */
+#define RLGPU_MUT_TEAM_DEMOS            16u   /* enableTeamDemos */
+typedef struct RlgpuMutators {
+    float gravity_z;
+    float boost_accel_ground, boost_accel_air, boost_used_per_second;
+    float jump_accel, jump_immediate_force;
+    float ball_max_speed;
+    float ball_damp_per_tick;
+    float respawn_delay, bump_cooldown_time, boost_pad_cooldown_big, boost_pad_cooldown_small;
+    float car_spawn_boost_amount;
+    float ball_hit_extra_force_scale, bump_force_scale;
+    float goal_base_threshold_y;
+    uint32_t flags;                  /* RLGPU_MUT_* */
+    uint32_t _pad;
+} RlgpuMutators;
 
 typedef struct RlgpuArenaState {
     int32_t num_cars;                /* 2, 4 or 6 */
@@ -183,6 +209,7 @@ typedef struct RlgpuArenaState {
     RlgpuPadState pads[RLGPU_NUM_PADS];   /* RocketSim order: 6 big then 28 small (RLConst.h:210-253) */
     RlgpuGymState gym;
     RlgpuArenaHidden hidden;
+    RlgpuMutators mutators;          /* meaningful when hidden.valid & RLGPU_HIDDEN_MUTATORS */
 } RlgpuArenaState;
 
 /* Step records (round 6): what a GameState is made of -- GameState::UpdateFromArena / PlayerData::UpdateFromCar, SIM/Utils/Gamestates/GameState.cpp:52-104,

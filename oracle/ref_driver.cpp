@@ -86,6 +86,20 @@ void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
     // BallState::rotMat (Ball.cpp:27-30).  Nothing else of RlgpuArenaHidden is read out here: valid = 0
     V3(s->hidden.ball_rot, bs.rotMat.forward); V3(s->hidden.ball_rot + 3, bs.rotMat.right); V3(s->hidden.ball_rot + 6, bs.rotMat.up);
     s->hidden.valid = 0;
+    {   // the arena's MutatorConfig, as far as RlgpuMutators carries it (the per-tick damping factor as btRigidBody::applyDamping forms it)
+        const MutatorConfig& mc = a->GetMutatorConfig();
+        RlgpuMutators& m = s->mutators;
+        m.gravity_z = mc.gravity.z; m.boost_accel_ground = mc.boostAccelGround; m.boost_accel_air = mc.boostAccelAir; m.boost_used_per_second = mc.boostUsedPerSecond;
+        m.jump_accel = mc.jumpAccel; m.jump_immediate_force = mc.jumpImmediateForce; m.ball_max_speed = mc.ballMaxSpeed;
+        m.ball_damp_per_tick = powf(1.0f - mc.ballDrag, 1.0f / 120.0f);
+        m.respawn_delay = mc.respawnDelay; m.bump_cooldown_time = mc.bumpCooldownTime; m.boost_pad_cooldown_big = mc.boostPadCooldown_Big; m.boost_pad_cooldown_small = mc.boostPadCooldown_Small;
+        m.car_spawn_boost_amount = mc.carSpawnBoostAmount; m.ball_hit_extra_force_scale = mc.ballHitExtraForceScale; m.bump_force_scale = mc.bumpForceScale;
+        m.goal_base_threshold_y = mc.goalBaseThresholdY;
+        m.flags = (mc.unlimitedFlips ? RLGPU_MUT_UNLIMITED_FLIPS : 0u) | (mc.unlimitedDoubleJumps ? RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS : 0u) |
+                  (mc.demoMode == DemoMode::ON_CONTACT ? RLGPU_MUT_DEMO_ON_CONTACT : mc.demoMode == DemoMode::DISABLED ? RLGPU_MUT_DEMO_DISABLED : 0u) |
+                  (mc.enableTeamDemos ? RLGPU_MUT_TEAM_DEMOS : 0u);
+        s->hidden.valid |= RLGPU_HIDDEN_MUTATORS;
+    }
     for (int i = 0; i < s->num_cars; i++) {
         Car* car = CarBySlot(a, i);
         RlgpuCarState& o = s->cars[i];
@@ -446,6 +460,24 @@ void* ref_arena_new_shuffled(int team_size, unsigned seed) {
 void ref_arena_rehash(void* h, int buckets) { ((Arena*)h)->_cars.rehash((size_t)buckets); }
 void ref_arena_free(void* h) { delete (Arena*)h; }
 void ref_arena_get_state(void* h, RlgpuArenaState* s) { GetArenaPhys((Arena*)h, s); }
+// MutatorConfig's run-time scalars (RlgpuMutators, include/rlgpu_state.h) onto the reference's arena: Arena::SetMutatorConfig (Arena.cpp:15-48) with the
+// fields the stepper leaves compiled in at their defaults.  ballDrag is given as the per-tick factor's source: the caller passes the drag itself in `ball_drag`.
+void ref_arena_set_mutators(void* h, const RlgpuMutators* m, float ball_drag) {
+    Arena* a = (Arena*)h;
+    MutatorConfig mc = a->GetMutatorConfig();
+    mc.gravity = Vec(0, 0, m->gravity_z);
+    mc.boostAccelGround = m->boost_accel_ground; mc.boostAccelAir = m->boost_accel_air; mc.boostUsedPerSecond = m->boost_used_per_second;
+    mc.jumpAccel = m->jump_accel; mc.jumpImmediateForce = m->jump_immediate_force;
+    mc.ballMaxSpeed = m->ball_max_speed; mc.ballDrag = ball_drag;
+    mc.respawnDelay = m->respawn_delay; mc.bumpCooldownTime = m->bump_cooldown_time;
+    mc.boostPadCooldown_Big = m->boost_pad_cooldown_big; mc.boostPadCooldown_Small = m->boost_pad_cooldown_small;
+    mc.carSpawnBoostAmount = m->car_spawn_boost_amount; mc.ballHitExtraForceScale = m->ball_hit_extra_force_scale; mc.bumpForceScale = m->bump_force_scale;
+    mc.goalBaseThresholdY = m->goal_base_threshold_y;
+    mc.unlimitedFlips = (m->flags & RLGPU_MUT_UNLIMITED_FLIPS) != 0; mc.unlimitedDoubleJumps = (m->flags & RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS) != 0;
+    mc.demoMode = (m->flags & RLGPU_MUT_DEMO_ON_CONTACT) ? DemoMode::ON_CONTACT : (m->flags & RLGPU_MUT_DEMO_DISABLED) ? DemoMode::DISABLED : DemoMode::NORMAL;
+    mc.enableTeamDemos = (m->flags & RLGPU_MUT_TEAM_DEMOS) != 0;
+    a->SetMutatorConfig(mc);
+}
 // The arena's hidden state into s->hidden (s: a state of this arena, from ref_arena_get_state): what btRSBroadphase remembers of its dynamic proxies --
 // the cell each was last filed under (btRSBroadphaseProxy::cellIdx) and the order in which they last ARRIVED in their cells, which is the order of
 // every cell's dynHandles list (btRSBroadphase.cpp:185-203,287-325: a proxy that changes cell is erased from its old 27 lists and pushed back onto
@@ -488,7 +520,7 @@ void ref_arena_get_hidden(void* h, RlgpuArenaState* s) {
         const RotMat rm = car->_rigidBody.getWorldTransform().getBasis();
         V3(s->hidden.wreck_rot[k], rm.forward); V3(s->hidden.wreck_rot[k] + 3, rm.right); V3(s->hidden.wreck_rot[k] + 6, rm.up);
     }
-    s->hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;
+    s->hidden.valid |= RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;   // (the mutators bit of ref_arena_get_state stays)
 }
 void ref_arena_set_state(void* h, const RlgpuArenaState* s) { SetArenaPhys((Arena*)h, s, true); }
 void ref_arena_set_controls(void* h, int slot, const float* c8) { CarBySlot((Arena*)h, slot)->controls = ArrToCtrl(c8); }

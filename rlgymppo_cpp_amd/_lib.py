@@ -122,6 +122,9 @@ SIGNATURES = {
     "rlgpu_learner_loss_scale": (_i, [_vp, _vp, _vp, _vp]),
     "rlgpu_learner_set_temperature": (_i, [_vp, _f]),
     "rlgpu_env_reseed": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "rlgpu_default_mutators": (None, [_vp]),
+    "rlgpu_ball_damp_per_tick": (_f, [_f]),
+    "rlgpu_env_set_mutators": (_i, [_vp, _vp]),
     "rlgpu_learner_set_sampler": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "rlgpu_learner_set_deterministic": (_i, [_vp, _i]),
     "rlgpu_learner_get_sampler": (_i, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -234,7 +234,7 @@ RLG_HD void car_update_air_torque(CarHot& c, bool update_air_control) {
 }
 
 // ---- Car::_UpdateJump (Car.cpp:507-554) -------------------------------------------------------------------
-RLG_HD void car_update_jump(CarHot& c, bool jump_pressed) {
+RLG_HD void car_update_jump(CarHot& c, bool jump_pressed, const Mutators& m) {
     const float dt = TICK_DT;
     bool on_ground = c.flags & CF_ON_GROUND;
     if (on_ground && !(c.flags & CF_IS_JUMPING)) {
@@ -253,12 +253,12 @@ RLG_HD void car_update_jump(CarHot& c, bool jump_pressed) {
     } else if (RLG_UNLIKELY(on_ground && jump_pressed)) {
         c.flags |= CF_IS_JUMPING;
         c.jump_time = 0.f;
-        V3 imp = up * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;
+        V3 imp = up * m.jump_immediate_force * UU2BT * K::CAR_MASS;   // MutatorConfig::jumpImmediateForce (Car.cpp:532)
         body_apply_central_impulse(c.b, imp, CAR_INV_MASS);
     }
     if (c.flags & CF_IS_JUMPING) {
         c.flags |= CF_HAS_JUMPED;
-        V3 f = up * K::JUMP_ACCEL;
+        V3 f = up * m.jump_accel;   // MutatorConfig::jumpAccel (Car.cpp:540)
         if (c.jump_time < K::JUMP_MIN_TIME) f *= 0.62f;
         c.b.force += f * UU2BT * K::CAR_MASS;
     }
@@ -290,7 +290,7 @@ RLG_HD void car_update_auto_flip(CarHot& c, bool jump_pressed) {
 }
 
 // ---- Car::_UpdateDoubleJumpOrFlip (Car.cpp:643-761) -------------------------------------------------------
-RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float forward_speed_uu) {
+RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float forward_speed_uu, const Mutators& m) {
     const float dt = TICK_DT;
     if (c.flags & CF_ON_GROUND) {
         c.flags &= ~(CF_HAS_DOUBLE_JUMPED | CF_HAS_FLIPPED);
@@ -303,7 +303,7 @@ RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float f
         if (RLG_UNLIKELY(jump_pressed && c.air_time_since_jump < K::DOUBLEJUMP_MAX_DELAY)) {
             float mag = fabsf(c.ctl.yaw) + fabsf(c.ctl.pitch) + fabsf(c.ctl.roll);
             bool is_flip = mag >= K::DODGE_DEADZONE;
-            bool can_use = !(c.flags & CF_HAS_DOUBLE_JUMPED) && !(c.flags & CF_HAS_FLIPPED);
+            bool can_use = (!(c.flags & CF_HAS_DOUBLE_JUMPED) && !(c.flags & CF_HAS_FLIPPED)) || (m.flags & (is_flip ? MUT_UNLIMITED_FLIPS : MUT_UNLIMITED_DOUBLE_JUMPS));   // Car.cpp:665-671
             if (c.flags & CF_IS_AUTOFLIPPING) can_use = false;
             if (can_use) {
                 if (is_flip) {
@@ -333,7 +333,7 @@ RLG_HD void car_update_double_jump_or_flip(CarHot& c, bool jump_pressed, float f
                         body_apply_central_impulse(c.b, dv * UU2BT * K::CAR_MASS, CAR_INV_MASS);
                     }
                 } else {
-                    V3 imp = col2(c.b.rot) * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;
+                    V3 imp = col2(c.b.rot) * K::JUMP_IMMEDIATE_FORCE * UU2BT * K::CAR_MASS;   // (the double jump keeps RLConst's force: Car.cpp:740 does not read the mutator)
                     body_apply_central_impulse(c.b, imp, CAR_INV_MASS);
                     c.flags |= CF_HAS_DOUBLE_JUMPED;
                 }
@@ -374,7 +374,7 @@ RLG_HD void car_update_auto_roll(CarHot& c, const CarWheels& t) {
 }
 
 // ---- Car::_UpdateBoost (Car.cpp:477-505) -------------------------------------------------------------------
-RLG_HD void car_update_boost(CarHot& c) {
+RLG_HD void car_update_boost(CarHot& c, const Mutators& m) {
     const float dt = TICK_DT;
     if (c.time_spent_boosting > 0) {
         if (!c.ctl.boost && c.time_spent_boosting >= K::BOOST_MIN_TIME) c.time_spent_boosting = 0.f;
@@ -383,8 +383,8 @@ RLG_HD void car_update_boost(CarHot& c) {
         c.time_spent_boosting = dt;
     }
     if (c.boost > 0 && c.time_spent_boosting > 0) {
-        c.boost = fmaxf(c.boost - K::BOOST_USED_PER_SECOND * dt, 0.f);
-        float acc = (c.flags & CF_ON_GROUND) ? K::BOOST_ACCEL_GROUND : K::BOOST_ACCEL_AIR;
+        c.boost = fmaxf(c.boost - m.boost_used_per_second * dt, 0.f);   // MutatorConfig::boostUsedPerSecond, boostAccelGround / Air (Car.cpp:497-499)
+        float acc = (c.flags & CF_ON_GROUND) ? m.boost_accel_ground : m.boost_accel_air;
         c.b.force += (acc * UU2BT) * col0(c.b.rot) * K::CAR_MASS;
     }
     c.boost = fminf(c.boost, K::BOOST_MAX);
@@ -398,7 +398,7 @@ RLG_HD M3 euler_to_rot(float yaw, float pitch, float roll) {  // Angle::ToRotMat
 }
 
 // ---- Car::Respawn (Car.cpp:43-56): spawn slot from the caller's RNG draw ------------------------------------
-RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
+RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd, float spawn_boost) {
     const float RX[4] = {-2304, -2688, 2304, 2688};
     int idx = (int)(rnd % 4u);
     Car n = {};
@@ -407,7 +407,7 @@ RLG_HD_COLD void car_respawn(Car& c, bool is_blue, uint32_t rnd) {
     n.b.rot = euler_to_rot(yaw, 0.f, 0.f);   // (Angle::ToRotMat with pitch = roll = 0: the same numbers as the yaw-only matrix up to the SIGN of its zeros, which the rigid body shows for one tick)
     n.b.vel = v3(0, 0, 0); n.b.angvel = v3(0, 0, 0);
     n.flags = CF_ON_GROUND;
-    n.boost = K::BOOST_SPAWN_AMOUNT;
+    n.boost = spawn_boost;   // MutatorConfig::carSpawnBoostAmount (Car.cpp:72)
     n.bh_tick_hit = -1; n.bh_tick_extra = -1;
     // carried wheel values and controls survive SetState in the reference
     n.ctl = c.ctl;
@@ -445,7 +445,7 @@ RLG_HD_SMALL bool car_tick_begin(Arena<NC>& A, int ci, uint32_t seed, uint32_t e
             uint32_t rnd[4];
             philox4(seed, 0x51ED270Bu, env_id, (uint32_t)A.tick_count, 0x100u + (uint32_t)ci, rnd);
             Car n = c;
-            car_respawn(n, (ci % 2) == 0, rnd[0]);
+            car_respawn(n, (ci % 2) == 0, rnd[0], A.mut.spawn_boost);
             n.frozen = true;
             c = n;
         }
@@ -462,7 +462,7 @@ RLG_HD_COLD void cars_respawn_ref_engine(Arena<NC>& A) {
         Car& c = A.cars[ci];
         if (!(c.flags & CF_IS_DEMOED) || c.demo_respawn_timer != 0.f) continue;
         Car n = c;
-        car_respawn(n, (ci % 2) == 0, (uint32_t)e.rand_int(0, 4));
+        car_respawn(n, (ci % 2) == 0, (uint32_t)e.rand_int(0, 4), A.mut.spawn_boost);
         n.frozen = true;
         c = n;
     }
@@ -669,9 +669,9 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
     RLG_SPROF(33);
     if (t.n_contact < 3) car_update_air_torque(c, t.n_contact == 0);
     else c.flags &= ~CF_IS_FLIPPING;
-    car_update_jump(c, jump_pressed);
+    car_update_jump(c, jump_pressed, A.mut);
     car_update_auto_flip(c, jump_pressed);
-    car_update_double_jump_or_flip(c, jump_pressed, t.forward_speed_uu);
+    car_update_double_jump_or_flip(c, jump_pressed, t.forward_speed_uu, A.mut);
     if (RLG_UNLIKELY(c.ctl.throttle != 0.f && ((t.n_contact > 0 && t.n_contact < 4) || (c.flags & CF_WORLD_CONTACT)))) car_update_auto_roll(c, t);
     c.flags &= ~CF_WORLD_CONTACT;
     RLG_SPROF(34);
@@ -704,7 +704,7 @@ RLG_HD void car_pre_tick_finish_body(Arena<NC>& A, CarHot& c, int ci, CarTickCtx
             }
         }
     }
-    car_update_boost(c);
+    car_update_boost(c, A.mut);
     RLG_SPROF(36);
 }
 

@@ -146,11 +146,11 @@ RLG_HD bool ball_probably_going_in(const Arena<NC>& A, float max_time, int& goal
     V3 bp = A.ball.b.pos * BT2UU, bv = A.ball.b.vel * BT2UU;
     if (fabsf(bv.y) < SIMD_EPS) return false;
     float dir = sgnf(bv.y);
-    float goal_y = K::GOAL_THRESHOLD_Y * dir;
+    float goal_y = A.mut.goal_threshold_y * dir;   // MutatorConfig::goalBaseThresholdY (Arena.cpp:836)
     float dist = fabsf(bp.y - goal_y);
     float t = dist / fabsf(bv.y);
     if (t > max_time) return false;
-    V3 grav = v3(0, 0, K::GRAVITY_Z);
+    V3 grav = v3(0, 0, A.mut.gravity_z);   // MutatorConfig::gravity (Arena.cpp:844)
     V3 ex = bp + (bv * t) + vdiv_rs(grav * t * t, 2.f);
     const float HW = 892.755f, GH = 642.775f;
     float margin = K::BALL_RADIUS * 0.1f + 0.f;
@@ -182,7 +182,7 @@ RLG_HD bool shooter_passer(const Arena<NC>& A, int team, int& shooter, bool find
 template <int NC>
 RLG_HD_T6A void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
     const float tickrate = 1.f / TICK_DT;
-    bool scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);  // Arena.cpp:949-957
+    bool scored = fabsf(A.ball.b.pos.y * BT2UU) > (A.mut.goal_threshold_y + K::BALL_RADIUS);  // Arena.cpp:949-957 (goalBaseThresholdY + ballRadius)
     int64_t buc = A.ball_update_counter;
     bool ball_shot = G.tracker_flags & 1u, scored_last = G.tracker_flags & 4u; int shot_goal_team = (G.tracker_flags & 2u) ? 1 : 0;
     if (buc > G.last_ball_update_count) {
@@ -228,7 +228,7 @@ RLG_HD_T6A void event_tracker_update(const Arena<NC>& A, GymEnv<NC>& G) {
         return;
     } else {
         ball_shot = false; scored = false; G.shot_cooldown = 0.f;  // ResetPersistentInfo, then _ballScoredLast = scored below
-        scored = fabsf(A.ball.b.pos.y * BT2UU) > (K::GOAL_THRESHOLD_Y + K::BALL_RADIUS);
+        scored = fabsf(A.ball.b.pos.y * BT2UU) > (A.mut.goal_threshold_y + K::BALL_RADIUS);
     }
     G.tracker_flags = (G.tracker_flags & ~7u) | (ball_shot ? 1u : 0u) | (shot_goal_team ? 2u : 0u) | (scored ? 4u : 0u);
     G.last_ball_update_count = buc;

@@ -96,10 +96,15 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
     }
     io.i(G.score_line[0]); io.i(G.score_line[1]); io.i(G.last_touch_car_id); io.l(G.last_tick_count); io.i(G.no_touch_steps);
     io.f(G.shot_cooldown);
-    {   // one word: the event tracker's three flags and, above them, the per-car loop order
+    {   // two words: the event tracker's three flags with the per-car loop order above them, and which players the step's GameState showed as demolished
+        // (Match::ParseActions gives those a zero action in the NEXT step, Match.cpp:44-52).  Until round 6 the second was not resident: it lived in the
+        // fused collection kernel's LDS copy for the length of a launch and was lost between launches and between k_env_step calls, so a demolished
+        // player's action was applied (and shown as its previous action) where the reference zeroes it -- found by the mutator fixture's random 2v2 rollout
+        // with ON_CONTACT demolitions; the older demolition fixture's victim happened to idle.
+        uint32_t sd = (G.tracker_flags >> 8) & 0xffu;
         uint32_t tf = (G.tracker_flags & 0xffu) | (A.car_order << 8);
-        io.u(tf);
-        G.tracker_flags = tf & 0xffu; A.car_order = tf >> 8;
+        io.u(tf); io.u(sd);
+        G.tracker_flags = (tf & 0xffu) | ((sd & 0xffu) << 8); A.car_order = tf >> 8;
     }
     io.l(G.last_ball_update_count);
     for (int b = 0; b <= NC; b += 2) {     // the broadphase history, two bodies per word
@@ -114,6 +119,12 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
     }
     io.u(G.episode_steps); io.u(G.reset_count);
     io.u(A.ref_engine);
+    {   // MutatorConfig's run-time scalars (MUTATOR_WORDS)
+        Mutators& m = A.mut;
+        io.f(m.gravity_z); io.f(m.boost_accel_ground); io.f(m.boost_accel_air); io.f(m.boost_used_per_second); io.f(m.jump_accel); io.f(m.jump_immediate_force);
+        io.f(m.ball_max_speed); io.f(m.ball_damp_per_tick); io.f(m.respawn_delay); io.f(m.bump_cooldown); io.f(m.pad_cooldown_big); io.f(m.pad_cooldown_small);
+        io.f(m.spawn_boost); io.f(m.ball_hit_extra_scale); io.f(m.bump_force_scale); io.f(m.goal_threshold_y); io.u(m.flags);
+    }
 }
 
 template <int NC>
@@ -124,9 +135,9 @@ constexpr size_t arena_num_words() {
     // page slack, garbage in the allocation behind it (the action table) when they did not.)  rlgpu_env_create refuses to run on a
     // mismatch, rlgpu_state_word_counts reports both numbers to the CPU tests.
 #ifdef RLG_TEST_EXTRA_WORD_ROWS   /* test build only (tools/build_variant.sh): the old defect on purpose, so the redzone test can be seen to catch it */
-    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 3 + (size_t)NC * RLG_TEST_EXTRA_WORD_ROWS;
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 4 + MUTATOR_WORDS + (size_t)NC * RLG_TEST_EXTRA_WORD_ROWS;
 #else
-    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 3;
+    return 4 + 21 + (size_t)NC * 89 + 68 + 10 + (size_t)(NC + 2) / 2 + (size_t)NC * (8 + RLGPU_NUM_EVENT_VALS + 1) + 4 + MUTATOR_WORDS;
 #endif
 }
 
@@ -157,6 +168,25 @@ RLG_HD void ctl_to(float* p, const Controls& c) {
     p[5] = c.jump ? 1.f : 0.f; p[6] = c.boost ? 1.f : 0.f; p[7] = c.handbrake ? 1.f : 0.f;
 }
 
+RLG_HD Mutators mutators_from_abi(const RlgpuMutators& a) {
+    Mutators m;
+    m.gravity_z = a.gravity_z; m.boost_accel_ground = a.boost_accel_ground; m.boost_accel_air = a.boost_accel_air; m.boost_used_per_second = a.boost_used_per_second;
+    m.jump_accel = a.jump_accel; m.jump_immediate_force = a.jump_immediate_force; m.ball_max_speed = a.ball_max_speed; m.ball_damp_per_tick = a.ball_damp_per_tick;
+    m.respawn_delay = a.respawn_delay; m.bump_cooldown = a.bump_cooldown_time; m.pad_cooldown_big = a.boost_pad_cooldown_big; m.pad_cooldown_small = a.boost_pad_cooldown_small;
+    m.spawn_boost = a.car_spawn_boost_amount; m.ball_hit_extra_scale = a.ball_hit_extra_force_scale; m.bump_force_scale = a.bump_force_scale;
+    m.goal_threshold_y = a.goal_base_threshold_y; m.flags = a.flags;
+    return m;
+}
+RLG_HD RlgpuMutators mutators_to_abi(const Mutators& m) {
+    RlgpuMutators a;
+    a.gravity_z = m.gravity_z; a.boost_accel_ground = m.boost_accel_ground; a.boost_accel_air = m.boost_accel_air; a.boost_used_per_second = m.boost_used_per_second;
+    a.jump_accel = m.jump_accel; a.jump_immediate_force = m.jump_immediate_force; a.ball_max_speed = m.ball_max_speed; a.ball_damp_per_tick = m.ball_damp_per_tick;
+    a.respawn_delay = m.respawn_delay; a.bump_cooldown_time = m.bump_cooldown; a.boost_pad_cooldown_big = m.pad_cooldown_big; a.boost_pad_cooldown_small = m.pad_cooldown_small;
+    a.car_spawn_boost_amount = m.spawn_boost; a.ball_hit_extra_force_scale = m.ball_hit_extra_scale; a.bump_force_scale = m.bump_force_scale;
+    a.goal_base_threshold_y = m.goal_threshold_y; a.flags = m.flags; a._pad = 0u;
+    return a;
+}
+
 template <int NC>
 RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& s) {
     A.tick_count = s.tick_count; A.ball_update_counter = s.ball_update_counter;
@@ -165,6 +195,7 @@ RLG_HD void arena_from_host(Arena<NC>& A, GymEnv<NC>& G, const RlgpuArenaState& 
     // clear: every recording, every state a user builds) means a fresh arena set to this state -- an env slot keeps its own history then (k_upload)
     for (int b = 0; b <= NC; b++) A.bp_hist[b] = (s.hidden.valid & RLGPU_HIDDEN_BP_HIST) ? s.hidden.bp_hist[b] : (uint16_t)0;
     A.ref_engine = (s.hidden.valid & RLGPU_HIDDEN_REF_ENGINE) ? s.hidden.ref_engine : 0u;   // (k_upload keeps the slot's engine when the state brings none)
+    if (s.hidden.valid & RLGPU_HIDDEN_MUTATORS) A.mut = mutators_from_abi(s.mutators); else A.mut = mutators_default();   // (k_upload: likewise)
     A.ball.b.pos = ld3(s.ball.pos) * UU2BT; A.ball.b.vel = ld3(s.ball.vel) * UU2BT; A.ball.b.angvel = ld3(s.ball.ang_vel);
     A.ball.vel_impulse_cache = ld3(s.ball.vel_impulse_cache) * UU2BT;
     {   // BallState::rotMat from the appended block (all zeros = a caller that knows nothing of it: a default BallState)
@@ -223,7 +254,8 @@ RLG_HD void arena_to_host(const Arena<NC>& A, const GymEnv<NC>& G, RlgpuArenaSta
     st3(s.hidden.ball_rot, col0(A.ball.b.rot)); st3(s.hidden.ball_rot + 3, col1(A.ball.b.rot)); st3(s.hidden.ball_rot + 6, col2(A.ball.b.rot));
     // the arena's other hidden state: the broadphase history of the dynamic proxies, and the basis a demolished car's rigid body has turned to
     // behind the stale rotation its state reports (car_ghost_rot, arena_world.h)
-    s.hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT | RLGPU_HIDDEN_REF_ENGINE;
+    s.hidden.valid = RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT | RLGPU_HIDDEN_REF_ENGINE | RLGPU_HIDDEN_MUTATORS;
+    s.mutators = mutators_to_abi(A.mut);
     s.hidden.ref_engine = A.ref_engine; s.hidden._pad = 0;
     for (int b = 0; b < 8; b++) s.hidden.bp_hist[b] = b <= NC ? A.bp_hist[b] : (uint16_t)0;
     for (int k = 0; k < RLGPU_MAX_CARS; k++) for (int q = 0; q < 9; q++) s.hidden.wreck_rot[k][q] = 0.f;

@@ -32,7 +32,7 @@ RLG_HD void on_car_ball_contact(Arena<NC>& A, int ci, V3 point_rel_ball) {   // 
         V3 hit_dir = safe_normalized(rel_pos * v3(1, 1, K::BALL_CAR_EXTRA_IMPULSE_Z_SCALE));
         V3 adj = car_fwd * dot(hit_dir, car_fwd) * (1 - K::BALL_CAR_EXTRA_IMPULSE_FORWARD_SCALE);
         hit_dir = safe_normalized(hit_dir - adj);
-        V3 added = (hit_dir * rel_speed) * curve_ball_car_extra(rel_speed) * 1.f;
+        V3 added = (hit_dir * rel_speed) * curve_ball_car_extra(rel_speed) * A.mut.ball_hit_extra_scale;
         car.bh_extra_hit_vel = added;
         ball.vel_impulse_cache += added * UU2BT;
     }
@@ -58,19 +58,20 @@ RLG_HD_COLD void on_car_car_contact(Arena<NC>& A, int ia, int ib, V3 local_a, V3
                 V3 lp = swapped ? local_b : local_a;
                 bool bumper = (lp.x * BT2UU) > K::BUMP_MIN_FORWARD_DIST;
                 if (bumper) {
-                    bool is_demo = (c1.flags & CF_IS_SUPERSONIC) != 0;
-                    if (is_demo) is_demo = (i1 % 2) != (i2 % 2);  // enableTeamDemos = false
+                    const uint32_t mf = A.mut.flags;   // MutatorConfig::demoMode, enableTeamDemos (Arena.cpp:375-388)
+                    bool is_demo = (mf & MUT_DEMO_ON_CONTACT) ? true : (mf & MUT_DEMO_DISABLED) ? false : (c1.flags & CF_IS_SUPERSONIC) != 0;
+                    if (is_demo && !(mf & MUT_TEAM_DEMOS)) is_demo = (i1 % 2) != (i2 % 2);
                     if (is_demo) {
-                        c2.flags |= CF_IS_DEMOED; c2.demo_respawn_timer = K::DEMO_RESPAWN_TIME;
+                        c2.flags |= CF_IS_DEMOED; c2.demo_respawn_timer = A.mut.respawn_delay;
                     } else {
                         bool ground_hit = c2.flags & CF_ON_GROUND;
                         float base = ground_hit ? curve_bump_ground(speed_towards) : curve_bump_air(speed_towards);
                         V3 hit_up = ground_hit ? col2(c2.b.rot) : v3(0, 0, 1);
-                        V3 imp = vel_dir * base + hit_up * curve_bump_up(speed_towards) * 1.f;
+                        V3 imp = vel_dir * base + hit_up * curve_bump_up(speed_towards) * A.mut.bump_force_scale;
                         c2.vel_impulse_cache += imp * UU2BT;
                     }
                     c1.car_contact_other = i2 + 1;
-                    c1.car_contact_cooldown = K::BUMP_COOLDOWN_TIME;
+                    c1.car_contact_cooldown = A.mut.bump_cooldown;
                     if ((i1 % 2) != (i2 % 2)) {  // Gym.cpp:30-38: only bumps on opponents count
                         ev.bump_mask |= (1u << i1);
                         if (is_demo) ev.bump_mask |= (1u << (8 + i1));
@@ -925,12 +926,12 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC, BIG>& W) {
     const bool ball_asleep = W.ball_asleep;
     W.needs_big = 0;
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
-    const float g = K::GRAVITY_Z * UU2BT;
+    const float g = A.mut.gravity_z * UU2BT;   // MutatorConfig::gravity (Arena.cpp:25: btDynamicsWorld::setGravity)
     // btRigidBody::setGravity keeps acceleration * (1 / m_inverseMass) (btRigidBody.cpp:132-139): not quite mass * g in float
     if (!ball_asleep) A.ball.b.force += v3(0, 0, g * (1.0f / BALL_INV_MASS));
     for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, g * (1.0f / CAR_INV_MASS));
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
-    A.ball.b.vel *= K::BALL_DAMP_PER_TICK;   // btPow(1 - linearDamping, timeStep)
+    A.ball.b.vel *= A.mut.ball_damp_per_tick;   // btPow(1 - linearDamping, timeStep), linearDamping = MutatorConfig::ballDrag (Arena.cpp:46)
 }
 
 // the narrowphase run inline (an env whose queue overflowed this tick, 1.8 per million env-ticks; the host build without a queue): cold calls, so
@@ -1321,7 +1322,7 @@ RLG_HD void pad_post_tick(Arena<NC>& A, int p) {
             Car& c = A.cars[locked - 1];
             c.boost = fminf(c.boost + (p < 6 ? K::PAD_BOOST_BIG : K::PAD_BOOST_SMALL), K::BOOST_MAX);
             pd.is_active = false;
-            pd.cooldown = p < 6 ? K::PAD_COOLDOWN_BIG : K::PAD_COOLDOWN_SMALL;
+            pd.cooldown = p < 6 ? A.mut.pad_cooldown_big : A.mut.pad_cooldown_small;   // BoostPad.cpp:100
         }
     }
     pd.prev_locked = (int8_t)locked;
@@ -1388,7 +1389,7 @@ RLG_HD_SMALL void tick_finish(Arena<NC>& A, const uint32_t* pad_tab, bool pads_d
     {   // Ball::_FinishPhysicsTick (Ball.cpp:112-138)
         Ball& b = A.ball;
         if (RLG_UNLIKELY(!is_zero(b.vel_impulse_cache))) { b.b.vel += b.vel_impulse_cache; b.vel_impulse_cache = v3(0, 0, 0); }
-        const float vmax = K::BALL_MAX_SPEED * UU2BT;
+        const float vmax = A.mut.ball_max_speed * UU2BT;   // Ball.cpp:126
         if (RLG_UNLIKELY(len2(b.b.vel) > vmax * vmax)) b.b.vel = normalized(b.b.vel) * vmax;
         if (RLG_UNLIKELY(len2(b.b.angvel) > K::BALL_MAX_ANG_SPEED * K::BALL_MAX_ANG_SPEED)) b.b.angvel = normalized(b.b.angvel) * K::BALL_MAX_ANG_SPEED;
         A.ball_update_counter++;

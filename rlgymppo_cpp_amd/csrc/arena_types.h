@@ -256,6 +256,33 @@ struct MeshView {
     int n_nodes, n_tris, n_fast;
 };
 
+// ---- MutatorConfig (RocketSim MutatorConfig.h:18-75), the part the stepper takes at run time: the scalars that change no collision shape, no mass and no
+// material (gravity along z, the boost / jump / ball-speed numbers, the timers, the demolition rules, the goal line).  One copy per env, part of its state
+// (RlgpuArenaState::mutators): read where the reference reads _mutatorConfig, so no register is held for it between uses.  Car / ball mass, the ball's
+// radius, friction and restitution stay compiled in (the facade refuses non-default values for those: include/RLGymSim_CPP/RocketSim/Arena.h).
+struct Mutators {
+    float gravity_z;                 // uu/s^2
+    float boost_accel_ground, boost_accel_air, boost_used_per_second;
+    float jump_accel, jump_immediate_force;
+    float ball_max_speed;            // uu/s
+    float ball_damp_per_tick;        // powf(1 - ballDrag, 1 / 120) as the C library rounds it (btRigidBody::applyDamping); derived on the host
+    float respawn_delay, bump_cooldown, pad_cooldown_big, pad_cooldown_small;
+    float spawn_boost;               // carSpawnBoostAmount
+    float ball_hit_extra_scale, bump_force_scale;
+    float goal_threshold_y;          // goalBaseThresholdY
+    uint32_t flags;                  // MUT_*
+};
+constexpr uint32_t MUT_UNLIMITED_FLIPS = 1u, MUT_UNLIMITED_DOUBLE_JUMPS = 2u, MUT_DEMO_ON_CONTACT = 4u, MUT_DEMO_DISABLED = 8u, MUT_TEAM_DEMOS = 16u;
+constexpr int MUTATOR_WORDS = 17;
+RLG_HD Mutators mutators_default() {
+    Mutators m;
+    m.gravity_z = K::GRAVITY_Z; m.boost_accel_ground = K::BOOST_ACCEL_GROUND; m.boost_accel_air = K::BOOST_ACCEL_AIR; m.boost_used_per_second = K::BOOST_USED_PER_SECOND;
+    m.jump_accel = K::JUMP_ACCEL; m.jump_immediate_force = K::JUMP_IMMEDIATE_FORCE; m.ball_max_speed = K::BALL_MAX_SPEED; m.ball_damp_per_tick = K::BALL_DAMP_PER_TICK;
+    m.respawn_delay = K::DEMO_RESPAWN_TIME; m.bump_cooldown = K::BUMP_COOLDOWN_TIME; m.pad_cooldown_big = K::PAD_COOLDOWN_BIG; m.pad_cooldown_small = K::PAD_COOLDOWN_SMALL;
+    m.spawn_boost = K::BOOST_SPAWN_AMOUNT; m.ball_hit_extra_scale = 1.f; m.bump_force_scale = 1.f; m.goal_threshold_y = K::GOAL_THRESHOLD_Y; m.flags = 0u;
+    return m;
+}
+
 // events a tick can raise towards the gym layer (Gym.cpp:6-38 callbacks)
 struct TickEvents {
     uint32_t bump_mask;  // bit i: car i bumped an opponent this tick ; bit 8+i : ... and it was a demo
@@ -275,6 +302,7 @@ struct Arena {
     // proxy's last setAabb (13 bits) and its arrival rank among the dynamic proxies (3 bits) -- arena_step.h bp_history_track.  All zero
     // = a fresh arena (what a state uploaded from the host starts as).
     uint16_t bp_hist[NC + 1];
+    Mutators mut;         // MutatorConfig's run-time scalars (above); every env of a batch starts with the batch's (GymConfig::mutators)
 };
 // the car the arena's per-car loops visit k-th (Arena.cpp:716-812 iterates an unordered set of car pointers)
 template <int NC>

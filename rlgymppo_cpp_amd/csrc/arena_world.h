@@ -533,7 +533,7 @@ RLG_HD bool ray_box_near(V3 from, V3 to, V3 lo, V3 hi) {
 // the respawn; resident layout: arena_io.h).
 RLG_HD const M3& car_ghost_rot(const Car& car) { return car.b.inv_inertia_w; }
 // (after car_tick_begin) this is the wreck's first pre-tick: Car::Demolish set the timer, one tick has been taken off it
-RLG_HD bool car_demolished_last_tick(const Car& car) { return (car.flags & CF_IS_DEMOED) && car.demo_respawn_timer == fmaxf(K::DEMO_RESPAWN_TIME - TICK_DT, 0.f); }
+RLG_HD bool car_demolished_last_tick(const Car& car, float respawn_delay) { return (car.flags & CF_IS_DEMOED) && car.demo_respawn_timer == fmaxf(respawn_delay - TICK_DT, 0.f); }
 template <int NC>
 RLG_HD int car_rank_of(const Arena<NC>& A, int slot) { for (int k = 0; k < NC; k++) if (car_at_rank(A, k) == slot) return k; return slot; }
 // last stage: the dynamic objects -- the ball (a btSphereShape), then the other cars' hitbox children (btBoxShape), each through the convex
@@ -559,7 +559,7 @@ RLG_HD void ray_ball_and_cars(const Arena<NC>& A, int self_car, V3 from, V3 to, 
         bool ghost = (o.flags & CF_IS_DEMOED) || o.frozen;
         // ... from ITS OWN pre-tick on: Car::_PreTickUpdate is what clears the body's contact response (Car.cpp:69-80), so on the first
         // tick after a demolition the cars the arena visits BEFORE the wreck still find a body like any other (Arena.cpp:716-812)
-        if (ghost && car_demolished_last_tick(o) && car_rank_of(A, self_car) < car_rank_of(A, k)) ghost = false;
+        if (ghost && car_demolished_last_tick(o, A.mut.respawn_delay) && car_rank_of(A, self_car) < car_rank_of(A, k)) ghost = false;
         const M3 R = (o.flags & CF_IS_DEMOED) ? car_ghost_rot(o) : o.b.rot;
         const V3 center = o.b.pos + R * hitbox_off();
         const V3 h = hitbox_half();

@@ -1236,6 +1236,20 @@ __global__ void __launch_bounds__(WAVE) k_env_fresh(EnvDev d) {
     LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
     load_env(d.words, d.n_envs, env, S.A, S.G);
     reset_pads(S.A);
+    S.A.mut = mutators_default();
+    store_env(d.words, d.n_envs, env, S.A, S.G);
+}
+// rlgpu_env_set_mutators: every env of the batch gets these MutatorConfig scalars (Arena::SetMutatorConfig on each of the reference's arenas, Gym.cpp:40-44)
+template <int NC>
+__global__ void __launch_bounds__(WAVE) k_set_mutators(EnvDev d, Mutators m) {
+    constexpr int LANES = lanes_per_block<NC>();
+    __shared__ __attribute__((aligned(16))) unsigned char lane_mem[LANES * lane_stride<NC>()];
+    if (threadIdx.x >= LANES) return;
+    const int env = blockIdx.x * LANES + threadIdx.x;
+    if (env >= d.n_envs) return;
+    LaneBlock<NC>& S = *reinterpret_cast<LaneBlock<NC>*>(lane_mem + (size_t)threadIdx.x * lane_stride<NC>());
+    load_env(d.words, d.n_envs, env, S.A, S.G);
+    S.A.mut = m;
     store_env(d.words, d.n_envs, env, S.A, S.G);
 }
 
@@ -1316,7 +1330,9 @@ __global__ void __launch_bounds__(WAVE) k_upload(EnvDev d, const RlgpuArenaState
     uint16_t hist[NC + 1];
     for (int b = 0; b <= NC; b++) hist[b] = A.bp_hist[b];
     const uint32_t engine = A.ref_engine;
+    const Mutators mut = A.mut;
     arena_from_host(A, G, src[i]);
+    if (!(src[i].hidden.valid & RLGPU_HIDDEN_MUTATORS)) A.mut = mut;                                          // (the env keeps the mutators it runs under)
     if (!(src[i].hidden.valid & RLGPU_HIDDEN_BP_HIST)) for (int b = 0; b <= NC; b++) A.bp_hist[b] = hist[b];   // (a state that carries a history brings its own)
     if (!(src[i].hidden.valid & RLGPU_HIDDEN_REF_ENGINE)) A.ref_engine = engine;                              // (likewise the reference-engine test mode: SetState does not touch the thread's engine)
     store_env(d.words, d.n_envs, env, A, G);
@@ -1663,6 +1679,22 @@ int rlgpu_env_load_cmf_dir(rlgpu_env* e, const char* dir) {
 
 
 
+void rlgpu_default_mutators(RlgpuMutators* m) { *m = mutators_to_abi(mutators_default()); }
+float rlgpu_ball_damp_per_tick(float ball_drag) { return powf(1.0f - ball_drag, TICK_DT); }   // btRigidBody::applyDamping's factor, by the host's C library
+int rlgpu_env_set_mutators(rlgpu_env* e, const RlgpuMutators* m) {
+    if (!m) { e->err = "rlgpu_env_set_mutators: null"; return RLGPU_ERR_ARG; }
+    if (!(m->ball_damp_per_tick > 0.f && m->ball_damp_per_tick <= 1.f) || !(m->ball_max_speed >= 0.f) || (m->flags & ~31u) ||
+        ((m->flags & RLGPU_MUT_DEMO_ON_CONTACT) && (m->flags & RLGPU_MUT_DEMO_DISABLED))) {
+        e->err = "rlgpu_env_set_mutators: ball_damp_per_tick must be in (0, 1] (rlgpu_ball_damp_per_tick(ballDrag)), ball_max_speed >= 0, flags a combination of RLGPU_MUT_* with at most one demo mode";
+        return RLGPU_ERR_ARG;
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    dim3 grid(RLG_NC_PICK(e->nc, env_grid<2>(e->d.n_envs), env_grid<4>(e->d.n_envs), env_grid<6>(e->d.n_envs))), block(WAVE);
+    DISPATCH_NC(e, k_set_mutators, grid, block, e->d, mutators_from_abi(*m));
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return RLGPU_OK;
+}
 int rlgpu_env_upload_states(rlgpu_env* e, const RlgpuArenaState* host, const int32_t* env_ids, int n) {
     if (n <= 0) return RLGPU_OK;
     HIPCHK(e, hipSetDevice(e->device));

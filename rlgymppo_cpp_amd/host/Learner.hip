@@ -264,6 +264,10 @@ Learner::Learner(EnvCreateFn envCreateFn_, LearnerConfig config_) : config(confi
     m.nPlayers = m.match->playerAmount;
     int rc = rlgpu_env_create(&m.env, m.device, m.nEnvs, m.match->teamSize, &gcfg);
     m.EnvCheck(rc, "create");
+    if (!ecr.gym->arena->GetMutatorConfig().IsDefault()) {   // Gym(match, tickSkip, carConfig, gameMode, mutatorConfig): every game of the batch runs under the probe env's mutators (Gym.cpp:40-44)
+        const RlgpuMutators mut = ecr.gym->arena->GetMutatorConfig().ToDevice();
+        m.EnvCheck(rlgpu_env_set_mutators(m.env, &mut), "set_mutators");
+    }
     RLGSC::LoadArenaMesh(m.env, m.rank != 0 || std::getenv("RLGPU_QUIET"));
     if (config.deviceStepMetrics) m.EnvCheck(rlgpu_env_enable_step_stats(m.env, 1), "enable_step_stats");
     m.nAgents = rlgpu_env_num_agents(m.env); m.Ddev = m.D = rlgpu_env_obs_size(m.env); m.A = rlgpu_env_num_actions(m.env);

@@ -110,6 +110,7 @@ SkillTracker::SkillTracker(const SkillTrackerConfig& config_, rlgpu_learner* lea
     g.seed_lo = (uint32_t)randomSeed + 7777u; g.seed_hi = 1;
     int rc = rlgpu_env_create(&m.env, 0, config.numEnvs, m.match->teamSize, &g);
     m.EnvCheck(rc, "create");
+    if (!m.gym->arena->GetMutatorConfig().IsDefault()) { const RlgpuMutators mut = m.gym->arena->GetMutatorConfig().ToDevice(); m.EnvCheck(rlgpu_env_set_mutators(m.env, &mut), "set_mutators"); }
     std::filesystem::path soccar = RocketSim::GetCollisionMeshFolder() / "soccar";
     if (!RocketSim::GetCollisionMeshFolder().empty() && std::filesystem::is_directory(soccar)) m.EnvCheck(rlgpu_env_load_cmf_dir(m.env, soccar.string().c_str()), "load_cmf_dir");
     else m.EnvCheck(rlgpu_env_set_procedural_mesh(m.env), "set_procedural_mesh");

@@ -82,7 +82,19 @@ class ArenaHidden(C.Structure):
     _fields_ = [("ball_rot", f32 * 9), ("valid", C.c_uint32), ("bp_hist", C.c_uint16 * 8), ("wreck_rot", (f32 * 9) * MAX_CARS), ("ref_engine", C.c_uint32), ("_pad", C.c_uint32)]
 
 
-HIDDEN_BP_HIST, HIDDEN_WRECK_ROT, HIDDEN_REF_ENGINE = 1, 2, 4
+HIDDEN_BP_HIST, HIDDEN_WRECK_ROT, HIDDEN_REF_ENGINE, HIDDEN_MUTATORS = 1, 2, 4, 8
+
+
+class Mutators(C.Structure):
+    """RlgpuMutators (include/rlgpu_state.h): MutatorConfig's run-time scalars; meaningful in a state when hidden.valid has HIDDEN_MUTATORS.
+    ball_damp_per_tick = powf(1 - ballDrag, 1 / 120) by the C library (rlgpu_ball_damp_per_tick)."""
+    _fields_ = [("gravity_z", f32), ("boost_accel_ground", f32), ("boost_accel_air", f32), ("boost_used_per_second", f32), ("jump_accel", f32), ("jump_immediate_force", f32),
+                ("ball_max_speed", f32), ("ball_damp_per_tick", f32), ("respawn_delay", f32), ("bump_cooldown_time", f32), ("boost_pad_cooldown_big", f32),
+                ("boost_pad_cooldown_small", f32), ("car_spawn_boost_amount", f32), ("ball_hit_extra_force_scale", f32), ("bump_force_scale", f32),
+                ("goal_base_threshold_y", f32), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+MUT_UNLIMITED_FLIPS, MUT_UNLIMITED_DOUBLE_JUMPS, MUT_DEMO_ON_CONTACT, MUT_DEMO_DISABLED, MUT_TEAM_DEMOS = 1, 2, 4, 8, 16
 
 
 IDENTITY9 = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
@@ -93,7 +105,7 @@ class ArenaState(C.Structure):
         ("num_cars", C.c_int32), ("car_order", C.c_uint32),
         ("tick_count", C.c_int64), ("ball_update_counter", C.c_int64),
         ("ball", BallState), ("cars", CarState * MAX_CARS), ("pads", PadState * NUM_PADS), ("gym", GymState),
-        ("hidden", ArenaHidden),
+        ("hidden", ArenaHidden), ("mutators", Mutators),
     ]
 
     def __init__(self, *a, **k):
@@ -105,13 +117,13 @@ class ArenaState(C.Structure):
         """Also takes a recording made before the `hidden` block was appended (the committed fixtures): the ball's basis is the identity there
         and nothing hidden travels (valid = 0), which is what those recordings meant."""
         b = bytes(buf)[offset:]
-        short = C.sizeof(cls) - C.sizeof(ArenaHidden)
+        short = C.sizeof(cls) - C.sizeof(ArenaHidden) - C.sizeof(Mutators)
         if len(b) == short:
-            out = type(C.Structure).from_buffer_copy(cls, b + bytes(C.sizeof(ArenaHidden)))
+            out = type(C.Structure).from_buffer_copy(cls, b + bytes(C.sizeof(cls) - short))
             out.hidden.ball_rot[:] = IDENTITY9
             return out
-        if short < len(b) < C.sizeof(cls):     # a recording of rounds 4 - 5: the block ended with wreck_rot (no ref_engine: 0 = the env's own streams)
-            b = b + bytes(C.sizeof(cls) - len(b))
+        if short < len(b) < C.sizeof(cls):     # a recording of rounds 4 - 5 (the block ended with wreck_rot: no ref_engine, 0 = the env's own streams) or of
+            b = b + bytes(C.sizeof(cls) - len(b))   # early round 6 (no mutators block: valid bit clear = RLConst's defaults)
         return type(C.Structure).from_buffer_copy(cls, b)
 
 

@@ -509,6 +509,44 @@ static int StandaloneGym() {
         CHECK(seen.goals == g0 + 3);
         delete cb;
     }
+    {   // MutatorConfig through the facade (Arena::SetMutatorConfig, Gym's constructor argument): the run-time fields reach the device, the compiled-in ones are refused
+        Arena* mu = Arena::Create(GameMode::SOCCAR);
+        Car* car = mu->AddCar(Team::BLUE); mu->AddCar(Team::ORANGE);
+        mu->ResetToRandomKickoff(5);
+        MutatorConfig mc(GameMode::SOCCAR);
+        mc.gravity = Vec(0, 0, -325.f); mc.ballMaxSpeed = 1000.f; mc.carSpawnBoostAmount = 77.f; mc.demoMode = DemoMode::DISABLED; mc.boostUsedPerSecond = 0.f;
+        mu->SetMutatorConfig(mc);
+        BallState up; up.pos = Vec(0, 0, 1500); up.vel = Vec(0, 0, -1); mu->ball->SetState(up);
+        car->controls.throttle = 1; car->controls.boost = true;
+        const float boost0 = car->GetState().boost;
+        mu->Step(60);
+        const BallState fell = mu->ball->GetState();
+        CHECK(fell.pos.z < 1500.f - 35.f && fell.pos.z > 1500.f - 45.f && fell.vel.z < -150.f && fell.vel.z > -170.f);   // 0.5 s of -325 uu/s^2, half of what the default drops it
+        CHECK(car->GetState().boost == boost0);                                                                          // boosting costs nothing under boostUsedPerSecond = 0
+        BallState fast; fast.pos = Vec(0, 0, 1000); fast.vel = Vec(3000, 0, 0); mu->ball->SetState(fast);
+        mu->Step(2);
+        CHECK(mu->ball->GetState().vel.Length() <= 1000.5f);                                                             // ballMaxSpeed
+        CHECK(mu->GetMutatorConfig().gravity.z == -325.f && !mu->GetMutatorConfig().IsDefault());
+        bool refused = false;
+        MutatorConfig big = mc; big.ballRadius = 120.f;
+        try { mu->SetMutatorConfig(big); } catch (const std::exception&) { refused = true; }
+        CHECK(refused);
+        refused = false;
+        MutatorConfig side = mc; side.gravity = Vec(100.f, 0, -650.f);
+        try { mu->SetMutatorConfig(side); } catch (const std::exception&) { refused = true; }
+        CHECK(refused);
+        delete mu;
+        // the same through Gym's constructor (SIM/Gym.cpp:40-44)
+        CombinedReward r0({{new VelocityPlayerToBallReward(), 1.f}}, true);
+        NoTouchCondition nt0(50);
+        Match mm(&r0, {&nt0}, &obs, &parser, &kickoff, 1, true);
+        Gym gm(&mm, 8, CAR_CONFIG_OCTANE, GameMode::SOCCAR, mc);
+        gm.Reset();
+        BallState up2; up2.pos = Vec(0, 0, 1500); up2.vel = Vec(0, 0, -1); gm.arena->ball->SetState(up2);
+        for (int i = 0; i < 8; i++) gm.Step({drive[0], drive[0]});                                                       // 64 ticks
+        const float z = gm.arena->ball->GetState().pos.z;
+        CHECK(z < 1500.f - 40.f && z > 1500.f - 52.f);
+    }
     {   // a gym without opponents: one car, one observation row with no other player in it
         CombinedReward solo({{new VelocityPlayerToBallReward(), 1.f}}, true);
         NoTouchCondition nt(4);

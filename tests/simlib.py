@@ -267,7 +267,8 @@ GYM_OBS_TOL = {
 # from it); and SaveBoostReward / TouchBallReward call powf as the host libm rounds it (arena_gym.h libm_powf)
 GYM_EXACT = {"ts8_random", "ts8_chase", "ts1_random", "1v1_timeout", "1v1_goal", "2v2_goal_assist_allterms", "2v2_shot_save_demo_zerosum",
              "2v2_padded3_zerosum_random", "3v3_allterms_random",
-             "1v0_push_into_goal", "1v0_timeout", "2v0_allterms_zerosum_random", "3v0_padded3_allterms"}
+             "1v0_push_into_goal", "1v0_timeout", "2v0_allterms_zerosum_random", "3v0_padded3_allterms",
+             "M1_1v1_goal_line", "M1_2v2_random"}     # (the last two: Gym rollouts under a non-default MutatorConfig, tests/golden/mutator_golden.npz)
 GYM_EXACT_OBS = set()     # (rollouts with bit-equal observations but a last-bit reward difference: none left)
 
 # steps up to which a free-running gym rollout is compared on the HIP path (resident arenas).  Empty since the manifold point's local point
@@ -276,7 +277,7 @@ GYM_EXACT_OBS = set()     # (rollouts with bit-equal observations but a last-bit
 GYM_HORIZON = {}
 # the host build's gym test hands the state over in uu after every step (one rounding per step the reference's resident arena does not
 # make): its random 2v2 rollout with hitbox contacts is compared up to here
-GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64}
+GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64, "M1_2v2_random": 80}
 
 
 def gym_cfg_for_case(team, tick_skip, obs_max_players, reward_kind, no_touch_steps):

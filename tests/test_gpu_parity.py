@@ -222,6 +222,12 @@ def test_hip_one_team_gym_rollouts_vs_reference_fixtures():
     test_hip_gym_rollouts_vs_reference_fixtures(np.load(os.path.join(GOLD, "sim_golden_one_team.npz")))
 
 
+def test_hip_gym_rollouts_under_mutators_vs_reference_fixtures():
+    """The two Gym rollouts the reference made under MutatorConfig M1 (tests/golden/mutator_golden.npz: goal line 5000 and gravity -325 as GameEventTracker sees
+    them through the arena, next to GoalScoreCondition's own constant) on the HIP path: the block arrives with the uploaded start state."""
+    test_hip_gym_rollouts_vs_reference_fixtures(np.load(os.path.join(GOLD, "mutator_golden.npz")))
+
+
 def test_hip_gym_rollouts_vs_reference_fixtures(sg):
     """Every committed rollout of the REAL reference Gym replayed on the HIP path, no port in between: 1v1 example stack (full 160
     steps, the NoTouch timeout, a goal), 2v2 with every CommonRewards term (goal + assist + shot pass; shot + save + bump + demo),
@@ -454,6 +460,60 @@ def test_hip_tapes_through_respawns_equal_the_reference():
                         compared += every
         env.close()
     assert compared >= 5500, compared
+
+
+def test_hip_tapes_under_mutators_equal_the_reference():
+    """VERDICT r05 "next" 6 on the GPU: the ten tapes of tests/golden/mutator_golden.npz (the reference under two MutatorConfigs in which every run-time field is
+    off its default) as envs of a batch -- each env's block arrives with its start state (RlgpuArenaState::mutators), and a second batch gets one set through
+    rlgpu_env_set_mutators and start states WITHOUT a block.  EQUAL to the reference in every field of every body, every pad's state and cooldown, every 10 ticks
+    over the whole tapes, and the engine's state with it."""
+    import ctypes as C
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import state_vec
+    mg = np.load(os.path.join(GOLD, "mutator_golden.npz")); sgm = np.load(os.path.join(GOLD, "sim_golden.npz"))
+    every = int(mg["every"]); names = [str(n) for n in mg["phys_names"]]
+
+    def vec(o): return np.concatenate([state_vec(o), [float(o.pads[p].is_active) for p in range(34)], [o.pads[p].cooldown for p in range(34)]])
+
+    def run(grp, nc, strip_block):
+        starts = [ArenaState.from_buffer_copy(mg[f"phys/{n}/start_raw"].tobytes()) for n in grp]
+        env = BatchedEnv(len(grp), nc // 2, mesh=(sgm["mesh_verts"], sgm["mesh_tris"]))
+        if strip_block:
+            m = type(starts[0].mutators).from_buffer_copy(bytes(starts[0].mutators))
+            assert env.lib.rlgpu_env_set_mutators(env.h, C.byref(m)) == 0
+            for s in starts: s.hidden.valid &= ~8
+        env.upload_states(starts)
+        tapes = [mg[f"phys/{n}/tape"] for n in grp]; T = max(len(t) for t in tapes)
+        ctl = np.zeros((len(grp), nc, 8), np.float32); compared = 0
+        for t in range(T):
+            for i, tp in enumerate(tapes):
+                if t < len(tp): ctl[i] = tp[t]
+            env.set_controls(ctl)
+            env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states()
+                for i, n in enumerate(grp):
+                    if t + 1 <= len(tapes[i]):
+                        j = (t + 1) // every - 1
+                        assert np.array_equal(vec(cur[i]), mg[f"phys/{n}/states"][j]), f"{n} tick {t + 1}: HIP state is not the reference's"
+                        assert cur[i].hidden.ref_engine == int(mg[f"phys/{n}/engines"][j]), f"{n} tick {t + 1}: the engines parted"
+                        assert cur[i].hidden.valid & 8 and cur[i].mutators.gravity_z == starts[i].mutators.gravity_z
+                        compared += every
+        env.close()
+        return compared
+
+    compared = 0
+    for nc in (2, 4, 6):
+        grp = [n for n in names if ArenaState.from_buffer_copy(mg[f"phys/{n}/start_raw"].tobytes()).num_cars == nc]
+        compared += run(grp, nc, False)                                   # M1 and M2 side by side in one batch
+    assert compared >= 14800, compared
+    assert run([n for n in names if n.startswith("M1/") and ArenaState.from_buffer_copy(mg[f"phys/{n}/start_raw"].tobytes()).num_cars == 2], 2, True) >= 2800
+    # a fresh batch runs RLConst's defaults, and says so
+    env = BatchedEnv(2, 1); st = env.download_states()
+    assert st[0].hidden.valid & 8 and st[0].mutators.gravity_z == -650.0 and st[0].mutators.ball_max_speed == 6000.0 and st[0].mutators.flags == 0
+    bad = type(st[0].mutators).from_buffer_copy(bytes(st[0].mutators)); bad.ball_damp_per_tick = 0.0
+    assert env.lib.rlgpu_env_set_mutators(env.h, C.byref(bad)) != 0       # refused loudly
+    env.close()
 
 
 @pytest.mark.parametrize("team", [1, 2, 3])
