@@ -151,8 +151,8 @@ struct CarConfig {
 inline const CarConfig CAR_CONFIG_OCTANE = [] { CarConfig c; c.hitboxSize = Vec(120.507f, 86.6994f, 38.6591f); c.hitboxPosOffset = Vec(13.87566f, 0, 20.755f); return c; }();
 enum class DemoMode : uint8_t { NORMAL, ON_CONTACT, DISABLED };
 // MutatorConfig.h (RS/Sim/MutatorConfig/MutatorConfig.h:18-75), the reference's fields under the reference's names.  The device stepper takes the ones that change
-// no collision shape, no mass and no material at run time (RlgpuMutators, include/rlgpu_state.h); carMass, ballMass, ballRadius, the four world friction /
-// restitution values and gravity's x / y stay compiled in and are refused off their defaults where they would be applied (Arena::SetMutatorConfig).
+// no collision shape and no mass at run time (RlgpuMutators, include/rlgpu_state.h: 24 of the 27); carMass, ballMass and ballRadius stay compiled in and
+// are refused off their defaults where they would be applied (Arena::SetMutatorConfig).
 struct MutatorConfig {
     Vec gravity = Vec(0, 0, RLConst::GRAVITY_Z);
     float carMass = RLConst::CAR_MASS_BT, carWorldFriction = RLConst::CARWORLD_COLLISION_FRICTION, carWorldRestitution = RLConst::CARWORLD_COLLISION_RESTITUTION;
@@ -169,12 +169,12 @@ struct MutatorConfig {
     // the fields the stepper has compiled in are at their defaults
     bool CompiledInFieldsAreDefault() const {
         const MutatorConfig d;
-        return gravity.x == 0 && gravity.y == 0 && carMass == d.carMass && carWorldFriction == d.carWorldFriction && carWorldRestitution == d.carWorldRestitution && ballMass == d.ballMass &&
-               ballWorldFriction == d.ballWorldFriction && ballWorldRestitution == d.ballWorldRestitution && ballRadius == d.ballRadius;
+        return carMass == d.carMass && ballMass == d.ballMass && ballRadius == d.ballRadius;
     }
     bool IsDefault() const {
         const MutatorConfig d;
-        return CompiledInFieldsAreDefault() && gravity.z == d.gravity.z && ballMaxSpeed == d.ballMaxSpeed && ballDrag == d.ballDrag && jumpAccel == d.jumpAccel &&
+        return CompiledInFieldsAreDefault() && gravity.x == 0 && gravity.y == 0 && gravity.z == d.gravity.z && carWorldFriction == d.carWorldFriction &&
+               carWorldRestitution == d.carWorldRestitution && ballWorldFriction == d.ballWorldFriction && ballWorldRestitution == d.ballWorldRestitution && ballMaxSpeed == d.ballMaxSpeed && ballDrag == d.ballDrag && jumpAccel == d.jumpAccel &&
                jumpImmediateForce == d.jumpImmediateForce && boostAccelGround == d.boostAccelGround && boostAccelAir == d.boostAccelAir &&
                boostUsedPerSecond == d.boostUsedPerSecond && respawnDelay == d.respawnDelay && bumpCooldownTime == d.bumpCooldownTime &&
                boostPadCooldown_Big == d.boostPadCooldown_Big && boostPadCooldown_Small == d.boostPadCooldown_Small && carSpawnBoostAmount == d.carSpawnBoostAmount &&
@@ -191,6 +191,8 @@ struct MutatorConfig {
         m.flags = (unlimitedFlips ? RLGPU_MUT_UNLIMITED_FLIPS : 0u) | (unlimitedDoubleJumps ? RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS : 0u) |
                   (demoMode == DemoMode::ON_CONTACT ? RLGPU_MUT_DEMO_ON_CONTACT : demoMode == DemoMode::DISABLED ? RLGPU_MUT_DEMO_DISABLED : 0u) | (enableTeamDemos ? RLGPU_MUT_TEAM_DEMOS : 0u);
         m._pad = 0;
+        m.gravity_x = gravity.x; m.gravity_y = gravity.y; m.car_world_friction = carWorldFriction; m.car_world_restitution = carWorldRestitution;
+        m.ball_world_friction = ballWorldFriction; m.ball_world_restitution = ballWorldRestitution;
         return m;
     }
 };

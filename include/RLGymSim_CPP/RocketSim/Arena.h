@@ -169,10 +169,10 @@ public:
     const std::vector<BoostPad*>& GetBoostPads() { return _boostPads; }
     const MutatorConfig& GetMutatorConfig() { return _mutatorConfig; }
     // Arena::SetMutatorConfig (Arena.cpp:15-48).  The run-time fields travel with the arena's state from here on (RlgpuArenaState::mutators: the next upload
-    // hands them to the env); car / ball mass, ball radius, the world friction / restitution values and a sideways gravity are compiled into the stepper.
+    // hands them to the env); car / ball mass and the ball's radius are compiled into the stepper.
     void SetMutatorConfig(const MutatorConfig& m) {
         if (!m.CompiledInFieldsAreDefault())
-            RG_ERR_CLOSE("Arena::SetMutatorConfig(): carMass, ballMass, ballRadius, carWorld / ballWorld friction and restitution and gravity.x / .y are compiled into the device stepper (defaults only)");
+            RG_ERR_CLOSE("Arena::SetMutatorConfig(): carMass, ballMass and ballRadius are compiled into the device stepper (defaults only)");
         _mutatorConfig = m;
         _state.mutators = m.ToDevice(); _state.hidden.valid |= RLGPU_HIDDEN_MUTATORS;
     }

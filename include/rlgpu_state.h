@@ -174,8 +174,7 @@ typedef struct RlgpuArenaHidden {
 /* MutatorConfig's run-time scalars (RocketSim MutatorConfig.h:18-75; round 6): what an env simulates with instead of RLConst's defaults.  The fields are the
  * reference's, in its units, except ball_damp_per_tick = powf(1 - ballDrag, 1 / 120) as the C library rounds it (btRigidBody::applyDamping computes that
  * every tick; the device has no bit-identical powf, so whoever fills the struct computes it on the host: rlgpu_default_mutators / the facade's
- * Arena::SetMutatorConfig).  NOT here, because they change a collision shape, a mass or a material and stay compiled in: carMass, ballMass, ballRadius,
- * carWorld / ballWorld friction and restitution, gravity's x / y.  A state carries its env's block when hidden.valid has RLGPU_HIDDEN_MUTATORS (downloads
+ * Arena::SetMutatorConfig).  NOT here, because they change a collision shape or a mass and stay compiled in: carMass, ballMass, ballRadius.  A state carries its env's block when hidden.valid has RLGPU_HIDDEN_MUTATORS (downloads
  * set it); an upload without the bit leaves the slot's mutators alone. */
 #define RLGPU_MUT_UNLIMITED_FLIPS        1u
 #define RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS 2u
@@ -194,6 +193,9 @@ typedef struct RlgpuMutators {
     float goal_base_threshold_y;
     uint32_t flags;                  /* RLGPU_MUT_* */
     uint32_t _pad;
+    float gravity_x, gravity_y;
+    float car_world_friction, car_world_restitution;
+    float ball_world_friction, ball_world_restitution;   /* the ball body's own values (Arena.cpp:44-45); against the static world Bullet takes min(f, 0.6) / max(r, 0.3) */
 } RlgpuMutators;
 
 typedef struct RlgpuArenaState {

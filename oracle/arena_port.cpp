@@ -143,7 +143,7 @@ int run_tape_contacts_t(RlgpuArenaState* s, const float* tape, int ticks, float*
         o[0] = (float)c.a; o[1] = (float)c.b; o[2] = (float)c.sid; o[3] = c.special ? 1.f : 0.f;
         o[4] = c.ra.x; o[5] = c.ra.y; o[6] = c.ra.z; o[7] = c.rb.x; o[8] = c.rb.y; o[9] = c.rb.z;
         o[10] = c.n.x; o[11] = c.n.y; o[12] = c.n.z; o[13] = c.dist;
-        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c);
+        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c, A.mut);
         if (out2) {   // the rows: friction direction[3], applied friction impulse, normal rhs, normal jac, body a's external impulses ext_f[3] / ext_t[3], friction rhs, friction jac, v.x, w.y
             float* q = out2 + 16 * (n - 1);
             for (int i = 0; i < 16; i++) q[i] = 0.f;
@@ -245,6 +245,31 @@ int port_ray_convex(const float* from3, const float* to3, const float* half3, fl
     const bool hit = ray_convex_hit(v3(from3[0], from3[1], from3[2]), v3(to3[0], to3[1], to3[2]), R, v3(pos3[0], pos3[1], pos3[2]), half, radius, 7, best);
     out4[0] = best.frac; out4[1] = best.normal.x; out4[2] = best.normal.y; out4[3] = best.normal.z;
     return hit ? 1 : 0;
+}
+// the static world as a wheel ray meets it (csrc/arena_world.h: ray_planes, then the mesh with Bullet's leaf admission for edge-tolerance hits): out4 = fraction,
+// normal; returns 1 on a hit.  from / to in Bullet units.  (tests/test_live_reference.py: rays beside triangle edges against btCollisionWorld::rayTest)
+int port_ray_world(const float* from3, const float* to3, float* out4) {
+    const V3 from = v3(from3[0], from3[1], from3[2]), to = v3(to3[0], to3[1], to3[2]);
+    RayHit best = ray_planes(from, to);
+    ray_mesh_walk(view(), from, to, best);
+    out4[0] = best.frac; out4[1] = best.normal.x; out4[2] = best.normal.y; out4[3] = best.normal.z;
+    return best.kind >= 0 ? 1 : 0;
+}
+// debugging probe: every stored triangle whose plane the segment crosses -- out per triangle: stored index, source index, hit fraction with / without the leaf admission (2 = no hit), admitted flag
+int port_ray_debug(const float* from3, const float* to3, float* out, int cap) {
+    const V3 from = v3(from3[0], from3[1], from3[2]), to = v3(to3[0], to3[1], to3[2]);
+    MeshView mv = view(); int n = 0;
+    for (int i = 0; i < mv.n_tris && n < cap; i++) {
+        const MeshTri& t = mv.tris[i];
+        const V3 v0 = v3(t.v0x, t.v0y, t.v0z), v1 = v3(t.v1x, t.v1y, t.v1z), v2 = v3(t.v2x, t.v2y, t.v2z);
+        RayHit a; a.kind = -1; a.frac = 1.f; a.normal = v3(0, 0, 0); RayHit b = a;
+        ray_triangle(v0, v1, v2, from, to, a, mv.bp, &t);
+        ray_triangle(v0, v1, v2, from, to, b);
+        if (b.kind != 0) continue;
+        float* o = out + 5 * n++;
+        o[0] = (float)i; o[1] = (float)g_mesh.source_tri[i]; o[2] = a.kind == 0 ? a.frac : 2.f; o[3] = b.frac; o[4] = ray_leaf_admits(mesh_leaf_frame(mv.bp, t.obj), v0, v1, v2, from, to) ? 1.f : 0.f;
+    }
+    return n;
 }
 // the host build of csrc/arena_world.h:adjust_internal_edge on stored triangle `stored_index` of the mesh port_set_mesh built
 // (g_mesh.source_tri maps it to the input's numbering): out7 = normal[3], point on the triangle[3], distance
@@ -378,7 +403,7 @@ static int debug_tick_t(RlgpuArenaState* s, float* out, int cap) {
         o[0] = (float)c.a; o[1] = (float)c.b; o[2] = (float)W.nrow[k]; o[3] = c.special ? 1.f : 0.f;
         o[4] = c.ra.x; o[5] = c.ra.y; o[6] = c.ra.z; o[7] = c.rb.x; o[8] = c.rb.y; o[9] = c.rb.z;
         o[10] = c.n.x; o[11] = c.n.y; o[12] = c.n.z; o[13] = c.dist;
-        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c);
+        o[14] = W.nrow[k] >= 0 ? W.R[W.nrow[k]].applied : 0.f; o[15] = contact_friction(c, A.mut);
     }
     return n;
 }

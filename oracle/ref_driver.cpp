@@ -95,6 +95,8 @@ void GetArenaPhys(Arena* a, RlgpuArenaState* s) {
         m.respawn_delay = mc.respawnDelay; m.bump_cooldown_time = mc.bumpCooldownTime; m.boost_pad_cooldown_big = mc.boostPadCooldown_Big; m.boost_pad_cooldown_small = mc.boostPadCooldown_Small;
         m.car_spawn_boost_amount = mc.carSpawnBoostAmount; m.ball_hit_extra_force_scale = mc.ballHitExtraForceScale; m.bump_force_scale = mc.bumpForceScale;
         m.goal_base_threshold_y = mc.goalBaseThresholdY;
+        m.gravity_x = mc.gravity.x; m.gravity_y = mc.gravity.y; m.car_world_friction = mc.carWorldFriction; m.car_world_restitution = mc.carWorldRestitution;
+        m.ball_world_friction = mc.ballWorldFriction; m.ball_world_restitution = mc.ballWorldRestitution;
         m.flags = (mc.unlimitedFlips ? RLGPU_MUT_UNLIMITED_FLIPS : 0u) | (mc.unlimitedDoubleJumps ? RLGPU_MUT_UNLIMITED_DOUBLE_JUMPS : 0u) |
                   (mc.demoMode == DemoMode::ON_CONTACT ? RLGPU_MUT_DEMO_ON_CONTACT : mc.demoMode == DemoMode::DISABLED ? RLGPU_MUT_DEMO_DISABLED : 0u) |
                   (mc.enableTeamDemos ? RLGPU_MUT_TEAM_DEMOS : 0u);
@@ -465,7 +467,8 @@ void ref_arena_get_state(void* h, RlgpuArenaState* s) { GetArenaPhys((Arena*)h, 
 void ref_arena_set_mutators(void* h, const RlgpuMutators* m, float ball_drag) {
     Arena* a = (Arena*)h;
     MutatorConfig mc = a->GetMutatorConfig();
-    mc.gravity = Vec(0, 0, m->gravity_z);
+    mc.gravity = Vec(m->gravity_x, m->gravity_y, m->gravity_z);
+    mc.carWorldFriction = m->car_world_friction; mc.carWorldRestitution = m->car_world_restitution; mc.ballWorldFriction = m->ball_world_friction; mc.ballWorldRestitution = m->ball_world_restitution;
     mc.boostAccelGround = m->boost_accel_ground; mc.boostAccelAir = m->boost_accel_air; mc.boostUsedPerSecond = m->boost_used_per_second;
     mc.jumpAccel = m->jump_accel; mc.jumpImmediateForce = m->jump_immediate_force;
     mc.ballMaxSpeed = m->ball_max_speed; mc.ballDrag = ball_drag;
@@ -847,6 +850,16 @@ extern "C" void ref_setter_samples(int team_size, int kind, int n, RlgpuArenaSta
 // state; the stepper's test mode (RlgpuArenaHidden::ref_engine) draws from the same state with the same formulas, so both sides can be compared for
 // equality through respawns and resets.  The engine's state is its last output (minstd_rand0).
 #include <sstream>
+// btCollisionWorld::rayTest with a ClosestRayResultCallback -- what btDefaultVehicleRaycaster::castRay runs for a wheel (btDefaultVehicleRaycaster.cpp:20-51) -- against
+// the arena's static world (park the ball and the cars elsewhere): out4 = closest hit fraction, world normal; returns 1 on a hit.  from / to in Bullet units.
+extern "C" int ref_ray_world(void* h, const float* from3, const float* to3, float* out4) {
+    Arena* a = (Arena*)h;
+    const btVector3 from(from3[0], from3[1], from3[2]), to(to3[0], to3[1], to3[2]);
+    btCollisionWorld::ClosestRayResultCallback cb(from, to, nullptr);
+    a->_bulletWorld.rayTest(from, to, cb);
+    out4[0] = cb.m_closestHitFraction; out4[1] = cb.m_hitNormalWorld.x(); out4[2] = cb.m_hitNormalWorld.y(); out4[3] = cb.m_hitNormalWorld.z();
+    return cb.hasHit() ? 1 : 0;
+}
 extern "C" void ref_seed_engine(unsigned state) { RocketSim::Math::GetRandEngine() = std::default_random_engine(state); }
 extern "C" unsigned ref_engine_state() { std::ostringstream os; os << RocketSim::Math::GetRandEngine(); return (unsigned)std::stoul(os.str()); }
 // `n` resets of one arena by the reference's own setters with the thread's engine started from `engine`: kind 0 RandomState(flags bit 0 ball speed, bit 1

@@ -517,7 +517,7 @@ RLG_HD void car_ray_pair(const Arena<NC>& A, MeshView mesh, const CollideQueue<N
     if (c == CAND_HOLE) return;
     const WheelTmp& w = t.w[i];
     float d;
-    if (ray_triangle_pair(mesh.tris[unpack_cand(c).ref], w.hard_point, w.contact_point, w.susp_len, d)) ray_key_min(ray_keys(t)[i], ray_key(d, slot));
+    if (ray_triangle_pair(mesh.bp, mesh.tris[unpack_cand(c).ref], w.hard_point, w.contact_point, w.susp_len, d)) ray_key_min(ray_keys(t)[i], ray_key(d, slot));
 }
 template <int NC>
 RLG_HD int car_ray_pairs(const Arena<NC>& A, const CollideQueue<NC>& Q, int ci) {

@@ -35,11 +35,16 @@ struct Contact {      // 44 B (LDS-resident on the device: 24..56 of them per en
                       // (creation order, Arena.cpp:1036-1101), 5.. = further mesh objects (mesh_sid; one manifold per .cmf file: Arena.cpp:1028-1054)
     int8_t special;   // ball-world contact: resolved through one averaged row (Arena.cpp:265-273)
 };
-RLG_HD float contact_friction(const Contact& c) {   // m_combinedFriction after the contact-added callback (Arena.cpp:283-427) / btManifoldResult.cpp:56-78
-    return c.b < 0 ? (c.a == 0 ? K::BALL_FRICTION : K::CARWORLD_FRICTION) : (c.b == 0 ? K::CARBALL_FRICTION : K::CARCAR_FRICTION);
+// m_combinedFriction / m_combinedRestitution after the contact-added callback (Arena.cpp:283-427): car-ball and car-car points get RLConst's values, car-world points
+// MutatorConfig's (Arena.cpp:425-426); a ball-world point keeps what btManifoldResult combined from the two bodies (btManifoldResult.cpp:56-78: against a static
+// body the smaller friction and the larger restitution; the arena's bodies have 0.6 / 0.3, Arena.cpp:505-506; the ball's are MutatorConfig's, Arena.cpp:44-45)
+RLG_HD float ball_world_friction(const Mutators& m) { const float a = m.ball_world_friction, b = K::WORLD_FRICTION; return (a < b) ? a : b; }
+RLG_HD float ball_world_restitution(const Mutators& m) { const float a = m.ball_world_restitution, b = K::WORLD_RESTITUTION; return (a > b) ? a : b; }
+RLG_HD float contact_friction(const Contact& c, const Mutators& m) {
+    return c.b < 0 ? (c.a == 0 ? ball_world_friction(m) : m.car_world_friction) : (c.b == 0 ? K::CARBALL_FRICTION : K::CARCAR_FRICTION);
 }
-RLG_HD float contact_restitution(const Contact& c) {
-    return c.b < 0 ? (c.a == 0 ? K::BALL_RESTITUTION : K::CARWORLD_RESTITUTION) : (c.b == 0 ? K::CARBALL_RESTITUTION : K::CARCAR_RESTITUTION);
+RLG_HD float contact_restitution(const Contact& c, const Mutators& m) {
+    return c.b < 0 ? (c.a == 0 ? ball_world_restitution(m) : m.car_world_restitution) : (c.b == 0 ? K::CARBALL_RESTITUTION : K::CARCAR_RESTITUTION);
 }
 
 template <int MAXC>

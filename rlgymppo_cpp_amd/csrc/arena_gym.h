@@ -150,7 +150,7 @@ RLG_HD bool ball_probably_going_in(const Arena<NC>& A, float max_time, int& goal
     float dist = fabsf(bp.y - goal_y);
     float t = dist / fabsf(bv.y);
     if (t > max_time) return false;
-    V3 grav = v3(0, 0, A.mut.gravity_z);   // MutatorConfig::gravity (Arena.cpp:844)
+    V3 grav = v3(A.mut.gravity_x, A.mut.gravity_y, A.mut.gravity_z);   // MutatorConfig::gravity (Arena.cpp:844)
     V3 ex = bp + (bv * t) + vdiv_rs(grav * t * t, 2.f);
     const float HW = 892.755f, GH = 642.775f;
     float margin = K::BALL_RADIUS * 0.1f + 0.f;

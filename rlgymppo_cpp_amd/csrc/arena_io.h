@@ -124,6 +124,7 @@ RLG_HD void arena_visit(Arena<NC>& A, GymEnv<NC>& G, IO& io) {
         io.f(m.gravity_z); io.f(m.boost_accel_ground); io.f(m.boost_accel_air); io.f(m.boost_used_per_second); io.f(m.jump_accel); io.f(m.jump_immediate_force);
         io.f(m.ball_max_speed); io.f(m.ball_damp_per_tick); io.f(m.respawn_delay); io.f(m.bump_cooldown); io.f(m.pad_cooldown_big); io.f(m.pad_cooldown_small);
         io.f(m.spawn_boost); io.f(m.ball_hit_extra_scale); io.f(m.bump_force_scale); io.f(m.goal_threshold_y); io.u(m.flags);
+        io.f(m.gravity_x); io.f(m.gravity_y); io.f(m.car_world_friction); io.f(m.car_world_restitution); io.f(m.ball_world_friction); io.f(m.ball_world_restitution);
     }
 }
 
@@ -175,6 +176,8 @@ RLG_HD Mutators mutators_from_abi(const RlgpuMutators& a) {
     m.respawn_delay = a.respawn_delay; m.bump_cooldown = a.bump_cooldown_time; m.pad_cooldown_big = a.boost_pad_cooldown_big; m.pad_cooldown_small = a.boost_pad_cooldown_small;
     m.spawn_boost = a.car_spawn_boost_amount; m.ball_hit_extra_scale = a.ball_hit_extra_force_scale; m.bump_force_scale = a.bump_force_scale;
     m.goal_threshold_y = a.goal_base_threshold_y; m.flags = a.flags;
+    m.gravity_x = a.gravity_x; m.gravity_y = a.gravity_y; m.car_world_friction = a.car_world_friction; m.car_world_restitution = a.car_world_restitution;
+    m.ball_world_friction = a.ball_world_friction; m.ball_world_restitution = a.ball_world_restitution;
     return m;
 }
 RLG_HD RlgpuMutators mutators_to_abi(const Mutators& m) {
@@ -184,6 +187,8 @@ RLG_HD RlgpuMutators mutators_to_abi(const Mutators& m) {
     a.respawn_delay = m.respawn_delay; a.bump_cooldown_time = m.bump_cooldown; a.boost_pad_cooldown_big = m.pad_cooldown_big; a.boost_pad_cooldown_small = m.pad_cooldown_small;
     a.car_spawn_boost_amount = m.spawn_boost; a.ball_hit_extra_force_scale = m.ball_hit_extra_scale; a.bump_force_scale = m.bump_force_scale;
     a.goal_base_threshold_y = m.goal_threshold_y; a.flags = m.flags; a._pad = 0u;
+    a.gravity_x = m.gravity_x; a.gravity_y = m.gravity_y; a.car_world_friction = m.car_world_friction; a.car_world_restitution = m.car_world_restitution;
+    a.ball_world_friction = m.ball_world_friction; a.ball_world_restitution = m.ball_world_restitution;
     return a;
 }
 

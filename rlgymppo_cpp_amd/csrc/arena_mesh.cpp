@@ -113,10 +113,11 @@ struct QTree {
 
 // One mesh object: the reference's tree over triangles [t0, t0 + n) of `src`; appends them to `out` in visiting order and this repo's
 // nodes to `bn` (the reference's tree cut off where a subtree holds <= 4 triangles, children in visiting order).  Returns the root.
-int build_part(const std::vector<MeshTri>& src, int t0, int n, std::vector<MeshTri>& out, std::vector<BuildNode>& bn, std::vector<int>* visit_order) {
+int build_part(const std::vector<MeshTri>& src, int t0, int n, std::vector<MeshTri>& out, std::vector<BuildNode>& bn, std::vector<int>* visit_order, std::vector<float>* frames) {
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int i = t0; i < t0 + n; i++) { float mn[3], mx[3]; tri_bounds(src[i], mn, mx); for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], mn[a]); hi[a] = std::max(hi[a], mx[a]); } }
     QBvhFrame F; F.set(lo, hi);
+    if (frames) for (int a = 0; a < 9; a++) frames->push_back(a < 3 ? F.mn[a] : (a < 6 ? F.mx[a - 3] : F.q[a - 6]));   // the object's quantization frame (MESH_FRAME_WORDS)
     std::vector<QLeaf> L(n);
     for (int i = 0; i < n; i++) {
         float mn[3], mx[3]; tri_bounds(src[t0 + i], mn, mx);
@@ -191,6 +192,7 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
     bn.reserve(2 * n_tris + 64);
     int root = -1;
     std::vector<int> part_n, part_of(n_tris, 0), part_first;
+    std::vector<float> frames;   // per mesh object: its btOptimizedBvh's quantization frame (bvhAabbMin, bvhAabbMax, bvhQuantization)
     if (n_tris > 0) {
         std::vector<MeshTri> ordered; ordered.reserve(n_tris);
         std::vector<int> src_of; src_of.reserve(n_tris);
@@ -202,7 +204,7 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             const int c = part_n[k];
             part_first.push_back(t0);
             for (int i = t0; i < t0 + c; i++) part_of[i] = (int)k;
-            roots.push_back(build_part(m.tris, t0, c, ordered, bn, &src_of)); t0 += c;
+            roots.push_back(build_part(m.tris, t0, c, ordered, bn, &src_of, &frames)); t0 += c;
         }
         while (roots.size() > 1) {
             std::vector<int> up;
@@ -351,6 +353,11 @@ HostMesh build_host_mesh(const float* verts_uu, int n_verts, const int32_t* tris
             }
             for (int a = 0; a < 3; a++) { memcpy(&boxes[o * 6 + a], &lo[a], 4); memcpy(&boxes[o * 6 + 3 + a], &hi[a], 4); }
         }
+        // ... and behind the cell masks, per mesh object (ALL of them, by MeshTri::obj) the quantization frame of its btOptimizedBvh: what a ray needs to know
+        // whether Bullet's tree walk would have reached a triangle's leaf at all (arena_world.h ray_leaf_admits)
+        const size_t at = m.grid.size();
+        m.grid.resize(at + frames.size(), 0u);
+        if (!frames.empty()) memcpy(&m.grid[at], frames.data(), 4 * frames.size());
     }
     if (n_tris == 0) return m;
     // breadth-first renumbering with sibling pairs adjacent

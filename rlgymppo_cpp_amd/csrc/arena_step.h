@@ -926,10 +926,10 @@ RLG_HD void world_step_begin(Arena<NC>& A, TickWork<NC, BIG>& W) {
     const bool ball_asleep = W.ball_asleep;
     W.needs_big = 0;
     // applyGravity (btDiscreteDynamicsWorld.cpp:265-276): active bodies only
-    const float g = A.mut.gravity_z * UU2BT;   // MutatorConfig::gravity (Arena.cpp:25: btDynamicsWorld::setGravity)
+    const V3 g = v3(A.mut.gravity_x, A.mut.gravity_y, A.mut.gravity_z) * UU2BT;   // MutatorConfig::gravity (Arena.cpp:25: btDynamicsWorld::setGravity)
     // btRigidBody::setGravity keeps acceleration * (1 / m_inverseMass) (btRigidBody.cpp:132-139): not quite mass * g in float
-    if (!ball_asleep) A.ball.b.force += v3(0, 0, g * (1.0f / BALL_INV_MASS));
-    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += v3(0, 0, g * (1.0f / CAR_INV_MASS));
+    if (!ball_asleep) A.ball.b.force += g * (1.0f / BALL_INV_MASS);
+    for (int i = 0; i < NC; i++) if (!A.cars[i].frozen) A.cars[i].b.force += g * (1.0f / CAR_INV_MASS);
     // predictUnconstraintMotion: damping (btRigidBody.cpp:153-165); car damping is 0 -> pow(1,dt) = 1
     A.ball.b.vel *= A.mut.ball_damp_per_tick;   // btPow(1 - linearDamping, timeStep), linearDamping = MutatorConfig::ballDrag (Arena.cpp:46)
 }
@@ -996,7 +996,7 @@ RLG_HD_MID void solver_prepare(Arena<NC>& A, MeshView mesh, TickEvents& ev, Tick
         float distance = sp_dist / (float)n_special;
         V3 normal = vdiv_bt(sp_normal, (float)n_special);
         spc.a = 0; spc.b = -1; spc.sid = 0; spc.special = 0; spc.n = normal; spc.dist = distance; spc.ra = normal * -distance; spc.rb = v3(0, 0, 0);
-        row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, K::BALL_FRICTION, K::BALL_RESTITUTION, false);
+        row_setup_normal(R[n_contact_rows], spc, B, spc.n, spc.ra, spc.rb, spc.dist, ball_world_friction(A.mut), ball_world_restitution(A.mut), false);
         row_setup_friction(R[nr], n_contact_rows, R[n_contact_rows], B, spc.n, spc.ra, spc.rb, false);
         nr++;
     }
@@ -1033,11 +1033,11 @@ RLG_HD_SMALL void solver_body_contacts(Arena<NC>& A, MeshView mesh, TickWork<NC,
 }
 
 template <int NC, int BIG>
-RLG_HD void solver_rows(TickWork<NC, BIG>& W, int k) {
+RLG_HD void solver_rows(const Mutators& mut, TickWork<NC, BIG>& W, int k) {
     const Contact& c = W.L.c[W.cidx[k]];
     const int ni = W.nrow[k];
     if (ni < 0) return;
-    row_setup_normal(W.R[ni], c, W.B, c.n, c.ra, c.rb, c.dist, contact_friction(c), contact_restitution(c), c.b >= 0);
+    row_setup_normal(W.R[ni], c, W.B, c.n, c.ra, c.rb, c.dist, contact_friction(c, mut), contact_restitution(c, mut), c.b >= 0);
     if (c.special) W.R[ni].skip = 1;
     const int fi = W.frow[k];
     if (fi >= 0) row_setup_friction(W.R[fi], ni, W.R[ni], W.B, c.n, c.ra, c.rb, c.b >= 0);
@@ -1150,7 +1150,7 @@ RLG_HD_NOINLINE void world_step_finish_big(Arena<NC>& A, MeshView mesh, TickEven
     for (int body = 0; body <= NC; body++) solver_body_setup(A, Wb, body);
     solver_prepare(A, mesh, ev, Wb, false);
     if (!fits || Wb.needs_big) RLG_DBG_COUNT(7);   // (not reachable: the big layout has room for whatever the mesh format can describe)
-    for (int k = 0; k < Wb.L.n; k++) solver_rows(Wb, k);
+    for (int k = 0; k < Wb.L.n; k++) solver_rows(A.mut, Wb, k);
     solver_iterate(Wb);
     for (int body = 0; body <= NC; body++) solver_finish(A, Wb, body);
 }
@@ -1175,7 +1175,7 @@ RLG_HD void world_step_finish(Arena<NC>& A, MeshView mesh, TickEvents& ev, TickW
             return;
         }
     }
-    for (int k = 0; k < W.L.n; k++) solver_rows(W, k);
+    for (int k = 0; k < W.L.n; k++) solver_rows(A.mut, W, k);
     solver_iterate(W);
     for (int body = 0; body <= NC; body++) solver_finish(A, W, body);
     RLG_PROF(5);

@@ -257,9 +257,9 @@ struct MeshView {
 };
 
 // ---- MutatorConfig (RocketSim MutatorConfig.h:18-75), the part the stepper takes at run time: the scalars that change no collision shape, no mass and no
-// material (gravity along z, the boost / jump / ball-speed numbers, the timers, the demolition rules, the goal line).  One copy per env, part of its state
-// (RlgpuArenaState::mutators): read where the reference reads _mutatorConfig, so no register is held for it between uses.  Car / ball mass, the ball's
-// radius, friction and restitution stay compiled in (the facade refuses non-default values for those: include/RLGymSim_CPP/RocketSim/Arena.h).
+// mass (gravity, the boost / jump / ball-speed numbers, the timers, the demolition rules, the goal line, the world friction / restitution values).  One copy per env, part of its state
+// (RlgpuArenaState::mutators): read where the reference reads _mutatorConfig, so no register is held for it between uses.  Car / ball mass and the ball's
+// radius stay compiled in (the facade refuses non-default values for those: include/RLGymSim_CPP/RocketSim/Arena.h).
 struct Mutators {
     float gravity_z;                 // uu/s^2
     float boost_accel_ground, boost_accel_air, boost_used_per_second;
@@ -270,16 +270,21 @@ struct Mutators {
     float spawn_boost;               // carSpawnBoostAmount
     float ball_hit_extra_scale, bump_force_scale;
     float goal_threshold_y;          // goalBaseThresholdY
+    float gravity_x, gravity_y;      // uu/s^2 (a sideways gravity: the same two body forces, Arena.cpp:25)
+    float car_world_friction, car_world_restitution;     // the car-world manifold points' combined values (Arena.cpp:425-426)
+    float ball_world_friction, ball_world_restitution;   // the ball body's own values: against the static world they combine as min(f, 0.6) / max(r, 0.3) (btManifoldResult.cpp:56-78, Arena.cpp:505-506)
     uint32_t flags;                  // MUT_*
 };
 constexpr uint32_t MUT_UNLIMITED_FLIPS = 1u, MUT_UNLIMITED_DOUBLE_JUMPS = 2u, MUT_DEMO_ON_CONTACT = 4u, MUT_DEMO_DISABLED = 8u, MUT_TEAM_DEMOS = 16u;
-constexpr int MUTATOR_WORDS = 17;
+constexpr int MUTATOR_WORDS = 23;
 RLG_HD Mutators mutators_default() {
     Mutators m;
     m.gravity_z = K::GRAVITY_Z; m.boost_accel_ground = K::BOOST_ACCEL_GROUND; m.boost_accel_air = K::BOOST_ACCEL_AIR; m.boost_used_per_second = K::BOOST_USED_PER_SECOND;
     m.jump_accel = K::JUMP_ACCEL; m.jump_immediate_force = K::JUMP_IMMEDIATE_FORCE; m.ball_max_speed = K::BALL_MAX_SPEED; m.ball_damp_per_tick = K::BALL_DAMP_PER_TICK;
     m.respawn_delay = K::DEMO_RESPAWN_TIME; m.bump_cooldown = K::BUMP_COOLDOWN_TIME; m.pad_cooldown_big = K::PAD_COOLDOWN_BIG; m.pad_cooldown_small = K::PAD_COOLDOWN_SMALL;
     m.spawn_boost = K::BOOST_SPAWN_AMOUNT; m.ball_hit_extra_scale = 1.f; m.bump_force_scale = 1.f; m.goal_threshold_y = K::GOAL_THRESHOLD_Y; m.flags = 0u;
+    m.gravity_x = 0.f; m.gravity_y = 0.f; m.car_world_friction = K::CARWORLD_FRICTION; m.car_world_restitution = K::CARWORLD_RESTITUTION;
+    m.ball_world_friction = K::BALL_FRICTION; m.ball_world_restitution = K::BALL_RESTITUTION;
     return m;
 }
 

@@ -93,12 +93,16 @@ RLG_HD bool tri_aabb_overlap(const MeshTri& t, V3 lo, V3 hi) {
 RLG_HD bool aabb_overlap(const BvhNode& n, V3 lo, V3 hi) {
     return !(n.minx > hi.x || n.maxx < lo.x || n.miny > hi.y || n.maxy < lo.y || n.minz > hi.z || n.maxz < lo.z);
 }
+// (the node's box grown by RAY_NODE_MARGIN: a ray test accepts hits up to 1e-4 x the triangle's height outside an edge -- 1.2 uu for the tallest wall triangle --
+// and Bullet's own quantized boxes are a few quanta wider than the vertices'; the walk must not cull what ray_leaf_admits is there to decide)
+constexpr float RAY_NODE_MARGIN = 0.05f;
 RLG_HD bool ray_aabb(const BvhNode& n, V3 from, V3 inv_d, float tmax) {
-    float t1 = (n.minx - from.x) * inv_d.x, t2 = (n.maxx - from.x) * inv_d.x;
+    const float m = RAY_NODE_MARGIN;
+    float t1 = ((n.minx - m) - from.x) * inv_d.x, t2 = ((n.maxx + m) - from.x) * inv_d.x;
     float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
-    t1 = (n.miny - from.y) * inv_d.y; t2 = (n.maxy - from.y) * inv_d.y;
+    t1 = ((n.miny - m) - from.y) * inv_d.y; t2 = ((n.maxy + m) - from.y) * inv_d.y;
     tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
-    t1 = (n.minz - from.z) * inv_d.z; t2 = (n.maxz - from.z) * inv_d.z;
+    t1 = ((n.minz - m) - from.z) * inv_d.z; t2 = ((n.maxz + m) - from.z) * inv_d.z;
     tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
     return tf >= fmaxf(tn, 0.f) && tn <= tmax;
 }
@@ -352,7 +356,55 @@ RLG_HD void collide_build_candidates(const Arena<NC>& A, MeshView mesh, bool bal
             if (car_collides(A.cars[ci]) && car_collides(A.cars[ib]) && cars_maybe_touch(A, ci, ib)) queue_pair(Q, ci, ib);
 }
 
-RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best) {
+// Bullet reaches a mesh triangle with a ray only through the triangle's LEAF of the mesh object's quantized tree (btBvhTriangleMeshShape::performRaycast ->
+// btQuantizedBvh::walkStacklessQuantizedTreeAgainstRay, btQuantizedBvh.cpp:531-650): the quantized box of the ray has to overlap the leaf's quantized box, and the
+// ray the dequantized one (btRayAabb2, btAabbUtil2.h:90-130).  A hit INSIDE its triangle passes both by construction; btTriangleRaycastCallback also accepts a
+// hit up to 1e-4 |n|^2 OUTSIDE an edge (edge_tolerance), and such a hit counts only if the walk got to the leaf -- next to an open edge (a goal mouth's post) it
+// may not have, and the ray goes on to what is behind.  Found in round 6 by the mutator fixture's `M2/cannon` tape (a wheel ray 0.19 uu beside the back wall's
+// edge at the goal post; before, the tolerance alone decided).  `frame`: the object's bvhAabbMin, bvhAabbMax, bvhQuantization (arena_mesh.cpp QBvhFrame).
+RLG_HD_COLD bool ray_leaf_admits(const float* frame, V3 v0, V3 v1, V3 v2, V3 from, V3 to) {
+    const float fmn[3] = {frame[0], frame[1], frame[2]}, fmx[3] = {frame[3], frame[4], frame[5]}, fq[3] = {frame[6], frame[7], frame[8]};
+    // the leaf's box as btOptimizedBvh::build made it (btOptimizedBvh.cpp:95-123): the vertices' box, a flat side widened, quantized outwards
+    float mn[3] = {fminf(fminf(v0.x, v1.x), v2.x), fminf(fminf(v0.y, v1.y), v2.y), fminf(fminf(v0.z, v1.z), v2.z)};
+    float mx[3] = {fmaxf(fmaxf(v0.x, v1.x), v2.x), fmaxf(fmaxf(v0.y, v1.y), v2.y), fmaxf(fmaxf(v0.z, v1.z), v2.z)};
+    uint16_t lmn[3], lmx[3], rmn[3], rmx[3];
+    const float rlo[3] = {fminf(from.x, to.x), fminf(from.y, to.y), fminf(from.z, to.z)}, rhi[3] = {fmaxf(from.x, to.x), fmaxf(from.y, to.y), fmaxf(from.z, to.z)};
+    for (int a = 0; a < 3; a++) {
+        if (mx[a] - mn[a] < 0.002f) { mx[a] = mx[a] + 0.001f; mn[a] = mn[a] - 0.001f; }
+        lmn[a] = (uint16_t)(((uint16_t)((mn[a] - fmn[a]) * fq[a])) & 0xfffe);                 // quantize(.., isMax = 0 / 1), btQuantizedBvh.h:331-358
+        lmx[a] = (uint16_t)(((uint16_t)((mx[a] - fmn[a]) * fq[a] + 1.f)) | 1);
+        const float clo = fminf(fmaxf(rlo[a], fmn[a]), fmx[a]), chi = fminf(fmaxf(rhi[a], fmn[a]), fmx[a]);   // quantizeWithClamp
+        rmn[a] = (uint16_t)(((uint16_t)((clo - fmn[a]) * fq[a])) & 0xfffe);
+        rmx[a] = (uint16_t)(((uint16_t)((chi - fmn[a]) * fq[a] + 1.f)) | 1);
+    }
+    for (int a = 0; a < 3; a++) if (!(rmn[a] <= lmx[a] && rmx[a] >= lmn[a])) return false;      // testQuantizedAabbAgainstQuantizedAabb
+    float b0[3], b1[3];
+    for (int a = 0; a < 3; a++) { float v = (float)lmn[a] / fq[a]; v += fmn[a]; b0[a] = v; float w = (float)lmx[a] / fq[a]; w += fmn[a]; b1[a] = w; }   // unQuantize
+    const V3 seg = to - from;
+    const V3 dir = safe_normalized(seg);
+    const float lambda_max = dot(dir, seg);
+    const float inv[3] = {dir.x == 0.f ? 1e18f : 1.0f / dir.x, dir.y == 0.f ? 1e18f : 1.0f / dir.y, dir.z == 0.f ? 1e18f : 1.0f / dir.z};   // BT_LARGE_FLOAT
+    const float src[3] = {from.x, from.y, from.z};
+    // btRayAabb2 with lambda_min = 0
+    float tmin = ((inv[0] < 0.f ? b1[0] : b0[0]) - src[0]) * inv[0], tmax = ((inv[0] < 0.f ? b0[0] : b1[0]) - src[0]) * inv[0];
+    const float tymin = ((inv[1] < 0.f ? b1[1] : b0[1]) - src[1]) * inv[1], tymax = ((inv[1] < 0.f ? b0[1] : b1[1]) - src[1]) * inv[1];
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    const float tzmin = ((inv[2] < 0.f ? b1[2] : b0[2]) - src[2]) * inv[2], tzmax = ((inv[2] < 0.f ? b0[2] : b1[2]) - src[2]) * inv[2];
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return (tmin < lambda_max) && (tmax > 0.f);
+}
+// the frame of mesh object `obj`: behind the broadphase blob (arena_mesh.cpp)
+RLG_HD const float* mesh_leaf_frame(const uint32_t* bp, uint32_t obj) {
+    const uint32_t n_obj = bp[0];
+    return reinterpret_cast<const float*>(bp + 1 + (size_t)n_obj * 6 + (size_t)(BP_CELLS_X * BP_CELLS_Y * BP_CELLS_Z) + (size_t)obj * 9);
+}
+
+// bp / tri: a MESH triangle's ray test (null for the static planes' two triangles, which no tree stands in front of)
+RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best, const uint32_t* bp = nullptr, const MeshTri* tri = nullptr) {
     V3 v10 = v1 - v0, v20 = v2 - v0;
     V3 tn = cross(v10, v20);
     float dist = dot(v0, tn);
@@ -365,10 +417,15 @@ RLG_HD void ray_triangle(V3 v0, V3 v1, V3 v2, V3 from, V3 to, RayHit& best) {
         float s = 1.f - d;
         V3 p = v3(s * from.x + d * to.x, s * from.y + d * to.y, s * from.z + d * to.z);
         V3 v0p = v0 - p, v1p = v1 - p;
-        if (dot(cross(v0p, v1p), tn) >= edge_tol) {
+        const float e0 = dot(cross(v0p, v1p), tn);
+        if (e0 >= edge_tol) {
             V3 v2p = v2 - p;
-            if (dot(cross(v1p, v2p), tn) >= edge_tol) {
-                if (dot(cross(v2p, v0p), tn) >= edge_tol) {
+            const float e1 = dot(cross(v1p, v2p), tn);
+            if (e1 >= edge_tol) {
+                const float e2 = dot(cross(v2p, v0p), tn);
+                if (e2 >= edge_tol) {
+                    // accepted by the tolerance only, i.e. outside the triangle: did Bullet's tree walk get to this leaf?
+                    if (RLG_UNLIKELY(bp != nullptr && (e0 < 0.f || e1 < 0.f || e2 < 0.f)) && !ray_leaf_admits(mesh_leaf_frame(bp, tri->obj), v0, v1, v2, from, to)) return;
                     V3 nn = normalized(tn);
                     best.frac = d; best.kind = 0;
                     best.normal = (da <= 0.f) ? -nn : nn;
@@ -463,9 +520,9 @@ RLG_HD RayHit ray_planes(V3 from, V3 to) {
 }
 
 // mesh stage, one (ray, triangle) pair: hit closer than `bound`?  (same test as ray_triangle)
-RLG_HD bool ray_triangle_pair(const MeshTri& t, V3 from, V3 to, float bound, float& d_out) {
+RLG_HD bool ray_triangle_pair(const uint32_t* bp, const MeshTri& t, V3 from, V3 to, float bound, float& d_out) {
     RayHit probe; probe.kind = -1; probe.frac = bound; probe.normal = v3(0, 0, 0);
-    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, probe);
+    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, probe, bp, &t);
     d_out = probe.frac;
     return probe.kind == 0;
 }
@@ -484,7 +541,7 @@ RLG_HD void ray_apply_mesh_key(MeshView mesh, const QT& Q, unsigned long long ke
     if (key == RAY_NO_HIT) return;
     const MeshTri& t = mesh.tris[unpack_cand(queue_cand(Q, (int)(uint32_t)key)).ref];
     RayHit h; h.kind = -1; h.frac = best.frac; h.normal = v3(0, 0, 0);
-    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, h);
+    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, h, mesh.bp, &t);
     if (h.kind == 0) best = h;   // recomputed from the winning triangle: same frac, and its ray-facing normal
 }
 // mesh stage without a candidate list (queue overflow): depth-first BVH walk
@@ -501,7 +558,7 @@ RLG_HD_COLD void ray_mesh_walk(MeshView mesh, V3 from, V3 to, RayHit& best) {
             if (cnt > 0) {
                 for (int k = 0; k < cnt; k++) {
                     const MeshTri& t = mesh.tris[nd.left_or_first + k];
-                    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best);
+                    ray_triangle(v3(t.v0x, t.v0y, t.v0z), v3(t.v1x, t.v1y, t.v1z), v3(t.v2x, t.v2y, t.v2z), from, to, best, mesh.bp, &t);
                 }
             } else next = (uint32_t)nd.left_or_first;   // left child first: leaves come out in ascending first-triangle order = the reference's visiting order
         }

@@ -811,7 +811,7 @@ __device__ RLG_TICK_INLINE void arena_tick_wave(unsigned char* lane_mem, int n_v
     wave_sync();
     if (__any(env_lane && Se.W.needs_big != 0)) tick_world_big<NC>(lane_mem, n_valid, mv, ev);   // (contacts beyond the LDS layout: nothing is dropped)
     RLG_FPROF(10); phase_sync(2);
-    if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.W, k);
+    if (grp_lane) for (int k = l_grp, n = Sg.W.L.n; k < n; k += LPE) solver_rows(Sg.A.mut, Sg.W, k);
     wave_sync();
     RLG_FPROF(11); phase_sync(2);
     if (env_lane) solver_iterate(Se.W);

@@ -91,7 +91,8 @@ class Mutators(C.Structure):
     _fields_ = [("gravity_z", f32), ("boost_accel_ground", f32), ("boost_accel_air", f32), ("boost_used_per_second", f32), ("jump_accel", f32), ("jump_immediate_force", f32),
                 ("ball_max_speed", f32), ("ball_damp_per_tick", f32), ("respawn_delay", f32), ("bump_cooldown_time", f32), ("boost_pad_cooldown_big", f32),
                 ("boost_pad_cooldown_small", f32), ("car_spawn_boost_amount", f32), ("ball_hit_extra_force_scale", f32), ("bump_force_scale", f32),
-                ("goal_base_threshold_y", f32), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+                ("goal_base_threshold_y", f32), ("flags", C.c_uint32), ("_pad", C.c_uint32), ("gravity_x", f32), ("gravity_y", f32),
+                ("car_world_friction", f32), ("car_world_restitution", f32), ("ball_world_friction", f32), ("ball_world_restitution", f32)]
 
 
 MUT_UNLIMITED_FLIPS, MUT_UNLIMITED_DOUBLE_JUMPS, MUT_DEMO_ON_CONTACT, MUT_DEMO_DISABLED, MUT_TEAM_DEMOS = 1, 2, 4, 8, 16

@@ -532,7 +532,7 @@ static int StandaloneGym() {
         try { mu->SetMutatorConfig(big); } catch (const std::exception&) { refused = true; }
         CHECK(refused);
         refused = false;
-        MutatorConfig side = mc; side.gravity = Vec(100.f, 0, -650.f);
+        MutatorConfig side = mc; side.carMass = 200.f;
         try { mu->SetMutatorConfig(side); } catch (const std::exception&) { refused = true; }
         CHECK(refused);
         delete mu;

@@ -4,10 +4,10 @@
 Arena::SetMutatorConfig (RocketSim Arena.cpp:15-48) on the live reference's arena (oracle/ref_driver.cpp:ref_arena_set_mutators), then tapes that make every one of
 those scalars matter, recorded every 10 ticks with the thread's random engine set to a known state (respawns draw from it: make_rng_golden.py):
 
-  M1  gravity -325, boost accel x 1.5 (ground) / x 0.6 (air), boost used x 0.5, jump accel x 1.25, immediate jump force x 0.8, ball max speed 2800, ball drag 0.12,
+  M1  gravity (120, -60, -325), car-world friction 0.15 / restitution 0.5, ball friction 0.2 / restitution 0.8, boost accel x 1.5 (ground) / x 0.6 (air), boost used x 0.5, jump accel x 1.25, immediate jump force x 0.8, ball max speed 2800, ball drag 0.12,
       respawn delay 1.5 s, bump cooldown 0.1 s, pad cooldowns 2.5 s / 1 s, spawn boost 61, ball-hit extra force x 1.6, bump force x 2, goal line 5000,
       unlimited flips AND double jumps, demolitions ON_CONTACT, team demolitions on
-  M2  gravity -1000, boost accel x 0.5 / x 1.4, boost used x 2, jump accel x 0.7, immediate x 1.3, ball max speed 8000, ball drag 0, respawn delay 0.5 s, bump cooldown
+  M2  gravity -1000, car-world friction 0.6 / restitution 0.1, ball friction 0.9 / restitution 0.1 (the arena's own 0.6 / 0.3 win: btManifoldResult.cpp:56-78), boost accel x 0.5 / x 1.4, boost used x 2, jump accel x 0.7, immediate x 1.3, ball max speed 8000, ball drag 0, respawn delay 0.5 s, bump cooldown
       0.6 s, pad cooldowns 20 s / 8 s, spawn boost 5, ball-hit extra x 0.25, bump force x 0.4, demolitions DISABLED
 
   tapes per set: `charge` (2v2 head-on charges on full boost, then the hunt: bumps / demolitions / respawns / pads), `hunt3` (3v3 hunt from a kickoff), `spam`
@@ -39,10 +39,12 @@ def mutator_sets():
     m1 = Mutators(gravity_z=-325.0, boost_accel_ground=d["boost_accel_ground"] * 1.5, boost_accel_air=d["boost_accel_air"] * 0.6, boost_used_per_second=d["boost_used_per_second"] * 0.5,
                   jump_accel=d["jump_accel"] * 1.25, jump_immediate_force=d["jump_immediate_force"] * 0.8, ball_max_speed=2800.0, respawn_delay=1.5, bump_cooldown_time=0.1,
                   boost_pad_cooldown_big=2.5, boost_pad_cooldown_small=1.0, car_spawn_boost_amount=61.0, ball_hit_extra_force_scale=1.6, bump_force_scale=2.0, goal_base_threshold_y=5000.0,
+                  gravity_x=120.0, gravity_y=-60.0, car_world_friction=0.15, car_world_restitution=0.5, ball_world_friction=0.2, ball_world_restitution=0.8,
                   flags=MUT_UNLIMITED_FLIPS | MUT_UNLIMITED_DOUBLE_JUMPS | MUT_DEMO_ON_CONTACT | MUT_TEAM_DEMOS)
     m2 = Mutators(gravity_z=-1000.0, boost_accel_ground=d["boost_accel_ground"] * 0.5, boost_accel_air=d["boost_accel_air"] * 1.4, boost_used_per_second=d["boost_used_per_second"] * 2.0,
                   jump_accel=d["jump_accel"] * 0.7, jump_immediate_force=d["jump_immediate_force"] * 1.3, ball_max_speed=8000.0, respawn_delay=0.5, bump_cooldown_time=0.6,
                   boost_pad_cooldown_big=20.0, boost_pad_cooldown_small=8.0, car_spawn_boost_amount=5.0, ball_hit_extra_force_scale=0.25, bump_force_scale=0.4, goal_base_threshold_y=5124.25,
+                  gravity_x=0.0, gravity_y=0.0, car_world_friction=0.6, car_world_restitution=0.1, ball_world_friction=0.9, ball_world_restitution=0.1,
                   flags=MUT_DEMO_DISABLED)
     return [("M1", m1, 0.12), ("M2", m2, 0.0)]
 

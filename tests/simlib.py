@@ -277,7 +277,7 @@ GYM_EXACT_OBS = set()     # (rollouts with bit-equal observations but a last-bit
 GYM_HORIZON = {}
 # the host build's gym test hands the state over in uu after every step (one rounding per step the reference's resident arena does not
 # make): its random 2v2 rollout with hitbox contacts is compared up to here
-GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64, "M1_2v2_random": 80}
+GYM_HORIZON_PORT = {"2v2_padded3_zerosum_random": 64, "M1_2v2_random": 64}
 
 
 def gym_cfg_for_case(team, tick_skip, obs_max_players, reward_kind, no_touch_steps):

@@ -876,7 +876,7 @@ def _mutator_vec(o):
 
 
 def test_port_tapes_under_mutators_equal_the_reference(port_lib):
-    """VERDICT r05 "next" 6, the run-time part of MutatorConfig (RlgpuMutators: gravity, boost / jump numbers, ball max speed and drag, respawn delay, bump cooldown,
+    """VERDICT r05 "next" 6, the run-time part of MutatorConfig (RlgpuMutators: gravity (all three components), the world friction / restitution values, boost / jump numbers, ball max speed and drag, respawn delay, bump cooldown,
     pad cooldowns, spawn boost, ball-hit and bump force scales, goal line, unlimited flips / double jumps, demolition mode, team demolitions).  Ten tapes recorded from
     the real reference after Arena::SetMutatorConfig with two sets in which EVERY one of those fields is off its default (tests/golden/make_mutator_golden.py: 2v2
     charges and a 3v3 hunt with ON_CONTACT team demolitions, short respawn delays and a 61 % spawn tank -- or no demolitions at all --, random-action tapes full of
@@ -906,6 +906,7 @@ def test_port_tapes_under_mutators_equal_the_reference(port_lib):
     (m.gravity_z, m.boost_accel_ground, m.boost_accel_air, m.boost_used_per_second, m.jump_accel, m.jump_immediate_force, m.ball_max_speed) = (-650.0, 2975 / 3.0, 3175 / 3.0, 100 / 3.0, 4375 / 3.0, 875 / 3.0, 6000.0)
     (m.ball_damp_per_tick, m.respawn_delay, m.bump_cooldown_time, m.boost_pad_cooldown_big, m.boost_pad_cooldown_small, m.car_spawn_boost_amount) = (float(np.float32(1 - 0.03) ** np.float32(1 / 120.0)), 3.0, 0.25, 10.0, 4.0, 100 / 3.0)
     (m.ball_hit_extra_force_scale, m.bump_force_scale, m.goal_base_threshold_y, m.flags) = (1.0, 1.0, 5124.25, 0)
+    (m.gravity_x, m.gravity_y, m.car_world_friction, m.car_world_restitution, m.ball_world_friction, m.ball_world_restitution) = (0.0, 0.0, 0.3, 0.3, 0.35, 0.6)
     tape = np.ascontiguousarray(mg["phys/M1/spam1/tape"], np.float32)
     od = (ArenaState * (len(tape) // every))(); oe = (ArenaState * (len(tape) // every))()
     port_lib.lib.port_run_tape(C.byref(d), tape.ctypes.data, len(tape), every, C.byref(od)); port_lib.lib.port_run_tape(C.byref(e), tape.ctypes.data, len(tape), every, C.byref(oe))
