@@ -181,6 +181,9 @@ typedef struct RlgpuArenaHidden {
 #define RLGPU_MUT_DEMO_ON_CONTACT        4u   /* DemoMode::ON_CONTACT */
 #define RLGPU_MUT_DEMO_DISABLED          8u   /* DemoMode::DISABLED (neither bit: NORMAL) */
 #define RLGPU_MUT_TEAM_DEMOS            16u   /* enableTeamDemos */
+#define RLGPU_MUT_RAY_PROXY_LISTS       32u   /* NOT a MutatorConfig field.  Wheel rays are cast against every dynamic body the reference's broadphase lists for the ray's cell
+                                               * (btRSBroadphase.cpp:326-337), not only those whose box the ray comes near: reproduces btSubsimplexConvexCast's occasional hit on a car
+                                               * the ray misses by 20 - 30 uu (32 iterations run out).  Exact, 2.7 - 4.8 % slower; off by default (csrc/arena_world.h ray_ball_and_cars) */
 typedef struct RlgpuMutators {
     float gravity_z;
     float boost_accel_ground, boost_accel_air, boost_used_per_second;

@@ -427,6 +427,34 @@ static void debug_wheels_t(RlgpuArenaState* s, int slot, float* out) {
         o[10] = wt.hard_point.z; o[11] = len(wt.impulse);
     }
 }
+// the suspension rays car `slot` casts in the state's next tick: per wheel from3, to3 (Bullet units)
+template <int NC>
+static void debug_wheel_rays_t(const RlgpuArenaState* s, int slot, float* out) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    const Car& car = A.cars[slot];
+    const V3 wheel_dir = car.b.rot * v3(0, 0, -1);
+    for (int i = 0; i < 4; i++) {
+        const V3 from = (car.b.rot * wheel_conn(i)) + car.b.pos, to = from + wheel_dir * wheel_ray_len(i);
+        float* o = out + 6 * i; o[0] = from.x; o[1] = from.y; o[2] = from.z; o[3] = to.x; o[4] = to.y; o[5] = to.z;
+    }
+}
+extern "C" void port_debug_wheel_rays(const RlgpuArenaState* s, int slot, float* out) {
+    if (s->num_cars == 2) debug_wheel_rays_t<2>(s, slot, out); else if (s->num_cars == 4) debug_wheel_rays_t<4>(s, slot, out); else debug_wheel_rays_t<6>(s, slot, out);
+}
+// the dynamic stage of a wheel ray (ball, other cars) on the state as it stands: out5 = kind, fraction, normal
+template <int NC>
+static void debug_ray_dynamic_t(const RlgpuArenaState* s, int self_car, const float* from3, const float* to3, float* out) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    RayHit best; best.kind = -1; best.frac = 1.f; best.normal = v3(0, 0, 0);
+    ray_ball_and_cars(A, self_car, v3(from3[0], from3[1], from3[2]), v3(to3[0], to3[1], to3[2]), best);
+    out[0] = (float)best.kind; out[1] = best.frac; out[2] = best.normal.x; out[3] = best.normal.y; out[4] = best.normal.z;
+    for (int k = 0; k < NC; k++) out[5 + k] = (float)((A.cars[k].frozen ? 1 : 0) | ((A.cars[k].flags & CF_IS_DEMOED) ? 2 : 0));
+}
+extern "C" void port_debug_ray_dynamic(const RlgpuArenaState* s, int self_car, const float* from3, const float* to3, float* out) {
+    if (s->num_cars == 2) debug_ray_dynamic_t<2>(s, self_car, from3, to3, out); else if (s->num_cars == 4) debug_ray_dynamic_t<4>(s, self_car, from3, to3, out); else debug_ray_dynamic_t<6>(s, self_car, from3, to3, out);
+}
 extern "C" void port_debug_wheels(RlgpuArenaState* s, int slot, float* out) {
     if (s->num_cars == 2) debug_wheels_t<2>(s, slot, out); else if (s->num_cars == 4) debug_wheels_t<4>(s, slot, out); else debug_wheels_t<6>(s, slot, out);
 }

@@ -276,6 +276,7 @@ struct Mutators {
     uint32_t flags;                  // MUT_*
 };
 constexpr uint32_t MUT_UNLIMITED_FLIPS = 1u, MUT_UNLIMITED_DOUBLE_JUMPS = 2u, MUT_DEMO_ON_CONTACT = 4u, MUT_DEMO_DISABLED = 8u, MUT_TEAM_DEMOS = 16u;
+constexpr uint32_t MUT_RAY_PROXY_LISTS = 32u;   // not a MutatorConfig field: wheel rays are cast against every dynamic proxy the reference's broadphase lists for them (arena_world.h ray_ball_and_cars)
 constexpr int MUTATOR_WORDS = 23;
 RLG_HD Mutators mutators_default() {
     Mutators m;

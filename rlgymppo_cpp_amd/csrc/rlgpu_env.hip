@@ -1683,7 +1683,7 @@ void rlgpu_default_mutators(RlgpuMutators* m) { *m = mutators_to_abi(mutators_de
 float rlgpu_ball_damp_per_tick(float ball_drag) { return powf(1.0f - ball_drag, TICK_DT); }   // btRigidBody::applyDamping's factor, by the host's C library
 int rlgpu_env_set_mutators(rlgpu_env* e, const RlgpuMutators* m) {
     if (!m) { e->err = "rlgpu_env_set_mutators: null"; return RLGPU_ERR_ARG; }
-    if (!(m->ball_damp_per_tick > 0.f && m->ball_damp_per_tick <= 1.f) || !(m->ball_max_speed >= 0.f) || (m->flags & ~31u) ||
+    if (!(m->ball_damp_per_tick > 0.f && m->ball_damp_per_tick <= 1.f) || !(m->ball_max_speed >= 0.f) || (m->flags & ~63u) ||
         ((m->flags & RLGPU_MUT_DEMO_ON_CONTACT) && (m->flags & RLGPU_MUT_DEMO_DISABLED))) {
         e->err = "rlgpu_env_set_mutators: ball_damp_per_tick must be in (0, 1] (rlgpu_ball_damp_per_tick(ballDrag)), ball_max_speed >= 0, flags a combination of RLGPU_MUT_* with at most one demo mode";
         return RLGPU_ERR_ARG;

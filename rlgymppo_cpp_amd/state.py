@@ -95,7 +95,7 @@ class Mutators(C.Structure):
                 ("car_world_friction", f32), ("car_world_restitution", f32), ("ball_world_friction", f32), ("ball_world_restitution", f32)]
 
 
-MUT_UNLIMITED_FLIPS, MUT_UNLIMITED_DOUBLE_JUMPS, MUT_DEMO_ON_CONTACT, MUT_DEMO_DISABLED, MUT_TEAM_DEMOS = 1, 2, 4, 8, 16
+MUT_UNLIMITED_FLIPS, MUT_UNLIMITED_DOUBLE_JUMPS, MUT_DEMO_ON_CONTACT, MUT_DEMO_DISABLED, MUT_TEAM_DEMOS, MUT_RAY_PROXY_LISTS = 1, 2, 4, 8, 16, 32
 
 
 IDENTITY9 = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)

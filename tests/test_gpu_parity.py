@@ -462,6 +462,29 @@ def test_hip_tapes_through_respawns_equal_the_reference():
     assert compared >= 5500, compared
 
 
+def test_hip_stress_tapes_of_round_6_equal_the_reference():
+    """Round 6 on the GPU: tests/golden/edge_golden.npz -- the 3v3 wall-play tape in which a wheel ray ends ON the side wall's plane at tick 360 (the plane's two
+    triangles decide such a ray, not an analytic sign test: csrc/arena_world.h ray_planes), and the two aerial tapes in which a wheel gets the convex cast's
+    far "hit" on a car it does not touch (RLGPU_MUT_RAY_PROXY_LISTS in their start states: ray_ball_and_cars) -- EQUAL to the reference every 10 ticks over their
+    whole length."""
+    from rlgymppo_cpp_amd.env import BatchedEnv
+    from simlib import state_vec
+    eg = np.load(os.path.join(GOLD, "edge_golden.npz")); sgm = np.load(os.path.join(GOLD, "sim_golden.npz")); every = int(eg["every"])
+    for name in [str(x) for x in eg["phys_names"]]:
+        st = ArenaState.from_buffer_copy(eg[f"phys/{name}/start_raw"].tobytes()); nc = st.num_cars
+        env = BatchedEnv(1, nc // 2, mesh=(sgm["mesh_verts"], sgm["mesh_tris"]))
+        env.upload_states([st])
+        tape = eg[f"phys/{name}/tape"]
+        for t in range(len(tape)):
+            env.set_controls(np.ascontiguousarray(tape[t][None], np.float32))
+            env.physics_ticks(1)
+            if (t + 1) % every == 0:
+                cur = env.download_states()[0]; j = (t + 1) // every - 1
+                assert np.array_equal(state_vec(cur), eg[f"phys/{name}/states"][j]), f"{name} tick {t + 1}: HIP state is not the reference's"
+                assert cur.hidden.ref_engine == int(eg[f"phys/{name}/engines"][j])
+        env.close()
+
+
 def test_hip_tapes_under_mutators_equal_the_reference():
     """VERDICT r05 "next" 6 on the GPU: the ten tapes of tests/golden/mutator_golden.npz (the reference under two MutatorConfigs in which every run-time field is
     off its default) as envs of a batch -- each env's block arrives with its start state (RlgpuArenaState::mutators), and a second batch gets one set through

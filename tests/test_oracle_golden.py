@@ -870,6 +870,34 @@ def test_port_tapes_through_respawns_equal_the_reference(port_lib):
     assert respawns >= 17 and ticks >= 5500, (respawns, ticks)
 
 
+def test_port_stress_tapes_of_round_6_equal_the_reference(port_lib):
+    """Round 6, tests/golden/edge_golden.npz (make_edge_golden.py).  (1) `walls_9044`: a 3v3 wall-play tape of the live reference -- cars started on walls, beside goal posts and on the
+    ceiling, random controls -- in which, at tick 360, a wheel ray's END point lies on the side wall's plane to the last bit.  An analytic sign test drops that
+    ray; the two triangles btStaticPlaneShape::processAllTriangles spans report a hit at fraction ~1 and Bullet takes it.  The host build equals the recording
+    in every field of every body every 10 ticks over all 400 ticks (csrc/arena_world.h ray_planes; with -DRLG_TEST_ANALYTIC_PLANE_SIGN it leaves at tick 360).
+    (2) `aerial_30118`, `aerial_80656`, `aerial_80142` (2v2, 2v2, 1v1): cars tumbling around the ball; somewhere in the tape a wheel ray gets btSubsimplexConvexCast's "hit" on a car it passes 20 - 30 uu away
+    from -- the cast's 32 iterations run out -- which the reference sees because its broadphase hands a short ray every dynamic proxy on the ray cell's list.  With
+    RLGPU_MUT_RAY_PROXY_LISTS (set in the recorded start states) the stepper casts against the same bodies and equals the recording over the whole tapes; WITHOUT
+    it -- the product's default, 2.7 % faster: the ray's box against the body's decides -- it has left both by their end, which is asserted too, so that the
+    default's one known difference stays on record."""
+    import ctypes as C
+    eg = np.load(os.path.join(GOLD, "edge_golden.npz")); every = int(eg["every"])
+    port_lib.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for name in [str(x) for x in eg["phys_names"]]:
+        st = ArenaState.from_buffer_copy(eg[f"phys/{name}/start_raw"].tobytes())
+        tape = np.ascontiguousarray(eg[f"phys/{name}/tape"], np.float32); want = eg[f"phys/{name}/states"]; engines = eg[f"phys/{name}/engines"]
+        outs = (ArenaState * (len(tape) // every))()
+        port_lib.lib.port_run_tape(C.byref(st), tape.ctypes.data, len(tape), every, C.byref(outs))
+        for j in range(len(tape) // every):
+            assert np.array_equal(state_vec(outs[j]), want[j]), f"{name} tick {(j + 1) * every}: not the reference's state"
+            assert outs[j].hidden.ref_engine == int(engines[j])
+        if name.startswith("aerial_"):      # the default build drops the artefact: the same tape without the switch has parted from the reference by the end
+            off = ArenaState.from_buffer_copy(eg[f"phys/{name}/start_raw"].tobytes()); assert off.mutators.flags & 32; off.mutators.flags &= ~32
+            o2 = (ArenaState * (len(tape) // every))()
+            port_lib.lib.port_run_tape(C.byref(off), tape.ctypes.data, len(tape), every, C.byref(o2))
+            assert not np.array_equal(state_vec(o2[-1]), want[-1]), f"{name}: the box test alone was expected to miss the cast's far hit"
+
+
 def _mutator_vec(o):
     from simlib import state_vec
     return np.concatenate([state_vec(o), [float(o.pads[p].is_active) for p in range(34)], [o.pads[p].cooldown for p in range(34)]])

@@ -3,7 +3,7 @@
 car-ball, car-car and wall contacts, bumps and demolitions all occur -- compared in BULLET units after every tick, like
 tools/raw_divergence.py.  With a fourth argument the live arena's car set is rehashed per tape (ref_arena_rehash), so the reference visits its
 cars in a different order from tape to tape; with a fifth ("hunt") every car boosts at the nearest opponent, steering by the reference's
-state of the tick before (demolitions, wrecks, respawns).          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash|-] [hunt]"""
+state of the tick before (demolitions, wrecks, respawns); with "walls" every car starts on a wall, beside or above a goal, or on the ceiling, at speed.\n          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash|-] [hunt|walls|aerial|corners]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,14 +26,61 @@ for seed in range(seed0, seed0 + n_tapes):
     team = 1 + seed % 3; nc = 2 * team
     k0 = ref.arena(team); ref.lib.ref_arena_reset_kickoff(k0, seed); s0 = ref.get_state(k0); ref.lib.ref_arena_free(k0)
     a = ref.arena(team)
-    if len(sys.argv) > 5:      # hunt: full tanks -- a demolition needs a SUPERSONIC attacker (Arena.cpp:372-385), which a kickoff's 33 boost does not buy
+    if len(sys.argv) > 5 and sys.argv[5] == "hunt":      # hunt: full tanks -- a demolition needs a SUPERSONIC attacker (Arena.cpp:372-385), which a kickoff's 33 boost does not buy
         for k in range(nc): s0.cars[k].boost = 100.0
+    if len(sys.argv) > 5 and sys.argv[5] == "walls":
+        # wall play (round 6: the kickoff tapes live on the floor; a car beside a goal post on the back wall found the ray-leaf hole): every car starts
+        # ON a side wall, a back wall next to / above the goal or the ceiling (clear of the fillets: a start INSIDE the geometry is not a state the game reaches),
+        # wheels on the surface, at speed, tank full
+        for k in range(nc):
+            kind = rng.randint(5)
+            if kind == 0:   side = rng.choice([-1.0, 1.0]); up = np.array([-side, 0, 0]); pos = np.array([side * (4096 - 17.0), rng.uniform(-3400, 3400), rng.uniform(420, 1600)])
+            elif kind == 1: side = rng.choice([-1.0, 1.0]); up = np.array([0, -side, 0]); pos = np.array([rng.choice([-1.0, 1.0]) * rng.uniform(1100, 2800), side * (5120 - 17.0), rng.uniform(420, 1600)])
+            elif kind == 2: side = rng.choice([-1.0, 1.0]); up = np.array([0, -side, 0]); pos = np.array([rng.choice([-1.0, 1.0]) * rng.uniform(960, 1100), side * (5120 - 17.0), rng.uniform(420, 800)])   # beside a goal post
+            elif kind == 3: up = np.array([0, 0, -1.0]); pos = np.array([rng.uniform(-3000, 3000), rng.uniform(-4000, 4000), 2044 - 17.0])
+            else:           side = rng.choice([-1.0, 1.0]); up = np.array([0, -side, 0]); pos = np.array([rng.uniform(-800, 800), side * (5120 - 17.0), rng.uniform(760, 1600)])   # above the goal mouth
+            t1 = np.cross(up, [0.3, 0.5, 0.8]); t1 /= np.linalg.norm(t1); ang = rng.uniform(0, 2 * np.pi)
+            fwd = np.cos(ang) * t1 + np.sin(ang) * np.cross(up, t1); right = np.cross(up, fwd)
+            c = s0.cars[k]
+            c.pos[:] = [float(x) for x in pos]; c.rot[:] = [float(x) for x in np.concatenate([fwd, right, up])]
+            c.vel[:] = [float(x) for x in fwd * rng.uniform(300, 2200)]; c.ang_vel[:] = [0.0, 0.0, 0.0]; c.boost = 100.0
+        s0.ball.pos[:] = [float(rng.uniform(-3000, 3000)), float(rng.uniform(-4000, 4000)), float(rng.uniform(100, 1800))]
+        s0.ball.vel[:] = [float(x) for x in rng.uniform(-1500, 1500, 3)]
+    if len(sys.argv) > 5 and sys.argv[5] in ("aerial", "corners"):
+        # aerial: every car in the air around the ball, any orientation, spinning, tank full -- air control, flips, ball hits in the air, landings on whatever comes
+        # corners: every car on the floor in a corner region or in front of a goal, heading for the 45-degree wall / the fillets / the goal frame at speed
+        def rand_rot():
+            q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        bp = np.array([rng.uniform(-2500, 2500), rng.uniform(-3500, 3500), rng.uniform(400, 1500)]) if sys.argv[5] == "aerial" else np.array([rng.uniform(-3000, 3000), rng.uniform(-4000, 4000), 93.15])
+        s0.ball.pos[:] = [float(x) for x in bp]; s0.ball.vel[:] = [float(x) for x in rng.uniform(-900, 900, 3) * (1.0 if sys.argv[5] == "aerial" else np.array([1, 1, 0]))]
+        for k in range(nc):
+            c = s0.cars[k]
+            if sys.argv[5] == "aerial":
+                for _ in range(200):      # clear of the other cars (a start with two hitboxes inside one another is not a state the game reaches)
+                    R = rand_rot(); off = rng.normal(size=3); off *= rng.uniform(250, 900) / np.linalg.norm(off); pos = bp + off; pos[2] = min(max(pos[2], 150.0), 1750.0)
+                    if all(np.linalg.norm(pos - np.array(list(s0.cars[j].pos))) > 330.0 for j in range(k)): break
+                c.pos[:] = [float(x) for x in pos]; c.rot[:] = [float(x) for x in np.concatenate([R[:, 0], R[:, 1], R[:, 2]])]
+                c.vel[:] = [float(x) for x in (bp - pos) / np.linalg.norm(bp - pos) * rng.uniform(200, 1800) + rng.uniform(-200, 200, 3)]
+                c.ang_vel[:] = [float(x) for x in rng.uniform(-4.5, 4.5, 3)]; c.flags = c.flags & ~0x1f        # off the ground
+            else:
+                sx, sy = rng.choice([-1.0, 1.0]), rng.choice([-1.0, 1.0])
+                if rng.rand() < 0.6: pos = np.array([sx * rng.uniform(2300, 3300), sy * rng.uniform(3300, 4300), 17.0]); aim = np.array([sx * 4096, sy * 5120, 17.0])      # towards a corner
+                else:                pos = np.array([rng.uniform(-1100, 1100), sy * rng.uniform(3600, 4600), 17.0]); aim = np.array([rng.choice([-1.0, 1.0]) * rng.uniform(700, 1100), sy * 5200, 17.0])   # towards a goal post
+                d = aim - pos; yaw = float(np.arctan2(d[1], d[0])) + rng.uniform(-0.4, 0.4)
+                c.pos[:] = [float(x) for x in pos]; c.rot[:] = [float(np.cos(yaw)), float(np.sin(yaw)), 0.0, float(-np.sin(yaw)), float(np.cos(yaw)), 0.0, 0.0, 0.0, 1.0]
+                c.vel[:] = [float(np.cos(yaw) * v) for v in [rng.uniform(800, 2200)]] + [0.0, 0.0]; c.vel[1] = float(np.sin(yaw) * np.hypot(c.vel[0], 0) / max(abs(np.cos(yaw)), 1e-3)) if False else float(np.sin(yaw) * abs(c.vel[0]) / max(abs(np.cos(yaw)), 0.2))
+                c.ang_vel[:] = [0.0, 0.0, 0.0]
+            c.boost = 100.0
     if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
     ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
     # both sides draw the respawn slots from the same engine state (RlgpuArenaHidden::ref_engine; oracle/ref_driver.cpp:ref_seed_engine): a tape stays
     # comparable through its respawns
     engine0 = 1 + (seed * 2654435761) % 2147483645
     ref.lib.ref_seed_engine(C.c_uint32(engine0)); s0.hidden.valid |= 4; s0.hidden.ref_engine = engine0
+    # parity mode for the wheel rays too (RLGPU_MUT_RAY_PROXY_LISTS, csrc/arena_world.h: every dynamic body on the broadphase's list gets the convex cast, as in the
+    # reference); RT_NO_RAY_LISTS=1 shows what the product's default -- the box test alone -- leaves out
+    if not os.environ.get("RT_NO_RAY_LISTS"): s0.hidden.valid |= 8; s0.mutators.flags |= 32
     tape = np.zeros((ticks, nc, 8), np.float32)
     for k in range(nc):
         t = 0
@@ -43,7 +90,7 @@ for seed in range(seed0, seed0 + n_tapes):
             c[0] = rng.choice([1.0, 1.0, 1.0, -1.0, 0.0]); c[1:5] = rng.choice([-1.0, 0.0, 0.0, 1.0], size=4)
             c[5] = float(rng.rand() < 0.15); c[6] = float(rng.rand() < 0.6); c[7] = float(rng.rand() < 0.1)
             tape[t:t + span, k] = c; t += span
-    hunt = len(sys.argv) > 5
+    hunt = len(sys.argv) > 5 and sys.argv[5] == "hunt"
     raw_r = np.zeros((ticks, 1 + nc, 18), np.float32)
     n_demo = 0; n_resp = 0; was = [False] * nc
     for t in range(ticks):
@@ -77,5 +124,31 @@ for seed in range(seed0, seed0 + n_tapes):
     first = next((t + 1 for t in range(ticks) if (bp[t] != br[t]).any()), None)
     exact += first is None; exact_ticks += (ticks if first is None else first - 1)
     print(f"seed {seed} {team}v{team} order {s0.car_order:x}: " + ("bit-identical for all %d ticks" % ticks if first is None else "first raw difference after tick %d" % first) + (f"  ({demos} car(s) demolished at the end)" if demos else ""), flush=True)
+    if first is not None and os.environ.get("RT_DEBUG"):
+        # where the two part: the first differing body, its wheels and the contact lists of that tick on both sides (re-run from the start: the reference's arena has moved on)
+        t = first - 1; d = np.argwhere(bp[t] != br[t]); body = int(d[0][0])
+        print("   differing (body, field):", d[:8].tolist()); print("   port", raw_p[t][body].tolist()); print("   ref ", raw_r[t][body].tolist())
+        b = ref.arena(team)
+        if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(b, 1 + (seed * 7) % 60)
+        ref.set_state(b, s0); ref.lib.ref_seed_engine(C.c_uint32(engine0))
+        for tt in range(first):
+            for k in range(nc): ref.set_controls(b, k, tape[tt, k])
+            ref.step(b, 1)
+        if body >= 1:
+            w = np.zeros((4, 12), np.float32); ref.lib.ref_debug_wheels(b, body - 1, w.ctypes.data_as(C.c_void_p)); print("   reference wheels of car", body - 1); print(w.round(4))
+        if body >= 1:
+            port.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            s4 = ArenaState.from_buffer_copy(bytes(s0)); o4 = (ArenaState * 1)()
+            if first > 1: port.lib.port_run_tape(C.byref(s4), tape.ctypes.data, first - 1, first - 1, C.byref(o4)); s4 = o4[0]
+            for k in range(nc): s4.cars[k].controls[:] = [float(x) for x in tape[first - 1, k]]
+            w2 = np.zeros((4, 12), np.float32); port.lib.port_debug_wheels(C.byref(s4), body - 1, w2.ctypes.data_as(C.c_void_p)); print("   port wheels (from its own state one tick earlier, handed over in uu)"); print(w2.round(4))
+        buf = np.zeros((64, 16), np.float32); n = ref.lib.ref_debug_manifolds(b, buf.ctypes.data_as(C.c_void_p), 64)
+        print("   reference manifold points (body0, body1, manifold, lifetime | normal | distance, applied):")
+        for i in range(n): print("    ", buf[i, :4], buf[i, 10:13].round(4), buf[i, 13], buf[i, 14])
+        out = np.zeros((64, 16), np.float32); port.lib.port_run_tape_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        s5 = ArenaState.from_buffer_copy(bytes(s0)); n2 = port.lib.port_run_tape_contacts(C.byref(s5), tape.ctypes.data, first, out.ctypes.data_as(C.c_void_p), 64, None, None)
+        print("   port contacts of that tick (a, b, sid, special | normal | distance, applied):")
+        for i in range(n2): print("    ", out[i, :4], out[i, 10:13].round(4), out[i, 13], out[i, 14])
+        ref.lib.ref_arena_free(b)
     ref.lib.ref_arena_free(a)
 print(f"{exact} of {n_tapes} random tapes bit-identical to the live reference over {ticks} ticks; {exact_ticks} ticks compared equal in all")
