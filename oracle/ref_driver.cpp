@@ -28,6 +28,7 @@
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btVoronoiSimplexSolver.h>
 #include <bullet3-3.24/BulletCollision/NarrowPhaseCollision/btGjkEpaPenetrationDepthSolver.h>
 #include <bullet3-3.24/BulletCollision/BroadphaseCollision/btRSBroadphase.h>
+#include <bullet3-3.24/BulletCollision/CollisionDispatch/btSimulationIslandManager.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btInternalEdgeUtility.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionObjectWrapper.h>
 #include <bullet3-3.24/BulletCollision/CollisionDispatch/btCollisionWorld.h>
@@ -679,6 +680,23 @@ extern "C" int ref_debug_manifolds(void* h, float* out, int cap_points) {
             n++;
         }
     }
+    return n;
+}
+
+// The order in which the solver visited the manifolds of the last tick: btSimulationIslandManager::m_islandmanifold as buildAndProcessIslands sorted it and handed it, island
+// by island, to the solver (btSimulationIslandManager.cpp:196-450).  The member is private; the explicit-instantiation idiom below reads it without touching the header.
+// Per manifold 2 floats: body0 kind, body1 kind (BodyKind above).
+namespace {
+struct IslandManifoldsTag { typedef btAlignedObjectArray<btPersistentManifold*> btSimulationIslandManager::*type; friend type get(IslandManifoldsTag); };
+template <class Tag, typename Tag::type M> struct PrivateMember { friend typename Tag::type get(Tag) { return M; } };
+template struct PrivateMember<IslandManifoldsTag, &btSimulationIslandManager::m_islandmanifold>;
+}
+extern "C" int ref_debug_island_order(void* h, float* out, int cap) {
+    Arena* a = (Arena*)h;
+    btSimulationIslandManager* mgr = a->_bulletWorld.getSimulationIslandManager();
+    btAlignedObjectArray<btPersistentManifold*>& arr = mgr->*get(IslandManifoldsTag());
+    int n = 0;
+    for (int i = 0; i < arr.size() && n < cap; i++) { out[2 * n] = BodyKind(arr[i]->getBody0()); out[2 * n + 1] = BodyKind(arr[i]->getBody1()); n++; }
     return n;
 }
 

@@ -833,6 +833,15 @@ RLG_HD_SMALL void bp_history_ranks(Arena<NC>& A, const TickWork<NC, BIG>& W) {
     for (int b = 0; b < NB; b++) A.bp_hist[b] = (uint16_t)((A.bp_hist[b] & ~7u) | (uint32_t)nr[b]);
 }
 
+// three or more cars on the ball in one tick: the callbacks in the order the ball's pairs were made (collide_merge)
+template <int NC, int BIG>
+RLG_HD_COLD void ball_callbacks_by_rank(Arena<NC>& A, TickWork<NC, BIG>& W) {
+    using LY = ContactLayout<NC, BIG>;
+    for (int r = 0; r < NC + 1; r++)
+        for (int ci = 0; ci < NC; ci++)
+            if (W.ball_hit[ci] && (int)(A.bp_hist[1 + ci] & 7u) == r) on_car_ball_contact(A, ci, W.L.c[LY::car_ball_slot(ci)].rb);
+}
+
 // per env: the contact-added callbacks that touch other bodies, the car-car pairs, and the solver order of all contacts.
 // Returns false -- BEFORE any callback has fired or any history has been written -- when the tick's contacts do not fit the layout (a car-car
 // point beyond the pair pool, more contacts than the solver has rows for): the caller redoes the env's world step with the big layout.
@@ -875,7 +884,8 @@ RLG_HD_BIG bool collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W,
         }
     }
     int total = W.body_n[0] + n_pair;
-    for (int ci = 0; ci < NC; ci++) total += (W.ball_hit[ci] ? 1 : 0) + W.body_n[1 + ci];
+    int n_ball = 0;
+    for (int ci = 0; ci < NC; ci++) { const int bh = W.ball_hit[ci] ? 1 : 0; n_ball += bh; total += bh + W.body_n[1 + ci]; }
     if (RLG_UNLIKELY(!fits || total > LY::MAXS)) return false;
     bp_history_ranks(A, W);    // (idempotent for a given set of movers: the big layout's second run files the same ranks)
     // The order of the solver's rows only matters between rows that share a body.  Count, per dynamic body, the manifolds with points
@@ -903,9 +913,14 @@ RLG_HD_BIG bool collide_merge(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W,
     if (max_man >= 2) collide_order<NC, BIG>(A, mesh, W, n_touching);
 #endif
     // ---- from here on the tick is committed to this layout: the contact-added callbacks that touch other bodies ----
-    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision)
-    for (int ci = 0; ci < NC; ci++)
-        if (RLG_UNLIKELY(W.ball_hit[ci])) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[LY::car_ball_slot(ci)].rb); }
+    // ball-touch callbacks in pair order (Arena::_BtCallback_OnCarBallCollision).  Each adds its extra hit velocity to the ball's impulse cache, so from three
+    // touching cars on the ORDER shows in the sum's last bit (two commute): the ball's pairs are made in the order of its cell's dynamic list, i.e. by the cars'
+    // arrival ranks (bp_history_ranks above; btRSBroadphase.cpp:393-469) -- not by slot.  (Round 6, tools/random_tapes.py ... aerial, seeds 70681 / 80921: three
+    // and four cars on the ball in one tick.)
+    if (RLG_UNLIKELY(n_ball >= 3)) { ball_car_touch = true; ball_callbacks_by_rank<NC, BIG>(A, W); }
+    else
+        for (int ci = 0; ci < NC; ci++)
+            if (RLG_UNLIKELY(W.ball_hit[ci])) { ball_car_touch = true; on_car_ball_contact(A, ci, L.c[LY::car_ball_slot(ci)].rb); }
     // ... and the car-car callbacks, pair by pair, point by point (Arena::_BtCallback_OnCarCarCollision(car1 = the manifold's body0 = the higher car,
     // car2): equal user indices, no swap, Arena.cpp:231-240)
     if (RLG_UNLIKELY(n_touching > 0)) for (int t = 0; t < n_touching; t++) {

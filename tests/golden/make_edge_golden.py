@@ -10,6 +10,10 @@
   aerial_30118 / _80656 / _80142   tools/random_tapes.py's `aerial` mode (frozen below), 2v2 / 2v2 / 1v1, 300 ticks: cars tumbling around the ball; at tick 46 (83, 35) a wheel ray gets a
                convex-cast "hit" on a car it passes 20 - 30 uu away from (see main()).  Pinned with RLGPU_MUT_RAY_PROXY_LISTS set in the start state.
 
+  aerial_80921   the same mode, 3v3: at tick 29 FOUR cars touch the ball at once.  Every touch adds its extra hit velocity to the ball's impulse cache
+               (Arena::_BtCallback_OnCarBallCollision), in the order the broadphase made the ball's pairs -- the cars' arrival ranks in its cell's list, not their
+               slots -- and from three terms on the order shows in the sum's last bit (csrc/arena_step.h collide_merge).
+
 Layout as respawn_golden.npz: start state (engine in its hidden block), controls per tick, the reference's state and engine every 10 ticks.
 usage: python tests/golden/make_edge_golden.py      (needs oracle/_ref: make -C oracle ref)
 """
@@ -126,7 +130,7 @@ def main():
     # hands a short ray every dynamic proxy on the ray cell's list (btRSBroadphase.cpp:326-337).  The start states carry RLGPU_MUT_RAY_PROXY_LISTS: with the switch
     # the stepper casts against the same bodies; without it (the product's default: the ray's box against the body's) these tapes leave at ticks 46 / 83 / 35.
     from rlgymppo_cpp_amd.state import HIDDEN_MUTATORS, MUT_RAY_PROXY_LISTS
-    for seed, drawn in ((30118, 400), (80656, 300), (80142, 300)):      # (`drawn`: the tape length the tool was run with when it found the seed -- the draws depend on it)
+    for seed, drawn in ((30118, 400), (80656, 300), (80142, 300), (80921, 300)):      # (the last: four cars on the ball in one tick -- see the file's head)      # (`drawn`: the tape length the tool was run with when it found the seed -- the draws depend on it)
         team, s0, engine0, rehash, tape = aerial_case(ref, seed, drawn)
         tape = tape[:300]
         s0.hidden.valid |= HIDDEN_MUTATORS; s0.mutators.flags |= MUT_RAY_PROXY_LISTS          # (s0 came from ref_arena_get_state: the block holds RLConst's defaults)

@@ -879,7 +879,8 @@ def test_port_stress_tapes_of_round_6_equal_the_reference(port_lib):
     from -- the cast's 32 iterations run out -- which the reference sees because its broadphase hands a short ray every dynamic proxy on the ray cell's list.  With
     RLGPU_MUT_RAY_PROXY_LISTS (set in the recorded start states) the stepper casts against the same bodies and equals the recording over the whole tapes; WITHOUT
     it -- the product's default, 2.7 % faster: the ray's box against the body's decides -- it has left both by their end, which is asserted too, so that the
-    default's one known difference stays on record."""
+    default's one known difference stays on record.  (3) `aerial_80921`: four cars touch the ball in ONE tick (29); their extra hit velocities are summed in the order
+    the broadphase made the ball's pairs (the cars' arrival ranks), which is what the last bit of the ball's velocity shows."""
     import ctypes as C
     eg = np.load(os.path.join(GOLD, "edge_golden.npz")); every = int(eg["every"])
     port_lib.lib.port_run_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -891,7 +892,7 @@ def test_port_stress_tapes_of_round_6_equal_the_reference(port_lib):
         for j in range(len(tape) // every):
             assert np.array_equal(state_vec(outs[j]), want[j]), f"{name} tick {(j + 1) * every}: not the reference's state"
             assert outs[j].hidden.ref_engine == int(engines[j])
-        if name.startswith("aerial_"):      # the default build drops the artefact: the same tape without the switch has parted from the reference by the end
+        if name.startswith("aerial_") and name != "aerial_80921":      # the default build drops the artefact: the same tape without the switch has parted from the reference by the end
             off = ArenaState.from_buffer_copy(eg[f"phys/{name}/start_raw"].tobytes()); assert off.mutators.flags & 32; off.mutators.flags &= ~32
             o2 = (ArenaState * (len(tape) // every))()
             port_lib.lib.port_run_tape(C.byref(off), tape.ctypes.data, len(tape), every, C.byref(o2))

@@ -145,6 +145,8 @@ for seed in range(seed0, seed0 + n_tapes):
         buf = np.zeros((64, 16), np.float32); n = ref.lib.ref_debug_manifolds(b, buf.ctypes.data_as(C.c_void_p), 64)
         print("   reference manifold points (body0, body1, manifold, lifetime | normal | distance, applied):")
         for i in range(n): print("    ", buf[i, :4], buf[i, 10:13].round(4), buf[i, 13], buf[i, 14])
+        io = np.zeros((64, 2), np.float32); ni = ref.lib.ref_debug_island_order(b, io.ctypes.data_as(C.c_void_p), 64)
+        print("   reference: the solver's manifold order (body0, body1):", [tuple(int(x) for x in io[i]) for i in range(ni)])
         out = np.zeros((64, 16), np.float32); port.lib.port_run_tape_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         s5 = ArenaState.from_buffer_copy(bytes(s0)); n2 = port.lib.port_run_tape_contacts(C.byref(s5), tape.ctypes.data, first, out.ctypes.data_as(C.c_void_p), 64, None, None)
         print("   port contacts of that tick (a, b, sid, special | normal | distance, applied):")
