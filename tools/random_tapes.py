@@ -3,7 +3,7 @@
 car-ball, car-car and wall contacts, bumps and demolitions all occur -- compared in BULLET units after every tick, like
 tools/raw_divergence.py.  With a fourth argument the live arena's car set is rehashed per tape (ref_arena_rehash), so the reference visits its
 cars in a different order from tape to tape; with a fifth ("hunt") every car boosts at the nearest opponent, steering by the reference's
-state of the tick before (demolitions, wrecks, respawns); with "walls" every car starts on a wall, beside or above a goal, or on the ceiling, at speed.\n          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash|-] [hunt|walls|aerial|corners]"""
+state of the tick before (demolitions, wrecks, respawns); with "walls" every car starts on a wall, beside or above a goal, or on the ceiling, at speed.\n          usage: random_tapes.py [tapes] [ticks] [first seed] [rehash|-] [hunt|walls|aerial|corners|scrum]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +46,18 @@ for seed in range(seed0, seed0 + n_tapes):
             c.vel[:] = [float(x) for x in fwd * rng.uniform(300, 2200)]; c.ang_vel[:] = [0.0, 0.0, 0.0]; c.boost = 100.0
         s0.ball.pos[:] = [float(rng.uniform(-3000, 3000)), float(rng.uniform(-4000, 4000)), float(rng.uniform(100, 1800))]
         s0.ball.vel[:] = [float(x) for x in rng.uniform(-1500, 1500, 3)]
+    if len(sys.argv) > 5 and sys.argv[5] == "scrum":
+        # every car on the floor in a ring around the ball, facing it, at speed: a pile-up in the first second -- car-car boxes, deep contacts, bumps, several cars
+        # on the ball at once, wheels on roofs
+        cx, cy = rng.uniform(-2500, 2500), rng.uniform(-3500, 3500)
+        s0.ball.pos[:] = [float(cx), float(cy), 93.15]; s0.ball.vel[:] = [0.0, 0.0, 0.0]
+        ang0 = rng.uniform(0, 2 * np.pi)
+        for k in range(nc):
+            a_k = ang0 + 2 * np.pi * k / nc + rng.uniform(-0.25, 0.25); rad = rng.uniform(700, 1300)
+            pos = np.array([cx + rad * np.cos(a_k), cy + rad * np.sin(a_k), 17.0]); yaw = a_k + np.pi + rng.uniform(-0.15, 0.15)
+            c = s0.cars[k]
+            c.pos[:] = [float(x) for x in pos]; c.rot[:] = [float(np.cos(yaw)), float(np.sin(yaw)), 0.0, float(-np.sin(yaw)), float(np.cos(yaw)), 0.0, 0.0, 0.0, 1.0]
+            v = rng.uniform(1200, 2250); c.vel[:] = [float(np.cos(yaw) * v), float(np.sin(yaw) * v), 0.0]; c.ang_vel[:] = [0.0, 0.0, 0.0]; c.boost = 100.0
     if len(sys.argv) > 5 and sys.argv[5] in ("aerial", "corners"):
         # aerial: every car in the air around the ball, any orientation, spinning, tank full -- air control, flips, ball hits in the air, landings on whatever comes
         # corners: every car on the floor in a corner region or in front of a goal, heading for the 45-degree wall / the fillets / the goal frame at speed
@@ -73,7 +85,12 @@ for seed in range(seed0, seed0 + n_tapes):
                 c.ang_vel[:] = [0.0, 0.0, 0.0]
             c.boost = 100.0
     if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
-    ref.set_state(a, s0); s0.car_order = ref.get_state(a).car_order
+    if os.environ.get("RT_MUT"):        # RT_MUT=M1 | M2: the arena under one of tests/golden/make_mutator_golden.py's non-default MutatorConfigs (both sides)
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); from make_mutator_golden import mutator_sets
+        _, mm, dd = [x for x in mutator_sets() if x[0] == os.environ["RT_MUT"]][0]
+        ref.lib.ref_arena_set_mutators.argtypes = [C.c_void_p, C.c_void_p, C.c_float]; ref.lib.ref_arena_set_mutators(a, C.byref(mm), C.c_float(dd))
+    ref.set_state(a, s0); got0 = ref.get_state(a); s0.car_order = got0.car_order
+    if os.environ.get("RT_MUT"): s0.mutators = got0.mutators; s0.hidden.valid |= 8
     # both sides draw the respawn slots from the same engine state (RlgpuArenaHidden::ref_engine; oracle/ref_driver.cpp:ref_seed_engine): a tape stays
     # comparable through its respawns
     engine0 = 1 + (seed * 2654435761) % 2147483645
