@@ -323,7 +323,33 @@ static void gym_step_t(RlgpuArenaState* s, const GymConfig* cfg, uint32_t env, c
     arena_to_host(A, G, *s);
 }
 
+// a whole rollout with the arena RESIDENT, as the HIP path keeps it (no hand-over in uu between steps): the host build's gym against the reference bit for bit
+template <int NC>
+static int gym_rollout_t(RlgpuArenaState* s, const GymConfig* cfg, const int32_t* actions, int steps, float* obs0, float* obs, float* rew, int32_t* done) {
+    Arena<NC> A; GymEnv<NC> G;
+    arena_from_host(A, G, *s);
+    MeshView mv = view();
+    PortWork<NC> W;
+    const int P = cfg->one_team ? NC / 2 : NC; const size_t D = (size_t)obs_size<NC>(*cfg);
+    if (obs0) gym_reset_env<NC>(A, G, *cfg, 0u, obs0, D, false);      // the episode's start on the uploaded state (no setter), first observation
+    int t = 0;
+    for (; t < steps; t++) {
+        gym_step_env<NC>(A, G, *cfg, mv, table(), actions + (size_t)t * P, 0u, obs + (size_t)t * P * D, D, rew + (size_t)t * P, done + t, W);
+        if (done[t]) { t++; break; }
+    }
+    arena_to_host(A, G, *s);
+    return t;
+}
+
 extern "C" {
+
+// steps taken (stops after the first done); obs0 [P][D] or null (no reset), obs [steps][P][D], rew [steps][P], done [steps]
+int port_gym_rollout(RlgpuArenaState* s, const void* cfg, const int32_t* actions, int steps, float* obs0, float* obs, float* rew, int32_t* done) {
+    const GymConfig* c = (const GymConfig*)cfg;
+    if (s->num_cars == 2) return gym_rollout_t<2>(s, c, actions, steps, obs0, obs, rew, done);
+    if (s->num_cars == 4) return gym_rollout_t<4>(s, c, actions, steps, obs0, obs, rew, done);
+    return gym_rollout_t<6>(s, c, actions, steps, obs0, obs, rew, done);
+}
 
 // row width of the obs builder `cfg` describes (DefaultOBS, or DefaultOBSPadded when obs_max_players is set)
 int port_obs_size(const void* cfg, int nc) { const GymConfig& g = *(const GymConfig*)cfg; return g.obs_max_players > 0 ? 51 + 38 * g.obs_max_players : 51 + 19 * (g.one_team ? nc / 2 : nc); }

@@ -526,6 +526,25 @@ void ref_arena_get_hidden(void* h, RlgpuArenaState* s) {
     }
     s->hidden.valid |= RLGPU_HIDDEN_BP_HIST | RLGPU_HIDDEN_WRECK_ROT;   // (the mutators bit of ref_arena_get_state stays)
 }
+// the proxy boxes of the arena's static planes (cap > 0) or mesh bodies (cap < 0: up to -cap) in world order: 6 floats each
+int ref_debug_plane_boxes(void* h, float* out, int cap) {
+    Arena* a = (Arena*)h; int n = 0; const int cap_ = cap;
+    if (cap < 0) { /* mesh bodies */ }
+    const btCollisionObjectArray& objs = a->_bulletWorld.getCollisionObjectArray();
+    for (int i = 0; i < objs.size() && n < (cap_ < 0 ? -cap_ : cap_); i++) {
+        if (objs[i]->getCollisionShape()->getShapeType() != (cap < 0 ? TRIANGLE_MESH_SHAPE_PROXYTYPE : STATIC_PLANE_PROXYTYPE)) continue;
+        btBroadphaseProxy* p = objs[i]->getBroadphaseHandle();
+        for (int k = 0; k < 3; k++) { out[6 * n + k] = p->m_aabbMin[k]; out[6 * n + 3 + k] = p->m_aabbMax[k]; }
+        n++;
+    }
+    return n;
+}
+// the broadphase's box of a dynamic body as the last setAabb left it (body 0: the ball, 1 + k: car slot k): min[3], max[3]
+void ref_debug_proxy_aabb(void* h, int body, float* out6) {
+    Arena* a = (Arena*)h;
+    btBroadphaseProxy* p = body == 0 ? a->ball->_rigidBody.getBroadphaseHandle() : CarBySlot(a, body - 1)->_rigidBody.getBroadphaseHandle();
+    for (int k = 0; k < 3; k++) { out6[k] = p->m_aabbMin[k]; out6[3 + k] = p->m_aabbMax[k]; }
+}
 void ref_arena_set_state(void* h, const RlgpuArenaState* s) { SetArenaPhys((Arena*)h, s, true); }
 void ref_arena_set_controls(void* h, int slot, const float* c8) { CarBySlot((Arena*)h, slot)->controls = ArrToCtrl(c8); }
 void ref_arena_step(void* h, int ticks) { ((Arena*)h)->Step(ticks); }

@@ -306,17 +306,11 @@ RLG_HD void event_values(const Snapshot<NC>& S, const GymEnv<NC>& G, int k, floa
     v[4] = S.touched[k] ? 1.f : 0.f; v[5] = (float)G.counters[k][3]; v[6] = (float)G.counters[k][4]; v[7] = (float)G.counters[k][1];
     v[8] = (float)G.counters[k][6]; v[9] = S.demoed[k] ? 1.f : 0.f; v[10] = S.boost_frac[k];
 }
-// powf as the reference's host libm returns it.  glibc's powf works in double and rounds once (its result is the correctly rounded one
-// but for arguments within 2^-26 relative of a rounding boundary); the device library's powf is a float algorithm good to 1 ulp, which
-// showed as last-bit differences in SaveBoostReward / TouchBallReward on the random 2v2 / 3v3 rollouts.  The double pow rounded to float
-// is correctly rounded too (double rounding aside), a few hundred cycles per player and STEP -- nothing next to the 8 ticks before it.
-RLG_HD float libm_powf(float x, float y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (float)pow((double)x, (double)y);
-#else
-    return powf(x, y);
-#endif
-}
+// powf as the reference's host libm returns it: glibc's algorithm restated (rl_libm.h rl_powf; its result is within 0.82 ulp, not always the correctly rounded
+// one).  The device library's powf is a float algorithm good to 1 ulp, which showed as last-bit differences in SaveBoostReward / TouchBallReward on the random
+// 2v2 / 3v3 rollouts (round 2); the double pow rounded to float that replaced it is correctly rounded, which glibc's is not quite (round 6: one reward of 120
+// live rollouts an ulp off).  A few hundred cycles per player and STEP -- nothing next to the 8 ticks before it; kept out of line.
+RLG_HD_COLD float libm_powf(float x, float y) { return rl_powf(x, y); }
 template <int NC>
 RLG_HD_T6B void compute_rewards(const Snapshot<NC>& S, GymEnv<NC>& G, const GymConfig& cfg, float* rew) {
     for (int k = 0; k < NC; k++) rew[k] = 0.f;

@@ -657,7 +657,8 @@ RLG_HD_T4 bool collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, 
     auto obj_box = [&](int o, V3& lo, V3& hi) {
         if (!mesh.bp) { lo = v3(-1e30f, -1e30f, -1e30f); hi = v3(1e30f, 1e30f, 1e30f); return; }
         const float* mb = reinterpret_cast<const float*>(mesh.bp + 1 + (size_t)o * 6);
-        lo = v3(mb[0], mb[1], mb[2]); hi = v3(mb[3], mb[4], mb[5]);
+        const V3 t = v3(BP_THRESHOLD, BP_THRESHOLD, BP_THRESHOLD);      // a static body's proxy is grown by the contact threshold like any other (world_plane_aabb)
+        lo = v3(mb[0], mb[1], mb[2]) - t; hi = v3(mb[3], mb[4], mb[5]) + t;
     };
     auto cell_objects = [&](int ci, int cj, int ck) -> uint32_t {     // the mesh objects on the static list of a broadphase cell
         if (!mesh.bp) return n_obj > 0 ? 1u : 0u;
@@ -678,7 +679,7 @@ RLG_HD_T4 bool collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, 
         for (uint32_t om = same ? cell_objects(a0, a1, a2) : 0u; om && same; om &= om - 1u) {
             V3 mlo, mhi; obj_box(__builtin_ctz(om), mlo, mhi); same = aabb_touch(il, ih, mlo, mhi) == aabb_touch(ol, oh, mlo, mhi);
         }
-        for (int s = 0; s < 4 && same; s++) { V3 slo, shi; world_plane_aabb(s, slo, shi); same = aabb_touch(il, ih, slo, shi) == aabb_touch(ol, oh, slo, shi); }
+        for (int s = 0; s < 4 && same; s++) { V3 slo, shi; world_plane_aabb(s, slo, shi, BP_THRESHOLD); same = aabb_touch(il, ih, slo, shi) == aabb_touch(ol, oh, slo, shi); }
         if (same) {   // against the other dynamic bodies: their own outer / inner boxes (the ball's box is exact)
             V3 bl, bh; ball_proxy_aabb(A.ball, bl, bh);
             same = aabb_touch(il, ih, bl, bh) == aabb_touch(ol, oh, bl, bh);
@@ -729,8 +730,8 @@ RLG_HD_T4 bool collide_order(Arena<NC>& A, MeshView mesh, TickWork<NC, BIG>& W, 
             for (int s = 1; s <= 4; s++) {
                 int cnt = 0, first = base + k;
                 if (k < nw_ && L.c[base + k].sid == s) { cnt = 1; k++; }
-                V3 slo, shi; world_plane_aabb(s - 1, slo, shi);
-                if (!aabb_touch(plo[p], phi[p], slo, shi) || !aabb_touch(xlo, xhi, slo, shi)) continue;
+                V3 slo, shi, glo, ghi; world_plane_aabb(s - 1, slo, shi); world_plane_aabb(s - 1, glo, ghi, BP_THRESHOLD);     // the shape's box; the proxy's
+                if (!aabb_touch(plo[p], phi[p], glo, ghi) || (p > 0 && !aabb_touch(xlo, xhi, slo, shi))) continue;
                 if (nm < LY::MAXM) { mkey[nm] = (int8_t)p; mfirst[nm] = (idx_t)first; mcnt[nm] = (int8_t)cnt; nm++; } else fits = false;
             }
         }
@@ -804,7 +805,10 @@ RLG_HD_SMALL void bp_history_cell(Arena<NC>& A, TickWork<NC, BIG>& W, int b) {
         h = ((uint32_t)bp_cell_index(i, j, k) << 3) | (uint32_t)b;
         A.bp_hist[b] = (uint16_t)h;
     }
-    if (b == 0 ? W.ball_asleep : !car_collides(A.cars[b - 1])) return;     // updateAabbs skips inactive objects
+    // btCollisionWorld::updateAabbs visits EVERY object (m_forceUpdateAllAabbs is Bullet's default and the reference leaves it, btCollisionWorld.cpp:62,178-193): a
+    // ball a state setter put down at rest somewhere else is filed under its new cell by the next tick, asleep or not (round 6: a live Gym rollout whose solver
+    // order depended on it, tools/live_gym_hip.py).  A wreck keeps the proxy it had (it neither moves nor collides until Car::Respawn re-files it).
+    if (b != 0 && !car_collides(A.cars[b - 1])) return;
     if (b == 0) { V3 lo, hi; ball_proxy_aabb(A.ball, lo, hi); bp_cell_of(lo, i, j, k); }
     else {       // the bracket around the proxy box names the cell without the predicted rotation in all but borderline poses
         V3 il, ih, ol, oh; car_proxy_bracket(A.cars[b - 1], il, ih, ol, oh);

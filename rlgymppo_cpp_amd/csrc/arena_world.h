@@ -459,16 +459,20 @@ RLG_HD void world_plane_body(int i, V3& n, V3& origin) {
     else { n = v3(-u, 0, 0); origin = v3(ex * UU2BT, 0.f * UU2BT, (h / 2) * UU2BT); }
 }
 
-// the proxy box of plane body i: RocketSim's btStaticPlaneShape::getAabb (btStaticPlaneShape.cpp:40-54) is a half space that ends 0.2
-// in front of the plane, so a body is only paired with a plane it is within reach of
-RLG_HD void world_plane_aabb(int i, V3& lo, V3& hi) {
+// the box of plane body i: RocketSim's btStaticPlaneShape::getAabb (btStaticPlaneShape.cpp:40-54) is a half space that ends 0.2 in front
+// of the plane, so a body is only paired with a plane it is within reach of.  `grow` = 0: the SHAPE's box, which a compound's child
+// test reads (btCompoundCollisionAlgorithm.cpp:127-141); `grow` = gContactBreakingThreshold = 0.02: the PROXY's box -- updateAabbs visits
+// the static bodies too (m_forceUpdateAllAabbs, btCollisionWorld.cpp:62,143-193), so from the first tick on the broadphase holds the grown
+// box like every other (the live reference's floor proxy ends at z = 0.22).  A ball whose own box ends between 0.2 and 0.22 has an (empty)
+// manifold with the floor, and an empty manifold still takes a place in the island sort (round 6, tools/live_gym_hip.py).
+RLG_HD void world_plane_aabb(int i, V3& lo, V3& hi, float grow = 0.f) {
     const float L = 1e18f;
     V3 n, o; world_plane_body(i, n, o);
     lo = v3(-L, -L, -L); hi = v3(L, L, L);
-    if (i == 0) hi.z = o.z + (0.f + 0.2f);
-    else if (i == 1) lo.z = o.z + (0.f - 0.2f);
-    else if (i == 2) hi.x = o.x + (0.f + 0.2f);
-    else lo.x = o.x + (0.f - 0.2f);
+    if (i == 0) hi.z = (o.z + (0.f + 0.2f)) + grow;
+    else if (i == 1) lo.z = (o.z + (0.f - 0.2f)) - grow;
+    else if (i == 2) hi.x = (o.x + (0.f + 0.2f)) + grow;
+    else lo.x = (o.x + (0.f - 0.2f)) - grow;
 }
 
 // What a contact point looks like by the time the solver reads it: btManifoldResult::addContactPoint stores the point in both

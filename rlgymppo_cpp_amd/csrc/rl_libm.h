@@ -184,4 +184,78 @@ RLG_HD float rl_asinf(float x) {
     return hx > 0 ? t : -t;
 }
 
+// rl_powf: flt-32/e_powf.c with powf_log2_data.c / exp2f_data.c (x86-64: TOINT_INTRINSICS 0, so POWF_SCALE = 1 and exp2_inline takes the SHIFT path), as the FMA
+// build evaluates it -- log2(x) by a 16-entry table and a degree-5 polynomial in double, y * log2(x), 2^that by a 32-entry table and a degree-3 polynomial.
+// glibc's result is within 0.82 ulp, NOT always the correctly rounded one: the double pow rounded to float that the device used through round 5 differed from
+// the reference's reward in one step of 120 live rollouts by an ulp (round 6, tools/live_gym_hip.py).  The tables are the C library's own (read out of this
+// image's libm.so.6; tests/cpp/libm_check.cpp compares the function with powf over 1e8 arguments).  Handled here: x a positive normal number and a result that
+// neither overflows nor is subnormal -- what CommonRewards.h feeds it; everything else goes to the platform's routine.
+RLG_HD float rl_powf(float x, float y) {
+    static const double LT[32] = {   // {invc, logc} x 16
+        0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2,
+        0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+        0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2,
+        0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+        0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2,
+        0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3,
+        0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3,
+        0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+        0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5,
+        0x1.0000000000000p+0, 0x0.0p+0,
+        0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,
+        0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3,
+        0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,
+        0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+        0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,
+        0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+    };
+    static const uint64_t ET[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+    };
+    const uint32_t ix = rl_f2u(x), iy = rl_f2u(y);
+    const uint32_t ay = iy & 0x7fffffffu;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || ay == 0u || ay >= 0x7f800000u) return powf(x, y);      // x <= 0, subnormal, inf or nan; y 0, inf or nan
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = LT[2 * i], logc = LT[2 * i + 1], z = (double)rl_u2f(iz);
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2, A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp+0;
+    const double r = fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = fma(A0, r, A1);
+    const double p = fma(A2, r, A3);
+    const double r4 = r2 * r2;
+    double q = fma(A4, r, y0);
+    q = fma(p, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    if (!(ylogx < 126.0 && ylogx > -126.0)) return powf(x, y);      // overflow, underflow and subnormal results: the C library's own tail
+    // exp2_inline (sign_bias 0)
+    const double SHIFT = 0x1.8p+47, C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double kd = ylogx + SHIFT;
+    uint64_t ki; memcpy(&ki, &kd, 8);
+    kd -= SHIFT;
+    const double rr = ylogx - kd;
+    uint64_t t = ET[ki % 32u];
+    t += ki << (52 - 5);
+    double s; memcpy(&s, &t, 8);
+    const double zz = fma(C0, rr, C1);
+    const double rr2 = rr * rr;
+    double e = fma(C2, rr, 1.0);
+    e = fma(zz, rr2, e);
+    e = e * s;
+    return (float)e;
+}
+
 }  // namespace rlg

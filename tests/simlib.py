@@ -416,3 +416,24 @@ def gameinst_replay(gg, case, reset_to, step, obs_tol, rew_exact, what):
         else:
             assert np.abs(got - trk[t]).max() < 2e-3 * max(1.0, np.abs(trk[t]).max()), f"{what} {case}: reward trackers at step {t}: {got} vs {trk[t]}"
     return ends
+
+
+class OneCaseFixture(dict):
+    """one gym rollout of an .npz in the layout of sim_golden.npz's gym/ entries, as the replaying tests read a fixture"""
+    @property
+    def files(self): return list(self.keys())
+
+
+def live_gym_cases(rec, gold):
+    """tests/golden/live_gym_golden.npz (tools/live_gym_hip.py --record): (case, one-case fixture, horizon) per rollout.  Every rollout is compared EXACTLY (GYM_EXACT).
+    horizon: with DefaultOBSPadded the reference's obs builder shuffles with the engine Car::Respawn draws from (DefaultOBSPadded.cpp:58-59), which the stepper's
+    replay of that engine does not follow (its shuffle is keyed Philox): such a rollout is comparable up to its first respawn."""
+    for case in [str(x) for x in rec["gym_names"]]:
+        entries = {k: rec[k] for k in rec.files if k.startswith(f"gym/{case}/")}
+        omp = int(entries[f"gym/{case}/cfg"][2]); o = entries[f"gym/{case}/obs"]; horizon = len(o)
+        if omp > 0:
+            resp = [t for t in range(1, len(o)) if ((o[t - 1][:, 69] == 1) & (o[t][:, 69] == 0)).any()]
+            if resp: horizon = resp[0]
+        GYM_EXACT.add(case)
+        if horizon < len(o): GYM_HORIZON[case] = GYM_HORIZON_PORT[case] = horizon
+        yield case, OneCaseFixture({"gym_names": np.array([case]), "mesh_verts": gold["mesh_verts"], "mesh_tris": gold["mesh_tris"], **entries}), horizon

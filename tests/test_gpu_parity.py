@@ -1708,3 +1708,16 @@ def test_fp16_operand_mode_with_dynamic_loss_scale(monkeypatch):
     assert sp == 1 and sc == 1
     core.check_redzones()   # no kernel of the fp16 mode wrote past a buffer of the learner (RLGPU_REDZONE, set above)
     core.close()
+
+
+def test_hip_live_gym_rollouts_equal_the_reference():
+    """Round 6 on the GPU: tests/golden/live_gym_golden.npz (tools/live_gym_hip.py --record; tests/test_oracle_golden.py::test_port_resident_gym_rollouts_equal_the_live_reference
+    says what each rollout carries) replayed by the body of test_hip_gym_rollouts_vs_reference_fixtures with EXACT comparison: done, every reward and every
+    observation row bit for bit (the other players' blocks in the reference's order; DefaultOBSPadded's shuffled lists as multisets; padded rollouts up to their first
+    respawn -- simlib.live_gym_cases)."""
+    from simlib import live_gym_cases
+    rec = np.load(os.path.join(GOLD, "live_gym_golden.npz")); gold = np.load(os.path.join(GOLD, "sim_golden.npz"))
+    n = 0
+    for case, fx, horizon in live_gym_cases(rec, gold):
+        test_hip_gym_rollouts_vs_reference_fixtures(fx); n += 1
+    assert n >= 13

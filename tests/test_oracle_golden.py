@@ -968,3 +968,34 @@ def test_port_state_setters_equal_the_reference_draw_for_draw(port_lib, team):
                 assert st.hidden.ref_engine == int(engines[i]), f"{key} reset {i}: the engines parted"
                 n += 1
     assert n == 6 * 64
+
+
+def test_port_resident_gym_rollouts_equal_the_live_reference(port_lib):
+    """Round 6, tests/golden/live_gym_golden.npz: thirteen rollouts of the LIVE reference Gym recorded by tools/live_gym_hip.py -- 1v1 / 2v2 / 3v3, every car in a ring
+    around the ball at speed or the ball rolling at a goal, every CommonRewards term plain or zero-sum, DefaultOBS or DefaultOBSPadded, default mutators or M1, random
+    actions -- the ones among 120 that found something and some that did not:
+      live_104 / _53   a ball put down AT REST away from the centre is filed under its new broadphase cell by the next tick although it sleeps (updateAabbs
+                  visits every object), and the static planes' proxies are grown by the contact threshold like any other: both only decide the ORDER of manifolds in a
+                  pile-up on the ball (csrc/arena_step.h bp_history_cell, csrc/arena_world.h world_plane_aabb; the stepper of round 5 leaves these two at steps 6 and 9);
+      live_55     glibc's powf is within 0.82 ulp, not correctly rounded: one reward an ulp off on the device until csrc/rl_libm.h rl_powf restated it.
+    The host build keeps the arena RESIDENT over the rollout here (port_gym_rollout: no hand-over in uu between steps), as the HIP path does, so the comparison is exact:
+    every reward and the fixed part of every observation row (ball, previous action, pads, self) bit for bit, done flags equal."""
+    from simlib import live_gym_cases
+    rec = np.load(os.path.join(GOLD, "live_gym_golden.npz")); gold = np.load(os.path.join(GOLD, "sim_golden.npz"))
+    port_lib.lib.port_gym_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    steps = 0
+    for case, fx, horizon in live_gym_cases(rec, gold):
+        team, tick_skip, omp, rk, nts = [int(x) for x in fx[f"gym/{case}/cfg"][:5]]; nc = 2 * team
+        cfg = gym_cfg_for_case(team, tick_skip, omp, rk, nts)
+        st = ArenaState.from_buffer_copy(fx[f"gym/{case}/start_raw"].tobytes())
+        acts = np.ascontiguousarray(fx[f"gym/{case}/actions"], np.int32); T = len(acts); D = fx[f"gym/{case}/obs"].shape[2]
+        obs0 = np.zeros((nc, D), np.float32); obs = np.zeros((T, nc, D), np.float32); rew = np.zeros((T, nc), np.float32); done = np.zeros(T, np.int32)
+        n = port_lib.lib.port_gym_rollout(C.byref(st), C.byref(cfg), acts.ctypes.data, T, obs0.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data)
+        assert n >= min(horizon, T), f"{case}: the host build's episode ended after {n} steps, the reference's ran {T}"
+        ro = fx[f"gym/{case}/obs"]; rr = fx[f"gym/{case}/rew"]; rd = fx[f"gym/{case}/done"]
+        for t in range(min(horizon, T)):
+            assert int(done[t]) == int(rd[t]), f"{case}: done differs at step {t}"
+            assert np.array_equal(rew[t].view(np.uint32), rr[t].view(np.uint32)), f"{case}: reward not bit-equal at step {t}: {rew[t]} vs {rr[t]}"
+            if not rd[t]: assert np.array_equal(obs[t][:, :70].view(np.uint32), ro[t][:, :70].view(np.uint32)), f"{case}: observation (fixed part) not bit-equal at step {t}"
+            steps += 1
+    assert steps >= 450, steps

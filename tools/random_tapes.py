@@ -84,6 +84,14 @@ for seed in range(seed0, seed0 + n_tapes):
                 c.vel[:] = [float(np.cos(yaw) * v) for v in [rng.uniform(800, 2200)]] + [0.0, 0.0]; c.vel[1] = float(np.sin(yaw) * np.hypot(c.vel[0], 0) / max(abs(np.cos(yaw)), 1e-3)) if False else float(np.sin(yaw) * abs(c.vel[0]) / max(abs(np.cos(yaw)), 0.2))
                 c.ang_vel[:] = [0.0, 0.0, 0.0]
             c.boost = 100.0
+    live = None
+    if os.environ.get("RT_LIVE"):
+        # RT_LIVE=<file>:<case>: start state and actions of one rollout recorded by tools/live_gym_hip.py --record, as a PHYSICS tape (the action table's controls held for
+        # the tick skip) -- with RT_DEBUG=1 the tick, body and contact lists where a Gym rollout that differs leaves the reference
+        path, case = os.environ["RT_LIVE"].rsplit(":", 1); live = np.load(path)
+        s0 = ArenaState.from_buffer_copy(live[f"gym/{case}/start_raw"].tobytes()); team = int(live[f"gym/{case}/cfg"][0]); nc = 2 * team
+        ref.lib.ref_arena_free(a); a = ref.arena(team)
+        if s0.mutators.flags & ~32: os.environ["RT_MUT"] = "M1"
     if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(a, 1 + (seed * 7) % 60)
     if os.environ.get("RT_MUT"):        # RT_MUT=M1 | M2: the arena under one of tests/golden/make_mutator_golden.py's non-default MutatorConfigs (both sides)
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); from make_mutator_golden import mutator_sets
@@ -93,7 +101,7 @@ for seed in range(seed0, seed0 + n_tapes):
     if os.environ.get("RT_MUT"): s0.mutators = got0.mutators; s0.hidden.valid |= 8
     # both sides draw the respawn slots from the same engine state (RlgpuArenaHidden::ref_engine; oracle/ref_driver.cpp:ref_seed_engine): a tape stays
     # comparable through its respawns
-    engine0 = 1 + (seed * 2654435761) % 2147483645
+    engine0 = 1 + (seed * 2654435761) % 2147483645 if live is None else int(s0.hidden.ref_engine)
     ref.lib.ref_seed_engine(C.c_uint32(engine0)); s0.hidden.valid |= 4; s0.hidden.ref_engine = engine0
     # parity mode for the wheel rays too (RLGPU_MUT_RAY_PROXY_LISTS, csrc/arena_world.h: every dynamic body on the broadphase's list gets the convex cast, as in the
     # reference); RT_NO_RAY_LISTS=1 shows what the product's default -- the box test alone -- leaves out
@@ -107,6 +115,10 @@ for seed in range(seed0, seed0 + n_tapes):
             c[0] = rng.choice([1.0, 1.0, 1.0, -1.0, 0.0]); c[1:5] = rng.choice([-1.0, 0.0, 0.0, 1.0], size=4)
             c[5] = float(rng.rand() < 0.15); c[6] = float(rng.rand() < 0.6); c[7] = float(rng.rand() < 0.1)
             tape[t:t + span, k] = c; t += span
+    if live is not None:
+        tab = np.zeros((128, 8), np.float32); ref.lib.ref_action_table(tab.ctypes.data_as(C.c_void_p), 128)
+        acts = live[f"gym/{case}/actions"]; skip = int(live[f"gym/{case}/cfg"][1]); ticks = len(acts) * skip
+        tape = np.ascontiguousarray(np.repeat(tab[acts], skip, axis=0), np.float32)
     hunt = len(sys.argv) > 5 and sys.argv[5] == "hunt"
     raw_r = np.zeros((ticks, 1 + nc, 18), np.float32)
     n_demo = 0; n_resp = 0; was = [False] * nc
