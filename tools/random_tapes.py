@@ -159,6 +159,7 @@ for seed in range(seed0, seed0 + n_tapes):
         print("   differing (body, field):", d[:8].tolist()); print("   port", raw_p[t][body].tolist()); print("   ref ", raw_r[t][body].tolist())
         b = ref.arena(team)
         if len(sys.argv) > 4 and sys.argv[4] != "-": ref.lib.ref_arena_rehash(b, 1 + (seed * 7) % 60)
+        if os.environ.get("RT_MUT"): ref.lib.ref_arena_set_mutators(b, C.byref(mm), C.c_float(dd))
         ref.set_state(b, s0); ref.lib.ref_seed_engine(C.c_uint32(engine0))
         for tt in range(first):
             for k in range(nc): ref.set_controls(b, k, tape[tt, k])
