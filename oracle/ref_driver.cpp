@@ -446,6 +446,35 @@ void* ref_arena_new(int team_size) {
     for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE); a->AddCar(Team::ORANGE); }
     return a;
 }
+// ... with every car built from one of CarConfig.cpp's presets (0 OCTANE, 1 DOMINUS, 2 PLANK, 3 BREAKOUT, 4 HYBRID, 5 MERC), as Gym's constructor
+// does with its carConfig argument (Gym.cpp:45-49); ref_car_config: the preset's numbers, for a check of the repo's own table
+static const CarConfig& preset_config(int preset) {
+    const CarConfig* all[6] = { &CAR_CONFIG_OCTANE, &CAR_CONFIG_DOMINUS, &CAR_CONFIG_PLANK, &CAR_CONFIG_BREAKOUT, &CAR_CONFIG_HYBRID, &CAR_CONFIG_MERC };
+    return *all[preset < 0 || preset > 5 ? 0 : preset];
+}
+void* ref_arena_new_cfg(int team_size, int preset) {
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE, preset_config(preset)); a->AddCar(Team::ORANGE, preset_config(preset)); }
+    return a;
+}
+// ... and from any CarConfig (the 17 numbers in ref_car_config's order): the bisection tool of tests/golden/make_carconfig_golden.py's `custom` tapes
+void* ref_arena_new_custom(int team_size, const float* v) {
+    CarConfig c;
+    c.hitboxSize = Vec(v[0], v[1], v[2]); c.hitboxPosOffset = Vec(v[3], v[4], v[5]);
+    c.frontWheels.wheelRadius = v[6]; c.frontWheels.suspensionRestLength = v[7]; c.frontWheels.connectionPointOffset = Vec(v[8], v[9], v[10]);
+    c.backWheels.wheelRadius = v[11]; c.backWheels.suspensionRestLength = v[12]; c.backWheels.connectionPointOffset = Vec(v[13], v[14], v[15]);
+    c.dodgeDeadzone = v[16];
+    Arena* a = Arena::Create(GameMode::SOCCAR);
+    for (int i = 0; i < team_size; i++) { a->AddCar(Team::BLUE, c); a->AddCar(Team::ORANGE, c); }
+    return a;
+}
+void ref_car_config(int preset, float* out17) {
+    const CarConfig& c = preset_config(preset);
+    const float v[17] = { c.hitboxSize.x, c.hitboxSize.y, c.hitboxSize.z, c.hitboxPosOffset.x, c.hitboxPosOffset.y, c.hitboxPosOffset.z,
+                          c.frontWheels.wheelRadius, c.frontWheels.suspensionRestLength, c.frontWheels.connectionPointOffset.x, c.frontWheels.connectionPointOffset.y, c.frontWheels.connectionPointOffset.z,
+                          c.backWheels.wheelRadius, c.backWheels.suspensionRestLength, c.backWheels.connectionPointOffset.x, c.backWheels.connectionPointOffset.y, c.backWheels.connectionPointOffset.z, c.dodgeDeadzone };
+    memcpy(out17, v, sizeof(v));
+}
 // The same arena with the cars at OTHER heap addresses: Arena::_cars is a std::unordered_set<Car*>, so the order of the reference's per-car
 // loops is a function of where malloc put the cars.  A few odd-sized allocations between the AddCar calls move them (kept: freeing would
 // give the addresses back); callers try seeds until ref_arena_get_state reports the car order they want to reproduce (tools/raw_divergence.py).
